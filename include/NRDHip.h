@@ -1,0 +1,71 @@
+// HIP execution back-end of the NRD pass chain for AMD Instinct MI355X (gfx950) -- thin C-ABI.
+//
+// The reference library only DESCRIBES dispatches; executing them is the job of its integration layer
+// (reference Integration/NRDIntegration.h:83-165, NRDIntegration.hpp). This header is what replaces that layer:
+//
+//   reference nrd::Integration::Initialize   (NRDIntegration.hpp:93-139, :292-454: creates the pool textures)   -> nrdHipCreateExecutor
+//   reference nrd::Integration::Destroy      (NRDIntegration.hpp:805-...)                                       -> nrdHipDestroyExecutor
+//   reference UserPool / Integration_SetResource (NRDIntegration.h:37-60: app textures by ResourceType slot)     -> nrdHipBindResource
+//   reference nrd::Integration::Denoise      (NRDIntegration.hpp:516-623: GetComputeDispatches + loop)           -> nrdHipDenoise
+//   reference nrd::Integration::Dispatch     (NRDIntegration.hpp:625-803: bind + constants + CmdDispatch)        -> nrdHipExecuteDispatches
+//   reference nrd::Integration::GetTotalMemoryUsageInMb (NRDIntegration.h:120-127)                               -> nrdHipGetPoolMemoryUsage
+//
+// Plain C types only: device pointers are void*, the stream is a hipStream_t passed as void*, formats and resource
+// slots are the numeric values of nrd::Format / nrd::ResourceType (include/NRDDescs.h). Every function returns an
+// nrd::Result value as uint32_t (0 = SUCCESS). Nothing here synchronises the device: launches are enqueued on the
+// executor's stream in dispatch order.
+#pragma once
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct NrdHipExecutor NrdHipExecutor;
+
+// A pitched 2D plane in device memory ("texture" of the reference). Texel (x, y) lives at
+// data + y * rowPitchBytes + x * bytesPerTexel(format). rowPitchBytes must be a multiple of the texel size.
+typedef struct NrdHipPlaneDesc {
+    void* data;
+    uint32_t rowPitchBytes;
+    uint32_t format; // nrd::Format
+    uint16_t width;
+    uint16_t height;
+} NrdHipPlaneDesc;
+
+// Creates the executor for an nrd::Instance (include/NRD.h) and allocates its permanent + transient pool planes
+// (one hipMalloc arena, 256-byte aligned rows) for textures of resourceWidth x resourceHeight.
+// "instance" is an nrd::Instance*; "hipStream" is a hipStream_t (NULL = default stream).
+uint32_t nrdHipCreateExecutor(void* instance, uint16_t resourceWidth, uint16_t resourceHeight, void* hipStream, NrdHipExecutor** executor);
+void nrdHipDestroyExecutor(NrdHipExecutor* executor);
+
+// Binds an application plane to an IN_* / OUT_* slot. The bytes are not copied; the binding persists until rebound.
+// Formats accepted in this build (anything else -> UNSUPPORTED):
+//   IN_MV RGBA16_SFLOAT | IN_NORMAL_ROUGHNESS R10_G10_B10_A2_UNORM | IN_VIEWZ R32_SFLOAT
+//   IN/OUT_{DIFF,SPEC}_RADIANCE_HITDIST RGBA16_SFLOAT | IN_PENUMBRA R16_SFLOAT | OUT_SHADOW_TRANSLUCENCY R8_UNORM
+//   IN_SIGNAL / OUT_SIGNAL RGBA32_SFLOAT | IN_{DIFF,SPEC}_CONFIDENCE, IN_DISOCCLUSION_THRESHOLD_MIX R8_UNORM
+uint32_t nrdHipBindResource(NrdHipExecutor* executor, uint32_t resourceType, const NrdHipPlaneDesc* plane);
+
+// Describes a pool plane (resourceType = TRANSIENT_POOL or PERMANENT_POOL, index into InstanceDesc::*Pool).
+// For tooling and parity tests (history inspection); the memory stays owned by the executor.
+uint32_t nrdHipGetPoolPlane(NrdHipExecutor* executor, uint32_t resourceType, uint32_t indexInPool, NrdHipPlaneDesc* plane);
+
+// Executes a dispatch list obtained from nrd::GetComputeDispatches on the executor's stream, in order.
+// "dispatchDescs" is a const nrd::DispatchDesc*.
+uint32_t nrdHipExecuteDispatches(NrdHipExecutor* executor, const void* dispatchDescs, uint32_t dispatchDescsNum);
+
+// nrd::GetComputeDispatches(identifiers) followed by nrdHipExecuteDispatches: one denoised frame.
+// nrd::SetCommonSettings / SetDenoiserSettings must have been called for this frame.
+uint32_t nrdHipDenoise(NrdHipExecutor* executor, const uint32_t* identifiers, uint32_t identifiersNum);
+
+// Bytes held by the pool arena (permanent, transient).
+uint32_t nrdHipGetPoolMemoryUsage(const NrdHipExecutor* executor, uint64_t* permanentBytes, uint64_t* transientBytes);
+
+// Last error text of this executor (never NULL).
+const char* nrdHipGetLastError(const NrdHipExecutor* executor);
+
+#ifdef __cplusplus
+}
+#endif

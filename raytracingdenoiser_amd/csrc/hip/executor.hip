@@ -1,0 +1,293 @@
+// HIP executor: owns the pool planes in HBM and turns an nrd::DispatchDesc list into kernel launches on one stream.
+// Plays the role of the reference integration layer (reference Integration/NRDIntegration.hpp:292-454 pool creation,
+// :516-623 Denoise, :625-803 Dispatch) -- without descriptor sets, barriers or a constant ring buffer: planes are raw
+// pointers, constants travel as kernel arguments, ordering is stream order.
+#include "NRD.h"
+#include "NRDHip.h"
+
+#include "passes.h"
+
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+using namespace nrdhip;
+
+namespace {
+
+uint32_t BytesPerTexel(nrd::Format f) {
+    using F = nrd::Format;
+    switch (f) {
+        case F::R8_UNORM: case F::R8_SNORM: case F::R8_UINT: case F::R8_SINT:
+            return 1;
+        case F::RG8_UNORM: case F::RG8_SNORM: case F::RG8_UINT: case F::RG8_SINT:
+        case F::R16_UNORM: case F::R16_SNORM: case F::R16_UINT: case F::R16_SINT: case F::R16_SFLOAT:
+            return 2;
+        case F::RGBA8_UNORM: case F::RGBA8_SNORM: case F::RGBA8_UINT: case F::RGBA8_SINT: case F::RGBA8_SRGB:
+        case F::RG16_UNORM: case F::RG16_SNORM: case F::RG16_UINT: case F::RG16_SINT: case F::RG16_SFLOAT:
+        case F::R32_UINT: case F::R32_SINT: case F::R32_SFLOAT:
+        case F::R10_G10_B10_A2_UNORM: case F::R10_G10_B10_A2_UINT: case F::R11_G11_B10_UFLOAT: case F::R9_G9_B9_E5_UFLOAT:
+            return 4;
+        case F::RGBA16_UNORM: case F::RGBA16_SNORM: case F::RGBA16_UINT: case F::RGBA16_SINT: case F::RGBA16_SFLOAT:
+        case F::RG32_UINT: case F::RG32_SINT: case F::RG32_SFLOAT:
+            return 8;
+        case F::RGB32_UINT: case F::RGB32_SINT: case F::RGB32_SFLOAT:
+            return 12;
+        case F::RGBA32_UINT: case F::RGBA32_SINT: case F::RGBA32_SFLOAT:
+            return 16;
+        default:
+            return 0;
+    }
+}
+
+// Format each user slot must have in this build (MAX_NUM = slot not supported)
+nrd::Format ExpectedUserFormat(nrd::ResourceType t) {
+    using R = nrd::ResourceType;
+    using F = nrd::Format;
+    switch (t) {
+        case R::IN_MV: return F::RGBA16_SFLOAT;
+        case R::IN_NORMAL_ROUGHNESS: return F::R10_G10_B10_A2_UNORM;
+        case R::IN_VIEWZ: return F::R32_SFLOAT;
+        case R::IN_DIFF_CONFIDENCE: case R::IN_SPEC_CONFIDENCE: case R::IN_DISOCCLUSION_THRESHOLD_MIX: return F::R8_UNORM;
+        case R::IN_DIFF_RADIANCE_HITDIST: case R::IN_SPEC_RADIANCE_HITDIST: return F::RGBA16_SFLOAT;
+        case R::OUT_DIFF_RADIANCE_HITDIST: case R::OUT_SPEC_RADIANCE_HITDIST: return F::RGBA16_SFLOAT;
+        case R::IN_PENUMBRA: return F::R16_SFLOAT;
+        case R::OUT_SHADOW_TRANSLUCENCY: return F::R8_UNORM;
+        case R::IN_SIGNAL: case R::OUT_SIGNAL: return F::RGBA32_SFLOAT;
+        default: return F::MAX_NUM;
+    }
+}
+
+} // namespace
+
+struct NrdHipExecutor {
+    nrd::Instance* instance = nullptr;
+    hipStream_t stream = nullptr;
+    uint16_t width = 0, height = 0;
+
+    uint8_t* arena = nullptr;
+    uint64_t permanentBytes = 0, transientBytes = 0;
+    std::vector<Plane> permanent, transient;
+    std::vector<nrd::Format> permanentFormat, transientFormat;
+
+    Plane user[(size_t)nrd::ResourceType::MAX_NUM] = {};
+    bool userBound[(size_t)nrd::ResourceType::MAX_NUM] = {};
+
+    std::vector<PassLauncher> launchers; // per pipeline index (nullptr = pass not implemented in this build)
+    std::vector<Plane> scratchPlanes;
+    std::string lastError;
+
+    uint32_t Fail(nrd::Result r, const std::string& msg) {
+        lastError = msg;
+        return (uint32_t)r;
+    }
+};
+
+static bool PlanPool(const nrd::TextureDesc* descs, uint32_t num, uint16_t w, uint16_t h, std::vector<Plane>& planes, std::vector<nrd::Format>& formats, uint64_t& offset) {
+    planes.resize(num);
+    formats.resize(num);
+    for (uint32_t i = 0; i < num; i++) {
+        uint32_t bpt = BytesPerTexel(descs[i].format);
+        if (!bpt)
+            return false;
+        int pw = (w + descs[i].downsampleFactor - 1) / descs[i].downsampleFactor;
+        int ph = (h + descs[i].downsampleFactor - 1) / descs[i].downsampleFactor;
+        uint32_t pitch = ((uint32_t)pw * bpt + 255u) & ~255u;
+        planes[i].ptr = (uint8_t*)(uintptr_t)offset; // patched to a real pointer once the arena exists
+        planes[i].pitch = pitch;
+        planes[i].w = pw;
+        planes[i].h = ph;
+        formats[i] = descs[i].format;
+        offset += ((uint64_t)pitch * (uint64_t)ph + 255u) & ~(uint64_t)255u;
+    }
+    return true;
+}
+
+extern "C" __attribute__((visibility("default"))) uint32_t nrdHipCreateExecutor(void* instance, uint16_t resourceWidth, uint16_t resourceHeight, void* hipStream, NrdHipExecutor** executor) {
+    if (!instance || !executor || !resourceWidth || !resourceHeight)
+        return (uint32_t)nrd::Result::INVALID_ARGUMENT;
+    *executor = nullptr;
+
+    int deviceCount = 0;
+    if (hipGetDeviceCount(&deviceCount) != hipSuccess || deviceCount == 0) {
+        fprintf(stderr, "nrdHipCreateExecutor: no HIP device available -- the NRD HIP back-end has no CPU fallback\n");
+        return (uint32_t)nrd::Result::FAILURE;
+    }
+
+    NrdHipExecutor* e = new NrdHipExecutor;
+    e->instance = (nrd::Instance*)instance;
+    e->stream = (hipStream_t)hipStream;
+    e->width = resourceWidth;
+    e->height = resourceHeight;
+
+    const nrd::InstanceDesc& desc = nrd::GetInstanceDesc(*e->instance);
+
+    uint64_t offset = 0;
+    bool ok = PlanPool(desc.permanentPool, desc.permanentPoolSize, resourceWidth, resourceHeight, e->permanent, e->permanentFormat, offset);
+    e->permanentBytes = offset;
+    ok = ok && PlanPool(desc.transientPool, desc.transientPoolSize, resourceWidth, resourceHeight, e->transient, e->transientFormat, offset);
+    e->transientBytes = offset - e->permanentBytes;
+    if (!ok) {
+        delete e;
+        return (uint32_t)nrd::Result::UNSUPPORTED;
+    }
+
+    if (offset) {
+        if (hipMalloc((void**)&e->arena, offset) != hipSuccess) {
+            delete e;
+            return (uint32_t)nrd::Result::FAILURE;
+        }
+        (void)hipMemsetAsync(e->arena, 0, offset, e->stream);
+        for (Plane& p : e->permanent)
+            p.ptr = e->arena + (uintptr_t)p.ptr;
+        for (Plane& p : e->transient)
+            p.ptr = e->arena + (uintptr_t)p.ptr;
+    }
+
+    // pipeline index -> launcher
+    e->launchers.assign(desc.pipelinesNum, nullptr);
+    const PassEntry* tables[3];
+    uint32_t counts[3];
+    tables[0] = GetCommonPasses(counts[0]);
+    tables[1] = GetReblurPasses(counts[1]);
+    tables[2] = GetSigmaPasses(counts[2]);
+    for (uint32_t p = 0; p < desc.pipelinesNum; p++)
+        for (int t = 0; t < 3; t++)
+            for (uint32_t i = 0; i < counts[t]; i++)
+                if (!strcmp(tables[t][i].shaderFileName, desc.pipelines[p].shaderFileName))
+                    e->launchers[p] = tables[t][i].launch;
+
+    *executor = e;
+    return (uint32_t)nrd::Result::SUCCESS;
+}
+
+extern "C" __attribute__((visibility("default"))) void nrdHipDestroyExecutor(NrdHipExecutor* e) {
+    if (!e)
+        return;
+    if (e->arena) {
+        (void)hipStreamSynchronize(e->stream);
+        (void)hipFree(e->arena);
+    }
+    delete e;
+}
+
+extern "C" __attribute__((visibility("default"))) uint32_t nrdHipBindResource(NrdHipExecutor* e, uint32_t resourceType, const NrdHipPlaneDesc* plane) {
+    if (!e || !plane)
+        return (uint32_t)nrd::Result::INVALID_ARGUMENT;
+    if (resourceType >= (uint32_t)nrd::ResourceType::TRANSIENT_POOL)
+        return e->Fail(nrd::Result::INVALID_ARGUMENT, "nrdHipBindResource: not a user slot");
+
+    nrd::Format expected = ExpectedUserFormat((nrd::ResourceType)resourceType);
+    if (expected == nrd::Format::MAX_NUM)
+        return e->Fail(nrd::Result::UNSUPPORTED, std::string("nrdHipBindResource: slot not supported in this build: ") + nrd::GetResourceTypeString((nrd::ResourceType)resourceType));
+    if (plane->format != (uint32_t)expected)
+        return e->Fail(nrd::Result::UNSUPPORTED, std::string("nrdHipBindResource: unexpected format for ") + nrd::GetResourceTypeString((nrd::ResourceType)resourceType));
+
+    uint32_t bpt = BytesPerTexel(expected);
+    if (!plane->data || plane->width != e->width || plane->height != e->height || plane->rowPitchBytes < plane->width * bpt || (plane->rowPitchBytes % bpt) != 0 ||
+        ((uintptr_t)plane->data % bpt) != 0)
+        return e->Fail(nrd::Result::INVALID_ARGUMENT, "nrdHipBindResource: bad pointer, size or pitch");
+
+    Plane& p = e->user[resourceType];
+    p.ptr = (uint8_t*)plane->data;
+    p.pitch = plane->rowPitchBytes;
+    p.w = plane->width;
+    p.h = plane->height;
+    e->userBound[resourceType] = true;
+    return (uint32_t)nrd::Result::SUCCESS;
+}
+
+extern "C" __attribute__((visibility("default"))) uint32_t nrdHipGetPoolPlane(NrdHipExecutor* e, uint32_t resourceType, uint32_t indexInPool, NrdHipPlaneDesc* plane) {
+    if (!e || !plane)
+        return (uint32_t)nrd::Result::INVALID_ARGUMENT;
+    const std::vector<Plane>* pool = nullptr;
+    const std::vector<nrd::Format>* formats = nullptr;
+    if (resourceType == (uint32_t)nrd::ResourceType::PERMANENT_POOL) {
+        pool = &e->permanent;
+        formats = &e->permanentFormat;
+    } else if (resourceType == (uint32_t)nrd::ResourceType::TRANSIENT_POOL) {
+        pool = &e->transient;
+        formats = &e->transientFormat;
+    }
+    if (!pool || indexInPool >= pool->size())
+        return e->Fail(nrd::Result::INVALID_ARGUMENT, "nrdHipGetPoolPlane: bad pool or index");
+    const Plane& p = (*pool)[indexInPool];
+    plane->data = p.ptr;
+    plane->rowPitchBytes = p.pitch;
+    plane->format = (uint32_t)(*formats)[indexInPool];
+    plane->width = (uint16_t)p.w;
+    plane->height = (uint16_t)p.h;
+    return (uint32_t)nrd::Result::SUCCESS;
+}
+
+extern "C" __attribute__((visibility("default"))) uint32_t nrdHipExecuteDispatches(NrdHipExecutor* e, const void* dispatchDescs, uint32_t dispatchDescsNum) {
+    if (!e || (!dispatchDescs && dispatchDescsNum))
+        return (uint32_t)nrd::Result::INVALID_ARGUMENT;
+    const nrd::DispatchDesc* descs = (const nrd::DispatchDesc*)dispatchDescs;
+
+    for (uint32_t i = 0; i < dispatchDescsNum; i++) {
+        const nrd::DispatchDesc& d = descs[i];
+        if (d.pipelineIndex >= e->launchers.size())
+            return e->Fail(nrd::Result::INVALID_ARGUMENT, "nrdHipExecuteDispatches: pipeline index out of range");
+        PassLauncher launch = e->launchers[d.pipelineIndex];
+        if (!launch)
+            return e->Fail(nrd::Result::UNSUPPORTED, std::string("nrdHipExecuteDispatches: no HIP kernel for pass '") + (d.name ? d.name : "?") + "' (" +
+                nrd::GetInstanceDesc(*e->instance).pipelines[d.pipelineIndex].shaderFileName + ")");
+
+        e->scratchPlanes.resize(d.resourcesNum);
+        for (uint32_t r = 0; r < d.resourcesNum; r++) {
+            const nrd::ResourceDesc& res = d.resources[r];
+            if (res.type == nrd::ResourceType::PERMANENT_POOL) {
+                if (res.indexInPool >= e->permanent.size())
+                    return e->Fail(nrd::Result::INVALID_ARGUMENT, "permanent pool index out of range");
+                e->scratchPlanes[r] = e->permanent[res.indexInPool];
+            } else if (res.type == nrd::ResourceType::TRANSIENT_POOL) {
+                if (res.indexInPool >= e->transient.size())
+                    return e->Fail(nrd::Result::INVALID_ARGUMENT, "transient pool index out of range");
+                e->scratchPlanes[r] = e->transient[res.indexInPool];
+            } else {
+                uint32_t t = (uint32_t)res.type;
+                if (t >= (uint32_t)nrd::ResourceType::MAX_NUM || !e->userBound[t])
+                    return e->Fail(nrd::Result::INVALID_ARGUMENT, std::string("resource not bound: ") + (nrd::GetResourceTypeString(res.type) ? nrd::GetResourceTypeString(res.type) : "?"));
+                e->scratchPlanes[r] = e->user[t];
+            }
+        }
+
+        PassArgs args;
+        args.planes = e->scratchPlanes.data();
+        args.planesNum = d.resourcesNum;
+        args.constants = d.constantBufferData;
+        args.constantsSize = d.constantBufferDataSize;
+        args.stream = e->stream;
+        launch(args);
+    }
+
+    hipError_t err = hipGetLastError();
+    if (err != hipSuccess)
+        return e->Fail(nrd::Result::FAILURE, std::string("HIP launch failed: ") + hipGetErrorString(err));
+    return (uint32_t)nrd::Result::SUCCESS;
+}
+
+extern "C" __attribute__((visibility("default"))) uint32_t nrdHipDenoise(NrdHipExecutor* e, const uint32_t* identifiers, uint32_t identifiersNum) {
+    if (!e)
+        return (uint32_t)nrd::Result::INVALID_ARGUMENT;
+    const nrd::DispatchDesc* descs = nullptr;
+    uint32_t num = 0;
+    nrd::Result r = nrd::GetComputeDispatches(*e->instance, identifiers, identifiersNum, descs, num);
+    if (r != nrd::Result::SUCCESS)
+        return e->Fail(r, "nrd::GetComputeDispatches failed");
+    return nrdHipExecuteDispatches(e, descs, num);
+}
+
+extern "C" __attribute__((visibility("default"))) uint32_t nrdHipGetPoolMemoryUsage(const NrdHipExecutor* e, uint64_t* permanentBytes, uint64_t* transientBytes) {
+    if (!e)
+        return (uint32_t)nrd::Result::INVALID_ARGUMENT;
+    if (permanentBytes)
+        *permanentBytes = e->permanentBytes;
+    if (transientBytes)
+        *transientBytes = e->transientBytes;
+    return (uint32_t)nrd::Result::SUCCESS;
+}
+
+extern "C" __attribute__((visibility("default"))) const char* nrdHipGetLastError(const NrdHipExecutor* e) { return e ? e->lastError.c_str() : "null executor"; }

@@ -1,0 +1,75 @@
+// Clear and REFERENCE passes (pure streaming kernels).
+//   Clear_Float / Clear_Uint          reference Shaders/Source/Clear_{Float,Uint}.cs.hlsl:16-23
+//   REFERENCE_TemporalAccumulation    reference Shaders/Source/REFERENCE_TemporalAccumulation.cs.hlsl:18-27
+//   REFERENCE_Copy                    reference Shaders/Source/REFERENCE_Copy.cs.hlsl:18-26
+// MI355X mapping: rows are processed as 16-byte vectors, one 256-thread block covers 256 vectors of one row segment,
+// so every wave issues full 1 KiB coalesced transactions; ~48 B/px of traffic and no reuse => HBM-bound.
+#include "../common/pass_constants.h"
+#include "nrdmath.h"
+#include "passes.h"
+
+namespace nrdhip {
+
+// ---- Clear: zero the whole plane (pitch included: padding bytes are never read) -----------------------------------
+__global__ __launch_bounds__(256) void ClearPlaneKernel(Plane out, uint32_t rowBytes16) {
+    uint32_t v = blockIdx.x * 256u + threadIdx.x;
+    uint32_t y = blockIdx.y;
+    if (v < rowBytes16)
+        ((uint4*)(out.ptr + (size_t)y * out.pitch))[v] = make_uint4(0, 0, 0, 0);
+}
+
+static void LaunchClear(const PassArgs& a) {
+    const Plane& out = a.planes[0];
+    uint32_t rowBytes16 = out.pitch / 16; // pitch is a multiple of 256
+    dim3 grid((rowBytes16 + 255) / 256, (unsigned)out.h, 1);
+    hipLaunchKernelGGL(ClearPlaneKernel, grid, dim3(256), 0, a.stream, out, rowBytes16);
+}
+
+// ---- REFERENCE accumulate: history = lerp(history, input, accumSpeed), in place -------------------------------------
+__global__ __launch_bounds__(256) void ReferenceAccumulateKernel(Plane input, Plane history, float accumSpeed) {
+    int x = blockIdx.x * 256 + threadIdx.x;
+    int y = blockIdx.y;
+    if (x >= history.w)
+        return;
+    float4 in = InBounds(input, x, y) ? LoadRGBA32F(input, x, y) : F4(0.0f);
+    float4 h = LoadRGBA32F(history, x, y);
+    StoreRGBA32F(history, x, y, Lerp(h, in, accumSpeed));
+}
+
+static void LaunchReferenceAccumulate(const PassArgs& a) {
+    const auto* c = (const nrdc::ReferenceAccumulateConstants*)a.constants;
+    const Plane& history = a.planes[1];
+    dim3 grid((unsigned)(history.w + 255) / 256, (unsigned)history.h, 1);
+    hipLaunchKernelGGL(ReferenceAccumulateKernel, grid, dim3(256), 0, a.stream, a.planes[0], history, c->gAccumSpeed);
+}
+
+// ---- REFERENCE copy: out = history where pixelUv.x > splitScreen -----------------------------------------------------
+__global__ __launch_bounds__(256) void ReferenceCopyKernel(Plane history, Plane out, float rectSizeInvX, float splitScreen) {
+    int x = blockIdx.x * 256 + threadIdx.x;
+    int y = blockIdx.y;
+    if (x >= out.w || !InBounds(history, x, y))
+        return;
+    float pixelUvX = (float(x) + 0.5f) * rectSizeInvX;
+    if (pixelUvX > splitScreen)
+        StoreRGBA32F(out, x, y, LoadRGBA32F(history, x, y));
+}
+
+static void LaunchReferenceCopy(const PassArgs& a) {
+    const auto* c = (const nrdc::ReferenceCopyConstants*)a.constants;
+    const Plane& out = a.planes[1];
+    dim3 grid((unsigned)(out.w + 255) / 256, (unsigned)out.h, 1);
+    hipLaunchKernelGGL(ReferenceCopyKernel, grid, dim3(256), 0, a.stream, a.planes[0], out, c->gRectSizeInv.x, c->gSplitScreen);
+}
+
+const PassEntry* GetCommonPasses(uint32_t& num) {
+    static const PassEntry kPasses[] = {
+        {"Clear_Float.cs", LaunchClear},
+        {"Clear_Uint.cs", LaunchClear},
+        {"REFERENCE_TemporalAccumulation.cs", LaunchReferenceAccumulate},
+        {"REFERENCE_Copy.cs", LaunchReferenceCopy},
+    };
+    num = sizeof(kPasses) / sizeof(kPasses[0]);
+    return kPasses;
+}
+
+} // namespace nrdhip

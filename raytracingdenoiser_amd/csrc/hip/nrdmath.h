@@ -1,0 +1,360 @@
+// Device math for the NRD pass chain: HLSL intrinsics with pinned definitions, bit-reproducible transcendentals, the
+// restated NVIDIA-RTX/MathLib subset the shaders call ("ml.hlsli" -- NOT vendored in the reference, fetched unpinned
+// at configure time, reference CMakeLists.txt:118-127), and the NRD.hlsli front-end/back-end codecs.
+//
+// Reproducibility contract (DESIGN.md "Numerics"): everything here is built from + - * / sqrt, comparisons, floor
+// and integer bit operations only, all IEEE-754 correctly rounded on gfx950 and on x86-64, and this file is compiled
+// with -ffp-contract=off. The CPU oracle (oracle/) restates the same definitions independently, so the two can be
+// compared bit-for-bit instead of through a loose tolerance that the chain's many thresholds would amplify.
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+
+namespace nrdhip {
+
+#ifndef NRD_D
+#    define NRD_D __device__ __forceinline__
+#endif
+
+// ------------------------------------------------------------------------------------------------ constants
+#define NRD_FP16_MAX 65504.0f
+#define NRD_PI 3.14159265358979323846f
+#define NRD_EPS 1e-6f
+#define NRD_INF 1e6f
+#define NRD_NORMAL_ENCODING_ERROR (0.75f / 255.0f) // R10G10B10A2 oct normals, reference Common.hlsli:76-78
+#define NRD_ROUGHNESS_SENSITIVITY 0.01f
+#define NRD_EXP_WEIGHT_DEFAULT_SCALE 3.0f
+#define NRD_CATROM_SHARPNESS 0.5f
+#define NRD_DISOCCLUSION_THRESHOLD 0.02f
+#define NRD_MAX_PERCENT_OF_LOBE_VOLUME 0.75f
+#define NRD_CURVATURE_Z_THRESHOLD 0.1f
+
+// ------------------------------------------------------------------------------------------------ scalar intrinsics
+NRD_D float Min(float a, float b) { return a < b ? a : b; }
+NRD_D float Max(float a, float b) { return a > b ? a : b; }
+NRD_D float Clamp(float x, float a, float b) { return Min(Max(x, a), b); }
+NRD_D float Sat(float x) { return Min(Max(x, 0.0f), 1.0f); }
+NRD_D float Lerp(float a, float b, float t) { return a + (b - a) * t; }
+NRD_D float Step(float edge, float x) { return x >= edge ? 1.0f : 0.0f; }
+NRD_D float Rcp(float x) { return 1.0f / x; }
+NRD_D float Sqrt(float x) { return __fsqrt_rn(x); }
+NRD_D float Rsqrt(float x) { return 1.0f / __fsqrt_rn(x); }
+NRD_D float Abs(float x) { return fabsf(x); }
+NRD_D float Floor(float x) { return floorf(x); }
+NRD_D float Frac(float x) { return x - floorf(x); }
+NRD_D uint32_t AsUint(float x) { return __float_as_uint(x); }
+NRD_D float AsFloat(uint32_t x) { return __uint_as_float(x); }
+
+// ------------------------------------------------------------------------------------------------ reproducible transcendentals
+// 2^x: nearest-integer split + degree-7 Taylor of 2^f on [-0.5, 0.5] (truncation < 6e-9), Horner, no FMA.
+NRD_D float Exp2(float x) {
+    x = Clamp(x, -125.0f, 125.0f);
+    float fi = floorf(x + 0.5f);
+    float f = x - fi;
+    float p = 1.5252733805e-5f;
+    p = p * f + 1.5403530393e-4f;
+    p = p * f + 1.3333558146e-3f;
+    p = p * f + 9.6181291076e-3f;
+    p = p * f + 5.5504108665e-2f;
+    p = p * f + 2.4022650696e-1f;
+    p = p * f + 6.9314718056e-1f;
+    p = p * f + 1.0f;
+    return p * AsFloat((uint32_t)((int)fi + 127) << 23);
+}
+
+// log2(x), x > 0 (x <= 0 returns -126): mantissa folded to [sqrt(1/2), sqrt(2)), atanh series in s = (m-1)/(m+1).
+NRD_D float Log2(float x) {
+    if (!(x > 0.0f))
+        return -126.0f;
+    uint32_t bits = AsUint(x);
+    int e = (int)(bits >> 23) - 127;
+    if (e == -127) { // denormal input: renormalise
+        bits = AsUint(x * 8388608.0f);
+        e = (int)(bits >> 23) - 127 - 23;
+    }
+    float m = AsFloat((bits & 0x007FFFFFu) | 0x3F800000u); // [1, 2)
+    if (m > 1.41421356f) {
+        m = m * 0.5f;
+        e += 1;
+    }
+    float s = (m - 1.0f) / (m + 1.0f);
+    float s2 = s * s;
+    float p = 0.22222222f; // 2/9
+    p = p * s2 + 0.28571429f;     // 2/7
+    p = p * s2 + 0.4f;            // 2/5
+    p = p * s2 + 0.66666667f;     // 2/3
+    p = p * s2 + 2.0f;
+    return float(e) + (p * s) * 1.44269504f;
+}
+
+NRD_D float Exp(float x) { return Exp2(x * 1.44269504f); }
+NRD_D float Log(float x) { return Log2(x) * 0.69314718f; }
+// x^y for x >= 0 (0^y = 0 for the y > 0 the chain uses)
+NRD_D float Pow(float x, float y) { return x <= 0.0f ? 0.0f : Exp2(y * Log2(x)); }
+
+// atan(x): Cephes-style reduction to |t| <= tan(pi/8) and a degree-9 odd polynomial (abs. error ~1e-7)
+NRD_D float Atan(float x) {
+    float a = Abs(x);
+    float base = 0.0f;
+    float t = a;
+    if (a > 2.41421356f) {
+        base = 1.57079633f;
+        t = -1.0f / a;
+    } else if (a > 0.41421356f) {
+        base = 0.78539816f;
+        t = (a - 1.0f) / (a + 1.0f);
+    }
+    float z = t * t;
+    float p = 8.05374449538e-2f;
+    p = p * z - 1.38776856032e-1f;
+    p = p * z + 1.99777106478e-1f;
+    p = p * z - 3.33329491539e-1f;
+    float r = base + (p * z * t + t);
+    return x < 0.0f ? -r : r;
+}
+
+// ------------------------------------------------------------------------------------------------ vectors
+NRD_D float2 F2(float x, float y) { return make_float2(x, y); }
+NRD_D float3 F3(float x, float y, float z) { return make_float3(x, y, z); }
+NRD_D float3 F3(float x) { return make_float3(x, x, x); }
+NRD_D float4 F4(float x, float y, float z, float w) { return make_float4(x, y, z, w); }
+NRD_D float4 F4(float3 v, float w) { return make_float4(v.x, v.y, v.z, w); }
+NRD_D float4 F4(float x) { return make_float4(x, x, x, x); }
+NRD_D float3 Xyz(float4 v) { return make_float3(v.x, v.y, v.z); }
+
+NRD_D float2 operator+(float2 a, float2 b) { return F2(a.x + b.x, a.y + b.y); }
+NRD_D float2 operator-(float2 a, float2 b) { return F2(a.x - b.x, a.y - b.y); }
+NRD_D float2 operator*(float2 a, float2 b) { return F2(a.x * b.x, a.y * b.y); }
+NRD_D float2 operator*(float2 a, float b) { return F2(a.x * b, a.y * b); }
+NRD_D float2 operator/(float2 a, float2 b) { return F2(a.x / b.x, a.y / b.y); }
+NRD_D float2 operator/(float2 a, float b) { return F2(a.x / b, a.y / b); }
+NRD_D float2 operator+(float2 a, float b) { return F2(a.x + b, a.y + b); }
+NRD_D float2 operator-(float2 a, float b) { return F2(a.x - b, a.y - b); }
+
+NRD_D float3 operator+(float3 a, float3 b) { return F3(a.x + b.x, a.y + b.y, a.z + b.z); }
+NRD_D float3 operator-(float3 a, float3 b) { return F3(a.x - b.x, a.y - b.y, a.z - b.z); }
+NRD_D float3 operator-(float3 a) { return F3(-a.x, -a.y, -a.z); }
+NRD_D float3 operator*(float3 a, float3 b) { return F3(a.x * b.x, a.y * b.y, a.z * b.z); }
+NRD_D float3 operator*(float3 a, float b) { return F3(a.x * b, a.y * b, a.z * b); }
+NRD_D float3 operator/(float3 a, float b) { return F3(a.x / b, a.y / b, a.z / b); }
+
+NRD_D float4 operator+(float4 a, float4 b) { return F4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w); }
+NRD_D float4 operator-(float4 a, float4 b) { return F4(a.x - b.x, a.y - b.y, a.z - b.z, a.w - b.w); }
+NRD_D float4 operator*(float4 a, float4 b) { return F4(a.x * b.x, a.y * b.y, a.z * b.z, a.w * b.w); }
+NRD_D float4 operator*(float4 a, float b) { return F4(a.x * b, a.y * b, a.z * b, a.w * b); }
+NRD_D float4 operator/(float4 a, float b) { return F4(a.x / b, a.y / b, a.z / b, a.w / b); }
+NRD_D float4 operator-(float4 a, float b) { return F4(a.x - b, a.y - b, a.z - b, a.w - b); }
+
+NRD_D float Dot(float2 a, float2 b) { return a.x * b.x + a.y * b.y; }
+NRD_D float Dot(float3 a, float3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
+NRD_D float Dot(float4 a, float4 b) { return a.x * b.x + a.y * b.y + a.z * b.z + a.w * b.w; }
+NRD_D float Sum(float4 a) { return a.x + a.y + a.z + a.w; } // dot( a, 1.0 )
+NRD_D float Length(float2 v) { return Sqrt(Dot(v, v)); }
+NRD_D float Length(float3 v) { return Sqrt(Dot(v, v)); }
+NRD_D float LengthSquared(float3 v) { return Dot(v, v); }
+NRD_D float LengthSquared(float2 v) { return Dot(v, v); }
+NRD_D float3 Normalize(float3 v) { return v * Rsqrt(Dot(v, v)); }
+NRD_D float3 Cross(float3 a, float3 b) { return F3(a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x); }
+NRD_D float3 Reflect(float3 i, float3 n) { return i - n * (2.0f * Dot(n, i)); }
+NRD_D float3 Lerp(float3 a, float3 b, float t) { return F3(Lerp(a.x, b.x, t), Lerp(a.y, b.y, t), Lerp(a.z, b.z, t)); }
+NRD_D float4 Lerp(float4 a, float4 b, float t) { return F4(Lerp(a.x, b.x, t), Lerp(a.y, b.y, t), Lerp(a.z, b.z, t), Lerp(a.w, b.w, t)); }
+NRD_D float2 Lerp(float2 a, float2 b, float t) { return F2(Lerp(a.x, b.x, t), Lerp(a.y, b.y, t)); }
+NRD_D float2 Sat(float2 v) { return F2(Sat(v.x), Sat(v.y)); }
+NRD_D float2 Floor(float2 v) { return F2(floorf(v.x), floorf(v.y)); }
+NRD_D float2 Abs(float2 v) { return F2(Abs(v.x), Abs(v.y)); }
+NRD_D float3 Abs(float3 v) { return F3(Abs(v.x), Abs(v.y), Abs(v.z)); }
+NRD_D float4 Abs(float4 v) { return F4(Abs(v.x), Abs(v.y), Abs(v.z), Abs(v.w)); }
+NRD_D float3 Max(float3 v, float s) { return F3(Max(v.x, s), Max(v.y, s), Max(v.z, s)); }
+NRD_D float4 Step(float4 edge, float4 x) { return F4(Step(edge.x, x.x), Step(edge.y, x.y), Step(edge.z, x.z), Step(edge.w, x.w)); }
+NRD_D float3 Step(float3 edge, float x) { return F3(Step(edge.x, x), Step(edge.y, x), Step(edge.z, x)); }
+
+// ------------------------------------------------------------------------------------------------ Math::
+NRD_D float LinearStep(float a, float b, float x) { return Sat((x - a) / (b - a)); }
+NRD_D float SmoothStep01(float x) {
+    x = Sat(x);
+    return x * x * (3.0f - 2.0f * x);
+}
+NRD_D float SmoothStep(float a, float b, float x) { return SmoothStep01(LinearStep(a, b, x)); }
+NRD_D float Sqrt01(float x) { return Sqrt(Sat(x)); }
+NRD_D float Pow01(float x, float y) { return Pow(Sat(x), y); }
+NRD_D float PositiveRcp(float x) { return 1.0f / Max(x, 1e-15f); }
+NRD_D float AcosApprox(float x) { return 1.41421356f * Sqrt(Sat(1.0f - x)); } // sqrt(2) * sqrt(saturate(1 - x))
+NRD_D float Pow5(float x) {                                                  // BRDF::Pow5 = (1 - x)^5 on saturated input
+    float t = Sat(1.0f - x);
+    float t2 = t * t;
+    return t2 * t2 * t;
+}
+
+// ------------------------------------------------------------------------------------------------ Geometry::
+// 4x4 matrices are 16 floats, column-major (csrc/common/pass_constants.h)
+NRD_D float3 RotateVector(const float* m, float3 v) { // (float3x3)M * v
+    return F3(m[0] * v.x + m[4] * v.y + m[8] * v.z, m[1] * v.x + m[5] * v.y + m[9] * v.z, m[2] * v.x + m[6] * v.y + m[10] * v.z);
+}
+NRD_D float3 RotateVectorInverse(const float* m, float3 v) { // transpose((float3x3)M) * v
+    return F3(m[0] * v.x + m[1] * v.y + m[2] * v.z, m[4] * v.x + m[5] * v.y + m[6] * v.z, m[8] * v.x + m[9] * v.y + m[10] * v.z);
+}
+NRD_D float3 AffineTransform(const float* m, float3 p) {
+    return F3(m[0] * p.x + m[4] * p.y + m[8] * p.z + m[12], m[1] * p.x + m[5] * p.y + m[9] * p.z + m[13], m[2] * p.x + m[6] * p.y + m[10] * p.z + m[14]);
+}
+NRD_D float4 ProjectiveTransform(const float* m, float3 p) {
+    return F4(m[0] * p.x + m[4] * p.y + m[8] * p.z + m[12], m[1] * p.x + m[5] * p.y + m[9] * p.z + m[13], m[2] * p.x + m[6] * p.y + m[10] * p.z + m[14],
+        m[3] * p.x + m[7] * p.y + m[11] * p.z + m[15]);
+}
+// clip -> uv with y flipped; points behind the camera are sent far off-screen
+NRD_D float2 GetScreenUv(const float* worldToClip, float3 X) {
+    float4 clip = ProjectiveTransform(worldToClip, X);
+    float2 uv = F2((clip.x / clip.w) * 0.5f + 0.5f, (clip.y / clip.w) * -0.5f + 0.5f);
+    return clip.w < 0.0f ? F2(99999.0f, 99999.0f) : uv;
+}
+// inverse of the above for a known viewZ: Xv.xy = (uv * frustum.zw + frustum.xy) * viewZ (perspective)
+NRD_D float3 ReconstructViewPosition(float2 uv, float4 frustum, float viewZ, float orthoMode) {
+    float s = viewZ * (1.0f - Abs(orthoMode)) + orthoMode;
+    return F3((uv.x * frustum.z + frustum.x) * s, (uv.y * frustum.w + frustum.y) * s, viewZ);
+}
+// rotator = (cos, sin, -sin, cos): v' = v.x * r.xz + v.y * r.yw
+NRD_D float2 RotateVector(float4 r, float2 v) { return F2(v.x * r.x + v.y * r.y, v.x * r.z + v.y * r.w); }
+NRD_D float4 ScaleRotator(float4 r, float2 s) { return F4(r.x * s.x, r.y * s.x, r.z * s.y, r.w * s.y); }
+// branch-free orthonormal basis (Duff et al. 2017): T, B such that {T, B, N} is right-handed
+NRD_D void GetBasis(float3 N, float3& T, float3& B) {
+    float sz = N.z >= 0.0f ? 1.0f : -1.0f;
+    float a = 1.0f / (sz + N.z);
+    float ya = N.y * a;
+    float b = N.x * ya;
+    float c = N.x * sz;
+    T = F3(c * N.x * a - 1.0f, sz * b, c);
+    B = F3(b, N.y * ya - sz, N.y);
+}
+
+// ------------------------------------------------------------------------------------------------ Color:: / Packing:: / Sequence::
+NRD_D float Luminance(float3 c) { return c.x * 0.2126f + c.y * 0.7152f + c.z * 0.0722f; }
+NRD_D float ColorClamp(float m1, float sigma, float x) { return Clamp(x, m1 - sigma, m1 + sigma); }
+NRD_D float3 LinearToYCoCg(float3 c) { // reference NRD.hlsli:356-363
+    return F3(c.x * 0.25f + c.y * 0.5f + c.z * 0.25f, c.x * 0.5f + c.y * 0.0f + c.z * -0.5f, c.x * -0.25f + c.y * 0.5f + c.z * -0.25f);
+}
+NRD_D float3 YCoCgToLinear(float3 c) { // reference NRD.hlsli:365-375
+    float t = c.x - c.z;
+    return F3(Max(t + c.y, 0.0f), Max(c.x + c.z, 0.0f), Max(t - c.y, 0.0f));
+}
+NRD_D uint32_t CheckerBoard(uint32_t x, uint32_t y, uint32_t frameIndex) { return ((x ^ y) ^ frameIndex) & 1u; }
+NRD_D uint32_t Bayer4x4ui(uint32_t x, uint32_t y, uint32_t frameIndex) {
+    x &= 3u;
+    y &= 3u;
+    uint32_t a = 2068378560u * (1u - (x >> 1)) + 1500172770u * (x >> 1);
+    uint32_t b = (y + ((x & 1u) << 2)) << 2;
+    return ((a >> b) + frameIndex) & 0xFu;
+}
+NRD_D float Bayer4x4(uint32_t x, uint32_t y, uint32_t frameIndex) { return (float(Bayer4x4ui(x, y, frameIndex)) + 0.5f) / 16.0f; }
+
+// Rng::Hash -- OUR definition (MathLib's is unavailable): PCG-style state seeded from (pixel, frame)
+struct RngHash {
+    uint32_t state;
+    NRD_D void Initialize(uint32_t x, uint32_t y, uint32_t frameIndex) {
+        uint32_t s = x * 0x9E3779B1u ^ (y * 0x85EBCA77u + 0xC2B2AE3Du) ^ (frameIndex * 0x27D4EB2Fu + 0x165667B1u);
+        s ^= s >> 15;
+        s *= 0x2C1B3C6Du;
+        s ^= s >> 12;
+        s *= 0x297A2D39u;
+        s ^= s >> 15;
+        state = s;
+    }
+    NRD_D uint32_t Next() {
+        state = state * 747796405u + 2891336453u;
+        uint32_t w = ((state >> ((state >> 28) + 4u)) ^ state) * 277803737u;
+        return (w >> 22) ^ w;
+    }
+    NRD_D float GetFloat() { return float(Next() >> 8) * (1.0f / 16777216.0f); }
+    NRD_D float2 GetFloat2() {
+        float a = GetFloat();
+        float b = GetFloat();
+        return F2(a, b);
+    }
+};
+
+// ------------------------------------------------------------------------------------------------ Filtering::
+struct Bilinear {
+    float2 origin;  // integer texel coords of the top-left tap
+    float2 weights; // fractional position inside the 2x2 footprint
+};
+NRD_D Bilinear GetBilinearFilter(float2 uv, float2 texSize) {
+    float2 t = uv * texSize - 0.5f;
+    Bilinear r;
+    r.origin = Floor(t);
+    r.weights = t - r.origin;
+    return r;
+}
+// order: (0,0) (1,0) (0,1) (1,1)
+NRD_D float4 GetBilinearCustomWeights(Bilinear f, float4 customWeights) {
+    float2 oneMinus = F2(1.0f - f.weights.x, 1.0f - f.weights.y);
+    float4 w = customWeights;
+    w.x *= oneMinus.x * oneMinus.y;
+    w.y *= f.weights.x * oneMinus.y;
+    w.z *= oneMinus.x * f.weights.y;
+    w.w *= f.weights.x * f.weights.y;
+    return w;
+}
+NRD_D float ApplyBilinearFilter(float s00, float s10, float s01, float s11, Bilinear f) {
+    return Lerp(Lerp(s00, s10, f.weights.x), Lerp(s01, s11, f.weights.x), f.weights.y);
+}
+NRD_D float ApplyBilinearCustomWeights(float s00, float s10, float s01, float s11, float4 w) {
+    float sum = w.x + w.y + w.z + w.w;
+    float r = s00 * w.x + s10 * w.y + s01 * w.z + s11 * w.w;
+    return sum < 0.0001f ? 0.0f : r / sum;
+}
+// top-left texel of the 4x4 Catmull-Rom footprint (reference REBLUR_TemporalAccumulation.hlsli:152-171)
+NRD_D float2 GetCatmullRomOrigin(float2 uv, float2 texSize) {
+    float2 t = uv * texSize - 0.5f;
+    return Floor(t) - 1.0f;
+}
+NRD_D float GetModifiedRoughnessFromNormalVariance(float linearRoughness, float3 nonNormalizedAverageNormal) {
+    float l = Length(nonNormalizedAverageNormal);
+    float kappa = Sat(1.0f - l * l) / Max(l * (3.0f - l * l), 1e-15f);
+    return Sqrt(Sat(linearRoughness * linearRoughness + kappa));
+}
+
+// ------------------------------------------------------------------------------------------------ ImportanceSampling::
+NRD_D float GetSpecularLobeTanHalfAngle(float linearRoughness, float percentOfVolume) {
+    float r = Sat(linearRoughness);
+    float p = Sat(percentOfVolume);
+    float m = r * r;
+    return m * Sqrt(p / (1.0f - p + NRD_EPS)); // the "fixed" MathLib form (see reference Reblur.cpp:384, RELAX_Common.hlsli:113-122)
+}
+NRD_D float GetSpecularDominantFactor(float NoV, float linearRoughness) { // G2 fit, reference NRD.hlsli:386-392
+    float a = 0.298475f * Log(39.4115f - 39.0029f * linearRoughness);
+    float f = Pow(Sat(1.0f - NoV), 10.8649f) * (1.0f - a) + a;
+    return Sat(f);
+}
+NRD_D float4 GetSpecularDominantDirection(float3 N, float3 V, float linearRoughness) {
+    float NoV = Abs(Dot(N, V));
+    float f = GetSpecularDominantFactor(NoV, linearRoughness);
+    float3 R = Reflect(-V, N);
+    float3 D = Normalize(Lerp(N, R, f));
+    return F4(D, f);
+}
+
+// ------------------------------------------------------------------------------------------------ NRD.hlsli codecs
+NRD_D float3 SafeNormalize(float3 v) { return v * Rsqrt(Dot(v, v) + 1e-9f); }
+NRD_D float3 DecodeUnitVectorOct(float2 p) { // unsigned input, not normalised; reference NRD.hlsli:333-343
+    float px = p.x * 2.0f - 1.0f, py = p.y * 2.0f - 1.0f;
+    float3 n = F3(px, py, 1.0f - Abs(px) - Abs(py));
+    float t = Sat(-n.z);
+    n.x -= t * (Step(0.0f, n.x) * 2.0f - 1.0f);
+    n.y -= t * (Step(0.0f, n.y) * 2.0f - 1.0f);
+    return n;
+}
+// IN_NORMAL_ROUGHNESS (R10G10B10A2_UNORM, oct normal, linear roughness, 2-bit material id) -> (N, roughness), materialID
+NRD_D float4 UnpackNormalAndRoughness(float4 p, float& materialID) { // reference NRD.hlsli:600-637
+    float3 n = DecodeUnitVectorOct(F2(p.x, p.y));
+    materialID = p.w * 3.0f;
+    return F4(SafeNormalize(n), p.z);
+}
+NRD_D float4 UnpackNormalAndRoughness(float4 p) {
+    float unused;
+    return UnpackNormalAndRoughness(p, unused);
+}
+NRD_D float GetHitDistanceNormalization(float viewZ, float4 hitDistParams, float roughness) { // reference NRD.hlsli:520-523
+    return (hitDistParams.x + Abs(viewZ) * hitDistParams.y) * Lerp(1.0f, hitDistParams.z, Sat(Exp2(hitDistParams.w * roughness * roughness)));
+}
+
+} // namespace nrdhip

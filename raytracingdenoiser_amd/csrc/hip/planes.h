@@ -1,0 +1,96 @@
+// Pitched HBM planes ("textures" of the reference become linear surfaces with a 256-byte-aligned row pitch) and the
+// texel codecs for every storage format the hot path uses. Quantisation on store is part of the contract
+// (history is fp16, accumulation speeds are UNORM8, ...), so each codec is spelled out:
+//   fp16   : round-to-nearest-even (v_cvt_f16_f32), denormals kept
+//   UNORMn : store floor(saturate(x) * (2^n - 1) + 0.5), load u / (2^n - 1)
+// Out-of-bounds semantics of the reference's texture units that the passes rely on are reproduced by the callers:
+// "Load" outside the plane returns 0, stores outside are dropped, clamp-samplers clamp the texel index.
+#pragma once
+
+#include <hip/hip_fp16.h>
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+
+namespace nrdhip {
+
+struct Plane {
+    uint8_t* ptr;   // device pointer to texel (0, 0)
+    uint32_t pitch; // bytes per row
+    int32_t w, h;   // texels
+};
+
+#define NRD_D __device__ __forceinline__
+
+NRD_D bool InBounds(const Plane& p, int x, int y) { return (unsigned)x < (unsigned)p.w && (unsigned)y < (unsigned)p.h; }
+
+template <typename T>
+NRD_D T* TexelPtr(const Plane& p, int x, int y) {
+    return (T*)(p.ptr + (size_t)y * p.pitch) + x;
+}
+
+// ---- fp16 -------------------------------------------------------------------------------------------------------
+NRD_D float HalfBitsToFloat(uint16_t h) { return __half2float(__ushort_as_half(h)); }
+NRD_D uint16_t FloatToHalfBits(float f) { return __half_as_ushort(__float2half_rn(f)); }
+
+// ---- R32_SFLOAT / R32_UINT / R16_UINT / R8_UINT -------------------------------------------------------------------
+NRD_D float LoadR32F(const Plane& p, int x, int y) { return *TexelPtr<const float>(p, x, y); }
+NRD_D void StoreR32F(const Plane& p, int x, int y, float v) { *TexelPtr<float>(p, x, y) = v; }
+NRD_D uint32_t LoadR32U(const Plane& p, int x, int y) { return *TexelPtr<const uint32_t>(p, x, y); }
+NRD_D void StoreR32U(const Plane& p, int x, int y, uint32_t v) { *TexelPtr<uint32_t>(p, x, y) = v; }
+NRD_D uint32_t LoadR16U(const Plane& p, int x, int y) { return *TexelPtr<const uint16_t>(p, x, y); }
+NRD_D void StoreR16U(const Plane& p, int x, int y, uint32_t v) { *TexelPtr<uint16_t>(p, x, y) = (uint16_t)v; }
+NRD_D uint32_t LoadR8U(const Plane& p, int x, int y) { return *TexelPtr<const uint8_t>(p, x, y); }
+NRD_D void StoreR8U(const Plane& p, int x, int y, uint32_t v) { *TexelPtr<uint8_t>(p, x, y) = (uint8_t)v; }
+
+// ---- R16_SFLOAT ---------------------------------------------------------------------------------------------------
+NRD_D float LoadR16F(const Plane& p, int x, int y) { return HalfBitsToFloat(*TexelPtr<const uint16_t>(p, x, y)); }
+NRD_D void StoreR16F(const Plane& p, int x, int y, float v) { *TexelPtr<uint16_t>(p, x, y) = FloatToHalfBits(v); }
+
+// ---- RGBA16_SFLOAT (one 8-byte access per texel) ------------------------------------------------------------------
+NRD_D float4 LoadRGBA16F(const Plane& p, int x, int y) {
+    uint2 raw = *TexelPtr<const uint2>(p, x, y);
+    float4 r;
+    r.x = HalfBitsToFloat((uint16_t)(raw.x & 0xFFFFu));
+    r.y = HalfBitsToFloat((uint16_t)(raw.x >> 16));
+    r.z = HalfBitsToFloat((uint16_t)(raw.y & 0xFFFFu));
+    r.w = HalfBitsToFloat((uint16_t)(raw.y >> 16));
+    return r;
+}
+NRD_D void StoreRGBA16F(const Plane& p, int x, int y, float4 v) {
+    uint2 raw;
+    raw.x = (uint32_t)FloatToHalfBits(v.x) | ((uint32_t)FloatToHalfBits(v.y) << 16);
+    raw.y = (uint32_t)FloatToHalfBits(v.z) | ((uint32_t)FloatToHalfBits(v.w) << 16);
+    *TexelPtr<uint2>(p, x, y) = raw;
+}
+
+// ---- RGBA32_SFLOAT --------------------------------------------------------------------------------------------------
+NRD_D float4 LoadRGBA32F(const Plane& p, int x, int y) { return *TexelPtr<const float4>(p, x, y); }
+NRD_D void StoreRGBA32F(const Plane& p, int x, int y, float4 v) { *TexelPtr<float4>(p, x, y) = v; }
+
+// ---- UNORM --------------------------------------------------------------------------------------------------------
+NRD_D float Saturate(float x) { return fminf(fmaxf(x, 0.0f), 1.0f); }
+NRD_D uint32_t ToUnorm(float x, float maxValue) { return (uint32_t)floorf(Saturate(x) * maxValue + 0.5f); }
+
+NRD_D float LoadR8Unorm(const Plane& p, int x, int y) { return float(*TexelPtr<const uint8_t>(p, x, y)) / 255.0f; }
+NRD_D void StoreR8Unorm(const Plane& p, int x, int y, float v) { *TexelPtr<uint8_t>(p, x, y) = (uint8_t)ToUnorm(v, 255.0f); }
+
+NRD_D float2 LoadRG8Unorm(const Plane& p, int x, int y) {
+    uint32_t raw = *TexelPtr<const uint16_t>(p, x, y);
+    return make_float2(float(raw & 0xFFu) / 255.0f, float(raw >> 8) / 255.0f);
+}
+NRD_D void StoreRG8Unorm(const Plane& p, int x, int y, float2 v) {
+    *TexelPtr<uint16_t>(p, x, y) = (uint16_t)(ToUnorm(v.x, 255.0f) | (ToUnorm(v.y, 255.0f) << 8));
+}
+
+NRD_D float4 DecodeR10G10B10A2(uint32_t raw) {
+    float4 r;
+    r.x = float(raw & 0x3FFu) / 1023.0f;
+    r.y = float((raw >> 10) & 0x3FFu) / 1023.0f;
+    r.z = float((raw >> 20) & 0x3FFu) / 1023.0f;
+    r.w = float(raw >> 30) / 3.0f;
+    return r;
+}
+NRD_D float4 LoadR10G10B10A2(const Plane& p, int x, int y) { return DecodeR10G10B10A2(*TexelPtr<const uint32_t>(p, x, y)); }
+
+} // namespace nrdhip

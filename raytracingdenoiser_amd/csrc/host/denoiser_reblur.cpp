@@ -1,0 +1,445 @@
+// REBLUR host tables for the radiance+hit-distance family: REBLUR_DIFFUSE, REBLUR_SPECULAR and
+// REBLUR_DIFFUSE_SPECULAR, generated from ONE parametrised description (the reference spells the three out in
+// Source/Denoisers/Reblur_{Diffuse,Specular,DiffuseSpecular}.hpp). Pool layouts, pass order, resource binding
+// order, permutation order (=> local pass indices and pipeline indices) and the per-frame permutation selection
+// are the reference's: Reblur.cpp:38-64 (formats), :104-210 (Update_Reblur), :297-406 (shared constants).
+#include "instance.h"
+
+#include <algorithm>
+#include <cstdio>
+
+namespace nrd {
+
+namespace {
+
+// Permutation counts: reference Reblur.cpp:26-30
+constexpr uint32_t HITDIST_RECONSTRUCTION_PERMUTATIONS = 4;
+constexpr uint32_t PREPASS_PERMUTATIONS = 2;
+constexpr uint32_t TEMPORAL_ACCUMULATION_PERMUTATIONS = 8;
+constexpr uint32_t POST_BLUR_PERMUTATIONS = 2;
+constexpr uint32_t TEMPORAL_STABILIZATION_PERMUTATIONS = 2;
+
+// Local pass indices; every pass except the first and the last two exists as {quality, performance} pair
+enum : uint32_t {
+    PASS_CLASSIFY_TILES = 0,
+    PASS_HITDIST_RECONSTRUCTION = PASS_CLASSIFY_TILES + 1,
+    PASS_PREPASS = PASS_HITDIST_RECONSTRUCTION + HITDIST_RECONSTRUCTION_PERMUTATIONS * 2,
+    PASS_TEMPORAL_ACCUMULATION = PASS_PREPASS + PREPASS_PERMUTATIONS * 2,
+    PASS_HISTORY_FIX = PASS_TEMPORAL_ACCUMULATION + TEMPORAL_ACCUMULATION_PERMUTATIONS * 2,
+    PASS_BLUR = PASS_HISTORY_FIX + 2,
+    PASS_POST_BLUR = PASS_BLUR + 2,
+    PASS_TEMPORAL_STABILIZATION = PASS_POST_BLUR + POST_BLUR_PERMUTATIONS * 2,
+    PASS_SPLIT_SCREEN = PASS_TEMPORAL_STABILIZATION + TEMPORAL_STABILIZATION_PERMUTATIONS * 2,
+    PASS_VALIDATION = PASS_SPLIT_SCREEN + 1,
+};
+
+constexpr Format FMT_SIGNAL = Format::RGBA16_SFLOAT;           // YCoCg radiance + normalised hit distance
+constexpr Format FMT_FAST = Format::R16_SFLOAT;                // fast-history luma
+constexpr Format FMT_PREV_VIEWZ = Format::R32_SFLOAT;
+constexpr Format FMT_PREV_NORMAL_ROUGHNESS = Format::R10_G10_B10_A2_UNORM; // follows the library's normal encoding
+constexpr Format FMT_PREV_INTERNAL_DATA = Format::R16_UINT;    // 6+6 bits of accumulated frames, 4 bits material id
+constexpr Format FMT_TILES = Format::R8_UNORM;
+constexpr Format FMT_HITDIST_FOR_TRACKING = Format::R16_SFLOAT;
+
+const uint16_t DUMMY = (uint16_t)ResourceType::IN_VIEWZ; // placeholder bound to optional, unused inputs
+
+} // namespace
+
+void InstanceImpl::Add_Reblur(DenoiserData& d, bool hasDiff, bool hasSpec) {
+    d.settings.reblur = ReblurSettings();
+    d.settingsSize = sizeof(ReblurSettings);
+
+    const char* family = hasDiff && hasSpec ? "DiffuseSpecular" : (hasDiff ? "Diffuse" : "Specular");
+    const uint32_t constSize = sizeof(nrdc::ReblurConstants);
+
+    // ---- permanent planes (history)
+    uint16_t next = PERMANENT_POOL_START;
+    const uint16_t P_PREV_VIEWZ = next++;
+    const uint16_t P_PREV_NORMAL_ROUGHNESS = next++;
+    const uint16_t P_PREV_INTERNAL_DATA = next++;
+    AddPermanent(FMT_PREV_VIEWZ);
+    AddPermanent(FMT_PREV_NORMAL_ROUGHNESS);
+    AddPermanent(FMT_PREV_INTERNAL_DATA);
+
+    uint16_t P_DIFF_HISTORY = 0, P_DIFF_FAST = 0, P_DIFF_STAB_PING = 0, P_DIFF_STAB_PONG = 0;
+    if (hasDiff) {
+        P_DIFF_HISTORY = next++;
+        P_DIFF_FAST = next++;
+        P_DIFF_STAB_PING = next++;
+        P_DIFF_STAB_PONG = next++;
+        AddPermanent(FMT_SIGNAL);
+        AddPermanent(FMT_FAST);
+        AddPermanent(Format::R16_SFLOAT);
+        AddPermanent(Format::R16_SFLOAT);
+    }
+    uint16_t P_SPEC_HISTORY = 0, P_SPEC_FAST = 0, P_SPEC_STAB_PING = 0, P_SPEC_STAB_PONG = 0, P_SPEC_HDT_PING = 0, P_SPEC_HDT_PONG = 0;
+    if (hasSpec) {
+        P_SPEC_HISTORY = next++;
+        P_SPEC_FAST = next++;
+        P_SPEC_STAB_PING = next++;
+        P_SPEC_STAB_PONG = next++;
+        P_SPEC_HDT_PING = next++;
+        P_SPEC_HDT_PONG = next++;
+        AddPermanent(FMT_SIGNAL);
+        AddPermanent(FMT_FAST);
+        AddPermanent(Format::R16_SFLOAT);
+        AddPermanent(Format::R16_SFLOAT);
+        AddPermanent(FMT_HITDIST_FOR_TRACKING);
+        AddPermanent(FMT_HITDIST_FOR_TRACKING);
+    }
+
+    // ---- transient planes (scratch)
+    next = TRANSIENT_POOL_START;
+    const uint16_t T_DATA1 = next++;
+    const uint16_t T_DATA2 = next++;
+    AddTransient(hasDiff && hasSpec ? Format::RG8_UNORM : Format::R8_UNORM);
+    AddTransient(hasSpec ? Format::R32_UINT : Format::R8_UINT); // diffuse-only keeps just the 4 occlusion bits
+    uint16_t T_SPEC_HDT = 0;
+    if (hasSpec) {
+        T_SPEC_HDT = next++;
+        AddTransient(FMT_HITDIST_FOR_TRACKING);
+    }
+    uint16_t T_DIFF_TMP2 = 0, T_DIFF_FAST = 0, T_SPEC_TMP2 = 0, T_SPEC_FAST = 0;
+    if (hasDiff) {
+        T_DIFF_TMP2 = next++;
+        T_DIFF_FAST = next++;
+        AddTransient(FMT_SIGNAL);
+        AddTransient(FMT_FAST);
+    }
+    if (hasSpec) {
+        T_SPEC_TMP2 = next++;
+        T_SPEC_FAST = next++;
+        AddTransient(FMT_SIGNAL);
+        AddTransient(FMT_FAST);
+    }
+    const uint16_t T_TILES = next++;
+    AddTransient(FMT_TILES, 16);
+
+    // The user-visible outputs double as scratch ("TEMP1")
+    const uint16_t DIFF_TEMP1 = (uint16_t)ResourceType::OUT_DIFF_RADIANCE_HITDIST, DIFF_TEMP2 = T_DIFF_TMP2;
+    const uint16_t SPEC_TEMP1 = (uint16_t)ResourceType::OUT_SPEC_RADIANCE_HITDIST, SPEC_TEMP2 = T_SPEC_TMP2;
+    const uint16_t IN_DIFF = (uint16_t)ResourceType::IN_DIFF_RADIANCE_HITDIST;
+    const uint16_t IN_SPEC = (uint16_t)ResourceType::IN_SPEC_RADIANCE_HITDIST;
+
+    char passName[96], shader[128];
+    auto Pass = [&](const char* what) {
+        snprintf(passName, sizeof(passName), "REBLUR_%s - %s", family, what);
+        BeginPass(InternString(passName));
+    };
+    // registers the {quality, performance} pair of a pass
+    auto EndPair = [&](const char* pass, const char* suffix) {
+        snprintf(shader, sizeof(shader), "REBLUR_%s_%s%s.cs", family, pass, suffix);
+        EndPass(shader, 8, 16, constSize);
+        snprintf(shader, sizeof(shader), "REBLUR_Perf_%s_%s%s.cs", family, pass, suffix);
+        EndPass(shader, 8, 16, constSize);
+    };
+
+    Pass("Classify tiles");
+    In(ResourceType::IN_VIEWZ);
+    Out(T_TILES);
+    EndPass("REBLUR_ClassifyTiles.cs", 16, 16, constSize);
+
+    for (uint32_t i = 0; i < HITDIST_RECONSTRUCTION_PERMUTATIONS; i++) {
+        bool is5x5 = (i >> 1) & 1, isPrepassEnabled = i & 1;
+        Pass("Hit distance reconstruction");
+        In(T_TILES);
+        In(ResourceType::IN_NORMAL_ROUGHNESS);
+        In(ResourceType::IN_VIEWZ);
+        if (hasDiff) In(IN_DIFF);
+        if (hasSpec) In(IN_SPEC);
+        if (hasDiff) Out(isPrepassEnabled ? DIFF_TEMP2 : DIFF_TEMP1);
+        if (hasSpec) Out(isPrepassEnabled ? SPEC_TEMP2 : SPEC_TEMP1);
+        EndPair("HitDistReconstruction", is5x5 ? "_5x5" : "");
+    }
+
+    for (uint32_t i = 0; i < PREPASS_PERMUTATIONS; i++) {
+        bool isAfterReconstruction = i & 1;
+        Pass("Pre-pass");
+        In(T_TILES);
+        In(ResourceType::IN_NORMAL_ROUGHNESS);
+        In(ResourceType::IN_VIEWZ);
+        if (hasDiff) In(isAfterReconstruction ? DIFF_TEMP2 : IN_DIFF);
+        if (hasSpec) In(isAfterReconstruction ? SPEC_TEMP2 : IN_SPEC);
+        if (hasDiff) Out(DIFF_TEMP1);
+        if (hasSpec) Out(SPEC_TEMP1);
+        if (hasSpec) Out(T_SPEC_HDT);
+        EndPair("PrePass", "");
+    }
+
+    for (uint32_t i = 0; i < TEMPORAL_ACCUMULATION_PERMUTATIONS; i++) {
+        bool hasDisocclusionThresholdMix = (i >> 2) & 1, hasConfidenceInputs = (i >> 1) & 1, isAfterPrepass = i & 1;
+        Pass("Temporal accumulation");
+        In(T_TILES);
+        In(ResourceType::IN_NORMAL_ROUGHNESS);
+        In(ResourceType::IN_VIEWZ);
+        In(ResourceType::IN_MV);
+        In(P_PREV_VIEWZ);
+        In(P_PREV_NORMAL_ROUGHNESS);
+        In(P_PREV_INTERNAL_DATA);
+        In(hasDisocclusionThresholdMix ? (uint16_t)ResourceType::IN_DISOCCLUSION_THRESHOLD_MIX : DUMMY);
+        if (hasDiff) In(hasConfidenceInputs ? (uint16_t)ResourceType::IN_DIFF_CONFIDENCE : DUMMY);
+        if (hasSpec) In(hasConfidenceInputs ? (uint16_t)ResourceType::IN_SPEC_CONFIDENCE : DUMMY);
+        if (hasDiff) In(isAfterPrepass ? DIFF_TEMP1 : IN_DIFF);
+        if (hasSpec) In(isAfterPrepass ? SPEC_TEMP1 : IN_SPEC);
+        if (hasDiff) In(P_DIFF_HISTORY);
+        if (hasSpec) In(P_SPEC_HISTORY);
+        if (hasDiff) In(P_DIFF_FAST);
+        if (hasSpec) In(P_SPEC_FAST);
+        if (hasSpec) In(P_SPEC_HDT_PING, P_SPEC_HDT_PONG);
+        if (hasSpec) In(T_SPEC_HDT);
+        if (hasDiff) Out(DIFF_TEMP2);
+        if (hasSpec) Out(SPEC_TEMP2);
+        if (hasDiff) Out(T_DIFF_FAST);
+        if (hasSpec) Out(T_SPEC_FAST);
+        if (hasSpec) Out(P_SPEC_HDT_PONG, P_SPEC_HDT_PING);
+        Out(T_DATA1);
+        Out(T_DATA2);
+        EndPair("TemporalAccumulation", "");
+    }
+
+    Pass("History fix");
+    In(T_TILES);
+    In(ResourceType::IN_NORMAL_ROUGHNESS);
+    In(T_DATA1);
+    In(ResourceType::IN_VIEWZ);
+    if (hasDiff) In(DIFF_TEMP2);
+    if (hasSpec) In(SPEC_TEMP2);
+    if (hasDiff) In(T_DIFF_FAST);
+    if (hasSpec) In(T_SPEC_FAST);
+    if (hasDiff) Out(DIFF_TEMP1);
+    if (hasSpec) Out(SPEC_TEMP1);
+    if (hasDiff) Out(P_DIFF_FAST);
+    if (hasSpec) Out(P_SPEC_FAST);
+    EndPair("HistoryFix", "");
+
+    Pass("Blur");
+    In(T_TILES);
+    In(ResourceType::IN_NORMAL_ROUGHNESS);
+    In(T_DATA1);
+    if (hasDiff) In(DIFF_TEMP1);
+    if (hasSpec) In(SPEC_TEMP1);
+    In(ResourceType::IN_VIEWZ);
+    if (hasDiff) Out(DIFF_TEMP2);
+    if (hasSpec) Out(SPEC_TEMP2);
+    Out(P_PREV_VIEWZ);
+    EndPair("Blur", "");
+
+    for (uint32_t i = 0; i < POST_BLUR_PERMUTATIONS; i++) {
+        bool isTemporalStabilization = i & 1;
+        Pass("Post-blur");
+        In(T_TILES);
+        In(ResourceType::IN_NORMAL_ROUGHNESS);
+        In(T_DATA1);
+        if (hasDiff) In(DIFF_TEMP2);
+        if (hasSpec) In(SPEC_TEMP2);
+        In(P_PREV_VIEWZ);
+        Out(P_PREV_NORMAL_ROUGHNESS);
+        if (hasDiff) Out(P_DIFF_HISTORY);
+        if (hasSpec) Out(P_SPEC_HISTORY);
+        if (!isTemporalStabilization) {
+            Out(P_PREV_INTERNAL_DATA);
+            if (hasDiff) Out(ResourceType::OUT_DIFF_RADIANCE_HITDIST);
+            if (hasSpec) Out(ResourceType::OUT_SPEC_RADIANCE_HITDIST);
+        }
+        EndPair("PostBlur", isTemporalStabilization ? "" : "_NoTemporalStabilization");
+    }
+
+    for (uint32_t i = 0; i < TEMPORAL_STABILIZATION_PERMUTATIONS; i++) {
+        bool hasRf0AndMetalness = i & 1;
+        Pass("Temporal stabilization");
+        In(T_TILES);
+        In(ResourceType::IN_NORMAL_ROUGHNESS);
+        if (hasSpec) In(hasRf0AndMetalness ? (uint16_t)ResourceType::IN_BASECOLOR_METALNESS : DUMMY);
+        In(P_PREV_VIEWZ);
+        In(T_DATA1);
+        In(T_DATA2);
+        if (hasDiff) In(P_DIFF_HISTORY);
+        if (hasSpec) In(P_SPEC_HISTORY);
+        if (hasDiff) In(P_DIFF_STAB_PING, P_DIFF_STAB_PONG);
+        if (hasSpec) In(P_SPEC_STAB_PING, P_SPEC_STAB_PONG);
+        if (hasSpec) In(P_SPEC_HDT_PONG, P_SPEC_HDT_PING);
+        Out(ResourceType::IN_MV); // optionally patched in place (specular MV modification)
+        Out(P_PREV_INTERNAL_DATA);
+        if (hasDiff) Out(ResourceType::OUT_DIFF_RADIANCE_HITDIST);
+        if (hasSpec) Out(ResourceType::OUT_SPEC_RADIANCE_HITDIST);
+        if (hasDiff) Out(P_DIFF_STAB_PONG, P_DIFF_STAB_PING);
+        if (hasSpec) Out(P_SPEC_STAB_PONG, P_SPEC_STAB_PING);
+        EndPair("TemporalStabilization", "");
+    }
+
+    Pass("Split screen");
+    In(ResourceType::IN_VIEWZ);
+    if (hasDiff) In(IN_DIFF);
+    if (hasSpec) In(IN_SPEC);
+    if (hasDiff) Out(ResourceType::OUT_DIFF_RADIANCE_HITDIST);
+    if (hasSpec) Out(ResourceType::OUT_SPEC_RADIANCE_HITDIST);
+    snprintf(shader, sizeof(shader), "REBLUR_%s_SplitScreen.cs", family);
+    EndPass(shader, 8, 16, constSize);
+
+    Pass("Validation");
+    In(ResourceType::IN_NORMAL_ROUGHNESS);
+    In(ResourceType::IN_VIEWZ);
+    In(ResourceType::IN_MV);
+    In(T_DATA1);
+    In(T_DATA2);
+    In(hasDiff ? IN_DIFF : DUMMY);
+    In(hasSpec ? IN_SPEC : DUMMY);
+    Out(ResourceType::OUT_VALIDATION);
+    EndPass("REBLUR_Validation.cs", 8, 16, sizeof(nrdc::ReblurValidationConstants), IGNORE_RS);
+}
+
+void InstanceImpl::Update_Reblur(const DenoiserData& d) {
+    const ReblurSettings& s = d.settings.reblur;
+    const CommonSettings& cs = m_CommonSettings;
+    const bool hasDiff = d.desc.denoiser != Denoiser::REBLUR_SPECULAR;
+    const bool hasSpec = d.desc.denoiser != Denoiser::REBLUR_DIFFUSE;
+
+    const bool enableHitDistanceReconstruction = s.hitDistanceReconstructionMode != HitDistanceReconstructionMode::OFF && s.checkerboardMode == CheckerboardMode::OFF;
+    const bool skipTemporalStabilization = s.maxStabilizedFrameNum == 0;
+    const bool skipPrePass = (s.diffusePrepassBlurRadius == 0.0f || !hasDiff) && (s.specularPrepassBlurRadius == 0.0f || !hasSpec) && s.checkerboardMode == CheckerboardMode::OFF;
+    const uint32_t perf = s.enablePerformanceMode ? 1 : 0;
+
+    auto Emit = [&](uint32_t localIndex) { FillReblurConstants(s, PushDispatch(d, localIndex)); };
+
+    if (cs.splitScreen >= 1.0f) { // pure passthrough
+        Emit(PASS_SPLIT_SCREEN);
+        return;
+    }
+
+    Emit(PASS_CLASSIFY_TILES);
+
+    if (enableHitDistanceReconstruction)
+        Emit(PASS_HITDIST_RECONSTRUCTION + (s.hitDistanceReconstructionMode == HitDistanceReconstructionMode::AREA_5X5 ? 4 : 0) + (!skipPrePass ? 2 : 0) + perf);
+
+    if (!skipPrePass)
+        Emit(PASS_PREPASS + (enableHitDistanceReconstruction ? 2 : 0) + perf);
+
+    Emit(PASS_TEMPORAL_ACCUMULATION + (cs.isDisocclusionThresholdMixAvailable ? 8 : 0) + (cs.isHistoryConfidenceAvailable ? 4 : 0) +
+         ((!skipPrePass || enableHitDistanceReconstruction) ? 2 : 0) + perf);
+    Emit(PASS_HISTORY_FIX + perf);
+    Emit(PASS_BLUR + perf);
+    Emit(PASS_POST_BLUR + (skipTemporalStabilization ? 0 : 2) + perf);
+
+    if (!skipTemporalStabilization)
+        Emit(PASS_TEMPORAL_STABILIZATION + (cs.isBaseColorMetalnessAvailable ? 2 : 0) + perf);
+
+    if (cs.splitScreen > 0.0f)
+        Emit(PASS_SPLIT_SCREEN);
+
+    if (cs.enableValidation) {
+        auto* c = (nrdc::ReblurValidationConstants*)PushDispatch(d, PASS_VALIDATION);
+        FillReblurConstants(s, c);
+        c->gHasDiffuse = hasDiff ? 1 : 0;
+        c->gHasSpecular = hasSpec ? 1 : 0;
+    }
+}
+
+static void StoreMatrix(float* dst, const nrdhost::Mat4& m) { memcpy(dst, &m, sizeof(float) * 16); }
+
+void InstanceImpl::FillReblurConstants(const ReblurSettings& s, void* data) {
+    if (!data)
+        return;
+    const CommonSettings& cs = m_CommonSettings;
+
+    const float resourceW = cs.resourceSize[0], resourceH = cs.resourceSize[1];
+    const float resourceWprev = cs.resourceSizePrev[0], resourceHprev = cs.resourceSizePrev[1];
+    const float rectW = cs.rectSize[0], rectH = cs.rectSize[1];
+    const float rectWprev = cs.rectSizePrev[0], rectHprev = cs.rectSizePrev[1];
+
+    const bool isRectChanged = cs.rectSize[0] != cs.rectSizePrev[0] || cs.rectSize[1] != cs.rectSizePrev[1];
+    const bool isHistoryReset = cs.accumulationMode != AccumulationMode::CONTINUE;
+    const float unproject = 1.0f / (0.5f * rectH * m_ProjectY);
+    const float worstResolutionScale = std::min(rectW / resourceW, rectH / resourceH);
+    const float maxBlurRadius = s.maxBlurRadius * worstResolutionScale;
+    const float disocclusionThresholdBonus = (1.0f + m_JitterDelta) / rectH;
+    const float stabilizationStrength = float(s.maxStabilizedFrameNum) / (1.0f + float(s.maxStabilizedFrameNum));
+    const float hitDistStabilizationStrength = float(s.maxStabilizedFrameNumForHitDistance) / (1.0f + float(s.maxStabilizedFrameNumForHitDistance));
+    const uint32_t maxAccumulatedFrameNum = std::min(s.maxAccumulatedFrameNum, REBLUR_MAX_HISTORY_FRAME_NUM);
+
+    uint32_t diffCheckerboard = 2, specCheckerboard = 2;
+    if (s.checkerboardMode == CheckerboardMode::BLACK) {
+        diffCheckerboard = 0;
+        specCheckerboard = 1;
+    } else if (s.checkerboardMode == CheckerboardMode::WHITE) {
+        diffCheckerboard = 1;
+        specCheckerboard = 0;
+    }
+
+    nrdc::ReblurConstants& c = *(nrdc::ReblurConstants*)data;
+    StoreMatrix(c.gWorldToClip, m_WorldToClip);
+    StoreMatrix(c.gViewToClip, m_ViewToClip);
+    StoreMatrix(c.gViewToWorld, m_ViewToWorld);
+    StoreMatrix(c.gWorldToViewPrev, m_WorldToViewPrev);
+    StoreMatrix(c.gWorldToClipPrev, m_WorldToClipPrev);
+    StoreMatrix(c.gWorldPrevToWorld, m_WorldPrevToWorld);
+    c.gRotatorPre = {m_RotatorPre[0], m_RotatorPre[1], m_RotatorPre[2], m_RotatorPre[3]};
+    c.gRotator = {m_Rotator[0], m_Rotator[1], m_Rotator[2], m_Rotator[3]};
+    c.gRotatorPost = {m_RotatorPost[0], m_RotatorPost[1], m_RotatorPost[2], m_RotatorPost[3]};
+    c.gFrustum = {m_Frustum[0], m_Frustum[1], m_Frustum[2], m_Frustum[3]};
+    c.gFrustumPrev = {m_FrustumPrev[0], m_FrustumPrev[1], m_FrustumPrev[2], m_FrustumPrev[3]};
+    c.gCameraDelta = {m_CameraDelta.x, m_CameraDelta.y, m_CameraDelta.z, 0.0f};
+    c.gHitDistParams = {s.hitDistanceParameters.A, s.hitDistanceParameters.B, s.hitDistanceParameters.C, s.hitDistanceParameters.D};
+    c.gViewVectorWorld = {m_ViewDirection.x, m_ViewDirection.y, m_ViewDirection.z, 0.0f};
+    c.gViewVectorWorldPrev = {m_ViewDirectionPrev.x, m_ViewDirectionPrev.y, m_ViewDirectionPrev.z, 0.0f};
+    c.gMvScale = {cs.motionVectorScale[0], cs.motionVectorScale[1], cs.motionVectorScale[2], cs.isMotionVectorInWorldSpace ? 1.0f : 0.0f};
+    c.gAntilagParams = {s.antilagSettings.luminanceSigmaScale, s.antilagSettings.luminanceSensitivity};
+    c.gResourceSize = {resourceW, resourceH};
+    c.gResourceSizeInv = {1.0f / resourceW, 1.0f / resourceH};
+    c.gResourceSizeInvPrev = {1.0f / resourceWprev, 1.0f / resourceHprev};
+    c.gRectSize = {rectW, rectH};
+    c.gRectSizeInv = {1.0f / rectW, 1.0f / rectH};
+    c.gRectSizePrev = {rectWprev, rectHprev};
+    c.gResolutionScale = {rectW / resourceW, rectH / resourceH};
+    c.gResolutionScalePrev = {rectWprev / resourceWprev, rectHprev / resourceHprev};
+    c.gRectOffset = {float(cs.rectOrigin[0]) / resourceW, float(cs.rectOrigin[1]) / resourceH};
+    c.gSpecProbabilityThresholdsForMvModification = {cs.isBaseColorMetalnessAvailable ? s.specularProbabilityThresholdsForMvModification[0] : 2.0f,
+        cs.isBaseColorMetalnessAvailable ? s.specularProbabilityThresholdsForMvModification[1] : 3.0f};
+    c.gJitter = {cs.cameraJitter[0], cs.cameraJitter[1]};
+    c.gPrintfAt = {cs.printfAt[0], cs.printfAt[1]};
+    c.gRectOrigin = {cs.rectOrigin[0], cs.rectOrigin[1]};
+    c.gRectSizeMinusOne = {int32_t(cs.rectSize[0]) - 1, int32_t(cs.rectSize[1]) - 1};
+    c.gDisocclusionThreshold = cs.disocclusionThreshold + disocclusionThresholdBonus;
+    c.gDisocclusionThresholdAlternate = cs.disocclusionThresholdAlternate + disocclusionThresholdBonus;
+    c.gCameraAttachedReflectionMaterialID = cs.cameraAttachedReflectionMaterialID;
+    c.gStrandMaterialID = cs.strandMaterialID;
+    c.gStrandThickness = cs.strandThickness;
+    c.gStabilizationStrength = isHistoryReset ? 0.0f : stabilizationStrength;
+    c.gHitDistStabilizationStrength = isHistoryReset ? 0.0f : hitDistStabilizationStrength; // set but unused by any pass (as in the reference)
+    c.gDebug = cs.debug;
+    c.gOrthoMode = m_OrthoMode;
+    c.gUnproject = unproject;
+    c.gDenoisingRange = cs.denoisingRange;
+    c.gPlaneDistSensitivity = s.planeDistanceSensitivity;
+    c.gFramerateScale = m_FrameRateScale;
+    c.gMaxBlurRadius = std::max(maxBlurRadius, s.minBlurRadius);
+    c.gMinBlurRadius = s.minBlurRadius;
+    c.gDiffPrepassBlurRadius = s.diffusePrepassBlurRadius * worstResolutionScale;
+    c.gSpecPrepassBlurRadius = s.specularPrepassBlurRadius * worstResolutionScale;
+    c.gMaxAccumulatedFrameNum = isHistoryReset ? 0.0f : float(maxAccumulatedFrameNum);
+    c.gMaxFastAccumulatedFrameNum = isHistoryReset ? 0.0f : float(s.maxFastAccumulatedFrameNum);
+    c.gAntiFirefly = s.enableAntiFirefly ? 1.0f : 0.0f;
+    c.gLobeAngleFraction = s.lobeAngleFraction * s.lobeAngleFraction; // squared: reference Reblur.cpp:384
+    c.gRoughnessFraction = s.roughnessFraction;
+    c.gResponsiveAccumulationRoughnessThreshold = s.responsiveAccumulationRoughnessThreshold;
+    c.gHistoryFixFrameNum = float(s.historyFixFrameNum);
+    c.gHistoryFixBasePixelStride = float(s.historyFixBasePixelStride);
+    c.gMinRectDimMulUnproject = std::min(rectW, rectH) * unproject;
+    c.gUsePrepassNotOnlyForSpecularMotionEstimation = s.usePrepassOnlyForSpecularMotionEstimation ? 0.0f : 1.0f;
+    c.gSplitScreen = cs.splitScreen;
+    c.gSplitScreenPrev = m_SplitScreenPrev;
+    c.gCheckerboardResolveAccumSpeed = m_CheckerboardResolveAccumSpeed;
+    c.gViewZScale = cs.viewZScale;
+    c.gFireflySuppressorMinRelativeScale = s.fireflySuppressorMinRelativeScale;
+    c.gMinHitDistanceWeight = s.minHitDistanceWeight;
+    c.gDiffMinMaterial = s.minMaterialForDiffuse;
+    c.gSpecMinMaterial = s.minMaterialForSpecular;
+    c.gHasHistoryConfidence = cs.isHistoryConfidenceAvailable ? 1 : 0;
+    c.gHasDisocclusionThresholdMix = cs.isDisocclusionThresholdMixAvailable ? 1 : 0;
+    c.gDiffCheckerboard = diffCheckerboard;
+    c.gSpecCheckerboard = specCheckerboard;
+    c.gFrameIndex = cs.frameIndex;
+    c.gIsRectChanged = isRectChanged ? 1 : 0;
+    c.gResetHistory = isHistoryReset ? 1 : 0;
+}
+
+} // namespace nrd
