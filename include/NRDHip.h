@@ -63,6 +63,12 @@ uint32_t nrdHipDenoise(NrdHipExecutor* executor, const uint32_t* identifiers, ui
 // Bytes held by the pool arena (permanent, transient).
 uint32_t nrdHipGetPoolMemoryUsage(const NrdHipExecutor* executor, uint64_t* permanentBytes, uint64_t* transientBytes);
 
+// Diagnostics: evaluates one primitive of the device numerics contract (DESIGN.md "Numerics") elementwise on device
+// arrays, so a harness can pin the GPU's codecs and transcendentals bit-for-bit against another implementation.
+//   op: 0 exp2, 1 log2, 2 atan, 3 pow(x, y = in2), 4 fp32->fp16->fp32 round trip, 5 x / in2, 6 sqrt, 7 1/sqrt
+// in2 may be NULL for unary ops. Launches on hipStream (a hipStream_t as void*, may be NULL).
+uint32_t nrdHipEvalNumerics(uint32_t op, const float* in1, const float* in2, float* out, uint32_t count, void* hipStream);
+
 // Last error text of this executor (never NULL).
 const char* nrdHipGetLastError(const NrdHipExecutor* executor);
 

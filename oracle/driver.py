@@ -1,0 +1,91 @@
+"""ORACLE -- TEST INFRASTRUCTURE, NOT PRODUCT CODE.
+
+Drives oracle/liboracle.so through a dispatch list obtained from the product's nrd::GetComputeDispatches, i.e. plays
+for the CPU oracle the role the HIP executor plays for the GPU: owns the pool planes (numpy, host memory) and calls
+one CPU pass per DispatchDesc. Importable only from tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+_DIR = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_DIR, "liboracle.so")
+
+
+class OraclePlane(C.Structure):
+    _fields_ = [("data", C.c_void_p), ("rowPitchBytes", C.c_uint32), ("format", C.c_uint32), ("width", C.c_uint16), ("height", C.c_uint16)]
+
+
+_lib = None
+
+
+def load():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError("oracle not built: run `make -C oracle`")
+        lib = C.CDLL(LIB_PATH)
+        lib.oracle_dispatch.argtypes = [C.c_char_p, C.c_void_p, C.c_uint32, C.POINTER(OraclePlane), C.c_uint32]
+        lib.oracle_dispatch.restype = C.c_int
+        lib.oracle_set_threads.argtypes, lib.oracle_set_threads.restype = [C.c_int], C.c_int
+        lib.oracle_f32tof16.argtypes, lib.oracle_f32tof16.restype = [C.c_float], C.c_uint32
+        lib.oracle_f16tof32.argtypes, lib.oracle_f16tof32.restype = [C.c_uint32], C.c_float
+        for name in ("oracle_exp2", "oracle_log2", "oracle_atan"):
+            getattr(lib, name).argtypes, getattr(lib, name).restype = [C.c_float], C.c_float
+        lib.oracle_pow.argtypes, lib.oracle_pow.restype = [C.c_float, C.c_float], C.c_float
+        _lib = lib
+    return _lib
+
+
+def _pitch(width, bpt):
+    return (width * bpt + 255) & ~255
+
+
+class OracleExecutor:
+    """CPU twin of raytracingdenoiser_amd.executor.HipExecutor."""
+
+    def __init__(self, instance, width, height, format_bytes, threads=0):
+        from raytracingdenoiser_amd import api  # ctypes plumbing of the public NRD API only
+
+        self.api = api
+        self.lib = load()
+        if threads:
+            self.lib.oracle_set_threads(threads)
+        self.instance = instance
+        self.width, self.height = width, height
+        self.pools = {}
+        for pool_type, descs in ((api.ResourceType.PERMANENT_POOL, instance.permanent_pool), (api.ResourceType.TRANSIENT_POOL, instance.transient_pool)):
+            planes = []
+            for fmt, ds in descs:
+                w, h = (width + ds - 1) // ds, (height + ds - 1) // ds
+                planes.append((np.zeros((h, _pitch(w, format_bytes[fmt])), dtype=np.uint8), fmt, w, h))
+            self.pools[pool_type] = planes
+        self.user = {}
+
+    def bind(self, resource_type, array, fmt):
+        """array: C-contiguous numpy array whose rows are plane rows ([H, W, C] or [H, W], any dtype)."""
+        assert array.flags["C_CONTIGUOUS"]
+        self.user[int(resource_type)] = (array, fmt, self.width, self.height)
+
+    def _plane(self, res):
+        _, rtype, index = res
+        api = self.api
+        if rtype in (api.ResourceType.PERMANENT_POOL, api.ResourceType.TRANSIENT_POOL):
+            arr, fmt, w, h = self.pools[rtype][index]
+        else:
+            arr, fmt, w, h = self.user[int(rtype)]
+        pitch = arr.strides[0]
+        return OraclePlane(arr.ctypes.data, pitch, int(fmt), w, h)
+
+    def execute(self, dispatches):
+        for d in dispatches:
+            planes = (OraclePlane * len(d.resources))(*[self._plane(r) for r in d.resources])
+            buf = C.create_string_buffer(d.constants, len(d.constants)) if d.constants else None
+            rc = self.lib.oracle_dispatch(d.shader.encode(), buf, len(d.constants), planes, len(d.resources))
+            if rc != 0:
+                raise RuntimeError("oracle has no pass '%s'" % d.shader)
+
+    def pool_plane(self, pool, index):
+        arr, fmt, w, _ = self.pools[pool][index]
+        return arr, fmt, w

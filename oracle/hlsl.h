@@ -1,0 +1,203 @@
+// ORACLE -- TEST INFRASTRUCTURE, NOT PRODUCT CODE. Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline
+// leg may load anything under oracle/. The shipped library (raytracingdenoiser_amd/lib/libNRD_hip.so) never does.
+//
+// HLSL-flavoured scalar/vector vocabulary for the CPU restatement of the NRD shader arithmetic, plus the
+// bit-reproducible transcendentals of the numerics contract (DESIGN.md "Numerics"): only + - * / sqrt, floor,
+// comparisons and integer bit operations are used, and this directory is compiled with -ffp-contract=off, so every
+// value is determined by IEEE-754 alone. Written independently of the HIP device header; the two must agree
+// bit-for-bit, which is what the parity tests check.
+//
+// PARITY UNPINNED: the reference ships no CPU implementation, no tests and no golden vectors, and its math library
+// (NVIDIA-RTX/MathLib, fetched unpinned at configure time -- reference CMakeLists.txt:118-127) is absent. Definitions
+// marked [ml] restate MathLib from its public behaviour and from anchors inside the reference.
+#pragma once
+
+#include <cmath>
+#include <cstdint>
+#include <cstring>
+
+namespace orc {
+
+// ------------------------------------------------------------------------------------------------ scalars
+inline uint32_t asuint(float x) {
+    uint32_t u;
+    memcpy(&u, &x, 4);
+    return u;
+}
+inline float asfloat(uint32_t u) {
+    float x;
+    memcpy(&x, &u, 4);
+    return x;
+}
+inline float min(float a, float b) { return a < b ? a : b; }
+inline float max(float a, float b) { return a > b ? a : b; }
+inline int min(int a, int b) { return a < b ? a : b; }
+inline int max(int a, int b) { return a > b ? a : b; }
+inline float clamp(float x, float a, float b) { return min(max(x, a), b); }
+inline int clamp(int x, int a, int b) { return min(max(x, a), b); }
+inline float saturate(float x) { return min(max(x, 0.0f), 1.0f); }
+inline float lerp(float a, float b, float t) { return a + (b - a) * t; }
+inline float step(float edge, float x) { return x >= edge ? 1.0f : 0.0f; }
+inline float rcp(float x) { return 1.0f / x; }
+inline float rsqrt(float x) { return 1.0f / sqrtf(x); }
+inline float frac(float x) { return x - floorf(x); }
+
+// 2^x: nearest-integer split, degree-7 Taylor of 2^f on [-0.5, 0.5], Horner
+inline float exp2(float x) {
+    x = clamp(x, -125.0f, 125.0f);
+    float fi = floorf(x + 0.5f);
+    float f = x - fi;
+    static const float c[8] = {1.0f, 6.9314718056e-1f, 2.4022650696e-1f, 5.5504108665e-2f, 9.6181291076e-3f, 1.3333558146e-3f, 1.5403530393e-4f, 1.5252733805e-5f};
+    float p = c[7];
+    for (int i = 6; i >= 0; i--)
+        p = p * f + c[i];
+    return p * asfloat((uint32_t)((int)fi + 127) << 23);
+}
+
+// log2(x) for x > 0 (else -126): m in [sqrt(1/2), sqrt(2)), 2 * atanh(s) / ln2 with s = (m - 1) / (m + 1)
+inline float log2(float x) {
+    if (!(x > 0.0f))
+        return -126.0f;
+    uint32_t bits = asuint(x);
+    int e = (int)(bits >> 23) - 127;
+    if (e == -127) {
+        bits = asuint(x * 8388608.0f);
+        e = (int)(bits >> 23) - 127 - 23;
+    }
+    float m = asfloat((bits & 0x007FFFFFu) | 0x3F800000u);
+    if (m > 1.41421356f) {
+        m = m * 0.5f;
+        e += 1;
+    }
+    float s = (m - 1.0f) / (m + 1.0f);
+    float s2 = s * s;
+    float p = 0.22222222f;
+    p = p * s2 + 0.28571429f;
+    p = p * s2 + 0.4f;
+    p = p * s2 + 0.66666667f;
+    p = p * s2 + 2.0f;
+    return float(e) + (p * s) * 1.44269504f;
+}
+
+inline float exp(float x) { return exp2(x * 1.44269504f); }
+inline float log(float x) { return log2(x) * 0.69314718f; }
+inline float pow(float x, float y) { return x <= 0.0f ? 0.0f : exp2(y * log2(x)); }
+
+// atan: reduction to |t| <= tan(pi/8), degree-9 odd polynomial (Cephes atanf coefficients)
+inline float atan(float x) {
+    float a = fabsf(x);
+    float base = 0.0f, t = a;
+    if (a > 2.41421356f) {
+        base = 1.57079633f;
+        t = -1.0f / a;
+    } else if (a > 0.41421356f) {
+        base = 0.78539816f;
+        t = (a - 1.0f) / (a + 1.0f);
+    }
+    float z = t * t;
+    float p = 8.05374449538e-2f;
+    p = p * z - 1.38776856032e-1f;
+    p = p * z + 1.99777106478e-1f;
+    p = p * z - 3.33329491539e-1f;
+    float r = base + (p * z * t + t);
+    return x < 0.0f ? -r : r;
+}
+
+// ------------------------------------------------------------------------------------------------ vectors
+struct float2 {
+    float x, y;
+    float2() : x(0), y(0) {}
+    float2(float a) : x(a), y(a) {}
+    float2(float a, float b) : x(a), y(b) {}
+};
+struct float3 {
+    float x, y, z;
+    float3() : x(0), y(0), z(0) {}
+    float3(float a) : x(a), y(a), z(a) {}
+    float3(float a, float b, float c) : x(a), y(b), z(c) {}
+    float2 xy() const { return float2(x, y); }
+};
+struct float4 {
+    float x, y, z, w;
+    float4() : x(0), y(0), z(0), w(0) {}
+    float4(float a) : x(a), y(a), z(a), w(a) {}
+    float4(float a, float b, float c, float d) : x(a), y(b), z(c), w(d) {}
+    float4(float3 v, float d) : x(v.x), y(v.y), z(v.z), w(d) {}
+    float3 xyz() const { return float3(x, y, z); }
+    float2 xy() const { return float2(x, y); }
+    float2 zw() const { return float2(z, w); }
+    float& operator[](int i) { return (&x)[i]; }
+    float operator[](int i) const { return (&x)[i]; }
+};
+struct int2 {
+    int x, y;
+    int2() : x(0), y(0) {}
+    int2(int a, int b) : x(a), y(b) {}
+};
+struct uint4 {
+    uint32_t x, y, z, w;
+};
+
+#define ORC_OP2(op)                                                                       \
+    inline float2 operator op(float2 a, float2 b) { return float2(a.x op b.x, a.y op b.y); } \
+    inline float2 operator op(float2 a, float b) { return float2(a.x op b, a.y op b); }      \
+    inline float2 operator op(float a, float2 b) { return float2(a op b.x, a op b.y); }
+#define ORC_OP3(op)                                                                                    \
+    inline float3 operator op(float3 a, float3 b) { return float3(a.x op b.x, a.y op b.y, a.z op b.z); } \
+    inline float3 operator op(float3 a, float b) { return float3(a.x op b, a.y op b, a.z op b); }        \
+    inline float3 operator op(float a, float3 b) { return float3(a op b.x, a op b.y, a op b.z); }
+#define ORC_OP4(op)                                                                                                 \
+    inline float4 operator op(float4 a, float4 b) { return float4(a.x op b.x, a.y op b.y, a.z op b.z, a.w op b.w); } \
+    inline float4 operator op(float4 a, float b) { return float4(a.x op b, a.y op b, a.z op b, a.w op b); }          \
+    inline float4 operator op(float a, float4 b) { return float4(a op b.x, a op b.y, a op b.z, a op b.w); }
+ORC_OP2(+) ORC_OP2(-) ORC_OP2(*) ORC_OP2(/)
+ORC_OP3(+) ORC_OP3(-) ORC_OP3(*) ORC_OP3(/)
+ORC_OP4(+) ORC_OP4(-) ORC_OP4(*) ORC_OP4(/)
+inline float3 operator-(float3 a) { return float3(-a.x, -a.y, -a.z); }
+inline float2 operator-(float2 a) { return float2(-a.x, -a.y); }
+inline float2& operator+=(float2& a, float2 b) { return a = a + b; }
+inline float3& operator+=(float3& a, float3 b) { return a = a + b; }
+inline float4& operator+=(float4& a, float4 b) { return a = a + b; }
+inline float2& operator*=(float2& a, float2 b) { return a = a * b; }
+inline float2& operator*=(float2& a, float b) { return a = a * b; }
+inline float3& operator*=(float3& a, float b) { return a = a * b; }
+inline float3& operator*=(float3& a, float3 b) { return a = a * b; }
+inline float4& operator*=(float4& a, float b) { return a = a * b; }
+inline float4& operator*=(float4& a, float4 b) { return a = a * b; }
+inline float2& operator/=(float2& a, float b) { return a = a / b; }
+inline float3& operator/=(float3& a, float b) { return a = a / b; }
+inline float4& operator-=(float4& a, float b) { return a = a - b; }
+
+inline float dot(float2 a, float2 b) { return a.x * b.x + a.y * b.y; }
+inline float dot(float3 a, float3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
+inline float dot(float4 a, float4 b) { return a.x * b.x + a.y * b.y + a.z * b.z + a.w * b.w; }
+inline float sum(float4 a) { return a.x + a.y + a.z + a.w; } // dot( a, 1.0 )
+inline float sum(float3 a) { return a.x + a.y + a.z; }
+inline float length(float2 v) { return sqrtf(dot(v, v)); }
+inline float length(float3 v) { return sqrtf(dot(v, v)); }
+inline float3 normalize(float3 v) { return v * rsqrt(dot(v, v)); }
+inline float3 cross(float3 a, float3 b) { return float3(a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x); }
+inline float3 reflect(float3 i, float3 n) { return i - n * (2.0f * dot(n, i)); }
+inline float2 lerp(float2 a, float2 b, float t) { return float2(lerp(a.x, b.x, t), lerp(a.y, b.y, t)); }
+inline float3 lerp(float3 a, float3 b, float t) { return float3(lerp(a.x, b.x, t), lerp(a.y, b.y, t), lerp(a.z, b.z, t)); }
+inline float4 lerp(float4 a, float4 b, float t) { return float4(lerp(a.x, b.x, t), lerp(a.y, b.y, t), lerp(a.z, b.z, t), lerp(a.w, b.w, t)); }
+inline float2 saturate(float2 v) { return float2(saturate(v.x), saturate(v.y)); }
+inline float2 floor(float2 v) { return float2(floorf(v.x), floorf(v.y)); }
+inline float2 abs(float2 v) { return float2(fabsf(v.x), fabsf(v.y)); }
+inline float3 abs(float3 v) { return float3(fabsf(v.x), fabsf(v.y), fabsf(v.z)); }
+inline float4 abs(float4 v) { return float4(fabsf(v.x), fabsf(v.y), fabsf(v.z), fabsf(v.w)); }
+inline float abs(float v) { return fabsf(v); }
+inline float3 max(float3 v, float s) { return float3(max(v.x, s), max(v.y, s), max(v.z, s)); }
+inline float2 max(float2 a, float2 b) { return float2(max(a.x, b.x), max(a.y, b.y)); }
+inline float2 min(float2 a, float2 b) { return float2(min(a.x, b.x), min(a.y, b.y)); }
+inline float3 step(float3 edge, float x) { return float3(step(edge.x, x), step(edge.y, x), step(edge.z, x)); }
+inline float4 step(float4 edge, float4 x) { return float4(step(edge.x, x.x), step(edge.y, x.y), step(edge.z, x.z), step(edge.w, x.w)); }
+inline float2 step(float2 edge, float2 x) { return float2(step(edge.x, x.x), step(edge.y, x.y)); }
+
+// 4x4 matrix as stored in the constant buffers: 16 floats, column-major
+struct float4x4 {
+    float m[16];
+    float at(int row, int col) const { return m[col * 4 + row]; }
+};
+
+} // namespace orc

@@ -1,0 +1,62 @@
+// ORACLE -- TEST INFRASTRUCTURE, NOT PRODUCT CODE (see oracle/hlsl.h).
+// C entry points used by tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg (through oracle/driver.py).
+#include "passes.h"
+
+#include <cstdio>
+#include <vector>
+
+#ifdef _OPENMP
+#    include <omp.h>
+#endif
+
+using namespace orc;
+
+extern "C" {
+
+struct OraclePlane { // same layout as NrdHipPlaneDesc, but "data" is HOST memory
+    void* data;
+    uint32_t rowPitchBytes;
+    uint32_t format;
+    uint16_t width, height;
+};
+
+// Runs one pass on the CPU. Returns 0 on success, 1 if the pass is unknown to the oracle.
+__attribute__((visibility("default"))) int oracle_dispatch(const char* shaderFileName, const void* constants, uint32_t constantsSize, const OraclePlane* planes, uint32_t planesNum) {
+    const PassEntry* tables[3];
+    uint32_t counts[3];
+    tables[0] = GetCommonPasses(counts[0]);
+    tables[1] = GetReblurPasses(counts[1]);
+    tables[2] = GetSigmaPasses(counts[2]);
+    for (int t = 0; t < 3; t++)
+        for (uint32_t i = 0; i < counts[t]; i++)
+            if (!strcmp(tables[t][i].shaderFileName, shaderFileName)) {
+                std::vector<Tex> tex(planesNum);
+                for (uint32_t p = 0; p < planesNum; p++)
+                    tex[p] = Tex(Plane{(uint8_t*)planes[p].data, planes[p].rowPitchBytes, planes[p].format, planes[p].width, planes[p].height});
+                PassIO io{tex.data(), planesNum, constants, constantsSize};
+                tables[t][i].fn(io);
+                return 0;
+            }
+    fprintf(stderr, "oracle_dispatch: unknown pass '%s'\n", shaderFileName);
+    return 1;
+}
+
+__attribute__((visibility("default"))) int oracle_set_threads(int n) {
+#ifdef _OPENMP
+    if (n > 0)
+        omp_set_num_threads(n);
+    return omp_get_max_threads();
+#else
+    (void)n;
+    return 1;
+#endif
+}
+
+// scalar probes so the tests can pin the numerics contract (codecs + transcendentals) value by value
+__attribute__((visibility("default"))) uint32_t oracle_f32tof16(float f) { return f32tof16(f); }
+__attribute__((visibility("default"))) float oracle_f16tof32(uint32_t h) { return f16tof32(h); }
+__attribute__((visibility("default"))) float oracle_exp2(float x) { return orc::exp2(x); }
+__attribute__((visibility("default"))) float oracle_log2(float x) { return orc::log2(x); }
+__attribute__((visibility("default"))) float oracle_atan(float x) { return orc::atan(x); }
+__attribute__((visibility("default"))) float oracle_pow(float x, float y) { return orc::pow(x, y); }
+}

@@ -252,7 +252,7 @@ class HipPlaneDesc(C.Structure):
 NRD_SYMBOLS = ["CreateInstance", "DestroyInstance", "GetLibraryDesc", "GetInstanceDesc", "SetCommonSettings", "SetDenoiserSettings",
                "GetComputeDispatches", "GetResourceTypeString", "GetDenoiserString"]
 NRD_HIP_SYMBOLS = ["nrdHipCreateExecutor", "nrdHipDestroyExecutor", "nrdHipBindResource", "nrdHipGetPoolPlane", "nrdHipExecuteDispatches",
-                   "nrdHipDenoise", "nrdHipGetPoolMemoryUsage", "nrdHipGetLastError"]
+                   "nrdHipDenoise", "nrdHipGetPoolMemoryUsage", "nrdHipGetLastError", "nrdHipEvalNumerics"]
 
 _lib = None
 
@@ -288,6 +288,8 @@ def load_library(path=None):
     lib.nrdHipGetPoolMemoryUsage.argtypes = [C.c_void_p, P(C.c_uint64), P(C.c_uint64)]
     lib.nrdHipGetPoolMemoryUsage.restype = C.c_uint32
     lib.nrdHipGetLastError.argtypes, lib.nrdHipGetLastError.restype = [C.c_void_p], C.c_char_p
+    lib.nrdHipEvalNumerics.argtypes = [C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p]
+    lib.nrdHipEvalNumerics.restype = C.c_uint32
     if path == LIB_PATH:
         _lib = lib
     return lib

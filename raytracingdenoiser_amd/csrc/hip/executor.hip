@@ -291,3 +291,15 @@ extern "C" __attribute__((visibility("default"))) uint32_t nrdHipGetPoolMemoryUs
 }
 
 extern "C" __attribute__((visibility("default"))) const char* nrdHipGetLastError(const NrdHipExecutor* e) { return e ? e->lastError.c_str() : "null executor"; }
+
+namespace nrdhip {
+void LaunchEvalNumerics(uint32_t op, const float* in1, const float* in2, float* out, uint32_t count, hipStream_t stream);
+}
+
+extern "C" __attribute__((visibility("default"))) uint32_t nrdHipEvalNumerics(uint32_t op, const float* in1, const float* in2, float* out, uint32_t count, void* hipStream) {
+    if (!in1 || !out || op > 7)
+        return (uint32_t)nrd::Result::INVALID_ARGUMENT;
+    if (count)
+        nrdhip::LaunchEvalNumerics(op, in1, in2, out, count, (hipStream_t)hipStream);
+    return hipGetLastError() == hipSuccess ? (uint32_t)nrd::Result::SUCCESS : (uint32_t)nrd::Result::FAILURE;
+}

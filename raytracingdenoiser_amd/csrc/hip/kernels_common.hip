@@ -61,6 +61,30 @@ static void LaunchReferenceCopy(const PassArgs& a) {
     hipLaunchKernelGGL(ReferenceCopyKernel, grid, dim3(256), 0, a.stream, a.planes[0], out, c->gRectSizeInv.x, c->gSplitScreen);
 }
 
+// ---- numerics probe (include/NRDHip.h: nrdHipEvalNumerics) ---------------------------------------------------------
+__global__ __launch_bounds__(256) void EvalNumericsKernel(uint32_t op, const float* in1, const float* in2, float* out, uint32_t count) {
+    uint32_t i = blockIdx.x * 256u + threadIdx.x;
+    if (i >= count)
+        return;
+    float a = in1[i], b = in2 ? in2[i] : 0.0f, r = 0.0f;
+    switch (op) {
+        case 0: r = Exp2(a); break;
+        case 1: r = Log2(a); break;
+        case 2: r = Atan(a); break;
+        case 3: r = Pow(a, b); break;
+        case 4: r = HalfBitsToFloat(FloatToHalfBits(a)); break;
+        case 5: r = a / b; break;
+        case 6: r = Sqrt(a); break;
+        case 7: r = Rsqrt(a); break;
+        default: break;
+    }
+    out[i] = r;
+}
+
+void LaunchEvalNumerics(uint32_t op, const float* in1, const float* in2, float* out, uint32_t count, hipStream_t stream) {
+    hipLaunchKernelGGL(EvalNumericsKernel, dim3((count + 255) / 256), dim3(256), 0, stream, op, in1, in2, out, count);
+}
+
 const PassEntry* GetCommonPasses(uint32_t& num) {
     static const PassEntry kPasses[] = {
         {"Clear_Float.cs", LaunchClear},

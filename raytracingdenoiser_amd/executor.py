@@ -1,0 +1,99 @@
+"""Plumbing over include/NRDHip.h: device memory comes from torch (ROCm), everything else is the C-ABI.
+
+There is no CPU path here: creating an executor without a visible GPU raises.
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import api
+
+_hip = None
+
+
+def _hip_runtime():
+    global _hip
+    if _hip is None:
+        _hip = C.CDLL("libamdhip64.so")
+        _hip.hipMemcpy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
+        _hip.hipMemcpy.restype = C.c_int
+    return _hip
+
+
+def texel_bytes(fmt):
+    return api.FORMAT_BYTES[api.Format(fmt)]
+
+
+class HipExecutor:
+    """One nrd::Instance bound to pool planes in HBM; launches the pass chain on `stream` (a torch.cuda.Stream or None)."""
+
+    def __init__(self, instance, width, height, stream=None):
+        import torch
+
+        if not torch.cuda.is_available():
+            raise RuntimeError("NRD HIP executor needs a GPU (no CPU fallback exists)")
+        self.instance = instance
+        self.lib = instance.lib
+        self.width, self.height = width, height
+        self.stream = stream
+        handle = C.c_void_p()
+        stream_ptr = C.c_void_p(stream.cuda_stream) if stream is not None else C.c_void_p(torch.cuda.current_stream().cuda_stream)
+        r = api.Result(self.lib.nrdHipCreateExecutor(instance.handle, width, height, stream_ptr, C.byref(handle)))
+        if r != api.Result.SUCCESS:
+            raise RuntimeError("nrdHipCreateExecutor failed: %s" % r.name)
+        self.handle = handle
+        self._bound = {}  # keeps tensors alive
+
+    def _check(self, code, what):
+        r = api.Result(code)
+        if r != api.Result.SUCCESS:
+            raise RuntimeError("%s failed: %s (%s)" % (what, r.name, self.lib.nrdHipGetLastError(self.handle).decode()))
+
+    def bind(self, resource_type, tensor, fmt):
+        """tensor: contiguous CUDA tensor whose rows are the plane rows (any dtype; [H, W, C] or [H, W])."""
+        assert tensor.is_cuda and tensor.is_contiguous()
+        pitch = tensor.stride(0) * tensor.element_size()
+        desc = api.HipPlaneDesc(tensor.data_ptr(), pitch, int(fmt), self.width, self.height)
+        self._check(self.lib.nrdHipBindResource(self.handle, int(resource_type), C.byref(desc)), "nrdHipBindResource(%s)" % api.ResourceType(resource_type).name)
+        self._bound[int(resource_type)] = tensor
+
+    def denoise(self, identifiers=None):
+        ids = identifiers if identifiers is not None else self.instance.identifiers
+        arr = (C.c_uint32 * len(ids))(*ids)
+        self._check(self.lib.nrdHipDenoise(self.handle, arr, len(ids)), "nrdHipDenoise")
+
+    def execute_raw(self, dispatch_ptr, num):
+        self._check(self.lib.nrdHipExecuteDispatches(self.handle, C.cast(dispatch_ptr, C.c_void_p), num), "nrdHipExecuteDispatches")
+
+    def pool_plane_desc(self, pool, index):
+        desc = api.HipPlaneDesc()
+        self._check(self.lib.nrdHipGetPoolPlane(self.handle, int(pool), index, C.byref(desc)), "nrdHipGetPoolPlane")
+        return desc
+
+    def read_pool_plane(self, pool, index):
+        """Synchronous device->host copy of a pool plane: returns (uint8 ndarray [h, pitch], Format, width)."""
+        import torch
+
+        torch.cuda.synchronize()
+        d = self.pool_plane_desc(pool, index)
+        host = np.empty((d.height, d.rowPitchBytes), dtype=np.uint8)
+        err = _hip_runtime().hipMemcpy(host.ctypes.data_as(C.c_void_p), C.c_void_p(d.data), host.nbytes, 2)
+        if err != 0:
+            raise RuntimeError("hipMemcpy D2H failed: %d" % err)
+        return host, api.Format(d.format), d.width
+
+    def pool_memory(self):
+        p, t = C.c_uint64(), C.c_uint64()
+        self._check(self.lib.nrdHipGetPoolMemoryUsage(self.handle, C.byref(p), C.byref(t)), "nrdHipGetPoolMemoryUsage")
+        return p.value, t.value
+
+    def destroy(self):
+        if self.handle:
+            self.lib.nrdHipDestroyExecutor(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.destroy()
+        except Exception:
+            pass

@@ -1,0 +1,91 @@
+"""The numerics contract (DESIGN.md "Numerics"): codecs and transcendentals are defined by IEEE-754 alone.
+CPU part pins the oracle against numpy; GPU part pins the HIP device functions against the oracle, bit for bit."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from oracle import driver as oracle_driver
+
+
+def _vec(fn, xs, restype=np.float32):
+    return np.array([fn(float(x)) for x in xs], dtype=restype)
+
+
+def test_oracle_fp16_codec_matches_ieee():
+    lib = oracle_driver.load()
+    # every half value decodes like numpy's binary16 and re-encodes to itself
+    halfs = np.arange(65536, dtype=np.uint16)
+    ref = halfs.view(np.float16).astype(np.float32)
+    finite = np.isfinite(ref)
+    dec = np.array([lib.oracle_f16tof32(int(h)) for h in halfs], dtype=np.float32)
+    assert np.array_equal(dec[finite].view(np.uint32), ref[finite].view(np.uint32))
+    enc = np.array([lib.oracle_f32tof16(float(v)) for v in ref[finite]], dtype=np.uint16)
+    assert np.array_equal(enc, halfs[finite])
+    # round-to-nearest-even on random floats incl. denormal halfs, overflow and ties
+    rng = np.random.default_rng(3)
+    xs = np.concatenate([rng.standard_normal(20000).astype(np.float32) * 10.0 ** rng.integers(-9, 6, 20000).astype(np.float32),
+                         np.array([65504.0, 65519.9, 65520.0, 1e9, 2.0 ** -24, 2.0 ** -25, 2.0 ** -25 * 1.0001, 6.1e-5, 0.0, -0.0, 1.0 + 2.0 ** -11, 1.0 + 3 * 2.0 ** -11],
+                                  dtype=np.float32)])
+    with np.errstate(over="ignore"):
+        want = xs.astype(np.float16).view(np.uint16)
+    got = np.array([lib.oracle_f32tof16(float(v)) for v in xs], dtype=np.uint16)
+    assert np.array_equal(got, want)
+
+
+def test_oracle_transcendentals_are_accurate():
+    lib = oracle_driver.load()
+    rng = np.random.default_rng(5)
+    x = rng.uniform(-30, 30, 4000).astype(np.float32)
+    assert np.max(np.abs(_vec(lib.oracle_exp2, x) / np.exp2(x.astype(np.float64)) - 1.0)) < 4e-7
+    p = np.exp(rng.uniform(-40, 40, 4000)).astype(np.float32)
+    assert np.max(np.abs(_vec(lib.oracle_log2, p) - np.log2(p.astype(np.float64)))) < 2e-6 * np.maximum(1.0, np.abs(np.log2(p))).max()
+    a = np.concatenate([rng.uniform(-5, 5, 3000), rng.uniform(-1e4, 1e4, 500), [0.0, 0.41421356, 2.41421356, 1.0]]).astype(np.float32)
+    assert np.max(np.abs(_vec(lib.oracle_atan, a) - np.arctan(a.astype(np.float64)))) < 3e-7
+    assert lib.oracle_exp2(0.0) == 1.0 and lib.oracle_exp2(3.0) == 8.0 and lib.oracle_log2(8.0) == 3.0 and lib.oracle_log2(1.0) == 0.0
+    assert lib.oracle_pow(0.0, 2.0) == 0.0 and abs(lib.oracle_pow(0.5, 4.0) - 0.0625) < 1e-7
+
+
+@pytest.mark.gpu
+def test_hip_numerics_bit_exact_vs_oracle():
+    import torch
+
+    from raytracingdenoiser_amd import api
+
+    lib = api.load_library()
+    ora = oracle_driver.load()
+    rng = np.random.default_rng(11)
+    n = 20000
+    cases = {
+        0: (rng.uniform(-40, 40, n), None, ora.oracle_exp2),
+        1: (np.exp(rng.uniform(-60, 60, n)), None, ora.oracle_log2),
+        2: (np.concatenate([rng.uniform(-6, 6, n - 1000), rng.uniform(-1e5, 1e5, 1000)]), None, ora.oracle_atan),
+        3: (rng.uniform(0, 1, n), rng.uniform(0.1, 40, n), ora.oracle_pow),
+        4: (rng.standard_normal(n) * 10.0 ** rng.integers(-9, 6, n), None, lambda v: ora.oracle_f16tof32(ora.oracle_f32tof16(v))),
+    }
+    for op, (a, b, fn) in cases.items():
+        a32 = a.astype(np.float32)
+        ta = torch.from_numpy(a32).cuda()
+        tb = torch.from_numpy(b.astype(np.float32)).cuda() if b is not None else None
+        out = torch.empty_like(ta)
+        r = lib.nrdHipEvalNumerics(op, ta.data_ptr(), tb.data_ptr() if tb is not None else None, out.data_ptr(), n, torch.cuda.current_stream().cuda_stream)
+        assert r == 0
+        got = out.cpu().numpy()
+        if b is None:
+            want = np.array([fn(float(v)) for v in a32], dtype=np.float32)
+        else:
+            want = np.array([fn(float(v), float(w)) for v, w in zip(a32, b.astype(np.float32))], dtype=np.float32)
+        ok = np.isfinite(want)
+        assert np.array_equal(got[ok].view(np.uint32), want[ok].view(np.uint32)), "op %d differs from the oracle" % op
+    # IEEE division / sqrt on the device (correctly rounded) vs numpy
+    a = (rng.standard_normal(n) * 10.0 ** rng.integers(-6, 6, n)).astype(np.float32)
+    b = (rng.standard_normal(n) * 10.0 ** rng.integers(-6, 6, n)).astype(np.float32)
+    ta, tb, out = torch.from_numpy(a).cuda(), torch.from_numpy(b).cuda(), torch.empty(n, device="cuda")
+    lib.nrdHipEvalNumerics(5, ta.data_ptr(), tb.data_ptr(), out.data_ptr(), n, torch.cuda.current_stream().cuda_stream)
+    assert np.array_equal(out.cpu().numpy().view(np.uint32), (a / b).view(np.uint32))
+    pa = np.abs(a)
+    ta = torch.from_numpy(pa).cuda()
+    lib.nrdHipEvalNumerics(6, ta.data_ptr(), None, out.data_ptr(), n, torch.cuda.current_stream().cuda_stream)
+    assert np.array_equal(out.cpu().numpy().view(np.uint32), np.sqrt(pa).view(np.uint32))
+    lib.nrdHipEvalNumerics(7, ta.data_ptr(), None, out.data_ptr(), n, torch.cuda.current_stream().cuda_stream)
+    assert np.array_equal(out.cpu().numpy().view(np.uint32), (np.float32(1.0) / np.sqrt(pa)).view(np.uint32))
