@@ -1,0 +1,220 @@
+// ORACLE -- TEST INFRASTRUCTURE, NOT PRODUCT CODE (see oracle/hlsl.h).
+// REBLUR shared pieces: constant block, storage packing, small helpers.
+//   constants : reference Shaders/Include/REBLUR_Config.hlsli:113-186
+//   helpers   : reference Shaders/Include/REBLUR_Common.hlsli:13-274
+#pragma once
+
+#include "ml.h"
+#include "tex.h"
+
+namespace orc {
+
+struct ReblurCB {
+    float4x4 gWorldToClip, gViewToClip, gViewToWorld, gWorldToViewPrev, gWorldToClipPrev, gWorldPrevToWorld;
+    float4 gRotatorPre, gRotator, gRotatorPost, gFrustum, gFrustumPrev, gCameraDelta, gHitDistParams, gViewVectorWorld, gViewVectorWorldPrev, gMvScale;
+    float2 gAntilagParams, gResourceSize, gResourceSizeInv, gResourceSizeInvPrev, gRectSize, gRectSizeInv, gRectSizePrev, gResolutionScale, gResolutionScalePrev,
+        gRectOffset, gSpecProbabilityThresholdsForMvModification, gJitter;
+    uint32_t gPrintfAt[2], gRectOrigin[2];
+    int gRectSizeMinusOne[2];
+    float gDisocclusionThreshold, gDisocclusionThresholdAlternate, gCameraAttachedReflectionMaterialID, gStrandMaterialID, gStrandThickness,
+        gStabilizationStrength, gHitDistStabilizationStrength, gDebug, gOrthoMode, gUnproject, gDenoisingRange, gPlaneDistSensitivity, gFramerateScale,
+        gMinBlurRadius, gMaxBlurRadius, gDiffPrepassBlurRadius, gSpecPrepassBlurRadius, gMaxAccumulatedFrameNum, gMaxFastAccumulatedFrameNum, gAntiFirefly,
+        gLobeAngleFraction, gRoughnessFraction, gResponsiveAccumulationRoughnessThreshold, gHistoryFixFrameNum, gHistoryFixBasePixelStride,
+        gMinRectDimMulUnproject, gUsePrepassNotOnlyForSpecularMotionEstimation, gSplitScreen, gSplitScreenPrev, gCheckerboardResolveAccumSpeed, gViewZScale,
+        gFireflySuppressorMinRelativeScale, gMinHitDistanceWeight, gDiffMinMaterial, gSpecMinMaterial;
+    uint32_t gHasHistoryConfidence, gHasDisocclusionThresholdMix, gDiffCheckerboard, gSpecCheckerboard, gFrameIndex, gIsRectChanged, gResetHistory;
+};
+static_assert(sizeof(ReblurCB) == 832, "REBLUR constant block");
+
+// REBLUR_Config.hlsli:58-61
+constexpr float REBLUR_MAX_ACCUM_FRAME_NUM = 63.0f; // 6 bits
+constexpr float REBLUR_MAX_MATERIALID_NUM = 15.0f;  // 4 bits
+// REBLUR_Config.hlsli:63-98
+constexpr float REBLUR_PRE_BLUR_FRACTION_SCALE = 2.0f;
+constexpr float REBLUR_PRE_BLUR_NON_LINEAR_ACCUM_SPEED = 1.0f / (1.0f + 10.0f);
+constexpr float REBLUR_BLUR_FRACTION_SCALE = 1.0f;
+constexpr float REBLUR_POST_BLUR_FRACTION_SCALE = 0.5f;
+constexpr float REBLUR_POST_BLUR_RADIUS_SCALE = 2.0f;
+constexpr float REBLUR_NORMAL_ULP = NRD_NORMAL_ENCODING_ERROR;
+constexpr float REBLUR_ALMOST_ZERO_ANGLE = 0.01745240643728351f; // cos( 89 deg )
+constexpr float REBLUR_FIREFLY_SUPPRESSOR_MAX_RELATIVE_INTENSITY = 38.0f;
+constexpr float REBLUR_FIREFLY_SUPPRESSOR_RADIUS_SCALE = 0.1f;
+constexpr float REBLUR_FIREFLY_SUPPRESSOR_FAST_RELATIVE_INTENSITY = 4.0f;
+constexpr int REBLUR_ANTI_FIREFLY_FILTER_RADIUS = 4;
+constexpr float REBLUR_ANTI_FIREFLY_SIGMA_SCALE = 2.0f;
+constexpr float REBLUR_ROUGHNESS_SENSITIVITY_IN_TA = NRD_ROUGHNESS_SENSITIVITY * 0.3f;
+constexpr float REBLUR_SAMPLES_PER_FRAME = 1.0f;
+constexpr float REBLUR_MAX_PERCENT_OF_LOBE_VOLUME_FOR_PRE_PASS = 0.3f;
+constexpr float REBLUR_COLOR_CLAMPING_SIGMA_SCALE = 2.0f;
+
+enum SpatialMode { PRE_BLUR = 0, BLUR = 1, POST_BLUR = 2 };
+
+// ---- storage packing: REBLUR_Common.hlsli:13-80 ; Packing::RgbaToUint / UintToRgba with 6,6,4,0 bits [ml] ---------
+inline uint32_t PackInternalData(float diffAccumSpeed, float specAccumSpeed, float materialID) {
+    float tx = diffAccumSpeed / REBLUR_MAX_ACCUM_FRAME_NUM, ty = specAccumSpeed / REBLUR_MAX_ACCUM_FRAME_NUM, tz = materialID / REBLUR_MAX_MATERIALID_NUM;
+    uint32_t p = (uint32_t)floorf(saturate(tx) * 63.0f + 0.5f);
+    p |= (uint32_t)floorf(saturate(ty) * 63.0f + 0.5f) << 6;
+    p |= (uint32_t)floorf(saturate(tz) * 15.0f + 0.5f) << 12;
+    return p;
+}
+inline float3 UnpackInternalData(uint32_t p) {
+    float3 t = float3(float(p & 63u) / 63.0f, float((p >> 6) & 63u) / 63.0f, float((p >> 12) & 15u) / 15.0f);
+    t.x *= REBLUR_MAX_ACCUM_FRAME_NUM;
+    t.y *= REBLUR_MAX_ACCUM_FRAME_NUM;
+    t.z *= REBLUR_MAX_MATERIALID_NUM;
+    return t;
+}
+// DATA1 is RG8 (diffuse+specular) or R8 (single signal: both channels alias .x)
+inline float2 PackData1(float diffAccumSpeed, float specAccumSpeed, bool hasDiff) {
+    float2 r = float2(saturate(diffAccumSpeed / REBLUR_MAX_ACCUM_FRAME_NUM), saturate(specAccumSpeed / REBLUR_MAX_ACCUM_FRAME_NUM));
+    if (!hasDiff)
+        r.x = r.y;
+    return r;
+}
+inline float2 UnpackData1(float4 texel, bool hasDiff) {
+    float2 p = float2(texel.x, texel.y);
+    if (!hasDiff)
+        p.y = p.x;
+    return p * REBLUR_MAX_ACCUM_FRAME_NUM;
+}
+inline uint32_t PackData2(float fbits, float curvature, float virtualHistoryAmount) {
+    uint32_t p = (uint32_t)(fbits + 0.5f);
+    p |= (uint32_t)(saturate(virtualHistoryAmount) * 255.0f + 0.5f) << 8;
+    p |= f32tof16(curvature) << 16;
+    return p;
+}
+inline float2 UnpackData2(uint32_t p, uint32_t& bits) {
+    bits = p & 0xFFu;
+    return float2(float((p >> 8) & 0xFFu) / 255.0f, f16tof32(p >> 16));
+}
+
+// ---- helpers: REBLUR_Common.hlsli:84-274 --------------------------------------------------------------------------
+inline float UnpackViewZ(const ReblurCB& c, float z) { return fabsf(z * c.gViewZScale); } // Common.hlsli:233
+inline float3 GetViewVector(const ReblurCB& c, float3 X, bool isViewSpace = false) {
+    return c.gOrthoMode == 0.0f ? normalize(-X) : (isViewSpace ? float3(0, 0, -1) : c.gViewVectorWorld.xyz());
+}
+inline float3 GetViewVectorPrev(const ReblurCB& c, float3 Xprev, float3 cameraDelta) {
+    return c.gOrthoMode == 0.0f ? normalize(cameraDelta - Xprev) : c.gViewVectorWorldPrev.xyz();
+}
+inline float GetMinAllowedLimitForHitDistNonLinearAccumSpeed(const ReblurCB& c, float roughness) {
+    float frameNum = 0.5f * GetSpecMagicCurve(roughness) * c.gMaxAccumulatedFrameNum;
+    return 1.0f / (1.0f + frameNum);
+}
+inline float GetFadeBasedOnAccumulatedFrames(const ReblurCB& c, float accumSpeed) {
+    float a = c.gHistoryFixFrameNum * 2.0f / 3.0f + 1e-6f;
+    float b = c.gHistoryFixFrameNum * 4.0f / 3.0f + 2e-6f;
+    return Math::LinearStep(a, b, accumSpeed);
+}
+inline float GetNonLinearAccumSpeed(float accumSpeed, float maxAccumSpeed, float confidence) { // hasData = true (no checkerboard)
+    return max(1.0f - confidence, 1.0f / (1.0f + min(accumSpeed, maxAccumSpeed)));
+}
+inline float RemapRoughnessToResponsiveFactor(const ReblurCB& c, float roughness) {
+    float amount = (roughness + NRD_EPS) / (c.gResponsiveAccumulationRoughnessThreshold + NRD_EPS);
+    return Math::SmoothStep01(amount);
+}
+inline float GetLumaScale(float currLuma, float newLuma) { return (newLuma + NRD_EPS) / (currLuma + NRD_EPS); }
+inline float4 MixHistoryAndCurrent(const ReblurCB& c, float4 history, float4 current, float f, float roughness = 1.0f) {
+    float4 r;
+    r.x = lerp(history.x, current.x, f);
+    r.y = lerp(history.y, current.y, f);
+    r.z = lerp(history.z, current.z, f);
+    r.w = lerp(history.w, current.w, max(f, GetMinAllowedLimitForHitDistNonLinearAccumSpeed(c, roughness)));
+    return r;
+}
+inline float GetLuma(float4 v) { return v.x; } // REBLUR_USE_YCOCG = 1
+inline float4 ChangeLuma(float4 v, float newLuma) {
+    float s = GetLumaScale(GetLuma(v), newLuma);
+    return float4(v.x * s, v.y * s, v.z * s, v.w);
+}
+inline float4 ClampNegativeToZero(float4 v) {
+    float3 rgb = _NRD_LinearToYCoCg(_NRD_YCoCgToLinear(v.xyz()));
+    return float4(rgb, saturate(v.w));
+}
+inline float ComputeAntilag(const ReblurCB& c, float history, float avg, float sigma, float accumSpeed) { // REBLUR_ANTILAG_MODE = 2
+    float h = history, a = avg;
+    float s = sigma * c.gAntilagParams.x;
+    float magic = c.gAntilagParams.y * c.gFramerateScale * c.gFramerateScale;
+    float hc = Color::Clamp(a, s, h);
+    float d = fabsf(h - hc) / (max(h, hc) + NRD_EPS);
+    return 1.0f / (1.0f + d * accumSpeed / magic);
+}
+inline void GetKernelBasis(float3 D, float3 N, float3& T, float3& B) {
+    Geometry::GetBasis(N, T, B);
+    if (fabsf(dot(D, N)) < 0.999f) {
+        float3 R = reflect(-D, N);
+        T = normalize(cross(N, R));
+        B = cross(R, T);
+    }
+}
+inline float2 GetTemporalAccumulationParams(const ReblurCB& c, float isInScreenMulFootprintQuality, float accumSpeed) {
+    accumSpeed *= REBLUR_SAMPLES_PER_FRAME;
+    float w = isInScreenMulFootprintQuality;
+    w *= accumSpeed / (1.0f + accumSpeed);
+    return float2(w, 1.0f + 3.0f * c.gFramerateScale * w);
+}
+inline bool CompareMaterials(float m0, float m, float minm) { return max(m0, minm) == max(m, minm); } // Common.hlsli:226-230
+
+// ---- history fetch: Common.hlsli:602-656 + REBLUR_Common.hlsli:305-361 ----------------------------------------------
+// Catmull-Rom over 12 taps realised as 5 bilinear fetches, or -- if !useBicubic -- the 2x2 footprint with custom weights
+struct HistoryFilter {
+    float4 w;      // 4 bilinear-fetch weights (bicubic) or the custom bilinear weights
+    float w4;
+    float sum;
+    float2 p0, p1, p2, p3, p4; // fetch positions in TEXEL units
+    int ox, oy;    // bilinear origin
+    float4 bw;     // custom bilinear weights
+    bool useBicubic;
+};
+inline HistoryFilter MakeHistoryFilter(float2 samplePos, float4 bilinearCustomWeights, bool useBicubic) {
+    const float S = NRD_CATROM_SHARPNESS;
+    HistoryFilter h;
+    float2 centerPos = floor(samplePos - 0.5f) + 0.5f;
+    float2 f = saturate(samplePos - centerPos);
+    float2 w0 = f * (f * (-S * f + 2.0f * S) - S);
+    float2 w1 = f * (f * ((2.0f - S) * f - (3.0f - S))) + 1.0f;
+    float2 w2 = f * (f * (-(2.0f - S) * f + (3.0f - 2.0f * S)) + S);
+    float2 w3 = f * (f * (S * f - S));
+    float2 w12 = w1 + w2;
+    float2 tc = w2 / w12;
+    float4 w = float4(w12.x * w0.y, w0.x * w12.y, w12.x * w12.y, w3.x * w12.y);
+    float w4 = w12.x * w3.y;
+    h.w = useBicubic ? w : bilinearCustomWeights;
+    h.w4 = useBicubic ? w4 : 0.0f;
+    h.sum = sum(h.w) + h.w4;
+    if (useBicubic) {
+        h.p0 = centerPos + float2(tc.x, -1.0f);
+        h.p1 = centerPos + float2(-1.0f, tc.y);
+        h.p2 = centerPos + float2(tc.x, tc.y);
+        h.p3 = centerPos + float2(2.0f, tc.y);
+        h.p4 = centerPos + float2(tc.x, 2.0f);
+    } else {
+        h.p0 = centerPos;
+        h.p1 = centerPos + float2(1.0f, 0.0f);
+        h.p2 = centerPos + float2(0.0f, 1.0f);
+        h.p3 = centerPos + float2(1.0f, 1.0f);
+        h.p4 = centerPos + f;
+    }
+    h.ox = (int)centerPos.x; // int3( centerPos, 0 ): truncation of k + 0.5
+    h.oy = (int)centerPos.y;
+    h.bw = bilinearCustomWeights;
+    h.useBicubic = useBicubic;
+    return h;
+}
+inline float4 FetchHistoryColor(const HistoryFilter& h, const Tex& tex) {
+    float4 color = tex.SampleLinearTexel(h.p0) * h.w.x;
+    color += tex.SampleLinearTexel(h.p1) * h.w.y;
+    color += tex.SampleLinearTexel(h.p2) * h.w.z;
+    color += tex.SampleLinearTexel(h.p3) * h.w.w;
+    color += tex.SampleLinearTexel(h.p4) * h.w4;
+    return h.sum < 0.0001f ? float4(0.0f) : color / h.sum;
+}
+inline float4 FetchHistoryBilinear(const HistoryFilter& h, const Tex& tex) {
+    float4 color = tex.Load(h.ox, h.oy) * h.bw.x;
+    color += tex.Load(h.ox + 1, h.oy) * h.bw.y;
+    color += tex.Load(h.ox, h.oy + 1) * h.bw.z;
+    color += tex.Load(h.ox + 1, h.oy + 1) * h.bw.w;
+    float s = sum(h.bw);
+    return s < 0.0001f ? float4(0.0f) : color / s;
+}
+
+} // namespace orc

@@ -76,7 +76,8 @@ def test_hip_numerics_bit_exact_vs_oracle():
         else:
             want = np.array([fn(float(v), float(w)) for v, w in zip(a32, b.astype(np.float32))], dtype=np.float32)
         ok = np.isfinite(want)
-        assert np.array_equal(got[ok].view(np.uint32), want[ok].view(np.uint32)), "op %d differs from the oracle" % op
+        bad = np.nonzero(got[ok].view(np.uint32) != want[ok].view(np.uint32))[0]
+        assert bad.size == 0, "op %d: %d / %d differ from the oracle, e.g. in=%r got=%r want=%r" % (op, bad.size, ok.sum(), a32[ok][bad[:4]], got[ok][bad[:4]], want[ok][bad[:4]])
     # IEEE division / sqrt on the device (correctly rounded) vs numpy
     a = (rng.standard_normal(n) * 10.0 ** rng.integers(-6, 6, n)).astype(np.float32)
     b = (rng.standard_normal(n) * 10.0 ** rng.integers(-6, 6, n)).astype(np.float32)
