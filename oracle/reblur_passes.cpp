@@ -1,2 +1,1456 @@
+// ORACLE -- TEST INFRASTRUCTURE, NOT PRODUCT CODE (see oracle/hlsl.h).
+//
+// CPU restatement of the REBLUR pass chain for the radiance+hit-distance denoisers (REBLUR_DIFFUSE, REBLUR_SPECULAR,
+// REBLUR_DIFFUSE_SPECULAR), quality mode, checkerboard OFF, hit-distance reconstruction OFF, no optional inputs
+// (history confidence / disocclusion threshold mix / base colour). One function per reference shader; every pixel is
+// independent inside a pass, so the LDS preloads of the shaders become clamped plane reads here.
+//   ClassifyTiles           reference Shaders/Source/REBLUR_ClassifyTiles.cs.hlsl:20-55
+//   PrePass                 reference Shaders/Include/REBLUR_PrePass.hlsli:11-108
+//   spatial filters         reference Shaders/Include/REBLUR_Common_DiffuseSpatialFilter.hlsli:22-213,
+//                                     REBLUR_Common_SpecularSpatialFilter.hlsli:22-277
+//   TemporalAccumulation    reference Shaders/Include/REBLUR_TemporalAccumulation.hlsli:11-931
+//   HistoryFix              reference Shaders/Include/REBLUR_HistoryFix.hlsli:11-463
+//   Blur / PostBlur         reference Shaders/Include/REBLUR_Blur.hlsli:11-74, REBLUR_PostBlur.hlsli:11-78
+//   TemporalStabilization   reference Shaders/Include/REBLUR_TemporalStabilization.hlsli:11-367
+//   SplitScreen             reference Shaders/Include/REBLUR_SplitScreen.hlsli:11-46
+// Binding order of planes = reference Source/Denoisers/Reblur_{Diffuse,Specular,DiffuseSpecular}.hpp.
 #include "passes.h"
-namespace orc { const PassEntry* GetReblurPasses(uint32_t& n) { n = 0; return nullptr; } }
+#include "reblur_common.h"
+
+#include <cstdio>
+#include <cstdlib>
+
+namespace orc {
+
+namespace {
+
+struct Cursor { // walks io.t in binding order
+    const PassIO& io;
+    uint32_t k = 0;
+    explicit Cursor(const PassIO& i) : io(i) {}
+    Tex* next() { return &io.t[k++]; }
+    Tex* nextIf(bool cond) { return cond ? &io.t[k++] : nullptr; }
+};
+
+// ================================================================================================ ClassifyTiles
+void ClassifyTiles(const PassIO& io) {
+    const ReblurCB& c = *(const ReblurCB*)io.constants;
+    const Tex& gIn_ViewZ = io.t[0];
+    Tex& gOut_Tiles = io.t[1];
+#pragma omp parallel for schedule(static)
+    for (int ty = 0; ty < gOut_Tiles.H(); ty++)
+        for (int tx = 0; tx < gOut_Tiles.W(); tx++) {
+            int sum = 0;
+            for (int j = 0; j < 16; j++)
+                for (int i = 0; i < 16; i++) {
+                    float viewZ = UnpackViewZ(c, gIn_ViewZ.Load(tx * 16 + i, ty * 16 + j).x);
+                    sum += viewZ > c.gDenoisingRange ? 1 : 0;
+                }
+            gOut_Tiles.Store(tx, ty, sum == 256 ? 1.0f : 0.0f);
+        }
+}
+
+// ================================================================================================ spatial filters
+struct SpatialCtx { // what PrePass / Blur / PostBlur share per pixel
+    int px, py;
+    float2 pixelUv;
+    float viewZ, roughness, materialID, NoV, frustumSize;
+    float3 N, Nv, Xv, Vv;
+    float4 rotator;
+    float2 data1; // accumulated frames (diff, spec); unused by the pre-pass
+};
+
+float4 DiffuseSpatialFilter(const ReblurCB& c, SpatialMode mode, const SpatialCtx& s, float4 diff, const Tex& gIn_Diff, const Tex& gIn_ViewZ, const Tex& gIn_Normal_Roughness) {
+    if (mode == PRE_BLUR && c.gDiffPrepassBlurRadius == 0.0f)
+        return diff;
+
+    float sum = 1.0f;
+    float fractionScale = 1.0f, radiusScale = 1.0f;
+    if (mode == PRE_BLUR)
+        fractionScale = REBLUR_PRE_BLUR_FRACTION_SCALE;
+    else if (mode == BLUR)
+        fractionScale = REBLUR_BLUR_FRACTION_SCALE;
+    else {
+        radiusScale = REBLUR_POST_BLUR_RADIUS_SCALE;
+        fractionScale = REBLUR_POST_BLUR_FRACTION_SCALE;
+    }
+
+    // Hit distance factor
+    float hitDistScale = _REBLUR_GetHitDistanceNormalization(s.viewZ, c.gHitDistParams, 1.0f);
+    float hitDist = diff.w * hitDistScale;
+    float hitDistFactor = GetHitDistFactor(hitDist, s.frustumSize);
+
+    // Blur radius
+    float diffNonLinearAccumSpeed, blurRadius, areaFactor;
+    if (mode == PRE_BLUR) {
+        diffNonLinearAccumSpeed = REBLUR_PRE_BLUR_NON_LINEAR_ACCUM_SPEED;
+        blurRadius = c.gDiffPrepassBlurRadius;
+        areaFactor = hitDistFactor;
+    } else {
+        float boost = 1.0f - GetFadeBasedOnAccumulatedFrames(c, s.data1.x);
+        boost *= 1.0f - BRDF::Pow5(s.NoV);
+        diffNonLinearAccumSpeed = 1.0f / (1.0f + REBLUR_SAMPLES_PER_FRAME * (1.0f - boost) * s.data1.x);
+        blurRadius = c.gMaxBlurRadius;
+        areaFactor = hitDistFactor * diffNonLinearAccumSpeed;
+    }
+    blurRadius *= Math::Sqrt01(areaFactor);
+    blurRadius *= radiusScale;
+    blurRadius = max(blurRadius, c.gMinBlurRadius);
+
+    // Weights
+    float2 geometryWeightParams = GetGeometryWeightParams(c.gPlaneDistSensitivity, s.frustumSize, s.Xv, s.Nv);
+    float normalWeightParam = GetNormalWeightParam(diffNonLinearAccumSpeed, c.gLobeAngleFraction) / fractionScale;
+    float2 hitDistanceWeightParams = GetHitDistanceWeightParams(diff.w, diffNonLinearAccumSpeed);
+    float minHitDistWeight = c.gMinHitDistanceWeight * fractionScale;
+    if (mode != PRE_BLUR)
+        minHitDistWeight *= sqrtf(diffNonLinearAccumSpeed);
+
+    // Screen-space sampling (REBLUR_USE_SCREEN_SPACE_SAMPLING_FOR_DIFFUSE = 1)
+    float2 skew = float2(1.0f);
+    if (mode != PRE_BLUR) {
+        skew = lerp(float2(1.0f - fabsf(s.Nv.x), 1.0f - fabsf(s.Nv.y)), float2(1.0f), s.NoV);
+        skew /= max(skew.x, skew.y);
+    }
+    skew *= c.gRectSizeInv * blurRadius;
+    float4 scaledRotator = Geometry::ScaleRotator(s.rotator, skew);
+
+    for (int n = 0; n < 8; n++) {
+        float3 offset = g_Special8[n];
+        float2 uv = s.pixelUv + Geometry::RotateVector(scaledRotator, float2(offset.x, offset.y));
+        uv = floor(uv * c.gRectSize) + 0.5f; // snap to the pixel centre
+        uv *= c.gRectSizeInv;
+        float2 uvScaled = min(uv * c.gResolutionScale, c.gResolutionScale - 0.5f * c.gResourceSizeInv); // ClampUvToViewport
+
+        float zs = UnpackViewZ(c, gIn_ViewZ.SampleNearest(uvScaled).x);
+        float materialIDs;
+        float4 Ns = NRD_FrontEnd_UnpackNormalAndRoughness(gIn_Normal_Roughness.SampleNearest(uvScaled), materialIDs);
+
+        float angle = Math::AcosApprox(dot(s.N, Ns.xyz()));
+        float3 Xvs = Geometry::ReconstructViewPosition(uv, c.gFrustum, zs, c.gOrthoMode);
+
+        float w = IsInScreenNearest(uv);
+        w *= ComputeWeight(dot(s.Nv, Xvs), geometryWeightParams.x, geometryWeightParams.y);
+        w *= CompareMaterials(s.materialID, materialIDs, c.gDiffMinMaterial) ? 1.0f : 0.0f;
+        w *= ComputeWeight(angle, normalWeightParam, 0.0f);
+
+        float4 smp = gIn_Diff.SampleNearest(uvScaled);
+        smp = w == 0.0f ? float4(0.0f) : smp; // Denanify
+
+        w *= lerp(minHitDistWeight, 1.0f, ComputeExponentialWeight(smp.w, hitDistanceWeightParams.x, hitDistanceWeightParams.y));
+        w *= GetGaussianWeight(offset.z);
+
+        sum += w;
+        diff += smp * w;
+    }
+
+    float invSum = Math::PositiveRcp(sum);
+    diff *= invSum;
+    return diff;
+}
+
+// returns the filtered signal; for the pre-pass also produces hitDistForTracking (written only if the radius != 0)
+float4 SpecularSpatialFilter(const ReblurCB& c, SpatialMode mode, const SpatialCtx& s, float4 spec, const Tex& gIn_Spec, const Tex& gIn_ViewZ,
+    const Tex& gIn_Normal_Roughness, Tex* gOut_SpecHitDistForTracking) {
+    float smc = GetSpecMagicCurve(s.roughness);
+    if (mode == PRE_BLUR && c.gSpecPrepassBlurRadius == 0.0f)
+        return spec;
+
+    RngHash rng;
+    if (mode == PRE_BLUR)
+        rng.Initialize((uint32_t)s.px, (uint32_t)s.py, c.gFrameIndex);
+
+    float sum = 1.0f;
+    float fractionScale = 1.0f, radiusScale = 1.0f;
+    if (mode == PRE_BLUR)
+        fractionScale = REBLUR_PRE_BLUR_FRACTION_SCALE;
+    else if (mode == BLUR)
+        fractionScale = REBLUR_BLUR_FRACTION_SCALE;
+    else {
+        radiusScale = REBLUR_POST_BLUR_RADIUS_SCALE;
+        fractionScale = REBLUR_POST_BLUR_FRACTION_SCALE;
+    }
+
+    // Hit distance factor
+    float4 Dv = ImportanceSampling::GetSpecularDominantDirection(s.Nv, s.Vv, s.roughness);
+    float NoD = fabsf(dot(s.Nv, Dv.xyz()));
+    float hitDistScale = _REBLUR_GetHitDistanceNormalization(s.viewZ, c.gHitDistParams, s.roughness);
+    float hitDist = spec.w * hitDistScale;
+    float hitDistFactor = GetHitDistFactor(hitDist, s.frustumSize);
+
+    // Blur radius
+    float hitDistForTracking = 0.0f, specNonLinearAccumSpeed, blurRadius, areaFactor;
+    if (mode == PRE_BLUR) {
+        specNonLinearAccumSpeed = REBLUR_PRE_BLUR_NON_LINEAR_ACCUM_SPEED;
+        hitDistForTracking = hitDist == 0.0f ? NRD_INF : hitDist;
+        blurRadius = c.gSpecPrepassBlurRadius;
+        areaFactor = s.roughness * hitDistFactor;
+    } else {
+        float boost = 1.0f - GetFadeBasedOnAccumulatedFrames(c, s.data1.y);
+        boost *= 1.0f - BRDF::Pow5(s.NoV);
+        boost *= smc;
+        specNonLinearAccumSpeed = 1.0f / (1.0f + REBLUR_SAMPLES_PER_FRAME * (1.0f - boost) * s.data1.y);
+        blurRadius = c.gMaxBlurRadius;
+        areaFactor = s.roughness * hitDistFactor * specNonLinearAccumSpeed;
+    }
+    blurRadius *= Math::Sqrt01(areaFactor);
+
+    if (mode == PRE_BLUR) {
+        float lobeTanHalfAngle = ImportanceSampling::GetSpecularLobeTanHalfAngle(s.roughness, REBLUR_MAX_PERCENT_OF_LOBE_VOLUME_FOR_PRE_PASS);
+        float lobeRadius = hitDist * NoD * lobeTanHalfAngle;
+        float minBlurRadius = lobeRadius / PixelRadiusToWorld(c.gUnproject, c.gOrthoMode, 1.0f, s.viewZ + hitDist * Dv.w);
+        blurRadius = min(blurRadius, minBlurRadius);
+    }
+    blurRadius *= radiusScale;
+    blurRadius = max(blurRadius, c.gMinBlurRadius * smc);
+
+    // Weights
+    float roughnessFractionScaled = saturate(c.gRoughnessFraction * fractionScale);
+    float2 geometryWeightParams = GetGeometryWeightParams(c.gPlaneDistSensitivity, s.frustumSize, s.Xv, s.Nv);
+    float normalWeightParam = GetNormalWeightParam(specNonLinearAccumSpeed, c.gLobeAngleFraction, s.roughness) / fractionScale;
+    float2 roughnessWeightParams = GetRoughnessWeightParams(s.roughness, roughnessFractionScaled);
+    float2 hitDistanceWeightParams = GetHitDistanceWeightParams(spec.w, specNonLinearAccumSpeed, s.roughness);
+    float minHitDistWeight = c.gMinHitDistanceWeight * fractionScale * smc;
+    if (mode != PRE_BLUR)
+        minHitDistWeight *= sqrtf(specNonLinearAccumSpeed);
+
+    // Sampling set-up: screen space for the pre-pass, world space along the (bent) lobe otherwise
+    float4 scaledRotator = float4(0.0f);
+    float3 T, B;
+    if (mode == PRE_BLUR) {
+        float2 skew = c.gRectSizeInv * blurRadius;
+        scaledRotator = Geometry::ScaleRotator(s.rotator, skew);
+    } else {
+        float bentFactor = sqrtf(hitDistFactor);
+        float skewFactor = lerp(0.25f + 0.75f * s.roughness, 1.0f, NoD);
+        skewFactor = lerp(skewFactor, 1.0f, specNonLinearAccumSpeed);
+        skewFactor = lerp(1.0f, skewFactor, bentFactor);
+        float3 bentDv = normalize(lerp(s.Nv, Dv.xyz(), bentFactor));
+        GetKernelBasis(bentDv, s.Nv, T, B);
+        float worldRadius = PixelRadiusToWorld(c.gUnproject, c.gOrthoMode, blurRadius, s.viewZ);
+        T *= worldRadius * skewFactor;
+        B *= worldRadius / skewFactor;
+    }
+
+    for (int n = 0; n < 8; n++) {
+        float3 offset = g_Special8[n];
+        float2 uv;
+        if (mode == PRE_BLUR)
+            uv = s.pixelUv + Geometry::RotateVector(scaledRotator, float2(offset.x, offset.y));
+        else
+            uv = GetKernelSampleCoordinates(c.gViewToClip, offset, s.Xv, T, B, s.rotator);
+
+        uv = floor(uv * c.gRectSize) + 0.5f;
+        uv *= c.gRectSizeInv;
+        float2 uvScaled = min(uv * c.gResolutionScale, c.gResolutionScale - 0.5f * c.gResourceSizeInv);
+
+        float zs = UnpackViewZ(c, gIn_ViewZ.SampleNearest(uvScaled).x);
+        float materialIDs;
+        float4 Ns = NRD_FrontEnd_UnpackNormalAndRoughness(gIn_Normal_Roughness.SampleNearest(uvScaled), materialIDs);
+
+        float angle = Math::AcosApprox(dot(s.N, Ns.xyz()));
+        float3 Xvs = Geometry::ReconstructViewPosition(uv, c.gFrustum, zs, c.gOrthoMode);
+
+        float w = IsInScreenNearest(uv);
+        w *= ComputeWeight(dot(s.Nv, Xvs), geometryWeightParams.x, geometryWeightParams.y);
+        w *= CompareMaterials(s.materialID, materialIDs, c.gSpecMinMaterial) ? 1.0f : 0.0f;
+        w *= ComputeWeight(angle, normalWeightParam, 0.0f);
+        w *= ComputeWeight(Ns.w, roughnessWeightParams.x, roughnessWeightParams.y);
+
+        float4 smp = gIn_Spec.SampleNearest(uvScaled);
+        smp = w == 0.0f ? float4(0.0f) : smp;
+
+        if (mode == PRE_BLUR) {
+            // stochastic min hit distance for tracking, ignoring zeros
+            float hs = smp.w * _REBLUR_GetHitDistanceNormalization(zs, c.gHitDistParams, Ns.w);
+            float d = length(Xvs - s.Xv) + NRD_EPS;
+            float geometryWeight = w * saturate(hs / d);
+            if (rng.GetFloat() < geometryWeight)
+                hitDistForTracking = min(hitDistForTracking, hs);
+
+            w *= c.gUsePrepassNotOnlyForSpecularMotionEstimation;
+
+            // samples close to the reflection contact should not be blurred
+            float t = hs / (d + hitDist);
+            w *= lerp(saturate(t), 1.0f, Math::LinearStep(0.5f, 1.0f, s.roughness));
+        }
+        w *= lerp(minHitDistWeight, 1.0f, ComputeExponentialWeight(smp.w, hitDistanceWeightParams.x, hitDistanceWeightParams.y));
+        w *= GetGaussianWeight(offset.z);
+
+        sum += w;
+        spec += smp * w;
+    }
+
+    float invSum = Math::PositiveRcp(sum);
+    spec *= invSum;
+
+    if (mode == PRE_BLUR)
+        gOut_SpecHitDistForTracking->Store(s.px, s.py, hitDistForTracking == NRD_INF ? 0.0f : hitDistForTracking);
+    return spec;
+}
+
+// fills the per-pixel context; returns false on the early-outs (sky tile / outside rect / beyond denoising range)
+bool MakeSpatialCtx(const ReblurCB& c, int px, int py, const Tex& gIn_Tiles, const Tex& gIn_ViewZ, const Tex& gIn_Normal_Roughness, float4 rotator, SpatialCtx& s, float* viewZpackedOut = nullptr) {
+    float isSky = gIn_Tiles.Load(px >> 4, py >> 4).x;
+    if (isSky != 0.0f || px > c.gRectSizeMinusOne[0] || py > c.gRectSizeMinusOne[1])
+        return false;
+    float viewZpacked = gIn_ViewZ.Load(px, py).x;
+    if (viewZpackedOut)
+        *viewZpackedOut = viewZpacked;
+    s.viewZ = UnpackViewZ(c, viewZpacked);
+    if (s.viewZ > c.gDenoisingRange)
+        return false;
+
+    float4 normalAndRoughness = NRD_FrontEnd_UnpackNormalAndRoughness(gIn_Normal_Roughness.Load(px, py), s.materialID);
+    s.px = px;
+    s.py = py;
+    s.N = normalAndRoughness.xyz();
+    s.Nv = Geometry::RotateVectorInverse(c.gViewToWorld, s.N);
+    s.roughness = normalAndRoughness.w;
+    s.pixelUv = float2(float(px) + 0.5f, float(py) + 0.5f) * c.gRectSizeInv;
+    s.Xv = Geometry::ReconstructViewPosition(s.pixelUv, c.gFrustum, s.viewZ, c.gOrthoMode);
+    s.Vv = GetViewVector(c, s.Xv, true);
+    s.NoV = fabsf(dot(s.Nv, s.Vv));
+    s.frustumSize = GetFrustumSize(c.gMinRectDimMulUnproject, c.gOrthoMode, s.viewZ);
+    s.rotator = rotator; // NRD_FRAME rotator mode: the per-frame base rotator, no per-pixel component
+    s.data1 = float2(0.0f);
+    return true;
+}
+
+// ================================================================================================ PrePass
+template <bool DIFF, bool SPEC>
+void PrePass(const PassIO& io) {
+    const ReblurCB& c = *(const ReblurCB*)io.constants;
+    Cursor cur(io);
+    const Tex& gIn_Tiles = *cur.next();
+    const Tex& gIn_Normal_Roughness = *cur.next();
+    const Tex& gIn_ViewZ = *cur.next();
+    const Tex* gIn_Diff = cur.nextIf(DIFF);
+    const Tex* gIn_Spec = cur.nextIf(SPEC);
+    Tex* gOut_Diff = cur.nextIf(DIFF);
+    Tex* gOut_Spec = cur.nextIf(SPEC);
+    Tex* gOut_SpecHitDistForTracking = cur.nextIf(SPEC);
+
+#pragma omp parallel for schedule(dynamic, 4)
+    for (int py = 0; py < (int)c.gRectSize.y; py++)
+        for (int px = 0; px < (int)c.gRectSize.x; px++) {
+            SpatialCtx s;
+            if (!MakeSpatialCtx(c, px, py, gIn_Tiles, gIn_ViewZ, gIn_Normal_Roughness, c.gRotatorPre, s))
+                continue;
+            if (DIFF) {
+                float4 diff = gIn_Diff->Load(px, py);
+                diff = DiffuseSpatialFilter(c, PRE_BLUR, s, diff, *gIn_Diff, gIn_ViewZ, gIn_Normal_Roughness);
+                gOut_Diff->Store(px, py, diff);
+            }
+            if (SPEC) {
+                float4 spec = gIn_Spec->Load(px, py);
+                spec = SpecularSpatialFilter(c, PRE_BLUR, s, spec, *gIn_Spec, gIn_ViewZ, gIn_Normal_Roughness, gOut_SpecHitDistForTracking);
+                gOut_Spec->Store(px, py, spec);
+            }
+        }
+}
+
+// ================================================================================================ Blur
+template <bool DIFF, bool SPEC>
+void Blur(const PassIO& io) {
+    const ReblurCB& c = *(const ReblurCB*)io.constants;
+    Cursor cur(io);
+    const Tex& gIn_Tiles = *cur.next();
+    const Tex& gIn_Normal_Roughness = *cur.next();
+    const Tex& gIn_Data1 = *cur.next();
+    const Tex* gIn_Diff = cur.nextIf(DIFF);
+    const Tex* gIn_Spec = cur.nextIf(SPEC);
+    const Tex& gIn_ViewZ = *cur.next();
+    Tex* gOut_Diff = cur.nextIf(DIFF);
+    Tex* gOut_Spec = cur.nextIf(SPEC);
+    Tex& gOut_ViewZ = *cur.next();
+
+#pragma omp parallel for schedule(dynamic, 4)
+    for (int py = 0; py < (int)c.gRectSize.y; py++)
+        for (int px = 0; px < (int)c.gRectSize.x; px++) {
+            // the copy of viewZ into PREV_VIEWZ happens BEFORE the denoising-range early-out (REBLUR_Blur.hlsli:22-27)
+            float isSky = gIn_Tiles.Load(px >> 4, py >> 4).x;
+            if (isSky != 0.0f || px > c.gRectSizeMinusOne[0] || py > c.gRectSizeMinusOne[1])
+                continue;
+            gOut_ViewZ.Store(px, py, gIn_ViewZ.Load(px, py).x);
+
+            SpatialCtx s;
+            if (!MakeSpatialCtx(c, px, py, gIn_Tiles, gIn_ViewZ, gIn_Normal_Roughness, c.gRotator, s))
+                continue;
+            s.data1 = UnpackData1(gIn_Data1.Load(px, py), DIFF);
+            if (DIFF) {
+                float4 diff = gIn_Diff->Load(px, py);
+                diff = DiffuseSpatialFilter(c, BLUR, s, diff, *gIn_Diff, gIn_ViewZ, gIn_Normal_Roughness);
+                gOut_Diff->Store(px, py, diff);
+            }
+            if (SPEC) {
+                float4 spec = gIn_Spec->Load(px, py);
+                spec = SpecularSpatialFilter(c, BLUR, s, spec, *gIn_Spec, gIn_ViewZ, gIn_Normal_Roughness, nullptr);
+                gOut_Spec->Store(px, py, spec);
+            }
+        }
+}
+
+// ================================================================================================ PostBlur
+template <bool DIFF, bool SPEC, bool NO_TS>
+void PostBlur(const PassIO& io) {
+    const ReblurCB& c = *(const ReblurCB*)io.constants;
+    Cursor cur(io);
+    const Tex& gIn_Tiles = *cur.next();
+    const Tex& gIn_Normal_Roughness = *cur.next();
+    const Tex& gIn_Data1 = *cur.next();
+    const Tex* gIn_Diff = cur.nextIf(DIFF);
+    const Tex* gIn_Spec = cur.nextIf(SPEC);
+    const Tex& gIn_ViewZ = *cur.next(); // PREV_VIEWZ written by Blur
+    Tex& gOut_Normal_Roughness = *cur.next();
+    Tex* gOut_Diff = cur.nextIf(DIFF);
+    Tex* gOut_Spec = cur.nextIf(SPEC);
+    Tex* gOut_InternalData = cur.nextIf(NO_TS);
+    Tex* gOut_DiffCopy = cur.nextIf(NO_TS && DIFF);
+    Tex* gOut_SpecCopy = cur.nextIf(NO_TS && SPEC);
+
+#pragma omp parallel for schedule(dynamic, 4)
+    for (int py = 0; py < (int)c.gRectSize.y; py++)
+        for (int px = 0; px < (int)c.gRectSize.x; px++) {
+            SpatialCtx s;
+            if (!MakeSpatialCtx(c, px, py, gIn_Tiles, gIn_ViewZ, gIn_Normal_Roughness, c.gRotatorPost, s))
+                continue;
+            s.data1 = UnpackData1(gIn_Data1.Load(px, py), DIFF);
+
+            gOut_Normal_Roughness.CopyTexelFrom(gIn_Normal_Roughness, px, py, 4); // same R10G10B10A2 format: the packed value round-trips exactly
+            if (NO_TS)
+                gOut_InternalData->StoreUint(px, py, PackInternalData(s.data1.x + 1.0f, s.data1.y + 1.0f, s.materialID));
+
+            if (DIFF) {
+                float4 diff = gIn_Diff->Load(px, py);
+                diff = DiffuseSpatialFilter(c, POST_BLUR, s, diff, *gIn_Diff, gIn_ViewZ, gIn_Normal_Roughness);
+                gOut_Diff->Store(px, py, diff);
+                if (NO_TS)
+                    gOut_DiffCopy->Store(px, py, diff);
+            }
+            if (SPEC) {
+                float4 spec = gIn_Spec->Load(px, py);
+                spec = SpecularSpatialFilter(c, POST_BLUR, s, spec, *gIn_Spec, gIn_ViewZ, gIn_Normal_Roughness, nullptr);
+                gOut_Spec->Store(px, py, spec);
+                if (NO_TS)
+                    gOut_SpecCopy->Store(px, py, spec);
+            }
+        }
+}
+
+// ================================================================================================ TemporalAccumulation
+template <bool DIFF, bool SPEC>
+void TemporalAccumulation(const PassIO& io) {
+    const ReblurCB& c = *(const ReblurCB*)io.constants;
+    Cursor cur(io);
+    const Tex& gIn_Tiles = *cur.next();
+    const Tex& gIn_Normal_Roughness = *cur.next();
+    const Tex& gIn_ViewZ = *cur.next();
+    const Tex& gIn_Mv = *cur.next();
+    const Tex& gPrev_ViewZ = *cur.next();
+    const Tex& gPrev_Normal_Roughness = *cur.next();
+    const Tex& gPrev_InternalData = *cur.next();
+    cur.next();      // gIn_DisocclusionThresholdMix (dummy)
+    cur.nextIf(DIFF); // gIn_DiffConfidence (dummy)
+    cur.nextIf(SPEC); // gIn_SpecConfidence (dummy)
+    const Tex* gIn_Diff = cur.nextIf(DIFF);
+    const Tex* gIn_Spec = cur.nextIf(SPEC);
+    const Tex* gHistory_Diff = cur.nextIf(DIFF);
+    const Tex* gHistory_Spec = cur.nextIf(SPEC);
+    const Tex* gHistory_DiffFast = cur.nextIf(DIFF);
+    const Tex* gHistory_SpecFast = cur.nextIf(SPEC);
+    const Tex* gPrev_SpecHitDistForTracking = cur.nextIf(SPEC);
+    const Tex* gIn_SpecHitDistForTracking = cur.nextIf(SPEC);
+    Tex* gOut_Diff = cur.nextIf(DIFF);
+    Tex* gOut_Spec = cur.nextIf(SPEC);
+    Tex* gOut_DiffFast = cur.nextIf(DIFF);
+    Tex* gOut_SpecFast = cur.nextIf(SPEC);
+    Tex* gOut_SpecHitDistForTracking = cur.nextIf(SPEC);
+    Tex& gOut_Data1 = *cur.next();
+    Tex& gOut_Data2 = *cur.next();
+
+    const int rw = c.gRectSizeMinusOne[0], rh = c.gRectSizeMinusOne[1];
+
+#pragma omp parallel for schedule(dynamic, 4)
+    for (int py = 0; py <= rh; py++)
+        for (int px = 0; px <= rw; px++) {
+            float isSky = gIn_Tiles.Load(px >> 4, py >> 4).x;
+            if (isSky != 0.0f)
+                continue;
+            float viewZ = UnpackViewZ(c, gIn_ViewZ.Load(px, py).x);
+            if (viewZ > c.gDenoisingRange)
+                continue;
+
+            // "shared memory": unpacked normal/roughness and hit distance for tracking at clamped positions
+            auto sNR = [&](int x, int y) { return NRD_FrontEnd_UnpackNormalAndRoughness(gIn_Normal_Roughness.Load(clamp(x, 0, rw), clamp(y, 0, rh))); };
+            auto sHitDistForTracking = [&](int x, int y) {
+                x = clamp(x, 0, rw);
+                y = clamp(y, 0, rh);
+                float hitDist = c.gSpecPrepassBlurRadius == 0.0f ? gIn_Spec->Load(x, y).w : gIn_SpecHitDistForTracking->Load(x, y).x;
+                return hitDist == 0.0f ? NRD_INF : hitDist;
+            };
+
+            // Current position
+            float2 pixelUv = float2(float(px) + 0.5f, float(py) + 0.5f) * c.gRectSizeInv;
+            float3 Xv = Geometry::ReconstructViewPosition(pixelUv, c.gFrustum, viewZ, c.gOrthoMode);
+            float3 X = Geometry::RotateVector(c.gViewToWorld, Xv);
+
+            // Hit distance for tracking, averaged normal and roughness variance over 3x3
+            float3 Navg = float3(0.0f);
+            float hitDistForTracking = NRD_INF, roughnessM1 = 0.0f, roughnessM2 = 0.0f;
+            for (int j = 0; j <= 2; j++)
+                for (int i = 0; i <= 2; i++) {
+                    float4 nr = sNR(px - 1 + i, py - 1 + j);
+                    if (i < 2 && j < 2)
+                        Navg += nr.xyz();
+                    if (SPEC) {
+                        hitDistForTracking = min(hitDistForTracking, sHitDistForTracking(px - 1 + i, py - 1 + j));
+                        float roughnessSq = nr.w * nr.w;
+                        roughnessM1 += roughnessSq;
+                        roughnessM2 += roughnessSq * roughnessSq;
+                    }
+                }
+            Navg /= 4.0f;
+
+            float materialID;
+            float4 normalAndRoughness = NRD_FrontEnd_UnpackNormalAndRoughness(gIn_Normal_Roughness.Load(px, py), materialID);
+            float3 N = normalAndRoughness.xyz();
+            float roughness = normalAndRoughness.w;
+
+            float roughnessModified = 0.0f, roughnessSigma = 0.0f, hitDistNormalization = 0.0f;
+            RngHash rng;
+            if (SPEC) {
+                roughnessModified = Filtering::GetModifiedRoughnessFromNormalVariance(roughness, Navg);
+                roughnessM1 /= 9.0f;
+                roughnessM2 /= 9.0f;
+                roughnessSigma = sqrtf(fabsf(roughnessM2 - roughnessM1 * roughnessM1)); // GetStdDev
+
+                rng.Initialize((uint32_t)px, (uint32_t)py, c.gFrameIndex);
+
+                hitDistForTracking = hitDistForTracking == NRD_INF ? 0.0f : hitDistForTracking;
+                hitDistNormalization = _REBLUR_GetHitDistanceNormalization(viewZ, c.gHitDistParams, roughness);
+                hitDistForTracking *= c.gSpecPrepassBlurRadius == 0.0f ? hitDistNormalization : 1.0f;
+                gOut_SpecHitDistForTracking->Store(px, py, hitDistForTracking);
+            }
+
+            // Previous position and surface motion uv
+            float4 mvRaw = gIn_Mv.Load(px, py);
+            float3 mv = float3(mvRaw.x, mvRaw.y, mvRaw.z) * c.gMvScale.xyz();
+            float3 Xprev = X;
+            float2 smbPixelUv = pixelUv + float2(mv.x, mv.y);
+            if (c.gMvScale.w == 0.0f) {
+                if (c.gMvScale.z == 0.0f)
+                    mv.z = Geometry::AffineTransform(c.gWorldToViewPrev, X).z - viewZ;
+                float viewZprev = viewZ + mv.z;
+                float3 Xvprevlocal = Geometry::ReconstructViewPosition(smbPixelUv, c.gFrustumPrev, viewZprev, c.gOrthoMode);
+                Xprev = Geometry::RotateVectorInverse(c.gWorldToViewPrev, Xvprevlocal) + c.gCameraDelta.xyz();
+            } else {
+                Xprev += mv;
+                smbPixelUv = Geometry::GetScreenUv(c.gWorldToClipPrev, Xprev);
+            }
+
+            // Previous viewZ over the 4x4 Catmull-Rom footprint; q<k> = quad k in (0,0)(1,0)(0,1)(1,1) order
+            float2 catromOrigin = Filtering::GetCatmullRomOrigin(smbPixelUv, c.gRectSizePrev);
+            int cx = (int)catromOrigin.x, cy = (int)catromOrigin.y;
+            auto quadZ = [&](int ox, int oy) {
+                return float4(gPrev_ViewZ.FetchClamped(cx + ox, cy + oy).x, gPrev_ViewZ.FetchClamped(cx + ox + 1, cy + oy).x, gPrev_ViewZ.FetchClamped(cx + ox, cy + oy + 1).x,
+                    gPrev_ViewZ.FetchClamped(cx + ox + 1, cy + oy + 1).x);
+            };
+            float4 smbViewZ0 = quadZ(0, 0), smbViewZ1 = quadZ(2, 0), smbViewZ2 = quadZ(0, 2), smbViewZ3 = quadZ(2, 2);
+            float3 prevViewZ0 = float3(UnpackViewZ(c, smbViewZ0.y), UnpackViewZ(c, smbViewZ0.z), UnpackViewZ(c, smbViewZ0.w));
+            float3 prevViewZ1 = float3(UnpackViewZ(c, smbViewZ1.x), UnpackViewZ(c, smbViewZ1.z), UnpackViewZ(c, smbViewZ1.w));
+            float3 prevViewZ2 = float3(UnpackViewZ(c, smbViewZ2.x), UnpackViewZ(c, smbViewZ2.y), UnpackViewZ(c, smbViewZ2.w));
+            float3 prevViewZ3 = float3(UnpackViewZ(c, smbViewZ3.x), UnpackViewZ(c, smbViewZ3.y), UnpackViewZ(c, smbViewZ3.z));
+
+            // Previous normal averaged over the valid pixels of the 2x2 footprint
+            Filtering::Bilinear smbBilinearFilter = Filtering::GetBilinearFilter(smbPixelUv, c.gRectSizePrev);
+            float3 smbNavg;
+            {
+                int bx = (int)smbBilinearFilter.origin.x, by = (int)smbBilinearFilter.origin.y; // taps outside the plane load 0 (our pinned choice; D3D ftou would clamp a negative origin)
+                float sumw = 0.0f;
+                float w = prevViewZ0.z < c.gDenoisingRange ? 1.0f : 0.0f;
+                smbNavg = NRD_FrontEnd_UnpackNormalAndRoughness(gPrev_Normal_Roughness.Load(bx, by)).xyz() * w;
+                sumw += w;
+                w = prevViewZ1.y < c.gDenoisingRange ? 1.0f : 0.0f;
+                smbNavg += NRD_FrontEnd_UnpackNormalAndRoughness(gPrev_Normal_Roughness.Load(bx + 1, by)).xyz() * w;
+                sumw += w;
+                w = prevViewZ2.y < c.gDenoisingRange ? 1.0f : 0.0f;
+                smbNavg += NRD_FrontEnd_UnpackNormalAndRoughness(gPrev_Normal_Roughness.Load(bx, by + 1)).xyz() * w;
+                sumw += w;
+                w = prevViewZ3.x < c.gDenoisingRange ? 1.0f : 0.0f;
+                smbNavg += NRD_FrontEnd_UnpackNormalAndRoughness(gPrev_Normal_Roughness.Load(bx + 1, by + 1)).xyz() * w;
+                sumw += w;
+                smbNavg /= sumw == 0.0f ? 1.0f : sumw;
+            }
+            smbNavg = Geometry::RotateVector(c.gWorldPrevToWorld, smbNavg);
+
+            // Parallax
+            float smbParallaxInPixels1 = ComputeParallaxInPixels(Xprev + c.gCameraDelta.xyz(), c.gOrthoMode == 0.0f ? smbPixelUv : pixelUv, c.gWorldToClipPrev, c.gRectSize);
+            float smbParallaxInPixels2 = ComputeParallaxInPixels(Xprev - c.gCameraDelta.xyz(), c.gOrthoMode == 0.0f ? pixelUv : smbPixelUv, c.gWorldToClip, c.gRectSize);
+            float smbParallaxInPixelsMax = max(smbParallaxInPixels1, smbParallaxInPixels2);
+            float smbParallaxInPixelsMin = min(smbParallaxInPixels1, smbParallaxInPixels2);
+
+            // Disocclusion: threshold
+            float pixelSize = PixelRadiusToWorld(c.gUnproject, c.gOrthoMode, 1.0f, viewZ);
+            float frustumSize = GetFrustumSize(c.gMinRectDimMulUnproject, c.gOrthoMode, viewZ);
+
+            float disocclusionThresholdMix = 0.0f;
+            if (materialID == c.gStrandMaterialID)
+                disocclusionThresholdMix = saturate(c.gStrandThickness / pixelSize); // NRD_GetNormalizedStrandThickness
+            float disocclusionThreshold = lerp(c.gDisocclusionThreshold, c.gDisocclusionThresholdAlternate, disocclusionThresholdMix);
+
+            float smallParallax = Math::LinearStep(0.25f, 0.0f, smbParallaxInPixelsMax);
+            disocclusionThreshold += 0.05f * smallParallax;
+
+            float3 V = GetViewVector(c, X);
+            float NoV = fabsf(dot(N, V));
+            float NoVstrict = lerp(NoV, 1.0f, saturate(smbParallaxInPixelsMax / 30.0f));
+            float4 smbDisocclusionThreshold = float4(GetDisocclusionThreshold(disocclusionThreshold, frustumSize, NoVstrict));
+            smbDisocclusionThreshold *= dot(smbNavg, Navg) > REBLUR_ALMOST_ZERO_ANGLE - 0.25f * smallParallax ? 1.0f : 0.0f;
+            smbDisocclusionThreshold *= IsInScreenBilinear(smbBilinearFilter.origin, c.gRectSizePrev);
+            smbDisocclusionThreshold -= NRD_EPS;
+
+            // Disocclusion: plane distance
+            float3 Xvprev = Geometry::AffineTransform(c.gWorldToViewPrev, Xprev);
+            float3 smbOcclusion0 = step(abs(prevViewZ0 - Xvprev.z), smbDisocclusionThreshold.x);
+            float3 smbOcclusion1 = step(abs(prevViewZ1 - Xvprev.z), smbDisocclusionThreshold.y);
+            float3 smbOcclusion2 = step(abs(prevViewZ2 - Xvprev.z), smbDisocclusionThreshold.z);
+            float3 smbOcclusion3 = step(abs(prevViewZ3 - Xvprev.z), smbDisocclusionThreshold.w);
+
+            // Disocclusion: materialID (R10G10B10A2 encoding carries one)
+            auto quadU = [&](int ox, int oy, uint32_t q[4]) {
+                q[0] = gPrev_InternalData.FetchUintClamped(cx + ox, cy + oy);
+                q[1] = gPrev_InternalData.FetchUintClamped(cx + ox + 1, cy + oy);
+                q[2] = gPrev_InternalData.FetchUintClamped(cx + ox, cy + oy + 1);
+                q[3] = gPrev_InternalData.FetchUintClamped(cx + ox + 1, cy + oy + 1);
+            };
+            uint32_t id0[4], id1[4], id2[4], id3[4];
+            quadU(0, 0, id0), quadU(2, 0, id1), quadU(0, 2, id2), quadU(2, 2, id3);
+            float minMaterialID = min(c.gSpecMinMaterial, c.gDiffMinMaterial);
+            auto matCmp = [&](uint32_t p) { return CompareMaterials(materialID, UnpackInternalData(p).z, minMaterialID) ? 1.0f : 0.0f; };
+            smbOcclusion0 = smbOcclusion0 * float3(matCmp(id0[1]), matCmp(id0[2]), matCmp(id0[3]));
+            smbOcclusion1 = smbOcclusion1 * float3(matCmp(id1[0]), matCmp(id1[2]), matCmp(id1[3]));
+            smbOcclusion2 = smbOcclusion2 * float3(matCmp(id2[0]), matCmp(id2[1]), matCmp(id2[3]));
+            smbOcclusion3 = smbOcclusion3 * float3(matCmp(id3[0]), matCmp(id3[1]), matCmp(id3[2]));
+            uint32_t smbInternalData[4] = {id0[3], id1[2], id2[1], id3[0]};
+
+            // 2x2 occlusion weights
+            float4 smbOcclusionWeights = Filtering::GetBilinearCustomWeights(smbBilinearFilter, float4(smbOcclusion0.z, smbOcclusion1.y, smbOcclusion2.y, smbOcclusion3.x));
+            bool smbAllowCatRom = sum(smbOcclusion0 + smbOcclusion1 + smbOcclusion2 + smbOcclusion3) > 11.5f;
+
+            float fbits = smbOcclusion0.z * 1.0f;
+            fbits += smbOcclusion1.y * 2.0f;
+            fbits += smbOcclusion2.y * 4.0f;
+            fbits += smbOcclusion3.x * 8.0f;
+
+            // Accumulation speed
+            float3 internalData00 = UnpackInternalData(smbInternalData[0]), internalData10 = UnpackInternalData(smbInternalData[1]);
+            float3 internalData01 = UnpackInternalData(smbInternalData[2]), internalData11 = UnpackInternalData(smbInternalData[3]);
+            float diffAccumSpeed = 0.0f, smbSpecAccumSpeed = 0.0f;
+            if (DIFF)
+                diffAccumSpeed = Filtering::ApplyBilinearCustomWeights(internalData00.x, internalData10.x, internalData01.x, internalData11.x, smbOcclusionWeights);
+            if (SPEC)
+                smbSpecAccumSpeed = Filtering::ApplyBilinearCustomWeights(internalData00.y, internalData10.y, internalData01.y, internalData11.y, smbOcclusionWeights);
+
+            // Footprint quality
+            float3 smbVprev = GetViewVectorPrev(c, Xprev, c.gCameraDelta.xyz());
+            float NoVprev = fabsf(dot(N, smbVprev));
+            float sizeQuality = (NoVprev + 1e-3f) / (NoV + 1e-3f);
+            sizeQuality *= sizeQuality;
+            sizeQuality = lerp(0.1f, 1.0f, saturate(sizeQuality));
+
+            float smbFootprintQuality = Filtering::ApplyBilinearFilter(smbOcclusion0.z, smbOcclusion1.y, smbOcclusion2.y, smbOcclusion3.x, smbBilinearFilter);
+            smbFootprintQuality = Math::Sqrt01(smbFootprintQuality);
+            smbFootprintQuality *= sizeQuality;
+
+            const float2 smbSamplePos = saturate(smbPixelUv) * c.gRectSizePrev;
+
+            // ---------------------------------------------------------------------------------------------- specular
+            float specAccumSpeed = 0.0f, curvature = 0.0f, virtualHistoryAmount = 0.0f;
+            if (SPEC) {
+                float specHistoryConfidence = smbFootprintQuality;
+                smbSpecAccumSpeed *= lerp(specHistoryConfidence, 1.0f, 1.0f / (1.0f + smbSpecAccumSpeed));
+                smbSpecAccumSpeed = min(smbSpecAccumSpeed, c.gMaxAccumulatedFrameNum);
+
+                float4 spec = gIn_Spec->Load(px, py);
+
+                // Curvature estimation along predicted motion
+                {
+                    float2 uvForZeroParallax = c.gOrthoMode == 0.0f ? smbPixelUv : pixelUv;
+                    float2 deltaUv = uvForZeroParallax - Geometry::GetScreenUv(c.gWorldToClipPrev, Xprev + c.gCameraDelta.xyz());
+                    deltaUv *= c.gRectSize;
+                    deltaUv /= max(smbParallaxInPixels1, 1.0f / 256.0f);
+
+                    // 10 edge
+                    float3 n10, x10;
+                    {
+                        float3 xv = Geometry::ReconstructViewPosition(pixelUv + float2(1, 0) * c.gRectSizeInv, c.gFrustum, 1.0f, c.gOrthoMode);
+                        float3 x = Geometry::RotateVector(c.gViewToWorld, xv);
+                        float3 v = GetViewVector(c, x);
+                        float3 o = c.gOrthoMode == 0.0f ? float3(0.0f) : x;
+                        x10 = o + v * dot(X - o, N) / dot(N, v);
+                        n10 = sNR(px + 1, py).xyz();
+                    }
+                    // 01 edge
+                    float3 n01, x01;
+                    {
+                        float3 xv = Geometry::ReconstructViewPosition(pixelUv + float2(0, 1) * c.gRectSizeInv, c.gFrustum, 1.0f, c.gOrthoMode);
+                        float3 x = Geometry::RotateVector(c.gViewToWorld, xv);
+                        float3 v = GetViewVector(c, x);
+                        float3 o = c.gOrthoMode == 0.0f ? float3(0.0f) : x;
+                        x01 = o + v * dot(X - o, N) / dot(N, v);
+                        n01 = sNR(px, py + 1).xyz();
+                    }
+                    // Mix
+                    float2 w = abs(deltaUv) + 1.0f / 256.0f;
+                    w /= w.x + w.y;
+                    float3 x = x10 * w.x + x01 * w.y;
+                    float3 n = normalize(n10 * w.x + n01 * w.y);
+
+                    // High parallax: flatten the surface on fast motion
+                    float deltaUvLenFixed = smbParallaxInPixelsMin;
+                    deltaUvLenFixed *= 1.0f + c.gFramerateScale * Sequence::Bayer4x4((uint32_t)px, (uint32_t)py, c.gFrameIndex);
+
+                    float2 motionUvHigh = pixelUv + deltaUvLenFixed * deltaUv * c.gRectSizeInv;
+                    motionUvHigh = (floor(motionUvHigh * c.gRectSize) + 0.5f) * c.gRectSizeInv;
+
+                    if (deltaUvLenFixed > 1.0f && IsInScreenNearest(motionUvHigh) != 0.0f) {
+                        float2 uvScaled = min(motionUvHigh * c.gResolutionScale, c.gResolutionScale - 0.5f * c.gResourceSizeInv);
+                        float zHigh = UnpackViewZ(c, gIn_ViewZ.SampleNearest(uvScaled).x);
+                        float3 xHigh = Geometry::ReconstructViewPosition(motionUvHigh, c.gFrustum, zHigh, c.gOrthoMode);
+                        xHigh = Geometry::RotateVector(c.gViewToWorld, xHigh);
+                        float3 nHigh = NRD_FrontEnd_UnpackNormalAndRoughness(gIn_Normal_Roughness.SampleNearest(uvScaled)).xyz();
+
+                        float zError = fabsf(zHigh - viewZ) * rcp(max(zHigh, viewZ));
+                        bool cmp = zError < NRD_CURVATURE_Z_THRESHOLD;
+                        n = cmp ? nHigh : n;
+                        x = cmp ? xHigh : x;
+                    }
+
+                    float3 edge = x - X;
+                    float edgeLenSq = Math::LengthSquared(edge);
+                    curvature = dot(n - N, edge) * Math::PositiveRcp(edgeLenSq);
+                }
+
+                // Virtual motion - coordinates
+                float3 Xvirtual = GetXvirtual(hitDistForTracking, curvature, X, Xprev, N, V, roughness);
+                float XvirtualLength = length(Xvirtual);
+
+                float2 vmbPixelUv = Geometry::GetScreenUv(c.gWorldToClipPrev, Xvirtual);
+                vmbPixelUv = materialID == c.gCameraAttachedReflectionMaterialID ? smbPixelUv : vmbPixelUv;
+
+                float2 vmbDelta = vmbPixelUv - smbPixelUv;
+                float vmbPixelsTraveled = length(vmbDelta * c.gRectSize);
+
+                // Virtual motion - roughness (gather of the previous roughness = blue channel of the packed texel)
+                Filtering::Bilinear vmbBilinearFilter = Filtering::GetBilinearFilter(vmbPixelUv, c.gRectSizePrev);
+                int vx = (int)vmbBilinearFilter.origin.x, vy = (int)vmbBilinearFilter.origin.y;
+                float2 relaxedRoughnessWeightParams = GetRelaxedRoughnessWeightParams(roughness * roughness, c.gRoughnessFraction, REBLUR_ROUGHNESS_SENSITIVITY_IN_TA);
+                float4 vmbRoughness = float4(gPrev_Normal_Roughness.FetchClamped(vx, vy).z, gPrev_Normal_Roughness.FetchClamped(vx + 1, vy).z,
+                    gPrev_Normal_Roughness.FetchClamped(vx, vy + 1).z, gPrev_Normal_Roughness.FetchClamped(vx + 1, vy + 1).z);
+                float4 roughnessWeight;
+                for (int k = 0; k < 4; k++)
+                    roughnessWeight[k] = ComputeNonExponentialWeightWithSigma(vmbRoughness[k] * vmbRoughness[k], relaxedRoughnessWeightParams.x, relaxedRoughnessWeightParams.y, roughnessSigma);
+                float jitterFriendly = Math::SmoothStep(1.0f, 0.0f, smbParallaxInPixelsMax);
+                for (int k = 0; k < 4; k++)
+                    roughnessWeight[k] = lerp(jitterFriendly, 1.0f, roughnessWeight[k]);
+                float virtualHistoryRoughnessBasedConfidence = Filtering::ApplyBilinearFilter(roughnessWeight.x, roughnessWeight.y, roughnessWeight.z, roughnessWeight.w, vmbBilinearFilter);
+
+                // Virtual motion - normal: parallax. Stochastic nearest tap of the bilinear footprint (REBLUR_USE_STF = 1)
+                auto stochasticBilinearFetch = [&](float2 uv) {
+                    Filtering::Bilinear f = Filtering::GetBilinearFilter(uv, c.gRectSizePrev);
+                    float2 rnd = rng.GetFloat2();
+                    f.origin += step(rnd, f.weights);
+                    float2 uvs = ((f.origin + 0.5f) / c.gRectSizePrev) * c.gResolutionScalePrev;
+                    return NRD_FrontEnd_UnpackNormalAndRoughness(gPrev_Normal_Roughness.SampleNearest(uvs));
+                };
+                float4 vmbNormalAndRoughness = stochasticBilinearFetch(vmbPixelUv);
+                float3 vmbN = Geometry::RotateVector(c.gWorldPrevToWorld, vmbNormalAndRoughness.xyz());
+                float Dfactor = ImportanceSampling::GetSpecularDominantFactor(NoV, roughness);
+                float virtualHistoryNormalBasedConfidence = 1.0f / (1.0f + 0.5f * Dfactor * saturate(length(N - vmbN) - REBLUR_NORMAL_ULP) * vmbPixelsTraveled);
+
+                // Patch "smbNavg" if "smb" motion is invalid
+                smbNavg = smbFootprintQuality == 0.0f ? vmbN : smbNavg;
+
+                // Virtual motion - disocclusion: plane distance and roughness
+                float4 vmbOcclusion;
+                {
+                    float4 vmbOcclusionThreshold = float4(disocclusionThreshold * frustumSize);
+                    vmbOcclusionThreshold *= lerp(0.25f, 1.0f, NoV);
+                    vmbOcclusionThreshold *= dot(vmbN, N) > REBLUR_ALMOST_ZERO_ANGLE ? 1.0f : 0.0f;
+                    vmbOcclusionThreshold *= dot(vmbN, smbNavg) > REBLUR_ALMOST_ZERO_ANGLE ? 1.0f : 0.0f;
+                    vmbOcclusionThreshold *= IsInScreenBilinear(vmbBilinearFilter.origin, c.gRectSizePrev);
+                    vmbOcclusionThreshold -= NRD_EPS;
+
+                    float4 vmbViewZ = float4(UnpackViewZ(c, gPrev_ViewZ.FetchClamped(vx, vy).x), UnpackViewZ(c, gPrev_ViewZ.FetchClamped(vx + 1, vy).x),
+                        UnpackViewZ(c, gPrev_ViewZ.FetchClamped(vx, vy + 1).x), UnpackViewZ(c, gPrev_ViewZ.FetchClamped(vx + 1, vy + 1).x));
+                    float3 vmbVv = Geometry::ReconstructViewPosition(vmbPixelUv, c.gFrustumPrev, 1.0f);
+                    float3 vmbV = Geometry::RotateVectorInverse(c.gWorldToViewPrev, vmbVv);
+                    float NoXcurr = dot(N, Xprev - c.gCameraDelta.xyz());
+                    float4 NoXprev = (N.x * vmbV.x + N.y * vmbV.y) * (c.gOrthoMode == 0.0f ? vmbViewZ : float4(c.gOrthoMode)) + N.z * vmbV.z * vmbViewZ;
+                    float4 vmbPlaneDist = abs(NoXprev - NoXcurr);
+
+                    vmbOcclusion = step(vmbPlaneDist, vmbOcclusionThreshold);
+                    vmbOcclusion *= step(float4(0.5f), roughnessWeight);
+                }
+
+                // Virtual motion - disocclusion: materialID
+                float3 vmbInternalData00 = UnpackInternalData(gPrev_InternalData.FetchUintClamped(vx, vy));
+                float3 vmbInternalData10 = UnpackInternalData(gPrev_InternalData.FetchUintClamped(vx + 1, vy));
+                float3 vmbInternalData01 = UnpackInternalData(gPrev_InternalData.FetchUintClamped(vx, vy + 1));
+                float3 vmbInternalData11 = UnpackInternalData(gPrev_InternalData.FetchUintClamped(vx + 1, vy + 1));
+                vmbOcclusion.x *= CompareMaterials(materialID, vmbInternalData00.z, c.gSpecMinMaterial) ? 1.0f : 0.0f;
+                vmbOcclusion.y *= CompareMaterials(materialID, vmbInternalData10.z, c.gSpecMinMaterial) ? 1.0f : 0.0f;
+                vmbOcclusion.z *= CompareMaterials(materialID, vmbInternalData01.z, c.gSpecMinMaterial) ? 1.0f : 0.0f;
+                vmbOcclusion.w *= CompareMaterials(materialID, vmbInternalData11.z, c.gSpecMinMaterial) ? 1.0f : 0.0f;
+
+                fbits += vmbOcclusion.x * 16.0f;
+                fbits += vmbOcclusion.y * 32.0f;
+                fbits += vmbOcclusion.z * 64.0f;
+                fbits += vmbOcclusion.w * 128.0f;
+
+                // Virtual motion - accumulation speed
+                float4 vmbOcclusionWeights = Filtering::GetBilinearCustomWeights(vmbBilinearFilter, vmbOcclusion);
+                float vmbSpecAccumSpeed = Filtering::ApplyBilinearCustomWeights(vmbInternalData00.y, vmbInternalData10.y, vmbInternalData01.y, vmbInternalData11.y, vmbOcclusionWeights);
+
+                float vmbFootprintQuality = Filtering::ApplyBilinearFilter(vmbOcclusion.x, vmbOcclusion.y, vmbOcclusion.z, vmbOcclusion.w, vmbBilinearFilter);
+                vmbFootprintQuality = Math::Sqrt01(vmbFootprintQuality);
+                vmbSpecAccumSpeed *= lerp(vmbFootprintQuality, 1.0f, 1.0f / (1.0f + vmbSpecAccumSpeed));
+
+                bool vmbAllowCatRom = sum(vmbOcclusion) > 3.5f;
+                vmbAllowCatRom = vmbAllowCatRom && smbAllowCatRom;
+
+                // How many radians can the travelled pixels be?
+                float curvatureAngleTan = pixelSize * fabsf(curvature);
+                curvatureAngleTan *= max(vmbPixelsTraveled / max(NoV, 0.01f), 1.0f);
+                curvatureAngleTan *= 2.0f;
+                float curvatureAngle = atan(curvatureAngleTan);
+
+                float percentOfVolume = NRD_MAX_PERCENT_OF_LOBE_VOLUME / (1.0f + vmbSpecAccumSpeed);
+                float lobeTanHalfAngle = ImportanceSampling::GetSpecularLobeTanHalfAngle(roughnessModified, percentOfVolume);
+                float lobeHalfAngle = atan(lobeTanHalfAngle);
+                lobeHalfAngle = max(lobeHalfAngle, NRD_NORMAL_ENCODING_ERROR);
+
+                // Virtual motion - normal: lobe overlapping
+                float normalWeight = GetEncodingAwareNormalWeight(N, vmbN, lobeHalfAngle, curvatureAngle, REBLUR_NORMAL_ULP);
+                normalWeight = lerp(Math::SmoothStep(1.0f, 0.0f, vmbPixelsTraveled), 1.0f, normalWeight);
+                virtualHistoryNormalBasedConfidence = min(virtualHistoryNormalBasedConfidence, normalWeight);
+
+                // Virtual history amount
+                virtualHistoryAmount = Math::SmoothStep(0.05f, 0.95f, Dfactor);
+                virtualHistoryAmount *= virtualHistoryNormalBasedConfidence;
+
+                // Virtual motion - virtual parallax difference
+                float virtualHistoryParallaxBasedConfidence;
+                {
+                    float hitDistForTrackingPrev = gPrev_SpecHitDistForTracking->SampleLinearTexel(vmbPixelUv * c.gResolutionScalePrev * float2(float(gPrev_SpecHitDistForTracking->W()), float(gPrev_SpecHitDistForTracking->H()))).x;
+                    float3 XvirtualPrev = GetXvirtual(hitDistForTrackingPrev, curvature, X, Xprev, N, V, roughness);
+
+                    float2 vmbPixelUvPrev = Geometry::GetScreenUv(c.gWorldToClipPrev, XvirtualPrev);
+                    vmbPixelUvPrev = materialID == c.gCameraAttachedReflectionMaterialID ? smbPixelUv : vmbPixelUvPrev;
+
+                    float pixelSizeAtXvirtual = PixelRadiusToWorld(c.gUnproject, c.gOrthoMode, 1.0f, XvirtualLength);
+                    float r = (lobeTanHalfAngle + curvatureAngle) * min(hitDistForTracking, hitDistForTrackingPrev) / pixelSizeAtXvirtual;
+                    float d = length((vmbPixelUvPrev - vmbPixelUv) * c.gRectSize);
+
+                    r = max(r, 0.1f);
+                    virtualHistoryParallaxBasedConfidence = Math::LinearStep(r, 0.0f, d);
+                }
+
+                // Virtual motion - normal & roughness prev-prev tests (1 iteration)
+                float stepBetweenTaps = min(vmbPixelsTraveled * c.gFramerateScale, 2.0f) + vmbPixelsTraveled / 1.0f;
+                vmbDelta *= Math::Rsqrt(Math::LengthSquared(vmbDelta));
+                vmbDelta = vmbDelta / c.gRectSizePrev;
+
+                relaxedRoughnessWeightParams = GetRelaxedRoughnessWeightParams(vmbNormalAndRoughness.w * vmbNormalAndRoughness.w, c.gRoughnessFraction, REBLUR_ROUGHNESS_SENSITIVITY_IN_TA);
+                {
+                    const float i = 1.0f;
+                    float2 vmbPixelUvPrev = vmbPixelUv + vmbDelta * i * stepBetweenTaps;
+                    float4 vmbNormalAndRoughnessPrev = stochasticBilinearFetch(vmbPixelUvPrev);
+
+                    float2 w;
+                    w.x = GetEncodingAwareNormalWeight(vmbNormalAndRoughness.xyz(), vmbNormalAndRoughnessPrev.xyz(), lobeHalfAngle, curvatureAngle * (1.0f + i * stepBetweenTaps), REBLUR_NORMAL_ULP);
+                    w.y = ComputeNonExponentialWeightWithSigma(vmbNormalAndRoughnessPrev.w * vmbNormalAndRoughnessPrev.w, relaxedRoughnessWeightParams.x, relaxedRoughnessWeightParams.y, roughnessSigma);
+                    w = lerp(float2(1.0f), w, saturate(stepBetweenTaps)); // cures "StochasticBilinear" issues
+                    w = IsInScreenNearest(vmbPixelUvPrev) != 0.0f ? w : float2(1.0f);
+
+                    virtualHistoryNormalBasedConfidence = min(virtualHistoryNormalBasedConfidence, w.x);
+                    virtualHistoryRoughnessBasedConfidence = min(virtualHistoryRoughnessBasedConfidence, w.y);
+                }
+
+                // Virtual history confidence
+                float virtualHistoryConfidenceForSmbRelaxation = virtualHistoryNormalBasedConfidence * virtualHistoryRoughnessBasedConfidence;
+                float virtualHistoryConfidence = virtualHistoryNormalBasedConfidence * virtualHistoryRoughnessBasedConfidence * virtualHistoryParallaxBasedConfidence;
+                virtualHistoryAmount *= virtualHistoryRoughnessBasedConfidence;
+
+                // Sample surface history
+                HistoryFilter smbFilter = MakeHistoryFilter(smbSamplePos, smbOcclusionWeights, smbAllowCatRom);
+                float4 smbSpecHistory = FetchHistoryColor(smbFilter, *gHistory_Spec);
+                float smbSpecFastHistory = FetchHistoryBilinear(smbFilter, *gHistory_SpecFast).x;
+
+                // Surface motion confidence
+                float surfaceHistoryConfidence;
+                {
+                    float a = atan(smbParallaxInPixelsMax * pixelSize / length(X));
+                    float nonLinearAccumSpeed = 1.0f / (1.0f + smbSpecAccumSpeed);
+                    float h = lerp(smbSpecHistory.w, spec.w, nonLinearAccumSpeed) * hitDistNormalization;
+
+                    float tana0 = ImportanceSampling::GetSpecularLobeTanHalfAngle(roughnessModified, NRD_MAX_PERCENT_OF_LOBE_VOLUME);
+                    tana0 *= lerp(NoV, 1.0f, roughnessModified);
+                    tana0 *= nonLinearAccumSpeed;
+                    tana0 /= GetHitDistFactor(h, frustumSize) + NRD_EPS;
+
+                    float a0 = atan(tana0);
+                    a0 = max(a0, NRD_NORMAL_ENCODING_ERROR);
+
+                    float f = Math::LinearStep(a0, 0.0f, a);
+                    surfaceHistoryConfidence = Math::Pow01(f, 4.0f);
+                }
+
+                // Responsive accumulation
+                float2 maxResponsiveFrameNum;
+                {
+                    float responsiveFactor = RemapRoughnessToResponsiveFactor(c, roughness);
+                    float smc = GetSpecMagicCurve(roughnessModified);
+                    float2 f = float2(dot(N, normalize(smbNavg)), dot(N, vmbN));
+                    float e = lerp(32.0f, 1.0f, smc) * (1.0f - responsiveFactor);
+                    f = lerp(smc, 1.0f, responsiveFactor) * float2(Math::Pow01(f.x, e), Math::Pow01(f.y, e));
+                    maxResponsiveFrameNum = max(c.gMaxAccumulatedFrameNum * f, float2(c.gHistoryFixFrameNum));
+                }
+
+                // Surface motion: max allowed frames
+                float smbMaxFrameNum = c.gMaxAccumulatedFrameNum;
+                smbMaxFrameNum *= surfaceHistoryConfidence;
+                smbMaxFrameNum = min(smbMaxFrameNum, maxResponsiveFrameNum.x);
+
+                float smbBoostedMaxFrameNum = max(smbMaxFrameNum, c.gHistoryFixFrameNum * (1.0f - virtualHistoryConfidenceForSmbRelaxation));
+                float smbSpecAccumSpeedBoosted = min(smbSpecAccumSpeed, smbBoostedMaxFrameNum);
+
+                // Virtual motion: max allowed frames
+                float vmbMaxFrameNum = c.gMaxAccumulatedFrameNum;
+                vmbMaxFrameNum *= virtualHistoryConfidence;
+                vmbMaxFrameNum = min(vmbMaxFrameNum, maxResponsiveFrameNum.y);
+
+                smbSpecAccumSpeed = min(smbSpecAccumSpeed, smbMaxFrameNum);
+                vmbSpecAccumSpeed = min(vmbSpecAccumSpeed, vmbMaxFrameNum);
+
+                // Fallback to "smb" if "vmb" history is short (works in both directions)
+                float magic = vmbSpecAccumSpeed > smbSpecAccumSpeed ? 8.0f : 0.5f;
+                virtualHistoryAmount *= 1.0f + (vmbSpecAccumSpeed - smbSpecAccumSpeed) / (magic * max(vmbSpecAccumSpeed, smbSpecAccumSpeed) + 1.0f);
+                virtualHistoryAmount = saturate(virtualHistoryAmount);
+
+                // Sample virtual history
+                HistoryFilter vmbFilter = MakeHistoryFilter(saturate(vmbPixelUv) * c.gRectSizePrev, vmbOcclusionWeights, vmbAllowCatRom);
+                float4 vmbSpecHistory = FetchHistoryColor(vmbFilter, *gHistory_Spec);
+                float vmbSpecFastHistory = FetchHistoryBilinear(vmbFilter, *gHistory_SpecFast).x;
+
+                smbSpecHistory = ClampNegativeToZero(smbSpecHistory);
+                vmbSpecHistory = ClampNegativeToZero(vmbSpecHistory);
+
+                // Accumulation
+                float smbSpecNonLinearAccumSpeed = 1.0f / (1.0f + smbSpecAccumSpeed);
+                float vmbSpecNonLinearAccumSpeed = 1.0f / (1.0f + vmbSpecAccumSpeed);
+
+                float4 smbSpec = MixHistoryAndCurrent(c, smbSpecHistory, spec, smbSpecNonLinearAccumSpeed, roughnessModified);
+                float4 vmbSpec = MixHistoryAndCurrent(c, vmbSpecHistory, spec, vmbSpecNonLinearAccumSpeed, roughnessModified);
+                float4 specResult = lerp(smbSpec, vmbSpec, virtualHistoryAmount);
+
+                specAccumSpeed = lerp(smbSpecAccumSpeedBoosted, vmbSpecAccumSpeed, virtualHistoryAmount);
+                float4 specHistory = lerp(smbSpecHistory, vmbSpecHistory, virtualHistoryAmount);
+
+                // Firefly suppressor
+                float specMaxRelativeIntensity = c.gFireflySuppressorMinRelativeScale + REBLUR_FIREFLY_SUPPRESSOR_MAX_RELATIVE_INTENSITY / (specAccumSpeed + 1.0f);
+                float specAntifireflyFactor = specAccumSpeed * c.gMaxBlurRadius * REBLUR_FIREFLY_SUPPRESSOR_RADIUS_SCALE;
+                specAntifireflyFactor /= 1.0f + specAntifireflyFactor;
+
+                float specLumaResult = GetLuma(specResult);
+                float specLumaClamped = min(specLumaResult, GetLuma(specHistory) * specMaxRelativeIntensity);
+                specLumaClamped = lerp(specLumaResult, specLumaClamped, specAntifireflyFactor);
+                specResult = ChangeLuma(specResult, specLumaClamped);
+
+                gOut_Spec->Store(px, py, specResult);
+
+                // Fast history
+                float smbSpecFastNonLinearAccumSpeed = GetNonLinearAccumSpeed(smbSpecAccumSpeed, c.gMaxFastAccumulatedFrameNum, surfaceHistoryConfidence);
+                float vmbSpecFastNonLinearAccumSpeed = GetNonLinearAccumSpeed(vmbSpecAccumSpeed, c.gMaxFastAccumulatedFrameNum, virtualHistoryConfidence);
+                float smbSpecFast = lerp(smbSpecFastHistory, GetLuma(spec), smbSpecFastNonLinearAccumSpeed);
+                float vmbSpecFast = lerp(vmbSpecFastHistory, GetLuma(spec), vmbSpecFastNonLinearAccumSpeed);
+                float specFastResult = lerp(smbSpecFast, vmbSpecFast, virtualHistoryAmount);
+
+                float specFastClamped = min(specFastResult, GetLuma(specHistory) * specMaxRelativeIntensity * REBLUR_FIREFLY_SUPPRESSOR_FAST_RELATIVE_INTENSITY);
+                specFastResult = lerp(specFastResult, specFastClamped, specAntifireflyFactor);
+                gOut_SpecFast->Store(px, py, specFastResult);
+            }
+
+            // Output: 4+4 occlusion bits, curvature, virtual history amount (R32_UINT, or the low byte only in R8_UINT)
+            gOut_Data2.StoreUint(px, py, PackData2(fbits, curvature, virtualHistoryAmount));
+
+            // ---------------------------------------------------------------------------------------------- diffuse
+            if (DIFF) {
+                float diffHistoryConfidence = smbFootprintQuality;
+                diffAccumSpeed *= lerp(diffHistoryConfidence, 1.0f, 1.0f / (1.0f + diffAccumSpeed));
+                diffAccumSpeed = min(diffAccumSpeed, c.gMaxAccumulatedFrameNum);
+
+                float4 diff = gIn_Diff->Load(px, py);
+
+                HistoryFilter smbFilter = MakeHistoryFilter(smbSamplePos, smbOcclusionWeights, smbAllowCatRom);
+                float4 smbDiffHistory = FetchHistoryColor(smbFilter, *gHistory_Diff);
+                float smbDiffFastHistory = FetchHistoryBilinear(smbFilter, *gHistory_DiffFast).x;
+                smbDiffHistory = ClampNegativeToZero(smbDiffHistory);
+
+                float diffNonLinearAccumSpeed = 1.0f / (1.0f + diffAccumSpeed);
+                float4 diffResult = MixHistoryAndCurrent(c, smbDiffHistory, diff, diffNonLinearAccumSpeed);
+
+                // Firefly suppressor
+                float diffMaxRelativeIntensity = c.gFireflySuppressorMinRelativeScale + REBLUR_FIREFLY_SUPPRESSOR_MAX_RELATIVE_INTENSITY / (diffAccumSpeed + 1.0f);
+                float diffAntifireflyFactor = diffAccumSpeed * c.gMaxBlurRadius * REBLUR_FIREFLY_SUPPRESSOR_RADIUS_SCALE;
+                diffAntifireflyFactor /= 1.0f + diffAntifireflyFactor;
+
+                float diffLumaResult = GetLuma(diffResult);
+                float diffLumaClamped = min(diffLumaResult, GetLuma(smbDiffHistory) * diffMaxRelativeIntensity);
+                diffLumaClamped = lerp(diffLumaResult, diffLumaClamped, diffAntifireflyFactor);
+                diffResult = ChangeLuma(diffResult, diffLumaClamped);
+                gOut_Diff->Store(px, py, diffResult);
+
+                // Fast history
+                float diffFastAccumSpeed = min(diffAccumSpeed, c.gMaxFastAccumulatedFrameNum);
+                float diffFastNonLinearAccumSpeed = 1.0f / (1.0f + diffFastAccumSpeed);
+                float diffFastResult = lerp(smbDiffFastHistory, GetLuma(diff), diffFastNonLinearAccumSpeed);
+                float diffFastClamped = min(diffFastResult, GetLuma(smbDiffHistory) * diffMaxRelativeIntensity * REBLUR_FIREFLY_SUPPRESSOR_FAST_RELATIVE_INTENSITY);
+                diffFastResult = lerp(diffFastResult, diffFastClamped, diffAntifireflyFactor);
+                gOut_DiffFast->Store(px, py, diffFastResult);
+            }
+
+            float2 d1 = PackData1(diffAccumSpeed, specAccumSpeed, DIFF);
+            gOut_Data1.Store(px, py, float4(d1.x, d1.y, 0.0f, 0.0f));
+        }
+}
+
+// ================================================================================================ HistoryFix
+// one signal (diffuse or specular) of the history-fix pass; returns the fixed signal and writes the fast history
+float4 HistoryFixSignal(const ReblurCB& c, bool isSpec, int px, int py, float4 sig, float frameNum, float strideBase, float roughness, float viewZ, float materialID,
+    float3 N, float3 Nv, float3 Xv, float2 pixelUv, float frustumSize, const Tex& gIn_ViewZ, const Tex& gIn_Normal_Roughness, const Tex& gIn_Data1, bool hasDiff,
+    const Tex& gIn_Signal, const Tex& gIn_Fast, Tex& gOut_Fast) {
+    const int rw = c.gRectSizeMinusOne[0], rh = c.gRectSizeMinusOne[1];
+    float smc = GetSpecMagicCurve(roughness);
+
+    // Stride between taps
+    float stride = strideBase * (frameNum < c.gHistoryFixFrameNum ? 1.0f : 0.0f);
+    if (isSpec)
+        stride *= lerp(0.5f, 1.0f, smc);
+    stride = floorf(stride);
+
+    // History reconstruction: 5x5 minus centre minus corners, sparse
+    if (stride != 0.0f) {
+        int stridei = (int)(stride + 0.5f);
+        float nonLinearAccumSpeed = 1.0f / (1.0f + frameNum);
+        float r = isSpec ? roughness : 1.0f;
+
+        float normalWeightParam = GetNormalWeightParam(nonLinearAccumSpeed, c.gLobeAngleFraction, r);
+        float2 geometryWeightParams = GetGeometryWeightParams(c.gPlaneDistSensitivity, frustumSize, Xv, Nv);
+        float2 relaxedRoughnessWeightParams = GetRelaxedRoughnessWeightParams(roughness * roughness, sqrtf(c.gRoughnessFraction));
+
+        float hitDistScale = _REBLUR_GetHitDistanceNormalization(viewZ, c.gHitDistParams, r);
+        float hitDist = sig.w * hitDistScale;
+        float hitDistFactor = GetHitDistFactor(hitDist, frustumSize);
+        float2 hitDistanceWeightParams = GetHitDistanceWeightParams(hitDistFactor, nonLinearAccumSpeed, r);
+
+        float sumw = 1.0f + frameNum;
+        sig *= sumw;
+
+        for (int j = -2; j <= 2; j++)
+            for (int i = -2; i <= 2; i++) {
+                if ((i == 0 && j == 0) || (::abs(i) + ::abs(j) == 4))
+                    continue;
+
+                float2 uv = pixelUv + float2(float(i), float(j)) * stride * c.gRectSizeInv;
+                int sx = clamp(px + i * stridei, 0, rw), sy = clamp(py + j * stridei, 0, rh);
+
+                float zs = UnpackViewZ(c, gIn_ViewZ.Load(sx, sy).x);
+                float materialIDs;
+                float4 Ns = NRD_FrontEnd_UnpackNormalAndRoughness(gIn_Normal_Roughness.Load(sx, sy), materialIDs);
+
+                float angle = Math::AcosApprox(dot(Ns.xyz(), N));
+                float3 Xvs = Geometry::ReconstructViewPosition(uv, c.gFrustum, zs, c.gOrthoMode);
+
+                float w = IsInScreenNearest(uv);
+                w *= ComputeWeight(dot(Nv, Xvs), geometryWeightParams.x, geometryWeightParams.y);
+                w *= CompareMaterials(materialID, materialIDs, isSpec ? c.gSpecMinMaterial : c.gDiffMinMaterial) ? 1.0f : 0.0f;
+                w *= ComputeExponentialWeight(angle, normalWeightParam, 0.0f);
+                if (isSpec)
+                    w *= ComputeExponentialWeight(Ns.w * Ns.w, relaxedRoughnessWeightParams.x, relaxedRoughnessWeightParams.y);
+
+                float2 d1 = UnpackData1(gIn_Data1.Load(sx, sy), hasDiff);
+                w *= 1.0f + (isSpec ? d1.y : d1.x);
+
+                float4 smp = gIn_Signal.Load(sx, sy);
+                smp = w == 0.0f ? float4(0.0f) : smp;
+
+                float hs = smp.w * hitDistScale;
+                float hsFactor = GetHitDistFactor(hs, frustumSize);
+                w *= ComputeExponentialWeight(hsFactor, hitDistanceWeightParams.x, hitDistanceWeightParams.y);
+
+                if (isSpec) { // low roughness: hit distances work as a non-noisy guide
+                    float d = fabsf(hitDist - hs) / (max(hitDist, hs) + 0.001f);
+                    float b = Math::LinearStep(0.03f, 0.05f, roughness);
+                    w *= Math::SmoothStep(0.2f + b, 0.05f + b, d);
+                }
+
+                sumw += w;
+                sig += smp * w;
+            }
+
+        sumw = Math::PositiveRcp(sumw);
+        sig *= sumw;
+    }
+
+    // Local variance of the fast history over 5x5 (clamped reads = the shader's LDS preload)
+    auto sLuma = [&](int x, int y) { return gIn_Fast.Load(clamp(x, 0, rw), clamp(y, 0, rh)).x; };
+    float center = sLuma(px, py);
+    float m1 = center, m2 = center * center;
+
+    float f = saturate(frameNum / (c.gHistoryFixFrameNum + NRD_EPS));
+    if (isSpec)
+        f = lerp(1.0f, f, smc);
+    center = lerp(GetLuma(sig), center, f);
+    gOut_Fast.Store(px, py, center);
+
+    for (int j = 0; j <= 4; j++)
+        for (int i = 0; i <= 4; i++) {
+            if (i == 2 && j == 2)
+                continue;
+            float d = sLuma(px - 2 + i, py - 2 + j);
+            m1 += d;
+            m2 += d * d;
+        }
+
+    float luma = GetLuma(sig);
+
+    // Anti-firefly: 9x9 minus the central 3x3
+    if (c.gAntiFirefly != 0.0f) {
+        float am1 = 0.0f, am2 = 0.0f;
+        const int R = REBLUR_ANTI_FIREFLY_FILTER_RADIUS;
+        for (int j = -R; j <= R; j++)
+            for (int i = -R; i <= R; i++) {
+                if (::abs(i) <= 1 && ::abs(j) <= 1)
+                    continue;
+                float d = gIn_Fast.Load(clamp(px + i, 0, rw), clamp(py + j, 0, rh)).x;
+                am1 += d;
+                am2 += d * d;
+            }
+        float invNorm = 1.0f / float((R * 2 + 1) * (R * 2 + 1) - 3 * 3);
+        am1 *= invNorm;
+        am2 *= invNorm;
+        float sigma = sqrtf(fabsf(am2 - am1 * am1)) * REBLUR_ANTI_FIREFLY_SIGMA_SCALE;
+        luma = clamp(luma, am1 - sigma, am1 + sigma);
+    }
+
+    // Fast-history clamping
+    m1 /= 25.0f;
+    m2 /= 25.0f;
+    float sigma = sqrtf(fabsf(m2 - m1 * m1)) * REBLUR_COLOR_CLAMPING_SIGMA_SCALE;
+    float lumaClamped = clamp(luma, m1 - sigma, m1 + sigma);
+    luma = lerp(lumaClamped, luma, 1.0f / (1.0f + (c.gMaxFastAccumulatedFrameNum < c.gMaxAccumulatedFrameNum ? 1.0f : 0.0f) * frameNum * 2.0f));
+
+    return ChangeLuma(sig, luma);
+}
+
+template <bool DIFF, bool SPEC>
+void HistoryFix(const PassIO& io) {
+    const ReblurCB& c = *(const ReblurCB*)io.constants;
+    Cursor cur(io);
+    const Tex& gIn_Tiles = *cur.next();
+    const Tex& gIn_Normal_Roughness = *cur.next();
+    const Tex& gIn_Data1 = *cur.next();
+    const Tex& gIn_ViewZ = *cur.next();
+    const Tex* gIn_Diff = cur.nextIf(DIFF);
+    const Tex* gIn_Spec = cur.nextIf(SPEC);
+    const Tex* gIn_DiffFast = cur.nextIf(DIFF);
+    const Tex* gIn_SpecFast = cur.nextIf(SPEC);
+    Tex* gOut_Diff = cur.nextIf(DIFF);
+    Tex* gOut_Spec = cur.nextIf(SPEC);
+    Tex* gOut_DiffFast = cur.nextIf(DIFF);
+    Tex* gOut_SpecFast = cur.nextIf(SPEC);
+
+#pragma omp parallel for schedule(dynamic, 4)
+    for (int py = 0; py <= c.gRectSizeMinusOne[1]; py++)
+        for (int px = 0; px <= c.gRectSizeMinusOne[0]; px++) {
+            float isSky = gIn_Tiles.Load(px >> 4, py >> 4).x;
+            if (isSky != 0.0f)
+                continue;
+            float viewZ = UnpackViewZ(c, gIn_ViewZ.Load(px, py).x);
+            if (viewZ > c.gDenoisingRange)
+                continue;
+
+            float materialID;
+            float4 normalAndRoughness = NRD_FrontEnd_UnpackNormalAndRoughness(gIn_Normal_Roughness.Load(px, py), materialID);
+            float3 N = normalAndRoughness.xyz();
+            float roughness = normalAndRoughness.w;
+
+            float frustumSize = GetFrustumSize(c.gMinRectDimMulUnproject, c.gOrthoMode, viewZ);
+            float2 pixelUv = float2(float(px) + 0.5f, float(py) + 0.5f) * c.gRectSizeInv;
+            float3 Xv = Geometry::ReconstructViewPosition(pixelUv, c.gFrustum, viewZ, c.gOrthoMode);
+            float3 Nv = Geometry::RotateVectorInverse(c.gViewToWorld, N);
+            float2 frameNum = UnpackData1(gIn_Data1.Load(px, py), DIFF);
+            float2 stride = c.gHistoryFixBasePixelStride / (2.0f + frameNum);
+
+            if (DIFF) {
+                float4 diff = HistoryFixSignal(c, false, px, py, gIn_Diff->Load(px, py), frameNum.x, stride.x, roughness, viewZ, materialID, N, Nv, Xv, pixelUv, frustumSize,
+                    gIn_ViewZ, gIn_Normal_Roughness, gIn_Data1, DIFF, *gIn_Diff, *gIn_DiffFast, *gOut_DiffFast);
+                if (getenv("ORACLE_DEBUG_PIXEL") && px == atoi(getenv("ORACLE_DEBUG_PIXEL")) && py == atoi(strchr(getenv("ORACLE_DEBUG_PIXEL"), ',') + 1))
+                    fprintf(stderr, "HF diff (%d,%d): %.9g %.9g %.9g %.9g framenum %g\n", px, py, diff.x, diff.y, diff.z, diff.w, frameNum.x);
+                gOut_Diff->Store(px, py, diff);
+            }
+            if (SPEC) {
+                float4 spec = HistoryFixSignal(c, true, px, py, gIn_Spec->Load(px, py), frameNum.y, stride.y, roughness, viewZ, materialID, N, Nv, Xv, pixelUv, frustumSize,
+                    gIn_ViewZ, gIn_Normal_Roughness, gIn_Data1, DIFF, *gIn_Spec, *gIn_SpecFast, *gOut_SpecFast);
+                gOut_Spec->Store(px, py, spec);
+            }
+        }
+}
+
+// ================================================================================================ TemporalStabilization
+template <bool DIFF, bool SPEC>
+void TemporalStabilization(const PassIO& io) {
+    const ReblurCB& c = *(const ReblurCB*)io.constants;
+    Cursor cur(io);
+    const Tex& gIn_Tiles = *cur.next();
+    const Tex& gIn_Normal_Roughness = *cur.next();
+    cur.nextIf(SPEC); // gIn_BaseColor_Metalness (dummy: MV modification is off without base colour)
+    const Tex& gIn_ViewZ = *cur.next(); // PREV_VIEWZ (already holds this frame's viewZ)
+    const Tex& gIn_Data1 = *cur.next();
+    const Tex& gIn_Data2 = *cur.next();
+    const Tex* gIn_Diff = cur.nextIf(DIFF);
+    const Tex* gIn_Spec = cur.nextIf(SPEC);
+    const Tex* gHistory_DiffLumaStabilized = cur.nextIf(DIFF);
+    const Tex* gHistory_SpecLumaStabilized = cur.nextIf(SPEC);
+    const Tex* gIn_SpecHitDistForTracking = cur.nextIf(SPEC);
+    const Tex& gInOut_Mv = *cur.next();
+    Tex& gOut_InternalData = *cur.next();
+    Tex* gOut_Diff = cur.nextIf(DIFF);
+    Tex* gOut_Spec = cur.nextIf(SPEC);
+    Tex* gOut_DiffLumaStabilized = cur.nextIf(DIFF);
+    Tex* gOut_SpecLumaStabilized = cur.nextIf(SPEC);
+
+    const int rw = c.gRectSizeMinusOne[0], rh = c.gRectSizeMinusOne[1];
+
+#pragma omp parallel for schedule(dynamic, 4)
+    for (int py = 0; py <= rh; py++)
+        for (int px = 0; px <= rw; px++) {
+            float isSky = gIn_Tiles.Load(px >> 4, py >> 4).x;
+            if (isSky != 0.0f)
+                continue;
+            float viewZ = UnpackViewZ(c, gIn_ViewZ.Load(px, py).x);
+            if (viewZ > c.gDenoisingRange)
+                continue;
+
+            // Position
+            float2 pixelUv = float2(float(px) + 0.5f, float(py) + 0.5f) * c.gRectSizeInv;
+            float3 Xv = Geometry::ReconstructViewPosition(pixelUv, c.gFrustum, viewZ, c.gOrthoMode);
+            float3 X = Geometry::RotateVector(c.gViewToWorld, Xv);
+
+            // Previous position and surface motion uv
+            float4 inMv = gInOut_Mv.Load(px, py);
+            float3 mv = float3(inMv.x, inMv.y, inMv.z) * c.gMvScale.xyz();
+            float3 Xprev = X;
+            float2 smbPixelUv = pixelUv + float2(mv.x, mv.y);
+            if (c.gMvScale.w == 0.0f) {
+                if (c.gMvScale.z == 0.0f)
+                    mv.z = Geometry::AffineTransform(c.gWorldToViewPrev, X).z - viewZ;
+                float viewZprev = viewZ + mv.z;
+                float3 Xvprevlocal = Geometry::ReconstructViewPosition(smbPixelUv, c.gFrustumPrev, viewZprev, c.gOrthoMode);
+                Xprev = Geometry::RotateVectorInverse(c.gWorldToViewPrev, Xvprevlocal) + c.gCameraDelta.xyz();
+            } else {
+                Xprev += mv;
+                smbPixelUv = Geometry::GetScreenUv(c.gWorldToClipPrev, Xprev);
+            }
+
+            float materialID;
+            float4 normalAndRoughness = NRD_FrontEnd_UnpackNormalAndRoughness(gIn_Normal_Roughness.Load(px, py), materialID);
+            float3 N = normalAndRoughness.xyz();
+            float roughness = normalAndRoughness.w;
+
+            uint32_t bits;
+            float2 data1 = UnpackData1(gIn_Data1.Load(px, py), DIFF);
+            float2 data2 = UnpackData2(gIn_Data2.LoadUint(px, py), bits);
+
+            // Surface motion footprint
+            Filtering::Bilinear smbBilinearFilter = Filtering::GetBilinearFilter(smbPixelUv, c.gRectSizePrev);
+            float4 smbOcclusion = float4((bits & 1u) ? 1.0f : 0.0f, (bits & 2u) ? 1.0f : 0.0f, (bits & 4u) ? 1.0f : 0.0f, (bits & 8u) ? 1.0f : 0.0f);
+            float4 smbOcclusionWeights = Filtering::GetBilinearCustomWeights(smbBilinearFilter, smbOcclusion);
+            bool smbAllowCatRom = sum(smbOcclusion) > 3.5f;
+            float smbFootprintQuality = Filtering::ApplyBilinearFilter(smbOcclusion.x, smbOcclusion.y, smbOcclusion.z, smbOcclusion.w, smbBilinearFilter);
+            smbFootprintQuality = Math::Sqrt01(smbFootprintQuality);
+
+            const float2 smbSamplePos = saturate(smbPixelUv) * c.gRectSizePrev;
+
+            // 3x3 luma statistics (clamped reads = LDS preload)
+            auto stats = [&](const Tex& tex, float& luma, float& m1, float& sigma) {
+                auto sL = [&](int x, int y) { return GetLuma(tex.Load(clamp(x, 0, rw), clamp(y, 0, rh))); };
+                luma = sL(px, py);
+                float M1 = luma, M2 = luma * luma, mn = NRD_INF, mx = -NRD_INF;
+                for (int j = 0; j <= 2; j++)
+                    for (int i = 0; i <= 2; i++) {
+                        if (i == 1 && j == 1)
+                            continue;
+                        float d = sL(px - 1 + i, py - 1 + j);
+                        M1 += d;
+                        M2 += d * d;
+                        mn = min(mn, d);
+                        mx = max(mx, d);
+                    }
+                M1 /= 9.0f;
+                M2 /= 9.0f;
+                m1 = M1;
+                sigma = sqrtf(fabsf(M2 - M1 * M1));
+                if (c.gMaxBlurRadius != 0.0f) // RCRS
+                    luma = clamp(luma, mn, mx);
+            };
+
+            if (DIFF) {
+                float diffLuma, diffLumaM1, diffLumaSigma;
+                stats(*gIn_Diff, diffLuma, diffLumaM1, diffLumaSigma);
+
+                HistoryFilter smbFilter = MakeHistoryFilter(smbSamplePos, smbOcclusionWeights, smbAllowCatRom);
+                float smbDiffLumaHistory = FetchHistoryColor(smbFilter, *gHistory_DiffLumaStabilized).x;
+                smbDiffLumaHistory = max(smbDiffLumaHistory, 0.0f);
+
+                float diffAntilag = ComputeAntilag(c, smbDiffLumaHistory, diffLumaM1, diffLumaSigma, smbFootprintQuality * data1.x);
+
+                float2 diffTemporalAccumulationParams = GetTemporalAccumulationParams(c, smbFootprintQuality, data1.x);
+                float diffHistoryWeight = diffTemporalAccumulationParams.x;
+                diffHistoryWeight *= diffAntilag;
+                diffHistoryWeight *= pixelUv.x >= c.gSplitScreen ? 1.0f : 0.0f;
+                diffHistoryWeight *= smbPixelUv.x >= c.gSplitScreenPrev ? 1.0f : 0.0f;
+
+                smbDiffLumaHistory = Color::Clamp(diffLumaM1, diffLumaSigma * diffTemporalAccumulationParams.y, smbDiffLumaHistory);
+                float diffLumaStabilized = lerp(diffLuma, smbDiffLumaHistory, min(diffHistoryWeight, c.gStabilizationStrength));
+
+                float4 diff = gIn_Diff->Load(px, py);
+                diff = ChangeLuma(diff, diffLumaStabilized);
+                gOut_Diff->Store(px, py, diff);
+                gOut_DiffLumaStabilized->Store(px, py, diffLumaStabilized);
+
+                data1.x += 1.0f;
+                float diffMinAccumSpeed = min(data1.x, c.gHistoryFixFrameNum);
+                data1.x = lerp(diffMinAccumSpeed, data1.x, diffAntilag);
+            }
+
+            if (SPEC) {
+                float specLuma, specLumaM1, specLumaSigma;
+                stats(*gIn_Spec, specLuma, specLumaM1, specLumaSigma);
+
+                float virtualHistoryAmount = data2.x;
+                float curvature = data2.y;
+
+                float4 spec = gIn_Spec->Load(px, py);
+                float hitDistForTracking = spec.w * _REBLUR_GetHitDistanceNormalization(viewZ, c.gHitDistParams, roughness);
+                if (c.gSpecPrepassBlurRadius != 0.0f)
+                    hitDistForTracking = min(hitDistForTracking, gIn_SpecHitDistForTracking->Load(px, py).x);
+
+                // Virtual motion
+                float3 V = GetViewVector(c, X);
+                float3 Xvirtual = GetXvirtual(hitDistForTracking, curvature, X, Xprev, N, V, roughness);
+                float2 vmbPixelUv = Geometry::GetScreenUv(c.gWorldToClipPrev, Xvirtual);
+                vmbPixelUv = materialID == c.gCameraAttachedReflectionMaterialID ? pixelUv : vmbPixelUv;
+
+                // (MV modification needs IN_BASECOLOR_METALNESS: gSpecProbabilityThresholdsForMvModification.x = 2 disables it)
+
+                HistoryFilter smbFilter = MakeHistoryFilter(smbSamplePos, smbOcclusionWeights, smbAllowCatRom);
+                float smbSpecLumaHistory = FetchHistoryColor(smbFilter, *gHistory_SpecLumaStabilized).x;
+
+                // Virtual motion footprint
+                Filtering::Bilinear vmbBilinearFilter = Filtering::GetBilinearFilter(vmbPixelUv, c.gRectSizePrev);
+                float4 vmbOcclusion = float4((bits & 16u) ? 1.0f : 0.0f, (bits & 32u) ? 1.0f : 0.0f, (bits & 64u) ? 1.0f : 0.0f, (bits & 128u) ? 1.0f : 0.0f);
+                float4 vmbOcclusionWeights = Filtering::GetBilinearCustomWeights(vmbBilinearFilter, vmbOcclusion);
+                bool vmbAllowCatRom = sum(vmbOcclusion) > 3.5f;
+                float vmbFootprintQuality = Filtering::ApplyBilinearFilter(vmbOcclusion.x, vmbOcclusion.y, vmbOcclusion.z, vmbOcclusion.w, vmbBilinearFilter);
+                vmbFootprintQuality = Math::Sqrt01(vmbFootprintQuality);
+
+                HistoryFilter vmbFilter = MakeHistoryFilter(saturate(vmbPixelUv) * c.gRectSizePrev, vmbOcclusionWeights, vmbAllowCatRom);
+                float vmbSpecLumaHistory = FetchHistoryColor(vmbFilter, *gHistory_SpecLumaStabilized).x;
+
+                smbSpecLumaHistory = max(smbSpecLumaHistory, 0.0f);
+                vmbSpecLumaHistory = max(vmbSpecLumaHistory, 0.0f);
+
+                float specLumaHistory = lerp(smbSpecLumaHistory, vmbSpecLumaHistory, virtualHistoryAmount);
+
+                float footprintQuality = lerp(smbFootprintQuality, vmbFootprintQuality, virtualHistoryAmount);
+                float specAntilag = ComputeAntilag(c, specLumaHistory, specLumaM1, specLumaSigma, footprintQuality * data1.y);
+
+                float2 specTemporalAccumulationParams = GetTemporalAccumulationParams(c, footprintQuality, data1.y);
+                float specHistoryWeight = specTemporalAccumulationParams.x;
+                specHistoryWeight *= specAntilag;
+                specHistoryWeight *= pixelUv.x >= c.gSplitScreen ? 1.0f : 0.0f;
+                specHistoryWeight *= virtualHistoryAmount != 1.0f ? (smbPixelUv.x >= c.gSplitScreenPrev ? 1.0f : 0.0f) : 1.0f;
+                specHistoryWeight *= virtualHistoryAmount != 0.0f ? (vmbPixelUv.x >= c.gSplitScreenPrev ? 1.0f : 0.0f) : 1.0f;
+
+                float responsiveFactor = RemapRoughnessToResponsiveFactor(c, roughness);
+                float smc = GetSpecMagicCurve(roughness);
+                float acceleration = lerp(smc, 1.0f, 0.5f + responsiveFactor * 0.5f);
+                specHistoryWeight *= materialID == c.gStrandMaterialID ? 0.5f : acceleration;
+
+                specLumaHistory = Color::Clamp(specLumaM1, specLumaSigma * specTemporalAccumulationParams.y, specLumaHistory);
+                float specLumaStabilized = lerp(specLuma, specLumaHistory, min(specHistoryWeight, c.gStabilizationStrength));
+
+                spec = ChangeLuma(spec, specLumaStabilized);
+                gOut_Spec->Store(px, py, spec);
+                gOut_SpecLumaStabilized->Store(px, py, specLumaStabilized);
+
+                data1.y += 1.0f;
+                float specMinAccumSpeed = min(data1.y, c.gHistoryFixFrameNum);
+                data1.y = lerp(specMinAccumSpeed, data1.y, specAntilag);
+            }
+
+            gOut_InternalData.StoreUint(px, py, PackInternalData(data1.x, data1.y, materialID));
+        }
+}
+
+// ================================================================================================ SplitScreen
+template <bool DIFF, bool SPEC>
+void SplitScreen(const PassIO& io) {
+    const ReblurCB& c = *(const ReblurCB*)io.constants;
+    Cursor cur(io);
+    const Tex& gIn_ViewZ = *cur.next();
+    const Tex* gIn_Diff = cur.nextIf(DIFF);
+    const Tex* gIn_Spec = cur.nextIf(SPEC);
+    Tex* gOut_Diff = cur.nextIf(DIFF);
+    Tex* gOut_Spec = cur.nextIf(SPEC);
+#pragma omp parallel for schedule(static)
+    for (int py = 0; py <= c.gRectSizeMinusOne[1]; py++)
+        for (int px = 0; px <= c.gRectSizeMinusOne[0]; px++) {
+            float2 pixelUv = float2(float(px) + 0.5f, float(py) + 0.5f) * c.gRectSizeInv;
+            if (pixelUv.x > c.gSplitScreen)
+                continue;
+            float viewZ = UnpackViewZ(c, gIn_ViewZ.Load(px, py).x);
+            float keep = viewZ < c.gDenoisingRange ? 1.0f : 0.0f;
+            if (DIFF)
+                gOut_Diff->Store(px, py, gIn_Diff->Load(px, py) * keep);
+            if (SPEC)
+                gOut_Spec->Store(px, py, gIn_Spec->Load(px, py) * keep);
+        }
+}
+
+} // namespace
+
+#define REBLUR_FAMILY(NAME, D, S)                                                                      \
+    {"REBLUR_" NAME "_PrePass.cs", PrePass<D, S>},                                                     \
+    {"REBLUR_" NAME "_TemporalAccumulation.cs", TemporalAccumulation<D, S>},                           \
+    {"REBLUR_" NAME "_HistoryFix.cs", HistoryFix<D, S>},                                               \
+    {"REBLUR_" NAME "_Blur.cs", Blur<D, S>},                                                           \
+    {"REBLUR_" NAME "_PostBlur.cs", PostBlur<D, S, false>},                                            \
+    {"REBLUR_" NAME "_PostBlur_NoTemporalStabilization.cs", PostBlur<D, S, true>},                     \
+    {"REBLUR_" NAME "_TemporalStabilization.cs", TemporalStabilization<D, S>},                         \
+    {"REBLUR_" NAME "_SplitScreen.cs", SplitScreen<D, S>},
+
+const PassEntry* GetReblurPasses(uint32_t& n) {
+    static const PassEntry k[] = {
+        {"REBLUR_ClassifyTiles.cs", ClassifyTiles},
+        REBLUR_FAMILY("Diffuse", true, false)
+        REBLUR_FAMILY("Specular", false, true)
+        REBLUR_FAMILY("DiffuseSpecular", true, true)
+    };
+    n = sizeof(k) / sizeof(k[0]);
+    return k;
+}
+
+} // namespace orc

@@ -260,7 +260,8 @@ extern "C" __attribute__((visibility("default"))) uint32_t nrdHipExecuteDispatch
         args.constants = d.constantBufferData;
         args.constantsSize = d.constantBufferDataSize;
         args.stream = e->stream;
-        launch(args);
+        if (const char* err = launch(args))
+            return e->Fail(nrd::Result::UNSUPPORTED, err);
     }
 
     hipError_t err = hipGetLastError();

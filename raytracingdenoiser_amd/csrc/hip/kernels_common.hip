@@ -18,11 +18,12 @@ __global__ __launch_bounds__(256) void ClearPlaneKernel(Plane out, uint32_t rowB
         ((uint4*)(out.ptr + (size_t)y * out.pitch))[v] = make_uint4(0, 0, 0, 0);
 }
 
-static void LaunchClear(const PassArgs& a) {
+static const char* LaunchClear(const PassArgs& a) {
     const Plane& out = a.planes[0];
     uint32_t rowBytes16 = out.pitch / 16; // pitch is a multiple of 256
     dim3 grid((rowBytes16 + 255) / 256, (unsigned)out.h, 1);
     hipLaunchKernelGGL(ClearPlaneKernel, grid, dim3(256), 0, a.stream, out, rowBytes16);
+    return nullptr;
 }
 
 // ---- REFERENCE accumulate: history = lerp(history, input, accumSpeed), in place -------------------------------------
@@ -36,11 +37,12 @@ __global__ __launch_bounds__(256) void ReferenceAccumulateKernel(Plane input, Pl
     StoreRGBA32F(history, x, y, Lerp(h, in, accumSpeed));
 }
 
-static void LaunchReferenceAccumulate(const PassArgs& a) {
+static const char* LaunchReferenceAccumulate(const PassArgs& a) {
     const auto* c = (const nrdc::ReferenceAccumulateConstants*)a.constants;
     const Plane& history = a.planes[1];
     dim3 grid((unsigned)(history.w + 255) / 256, (unsigned)history.h, 1);
     hipLaunchKernelGGL(ReferenceAccumulateKernel, grid, dim3(256), 0, a.stream, a.planes[0], history, c->gAccumSpeed);
+    return nullptr;
 }
 
 // ---- REFERENCE copy: out = history where pixelUv.x > splitScreen -----------------------------------------------------
@@ -54,11 +56,12 @@ __global__ __launch_bounds__(256) void ReferenceCopyKernel(Plane history, Plane 
         StoreRGBA32F(out, x, y, LoadRGBA32F(history, x, y));
 }
 
-static void LaunchReferenceCopy(const PassArgs& a) {
+static const char* LaunchReferenceCopy(const PassArgs& a) {
     const auto* c = (const nrdc::ReferenceCopyConstants*)a.constants;
     const Plane& out = a.planes[1];
     dim3 grid((unsigned)(out.w + 255) / 256, (unsigned)out.h, 1);
     hipLaunchKernelGGL(ReferenceCopyKernel, grid, dim3(256), 0, a.stream, a.planes[0], out, c->gRectSizeInv.x, c->gSplitScreen);
+    return nullptr;
 }
 
 // ---- numerics probe (include/NRDHip.h: nrdHipEvalNumerics) ---------------------------------------------------------

@@ -1,0 +1,522 @@
+// REBLUR HistoryFix and TemporalStabilization as HIP kernels for gfx950.
+//   HistoryFix              reference Shaders/Include/REBLUR_HistoryFix.hlsli:11-463
+//   TemporalStabilization   reference Shaders/Include/REBLUR_TemporalStabilization.hlsli:11-367
+//
+// MI355X mapping. Both are LDS-tile stencils over a scalar luma plane plus per-pixel work:
+//   HistoryFix: 36x12 LDS tiles (32x8 outputs + halo 2) of the fast-history luma (one per signal) feed the 5x5 moments;
+//     the 5x5-minus-corners history reconstruction is a strided gather that only runs where fewer than
+//     historyFixFrameNum frames are accumulated (disocclusions), the 9x9 anti-firefly box (off by default) reads global.
+//   TemporalStabilization: 34x10 LDS tiles (halo 1) of luma = .x of the YCoCg signal, decoded once per workgroup, feed
+//     the 3x3 moments and the min/max clamp; the stabilised-luma history comes through Catmull-Rom fetches of an R16F plane.
+// LDS rows are padded to an odd dword count (37 / 35) so that the two rows a wave touches start in different banks.
+#include "passes.h"
+#include "reblur_device.h"
+
+namespace nrdhip {
+
+constexpr int TILE_X = 32;
+constexpr int TILE_Y = 8;
+
+static const char* CheckSupportedHistory(const ReblurCB& c) {
+    if (c.gDiffCheckerboard != 2 || c.gSpecCheckerboard != 2)
+        return "REBLUR: checkerboard modes are not implemented in the HIP back-end yet";
+    if (c.gRectOrigin.x != 0 || c.gRectOrigin.y != 0 || c.gResolutionScale.x != 1.0f || c.gResolutionScale.y != 1.0f || c.gResolutionScalePrev.x != 1.0f || c.gResolutionScalePrev.y != 1.0f)
+        return "REBLUR: dynamic resolution (rect != resource) is not implemented in the HIP back-end yet";
+    if (c.gOrthoMode != 0.0f)
+        return "REBLUR: orthographic projection is not supported (SURVEY.md section 8c)";
+    return nullptr;
+}
+
+NRD_D bool BlockHasGeometry(const Plane& tiles) {
+    const int tileY = (blockIdx.y * TILE_Y) >> 4, tileX0 = (blockIdx.x * TILE_X) >> 4;
+    bool any = false;
+    for (int t = 0; t < TILE_X / 16; t++)
+        if (tileX0 + t < tiles.w && tileY < tiles.h)
+            any |= LoadR8Unorm(tiles, tileX0 + t, tileY) == 0.0f;
+    return any;
+}
+
+// ================================================================================================ HistoryFix
+namespace hf {
+constexpr int BORDER = 2;
+constexpr int BUF_X = TILE_X + 2 * BORDER; // 36
+constexpr int BUF_Y = TILE_Y + 2 * BORDER; // 12
+constexpr int BUF_STRIDE = BUF_X + 1;      // 37
+} // namespace hf
+
+struct HfPlanes {
+    Plane tiles, normalRoughness, data1, viewZ, inDiff, inSpec, inDiffFast, inSpecFast, outDiff, outSpec, outDiffFast, outSpecFast;
+};
+
+struct HfPixel {
+    int px, py, tx, ty;
+    float viewZ, roughness, materialID, frustumSize;
+    float3 N, Nv, Xv;
+    float2 pixelUv;
+};
+
+template <bool IS_SPEC, bool DIFF, bool SPEC>
+NRD_D float4 HistoryFixSignal(const ReblurCB& c, const HfPlanes& P, const HfPixel& s, float4 sig, float frameNum, float strideBase, const Plane& gIn_Signal, const Plane& gIn_Fast,
+    const Plane& gOut_Fast, const float* s_Luma) {
+    const int rw = c.gRectSizeMinusOne.x, rh = c.gRectSizeMinusOne.y;
+    const float smc = GetSpecMagicCurve(s.roughness);
+
+    float stride = strideBase * (frameNum < c.gHistoryFixFrameNum ? 1.0f : 0.0f);
+    if (IS_SPEC)
+        stride *= Lerp(0.5f, 1.0f, smc);
+    stride = floorf(stride);
+
+    if (stride != 0.0f) {
+        const int stridei = (int)(stride + 0.5f);
+        const float nonLinearAccumSpeed = 1.0f / (1.0f + frameNum);
+        const float r = IS_SPEC ? s.roughness : 1.0f;
+        const float2 rectSizeInv = ToF2(c.gRectSizeInv);
+        const float4 hitDistParams = ToF4(c.gHitDistParams);
+
+        float normalWeightParam = GetNormalWeightParam(nonLinearAccumSpeed, c.gLobeAngleFraction, r);
+        float2 geometryWeightParams = GetGeometryWeightParams(c.gPlaneDistSensitivity, s.frustumSize, s.Xv, s.Nv);
+        float2 relaxedRoughnessWeightParams = GetRelaxedRoughnessWeightParams(s.roughness * s.roughness, Sqrt(c.gRoughnessFraction));
+
+        float hitDistScale = GetHitDistanceNormalization(s.viewZ, hitDistParams, r);
+        float hitDist = sig.w * hitDistScale;
+        float hitDistFactor = GetHitDistFactor(hitDist, s.frustumSize);
+        float2 hitDistanceWeightParams = GetHitDistanceWeightParams(hitDistFactor, nonLinearAccumSpeed, r);
+
+        float sumw = 1.0f + frameNum;
+        sig = sig * sumw;
+
+        for (int j = -2; j <= 2; j++) {
+            for (int i = -2; i <= 2; i++) {
+                if ((i == 0 && j == 0) || (abs(i) + abs(j) == 4))
+                    continue;
+
+                float2 uv = s.pixelUv + F2(float(i), float(j)) * stride * rectSizeInv;
+                int sx = ClampI(s.px + i * stridei, 0, rw), sy = ClampI(s.py + j * stridei, 0, rh);
+
+                float zs = UnpackViewZ(c, LoadR32F(P.viewZ, sx, sy));
+                float materialIDs;
+                float4 Ns = UnpackNormalAndRoughness(LoadR10G10B10A2(P.normalRoughness, sx, sy), materialIDs);
+
+                float angle = AcosApprox(Dot(Xyz(Ns), s.N));
+                float3 Xvs = ReconstructViewPosition(uv, ToF4(c.gFrustum), zs, c.gOrthoMode);
+
+                float w = IsInScreenNearest(uv);
+                w *= ComputeWeight(Dot(s.Nv, Xvs), geometryWeightParams.x, geometryWeightParams.y);
+                w *= CompareMaterials(s.materialID, materialIDs, IS_SPEC ? c.gSpecMinMaterial : c.gDiffMinMaterial) ? 1.0f : 0.0f;
+                w *= ComputeExponentialWeight(angle, normalWeightParam, 0.0f);
+                if (IS_SPEC)
+                    w *= ComputeExponentialWeight(Ns.w * Ns.w, relaxedRoughnessWeightParams.x, relaxedRoughnessWeightParams.y);
+
+                float2 d1 = LoadData1<DIFF, SPEC>(P.data1, sx, sy);
+                w *= 1.0f + (IS_SPEC ? d1.y : d1.x);
+
+                float4 smp = LoadRGBA16F(gIn_Signal, sx, sy);
+                smp = w == 0.0f ? F4(0.0f) : smp;
+
+                float hs = smp.w * hitDistScale;
+                float hsFactor = GetHitDistFactor(hs, s.frustumSize);
+                w *= ComputeExponentialWeight(hsFactor, hitDistanceWeightParams.x, hitDistanceWeightParams.y);
+
+                if (IS_SPEC) {
+                    float d = Abs(hitDist - hs) / (Max(hitDist, hs) + 0.001f);
+                    float b = LinearStep(0.03f, 0.05f, s.roughness);
+                    w *= SmoothStep(0.2f + b, 0.05f + b, d);
+                }
+
+                sumw += w;
+                sig = sig + smp * w;
+            }
+        }
+
+        sumw = PositiveRcp(sumw);
+        sig = sig * sumw;
+    }
+
+    // Local variance of the fast history over 5x5 from the LDS tile
+    float center = s_Luma[(s.ty + hf::BORDER) * hf::BUF_STRIDE + s.tx + hf::BORDER];
+    float m1 = center, m2 = center * center;
+
+    float f = Sat(frameNum / (c.gHistoryFixFrameNum + NRD_EPS));
+    if (IS_SPEC)
+        f = Lerp(1.0f, f, smc);
+    center = Lerp(GetLuma(sig), center, f);
+    StoreR16F(gOut_Fast, s.px, s.py, center);
+
+#pragma unroll
+    for (int j = 0; j <= 4; j++) {
+#pragma unroll
+        for (int i = 0; i <= 4; i++) {
+            if (i == 2 && j == 2)
+                continue;
+            float d = s_Luma[(s.ty + j) * hf::BUF_STRIDE + s.tx + i];
+            m1 += d;
+            m2 += d * d;
+        }
+    }
+
+    float luma = GetLuma(sig);
+
+    // Anti-firefly: 9x9 minus the central 3x3 (off by default)
+    if (c.gAntiFirefly != 0.0f) {
+        float am1 = 0.0f, am2 = 0.0f;
+        const int R = REBLUR_ANTI_FIREFLY_FILTER_RADIUS;
+        for (int j = -R; j <= R; j++)
+            for (int i = -R; i <= R; i++) {
+                if (abs(i) <= 1 && abs(j) <= 1)
+                    continue;
+                float d = LoadR16F(gIn_Fast, ClampI(s.px + i, 0, rw), ClampI(s.py + j, 0, rh));
+                am1 += d;
+                am2 += d * d;
+            }
+        float invNorm = 1.0f / float((R * 2 + 1) * (R * 2 + 1) - 3 * 3);
+        am1 *= invNorm;
+        am2 *= invNorm;
+        float sigma = Sqrt(Abs(am2 - am1 * am1)) * REBLUR_ANTI_FIREFLY_SIGMA_SCALE;
+        luma = Clamp(luma, am1 - sigma, am1 + sigma);
+    }
+
+    m1 /= 25.0f;
+    m2 /= 25.0f;
+    float sigma = Sqrt(Abs(m2 - m1 * m1)) * REBLUR_COLOR_CLAMPING_SIGMA_SCALE;
+    float lumaClamped = Clamp(luma, m1 - sigma, m1 + sigma);
+    luma = Lerp(lumaClamped, luma, 1.0f / (1.0f + (c.gMaxFastAccumulatedFrameNum < c.gMaxAccumulatedFrameNum ? 1.0f : 0.0f) * frameNum * 2.0f));
+
+    return ChangeLuma(sig, luma);
+}
+
+template <bool DIFF, bool SPEC>
+__global__ __launch_bounds__(TILE_X* TILE_Y) void ReblurHistoryFixKernel(ReblurCB c, HfPlanes P) {
+    __shared__ float s_DiffLuma[DIFF ? hf::BUF_Y * hf::BUF_STRIDE : 1];
+    __shared__ float s_SpecLuma[SPEC ? hf::BUF_Y * hf::BUF_STRIDE : 1];
+
+    const int tx = threadIdx.x % TILE_X, ty = threadIdx.x / TILE_X;
+    const int px = blockIdx.x * TILE_X + tx, py = blockIdx.y * TILE_Y + ty;
+    const int rw = c.gRectSizeMinusOne.x, rh = c.gRectSizeMinusOne.y;
+
+    if (!BlockHasGeometry(P.tiles))
+        return;
+    {
+        const int baseX = blockIdx.x * TILE_X - hf::BORDER, baseY = blockIdx.y * TILE_Y - hf::BORDER;
+        for (int i = threadIdx.x; i < hf::BUF_X * hf::BUF_Y; i += TILE_X * TILE_Y) {
+            int lx = i % hf::BUF_X, ly = i / hf::BUF_X;
+            int gx = ClampI(baseX + lx, 0, rw), gy = ClampI(baseY + ly, 0, rh);
+            if (DIFF)
+                s_DiffLuma[ly * hf::BUF_STRIDE + lx] = LoadR16F(P.inDiffFast, gx, gy);
+            if (SPEC)
+                s_SpecLuma[ly * hf::BUF_STRIDE + lx] = LoadR16F(P.inSpecFast, gx, gy);
+        }
+    }
+    __syncthreads();
+
+    if (px > rw || py > rh)
+        return;
+    if (LoadR8Unorm(P.tiles, px >> 4, py >> 4) != 0.0f)
+        return;
+    HfPixel s;
+    s.viewZ = UnpackViewZ(c, LoadR32F(P.viewZ, px, py));
+    if (s.viewZ > c.gDenoisingRange)
+        return;
+
+    s.px = px, s.py = py, s.tx = tx, s.ty = ty;
+    float4 normalAndRoughness = UnpackNormalAndRoughness(LoadR10G10B10A2(P.normalRoughness, px, py), s.materialID);
+    s.N = Xyz(normalAndRoughness);
+    s.roughness = normalAndRoughness.w;
+    s.frustumSize = GetFrustumSize(c.gMinRectDimMulUnproject, c.gOrthoMode, s.viewZ);
+    s.pixelUv = F2(float(px) + 0.5f, float(py) + 0.5f) * ToF2(c.gRectSizeInv);
+    s.Xv = ReconstructViewPosition(s.pixelUv, ToF4(c.gFrustum), s.viewZ, c.gOrthoMode);
+    s.Nv = RotateVectorInverse(c.gViewToWorld, s.N);
+    float2 frameNum = LoadData1<DIFF, SPEC>(P.data1, px, py);
+    float2 stride = F2(c.gHistoryFixBasePixelStride / (2.0f + frameNum.x), c.gHistoryFixBasePixelStride / (2.0f + frameNum.y));
+
+    if (DIFF) {
+        float4 diff = HistoryFixSignal<false, DIFF, SPEC>(c, P, s, LoadRGBA16F(P.inDiff, px, py), frameNum.x, stride.x, P.inDiff, P.inDiffFast, P.outDiffFast, s_DiffLuma);
+        StoreRGBA16F(P.outDiff, px, py, diff);
+    }
+    if (SPEC) {
+        float4 spec = HistoryFixSignal<true, DIFF, SPEC>(c, P, s, LoadRGBA16F(P.inSpec, px, py), frameNum.y, stride.y, P.inSpec, P.inSpecFast, P.outSpecFast, s_SpecLuma);
+        StoreRGBA16F(P.outSpec, px, py, spec);
+    }
+}
+
+template <bool DIFF, bool SPEC>
+static const char* LaunchHistoryFix(const PassArgs& a) {
+    const ReblurCB& c = *(const ReblurCB*)a.constants;
+    if (const char* err = CheckSupportedHistory(c))
+        return err;
+    HfPlanes P = {};
+    uint32_t k = 0;
+    P.tiles = a.planes[k++];
+    P.normalRoughness = a.planes[k++];
+    P.data1 = a.planes[k++];
+    P.viewZ = a.planes[k++];
+    if (DIFF) P.inDiff = a.planes[k++];
+    if (SPEC) P.inSpec = a.planes[k++];
+    if (DIFF) P.inDiffFast = a.planes[k++];
+    if (SPEC) P.inSpecFast = a.planes[k++];
+    if (DIFF) P.outDiff = a.planes[k++];
+    if (SPEC) P.outSpec = a.planes[k++];
+    if (DIFF) P.outDiffFast = a.planes[k++];
+    if (SPEC) P.outSpecFast = a.planes[k++];
+    if (k != a.planesNum)
+        return "REBLUR history fix: unexpected resource count";
+    dim3 grid = GridFor(c.gRectSizeMinusOne.x + 1, c.gRectSizeMinusOne.y + 1, TILE_X, TILE_Y);
+    hipLaunchKernelGGL((ReblurHistoryFixKernel<DIFF, SPEC>), grid, dim3(TILE_X * TILE_Y), 0, a.stream, c, P);
+    return nullptr;
+}
+
+// ================================================================================================ TemporalStabilization
+namespace ts {
+constexpr int BORDER = 1;
+constexpr int BUF_X = TILE_X + 2 * BORDER; // 34
+constexpr int BUF_Y = TILE_Y + 2 * BORDER; // 10
+constexpr int BUF_STRIDE = BUF_X + 1;      // 35
+} // namespace ts
+
+struct TsPlanes {
+    Plane tiles, normalRoughness, viewZ, data1, data2, inDiff, inSpec, historyDiffLuma, historySpecLuma, inSpecHitDistForTracking, mv, outInternalData, outDiff, outSpec, outDiffLuma,
+        outSpecLuma;
+};
+
+// 3x3 luma statistics from the LDS tile: centre luma (min/max clamped), mean, sigma
+NRD_D void LumaStats(const ReblurCB& c, const float* s_Luma, int tx, int ty, float& luma, float& m1, float& sigma) {
+    luma = s_Luma[(ty + ts::BORDER) * ts::BUF_STRIDE + tx + ts::BORDER];
+    float M1 = luma, M2 = luma * luma, mn = NRD_INF, mx = -NRD_INF;
+#pragma unroll
+    for (int j = 0; j <= 2; j++) {
+#pragma unroll
+        for (int i = 0; i <= 2; i++) {
+            if (i == 1 && j == 1)
+                continue;
+            float d = s_Luma[(ty + j) * ts::BUF_STRIDE + tx + i];
+            M1 += d;
+            M2 += d * d;
+            mn = Min(mn, d);
+            mx = Max(mx, d);
+        }
+    }
+    M1 /= 9.0f;
+    M2 /= 9.0f;
+    m1 = M1;
+    sigma = Sqrt(Abs(M2 - M1 * M1));
+    if (c.gMaxBlurRadius != 0.0f)
+        luma = Clamp(luma, mn, mx);
+}
+
+template <bool DIFF, bool SPEC>
+__global__ __launch_bounds__(TILE_X* TILE_Y) void ReblurTemporalStabilizationKernel(ReblurCB c, TsPlanes P) {
+    __shared__ float s_DiffLuma[DIFF ? ts::BUF_Y * ts::BUF_STRIDE : 1];
+    __shared__ float s_SpecLuma[SPEC ? ts::BUF_Y * ts::BUF_STRIDE : 1];
+
+    const int tx = threadIdx.x % TILE_X, ty = threadIdx.x / TILE_X;
+    const int px = blockIdx.x * TILE_X + tx, py = blockIdx.y * TILE_Y + ty;
+    const int rw = c.gRectSizeMinusOne.x, rh = c.gRectSizeMinusOne.y;
+
+    if (!BlockHasGeometry(P.tiles))
+        return;
+    {
+        const int baseX = blockIdx.x * TILE_X - ts::BORDER, baseY = blockIdx.y * TILE_Y - ts::BORDER;
+        for (int i = threadIdx.x; i < ts::BUF_X * ts::BUF_Y; i += TILE_X * TILE_Y) {
+            int lx = i % ts::BUF_X, ly = i / ts::BUF_X;
+            int gx = ClampI(baseX + lx, 0, rw), gy = ClampI(baseY + ly, 0, rh);
+            if (DIFF)
+                s_DiffLuma[ly * ts::BUF_STRIDE + lx] = GetLuma(LoadRGBA16F(P.inDiff, gx, gy));
+            if (SPEC)
+                s_SpecLuma[ly * ts::BUF_STRIDE + lx] = GetLuma(LoadRGBA16F(P.inSpec, gx, gy));
+        }
+    }
+    __syncthreads();
+
+    if (px > rw || py > rh)
+        return;
+    if (LoadR8Unorm(P.tiles, px >> 4, py >> 4) != 0.0f)
+        return;
+    const float viewZ = UnpackViewZ(c, LoadR32F(P.viewZ, px, py));
+    if (viewZ > c.gDenoisingRange)
+        return;
+
+    const float2 rectSizeInv = ToF2(c.gRectSizeInv), rectSizePrev = ToF2(c.gRectSizePrev);
+    const float3 cameraDelta = ToF3(c.gCameraDelta);
+    const float4 frustum = ToF4(c.gFrustum), frustumPrev = ToF4(c.gFrustumPrev);
+
+    // Position
+    float2 pixelUv = F2(float(px) + 0.5f, float(py) + 0.5f) * rectSizeInv;
+    float3 Xv = ReconstructViewPosition(pixelUv, frustum, viewZ, c.gOrthoMode);
+    float3 X = RotateVector(c.gViewToWorld, Xv);
+
+    // Previous position and surface motion uv
+    float4 inMv = LoadRGBA16F(P.mv, px, py);
+    float3 mv = F3(inMv.x, inMv.y, inMv.z) * F3(c.gMvScale.x, c.gMvScale.y, c.gMvScale.z);
+    float3 Xprev = X;
+    float2 smbPixelUv = pixelUv + F2(mv.x, mv.y);
+    if (c.gMvScale.w == 0.0f) {
+        if (c.gMvScale.z == 0.0f)
+            mv.z = AffineTransform(c.gWorldToViewPrev, X).z - viewZ;
+        float viewZprev = viewZ + mv.z;
+        float3 Xvprevlocal = ReconstructViewPosition(smbPixelUv, frustumPrev, viewZprev, c.gOrthoMode);
+        Xprev = RotateVectorInverse(c.gWorldToViewPrev, Xvprevlocal) + cameraDelta;
+    } else {
+        Xprev = Xprev + mv;
+        smbPixelUv = GetScreenUv(c.gWorldToClipPrev, Xprev);
+    }
+
+    float materialID;
+    float4 normalAndRoughness = UnpackNormalAndRoughness(LoadR10G10B10A2(P.normalRoughness, px, py), materialID);
+    float3 N = Xyz(normalAndRoughness);
+    float roughness = normalAndRoughness.w;
+
+    uint32_t bits;
+    float2 data1 = LoadData1<DIFF, SPEC>(P.data1, px, py);
+    float2 data2 = UnpackData2(SPEC ? LoadR32U(P.data2, px, py) : LoadR8U(P.data2, px, py), bits);
+
+    // Surface motion footprint
+    Bilinear smbBilinearFilter = GetBilinearFilter(smbPixelUv, rectSizePrev);
+    float4 smbOcclusion = F4((bits & 1u) ? 1.0f : 0.0f, (bits & 2u) ? 1.0f : 0.0f, (bits & 4u) ? 1.0f : 0.0f, (bits & 8u) ? 1.0f : 0.0f);
+    float4 smbOcclusionWeights = GetBilinearCustomWeights(smbBilinearFilter, smbOcclusion);
+    bool smbAllowCatRom = Sum(smbOcclusion) > 3.5f;
+    float smbFootprintQuality = ApplyBilinearFilter(smbOcclusion.x, smbOcclusion.y, smbOcclusion.z, smbOcclusion.w, smbBilinearFilter);
+    smbFootprintQuality = Sqrt01(smbFootprintQuality);
+
+    const float2 smbSamplePos = Sat(smbPixelUv) * rectSizePrev;
+
+    if (DIFF) {
+        float diffLuma, diffLumaM1, diffLumaSigma;
+        LumaStats(c, s_DiffLuma, tx, ty, diffLuma, diffLumaM1, diffLumaSigma);
+
+        HistoryFilter smbFilter = MakeHistoryFilter(smbSamplePos, smbOcclusionWeights, smbAllowCatRom);
+        float smbDiffLumaHistory = FetchHistoryR16F(smbFilter, P.historyDiffLuma);
+        smbDiffLumaHistory = Max(smbDiffLumaHistory, 0.0f);
+
+        float diffAntilag = ComputeAntilag(c, smbDiffLumaHistory, diffLumaM1, diffLumaSigma, smbFootprintQuality * data1.x);
+
+        float2 diffTemporalAccumulationParams = GetTemporalAccumulationParams(c, smbFootprintQuality, data1.x);
+        float diffHistoryWeight = diffTemporalAccumulationParams.x;
+        diffHistoryWeight *= diffAntilag;
+        diffHistoryWeight *= pixelUv.x >= c.gSplitScreen ? 1.0f : 0.0f;
+        diffHistoryWeight *= smbPixelUv.x >= c.gSplitScreenPrev ? 1.0f : 0.0f;
+
+        smbDiffLumaHistory = ColorClamp(diffLumaM1, diffLumaSigma * diffTemporalAccumulationParams.y, smbDiffLumaHistory);
+        float diffLumaStabilized = Lerp(diffLuma, smbDiffLumaHistory, Min(diffHistoryWeight, c.gStabilizationStrength));
+
+        float4 diff = LoadRGBA16F(P.inDiff, px, py);
+        diff = ChangeLuma(diff, diffLumaStabilized);
+        StoreRGBA16F(P.outDiff, px, py, diff);
+        StoreR16F(P.outDiffLuma, px, py, diffLumaStabilized);
+
+        data1.x += 1.0f;
+        float diffMinAccumSpeed = Min(data1.x, c.gHistoryFixFrameNum);
+        data1.x = Lerp(diffMinAccumSpeed, data1.x, diffAntilag);
+    }
+
+    if (SPEC) {
+        float specLuma, specLumaM1, specLumaSigma;
+        LumaStats(c, s_SpecLuma, tx, ty, specLuma, specLumaM1, specLumaSigma);
+
+        float virtualHistoryAmount = data2.x;
+        float curvature = data2.y;
+
+        float4 spec = LoadRGBA16F(P.inSpec, px, py);
+        float hitDistForTracking = spec.w * GetHitDistanceNormalization(viewZ, ToF4(c.gHitDistParams), roughness);
+        if (c.gSpecPrepassBlurRadius != 0.0f)
+            hitDistForTracking = Min(hitDistForTracking, LoadR16F(P.inSpecHitDistForTracking, px, py));
+
+        float3 V = GetViewVector(c, X);
+        float3 Xvirtual = GetXvirtual(hitDistForTracking, curvature, X, Xprev, N, V, roughness);
+        float2 vmbPixelUv = GetScreenUv(c.gWorldToClipPrev, Xvirtual);
+        vmbPixelUv = materialID == c.gCameraAttachedReflectionMaterialID ? pixelUv : vmbPixelUv;
+
+        HistoryFilter smbFilter = MakeHistoryFilter(smbSamplePos, smbOcclusionWeights, smbAllowCatRom);
+        float smbSpecLumaHistory = FetchHistoryR16F(smbFilter, P.historySpecLuma);
+
+        Bilinear vmbBilinearFilter = GetBilinearFilter(vmbPixelUv, rectSizePrev);
+        float4 vmbOcclusion = F4((bits & 16u) ? 1.0f : 0.0f, (bits & 32u) ? 1.0f : 0.0f, (bits & 64u) ? 1.0f : 0.0f, (bits & 128u) ? 1.0f : 0.0f);
+        float4 vmbOcclusionWeights = GetBilinearCustomWeights(vmbBilinearFilter, vmbOcclusion);
+        bool vmbAllowCatRom = Sum(vmbOcclusion) > 3.5f;
+        float vmbFootprintQuality = ApplyBilinearFilter(vmbOcclusion.x, vmbOcclusion.y, vmbOcclusion.z, vmbOcclusion.w, vmbBilinearFilter);
+        vmbFootprintQuality = Sqrt01(vmbFootprintQuality);
+
+        HistoryFilter vmbFilter = MakeHistoryFilter(Sat(vmbPixelUv) * rectSizePrev, vmbOcclusionWeights, vmbAllowCatRom);
+        float vmbSpecLumaHistory = FetchHistoryR16F(vmbFilter, P.historySpecLuma);
+
+        smbSpecLumaHistory = Max(smbSpecLumaHistory, 0.0f);
+        vmbSpecLumaHistory = Max(vmbSpecLumaHistory, 0.0f);
+
+        float specLumaHistory = Lerp(smbSpecLumaHistory, vmbSpecLumaHistory, virtualHistoryAmount);
+
+        float footprintQuality = Lerp(smbFootprintQuality, vmbFootprintQuality, virtualHistoryAmount);
+        float specAntilag = ComputeAntilag(c, specLumaHistory, specLumaM1, specLumaSigma, footprintQuality * data1.y);
+
+        float2 specTemporalAccumulationParams = GetTemporalAccumulationParams(c, footprintQuality, data1.y);
+        float specHistoryWeight = specTemporalAccumulationParams.x;
+        specHistoryWeight *= specAntilag;
+        specHistoryWeight *= pixelUv.x >= c.gSplitScreen ? 1.0f : 0.0f;
+        specHistoryWeight *= virtualHistoryAmount != 1.0f ? (smbPixelUv.x >= c.gSplitScreenPrev ? 1.0f : 0.0f) : 1.0f;
+        specHistoryWeight *= virtualHistoryAmount != 0.0f ? (vmbPixelUv.x >= c.gSplitScreenPrev ? 1.0f : 0.0f) : 1.0f;
+
+        float responsiveFactor = RemapRoughnessToResponsiveFactor(c, roughness);
+        float smc = GetSpecMagicCurve(roughness);
+        float acceleration = Lerp(smc, 1.0f, 0.5f + responsiveFactor * 0.5f);
+        specHistoryWeight *= materialID == c.gStrandMaterialID ? 0.5f : acceleration;
+
+        specLumaHistory = ColorClamp(specLumaM1, specLumaSigma * specTemporalAccumulationParams.y, specLumaHistory);
+        float specLumaStabilized = Lerp(specLuma, specLumaHistory, Min(specHistoryWeight, c.gStabilizationStrength));
+
+        spec = ChangeLuma(spec, specLumaStabilized);
+        StoreRGBA16F(P.outSpec, px, py, spec);
+        StoreR16F(P.outSpecLuma, px, py, specLumaStabilized);
+
+        data1.y += 1.0f;
+        float specMinAccumSpeed = Min(data1.y, c.gHistoryFixFrameNum);
+        data1.y = Lerp(specMinAccumSpeed, data1.y, specAntilag);
+    }
+
+    StoreR16U(P.outInternalData, px, py, PackInternalData(data1.x, data1.y, materialID));
+}
+
+template <bool DIFF, bool SPEC>
+static const char* LaunchTemporalStabilization(const PassArgs& a) {
+    const ReblurCB& c = *(const ReblurCB*)a.constants;
+    if (const char* err = CheckSupportedHistory(c))
+        return err;
+    if (c.gSpecProbabilityThresholdsForMvModification.x < 1.0f)
+        return "REBLUR: specular MV modification (IN_BASECOLOR_METALNESS) is not implemented in the HIP back-end yet";
+    TsPlanes P = {};
+    uint32_t k = 0;
+    P.tiles = a.planes[k++];
+    P.normalRoughness = a.planes[k++];
+    if (SPEC) k++; // base colour / metalness (dummy)
+    P.viewZ = a.planes[k++];
+    P.data1 = a.planes[k++];
+    P.data2 = a.planes[k++];
+    if (DIFF) P.inDiff = a.planes[k++];
+    if (SPEC) P.inSpec = a.planes[k++];
+    if (DIFF) P.historyDiffLuma = a.planes[k++];
+    if (SPEC) P.historySpecLuma = a.planes[k++];
+    if (SPEC) P.inSpecHitDistForTracking = a.planes[k++];
+    P.mv = a.planes[k++];
+    P.outInternalData = a.planes[k++];
+    if (DIFF) P.outDiff = a.planes[k++];
+    if (SPEC) P.outSpec = a.planes[k++];
+    if (DIFF) P.outDiffLuma = a.planes[k++];
+    if (SPEC) P.outSpecLuma = a.planes[k++];
+    if (k != a.planesNum)
+        return "REBLUR temporal stabilization: unexpected resource count";
+    dim3 grid = GridFor(c.gRectSizeMinusOne.x + 1, c.gRectSizeMinusOne.y + 1, TILE_X, TILE_Y);
+    hipLaunchKernelGGL((ReblurTemporalStabilizationKernel<DIFF, SPEC>), grid, dim3(TILE_X * TILE_Y), 0, a.stream, c, P);
+    return nullptr;
+}
+
+#define REBLUR_HISTORY_FAMILY(NAME, D, S)                                        \
+    {"REBLUR_" NAME "_HistoryFix.cs", LaunchHistoryFix<D, S>},                   \
+    {"REBLUR_" NAME "_TemporalStabilization.cs", LaunchTemporalStabilization<D, S>},
+
+const PassEntry* GetReblurHistoryPasses(uint32_t& num) {
+    static const PassEntry k[] = {
+        REBLUR_HISTORY_FAMILY("Diffuse", true, false)
+        REBLUR_HISTORY_FAMILY("Specular", false, true)
+        REBLUR_HISTORY_FAMILY("DiffuseSpecular", true, true)
+    };
+    num = sizeof(k) / sizeof(k[0]);
+    return k;
+}
+
+} // namespace nrdhip

@@ -1,0 +1,486 @@
+// REBLUR spatial passes as HIP kernels for gfx950: ClassifyTiles, PrePass, Blur, PostBlur, SplitScreen.
+//   ClassifyTiles   reference Shaders/Source/REBLUR_ClassifyTiles.cs.hlsl:20-55
+//   PrePass         reference Shaders/Include/REBLUR_PrePass.hlsli:11-108
+//   Blur            reference Shaders/Include/REBLUR_Blur.hlsli:11-74
+//   PostBlur        reference Shaders/Include/REBLUR_PostBlur.hlsli:11-78
+//   filters         reference Shaders/Include/REBLUR_Common_{Diffuse,Specular}SpatialFilter.hlsli
+//   SplitScreen     reference Shaders/Include/REBLUR_SplitScreen.hlsli:11-46
+//
+// MI355X mapping. These are SPARSE GATHER passes (8 data-dependent taps per signal at radii up to 30-60 px), not
+// stencils: LDS tiling would need (16+120)^2 halos, so taps are served by the 4 MiB L2 / 256 MiB Infinity Cache and the
+// kernels are bound by the texel-request rate and by latency hiding, not by HBM streaming. What we do for the memory
+// system: 32x8-pixel workgroups (one wave = 2 rows x 32 px, so the centre loads/stores of a wave are 2 x 256 B
+// segments of an RGBA16F plane and 2 x 128 B of an R32F plane), the 832-byte constant block travels as a kernel
+// argument (scalar loads, no constant-buffer indirection), sky tiles exit before touching any signal plane, and
+// workgroups are issued in plain row-major order so neighbouring blocks share taps in L2.
+// ClassifyTiles is one wave per 16x16 tile: each lane reads one 16-byte vector (4 px) and the tile verdict is a single
+// wave-wide vote -- no LDS, no atomics.
+#include "passes.h"
+#include "reblur_device.h"
+
+namespace nrdhip {
+
+constexpr int TILE_X = 32;
+constexpr int TILE_Y = 8;
+
+// ================================================================================================ ClassifyTiles
+__global__ __launch_bounds__(256) void ReblurClassifyTilesKernel(Plane viewZ, Plane tiles, float viewZScale, float denoisingRange) {
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int tileIndex = blockIdx.x * 4 + wave;
+    const int tilesPerRow = tiles.w;
+    if (tileIndex >= tiles.w * tiles.h)
+        return;
+    const int tx = tileIndex % tilesPerRow, ty = tileIndex / tilesPerRow;
+    const int x = tx * 16 + (lane & 3) * 4, y = ty * 16 + (lane >> 2);
+
+    bool allSky = true;
+    if (y < viewZ.h && x + 3 < viewZ.w) {
+        float4 z = *(const float4*)TexelPtr<const float>(viewZ, x, y); // tile rows are 64-byte aligned
+        allSky = Abs(z.x * viewZScale) > denoisingRange && Abs(z.y * viewZScale) > denoisingRange && Abs(z.z * viewZScale) > denoisingRange && Abs(z.w * viewZScale) > denoisingRange;
+    } else {
+        for (int i = 0; i < 4; i++) {
+            float z = InBounds(viewZ, x + i, y) ? LoadR32F(viewZ, x + i, y) : 0.0f; // out-of-bounds load = 0 => a partial edge tile is never sky
+            allSky = allSky && Abs(z * viewZScale) > denoisingRange;
+        }
+    }
+    bool tileIsSky = __all(allSky);
+    if (lane == 0)
+        StoreR8Unorm(tiles, tx, ty, tileIsSky ? 1.0f : 0.0f);
+}
+
+static const char* LaunchClassifyTiles(const PassArgs& a) {
+    const ReblurCB& c = *(const ReblurCB*)a.constants;
+    const Plane& tiles = a.planes[1];
+    int numTiles = tiles.w * tiles.h;
+    hipLaunchKernelGGL(ReblurClassifyTilesKernel, dim3((numTiles + 3) / 4), dim3(256), 0, a.stream, a.planes[0], tiles, c.gViewZScale, c.gDenoisingRange);
+    return nullptr;
+}
+
+// ================================================================================================ spatial filters
+struct SpatialCtx {
+    int px, py;
+    float2 pixelUv;
+    float viewZ, roughness, materialID, NoV, frustumSize;
+    float3 N, Nv, Xv, Vv;
+    float4 rotator;
+    float2 data1;
+};
+
+template <SpatialMode MODE>
+NRD_D float4 DiffuseSpatialFilter(const ReblurCB& c, const SpatialCtx& s, float4 diff, const Plane& gIn_Diff, const Plane& gIn_ViewZ, const Plane& gIn_Normal_Roughness) {
+    if (MODE == PRE_BLUR && c.gDiffPrepassBlurRadius == 0.0f)
+        return diff;
+
+    float sum = 1.0f;
+    float fractionScale = 1.0f, radiusScale = 1.0f;
+    if (MODE == PRE_BLUR)
+        fractionScale = REBLUR_PRE_BLUR_FRACTION_SCALE;
+    else if (MODE == BLUR)
+        fractionScale = REBLUR_BLUR_FRACTION_SCALE;
+    else {
+        radiusScale = REBLUR_POST_BLUR_RADIUS_SCALE;
+        fractionScale = REBLUR_POST_BLUR_FRACTION_SCALE;
+    }
+
+    const float4 hitDistParams = ToF4(c.gHitDistParams);
+    float hitDistScale = GetHitDistanceNormalization(s.viewZ, hitDistParams, 1.0f);
+    float hitDist = diff.w * hitDistScale;
+    float hitDistFactor = GetHitDistFactor(hitDist, s.frustumSize);
+
+    float diffNonLinearAccumSpeed, blurRadius, areaFactor;
+    if (MODE == PRE_BLUR) {
+        diffNonLinearAccumSpeed = REBLUR_PRE_BLUR_NON_LINEAR_ACCUM_SPEED;
+        blurRadius = c.gDiffPrepassBlurRadius;
+        areaFactor = hitDistFactor;
+    } else {
+        float boost = 1.0f - GetFadeBasedOnAccumulatedFrames(c, s.data1.x);
+        boost *= 1.0f - Pow5(s.NoV);
+        diffNonLinearAccumSpeed = 1.0f / (1.0f + REBLUR_SAMPLES_PER_FRAME * (1.0f - boost) * s.data1.x);
+        blurRadius = c.gMaxBlurRadius;
+        areaFactor = hitDistFactor * diffNonLinearAccumSpeed;
+    }
+    blurRadius *= Sqrt01(areaFactor);
+    blurRadius *= radiusScale;
+    blurRadius = Max(blurRadius, c.gMinBlurRadius);
+
+    float2 geometryWeightParams = GetGeometryWeightParams(c.gPlaneDistSensitivity, s.frustumSize, s.Xv, s.Nv);
+    float normalWeightParam = GetNormalWeightParam(diffNonLinearAccumSpeed, c.gLobeAngleFraction) / fractionScale;
+    float2 hitDistanceWeightParams = GetHitDistanceWeightParams(diff.w, diffNonLinearAccumSpeed);
+    float minHitDistWeight = c.gMinHitDistanceWeight * fractionScale;
+    if (MODE != PRE_BLUR)
+        minHitDistWeight *= Sqrt(diffNonLinearAccumSpeed);
+
+    const float2 rectSize = ToF2(c.gRectSize), rectSizeInv = ToF2(c.gRectSizeInv), resolutionScale = ToF2(c.gResolutionScale);
+    const float2 uvMax = resolutionScale - ToF2(c.gResourceSizeInv) * 0.5f;
+
+    float2 skew = F2(1.0f, 1.0f);
+    if (MODE != PRE_BLUR) {
+        skew = Lerp(F2(1.0f - Abs(s.Nv.x), 1.0f - Abs(s.Nv.y)), F2(1.0f, 1.0f), s.NoV);
+        skew = skew / Max(skew.x, skew.y);
+    }
+    skew = skew * (rectSizeInv * blurRadius);
+    float4 scaledRotator = ScaleRotator(s.rotator, skew);
+
+#pragma unroll
+    for (int n = 0; n < 8; n++) {
+        float3 offset = F3(g_Special8[n][0], g_Special8[n][1], g_Special8[n][2]);
+        float2 uv = s.pixelUv + RotateVector(scaledRotator, F2(offset.x, offset.y));
+        uv = Floor(uv * rectSize) + 0.5f;
+        uv = uv * rectSizeInv;
+        float2 uvScaled = F2(Min(uv.x * resolutionScale.x, uvMax.x), Min(uv.y * resolutionScale.y, uvMax.y));
+
+        int2 tz = NearestTexel(gIn_ViewZ, uvScaled);
+        float zs = UnpackViewZ(c, LoadR32F(gIn_ViewZ, tz.x, tz.y));
+        int2 tn = NearestTexel(gIn_Normal_Roughness, uvScaled);
+        float materialIDs;
+        float4 Ns = UnpackNormalAndRoughness(LoadR10G10B10A2(gIn_Normal_Roughness, tn.x, tn.y), materialIDs);
+
+        float angle = AcosApprox(Dot(s.N, Xyz(Ns)));
+        float3 Xvs = ReconstructViewPosition(uv, ToF4(c.gFrustum), zs, c.gOrthoMode);
+
+        float w = IsInScreenNearest(uv);
+        w *= ComputeWeight(Dot(s.Nv, Xvs), geometryWeightParams.x, geometryWeightParams.y);
+        w *= CompareMaterials(s.materialID, materialIDs, c.gDiffMinMaterial) ? 1.0f : 0.0f;
+        w *= ComputeWeight(angle, normalWeightParam, 0.0f);
+
+        int2 ts = NearestTexel(gIn_Diff, uvScaled);
+        float4 smp = LoadRGBA16F(gIn_Diff, ts.x, ts.y);
+        smp = w == 0.0f ? F4(0.0f) : smp;
+
+        w *= Lerp(minHitDistWeight, 1.0f, ComputeExponentialWeight(smp.w, hitDistanceWeightParams.x, hitDistanceWeightParams.y));
+        w *= GetGaussianWeight(offset.z);
+
+        sum += w;
+        diff = diff + smp * w;
+    }
+
+    float invSum = PositiveRcp(sum);
+    return diff * invSum;
+}
+
+template <SpatialMode MODE>
+NRD_D float4 SpecularSpatialFilter(const ReblurCB& c, const SpatialCtx& s, float4 spec, const Plane& gIn_Spec, const Plane& gIn_ViewZ, const Plane& gIn_Normal_Roughness,
+    const Plane& gOut_SpecHitDistForTracking) {
+    float smc = GetSpecMagicCurve(s.roughness);
+    if (MODE == PRE_BLUR && c.gSpecPrepassBlurRadius == 0.0f)
+        return spec;
+
+    RngHash rng;
+    if (MODE == PRE_BLUR)
+        rng.Initialize((uint32_t)s.px, (uint32_t)s.py, c.gFrameIndex);
+
+    float sum = 1.0f;
+    float fractionScale = 1.0f, radiusScale = 1.0f;
+    if (MODE == PRE_BLUR)
+        fractionScale = REBLUR_PRE_BLUR_FRACTION_SCALE;
+    else if (MODE == BLUR)
+        fractionScale = REBLUR_BLUR_FRACTION_SCALE;
+    else {
+        radiusScale = REBLUR_POST_BLUR_RADIUS_SCALE;
+        fractionScale = REBLUR_POST_BLUR_FRACTION_SCALE;
+    }
+
+    const float4 hitDistParams = ToF4(c.gHitDistParams);
+    float4 Dv = GetSpecularDominantDirection(s.Nv, s.Vv, s.roughness);
+    float NoD = Abs(Dot(s.Nv, Xyz(Dv)));
+    float hitDistScale = GetHitDistanceNormalization(s.viewZ, hitDistParams, s.roughness);
+    float hitDist = spec.w * hitDistScale;
+    float hitDistFactor = GetHitDistFactor(hitDist, s.frustumSize);
+
+    float hitDistForTracking = 0.0f, specNonLinearAccumSpeed, blurRadius, areaFactor;
+    if (MODE == PRE_BLUR) {
+        specNonLinearAccumSpeed = REBLUR_PRE_BLUR_NON_LINEAR_ACCUM_SPEED;
+        hitDistForTracking = hitDist == 0.0f ? NRD_INF : hitDist;
+        blurRadius = c.gSpecPrepassBlurRadius;
+        areaFactor = s.roughness * hitDistFactor;
+    } else {
+        float boost = 1.0f - GetFadeBasedOnAccumulatedFrames(c, s.data1.y);
+        boost *= 1.0f - Pow5(s.NoV);
+        boost *= smc;
+        specNonLinearAccumSpeed = 1.0f / (1.0f + REBLUR_SAMPLES_PER_FRAME * (1.0f - boost) * s.data1.y);
+        blurRadius = c.gMaxBlurRadius;
+        areaFactor = s.roughness * hitDistFactor * specNonLinearAccumSpeed;
+    }
+    blurRadius *= Sqrt01(areaFactor);
+
+    if (MODE == PRE_BLUR) {
+        float lobeTanHalfAngle = GetSpecularLobeTanHalfAngle(s.roughness, REBLUR_MAX_PERCENT_OF_LOBE_VOLUME_FOR_PRE_PASS);
+        float lobeRadius = hitDist * NoD * lobeTanHalfAngle;
+        float minBlurRadius = lobeRadius / PixelRadiusToWorld(c.gUnproject, c.gOrthoMode, 1.0f, s.viewZ + hitDist * Dv.w);
+        blurRadius = Min(blurRadius, minBlurRadius);
+    }
+    blurRadius *= radiusScale;
+    blurRadius = Max(blurRadius, c.gMinBlurRadius * smc);
+
+    float roughnessFractionScaled = Sat(c.gRoughnessFraction * fractionScale);
+    float2 geometryWeightParams = GetGeometryWeightParams(c.gPlaneDistSensitivity, s.frustumSize, s.Xv, s.Nv);
+    float normalWeightParam = GetNormalWeightParam(specNonLinearAccumSpeed, c.gLobeAngleFraction, s.roughness) / fractionScale;
+    float2 roughnessWeightParams = GetRoughnessWeightParams(s.roughness, roughnessFractionScaled);
+    float2 hitDistanceWeightParams = GetHitDistanceWeightParams(spec.w, specNonLinearAccumSpeed, s.roughness);
+    float minHitDistWeight = c.gMinHitDistanceWeight * fractionScale * smc;
+    if (MODE != PRE_BLUR)
+        minHitDistWeight *= Sqrt(specNonLinearAccumSpeed);
+
+    const float2 rectSize = ToF2(c.gRectSize), rectSizeInv = ToF2(c.gRectSizeInv), resolutionScale = ToF2(c.gResolutionScale);
+    const float2 uvMax = resolutionScale - ToF2(c.gResourceSizeInv) * 0.5f;
+
+    float4 scaledRotator = F4(0.0f);
+    float3 T = F3(0.0f), B = F3(0.0f);
+    if (MODE == PRE_BLUR) {
+        float2 skew = rectSizeInv * blurRadius;
+        scaledRotator = ScaleRotator(s.rotator, skew);
+    } else {
+        float bentFactor = Sqrt(hitDistFactor);
+        float skewFactor = Lerp(0.25f + 0.75f * s.roughness, 1.0f, NoD);
+        skewFactor = Lerp(skewFactor, 1.0f, specNonLinearAccumSpeed);
+        skewFactor = Lerp(1.0f, skewFactor, bentFactor);
+        float3 bentDv = Normalize(Lerp(s.Nv, Xyz(Dv), bentFactor));
+        GetKernelBasis(bentDv, s.Nv, T, B);
+        float worldRadius = PixelRadiusToWorld(c.gUnproject, c.gOrthoMode, blurRadius, s.viewZ);
+        T = T * (worldRadius * skewFactor);
+        B = B * (worldRadius / skewFactor);
+    }
+
+#pragma unroll
+    for (int n = 0; n < 8; n++) {
+        float3 offset = F3(g_Special8[n][0], g_Special8[n][1], g_Special8[n][2]);
+        float2 uv;
+        if (MODE == PRE_BLUR)
+            uv = s.pixelUv + RotateVector(scaledRotator, F2(offset.x, offset.y));
+        else
+            uv = GetKernelSampleCoordinates(c.gViewToClip, offset, s.Xv, T, B, s.rotator);
+
+        uv = Floor(uv * rectSize) + 0.5f;
+        uv = uv * rectSizeInv;
+        float2 uvScaled = F2(Min(uv.x * resolutionScale.x, uvMax.x), Min(uv.y * resolutionScale.y, uvMax.y));
+
+        int2 tz = NearestTexel(gIn_ViewZ, uvScaled);
+        float zs = UnpackViewZ(c, LoadR32F(gIn_ViewZ, tz.x, tz.y));
+        int2 tn = NearestTexel(gIn_Normal_Roughness, uvScaled);
+        float materialIDs;
+        float4 Ns = UnpackNormalAndRoughness(LoadR10G10B10A2(gIn_Normal_Roughness, tn.x, tn.y), materialIDs);
+
+        float angle = AcosApprox(Dot(s.N, Xyz(Ns)));
+        float3 Xvs = ReconstructViewPosition(uv, ToF4(c.gFrustum), zs, c.gOrthoMode);
+
+        float w = IsInScreenNearest(uv);
+        w *= ComputeWeight(Dot(s.Nv, Xvs), geometryWeightParams.x, geometryWeightParams.y);
+        w *= CompareMaterials(s.materialID, materialIDs, c.gSpecMinMaterial) ? 1.0f : 0.0f;
+        w *= ComputeWeight(angle, normalWeightParam, 0.0f);
+        w *= ComputeWeight(Ns.w, roughnessWeightParams.x, roughnessWeightParams.y);
+
+        int2 ts = NearestTexel(gIn_Spec, uvScaled);
+        float4 smp = LoadRGBA16F(gIn_Spec, ts.x, ts.y);
+        smp = w == 0.0f ? F4(0.0f) : smp;
+
+        if (MODE == PRE_BLUR) {
+            float hs = smp.w * GetHitDistanceNormalization(zs, hitDistParams, Ns.w);
+            float d = Length(Xvs - s.Xv) + NRD_EPS;
+            float geometryWeight = w * Sat(hs / d);
+            if (rng.GetFloat() < geometryWeight)
+                hitDistForTracking = Min(hitDistForTracking, hs);
+
+            w *= c.gUsePrepassNotOnlyForSpecularMotionEstimation;
+
+            float t = hs / (d + hitDist);
+            w *= Lerp(Sat(t), 1.0f, LinearStep(0.5f, 1.0f, s.roughness));
+        }
+        w *= Lerp(minHitDistWeight, 1.0f, ComputeExponentialWeight(smp.w, hitDistanceWeightParams.x, hitDistanceWeightParams.y));
+        w *= GetGaussianWeight(offset.z);
+
+        sum += w;
+        spec = spec + smp * w;
+    }
+
+    float invSum = PositiveRcp(sum);
+    spec = spec * invSum;
+
+    if (MODE == PRE_BLUR)
+        StoreR16F(gOut_SpecHitDistForTracking, s.px, s.py, hitDistForTracking == NRD_INF ? 0.0f : hitDistForTracking);
+    return spec;
+}
+
+// per-pixel context; false = early-out (sky tile, outside the rect, beyond the denoising range)
+NRD_D bool MakeSpatialCtx(const ReblurCB& c, int px, int py, float viewZ, const Plane& gIn_Normal_Roughness, float4 rotator, SpatialCtx& s) {
+    s.viewZ = viewZ;
+    if (viewZ > c.gDenoisingRange)
+        return false;
+    float4 normalAndRoughness = UnpackNormalAndRoughness(LoadR10G10B10A2(gIn_Normal_Roughness, px, py), s.materialID);
+    s.px = px;
+    s.py = py;
+    s.N = Xyz(normalAndRoughness);
+    s.Nv = RotateVectorInverse(c.gViewToWorld, s.N);
+    s.roughness = normalAndRoughness.w;
+    s.pixelUv = F2(float(px) + 0.5f, float(py) + 0.5f) * ToF2(c.gRectSizeInv);
+    s.Xv = ReconstructViewPosition(s.pixelUv, ToF4(c.gFrustum), viewZ, c.gOrthoMode);
+    s.Vv = GetViewVector(c, s.Xv, true);
+    s.NoV = Abs(Dot(s.Nv, s.Vv));
+    s.frustumSize = GetFrustumSize(c.gMinRectDimMulUnproject, c.gOrthoMode, viewZ);
+    s.rotator = rotator;
+    s.data1 = F2(0.0f, 0.0f);
+    return true;
+}
+
+struct SpatialPlanes {
+    Plane tiles, normalRoughness, viewZ, data1;
+    Plane inDiff, inSpec;
+    Plane outDiff, outSpec;
+    Plane outHitDistForTracking; // pre-pass
+    Plane outViewZ;              // blur
+    Plane outNormalRoughness;    // post-blur
+    Plane outInternalData, outDiffCopy, outSpecCopy; // post-blur without temporal stabilization
+};
+
+template <SpatialMode MODE, bool DIFF, bool SPEC, bool NO_TS>
+__global__ __launch_bounds__(TILE_X* TILE_Y) void ReblurSpatialKernel(ReblurCB c, SpatialPlanes P) {
+    const int px = blockIdx.x * TILE_X + (threadIdx.x % TILE_X);
+    const int py = blockIdx.y * TILE_Y + (threadIdx.x / TILE_X);
+    if (px > c.gRectSizeMinusOne.x || py > c.gRectSizeMinusOne.y)
+        return;
+    if (LoadR8Unorm(P.tiles, px >> 4, py >> 4) != 0.0f)
+        return;
+
+    const float viewZpacked = LoadR32F(P.viewZ, px, py);
+    if (MODE == BLUR)
+        StoreR32F(P.outViewZ, px, py, viewZpacked); // PREV_VIEWZ, before the denoising-range early-out
+
+    SpatialCtx s;
+    const nrdc::F4 rot = MODE == PRE_BLUR ? c.gRotatorPre : (MODE == BLUR ? c.gRotator : c.gRotatorPost);
+    if (!MakeSpatialCtx(c, px, py, UnpackViewZ(c, viewZpacked), P.normalRoughness, ToF4(rot), s))
+        return;
+
+    if (MODE != PRE_BLUR)
+        s.data1 = LoadData1<DIFF, SPEC>(P.data1, px, py);
+
+    if (MODE == POST_BLUR) {
+        StoreR32U(P.outNormalRoughness, px, py, LoadR32U(P.normalRoughness, px, py)); // packed texel copied verbatim
+        if (NO_TS)
+            StoreR16U(P.outInternalData, px, py, PackInternalData(s.data1.x + 1.0f, s.data1.y + 1.0f, s.materialID));
+    }
+
+    if (DIFF) {
+        float4 diff = LoadRGBA16F(P.inDiff, px, py);
+        diff = DiffuseSpatialFilter<MODE>(c, s, diff, P.inDiff, P.viewZ, P.normalRoughness);
+        StoreRGBA16F(P.outDiff, px, py, diff);
+        if (MODE == POST_BLUR && NO_TS)
+            StoreRGBA16F(P.outDiffCopy, px, py, diff);
+    }
+    if (SPEC) {
+        float4 spec = LoadRGBA16F(P.inSpec, px, py);
+        spec = SpecularSpatialFilter<MODE>(c, s, spec, P.inSpec, P.viewZ, P.normalRoughness, P.outHitDistForTracking);
+        StoreRGBA16F(P.outSpec, px, py, spec);
+        if (MODE == POST_BLUR && NO_TS)
+            StoreRGBA16F(P.outSpecCopy, px, py, spec);
+    }
+}
+
+static const char* CheckSupported(const ReblurCB& c) {
+    if (c.gDiffCheckerboard != 2 || c.gSpecCheckerboard != 2)
+        return "REBLUR: checkerboard modes are not implemented in the HIP back-end yet";
+    if (c.gHasHistoryConfidence || c.gHasDisocclusionThresholdMix)
+        return "REBLUR: history-confidence / disocclusion-threshold-mix inputs are not implemented in the HIP back-end yet";
+    if (c.gRectOrigin.x != 0 || c.gRectOrigin.y != 0 || c.gResolutionScale.x != 1.0f || c.gResolutionScale.y != 1.0f)
+        return "REBLUR: dynamic resolution (rect != resource) is not implemented in the HIP back-end yet";
+    if (c.gOrthoMode != 0.0f)
+        return "REBLUR: orthographic projection is not supported (SURVEY.md section 8c)";
+    return nullptr;
+}
+
+template <SpatialMode MODE, bool DIFF, bool SPEC, bool NO_TS>
+static const char* LaunchSpatial(const PassArgs& a) {
+    const ReblurCB& c = *(const ReblurCB*)a.constants;
+    if (const char* err = CheckSupported(c))
+        return err;
+
+    SpatialPlanes P = {};
+    uint32_t k = 0;
+    P.tiles = a.planes[k++];
+    P.normalRoughness = a.planes[k++];
+    if (MODE == PRE_BLUR) {
+        P.viewZ = a.planes[k++];
+        if (DIFF) P.inDiff = a.planes[k++];
+        if (SPEC) P.inSpec = a.planes[k++];
+        if (DIFF) P.outDiff = a.planes[k++];
+        if (SPEC) P.outSpec = a.planes[k++];
+        if (SPEC) P.outHitDistForTracking = a.planes[k++];
+    } else {
+        P.data1 = a.planes[k++];
+        if (DIFF) P.inDiff = a.planes[k++];
+        if (SPEC) P.inSpec = a.planes[k++];
+        P.viewZ = a.planes[k++];
+        if (MODE == BLUR) {
+            if (DIFF) P.outDiff = a.planes[k++];
+            if (SPEC) P.outSpec = a.planes[k++];
+            P.outViewZ = a.planes[k++];
+        } else {
+            P.outNormalRoughness = a.planes[k++];
+            if (DIFF) P.outDiff = a.planes[k++];
+            if (SPEC) P.outSpec = a.planes[k++];
+            if (NO_TS) {
+                P.outInternalData = a.planes[k++];
+                if (DIFF) P.outDiffCopy = a.planes[k++];
+                if (SPEC) P.outSpecCopy = a.planes[k++];
+            }
+        }
+    }
+    if (k != a.planesNum)
+        return "REBLUR spatial pass: unexpected resource count";
+
+    dim3 grid = GridFor(c.gRectSizeMinusOne.x + 1, c.gRectSizeMinusOne.y + 1, TILE_X, TILE_Y);
+    hipLaunchKernelGGL((ReblurSpatialKernel<MODE, DIFF, SPEC, NO_TS>), grid, dim3(TILE_X * TILE_Y), 0, a.stream, c, P);
+    return nullptr;
+}
+
+// ================================================================================================ SplitScreen
+template <bool DIFF, bool SPEC>
+__global__ __launch_bounds__(256) void ReblurSplitScreenKernel(ReblurCB c, Plane viewZ, Plane inDiff, Plane inSpec, Plane outDiff, Plane outSpec) {
+    const int px = blockIdx.x * TILE_X + (threadIdx.x % TILE_X);
+    const int py = blockIdx.y * TILE_Y + (threadIdx.x / TILE_X);
+    if (px > c.gRectSizeMinusOne.x || py > c.gRectSizeMinusOne.y)
+        return;
+    float pixelUvX = (float(px) + 0.5f) * c.gRectSizeInv.x;
+    if (pixelUvX > c.gSplitScreen)
+        return;
+    float z = UnpackViewZ(c, LoadR32F(viewZ, px, py));
+    float keep = z < c.gDenoisingRange ? 1.0f : 0.0f;
+    if (DIFF)
+        StoreRGBA16F(outDiff, px, py, LoadRGBA16F(inDiff, px, py) * keep);
+    if (SPEC)
+        StoreRGBA16F(outSpec, px, py, LoadRGBA16F(inSpec, px, py) * keep);
+}
+
+template <bool DIFF, bool SPEC>
+static const char* LaunchSplitScreen(const PassArgs& a) {
+    const ReblurCB& c = *(const ReblurCB*)a.constants;
+    if (const char* err = CheckSupported(c))
+        return err;
+    uint32_t k = 0;
+    Plane viewZ = a.planes[k++], inDiff = {}, inSpec = {}, outDiff = {}, outSpec = {};
+    if (DIFF) inDiff = a.planes[k++];
+    if (SPEC) inSpec = a.planes[k++];
+    if (DIFF) outDiff = a.planes[k++];
+    if (SPEC) outSpec = a.planes[k++];
+    dim3 grid = GridFor(c.gRectSizeMinusOne.x + 1, c.gRectSizeMinusOne.y + 1, TILE_X, TILE_Y);
+    hipLaunchKernelGGL((ReblurSplitScreenKernel<DIFF, SPEC>), grid, dim3(256), 0, a.stream, c, viewZ, inDiff, inSpec, outDiff, outSpec);
+    return nullptr;
+}
+
+#define REBLUR_SPATIAL_FAMILY(NAME, D, S)                                                              \
+    {"REBLUR_" NAME "_PrePass.cs", LaunchSpatial<PRE_BLUR, D, S, false>},                              \
+    {"REBLUR_" NAME "_Blur.cs", LaunchSpatial<BLUR, D, S, false>},                                     \
+    {"REBLUR_" NAME "_PostBlur.cs", LaunchSpatial<POST_BLUR, D, S, false>},                            \
+    {"REBLUR_" NAME "_PostBlur_NoTemporalStabilization.cs", LaunchSpatial<POST_BLUR, D, S, true>},     \
+    {"REBLUR_" NAME "_SplitScreen.cs", LaunchSplitScreen<D, S>},
+
+const PassEntry* GetReblurSpatialPasses(uint32_t& num) {
+    static const PassEntry k[] = {
+        {"REBLUR_ClassifyTiles.cs", LaunchClassifyTiles},
+        REBLUR_SPATIAL_FAMILY("Diffuse", true, false)
+        REBLUR_SPATIAL_FAMILY("Specular", false, true)
+        REBLUR_SPATIAL_FAMILY("DiffuseSpecular", true, true)
+    };
+    num = sizeof(k) / sizeof(k[0]);
+    return k;
+}
+
+} // namespace nrdhip

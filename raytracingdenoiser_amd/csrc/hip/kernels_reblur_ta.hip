@@ -1,0 +1,671 @@
+// REBLUR TemporalAccumulation as a HIP kernel for gfx950.
+//   reference Shaders/Include/REBLUR_TemporalAccumulation.hlsli:11-931 (quality mode, R10G10B10A2 normals, no optional inputs)
+//
+// MI355X mapping. 32x8-pixel workgroups (4 waves of 2 rows x 32 px). The 3x3 neighbourhood statistics (averaged
+// normal, roughness variance, minimum hit distance for tracking) and the two curvature edge normals come from a
+// 34x10 LDS tile holding the UNPACKED normal+roughness (float4) and the tracking hit distance, filled cooperatively
+// with border-clamped loads -- every texel is decoded once per workgroup instead of 9+2 times per pixel. The row stride
+// of the float4 tile is 35 slots (560 B): rows of a wave start on different 16-byte slots, so the ds_read_b128 taps
+// of the two rows do not collide. Everything after that is per-pixel: reprojection, the 4x4 previous-depth footprint,
+// disocclusion tests, virtual-motion tracking, Catmull-Rom history fetches (5 bilinear fetches, i.e. 20 fp16 texels per
+// plane) and the accumulation itself. The kernel is latency/ALU bound, not HBM bound: ~66 B/px are read and 28 B/px
+// written against several hundred dependent VALU ops per pixel, so occupancy (VGPRs) is the lever, not bytes.
+#include "passes.h"
+#include "reblur_device.h"
+
+namespace nrdhip {
+
+constexpr int TILE_X = 32;
+constexpr int TILE_Y = 8;
+constexpr int BORDER = 1;
+constexpr int BUF_X = TILE_X + 2 * BORDER; // 34
+constexpr int BUF_Y = TILE_Y + 2 * BORDER; // 10
+constexpr int BUF_STRIDE = BUF_X + 1;      // 35 float4 slots per row
+
+struct TaPlanes {
+    Plane tiles, normalRoughness, viewZ, mv, prevViewZ, prevNormalRoughness, prevInternalData;
+    Plane inDiff, inSpec, historyDiff, historySpec, historyDiffFast, historySpecFast, prevSpecHitDistForTracking, inSpecHitDistForTracking;
+    Plane outDiff, outSpec, outDiffFast, outSpecFast, outSpecHitDistForTracking, outData1, outData2;
+};
+
+template <bool DIFF, bool SPEC>
+__global__ __launch_bounds__(TILE_X* TILE_Y) void ReblurTemporalAccumulationKernel(ReblurCB c, TaPlanes P) {
+    __shared__ float4 s_Normal_Roughness[BUF_Y * BUF_STRIDE];
+    __shared__ float s_HitDistForTracking[BUF_Y * BUF_STRIDE];
+
+    const int tx = threadIdx.x % TILE_X, ty = threadIdx.x / TILE_X;
+    const int px = blockIdx.x * TILE_X + tx, py = blockIdx.y * TILE_Y + ty;
+    const int rw = c.gRectSizeMinusOne.x, rh = c.gRectSizeMinusOne.y;
+
+    // ---- cooperative preload (clamped to the rect), skipped when every 16x16 tile under this block is sky
+    {
+        const int tileY = (blockIdx.y * TILE_Y) >> 4, tileX0 = (blockIdx.x * TILE_X) >> 4;
+        bool anyGeometry = false;
+        for (int t = 0; t < TILE_X / 16; t++)
+            if (tileX0 + t < P.tiles.w && tileY < P.tiles.h)
+                anyGeometry |= LoadR8Unorm(P.tiles, tileX0 + t, tileY) == 0.0f;
+        if (!anyGeometry)
+            return; // uniform across the block
+
+        const int baseX = blockIdx.x * TILE_X - BORDER, baseY = blockIdx.y * TILE_Y - BORDER;
+        for (int i = threadIdx.x; i < BUF_X * BUF_Y; i += TILE_X * TILE_Y) {
+            int lx = i % BUF_X, ly = i / BUF_X;
+            int gx = ClampI(baseX + lx, 0, rw), gy = ClampI(baseY + ly, 0, rh);
+            s_Normal_Roughness[ly * BUF_STRIDE + lx] = UnpackNormalAndRoughness(LoadR10G10B10A2(P.normalRoughness, gx, gy));
+            if (SPEC) {
+                float hitDist = c.gSpecPrepassBlurRadius == 0.0f ? LoadRGBA16F(P.inSpec, gx, gy).w : LoadR16F(P.inSpecHitDistForTracking, gx, gy);
+                s_HitDistForTracking[ly * BUF_STRIDE + lx] = hitDist == 0.0f ? NRD_INF : hitDist;
+            }
+        }
+    }
+    __syncthreads();
+
+    if (px > rw || py > rh)
+        return;
+    if (LoadR8Unorm(P.tiles, px >> 4, py >> 4) != 0.0f)
+        return;
+    const float viewZ = UnpackViewZ(c, LoadR32F(P.viewZ, px, py));
+    if (viewZ > c.gDenoisingRange)
+        return;
+
+    const float2 rectSize = ToF2(c.gRectSize), rectSizeInv = ToF2(c.gRectSizeInv), rectSizePrev = ToF2(c.gRectSizePrev);
+    const float3 cameraDelta = ToF3(c.gCameraDelta);
+    const float4 frustum = ToF4(c.gFrustum), frustumPrev = ToF4(c.gFrustumPrev), hitDistParams = ToF4(c.gHitDistParams);
+
+    // Current position
+    float2 pixelUv = F2(float(px) + 0.5f, float(py) + 0.5f) * rectSizeInv;
+    float3 Xv = ReconstructViewPosition(pixelUv, frustum, viewZ, c.gOrthoMode);
+    float3 X = RotateVector(c.gViewToWorld, Xv);
+
+    // 3x3: averaged normal (2x2 part), roughness moments, min hit distance for tracking
+    float3 Navg = F3(0.0f);
+    float hitDistForTracking = NRD_INF, roughnessM1 = 0.0f, roughnessM2 = 0.0f;
+#pragma unroll
+    for (int j = 0; j <= 2; j++) {
+#pragma unroll
+        for (int i = 0; i <= 2; i++) {
+            int o = (ty + j) * BUF_STRIDE + tx + i;
+            float4 nr = s_Normal_Roughness[o];
+            if (i < 2 && j < 2)
+                Navg = Navg + Xyz(nr);
+            if (SPEC) {
+                hitDistForTracking = Min(hitDistForTracking, s_HitDistForTracking[o]);
+                float roughnessSq = nr.w * nr.w;
+                roughnessM1 += roughnessSq;
+                roughnessM2 += roughnessSq * roughnessSq;
+            }
+        }
+    }
+    Navg = Navg / 4.0f;
+
+    float materialID;
+    float4 normalAndRoughness = UnpackNormalAndRoughness(LoadR10G10B10A2(P.normalRoughness, px, py), materialID);
+    float3 N = Xyz(normalAndRoughness);
+    float roughness = normalAndRoughness.w;
+
+    float roughnessModified = 0.0f, roughnessSigma = 0.0f, hitDistNormalization = 0.0f;
+    RngHash rng;
+    if (SPEC) {
+        roughnessModified = GetModifiedRoughnessFromNormalVariance(roughness, Navg);
+        roughnessM1 /= 9.0f;
+        roughnessM2 /= 9.0f;
+        roughnessSigma = Sqrt(Abs(roughnessM2 - roughnessM1 * roughnessM1));
+
+        rng.Initialize((uint32_t)px, (uint32_t)py, c.gFrameIndex);
+
+        hitDistForTracking = hitDistForTracking == NRD_INF ? 0.0f : hitDistForTracking;
+        hitDistNormalization = GetHitDistanceNormalization(viewZ, hitDistParams, roughness);
+        hitDistForTracking *= c.gSpecPrepassBlurRadius == 0.0f ? hitDistNormalization : 1.0f;
+        StoreR16F(P.outSpecHitDistForTracking, px, py, hitDistForTracking);
+    }
+
+    // Previous position and surface motion uv
+    float4 mvRaw = LoadRGBA16F(P.mv, px, py);
+    float3 mv = F3(mvRaw.x, mvRaw.y, mvRaw.z) * F3(c.gMvScale.x, c.gMvScale.y, c.gMvScale.z);
+    float3 Xprev = X;
+    float2 smbPixelUv = pixelUv + F2(mv.x, mv.y);
+    if (c.gMvScale.w == 0.0f) {
+        if (c.gMvScale.z == 0.0f)
+            mv.z = AffineTransform(c.gWorldToViewPrev, X).z - viewZ;
+        float viewZprev = viewZ + mv.z;
+        float3 Xvprevlocal = ReconstructViewPosition(smbPixelUv, frustumPrev, viewZprev, c.gOrthoMode);
+        Xprev = RotateVectorInverse(c.gWorldToViewPrev, Xvprevlocal) + cameraDelta;
+    } else {
+        Xprev = Xprev + mv;
+        smbPixelUv = GetScreenUv(c.gWorldToClipPrev, Xprev);
+    }
+
+    // Previous viewZ: 4x4 footprint as four 2x2 quads in (0,0)(1,0)(0,1)(1,1) order
+    float2 catromOrigin = GetCatmullRomOrigin(smbPixelUv, rectSizePrev);
+    const int cx = (int)catromOrigin.x, cy = (int)catromOrigin.y;
+#define QUADZ(ox, oy) \
+    F4(FetchClampedR32F(P.prevViewZ, cx + ox, cy + oy), FetchClampedR32F(P.prevViewZ, cx + ox + 1, cy + oy), FetchClampedR32F(P.prevViewZ, cx + ox, cy + oy + 1), FetchClampedR32F(P.prevViewZ, cx + ox + 1, cy + oy + 1))
+    float4 smbViewZ0 = QUADZ(0, 0), smbViewZ1 = QUADZ(2, 0), smbViewZ2 = QUADZ(0, 2), smbViewZ3 = QUADZ(2, 2);
+#undef QUADZ
+    float3 prevViewZ0 = F3(UnpackViewZ(c, smbViewZ0.y), UnpackViewZ(c, smbViewZ0.z), UnpackViewZ(c, smbViewZ0.w));
+    float3 prevViewZ1 = F3(UnpackViewZ(c, smbViewZ1.x), UnpackViewZ(c, smbViewZ1.z), UnpackViewZ(c, smbViewZ1.w));
+    float3 prevViewZ2 = F3(UnpackViewZ(c, smbViewZ2.x), UnpackViewZ(c, smbViewZ2.y), UnpackViewZ(c, smbViewZ2.w));
+    float3 prevViewZ3 = F3(UnpackViewZ(c, smbViewZ3.x), UnpackViewZ(c, smbViewZ3.y), UnpackViewZ(c, smbViewZ3.z));
+
+    // Previous normal averaged over the valid pixels of the 2x2 footprint
+    Bilinear smbBilinearFilter = GetBilinearFilter(smbPixelUv, rectSizePrev);
+    float3 smbNavg;
+    {
+        int bx = (int)smbBilinearFilter.origin.x, by = (int)smbBilinearFilter.origin.y;
+        float sumw = 0.0f;
+        float w = prevViewZ0.z < c.gDenoisingRange ? 1.0f : 0.0f;
+        smbNavg = Xyz(UnpackNormalAndRoughness(LoadR10G10B10A2OrZero(P.prevNormalRoughness, bx, by))) * w;
+        sumw += w;
+        w = prevViewZ1.y < c.gDenoisingRange ? 1.0f : 0.0f;
+        smbNavg = smbNavg + Xyz(UnpackNormalAndRoughness(LoadR10G10B10A2OrZero(P.prevNormalRoughness, bx + 1, by))) * w;
+        sumw += w;
+        w = prevViewZ2.y < c.gDenoisingRange ? 1.0f : 0.0f;
+        smbNavg = smbNavg + Xyz(UnpackNormalAndRoughness(LoadR10G10B10A2OrZero(P.prevNormalRoughness, bx, by + 1))) * w;
+        sumw += w;
+        w = prevViewZ3.x < c.gDenoisingRange ? 1.0f : 0.0f;
+        smbNavg = smbNavg + Xyz(UnpackNormalAndRoughness(LoadR10G10B10A2OrZero(P.prevNormalRoughness, bx + 1, by + 1))) * w;
+        sumw += w;
+        smbNavg = smbNavg / (sumw == 0.0f ? 1.0f : sumw);
+    }
+    smbNavg = RotateVector(c.gWorldPrevToWorld, smbNavg);
+
+    // Parallax
+    float smbParallaxInPixels1 = ComputeParallaxInPixels(Xprev + cameraDelta, c.gOrthoMode == 0.0f ? smbPixelUv : pixelUv, c.gWorldToClipPrev, rectSize);
+    float smbParallaxInPixels2 = ComputeParallaxInPixels(Xprev - cameraDelta, c.gOrthoMode == 0.0f ? pixelUv : smbPixelUv, c.gWorldToClip, rectSize);
+    float smbParallaxInPixelsMax = Max(smbParallaxInPixels1, smbParallaxInPixels2);
+    float smbParallaxInPixelsMin = Min(smbParallaxInPixels1, smbParallaxInPixels2);
+
+    // Disocclusion: threshold
+    float pixelSize = PixelRadiusToWorld(c.gUnproject, c.gOrthoMode, 1.0f, viewZ);
+    float frustumSize = GetFrustumSize(c.gMinRectDimMulUnproject, c.gOrthoMode, viewZ);
+
+    float disocclusionThresholdMix = 0.0f;
+    if (materialID == c.gStrandMaterialID)
+        disocclusionThresholdMix = Sat(c.gStrandThickness / pixelSize);
+    float disocclusionThreshold = Lerp(c.gDisocclusionThreshold, c.gDisocclusionThresholdAlternate, disocclusionThresholdMix);
+
+    float smallParallax = LinearStep(0.25f, 0.0f, smbParallaxInPixelsMax);
+    disocclusionThreshold += 0.05f * smallParallax;
+
+    float3 V = GetViewVector(c, X);
+    float NoV = Abs(Dot(N, V));
+    float NoVstrict = Lerp(NoV, 1.0f, Sat(smbParallaxInPixelsMax / 30.0f));
+    float4 smbDisocclusionThreshold = F4(GetDisocclusionThreshold(disocclusionThreshold, frustumSize, NoVstrict));
+    smbDisocclusionThreshold = smbDisocclusionThreshold * (Dot(smbNavg, Navg) > REBLUR_ALMOST_ZERO_ANGLE - 0.25f * smallParallax ? 1.0f : 0.0f);
+    smbDisocclusionThreshold = smbDisocclusionThreshold * IsInScreenBilinear(smbBilinearFilter.origin, rectSizePrev);
+    smbDisocclusionThreshold = smbDisocclusionThreshold - NRD_EPS;
+
+    // Disocclusion: plane distance
+    float3 Xvprev = AffineTransform(c.gWorldToViewPrev, Xprev);
+    float3 smbOcclusion0 = Step(Abs(prevViewZ0 - F3(Xvprev.z)), smbDisocclusionThreshold.x);
+    float3 smbOcclusion1 = Step(Abs(prevViewZ1 - F3(Xvprev.z)), smbDisocclusionThreshold.y);
+    float3 smbOcclusion2 = Step(Abs(prevViewZ2 - F3(Xvprev.z)), smbDisocclusionThreshold.z);
+    float3 smbOcclusion3 = Step(Abs(prevViewZ3 - F3(Xvprev.z)), smbDisocclusionThreshold.w);
+
+    // Disocclusion: materialID
+    uint32_t id0[4], id1[4], id2[4], id3[4];
+#define QUADU(q, ox, oy)                                                   \
+    q[0] = FetchClampedR16U(P.prevInternalData, cx + ox, cy + oy);         \
+    q[1] = FetchClampedR16U(P.prevInternalData, cx + ox + 1, cy + oy);     \
+    q[2] = FetchClampedR16U(P.prevInternalData, cx + ox, cy + oy + 1);     \
+    q[3] = FetchClampedR16U(P.prevInternalData, cx + ox + 1, cy + oy + 1);
+    QUADU(id0, 0, 0) QUADU(id1, 2, 0) QUADU(id2, 0, 2) QUADU(id3, 2, 2)
+#undef QUADU
+    float minMaterialID = Min(c.gSpecMinMaterial, c.gDiffMinMaterial);
+#define MATCMP(p) (CompareMaterials(materialID, UnpackInternalData(p).z, minMaterialID) ? 1.0f : 0.0f)
+    smbOcclusion0 = smbOcclusion0 * F3(MATCMP(id0[1]), MATCMP(id0[2]), MATCMP(id0[3]));
+    smbOcclusion1 = smbOcclusion1 * F3(MATCMP(id1[0]), MATCMP(id1[2]), MATCMP(id1[3]));
+    smbOcclusion2 = smbOcclusion2 * F3(MATCMP(id2[0]), MATCMP(id2[1]), MATCMP(id2[3]));
+    smbOcclusion3 = smbOcclusion3 * F3(MATCMP(id3[0]), MATCMP(id3[1]), MATCMP(id3[2]));
+#undef MATCMP
+    const uint32_t smbInternalData0 = id0[3], smbInternalData1 = id1[2], smbInternalData2 = id2[1], smbInternalData3 = id3[0];
+
+    // 2x2 occlusion weights
+    float4 smbOcclusionWeights = GetBilinearCustomWeights(smbBilinearFilter, F4(smbOcclusion0.z, smbOcclusion1.y, smbOcclusion2.y, smbOcclusion3.x));
+    float3 occSum = smbOcclusion0 + smbOcclusion1 + smbOcclusion2 + smbOcclusion3;
+    bool smbAllowCatRom = (occSum.x + occSum.y + occSum.z) > 11.5f;
+
+    float fbits = smbOcclusion0.z * 1.0f;
+    fbits += smbOcclusion1.y * 2.0f;
+    fbits += smbOcclusion2.y * 4.0f;
+    fbits += smbOcclusion3.x * 8.0f;
+
+    // Accumulation speed
+    float3 internalData00 = UnpackInternalData(smbInternalData0), internalData10 = UnpackInternalData(smbInternalData1);
+    float3 internalData01 = UnpackInternalData(smbInternalData2), internalData11 = UnpackInternalData(smbInternalData3);
+    float diffAccumSpeed = 0.0f, smbSpecAccumSpeed = 0.0f;
+    if (DIFF)
+        diffAccumSpeed = ApplyBilinearCustomWeights(internalData00.x, internalData10.x, internalData01.x, internalData11.x, smbOcclusionWeights);
+    if (SPEC)
+        smbSpecAccumSpeed = ApplyBilinearCustomWeights(internalData00.y, internalData10.y, internalData01.y, internalData11.y, smbOcclusionWeights);
+
+    // Footprint quality
+    float3 smbVprev = GetViewVectorPrev(c, Xprev, cameraDelta);
+    float NoVprev = Abs(Dot(N, smbVprev));
+    float sizeQuality = (NoVprev + 1e-3f) / (NoV + 1e-3f);
+    sizeQuality *= sizeQuality;
+    sizeQuality = Lerp(0.1f, 1.0f, Sat(sizeQuality));
+
+    float smbFootprintQuality = ApplyBilinearFilter(smbOcclusion0.z, smbOcclusion1.y, smbOcclusion2.y, smbOcclusion3.x, smbBilinearFilter);
+    smbFootprintQuality = Sqrt01(smbFootprintQuality);
+    smbFootprintQuality *= sizeQuality;
+
+    const float2 smbSamplePos = Sat(smbPixelUv) * rectSizePrev;
+
+    // ------------------------------------------------------------------------------------------------ specular
+    float specAccumSpeed = 0.0f, curvature = 0.0f, virtualHistoryAmount = 0.0f;
+    if (SPEC) {
+        float specHistoryConfidence = smbFootprintQuality;
+        smbSpecAccumSpeed *= Lerp(specHistoryConfidence, 1.0f, 1.0f / (1.0f + smbSpecAccumSpeed));
+        smbSpecAccumSpeed = Min(smbSpecAccumSpeed, c.gMaxAccumulatedFrameNum);
+
+        float4 spec = LoadRGBA16F(P.inSpec, px, py);
+
+        // Curvature estimation along predicted motion
+        {
+            float2 uvForZeroParallax = c.gOrthoMode == 0.0f ? smbPixelUv : pixelUv;
+            float2 deltaUv = uvForZeroParallax - GetScreenUv(c.gWorldToClipPrev, Xprev + cameraDelta);
+            deltaUv = deltaUv * rectSize;
+            deltaUv = deltaUv / Max(smbParallaxInPixels1, 1.0f / 256.0f);
+
+            float3 n10, x10;
+            {
+                float3 xv = ReconstructViewPosition(pixelUv + F2(1.0f, 0.0f) * rectSizeInv, frustum, 1.0f, c.gOrthoMode);
+                float3 x = RotateVector(c.gViewToWorld, xv);
+                float3 v = GetViewVector(c, x);
+                float3 o = c.gOrthoMode == 0.0f ? F3(0.0f) : x;
+                x10 = o + v * Dot(X - o, N) / Dot(N, v);
+                n10 = Xyz(s_Normal_Roughness[(ty + BORDER) * BUF_STRIDE + tx + BORDER + 1]);
+            }
+            float3 n01, x01;
+            {
+                float3 xv = ReconstructViewPosition(pixelUv + F2(0.0f, 1.0f) * rectSizeInv, frustum, 1.0f, c.gOrthoMode);
+                float3 x = RotateVector(c.gViewToWorld, xv);
+                float3 v = GetViewVector(c, x);
+                float3 o = c.gOrthoMode == 0.0f ? F3(0.0f) : x;
+                x01 = o + v * Dot(X - o, N) / Dot(N, v);
+                n01 = Xyz(s_Normal_Roughness[(ty + BORDER + 1) * BUF_STRIDE + tx + BORDER]);
+            }
+            float2 w = Abs(deltaUv) + 1.0f / 256.0f;
+            w = w / (w.x + w.y);
+            float3 x = x10 * w.x + x01 * w.y;
+            float3 n = Normalize(n10 * w.x + n01 * w.y);
+
+            // High parallax: flatten the surface on fast motion
+            float deltaUvLenFixed = smbParallaxInPixelsMin;
+            deltaUvLenFixed *= 1.0f + c.gFramerateScale * Bayer4x4((uint32_t)px, (uint32_t)py, c.gFrameIndex);
+
+            float2 motionUvHigh = pixelUv + deltaUv * deltaUvLenFixed * rectSizeInv;
+            motionUvHigh = (Floor(motionUvHigh * rectSize) + 0.5f) * rectSizeInv;
+
+            if (deltaUvLenFixed > 1.0f && IsInScreenNearest(motionUvHigh) != 0.0f) {
+                const float2 resolutionScale = ToF2(c.gResolutionScale);
+                const float2 uvMax = resolutionScale - ToF2(c.gResourceSizeInv) * 0.5f;
+                float2 uvScaled = F2(Min(motionUvHigh.x * resolutionScale.x, uvMax.x), Min(motionUvHigh.y * resolutionScale.y, uvMax.y));
+                int2 tz = NearestTexel(P.viewZ, uvScaled);
+                float zHigh = UnpackViewZ(c, LoadR32F(P.viewZ, tz.x, tz.y));
+                float3 xHigh = ReconstructViewPosition(motionUvHigh, frustum, zHigh, c.gOrthoMode);
+                xHigh = RotateVector(c.gViewToWorld, xHigh);
+                int2 tn = NearestTexel(P.normalRoughness, uvScaled);
+                float3 nHigh = Xyz(UnpackNormalAndRoughness(LoadR10G10B10A2(P.normalRoughness, tn.x, tn.y)));
+
+                float zError = Abs(zHigh - viewZ) * Rcp(Max(zHigh, viewZ));
+                bool cmp = zError < NRD_CURVATURE_Z_THRESHOLD;
+                n = cmp ? nHigh : n;
+                x = cmp ? xHigh : x;
+            }
+
+            float3 edge = x - X;
+            float edgeLenSq = LengthSquared(edge);
+            curvature = Dot(n - N, edge) * PositiveRcp(edgeLenSq);
+        }
+
+        // Virtual motion - coordinates
+        float3 Xvirtual = GetXvirtual(hitDistForTracking, curvature, X, Xprev, N, V, roughness);
+        float XvirtualLength = Length(Xvirtual);
+
+        float2 vmbPixelUv = GetScreenUv(c.gWorldToClipPrev, Xvirtual);
+        vmbPixelUv = materialID == c.gCameraAttachedReflectionMaterialID ? smbPixelUv : vmbPixelUv;
+
+        float2 vmbDelta = vmbPixelUv - smbPixelUv;
+        float vmbPixelsTraveled = Length(vmbDelta * rectSize);
+
+        // Virtual motion - roughness
+        Bilinear vmbBilinearFilter = GetBilinearFilter(vmbPixelUv, rectSizePrev);
+        const int vx = (int)vmbBilinearFilter.origin.x, vy = (int)vmbBilinearFilter.origin.y;
+        float2 relaxedRoughnessWeightParams = GetRelaxedRoughnessWeightParams(roughness * roughness, c.gRoughnessFraction, REBLUR_ROUGHNESS_SENSITIVITY_IN_TA);
+        float4 vmbRoughness = F4(FetchClampedR10G10B10A2(P.prevNormalRoughness, vx, vy).z, FetchClampedR10G10B10A2(P.prevNormalRoughness, vx + 1, vy).z,
+            FetchClampedR10G10B10A2(P.prevNormalRoughness, vx, vy + 1).z, FetchClampedR10G10B10A2(P.prevNormalRoughness, vx + 1, vy + 1).z);
+        float4 roughnessWeight;
+        roughnessWeight.x = ComputeNonExponentialWeightWithSigma(vmbRoughness.x * vmbRoughness.x, relaxedRoughnessWeightParams.x, relaxedRoughnessWeightParams.y, roughnessSigma);
+        roughnessWeight.y = ComputeNonExponentialWeightWithSigma(vmbRoughness.y * vmbRoughness.y, relaxedRoughnessWeightParams.x, relaxedRoughnessWeightParams.y, roughnessSigma);
+        roughnessWeight.z = ComputeNonExponentialWeightWithSigma(vmbRoughness.z * vmbRoughness.z, relaxedRoughnessWeightParams.x, relaxedRoughnessWeightParams.y, roughnessSigma);
+        roughnessWeight.w = ComputeNonExponentialWeightWithSigma(vmbRoughness.w * vmbRoughness.w, relaxedRoughnessWeightParams.x, relaxedRoughnessWeightParams.y, roughnessSigma);
+        float jitterFriendly = SmoothStep(1.0f, 0.0f, smbParallaxInPixelsMax);
+        roughnessWeight = F4(Lerp(jitterFriendly, 1.0f, roughnessWeight.x), Lerp(jitterFriendly, 1.0f, roughnessWeight.y), Lerp(jitterFriendly, 1.0f, roughnessWeight.z),
+            Lerp(jitterFriendly, 1.0f, roughnessWeight.w));
+        float virtualHistoryRoughnessBasedConfidence = ApplyBilinearFilter(roughnessWeight.x, roughnessWeight.y, roughnessWeight.z, roughnessWeight.w, vmbBilinearFilter);
+
+        // Virtual motion - normal: parallax; stochastic nearest tap of the bilinear footprint
+        const float2 resolutionScalePrev = ToF2(c.gResolutionScalePrev);
+        auto stochasticBilinearFetch = [&](float2 uv) {
+            Bilinear f = GetBilinearFilter(uv, rectSizePrev);
+            float2 rnd = rng.GetFloat2();
+            f.origin = f.origin + F2(Step(rnd.x, f.weights.x), Step(rnd.y, f.weights.y));
+            float2 uvs = ((f.origin + 0.5f) / rectSizePrev) * resolutionScalePrev;
+            int2 t = NearestTexel(P.prevNormalRoughness, uvs);
+            return UnpackNormalAndRoughness(LoadR10G10B10A2(P.prevNormalRoughness, t.x, t.y));
+        };
+        float4 vmbNormalAndRoughness = stochasticBilinearFetch(vmbPixelUv);
+        float3 vmbN = RotateVector(c.gWorldPrevToWorld, Xyz(vmbNormalAndRoughness));
+        float Dfactor = GetSpecularDominantFactor(NoV, roughness);
+        float virtualHistoryNormalBasedConfidence = 1.0f / (1.0f + 0.5f * Dfactor * Sat(Length(N - vmbN) - REBLUR_NORMAL_ULP) * vmbPixelsTraveled);
+
+        smbNavg = smbFootprintQuality == 0.0f ? vmbN : smbNavg;
+
+        // Virtual motion - disocclusion: plane distance and roughness
+        float4 vmbOcclusion;
+        {
+            float4 vmbOcclusionThreshold = F4(disocclusionThreshold * frustumSize);
+            vmbOcclusionThreshold = vmbOcclusionThreshold * Lerp(0.25f, 1.0f, NoV);
+            vmbOcclusionThreshold = vmbOcclusionThreshold * (Dot(vmbN, N) > REBLUR_ALMOST_ZERO_ANGLE ? 1.0f : 0.0f);
+            vmbOcclusionThreshold = vmbOcclusionThreshold * (Dot(vmbN, smbNavg) > REBLUR_ALMOST_ZERO_ANGLE ? 1.0f : 0.0f);
+            vmbOcclusionThreshold = vmbOcclusionThreshold * IsInScreenBilinear(vmbBilinearFilter.origin, rectSizePrev);
+            vmbOcclusionThreshold = vmbOcclusionThreshold - NRD_EPS;
+
+            float4 vmbViewZ = F4(UnpackViewZ(c, FetchClampedR32F(P.prevViewZ, vx, vy)), UnpackViewZ(c, FetchClampedR32F(P.prevViewZ, vx + 1, vy)),
+                UnpackViewZ(c, FetchClampedR32F(P.prevViewZ, vx, vy + 1)), UnpackViewZ(c, FetchClampedR32F(P.prevViewZ, vx + 1, vy + 1)));
+            float3 vmbVv = ReconstructViewPosition(vmbPixelUv, frustumPrev, 1.0f, 0.0f);
+            float3 vmbV = RotateVectorInverse(c.gWorldToViewPrev, vmbVv);
+            float NoXcurr = Dot(N, Xprev - cameraDelta);
+            float4 NoXprev = (c.gOrthoMode == 0.0f ? vmbViewZ : F4(c.gOrthoMode)) * (N.x * vmbV.x + N.y * vmbV.y) + vmbViewZ * (N.z * vmbV.z);
+            float4 vmbPlaneDist = Abs(NoXprev - NoXcurr);
+
+            vmbOcclusion = Step(vmbPlaneDist, vmbOcclusionThreshold);
+            vmbOcclusion = vmbOcclusion * Step(F4(0.5f), roughnessWeight);
+        }
+
+        // Virtual motion - disocclusion: materialID
+        float3 vmbInternalData00 = UnpackInternalData(FetchClampedR16U(P.prevInternalData, vx, vy));
+        float3 vmbInternalData10 = UnpackInternalData(FetchClampedR16U(P.prevInternalData, vx + 1, vy));
+        float3 vmbInternalData01 = UnpackInternalData(FetchClampedR16U(P.prevInternalData, vx, vy + 1));
+        float3 vmbInternalData11 = UnpackInternalData(FetchClampedR16U(P.prevInternalData, vx + 1, vy + 1));
+        vmbOcclusion.x *= CompareMaterials(materialID, vmbInternalData00.z, c.gSpecMinMaterial) ? 1.0f : 0.0f;
+        vmbOcclusion.y *= CompareMaterials(materialID, vmbInternalData10.z, c.gSpecMinMaterial) ? 1.0f : 0.0f;
+        vmbOcclusion.z *= CompareMaterials(materialID, vmbInternalData01.z, c.gSpecMinMaterial) ? 1.0f : 0.0f;
+        vmbOcclusion.w *= CompareMaterials(materialID, vmbInternalData11.z, c.gSpecMinMaterial) ? 1.0f : 0.0f;
+
+        fbits += vmbOcclusion.x * 16.0f;
+        fbits += vmbOcclusion.y * 32.0f;
+        fbits += vmbOcclusion.z * 64.0f;
+        fbits += vmbOcclusion.w * 128.0f;
+
+        // Virtual motion - accumulation speed
+        float4 vmbOcclusionWeights = GetBilinearCustomWeights(vmbBilinearFilter, vmbOcclusion);
+        float vmbSpecAccumSpeed = ApplyBilinearCustomWeights(vmbInternalData00.y, vmbInternalData10.y, vmbInternalData01.y, vmbInternalData11.y, vmbOcclusionWeights);
+
+        float vmbFootprintQuality = ApplyBilinearFilter(vmbOcclusion.x, vmbOcclusion.y, vmbOcclusion.z, vmbOcclusion.w, vmbBilinearFilter);
+        vmbFootprintQuality = Sqrt01(vmbFootprintQuality);
+        vmbSpecAccumSpeed *= Lerp(vmbFootprintQuality, 1.0f, 1.0f / (1.0f + vmbSpecAccumSpeed));
+
+        bool vmbAllowCatRom = Sum(vmbOcclusion) > 3.5f;
+        vmbAllowCatRom = vmbAllowCatRom && smbAllowCatRom;
+
+        float curvatureAngleTan = pixelSize * Abs(curvature);
+        curvatureAngleTan *= Max(vmbPixelsTraveled / Max(NoV, 0.01f), 1.0f);
+        curvatureAngleTan *= 2.0f;
+        float curvatureAngle = Atan(curvatureAngleTan);
+
+        float percentOfVolume = NRD_MAX_PERCENT_OF_LOBE_VOLUME / (1.0f + vmbSpecAccumSpeed);
+        float lobeTanHalfAngle = GetSpecularLobeTanHalfAngle(roughnessModified, percentOfVolume);
+        float lobeHalfAngle = Atan(lobeTanHalfAngle);
+        lobeHalfAngle = Max(lobeHalfAngle, NRD_NORMAL_ENCODING_ERROR);
+
+        float normalWeight = GetEncodingAwareNormalWeight(N, vmbN, lobeHalfAngle, curvatureAngle, REBLUR_NORMAL_ULP);
+        normalWeight = Lerp(SmoothStep(1.0f, 0.0f, vmbPixelsTraveled), 1.0f, normalWeight);
+        virtualHistoryNormalBasedConfidence = Min(virtualHistoryNormalBasedConfidence, normalWeight);
+
+        virtualHistoryAmount = SmoothStep(0.05f, 0.95f, Dfactor);
+        virtualHistoryAmount *= virtualHistoryNormalBasedConfidence;
+
+        // Virtual motion - virtual parallax difference
+        float virtualHistoryParallaxBasedConfidence;
+        {
+            float hitDistForTrackingPrev =
+                SampleLinearR16F(P.prevSpecHitDistForTracking, vmbPixelUv * resolutionScalePrev * F2(float(P.prevSpecHitDistForTracking.w), float(P.prevSpecHitDistForTracking.h)));
+            float3 XvirtualPrev = GetXvirtual(hitDistForTrackingPrev, curvature, X, Xprev, N, V, roughness);
+
+            float2 vmbPixelUvPrev = GetScreenUv(c.gWorldToClipPrev, XvirtualPrev);
+            vmbPixelUvPrev = materialID == c.gCameraAttachedReflectionMaterialID ? smbPixelUv : vmbPixelUvPrev;
+
+            float pixelSizeAtXvirtual = PixelRadiusToWorld(c.gUnproject, c.gOrthoMode, 1.0f, XvirtualLength);
+            float r = (lobeTanHalfAngle + curvatureAngle) * Min(hitDistForTracking, hitDistForTrackingPrev) / pixelSizeAtXvirtual;
+            float d = Length((vmbPixelUvPrev - vmbPixelUv) * rectSize);
+
+            r = Max(r, 0.1f);
+            virtualHistoryParallaxBasedConfidence = LinearStep(r, 0.0f, d);
+        }
+
+        // Virtual motion - normal & roughness prev-prev tests (1 iteration)
+        float stepBetweenTaps = Min(vmbPixelsTraveled * c.gFramerateScale, 2.0f) + vmbPixelsTraveled / 1.0f;
+        vmbDelta = vmbDelta * Rsqrt(LengthSquared(vmbDelta));
+        vmbDelta = vmbDelta / rectSizePrev;
+
+        relaxedRoughnessWeightParams = GetRelaxedRoughnessWeightParams(vmbNormalAndRoughness.w * vmbNormalAndRoughness.w, c.gRoughnessFraction, REBLUR_ROUGHNESS_SENSITIVITY_IN_TA);
+        {
+            const float i = 1.0f;
+            float2 vmbPixelUvPrev = vmbPixelUv + vmbDelta * i * stepBetweenTaps;
+            float4 vmbNormalAndRoughnessPrev = stochasticBilinearFetch(vmbPixelUvPrev);
+
+            float2 w;
+            w.x = GetEncodingAwareNormalWeight(Xyz(vmbNormalAndRoughness), Xyz(vmbNormalAndRoughnessPrev), lobeHalfAngle, curvatureAngle * (1.0f + i * stepBetweenTaps), REBLUR_NORMAL_ULP);
+            w.y = ComputeNonExponentialWeightWithSigma(vmbNormalAndRoughnessPrev.w * vmbNormalAndRoughnessPrev.w, relaxedRoughnessWeightParams.x, relaxedRoughnessWeightParams.y, roughnessSigma);
+            w = Lerp(F2(1.0f, 1.0f), w, Sat(stepBetweenTaps));
+            w = IsInScreenNearest(vmbPixelUvPrev) != 0.0f ? w : F2(1.0f, 1.0f);
+
+            virtualHistoryNormalBasedConfidence = Min(virtualHistoryNormalBasedConfidence, w.x);
+            virtualHistoryRoughnessBasedConfidence = Min(virtualHistoryRoughnessBasedConfidence, w.y);
+        }
+
+        float virtualHistoryConfidenceForSmbRelaxation = virtualHistoryNormalBasedConfidence * virtualHistoryRoughnessBasedConfidence;
+        float virtualHistoryConfidence = virtualHistoryNormalBasedConfidence * virtualHistoryRoughnessBasedConfidence * virtualHistoryParallaxBasedConfidence;
+        virtualHistoryAmount *= virtualHistoryRoughnessBasedConfidence;
+
+        // Sample surface history
+        HistoryFilter smbFilter = MakeHistoryFilter(smbSamplePos, smbOcclusionWeights, smbAllowCatRom);
+        float4 smbSpecHistory = FetchHistoryRGBA16F(smbFilter, P.historySpec);
+        float smbSpecFastHistory = FetchHistoryBilinearR16F(smbFilter, P.historySpecFast);
+
+        float surfaceHistoryConfidence;
+        {
+            float a = Atan(smbParallaxInPixelsMax * pixelSize / Length(X));
+            float nonLinearAccumSpeed = 1.0f / (1.0f + smbSpecAccumSpeed);
+            float h = Lerp(smbSpecHistory.w, spec.w, nonLinearAccumSpeed) * hitDistNormalization;
+
+            float tana0 = GetSpecularLobeTanHalfAngle(roughnessModified, NRD_MAX_PERCENT_OF_LOBE_VOLUME);
+            tana0 *= Lerp(NoV, 1.0f, roughnessModified);
+            tana0 *= nonLinearAccumSpeed;
+            tana0 /= GetHitDistFactor(h, frustumSize) + NRD_EPS;
+
+            float a0 = Atan(tana0);
+            a0 = Max(a0, NRD_NORMAL_ENCODING_ERROR);
+
+            float f = LinearStep(a0, 0.0f, a);
+            surfaceHistoryConfidence = Pow01(f, 4.0f);
+        }
+
+        // Responsive accumulation
+        float2 maxResponsiveFrameNum;
+        {
+            float responsiveFactor = RemapRoughnessToResponsiveFactor(c, roughness);
+            float smc = GetSpecMagicCurve(roughnessModified);
+            float2 f = F2(Dot(N, Normalize(smbNavg)), Dot(N, vmbN));
+            float e = Lerp(32.0f, 1.0f, smc) * (1.0f - responsiveFactor);
+            f = F2(Pow01(f.x, e), Pow01(f.y, e)) * Lerp(smc, 1.0f, responsiveFactor);
+            maxResponsiveFrameNum = F2(Max(c.gMaxAccumulatedFrameNum * f.x, c.gHistoryFixFrameNum), Max(c.gMaxAccumulatedFrameNum * f.y, c.gHistoryFixFrameNum));
+        }
+
+        float smbMaxFrameNum = c.gMaxAccumulatedFrameNum;
+        smbMaxFrameNum *= surfaceHistoryConfidence;
+        smbMaxFrameNum = Min(smbMaxFrameNum, maxResponsiveFrameNum.x);
+
+        float smbBoostedMaxFrameNum = Max(smbMaxFrameNum, c.gHistoryFixFrameNum * (1.0f - virtualHistoryConfidenceForSmbRelaxation));
+        float smbSpecAccumSpeedBoosted = Min(smbSpecAccumSpeed, smbBoostedMaxFrameNum);
+
+        float vmbMaxFrameNum = c.gMaxAccumulatedFrameNum;
+        vmbMaxFrameNum *= virtualHistoryConfidence;
+        vmbMaxFrameNum = Min(vmbMaxFrameNum, maxResponsiveFrameNum.y);
+
+        smbSpecAccumSpeed = Min(smbSpecAccumSpeed, smbMaxFrameNum);
+        vmbSpecAccumSpeed = Min(vmbSpecAccumSpeed, vmbMaxFrameNum);
+
+        float magic = vmbSpecAccumSpeed > smbSpecAccumSpeed ? 8.0f : 0.5f;
+        virtualHistoryAmount *= 1.0f + (vmbSpecAccumSpeed - smbSpecAccumSpeed) / (magic * Max(vmbSpecAccumSpeed, smbSpecAccumSpeed) + 1.0f);
+        virtualHistoryAmount = Sat(virtualHistoryAmount);
+
+        // Sample virtual history
+        HistoryFilter vmbFilter = MakeHistoryFilter(Sat(vmbPixelUv) * rectSizePrev, vmbOcclusionWeights, vmbAllowCatRom);
+        float4 vmbSpecHistory = FetchHistoryRGBA16F(vmbFilter, P.historySpec);
+        float vmbSpecFastHistory = FetchHistoryBilinearR16F(vmbFilter, P.historySpecFast);
+
+        smbSpecHistory = ClampNegativeToZero(smbSpecHistory);
+        vmbSpecHistory = ClampNegativeToZero(vmbSpecHistory);
+
+        float smbSpecNonLinearAccumSpeed = 1.0f / (1.0f + smbSpecAccumSpeed);
+        float vmbSpecNonLinearAccumSpeed = 1.0f / (1.0f + vmbSpecAccumSpeed);
+
+        float4 smbSpec = MixHistoryAndCurrent(c, smbSpecHistory, spec, smbSpecNonLinearAccumSpeed, roughnessModified);
+        float4 vmbSpec = MixHistoryAndCurrent(c, vmbSpecHistory, spec, vmbSpecNonLinearAccumSpeed, roughnessModified);
+        float4 specResult = Lerp(smbSpec, vmbSpec, virtualHistoryAmount);
+
+        specAccumSpeed = Lerp(smbSpecAccumSpeedBoosted, vmbSpecAccumSpeed, virtualHistoryAmount);
+        float4 specHistory = Lerp(smbSpecHistory, vmbSpecHistory, virtualHistoryAmount);
+
+        // Firefly suppressor
+        float specMaxRelativeIntensity = c.gFireflySuppressorMinRelativeScale + REBLUR_FIREFLY_SUPPRESSOR_MAX_RELATIVE_INTENSITY / (specAccumSpeed + 1.0f);
+        float specAntifireflyFactor = specAccumSpeed * c.gMaxBlurRadius * REBLUR_FIREFLY_SUPPRESSOR_RADIUS_SCALE;
+        specAntifireflyFactor /= 1.0f + specAntifireflyFactor;
+
+        float specLumaResult = GetLuma(specResult);
+        float specLumaClamped = Min(specLumaResult, GetLuma(specHistory) * specMaxRelativeIntensity);
+        specLumaClamped = Lerp(specLumaResult, specLumaClamped, specAntifireflyFactor);
+        specResult = ChangeLuma(specResult, specLumaClamped);
+
+        StoreRGBA16F(P.outSpec, px, py, specResult);
+
+        // Fast history
+        float smbSpecFastNonLinearAccumSpeed = GetNonLinearAccumSpeed(smbSpecAccumSpeed, c.gMaxFastAccumulatedFrameNum, surfaceHistoryConfidence);
+        float vmbSpecFastNonLinearAccumSpeed = GetNonLinearAccumSpeed(vmbSpecAccumSpeed, c.gMaxFastAccumulatedFrameNum, virtualHistoryConfidence);
+        float smbSpecFast = Lerp(smbSpecFastHistory, GetLuma(spec), smbSpecFastNonLinearAccumSpeed);
+        float vmbSpecFast = Lerp(vmbSpecFastHistory, GetLuma(spec), vmbSpecFastNonLinearAccumSpeed);
+        float specFastResult = Lerp(smbSpecFast, vmbSpecFast, virtualHistoryAmount);
+
+        float specFastClamped = Min(specFastResult, GetLuma(specHistory) * specMaxRelativeIntensity * REBLUR_FIREFLY_SUPPRESSOR_FAST_RELATIVE_INTENSITY);
+        specFastResult = Lerp(specFastResult, specFastClamped, specAntifireflyFactor);
+        StoreR16F(P.outSpecFast, px, py, specFastResult);
+    }
+
+    // DATA2: occlusion bits, curvature, virtual history amount (R32_UINT; diffuse-only keeps the low byte in R8_UINT)
+    {
+        uint32_t packed = PackData2(fbits, curvature, virtualHistoryAmount);
+        if (SPEC)
+            StoreR32U(P.outData2, px, py, packed);
+        else
+            StoreR8U(P.outData2, px, py, packed);
+    }
+
+    // ------------------------------------------------------------------------------------------------ diffuse
+    if (DIFF) {
+        float diffHistoryConfidence = smbFootprintQuality;
+        diffAccumSpeed *= Lerp(diffHistoryConfidence, 1.0f, 1.0f / (1.0f + diffAccumSpeed));
+        diffAccumSpeed = Min(diffAccumSpeed, c.gMaxAccumulatedFrameNum);
+
+        float4 diff = LoadRGBA16F(P.inDiff, px, py);
+
+        HistoryFilter smbFilter = MakeHistoryFilter(smbSamplePos, smbOcclusionWeights, smbAllowCatRom);
+        float4 smbDiffHistory = FetchHistoryRGBA16F(smbFilter, P.historyDiff);
+        float smbDiffFastHistory = FetchHistoryBilinearR16F(smbFilter, P.historyDiffFast);
+        smbDiffHistory = ClampNegativeToZero(smbDiffHistory);
+
+        float diffNonLinearAccumSpeed = 1.0f / (1.0f + diffAccumSpeed);
+        float4 diffResult = MixHistoryAndCurrent(c, smbDiffHistory, diff, diffNonLinearAccumSpeed);
+
+        float diffMaxRelativeIntensity = c.gFireflySuppressorMinRelativeScale + REBLUR_FIREFLY_SUPPRESSOR_MAX_RELATIVE_INTENSITY / (diffAccumSpeed + 1.0f);
+        float diffAntifireflyFactor = diffAccumSpeed * c.gMaxBlurRadius * REBLUR_FIREFLY_SUPPRESSOR_RADIUS_SCALE;
+        diffAntifireflyFactor /= 1.0f + diffAntifireflyFactor;
+
+        float diffLumaResult = GetLuma(diffResult);
+        float diffLumaClamped = Min(diffLumaResult, GetLuma(smbDiffHistory) * diffMaxRelativeIntensity);
+        diffLumaClamped = Lerp(diffLumaResult, diffLumaClamped, diffAntifireflyFactor);
+        diffResult = ChangeLuma(diffResult, diffLumaClamped);
+        StoreRGBA16F(P.outDiff, px, py, diffResult);
+
+        float diffFastAccumSpeed = Min(diffAccumSpeed, c.gMaxFastAccumulatedFrameNum);
+        float diffFastNonLinearAccumSpeed = 1.0f / (1.0f + diffFastAccumSpeed);
+        float diffFastResult = Lerp(smbDiffFastHistory, GetLuma(diff), diffFastNonLinearAccumSpeed);
+        float diffFastClamped = Min(diffFastResult, GetLuma(smbDiffHistory) * diffMaxRelativeIntensity * REBLUR_FIREFLY_SUPPRESSOR_FAST_RELATIVE_INTENSITY);
+        diffFastResult = Lerp(diffFastResult, diffFastClamped, diffAntifireflyFactor);
+        StoreR16F(P.outDiffFast, px, py, diffFastResult);
+    }
+
+    StoreData1<DIFF, SPEC>(P.outData1, px, py, diffAccumSpeed, specAccumSpeed);
+}
+
+template <bool DIFF, bool SPEC>
+static const char* LaunchTemporalAccumulation(const PassArgs& a) {
+    const ReblurCB& c = *(const ReblurCB*)a.constants;
+    if (c.gDiffCheckerboard != 2 || c.gSpecCheckerboard != 2)
+        return "REBLUR: checkerboard modes are not implemented in the HIP back-end yet";
+    if (c.gHasHistoryConfidence || c.gHasDisocclusionThresholdMix)
+        return "REBLUR: history-confidence / disocclusion-threshold-mix inputs are not implemented in the HIP back-end yet";
+    if (c.gRectOrigin.x != 0 || c.gRectOrigin.y != 0 || c.gResolutionScale.x != 1.0f || c.gResolutionScale.y != 1.0f || c.gResolutionScalePrev.x != 1.0f || c.gResolutionScalePrev.y != 1.0f)
+        return "REBLUR: dynamic resolution (rect != resource) is not implemented in the HIP back-end yet";
+    if (c.gOrthoMode != 0.0f)
+        return "REBLUR: orthographic projection is not supported (SURVEY.md section 8c)";
+
+    TaPlanes P = {};
+    uint32_t k = 0;
+    P.tiles = a.planes[k++];
+    P.normalRoughness = a.planes[k++];
+    P.viewZ = a.planes[k++];
+    P.mv = a.planes[k++];
+    P.prevViewZ = a.planes[k++];
+    P.prevNormalRoughness = a.planes[k++];
+    P.prevInternalData = a.planes[k++];
+    k++;           // disocclusion threshold mix (dummy)
+    if (DIFF) k++; // diffuse confidence (dummy)
+    if (SPEC) k++; // specular confidence (dummy)
+    if (DIFF) P.inDiff = a.planes[k++];
+    if (SPEC) P.inSpec = a.planes[k++];
+    if (DIFF) P.historyDiff = a.planes[k++];
+    if (SPEC) P.historySpec = a.planes[k++];
+    if (DIFF) P.historyDiffFast = a.planes[k++];
+    if (SPEC) P.historySpecFast = a.planes[k++];
+    if (SPEC) P.prevSpecHitDistForTracking = a.planes[k++];
+    if (SPEC) P.inSpecHitDistForTracking = a.planes[k++];
+    if (DIFF) P.outDiff = a.planes[k++];
+    if (SPEC) P.outSpec = a.planes[k++];
+    if (DIFF) P.outDiffFast = a.planes[k++];
+    if (SPEC) P.outSpecFast = a.planes[k++];
+    if (SPEC) P.outSpecHitDistForTracking = a.planes[k++];
+    P.outData1 = a.planes[k++];
+    P.outData2 = a.planes[k++];
+    if (k != a.planesNum)
+        return "REBLUR temporal accumulation: unexpected resource count";
+
+    dim3 grid = GridFor(c.gRectSizeMinusOne.x + 1, c.gRectSizeMinusOne.y + 1, TILE_X, TILE_Y);
+    hipLaunchKernelGGL((ReblurTemporalAccumulationKernel<DIFF, SPEC>), grid, dim3(TILE_X * TILE_Y), 0, a.stream, c, P);
+    return nullptr;
+}
+
+const PassEntry* GetReblurTemporalAccumulationPasses(uint32_t& num) {
+    static const PassEntry k[] = {
+        {"REBLUR_Diffuse_TemporalAccumulation.cs", LaunchTemporalAccumulation<true, false>},
+        {"REBLUR_Specular_TemporalAccumulation.cs", LaunchTemporalAccumulation<false, true>},
+        {"REBLUR_DiffuseSpecular_TemporalAccumulation.cs", LaunchTemporalAccumulation<true, true>},
+    };
+    num = sizeof(k) / sizeof(k[0]);
+    return k;
+}
+
+} // namespace nrdhip

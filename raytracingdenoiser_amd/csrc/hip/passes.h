@@ -16,7 +16,8 @@ struct PassArgs {
     hipStream_t stream;
 };
 
-typedef void (*PassLauncher)(const PassArgs& args);
+// returns nullptr on success, or a static message if the dispatch cannot be executed by this build (nothing is launched then)
+typedef const char* (*PassLauncher)(const PassArgs& args);
 
 struct PassEntry {
     const char* shaderFileName;

@@ -31,7 +31,14 @@ NRD_D T* TexelPtr(const Plane& p, int x, int y) {
 
 // ---- fp16 -------------------------------------------------------------------------------------------------------
 NRD_D float HalfBitsToFloat(uint16_t h) { return __half2float(__ushort_as_half(h)); }
-NRD_D uint16_t FloatToHalfBits(float f) { return __half_as_ushort(__float2half_rn(f)); }
+// The conversion is an opaque instruction on purpose: left to the compiler, "fp32 multiply -> convert" is fused into
+// v_fma_mixlo_f16, which rounds the exact product ONCE (to fp16) instead of twice (fp32, then fp16). That is a different
+// result whenever the fp32 product lands on an fp16 tie, and the numerics contract pins the two-step rounding.
+NRD_D uint16_t FloatToHalfBits(float f) {
+    uint32_t h;
+    asm("v_cvt_f16_f32 %0, %1" : "=v"(h) : "v"(f));
+    return (uint16_t)h;
+}
 
 // ---- R32_SFLOAT / R32_UINT / R16_UINT / R8_UINT -------------------------------------------------------------------
 NRD_D float LoadR32F(const Plane& p, int x, int y) { return *TexelPtr<const float>(p, x, y); }

@@ -1,0 +1,366 @@
+// REBLUR device-side shared pieces: compile-time settings, storage packing, per-signal helpers, history fetch.
+//   settings  : reference Shaders/Include/REBLUR_Config.hlsli:13-98
+//   packing   : reference Shaders/Include/REBLUR_Common.hlsli:13-80
+//   helpers   : reference Shaders/Include/REBLUR_Common.hlsli:84-361, Common.hlsli:226-656
+// Every formula keeps the operation order pinned in DESIGN.md "Numerics" so results are reproducible bit-for-bit.
+#pragma once
+
+#include "../common/pass_constants.h"
+#include "nrdmath.h"
+#include "planes.h"
+
+namespace nrdhip {
+
+typedef nrdc::ReblurConstants ReblurCB;
+
+#define REBLUR_MAX_ACCUM_FRAME_NUM 63.0f
+#define REBLUR_MAX_MATERIALID_NUM 15.0f
+#define REBLUR_PRE_BLUR_FRACTION_SCALE 2.0f
+#define REBLUR_PRE_BLUR_NON_LINEAR_ACCUM_SPEED (1.0f / (1.0f + 10.0f))
+#define REBLUR_BLUR_FRACTION_SCALE 1.0f
+#define REBLUR_POST_BLUR_FRACTION_SCALE 0.5f
+#define REBLUR_POST_BLUR_RADIUS_SCALE 2.0f
+#define REBLUR_NORMAL_ULP NRD_NORMAL_ENCODING_ERROR
+#define REBLUR_ALMOST_ZERO_ANGLE 0.01745240643728351f // cos( 89 deg )
+#define REBLUR_FIREFLY_SUPPRESSOR_MAX_RELATIVE_INTENSITY 38.0f
+#define REBLUR_FIREFLY_SUPPRESSOR_RADIUS_SCALE 0.1f
+#define REBLUR_FIREFLY_SUPPRESSOR_FAST_RELATIVE_INTENSITY 4.0f
+#define REBLUR_ANTI_FIREFLY_FILTER_RADIUS 4
+#define REBLUR_ANTI_FIREFLY_SIGMA_SCALE 2.0f
+#define REBLUR_ROUGHNESS_SENSITIVITY_IN_TA (NRD_ROUGHNESS_SENSITIVITY * 0.3f)
+#define REBLUR_SAMPLES_PER_FRAME 1.0f
+#define REBLUR_MAX_PERCENT_OF_LOBE_VOLUME_FOR_PRE_PASS 0.3f
+#define REBLUR_COLOR_CLAMPING_SIGMA_SCALE 2.0f
+
+enum SpatialMode { PRE_BLUR = 0, BLUR = 1, POST_BLUR = 2 };
+
+NRD_D float4 ToF4(nrdc::F4 v) { return F4(v.x, v.y, v.z, v.w); }
+NRD_D float3 ToF3(nrdc::F4 v) { return F3(v.x, v.y, v.z); }
+NRD_D float2 ToF2(nrdc::F2 v) { return F2(v.x, v.y); }
+
+// ---- Poisson-like 8-tap kernel (reference Common.hlsli:181-192) + Gaussian tap weight exp(-0.66 r^2) ------------------
+__device__ __constant__ const float g_Special8[8][3] = {{-1.0f, 0.0f, 1.0f}, {0.0f, 1.0f, 1.0f}, {1.0f, 0.0f, 1.0f}, {0.0f, -1.0f, 1.0f},
+    {-0.25f * 1.41421356f, 0.25f * 1.41421356f, 0.5f}, {0.25f * 1.41421356f, 0.25f * 1.41421356f, 0.5f}, {0.25f * 1.41421356f, -0.25f * 1.41421356f, 0.5f},
+    {-0.25f * 1.41421356f, -0.25f * 1.41421356f, 0.5f}};
+
+// ---- storage packing ----------------------------------------------------------------------------------------------
+NRD_D uint32_t PackInternalData(float diffAccumSpeed, float specAccumSpeed, float materialID) {
+    float tx = diffAccumSpeed / REBLUR_MAX_ACCUM_FRAME_NUM, ty = specAccumSpeed / REBLUR_MAX_ACCUM_FRAME_NUM, tz = materialID / REBLUR_MAX_MATERIALID_NUM;
+    uint32_t p = (uint32_t)floorf(Sat(tx) * 63.0f + 0.5f);
+    p |= (uint32_t)floorf(Sat(ty) * 63.0f + 0.5f) << 6;
+    p |= (uint32_t)floorf(Sat(tz) * 15.0f + 0.5f) << 12;
+    return p;
+}
+NRD_D float3 UnpackInternalData(uint32_t p) {
+    float3 t = F3(float(p & 63u) / 63.0f, float((p >> 6) & 63u) / 63.0f, float((p >> 12) & 15u) / 15.0f);
+    t.x *= REBLUR_MAX_ACCUM_FRAME_NUM;
+    t.y *= REBLUR_MAX_ACCUM_FRAME_NUM;
+    t.z *= REBLUR_MAX_MATERIALID_NUM;
+    return t;
+}
+// DATA1: RG8_UNORM for diffuse+specular, R8_UNORM for a single signal (both channels alias)
+template <bool DIFF, bool SPEC>
+NRD_D void StoreData1(const Plane& p, int x, int y, float diffAccumSpeed, float specAccumSpeed) {
+    float rx = Sat(diffAccumSpeed / REBLUR_MAX_ACCUM_FRAME_NUM), ry = Sat(specAccumSpeed / REBLUR_MAX_ACCUM_FRAME_NUM);
+    if (DIFF && SPEC)
+        StoreRG8Unorm(p, x, y, F2(rx, ry));
+    else
+        StoreR8Unorm(p, x, y, DIFF ? rx : ry);
+}
+template <bool DIFF, bool SPEC>
+NRD_D float2 LoadData1(const Plane& p, int x, int y) {
+    float2 v;
+    if (DIFF && SPEC)
+        v = LoadRG8Unorm(p, x, y);
+    else {
+        float s = LoadR8Unorm(p, x, y);
+        v = DIFF ? F2(s, 0.0f) : F2(s, s); // single-signal: .y aliases .x for specular; diffuse never reads .y
+    }
+    return v * REBLUR_MAX_ACCUM_FRAME_NUM;
+}
+NRD_D uint32_t PackData2(float fbits, float curvature, float virtualHistoryAmount) {
+    uint32_t p = (uint32_t)(fbits + 0.5f);
+    p |= (uint32_t)(Sat(virtualHistoryAmount) * 255.0f + 0.5f) << 8;
+    p |= (uint32_t)FloatToHalfBits(curvature) << 16;
+    return p;
+}
+NRD_D float2 UnpackData2(uint32_t p, uint32_t& bits) {
+    bits = p & 0xFFu;
+    return F2(float((p >> 8) & 0xFFu) / 255.0f, HalfBitsToFloat((uint16_t)(p >> 16)));
+}
+
+// ---- helpers ------------------------------------------------------------------------------------------------------
+NRD_D float UnpackViewZ(const ReblurCB& c, float z) { return Abs(z * c.gViewZScale); }
+NRD_D float3 GetViewVector(const ReblurCB& c, float3 X, bool isViewSpace = false) {
+    return c.gOrthoMode == 0.0f ? Normalize(-X) : (isViewSpace ? F3(0.0f, 0.0f, -1.0f) : ToF3(c.gViewVectorWorld));
+}
+NRD_D float3 GetViewVectorPrev(const ReblurCB& c, float3 Xprev, float3 cameraDelta) {
+    return c.gOrthoMode == 0.0f ? Normalize(cameraDelta - Xprev) : ToF3(c.gViewVectorWorldPrev);
+}
+NRD_D float PixelRadiusToWorld(float unproject, float orthoMode, float pixelRadius, float viewZ) { return pixelRadius * unproject * Lerp(viewZ, 1.0f, Abs(orthoMode)); }
+NRD_D float GetFrustumSize(float minRectDimMulUnproject, float orthoMode, float viewZ) { return minRectDimMulUnproject * Lerp(viewZ, 1.0f, Abs(orthoMode)); }
+NRD_D float GetHitDistFactor(float hitDist, float frustumSize) { return Sat(hitDist / frustumSize); }
+NRD_D float IsInScreenNearest(float2 uv) { return (uv.x > 0.0f && uv.y > 0.0f && uv.x < 1.0f && uv.y < 1.0f) ? 1.0f : 0.0f; }
+NRD_D float4 IsInScreenBilinear(float2 footprintOrigin, float2 rectSize) {
+    float4 p = F4(footprintOrigin.x, footprintOrigin.y, footprintOrigin.x + 1.0f, footprintOrigin.y + 1.0f);
+    float4 r = F4(p.x >= 0.0f ? 1.0f : 0.0f, p.y >= 0.0f ? 1.0f : 0.0f, p.z >= 0.0f ? 1.0f : 0.0f, p.w >= 0.0f ? 1.0f : 0.0f);
+    r = r * F4(p.x < rectSize.x ? 1.0f : 0.0f, p.y < rectSize.y ? 1.0f : 0.0f, p.z < rectSize.x ? 1.0f : 0.0f, p.w < rectSize.y ? 1.0f : 0.0f);
+    return F4(r.x * r.y, r.z * r.y, r.x * r.w, r.z * r.w);
+}
+NRD_D float GetSpecMagicCurve(float roughness, float power = 0.25f) {
+    float f = 1.0f - Exp2(-200.0f * roughness * roughness);
+    f *= Pow01(roughness, power);
+    return f;
+}
+NRD_D float ComputeParallaxInPixels(float3 X, float2 uvForZeroParallax, const float* mWorldToClip, float2 rectSize) {
+    float2 uv = GetScreenUv(mWorldToClip, X);
+    float2 parallaxInUv = uv - uvForZeroParallax;
+    return Length(parallaxInUv * rectSize);
+}
+NRD_D float3 GetXvirtual(float hitDist, float curvature, float3 X, float3 Xprev, float3 N, float3 V, float roughness) {
+    float4 D = GetSpecularDominantDirection(N, V, roughness);
+    float3 Iw = V;
+
+    float3 reflectionRay = Xyz(D) * hitDist;
+    float3 T, B;
+    GetBasis(N, T, B);
+    float3 O = F3(Dot(T, reflectionRay), Dot(B, reflectionRay), Dot(N, reflectionRay));
+    O.z = -O.z;
+
+    float mag = 1.0f / (2.0f * curvature * O.z - 1.0f);
+    float f = Length(X);
+    f *= 1.0f - Abs(Dot(N, V));
+    f *= Max(curvature, 0.0f);
+    mag *= 1.0f / (1.0f + f);
+
+    float3 I = O * mag;
+    Iw = Iw * Length(I);
+
+    float closenessToSurface = Sat(Length(Iw) / (hitDist + NRD_EPS));
+    float3 origin = Lerp(Xprev, X, closenessToSurface * D.w);
+    return origin - Iw * D.w;
+}
+NRD_D float2 GetKernelSampleCoordinates(const float* mToClip, float3 offset, float3 X, float3 T, float3 B, float4 rotator) {
+    float2 o = RotateVector(rotator, F2(offset.x, offset.y));
+    float3 p = X + T * o.x + B * o.y;
+    float4 clip4 = ProjectiveTransform(mToClip, p);
+    float3 clip = F3(clip4.x, clip4.y, clip4.w);
+    clip.x /= clip.z;
+    clip.y /= clip.z;
+    clip.y = -clip.y;
+    return F2(clip.x * 0.5f + 0.5f, clip.y * 0.5f + 0.5f);
+}
+NRD_D float GetNormalWeightParam(float nonLinearAccumSpeed, float lobeAngleFraction, float roughness = 1.0f) {
+    float percentOfVolume = NRD_MAX_PERCENT_OF_LOBE_VOLUME * Lerp(lobeAngleFraction, 1.0f, nonLinearAccumSpeed);
+    float tanHalfAngle = GetSpecularLobeTanHalfAngle(roughness, percentOfVolume);
+    float angle = Atan(tanHalfAngle);
+    angle = Max(angle, NRD_NORMAL_ENCODING_ERROR);
+    return 1.0f / angle;
+}
+NRD_D float2 GetGeometryWeightParams(float planeDistSensitivity, float frustumSize, float3 Xv, float3 Nv) {
+    float norm = planeDistSensitivity * frustumSize;
+    float a = 1.0f / norm;
+    float b = Dot(Nv, Xv) * a;
+    return F2(a, -b);
+}
+NRD_D float2 GetHitDistanceWeightParams(float hitDist, float nonLinearAccumSpeed, float roughness = 1.0f) {
+    float smc = GetSpecMagicCurve(roughness);
+    float norm = Lerp(0.0005f, 1.0f, Min(nonLinearAccumSpeed, smc));
+    float a = 1.0f / norm;
+    float b = hitDist * a;
+    return F2(a, -b);
+}
+NRD_D float2 GetRoughnessWeightParams(float roughness, float fraction, float sensitivity = NRD_ROUGHNESS_SENSITIVITY) {
+    float a = 1.0f / Lerp(sensitivity, 1.0f, Sat(roughness * fraction));
+    float b = roughness * a;
+    return F2(a, -b);
+}
+NRD_D float2 GetRelaxedRoughnessWeightParams(float m, float fraction = 1.0f, float sensitivity = NRD_ROUGHNESS_SENSITIVITY) {
+    float a = 1.0f / Lerp(sensitivity, 1.0f, Lerp(m * m, m, fraction));
+    float b = m * a;
+    return F2(a, -b);
+}
+NRD_D float ExpApprox(float x) { return Rcp(x * x - x + 1.0f); }
+NRD_D float ComputeExponentialWeight(float x, float px, float py) { return ExpApprox(-NRD_EXP_WEIGHT_DEFAULT_SCALE * Abs(x * px + py)); }
+NRD_D float ComputeNonExponentialWeight(float x, float px, float py) { return SmoothStep(1.0f, 0.0f, Abs(x * px + py)); }
+NRD_D float ComputeNonExponentialWeightWithSigma(float x, float px, float py, float sigma) { return SmoothStep(1.0f, 0.0f, Abs(x * px + py) - sigma * px); }
+NRD_D float ComputeWeight(float x, float px, float py) { return ComputeNonExponentialWeight(x, px, py); }
+NRD_D float GetGaussianWeight(float r) { return Exp(-0.66f * r * r); }
+NRD_D float GetEncodingAwareNormalWeight(float3 Ncurr, float3 Nprev, float maxAngle, float curvatureAngle, float thresholdAngle) {
+    float cosa = Dot(Ncurr, Nprev);
+    float angle = AcosApprox(cosa);
+    return SmoothStep01(1.0f - (angle - curvatureAngle - thresholdAngle) / maxAngle);
+}
+NRD_D float GetDisocclusionThreshold(float disocclusionThreshold, float frustumSize, float NoV) { return frustumSize * Sat(disocclusionThreshold / Max(0.01f, NoV)); }
+NRD_D bool CompareMaterials(float m0, float m, float minm) { return Max(m0, minm) == Max(m, minm); }
+
+NRD_D float GetMinAllowedLimitForHitDistNonLinearAccumSpeed(const ReblurCB& c, float roughness) {
+    float frameNum = 0.5f * GetSpecMagicCurve(roughness) * c.gMaxAccumulatedFrameNum;
+    return 1.0f / (1.0f + frameNum);
+}
+NRD_D float GetFadeBasedOnAccumulatedFrames(const ReblurCB& c, float accumSpeed) {
+    float a = c.gHistoryFixFrameNum * 2.0f / 3.0f + 1e-6f;
+    float b = c.gHistoryFixFrameNum * 4.0f / 3.0f + 2e-6f;
+    return LinearStep(a, b, accumSpeed);
+}
+NRD_D float GetNonLinearAccumSpeed(float accumSpeed, float maxAccumSpeed, float confidence) { return Max(1.0f - confidence, 1.0f / (1.0f + Min(accumSpeed, maxAccumSpeed))); }
+NRD_D float RemapRoughnessToResponsiveFactor(const ReblurCB& c, float roughness) {
+    float amount = (roughness + NRD_EPS) / (c.gResponsiveAccumulationRoughnessThreshold + NRD_EPS);
+    return SmoothStep01(amount);
+}
+NRD_D float GetLumaScale(float currLuma, float newLuma) { return (newLuma + NRD_EPS) / (currLuma + NRD_EPS); }
+NRD_D float4 MixHistoryAndCurrent(const ReblurCB& c, float4 history, float4 current, float f, float roughness = 1.0f) {
+    float4 r;
+    r.x = Lerp(history.x, current.x, f);
+    r.y = Lerp(history.y, current.y, f);
+    r.z = Lerp(history.z, current.z, f);
+    r.w = Lerp(history.w, current.w, Max(f, GetMinAllowedLimitForHitDistNonLinearAccumSpeed(c, roughness)));
+    return r;
+}
+NRD_D float GetLuma(float4 v) { return v.x; }
+NRD_D float4 ChangeLuma(float4 v, float newLuma) {
+    float s = GetLumaScale(GetLuma(v), newLuma);
+    return F4(v.x * s, v.y * s, v.z * s, v.w);
+}
+NRD_D float4 ClampNegativeToZero(float4 v) {
+    float3 rgb = LinearToYCoCg(YCoCgToLinear(Xyz(v)));
+    return F4(rgb, Sat(v.w));
+}
+NRD_D float ComputeAntilag(const ReblurCB& c, float history, float avg, float sigma, float accumSpeed) {
+    float h = history, a = avg;
+    float s = sigma * c.gAntilagParams.x;
+    float magic = c.gAntilagParams.y * c.gFramerateScale * c.gFramerateScale;
+    float hc = ColorClamp(a, s, h);
+    float d = Abs(h - hc) / (Max(h, hc) + NRD_EPS);
+    return 1.0f / (1.0f + d * accumSpeed / magic);
+}
+NRD_D void GetKernelBasis(float3 D, float3 N, float3& T, float3& B) {
+    GetBasis(N, T, B);
+    if (Abs(Dot(D, N)) < 0.999f) {
+        float3 R = Reflect(-D, N);
+        T = Normalize(Cross(N, R));
+        B = Cross(R, T);
+    }
+}
+NRD_D float2 GetTemporalAccumulationParams(const ReblurCB& c, float isInScreenMulFootprintQuality, float accumSpeed) {
+    accumSpeed *= REBLUR_SAMPLES_PER_FRAME;
+    float w = isInScreenMulFootprintQuality;
+    w *= accumSpeed / (1.0f + accumSpeed);
+    return F2(w, 1.0f + 3.0f * c.gFramerateScale * w);
+}
+
+// ---- clamp-addressed fetches (what a clamp sampler / gather does at the border) ------------------------------------------
+NRD_D int ClampI(int x, int a, int b) { return x < a ? a : (x > b ? b : x); }
+NRD_D float FetchClampedR32F(const Plane& p, int x, int y) { return LoadR32F(p, ClampI(x, 0, p.w - 1), ClampI(y, 0, p.h - 1)); }
+NRD_D float FetchClampedR16F(const Plane& p, int x, int y) { return LoadR16F(p, ClampI(x, 0, p.w - 1), ClampI(y, 0, p.h - 1)); }
+NRD_D float4 FetchClampedRGBA16F(const Plane& p, int x, int y) { return LoadRGBA16F(p, ClampI(x, 0, p.w - 1), ClampI(y, 0, p.h - 1)); }
+NRD_D float4 FetchClampedR10G10B10A2(const Plane& p, int x, int y) { return LoadR10G10B10A2(p, ClampI(x, 0, p.w - 1), ClampI(y, 0, p.h - 1)); }
+NRD_D uint32_t FetchClampedR16U(const Plane& p, int x, int y) { return LoadR16U(p, ClampI(x, 0, p.w - 1), ClampI(y, 0, p.h - 1)); }
+// zero outside (Texture2D::Load / operator[])
+NRD_D float4 LoadRGBA16FOrZero(const Plane& p, int x, int y) { return InBounds(p, x, y) ? LoadRGBA16F(p, x, y) : F4(0.0f); }
+NRD_D float LoadR16FOrZero(const Plane& p, int x, int y) { return InBounds(p, x, y) ? LoadR16F(p, x, y) : 0.0f; }
+NRD_D float4 LoadR10G10B10A2OrZero(const Plane& p, int x, int y) { return InBounds(p, x, y) ? LoadR10G10B10A2(p, x, y) : F4(0.0f); }
+
+// SampleLevel( gNearestClamp, uv, 0 ): texel index
+NRD_D int2 NearestTexel(const Plane& p, float2 uv) {
+    return make_int2(ClampI((int)floorf(uv.x * float(p.w)), 0, p.w - 1), ClampI((int)floorf(uv.y * float(p.h)), 0, p.h - 1));
+}
+
+// SampleLevel( gLinearClamp, ... ) with the position in TEXEL units; weights in fp32, fixed evaluation order
+struct LinearTaps {
+    int x0, y0;
+    float w00, w10, w01, w11;
+};
+NRD_D LinearTaps MakeLinearTaps(float2 pos) {
+    float tx = pos.x - 0.5f, ty = pos.y - 0.5f;
+    float fx0 = floorf(tx), fy0 = floorf(ty);
+    float fx = tx - fx0, fy = ty - fy0;
+    LinearTaps t;
+    t.x0 = (int)fx0;
+    t.y0 = (int)fy0;
+    t.w00 = (1.0f - fx) * (1.0f - fy);
+    t.w10 = fx * (1.0f - fy);
+    t.w01 = (1.0f - fx) * fy;
+    t.w11 = fx * fy;
+    return t;
+}
+NRD_D float4 SampleLinearRGBA16F(const Plane& p, float2 pos) {
+    LinearTaps t = MakeLinearTaps(pos);
+    float4 s00 = FetchClampedRGBA16F(p, t.x0, t.y0), s10 = FetchClampedRGBA16F(p, t.x0 + 1, t.y0), s01 = FetchClampedRGBA16F(p, t.x0, t.y0 + 1),
+           s11 = FetchClampedRGBA16F(p, t.x0 + 1, t.y0 + 1);
+    return s00 * t.w00 + s10 * t.w10 + s01 * t.w01 + s11 * t.w11;
+}
+NRD_D float SampleLinearR16F(const Plane& p, float2 pos) {
+    LinearTaps t = MakeLinearTaps(pos);
+    float s00 = FetchClampedR16F(p, t.x0, t.y0), s10 = FetchClampedR16F(p, t.x0 + 1, t.y0), s01 = FetchClampedR16F(p, t.x0, t.y0 + 1), s11 = FetchClampedR16F(p, t.x0 + 1, t.y0 + 1);
+    return s00 * t.w00 + s10 * t.w10 + s01 * t.w01 + s11 * t.w11;
+}
+
+// ---- history fetch: Catmull-Rom (12 taps as 5 bilinear fetches) with fallback to custom-weight bilinear ---------------------
+struct HistoryFilter {
+    float4 w;
+    float w4, sum;
+    float2 p0, p1, p2, p3, p4; // texel units
+    int ox, oy;
+    float4 bw;
+};
+NRD_D HistoryFilter MakeHistoryFilter(float2 samplePos, float4 bilinearCustomWeights, bool useBicubic) {
+    const float S = NRD_CATROM_SHARPNESS;
+    HistoryFilter h;
+    float2 centerPos = Floor(samplePos - 0.5f) + 0.5f;
+    float2 f = Sat(samplePos - centerPos);
+    float2 w0 = f * (f * (f * -S + 2.0f * S) - S);
+    float2 w1 = f * (f * (f * (2.0f - S) - (3.0f - S))) + 1.0f;
+    float2 w2 = f * (f * (f * -(2.0f - S) + (3.0f - 2.0f * S)) + S);
+    float2 w3 = f * (f * (f * S - S));
+    float2 w12 = w1 + w2;
+    float2 tc = w2 / w12;
+    float4 w = F4(w12.x * w0.y, w0.x * w12.y, w12.x * w12.y, w3.x * w12.y);
+    float w4 = w12.x * w3.y;
+    h.w = useBicubic ? w : bilinearCustomWeights;
+    h.w4 = useBicubic ? w4 : 0.0f;
+    h.sum = Sum(h.w) + h.w4;
+    if (useBicubic) {
+        h.p0 = centerPos + F2(tc.x, -1.0f);
+        h.p1 = centerPos + F2(-1.0f, tc.y);
+        h.p2 = centerPos + F2(tc.x, tc.y);
+        h.p3 = centerPos + F2(2.0f, tc.y);
+        h.p4 = centerPos + F2(tc.x, 2.0f);
+    } else {
+        h.p0 = centerPos;
+        h.p1 = centerPos + F2(1.0f, 0.0f);
+        h.p2 = centerPos + F2(0.0f, 1.0f);
+        h.p3 = centerPos + F2(1.0f, 1.0f);
+        h.p4 = centerPos + f;
+    }
+    h.ox = (int)centerPos.x;
+    h.oy = (int)centerPos.y;
+    h.bw = bilinearCustomWeights;
+    return h;
+}
+NRD_D float4 FetchHistoryRGBA16F(const HistoryFilter& h, const Plane& tex) {
+    float4 color = SampleLinearRGBA16F(tex, h.p0) * h.w.x;
+    color = color + SampleLinearRGBA16F(tex, h.p1) * h.w.y;
+    color = color + SampleLinearRGBA16F(tex, h.p2) * h.w.z;
+    color = color + SampleLinearRGBA16F(tex, h.p3) * h.w.w;
+    color = color + SampleLinearRGBA16F(tex, h.p4) * h.w4;
+    return h.sum < 0.0001f ? F4(0.0f) : color / h.sum;
+}
+NRD_D float FetchHistoryR16F(const HistoryFilter& h, const Plane& tex) {
+    float color = SampleLinearR16F(tex, h.p0) * h.w.x;
+    color += SampleLinearR16F(tex, h.p1) * h.w.y;
+    color += SampleLinearR16F(tex, h.p2) * h.w.z;
+    color += SampleLinearR16F(tex, h.p3) * h.w.w;
+    color += SampleLinearR16F(tex, h.p4) * h.w4;
+    return h.sum < 0.0001f ? 0.0f : color / h.sum;
+}
+NRD_D float FetchHistoryBilinearR16F(const HistoryFilter& h, const Plane& tex) {
+    float color = LoadR16FOrZero(tex, h.ox, h.oy) * h.bw.x;
+    color += LoadR16FOrZero(tex, h.ox + 1, h.oy) * h.bw.y;
+    color += LoadR16FOrZero(tex, h.ox, h.oy + 1) * h.bw.z;
+    color += LoadR16FOrZero(tex, h.ox + 1, h.oy + 1) * h.bw.w;
+    float s = Sum(h.bw);
+    return s < 0.0001f ? 0.0f : color / s;
+}
+
+} // namespace nrdhip

@@ -1,0 +1,238 @@
+"""Synthetic G-buffer + 1-rpp noisy signal generator: the input side of the path.
+
+An analytic scene (ground plane y = 0, three spheres, sky) seen by a slowly dollying / yawing left-handed pinhole
+camera, "path traced" with one diffuse and one specular bounce ray per pixel against the same analytic primitives.
+Outputs are packed exactly as an application would hand them to NRD:
+  IN_VIEWZ R32F | IN_NORMAL_ROUGHNESS R10G10B10A2 (NRD_FrontEnd_PackNormalAndRoughness, reference NRD.hlsli:640-667)
+  IN_MV RGBA16F | IN_DIFF/SPEC_RADIANCE_HITDIST RGBA16F (REBLUR_FrontEnd_PackRadianceAndNormHitDist, NRD.hlsli:732-743,
+  hit distances normalised with REBLUR_FrontEnd_GetNormHitDist, NRD.hlsli:722-727) | IN_PENUMBRA R16F for SIGMA.
+Pure torch, device-agnostic: tests generate on the CPU (and feed the same tensors to the oracle and to the GPU), the
+benchmark generates directly in HBM. Not part of the denoiser.
+"""
+import math
+
+import torch
+
+SKY_VIEWZ = 1.0e6  # > CommonSettings::denoisingRange (5e5): exercises the tile early-outs
+HIT_DIST_PARAMS = (3.0, 0.1, 20.0, -25.0)
+FP16_MAX = 65504.0
+
+SPHERES = [  # centre xyz, radius, albedo rgb, roughness
+    ((-1.6, 0.9, 4.5), 0.9, (0.9, 0.25, 0.2), 0.15),
+    ((0.3, 0.6, 3.2), 0.6, (0.2, 0.7, 0.9), 0.45),
+    ((1.9, 1.2, 5.5), 1.2, (0.85, 0.8, 0.3), 0.05),
+]
+LIGHT_DIR = (0.35, 0.8, -0.48)  # direction TO the sun (normalised below)
+
+
+class Camera:
+    """LH camera: +x right, +y up, +z forward; clip = viewToClip * view (D3D style, depth = z / w)."""
+
+    def __init__(self, width, height, frame, fov_y_deg=60.0, z_near=0.1, z_far=1000.0, static=False):
+        self.width, self.height = width, height
+        t = 0.0 if static else float(frame)
+        yaw = math.radians(0.1 * t) + math.radians(8.0)
+        pitch = math.radians(-9.0)
+        self.pos = (0.2 + 0.004 * t, 1.5, -1.0 + 0.01 * t)
+        cy, sy, cp, sp = math.cos(yaw), math.sin(yaw), math.cos(pitch), math.sin(pitch)
+        fwd = (sy * cp, sp, cy * cp)
+        right = (cy, 0.0, -sy)
+        up = (fwd[1] * right[2] - fwd[2] * right[1], fwd[2] * right[0] - fwd[0] * right[2], fwd[0] * right[1] - fwd[1] * right[0])
+        self.right, self.up, self.fwd = right, up, fwd
+        f = 1.0 / math.tan(math.radians(fov_y_deg) * 0.5)
+        a = width / height
+        self.fx, self.fy = f / a, f
+        # column-major 4x4
+        self.view_to_clip = [self.fx, 0, 0, 0, 0, self.fy, 0, 0, 0, 0, z_far / (z_far - z_near), 1.0, 0, 0, -z_near * z_far / (z_far - z_near), 0]
+        rows = (right, up, fwd)
+        tr = [-(r[0] * self.pos[0] + r[1] * self.pos[1] + r[2] * self.pos[2]) for r in rows]
+        self.world_to_view = [right[0], up[0], fwd[0], 0, right[1], up[1], fwd[1], 0, right[2], up[2], fwd[2], 0, tr[0], tr[1], tr[2], 1.0]
+
+
+def _hash_uniform(x, y, frame, seed):
+    """Integer hash of (x, y, frame, seed) -> float32 in (0, 1); int64 arithmetic so CPU and GPU agree bit-for-bit."""
+    m = 0xFFFFFFFF
+    h = (x * 0x9E3779B1 + y * 0x85EBCA77 + frame * 0xC2B2AE3D + seed * 0x27D4EB2F + 0x165667B1) & m
+    h = ((h ^ (h >> 15)) * 0x2C1B3C6D) & m
+    h = ((h ^ (h >> 12)) * 0x297A2D39) & m
+    h = h ^ (h >> 15)
+    return ((h >> 8).to(torch.float32) + 0.5) * (1.0 / 16777216.0)
+
+
+def _dot(a, b):
+    return (a * b).sum(-1)
+
+
+def _normalize(v):
+    return v / torch.sqrt(_dot(v, v)).clamp_min(1e-20).unsqueeze(-1)
+
+
+def _trace(o, d, dev):
+    """Nearest hit of rays o + t d (d need not be normalised) with the scene. Returns t (inf on miss), normal, albedo, roughness."""
+    shape = o.shape[:-1]
+    t_best = torch.full(shape, float("inf"), device=dev)
+    n_best = torch.zeros(shape + (3,), device=dev)
+    alb = torch.zeros(shape + (3,), device=dev)
+    rough = torch.zeros(shape, device=dev)
+
+    # ground plane y = 0 with a roughness / albedo checker
+    dy = d[..., 1]
+    tp = torch.where(dy < -1e-6, -o[..., 1] / dy.clamp(max=-1e-6), torch.full_like(dy, float("inf")))
+    tp = torch.where(tp > 1e-3, tp, torch.full_like(tp, float("inf")))
+    hit = tp < t_best
+    p = o + d * torch.where(hit, tp, torch.zeros_like(tp)).unsqueeze(-1)
+    checker = ((torch.floor(p[..., 0] * 0.5) + torch.floor(p[..., 2] * 0.5)) % 2.0) != 0
+    t_best = torch.where(hit, tp, t_best)
+    n_best = torch.where(hit.unsqueeze(-1), torch.tensor([0.0, 1.0, 0.0], device=dev).expand_as(n_best), n_best)
+    plane_alb = torch.where(checker.unsqueeze(-1), torch.tensor([0.75, 0.75, 0.75], device=dev), torch.tensor([0.3, 0.32, 0.35], device=dev))
+    alb = torch.where(hit.unsqueeze(-1), plane_alb, alb)
+    rough = torch.where(hit, torch.where(checker, torch.full_like(rough, 0.9), torch.full_like(rough, 0.25)), rough)
+
+    for (c, r, a, ro) in SPHERES:
+        cc = torch.tensor(c, device=dev)
+        oc = o - cc
+        A = _dot(d, d)
+        B = 2.0 * _dot(d, oc)
+        C = _dot(oc, oc) - r * r
+        disc = B * B - 4.0 * A * C
+        sq = torch.sqrt(disc.clamp_min(0.0))
+        t0 = (-B - sq) / (2.0 * A)
+        ts = torch.where((disc > 0) & (t0 > 1e-3), t0, torch.full_like(t0, float("inf")))
+        hit = ts < t_best
+        ph = o + d * torch.where(hit, ts, torch.zeros_like(ts)).unsqueeze(-1)
+        n = (ph - cc) / r
+        t_best = torch.where(hit, ts, t_best)
+        n_best = torch.where(hit.unsqueeze(-1), n, n_best)
+        alb = torch.where(hit.unsqueeze(-1), torch.tensor(a, device=dev).expand_as(alb), alb)
+        rough = torch.where(hit, torch.full_like(rough, ro), rough)
+    return t_best, n_best, alb, rough
+
+
+def _sky(d, dev):
+    up = d[..., 1].clamp(0.0, 1.0).unsqueeze(-1)
+    return torch.tensor([0.35, 0.5, 0.8], device=dev) * (0.4 + 0.6 * up)
+
+
+def _shade(p, n, alb, dev):
+    """Direct sun (with hard shadow) + ambient: the 'radiance' a bounce ray brings back."""
+    L = _normalize(torch.tensor(LIGHT_DIR, device=dev)).expand_as(n)
+    ts, _, _, _ = _trace(p + n * 1e-3, L, dev)
+    lit = torch.isinf(ts).to(torch.float32)
+    ndl = _dot(n, L).clamp_min(0.0) * lit
+    return alb * (2.5 * ndl.unsqueeze(-1) + 0.15)
+
+
+def _basis(n):
+    s = torch.where(n[..., 2] >= 0, torch.ones_like(n[..., 2]), -torch.ones_like(n[..., 2]))
+    a = -1.0 / (s + n[..., 2])
+    b = n[..., 0] * n[..., 1] * a
+    t = torch.stack([1.0 + s * n[..., 0] * n[..., 0] * a, s * b, -s * n[..., 0]], -1)
+    bt = torch.stack([b, s + n[..., 1] * n[..., 1] * a, -n[..., 1]], -1)
+    return t, bt
+
+
+def _oct_encode(n):
+    n = n / n.abs().sum(-1, keepdim=True)
+    wrap = (1.0 - n[..., [1, 0]].abs()) * torch.where(n[..., :2] >= 0, torch.ones_like(n[..., :2]), -torch.ones_like(n[..., :2]))
+    xy = torch.where((n[..., 2] >= 0).unsqueeze(-1), n[..., :2], wrap)
+    return xy * 0.5 + 0.5
+
+
+def pack_normal_roughness(n, roughness, material_id):
+    """NRD_FrontEnd_PackNormalAndRoughness -> R10G10B10A2_UNORM words (int32 tensor)."""
+    e = _oct_encode(n)
+    q = lambda v, m: torch.floor(v.clamp(0.0, 1.0) * m + 0.5).to(torch.int64)
+    word = q(e[..., 0], 1023.0) | (q(e[..., 1], 1023.0) << 10) | (q(roughness, 1023.0) << 20) | (q(material_id / 3.0, 3.0) << 30)
+    word = torch.where(word >= 2 ** 31, word - 2 ** 32, word)
+    return word.to(torch.int32)
+
+
+def _ycocg(c):
+    y = c[..., 0] * 0.25 + c[..., 1] * 0.5 + c[..., 2] * 0.25
+    co = c[..., 0] * 0.5 - c[..., 2] * 0.5
+    cg = -c[..., 0] * 0.25 + c[..., 1] * 0.5 - c[..., 2] * 0.25
+    return torch.stack([y, co, cg], -1)
+
+
+def _norm_hit_dist(hit_dist, view_z, roughness):
+    A, B, C, D = HIT_DIST_PARAMS
+    f = (A + view_z.abs() * B) * (1.0 + (C - 1.0) * torch.exp2(D * roughness * roughness).clamp(0.0, 1.0))
+    return (hit_dist / f).clamp(0.0, 1.0)
+
+
+def render_frame(width, height, frame, device="cpu", static_camera=False, noise=True, seed=7, want=("reblur",)):
+    """Returns a dict with the packed planes and the camera (for CommonSettings)."""
+    dev = torch.device(device)
+    cam = Camera(width, height, frame, static=static_camera)
+    ys, xs = torch.meshgrid(torch.arange(height, device=dev), torch.arange(width, device=dev), indexing="ij")
+    u = (xs.to(torch.float32) + 0.5) / width
+    v = (ys.to(torch.float32) + 0.5) / height
+    dvx = (2.0 * u - 1.0) / cam.fx
+    dvy = (1.0 - 2.0 * v) / cam.fy
+    R = torch.tensor([cam.right, cam.up, cam.fwd], device=dev, dtype=torch.float32)  # rows: view axes in world space
+    d = dvx.unsqueeze(-1) * R[0] + dvy.unsqueeze(-1) * R[1] + R[2]  # view z = 1 => ray parameter == viewZ
+    o = torch.tensor(cam.pos, device=dev, dtype=torch.float32).expand_as(d)
+
+    t, n, alb, rough = _trace(o, d, dev)
+    is_sky = torch.isinf(t)
+    view_z = torch.where(is_sky, torch.full_like(t, SKY_VIEWZ), t)
+    n = torch.where(is_sky.unsqueeze(-1), torch.tensor([0.0, 0.0, -1.0], device=dev).expand_as(n), _normalize(n))
+    p = o + d * torch.where(is_sky, torch.zeros_like(t), t).unsqueeze(-1)
+
+    out = {"camera": cam, "viewz": view_z.contiguous(), "is_sky": is_sky}
+    out["normal_roughness"] = pack_normal_roughness(n, rough, torch.zeros_like(rough)).contiguous()
+    out["mv"] = torch.zeros((height, width, 4), dtype=torch.float16, device=dev)  # static scene, world-space MVs scaled by 0
+
+    xi, yi = xs.to(torch.int64), ys.to(torch.int64)
+    fr = frame if noise else 0
+    if "reblur" in want:
+        vdir = _normalize(-d)
+        # diffuse bounce: cosine-weighted direction around n
+        u1, u2 = _hash_uniform(xi, yi, fr, seed), _hash_uniform(xi, yi, fr, seed + 1)
+        tb, bb = _basis(n)
+        r, phi = torch.sqrt(u1), 2.0 * math.pi * u2
+        ld = torch.stack([r * torch.cos(phi), r * torch.sin(phi), torch.sqrt((1.0 - u1).clamp_min(0.0))], -1)
+        wd = _normalize(tb * ld[..., 0:1] + bb * ld[..., 1:2] + n * ld[..., 2:3])
+        th, nh, ah, _ = _trace(p + n * 1e-3, wd, dev)
+        miss = torch.isinf(th)
+        ph = p + wd * torch.where(miss, torch.zeros_like(th), th).unsqueeze(-1)
+        rad = torch.where(miss.unsqueeze(-1), _sky(wd, dev), _shade(ph, _normalize(nh + 1e-9), ah, dev))
+        hit_d = torch.where(miss, torch.full_like(th, 1000.0), th)
+        rad = torch.where(is_sky.unsqueeze(-1), torch.zeros_like(rad), rad).clamp(0.0, 250.0)
+        nhd = torch.where(is_sky, torch.zeros_like(hit_d), _norm_hit_dist(hit_d, view_z, torch.ones_like(rough)))
+        out["diff"] = torch.cat([_ycocg(rad), nhd.unsqueeze(-1)], -1).clamp(-FP16_MAX, FP16_MAX).to(torch.float16).contiguous()
+
+        # specular bounce: mirror direction jittered inside a roughness-sized lobe
+        u3, u4 = _hash_uniform(xi, yi, fr, seed + 2), _hash_uniform(xi, yi, fr, seed + 3)
+        refl = _normalize(-vdir + n * (2.0 * _dot(n, vdir)).unsqueeze(-1))
+        tr_, br_ = _basis(refl)
+        rr = (rough * rough).unsqueeze(-1) * torch.sqrt(u3).unsqueeze(-1)
+        ws = _normalize(refl + (tr_ * torch.cos(2.0 * math.pi * u4).unsqueeze(-1) + br_ * torch.sin(2.0 * math.pi * u4).unsqueeze(-1)) * rr)
+        below = _dot(ws, n) <= 0.0
+        th, nh, ah, _ = _trace(p + n * 1e-3, ws, dev)
+        miss = torch.isinf(th)
+        ph = p + ws * torch.where(miss, torch.zeros_like(th), th).unsqueeze(-1)
+        rad = torch.where(miss.unsqueeze(-1), _sky(ws, dev), _shade(ph, _normalize(nh + 1e-9), ah, dev))
+        hit_d = torch.where(miss, torch.full_like(th, 1000.0), th)
+        hit_d = torch.where(below, torch.zeros_like(hit_d), hit_d)  # rays into the surface: hitDist = 0 (handled by NRD)
+        rad = torch.where((is_sky | below).unsqueeze(-1), torch.zeros_like(rad), rad).clamp(0.0, 250.0)
+        nhd = torch.where(is_sky, torch.zeros_like(hit_d), _norm_hit_dist(hit_d, view_z, rough))
+        out["spec"] = torch.cat([_ycocg(rad), nhd.unsqueeze(-1)], -1).clamp(-FP16_MAX, FP16_MAX).to(torch.float16).contiguous()
+
+    if "sigma" in want:
+        # sun with a 0.25 deg angular radius... widened to 1.5 deg so penumbrae span pixels at test resolutions
+        L = _normalize(torch.tensor(LIGHT_DIR, device=dev))
+        tan_r = math.tan(math.radians(1.5))
+        u5, u6 = _hash_uniform(xi, yi, fr, seed + 4), _hash_uniform(xi, yi, fr, seed + 5)
+        tl, bl = _basis(L.expand_as(n))
+        rr = tan_r * torch.sqrt(u5).unsqueeze(-1)
+        wl = _normalize(L + (tl * torch.cos(2.0 * math.pi * u6).unsqueeze(-1) + bl * torch.sin(2.0 * math.pi * u6).unsqueeze(-1)) * rr)
+        ndl = _dot(n, L.expand_as(n))
+        ts, _, _, _ = _trace(p + n * 1e-3, wl, dev)
+        # SIGMA_FrontEnd_PackPenumbra (NRD.hlsli:828-834): distanceToOccluder * tanOfLightAngularRadius, NoL<=0 -> 0, miss -> FP16_MAX
+        pen = torch.where(torch.isinf(ts), torch.full_like(ts, FP16_MAX), (ts * tan_r).clamp(max=FP16_MAX))
+        pen = torch.where(ndl <= 0.0, torch.zeros_like(pen), pen)
+        pen = torch.where(is_sky, torch.full_like(pen, FP16_MAX), pen)
+        out["penumbra"] = pen.to(torch.float16).contiguous()
+        out["light_dir"] = tuple(float(x) for x in L)
+    return out

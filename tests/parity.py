@@ -1,0 +1,194 @@
+"""Parity harness: runs the same synthetic frame sequence through the CPU oracle and through the HIP path (both driven
+by the SAME nrd::GetComputeDispatches lists from the product's host) and compares planes. Used by tests/ and smoke()."""
+import numpy as np
+import torch
+
+from oracle import driver as oracle_driver
+from raytracingdenoiser_amd import api, synth
+
+RT = api.ResourceType
+F = api.Format
+
+REL_TOL = 1e-3  # BASELINE.json north_star: <= 1e-3 relative per pixel (bit-exact for REFERENCE)
+
+
+def common_settings(cam, cam_prev, width, height, frame_index, **kw):
+    cs = api.CommonSettings(resourceSize=(width, height), rectSize=(width, height), resourceSizePrev=(width, height), rectSizePrev=(width, height),
+                            timeDeltaBetweenFrames=16.667, frameIndex=frame_index, isMotionVectorInWorldSpace=True, motionVectorScale=(0.0, 0.0, 0.0), **kw)
+    for i in range(16):
+        cs.viewToClipMatrix[i] = cam.view_to_clip[i]
+        cs.viewToClipMatrixPrev[i] = cam_prev.view_to_clip[i]
+        cs.worldToViewMatrix[i] = cam.world_to_view[i]
+        cs.worldToViewMatrixPrev[i] = cam_prev.world_to_view[i]
+    return cs
+
+
+DENOISERS = {
+    "REBLUR_DIFFUSE": (api.Denoiser.REBLUR_DIFFUSE, ("reblur",)),
+    "REBLUR_SPECULAR": (api.Denoiser.REBLUR_SPECULAR, ("reblur",)),
+    "REBLUR_DIFFUSE_SPECULAR": (api.Denoiser.REBLUR_DIFFUSE_SPECULAR, ("reblur",)),
+    "SIGMA_SHADOW": (api.Denoiser.SIGMA_SHADOW, ("sigma",)),
+}
+
+
+def user_planes(name, frame):
+    """(ResourceType, tensor, Format) inputs of a denoiser for one generated frame."""
+    planes = [(RT.IN_MV, frame["mv"], F.RGBA16_SFLOAT), (RT.IN_NORMAL_ROUGHNESS, frame["normal_roughness"], F.R10_G10_B10_A2_UNORM), (RT.IN_VIEWZ, frame["viewz"], F.R32_SFLOAT)]
+    if name in ("REBLUR_DIFFUSE", "REBLUR_DIFFUSE_SPECULAR"):
+        planes.append((RT.IN_DIFF_RADIANCE_HITDIST, frame["diff"], F.RGBA16_SFLOAT))
+    if name in ("REBLUR_SPECULAR", "REBLUR_DIFFUSE_SPECULAR"):
+        planes.append((RT.IN_SPEC_RADIANCE_HITDIST, frame["spec"], F.RGBA16_SFLOAT))
+    if name == "SIGMA_SHADOW":
+        planes.append((RT.IN_PENUMBRA, frame["penumbra"], F.R16_SFLOAT))
+    return planes
+
+
+def output_planes(name, width, height):
+    """(ResourceType, dtype, channels, Format)"""
+    outs = []
+    if name in ("REBLUR_DIFFUSE", "REBLUR_DIFFUSE_SPECULAR"):
+        outs.append((RT.OUT_DIFF_RADIANCE_HITDIST, torch.float16, 4, F.RGBA16_SFLOAT))
+    if name in ("REBLUR_SPECULAR", "REBLUR_DIFFUSE_SPECULAR"):
+        outs.append((RT.OUT_SPEC_RADIANCE_HITDIST, torch.float16, 4, F.RGBA16_SFLOAT))
+    if name == "SIGMA_SHADOW":
+        outs.append((RT.OUT_SHADOW_TRANSLUCENCY, torch.uint8, 1, F.R8_UNORM))
+    return outs
+
+
+def denoiser_settings(name, frame, overrides=None):
+    if name.startswith("REBLUR"):
+        s = api.ReblurSettings(**(overrides or {}))
+    elif name == "SIGMA_SHADOW":
+        s = api.SigmaSettings(lightDirection=frame["light_dir"], **(overrides or {}))
+    else:
+        raise KeyError(name)
+    return s
+
+
+def decode_plane(raw, fmt, width):
+    """uint8 [h, pitch] -> float32 / uint32 array [h, w, c] of texel values (for error metrics)."""
+    h = raw.shape[0]
+    bpt = api.FORMAT_BYTES[fmt]
+    body = np.ascontiguousarray(raw[:, : width * bpt])
+    if fmt == F.RGBA16_SFLOAT:
+        return body.view(np.float16).reshape(h, width, 4).astype(np.float32)
+    if fmt == F.R16_SFLOAT:
+        return body.view(np.float16).reshape(h, width, 1).astype(np.float32)
+    if fmt == F.R32_SFLOAT:
+        return body.view(np.float32).reshape(h, width, 1)
+    if fmt == F.RGBA32_SFLOAT:
+        return body.view(np.float32).reshape(h, width, 4)
+    if fmt in (F.R8_UNORM, F.R8_UINT):
+        return body.reshape(h, width, 1).astype(np.float32)
+    if fmt == F.RG8_UNORM:
+        return body.reshape(h, width, 2).astype(np.float32)
+    if fmt == F.RGBA8_UNORM:
+        return body.reshape(h, width, 4).astype(np.float32)
+    if fmt == F.R16_UINT:
+        return body.view(np.uint16).reshape(h, width, 1).astype(np.float32)
+    if fmt in (F.R32_UINT, F.R10_G10_B10_A2_UNORM):
+        return body.view(np.uint32).reshape(h, width, 1).astype(np.float64)
+    raise KeyError(fmt)
+
+
+def rel_error(got, want, floor=1e-3):
+    """max over texels of |got - want| / max(|want|, floor); NaNs count as infinite error unless both are NaN."""
+    got = got.astype(np.float64)
+    want = want.astype(np.float64)
+    both_nan = np.isnan(got) & np.isnan(want)
+    err = np.abs(got - want) / np.maximum(np.abs(want), floor)
+    err = np.where(both_nan, 0.0, err)
+    err = np.where(np.isnan(err), np.inf, err)
+    return float(err.max()) if err.size else 0.0
+
+
+class OracleRun:
+    def __init__(self, name, width, height, threads=0):
+        self.name, self.width, self.height = name, width, height
+        self.inst = api.Instance([(0, DENOISERS[name][0])])
+        self.ex = oracle_driver.OracleExecutor(self.inst, width, height, api.FORMAT_BYTES, threads=threads)
+        self.outs = {}
+        for rt, dtype, ch, fmt in output_planes(name, width, height):
+            arr = np.zeros((height, width, ch), dtype=np.float16 if dtype == torch.float16 else np.uint8)
+            self.outs[rt] = (arr, fmt)
+            self.ex.bind(rt, arr, fmt)
+        self.last_dispatches = []
+
+    def step(self, frame, cs, settings=None):
+        for rt, t, fmt in user_planes(self.name, frame):
+            self.ex.bind(rt, np.ascontiguousarray(t.cpu().numpy()), fmt)
+        if settings is not None:
+            assert self.inst.set_denoiser_settings(0, settings) == api.Result.SUCCESS
+        assert self.inst.set_common_settings(cs) == api.Result.SUCCESS
+        r, ds = self.inst.get_compute_dispatches()
+        assert r == api.Result.SUCCESS
+        self.last_dispatches = ds
+        self.ex.execute(ds)
+
+    def output(self, rt):
+        arr, fmt = self.outs[rt]
+        return arr.astype(np.float32)
+
+
+class HipRun:
+    def __init__(self, name, width, height):
+        from raytracingdenoiser_amd.executor import HipExecutor
+
+        self.name, self.width, self.height = name, width, height
+        self.inst = api.Instance([(0, DENOISERS[name][0])])
+        self.ex = HipExecutor(self.inst, width, height)
+        self.outs = {}
+        for rt, dtype, ch, fmt in output_planes(name, width, height):
+            t = torch.zeros((height, width, ch), dtype=dtype, device="cuda")
+            self.outs[rt] = (t, fmt)
+            self.ex.bind(rt, t, fmt)
+
+    def step(self, frame, cs, settings=None):
+        for rt, t, fmt in user_planes(self.name, frame):
+            self.ex.bind(rt, t.cuda().contiguous(), fmt)
+        if settings is not None:
+            assert self.inst.set_denoiser_settings(0, settings) == api.Result.SUCCESS
+        assert self.inst.set_common_settings(cs) == api.Result.SUCCESS
+        self.ex.denoise()
+
+    def output(self, rt):
+        t, fmt = self.outs[rt]
+        return t.cpu().numpy().astype(np.float32)
+
+
+def generate_sequence(name, width, height, frames, static_camera=False, noise=True, device="cpu"):
+    return [synth.render_frame(width, height, f, device=device, static_camera=static_camera, noise=noise, want=DENOISERS[name][1]) for f in range(frames)]
+
+
+def run_parity(name, width=192, height=128, frames=4, verbose=False, settings_overrides=None, static_camera=False, check_pools=True):
+    """Returns the worst relative error between the HIP path and the oracle over all frames, user outputs and pool planes."""
+    seq = generate_sequence(name, width, height, frames, static_camera=static_camera)
+    ora, hip = OracleRun(name, width, height), HipRun(name, width, height)
+    worst = 0.0
+    for f, frame in enumerate(seq):
+        cam, cam_prev = frame["camera"], seq[max(f - 1, 0)]["camera"]
+        cs = common_settings(cam, cam_prev, width, height, f)
+        st = denoiser_settings(name, frame, settings_overrides)
+        ora.step(frame, cs, st)
+        hip.step(frame, common_settings(cam, cam_prev, width, height, f), denoiser_settings(name, frame, settings_overrides))
+        for rt in ora.outs:
+            want, got = ora.output(rt), hip.output(rt)
+            e = rel_error(got, want)
+            exact = float(np.mean(got == want))
+            worst = max(worst, e)
+            if verbose:
+                print("frame %d %-28s max rel err %.3g  bit-exact texels %.4f%%" % (f, rt.name, e, 100.0 * exact))
+        if check_pools:
+            for pool in (RT.PERMANENT_POOL, RT.TRANSIENT_POOL):
+                descs = ora.inst.permanent_pool if pool == RT.PERMANENT_POOL else ora.inst.transient_pool
+                for i in range(len(descs)):
+                    o_raw, fmt, w = ora.ex.pool_plane(pool, i)
+                    h_raw, hfmt, hw = hip.ex.read_pool_plane(pool, i)
+                    assert fmt == hfmt and w == hw
+                    want, got = decode_plane(o_raw, fmt, w), decode_plane(h_raw, fmt, w)
+                    e = rel_error(got, want)
+                    worst = max(worst, e)
+                    if verbose and e > 0:
+                        bad = np.argwhere(np.any(got != want, axis=-1))
+                        print("frame %d %s[%d] %-22s max rel err %.3g  differing texels %d  first %s" % (f, pool.name, i, fmt.name, e, len(bad), bad[:3].tolist()))
+    return worst

@@ -1,0 +1,98 @@
+"""REBLUR chain: oracle known-answer properties on the CPU, HIP-vs-oracle parity on the GPU.
+Known answers: SURVEY.md section 8c (2) constant radiance -> unchanged, (3) all-sky -> untouched, (4) splitScreen >= 1 ->
+passthrough, (6) accumulated-frame counter 1, 2, 3, ... on a static scene."""
+import numpy as np
+import pytest
+import torch
+
+import parity
+from raytracingdenoiser_amd import api
+
+RT = api.ResourceType
+W, H = 160, 96
+
+
+def _run_oracle(name, seq, overrides=None, cs_kw=None):
+    ora = parity.OracleRun(name, W, H)
+    for f, frame in enumerate(seq):
+        cs = parity.common_settings(frame["camera"], seq[max(f - 1, 0)]["camera"], W, H, f, **(cs_kw or {}))
+        ora.step(frame, cs, parity.denoiser_settings(name, frame, overrides))
+    return ora
+
+
+def test_oracle_energy_is_preserved_and_noise_drops():
+    name = "REBLUR_DIFFUSE_SPECULAR"
+    seq = parity.generate_sequence(name, W, H, 8)
+    ora = _run_oracle(name, seq)
+    m = ~seq[-1]["is_sky"].numpy()
+    for rt, key in ((RT.OUT_DIFF_RADIANCE_HITDIST, "diff"), (RT.OUT_SPEC_RADIANCE_HITDIST, "spec")):
+        out = ora.output(rt)
+        noisy = seq[-1][key].float().numpy()
+        assert not np.isnan(out).any()
+        assert abs(out[m][:, 0].mean() - noisy[m][:, 0].mean()) < 0.03 * noisy[m][:, 0].mean()  # normalised filters keep the mean
+        assert out[m][:, 0].std() < 0.9 * noisy[m][:, 0].std()
+    always_sky = np.all(np.stack([fr["is_sky"].numpy() for fr in seq]), axis=0)
+    assert np.all(ora.output(RT.OUT_DIFF_RADIANCE_HITDIST)[always_sky] == 0)  # sky pixels are never written (cleared on frame 0)
+
+
+def test_oracle_constant_signal_is_a_fixed_point():
+    name = "REBLUR_DIFFUSE_SPECULAR"
+    seq = parity.generate_sequence(name, W, H, 5, static_camera=True, noise=False)
+    const = torch.tensor([0.5, 0.0625, -0.03125, 0.25], dtype=torch.float16)
+    for fr in seq:
+        fr["diff"] = const.expand(H, W, 4).contiguous()
+        fr["spec"] = const.expand(H, W, 4).contiguous()
+    ora = _run_oracle(name, seq)
+    m = ~seq[-1]["is_sky"].numpy()
+    for rt in (RT.OUT_DIFF_RADIANCE_HITDIST, RT.OUT_SPEC_RADIANCE_HITDIST):
+        out = ora.output(rt)[m]
+        assert np.max(np.abs(out - const.float().numpy())) < 2e-3  # weighted means of a constant, up to fp16 storage rounding
+
+
+def test_oracle_accumulated_frames_count_up():
+    name = "REBLUR_DIFFUSE"
+    seq = parity.generate_sequence(name, W, H, 6, static_camera=True, noise=False)
+    ora = parity.OracleRun(name, W, H)
+    m = ~seq[0]["is_sky"].numpy()
+    for f, frame in enumerate(seq):
+        cs = parity.common_settings(frame["camera"], seq[max(f - 1, 0)]["camera"], W, H, f)
+        ora.step(frame, cs, parity.denoiser_settings(name, frame))
+        raw, fmt, w = ora.ex.pool_plane(RT.PERMANENT_POOL, 2)  # PREV_INTERNAL_DATA (R16_UINT)
+        accum = (raw[:, : w * 2].copy().view(np.uint16) & 63)[m]
+        assert np.median(accum) == f + 1  # frame k stores min(k, maxAccumulatedFrameNum) + 1
+
+
+def test_oracle_all_sky_and_split_screen_passthrough():
+    name = "REBLUR_DIFFUSE_SPECULAR"
+    seq = parity.generate_sequence(name, W, H, 2)
+    for fr in seq:
+        fr["viewz"] = torch.full_like(fr["viewz"], 1.0e6)
+    ora = _run_oracle(name, seq)
+    assert np.all(ora.output(RT.OUT_DIFF_RADIANCE_HITDIST) == 0) and np.all(ora.output(RT.OUT_SPEC_RADIANCE_HITDIST) == 0)
+
+    seq = parity.generate_sequence(name, W, H, 2)
+    ora = _run_oracle(name, seq, cs_kw=dict(splitScreen=1.0))
+    m = ~seq[-1]["is_sky"].numpy()
+    assert np.array_equal(ora.output(RT.OUT_DIFF_RADIANCE_HITDIST)[m], seq[-1]["diff"].float().numpy()[m])
+    assert [d.shader for d in ora.last_dispatches] == ["REBLUR_DiffuseSpecular_SplitScreen.cs"]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", ["REBLUR_DIFFUSE_SPECULAR", "REBLUR_DIFFUSE", "REBLUR_SPECULAR"])
+def test_hip_matches_oracle(name):
+    worst = parity.run_parity(name, width=192, height=128, frames=6, verbose=True)
+    assert worst <= parity.REL_TOL
+
+
+@pytest.mark.gpu
+def test_hip_matches_oracle_odd_size_no_stabilization():
+    # ragged edges (not multiples of 32 / 16 / 8) and the PostBlur_NoTemporalStabilization permutation
+    worst = parity.run_parity("REBLUR_DIFFUSE_SPECULAR", width=211, height=117, frames=4, verbose=True, settings_overrides=dict(maxStabilizedFrameNum=0))
+    assert worst <= parity.REL_TOL
+
+
+@pytest.mark.gpu
+def test_hip_matches_oracle_antifirefly_and_no_prepass():
+    worst = parity.run_parity("REBLUR_DIFFUSE_SPECULAR", width=160, height=96, frames=4, verbose=True,
+                              settings_overrides=dict(enableAntiFirefly=True, diffusePrepassBlurRadius=0.0, specularPrepassBlurRadius=0.0))
+    assert worst <= parity.REL_TOL
