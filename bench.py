@@ -1,0 +1,224 @@
+#!/usr/bin/env python3
+"""Benchmark of the NRD hot path on MI355X: REBLUR_DIFFUSE_SPECULAR @ 2560x1440 (BASELINE.json metric).
+
+A "step" is one denoised frame = one full pass list (ClassifyTiles, PrePass, TemporalAccumulation, HistoryFix, Blur,
+PostBlur, TemporalStabilization) over one synthetic frame whose inputs are ALREADY resident in HBM (generated on the
+GPU before the timed region). Prints ONE JSON line (see DESIGN.md "Measurement"):
+
+  value         Mpixels/s of the whole job = steps * 2560 * 1440 / wall time of the timed region (max over ranks)
+  roofline      for the dominant kernel: algorithmic bytes per launch / its mean duration,
+                measured live with HIP events recorded on the executor's stream around every dispatch
+  cpu_baseline  the CPU oracle (oracle/, kind "port": the reference has no CPU implementation) on the host cores,
+                on a bounded sample of the same workload (N = 1, rank 0 only)
+
+  python bench.py [--gpus N] [--steps K] [--warmup W] [--width 2560 --height 1440] [--no-cpu-baseline]
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+import torch
+
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E peak (MI355X_MICROARCH.md); ~6300 GB/s is what a float4 copy achieves
+
+# Algorithmic (compulsory) bytes per pixel and per pass for REBLUR_DIFFUSE_SPECULAR with the reference pool formats
+# (each plane read / written once per pass).
+REBLUR_DS_BYTES_PER_PIXEL = {
+    "REBLUR_ClassifyTiles.cs": 4,
+    "REBLUR_DiffuseSpecular_PrePass.cs": 42,
+    "REBLUR_DiffuseSpecular_TemporalAccumulation.cs": 94,
+    "REBLUR_DiffuseSpecular_HistoryFix.cs": 50,
+    "REBLUR_DiffuseSpecular_Blur.cs": 46,
+    "REBLUR_DiffuseSpecular_PostBlur.cs": 46,
+    "REBLUR_DiffuseSpecular_TemporalStabilization.cs": 66,
+}
+TOTAL_BYTES_PER_PIXEL = sum(REBLUR_DS_BYTES_PER_PIXEL.values())  # 348
+
+
+def parse_args():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=64)
+    ap.add_argument("--warmup", type=int, default=32)
+    ap.add_argument("--width", type=int, default=2560)
+    ap.add_argument("--height", type=int, default=1440)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-frames", type=int, default=3)
+    ap.add_argument("--distinct-frames", type=int, default=0, help="number of distinct generated frames to cycle through (0 = warmup + steps)")
+    return ap.parse_args()
+
+
+def cpu_baseline(width, height, frames, seq):
+    """Times the CPU oracle on the first `frames` frames of the same sequence (all host cores, OpenMP over rows)."""
+    import parity
+    from oracle import driver as oracle_driver
+
+    cores = os.cpu_count() or 1
+    threads = oracle_driver.load().oracle_set_threads(cores)
+    ora = parity.OracleRun("REBLUR_DIFFUSE_SPECULAR", width, height, threads=threads)
+    host_seq = [{k: (v.cpu() if torch.is_tensor(v) else v) for k, v in fr.items()} for fr in seq[:frames]]
+    t0 = time.perf_counter()
+    for f, frame in enumerate(host_seq):
+        cs = parity.common_settings(frame["camera"], host_seq[max(f - 1, 0)]["camera"], width, height, f)
+        ora.step(frame, cs, parity.denoiser_settings("REBLUR_DIFFUSE_SPECULAR", frame))
+    dt = time.perf_counter() - t0
+    return {
+        "value": round(frames * width * height / dt / 1e6, 4),
+        "unit": "Mpixels/s",
+        "cores": threads,
+        "kind": "port",
+        "sample": "first %d frames of the same %dx%d REBLUR_DIFFUSE_SPECULAR sequence (incl. the CLEAR_AND_RESTART frame), %.1f s" % (frames, width, height, dt),
+    }
+
+
+def main():
+    args = parse_args()
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    distributed = world > 1
+    if args.gpus != world and not (args.gpus == 1 and world == 1):
+        if rank == 0:
+            print("bench.py: --gpus %d but WORLD_SIZE=%d; launch with torch.distributed.run --nproc-per-node %d" % (args.gpus, world, args.gpus), file=sys.stderr)
+    assert torch.cuda.is_available(), "bench.py needs a GPU: the HIP path has no CPU fallback"
+    torch.cuda.set_device(local_rank)
+    if distributed:
+        import torch.distributed as dist
+
+        dist.init_process_group("nccl")  # RCCL
+
+    import parity
+    from raytracingdenoiser_amd import api
+    from raytracingdenoiser_amd import build as native_build
+    from raytracingdenoiser_amd.executor import HipExecutor
+    from raytracingdenoiser_amd import sharding
+
+    if rank == 0:
+        native_build.build_product()
+    if distributed:
+        dist.barrier()
+
+    W, H = args.width, args.height
+    name = "REBLUR_DIFFUSE_SPECULAR"
+    total = args.warmup + args.steps
+    distinct = args.distinct_frames or total
+
+    # ---- synthetic inputs, generated straight into HBM (118 MB per 1440p frame; 96 frames = 11 GB of 288 GB)
+    seq = parity.generate_sequence(name, W, H, distinct, device="cuda")
+    torch.cuda.synchronize()
+
+    inst = api.Instance([(0, api.Denoiser.REBLUR_DIFFUSE_SPECULAR)])
+    ex = HipExecutor(inst, W, H)
+    out_diff = torch.zeros((H, W, 4), dtype=torch.float16, device="cuda")
+    out_spec = torch.zeros((H, W, 4), dtype=torch.float16, device="cuda")
+    ex.bind(api.ResourceType.OUT_DIFF_RADIANCE_HITDIST, out_diff, api.Format.RGBA16_SFLOAT)
+    ex.bind(api.ResourceType.OUT_SPEC_RADIANCE_HITDIST, out_spec, api.Format.RGBA16_SFLOAT)
+    shard = sharding.FrameSharder(ex, inst, W, H, rank, world, [out_diff, out_spec]) if distributed else None
+
+    settings = parity.denoiser_settings(name, seq[0])
+    assert inst.set_denoiser_settings(0, settings) == api.Result.SUCCESS
+    frames_cs = []
+    for f in range(total):
+        cur, prev = seq[f % distinct], seq[(f - 1) % distinct] if f > 0 else seq[0]
+        frames_cs.append(parity.common_settings(cur["camera"], prev["camera"], W, H, f))
+
+    def step(f):
+        frame = seq[f % distinct]
+        for rt, t, fmt in parity.user_planes(name, frame):
+            ex.bind(rt, t, fmt)
+        assert inst.set_common_settings(frames_cs[f]) == api.Result.SUCCESS
+        if shard is not None:
+            shard.denoise()
+        else:
+            ex.denoise()
+
+    def fence():
+        if distributed:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for f in range(args.warmup):
+        step(f)
+    fence()
+
+    ex.set_profiling(True)
+    t0 = time.perf_counter()
+    for f in range(args.warmup, total):
+        step(f)
+    fence()
+    elapsed = time.perf_counter() - t0
+    timings = ex.collect_pass_timings()
+    ex.set_profiling(False)
+
+    if distributed:
+        tt = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+
+    if rank != 0:
+        if distributed:
+            dist.barrier()
+            dist.destroy_process_group()
+        return
+
+    ms_per_step = elapsed * 1e3 / args.steps
+    mpix_s = args.steps * W * H / elapsed / 1e6
+
+    # ---- roofline of the dominant kernel (live HIP-event timings of this very run)
+    rows = W * H if shard is None else shard.pixels_per_rank()
+    passes = {}
+    for shader, (ms, n) in timings.items():
+        bpp = REBLUR_DS_BYTES_PER_PIXEL.get(shader)
+        if bpp is None or n == 0:
+            continue
+        avg_ms = ms / n
+        passes[shader] = {"avg_ms": round(avg_ms, 4), "launches": n, "bytes_per_launch": bpp * rows, "GBps": round(bpp * rows / (avg_ms * 1e-3) / 1e9, 1)}
+    dominant = max(passes, key=lambda k: passes[k]["avg_ms"]) if passes else None
+    roofline = None
+    if dominant:
+        achieved = passes[dominant]["GBps"]
+        roofline = {"bound": "hbm", "kernel": dominant, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
+                    "traffic": None, "avg_kernel_ms": passes[dominant]["avg_ms"], "algorithmic_bytes_per_launch": passes[dominant]["bytes_per_launch"]}
+    gpu_ms = sum(p["avg_ms"] for p in passes.values())
+    whole_chain = {"algorithmic_bytes_per_frame": TOTAL_BYTES_PER_PIXEL * W * H, "sum_kernel_ms": round(gpu_ms, 4),
+                   "GBps": round(TOTAL_BYTES_PER_PIXEL * rows / (gpu_ms * 1e-3) / 1e9, 1) if gpu_ms else None,
+                   "frac_of_peak": round(TOTAL_BYTES_PER_PIXEL * rows / (gpu_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if gpu_ms else None}
+
+    result = {
+        "metric": "Mpixels/s REBLUR_DIFFUSE_SPECULAR @1440p",
+        "value": round(mpix_s, 2),
+        "unit": "Mpixels/s",
+        "n_gpus": world,
+        "steps": args.steps,
+        "warmup": args.warmup,
+        "ms_per_step": round(ms_per_step, 4),
+        "higher_is_better": True,
+        "scaling": "strong",
+        "vs_baseline": None,
+        "dtype": "f32",
+        "data": "synthetic",
+        "config": {"workload": "REBLUR_DIFFUSE_SPECULAR %dx%d, default ReblurSettings, analytic scene + 1rpp noise, moving camera" % (W, H),
+                   "parallelism": "1 GPU" if world == 1 else "row strips x%d + RCCL all-gather" % world,
+                   "storage": "reference pool formats (fp16 history, R10G10B10A2 normals), 348 B/px/frame compulsory traffic"},
+        "roofline": roofline,
+        "whole_chain": whole_chain,
+        "passes": passes,
+    }
+    if not args.no_cpu_baseline and world == 1:
+        result["cpu_baseline"] = cpu_baseline(W, H, min(args.cpu_frames, distinct), seq)
+    else:
+        result["cpu_baseline"] = None
+    print(json.dumps(result))
+    if distributed:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

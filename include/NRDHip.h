@@ -41,6 +41,13 @@ typedef struct NrdHipPlaneDesc {
 uint32_t nrdHipCreateExecutor(void* instance, uint16_t resourceWidth, uint16_t resourceHeight, void* hipStream, NrdHipExecutor** executor);
 void nrdHipDestroyExecutor(NrdHipExecutor* executor);
 
+// Same, but the pool arena is provided (and owned) by the caller, which is the reference's own model ("NRD allocates no GPU
+// memory": reference Integration creates the pool textures from InstanceDesc). "arena" must be device memory of at least
+// nrdHipGetArenaSize() bytes, 256-byte aligned; it is zero-filled on the stream. Lets a host that owns the memory (e.g. a
+// tensor library) alias pool planes for collectives.
+uint64_t nrdHipGetArenaSize(void* instance, uint16_t resourceWidth, uint16_t resourceHeight);
+uint32_t nrdHipCreateExecutorWithArena(void* instance, uint16_t resourceWidth, uint16_t resourceHeight, void* hipStream, void* arena, uint64_t arenaSize, NrdHipExecutor** executor);
+
 // Binds an application plane to an IN_* / OUT_* slot. The bytes are not copied; the binding persists until rebound.
 // Formats accepted in this build (anything else -> UNSUPPORTED):
 //   IN_MV RGBA16_SFLOAT | IN_NORMAL_ROUGHNESS R10_G10_B10_A2_UNORM | IN_VIEWZ R32_SFLOAT
@@ -59,6 +66,13 @@ uint32_t nrdHipExecuteDispatches(NrdHipExecutor* executor, const void* dispatchD
 // nrd::GetComputeDispatches(identifiers) followed by nrdHipExecuteDispatches: one denoised frame.
 // nrd::SetCommonSettings / SetDenoiserSettings must have been called for this frame.
 uint32_t nrdHipDenoise(NrdHipExecutor* executor, const uint32_t* identifiers, uint32_t identifiersNum);
+
+// Per-pass GPU timing. When enabled, every dispatch is bracketed by hipEvents on the executor's stream.
+// nrdHipCollectPassTimings synchronises the stream, folds all brackets recorded since the last collect into per-pipeline
+// totals and returns the number of pipelines written: pipelineIndices[i] (index into InstanceDesc::pipelines),
+// milliseconds[i] (sum of durations) and launches[i] (count). Pass capacity >= InstanceDesc::pipelinesNum.
+uint32_t nrdHipSetProfiling(NrdHipExecutor* executor, uint32_t enable);
+uint32_t nrdHipCollectPassTimings(NrdHipExecutor* executor, uint32_t* pipelineIndices, double* milliseconds, uint32_t* launches, uint32_t capacity, uint32_t* written);
 
 // Bytes held by the pool arena (permanent, transient).
 uint32_t nrdHipGetPoolMemoryUsage(const NrdHipExecutor* executor, uint64_t* permanentBytes, uint64_t* transientBytes);

@@ -252,7 +252,8 @@ class HipPlaneDesc(C.Structure):
 NRD_SYMBOLS = ["CreateInstance", "DestroyInstance", "GetLibraryDesc", "GetInstanceDesc", "SetCommonSettings", "SetDenoiserSettings",
                "GetComputeDispatches", "GetResourceTypeString", "GetDenoiserString"]
 NRD_HIP_SYMBOLS = ["nrdHipCreateExecutor", "nrdHipDestroyExecutor", "nrdHipBindResource", "nrdHipGetPoolPlane", "nrdHipExecuteDispatches",
-                   "nrdHipDenoise", "nrdHipGetPoolMemoryUsage", "nrdHipGetLastError", "nrdHipEvalNumerics"]
+                   "nrdHipDenoise", "nrdHipGetPoolMemoryUsage", "nrdHipGetLastError", "nrdHipEvalNumerics", "nrdHipGetArenaSize",
+                   "nrdHipCreateExecutorWithArena", "nrdHipSetProfiling", "nrdHipCollectPassTimings"]
 
 _lib = None
 
@@ -288,6 +289,12 @@ def load_library(path=None):
     lib.nrdHipGetPoolMemoryUsage.argtypes = [C.c_void_p, P(C.c_uint64), P(C.c_uint64)]
     lib.nrdHipGetPoolMemoryUsage.restype = C.c_uint32
     lib.nrdHipGetLastError.argtypes, lib.nrdHipGetLastError.restype = [C.c_void_p], C.c_char_p
+    lib.nrdHipGetArenaSize.argtypes, lib.nrdHipGetArenaSize.restype = [C.c_void_p, C.c_uint16, C.c_uint16], C.c_uint64
+    lib.nrdHipCreateExecutorWithArena.argtypes = [C.c_void_p, C.c_uint16, C.c_uint16, C.c_void_p, C.c_void_p, C.c_uint64, P(C.c_void_p)]
+    lib.nrdHipCreateExecutorWithArena.restype = C.c_uint32
+    lib.nrdHipSetProfiling.argtypes, lib.nrdHipSetProfiling.restype = [C.c_void_p, C.c_uint32], C.c_uint32
+    lib.nrdHipCollectPassTimings.argtypes = [C.c_void_p, P(C.c_uint32), P(C.c_double), P(C.c_uint32), C.c_uint32, P(C.c_uint32)]
+    lib.nrdHipCollectPassTimings.restype = C.c_uint32
     lib.nrdHipEvalNumerics.argtypes = [C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p]
     lib.nrdHipEvalNumerics.restype = C.c_uint32
     if path == LIB_PATH:

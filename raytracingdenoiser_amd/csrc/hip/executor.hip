@@ -67,6 +67,14 @@ struct NrdHipExecutor {
     uint16_t width = 0, height = 0;
 
     uint8_t* arena = nullptr;
+    bool ownsArena = true;
+    bool profiling = false;
+    struct Bracket {
+        hipEvent_t start, stop;
+        uint16_t pipelineIndex;
+    };
+    std::vector<Bracket> brackets;   // recorded since the last collect
+    std::vector<hipEvent_t> eventPool; // recycled events
     uint64_t permanentBytes = 0, transientBytes = 0;
     std::vector<Plane> permanent, transient;
     std::vector<nrd::Format> permanentFormat, transientFormat;
@@ -104,7 +112,7 @@ static bool PlanPool(const nrd::TextureDesc* descs, uint32_t num, uint16_t w, ui
     return true;
 }
 
-extern "C" __attribute__((visibility("default"))) uint32_t nrdHipCreateExecutor(void* instance, uint16_t resourceWidth, uint16_t resourceHeight, void* hipStream, NrdHipExecutor** executor) {
+static uint32_t CreateExecutorImpl(void* instance, uint16_t resourceWidth, uint16_t resourceHeight, void* hipStream, void* userArena, uint64_t userArenaSize, NrdHipExecutor** executor) {
     if (!instance || !executor || !resourceWidth || !resourceHeight)
         return (uint32_t)nrd::Result::INVALID_ARGUMENT;
     *executor = nullptr;
@@ -134,7 +142,14 @@ extern "C" __attribute__((visibility("default"))) uint32_t nrdHipCreateExecutor(
     }
 
     if (offset) {
-        if (hipMalloc((void**)&e->arena, offset) != hipSuccess) {
+        if (userArena) {
+            if (userArenaSize < offset || ((uintptr_t)userArena & 255u) != 0) {
+                delete e;
+                return (uint32_t)nrd::Result::INVALID_ARGUMENT;
+            }
+            e->arena = (uint8_t*)userArena;
+            e->ownsArena = false;
+        } else if (hipMalloc((void**)&e->arena, offset) != hipSuccess) {
             delete e;
             return (uint32_t)nrd::Result::FAILURE;
         }
@@ -162,14 +177,91 @@ extern "C" __attribute__((visibility("default"))) uint32_t nrdHipCreateExecutor(
     return (uint32_t)nrd::Result::SUCCESS;
 }
 
+extern "C" __attribute__((visibility("default"))) uint32_t nrdHipCreateExecutor(void* instance, uint16_t resourceWidth, uint16_t resourceHeight, void* hipStream, NrdHipExecutor** executor) {
+    return CreateExecutorImpl(instance, resourceWidth, resourceHeight, hipStream, nullptr, 0, executor);
+}
+
+extern "C" __attribute__((visibility("default"))) uint32_t nrdHipCreateExecutorWithArena(void* instance, uint16_t resourceWidth, uint16_t resourceHeight, void* hipStream, void* arena, uint64_t arenaSize,
+    NrdHipExecutor** executor) {
+    if (!arena)
+        return (uint32_t)nrd::Result::INVALID_ARGUMENT;
+    return CreateExecutorImpl(instance, resourceWidth, resourceHeight, hipStream, arena, arenaSize, executor);
+}
+
+extern "C" __attribute__((visibility("default"))) uint64_t nrdHipGetArenaSize(void* instance, uint16_t resourceWidth, uint16_t resourceHeight) {
+    if (!instance || !resourceWidth || !resourceHeight)
+        return 0;
+    const nrd::InstanceDesc& desc = nrd::GetInstanceDesc(*(nrd::Instance*)instance);
+    std::vector<Plane> planes;
+    std::vector<nrd::Format> formats;
+    uint64_t offset = 0;
+    if (!PlanPool(desc.permanentPool, desc.permanentPoolSize, resourceWidth, resourceHeight, planes, formats, offset))
+        return 0;
+    if (!PlanPool(desc.transientPool, desc.transientPoolSize, resourceWidth, resourceHeight, planes, formats, offset))
+        return 0;
+    return offset;
+}
+
 extern "C" __attribute__((visibility("default"))) void nrdHipDestroyExecutor(NrdHipExecutor* e) {
     if (!e)
         return;
-    if (e->arena) {
-        (void)hipStreamSynchronize(e->stream);
-        (void)hipFree(e->arena);
+    (void)hipStreamSynchronize(e->stream);
+    for (auto& b : e->brackets) {
+        (void)hipEventDestroy(b.start);
+        (void)hipEventDestroy(b.stop);
     }
+    for (hipEvent_t ev : e->eventPool)
+        (void)hipEventDestroy(ev);
+    if (e->arena && e->ownsArena)
+        (void)hipFree(e->arena);
     delete e;
+}
+
+static hipEvent_t AcquireEvent(NrdHipExecutor* e) {
+    if (!e->eventPool.empty()) {
+        hipEvent_t ev = e->eventPool.back();
+        e->eventPool.pop_back();
+        return ev;
+    }
+    hipEvent_t ev = nullptr;
+    (void)hipEventCreate(&ev);
+    return ev;
+}
+
+extern "C" __attribute__((visibility("default"))) uint32_t nrdHipSetProfiling(NrdHipExecutor* e, uint32_t enable) {
+    if (!e)
+        return (uint32_t)nrd::Result::INVALID_ARGUMENT;
+    e->profiling = enable != 0;
+    return (uint32_t)nrd::Result::SUCCESS;
+}
+
+extern "C" __attribute__((visibility("default"))) uint32_t nrdHipCollectPassTimings(NrdHipExecutor* e, uint32_t* pipelineIndices, double* milliseconds, uint32_t* launches, uint32_t capacity, uint32_t* written) {
+    if (!e || !pipelineIndices || !milliseconds || !launches || !written)
+        return (uint32_t)nrd::Result::INVALID_ARGUMENT;
+    if (hipStreamSynchronize(e->stream) != hipSuccess)
+        return e->Fail(nrd::Result::FAILURE, "hipStreamSynchronize failed");
+    std::vector<double> ms(e->launchers.size(), 0.0);
+    std::vector<uint32_t> n(e->launchers.size(), 0);
+    for (auto& b : e->brackets) {
+        float t = 0.0f;
+        if (hipEventElapsedTime(&t, b.start, b.stop) == hipSuccess && b.pipelineIndex < ms.size()) {
+            ms[b.pipelineIndex] += t;
+            n[b.pipelineIndex]++;
+        }
+        e->eventPool.push_back(b.start);
+        e->eventPool.push_back(b.stop);
+    }
+    e->brackets.clear();
+    uint32_t k = 0;
+    for (size_t i = 0; i < ms.size() && k < capacity; i++)
+        if (n[i]) {
+            pipelineIndices[k] = (uint32_t)i;
+            milliseconds[k] = ms[i];
+            launches[k] = n[i];
+            k++;
+        }
+    *written = k;
+    return (uint32_t)nrd::Result::SUCCESS;
 }
 
 extern "C" __attribute__((visibility("default"))) uint32_t nrdHipBindResource(NrdHipExecutor* e, uint32_t resourceType, const NrdHipPlaneDesc* plane) {
@@ -260,7 +352,19 @@ extern "C" __attribute__((visibility("default"))) uint32_t nrdHipExecuteDispatch
         args.constants = d.constantBufferData;
         args.constantsSize = d.constantBufferDataSize;
         args.stream = e->stream;
-        if (const char* err = launch(args))
+        NrdHipExecutor::Bracket bracket = {};
+        if (e->profiling) {
+            bracket.start = AcquireEvent(e);
+            bracket.stop = AcquireEvent(e);
+            bracket.pipelineIndex = d.pipelineIndex;
+            (void)hipEventRecord(bracket.start, e->stream);
+        }
+        const char* err = launch(args);
+        if (e->profiling) {
+            (void)hipEventRecord(bracket.stop, e->stream);
+            e->brackets.push_back(bracket);
+        }
+        if (err)
             return e->Fail(nrd::Result::UNSUPPORTED, err);
     }
 

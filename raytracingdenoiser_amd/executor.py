@@ -38,9 +38,13 @@ class HipExecutor:
         self.stream = stream
         handle = C.c_void_p()
         stream_ptr = C.c_void_p(stream.cuda_stream) if stream is not None else C.c_void_p(torch.cuda.current_stream().cuda_stream)
-        r = api.Result(self.lib.nrdHipCreateExecutor(instance.handle, width, height, stream_ptr, C.byref(handle)))
+        # the pool arena is a torch allocation, so pool planes can be aliased as tensors (needed for the RCCL all-gather)
+        size = self.lib.nrdHipGetArenaSize(instance.handle, width, height)
+        self.arena = torch.zeros(max(size, 256), dtype=torch.uint8, device="cuda")
+        assert self.arena.data_ptr() % 256 == 0
+        r = api.Result(self.lib.nrdHipCreateExecutorWithArena(instance.handle, width, height, stream_ptr, self.arena.data_ptr(), size, C.byref(handle)))
         if r != api.Result.SUCCESS:
-            raise RuntimeError("nrdHipCreateExecutor failed: %s" % r.name)
+            raise RuntimeError("nrdHipCreateExecutorWithArena failed: %s" % r.name)
         self.handle = handle
         self._bound = {}  # keeps tensors alive
 
@@ -81,6 +85,22 @@ class HipExecutor:
         if err != 0:
             raise RuntimeError("hipMemcpy D2H failed: %d" % err)
         return host, api.Format(d.format), d.width
+
+    def pool_plane_tensor(self, pool, index):
+        """uint8 tensor view [h, pitch] aliasing a pool plane inside the arena (no copy)."""
+        d = self.pool_plane_desc(pool, index)
+        off = d.data - self.arena.data_ptr()
+        return self.arena[off : off + d.height * d.rowPitchBytes].view(d.height, d.rowPitchBytes)
+
+    def set_profiling(self, enable):
+        self._check(self.lib.nrdHipSetProfiling(self.handle, 1 if enable else 0), "nrdHipSetProfiling")
+
+    def collect_pass_timings(self):
+        """{shaderFileName: (total_ms, launches)} for all dispatches since the last collect (synchronises the stream)."""
+        n = len(self.instance.pipelines)
+        idx, ms, cnt, written = (C.c_uint32 * n)(), (C.c_double * n)(), (C.c_uint32 * n)(), C.c_uint32()
+        self._check(self.lib.nrdHipCollectPassTimings(self.handle, idx, ms, cnt, n, C.byref(written)), "nrdHipCollectPassTimings")
+        return {self.instance.pipelines[idx[i]]: (ms[i], cnt[i]) for i in range(written.value)}
 
     def pool_memory(self):
         p, t = C.c_uint64(), C.c_uint64()
