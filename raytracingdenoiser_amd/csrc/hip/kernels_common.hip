@@ -79,6 +79,12 @@ __global__ __launch_bounds__(256) void EvalNumericsKernel(uint32_t op, const flo
         case 5: r = a / b; break;
         case 6: r = Sqrt(a); break;
         case 7: r = Rsqrt(a); break;
+        case 8: r = NRD_DIV_1023(a); break;
+        case 9: r = NRD_DIV_255(a); break;
+        case 10: r = NRD_DIV_63(a); break;
+        case 11: r = NRD_DIV_15(a); break;
+        case 12: r = NRD_DIV_3(a); break;
+        case 13: r = Exp(-0.66f * a * a); break; // GetGaussianWeight
         default: break;
     }
     out[i] = r;

@@ -129,11 +129,11 @@ NRD_D float4 DiffuseSpatialFilter(const ReblurCB& c, const SpatialCtx& s, float4
         uv = uv * rectSizeInv;
         float2 uvScaled = F2(Min(uv.x * resolutionScale.x, uvMax.x), Min(uv.y * resolutionScale.y, uvMax.y));
 
-        int2 tz = NearestTexel(gIn_ViewZ, uvScaled);
+        // all planes of a pass have the resource size (checked by the executor): one texel index serves the three fetches
+        const int2 tz = NearestTexel(gIn_ViewZ, uvScaled);
         float zs = UnpackViewZ(c, LoadR32F(gIn_ViewZ, tz.x, tz.y));
-        int2 tn = NearestTexel(gIn_Normal_Roughness, uvScaled);
         float materialIDs;
-        float4 Ns = UnpackNormalAndRoughness(LoadR10G10B10A2(gIn_Normal_Roughness, tn.x, tn.y), materialIDs);
+        float4 Ns = UnpackNormalAndRoughness(LoadR10G10B10A2(gIn_Normal_Roughness, tz.x, tz.y), materialIDs);
 
         float angle = AcosApprox(Dot(s.N, Xyz(Ns)));
         float3 Xvs = ReconstructViewPosition(uv, ToF4(c.gFrustum), zs, c.gOrthoMode);
@@ -143,12 +143,11 @@ NRD_D float4 DiffuseSpatialFilter(const ReblurCB& c, const SpatialCtx& s, float4
         w *= CompareMaterials(s.materialID, materialIDs, c.gDiffMinMaterial) ? 1.0f : 0.0f;
         w *= ComputeWeight(angle, normalWeightParam, 0.0f);
 
-        int2 ts = NearestTexel(gIn_Diff, uvScaled);
-        float4 smp = LoadRGBA16F(gIn_Diff, ts.x, ts.y);
+        float4 smp = LoadRGBA16F(gIn_Diff, tz.x, tz.y);
         smp = w == 0.0f ? F4(0.0f) : smp;
 
         w *= Lerp(minHitDistWeight, 1.0f, ComputeExponentialWeight(smp.w, hitDistanceWeightParams.x, hitDistanceWeightParams.y));
-        w *= GetGaussianWeight(offset.z);
+        w *= n < 4 ? REBLUR_GAUSSIAN_WEIGHT_Z1 : REBLUR_GAUSSIAN_WEIGHT_Z05; // = GetGaussianWeight( offset.z )
 
         sum += w;
         diff = diff + smp * w;
@@ -254,11 +253,11 @@ NRD_D float4 SpecularSpatialFilter(const ReblurCB& c, const SpatialCtx& s, float
         uv = uv * rectSizeInv;
         float2 uvScaled = F2(Min(uv.x * resolutionScale.x, uvMax.x), Min(uv.y * resolutionScale.y, uvMax.y));
 
-        int2 tz = NearestTexel(gIn_ViewZ, uvScaled);
+        // all planes of a pass have the resource size (checked by the executor): one texel index serves the three fetches
+        const int2 tz = NearestTexel(gIn_ViewZ, uvScaled);
         float zs = UnpackViewZ(c, LoadR32F(gIn_ViewZ, tz.x, tz.y));
-        int2 tn = NearestTexel(gIn_Normal_Roughness, uvScaled);
         float materialIDs;
-        float4 Ns = UnpackNormalAndRoughness(LoadR10G10B10A2(gIn_Normal_Roughness, tn.x, tn.y), materialIDs);
+        float4 Ns = UnpackNormalAndRoughness(LoadR10G10B10A2(gIn_Normal_Roughness, tz.x, tz.y), materialIDs);
 
         float angle = AcosApprox(Dot(s.N, Xyz(Ns)));
         float3 Xvs = ReconstructViewPosition(uv, ToF4(c.gFrustum), zs, c.gOrthoMode);
@@ -269,8 +268,7 @@ NRD_D float4 SpecularSpatialFilter(const ReblurCB& c, const SpatialCtx& s, float
         w *= ComputeWeight(angle, normalWeightParam, 0.0f);
         w *= ComputeWeight(Ns.w, roughnessWeightParams.x, roughnessWeightParams.y);
 
-        int2 ts = NearestTexel(gIn_Spec, uvScaled);
-        float4 smp = LoadRGBA16F(gIn_Spec, ts.x, ts.y);
+        float4 smp = LoadRGBA16F(gIn_Spec, tz.x, tz.y);
         smp = w == 0.0f ? F4(0.0f) : smp;
 
         if (MODE == PRE_BLUR) {
@@ -286,7 +284,7 @@ NRD_D float4 SpecularSpatialFilter(const ReblurCB& c, const SpatialCtx& s, float
             w *= Lerp(Sat(t), 1.0f, LinearStep(0.5f, 1.0f, s.roughness));
         }
         w *= Lerp(minHitDistWeight, 1.0f, ComputeExponentialWeight(smp.w, hitDistanceWeightParams.x, hitDistanceWeightParams.y));
-        w *= GetGaussianWeight(offset.z);
+        w *= n < 4 ? REBLUR_GAUSSIAN_WEIGHT_Z1 : REBLUR_GAUSSIAN_WEIGHT_Z05; // = GetGaussianWeight( offset.z )
 
         sum += w;
         spec = spec + smp * w;

@@ -24,10 +24,25 @@ struct Plane {
 
 NRD_D bool InBounds(const Plane& p, int x, int y) { return (unsigned)x < (unsigned)p.w && (unsigned)y < (unsigned)p.h; }
 
+// 32-bit byte offsets (planes are far below 4 GiB): one v_mad_u32 instead of 64-bit multiply-adds per access
 template <typename T>
 NRD_D T* TexelPtr(const Plane& p, int x, int y) {
-    return (T*)(p.ptr + (size_t)y * p.pitch) + x;
+    return (T*)(p.ptr + ((uint32_t)y * p.pitch + (uint32_t)x * (uint32_t)sizeof(T)));
 }
+
+// k / c for a small non-negative integer k held in a float, bit-identical to the IEEE quotient but 3 VALU ops instead
+// of the ~11 of a generic correctly rounded division: q0 = k * RN(1/c), r = fma(-q0, c, k) (exact), q = fma(r, RN(1/c), q0).
+// Exhaustively verified for every numerator the codecs can produce (tests/test_numerics.py: c = 1023, 255, 63, 15, 3).
+NRD_D float DivSmallIntByConst(float k, float c, float rcpC) {
+    float q0 = k * rcpC;
+    float r = __builtin_fmaf(-q0, c, k);
+    return __builtin_fmaf(r, rcpC, q0);
+}
+#define NRD_DIV_1023(k) DivSmallIntByConst(k, 1023.0f, 0.0009775171056389809f)
+#define NRD_DIV_255(k) DivSmallIntByConst(k, 255.0f, 0.003921568859368563f)
+#define NRD_DIV_63(k) DivSmallIntByConst(k, 63.0f, 0.01587301678955555f)
+#define NRD_DIV_15(k) DivSmallIntByConst(k, 15.0f, 0.06666667014360428f)
+#define NRD_DIV_3(k) DivSmallIntByConst(k, 3.0f, 0.3333333432674408f)
 
 // ---- fp16 -------------------------------------------------------------------------------------------------------
 NRD_D float HalfBitsToFloat(uint16_t h) { return __half2float(__ushort_as_half(h)); }
@@ -79,12 +94,12 @@ NRD_D void StoreRGBA32F(const Plane& p, int x, int y, float4 v) { *TexelPtr<floa
 NRD_D float Saturate(float x) { return fminf(fmaxf(x, 0.0f), 1.0f); }
 NRD_D uint32_t ToUnorm(float x, float maxValue) { return (uint32_t)floorf(Saturate(x) * maxValue + 0.5f); }
 
-NRD_D float LoadR8Unorm(const Plane& p, int x, int y) { return float(*TexelPtr<const uint8_t>(p, x, y)) / 255.0f; }
+NRD_D float LoadR8Unorm(const Plane& p, int x, int y) { return NRD_DIV_255(float(*TexelPtr<const uint8_t>(p, x, y))); }
 NRD_D void StoreR8Unorm(const Plane& p, int x, int y, float v) { *TexelPtr<uint8_t>(p, x, y) = (uint8_t)ToUnorm(v, 255.0f); }
 
 NRD_D float2 LoadRG8Unorm(const Plane& p, int x, int y) {
     uint32_t raw = *TexelPtr<const uint16_t>(p, x, y);
-    return make_float2(float(raw & 0xFFu) / 255.0f, float(raw >> 8) / 255.0f);
+    return make_float2(NRD_DIV_255(float(raw & 0xFFu)), NRD_DIV_255(float(raw >> 8)));
 }
 NRD_D void StoreRG8Unorm(const Plane& p, int x, int y, float2 v) {
     *TexelPtr<uint16_t>(p, x, y) = (uint16_t)(ToUnorm(v.x, 255.0f) | (ToUnorm(v.y, 255.0f) << 8));
@@ -92,10 +107,10 @@ NRD_D void StoreRG8Unorm(const Plane& p, int x, int y, float2 v) {
 
 NRD_D float4 DecodeR10G10B10A2(uint32_t raw) {
     float4 r;
-    r.x = float(raw & 0x3FFu) / 1023.0f;
-    r.y = float((raw >> 10) & 0x3FFu) / 1023.0f;
-    r.z = float((raw >> 20) & 0x3FFu) / 1023.0f;
-    r.w = float(raw >> 30) / 3.0f;
+    r.x = NRD_DIV_1023(float(raw & 0x3FFu));
+    r.y = NRD_DIV_1023(float((raw >> 10) & 0x3FFu));
+    r.z = NRD_DIV_1023(float((raw >> 20) & 0x3FFu));
+    r.w = NRD_DIV_3(float(raw >> 30));
     return r;
 }
 NRD_D float4 LoadR10G10B10A2(const Plane& p, int x, int y) { return DecodeR10G10B10A2(*TexelPtr<const uint32_t>(p, x, y)); }

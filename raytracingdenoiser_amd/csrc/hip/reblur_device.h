@@ -38,7 +38,11 @@ NRD_D float4 ToF4(nrdc::F4 v) { return F4(v.x, v.y, v.z, v.w); }
 NRD_D float3 ToF3(nrdc::F4 v) { return F3(v.x, v.y, v.z); }
 NRD_D float2 ToF2(nrdc::F2 v) { return F2(v.x, v.y); }
 
-// ---- Poisson-like 8-tap kernel (reference Common.hlsli:181-192) + Gaussian tap weight exp(-0.66 r^2) ------------------
+// ---- Poisson-like 8-tap kernel (reference Common.hlsli:181-192) ------------------------------------------------------
+// GetGaussianWeight( offset.z ) = Exp( -0.66 z^2 ) only ever sees z = 1 and z = 0.5: the two results of OUR Exp() are
+// baked in as bit patterns (0x3f04505e, 0x3f590f90; tests/test_numerics.py re-derives them on the GPU).
+#define REBLUR_GAUSSIAN_WEIGHT_Z1 0.5168513059616089f
+#define REBLUR_GAUSSIAN_WEIGHT_Z05 0.8478937149047852f
 __device__ __constant__ const float g_Special8[8][3] = {{-1.0f, 0.0f, 1.0f}, {0.0f, 1.0f, 1.0f}, {1.0f, 0.0f, 1.0f}, {0.0f, -1.0f, 1.0f},
     {-0.25f * 1.41421356f, 0.25f * 1.41421356f, 0.5f}, {0.25f * 1.41421356f, 0.25f * 1.41421356f, 0.5f}, {0.25f * 1.41421356f, -0.25f * 1.41421356f, 0.5f},
     {-0.25f * 1.41421356f, -0.25f * 1.41421356f, 0.5f}};
@@ -52,7 +56,7 @@ NRD_D uint32_t PackInternalData(float diffAccumSpeed, float specAccumSpeed, floa
     return p;
 }
 NRD_D float3 UnpackInternalData(uint32_t p) {
-    float3 t = F3(float(p & 63u) / 63.0f, float((p >> 6) & 63u) / 63.0f, float((p >> 12) & 15u) / 15.0f);
+    float3 t = F3(NRD_DIV_63(float(p & 63u)), NRD_DIV_63(float((p >> 6) & 63u)), NRD_DIV_15(float((p >> 12) & 15u)));
     t.x *= REBLUR_MAX_ACCUM_FRAME_NUM;
     t.y *= REBLUR_MAX_ACCUM_FRAME_NUM;
     t.z *= REBLUR_MAX_MATERIALID_NUM;
@@ -86,7 +90,7 @@ NRD_D uint32_t PackData2(float fbits, float curvature, float virtualHistoryAmoun
 }
 NRD_D float2 UnpackData2(uint32_t p, uint32_t& bits) {
     bits = p & 0xFFu;
-    return F2(float((p >> 8) & 0xFFu) / 255.0f, HalfBitsToFloat((uint16_t)(p >> 16)));
+    return F2(NRD_DIV_255(float((p >> 8) & 0xFFu)), HalfBitsToFloat((uint16_t)(p >> 16)));
 }
 
 // ---- helpers ------------------------------------------------------------------------------------------------------

@@ -90,3 +90,26 @@ def test_hip_numerics_bit_exact_vs_oracle():
     assert np.array_equal(out.cpu().numpy().view(np.uint32), np.sqrt(pa).view(np.uint32))
     lib.nrdHipEvalNumerics(7, ta.data_ptr(), None, out.data_ptr(), n, torch.cuda.current_stream().cuda_stream)
     assert np.array_equal(out.cpu().numpy().view(np.uint32), (np.float32(1.0) / np.sqrt(pa)).view(np.uint32))
+
+
+@pytest.mark.gpu
+def test_hip_exact_constant_division_and_gaussian_constants():
+    """planes.h: k / c via q0 = k*R, r = fma(-q0,c,k), q = fma(r,R,q0) equals the IEEE quotient for every numerator the codecs
+    produce; reblur_device.h: the two baked Gaussian tap weights equal Exp(-0.66 z^2) evaluated on the device."""
+    import torch
+
+    from raytracingdenoiser_amd import api
+
+    lib = api.load_library()
+    stream = torch.cuda.current_stream().cuda_stream
+    for op, c, n in ((8, 1023.0, 1024), (9, 255.0, 256), (10, 63.0, 64), (11, 15.0, 16), (12, 3.0, 4)):
+        k = np.arange(n, dtype=np.float32)
+        t, out = torch.from_numpy(k).cuda(), torch.empty(n, device="cuda")
+        assert lib.nrdHipEvalNumerics(op, t.data_ptr(), None, out.data_ptr(), n, stream) == 0
+        assert np.array_equal(out.cpu().numpy().view(np.uint32), (k / np.float32(c)).view(np.uint32))
+    z = np.array([1.0, 0.5], dtype=np.float32)
+    t, out = torch.from_numpy(z).cuda(), torch.empty(2, device="cuda")
+    assert lib.nrdHipEvalNumerics(13, t.data_ptr(), None, out.data_ptr(), 2, stream) == 0
+    assert out.cpu().numpy().view(np.uint32).tolist() == [0x3F04505E, 0x3F590F90]
+    ora = oracle_driver.load()
+    assert np.float32(ora.oracle_exp2(float(np.float32(np.float32(-0.66) * np.float32(1.0) * np.float32(1.0)) * np.float32(1.44269504)))).view(np.uint32) == 0x3F04505E
