@@ -1,2 +1,470 @@
+// ORACLE -- TEST INFRASTRUCTURE, NOT PRODUCT CODE (see oracle/hlsl.h).
+//
+// CPU restatement of the SIGMA_SHADOW pass chain (shadow only, no translucency).
+//   ClassifyTiles           reference Shaders/Include/SIGMA_ClassifyTiles.hlsli:11-81
+//   SmoothTiles             reference Shaders/Include/SIGMA_SmoothTiles.hlsli:11-48
+//   Copy                    reference Shaders/Include/SIGMA_Copy.hlsli:11-24
+//   Blur / PostBlur         reference Shaders/Include/SIGMA_Blur.hlsli:11-268 (SIGMA_FIRST_PASS / not)
+//   TemporalStabilization   reference Shaders/Include/SIGMA_TemporalStabilization.hlsli:11-226
+//   SplitScreen             reference Shaders/Include/SIGMA_SplitScreen.hlsli:11-35
+//   helpers                 reference Shaders/Include/SIGMA_Common.hlsli:11-125, SIGMA_Config.hlsli:13-36
+// Binding order of planes = reference Source/Denoisers/Sigma_Shadow.hpp:50-155.
 #include "passes.h"
-namespace orc { const PassEntry* GetSigmaPasses(uint32_t& n) { n = 0; return nullptr; } }
+#include "reblur_common.h" // MakeHistoryFilter (shared Common.hlsli:602-656 machinery), CompareMaterials etc.
+
+namespace orc {
+
+namespace {
+
+struct SigmaCB { // reference Shaders/Include/SIGMA_Config.hlsli:45-80
+    float4x4 gWorldToView, gViewToClip, gWorldToClipPrev, gWorldToViewPrev;
+    float4 gRotator, gRotatorPost, gViewVectorWorld, gLightDirectionView, gFrustum, gFrustumPrev, gCameraDelta, gMvScale;
+    float2 gResourceSizeInv, gResourceSizeInvPrev, gRectSize, gRectSizeInv, gRectSizePrev, gResolutionScale, gRectOffset;
+    uint32_t gPrintfAt[2], gRectOrigin[2];
+    int gRectSizeMinusOne[2], gTilesSizeMinusOne[2];
+    float gOrthoMode, gUnproject, gDenoisingRange, gPlaneDistSensitivity, gStabilizationStrength, gDebug, gSplitScreen, gViewZScale, gMinRectDimMulUnproject;
+    uint32_t gFrameIndex, gIsRectChanged;
+};
+static_assert(sizeof(SigmaCB) == 516, "SIGMA constant block");
+
+constexpr float SIGMA_MAX_PIXEL_RADIUS = 32.0f;
+constexpr float SIGMA_TS_SIGMA_SCALE = 3.0f;
+constexpr float SIGMA_MAX_ACCUM_FRAME_NUM = 7.0f;
+constexpr int BORDER = 2;
+
+inline float UnpackViewZ(const SigmaCB& c, float z) { return fabsf(z * c.gViewZScale); }
+inline bool IsLit(float p) { return p >= NRD_FP16_MAX; }
+inline float PackShadow(float s) { return Math::Sqrt01(s); }
+inline float UnpackShadow(float s) { return s * s; } // SIGMA_BackEnd_UnpackShadow, NRD.hlsli:931
+inline float3 GetViewVectorV(const SigmaCB& c, float3 X) { return c.gOrthoMode == 0.0f ? normalize(-X) : float3(0, 0, -1); }
+
+// SIGMA_Common.hlsli:21-33 (5x5 radius-estimation kernel => minimum radius 2)
+inline float GetKernelRadiusInPixels(float hitDist, float unprojectZ, float scale = 1.0f) {
+    float unclampedRadius = hitDist / unprojectZ;
+    unclampedRadius *= scale;
+    float minRadius = min(unclampedRadius, 2.0f);
+    return clamp(unclampedRadius, minRadius, SIGMA_MAX_PIXEL_RADIUS);
+}
+inline float AreBothLitOrUnlit(float penumbra1, float penumbra2) { return ((penumbra1 == 0.0f) == (penumbra2 == 0.0f)) ? 1.0f : 0.0f; }
+
+// SIGMA_Common.hlsli:45-92 restated in scalar form; returns channel .y of the bicubically filtered RG8 tile map
+inline void BicubicAxis(float f, float& w0, float& w1, float& wz) {
+    const float k = 1.0f / 6.0f;
+    float f2 = f * f, f3 = f2 * f;
+    float phix = k * (-1.0f * f3 + 3.0f * f2 + -3.0f * f + 1.0f);
+    float phiy = k * (3.0f * f3 + -6.0f * f2 + 0.0f * f + 4.0f);
+    float phiz = k * (-3.0f * f3 + 3.0f * f2 + 3.0f * f + 1.0f);
+    float phiw = k * (1.0f * f3 + 0.0f * f2 + 0.0f * f + 0.0f);
+    w0 = 1.0f + 1.0f * f + -1.0f * phiy / (phix + phiy);
+    w1 = 1.0f + -1.0f * f + 1.0f * phiw / (phiz + phiw);
+    wz = phix + phiy;
+}
+inline float TextureCubicY(const Tex& tex, float2 uv) {
+    float2 size = float2(float(tex.W()), float(tex.H()));
+    float dx = -1.0f / size.x, dy = -1.0f / size.y;
+    float2 t = uv * size - 0.5f;
+    float2 f = float2(frac(t.x), frac(t.y));
+    float xw0, xw1, xwz, yw0, yw1, ywz;
+    BicubicAxis(f.x, xw0, xw1, xwz);
+    BicubicAxis(f.y, yw0, yw1, ywz);
+    // uv_10_00 = uv.xyxy + (1,1,-1,-1) * xw.xxyy * (dx,-0,dx,-0)  ->  x coordinates only move
+    float u10 = uv.x + 1.0f * xw0 * dx, u00 = uv.x + -1.0f * xw1 * dx;
+    // uv_11_01 = uv_10_00 + yw.x * (-0,dy,-0,dy) ; uv_10_00 -= yw.y * (-0,dy,-0,dy)
+    float v1 = uv.y + yw0 * dy, v0 = uv.y - yw1 * dy;
+    float c00 = tex.SampleLinearTexel(float2(u00, v0) * size).y;
+    float c10 = tex.SampleLinearTexel(float2(u10, v0) * size).y;
+    float c01 = tex.SampleLinearTexel(float2(u00, v1) * size).y;
+    float c11 = tex.SampleLinearTexel(float2(u10, v1) * size).y;
+    float tx = ywz, ty = xwz; // return float2( yw.z, xw.z )
+    c00 = lerp(c00, c01, tx);
+    c10 = lerp(c10, c11, tx);
+    return lerp(c00, c10, ty);
+}
+
+// ================================================================================================ ClassifyTiles
+void ClassifyTiles(const PassIO& io) {
+    const SigmaCB& c = *(const SigmaCB*)io.constants;
+    const Tex& gIn_ViewZ = io.t[0];
+    const Tex& gIn_Penumbra = io.t[1];
+    Tex& gOut_Tiles = io.t[2];
+#pragma omp parallel for schedule(static)
+    for (int ty = 0; ty < gOut_Tiles.H(); ty++)
+        for (int tx = 0; tx < gOut_Tiles.W(); tx++) {
+            uint32_t lit = 0, umbra = 0, inf = 0;
+            float maxRadius = 0.0f;
+            for (int j = 0; j < 16; j++)
+                for (int i = 0; i < 16; i++) {
+                    int x = tx * 16 + i, y = ty * 16 + j;
+                    float h = gIn_Penumbra.Load(x, y).x;
+                    float viewZ = UnpackViewZ(c, gIn_ViewZ.Load(x, y).x);
+                    bool isInf = viewZ > c.gDenoisingRange, isShadow = h == 0.0f, isLitP = IsLit(h);
+                    lit += (isLitP || isInf || isShadow) ? 1 : 0;
+                    umbra += (!isLitP || isInf || isShadow) ? 1 : 0; // isOpaque = true without translucency
+                    inf += isInf ? 1 : 0;
+                    float hitDist = (isLitP || isInf) ? 0.0f : h;
+                    float pixelSize = PixelRadiusToWorld(c.gUnproject, c.gOrthoMode, 1.0f, viewZ);
+                    maxRadius = max(GetKernelRadiusInPixels(hitDist, pixelSize), maxRadius);
+                }
+            bool isLitT = lit == 256, isUmbra = umbra == 256, isInfT = inf == 256;
+            float4 result = float4((isLitT || isUmbra) ? 0.0f : 1.0f, saturate(maxRadius / 16.0f), isInfT ? 1.0f : 0.0f, 0.0f);
+            gOut_Tiles.Store(tx, ty, result);
+        }
+}
+
+// ================================================================================================ SmoothTiles
+void SmoothTiles(const PassIO& io) {
+    const SigmaCB& c = *(const SigmaCB*)io.constants;
+    const Tex& gIn_Tiles = io.t[0];
+    Tex& gOut_Tiles = io.t[1];
+    for (int y = 0; y < gOut_Tiles.H(); y++)
+        for (int x = 0; x < gOut_Tiles.W(); x++) {
+            float4 center = gIn_Tiles.Load(x, y);
+            float blurry = 0.0f, sumw = 0.0f;
+            float k = 1.01f / (center.y + 0.01f);
+            for (int j = 0; j <= 2; j++)
+                for (int i = 0; i <= 2; i++) {
+                    float d = length(float2(float(i), float(j)) - 1.0f);
+                    float w = exp2(-k * d * d);
+                    int sx = clamp(x - 1 + i, 0, c.gTilesSizeMinusOne[0]), sy = clamp(y - 1 + j, 0, c.gTilesSizeMinusOne[1]);
+                    blurry += gIn_Tiles.Load(sx, sy).x * w;
+                    sumw += w;
+                }
+            blurry /= sumw;
+            gOut_Tiles.Store(x, y, float4(center.z, blurry, 0.0f, 0.0f));
+        }
+}
+
+// ================================================================================================ Copy
+void Copy(const PassIO& io) {
+    const SigmaCB& c = *(const SigmaCB*)io.constants;
+    const Tex& gIn_Tiles = io.t[0];
+    const Tex& gIn_History = io.t[1];
+    const Tex& gIn_HistoryLength = io.t[2];
+    Tex& gOut_History = io.t[3];
+    Tex& gOut_HistoryLength = io.t[4];
+#pragma omp parallel for schedule(static)
+    for (int y = 0; y < gOut_History.H(); y++)
+        for (int x = 0; x < gOut_History.W(); x++) {
+            float isSky = gIn_Tiles.Load(x >> 4, y >> 4).x;
+            if (isSky != 0.0f && !c.gIsRectChanged)
+                continue;
+            gOut_History.Store(x, y, gIn_History.Load(x, y)); // R8 -> R8: the stored byte round-trips exactly
+            gOut_HistoryLength.StoreUint(x, y, gIn_HistoryLength.LoadUint(x, y));
+        }
+}
+
+// ================================================================================================ Blur / PostBlur
+template <bool FIRST_PASS>
+void Blur(const PassIO& io) {
+    const SigmaCB& c = *(const SigmaCB*)io.constants;
+    uint32_t k = 0;
+    const Tex& gIn_ViewZ = io.t[k++];
+    const Tex& gIn_Normal_Roughness = io.t[k++];
+    const Tex& gIn_Penumbra = io.t[k++];
+    const Tex& gIn_Tiles = io.t[k++];
+    const Tex* gIn_Shadow = FIRST_PASS ? nullptr : &io.t[k++];
+    Tex& gOut_Penumbra = io.t[k++];
+    Tex& gOut_Shadow = io.t[k++];
+    const int rw = c.gRectSizeMinusOne[0], rh = c.gRectSizeMinusOne[1];
+
+#pragma omp parallel for schedule(dynamic, 4)
+    for (int py = 0; py <= rh; py++)
+        for (int px = 0; px <= rw; px++) {
+            float isSky = gIn_Tiles.Load(px >> 4, py >> 4).x;
+            if (isSky != 0.0f)
+                continue;
+
+            // "shared memory" with clamped coordinates
+            auto sPenumbra = [&](int x, int y) { return gIn_Penumbra.Load(clamp(x, 0, rw), clamp(y, 0, rh)).x; };
+            auto sViewZ = [&](int x, int y) { return UnpackViewZ(c, gIn_ViewZ.Load(clamp(x, 0, rw), clamp(y, 0, rh)).x); };
+            auto sShadow = [&](int x, int y) {
+                x = clamp(x, 0, rw), y = clamp(y, 0, rh);
+                if (FIRST_PASS)
+                    return IsLit(gIn_Penumbra.Load(x, y).x) ? 1.0f : 0.0f;
+                return UnpackShadow(gIn_Shadow->Load(x, y).x);
+            };
+
+            float centerPenumbra = sPenumbra(px, py);
+            float viewZ = sViewZ(px, py);
+            if (viewZ > c.gDenoisingRange)
+                continue;
+
+            float2 pixelUv = float2(float(px) + 0.5f, float(py) + 0.5f) * c.gRectSizeInv;
+            float tileValue = TextureCubicY(gIn_Tiles, pixelUv * c.gResolutionScale);
+
+            if (tileValue == 0.0f || centerPenumbra == 0.0f) {
+                gOut_Penumbra.Store(px, py, centerPenumbra);
+                gOut_Shadow.Store(px, py, PackShadow(sShadow(px, py)));
+                continue;
+            }
+
+            float3 Xv = Geometry::ReconstructViewPosition(pixelUv, c.gFrustum, viewZ, c.gOrthoMode);
+            float3 N = NRD_FrontEnd_UnpackNormalAndRoughness(gIn_Normal_Roughness.Load(px, py)).xyz();
+            float3 Nv = Geometry::RotateVector(c.gWorldToView, N);
+
+            float pixelSize = PixelRadiusToWorld(c.gUnproject, c.gOrthoMode, 1.0f, viewZ);
+            float frustumSize = GetFrustumSize(c.gMinRectDimMulUnproject, c.gOrthoMode, viewZ);
+            float3 Vv = GetViewVectorV(c, Xv);
+            float NoV = fabsf(dot(Nv, Vv));
+            float2 geometryWeightParams = GetGeometryWeightParams(c.gPlaneDistSensitivity, frustumSize, Xv, Nv);
+
+            // Dense 5x5: penumbra size estimate + shadow filter
+            float sumx = 0.0f, sumy = 0.0f, penumbra = 0.0f, result = 0.0f, centerTap = 0.0f;
+            for (int j = 0; j <= BORDER * 2; j++)
+                for (int i = 0; i <= BORDER * 2; i++) {
+                    int x = px - BORDER + i, y = py - BORDER + j;
+                    float penum = sPenumbra(x, y), zs = sViewZ(x, y), s = sShadow(x, y);
+
+                    float w = 1.0f;
+                    if (i == BORDER && j == BORDER)
+                        centerTap = s;
+                    else {
+                        float2 uv = pixelUv + float2(float(i - BORDER), float(j - BORDER)) * c.gRectSizeInv;
+                        float3 Xvs = Geometry::ReconstructViewPosition(uv, c.gFrustum, zs, c.gOrthoMode);
+                        w *= ComputeWeight(dot(Nv, Xvs), geometryWeightParams.x, geometryWeightParams.y);
+                        w *= AreBothLitOrUnlit(centerPenumbra, penum);
+                        w *= GetGaussianWeight(length(float2(float(i - BORDER), float(j - BORDER)) / float(BORDER)));
+                    }
+
+                    result += w == 0.0f ? 0.0f : s * w;
+                    sumx += w;
+
+                    w *= pixelSize / (pixelSize + penum);
+                    w *= IsLit(penum) ? 0.0f : 1.0f;
+
+                    penumbra += w == 0.0f ? 0.0f : penum * w;
+                    sumy += w;
+                }
+
+            result /= sumx;
+            sumx = 1.0f;
+            penumbra /= max(sumy, NRD_EPS);
+            sumy = sumy != 0.0f ? 1.0f : 0.0f;
+
+            // Avoid a blurry result if the penumbra is smaller than the dense kernel
+            float penumbraInPixels = penumbra / pixelSize;
+            float f = Math::SmoothStep(0.0f, float(BORDER), penumbraInPixels);
+            result = lerp(centerTap, result, f);
+
+            // Sparse 8-tap blur
+            f = lerp(4.0f, 1.0f, f);
+            result *= f;
+            penumbra *= f;
+            sumx *= f;
+            sumy *= f;
+
+            float blurRadius = GetKernelRadiusInPixels(penumbra, pixelSize, tileValue);
+            float4 rotator = FIRST_PASS ? c.gRotator : c.gRotatorPost;
+
+            float2 skew = lerp(float2(1.0f - fabsf(Nv.x), 1.0f - fabsf(Nv.y)), float2(1.0f), NoV);
+            skew /= max(skew.x, skew.y);
+            skew *= c.gRectSizeInv * blurRadius;
+            float4 scaledRotator = Geometry::ScaleRotator(rotator, skew);
+
+            float invEstimatedPenumbra = 1.0f / max(penumbra, NRD_EPS);
+
+            for (int n = 0; n < 8; n++) {
+                float3 offset = g_Special8[n];
+                float2 uv = pixelUv + Geometry::RotateVector(scaledRotator, float2(offset.x, offset.y));
+                uv = (floor(uv * c.gRectSize) + 0.5f) * c.gRectSizeInv;
+                float2 uvScaled = min(uv * c.gResolutionScale, c.gResolutionScale - 0.5f * c.gResourceSizeInv);
+
+                float penum = gIn_Penumbra.SampleNearest(uvScaled).x;
+                float zs = UnpackViewZ(c, gIn_ViewZ.SampleNearest(uvScaled).x);
+                float s = FIRST_PASS ? (IsLit(penum) ? 1.0f : 0.0f) : UnpackShadow(gIn_Shadow->SampleNearest(uvScaled).x);
+
+                float3 Xvs = Geometry::ReconstructViewPosition(uv, c.gFrustum, zs, c.gOrthoMode);
+
+                float w = IsInScreenNearest(uv);
+                w *= ComputeWeight(dot(Nv, Xvs), geometryWeightParams.x, geometryWeightParams.y);
+                w *= AreBothLitOrUnlit(centerPenumbra, penum);
+                w *= GetGaussianWeight(offset.z);
+                w *= saturate(penum * invEstimatedPenumbra); // avoid umbra leaking inside a wide penumbra
+
+                result += w == 0.0f ? 0.0f : s * w;
+                sumx += w;
+
+                w *= pixelSize / (pixelSize + penum);
+                w *= IsLit(penum) ? 0.0f : 1.0f;
+
+                penumbra += w == 0.0f ? 0.0f : penum * w;
+                sumy += w;
+            }
+
+            result /= sumx;
+            penumbra = sumy == 0.0f ? centerPenumbra : penumbra / sumy;
+
+            if (FIRST_PASS || c.gStabilizationStrength != 0.0f)
+                gOut_Penumbra.Store(px, py, penumbra);
+            gOut_Shadow.Store(px, py, PackShadow(result));
+        }
+}
+
+// ================================================================================================ TemporalStabilization
+inline uint32_t PackViewZAndHistoryLength(float viewZ, float historyLength) {
+    uint32_t p = asuint(viewZ) & ~7u;
+    uint32_t h = (uint32_t)(historyLength + 0.5f);
+    p |= h < 7u ? h : 7u;
+    return p;
+}
+
+void TemporalStabilization(const PassIO& io) {
+    const SigmaCB& c = *(const SigmaCB*)io.constants;
+    const Tex& gIn_ViewZ = io.t[0];
+    const Tex& gIn_Mv = io.t[1];
+    const Tex& gIn_Penumbra = io.t[2];
+    const Tex& gIn_Shadow = io.t[3];
+    const Tex& gIn_History = io.t[4];
+    const Tex& gIn_HistoryLength = io.t[5];
+    const Tex& gIn_Tiles = io.t[6];
+    Tex& gOut_Shadow = io.t[7];
+    Tex& gOut_HistoryLength = io.t[8];
+    const int rw = c.gRectSizeMinusOne[0], rh = c.gRectSizeMinusOne[1];
+
+#pragma omp parallel for schedule(dynamic, 4)
+    for (int py = 0; py <= rh; py++)
+        for (int px = 0; px <= rw; px++) {
+            float isSky = gIn_Tiles.Load(px >> 4, py >> 4).x;
+            auto sShadow = [&](int x, int y) { return UnpackShadow(gIn_Shadow.Load(clamp(x, 0, rw), clamp(y, 0, rh)).x); };
+            auto sPenumbra = [&](int x, int y) { return gIn_Penumbra.Load(clamp(x, 0, rw), clamp(y, 0, rh)).x; };
+
+            float centerPenumbra = sPenumbra(px, py);
+            float viewZ = UnpackViewZ(c, gIn_ViewZ.Load(px, py).x);
+            if (isSky != 0.0f || viewZ > c.gDenoisingRange)
+                continue;
+
+            float2 pixelUv = float2(float(px) + 0.5f, float(py) + 0.5f) * c.gRectSizeInv;
+            float tileValue = TextureCubicY(gIn_Tiles, pixelUv * c.gResolutionScale);
+            bool isHardShadow = tileValue == 0.0f || centerPenumbra == 0.0f;
+            if (isHardShadow) {
+                gOut_Shadow.Store(px, py, PackShadow(sShadow(px, py)));
+                gOut_HistoryLength.StoreUint(px, py, PackViewZAndHistoryLength(viewZ, SIGMA_MAX_ACCUM_FRAME_NUM));
+                continue;
+            }
+
+            // Local variance over 5x5
+            float sumw = 0.0f, m1 = 0.0f, m2 = 0.0f, input = 0.0f;
+            for (int j = 0; j <= BORDER * 2; j++)
+                for (int i = 0; i <= BORDER * 2; i++) {
+                    int x = px - BORDER + i, y = py - BORDER + j;
+                    float s = sShadow(x, y);
+                    float w = 1.0f;
+                    if (i == BORDER && j == BORDER)
+                        input = s;
+                    else {
+                        float penum = sPenumbra(x, y);
+                        w = AreBothLitOrUnlit(centerPenumbra, penum);
+                        w *= GetGaussianWeight(length(float2(float(i - BORDER), float(j - BORDER)) / float(BORDER)));
+                    }
+                    m1 += s * w;
+                    m2 += s * s * w;
+                    sumw += w;
+                }
+            m1 /= sumw;
+            m2 /= sumw;
+            float sigma = sqrtf(fabsf(m2 - m1 * m1));
+
+            // Current and previous positions
+            float3 Xv = Geometry::ReconstructViewPosition(pixelUv, c.gFrustum, viewZ, c.gOrthoMode);
+            float3 X = Geometry::RotateVectorInverse(c.gWorldToView, Xv);
+
+            float4 mvRaw = gIn_Mv.Load(px, py);
+            float3 mv = float3(mvRaw.x, mvRaw.y, mvRaw.z) * c.gMvScale.xyz();
+            float3 Xprev = X;
+            float2 smbPixelUv = pixelUv + float2(mv.x, mv.y);
+            if (c.gMvScale.w == 0.0f) {
+                if (c.gMvScale.z == 0.0f)
+                    mv.z = Geometry::AffineTransform(c.gWorldToViewPrev, X).z - viewZ;
+                float viewZprev = viewZ + mv.z;
+                float3 Xvprevlocal = Geometry::ReconstructViewPosition(smbPixelUv, c.gFrustumPrev, viewZprev, c.gOrthoMode);
+                Xprev = Geometry::RotateVectorInverse(c.gWorldToViewPrev, Xvprevlocal) + c.gCameraDelta.xyz();
+            } else {
+                Xprev += mv;
+                smbPixelUv = Geometry::GetScreenUv(c.gWorldToClipPrev, Xprev);
+            }
+
+            // History length: 2x2 gather of (viewZ | length) words
+            Filtering::Bilinear smbBilinearFilter = Filtering::GetBilinearFilter(smbPixelUv, c.gRectSizePrev);
+            int bx = (int)smbBilinearFilter.origin.x, by = (int)smbBilinearFilter.origin.y;
+            uint32_t prevData[4] = {gIn_HistoryLength.FetchUintClamped(bx, by), gIn_HistoryLength.FetchUintClamped(bx + 1, by), gIn_HistoryLength.FetchUintClamped(bx, by + 1),
+                gIn_HistoryLength.FetchUintClamped(bx + 1, by + 1)};
+            float4 prevViewZ = float4(asfloat(prevData[0] & ~7u), asfloat(prevData[1] & ~7u), asfloat(prevData[2] & ~7u), asfloat(prevData[3] & ~7u));
+            float4 prevHistoryLength = float4(float(prevData[0] & 7u), float(prevData[1] & 7u), float(prevData[2] & 7u), float(prevData[3] & 7u));
+
+            float frustumSize = GetFrustumSize(c.gMinRectDimMulUnproject, c.gOrthoMode, viewZ);
+            float disocclusionThreshold = GetDisocclusionThreshold(NRD_DISOCCLUSION_THRESHOLD, frustumSize, 1.0f);
+            disocclusionThreshold *= IsInScreenNearest(smbPixelUv);
+            disocclusionThreshold -= NRD_EPS;
+
+            float3 Xvprev = Geometry::AffineTransform(c.gWorldToViewPrev, Xprev);
+            float4 smbPlaneDist = abs(prevViewZ - Xvprev.z);
+            float4 smbOcclusion = step(smbPlaneDist, float4(disocclusionThreshold));
+
+            float4 smbOcclusionWeights = Filtering::GetBilinearCustomWeights(smbBilinearFilter, smbOcclusion);
+            float historyLength = Filtering::ApplyBilinearCustomWeights(prevHistoryLength.x, prevHistoryLength.y, prevHistoryLength.z, prevHistoryLength.w, smbOcclusionWeights);
+
+            // Sample history. NB: the weights sum to <= 1, so this test never passes and the fetch is always custom-weight bilinear
+            // (kept exactly as in the reference, SIGMA_TemporalStabilization.hlsli:151)
+            bool isCatRomAllowed = sum(smbOcclusionWeights) > 3.5f;
+            HistoryFilter hf = MakeHistoryFilter(saturate(smbPixelUv) * c.gRectSizePrev, smbOcclusionWeights, isCatRomAllowed);
+            float history = FetchHistoryColor(hf, gIn_History).x;
+            history = saturate(history);
+            history = UnpackShadow(history);
+
+            // Clamp history
+            sigma *= lerp(SIGMA_TS_SIGMA_SCALE, 1.0f, 1.0f / (1.0f + historyLength));
+            float inputMin = m1 - sigma, inputMax = m1 + sigma;
+            float historyClamped = clamp(history, inputMin, inputMax);
+
+            // Antilag
+            float antilag = fabsf(historyClamped - history);
+            antilag = Math::Sqrt01(antilag);
+            antilag = saturate(1.0f - antilag);
+            historyLength *= antilag;
+
+            float historyWeight = historyLength / (1.0f + historyLength);
+            float streetMagic = 0.6f * historyWeight * antilag;
+            historyClamped = lerp(historyClamped, history, streetMagic);
+
+            float result = lerp(input, historyClamped, min(c.gStabilizationStrength, historyWeight));
+            historyLength = min(historyLength + 1.0f, SIGMA_MAX_ACCUM_FRAME_NUM);
+
+            gOut_Shadow.Store(px, py, PackShadow(result));
+            gOut_HistoryLength.StoreUint(px, py, PackViewZAndHistoryLength(viewZ, historyLength));
+        }
+}
+
+// ================================================================================================ SplitScreen
+void SplitScreen(const PassIO& io) {
+    const SigmaCB& c = *(const SigmaCB*)io.constants;
+    const Tex& gIn_ViewZ = io.t[0];
+    const Tex& gIn_Penumbra = io.t[1];
+    Tex& gOut_Shadow = io.t[2];
+    for (int py = 0; py <= c.gRectSizeMinusOne[1]; py++)
+        for (int px = 0; px <= c.gRectSizeMinusOne[0]; px++) {
+            float2 pixelUv = float2(float(px) + 0.5f, float(py) + 0.5f) * c.gRectSizeInv;
+            if (pixelUv.x > c.gSplitScreen)
+                continue;
+            float viewZ = UnpackViewZ(c, gIn_ViewZ.Load(px, py).x);
+            float s = IsLit(gIn_Penumbra.Load(px, py).x) ? 1.0f : 0.0f;
+            gOut_Shadow.Store(px, py, s * (viewZ < c.gDenoisingRange ? 1.0f : 0.0f));
+        }
+}
+
+} // namespace
+
+const PassEntry* GetSigmaPasses(uint32_t& n) {
+    static const PassEntry k[] = {
+        {"SIGMA_Shadow_ClassifyTiles.cs", ClassifyTiles},
+        {"SIGMA_SmoothTiles.cs", SmoothTiles},
+        {"SIGMA_Copy.cs", Copy},
+        {"SIGMA_Shadow_Blur.cs", Blur<true>},
+        {"SIGMA_Shadow_PostBlur.cs", Blur<false>},
+        {"SIGMA_Shadow_TemporalStabilization.cs", TemporalStabilization},
+        {"SIGMA_Shadow_SplitScreen.cs", SplitScreen},
+    };
+    n = sizeof(k) / sizeof(k[0]);
+    return k;
+}
+
+} // namespace orc

@@ -1,4 +1,598 @@
+// SIGMA_SHADOW pass chain as HIP kernels for gfx950.
+//   ClassifyTiles           reference Shaders/Include/SIGMA_ClassifyTiles.hlsli:11-81
+//   SmoothTiles             reference Shaders/Include/SIGMA_SmoothTiles.hlsli:11-48
+//   Copy                    reference Shaders/Include/SIGMA_Copy.hlsli:11-24
+//   Blur / PostBlur         reference Shaders/Include/SIGMA_Blur.hlsli:11-268
+//   TemporalStabilization   reference Shaders/Include/SIGMA_TemporalStabilization.hlsli:11-226
+//   SplitScreen             reference Shaders/Include/SIGMA_SplitScreen.hlsli:11-35
+//
+// MI355X mapping. The chain moves only ~68 B/px (R16F penumbra, R8 shadow, R32F viewZ), so at 1080p a frame is ~140 MB =
+// tens of microseconds of HBM time: it is launch- and latency-bound, and the win is in doing little work: hard-shadow and
+// fully-lit tiles leave through the bicubic tile test before any filtering. ClassifyTiles is one wave per 16x16 tile with
+// wave-wide reductions (__all / shuffle-max) instead of the reference's LDS atomics. Blur / PostBlur / TS stage a 36x12
+// (halo 2) LDS tile of {penumbra, viewZ, shadow} decoded once per workgroup for the dense 5x5 part; the sparse 8-tap part
+// gathers from global (L2). LDS rows are padded to 37 dwords.
+#include "../common/pass_constants.h"
 #include "passes.h"
+#include "reblur_device.h" // shared Common.hlsli helpers (weights, history fetch, clamp-addressed fetches)
+
 namespace nrdhip {
-const PassEntry* GetSigmaPasses(uint32_t& num) { num = 0; return nullptr; }
+
+typedef nrdc::SigmaConstants SigmaCB;
+
+constexpr int TILE_X = 32;
+constexpr int TILE_Y = 8;
+constexpr int BORDER = 2;
+constexpr int BUF_X = TILE_X + 2 * BORDER; // 36
+constexpr int BUF_Y = TILE_Y + 2 * BORDER; // 12
+constexpr int BUF_STRIDE = BUF_X + 1;      // 37
+
+#define SIGMA_MAX_PIXEL_RADIUS 32.0f
+#define SIGMA_TS_SIGMA_SCALE 3.0f
+#define SIGMA_MAX_ACCUM_FRAME_NUM 7.0f
+
+NRD_D float UnpackViewZ(const SigmaCB& c, float z) { return Abs(z * c.gViewZScale); }
+NRD_D bool IsLit(float p) { return p >= NRD_FP16_MAX; }
+NRD_D float PackShadow(float s) { return Sqrt01(s); }
+NRD_D float UnpackShadow(float s) { return s * s; }
+NRD_D float GetKernelRadiusInPixels(float hitDist, float unprojectZ, float scale = 1.0f) {
+    float unclampedRadius = hitDist / unprojectZ;
+    unclampedRadius *= scale;
+    float minRadius = Min(unclampedRadius, 2.0f);
+    return Clamp(unclampedRadius, minRadius, SIGMA_MAX_PIXEL_RADIUS);
 }
+NRD_D float AreBothLitOrUnlit(float penumbra1, float penumbra2) { return ((penumbra1 == 0.0f) == (penumbra2 == 0.0f)) ? 1.0f : 0.0f; }
+
+// ---- bicubic lookup of channel .y of the RG8 smoothed tile map (SIGMA_Common.hlsli:45-92) -------------------------------
+NRD_D float FetchClampedRG8y(const Plane& p, int x, int y) {
+    uint32_t raw = *TexelPtr<const uint16_t>(p, ClampI(x, 0, p.w - 1), ClampI(y, 0, p.h - 1));
+    return NRD_DIV_255(float(raw >> 8));
+}
+NRD_D float SampleLinearRG8y(const Plane& p, float2 pos) {
+    LinearTaps t = MakeLinearTaps(pos);
+    float s00 = FetchClampedRG8y(p, t.x0, t.y0), s10 = FetchClampedRG8y(p, t.x0 + 1, t.y0), s01 = FetchClampedRG8y(p, t.x0, t.y0 + 1), s11 = FetchClampedRG8y(p, t.x0 + 1, t.y0 + 1);
+    return s00 * t.w00 + s10 * t.w10 + s01 * t.w01 + s11 * t.w11;
+}
+NRD_D void BicubicAxis(float f, float& w0, float& w1, float& wz) {
+    const float k = 1.0f / 6.0f;
+    float f2 = f * f, f3 = f2 * f;
+    float phix = k * (-1.0f * f3 + 3.0f * f2 + -3.0f * f + 1.0f);
+    float phiy = k * (3.0f * f3 + -6.0f * f2 + 0.0f * f + 4.0f);
+    float phiz = k * (-3.0f * f3 + 3.0f * f2 + 3.0f * f + 1.0f);
+    float phiw = k * (1.0f * f3 + 0.0f * f2 + 0.0f * f + 0.0f);
+    w0 = 1.0f + 1.0f * f + -1.0f * phiy / (phix + phiy);
+    w1 = 1.0f + -1.0f * f + 1.0f * phiw / (phiz + phiw);
+    wz = phix + phiy;
+}
+NRD_D float TextureCubicY(const Plane& tex, float2 uv) {
+    float2 size = F2(float(tex.w), float(tex.h));
+    float dx = -1.0f / size.x, dy = -1.0f / size.y;
+    float2 t = uv * size - 0.5f;
+    float2 f = F2(Frac(t.x), Frac(t.y));
+    float xw0, xw1, xwz, yw0, yw1, ywz;
+    BicubicAxis(f.x, xw0, xw1, xwz);
+    BicubicAxis(f.y, yw0, yw1, ywz);
+    float u10 = uv.x + 1.0f * xw0 * dx, u00 = uv.x + -1.0f * xw1 * dx;
+    float v1 = uv.y + yw0 * dy, v0 = uv.y - yw1 * dy;
+    float c00 = SampleLinearRG8y(tex, F2(u00, v0) * size);
+    float c10 = SampleLinearRG8y(tex, F2(u10, v0) * size);
+    float c01 = SampleLinearRG8y(tex, F2(u00, v1) * size);
+    float c11 = SampleLinearRG8y(tex, F2(u10, v1) * size);
+    float tx = ywz, ty = xwz;
+    c00 = Lerp(c00, c01, tx);
+    c10 = Lerp(c10, c11, tx);
+    return Lerp(c00, c10, ty);
+}
+NRD_D float LoadTileX(const Plane& tiles, int tx, int ty) { // .x of the RG8 smoothed tile map, 0 outside
+    if (!InBounds(tiles, tx, ty))
+        return 0.0f;
+    uint32_t raw = *TexelPtr<const uint16_t>(tiles, tx, ty);
+    return NRD_DIV_255(float(raw & 0xFFu));
+}
+
+// ================================================================================================ ClassifyTiles
+__global__ __launch_bounds__(256) void SigmaClassifyTilesKernel(SigmaCB c, Plane viewZ, Plane penumbra, Plane tiles) {
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int tileIndex = blockIdx.x * 4 + wave;
+    if (tileIndex >= tiles.w * tiles.h)
+        return;
+    const int tx = tileIndex % tiles.w, ty = tileIndex / tiles.w;
+    const int x0 = tx * 16 + (lane & 3) * 4, y = ty * 16 + (lane >> 2);
+
+    bool allLit = true, allUmbra = true, allInf = true;
+    float maxRadius = 0.0f;
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        int x = x0 + i;
+        float h = InBounds(penumbra, x, y) ? LoadR16F(penumbra, x, y) : 0.0f;
+        float z = UnpackViewZ(c, InBounds(viewZ, x, y) ? LoadR32F(viewZ, x, y) : 0.0f);
+        bool isInf = z > c.gDenoisingRange, isShadow = h == 0.0f, isLitP = IsLit(h);
+        allLit = allLit && (isLitP || isInf || isShadow);
+        allUmbra = allUmbra && (!isLitP || isInf || isShadow);
+        allInf = allInf && isInf;
+        float hitDist = (isLitP || isInf) ? 0.0f : h;
+        float pixelSize = PixelRadiusToWorld(c.gUnproject, c.gOrthoMode, 1.0f, z);
+        maxRadius = Max(GetKernelRadiusInPixels(hitDist, pixelSize), maxRadius);
+    }
+    allLit = __all(allLit);
+    allUmbra = __all(allUmbra);
+    allInf = __all(allInf);
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1)
+        maxRadius = Max(maxRadius, __shfl_xor(maxRadius, o, 64));
+
+    if (lane == 0) {
+        uint32_t r = ToUnorm((allLit || allUmbra) ? 0.0f : 1.0f, 255.0f);
+        r |= ToUnorm(Sat(maxRadius / 16.0f), 255.0f) << 8;
+        r |= ToUnorm(allInf ? 1.0f : 0.0f, 255.0f) << 16;
+        *TexelPtr<uint32_t>(tiles, tx, ty) = r; // RGBA8_UNORM, .w = 0
+    }
+}
+
+static const char* CheckSupportedSigma(const SigmaCB& c) {
+    if (c.gRectOrigin.x != 0 || c.gRectOrigin.y != 0 || c.gResolutionScale.x != 1.0f || c.gResolutionScale.y != 1.0f || c.gIsRectChanged)
+        return "SIGMA: dynamic resolution (rect != resource) is not implemented in the HIP back-end yet";
+    if (c.gOrthoMode != 0.0f)
+        return "SIGMA: orthographic projection is not supported (SURVEY.md section 8c)";
+    return nullptr;
+}
+
+static const char* LaunchClassifyTiles(const PassArgs& a) {
+    const SigmaCB& c = *(const SigmaCB*)a.constants;
+    if (const char* err = CheckSupportedSigma(c))
+        return err;
+    const Plane& tiles = a.planes[2];
+    int numTiles = tiles.w * tiles.h;
+    hipLaunchKernelGGL(SigmaClassifyTilesKernel, dim3((numTiles + 3) / 4), dim3(256), 0, a.stream, c, a.planes[0], a.planes[1], tiles);
+    return nullptr;
+}
+
+// ================================================================================================ SmoothTiles
+__global__ __launch_bounds__(256) void SigmaSmoothTilesKernel(SigmaCB c, Plane inTiles, Plane outTiles) {
+    const int x = blockIdx.x * 16 + (threadIdx.x & 15), y = blockIdx.y * 16 + (threadIdx.x >> 4);
+    if (!InBounds(outTiles, x, y))
+        return;
+    uint32_t raw = *TexelPtr<const uint32_t>(inTiles, x, y);
+    float centerY = NRD_DIV_255(float((raw >> 8) & 0xFFu)), centerZ = NRD_DIV_255(float((raw >> 16) & 0xFFu));
+    float blurry = 0.0f, sumw = 0.0f;
+    float k = 1.01f / (centerY + 0.01f);
+#pragma unroll
+    for (int j = 0; j <= 2; j++) {
+#pragma unroll
+        for (int i = 0; i <= 2; i++) {
+            float d = Length(F2(float(i), float(j)) - 1.0f);
+            float w = Exp2(-k * d * d);
+            int sx = ClampI(x - 1 + i, 0, c.gTilesSizeMinusOne.x), sy = ClampI(y - 1 + j, 0, c.gTilesSizeMinusOne.y);
+            uint32_t t = *TexelPtr<const uint32_t>(inTiles, sx, sy);
+            blurry += NRD_DIV_255(float(t & 0xFFu)) * w;
+            sumw += w;
+        }
+    }
+    blurry /= sumw;
+    StoreRG8Unorm(outTiles, x, y, F2(centerZ, blurry));
+}
+
+static const char* LaunchSmoothTiles(const PassArgs& a) {
+    const SigmaCB& c = *(const SigmaCB*)a.constants;
+    const Plane& out = a.planes[1];
+    hipLaunchKernelGGL(SigmaSmoothTilesKernel, GridFor(out.w, out.h, 16, 16), dim3(256), 0, a.stream, c, a.planes[0], out);
+    return nullptr;
+}
+
+// ================================================================================================ Copy
+__global__ __launch_bounds__(256) void SigmaCopyKernel(SigmaCB c, Plane tiles, Plane inHistory, Plane inHistoryLength, Plane outHistory, Plane outHistoryLength) {
+    // 4 pixels per thread: 4 bytes of R8 shadow and 16 bytes of R32_UINT history length
+    const int x = (blockIdx.x * 64 + (threadIdx.x & 63)) * 4, y = blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (y >= outHistory.h || x >= outHistory.w)
+        return;
+    if (LoadTileX(tiles, x >> 4, y >> 4) != 0.0f && !c.gIsRectChanged)
+        return;
+    const bool aligned = ((((uintptr_t)inHistory.ptr | (uintptr_t)outHistory.ptr) | inHistory.pitch | outHistory.pitch) & 3u) == 0;
+    if (x + 3 < outHistory.w && aligned) {
+        *(uint32_t*)TexelPtr<uint8_t>(outHistory, x, y) = *(const uint32_t*)TexelPtr<const uint8_t>(inHistory, x, y);
+        *(uint4*)TexelPtr<uint32_t>(outHistoryLength, x, y) = *(const uint4*)TexelPtr<const uint32_t>(inHistoryLength, x, y);
+    } else {
+        for (int i = 0; i < 4 && x + i < outHistory.w; i++) {
+            *TexelPtr<uint8_t>(outHistory, x + i, y) = *TexelPtr<const uint8_t>(inHistory, x + i, y);
+            StoreR32U(outHistoryLength, x + i, y, LoadR32U(inHistoryLength, x + i, y));
+        }
+    }
+}
+
+static const char* LaunchCopy(const PassArgs& a) {
+    const SigmaCB& c = *(const SigmaCB*)a.constants;
+    const Plane& out = a.planes[3];
+    dim3 grid((unsigned)((out.w + 255) / 256), (unsigned)((out.h + 3) / 4), 1);
+    hipLaunchKernelGGL(SigmaCopyKernel, grid, dim3(256), 0, a.stream, c, a.planes[0], a.planes[1], a.planes[2], out, a.planes[4]);
+    return nullptr;
+}
+
+// ================================================================================================ Blur / PostBlur
+struct BlurPlanes {
+    Plane viewZ, normalRoughness, penumbra, tiles, shadow, outPenumbra, outShadow;
+};
+
+template <bool FIRST_PASS>
+__global__ __launch_bounds__(TILE_X* TILE_Y) void SigmaBlurKernel(SigmaCB c, BlurPlanes P) {
+    __shared__ float s_Penumbra[BUF_Y * BUF_STRIDE];
+    __shared__ float s_ViewZ[BUF_Y * BUF_STRIDE];
+    __shared__ float s_Shadow[BUF_Y * BUF_STRIDE];
+
+    const int tx = threadIdx.x % TILE_X, ty = threadIdx.x / TILE_X;
+    const int px = blockIdx.x * TILE_X + tx, py = blockIdx.y * TILE_Y + ty;
+    const int rw = c.gRectSizeMinusOne.x, rh = c.gRectSizeMinusOne.y;
+
+    {
+        const int tileY = (blockIdx.y * TILE_Y) >> 4, tileX0 = (blockIdx.x * TILE_X) >> 4;
+        bool anyGeometry = false;
+        for (int t = 0; t < TILE_X / 16; t++)
+            anyGeometry |= InBounds(P.tiles, tileX0 + t, tileY) && LoadTileX(P.tiles, tileX0 + t, tileY) == 0.0f;
+        if (!anyGeometry)
+            return;
+        const int baseX = blockIdx.x * TILE_X - BORDER, baseY = blockIdx.y * TILE_Y - BORDER;
+        for (int i = threadIdx.x; i < BUF_X * BUF_Y; i += TILE_X * TILE_Y) {
+            int lx = i % BUF_X, ly = i / BUF_X;
+            int gx = ClampI(baseX + lx, 0, rw), gy = ClampI(baseY + ly, 0, rh);
+            float pen = LoadR16F(P.penumbra, gx, gy);
+            s_Penumbra[ly * BUF_STRIDE + lx] = pen;
+            s_ViewZ[ly * BUF_STRIDE + lx] = UnpackViewZ(c, LoadR32F(P.viewZ, gx, gy));
+            s_Shadow[ly * BUF_STRIDE + lx] = FIRST_PASS ? (IsLit(pen) ? 1.0f : 0.0f) : UnpackShadow(LoadR8Unorm(P.shadow, gx, gy));
+        }
+    }
+    __syncthreads();
+
+    if (px > rw || py > rh)
+        return;
+    if (LoadTileX(P.tiles, px >> 4, py >> 4) != 0.0f)
+        return;
+
+    const int so = (ty + BORDER) * BUF_STRIDE + tx + BORDER;
+    const float centerPenumbra = s_Penumbra[so];
+    const float viewZ = s_ViewZ[so];
+    if (viewZ > c.gDenoisingRange)
+        return;
+
+    const float2 rectSize = ToF2(c.gRectSize), rectSizeInv = ToF2(c.gRectSizeInv), resolutionScale = ToF2(c.gResolutionScale);
+    const float4 frustum = ToF4(c.gFrustum);
+
+    float2 pixelUv = F2(float(px) + 0.5f, float(py) + 0.5f) * rectSizeInv;
+    float tileValue = TextureCubicY(P.tiles, pixelUv * resolutionScale);
+
+    if (tileValue == 0.0f || centerPenumbra == 0.0f) {
+        StoreR16F(P.outPenumbra, px, py, centerPenumbra);
+        StoreR8Unorm(P.outShadow, px, py, PackShadow(s_Shadow[so]));
+        return;
+    }
+
+    float3 Xv = ReconstructViewPosition(pixelUv, frustum, viewZ, c.gOrthoMode);
+    float3 N = Xyz(UnpackNormalAndRoughness(LoadR10G10B10A2(P.normalRoughness, px, py)));
+    float3 Nv = RotateVector(c.gWorldToView, N);
+
+    float pixelSize = PixelRadiusToWorld(c.gUnproject, c.gOrthoMode, 1.0f, viewZ);
+    float frustumSize = GetFrustumSize(c.gMinRectDimMulUnproject, c.gOrthoMode, viewZ);
+    float3 Vv = c.gOrthoMode == 0.0f ? Normalize(-Xv) : F3(0.0f, 0.0f, -1.0f);
+    float NoV = Abs(Dot(Nv, Vv));
+    float2 geometryWeightParams = GetGeometryWeightParams(c.gPlaneDistSensitivity, frustumSize, Xv, Nv);
+
+    float sumx = 0.0f, sumy = 0.0f, penumbra = 0.0f, result = 0.0f, centerTap = 0.0f;
+#pragma unroll
+    for (int j = 0; j <= BORDER * 2; j++) {
+#pragma unroll
+        for (int i = 0; i <= BORDER * 2; i++) {
+            const int o = (ty + j) * BUF_STRIDE + tx + i;
+            float penum = s_Penumbra[o], zs = s_ViewZ[o], s = s_Shadow[o];
+
+            float w = 1.0f;
+            if (i == BORDER && j == BORDER)
+                centerTap = s;
+            else {
+                float2 uv = pixelUv + F2(float(i - BORDER), float(j - BORDER)) * rectSizeInv;
+                float3 Xvs = ReconstructViewPosition(uv, frustum, zs, c.gOrthoMode);
+                w *= ComputeWeight(Dot(Nv, Xvs), geometryWeightParams.x, geometryWeightParams.y);
+                w *= AreBothLitOrUnlit(centerPenumbra, penum);
+                w *= GetGaussianWeight(Length(F2(float(i - BORDER), float(j - BORDER)) / float(BORDER)));
+            }
+
+            result += w == 0.0f ? 0.0f : s * w;
+            sumx += w;
+
+            w *= pixelSize / (pixelSize + penum);
+            w *= IsLit(penum) ? 0.0f : 1.0f;
+
+            penumbra += w == 0.0f ? 0.0f : penum * w;
+            sumy += w;
+        }
+    }
+
+    result /= sumx;
+    sumx = 1.0f;
+    penumbra /= Max(sumy, NRD_EPS);
+    sumy = sumy != 0.0f ? 1.0f : 0.0f;
+
+    float penumbraInPixels = penumbra / pixelSize;
+    float f = SmoothStep(0.0f, float(BORDER), penumbraInPixels);
+    result = Lerp(centerTap, result, f);
+
+    f = Lerp(4.0f, 1.0f, f);
+    result *= f;
+    penumbra *= f;
+    sumx *= f;
+    sumy *= f;
+
+    float blurRadius = GetKernelRadiusInPixels(penumbra, pixelSize, tileValue);
+    float4 rotator = ToF4(FIRST_PASS ? c.gRotator : c.gRotatorPost);
+
+    float2 skew = Lerp(F2(1.0f - Abs(Nv.x), 1.0f - Abs(Nv.y)), F2(1.0f, 1.0f), NoV);
+    skew = skew / Max(skew.x, skew.y);
+    skew = skew * (rectSizeInv * blurRadius);
+    float4 scaledRotator = ScaleRotator(rotator, skew);
+
+    float invEstimatedPenumbra = 1.0f / Max(penumbra, NRD_EPS);
+    const float2 uvMax = resolutionScale - ToF2(c.gResourceSizeInv) * 0.5f;
+
+#pragma unroll
+    for (int n = 0; n < 8; n++) {
+        float3 offset = F3(g_Special8[n][0], g_Special8[n][1], g_Special8[n][2]);
+        float2 uv = pixelUv + RotateVector(scaledRotator, F2(offset.x, offset.y));
+        uv = (Floor(uv * rectSize) + 0.5f) * rectSizeInv;
+        float2 uvScaled = F2(Min(uv.x * resolutionScale.x, uvMax.x), Min(uv.y * resolutionScale.y, uvMax.y));
+
+        const int2 t = NearestTexel(P.penumbra, uvScaled);
+        float penum = LoadR16F(P.penumbra, t.x, t.y);
+        float zs = UnpackViewZ(c, LoadR32F(P.viewZ, t.x, t.y));
+        float s = FIRST_PASS ? (IsLit(penum) ? 1.0f : 0.0f) : UnpackShadow(LoadR8Unorm(P.shadow, t.x, t.y));
+
+        float3 Xvs = ReconstructViewPosition(uv, frustum, zs, c.gOrthoMode);
+
+        float w = IsInScreenNearest(uv);
+        w *= ComputeWeight(Dot(Nv, Xvs), geometryWeightParams.x, geometryWeightParams.y);
+        w *= AreBothLitOrUnlit(centerPenumbra, penum);
+        w *= n < 4 ? REBLUR_GAUSSIAN_WEIGHT_Z1 : REBLUR_GAUSSIAN_WEIGHT_Z05;
+        w *= Sat(penum * invEstimatedPenumbra);
+
+        result += w == 0.0f ? 0.0f : s * w;
+        sumx += w;
+
+        w *= pixelSize / (pixelSize + penum);
+        w *= IsLit(penum) ? 0.0f : 1.0f;
+
+        penumbra += w == 0.0f ? 0.0f : penum * w;
+        sumy += w;
+    }
+
+    result /= sumx;
+    penumbra = sumy == 0.0f ? centerPenumbra : penumbra / sumy;
+
+    if (FIRST_PASS || c.gStabilizationStrength != 0.0f)
+        StoreR16F(P.outPenumbra, px, py, penumbra);
+    StoreR8Unorm(P.outShadow, px, py, PackShadow(result));
+}
+
+template <bool FIRST_PASS>
+static const char* LaunchBlur(const PassArgs& a) {
+    const SigmaCB& c = *(const SigmaCB*)a.constants;
+    if (const char* err = CheckSupportedSigma(c))
+        return err;
+    BlurPlanes P = {};
+    uint32_t k = 0;
+    P.viewZ = a.planes[k++];
+    P.normalRoughness = a.planes[k++];
+    P.penumbra = a.planes[k++];
+    P.tiles = a.planes[k++];
+    if (!FIRST_PASS)
+        P.shadow = a.planes[k++];
+    P.outPenumbra = a.planes[k++];
+    P.outShadow = a.planes[k++];
+    if (k != a.planesNum)
+        return "SIGMA blur: unexpected resource count";
+    dim3 grid = GridFor(c.gRectSizeMinusOne.x + 1, c.gRectSizeMinusOne.y + 1, TILE_X, TILE_Y);
+    hipLaunchKernelGGL((SigmaBlurKernel<FIRST_PASS>), grid, dim3(TILE_X * TILE_Y), 0, a.stream, c, P);
+    return nullptr;
+}
+
+// ================================================================================================ TemporalStabilization
+struct TsPlanes {
+    Plane viewZ, mv, penumbra, shadow, history, historyLength, tiles, outShadow, outHistoryLength;
+};
+
+NRD_D uint32_t PackViewZAndHistoryLength(float viewZ, float historyLength) {
+    uint32_t p = AsUint(viewZ) & ~7u;
+    uint32_t h = (uint32_t)(historyLength + 0.5f);
+    p |= h < 7u ? h : 7u;
+    return p;
+}
+NRD_D uint32_t FetchClampedR32U(const Plane& p, int x, int y) { return LoadR32U(p, ClampI(x, 0, p.w - 1), ClampI(y, 0, p.h - 1)); }
+NRD_D float FetchClampedR8Unorm(const Plane& p, int x, int y) { return LoadR8Unorm(p, ClampI(x, 0, p.w - 1), ClampI(y, 0, p.h - 1)); }
+NRD_D float SampleLinearR8Unorm(const Plane& p, float2 pos) {
+    LinearTaps t = MakeLinearTaps(pos);
+    float s00 = FetchClampedR8Unorm(p, t.x0, t.y0), s10 = FetchClampedR8Unorm(p, t.x0 + 1, t.y0), s01 = FetchClampedR8Unorm(p, t.x0, t.y0 + 1), s11 = FetchClampedR8Unorm(p, t.x0 + 1, t.y0 + 1);
+    return s00 * t.w00 + s10 * t.w10 + s01 * t.w01 + s11 * t.w11;
+}
+NRD_D float FetchHistoryR8Unorm(const HistoryFilter& h, const Plane& tex) {
+    float color = SampleLinearR8Unorm(tex, h.p0) * h.w.x;
+    color += SampleLinearR8Unorm(tex, h.p1) * h.w.y;
+    color += SampleLinearR8Unorm(tex, h.p2) * h.w.z;
+    color += SampleLinearR8Unorm(tex, h.p3) * h.w.w;
+    color += SampleLinearR8Unorm(tex, h.p4) * h.w4;
+    return h.sum < 0.0001f ? 0.0f : color / h.sum;
+}
+
+__global__ __launch_bounds__(TILE_X* TILE_Y) void SigmaTemporalStabilizationKernel(SigmaCB c, TsPlanes P) {
+    __shared__ float s_Penumbra[BUF_Y * BUF_STRIDE];
+    __shared__ float s_Shadow[BUF_Y * BUF_STRIDE];
+
+    const int tx = threadIdx.x % TILE_X, ty = threadIdx.x / TILE_X;
+    const int px = blockIdx.x * TILE_X + tx, py = blockIdx.y * TILE_Y + ty;
+    const int rw = c.gRectSizeMinusOne.x, rh = c.gRectSizeMinusOne.y;
+
+    {
+        const int tileY = (blockIdx.y * TILE_Y) >> 4, tileX0 = (blockIdx.x * TILE_X) >> 4;
+        bool anyGeometry = false;
+        for (int t = 0; t < TILE_X / 16; t++)
+            anyGeometry |= InBounds(P.tiles, tileX0 + t, tileY) && LoadTileX(P.tiles, tileX0 + t, tileY) == 0.0f;
+        if (!anyGeometry)
+            return;
+        const int baseX = blockIdx.x * TILE_X - BORDER, baseY = blockIdx.y * TILE_Y - BORDER;
+        for (int i = threadIdx.x; i < BUF_X * BUF_Y; i += TILE_X * TILE_Y) {
+            int lx = i % BUF_X, ly = i / BUF_X;
+            int gx = ClampI(baseX + lx, 0, rw), gy = ClampI(baseY + ly, 0, rh);
+            s_Shadow[ly * BUF_STRIDE + lx] = UnpackShadow(LoadR8Unorm(P.shadow, gx, gy));
+            s_Penumbra[ly * BUF_STRIDE + lx] = LoadR16F(P.penumbra, gx, gy);
+        }
+    }
+    __syncthreads();
+
+    if (px > rw || py > rh)
+        return;
+    const int so = (ty + BORDER) * BUF_STRIDE + tx + BORDER;
+    const float centerPenumbra = s_Penumbra[so];
+    const float viewZ = UnpackViewZ(c, LoadR32F(P.viewZ, px, py));
+    if (LoadTileX(P.tiles, px >> 4, py >> 4) != 0.0f || viewZ > c.gDenoisingRange)
+        return;
+
+    const float2 rectSizeInv = ToF2(c.gRectSizeInv), rectSizePrev = ToF2(c.gRectSizePrev), resolutionScale = ToF2(c.gResolutionScale);
+    const float3 cameraDelta = ToF3(c.gCameraDelta);
+
+    float2 pixelUv = F2(float(px) + 0.5f, float(py) + 0.5f) * rectSizeInv;
+    float tileValue = TextureCubicY(P.tiles, pixelUv * resolutionScale);
+    bool isHardShadow = tileValue == 0.0f || centerPenumbra == 0.0f;
+    if (isHardShadow) {
+        StoreR8Unorm(P.outShadow, px, py, PackShadow(s_Shadow[so]));
+        StoreR32U(P.outHistoryLength, px, py, PackViewZAndHistoryLength(viewZ, SIGMA_MAX_ACCUM_FRAME_NUM));
+        return;
+    }
+
+    float sumw = 0.0f, m1 = 0.0f, m2 = 0.0f, input = 0.0f;
+#pragma unroll
+    for (int j = 0; j <= BORDER * 2; j++) {
+#pragma unroll
+        for (int i = 0; i <= BORDER * 2; i++) {
+            const int o = (ty + j) * BUF_STRIDE + tx + i;
+            float s = s_Shadow[o];
+            float w = 1.0f;
+            if (i == BORDER && j == BORDER)
+                input = s;
+            else {
+                float penum = s_Penumbra[o];
+                w = AreBothLitOrUnlit(centerPenumbra, penum);
+                w *= GetGaussianWeight(Length(F2(float(i - BORDER), float(j - BORDER)) / float(BORDER)));
+            }
+            m1 += s * w;
+            m2 += s * s * w;
+            sumw += w;
+        }
+    }
+    m1 /= sumw;
+    m2 /= sumw;
+    float sigma = Sqrt(Abs(m2 - m1 * m1));
+
+    float3 Xv = ReconstructViewPosition(pixelUv, ToF4(c.gFrustum), viewZ, c.gOrthoMode);
+    float3 X = RotateVectorInverse(c.gWorldToView, Xv);
+
+    float4 mvRaw = LoadRGBA16F(P.mv, px, py);
+    float3 mv = F3(mvRaw.x, mvRaw.y, mvRaw.z) * F3(c.gMvScale.x, c.gMvScale.y, c.gMvScale.z);
+    float3 Xprev = X;
+    float2 smbPixelUv = pixelUv + F2(mv.x, mv.y);
+    if (c.gMvScale.w == 0.0f) {
+        if (c.gMvScale.z == 0.0f)
+            mv.z = AffineTransform(c.gWorldToViewPrev, X).z - viewZ;
+        float viewZprev = viewZ + mv.z;
+        float3 Xvprevlocal = ReconstructViewPosition(smbPixelUv, ToF4(c.gFrustumPrev), viewZprev, c.gOrthoMode);
+        Xprev = RotateVectorInverse(c.gWorldToViewPrev, Xvprevlocal) + cameraDelta;
+    } else {
+        Xprev = Xprev + mv;
+        smbPixelUv = GetScreenUv(c.gWorldToClipPrev, Xprev);
+    }
+
+    Bilinear smbBilinearFilter = GetBilinearFilter(smbPixelUv, rectSizePrev);
+    const int bx = (int)smbBilinearFilter.origin.x, by = (int)smbBilinearFilter.origin.y;
+    uint32_t d0 = FetchClampedR32U(P.historyLength, bx, by), d1 = FetchClampedR32U(P.historyLength, bx + 1, by), d2 = FetchClampedR32U(P.historyLength, bx, by + 1),
+             d3 = FetchClampedR32U(P.historyLength, bx + 1, by + 1);
+    float4 prevViewZ = F4(AsFloat(d0 & ~7u), AsFloat(d1 & ~7u), AsFloat(d2 & ~7u), AsFloat(d3 & ~7u));
+    float4 prevHistoryLength = F4(float(d0 & 7u), float(d1 & 7u), float(d2 & 7u), float(d3 & 7u));
+
+    float frustumSize = GetFrustumSize(c.gMinRectDimMulUnproject, c.gOrthoMode, viewZ);
+    float disocclusionThreshold = GetDisocclusionThreshold(NRD_DISOCCLUSION_THRESHOLD, frustumSize, 1.0f);
+    disocclusionThreshold *= IsInScreenNearest(smbPixelUv);
+    disocclusionThreshold -= NRD_EPS;
+
+    float3 Xvprev = AffineTransform(c.gWorldToViewPrev, Xprev);
+    float4 smbPlaneDist = Abs(prevViewZ - Xvprev.z);
+    float4 smbOcclusion = Step(smbPlaneDist, F4(disocclusionThreshold));
+
+    float4 smbOcclusionWeights = GetBilinearCustomWeights(smbBilinearFilter, smbOcclusion);
+    float historyLength = ApplyBilinearCustomWeights(prevHistoryLength.x, prevHistoryLength.y, prevHistoryLength.z, prevHistoryLength.w, smbOcclusionWeights);
+
+    bool isCatRomAllowed = Sum(smbOcclusionWeights) > 3.5f; // never true (weights sum to <= 1): kept as in the reference
+    HistoryFilter hf = MakeHistoryFilter(Sat(smbPixelUv) * rectSizePrev, smbOcclusionWeights, isCatRomAllowed);
+    float history = FetchHistoryR8Unorm(hf, P.history);
+    history = Sat(history);
+    history = UnpackShadow(history);
+
+    sigma *= Lerp(SIGMA_TS_SIGMA_SCALE, 1.0f, 1.0f / (1.0f + historyLength));
+    float inputMin = m1 - sigma, inputMax = m1 + sigma;
+    float historyClamped = Clamp(history, inputMin, inputMax);
+
+    float antilag = Abs(historyClamped - history);
+    antilag = Sqrt01(antilag);
+    antilag = Sat(1.0f - antilag);
+    historyLength *= antilag;
+
+    float historyWeight = historyLength / (1.0f + historyLength);
+    float streetMagic = 0.6f * historyWeight * antilag;
+    historyClamped = Lerp(historyClamped, history, streetMagic);
+
+    float result = Lerp(input, historyClamped, Min(c.gStabilizationStrength, historyWeight));
+    historyLength = Min(historyLength + 1.0f, SIGMA_MAX_ACCUM_FRAME_NUM);
+
+    StoreR8Unorm(P.outShadow, px, py, PackShadow(result));
+    StoreR32U(P.outHistoryLength, px, py, PackViewZAndHistoryLength(viewZ, historyLength));
+}
+
+static const char* LaunchTemporalStabilization(const PassArgs& a) {
+    const SigmaCB& c = *(const SigmaCB*)a.constants;
+    if (const char* err = CheckSupportedSigma(c))
+        return err;
+    if (a.planesNum != 9)
+        return "SIGMA temporal stabilization: unexpected resource count";
+    TsPlanes P = {a.planes[0], a.planes[1], a.planes[2], a.planes[3], a.planes[4], a.planes[5], a.planes[6], a.planes[7], a.planes[8]};
+    dim3 grid = GridFor(c.gRectSizeMinusOne.x + 1, c.gRectSizeMinusOne.y + 1, TILE_X, TILE_Y);
+    hipLaunchKernelGGL(SigmaTemporalStabilizationKernel, grid, dim3(TILE_X * TILE_Y), 0, a.stream, c, P);
+    return nullptr;
+}
+
+// ================================================================================================ SplitScreen
+__global__ __launch_bounds__(256) void SigmaSplitScreenKernel(SigmaCB c, Plane viewZ, Plane penumbra, Plane outShadow) {
+    const int px = blockIdx.x * TILE_X + (threadIdx.x % TILE_X), py = blockIdx.y * TILE_Y + (threadIdx.x / TILE_X);
+    if (px > c.gRectSizeMinusOne.x || py > c.gRectSizeMinusOne.y)
+        return;
+    float pixelUvX = (float(px) + 0.5f) * c.gRectSizeInv.x;
+    if (pixelUvX > c.gSplitScreen)
+        return;
+    float z = UnpackViewZ(c, LoadR32F(viewZ, px, py));
+    float s = IsLit(LoadR16F(penumbra, px, py)) ? 1.0f : 0.0f;
+    StoreR8Unorm(outShadow, px, py, s * (z < c.gDenoisingRange ? 1.0f : 0.0f));
+}
+
+static const char* LaunchSplitScreen(const PassArgs& a) {
+    const SigmaCB& c = *(const SigmaCB*)a.constants;
+    dim3 grid = GridFor(c.gRectSizeMinusOne.x + 1, c.gRectSizeMinusOne.y + 1, TILE_X, TILE_Y);
+    hipLaunchKernelGGL(SigmaSplitScreenKernel, grid, dim3(256), 0, a.stream, c, a.planes[0], a.planes[1], a.planes[2]);
+    return nullptr;
+}
+
+const PassEntry* GetSigmaPasses(uint32_t& num) {
+    static const PassEntry k[] = {
+        {"SIGMA_Shadow_ClassifyTiles.cs", LaunchClassifyTiles},
+        {"SIGMA_SmoothTiles.cs", LaunchSmoothTiles},
+        {"SIGMA_Copy.cs", LaunchCopy},
+        {"SIGMA_Shadow_Blur.cs", LaunchBlur<true>},
+        {"SIGMA_Shadow_PostBlur.cs", LaunchBlur<false>},
+        {"SIGMA_Shadow_TemporalStabilization.cs", LaunchTemporalStabilization},
+        {"SIGMA_Shadow_SplitScreen.cs", LaunchSplitScreen},
+    };
+    num = sizeof(k) / sizeof(k[0]);
+    return k;
+}
+
+} // namespace nrdhip
