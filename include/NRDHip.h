@@ -67,6 +67,15 @@ uint32_t nrdHipExecuteDispatches(NrdHipExecutor* executor, const void* dispatchD
 // nrd::SetCommonSettings / SetDenoiserSettings must have been called for this frame.
 uint32_t nrdHipDenoise(NrdHipExecutor* executor, const uint32_t* identifiers, uint32_t identifiersNum);
 
+// Multi-GPU row-strip sharding: restricts this executor to PRODUCING rows [rowBegin, rowEnd) of the final outputs and of the
+// permanent (history) planes. Planes stay full-size; every pass is launched on the strip extended by the cumulative reach of the
+// passes that follow it in the dispatch list (temporal stabilization 1 row, post-blur / blur 2 x their maximum radius,
+// history fix 2 x stride, ...), so the owned rows are bit-identical to a single-GPU run provided the caller makes the other
+// ranks' owned rows of the permanent planes available before the next frame (one in-place all-gather per plane: owned strips
+// are contiguous row ranges). rowBegin = 0, rowEnd >= height restores whole-frame execution. Passes the executor cannot bound
+// (anything but the REBLUR chain in this build) always run on the whole frame.
+uint32_t nrdHipSetOwnedRows(NrdHipExecutor* executor, uint32_t rowBegin, uint32_t rowEnd);
+
 // Per-pass GPU timing. When enabled, every dispatch is bracketed by hipEvents on the executor's stream.
 // nrdHipCollectPassTimings synchronises the stream, folds all brackets recorded since the last collect into per-pipeline
 // totals and returns the number of pipelines written: pipelineIndices[i] (index into InstanceDesc::pipelines),

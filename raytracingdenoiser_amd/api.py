@@ -253,7 +253,7 @@ NRD_SYMBOLS = ["CreateInstance", "DestroyInstance", "GetLibraryDesc", "GetInstan
                "GetComputeDispatches", "GetResourceTypeString", "GetDenoiserString"]
 NRD_HIP_SYMBOLS = ["nrdHipCreateExecutor", "nrdHipDestroyExecutor", "nrdHipBindResource", "nrdHipGetPoolPlane", "nrdHipExecuteDispatches",
                    "nrdHipDenoise", "nrdHipGetPoolMemoryUsage", "nrdHipGetLastError", "nrdHipEvalNumerics", "nrdHipGetArenaSize",
-                   "nrdHipCreateExecutorWithArena", "nrdHipSetProfiling", "nrdHipCollectPassTimings"]
+                   "nrdHipCreateExecutorWithArena", "nrdHipSetProfiling", "nrdHipCollectPassTimings", "nrdHipSetOwnedRows"]
 
 _lib = None
 
@@ -292,6 +292,7 @@ def load_library(path=None):
     lib.nrdHipGetArenaSize.argtypes, lib.nrdHipGetArenaSize.restype = [C.c_void_p, C.c_uint16, C.c_uint16], C.c_uint64
     lib.nrdHipCreateExecutorWithArena.argtypes = [C.c_void_p, C.c_uint16, C.c_uint16, C.c_void_p, C.c_void_p, C.c_uint64, P(C.c_void_p)]
     lib.nrdHipCreateExecutorWithArena.restype = C.c_uint32
+    lib.nrdHipSetOwnedRows.argtypes, lib.nrdHipSetOwnedRows.restype = [C.c_void_p, C.c_uint32, C.c_uint32], C.c_uint32
     lib.nrdHipSetProfiling.argtypes, lib.nrdHipSetProfiling.restype = [C.c_void_p, C.c_uint32], C.c_uint32
     lib.nrdHipCollectPassTimings.argtypes = [C.c_void_p, P(C.c_uint32), P(C.c_double), P(C.c_uint32), C.c_uint32, P(C.c_uint32)]
     lib.nrdHipCollectPassTimings.restype = C.c_uint32

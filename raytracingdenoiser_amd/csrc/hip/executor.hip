@@ -7,6 +7,10 @@
 
 #include "passes.h"
 
+#include "../common/pass_constants.h"
+
+#include <climits>
+#include <cmath>
 #include <cstdio>
 #include <cstring>
 #include <string>
@@ -68,6 +72,8 @@ struct NrdHipExecutor {
 
     uint8_t* arena = nullptr;
     bool ownsArena = true;
+    int ownedRowBegin = 0, ownedRowEnd = INT_MAX;
+    std::vector<int> rowMargin; // per dispatch of the current list
     bool profiling = false;
     struct Bracket {
         hipEvent_t start, stop;
@@ -313,10 +319,58 @@ extern "C" __attribute__((visibility("default"))) uint32_t nrdHipGetPoolPlane(Nr
     return (uint32_t)nrd::Result::SUCCESS;
 }
 
+// Rows of its INPUT planes (produced earlier in the same frame) a pass reads around an output row. -1 = unknown pass: it and
+// everything before it run on the whole frame.
+static int PassReachRows(const char* shader, const void* constants, uint32_t constantsSize) {
+    if (strncmp(shader, "REBLUR_", 7) != 0 || !constants || constantsSize < sizeof(nrdc::ReblurConstants))
+        return -1;
+    const nrdc::ReblurConstants& c = *(const nrdc::ReblurConstants*)constants;
+    const float kSlack = 2.0f; // world-space specular taps are bounded by ~1x the pixel radius on screen; 2x is the safety factor
+    if (strstr(shader, "_TemporalStabilization"))
+        return 1;
+    if (strstr(shader, "_PostBlur"))
+        return (int)std::ceil(kSlack * std::fmax(2.0f * c.gMaxBlurRadius, c.gMinBlurRadius)) + 2;
+    if (strstr(shader, "_Blur"))
+        return (int)std::ceil(kSlack * std::fmax(c.gMaxBlurRadius, c.gMinBlurRadius)) + 2;
+    if (strstr(shader, "_HistoryFix"))
+        return 2 * (int)std::floor(c.gHistoryFixBasePixelStride / 2.0f) + 4 + 2;
+    if (strstr(shader, "_TemporalAccumulation"))
+        return 1;
+    if (strstr(shader, "_PrePass") || strstr(shader, "_SplitScreen") || strstr(shader, "ClassifyTiles"))
+        return 0; // read user inputs only
+    return -1;
+}
+
+extern "C" __attribute__((visibility("default"))) uint32_t nrdHipSetOwnedRows(NrdHipExecutor* e, uint32_t rowBegin, uint32_t rowEnd) {
+    if (!e || rowBegin > rowEnd)
+        return (uint32_t)nrd::Result::INVALID_ARGUMENT;
+    e->ownedRowBegin = (int)rowBegin;
+    e->ownedRowEnd = rowEnd >= e->height ? INT_MAX : (int)rowEnd;
+    return (uint32_t)nrd::Result::SUCCESS;
+}
+
 extern "C" __attribute__((visibility("default"))) uint32_t nrdHipExecuteDispatches(NrdHipExecutor* e, const void* dispatchDescs, uint32_t dispatchDescsNum) {
     if (!e || (!dispatchDescs && dispatchDescsNum))
         return (uint32_t)nrd::Result::INVALID_ARGUMENT;
     const nrd::DispatchDesc* descs = (const nrd::DispatchDesc*)dispatchDescs;
+
+    // Row-strip sharding: walk the list backwards accumulating the reach of the later passes
+    const bool sharded = e->ownedRowBegin > 0 || e->ownedRowEnd != INT_MAX;
+    e->rowMargin.assign(dispatchDescsNum, -1);
+    if (sharded) {
+        const nrd::InstanceDesc& idesc = nrd::GetInstanceDesc(*e->instance);
+        int margin = 0;
+        for (int i = (int)dispatchDescsNum - 1; i >= 0; i--) {
+            const nrd::DispatchDesc& d = descs[i];
+            int reach = d.pipelineIndex < idesc.pipelinesNum ? PassReachRows(idesc.pipelines[d.pipelineIndex].shaderFileName, d.constantBufferData, d.constantBufferDataSize) : -1;
+            if (reach < 0 || margin < 0) {
+                margin = -1; // whole frame from here backwards
+                continue;
+            }
+            e->rowMargin[i] = margin;
+            margin += reach;
+        }
+    }
 
     for (uint32_t i = 0; i < dispatchDescsNum; i++) {
         const nrd::DispatchDesc& d = descs[i];
@@ -352,6 +406,12 @@ extern "C" __attribute__((visibility("default"))) uint32_t nrdHipExecuteDispatch
         args.constants = d.constantBufferData;
         args.constantsSize = d.constantBufferDataSize;
         args.stream = e->stream;
+        args.rowBegin = 0;
+        args.rowEnd = INT_MAX;
+        if (sharded && e->rowMargin[i] >= 0) {
+            args.rowBegin = e->ownedRowBegin - e->rowMargin[i];
+            args.rowEnd = e->ownedRowEnd == INT_MAX ? INT_MAX : e->ownedRowEnd + e->rowMargin[i];
+        }
         NrdHipExecutor::Bracket bracket = {};
         if (e->profiling) {
             bracket.start = AcquireEvent(e);

@@ -27,8 +27,8 @@ static const char* CheckSupportedHistory(const ReblurCB& c) {
     return nullptr;
 }
 
-NRD_D bool BlockHasGeometry(const Plane& tiles) {
-    const int tileY = (blockIdx.y * TILE_Y) >> 4, tileX0 = (blockIdx.x * TILE_X) >> 4;
+NRD_D bool BlockHasGeometry(const Plane& tiles, int blockY) {
+    const int tileY = (blockY * TILE_Y) >> 4, tileX0 = (blockIdx.x * TILE_X) >> 4;
     bool any = false;
     for (int t = 0; t < TILE_X / 16; t++)
         if (tileX0 + t < tiles.w && tileY < tiles.h)
@@ -185,18 +185,19 @@ NRD_D float4 HistoryFixSignal(const ReblurCB& c, const HfPlanes& P, const HfPixe
 }
 
 template <bool DIFF, bool SPEC>
-__global__ __launch_bounds__(TILE_X* TILE_Y) void ReblurHistoryFixKernel(ReblurCB c, HfPlanes P) {
+__global__ __launch_bounds__(TILE_X* TILE_Y) void ReblurHistoryFixKernel(ReblurCB c, HfPlanes P, RowRange rr) {
     __shared__ float s_DiffLuma[DIFF ? hf::BUF_Y * hf::BUF_STRIDE : 1];
     __shared__ float s_SpecLuma[SPEC ? hf::BUF_Y * hf::BUF_STRIDE : 1];
 
     const int tx = threadIdx.x % TILE_X, ty = threadIdx.x / TILE_X;
-    const int px = blockIdx.x * TILE_X + tx, py = blockIdx.y * TILE_Y + ty;
+    const int blockY = blockIdx.y + rr.firstBlockY;
+    const int px = blockIdx.x * TILE_X + tx, py = blockY * TILE_Y + ty;
     const int rw = c.gRectSizeMinusOne.x, rh = c.gRectSizeMinusOne.y;
 
-    if (!BlockHasGeometry(P.tiles))
+    if (!BlockHasGeometry(P.tiles, blockY))
         return;
     {
-        const int baseX = blockIdx.x * TILE_X - hf::BORDER, baseY = blockIdx.y * TILE_Y - hf::BORDER;
+        const int baseX = blockIdx.x * TILE_X - hf::BORDER, baseY = blockY * TILE_Y - hf::BORDER;
         for (int i = threadIdx.x; i < hf::BUF_X * hf::BUF_Y; i += TILE_X * TILE_Y) {
             int lx = i % hf::BUF_X, ly = i / hf::BUF_X;
             int gx = ClampI(baseX + lx, 0, rw), gy = ClampI(baseY + ly, 0, rh);
@@ -208,7 +209,7 @@ __global__ __launch_bounds__(TILE_X* TILE_Y) void ReblurHistoryFixKernel(ReblurC
     }
     __syncthreads();
 
-    if (px > rw || py > rh)
+    if (px > rw || py > rh || py < rr.rowBegin || py >= rr.rowEnd)
         return;
     if (LoadR8Unorm(P.tiles, px >> 4, py >> 4) != 0.0f)
         return;
@@ -259,8 +260,8 @@ static const char* LaunchHistoryFix(const PassArgs& a) {
     if (SPEC) P.outSpecFast = a.planes[k++];
     if (k != a.planesNum)
         return "REBLUR history fix: unexpected resource count";
-    dim3 grid = GridFor(c.gRectSizeMinusOne.x + 1, c.gRectSizeMinusOne.y + 1, TILE_X, TILE_Y);
-    hipLaunchKernelGGL((ReblurHistoryFixKernel<DIFF, SPEC>), grid, dim3(TILE_X * TILE_Y), 0, a.stream, c, P);
+    RowGrid g = GridForRows(c.gRectSizeMinusOne.x + 1, c.gRectSizeMinusOne.y + 1, TILE_X, TILE_Y, a.rowBegin, a.rowEnd);
+    hipLaunchKernelGGL((ReblurHistoryFixKernel<DIFF, SPEC>), g.grid, dim3(TILE_X * TILE_Y), 0, a.stream, c, P, RowRange{g.firstBlockY, g.rowBegin, g.rowEnd});
     return nullptr;
 }
 
@@ -303,18 +304,19 @@ NRD_D void LumaStats(const ReblurCB& c, const float* s_Luma, int tx, int ty, flo
 }
 
 template <bool DIFF, bool SPEC>
-__global__ __launch_bounds__(TILE_X* TILE_Y) void ReblurTemporalStabilizationKernel(ReblurCB c, TsPlanes P) {
+__global__ __launch_bounds__(TILE_X* TILE_Y) void ReblurTemporalStabilizationKernel(ReblurCB c, TsPlanes P, RowRange rr) {
     __shared__ float s_DiffLuma[DIFF ? ts::BUF_Y * ts::BUF_STRIDE : 1];
     __shared__ float s_SpecLuma[SPEC ? ts::BUF_Y * ts::BUF_STRIDE : 1];
 
     const int tx = threadIdx.x % TILE_X, ty = threadIdx.x / TILE_X;
-    const int px = blockIdx.x * TILE_X + tx, py = blockIdx.y * TILE_Y + ty;
+    const int blockY = blockIdx.y + rr.firstBlockY;
+    const int px = blockIdx.x * TILE_X + tx, py = blockY * TILE_Y + ty;
     const int rw = c.gRectSizeMinusOne.x, rh = c.gRectSizeMinusOne.y;
 
-    if (!BlockHasGeometry(P.tiles))
+    if (!BlockHasGeometry(P.tiles, blockY))
         return;
     {
-        const int baseX = blockIdx.x * TILE_X - ts::BORDER, baseY = blockIdx.y * TILE_Y - ts::BORDER;
+        const int baseX = blockIdx.x * TILE_X - ts::BORDER, baseY = blockY * TILE_Y - ts::BORDER;
         for (int i = threadIdx.x; i < ts::BUF_X * ts::BUF_Y; i += TILE_X * TILE_Y) {
             int lx = i % ts::BUF_X, ly = i / ts::BUF_X;
             int gx = ClampI(baseX + lx, 0, rw), gy = ClampI(baseY + ly, 0, rh);
@@ -326,7 +328,7 @@ __global__ __launch_bounds__(TILE_X* TILE_Y) void ReblurTemporalStabilizationKer
     }
     __syncthreads();
 
-    if (px > rw || py > rh)
+    if (px > rw || py > rh || py < rr.rowBegin || py >= rr.rowEnd)
         return;
     if (LoadR8Unorm(P.tiles, px >> 4, py >> 4) != 0.0f)
         return;
@@ -500,8 +502,8 @@ static const char* LaunchTemporalStabilization(const PassArgs& a) {
     if (SPEC) P.outSpecLuma = a.planes[k++];
     if (k != a.planesNum)
         return "REBLUR temporal stabilization: unexpected resource count";
-    dim3 grid = GridFor(c.gRectSizeMinusOne.x + 1, c.gRectSizeMinusOne.y + 1, TILE_X, TILE_Y);
-    hipLaunchKernelGGL((ReblurTemporalStabilizationKernel<DIFF, SPEC>), grid, dim3(TILE_X * TILE_Y), 0, a.stream, c, P);
+    RowGrid g = GridForRows(c.gRectSizeMinusOne.x + 1, c.gRectSizeMinusOne.y + 1, TILE_X, TILE_Y, a.rowBegin, a.rowEnd);
+    hipLaunchKernelGGL((ReblurTemporalStabilizationKernel<DIFF, SPEC>), g.grid, dim3(TILE_X * TILE_Y), 0, a.stream, c, P, RowRange{g.firstBlockY, g.rowBegin, g.rowEnd});
     return nullptr;
 }
 

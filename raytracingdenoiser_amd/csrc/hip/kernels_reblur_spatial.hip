@@ -330,10 +330,10 @@ struct SpatialPlanes {
 };
 
 template <SpatialMode MODE, bool DIFF, bool SPEC, bool NO_TS>
-__global__ __launch_bounds__(TILE_X* TILE_Y) void ReblurSpatialKernel(ReblurCB c, SpatialPlanes P) {
+__global__ __launch_bounds__(TILE_X* TILE_Y) void ReblurSpatialKernel(ReblurCB c, SpatialPlanes P, RowRange rr) {
     const int px = blockIdx.x * TILE_X + (threadIdx.x % TILE_X);
-    const int py = blockIdx.y * TILE_Y + (threadIdx.x / TILE_X);
-    if (px > c.gRectSizeMinusOne.x || py > c.gRectSizeMinusOne.y)
+    const int py = (blockIdx.y + rr.firstBlockY) * TILE_Y + (threadIdx.x / TILE_X);
+    if (px > c.gRectSizeMinusOne.x || py > c.gRectSizeMinusOne.y || py < rr.rowBegin || py >= rr.rowEnd)
         return;
     if (LoadR8Unorm(P.tiles, px >> 4, py >> 4) != 0.0f)
         return;
@@ -424,17 +424,17 @@ static const char* LaunchSpatial(const PassArgs& a) {
     if (k != a.planesNum)
         return "REBLUR spatial pass: unexpected resource count";
 
-    dim3 grid = GridFor(c.gRectSizeMinusOne.x + 1, c.gRectSizeMinusOne.y + 1, TILE_X, TILE_Y);
-    hipLaunchKernelGGL((ReblurSpatialKernel<MODE, DIFF, SPEC, NO_TS>), grid, dim3(TILE_X * TILE_Y), 0, a.stream, c, P);
+    RowGrid g = GridForRows(c.gRectSizeMinusOne.x + 1, c.gRectSizeMinusOne.y + 1, TILE_X, TILE_Y, a.rowBegin, a.rowEnd);
+    hipLaunchKernelGGL((ReblurSpatialKernel<MODE, DIFF, SPEC, NO_TS>), g.grid, dim3(TILE_X * TILE_Y), 0, a.stream, c, P, RowRange{g.firstBlockY, g.rowBegin, g.rowEnd});
     return nullptr;
 }
 
 // ================================================================================================ SplitScreen
 template <bool DIFF, bool SPEC>
-__global__ __launch_bounds__(256) void ReblurSplitScreenKernel(ReblurCB c, Plane viewZ, Plane inDiff, Plane inSpec, Plane outDiff, Plane outSpec) {
+__global__ __launch_bounds__(256) void ReblurSplitScreenKernel(ReblurCB c, Plane viewZ, Plane inDiff, Plane inSpec, Plane outDiff, Plane outSpec, RowRange rr) {
     const int px = blockIdx.x * TILE_X + (threadIdx.x % TILE_X);
-    const int py = blockIdx.y * TILE_Y + (threadIdx.x / TILE_X);
-    if (px > c.gRectSizeMinusOne.x || py > c.gRectSizeMinusOne.y)
+    const int py = (blockIdx.y + rr.firstBlockY) * TILE_Y + (threadIdx.x / TILE_X);
+    if (px > c.gRectSizeMinusOne.x || py > c.gRectSizeMinusOne.y || py < rr.rowBegin || py >= rr.rowEnd)
         return;
     float pixelUvX = (float(px) + 0.5f) * c.gRectSizeInv.x;
     if (pixelUvX > c.gSplitScreen)
@@ -458,8 +458,8 @@ static const char* LaunchSplitScreen(const PassArgs& a) {
     if (SPEC) inSpec = a.planes[k++];
     if (DIFF) outDiff = a.planes[k++];
     if (SPEC) outSpec = a.planes[k++];
-    dim3 grid = GridFor(c.gRectSizeMinusOne.x + 1, c.gRectSizeMinusOne.y + 1, TILE_X, TILE_Y);
-    hipLaunchKernelGGL((ReblurSplitScreenKernel<DIFF, SPEC>), grid, dim3(256), 0, a.stream, c, viewZ, inDiff, inSpec, outDiff, outSpec);
+    RowGrid g = GridForRows(c.gRectSizeMinusOne.x + 1, c.gRectSizeMinusOne.y + 1, TILE_X, TILE_Y, a.rowBegin, a.rowEnd);
+    hipLaunchKernelGGL((ReblurSplitScreenKernel<DIFF, SPEC>), g.grid, dim3(256), 0, a.stream, c, viewZ, inDiff, inSpec, outDiff, outSpec, RowRange{g.firstBlockY, g.rowBegin, g.rowEnd});
     return nullptr;
 }
 

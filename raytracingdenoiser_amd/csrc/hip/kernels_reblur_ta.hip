@@ -29,17 +29,18 @@ struct TaPlanes {
 };
 
 template <bool DIFF, bool SPEC>
-__global__ __launch_bounds__(TILE_X* TILE_Y) void ReblurTemporalAccumulationKernel(ReblurCB c, TaPlanes P) {
+__global__ __launch_bounds__(TILE_X* TILE_Y) void ReblurTemporalAccumulationKernel(ReblurCB c, TaPlanes P, RowRange rr) {
     __shared__ float4 s_Normal_Roughness[BUF_Y * BUF_STRIDE];
     __shared__ float s_HitDistForTracking[BUF_Y * BUF_STRIDE];
 
     const int tx = threadIdx.x % TILE_X, ty = threadIdx.x / TILE_X;
-    const int px = blockIdx.x * TILE_X + tx, py = blockIdx.y * TILE_Y + ty;
+    const int blockY = blockIdx.y + rr.firstBlockY;
+    const int px = blockIdx.x * TILE_X + tx, py = blockY * TILE_Y + ty;
     const int rw = c.gRectSizeMinusOne.x, rh = c.gRectSizeMinusOne.y;
 
     // ---- cooperative preload (clamped to the rect), skipped when every 16x16 tile under this block is sky
     {
-        const int tileY = (blockIdx.y * TILE_Y) >> 4, tileX0 = (blockIdx.x * TILE_X) >> 4;
+        const int tileY = (blockY * TILE_Y) >> 4, tileX0 = (blockIdx.x * TILE_X) >> 4;
         bool anyGeometry = false;
         for (int t = 0; t < TILE_X / 16; t++)
             if (tileX0 + t < P.tiles.w && tileY < P.tiles.h)
@@ -47,7 +48,7 @@ __global__ __launch_bounds__(TILE_X* TILE_Y) void ReblurTemporalAccumulationKern
         if (!anyGeometry)
             return; // uniform across the block
 
-        const int baseX = blockIdx.x * TILE_X - BORDER, baseY = blockIdx.y * TILE_Y - BORDER;
+        const int baseX = blockIdx.x * TILE_X - BORDER, baseY = blockY * TILE_Y - BORDER;
         for (int i = threadIdx.x; i < BUF_X * BUF_Y; i += TILE_X * TILE_Y) {
             int lx = i % BUF_X, ly = i / BUF_X;
             int gx = ClampI(baseX + lx, 0, rw), gy = ClampI(baseY + ly, 0, rh);
@@ -60,7 +61,7 @@ __global__ __launch_bounds__(TILE_X* TILE_Y) void ReblurTemporalAccumulationKern
     }
     __syncthreads();
 
-    if (px > rw || py > rh)
+    if (px > rw || py > rh || py < rr.rowBegin || py >= rr.rowEnd)
         return;
     if (LoadR8Unorm(P.tiles, px >> 4, py >> 4) != 0.0f)
         return;
@@ -653,8 +654,8 @@ static const char* LaunchTemporalAccumulation(const PassArgs& a) {
     if (k != a.planesNum)
         return "REBLUR temporal accumulation: unexpected resource count";
 
-    dim3 grid = GridFor(c.gRectSizeMinusOne.x + 1, c.gRectSizeMinusOne.y + 1, TILE_X, TILE_Y);
-    hipLaunchKernelGGL((ReblurTemporalAccumulationKernel<DIFF, SPEC>), grid, dim3(TILE_X * TILE_Y), 0, a.stream, c, P);
+    RowGrid g = GridForRows(c.gRectSizeMinusOne.x + 1, c.gRectSizeMinusOne.y + 1, TILE_X, TILE_Y, a.rowBegin, a.rowEnd);
+    hipLaunchKernelGGL((ReblurTemporalAccumulationKernel<DIFF, SPEC>), g.grid, dim3(TILE_X * TILE_Y), 0, a.stream, c, P, RowRange{g.firstBlockY, g.rowBegin, g.rowEnd});
     return nullptr;
 }
 

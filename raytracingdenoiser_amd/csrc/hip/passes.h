@@ -14,6 +14,9 @@ struct PassArgs {
     const void* constants;    // DispatchDesc::constantBufferData
     uint32_t constantsSize;
     hipStream_t stream;
+    // rows [rowBegin, rowEnd) this rank has to produce in this pass (multi-GPU row-strip sharding; the whole frame by default).
+    // Pixels outside are left untouched; planes stay full-size, so all neighbourhood reads keep their single-GPU meaning.
+    int rowBegin, rowEnd;
 };
 
 // returns nullptr on success, or a static message if the dispatch cannot be executed by this build (nothing is launched then)
@@ -30,5 +33,27 @@ const PassEntry* GetReblurPasses(uint32_t& num);
 const PassEntry* GetSigmaPasses(uint32_t& num);
 
 inline dim3 GridFor(int w, int h, int tileW, int tileH) { return dim3((unsigned)((w + tileW - 1) / tileW), (unsigned)((h + tileH - 1) / tileH), 1); }
+
+// Grid covering rows [rowBegin, rowEnd) clipped to [0, h) with tileH-row blocks that stay aligned to the full-frame tiling;
+// firstBlockY is added to blockIdx.y inside the kernel.
+struct RowGrid {
+    dim3 grid;
+    int firstBlockY, rowBegin, rowEnd;
+};
+inline RowGrid GridForRows(int w, int h, int tileW, int tileH, int rowBegin, int rowEnd) {
+    RowGrid g;
+    g.rowBegin = rowBegin < 0 ? 0 : rowBegin;
+    g.rowEnd = rowEnd > h ? h : rowEnd;
+    if (g.rowEnd < g.rowBegin)
+        g.rowEnd = g.rowBegin;
+    g.firstBlockY = g.rowBegin / tileH;
+    int lastBlockY = (g.rowEnd + tileH - 1) / tileH;
+    int ny = lastBlockY - g.firstBlockY;
+    g.grid = dim3((unsigned)((w + tileW - 1) / tileW), (unsigned)(ny > 0 ? ny : 1), 1);
+    return g;
+}
+struct RowRange { // kernel argument
+    int firstBlockY, rowBegin, rowEnd;
+};
 
 } // namespace nrdhip

@@ -92,6 +92,9 @@ class HipExecutor:
         off = d.data - self.arena.data_ptr()
         return self.arena[off : off + d.height * d.rowPitchBytes].view(d.height, d.rowPitchBytes)
 
+    def set_owned_rows(self, row_begin, row_end):
+        self._check(self.lib.nrdHipSetOwnedRows(self.handle, row_begin, row_end), "nrdHipSetOwnedRows")
+
     def set_profiling(self, enable):
         self._check(self.lib.nrdHipSetProfiling(self.handle, 1 if enable else 0), "nrdHipSetProfiling")
 
