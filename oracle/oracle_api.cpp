@@ -22,12 +22,13 @@ struct OraclePlane { // same layout as NrdHipPlaneDesc, but "data" is HOST memor
 
 // Runs one pass on the CPU. Returns 0 on success, 1 if the pass is unknown to the oracle.
 __attribute__((visibility("default"))) int oracle_dispatch(const char* shaderFileName, const void* constants, uint32_t constantsSize, const OraclePlane* planes, uint32_t planesNum) {
-    const PassEntry* tables[3];
-    uint32_t counts[3];
+    const PassEntry* tables[4];
+    uint32_t counts[4];
     tables[0] = GetCommonPasses(counts[0]);
     tables[1] = GetReblurPasses(counts[1]);
     tables[2] = GetSigmaPasses(counts[2]);
-    for (int t = 0; t < 3; t++)
+    tables[3] = GetRelaxPasses(counts[3]);
+    for (int t = 0; t < 4; t++)
         for (uint32_t i = 0; i < counts[t]; i++)
             if (!strcmp(tables[t][i].shaderFileName, shaderFileName)) {
                 std::vector<Tex> tex(planesNum);

@@ -24,5 +24,6 @@ struct PassEntry {
 const PassEntry* GetCommonPasses(uint32_t& n);
 const PassEntry* GetReblurPasses(uint32_t& n);
 const PassEntry* GetSigmaPasses(uint32_t& n);
+const PassEntry* GetRelaxPasses(uint32_t& n);
 
 } // namespace orc

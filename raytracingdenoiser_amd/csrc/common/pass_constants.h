@@ -155,4 +155,95 @@ struct SigmaConstants {
 };
 static_assert(sizeof(SigmaConstants) == 516, "SIGMA shared constants must be 516 bytes");
 
+// RELAX shared block: reference Shaders/Include/RELAX_Config.hlsli:21-99 (field order), filled by Source/Relax.cpp:58-177
+struct RelaxConstants {
+    float gWorldToClip[16];
+    float gWorldToClipPrev[16];
+    float gWorldToViewPrev[16];
+    float gWorldPrevToWorld[16];
+    F4 gRotatorPre;
+    F4 gFrustumRight;
+    F4 gFrustumUp;
+    F4 gFrustumForward;
+    F4 gPrevFrustumRight;
+    F4 gPrevFrustumUp;
+    F4 gPrevFrustumForward;
+    F4 gCameraDelta;
+    F4 gMvScale;
+    F2 gJitter;
+    F2 gResolutionScale;
+    F2 gRectOffset;
+    F2 gResourceSizeInv;
+    F2 gResourceSize;
+    F2 gRectSizeInv;
+    F2 gRectSizePrev;
+    F2 gResourceSizeInvPrev;
+    U2 gPrintfAt;
+    U2 gRectOrigin;
+    I2 gRectSize;
+    float gSpecMaxAccumulatedFrameNum;
+    float gSpecMaxFastAccumulatedFrameNum;
+    float gDiffMaxAccumulatedFrameNum;
+    float gDiffMaxFastAccumulatedFrameNum;
+    float gDisocclusionThreshold;
+    float gDisocclusionThresholdAlternate;
+    float gCameraAttachedReflectionMaterialID;
+    float gStrandMaterialID;
+    float gStrandThickness;
+    float gRoughnessFraction;
+    float gSpecVarianceBoost;
+    float gSplitScreen;
+    float gDiffBlurRadius;
+    float gSpecBlurRadius;
+    float gDepthThreshold;
+    float gLobeAngleFraction;
+    float gSpecLobeAngleSlack;
+    float gHistoryFixEdgeStoppingNormalPower;
+    float gRoughnessEdgeStoppingRelaxation;
+    float gNormalEdgeStoppingRelaxation;
+    float gColorBoxSigmaScale;
+    float gHistoryAccelerationAmount;
+    float gHistoryResetTemporalSigmaScale;
+    float gHistoryResetSpatialSigmaScale;
+    float gHistoryResetAmount;
+    float gDenoisingRange;
+    float gSpecPhiLuminance;
+    float gDiffPhiLuminance;
+    float gDiffMaxLuminanceRelativeDifference;
+    float gSpecMaxLuminanceRelativeDifference;
+    float gLuminanceEdgeStoppingRelaxation;
+    float gConfidenceDrivenRelaxationMultiplier;
+    float gConfidenceDrivenLuminanceEdgeStoppingRelaxation;
+    float gConfidenceDrivenNormalEdgeStoppingRelaxation;
+    float gDebug;
+    float gOrthoMode;
+    float gUnproject;
+    float gFramerateScale;
+    float gCheckerboardResolveAccumSpeed;
+    float gJitterDelta;
+    float gHistoryFixFrameNum;
+    float gHistoryFixBasePixelStride;
+    float gHistoryThreshold;
+    float gViewZScale;
+    float gMinHitDistanceWeight;
+    float gDiffMinMaterial;
+    float gSpecMinMaterial;
+    uint32_t gRoughnessEdgeStoppingEnabled;
+    uint32_t gFrameIndex;
+    uint32_t gDiffCheckerboard;
+    uint32_t gSpecCheckerboard;
+    uint32_t gHasHistoryConfidence;
+    uint32_t gHasDisocclusionThresholdMix;
+    uint32_t gResetHistory;
+};
+static_assert(sizeof(RelaxConstants) == 704, "RELAX shared constants must be 704 bytes");
+
+// A-trous passes (both flavours) append the iteration parameters: reference Shaders/Resources/RELAX_Atrous.resources.hlsli:11-15
+struct RelaxAtrousConstants {
+    RelaxConstants shared;
+    uint32_t gStepSize;
+    uint32_t gIsLastPass;
+};
+static_assert(sizeof(RelaxAtrousConstants) == 712, "RELAX a-trous constants");
+
 } // namespace nrdc

@@ -56,6 +56,8 @@ nrd::Format ExpectedUserFormat(nrd::ResourceType t) {
         case R::IN_DIFF_CONFIDENCE: case R::IN_SPEC_CONFIDENCE: case R::IN_DISOCCLUSION_THRESHOLD_MIX: return F::R8_UNORM;
         case R::IN_DIFF_RADIANCE_HITDIST: case R::IN_SPEC_RADIANCE_HITDIST: return F::RGBA16_SFLOAT;
         case R::OUT_DIFF_RADIANCE_HITDIST: case R::OUT_SPEC_RADIANCE_HITDIST: return F::RGBA16_SFLOAT;
+        case R::IN_DIFF_SH0: case R::IN_DIFF_SH1: case R::IN_SPEC_SH0: case R::IN_SPEC_SH1: return F::RGBA16_SFLOAT;
+        case R::OUT_DIFF_SH0: case R::OUT_DIFF_SH1: case R::OUT_SPEC_SH0: case R::OUT_SPEC_SH1: return F::RGBA16_SFLOAT;
         case R::IN_PENUMBRA: return F::R16_SFLOAT;
         case R::OUT_SHADOW_TRANSLUCENCY: return F::R8_UNORM;
         case R::IN_SIGNAL: case R::OUT_SIGNAL: return F::RGBA32_SFLOAT;
@@ -168,13 +170,14 @@ static uint32_t CreateExecutorImpl(void* instance, uint16_t resourceWidth, uint1
 
     // pipeline index -> launcher
     e->launchers.assign(desc.pipelinesNum, nullptr);
-    const PassEntry* tables[3];
-    uint32_t counts[3];
+    const PassEntry* tables[4];
+    uint32_t counts[4];
     tables[0] = GetCommonPasses(counts[0]);
     tables[1] = GetReblurPasses(counts[1]);
     tables[2] = GetSigmaPasses(counts[2]);
+    tables[3] = GetRelaxPasses(counts[3]);
     for (uint32_t p = 0; p < desc.pipelinesNum; p++)
-        for (int t = 0; t < 3; t++)
+        for (int t = 0; t < 4; t++)
             for (uint32_t i = 0; i < counts[t]; i++)
                 if (!strcmp(tables[t][i].shaderFileName, desc.pipelines[p].shaderFileName))
                     e->launchers[p] = tables[t][i].launch;

@@ -1,0 +1,598 @@
+// RELAX a-trous wavelet passes as HIP kernels for gfx950.
+//   AtrousSmem   reference Shaders/Include/RELAX_AtrousSmem.hlsli:10-455  (first iteration: 3x3 or 5x5 around the pixel)
+//   Atrous       reference Shaders/Include/RELAX_Atrous.hlsli:10-240      (iterations 2..N: 8 taps at +-stepSize)
+//
+// MI355X mapping.
+//   AtrousSmem is a dense stencil: 32x8-pixel workgroups stage a 36x12 halo tile (halo 2) of every per-pixel quantity the
+//     window needs -- radiance+2nd moment per signal, SH1 per signal, decoded normal/roughness, world position + material
+//     id -- in LDS once (up to 6 float4 planes = 41 KiB), so each plane is read from HBM ~1.7x instead of 25x. Rows are
+//     padded to 37 float4 so the rows a wave touches start in different banks.
+//   Atrous is the HBM-bound loop of the chain (BASELINE config 5: five iterations at 3840x2160): per iteration every
+//     signal plane is read once and written once; the 8 taps of a pixel are +-step texels away, so the lanes of a wave
+//     read three contiguous row segments per plane (rows y-step, y, y+step), and the working set of a band of rows
+//     (3 rows x planes) stays in the 4 MiB L2 of the XCD that owns the band. Guides are tested first and the radiance
+//     planes are only touched for taps whose geometric weight survives (as in the reference).
+#include "relax_device.h"
+
+namespace nrdhip {
+
+namespace {
+
+constexpr int TILE_X = RELAX_TILE_X;
+constexpr int TILE_Y = RELAX_TILE_Y;
+
+struct AtrousPlanes {
+    Plane tiles, historyLength, specReprojectionConfidence, normalRoughness, viewZ;
+    Plane outNormalRoughness, outMaterialID, outViewZ; // AtrousSmem only
+    SignalPlanes spec, diff;
+};
+
+template <bool DIFF, bool SPEC, bool SH, bool SMEM>
+bool BindAtrous(const PassArgs& a, AtrousPlanes& P) {
+    PlaneCursor cur(a);
+    P.tiles = cur.next();
+    if (SPEC) P.spec.in = cur.next();
+    if (DIFF) P.diff.in = cur.next();
+    P.historyLength = cur.next();
+    if (SPEC) P.specReprojectionConfidence = cur.next();
+    P.normalRoughness = cur.next();
+    P.viewZ = cur.next();
+    if (SPEC) P.spec.confidence = cur.next();
+    if (DIFF) P.diff.confidence = cur.next();
+    if (SH && SPEC) P.spec.inSh = cur.next();
+    if (SH && DIFF) P.diff.inSh = cur.next();
+    if (SPEC) P.spec.out = cur.next();
+    if (DIFF) P.diff.out = cur.next();
+    if (SMEM) {
+        P.outNormalRoughness = cur.next();
+        P.outMaterialID = cur.next();
+        P.outViewZ = cur.next();
+    }
+    if (SH && SPEC) P.spec.outSh = cur.next();
+    if (SH && DIFF) P.diff.outSh = cur.next();
+    return cur.complete();
+}
+
+// per-pixel weight parameters shared by both flavours (confidence-driven relaxation included)
+struct SpecParams {
+    float centerLuminance, phiLIlluminationInv, luminanceWeightRelaxation, normalWeightParamSimplified;
+    float2 normalWeightParams, roughnessWeightParams;
+};
+struct DiffParams {
+    float centerLuminance, phiLIlluminationInv, luminanceWeightRelaxation, normalWeightParam;
+};
+
+// ================================================================================================ AtrousSmem
+namespace sm {
+constexpr int BORDER = 2;
+constexpr int BUF_X = TILE_X + 2 * BORDER; // 36
+constexpr int BUF_Y = TILE_Y + 2 * BORDER; // 12
+constexpr int BUF_STRIDE = BUF_X + 1;      // 37
+constexpr int BUF_SIZE = BUF_Y * BUF_STRIDE;
+} // namespace sm
+
+template <bool DIFF, bool SPEC, bool SH>
+__global__ __launch_bounds__(256) void RelaxAtrousSmemKernel(AtrousPlanes P, RelaxCB c, RowRange rows) {
+    __shared__ float4 s_Spec[SPEC ? sm::BUF_SIZE : 1], s_SpecSH[(SPEC && SH) ? sm::BUF_SIZE : 1];
+    __shared__ float4 s_Diff[DIFF ? sm::BUF_SIZE : 1], s_DiffSH[(DIFF && SH) ? sm::BUF_SIZE : 1];
+    __shared__ float4 s_Normal_Roughness[sm::BUF_SIZE], s_WorldPos_MaterialID[sm::BUF_SIZE];
+
+    const int blockY = blockIdx.y + rows.firstBlockY;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    const int px = blockIdx.x * TILE_X + tx, py = blockY * TILE_Y + ty;
+    const int rectW = c.shared.gRectSize.x, rectH = c.shared.gRectSize.y;
+    const bool inRows = py >= rows.rowBegin && py < rows.rowEnd;
+
+    // Every thread the reference launches (8x8 groups over the rect) forwards the guides to the "previous frame" planes,
+    // sky or not; threads of all-sky tiles read unwritten group-shared memory there, which we define as zero.
+    const bool inGrid = px < ((rectW + 7) & ~7) && py < ((rectH + 7) & ~7);
+    const bool blockHasGeometry = RelaxBlockHasGeometry(P.tiles, blockY);
+
+    if (blockHasGeometry) {
+        for (int idx = threadIdx.x; idx < sm::BUF_X * sm::BUF_Y; idx += 256) {
+            int lx = idx % sm::BUF_X, ly = idx / sm::BUF_X;
+            int gx = ClampI(blockIdx.x * TILE_X - sm::BORDER + lx, 0, rectW - 1), gy = ClampI(blockY * TILE_Y - sm::BORDER + ly, 0, rectH - 1);
+            int li = ly * sm::BUF_STRIDE + lx;
+            if (SPEC) s_Spec[li] = LoadRGBA16F(P.spec.in, gx, gy);
+            if (SPEC && SH) s_SpecSH[li] = LoadRGBA16F(P.spec.inSh, gx, gy);
+            if (DIFF) s_Diff[li] = LoadRGBA16F(P.diff.in, gx, gy);
+            if (DIFF && SH) s_DiffSH[li] = LoadRGBA16F(P.diff.inSh, gx, gy);
+            float materialID;
+            s_Normal_Roughness[li] = UnpackNormalAndRoughness(LoadR10G10B10A2(P.normalRoughness, gx, gy), materialID);
+            float viewZ = RelaxUnpackViewZ(c, LoadR32F(P.viewZ, gx, gy));
+            s_WorldPos_MaterialID[li] = F4(GetCurrentWorldPosFromPixelPos(c, gx, gy, viewZ), materialID);
+        }
+    }
+    __syncthreads();
+
+    if (!inGrid || !inRows)
+        return;
+
+    const int lx = tx + sm::BORDER, ly = ty + sm::BORDER, lc = ly * sm::BUF_STRIDE + lx;
+    const bool tileIsSky = LoadR8UnormOrZero(P.tiles, px >> 4, py >> 4) != 0.0f;
+
+    const float viewZpacked = LoadR32FOrZero(P.viewZ, px, py);
+    if (InBounds(P.outViewZ, px, py))
+        StoreR32F(P.outViewZ, px, py, viewZpacked);
+
+    float4 normalRoughness = F4(0.0f);
+    float4 centerWorldPosMaterialID = F4(0.0f);
+    if (!tileIsSky) {
+        normalRoughness = s_Normal_Roughness[lc];
+        centerWorldPosMaterialID = s_WorldPos_MaterialID[lc];
+    }
+    const float centerViewZ = RelaxUnpackViewZ(c, viewZpacked);
+    if (centerViewZ > c.shared.gDenoisingRange)
+        normalRoughness = F4(1.0f / 255.0f);
+    const float centerMaterialID = centerWorldPosMaterialID.w;
+    if (InBounds(P.outNormalRoughness, px, py)) {
+        StoreRGBA8Unorm(P.outNormalRoughness, px, py, PackPrevNormalRoughness(normalRoughness));
+        StoreR8Unorm(P.outMaterialID, px, py, centerMaterialID / 255.0f);
+    }
+
+    if (tileIsSky || px >= rectW || py >= rectH)
+        return;
+    if (centerViewZ > c.shared.gDenoisingRange)
+        return;
+
+    const float3 centerWorldPos = Xyz(centerWorldPosMaterialID);
+    const float3 centerNormal = Xyz(normalRoughness);
+    const float centerRoughness = normalRoughness.w;
+    const float historyLength = 255.0f * LoadR8Unorm(P.historyLength, px, py);
+
+    if (historyLength >= c.shared.gHistoryThreshold) {
+        // 3x3 gaussian-filtered variance
+        float4 specularSum = F4(0.0f), diffuseSum = F4(0.0f);
+#pragma unroll
+        for (int dx = -1; dx <= 1; dx++)
+#pragma unroll
+            for (int dy = -1; dy <= 1; dy++) {
+                const float k = (dx == 0 ? 0.5f : 0.25f) * (dy == 0 ? 0.5f : 0.25f); // {1/4, 1/8; 1/8, 1/16}
+                const int li = (ly + dy) * sm::BUF_STRIDE + (lx + dx);
+                if (SPEC) specularSum = specularSum + s_Spec[li] * k;
+                if (DIFF) diffuseSum = diffuseSum + s_Diff[li] * k;
+            }
+        const float specular1stMomentV = Luminance(Xyz(specularSum));
+        const float centerSpecularVar = Max(0.0f, specularSum.w - specular1stMomentV * specular1stMomentV);
+        const float diffuse1stMomentV = Luminance(Xyz(diffuseSum));
+        const float centerDiffuseVar = Max(0.0f, diffuseSum.w - diffuse1stMomentV * diffuse1stMomentV);
+
+        float diffuseLobeAngleFraction = c.shared.gLobeAngleFraction;
+
+        SpecParams sp = {};
+        float roughnessModified = 0.0f;
+        float3 centerV = F3(0.0f);
+        if (SPEC) {
+            sp.centerLuminance = Luminance(Xyz(s_Spec[lc]));
+            sp.phiLIlluminationInv = 1.0f / Max(1.0e-4f, c.shared.gSpecPhiLuminance * Sqrt(centerSpecularVar));
+            sp.roughnessWeightParams = GetRoughnessWeightParams(centerRoughness, c.shared.gRoughnessFraction);
+            float diffuseLobeAngleFractionForSimplifiedSpecularNormalWeight = diffuseLobeAngleFraction;
+            float specularLobeAngleFraction = c.shared.gLobeAngleFraction;
+            const float specularReprojectionConfidence = LoadR8Unorm(P.specReprojectionConfidence, px, py);
+            sp.luminanceWeightRelaxation = Lerp(1.0f, specularReprojectionConfidence, c.shared.gLuminanceEdgeStoppingRelaxation);
+            if (c.shared.gHasHistoryConfidence) {
+                float specConfidenceDrivenRelaxation = Sat(c.shared.gConfidenceDrivenRelaxationMultiplier * (1.0f - LoadR8Unorm(P.spec.confidence, px, py)));
+                float r = Sat(specConfidenceDrivenRelaxation * c.shared.gConfidenceDrivenNormalEdgeStoppingRelaxation);
+                diffuseLobeAngleFractionForSimplifiedSpecularNormalWeight = Lerp(diffuseLobeAngleFraction, 1.0f, r);
+                specularLobeAngleFraction = Lerp(specularLobeAngleFraction, 1.0f, r);
+                r = Sat(specConfidenceDrivenRelaxation * c.shared.gConfidenceDrivenLuminanceEdgeStoppingRelaxation);
+                sp.luminanceWeightRelaxation *= 1.0f - r;
+            }
+            sp.normalWeightParamSimplified = GetNormalWeightParam2(1.0f, diffuseLobeAngleFractionForSimplifiedSpecularNormalWeight);
+            sp.normalWeightParams = GetNormalWeightParams_ATrous(centerRoughness, historyLength, specularReprojectionConfidence, c.shared.gNormalEdgeStoppingRelaxation,
+                specularLobeAngleFraction, c.shared.gSpecLobeAngleSlack);
+            if (SH)
+                roughnessModified = s_SpecSH[lc].w;
+            centerV = -Normalize(centerWorldPos);
+        }
+
+        DiffParams dp = {};
+        dp.luminanceWeightRelaxation = 1.0f;
+        if (DIFF) {
+            dp.centerLuminance = Luminance(Xyz(s_Diff[lc]));
+            dp.phiLIlluminationInv = 1.0f / Max(1.0e-4f, c.shared.gDiffPhiLuminance * Sqrt(centerDiffuseVar));
+            if (c.shared.gHasHistoryConfidence) {
+                float diffConfidenceDrivenRelaxation = Sat(c.shared.gConfidenceDrivenRelaxationMultiplier * (1.0f - LoadR8Unorm(P.diff.confidence, px, py)));
+                float r = Sat(diffConfidenceDrivenRelaxation * c.shared.gConfidenceDrivenNormalEdgeStoppingRelaxation);
+                diffuseLobeAngleFraction = Lerp(diffuseLobeAngleFraction, 1.0f, r);
+                r = Sat(diffConfidenceDrivenRelaxation * c.shared.gConfidenceDrivenLuminanceEdgeStoppingRelaxation);
+                dp.luminanceWeightRelaxation = 1.0f - r;
+            }
+            dp.normalWeightParam = GetNormalWeightParam2(1.0f, diffuseLobeAngleFraction);
+        }
+
+        float sumWSpecular = 0.0f, sumWDiffuse = 0.0f;
+        float4 sumSpecular = F4(0.0f), sumSpecularSH = F4(0.0f), sumDiffuse = F4(0.0f), sumDiffuseSH = F4(0.0f);
+        const float depthThreshold = c.shared.gDepthThreshold * centerViewZ;
+
+#pragma unroll
+        for (int cx = -1; cx <= 1; cx++)
+#pragma unroll
+            for (int cy = -1; cy <= 1; cy++) {
+                const int qx = px + cx, qy = py + cy;
+                const bool isCenter = cx == 0 && cy == 0;
+                const bool isInside = qx >= 0 && qy >= 0 && qx < rectW && qy < rectH;
+                const float kernelW = isInside ? (cx == 0 ? 0.44198f : 0.27901f) * (cy == 0 ? 0.44198f : 0.27901f) : 0.0f;
+                const int li = (ly + cy) * sm::BUF_STRIDE + (lx + cx);
+
+                const float4 sampleNormalRoughness = s_Normal_Roughness[li];
+                const float3 sampleNormal = Xyz(sampleNormalRoughness);
+                const float sampleRoughness = sampleNormalRoughness.w;
+                const float4 sampleWorldPosMaterialID = s_WorldPos_MaterialID[li];
+                const float3 sampleWorldPos = Xyz(sampleWorldPosMaterialID);
+                const float sampleMaterialID = sampleWorldPosMaterialID.w;
+
+                float geometryW = GetPlaneDistanceWeight_Atrous(centerWorldPos, centerNormal, sampleWorldPos, depthThreshold);
+                geometryW *= kernelW;
+
+                if (SPEC) {
+                    float angles = AcosApprox(Dot(centerNormal, sampleNormal));
+                    float3 sampleV = -Normalize(sampleWorldPos + c.shared.gRoughnessEdgeStoppingRelaxation * centerWorldPos);
+                    float normalWSpecularSimplified = ComputeWeight(angles, sp.normalWeightParamSimplified, 0.0f);
+                    float normalWSpecular = GetSpecularNormalWeight_ATrous(sp.normalWeightParams, centerNormal, sampleNormal, centerV, sampleV);
+                    float roughnessWSpecular = ComputeWeight(sampleRoughness, sp.roughnessWeightParams.x, sp.roughnessWeightParams.y);
+
+                    float4 sampleSpecular = s_Spec[li];
+                    float sampleSpecularLuminance = Luminance(Xyz(sampleSpecular));
+                    float specularLuminanceW = Abs(sp.centerLuminance - sampleSpecularLuminance) * sp.phiLIlluminationInv;
+                    specularLuminanceW = Min(c.shared.gSpecMaxLuminanceRelativeDifference, specularLuminanceW);
+                    specularLuminanceW *= sp.luminanceWeightRelaxation;
+
+                    float wSpecular = geometryW * Exp(-specularLuminanceW);
+                    wSpecular *= c.shared.gRoughnessEdgeStoppingEnabled ? (normalWSpecular * roughnessWSpecular) : normalWSpecularSimplified;
+                    wSpecular = isCenter ? kernelW : wSpecular;
+                    wSpecular *= Cmp(CompareMaterials(sampleMaterialID, centerMaterialID, c.shared.gSpecMinMaterial));
+
+                    sumWSpecular += wSpecular;
+                    sumSpecular = sumSpecular + wSpecular * sampleSpecular;
+                    if (SH)
+                        sumSpecularSH = sumSpecularSH + wSpecular * s_SpecSH[li];
+                }
+                if (DIFF) {
+                    float angled = AcosApprox(Dot(centerNormal, sampleNormal));
+                    float normalWDiffuse = ComputeWeight(angled, dp.normalWeightParam, 0.0f);
+
+                    float4 sampleDiffuse = s_Diff[li];
+                    float sampleDiffuseLuminance = Luminance(Xyz(sampleDiffuse));
+                    float diffuseLuminanceW = Abs(dp.centerLuminance - sampleDiffuseLuminance) * dp.phiLIlluminationInv;
+                    diffuseLuminanceW = Min(c.shared.gDiffMaxLuminanceRelativeDifference, diffuseLuminanceW);
+                    diffuseLuminanceW *= dp.luminanceWeightRelaxation;
+
+                    float wDiffuse = geometryW * normalWDiffuse * Exp(-diffuseLuminanceW);
+                    wDiffuse = isCenter ? kernelW : wDiffuse;
+                    wDiffuse *= Cmp(CompareMaterials(sampleMaterialID, centerMaterialID, c.shared.gDiffMinMaterial));
+
+                    sumWDiffuse += wDiffuse;
+                    sumDiffuse = sumDiffuse + wDiffuse * sampleDiffuse;
+                    if (SH)
+                        sumDiffuseSH = sumDiffuseSH + wDiffuse * s_DiffSH[li];
+                }
+            }
+
+        if (SPEC) {
+            sumWSpecular = Max(sumWSpecular, 1e-6f);
+            sumSpecular = sumSpecular / sumWSpecular;
+            float m1 = Luminance(Xyz(sumSpecular));
+            float variance = Max(0.0f, sumSpecular.w - m1 * m1);
+            StoreRGBA16F(P.spec.out, px, py, F4(Xyz(sumSpecular), variance));
+            if (SH)
+                StoreRGBA16F(P.spec.outSh, px, py, F4(Xyz(sumSpecularSH) / sumWSpecular, roughnessModified));
+        }
+        if (DIFF) {
+            sumWDiffuse = Max(sumWDiffuse, 1e-6f);
+            sumDiffuse = sumDiffuse / sumWDiffuse;
+            float m1 = Luminance(Xyz(sumDiffuse));
+            float variance = Max(0.0f, sumDiffuse.w - m1 * m1);
+            StoreRGBA16F(P.diff.out, px, py, F4(Xyz(sumDiffuse), variance));
+            if (SH)
+                StoreRGBA16F(P.diff.outSh, px, py, sumDiffuseSH / sumWDiffuse);
+        }
+    } else {
+        // spatial variance estimation over 5x5
+        float sumWSpecular = 0.0f, sumSpecular1stMoment = 0.0f, sumSpecular2ndMoment = 0.0f;
+        float3 sumSpecularIllumination = F3(0.0f);
+        float4 sumSpecularSH = F4(0.0f);
+        float sumWDiffuse = 0.0f, sumDiffuse1stMoment = 0.0f, sumDiffuse2ndMoment = 0.0f;
+        float3 sumDiffuseIllumination = F3(0.0f);
+        float4 sumDiffuseSH = F4(0.0f);
+
+        const float diffuseNormalWeightParam = GetNormalWeightParam2(1.0f, c.shared.gLobeAngleFraction);
+
+        for (int cx = -2; cx <= 2; cx++)
+            for (int cy = -2; cy <= 2; cy++) {
+                const int li = (ly + cy) * sm::BUF_STRIDE + (lx + cx);
+                const float3 sampleNormal = Xyz(s_Normal_Roughness[li]);
+                const float sampleMaterialID = s_WorldPos_MaterialID[li].w;
+
+                const float depthW = 1.0f;
+                float angle = AcosApprox(Dot(centerNormal, sampleNormal));
+                float normalW = ComputeWeight(angle, diffuseNormalWeightParam, 0.0f);
+
+                if (SPEC) {
+                    float4 sampleSpecular = s_Spec[li];
+                    float sample1stMoment = Luminance(Xyz(sampleSpecular));
+                    float specularW = normalW * depthW;
+                    specularW *= Cmp(CompareMaterials(sampleMaterialID, centerMaterialID, c.shared.gSpecMinMaterial));
+                    sumWSpecular += specularW;
+                    sumSpecularIllumination = sumSpecularIllumination + Xyz(sampleSpecular) * specularW;
+                    sumSpecular1stMoment += sample1stMoment * specularW;
+                    sumSpecular2ndMoment += sampleSpecular.w * specularW;
+                    if (SH)
+                        sumSpecularSH = sumSpecularSH + s_SpecSH[li] * specularW;
+                }
+                if (DIFF) {
+                    float4 sampleDiffuse = s_Diff[li];
+                    float sample1stMoment = Luminance(Xyz(sampleDiffuse));
+                    float diffuseW = normalW * depthW;
+                    diffuseW *= Cmp(CompareMaterials(sampleMaterialID, centerMaterialID, c.shared.gDiffMinMaterial));
+                    sumWDiffuse += diffuseW;
+                    sumDiffuseIllumination = sumDiffuseIllumination + Xyz(sampleDiffuse) * diffuseW;
+                    sumDiffuse1stMoment += sample1stMoment * diffuseW;
+                    sumDiffuse2ndMoment += sampleDiffuse.w * diffuseW;
+                    if (SH)
+                        sumDiffuseSH = sumDiffuseSH + s_DiffSH[li] * diffuseW;
+                }
+            }
+
+        const float boost = Max(1.0f, 4.0f / (historyLength + 1.0f));
+        if (SPEC) {
+            sumWSpecular = Max(sumWSpecular, 1e-6f);
+            sumSpecularIllumination = sumSpecularIllumination / sumWSpecular;
+            sumSpecular1stMoment /= sumWSpecular;
+            sumSpecular2ndMoment /= sumWSpecular;
+            float variance = Max(0.0f, sumSpecular2ndMoment - sumSpecular1stMoment * sumSpecular1stMoment);
+            variance *= boost;
+            StoreRGBA16F(P.spec.out, px, py, F4(sumSpecularIllumination, variance));
+            if (SH) {
+                float roughnessModified = s_SpecSH[lc].w;
+                StoreRGBA16F(P.spec.outSh, px, py, F4(Xyz(sumSpecularSH) / sumWSpecular, roughnessModified));
+            }
+        }
+        if (DIFF) {
+            sumWDiffuse = Max(sumWDiffuse, 1e-6f);
+            sumDiffuseIllumination = sumDiffuseIllumination / sumWDiffuse;
+            sumDiffuse1stMoment /= sumWDiffuse;
+            sumDiffuse2ndMoment /= sumWDiffuse;
+            float variance = Max(0.0f, sumDiffuse2ndMoment - sumDiffuse1stMoment * sumDiffuse1stMoment);
+            variance *= boost;
+            StoreRGBA16F(P.diff.out, px, py, F4(sumDiffuseIllumination, variance));
+            if (SH)
+                StoreRGBA16F(P.diff.outSh, px, py, sumDiffuseSH / sumWDiffuse);
+        }
+    }
+}
+
+template <bool DIFF, bool SPEC, bool SH>
+const char* LaunchAtrousSmem(const PassArgs& a) {
+    if (const char* e = CheckSupportedRelax(a))
+        return e;
+    AtrousPlanes P = {};
+    if (!BindAtrous<DIFF, SPEC, SH, true>(a, P))
+        return "RELAX AtrousSmem: unexpected resource count";
+    RelaxCB c = LoadRelaxConstants(a);
+    // the grid covers the reference's 8x8-group launch area (rect rounded up to 8)
+    RowGrid g = GridForRows((c.shared.gRectSize.x + 7) & ~7, (c.shared.gRectSize.y + 7) & ~7, TILE_X, TILE_Y, a.rowBegin, a.rowEnd);
+    if (a.rowEnd >= c.shared.gRectSize.y) // the owner of the last rows also owns the rounding rows below the rect
+        g.rowEnd = (c.shared.gRectSize.y + 7) & ~7;
+    hipLaunchKernelGGL((RelaxAtrousSmemKernel<DIFF, SPEC, SH>), g.grid, dim3(256), 0, a.stream, P, c, RowRange{g.firstBlockY, g.rowBegin, g.rowEnd});
+    return nullptr;
+}
+
+// ================================================================================================ Atrous
+template <bool DIFF, bool SPEC, bool SH>
+__global__ __launch_bounds__(256) void RelaxAtrousKernel(AtrousPlanes P, RelaxCB c, RowRange rows) {
+    const int blockY = blockIdx.y + rows.firstBlockY;
+    const int px = blockIdx.x * TILE_X + (threadIdx.x & 31), py = blockY * TILE_Y + (threadIdx.x >> 5);
+    const int rectW = c.shared.gRectSize.x, rectH = c.shared.gRectSize.y;
+    if (px >= rectW || py >= rectH || py < rows.rowBegin || py >= rows.rowEnd)
+        return;
+    if (LoadR8Unorm(P.tiles, px >> 4, py >> 4) != 0.0f)
+        return;
+    const float centerViewZ = RelaxUnpackViewZ(c, LoadR32F(P.viewZ, px, py));
+    if (centerViewZ > c.shared.gDenoisingRange)
+        return;
+
+    float centerMaterialID;
+    const float4 centerNormalRoughness = UnpackNormalAndRoughness(LoadR10G10B10A2(P.normalRoughness, px, py), centerMaterialID);
+    const float3 centerNormal = Xyz(centerNormalRoughness);
+    const float centerRoughness = centerNormalRoughness.w;
+    const float historyLength = 255.0f * LoadR8Unorm(P.historyLength, px, py);
+    const int stepSize = (int)c.gStepSize;
+
+    float diffuseLobeAngleFraction = c.shared.gLobeAngleFraction / Sqrt(float(c.gStepSize));
+    if (SH)
+        diffuseLobeAngleFraction = 1.0f / Sqrt(float(c.gStepSize));
+    diffuseLobeAngleFraction = Lerp(0.99f, diffuseLobeAngleFraction, Sat(historyLength / 5.0f));
+
+    SpecParams sp = {};
+    sp.luminanceWeightRelaxation = 1.0f;
+    float4 sumSpecular = F4(0.0f), sumSpecularSH = F4(0.0f);
+    float sumWSpecular = 0.44198f * 0.44198f, roughnessModified = 0.0f;
+    if (SPEC) {
+        const float4 centerSpecular = LoadRGBA16F(P.spec.in, px, py);
+        sp.centerLuminance = Luminance(Xyz(centerSpecular));
+        const float centerSpecularVar = centerSpecular.w;
+        sp.phiLIlluminationInv = 1.0f / Max(1.0e-4f, c.shared.gSpecPhiLuminance * Sqrt(centerSpecularVar));
+
+        sp.roughnessWeightParams = GetRoughnessWeightParams(centerRoughness, c.shared.gRoughnessFraction);
+        float diffuseLobeAngleFractionForSimplifiedSpecularNormalWeight = diffuseLobeAngleFraction;
+        float specularLobeAngleFraction = c.shared.gLobeAngleFraction;
+        const float specularReprojectionConfidence = LoadR8Unorm(P.specReprojectionConfidence, px, py);
+        if (c.gStepSize <= 4)
+            sp.luminanceWeightRelaxation = Lerp(1.0f, specularReprojectionConfidence, c.shared.gLuminanceEdgeStoppingRelaxation);
+        if (c.shared.gHasHistoryConfidence) {
+            float specConfidenceDrivenRelaxation = Sat(c.shared.gConfidenceDrivenRelaxationMultiplier * (1.0f - LoadR8Unorm(P.spec.confidence, px, py)));
+            float r = Sat(specConfidenceDrivenRelaxation * c.shared.gConfidenceDrivenNormalEdgeStoppingRelaxation);
+            diffuseLobeAngleFractionForSimplifiedSpecularNormalWeight = Lerp(diffuseLobeAngleFraction, 1.0f, r);
+            specularLobeAngleFraction = Lerp(specularLobeAngleFraction, 1.0f, r);
+            r = Sat(specConfidenceDrivenRelaxation * c.shared.gConfidenceDrivenLuminanceEdgeStoppingRelaxation);
+            sp.luminanceWeightRelaxation *= 1.0f - r;
+        }
+        sp.normalWeightParamSimplified = GetNormalWeightParam2(1.0f, diffuseLobeAngleFractionForSimplifiedSpecularNormalWeight);
+        sp.normalWeightParams = GetNormalWeightParams_ATrous(centerRoughness, historyLength, specularReprojectionConfidence, c.shared.gNormalEdgeStoppingRelaxation, specularLobeAngleFraction,
+            c.shared.gSpecLobeAngleSlack);
+
+        sumSpecular = centerSpecular * F4(sumWSpecular, sumWSpecular, sumWSpecular, sumWSpecular * sumWSpecular);
+        if (SH) {
+            const float4 centerSpecularSH = LoadRGBA16F(P.spec.inSh, px, py);
+            sumSpecularSH = centerSpecularSH * sumWSpecular;
+            roughnessModified = centerSpecularSH.w;
+        }
+    }
+
+    DiffParams dp = {};
+    dp.luminanceWeightRelaxation = 1.0f;
+    float4 sumDiffuse = F4(0.0f), sumDiffuseSH = F4(0.0f);
+    float sumWDiffuse = 0.44198f * 0.44198f;
+    if (DIFF) {
+        const float4 centerDiffuse = LoadRGBA16F(P.diff.in, px, py);
+        dp.centerLuminance = Luminance(Xyz(centerDiffuse));
+        const float centerDiffuseVar = centerDiffuse.w;
+        dp.phiLIlluminationInv = 1.0f / Max(1.0e-4f, c.shared.gDiffPhiLuminance * Sqrt(centerDiffuseVar));
+        if (c.shared.gHasHistoryConfidence) {
+            float diffConfidenceDrivenRelaxation = Sat(c.shared.gConfidenceDrivenRelaxationMultiplier * (1.0f - LoadR8Unorm(P.diff.confidence, px, py)));
+            float r = Sat(diffConfidenceDrivenRelaxation * c.shared.gConfidenceDrivenNormalEdgeStoppingRelaxation);
+            diffuseLobeAngleFraction = Lerp(diffuseLobeAngleFraction, 1.0f, r);
+            r = Sat(diffConfidenceDrivenRelaxation * c.shared.gConfidenceDrivenLuminanceEdgeStoppingRelaxation);
+            dp.luminanceWeightRelaxation = 1.0f - r;
+        }
+        dp.normalWeightParam = GetNormalWeightParam2(1.0f, diffuseLobeAngleFraction);
+        sumDiffuse = centerDiffuse * F4(sumWDiffuse, sumWDiffuse, sumWDiffuse, sumWDiffuse * sumWDiffuse);
+        if (SH)
+            sumDiffuseSH = LoadRGBA16F(P.diff.inSh, px, py) * sumWDiffuse;
+    }
+
+    const float3 centerWorldPos = GetCurrentWorldPosFromPixelPos(c, px, py, centerViewZ);
+    const float3 centerV = -Normalize(centerWorldPos);
+    const float depthThreshold = c.shared.gDepthThreshold * centerViewZ;
+
+    // random offsets against ringing at large steps
+    int offx = 0, offy = 0;
+    if (c.gStepSize > 4) {
+        RngHash rng;
+        rng.Initialize((uint32_t)px, (uint32_t)py, c.shared.gFrameIndex);
+        float2 rnd = rng.GetFloat2();
+        offx = (int)(float(c.gStepSize) * 0.5f * (rnd.x - 0.5f));
+        offy = (int)(float(c.gStepSize) * 0.5f * (rnd.y - 0.5f));
+    }
+
+#pragma unroll
+    for (int yy = -1; yy <= 1; yy++)
+#pragma unroll
+        for (int xx = -1; xx <= 1; xx++) {
+            if (xx == 0 && yy == 0)
+                continue;
+            const int qx = px + offx + xx * stepSize, qy = py + offy + yy * stepSize;
+            const bool isInside = qx >= 0 && qy >= 0 && qx < rectW && qy < rectH;
+            const float kernelW = (xx == 0 ? 0.44198f : 0.27901f) * (yy == 0 ? 0.44198f : 0.27901f);
+
+            float sampleMaterialID;
+            const float4 sampleNormalRoughness = UnpackNormalAndRoughness(LoadR10G10B10A2OrZero(P.normalRoughness, qx, qy), sampleMaterialID);
+            const float3 sampleNormal = Xyz(sampleNormalRoughness);
+            const float sampleRoughness = sampleNormalRoughness.w;
+            const float sampleViewZ = RelaxUnpackViewZ(c, LoadR32FOrZero(P.viewZ, qx, qy));
+            const float3 sampleWorldPos = GetCurrentWorldPosFromPixelPos(c, qx, qy, sampleViewZ);
+
+            float geometryW = GetPlaneDistanceWeight_Atrous(centerWorldPos, centerNormal, sampleWorldPos, depthThreshold);
+            geometryW *= kernelW;
+            geometryW *= Cmp(isInside && sampleViewZ < c.shared.gDenoisingRange);
+
+            if (SPEC) {
+                float3 sampleV = -Normalize(sampleWorldPos + c.shared.gRoughnessEdgeStoppingRelaxation * centerWorldPos);
+                float angles = AcosApprox(Dot(centerNormal, sampleNormal));
+                float normalWSpecularSimplified = ComputeWeight(angles, sp.normalWeightParamSimplified, 0.0f);
+                float normalWSpecular = GetSpecularNormalWeight_ATrous(sp.normalWeightParams, centerNormal, sampleNormal, centerV, sampleV);
+                float roughnessWSpecular = ComputeWeight(sampleRoughness, sp.roughnessWeightParams.x, sp.roughnessWeightParams.y);
+
+                float wSpecular = geometryW * (c.shared.gRoughnessEdgeStoppingEnabled ? (normalWSpecular * roughnessWSpecular) : normalWSpecularSimplified);
+                wSpecular *= Cmp(CompareMaterials(sampleMaterialID, centerMaterialID, c.shared.gSpecMinMaterial));
+                if (wSpecular > 1e-4f) {
+                    float4 sampleSpecular = LoadRGBA16FOrZero(P.spec.in, qx, qy);
+                    float sampleSpecularLuminance = Luminance(Xyz(sampleSpecular));
+                    float specularLuminanceW = Abs(sp.centerLuminance - sampleSpecularLuminance) * sp.phiLIlluminationInv;
+                    specularLuminanceW = Min(c.shared.gSpecMaxLuminanceRelativeDifference, specularLuminanceW);
+                    specularLuminanceW *= sp.luminanceWeightRelaxation;
+                    wSpecular *= Exp(-specularLuminanceW);
+
+                    sumWSpecular += wSpecular;
+                    sumSpecular = sumSpecular + F4(wSpecular, wSpecular, wSpecular, wSpecular * wSpecular) * sampleSpecular;
+                    if (SH)
+                        sumSpecularSH = sumSpecularSH + LoadRGBA16FOrZero(P.spec.inSh, qx, qy) * wSpecular;
+                }
+            }
+            if (DIFF) {
+                float angled = AcosApprox(Dot(centerNormal, sampleNormal));
+                float normalWDiffuse = ComputeWeight(angled, dp.normalWeightParam, 0.0f);
+                float wDiffuse = geometryW * normalWDiffuse;
+                wDiffuse *= Cmp(CompareMaterials(sampleMaterialID, centerMaterialID, c.shared.gDiffMinMaterial));
+                if (wDiffuse > 1e-4f) {
+                    float4 sampleDiffuse = LoadRGBA16FOrZero(P.diff.in, qx, qy);
+                    float sampleDiffuseLuminance = Luminance(Xyz(sampleDiffuse));
+                    float diffuseLuminanceW = Abs(dp.centerLuminance - sampleDiffuseLuminance) * dp.phiLIlluminationInv;
+                    diffuseLuminanceW = Min(c.shared.gDiffMaxLuminanceRelativeDifference, diffuseLuminanceW);
+                    diffuseLuminanceW *= dp.luminanceWeightRelaxation;
+                    wDiffuse *= Exp(-diffuseLuminanceW);
+
+                    sumWDiffuse += wDiffuse;
+                    sumDiffuse = sumDiffuse + F4(wDiffuse, wDiffuse, wDiffuse, wDiffuse * wDiffuse) * sampleDiffuse;
+                    if (SH)
+                        sumDiffuseSH = sumDiffuseSH + LoadRGBA16FOrZero(P.diff.inSh, qx, qy) * wDiffuse;
+                }
+            }
+        }
+
+    if (SPEC) {
+        float4 filtered = sumSpecular / F4(sumWSpecular, sumWSpecular, sumWSpecular, sumWSpecular * sumWSpecular);
+        if (SH) {
+            if (c.gIsLastPass == 1)
+                filtered = F4(LinearToYCoCg(Xyz(filtered)), filtered.w);
+            StoreRGBA16F(P.spec.outSh, px, py, F4(Xyz(sumSpecularSH) / sumWSpecular, roughnessModified));
+        }
+        StoreRGBA16F(P.spec.out, px, py, filtered);
+    }
+    if (DIFF) {
+        float4 filtered = sumDiffuse / F4(sumWDiffuse, sumWDiffuse, sumWDiffuse, sumWDiffuse * sumWDiffuse);
+        if (SH) {
+            if (c.gIsLastPass == 1)
+                filtered = F4(LinearToYCoCg(Xyz(filtered)), filtered.w);
+            StoreRGBA16F(P.diff.outSh, px, py, sumDiffuseSH / sumWDiffuse);
+        }
+        StoreRGBA16F(P.diff.out, px, py, filtered);
+    }
+}
+
+template <bool DIFF, bool SPEC, bool SH>
+const char* LaunchAtrous(const PassArgs& a) {
+    if (const char* e = CheckSupportedRelax(a))
+        return e;
+    if (a.constantsSize < sizeof(RelaxCB))
+        return "RELAX Atrous: constant block too small";
+    AtrousPlanes P = {};
+    if (!BindAtrous<DIFF, SPEC, SH, false>(a, P))
+        return "RELAX Atrous: unexpected resource count";
+    RelaxCB c = LoadRelaxConstants(a);
+    RowGrid g = GridForRows(c.shared.gRectSize.x, c.shared.gRectSize.y, TILE_X, TILE_Y, a.rowBegin, a.rowEnd);
+    hipLaunchKernelGGL((RelaxAtrousKernel<DIFF, SPEC, SH>), g.grid, dim3(256), 0, a.stream, P, c, RowRange{g.firstBlockY, g.rowBegin, g.rowEnd});
+    return nullptr;
+}
+
+} // namespace
+
+#define RELAX_ATROUS_VARIANT(name, D, S, H)                           \
+    {"RELAX_" name "_AtrousSmem.cs", LaunchAtrousSmem<D, S, H>},     \
+    {"RELAX_" name "_Atrous.cs", LaunchAtrous<D, S, H>}
+
+const PassEntry* GetRelaxAtrousPasses(uint32_t& num) {
+    static const PassEntry k[] = {
+        RELAX_ATROUS_VARIANT("Diffuse", true, false, false),
+        RELAX_ATROUS_VARIANT("DiffuseSh", true, false, true),
+        RELAX_ATROUS_VARIANT("Specular", false, true, false),
+        RELAX_ATROUS_VARIANT("SpecularSh", false, true, true),
+        RELAX_ATROUS_VARIANT("DiffuseSpecular", true, true, false),
+        RELAX_ATROUS_VARIANT("DiffuseSpecularSh", true, true, true),
+    };
+    num = sizeof(k) / sizeof(k[0]);
+    return k;
+}
+
+} // namespace nrdhip

@@ -1,0 +1,462 @@
+// RELAX per-pixel passes as HIP kernels for gfx950: ClassifyTiles, PrePass, HistoryFix, SplitScreen.
+//   ClassifyTiles   reference Shaders/Source/RELAX_ClassifyTiles.cs.hlsl:19-53
+//   PrePass         reference Shaders/Include/RELAX_PrePass.hlsli:13-346
+//   HistoryFix      reference Shaders/Include/RELAX_HistoryFix.hlsli:11-160
+//   SplitScreen     reference Shaders/Include/RELAX_SplitScreen.hlsli:10-52
+//
+// MI355X mapping. PrePass is a sparse gather (8 Poisson taps per signal at radii up to 30-50 px) and HistoryFix a sparse
+// 5x5 cross-bilateral with strides up to 14 px that only runs on freshly disoccluded pixels: neither has a stencil an LDS
+// tile could cover, so taps are served by L2 / Infinity Cache. 32x8-pixel workgroups keep the centre accesses of a wave
+// in two 256-byte RGBA16F row segments; the 704-byte constant block travels as a kernel argument (scalar loads); sky
+// tiles leave before touching a signal plane. All variants (diffuse / specular / both, +-SH) come from one template.
+// ClassifyTiles is one wave per 16x16 tile with a wave-wide vote, no LDS and no atomics.
+#include "relax_device.h"
+
+namespace nrdhip {
+
+namespace {
+
+constexpr int TILE_X = RELAX_TILE_X;
+constexpr int TILE_Y = RELAX_TILE_Y;
+
+__device__ __constant__ const float g_Poisson8[8][3] = { // reference Shaders/Include/Poisson.hlsli:40-50
+    {-0.4706069f, -0.4427112f, +0.6461146f}, {-0.9057375f, +0.3003471f, +0.9542373f}, {-0.3487388f, +0.4037880f, +0.5335386f}, {+0.1023042f, +0.6439373f, +0.6520134f},
+    {+0.5699277f, +0.3513750f, +0.6695386f}, {+0.2939128f, -0.1131226f, +0.3149309f}, {+0.7836658f, -0.4208784f, +0.8895339f}, {+0.1564120f, -0.8198990f, +0.8346850f}};
+
+// ================================================================================================ ClassifyTiles
+__global__ __launch_bounds__(256) void RelaxClassifyTilesKernel(Plane viewZ, Plane tiles, float denoisingRange) {
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int tileIndex = blockIdx.x * 4 + wave;
+    if (tileIndex >= tiles.w * tiles.h)
+        return;
+    const int tx = tileIndex % tiles.w, ty = tileIndex / tiles.w;
+    const int x = tx * 16 + (lane & 3) * 4, y = ty * 16 + (lane >> 2);
+
+    bool allSky = true;
+    if (y < viewZ.h && x + 3 < viewZ.w) {
+        float4 z = *(const float4*)TexelPtr<const float>(viewZ, x, y); // tile rows are 64-byte aligned
+        allSky = Abs(z.x) > denoisingRange && Abs(z.y) > denoisingRange && Abs(z.z) > denoisingRange && Abs(z.w) > denoisingRange;
+    } else {
+        for (int i = 0; i < 4; i++)
+            allSky = allSky && Abs(LoadR32FOrZero(viewZ, x + i, y)) > denoisingRange; // out-of-bounds load = 0: a partial edge tile is never sky
+    }
+    bool tileIsSky = __all(allSky);
+    if (lane == 0)
+        StoreR8Unorm(tiles, tx, ty, tileIsSky ? 1.0f : 0.0f);
+}
+
+const char* LaunchClassifyTiles(const PassArgs& a) {
+    if (const char* e = CheckSupportedRelax(a))
+        return e;
+    const nrdc::RelaxConstants& c = *(const nrdc::RelaxConstants*)a.constants;
+    const Plane& tiles = a.planes[1];
+    int numTiles = tiles.w * tiles.h;
+    hipLaunchKernelGGL(RelaxClassifyTilesKernel, dim3((numTiles + 3) / 4), dim3(256), 0, a.stream, a.planes[0], tiles, c.gDenoisingRange);
+    return nullptr;
+}
+
+// ================================================================================================ PrePass
+struct PrePassPlanes {
+    Plane tiles, normalRoughness, viewZ;
+    SignalPlanes spec, diff;
+};
+
+struct PrePassTap {
+    float2 uv;
+    int2 texel; // nearest texel of the guides (and of the signal: same size, no checkerboard)
+};
+
+NRD_D PrePassTap MakeTap(const RelaxCB& c, const Plane& guide, float2 pixelUv, float2 rectSize, float4 rotator, int i, float blurRadius) {
+    PrePassTap t;
+    float2 uv = pixelUv * rectSize + RotateVector(rotator, F2(g_Poisson8[i][0], g_Poisson8[i][1])) * blurRadius;
+    uv = Floor(uv) + 0.5f;
+    uv = uv * ToF2(c.shared.gRectSizeInv); // ApplyCheckerboardShift is the identity without checkerboarding
+    float2 uvScaled = RelaxClampUvToViewport(c, uv);
+    t.uv = uv;
+    t.texel = NearestTexel(guide, uvScaled + ToF2(c.shared.gRectOffset));
+    return t;
+}
+
+template <bool DIFF, bool SPEC, bool SH>
+__global__ __launch_bounds__(256) void RelaxPrePassKernel(PrePassPlanes P, RelaxCB c, RowRange rows) {
+    const int blockY = blockIdx.y + rows.firstBlockY;
+    const int px = blockIdx.x * TILE_X + (threadIdx.x & 31), py = blockY * TILE_Y + (threadIdx.x >> 5);
+    const int rectW = c.shared.gRectSize.x, rectH = c.shared.gRectSize.y;
+    if (px >= rectW || py >= rectH || py < rows.rowBegin || py >= rows.rowEnd)
+        return;
+    if (LoadR8Unorm(P.tiles, px >> 4, py >> 4) != 0.0f)
+        return;
+    float centerViewZ = RelaxUnpackViewZ(c, LoadR32F(P.viewZ, px, py));
+    if (centerViewZ > c.shared.gDenoisingRange)
+        return;
+
+    float centerMaterialID;
+    float4 centerNormalRoughness = UnpackNormalAndRoughness(LoadR10G10B10A2(P.normalRoughness, px, py), centerMaterialID);
+    float3 centerNormal = Xyz(centerNormalRoughness);
+    float centerRoughness = centerNormalRoughness.w;
+    float3 centerWorldPos = GetCurrentWorldPosFromPixelPos(c, px, py, centerViewZ);
+    const float4 rotator = ToF4(c.shared.gRotatorPre);
+    const float2 rectSize = F2(float(rectW), float(rectH));
+    const float2 pixelUv = F2(float(px) + 0.5f, float(py) + 0.5f) * ToF2(c.shared.gRectSizeInv);
+    const float minRectDim = float(rectW < rectH ? rectW : rectH);
+
+    if (DIFF) {
+        float4 diffuseIllumination = LoadRGBA16F(P.diff.in, px, py);
+        float4 diffuseSH = SH ? LoadRGBA16F(P.diff.inSh, px, py) : F4(0.0f);
+
+        if (c.shared.gDiffBlurRadius > 0.0f) {
+            float frustumSize = PixelRadiusToWorld(c.shared.gUnproject, c.shared.gOrthoMode, minRectDim, centerViewZ);
+            float hitDist = diffuseIllumination.w == 0.0f ? 1.0f : diffuseIllumination.w;
+            float hitDistFactor = GetHitDistFactor(hitDist, frustumSize);
+            float blurRadius = c.shared.gDiffBlurRadius * hitDistFactor;
+            if (diffuseIllumination.w == 0.0f)
+                blurRadius = Max(blurRadius, 1.0f);
+
+            float normalWeightParam = GetNormalWeightParam2(1.0f, 0.25f * c.shared.gLobeAngleFraction);
+            float2 hitDistanceWeightParams = GetHitDistanceWeightParams(diffuseIllumination.w, 1.0f / 9.0f);
+            float weightSum = 1.0f;
+
+#pragma unroll 2
+            for (int i = 0; i < 8; i++) {
+                PrePassTap t = MakeTap(c, P.viewZ, pixelUv, rectSize, rotator, i, blurRadius);
+
+                float sampleMaterialID;
+                float3 sampleNormal = Xyz(UnpackNormalAndRoughness(LoadR10G10B10A2(P.normalRoughness, t.texel.x, t.texel.y), sampleMaterialID));
+                float sampleViewZ = RelaxUnpackViewZ(c, LoadR32F(P.viewZ, t.texel.x, t.texel.y));
+                float3 sampleWorldPos = GetCurrentWorldPosFromClipSpaceXY(c, t.uv * 2.0f - 1.0f, sampleViewZ);
+
+                float sampleWeight = IsInScreenNearest(t.uv);
+                sampleWeight *= Cmp(sampleViewZ < c.shared.gDenoisingRange);
+                sampleWeight *= Cmp(CompareMaterials(centerMaterialID, sampleMaterialID, c.shared.gDiffMinMaterial));
+                sampleWeight *= GetPlaneDistanceWeight(centerWorldPos, centerNormal, centerViewZ, sampleWorldPos, c.shared.gDepthThreshold);
+                float angle = AcosApprox(Dot(centerNormal, sampleNormal));
+                sampleWeight *= ComputeWeight(angle, normalWeightParam, 0.0f);
+
+                float4 sampleDiffuseIllumination = Denanify(sampleWeight, LoadRGBA16F(P.diff.in, t.texel.x, t.texel.y));
+                sampleWeight *= Lerp(c.shared.gMinHitDistanceWeight, 1.0f, ComputeExponentialWeight(sampleDiffuseIllumination.w, hitDistanceWeightParams.x, hitDistanceWeightParams.y));
+                sampleWeight *= GetGaussianWeight(g_Poisson8[i][2]);
+
+                weightSum += sampleWeight;
+                diffuseIllumination = diffuseIllumination + sampleDiffuseIllumination * sampleWeight;
+                if (SH) {
+                    float4 sampleDiffuseSH = Denanify(sampleWeight, LoadRGBA16F(P.diff.inSh, t.texel.x, t.texel.y));
+                    diffuseSH = diffuseSH + sampleDiffuseSH * sampleWeight;
+                }
+            }
+            diffuseIllumination = diffuseIllumination / weightSum;
+            if (SH)
+                diffuseSH = diffuseSH / weightSum;
+        }
+        StoreRGBA16F(P.diff.out, px, py, Clamp4(diffuseIllumination, 0.0f, NRD_FP16_MAX));
+        if (SH)
+            StoreRGBA16F(P.diff.outSh, px, py, Clamp4(diffuseSH, -NRD_FP16_MAX, NRD_FP16_MAX));
+    }
+
+    if (SPEC) {
+        float4 specularIllumination = LoadRGBA16F(P.spec.in, px, py);
+        float4 specularSH = SH ? LoadRGBA16F(P.spec.inSh, px, py) : F4(0.0f);
+        specularIllumination.w = Max(0.0f, Min(c.shared.gDenoisingRange, specularIllumination.w));
+
+        if (c.shared.gSpecBlurRadius > 0.0f) {
+            float3 viewVector = Normalize(-centerWorldPos);
+            float4 D = GetSpecularDominantDirection(centerNormal, viewVector, centerRoughness);
+            float NoD = Abs(Dot(centerNormal, Xyz(D)));
+
+            float frustumSize = PixelRadiusToWorld(c.shared.gUnproject, c.shared.gOrthoMode, minRectDim, centerViewZ);
+            float hitDist = specularIllumination.w == 0.0f ? 1.0f : specularIllumination.w;
+            float hitDistFactor = GetHitDistFactor(hitDist * NoD, frustumSize);
+
+            float smc = GetSpecMagicCurve(centerRoughness);
+            float blurRadius = c.shared.gSpecBlurRadius * hitDistFactor * smc;
+            float lobeTanHalfAngle = GetSpecularLobeTanHalfAngle(centerRoughness, 0.75f);
+            float lobeRadius = hitDist * NoD * lobeTanHalfAngle;
+            float minBlurRadius = lobeRadius / PixelRadiusToWorld(c.shared.gUnproject, c.shared.gOrthoMode, 1.0f, centerViewZ + hitDist * D.w);
+            blurRadius = Min(blurRadius, minBlurRadius);
+            if (specularIllumination.w == 0.0f)
+                blurRadius = Max(blurRadius, 1.0f);
+
+            float normalWeightParam = GetNormalWeightParam2(centerRoughness, 0.5f * c.shared.gLobeAngleFraction);
+            float2 hitDistanceWeightParams = GetHitDistanceWeightParams(specularIllumination.w, 1.0f / 9.0f, centerRoughness);
+            float2 roughnessWeightParams = GetRoughnessWeightParams(centerRoughness, c.shared.gRoughnessFraction);
+
+            float specMinHitDistanceWeight = specularIllumination.w == 0.0f ? 1.0f : c.shared.gMinHitDistanceWeight * smc;
+            float specularHitT = specularIllumination.w == 0.0f ? c.shared.gDenoisingRange : specularIllumination.w;
+            float minHitT = specularHitT == 0.0f ? NRD_INF : specularHitT;
+            float weightSum = 1.0f;
+            float3 rgb = Xyz(specularIllumination);
+            const float roughnessRelax = LinearStep(0.5f, 1.0f, centerRoughness);
+
+#pragma unroll 2
+            for (int i = 0; i < 8; i++) {
+                PrePassTap t = MakeTap(c, P.viewZ, pixelUv, rectSize, rotator, i, blurRadius);
+
+                float sampleMaterialID;
+                float4 sampleNormalRoughness = UnpackNormalAndRoughness(LoadR10G10B10A2(P.normalRoughness, t.texel.x, t.texel.y), sampleMaterialID);
+                float3 sampleNormal = Xyz(sampleNormalRoughness);
+                float sampleRoughness = sampleNormalRoughness.w;
+                float sampleViewZ = RelaxUnpackViewZ(c, LoadR32F(P.viewZ, t.texel.x, t.texel.y));
+
+                float sampleWeight = IsInScreenNearest(t.uv);
+                sampleWeight *= Cmp(sampleViewZ < c.shared.gDenoisingRange);
+                sampleWeight *= Cmp(CompareMaterials(centerMaterialID, sampleMaterialID, c.shared.gSpecMinMaterial));
+                sampleWeight *= ComputeWeight(sampleRoughness, roughnessWeightParams.x, roughnessWeightParams.y);
+                float angle = AcosApprox(Dot(centerNormal, sampleNormal));
+                sampleWeight *= ComputeWeight(angle, normalWeightParam, 0.0f);
+
+                float3 sampleWorldPos = GetCurrentWorldPosFromClipSpaceXY(c, t.uv * 2.0f - 1.0f, sampleViewZ);
+                sampleWeight *= GetPlaneDistanceWeight(centerWorldPos, centerNormal, centerViewZ, sampleWorldPos, c.shared.gDepthThreshold);
+
+                float4 sampleSpecularIllumination = Denanify(sampleWeight, LoadRGBA16F(P.spec.in, t.texel.x, t.texel.y));
+                sampleWeight *= Lerp(specMinHitDistanceWeight, 1.0f, ComputeExponentialWeight(sampleSpecularIllumination.w, hitDistanceWeightParams.x, hitDistanceWeightParams.y));
+                sampleWeight *= GetGaussianWeight(g_Poisson8[i][2]);
+
+                float d = Length(sampleWorldPos - centerWorldPos);
+                float h = sampleSpecularIllumination.w;
+                float tt = h / (specularIllumination.w + d);
+                sampleWeight *= Lerp(Sat(tt), 1.0f, roughnessRelax);
+
+                weightSum += sampleWeight;
+                rgb = rgb + Xyz(sampleSpecularIllumination) * sampleWeight;
+                if (SH) {
+                    float4 sampleSpecularSH = Denanify(sampleWeight, LoadRGBA16F(P.spec.inSh, t.texel.x, t.texel.y));
+                    specularSH = specularSH + sampleSpecularSH * sampleWeight;
+                }
+                if (sampleWeight != 0.0f)
+                    minHitT = Min(minHitT, sampleSpecularIllumination.w == 0.0f ? NRD_INF : sampleSpecularIllumination.w);
+            }
+            rgb = rgb / weightSum;
+            specularIllumination = F4(rgb, minHitT == NRD_INF ? 0.0f : minHitT);
+            if (SH)
+                specularSH = specularSH / weightSum;
+        }
+        StoreRGBA16F(P.spec.out, px, py, Clamp4(specularIllumination, 0.0f, NRD_FP16_MAX));
+        if (SH)
+            StoreRGBA16F(P.spec.outSh, px, py, Clamp4(specularSH, -NRD_FP16_MAX, NRD_FP16_MAX));
+    }
+}
+
+template <bool DIFF, bool SPEC, bool SH>
+const char* LaunchPrePass(const PassArgs& a) {
+    if (const char* e = CheckSupportedRelax(a))
+        return e;
+    PlaneCursor cur(a);
+    PrePassPlanes P = {};
+    P.tiles = cur.next();
+    if (SPEC) P.spec.in = cur.next();
+    if (DIFF) P.diff.in = cur.next();
+    P.normalRoughness = cur.next();
+    P.viewZ = cur.next();
+    if (SH && SPEC) P.spec.inSh = cur.next();
+    if (SH && DIFF) P.diff.inSh = cur.next();
+    if (SPEC) P.spec.out = cur.next();
+    if (DIFF) P.diff.out = cur.next();
+    if (SH && SPEC) P.spec.outSh = cur.next();
+    if (SH && DIFF) P.diff.outSh = cur.next();
+    if (!cur.complete())
+        return "RELAX PrePass: unexpected resource count";
+    RelaxCB c = LoadRelaxConstants(a);
+    RowGrid g = GridForRows(c.shared.gRectSize.x, c.shared.gRectSize.y, TILE_X, TILE_Y, a.rowBegin, a.rowEnd);
+    hipLaunchKernelGGL((RelaxPrePassKernel<DIFF, SPEC, SH>), g.grid, dim3(256), 0, a.stream, P, c, RowRange{g.firstBlockY, g.rowBegin, g.rowEnd});
+    return nullptr;
+}
+
+// ================================================================================================ HistoryFix
+struct HistoryFixPlanes {
+    Plane tiles, historyLength, normalRoughness, viewZ;
+    SignalPlanes spec, diff;
+};
+
+template <bool DIFF, bool SPEC, bool SH>
+__global__ __launch_bounds__(256) void RelaxHistoryFixKernel(HistoryFixPlanes P, RelaxCB c, RowRange rows) {
+    const int blockY = blockIdx.y + rows.firstBlockY;
+    const int px = blockIdx.x * TILE_X + (threadIdx.x & 31), py = blockY * TILE_Y + (threadIdx.x >> 5);
+    const int rectW = c.shared.gRectSize.x, rectH = c.shared.gRectSize.y;
+    if (px >= rectW || py >= rectH || py < rows.rowBegin || py >= rows.rowEnd)
+        return;
+    if (LoadR8Unorm(P.tiles, px >> 4, py >> 4) != 0.0f)
+        return;
+    float centerViewZ = RelaxUnpackViewZ(c, LoadR32F(P.viewZ, px, py));
+    float historyLength = 255.0f * LoadR8Unorm(P.historyLength, px, py);
+    if (centerViewZ > c.shared.gDenoisingRange || (historyLength > c.shared.gHistoryFixFrameNum || c.shared.gHistoryFixFrameNum == 1.0f))
+        return;
+
+    float centerMaterialID;
+    float4 centerNormalRoughness = UnpackNormalAndRoughness(LoadR10G10B10A2(P.normalRoughness, px, py), centerMaterialID);
+    float3 centerNormal = Xyz(centerNormalRoughness);
+    float centerRoughness = centerNormalRoughness.w;
+    float3 centerWorldPos = GetCurrentWorldPosFromPixelPos(c, px, py, centerViewZ);
+    float3 centerV = -Normalize(centerWorldPos);
+    float depthThreshold = c.shared.gDepthThreshold * centerViewZ;
+
+    float4 diffuseSum = DIFF ? LoadRGBA16F(P.diff.in, px, py) : F4(0.0f);
+    float4 diffuseSumSH = (DIFF && SH) ? LoadRGBA16F(P.diff.inSh, px, py) : F4(0.0f);
+    float diffuseWSum = 1.0f;
+    float4 specularSum = SPEC ? LoadRGBA16F(P.spec.in, px, py) : F4(0.0f);
+    float4 specularSumSH = (SPEC && SH) ? LoadRGBA16F(P.spec.inSh, px, py) : F4(0.0f);
+    float roughnessModified = specularSumSH.w;
+    float specularWSum = 1.0f;
+    float2 specularNormalWeightParams = SPEC ? GetNormalWeightParams_ATrous(centerRoughness, 5.0f, 1.0f, 0.0f, c.shared.gLobeAngleFraction, c.shared.gSpecLobeAngleSlack) : F2(0.0f, 0.0f);
+    const float normalPower = Max(c.shared.gHistoryFixEdgeStoppingNormalPower, 0.01f);
+
+    float r = c.shared.gHistoryFixBasePixelStride / (1.0f + historyLength);
+    r = floorf(r + 0.5f);
+
+    for (int j = -2; j <= 2; j++)
+        for (int i = -2; i <= 2; i++) {
+            int dx = (int)(float(i) * r), dy = (int)(float(j) * r);
+            int sx = px + dx, sy = py + dy;
+            bool isInside = sx >= 0 && sy >= 0 && sx < rectW && sy < rectH;
+            if (i == 0 && j == 0)
+                continue;
+
+            float sampleMaterialID;
+            float3 sampleNormal = Xyz(UnpackNormalAndRoughness(LoadR10G10B10A2OrZero(P.normalRoughness, sx, sy), sampleMaterialID));
+            float sampleViewZ = RelaxUnpackViewZ(c, LoadR32FOrZero(P.viewZ, sx, sy));
+            float3 sampleWorldPos = GetCurrentWorldPosFromPixelPos(c, sx, sy, sampleViewZ);
+            float geometryWeight = GetPlaneDistanceWeight_Atrous(centerWorldPos, centerNormal, sampleWorldPos, depthThreshold);
+
+            if (DIFF) {
+                float diffuseW = geometryWeight;
+                diffuseW *= Pow(Max(0.01f, Dot(centerNormal, sampleNormal)), normalPower);
+                diffuseW = isInside ? diffuseW : 0.0f;
+                diffuseW *= Cmp(CompareMaterials(sampleMaterialID, centerMaterialID, c.shared.gDiffMinMaterial));
+                if (diffuseW > 1e-4f) {
+                    diffuseSum = diffuseSum + LoadRGBA16FOrZero(P.diff.in, sx, sy) * diffuseW;
+                    if (SH)
+                        diffuseSumSH = diffuseSumSH + LoadRGBA16FOrZero(P.diff.inSh, sx, sy) * diffuseW;
+                    diffuseWSum += diffuseW;
+                }
+            }
+            if (SPEC) {
+                float3 sampleV = -Normalize(sampleWorldPos + c.shared.gRoughnessEdgeStoppingRelaxation * centerWorldPos);
+                float specularW = geometryWeight;
+                specularW *= GetSpecularNormalWeight_ATrous(specularNormalWeightParams, centerNormal, sampleNormal, centerV, sampleV);
+                specularW = isInside ? specularW : 0.0f;
+                specularW *= Cmp(CompareMaterials(sampleMaterialID, centerMaterialID, c.shared.gSpecMinMaterial));
+                if (specularW > 1e-4f) {
+                    specularSum = specularSum + LoadRGBA16FOrZero(P.spec.in, sx, sy) * specularW;
+                    if (SH)
+                        specularSumSH = specularSumSH + LoadRGBA16FOrZero(P.spec.inSh, sx, sy) * specularW;
+                    specularWSum += specularW;
+                }
+            }
+        }
+
+    if (DIFF) {
+        StoreRGBA16F(P.diff.out, px, py, diffuseSum / diffuseWSum);
+        if (SH)
+            StoreRGBA16F(P.diff.outSh, px, py, diffuseSumSH / diffuseWSum);
+    }
+    if (SPEC) {
+        StoreRGBA16F(P.spec.out, px, py, specularSum / specularWSum);
+        if (SH)
+            StoreRGBA16F(P.spec.outSh, px, py, F4(Xyz(specularSumSH) / specularWSum, roughnessModified));
+    }
+}
+
+template <bool DIFF, bool SPEC, bool SH>
+const char* LaunchHistoryFix(const PassArgs& a) {
+    if (const char* e = CheckSupportedRelax(a))
+        return e;
+    PlaneCursor cur(a);
+    HistoryFixPlanes P = {};
+    P.tiles = cur.next();
+    if (SPEC) P.spec.in = cur.next();
+    if (DIFF) P.diff.in = cur.next();
+    P.historyLength = cur.next();
+    P.normalRoughness = cur.next();
+    P.viewZ = cur.next();
+    if (SH && SPEC) P.spec.inSh = cur.next();
+    if (SH && DIFF) P.diff.inSh = cur.next();
+    if (SPEC) P.spec.out = cur.next();
+    if (DIFF) P.diff.out = cur.next();
+    if (SH && SPEC) P.spec.outSh = cur.next();
+    if (SH && DIFF) P.diff.outSh = cur.next();
+    if (!cur.complete())
+        return "RELAX HistoryFix: unexpected resource count";
+    RelaxCB c = LoadRelaxConstants(a);
+    RowGrid g = GridForRows(c.shared.gRectSize.x, c.shared.gRectSize.y, TILE_X, TILE_Y, a.rowBegin, a.rowEnd);
+    hipLaunchKernelGGL((RelaxHistoryFixKernel<DIFF, SPEC, SH>), g.grid, dim3(256), 0, a.stream, P, c, RowRange{g.firstBlockY, g.rowBegin, g.rowEnd});
+    return nullptr;
+}
+
+// ================================================================================================ SplitScreen
+struct SplitScreenPlanes {
+    Plane viewZ;
+    SignalPlanes spec, diff;
+};
+
+template <bool DIFF, bool SPEC, bool SH>
+__global__ __launch_bounds__(256) void RelaxSplitScreenKernel(SplitScreenPlanes P, RelaxCB c, RowRange rows) {
+    const int blockY = blockIdx.y + rows.firstBlockY;
+    const int px = blockIdx.x * TILE_X + (threadIdx.x & 31), py = blockY * TILE_Y + (threadIdx.x >> 5);
+    if (px >= c.shared.gRectSize.x || py >= c.shared.gRectSize.y || py < rows.rowBegin || py >= rows.rowEnd)
+        return;
+    float2 pixelUv = F2(float(px) + 0.5f, float(py) + 0.5f) * ToF2(c.shared.gRectSizeInv);
+    if (pixelUv.x > c.shared.gSplitScreen)
+        return;
+    float viewZ = RelaxUnpackViewZ(c, LoadR32F(P.viewZ, px, py));
+    float keep = Cmp(viewZ < c.shared.gDenoisingRange);
+    if (DIFF) {
+        float4 v = LoadRGBA16F(P.diff.in, px, py);
+        if (SH)
+            v = F4(LinearToYCoCg(Xyz(v)), v.w);
+        StoreRGBA16F(P.diff.out, px, py, v * keep);
+        if (SH)
+            StoreRGBA16F(P.diff.outSh, px, py, LoadRGBA16F(P.diff.inSh, px, py) * keep);
+    }
+    if (SPEC) {
+        float4 v = LoadRGBA16F(P.spec.in, px, py);
+        if (SH)
+            v = F4(LinearToYCoCg(Xyz(v)), v.w);
+        StoreRGBA16F(P.spec.out, px, py, v * keep);
+        if (SH)
+            StoreRGBA16F(P.spec.outSh, px, py, LoadRGBA16F(P.spec.inSh, px, py) * keep);
+    }
+}
+
+template <bool DIFF, bool SPEC, bool SH>
+const char* LaunchSplitScreen(const PassArgs& a) {
+    if (const char* e = CheckSupportedRelax(a))
+        return e;
+    PlaneCursor cur(a);
+    SplitScreenPlanes P = {};
+    P.viewZ = cur.next();
+    if (DIFF) P.diff.in = cur.next();
+    if (SPEC) P.spec.in = cur.next();
+    if (SH && DIFF) P.diff.inSh = cur.next();
+    if (SH && SPEC) P.spec.inSh = cur.next();
+    if (DIFF) P.diff.out = cur.next();
+    if (SPEC) P.spec.out = cur.next();
+    if (SH && DIFF) P.diff.outSh = cur.next();
+    if (SH && SPEC) P.spec.outSh = cur.next();
+    if (!cur.complete())
+        return "RELAX SplitScreen: unexpected resource count";
+    RelaxCB c = LoadRelaxConstants(a);
+    RowGrid g = GridForRows(c.shared.gRectSize.x, c.shared.gRectSize.y, TILE_X, TILE_Y, a.rowBegin, a.rowEnd);
+    hipLaunchKernelGGL((RelaxSplitScreenKernel<DIFF, SPEC, SH>), g.grid, dim3(256), 0, a.stream, P, c, RowRange{g.firstBlockY, g.rowBegin, g.rowEnd});
+    return nullptr;
+}
+
+} // namespace
+
+#define RELAX_SPATIAL_VARIANT(name, D, S, H)                            \
+    {"RELAX_" name "_PrePass.cs", LaunchPrePass<D, S, H>},             \
+    {"RELAX_" name "_HistoryFix.cs", LaunchHistoryFix<D, S, H>},       \
+    {"RELAX_" name "_SplitScreen.cs", LaunchSplitScreen<D, S, H>}
+
+const PassEntry* GetRelaxSpatialPasses(uint32_t& num) {
+    static const PassEntry k[] = {
+        {"RELAX_ClassifyTiles.cs", LaunchClassifyTiles},
+        RELAX_SPATIAL_VARIANT("Diffuse", true, false, false),
+        RELAX_SPATIAL_VARIANT("DiffuseSh", true, false, true),
+        RELAX_SPATIAL_VARIANT("Specular", false, true, false),
+        RELAX_SPATIAL_VARIANT("SpecularSh", false, true, true),
+        RELAX_SPATIAL_VARIANT("DiffuseSpecular", true, true, false),
+        RELAX_SPATIAL_VARIANT("DiffuseSpecularSh", true, true, true),
+    };
+    num = sizeof(k) / sizeof(k[0]);
+    return k;
+}
+
+} // namespace nrdhip

@@ -1,0 +1,806 @@
+// RELAX TemporalAccumulation and HistoryClamping as HIP kernels for gfx950.
+//   TemporalAccumulation   reference Shaders/Include/RELAX_TemporalAccumulation.hlsli:10-931
+//   HistoryClamping        reference Shaders/Include/RELAX_HistoryClamping.hlsli:10-330
+//
+// MI355X mapping.
+//   TemporalAccumulation: 32x8-pixel workgroups; a 34x10 LDS tile (halo 1) of (normal.xyz, specular hitT), decoded once
+//     per workgroup, feeds the 3x3 normal average / min-hitT and the curvature edges. The history reads are data-dependent
+//     gathers (12-tap footprint validation + Catmull-Rom as 5 bilinear fetches per RGBA16F history plane, surface AND
+//     virtual motion): they go through L2; consecutive lanes reproject to neighbouring texels, so a wave's gather still
+//     lands in a handful of 256-byte row segments.
+//   HistoryClamping: 36x12 LDS tiles (halo 2) of responsive history in YCoCg and of the noisy input + validity, one pair
+//     per signal, feed the 5x5 moments; everything else is per-pixel arithmetic.
+// LDS rows are padded to an odd float4 count (35 / 37) so the rows a wave touches start in different banks.
+#include "relax_device.h"
+
+namespace nrdhip {
+
+namespace {
+
+constexpr int TILE_X = RELAX_TILE_X;
+constexpr int TILE_Y = RELAX_TILE_Y;
+
+// ================================================================================================ TemporalAccumulation
+namespace ta {
+constexpr int BORDER = 1;
+constexpr int BUF_X = TILE_X + 2 * BORDER; // 34
+constexpr int BUF_Y = TILE_Y + 2 * BORDER; // 10
+constexpr int BUF_STRIDE = BUF_X + 1;      // 35
+} // namespace ta
+
+struct TaPlanes {
+    Plane tiles, mv, normalRoughness, viewZ, prevNormalRoughness, prevViewZ, prevSpecHitDist, prevHistoryLength, prevMaterialID, disocclusionThresholdMix;
+    Plane outSpecHitDist, outHistoryLength, outSpecReprojectionConfidence;
+    SignalPlanes spec, diff;
+};
+
+template <bool DIFF, bool SPEC, bool SH>
+__global__ __launch_bounds__(256) void RelaxTemporalAccumulationKernel(TaPlanes P, RelaxCB c, RowRange rows) {
+    __shared__ float4 s_NormalSpecHitT[ta::BUF_Y * ta::BUF_STRIDE];
+
+    const int blockY = blockIdx.y + rows.firstBlockY;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    const int px = blockIdx.x * TILE_X + tx, py = blockY * TILE_Y + ty;
+    const int rectW = c.shared.gRectSize.x, rectH = c.shared.gRectSize.y;
+
+    if (!RelaxBlockHasGeometry(P.tiles, blockY)) // uniform per workgroup
+        return;
+
+    // preload (normal, specular hitT) at rect-clamped coordinates
+    for (int idx = threadIdx.x; idx < ta::BUF_X * ta::BUF_Y; idx += 256) {
+        int lx = idx % ta::BUF_X, ly = idx / ta::BUF_X;
+        int gx = ClampI(blockIdx.x * TILE_X - ta::BORDER + lx, 0, rectW - 1), gy = ClampI(blockY * TILE_Y - ta::BORDER + ly, 0, rectH - 1);
+        float4 v = UnpackNormalAndRoughness(LoadR10G10B10A2(P.normalRoughness, gx, gy));
+        if (SPEC)
+            v.w = LoadRGBA16F(P.spec.in, gx, gy).w;
+        s_NormalSpecHitT[ly * ta::BUF_STRIDE + lx] = v;
+    }
+    __syncthreads();
+
+    if (px >= rectW || py >= rectH || py < rows.rowBegin || py >= rows.rowEnd)
+        return;
+    if (LoadR8Unorm(P.tiles, px >> 4, py >> 4) != 0.0f)
+        return;
+    const float currentLinearZ = RelaxUnpackViewZ(c, LoadR32F(P.viewZ, px, py));
+    if (currentLinearZ > c.shared.gDenoisingRange)
+        return;
+
+    auto Shared = [&](int dx, int dy) { return s_NormalSpecHitT[(ty + ta::BORDER + dy) * ta::BUF_STRIDE + (tx + ta::BORDER + dx)]; };
+
+    float currentMaterialID;
+    float4 currentNormalRoughness = UnpackNormalAndRoughness(LoadR10G10B10A2(P.normalRoughness, px, py), currentMaterialID);
+    const float3 currentNormal = Xyz(currentNormalRoughness);
+    const float currentRoughness = currentNormalRoughness.w;
+
+    const float3 currentWorldPos = GetCurrentWorldPosFromPixelPos(c, px, py, currentLinearZ);
+    const float3 currentViewVector = currentWorldPos;
+    const float3 V = -Normalize(currentViewVector);
+    const float NoV = Abs(Dot(currentNormal, V));
+
+    const float2 rectSize = F2(float(rectW), float(rectH));
+    const float2 rectSizeInv = ToF2(c.shared.gRectSizeInv);
+    const float2 rectSizePrev = ToF2(c.shared.gRectSizePrev);
+    const float3 cameraDelta = ToF3(c.shared.gCameraDelta);
+    const float2 resolutionScalePrev = rectSizePrev * ToF2(c.shared.gResourceSizeInvPrev);
+
+    // previous position
+    const float2 pixelUv = F2(float(px) + 0.5f, float(py) + 0.5f) * rectSizeInv;
+    float4 mvRaw = LoadRGBA16F(P.mv, px, py);
+    float3 mv = Xyz(mvRaw) * ToF3(c.shared.gMvScale);
+    float3 prevWorldPos = currentWorldPos;
+    float2 prevUVSMB = pixelUv + F2(mv.x, mv.y);
+    if (c.shared.gMvScale.w == 0.0f) {
+        if (c.shared.gMvScale.z == 0.0f)
+            mv.z = AffineTransform(c.shared.gWorldToViewPrev, currentWorldPos).z - currentLinearZ;
+        prevWorldPos = GetPreviousWorldPosFromClipSpaceXY(c, prevUVSMB * 2.0f - 1.0f, currentLinearZ + mv.z) + cameraDelta;
+    } else {
+        prevWorldPos = prevWorldPos + mv;
+        prevUVSMB = GetScreenUv(c.shared.gWorldToClipPrev, prevWorldPos);
+    }
+
+    // noisy inputs
+    const float3 diffuseIllumination = DIFF ? Xyz(LoadRGBA16F(P.diff.in, px, py)) : F3(0.0f);
+    const float4 diffuseSH = (DIFF && SH) ? LoadRGBA16F(P.diff.inSh, px, py) : F4(0.0f);
+    const float4 specularIllumination = SPEC ? LoadRGBA16F(P.spec.in, px, py) : F4(0.0f);
+    const float4 specularSH = (SPEC && SH) ? LoadRGBA16F(P.spec.inSh, px, py) : F4(0.0f);
+
+    // average normal and min hit distance in 3x3
+    float hitTM1 = Shared(0, 0).w;
+    float minHitDist3x3 = hitTM1 == 0.0f ? NRD_INF : hitTM1;
+    float3 currentNormalAveraged = currentNormal;
+#pragma unroll
+    for (int i = -1; i <= 1; i++)
+#pragma unroll
+        for (int j = -1; j <= 1; j++) {
+            if (i == 0 && j == 0)
+                continue;
+            float4 normalSpecHitT = Shared(i, j);
+            minHitDist3x3 = Min(minHitDist3x3, normalSpecHitT.w == 0.0f ? NRD_INF : normalSpecHitT.w);
+            currentNormalAveraged = currentNormalAveraged + Xyz(normalSpecHitT);
+        }
+    currentNormalAveraged = currentNormalAveraged / 9.0f;
+
+    const float currentRoughnessModified = SPEC ? GetModifiedRoughnessFromNormalVariance(currentRoughness, currentNormalAveraged) : 0.0f;
+
+    const float specular1stMoment = Luminance(Xyz(specularIllumination));
+    const float specular2ndMoment = specular1stMoment * specular1stMoment;
+    const float diffuse1stMoment = Luminance(diffuseIllumination);
+    const float diffuse2ndMoment = diffuse1stMoment * diffuse1stMoment;
+
+    // surface parallax
+    const float smbParallaxInPixels1 = ComputeParallaxInPixels(prevWorldPos + cameraDelta, prevUVSMB, c.shared.gWorldToClipPrev, rectSize);
+    const float smbParallaxInPixels2 = ComputeParallaxInPixels(prevWorldPos - cameraDelta, pixelUv, c.shared.gWorldToClip, rectSize);
+    const float smbParallaxInPixelsMax = Max(smbParallaxInPixels1, smbParallaxInPixels2);
+    const float smbParallaxInPixelsMin = Min(smbParallaxInPixels1, smbParallaxInPixels2);
+
+    const float pixelSize = PixelRadiusToWorld(c.shared.gUnproject, c.shared.gOrthoMode, 1.0f, currentLinearZ);
+
+    // disocclusion threshold
+    float disocclusionThresholdMix = 0.0f;
+    if (currentMaterialID == c.shared.gStrandMaterialID)
+        disocclusionThresholdMix = Sat(c.shared.gStrandThickness / pixelSize);
+    if (c.shared.gHasDisocclusionThresholdMix)
+        disocclusionThresholdMix = LoadR8Unorm(P.disocclusionThresholdMix, px, py);
+    const float disocclusionThreshold = Lerp(c.shared.gDisocclusionThreshold, c.shared.gDisocclusionThresholdAlternate, disocclusionThresholdMix);
+
+    // ---------------------------------------------------------------- surface motion based history
+    float footprintQuality, historyLength, SMBReprojectionFound;
+    float4 prevDiffuseIllumAnd2ndMomentSMB = F4(0.0f), prevDiffuseSH = F4(0.0f), prevDiffuseResponsiveSH = F4(0.0f);
+    float3 prevDiffuseResponsiveSMB = F3(0.0f);
+    float4 prevSpecularIllumAnd2ndMomentSMB = F4(0.0f), prevSpecularSMBSH = F4(0.0f), prevSpecularSMBResponsiveSH = F4(0.0f);
+    float3 prevSpecularResponsiveSMB = F3(0.0f);
+    float prevReflectionHitTSMB = 0.0f;
+    {
+        const float3 smbNormal = Normalize(currentNormalAveraged);
+        const float2 prevPixelPosFloat = prevUVSMB * rectSizePrev;
+        const float2 originF = Floor(prevPixelPosFloat - 0.5f);
+        const int bx = (int)originF.x, by = (int)originF.y;
+        const float2 bilinearWeights = F2(Frac(prevPixelPosFloat.x - 0.5f), Frac(prevPixelPosFloat.y - 0.5f));
+
+        const float frustumSize = pixelSize * float(rectW < rectH ? rectW : rectH);
+        const float disocclusionThresholdSlopeScale = 1.0f / Lerp(Lerp(0.05f, 1.0f, NoV), 1.0f, Sat(smbParallaxInPixelsMax / 30.0f));
+        float4 smbDisocclusionThreshold = F4(Sat(disocclusionThreshold * disocclusionThresholdSlopeScale) * frustumSize);
+        smbDisocclusionThreshold = smbDisocclusionThreshold * IsInScreenBilinear(originF, rectSizePrev);
+        smbDisocclusionThreshold = smbDisocclusionThreshold - NRD_EPS;
+
+        const float prevViewPosZ = AffineTransform(c.shared.gWorldToViewPrev, prevWorldPos).z;
+        const float minMaterialID = Min(c.shared.gSpecMinMaterial, c.shared.gDiffMinMaterial);
+        auto Valid = [&](int dx, int dy, float threshold) {
+            float z = RelaxUnpackViewZ(c, FetchClampedR32F(P.prevViewZ, bx + dx, by + dy));
+            float m = FetchClampedR8Unorm(P.prevMaterialID, bx + dx, by + dy) * 255.0f;
+            float v = Step(Abs(z - prevViewPosZ), threshold);
+            return v * Cmp(CompareMaterials(currentMaterialID, m, minMaterialID));
+        };
+        const float3 tapsValid0 = F3(Valid(0, -1, smbDisocclusionThreshold.x), Valid(-1, 0, smbDisocclusionThreshold.x), Valid(0, 0, smbDisocclusionThreshold.x));
+        const float3 tapsValid1 = F3(Valid(1, -1, smbDisocclusionThreshold.y), Valid(1, 0, smbDisocclusionThreshold.y), Valid(2, 0, smbDisocclusionThreshold.y));
+        const float3 tapsValid2 = F3(Valid(-1, 1, smbDisocclusionThreshold.z), Valid(0, 1, smbDisocclusionThreshold.z), Valid(0, 2, smbDisocclusionThreshold.z));
+        const float3 tapsValid3 = F3(Valid(1, 1, smbDisocclusionThreshold.w), Valid(2, 1, smbDisocclusionThreshold.w), Valid(1, 2, smbDisocclusionThreshold.w));
+
+        const float3 tapsSum = tapsValid0 + tapsValid1 + tapsValid2 + tapsValid3;
+        float bicubicFootprintValid = (tapsSum.x + tapsSum.y + tapsSum.z) > 11.5f ? 1.0f : 0.0f;
+        float4 bilinearTapsValid = F4(tapsValid0.z, tapsValid1.y, tapsValid2.y, tapsValid3.x);
+
+        float3 prevNormalFlat = Xyz(UnpackPrevNormalRoughness(SampleLinearRGBA8Unorm(P.prevNormalRoughness, F2(float(bx) + 1.0f, float(by) + 1.0f))));
+        prevNormalFlat = RotateVector(c.shared.gWorldPrevToWorld, prevNormalFlat);
+        if (Dot(smbNormal, prevNormalFlat) < 0.0f) {
+            bilinearTapsValid = F4(0.0f);
+            bicubicFootprintValid = 0.0f;
+        }
+
+        Bilinear bilinear;
+        bilinear.origin = originF;
+        bilinear.weights = bilinearWeights;
+        const float4 bilinearCustomWeights = GetBilinearCustomWeights(bilinear, bilinearTapsValid);
+        const bool useBicubic = bicubicFootprintValid > 0.0f;
+
+        const HistoryFilter hf = MakeHistoryFilter(prevPixelPosFloat, bilinearCustomWeights, useBicubic);
+        if (DIFF) {
+            prevDiffuseIllumAnd2ndMomentSMB = Max0(FetchHistoryRGBA16F(hf, P.diff.prev));
+            prevDiffuseResponsiveSMB = Xyz(Max0(FetchHistoryRGBA16F(hf, P.diff.fast)));
+        }
+        if (SPEC) {
+            prevSpecularIllumAnd2ndMomentSMB = Max0(FetchHistoryRGBA16F(hf, P.spec.prev));
+            prevSpecularResponsiveSMB = Xyz(Max0(FetchHistoryRGBA16F(hf, P.spec.fast)));
+        }
+        if (SH) {
+            if (DIFF) {
+                prevDiffuseSH = BilinearWithCustomWeightsRGBA16F(P.diff.prevSh, bx, by, bilinearCustomWeights);
+                prevDiffuseResponsiveSH = BilinearWithCustomWeightsRGBA16F(P.diff.fastSh, bx, by, bilinearCustomWeights);
+            }
+            if (SPEC) {
+                prevSpecularSMBSH = BilinearWithCustomWeightsRGBA16F(P.spec.prevSh, bx, by, bilinearCustomWeights);
+                prevSpecularSMBResponsiveSH = BilinearWithCustomWeightsRGBA16F(P.spec.fastSh, bx, by, bilinearCustomWeights);
+            }
+        }
+
+        historyLength = 255.0f * BilinearWithCustomWeightsImmediateFloat(FetchClampedR8Unorm(P.prevHistoryLength, bx, by), FetchClampedR8Unorm(P.prevHistoryLength, bx + 1, by),
+                                     FetchClampedR8Unorm(P.prevHistoryLength, bx, by + 1), FetchClampedR8Unorm(P.prevHistoryLength, bx + 1, by + 1), bilinearCustomWeights);
+        if (SPEC) {
+            prevReflectionHitTSMB = BilinearWithCustomWeightsImmediateFloat(FetchClampedR16F(P.prevSpecHitDist, bx, by), FetchClampedR16F(P.prevSpecHitDist, bx + 1, by),
+                FetchClampedR16F(P.prevSpecHitDist, bx, by + 1), FetchClampedR16F(P.prevSpecHitDist, bx + 1, by + 1), bilinearCustomWeights);
+            prevReflectionHitTSMB = Max(0.001f, prevReflectionHitTSMB);
+        }
+
+        SMBReprojectionFound = bicubicFootprintValid > 0.0f ? 2.0f : 1.0f;
+        footprintQuality = bicubicFootprintValid > 0.0f ? 1.0f : Sum(bilinearCustomWeights);
+        const bool anyValid = bilinearTapsValid.x != 0.0f || bilinearTapsValid.y != 0.0f || bilinearTapsValid.z != 0.0f || bilinearTapsValid.w != 0.0f;
+        if (!anyValid) {
+            SMBReprojectionFound = 0.0f;
+            footprintQuality = 0.0f;
+        }
+    }
+
+    historyLength = historyLength + 1.0f;
+    historyLength = Min(RELAX_MAX_ACCUM_FRAME_NUM, historyLength);
+
+    // avoid footprint stretching due to the changed viewing angle
+    const float3 Vprev = -Normalize(prevWorldPos - cameraDelta);
+    const float NoVprev = Abs(Dot(currentNormal, Vprev));
+    float sizeQuality = (NoVprev + 1e-3f) / (NoV + 1e-3f);
+    sizeQuality *= sizeQuality;
+    sizeQuality *= sizeQuality;
+    footprintQuality *= Lerp(0.1f, 1.0f, Sat(sizeQuality + Abs(c.shared.gOrthoMode)));
+
+    if (footprintQuality < 1.0f) {
+        historyLength *= Sqrt(footprintQuality);
+        historyLength = Max(historyLength, 1.0f);
+    }
+    historyLength = c.shared.gResetHistory != 0 ? 1.0f : historyLength;
+
+    const float maxAccumulatedFrameNum = 1.0f + ((DIFF && SPEC) ? Max(c.shared.gDiffMaxAccumulatedFrameNum, c.shared.gSpecMaxAccumulatedFrameNum)
+                                                                 : (DIFF ? c.shared.gDiffMaxAccumulatedFrameNum : c.shared.gSpecMaxAccumulatedFrameNum));
+    historyLength = Min(historyLength, maxAccumulatedFrameNum);
+
+    if (DIFF) {
+        float diffMaxAccumulatedFrameNum = c.shared.gDiffMaxAccumulatedFrameNum;
+        float diffMaxFastAccumulatedFrameNum = c.shared.gDiffMaxFastAccumulatedFrameNum;
+        if (c.shared.gHasHistoryConfidence) {
+            float inDiffConfidence = LoadR8Unorm(P.diff.confidence, px, py);
+            diffMaxAccumulatedFrameNum *= inDiffConfidence;
+            diffMaxFastAccumulatedFrameNum *= inDiffConfidence;
+        }
+        const float diffHistoryLength = historyLength;
+        const float diffuseAlpha = SMBReprojectionFound > 0.0f ? Max(1.0f / (diffMaxAccumulatedFrameNum + 1.0f), 1.0f / diffHistoryLength) : 1.0f;
+        const float diffuseAlphaResponsive = SMBReprojectionFound > 0.0f ? Max(1.0f / (diffMaxFastAccumulatedFrameNum + 1.0f), 1.0f / diffHistoryLength) : 1.0f;
+
+        float4 accumulated = Lerp(prevDiffuseIllumAnd2ndMomentSMB, F4(diffuseIllumination, diffuse2ndMoment), diffuseAlpha);
+        float3 accumulatedResponsive = Lerp(prevDiffuseResponsiveSMB, diffuseIllumination, diffuseAlphaResponsive);
+        StoreRGBA16F(P.diff.out, px, py, accumulated);
+        StoreRGBA16F(P.diff.outFast, px, py, F4(accumulatedResponsive, 0.0f));
+        if (SH) {
+            StoreRGBA16F(P.diff.outSh, px, py, Lerp(prevDiffuseSH, diffuseSH, diffuseAlpha));
+            StoreRGBA16F(P.diff.outFastSh, px, py, Lerp(prevDiffuseResponsiveSH, diffuseSH, diffuseAlphaResponsive));
+        }
+    }
+
+    StoreR8Unorm(P.outHistoryLength, px, py, historyLength / 255.0f);
+
+    if (SPEC) {
+        float specMaxAccumulatedFrameNum = c.shared.gSpecMaxAccumulatedFrameNum;
+        float specMaxFastAccumulatedFrameNum = c.shared.gSpecMaxFastAccumulatedFrameNum;
+        if (c.shared.gHasHistoryConfidence) {
+            float inSpecConfidence = LoadR8Unorm(P.spec.confidence, px, py);
+            specMaxAccumulatedFrameNum *= inSpecConfidence;
+            specMaxFastAccumulatedFrameNum *= inSpecConfidence;
+        }
+        const float specHistoryLength = historyLength;
+        const float specHistoryFrames = Min(specMaxAccumulatedFrameNum, specHistoryLength);
+        const float specHistoryResponsiveFrames = Min(specMaxFastAccumulatedFrameNum, specHistoryLength);
+
+        const float hitDist = minHitDist3x3 == NRD_INF ? 0.0f : minHitDist3x3;
+
+        // curvature along the direction of motion
+        float curvature;
+        {
+            float2 deltaUv = prevUVSMB - GetScreenUv(c.shared.gWorldToClipPrev, prevWorldPos + cameraDelta);
+            deltaUv = deltaUv * rectSize;
+            deltaUv = deltaUv / Max(smbParallaxInPixels1, 1.0f / 256.0f);
+
+            float3 n10, x10, n01, x01;
+            {
+                float3 x = GetCurrentWorldPosFromClipSpaceXY(c, (pixelUv + F2(1.0f, 0.0f) * rectSizeInv) * 2.0f - 1.0f, 1.0f);
+                float3 v = Normalize(-x);
+                x10 = F3(0.0f) + v * Dot(currentWorldPos - F3(0.0f), currentNormal) / Dot(currentNormal, v);
+                n10 = Xyz(Shared(1, 0));
+            }
+            {
+                float3 x = GetCurrentWorldPosFromClipSpaceXY(c, (pixelUv + F2(0.0f, 1.0f) * rectSizeInv) * 2.0f - 1.0f, 1.0f);
+                float3 v = Normalize(-x);
+                x01 = F3(0.0f) + v * Dot(currentWorldPos - F3(0.0f), currentNormal) / Dot(currentNormal, v);
+                n01 = Xyz(Shared(0, 1));
+            }
+
+            float2 w = Abs(deltaUv) + 1.0f / 256.0f;
+            w = w / (w.x + w.y);
+            float3 x = x10 * w.x + x01 * w.y;
+            float3 n = Normalize(n10 * w.x + n01 * w.y);
+
+            float deltaUvLenFixed = smbParallaxInPixelsMin;
+            deltaUvLenFixed *= 1.0f;
+            deltaUvLenFixed *= 1.0f + c.shared.gFramerateScale * Bayer4x4((uint32_t)px, (uint32_t)py, c.shared.gFrameIndex);
+
+            float2 motionUvHigh = pixelUv + deltaUv * deltaUvLenFixed * rectSizeInv;
+            motionUvHigh = (Floor(motionUvHigh * rectSize) + 0.5f) * rectSizeInv;
+            if (deltaUvLenFixed > 1.0f && IsInScreenNearest(motionUvHigh) != 0.0f) {
+                float2 uvScaled = RelaxClampUvToViewport(c, motionUvHigh) + ToF2(c.shared.gRectOffset);
+                int2 q = NearestTexel(P.viewZ, uvScaled);
+                float zHigh = RelaxUnpackViewZ(c, LoadR32F(P.viewZ, q.x, q.y));
+                float3 xHigh = GetCurrentWorldPosFromClipSpaceXY(c, motionUvHigh * 2.0f - 1.0f, zHigh);
+                float3 nHigh = Xyz(UnpackNormalAndRoughness(LoadR10G10B10A2(P.normalRoughness, q.x, q.y)));
+                float zError = Abs(zHigh - currentLinearZ) * Rcp(Max(zHigh, currentLinearZ));
+                bool cmp = zError < NRD_CURVATURE_Z_THRESHOLD;
+                n = cmp ? nHigh : n;
+                x = cmp ? xHigh : x;
+            }
+
+            float3 edge = x - currentWorldPos;
+            float edgeLenSq = LengthSquared(edge);
+            curvature = Dot(n - currentNormal, edge) * PositiveRcp(edgeLenSq);
+        }
+
+        const float hitDistFocused = ApplyThinLensEquation(hitDist, curvature);
+
+        // ---------------------------------------------------------------- virtual motion based history
+        float4 prevSpecularIllumAnd2ndMomentVMB = F4(0.0f), prevSpecularResponsiveVMB = F4(0.0f), prevSpecularVMBSH = F4(0.0f), prevSpecularVMBResponsiveSH = F4(0.0f);
+        float3 prevNormalVMB = currentNormal;
+        float prevRoughnessVMB = 0.0f, prevReflectionHitTVMB = c.shared.gDenoisingRange, VMBReprojectionFound;
+        float2 prevUVVMB;
+        {
+            const float3 virtualViewVector = Normalize(currentViewVector) * hitDistFocused;
+            const float3 prevVirtualWorldPos = prevWorldPos + virtualViewVector;
+
+            prevUVVMB = ScreenUvNoKill(c.shared.gWorldToClipPrev, prevVirtualWorldPos);
+            prevUVVMB = currentMaterialID == c.shared.gCameraAttachedReflectionMaterialID ? prevUVSMB : prevUVVMB;
+
+            const float2 prevVirtualPixelPosFloat = prevUVVMB * rectSizePrev;
+            const float2 originF = Floor(prevVirtualPixelPosFloat - 0.5f);
+            const int bx = (int)originF.x, by = (int)originF.y;
+            const float2 bilinearWeights = F2(Frac(prevVirtualPixelPosFloat.x - 0.5f), Frac(prevVirtualPixelPosFloat.y - 0.5f));
+
+            const float3 currentWorldPosShifted = currentWorldPos - cameraDelta;
+
+            float4 vmbDisocclusionThreshold = F4(disocclusionThreshold * currentLinearZ);
+            vmbDisocclusionThreshold = vmbDisocclusionThreshold * IsInScreenBilinear(originF, rectSizePrev);
+            vmbDisocclusionThreshold = vmbDisocclusionThreshold - NRD_EPS;
+
+            auto TapValid = [&](int dx, int dy, float threshold) {
+                float z = RelaxUnpackViewZ(c, FetchClampedR32F(P.prevViewZ, bx + dx, by + dy));
+                float3 prevWorldPosInTap = GetPreviousWorldPosFromPixelPos(c, bx + dx, by + dy, z);
+                float3 posDiff = currentWorldPosShifted - prevWorldPosInTap;
+                float maxPlaneDistance = Abs(Dot(posDiff, currentNormal));
+                float valid = maxPlaneDistance > threshold ? 0.0f : 1.0f;
+                float m = FetchClampedR8Unorm(P.prevMaterialID, bx + dx, by + dy) * 255.0f;
+                return valid * Cmp(CompareMaterials(currentMaterialID, m, c.shared.gSpecMinMaterial));
+            };
+            const float4 bilinearTapsValid = F4(TapValid(0, 0, vmbDisocclusionThreshold.x), TapValid(1, 0, vmbDisocclusionThreshold.y), TapValid(0, 1, vmbDisocclusionThreshold.z),
+                TapValid(1, 1, vmbDisocclusionThreshold.w));
+            const bool anyValid = bilinearTapsValid.x != 0.0f || bilinearTapsValid.y != 0.0f || bilinearTapsValid.z != 0.0f || bilinearTapsValid.w != 0.0f;
+            const bool allValid = bilinearTapsValid.x != 0.0f && bilinearTapsValid.y != 0.0f && bilinearTapsValid.z != 0.0f && bilinearTapsValid.w != 0.0f;
+
+            if (anyValid) {
+                Bilinear bilinear;
+                bilinear.origin = originF;
+                bilinear.weights = bilinearWeights;
+                const float4 bilinearCustomWeights = GetBilinearCustomWeights(bilinear, bilinearTapsValid);
+                const bool useBicubic = SMBReprojectionFound == 2.0f && allValid;
+
+                const HistoryFilter hf = MakeHistoryFilter(prevVirtualPixelPosFloat, bilinearCustomWeights, useBicubic);
+                prevSpecularIllumAnd2ndMomentVMB = Max0(FetchHistoryRGBA16F(hf, P.spec.prev));
+                prevSpecularResponsiveVMB = Max0(FetchHistoryRGBA16F(hf, P.spec.fast));
+                if (SH) {
+                    prevSpecularVMBSH = BilinearWithCustomWeightsRGBA16F(P.spec.prevSh, bx, by, bilinearCustomWeights);
+                    prevSpecularVMBResponsiveSH = BilinearWithCustomWeightsRGBA16F(P.spec.fastSh, bx, by, bilinearCustomWeights);
+                }
+
+                prevReflectionHitTVMB = SampleLinearR16F(P.prevSpecHitDist, prevUVVMB * resolutionScalePrev * F2(float(P.prevSpecHitDist.w), float(P.prevSpecHitDist.h)));
+                prevReflectionHitTVMB = Max(0.001f, prevReflectionHitTVMB);
+
+                float4 prevNormalRoughness = UnpackPrevNormalRoughness(
+                    SampleLinearRGBA8Unorm(P.prevNormalRoughness, prevUVVMB * resolutionScalePrev * F2(float(P.prevNormalRoughness.w), float(P.prevNormalRoughness.h))));
+                prevNormalVMB = RotateVector(c.shared.gWorldPrevToWorld, Xyz(prevNormalRoughness));
+                prevRoughnessVMB = prevNormalRoughness.w;
+            }
+            VMBReprojectionFound = allValid ? 1.0f : 0.0f;
+        }
+
+        // amount of virtual motion
+        const float4 D = GetSpecularDominantDirection(currentNormal, V, currentRoughnessModified);
+        float virtualHistoryAmount = VMBReprojectionFound * D.w;
+        virtualHistoryAmount *= 1.0f;
+        virtualHistoryAmount *= Cmp(Dot(prevNormalVMB, currentNormalAveraged) > 0.0f);
+
+        float2 uvDiff = prevUVVMB - prevUVSMB;
+        const float uvDiffLengthInPixels = Length(uvDiff * rectSize);
+
+        float tanCurvature = Abs(curvature * pixelSize);
+        tanCurvature *= Max(uvDiffLengthInPixels / Max(NoV, 0.01f), 1.0f);
+        const float curvatureAngle = Atan(tanCurvature);
+
+        const float lobeHalfAngle = Max(Atan(GetSpecLobeTanHalfAngleOld(currentRoughnessModified)), RELAX_NORMAL_ULP);
+        const float normalWeight = GetEncodingAwareNormalWeightR(currentNormal, prevNormalVMB, lobeHalfAngle, curvatureAngle, RELAX_NORMAL_ULP, true);
+        virtualHistoryAmount *= Lerp(1.0f - Sat(uvDiffLengthInPixels), 1.0f, normalWeight);
+
+        const float2 relaxedRoughnessWeightParams = GetRelaxedRoughnessWeightParams(currentRoughness * currentRoughness, c.shared.gRoughnessFraction);
+        float virtualRoughnessWeight = ComputeWeight(prevRoughnessVMB * prevRoughnessVMB, relaxedRoughnessWeightParams.x, relaxedRoughnessWeightParams.y);
+        virtualRoughnessWeight = Lerp(1.0f - Sat(uvDiffLengthInPixels), 1.0f, virtualRoughnessWeight);
+        virtualHistoryAmount *= virtualRoughnessWeight;
+        float specVMBConfidence = virtualRoughnessWeight * 0.9f + 0.1f;
+
+        // look back 1 and 2 frames
+        uvDiff = uvDiff * Rsqrt(LengthSquared(uvDiff));
+        uvDiff = uvDiff / rectSizePrev;
+        uvDiff = uvDiff * (Sat(uvDiffLengthInPixels / 0.1f) + uvDiffLengthInPixels / 2.0f);
+        const float2 backUV1 = prevUVVMB + uvDiff * 1.0f;
+        const float2 backUV2 = prevUVVMB + uvDiff * 2.0f;
+        const float2 prevNrSize = F2(float(P.prevNormalRoughness.w), float(P.prevNormalRoughness.h));
+        const float4 backNormalRoughness1 = UnpackPrevNormalRoughness(SampleLinearRGBA8Unorm(P.prevNormalRoughness, backUV1 * resolutionScalePrev * prevNrSize));
+        const float4 backNormalRoughness2 = UnpackPrevNormalRoughness(SampleLinearRGBA8Unorm(P.prevNormalRoughness, backUV2 * resolutionScalePrev * prevNrSize));
+        const float3 backNormal1 = RotateVector(c.shared.gWorldPrevToWorld, Xyz(backNormalRoughness1));
+        const float3 backNormal2 = RotateVector(c.shared.gWorldPrevToWorld, Xyz(backNormalRoughness2));
+        float prevPrevNormalWeight = IsInScreenNearest(backUV1) != 0.0f ? GetEncodingAwareNormalWeightR(prevNormalVMB, backNormal1, lobeHalfAngle, curvatureAngle * 2.0f, RELAX_NORMAL_ULP, true) : 1.0f;
+        prevPrevNormalWeight *= IsInScreenNearest(backUV2) != 0.0f ? GetEncodingAwareNormalWeightR(prevNormalVMB, backNormal2, lobeHalfAngle, curvatureAngle * 3.0f, RELAX_NORMAL_ULP, true) : 1.0f;
+        virtualHistoryAmount *= 0.33f + 0.67f * prevPrevNormalWeight;
+        specVMBConfidence *= 0.33f + 0.67f * prevPrevNormalWeight;
+        float rw = ComputeWeight(backNormalRoughness1.w * backNormalRoughness1.w, relaxedRoughnessWeightParams.x, relaxedRoughnessWeightParams.y);
+        rw *= ComputeWeight(backNormalRoughness2.w * backNormalRoughness2.w, relaxedRoughnessWeightParams.x, relaxedRoughnessWeightParams.y);
+        virtualHistoryAmount *= rw * 0.9f + 0.1f;
+
+        // hit distance confidence
+        const float SMC = GetSpecMagicCurve(currentRoughnessModified);
+        const float hitDistC = Lerp(specularIllumination.w, prevReflectionHitTSMB, SMC);
+        const float hitDist1 = ApplyThinLensEquation(hitDistC, curvature);
+        const float hitDist2 = ApplyThinLensEquation(prevReflectionHitTVMB, curvature);
+        const float maxDist = Max(hitDist1, hitDist2);
+        const float dHitT = Abs(hitDist1 - hitDist2);
+        const float dHitTMultiplier = Lerp(20.0f, 0.0f, SMC);
+        float virtualHistoryHitDistConfidence = 1.0f - Sat(dHitTMultiplier * dHitT / (currentLinearZ + maxDist));
+        virtualHistoryHitDistConfidence = Lerp(virtualHistoryHitDistConfidence, 1.0f, SMC);
+
+        // virtual UV discrepancy
+        const float3 virtualWorldPos = GetXvirtual(hitDist, curvature, currentWorldPos, prevWorldPos, currentNormal, V, currentRoughness);
+        const float virtualWorldPosLength = Length(virtualWorldPos);
+        const float hitDistForTrackingPrev = prevSpecularResponsiveVMB.w;
+        const float3 prevVirtualWorldPos2 = GetXvirtual(hitDistForTrackingPrev, curvature, currentWorldPos, prevWorldPos, currentNormal, V, currentRoughness);
+        const float virtualWorldPosLengthPrev = Length(prevVirtualWorldPos2);
+        float2 prevUVVMBTest = ScreenUvNoKill(c.shared.gWorldToClipPrev, prevVirtualWorldPos2);
+        prevUVVMBTest = currentMaterialID == c.shared.gCameraAttachedReflectionMaterialID ? prevUVSMB : prevUVVMBTest;
+
+        float lobeTanHalfAngle = GetSpecLobeTanHalfAngleOld(currentRoughness, 0.6f);
+        lobeTanHalfAngle = Max(lobeTanHalfAngle, 0.5f * rectSizeInv.x);
+        const float unproj1 = Min(hitDist, hitDistForTrackingPrev) / PixelRadiusToWorld(c.shared.gUnproject, c.shared.gOrthoMode, 1.0f, Max(virtualWorldPosLength, virtualWorldPosLengthPrev));
+        const float lobeRadiusInPixels = lobeTanHalfAngle * unproj1;
+        const float deltaParallaxInPixels = Length((prevUVVMBTest - prevUVVMB) * rectSize);
+        virtualHistoryHitDistConfidence *= SmoothStep(lobeRadiusInPixels + 0.25f, 0.0f, deltaParallaxInPixels);
+
+        // surface motion signal
+        const float specSMBConfidence = (SMBReprojectionFound > 0.0f ? 1.0f : 0.0f) * GetEncodingAwareNormalWeightR(V, Vprev, lobeHalfAngle * NoV / c.shared.gFramerateScale, 0.0f, 0.0f, false);
+        float specSMBAlpha = 1.0f - specSMBConfidence;
+        float specSMBResponsiveAlpha = 1.0f - specSMBConfidence;
+        specSMBAlpha = Max(specSMBAlpha, 1.0f / (1.0f + specHistoryFrames));
+        specSMBResponsiveAlpha = Max(specSMBAlpha, 1.0f / (1.0f + specHistoryResponsiveFrames));
+
+        const float3 specRgb = Xyz(specularIllumination);
+        const float3 accumulatedSpecularSMB = Lerp(Xyz(prevSpecularIllumAnd2ndMomentSMB), specRgb, specSMBAlpha);
+        const float accumulatedSpecularSMBHitT = Lerp(prevReflectionHitTSMB, specularIllumination.w, Max(specSMBAlpha, 0.1f));
+        const float accumulatedSpecularM2SMB = Lerp(prevSpecularIllumAnd2ndMomentSMB.w, specular2ndMoment, specSMBAlpha);
+        const float3 accumulatedSpecularSMBResponsive = Lerp(prevSpecularResponsiveSMB, specRgb, specSMBResponsiveAlpha);
+
+        // virtual motion signal
+        float specVMBAlpha = 1.0f - specVMBConfidence;
+        float specVMBResponsiveAlpha = 1.0f - specVMBConfidence * virtualHistoryHitDistConfidence;
+        float specVMBHitTAlpha = specVMBResponsiveAlpha;
+        specVMBAlpha = Max(specVMBAlpha, 1.0f / (1.0f + specHistoryFrames));
+        specVMBResponsiveAlpha = Max(specVMBResponsiveAlpha, 1.0f / (1.0f + specHistoryResponsiveFrames));
+        specVMBHitTAlpha = Max(specVMBHitTAlpha, 1.0f / (1.0f + specHistoryFrames));
+
+        const float3 accumulatedSpecularVMB = Lerp(Xyz(prevSpecularIllumAnd2ndMomentVMB), specRgb, specVMBAlpha);
+        const float accumulatedSpecularVMBHitT = Lerp(prevReflectionHitTVMB, specularIllumination.w, Max(specVMBHitTAlpha, 0.1f));
+        const float accumulatedSpecularM2VMB = Lerp(prevSpecularIllumAnd2ndMomentVMB.w, specular2ndMoment, specVMBAlpha);
+        const float3 accumulatedSpecularVMBResponsive = Lerp(Xyz(prevSpecularResponsiveVMB), specRgb, specVMBResponsiveAlpha);
+
+        // fall back to surface motion if virtual motion doesn't go well
+        virtualHistoryAmount *= Sat(specVMBConfidence / (specSMBConfidence + NRD_EPS));
+
+        const float accumulatedReflectionHitT = Lerp(accumulatedSpecularSMBHitT, accumulatedSpecularVMBHitT, virtualHistoryAmount);
+        const float3 accumulatedSpecularIllumination = Lerp(accumulatedSpecularSMB, accumulatedSpecularVMB, virtualHistoryAmount);
+        const float3 accumulatedSpecularIlluminationResponsive = Lerp(accumulatedSpecularSMBResponsive, accumulatedSpecularVMBResponsive, virtualHistoryAmount);
+        float accumulatedSpecular2ndMoment = Lerp(accumulatedSpecularM2SMB, accumulatedSpecularM2VMB, virtualHistoryAmount);
+
+        if (SH) {
+            const float4 accumulatedSpecularSMBSH = Lerp(prevSpecularSMBSH, specularSH, specSMBAlpha);
+            const float4 accumulatedSpecularSMBResponsiveSH = Lerp(prevSpecularSMBResponsiveSH, specularSH, specSMBResponsiveAlpha);
+            const float4 accumulatedSpecularVMBSH = Lerp(prevSpecularVMBSH, specularSH, specVMBAlpha);
+            const float4 accumulatedSpecularVMBResponsiveSH = Lerp(prevSpecularVMBResponsiveSH, specularSH, specVMBResponsiveAlpha);
+            const float4 accumulatedSpecularSH = Lerp(accumulatedSpecularSMBSH, accumulatedSpecularVMBSH, virtualHistoryAmount);
+            const float4 accumulatedSpecularResponsiveSH = Lerp(accumulatedSpecularSMBResponsiveSH, accumulatedSpecularVMBResponsiveSH, virtualHistoryAmount);
+            StoreRGBA16F(P.spec.outSh, px, py, F4(Xyz(accumulatedSpecularSH), currentRoughnessModified));
+            StoreRGBA16F(P.spec.outFastSh, px, py, accumulatedSpecularResponsiveSH);
+        }
+
+        const float specularHistoryConfidence = Lerp(specSMBConfidence, specVMBConfidence, virtualHistoryAmount);
+        if (accumulatedSpecular2ndMoment == 0.0f)
+            accumulatedSpecular2ndMoment = c.shared.gSpecVarianceBoost * (1.0f - specularHistoryConfidence);
+
+        StoreRGBA16F(P.spec.out, px, py, F4(accumulatedSpecularIllumination, accumulatedSpecular2ndMoment));
+        StoreRGBA16F(P.spec.outFast, px, py, F4(accumulatedSpecularIlluminationResponsive, hitDist));
+        StoreR16F(P.outSpecHitDist, px, py, accumulatedReflectionHitT);
+        StoreR8Unorm(P.outSpecReprojectionConfidence, px, py, specularHistoryConfidence);
+    }
+}
+
+template <bool DIFF, bool SPEC, bool SH>
+const char* LaunchTemporalAccumulation(const PassArgs& a) {
+    if (const char* e = CheckSupportedRelax(a))
+        return e;
+    PlaneCursor cur(a);
+    TaPlanes P = {};
+    P.tiles = cur.next();
+    if (SPEC) P.spec.in = cur.next();
+    if (DIFF) P.diff.in = cur.next();
+    P.mv = cur.next();
+    P.normalRoughness = cur.next();
+    P.viewZ = cur.next();
+    if (SPEC) P.spec.fast = cur.next();
+    if (DIFF) P.diff.fast = cur.next();
+    if (SPEC) P.spec.prev = cur.next();
+    if (DIFF) P.diff.prev = cur.next();
+    P.prevNormalRoughness = cur.next();
+    P.prevViewZ = cur.next();
+    if (SPEC) P.prevSpecHitDist = cur.next();
+    P.prevHistoryLength = cur.next();
+    P.prevMaterialID = cur.next();
+    if (SPEC) P.spec.confidence = cur.next();
+    if (DIFF) P.diff.confidence = cur.next();
+    P.disocclusionThresholdMix = cur.next();
+    if (SH && SPEC) P.spec.inSh = cur.next();
+    if (SH && DIFF) P.diff.inSh = cur.next();
+    if (SH && SPEC) P.spec.fastSh = cur.next();
+    if (SH && DIFF) P.diff.fastSh = cur.next();
+    if (SH && SPEC) P.spec.prevSh = cur.next();
+    if (SH && DIFF) P.diff.prevSh = cur.next();
+    if (SPEC) P.spec.out = cur.next();
+    if (DIFF) P.diff.out = cur.next();
+    if (SPEC) P.spec.outFast = cur.next();
+    if (DIFF) P.diff.outFast = cur.next();
+    if (SPEC) P.outSpecHitDist = cur.next();
+    P.outHistoryLength = cur.next();
+    if (SPEC) P.outSpecReprojectionConfidence = cur.next();
+    if (SH && SPEC) P.spec.outSh = cur.next();
+    if (SH && DIFF) P.diff.outSh = cur.next();
+    if (SH && SPEC) P.spec.outFastSh = cur.next();
+    if (SH && DIFF) P.diff.outFastSh = cur.next();
+    if (!cur.complete())
+        return "RELAX TemporalAccumulation: unexpected resource count";
+    RelaxCB c = LoadRelaxConstants(a);
+    RowGrid g = GridForRows(c.shared.gRectSize.x, c.shared.gRectSize.y, TILE_X, TILE_Y, a.rowBegin, a.rowEnd);
+    hipLaunchKernelGGL((RelaxTemporalAccumulationKernel<DIFF, SPEC, SH>), g.grid, dim3(256), 0, a.stream, P, c, RowRange{g.firstBlockY, g.rowBegin, g.rowEnd});
+    return nullptr;
+}
+
+// ================================================================================================ HistoryClamping
+namespace hc {
+constexpr int BORDER = 2;
+constexpr int BUF_X = TILE_X + 2 * BORDER; // 36
+constexpr int BUF_Y = TILE_Y + 2 * BORDER; // 12
+constexpr int BUF_STRIDE = BUF_X + 1;      // 37
+constexpr int BUF_SIZE = BUF_Y * BUF_STRIDE;
+} // namespace hc
+
+struct HcPlanes {
+    Plane tiles, viewZ, historyLength, outHistoryLength;
+    SignalPlanes spec, diff;
+};
+
+struct ClampOut {
+    float4 slow, fast;
+    float clampingFactor;
+};
+
+template <bool IS_SPEC>
+NRD_D ClampOut ClampSignal(const RelaxCB& c, float3 fastM1, float3 fastM2, float3 noisyM1, float noisyM2, float4 fastCenterYCoCg, float4 slowIn, float3 noisyCenter, float historyLength) {
+    const float maxFast = IS_SPEC ? c.shared.gSpecMaxFastAccumulatedFrameNum : c.shared.gDiffMaxFastAccumulatedFrameNum;
+    const float maxSlow = IS_SPEC ? c.shared.gSpecMaxAccumulatedFrameNum : c.shared.gDiffMaxAccumulatedFrameNum;
+    const bool isFixed = historyLength <= c.shared.gHistoryFixFrameNum; // history-fix pixel: responsive history is copied, no clamping
+
+    float3 sigma = Sqrt3(Max3(F3(0.0f), fastM2 - fastM1 * fastM1));
+    float3 colorMin = fastM1 - c.shared.gColorBoxSigmaScale * sigma;
+    float3 colorMax = fastM1 + c.shared.gColorBoxSigmaScale * sigma;
+    colorMin = Min3(colorMin, Xyz(fastCenterYCoCg));
+    colorMax = Max3(colorMax, Xyz(fastCenterYCoCg));
+
+    float3 slowYCoCg = RgbToYCoCg(Xyz(slowIn));
+    float3 clampedYCoCg = slowYCoCg;
+    if (maxFast < maxSlow)
+        clampedYCoCg = Min3(Max3(slowYCoCg, colorMin), colorMax);
+    float3 clamped = YCoCgToRgb(clampedYCoCg);
+
+    float4 outSlow = F4(clamped, slowIn.w);
+    float3 fastCenter = YCoCgToRgb(Xyz(fastCenterYCoCg));
+    float4 outFast = F4(fastCenter, IS_SPEC ? fastCenterYCoCg.w : 0.0f);
+    if (isFixed)
+        outSlow = IS_SPEC ? outFast : F4(Xyz(outFast), outSlow.w);
+
+    float clampingFactor = (clampedYCoCg.x - slowYCoCg.x) == 0.0f ? 0.0f : Sat((clampedYCoCg.x - slowYCoCg.x) / (fastCenterYCoCg.x - slowYCoCg.x));
+    if (isFixed)
+        clampingFactor = 1.0f;
+
+    float historyDifferenceL = (IS_SPEC ? 0.33f * RELAX_ANTILAG_ACCELERATION_AMOUNT_SCALE : RELAX_ANTILAG_ACCELERATION_AMOUNT_SCALE) * c.shared.gHistoryAccelerationAmount *
+                               Luminance(Abs(fastCenter - Xyz(slowIn)));
+    historyDifferenceL *= clampingFactor;
+    if (isFixed)
+        historyDifferenceL = 0.0f;
+
+    float3 distanceToNoisy = noisyM1 - fastCenter;
+    float distanceToNoisyL = Luminance(Abs(distanceToNoisy));
+    float3 acceleration = distanceToNoisyL == 0.0f ? F3(0.0f) : distanceToNoisy * historyDifferenceL / distanceToNoisyL;
+    float accelerationL = Luminance(Abs(acceleration));
+    float ratio = accelerationL == 0.0f ? 0.0f : distanceToNoisyL / accelerationL;
+    if (ratio < 1.0f)
+        acceleration = acceleration * ratio;
+    if (ratio <= 0.0f)
+        acceleration = F3(0.0f);
+
+    float3 slowRgb = Xyz(outSlow) + acceleration;
+    float3 fastRgb = Xyz(outFast) + acceleration;
+
+    float slowL = Luminance(Xyz(slowIn));
+    float noisyL = Luminance(noisyM1);
+    float temporalSigma = c.shared.gHistoryResetTemporalSigmaScale * Sqrt(Max(0.0f, noisyM2 - noisyL * noisyL));
+    float spatialSigma = c.shared.gHistoryResetSpatialSigmaScale * sigma.x;
+    float resetAmount = (IS_SPEC ? 0.5f * c.shared.gHistoryResetAmount : c.shared.gHistoryResetAmount) * Max(0.0f, Abs(slowL - noisyL) - spatialSigma - temporalSigma) /
+                        (1.0e-6f + Max(slowL, noisyL) + spatialSigma + temporalSigma);
+    resetAmount = Sat(resetAmount);
+    slowRgb = Lerp(slowRgb, noisyCenter, resetAmount);
+    fastRgb = Lerp(fastRgb, noisyCenter, resetAmount);
+
+    float outL = Luminance(slowRgb);
+    float momentCorrection = outL * outL - slowL * slowL;
+    float a = Max(0.0f, outSlow.w + momentCorrection);
+
+    ClampOut o;
+    o.slow = F4(slowRgb, a);
+    o.fast = F4(fastRgb, outFast.w);
+    o.clampingFactor = clampingFactor;
+    return o;
+}
+
+template <bool IS_SPEC, bool SH>
+NRD_D void ResolveSignal(const RelaxCB& c, const SignalPlanes& S, const float4* s_Fast, const float4* s_Noisy, int px, int py, int lx, int ly, float historyLength) {
+    float3 fastM1 = F3(0.0f), fastM2 = F3(0.0f), noisyM1 = F3(0.0f);
+    float noisyM2 = 0.0f, sum = 0.0f;
+#pragma unroll
+    for (int dx = -2; dx <= 2; dx++)
+#pragma unroll
+        for (int dy = -2; dy <= 2; dy++) {
+            const int li = (ly + dy) * hc::BUF_STRIDE + (lx + dx);
+            float4 noisy = s_Noisy[li];
+            if (noisy.w != 0.0f) {
+                float3 sampleYCoCg = Xyz(s_Fast[li]);
+                fastM1 = fastM1 + sampleYCoCg;
+                fastM2 = fastM2 + sampleYCoCg * sampleYCoCg;
+                float noisyLuminance = Luminance(Xyz(noisy));
+                noisyM1 = noisyM1 + Xyz(noisy);
+                noisyM2 += noisyLuminance * noisyLuminance;
+                sum += noisy.w;
+            }
+        }
+    fastM1 = fastM1 / sum;
+    fastM2 = fastM2 / sum;
+    noisyM1 = noisyM1 / sum;
+    noisyM2 /= sum;
+
+    const int lc = ly * hc::BUF_STRIDE + lx;
+    ClampOut o = ClampSignal<IS_SPEC>(c, fastM1, fastM2, noisyM1, noisyM2, s_Fast[lc], LoadRGBA16F(S.in, px, py), Xyz(s_Noisy[lc]), historyLength);
+    StoreRGBA16F(S.out, px, py, o.slow);
+    StoreRGBA16F(S.outFast, px, py, o.fast);
+    if (SH) {
+        float4 sh = LoadRGBA16F(S.inSh, px, py), shFast = LoadRGBA16F(S.fastSh, px, py);
+        StoreRGBA16F(S.outSh, px, py, Lerp(sh, shFast, o.clampingFactor));
+        StoreRGBA16F(S.outFastSh, px, py, shFast);
+    }
+}
+
+template <bool DIFF, bool SPEC, bool SH>
+__global__ __launch_bounds__(256) void RelaxHistoryClampingKernel(HcPlanes P, RelaxCB c, RowRange rows) {
+    __shared__ float4 s_SpecFast[SPEC ? hc::BUF_SIZE : 1], s_SpecNoisy[SPEC ? hc::BUF_SIZE : 1];
+    __shared__ float4 s_DiffFast[DIFF ? hc::BUF_SIZE : 1], s_DiffNoisy[DIFF ? hc::BUF_SIZE : 1];
+
+    const int blockY = blockIdx.y + rows.firstBlockY;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    const int px = blockIdx.x * TILE_X + tx, py = blockY * TILE_Y + ty;
+    const int rectW = c.shared.gRectSize.x, rectH = c.shared.gRectSize.y;
+
+    if (!RelaxBlockHasGeometry(P.tiles, blockY))
+        return;
+
+    for (int idx = threadIdx.x; idx < hc::BUF_X * hc::BUF_Y; idx += 256) {
+        int lx = idx % hc::BUF_X, ly = idx / hc::BUF_X;
+        int gx = ClampI(blockIdx.x * TILE_X - hc::BORDER + lx, 0, rectW - 1), gy = ClampI(blockY * TILE_Y - hc::BORDER + ly, 0, rectH - 1);
+        float isValid = Cmp(LoadR32F(P.viewZ, gx, gy) < c.shared.gDenoisingRange); // raw viewZ as in the reference
+        int li = ly * hc::BUF_STRIDE + lx;
+        if (SPEC) {
+            float4 f = LoadRGBA16F(P.spec.fast, gx, gy);
+            s_SpecFast[li] = F4(RgbToYCoCg(Xyz(f)), f.w);
+            s_SpecNoisy[li] = F4(Xyz(LoadRGBA16F(P.spec.noisy, gx, gy)), isValid);
+        }
+        if (DIFF) {
+            float4 f = LoadRGBA16F(P.diff.fast, gx, gy);
+            s_DiffFast[li] = F4(RgbToYCoCg(Xyz(f)), f.w);
+            s_DiffNoisy[li] = F4(Xyz(LoadRGBA16F(P.diff.noisy, gx, gy)), isValid);
+        }
+    }
+    __syncthreads();
+
+    if (px >= rectW || py >= rectH || py < rows.rowBegin || py >= rows.rowEnd)
+        return;
+    if (LoadR8Unorm(P.tiles, px >> 4, py >> 4) != 0.0f)
+        return;
+    const int lx = tx + hc::BORDER, ly = ty + hc::BORDER;
+    const float centerValid = SPEC ? s_SpecNoisy[ly * hc::BUF_STRIDE + lx].w : s_DiffNoisy[ly * hc::BUF_STRIDE + lx].w;
+    if (centerValid == 0.0f)
+        return;
+
+    const float historyLength = 255.0f * LoadR8Unorm(P.historyLength, px, py);
+    if (SPEC)
+        ResolveSignal<true, SH>(c, P.spec, s_SpecFast, s_SpecNoisy, px, py, lx, ly, historyLength);
+    if (DIFF)
+        ResolveSignal<false, SH>(c, P.diff, s_DiffFast, s_DiffNoisy, px, py, lx, ly, historyLength);
+    StoreR8Unorm(P.outHistoryLength, px, py, historyLength / 255.0f);
+}
+
+template <bool DIFF, bool SPEC, bool SH>
+const char* LaunchHistoryClamping(const PassArgs& a) {
+    if (const char* e = CheckSupportedRelax(a))
+        return e;
+    PlaneCursor cur(a);
+    HcPlanes P = {};
+    P.tiles = cur.next();
+    P.viewZ = cur.next();
+    if (SPEC) P.spec.noisy = cur.next();
+    if (DIFF) P.diff.noisy = cur.next();
+    if (SPEC) P.spec.in = cur.next();
+    if (DIFF) P.diff.in = cur.next();
+    if (SPEC) P.spec.fast = cur.next();
+    if (DIFF) P.diff.fast = cur.next();
+    P.historyLength = cur.next();
+    if (SH && SPEC) P.spec.inSh = cur.next();
+    if (SH && DIFF) P.diff.inSh = cur.next();
+    if (SH && SPEC) P.spec.fastSh = cur.next();
+    if (SH && DIFF) P.diff.fastSh = cur.next();
+    if (SPEC) P.spec.out = cur.next();
+    if (DIFF) P.diff.out = cur.next();
+    if (SPEC) P.spec.outFast = cur.next();
+    if (DIFF) P.diff.outFast = cur.next();
+    P.outHistoryLength = cur.next();
+    if (SH && SPEC) P.spec.outSh = cur.next();
+    if (SH && DIFF) P.diff.outSh = cur.next();
+    if (SH && SPEC) P.spec.outFastSh = cur.next();
+    if (SH && DIFF) P.diff.outFastSh = cur.next();
+    if (!cur.complete())
+        return "RELAX HistoryClamping: unexpected resource count";
+    RelaxCB c = LoadRelaxConstants(a);
+    RowGrid g = GridForRows(c.shared.gRectSize.x, c.shared.gRectSize.y, TILE_X, TILE_Y, a.rowBegin, a.rowEnd);
+    hipLaunchKernelGGL((RelaxHistoryClampingKernel<DIFF, SPEC, SH>), g.grid, dim3(256), 0, a.stream, P, c, RowRange{g.firstBlockY, g.rowBegin, g.rowEnd});
+    return nullptr;
+}
+
+} // namespace
+
+#define RELAX_TA_VARIANT(name, D, S, H)                                                \
+    {"RELAX_" name "_TemporalAccumulation.cs", LaunchTemporalAccumulation<D, S, H>},  \
+    {"RELAX_" name "_HistoryClamping.cs", LaunchHistoryClamping<D, S, H>}
+
+const PassEntry* GetRelaxTemporalPasses(uint32_t& num) {
+    static const PassEntry k[] = {
+        RELAX_TA_VARIANT("Diffuse", true, false, false),
+        RELAX_TA_VARIANT("DiffuseSh", true, false, true),
+        RELAX_TA_VARIANT("Specular", false, true, false),
+        RELAX_TA_VARIANT("SpecularSh", false, true, true),
+        RELAX_TA_VARIANT("DiffuseSpecular", true, true, false),
+        RELAX_TA_VARIANT("DiffuseSpecularSh", true, true, true),
+    };
+    num = sizeof(k) / sizeof(k[0]);
+    return k;
+}
+
+} // namespace nrdhip

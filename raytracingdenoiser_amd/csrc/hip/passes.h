@@ -31,6 +31,7 @@ struct PassEntry {
 const PassEntry* GetCommonPasses(uint32_t& num);
 const PassEntry* GetReblurPasses(uint32_t& num);
 const PassEntry* GetSigmaPasses(uint32_t& num);
+const PassEntry* GetRelaxPasses(uint32_t& num);
 
 inline dim3 GridFor(int w, int h, int tileW, int tileH) { return dim3((unsigned)((w + tileW - 1) / tileW), (unsigned)((h + tileH - 1) / tileH), 1); }
 

@@ -133,6 +133,14 @@ Result InstanceImpl::Create(const InstanceCreationDesc& desc) {
             case Denoiser::REBLUR_DIFFUSE_SPECULAR:
                 Add_Reblur(data, true, true);
                 break;
+            case Denoiser::RELAX_DIFFUSE:
+            case Denoiser::RELAX_DIFFUSE_SH:
+            case Denoiser::RELAX_SPECULAR:
+            case Denoiser::RELAX_SPECULAR_SH:
+            case Denoiser::RELAX_DIFFUSE_SPECULAR:
+            case Denoiser::RELAX_DIFFUSE_SPECULAR_SH:
+                Add_RelaxVariant(data);
+                break;
             case Denoiser::SIGMA_SHADOW:
                 Add_SigmaShadow(data);
                 break;
@@ -506,6 +514,14 @@ Result InstanceImpl::GetComputeDispatches(const Identifier* identifiers, uint32_
             case Denoiser::REBLUR_SPECULAR:
             case Denoiser::REBLUR_DIFFUSE_SPECULAR:
                 Update_Reblur(d);
+                break;
+            case Denoiser::RELAX_DIFFUSE:
+            case Denoiser::RELAX_DIFFUSE_SH:
+            case Denoiser::RELAX_SPECULAR:
+            case Denoiser::RELAX_SPECULAR_SH:
+            case Denoiser::RELAX_DIFFUSE_SPECULAR:
+            case Denoiser::RELAX_DIFFUSE_SPECULAR_SH:
+                Update_Relax(d);
                 break;
             case Denoiser::SIGMA_SHADOW:
                 Update_SigmaShadow(d);

@@ -93,6 +93,8 @@ struct ClearResource {
     bool isInteger;
 };
 
+bool IsRelax(Denoiser d);
+
 class InstanceImpl {
 public:
     explicit InstanceImpl(const AllocationCallbacks& cb);
@@ -114,6 +116,11 @@ private:
     void Add_Reblur(DenoiserData& d, bool hasDiff, bool hasSpec);
     void Update_Reblur(const DenoiserData& d);
     void FillReblurConstants(const ReblurSettings& settings, void* data);
+
+    void Add_Relax(DenoiserData& d, bool hasDiff, bool hasSpec, bool sh);
+    void Add_RelaxVariant(DenoiserData& d);
+    void Update_Relax(const DenoiserData& d);
+    void FillRelaxConstants(const RelaxSettings& settings, void* data);
 
     void Add_SigmaShadow(DenoiserData& d);
     void Update_SigmaShadow(const DenoiserData& d);

@@ -13,6 +13,12 @@ const nrd::Denoiser g_Supported[] = {
     nrd::Denoiser::REBLUR_DIFFUSE,
     nrd::Denoiser::REBLUR_SPECULAR,
     nrd::Denoiser::REBLUR_DIFFUSE_SPECULAR,
+    nrd::Denoiser::RELAX_DIFFUSE,
+    nrd::Denoiser::RELAX_DIFFUSE_SH,
+    nrd::Denoiser::RELAX_SPECULAR,
+    nrd::Denoiser::RELAX_SPECULAR_SH,
+    nrd::Denoiser::RELAX_DIFFUSE_SPECULAR,
+    nrd::Denoiser::RELAX_DIFFUSE_SPECULAR_SH,
     nrd::Denoiser::SIGMA_SHADOW,
     nrd::Denoiser::REFERENCE,
 };

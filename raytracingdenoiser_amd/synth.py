@@ -160,6 +160,17 @@ def _norm_hit_dist(hit_dist, view_z, roughness):
     return (hit_dist / f).clamp(0.0, 1.0)
 
 
+def _pack_relax(out, name, radiance, hit_dist, direction):
+    """RELAX_FrontEnd_PackRadianceAndHitDist / RELAX_FrontEnd_PackSh (reference NRD.hlsli:789-818), both RGBA16F:
+    <name>_relax = SH0 = (radiance, hitDist in world units), <name>_relax_sh1 = (direction * luminance, 0)."""
+    radiance = radiance.clamp(0.0, FP16_MAX)
+    hit_dist = hit_dist.clamp(0.0, FP16_MAX)
+    out[name + "_relax"] = torch.cat([radiance, hit_dist.unsqueeze(-1)], -1).to(torch.float16).contiguous()
+    luma = radiance[..., 0] * 0.2126 + radiance[..., 1] * 0.7152 + radiance[..., 2] * 0.0722
+    sh1 = torch.cat([direction.clamp(-1.0, 1.0) * luma.unsqueeze(-1), torch.zeros_like(luma).unsqueeze(-1)], -1)
+    out[name + "_relax_sh1"] = sh1.clamp(-FP16_MAX, FP16_MAX).to(torch.float16).contiguous()
+
+
 def render_frame(width, height, frame, device="cpu", static_camera=False, noise=True, seed=7, want=("reblur",)):
     """Returns a dict with the packed planes and the camera (for CommonSettings)."""
     dev = torch.device(device)
@@ -185,7 +196,7 @@ def render_frame(width, height, frame, device="cpu", static_camera=False, noise=
 
     xi, yi = xs.to(torch.int64), ys.to(torch.int64)
     fr = frame if noise else 0
-    if "reblur" in want:
+    if "reblur" in want or "relax" in want:
         vdir = _normalize(-d)
         # diffuse bounce: cosine-weighted direction around n
         u1, u2 = _hash_uniform(xi, yi, fr, seed), _hash_uniform(xi, yi, fr, seed + 1)
@@ -201,6 +212,8 @@ def render_frame(width, height, frame, device="cpu", static_camera=False, noise=
         rad = torch.where(is_sky.unsqueeze(-1), torch.zeros_like(rad), rad).clamp(0.0, 250.0)
         nhd = torch.where(is_sky, torch.zeros_like(hit_d), _norm_hit_dist(hit_d, view_z, torch.ones_like(rough)))
         out["diff"] = torch.cat([_ycocg(rad), nhd.unsqueeze(-1)], -1).clamp(-FP16_MAX, FP16_MAX).to(torch.float16).contiguous()
+        if "relax" in want:
+            _pack_relax(out, "diff", rad, torch.where(is_sky, torch.zeros_like(hit_d), hit_d), wd)
 
         # specular bounce: mirror direction jittered inside a roughness-sized lobe
         u3, u4 = _hash_uniform(xi, yi, fr, seed + 2), _hash_uniform(xi, yi, fr, seed + 3)
@@ -218,6 +231,8 @@ def render_frame(width, height, frame, device="cpu", static_camera=False, noise=
         rad = torch.where((is_sky | below).unsqueeze(-1), torch.zeros_like(rad), rad).clamp(0.0, 250.0)
         nhd = torch.where(is_sky, torch.zeros_like(hit_d), _norm_hit_dist(hit_d, view_z, rough))
         out["spec"] = torch.cat([_ycocg(rad), nhd.unsqueeze(-1)], -1).clamp(-FP16_MAX, FP16_MAX).to(torch.float16).contiguous()
+        if "relax" in want:
+            _pack_relax(out, "spec", rad, torch.where(is_sky, torch.zeros_like(hit_d), hit_d), ws)
 
     if "sigma" in want:
         # sun with a 0.25 deg angular radius... widened to 1.5 deg so penumbrae span pixels at test resolutions

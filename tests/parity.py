@@ -28,7 +28,21 @@ DENOISERS = {
     "REBLUR_SPECULAR": (api.Denoiser.REBLUR_SPECULAR, ("reblur",)),
     "REBLUR_DIFFUSE_SPECULAR": (api.Denoiser.REBLUR_DIFFUSE_SPECULAR, ("reblur",)),
     "SIGMA_SHADOW": (api.Denoiser.SIGMA_SHADOW, ("sigma",)),
+    "RELAX_DIFFUSE": (api.Denoiser.RELAX_DIFFUSE, ("relax",)),
+    "RELAX_DIFFUSE_SH": (api.Denoiser.RELAX_DIFFUSE_SH, ("relax",)),
+    "RELAX_SPECULAR": (api.Denoiser.RELAX_SPECULAR, ("relax",)),
+    "RELAX_SPECULAR_SH": (api.Denoiser.RELAX_SPECULAR_SH, ("relax",)),
+    "RELAX_DIFFUSE_SPECULAR": (api.Denoiser.RELAX_DIFFUSE_SPECULAR, ("relax",)),
+    "RELAX_DIFFUSE_SPECULAR_SH": (api.Denoiser.RELAX_DIFFUSE_SPECULAR_SH, ("relax",)),
 }
+
+
+def _relax_signals(name):
+    """(has diffuse, has specular, SH) of a RELAX variant name"""
+    body = name[len("RELAX_"):]
+    sh = body.endswith("_SH")
+    body = body[:-3] if sh else body
+    return "DIFFUSE" in body, "SPECULAR" in body, sh
 
 
 def user_planes(name, frame):
@@ -40,6 +54,16 @@ def user_planes(name, frame):
         planes.append((RT.IN_SPEC_RADIANCE_HITDIST, frame["spec"], F.RGBA16_SFLOAT))
     if name == "SIGMA_SHADOW":
         planes.append((RT.IN_PENUMBRA, frame["penumbra"], F.R16_SFLOAT))
+    if name.startswith("RELAX"):
+        has_diff, has_spec, sh = _relax_signals(name)
+        if has_diff:
+            planes.append((RT.IN_DIFF_SH0 if sh else RT.IN_DIFF_RADIANCE_HITDIST, frame["diff_relax"], F.RGBA16_SFLOAT))
+            if sh:
+                planes.append((RT.IN_DIFF_SH1, frame["diff_relax_sh1"], F.RGBA16_SFLOAT))
+        if has_spec:
+            planes.append((RT.IN_SPEC_SH0 if sh else RT.IN_SPEC_RADIANCE_HITDIST, frame["spec_relax"], F.RGBA16_SFLOAT))
+            if sh:
+                planes.append((RT.IN_SPEC_SH1, frame["spec_relax_sh1"], F.RGBA16_SFLOAT))
     return planes
 
 
@@ -52,6 +76,16 @@ def output_planes(name, width, height):
         outs.append((RT.OUT_SPEC_RADIANCE_HITDIST, torch.float16, 4, F.RGBA16_SFLOAT))
     if name == "SIGMA_SHADOW":
         outs.append((RT.OUT_SHADOW_TRANSLUCENCY, torch.uint8, 1, F.R8_UNORM))
+    if name.startswith("RELAX"):
+        has_diff, has_spec, sh = _relax_signals(name)
+        if has_diff:
+            outs.append((RT.OUT_DIFF_SH0 if sh else RT.OUT_DIFF_RADIANCE_HITDIST, torch.float16, 4, F.RGBA16_SFLOAT))
+            if sh:
+                outs.append((RT.OUT_DIFF_SH1, torch.float16, 4, F.RGBA16_SFLOAT))
+        if has_spec:
+            outs.append((RT.OUT_SPEC_SH0 if sh else RT.OUT_SPEC_RADIANCE_HITDIST, torch.float16, 4, F.RGBA16_SFLOAT))
+            if sh:
+                outs.append((RT.OUT_SPEC_SH1, torch.float16, 4, F.RGBA16_SFLOAT))
     return outs
 
 
@@ -60,6 +94,8 @@ def denoiser_settings(name, frame, overrides=None):
         s = api.ReblurSettings(**(overrides or {}))
     elif name == "SIGMA_SHADOW":
         s = api.SigmaSettings(lightDirection=frame["light_dir"], **(overrides or {}))
+    elif name.startswith("RELAX"):
+        s = api.RelaxSettings(**(overrides or {}))
     else:
         raise KeyError(name)
     return s

@@ -1,0 +1,175 @@
+"""RELAX chain: host-table checks and oracle known-answer properties on the CPU, HIP-vs-oracle parity on the GPU.
+Known answers: SURVEY.md section 8c (2) constant radiance -> unchanged, (3) all-sky -> untouched, (4) splitScreen >= 1 ->
+passthrough, (6) history length 1, 2, 3, ... on a static scene; a-trous iteration count and ping-pong binding order follow
+reference Source/Relax.cpp:262-276."""
+import numpy as np
+import pytest
+import torch
+
+import parity
+from raytracingdenoiser_amd import api
+
+RT = api.ResourceType
+W, H = 160, 96
+ALL = ["RELAX_DIFFUSE", "RELAX_DIFFUSE_SH", "RELAX_SPECULAR", "RELAX_SPECULAR_SH", "RELAX_DIFFUSE_SPECULAR", "RELAX_DIFFUSE_SPECULAR_SH"]
+
+
+def _run_oracle(name, seq, overrides=None, cs_kw=None, width=W, height=H):
+    ora = parity.OracleRun(name, width, height)
+    for f, frame in enumerate(seq):
+        cs = parity.common_settings(frame["camera"], seq[max(f - 1, 0)]["camera"], width, height, f, **(cs_kw or {}))
+        ora.step(frame, cs, parity.denoiser_settings(name, frame, overrides))
+    return ora
+
+
+# ---------------------------------------------------------------------------------------------------- host tables
+def test_pool_layout_matches_reference_tables():
+    # reference Source/Denoisers/Relax_DiffuseSpecularSh.hpp:20-78 / Relax_Diffuse.hpp:18-46
+    F = api.Format
+    inst = api.Instance([(0, api.Denoiser.RELAX_DIFFUSE_SPECULAR_SH)])
+    assert [p[0] for p in inst.permanent_pool] == [F.RGBA16_SFLOAT] * 8 + [F.R16_SFLOAT, F.R16_SFLOAT, F.R8_UNORM, F.RGBA8_UNORM, F.R8_UNORM, F.R32_SFLOAT]
+    assert inst.transient_pool == [(F.RGBA16_SFLOAT, 1)] * 8 + [(F.R8_UNORM, 1), (F.R8_UNORM, 16), (F.R8_UNORM, 1)]
+    inst = api.Instance([(0, api.Denoiser.RELAX_DIFFUSE)])
+    assert [p[0] for p in inst.permanent_pool] == [F.RGBA16_SFLOAT] * 2 + [F.R8_UNORM, F.RGBA8_UNORM, F.R8_UNORM, F.R32_SFLOAT]
+    assert inst.transient_pool == [(F.RGBA16_SFLOAT, 1)] * 2 + [(F.R8_UNORM, 16), (F.R8_UNORM, 1)]
+    inst = api.Instance([(0, api.Denoiser.RELAX_SPECULAR)])
+    assert len(inst.permanent_pool) == 8 and len(inst.transient_pool) == 5
+
+
+@pytest.mark.parametrize("iterations", [2, 3, 5, 8])
+def test_atrous_chain_ping_pongs_into_the_user_outputs(iterations):
+    name = "RELAX_DIFFUSE_SPECULAR"
+    seq = parity.generate_sequence(name, 64, 48, 1)
+    inst = api.Instance([(0, parity.DENOISERS[name][0])])
+    assert inst.set_denoiser_settings(0, api.RelaxSettings(atrousIterationNum=iterations)) == api.Result.SUCCESS
+    assert inst.set_common_settings(parity.common_settings(seq[0]["camera"], seq[0]["camera"], 64, 48, 1, accumulationMode=0)) == api.Result.SUCCESS
+    r, ds = inst.get_compute_dispatches()
+    assert r == api.Result.SUCCESS
+    atrous = [d for d in ds if "Atrous" in d.shader]
+    assert [d.shader for d in atrous] == ["RELAX_DiffuseSpecular_AtrousSmem.cs"] + ["RELAX_DiffuseSpecular_Atrous.cs"] * (iterations - 1)
+    # each iteration reads what the previous one wrote (resources 1, 2 = spec, diff inputs; outputs follow the 8 inputs)
+    is_output = lambda r: r[0] == api.DescriptorType.STORAGE_TEXTURE
+    for prev, cur in zip(atrous, atrous[1:]):
+        prev_outs = [r[1:] for r in prev.resources if is_output(r)][:2]
+        assert [cur.resources[1][1:], cur.resources[2][1:]] == prev_outs
+    last_outs = [r[1] for r in atrous[-1].resources if is_output(r)]
+    assert last_outs == [RT.OUT_SPEC_RADIANCE_HITDIST, RT.OUT_DIFF_RADIANCE_HITDIST]
+    steps = [np.frombuffer(d.constants, dtype=np.uint32)[-2:].tolist() for d in atrous]
+    assert steps == [[1 << i, 1 if i == iterations - 1 else 0] for i in range(iterations)]
+
+
+def test_constant_block_sizes_and_frustum_basis():
+    name = "RELAX_DIFFUSE_SPECULAR_SH"
+    seq = parity.generate_sequence(name, 64, 48, 1)
+    inst = api.Instance([(0, parity.DENOISERS[name][0])])
+    cam = seq[0]["camera"]
+    assert inst.set_common_settings(parity.common_settings(cam, cam, 64, 48, 0)) == api.Result.SUCCESS
+    r, ds = inst.get_compute_dispatches()
+    by_shader = {d.shader: d for d in ds}
+    assert len(by_shader["RELAX_DiffuseSpecularSh_PrePass.cs"].constants) == 704
+    assert len(by_shader["RELAX_DiffuseSpecularSh_Atrous.cs"].constants) == 712
+    c = np.frombuffer(by_shader["RELAX_ClassifyTiles.cs"].constants, dtype=np.float32)
+    right, up, fwd = c[68:71], c[72:75], c[76:79]  # gFrustumRight / Up / Forward after 4 matrices + gRotatorPre
+    # X = viewZ * (forward + right * clipX - up * clipY) must reproduce the camera rays of the synthetic scene
+    for (u, v) in ((0.5, 0.5), (0.1, 0.9), (1.0, 0.0)):
+        clip = (2.0 * u - 1.0, 2.0 * v - 1.0)
+        x = fwd + right * clip[0] - up * clip[1]
+        d = (clip[0] / cam.fx) * np.array(cam.right) + (-clip[1] / cam.fy) * np.array(cam.up) + np.array(cam.fwd)
+        assert np.allclose(x, d, atol=1e-5)
+
+
+# ---------------------------------------------------------------------------------------------------- oracle known answers
+@pytest.mark.parametrize("name", ["RELAX_DIFFUSE_SPECULAR", "RELAX_DIFFUSE_SPECULAR_SH"])
+def test_oracle_noise_drops_and_energy_is_preserved(name):
+    seq = parity.generate_sequence(name, W, H, 8)
+    ora = _run_oracle(name, seq)
+    m = ~seq[-1]["is_sky"].numpy()
+    sh = name.endswith("_SH")
+    for sig in ("diff", "spec"):
+        rt = getattr(RT, "OUT_%s_%s" % (sig.upper(), "SH0" if sh else "RADIANCE_HITDIST"))
+        out = ora.output(rt)
+        noisy = seq[-1][sig + "_relax"].float().numpy()
+        assert not np.isnan(out).any()
+        luma = lambda a: a[..., 0] * 0.25 + a[..., 1] * 0.5 + a[..., 2] * 0.25  # Y of YCoCg
+        out_y = out[..., 0] if sh else luma(out)  # SH outputs are already YCoCg
+        assert abs(out_y[m].mean() - luma(noisy)[m].mean()) < 0.06 * luma(noisy)[m].mean()
+        assert out_y[m].std() < 0.9 * luma(noisy)[m].std()
+    always_sky = np.all(np.stack([fr["is_sky"].numpy() for fr in seq]), axis=0)
+    assert np.all(ora.output(rt)[always_sky] == 0)  # sky pixels are never written (cleared on frame 0)
+
+
+def test_oracle_single_signal_variants_equal_the_combined_one():
+    seq = parity.generate_sequence("RELAX_DIFFUSE_SPECULAR_SH", W, H, 4)
+    both = _run_oracle("RELAX_DIFFUSE_SPECULAR_SH", seq)
+    diff = _run_oracle("RELAX_DIFFUSE_SH", seq)
+    spec = _run_oracle("RELAX_SPECULAR_SH", seq)
+    for rt in (RT.OUT_DIFF_SH0, RT.OUT_DIFF_SH1):
+        assert np.array_equal(both.output(rt), diff.output(rt))
+    for rt in (RT.OUT_SPEC_SH0, RT.OUT_SPEC_SH1):
+        assert np.array_equal(both.output(rt), spec.output(rt))
+
+
+def test_oracle_constant_signal_is_a_fixed_point():
+    name = "RELAX_DIFFUSE_SPECULAR"
+    seq = parity.generate_sequence(name, W, H, 5, static_camera=True, noise=False)
+    const = torch.tensor([0.5, 0.25, 0.125, 2.0], dtype=torch.float16)
+    for fr in seq:
+        fr["diff_relax"] = const.expand(H, W, 4).contiguous()
+        fr["spec_relax"] = const.expand(H, W, 4).contiguous()
+    ora = _run_oracle(name, seq)
+    m = ~seq[-1]["is_sky"].numpy()
+    for rt in (RT.OUT_DIFF_RADIANCE_HITDIST, RT.OUT_SPEC_RADIANCE_HITDIST):
+        out = ora.output(rt)[m]
+        assert np.max(np.abs(out[:, :3] - const.float().numpy()[:3])) < 2e-3  # weighted means of a constant, up to fp16 rounding
+        assert np.max(out[:, 3]) < 1e-3  # .w carries the luminance variance: zero for a constant signal
+
+
+def test_oracle_history_length_counts_up():
+    name = "RELAX_DIFFUSE"
+    seq = parity.generate_sequence(name, W, H, 6, static_camera=True, noise=False)
+    ora = parity.OracleRun(name, W, H)
+    m = ~seq[0]["is_sky"].numpy()
+    m[:2], m[-2:], m[:, :2], m[:, -2:] = False, False, False, False
+    for f, frame in enumerate(seq):
+        cs = parity.common_settings(frame["camera"], seq[max(f - 1, 0)]["camera"], W, H, f)
+        ora.step(frame, cs, parity.denoiser_settings(name, frame))
+        raw, fmt, w = ora.ex.pool_plane(RT.PERMANENT_POOL, 2)  # HISTORY_LENGTH_PREV (R8_UNORM)
+        assert np.median(raw[:, :w][m]) == f + 1
+
+
+def test_oracle_all_sky_and_split_screen_passthrough():
+    name = "RELAX_DIFFUSE_SPECULAR"
+    seq = parity.generate_sequence(name, W, H, 2)
+    for fr in seq:
+        fr["viewz"] = torch.full_like(fr["viewz"], 1.0e6)
+    ora = _run_oracle(name, seq)
+    assert np.all(ora.output(RT.OUT_DIFF_RADIANCE_HITDIST) == 0) and np.all(ora.output(RT.OUT_SPEC_RADIANCE_HITDIST) == 0)
+
+    seq = parity.generate_sequence(name, W, H, 2)
+    ora = _run_oracle(name, seq, cs_kw=dict(splitScreen=1.0))
+    m = ~seq[-1]["is_sky"].numpy()
+    assert np.array_equal(ora.output(RT.OUT_DIFF_RADIANCE_HITDIST)[m], seq[-1]["diff_relax"].float().numpy()[m])
+    assert [d.shader for d in ora.last_dispatches] == ["RELAX_DiffuseSpecular_SplitScreen.cs"]
+
+
+# ---------------------------------------------------------------------------------------------------- HIP parity
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", ALL)
+def test_hip_matches_oracle(name):
+    worst = parity.run_parity(name, width=192, height=128, frames=6, verbose=True)
+    assert worst <= parity.REL_TOL
+
+
+@pytest.mark.gpu
+def test_hip_matches_oracle_odd_size_and_more_iterations():
+    # ragged edges (not multiples of 32 / 16 / 8), 7 a-trous iterations (random tap offsets at steps 8..64)
+    worst = parity.run_parity("RELAX_DIFFUSE_SPECULAR_SH", width=211, height=117, frames=4, verbose=True, settings_overrides=dict(atrousIterationNum=7))
+    assert worst <= parity.REL_TOL
+
+
+@pytest.mark.gpu
+def test_hip_matches_oracle_no_prepass_no_roughness_edge_stopping():
+    worst = parity.run_parity("RELAX_DIFFUSE_SPECULAR", width=160, height=96, frames=4, verbose=True,
+                              settings_overrides=dict(diffusePrepassBlurRadius=0.0, specularPrepassBlurRadius=0.0, enableRoughnessEdgeStopping=False, historyFixFrameNum=0,
+                                                      spatialVarianceEstimationHistoryThreshold=0))
+    assert worst <= parity.REL_TOL
