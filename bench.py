@@ -1,5 +1,6 @@
 #!/usr/bin/env python3
-"""Benchmark of the NRD hot path on MI355X: REBLUR_DIFFUSE_SPECULAR @ 2560x1440 (BASELINE.json metric).
+"""Benchmark of the NRD hot path on MI355X: REBLUR_DIFFUSE_SPECULAR @ 2560x1440 (BASELINE.json metric) by default;
+--workload relax_ds_sh runs BASELINE.json config 5 (RELAX_DIFFUSE_SPECULAR_SH, 3840x2160, 5 a-trous iterations).
 
 A "step" is one denoised frame = one full pass list (ClassifyTiles, PrePass, TemporalAccumulation, HistoryFix, Blur,
 PostBlur, TemporalStabilization) over one synthetic frame whose inputs are ALREADY resident in HBM (generated on the
@@ -11,7 +12,7 @@ GPU before the timed region). Prints ONE JSON line (see DESIGN.md "Measurement")
   cpu_baseline  the CPU oracle (oracle/, kind "port": the reference has no CPU implementation) on the host cores,
                 on a bounded sample of the same workload (N = 1, rank 0 only)
 
-  python bench.py [--gpus N] [--steps K] [--warmup W] [--width 2560 --height 1440] [--no-cpu-baseline]
+  python bench.py [--gpus N] [--steps K] [--warmup W] [--workload reblur_ds|relax_ds_sh|relax_ds] [--width 2560 --height 1440] [--no-cpu-baseline]
 """
 import argparse
 import json
@@ -38,7 +39,32 @@ REBLUR_DS_BYTES_PER_PIXEL = {
     "REBLUR_DiffuseSpecular_PostBlur.cs": 46,
     "REBLUR_DiffuseSpecular_TemporalStabilization.cs": 66,
 }
-TOTAL_BYTES_PER_PIXEL = sum(REBLUR_DS_BYTES_PER_PIXEL.values())  # 348
+# RELAX: SH variant = BASELINE.json config 5; the a-trous entry is per iteration (42 B/px of it are reads)
+RELAX_DS_SH_BYTES_PER_PIXEL = {
+    "RELAX_ClassifyTiles.cs": 4,
+    "RELAX_DiffuseSpecularSh_PrePass.cs": 72,
+    "RELAX_DiffuseSpecularSh_TemporalAccumulation.cs": 192,
+    "RELAX_DiffuseSpecularSh_HistoryFix.cs": 5,
+    "RELAX_DiffuseSpecularSh_HistoryClamping.cs": 150,
+    "RELAX_DiffuseSpecularSh_AtrousSmem.cs": 83,
+    "RELAX_DiffuseSpecularSh_Atrous.cs": 74,
+}
+RELAX_DS_BYTES_PER_PIXEL = {
+    "RELAX_ClassifyTiles.cs": 4,
+    "RELAX_DiffuseSpecular_PrePass.cs": 40,
+    "RELAX_DiffuseSpecular_TemporalAccumulation.cs": 112,
+    "RELAX_DiffuseSpecular_HistoryFix.cs": 5,
+    "RELAX_DiffuseSpecular_HistoryClamping.cs": 86,
+    "RELAX_DiffuseSpecular_AtrousSmem.cs": 51,
+    "RELAX_DiffuseSpecular_Atrous.cs": 42,
+}
+
+# workload -> (denoiser, default size, bytes/px per pass, a-trous launches per frame with the default settings)
+WORKLOADS = {
+    "reblur_ds": ("REBLUR_DIFFUSE_SPECULAR", (2560, 1440), REBLUR_DS_BYTES_PER_PIXEL),
+    "relax_ds_sh": ("RELAX_DIFFUSE_SPECULAR_SH", (3840, 2160), RELAX_DS_SH_BYTES_PER_PIXEL),
+    "relax_ds": ("RELAX_DIFFUSE_SPECULAR", (3840, 2160), RELAX_DS_BYTES_PER_PIXEL),
+}
 
 
 def parse_args():
@@ -46,34 +72,35 @@ def parse_args():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=64)
     ap.add_argument("--warmup", type=int, default=32)
-    ap.add_argument("--width", type=int, default=2560)
-    ap.add_argument("--height", type=int, default=1440)
+    ap.add_argument("--workload", choices=sorted(WORKLOADS), default="reblur_ds", help="reblur_ds = the BASELINE.json metric (default); relax_ds_sh = config 5 (4K)")
+    ap.add_argument("--width", type=int, default=0)
+    ap.add_argument("--height", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-frames", type=int, default=3)
     ap.add_argument("--distinct-frames", type=int, default=0, help="number of distinct generated frames to cycle through (0 = warmup + steps)")
     return ap.parse_args()
 
 
-def cpu_baseline(width, height, frames, seq):
+def cpu_baseline(name, width, height, frames, seq):
     """Times the CPU oracle on the first `frames` frames of the same sequence (all host cores, OpenMP over rows)."""
     import parity
     from oracle import driver as oracle_driver
 
     cores = os.cpu_count() or 1
     threads = oracle_driver.load().oracle_set_threads(cores)
-    ora = parity.OracleRun("REBLUR_DIFFUSE_SPECULAR", width, height, threads=threads)
+    ora = parity.OracleRun(name, width, height, threads=threads)
     host_seq = [{k: (v.cpu() if torch.is_tensor(v) else v) for k, v in fr.items()} for fr in seq[:frames]]
     t0 = time.perf_counter()
     for f, frame in enumerate(host_seq):
         cs = parity.common_settings(frame["camera"], host_seq[max(f - 1, 0)]["camera"], width, height, f)
-        ora.step(frame, cs, parity.denoiser_settings("REBLUR_DIFFUSE_SPECULAR", frame))
+        ora.step(frame, cs, parity.denoiser_settings(name, frame))
     dt = time.perf_counter() - t0
     return {
         "value": round(frames * width * height / dt / 1e6, 4),
         "unit": "Mpixels/s",
         "cores": threads,
         "kind": "port",
-        "sample": "first %d frames of the same %dx%d REBLUR_DIFFUSE_SPECULAR sequence (incl. the CLEAR_AND_RESTART frame), %.1f s" % (frames, width, height, dt),
+        "sample": "first %d frames of the same %dx%d %s sequence (incl. the CLEAR_AND_RESTART frame), %.1f s" % (frames, width, height, name, dt),
     }
 
 
@@ -104,8 +131,8 @@ def main():
     if distributed:
         dist.barrier()
 
-    W, H = args.width, args.height
-    name = "REBLUR_DIFFUSE_SPECULAR"
+    name, default_size, bytes_per_pixel = WORKLOADS[args.workload]
+    W, H = args.width or default_size[0], args.height or default_size[1]
     total = args.warmup + args.steps
     distinct = args.distinct_frames or total
 
@@ -113,23 +140,32 @@ def main():
     seq = parity.generate_sequence(name, W, H, distinct, device="cuda")
     torch.cuda.synchronize()
 
-    inst = api.Instance([(0, api.Denoiser.REBLUR_DIFFUSE_SPECULAR)])
+    inst = api.Instance([(0, parity.DENOISERS[name][0])])
     ex = HipExecutor(inst, W, H)
-    out_diff = torch.zeros((H, W, 4), dtype=torch.float16, device="cuda")
-    out_spec = torch.zeros((H, W, 4), dtype=torch.float16, device="cuda")
-    ex.bind(api.ResourceType.OUT_DIFF_RADIANCE_HITDIST, out_diff, api.Format.RGBA16_SFLOAT)
-    ex.bind(api.ResourceType.OUT_SPEC_RADIANCE_HITDIST, out_spec, api.Format.RGBA16_SFLOAT)
-    shard = sharding.FrameSharder(ex, inst, W, H, rank, world, [out_diff, out_spec]) if distributed else None
+    outputs = []
+    for rt, dtype, ch, fmt in parity.output_planes(name, W, H):
+        t = torch.zeros((H, W, ch), dtype=dtype, device="cuda")
+        ex.bind(rt, t, fmt)
+        outputs.append(t)
+    shard = sharding.FrameSharder(ex, inst, W, H, rank, world, outputs) if distributed else None
 
     settings = parity.denoiser_settings(name, seq[0])
     assert inst.set_denoiser_settings(0, settings) == api.Result.SUCCESS
+    def frame_of(f):
+        # distinct < total: walk the generated frames back and forth so consecutive frames always have neighbouring cameras
+        if distinct >= total or distinct == 1:
+            return seq[min(f, distinct - 1)]
+        period = 2 * (distinct - 1)
+        k = f % period
+        return seq[k if k < distinct else period - k]
+
     frames_cs = []
     for f in range(total):
-        cur, prev = seq[f % distinct], seq[(f - 1) % distinct] if f > 0 else seq[0]
+        cur, prev = frame_of(f), frame_of(max(f - 1, 0))
         frames_cs.append(parity.common_settings(cur["camera"], prev["camera"], W, H, f))
 
     def step(f):
-        frame = seq[f % distinct]
+        frame = frame_of(f)
         for rt, t, fmt in parity.user_planes(name, frame):
             ex.bind(rt, t, fmt)
         assert inst.set_common_settings(frames_cs[f]) == api.Result.SUCCESS
@@ -174,7 +210,7 @@ def main():
     rows = W * H if shard is None else shard.pixels_per_rank()
     passes = {}
     for shader, (ms, n) in timings.items():
-        bpp = REBLUR_DS_BYTES_PER_PIXEL.get(shader)
+        bpp = bytes_per_pixel.get(shader)
         if bpp is None or n == 0:
             continue
         avg_ms = ms / n
@@ -185,13 +221,16 @@ def main():
         achieved = passes[dominant]["GBps"]
         roofline = {"bound": "hbm", "kernel": dominant, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
                     "traffic": None, "avg_kernel_ms": passes[dominant]["avg_ms"], "algorithmic_bytes_per_launch": passes[dominant]["bytes_per_launch"]}
-    gpu_ms = sum(p["avg_ms"] for p in passes.values())
-    whole_chain = {"algorithmic_bytes_per_frame": TOTAL_BYTES_PER_PIXEL * W * H, "sum_kernel_ms": round(gpu_ms, 4),
-                   "GBps": round(TOTAL_BYTES_PER_PIXEL * rows / (gpu_ms * 1e-3) / 1e9, 1) if gpu_ms else None,
-                   "frac_of_peak": round(TOTAL_BYTES_PER_PIXEL * rows / (gpu_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if gpu_ms else None}
+    # per frame: every pass once, except the dilated a-trous pass which runs (launches / steps) times
+    per_frame = {k: p["launches"] / args.steps for k, p in passes.items()}
+    gpu_ms = sum(p["avg_ms"] * per_frame[k] for k, p in passes.items())
+    total_bpp = sum(bytes_per_pixel[k] * per_frame[k] for k in passes)
+    whole_chain = {"algorithmic_bytes_per_pixel": round(total_bpp, 1), "algorithmic_bytes_per_frame": int(total_bpp * W * H), "sum_kernel_ms": round(gpu_ms, 4),
+                   "GBps": round(total_bpp * rows / (gpu_ms * 1e-3) / 1e9, 1) if gpu_ms else None,
+                   "frac_of_peak": round(total_bpp * rows / (gpu_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if gpu_ms else None}
 
     result = {
-        "metric": "Mpixels/s REBLUR_DIFFUSE_SPECULAR @1440p",
+        "metric": "Mpixels/s %s @%s" % (name, {(2560, 1440): "1440p", (3840, 2160): "4K", (1920, 1080): "1080p"}.get((W, H), "%dx%d" % (W, H))),
         "value": round(mpix_s, 2),
         "unit": "Mpixels/s",
         "n_gpus": world,
@@ -203,15 +242,15 @@ def main():
         "vs_baseline": None,
         "dtype": "f32",
         "data": "synthetic",
-        "config": {"workload": "REBLUR_DIFFUSE_SPECULAR %dx%d, default ReblurSettings, analytic scene + 1rpp noise, moving camera" % (W, H),
+        "config": {"workload": "%s %dx%d, default settings, analytic scene + 1rpp noise, moving camera" % (name, W, H),
                    "parallelism": "1 GPU" if world == 1 else "row strips x%d + RCCL all-gather" % world,
-                   "storage": "reference pool formats (fp16 history, R10G10B10A2 normals), 348 B/px/frame compulsory traffic"},
+                   "storage": "reference pool formats (fp16 history, R10G10B10A2 normals), %.0f B/px/frame compulsory traffic" % total_bpp},
         "roofline": roofline,
         "whole_chain": whole_chain,
         "passes": passes,
     }
     if not args.no_cpu_baseline and world == 1:
-        result["cpu_baseline"] = cpu_baseline(W, H, min(args.cpu_frames, distinct), seq)
+        result["cpu_baseline"] = cpu_baseline(name, W, H, min(args.cpu_frames, distinct), seq)
     else:
         result["cpu_baseline"] = None
     print(json.dumps(result))

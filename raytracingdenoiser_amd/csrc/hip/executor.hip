@@ -325,6 +325,24 @@ extern "C" __attribute__((visibility("default"))) uint32_t nrdHipGetPoolPlane(Nr
 // Rows of its INPUT planes (produced earlier in the same frame) a pass reads around an output row. -1 = unknown pass: it and
 // everything before it run on the whole frame.
 static int PassReachRows(const char* shader, const void* constants, uint32_t constantsSize) {
+    if (!strncmp(shader, "RELAX_", 6) && constants && constantsSize >= sizeof(nrdc::RelaxConstants)) {
+        const nrdc::RelaxConstants& c = *(const nrdc::RelaxConstants*)constants;
+        if (strstr(shader, "_AtrousSmem") || strstr(shader, "_HistoryClamping"))
+            return 2; // 5x5 windows
+        if (strstr(shader, "_Atrous")) {
+            if (constantsSize < sizeof(nrdc::RelaxAtrousConstants))
+                return -1;
+            const uint32_t step = ((const nrdc::RelaxAtrousConstants*)constants)->gStepSize;
+            return (int)(step + (step > 4 ? (step + 3) / 4 : 0)); // +-step taps, shifted by up to step / 4 at the large steps
+        }
+        if (strstr(shader, "_HistoryFix"))
+            return 2 * (int)std::floor(c.gHistoryFixBasePixelStride / 2.0f + 0.5f); // 5x5 taps at stride <= base / (1 + 1)
+        if (strstr(shader, "_TemporalAccumulation"))
+            return 1;
+        if (strstr(shader, "_PrePass") || strstr(shader, "_SplitScreen") || strstr(shader, "ClassifyTiles"))
+            return 0; // read user inputs only
+        return -1;
+    }
     if (strncmp(shader, "REBLUR_", 7) != 0 || !constants || constantsSize < sizeof(nrdc::ReblurConstants))
         return -1;
     const nrdc::ReblurConstants& c = *(const nrdc::ReblurConstants*)constants;

@@ -41,24 +41,27 @@ def test_strip_all_gather_gloo_world2():
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("world,height,overrides", [
-    (3, 288, dict(maxBlurRadius=4.0, diffusePrepassBlurRadius=6.0, specularPrepassBlurRadius=6.0)),  # margins < strip: real partial compute
-    (2, 720, None),  # default radii: margin ~200 rows on a 360-row strip
+@pytest.mark.parametrize("name,world,height,overrides", [
+    ("REBLUR_DIFFUSE_SPECULAR", 3, 288, dict(maxBlurRadius=4.0, diffusePrepassBlurRadius=6.0, specularPrepassBlurRadius=6.0)),  # margins < strip: real partial compute
+    ("REBLUR_DIFFUSE_SPECULAR", 2, 720, None),  # default radii: margin ~200 rows on a 360-row strip
+    ("RELAX_DIFFUSE_SPECULAR_SH", 3, 288, dict(atrousIterationNum=4)),  # a-trous reach 2+2+5+10 rows plus history fix / clamping
+    ("RELAX_DIFFUSE_SPECULAR", 2, 360, None),
 ])
-def test_virtual_ranks_reproduce_single_gpu(world, height, overrides):
+def test_virtual_ranks_reproduce_single_gpu(name, world, height, overrides):
     import parity
     from raytracingdenoiser_amd.executor import HipExecutor
 
-    name, W, H, frames = "REBLUR_DIFFUSE_SPECULAR", 256, height, 5
+    W, H, frames = 256, height, 5
     RT, F = api.ResourceType, api.Format
     seq = parity.generate_sequence(name, W, H, frames)
 
     def make_run():
-        inst = api.Instance([(0, api.Denoiser.REBLUR_DIFFUSE_SPECULAR)])
+        inst = api.Instance([(0, parity.DENOISERS[name][0])])
         ex = HipExecutor(inst, W, H)
-        outs = [torch.zeros((H, W, 4), dtype=torch.float16, device="cuda") for _ in range(2)]
-        ex.bind(RT.OUT_DIFF_RADIANCE_HITDIST, outs[0], F.RGBA16_SFLOAT)
-        ex.bind(RT.OUT_SPEC_RADIANCE_HITDIST, outs[1], F.RGBA16_SFLOAT)
+        outs = []
+        for rt, dtype, ch, fmt in parity.output_planes(name, W, H):
+            outs.append(torch.zeros((H, W, ch), dtype=dtype, device="cuda"))
+            ex.bind(rt, outs[-1], fmt)
         return inst, ex, outs
 
     ref_inst, ref_ex, ref_outs = make_run()
