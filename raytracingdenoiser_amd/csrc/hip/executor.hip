@@ -85,6 +85,7 @@ struct NrdHipExecutor {
     std::vector<hipEvent_t> eventPool; // recycled events
     uint64_t permanentBytes = 0, transientBytes = 0;
     std::vector<Plane> permanent, transient;
+    Plane decodedNormalRoughness = {}; // internal float4 cache of IN_NORMAL_ROUGHNESS (not an NRD pool plane; own allocation)
     std::vector<nrd::Format> permanentFormat, transientFormat;
 
     Plane user[(size_t)nrd::ResourceType::MAX_NUM] = {};
@@ -223,6 +224,8 @@ extern "C" __attribute__((visibility("default"))) void nrdHipDestroyExecutor(Nrd
         (void)hipEventDestroy(ev);
     if (e->arena && e->ownsArena)
         (void)hipFree(e->arena);
+    if (e->decodedNormalRoughness.ptr)
+        (void)hipFree(e->decodedNormalRoughness.ptr);
     delete e;
 }
 
@@ -393,6 +396,33 @@ extern "C" __attribute__((visibility("default"))) uint32_t nrdHipExecuteDispatch
         }
     }
 
+    // Decoded-guide cache: if any dispatch reads IN_NORMAL_ROUGHNESS, decode the bound plane once for the whole list
+    Plane decoded = {};
+    {
+        const uint32_t slot = (uint32_t)nrd::ResourceType::IN_NORMAL_ROUGHNESS;
+        bool used = false;
+        for (uint32_t i = 0; i < dispatchDescsNum && !used; i++)
+            for (uint32_t r = 0; r < descs[i].resourcesNum && !used; r++)
+                used = descs[i].resources[r].type == nrd::ResourceType::IN_NORMAL_ROUGHNESS && descs[i].resources[r].descriptorType == nrd::DescriptorType::TEXTURE;
+        if (used && e->userBound[slot]) {
+            const Plane& packed = e->user[slot];
+            Plane& cache = e->decodedNormalRoughness;
+            if (!cache.ptr || cache.w != packed.w || cache.h != packed.h) {
+                if (cache.ptr)
+                    (void)hipFree(cache.ptr);
+                cache = Plane{};
+                const uint32_t pitch = ((uint32_t)packed.w * 16u + 255u) & ~255u;
+                if (hipMalloc((void**)&cache.ptr, (size_t)pitch * (size_t)packed.h) != hipSuccess)
+                    return e->Fail(nrd::Result::FAILURE, "nrdHipExecuteDispatches: cannot allocate the decoded normal/roughness cache");
+                cache.pitch = pitch;
+                cache.w = packed.w;
+                cache.h = packed.h;
+            }
+            LaunchDecodeNormalRoughness(packed, cache, e->stream);
+            decoded = cache;
+        }
+    }
+
     for (uint32_t i = 0; i < dispatchDescsNum; i++) {
         const nrd::DispatchDesc& d = descs[i];
         if (d.pipelineIndex >= e->launchers.size())
@@ -429,6 +459,7 @@ extern "C" __attribute__((visibility("default"))) uint32_t nrdHipExecuteDispatch
         args.stream = e->stream;
         args.rowBegin = 0;
         args.rowEnd = INT_MAX;
+        args.decodedNormalRoughness = decoded;
         if (sharded && e->rowMargin[i] >= 0) {
             args.rowBegin = e->ownedRowBegin - e->rowMargin[i];
             args.rowEnd = e->ownedRowEnd == INT_MAX ? INT_MAX : e->ownedRowEnd + e->rowMargin[i];

@@ -7,8 +7,21 @@
 #include "../common/pass_constants.h"
 #include "nrdmath.h"
 #include "passes.h"
+#include "reblur_device.h"
 
 namespace nrdhip {
+
+// ---- decoded guides: IN_NORMAL_ROUGHNESS (R10G10B10A2) -> float4 cache, once per frame (reblur_device.h "decoded guides") -----
+// 4 B read + 16 B written per texel, one texel per lane: a wave reads 256 B and writes 1 KiB, both contiguous.
+__global__ __launch_bounds__(256) void DecodeNormalRoughnessKernel(Plane packed, Plane decoded) {
+    const int x = blockIdx.x * 256 + threadIdx.x, y = blockIdx.y;
+    if (x < packed.w)
+        StoreRGBA32F(decoded, x, y, EncodeDecodedNormalRoughness(LoadR32U(packed, x, y)));
+}
+
+void LaunchDecodeNormalRoughness(const Plane& packed, const Plane& decoded, hipStream_t stream) {
+    hipLaunchKernelGGL(DecodeNormalRoughnessKernel, dim3((unsigned)((packed.w + 255) / 256), (unsigned)packed.h, 1), dim3(256), 0, stream, packed, decoded);
+}
 
 // ---- Clear: zero the whole plane (pitch included: padding bytes are never read) -----------------------------------
 __global__ __launch_bounds__(256) void ClearPlaneKernel(Plane out, uint32_t rowBytes16) {

@@ -46,6 +46,7 @@ constexpr int BUF_STRIDE = BUF_X + 1;      // 37
 
 struct HfPlanes {
     Plane tiles, normalRoughness, data1, viewZ, inDiff, inSpec, inDiffFast, inSpecFast, outDiff, outSpec, outDiffFast, outSpecFast;
+    Plane decodedNR; // executor's float4 cache of normalRoughness (reblur_device.h "decoded guides")
 };
 
 struct HfPixel {
@@ -95,7 +96,7 @@ NRD_D float4 HistoryFixSignal(const ReblurCB& c, const HfPlanes& P, const HfPixe
 
                 float zs = UnpackViewZ(c, LoadR32F(P.viewZ, sx, sy));
                 float materialIDs;
-                float4 Ns = UnpackNormalAndRoughness(LoadR10G10B10A2(P.normalRoughness, sx, sy), materialIDs);
+                float4 Ns = LoadDecodedNormalRoughness(P.decodedNR, sx, sy, materialIDs);
 
                 float angle = AcosApprox(Dot(Xyz(Ns), s.N));
                 float3 Xvs = ReconstructViewPosition(uv, ToF4(c.gFrustum), zs, c.gOrthoMode);
@@ -219,7 +220,7 @@ __global__ __launch_bounds__(TILE_X* TILE_Y) void ReblurHistoryFixKernel(ReblurC
         return;
 
     s.px = px, s.py = py, s.tx = tx, s.ty = ty;
-    float4 normalAndRoughness = UnpackNormalAndRoughness(LoadR10G10B10A2(P.normalRoughness, px, py), s.materialID);
+    float4 normalAndRoughness = LoadDecodedNormalRoughness(P.decodedNR, px, py, s.materialID);
     s.N = Xyz(normalAndRoughness);
     s.roughness = normalAndRoughness.w;
     s.frustumSize = GetFrustumSize(c.gMinRectDimMulUnproject, c.gOrthoMode, s.viewZ);
@@ -248,6 +249,9 @@ static const char* LaunchHistoryFix(const PassArgs& a) {
     uint32_t k = 0;
     P.tiles = a.planes[k++];
     P.normalRoughness = a.planes[k++];
+    P.decodedNR = a.decodedNormalRoughness;
+    if (!P.decodedNR.ptr)
+        return "REBLUR HistoryFix: the decoded normal/roughness cache is missing (IN_NORMAL_ROUGHNESS not bound?)";
     P.data1 = a.planes[k++];
     P.viewZ = a.planes[k++];
     if (DIFF) P.inDiff = a.planes[k++];
@@ -276,6 +280,7 @@ constexpr int BUF_STRIDE = BUF_X + 1;      // 35
 struct TsPlanes {
     Plane tiles, normalRoughness, viewZ, data1, data2, inDiff, inSpec, historyDiffLuma, historySpecLuma, inSpecHitDistForTracking, mv, outInternalData, outDiff, outSpec, outDiffLuma,
         outSpecLuma;
+    Plane decodedNR;
 };
 
 // 3x3 luma statistics from the LDS tile: centre luma (min/max clamped), mean, sigma
@@ -362,7 +367,7 @@ __global__ __launch_bounds__(TILE_X* TILE_Y) void ReblurTemporalStabilizationKer
     }
 
     float materialID;
-    float4 normalAndRoughness = UnpackNormalAndRoughness(LoadR10G10B10A2(P.normalRoughness, px, py), materialID);
+    float4 normalAndRoughness = LoadDecodedNormalRoughness(P.decodedNR, px, py, materialID);
     float3 N = Xyz(normalAndRoughness);
     float roughness = normalAndRoughness.w;
 
@@ -485,6 +490,9 @@ static const char* LaunchTemporalStabilization(const PassArgs& a) {
     uint32_t k = 0;
     P.tiles = a.planes[k++];
     P.normalRoughness = a.planes[k++];
+    P.decodedNR = a.decodedNormalRoughness;
+    if (!P.decodedNR.ptr)
+        return "REBLUR TemporalStabilization: the decoded normal/roughness cache is missing (IN_NORMAL_ROUGHNESS not bound?)";
     if (SPEC) k++; // base colour / metalness (dummy)
     P.viewZ = a.planes[k++];
     P.data1 = a.planes[k++];

@@ -133,7 +133,7 @@ NRD_D float4 DiffuseSpatialFilter(const ReblurCB& c, const SpatialCtx& s, float4
         const int2 tz = NearestTexel(gIn_ViewZ, uvScaled);
         float zs = UnpackViewZ(c, LoadR32F(gIn_ViewZ, tz.x, tz.y));
         float materialIDs;
-        float4 Ns = UnpackNormalAndRoughness(LoadR10G10B10A2(gIn_Normal_Roughness, tz.x, tz.y), materialIDs);
+        float4 Ns = LoadDecodedNormalRoughness(gIn_Normal_Roughness, tz.x, tz.y, materialIDs);
 
         float angle = AcosApprox(Dot(s.N, Xyz(Ns)));
         float3 Xvs = ReconstructViewPosition(uv, ToF4(c.gFrustum), zs, c.gOrthoMode);
@@ -257,7 +257,7 @@ NRD_D float4 SpecularSpatialFilter(const ReblurCB& c, const SpatialCtx& s, float
         const int2 tz = NearestTexel(gIn_ViewZ, uvScaled);
         float zs = UnpackViewZ(c, LoadR32F(gIn_ViewZ, tz.x, tz.y));
         float materialIDs;
-        float4 Ns = UnpackNormalAndRoughness(LoadR10G10B10A2(gIn_Normal_Roughness, tz.x, tz.y), materialIDs);
+        float4 Ns = LoadDecodedNormalRoughness(gIn_Normal_Roughness, tz.x, tz.y, materialIDs);
 
         float angle = AcosApprox(Dot(s.N, Xyz(Ns)));
         float3 Xvs = ReconstructViewPosition(uv, ToF4(c.gFrustum), zs, c.gOrthoMode);
@@ -303,7 +303,7 @@ NRD_D bool MakeSpatialCtx(const ReblurCB& c, int px, int py, float viewZ, const 
     s.viewZ = viewZ;
     if (viewZ > c.gDenoisingRange)
         return false;
-    float4 normalAndRoughness = UnpackNormalAndRoughness(LoadR10G10B10A2(gIn_Normal_Roughness, px, py), s.materialID);
+    float4 normalAndRoughness = LoadDecodedNormalRoughness(gIn_Normal_Roughness, px, py, s.materialID);
     s.px = px;
     s.py = py;
     s.N = Xyz(normalAndRoughness);
@@ -321,6 +321,7 @@ NRD_D bool MakeSpatialCtx(const ReblurCB& c, int px, int py, float viewZ, const 
 
 struct SpatialPlanes {
     Plane tiles, normalRoughness, viewZ, data1;
+    Plane decodedNR; // executor's float4 cache of normalRoughness (reblur_device.h "decoded guides")
     Plane inDiff, inSpec;
     Plane outDiff, outSpec;
     Plane outHitDistForTracking; // pre-pass
@@ -344,7 +345,7 @@ __global__ __launch_bounds__(TILE_X* TILE_Y) void ReblurSpatialKernel(ReblurCB c
 
     SpatialCtx s;
     const nrdc::F4 rot = MODE == PRE_BLUR ? c.gRotatorPre : (MODE == BLUR ? c.gRotator : c.gRotatorPost);
-    if (!MakeSpatialCtx(c, px, py, UnpackViewZ(c, viewZpacked), P.normalRoughness, ToF4(rot), s))
+    if (!MakeSpatialCtx(c, px, py, UnpackViewZ(c, viewZpacked), P.decodedNR, ToF4(rot), s))
         return;
 
     if (MODE != PRE_BLUR)
@@ -358,14 +359,14 @@ __global__ __launch_bounds__(TILE_X* TILE_Y) void ReblurSpatialKernel(ReblurCB c
 
     if (DIFF) {
         float4 diff = LoadRGBA16F(P.inDiff, px, py);
-        diff = DiffuseSpatialFilter<MODE>(c, s, diff, P.inDiff, P.viewZ, P.normalRoughness);
+        diff = DiffuseSpatialFilter<MODE>(c, s, diff, P.inDiff, P.viewZ, P.decodedNR);
         StoreRGBA16F(P.outDiff, px, py, diff);
         if (MODE == POST_BLUR && NO_TS)
             StoreRGBA16F(P.outDiffCopy, px, py, diff);
     }
     if (SPEC) {
         float4 spec = LoadRGBA16F(P.inSpec, px, py);
-        spec = SpecularSpatialFilter<MODE>(c, s, spec, P.inSpec, P.viewZ, P.normalRoughness, P.outHitDistForTracking);
+        spec = SpecularSpatialFilter<MODE>(c, s, spec, P.inSpec, P.viewZ, P.decodedNR, P.outHitDistForTracking);
         StoreRGBA16F(P.outSpec, px, py, spec);
         if (MODE == POST_BLUR && NO_TS)
             StoreRGBA16F(P.outSpecCopy, px, py, spec);
@@ -394,6 +395,9 @@ static const char* LaunchSpatial(const PassArgs& a) {
     uint32_t k = 0;
     P.tiles = a.planes[k++];
     P.normalRoughness = a.planes[k++];
+    P.decodedNR = a.decodedNormalRoughness;
+    if (!P.decodedNR.ptr)
+        return "REBLUR spatial pass: the decoded normal/roughness cache is missing (IN_NORMAL_ROUGHNESS not bound?)";
     if (MODE == PRE_BLUR) {
         P.viewZ = a.planes[k++];
         if (DIFF) P.inDiff = a.planes[k++];

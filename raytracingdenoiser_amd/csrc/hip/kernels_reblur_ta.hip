@@ -24,6 +24,7 @@ constexpr int BUF_STRIDE = BUF_X + 1;      // 35 float4 slots per row
 
 struct TaPlanes {
     Plane tiles, normalRoughness, viewZ, mv, prevViewZ, prevNormalRoughness, prevInternalData;
+    Plane decodedNR; // executor's float4 cache of normalRoughness (reblur_device.h "decoded guides")
     Plane inDiff, inSpec, historyDiff, historySpec, historyDiffFast, historySpecFast, prevSpecHitDistForTracking, inSpecHitDistForTracking;
     Plane outDiff, outSpec, outDiffFast, outSpecFast, outSpecHitDistForTracking, outData1, outData2;
 };
@@ -52,7 +53,7 @@ __global__ __launch_bounds__(TILE_X* TILE_Y) void ReblurTemporalAccumulationKern
         for (int i = threadIdx.x; i < BUF_X * BUF_Y; i += TILE_X * TILE_Y) {
             int lx = i % BUF_X, ly = i / BUF_X;
             int gx = ClampI(baseX + lx, 0, rw), gy = ClampI(baseY + ly, 0, rh);
-            s_Normal_Roughness[ly * BUF_STRIDE + lx] = UnpackNormalAndRoughness(LoadR10G10B10A2(P.normalRoughness, gx, gy));
+            s_Normal_Roughness[ly * BUF_STRIDE + lx] = LoadDecodedNormalRoughness(P.decodedNR, gx, gy);
             if (SPEC) {
                 float hitDist = c.gSpecPrepassBlurRadius == 0.0f ? LoadRGBA16F(P.inSpec, gx, gy).w : LoadR16F(P.inSpecHitDistForTracking, gx, gy);
                 s_HitDistForTracking[ly * BUF_STRIDE + lx] = hitDist == 0.0f ? NRD_INF : hitDist;
@@ -100,7 +101,7 @@ __global__ __launch_bounds__(TILE_X* TILE_Y) void ReblurTemporalAccumulationKern
     Navg = Navg / 4.0f;
 
     float materialID;
-    float4 normalAndRoughness = UnpackNormalAndRoughness(LoadR10G10B10A2(P.normalRoughness, px, py), materialID);
+    float4 normalAndRoughness = LoadDecodedNormalRoughness(P.decodedNR, px, py, materialID);
     float3 N = Xyz(normalAndRoughness);
     float roughness = normalAndRoughness.w;
 
@@ -308,7 +309,7 @@ __global__ __launch_bounds__(TILE_X* TILE_Y) void ReblurTemporalAccumulationKern
                 float3 xHigh = ReconstructViewPosition(motionUvHigh, frustum, zHigh, c.gOrthoMode);
                 xHigh = RotateVector(c.gViewToWorld, xHigh);
                 int2 tn = NearestTexel(P.normalRoughness, uvScaled);
-                float3 nHigh = Xyz(UnpackNormalAndRoughness(LoadR10G10B10A2(P.normalRoughness, tn.x, tn.y)));
+                float3 nHigh = Xyz(LoadDecodedNormalRoughness(P.decodedNR, tn.x, tn.y));
 
                 float zError = Abs(zHigh - viewZ) * Rcp(Max(zHigh, viewZ));
                 bool cmp = zError < NRD_CURVATURE_Z_THRESHOLD;
@@ -628,6 +629,9 @@ static const char* LaunchTemporalAccumulation(const PassArgs& a) {
     uint32_t k = 0;
     P.tiles = a.planes[k++];
     P.normalRoughness = a.planes[k++];
+    P.decodedNR = a.decodedNormalRoughness;
+    if (!P.decodedNR.ptr)
+        return "REBLUR TemporalAccumulation: the decoded normal/roughness cache is missing (IN_NORMAL_ROUGHNESS not bound?)";
     P.viewZ = a.planes[k++];
     P.mv = a.planes[k++];
     P.prevViewZ = a.planes[k++];

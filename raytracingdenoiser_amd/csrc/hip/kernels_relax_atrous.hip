@@ -24,6 +24,7 @@ constexpr int TILE_Y = RELAX_TILE_Y;
 struct AtrousPlanes {
     Plane tiles, historyLength, specReprojectionConfidence, normalRoughness, viewZ;
     Plane outNormalRoughness, outMaterialID, outViewZ; // AtrousSmem only
+    Plane decodedNR; // executor's float4 cache of normalRoughness (reblur_device.h "decoded guides")
     SignalPlanes spec, diff;
 };
 
@@ -50,7 +51,8 @@ bool BindAtrous(const PassArgs& a, AtrousPlanes& P) {
     }
     if (SH && SPEC) P.spec.outSh = cur.next();
     if (SH && DIFF) P.diff.outSh = cur.next();
-    return cur.complete();
+    P.decodedNR = a.decodedNormalRoughness;
+    return cur.complete() && P.decodedNR.ptr;
 }
 
 // per-pixel weight parameters shared by both flavours (confidence-driven relaxation included)
@@ -98,7 +100,7 @@ __global__ __launch_bounds__(256) void RelaxAtrousSmemKernel(AtrousPlanes P, Rel
             if (DIFF) s_Diff[li] = LoadRGBA16F(P.diff.in, gx, gy);
             if (DIFF && SH) s_DiffSH[li] = LoadRGBA16F(P.diff.inSh, gx, gy);
             float materialID;
-            s_Normal_Roughness[li] = UnpackNormalAndRoughness(LoadR10G10B10A2(P.normalRoughness, gx, gy), materialID);
+            s_Normal_Roughness[li] = LoadDecodedNormalRoughness(P.decodedNR, gx, gy, materialID);
             float viewZ = RelaxUnpackViewZ(c, LoadR32F(P.viewZ, gx, gy));
             s_WorldPos_MaterialID[li] = F4(GetCurrentWorldPosFromPixelPos(c, gx, gy, viewZ), materialID);
         }
@@ -393,7 +395,7 @@ __global__ __launch_bounds__(256) void RelaxAtrousKernel(AtrousPlanes P, RelaxCB
         return;
 
     float centerMaterialID;
-    const float4 centerNormalRoughness = UnpackNormalAndRoughness(LoadR10G10B10A2(P.normalRoughness, px, py), centerMaterialID);
+    const float4 centerNormalRoughness = LoadDecodedNormalRoughness(P.decodedNR, px, py, centerMaterialID);
     const float3 centerNormal = Xyz(centerNormalRoughness);
     const float centerRoughness = centerNormalRoughness.w;
     const float historyLength = 255.0f * LoadR8Unorm(P.historyLength, px, py);
@@ -487,7 +489,7 @@ __global__ __launch_bounds__(256) void RelaxAtrousKernel(AtrousPlanes P, RelaxCB
             const float kernelW = (xx == 0 ? 0.44198f : 0.27901f) * (yy == 0 ? 0.44198f : 0.27901f);
 
             float sampleMaterialID;
-            const float4 sampleNormalRoughness = UnpackNormalAndRoughness(LoadR10G10B10A2OrZero(P.normalRoughness, qx, qy), sampleMaterialID);
+            const float4 sampleNormalRoughness = LoadDecodedNormalRoughnessOrZero(P.decodedNR, qx, qy, sampleMaterialID);
             const float3 sampleNormal = Xyz(sampleNormalRoughness);
             const float sampleRoughness = sampleNormalRoughness.w;
             const float sampleViewZ = RelaxUnpackViewZ(c, LoadR32FOrZero(P.viewZ, qx, qy));

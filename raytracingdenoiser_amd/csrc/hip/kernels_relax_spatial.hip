@@ -58,6 +58,7 @@ const char* LaunchClassifyTiles(const PassArgs& a) {
 // ================================================================================================ PrePass
 struct PrePassPlanes {
     Plane tiles, normalRoughness, viewZ;
+    Plane decodedNR; // executor's float4 cache of normalRoughness (reblur_device.h "decoded guides")
     SignalPlanes spec, diff;
 };
 
@@ -91,7 +92,7 @@ __global__ __launch_bounds__(256) void RelaxPrePassKernel(PrePassPlanes P, Relax
         return;
 
     float centerMaterialID;
-    float4 centerNormalRoughness = UnpackNormalAndRoughness(LoadR10G10B10A2(P.normalRoughness, px, py), centerMaterialID);
+    float4 centerNormalRoughness = LoadDecodedNormalRoughness(P.decodedNR, px, py, centerMaterialID);
     float3 centerNormal = Xyz(centerNormalRoughness);
     float centerRoughness = centerNormalRoughness.w;
     float3 centerWorldPos = GetCurrentWorldPosFromPixelPos(c, px, py, centerViewZ);
@@ -121,7 +122,7 @@ __global__ __launch_bounds__(256) void RelaxPrePassKernel(PrePassPlanes P, Relax
                 PrePassTap t = MakeTap(c, P.viewZ, pixelUv, rectSize, rotator, i, blurRadius);
 
                 float sampleMaterialID;
-                float3 sampleNormal = Xyz(UnpackNormalAndRoughness(LoadR10G10B10A2(P.normalRoughness, t.texel.x, t.texel.y), sampleMaterialID));
+                float3 sampleNormal = Xyz(LoadDecodedNormalRoughness(P.decodedNR, t.texel.x, t.texel.y, sampleMaterialID));
                 float sampleViewZ = RelaxUnpackViewZ(c, LoadR32F(P.viewZ, t.texel.x, t.texel.y));
                 float3 sampleWorldPos = GetCurrentWorldPosFromClipSpaceXY(c, t.uv * 2.0f - 1.0f, sampleViewZ);
 
@@ -191,7 +192,7 @@ __global__ __launch_bounds__(256) void RelaxPrePassKernel(PrePassPlanes P, Relax
                 PrePassTap t = MakeTap(c, P.viewZ, pixelUv, rectSize, rotator, i, blurRadius);
 
                 float sampleMaterialID;
-                float4 sampleNormalRoughness = UnpackNormalAndRoughness(LoadR10G10B10A2(P.normalRoughness, t.texel.x, t.texel.y), sampleMaterialID);
+                float4 sampleNormalRoughness = LoadDecodedNormalRoughness(P.decodedNR, t.texel.x, t.texel.y, sampleMaterialID);
                 float3 sampleNormal = Xyz(sampleNormalRoughness);
                 float sampleRoughness = sampleNormalRoughness.w;
                 float sampleViewZ = RelaxUnpackViewZ(c, LoadR32F(P.viewZ, t.texel.x, t.texel.y));
@@ -252,8 +253,9 @@ const char* LaunchPrePass(const PassArgs& a) {
     if (DIFF) P.diff.out = cur.next();
     if (SH && SPEC) P.spec.outSh = cur.next();
     if (SH && DIFF) P.diff.outSh = cur.next();
-    if (!cur.complete())
-        return "RELAX PrePass: unexpected resource count";
+    P.decodedNR = a.decodedNormalRoughness;
+    if (!cur.complete() || !P.decodedNR.ptr)
+        return "RELAX PrePass: unexpected resource count or missing decoded normal/roughness cache";
     RelaxCB c = LoadRelaxConstants(a);
     RowGrid g = GridForRows(c.shared.gRectSize.x, c.shared.gRectSize.y, TILE_X, TILE_Y, a.rowBegin, a.rowEnd);
     hipLaunchKernelGGL((RelaxPrePassKernel<DIFF, SPEC, SH>), g.grid, dim3(256), 0, a.stream, P, c, RowRange{g.firstBlockY, g.rowBegin, g.rowEnd});
@@ -263,6 +265,7 @@ const char* LaunchPrePass(const PassArgs& a) {
 // ================================================================================================ HistoryFix
 struct HistoryFixPlanes {
     Plane tiles, historyLength, normalRoughness, viewZ;
+    Plane decodedNR;
     SignalPlanes spec, diff;
 };
 
@@ -281,7 +284,7 @@ __global__ __launch_bounds__(256) void RelaxHistoryFixKernel(HistoryFixPlanes P,
         return;
 
     float centerMaterialID;
-    float4 centerNormalRoughness = UnpackNormalAndRoughness(LoadR10G10B10A2(P.normalRoughness, px, py), centerMaterialID);
+    float4 centerNormalRoughness = LoadDecodedNormalRoughness(P.decodedNR, px, py, centerMaterialID);
     float3 centerNormal = Xyz(centerNormalRoughness);
     float centerRoughness = centerNormalRoughness.w;
     float3 centerWorldPos = GetCurrentWorldPosFromPixelPos(c, px, py, centerViewZ);
@@ -310,7 +313,7 @@ __global__ __launch_bounds__(256) void RelaxHistoryFixKernel(HistoryFixPlanes P,
                 continue;
 
             float sampleMaterialID;
-            float3 sampleNormal = Xyz(UnpackNormalAndRoughness(LoadR10G10B10A2OrZero(P.normalRoughness, sx, sy), sampleMaterialID));
+            float3 sampleNormal = Xyz(LoadDecodedNormalRoughnessOrZero(P.decodedNR, sx, sy, sampleMaterialID));
             float sampleViewZ = RelaxUnpackViewZ(c, LoadR32FOrZero(P.viewZ, sx, sy));
             float3 sampleWorldPos = GetCurrentWorldPosFromPixelPos(c, sx, sy, sampleViewZ);
             float geometryWeight = GetPlaneDistanceWeight_Atrous(centerWorldPos, centerNormal, sampleWorldPos, depthThreshold);
@@ -372,8 +375,9 @@ const char* LaunchHistoryFix(const PassArgs& a) {
     if (DIFF) P.diff.out = cur.next();
     if (SH && SPEC) P.spec.outSh = cur.next();
     if (SH && DIFF) P.diff.outSh = cur.next();
-    if (!cur.complete())
-        return "RELAX HistoryFix: unexpected resource count";
+    P.decodedNR = a.decodedNormalRoughness;
+    if (!cur.complete() || !P.decodedNR.ptr)
+        return "RELAX HistoryFix: unexpected resource count or missing decoded normal/roughness cache";
     RelaxCB c = LoadRelaxConstants(a);
     RowGrid g = GridForRows(c.shared.gRectSize.x, c.shared.gRectSize.y, TILE_X, TILE_Y, a.rowBegin, a.rowEnd);
     hipLaunchKernelGGL((RelaxHistoryFixKernel<DIFF, SPEC, SH>), g.grid, dim3(256), 0, a.stream, P, c, RowRange{g.firstBlockY, g.rowBegin, g.rowEnd});

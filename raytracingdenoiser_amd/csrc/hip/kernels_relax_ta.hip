@@ -31,6 +31,7 @@ constexpr int BUF_STRIDE = BUF_X + 1;      // 35
 struct TaPlanes {
     Plane tiles, mv, normalRoughness, viewZ, prevNormalRoughness, prevViewZ, prevSpecHitDist, prevHistoryLength, prevMaterialID, disocclusionThresholdMix;
     Plane outSpecHitDist, outHistoryLength, outSpecReprojectionConfidence;
+    Plane decodedNR; // executor's float4 cache of normalRoughness (reblur_device.h "decoded guides")
     SignalPlanes spec, diff;
 };
 
@@ -50,7 +51,7 @@ __global__ __launch_bounds__(256) void RelaxTemporalAccumulationKernel(TaPlanes 
     for (int idx = threadIdx.x; idx < ta::BUF_X * ta::BUF_Y; idx += 256) {
         int lx = idx % ta::BUF_X, ly = idx / ta::BUF_X;
         int gx = ClampI(blockIdx.x * TILE_X - ta::BORDER + lx, 0, rectW - 1), gy = ClampI(blockY * TILE_Y - ta::BORDER + ly, 0, rectH - 1);
-        float4 v = UnpackNormalAndRoughness(LoadR10G10B10A2(P.normalRoughness, gx, gy));
+        float4 v = LoadDecodedNormalRoughness(P.decodedNR, gx, gy);
         if (SPEC)
             v.w = LoadRGBA16F(P.spec.in, gx, gy).w;
         s_NormalSpecHitT[ly * ta::BUF_STRIDE + lx] = v;
@@ -68,7 +69,7 @@ __global__ __launch_bounds__(256) void RelaxTemporalAccumulationKernel(TaPlanes 
     auto Shared = [&](int dx, int dy) { return s_NormalSpecHitT[(ty + ta::BORDER + dy) * ta::BUF_STRIDE + (tx + ta::BORDER + dx)]; };
 
     float currentMaterialID;
-    float4 currentNormalRoughness = UnpackNormalAndRoughness(LoadR10G10B10A2(P.normalRoughness, px, py), currentMaterialID);
+    float4 currentNormalRoughness = LoadDecodedNormalRoughness(P.decodedNR, px, py, currentMaterialID);
     const float3 currentNormal = Xyz(currentNormalRoughness);
     const float currentRoughness = currentNormalRoughness.w;
 
@@ -326,7 +327,7 @@ __global__ __launch_bounds__(256) void RelaxTemporalAccumulationKernel(TaPlanes 
                 int2 q = NearestTexel(P.viewZ, uvScaled);
                 float zHigh = RelaxUnpackViewZ(c, LoadR32F(P.viewZ, q.x, q.y));
                 float3 xHigh = GetCurrentWorldPosFromClipSpaceXY(c, motionUvHigh * 2.0f - 1.0f, zHigh);
-                float3 nHigh = Xyz(UnpackNormalAndRoughness(LoadR10G10B10A2(P.normalRoughness, q.x, q.y)));
+                float3 nHigh = Xyz(LoadDecodedNormalRoughness(P.decodedNR, q.x, q.y));
                 float zError = Abs(zHigh - currentLinearZ) * Rcp(Max(zHigh, currentLinearZ));
                 bool cmp = zError < NRD_CURVATURE_Z_THRESHOLD;
                 n = cmp ? nHigh : n;
@@ -569,8 +570,9 @@ const char* LaunchTemporalAccumulation(const PassArgs& a) {
     if (SH && DIFF) P.diff.outSh = cur.next();
     if (SH && SPEC) P.spec.outFastSh = cur.next();
     if (SH && DIFF) P.diff.outFastSh = cur.next();
-    if (!cur.complete())
-        return "RELAX TemporalAccumulation: unexpected resource count";
+    P.decodedNR = a.decodedNormalRoughness;
+    if (!cur.complete() || !P.decodedNR.ptr)
+        return "RELAX TemporalAccumulation: unexpected resource count or missing decoded normal/roughness cache";
     RelaxCB c = LoadRelaxConstants(a);
     RowGrid g = GridForRows(c.shared.gRectSize.x, c.shared.gRectSize.y, TILE_X, TILE_Y, a.rowBegin, a.rowEnd);
     hipLaunchKernelGGL((RelaxTemporalAccumulationKernel<DIFF, SPEC, SH>), g.grid, dim3(256), 0, a.stream, P, c, RowRange{g.firstBlockY, g.rowBegin, g.rowEnd});

@@ -17,6 +17,9 @@ struct PassArgs {
     // rows [rowBegin, rowEnd) this rank has to produce in this pass (multi-GPU row-strip sharding; the whole frame by default).
     // Pixels outside are left untouched; planes stay full-size, so all neighbourhood reads keep their single-GPU meaning.
     int rowBegin, rowEnd;
+    // executor-internal cache of IN_NORMAL_ROUGHNESS decoded once per frame (float4 per texel: N.xyz, packed roughness | material
+    // bits -- reblur_device.h "decoded guides"); ptr == nullptr when the dispatch list does not bind IN_NORMAL_ROUGHNESS
+    Plane decodedNormalRoughness;
 };
 
 // returns nullptr on success, or a static message if the dispatch cannot be executed by this build (nothing is launched then)
@@ -32,6 +35,9 @@ const PassEntry* GetCommonPasses(uint32_t& num);
 const PassEntry* GetReblurPasses(uint32_t& num);
 const PassEntry* GetSigmaPasses(uint32_t& num);
 const PassEntry* GetRelaxPasses(uint32_t& num);
+
+// decodes a whole R10G10B10A2 normal+roughness plane into the float4 cache (kernels_common.hip)
+void LaunchDecodeNormalRoughness(const Plane& packed, const Plane& decoded, hipStream_t stream);
 
 inline dim3 GridFor(int w, int h, int tileW, int tileH) { return dim3((unsigned)((w + tileW - 1) / tileW), (unsigned)((h + tileH - 1) / tileH), 1); }
 

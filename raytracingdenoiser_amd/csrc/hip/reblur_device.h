@@ -253,6 +253,34 @@ NRD_D float2 GetTemporalAccumulationParams(const ReblurCB& c, float isInScreenMu
     return F2(w, 1.0f + 3.0f * c.gFramerateScale * w);
 }
 
+// ---- decoded guides ----------------------------------------------------------------------------------------------------
+// NRD_FrontEnd_UnpackNormalAndRoughness costs ~60 VALU instructions (oct decode, rsqrt = sqrt + divide) and the spatial passes
+// evaluate it at every tap of every pass. The executor therefore decodes IN_NORMAL_ROUGHNESS ONCE per frame into a float4 plane
+// (N.xyz as computed by UnpackNormalAndRoughness, w = the 12 roughness | materialID bits of the packed texel) and the kernels
+// fetch 16 bytes instead of re-deriving the normal: same values bit for bit, 4x the tap bytes (L2-served), ~55 instructions
+// less per tap -- the kernels are VALU-bound (profiles/), not bandwidth-bound.
+NRD_D float4 EncodeDecodedNormalRoughness(uint32_t raw) {
+    float unused;
+    float4 nr = UnpackNormalAndRoughness(DecodeR10G10B10A2(raw), unused);
+    return F4(nr.x, nr.y, nr.z, AsFloat(raw >> 20));
+}
+NRD_D float4 DecodedToNormalRoughness(float4 d, float& materialID) {
+    const uint32_t bits = AsUint(d.w);
+    materialID = NRD_DIV_3(float(bits >> 10)) * 3.0f; // = p.w * 3 of UnpackNormalAndRoughness
+    return F4(d.x, d.y, d.z, NRD_DIV_1023(float(bits & 0x3FFu)));
+}
+NRD_D float4 LoadDecodedNormalRoughness(const Plane& decoded, int x, int y, float& materialID) { return DecodedToNormalRoughness(LoadRGBA32F(decoded, x, y), materialID); }
+NRD_D float4 LoadDecodedNormalRoughness(const Plane& decoded, int x, int y) {
+    float unused;
+    return LoadDecodedNormalRoughness(decoded, x, y, unused);
+}
+// Texture2D::Load semantics: outside the plane the packed texel reads as 0
+NRD_D float4 LoadDecodedNormalRoughnessOrZero(const Plane& decoded, int x, int y, float& materialID) {
+    if (InBounds(decoded, x, y))
+        return LoadDecodedNormalRoughness(decoded, x, y, materialID);
+    return UnpackNormalAndRoughness(F4(0.0f), materialID);
+}
+
 // ---- clamp-addressed fetches (what a clamp sampler / gather does at the border) ------------------------------------------
 NRD_D int ClampI(int x, int a, int b) { return x < a ? a : (x > b ? b : x); }
 NRD_D float FetchClampedR32F(const Plane& p, int x, int y) { return LoadR32F(p, ClampI(x, 0, p.w - 1), ClampI(y, 0, p.h - 1)); }
