@@ -155,45 +155,42 @@ inline float2 GetTemporalAccumulationParams(const ReblurCB& c, float isInScreenM
 inline bool CompareMaterials(float m0, float m, float minm) { return max(m0, minm) == max(m, minm); } // Common.hlsli:226-230
 
 // ---- history fetch: Common.hlsli:602-656 + REBLUR_Common.hlsli:305-361 ----------------------------------------------
-// Catmull-Rom over 12 taps realised as 5 bilinear fetches, or -- if !useBicubic -- the 2x2 footprint with custom weights
+// The shaders realise Catmull-Rom over the 4x4-minus-corners footprint as 5 bilinear texture fetches (or -- if !useBicubic --
+// the 2x2 footprint with custom weights). Each of those fetches is restated here on the texels it actually blends:
+//   fetch 0 / 4 : rows j-1 / j+2, columns k, k+1, horizontal fraction tc.x      (their vertical fraction is exactly 0)
+//   fetch 1 / 3 : columns k-1 / k+2, rows j, j+1, vertical fraction tc.y        (their horizontal fraction is exactly 0)
+//   fetch 2     : the central 2x2 at fractions (tc.x, tc.y)
+// i.e. 12 distinct texels with (k, j) = floor(samplePos - 0.5); texel coordinates clamp to the plane like the sampler does.
+// The fractions are tc itself (a texture unit would quantise them to 8 bits; we keep fp32).
 struct HistoryFilter {
-    float4 w;      // 4 bilinear-fetch weights (bicubic) or the custom bilinear weights
-    float w4;
+    float4 w;      // weights of fetches 0..3 (bicubic) or the custom bilinear weights of the 2x2 footprint
+    float w4;      // weight of fetch 4 (0 without bicubic)
     float sum;
-    float2 p0, p1, p2, p3, p4; // fetch positions in TEXEL units
-    int ox, oy;    // bilinear origin
+    float2 tc;     // bilinear fractions inside the central 2x2
+    int kx, ky;    // (k, j): floor-based origin of the central 2x2 (clamp-addressed fetches)
+    int ox, oy;    // origin as the shaders' Load-based bilinear path computes it: int( centerPos ), truncation
     float4 bw;     // custom bilinear weights
     bool useBicubic;
 };
 inline HistoryFilter MakeHistoryFilter(float2 samplePos, float4 bilinearCustomWeights, bool useBicubic) {
     const float S = NRD_CATROM_SHARPNESS;
     HistoryFilter h;
-    float2 centerPos = floor(samplePos - 0.5f) + 0.5f;
+    float2 origin = floor(samplePos - 0.5f);
+    float2 centerPos = origin + 0.5f;
     float2 f = saturate(samplePos - centerPos);
     float2 w0 = f * (f * (-S * f + 2.0f * S) - S);
     float2 w1 = f * (f * ((2.0f - S) * f - (3.0f - S))) + 1.0f;
     float2 w2 = f * (f * (-(2.0f - S) * f + (3.0f - 2.0f * S)) + S);
     float2 w3 = f * (f * (S * f - S));
     float2 w12 = w1 + w2;
-    float2 tc = w2 / w12;
     float4 w = float4(w12.x * w0.y, w0.x * w12.y, w12.x * w12.y, w3.x * w12.y);
     float w4 = w12.x * w3.y;
     h.w = useBicubic ? w : bilinearCustomWeights;
     h.w4 = useBicubic ? w4 : 0.0f;
     h.sum = sum(h.w) + h.w4;
-    if (useBicubic) {
-        h.p0 = centerPos + float2(tc.x, -1.0f);
-        h.p1 = centerPos + float2(-1.0f, tc.y);
-        h.p2 = centerPos + float2(tc.x, tc.y);
-        h.p3 = centerPos + float2(2.0f, tc.y);
-        h.p4 = centerPos + float2(tc.x, 2.0f);
-    } else {
-        h.p0 = centerPos;
-        h.p1 = centerPos + float2(1.0f, 0.0f);
-        h.p2 = centerPos + float2(0.0f, 1.0f);
-        h.p3 = centerPos + float2(1.0f, 1.0f);
-        h.p4 = centerPos + f;
-    }
+    h.tc = w2 / w12;
+    h.kx = (int)origin.x;
+    h.ky = (int)origin.y;
     h.ox = (int)centerPos.x; // int3( centerPos, 0 ): truncation of k + 0.5
     h.oy = (int)centerPos.y;
     h.bw = bilinearCustomWeights;
@@ -201,11 +198,26 @@ inline HistoryFilter MakeHistoryFilter(float2 samplePos, float4 bilinearCustomWe
     return h;
 }
 inline float4 FetchHistoryColor(const HistoryFilter& h, const Tex& tex) {
-    float4 color = tex.SampleLinearTexel(h.p0) * h.w.x;
-    color += tex.SampleLinearTexel(h.p1) * h.w.y;
-    color += tex.SampleLinearTexel(h.p2) * h.w.z;
-    color += tex.SampleLinearTexel(h.p3) * h.w.w;
-    color += tex.SampleLinearTexel(h.p4) * h.w4;
+    auto T = [&](int dx, int dy) { return tex.FetchClamped(h.kx + dx, h.ky + dy); };
+    float4 color;
+    if (h.useBicubic) {
+        float fx = h.tc.x, fy = h.tc.y, gx = 1.0f - fx, gy = 1.0f - fy;
+        float4 s0 = T(0, -1) * gx + T(1, -1) * fx;
+        float4 s1 = T(-1, 0) * gy + T(-1, 1) * fy;
+        float4 s2 = T(0, 0) * (gx * gy) + T(1, 0) * (fx * gy) + T(0, 1) * (gx * fy) + T(1, 1) * (fx * fy);
+        float4 s3 = T(2, 0) * gy + T(2, 1) * fy;
+        float4 s4 = T(0, 2) * gx + T(1, 2) * fx;
+        color = s0 * h.w.x;
+        color += s1 * h.w.y;
+        color += s2 * h.w.z;
+        color += s3 * h.w.w;
+        color += s4 * h.w4;
+    } else {
+        color = T(0, 0) * h.w.x;
+        color += T(1, 0) * h.w.y;
+        color += T(0, 1) * h.w.z;
+        color += T(1, 1) * h.w.w;
+    }
     return h.sum < 0.0001f ? float4(0.0f) : color / h.sum;
 }
 inline float4 FetchHistoryBilinear(const HistoryFilter& h, const Tex& tex) {

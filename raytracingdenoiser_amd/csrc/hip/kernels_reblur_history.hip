@@ -389,7 +389,7 @@ __global__ __launch_bounds__(TILE_X* TILE_Y) void ReblurTemporalStabilizationKer
         float diffLuma, diffLumaM1, diffLumaSigma;
         LumaStats(c, s_DiffLuma, tx, ty, diffLuma, diffLumaM1, diffLumaSigma);
 
-        HistoryFilter smbFilter = MakeHistoryFilter(smbSamplePos, smbOcclusionWeights, smbAllowCatRom);
+        HistoryFilter smbFilter = MakeHistoryFilter(smbSamplePos, smbOcclusionWeights, smbAllowCatRom, P.historyDiffLuma);
         float smbDiffLumaHistory = FetchHistoryR16F(smbFilter, P.historyDiffLuma);
         smbDiffLumaHistory = Max(smbDiffLumaHistory, 0.0f);
 
@@ -431,7 +431,7 @@ __global__ __launch_bounds__(TILE_X* TILE_Y) void ReblurTemporalStabilizationKer
         float2 vmbPixelUv = GetScreenUv(c.gWorldToClipPrev, Xvirtual);
         vmbPixelUv = materialID == c.gCameraAttachedReflectionMaterialID ? pixelUv : vmbPixelUv;
 
-        HistoryFilter smbFilter = MakeHistoryFilter(smbSamplePos, smbOcclusionWeights, smbAllowCatRom);
+        HistoryFilter smbFilter = MakeHistoryFilter(smbSamplePos, smbOcclusionWeights, smbAllowCatRom, P.historySpecLuma);
         float smbSpecLumaHistory = FetchHistoryR16F(smbFilter, P.historySpecLuma);
 
         Bilinear vmbBilinearFilter = GetBilinearFilter(vmbPixelUv, rectSizePrev);
@@ -441,7 +441,7 @@ __global__ __launch_bounds__(TILE_X* TILE_Y) void ReblurTemporalStabilizationKer
         float vmbFootprintQuality = ApplyBilinearFilter(vmbOcclusion.x, vmbOcclusion.y, vmbOcclusion.z, vmbOcclusion.w, vmbBilinearFilter);
         vmbFootprintQuality = Sqrt01(vmbFootprintQuality);
 
-        HistoryFilter vmbFilter = MakeHistoryFilter(Sat(vmbPixelUv) * rectSizePrev, vmbOcclusionWeights, vmbAllowCatRom);
+        HistoryFilter vmbFilter = MakeHistoryFilter(Sat(vmbPixelUv) * rectSizePrev, vmbOcclusionWeights, vmbAllowCatRom, P.historySpecLuma);
         float vmbSpecLumaHistory = FetchHistoryR16F(vmbFilter, P.historySpecLuma);
 
         smbSpecLumaHistory = Max(smbSpecLumaHistory, 0.0f);

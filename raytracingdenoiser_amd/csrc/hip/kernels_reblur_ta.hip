@@ -474,7 +474,7 @@ __global__ __launch_bounds__(TILE_X* TILE_Y) void ReblurTemporalAccumulationKern
         virtualHistoryAmount *= virtualHistoryRoughnessBasedConfidence;
 
         // Sample surface history
-        HistoryFilter smbFilter = MakeHistoryFilter(smbSamplePos, smbOcclusionWeights, smbAllowCatRom);
+        HistoryFilter smbFilter = MakeHistoryFilter(smbSamplePos, smbOcclusionWeights, smbAllowCatRom, P.historySpec);
         float4 smbSpecHistory = FetchHistoryRGBA16F(smbFilter, P.historySpec);
         float smbSpecFastHistory = FetchHistoryBilinearR16F(smbFilter, P.historySpecFast);
 
@@ -526,7 +526,7 @@ __global__ __launch_bounds__(TILE_X* TILE_Y) void ReblurTemporalAccumulationKern
         virtualHistoryAmount = Sat(virtualHistoryAmount);
 
         // Sample virtual history
-        HistoryFilter vmbFilter = MakeHistoryFilter(Sat(vmbPixelUv) * rectSizePrev, vmbOcclusionWeights, vmbAllowCatRom);
+        HistoryFilter vmbFilter = MakeHistoryFilter(Sat(vmbPixelUv) * rectSizePrev, vmbOcclusionWeights, vmbAllowCatRom, P.historySpec);
         float4 vmbSpecHistory = FetchHistoryRGBA16F(vmbFilter, P.historySpec);
         float vmbSpecFastHistory = FetchHistoryBilinearR16F(vmbFilter, P.historySpecFast);
 
@@ -584,7 +584,7 @@ __global__ __launch_bounds__(TILE_X* TILE_Y) void ReblurTemporalAccumulationKern
 
         float4 diff = LoadRGBA16F(P.inDiff, px, py);
 
-        HistoryFilter smbFilter = MakeHistoryFilter(smbSamplePos, smbOcclusionWeights, smbAllowCatRom);
+        HistoryFilter smbFilter = MakeHistoryFilter(smbSamplePos, smbOcclusionWeights, smbAllowCatRom, P.historyDiff);
         float4 smbDiffHistory = FetchHistoryRGBA16F(smbFilter, P.historyDiff);
         float smbDiffFastHistory = FetchHistoryBilinearR16F(smbFilter, P.historyDiffFast);
         smbDiffHistory = ClampNegativeToZero(smbDiffHistory);

@@ -194,7 +194,7 @@ __global__ __launch_bounds__(256) void RelaxTemporalAccumulationKernel(TaPlanes 
         const float4 bilinearCustomWeights = GetBilinearCustomWeights(bilinear, bilinearTapsValid);
         const bool useBicubic = bicubicFootprintValid > 0.0f;
 
-        const HistoryFilter hf = MakeHistoryFilter(prevPixelPosFloat, bilinearCustomWeights, useBicubic);
+        const HistoryFilter hf = MakeHistoryFilter(prevPixelPosFloat, bilinearCustomWeights, useBicubic, SPEC ? P.spec.prev : P.diff.prev);
         if (DIFF) {
             prevDiffuseIllumAnd2ndMomentSMB = Max0(FetchHistoryRGBA16F(hf, P.diff.prev));
             prevDiffuseResponsiveSMB = Xyz(Max0(FetchHistoryRGBA16F(hf, P.diff.fast)));
@@ -385,7 +385,7 @@ __global__ __launch_bounds__(256) void RelaxTemporalAccumulationKernel(TaPlanes 
                 const float4 bilinearCustomWeights = GetBilinearCustomWeights(bilinear, bilinearTapsValid);
                 const bool useBicubic = SMBReprojectionFound == 2.0f && allValid;
 
-                const HistoryFilter hf = MakeHistoryFilter(prevVirtualPixelPosFloat, bilinearCustomWeights, useBicubic);
+                const HistoryFilter hf = MakeHistoryFilter(prevVirtualPixelPosFloat, bilinearCustomWeights, useBicubic, P.spec.prev);
                 prevSpecularIllumAnd2ndMomentVMB = Max0(FetchHistoryRGBA16F(hf, P.spec.prev));
                 prevSpecularResponsiveVMB = Max0(FetchHistoryRGBA16F(hf, P.spec.fast));
                 if (SH) {

@@ -402,19 +402,8 @@ NRD_D uint32_t PackViewZAndHistoryLength(float viewZ, float historyLength) {
     return p;
 }
 NRD_D uint32_t FetchClampedR32U(const Plane& p, int x, int y) { return LoadR32U(p, ClampI(x, 0, p.w - 1), ClampI(y, 0, p.h - 1)); }
-NRD_D float FetchClampedR8Unorm(const Plane& p, int x, int y) { return LoadR8Unorm(p, ClampI(x, 0, p.w - 1), ClampI(y, 0, p.h - 1)); }
-NRD_D float SampleLinearR8Unorm(const Plane& p, float2 pos) {
-    LinearTaps t = MakeLinearTaps(pos);
-    float s00 = FetchClampedR8Unorm(p, t.x0, t.y0), s10 = FetchClampedR8Unorm(p, t.x0 + 1, t.y0), s01 = FetchClampedR8Unorm(p, t.x0, t.y0 + 1), s11 = FetchClampedR8Unorm(p, t.x0 + 1, t.y0 + 1);
-    return s00 * t.w00 + s10 * t.w10 + s01 * t.w01 + s11 * t.w11;
-}
 NRD_D float FetchHistoryR8Unorm(const HistoryFilter& h, const Plane& tex) {
-    float color = SampleLinearR8Unorm(tex, h.p0) * h.w.x;
-    color += SampleLinearR8Unorm(tex, h.p1) * h.w.y;
-    color += SampleLinearR8Unorm(tex, h.p2) * h.w.z;
-    color += SampleLinearR8Unorm(tex, h.p3) * h.w.w;
-    color += SampleLinearR8Unorm(tex, h.p4) * h.w4;
-    return h.sum < 0.0001f ? 0.0f : color / h.sum;
+    return FetchHistoryGeneric<float>(h, tex, [](const Plane& p, int x, int y) { return LoadR8Unorm(p, x, y); }, 0.0f);
 }
 
 __global__ __launch_bounds__(TILE_X* TILE_Y) void SigmaTemporalStabilizationKernel(SigmaCB c, TsPlanes P) {
@@ -524,7 +513,7 @@ __global__ __launch_bounds__(TILE_X* TILE_Y) void SigmaTemporalStabilizationKern
     float historyLength = ApplyBilinearCustomWeights(prevHistoryLength.x, prevHistoryLength.y, prevHistoryLength.z, prevHistoryLength.w, smbOcclusionWeights);
 
     bool isCatRomAllowed = Sum(smbOcclusionWeights) > 3.5f; // never true (weights sum to <= 1): kept as in the reference
-    HistoryFilter hf = MakeHistoryFilter(Sat(smbPixelUv) * rectSizePrev, smbOcclusionWeights, isCatRomAllowed);
+    HistoryFilter hf = MakeHistoryFilter(Sat(smbPixelUv) * rectSizePrev, smbOcclusionWeights, isCatRomAllowed, P.history);
     float history = FetchHistoryR8Unorm(hf, P.history);
     history = Sat(history);
     history = UnpackShadow(history);

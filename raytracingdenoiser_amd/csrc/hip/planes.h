@@ -24,10 +24,11 @@ struct Plane {
 
 NRD_D bool InBounds(const Plane& p, int x, int y) { return (unsigned)x < (unsigned)p.w && (unsigned)y < (unsigned)p.h; }
 
-// 32-bit byte offsets (planes are far below 4 GiB): one v_mad_u32 instead of 64-bit multiply-adds per access
+// 32-bit byte offsets (planes are far below 4 GiB) from a 24-bit multiply (row index and pitch are both < 2^24): one full-rate
+// v_mad_u32_u24 instead of a quarter-rate v_mul_lo_u32 or 64-bit multiply-adds per access
 template <typename T>
 NRD_D T* TexelPtr(const Plane& p, int x, int y) {
-    return (T*)(p.ptr + ((uint32_t)y * p.pitch + (uint32_t)x * (uint32_t)sizeof(T)));
+    return (T*)(p.ptr + (__umul24((uint32_t)y, p.pitch) + (uint32_t)x * (uint32_t)sizeof(T)));
 }
 
 // k / c for a small non-negative integer k held in a float, bit-identical to the IEEE quotient but 3 VALU ops instead

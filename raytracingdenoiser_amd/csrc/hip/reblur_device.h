@@ -328,63 +328,82 @@ NRD_D float SampleLinearR16F(const Plane& p, float2 pos) {
     return s00 * t.w00 + s10 * t.w10 + s01 * t.w01 + s11 * t.w11;
 }
 
-// ---- history fetch: Catmull-Rom (12 taps as 5 bilinear fetches) with fallback to custom-weight bilinear ---------------------
+// ---- history fetch: Catmull-Rom with fallback to custom-weight bilinear -----------------------------------------------------
+// The shaders realise Catmull-Rom over the 4x4-minus-corners footprint as 5 bilinear texture fetches. A texture unit does the
+// 20 texel reads for free; here every read is address arithmetic + a load + fp16 conversions, and TemporalAccumulation does
+// 6 such fetches per pixel. Each fetch is therefore restated on the texels it actually blends (the other taps of fetches 0, 1,
+// 3, 4 have weight exactly 0): 12 distinct texels, (k, j) = floor(samplePos - 0.5), clamp-addressed like the sampler;
+//   fetch 0 / 4 : rows j-1 / j+2, columns k, k+1, fraction tc.x        fetch 1 / 3 : columns k-1 / k+2, rows j, j+1, fraction tc.y
+//   fetch 2     : central 2x2 at (tc.x, tc.y)
+// and the clamped coordinates are computed once per footprint and shared by every plane fetched through it.
 struct HistoryFilter {
-    float4 w;
+    float4 w;       // weights of fetches 0..3 (bicubic) or the custom bilinear weights of the 2x2 footprint
     float w4, sum;
-    float2 p0, p1, p2, p3, p4; // texel units
-    int ox, oy;
+    float2 tc;      // bilinear fractions inside the central 2x2
+    int x[4], y[4]; // clamped texel coordinates k-1 .. k+2, j-1 .. j+2
+    int ox, oy;     // origin of the shaders' Load-based bilinear path: int( centerPos ), truncation
     float4 bw;
+    bool useBicubic;
 };
-NRD_D HistoryFilter MakeHistoryFilter(float2 samplePos, float4 bilinearCustomWeights, bool useBicubic) {
+NRD_D HistoryFilter MakeHistoryFilter(float2 samplePos, float4 bilinearCustomWeights, bool useBicubic, const Plane& dims) {
     const float S = NRD_CATROM_SHARPNESS;
     HistoryFilter h;
-    float2 centerPos = Floor(samplePos - 0.5f) + 0.5f;
+    float2 origin = Floor(samplePos - 0.5f);
+    float2 centerPos = origin + 0.5f;
     float2 f = Sat(samplePos - centerPos);
     float2 w0 = f * (f * (f * -S + 2.0f * S) - S);
     float2 w1 = f * (f * (f * (2.0f - S) - (3.0f - S))) + 1.0f;
     float2 w2 = f * (f * (f * -(2.0f - S) + (3.0f - 2.0f * S)) + S);
     float2 w3 = f * (f * (f * S - S));
     float2 w12 = w1 + w2;
-    float2 tc = w2 / w12;
     float4 w = F4(w12.x * w0.y, w0.x * w12.y, w12.x * w12.y, w3.x * w12.y);
     float w4 = w12.x * w3.y;
     h.w = useBicubic ? w : bilinearCustomWeights;
     h.w4 = useBicubic ? w4 : 0.0f;
     h.sum = Sum(h.w) + h.w4;
-    if (useBicubic) {
-        h.p0 = centerPos + F2(tc.x, -1.0f);
-        h.p1 = centerPos + F2(-1.0f, tc.y);
-        h.p2 = centerPos + F2(tc.x, tc.y);
-        h.p3 = centerPos + F2(2.0f, tc.y);
-        h.p4 = centerPos + F2(tc.x, 2.0f);
-    } else {
-        h.p0 = centerPos;
-        h.p1 = centerPos + F2(1.0f, 0.0f);
-        h.p2 = centerPos + F2(0.0f, 1.0f);
-        h.p3 = centerPos + F2(1.0f, 1.0f);
-        h.p4 = centerPos + f;
+    h.tc = w2 / w12;
+    const int kx = (int)origin.x, ky = (int)origin.y;
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        h.x[i] = ClampI(kx - 1 + i, 0, dims.w - 1);
+        h.y[i] = ClampI(ky - 1 + i, 0, dims.h - 1);
     }
     h.ox = (int)centerPos.x;
     h.oy = (int)centerPos.y;
     h.bw = bilinearCustomWeights;
+    h.useBicubic = useBicubic;
     return h;
 }
+// V = float4 / float; load(plane, x, y) reads one in-bounds texel
+template <typename V, typename LoadFn>
+NRD_D V FetchHistoryGeneric(const HistoryFilter& h, const Plane& tex, LoadFn load, V zero) {
+    const V t00 = load(tex, h.x[1], h.y[1]), t10 = load(tex, h.x[2], h.y[1]), t01 = load(tex, h.x[1], h.y[2]), t11 = load(tex, h.x[2], h.y[2]);
+    V color;
+    if (h.useBicubic) {
+        const float fx = h.tc.x, fy = h.tc.y, gx = 1.0f - fx, gy = 1.0f - fy;
+        V s0 = load(tex, h.x[1], h.y[0]) * gx + load(tex, h.x[2], h.y[0]) * fx;
+        V s1 = load(tex, h.x[0], h.y[1]) * gy + load(tex, h.x[0], h.y[2]) * fy;
+        V s2 = t00 * (gx * gy) + t10 * (fx * gy) + t01 * (gx * fy) + t11 * (fx * fy);
+        V s3 = load(tex, h.x[3], h.y[1]) * gy + load(tex, h.x[3], h.y[2]) * fy;
+        V s4 = load(tex, h.x[1], h.y[3]) * gx + load(tex, h.x[2], h.y[3]) * fx;
+        color = s0 * h.w.x;
+        color = color + s1 * h.w.y;
+        color = color + s2 * h.w.z;
+        color = color + s3 * h.w.w;
+        color = color + s4 * h.w4;
+    } else {
+        color = t00 * h.w.x;
+        color = color + t10 * h.w.y;
+        color = color + t01 * h.w.z;
+        color = color + t11 * h.w.w;
+    }
+    return h.sum < 0.0001f ? zero : color / h.sum;
+}
 NRD_D float4 FetchHistoryRGBA16F(const HistoryFilter& h, const Plane& tex) {
-    float4 color = SampleLinearRGBA16F(tex, h.p0) * h.w.x;
-    color = color + SampleLinearRGBA16F(tex, h.p1) * h.w.y;
-    color = color + SampleLinearRGBA16F(tex, h.p2) * h.w.z;
-    color = color + SampleLinearRGBA16F(tex, h.p3) * h.w.w;
-    color = color + SampleLinearRGBA16F(tex, h.p4) * h.w4;
-    return h.sum < 0.0001f ? F4(0.0f) : color / h.sum;
+    return FetchHistoryGeneric<float4>(h, tex, [](const Plane& p, int x, int y) { return LoadRGBA16F(p, x, y); }, F4(0.0f));
 }
 NRD_D float FetchHistoryR16F(const HistoryFilter& h, const Plane& tex) {
-    float color = SampleLinearR16F(tex, h.p0) * h.w.x;
-    color += SampleLinearR16F(tex, h.p1) * h.w.y;
-    color += SampleLinearR16F(tex, h.p2) * h.w.z;
-    color += SampleLinearR16F(tex, h.p3) * h.w.w;
-    color += SampleLinearR16F(tex, h.p4) * h.w4;
-    return h.sum < 0.0001f ? 0.0f : color / h.sum;
+    return FetchHistoryGeneric<float>(h, tex, [](const Plane& p, int x, int y) { return LoadR16F(p, x, y); }, 0.0f);
 }
 NRD_D float FetchHistoryBilinearR16F(const HistoryFilter& h, const Plane& tex) {
     float color = LoadR16FOrZero(tex, h.ox, h.oy) * h.bw.x;
