@@ -30,14 +30,28 @@ struct TaPlanes {
 };
 
 template <bool DIFF, bool SPEC>
-__global__ __launch_bounds__(TILE_X* TILE_Y) void ReblurTemporalAccumulationKernel(ReblurCB c, TaPlanes P, RowRange rr) {
+__global__ __launch_bounds__(TILE_X* TILE_Y, 3) void ReblurTemporalAccumulationKernel(ReblurCB cArg, TaPlanes P, RowRange rr) {
     __shared__ float4 s_Normal_Roughness[BUF_Y * BUF_STRIDE];
+    // The 832-byte constant block + ~20 planes need > 200 SGPRs (102 exist), which the compiler resolves by spilling scalars into
+    // VGPR lanes (v_writelane / v_readlane + hazard nops on every use). The body therefore reads the constants from an LDS copy
+    // (uniform-address ds_read, off the VALU); only the prologue touches the kernel-argument copy.
+    __shared__ ReblurCB s_Constants;
+
+    // SGPR diet (planes.h): one (w, h) for every full-resolution plane, one pitch per pool format; verified by the launcher
+    {
+        const Plane size = P.viewZ, rgba16 = DIFF ? P.historyDiff : P.historySpec, r16 = DIFF ? P.historyDiffFast : P.historySpecFast;
+        ShareSize(P.decodedNR, size), ShareSize(P.mv, size), ShareSize(P.prevViewZ, size), ShareSize(P.prevNormalRoughness, size), ShareSize(P.prevInternalData, size);
+        ShareSize(P.inDiff, size), ShareSize(P.inSpec, size), ShareSize(P.inSpecHitDistForTracking, size), ShareSize(P.outData1, size), ShareSize(P.outData2, size);
+        ShareLayout(P.historyDiff, rgba16), ShareLayout(P.historySpec, rgba16), ShareLayout(P.outDiff, rgba16), ShareLayout(P.outSpec, rgba16);
+        ShareLayout(P.historyDiffFast, r16), ShareLayout(P.historySpecFast, r16), ShareLayout(P.prevSpecHitDistForTracking, r16), ShareLayout(P.outDiffFast, r16), ShareLayout(P.outSpecFast, r16),
+            ShareLayout(P.outSpecHitDistForTracking, r16);
+    }
     __shared__ float s_HitDistForTracking[BUF_Y * BUF_STRIDE];
 
     const int tx = threadIdx.x % TILE_X, ty = threadIdx.x / TILE_X;
     const int blockY = blockIdx.y + rr.firstBlockY;
     const int px = blockIdx.x * TILE_X + tx, py = blockY * TILE_Y + ty;
-    const int rw = c.gRectSizeMinusOne.x, rh = c.gRectSizeMinusOne.y;
+    const int rw = cArg.gRectSizeMinusOne.x, rh = cArg.gRectSizeMinusOne.y;
 
     // ---- cooperative preload (clamped to the rect), skipped when every 16x16 tile under this block is sky
     {
@@ -55,12 +69,20 @@ __global__ __launch_bounds__(TILE_X* TILE_Y) void ReblurTemporalAccumulationKern
             int gx = ClampI(baseX + lx, 0, rw), gy = ClampI(baseY + ly, 0, rh);
             s_Normal_Roughness[ly * BUF_STRIDE + lx] = LoadDecodedNormalRoughness(P.decodedNR, gx, gy);
             if (SPEC) {
-                float hitDist = c.gSpecPrepassBlurRadius == 0.0f ? LoadRGBA16F(P.inSpec, gx, gy).w : LoadR16F(P.inSpecHitDistForTracking, gx, gy);
+                float hitDist = cArg.gSpecPrepassBlurRadius == 0.0f ? LoadRGBA16F(P.inSpec, gx, gy).w : LoadR16F(P.inSpecHitDistForTracking, gx, gy);
                 s_HitDistForTracking[ly * BUF_STRIDE + lx] = hitDist == 0.0f ? NRD_INF : hitDist;
             }
         }
+        // constants: kernel-argument segment (cArg is the first argument, offset 0) -> LDS, one dword per thread
+        const uint32_t __attribute__((address_space(4)))* kernarg = (const uint32_t __attribute__((address_space(4)))*)__builtin_amdgcn_kernarg_segment_ptr();
+        if (threadIdx.x < sizeof(ReblurCB) / 4)
+            ((uint32_t*)&s_Constants)[threadIdx.x] = kernarg[threadIdx.x];
     }
     __syncthreads();
+    const ReblurCB& c = s_Constants;
+// Constants are re-read from LDS after each phase boundary instead of being kept in VGPRs for the whole kernel (a compiler
+// memory barrier: the LDS loads cannot be hoisted above it)
+#define NRD_CONSTANTS_PHASE() asm volatile("" ::: "memory")
 
     if (px > rw || py > rh || py < rr.rowBegin || py >= rr.rowEnd)
         return;
@@ -121,6 +143,7 @@ __global__ __launch_bounds__(TILE_X* TILE_Y) void ReblurTemporalAccumulationKern
         StoreR16F(P.outSpecHitDistForTracking, px, py, hitDistForTracking);
     }
 
+    NRD_CONSTANTS_PHASE();
     // Previous position and surface motion uv
     float4 mvRaw = LoadRGBA16F(P.mv, px, py);
     float3 mv = F3(mvRaw.x, mvRaw.y, mvRaw.z) * F3(c.gMvScale.x, c.gMvScale.y, c.gMvScale.z);
@@ -171,6 +194,7 @@ __global__ __launch_bounds__(TILE_X* TILE_Y) void ReblurTemporalAccumulationKern
     }
     smbNavg = RotateVector(c.gWorldPrevToWorld, smbNavg);
 
+    NRD_CONSTANTS_PHASE();
     // Parallax
     float smbParallaxInPixels1 = ComputeParallaxInPixels(Xprev + cameraDelta, c.gOrthoMode == 0.0f ? smbPixelUv : pixelUv, c.gWorldToClipPrev, rectSize);
     float smbParallaxInPixels2 = ComputeParallaxInPixels(Xprev - cameraDelta, c.gOrthoMode == 0.0f ? pixelUv : smbPixelUv, c.gWorldToClip, rectSize);
@@ -222,6 +246,7 @@ __global__ __launch_bounds__(TILE_X* TILE_Y) void ReblurTemporalAccumulationKern
 #undef MATCMP
     const uint32_t smbInternalData0 = id0[3], smbInternalData1 = id1[2], smbInternalData2 = id2[1], smbInternalData3 = id3[0];
 
+    NRD_CONSTANTS_PHASE();
     // 2x2 occlusion weights
     float4 smbOcclusionWeights = GetBilinearCustomWeights(smbBilinearFilter, F4(smbOcclusion0.z, smbOcclusion1.y, smbOcclusion2.y, smbOcclusion3.x));
     float3 occSum = smbOcclusion0 + smbOcclusion1 + smbOcclusion2 + smbOcclusion3;
@@ -254,6 +279,43 @@ __global__ __launch_bounds__(TILE_X* TILE_Y) void ReblurTemporalAccumulationKern
 
     const float2 smbSamplePos = Sat(smbPixelUv) * rectSizePrev;
 
+    NRD_CONSTANTS_PHASE();
+    // ------------------------------------------------------------------------------------------------ diffuse
+    // (before the long specular section: everything the diffuse part needs from the shared footprint dies here, not after it)
+    if (DIFF) {
+        float diffHistoryConfidence = smbFootprintQuality;
+        diffAccumSpeed *= Lerp(diffHistoryConfidence, 1.0f, 1.0f / (1.0f + diffAccumSpeed));
+        diffAccumSpeed = Min(diffAccumSpeed, c.gMaxAccumulatedFrameNum);
+
+        float4 diff = LoadRGBA16F(P.inDiff, px, py);
+
+        HistoryFilter smbFilter = MakeHistoryFilter(smbSamplePos, smbOcclusionWeights, smbAllowCatRom, P.historyDiff);
+        float4 smbDiffHistory = FetchHistoryRGBA16F(smbFilter, P.historyDiff);
+        float smbDiffFastHistory = FetchHistoryBilinearR16F(smbFilter, P.historyDiffFast);
+        smbDiffHistory = ClampNegativeToZero(smbDiffHistory);
+
+        float diffNonLinearAccumSpeed = 1.0f / (1.0f + diffAccumSpeed);
+        float4 diffResult = MixHistoryAndCurrent(c, smbDiffHistory, diff, diffNonLinearAccumSpeed);
+
+        float diffMaxRelativeIntensity = c.gFireflySuppressorMinRelativeScale + REBLUR_FIREFLY_SUPPRESSOR_MAX_RELATIVE_INTENSITY / (diffAccumSpeed + 1.0f);
+        float diffAntifireflyFactor = diffAccumSpeed * c.gMaxBlurRadius * REBLUR_FIREFLY_SUPPRESSOR_RADIUS_SCALE;
+        diffAntifireflyFactor /= 1.0f + diffAntifireflyFactor;
+
+        float diffLumaResult = GetLuma(diffResult);
+        float diffLumaClamped = Min(diffLumaResult, GetLuma(smbDiffHistory) * diffMaxRelativeIntensity);
+        diffLumaClamped = Lerp(diffLumaResult, diffLumaClamped, diffAntifireflyFactor);
+        diffResult = ChangeLuma(diffResult, diffLumaClamped);
+        StoreRGBA16F(P.outDiff, px, py, diffResult);
+
+        float diffFastAccumSpeed = Min(diffAccumSpeed, c.gMaxFastAccumulatedFrameNum);
+        float diffFastNonLinearAccumSpeed = 1.0f / (1.0f + diffFastAccumSpeed);
+        float diffFastResult = Lerp(smbDiffFastHistory, GetLuma(diff), diffFastNonLinearAccumSpeed);
+        float diffFastClamped = Min(diffFastResult, GetLuma(smbDiffHistory) * diffMaxRelativeIntensity * REBLUR_FIREFLY_SUPPRESSOR_FAST_RELATIVE_INTENSITY);
+        diffFastResult = Lerp(diffFastResult, diffFastClamped, diffAntifireflyFactor);
+        StoreR16F(P.outDiffFast, px, py, diffFastResult);
+    }
+
+
     // ------------------------------------------------------------------------------------------------ specular
     float specAccumSpeed = 0.0f, curvature = 0.0f, virtualHistoryAmount = 0.0f;
     if (SPEC) {
@@ -263,6 +325,7 @@ __global__ __launch_bounds__(TILE_X* TILE_Y) void ReblurTemporalAccumulationKern
 
         float4 spec = LoadRGBA16F(P.inSpec, px, py);
 
+        NRD_CONSTANTS_PHASE();
         // Curvature estimation along predicted motion
         {
             float2 uvForZeroParallax = c.gOrthoMode == 0.0f ? smbPixelUv : pixelUv;
@@ -322,6 +385,7 @@ __global__ __launch_bounds__(TILE_X* TILE_Y) void ReblurTemporalAccumulationKern
             curvature = Dot(n - N, edge) * PositiveRcp(edgeLenSq);
         }
 
+        NRD_CONSTANTS_PHASE();
         // Virtual motion - coordinates
         float3 Xvirtual = GetXvirtual(hitDistForTracking, curvature, X, Xprev, N, V, roughness);
         float XvirtualLength = Length(Xvirtual);
@@ -365,6 +429,7 @@ __global__ __launch_bounds__(TILE_X* TILE_Y) void ReblurTemporalAccumulationKern
 
         smbNavg = smbFootprintQuality == 0.0f ? vmbN : smbNavg;
 
+        NRD_CONSTANTS_PHASE();
         // Virtual motion - disocclusion: plane distance and roughness
         float4 vmbOcclusion;
         {
@@ -430,6 +495,7 @@ __global__ __launch_bounds__(TILE_X* TILE_Y) void ReblurTemporalAccumulationKern
         virtualHistoryAmount = SmoothStep(0.05f, 0.95f, Dfactor);
         virtualHistoryAmount *= virtualHistoryNormalBasedConfidence;
 
+        NRD_CONSTANTS_PHASE();
         // Virtual motion - virtual parallax difference
         float virtualHistoryParallaxBasedConfidence;
         {
@@ -473,6 +539,7 @@ __global__ __launch_bounds__(TILE_X* TILE_Y) void ReblurTemporalAccumulationKern
         float virtualHistoryConfidence = virtualHistoryNormalBasedConfidence * virtualHistoryRoughnessBasedConfidence * virtualHistoryParallaxBasedConfidence;
         virtualHistoryAmount *= virtualHistoryRoughnessBasedConfidence;
 
+        NRD_CONSTANTS_PHASE();
         // Sample surface history
         HistoryFilter smbFilter = MakeHistoryFilter(smbSamplePos, smbOcclusionWeights, smbAllowCatRom, P.historySpec);
         float4 smbSpecHistory = FetchHistoryRGBA16F(smbFilter, P.historySpec);
@@ -525,6 +592,7 @@ __global__ __launch_bounds__(TILE_X* TILE_Y) void ReblurTemporalAccumulationKern
         virtualHistoryAmount *= 1.0f + (vmbSpecAccumSpeed - smbSpecAccumSpeed) / (magic * Max(vmbSpecAccumSpeed, smbSpecAccumSpeed) + 1.0f);
         virtualHistoryAmount = Sat(virtualHistoryAmount);
 
+        NRD_CONSTANTS_PHASE();
         // Sample virtual history
         HistoryFilter vmbFilter = MakeHistoryFilter(Sat(vmbPixelUv) * rectSizePrev, vmbOcclusionWeights, vmbAllowCatRom, P.historySpec);
         float4 vmbSpecHistory = FetchHistoryRGBA16F(vmbFilter, P.historySpec);
@@ -567,6 +635,7 @@ __global__ __launch_bounds__(TILE_X* TILE_Y) void ReblurTemporalAccumulationKern
         StoreR16F(P.outSpecFast, px, py, specFastResult);
     }
 
+    NRD_CONSTANTS_PHASE();
     // DATA2: occlusion bits, curvature, virtual history amount (R32_UINT; diffuse-only keeps the low byte in R8_UINT)
     {
         uint32_t packed = PackData2(fbits, curvature, virtualHistoryAmount);
@@ -574,40 +643,6 @@ __global__ __launch_bounds__(TILE_X* TILE_Y) void ReblurTemporalAccumulationKern
             StoreR32U(P.outData2, px, py, packed);
         else
             StoreR8U(P.outData2, px, py, packed);
-    }
-
-    // ------------------------------------------------------------------------------------------------ diffuse
-    if (DIFF) {
-        float diffHistoryConfidence = smbFootprintQuality;
-        diffAccumSpeed *= Lerp(diffHistoryConfidence, 1.0f, 1.0f / (1.0f + diffAccumSpeed));
-        diffAccumSpeed = Min(diffAccumSpeed, c.gMaxAccumulatedFrameNum);
-
-        float4 diff = LoadRGBA16F(P.inDiff, px, py);
-
-        HistoryFilter smbFilter = MakeHistoryFilter(smbSamplePos, smbOcclusionWeights, smbAllowCatRom, P.historyDiff);
-        float4 smbDiffHistory = FetchHistoryRGBA16F(smbFilter, P.historyDiff);
-        float smbDiffFastHistory = FetchHistoryBilinearR16F(smbFilter, P.historyDiffFast);
-        smbDiffHistory = ClampNegativeToZero(smbDiffHistory);
-
-        float diffNonLinearAccumSpeed = 1.0f / (1.0f + diffAccumSpeed);
-        float4 diffResult = MixHistoryAndCurrent(c, smbDiffHistory, diff, diffNonLinearAccumSpeed);
-
-        float diffMaxRelativeIntensity = c.gFireflySuppressorMinRelativeScale + REBLUR_FIREFLY_SUPPRESSOR_MAX_RELATIVE_INTENSITY / (diffAccumSpeed + 1.0f);
-        float diffAntifireflyFactor = diffAccumSpeed * c.gMaxBlurRadius * REBLUR_FIREFLY_SUPPRESSOR_RADIUS_SCALE;
-        diffAntifireflyFactor /= 1.0f + diffAntifireflyFactor;
-
-        float diffLumaResult = GetLuma(diffResult);
-        float diffLumaClamped = Min(diffLumaResult, GetLuma(smbDiffHistory) * diffMaxRelativeIntensity);
-        diffLumaClamped = Lerp(diffLumaResult, diffLumaClamped, diffAntifireflyFactor);
-        diffResult = ChangeLuma(diffResult, diffLumaClamped);
-        StoreRGBA16F(P.outDiff, px, py, diffResult);
-
-        float diffFastAccumSpeed = Min(diffAccumSpeed, c.gMaxFastAccumulatedFrameNum);
-        float diffFastNonLinearAccumSpeed = 1.0f / (1.0f + diffFastAccumSpeed);
-        float diffFastResult = Lerp(smbDiffFastHistory, GetLuma(diff), diffFastNonLinearAccumSpeed);
-        float diffFastClamped = Min(diffFastResult, GetLuma(smbDiffHistory) * diffMaxRelativeIntensity * REBLUR_FIREFLY_SUPPRESSOR_FAST_RELATIVE_INTENSITY);
-        diffFastResult = Lerp(diffFastResult, diffFastClamped, diffAntifireflyFactor);
-        StoreR16F(P.outDiffFast, px, py, diffFastResult);
     }
 
     StoreData1<DIFF, SPEC>(P.outData1, px, py, diffAccumSpeed, specAccumSpeed);
@@ -657,6 +692,17 @@ static const char* LaunchTemporalAccumulation(const PassArgs& a) {
     P.outData2 = a.planes[k++];
     if (k != a.planesNum)
         return "REBLUR temporal accumulation: unexpected resource count";
+    {
+        const Plane size = P.viewZ, rgba16 = DIFF ? P.historyDiff : P.historySpec, r16 = DIFF ? P.historyDiffFast : P.historySpecFast;
+        bool ok = SameSize(P.decodedNR, size) && SameSize(P.mv, size) && SameSize(P.prevViewZ, size) && SameSize(P.prevNormalRoughness, size) && SameSize(P.prevInternalData, size) &&
+                  SameSize(P.inDiff, size) && SameSize(P.inSpec, size) && SameSize(P.inSpecHitDistForTracking, size) && SameSize(P.outData1, size) && SameSize(P.outData2, size) &&
+                  SameSize(rgba16, size) && SameSize(r16, size);
+        ok = ok && SameLayout(P.historyDiff, rgba16) && SameLayout(P.historySpec, rgba16) && SameLayout(P.outDiff, rgba16) && SameLayout(P.outSpec, rgba16);
+        ok = ok && SameLayout(P.historyDiffFast, r16) && SameLayout(P.historySpecFast, r16) && SameLayout(P.prevSpecHitDistForTracking, r16) && SameLayout(P.outDiffFast, r16) &&
+             SameLayout(P.outSpecFast, r16) && SameLayout(P.outSpecHitDistForTracking, r16);
+        if (!ok)
+            return "REBLUR temporal accumulation: planes of one frame must share their size (and pool planes of one format their pitch)";
+    }
 
     RowGrid g = GridForRows(c.gRectSizeMinusOne.x + 1, c.gRectSizeMinusOne.y + 1, TILE_X, TILE_Y, a.rowBegin, a.rowEnd);
     hipLaunchKernelGGL((ReblurTemporalAccumulationKernel<DIFF, SPEC>), g.grid, dim3(TILE_X * TILE_Y), 0, a.stream, c, P, RowRange{g.firstBlockY, g.rowBegin, g.rowEnd});

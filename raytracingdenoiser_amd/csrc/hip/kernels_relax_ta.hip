@@ -36,13 +36,31 @@ struct TaPlanes {
 };
 
 template <bool DIFF, bool SPEC, bool SH>
-__global__ __launch_bounds__(256) void RelaxTemporalAccumulationKernel(TaPlanes P, RelaxCB c, RowRange rows) {
+__global__ __launch_bounds__(256, 3) void RelaxTemporalAccumulationKernel(RelaxCB cArg, TaPlanes P, RowRange rows) {
     __shared__ float4 s_NormalSpecHitT[ta::BUF_Y * ta::BUF_STRIDE];
+    // The constant block + up to 35 planes need far more than the 102 SGPRs there are; left alone the compiler spills scalars into
+    // VGPR lanes (v_writelane / v_readlane + hazard nops on every use). The body reads the constants from an LDS copy instead
+    // (uniform-address ds_read, off the VALU), re-read per phase; only the prologue touches the kernel-argument copy.
+    __shared__ RelaxCB s_Constants;
+
+    // SGPR diet (planes.h): one (w, h) for every full-resolution plane, one pitch for all RGBA16F pool planes; verified by the launcher
+    {
+        const Plane size = P.viewZ, rgba16 = SPEC ? P.spec.prev : P.diff.prev;
+        ShareSize(P.decodedNR, size), ShareSize(P.mv, size), ShareSize(P.prevNormalRoughness, size), ShareSize(P.prevViewZ, size), ShareSize(P.prevSpecHitDist, size);
+        ShareSize(P.prevHistoryLength, size), ShareSize(P.prevMaterialID, size), ShareSize(P.outSpecHitDist, size), ShareSize(P.outHistoryLength, size), ShareSize(P.outSpecReprojectionConfidence, size);
+        SignalPlanes* sig[2] = {&P.spec, &P.diff};
+#pragma unroll
+        for (int s = 0; s < 2; s++) {
+            ShareSize(sig[s]->in, size), ShareSize(sig[s]->inSh, size);
+            ShareLayout(sig[s]->prev, rgba16), ShareLayout(sig[s]->prevSh, rgba16), ShareLayout(sig[s]->fast, rgba16), ShareLayout(sig[s]->fastSh, rgba16);
+            ShareLayout(sig[s]->out, rgba16), ShareLayout(sig[s]->outSh, rgba16), ShareLayout(sig[s]->outFast, rgba16), ShareLayout(sig[s]->outFastSh, rgba16);
+        }
+    }
 
     const int blockY = blockIdx.y + rows.firstBlockY;
     const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
     const int px = blockIdx.x * TILE_X + tx, py = blockY * TILE_Y + ty;
-    const int rectW = c.shared.gRectSize.x, rectH = c.shared.gRectSize.y;
+    const int rectW = cArg.shared.gRectSize.x, rectH = cArg.shared.gRectSize.y;
 
     if (!RelaxBlockHasGeometry(P.tiles, blockY)) // uniform per workgroup
         return;
@@ -56,7 +74,15 @@ __global__ __launch_bounds__(256) void RelaxTemporalAccumulationKernel(TaPlanes 
             v.w = LoadRGBA16F(P.spec.in, gx, gy).w;
         s_NormalSpecHitT[ly * ta::BUF_STRIDE + lx] = v;
     }
+    {
+        // constants: kernel-argument segment (cArg is the first argument, offset 0) -> LDS, one dword per thread
+        const uint32_t __attribute__((address_space(4)))* kernarg = (const uint32_t __attribute__((address_space(4)))*)__builtin_amdgcn_kernarg_segment_ptr();
+        if (threadIdx.x < sizeof(RelaxCB) / 4)
+            ((uint32_t*)&s_Constants)[threadIdx.x] = kernarg[threadIdx.x];
+    }
     __syncthreads();
+    const RelaxCB& c = s_Constants;
+#define NRD_CONSTANTS_PHASE() asm volatile("" ::: "memory")
 
     if (px >= rectW || py >= rectH || py < rows.rowBegin || py >= rows.rowEnd)
         return;
@@ -128,6 +154,7 @@ __global__ __launch_bounds__(256) void RelaxTemporalAccumulationKernel(TaPlanes 
     const float diffuse1stMoment = Luminance(diffuseIllumination);
     const float diffuse2ndMoment = diffuse1stMoment * diffuse1stMoment;
 
+    NRD_CONSTANTS_PHASE();
     // surface parallax
     const float smbParallaxInPixels1 = ComputeParallaxInPixels(prevWorldPos + cameraDelta, prevUVSMB, c.shared.gWorldToClipPrev, rectSize);
     const float smbParallaxInPixels2 = ComputeParallaxInPixels(prevWorldPos - cameraDelta, pixelUv, c.shared.gWorldToClip, rectSize);
@@ -144,6 +171,7 @@ __global__ __launch_bounds__(256) void RelaxTemporalAccumulationKernel(TaPlanes 
         disocclusionThresholdMix = LoadR8Unorm(P.disocclusionThresholdMix, px, py);
     const float disocclusionThreshold = Lerp(c.shared.gDisocclusionThreshold, c.shared.gDisocclusionThresholdAlternate, disocclusionThresholdMix);
 
+    NRD_CONSTANTS_PHASE();
     // ---------------------------------------------------------------- surface motion based history
     float footprintQuality, historyLength, SMBReprojectionFound;
     float4 prevDiffuseIllumAnd2ndMomentSMB = F4(0.0f), prevDiffuseSH = F4(0.0f), prevDiffuseResponsiveSH = F4(0.0f);
@@ -231,6 +259,7 @@ __global__ __launch_bounds__(256) void RelaxTemporalAccumulationKernel(TaPlanes 
         }
     }
 
+    NRD_CONSTANTS_PHASE();
     historyLength = historyLength + 1.0f;
     historyLength = Min(RELAX_MAX_ACCUM_FRAME_NUM, historyLength);
 
@@ -290,6 +319,7 @@ __global__ __launch_bounds__(256) void RelaxTemporalAccumulationKernel(TaPlanes 
 
         const float hitDist = minHitDist3x3 == NRD_INF ? 0.0f : minHitDist3x3;
 
+        NRD_CONSTANTS_PHASE();
         // curvature along the direction of motion
         float curvature;
         {
@@ -341,6 +371,7 @@ __global__ __launch_bounds__(256) void RelaxTemporalAccumulationKernel(TaPlanes 
 
         const float hitDistFocused = ApplyThinLensEquation(hitDist, curvature);
 
+        NRD_CONSTANTS_PHASE();
         // ---------------------------------------------------------------- virtual motion based history
         float4 prevSpecularIllumAnd2ndMomentVMB = F4(0.0f), prevSpecularResponsiveVMB = F4(0.0f), prevSpecularVMBSH = F4(0.0f), prevSpecularVMBResponsiveSH = F4(0.0f);
         float3 prevNormalVMB = currentNormal;
@@ -404,6 +435,7 @@ __global__ __launch_bounds__(256) void RelaxTemporalAccumulationKernel(TaPlanes 
             VMBReprojectionFound = allValid ? 1.0f : 0.0f;
         }
 
+        NRD_CONSTANTS_PHASE();
         // amount of virtual motion
         const float4 D = GetSpecularDominantDirection(currentNormal, V, currentRoughnessModified);
         float virtualHistoryAmount = VMBReprojectionFound * D.w;
@@ -446,6 +478,7 @@ __global__ __launch_bounds__(256) void RelaxTemporalAccumulationKernel(TaPlanes 
         rw *= ComputeWeight(backNormalRoughness2.w * backNormalRoughness2.w, relaxedRoughnessWeightParams.x, relaxedRoughnessWeightParams.y);
         virtualHistoryAmount *= rw * 0.9f + 0.1f;
 
+        NRD_CONSTANTS_PHASE();
         // hit distance confidence
         const float SMC = GetSpecMagicCurve(currentRoughnessModified);
         const float hitDistC = Lerp(specularIllumination.w, prevReflectionHitTSMB, SMC);
@@ -473,6 +506,7 @@ __global__ __launch_bounds__(256) void RelaxTemporalAccumulationKernel(TaPlanes 
         const float deltaParallaxInPixels = Length((prevUVVMBTest - prevUVVMB) * rectSize);
         virtualHistoryHitDistConfidence *= SmoothStep(lobeRadiusInPixels + 0.25f, 0.0f, deltaParallaxInPixels);
 
+        NRD_CONSTANTS_PHASE();
         // surface motion signal
         const float specSMBConfidence = (SMBReprojectionFound > 0.0f ? 1.0f : 0.0f) * GetEncodingAwareNormalWeightR(V, Vprev, lobeHalfAngle * NoV / c.shared.gFramerateScale, 0.0f, 0.0f, false);
         float specSMBAlpha = 1.0f - specSMBConfidence;
@@ -573,9 +607,21 @@ const char* LaunchTemporalAccumulation(const PassArgs& a) {
     P.decodedNR = a.decodedNormalRoughness;
     if (!cur.complete() || !P.decodedNR.ptr)
         return "RELAX TemporalAccumulation: unexpected resource count or missing decoded normal/roughness cache";
+    {
+        const Plane size = P.viewZ, rgba16 = SPEC ? P.spec.prev : P.diff.prev;
+        bool ok = SameSize(P.decodedNR, size) && SameSize(P.mv, size) && SameSize(P.prevNormalRoughness, size) && SameSize(P.prevViewZ, size) && SameSize(P.prevSpecHitDist, size) &&
+                  SameSize(P.prevHistoryLength, size) && SameSize(P.prevMaterialID, size) && SameSize(P.outSpecHitDist, size) && SameSize(P.outHistoryLength, size) &&
+                  SameSize(P.outSpecReprojectionConfidence, size) && SameSize(rgba16, size);
+        const SignalPlanes* sig[2] = {&P.spec, &P.diff};
+        for (int s = 0; s < 2; s++)
+            ok = ok && SameSize(sig[s]->in, size) && SameSize(sig[s]->inSh, size) && SameLayout(sig[s]->prev, rgba16) && SameLayout(sig[s]->prevSh, rgba16) && SameLayout(sig[s]->fast, rgba16) &&
+                 SameLayout(sig[s]->fastSh, rgba16) && SameLayout(sig[s]->out, rgba16) && SameLayout(sig[s]->outSh, rgba16) && SameLayout(sig[s]->outFast, rgba16) && SameLayout(sig[s]->outFastSh, rgba16);
+        if (!ok)
+            return "RELAX TemporalAccumulation: planes of one frame must share their size (and the RGBA16F pool planes their pitch)";
+    }
     RelaxCB c = LoadRelaxConstants(a);
     RowGrid g = GridForRows(c.shared.gRectSize.x, c.shared.gRectSize.y, TILE_X, TILE_Y, a.rowBegin, a.rowEnd);
-    hipLaunchKernelGGL((RelaxTemporalAccumulationKernel<DIFF, SPEC, SH>), g.grid, dim3(256), 0, a.stream, P, c, RowRange{g.firstBlockY, g.rowBegin, g.rowEnd});
+    hipLaunchKernelGGL((RelaxTemporalAccumulationKernel<DIFF, SPEC, SH>), g.grid, dim3(256), 0, a.stream, c, P, RowRange{g.firstBlockY, g.rowBegin, g.rowEnd});
     return nullptr;
 }
 

@@ -22,6 +22,22 @@ struct Plane {
 
 #define NRD_D __device__ __forceinline__
 
+// SGPR diet for kernels that bind dozens of planes (a Plane costs 5 SGPRs and the temporal passes bind 20-35 of them, which
+// otherwise spills scalars into VGPR lanes): pool planes of one format share their pitch, and every full-resolution plane shares
+// (w, h). The launcher verifies that with SameLayout / SameSize, the kernel overwrites the fields of its by-value Plane copies
+// with those of one representative, and the redundant kernel-argument loads disappear.
+NRD_D void ShareLayout(Plane& p, const Plane& ref) {
+    p.pitch = ref.pitch;
+    p.w = ref.w;
+    p.h = ref.h;
+}
+NRD_D void ShareSize(Plane& p, const Plane& ref) {
+    p.w = ref.w;
+    p.h = ref.h;
+}
+inline bool SameSize(const Plane& a, const Plane& b) { return !a.ptr || !b.ptr || (a.w == b.w && a.h == b.h); }
+inline bool SameLayout(const Plane& a, const Plane& b) { return !a.ptr || !b.ptr || (a.pitch == b.pitch && a.w == b.w && a.h == b.h); }
+
 NRD_D bool InBounds(const Plane& p, int x, int y) { return (unsigned)x < (unsigned)p.w && (unsigned)y < (unsigned)p.h; }
 
 // 32-bit byte offsets (planes are far below 4 GiB) from a 24-bit multiply (row index and pitch are both < 2^24): one full-rate

@@ -399,8 +399,43 @@ NRD_D V FetchHistoryGeneric(const HistoryFilter& h, const Plane& tex, LoadFn loa
     }
     return h.sum < 0.0001f ? zero : color / h.sum;
 }
+// Two / four horizontally adjacent RGBA16F texels with one 16-byte request each (8-byte aligned: legal for global_load_dwordx4).
+// The temporal passes are limited by the number of L1 requests, not by bytes: one request per texel pair halves them.
+struct alignas(8) RGBA16Fx2Raw {
+    uint32_t v[4];
+};
+NRD_D float4 DecodeRGBA16F(uint32_t lo, uint32_t hi) {
+    return F4(HalfBitsToFloat((uint16_t)(lo & 0xFFFFu)), HalfBitsToFloat((uint16_t)(lo >> 16)), HalfBitsToFloat((uint16_t)(hi & 0xFFFFu)), HalfBitsToFloat((uint16_t)(hi >> 16)));
+}
+NRD_D void LoadRGBA16Fx2(const Plane& p, int x, int y, float4& a, float4& b) {
+    const RGBA16Fx2Raw raw = *(const RGBA16Fx2Raw*)TexelPtr<const uint2>(p, x, y);
+    a = DecodeRGBA16F(raw.v[0], raw.v[1]);
+    b = DecodeRGBA16F(raw.v[2], raw.v[3]);
+}
 NRD_D float4 FetchHistoryRGBA16F(const HistoryFilter& h, const Plane& tex) {
-    return FetchHistoryGeneric<float4>(h, tex, [](const Plane& p, int x, int y) { return LoadRGBA16F(p, x, y); }, F4(0.0f));
+    // interior footprint (no coordinate was clamped): the 12 texels are 2 + 4 + 4 + 2 contiguous runs -> 6 requests instead of 12
+    const bool interior = h.x[3] - h.x[0] == 3 && h.y[3] - h.y[0] == 3;
+    if (!(interior && h.useBicubic))
+        return FetchHistoryGeneric<float4>(h, tex, [](const Plane& p, int x, int y) { return LoadRGBA16F(p, x, y); }, F4(0.0f));
+    float4 a0, a1, b0, b1, b2, b3, c0, c1, c2, c3, d0, d1;
+    LoadRGBA16Fx2(tex, h.x[1], h.y[0], a0, a1);
+    LoadRGBA16Fx2(tex, h.x[0], h.y[1], b0, b1);
+    LoadRGBA16Fx2(tex, h.x[2], h.y[1], b2, b3);
+    LoadRGBA16Fx2(tex, h.x[0], h.y[2], c0, c1);
+    LoadRGBA16Fx2(tex, h.x[2], h.y[2], c2, c3);
+    LoadRGBA16Fx2(tex, h.x[1], h.y[3], d0, d1);
+    const float fx = h.tc.x, fy = h.tc.y, gx = 1.0f - fx, gy = 1.0f - fy;
+    float4 s0 = a0 * gx + a1 * fx;
+    float4 s1 = b0 * gy + c0 * fy;
+    float4 s2 = b1 * (gx * gy) + b2 * (fx * gy) + c1 * (gx * fy) + c2 * (fx * fy);
+    float4 s3 = b3 * gy + c3 * fy;
+    float4 s4 = d0 * gx + d1 * fx;
+    float4 color = s0 * h.w.x;
+    color = color + s1 * h.w.y;
+    color = color + s2 * h.w.z;
+    color = color + s3 * h.w.w;
+    color = color + s4 * h.w4;
+    return h.sum < 0.0001f ? F4(0.0f) : color / h.sum;
 }
 NRD_D float FetchHistoryR16F(const HistoryFilter& h, const Plane& tex) {
     return FetchHistoryGeneric<float>(h, tex, [](const Plane& p, int x, int y) { return LoadR16F(p, x, y); }, 0.0f);
