@@ -28,6 +28,13 @@ import torch
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E peak (MI355X_MICROARCH.md); ~6300 GB/s is what a float4 copy achieves
 
+# Published reference numbers for the exact metric (reference README.md:18, RTX 4080, 1440p native)
+PUBLISHED_MPIX_S = {("REBLUR_DIFFUSE_SPECULAR", 2560, 1440): 1603.0, ("RELAX_DIFFUSE_SPECULAR", 2560, 1440): 1229.0, ("RELAX_DIFFUSE_SPECULAR_SH", 2560, 1440): 760.0}
+
+# HBM traffic per launch from hardware counters: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes, tools/pmc_run.sh), stored
+# by tools/pmc_to_json.py. FETCH_SIZE is doubled (MI355X_MICROARCH.md "HBM": gfx950 tallies 128-B requests at 64 B); both are KiB.
+PMC_TRAFFIC_FILE = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+
 # Algorithmic (compulsory) bytes per pixel and per pass for REBLUR_DIFFUSE_SPECULAR with the reference pool formats
 # (each plane read / written once per pass).
 REBLUR_DS_BYTES_PER_PIXEL = {
@@ -219,8 +226,17 @@ def main():
     roofline = None
     if dominant:
         achieved = passes[dominant]["GBps"]
+        traffic, traffic_source = None, None
+        if world == 1 and os.path.exists(PMC_TRAFFIC_FILE):
+            entry = json.load(open(PMC_TRAFFIC_FILE)).get("%s_%dx%d" % (name, W, H), {})
+            k = entry.get("kernels", {}).get(dominant)
+            if k:
+                traffic = int((2.0 * k["FETCH_SIZE_KiB"] + k["WRITE_SIZE_KiB"]) * 1024)
+                traffic_source = entry.get("source")
         roofline = {"bound": "hbm", "kernel": dominant, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
-                    "traffic": None, "avg_kernel_ms": passes[dominant]["avg_ms"], "algorithmic_bytes_per_launch": passes[dominant]["bytes_per_launch"]}
+                    "traffic": traffic, "traffic_source": traffic_source, "avg_kernel_ms": passes[dominant]["avg_ms"],
+                    "algorithmic_bytes_per_launch": passes[dominant]["bytes_per_launch"],
+                    "note": "the chain is VALU-bound, not HBM-bound (profiles/: SQ_ACTIVE_INST_VALU = 70-95 % of the SIMD cycles); see DESIGN.md section 3"}
     # per frame: every pass once, except the dilated a-trous pass which runs (launches / steps) times
     per_frame = {k: p["launches"] / args.steps for k, p in passes.items()}
     gpu_ms = sum(p["avg_ms"] * per_frame[k] for k, p in passes.items())
@@ -239,7 +255,7 @@ def main():
         "ms_per_step": round(ms_per_step, 4),
         "higher_is_better": True,
         "scaling": "strong",
-        "vs_baseline": None,
+        "vs_baseline": round(mpix_s / PUBLISHED_MPIX_S[(name, W, H)], 3) if world == 1 and (name, W, H) in PUBLISHED_MPIX_S else None,
         "dtype": "f32",
         "data": "synthetic",
         "config": {"workload": "%s %dx%d, default settings, analytic scene + 1rpp noise, moving camera" % (name, W, H),

@@ -1,0 +1,45 @@
+"""Folds the FETCH_SIZE / WRITE_SIZE summaries written by tools/pmc_run.sh into profiles/pmc_traffic.json (read by bench.py).
+usage: python tools/pmc_to_json.py <workload key, e.g. REBLUR_DIFFUSE_SPECULAR_2560x1440> <fetch summary.txt> <write summary.txt> <source note>"""
+import json
+import os
+import re
+import sys
+
+KERNEL_TO_SHADER = [  # kernel-name fragments -> shader file name suffix (family prefix is added from the workload)
+    ("ClassifyTiles", "ClassifyTiles.cs"), ("TemporalAccumulation", "TemporalAccumulation.cs"), ("HistoryFix", "HistoryFix.cs"), ("HistoryClamping", "HistoryClamping.cs"),
+    ("TemporalStabilization", "TemporalStabilization.cs"), ("AtrousSmem", "AtrousSmem.cs"), ("RelaxAtrousKernel", "Atrous.cs"), ("PrePass", "PrePass.cs"),
+    ("SpatialMode)0", "PrePass.cs"), ("SpatialMode)1", "Blur.cs"), ("SpatialMode)2", "PostBlur.cs"),
+]
+
+
+def parse(path):
+    out = {}
+    for line in open(path).read().splitlines()[1:]:
+        m = re.match(r"(.*?)\s+(\d+)\s+([\d.]+)\s+([\d.e+-]+)\s*$", line)
+        if m:
+            out[m.group(1).strip()] = float(m.group(4))
+    return out
+
+
+def main():
+    key, fetch_file, write_file, source = sys.argv[1:5]
+    family = {"REBLUR_DIFFUSE_SPECULAR": "REBLUR_DiffuseSpecular_", "RELAX_DIFFUSE_SPECULAR_SH": "RELAX_DiffuseSpecularSh_", "RELAX_DIFFUSE_SPECULAR": "RELAX_DiffuseSpecular_"}[key.rsplit("_", 1)[0]]
+    fetch, write = parse(fetch_file), parse(write_file)
+    kernels = {}
+    for kname, f in fetch.items():
+        for frag, suffix in KERNEL_TO_SHADER:
+            if frag in kname:
+                shader = (family.split("_")[0] + "_" + suffix) if suffix == "ClassifyTiles.cs" else family + suffix
+                w = next((v for k, v in write.items() if k == kname), None)
+                if w is not None:
+                    kernels[shader] = {"FETCH_SIZE_KiB": f, "WRITE_SIZE_KiB": w}
+                break
+    path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles", "pmc_traffic.json")
+    data = json.load(open(path)) if os.path.exists(path) else {}
+    data[key] = {"source": source, "kernels": kernels}
+    json.dump(data, open(path, "w"), indent=1, sort_keys=True)
+    print(json.dumps(data[key], indent=1))
+
+
+if __name__ == "__main__":
+    main()
