@@ -449,9 +449,9 @@ void TemporalAccumulation(const PassIO& io) {
     const Tex& gPrev_ViewZ = *cur.next();
     const Tex& gPrev_Normal_Roughness = *cur.next();
     const Tex& gPrev_InternalData = *cur.next();
-    cur.next();      // gIn_DisocclusionThresholdMix (dummy)
-    cur.nextIf(DIFF); // gIn_DiffConfidence (dummy)
-    cur.nextIf(SPEC); // gIn_SpecConfidence (dummy)
+    const Tex& gIn_DisocclusionThresholdMix = *cur.next(); // a dummy plane unless gHasDisocclusionThresholdMix
+    const Tex* gIn_DiffConfidence = cur.nextIf(DIFF);      // dummies unless gHasHistoryConfidence
+    const Tex* gIn_SpecConfidence = cur.nextIf(SPEC);
     const Tex* gIn_Diff = cur.nextIf(DIFF);
     const Tex* gIn_Spec = cur.nextIf(SPEC);
     const Tex* gHistory_Diff = cur.nextIf(DIFF);
@@ -596,6 +596,8 @@ void TemporalAccumulation(const PassIO& io) {
             float disocclusionThresholdMix = 0.0f;
             if (materialID == c.gStrandMaterialID)
                 disocclusionThresholdMix = saturate(c.gStrandThickness / pixelSize); // NRD_GetNormalizedStrandThickness
+            if (c.gHasDisocclusionThresholdMix)
+                disocclusionThresholdMix = gIn_DisocclusionThresholdMix.Load((int)c.gRectOrigin[0] + px, (int)c.gRectOrigin[1] + py).x;
             float disocclusionThreshold = lerp(c.gDisocclusionThreshold, c.gDisocclusionThresholdAlternate, disocclusionThresholdMix);
 
             float smallParallax = Math::LinearStep(0.25f, 0.0f, smbParallaxInPixelsMax);
@@ -668,6 +670,8 @@ void TemporalAccumulation(const PassIO& io) {
             float specAccumSpeed = 0.0f, curvature = 0.0f, virtualHistoryAmount = 0.0f;
             if (SPEC) {
                 float specHistoryConfidence = smbFootprintQuality;
+                if (c.gHasHistoryConfidence)
+                    specHistoryConfidence *= gIn_SpecConfidence->Load((int)c.gRectOrigin[0] + px, (int)c.gRectOrigin[1] + py).x;
                 smbSpecAccumSpeed *= lerp(specHistoryConfidence, 1.0f, 1.0f / (1.0f + smbSpecAccumSpeed));
                 smbSpecAccumSpeed = min(smbSpecAccumSpeed, c.gMaxAccumulatedFrameNum);
 
@@ -987,6 +991,8 @@ void TemporalAccumulation(const PassIO& io) {
             // ---------------------------------------------------------------------------------------------- diffuse
             if (DIFF) {
                 float diffHistoryConfidence = smbFootprintQuality;
+                if (c.gHasHistoryConfidence)
+                    diffHistoryConfidence *= gIn_DiffConfidence->Load((int)c.gRectOrigin[0] + px, (int)c.gRectOrigin[1] + py).x;
                 diffAccumSpeed *= lerp(diffHistoryConfidence, 1.0f, 1.0f / (1.0f + diffAccumSpeed));
                 diffAccumSpeed = min(diffAccumSpeed, c.gMaxAccumulatedFrameNum);
 
@@ -1405,6 +1411,96 @@ void TemporalStabilization(const PassIO& io) {
         }
 }
 
+// ================================================================================================ HitDistReconstruction
+// reference Shaders/Include/REBLUR_HitDistReconstruction.hlsli:10-160 (REBLUR_USE_DECOMPRESSED_HIT_DIST_IN_RECONSTRUCTION = 0,
+// non-performance mode). BORDER = 1 -> 3x3, 2 -> 5x5 window; the window is read at rect-clamped coordinates like the LDS preload.
+template <bool DIFF, bool SPEC, int BORDER>
+void HitDistReconstruction(const PassIO& io) {
+    const ReblurCB& c = *(const ReblurCB*)io.constants;
+    Cursor cur(io);
+    const Tex& gIn_Tiles = *cur.next();
+    const Tex& gIn_Normal_Roughness = *cur.next();
+    const Tex& gIn_ViewZ = *cur.next();
+    const Tex* gIn_Diff = cur.nextIf(DIFF);
+    const Tex* gIn_Spec = cur.nextIf(SPEC);
+    Tex* gOut_Diff = cur.nextIf(DIFF);
+    Tex* gOut_Spec = cur.nextIf(SPEC);
+    const int rw = c.gRectSizeMinusOne[0], rh = c.gRectSizeMinusOne[1];
+    const int ox = (int)c.gRectOrigin[0], oy = (int)c.gRectOrigin[1];
+
+#pragma omp parallel for schedule(dynamic, 4)
+    for (int py = 0; py <= rh; py++)
+        for (int px = 0; px <= rw; px++) {
+            if (gIn_Tiles.Load(px >> 4, py >> 4).x != 0.0f)
+                continue;
+            auto ViewZ = [&](int x, int y) { return UnpackViewZ(c, gIn_ViewZ.Load(ox + clamp(x, 0, rw), oy + clamp(y, 0, rh)).x); };
+            auto NormalRoughness = [&](int x, int y) { return NRD_FrontEnd_UnpackNormalAndRoughness(gIn_Normal_Roughness.Load(ox + clamp(x, 0, rw), oy + clamp(y, 0, rh))); };
+            auto HitDist = [&](int x, int y) {
+                x = clamp(x, 0, rw), y = clamp(y, 0, rh);
+                return float2(DIFF ? gIn_Diff->Load(x, y).w : 0.0f, SPEC ? gIn_Spec->Load(x, y).w : 0.0f);
+            };
+            const float centerZ = ViewZ(px, py);
+            if (centerZ > c.gDenoisingRange)
+                continue;
+
+            float4 normalAndRoughness = NormalRoughness(px, py);
+            float3 N = normalAndRoughness.xyz();
+            float roughness = normalAndRoughness.w;
+
+            float2 pixelUv = float2(float(px) + 0.5f, float(py) + 0.5f) * c.gRectSizeInv;
+            float3 Xv = Geometry::ReconstructViewPosition(pixelUv, c.gFrustum, centerZ, c.gOrthoMode);
+            float3 Nv = Geometry::RotateVectorInverse(c.gViewToWorld, N);
+            float frustumSize = GetFrustumSize(c.gMinRectDimMulUnproject, c.gOrthoMode, centerZ);
+
+            float2 geometryWeightParams = GetGeometryWeightParams(c.gPlaneDistSensitivity, frustumSize, Xv, Nv);
+            float2 relaxedRoughnessWeightParams = GetRelaxedRoughnessWeightParams(roughness * roughness);
+            float diffNormalWeightParam = GetNormalWeightParam(1.0f, 1.0f);
+            float specNormalWeightParam = GetNormalWeightParam(1.0f, 1.0f, roughness);
+
+            float2 center = HitDist(px, py);
+            float2 sum = float2(center.x != 0.0f ? 1000.0f : 0.0f, center.y != 0.0f ? 1000.0f : 0.0f);
+            center = center * sum;
+
+            for (int j = 0; j <= BORDER * 2; j++)
+                for (int i = 0; i <= BORDER * 2; i++) {
+                    float2 o = float2(float(i - BORDER), float(j - BORDER));
+                    if (o.x == 0.0f && o.y == 0.0f)
+                        continue;
+                    int sx = px + i - BORDER, sy = py + j - BORDER;
+                    float2 data = HitDist(sx, sy);
+                    float dataZ = ViewZ(sx, sy);
+
+                    float w = IsInScreenNearest(pixelUv + o * c.gRectSizeInv);
+                    w *= GetGaussianWeight(length(o) * 0.5f);
+
+                    float2 uv = pixelUv + o * c.gRectSizeInv;
+                    float3 Xvs = Geometry::ReconstructViewPosition(uv, c.gFrustum, dataZ, c.gOrthoMode);
+                    w *= ComputeWeight(dot(Nv, Xvs), geometryWeightParams.x, geometryWeightParams.y);
+
+                    float2 ww = float2(w);
+                    float4 sampleNormalAndRoughness = NormalRoughness(sx, sy);
+                    float cosa = dot(N, sampleNormalAndRoughness.xyz());
+                    float angle = Math::AcosApprox(cosa);
+                    ww.x *= ComputeExponentialWeight(angle, diffNormalWeightParam, 0.0f);
+                    ww.y *= ComputeExponentialWeight(angle, specNormalWeightParam, 0.0f);
+                    ww.y *= ComputeExponentialWeight(sampleNormalAndRoughness.w * sampleNormalAndRoughness.w, relaxedRoughnessWeightParams.x, relaxedRoughnessWeightParams.y);
+
+                    data.x = ww.x == 0.0f ? 0.0f : data.x; // Denanify
+                    data.y = ww.y == 0.0f ? 0.0f : data.y;
+                    ww = ww * float2(data.x != 0.0f ? 1.0f : 0.0f, data.y != 0.0f ? 1.0f : 0.0f);
+
+                    center += data * ww;
+                    sum += ww;
+                }
+            center = center / max(sum, float2(NRD_EPS));
+
+            if (DIFF)
+                gOut_Diff->Store(px, py, float4(gIn_Diff->Load(px, py).xyz(), center.x));
+            if (SPEC)
+                gOut_Spec->Store(px, py, float4(gIn_Spec->Load(px, py).xyz(), center.y));
+        }
+}
+
 // ================================================================================================ SplitScreen
 template <bool DIFF, bool SPEC>
 void SplitScreen(const PassIO& io) {
@@ -1433,6 +1529,8 @@ void SplitScreen(const PassIO& io) {
 } // namespace
 
 #define REBLUR_FAMILY(NAME, D, S)                                                                      \
+    {"REBLUR_" NAME "_HitDistReconstruction.cs", HitDistReconstruction<D, S, 1>},                      \
+    {"REBLUR_" NAME "_HitDistReconstruction_5x5.cs", HitDistReconstruction<D, S, 2>},                  \
     {"REBLUR_" NAME "_PrePass.cs", PrePass<D, S>},                                                     \
     {"REBLUR_" NAME "_TemporalAccumulation.cs", TemporalAccumulation<D, S>},                           \
     {"REBLUR_" NAME "_HistoryFix.cs", HistoryFix<D, S>},                                               \

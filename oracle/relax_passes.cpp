@@ -195,6 +195,100 @@ void ClassifyTiles(const PassIO& io) {
         }
 }
 
+// ================================================================================================ HitDistReconstruction
+// reference Shaders/Include/RELAX_HitDistReconstruction.hlsli:10-160. BORDER = 1 -> 3x3, 2 -> 5x5. Hit distances are (spec, diff);
+// the window is read at rect-clamped coordinates like the LDS preload. NOTE (kept): the roughness weight is fed the CENTER
+// roughness, so it evaluates to exactly 1.
+template <bool DIFF, bool SPEC, int BORDER>
+void HitDistReconstruction(const PassIO& io) {
+    const RelaxCB& c = *(const RelaxCB*)io.constants;
+    Cursor cur{io.t};
+    Sig spec, diff;
+    const Tex& gIn_Tiles = *cur.next();
+    if (SPEC) spec.in = cur.next();
+    if (DIFF) diff.in = cur.next();
+    const Tex& gIn_Normal_Roughness = *cur.next();
+    const Tex& gIn_ViewZ = *cur.next();
+    if (SPEC) spec.out = cur.next();
+    if (DIFF) diff.out = cur.next();
+    const int rectW = c.gRectSize[0], rectH = c.gRectSize[1];
+    const int ox = (int)c.gRectOrigin[0], oy = (int)c.gRectOrigin[1];
+
+#pragma omp parallel for schedule(dynamic, 4)
+    for (int py = 0; py < rectH; py++)
+        for (int px = 0; px < rectW; px++) {
+            if (gIn_Tiles.Load(px >> 4, py >> 4).x != 0.0f)
+                continue;
+            auto Cx = [&](int x) { return clamp(x, 0, rectW - 1); };
+            auto Cy = [&](int y) { return clamp(y, 0, rectH - 1); };
+            auto ViewZ = [&](int x, int y) { return UnpackViewZ(c, gIn_ViewZ.Load(ox + Cx(x), oy + Cy(y)).x); };
+            auto HitDist = [&](int x, int y) { return float2(SPEC ? spec.in->Load(Cx(x), Cy(y)).w : c.gDenoisingRange, DIFF ? diff.in->Load(Cx(x), Cy(y)).w : c.gDenoisingRange); };
+            const float centerViewZ = ViewZ(px, py);
+            if (centerViewZ > c.gDenoisingRange)
+                continue;
+
+            float2 pixelUv = float2(float(px) + 0.5f, float(py) + 0.5f) * c.gRectSizeInv;
+            float4 normalAndRoughness = NRD_FrontEnd_UnpackNormalAndRoughness(gIn_Normal_Roughness.Load(ox + px, oy + py));
+            float3 centerNormal = normalAndRoughness.xyz();
+            float centerRoughness = normalAndRoughness.w;
+            float2 centerHitDist = HitDist(px, py);
+
+            float2 relaxedRoughnessWeightParams = GetRelaxedRoughnessWeightParams(centerRoughness * centerRoughness);
+            float specularNormalWeightParam = GetNormalWeightParam(1.0f, 1.0f, centerRoughness);
+            float diffuseNormalWeightParam = GetNormalWeightParam(1.0f, 1.0f);
+
+            float sumSpecularWeight = 1000.0f * Cmp(centerHitDist.x != 0.0f);
+            float sumSpecularHitDist = centerHitDist.x * sumSpecularWeight;
+            float sumDiffuseWeight = 1000.0f * Cmp(centerHitDist.y != 0.0f);
+            float sumDiffuseHitDist = centerHitDist.y * sumDiffuseWeight;
+
+            for (int dy = 0; dy <= BORDER * 2; dy++)
+                for (int dx = 0; dx <= BORDER * 2; dx++) {
+                    int ix = dx - BORDER, iy = dy - BORDER;
+                    if (ix == 0 && iy == 0)
+                        continue;
+                    float2 o = float2(float(ix), float(iy));
+                    float3 sampleNormal = NRD_FrontEnd_UnpackNormalAndRoughness(gIn_Normal_Roughness.Load(ox + Cx(px + ix), oy + Cy(py + iy))).xyz();
+                    float2 sampleHitDist = HitDist(px + ix, py + iy);
+                    float sampleViewZ = ViewZ(px + ix, py + iy);
+                    float cosa = dot(centerNormal, sampleNormal);
+                    float angle = Math::AcosApprox(cosa);
+
+                    float w = IsInScreenNearest(pixelUv + o * c.gRectSizeInv);
+                    w *= Cmp(sampleViewZ < c.gDenoisingRange);
+                    w *= GetGaussianWeight(length(o) * 0.5f);
+                    w *= GetBilateralWeight(sampleViewZ, centerViewZ);
+
+                    if (SPEC) {
+                        float specularWeight = w;
+                        specularWeight *= ComputeExponentialWeight(angle, specularNormalWeightParam, 0.0f);
+                        specularWeight *= ComputeExponentialWeight(normalAndRoughness.w * normalAndRoughness.w, relaxedRoughnessWeightParams.x, relaxedRoughnessWeightParams.y);
+                        float sampleSpecularHitDist = specularWeight == 0.0f ? 0.0f : sampleHitDist.x; // Denanify
+                        specularWeight *= Cmp(sampleSpecularHitDist != 0.0f);
+                        sumSpecularHitDist += sampleSpecularHitDist * specularWeight;
+                        sumSpecularWeight += specularWeight;
+                    }
+                    if (DIFF) {
+                        float diffuseWeight = w;
+                        diffuseWeight *= ComputeExponentialWeight(angle, diffuseNormalWeightParam, 0.0f);
+                        float sampleDiffuseHitDist = diffuseWeight == 0.0f ? 0.0f : sampleHitDist.y; // Denanify
+                        diffuseWeight *= Cmp(sampleDiffuseHitDist != 0.0f);
+                        sumDiffuseHitDist += diffuseWeight == 0.0f ? 0.0f : sampleDiffuseHitDist * diffuseWeight;
+                        sumDiffuseWeight += diffuseWeight;
+                    }
+                }
+
+            if (SPEC) {
+                sumSpecularHitDist /= max(sumSpecularWeight, 1e-6f);
+                spec.out->Store(px, py, float4(spec.in->Load(px, py).xyz(), sumSpecularHitDist));
+            }
+            if (DIFF) {
+                sumDiffuseHitDist /= max(sumDiffuseWeight, 1e-6f);
+                diff.out->Store(px, py, float4(diff.in->Load(px, py).xyz(), sumDiffuseHitDist));
+            }
+        }
+}
+
 // ================================================================================================ PrePass
 template <bool DIFF, bool SPEC, bool SH>
 void PrePass(const PassIO& io) {
@@ -1743,6 +1837,87 @@ void Atrous(const PassIO& io) {
         }
 }
 
+// ================================================================================================ Copy / AntiFirefly
+// (only dispatched when RelaxSettings::enableAntiFirefly: history -> user output plane -> RCRS filter -> history)
+template <bool DIFF, bool SPEC>
+void Copy(const PassIO& io) { // reference Shaders/Include/RELAX_Copy.hlsli:10-24
+    const RelaxCB& c = *(const RelaxCB*)io.constants;
+    Cursor cur{io.t};
+    Sig spec, diff;
+    if (SPEC) spec.in = cur.next();
+    if (DIFF) diff.in = cur.next();
+    if (SPEC) spec.out = cur.next();
+    if (DIFF) diff.out = cur.next();
+    const int gridW = (c.gRectSize[0] + 7) / 8 * 8, gridH = (c.gRectSize[1] + 7) / 8 * 8;
+    for (int py = 0; py < gridH; py++)
+        for (int px = 0; px < gridW; px++) {
+            if (SPEC) spec.out->Store(px, py, spec.in->Load(px, py));
+            if (DIFF) diff.out->Store(px, py, diff.in->Load(px, py));
+        }
+}
+
+// cross-bilateral rank-conditioned rank-selection over the 3x3 neighbourhood; reference Shaders/Include/RELAX_AntiFirefly.hlsli:10-210
+template <bool DIFF, bool SPEC>
+void AntiFirefly(const PassIO& io) {
+    const RelaxCB& c = *(const RelaxCB*)io.constants;
+    Cursor cur{io.t};
+    Sig spec, diff;
+    const Tex& gIn_Tiles = *cur.next();
+    if (SPEC) spec.in = cur.next();
+    if (DIFF) diff.in = cur.next();
+    const Tex& gIn_Normal_Roughness = *cur.next();
+    const Tex& gIn_ViewZ = *cur.next();
+    if (SPEC) spec.out = cur.next();
+    if (DIFF) diff.out = cur.next();
+    const int rectW = c.gRectSize[0], rectH = c.gRectSize[1];
+
+#pragma omp parallel for schedule(dynamic, 4)
+    for (int py = 0; py < rectH; py++)
+        for (int px = 0; px < rectW; px++) {
+            if (gIn_Tiles.Load(px >> 4, py >> 4).x != 0.0f)
+                continue;
+            if (UnpackViewZ(c, gIn_ViewZ.Load(px, py).x) > c.gDenoisingRange)
+                continue;
+            auto MaterialID = [&](int x, int y) {
+                float m;
+                NRD_FrontEnd_UnpackNormalAndRoughness(gIn_Normal_Roughness.Load(x, y), m);
+                return m;
+            };
+            const float centerMaterialID = MaterialID(px, py);
+            auto Filter = [&](const Sig& s, float minMaterial) {
+                float4 center = s.in->Load(px, py);
+                float centerLuminance = Color::Luminance(center.xyz());
+                float maxLuminance = -1.0f, minLuminance = 1.0e6f;
+                int maxX = px, maxY = py, minX = px, minY = py;
+                for (int yy = -1; yy <= 1; yy++)
+                    for (int xx = -1; xx <= 1; xx++) {
+                        int qx = px + xx, qy = py + yy;
+                        if ((xx == 0 && yy == 0) || qx < 0 || qy < 0 || qx >= rectW || qy >= rectH)
+                            continue;
+                        float luminance = Color::Luminance(s.in->Load(qx, qy).xyz());
+                        if (CompareMaterials(MaterialID(qx, qy), centerMaterialID, minMaterial)) {
+                            if (luminance > maxLuminance) {
+                                maxLuminance = luminance;
+                                maxX = qx, maxY = qy;
+                            }
+                            if (luminance < minLuminance) {
+                                minLuminance = luminance;
+                                minX = qx, minY = qy;
+                            }
+                        }
+                    }
+                int sx = px, sy = py;
+                if (centerLuminance > maxLuminance)
+                    sx = maxX, sy = maxY;
+                if (centerLuminance < minLuminance)
+                    sx = minX, sy = minY;
+                s.out->Store(px, py, float4(s.in->Load(sx, sy).xyz(), center.w));
+            };
+            if (SPEC) Filter(spec, c.gSpecMinMaterial);
+            if (DIFF) Filter(diff, c.gDiffMinMaterial);
+        }
+}
+
 // ================================================================================================ SplitScreen
 template <bool DIFF, bool SPEC, bool SH>
 void SplitScreen(const PassIO& io) {
@@ -1790,11 +1965,20 @@ void SplitScreen(const PassIO& io) {
     {"RELAX_" name "_HistoryClamping.cs", HistoryClamping<D, S, H>},         \
     {"RELAX_" name "_AtrousSmem.cs", AtrousSmem<D, S, H>},                   \
     {"RELAX_" name "_Atrous.cs", Atrous<D, S, H>},                           \
+    {"RELAX_" name "_Copy.cs", Copy<D, S>},                                    \
+    {"RELAX_" name "_AntiFirefly.cs", AntiFirefly<D, S>},                      \
     {"RELAX_" name "_SplitScreen.cs", SplitScreen<D, S, H>}
+
+#define RELAX_HITDIST(name, D, S)                                                          \
+    {"RELAX_" name "_HitDistReconstruction.cs", HitDistReconstruction<D, S, 1>},           \
+    {"RELAX_" name "_HitDistReconstruction_5x5.cs", HitDistReconstruction<D, S, 2>}
 
 const PassEntry* GetRelaxPasses(uint32_t& n) {
     static const PassEntry k[] = {
         {"RELAX_ClassifyTiles.cs", ClassifyTiles},
+        RELAX_HITDIST("Diffuse", true, false),
+        RELAX_HITDIST("Specular", false, true),
+        RELAX_HITDIST("DiffuseSpecular", true, true),
         RELAX_VARIANT("Diffuse", true, false, false),
         RELAX_VARIANT("DiffuseSh", true, false, true),
         RELAX_VARIANT("Specular", false, true, false),

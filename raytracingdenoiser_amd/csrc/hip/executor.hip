@@ -340,11 +340,11 @@ static int PassReachRows(const char* shader, const void* constants, uint32_t con
         }
         if (strstr(shader, "_HistoryFix"))
             return 2 * (int)std::floor(c.gHistoryFixBasePixelStride / 2.0f + 0.5f); // 5x5 taps at stride <= base / (1 + 1)
-        if (strstr(shader, "_TemporalAccumulation"))
+        if (strstr(shader, "_TemporalAccumulation") || strstr(shader, "_AntiFirefly"))
             return 1;
         if (strstr(shader, "_PrePass") || strstr(shader, "_SplitScreen") || strstr(shader, "ClassifyTiles"))
             return 0; // read user inputs only
-        return -1;
+        return -1; // incl. _Copy and _HitDistReconstruction (the pre-pass then gathers from its output at blur-radius distance) (whole-plane copy of the history, only with anti-firefly): everything up to it runs on the whole frame
     }
     if (strncmp(shader, "REBLUR_", 7) != 0 || !constants || constantsSize < sizeof(nrdc::ReblurConstants))
         return -1;
@@ -362,7 +362,7 @@ static int PassReachRows(const char* shader, const void* constants, uint32_t con
         return 1;
     if (strstr(shader, "_PrePass") || strstr(shader, "_SplitScreen") || strstr(shader, "ClassifyTiles"))
         return 0; // read user inputs only
-    return -1;
+    return -1; // incl. _HitDistReconstruction (the pre-pass then gathers from its output at blur-radius distance)
 }
 
 extern "C" __attribute__((visibility("default"))) uint32_t nrdHipSetOwnedRows(NrdHipExecutor* e, uint32_t rowBegin, uint32_t rowEnd) {

@@ -376,8 +376,6 @@ __global__ __launch_bounds__(TILE_X* TILE_Y) void ReblurSpatialKernel(ReblurCB c
 static const char* CheckSupported(const ReblurCB& c) {
     if (c.gDiffCheckerboard != 2 || c.gSpecCheckerboard != 2)
         return "REBLUR: checkerboard modes are not implemented in the HIP back-end yet";
-    if (c.gHasHistoryConfidence || c.gHasDisocclusionThresholdMix)
-        return "REBLUR: history-confidence / disocclusion-threshold-mix inputs are not implemented in the HIP back-end yet";
     if (c.gRectOrigin.x != 0 || c.gRectOrigin.y != 0 || c.gResolutionScale.x != 1.0f || c.gResolutionScale.y != 1.0f)
         return "REBLUR: dynamic resolution (rect != resource) is not implemented in the HIP back-end yet";
     if (c.gOrthoMode != 0.0f)
@@ -467,7 +465,112 @@ static const char* LaunchSplitScreen(const PassArgs& a) {
     return nullptr;
 }
 
+// ================================================================================================ HitDistReconstruction
+// reference Shaders/Include/REBLUR_HitDistReconstruction.hlsli:10-160 (normalised hit distances, non-performance mode).
+// An optional pass (HitDistanceReconstructionMode != OFF): the 3x3 / 5x5 window is read straight from L1/L2 at rect-clamped
+// coordinates -- 8 / 24 taps of (decoded normal 16 B, viewZ 4 B, hit distance 2 x 8 B) -- instead of staging an LDS tile.
+struct HitDistPlanes {
+    Plane tiles, viewZ, decodedNR, inDiff, inSpec, outDiff, outSpec;
+};
+
+template <bool DIFF, bool SPEC, int BORDER>
+__global__ __launch_bounds__(TILE_X* TILE_Y) void ReblurHitDistReconstructionKernel(ReblurCB c, HitDistPlanes P, RowRange rr) {
+    const int px = blockIdx.x * TILE_X + (threadIdx.x % TILE_X);
+    const int py = (blockIdx.y + rr.firstBlockY) * TILE_Y + (threadIdx.x / TILE_X);
+    const int rw = c.gRectSizeMinusOne.x, rh = c.gRectSizeMinusOne.y;
+    if (px > rw || py > rh || py < rr.rowBegin || py >= rr.rowEnd)
+        return;
+    if (LoadR8Unorm(P.tiles, px >> 4, py >> 4) != 0.0f)
+        return;
+    const float centerZ = UnpackViewZ(c, LoadR32F(P.viewZ, px, py));
+    if (centerZ > c.gDenoisingRange)
+        return;
+
+    const float4 normalAndRoughness = LoadDecodedNormalRoughness(P.decodedNR, px, py);
+    const float3 N = Xyz(normalAndRoughness);
+    const float roughness = normalAndRoughness.w;
+
+    const float2 rectSizeInv = ToF2(c.gRectSizeInv);
+    const float4 frustum = ToF4(c.gFrustum);
+    const float2 pixelUv = F2(float(px) + 0.5f, float(py) + 0.5f) * rectSizeInv;
+    const float3 Xv = ReconstructViewPosition(pixelUv, frustum, centerZ, c.gOrthoMode);
+    const float3 Nv = RotateVectorInverse(c.gViewToWorld, N);
+    const float frustumSize = GetFrustumSize(c.gMinRectDimMulUnproject, c.gOrthoMode, centerZ);
+
+    const float2 geometryWeightParams = GetGeometryWeightParams(c.gPlaneDistSensitivity, frustumSize, Xv, Nv);
+    const float2 relaxedRoughnessWeightParams = GetRelaxedRoughnessWeightParams(roughness * roughness);
+    const float diffNormalWeightParam = GetNormalWeightParam(1.0f, 1.0f);
+    const float specNormalWeightParam = GetNormalWeightParam(1.0f, 1.0f, roughness);
+
+    const float4 centerDiff = DIFF ? LoadRGBA16F(P.inDiff, px, py) : F4(0.0f), centerSpec = SPEC ? LoadRGBA16F(P.inSpec, px, py) : F4(0.0f);
+    float2 center = F2(centerDiff.w, centerSpec.w);
+    float2 sum = F2(center.x != 0.0f ? 1000.0f : 0.0f, center.y != 0.0f ? 1000.0f : 0.0f);
+    center = center * sum;
+
+    for (int j = 0; j <= BORDER * 2; j++)
+        for (int i = 0; i <= BORDER * 2; i++) {
+            const float2 o = F2(float(i - BORDER), float(j - BORDER));
+            if (o.x == 0.0f && o.y == 0.0f)
+                continue;
+            const int sx = ClampI(px + i - BORDER, 0, rw), sy = ClampI(py + j - BORDER, 0, rh);
+            float2 data = F2(DIFF ? LoadRGBA16F(P.inDiff, sx, sy).w : 0.0f, SPEC ? LoadRGBA16F(P.inSpec, sx, sy).w : 0.0f);
+            const float dataZ = UnpackViewZ(c, LoadR32F(P.viewZ, sx, sy));
+
+            float w = IsInScreenNearest(pixelUv + o * rectSizeInv);
+            w *= GetGaussianWeight(Length(o) * 0.5f);
+
+            const float2 uv = pixelUv + o * rectSizeInv;
+            const float3 Xvs = ReconstructViewPosition(uv, frustum, dataZ, c.gOrthoMode);
+            w *= ComputeWeight(Dot(Nv, Xvs), geometryWeightParams.x, geometryWeightParams.y);
+
+            float2 ww = F2(w, w);
+            const float4 sampleNormalAndRoughness = LoadDecodedNormalRoughness(P.decodedNR, sx, sy);
+            const float cosa = Dot(N, Xyz(sampleNormalAndRoughness));
+            const float angle = AcosApprox(cosa);
+            ww.x *= ComputeExponentialWeight(angle, diffNormalWeightParam, 0.0f);
+            ww.y *= ComputeExponentialWeight(angle, specNormalWeightParam, 0.0f);
+            ww.y *= ComputeExponentialWeight(sampleNormalAndRoughness.w * sampleNormalAndRoughness.w, relaxedRoughnessWeightParams.x, relaxedRoughnessWeightParams.y);
+
+            data.x = ww.x == 0.0f ? 0.0f : data.x;
+            data.y = ww.y == 0.0f ? 0.0f : data.y;
+            ww = ww * F2(data.x != 0.0f ? 1.0f : 0.0f, data.y != 0.0f ? 1.0f : 0.0f);
+
+            center = center + data * ww;
+            sum = sum + ww;
+        }
+    center = center / F2(Max(sum.x, NRD_EPS), Max(sum.y, NRD_EPS));
+
+    if (DIFF)
+        StoreRGBA16F(P.outDiff, px, py, F4(Xyz(centerDiff), center.x));
+    if (SPEC)
+        StoreRGBA16F(P.outSpec, px, py, F4(Xyz(centerSpec), center.y));
+}
+
+template <bool DIFF, bool SPEC, int BORDER>
+static const char* LaunchHitDistReconstruction(const PassArgs& a) {
+    const ReblurCB& c = *(const ReblurCB*)a.constants;
+    if (const char* err = CheckSupported(c))
+        return err;
+    HitDistPlanes P = {};
+    uint32_t k = 0;
+    P.tiles = a.planes[k++];
+    k++; // packed normal / roughness: read through the decoded cache
+    P.viewZ = a.planes[k++];
+    if (DIFF) P.inDiff = a.planes[k++];
+    if (SPEC) P.inSpec = a.planes[k++];
+    if (DIFF) P.outDiff = a.planes[k++];
+    if (SPEC) P.outSpec = a.planes[k++];
+    P.decodedNR = a.decodedNormalRoughness;
+    if (k != a.planesNum || !P.decodedNR.ptr)
+        return "REBLUR hit distance reconstruction: unexpected resource count or missing decoded normal/roughness cache";
+    RowGrid g = GridForRows(c.gRectSizeMinusOne.x + 1, c.gRectSizeMinusOne.y + 1, TILE_X, TILE_Y, a.rowBegin, a.rowEnd);
+    hipLaunchKernelGGL((ReblurHitDistReconstructionKernel<DIFF, SPEC, BORDER>), g.grid, dim3(TILE_X * TILE_Y), 0, a.stream, c, P, RowRange{g.firstBlockY, g.rowBegin, g.rowEnd});
+    return nullptr;
+}
+
 #define REBLUR_SPATIAL_FAMILY(NAME, D, S)                                                              \
+    {"REBLUR_" NAME "_HitDistReconstruction.cs", LaunchHitDistReconstruction<D, S, 1>},                \
+    {"REBLUR_" NAME "_HitDistReconstruction_5x5.cs", LaunchHitDistReconstruction<D, S, 2>},            \
     {"REBLUR_" NAME "_PrePass.cs", LaunchSpatial<PRE_BLUR, D, S, false>},                              \
     {"REBLUR_" NAME "_Blur.cs", LaunchSpatial<BLUR, D, S, false>},                                     \
     {"REBLUR_" NAME "_PostBlur.cs", LaunchSpatial<POST_BLUR, D, S, false>},                            \

@@ -25,6 +25,7 @@ constexpr int BUF_STRIDE = BUF_X + 1;      // 35 float4 slots per row
 struct TaPlanes {
     Plane tiles, normalRoughness, viewZ, mv, prevViewZ, prevNormalRoughness, prevInternalData;
     Plane decodedNR; // executor's float4 cache of normalRoughness (reblur_device.h "decoded guides")
+    Plane disocclusionThresholdMix, diffConfidence, specConfidence; // R8_UNORM user inputs; dummies unless the gHas* flags are set
     Plane inDiff, inSpec, historyDiff, historySpec, historyDiffFast, historySpecFast, prevSpecHitDistForTracking, inSpecHitDistForTracking;
     Plane outDiff, outSpec, outDiffFast, outSpecFast, outSpecHitDistForTracking, outData1, outData2;
 };
@@ -208,6 +209,8 @@ __global__ __launch_bounds__(TILE_X* TILE_Y, 3) void ReblurTemporalAccumulationK
     float disocclusionThresholdMix = 0.0f;
     if (materialID == c.gStrandMaterialID)
         disocclusionThresholdMix = Sat(c.gStrandThickness / pixelSize);
+    if (c.gHasDisocclusionThresholdMix)
+        disocclusionThresholdMix = LoadR8Unorm(P.disocclusionThresholdMix, px, py);
     float disocclusionThreshold = Lerp(c.gDisocclusionThreshold, c.gDisocclusionThresholdAlternate, disocclusionThresholdMix);
 
     float smallParallax = LinearStep(0.25f, 0.0f, smbParallaxInPixelsMax);
@@ -284,6 +287,8 @@ __global__ __launch_bounds__(TILE_X* TILE_Y, 3) void ReblurTemporalAccumulationK
     // (before the long specular section: everything the diffuse part needs from the shared footprint dies here, not after it)
     if (DIFF) {
         float diffHistoryConfidence = smbFootprintQuality;
+        if (c.gHasHistoryConfidence)
+            diffHistoryConfidence *= LoadR8Unorm(P.diffConfidence, px, py);
         diffAccumSpeed *= Lerp(diffHistoryConfidence, 1.0f, 1.0f / (1.0f + diffAccumSpeed));
         diffAccumSpeed = Min(diffAccumSpeed, c.gMaxAccumulatedFrameNum);
 
@@ -320,6 +325,8 @@ __global__ __launch_bounds__(TILE_X* TILE_Y, 3) void ReblurTemporalAccumulationK
     float specAccumSpeed = 0.0f, curvature = 0.0f, virtualHistoryAmount = 0.0f;
     if (SPEC) {
         float specHistoryConfidence = smbFootprintQuality;
+        if (c.gHasHistoryConfidence)
+            specHistoryConfidence *= LoadR8Unorm(P.specConfidence, px, py);
         smbSpecAccumSpeed *= Lerp(specHistoryConfidence, 1.0f, 1.0f / (1.0f + smbSpecAccumSpeed));
         smbSpecAccumSpeed = Min(smbSpecAccumSpeed, c.gMaxAccumulatedFrameNum);
 
@@ -653,8 +660,6 @@ static const char* LaunchTemporalAccumulation(const PassArgs& a) {
     const ReblurCB& c = *(const ReblurCB*)a.constants;
     if (c.gDiffCheckerboard != 2 || c.gSpecCheckerboard != 2)
         return "REBLUR: checkerboard modes are not implemented in the HIP back-end yet";
-    if (c.gHasHistoryConfidence || c.gHasDisocclusionThresholdMix)
-        return "REBLUR: history-confidence / disocclusion-threshold-mix inputs are not implemented in the HIP back-end yet";
     if (c.gRectOrigin.x != 0 || c.gRectOrigin.y != 0 || c.gResolutionScale.x != 1.0f || c.gResolutionScale.y != 1.0f || c.gResolutionScalePrev.x != 1.0f || c.gResolutionScalePrev.y != 1.0f)
         return "REBLUR: dynamic resolution (rect != resource) is not implemented in the HIP back-end yet";
     if (c.gOrthoMode != 0.0f)
@@ -672,9 +677,9 @@ static const char* LaunchTemporalAccumulation(const PassArgs& a) {
     P.prevViewZ = a.planes[k++];
     P.prevNormalRoughness = a.planes[k++];
     P.prevInternalData = a.planes[k++];
-    k++;           // disocclusion threshold mix (dummy)
-    if (DIFF) k++; // diffuse confidence (dummy)
-    if (SPEC) k++; // specular confidence (dummy)
+    P.disocclusionThresholdMix = a.planes[k++];
+    if (DIFF) P.diffConfidence = a.planes[k++];
+    if (SPEC) P.specConfidence = a.planes[k++];
     if (DIFF) P.inDiff = a.planes[k++];
     if (SPEC) P.inSpec = a.planes[k++];
     if (DIFF) P.historyDiff = a.planes[k++];

@@ -55,6 +55,113 @@ const char* LaunchClassifyTiles(const PassArgs& a) {
     return nullptr;
 }
 
+// ================================================================================================ HitDistReconstruction
+// reference Shaders/Include/RELAX_HitDistReconstruction.hlsli:10-160; an optional pass, the 3x3 / 5x5 window is read at
+// rect-clamped coordinates straight from L1/L2. Hit distances are (spec, diff). NOTE (kept): the reference feeds the CENTER
+// roughness to the roughness weight, which therefore evaluates to exactly 1.
+struct HitDistPlanes {
+    Plane tiles, viewZ, decodedNR;
+    SignalPlanes spec, diff;
+};
+
+template <bool DIFF, bool SPEC, int BORDER>
+__global__ __launch_bounds__(256) void RelaxHitDistReconstructionKernel(HitDistPlanes P, RelaxCB c, RowRange rows) {
+    const int blockY = blockIdx.y + rows.firstBlockY;
+    const int px = blockIdx.x * TILE_X + (threadIdx.x & 31), py = blockY * TILE_Y + (threadIdx.x >> 5);
+    const int rectW = c.shared.gRectSize.x, rectH = c.shared.gRectSize.y;
+    if (px >= rectW || py >= rectH || py < rows.rowBegin || py >= rows.rowEnd)
+        return;
+    if (LoadR8Unorm(P.tiles, px >> 4, py >> 4) != 0.0f)
+        return;
+    const float centerViewZ = RelaxUnpackViewZ(c, LoadR32F(P.viewZ, px, py));
+    if (centerViewZ > c.shared.gDenoisingRange)
+        return;
+
+    const float2 rectSizeInv = ToF2(c.shared.gRectSizeInv);
+    const float2 pixelUv = F2(float(px) + 0.5f, float(py) + 0.5f) * rectSizeInv;
+    const float4 normalAndRoughness = LoadDecodedNormalRoughness(P.decodedNR, px, py);
+    const float3 centerNormal = Xyz(normalAndRoughness);
+    const float centerRoughness = normalAndRoughness.w;
+    const float4 centerSpec = SPEC ? LoadRGBA16F(P.spec.in, px, py) : F4(0.0f), centerDiff = DIFF ? LoadRGBA16F(P.diff.in, px, py) : F4(0.0f);
+    const float2 centerHitDist = F2(SPEC ? centerSpec.w : c.shared.gDenoisingRange, DIFF ? centerDiff.w : c.shared.gDenoisingRange);
+
+    const float2 relaxedRoughnessWeightParams = GetRelaxedRoughnessWeightParams(centerRoughness * centerRoughness);
+    const float specularNormalWeightParam = GetNormalWeightParam(1.0f, 1.0f, centerRoughness);
+    const float diffuseNormalWeightParam = GetNormalWeightParam(1.0f, 1.0f);
+
+    float sumSpecularWeight = 1000.0f * Cmp(centerHitDist.x != 0.0f);
+    float sumSpecularHitDist = centerHitDist.x * sumSpecularWeight;
+    float sumDiffuseWeight = 1000.0f * Cmp(centerHitDist.y != 0.0f);
+    float sumDiffuseHitDist = centerHitDist.y * sumDiffuseWeight;
+
+    for (int dy = 0; dy <= BORDER * 2; dy++)
+        for (int dx = 0; dx <= BORDER * 2; dx++) {
+            const int ix = dx - BORDER, iy = dy - BORDER;
+            if (ix == 0 && iy == 0)
+                continue;
+            const float2 o = F2(float(ix), float(iy));
+            const int sx = ClampI(px + ix, 0, rectW - 1), sy = ClampI(py + iy, 0, rectH - 1);
+            const float3 sampleNormal = Xyz(LoadDecodedNormalRoughness(P.decodedNR, sx, sy));
+            const float sampleViewZ = RelaxUnpackViewZ(c, LoadR32F(P.viewZ, sx, sy));
+            const float cosa = Dot(centerNormal, sampleNormal);
+            const float angle = AcosApprox(cosa);
+
+            float w = IsInScreenNearest(pixelUv + o * rectSizeInv);
+            w *= Cmp(sampleViewZ < c.shared.gDenoisingRange);
+            w *= GetGaussianWeight(Length(o) * 0.5f);
+            w *= LinearStep(0.03f, 0.0f, Abs(sampleViewZ - centerViewZ) * Rcp(Max(sampleViewZ, centerViewZ))); // GetBilateralWeight
+
+            if (SPEC) {
+                float specularWeight = w;
+                specularWeight *= ComputeExponentialWeight(angle, specularNormalWeightParam, 0.0f);
+                specularWeight *= ComputeExponentialWeight(normalAndRoughness.w * normalAndRoughness.w, relaxedRoughnessWeightParams.x, relaxedRoughnessWeightParams.y);
+                float sampleSpecularHitDist = specularWeight == 0.0f ? 0.0f : LoadRGBA16F(P.spec.in, sx, sy).w;
+                specularWeight *= Cmp(sampleSpecularHitDist != 0.0f);
+                sumSpecularHitDist += sampleSpecularHitDist * specularWeight;
+                sumSpecularWeight += specularWeight;
+            }
+            if (DIFF) {
+                float diffuseWeight = w;
+                diffuseWeight *= ComputeExponentialWeight(angle, diffuseNormalWeightParam, 0.0f);
+                float sampleDiffuseHitDist = diffuseWeight == 0.0f ? 0.0f : LoadRGBA16F(P.diff.in, sx, sy).w;
+                diffuseWeight *= Cmp(sampleDiffuseHitDist != 0.0f);
+                sumDiffuseHitDist += diffuseWeight == 0.0f ? 0.0f : sampleDiffuseHitDist * diffuseWeight;
+                sumDiffuseWeight += diffuseWeight;
+            }
+        }
+
+    if (SPEC) {
+        sumSpecularHitDist /= Max(sumSpecularWeight, 1e-6f);
+        StoreRGBA16F(P.spec.out, px, py, F4(Xyz(centerSpec), sumSpecularHitDist));
+    }
+    if (DIFF) {
+        sumDiffuseHitDist /= Max(sumDiffuseWeight, 1e-6f);
+        StoreRGBA16F(P.diff.out, px, py, F4(Xyz(centerDiff), sumDiffuseHitDist));
+    }
+}
+
+template <bool DIFF, bool SPEC, int BORDER>
+const char* LaunchHitDistReconstruction(const PassArgs& a) {
+    if (const char* e = CheckSupportedRelax(a))
+        return e;
+    PlaneCursor cur(a);
+    HitDistPlanes P = {};
+    P.tiles = cur.next();
+    if (SPEC) P.spec.in = cur.next();
+    if (DIFF) P.diff.in = cur.next();
+    cur.next(); // packed normal / roughness: read through the decoded cache
+    P.viewZ = cur.next();
+    if (SPEC) P.spec.out = cur.next();
+    if (DIFF) P.diff.out = cur.next();
+    P.decodedNR = a.decodedNormalRoughness;
+    if (!cur.complete() || !P.decodedNR.ptr)
+        return "RELAX HitDistReconstruction: unexpected resource count or missing decoded normal/roughness cache";
+    RelaxCB c = LoadRelaxConstants(a);
+    RowGrid g = GridForRows(c.shared.gRectSize.x, c.shared.gRectSize.y, TILE_X, TILE_Y, a.rowBegin, a.rowEnd);
+    hipLaunchKernelGGL((RelaxHitDistReconstructionKernel<DIFF, SPEC, BORDER>), g.grid, dim3(256), 0, a.stream, P, c, RowRange{g.firstBlockY, g.rowBegin, g.rowEnd});
+    return nullptr;
+}
+
 // ================================================================================================ PrePass
 struct PrePassPlanes {
     Plane tiles, normalRoughness, viewZ;
@@ -384,6 +491,125 @@ const char* LaunchHistoryFix(const PassArgs& a) {
     return nullptr;
 }
 
+// ================================================================================================ Copy / AntiFirefly
+// Only dispatched with RelaxSettings::enableAntiFirefly: history -> user output planes, then a 3x3 rank-conditioned
+// rank-selection filter back into the history (reference Shaders/Include/RELAX_Copy.hlsli, RELAX_AntiFirefly.hlsli).
+struct CopyPlanes {
+    SignalPlanes spec, diff;
+};
+
+template <bool DIFF, bool SPEC>
+__global__ __launch_bounds__(256) void RelaxCopyKernel(CopyPlanes P, int gridW, int gridH) {
+    const int px = blockIdx.x * TILE_X + (threadIdx.x & 31), py = blockIdx.y * TILE_Y + (threadIdx.x >> 5);
+    if (px >= gridW || py >= gridH)
+        return;
+    if (SPEC && InBounds(P.spec.out, px, py))
+        StoreRGBA16F(P.spec.out, px, py, LoadRGBA16FOrZero(P.spec.in, px, py));
+    if (DIFF && InBounds(P.diff.out, px, py))
+        StoreRGBA16F(P.diff.out, px, py, LoadRGBA16FOrZero(P.diff.in, px, py));
+}
+
+template <bool DIFF, bool SPEC>
+const char* LaunchCopy(const PassArgs& a) {
+    if (const char* e = CheckSupportedRelax(a))
+        return e;
+    PlaneCursor cur(a);
+    CopyPlanes P = {};
+    if (SPEC) P.spec.in = cur.next();
+    if (DIFF) P.diff.in = cur.next();
+    if (SPEC) P.spec.out = cur.next();
+    if (DIFF) P.diff.out = cur.next();
+    if (!cur.complete())
+        return "RELAX Copy: unexpected resource count";
+    RelaxCB c = LoadRelaxConstants(a);
+    const int gridW = (c.shared.gRectSize.x + 7) & ~7, gridH = (c.shared.gRectSize.y + 7) & ~7; // the reference's 8x8 groups over the rect
+    hipLaunchKernelGGL((RelaxCopyKernel<DIFF, SPEC>), GridFor(gridW, gridH, TILE_X, TILE_Y), dim3(256), 0, a.stream, P, gridW, gridH);
+    return nullptr;
+}
+
+struct AntiFireflyPlanes {
+    Plane tiles, viewZ, decodedNR;
+    SignalPlanes spec, diff;
+};
+
+template <bool IS_SPEC>
+NRD_D void AntiFireflySignal(const RelaxCB& c, const SignalPlanes& S, const Plane& decodedNR, int px, int py, float centerMaterialID) {
+    const int rectW = c.shared.gRectSize.x, rectH = c.shared.gRectSize.y;
+    const float minMaterial = IS_SPEC ? c.shared.gSpecMinMaterial : c.shared.gDiffMinMaterial;
+    const float4 center = LoadRGBA16F(S.in, px, py);
+    const float centerLuminance = Luminance(Xyz(center));
+    float maxLuminance = -1.0f, minLuminance = 1.0e6f;
+    float3 maxValue = Xyz(center), minValue = Xyz(center);
+#pragma unroll
+    for (int yy = -1; yy <= 1; yy++)
+#pragma unroll
+        for (int xx = -1; xx <= 1; xx++) {
+            const int qx = px + xx, qy = py + yy;
+            if ((xx == 0 && yy == 0) || qx < 0 || qy < 0 || qx >= rectW || qy >= rectH)
+                continue;
+            const float3 value = Xyz(LoadRGBA16F(S.in, qx, qy));
+            const float luminance = Luminance(value);
+            float sampleMaterialID;
+            LoadDecodedNormalRoughness(decodedNR, qx, qy, sampleMaterialID);
+            if (CompareMaterials(sampleMaterialID, centerMaterialID, minMaterial)) {
+                if (luminance > maxLuminance) {
+                    maxLuminance = luminance;
+                    maxValue = value;
+                }
+                if (luminance < minLuminance) {
+                    minLuminance = luminance;
+                    minValue = value;
+                }
+            }
+        }
+    float3 result = Xyz(center);
+    if (centerLuminance > maxLuminance)
+        result = maxValue;
+    if (centerLuminance < minLuminance)
+        result = minValue;
+    StoreRGBA16F(S.out, px, py, F4(result, center.w));
+}
+
+template <bool DIFF, bool SPEC>
+__global__ __launch_bounds__(256) void RelaxAntiFireflyKernel(AntiFireflyPlanes P, RelaxCB c, RowRange rows) {
+    const int blockY = blockIdx.y + rows.firstBlockY;
+    const int px = blockIdx.x * TILE_X + (threadIdx.x & 31), py = blockY * TILE_Y + (threadIdx.x >> 5);
+    if (px >= c.shared.gRectSize.x || py >= c.shared.gRectSize.y || py < rows.rowBegin || py >= rows.rowEnd)
+        return;
+    if (LoadR8Unorm(P.tiles, px >> 4, py >> 4) != 0.0f)
+        return;
+    if (RelaxUnpackViewZ(c, LoadR32F(P.viewZ, px, py)) > c.shared.gDenoisingRange)
+        return;
+    float centerMaterialID;
+    LoadDecodedNormalRoughness(P.decodedNR, px, py, centerMaterialID);
+    if (SPEC)
+        AntiFireflySignal<true>(c, P.spec, P.decodedNR, px, py, centerMaterialID);
+    if (DIFF)
+        AntiFireflySignal<false>(c, P.diff, P.decodedNR, px, py, centerMaterialID);
+}
+
+template <bool DIFF, bool SPEC>
+const char* LaunchAntiFirefly(const PassArgs& a) {
+    if (const char* e = CheckSupportedRelax(a))
+        return e;
+    PlaneCursor cur(a);
+    AntiFireflyPlanes P = {};
+    P.tiles = cur.next();
+    if (SPEC) P.spec.in = cur.next();
+    if (DIFF) P.diff.in = cur.next();
+    cur.next(); // packed normal / roughness: read through the decoded cache
+    P.viewZ = cur.next();
+    if (SPEC) P.spec.out = cur.next();
+    if (DIFF) P.diff.out = cur.next();
+    P.decodedNR = a.decodedNormalRoughness;
+    if (!cur.complete() || !P.decodedNR.ptr)
+        return "RELAX AntiFirefly: unexpected resource count or missing decoded normal/roughness cache";
+    RelaxCB c = LoadRelaxConstants(a);
+    RowGrid g = GridForRows(c.shared.gRectSize.x, c.shared.gRectSize.y, TILE_X, TILE_Y, a.rowBegin, a.rowEnd);
+    hipLaunchKernelGGL((RelaxAntiFireflyKernel<DIFF, SPEC>), g.grid, dim3(256), 0, a.stream, P, c, RowRange{g.firstBlockY, g.rowBegin, g.rowEnd});
+    return nullptr;
+}
+
 // ================================================================================================ SplitScreen
 struct SplitScreenPlanes {
     Plane viewZ;
@@ -447,11 +673,20 @@ const char* LaunchSplitScreen(const PassArgs& a) {
 #define RELAX_SPATIAL_VARIANT(name, D, S, H)                            \
     {"RELAX_" name "_PrePass.cs", LaunchPrePass<D, S, H>},             \
     {"RELAX_" name "_HistoryFix.cs", LaunchHistoryFix<D, S, H>},       \
+    {"RELAX_" name "_Copy.cs", LaunchCopy<D, S>},                      \
+    {"RELAX_" name "_AntiFirefly.cs", LaunchAntiFirefly<D, S>},        \
     {"RELAX_" name "_SplitScreen.cs", LaunchSplitScreen<D, S, H>}
+
+#define RELAX_HITDIST(name, D, S)                                                              \
+    {"RELAX_" name "_HitDistReconstruction.cs", LaunchHitDistReconstruction<D, S, 1>},         \
+    {"RELAX_" name "_HitDistReconstruction_5x5.cs", LaunchHitDistReconstruction<D, S, 2>}
 
 const PassEntry* GetRelaxSpatialPasses(uint32_t& num) {
     static const PassEntry k[] = {
         {"RELAX_ClassifyTiles.cs", LaunchClassifyTiles},
+        RELAX_HITDIST("Diffuse", true, false),
+        RELAX_HITDIST("Specular", false, true),
+        RELAX_HITDIST("DiffuseSpecular", true, true),
         RELAX_SPATIAL_VARIANT("Diffuse", true, false, false),
         RELAX_SPATIAL_VARIANT("DiffuseSh", true, false, true),
         RELAX_SPATIAL_VARIANT("Specular", false, true, false),

@@ -234,6 +234,20 @@ def render_frame(width, height, frame, device="cpu", static_camera=False, noise=
         if "relax" in want:
             _pack_relax(out, "spec", rad, torch.where(is_sky, torch.zeros_like(hit_d), hit_d), ws)
 
+    if "holes" in want:
+        # probabilistic sampling: about half of the pixels carry no hit distance (0 = "invalid", to be reconstructed by NRD)
+        hole = _hash_uniform(xi, yi, fr, seed + 20) < 0.5
+        for key in ("diff", "spec", "diff_relax", "spec_relax"):
+            if key in out:
+                out[key][..., 3] = torch.where(hole, torch.zeros_like(out[key][..., 3]), out[key][..., 3])
+
+    if "confidence" in want:
+        # optional guides (R8_UNORM): history confidence per signal and the disocclusion-threshold mix, smooth fields + per-frame hash noise
+        for k, key in enumerate(("diff_confidence", "spec_confidence", "disocclusion_mix")):
+            field = 0.5 + 0.5 * torch.sin(u * (7.0 + 3.0 * k) + 0.37 * frame) * torch.cos(v * (5.0 + 2.0 * k) - 0.21 * frame)
+            field = (0.75 * field + 0.25 * _hash_uniform(xi, yi, fr, seed + 10 + k)).clamp(0.0, 1.0)
+            out[key] = torch.floor(field * 255.0 + 0.5).to(torch.uint8).contiguous()
+
     if "sigma" in want:
         # sun with a 0.25 deg angular radius... widened to 1.5 deg so penumbrae span pixels at test resolutions
         L = _normalize(torch.tensor(LIGHT_DIR, device=dev))

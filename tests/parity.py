@@ -47,6 +47,14 @@ def _relax_signals(name):
 
 def user_planes(name, frame):
     """(ResourceType, tensor, Format) inputs of a denoiser for one generated frame."""
+    extra = []
+    if "diff_confidence" in frame:  # generated with want=(..., "confidence"): optional guides, consumed when CommonSettings enables them
+        extra = [(RT.IN_DIFF_CONFIDENCE, frame["diff_confidence"], F.R8_UNORM), (RT.IN_SPEC_CONFIDENCE, frame["spec_confidence"], F.R8_UNORM),
+                 (RT.IN_DISOCCLUSION_THRESHOLD_MIX, frame["disocclusion_mix"], F.R8_UNORM)]
+    return _user_planes(name, frame) + extra
+
+
+def _user_planes(name, frame):
     planes = [(RT.IN_MV, frame["mv"], F.RGBA16_SFLOAT), (RT.IN_NORMAL_ROUGHNESS, frame["normal_roughness"], F.R10_G10_B10_A2_UNORM), (RT.IN_VIEWZ, frame["viewz"], F.R32_SFLOAT)]
     if name in ("REBLUR_DIFFUSE", "REBLUR_DIFFUSE_SPECULAR"):
         planes.append((RT.IN_DIFF_RADIANCE_HITDIST, frame["diff"], F.RGBA16_SFLOAT))
@@ -192,21 +200,22 @@ class HipRun:
         return t.cpu().numpy().astype(np.float32)
 
 
-def generate_sequence(name, width, height, frames, static_camera=False, noise=True, device="cpu"):
-    return [synth.render_frame(width, height, f, device=device, static_camera=static_camera, noise=noise, want=DENOISERS[name][1]) for f in range(frames)]
+def generate_sequence(name, width, height, frames, static_camera=False, noise=True, device="cpu", extra_want=()):
+    return [synth.render_frame(width, height, f, device=device, static_camera=static_camera, noise=noise, want=tuple(DENOISERS[name][1]) + tuple(extra_want)) for f in range(frames)]
 
 
-def run_parity(name, width=192, height=128, frames=4, verbose=False, settings_overrides=None, static_camera=False, check_pools=True):
+def run_parity(name, width=192, height=128, frames=4, verbose=False, settings_overrides=None, static_camera=False, check_pools=True, cs_kw=None, extra_want=()):
     """Returns the worst relative error between the HIP path and the oracle over all frames, user outputs and pool planes."""
-    seq = generate_sequence(name, width, height, frames, static_camera=static_camera)
+    seq = generate_sequence(name, width, height, frames, static_camera=static_camera, extra_want=extra_want)
+    cs_kw = cs_kw or {}
     ora, hip = OracleRun(name, width, height), HipRun(name, width, height)
     worst = 0.0
     for f, frame in enumerate(seq):
         cam, cam_prev = frame["camera"], seq[max(f - 1, 0)]["camera"]
-        cs = common_settings(cam, cam_prev, width, height, f)
+        cs = common_settings(cam, cam_prev, width, height, f, **cs_kw)
         st = denoiser_settings(name, frame, settings_overrides)
         ora.step(frame, cs, st)
-        hip.step(frame, common_settings(cam, cam_prev, width, height, f), denoiser_settings(name, frame, settings_overrides))
+        hip.step(frame, common_settings(cam, cam_prev, width, height, f, **cs_kw), denoiser_settings(name, frame, settings_overrides))
         for rt in ora.outs:
             want, got = ora.output(rt), hip.output(rt)
             e = rel_error(got, want)

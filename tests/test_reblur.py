@@ -77,6 +77,24 @@ def test_oracle_all_sky_and_split_screen_passthrough():
     assert [d.shader for d in ora.last_dispatches] == ["REBLUR_DiffuseSpecular_SplitScreen.cs"]
 
 
+def test_oracle_neutral_confidence_inputs_change_nothing():
+    # confidence = 1 and disocclusion mix = 0 are the neutral elements of the optional guide inputs
+    name = "REBLUR_DIFFUSE_SPECULAR"
+    seq = parity.generate_sequence(name, W, H, 4, extra_want=("confidence",))
+    for fr in seq:
+        fr["diff_confidence"] = torch.full_like(fr["diff_confidence"], 255)
+        fr["spec_confidence"] = torch.full_like(fr["spec_confidence"], 255)
+        fr["disocclusion_mix"] = torch.zeros_like(fr["disocclusion_mix"])
+    with_guides = _run_oracle(name, seq, cs_kw=dict(isHistoryConfidenceAvailable=True, isDisocclusionThresholdMixAvailable=True))
+    without = _run_oracle(name, seq)
+    for rt in without.outs:
+        assert np.array_equal(with_guides.output(rt), without.output(rt))
+    # and non-neutral guides do change the result
+    seq2 = parity.generate_sequence(name, W, H, 4, extra_want=("confidence",))
+    changed = _run_oracle(name, seq2, cs_kw=dict(isHistoryConfidenceAvailable=True, isDisocclusionThresholdMixAvailable=True))
+    assert any(not np.array_equal(changed.output(rt), without.output(rt)) for rt in without.outs)
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("name", ["REBLUR_DIFFUSE_SPECULAR", "REBLUR_DIFFUSE", "REBLUR_SPECULAR"])
 def test_hip_matches_oracle(name):
@@ -88,6 +106,24 @@ def test_hip_matches_oracle(name):
 def test_hip_matches_oracle_odd_size_no_stabilization():
     # ragged edges (not multiples of 32 / 16 / 8) and the PostBlur_NoTemporalStabilization permutation
     worst = parity.run_parity("REBLUR_DIFFUSE_SPECULAR", width=211, height=117, frames=4, verbose=True, settings_overrides=dict(maxStabilizedFrameNum=0))
+    assert worst <= parity.REL_TOL
+
+
+@pytest.mark.gpu
+def test_hip_matches_oracle_with_confidence_and_disocclusion_mix_inputs():
+    worst = parity.run_parity("REBLUR_DIFFUSE_SPECULAR", width=160, height=96, frames=5, verbose=True, extra_want=("confidence",),
+                              cs_kw=dict(isHistoryConfidenceAvailable=True, isDisocclusionThresholdMixAvailable=True))
+    assert worst <= parity.REL_TOL
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name,mode,prepass", [("REBLUR_DIFFUSE_SPECULAR", 1, True), ("REBLUR_DIFFUSE_SPECULAR", 2, False), ("REBLUR_DIFFUSE", 2, True)])
+def test_hip_matches_oracle_hit_distance_reconstruction(name, mode, prepass):
+    # half of the input hit distances are missing; mode 1 = AREA_3X3, 2 = AREA_5X5; with and without the pre-pass behind it
+    overrides = dict(hitDistanceReconstructionMode=mode)
+    if not prepass:
+        overrides.update(diffusePrepassBlurRadius=0.0, specularPrepassBlurRadius=0.0)
+    worst = parity.run_parity(name, width=176, height=104, frames=3, verbose=True, extra_want=("holes",), settings_overrides=overrides)
     assert worst <= parity.REL_TOL
 
 

@@ -152,6 +152,45 @@ def test_oracle_all_sky_and_split_screen_passthrough():
     assert [d.shader for d in ora.last_dispatches] == ["RELAX_DiffuseSpecular_SplitScreen.cs"]
 
 
+def test_oracle_neutral_confidence_inputs_change_nothing():
+    # confidence = 1 and disocclusion mix = 0 are the neutral elements of the optional guide inputs
+    name = "RELAX_DIFFUSE_SPECULAR"
+    seq = parity.generate_sequence(name, W, H, 4, extra_want=("confidence",))
+    for fr in seq:
+        fr["diff_confidence"] = torch.full_like(fr["diff_confidence"], 255)
+        fr["spec_confidence"] = torch.full_like(fr["spec_confidence"], 255)
+        fr["disocclusion_mix"] = torch.zeros_like(fr["disocclusion_mix"])
+    with_guides = _run_oracle(name, seq, cs_kw=dict(isHistoryConfidenceAvailable=True, isDisocclusionThresholdMixAvailable=True))
+    without = _run_oracle(name, seq)
+    for rt in without.outs:
+        assert np.array_equal(with_guides.output(rt), without.output(rt))
+    # and non-neutral guides do change the result
+    seq2 = parity.generate_sequence(name, W, H, 4, extra_want=("confidence",))
+    changed = _run_oracle(name, seq2, cs_kw=dict(isHistoryConfidenceAvailable=True, isDisocclusionThresholdMixAvailable=True))
+    assert any(not np.array_equal(changed.output(rt), without.output(rt)) for rt in without.outs)
+
+
+def test_oracle_antifirefly_removes_an_isolated_outlier():
+    name = "RELAX_DIFFUSE"
+    seq = parity.generate_sequence(name, W, H, 3, static_camera=True, noise=False)
+    m = ~seq[0]["is_sky"].numpy()
+    ys, xs = np.nonzero(m[8:-8, 8:-8])
+    y, x = int(ys[len(ys) // 2]) + 8, int(xs[len(xs) // 2]) + 8
+    assert m[y - 2 : y + 3, x - 2 : x + 3].all()
+    const = torch.tensor([0.5, 0.5, 0.5, 2.0], dtype=torch.float16)
+    for fr in seq:
+        fr["diff_relax"] = const.expand(H, W, 4).clone()
+        fr["diff_relax"][y, x, :3] = 200.0  # a firefly in every frame
+    overrides = dict(diffusePrepassBlurRadius=0.0, atrousIterationNum=2)
+    plain = _run_oracle(name, seq, overrides=overrides).output(RT.OUT_DIFF_RADIANCE_HITDIST)
+    filtered = _run_oracle(name, seq, overrides=dict(enableAntiFirefly=True, **overrides)).output(RT.OUT_DIFF_RADIANCE_HITDIST)
+    assert plain[y, x, 0] > 5.0  # the outlier survives temporal accumulation + 2 a-trous iterations ...
+    assert abs(filtered[y, x, 0] - 0.5) < 0.05  # ... but not the rank-selection filter
+    far = np.ones_like(m)
+    far[max(y - 40, 0) : y + 41, max(x - 40, 0) : x + 41] = False  # history fix (stride <= 7) and the a-trous taps spread the outlier
+    assert far[m].any() and np.array_equal(plain[far & m], filtered[far & m])
+
+
 # ---------------------------------------------------------------------------------------------------- HIP parity
 @pytest.mark.gpu
 @pytest.mark.parametrize("name", ALL)
@@ -164,6 +203,31 @@ def test_hip_matches_oracle(name):
 def test_hip_matches_oracle_odd_size_and_more_iterations():
     # ragged edges (not multiples of 32 / 16 / 8), 7 a-trous iterations (random tap offsets at steps 8..64)
     worst = parity.run_parity("RELAX_DIFFUSE_SPECULAR_SH", width=211, height=117, frames=4, verbose=True, settings_overrides=dict(atrousIterationNum=7))
+    assert worst <= parity.REL_TOL
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", ["RELAX_DIFFUSE_SPECULAR", "RELAX_DIFFUSE_SPECULAR_SH"])
+def test_hip_matches_oracle_with_confidence_and_disocclusion_mix_inputs(name):
+    # IN_DIFF/SPEC_CONFIDENCE shorten the accumulation and relax the a-trous weights, IN_DISOCCLUSION_THRESHOLD_MIX switches thresholds
+    worst = parity.run_parity(name, width=160, height=96, frames=5, verbose=True, extra_want=("confidence",),
+                              cs_kw=dict(isHistoryConfidenceAvailable=True, isDisocclusionThresholdMixAvailable=True),
+                              settings_overrides=dict(confidenceDrivenRelaxationMultiplier=1.0, confidenceDrivenLuminanceEdgeStoppingRelaxation=0.5, confidenceDrivenNormalEdgeStoppingRelaxation=0.5))
+    assert worst <= parity.REL_TOL
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", ["RELAX_DIFFUSE_SPECULAR", "RELAX_SPECULAR_SH"])
+def test_hip_matches_oracle_antifirefly(name):
+    worst = parity.run_parity(name, width=176, height=104, frames=4, verbose=True, settings_overrides=dict(enableAntiFirefly=True))
+    assert worst <= parity.REL_TOL
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name,mode", [("RELAX_DIFFUSE_SPECULAR", 1), ("RELAX_DIFFUSE_SPECULAR_SH", 2), ("RELAX_SPECULAR", 2)])
+def test_hip_matches_oracle_hit_distance_reconstruction(name, mode):
+    # half of the input hit distances are missing; mode 1 = AREA_3X3, 2 = AREA_5X5
+    worst = parity.run_parity(name, width=176, height=104, frames=3, verbose=True, extra_want=("holes",), settings_overrides=dict(hitDistanceReconstructionMode=mode))
     assert worst <= parity.REL_TOL
 
 
