@@ -429,7 +429,7 @@ __global__ __launch_bounds__(TILE_X* TILE_Y) void ReblurTemporalStabilizationKer
         float3 V = GetViewVector(c, X);
         float3 Xvirtual = GetXvirtual(hitDistForTracking, curvature, X, Xprev, N, V, roughness);
         float2 vmbPixelUv = GetScreenUv(c.gWorldToClipPrev, Xvirtual);
-        vmbPixelUv = materialID == c.gCameraAttachedReflectionMaterialID ? pixelUv : vmbPixelUv;
+        vmbPixelUv = Select(materialID == c.gCameraAttachedReflectionMaterialID, pixelUv, vmbPixelUv);
 
         HistoryFilter smbFilter = MakeHistoryFilter(smbSamplePos, smbOcclusionWeights, smbAllowCatRom, P.historySpecLuma);
         float smbSpecLumaHistory = FetchHistoryR16F(smbFilter, P.historySpecLuma);

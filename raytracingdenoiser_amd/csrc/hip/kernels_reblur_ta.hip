@@ -31,7 +31,7 @@ struct TaPlanes {
 };
 
 template <bool DIFF, bool SPEC>
-__global__ __launch_bounds__(TILE_X* TILE_Y, 3) void ReblurTemporalAccumulationKernel(ReblurCB cArg, TaPlanes P, RowRange rr) {
+__global__ __launch_bounds__(TILE_X* TILE_Y, 2) void ReblurTemporalAccumulationKernel(ReblurCB cArg, TaPlanes P, RowRange rr) {
     __shared__ float4 s_Normal_Roughness[BUF_Y * BUF_STRIDE];
     // The 832-byte constant block + ~20 planes need > 200 SGPRs (102 exist), which the compiler resolves by spilling scalars into
     // VGPR lanes (v_writelane / v_readlane + hazard nops on every use). The body therefore reads the constants from an LDS copy
@@ -335,7 +335,7 @@ __global__ __launch_bounds__(TILE_X* TILE_Y, 3) void ReblurTemporalAccumulationK
         NRD_CONSTANTS_PHASE();
         // Curvature estimation along predicted motion
         {
-            float2 uvForZeroParallax = c.gOrthoMode == 0.0f ? smbPixelUv : pixelUv;
+            float2 uvForZeroParallax = Select(c.gOrthoMode == 0.0f, smbPixelUv, pixelUv);
             float2 deltaUv = uvForZeroParallax - GetScreenUv(c.gWorldToClipPrev, Xprev + cameraDelta);
             deltaUv = deltaUv * rectSize;
             deltaUv = deltaUv / Max(smbParallaxInPixels1, 1.0f / 256.0f);
@@ -345,7 +345,7 @@ __global__ __launch_bounds__(TILE_X* TILE_Y, 3) void ReblurTemporalAccumulationK
                 float3 xv = ReconstructViewPosition(pixelUv + F2(1.0f, 0.0f) * rectSizeInv, frustum, 1.0f, c.gOrthoMode);
                 float3 x = RotateVector(c.gViewToWorld, xv);
                 float3 v = GetViewVector(c, x);
-                float3 o = c.gOrthoMode == 0.0f ? F3(0.0f) : x;
+                float3 o = Select(c.gOrthoMode == 0.0f, F3(0.0f), x);
                 x10 = o + v * Dot(X - o, N) / Dot(N, v);
                 n10 = Xyz(s_Normal_Roughness[(ty + BORDER) * BUF_STRIDE + tx + BORDER + 1]);
             }
@@ -354,7 +354,7 @@ __global__ __launch_bounds__(TILE_X* TILE_Y, 3) void ReblurTemporalAccumulationK
                 float3 xv = ReconstructViewPosition(pixelUv + F2(0.0f, 1.0f) * rectSizeInv, frustum, 1.0f, c.gOrthoMode);
                 float3 x = RotateVector(c.gViewToWorld, xv);
                 float3 v = GetViewVector(c, x);
-                float3 o = c.gOrthoMode == 0.0f ? F3(0.0f) : x;
+                float3 o = Select(c.gOrthoMode == 0.0f, F3(0.0f), x);
                 x01 = o + v * Dot(X - o, N) / Dot(N, v);
                 n01 = Xyz(s_Normal_Roughness[(ty + BORDER + 1) * BUF_STRIDE + tx + BORDER]);
             }
@@ -383,8 +383,8 @@ __global__ __launch_bounds__(TILE_X* TILE_Y, 3) void ReblurTemporalAccumulationK
 
                 float zError = Abs(zHigh - viewZ) * Rcp(Max(zHigh, viewZ));
                 bool cmp = zError < NRD_CURVATURE_Z_THRESHOLD;
-                n = cmp ? nHigh : n;
-                x = cmp ? xHigh : x;
+                n = Select(cmp, nHigh, n);
+                x = Select(cmp, xHigh, x);
             }
 
             float3 edge = x - X;
@@ -398,7 +398,7 @@ __global__ __launch_bounds__(TILE_X* TILE_Y, 3) void ReblurTemporalAccumulationK
         float XvirtualLength = Length(Xvirtual);
 
         float2 vmbPixelUv = GetScreenUv(c.gWorldToClipPrev, Xvirtual);
-        vmbPixelUv = materialID == c.gCameraAttachedReflectionMaterialID ? smbPixelUv : vmbPixelUv;
+        vmbPixelUv = Select(materialID == c.gCameraAttachedReflectionMaterialID, smbPixelUv, vmbPixelUv);
 
         float2 vmbDelta = vmbPixelUv - smbPixelUv;
         float vmbPixelsTraveled = Length(vmbDelta * rectSize);
@@ -434,7 +434,7 @@ __global__ __launch_bounds__(TILE_X* TILE_Y, 3) void ReblurTemporalAccumulationK
         float Dfactor = GetSpecularDominantFactor(NoV, roughness);
         float virtualHistoryNormalBasedConfidence = 1.0f / (1.0f + 0.5f * Dfactor * Sat(Length(N - vmbN) - REBLUR_NORMAL_ULP) * vmbPixelsTraveled);
 
-        smbNavg = smbFootprintQuality == 0.0f ? vmbN : smbNavg;
+        smbNavg = Select(smbFootprintQuality == 0.0f, vmbN, smbNavg);
 
         NRD_CONSTANTS_PHASE();
         // Virtual motion - disocclusion: plane distance and roughness
@@ -511,7 +511,7 @@ __global__ __launch_bounds__(TILE_X* TILE_Y, 3) void ReblurTemporalAccumulationK
             float3 XvirtualPrev = GetXvirtual(hitDistForTrackingPrev, curvature, X, Xprev, N, V, roughness);
 
             float2 vmbPixelUvPrev = GetScreenUv(c.gWorldToClipPrev, XvirtualPrev);
-            vmbPixelUvPrev = materialID == c.gCameraAttachedReflectionMaterialID ? smbPixelUv : vmbPixelUvPrev;
+            vmbPixelUvPrev = Select(materialID == c.gCameraAttachedReflectionMaterialID, smbPixelUv, vmbPixelUvPrev);
 
             float pixelSizeAtXvirtual = PixelRadiusToWorld(c.gUnproject, c.gOrthoMode, 1.0f, XvirtualLength);
             float r = (lobeTanHalfAngle + curvatureAngle) * Min(hitDistForTracking, hitDistForTrackingPrev) / pixelSizeAtXvirtual;
@@ -536,7 +536,7 @@ __global__ __launch_bounds__(TILE_X* TILE_Y, 3) void ReblurTemporalAccumulationK
             w.x = GetEncodingAwareNormalWeight(Xyz(vmbNormalAndRoughness), Xyz(vmbNormalAndRoughnessPrev), lobeHalfAngle, curvatureAngle * (1.0f + i * stepBetweenTaps), REBLUR_NORMAL_ULP);
             w.y = ComputeNonExponentialWeightWithSigma(vmbNormalAndRoughnessPrev.w * vmbNormalAndRoughnessPrev.w, relaxedRoughnessWeightParams.x, relaxedRoughnessWeightParams.y, roughnessSigma);
             w = Lerp(F2(1.0f, 1.0f), w, Sat(stepBetweenTaps));
-            w = IsInScreenNearest(vmbPixelUvPrev) != 0.0f ? w : F2(1.0f, 1.0f);
+            w = Select(IsInScreenNearest(vmbPixelUvPrev) != 0.0f, w, F2(1.0f, 1.0f));
 
             virtualHistoryNormalBasedConfidence = Min(virtualHistoryNormalBasedConfidence, w.x);
             virtualHistoryRoughnessBasedConfidence = Min(virtualHistoryRoughnessBasedConfidence, w.y);

@@ -360,8 +360,8 @@ __global__ __launch_bounds__(256, 3) void RelaxTemporalAccumulationKernel(RelaxC
                 float3 nHigh = Xyz(LoadDecodedNormalRoughness(P.decodedNR, q.x, q.y));
                 float zError = Abs(zHigh - currentLinearZ) * Rcp(Max(zHigh, currentLinearZ));
                 bool cmp = zError < NRD_CURVATURE_Z_THRESHOLD;
-                n = cmp ? nHigh : n;
-                x = cmp ? xHigh : x;
+                n = Select(cmp, nHigh, n);
+                x = Select(cmp, xHigh, x);
             }
 
             float3 edge = x - currentWorldPos;
@@ -382,7 +382,7 @@ __global__ __launch_bounds__(256, 3) void RelaxTemporalAccumulationKernel(RelaxC
             const float3 prevVirtualWorldPos = prevWorldPos + virtualViewVector;
 
             prevUVVMB = ScreenUvNoKill(c.shared.gWorldToClipPrev, prevVirtualWorldPos);
-            prevUVVMB = currentMaterialID == c.shared.gCameraAttachedReflectionMaterialID ? prevUVSMB : prevUVVMB;
+            prevUVVMB = Select(currentMaterialID == c.shared.gCameraAttachedReflectionMaterialID, prevUVSMB, prevUVVMB);
 
             const float2 prevVirtualPixelPosFloat = prevUVVMB * rectSizePrev;
             const float2 originF = Floor(prevVirtualPixelPosFloat - 0.5f);
@@ -497,7 +497,7 @@ __global__ __launch_bounds__(256, 3) void RelaxTemporalAccumulationKernel(RelaxC
         const float3 prevVirtualWorldPos2 = GetXvirtual(hitDistForTrackingPrev, curvature, currentWorldPos, prevWorldPos, currentNormal, V, currentRoughness);
         const float virtualWorldPosLengthPrev = Length(prevVirtualWorldPos2);
         float2 prevUVVMBTest = ScreenUvNoKill(c.shared.gWorldToClipPrev, prevVirtualWorldPos2);
-        prevUVVMBTest = currentMaterialID == c.shared.gCameraAttachedReflectionMaterialID ? prevUVSMB : prevUVVMBTest;
+        prevUVVMBTest = Select(currentMaterialID == c.shared.gCameraAttachedReflectionMaterialID, prevUVSMB, prevUVVMBTest);
 
         float lobeTanHalfAngle = GetSpecLobeTanHalfAngleOld(currentRoughness, 0.6f);
         lobeTanHalfAngle = Max(lobeTanHalfAngle, 0.5f * rectSizeInv.x);

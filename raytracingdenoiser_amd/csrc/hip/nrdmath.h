@@ -147,6 +147,12 @@ NRD_D float4 operator*(float4 a, float b) { return F4(a.x * b, a.y * b, a.z * b,
 NRD_D float4 operator/(float4 a, float b) { return F4(a.x / b, a.y / b, a.z / b, a.w / b); }
 NRD_D float4 operator-(float4 a, float b) { return F4(a.x - b, a.y - b, a.z - b, a.w - b); }
 
+// component-wise select: `cond ? a : b` on two vector LVALUES is an lvalue conditional, which the compiler implements as a
+// select between the addresses of two stack copies (scratch memory traffic); selecting per component keeps it in registers
+NRD_D float2 Select(bool c, float2 a, float2 b) { return F2(c ? a.x : b.x, c ? a.y : b.y); }
+NRD_D float3 Select(bool c, float3 a, float3 b) { return F3(c ? a.x : b.x, c ? a.y : b.y, c ? a.z : b.z); }
+NRD_D float4 Select(bool c, float4 a, float4 b) { return F4(c ? a.x : b.x, c ? a.y : b.y, c ? a.z : b.z, c ? a.w : b.w); }
+
 NRD_D float Dot(float2 a, float2 b) { return a.x * b.x + a.y * b.y; }
 NRD_D float Dot(float3 a, float3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
 NRD_D float Dot(float4 a, float4 b) { return a.x * b.x + a.y * b.y + a.z * b.z + a.w * b.w; }
