@@ -86,6 +86,7 @@ struct NrdHipExecutor {
     uint64_t permanentBytes = 0, transientBytes = 0;
     std::vector<Plane> permanent, transient;
     Plane decodedNormalRoughness = {}; // internal float4 cache of IN_NORMAL_ROUGHNESS (not an NRD pool plane; own allocation)
+    Plane worldPosViewZ = {};          // internal float4 scratch of the RELAX a-trous chain (world position + viewZ per pixel)
     std::vector<nrd::Format> permanentFormat, transientFormat;
 
     Plane user[(size_t)nrd::ResourceType::MAX_NUM] = {};
@@ -226,6 +227,8 @@ extern "C" __attribute__((visibility("default"))) void nrdHipDestroyExecutor(Nrd
         (void)hipFree(e->arena);
     if (e->decodedNormalRoughness.ptr)
         (void)hipFree(e->decodedNormalRoughness.ptr);
+    if (e->worldPosViewZ.ptr)
+        (void)hipFree(e->worldPosViewZ.ptr);
     delete e;
 }
 
@@ -422,6 +425,26 @@ extern "C" __attribute__((visibility("default"))) uint32_t nrdHipExecuteDispatch
             decoded = cache;
         }
     }
+    // World-position scratch of the RELAX a-trous chain (same geometry as the decoded-guide cache)
+    Plane worldPos = {};
+    if (decoded.ptr) {
+        const nrd::InstanceDesc& idesc = nrd::GetInstanceDesc(*e->instance);
+        bool used = false;
+        for (uint32_t i = 0; i < dispatchDescsNum && !used; i++)
+            used = descs[i].pipelineIndex < idesc.pipelinesNum && strstr(idesc.pipelines[descs[i].pipelineIndex].shaderFileName, "_Atrous") != nullptr;
+        if (used) {
+            Plane& cache = e->worldPosViewZ;
+            if (!cache.ptr || cache.w != decoded.w || cache.h != decoded.h) {
+                if (cache.ptr)
+                    (void)hipFree(cache.ptr);
+                cache = decoded;
+                cache.ptr = nullptr;
+                if (hipMalloc((void**)&cache.ptr, (size_t)cache.pitch * (size_t)cache.h) != hipSuccess)
+                    return e->Fail(nrd::Result::FAILURE, "nrdHipExecuteDispatches: cannot allocate the a-trous world-position scratch plane");
+            }
+            worldPos = cache;
+        }
+    }
 
     for (uint32_t i = 0; i < dispatchDescsNum; i++) {
         const nrd::DispatchDesc& d = descs[i];
@@ -460,6 +483,7 @@ extern "C" __attribute__((visibility("default"))) uint32_t nrdHipExecuteDispatch
         args.rowBegin = 0;
         args.rowEnd = INT_MAX;
         args.decodedNormalRoughness = decoded;
+        args.worldPosViewZ = worldPos;
         if (sharded && e->rowMargin[i] >= 0) {
             args.rowBegin = e->ownedRowBegin - e->rowMargin[i];
             args.rowEnd = e->ownedRowEnd == INT_MAX ? INT_MAX : e->ownedRowEnd + e->rowMargin[i];

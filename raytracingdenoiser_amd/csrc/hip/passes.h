@@ -20,6 +20,9 @@ struct PassArgs {
     // executor-internal cache of IN_NORMAL_ROUGHNESS decoded once per frame (float4 per texel: N.xyz, packed roughness | material
     // bits -- reblur_device.h "decoded guides"); ptr == nullptr when the dispatch list does not bind IN_NORMAL_ROUGHNESS
     Plane decodedNormalRoughness;
+    // executor-internal scratch plane of the RELAX a-trous chain (float4 per pixel: world position, viewZ): written by the first
+    // iteration (AtrousSmem) for every pixel, read by the taps of the dilated iterations; ptr == nullptr outside RELAX lists
+    Plane worldPosViewZ;
 };
 
 // returns nullptr on success, or a static message if the dispatch cannot be executed by this build (nothing is launched then)
