@@ -24,7 +24,25 @@ def exchange_strips(planes, row_begin, row_end, group=None):
 
     for p in planes:
         assert p.dim() == 2 and p.is_contiguous()
-        dist.all_gather_into_tensor(p.view(-1), p[row_begin:row_end].reshape(-1), group=group)
+
+    def gather_all():
+        for p in planes:
+            dist.all_gather_into_tensor(p.view(-1), p[row_begin:row_end].reshape(-1), group=group)
+
+    # RCCL: issue the per-plane all-gathers as ONE grouped collective (a dozen small launches per frame otherwise); gloo (CPU tests)
+    # and anything unexpected take the plain loop
+    if planes and planes[0].is_cuda and dist.get_backend(group) == "nccl" and hasattr(dist, "_coalescing_manager"):
+        try:
+            with dist._coalescing_manager(group=group, device=planes[0].device, async_ops=False):
+                gather_all()
+            return
+        except Exception:  # noqa: BLE001 -- private torch API: fall back rather than fail the frame
+            try:  # drop a half-recorded op list, or the plain calls below would be recorded instead of executed
+                c10d = dist.distributed_c10d
+                c10d._world.pg_coalesce_state.pop(group or c10d._get_default_group(), None)
+            except Exception:  # noqa: BLE001
+                pass
+    gather_all()
 
 
 class FrameSharder:
