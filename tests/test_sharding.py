@@ -40,6 +40,33 @@ def test_strip_all_gather_gloo_world2():
     assert results == [(0, True), (1, True)]
 
 
+def _nccl_world1_worker(q):
+    import torch.distributed as dist
+
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(29600 + (os.getpid() % 300))
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", rank=0, world_size=1)
+    planes = [torch.arange(64 * 256, dtype=torch.int32, device="cuda").to(torch.uint8).view(64, 256).contiguous(), torch.full((64, 512), 7, dtype=torch.uint8, device="cuda")]
+    want = [p.clone() for p in planes]
+    sharding.exchange_strips(planes, 0, 64)  # world size 1: the grouped RCCL all-gather must be the identity
+    torch.cuda.synchronize()
+    q.put(all(torch.equal(a, b) for a, b in zip(planes, want)))
+    dist.destroy_process_group()
+
+
+@pytest.mark.gpu
+def test_grouped_rccl_all_gather_world1():
+    # exercises the RCCL (backend "nccl") code path of exchange_strips, including the grouped-collective fast path, on one GPU
+    import torch.multiprocessing as mp
+
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    p = ctx.Process(target=_nccl_world1_worker, args=(q,))
+    p.start()
+    assert q.get(timeout=180) is True
+    p.join(timeout=60)
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("name,world,height,overrides", [
     ("REBLUR_DIFFUSE_SPECULAR", 3, 288, dict(maxBlurRadius=4.0, diffusePrepassBlurRadius=6.0, specularPrepassBlurRadius=6.0)),  # margins < strip: real partial compute
