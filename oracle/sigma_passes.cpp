@@ -1,6 +1,7 @@
 // ORACLE -- TEST INFRASTRUCTURE, NOT PRODUCT CODE (see oracle/hlsl.h).
 //
-// CPU restatement of the SIGMA_SHADOW pass chain (shadow only, no translucency).
+// CPU restatement of the SIGMA_SHADOW and SIGMA_SHADOW_TRANSLUCENCY pass chains. One template per pass, instantiated for
+// SIGMA_TYPE = float (shadow) and float4 (shadow + translucent colour, "#ifdef SIGMA_TRANSLUCENT" in the reference).
 //   ClassifyTiles           reference Shaders/Include/SIGMA_ClassifyTiles.hlsli:11-81
 //   SmoothTiles             reference Shaders/Include/SIGMA_SmoothTiles.hlsli:11-48
 //   Copy                    reference Shaders/Include/SIGMA_Copy.hlsli:11-24
@@ -8,7 +9,7 @@
 //   TemporalStabilization   reference Shaders/Include/SIGMA_TemporalStabilization.hlsli:11-226
 //   SplitScreen             reference Shaders/Include/SIGMA_SplitScreen.hlsli:11-35
 //   helpers                 reference Shaders/Include/SIGMA_Common.hlsli:11-125, SIGMA_Config.hlsli:13-36
-// Binding order of planes = reference Source/Denoisers/Sigma_Shadow.hpp:50-155.
+// Binding order of planes = reference Source/Denoisers/Sigma_Shadow.hpp:50-155 / Sigma_ShadowTranslucency.hpp:50-158.
 #include "passes.h"
 #include "reblur_common.h" // MakeHistoryFilter (shared Common.hlsli:602-656 machinery), CompareMaterials etc.
 
@@ -36,6 +37,27 @@ inline float UnpackViewZ(const SigmaCB& c, float z) { return fabsf(z * c.gViewZS
 inline bool IsLit(float p) { return p >= NRD_FP16_MAX; }
 inline float PackShadow(float s) { return Math::Sqrt01(s); }
 inline float UnpackShadow(float s) { return s * s; } // SIGMA_BackEnd_UnpackShadow, NRD.hlsli:931
+inline float4 PackShadow(float4 s) { return float4(Math::Sqrt01(s.x), Math::Sqrt01(s.y), Math::Sqrt01(s.z), Math::Sqrt01(s.w)); }
+inline float4 UnpackShadow(float4 s) { return s * s; }
+
+// SIGMA_TYPE (SIGMA_Config.hlsli:39-43) and the handful of component-wise intrinsics the passes apply to it
+template <bool TRANSLUCENT> struct SigmaType;
+template <> struct SigmaType<false> {
+    typedef float type;
+    static float From(float4 v) { return v.x; }
+    static float X(float v) { return v; }
+};
+template <> struct SigmaType<true> {
+    typedef float4 type;
+    static float4 From(float4 v) { return v; }
+    static float X(float4 v) { return v.x; }
+};
+inline float StdDev(float m1, float m2) { return sqrtf(fabsf(m2 - m1 * m1)); } // GetStdDev, Common.hlsli:227
+inline float4 StdDev(float4 m1, float4 m2) { return float4(StdDev(m1.x, m2.x), StdDev(m1.y, m2.y), StdDev(m1.z, m2.z), StdDev(m1.w, m2.w)); }
+inline float Clamp(float x, float a, float b) { return clamp(x, a, b); }
+inline float4 Clamp(float4 x, float4 a, float4 b) { return float4(clamp(x.x, a.x, b.x), clamp(x.y, a.y, b.y), clamp(x.z, a.z, b.z), clamp(x.w, a.w, b.w)); }
+inline float Saturate(float x) { return saturate(x); }
+inline float4 Saturate(float4 x) { return float4(saturate(x.x), saturate(x.y), saturate(x.z), saturate(x.w)); }
 inline float3 GetViewVectorV(const SigmaCB& c, float3 X) { return c.gOrthoMode == 0.0f ? normalize(-X) : float3(0, 0, -1); }
 
 // SIGMA_Common.hlsli:21-33 (5x5 radius-estimation kernel => minimum radius 2)
@@ -82,11 +104,14 @@ inline float TextureCubicY(const Tex& tex, float2 uv) {
 }
 
 // ================================================================================================ ClassifyTiles
+template <bool TRANSLUCENT>
 void ClassifyTiles(const PassIO& io) {
     const SigmaCB& c = *(const SigmaCB*)io.constants;
-    const Tex& gIn_ViewZ = io.t[0];
-    const Tex& gIn_Penumbra = io.t[1];
-    Tex& gOut_Tiles = io.t[2];
+    uint32_t k = 0;
+    const Tex& gIn_ViewZ = io.t[k++];
+    const Tex& gIn_Penumbra = io.t[k++];
+    const Tex* gIn_Shadow_Translucency = TRANSLUCENT ? &io.t[k++] : nullptr;
+    Tex& gOut_Tiles = io.t[k++];
 #pragma omp parallel for schedule(static)
     for (int ty = 0; ty < gOut_Tiles.H(); ty++)
         for (int tx = 0; tx < gOut_Tiles.W(); tx++) {
@@ -98,8 +123,13 @@ void ClassifyTiles(const PassIO& io) {
                     float h = gIn_Penumbra.Load(x, y).x;
                     float viewZ = UnpackViewZ(c, gIn_ViewZ.Load(x, y).x);
                     bool isInf = viewZ > c.gDenoisingRange, isShadow = h == 0.0f, isLitP = IsLit(h);
+                    bool isOpaque = true;
+                    if (TRANSLUCENT) {
+                        float4 t = gIn_Shadow_Translucency->Load(x, y);
+                        isOpaque = Color::Luminance(float3(t.y, t.z, t.w)) < 0.003f;
+                    }
                     lit += (isLitP || isInf || isShadow) ? 1 : 0;
-                    umbra += (!isLitP || isInf || isShadow) ? 1 : 0; // isOpaque = true without translucency
+                    umbra += ((!isLitP && isOpaque) || isInf || isShadow) ? 1 : 0;
                     inf += isInf ? 1 : 0;
                     float hitDist = (isLitP || isInf) ? 0.0f : h;
                     float pixelSize = PixelRadiusToWorld(c.gUnproject, c.gOrthoMode, 1.0f, viewZ);
@@ -148,21 +178,24 @@ void Copy(const PassIO& io) {
             float isSky = gIn_Tiles.Load(x >> 4, y >> 4).x;
             if (isSky != 0.0f && !c.gIsRectChanged)
                 continue;
-            gOut_History.Store(x, y, gIn_History.Load(x, y)); // R8 -> R8: the stored byte round-trips exactly
+            gOut_History.Store(x, y, gIn_History.Load(x, y)); // R8 -> R8 / RGBA8 -> RGBA8: the stored bytes round-trip exactly
             gOut_HistoryLength.StoreUint(x, y, gIn_HistoryLength.LoadUint(x, y));
         }
 }
 
 // ================================================================================================ Blur / PostBlur
-template <bool FIRST_PASS>
+template <bool FIRST_PASS, bool TRANSLUCENT>
 void Blur(const PassIO& io) {
+    typedef SigmaType<TRANSLUCENT> ST;
+    typedef typename ST::type S;
+    constexpr bool READS_SHADOW = !FIRST_PASS || TRANSLUCENT; // SIGMA_Blur.hlsli:25
     const SigmaCB& c = *(const SigmaCB*)io.constants;
     uint32_t k = 0;
     const Tex& gIn_ViewZ = io.t[k++];
     const Tex& gIn_Normal_Roughness = io.t[k++];
     const Tex& gIn_Penumbra = io.t[k++];
     const Tex& gIn_Tiles = io.t[k++];
-    const Tex* gIn_Shadow = FIRST_PASS ? nullptr : &io.t[k++];
+    const Tex* gIn_Shadow = READS_SHADOW ? &io.t[k++] : nullptr; // TEMP_1, or IN_TRANSLUCENCY in the translucent first pass
     Tex& gOut_Penumbra = io.t[k++];
     Tex& gOut_Shadow = io.t[k++];
     const int rw = c.gRectSizeMinusOne[0], rh = c.gRectSizeMinusOne[1];
@@ -177,11 +210,14 @@ void Blur(const PassIO& io) {
             // "shared memory" with clamped coordinates
             auto sPenumbra = [&](int x, int y) { return gIn_Penumbra.Load(clamp(x, 0, rw), clamp(y, 0, rh)).x; };
             auto sViewZ = [&](int x, int y) { return UnpackViewZ(c, gIn_ViewZ.Load(clamp(x, 0, rw), clamp(y, 0, rh)).x); };
-            auto sShadow = [&](int x, int y) {
+            auto sShadow = [&](int x, int y) -> S {
                 x = clamp(x, 0, rw), y = clamp(y, 0, rh);
-                if (FIRST_PASS)
-                    return IsLit(gIn_Penumbra.Load(x, y).x) ? 1.0f : 0.0f;
-                return UnpackShadow(gIn_Shadow->Load(x, y).x);
+                S s;
+                if (READS_SHADOW)
+                    s = ST::From(gIn_Shadow->Load(x, y));
+                else
+                    s = S(IsLit(gIn_Penumbra.Load(x, y).x) ? 1.0f : 0.0f);
+                return FIRST_PASS ? s : UnpackShadow(s);
             };
 
             float centerPenumbra = sPenumbra(px, py);
@@ -209,11 +245,13 @@ void Blur(const PassIO& io) {
             float2 geometryWeightParams = GetGeometryWeightParams(c.gPlaneDistSensitivity, frustumSize, Xv, Nv);
 
             // Dense 5x5: penumbra size estimate + shadow filter
-            float sumx = 0.0f, sumy = 0.0f, penumbra = 0.0f, result = 0.0f, centerTap = 0.0f;
+            float sumx = 0.0f, sumy = 0.0f, penumbra = 0.0f;
+            S result = S(0.0f), centerTap = S(0.0f);
             for (int j = 0; j <= BORDER * 2; j++)
                 for (int i = 0; i <= BORDER * 2; i++) {
                     int x = px - BORDER + i, y = py - BORDER + j;
-                    float penum = sPenumbra(x, y), zs = sViewZ(x, y), s = sShadow(x, y);
+                    float penum = sPenumbra(x, y), zs = sViewZ(x, y);
+                    S s = sShadow(x, y);
 
                     float w = 1.0f;
                     if (i == BORDER && j == BORDER)
@@ -226,7 +264,7 @@ void Blur(const PassIO& io) {
                         w *= GetGaussianWeight(length(float2(float(i - BORDER), float(j - BORDER)) / float(BORDER)));
                     }
 
-                    result += w == 0.0f ? 0.0f : s * w;
+                    result = result + (w == 0.0f ? S(0.0f) : s * w);
                     sumx += w;
 
                     w *= pixelSize / (pixelSize + penum);
@@ -236,7 +274,7 @@ void Blur(const PassIO& io) {
                     sumy += w;
                 }
 
-            result /= sumx;
+            result = result / sumx;
             sumx = 1.0f;
             penumbra /= max(sumy, NRD_EPS);
             sumy = sumy != 0.0f ? 1.0f : 0.0f;
@@ -248,7 +286,7 @@ void Blur(const PassIO& io) {
 
             // Sparse 8-tap blur
             f = lerp(4.0f, 1.0f, f);
-            result *= f;
+            result = result * f;
             penumbra *= f;
             sumx *= f;
             sumy *= f;
@@ -271,7 +309,13 @@ void Blur(const PassIO& io) {
 
                 float penum = gIn_Penumbra.SampleNearest(uvScaled).x;
                 float zs = UnpackViewZ(c, gIn_ViewZ.SampleNearest(uvScaled).x);
-                float s = FIRST_PASS ? (IsLit(penum) ? 1.0f : 0.0f) : UnpackShadow(gIn_Shadow->SampleNearest(uvScaled).x);
+                S s;
+                if (READS_SHADOW)
+                    s = ST::From(gIn_Shadow->SampleNearest(uvScaled));
+                else
+                    s = S(IsLit(penum) ? 1.0f : 0.0f);
+                if (!FIRST_PASS)
+                    s = UnpackShadow(s);
 
                 float3 Xvs = Geometry::ReconstructViewPosition(uv, c.gFrustum, zs, c.gOrthoMode);
 
@@ -281,7 +325,7 @@ void Blur(const PassIO& io) {
                 w *= GetGaussianWeight(offset.z);
                 w *= saturate(penum * invEstimatedPenumbra); // avoid umbra leaking inside a wide penumbra
 
-                result += w == 0.0f ? 0.0f : s * w;
+                result = result + (w == 0.0f ? S(0.0f) : s * w);
                 sumx += w;
 
                 w *= pixelSize / (pixelSize + penum);
@@ -291,7 +335,7 @@ void Blur(const PassIO& io) {
                 sumy += w;
             }
 
-            result /= sumx;
+            result = result / sumx;
             penumbra = sumy == 0.0f ? centerPenumbra : penumbra / sumy;
 
             if (FIRST_PASS || c.gStabilizationStrength != 0.0f)
@@ -308,7 +352,10 @@ inline uint32_t PackViewZAndHistoryLength(float viewZ, float historyLength) {
     return p;
 }
 
+template <bool TRANSLUCENT>
 void TemporalStabilization(const PassIO& io) {
+    typedef SigmaType<TRANSLUCENT> ST;
+    typedef typename ST::type S;
     const SigmaCB& c = *(const SigmaCB*)io.constants;
     const Tex& gIn_ViewZ = io.t[0];
     const Tex& gIn_Mv = io.t[1];
@@ -325,7 +372,7 @@ void TemporalStabilization(const PassIO& io) {
     for (int py = 0; py <= rh; py++)
         for (int px = 0; px <= rw; px++) {
             float isSky = gIn_Tiles.Load(px >> 4, py >> 4).x;
-            auto sShadow = [&](int x, int y) { return UnpackShadow(gIn_Shadow.Load(clamp(x, 0, rw), clamp(y, 0, rh)).x); };
+            auto sShadow = [&](int x, int y) -> S { return UnpackShadow(ST::From(gIn_Shadow.Load(clamp(x, 0, rw), clamp(y, 0, rh)))); };
             auto sPenumbra = [&](int x, int y) { return gIn_Penumbra.Load(clamp(x, 0, rw), clamp(y, 0, rh)).x; };
 
             float centerPenumbra = sPenumbra(px, py);
@@ -343,11 +390,12 @@ void TemporalStabilization(const PassIO& io) {
             }
 
             // Local variance over 5x5
-            float sumw = 0.0f, m1 = 0.0f, m2 = 0.0f, input = 0.0f;
+            float sumw = 0.0f;
+            S m1 = S(0.0f), m2 = S(0.0f), input = S(0.0f);
             for (int j = 0; j <= BORDER * 2; j++)
                 for (int i = 0; i <= BORDER * 2; i++) {
                     int x = px - BORDER + i, y = py - BORDER + j;
-                    float s = sShadow(x, y);
+                    S s = sShadow(x, y);
                     float w = 1.0f;
                     if (i == BORDER && j == BORDER)
                         input = s;
@@ -356,13 +404,13 @@ void TemporalStabilization(const PassIO& io) {
                         w = AreBothLitOrUnlit(centerPenumbra, penum);
                         w *= GetGaussianWeight(length(float2(float(i - BORDER), float(j - BORDER)) / float(BORDER)));
                     }
-                    m1 += s * w;
-                    m2 += s * s * w;
+                    m1 = m1 + s * w;
+                    m2 = m2 + s * s * w;
                     sumw += w;
                 }
-            m1 /= sumw;
-            m2 /= sumw;
-            float sigma = sqrtf(fabsf(m2 - m1 * m1));
+            m1 = m1 / sumw;
+            m2 = m2 / sumw;
+            S sigma = StdDev(m1, m2);
 
             // Current and previous positions
             float3 Xv = Geometry::ReconstructViewPosition(pixelUv, c.gFrustum, viewZ, c.gOrthoMode);
@@ -407,17 +455,17 @@ void TemporalStabilization(const PassIO& io) {
             // (kept exactly as in the reference, SIGMA_TemporalStabilization.hlsli:151)
             bool isCatRomAllowed = sum(smbOcclusionWeights) > 3.5f;
             HistoryFilter hf = MakeHistoryFilter(saturate(smbPixelUv) * c.gRectSizePrev, smbOcclusionWeights, isCatRomAllowed);
-            float history = FetchHistoryColor(hf, gIn_History).x;
-            history = saturate(history);
+            S history = ST::From(FetchHistoryColor(hf, gIn_History));
+            history = Saturate(history);
             history = UnpackShadow(history);
 
             // Clamp history
-            sigma *= lerp(SIGMA_TS_SIGMA_SCALE, 1.0f, 1.0f / (1.0f + historyLength));
-            float inputMin = m1 - sigma, inputMax = m1 + sigma;
-            float historyClamped = clamp(history, inputMin, inputMax);
+            sigma = sigma * lerp(SIGMA_TS_SIGMA_SCALE, 1.0f, 1.0f / (1.0f + historyLength));
+            S inputMin = m1 - sigma, inputMax = m1 + sigma;
+            S historyClamped = Clamp(history, inputMin, inputMax);
 
-            // Antilag
-            float antilag = fabsf(historyClamped - history);
+            // Antilag (on the shadow channel only)
+            float antilag = fabsf(ST::X(historyClamped) - ST::X(history));
             antilag = Math::Sqrt01(antilag);
             antilag = saturate(1.0f - antilag);
             historyLength *= antilag;
@@ -426,7 +474,7 @@ void TemporalStabilization(const PassIO& io) {
             float streetMagic = 0.6f * historyWeight * antilag;
             historyClamped = lerp(historyClamped, history, streetMagic);
 
-            float result = lerp(input, historyClamped, min(c.gStabilizationStrength, historyWeight));
+            S result = lerp(input, historyClamped, min(c.gStabilizationStrength, historyWeight));
             historyLength = min(historyLength + 1.0f, SIGMA_MAX_ACCUM_FRAME_NUM);
 
             gOut_Shadow.Store(px, py, PackShadow(result));
@@ -435,18 +483,23 @@ void TemporalStabilization(const PassIO& io) {
 }
 
 // ================================================================================================ SplitScreen
+template <bool TRANSLUCENT>
 void SplitScreen(const PassIO& io) {
+    typedef SigmaType<TRANSLUCENT> ST;
+    typedef typename ST::type S;
     const SigmaCB& c = *(const SigmaCB*)io.constants;
-    const Tex& gIn_ViewZ = io.t[0];
-    const Tex& gIn_Penumbra = io.t[1];
-    Tex& gOut_Shadow = io.t[2];
+    uint32_t k = 0;
+    const Tex& gIn_ViewZ = io.t[k++];
+    const Tex& gIn_Penumbra = io.t[k++];
+    const Tex* gIn_Shadow_Translucency = TRANSLUCENT ? &io.t[k++] : nullptr;
+    Tex& gOut_Shadow = io.t[k++];
     for (int py = 0; py <= c.gRectSizeMinusOne[1]; py++)
         for (int px = 0; px <= c.gRectSizeMinusOne[0]; px++) {
             float2 pixelUv = float2(float(px) + 0.5f, float(py) + 0.5f) * c.gRectSizeInv;
             if (pixelUv.x > c.gSplitScreen)
                 continue;
             float viewZ = UnpackViewZ(c, gIn_ViewZ.Load(px, py).x);
-            float s = IsLit(gIn_Penumbra.Load(px, py).x) ? 1.0f : 0.0f;
+            S s = TRANSLUCENT ? ST::From(gIn_Shadow_Translucency->Load(px, py)) : S(IsLit(gIn_Penumbra.Load(px, py).x) ? 1.0f : 0.0f);
             gOut_Shadow.Store(px, py, s * (viewZ < c.gDenoisingRange ? 1.0f : 0.0f));
         }
 }
@@ -455,13 +508,18 @@ void SplitScreen(const PassIO& io) {
 
 const PassEntry* GetSigmaPasses(uint32_t& n) {
     static const PassEntry k[] = {
-        {"SIGMA_Shadow_ClassifyTiles.cs", ClassifyTiles},
+        {"SIGMA_Shadow_ClassifyTiles.cs", ClassifyTiles<false>},
         {"SIGMA_SmoothTiles.cs", SmoothTiles},
         {"SIGMA_Copy.cs", Copy},
-        {"SIGMA_Shadow_Blur.cs", Blur<true>},
-        {"SIGMA_Shadow_PostBlur.cs", Blur<false>},
-        {"SIGMA_Shadow_TemporalStabilization.cs", TemporalStabilization},
-        {"SIGMA_Shadow_SplitScreen.cs", SplitScreen},
+        {"SIGMA_Shadow_Blur.cs", Blur<true, false>},
+        {"SIGMA_Shadow_PostBlur.cs", Blur<false, false>},
+        {"SIGMA_Shadow_TemporalStabilization.cs", TemporalStabilization<false>},
+        {"SIGMA_Shadow_SplitScreen.cs", SplitScreen<false>},
+        {"SIGMA_ShadowTranslucency_ClassifyTiles.cs", ClassifyTiles<true>},
+        {"SIGMA_ShadowTranslucency_Blur.cs", Blur<true, true>},
+        {"SIGMA_ShadowTranslucency_PostBlur.cs", Blur<false, true>},
+        {"SIGMA_ShadowTranslucency_TemporalStabilization.cs", TemporalStabilization<true>},
+        {"SIGMA_ShadowTranslucency_SplitScreen.cs", SplitScreen<true>},
     };
     n = sizeof(k) / sizeof(k[0]);
     return k;

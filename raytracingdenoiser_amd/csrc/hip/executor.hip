@@ -46,7 +46,8 @@ uint32_t BytesPerTexel(nrd::Format f) {
 }
 
 // Format each user slot must have in this build (MAX_NUM = slot not supported)
-nrd::Format ExpectedUserFormat(nrd::ResourceType t) {
+// translucentShadow: the instance holds SIGMA_SHADOW_TRANSLUCENCY, whose output is (shadow, translucent colour) in RGBA8
+nrd::Format ExpectedUserFormat(nrd::ResourceType t, bool translucentShadow) {
     using R = nrd::ResourceType;
     using F = nrd::Format;
     switch (t) {
@@ -59,7 +60,8 @@ nrd::Format ExpectedUserFormat(nrd::ResourceType t) {
         case R::IN_DIFF_SH0: case R::IN_DIFF_SH1: case R::IN_SPEC_SH0: case R::IN_SPEC_SH1: return F::RGBA16_SFLOAT;
         case R::OUT_DIFF_SH0: case R::OUT_DIFF_SH1: case R::OUT_SPEC_SH0: case R::OUT_SPEC_SH1: return F::RGBA16_SFLOAT;
         case R::IN_PENUMBRA: return F::R16_SFLOAT;
-        case R::OUT_SHADOW_TRANSLUCENCY: return F::R8_UNORM;
+        case R::IN_TRANSLUCENCY: return F::RGBA8_UNORM;
+        case R::OUT_SHADOW_TRANSLUCENCY: return translucentShadow ? F::RGBA8_UNORM : F::R8_UNORM;
         case R::IN_SIGNAL: case R::OUT_SIGNAL: return F::RGBA32_SFLOAT;
         default: return F::MAX_NUM;
     }
@@ -94,6 +96,8 @@ struct NrdHipExecutor {
 
     std::vector<PassLauncher> launchers; // per pipeline index (nullptr = pass not implemented in this build)
     std::vector<Plane> scratchPlanes;
+    std::vector<uint8_t> scratchBytesPerTexel;
+    bool translucentShadow = false; // a SIGMA_ShadowTranslucency_* pipeline exists: OUT_SHADOW_TRANSLUCENCY is RGBA8
     std::string lastError;
 
     uint32_t Fail(nrd::Result r, const std::string& msg) {
@@ -183,6 +187,8 @@ static uint32_t CreateExecutorImpl(void* instance, uint16_t resourceWidth, uint1
             for (uint32_t i = 0; i < counts[t]; i++)
                 if (!strcmp(tables[t][i].shaderFileName, desc.pipelines[p].shaderFileName))
                     e->launchers[p] = tables[t][i].launch;
+    for (uint32_t p = 0; p < desc.pipelinesNum; p++)
+        e->translucentShadow |= strstr(desc.pipelines[p].shaderFileName, "SIGMA_ShadowTranslucency_") != nullptr;
 
     *executor = e;
     return (uint32_t)nrd::Result::SUCCESS;
@@ -285,7 +291,7 @@ extern "C" __attribute__((visibility("default"))) uint32_t nrdHipBindResource(Nr
     if (resourceType >= (uint32_t)nrd::ResourceType::TRANSIENT_POOL)
         return e->Fail(nrd::Result::INVALID_ARGUMENT, "nrdHipBindResource: not a user slot");
 
-    nrd::Format expected = ExpectedUserFormat((nrd::ResourceType)resourceType);
+    nrd::Format expected = ExpectedUserFormat((nrd::ResourceType)resourceType, e->translucentShadow);
     if (expected == nrd::Format::MAX_NUM)
         return e->Fail(nrd::Result::UNSUPPORTED, std::string("nrdHipBindResource: slot not supported in this build: ") + nrd::GetResourceTypeString((nrd::ResourceType)resourceType));
     if (plane->format != (uint32_t)expected)
@@ -456,27 +462,32 @@ extern "C" __attribute__((visibility("default"))) uint32_t nrdHipExecuteDispatch
                 nrd::GetInstanceDesc(*e->instance).pipelines[d.pipelineIndex].shaderFileName + ")");
 
         e->scratchPlanes.resize(d.resourcesNum);
+        e->scratchBytesPerTexel.resize(d.resourcesNum);
         for (uint32_t r = 0; r < d.resourcesNum; r++) {
             const nrd::ResourceDesc& res = d.resources[r];
             if (res.type == nrd::ResourceType::PERMANENT_POOL) {
                 if (res.indexInPool >= e->permanent.size())
                     return e->Fail(nrd::Result::INVALID_ARGUMENT, "permanent pool index out of range");
                 e->scratchPlanes[r] = e->permanent[res.indexInPool];
+                e->scratchBytesPerTexel[r] = (uint8_t)BytesPerTexel(e->permanentFormat[res.indexInPool]);
             } else if (res.type == nrd::ResourceType::TRANSIENT_POOL) {
                 if (res.indexInPool >= e->transient.size())
                     return e->Fail(nrd::Result::INVALID_ARGUMENT, "transient pool index out of range");
                 e->scratchPlanes[r] = e->transient[res.indexInPool];
+                e->scratchBytesPerTexel[r] = (uint8_t)BytesPerTexel(e->transientFormat[res.indexInPool]);
             } else {
                 uint32_t t = (uint32_t)res.type;
                 if (t >= (uint32_t)nrd::ResourceType::MAX_NUM || !e->userBound[t])
                     return e->Fail(nrd::Result::INVALID_ARGUMENT, std::string("resource not bound: ") + (nrd::GetResourceTypeString(res.type) ? nrd::GetResourceTypeString(res.type) : "?"));
                 e->scratchPlanes[r] = e->user[t];
+                e->scratchBytesPerTexel[r] = (uint8_t)BytesPerTexel(ExpectedUserFormat(res.type, e->translucentShadow));
             }
         }
 
         PassArgs args;
         args.planes = e->scratchPlanes.data();
         args.planesNum = d.resourcesNum;
+        args.bytesPerTexel = e->scratchBytesPerTexel.data();
         args.constants = d.constantBufferData;
         args.constantsSize = d.constantBufferDataSize;
         args.stream = e->stream;

@@ -1,4 +1,5 @@
-// SIGMA_SHADOW pass chain as HIP kernels for gfx950.
+// SIGMA_SHADOW and SIGMA_SHADOW_TRANSLUCENCY pass chains as HIP kernels for gfx950 (one template per pass over SIGMA_TYPE:
+// float = shadow in R8, float4 = shadow + translucent colour in RGBA8; reference "#ifdef SIGMA_TRANSLUCENT").
 //   ClassifyTiles           reference Shaders/Include/SIGMA_ClassifyTiles.hlsli:11-81
 //   SmoothTiles             reference Shaders/Include/SIGMA_SmoothTiles.hlsli:11-48
 //   Copy                    reference Shaders/Include/SIGMA_Copy.hlsli:11-24
@@ -35,6 +36,36 @@ NRD_D float UnpackViewZ(const SigmaCB& c, float z) { return Abs(z * c.gViewZScal
 NRD_D bool IsLit(float p) { return p >= NRD_FP16_MAX; }
 NRD_D float PackShadow(float s) { return Sqrt01(s); }
 NRD_D float UnpackShadow(float s) { return s * s; }
+NRD_D float4 PackShadow(float4 s) { return F4(Sqrt01(s.x), Sqrt01(s.y), Sqrt01(s.z), Sqrt01(s.w)); }
+NRD_D float4 UnpackShadow(float4 s) { return s * s; }
+
+// SIGMA_TYPE (reference SIGMA_Config.hlsli:39-43): storage codec + the component-wise intrinsics the passes apply to it
+template <bool TRANSLUCENT>
+struct SigmaType;
+template <>
+struct SigmaType<false> {
+    typedef float type;
+    static NRD_D float Load(const Plane& p, int x, int y) { return LoadR8Unorm(p, x, y); }
+    static NRD_D void Store(const Plane& p, int x, int y, float v) { StoreR8Unorm(p, x, y, v); }
+    static NRD_D float Splat(float v) { return v; }
+    static NRD_D float X(float v) { return v; }
+};
+template <>
+struct SigmaType<true> {
+    typedef float4 type;
+    static NRD_D float4 Load(const Plane& p, int x, int y) { return LoadRGBA8Unorm(p, x, y); }
+    static NRD_D void Store(const Plane& p, int x, int y, float4 v) { StoreRGBA8Unorm(p, x, y, v); }
+    static NRD_D float4 Splat(float v) { return F4(v); }
+    static NRD_D float X(float4 v) { return v.x; }
+};
+NRD_D float ZeroIf(bool c, float v) { return c ? 0.0f : v; }
+NRD_D float4 ZeroIf(bool c, float4 v) { return Select(c, F4(0.0f), v); }
+NRD_D float StdDev(float m1, float m2) { return Sqrt(Abs(m2 - m1 * m1)); }
+NRD_D float4 StdDev(float4 m1, float4 m2) { return F4(StdDev(m1.x, m2.x), StdDev(m1.y, m2.y), StdDev(m1.z, m2.z), StdDev(m1.w, m2.w)); }
+NRD_D float ClampV(float x, float a, float b) { return Clamp(x, a, b); }
+NRD_D float4 ClampV(float4 x, float4 a, float4 b) { return F4(Clamp(x.x, a.x, b.x), Clamp(x.y, a.y, b.y), Clamp(x.z, a.z, b.z), Clamp(x.w, a.w, b.w)); }
+NRD_D float SatV(float x) { return Sat(x); }
+NRD_D float4 SatV(float4 x) { return F4(Sat(x.x), Sat(x.y), Sat(x.z), Sat(x.w)); }
 NRD_D float GetKernelRadiusInPixels(float hitDist, float unprojectZ, float scale = 1.0f) {
     float unclampedRadius = hitDist / unprojectZ;
     unclampedRadius *= scale;
@@ -91,7 +122,8 @@ NRD_D float LoadTileX(const Plane& tiles, int tx, int ty) { // .x of the RG8 smo
 }
 
 // ================================================================================================ ClassifyTiles
-__global__ __launch_bounds__(256) void SigmaClassifyTilesKernel(SigmaCB c, Plane viewZ, Plane penumbra, Plane tiles) {
+template <bool TRANSLUCENT>
+__global__ __launch_bounds__(256) void SigmaClassifyTilesKernel(SigmaCB c, Plane viewZ, Plane penumbra, Plane translucency, Plane tiles) {
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int tileIndex = blockIdx.x * 4 + wave;
     if (tileIndex >= tiles.w * tiles.h)
@@ -108,7 +140,12 @@ __global__ __launch_bounds__(256) void SigmaClassifyTilesKernel(SigmaCB c, Plane
         float z = UnpackViewZ(c, InBounds(viewZ, x, y) ? LoadR32F(viewZ, x, y) : 0.0f);
         bool isInf = z > c.gDenoisingRange, isShadow = h == 0.0f, isLitP = IsLit(h);
         allLit = allLit && (isLitP || isInf || isShadow);
-        allUmbra = allUmbra && (!isLitP || isInf || isShadow);
+        bool isOpaque = true;
+        if (TRANSLUCENT) {
+            float4 t = InBounds(translucency, x, y) ? LoadRGBA8Unorm(translucency, x, y) : F4(0.0f);
+            isOpaque = Luminance(F3(t.y, t.z, t.w)) < 0.003f;
+        }
+        allUmbra = allUmbra && ((!isLitP && isOpaque) || isInf || isShadow);
         allInf = allInf && isInf;
         float hitDist = (isLitP || isInf) ? 0.0f : h;
         float pixelSize = PixelRadiusToWorld(c.gUnproject, c.gOrthoMode, 1.0f, z);
@@ -137,13 +174,16 @@ static const char* CheckSupportedSigma(const SigmaCB& c) {
     return nullptr;
 }
 
+template <bool TRANSLUCENT>
 static const char* LaunchClassifyTiles(const PassArgs& a) {
     const SigmaCB& c = *(const SigmaCB*)a.constants;
     if (const char* err = CheckSupportedSigma(c))
         return err;
-    const Plane& tiles = a.planes[2];
+    if (a.planesNum != (TRANSLUCENT ? 4u : 3u))
+        return "SIGMA classify tiles: unexpected resource count";
+    const Plane& tiles = a.planes[a.planesNum - 1];
     int numTiles = tiles.w * tiles.h;
-    hipLaunchKernelGGL(SigmaClassifyTilesKernel, dim3((numTiles + 3) / 4), dim3(256), 0, a.stream, c, a.planes[0], a.planes[1], tiles);
+    hipLaunchKernelGGL((SigmaClassifyTilesKernel<TRANSLUCENT>), dim3((numTiles + 3) / 4), dim3(256), 0, a.stream, c, a.planes[0], a.planes[1], TRANSLUCENT ? a.planes[2] : Plane{}, tiles);
     return nullptr;
 }
 
@@ -180,20 +220,25 @@ static const char* LaunchSmoothTiles(const PassArgs& a) {
 }
 
 // ================================================================================================ Copy
+template <typename TEXEL> // uint8_t (R8 shadow) or uint32_t (RGBA8 shadow + translucency)
 __global__ __launch_bounds__(256) void SigmaCopyKernel(SigmaCB c, Plane tiles, Plane inHistory, Plane inHistoryLength, Plane outHistory, Plane outHistoryLength) {
-    // 4 pixels per thread: 4 bytes of R8 shadow and 16 bytes of R32_UINT history length
+    // 4 pixels per thread: 4 (or 16) bytes of shadow history and 16 bytes of R32_UINT history length
+    struct alignas(sizeof(TEXEL) * 4) Texel4 {
+        TEXEL v[4];
+    };
     const int x = (blockIdx.x * 64 + (threadIdx.x & 63)) * 4, y = blockIdx.y * 4 + (threadIdx.x >> 6);
     if (y >= outHistory.h || x >= outHistory.w)
         return;
     if (LoadTileX(tiles, x >> 4, y >> 4) != 0.0f && !c.gIsRectChanged)
         return;
-    const bool aligned = ((((uintptr_t)inHistory.ptr | (uintptr_t)outHistory.ptr) | inHistory.pitch | outHistory.pitch) & 3u) == 0;
+    const bool aligned = ((((uintptr_t)inHistory.ptr | (uintptr_t)outHistory.ptr) | inHistory.pitch | outHistory.pitch) & (sizeof(Texel4) - 1)) == 0 &&
+                         ((((uintptr_t)inHistoryLength.ptr | (uintptr_t)outHistoryLength.ptr) | inHistoryLength.pitch | outHistoryLength.pitch) & 15u) == 0;
     if (x + 3 < outHistory.w && aligned) {
-        *(uint32_t*)TexelPtr<uint8_t>(outHistory, x, y) = *(const uint32_t*)TexelPtr<const uint8_t>(inHistory, x, y);
+        *(Texel4*)TexelPtr<TEXEL>(outHistory, x, y) = *(const Texel4*)TexelPtr<const TEXEL>(inHistory, x, y);
         *(uint4*)TexelPtr<uint32_t>(outHistoryLength, x, y) = *(const uint4*)TexelPtr<const uint32_t>(inHistoryLength, x, y);
     } else {
         for (int i = 0; i < 4 && x + i < outHistory.w; i++) {
-            *TexelPtr<uint8_t>(outHistory, x + i, y) = *TexelPtr<const uint8_t>(inHistory, x + i, y);
+            *TexelPtr<TEXEL>(outHistory, x + i, y) = *TexelPtr<const TEXEL>(inHistory, x + i, y);
             StoreR32U(outHistoryLength, x + i, y, LoadR32U(inHistoryLength, x + i, y));
         }
     }
@@ -203,7 +248,14 @@ static const char* LaunchCopy(const PassArgs& a) {
     const SigmaCB& c = *(const SigmaCB*)a.constants;
     const Plane& out = a.planes[3];
     dim3 grid((unsigned)((out.w + 255) / 256), (unsigned)((out.h + 3) / 4), 1);
-    hipLaunchKernelGGL(SigmaCopyKernel, grid, dim3(256), 0, a.stream, c, a.planes[0], a.planes[1], a.planes[2], out, a.planes[4]);
+    if (a.planesNum != 5 || a.bytesPerTexel[1] != a.bytesPerTexel[3])
+        return "SIGMA copy: unexpected resources";
+    if (a.bytesPerTexel[3] == 4)
+        hipLaunchKernelGGL(SigmaCopyKernel<uint32_t>, grid, dim3(256), 0, a.stream, c, a.planes[0], a.planes[1], a.planes[2], out, a.planes[4]);
+    else if (a.bytesPerTexel[3] == 1)
+        hipLaunchKernelGGL(SigmaCopyKernel<uint8_t>, grid, dim3(256), 0, a.stream, c, a.planes[0], a.planes[1], a.planes[2], out, a.planes[4]);
+    else
+        return "SIGMA copy: unexpected history format";
     return nullptr;
 }
 
@@ -212,11 +264,14 @@ struct BlurPlanes {
     Plane viewZ, normalRoughness, penumbra, tiles, shadow, outPenumbra, outShadow;
 };
 
-template <bool FIRST_PASS>
+template <bool FIRST_PASS, bool TRANSLUCENT>
 __global__ __launch_bounds__(TILE_X* TILE_Y) void SigmaBlurKernel(SigmaCB c, BlurPlanes P) {
+    typedef SigmaType<TRANSLUCENT> ST;
+    typedef typename ST::type S;
+    constexpr bool READS_SHADOW = !FIRST_PASS || TRANSLUCENT; // the translucent first pass reads IN_TRANSLUCENCY (not unpacked)
     __shared__ float s_Penumbra[BUF_Y * BUF_STRIDE];
     __shared__ float s_ViewZ[BUF_Y * BUF_STRIDE];
-    __shared__ float s_Shadow[BUF_Y * BUF_STRIDE];
+    __shared__ S s_Shadow[BUF_Y * BUF_STRIDE];
 
     const int tx = threadIdx.x % TILE_X, ty = threadIdx.x / TILE_X;
     const int px = blockIdx.x * TILE_X + tx, py = blockIdx.y * TILE_Y + ty;
@@ -236,7 +291,12 @@ __global__ __launch_bounds__(TILE_X* TILE_Y) void SigmaBlurKernel(SigmaCB c, Blu
             float pen = LoadR16F(P.penumbra, gx, gy);
             s_Penumbra[ly * BUF_STRIDE + lx] = pen;
             s_ViewZ[ly * BUF_STRIDE + lx] = UnpackViewZ(c, LoadR32F(P.viewZ, gx, gy));
-            s_Shadow[ly * BUF_STRIDE + lx] = FIRST_PASS ? (IsLit(pen) ? 1.0f : 0.0f) : UnpackShadow(LoadR8Unorm(P.shadow, gx, gy));
+            S s;
+            if (READS_SHADOW)
+                s = ST::Load(P.shadow, gx, gy);
+            else
+                s = ST::Splat(IsLit(pen) ? 1.0f : 0.0f);
+            s_Shadow[ly * BUF_STRIDE + lx] = FIRST_PASS ? s : UnpackShadow(s);
         }
     }
     __syncthreads();
@@ -260,7 +320,7 @@ __global__ __launch_bounds__(TILE_X* TILE_Y) void SigmaBlurKernel(SigmaCB c, Blu
 
     if (tileValue == 0.0f || centerPenumbra == 0.0f) {
         StoreR16F(P.outPenumbra, px, py, centerPenumbra);
-        StoreR8Unorm(P.outShadow, px, py, PackShadow(s_Shadow[so]));
+        ST::Store(P.outShadow, px, py, PackShadow(s_Shadow[so]));
         return;
     }
 
@@ -274,13 +334,15 @@ __global__ __launch_bounds__(TILE_X* TILE_Y) void SigmaBlurKernel(SigmaCB c, Blu
     float NoV = Abs(Dot(Nv, Vv));
     float2 geometryWeightParams = GetGeometryWeightParams(c.gPlaneDistSensitivity, frustumSize, Xv, Nv);
 
-    float sumx = 0.0f, sumy = 0.0f, penumbra = 0.0f, result = 0.0f, centerTap = 0.0f;
+    float sumx = 0.0f, sumy = 0.0f, penumbra = 0.0f;
+    S result = ST::Splat(0.0f), centerTap = ST::Splat(0.0f);
 #pragma unroll
     for (int j = 0; j <= BORDER * 2; j++) {
 #pragma unroll
         for (int i = 0; i <= BORDER * 2; i++) {
             const int o = (ty + j) * BUF_STRIDE + tx + i;
-            float penum = s_Penumbra[o], zs = s_ViewZ[o], s = s_Shadow[o];
+            float penum = s_Penumbra[o], zs = s_ViewZ[o];
+            S s = s_Shadow[o];
 
             float w = 1.0f;
             if (i == BORDER && j == BORDER)
@@ -293,7 +355,7 @@ __global__ __launch_bounds__(TILE_X* TILE_Y) void SigmaBlurKernel(SigmaCB c, Blu
                 w *= GetGaussianWeight(Length(F2(float(i - BORDER), float(j - BORDER)) / float(BORDER)));
             }
 
-            result += w == 0.0f ? 0.0f : s * w;
+            result = result + ZeroIf(w == 0.0f, s * w);
             sumx += w;
 
             w *= pixelSize / (pixelSize + penum);
@@ -304,7 +366,7 @@ __global__ __launch_bounds__(TILE_X* TILE_Y) void SigmaBlurKernel(SigmaCB c, Blu
         }
     }
 
-    result /= sumx;
+    result = result / sumx;
     sumx = 1.0f;
     penumbra /= Max(sumy, NRD_EPS);
     sumy = sumy != 0.0f ? 1.0f : 0.0f;
@@ -314,7 +376,7 @@ __global__ __launch_bounds__(TILE_X* TILE_Y) void SigmaBlurKernel(SigmaCB c, Blu
     result = Lerp(centerTap, result, f);
 
     f = Lerp(4.0f, 1.0f, f);
-    result *= f;
+    result = result * f;
     penumbra *= f;
     sumx *= f;
     sumy *= f;
@@ -340,7 +402,13 @@ __global__ __launch_bounds__(TILE_X* TILE_Y) void SigmaBlurKernel(SigmaCB c, Blu
         const int2 t = NearestTexel(P.penumbra, uvScaled);
         float penum = LoadR16F(P.penumbra, t.x, t.y);
         float zs = UnpackViewZ(c, LoadR32F(P.viewZ, t.x, t.y));
-        float s = FIRST_PASS ? (IsLit(penum) ? 1.0f : 0.0f) : UnpackShadow(LoadR8Unorm(P.shadow, t.x, t.y));
+        S s;
+        if (READS_SHADOW)
+            s = ST::Load(P.shadow, t.x, t.y);
+        else
+            s = ST::Splat(IsLit(penum) ? 1.0f : 0.0f);
+        if (!FIRST_PASS)
+            s = UnpackShadow(s);
 
         float3 Xvs = ReconstructViewPosition(uv, frustum, zs, c.gOrthoMode);
 
@@ -350,7 +418,7 @@ __global__ __launch_bounds__(TILE_X* TILE_Y) void SigmaBlurKernel(SigmaCB c, Blu
         w *= n < 4 ? REBLUR_GAUSSIAN_WEIGHT_Z1 : REBLUR_GAUSSIAN_WEIGHT_Z05;
         w *= Sat(penum * invEstimatedPenumbra);
 
-        result += w == 0.0f ? 0.0f : s * w;
+        result = result + ZeroIf(w == 0.0f, s * w);
         sumx += w;
 
         w *= pixelSize / (pixelSize + penum);
@@ -360,15 +428,15 @@ __global__ __launch_bounds__(TILE_X* TILE_Y) void SigmaBlurKernel(SigmaCB c, Blu
         sumy += w;
     }
 
-    result /= sumx;
+    result = result / sumx;
     penumbra = sumy == 0.0f ? centerPenumbra : penumbra / sumy;
 
     if (FIRST_PASS || c.gStabilizationStrength != 0.0f)
         StoreR16F(P.outPenumbra, px, py, penumbra);
-    StoreR8Unorm(P.outShadow, px, py, PackShadow(result));
+    ST::Store(P.outShadow, px, py, PackShadow(result));
 }
 
-template <bool FIRST_PASS>
+template <bool FIRST_PASS, bool TRANSLUCENT>
 static const char* LaunchBlur(const PassArgs& a) {
     const SigmaCB& c = *(const SigmaCB*)a.constants;
     if (const char* err = CheckSupportedSigma(c))
@@ -379,14 +447,14 @@ static const char* LaunchBlur(const PassArgs& a) {
     P.normalRoughness = a.planes[k++];
     P.penumbra = a.planes[k++];
     P.tiles = a.planes[k++];
-    if (!FIRST_PASS)
+    if (!FIRST_PASS || TRANSLUCENT)
         P.shadow = a.planes[k++];
     P.outPenumbra = a.planes[k++];
     P.outShadow = a.planes[k++];
     if (k != a.planesNum)
         return "SIGMA blur: unexpected resource count";
     dim3 grid = GridFor(c.gRectSizeMinusOne.x + 1, c.gRectSizeMinusOne.y + 1, TILE_X, TILE_Y);
-    hipLaunchKernelGGL((SigmaBlurKernel<FIRST_PASS>), grid, dim3(TILE_X * TILE_Y), 0, a.stream, c, P);
+    hipLaunchKernelGGL((SigmaBlurKernel<FIRST_PASS, TRANSLUCENT>), grid, dim3(TILE_X * TILE_Y), 0, a.stream, c, P);
     return nullptr;
 }
 
@@ -402,13 +470,18 @@ NRD_D uint32_t PackViewZAndHistoryLength(float viewZ, float historyLength) {
     return p;
 }
 NRD_D uint32_t FetchClampedR32U(const Plane& p, int x, int y) { return LoadR32U(p, ClampI(x, 0, p.w - 1), ClampI(y, 0, p.h - 1)); }
-NRD_D float FetchHistoryR8Unorm(const HistoryFilter& h, const Plane& tex) {
-    return FetchHistoryGeneric<float>(h, tex, [](const Plane& p, int x, int y) { return LoadR8Unorm(p, x, y); }, 0.0f);
+template <bool TRANSLUCENT>
+NRD_D typename SigmaType<TRANSLUCENT>::type FetchShadowHistory(const HistoryFilter& h, const Plane& tex) {
+    typedef SigmaType<TRANSLUCENT> ST;
+    return FetchHistoryGeneric<typename ST::type>(h, tex, [](const Plane& p, int x, int y) { return ST::Load(p, x, y); }, ST::Splat(0.0f));
 }
 
+template <bool TRANSLUCENT>
 __global__ __launch_bounds__(TILE_X* TILE_Y) void SigmaTemporalStabilizationKernel(SigmaCB c, TsPlanes P) {
+    typedef SigmaType<TRANSLUCENT> ST;
+    typedef typename ST::type S;
     __shared__ float s_Penumbra[BUF_Y * BUF_STRIDE];
-    __shared__ float s_Shadow[BUF_Y * BUF_STRIDE];
+    __shared__ S s_Shadow[BUF_Y * BUF_STRIDE];
 
     const int tx = threadIdx.x % TILE_X, ty = threadIdx.x / TILE_X;
     const int px = blockIdx.x * TILE_X + tx, py = blockIdx.y * TILE_Y + ty;
@@ -425,7 +498,7 @@ __global__ __launch_bounds__(TILE_X* TILE_Y) void SigmaTemporalStabilizationKern
         for (int i = threadIdx.x; i < BUF_X * BUF_Y; i += TILE_X * TILE_Y) {
             int lx = i % BUF_X, ly = i / BUF_X;
             int gx = ClampI(baseX + lx, 0, rw), gy = ClampI(baseY + ly, 0, rh);
-            s_Shadow[ly * BUF_STRIDE + lx] = UnpackShadow(LoadR8Unorm(P.shadow, gx, gy));
+            s_Shadow[ly * BUF_STRIDE + lx] = UnpackShadow(ST::Load(P.shadow, gx, gy));
             s_Penumbra[ly * BUF_STRIDE + lx] = LoadR16F(P.penumbra, gx, gy);
         }
     }
@@ -446,18 +519,19 @@ __global__ __launch_bounds__(TILE_X* TILE_Y) void SigmaTemporalStabilizationKern
     float tileValue = TextureCubicY(P.tiles, pixelUv * resolutionScale);
     bool isHardShadow = tileValue == 0.0f || centerPenumbra == 0.0f;
     if (isHardShadow) {
-        StoreR8Unorm(P.outShadow, px, py, PackShadow(s_Shadow[so]));
+        ST::Store(P.outShadow, px, py, PackShadow(s_Shadow[so]));
         StoreR32U(P.outHistoryLength, px, py, PackViewZAndHistoryLength(viewZ, SIGMA_MAX_ACCUM_FRAME_NUM));
         return;
     }
 
-    float sumw = 0.0f, m1 = 0.0f, m2 = 0.0f, input = 0.0f;
+    float sumw = 0.0f;
+    S m1 = ST::Splat(0.0f), m2 = ST::Splat(0.0f), input = ST::Splat(0.0f);
 #pragma unroll
     for (int j = 0; j <= BORDER * 2; j++) {
 #pragma unroll
         for (int i = 0; i <= BORDER * 2; i++) {
             const int o = (ty + j) * BUF_STRIDE + tx + i;
-            float s = s_Shadow[o];
+            S s = s_Shadow[o];
             float w = 1.0f;
             if (i == BORDER && j == BORDER)
                 input = s;
@@ -466,14 +540,14 @@ __global__ __launch_bounds__(TILE_X* TILE_Y) void SigmaTemporalStabilizationKern
                 w = AreBothLitOrUnlit(centerPenumbra, penum);
                 w *= GetGaussianWeight(Length(F2(float(i - BORDER), float(j - BORDER)) / float(BORDER)));
             }
-            m1 += s * w;
-            m2 += s * s * w;
+            m1 = m1 + s * w;
+            m2 = m2 + s * s * w;
             sumw += w;
         }
     }
-    m1 /= sumw;
-    m2 /= sumw;
-    float sigma = Sqrt(Abs(m2 - m1 * m1));
+    m1 = m1 / sumw;
+    m2 = m2 / sumw;
+    S sigma = StdDev(m1, m2);
 
     float3 Xv = ReconstructViewPosition(pixelUv, ToF4(c.gFrustum), viewZ, c.gOrthoMode);
     float3 X = RotateVectorInverse(c.gWorldToView, Xv);
@@ -514,15 +588,15 @@ __global__ __launch_bounds__(TILE_X* TILE_Y) void SigmaTemporalStabilizationKern
 
     bool isCatRomAllowed = Sum(smbOcclusionWeights) > 3.5f; // never true (weights sum to <= 1): kept as in the reference
     HistoryFilter hf = MakeHistoryFilter(Sat(smbPixelUv) * rectSizePrev, smbOcclusionWeights, isCatRomAllowed, P.history);
-    float history = FetchHistoryR8Unorm(hf, P.history);
-    history = Sat(history);
+    S history = FetchShadowHistory<TRANSLUCENT>(hf, P.history);
+    history = SatV(history);
     history = UnpackShadow(history);
 
-    sigma *= Lerp(SIGMA_TS_SIGMA_SCALE, 1.0f, 1.0f / (1.0f + historyLength));
-    float inputMin = m1 - sigma, inputMax = m1 + sigma;
-    float historyClamped = Clamp(history, inputMin, inputMax);
+    sigma = sigma * Lerp(SIGMA_TS_SIGMA_SCALE, 1.0f, 1.0f / (1.0f + historyLength));
+    S inputMin = m1 - sigma, inputMax = m1 + sigma;
+    S historyClamped = ClampV(history, inputMin, inputMax);
 
-    float antilag = Abs(historyClamped - history);
+    float antilag = Abs(ST::X(historyClamped) - ST::X(history)); // the shadow channel drives the antilag
     antilag = Sqrt01(antilag);
     antilag = Sat(1.0f - antilag);
     historyLength *= antilag;
@@ -531,13 +605,14 @@ __global__ __launch_bounds__(TILE_X* TILE_Y) void SigmaTemporalStabilizationKern
     float streetMagic = 0.6f * historyWeight * antilag;
     historyClamped = Lerp(historyClamped, history, streetMagic);
 
-    float result = Lerp(input, historyClamped, Min(c.gStabilizationStrength, historyWeight));
+    S result = Lerp(input, historyClamped, Min(c.gStabilizationStrength, historyWeight));
     historyLength = Min(historyLength + 1.0f, SIGMA_MAX_ACCUM_FRAME_NUM);
 
-    StoreR8Unorm(P.outShadow, px, py, PackShadow(result));
+    ST::Store(P.outShadow, px, py, PackShadow(result));
     StoreR32U(P.outHistoryLength, px, py, PackViewZAndHistoryLength(viewZ, historyLength));
 }
 
+template <bool TRANSLUCENT>
 static const char* LaunchTemporalStabilization(const PassArgs& a) {
     const SigmaCB& c = *(const SigmaCB*)a.constants;
     if (const char* err = CheckSupportedSigma(c))
@@ -546,12 +621,14 @@ static const char* LaunchTemporalStabilization(const PassArgs& a) {
         return "SIGMA temporal stabilization: unexpected resource count";
     TsPlanes P = {a.planes[0], a.planes[1], a.planes[2], a.planes[3], a.planes[4], a.planes[5], a.planes[6], a.planes[7], a.planes[8]};
     dim3 grid = GridFor(c.gRectSizeMinusOne.x + 1, c.gRectSizeMinusOne.y + 1, TILE_X, TILE_Y);
-    hipLaunchKernelGGL(SigmaTemporalStabilizationKernel, grid, dim3(TILE_X * TILE_Y), 0, a.stream, c, P);
+    hipLaunchKernelGGL(SigmaTemporalStabilizationKernel<TRANSLUCENT>, grid, dim3(TILE_X * TILE_Y), 0, a.stream, c, P);
     return nullptr;
 }
 
 // ================================================================================================ SplitScreen
-__global__ __launch_bounds__(256) void SigmaSplitScreenKernel(SigmaCB c, Plane viewZ, Plane penumbra, Plane outShadow) {
+template <bool TRANSLUCENT>
+__global__ __launch_bounds__(256) void SigmaSplitScreenKernel(SigmaCB c, Plane viewZ, Plane penumbra, Plane translucency, Plane outShadow) {
+    typedef SigmaType<TRANSLUCENT> ST;
     const int px = blockIdx.x * TILE_X + (threadIdx.x % TILE_X), py = blockIdx.y * TILE_Y + (threadIdx.x / TILE_X);
     if (px > c.gRectSizeMinusOne.x || py > c.gRectSizeMinusOne.y)
         return;
@@ -559,26 +636,38 @@ __global__ __launch_bounds__(256) void SigmaSplitScreenKernel(SigmaCB c, Plane v
     if (pixelUvX > c.gSplitScreen)
         return;
     float z = UnpackViewZ(c, LoadR32F(viewZ, px, py));
-    float s = IsLit(LoadR16F(penumbra, px, py)) ? 1.0f : 0.0f;
-    StoreR8Unorm(outShadow, px, py, s * (z < c.gDenoisingRange ? 1.0f : 0.0f));
+    typename ST::type s;
+    if (TRANSLUCENT)
+        s = ST::Load(translucency, px, py);
+    else
+        s = ST::Splat(IsLit(LoadR16F(penumbra, px, py)) ? 1.0f : 0.0f);
+    ST::Store(outShadow, px, py, s * (z < c.gDenoisingRange ? 1.0f : 0.0f));
 }
 
+template <bool TRANSLUCENT>
 static const char* LaunchSplitScreen(const PassArgs& a) {
     const SigmaCB& c = *(const SigmaCB*)a.constants;
+    if (a.planesNum != (TRANSLUCENT ? 4u : 3u))
+        return "SIGMA split screen: unexpected resource count";
     dim3 grid = GridFor(c.gRectSizeMinusOne.x + 1, c.gRectSizeMinusOne.y + 1, TILE_X, TILE_Y);
-    hipLaunchKernelGGL(SigmaSplitScreenKernel, grid, dim3(256), 0, a.stream, c, a.planes[0], a.planes[1], a.planes[2]);
+    hipLaunchKernelGGL(SigmaSplitScreenKernel<TRANSLUCENT>, grid, dim3(256), 0, a.stream, c, a.planes[0], a.planes[1], TRANSLUCENT ? a.planes[2] : Plane{}, a.planes[a.planesNum - 1]);
     return nullptr;
 }
 
 const PassEntry* GetSigmaPasses(uint32_t& num) {
     static const PassEntry k[] = {
-        {"SIGMA_Shadow_ClassifyTiles.cs", LaunchClassifyTiles},
+        {"SIGMA_Shadow_ClassifyTiles.cs", LaunchClassifyTiles<false>},
         {"SIGMA_SmoothTiles.cs", LaunchSmoothTiles},
         {"SIGMA_Copy.cs", LaunchCopy},
-        {"SIGMA_Shadow_Blur.cs", LaunchBlur<true>},
-        {"SIGMA_Shadow_PostBlur.cs", LaunchBlur<false>},
-        {"SIGMA_Shadow_TemporalStabilization.cs", LaunchTemporalStabilization},
-        {"SIGMA_Shadow_SplitScreen.cs", LaunchSplitScreen},
+        {"SIGMA_Shadow_Blur.cs", LaunchBlur<true, false>},
+        {"SIGMA_Shadow_PostBlur.cs", LaunchBlur<false, false>},
+        {"SIGMA_Shadow_TemporalStabilization.cs", LaunchTemporalStabilization<false>},
+        {"SIGMA_Shadow_SplitScreen.cs", LaunchSplitScreen<false>},
+        {"SIGMA_ShadowTranslucency_ClassifyTiles.cs", LaunchClassifyTiles<true>},
+        {"SIGMA_ShadowTranslucency_Blur.cs", LaunchBlur<true, true>},
+        {"SIGMA_ShadowTranslucency_PostBlur.cs", LaunchBlur<false, true>},
+        {"SIGMA_ShadowTranslucency_TemporalStabilization.cs", LaunchTemporalStabilization<true>},
+        {"SIGMA_ShadowTranslucency_SplitScreen.cs", LaunchSplitScreen<true>},
     };
     num = sizeof(k) / sizeof(k[0]);
     return k;

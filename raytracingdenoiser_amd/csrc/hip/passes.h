@@ -11,6 +11,7 @@ namespace nrdhip {
 struct PassArgs {
     const Plane* planes;      // DispatchDesc::resources resolved to planes, same order (inputs then outputs)
     uint32_t planesNum;
+    const uint8_t* bytesPerTexel; // per plane, for the few launchers shared between storage formats (SIGMA_Copy.cs)
     const void* constants;    // DispatchDesc::constantBufferData
     uint32_t constantsSize;
     hipStream_t stream;

@@ -122,6 +122,14 @@ NRD_D void StoreRG8Unorm(const Plane& p, int x, int y, float2 v) {
     *TexelPtr<uint16_t>(p, x, y) = (uint16_t)(ToUnorm(v.x, 255.0f) | (ToUnorm(v.y, 255.0f) << 8));
 }
 
+NRD_D float4 LoadRGBA8Unorm(const Plane& p, int x, int y) {
+    uint32_t raw = *TexelPtr<const uint32_t>(p, x, y);
+    return make_float4(NRD_DIV_255(float(raw & 0xFFu)), NRD_DIV_255(float((raw >> 8) & 0xFFu)), NRD_DIV_255(float((raw >> 16) & 0xFFu)), NRD_DIV_255(float(raw >> 24)));
+}
+NRD_D void StoreRGBA8Unorm(const Plane& p, int x, int y, float4 v) {
+    *TexelPtr<uint32_t>(p, x, y) = ToUnorm(v.x, 255.0f) | (ToUnorm(v.y, 255.0f) << 8) | (ToUnorm(v.z, 255.0f) << 16) | (ToUnorm(v.w, 255.0f) << 24);
+}
+
 NRD_D float4 DecodeR10G10B10A2(uint32_t raw) {
     float4 r;
     r.x = NRD_DIV_1023(float(raw & 0x3FFu));

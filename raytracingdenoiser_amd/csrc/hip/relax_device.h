@@ -68,13 +68,6 @@ struct SignalPlanes {
 };
 
 // ---- extra codecs ------------------------------------------------------------------------------------------------
-NRD_D float4 LoadRGBA8Unorm(const Plane& p, int x, int y) {
-    uint32_t raw = *TexelPtr<const uint32_t>(p, x, y);
-    return F4(NRD_DIV_255(float(raw & 0xFFu)), NRD_DIV_255(float((raw >> 8) & 0xFFu)), NRD_DIV_255(float((raw >> 16) & 0xFFu)), NRD_DIV_255(float(raw >> 24)));
-}
-NRD_D void StoreRGBA8Unorm(const Plane& p, int x, int y, float4 v) {
-    *TexelPtr<uint32_t>(p, x, y) = ToUnorm(v.x, 255.0f) | (ToUnorm(v.y, 255.0f) << 8) | (ToUnorm(v.z, 255.0f) << 16) | (ToUnorm(v.w, 255.0f) << 24);
-}
 NRD_D float4 FetchClampedRGBA8Unorm(const Plane& p, int x, int y) { return LoadRGBA8Unorm(p, ClampI(x, 0, p.w - 1), ClampI(y, 0, p.h - 1)); }
 NRD_D float FetchClampedR8Unorm(const Plane& p, int x, int y) { return LoadR8Unorm(p, ClampI(x, 0, p.w - 1), ClampI(y, 0, p.h - 1)); }
 NRD_D float4 SampleLinearRGBA8Unorm(const Plane& p, float2 pos) {

@@ -1,8 +1,11 @@
-// SIGMA_SHADOW host tables. Pool layout, pass order and binding order: reference Source/Denoisers/Sigma_Shadow.hpp:11-157;
+// SIGMA_SHADOW and SIGMA_SHADOW_TRANSLUCENCY host tables (one parametrised description). Pool layout, pass order and binding
+// order: reference Source/Denoisers/Sigma_Shadow.hpp:11-157 and Sigma_ShadowTranslucency.hpp:11-160 (RGBA8 instead of R8 shadow
+// planes, IN_TRANSLUCENCY appended to ClassifyTiles / Blur / SplitScreen);
 // per-frame selection: reference Source/Sigma.cpp:25-90; shared constants: Sigma.cpp:92-145.
 #include "instance.h"
 
 #include <algorithm>
+#include <cstdio>
 
 namespace nrd {
 
@@ -71,34 +74,46 @@ static void FillSigmaConstants(const SigmaSettings& s, const CommonSettings& cs,
     c.gIsRectChanged = isRectChanged ? 1 : 0;
 }
 
-void InstanceImpl::Add_SigmaShadow(DenoiserData& d) {
+void InstanceImpl::Add_SigmaShadow(DenoiserData& d, bool translucent) {
     d.settings.sigma = SigmaSettings();
     d.settingsSize = sizeof(SigmaSettings);
     const uint32_t constSize = sizeof(nrdc::SigmaConstants);
+    const Format shadowFormat = translucent ? Format::RGBA8_UNORM : Format::R8_UNORM;
+    char family[40], passName[96], shader[96];
+    snprintf(family, sizeof(family), "%s", translucent ? "SIGMA_ShadowTranslucency" : "SIGMA_Shadow");
+    auto Pass = [&](const char* what) {
+        snprintf(passName, sizeof(passName), "%s - %s", family, what);
+        BeginPass(InternString(passName));
+    };
+    auto Shader = [&](const char* stage) {
+        snprintf(shader, sizeof(shader), "%s_%s.cs", family, stage);
+        return (const char*)shader;
+    };
 
     AddPermanent(Format::R32_UINT); // viewZ (29 bits) packed with 3 bits of history length
 
     AddTransient(Format::R16_SFLOAT);      // DATA_1: penumbra after pass 1
     AddTransient(Format::R16_SFLOAT);      // DATA_2: penumbra after pass 2
-    AddTransient(Format::R8_UNORM);        // TEMP_1: shadow after pass 1
-    AddTransient(Format::R8_UNORM);        // TEMP_2: shadow after pass 2
-    AddTransient(Format::R8_UNORM);        // HISTORY: copy of the previous output
+    AddTransient(shadowFormat);            // TEMP_1: shadow (+ translucency) after pass 1
+    AddTransient(shadowFormat);            // TEMP_2: shadow after pass 2
+    AddTransient(shadowFormat);            // HISTORY: copy of the previous output
     AddTransient(Format::R32_UINT);        // HISTORY_LENGTH copy
     AddTransient(Format::RGBA8_UNORM, 16); // TILES
     AddTransient(Format::RG8_UNORM, 16);   // SMOOTHED_TILES
 
-    BeginPass("SIGMA_Shadow - Classify tiles");
+    Pass("Classify tiles");
     In(ResourceType::IN_VIEWZ);
     In(ResourceType::IN_PENUMBRA);
+    if (translucent) In(ResourceType::IN_TRANSLUCENCY);
     Out(T_TILES);
-    EndPass("SIGMA_Shadow_ClassifyTiles.cs", 16, 16, constSize);
+    EndPass(Shader("ClassifyTiles"), 16, 16, constSize);
 
-    BeginPass("SIGMA_Shadow - Smooth tiles");
+    Pass("Smooth tiles");
     In(T_TILES);
     Out(T_SMOOTHED_TILES);
     EndPass("SIGMA_SmoothTiles.cs", 16, 16, constSize, 16);
 
-    BeginPass("SIGMA_Shadow - Copy");
+    Pass("Copy");
     In(T_SMOOTHED_TILES);
     In(ResourceType::OUT_SHADOW_TRANSLUCENCY);
     In(P_HISTORY_LENGTH);
@@ -106,18 +121,19 @@ void InstanceImpl::Add_SigmaShadow(DenoiserData& d) {
     Out(T_HISTORY_LENGTH);
     EndPass("SIGMA_Copy.cs", 8, 16, constSize, USE_MAX_DIMS);
 
-    BeginPass("SIGMA_Shadow - Blur");
+    Pass("Blur");
     In(ResourceType::IN_VIEWZ);
     In(ResourceType::IN_NORMAL_ROUGHNESS);
     In(ResourceType::IN_PENUMBRA);
     In(T_SMOOTHED_TILES);
+    if (translucent) In(ResourceType::IN_TRANSLUCENCY);
     Out(T_DATA_1);
     Out(T_TEMP_1);
-    EndPass("SIGMA_Shadow_Blur.cs", 8, 16, constSize, USE_MAX_DIMS);
+    EndPass(Shader("Blur"), 8, 16, constSize, translucent ? 1 : USE_MAX_DIMS); // sic: the two reference tables differ here
 
     for (int i = 0; i < 2; i++) {
         bool isStabilizationEnabled = i & 1;
-        BeginPass("SIGMA_Shadow - Post-blur");
+        Pass("Post-blur");
         In(ResourceType::IN_VIEWZ);
         In(ResourceType::IN_NORMAL_ROUGHNESS);
         In(T_DATA_1);
@@ -125,10 +141,10 @@ void InstanceImpl::Add_SigmaShadow(DenoiserData& d) {
         In(T_TEMP_1);
         Out(T_DATA_2);
         Out(isStabilizationEnabled ? (uint16_t)T_TEMP_2 : (uint16_t)ResourceType::OUT_SHADOW_TRANSLUCENCY);
-        EndPass("SIGMA_Shadow_PostBlur.cs", 8, 16, constSize);
+        EndPass(Shader("PostBlur"), 8, 16, constSize);
     }
 
-    BeginPass("SIGMA_Shadow - Temporal stabilization");
+    Pass("Temporal stabilization");
     In(ResourceType::IN_VIEWZ);
     In(ResourceType::IN_MV);
     In(T_DATA_2);
@@ -138,13 +154,14 @@ void InstanceImpl::Add_SigmaShadow(DenoiserData& d) {
     In(T_SMOOTHED_TILES);
     Out(ResourceType::OUT_SHADOW_TRANSLUCENCY);
     Out(P_HISTORY_LENGTH);
-    EndPass("SIGMA_Shadow_TemporalStabilization.cs", 8, 16, constSize);
+    EndPass(Shader("TemporalStabilization"), 8, 16, constSize);
 
-    BeginPass("SIGMA_Shadow - Split screen");
+    Pass("Split screen");
     In(ResourceType::IN_VIEWZ);
     In(ResourceType::IN_PENUMBRA);
+    if (translucent) In(ResourceType::IN_TRANSLUCENCY);
     Out(ResourceType::OUT_SHADOW_TRANSLUCENCY);
-    EndPass("SIGMA_Shadow_SplitScreen.cs", 8, 16, constSize);
+    EndPass(Shader("SplitScreen"), 8, 16, constSize);
 }
 
 void InstanceImpl::Update_SigmaShadow(const DenoiserData& d) {

@@ -142,7 +142,10 @@ Result InstanceImpl::Create(const InstanceCreationDesc& desc) {
                 Add_RelaxVariant(data);
                 break;
             case Denoiser::SIGMA_SHADOW:
-                Add_SigmaShadow(data);
+                Add_SigmaShadow(data, false);
+                break;
+            case Denoiser::SIGMA_SHADOW_TRANSLUCENCY:
+                Add_SigmaShadow(data, true);
                 break;
             case Denoiser::REFERENCE:
                 Add_Reference(data);
@@ -524,6 +527,7 @@ Result InstanceImpl::GetComputeDispatches(const Identifier* identifiers, uint32_
                 Update_Relax(d);
                 break;
             case Denoiser::SIGMA_SHADOW:
+            case Denoiser::SIGMA_SHADOW_TRANSLUCENCY:
                 Update_SigmaShadow(d);
                 break;
             case Denoiser::REFERENCE:

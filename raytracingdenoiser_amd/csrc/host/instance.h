@@ -122,7 +122,7 @@ private:
     void Update_Relax(const DenoiserData& d);
     void FillRelaxConstants(const RelaxSettings& settings, void* data);
 
-    void Add_SigmaShadow(DenoiserData& d);
+    void Add_SigmaShadow(DenoiserData& d, bool translucent);
     void Update_SigmaShadow(const DenoiserData& d);
 
     // ---- table building helpers

@@ -20,6 +20,7 @@ const nrd::Denoiser g_Supported[] = {
     nrd::Denoiser::RELAX_DIFFUSE_SPECULAR,
     nrd::Denoiser::RELAX_DIFFUSE_SPECULAR_SH,
     nrd::Denoiser::SIGMA_SHADOW,
+    nrd::Denoiser::SIGMA_SHADOW_TRANSLUCENCY,
     nrd::Denoiser::REFERENCE,
 };
 

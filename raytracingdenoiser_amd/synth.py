@@ -5,7 +5,7 @@ camera, "path traced" with one diffuse and one specular bounce ray per pixel aga
 Outputs are packed exactly as an application would hand them to NRD:
   IN_VIEWZ R32F | IN_NORMAL_ROUGHNESS R10G10B10A2 (NRD_FrontEnd_PackNormalAndRoughness, reference NRD.hlsli:640-667)
   IN_MV RGBA16F | IN_DIFF/SPEC_RADIANCE_HITDIST RGBA16F (REBLUR_FrontEnd_PackRadianceAndNormHitDist, NRD.hlsli:732-743,
-  hit distances normalised with REBLUR_FrontEnd_GetNormHitDist, NRD.hlsli:722-727) | IN_PENUMBRA R16F for SIGMA.
+  hit distances normalised with REBLUR_FrontEnd_GetNormHitDist, NRD.hlsli:722-727) | IN_PENUMBRA R16F (+ IN_TRANSLUCENCY RGBA8) for SIGMA.
 Pure torch, device-agnostic: tests generate on the CPU (and feed the same tensors to the oracle and to the GPU), the
 benchmark generates directly in HBM. Not part of the denoiser.
 """
@@ -257,11 +257,18 @@ def render_frame(width, height, frame, device="cpu", static_camera=False, noise=
         rr = tan_r * torch.sqrt(u5).unsqueeze(-1)
         wl = _normalize(L + (tl * torch.cos(2.0 * math.pi * u6).unsqueeze(-1) + bl * torch.sin(2.0 * math.pi * u6).unsqueeze(-1)) * rr)
         ndl = _dot(n, L.expand_as(n))
-        ts, _, _, _ = _trace(p + n * 1e-3, wl, dev)
+        ts, _, occluder_albedo, occluder_roughness = _trace(p + n * 1e-3, wl, dev)
         # SIGMA_FrontEnd_PackPenumbra (NRD.hlsli:828-834): distanceToOccluder * tanOfLightAngularRadius, NoL<=0 -> 0, miss -> FP16_MAX
         pen = torch.where(torch.isinf(ts), torch.full_like(ts, FP16_MAX), (ts * tan_r).clamp(max=FP16_MAX))
         pen = torch.where(ndl <= 0.0, torch.zeros_like(pen), pen)
         pen = torch.where(is_sky, torch.full_like(pen, FP16_MAX), pen)
         out["penumbra"] = pen.to(torch.float16).contiguous()
+        # IN_TRANSLUCENCY for SIGMA_SHADOW_TRANSLUCENCY = SIGMA_FrontEnd_PackTranslucency (NRD.hlsli:848-855): x = "distance to occluder
+        # >= FP16_MAX" (lit), yzw = saturate(translucency). The cyan sphere (roughness 0.45) is stained glass, everything else is opaque.
+        lit = pen >= FP16_MAX
+        glass = (occluder_roughness == 0.45) & ~lit
+        tr = torch.where(lit.unsqueeze(-1), torch.ones_like(occluder_albedo), torch.where(glass.unsqueeze(-1), occluder_albedo, torch.zeros_like(occluder_albedo)))
+        tr4 = torch.cat([lit.to(torch.float32).unsqueeze(-1), tr.clamp(0.0, 1.0)], -1)
+        out["translucency"] = torch.floor(tr4 * 255.0 + 0.5).to(torch.uint8).contiguous()
         out["light_dir"] = tuple(float(x) for x in L)
     return out

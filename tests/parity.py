@@ -28,6 +28,7 @@ DENOISERS = {
     "REBLUR_SPECULAR": (api.Denoiser.REBLUR_SPECULAR, ("reblur",)),
     "REBLUR_DIFFUSE_SPECULAR": (api.Denoiser.REBLUR_DIFFUSE_SPECULAR, ("reblur",)),
     "SIGMA_SHADOW": (api.Denoiser.SIGMA_SHADOW, ("sigma",)),
+    "SIGMA_SHADOW_TRANSLUCENCY": (api.Denoiser.SIGMA_SHADOW_TRANSLUCENCY, ("sigma",)),
     "RELAX_DIFFUSE": (api.Denoiser.RELAX_DIFFUSE, ("relax",)),
     "RELAX_DIFFUSE_SH": (api.Denoiser.RELAX_DIFFUSE_SH, ("relax",)),
     "RELAX_SPECULAR": (api.Denoiser.RELAX_SPECULAR, ("relax",)),
@@ -60,8 +61,10 @@ def _user_planes(name, frame):
         planes.append((RT.IN_DIFF_RADIANCE_HITDIST, frame["diff"], F.RGBA16_SFLOAT))
     if name in ("REBLUR_SPECULAR", "REBLUR_DIFFUSE_SPECULAR"):
         planes.append((RT.IN_SPEC_RADIANCE_HITDIST, frame["spec"], F.RGBA16_SFLOAT))
-    if name == "SIGMA_SHADOW":
+    if name.startswith("SIGMA_SHADOW"):
         planes.append((RT.IN_PENUMBRA, frame["penumbra"], F.R16_SFLOAT))
+    if name == "SIGMA_SHADOW_TRANSLUCENCY":
+        planes.append((RT.IN_TRANSLUCENCY, frame["translucency"], F.RGBA8_UNORM))
     if name.startswith("RELAX"):
         has_diff, has_spec, sh = _relax_signals(name)
         if has_diff:
@@ -84,6 +87,8 @@ def output_planes(name, width, height):
         outs.append((RT.OUT_SPEC_RADIANCE_HITDIST, torch.float16, 4, F.RGBA16_SFLOAT))
     if name == "SIGMA_SHADOW":
         outs.append((RT.OUT_SHADOW_TRANSLUCENCY, torch.uint8, 1, F.R8_UNORM))
+    if name == "SIGMA_SHADOW_TRANSLUCENCY":
+        outs.append((RT.OUT_SHADOW_TRANSLUCENCY, torch.uint8, 4, F.RGBA8_UNORM))
     if name.startswith("RELAX"):
         has_diff, has_spec, sh = _relax_signals(name)
         if has_diff:
@@ -100,7 +105,7 @@ def output_planes(name, width, height):
 def denoiser_settings(name, frame, overrides=None):
     if name.startswith("REBLUR"):
         s = api.ReblurSettings(**(overrides or {}))
-    elif name == "SIGMA_SHADOW":
+    elif name.startswith("SIGMA_SHADOW"):
         s = api.SigmaSettings(lightDirection=frame["light_dir"], **(overrides or {}))
     elif name.startswith("RELAX"):
         s = api.RelaxSettings(**(overrides or {}))

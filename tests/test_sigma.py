@@ -59,3 +59,71 @@ def test_hip_matches_oracle(size):
 def test_hip_matches_oracle_without_stabilization():
     worst = parity.run_parity("SIGMA_SHADOW", width=160, height=96, frames=3, verbose=True, settings_overrides=dict(maxStabilizedFrameNum=0))
     assert worst <= parity.REL_TOL
+
+
+# ---------------------------------------------------------------------------------------------- SIGMA_SHADOW_TRANSLUCENCY
+def _run_translucent(seq):
+    ora = parity.OracleRun("SIGMA_SHADOW_TRANSLUCENCY", W, H)
+    for f, frame in enumerate(seq):
+        cs = parity.common_settings(frame["camera"], seq[max(f - 1, 0)]["camera"], W, H, f)
+        ora.step(frame, cs, parity.denoiser_settings("SIGMA_SHADOW_TRANSLUCENCY", frame))
+    return ora
+
+
+def test_translucency_host_tables():
+    """reference Source/Denoisers/Sigma_ShadowTranslucency.hpp: RGBA8 shadow planes, IN_TRANSLUCENCY appended to 3 passes"""
+    seq = parity.generate_sequence("SIGMA_SHADOW_TRANSLUCENCY", W, H, 2)
+    ora = _run_translucent(seq)
+    assert [d.shader for d in ora.last_dispatches] == [
+        "SIGMA_ShadowTranslucency_ClassifyTiles.cs", "SIGMA_SmoothTiles.cs", "SIGMA_Copy.cs", "SIGMA_ShadowTranslucency_Blur.cs",
+        "SIGMA_ShadowTranslucency_PostBlur.cs", "SIGMA_ShadowTranslucency_TemporalStabilization.cs"]
+    fmts = [t[0] for t in ora.inst.transient_pool]
+    assert fmts.count(api.Format.RGBA8_UNORM) == 4  # TEMP_1, TEMP_2, HISTORY + TILES
+    assert fmts.count(api.Format.R8_UNORM) == 0
+    blur = ora.last_dispatches[3]
+    assert len(blur.resources) == 7 and blur.resources[4][1] == RT.IN_TRANSLUCENCY
+
+
+def test_translucency_x_channel_tracks_opaque_denoiser():
+    """With an all-opaque translucency input (yzw = 0 in shadow, x = lit flag) the .x channel goes through the same arithmetic as
+    SIGMA_SHADOW, and yzw of a fully lit / fully shadowed frame are the fixed points 1 / 0."""
+    seq = parity.generate_sequence("SIGMA_SHADOW_TRANSLUCENCY", W, H, 5)
+    for fr in seq:
+        lit = (fr["penumbra"].float() >= 65504.0)
+        t = torch.zeros((H, W, 4), dtype=torch.uint8)
+        t[..., 0] = lit.to(torch.uint8) * 255
+        t[..., 1:] = (lit.to(torch.uint8) * 255).unsqueeze(-1)
+        fr["translucency"] = t
+    out_t = _run_translucent(seq).output(RT.OUT_SHADOW_TRANSLUCENCY)
+    out_s = _run(seq).output(RT.OUT_SHADOW_TRANSLUCENCY)[..., 0]
+    m = ~seq[-1]["is_sky"].numpy()
+    assert np.array_equal(out_t[..., 0][m], out_s[m])
+    # every channel carries the same signal here
+    for ch in (1, 2, 3):
+        assert np.array_equal(out_t[..., ch][m], out_t[..., 0][m])
+
+
+def test_translucency_keeps_colour_under_glass():
+    seq = parity.generate_sequence("SIGMA_SHADOW_TRANSLUCENCY", W, H, 6)
+    out = _run_translucent(seq).output(RT.OUT_SHADOW_TRANSLUCENCY) / 255.0
+    out = out * out  # SIGMA_BackEnd_UnpackShadow
+    fr = seq[-1]
+    t = fr["translucency"].numpy()
+    glass = (t[..., 0] == 0) & (t[..., 1:].max(-1) > 0) & ~fr["is_sky"].numpy()
+    assert glass.sum() > 20  # the scene has a stained-glass shadow
+    # under the glass the shadow term is dark but the translucent colour survives, with the glass tint (blue > red)
+    assert out[glass][:, 0].mean() < 0.5
+    assert out[glass][:, 3].mean() > out[glass][:, 1].mean() + 0.05
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("size", [(192, 128), (211, 117)])
+def test_hip_matches_oracle_translucency(size):
+    worst = parity.run_parity("SIGMA_SHADOW_TRANSLUCENCY", width=size[0], height=size[1], frames=6, verbose=True)
+    assert worst <= parity.REL_TOL
+
+
+@pytest.mark.gpu
+def test_hip_matches_oracle_translucency_without_stabilization():
+    worst = parity.run_parity("SIGMA_SHADOW_TRANSLUCENCY", width=160, height=96, frames=3, verbose=True, settings_overrides=dict(maxStabilizedFrameNum=0))
+    assert worst <= parity.REL_TOL
