@@ -1,0 +1,94 @@
+"""Per-rank compute time of the row-strip sharding, measured on ONE GPU (the box has no second GPU to run the real thing).
+
+For N in (1, 2, 4, 8) the worst-placed rank (a middle strip: halo on both sides) runs the bench sequence with nrdHipSetOwnedRows;
+a full-frame executor runs next to it and its permanent planes / outputs are copied in after every frame, which is what the
+all-gather of the real run delivers. Reported: ms/frame of the strip executor (cuda events around denoise()), the redundant-
+compute factor against the ideal 1/N, and the bytes the all-gather moves per frame. The collective itself is NOT measured here.
+usage: python tools/model_scaling.py [--workload reblur_ds] [--frames 24] [--warmup 16] > gpurun_out/scaling_model.json"""
+import argparse
+import json
+import os
+import sys
+
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+
+def main():
+    import bench
+    import parity
+    from raytracingdenoiser_amd import api, sharding
+    from raytracingdenoiser_amd.executor import HipExecutor
+
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--workload", default="reblur_ds")
+    ap.add_argument("--frames", type=int, default=24)
+    ap.add_argument("--warmup", type=int, default=16)
+    ap.add_argument("--worlds", default="1,2,4,8")
+    args = ap.parse_args()
+    name, (W, H), _ = bench.WORKLOADS[args.workload]
+    total = args.warmup + args.frames
+    seq = parity.generate_sequence(name, W, H, total, device="cuda")
+
+    def make():
+        inst = api.Instance([(0, parity.DENOISERS[name][0])])
+        ex = HipExecutor(inst, W, H)
+        outs = []
+        for rt, dtype, ch, fmt in parity.output_planes(name, W, H):
+            outs.append(torch.zeros((H, W, ch), dtype=dtype, device="cuda"))
+            ex.bind(rt, outs[-1], fmt)
+        assert inst.set_denoiser_settings(0, parity.denoiser_settings(name, seq[0])) == api.Result.SUCCESS
+        return inst, ex, outs
+
+    def planes_of(inst, ex, outs):
+        ps = [ex.pool_plane_tensor(api.ResourceType.PERMANENT_POOL, i) for i, (fmt, ds) in enumerate(inst.permanent_pool) if ds == 1]
+        return ps + [o.view(-1).view(dtype=torch.uint8).view(H, -1) for o in outs]
+
+    results = []
+    for world in [int(w) for w in args.worlds.split(",")]:
+        ref = make()
+        ref_planes = planes_of(*ref)
+        rank = world // 2
+        run = make()
+        shard = sharding.FrameSharder(run[1], run[0], W, H, rank, world, run[2]) if world > 1 else None
+        run_planes = planes_of(*run)
+        ms = []
+        for f in range(total):
+            frame = seq[f]
+            cs = parity.common_settings(frame["camera"], seq[max(f - 1, 0)]["camera"], W, H, f)
+            for inst, ex, _ in (ref, run):
+                for rt, t, fmt in parity.user_planes(name, frame):
+                    ex.bind(rt, t, fmt)
+                assert inst.set_common_settings(cs) == api.Result.SUCCESS
+            ref[1].denoise()
+            torch.cuda.synchronize()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            run[1].denoise()
+            e1.record()
+            torch.cuda.synchronize()
+            if f >= args.warmup:
+                ms.append(e0.elapsed_time(e1))
+            if shard is not None and shard.rows is not None:  # what the all-gather delivers: every row this rank does not own
+                rb, re = shard.rows
+                for src, dst in zip(ref_planes, run_planes):
+                    dst[:rb].copy_(src[:rb])
+                    dst[re:].copy_(src[re:])
+        torch.cuda.synchronize()
+        gather_bytes = sum(p.shape[0] * p.shape[1] for p in run_planes) if world > 1 else 0
+        results.append({"world": world, "rank": rank, "rows": list(shard.rows) if shard and shard.rows else [0, H], "ms_per_frame": round(sum(ms) / len(ms), 4),
+                        "all_gather_bytes_per_frame": gather_bytes})
+        for inst, ex, _ in (ref, run):
+            ex.destroy()
+    base = results[0]["ms_per_frame"]
+    for r in results:
+        r["compute_speedup_bound"] = round(base / r["ms_per_frame"], 3)
+        r["redundant_compute_factor"] = round(r["ms_per_frame"] * r["world"] / base, 3)
+    print(json.dumps({"workload": "%s %dx%d" % (name, W, H), "note": "per-rank compute only, middle strip, one MI355X; collective not included", "ranks": results}))
+
+
+if __name__ == "__main__":
+    main()
