@@ -66,11 +66,15 @@ RELAX_DS_BYTES_PER_PIXEL = {
     "RELAX_DiffuseSpecular_Atrous.cs": 42,
 }
 
-# workload -> (denoiser, default size, bytes/px per pass, a-trous launches per frame with the default settings)
+# performance mode (ReblurSettings::enablePerformanceMode): same planes per pass, "REBLUR_Perf_*" pipelines
+REBLUR_DS_PERF_BYTES_PER_PIXEL = {k.replace("REBLUR_DiffuseSpecular_", "REBLUR_Perf_DiffuseSpecular_"): v for k, v in REBLUR_DS_BYTES_PER_PIXEL.items()}
+
+# workload -> (denoiser, default size, bytes/px per pass, denoiser-settings overrides (None = library defaults))
 WORKLOADS = {
-    "reblur_ds": ("REBLUR_DIFFUSE_SPECULAR", (2560, 1440), REBLUR_DS_BYTES_PER_PIXEL),
-    "relax_ds_sh": ("RELAX_DIFFUSE_SPECULAR_SH", (3840, 2160), RELAX_DS_SH_BYTES_PER_PIXEL),
-    "relax_ds": ("RELAX_DIFFUSE_SPECULAR", (3840, 2160), RELAX_DS_BYTES_PER_PIXEL),
+    "reblur_ds": ("REBLUR_DIFFUSE_SPECULAR", (2560, 1440), REBLUR_DS_BYTES_PER_PIXEL, None),
+    "reblur_ds_perf": ("REBLUR_DIFFUSE_SPECULAR", (2560, 1440), REBLUR_DS_PERF_BYTES_PER_PIXEL, {"enablePerformanceMode": True}),
+    "relax_ds_sh": ("RELAX_DIFFUSE_SPECULAR_SH", (3840, 2160), RELAX_DS_SH_BYTES_PER_PIXEL, None),
+    "relax_ds": ("RELAX_DIFFUSE_SPECULAR", (3840, 2160), RELAX_DS_BYTES_PER_PIXEL, None),
 }
 
 
@@ -79,7 +83,7 @@ def parse_args():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=64)
     ap.add_argument("--warmup", type=int, default=32)
-    ap.add_argument("--workload", choices=sorted(WORKLOADS), default="reblur_ds", help="reblur_ds = the BASELINE.json metric (default); relax_ds_sh = config 5 (4K)")
+    ap.add_argument("--workload", choices=sorted(WORKLOADS), default="reblur_ds", help="reblur_ds = the BASELINE.json metric (default); reblur_ds_perf = same in NRD's performance mode; relax_ds_sh = config 5 (4K)")
     ap.add_argument("--width", type=int, default=0)
     ap.add_argument("--height", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -88,7 +92,7 @@ def parse_args():
     return ap.parse_args()
 
 
-def cpu_baseline(name, width, height, frames, seq):
+def cpu_baseline(name, width, height, frames, seq, overrides=None):
     """Times the CPU oracle on the first `frames` frames of the same sequence (all host cores, OpenMP over rows)."""
     import parity
     from oracle import driver as oracle_driver
@@ -100,7 +104,7 @@ def cpu_baseline(name, width, height, frames, seq):
     t0 = time.perf_counter()
     for f, frame in enumerate(host_seq):
         cs = parity.common_settings(frame["camera"], host_seq[max(f - 1, 0)]["camera"], width, height, f)
-        ora.step(frame, cs, parity.denoiser_settings(name, frame))
+        ora.step(frame, cs, parity.denoiser_settings(name, frame, overrides))
     dt = time.perf_counter() - t0
     return {
         "value": round(frames * width * height / dt / 1e6, 4),
@@ -138,7 +142,7 @@ def main():
     if distributed:
         dist.barrier()
 
-    name, default_size, bytes_per_pixel = WORKLOADS[args.workload]
+    name, default_size, bytes_per_pixel, overrides = WORKLOADS[args.workload]
     W, H = args.width or default_size[0], args.height or default_size[1]
     total = args.warmup + args.steps
     distinct = args.distinct_frames or total
@@ -156,7 +160,7 @@ def main():
         outputs.append(t)
     shard = sharding.FrameSharder(ex, inst, W, H, rank, world, outputs) if distributed else None
 
-    settings = parity.denoiser_settings(name, seq[0])
+    settings = parity.denoiser_settings(name, seq[0], overrides)
     assert inst.set_denoiser_settings(0, settings) == api.Result.SUCCESS
     def frame_of(f):
         # distinct < total: walk the generated frames back and forth so consecutive frames always have neighbouring cameras
@@ -246,7 +250,8 @@ def main():
                    "frac_of_peak": round(total_bpp * rows / (gpu_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if gpu_ms else None}
 
     result = {
-        "metric": "Mpixels/s %s @%s" % (name, {(2560, 1440): "1440p", (3840, 2160): "4K", (1920, 1080): "1080p"}.get((W, H), "%dx%d" % (W, H))),
+        "metric": "Mpixels/s %s @%s%s" % (name, {(2560, 1440): "1440p", (3840, 2160): "4K", (1920, 1080): "1080p"}.get((W, H), "%dx%d" % (W, H)),
+                                         "" if overrides is None else " (%s)" % ", ".join("%s=%s" % kv for kv in sorted(overrides.items()))),
         "value": round(mpix_s, 2),
         "unit": "Mpixels/s",
         "n_gpus": world,
@@ -255,10 +260,10 @@ def main():
         "ms_per_step": round(ms_per_step, 4),
         "higher_is_better": True,
         "scaling": "strong",
-        "vs_baseline": round(mpix_s / PUBLISHED_MPIX_S[(name, W, H)], 3) if world == 1 and (name, W, H) in PUBLISHED_MPIX_S else None,
+        "vs_baseline": round(mpix_s / PUBLISHED_MPIX_S[(name, W, H)], 3) if world == 1 and overrides is None and (name, W, H) in PUBLISHED_MPIX_S else None,
         "dtype": "f32",
         "data": "synthetic",
-        "config": {"workload": "%s %dx%d, default settings, analytic scene + 1rpp noise, moving camera" % (name, W, H),
+        "config": {"workload": "%s %dx%d, %s, analytic scene + 1rpp noise, moving camera" % (name, W, H, "default settings" if overrides is None else "settings %s" % overrides),
                    "parallelism": "1 GPU" if world == 1 else "row strips x%d + RCCL all-gather" % world,
                    "storage": "reference pool formats (fp16 history, R10G10B10A2 normals), %.0f B/px/frame compulsory traffic" % total_bpp},
         "roofline": roofline,
@@ -266,7 +271,7 @@ def main():
         "passes": passes,
     }
     if not args.no_cpu_baseline and world == 1:
-        result["cpu_baseline"] = cpu_baseline(name, W, H, min(args.cpu_frames, distinct), seq)
+        result["cpu_baseline"] = cpu_baseline(name, W, H, min(args.cpu_frames, distinct), seq, overrides)
     else:
         result["cpu_baseline"] = None
     print(json.dumps(result))

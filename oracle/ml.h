@@ -245,6 +245,9 @@ inline float4 REBLUR_FrontEnd_PackRadianceAndNormHitDist(float3 radiance, float 
 inline float4 REBLUR_BackEnd_UnpackRadianceAndNormHitDist(float4 d) { return float4(_NRD_YCoCgToLinear(d.xyz()), d.w); } // NRD.hlsli:863-868
 
 // ================================================================================================ [com] Common.hlsli
+static const float3 g_Special6[6] = { // Common.hlsli:170-179 (performance mode); 0.5 * sqrt(3) and 0.15 * sqrt(3) rounded to fp32
+    float3(-0.8660254f, -0.5f, 1.0f), float3(0.0f, 1.0f, 1.0f), float3(0.8660254f, -0.5f, 1.0f),
+    float3(0.0f, -0.3f, 0.3f), float3(0.25980762f, 0.15f, 0.3f), float3(-0.25980762f, 0.15f, 0.3f)};
 static const float3 g_Special8[8] = { // Common.hlsli:181-192
     float3(-1.0f, 0.0f, 1.0f), float3(0.0f, 1.0f, 1.0f), float3(1.0f, 0.0f, 1.0f), float3(0.0f, -1.0f, 1.0f),
     float3(-0.25f * 1.41421356f, 0.25f * 1.41421356f, 0.5f), float3(0.25f * 1.41421356f, 0.25f * 1.41421356f, 0.5f),

@@ -58,6 +58,7 @@ struct SpatialCtx { // what PrePass / Blur / PostBlur share per pixel
     float3 N, Nv, Xv, Vv;
     float4 rotator;
     float2 data1; // accumulated frames (diff, spec); unused by the pre-pass
+    bool perf;    // REBLUR_PERFORMANCE_MODE (REBLUR_Config.hlsli:196-238): 6 taps of g_Special6, screen-space sampling for specular too
 };
 
 float4 DiffuseSpatialFilter(const ReblurCB& c, SpatialMode mode, const SpatialCtx& s, float4 diff, const Tex& gIn_Diff, const Tex& gIn_ViewZ, const Tex& gIn_Normal_Roughness) {
@@ -114,8 +115,9 @@ float4 DiffuseSpatialFilter(const ReblurCB& c, SpatialMode mode, const SpatialCt
     skew *= c.gRectSizeInv * blurRadius;
     float4 scaledRotator = Geometry::ScaleRotator(s.rotator, skew);
 
-    for (int n = 0; n < 8; n++) {
-        float3 offset = g_Special8[n];
+    const int sampleNum = s.perf ? 6 : 8;
+    for (int n = 0; n < sampleNum; n++) {
+        float3 offset = s.perf ? g_Special6[n] : g_Special8[n];
         float2 uv = s.pixelUv + Geometry::RotateVector(scaledRotator, float2(offset.x, offset.y));
         uv = floor(uv * c.gRectSize) + 0.5f; // snap to the pixel centre
         uv *= c.gRectSizeInv;
@@ -213,10 +215,11 @@ float4 SpecularSpatialFilter(const ReblurCB& c, SpatialMode mode, const SpatialC
     if (mode != PRE_BLUR)
         minHitDistWeight *= sqrtf(specNonLinearAccumSpeed);
 
-    // Sampling set-up: screen space for the pre-pass, world space along the (bent) lobe otherwise
+    // Sampling set-up: screen space for the pre-pass (and for every pass in performance mode), world space along the (bent) lobe otherwise
+    const bool screenSpace = mode == PRE_BLUR || s.perf; // REBLUR_USE_SCREEN_SPACE_SAMPLING_FOR_SPECULAR
     float4 scaledRotator = float4(0.0f);
     float3 T, B;
-    if (mode == PRE_BLUR) {
+    if (screenSpace) {
         float2 skew = c.gRectSizeInv * blurRadius;
         scaledRotator = Geometry::ScaleRotator(s.rotator, skew);
     } else {
@@ -231,10 +234,11 @@ float4 SpecularSpatialFilter(const ReblurCB& c, SpatialMode mode, const SpatialC
         B *= worldRadius / skewFactor;
     }
 
-    for (int n = 0; n < 8; n++) {
-        float3 offset = g_Special8[n];
+    const int sampleNum = s.perf ? 6 : 8;
+    for (int n = 0; n < sampleNum; n++) {
+        float3 offset = s.perf ? g_Special6[n] : g_Special8[n];
         float2 uv;
-        if (mode == PRE_BLUR)
+        if (screenSpace)
             uv = s.pixelUv + Geometry::RotateVector(scaledRotator, float2(offset.x, offset.y));
         else
             uv = GetKernelSampleCoordinates(c.gViewToClip, offset, s.Xv, T, B, s.rotator);
@@ -289,7 +293,8 @@ float4 SpecularSpatialFilter(const ReblurCB& c, SpatialMode mode, const SpatialC
 }
 
 // fills the per-pixel context; returns false on the early-outs (sky tile / outside rect / beyond denoising range)
-bool MakeSpatialCtx(const ReblurCB& c, int px, int py, const Tex& gIn_Tiles, const Tex& gIn_ViewZ, const Tex& gIn_Normal_Roughness, float4 rotator, SpatialCtx& s, float* viewZpackedOut = nullptr) {
+bool MakeSpatialCtx(const ReblurCB& c, int px, int py, const Tex& gIn_Tiles, const Tex& gIn_ViewZ, const Tex& gIn_Normal_Roughness, float4 rotator, bool perf, SpatialCtx& s, float* viewZpackedOut = nullptr) {
+    s.perf = perf;
     float isSky = gIn_Tiles.Load(px >> 4, py >> 4).x;
     if (isSky != 0.0f || px > c.gRectSizeMinusOne[0] || py > c.gRectSizeMinusOne[1])
         return false;
@@ -317,7 +322,7 @@ bool MakeSpatialCtx(const ReblurCB& c, int px, int py, const Tex& gIn_Tiles, con
 }
 
 // ================================================================================================ PrePass
-template <bool DIFF, bool SPEC>
+template <bool DIFF, bool SPEC, bool PERF>
 void PrePass(const PassIO& io) {
     const ReblurCB& c = *(const ReblurCB*)io.constants;
     Cursor cur(io);
@@ -334,7 +339,7 @@ void PrePass(const PassIO& io) {
     for (int py = 0; py < (int)c.gRectSize.y; py++)
         for (int px = 0; px < (int)c.gRectSize.x; px++) {
             SpatialCtx s;
-            if (!MakeSpatialCtx(c, px, py, gIn_Tiles, gIn_ViewZ, gIn_Normal_Roughness, c.gRotatorPre, s))
+            if (!MakeSpatialCtx(c, px, py, gIn_Tiles, gIn_ViewZ, gIn_Normal_Roughness, c.gRotatorPre, PERF, s))
                 continue;
             if (DIFF) {
                 float4 diff = gIn_Diff->Load(px, py);
@@ -350,7 +355,7 @@ void PrePass(const PassIO& io) {
 }
 
 // ================================================================================================ Blur
-template <bool DIFF, bool SPEC>
+template <bool DIFF, bool SPEC, bool PERF>
 void Blur(const PassIO& io) {
     const ReblurCB& c = *(const ReblurCB*)io.constants;
     Cursor cur(io);
@@ -374,7 +379,7 @@ void Blur(const PassIO& io) {
             gOut_ViewZ.Store(px, py, gIn_ViewZ.Load(px, py).x);
 
             SpatialCtx s;
-            if (!MakeSpatialCtx(c, px, py, gIn_Tiles, gIn_ViewZ, gIn_Normal_Roughness, c.gRotator, s))
+            if (!MakeSpatialCtx(c, px, py, gIn_Tiles, gIn_ViewZ, gIn_Normal_Roughness, c.gRotator, PERF, s))
                 continue;
             s.data1 = UnpackData1(gIn_Data1.Load(px, py), DIFF);
             if (DIFF) {
@@ -391,7 +396,7 @@ void Blur(const PassIO& io) {
 }
 
 // ================================================================================================ PostBlur
-template <bool DIFF, bool SPEC, bool NO_TS>
+template <bool DIFF, bool SPEC, bool NO_TS, bool PERF>
 void PostBlur(const PassIO& io) {
     const ReblurCB& c = *(const ReblurCB*)io.constants;
     Cursor cur(io);
@@ -412,7 +417,7 @@ void PostBlur(const PassIO& io) {
     for (int py = 0; py < (int)c.gRectSize.y; py++)
         for (int px = 0; px < (int)c.gRectSize.x; px++) {
             SpatialCtx s;
-            if (!MakeSpatialCtx(c, px, py, gIn_Tiles, gIn_ViewZ, gIn_Normal_Roughness, c.gRotatorPost, s))
+            if (!MakeSpatialCtx(c, px, py, gIn_Tiles, gIn_ViewZ, gIn_Normal_Roughness, c.gRotatorPost, PERF, s))
                 continue;
             s.data1 = UnpackData1(gIn_Data1.Load(px, py), DIFF);
 
@@ -438,7 +443,7 @@ void PostBlur(const PassIO& io) {
 }
 
 // ================================================================================================ TemporalAccumulation
-template <bool DIFF, bool SPEC>
+template <bool DIFF, bool SPEC, bool PERF>
 void TemporalAccumulation(const PassIO& io) {
     const ReblurCB& c = *(const ReblurCB*)io.constants;
     Cursor cur(io);
@@ -637,7 +642,7 @@ void TemporalAccumulation(const PassIO& io) {
 
             // 2x2 occlusion weights
             float4 smbOcclusionWeights = Filtering::GetBilinearCustomWeights(smbBilinearFilter, float4(smbOcclusion0.z, smbOcclusion1.y, smbOcclusion2.y, smbOcclusion3.x));
-            bool smbAllowCatRom = sum(smbOcclusion0 + smbOcclusion1 + smbOcclusion2 + smbOcclusion3) > 11.5f;
+            bool smbAllowCatRom = sum(smbOcclusion0 + smbOcclusion1 + smbOcclusion2 + smbOcclusion3) > 11.5f && !PERF; // REBLUR_USE_CATROM_FOR_SURFACE_MOTION_IN_TA
 
             float fbits = smbOcclusion0.z * 1.0f;
             fbits += smbOcclusion1.y * 2.0f;
@@ -820,7 +825,7 @@ void TemporalAccumulation(const PassIO& io) {
                 vmbFootprintQuality = Math::Sqrt01(vmbFootprintQuality);
                 vmbSpecAccumSpeed *= lerp(vmbFootprintQuality, 1.0f, 1.0f / (1.0f + vmbSpecAccumSpeed));
 
-                bool vmbAllowCatRom = sum(vmbOcclusion) > 3.5f;
+                bool vmbAllowCatRom = sum(vmbOcclusion) > 3.5f && !PERF; // REBLUR_USE_CATROM_FOR_VIRTUAL_MOTION_IN_TA
                 vmbAllowCatRom = vmbAllowCatRom && smbAllowCatRom;
 
                 // How many radians can the travelled pixels be?
@@ -1033,7 +1038,7 @@ void TemporalAccumulation(const PassIO& io) {
 
 // ================================================================================================ HistoryFix
 // one signal (diffuse or specular) of the history-fix pass; returns the fixed signal and writes the fast history
-float4 HistoryFixSignal(const ReblurCB& c, bool isSpec, int px, int py, float4 sig, float frameNum, float strideBase, float roughness, float viewZ, float materialID,
+float4 HistoryFixSignal(const ReblurCB& c, bool isSpec, bool perf, int px, int py, float4 sig, float frameNum, float strideBase, float roughness, float viewZ, float materialID,
     float3 N, float3 Nv, float3 Xv, float2 pixelUv, float frustumSize, const Tex& gIn_ViewZ, const Tex& gIn_Normal_Roughness, const Tex& gIn_Data1, bool hasDiff,
     const Tex& gIn_Signal, const Tex& gIn_Fast, Tex& gOut_Fast) {
     const int rw = c.gRectSizeMinusOne[0], rh = c.gRectSizeMinusOne[1];
@@ -1061,6 +1066,8 @@ float4 HistoryFixSignal(const ReblurCB& c, bool isSpec, int px, int py, float4 s
         float2 hitDistanceWeightParams = GetHitDistanceWeightParams(hitDistFactor, nonLinearAccumSpeed, r);
 
         float sumw = 1.0f + frameNum;
+        if (perf) // REBLUR_HistoryFix.hlsli:88-90 / 292-294
+            sumw = 1.0f + 1.0f / (1.0f + c.gMaxAccumulatedFrameNum) - nonLinearAccumSpeed;
         sig *= sumw;
 
         for (int j = -2; j <= 2; j++)
@@ -1085,8 +1092,10 @@ float4 HistoryFixSignal(const ReblurCB& c, bool isSpec, int px, int py, float4 s
                 if (isSpec)
                     w *= ComputeExponentialWeight(Ns.w * Ns.w, relaxedRoughnessWeightParams.x, relaxedRoughnessWeightParams.y);
 
-                float2 d1 = UnpackData1(gIn_Data1.Load(sx, sy), hasDiff);
-                w *= 1.0f + (isSpec ? d1.y : d1.x);
+                if (!perf) {
+                    float2 d1 = UnpackData1(gIn_Data1.Load(sx, sy), hasDiff);
+                    w *= 1.0f + (isSpec ? d1.y : d1.x);
+                }
 
                 float4 smp = gIn_Signal.Load(sx, sy);
                 smp = w == 0.0f ? float4(0.0f) : smp;
@@ -1134,7 +1143,7 @@ float4 HistoryFixSignal(const ReblurCB& c, bool isSpec, int px, int py, float4 s
     // Anti-firefly: 9x9 minus the central 3x3
     if (c.gAntiFirefly != 0.0f) {
         float am1 = 0.0f, am2 = 0.0f;
-        const int R = REBLUR_ANTI_FIREFLY_FILTER_RADIUS;
+        const int R = perf ? 3 : REBLUR_ANTI_FIREFLY_FILTER_RADIUS; // REBLUR_Config.hlsli:236-237
         for (int j = -R; j <= R; j++)
             for (int i = -R; i <= R; i++) {
                 if (::abs(i) <= 1 && ::abs(j) <= 1)
@@ -1160,7 +1169,7 @@ float4 HistoryFixSignal(const ReblurCB& c, bool isSpec, int px, int py, float4 s
     return ChangeLuma(sig, luma);
 }
 
-template <bool DIFF, bool SPEC>
+template <bool DIFF, bool SPEC, bool PERF>
 void HistoryFix(const PassIO& io) {
     const ReblurCB& c = *(const ReblurCB*)io.constants;
     Cursor cur(io);
@@ -1200,14 +1209,14 @@ void HistoryFix(const PassIO& io) {
             float2 stride = c.gHistoryFixBasePixelStride / (2.0f + frameNum);
 
             if (DIFF) {
-                float4 diff = HistoryFixSignal(c, false, px, py, gIn_Diff->Load(px, py), frameNum.x, stride.x, roughness, viewZ, materialID, N, Nv, Xv, pixelUv, frustumSize,
+                float4 diff = HistoryFixSignal(c, false, PERF, px, py, gIn_Diff->Load(px, py), frameNum.x, stride.x, roughness, viewZ, materialID, N, Nv, Xv, pixelUv, frustumSize,
                     gIn_ViewZ, gIn_Normal_Roughness, gIn_Data1, DIFF, *gIn_Diff, *gIn_DiffFast, *gOut_DiffFast);
                 if (getenv("ORACLE_DEBUG_PIXEL") && px == atoi(getenv("ORACLE_DEBUG_PIXEL")) && py == atoi(strchr(getenv("ORACLE_DEBUG_PIXEL"), ',') + 1))
                     fprintf(stderr, "HF diff (%d,%d): %.9g %.9g %.9g %.9g framenum %g\n", px, py, diff.x, diff.y, diff.z, diff.w, frameNum.x);
                 gOut_Diff->Store(px, py, diff);
             }
             if (SPEC) {
-                float4 spec = HistoryFixSignal(c, true, px, py, gIn_Spec->Load(px, py), frameNum.y, stride.y, roughness, viewZ, materialID, N, Nv, Xv, pixelUv, frustumSize,
+                float4 spec = HistoryFixSignal(c, true, PERF, px, py, gIn_Spec->Load(px, py), frameNum.y, stride.y, roughness, viewZ, materialID, N, Nv, Xv, pixelUv, frustumSize,
                     gIn_ViewZ, gIn_Normal_Roughness, gIn_Data1, DIFF, *gIn_Spec, *gIn_SpecFast, *gOut_SpecFast);
                 gOut_Spec->Store(px, py, spec);
             }
@@ -1215,7 +1224,7 @@ void HistoryFix(const PassIO& io) {
 }
 
 // ================================================================================================ TemporalStabilization
-template <bool DIFF, bool SPEC>
+template <bool DIFF, bool SPEC, bool PERF>
 void TemporalStabilization(const PassIO& io) {
     const ReblurCB& c = *(const ReblurCB*)io.constants;
     Cursor cur(io);
@@ -1283,7 +1292,7 @@ void TemporalStabilization(const PassIO& io) {
             Filtering::Bilinear smbBilinearFilter = Filtering::GetBilinearFilter(smbPixelUv, c.gRectSizePrev);
             float4 smbOcclusion = float4((bits & 1u) ? 1.0f : 0.0f, (bits & 2u) ? 1.0f : 0.0f, (bits & 4u) ? 1.0f : 0.0f, (bits & 8u) ? 1.0f : 0.0f);
             float4 smbOcclusionWeights = Filtering::GetBilinearCustomWeights(smbBilinearFilter, smbOcclusion);
-            bool smbAllowCatRom = sum(smbOcclusion) > 3.5f;
+            bool smbAllowCatRom = sum(smbOcclusion) > 3.5f && !PERF; // REBLUR_USE_CATROM_FOR_SURFACE_MOTION_IN_TS
             float smbFootprintQuality = Filtering::ApplyBilinearFilter(smbOcclusion.x, smbOcclusion.y, smbOcclusion.z, smbOcclusion.w, smbBilinearFilter);
             smbFootprintQuality = Math::Sqrt01(smbFootprintQuality);
 
@@ -1308,7 +1317,7 @@ void TemporalStabilization(const PassIO& io) {
                 M2 /= 9.0f;
                 m1 = M1;
                 sigma = sqrtf(fabsf(M2 - M1 * M1));
-                if (c.gMaxBlurRadius != 0.0f) // RCRS
+                if (!PERF && c.gMaxBlurRadius != 0.0f) // RCRS (not in performance mode)
                     luma = clamp(luma, mn, mx);
             };
 
@@ -1368,7 +1377,7 @@ void TemporalStabilization(const PassIO& io) {
                 Filtering::Bilinear vmbBilinearFilter = Filtering::GetBilinearFilter(vmbPixelUv, c.gRectSizePrev);
                 float4 vmbOcclusion = float4((bits & 16u) ? 1.0f : 0.0f, (bits & 32u) ? 1.0f : 0.0f, (bits & 64u) ? 1.0f : 0.0f, (bits & 128u) ? 1.0f : 0.0f);
                 float4 vmbOcclusionWeights = Filtering::GetBilinearCustomWeights(vmbBilinearFilter, vmbOcclusion);
-                bool vmbAllowCatRom = sum(vmbOcclusion) > 3.5f;
+                bool vmbAllowCatRom = sum(vmbOcclusion) > 3.5f && !PERF; // REBLUR_USE_CATROM_FOR_VIRTUAL_MOTION_IN_TS
                 float vmbFootprintQuality = Filtering::ApplyBilinearFilter(vmbOcclusion.x, vmbOcclusion.y, vmbOcclusion.z, vmbOcclusion.w, vmbBilinearFilter);
                 vmbFootprintQuality = Math::Sqrt01(vmbFootprintQuality);
 
@@ -1414,7 +1423,7 @@ void TemporalStabilization(const PassIO& io) {
 // ================================================================================================ HitDistReconstruction
 // reference Shaders/Include/REBLUR_HitDistReconstruction.hlsli:10-160 (REBLUR_USE_DECOMPRESSED_HIT_DIST_IN_RECONSTRUCTION = 0,
 // non-performance mode). BORDER = 1 -> 3x3, 2 -> 5x5 window; the window is read at rect-clamped coordinates like the LDS preload.
-template <bool DIFF, bool SPEC, int BORDER>
+template <bool DIFF, bool SPEC, int BORDER, bool PERF>
 void HitDistReconstruction(const PassIO& io) {
     const ReblurCB& c = *(const ReblurCB*)io.constants;
     Cursor cur(io);
@@ -1478,12 +1487,14 @@ void HitDistReconstruction(const PassIO& io) {
                     w *= ComputeWeight(dot(Nv, Xvs), geometryWeightParams.x, geometryWeightParams.y);
 
                     float2 ww = float2(w);
-                    float4 sampleNormalAndRoughness = NormalRoughness(sx, sy);
-                    float cosa = dot(N, sampleNormalAndRoughness.xyz());
-                    float angle = Math::AcosApprox(cosa);
-                    ww.x *= ComputeExponentialWeight(angle, diffNormalWeightParam, 0.0f);
-                    ww.y *= ComputeExponentialWeight(angle, specNormalWeightParam, 0.0f);
-                    ww.y *= ComputeExponentialWeight(sampleNormalAndRoughness.w * sampleNormalAndRoughness.w, relaxedRoughnessWeightParams.x, relaxedRoughnessWeightParams.y);
+                    if (!PERF) {
+                        float4 sampleNormalAndRoughness = NormalRoughness(sx, sy);
+                        float cosa = dot(N, sampleNormalAndRoughness.xyz());
+                        float angle = Math::AcosApprox(cosa);
+                        ww.x *= ComputeExponentialWeight(angle, diffNormalWeightParam, 0.0f);
+                        ww.y *= ComputeExponentialWeight(angle, specNormalWeightParam, 0.0f);
+                        ww.y *= ComputeExponentialWeight(sampleNormalAndRoughness.w * sampleNormalAndRoughness.w, relaxedRoughnessWeightParams.x, relaxedRoughnessWeightParams.y);
+                    }
 
                     data.x = ww.x == 0.0f ? 0.0f : data.x; // Denanify
                     data.y = ww.y == 0.0f ? 0.0f : data.y;
@@ -1528,16 +1539,20 @@ void SplitScreen(const PassIO& io) {
 
 } // namespace
 
+// quality and performance ("REBLUR_Perf_*", REBLUR_PERFORMANCE_MODE) permutations of one signal family
+#define REBLUR_PASSES(PREFIX, NAME, D, S, P)                                                            \
+    {PREFIX NAME "_HitDistReconstruction.cs", HitDistReconstruction<D, S, 1, P>},                      \
+    {PREFIX NAME "_HitDistReconstruction_5x5.cs", HitDistReconstruction<D, S, 2, P>},                  \
+    {PREFIX NAME "_PrePass.cs", PrePass<D, S, P>},                                                     \
+    {PREFIX NAME "_TemporalAccumulation.cs", TemporalAccumulation<D, S, P>},                           \
+    {PREFIX NAME "_HistoryFix.cs", HistoryFix<D, S, P>},                                               \
+    {PREFIX NAME "_Blur.cs", Blur<D, S, P>},                                                           \
+    {PREFIX NAME "_PostBlur.cs", PostBlur<D, S, false, P>},                                            \
+    {PREFIX NAME "_PostBlur_NoTemporalStabilization.cs", PostBlur<D, S, true, P>},                     \
+    {PREFIX NAME "_TemporalStabilization.cs", TemporalStabilization<D, S, P>},
 #define REBLUR_FAMILY(NAME, D, S)                                                                      \
-    {"REBLUR_" NAME "_HitDistReconstruction.cs", HitDistReconstruction<D, S, 1>},                      \
-    {"REBLUR_" NAME "_HitDistReconstruction_5x5.cs", HitDistReconstruction<D, S, 2>},                  \
-    {"REBLUR_" NAME "_PrePass.cs", PrePass<D, S>},                                                     \
-    {"REBLUR_" NAME "_TemporalAccumulation.cs", TemporalAccumulation<D, S>},                           \
-    {"REBLUR_" NAME "_HistoryFix.cs", HistoryFix<D, S>},                                               \
-    {"REBLUR_" NAME "_Blur.cs", Blur<D, S>},                                                           \
-    {"REBLUR_" NAME "_PostBlur.cs", PostBlur<D, S, false>},                                            \
-    {"REBLUR_" NAME "_PostBlur_NoTemporalStabilization.cs", PostBlur<D, S, true>},                     \
-    {"REBLUR_" NAME "_TemporalStabilization.cs", TemporalStabilization<D, S>},                         \
+    REBLUR_PASSES("REBLUR_", NAME, D, S, false)                                                        \
+    REBLUR_PASSES("REBLUR_Perf_", NAME, D, S, true)                                                    \
     {"REBLUR_" NAME "_SplitScreen.cs", SplitScreen<D, S>},
 
 const PassEntry* GetReblurPasses(uint32_t& n) {

@@ -56,7 +56,8 @@ struct HfPixel {
     float2 pixelUv;
 };
 
-template <bool IS_SPEC, bool DIFF, bool SPEC>
+// PERF = REBLUR_PERFORMANCE_MODE (reference REBLUR_HistoryFix.hlsli:88-90 / 139-141 / 292-294 / 338-340, REBLUR_Config.hlsli:236-237)
+template <bool IS_SPEC, bool DIFF, bool SPEC, bool PERF>
 NRD_D float4 HistoryFixSignal(const ReblurCB& c, const HfPlanes& P, const HfPixel& s, float4 sig, float frameNum, float strideBase, const Plane& gIn_Signal, const Plane& gIn_Fast,
     const Plane& gOut_Fast, const float* s_Luma) {
     const int rw = c.gRectSizeMinusOne.x, rh = c.gRectSizeMinusOne.y;
@@ -84,6 +85,8 @@ NRD_D float4 HistoryFixSignal(const ReblurCB& c, const HfPlanes& P, const HfPixe
         float2 hitDistanceWeightParams = GetHitDistanceWeightParams(hitDistFactor, nonLinearAccumSpeed, r);
 
         float sumw = 1.0f + frameNum;
+        if (PERF)
+            sumw = 1.0f + 1.0f / (1.0f + c.gMaxAccumulatedFrameNum) - nonLinearAccumSpeed;
         sig = sig * sumw;
 
         for (int j = -2; j <= 2; j++) {
@@ -108,8 +111,10 @@ NRD_D float4 HistoryFixSignal(const ReblurCB& c, const HfPlanes& P, const HfPixe
                 if (IS_SPEC)
                     w *= ComputeExponentialWeight(Ns.w * Ns.w, relaxedRoughnessWeightParams.x, relaxedRoughnessWeightParams.y);
 
-                float2 d1 = LoadData1<DIFF, SPEC>(P.data1, sx, sy);
-                w *= 1.0f + (IS_SPEC ? d1.y : d1.x);
+                if (!PERF) {
+                    float2 d1 = LoadData1<DIFF, SPEC>(P.data1, sx, sy);
+                    w *= 1.0f + (IS_SPEC ? d1.y : d1.x);
+                }
 
                 float4 smp = LoadRGBA16F(gIn_Signal, sx, sy);
                 smp = w == 0.0f ? F4(0.0f) : smp;
@@ -160,7 +165,7 @@ NRD_D float4 HistoryFixSignal(const ReblurCB& c, const HfPlanes& P, const HfPixe
     // Anti-firefly: 9x9 minus the central 3x3 (off by default)
     if (c.gAntiFirefly != 0.0f) {
         float am1 = 0.0f, am2 = 0.0f;
-        const int R = REBLUR_ANTI_FIREFLY_FILTER_RADIUS;
+        const int R = PERF ? 3 : REBLUR_ANTI_FIREFLY_FILTER_RADIUS;
         for (int j = -R; j <= R; j++)
             for (int i = -R; i <= R; i++) {
                 if (abs(i) <= 1 && abs(j) <= 1)
@@ -185,7 +190,7 @@ NRD_D float4 HistoryFixSignal(const ReblurCB& c, const HfPlanes& P, const HfPixe
     return ChangeLuma(sig, luma);
 }
 
-template <bool DIFF, bool SPEC>
+template <bool DIFF, bool SPEC, bool PERF>
 __global__ __launch_bounds__(TILE_X* TILE_Y) void ReblurHistoryFixKernel(ReblurCB c, HfPlanes P, RowRange rr) {
     __shared__ float s_DiffLuma[DIFF ? hf::BUF_Y * hf::BUF_STRIDE : 1];
     __shared__ float s_SpecLuma[SPEC ? hf::BUF_Y * hf::BUF_STRIDE : 1];
@@ -231,16 +236,16 @@ __global__ __launch_bounds__(TILE_X* TILE_Y) void ReblurHistoryFixKernel(ReblurC
     float2 stride = F2(c.gHistoryFixBasePixelStride / (2.0f + frameNum.x), c.gHistoryFixBasePixelStride / (2.0f + frameNum.y));
 
     if (DIFF) {
-        float4 diff = HistoryFixSignal<false, DIFF, SPEC>(c, P, s, LoadRGBA16F(P.inDiff, px, py), frameNum.x, stride.x, P.inDiff, P.inDiffFast, P.outDiffFast, s_DiffLuma);
+        float4 diff = HistoryFixSignal<false, DIFF, SPEC, PERF>(c, P, s, LoadRGBA16F(P.inDiff, px, py), frameNum.x, stride.x, P.inDiff, P.inDiffFast, P.outDiffFast, s_DiffLuma);
         StoreRGBA16F(P.outDiff, px, py, diff);
     }
     if (SPEC) {
-        float4 spec = HistoryFixSignal<true, DIFF, SPEC>(c, P, s, LoadRGBA16F(P.inSpec, px, py), frameNum.y, stride.y, P.inSpec, P.inSpecFast, P.outSpecFast, s_SpecLuma);
+        float4 spec = HistoryFixSignal<true, DIFF, SPEC, PERF>(c, P, s, LoadRGBA16F(P.inSpec, px, py), frameNum.y, stride.y, P.inSpec, P.inSpecFast, P.outSpecFast, s_SpecLuma);
         StoreRGBA16F(P.outSpec, px, py, spec);
     }
 }
 
-template <bool DIFF, bool SPEC>
+template <bool DIFF, bool SPEC, bool PERF>
 static const char* LaunchHistoryFix(const PassArgs& a) {
     const ReblurCB& c = *(const ReblurCB*)a.constants;
     if (const char* err = CheckSupportedHistory(c))
@@ -265,7 +270,7 @@ static const char* LaunchHistoryFix(const PassArgs& a) {
     if (k != a.planesNum)
         return "REBLUR history fix: unexpected resource count";
     RowGrid g = GridForRows(c.gRectSizeMinusOne.x + 1, c.gRectSizeMinusOne.y + 1, TILE_X, TILE_Y, a.rowBegin, a.rowEnd);
-    hipLaunchKernelGGL((ReblurHistoryFixKernel<DIFF, SPEC>), g.grid, dim3(TILE_X * TILE_Y), 0, a.stream, c, P, RowRange{g.firstBlockY, g.rowBegin, g.rowEnd});
+    hipLaunchKernelGGL((ReblurHistoryFixKernel<DIFF, SPEC, PERF>), g.grid, dim3(TILE_X * TILE_Y), 0, a.stream, c, P, RowRange{g.firstBlockY, g.rowBegin, g.rowEnd});
     return nullptr;
 }
 
@@ -284,6 +289,7 @@ struct TsPlanes {
 };
 
 // 3x3 luma statistics from the LDS tile: centre luma (min/max clamped), mean, sigma
+template <bool PERF> // PERF: no RCRS clamp of the centre luma (reference REBLUR_TemporalStabilization.hlsli:118-135)
 NRD_D void LumaStats(const ReblurCB& c, const float* s_Luma, int tx, int ty, float& luma, float& m1, float& sigma) {
     luma = s_Luma[(ty + ts::BORDER) * ts::BUF_STRIDE + tx + ts::BORDER];
     float M1 = luma, M2 = luma * luma, mn = NRD_INF, mx = -NRD_INF;
@@ -304,11 +310,11 @@ NRD_D void LumaStats(const ReblurCB& c, const float* s_Luma, int tx, int ty, flo
     M2 /= 9.0f;
     m1 = M1;
     sigma = Sqrt(Abs(M2 - M1 * M1));
-    if (c.gMaxBlurRadius != 0.0f)
+    if (!PERF && c.gMaxBlurRadius != 0.0f)
         luma = Clamp(luma, mn, mx);
 }
 
-template <bool DIFF, bool SPEC>
+template <bool DIFF, bool SPEC, bool PERF>
 __global__ __launch_bounds__(TILE_X* TILE_Y) void ReblurTemporalStabilizationKernel(ReblurCB c, TsPlanes P, RowRange rr) {
     __shared__ float s_DiffLuma[DIFF ? ts::BUF_Y * ts::BUF_STRIDE : 1];
     __shared__ float s_SpecLuma[SPEC ? ts::BUF_Y * ts::BUF_STRIDE : 1];
@@ -379,7 +385,7 @@ __global__ __launch_bounds__(TILE_X* TILE_Y) void ReblurTemporalStabilizationKer
     Bilinear smbBilinearFilter = GetBilinearFilter(smbPixelUv, rectSizePrev);
     float4 smbOcclusion = F4((bits & 1u) ? 1.0f : 0.0f, (bits & 2u) ? 1.0f : 0.0f, (bits & 4u) ? 1.0f : 0.0f, (bits & 8u) ? 1.0f : 0.0f);
     float4 smbOcclusionWeights = GetBilinearCustomWeights(smbBilinearFilter, smbOcclusion);
-    bool smbAllowCatRom = Sum(smbOcclusion) > 3.5f;
+    bool smbAllowCatRom = Sum(smbOcclusion) > 3.5f && !PERF; // REBLUR_USE_CATROM_FOR_SURFACE_MOTION_IN_TS
     float smbFootprintQuality = ApplyBilinearFilter(smbOcclusion.x, smbOcclusion.y, smbOcclusion.z, smbOcclusion.w, smbBilinearFilter);
     smbFootprintQuality = Sqrt01(smbFootprintQuality);
 
@@ -387,7 +393,7 @@ __global__ __launch_bounds__(TILE_X* TILE_Y) void ReblurTemporalStabilizationKer
 
     if (DIFF) {
         float diffLuma, diffLumaM1, diffLumaSigma;
-        LumaStats(c, s_DiffLuma, tx, ty, diffLuma, diffLumaM1, diffLumaSigma);
+        LumaStats<PERF>(c, s_DiffLuma, tx, ty, diffLuma, diffLumaM1, diffLumaSigma);
 
         HistoryFilter smbFilter = MakeHistoryFilter(smbSamplePos, smbOcclusionWeights, smbAllowCatRom, P.historyDiffLuma);
         float smbDiffLumaHistory = FetchHistoryR16F(smbFilter, P.historyDiffLuma);
@@ -416,7 +422,7 @@ __global__ __launch_bounds__(TILE_X* TILE_Y) void ReblurTemporalStabilizationKer
 
     if (SPEC) {
         float specLuma, specLumaM1, specLumaSigma;
-        LumaStats(c, s_SpecLuma, tx, ty, specLuma, specLumaM1, specLumaSigma);
+        LumaStats<PERF>(c, s_SpecLuma, tx, ty, specLuma, specLumaM1, specLumaSigma);
 
         float virtualHistoryAmount = data2.x;
         float curvature = data2.y;
@@ -437,7 +443,7 @@ __global__ __launch_bounds__(TILE_X* TILE_Y) void ReblurTemporalStabilizationKer
         Bilinear vmbBilinearFilter = GetBilinearFilter(vmbPixelUv, rectSizePrev);
         float4 vmbOcclusion = F4((bits & 16u) ? 1.0f : 0.0f, (bits & 32u) ? 1.0f : 0.0f, (bits & 64u) ? 1.0f : 0.0f, (bits & 128u) ? 1.0f : 0.0f);
         float4 vmbOcclusionWeights = GetBilinearCustomWeights(vmbBilinearFilter, vmbOcclusion);
-        bool vmbAllowCatRom = Sum(vmbOcclusion) > 3.5f;
+        bool vmbAllowCatRom = Sum(vmbOcclusion) > 3.5f && !PERF; // REBLUR_USE_CATROM_FOR_VIRTUAL_MOTION_IN_TS
         float vmbFootprintQuality = ApplyBilinearFilter(vmbOcclusion.x, vmbOcclusion.y, vmbOcclusion.z, vmbOcclusion.w, vmbBilinearFilter);
         vmbFootprintQuality = Sqrt01(vmbFootprintQuality);
 
@@ -479,7 +485,7 @@ __global__ __launch_bounds__(TILE_X* TILE_Y) void ReblurTemporalStabilizationKer
     StoreR16U(P.outInternalData, px, py, PackInternalData(data1.x, data1.y, materialID));
 }
 
-template <bool DIFF, bool SPEC>
+template <bool DIFF, bool SPEC, bool PERF>
 static const char* LaunchTemporalStabilization(const PassArgs& a) {
     const ReblurCB& c = *(const ReblurCB*)a.constants;
     if (const char* err = CheckSupportedHistory(c))
@@ -511,13 +517,15 @@ static const char* LaunchTemporalStabilization(const PassArgs& a) {
     if (k != a.planesNum)
         return "REBLUR temporal stabilization: unexpected resource count";
     RowGrid g = GridForRows(c.gRectSizeMinusOne.x + 1, c.gRectSizeMinusOne.y + 1, TILE_X, TILE_Y, a.rowBegin, a.rowEnd);
-    hipLaunchKernelGGL((ReblurTemporalStabilizationKernel<DIFF, SPEC>), g.grid, dim3(TILE_X * TILE_Y), 0, a.stream, c, P, RowRange{g.firstBlockY, g.rowBegin, g.rowEnd});
+    hipLaunchKernelGGL((ReblurTemporalStabilizationKernel<DIFF, SPEC, PERF>), g.grid, dim3(TILE_X * TILE_Y), 0, a.stream, c, P, RowRange{g.firstBlockY, g.rowBegin, g.rowEnd});
     return nullptr;
 }
 
-#define REBLUR_HISTORY_FAMILY(NAME, D, S)                                        \
-    {"REBLUR_" NAME "_HistoryFix.cs", LaunchHistoryFix<D, S>},                   \
-    {"REBLUR_" NAME "_TemporalStabilization.cs", LaunchTemporalStabilization<D, S>},
+#define REBLUR_HISTORY_FAMILY(NAME, D, S)                                                            \
+    {"REBLUR_" NAME "_HistoryFix.cs", LaunchHistoryFix<D, S, false>},                                \
+    {"REBLUR_" NAME "_TemporalStabilization.cs", LaunchTemporalStabilization<D, S, false>},          \
+    {"REBLUR_Perf_" NAME "_HistoryFix.cs", LaunchHistoryFix<D, S, true>},                            \
+    {"REBLUR_Perf_" NAME "_TemporalStabilization.cs", LaunchTemporalStabilization<D, S, true>},
 
 const PassEntry* GetReblurHistoryPasses(uint32_t& num) {
     static const PassEntry k[] = {

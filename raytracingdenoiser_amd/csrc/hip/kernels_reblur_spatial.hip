@@ -66,7 +66,16 @@ struct SpatialCtx {
     float2 data1;
 };
 
-template <SpatialMode MODE>
+// PERF = REBLUR_PERFORMANCE_MODE (reference REBLUR_Config.hlsli:196-238): 6 taps of g_Special6 instead of 8 of g_Special8, and
+// screen-space sampling for the specular Blur / PostBlur too
+template <bool PERF>
+NRD_D float PoissonGaussianWeight(int n) { // = GetGaussianWeight( offset.z ), baked (reblur_device.h)
+    if (PERF)
+        return n < 3 ? REBLUR_GAUSSIAN_WEIGHT_Z1 : REBLUR_GAUSSIAN_WEIGHT_Z03;
+    return n < 4 ? REBLUR_GAUSSIAN_WEIGHT_Z1 : REBLUR_GAUSSIAN_WEIGHT_Z05;
+}
+
+template <SpatialMode MODE, bool PERF>
 NRD_D float4 DiffuseSpatialFilter(const ReblurCB& c, const SpatialCtx& s, float4 diff, const Plane& gIn_Diff, const Plane& gIn_ViewZ, const Plane& gIn_Normal_Roughness) {
     if (MODE == PRE_BLUR && c.gDiffPrepassBlurRadius == 0.0f)
         return diff;
@@ -122,8 +131,8 @@ NRD_D float4 DiffuseSpatialFilter(const ReblurCB& c, const SpatialCtx& s, float4
     float4 scaledRotator = ScaleRotator(s.rotator, skew);
 
 #pragma unroll
-    for (int n = 0; n < 8; n++) {
-        float3 offset = F3(g_Special8[n][0], g_Special8[n][1], g_Special8[n][2]);
+    for (int n = 0; n < (PERF ? 6 : 8); n++) {
+        float3 offset = PERF ? F3(g_Special6[n][0], g_Special6[n][1], g_Special6[n][2]) : F3(g_Special8[n][0], g_Special8[n][1], g_Special8[n][2]);
         float2 uv = s.pixelUv + RotateVector(scaledRotator, F2(offset.x, offset.y));
         uv = Floor(uv * rectSize) + 0.5f;
         uv = uv * rectSizeInv;
@@ -147,7 +156,7 @@ NRD_D float4 DiffuseSpatialFilter(const ReblurCB& c, const SpatialCtx& s, float4
         smp = w == 0.0f ? F4(0.0f) : smp;
 
         w *= Lerp(minHitDistWeight, 1.0f, ComputeExponentialWeight(smp.w, hitDistanceWeightParams.x, hitDistanceWeightParams.y));
-        w *= n < 4 ? REBLUR_GAUSSIAN_WEIGHT_Z1 : REBLUR_GAUSSIAN_WEIGHT_Z05; // = GetGaussianWeight( offset.z )
+        w *= PoissonGaussianWeight<PERF>(n);
 
         sum += w;
         diff = diff + smp * w;
@@ -157,7 +166,7 @@ NRD_D float4 DiffuseSpatialFilter(const ReblurCB& c, const SpatialCtx& s, float4
     return diff * invSum;
 }
 
-template <SpatialMode MODE>
+template <SpatialMode MODE, bool PERF>
 NRD_D float4 SpecularSpatialFilter(const ReblurCB& c, const SpatialCtx& s, float4 spec, const Plane& gIn_Spec, const Plane& gIn_ViewZ, const Plane& gIn_Normal_Roughness,
     const Plane& gOut_SpecHitDistForTracking) {
     float smc = GetSpecMagicCurve(s.roughness);
@@ -223,9 +232,10 @@ NRD_D float4 SpecularSpatialFilter(const ReblurCB& c, const SpatialCtx& s, float
     const float2 rectSize = ToF2(c.gRectSize), rectSizeInv = ToF2(c.gRectSizeInv), resolutionScale = ToF2(c.gResolutionScale);
     const float2 uvMax = resolutionScale - ToF2(c.gResourceSizeInv) * 0.5f;
 
+    constexpr bool SCREEN_SPACE = MODE == PRE_BLUR || PERF; // REBLUR_USE_SCREEN_SPACE_SAMPLING_FOR_SPECULAR
     float4 scaledRotator = F4(0.0f);
     float3 T = F3(0.0f), B = F3(0.0f);
-    if (MODE == PRE_BLUR) {
+    if (SCREEN_SPACE) {
         float2 skew = rectSizeInv * blurRadius;
         scaledRotator = ScaleRotator(s.rotator, skew);
     } else {
@@ -241,10 +251,10 @@ NRD_D float4 SpecularSpatialFilter(const ReblurCB& c, const SpatialCtx& s, float
     }
 
 #pragma unroll
-    for (int n = 0; n < 8; n++) {
-        float3 offset = F3(g_Special8[n][0], g_Special8[n][1], g_Special8[n][2]);
+    for (int n = 0; n < (PERF ? 6 : 8); n++) {
+        float3 offset = PERF ? F3(g_Special6[n][0], g_Special6[n][1], g_Special6[n][2]) : F3(g_Special8[n][0], g_Special8[n][1], g_Special8[n][2]);
         float2 uv;
-        if (MODE == PRE_BLUR)
+        if (SCREEN_SPACE)
             uv = s.pixelUv + RotateVector(scaledRotator, F2(offset.x, offset.y));
         else
             uv = GetKernelSampleCoordinates(c.gViewToClip, offset, s.Xv, T, B, s.rotator);
@@ -284,7 +294,7 @@ NRD_D float4 SpecularSpatialFilter(const ReblurCB& c, const SpatialCtx& s, float
             w *= Lerp(Sat(t), 1.0f, LinearStep(0.5f, 1.0f, s.roughness));
         }
         w *= Lerp(minHitDistWeight, 1.0f, ComputeExponentialWeight(smp.w, hitDistanceWeightParams.x, hitDistanceWeightParams.y));
-        w *= n < 4 ? REBLUR_GAUSSIAN_WEIGHT_Z1 : REBLUR_GAUSSIAN_WEIGHT_Z05; // = GetGaussianWeight( offset.z )
+        w *= PoissonGaussianWeight<PERF>(n);
 
         sum += w;
         spec = spec + smp * w;
@@ -330,7 +340,7 @@ struct SpatialPlanes {
     Plane outInternalData, outDiffCopy, outSpecCopy; // post-blur without temporal stabilization
 };
 
-template <SpatialMode MODE, bool DIFF, bool SPEC, bool NO_TS>
+template <SpatialMode MODE, bool DIFF, bool SPEC, bool NO_TS, bool PERF>
 __global__ __launch_bounds__(TILE_X* TILE_Y) void ReblurSpatialKernel(ReblurCB c, SpatialPlanes P, RowRange rr) {
     const int px = blockIdx.x * TILE_X + (threadIdx.x % TILE_X);
     const int py = (blockIdx.y + rr.firstBlockY) * TILE_Y + (threadIdx.x / TILE_X);
@@ -359,14 +369,14 @@ __global__ __launch_bounds__(TILE_X* TILE_Y) void ReblurSpatialKernel(ReblurCB c
 
     if (DIFF) {
         float4 diff = LoadRGBA16F(P.inDiff, px, py);
-        diff = DiffuseSpatialFilter<MODE>(c, s, diff, P.inDiff, P.viewZ, P.decodedNR);
+        diff = DiffuseSpatialFilter<MODE, PERF>(c, s, diff, P.inDiff, P.viewZ, P.decodedNR);
         StoreRGBA16F(P.outDiff, px, py, diff);
         if (MODE == POST_BLUR && NO_TS)
             StoreRGBA16F(P.outDiffCopy, px, py, diff);
     }
     if (SPEC) {
         float4 spec = LoadRGBA16F(P.inSpec, px, py);
-        spec = SpecularSpatialFilter<MODE>(c, s, spec, P.inSpec, P.viewZ, P.decodedNR, P.outHitDistForTracking);
+        spec = SpecularSpatialFilter<MODE, PERF>(c, s, spec, P.inSpec, P.viewZ, P.decodedNR, P.outHitDistForTracking);
         StoreRGBA16F(P.outSpec, px, py, spec);
         if (MODE == POST_BLUR && NO_TS)
             StoreRGBA16F(P.outSpecCopy, px, py, spec);
@@ -383,7 +393,7 @@ static const char* CheckSupported(const ReblurCB& c) {
     return nullptr;
 }
 
-template <SpatialMode MODE, bool DIFF, bool SPEC, bool NO_TS>
+template <SpatialMode MODE, bool DIFF, bool SPEC, bool NO_TS, bool PERF>
 static const char* LaunchSpatial(const PassArgs& a) {
     const ReblurCB& c = *(const ReblurCB*)a.constants;
     if (const char* err = CheckSupported(c))
@@ -427,7 +437,7 @@ static const char* LaunchSpatial(const PassArgs& a) {
         return "REBLUR spatial pass: unexpected resource count";
 
     RowGrid g = GridForRows(c.gRectSizeMinusOne.x + 1, c.gRectSizeMinusOne.y + 1, TILE_X, TILE_Y, a.rowBegin, a.rowEnd);
-    hipLaunchKernelGGL((ReblurSpatialKernel<MODE, DIFF, SPEC, NO_TS>), g.grid, dim3(TILE_X * TILE_Y), 0, a.stream, c, P, RowRange{g.firstBlockY, g.rowBegin, g.rowEnd});
+    hipLaunchKernelGGL((ReblurSpatialKernel<MODE, DIFF, SPEC, NO_TS, PERF>), g.grid, dim3(TILE_X * TILE_Y), 0, a.stream, c, P, RowRange{g.firstBlockY, g.rowBegin, g.rowEnd});
     return nullptr;
 }
 
@@ -466,14 +476,14 @@ static const char* LaunchSplitScreen(const PassArgs& a) {
 }
 
 // ================================================================================================ HitDistReconstruction
-// reference Shaders/Include/REBLUR_HitDistReconstruction.hlsli:10-160 (normalised hit distances, non-performance mode).
+// reference Shaders/Include/REBLUR_HitDistReconstruction.hlsli:10-160 (normalised hit distances; PERF drops the normal / roughness weights).
 // An optional pass (HitDistanceReconstructionMode != OFF): the 3x3 / 5x5 window is read straight from L1/L2 at rect-clamped
 // coordinates -- 8 / 24 taps of (decoded normal 16 B, viewZ 4 B, hit distance 2 x 8 B) -- instead of staging an LDS tile.
 struct HitDistPlanes {
     Plane tiles, viewZ, decodedNR, inDiff, inSpec, outDiff, outSpec;
 };
 
-template <bool DIFF, bool SPEC, int BORDER>
+template <bool DIFF, bool SPEC, int BORDER, bool PERF>
 __global__ __launch_bounds__(TILE_X* TILE_Y) void ReblurHitDistReconstructionKernel(ReblurCB c, HitDistPlanes P, RowRange rr) {
     const int px = blockIdx.x * TILE_X + (threadIdx.x % TILE_X);
     const int py = (blockIdx.y + rr.firstBlockY) * TILE_Y + (threadIdx.x / TILE_X);
@@ -524,12 +534,14 @@ __global__ __launch_bounds__(TILE_X* TILE_Y) void ReblurHitDistReconstructionKer
             w *= ComputeWeight(Dot(Nv, Xvs), geometryWeightParams.x, geometryWeightParams.y);
 
             float2 ww = F2(w, w);
-            const float4 sampleNormalAndRoughness = LoadDecodedNormalRoughness(P.decodedNR, sx, sy);
-            const float cosa = Dot(N, Xyz(sampleNormalAndRoughness));
-            const float angle = AcosApprox(cosa);
-            ww.x *= ComputeExponentialWeight(angle, diffNormalWeightParam, 0.0f);
-            ww.y *= ComputeExponentialWeight(angle, specNormalWeightParam, 0.0f);
-            ww.y *= ComputeExponentialWeight(sampleNormalAndRoughness.w * sampleNormalAndRoughness.w, relaxedRoughnessWeightParams.x, relaxedRoughnessWeightParams.y);
+            if (!PERF) {
+                const float4 sampleNormalAndRoughness = LoadDecodedNormalRoughness(P.decodedNR, sx, sy);
+                const float cosa = Dot(N, Xyz(sampleNormalAndRoughness));
+                const float angle = AcosApprox(cosa);
+                ww.x *= ComputeExponentialWeight(angle, diffNormalWeightParam, 0.0f);
+                ww.y *= ComputeExponentialWeight(angle, specNormalWeightParam, 0.0f);
+                ww.y *= ComputeExponentialWeight(sampleNormalAndRoughness.w * sampleNormalAndRoughness.w, relaxedRoughnessWeightParams.x, relaxedRoughnessWeightParams.y);
+            }
 
             data.x = ww.x == 0.0f ? 0.0f : data.x;
             data.y = ww.y == 0.0f ? 0.0f : data.y;
@@ -546,7 +558,7 @@ __global__ __launch_bounds__(TILE_X* TILE_Y) void ReblurHitDistReconstructionKer
         StoreRGBA16F(P.outSpec, px, py, F4(Xyz(centerSpec), center.y));
 }
 
-template <bool DIFF, bool SPEC, int BORDER>
+template <bool DIFF, bool SPEC, int BORDER, bool PERF>
 static const char* LaunchHitDistReconstruction(const PassArgs& a) {
     const ReblurCB& c = *(const ReblurCB*)a.constants;
     if (const char* err = CheckSupported(c))
@@ -564,17 +576,21 @@ static const char* LaunchHitDistReconstruction(const PassArgs& a) {
     if (k != a.planesNum || !P.decodedNR.ptr)
         return "REBLUR hit distance reconstruction: unexpected resource count or missing decoded normal/roughness cache";
     RowGrid g = GridForRows(c.gRectSizeMinusOne.x + 1, c.gRectSizeMinusOne.y + 1, TILE_X, TILE_Y, a.rowBegin, a.rowEnd);
-    hipLaunchKernelGGL((ReblurHitDistReconstructionKernel<DIFF, SPEC, BORDER>), g.grid, dim3(TILE_X * TILE_Y), 0, a.stream, c, P, RowRange{g.firstBlockY, g.rowBegin, g.rowEnd});
+    hipLaunchKernelGGL((ReblurHitDistReconstructionKernel<DIFF, SPEC, BORDER, PERF>), g.grid, dim3(TILE_X * TILE_Y), 0, a.stream, c, P, RowRange{g.firstBlockY, g.rowBegin, g.rowEnd});
     return nullptr;
 }
 
+// quality and performance ("REBLUR_Perf_*") permutations of one signal family
+#define REBLUR_SPATIAL_PASSES(PREFIX, NAME, D, S, P)                                                     \
+    {PREFIX NAME "_HitDistReconstruction.cs", LaunchHitDistReconstruction<D, S, 1, P>},                \
+    {PREFIX NAME "_HitDistReconstruction_5x5.cs", LaunchHitDistReconstruction<D, S, 2, P>},            \
+    {PREFIX NAME "_PrePass.cs", LaunchSpatial<PRE_BLUR, D, S, false, P>},                              \
+    {PREFIX NAME "_Blur.cs", LaunchSpatial<BLUR, D, S, false, P>},                                     \
+    {PREFIX NAME "_PostBlur.cs", LaunchSpatial<POST_BLUR, D, S, false, P>},                            \
+    {PREFIX NAME "_PostBlur_NoTemporalStabilization.cs", LaunchSpatial<POST_BLUR, D, S, true, P>},
 #define REBLUR_SPATIAL_FAMILY(NAME, D, S)                                                              \
-    {"REBLUR_" NAME "_HitDistReconstruction.cs", LaunchHitDistReconstruction<D, S, 1>},                \
-    {"REBLUR_" NAME "_HitDistReconstruction_5x5.cs", LaunchHitDistReconstruction<D, S, 2>},            \
-    {"REBLUR_" NAME "_PrePass.cs", LaunchSpatial<PRE_BLUR, D, S, false>},                              \
-    {"REBLUR_" NAME "_Blur.cs", LaunchSpatial<BLUR, D, S, false>},                                     \
-    {"REBLUR_" NAME "_PostBlur.cs", LaunchSpatial<POST_BLUR, D, S, false>},                            \
-    {"REBLUR_" NAME "_PostBlur_NoTemporalStabilization.cs", LaunchSpatial<POST_BLUR, D, S, true>},     \
+    REBLUR_SPATIAL_PASSES("REBLUR_", NAME, D, S, false)                                                \
+    REBLUR_SPATIAL_PASSES("REBLUR_Perf_", NAME, D, S, true)                                            \
     {"REBLUR_" NAME "_SplitScreen.cs", LaunchSplitScreen<D, S>},
 
 const PassEntry* GetReblurSpatialPasses(uint32_t& num) {

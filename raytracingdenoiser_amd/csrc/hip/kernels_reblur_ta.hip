@@ -30,7 +30,8 @@ struct TaPlanes {
     Plane outDiff, outSpec, outDiffFast, outSpecFast, outSpecHitDistForTracking, outData1, outData2;
 };
 
-template <bool DIFF, bool SPEC>
+// PERF = REBLUR_PERFORMANCE_MODE: no Catmull-Rom history fetches (REBLUR_USE_CATROM_FOR_*_MOTION_IN_TA = 0, REBLUR_Config.hlsli:196-201)
+template <bool DIFF, bool SPEC, bool PERF>
 __global__ __launch_bounds__(TILE_X* TILE_Y, 2) void ReblurTemporalAccumulationKernel(ReblurCB cArg, TaPlanes P, RowRange rr) {
     __shared__ float4 s_Normal_Roughness[BUF_Y * BUF_STRIDE];
     // The 832-byte constant block + ~20 planes need > 200 SGPRs (102 exist), which the compiler resolves by spilling scalars into
@@ -253,7 +254,7 @@ __global__ __launch_bounds__(TILE_X* TILE_Y, 2) void ReblurTemporalAccumulationK
     // 2x2 occlusion weights
     float4 smbOcclusionWeights = GetBilinearCustomWeights(smbBilinearFilter, F4(smbOcclusion0.z, smbOcclusion1.y, smbOcclusion2.y, smbOcclusion3.x));
     float3 occSum = smbOcclusion0 + smbOcclusion1 + smbOcclusion2 + smbOcclusion3;
-    bool smbAllowCatRom = (occSum.x + occSum.y + occSum.z) > 11.5f;
+    bool smbAllowCatRom = (occSum.x + occSum.y + occSum.z) > 11.5f && !PERF;
 
     float fbits = smbOcclusion0.z * 1.0f;
     fbits += smbOcclusion1.y * 2.0f;
@@ -482,7 +483,7 @@ __global__ __launch_bounds__(TILE_X* TILE_Y, 2) void ReblurTemporalAccumulationK
         vmbFootprintQuality = Sqrt01(vmbFootprintQuality);
         vmbSpecAccumSpeed *= Lerp(vmbFootprintQuality, 1.0f, 1.0f / (1.0f + vmbSpecAccumSpeed));
 
-        bool vmbAllowCatRom = Sum(vmbOcclusion) > 3.5f;
+        bool vmbAllowCatRom = Sum(vmbOcclusion) > 3.5f && !PERF;
         vmbAllowCatRom = vmbAllowCatRom && smbAllowCatRom;
 
         float curvatureAngleTan = pixelSize * Abs(curvature);
@@ -655,7 +656,7 @@ __global__ __launch_bounds__(TILE_X* TILE_Y, 2) void ReblurTemporalAccumulationK
     StoreData1<DIFF, SPEC>(P.outData1, px, py, diffAccumSpeed, specAccumSpeed);
 }
 
-template <bool DIFF, bool SPEC>
+template <bool DIFF, bool SPEC, bool PERF>
 static const char* LaunchTemporalAccumulation(const PassArgs& a) {
     const ReblurCB& c = *(const ReblurCB*)a.constants;
     if (c.gDiffCheckerboard != 2 || c.gSpecCheckerboard != 2)
@@ -710,15 +711,18 @@ static const char* LaunchTemporalAccumulation(const PassArgs& a) {
     }
 
     RowGrid g = GridForRows(c.gRectSizeMinusOne.x + 1, c.gRectSizeMinusOne.y + 1, TILE_X, TILE_Y, a.rowBegin, a.rowEnd);
-    hipLaunchKernelGGL((ReblurTemporalAccumulationKernel<DIFF, SPEC>), g.grid, dim3(TILE_X * TILE_Y), 0, a.stream, c, P, RowRange{g.firstBlockY, g.rowBegin, g.rowEnd});
+    hipLaunchKernelGGL((ReblurTemporalAccumulationKernel<DIFF, SPEC, PERF>), g.grid, dim3(TILE_X * TILE_Y), 0, a.stream, c, P, RowRange{g.firstBlockY, g.rowBegin, g.rowEnd});
     return nullptr;
 }
 
 const PassEntry* GetReblurTemporalAccumulationPasses(uint32_t& num) {
     static const PassEntry k[] = {
-        {"REBLUR_Diffuse_TemporalAccumulation.cs", LaunchTemporalAccumulation<true, false>},
-        {"REBLUR_Specular_TemporalAccumulation.cs", LaunchTemporalAccumulation<false, true>},
-        {"REBLUR_DiffuseSpecular_TemporalAccumulation.cs", LaunchTemporalAccumulation<true, true>},
+        {"REBLUR_Diffuse_TemporalAccumulation.cs", LaunchTemporalAccumulation<true, false, false>},
+        {"REBLUR_Specular_TemporalAccumulation.cs", LaunchTemporalAccumulation<false, true, false>},
+        {"REBLUR_DiffuseSpecular_TemporalAccumulation.cs", LaunchTemporalAccumulation<true, true, false>},
+        {"REBLUR_Perf_Diffuse_TemporalAccumulation.cs", LaunchTemporalAccumulation<true, false, true>},
+        {"REBLUR_Perf_Specular_TemporalAccumulation.cs", LaunchTemporalAccumulation<false, true, true>},
+        {"REBLUR_Perf_DiffuseSpecular_TemporalAccumulation.cs", LaunchTemporalAccumulation<true, true, true>},
     };
     num = sizeof(k) / sizeof(k[0]);
     return k;

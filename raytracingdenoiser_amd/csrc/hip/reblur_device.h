@@ -43,6 +43,10 @@ NRD_D float2 ToF2(nrdc::F2 v) { return F2(v.x, v.y); }
 // baked in as bit patterns (0x3f04505e, 0x3f590f90; tests/test_numerics.py re-derives them on the GPU).
 #define REBLUR_GAUSSIAN_WEIGHT_Z1 0.5168513059616089f
 #define REBLUR_GAUSSIAN_WEIGHT_Z05 0.8478937149047852f
+#define REBLUR_GAUSSIAN_WEIGHT_Z03 0.9423297643661499f // 0x3f713c86: the inner ring of g_Special6 (performance mode)
+// g_Special6 (reference Common.hlsli:170-179): 0.5 * sqrt(3) and 0.15 * sqrt(3) rounded to fp32
+__device__ __constant__ const float g_Special6[6][3] = {{-0.8660254f, -0.5f, 1.0f}, {0.0f, 1.0f, 1.0f}, {0.8660254f, -0.5f, 1.0f},
+    {0.0f, -0.3f, 0.3f}, {0.25980762f, 0.15f, 0.3f}, {-0.25980762f, 0.15f, 0.3f}};
 __device__ __constant__ const float g_Special8[8][3] = {{-1.0f, 0.0f, 1.0f}, {0.0f, 1.0f, 1.0f}, {1.0f, 0.0f, 1.0f}, {0.0f, -1.0f, 1.0f},
     {-0.25f * 1.41421356f, 0.25f * 1.41421356f, 0.5f}, {0.25f * 1.41421356f, 0.25f * 1.41421356f, 0.5f}, {0.25f * 1.41421356f, -0.25f * 1.41421356f, 0.5f},
     {-0.25f * 1.41421356f, -0.25f * 1.41421356f, 0.5f}};

@@ -107,9 +107,9 @@ def test_hip_exact_constant_division_and_gaussian_constants():
         t, out = torch.from_numpy(k).cuda(), torch.empty(n, device="cuda")
         assert lib.nrdHipEvalNumerics(op, t.data_ptr(), None, out.data_ptr(), n, stream) == 0
         assert np.array_equal(out.cpu().numpy().view(np.uint32), (k / np.float32(c)).view(np.uint32))
-    z = np.array([1.0, 0.5], dtype=np.float32)
-    t, out = torch.from_numpy(z).cuda(), torch.empty(2, device="cuda")
-    assert lib.nrdHipEvalNumerics(13, t.data_ptr(), None, out.data_ptr(), 2, stream) == 0
-    assert out.cpu().numpy().view(np.uint32).tolist() == [0x3F04505E, 0x3F590F90]
+    z = np.array([1.0, 0.5, 0.3], dtype=np.float32)  # offset.z of g_Special8 (1, 0.5) and g_Special6 (1, 0.3)
+    t, out = torch.from_numpy(z).cuda(), torch.empty(3, device="cuda")
+    assert lib.nrdHipEvalNumerics(13, t.data_ptr(), None, out.data_ptr(), 3, stream) == 0
+    assert out.cpu().numpy().view(np.uint32).tolist() == [0x3F04505E, 0x3F590F90, 0x3F713C86]
     ora = oracle_driver.load()
     assert np.float32(ora.oracle_exp2(float(np.float32(np.float32(-0.66) * np.float32(1.0) * np.float32(1.0)) * np.float32(1.44269504)))).view(np.uint32) == 0x3F04505E

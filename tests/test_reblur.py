@@ -132,3 +132,40 @@ def test_hip_matches_oracle_antifirefly_and_no_prepass():
     worst = parity.run_parity("REBLUR_DIFFUSE_SPECULAR", width=160, height=96, frames=4, verbose=True,
                               settings_overrides=dict(enableAntiFirefly=True, diffusePrepassBlurRadius=0.0, specularPrepassBlurRadius=0.0))
     assert worst <= parity.REL_TOL
+
+
+# ---------------------------------------------------------------------------------------------- performance mode
+def test_oracle_performance_mode_selects_perf_permutations_and_still_denoises():
+    """ReblurSettings::enablePerformanceMode -> "REBLUR_Perf_*" pipelines (reference Source/Reblur.cpp:148-190, REBLUR_Config.hlsli:196-238):
+    a cheaper filter, not a different estimator -- same mean, noise still drops, result differs from the quality mode."""
+    name = "REBLUR_DIFFUSE_SPECULAR"
+    seq = parity.generate_sequence(name, W, H, 8)
+    quality = _run_oracle(name, seq)
+    perf = _run_oracle(name, seq, overrides=dict(enablePerformanceMode=True))
+    shaders = [d.shader for d in perf.last_dispatches]
+    assert shaders[0] == "REBLUR_ClassifyTiles.cs" and all(s.startswith("REBLUR_Perf_DiffuseSpecular_") for s in shaders[1:]) and len(shaders) == 7
+    m = ~seq[-1]["is_sky"].numpy()
+    for rt, key in ((RT.OUT_DIFF_RADIANCE_HITDIST, "diff"), (RT.OUT_SPEC_RADIANCE_HITDIST, "spec")):
+        q, p, noisy = quality.output(rt)[m][:, 0], perf.output(rt)[m][:, 0], seq[-1][key].float().numpy()[m][:, 0]
+        assert not np.array_equal(q, p)
+        assert abs(p.mean() - noisy.mean()) < 0.03 * noisy.mean()
+        assert p.std() < 0.9 * noisy.std()
+        assert np.abs(p - q).mean() < 0.1 * q.mean()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", ["REBLUR_DIFFUSE_SPECULAR", "REBLUR_DIFFUSE", "REBLUR_SPECULAR"])
+def test_hip_matches_oracle_performance_mode(name):
+    worst = parity.run_parity(name, width=192, height=128, frames=6, verbose=True, settings_overrides=dict(enablePerformanceMode=True))
+    assert worst <= parity.REL_TOL
+
+
+@pytest.mark.gpu
+def test_hip_matches_oracle_performance_mode_options():
+    # Perf permutations of the optional passes: 3x3 hit-distance reconstruction, anti-firefly (radius 3), no temporal stabilisation, odd size
+    worst = parity.run_parity("REBLUR_DIFFUSE_SPECULAR", width=211, height=117, frames=4, verbose=True, extra_want=("holes",),
+                              settings_overrides=dict(enablePerformanceMode=True, hitDistanceReconstructionMode=1, enableAntiFirefly=True, maxStabilizedFrameNum=0))
+    assert worst <= parity.REL_TOL
+    worst = parity.run_parity("REBLUR_DIFFUSE_SPECULAR", width=160, height=96, frames=3, verbose=True, extra_want=("holes",),
+                              settings_overrides=dict(enablePerformanceMode=True, hitDistanceReconstructionMode=2, diffusePrepassBlurRadius=0.0, specularPrepassBlurRadius=0.0))
+    assert worst <= parity.REL_TOL

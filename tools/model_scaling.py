@@ -29,7 +29,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=16)
     ap.add_argument("--worlds", default="1,2,4,8")
     args = ap.parse_args()
-    name, (W, H), _ = bench.WORKLOADS[args.workload]
+    name, (W, H), _, _ = bench.WORKLOADS[args.workload]
     total = args.warmup + args.frames
     seq = parity.generate_sequence(name, W, H, total, device="cuda")
 
