@@ -69,11 +69,29 @@ RELAX_DS_BYTES_PER_PIXEL = {
 # performance mode (ReblurSettings::enablePerformanceMode): same planes per pass, "REBLUR_Perf_*" pipelines
 REBLUR_DS_PERF_BYTES_PER_PIXEL = {k.replace("REBLUR_DiffuseSpecular_", "REBLUR_Perf_DiffuseSpecular_"): v for k, v in REBLUR_DS_BYTES_PER_PIXEL.items()}
 
+# SIGMA_SHADOW (BASELINE.json configs[1], 1080p): SURVEY.md section 8a, 68 B/px in total; tiles passes are per 16x16 tile (negligible)
+SIGMA_SHADOW_BYTES_PER_PIXEL = {
+    "SIGMA_Shadow_ClassifyTiles.cs": 6,
+    "SIGMA_Copy.cs": 10,
+    "SIGMA_Shadow_Blur.cs": 13,
+    "SIGMA_Shadow_PostBlur.cs": 14,
+    "SIGMA_Shadow_TemporalStabilization.cs": 25,
+}
+SIGMA_TRANSLUCENCY_BYTES_PER_PIXEL = {
+    "SIGMA_ShadowTranslucency_ClassifyTiles.cs": 10,
+    "SIGMA_Copy.cs": 16,
+    "SIGMA_ShadowTranslucency_Blur.cs": 20,
+    "SIGMA_ShadowTranslucency_PostBlur.cs": 20,
+    "SIGMA_ShadowTranslucency_TemporalStabilization.cs": 34,
+}
+
 # workload -> (denoiser, default size, bytes/px per pass, denoiser-settings overrides (None = library defaults))
 WORKLOADS = {
     "reblur_ds": ("REBLUR_DIFFUSE_SPECULAR", (2560, 1440), REBLUR_DS_BYTES_PER_PIXEL, None),
     "reblur_ds_perf": ("REBLUR_DIFFUSE_SPECULAR", (2560, 1440), REBLUR_DS_PERF_BYTES_PER_PIXEL, {"enablePerformanceMode": True}),
     "relax_ds_sh": ("RELAX_DIFFUSE_SPECULAR_SH", (3840, 2160), RELAX_DS_SH_BYTES_PER_PIXEL, None),
+    "sigma_shadow": ("SIGMA_SHADOW", (1920, 1080), SIGMA_SHADOW_BYTES_PER_PIXEL, None),
+    "sigma_translucency": ("SIGMA_SHADOW_TRANSLUCENCY", (1920, 1080), SIGMA_TRANSLUCENCY_BYTES_PER_PIXEL, None),
     "relax_ds": ("RELAX_DIFFUSE_SPECULAR", (3840, 2160), RELAX_DS_BYTES_PER_PIXEL, None),
 }
 
