@@ -45,7 +45,8 @@ constexpr float REBLUR_ANTI_FIREFLY_SIGMA_SCALE = 2.0f;
 constexpr float REBLUR_ROUGHNESS_SENSITIVITY_IN_TA = NRD_ROUGHNESS_SENSITIVITY * 0.3f;
 constexpr float REBLUR_SAMPLES_PER_FRAME = 1.0f;
 constexpr float REBLUR_MAX_PERCENT_OF_LOBE_VOLUME_FOR_PRE_PASS = 0.3f;
-constexpr float REBLUR_COLOR_CLAMPING_SIGMA_SCALE = 2.0f;
+constexpr float REBLUR_COLOR_CLAMPING_SIGMA_SCALE = 2.0f;           // radiance signals
+constexpr float REBLUR_COLOR_CLAMPING_SIGMA_SCALE_OCCLUSION = 1.0f; // REBLUR_OCCLUSION (REBLUR_Config.hlsli:94-98)
 
 enum SpatialMode { PRE_BLUR = 0, BLUR = 1, POST_BLUR = 2 };
 
@@ -130,6 +131,28 @@ inline float4 ClampNegativeToZero(float4 v) {
     float3 rgb = _NRD_LinearToYCoCg(_NRD_YCoCgToLinear(v.xyz()));
     return float4(rgb, saturate(v.w));
 }
+// REBLUR_TYPE (REBLUR_Config.hlsli:100-105) and its overloaded helpers (REBLUR_Common.hlsli:148-170): in the *_OCCLUSION denoisers the
+// signal is the normalised hit distance alone, a float
+template <bool OCCLUSION> struct ReblurSignal;
+template <> struct ReblurSignal<false> {
+    typedef float4 type;
+    static float4 From(float4 texel) { return texel; }
+    static float4 WithHitDist(float4 s, float hitDist) { return float4(s.x, s.y, s.z, hitDist); }
+};
+template <> struct ReblurSignal<true> {
+    typedef float type;
+    static float From(float4 texel) { return texel.x; }
+    static float WithHitDist(float, float hitDist) { return hitDist; }
+};
+inline float ExtractHitDist(float4 v) { return v.w; }
+inline float ExtractHitDist(float v) { return v; }
+inline float GetLuma(float v) { return v; }
+inline float ChangeLuma(float, float newLuma) { return newLuma; }
+inline float ClampNegativeToZero(float v) { return saturate(v); } // ClampNegativeHitDistToZero
+inline float MixHistoryAndCurrent(const ReblurCB& c, float history, float current, float f, float roughness = 1.0f) {
+    return lerp(history, current, max(f, GetMinAllowedLimitForHitDistNonLinearAccumSpeed(c, roughness)));
+}
+
 inline float ComputeAntilag(const ReblurCB& c, float history, float avg, float sigma, float accumSpeed) { // REBLUR_ANTILAG_MODE = 2
     float h = history, a = avg;
     float s = sigma * c.gAntilagParams.x;

@@ -61,7 +61,10 @@ struct SpatialCtx { // what PrePass / Blur / PostBlur share per pixel
     bool perf;    // REBLUR_PERFORMANCE_MODE (REBLUR_Config.hlsli:196-238): 6 taps of g_Special6, screen-space sampling for specular too
 };
 
-float4 DiffuseSpatialFilter(const ReblurCB& c, SpatialMode mode, const SpatialCtx& s, float4 diff, const Tex& gIn_Diff, const Tex& gIn_ViewZ, const Tex& gIn_Normal_Roughness) {
+template <typename S> // S = REBLUR_TYPE: float4 (radiance + hit distance) or float (occlusion: hit distance only)
+S DiffuseSpatialFilter(const ReblurCB& c, SpatialMode mode, const SpatialCtx& s, S diff, const Tex& gIn_Diff, const Tex& gIn_ViewZ, const Tex& gIn_Normal_Roughness) {
+    constexpr bool OCC = sizeof(S) == sizeof(float);
+    typedef ReblurSignal<OCC> Sig;
     if (mode == PRE_BLUR && c.gDiffPrepassBlurRadius == 0.0f)
         return diff;
 
@@ -78,7 +81,7 @@ float4 DiffuseSpatialFilter(const ReblurCB& c, SpatialMode mode, const SpatialCt
 
     // Hit distance factor
     float hitDistScale = _REBLUR_GetHitDistanceNormalization(s.viewZ, c.gHitDistParams, 1.0f);
-    float hitDist = diff.w * hitDistScale;
+    float hitDist = ExtractHitDist(diff) * hitDistScale;
     float hitDistFactor = GetHitDistFactor(hitDist, s.frustumSize);
 
     // Blur radius
@@ -101,9 +104,9 @@ float4 DiffuseSpatialFilter(const ReblurCB& c, SpatialMode mode, const SpatialCt
     // Weights
     float2 geometryWeightParams = GetGeometryWeightParams(c.gPlaneDistSensitivity, s.frustumSize, s.Xv, s.Nv);
     float normalWeightParam = GetNormalWeightParam(diffNonLinearAccumSpeed, c.gLobeAngleFraction) / fractionScale;
-    float2 hitDistanceWeightParams = GetHitDistanceWeightParams(diff.w, diffNonLinearAccumSpeed);
+    float2 hitDistanceWeightParams = GetHitDistanceWeightParams(ExtractHitDist(diff), diffNonLinearAccumSpeed);
     float minHitDistWeight = c.gMinHitDistanceWeight * fractionScale;
-    if (mode != PRE_BLUR)
+    if (mode != PRE_BLUR && !OCC) // REBLUR_Common_DiffuseSpatialFilter.hlsli:76
         minHitDistWeight *= sqrtf(diffNonLinearAccumSpeed);
 
     // Screen-space sampling (REBLUR_USE_SCREEN_SPACE_SAMPLING_FOR_DIFFUSE = 1)
@@ -135,24 +138,27 @@ float4 DiffuseSpatialFilter(const ReblurCB& c, SpatialMode mode, const SpatialCt
         w *= CompareMaterials(s.materialID, materialIDs, c.gDiffMinMaterial) ? 1.0f : 0.0f;
         w *= ComputeWeight(angle, normalWeightParam, 0.0f);
 
-        float4 smp = gIn_Diff.SampleNearest(uvScaled);
-        smp = w == 0.0f ? float4(0.0f) : smp; // Denanify
+        S smp = Sig::From(gIn_Diff.SampleNearest(uvScaled));
+        smp = w == 0.0f ? S(0.0f) : smp; // Denanify
 
-        w *= lerp(minHitDistWeight, 1.0f, ComputeExponentialWeight(smp.w, hitDistanceWeightParams.x, hitDistanceWeightParams.y));
+        w *= lerp(minHitDistWeight, 1.0f, ComputeExponentialWeight(ExtractHitDist(smp), hitDistanceWeightParams.x, hitDistanceWeightParams.y));
         w *= GetGaussianWeight(offset.z);
 
         sum += w;
-        diff += smp * w;
+        diff = diff + smp * w;
     }
 
     float invSum = Math::PositiveRcp(sum);
-    diff *= invSum;
+    diff = diff * invSum;
     return diff;
 }
 
 // returns the filtered signal; for the pre-pass also produces hitDistForTracking (written only if the radius != 0)
-float4 SpecularSpatialFilter(const ReblurCB& c, SpatialMode mode, const SpatialCtx& s, float4 spec, const Tex& gIn_Spec, const Tex& gIn_ViewZ,
+template <typename S>
+S SpecularSpatialFilter(const ReblurCB& c, SpatialMode mode, const SpatialCtx& s, S spec, const Tex& gIn_Spec, const Tex& gIn_ViewZ,
     const Tex& gIn_Normal_Roughness, Tex* gOut_SpecHitDistForTracking) {
+    constexpr bool OCC = sizeof(S) == sizeof(float);
+    typedef ReblurSignal<OCC> Sig;
     float smc = GetSpecMagicCurve(s.roughness);
     if (mode == PRE_BLUR && c.gSpecPrepassBlurRadius == 0.0f)
         return spec;
@@ -176,7 +182,7 @@ float4 SpecularSpatialFilter(const ReblurCB& c, SpatialMode mode, const SpatialC
     float4 Dv = ImportanceSampling::GetSpecularDominantDirection(s.Nv, s.Vv, s.roughness);
     float NoD = fabsf(dot(s.Nv, Dv.xyz()));
     float hitDistScale = _REBLUR_GetHitDistanceNormalization(s.viewZ, c.gHitDistParams, s.roughness);
-    float hitDist = spec.w * hitDistScale;
+    float hitDist = ExtractHitDist(spec) * hitDistScale;
     float hitDistFactor = GetHitDistFactor(hitDist, s.frustumSize);
 
     // Blur radius
@@ -210,9 +216,9 @@ float4 SpecularSpatialFilter(const ReblurCB& c, SpatialMode mode, const SpatialC
     float2 geometryWeightParams = GetGeometryWeightParams(c.gPlaneDistSensitivity, s.frustumSize, s.Xv, s.Nv);
     float normalWeightParam = GetNormalWeightParam(specNonLinearAccumSpeed, c.gLobeAngleFraction, s.roughness) / fractionScale;
     float2 roughnessWeightParams = GetRoughnessWeightParams(s.roughness, roughnessFractionScaled);
-    float2 hitDistanceWeightParams = GetHitDistanceWeightParams(spec.w, specNonLinearAccumSpeed, s.roughness);
+    float2 hitDistanceWeightParams = GetHitDistanceWeightParams(ExtractHitDist(spec), specNonLinearAccumSpeed, s.roughness);
     float minHitDistWeight = c.gMinHitDistanceWeight * fractionScale * smc;
-    if (mode != PRE_BLUR)
+    if (mode != PRE_BLUR && !OCC) // REBLUR_Common_SpecularSpatialFilter.hlsli:98
         minHitDistWeight *= sqrtf(specNonLinearAccumSpeed);
 
     // Sampling set-up: screen space for the pre-pass (and for every pass in performance mode), world space along the (bent) lobe otherwise
@@ -260,12 +266,12 @@ float4 SpecularSpatialFilter(const ReblurCB& c, SpatialMode mode, const SpatialC
         w *= ComputeWeight(angle, normalWeightParam, 0.0f);
         w *= ComputeWeight(Ns.w, roughnessWeightParams.x, roughnessWeightParams.y);
 
-        float4 smp = gIn_Spec.SampleNearest(uvScaled);
-        smp = w == 0.0f ? float4(0.0f) : smp;
+        S smp = Sig::From(gIn_Spec.SampleNearest(uvScaled));
+        smp = w == 0.0f ? S(0.0f) : smp;
 
         if (mode == PRE_BLUR) {
             // stochastic min hit distance for tracking, ignoring zeros
-            float hs = smp.w * _REBLUR_GetHitDistanceNormalization(zs, c.gHitDistParams, Ns.w);
+            float hs = ExtractHitDist(smp) * _REBLUR_GetHitDistanceNormalization(zs, c.gHitDistParams, Ns.w);
             float d = length(Xvs - s.Xv) + NRD_EPS;
             float geometryWeight = w * saturate(hs / d);
             if (rng.GetFloat() < geometryWeight)
@@ -277,15 +283,15 @@ float4 SpecularSpatialFilter(const ReblurCB& c, SpatialMode mode, const SpatialC
             float t = hs / (d + hitDist);
             w *= lerp(saturate(t), 1.0f, Math::LinearStep(0.5f, 1.0f, s.roughness));
         }
-        w *= lerp(minHitDistWeight, 1.0f, ComputeExponentialWeight(smp.w, hitDistanceWeightParams.x, hitDistanceWeightParams.y));
+        w *= lerp(minHitDistWeight, 1.0f, ComputeExponentialWeight(ExtractHitDist(smp), hitDistanceWeightParams.x, hitDistanceWeightParams.y));
         w *= GetGaussianWeight(offset.z);
 
         sum += w;
-        spec += smp * w;
+        spec = spec + smp * w;
     }
 
     float invSum = Math::PositiveRcp(sum);
-    spec *= invSum;
+    spec = spec * invSum;
 
     if (mode == PRE_BLUR)
         gOut_SpecHitDistForTracking->Store(s.px, s.py, hitDistForTracking == NRD_INF ? 0.0f : hitDistForTracking);
@@ -343,20 +349,22 @@ void PrePass(const PassIO& io) {
                 continue;
             if (DIFF) {
                 float4 diff = gIn_Diff->Load(px, py);
-                diff = DiffuseSpatialFilter(c, PRE_BLUR, s, diff, *gIn_Diff, gIn_ViewZ, gIn_Normal_Roughness);
+                diff = DiffuseSpatialFilter<float4>(c, PRE_BLUR, s, diff, *gIn_Diff, gIn_ViewZ, gIn_Normal_Roughness);
                 gOut_Diff->Store(px, py, diff);
             }
             if (SPEC) {
                 float4 spec = gIn_Spec->Load(px, py);
-                spec = SpecularSpatialFilter(c, PRE_BLUR, s, spec, *gIn_Spec, gIn_ViewZ, gIn_Normal_Roughness, gOut_SpecHitDistForTracking);
+                spec = SpecularSpatialFilter<float4>(c, PRE_BLUR, s, spec, *gIn_Spec, gIn_ViewZ, gIn_Normal_Roughness, gOut_SpecHitDistForTracking);
                 gOut_Spec->Store(px, py, spec);
             }
         }
 }
 
 // ================================================================================================ Blur
-template <bool DIFF, bool SPEC, bool PERF>
+template <bool DIFF, bool SPEC, bool PERF, bool OCC>
 void Blur(const PassIO& io) {
+    typedef ReblurSignal<OCC> Sig;
+    typedef typename Sig::type S;
     const ReblurCB& c = *(const ReblurCB*)io.constants;
     Cursor cur(io);
     const Tex& gIn_Tiles = *cur.next();
@@ -383,21 +391,23 @@ void Blur(const PassIO& io) {
                 continue;
             s.data1 = UnpackData1(gIn_Data1.Load(px, py), DIFF);
             if (DIFF) {
-                float4 diff = gIn_Diff->Load(px, py);
-                diff = DiffuseSpatialFilter(c, BLUR, s, diff, *gIn_Diff, gIn_ViewZ, gIn_Normal_Roughness);
+                S diff = Sig::From(gIn_Diff->Load(px, py));
+                diff = DiffuseSpatialFilter<S>(c, BLUR, s, diff, *gIn_Diff, gIn_ViewZ, gIn_Normal_Roughness);
                 gOut_Diff->Store(px, py, diff);
             }
             if (SPEC) {
-                float4 spec = gIn_Spec->Load(px, py);
-                spec = SpecularSpatialFilter(c, BLUR, s, spec, *gIn_Spec, gIn_ViewZ, gIn_Normal_Roughness, nullptr);
+                S spec = Sig::From(gIn_Spec->Load(px, py));
+                spec = SpecularSpatialFilter<S>(c, BLUR, s, spec, *gIn_Spec, gIn_ViewZ, gIn_Normal_Roughness, nullptr);
                 gOut_Spec->Store(px, py, spec);
             }
         }
 }
 
 // ================================================================================================ PostBlur
-template <bool DIFF, bool SPEC, bool NO_TS, bool PERF>
+template <bool DIFF, bool SPEC, bool NO_TS, bool PERF, bool OCC>
 void PostBlur(const PassIO& io) {
+    typedef ReblurSignal<OCC> Sig;
+    typedef typename Sig::type S;
     const ReblurCB& c = *(const ReblurCB*)io.constants;
     Cursor cur(io);
     const Tex& gIn_Tiles = *cur.next();
@@ -410,8 +420,8 @@ void PostBlur(const PassIO& io) {
     Tex* gOut_Diff = cur.nextIf(DIFF);
     Tex* gOut_Spec = cur.nextIf(SPEC);
     Tex* gOut_InternalData = cur.nextIf(NO_TS);
-    Tex* gOut_DiffCopy = cur.nextIf(NO_TS && DIFF);
-    Tex* gOut_SpecCopy = cur.nextIf(NO_TS && SPEC);
+    Tex* gOut_DiffCopy = cur.nextIf(NO_TS && DIFF && !OCC); // no copy in the occlusion family (the output itself is next frame's history)
+    Tex* gOut_SpecCopy = cur.nextIf(NO_TS && SPEC && !OCC);
 
 #pragma omp parallel for schedule(dynamic, 4)
     for (int py = 0; py < (int)c.gRectSize.y; py++)
@@ -426,25 +436,27 @@ void PostBlur(const PassIO& io) {
                 gOut_InternalData->StoreUint(px, py, PackInternalData(s.data1.x + 1.0f, s.data1.y + 1.0f, s.materialID));
 
             if (DIFF) {
-                float4 diff = gIn_Diff->Load(px, py);
-                diff = DiffuseSpatialFilter(c, POST_BLUR, s, diff, *gIn_Diff, gIn_ViewZ, gIn_Normal_Roughness);
+                S diff = Sig::From(gIn_Diff->Load(px, py));
+                diff = DiffuseSpatialFilter<S>(c, POST_BLUR, s, diff, *gIn_Diff, gIn_ViewZ, gIn_Normal_Roughness);
                 gOut_Diff->Store(px, py, diff);
-                if (NO_TS)
+                if (NO_TS && !OCC)
                     gOut_DiffCopy->Store(px, py, diff);
             }
             if (SPEC) {
-                float4 spec = gIn_Spec->Load(px, py);
-                spec = SpecularSpatialFilter(c, POST_BLUR, s, spec, *gIn_Spec, gIn_ViewZ, gIn_Normal_Roughness, nullptr);
+                S spec = Sig::From(gIn_Spec->Load(px, py));
+                spec = SpecularSpatialFilter<S>(c, POST_BLUR, s, spec, *gIn_Spec, gIn_ViewZ, gIn_Normal_Roughness, nullptr);
                 gOut_Spec->Store(px, py, spec);
-                if (NO_TS)
+                if (NO_TS && !OCC)
                     gOut_SpecCopy->Store(px, py, spec);
             }
         }
 }
 
 // ================================================================================================ TemporalAccumulation
-template <bool DIFF, bool SPEC, bool PERF>
+template <bool DIFF, bool SPEC, bool PERF, bool OCC>
 void TemporalAccumulation(const PassIO& io) {
+    typedef ReblurSignal<OCC> Sig;
+    typedef typename Sig::type S;
     const ReblurCB& c = *(const ReblurCB*)io.constants;
     Cursor cur(io);
     const Tex& gIn_Tiles = *cur.next();
@@ -464,14 +476,14 @@ void TemporalAccumulation(const PassIO& io) {
     const Tex* gHistory_DiffFast = cur.nextIf(DIFF);
     const Tex* gHistory_SpecFast = cur.nextIf(SPEC);
     const Tex* gPrev_SpecHitDistForTracking = cur.nextIf(SPEC);
-    const Tex* gIn_SpecHitDistForTracking = cur.nextIf(SPEC);
+    const Tex* gIn_SpecHitDistForTracking = cur.nextIf(SPEC && !OCC); // written by the pre-pass, which the occlusion family does not have
     Tex* gOut_Diff = cur.nextIf(DIFF);
     Tex* gOut_Spec = cur.nextIf(SPEC);
     Tex* gOut_DiffFast = cur.nextIf(DIFF);
     Tex* gOut_SpecFast = cur.nextIf(SPEC);
     Tex* gOut_SpecHitDistForTracking = cur.nextIf(SPEC);
     Tex& gOut_Data1 = *cur.next();
-    Tex& gOut_Data2 = *cur.next();
+    Tex* gOut_Data2 = cur.nextIf(!OCC); // REBLUR_TemporalAccumulation.hlsli:822-824
 
     const int rw = c.gRectSizeMinusOne[0], rh = c.gRectSizeMinusOne[1];
 
@@ -490,7 +502,7 @@ void TemporalAccumulation(const PassIO& io) {
             auto sHitDistForTracking = [&](int x, int y) {
                 x = clamp(x, 0, rw);
                 y = clamp(y, 0, rh);
-                float hitDist = c.gSpecPrepassBlurRadius == 0.0f ? gIn_Spec->Load(x, y).w : gIn_SpecHitDistForTracking->Load(x, y).x;
+                float hitDist = (OCC || c.gSpecPrepassBlurRadius == 0.0f) ? ExtractHitDist(Sig::From(gIn_Spec->Load(x, y))) : gIn_SpecHitDistForTracking->Load(x, y).x;
                 return hitDist == 0.0f ? NRD_INF : hitDist;
             };
 
@@ -533,7 +545,7 @@ void TemporalAccumulation(const PassIO& io) {
 
                 hitDistForTracking = hitDistForTracking == NRD_INF ? 0.0f : hitDistForTracking;
                 hitDistNormalization = _REBLUR_GetHitDistanceNormalization(viewZ, c.gHitDistParams, roughness);
-                hitDistForTracking *= c.gSpecPrepassBlurRadius == 0.0f ? hitDistNormalization : 1.0f;
+                hitDistForTracking *= (OCC || c.gSpecPrepassBlurRadius == 0.0f) ? hitDistNormalization : 1.0f;
                 gOut_SpecHitDistForTracking->Store(px, py, hitDistForTracking);
             }
 
@@ -680,7 +692,7 @@ void TemporalAccumulation(const PassIO& io) {
                 smbSpecAccumSpeed *= lerp(specHistoryConfidence, 1.0f, 1.0f / (1.0f + smbSpecAccumSpeed));
                 smbSpecAccumSpeed = min(smbSpecAccumSpeed, c.gMaxAccumulatedFrameNum);
 
-                float4 spec = gIn_Spec->Load(px, py);
+                S spec = Sig::From(gIn_Spec->Load(px, py));
 
                 // Curvature estimation along predicted motion
                 {
@@ -893,7 +905,7 @@ void TemporalAccumulation(const PassIO& io) {
 
                 // Sample surface history
                 HistoryFilter smbFilter = MakeHistoryFilter(smbSamplePos, smbOcclusionWeights, smbAllowCatRom);
-                float4 smbSpecHistory = FetchHistoryColor(smbFilter, *gHistory_Spec);
+                S smbSpecHistory = Sig::From(FetchHistoryColor(smbFilter, *gHistory_Spec));
                 float smbSpecFastHistory = FetchHistoryBilinear(smbFilter, *gHistory_SpecFast).x;
 
                 // Surface motion confidence
@@ -901,7 +913,7 @@ void TemporalAccumulation(const PassIO& io) {
                 {
                     float a = atan(smbParallaxInPixelsMax * pixelSize / length(X));
                     float nonLinearAccumSpeed = 1.0f / (1.0f + smbSpecAccumSpeed);
-                    float h = lerp(smbSpecHistory.w, spec.w, nonLinearAccumSpeed) * hitDistNormalization;
+                    float h = lerp(ExtractHitDist(smbSpecHistory), ExtractHitDist(spec), nonLinearAccumSpeed) * hitDistNormalization;
 
                     float tana0 = ImportanceSampling::GetSpecularLobeTanHalfAngle(roughnessModified, NRD_MAX_PERCENT_OF_LOBE_VOLUME);
                     tana0 *= lerp(NoV, 1.0f, roughnessModified);
@@ -949,7 +961,7 @@ void TemporalAccumulation(const PassIO& io) {
 
                 // Sample virtual history
                 HistoryFilter vmbFilter = MakeHistoryFilter(saturate(vmbPixelUv) * c.gRectSizePrev, vmbOcclusionWeights, vmbAllowCatRom);
-                float4 vmbSpecHistory = FetchHistoryColor(vmbFilter, *gHistory_Spec);
+                S vmbSpecHistory = Sig::From(FetchHistoryColor(vmbFilter, *gHistory_Spec));
                 float vmbSpecFastHistory = FetchHistoryBilinear(vmbFilter, *gHistory_SpecFast).x;
 
                 smbSpecHistory = ClampNegativeToZero(smbSpecHistory);
@@ -959,22 +971,25 @@ void TemporalAccumulation(const PassIO& io) {
                 float smbSpecNonLinearAccumSpeed = 1.0f / (1.0f + smbSpecAccumSpeed);
                 float vmbSpecNonLinearAccumSpeed = 1.0f / (1.0f + vmbSpecAccumSpeed);
 
-                float4 smbSpec = MixHistoryAndCurrent(c, smbSpecHistory, spec, smbSpecNonLinearAccumSpeed, roughnessModified);
-                float4 vmbSpec = MixHistoryAndCurrent(c, vmbSpecHistory, spec, vmbSpecNonLinearAccumSpeed, roughnessModified);
-                float4 specResult = lerp(smbSpec, vmbSpec, virtualHistoryAmount);
+                S smbSpec = MixHistoryAndCurrent(c, smbSpecHistory, spec, smbSpecNonLinearAccumSpeed, roughnessModified);
+                S vmbSpec = MixHistoryAndCurrent(c, vmbSpecHistory, spec, vmbSpecNonLinearAccumSpeed, roughnessModified);
+                S specResult = lerp(smbSpec, vmbSpec, virtualHistoryAmount);
 
                 specAccumSpeed = lerp(smbSpecAccumSpeedBoosted, vmbSpecAccumSpeed, virtualHistoryAmount);
-                float4 specHistory = lerp(smbSpecHistory, vmbSpecHistory, virtualHistoryAmount);
+                S specHistory = lerp(smbSpecHistory, vmbSpecHistory, virtualHistoryAmount);
 
-                // Firefly suppressor
-                float specMaxRelativeIntensity = c.gFireflySuppressorMinRelativeScale + REBLUR_FIREFLY_SUPPRESSOR_MAX_RELATIVE_INTENSITY / (specAccumSpeed + 1.0f);
-                float specAntifireflyFactor = specAccumSpeed * c.gMaxBlurRadius * REBLUR_FIREFLY_SUPPRESSOR_RADIUS_SCALE;
-                specAntifireflyFactor /= 1.0f + specAntifireflyFactor;
+                // Firefly suppressor (not in the occlusion family: REBLUR_TemporalAccumulation.hlsli:757, 788)
+                float specMaxRelativeIntensity = 0.0f, specAntifireflyFactor = 0.0f;
+                if (!OCC) {
+                    specMaxRelativeIntensity = c.gFireflySuppressorMinRelativeScale + REBLUR_FIREFLY_SUPPRESSOR_MAX_RELATIVE_INTENSITY / (specAccumSpeed + 1.0f);
+                    specAntifireflyFactor = specAccumSpeed * c.gMaxBlurRadius * REBLUR_FIREFLY_SUPPRESSOR_RADIUS_SCALE;
+                    specAntifireflyFactor /= 1.0f + specAntifireflyFactor;
 
-                float specLumaResult = GetLuma(specResult);
-                float specLumaClamped = min(specLumaResult, GetLuma(specHistory) * specMaxRelativeIntensity);
-                specLumaClamped = lerp(specLumaResult, specLumaClamped, specAntifireflyFactor);
-                specResult = ChangeLuma(specResult, specLumaClamped);
+                    float specLumaResult = GetLuma(specResult);
+                    float specLumaClamped = min(specLumaResult, GetLuma(specHistory) * specMaxRelativeIntensity);
+                    specLumaClamped = lerp(specLumaResult, specLumaClamped, specAntifireflyFactor);
+                    specResult = ChangeLuma(specResult, specLumaClamped);
+                }
 
                 gOut_Spec->Store(px, py, specResult);
 
@@ -985,13 +1000,16 @@ void TemporalAccumulation(const PassIO& io) {
                 float vmbSpecFast = lerp(vmbSpecFastHistory, GetLuma(spec), vmbSpecFastNonLinearAccumSpeed);
                 float specFastResult = lerp(smbSpecFast, vmbSpecFast, virtualHistoryAmount);
 
-                float specFastClamped = min(specFastResult, GetLuma(specHistory) * specMaxRelativeIntensity * REBLUR_FIREFLY_SUPPRESSOR_FAST_RELATIVE_INTENSITY);
-                specFastResult = lerp(specFastResult, specFastClamped, specAntifireflyFactor);
+                if (!OCC) {
+                    float specFastClamped = min(specFastResult, GetLuma(specHistory) * specMaxRelativeIntensity * REBLUR_FIREFLY_SUPPRESSOR_FAST_RELATIVE_INTENSITY);
+                    specFastResult = lerp(specFastResult, specFastClamped, specAntifireflyFactor);
+                }
                 gOut_SpecFast->Store(px, py, specFastResult);
             }
 
             // Output: 4+4 occlusion bits, curvature, virtual history amount (R32_UINT, or the low byte only in R8_UINT)
-            gOut_Data2.StoreUint(px, py, PackData2(fbits, curvature, virtualHistoryAmount));
+            if (!OCC)
+                gOut_Data2->StoreUint(px, py, PackData2(fbits, curvature, virtualHistoryAmount));
 
             // ---------------------------------------------------------------------------------------------- diffuse
             if (DIFF) {
@@ -1001,33 +1019,38 @@ void TemporalAccumulation(const PassIO& io) {
                 diffAccumSpeed *= lerp(diffHistoryConfidence, 1.0f, 1.0f / (1.0f + diffAccumSpeed));
                 diffAccumSpeed = min(diffAccumSpeed, c.gMaxAccumulatedFrameNum);
 
-                float4 diff = gIn_Diff->Load(px, py);
+                S diff = Sig::From(gIn_Diff->Load(px, py));
 
                 HistoryFilter smbFilter = MakeHistoryFilter(smbSamplePos, smbOcclusionWeights, smbAllowCatRom);
-                float4 smbDiffHistory = FetchHistoryColor(smbFilter, *gHistory_Diff);
+                S smbDiffHistory = Sig::From(FetchHistoryColor(smbFilter, *gHistory_Diff));
                 float smbDiffFastHistory = FetchHistoryBilinear(smbFilter, *gHistory_DiffFast).x;
                 smbDiffHistory = ClampNegativeToZero(smbDiffHistory);
 
                 float diffNonLinearAccumSpeed = 1.0f / (1.0f + diffAccumSpeed);
-                float4 diffResult = MixHistoryAndCurrent(c, smbDiffHistory, diff, diffNonLinearAccumSpeed);
+                S diffResult = MixHistoryAndCurrent(c, smbDiffHistory, diff, diffNonLinearAccumSpeed);
 
-                // Firefly suppressor
-                float diffMaxRelativeIntensity = c.gFireflySuppressorMinRelativeScale + REBLUR_FIREFLY_SUPPRESSOR_MAX_RELATIVE_INTENSITY / (diffAccumSpeed + 1.0f);
-                float diffAntifireflyFactor = diffAccumSpeed * c.gMaxBlurRadius * REBLUR_FIREFLY_SUPPRESSOR_RADIUS_SCALE;
-                diffAntifireflyFactor /= 1.0f + diffAntifireflyFactor;
+                // Firefly suppressor (not in the occlusion family: REBLUR_TemporalAccumulation.hlsli:889, 918)
+                float diffMaxRelativeIntensity = 0.0f, diffAntifireflyFactor = 0.0f;
+                if (!OCC) {
+                    diffMaxRelativeIntensity = c.gFireflySuppressorMinRelativeScale + REBLUR_FIREFLY_SUPPRESSOR_MAX_RELATIVE_INTENSITY / (diffAccumSpeed + 1.0f);
+                    diffAntifireflyFactor = diffAccumSpeed * c.gMaxBlurRadius * REBLUR_FIREFLY_SUPPRESSOR_RADIUS_SCALE;
+                    diffAntifireflyFactor /= 1.0f + diffAntifireflyFactor;
 
-                float diffLumaResult = GetLuma(diffResult);
-                float diffLumaClamped = min(diffLumaResult, GetLuma(smbDiffHistory) * diffMaxRelativeIntensity);
-                diffLumaClamped = lerp(diffLumaResult, diffLumaClamped, diffAntifireflyFactor);
-                diffResult = ChangeLuma(diffResult, diffLumaClamped);
+                    float diffLumaResult = GetLuma(diffResult);
+                    float diffLumaClamped = min(diffLumaResult, GetLuma(smbDiffHistory) * diffMaxRelativeIntensity);
+                    diffLumaClamped = lerp(diffLumaResult, diffLumaClamped, diffAntifireflyFactor);
+                    diffResult = ChangeLuma(diffResult, diffLumaClamped);
+                }
                 gOut_Diff->Store(px, py, diffResult);
 
                 // Fast history
                 float diffFastAccumSpeed = min(diffAccumSpeed, c.gMaxFastAccumulatedFrameNum);
                 float diffFastNonLinearAccumSpeed = 1.0f / (1.0f + diffFastAccumSpeed);
                 float diffFastResult = lerp(smbDiffFastHistory, GetLuma(diff), diffFastNonLinearAccumSpeed);
-                float diffFastClamped = min(diffFastResult, GetLuma(smbDiffHistory) * diffMaxRelativeIntensity * REBLUR_FIREFLY_SUPPRESSOR_FAST_RELATIVE_INTENSITY);
-                diffFastResult = lerp(diffFastResult, diffFastClamped, diffAntifireflyFactor);
+                if (!OCC) {
+                    float diffFastClamped = min(diffFastResult, GetLuma(smbDiffHistory) * diffMaxRelativeIntensity * REBLUR_FIREFLY_SUPPRESSOR_FAST_RELATIVE_INTENSITY);
+                    diffFastResult = lerp(diffFastResult, diffFastClamped, diffAntifireflyFactor);
+                }
                 gOut_DiffFast->Store(px, py, diffFastResult);
             }
 
@@ -1038,9 +1061,12 @@ void TemporalAccumulation(const PassIO& io) {
 
 // ================================================================================================ HistoryFix
 // one signal (diffuse or specular) of the history-fix pass; returns the fixed signal and writes the fast history
-float4 HistoryFixSignal(const ReblurCB& c, bool isSpec, bool perf, int px, int py, float4 sig, float frameNum, float strideBase, float roughness, float viewZ, float materialID,
+template <typename S>
+S HistoryFixSignal(const ReblurCB& c, bool isSpec, bool perf, int px, int py, S sig, float frameNum, float strideBase, float roughness, float viewZ, float materialID,
     float3 N, float3 Nv, float3 Xv, float2 pixelUv, float frustumSize, const Tex& gIn_ViewZ, const Tex& gIn_Normal_Roughness, const Tex& gIn_Data1, bool hasDiff,
     const Tex& gIn_Signal, const Tex& gIn_Fast, Tex& gOut_Fast) {
+    constexpr bool OCC = sizeof(S) == sizeof(float);
+    typedef ReblurSignal<OCC> Sig;
     const int rw = c.gRectSizeMinusOne[0], rh = c.gRectSizeMinusOne[1];
     float smc = GetSpecMagicCurve(roughness);
 
@@ -1061,14 +1087,14 @@ float4 HistoryFixSignal(const ReblurCB& c, bool isSpec, bool perf, int px, int p
         float2 relaxedRoughnessWeightParams = GetRelaxedRoughnessWeightParams(roughness * roughness, sqrtf(c.gRoughnessFraction));
 
         float hitDistScale = _REBLUR_GetHitDistanceNormalization(viewZ, c.gHitDistParams, r);
-        float hitDist = sig.w * hitDistScale;
+        float hitDist = ExtractHitDist(sig) * hitDistScale;
         float hitDistFactor = GetHitDistFactor(hitDist, frustumSize);
         float2 hitDistanceWeightParams = GetHitDistanceWeightParams(hitDistFactor, nonLinearAccumSpeed, r);
 
         float sumw = 1.0f + frameNum;
         if (perf) // REBLUR_HistoryFix.hlsli:88-90 / 292-294
             sumw = 1.0f + 1.0f / (1.0f + c.gMaxAccumulatedFrameNum) - nonLinearAccumSpeed;
-        sig *= sumw;
+        sig = sig * sumw;
 
         for (int j = -2; j <= 2; j++)
             for (int i = -2; i <= 2; i++) {
@@ -1097,10 +1123,10 @@ float4 HistoryFixSignal(const ReblurCB& c, bool isSpec, bool perf, int px, int p
                     w *= 1.0f + (isSpec ? d1.y : d1.x);
                 }
 
-                float4 smp = gIn_Signal.Load(sx, sy);
-                smp = w == 0.0f ? float4(0.0f) : smp;
+                S smp = Sig::From(gIn_Signal.Load(sx, sy));
+                smp = w == 0.0f ? S(0.0f) : smp;
 
-                float hs = smp.w * hitDistScale;
+                float hs = ExtractHitDist(smp) * hitDistScale;
                 float hsFactor = GetHitDistFactor(hs, frustumSize);
                 w *= ComputeExponentialWeight(hsFactor, hitDistanceWeightParams.x, hitDistanceWeightParams.y);
 
@@ -1111,11 +1137,11 @@ float4 HistoryFixSignal(const ReblurCB& c, bool isSpec, bool perf, int px, int p
                 }
 
                 sumw += w;
-                sig += smp * w;
+                sig = sig + smp * w;
             }
 
         sumw = Math::PositiveRcp(sumw);
-        sig *= sumw;
+        sig = sig * sumw;
     }
 
     // Local variance of the fast history over 5x5 (clamped reads = the shader's LDS preload)
@@ -1140,8 +1166,8 @@ float4 HistoryFixSignal(const ReblurCB& c, bool isSpec, bool perf, int px, int p
 
     float luma = GetLuma(sig);
 
-    // Anti-firefly: 9x9 minus the central 3x3
-    if (c.gAntiFirefly != 0.0f) {
+    // Anti-firefly: 9x9 minus the central 3x3 (REBLUR_USE_ANTIFIREFLY = 0 in the occlusion family)
+    if (c.gAntiFirefly != 0.0f && !OCC) {
         float am1 = 0.0f, am2 = 0.0f;
         const int R = perf ? 3 : REBLUR_ANTI_FIREFLY_FILTER_RADIUS; // REBLUR_Config.hlsli:236-237
         for (int j = -R; j <= R; j++)
@@ -1162,15 +1188,17 @@ float4 HistoryFixSignal(const ReblurCB& c, bool isSpec, bool perf, int px, int p
     // Fast-history clamping
     m1 /= 25.0f;
     m2 /= 25.0f;
-    float sigma = sqrtf(fabsf(m2 - m1 * m1)) * REBLUR_COLOR_CLAMPING_SIGMA_SCALE;
+    float sigma = sqrtf(fabsf(m2 - m1 * m1)) * (OCC ? REBLUR_COLOR_CLAMPING_SIGMA_SCALE_OCCLUSION : REBLUR_COLOR_CLAMPING_SIGMA_SCALE);
     float lumaClamped = clamp(luma, m1 - sigma, m1 + sigma);
     luma = lerp(lumaClamped, luma, 1.0f / (1.0f + (c.gMaxFastAccumulatedFrameNum < c.gMaxAccumulatedFrameNum ? 1.0f : 0.0f) * frameNum * 2.0f));
 
     return ChangeLuma(sig, luma);
 }
 
-template <bool DIFF, bool SPEC, bool PERF>
+template <bool DIFF, bool SPEC, bool PERF, bool OCC>
 void HistoryFix(const PassIO& io) {
+    typedef ReblurSignal<OCC> Sig;
+    typedef typename Sig::type S;
     const ReblurCB& c = *(const ReblurCB*)io.constants;
     Cursor cur(io);
     const Tex& gIn_Tiles = *cur.next();
@@ -1209,14 +1237,12 @@ void HistoryFix(const PassIO& io) {
             float2 stride = c.gHistoryFixBasePixelStride / (2.0f + frameNum);
 
             if (DIFF) {
-                float4 diff = HistoryFixSignal(c, false, PERF, px, py, gIn_Diff->Load(px, py), frameNum.x, stride.x, roughness, viewZ, materialID, N, Nv, Xv, pixelUv, frustumSize,
+                S diff = HistoryFixSignal<S>(c, false, PERF, px, py, Sig::From(gIn_Diff->Load(px, py)), frameNum.x, stride.x, roughness, viewZ, materialID, N, Nv, Xv, pixelUv, frustumSize,
                     gIn_ViewZ, gIn_Normal_Roughness, gIn_Data1, DIFF, *gIn_Diff, *gIn_DiffFast, *gOut_DiffFast);
-                if (getenv("ORACLE_DEBUG_PIXEL") && px == atoi(getenv("ORACLE_DEBUG_PIXEL")) && py == atoi(strchr(getenv("ORACLE_DEBUG_PIXEL"), ',') + 1))
-                    fprintf(stderr, "HF diff (%d,%d): %.9g %.9g %.9g %.9g framenum %g\n", px, py, diff.x, diff.y, diff.z, diff.w, frameNum.x);
                 gOut_Diff->Store(px, py, diff);
             }
             if (SPEC) {
-                float4 spec = HistoryFixSignal(c, true, PERF, px, py, gIn_Spec->Load(px, py), frameNum.y, stride.y, roughness, viewZ, materialID, N, Nv, Xv, pixelUv, frustumSize,
+                S spec = HistoryFixSignal<S>(c, true, PERF, px, py, Sig::From(gIn_Spec->Load(px, py)), frameNum.y, stride.y, roughness, viewZ, materialID, N, Nv, Xv, pixelUv, frustumSize,
                     gIn_ViewZ, gIn_Normal_Roughness, gIn_Data1, DIFF, *gIn_Spec, *gIn_SpecFast, *gOut_SpecFast);
                 gOut_Spec->Store(px, py, spec);
             }
@@ -1423,8 +1449,9 @@ void TemporalStabilization(const PassIO& io) {
 // ================================================================================================ HitDistReconstruction
 // reference Shaders/Include/REBLUR_HitDistReconstruction.hlsli:10-160 (REBLUR_USE_DECOMPRESSED_HIT_DIST_IN_RECONSTRUCTION = 0,
 // non-performance mode). BORDER = 1 -> 3x3, 2 -> 5x5 window; the window is read at rect-clamped coordinates like the LDS preload.
-template <bool DIFF, bool SPEC, int BORDER, bool PERF>
+template <bool DIFF, bool SPEC, int BORDER, bool PERF, bool OCC>
 void HitDistReconstruction(const PassIO& io) {
+    typedef ReblurSignal<OCC> Sig;
     const ReblurCB& c = *(const ReblurCB*)io.constants;
     Cursor cur(io);
     const Tex& gIn_Tiles = *cur.next();
@@ -1446,7 +1473,7 @@ void HitDistReconstruction(const PassIO& io) {
             auto NormalRoughness = [&](int x, int y) { return NRD_FrontEnd_UnpackNormalAndRoughness(gIn_Normal_Roughness.Load(ox + clamp(x, 0, rw), oy + clamp(y, 0, rh))); };
             auto HitDist = [&](int x, int y) {
                 x = clamp(x, 0, rw), y = clamp(y, 0, rh);
-                return float2(DIFF ? gIn_Diff->Load(x, y).w : 0.0f, SPEC ? gIn_Spec->Load(x, y).w : 0.0f);
+                return float2(DIFF ? ExtractHitDist(Sig::From(gIn_Diff->Load(x, y))) : 0.0f, SPEC ? ExtractHitDist(Sig::From(gIn_Spec->Load(x, y))) : 0.0f);
             };
             const float centerZ = ViewZ(px, py);
             if (centerZ > c.gDenoisingRange)
@@ -1506,9 +1533,9 @@ void HitDistReconstruction(const PassIO& io) {
             center = center / max(sum, float2(NRD_EPS));
 
             if (DIFF)
-                gOut_Diff->Store(px, py, float4(gIn_Diff->Load(px, py).xyz(), center.x));
+                gOut_Diff->Store(px, py, Sig::WithHitDist(Sig::From(gIn_Diff->Load(px, py)), center.x));
             if (SPEC)
-                gOut_Spec->Store(px, py, float4(gIn_Spec->Load(px, py).xyz(), center.y));
+                gOut_Spec->Store(px, py, Sig::WithHitDist(Sig::From(gIn_Spec->Load(px, py)), center.y));
         }
 }
 
@@ -1541,15 +1568,22 @@ void SplitScreen(const PassIO& io) {
 
 // quality and performance ("REBLUR_Perf_*", REBLUR_PERFORMANCE_MODE) permutations of one signal family
 #define REBLUR_PASSES(PREFIX, NAME, D, S, P)                                                            \
-    {PREFIX NAME "_HitDistReconstruction.cs", HitDistReconstruction<D, S, 1, P>},                      \
-    {PREFIX NAME "_HitDistReconstruction_5x5.cs", HitDistReconstruction<D, S, 2, P>},                  \
+    {PREFIX NAME "_HitDistReconstruction.cs", HitDistReconstruction<D, S, 1, P, false>},               \
+    {PREFIX NAME "_HitDistReconstruction_5x5.cs", HitDistReconstruction<D, S, 2, P, false>},           \
     {PREFIX NAME "_PrePass.cs", PrePass<D, S, P>},                                                     \
-    {PREFIX NAME "_TemporalAccumulation.cs", TemporalAccumulation<D, S, P>},                           \
-    {PREFIX NAME "_HistoryFix.cs", HistoryFix<D, S, P>},                                               \
-    {PREFIX NAME "_Blur.cs", Blur<D, S, P>},                                                           \
-    {PREFIX NAME "_PostBlur.cs", PostBlur<D, S, false, P>},                                            \
-    {PREFIX NAME "_PostBlur_NoTemporalStabilization.cs", PostBlur<D, S, true, P>},                     \
-    {PREFIX NAME "_TemporalStabilization.cs", TemporalStabilization<D, S, P>},
+    {PREFIX NAME "_TemporalAccumulation.cs", TemporalAccumulation<D, S, P, false>},                    \
+    {PREFIX NAME "_HistoryFix.cs", HistoryFix<D, S, P, false>},                                        \
+    {PREFIX NAME "_Blur.cs", Blur<D, S, P, false>},                                                    \
+    {PREFIX NAME "_PostBlur.cs", PostBlur<D, S, false, P, false>},                                     \
+    {PREFIX NAME "_PostBlur_NoTemporalStabilization.cs", PostBlur<D, S, true, P, false>},              \
+    {PREFIX NAME "_TemporalStabilization.cs", TemporalStabilization<D, S, P>},                         \
+    /* occlusion family (REBLUR_TYPE = float, R16_UNORM planes): no pre-pass, no temporal stabilisation */ \
+    {PREFIX NAME "Occlusion_HitDistReconstruction.cs", HitDistReconstruction<D, S, 1, P, true>},       \
+    {PREFIX NAME "Occlusion_HitDistReconstruction_5x5.cs", HitDistReconstruction<D, S, 2, P, true>},   \
+    {PREFIX NAME "Occlusion_TemporalAccumulation.cs", TemporalAccumulation<D, S, P, true>},            \
+    {PREFIX NAME "Occlusion_HistoryFix.cs", HistoryFix<D, S, P, true>},                                \
+    {PREFIX NAME "Occlusion_Blur.cs", Blur<D, S, P, true>},                                            \
+    {PREFIX NAME "Occlusion_PostBlur_NoTemporalStabilization.cs", PostBlur<D, S, true, P, true>},
 #define REBLUR_FAMILY(NAME, D, S)                                                                      \
     REBLUR_PASSES("REBLUR_", NAME, D, S, false)                                                        \
     REBLUR_PASSES("REBLUR_Perf_", NAME, D, S, true)                                                    \

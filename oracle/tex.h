@@ -19,6 +19,7 @@ enum Fmt : uint32_t {
     FMT_R8_UINT = 2,
     FMT_RG8_UNORM = 4,
     FMT_RGBA8_UNORM = 8,
+    FMT_R16_UNORM = 13,
     FMT_R16_UINT = 15,
     FMT_R16_SFLOAT = 17,
     FMT_RGBA16_SFLOAT = 27,
@@ -97,6 +98,8 @@ struct Tex {
             }
             case FMT_R16_SFLOAT:
                 return float4(f16tof32(((const uint16_t*)r)[x]), 0, 0, 0);
+            case FMT_R16_UNORM:
+                return float4(float(((const uint16_t*)r)[x]) / 65535.0f, 0, 0, 0);
             case FMT_RGBA16_SFLOAT: {
                 const uint16_t* h = (const uint16_t*)r + x * 4;
                 return float4(f16tof32(h[0]), f16tof32(h[1]), f16tof32(h[2]), f16tof32(h[3]));
@@ -168,6 +171,9 @@ struct Tex {
             }
             case FMT_R16_SFLOAT:
                 ((uint16_t*)r)[x] = (uint16_t)f32tof16(v.x);
+                break;
+            case FMT_R16_UNORM:
+                ((uint16_t*)r)[x] = (uint16_t)ToUnorm(v.x, 65535.0f);
                 break;
             case FMT_RGBA16_SFLOAT: {
                 uint16_t* h = (uint16_t*)r + x * 4;

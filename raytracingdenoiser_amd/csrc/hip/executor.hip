@@ -59,6 +59,7 @@ nrd::Format ExpectedUserFormat(nrd::ResourceType t, bool translucentShadow) {
         case R::OUT_DIFF_RADIANCE_HITDIST: case R::OUT_SPEC_RADIANCE_HITDIST: return F::RGBA16_SFLOAT;
         case R::IN_DIFF_SH0: case R::IN_DIFF_SH1: case R::IN_SPEC_SH0: case R::IN_SPEC_SH1: return F::RGBA16_SFLOAT;
         case R::OUT_DIFF_SH0: case R::OUT_DIFF_SH1: case R::OUT_SPEC_SH0: case R::OUT_SPEC_SH1: return F::RGBA16_SFLOAT;
+        case R::IN_DIFF_HITDIST: case R::IN_SPEC_HITDIST: case R::OUT_DIFF_HITDIST: case R::OUT_SPEC_HITDIST: return F::R16_UNORM; // REBLUR occlusion family
         case R::IN_PENUMBRA: return F::R16_SFLOAT;
         case R::IN_TRANSLUCENCY: return F::RGBA8_UNORM;
         case R::OUT_SHADOW_TRANSLUCENCY: return translucentShadow ? F::RGBA8_UNORM : F::R8_UNORM;
@@ -549,7 +550,7 @@ void LaunchEvalNumerics(uint32_t op, const float* in1, const float* in2, float* 
 }
 
 extern "C" __attribute__((visibility("default"))) uint32_t nrdHipEvalNumerics(uint32_t op, const float* in1, const float* in2, float* out, uint32_t count, void* hipStream) {
-    if (!in1 || !out || op > 13)
+    if (!in1 || !out || op > 14)
         return (uint32_t)nrd::Result::INVALID_ARGUMENT;
     if (count)
         nrdhip::LaunchEvalNumerics(op, in1, in2, out, count, (hipStream_t)hipStream);

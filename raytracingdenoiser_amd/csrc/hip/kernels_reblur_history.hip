@@ -57,9 +57,11 @@ struct HfPixel {
 };
 
 // PERF = REBLUR_PERFORMANCE_MODE (reference REBLUR_HistoryFix.hlsli:88-90 / 139-141 / 292-294 / 338-340, REBLUR_Config.hlsli:236-237)
-template <bool IS_SPEC, bool DIFF, bool SPEC, bool PERF>
-NRD_D float4 HistoryFixSignal(const ReblurCB& c, const HfPlanes& P, const HfPixel& s, float4 sig, float frameNum, float strideBase, const Plane& gIn_Signal, const Plane& gIn_Fast,
-    const Plane& gOut_Fast, const float* s_Luma) {
+template <bool IS_SPEC, bool DIFF, bool SPEC, bool PERF, bool OCC>
+NRD_D typename ReblurSignal<OCC>::type HistoryFixSignal(const ReblurCB& c, const HfPlanes& P, const HfPixel& s, typename ReblurSignal<OCC>::type sig, float frameNum, float strideBase,
+    const Plane& gIn_Signal, const Plane& gIn_Fast, const Plane& gOut_Fast, const float* s_Luma) {
+    typedef ReblurSignal<OCC> Sig;
+    typedef typename Sig::type S;
     const int rw = c.gRectSizeMinusOne.x, rh = c.gRectSizeMinusOne.y;
     const float smc = GetSpecMagicCurve(s.roughness);
 
@@ -80,7 +82,7 @@ NRD_D float4 HistoryFixSignal(const ReblurCB& c, const HfPlanes& P, const HfPixe
         float2 relaxedRoughnessWeightParams = GetRelaxedRoughnessWeightParams(s.roughness * s.roughness, Sqrt(c.gRoughnessFraction));
 
         float hitDistScale = GetHitDistanceNormalization(s.viewZ, hitDistParams, r);
-        float hitDist = sig.w * hitDistScale;
+        float hitDist = ExtractHitDist(sig) * hitDistScale;
         float hitDistFactor = GetHitDistFactor(hitDist, s.frustumSize);
         float2 hitDistanceWeightParams = GetHitDistanceWeightParams(hitDistFactor, nonLinearAccumSpeed, r);
 
@@ -116,10 +118,10 @@ NRD_D float4 HistoryFixSignal(const ReblurCB& c, const HfPlanes& P, const HfPixe
                     w *= 1.0f + (IS_SPEC ? d1.y : d1.x);
                 }
 
-                float4 smp = LoadRGBA16F(gIn_Signal, sx, sy);
-                smp = w == 0.0f ? F4(0.0f) : smp;
+                S smp = Sig::Load(gIn_Signal, sx, sy);
+                smp = w == 0.0f ? Sig::Zero() : smp;
 
-                float hs = smp.w * hitDistScale;
+                float hs = ExtractHitDist(smp) * hitDistScale;
                 float hsFactor = GetHitDistFactor(hs, s.frustumSize);
                 w *= ComputeExponentialWeight(hsFactor, hitDistanceWeightParams.x, hitDistanceWeightParams.y);
 
@@ -146,7 +148,7 @@ NRD_D float4 HistoryFixSignal(const ReblurCB& c, const HfPlanes& P, const HfPixe
     if (IS_SPEC)
         f = Lerp(1.0f, f, smc);
     center = Lerp(GetLuma(sig), center, f);
-    StoreR16F(gOut_Fast, s.px, s.py, center);
+    Sig::StoreFast(gOut_Fast, s.px, s.py, center);
 
 #pragma unroll
     for (int j = 0; j <= 4; j++) {
@@ -162,8 +164,8 @@ NRD_D float4 HistoryFixSignal(const ReblurCB& c, const HfPlanes& P, const HfPixe
 
     float luma = GetLuma(sig);
 
-    // Anti-firefly: 9x9 minus the central 3x3 (off by default)
-    if (c.gAntiFirefly != 0.0f) {
+    // Anti-firefly: 9x9 minus the central 3x3 (off by default; compiled out in the occlusion family, REBLUR_USE_ANTIFIREFLY = 0)
+    if (!OCC && c.gAntiFirefly != 0.0f) {
         float am1 = 0.0f, am2 = 0.0f;
         const int R = PERF ? 3 : REBLUR_ANTI_FIREFLY_FILTER_RADIUS;
         for (int j = -R; j <= R; j++)
@@ -183,15 +185,17 @@ NRD_D float4 HistoryFixSignal(const ReblurCB& c, const HfPlanes& P, const HfPixe
 
     m1 /= 25.0f;
     m2 /= 25.0f;
-    float sigma = Sqrt(Abs(m2 - m1 * m1)) * REBLUR_COLOR_CLAMPING_SIGMA_SCALE;
+    float sigma = Sqrt(Abs(m2 - m1 * m1)) * (OCC ? REBLUR_COLOR_CLAMPING_SIGMA_SCALE_OCCLUSION : REBLUR_COLOR_CLAMPING_SIGMA_SCALE);
     float lumaClamped = Clamp(luma, m1 - sigma, m1 + sigma);
     luma = Lerp(lumaClamped, luma, 1.0f / (1.0f + (c.gMaxFastAccumulatedFrameNum < c.gMaxAccumulatedFrameNum ? 1.0f : 0.0f) * frameNum * 2.0f));
 
     return ChangeLuma(sig, luma);
 }
 
-template <bool DIFF, bool SPEC, bool PERF>
+template <bool DIFF, bool SPEC, bool PERF, bool OCC>
 __global__ __launch_bounds__(TILE_X* TILE_Y) void ReblurHistoryFixKernel(ReblurCB c, HfPlanes P, RowRange rr) {
+    typedef ReblurSignal<OCC> Sig;
+    typedef typename Sig::type S;
     __shared__ float s_DiffLuma[DIFF ? hf::BUF_Y * hf::BUF_STRIDE : 1];
     __shared__ float s_SpecLuma[SPEC ? hf::BUF_Y * hf::BUF_STRIDE : 1];
 
@@ -208,9 +212,9 @@ __global__ __launch_bounds__(TILE_X* TILE_Y) void ReblurHistoryFixKernel(ReblurC
             int lx = i % hf::BUF_X, ly = i / hf::BUF_X;
             int gx = ClampI(baseX + lx, 0, rw), gy = ClampI(baseY + ly, 0, rh);
             if (DIFF)
-                s_DiffLuma[ly * hf::BUF_STRIDE + lx] = LoadR16F(P.inDiffFast, gx, gy);
+                s_DiffLuma[ly * hf::BUF_STRIDE + lx] = Sig::LoadFast(P.inDiffFast, gx, gy);
             if (SPEC)
-                s_SpecLuma[ly * hf::BUF_STRIDE + lx] = LoadR16F(P.inSpecFast, gx, gy);
+                s_SpecLuma[ly * hf::BUF_STRIDE + lx] = Sig::LoadFast(P.inSpecFast, gx, gy);
         }
     }
     __syncthreads();
@@ -236,16 +240,16 @@ __global__ __launch_bounds__(TILE_X* TILE_Y) void ReblurHistoryFixKernel(ReblurC
     float2 stride = F2(c.gHistoryFixBasePixelStride / (2.0f + frameNum.x), c.gHistoryFixBasePixelStride / (2.0f + frameNum.y));
 
     if (DIFF) {
-        float4 diff = HistoryFixSignal<false, DIFF, SPEC, PERF>(c, P, s, LoadRGBA16F(P.inDiff, px, py), frameNum.x, stride.x, P.inDiff, P.inDiffFast, P.outDiffFast, s_DiffLuma);
-        StoreRGBA16F(P.outDiff, px, py, diff);
+        S diff = HistoryFixSignal<false, DIFF, SPEC, PERF, OCC>(c, P, s, Sig::Load(P.inDiff, px, py), frameNum.x, stride.x, P.inDiff, P.inDiffFast, P.outDiffFast, s_DiffLuma);
+        Sig::Store(P.outDiff, px, py, diff);
     }
     if (SPEC) {
-        float4 spec = HistoryFixSignal<true, DIFF, SPEC, PERF>(c, P, s, LoadRGBA16F(P.inSpec, px, py), frameNum.y, stride.y, P.inSpec, P.inSpecFast, P.outSpecFast, s_SpecLuma);
-        StoreRGBA16F(P.outSpec, px, py, spec);
+        S spec = HistoryFixSignal<true, DIFF, SPEC, PERF, OCC>(c, P, s, Sig::Load(P.inSpec, px, py), frameNum.y, stride.y, P.inSpec, P.inSpecFast, P.outSpecFast, s_SpecLuma);
+        Sig::Store(P.outSpec, px, py, spec);
     }
 }
 
-template <bool DIFF, bool SPEC, bool PERF>
+template <bool DIFF, bool SPEC, bool PERF, bool OCC>
 static const char* LaunchHistoryFix(const PassArgs& a) {
     const ReblurCB& c = *(const ReblurCB*)a.constants;
     if (const char* err = CheckSupportedHistory(c))
@@ -270,7 +274,7 @@ static const char* LaunchHistoryFix(const PassArgs& a) {
     if (k != a.planesNum)
         return "REBLUR history fix: unexpected resource count";
     RowGrid g = GridForRows(c.gRectSizeMinusOne.x + 1, c.gRectSizeMinusOne.y + 1, TILE_X, TILE_Y, a.rowBegin, a.rowEnd);
-    hipLaunchKernelGGL((ReblurHistoryFixKernel<DIFF, SPEC, PERF>), g.grid, dim3(TILE_X * TILE_Y), 0, a.stream, c, P, RowRange{g.firstBlockY, g.rowBegin, g.rowEnd});
+    hipLaunchKernelGGL((ReblurHistoryFixKernel<DIFF, SPEC, PERF, OCC>), g.grid, dim3(TILE_X * TILE_Y), 0, a.stream, c, P, RowRange{g.firstBlockY, g.rowBegin, g.rowEnd});
     return nullptr;
 }
 
@@ -522,9 +526,11 @@ static const char* LaunchTemporalStabilization(const PassArgs& a) {
 }
 
 #define REBLUR_HISTORY_FAMILY(NAME, D, S)                                                            \
-    {"REBLUR_" NAME "_HistoryFix.cs", LaunchHistoryFix<D, S, false>},                                \
+    {"REBLUR_" NAME "_HistoryFix.cs", LaunchHistoryFix<D, S, false, false>},                         \
     {"REBLUR_" NAME "_TemporalStabilization.cs", LaunchTemporalStabilization<D, S, false>},          \
-    {"REBLUR_Perf_" NAME "_HistoryFix.cs", LaunchHistoryFix<D, S, true>},                            \
+    {"REBLUR_Perf_" NAME "_HistoryFix.cs", LaunchHistoryFix<D, S, true, false>},                     \
+    {"REBLUR_" NAME "Occlusion_HistoryFix.cs", LaunchHistoryFix<D, S, false, true>},                 \
+    {"REBLUR_Perf_" NAME "Occlusion_HistoryFix.cs", LaunchHistoryFix<D, S, true, true>},             \
     {"REBLUR_Perf_" NAME "_TemporalStabilization.cs", LaunchTemporalStabilization<D, S, true>},
 
 const PassEntry* GetReblurHistoryPasses(uint32_t& num) {

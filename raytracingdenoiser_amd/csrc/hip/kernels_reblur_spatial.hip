@@ -75,8 +75,12 @@ NRD_D float PoissonGaussianWeight(int n) { // = GetGaussianWeight( offset.z ), b
     return n < 4 ? REBLUR_GAUSSIAN_WEIGHT_Z1 : REBLUR_GAUSSIAN_WEIGHT_Z05;
 }
 
-template <SpatialMode MODE, bool PERF>
-NRD_D float4 DiffuseSpatialFilter(const ReblurCB& c, const SpatialCtx& s, float4 diff, const Plane& gIn_Diff, const Plane& gIn_ViewZ, const Plane& gIn_Normal_Roughness) {
+// OCC = occlusion family: the signal is the hit distance alone (REBLUR_TYPE float, R16_UNORM planes)
+template <SpatialMode MODE, bool PERF, bool OCC>
+NRD_D typename ReblurSignal<OCC>::type DiffuseSpatialFilter(const ReblurCB& c, const SpatialCtx& s, typename ReblurSignal<OCC>::type diff, const Plane& gIn_Diff, const Plane& gIn_ViewZ,
+    const Plane& gIn_Normal_Roughness) {
+    typedef ReblurSignal<OCC> Sig;
+    typedef typename Sig::type S;
     if (MODE == PRE_BLUR && c.gDiffPrepassBlurRadius == 0.0f)
         return diff;
 
@@ -93,7 +97,7 @@ NRD_D float4 DiffuseSpatialFilter(const ReblurCB& c, const SpatialCtx& s, float4
 
     const float4 hitDistParams = ToF4(c.gHitDistParams);
     float hitDistScale = GetHitDistanceNormalization(s.viewZ, hitDistParams, 1.0f);
-    float hitDist = diff.w * hitDistScale;
+    float hitDist = ExtractHitDist(diff) * hitDistScale;
     float hitDistFactor = GetHitDistFactor(hitDist, s.frustumSize);
 
     float diffNonLinearAccumSpeed, blurRadius, areaFactor;
@@ -114,9 +118,9 @@ NRD_D float4 DiffuseSpatialFilter(const ReblurCB& c, const SpatialCtx& s, float4
 
     float2 geometryWeightParams = GetGeometryWeightParams(c.gPlaneDistSensitivity, s.frustumSize, s.Xv, s.Nv);
     float normalWeightParam = GetNormalWeightParam(diffNonLinearAccumSpeed, c.gLobeAngleFraction) / fractionScale;
-    float2 hitDistanceWeightParams = GetHitDistanceWeightParams(diff.w, diffNonLinearAccumSpeed);
+    float2 hitDistanceWeightParams = GetHitDistanceWeightParams(ExtractHitDist(diff), diffNonLinearAccumSpeed);
     float minHitDistWeight = c.gMinHitDistanceWeight * fractionScale;
-    if (MODE != PRE_BLUR)
+    if (MODE != PRE_BLUR && !OCC)
         minHitDistWeight *= Sqrt(diffNonLinearAccumSpeed);
 
     const float2 rectSize = ToF2(c.gRectSize), rectSizeInv = ToF2(c.gRectSizeInv), resolutionScale = ToF2(c.gResolutionScale);
@@ -152,10 +156,10 @@ NRD_D float4 DiffuseSpatialFilter(const ReblurCB& c, const SpatialCtx& s, float4
         w *= CompareMaterials(s.materialID, materialIDs, c.gDiffMinMaterial) ? 1.0f : 0.0f;
         w *= ComputeWeight(angle, normalWeightParam, 0.0f);
 
-        float4 smp = LoadRGBA16F(gIn_Diff, tz.x, tz.y);
-        smp = w == 0.0f ? F4(0.0f) : smp;
+        S smp = Sig::Load(gIn_Diff, tz.x, tz.y);
+        smp = w == 0.0f ? Sig::Zero() : smp;
 
-        w *= Lerp(minHitDistWeight, 1.0f, ComputeExponentialWeight(smp.w, hitDistanceWeightParams.x, hitDistanceWeightParams.y));
+        w *= Lerp(minHitDistWeight, 1.0f, ComputeExponentialWeight(ExtractHitDist(smp), hitDistanceWeightParams.x, hitDistanceWeightParams.y));
         w *= PoissonGaussianWeight<PERF>(n);
 
         sum += w;
@@ -166,9 +170,11 @@ NRD_D float4 DiffuseSpatialFilter(const ReblurCB& c, const SpatialCtx& s, float4
     return diff * invSum;
 }
 
-template <SpatialMode MODE, bool PERF>
-NRD_D float4 SpecularSpatialFilter(const ReblurCB& c, const SpatialCtx& s, float4 spec, const Plane& gIn_Spec, const Plane& gIn_ViewZ, const Plane& gIn_Normal_Roughness,
-    const Plane& gOut_SpecHitDistForTracking) {
+template <SpatialMode MODE, bool PERF, bool OCC>
+NRD_D typename ReblurSignal<OCC>::type SpecularSpatialFilter(const ReblurCB& c, const SpatialCtx& s, typename ReblurSignal<OCC>::type spec, const Plane& gIn_Spec, const Plane& gIn_ViewZ,
+    const Plane& gIn_Normal_Roughness, const Plane& gOut_SpecHitDistForTracking) {
+    typedef ReblurSignal<OCC> Sig;
+    typedef typename Sig::type S;
     float smc = GetSpecMagicCurve(s.roughness);
     if (MODE == PRE_BLUR && c.gSpecPrepassBlurRadius == 0.0f)
         return spec;
@@ -192,7 +198,7 @@ NRD_D float4 SpecularSpatialFilter(const ReblurCB& c, const SpatialCtx& s, float
     float4 Dv = GetSpecularDominantDirection(s.Nv, s.Vv, s.roughness);
     float NoD = Abs(Dot(s.Nv, Xyz(Dv)));
     float hitDistScale = GetHitDistanceNormalization(s.viewZ, hitDistParams, s.roughness);
-    float hitDist = spec.w * hitDistScale;
+    float hitDist = ExtractHitDist(spec) * hitDistScale;
     float hitDistFactor = GetHitDistFactor(hitDist, s.frustumSize);
 
     float hitDistForTracking = 0.0f, specNonLinearAccumSpeed, blurRadius, areaFactor;
@@ -224,9 +230,9 @@ NRD_D float4 SpecularSpatialFilter(const ReblurCB& c, const SpatialCtx& s, float
     float2 geometryWeightParams = GetGeometryWeightParams(c.gPlaneDistSensitivity, s.frustumSize, s.Xv, s.Nv);
     float normalWeightParam = GetNormalWeightParam(specNonLinearAccumSpeed, c.gLobeAngleFraction, s.roughness) / fractionScale;
     float2 roughnessWeightParams = GetRoughnessWeightParams(s.roughness, roughnessFractionScaled);
-    float2 hitDistanceWeightParams = GetHitDistanceWeightParams(spec.w, specNonLinearAccumSpeed, s.roughness);
+    float2 hitDistanceWeightParams = GetHitDistanceWeightParams(ExtractHitDist(spec), specNonLinearAccumSpeed, s.roughness);
     float minHitDistWeight = c.gMinHitDistanceWeight * fractionScale * smc;
-    if (MODE != PRE_BLUR)
+    if (MODE != PRE_BLUR && !OCC)
         minHitDistWeight *= Sqrt(specNonLinearAccumSpeed);
 
     const float2 rectSize = ToF2(c.gRectSize), rectSizeInv = ToF2(c.gRectSizeInv), resolutionScale = ToF2(c.gResolutionScale);
@@ -278,11 +284,11 @@ NRD_D float4 SpecularSpatialFilter(const ReblurCB& c, const SpatialCtx& s, float
         w *= ComputeWeight(angle, normalWeightParam, 0.0f);
         w *= ComputeWeight(Ns.w, roughnessWeightParams.x, roughnessWeightParams.y);
 
-        float4 smp = LoadRGBA16F(gIn_Spec, tz.x, tz.y);
-        smp = w == 0.0f ? F4(0.0f) : smp;
+        S smp = Sig::Load(gIn_Spec, tz.x, tz.y);
+        smp = w == 0.0f ? Sig::Zero() : smp;
 
         if (MODE == PRE_BLUR) {
-            float hs = smp.w * GetHitDistanceNormalization(zs, hitDistParams, Ns.w);
+            float hs = ExtractHitDist(smp) * GetHitDistanceNormalization(zs, hitDistParams, Ns.w);
             float d = Length(Xvs - s.Xv) + NRD_EPS;
             float geometryWeight = w * Sat(hs / d);
             if (rng.GetFloat() < geometryWeight)
@@ -293,7 +299,7 @@ NRD_D float4 SpecularSpatialFilter(const ReblurCB& c, const SpatialCtx& s, float
             float t = hs / (d + hitDist);
             w *= Lerp(Sat(t), 1.0f, LinearStep(0.5f, 1.0f, s.roughness));
         }
-        w *= Lerp(minHitDistWeight, 1.0f, ComputeExponentialWeight(smp.w, hitDistanceWeightParams.x, hitDistanceWeightParams.y));
+        w *= Lerp(minHitDistWeight, 1.0f, ComputeExponentialWeight(ExtractHitDist(smp), hitDistanceWeightParams.x, hitDistanceWeightParams.y));
         w *= PoissonGaussianWeight<PERF>(n);
 
         sum += w;
@@ -340,8 +346,10 @@ struct SpatialPlanes {
     Plane outInternalData, outDiffCopy, outSpecCopy; // post-blur without temporal stabilization
 };
 
-template <SpatialMode MODE, bool DIFF, bool SPEC, bool NO_TS, bool PERF>
+template <SpatialMode MODE, bool DIFF, bool SPEC, bool NO_TS, bool PERF, bool OCC>
 __global__ __launch_bounds__(TILE_X* TILE_Y) void ReblurSpatialKernel(ReblurCB c, SpatialPlanes P, RowRange rr) {
+    typedef ReblurSignal<OCC> Sig;
+    typedef typename Sig::type S;
     const int px = blockIdx.x * TILE_X + (threadIdx.x % TILE_X);
     const int py = (blockIdx.y + rr.firstBlockY) * TILE_Y + (threadIdx.x / TILE_X);
     if (px > c.gRectSizeMinusOne.x || py > c.gRectSizeMinusOne.y || py < rr.rowBegin || py >= rr.rowEnd)
@@ -368,18 +376,18 @@ __global__ __launch_bounds__(TILE_X* TILE_Y) void ReblurSpatialKernel(ReblurCB c
     }
 
     if (DIFF) {
-        float4 diff = LoadRGBA16F(P.inDiff, px, py);
-        diff = DiffuseSpatialFilter<MODE, PERF>(c, s, diff, P.inDiff, P.viewZ, P.decodedNR);
-        StoreRGBA16F(P.outDiff, px, py, diff);
-        if (MODE == POST_BLUR && NO_TS)
-            StoreRGBA16F(P.outDiffCopy, px, py, diff);
+        S diff = Sig::Load(P.inDiff, px, py);
+        diff = DiffuseSpatialFilter<MODE, PERF, OCC>(c, s, diff, P.inDiff, P.viewZ, P.decodedNR);
+        Sig::Store(P.outDiff, px, py, diff);
+        if (MODE == POST_BLUR && NO_TS && !OCC) // the occlusion family has no separate history copy: its output is the history
+            Sig::Store(P.outDiffCopy, px, py, diff);
     }
     if (SPEC) {
-        float4 spec = LoadRGBA16F(P.inSpec, px, py);
-        spec = SpecularSpatialFilter<MODE, PERF>(c, s, spec, P.inSpec, P.viewZ, P.decodedNR, P.outHitDistForTracking);
-        StoreRGBA16F(P.outSpec, px, py, spec);
-        if (MODE == POST_BLUR && NO_TS)
-            StoreRGBA16F(P.outSpecCopy, px, py, spec);
+        S spec = Sig::Load(P.inSpec, px, py);
+        spec = SpecularSpatialFilter<MODE, PERF, OCC>(c, s, spec, P.inSpec, P.viewZ, P.decodedNR, P.outHitDistForTracking);
+        Sig::Store(P.outSpec, px, py, spec);
+        if (MODE == POST_BLUR && NO_TS && !OCC)
+            Sig::Store(P.outSpecCopy, px, py, spec);
     }
 }
 
@@ -393,7 +401,7 @@ static const char* CheckSupported(const ReblurCB& c) {
     return nullptr;
 }
 
-template <SpatialMode MODE, bool DIFF, bool SPEC, bool NO_TS, bool PERF>
+template <SpatialMode MODE, bool DIFF, bool SPEC, bool NO_TS, bool PERF, bool OCC>
 static const char* LaunchSpatial(const PassArgs& a) {
     const ReblurCB& c = *(const ReblurCB*)a.constants;
     if (const char* err = CheckSupported(c))
@@ -428,8 +436,8 @@ static const char* LaunchSpatial(const PassArgs& a) {
             if (SPEC) P.outSpec = a.planes[k++];
             if (NO_TS) {
                 P.outInternalData = a.planes[k++];
-                if (DIFF) P.outDiffCopy = a.planes[k++];
-                if (SPEC) P.outSpecCopy = a.planes[k++];
+                if (DIFF && !OCC) P.outDiffCopy = a.planes[k++];
+                if (SPEC && !OCC) P.outSpecCopy = a.planes[k++];
             }
         }
     }
@@ -437,12 +445,13 @@ static const char* LaunchSpatial(const PassArgs& a) {
         return "REBLUR spatial pass: unexpected resource count";
 
     RowGrid g = GridForRows(c.gRectSizeMinusOne.x + 1, c.gRectSizeMinusOne.y + 1, TILE_X, TILE_Y, a.rowBegin, a.rowEnd);
-    hipLaunchKernelGGL((ReblurSpatialKernel<MODE, DIFF, SPEC, NO_TS, PERF>), g.grid, dim3(TILE_X * TILE_Y), 0, a.stream, c, P, RowRange{g.firstBlockY, g.rowBegin, g.rowEnd});
+    hipLaunchKernelGGL((ReblurSpatialKernel<MODE, DIFF, SPEC, NO_TS, PERF, OCC>), g.grid, dim3(TILE_X * TILE_Y), 0, a.stream, c, P, RowRange{g.firstBlockY, g.rowBegin, g.rowEnd});
     return nullptr;
 }
 
 // ================================================================================================ SplitScreen
-template <bool DIFF, bool SPEC>
+// OCC: the occlusion family binds its R16_UNORM planes to the radiance family's split-screen pipeline (the shader only scales .x there)
+template <bool DIFF, bool SPEC, bool OCC>
 __global__ __launch_bounds__(256) void ReblurSplitScreenKernel(ReblurCB c, Plane viewZ, Plane inDiff, Plane inSpec, Plane outDiff, Plane outSpec, RowRange rr) {
     const int px = blockIdx.x * TILE_X + (threadIdx.x % TILE_X);
     const int py = (blockIdx.y + rr.firstBlockY) * TILE_Y + (threadIdx.x / TILE_X);
@@ -453,10 +462,11 @@ __global__ __launch_bounds__(256) void ReblurSplitScreenKernel(ReblurCB c, Plane
         return;
     float z = UnpackViewZ(c, LoadR32F(viewZ, px, py));
     float keep = z < c.gDenoisingRange ? 1.0f : 0.0f;
+    typedef ReblurSignal<OCC> Sig;
     if (DIFF)
-        StoreRGBA16F(outDiff, px, py, LoadRGBA16F(inDiff, px, py) * keep);
+        Sig::Store(outDiff, px, py, Sig::Load(inDiff, px, py) * keep);
     if (SPEC)
-        StoreRGBA16F(outSpec, px, py, LoadRGBA16F(inSpec, px, py) * keep);
+        Sig::Store(outSpec, px, py, Sig::Load(inSpec, px, py) * keep);
 }
 
 template <bool DIFF, bool SPEC>
@@ -470,8 +480,20 @@ static const char* LaunchSplitScreen(const PassArgs& a) {
     if (SPEC) inSpec = a.planes[k++];
     if (DIFF) outDiff = a.planes[k++];
     if (SPEC) outSpec = a.planes[k++];
+    if (k != a.planesNum)
+        return "REBLUR split screen: unexpected resource count";
     RowGrid g = GridForRows(c.gRectSizeMinusOne.x + 1, c.gRectSizeMinusOne.y + 1, TILE_X, TILE_Y, a.rowBegin, a.rowEnd);
-    hipLaunchKernelGGL((ReblurSplitScreenKernel<DIFF, SPEC>), g.grid, dim3(256), 0, a.stream, c, viewZ, inDiff, inSpec, outDiff, outSpec, RowRange{g.firstBlockY, g.rowBegin, g.rowEnd});
+    const RowRange rows = {g.firstBlockY, g.rowBegin, g.rowEnd};
+    const uint32_t bytesPerTexel = a.bytesPerTexel[1]; // 8 = RGBA16F (radiance family), 2 = R16_UNORM (occlusion family on the same pipeline)
+    for (uint32_t i = 1; i < k; i++)
+        if (a.bytesPerTexel[i] != bytesPerTexel)
+            return "REBLUR split screen: mixed signal formats";
+    if (bytesPerTexel == 8)
+        hipLaunchKernelGGL((ReblurSplitScreenKernel<DIFF, SPEC, false>), g.grid, dim3(256), 0, a.stream, c, viewZ, inDiff, inSpec, outDiff, outSpec, rows);
+    else if (bytesPerTexel == 2)
+        hipLaunchKernelGGL((ReblurSplitScreenKernel<DIFF, SPEC, true>), g.grid, dim3(256), 0, a.stream, c, viewZ, inDiff, inSpec, outDiff, outSpec, rows);
+    else
+        return "REBLUR split screen: unexpected signal format";
     return nullptr;
 }
 
@@ -483,8 +505,10 @@ struct HitDistPlanes {
     Plane tiles, viewZ, decodedNR, inDiff, inSpec, outDiff, outSpec;
 };
 
-template <bool DIFF, bool SPEC, int BORDER, bool PERF>
+template <bool DIFF, bool SPEC, int BORDER, bool PERF, bool OCC>
 __global__ __launch_bounds__(TILE_X* TILE_Y) void ReblurHitDistReconstructionKernel(ReblurCB c, HitDistPlanes P, RowRange rr) {
+    typedef ReblurSignal<OCC> Sig;
+    typedef typename Sig::type S;
     const int px = blockIdx.x * TILE_X + (threadIdx.x % TILE_X);
     const int py = (blockIdx.y + rr.firstBlockY) * TILE_Y + (threadIdx.x / TILE_X);
     const int rw = c.gRectSizeMinusOne.x, rh = c.gRectSizeMinusOne.y;
@@ -512,8 +536,8 @@ __global__ __launch_bounds__(TILE_X* TILE_Y) void ReblurHitDistReconstructionKer
     const float diffNormalWeightParam = GetNormalWeightParam(1.0f, 1.0f);
     const float specNormalWeightParam = GetNormalWeightParam(1.0f, 1.0f, roughness);
 
-    const float4 centerDiff = DIFF ? LoadRGBA16F(P.inDiff, px, py) : F4(0.0f), centerSpec = SPEC ? LoadRGBA16F(P.inSpec, px, py) : F4(0.0f);
-    float2 center = F2(centerDiff.w, centerSpec.w);
+    const S centerDiff = DIFF ? Sig::Load(P.inDiff, px, py) : Sig::Zero(), centerSpec = SPEC ? Sig::Load(P.inSpec, px, py) : Sig::Zero();
+    float2 center = F2(ExtractHitDist(centerDiff), ExtractHitDist(centerSpec));
     float2 sum = F2(center.x != 0.0f ? 1000.0f : 0.0f, center.y != 0.0f ? 1000.0f : 0.0f);
     center = center * sum;
 
@@ -523,7 +547,7 @@ __global__ __launch_bounds__(TILE_X* TILE_Y) void ReblurHitDistReconstructionKer
             if (o.x == 0.0f && o.y == 0.0f)
                 continue;
             const int sx = ClampI(px + i - BORDER, 0, rw), sy = ClampI(py + j - BORDER, 0, rh);
-            float2 data = F2(DIFF ? LoadRGBA16F(P.inDiff, sx, sy).w : 0.0f, SPEC ? LoadRGBA16F(P.inSpec, sx, sy).w : 0.0f);
+            float2 data = F2(DIFF ? ExtractHitDist(Sig::Load(P.inDiff, sx, sy)) : 0.0f, SPEC ? ExtractHitDist(Sig::Load(P.inSpec, sx, sy)) : 0.0f);
             const float dataZ = UnpackViewZ(c, LoadR32F(P.viewZ, sx, sy));
 
             float w = IsInScreenNearest(pixelUv + o * rectSizeInv);
@@ -553,12 +577,12 @@ __global__ __launch_bounds__(TILE_X* TILE_Y) void ReblurHitDistReconstructionKer
     center = center / F2(Max(sum.x, NRD_EPS), Max(sum.y, NRD_EPS));
 
     if (DIFF)
-        StoreRGBA16F(P.outDiff, px, py, F4(Xyz(centerDiff), center.x));
+        Sig::Store(P.outDiff, px, py, Sig::WithHitDist(centerDiff, center.x));
     if (SPEC)
-        StoreRGBA16F(P.outSpec, px, py, F4(Xyz(centerSpec), center.y));
+        Sig::Store(P.outSpec, px, py, Sig::WithHitDist(centerSpec, center.y));
 }
 
-template <bool DIFF, bool SPEC, int BORDER, bool PERF>
+template <bool DIFF, bool SPEC, int BORDER, bool PERF, bool OCC>
 static const char* LaunchHitDistReconstruction(const PassArgs& a) {
     const ReblurCB& c = *(const ReblurCB*)a.constants;
     if (const char* err = CheckSupported(c))
@@ -576,18 +600,23 @@ static const char* LaunchHitDistReconstruction(const PassArgs& a) {
     if (k != a.planesNum || !P.decodedNR.ptr)
         return "REBLUR hit distance reconstruction: unexpected resource count or missing decoded normal/roughness cache";
     RowGrid g = GridForRows(c.gRectSizeMinusOne.x + 1, c.gRectSizeMinusOne.y + 1, TILE_X, TILE_Y, a.rowBegin, a.rowEnd);
-    hipLaunchKernelGGL((ReblurHitDistReconstructionKernel<DIFF, SPEC, BORDER, PERF>), g.grid, dim3(TILE_X * TILE_Y), 0, a.stream, c, P, RowRange{g.firstBlockY, g.rowBegin, g.rowEnd});
+    hipLaunchKernelGGL((ReblurHitDistReconstructionKernel<DIFF, SPEC, BORDER, PERF, OCC>), g.grid, dim3(TILE_X * TILE_Y), 0, a.stream, c, P, RowRange{g.firstBlockY, g.rowBegin, g.rowEnd});
     return nullptr;
 }
 
 // quality and performance ("REBLUR_Perf_*") permutations of one signal family
 #define REBLUR_SPATIAL_PASSES(PREFIX, NAME, D, S, P)                                                     \
-    {PREFIX NAME "_HitDistReconstruction.cs", LaunchHitDistReconstruction<D, S, 1, P>},                \
-    {PREFIX NAME "_HitDistReconstruction_5x5.cs", LaunchHitDistReconstruction<D, S, 2, P>},            \
-    {PREFIX NAME "_PrePass.cs", LaunchSpatial<PRE_BLUR, D, S, false, P>},                              \
-    {PREFIX NAME "_Blur.cs", LaunchSpatial<BLUR, D, S, false, P>},                                     \
-    {PREFIX NAME "_PostBlur.cs", LaunchSpatial<POST_BLUR, D, S, false, P>},                            \
-    {PREFIX NAME "_PostBlur_NoTemporalStabilization.cs", LaunchSpatial<POST_BLUR, D, S, true, P>},
+    {PREFIX NAME "_HitDistReconstruction.cs", LaunchHitDistReconstruction<D, S, 1, P, false>},         \
+    {PREFIX NAME "_HitDistReconstruction_5x5.cs", LaunchHitDistReconstruction<D, S, 2, P, false>},     \
+    {PREFIX NAME "_PrePass.cs", LaunchSpatial<PRE_BLUR, D, S, false, P, false>},                       \
+    {PREFIX NAME "_Blur.cs", LaunchSpatial<BLUR, D, S, false, P, false>},                              \
+    {PREFIX NAME "_PostBlur.cs", LaunchSpatial<POST_BLUR, D, S, false, P, false>},                     \
+    {PREFIX NAME "_PostBlur_NoTemporalStabilization.cs", LaunchSpatial<POST_BLUR, D, S, true, P, false>}, \
+    /* occlusion family: hit distance only (R16_UNORM), no pre-pass, post-blur always without temporal stabilisation */ \
+    {PREFIX NAME "Occlusion_HitDistReconstruction.cs", LaunchHitDistReconstruction<D, S, 1, P, true>}, \
+    {PREFIX NAME "Occlusion_HitDistReconstruction_5x5.cs", LaunchHitDistReconstruction<D, S, 2, P, true>}, \
+    {PREFIX NAME "Occlusion_Blur.cs", LaunchSpatial<BLUR, D, S, false, P, true>},                      \
+    {PREFIX NAME "Occlusion_PostBlur_NoTemporalStabilization.cs", LaunchSpatial<POST_BLUR, D, S, true, P, true>},
 #define REBLUR_SPATIAL_FAMILY(NAME, D, S)                                                              \
     REBLUR_SPATIAL_PASSES("REBLUR_", NAME, D, S, false)                                                \
     REBLUR_SPATIAL_PASSES("REBLUR_Perf_", NAME, D, S, true)                                            \

@@ -31,8 +31,11 @@ struct TaPlanes {
 };
 
 // PERF = REBLUR_PERFORMANCE_MODE: no Catmull-Rom history fetches (REBLUR_USE_CATROM_FOR_*_MOTION_IN_TA = 0, REBLUR_Config.hlsli:196-201)
-template <bool DIFF, bool SPEC, bool PERF>
+// OCC = occlusion family (REBLUR_OCCLUSION): hit-distance-only signals in R16_UNORM, no pre-pass output to read, no DATA2, no firefly suppressor
+template <bool DIFF, bool SPEC, bool PERF, bool OCC>
 __global__ __launch_bounds__(TILE_X* TILE_Y, 2) void ReblurTemporalAccumulationKernel(ReblurCB cArg, TaPlanes P, RowRange rr) {
+    typedef ReblurSignal<OCC> Sig;
+    typedef typename Sig::type S;
     __shared__ float4 s_Normal_Roughness[BUF_Y * BUF_STRIDE];
     // The 832-byte constant block + ~20 planes need > 200 SGPRs (102 exist), which the compiler resolves by spilling scalars into
     // VGPR lanes (v_writelane / v_readlane + hazard nops on every use). The body therefore reads the constants from an LDS copy
@@ -44,7 +47,12 @@ __global__ __launch_bounds__(TILE_X* TILE_Y, 2) void ReblurTemporalAccumulationK
         const Plane size = P.viewZ, rgba16 = DIFF ? P.historyDiff : P.historySpec, r16 = DIFF ? P.historyDiffFast : P.historySpecFast;
         ShareSize(P.decodedNR, size), ShareSize(P.mv, size), ShareSize(P.prevViewZ, size), ShareSize(P.prevNormalRoughness, size), ShareSize(P.prevInternalData, size);
         ShareSize(P.inDiff, size), ShareSize(P.inSpec, size), ShareSize(P.inSpecHitDistForTracking, size), ShareSize(P.outData1, size), ShareSize(P.outData2, size);
-        ShareLayout(P.historyDiff, rgba16), ShareLayout(P.historySpec, rgba16), ShareLayout(P.outDiff, rgba16), ShareLayout(P.outSpec, rgba16);
+        if (OCC) { // the history planes are the user's OUT_*_HITDIST (own pitch); only the pool outputs share a layout
+            const Plane sig = DIFF ? P.outDiff : P.outSpec;
+            ShareSize(P.historyDiff, size), ShareSize(P.historySpec, size), ShareLayout(P.outDiff, sig), ShareLayout(P.outSpec, sig);
+        } else {
+            ShareLayout(P.historyDiff, rgba16), ShareLayout(P.historySpec, rgba16), ShareLayout(P.outDiff, rgba16), ShareLayout(P.outSpec, rgba16);
+        }
         ShareLayout(P.historyDiffFast, r16), ShareLayout(P.historySpecFast, r16), ShareLayout(P.prevSpecHitDistForTracking, r16), ShareLayout(P.outDiffFast, r16), ShareLayout(P.outSpecFast, r16),
             ShareLayout(P.outSpecHitDistForTracking, r16);
     }
@@ -71,7 +79,7 @@ __global__ __launch_bounds__(TILE_X* TILE_Y, 2) void ReblurTemporalAccumulationK
             int gx = ClampI(baseX + lx, 0, rw), gy = ClampI(baseY + ly, 0, rh);
             s_Normal_Roughness[ly * BUF_STRIDE + lx] = LoadDecodedNormalRoughness(P.decodedNR, gx, gy);
             if (SPEC) {
-                float hitDist = cArg.gSpecPrepassBlurRadius == 0.0f ? LoadRGBA16F(P.inSpec, gx, gy).w : LoadR16F(P.inSpecHitDistForTracking, gx, gy);
+                float hitDist = (OCC || cArg.gSpecPrepassBlurRadius == 0.0f) ? ExtractHitDist(Sig::Load(P.inSpec, gx, gy)) : LoadR16F(P.inSpecHitDistForTracking, gx, gy);
                 s_HitDistForTracking[ly * BUF_STRIDE + lx] = hitDist == 0.0f ? NRD_INF : hitDist;
             }
         }
@@ -141,7 +149,7 @@ __global__ __launch_bounds__(TILE_X* TILE_Y, 2) void ReblurTemporalAccumulationK
 
         hitDistForTracking = hitDistForTracking == NRD_INF ? 0.0f : hitDistForTracking;
         hitDistNormalization = GetHitDistanceNormalization(viewZ, hitDistParams, roughness);
-        hitDistForTracking *= c.gSpecPrepassBlurRadius == 0.0f ? hitDistNormalization : 1.0f;
+        hitDistForTracking *= (OCC || c.gSpecPrepassBlurRadius == 0.0f) ? hitDistNormalization : 1.0f;
         StoreR16F(P.outSpecHitDistForTracking, px, py, hitDistForTracking);
     }
 
@@ -293,32 +301,37 @@ __global__ __launch_bounds__(TILE_X* TILE_Y, 2) void ReblurTemporalAccumulationK
         diffAccumSpeed *= Lerp(diffHistoryConfidence, 1.0f, 1.0f / (1.0f + diffAccumSpeed));
         diffAccumSpeed = Min(diffAccumSpeed, c.gMaxAccumulatedFrameNum);
 
-        float4 diff = LoadRGBA16F(P.inDiff, px, py);
+        S diff = Sig::Load(P.inDiff, px, py);
 
         HistoryFilter smbFilter = MakeHistoryFilter(smbSamplePos, smbOcclusionWeights, smbAllowCatRom, P.historyDiff);
-        float4 smbDiffHistory = FetchHistoryRGBA16F(smbFilter, P.historyDiff);
-        float smbDiffFastHistory = FetchHistoryBilinearR16F(smbFilter, P.historyDiffFast);
+        S smbDiffHistory = Sig::FetchHistory(smbFilter, P.historyDiff);
+        float smbDiffFastHistory = Sig::FetchFastBilinear(smbFilter, P.historyDiffFast);
         smbDiffHistory = ClampNegativeToZero(smbDiffHistory);
 
         float diffNonLinearAccumSpeed = 1.0f / (1.0f + diffAccumSpeed);
-        float4 diffResult = MixHistoryAndCurrent(c, smbDiffHistory, diff, diffNonLinearAccumSpeed);
+        S diffResult = MixHistoryAndCurrent(c, smbDiffHistory, diff, diffNonLinearAccumSpeed);
 
-        float diffMaxRelativeIntensity = c.gFireflySuppressorMinRelativeScale + REBLUR_FIREFLY_SUPPRESSOR_MAX_RELATIVE_INTENSITY / (diffAccumSpeed + 1.0f);
-        float diffAntifireflyFactor = diffAccumSpeed * c.gMaxBlurRadius * REBLUR_FIREFLY_SUPPRESSOR_RADIUS_SCALE;
-        diffAntifireflyFactor /= 1.0f + diffAntifireflyFactor;
+        float diffMaxRelativeIntensity = 0.0f, diffAntifireflyFactor = 0.0f;
+        if (!OCC) { // firefly suppressor
+            diffMaxRelativeIntensity = c.gFireflySuppressorMinRelativeScale + REBLUR_FIREFLY_SUPPRESSOR_MAX_RELATIVE_INTENSITY / (diffAccumSpeed + 1.0f);
+            diffAntifireflyFactor = diffAccumSpeed * c.gMaxBlurRadius * REBLUR_FIREFLY_SUPPRESSOR_RADIUS_SCALE;
+            diffAntifireflyFactor /= 1.0f + diffAntifireflyFactor;
 
-        float diffLumaResult = GetLuma(diffResult);
-        float diffLumaClamped = Min(diffLumaResult, GetLuma(smbDiffHistory) * diffMaxRelativeIntensity);
-        diffLumaClamped = Lerp(diffLumaResult, diffLumaClamped, diffAntifireflyFactor);
-        diffResult = ChangeLuma(diffResult, diffLumaClamped);
-        StoreRGBA16F(P.outDiff, px, py, diffResult);
+            float diffLumaResult = GetLuma(diffResult);
+            float diffLumaClamped = Min(diffLumaResult, GetLuma(smbDiffHistory) * diffMaxRelativeIntensity);
+            diffLumaClamped = Lerp(diffLumaResult, diffLumaClamped, diffAntifireflyFactor);
+            diffResult = ChangeLuma(diffResult, diffLumaClamped);
+        }
+        Sig::Store(P.outDiff, px, py, diffResult);
 
         float diffFastAccumSpeed = Min(diffAccumSpeed, c.gMaxFastAccumulatedFrameNum);
         float diffFastNonLinearAccumSpeed = 1.0f / (1.0f + diffFastAccumSpeed);
         float diffFastResult = Lerp(smbDiffFastHistory, GetLuma(diff), diffFastNonLinearAccumSpeed);
-        float diffFastClamped = Min(diffFastResult, GetLuma(smbDiffHistory) * diffMaxRelativeIntensity * REBLUR_FIREFLY_SUPPRESSOR_FAST_RELATIVE_INTENSITY);
-        diffFastResult = Lerp(diffFastResult, diffFastClamped, diffAntifireflyFactor);
-        StoreR16F(P.outDiffFast, px, py, diffFastResult);
+        if (!OCC) {
+            float diffFastClamped = Min(diffFastResult, GetLuma(smbDiffHistory) * diffMaxRelativeIntensity * REBLUR_FIREFLY_SUPPRESSOR_FAST_RELATIVE_INTENSITY);
+            diffFastResult = Lerp(diffFastResult, diffFastClamped, diffAntifireflyFactor);
+        }
+        Sig::StoreFast(P.outDiffFast, px, py, diffFastResult);
     }
 
 
@@ -331,7 +344,7 @@ __global__ __launch_bounds__(TILE_X* TILE_Y, 2) void ReblurTemporalAccumulationK
         smbSpecAccumSpeed *= Lerp(specHistoryConfidence, 1.0f, 1.0f / (1.0f + smbSpecAccumSpeed));
         smbSpecAccumSpeed = Min(smbSpecAccumSpeed, c.gMaxAccumulatedFrameNum);
 
-        float4 spec = LoadRGBA16F(P.inSpec, px, py);
+        S spec = Sig::Load(P.inSpec, px, py);
 
         NRD_CONSTANTS_PHASE();
         // Curvature estimation along predicted motion
@@ -550,14 +563,14 @@ __global__ __launch_bounds__(TILE_X* TILE_Y, 2) void ReblurTemporalAccumulationK
         NRD_CONSTANTS_PHASE();
         // Sample surface history
         HistoryFilter smbFilter = MakeHistoryFilter(smbSamplePos, smbOcclusionWeights, smbAllowCatRom, P.historySpec);
-        float4 smbSpecHistory = FetchHistoryRGBA16F(smbFilter, P.historySpec);
-        float smbSpecFastHistory = FetchHistoryBilinearR16F(smbFilter, P.historySpecFast);
+        S smbSpecHistory = Sig::FetchHistory(smbFilter, P.historySpec);
+        float smbSpecFastHistory = Sig::FetchFastBilinear(smbFilter, P.historySpecFast);
 
         float surfaceHistoryConfidence;
         {
             float a = Atan(smbParallaxInPixelsMax * pixelSize / Length(X));
             float nonLinearAccumSpeed = 1.0f / (1.0f + smbSpecAccumSpeed);
-            float h = Lerp(smbSpecHistory.w, spec.w, nonLinearAccumSpeed) * hitDistNormalization;
+            float h = Lerp(ExtractHitDist(smbSpecHistory), ExtractHitDist(spec), nonLinearAccumSpeed) * hitDistNormalization;
 
             float tana0 = GetSpecularLobeTanHalfAngle(roughnessModified, NRD_MAX_PERCENT_OF_LOBE_VOLUME);
             tana0 *= Lerp(NoV, 1.0f, roughnessModified);
@@ -603,8 +616,8 @@ __global__ __launch_bounds__(TILE_X* TILE_Y, 2) void ReblurTemporalAccumulationK
         NRD_CONSTANTS_PHASE();
         // Sample virtual history
         HistoryFilter vmbFilter = MakeHistoryFilter(Sat(vmbPixelUv) * rectSizePrev, vmbOcclusionWeights, vmbAllowCatRom, P.historySpec);
-        float4 vmbSpecHistory = FetchHistoryRGBA16F(vmbFilter, P.historySpec);
-        float vmbSpecFastHistory = FetchHistoryBilinearR16F(vmbFilter, P.historySpecFast);
+        S vmbSpecHistory = Sig::FetchHistory(vmbFilter, P.historySpec);
+        float vmbSpecFastHistory = Sig::FetchFastBilinear(vmbFilter, P.historySpecFast);
 
         smbSpecHistory = ClampNegativeToZero(smbSpecHistory);
         vmbSpecHistory = ClampNegativeToZero(vmbSpecHistory);
@@ -612,24 +625,27 @@ __global__ __launch_bounds__(TILE_X* TILE_Y, 2) void ReblurTemporalAccumulationK
         float smbSpecNonLinearAccumSpeed = 1.0f / (1.0f + smbSpecAccumSpeed);
         float vmbSpecNonLinearAccumSpeed = 1.0f / (1.0f + vmbSpecAccumSpeed);
 
-        float4 smbSpec = MixHistoryAndCurrent(c, smbSpecHistory, spec, smbSpecNonLinearAccumSpeed, roughnessModified);
-        float4 vmbSpec = MixHistoryAndCurrent(c, vmbSpecHistory, spec, vmbSpecNonLinearAccumSpeed, roughnessModified);
-        float4 specResult = Lerp(smbSpec, vmbSpec, virtualHistoryAmount);
+        S smbSpec = MixHistoryAndCurrent(c, smbSpecHistory, spec, smbSpecNonLinearAccumSpeed, roughnessModified);
+        S vmbSpec = MixHistoryAndCurrent(c, vmbSpecHistory, spec, vmbSpecNonLinearAccumSpeed, roughnessModified);
+        S specResult = Lerp(smbSpec, vmbSpec, virtualHistoryAmount);
 
         specAccumSpeed = Lerp(smbSpecAccumSpeedBoosted, vmbSpecAccumSpeed, virtualHistoryAmount);
-        float4 specHistory = Lerp(smbSpecHistory, vmbSpecHistory, virtualHistoryAmount);
+        S specHistory = Lerp(smbSpecHistory, vmbSpecHistory, virtualHistoryAmount);
 
-        // Firefly suppressor
-        float specMaxRelativeIntensity = c.gFireflySuppressorMinRelativeScale + REBLUR_FIREFLY_SUPPRESSOR_MAX_RELATIVE_INTENSITY / (specAccumSpeed + 1.0f);
-        float specAntifireflyFactor = specAccumSpeed * c.gMaxBlurRadius * REBLUR_FIREFLY_SUPPRESSOR_RADIUS_SCALE;
-        specAntifireflyFactor /= 1.0f + specAntifireflyFactor;
+        // Firefly suppressor (not in the occlusion family)
+        float specMaxRelativeIntensity = 0.0f, specAntifireflyFactor = 0.0f;
+        if (!OCC) {
+            specMaxRelativeIntensity = c.gFireflySuppressorMinRelativeScale + REBLUR_FIREFLY_SUPPRESSOR_MAX_RELATIVE_INTENSITY / (specAccumSpeed + 1.0f);
+            specAntifireflyFactor = specAccumSpeed * c.gMaxBlurRadius * REBLUR_FIREFLY_SUPPRESSOR_RADIUS_SCALE;
+            specAntifireflyFactor /= 1.0f + specAntifireflyFactor;
 
-        float specLumaResult = GetLuma(specResult);
-        float specLumaClamped = Min(specLumaResult, GetLuma(specHistory) * specMaxRelativeIntensity);
-        specLumaClamped = Lerp(specLumaResult, specLumaClamped, specAntifireflyFactor);
-        specResult = ChangeLuma(specResult, specLumaClamped);
+            float specLumaResult = GetLuma(specResult);
+            float specLumaClamped = Min(specLumaResult, GetLuma(specHistory) * specMaxRelativeIntensity);
+            specLumaClamped = Lerp(specLumaResult, specLumaClamped, specAntifireflyFactor);
+            specResult = ChangeLuma(specResult, specLumaClamped);
+        }
 
-        StoreRGBA16F(P.outSpec, px, py, specResult);
+        Sig::Store(P.outSpec, px, py, specResult);
 
         // Fast history
         float smbSpecFastNonLinearAccumSpeed = GetNonLinearAccumSpeed(smbSpecAccumSpeed, c.gMaxFastAccumulatedFrameNum, surfaceHistoryConfidence);
@@ -638,14 +654,16 @@ __global__ __launch_bounds__(TILE_X* TILE_Y, 2) void ReblurTemporalAccumulationK
         float vmbSpecFast = Lerp(vmbSpecFastHistory, GetLuma(spec), vmbSpecFastNonLinearAccumSpeed);
         float specFastResult = Lerp(smbSpecFast, vmbSpecFast, virtualHistoryAmount);
 
-        float specFastClamped = Min(specFastResult, GetLuma(specHistory) * specMaxRelativeIntensity * REBLUR_FIREFLY_SUPPRESSOR_FAST_RELATIVE_INTENSITY);
-        specFastResult = Lerp(specFastResult, specFastClamped, specAntifireflyFactor);
-        StoreR16F(P.outSpecFast, px, py, specFastResult);
+        if (!OCC) {
+            float specFastClamped = Min(specFastResult, GetLuma(specHistory) * specMaxRelativeIntensity * REBLUR_FIREFLY_SUPPRESSOR_FAST_RELATIVE_INTENSITY);
+            specFastResult = Lerp(specFastResult, specFastClamped, specAntifireflyFactor);
+        }
+        Sig::StoreFast(P.outSpecFast, px, py, specFastResult);
     }
 
     NRD_CONSTANTS_PHASE();
     // DATA2: occlusion bits, curvature, virtual history amount (R32_UINT; diffuse-only keeps the low byte in R8_UINT)
-    {
+    if (!OCC) {
         uint32_t packed = PackData2(fbits, curvature, virtualHistoryAmount);
         if (SPEC)
             StoreR32U(P.outData2, px, py, packed);
@@ -656,7 +674,7 @@ __global__ __launch_bounds__(TILE_X* TILE_Y, 2) void ReblurTemporalAccumulationK
     StoreData1<DIFF, SPEC>(P.outData1, px, py, diffAccumSpeed, specAccumSpeed);
 }
 
-template <bool DIFF, bool SPEC, bool PERF>
+template <bool DIFF, bool SPEC, bool PERF, bool OCC>
 static const char* LaunchTemporalAccumulation(const PassArgs& a) {
     const ReblurCB& c = *(const ReblurCB*)a.constants;
     if (c.gDiffCheckerboard != 2 || c.gSpecCheckerboard != 2)
@@ -688,14 +706,14 @@ static const char* LaunchTemporalAccumulation(const PassArgs& a) {
     if (DIFF) P.historyDiffFast = a.planes[k++];
     if (SPEC) P.historySpecFast = a.planes[k++];
     if (SPEC) P.prevSpecHitDistForTracking = a.planes[k++];
-    if (SPEC) P.inSpecHitDistForTracking = a.planes[k++];
+    if (SPEC && !OCC) P.inSpecHitDistForTracking = a.planes[k++];
     if (DIFF) P.outDiff = a.planes[k++];
     if (SPEC) P.outSpec = a.planes[k++];
     if (DIFF) P.outDiffFast = a.planes[k++];
     if (SPEC) P.outSpecFast = a.planes[k++];
     if (SPEC) P.outSpecHitDistForTracking = a.planes[k++];
     P.outData1 = a.planes[k++];
-    P.outData2 = a.planes[k++];
+    if (!OCC) P.outData2 = a.planes[k++];
     if (k != a.planesNum)
         return "REBLUR temporal accumulation: unexpected resource count";
     {
@@ -703,7 +721,12 @@ static const char* LaunchTemporalAccumulation(const PassArgs& a) {
         bool ok = SameSize(P.decodedNR, size) && SameSize(P.mv, size) && SameSize(P.prevViewZ, size) && SameSize(P.prevNormalRoughness, size) && SameSize(P.prevInternalData, size) &&
                   SameSize(P.inDiff, size) && SameSize(P.inSpec, size) && SameSize(P.inSpecHitDistForTracking, size) && SameSize(P.outData1, size) && SameSize(P.outData2, size) &&
                   SameSize(rgba16, size) && SameSize(r16, size);
-        ok = ok && SameLayout(P.historyDiff, rgba16) && SameLayout(P.historySpec, rgba16) && SameLayout(P.outDiff, rgba16) && SameLayout(P.outSpec, rgba16);
+        if (OCC) {
+            const Plane sig = DIFF ? P.outDiff : P.outSpec;
+            ok = ok && SameSize(P.historyDiff, size) && SameSize(P.historySpec, size) && SameLayout(P.outDiff, sig) && SameLayout(P.outSpec, sig);
+        } else {
+            ok = ok && SameLayout(P.historyDiff, rgba16) && SameLayout(P.historySpec, rgba16) && SameLayout(P.outDiff, rgba16) && SameLayout(P.outSpec, rgba16);
+        }
         ok = ok && SameLayout(P.historyDiffFast, r16) && SameLayout(P.historySpecFast, r16) && SameLayout(P.prevSpecHitDistForTracking, r16) && SameLayout(P.outDiffFast, r16) &&
              SameLayout(P.outSpecFast, r16) && SameLayout(P.outSpecHitDistForTracking, r16);
         if (!ok)
@@ -711,18 +734,24 @@ static const char* LaunchTemporalAccumulation(const PassArgs& a) {
     }
 
     RowGrid g = GridForRows(c.gRectSizeMinusOne.x + 1, c.gRectSizeMinusOne.y + 1, TILE_X, TILE_Y, a.rowBegin, a.rowEnd);
-    hipLaunchKernelGGL((ReblurTemporalAccumulationKernel<DIFF, SPEC, PERF>), g.grid, dim3(TILE_X * TILE_Y), 0, a.stream, c, P, RowRange{g.firstBlockY, g.rowBegin, g.rowEnd});
+    hipLaunchKernelGGL((ReblurTemporalAccumulationKernel<DIFF, SPEC, PERF, OCC>), g.grid, dim3(TILE_X * TILE_Y), 0, a.stream, c, P, RowRange{g.firstBlockY, g.rowBegin, g.rowEnd});
     return nullptr;
 }
 
 const PassEntry* GetReblurTemporalAccumulationPasses(uint32_t& num) {
     static const PassEntry k[] = {
-        {"REBLUR_Diffuse_TemporalAccumulation.cs", LaunchTemporalAccumulation<true, false, false>},
-        {"REBLUR_Specular_TemporalAccumulation.cs", LaunchTemporalAccumulation<false, true, false>},
-        {"REBLUR_DiffuseSpecular_TemporalAccumulation.cs", LaunchTemporalAccumulation<true, true, false>},
-        {"REBLUR_Perf_Diffuse_TemporalAccumulation.cs", LaunchTemporalAccumulation<true, false, true>},
-        {"REBLUR_Perf_Specular_TemporalAccumulation.cs", LaunchTemporalAccumulation<false, true, true>},
-        {"REBLUR_Perf_DiffuseSpecular_TemporalAccumulation.cs", LaunchTemporalAccumulation<true, true, true>},
+        {"REBLUR_Diffuse_TemporalAccumulation.cs", LaunchTemporalAccumulation<true, false, false, false>},
+        {"REBLUR_Specular_TemporalAccumulation.cs", LaunchTemporalAccumulation<false, true, false, false>},
+        {"REBLUR_DiffuseSpecular_TemporalAccumulation.cs", LaunchTemporalAccumulation<true, true, false, false>},
+        {"REBLUR_Perf_Diffuse_TemporalAccumulation.cs", LaunchTemporalAccumulation<true, false, true, false>},
+        {"REBLUR_Perf_Specular_TemporalAccumulation.cs", LaunchTemporalAccumulation<false, true, true, false>},
+        {"REBLUR_Perf_DiffuseSpecular_TemporalAccumulation.cs", LaunchTemporalAccumulation<true, true, true, false>},
+        {"REBLUR_DiffuseOcclusion_TemporalAccumulation.cs", LaunchTemporalAccumulation<true, false, false, true>},
+        {"REBLUR_SpecularOcclusion_TemporalAccumulation.cs", LaunchTemporalAccumulation<false, true, false, true>},
+        {"REBLUR_DiffuseSpecularOcclusion_TemporalAccumulation.cs", LaunchTemporalAccumulation<true, true, false, true>},
+        {"REBLUR_Perf_DiffuseOcclusion_TemporalAccumulation.cs", LaunchTemporalAccumulation<true, false, true, true>},
+        {"REBLUR_Perf_SpecularOcclusion_TemporalAccumulation.cs", LaunchTemporalAccumulation<false, true, true, true>},
+        {"REBLUR_Perf_DiffuseSpecularOcclusion_TemporalAccumulation.cs", LaunchTemporalAccumulation<true, true, true, true>},
     };
     num = sizeof(k) / sizeof(k[0]);
     return k;

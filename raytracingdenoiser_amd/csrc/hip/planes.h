@@ -49,7 +49,7 @@ NRD_D T* TexelPtr(const Plane& p, int x, int y) {
 
 // k / c for a small non-negative integer k held in a float, bit-identical to the IEEE quotient but 3 VALU ops instead
 // of the ~11 of a generic correctly rounded division: q0 = k * RN(1/c), r = fma(-q0, c, k) (exact), q = fma(r, RN(1/c), q0).
-// Exhaustively verified for every numerator the codecs can produce (tests/test_numerics.py: c = 1023, 255, 63, 15, 3).
+// Exhaustively verified for every numerator the codecs can produce (tests/test_numerics.py: c = 65535, 1023, 255, 63, 15, 3).
 NRD_D float DivSmallIntByConst(float k, float c, float rcpC) {
     float q0 = k * rcpC;
     float r = __builtin_fmaf(-q0, c, k);
@@ -57,6 +57,7 @@ NRD_D float DivSmallIntByConst(float k, float c, float rcpC) {
 }
 #define NRD_DIV_1023(k) DivSmallIntByConst(k, 1023.0f, 0.0009775171056389809f)
 #define NRD_DIV_255(k) DivSmallIntByConst(k, 255.0f, 0.003921568859368563f)
+#define NRD_DIV_65535(k) DivSmallIntByConst(k, 65535.0f, 1.5259021893143654e-05f)
 #define NRD_DIV_63(k) DivSmallIntByConst(k, 63.0f, 0.01587301678955555f)
 #define NRD_DIV_15(k) DivSmallIntByConst(k, 15.0f, 0.06666667014360428f)
 #define NRD_DIV_3(k) DivSmallIntByConst(k, 3.0f, 0.3333333432674408f)
@@ -113,6 +114,10 @@ NRD_D uint32_t ToUnorm(float x, float maxValue) { return (uint32_t)floorf(Satura
 
 NRD_D float LoadR8Unorm(const Plane& p, int x, int y) { return NRD_DIV_255(float(*TexelPtr<const uint8_t>(p, x, y))); }
 NRD_D void StoreR8Unorm(const Plane& p, int x, int y, float v) { *TexelPtr<uint8_t>(p, x, y) = (uint8_t)ToUnorm(v, 255.0f); }
+
+// R16_UNORM (signals and fast history of the REBLUR occlusion family)
+NRD_D float LoadR16Unorm(const Plane& p, int x, int y) { return NRD_DIV_65535(float(*TexelPtr<const uint16_t>(p, x, y))); }
+NRD_D void StoreR16Unorm(const Plane& p, int x, int y, float v) { *TexelPtr<uint16_t>(p, x, y) = (uint16_t)ToUnorm(v, 65535.0f); }
 
 NRD_D float2 LoadRG8Unorm(const Plane& p, int x, int y) {
     uint32_t raw = *TexelPtr<const uint16_t>(p, x, y);

@@ -30,7 +30,8 @@ typedef nrdc::ReblurConstants ReblurCB;
 #define REBLUR_ROUGHNESS_SENSITIVITY_IN_TA (NRD_ROUGHNESS_SENSITIVITY * 0.3f)
 #define REBLUR_SAMPLES_PER_FRAME 1.0f
 #define REBLUR_MAX_PERCENT_OF_LOBE_VOLUME_FOR_PRE_PASS 0.3f
-#define REBLUR_COLOR_CLAMPING_SIGMA_SCALE 2.0f
+#define REBLUR_COLOR_CLAMPING_SIGMA_SCALE 2.0f           // radiance signals
+#define REBLUR_COLOR_CLAMPING_SIGMA_SCALE_OCCLUSION 1.0f // REBLUR_OCCLUSION (reference REBLUR_Config.hlsli:94-98)
 
 enum SpatialMode { PRE_BLUR = 0, BLUR = 1, POST_BLUR = 2 };
 
@@ -233,6 +234,15 @@ NRD_D float4 ChangeLuma(float4 v, float newLuma) {
 NRD_D float4 ClampNegativeToZero(float4 v) {
     float3 rgb = LinearToYCoCg(YCoCgToLinear(Xyz(v)));
     return F4(rgb, Sat(v.w));
+}
+// the float overloads of the occlusion family (REBLUR_TYPE = float: the normalised hit distance alone; reference REBLUR_Common.hlsli:148-170)
+NRD_D float ExtractHitDist(float4 v) { return v.w; }
+NRD_D float ExtractHitDist(float v) { return v; }
+NRD_D float GetLuma(float v) { return v; }
+NRD_D float ChangeLuma(float, float newLuma) { return newLuma; }
+NRD_D float ClampNegativeToZero(float v) { return Sat(v); }
+NRD_D float MixHistoryAndCurrent(const ReblurCB& c, float history, float current, float f, float roughness = 1.0f) {
+    return Lerp(history, current, Max(f, GetMinAllowedLimitForHitDistNonLinearAccumSpeed(c, roughness)));
 }
 NRD_D float ComputeAntilag(const ReblurCB& c, float history, float avg, float sigma, float accumSpeed) {
     float h = history, a = avg;
@@ -452,5 +462,45 @@ NRD_D float FetchHistoryBilinearR16F(const HistoryFilter& h, const Plane& tex) {
     float s = Sum(h.bw);
     return s < 0.0001f ? 0.0f : color / s;
 }
+
+
+// REBLUR_TYPE and its storage: radiance + hit distance in RGBA16F with an R16F fast history, or (occlusion family) the hit distance
+// alone in R16_UNORM with an R16_UNORM fast history (reference Reblur.cpp:38-45)
+template <bool OCCLUSION>
+struct ReblurSignal;
+template <>
+struct ReblurSignal<false> {
+    typedef float4 type;
+    static NRD_D float4 Zero() { return F4(0.0f); }
+    static NRD_D float4 Load(const Plane& p, int x, int y) { return LoadRGBA16F(p, x, y); }
+    static NRD_D void Store(const Plane& p, int x, int y, float4 v) { StoreRGBA16F(p, x, y, v); }
+    static NRD_D float4 WithHitDist(float4 s, float hitDist) { return F4(s.x, s.y, s.z, hitDist); }
+    static NRD_D float4 FetchHistory(const HistoryFilter& h, const Plane& tex) { return FetchHistoryRGBA16F(h, tex); }
+    static NRD_D float LoadFast(const Plane& p, int x, int y) { return LoadR16F(p, x, y); }
+    static NRD_D void StoreFast(const Plane& p, int x, int y, float v) { StoreR16F(p, x, y, v); }
+    static NRD_D float FetchFastBilinear(const HistoryFilter& h, const Plane& tex) { return FetchHistoryBilinearR16F(h, tex); }
+};
+template <>
+struct ReblurSignal<true> {
+    typedef float type;
+    static NRD_D float Zero() { return 0.0f; }
+    static NRD_D float Load(const Plane& p, int x, int y) { return LoadR16Unorm(p, x, y); }
+    static NRD_D void Store(const Plane& p, int x, int y, float v) { StoreR16Unorm(p, x, y, v); }
+    static NRD_D float WithHitDist(float, float hitDist) { return hitDist; }
+    static NRD_D float FetchHistory(const HistoryFilter& h, const Plane& tex) {
+        return FetchHistoryGeneric<float>(h, tex, [](const Plane& p, int x, int y) { return LoadR16Unorm(p, x, y); }, 0.0f);
+    }
+    static NRD_D float LoadFast(const Plane& p, int x, int y) { return LoadR16Unorm(p, x, y); }
+    static NRD_D void StoreFast(const Plane& p, int x, int y, float v) { StoreR16Unorm(p, x, y, v); }
+    static NRD_D float FetchFastBilinear(const HistoryFilter& h, const Plane& tex) {
+        auto at = [&](int x, int y) { return InBounds(tex, x, y) ? LoadR16Unorm(tex, x, y) : 0.0f; };
+        float color = at(h.ox, h.oy) * h.bw.x;
+        color += at(h.ox + 1, h.oy) * h.bw.y;
+        color += at(h.ox, h.oy + 1) * h.bw.z;
+        color += at(h.ox + 1, h.oy + 1) * h.bw.w;
+        float s = Sum(h.bw);
+        return s < 0.0001f ? 0.0f : color / s;
+    }
+};
 
 } // namespace nrdhip

@@ -334,6 +334,230 @@ void InstanceImpl::Update_Reblur(const DenoiserData& d) {
     }
 }
 
+// ================================================================================================ occlusion-only family
+// REBLUR_DIFFUSE_OCCLUSION / _SPECULAR_OCCLUSION / _DIFFUSE_SPECULAR_OCCLUSION: the signal is the normalised hit distance alone
+// (R16_UNORM planes), there is no pre-pass and no temporal stabilisation. Tables: reference
+// Source/Denoisers/Reblur_{Diffuse,Specular,DiffuseSpecular}Occlusion.hpp; per-frame selection: Reblur.cpp:212-296.
+namespace {
+constexpr uint32_t OCC_HITDIST_RECONSTRUCTION_PERMUTATIONS = 2;
+constexpr uint32_t OCC_TEMPORAL_ACCUMULATION_PERMUTATIONS = 8;
+enum : uint32_t {
+    OCC_PASS_CLASSIFY_TILES = 0,
+    OCC_PASS_HITDIST_RECONSTRUCTION = OCC_PASS_CLASSIFY_TILES + 1,
+    OCC_PASS_TEMPORAL_ACCUMULATION = OCC_PASS_HITDIST_RECONSTRUCTION + OCC_HITDIST_RECONSTRUCTION_PERMUTATIONS * 2,
+    OCC_PASS_HISTORY_FIX = OCC_PASS_TEMPORAL_ACCUMULATION + OCC_TEMPORAL_ACCUMULATION_PERMUTATIONS * 2,
+    OCC_PASS_BLUR = OCC_PASS_HISTORY_FIX + 2,
+    OCC_PASS_POST_BLUR = OCC_PASS_BLUR + 2,
+    OCC_PASS_SPLIT_SCREEN = OCC_PASS_POST_BLUR + 2,
+    OCC_PASS_VALIDATION = OCC_PASS_SPLIT_SCREEN + 1,
+};
+constexpr Format FMT_OCCLUSION = Format::R16_UNORM;
+constexpr Format FMT_OCCLUSION_FAST = Format::R16_UNORM;
+} // namespace
+
+void InstanceImpl::Add_ReblurOcclusion(DenoiserData& d, bool hasDiff, bool hasSpec) {
+    d.settings.reblur = ReblurSettings();
+    d.settingsSize = sizeof(ReblurSettings);
+
+    const char* family = hasDiff && hasSpec ? "DiffuseSpecularOcclusion" : (hasDiff ? "DiffuseOcclusion" : "SpecularOcclusion");
+    const char* splitScreenFamily = hasDiff && hasSpec ? "DiffuseSpecular" : (hasDiff ? "Diffuse" : "Specular"); // sic: the radiance family's shader
+    const uint32_t constSize = sizeof(nrdc::ReblurConstants);
+
+    uint16_t next = PERMANENT_POOL_START;
+    const uint16_t P_PREV_VIEWZ = next++;
+    const uint16_t P_PREV_NORMAL_ROUGHNESS = next++;
+    const uint16_t P_PREV_INTERNAL_DATA = next++;
+    AddPermanent(FMT_PREV_VIEWZ);
+    AddPermanent(FMT_PREV_NORMAL_ROUGHNESS);
+    AddPermanent(FMT_PREV_INTERNAL_DATA);
+    uint16_t P_DIFF_FAST = 0, P_SPEC_FAST = 0, P_SPEC_HDT_PING = 0, P_SPEC_HDT_PONG = 0;
+    if (hasDiff) {
+        P_DIFF_FAST = next++;
+        AddPermanent(FMT_OCCLUSION_FAST);
+    }
+    if (hasSpec) {
+        P_SPEC_FAST = next++;
+        P_SPEC_HDT_PING = next++;
+        P_SPEC_HDT_PONG = next++;
+        AddPermanent(FMT_OCCLUSION_FAST);
+        AddPermanent(FMT_HITDIST_FOR_TRACKING);
+        AddPermanent(FMT_HITDIST_FOR_TRACKING);
+    }
+
+    next = TRANSIENT_POOL_START;
+    const uint16_t T_DATA1 = next++;
+    AddTransient(hasDiff && hasSpec ? Format::RG8_UNORM : Format::R8_UNORM);
+    uint16_t T_DIFF_TMP2 = 0, T_DIFF_FAST = 0, T_SPEC_TMP2 = 0, T_SPEC_FAST = 0;
+    if (hasDiff) {
+        T_DIFF_TMP2 = next++;
+        T_DIFF_FAST = next++;
+        AddTransient(FMT_OCCLUSION);
+        AddTransient(FMT_OCCLUSION_FAST);
+    }
+    if (hasSpec) {
+        T_SPEC_TMP2 = next++;
+        T_SPEC_FAST = next++;
+        AddTransient(FMT_OCCLUSION);
+        AddTransient(FMT_OCCLUSION_FAST);
+    }
+    const uint16_t T_TILES = next++;
+    AddTransient(FMT_TILES, 16);
+
+    const uint16_t DIFF_TEMP1 = (uint16_t)ResourceType::OUT_DIFF_HITDIST, DIFF_TEMP2 = T_DIFF_TMP2;
+    const uint16_t SPEC_TEMP1 = (uint16_t)ResourceType::OUT_SPEC_HITDIST, SPEC_TEMP2 = T_SPEC_TMP2;
+    const uint16_t IN_DIFF = (uint16_t)ResourceType::IN_DIFF_HITDIST, IN_SPEC = (uint16_t)ResourceType::IN_SPEC_HITDIST;
+
+    char passName[96], shader[128];
+    auto Pass = [&](const char* what) {
+        snprintf(passName, sizeof(passName), "REBLUR_%s - %s", family, what);
+        BeginPass(InternString(passName));
+    };
+    auto EndPair = [&](const char* pass, const char* suffix) {
+        snprintf(shader, sizeof(shader), "REBLUR_%s_%s%s.cs", family, pass, suffix);
+        EndPass(shader, 8, 16, constSize);
+        snprintf(shader, sizeof(shader), "REBLUR_Perf_%s_%s%s.cs", family, pass, suffix);
+        EndPass(shader, 8, 16, constSize);
+    };
+
+    Pass("Classify tiles");
+    In(ResourceType::IN_VIEWZ);
+    Out(T_TILES);
+    EndPass("REBLUR_ClassifyTiles.cs", 16, 16, constSize);
+
+    for (uint32_t i = 0; i < OCC_HITDIST_RECONSTRUCTION_PERMUTATIONS; i++) {
+        bool is5x5 = i & 1;
+        Pass("Hit distance reconstruction");
+        In(T_TILES);
+        In(ResourceType::IN_NORMAL_ROUGHNESS);
+        In(ResourceType::IN_VIEWZ);
+        if (hasDiff) In(IN_DIFF);
+        if (hasSpec) In(IN_SPEC);
+        if (hasDiff) Out(DIFF_TEMP1);
+        if (hasSpec) Out(SPEC_TEMP1);
+        EndPair("HitDistReconstruction", is5x5 ? "_5x5" : "");
+    }
+
+    for (uint32_t i = 0; i < OCC_TEMPORAL_ACCUMULATION_PERMUTATIONS; i++) {
+        bool hasDisocclusionThresholdMix = (i >> 2) & 1, hasConfidenceInputs = (i >> 1) & 1, isAfterReconstruction = i & 1;
+        Pass("Temporal accumulation");
+        In(T_TILES);
+        In(ResourceType::IN_NORMAL_ROUGHNESS);
+        In(ResourceType::IN_VIEWZ);
+        In(ResourceType::IN_MV);
+        In(P_PREV_VIEWZ);
+        In(P_PREV_NORMAL_ROUGHNESS);
+        In(P_PREV_INTERNAL_DATA);
+        In(hasDisocclusionThresholdMix ? (uint16_t)ResourceType::IN_DISOCCLUSION_THRESHOLD_MIX : DUMMY);
+        if (hasDiff) In(hasConfidenceInputs ? (uint16_t)ResourceType::IN_DIFF_CONFIDENCE : DUMMY);
+        if (hasSpec) In(hasConfidenceInputs ? (uint16_t)ResourceType::IN_SPEC_CONFIDENCE : DUMMY);
+        if (hasDiff) In(isAfterReconstruction ? DIFF_TEMP1 : IN_DIFF);
+        if (hasSpec) In(isAfterReconstruction ? SPEC_TEMP1 : IN_SPEC);
+        if (hasDiff) In(ResourceType::OUT_DIFF_HITDIST); // the previous output is the history
+        if (hasSpec) In(ResourceType::OUT_SPEC_HITDIST);
+        if (hasDiff) In(P_DIFF_FAST);
+        if (hasSpec) In(P_SPEC_FAST);
+        if (hasSpec) In(P_SPEC_HDT_PING, P_SPEC_HDT_PONG);
+        if (hasDiff) Out(DIFF_TEMP2);
+        if (hasSpec) Out(SPEC_TEMP2);
+        if (hasDiff) Out(T_DIFF_FAST);
+        if (hasSpec) Out(T_SPEC_FAST);
+        if (hasSpec) Out(P_SPEC_HDT_PONG, P_SPEC_HDT_PING);
+        Out(T_DATA1);
+        EndPair("TemporalAccumulation", "");
+    }
+
+    Pass("History fix");
+    In(T_TILES);
+    In(ResourceType::IN_NORMAL_ROUGHNESS);
+    In(T_DATA1);
+    In(ResourceType::IN_VIEWZ);
+    if (hasDiff) In(DIFF_TEMP2);
+    if (hasSpec) In(SPEC_TEMP2);
+    if (hasDiff) In(T_DIFF_FAST);
+    if (hasSpec) In(T_SPEC_FAST);
+    if (hasDiff) Out(DIFF_TEMP1);
+    if (hasSpec) Out(SPEC_TEMP1);
+    if (hasDiff) Out(P_DIFF_FAST);
+    if (hasSpec) Out(P_SPEC_FAST);
+    EndPair("HistoryFix", "");
+
+    Pass("Blur");
+    In(T_TILES);
+    In(ResourceType::IN_NORMAL_ROUGHNESS);
+    In(T_DATA1);
+    if (hasDiff) In(DIFF_TEMP1);
+    if (hasSpec) In(SPEC_TEMP1);
+    In(ResourceType::IN_VIEWZ);
+    if (hasDiff) Out(DIFF_TEMP2);
+    if (hasSpec) Out(SPEC_TEMP2);
+    Out(P_PREV_VIEWZ);
+    EndPair("Blur", "");
+
+    Pass("Post-blur");
+    In(T_TILES);
+    In(ResourceType::IN_NORMAL_ROUGHNESS);
+    In(T_DATA1);
+    if (hasDiff) In(DIFF_TEMP2);
+    if (hasSpec) In(SPEC_TEMP2);
+    In(P_PREV_VIEWZ);
+    Out(P_PREV_NORMAL_ROUGHNESS);
+    if (hasDiff) Out(ResourceType::OUT_DIFF_HITDIST);
+    if (hasSpec) Out(ResourceType::OUT_SPEC_HITDIST);
+    Out(P_PREV_INTERNAL_DATA);
+    EndPair("PostBlur", "_NoTemporalStabilization");
+
+    Pass("Split screen");
+    In(ResourceType::IN_VIEWZ);
+    if (hasDiff) In(IN_DIFF);
+    if (hasSpec) In(IN_SPEC);
+    if (hasDiff) Out(ResourceType::OUT_DIFF_HITDIST);
+    if (hasSpec) Out(ResourceType::OUT_SPEC_HITDIST);
+    snprintf(shader, sizeof(shader), "REBLUR_%s_SplitScreen.cs", splitScreenFamily);
+    EndPass(shader, 8, 16, constSize);
+
+    Pass("Validation");
+    In(ResourceType::IN_NORMAL_ROUGHNESS);
+    In(ResourceType::IN_VIEWZ);
+    In(ResourceType::IN_MV);
+    In(T_DATA1);
+    In(T_DATA1); // sic: no DATA2 in the occlusion family
+    In(hasDiff ? IN_DIFF : IN_SPEC);
+    In(hasSpec ? IN_SPEC : IN_DIFF);
+    Out(ResourceType::OUT_VALIDATION);
+    EndPass("REBLUR_Validation.cs", 8, 16, sizeof(nrdc::ReblurValidationConstants), IGNORE_RS);
+}
+
+void InstanceImpl::Update_ReblurOcclusion(const DenoiserData& d) {
+    const ReblurSettings& s = d.settings.reblur;
+    const CommonSettings& cs = m_CommonSettings;
+    const bool hasDiff = d.desc.denoiser != Denoiser::REBLUR_SPECULAR_OCCLUSION;
+    const bool hasSpec = d.desc.denoiser != Denoiser::REBLUR_DIFFUSE_OCCLUSION;
+    const bool enableHitDistanceReconstruction = s.hitDistanceReconstructionMode != HitDistanceReconstructionMode::OFF && s.checkerboardMode == CheckerboardMode::OFF;
+    const uint32_t perf = s.enablePerformanceMode ? 1 : 0;
+
+    auto Emit = [&](uint32_t localIndex) { FillReblurConstants(s, PushDispatch(d, localIndex)); };
+
+    if (cs.splitScreen >= 1.0f) {
+        Emit(OCC_PASS_SPLIT_SCREEN);
+        return;
+    }
+    Emit(OCC_PASS_CLASSIFY_TILES);
+    if (enableHitDistanceReconstruction)
+        Emit(OCC_PASS_HITDIST_RECONSTRUCTION + (s.hitDistanceReconstructionMode == HitDistanceReconstructionMode::AREA_5X5 ? 2 : 0) + perf);
+    Emit(OCC_PASS_TEMPORAL_ACCUMULATION + (cs.isDisocclusionThresholdMixAvailable ? 8 : 0) + (cs.isHistoryConfidenceAvailable ? 4 : 0) + (enableHitDistanceReconstruction ? 2 : 0) + perf);
+    Emit(OCC_PASS_HISTORY_FIX + (!s.enableAntiFirefly ? 1 : 0)); // sic (reference Reblur.cpp:264): the permutation follows enableAntiFirefly, not the performance mode
+    Emit(OCC_PASS_BLUR + perf);
+    Emit(OCC_PASS_POST_BLUR + perf);
+    if (cs.splitScreen > 0.0f)
+        Emit(OCC_PASS_SPLIT_SCREEN);
+    if (cs.enableValidation) {
+        auto* c = (nrdc::ReblurValidationConstants*)PushDispatch(d, OCC_PASS_VALIDATION);
+        FillReblurConstants(s, c);
+        c->gHasDiffuse = hasDiff ? 1 : 0;
+        c->gHasSpecular = hasSpec ? 1 : 0;
+    }
+}
+
 static void StoreMatrix(float* dst, const nrdhost::Mat4& m) { memcpy(dst, &m, sizeof(float) * 16); }
 
 void InstanceImpl::FillReblurConstants(const ReblurSettings& s, void* data) {

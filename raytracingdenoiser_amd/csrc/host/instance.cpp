@@ -133,6 +133,15 @@ Result InstanceImpl::Create(const InstanceCreationDesc& desc) {
             case Denoiser::REBLUR_DIFFUSE_SPECULAR:
                 Add_Reblur(data, true, true);
                 break;
+            case Denoiser::REBLUR_DIFFUSE_OCCLUSION:
+                Add_ReblurOcclusion(data, true, false);
+                break;
+            case Denoiser::REBLUR_SPECULAR_OCCLUSION:
+                Add_ReblurOcclusion(data, false, true);
+                break;
+            case Denoiser::REBLUR_DIFFUSE_SPECULAR_OCCLUSION:
+                Add_ReblurOcclusion(data, true, true);
+                break;
             case Denoiser::RELAX_DIFFUSE:
             case Denoiser::RELAX_DIFFUSE_SH:
             case Denoiser::RELAX_SPECULAR:
@@ -517,6 +526,11 @@ Result InstanceImpl::GetComputeDispatches(const Identifier* identifiers, uint32_
             case Denoiser::REBLUR_SPECULAR:
             case Denoiser::REBLUR_DIFFUSE_SPECULAR:
                 Update_Reblur(d);
+                break;
+            case Denoiser::REBLUR_DIFFUSE_OCCLUSION:
+            case Denoiser::REBLUR_SPECULAR_OCCLUSION:
+            case Denoiser::REBLUR_DIFFUSE_SPECULAR_OCCLUSION:
+                Update_ReblurOcclusion(d);
                 break;
             case Denoiser::RELAX_DIFFUSE:
             case Denoiser::RELAX_DIFFUSE_SH:

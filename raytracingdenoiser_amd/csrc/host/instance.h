@@ -115,6 +115,8 @@ private:
 
     void Add_Reblur(DenoiserData& d, bool hasDiff, bool hasSpec);
     void Update_Reblur(const DenoiserData& d);
+    void Add_ReblurOcclusion(DenoiserData& d, bool hasDiff, bool hasSpec);
+    void Update_ReblurOcclusion(const DenoiserData& d);
     void FillReblurConstants(const ReblurSettings& settings, void* data);
 
     void Add_Relax(DenoiserData& d, bool hasDiff, bool hasSpec, bool sh);

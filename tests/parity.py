@@ -27,6 +27,9 @@ DENOISERS = {
     "REBLUR_DIFFUSE": (api.Denoiser.REBLUR_DIFFUSE, ("reblur",)),
     "REBLUR_SPECULAR": (api.Denoiser.REBLUR_SPECULAR, ("reblur",)),
     "REBLUR_DIFFUSE_SPECULAR": (api.Denoiser.REBLUR_DIFFUSE_SPECULAR, ("reblur",)),
+    "REBLUR_DIFFUSE_OCCLUSION": (api.Denoiser.REBLUR_DIFFUSE_OCCLUSION, ("reblur",)),
+    "REBLUR_SPECULAR_OCCLUSION": (api.Denoiser.REBLUR_SPECULAR_OCCLUSION, ("reblur",)),
+    "REBLUR_DIFFUSE_SPECULAR_OCCLUSION": (api.Denoiser.REBLUR_DIFFUSE_SPECULAR_OCCLUSION, ("reblur",)),
     "SIGMA_SHADOW": (api.Denoiser.SIGMA_SHADOW, ("sigma",)),
     "SIGMA_SHADOW_TRANSLUCENCY": (api.Denoiser.SIGMA_SHADOW_TRANSLUCENCY, ("sigma",)),
     "RELAX_DIFFUSE": (api.Denoiser.RELAX_DIFFUSE, ("relax",)),
@@ -55,12 +58,22 @@ def user_planes(name, frame):
     return _user_planes(name, frame) + extra
 
 
+def _hitdist_unorm16(signal):
+    """normalised hit distance (.w of a packed REBLUR signal) as R16_UNORM texels (int16 tensor holding the uint16 bit patterns)"""
+    q = torch.floor(signal[..., 3].float().clamp(0.0, 1.0) * 65535.0 + 0.5).to(torch.int32)
+    return torch.where(q >= 32768, q - 65536, q).to(torch.int16).contiguous()
+
+
 def _user_planes(name, frame):
     planes = [(RT.IN_MV, frame["mv"], F.RGBA16_SFLOAT), (RT.IN_NORMAL_ROUGHNESS, frame["normal_roughness"], F.R10_G10_B10_A2_UNORM), (RT.IN_VIEWZ, frame["viewz"], F.R32_SFLOAT)]
     if name in ("REBLUR_DIFFUSE", "REBLUR_DIFFUSE_SPECULAR"):
         planes.append((RT.IN_DIFF_RADIANCE_HITDIST, frame["diff"], F.RGBA16_SFLOAT))
     if name in ("REBLUR_SPECULAR", "REBLUR_DIFFUSE_SPECULAR"):
         planes.append((RT.IN_SPEC_RADIANCE_HITDIST, frame["spec"], F.RGBA16_SFLOAT))
+    if name in ("REBLUR_DIFFUSE_OCCLUSION", "REBLUR_DIFFUSE_SPECULAR_OCCLUSION"):
+        planes.append((RT.IN_DIFF_HITDIST, _hitdist_unorm16(frame["diff"]), F.R16_UNORM))
+    if name in ("REBLUR_SPECULAR_OCCLUSION", "REBLUR_DIFFUSE_SPECULAR_OCCLUSION"):
+        planes.append((RT.IN_SPEC_HITDIST, _hitdist_unorm16(frame["spec"]), F.R16_UNORM))
     if name.startswith("SIGMA_SHADOW"):
         planes.append((RT.IN_PENUMBRA, frame["penumbra"], F.R16_SFLOAT))
     if name == "SIGMA_SHADOW_TRANSLUCENCY":
@@ -85,6 +98,10 @@ def output_planes(name, width, height):
         outs.append((RT.OUT_DIFF_RADIANCE_HITDIST, torch.float16, 4, F.RGBA16_SFLOAT))
     if name in ("REBLUR_SPECULAR", "REBLUR_DIFFUSE_SPECULAR"):
         outs.append((RT.OUT_SPEC_RADIANCE_HITDIST, torch.float16, 4, F.RGBA16_SFLOAT))
+    if name in ("REBLUR_DIFFUSE_OCCLUSION", "REBLUR_DIFFUSE_SPECULAR_OCCLUSION"):
+        outs.append((RT.OUT_DIFF_HITDIST, torch.int16, 1, F.R16_UNORM))
+    if name in ("REBLUR_SPECULAR_OCCLUSION", "REBLUR_DIFFUSE_SPECULAR_OCCLUSION"):
+        outs.append((RT.OUT_SPEC_HITDIST, torch.int16, 1, F.R16_UNORM))
     if name == "SIGMA_SHADOW":
         outs.append((RT.OUT_SHADOW_TRANSLUCENCY, torch.uint8, 1, F.R8_UNORM))
     if name == "SIGMA_SHADOW_TRANSLUCENCY":
@@ -133,7 +150,7 @@ def decode_plane(raw, fmt, width):
         return body.reshape(h, width, 2).astype(np.float32)
     if fmt == F.RGBA8_UNORM:
         return body.reshape(h, width, 4).astype(np.float32)
-    if fmt == F.R16_UINT:
+    if fmt in (F.R16_UINT, F.R16_UNORM):
         return body.view(np.uint16).reshape(h, width, 1).astype(np.float32)
     if fmt in (F.R32_UINT, F.R10_G10_B10_A2_UNORM):
         return body.view(np.uint32).reshape(h, width, 1).astype(np.float64)
@@ -158,7 +175,7 @@ class OracleRun:
         self.ex = oracle_driver.OracleExecutor(self.inst, width, height, api.FORMAT_BYTES, threads=threads)
         self.outs = {}
         for rt, dtype, ch, fmt in output_planes(name, width, height):
-            arr = np.zeros((height, width, ch), dtype=np.float16 if dtype == torch.float16 else np.uint8)
+            arr = np.zeros((height, width, ch), dtype={torch.float16: np.float16, torch.int16: np.uint16}.get(dtype, np.uint8))
             self.outs[rt] = (arr, fmt)
             self.ex.bind(rt, arr, fmt)
         self.last_dispatches = []
@@ -202,7 +219,8 @@ class HipRun:
 
     def output(self, rt):
         t, fmt = self.outs[rt]
-        return t.cpu().numpy().astype(np.float32)
+        a = t.cpu().numpy()
+        return (a.view(np.uint16) if a.dtype == np.int16 else a).astype(np.float32)  # int16 tensors hold R16_UNORM bit patterns
 
 
 def generate_sequence(name, width, height, frames, static_camera=False, noise=True, device="cpu", extra_want=()):

@@ -102,7 +102,7 @@ def test_hip_exact_constant_division_and_gaussian_constants():
 
     lib = api.load_library()
     stream = torch.cuda.current_stream().cuda_stream
-    for op, c, n in ((8, 1023.0, 1024), (9, 255.0, 256), (10, 63.0, 64), (11, 15.0, 16), (12, 3.0, 4)):
+    for op, c, n in ((8, 1023.0, 1024), (9, 255.0, 256), (10, 63.0, 64), (11, 15.0, 16), (12, 3.0, 4), (14, 65535.0, 65536)):
         k = np.arange(n, dtype=np.float32)
         t, out = torch.from_numpy(k).cuda(), torch.empty(n, device="cuda")
         assert lib.nrdHipEvalNumerics(op, t.data_ptr(), None, out.data_ptr(), n, stream) == 0

@@ -169,3 +169,57 @@ def test_hip_matches_oracle_performance_mode_options():
     worst = parity.run_parity("REBLUR_DIFFUSE_SPECULAR", width=160, height=96, frames=3, verbose=True, extra_want=("holes",),
                               settings_overrides=dict(enablePerformanceMode=True, hitDistanceReconstructionMode=2, diffusePrepassBlurRadius=0.0, specularPrepassBlurRadius=0.0))
     assert worst <= parity.REL_TOL
+
+
+# ---------------------------------------------------------------------------------------------- occlusion family
+OCCLUSION = ["REBLUR_DIFFUSE_SPECULAR_OCCLUSION", "REBLUR_DIFFUSE_OCCLUSION", "REBLUR_SPECULAR_OCCLUSION"]
+
+
+def test_oracle_occlusion_family_tables_and_denoising():
+    """REBLUR_*_OCCLUSION (reference Denoisers/Reblur_*Occlusion.hpp, Reblur.cpp:212-296): hit distance only, R16_UNORM planes, no pre-pass, no
+    temporal stabilisation; the history-fix permutation follows enableAntiFirefly (a reference quirk); diffuse output is independent of the
+    specular signal; the filter keeps the mean and lowers the noise."""
+    seq = parity.generate_sequence("REBLUR_DIFFUSE_SPECULAR_OCCLUSION", W, H, 6)
+    ds = _run_oracle("REBLUR_DIFFUSE_SPECULAR_OCCLUSION", seq)
+    assert [d.shader for d in ds.last_dispatches] == [
+        "REBLUR_ClassifyTiles.cs", "REBLUR_DiffuseSpecularOcclusion_TemporalAccumulation.cs", "REBLUR_Perf_DiffuseSpecularOcclusion_HistoryFix.cs",
+        "REBLUR_DiffuseSpecularOcclusion_Blur.cs", "REBLUR_DiffuseSpecularOcclusion_PostBlur_NoTemporalStabilization.cs"]
+    assert [f for f, _ in ds.inst.permanent_pool] == [api.Format.R32_SFLOAT, api.Format.R10_G10_B10_A2_UNORM, api.Format.R16_UINT, api.Format.R16_UNORM, api.Format.R16_UNORM,
+                                                      api.Format.R16_SFLOAT, api.Format.R16_SFLOAT]
+    af = _run_oracle("REBLUR_DIFFUSE_SPECULAR_OCCLUSION", seq[:2], overrides=dict(enableAntiFirefly=True, enablePerformanceMode=True, hitDistanceReconstructionMode=2))
+    assert [d.shader for d in af.last_dispatches][1:4] == ["REBLUR_Perf_DiffuseSpecularOcclusion_HitDistReconstruction_5x5.cs",
+                                                           "REBLUR_Perf_DiffuseSpecularOcclusion_TemporalAccumulation.cs", "REBLUR_DiffuseSpecularOcclusion_HistoryFix.cs"]
+    d_only = _run_oracle("REBLUR_DIFFUSE_OCCLUSION", seq)
+    assert np.array_equal(d_only.output(RT.OUT_DIFF_HITDIST), ds.output(RT.OUT_DIFF_HITDIST))
+    m = ~seq[-1]["is_sky"].numpy()
+    for rt, key in ((RT.OUT_DIFF_HITDIST, "diff"), (RT.OUT_SPEC_HITDIST, "spec")):
+        out, noisy = ds.output(rt)[m][:, 0] / 65535.0, seq[-1][key].float().numpy()[m][:, 3]
+        assert abs(out.mean() - noisy.mean()) < 0.03 and out.std() < 0.8 * noisy.std()
+
+
+def test_oracle_occlusion_constant_signal_is_a_fixed_point():
+    seq = parity.generate_sequence("REBLUR_DIFFUSE_OCCLUSION", W, H, 4)
+    for fr in seq:
+        fr["diff"][..., 3] = 0.5
+    out = _run_oracle("REBLUR_DIFFUSE_OCCLUSION", seq).output(RT.OUT_DIFF_HITDIST)[..., 0]
+    m = ~np.any(np.stack([fr["is_sky"].numpy() for fr in seq]), axis=0)
+    d = np.abs(out[m] - 32768.0)  # 0.5 in R16_UNORM; every pass of every frame re-quantises a normalised mean of equal values
+    assert d.max() <= 8.0 and np.mean(d == 0.0) > 0.99
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", OCCLUSION)
+def test_hip_matches_oracle_occlusion(name):
+    worst = parity.run_parity(name, width=192, height=128, frames=6, verbose=True)
+    assert worst <= parity.REL_TOL
+
+
+@pytest.mark.gpu
+def test_hip_matches_oracle_occlusion_options():
+    # odd size (user-plane pitch != pool pitch), performance mode, 3x3 reconstruction of missing hit distances, quality history-fix permutation
+    worst = parity.run_parity("REBLUR_DIFFUSE_SPECULAR_OCCLUSION", width=211, height=117, frames=4, verbose=True, extra_want=("holes",),
+                              settings_overrides=dict(enablePerformanceMode=True, hitDistanceReconstructionMode=1, enableAntiFirefly=True))
+    assert worst <= parity.REL_TOL
+    worst = parity.run_parity("REBLUR_SPECULAR_OCCLUSION", width=160, height=96, frames=4, verbose=True, extra_want=("holes", "confidence"),
+                              settings_overrides=dict(hitDistanceReconstructionMode=2), cs_kw=dict(isHistoryConfidenceAvailable=True, isDisocclusionThresholdMixAvailable=True))
+    assert worst <= parity.REL_TOL
