@@ -62,7 +62,8 @@ struct SpatialCtx { // what PrePass / Blur / PostBlur share per pixel
 };
 
 template <typename S> // S = REBLUR_TYPE: float4 (radiance + hit distance) or float (occlusion: hit distance only)
-S DiffuseSpatialFilter(const ReblurCB& c, SpatialMode mode, const SpatialCtx& s, S diff, const Tex& gIn_Diff, const Tex& gIn_ViewZ, const Tex& gIn_Normal_Roughness) {
+S DiffuseSpatialFilter(const ReblurCB& c, SpatialMode mode, const SpatialCtx& s, S diff, const Tex& gIn_Diff, const Tex& gIn_ViewZ, const Tex& gIn_Normal_Roughness,
+    float4* diffSh = nullptr, const Tex* gIn_DiffSh = nullptr) { // REBLUR_SH: the SH1 plane is filtered with the same weights (all 4 components)
     constexpr bool OCC = sizeof(S) == sizeof(float);
     typedef ReblurSignal<OCC> Sig;
     if (mode == PRE_BLUR && c.gDiffPrepassBlurRadius == 0.0f)
@@ -146,17 +147,24 @@ S DiffuseSpatialFilter(const ReblurCB& c, SpatialMode mode, const SpatialCtx& s,
 
         sum += w;
         diff = diff + smp * w;
+        if (diffSh) {
+            float4 sh = gIn_DiffSh->SampleNearest(uvScaled);
+            sh = w == 0.0f ? float4(0.0f) : sh;
+            *diffSh += sh * w;
+        }
     }
 
     float invSum = Math::PositiveRcp(sum);
     diff = diff * invSum;
+    if (diffSh)
+        *diffSh *= invSum;
     return diff;
 }
 
 // returns the filtered signal; for the pre-pass also produces hitDistForTracking (written only if the radius != 0)
 template <typename S>
 S SpecularSpatialFilter(const ReblurCB& c, SpatialMode mode, const SpatialCtx& s, S spec, const Tex& gIn_Spec, const Tex& gIn_ViewZ,
-    const Tex& gIn_Normal_Roughness, Tex* gOut_SpecHitDistForTracking) {
+    const Tex& gIn_Normal_Roughness, Tex* gOut_SpecHitDistForTracking, float4* specSh = nullptr, const Tex* gIn_SpecSh = nullptr) { // REBLUR_SH: .xyz only (.w = roughness for AA)
     constexpr bool OCC = sizeof(S) == sizeof(float);
     typedef ReblurSignal<OCC> Sig;
     float smc = GetSpecMagicCurve(s.roughness);
@@ -288,10 +296,17 @@ S SpecularSpatialFilter(const ReblurCB& c, SpatialMode mode, const SpatialCtx& s
 
         sum += w;
         spec = spec + smp * w;
+        if (specSh) {
+            float4 sh = gIn_SpecSh->SampleNearest(uvScaled);
+            sh = w == 0.0f ? float4(0.0f) : sh;
+            specSh->x += sh.x * w, specSh->y += sh.y * w, specSh->z += sh.z * w;
+        }
     }
 
     float invSum = Math::PositiveRcp(sum);
     spec = spec * invSum;
+    if (specSh)
+        specSh->x *= invSum, specSh->y *= invSum, specSh->z *= invSum;
 
     if (mode == PRE_BLUR)
         gOut_SpecHitDistForTracking->Store(s.px, s.py, hitDistForTracking == NRD_INF ? 0.0f : hitDistForTracking);
@@ -328,7 +343,7 @@ bool MakeSpatialCtx(const ReblurCB& c, int px, int py, const Tex& gIn_Tiles, con
 }
 
 // ================================================================================================ PrePass
-template <bool DIFF, bool SPEC, bool PERF>
+template <bool DIFF, bool SPEC, bool PERF, bool SH>
 void PrePass(const PassIO& io) {
     const ReblurCB& c = *(const ReblurCB*)io.constants;
     Cursor cur(io);
@@ -337,9 +352,13 @@ void PrePass(const PassIO& io) {
     const Tex& gIn_ViewZ = *cur.next();
     const Tex* gIn_Diff = cur.nextIf(DIFF);
     const Tex* gIn_Spec = cur.nextIf(SPEC);
+    const Tex* gIn_DiffSh = cur.nextIf(DIFF && SH);
+    const Tex* gIn_SpecSh = cur.nextIf(SPEC && SH);
     Tex* gOut_Diff = cur.nextIf(DIFF);
     Tex* gOut_Spec = cur.nextIf(SPEC);
     Tex* gOut_SpecHitDistForTracking = cur.nextIf(SPEC);
+    Tex* gOut_DiffSh = cur.nextIf(DIFF && SH);
+    Tex* gOut_SpecSh = cur.nextIf(SPEC && SH);
 
 #pragma omp parallel for schedule(dynamic, 4)
     for (int py = 0; py < (int)c.gRectSize.y; py++)
@@ -349,19 +368,25 @@ void PrePass(const PassIO& io) {
                 continue;
             if (DIFF) {
                 float4 diff = gIn_Diff->Load(px, py);
-                diff = DiffuseSpatialFilter<float4>(c, PRE_BLUR, s, diff, *gIn_Diff, gIn_ViewZ, gIn_Normal_Roughness);
+                float4 diffSh = SH ? gIn_DiffSh->Load(px, py) : float4(0.0f);
+                diff = DiffuseSpatialFilter<float4>(c, PRE_BLUR, s, diff, *gIn_Diff, gIn_ViewZ, gIn_Normal_Roughness, SH ? &diffSh : nullptr, gIn_DiffSh);
                 gOut_Diff->Store(px, py, diff);
+                if (SH)
+                    gOut_DiffSh->Store(px, py, diffSh);
             }
             if (SPEC) {
                 float4 spec = gIn_Spec->Load(px, py);
-                spec = SpecularSpatialFilter<float4>(c, PRE_BLUR, s, spec, *gIn_Spec, gIn_ViewZ, gIn_Normal_Roughness, gOut_SpecHitDistForTracking);
+                float4 specSh = SH ? gIn_SpecSh->Load(px, py) : float4(0.0f);
+                spec = SpecularSpatialFilter<float4>(c, PRE_BLUR, s, spec, *gIn_Spec, gIn_ViewZ, gIn_Normal_Roughness, gOut_SpecHitDistForTracking, SH ? &specSh : nullptr, gIn_SpecSh);
                 gOut_Spec->Store(px, py, spec);
+                if (SH)
+                    gOut_SpecSh->Store(px, py, specSh);
             }
         }
 }
 
 // ================================================================================================ Blur
-template <bool DIFF, bool SPEC, bool PERF, bool OCC>
+template <bool DIFF, bool SPEC, bool PERF, bool OCC, bool SH>
 void Blur(const PassIO& io) {
     typedef ReblurSignal<OCC> Sig;
     typedef typename Sig::type S;
@@ -373,9 +398,13 @@ void Blur(const PassIO& io) {
     const Tex* gIn_Diff = cur.nextIf(DIFF);
     const Tex* gIn_Spec = cur.nextIf(SPEC);
     const Tex& gIn_ViewZ = *cur.next();
+    const Tex* gIn_DiffSh = cur.nextIf(DIFF && SH);
+    const Tex* gIn_SpecSh = cur.nextIf(SPEC && SH);
     Tex* gOut_Diff = cur.nextIf(DIFF);
     Tex* gOut_Spec = cur.nextIf(SPEC);
     Tex& gOut_ViewZ = *cur.next();
+    Tex* gOut_DiffSh = cur.nextIf(DIFF && SH);
+    Tex* gOut_SpecSh = cur.nextIf(SPEC && SH);
 
 #pragma omp parallel for schedule(dynamic, 4)
     for (int py = 0; py < (int)c.gRectSize.y; py++)
@@ -392,19 +421,25 @@ void Blur(const PassIO& io) {
             s.data1 = UnpackData1(gIn_Data1.Load(px, py), DIFF);
             if (DIFF) {
                 S diff = Sig::From(gIn_Diff->Load(px, py));
-                diff = DiffuseSpatialFilter<S>(c, BLUR, s, diff, *gIn_Diff, gIn_ViewZ, gIn_Normal_Roughness);
+                float4 diffSh = SH ? gIn_DiffSh->Load(px, py) : float4(0.0f);
+                diff = DiffuseSpatialFilter<S>(c, BLUR, s, diff, *gIn_Diff, gIn_ViewZ, gIn_Normal_Roughness, SH ? &diffSh : nullptr, gIn_DiffSh);
                 gOut_Diff->Store(px, py, diff);
+                if (SH)
+                    gOut_DiffSh->Store(px, py, diffSh);
             }
             if (SPEC) {
                 S spec = Sig::From(gIn_Spec->Load(px, py));
-                spec = SpecularSpatialFilter<S>(c, BLUR, s, spec, *gIn_Spec, gIn_ViewZ, gIn_Normal_Roughness, nullptr);
+                float4 specSh = SH ? gIn_SpecSh->Load(px, py) : float4(0.0f);
+                spec = SpecularSpatialFilter<S>(c, BLUR, s, spec, *gIn_Spec, gIn_ViewZ, gIn_Normal_Roughness, nullptr, SH ? &specSh : nullptr, gIn_SpecSh);
                 gOut_Spec->Store(px, py, spec);
+                if (SH)
+                    gOut_SpecSh->Store(px, py, specSh);
             }
         }
 }
 
 // ================================================================================================ PostBlur
-template <bool DIFF, bool SPEC, bool NO_TS, bool PERF, bool OCC>
+template <bool DIFF, bool SPEC, bool NO_TS, bool PERF, bool OCC, bool SH>
 void PostBlur(const PassIO& io) {
     typedef ReblurSignal<OCC> Sig;
     typedef typename Sig::type S;
@@ -416,12 +451,18 @@ void PostBlur(const PassIO& io) {
     const Tex* gIn_Diff = cur.nextIf(DIFF);
     const Tex* gIn_Spec = cur.nextIf(SPEC);
     const Tex& gIn_ViewZ = *cur.next(); // PREV_VIEWZ written by Blur
+    const Tex* gIn_DiffSh = cur.nextIf(DIFF && SH);
+    const Tex* gIn_SpecSh = cur.nextIf(SPEC && SH);
     Tex& gOut_Normal_Roughness = *cur.next();
     Tex* gOut_Diff = cur.nextIf(DIFF);
     Tex* gOut_Spec = cur.nextIf(SPEC);
     Tex* gOut_InternalData = cur.nextIf(NO_TS);
     Tex* gOut_DiffCopy = cur.nextIf(NO_TS && DIFF && !OCC); // no copy in the occlusion family (the output itself is next frame's history)
     Tex* gOut_SpecCopy = cur.nextIf(NO_TS && SPEC && !OCC);
+    Tex* gOut_DiffShCopy = cur.nextIf(NO_TS && DIFF && SH);
+    Tex* gOut_SpecShCopy = cur.nextIf(NO_TS && SPEC && SH);
+    Tex* gOut_DiffSh = cur.nextIf(DIFF && SH);
+    Tex* gOut_SpecSh = cur.nextIf(SPEC && SH);
 
 #pragma omp parallel for schedule(dynamic, 4)
     for (int py = 0; py < (int)c.gRectSize.y; py++)
@@ -437,23 +478,33 @@ void PostBlur(const PassIO& io) {
 
             if (DIFF) {
                 S diff = Sig::From(gIn_Diff->Load(px, py));
-                diff = DiffuseSpatialFilter<S>(c, POST_BLUR, s, diff, *gIn_Diff, gIn_ViewZ, gIn_Normal_Roughness);
+                float4 diffSh = SH ? gIn_DiffSh->Load(px, py) : float4(0.0f);
+                diff = DiffuseSpatialFilter<S>(c, POST_BLUR, s, diff, *gIn_Diff, gIn_ViewZ, gIn_Normal_Roughness, SH ? &diffSh : nullptr, gIn_DiffSh);
                 gOut_Diff->Store(px, py, diff);
+                if (SH)
+                    gOut_DiffSh->Store(px, py, diffSh);
                 if (NO_TS && !OCC)
                     gOut_DiffCopy->Store(px, py, diff);
+                if (NO_TS && SH)
+                    gOut_DiffShCopy->Store(px, py, diffSh);
             }
             if (SPEC) {
                 S spec = Sig::From(gIn_Spec->Load(px, py));
-                spec = SpecularSpatialFilter<S>(c, POST_BLUR, s, spec, *gIn_Spec, gIn_ViewZ, gIn_Normal_Roughness, nullptr);
+                float4 specSh = SH ? gIn_SpecSh->Load(px, py) : float4(0.0f);
+                spec = SpecularSpatialFilter<S>(c, POST_BLUR, s, spec, *gIn_Spec, gIn_ViewZ, gIn_Normal_Roughness, nullptr, SH ? &specSh : nullptr, gIn_SpecSh);
                 gOut_Spec->Store(px, py, spec);
+                if (SH)
+                    gOut_SpecSh->Store(px, py, specSh);
                 if (NO_TS && !OCC)
                     gOut_SpecCopy->Store(px, py, spec);
+                if (NO_TS && SH)
+                    gOut_SpecShCopy->Store(px, py, specSh);
             }
         }
 }
 
 // ================================================================================================ TemporalAccumulation
-template <bool DIFF, bool SPEC, bool PERF, bool OCC>
+template <bool DIFF, bool SPEC, bool PERF, bool OCC, bool SH>
 void TemporalAccumulation(const PassIO& io) {
     typedef ReblurSignal<OCC> Sig;
     typedef typename Sig::type S;
@@ -477,6 +528,10 @@ void TemporalAccumulation(const PassIO& io) {
     const Tex* gHistory_SpecFast = cur.nextIf(SPEC);
     const Tex* gPrev_SpecHitDistForTracking = cur.nextIf(SPEC);
     const Tex* gIn_SpecHitDistForTracking = cur.nextIf(SPEC && !OCC); // written by the pre-pass, which the occlusion family does not have
+    const Tex* gIn_DiffSh = cur.nextIf(DIFF && SH);
+    const Tex* gIn_SpecSh = cur.nextIf(SPEC && SH);
+    const Tex* gHistory_DiffSh = cur.nextIf(DIFF && SH);
+    const Tex* gHistory_SpecSh = cur.nextIf(SPEC && SH);
     Tex* gOut_Diff = cur.nextIf(DIFF);
     Tex* gOut_Spec = cur.nextIf(SPEC);
     Tex* gOut_DiffFast = cur.nextIf(DIFF);
@@ -484,6 +539,8 @@ void TemporalAccumulation(const PassIO& io) {
     Tex* gOut_SpecHitDistForTracking = cur.nextIf(SPEC);
     Tex& gOut_Data1 = *cur.next();
     Tex* gOut_Data2 = cur.nextIf(!OCC); // REBLUR_TemporalAccumulation.hlsli:822-824
+    Tex* gOut_DiffSh = cur.nextIf(DIFF && SH);
+    Tex* gOut_SpecSh = cur.nextIf(SPEC && SH);
 
     const int rw = c.gRectSizeMinusOne[0], rh = c.gRectSizeMinusOne[1];
 
@@ -975,6 +1032,17 @@ void TemporalAccumulation(const PassIO& io) {
                 S vmbSpec = MixHistoryAndCurrent(c, vmbSpecHistory, spec, vmbSpecNonLinearAccumSpeed, roughnessModified);
                 S specResult = lerp(smbSpec, vmbSpec, virtualHistoryAmount);
 
+                float4 specShResult = float4(0.0f);
+                if (SH) { // REBLUR_TemporalAccumulation.hlsli:742-751; the SH history is fetched with the custom-weight bilinear filter (REBLUR_Common.hlsli:350-361)
+                    float4 smbSpecShHistory = FetchHistoryBilinear(smbFilter, *gHistory_SpecSh);
+                    float4 vmbSpecShHistory = FetchHistoryBilinear(vmbFilter, *gHistory_SpecSh);
+                    float4 specSh = gIn_SpecSh->Load(px, py);
+                    float4 smbShSpec = lerp(smbSpecShHistory, specSh, smbSpecNonLinearAccumSpeed);
+                    float4 vmbShSpec = lerp(vmbSpecShHistory, specSh, vmbSpecNonLinearAccumSpeed);
+                    specShResult = lerp(smbShSpec, vmbShSpec, virtualHistoryAmount);
+                    specShResult.w = roughnessModified; // assists AA during the SG resolve; never blurred
+                }
+
                 specAccumSpeed = lerp(smbSpecAccumSpeedBoosted, vmbSpecAccumSpeed, virtualHistoryAmount);
                 S specHistory = lerp(smbSpecHistory, vmbSpecHistory, virtualHistoryAmount);
 
@@ -989,9 +1057,15 @@ void TemporalAccumulation(const PassIO& io) {
                     float specLumaClamped = min(specLumaResult, GetLuma(specHistory) * specMaxRelativeIntensity);
                     specLumaClamped = lerp(specLumaResult, specLumaClamped, specAntifireflyFactor);
                     specResult = ChangeLuma(specResult, specLumaClamped);
+                    if (SH) {
+                        float k = GetLumaScale(length(specShResult.xyz()), specLumaClamped);
+                        specShResult.x *= k, specShResult.y *= k, specShResult.z *= k;
+                    }
                 }
 
                 gOut_Spec->Store(px, py, specResult);
+                if (SH)
+                    gOut_SpecSh->Store(px, py, specShResult);
 
                 // Fast history
                 float smbSpecFastNonLinearAccumSpeed = GetNonLinearAccumSpeed(smbSpecAccumSpeed, c.gMaxFastAccumulatedFrameNum, surfaceHistoryConfidence);
@@ -1028,6 +1102,11 @@ void TemporalAccumulation(const PassIO& io) {
 
                 float diffNonLinearAccumSpeed = 1.0f / (1.0f + diffAccumSpeed);
                 S diffResult = MixHistoryAndCurrent(c, smbDiffHistory, diff, diffNonLinearAccumSpeed);
+                float4 diffShResult = float4(0.0f);
+                if (SH) { // REBLUR_TemporalAccumulation.hlsli:883-886
+                    float4 smbDiffShHistory = FetchHistoryBilinear(smbFilter, *gHistory_DiffSh);
+                    diffShResult = MixHistoryAndCurrent(c, smbDiffShHistory, gIn_DiffSh->Load(px, py), diffNonLinearAccumSpeed);
+                }
 
                 // Firefly suppressor (not in the occlusion family: REBLUR_TemporalAccumulation.hlsli:889, 918)
                 float diffMaxRelativeIntensity = 0.0f, diffAntifireflyFactor = 0.0f;
@@ -1040,8 +1119,14 @@ void TemporalAccumulation(const PassIO& io) {
                     float diffLumaClamped = min(diffLumaResult, GetLuma(smbDiffHistory) * diffMaxRelativeIntensity);
                     diffLumaClamped = lerp(diffLumaResult, diffLumaClamped, diffAntifireflyFactor);
                     diffResult = ChangeLuma(diffResult, diffLumaClamped);
+                    if (SH) {
+                        float k = GetLumaScale(length(diffShResult.xyz()), diffLumaClamped);
+                        diffShResult.x *= k, diffShResult.y *= k, diffShResult.z *= k;
+                    }
                 }
                 gOut_Diff->Store(px, py, diffResult);
+                if (SH)
+                    gOut_DiffSh->Store(px, py, diffShResult);
 
                 // Fast history
                 float diffFastAccumSpeed = min(diffAccumSpeed, c.gMaxFastAccumulatedFrameNum);
@@ -1064,7 +1149,7 @@ void TemporalAccumulation(const PassIO& io) {
 template <typename S>
 S HistoryFixSignal(const ReblurCB& c, bool isSpec, bool perf, int px, int py, S sig, float frameNum, float strideBase, float roughness, float viewZ, float materialID,
     float3 N, float3 Nv, float3 Xv, float2 pixelUv, float frustumSize, const Tex& gIn_ViewZ, const Tex& gIn_Normal_Roughness, const Tex& gIn_Data1, bool hasDiff,
-    const Tex& gIn_Signal, const Tex& gIn_Fast, Tex& gOut_Fast) {
+    const Tex& gIn_Signal, const Tex& gIn_Fast, Tex& gOut_Fast, float4* sh = nullptr, const Tex* gIn_Sh = nullptr) { // REBLUR_SH: SH1 plane rides along (specular: .xyz only)
     constexpr bool OCC = sizeof(S) == sizeof(float);
     typedef ReblurSignal<OCC> Sig;
     const int rw = c.gRectSizeMinusOne[0], rh = c.gRectSizeMinusOne[1];
@@ -1095,6 +1180,11 @@ S HistoryFixSignal(const ReblurCB& c, bool isSpec, bool perf, int px, int py, S 
         if (perf) // REBLUR_HistoryFix.hlsli:88-90 / 292-294
             sumw = 1.0f + 1.0f / (1.0f + c.gMaxAccumulatedFrameNum) - nonLinearAccumSpeed;
         sig = sig * sumw;
+        if (sh) {
+            sh->x *= sumw, sh->y *= sumw, sh->z *= sumw;
+            if (!isSpec)
+                sh->w *= sumw;
+        }
 
         for (int j = -2; j <= 2; j++)
             for (int i = -2; i <= 2; i++) {
@@ -1138,10 +1228,22 @@ S HistoryFixSignal(const ReblurCB& c, bool isSpec, bool perf, int px, int py, S 
 
                 sumw += w;
                 sig = sig + smp * w;
+                if (sh) {
+                    float4 t = gIn_Sh->Load(sx, sy);
+                    t = w == 0.0f ? float4(0.0f) : t;
+                    sh->x += t.x * w, sh->y += t.y * w, sh->z += t.z * w;
+                    if (!isSpec)
+                        sh->w += t.w * w;
+                }
             }
 
         sumw = Math::PositiveRcp(sumw);
         sig = sig * sumw;
+        if (sh) {
+            sh->x *= sumw, sh->y *= sumw, sh->z *= sumw;
+            if (!isSpec)
+                sh->w *= sumw;
+        }
     }
 
     // Local variance of the fast history over 5x5 (clamped reads = the shader's LDS preload)
@@ -1192,10 +1294,14 @@ S HistoryFixSignal(const ReblurCB& c, bool isSpec, bool perf, int px, int py, S 
     float lumaClamped = clamp(luma, m1 - sigma, m1 + sigma);
     luma = lerp(lumaClamped, luma, 1.0f / (1.0f + (c.gMaxFastAccumulatedFrameNum < c.gMaxAccumulatedFrameNum ? 1.0f : 0.0f) * frameNum * 2.0f));
 
+    if (sh) { // REBLUR_HistoryFix.hlsli:247-249
+        float k = GetLumaScale(length(sh->xyz()), luma);
+        sh->x *= k, sh->y *= k, sh->z *= k;
+    }
     return ChangeLuma(sig, luma);
 }
 
-template <bool DIFF, bool SPEC, bool PERF, bool OCC>
+template <bool DIFF, bool SPEC, bool PERF, bool OCC, bool SH>
 void HistoryFix(const PassIO& io) {
     typedef ReblurSignal<OCC> Sig;
     typedef typename Sig::type S;
@@ -1209,10 +1315,14 @@ void HistoryFix(const PassIO& io) {
     const Tex* gIn_Spec = cur.nextIf(SPEC);
     const Tex* gIn_DiffFast = cur.nextIf(DIFF);
     const Tex* gIn_SpecFast = cur.nextIf(SPEC);
+    const Tex* gIn_DiffSh = cur.nextIf(DIFF && SH);
+    const Tex* gIn_SpecSh = cur.nextIf(SPEC && SH);
     Tex* gOut_Diff = cur.nextIf(DIFF);
     Tex* gOut_Spec = cur.nextIf(SPEC);
     Tex* gOut_DiffFast = cur.nextIf(DIFF);
     Tex* gOut_SpecFast = cur.nextIf(SPEC);
+    Tex* gOut_DiffSh = cur.nextIf(DIFF && SH);
+    Tex* gOut_SpecSh = cur.nextIf(SPEC && SH);
 
 #pragma omp parallel for schedule(dynamic, 4)
     for (int py = 0; py <= c.gRectSizeMinusOne[1]; py++)
@@ -1237,20 +1347,26 @@ void HistoryFix(const PassIO& io) {
             float2 stride = c.gHistoryFixBasePixelStride / (2.0f + frameNum);
 
             if (DIFF) {
+                float4 diffSh = SH ? gIn_DiffSh->Load(px, py) : float4(0.0f);
                 S diff = HistoryFixSignal<S>(c, false, PERF, px, py, Sig::From(gIn_Diff->Load(px, py)), frameNum.x, stride.x, roughness, viewZ, materialID, N, Nv, Xv, pixelUv, frustumSize,
-                    gIn_ViewZ, gIn_Normal_Roughness, gIn_Data1, DIFF, *gIn_Diff, *gIn_DiffFast, *gOut_DiffFast);
+                    gIn_ViewZ, gIn_Normal_Roughness, gIn_Data1, DIFF, *gIn_Diff, *gIn_DiffFast, *gOut_DiffFast, SH ? &diffSh : nullptr, gIn_DiffSh);
                 gOut_Diff->Store(px, py, diff);
+                if (SH)
+                    gOut_DiffSh->Store(px, py, diffSh);
             }
             if (SPEC) {
+                float4 specSh = SH ? gIn_SpecSh->Load(px, py) : float4(0.0f);
                 S spec = HistoryFixSignal<S>(c, true, PERF, px, py, Sig::From(gIn_Spec->Load(px, py)), frameNum.y, stride.y, roughness, viewZ, materialID, N, Nv, Xv, pixelUv, frustumSize,
-                    gIn_ViewZ, gIn_Normal_Roughness, gIn_Data1, DIFF, *gIn_Spec, *gIn_SpecFast, *gOut_SpecFast);
+                    gIn_ViewZ, gIn_Normal_Roughness, gIn_Data1, DIFF, *gIn_Spec, *gIn_SpecFast, *gOut_SpecFast, SH ? &specSh : nullptr, gIn_SpecSh);
                 gOut_Spec->Store(px, py, spec);
+                if (SH)
+                    gOut_SpecSh->Store(px, py, specSh);
             }
         }
 }
 
 // ================================================================================================ TemporalStabilization
-template <bool DIFF, bool SPEC, bool PERF>
+template <bool DIFF, bool SPEC, bool PERF, bool SH>
 void TemporalStabilization(const PassIO& io) {
     const ReblurCB& c = *(const ReblurCB*)io.constants;
     Cursor cur(io);
@@ -1265,12 +1381,16 @@ void TemporalStabilization(const PassIO& io) {
     const Tex* gHistory_DiffLumaStabilized = cur.nextIf(DIFF);
     const Tex* gHistory_SpecLumaStabilized = cur.nextIf(SPEC);
     const Tex* gIn_SpecHitDistForTracking = cur.nextIf(SPEC);
+    const Tex* gIn_DiffSh = cur.nextIf(DIFF && SH);
+    const Tex* gIn_SpecSh = cur.nextIf(SPEC && SH);
     const Tex& gInOut_Mv = *cur.next();
     Tex& gOut_InternalData = *cur.next();
     Tex* gOut_Diff = cur.nextIf(DIFF);
     Tex* gOut_Spec = cur.nextIf(SPEC);
     Tex* gOut_DiffLumaStabilized = cur.nextIf(DIFF);
     Tex* gOut_SpecLumaStabilized = cur.nextIf(SPEC);
+    Tex* gOut_DiffSh = cur.nextIf(DIFF && SH);
+    Tex* gOut_SpecSh = cur.nextIf(SPEC && SH);
 
     const int rw = c.gRectSizeMinusOne[0], rh = c.gRectSizeMinusOne[1];
 
@@ -1370,6 +1490,11 @@ void TemporalStabilization(const PassIO& io) {
                 diff = ChangeLuma(diff, diffLumaStabilized);
                 gOut_Diff->Store(px, py, diff);
                 gOut_DiffLumaStabilized->Store(px, py, diffLumaStabilized);
+                if (SH) { // REBLUR_TemporalStabilization.hlsli:166-176
+                    float4 diffSh = gIn_DiffSh->Load(px, py);
+                    float k = GetLumaScale(length(diffSh.xyz()), diffLumaStabilized);
+                    gOut_DiffSh->Store(px, py, float4(diffSh.x * k, diffSh.y * k, diffSh.z * k, diffSh.w));
+                }
 
                 data1.x += 1.0f;
                 float diffMinAccumSpeed = min(data1.x, c.gHistoryFixFrameNum);
@@ -1436,6 +1561,11 @@ void TemporalStabilization(const PassIO& io) {
                 spec = ChangeLuma(spec, specLumaStabilized);
                 gOut_Spec->Store(px, py, spec);
                 gOut_SpecLumaStabilized->Store(px, py, specLumaStabilized);
+                if (SH) { // REBLUR_TemporalStabilization.hlsli:346-356
+                    float4 specSh = gIn_SpecSh->Load(px, py);
+                    float k = GetLumaScale(length(specSh.xyz()), specLumaStabilized);
+                    gOut_SpecSh->Store(px, py, float4(specSh.x * k, specSh.y * k, specSh.z * k, specSh.w));
+                }
 
                 data1.y += 1.0f;
                 float specMinAccumSpeed = min(data1.y, c.gHistoryFixFrameNum);
@@ -1540,15 +1670,19 @@ void HitDistReconstruction(const PassIO& io) {
 }
 
 // ================================================================================================ SplitScreen
-template <bool DIFF, bool SPEC>
+template <bool DIFF, bool SPEC, bool SH>
 void SplitScreen(const PassIO& io) {
     const ReblurCB& c = *(const ReblurCB*)io.constants;
     Cursor cur(io);
     const Tex& gIn_ViewZ = *cur.next();
     const Tex* gIn_Diff = cur.nextIf(DIFF);
     const Tex* gIn_Spec = cur.nextIf(SPEC);
+    const Tex* gIn_DiffSh = cur.nextIf(DIFF && SH);
+    const Tex* gIn_SpecSh = cur.nextIf(SPEC && SH);
     Tex* gOut_Diff = cur.nextIf(DIFF);
     Tex* gOut_Spec = cur.nextIf(SPEC);
+    Tex* gOut_DiffSh = cur.nextIf(DIFF && SH);
+    Tex* gOut_SpecSh = cur.nextIf(SPEC && SH);
 #pragma omp parallel for schedule(static)
     for (int py = 0; py <= c.gRectSizeMinusOne[1]; py++)
         for (int px = 0; px <= c.gRectSizeMinusOne[0]; px++) {
@@ -1561,33 +1695,45 @@ void SplitScreen(const PassIO& io) {
                 gOut_Diff->Store(px, py, gIn_Diff->Load(px, py) * keep);
             if (SPEC)
                 gOut_Spec->Store(px, py, gIn_Spec->Load(px, py) * keep);
+            if (DIFF && SH)
+                gOut_DiffSh->Store(px, py, gIn_DiffSh->Load(px, py) * keep);
+            if (SPEC && SH)
+                gOut_SpecSh->Store(px, py, gIn_SpecSh->Load(px, py) * keep);
         }
 }
 
 } // namespace
 
-// quality and performance ("REBLUR_Perf_*", REBLUR_PERFORMANCE_MODE) permutations of one signal family
+// quality and performance ("REBLUR_Perf_*", REBLUR_PERFORMANCE_MODE) permutations of one signal family; the SH family ("Sh": an SH1 plane per
+// signal rides along) reuses the radiance family's hit-distance reconstruction; the occlusion family has no pre-pass / stabilisation
 #define REBLUR_PASSES(PREFIX, NAME, D, S, P)                                                            \
     {PREFIX NAME "_HitDistReconstruction.cs", HitDistReconstruction<D, S, 1, P, false>},               \
     {PREFIX NAME "_HitDistReconstruction_5x5.cs", HitDistReconstruction<D, S, 2, P, false>},           \
-    {PREFIX NAME "_PrePass.cs", PrePass<D, S, P>},                                                     \
-    {PREFIX NAME "_TemporalAccumulation.cs", TemporalAccumulation<D, S, P, false>},                    \
-    {PREFIX NAME "_HistoryFix.cs", HistoryFix<D, S, P, false>},                                        \
-    {PREFIX NAME "_Blur.cs", Blur<D, S, P, false>},                                                    \
-    {PREFIX NAME "_PostBlur.cs", PostBlur<D, S, false, P, false>},                                     \
-    {PREFIX NAME "_PostBlur_NoTemporalStabilization.cs", PostBlur<D, S, true, P, false>},              \
-    {PREFIX NAME "_TemporalStabilization.cs", TemporalStabilization<D, S, P>},                         \
-    /* occlusion family (REBLUR_TYPE = float, R16_UNORM planes): no pre-pass, no temporal stabilisation */ \
+    {PREFIX NAME "_PrePass.cs", PrePass<D, S, P, false>},                                              \
+    {PREFIX NAME "_TemporalAccumulation.cs", TemporalAccumulation<D, S, P, false, false>},             \
+    {PREFIX NAME "_HistoryFix.cs", HistoryFix<D, S, P, false, false>},                                 \
+    {PREFIX NAME "_Blur.cs", Blur<D, S, P, false, false>},                                             \
+    {PREFIX NAME "_PostBlur.cs", PostBlur<D, S, false, P, false, false>},                              \
+    {PREFIX NAME "_PostBlur_NoTemporalStabilization.cs", PostBlur<D, S, true, P, false, false>},       \
+    {PREFIX NAME "_TemporalStabilization.cs", TemporalStabilization<D, S, P, false>},                  \
+    {PREFIX NAME "Sh_PrePass.cs", PrePass<D, S, P, true>},                                             \
+    {PREFIX NAME "Sh_TemporalAccumulation.cs", TemporalAccumulation<D, S, P, false, true>},            \
+    {PREFIX NAME "Sh_HistoryFix.cs", HistoryFix<D, S, P, false, true>},                                \
+    {PREFIX NAME "Sh_Blur.cs", Blur<D, S, P, false, true>},                                            \
+    {PREFIX NAME "Sh_PostBlur.cs", PostBlur<D, S, false, P, false, true>},                             \
+    {PREFIX NAME "Sh_PostBlur_NoTemporalStabilization.cs", PostBlur<D, S, true, P, false, true>},      \
+    {PREFIX NAME "Sh_TemporalStabilization.cs", TemporalStabilization<D, S, P, true>},                 \
     {PREFIX NAME "Occlusion_HitDistReconstruction.cs", HitDistReconstruction<D, S, 1, P, true>},       \
     {PREFIX NAME "Occlusion_HitDistReconstruction_5x5.cs", HitDistReconstruction<D, S, 2, P, true>},   \
-    {PREFIX NAME "Occlusion_TemporalAccumulation.cs", TemporalAccumulation<D, S, P, true>},            \
-    {PREFIX NAME "Occlusion_HistoryFix.cs", HistoryFix<D, S, P, true>},                                \
-    {PREFIX NAME "Occlusion_Blur.cs", Blur<D, S, P, true>},                                            \
-    {PREFIX NAME "Occlusion_PostBlur_NoTemporalStabilization.cs", PostBlur<D, S, true, P, true>},
+    {PREFIX NAME "Occlusion_TemporalAccumulation.cs", TemporalAccumulation<D, S, P, true, false>},     \
+    {PREFIX NAME "Occlusion_HistoryFix.cs", HistoryFix<D, S, P, true, false>},                         \
+    {PREFIX NAME "Occlusion_Blur.cs", Blur<D, S, P, true, false>},                                     \
+    {PREFIX NAME "Occlusion_PostBlur_NoTemporalStabilization.cs", PostBlur<D, S, true, P, true, false>},
 #define REBLUR_FAMILY(NAME, D, S)                                                                      \
     REBLUR_PASSES("REBLUR_", NAME, D, S, false)                                                        \
     REBLUR_PASSES("REBLUR_Perf_", NAME, D, S, true)                                                    \
-    {"REBLUR_" NAME "_SplitScreen.cs", SplitScreen<D, S>},
+    {"REBLUR_" NAME "_SplitScreen.cs", SplitScreen<D, S, false>},                                      \
+    {"REBLUR_" NAME "Sh_SplitScreen.cs", SplitScreen<D, S, true>},
 
 const PassEntry* GetReblurPasses(uint32_t& n) {
     static const PassEntry k[] = {

@@ -46,6 +46,7 @@ constexpr int BUF_STRIDE = BUF_X + 1;      // 37
 
 struct HfPlanes {
     Plane tiles, normalRoughness, data1, viewZ, inDiff, inSpec, inDiffFast, inSpecFast, outDiff, outSpec, outDiffFast, outSpecFast;
+    Plane inDiffSh, inSpecSh, outDiffSh, outSpecSh; // SH family
     Plane decodedNR; // executor's float4 cache of normalRoughness (reblur_device.h "decoded guides")
 };
 
@@ -57,9 +58,9 @@ struct HfPixel {
 };
 
 // PERF = REBLUR_PERFORMANCE_MODE (reference REBLUR_HistoryFix.hlsli:88-90 / 139-141 / 292-294 / 338-340, REBLUR_Config.hlsli:236-237)
-template <bool IS_SPEC, bool DIFF, bool SPEC, bool PERF, bool OCC>
+template <bool IS_SPEC, bool DIFF, bool SPEC, bool PERF, bool OCC, bool SH>
 NRD_D typename ReblurSignal<OCC>::type HistoryFixSignal(const ReblurCB& c, const HfPlanes& P, const HfPixel& s, typename ReblurSignal<OCC>::type sig, float frameNum, float strideBase,
-    const Plane& gIn_Signal, const Plane& gIn_Fast, const Plane& gOut_Fast, const float* s_Luma) {
+    const Plane& gIn_Signal, const Plane& gIn_Fast, const Plane& gOut_Fast, const float* s_Luma, float4& sh, const Plane& gIn_Sh) { // SH: the SH1 plane rides along (specular: .xyz only)
     typedef ReblurSignal<OCC> Sig;
     typedef typename Sig::type S;
     const int rw = c.gRectSizeMinusOne.x, rh = c.gRectSizeMinusOne.y;
@@ -90,6 +91,8 @@ NRD_D typename ReblurSignal<OCC>::type HistoryFixSignal(const ReblurCB& c, const
         if (PERF)
             sumw = 1.0f + 1.0f / (1.0f + c.gMaxAccumulatedFrameNum) - nonLinearAccumSpeed;
         sig = sig * sumw;
+        if (SH)
+            sh = F4(sh.x * sumw, sh.y * sumw, sh.z * sumw, IS_SPEC ? sh.w : sh.w * sumw);
 
         for (int j = -2; j <= 2; j++) {
             for (int i = -2; i <= 2; i++) {
@@ -133,11 +136,18 @@ NRD_D typename ReblurSignal<OCC>::type HistoryFixSignal(const ReblurCB& c, const
 
                 sumw += w;
                 sig = sig + smp * w;
+                if (SH) {
+                    float4 t = LoadRGBA16F(gIn_Sh, sx, sy);
+                    t = Select(w == 0.0f, F4(0.0f), t);
+                    sh = F4(sh.x + t.x * w, sh.y + t.y * w, sh.z + t.z * w, IS_SPEC ? sh.w : sh.w + t.w * w);
+                }
             }
         }
 
         sumw = PositiveRcp(sumw);
         sig = sig * sumw;
+        if (SH)
+            sh = F4(sh.x * sumw, sh.y * sumw, sh.z * sumw, IS_SPEC ? sh.w : sh.w * sumw);
     }
 
     // Local variance of the fast history over 5x5 from the LDS tile
@@ -189,10 +199,14 @@ NRD_D typename ReblurSignal<OCC>::type HistoryFixSignal(const ReblurCB& c, const
     float lumaClamped = Clamp(luma, m1 - sigma, m1 + sigma);
     luma = Lerp(lumaClamped, luma, 1.0f / (1.0f + (c.gMaxFastAccumulatedFrameNum < c.gMaxAccumulatedFrameNum ? 1.0f : 0.0f) * frameNum * 2.0f));
 
+    if (SH) {
+        float k = GetLumaScale(Length(Xyz(sh)), luma);
+        sh = F4(sh.x * k, sh.y * k, sh.z * k, sh.w);
+    }
     return ChangeLuma(sig, luma);
 }
 
-template <bool DIFF, bool SPEC, bool PERF, bool OCC>
+template <bool DIFF, bool SPEC, bool PERF, bool OCC, bool SH>
 __global__ __launch_bounds__(TILE_X* TILE_Y) void ReblurHistoryFixKernel(ReblurCB c, HfPlanes P, RowRange rr) {
     typedef ReblurSignal<OCC> Sig;
     typedef typename Sig::type S;
@@ -240,16 +254,26 @@ __global__ __launch_bounds__(TILE_X* TILE_Y) void ReblurHistoryFixKernel(ReblurC
     float2 stride = F2(c.gHistoryFixBasePixelStride / (2.0f + frameNum.x), c.gHistoryFixBasePixelStride / (2.0f + frameNum.y));
 
     if (DIFF) {
-        S diff = HistoryFixSignal<false, DIFF, SPEC, PERF, OCC>(c, P, s, Sig::Load(P.inDiff, px, py), frameNum.x, stride.x, P.inDiff, P.inDiffFast, P.outDiffFast, s_DiffLuma);
+        float4 diffSh = F4(0.0f);
+        if (SH)
+            diffSh = LoadRGBA16F(P.inDiffSh, px, py);
+        S diff = HistoryFixSignal<false, DIFF, SPEC, PERF, OCC, SH>(c, P, s, Sig::Load(P.inDiff, px, py), frameNum.x, stride.x, P.inDiff, P.inDiffFast, P.outDiffFast, s_DiffLuma, diffSh, P.inDiffSh);
         Sig::Store(P.outDiff, px, py, diff);
+        if (SH)
+            StoreRGBA16F(P.outDiffSh, px, py, diffSh);
     }
     if (SPEC) {
-        S spec = HistoryFixSignal<true, DIFF, SPEC, PERF, OCC>(c, P, s, Sig::Load(P.inSpec, px, py), frameNum.y, stride.y, P.inSpec, P.inSpecFast, P.outSpecFast, s_SpecLuma);
+        float4 specSh = F4(0.0f);
+        if (SH)
+            specSh = LoadRGBA16F(P.inSpecSh, px, py);
+        S spec = HistoryFixSignal<true, DIFF, SPEC, PERF, OCC, SH>(c, P, s, Sig::Load(P.inSpec, px, py), frameNum.y, stride.y, P.inSpec, P.inSpecFast, P.outSpecFast, s_SpecLuma, specSh, P.inSpecSh);
         Sig::Store(P.outSpec, px, py, spec);
+        if (SH)
+            StoreRGBA16F(P.outSpecSh, px, py, specSh);
     }
 }
 
-template <bool DIFF, bool SPEC, bool PERF, bool OCC>
+template <bool DIFF, bool SPEC, bool PERF, bool OCC, bool SH>
 static const char* LaunchHistoryFix(const PassArgs& a) {
     const ReblurCB& c = *(const ReblurCB*)a.constants;
     if (const char* err = CheckSupportedHistory(c))
@@ -267,14 +291,18 @@ static const char* LaunchHistoryFix(const PassArgs& a) {
     if (SPEC) P.inSpec = a.planes[k++];
     if (DIFF) P.inDiffFast = a.planes[k++];
     if (SPEC) P.inSpecFast = a.planes[k++];
+    if (DIFF && SH) P.inDiffSh = a.planes[k++];
+    if (SPEC && SH) P.inSpecSh = a.planes[k++];
     if (DIFF) P.outDiff = a.planes[k++];
     if (SPEC) P.outSpec = a.planes[k++];
     if (DIFF) P.outDiffFast = a.planes[k++];
     if (SPEC) P.outSpecFast = a.planes[k++];
+    if (DIFF && SH) P.outDiffSh = a.planes[k++];
+    if (SPEC && SH) P.outSpecSh = a.planes[k++];
     if (k != a.planesNum)
         return "REBLUR history fix: unexpected resource count";
     RowGrid g = GridForRows(c.gRectSizeMinusOne.x + 1, c.gRectSizeMinusOne.y + 1, TILE_X, TILE_Y, a.rowBegin, a.rowEnd);
-    hipLaunchKernelGGL((ReblurHistoryFixKernel<DIFF, SPEC, PERF, OCC>), g.grid, dim3(TILE_X * TILE_Y), 0, a.stream, c, P, RowRange{g.firstBlockY, g.rowBegin, g.rowEnd});
+    hipLaunchKernelGGL((ReblurHistoryFixKernel<DIFF, SPEC, PERF, OCC, SH>), g.grid, dim3(TILE_X * TILE_Y), 0, a.stream, c, P, RowRange{g.firstBlockY, g.rowBegin, g.rowEnd});
     return nullptr;
 }
 
@@ -289,6 +317,7 @@ constexpr int BUF_STRIDE = BUF_X + 1;      // 35
 struct TsPlanes {
     Plane tiles, normalRoughness, viewZ, data1, data2, inDiff, inSpec, historyDiffLuma, historySpecLuma, inSpecHitDistForTracking, mv, outInternalData, outDiff, outSpec, outDiffLuma,
         outSpecLuma;
+    Plane inDiffSh, inSpecSh, outDiffSh, outSpecSh; // SH family
     Plane decodedNR;
 };
 
@@ -318,7 +347,7 @@ NRD_D void LumaStats(const ReblurCB& c, const float* s_Luma, int tx, int ty, flo
         luma = Clamp(luma, mn, mx);
 }
 
-template <bool DIFF, bool SPEC, bool PERF>
+template <bool DIFF, bool SPEC, bool PERF, bool SH>
 __global__ __launch_bounds__(TILE_X* TILE_Y) void ReblurTemporalStabilizationKernel(ReblurCB c, TsPlanes P, RowRange rr) {
     __shared__ float s_DiffLuma[DIFF ? ts::BUF_Y * ts::BUF_STRIDE : 1];
     __shared__ float s_SpecLuma[SPEC ? ts::BUF_Y * ts::BUF_STRIDE : 1];
@@ -418,6 +447,11 @@ __global__ __launch_bounds__(TILE_X* TILE_Y) void ReblurTemporalStabilizationKer
         diff = ChangeLuma(diff, diffLumaStabilized);
         StoreRGBA16F(P.outDiff, px, py, diff);
         StoreR16F(P.outDiffLuma, px, py, diffLumaStabilized);
+        if (SH) {
+            float4 diffSh = LoadRGBA16F(P.inDiffSh, px, py);
+            float k = GetLumaScale(Length(Xyz(diffSh)), diffLumaStabilized);
+            StoreRGBA16F(P.outDiffSh, px, py, F4(diffSh.x * k, diffSh.y * k, diffSh.z * k, diffSh.w));
+        }
 
         data1.x += 1.0f;
         float diffMinAccumSpeed = Min(data1.x, c.gHistoryFixFrameNum);
@@ -480,6 +514,11 @@ __global__ __launch_bounds__(TILE_X* TILE_Y) void ReblurTemporalStabilizationKer
         spec = ChangeLuma(spec, specLumaStabilized);
         StoreRGBA16F(P.outSpec, px, py, spec);
         StoreR16F(P.outSpecLuma, px, py, specLumaStabilized);
+        if (SH) {
+            float4 specSh = LoadRGBA16F(P.inSpecSh, px, py);
+            float k = GetLumaScale(Length(Xyz(specSh)), specLumaStabilized);
+            StoreRGBA16F(P.outSpecSh, px, py, F4(specSh.x * k, specSh.y * k, specSh.z * k, specSh.w));
+        }
 
         data1.y += 1.0f;
         float specMinAccumSpeed = Min(data1.y, c.gHistoryFixFrameNum);
@@ -489,7 +528,7 @@ __global__ __launch_bounds__(TILE_X* TILE_Y) void ReblurTemporalStabilizationKer
     StoreR16U(P.outInternalData, px, py, PackInternalData(data1.x, data1.y, materialID));
 }
 
-template <bool DIFF, bool SPEC, bool PERF>
+template <bool DIFF, bool SPEC, bool PERF, bool SH>
 static const char* LaunchTemporalStabilization(const PassArgs& a) {
     const ReblurCB& c = *(const ReblurCB*)a.constants;
     if (const char* err = CheckSupportedHistory(c))
@@ -512,26 +551,34 @@ static const char* LaunchTemporalStabilization(const PassArgs& a) {
     if (DIFF) P.historyDiffLuma = a.planes[k++];
     if (SPEC) P.historySpecLuma = a.planes[k++];
     if (SPEC) P.inSpecHitDistForTracking = a.planes[k++];
+    if (DIFF && SH) P.inDiffSh = a.planes[k++];
+    if (SPEC && SH) P.inSpecSh = a.planes[k++];
     P.mv = a.planes[k++];
     P.outInternalData = a.planes[k++];
     if (DIFF) P.outDiff = a.planes[k++];
     if (SPEC) P.outSpec = a.planes[k++];
     if (DIFF) P.outDiffLuma = a.planes[k++];
     if (SPEC) P.outSpecLuma = a.planes[k++];
+    if (DIFF && SH) P.outDiffSh = a.planes[k++];
+    if (SPEC && SH) P.outSpecSh = a.planes[k++];
     if (k != a.planesNum)
         return "REBLUR temporal stabilization: unexpected resource count";
     RowGrid g = GridForRows(c.gRectSizeMinusOne.x + 1, c.gRectSizeMinusOne.y + 1, TILE_X, TILE_Y, a.rowBegin, a.rowEnd);
-    hipLaunchKernelGGL((ReblurTemporalStabilizationKernel<DIFF, SPEC, PERF>), g.grid, dim3(TILE_X * TILE_Y), 0, a.stream, c, P, RowRange{g.firstBlockY, g.rowBegin, g.rowEnd});
+    hipLaunchKernelGGL((ReblurTemporalStabilizationKernel<DIFF, SPEC, PERF, SH>), g.grid, dim3(TILE_X * TILE_Y), 0, a.stream, c, P, RowRange{g.firstBlockY, g.rowBegin, g.rowEnd});
     return nullptr;
 }
 
-#define REBLUR_HISTORY_FAMILY(NAME, D, S)                                                            \
-    {"REBLUR_" NAME "_HistoryFix.cs", LaunchHistoryFix<D, S, false, false>},                         \
-    {"REBLUR_" NAME "_TemporalStabilization.cs", LaunchTemporalStabilization<D, S, false>},          \
-    {"REBLUR_Perf_" NAME "_HistoryFix.cs", LaunchHistoryFix<D, S, true, false>},                     \
-    {"REBLUR_" NAME "Occlusion_HistoryFix.cs", LaunchHistoryFix<D, S, false, true>},                 \
-    {"REBLUR_Perf_" NAME "Occlusion_HistoryFix.cs", LaunchHistoryFix<D, S, true, true>},             \
-    {"REBLUR_Perf_" NAME "_TemporalStabilization.cs", LaunchTemporalStabilization<D, S, true>},
+#define REBLUR_HISTORY_FAMILY(NAME, D, S)                                                                         \
+    {"REBLUR_" NAME "_HistoryFix.cs", LaunchHistoryFix<D, S, false, false, false>},                               \
+    {"REBLUR_" NAME "_TemporalStabilization.cs", LaunchTemporalStabilization<D, S, false, false>},                \
+    {"REBLUR_Perf_" NAME "_HistoryFix.cs", LaunchHistoryFix<D, S, true, false, false>},                           \
+    {"REBLUR_Perf_" NAME "_TemporalStabilization.cs", LaunchTemporalStabilization<D, S, true, false>},            \
+    {"REBLUR_" NAME "Sh_HistoryFix.cs", LaunchHistoryFix<D, S, false, false, true>},                              \
+    {"REBLUR_" NAME "Sh_TemporalStabilization.cs", LaunchTemporalStabilization<D, S, false, true>},               \
+    {"REBLUR_Perf_" NAME "Sh_HistoryFix.cs", LaunchHistoryFix<D, S, true, false, true>},                          \
+    {"REBLUR_Perf_" NAME "Sh_TemporalStabilization.cs", LaunchTemporalStabilization<D, S, true, true>},           \
+    {"REBLUR_" NAME "Occlusion_HistoryFix.cs", LaunchHistoryFix<D, S, false, true, false>},                       \
+    {"REBLUR_Perf_" NAME "Occlusion_HistoryFix.cs", LaunchHistoryFix<D, S, true, true, false>},
 
 const PassEntry* GetReblurHistoryPasses(uint32_t& num) {
     static const PassEntry k[] = {

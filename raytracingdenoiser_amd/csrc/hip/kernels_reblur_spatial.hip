@@ -76,9 +76,10 @@ NRD_D float PoissonGaussianWeight(int n) { // = GetGaussianWeight( offset.z ), b
 }
 
 // OCC = occlusion family: the signal is the hit distance alone (REBLUR_TYPE float, R16_UNORM planes)
-template <SpatialMode MODE, bool PERF, bool OCC>
+// SH = the *_SH denoisers: an SH1 plane (RGBA16F) rides on the same taps and weights (diffuse: all 4 components, specular: .xyz only)
+template <SpatialMode MODE, bool PERF, bool OCC, bool SH>
 NRD_D typename ReblurSignal<OCC>::type DiffuseSpatialFilter(const ReblurCB& c, const SpatialCtx& s, typename ReblurSignal<OCC>::type diff, const Plane& gIn_Diff, const Plane& gIn_ViewZ,
-    const Plane& gIn_Normal_Roughness) {
+    const Plane& gIn_Normal_Roughness, float4& diffSh, const Plane& gIn_DiffSh) {
     typedef ReblurSignal<OCC> Sig;
     typedef typename Sig::type S;
     if (MODE == PRE_BLUR && c.gDiffPrepassBlurRadius == 0.0f)
@@ -164,15 +165,22 @@ NRD_D typename ReblurSignal<OCC>::type DiffuseSpatialFilter(const ReblurCB& c, c
 
         sum += w;
         diff = diff + smp * w;
+        if (SH) {
+            float4 sh = LoadRGBA16F(gIn_DiffSh, tz.x, tz.y);
+            sh = Select(w == 0.0f, F4(0.0f), sh);
+            diffSh = diffSh + sh * w;
+        }
     }
 
     float invSum = PositiveRcp(sum);
+    if (SH)
+        diffSh = diffSh * invSum;
     return diff * invSum;
 }
 
-template <SpatialMode MODE, bool PERF, bool OCC>
+template <SpatialMode MODE, bool PERF, bool OCC, bool SH>
 NRD_D typename ReblurSignal<OCC>::type SpecularSpatialFilter(const ReblurCB& c, const SpatialCtx& s, typename ReblurSignal<OCC>::type spec, const Plane& gIn_Spec, const Plane& gIn_ViewZ,
-    const Plane& gIn_Normal_Roughness, const Plane& gOut_SpecHitDistForTracking) {
+    const Plane& gIn_Normal_Roughness, const Plane& gOut_SpecHitDistForTracking, float4& specSh, const Plane& gIn_SpecSh) {
     typedef ReblurSignal<OCC> Sig;
     typedef typename Sig::type S;
     float smc = GetSpecMagicCurve(s.roughness);
@@ -304,10 +312,17 @@ NRD_D typename ReblurSignal<OCC>::type SpecularSpatialFilter(const ReblurCB& c, 
 
         sum += w;
         spec = spec + smp * w;
+        if (SH) {
+            float4 sh = LoadRGBA16F(gIn_SpecSh, tz.x, tz.y);
+            sh = Select(w == 0.0f, F4(0.0f), sh);
+            specSh.x += sh.x * w, specSh.y += sh.y * w, specSh.z += sh.z * w;
+        }
     }
 
     float invSum = PositiveRcp(sum);
     spec = spec * invSum;
+    if (SH)
+        specSh.x *= invSum, specSh.y *= invSum, specSh.z *= invSum;
 
     if (MODE == PRE_BLUR)
         StoreR16F(gOut_SpecHitDistForTracking, s.px, s.py, hitDistForTracking == NRD_INF ? 0.0f : hitDistForTracking);
@@ -344,9 +359,10 @@ struct SpatialPlanes {
     Plane outViewZ;              // blur
     Plane outNormalRoughness;    // post-blur
     Plane outInternalData, outDiffCopy, outSpecCopy; // post-blur without temporal stabilization
+    Plane inDiffSh, inSpecSh, outDiffSh, outSpecSh, outDiffShCopy, outSpecShCopy; // SH family
 };
 
-template <SpatialMode MODE, bool DIFF, bool SPEC, bool NO_TS, bool PERF, bool OCC>
+template <SpatialMode MODE, bool DIFF, bool SPEC, bool NO_TS, bool PERF, bool OCC, bool SH>
 __global__ __launch_bounds__(TILE_X* TILE_Y) void ReblurSpatialKernel(ReblurCB c, SpatialPlanes P, RowRange rr) {
     typedef ReblurSignal<OCC> Sig;
     typedef typename Sig::type S;
@@ -377,17 +393,31 @@ __global__ __launch_bounds__(TILE_X* TILE_Y) void ReblurSpatialKernel(ReblurCB c
 
     if (DIFF) {
         S diff = Sig::Load(P.inDiff, px, py);
-        diff = DiffuseSpatialFilter<MODE, PERF, OCC>(c, s, diff, P.inDiff, P.viewZ, P.decodedNR);
+        float4 diffSh = F4(0.0f);
+        if (SH)
+            diffSh = LoadRGBA16F(P.inDiffSh, px, py);
+        diff = DiffuseSpatialFilter<MODE, PERF, OCC, SH>(c, s, diff, P.inDiff, P.viewZ, P.decodedNR, diffSh, P.inDiffSh);
         Sig::Store(P.outDiff, px, py, diff);
+        if (SH)
+            StoreRGBA16F(P.outDiffSh, px, py, diffSh);
         if (MODE == POST_BLUR && NO_TS && !OCC) // the occlusion family has no separate history copy: its output is the history
             Sig::Store(P.outDiffCopy, px, py, diff);
+        if (MODE == POST_BLUR && NO_TS && SH)
+            StoreRGBA16F(P.outDiffShCopy, px, py, diffSh);
     }
     if (SPEC) {
         S spec = Sig::Load(P.inSpec, px, py);
-        spec = SpecularSpatialFilter<MODE, PERF, OCC>(c, s, spec, P.inSpec, P.viewZ, P.decodedNR, P.outHitDistForTracking);
+        float4 specSh = F4(0.0f);
+        if (SH)
+            specSh = LoadRGBA16F(P.inSpecSh, px, py);
+        spec = SpecularSpatialFilter<MODE, PERF, OCC, SH>(c, s, spec, P.inSpec, P.viewZ, P.decodedNR, P.outHitDistForTracking, specSh, P.inSpecSh);
         Sig::Store(P.outSpec, px, py, spec);
+        if (SH)
+            StoreRGBA16F(P.outSpecSh, px, py, specSh);
         if (MODE == POST_BLUR && NO_TS && !OCC)
             Sig::Store(P.outSpecCopy, px, py, spec);
+        if (MODE == POST_BLUR && NO_TS && SH)
+            StoreRGBA16F(P.outSpecShCopy, px, py, specSh);
     }
 }
 
@@ -401,7 +431,7 @@ static const char* CheckSupported(const ReblurCB& c) {
     return nullptr;
 }
 
-template <SpatialMode MODE, bool DIFF, bool SPEC, bool NO_TS, bool PERF, bool OCC>
+template <SpatialMode MODE, bool DIFF, bool SPEC, bool NO_TS, bool PERF, bool OCC, bool SH>
 static const char* LaunchSpatial(const PassArgs& a) {
     const ReblurCB& c = *(const ReblurCB*)a.constants;
     if (const char* err = CheckSupported(c))
@@ -418,18 +448,26 @@ static const char* LaunchSpatial(const PassArgs& a) {
         P.viewZ = a.planes[k++];
         if (DIFF) P.inDiff = a.planes[k++];
         if (SPEC) P.inSpec = a.planes[k++];
+        if (DIFF && SH) P.inDiffSh = a.planes[k++];
+        if (SPEC && SH) P.inSpecSh = a.planes[k++];
         if (DIFF) P.outDiff = a.planes[k++];
         if (SPEC) P.outSpec = a.planes[k++];
         if (SPEC) P.outHitDistForTracking = a.planes[k++];
+        if (DIFF && SH) P.outDiffSh = a.planes[k++];
+        if (SPEC && SH) P.outSpecSh = a.planes[k++];
     } else {
         P.data1 = a.planes[k++];
         if (DIFF) P.inDiff = a.planes[k++];
         if (SPEC) P.inSpec = a.planes[k++];
         P.viewZ = a.planes[k++];
+        if (DIFF && SH) P.inDiffSh = a.planes[k++];
+        if (SPEC && SH) P.inSpecSh = a.planes[k++];
         if (MODE == BLUR) {
             if (DIFF) P.outDiff = a.planes[k++];
             if (SPEC) P.outSpec = a.planes[k++];
             P.outViewZ = a.planes[k++];
+            if (DIFF && SH) P.outDiffSh = a.planes[k++];
+            if (SPEC && SH) P.outSpecSh = a.planes[k++];
         } else {
             P.outNormalRoughness = a.planes[k++];
             if (DIFF) P.outDiff = a.planes[k++];
@@ -438,21 +476,26 @@ static const char* LaunchSpatial(const PassArgs& a) {
                 P.outInternalData = a.planes[k++];
                 if (DIFF && !OCC) P.outDiffCopy = a.planes[k++];
                 if (SPEC && !OCC) P.outSpecCopy = a.planes[k++];
+                if (DIFF && SH) P.outDiffShCopy = a.planes[k++];
+                if (SPEC && SH) P.outSpecShCopy = a.planes[k++];
             }
+            if (DIFF && SH) P.outDiffSh = a.planes[k++];
+            if (SPEC && SH) P.outSpecSh = a.planes[k++];
         }
     }
     if (k != a.planesNum)
         return "REBLUR spatial pass: unexpected resource count";
 
     RowGrid g = GridForRows(c.gRectSizeMinusOne.x + 1, c.gRectSizeMinusOne.y + 1, TILE_X, TILE_Y, a.rowBegin, a.rowEnd);
-    hipLaunchKernelGGL((ReblurSpatialKernel<MODE, DIFF, SPEC, NO_TS, PERF, OCC>), g.grid, dim3(TILE_X * TILE_Y), 0, a.stream, c, P, RowRange{g.firstBlockY, g.rowBegin, g.rowEnd});
+    hipLaunchKernelGGL((ReblurSpatialKernel<MODE, DIFF, SPEC, NO_TS, PERF, OCC, SH>), g.grid, dim3(TILE_X * TILE_Y), 0, a.stream, c, P, RowRange{g.firstBlockY, g.rowBegin, g.rowEnd});
     return nullptr;
 }
 
 // ================================================================================================ SplitScreen
 // OCC: the occlusion family binds its R16_UNORM planes to the radiance family's split-screen pipeline (the shader only scales .x there)
 template <bool DIFF, bool SPEC, bool OCC>
-__global__ __launch_bounds__(256) void ReblurSplitScreenKernel(ReblurCB c, Plane viewZ, Plane inDiff, Plane inSpec, Plane outDiff, Plane outSpec, RowRange rr) {
+__global__ __launch_bounds__(256) void ReblurSplitScreenKernel(ReblurCB c, Plane viewZ, Plane inDiff, Plane inSpec, Plane outDiff, Plane outSpec, Plane inDiffSh, Plane inSpecSh, Plane outDiffSh,
+    Plane outSpecSh, RowRange rr) {
     const int px = blockIdx.x * TILE_X + (threadIdx.x % TILE_X);
     const int py = (blockIdx.y + rr.firstBlockY) * TILE_Y + (threadIdx.x / TILE_X);
     if (px > c.gRectSizeMinusOne.x || py > c.gRectSizeMinusOne.y || py < rr.rowBegin || py >= rr.rowEnd)
@@ -467,19 +510,27 @@ __global__ __launch_bounds__(256) void ReblurSplitScreenKernel(ReblurCB c, Plane
         Sig::Store(outDiff, px, py, Sig::Load(inDiff, px, py) * keep);
     if (SPEC)
         Sig::Store(outSpec, px, py, Sig::Load(inSpec, px, py) * keep);
+    if (DIFF && inDiffSh.ptr) // SH family (uniform branch)
+        StoreRGBA16F(outDiffSh, px, py, LoadRGBA16F(inDiffSh, px, py) * keep);
+    if (SPEC && inSpecSh.ptr)
+        StoreRGBA16F(outSpecSh, px, py, LoadRGBA16F(inSpecSh, px, py) * keep);
 }
 
-template <bool DIFF, bool SPEC>
+template <bool DIFF, bool SPEC, bool SH>
 static const char* LaunchSplitScreen(const PassArgs& a) {
     const ReblurCB& c = *(const ReblurCB*)a.constants;
     if (const char* err = CheckSupported(c))
         return err;
     uint32_t k = 0;
-    Plane viewZ = a.planes[k++], inDiff = {}, inSpec = {}, outDiff = {}, outSpec = {};
+    Plane viewZ = a.planes[k++], inDiff = {}, inSpec = {}, outDiff = {}, outSpec = {}, inDiffSh = {}, inSpecSh = {}, outDiffSh = {}, outSpecSh = {};
     if (DIFF) inDiff = a.planes[k++];
     if (SPEC) inSpec = a.planes[k++];
+    if (DIFF && SH) inDiffSh = a.planes[k++];
+    if (SPEC && SH) inSpecSh = a.planes[k++];
     if (DIFF) outDiff = a.planes[k++];
     if (SPEC) outSpec = a.planes[k++];
+    if (DIFF && SH) outDiffSh = a.planes[k++];
+    if (SPEC && SH) outSpecSh = a.planes[k++];
     if (k != a.planesNum)
         return "REBLUR split screen: unexpected resource count";
     RowGrid g = GridForRows(c.gRectSizeMinusOne.x + 1, c.gRectSizeMinusOne.y + 1, TILE_X, TILE_Y, a.rowBegin, a.rowEnd);
@@ -489,9 +540,9 @@ static const char* LaunchSplitScreen(const PassArgs& a) {
         if (a.bytesPerTexel[i] != bytesPerTexel)
             return "REBLUR split screen: mixed signal formats";
     if (bytesPerTexel == 8)
-        hipLaunchKernelGGL((ReblurSplitScreenKernel<DIFF, SPEC, false>), g.grid, dim3(256), 0, a.stream, c, viewZ, inDiff, inSpec, outDiff, outSpec, rows);
+        hipLaunchKernelGGL((ReblurSplitScreenKernel<DIFF, SPEC, false>), g.grid, dim3(256), 0, a.stream, c, viewZ, inDiff, inSpec, outDiff, outSpec, inDiffSh, inSpecSh, outDiffSh, outSpecSh, rows);
     else if (bytesPerTexel == 2)
-        hipLaunchKernelGGL((ReblurSplitScreenKernel<DIFF, SPEC, true>), g.grid, dim3(256), 0, a.stream, c, viewZ, inDiff, inSpec, outDiff, outSpec, rows);
+        hipLaunchKernelGGL((ReblurSplitScreenKernel<DIFF, SPEC, true>), g.grid, dim3(256), 0, a.stream, c, viewZ, inDiff, inSpec, outDiff, outSpec, inDiffSh, inSpecSh, outDiffSh, outSpecSh, rows);
     else
         return "REBLUR split screen: unexpected signal format";
     return nullptr;
@@ -604,23 +655,28 @@ static const char* LaunchHitDistReconstruction(const PassArgs& a) {
     return nullptr;
 }
 
-// quality and performance ("REBLUR_Perf_*") permutations of one signal family
-#define REBLUR_SPATIAL_PASSES(PREFIX, NAME, D, S, P)                                                     \
-    {PREFIX NAME "_HitDistReconstruction.cs", LaunchHitDistReconstruction<D, S, 1, P, false>},         \
-    {PREFIX NAME "_HitDistReconstruction_5x5.cs", LaunchHitDistReconstruction<D, S, 2, P, false>},     \
-    {PREFIX NAME "_PrePass.cs", LaunchSpatial<PRE_BLUR, D, S, false, P, false>},                       \
-    {PREFIX NAME "_Blur.cs", LaunchSpatial<BLUR, D, S, false, P, false>},                              \
-    {PREFIX NAME "_PostBlur.cs", LaunchSpatial<POST_BLUR, D, S, false, P, false>},                     \
-    {PREFIX NAME "_PostBlur_NoTemporalStabilization.cs", LaunchSpatial<POST_BLUR, D, S, true, P, false>}, \
-    /* occlusion family: hit distance only (R16_UNORM), no pre-pass, post-blur always without temporal stabilisation */ \
-    {PREFIX NAME "Occlusion_HitDistReconstruction.cs", LaunchHitDistReconstruction<D, S, 1, P, true>}, \
-    {PREFIX NAME "Occlusion_HitDistReconstruction_5x5.cs", LaunchHitDistReconstruction<D, S, 2, P, true>}, \
-    {PREFIX NAME "Occlusion_Blur.cs", LaunchSpatial<BLUR, D, S, false, P, true>},                      \
-    {PREFIX NAME "Occlusion_PostBlur_NoTemporalStabilization.cs", LaunchSpatial<POST_BLUR, D, S, true, P, true>},
+// quality and performance ("REBLUR_Perf_*") permutations of one signal family; "Sh" = SH family (reuses the radiance family's hit-distance
+// reconstruction), "Occlusion" = hit distance only (R16_UNORM), no pre-pass, post-blur always without temporal stabilisation
+#define REBLUR_SPATIAL_PASSES(PREFIX, NAME, D, S, P)                                                                   \
+    {PREFIX NAME "_HitDistReconstruction.cs", LaunchHitDistReconstruction<D, S, 1, P, false>},                       \
+    {PREFIX NAME "_HitDistReconstruction_5x5.cs", LaunchHitDistReconstruction<D, S, 2, P, false>},                   \
+    {PREFIX NAME "_PrePass.cs", LaunchSpatial<PRE_BLUR, D, S, false, P, false, false>},                              \
+    {PREFIX NAME "_Blur.cs", LaunchSpatial<BLUR, D, S, false, P, false, false>},                                     \
+    {PREFIX NAME "_PostBlur.cs", LaunchSpatial<POST_BLUR, D, S, false, P, false, false>},                            \
+    {PREFIX NAME "_PostBlur_NoTemporalStabilization.cs", LaunchSpatial<POST_BLUR, D, S, true, P, false, false>},     \
+    {PREFIX NAME "Sh_PrePass.cs", LaunchSpatial<PRE_BLUR, D, S, false, P, false, true>},                             \
+    {PREFIX NAME "Sh_Blur.cs", LaunchSpatial<BLUR, D, S, false, P, false, true>},                                    \
+    {PREFIX NAME "Sh_PostBlur.cs", LaunchSpatial<POST_BLUR, D, S, false, P, false, true>},                           \
+    {PREFIX NAME "Sh_PostBlur_NoTemporalStabilization.cs", LaunchSpatial<POST_BLUR, D, S, true, P, false, true>},    \
+    {PREFIX NAME "Occlusion_HitDistReconstruction.cs", LaunchHitDistReconstruction<D, S, 1, P, true>},               \
+    {PREFIX NAME "Occlusion_HitDistReconstruction_5x5.cs", LaunchHitDistReconstruction<D, S, 2, P, true>},           \
+    {PREFIX NAME "Occlusion_Blur.cs", LaunchSpatial<BLUR, D, S, false, P, true, false>},                             \
+    {PREFIX NAME "Occlusion_PostBlur_NoTemporalStabilization.cs", LaunchSpatial<POST_BLUR, D, S, true, P, true, false>},
 #define REBLUR_SPATIAL_FAMILY(NAME, D, S)                                                              \
     REBLUR_SPATIAL_PASSES("REBLUR_", NAME, D, S, false)                                                \
     REBLUR_SPATIAL_PASSES("REBLUR_Perf_", NAME, D, S, true)                                            \
-    {"REBLUR_" NAME "_SplitScreen.cs", LaunchSplitScreen<D, S>},
+    {"REBLUR_" NAME "_SplitScreen.cs", LaunchSplitScreen<D, S, false>},                                \
+    {"REBLUR_" NAME "Sh_SplitScreen.cs", LaunchSplitScreen<D, S, true>},
 
 const PassEntry* GetReblurSpatialPasses(uint32_t& num) {
     static const PassEntry k[] = {

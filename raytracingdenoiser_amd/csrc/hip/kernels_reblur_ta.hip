@@ -28,11 +28,13 @@ struct TaPlanes {
     Plane disocclusionThresholdMix, diffConfidence, specConfidence; // R8_UNORM user inputs; dummies unless the gHas* flags are set
     Plane inDiff, inSpec, historyDiff, historySpec, historyDiffFast, historySpecFast, prevSpecHitDistForTracking, inSpecHitDistForTracking;
     Plane outDiff, outSpec, outDiffFast, outSpecFast, outSpecHitDistForTracking, outData1, outData2;
+    Plane inDiffSh, inSpecSh, historyDiffSh, historySpecSh, outDiffSh, outSpecSh; // SH family (RGBA16F)
 };
 
 // PERF = REBLUR_PERFORMANCE_MODE: no Catmull-Rom history fetches (REBLUR_USE_CATROM_FOR_*_MOTION_IN_TA = 0, REBLUR_Config.hlsli:196-201)
 // OCC = occlusion family (REBLUR_OCCLUSION): hit-distance-only signals in R16_UNORM, no pre-pass output to read, no DATA2, no firefly suppressor
-template <bool DIFF, bool SPEC, bool PERF, bool OCC>
+// SH = the *_SH denoisers: the SH1 plane of every signal is accumulated with the same speeds (custom-weight bilinear history fetch)
+template <bool DIFF, bool SPEC, bool PERF, bool OCC, bool SH>
 __global__ __launch_bounds__(TILE_X* TILE_Y, 2) void ReblurTemporalAccumulationKernel(ReblurCB cArg, TaPlanes P, RowRange rr) {
     typedef ReblurSignal<OCC> Sig;
     typedef typename Sig::type S;
@@ -310,6 +312,11 @@ __global__ __launch_bounds__(TILE_X* TILE_Y, 2) void ReblurTemporalAccumulationK
 
         float diffNonLinearAccumSpeed = 1.0f / (1.0f + diffAccumSpeed);
         S diffResult = MixHistoryAndCurrent(c, smbDiffHistory, diff, diffNonLinearAccumSpeed);
+        float4 diffShResult = F4(0.0f);
+        if (SH) {
+            float4 smbDiffShHistory = FetchHistoryBilinearRGBA16F(smbFilter, P.historyDiffSh);
+            diffShResult = MixHistoryAndCurrent(c, smbDiffShHistory, LoadRGBA16F(P.inDiffSh, px, py), diffNonLinearAccumSpeed);
+        }
 
         float diffMaxRelativeIntensity = 0.0f, diffAntifireflyFactor = 0.0f;
         if (!OCC) { // firefly suppressor
@@ -321,8 +328,14 @@ __global__ __launch_bounds__(TILE_X* TILE_Y, 2) void ReblurTemporalAccumulationK
             float diffLumaClamped = Min(diffLumaResult, GetLuma(smbDiffHistory) * diffMaxRelativeIntensity);
             diffLumaClamped = Lerp(diffLumaResult, diffLumaClamped, diffAntifireflyFactor);
             diffResult = ChangeLuma(diffResult, diffLumaClamped);
+            if (SH) {
+                float k = GetLumaScale(Length(Xyz(diffShResult)), diffLumaClamped);
+                diffShResult = F4(diffShResult.x * k, diffShResult.y * k, diffShResult.z * k, diffShResult.w);
+            }
         }
         Sig::Store(P.outDiff, px, py, diffResult);
+        if (SH)
+            StoreRGBA16F(P.outDiffSh, px, py, diffShResult);
 
         float diffFastAccumSpeed = Min(diffAccumSpeed, c.gMaxFastAccumulatedFrameNum);
         float diffFastNonLinearAccumSpeed = 1.0f / (1.0f + diffFastAccumSpeed);
@@ -629,6 +642,17 @@ __global__ __launch_bounds__(TILE_X* TILE_Y, 2) void ReblurTemporalAccumulationK
         S vmbSpec = MixHistoryAndCurrent(c, vmbSpecHistory, spec, vmbSpecNonLinearAccumSpeed, roughnessModified);
         S specResult = Lerp(smbSpec, vmbSpec, virtualHistoryAmount);
 
+        float4 specShResult = F4(0.0f);
+        if (SH) {
+            float4 smbSpecShHistory = FetchHistoryBilinearRGBA16F(smbFilter, P.historySpecSh);
+            float4 vmbSpecShHistory = FetchHistoryBilinearRGBA16F(vmbFilter, P.historySpecSh);
+            float4 specSh = LoadRGBA16F(P.inSpecSh, px, py);
+            float4 smbShSpec = Lerp(smbSpecShHistory, specSh, smbSpecNonLinearAccumSpeed);
+            float4 vmbShSpec = Lerp(vmbSpecShHistory, specSh, vmbSpecNonLinearAccumSpeed);
+            specShResult = Lerp(smbShSpec, vmbShSpec, virtualHistoryAmount);
+            specShResult.w = roughnessModified; // assists AA during the SG resolve; never blurred
+        }
+
         specAccumSpeed = Lerp(smbSpecAccumSpeedBoosted, vmbSpecAccumSpeed, virtualHistoryAmount);
         S specHistory = Lerp(smbSpecHistory, vmbSpecHistory, virtualHistoryAmount);
 
@@ -643,9 +667,15 @@ __global__ __launch_bounds__(TILE_X* TILE_Y, 2) void ReblurTemporalAccumulationK
             float specLumaClamped = Min(specLumaResult, GetLuma(specHistory) * specMaxRelativeIntensity);
             specLumaClamped = Lerp(specLumaResult, specLumaClamped, specAntifireflyFactor);
             specResult = ChangeLuma(specResult, specLumaClamped);
+            if (SH) {
+                float k = GetLumaScale(Length(Xyz(specShResult)), specLumaClamped);
+                specShResult = F4(specShResult.x * k, specShResult.y * k, specShResult.z * k, specShResult.w);
+            }
         }
 
         Sig::Store(P.outSpec, px, py, specResult);
+        if (SH)
+            StoreRGBA16F(P.outSpecSh, px, py, specShResult);
 
         // Fast history
         float smbSpecFastNonLinearAccumSpeed = GetNonLinearAccumSpeed(smbSpecAccumSpeed, c.gMaxFastAccumulatedFrameNum, surfaceHistoryConfidence);
@@ -674,7 +704,7 @@ __global__ __launch_bounds__(TILE_X* TILE_Y, 2) void ReblurTemporalAccumulationK
     StoreData1<DIFF, SPEC>(P.outData1, px, py, diffAccumSpeed, specAccumSpeed);
 }
 
-template <bool DIFF, bool SPEC, bool PERF, bool OCC>
+template <bool DIFF, bool SPEC, bool PERF, bool OCC, bool SH>
 static const char* LaunchTemporalAccumulation(const PassArgs& a) {
     const ReblurCB& c = *(const ReblurCB*)a.constants;
     if (c.gDiffCheckerboard != 2 || c.gSpecCheckerboard != 2)
@@ -707,6 +737,10 @@ static const char* LaunchTemporalAccumulation(const PassArgs& a) {
     if (SPEC) P.historySpecFast = a.planes[k++];
     if (SPEC) P.prevSpecHitDistForTracking = a.planes[k++];
     if (SPEC && !OCC) P.inSpecHitDistForTracking = a.planes[k++];
+    if (DIFF && SH) P.inDiffSh = a.planes[k++];
+    if (SPEC && SH) P.inSpecSh = a.planes[k++];
+    if (DIFF && SH) P.historyDiffSh = a.planes[k++];
+    if (SPEC && SH) P.historySpecSh = a.planes[k++];
     if (DIFF) P.outDiff = a.planes[k++];
     if (SPEC) P.outSpec = a.planes[k++];
     if (DIFF) P.outDiffFast = a.planes[k++];
@@ -714,6 +748,8 @@ static const char* LaunchTemporalAccumulation(const PassArgs& a) {
     if (SPEC) P.outSpecHitDistForTracking = a.planes[k++];
     P.outData1 = a.planes[k++];
     if (!OCC) P.outData2 = a.planes[k++];
+    if (DIFF && SH) P.outDiffSh = a.planes[k++];
+    if (SPEC && SH) P.outSpecSh = a.planes[k++];
     if (k != a.planesNum)
         return "REBLUR temporal accumulation: unexpected resource count";
     {
@@ -734,24 +770,22 @@ static const char* LaunchTemporalAccumulation(const PassArgs& a) {
     }
 
     RowGrid g = GridForRows(c.gRectSizeMinusOne.x + 1, c.gRectSizeMinusOne.y + 1, TILE_X, TILE_Y, a.rowBegin, a.rowEnd);
-    hipLaunchKernelGGL((ReblurTemporalAccumulationKernel<DIFF, SPEC, PERF, OCC>), g.grid, dim3(TILE_X * TILE_Y), 0, a.stream, c, P, RowRange{g.firstBlockY, g.rowBegin, g.rowEnd});
+    hipLaunchKernelGGL((ReblurTemporalAccumulationKernel<DIFF, SPEC, PERF, OCC, SH>), g.grid, dim3(TILE_X * TILE_Y), 0, a.stream, c, P, RowRange{g.firstBlockY, g.rowBegin, g.rowEnd});
     return nullptr;
 }
 
 const PassEntry* GetReblurTemporalAccumulationPasses(uint32_t& num) {
     static const PassEntry k[] = {
-        {"REBLUR_Diffuse_TemporalAccumulation.cs", LaunchTemporalAccumulation<true, false, false, false>},
-        {"REBLUR_Specular_TemporalAccumulation.cs", LaunchTemporalAccumulation<false, true, false, false>},
-        {"REBLUR_DiffuseSpecular_TemporalAccumulation.cs", LaunchTemporalAccumulation<true, true, false, false>},
-        {"REBLUR_Perf_Diffuse_TemporalAccumulation.cs", LaunchTemporalAccumulation<true, false, true, false>},
-        {"REBLUR_Perf_Specular_TemporalAccumulation.cs", LaunchTemporalAccumulation<false, true, true, false>},
-        {"REBLUR_Perf_DiffuseSpecular_TemporalAccumulation.cs", LaunchTemporalAccumulation<true, true, true, false>},
-        {"REBLUR_DiffuseOcclusion_TemporalAccumulation.cs", LaunchTemporalAccumulation<true, false, false, true>},
-        {"REBLUR_SpecularOcclusion_TemporalAccumulation.cs", LaunchTemporalAccumulation<false, true, false, true>},
-        {"REBLUR_DiffuseSpecularOcclusion_TemporalAccumulation.cs", LaunchTemporalAccumulation<true, true, false, true>},
-        {"REBLUR_Perf_DiffuseOcclusion_TemporalAccumulation.cs", LaunchTemporalAccumulation<true, false, true, true>},
-        {"REBLUR_Perf_SpecularOcclusion_TemporalAccumulation.cs", LaunchTemporalAccumulation<false, true, true, true>},
-        {"REBLUR_Perf_DiffuseSpecularOcclusion_TemporalAccumulation.cs", LaunchTemporalAccumulation<true, true, true, true>},
+#define REBLUR_TA_FAMILY(NAME, D, S)                                                                                 \
+    {"REBLUR_" NAME "_TemporalAccumulation.cs", LaunchTemporalAccumulation<D, S, false, false, false>},            \
+    {"REBLUR_Perf_" NAME "_TemporalAccumulation.cs", LaunchTemporalAccumulation<D, S, true, false, false>},        \
+    {"REBLUR_" NAME "Sh_TemporalAccumulation.cs", LaunchTemporalAccumulation<D, S, false, false, true>},           \
+    {"REBLUR_Perf_" NAME "Sh_TemporalAccumulation.cs", LaunchTemporalAccumulation<D, S, true, false, true>},       \
+    {"REBLUR_" NAME "Occlusion_TemporalAccumulation.cs", LaunchTemporalAccumulation<D, S, false, true, false>},    \
+    {"REBLUR_Perf_" NAME "Occlusion_TemporalAccumulation.cs", LaunchTemporalAccumulation<D, S, true, true, false>},
+        REBLUR_TA_FAMILY("Diffuse", true, false)
+        REBLUR_TA_FAMILY("Specular", false, true)
+        REBLUR_TA_FAMILY("DiffuseSpecular", true, true)
     };
     num = sizeof(k) / sizeof(k[0]);
     return k;

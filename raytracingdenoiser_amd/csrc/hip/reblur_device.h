@@ -454,6 +454,16 @@ NRD_D float4 FetchHistoryRGBA16F(const HistoryFilter& h, const Plane& tex) {
 NRD_D float FetchHistoryR16F(const HistoryFilter& h, const Plane& tex) {
     return FetchHistoryGeneric<float>(h, tex, [](const Plane& p, int x, int y) { return LoadR16F(p, x, y); }, 0.0f);
 }
+// custom-weight bilinear fetch of an RGBA16F plane (the SH1 histories; reference REBLUR_Common.hlsli:350-361 fetches them this way)
+NRD_D float4 FetchHistoryBilinearRGBA16F(const HistoryFilter& h, const Plane& tex) {
+    auto at = [&](int x, int y) { return InBounds(tex, x, y) ? LoadRGBA16F(tex, x, y) : F4(0.0f); };
+    float4 color = at(h.ox, h.oy) * h.bw.x;
+    color = color + at(h.ox + 1, h.oy) * h.bw.y;
+    color = color + at(h.ox, h.oy + 1) * h.bw.z;
+    color = color + at(h.ox + 1, h.oy + 1) * h.bw.w;
+    float s = Sum(h.bw);
+    return s < 0.0001f ? F4(0.0f) : color / s;
+}
 NRD_D float FetchHistoryBilinearR16F(const HistoryFilter& h, const Plane& tex) {
     float color = LoadR16FOrZero(tex, h.ox, h.oy) * h.bw.x;
     color += LoadR16FOrZero(tex, h.ox + 1, h.oy) * h.bw.y;

@@ -45,11 +45,14 @@ const uint16_t DUMMY = (uint16_t)ResourceType::IN_VIEWZ; // placeholder bound to
 
 } // namespace
 
-void InstanceImpl::Add_Reblur(DenoiserData& d, bool hasDiff, bool hasSpec) {
+// sh: the REBLUR_*_SH denoisers (reference Source/Denoisers/Reblur_{Diffuse,Specular,DiffuseSpecular}Sh.hpp): every signal carries a second
+// RGBA16F plane (SH1) through all passes; inputs / outputs are the IN_/OUT_*_SH0 and _SH1 slots
+void InstanceImpl::Add_Reblur(DenoiserData& d, bool hasDiff, bool hasSpec, bool sh) {
     d.settings.reblur = ReblurSettings();
     d.settingsSize = sizeof(ReblurSettings);
 
-    const char* family = hasDiff && hasSpec ? "DiffuseSpecular" : (hasDiff ? "Diffuse" : "Specular");
+    const char* baseFamily = hasDiff && hasSpec ? "DiffuseSpecular" : (hasDiff ? "Diffuse" : "Specular");
+    const char* family = !sh ? baseFamily : (hasDiff && hasSpec ? "DiffuseSpecularSh" : (hasDiff ? "DiffuseSh" : "SpecularSh"));
     const uint32_t constSize = sizeof(nrdc::ReblurConstants);
 
     // ---- permanent planes (history)
@@ -72,18 +75,27 @@ void InstanceImpl::Add_Reblur(DenoiserData& d, bool hasDiff, bool hasSpec) {
         AddPermanent(Format::R16_SFLOAT);
         AddPermanent(Format::R16_SFLOAT);
     }
+    uint16_t P_DIFF_SH_HISTORY = 0, P_SPEC_SH_HISTORY = 0;
+    if (hasDiff && sh) {
+        P_DIFF_SH_HISTORY = next++;
+        AddPermanent(FMT_SIGNAL);
+    }
     uint16_t P_SPEC_HISTORY = 0, P_SPEC_FAST = 0, P_SPEC_STAB_PING = 0, P_SPEC_STAB_PONG = 0, P_SPEC_HDT_PING = 0, P_SPEC_HDT_PONG = 0;
     if (hasSpec) {
         P_SPEC_HISTORY = next++;
         P_SPEC_FAST = next++;
         P_SPEC_STAB_PING = next++;
         P_SPEC_STAB_PONG = next++;
+        if (sh)
+            P_SPEC_SH_HISTORY = next++;
         P_SPEC_HDT_PING = next++;
         P_SPEC_HDT_PONG = next++;
         AddPermanent(FMT_SIGNAL);
         AddPermanent(FMT_FAST);
         AddPermanent(Format::R16_SFLOAT);
         AddPermanent(Format::R16_SFLOAT);
+        if (sh)
+            AddPermanent(FMT_SIGNAL);
         AddPermanent(FMT_HITDIST_FOR_TRACKING);
         AddPermanent(FMT_HITDIST_FOR_TRACKING);
     }
@@ -99,27 +111,42 @@ void InstanceImpl::Add_Reblur(DenoiserData& d, bool hasDiff, bool hasSpec) {
         T_SPEC_HDT = next++;
         AddTransient(FMT_HITDIST_FOR_TRACKING);
     }
-    uint16_t T_DIFF_TMP2 = 0, T_DIFF_FAST = 0, T_SPEC_TMP2 = 0, T_SPEC_FAST = 0;
+    uint16_t T_DIFF_TMP2 = 0, T_DIFF_FAST = 0, T_SPEC_TMP2 = 0, T_SPEC_FAST = 0, T_DIFF_SH_TMP2 = 0, T_SPEC_SH_TMP2 = 0;
     if (hasDiff) {
         T_DIFF_TMP2 = next++;
         T_DIFF_FAST = next++;
         AddTransient(FMT_SIGNAL);
         AddTransient(FMT_FAST);
+        if (sh) {
+            T_DIFF_SH_TMP2 = next++;
+            AddTransient(FMT_SIGNAL);
+        }
     }
     if (hasSpec) {
         T_SPEC_TMP2 = next++;
         T_SPEC_FAST = next++;
         AddTransient(FMT_SIGNAL);
         AddTransient(FMT_FAST);
+        if (sh) {
+            T_SPEC_SH_TMP2 = next++;
+            AddTransient(FMT_SIGNAL);
+        }
     }
     const uint16_t T_TILES = next++;
     AddTransient(FMT_TILES, 16);
 
     // The user-visible outputs double as scratch ("TEMP1")
-    const uint16_t DIFF_TEMP1 = (uint16_t)ResourceType::OUT_DIFF_RADIANCE_HITDIST, DIFF_TEMP2 = T_DIFF_TMP2;
-    const uint16_t SPEC_TEMP1 = (uint16_t)ResourceType::OUT_SPEC_RADIANCE_HITDIST, SPEC_TEMP2 = T_SPEC_TMP2;
-    const uint16_t IN_DIFF = (uint16_t)ResourceType::IN_DIFF_RADIANCE_HITDIST;
-    const uint16_t IN_SPEC = (uint16_t)ResourceType::IN_SPEC_RADIANCE_HITDIST;
+    const uint16_t OUT_DIFF = (uint16_t)(sh ? ResourceType::OUT_DIFF_SH0 : ResourceType::OUT_DIFF_RADIANCE_HITDIST);
+    const uint16_t OUT_SPEC = (uint16_t)(sh ? ResourceType::OUT_SPEC_SH0 : ResourceType::OUT_SPEC_RADIANCE_HITDIST);
+    const uint16_t DIFF_TEMP1 = OUT_DIFF, DIFF_TEMP2 = T_DIFF_TMP2;
+    const uint16_t SPEC_TEMP1 = OUT_SPEC, SPEC_TEMP2 = T_SPEC_TMP2;
+    const uint16_t IN_DIFF = (uint16_t)(sh ? ResourceType::IN_DIFF_SH0 : ResourceType::IN_DIFF_RADIANCE_HITDIST);
+    const uint16_t IN_SPEC = (uint16_t)(sh ? ResourceType::IN_SPEC_SH0 : ResourceType::IN_SPEC_RADIANCE_HITDIST);
+    // SH1 planes: the user outputs double as scratch here too
+    const uint16_t IN_DIFF_SH = (uint16_t)ResourceType::IN_DIFF_SH1, IN_SPEC_SH = (uint16_t)ResourceType::IN_SPEC_SH1;
+    const uint16_t DIFF_SH_TEMP1 = (uint16_t)ResourceType::OUT_DIFF_SH1, DIFF_SH_TEMP2 = T_DIFF_SH_TMP2;
+    const uint16_t SPEC_SH_TEMP1 = (uint16_t)ResourceType::OUT_SPEC_SH1, SPEC_SH_TEMP2 = T_SPEC_SH_TMP2;
+    const bool diffSh = hasDiff && sh, specSh = hasSpec && sh;
 
     char passName[96], shader[128];
     auto Pass = [&](const char* what) {
@@ -149,7 +176,12 @@ void InstanceImpl::Add_Reblur(DenoiserData& d, bool hasDiff, bool hasSpec) {
         if (hasSpec) In(IN_SPEC);
         if (hasDiff) Out(isPrepassEnabled ? DIFF_TEMP2 : DIFF_TEMP1);
         if (hasSpec) Out(isPrepassEnabled ? SPEC_TEMP2 : SPEC_TEMP1);
-        EndPair("HitDistReconstruction", is5x5 ? "_5x5" : "");
+        { // the SH family reuses the radiance family's reconstruction shaders (the hit distance lives in .w of SH0)
+            const char* keep = family;
+            family = baseFamily;
+            EndPair("HitDistReconstruction", is5x5 ? "_5x5" : "");
+            family = keep;
+        }
     }
 
     for (uint32_t i = 0; i < PREPASS_PERMUTATIONS; i++) {
@@ -160,9 +192,13 @@ void InstanceImpl::Add_Reblur(DenoiserData& d, bool hasDiff, bool hasSpec) {
         In(ResourceType::IN_VIEWZ);
         if (hasDiff) In(isAfterReconstruction ? DIFF_TEMP2 : IN_DIFF);
         if (hasSpec) In(isAfterReconstruction ? SPEC_TEMP2 : IN_SPEC);
+        if (diffSh) In(IN_DIFF_SH);
+        if (specSh) In(IN_SPEC_SH);
         if (hasDiff) Out(DIFF_TEMP1);
         if (hasSpec) Out(SPEC_TEMP1);
         if (hasSpec) Out(T_SPEC_HDT);
+        if (diffSh) Out(DIFF_SH_TEMP1);
+        if (specSh) Out(SPEC_SH_TEMP1);
         EndPair("PrePass", "");
     }
 
@@ -187,6 +223,10 @@ void InstanceImpl::Add_Reblur(DenoiserData& d, bool hasDiff, bool hasSpec) {
         if (hasSpec) In(P_SPEC_FAST);
         if (hasSpec) In(P_SPEC_HDT_PING, P_SPEC_HDT_PONG);
         if (hasSpec) In(T_SPEC_HDT);
+        if (diffSh) In(isAfterPrepass ? DIFF_SH_TEMP1 : IN_DIFF_SH);
+        if (specSh) In(isAfterPrepass ? SPEC_SH_TEMP1 : IN_SPEC_SH);
+        if (diffSh) In(P_DIFF_SH_HISTORY);
+        if (specSh) In(P_SPEC_SH_HISTORY);
         if (hasDiff) Out(DIFF_TEMP2);
         if (hasSpec) Out(SPEC_TEMP2);
         if (hasDiff) Out(T_DIFF_FAST);
@@ -194,6 +234,8 @@ void InstanceImpl::Add_Reblur(DenoiserData& d, bool hasDiff, bool hasSpec) {
         if (hasSpec) Out(P_SPEC_HDT_PONG, P_SPEC_HDT_PING);
         Out(T_DATA1);
         Out(T_DATA2);
+        if (diffSh) Out(DIFF_SH_TEMP2);
+        if (specSh) Out(SPEC_SH_TEMP2);
         EndPair("TemporalAccumulation", "");
     }
 
@@ -206,10 +248,14 @@ void InstanceImpl::Add_Reblur(DenoiserData& d, bool hasDiff, bool hasSpec) {
     if (hasSpec) In(SPEC_TEMP2);
     if (hasDiff) In(T_DIFF_FAST);
     if (hasSpec) In(T_SPEC_FAST);
+    if (diffSh) In(DIFF_SH_TEMP2);
+    if (specSh) In(SPEC_SH_TEMP2);
     if (hasDiff) Out(DIFF_TEMP1);
     if (hasSpec) Out(SPEC_TEMP1);
     if (hasDiff) Out(P_DIFF_FAST);
     if (hasSpec) Out(P_SPEC_FAST);
+    if (diffSh) Out(DIFF_SH_TEMP1);
+    if (specSh) Out(SPEC_SH_TEMP1);
     EndPair("HistoryFix", "");
 
     Pass("Blur");
@@ -219,9 +265,13 @@ void InstanceImpl::Add_Reblur(DenoiserData& d, bool hasDiff, bool hasSpec) {
     if (hasDiff) In(DIFF_TEMP1);
     if (hasSpec) In(SPEC_TEMP1);
     In(ResourceType::IN_VIEWZ);
+    if (diffSh) In(DIFF_SH_TEMP1);
+    if (specSh) In(SPEC_SH_TEMP1);
     if (hasDiff) Out(DIFF_TEMP2);
     if (hasSpec) Out(SPEC_TEMP2);
     Out(P_PREV_VIEWZ);
+    if (diffSh) Out(DIFF_SH_TEMP2);
+    if (specSh) Out(SPEC_SH_TEMP2);
     EndPair("Blur", "");
 
     for (uint32_t i = 0; i < POST_BLUR_PERMUTATIONS; i++) {
@@ -233,14 +283,20 @@ void InstanceImpl::Add_Reblur(DenoiserData& d, bool hasDiff, bool hasSpec) {
         if (hasDiff) In(DIFF_TEMP2);
         if (hasSpec) In(SPEC_TEMP2);
         In(P_PREV_VIEWZ);
+        if (diffSh) In(DIFF_SH_TEMP2);
+        if (specSh) In(SPEC_SH_TEMP2);
         Out(P_PREV_NORMAL_ROUGHNESS);
         if (hasDiff) Out(P_DIFF_HISTORY);
         if (hasSpec) Out(P_SPEC_HISTORY);
         if (!isTemporalStabilization) {
             Out(P_PREV_INTERNAL_DATA);
-            if (hasDiff) Out(ResourceType::OUT_DIFF_RADIANCE_HITDIST);
-            if (hasSpec) Out(ResourceType::OUT_SPEC_RADIANCE_HITDIST);
+            if (hasDiff) Out(OUT_DIFF);
+            if (hasSpec) Out(OUT_SPEC);
+            if (diffSh) Out(ResourceType::OUT_DIFF_SH1);
+            if (specSh) Out(ResourceType::OUT_SPEC_SH1);
         }
+        if (diffSh) Out(P_DIFF_SH_HISTORY);
+        if (specSh) Out(P_SPEC_SH_HISTORY);
         EndPair("PostBlur", isTemporalStabilization ? "" : "_NoTemporalStabilization");
     }
 
@@ -258,12 +314,16 @@ void InstanceImpl::Add_Reblur(DenoiserData& d, bool hasDiff, bool hasSpec) {
         if (hasDiff) In(P_DIFF_STAB_PING, P_DIFF_STAB_PONG);
         if (hasSpec) In(P_SPEC_STAB_PING, P_SPEC_STAB_PONG);
         if (hasSpec) In(P_SPEC_HDT_PONG, P_SPEC_HDT_PING);
+        if (diffSh) In(P_DIFF_SH_HISTORY);
+        if (specSh) In(P_SPEC_SH_HISTORY);
         Out(ResourceType::IN_MV); // optionally patched in place (specular MV modification)
         Out(P_PREV_INTERNAL_DATA);
-        if (hasDiff) Out(ResourceType::OUT_DIFF_RADIANCE_HITDIST);
-        if (hasSpec) Out(ResourceType::OUT_SPEC_RADIANCE_HITDIST);
+        if (hasDiff) Out(OUT_DIFF);
+        if (hasSpec) Out(OUT_SPEC);
         if (hasDiff) Out(P_DIFF_STAB_PONG, P_DIFF_STAB_PING);
         if (hasSpec) Out(P_SPEC_STAB_PONG, P_SPEC_STAB_PING);
+        if (diffSh) Out(ResourceType::OUT_DIFF_SH1);
+        if (specSh) Out(ResourceType::OUT_SPEC_SH1);
         EndPair("TemporalStabilization", "");
     }
 
@@ -271,8 +331,12 @@ void InstanceImpl::Add_Reblur(DenoiserData& d, bool hasDiff, bool hasSpec) {
     In(ResourceType::IN_VIEWZ);
     if (hasDiff) In(IN_DIFF);
     if (hasSpec) In(IN_SPEC);
-    if (hasDiff) Out(ResourceType::OUT_DIFF_RADIANCE_HITDIST);
-    if (hasSpec) Out(ResourceType::OUT_SPEC_RADIANCE_HITDIST);
+    if (diffSh) In(IN_DIFF_SH);
+    if (specSh) In(IN_SPEC_SH);
+    if (hasDiff) Out(OUT_DIFF);
+    if (hasSpec) Out(OUT_SPEC);
+    if (diffSh) Out(ResourceType::OUT_DIFF_SH1);
+    if (specSh) Out(ResourceType::OUT_SPEC_SH1);
     snprintf(shader, sizeof(shader), "REBLUR_%s_SplitScreen.cs", family);
     EndPass(shader, 8, 16, constSize);
 
@@ -291,8 +355,8 @@ void InstanceImpl::Add_Reblur(DenoiserData& d, bool hasDiff, bool hasSpec) {
 void InstanceImpl::Update_Reblur(const DenoiserData& d) {
     const ReblurSettings& s = d.settings.reblur;
     const CommonSettings& cs = m_CommonSettings;
-    const bool hasDiff = d.desc.denoiser != Denoiser::REBLUR_SPECULAR;
-    const bool hasSpec = d.desc.denoiser != Denoiser::REBLUR_DIFFUSE;
+    const bool hasDiff = d.desc.denoiser != Denoiser::REBLUR_SPECULAR && d.desc.denoiser != Denoiser::REBLUR_SPECULAR_SH;
+    const bool hasSpec = d.desc.denoiser != Denoiser::REBLUR_DIFFUSE && d.desc.denoiser != Denoiser::REBLUR_DIFFUSE_SH;
 
     const bool enableHitDistanceReconstruction = s.hitDistanceReconstructionMode != HitDistanceReconstructionMode::OFF && s.checkerboardMode == CheckerboardMode::OFF;
     const bool skipTemporalStabilization = s.maxStabilizedFrameNum == 0;

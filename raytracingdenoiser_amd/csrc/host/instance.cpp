@@ -125,13 +125,22 @@ Result InstanceImpl::Create(const InstanceCreationDesc& desc) {
 
         switch (dd.denoiser) {
             case Denoiser::REBLUR_DIFFUSE:
-                Add_Reblur(data, true, false);
+                Add_Reblur(data, true, false, false);
                 break;
             case Denoiser::REBLUR_SPECULAR:
-                Add_Reblur(data, false, true);
+                Add_Reblur(data, false, true, false);
                 break;
             case Denoiser::REBLUR_DIFFUSE_SPECULAR:
-                Add_Reblur(data, true, true);
+                Add_Reblur(data, true, true, false);
+                break;
+            case Denoiser::REBLUR_DIFFUSE_SH:
+                Add_Reblur(data, true, false, true);
+                break;
+            case Denoiser::REBLUR_SPECULAR_SH:
+                Add_Reblur(data, false, true, true);
+                break;
+            case Denoiser::REBLUR_DIFFUSE_SPECULAR_SH:
+                Add_Reblur(data, true, true, true);
                 break;
             case Denoiser::REBLUR_DIFFUSE_OCCLUSION:
                 Add_ReblurOcclusion(data, true, false);
@@ -525,6 +534,9 @@ Result InstanceImpl::GetComputeDispatches(const Identifier* identifiers, uint32_
             case Denoiser::REBLUR_DIFFUSE:
             case Denoiser::REBLUR_SPECULAR:
             case Denoiser::REBLUR_DIFFUSE_SPECULAR:
+            case Denoiser::REBLUR_DIFFUSE_SH:
+            case Denoiser::REBLUR_SPECULAR_SH:
+            case Denoiser::REBLUR_DIFFUSE_SPECULAR_SH:
                 Update_Reblur(d);
                 break;
             case Denoiser::REBLUR_DIFFUSE_OCCLUSION:

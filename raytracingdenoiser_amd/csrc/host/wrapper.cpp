@@ -13,6 +13,9 @@ const nrd::Denoiser g_Supported[] = {
     nrd::Denoiser::REBLUR_DIFFUSE,
     nrd::Denoiser::REBLUR_SPECULAR,
     nrd::Denoiser::REBLUR_DIFFUSE_SPECULAR,
+    nrd::Denoiser::REBLUR_DIFFUSE_SH,
+    nrd::Denoiser::REBLUR_SPECULAR_SH,
+    nrd::Denoiser::REBLUR_DIFFUSE_SPECULAR_SH,
     nrd::Denoiser::REBLUR_DIFFUSE_OCCLUSION,
     nrd::Denoiser::REBLUR_SPECULAR_OCCLUSION,
     nrd::Denoiser::REBLUR_DIFFUSE_SPECULAR_OCCLUSION,

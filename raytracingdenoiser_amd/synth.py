@@ -160,6 +160,14 @@ def _norm_hit_dist(hit_dist, view_z, roughness):
     return (hit_dist / f).clamp(0.0, 1.0)
 
 
+def _reblur_sh1(radiance, direction):
+    """REBLUR_FrontEnd_PackSh (reference NRD.hlsli:745-762): SH0 = (Y, Co, Cg, normHitDist) -- the same texel as the non-SH packing --
+    and SH1 = (direction * Y, sharpness = 0), RGBA16F."""
+    y = _ycocg(radiance.clamp(0.0, FP16_MAX))[..., 0]
+    sh1 = torch.cat([direction.clamp(-1.0, 1.0) * y.unsqueeze(-1), torch.zeros_like(y).unsqueeze(-1)], -1)
+    return sh1.clamp(-FP16_MAX, FP16_MAX).to(torch.float16).contiguous()
+
+
 def _pack_relax(out, name, radiance, hit_dist, direction):
     """RELAX_FrontEnd_PackRadianceAndHitDist / RELAX_FrontEnd_PackSh (reference NRD.hlsli:789-818), both RGBA16F:
     <name>_relax = SH0 = (radiance, hitDist in world units), <name>_relax_sh1 = (direction * luminance, 0)."""
@@ -212,6 +220,7 @@ def render_frame(width, height, frame, device="cpu", static_camera=False, noise=
         rad = torch.where(is_sky.unsqueeze(-1), torch.zeros_like(rad), rad).clamp(0.0, 250.0)
         nhd = torch.where(is_sky, torch.zeros_like(hit_d), _norm_hit_dist(hit_d, view_z, torch.ones_like(rough)))
         out["diff"] = torch.cat([_ycocg(rad), nhd.unsqueeze(-1)], -1).clamp(-FP16_MAX, FP16_MAX).to(torch.float16).contiguous()
+        out["diff_sh1"] = _reblur_sh1(rad, wd)
         if "relax" in want:
             _pack_relax(out, "diff", rad, torch.where(is_sky, torch.zeros_like(hit_d), hit_d), wd)
 
@@ -231,6 +240,7 @@ def render_frame(width, height, frame, device="cpu", static_camera=False, noise=
         rad = torch.where((is_sky | below).unsqueeze(-1), torch.zeros_like(rad), rad).clamp(0.0, 250.0)
         nhd = torch.where(is_sky, torch.zeros_like(hit_d), _norm_hit_dist(hit_d, view_z, rough))
         out["spec"] = torch.cat([_ycocg(rad), nhd.unsqueeze(-1)], -1).clamp(-FP16_MAX, FP16_MAX).to(torch.float16).contiguous()
+        out["spec_sh1"] = _reblur_sh1(rad, ws)
         if "relax" in want:
             _pack_relax(out, "spec", rad, torch.where(is_sky, torch.zeros_like(hit_d), hit_d), ws)
 

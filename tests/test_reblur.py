@@ -223,3 +223,45 @@ def test_hip_matches_oracle_occlusion_options():
     worst = parity.run_parity("REBLUR_SPECULAR_OCCLUSION", width=160, height=96, frames=4, verbose=True, extra_want=("holes", "confidence"),
                               settings_overrides=dict(hitDistanceReconstructionMode=2), cs_kw=dict(isHistoryConfidenceAvailable=True, isDisocclusionThresholdMixAvailable=True))
     assert worst <= parity.REL_TOL
+
+
+# ---------------------------------------------------------------------------------------------- SH family
+SH_FAMILY = ["REBLUR_DIFFUSE_SPECULAR_SH", "REBLUR_DIFFUSE_SH", "REBLUR_SPECULAR_SH"]
+
+
+def test_oracle_sh_family_adds_a_plane_without_touching_sh0():
+    """REBLUR_*_SH (reference Denoisers/Reblur_*Sh.hpp): SH0 = the non-SH texel, so OUT_*_SH0 must equal the output of the non-SH denoiser bit
+    for bit; SH1 (direction * luma) is filtered with the same weights -- its length follows the denoised luma, its noise drops."""
+    seq = parity.generate_sequence("REBLUR_DIFFUSE_SPECULAR_SH", W, H, 6)
+    sh = _run_oracle("REBLUR_DIFFUSE_SPECULAR_SH", seq)
+    plain = _run_oracle("REBLUR_DIFFUSE_SPECULAR", seq)
+    shaders = [d.shader for d in sh.last_dispatches]
+    assert shaders == ["REBLUR_ClassifyTiles.cs"] + ["REBLUR_DiffuseSpecularSh_%s.cs" % p for p in ("PrePass", "TemporalAccumulation", "HistoryFix", "Blur", "PostBlur", "TemporalStabilization")]
+    assert len(sh.inst.permanent_pool) == len(plain.inst.permanent_pool) + 2 and len(sh.inst.transient_pool) == len(plain.inst.transient_pool) + 2
+    assert np.array_equal(sh.output(RT.OUT_DIFF_SH0), plain.output(RT.OUT_DIFF_RADIANCE_HITDIST))
+    assert np.array_equal(sh.output(RT.OUT_SPEC_SH0), plain.output(RT.OUT_SPEC_RADIANCE_HITDIST))
+    m = ~seq[-1]["is_sky"].numpy()
+    for rt, key in ((RT.OUT_DIFF_SH1, "diff_sh1"), (RT.OUT_SPEC_SH1, "spec_sh1")):
+        out, noisy = sh.output(rt)[m][:, :3], seq[-1][key].float().numpy()[m][:, :3]
+        assert not np.isnan(out).any() and out.std() < 0.9 * noisy.std()
+    # hit-distance reconstruction reuses the radiance family's shader
+    hd = _run_oracle("REBLUR_DIFFUSE_SH", seq[:2], overrides=dict(hitDistanceReconstructionMode=1))
+    assert [d.shader for d in hd.last_dispatches][1] == "REBLUR_Diffuse_HitDistReconstruction.cs"
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", SH_FAMILY)
+def test_hip_matches_oracle_sh(name):
+    worst = parity.run_parity(name, width=192, height=128, frames=6, verbose=True)
+    assert worst <= parity.REL_TOL
+
+
+@pytest.mark.gpu
+def test_hip_matches_oracle_sh_options():
+    # odd size, no temporal stabilisation (history copies of SH0 and SH1), performance mode, 5x5 hit-distance reconstruction, anti-firefly
+    worst = parity.run_parity("REBLUR_DIFFUSE_SPECULAR_SH", width=211, height=117, frames=4, verbose=True, extra_want=("holes",),
+                              settings_overrides=dict(maxStabilizedFrameNum=0, enablePerformanceMode=True, hitDistanceReconstructionMode=2, enableAntiFirefly=True))
+    assert worst <= parity.REL_TOL
+    worst = parity.run_parity("REBLUR_SPECULAR_SH", width=160, height=96, frames=3, verbose=True,
+                              settings_overrides=dict(diffusePrepassBlurRadius=0.0, specularPrepassBlurRadius=0.0), cs_kw=dict(splitScreen=0.4))
+    assert worst <= parity.REL_TOL
