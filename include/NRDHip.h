@@ -52,7 +52,7 @@ uint32_t nrdHipCreateExecutorWithArena(void* instance, uint16_t resourceWidth, u
 // Formats accepted in this build (anything else -> UNSUPPORTED):
 //   IN_MV RGBA16_SFLOAT | IN_NORMAL_ROUGHNESS R10_G10_B10_A2_UNORM | IN_VIEWZ R32_SFLOAT
 //   IN/OUT_{DIFF,SPEC}_RADIANCE_HITDIST RGBA16_SFLOAT | IN/OUT_{DIFF,SPEC}_SH0, _SH1 RGBA16_SFLOAT (REBLUR / RELAX SH variants)
-//   IN/OUT_{DIFF,SPEC}_HITDIST R16_UNORM (REBLUR occlusion family) | IN_PENUMBRA R16_SFLOAT | IN_TRANSLUCENCY RGBA8_UNORM
+//   IN/OUT_{DIFF,SPEC}_HITDIST R16_UNORM (REBLUR occlusion family) | IN/OUT_DIFF_DIRECTION_HITDIST RGBA16_SNORM | IN_PENUMBRA R16_SFLOAT | IN_TRANSLUCENCY RGBA8_UNORM
 //   OUT_SHADOW_TRANSLUCENCY R8_UNORM (SIGMA_SHADOW) or RGBA8_UNORM (an instance holding SIGMA_SHADOW_TRANSLUCENCY)
 //   IN_SIGNAL / OUT_SIGNAL RGBA32_SFLOAT | IN_{DIFF,SPEC}_CONFIDENCE, IN_DISOCCLUSION_THRESHOLD_MIX R8_UNORM
 // include/NRD.hip.h has the device functions that produce / consume these encodings (the NRD.hlsli front-end and back-end).
@@ -92,7 +92,7 @@ uint32_t nrdHipGetPoolMemoryUsage(const NrdHipExecutor* executor, uint64_t* perm
 // Diagnostics: evaluates one primitive of the device numerics contract (DESIGN.md "Numerics") elementwise on device
 // arrays, so a harness can pin the GPU's codecs and transcendentals bit-for-bit against another implementation.
 //   op: 0 exp2, 1 log2, 2 atan, 3 pow(x, y = in2), 4 fp32->fp16->fp32 round trip, 5 x / in2, 6 sqrt, 7 1/sqrt,
-//       8..12 small-integer / {1023, 255, 63, 15, 3} (the codecs' 3-op exact division), 13 exp(-0.66 x^2), 14 small-integer / 65535
+//       8..12 small-integer / {1023, 255, 63, 15, 3} (the codecs' 3-op exact division), 13 exp(-0.66 x^2), 14 small-integer / 65535, 15 int16 / 32767
 // in2 may be NULL for unary ops. Launches on hipStream (a hipStream_t as void*, may be NULL).
 uint32_t nrdHipEvalNumerics(uint32_t op, const float* in1, const float* in2, float* out, uint32_t count, void* hipStream);
 

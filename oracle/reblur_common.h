@@ -131,26 +131,60 @@ inline float4 ClampNegativeToZero(float4 v) {
     float3 rgb = _NRD_LinearToYCoCg(_NRD_YCoCgToLinear(v.xyz()));
     return float4(rgb, saturate(v.w));
 }
-// REBLUR_TYPE (REBLUR_Config.hlsli:100-105) and its overloaded helpers (REBLUR_Common.hlsli:148-170): in the *_OCCLUSION denoisers the
-// signal is the normalised hit distance alone, a float
-template <bool OCCLUSION> struct ReblurSignal;
-template <> struct ReblurSignal<false> {
+// REBLUR_TYPE (REBLUR_Config.hlsli:100-105) and its overloaded helpers (REBLUR_Common.hlsli:148-215). Three kinds of signal:
+//   0 radiance            float4 (YCoCg radiance, normalised hit distance), RGBA16F
+//   1 occlusion           float  (the normalised hit distance alone), R16_UNORM                      -- REBLUR_OCCLUSION
+//   2 directional occl.   float4 (direction * hit distance?, normalised hit distance), RGBA16_SNORM  -- REBLUR_DIRECTIONAL_OCCLUSION:
+//                         same arithmetic as radiance except that the "luma" of the signal is its .w
+enum { SIGNAL_RADIANCE = 0, SIGNAL_OCCLUSION = 1, SIGNAL_DIRECTIONAL_OCCLUSION = 2 };
+struct DirOcc { // distinct type so that GetLuma / ChangeLuma / ClampNegativeToZero can be overloaded
+    float4 v;
+    DirOcc() {}
+    explicit DirOcc(float a) : v(a) {}
+    explicit DirOcc(float4 a) : v(a) {}
+    operator float4() const { return v; }
+};
+inline DirOcc operator+(DirOcc a, DirOcc b) { return DirOcc(a.v + b.v); }
+inline DirOcc operator*(DirOcc a, float b) { return DirOcc(a.v * b); }
+inline DirOcc lerp(DirOcc a, DirOcc b, float t) { return DirOcc(lerp(a.v, b.v, t)); }
+
+template <int KIND> struct ReblurSignal;
+template <> struct ReblurSignal<SIGNAL_RADIANCE> {
     typedef float4 type;
     static float4 From(float4 texel) { return texel; }
     static float4 WithHitDist(float4 s, float hitDist) { return float4(s.x, s.y, s.z, hitDist); }
 };
-template <> struct ReblurSignal<true> {
+template <> struct ReblurSignal<SIGNAL_OCCLUSION> {
     typedef float type;
     static float From(float4 texel) { return texel.x; }
     static float WithHitDist(float, float hitDist) { return hitDist; }
 };
+template <> struct ReblurSignal<SIGNAL_DIRECTIONAL_OCCLUSION> {
+    typedef DirOcc type;
+    static DirOcc From(float4 texel) { return DirOcc(texel); }
+    static DirOcc WithHitDist(DirOcc s, float hitDist) { return DirOcc(float4(s.v.x, s.v.y, s.v.z, hitDist)); }
+};
+template <typename S> struct SignalKind { enum { value = SIGNAL_RADIANCE }; };
+template <> struct SignalKind<float> { enum { value = SIGNAL_OCCLUSION }; };
+template <> struct SignalKind<DirOcc> { enum { value = SIGNAL_DIRECTIONAL_OCCLUSION }; };
+
 inline float ExtractHitDist(float4 v) { return v.w; }
 inline float ExtractHitDist(float v) { return v; }
+inline float ExtractHitDist(DirOcc s) { return s.v.w; }
 inline float GetLuma(float v) { return v; }
+inline float GetLuma(DirOcc s) { return s.v.w; }
 inline float ChangeLuma(float, float newLuma) { return newLuma; }
+inline DirOcc ChangeLuma(DirOcc s, float newLuma) {
+    float k = GetLumaScale(s.v.w, newLuma);
+    return DirOcc(float4(s.v.x * k, s.v.y * k, s.v.z * k, newLuma));
+}
 inline float ClampNegativeToZero(float v) { return saturate(v); } // ClampNegativeHitDistToZero
+inline DirOcc ClampNegativeToZero(DirOcc s) { return ChangeLuma(s, saturate(s.v.w)); }
 inline float MixHistoryAndCurrent(const ReblurCB& c, float history, float current, float f, float roughness = 1.0f) {
     return lerp(history, current, max(f, GetMinAllowedLimitForHitDistNonLinearAccumSpeed(c, roughness)));
+}
+inline DirOcc MixHistoryAndCurrent(const ReblurCB& c, DirOcc history, DirOcc current, float f, float roughness = 1.0f) {
+    return DirOcc(MixHistoryAndCurrent(c, history.v, current.v, f, roughness));
 }
 
 inline float ComputeAntilag(const ReblurCB& c, float history, float avg, float sigma, float accumSpeed) { // REBLUR_ANTILAG_MODE = 2

@@ -64,8 +64,9 @@ struct SpatialCtx { // what PrePass / Blur / PostBlur share per pixel
 template <typename S> // S = REBLUR_TYPE: float4 (radiance + hit distance) or float (occlusion: hit distance only)
 S DiffuseSpatialFilter(const ReblurCB& c, SpatialMode mode, const SpatialCtx& s, S diff, const Tex& gIn_Diff, const Tex& gIn_ViewZ, const Tex& gIn_Normal_Roughness,
     float4* diffSh = nullptr, const Tex* gIn_DiffSh = nullptr) { // REBLUR_SH: the SH1 plane is filtered with the same weights (all 4 components)
-    constexpr bool OCC = sizeof(S) == sizeof(float);
-    typedef ReblurSignal<OCC> Sig;
+    constexpr int KIND = SignalKind<S>::value;
+    constexpr bool OCC = KIND == SIGNAL_OCCLUSION;
+    typedef ReblurSignal<KIND> Sig;
     if (mode == PRE_BLUR && c.gDiffPrepassBlurRadius == 0.0f)
         return diff;
 
@@ -165,8 +166,9 @@ S DiffuseSpatialFilter(const ReblurCB& c, SpatialMode mode, const SpatialCtx& s,
 template <typename S>
 S SpecularSpatialFilter(const ReblurCB& c, SpatialMode mode, const SpatialCtx& s, S spec, const Tex& gIn_Spec, const Tex& gIn_ViewZ,
     const Tex& gIn_Normal_Roughness, Tex* gOut_SpecHitDistForTracking, float4* specSh = nullptr, const Tex* gIn_SpecSh = nullptr) { // REBLUR_SH: .xyz only (.w = roughness for AA)
-    constexpr bool OCC = sizeof(S) == sizeof(float);
-    typedef ReblurSignal<OCC> Sig;
+    constexpr int KIND = SignalKind<S>::value;
+    constexpr bool OCC = KIND == SIGNAL_OCCLUSION;
+    typedef ReblurSignal<KIND> Sig;
     float smc = GetSpecMagicCurve(s.roughness);
     if (mode == PRE_BLUR && c.gSpecPrepassBlurRadius == 0.0f)
         return spec;
@@ -343,8 +345,10 @@ bool MakeSpatialCtx(const ReblurCB& c, int px, int py, const Tex& gIn_Tiles, con
 }
 
 // ================================================================================================ PrePass
-template <bool DIFF, bool SPEC, bool PERF, bool SH>
+template <bool DIFF, bool SPEC, bool PERF, bool SH, int KIND>
 void PrePass(const PassIO& io) {
+    typedef ReblurSignal<KIND> Sig;
+    typedef typename Sig::type S;
     const ReblurCB& c = *(const ReblurCB*)io.constants;
     Cursor cur(io);
     const Tex& gIn_Tiles = *cur.next();
@@ -367,17 +371,17 @@ void PrePass(const PassIO& io) {
             if (!MakeSpatialCtx(c, px, py, gIn_Tiles, gIn_ViewZ, gIn_Normal_Roughness, c.gRotatorPre, PERF, s))
                 continue;
             if (DIFF) {
-                float4 diff = gIn_Diff->Load(px, py);
+                S diff = Sig::From(gIn_Diff->Load(px, py));
                 float4 diffSh = SH ? gIn_DiffSh->Load(px, py) : float4(0.0f);
-                diff = DiffuseSpatialFilter<float4>(c, PRE_BLUR, s, diff, *gIn_Diff, gIn_ViewZ, gIn_Normal_Roughness, SH ? &diffSh : nullptr, gIn_DiffSh);
+                diff = DiffuseSpatialFilter<S>(c, PRE_BLUR, s, diff, *gIn_Diff, gIn_ViewZ, gIn_Normal_Roughness, SH ? &diffSh : nullptr, gIn_DiffSh);
                 gOut_Diff->Store(px, py, diff);
                 if (SH)
                     gOut_DiffSh->Store(px, py, diffSh);
             }
             if (SPEC) {
-                float4 spec = gIn_Spec->Load(px, py);
+                S spec = Sig::From(gIn_Spec->Load(px, py));
                 float4 specSh = SH ? gIn_SpecSh->Load(px, py) : float4(0.0f);
-                spec = SpecularSpatialFilter<float4>(c, PRE_BLUR, s, spec, *gIn_Spec, gIn_ViewZ, gIn_Normal_Roughness, gOut_SpecHitDistForTracking, SH ? &specSh : nullptr, gIn_SpecSh);
+                spec = SpecularSpatialFilter<S>(c, PRE_BLUR, s, spec, *gIn_Spec, gIn_ViewZ, gIn_Normal_Roughness, gOut_SpecHitDistForTracking, SH ? &specSh : nullptr, gIn_SpecSh);
                 gOut_Spec->Store(px, py, spec);
                 if (SH)
                     gOut_SpecSh->Store(px, py, specSh);
@@ -386,9 +390,10 @@ void PrePass(const PassIO& io) {
 }
 
 // ================================================================================================ Blur
-template <bool DIFF, bool SPEC, bool PERF, bool OCC, bool SH>
+template <bool DIFF, bool SPEC, bool PERF, int KIND, bool SH>
 void Blur(const PassIO& io) {
-    typedef ReblurSignal<OCC> Sig;
+    typedef ReblurSignal<KIND> Sig;
+    constexpr bool OCC = KIND == SIGNAL_OCCLUSION;
     typedef typename Sig::type S;
     const ReblurCB& c = *(const ReblurCB*)io.constants;
     Cursor cur(io);
@@ -439,9 +444,10 @@ void Blur(const PassIO& io) {
 }
 
 // ================================================================================================ PostBlur
-template <bool DIFF, bool SPEC, bool NO_TS, bool PERF, bool OCC, bool SH>
+template <bool DIFF, bool SPEC, bool NO_TS, bool PERF, int KIND, bool SH>
 void PostBlur(const PassIO& io) {
-    typedef ReblurSignal<OCC> Sig;
+    typedef ReblurSignal<KIND> Sig;
+    constexpr bool OCC = KIND == SIGNAL_OCCLUSION;
     typedef typename Sig::type S;
     const ReblurCB& c = *(const ReblurCB*)io.constants;
     Cursor cur(io);
@@ -504,9 +510,10 @@ void PostBlur(const PassIO& io) {
 }
 
 // ================================================================================================ TemporalAccumulation
-template <bool DIFF, bool SPEC, bool PERF, bool OCC, bool SH>
+template <bool DIFF, bool SPEC, bool PERF, int KIND, bool SH>
 void TemporalAccumulation(const PassIO& io) {
-    typedef ReblurSignal<OCC> Sig;
+    typedef ReblurSignal<KIND> Sig;
+    constexpr bool OCC = KIND == SIGNAL_OCCLUSION;
     typedef typename Sig::type S;
     const ReblurCB& c = *(const ReblurCB*)io.constants;
     Cursor cur(io);
@@ -711,7 +718,7 @@ void TemporalAccumulation(const PassIO& io) {
 
             // 2x2 occlusion weights
             float4 smbOcclusionWeights = Filtering::GetBilinearCustomWeights(smbBilinearFilter, float4(smbOcclusion0.z, smbOcclusion1.y, smbOcclusion2.y, smbOcclusion3.x));
-            bool smbAllowCatRom = sum(smbOcclusion0 + smbOcclusion1 + smbOcclusion2 + smbOcclusion3) > 11.5f && !PERF; // REBLUR_USE_CATROM_FOR_SURFACE_MOTION_IN_TA
+            bool smbAllowCatRom = sum(smbOcclusion0 + smbOcclusion1 + smbOcclusion2 + smbOcclusion3) > 11.5f && !PERF && KIND != SIGNAL_DIRECTIONAL_OCCLUSION; // REBLUR_USE_CATROM_FOR_SURFACE_MOTION_IN_TA
 
             float fbits = smbOcclusion0.z * 1.0f;
             fbits += smbOcclusion1.y * 2.0f;
@@ -894,7 +901,7 @@ void TemporalAccumulation(const PassIO& io) {
                 vmbFootprintQuality = Math::Sqrt01(vmbFootprintQuality);
                 vmbSpecAccumSpeed *= lerp(vmbFootprintQuality, 1.0f, 1.0f / (1.0f + vmbSpecAccumSpeed));
 
-                bool vmbAllowCatRom = sum(vmbOcclusion) > 3.5f && !PERF; // REBLUR_USE_CATROM_FOR_VIRTUAL_MOTION_IN_TA
+                bool vmbAllowCatRom = sum(vmbOcclusion) > 3.5f && !PERF && KIND != SIGNAL_DIRECTIONAL_OCCLUSION; // REBLUR_USE_CATROM_FOR_VIRTUAL_MOTION_IN_TA
                 vmbAllowCatRom = vmbAllowCatRom && smbAllowCatRom;
 
                 // How many radians can the travelled pixels be?
@@ -1048,7 +1055,7 @@ void TemporalAccumulation(const PassIO& io) {
 
                 // Firefly suppressor (not in the occlusion family: REBLUR_TemporalAccumulation.hlsli:757, 788)
                 float specMaxRelativeIntensity = 0.0f, specAntifireflyFactor = 0.0f;
-                if (!OCC) {
+                if (KIND == SIGNAL_RADIANCE) {
                     specMaxRelativeIntensity = c.gFireflySuppressorMinRelativeScale + REBLUR_FIREFLY_SUPPRESSOR_MAX_RELATIVE_INTENSITY / (specAccumSpeed + 1.0f);
                     specAntifireflyFactor = specAccumSpeed * c.gMaxBlurRadius * REBLUR_FIREFLY_SUPPRESSOR_RADIUS_SCALE;
                     specAntifireflyFactor /= 1.0f + specAntifireflyFactor;
@@ -1074,7 +1081,7 @@ void TemporalAccumulation(const PassIO& io) {
                 float vmbSpecFast = lerp(vmbSpecFastHistory, GetLuma(spec), vmbSpecFastNonLinearAccumSpeed);
                 float specFastResult = lerp(smbSpecFast, vmbSpecFast, virtualHistoryAmount);
 
-                if (!OCC) {
+                if (KIND == SIGNAL_RADIANCE) {
                     float specFastClamped = min(specFastResult, GetLuma(specHistory) * specMaxRelativeIntensity * REBLUR_FIREFLY_SUPPRESSOR_FAST_RELATIVE_INTENSITY);
                     specFastResult = lerp(specFastResult, specFastClamped, specAntifireflyFactor);
                 }
@@ -1110,7 +1117,7 @@ void TemporalAccumulation(const PassIO& io) {
 
                 // Firefly suppressor (not in the occlusion family: REBLUR_TemporalAccumulation.hlsli:889, 918)
                 float diffMaxRelativeIntensity = 0.0f, diffAntifireflyFactor = 0.0f;
-                if (!OCC) {
+                if (KIND == SIGNAL_RADIANCE) {
                     diffMaxRelativeIntensity = c.gFireflySuppressorMinRelativeScale + REBLUR_FIREFLY_SUPPRESSOR_MAX_RELATIVE_INTENSITY / (diffAccumSpeed + 1.0f);
                     diffAntifireflyFactor = diffAccumSpeed * c.gMaxBlurRadius * REBLUR_FIREFLY_SUPPRESSOR_RADIUS_SCALE;
                     diffAntifireflyFactor /= 1.0f + diffAntifireflyFactor;
@@ -1132,7 +1139,7 @@ void TemporalAccumulation(const PassIO& io) {
                 float diffFastAccumSpeed = min(diffAccumSpeed, c.gMaxFastAccumulatedFrameNum);
                 float diffFastNonLinearAccumSpeed = 1.0f / (1.0f + diffFastAccumSpeed);
                 float diffFastResult = lerp(smbDiffFastHistory, GetLuma(diff), diffFastNonLinearAccumSpeed);
-                if (!OCC) {
+                if (KIND == SIGNAL_RADIANCE) {
                     float diffFastClamped = min(diffFastResult, GetLuma(smbDiffHistory) * diffMaxRelativeIntensity * REBLUR_FIREFLY_SUPPRESSOR_FAST_RELATIVE_INTENSITY);
                     diffFastResult = lerp(diffFastResult, diffFastClamped, diffAntifireflyFactor);
                 }
@@ -1150,8 +1157,9 @@ template <typename S>
 S HistoryFixSignal(const ReblurCB& c, bool isSpec, bool perf, int px, int py, S sig, float frameNum, float strideBase, float roughness, float viewZ, float materialID,
     float3 N, float3 Nv, float3 Xv, float2 pixelUv, float frustumSize, const Tex& gIn_ViewZ, const Tex& gIn_Normal_Roughness, const Tex& gIn_Data1, bool hasDiff,
     const Tex& gIn_Signal, const Tex& gIn_Fast, Tex& gOut_Fast, float4* sh = nullptr, const Tex* gIn_Sh = nullptr) { // REBLUR_SH: SH1 plane rides along (specular: .xyz only)
-    constexpr bool OCC = sizeof(S) == sizeof(float);
-    typedef ReblurSignal<OCC> Sig;
+    constexpr int KIND = SignalKind<S>::value;
+    constexpr bool OCC = KIND == SIGNAL_OCCLUSION;
+    typedef ReblurSignal<KIND> Sig;
     const int rw = c.gRectSizeMinusOne[0], rh = c.gRectSizeMinusOne[1];
     float smc = GetSpecMagicCurve(roughness);
 
@@ -1269,7 +1277,7 @@ S HistoryFixSignal(const ReblurCB& c, bool isSpec, bool perf, int px, int py, S 
     float luma = GetLuma(sig);
 
     // Anti-firefly: 9x9 minus the central 3x3 (REBLUR_USE_ANTIFIREFLY = 0 in the occlusion family)
-    if (c.gAntiFirefly != 0.0f && !OCC) {
+    if (c.gAntiFirefly != 0.0f && KIND == SIGNAL_RADIANCE) {
         float am1 = 0.0f, am2 = 0.0f;
         const int R = perf ? 3 : REBLUR_ANTI_FIREFLY_FILTER_RADIUS; // REBLUR_Config.hlsli:236-237
         for (int j = -R; j <= R; j++)
@@ -1290,7 +1298,7 @@ S HistoryFixSignal(const ReblurCB& c, bool isSpec, bool perf, int px, int py, S 
     // Fast-history clamping
     m1 /= 25.0f;
     m2 /= 25.0f;
-    float sigma = sqrtf(fabsf(m2 - m1 * m1)) * (OCC ? REBLUR_COLOR_CLAMPING_SIGMA_SCALE_OCCLUSION : REBLUR_COLOR_CLAMPING_SIGMA_SCALE);
+    float sigma = sqrtf(fabsf(m2 - m1 * m1)) * (KIND != SIGNAL_RADIANCE ? REBLUR_COLOR_CLAMPING_SIGMA_SCALE_OCCLUSION : REBLUR_COLOR_CLAMPING_SIGMA_SCALE);
     float lumaClamped = clamp(luma, m1 - sigma, m1 + sigma);
     luma = lerp(lumaClamped, luma, 1.0f / (1.0f + (c.gMaxFastAccumulatedFrameNum < c.gMaxAccumulatedFrameNum ? 1.0f : 0.0f) * frameNum * 2.0f));
 
@@ -1301,9 +1309,10 @@ S HistoryFixSignal(const ReblurCB& c, bool isSpec, bool perf, int px, int py, S 
     return ChangeLuma(sig, luma);
 }
 
-template <bool DIFF, bool SPEC, bool PERF, bool OCC, bool SH>
+template <bool DIFF, bool SPEC, bool PERF, int KIND, bool SH>
 void HistoryFix(const PassIO& io) {
-    typedef ReblurSignal<OCC> Sig;
+    typedef ReblurSignal<KIND> Sig;
+    constexpr bool OCC = KIND == SIGNAL_OCCLUSION;
     typedef typename Sig::type S;
     const ReblurCB& c = *(const ReblurCB*)io.constants;
     Cursor cur(io);
@@ -1366,8 +1375,10 @@ void HistoryFix(const PassIO& io) {
 }
 
 // ================================================================================================ TemporalStabilization
-template <bool DIFF, bool SPEC, bool PERF, bool SH>
+template <bool DIFF, bool SPEC, bool PERF, bool SH, int KIND>
 void TemporalStabilization(const PassIO& io) {
+    typedef ReblurSignal<KIND> Sig;
+    typedef typename Sig::type S;
     const ReblurCB& c = *(const ReblurCB*)io.constants;
     Cursor cur(io);
     const Tex& gIn_Tiles = *cur.next();
@@ -1446,7 +1457,7 @@ void TemporalStabilization(const PassIO& io) {
 
             // 3x3 luma statistics (clamped reads = LDS preload)
             auto stats = [&](const Tex& tex, float& luma, float& m1, float& sigma) {
-                auto sL = [&](int x, int y) { return GetLuma(tex.Load(clamp(x, 0, rw), clamp(y, 0, rh))); };
+                auto sL = [&](int x, int y) { return GetLuma(Sig::From(tex.Load(clamp(x, 0, rw), clamp(y, 0, rh)))); };
                 luma = sL(px, py);
                 float M1 = luma, M2 = luma * luma, mn = NRD_INF, mx = -NRD_INF;
                 for (int j = 0; j <= 2; j++)
@@ -1486,7 +1497,7 @@ void TemporalStabilization(const PassIO& io) {
                 smbDiffLumaHistory = Color::Clamp(diffLumaM1, diffLumaSigma * diffTemporalAccumulationParams.y, smbDiffLumaHistory);
                 float diffLumaStabilized = lerp(diffLuma, smbDiffLumaHistory, min(diffHistoryWeight, c.gStabilizationStrength));
 
-                float4 diff = gIn_Diff->Load(px, py);
+                S diff = Sig::From(gIn_Diff->Load(px, py));
                 diff = ChangeLuma(diff, diffLumaStabilized);
                 gOut_Diff->Store(px, py, diff);
                 gOut_DiffLumaStabilized->Store(px, py, diffLumaStabilized);
@@ -1508,8 +1519,8 @@ void TemporalStabilization(const PassIO& io) {
                 float virtualHistoryAmount = data2.x;
                 float curvature = data2.y;
 
-                float4 spec = gIn_Spec->Load(px, py);
-                float hitDistForTracking = spec.w * _REBLUR_GetHitDistanceNormalization(viewZ, c.gHitDistParams, roughness);
+                S spec = Sig::From(gIn_Spec->Load(px, py));
+                float hitDistForTracking = ExtractHitDist(spec) * _REBLUR_GetHitDistanceNormalization(viewZ, c.gHitDistParams, roughness);
                 if (c.gSpecPrepassBlurRadius != 0.0f)
                     hitDistForTracking = min(hitDistForTracking, gIn_SpecHitDistForTracking->Load(px, py).x);
 
@@ -1579,9 +1590,10 @@ void TemporalStabilization(const PassIO& io) {
 // ================================================================================================ HitDistReconstruction
 // reference Shaders/Include/REBLUR_HitDistReconstruction.hlsli:10-160 (REBLUR_USE_DECOMPRESSED_HIT_DIST_IN_RECONSTRUCTION = 0,
 // non-performance mode). BORDER = 1 -> 3x3, 2 -> 5x5 window; the window is read at rect-clamped coordinates like the LDS preload.
-template <bool DIFF, bool SPEC, int BORDER, bool PERF, bool OCC>
+template <bool DIFF, bool SPEC, int BORDER, bool PERF, int KIND>
 void HitDistReconstruction(const PassIO& io) {
-    typedef ReblurSignal<OCC> Sig;
+    typedef ReblurSignal<KIND> Sig;
+    constexpr bool OCC = KIND == SIGNAL_OCCLUSION;
     const ReblurCB& c = *(const ReblurCB*)io.constants;
     Cursor cur(io);
     const Tex& gIn_Tiles = *cur.next();
@@ -1709,26 +1721,35 @@ void SplitScreen(const PassIO& io) {
 #define REBLUR_PASSES(PREFIX, NAME, D, S, P)                                                            \
     {PREFIX NAME "_HitDistReconstruction.cs", HitDistReconstruction<D, S, 1, P, false>},               \
     {PREFIX NAME "_HitDistReconstruction_5x5.cs", HitDistReconstruction<D, S, 2, P, false>},           \
-    {PREFIX NAME "_PrePass.cs", PrePass<D, S, P, false>},                                              \
+    {PREFIX NAME "_PrePass.cs", PrePass<D, S, P, false, 0>},                                              \
     {PREFIX NAME "_TemporalAccumulation.cs", TemporalAccumulation<D, S, P, false, false>},             \
     {PREFIX NAME "_HistoryFix.cs", HistoryFix<D, S, P, false, false>},                                 \
     {PREFIX NAME "_Blur.cs", Blur<D, S, P, false, false>},                                             \
     {PREFIX NAME "_PostBlur.cs", PostBlur<D, S, false, P, false, false>},                              \
     {PREFIX NAME "_PostBlur_NoTemporalStabilization.cs", PostBlur<D, S, true, P, false, false>},       \
-    {PREFIX NAME "_TemporalStabilization.cs", TemporalStabilization<D, S, P, false>},                  \
-    {PREFIX NAME "Sh_PrePass.cs", PrePass<D, S, P, true>},                                             \
+    {PREFIX NAME "_TemporalStabilization.cs", TemporalStabilization<D, S, P, false, 0>},                  \
+    {PREFIX NAME "Sh_PrePass.cs", PrePass<D, S, P, true, 0>},                                             \
     {PREFIX NAME "Sh_TemporalAccumulation.cs", TemporalAccumulation<D, S, P, false, true>},            \
     {PREFIX NAME "Sh_HistoryFix.cs", HistoryFix<D, S, P, false, true>},                                \
     {PREFIX NAME "Sh_Blur.cs", Blur<D, S, P, false, true>},                                            \
     {PREFIX NAME "Sh_PostBlur.cs", PostBlur<D, S, false, P, false, true>},                             \
     {PREFIX NAME "Sh_PostBlur_NoTemporalStabilization.cs", PostBlur<D, S, true, P, false, true>},      \
-    {PREFIX NAME "Sh_TemporalStabilization.cs", TemporalStabilization<D, S, P, true>},                 \
+    {PREFIX NAME "Sh_TemporalStabilization.cs", TemporalStabilization<D, S, P, true, 0>},                 \
     {PREFIX NAME "Occlusion_HitDistReconstruction.cs", HitDistReconstruction<D, S, 1, P, true>},       \
     {PREFIX NAME "Occlusion_HitDistReconstruction_5x5.cs", HitDistReconstruction<D, S, 2, P, true>},   \
     {PREFIX NAME "Occlusion_TemporalAccumulation.cs", TemporalAccumulation<D, S, P, true, false>},     \
     {PREFIX NAME "Occlusion_HistoryFix.cs", HistoryFix<D, S, P, true, false>},                         \
     {PREFIX NAME "Occlusion_Blur.cs", Blur<D, S, P, true, false>},                                     \
     {PREFIX NAME "Occlusion_PostBlur_NoTemporalStabilization.cs", PostBlur<D, S, true, P, true, false>},
+// REBLUR_DIFFUSE_DIRECTIONAL_OCCLUSION: the diffuse chain on RGBA16_SNORM (direction, hit distance) texels whose "luma" is .w
+#define REBLUR_DIRECTIONAL_OCCLUSION_PASSES(PREFIX, P)                                                                                  \
+    {PREFIX "DiffuseDirectionalOcclusion_PrePass.cs", PrePass<true, false, P, false, 2>},                                              \
+    {PREFIX "DiffuseDirectionalOcclusion_TemporalAccumulation.cs", TemporalAccumulation<true, false, P, 2, false>},                    \
+    {PREFIX "DiffuseDirectionalOcclusion_HistoryFix.cs", HistoryFix<true, false, P, 2, false>},                                        \
+    {PREFIX "DiffuseDirectionalOcclusion_Blur.cs", Blur<true, false, P, 2, false>},                                                    \
+    {PREFIX "DiffuseDirectionalOcclusion_PostBlur.cs", PostBlur<true, false, false, P, 2, false>},                                     \
+    {PREFIX "DiffuseDirectionalOcclusion_PostBlur_NoTemporalStabilization.cs", PostBlur<true, false, true, P, 2, false>},              \
+    {PREFIX "DiffuseDirectionalOcclusion_TemporalStabilization.cs", TemporalStabilization<true, false, P, false, 2>},
 #define REBLUR_FAMILY(NAME, D, S)                                                                      \
     REBLUR_PASSES("REBLUR_", NAME, D, S, false)                                                        \
     REBLUR_PASSES("REBLUR_Perf_", NAME, D, S, true)                                                    \
@@ -1741,6 +1762,8 @@ const PassEntry* GetReblurPasses(uint32_t& n) {
         REBLUR_FAMILY("Diffuse", true, false)
         REBLUR_FAMILY("Specular", false, true)
         REBLUR_FAMILY("DiffuseSpecular", true, true)
+        REBLUR_DIRECTIONAL_OCCLUSION_PASSES("REBLUR_", false)
+        REBLUR_DIRECTIONAL_OCCLUSION_PASSES("REBLUR_Perf_", true)
     };
     n = sizeof(k) / sizeof(k[0]);
     return k;

@@ -22,6 +22,7 @@ enum Fmt : uint32_t {
     FMT_R16_UNORM = 13,
     FMT_R16_UINT = 15,
     FMT_R16_SFLOAT = 17,
+    FMT_RGBA16_SNORM = 24,
     FMT_RGBA16_SFLOAT = 27,
     FMT_R32_UINT = 28,
     FMT_R32_SFLOAT = 30,
@@ -66,6 +67,12 @@ inline uint32_t f32tof16(float f) {
 }
 
 inline uint32_t ToUnorm(float x, float maxValue) { return (uint32_t)floorf(saturate(x) * maxValue + 0.5f); }
+// SNORM16: clamp to [-1, 1], scale by 32767, round half away from zero; decode = max(i / 32767, -1)
+inline int32_t ToSnorm16(float x) {
+    float c = min(max(x, -1.0f), 1.0f) * 32767.0f;
+    return c >= 0.0f ? (int32_t)floorf(c + 0.5f) : -(int32_t)floorf(-c + 0.5f);
+}
+inline float FromSnorm16(int16_t v) { return max(float(v) / 32767.0f, -1.0f); }
 
 // ---- plane view ----------------------------------------------------------------------------------------------------
 struct Plane {
@@ -103,6 +110,10 @@ struct Tex {
             case FMT_RGBA16_SFLOAT: {
                 const uint16_t* h = (const uint16_t*)r + x * 4;
                 return float4(f16tof32(h[0]), f16tof32(h[1]), f16tof32(h[2]), f16tof32(h[3]));
+            }
+            case FMT_RGBA16_SNORM: {
+                const int16_t* h = (const int16_t*)r + x * 4;
+                return float4(FromSnorm16(h[0]), FromSnorm16(h[1]), FromSnorm16(h[2]), FromSnorm16(h[3]));
             }
             case FMT_R8_UNORM:
                 return float4(float(r[x]) / 255.0f, 0, 0, 0);
@@ -178,6 +189,11 @@ struct Tex {
             case FMT_RGBA16_SFLOAT: {
                 uint16_t* h = (uint16_t*)r + x * 4;
                 h[0] = (uint16_t)f32tof16(v.x), h[1] = (uint16_t)f32tof16(v.y), h[2] = (uint16_t)f32tof16(v.z), h[3] = (uint16_t)f32tof16(v.w);
+                break;
+            }
+            case FMT_RGBA16_SNORM: {
+                int16_t* h = (int16_t*)r + x * 4;
+                h[0] = (int16_t)ToSnorm16(v.x), h[1] = (int16_t)ToSnorm16(v.y), h[2] = (int16_t)ToSnorm16(v.z), h[3] = (int16_t)ToSnorm16(v.w);
                 break;
             }
             case FMT_R8_UNORM:

@@ -53,7 +53,7 @@ Format = enum.IntEnum("Format", {n: i for i, n in enumerate(_FORMATS)})
 FORMAT_BYTES = {
     Format.R8_UNORM: 1, Format.R8_UINT: 1, Format.RG8_UNORM: 2, Format.R16_UINT: 2, Format.R16_SFLOAT: 2, Format.R16_UNORM: 2,
     Format.RGBA8_UNORM: 4, Format.R32_UINT: 4, Format.R32_SFLOAT: 4, Format.R10_G10_B10_A2_UNORM: 4, Format.RG16_SFLOAT: 4,
-    Format.RGBA16_SFLOAT: 8, Format.RGBA32_SFLOAT: 16, Format.R11_G11_B10_UFLOAT: 4,
+    Format.RGBA16_SFLOAT: 8, Format.RGBA16_SNORM: 8, Format.RGBA32_SFLOAT: 16, Format.R11_G11_B10_UFLOAT: 4,
 }
 
 

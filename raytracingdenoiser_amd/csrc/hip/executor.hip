@@ -20,6 +20,9 @@ using namespace nrdhip;
 
 namespace {
 
+static_assert((uint32_t)nrd::Format::R16_UNORM == FORMAT_R16_UNORM && (uint32_t)nrd::Format::RGBA16_SNORM == FORMAT_RGBA16_SNORM && (uint32_t)nrd::Format::RGBA16_SFLOAT == FORMAT_RGBA16_SFLOAT,
+    "passes.h format constants");
+
 uint32_t BytesPerTexel(nrd::Format f) {
     using F = nrd::Format;
     switch (f) {
@@ -59,6 +62,7 @@ nrd::Format ExpectedUserFormat(nrd::ResourceType t, bool translucentShadow) {
         case R::OUT_DIFF_RADIANCE_HITDIST: case R::OUT_SPEC_RADIANCE_HITDIST: return F::RGBA16_SFLOAT;
         case R::IN_DIFF_SH0: case R::IN_DIFF_SH1: case R::IN_SPEC_SH0: case R::IN_SPEC_SH1: return F::RGBA16_SFLOAT;
         case R::OUT_DIFF_SH0: case R::OUT_DIFF_SH1: case R::OUT_SPEC_SH0: case R::OUT_SPEC_SH1: return F::RGBA16_SFLOAT;
+        case R::IN_DIFF_DIRECTION_HITDIST: case R::OUT_DIFF_DIRECTION_HITDIST: return F::RGBA16_SNORM; // REBLUR_DIFFUSE_DIRECTIONAL_OCCLUSION
         case R::IN_DIFF_HITDIST: case R::IN_SPEC_HITDIST: case R::OUT_DIFF_HITDIST: case R::OUT_SPEC_HITDIST: return F::R16_UNORM; // REBLUR occlusion family
         case R::IN_PENUMBRA: return F::R16_SFLOAT;
         case R::IN_TRANSLUCENCY: return F::RGBA8_UNORM;
@@ -97,7 +101,7 @@ struct NrdHipExecutor {
 
     std::vector<PassLauncher> launchers; // per pipeline index (nullptr = pass not implemented in this build)
     std::vector<Plane> scratchPlanes;
-    std::vector<uint8_t> scratchBytesPerTexel;
+    std::vector<uint8_t> scratchBytesPerTexel, scratchFormats;
     bool translucentShadow = false; // a SIGMA_ShadowTranslucency_* pipeline exists: OUT_SHADOW_TRANSLUCENCY is RGBA8
     std::string lastError;
 
@@ -464,6 +468,7 @@ extern "C" __attribute__((visibility("default"))) uint32_t nrdHipExecuteDispatch
 
         e->scratchPlanes.resize(d.resourcesNum);
         e->scratchBytesPerTexel.resize(d.resourcesNum);
+        e->scratchFormats.resize(d.resourcesNum);
         for (uint32_t r = 0; r < d.resourcesNum; r++) {
             const nrd::ResourceDesc& res = d.resources[r];
             if (res.type == nrd::ResourceType::PERMANENT_POOL) {
@@ -471,17 +476,20 @@ extern "C" __attribute__((visibility("default"))) uint32_t nrdHipExecuteDispatch
                     return e->Fail(nrd::Result::INVALID_ARGUMENT, "permanent pool index out of range");
                 e->scratchPlanes[r] = e->permanent[res.indexInPool];
                 e->scratchBytesPerTexel[r] = (uint8_t)BytesPerTexel(e->permanentFormat[res.indexInPool]);
+                e->scratchFormats[r] = (uint8_t)e->permanentFormat[res.indexInPool];
             } else if (res.type == nrd::ResourceType::TRANSIENT_POOL) {
                 if (res.indexInPool >= e->transient.size())
                     return e->Fail(nrd::Result::INVALID_ARGUMENT, "transient pool index out of range");
                 e->scratchPlanes[r] = e->transient[res.indexInPool];
                 e->scratchBytesPerTexel[r] = (uint8_t)BytesPerTexel(e->transientFormat[res.indexInPool]);
+                e->scratchFormats[r] = (uint8_t)e->transientFormat[res.indexInPool];
             } else {
                 uint32_t t = (uint32_t)res.type;
                 if (t >= (uint32_t)nrd::ResourceType::MAX_NUM || !e->userBound[t])
                     return e->Fail(nrd::Result::INVALID_ARGUMENT, std::string("resource not bound: ") + (nrd::GetResourceTypeString(res.type) ? nrd::GetResourceTypeString(res.type) : "?"));
                 e->scratchPlanes[r] = e->user[t];
                 e->scratchBytesPerTexel[r] = (uint8_t)BytesPerTexel(ExpectedUserFormat(res.type, e->translucentShadow));
+                e->scratchFormats[r] = (uint8_t)ExpectedUserFormat(res.type, e->translucentShadow);
             }
         }
 
@@ -489,6 +497,7 @@ extern "C" __attribute__((visibility("default"))) uint32_t nrdHipExecuteDispatch
         args.planes = e->scratchPlanes.data();
         args.planesNum = d.resourcesNum;
         args.bytesPerTexel = e->scratchBytesPerTexel.data();
+        args.formats = e->scratchFormats.data();
         args.constants = d.constantBufferData;
         args.constantsSize = d.constantBufferDataSize;
         args.stream = e->stream;
@@ -550,7 +559,7 @@ void LaunchEvalNumerics(uint32_t op, const float* in1, const float* in2, float* 
 }
 
 extern "C" __attribute__((visibility("default"))) uint32_t nrdHipEvalNumerics(uint32_t op, const float* in1, const float* in2, float* out, uint32_t count, void* hipStream) {
-    if (!in1 || !out || op > 14)
+    if (!in1 || !out || op > 15)
         return (uint32_t)nrd::Result::INVALID_ARGUMENT;
     if (count)
         nrdhip::LaunchEvalNumerics(op, in1, in2, out, count, (hipStream_t)hipStream);

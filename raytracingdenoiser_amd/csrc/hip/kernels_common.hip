@@ -99,6 +99,7 @@ __global__ __launch_bounds__(256) void EvalNumericsKernel(uint32_t op, const flo
         case 12: r = NRD_DIV_3(a); break;
         case 13: r = Exp(-0.66f * a * a); break; // GetGaussianWeight
         case 14: r = NRD_DIV_65535(a); break;
+        case 15: r = NRD_DIV_32767(a); break;
         default: break;
     }
     out[i] = r;

@@ -58,10 +58,11 @@ struct HfPixel {
 };
 
 // PERF = REBLUR_PERFORMANCE_MODE (reference REBLUR_HistoryFix.hlsli:88-90 / 139-141 / 292-294 / 338-340, REBLUR_Config.hlsli:236-237)
-template <bool IS_SPEC, bool DIFF, bool SPEC, bool PERF, bool OCC, bool SH>
-NRD_D typename ReblurSignal<OCC>::type HistoryFixSignal(const ReblurCB& c, const HfPlanes& P, const HfPixel& s, typename ReblurSignal<OCC>::type sig, float frameNum, float strideBase,
+template <bool IS_SPEC, bool DIFF, bool SPEC, bool PERF, int KIND, bool SH>
+NRD_D typename ReblurSignal<KIND>::type HistoryFixSignal(const ReblurCB& c, const HfPlanes& P, const HfPixel& s, typename ReblurSignal<KIND>::type sig, float frameNum, float strideBase,
     const Plane& gIn_Signal, const Plane& gIn_Fast, const Plane& gOut_Fast, const float* s_Luma, float4& sh, const Plane& gIn_Sh) { // SH: the SH1 plane rides along (specular: .xyz only)
-    typedef ReblurSignal<OCC> Sig;
+    typedef ReblurSignal<KIND> Sig;
+    constexpr bool OCC = KIND == SIGNAL_OCCLUSION;
     typedef typename Sig::type S;
     const int rw = c.gRectSizeMinusOne.x, rh = c.gRectSizeMinusOne.y;
     const float smc = GetSpecMagicCurve(s.roughness);
@@ -122,7 +123,7 @@ NRD_D typename ReblurSignal<OCC>::type HistoryFixSignal(const ReblurCB& c, const
                 }
 
                 S smp = Sig::Load(gIn_Signal, sx, sy);
-                smp = w == 0.0f ? Sig::Zero() : smp;
+                smp = Select(w == 0.0f, Sig::Zero(), smp);
 
                 float hs = ExtractHitDist(smp) * hitDistScale;
                 float hsFactor = GetHitDistFactor(hs, s.frustumSize);
@@ -175,7 +176,7 @@ NRD_D typename ReblurSignal<OCC>::type HistoryFixSignal(const ReblurCB& c, const
     float luma = GetLuma(sig);
 
     // Anti-firefly: 9x9 minus the central 3x3 (off by default; compiled out in the occlusion family, REBLUR_USE_ANTIFIREFLY = 0)
-    if (!OCC && c.gAntiFirefly != 0.0f) {
+    if (KIND == SIGNAL_RADIANCE && c.gAntiFirefly != 0.0f) {
         float am1 = 0.0f, am2 = 0.0f;
         const int R = PERF ? 3 : REBLUR_ANTI_FIREFLY_FILTER_RADIUS;
         for (int j = -R; j <= R; j++)
@@ -195,7 +196,7 @@ NRD_D typename ReblurSignal<OCC>::type HistoryFixSignal(const ReblurCB& c, const
 
     m1 /= 25.0f;
     m2 /= 25.0f;
-    float sigma = Sqrt(Abs(m2 - m1 * m1)) * (OCC ? REBLUR_COLOR_CLAMPING_SIGMA_SCALE_OCCLUSION : REBLUR_COLOR_CLAMPING_SIGMA_SCALE);
+    float sigma = Sqrt(Abs(m2 - m1 * m1)) * (KIND != SIGNAL_RADIANCE ? REBLUR_COLOR_CLAMPING_SIGMA_SCALE_OCCLUSION : REBLUR_COLOR_CLAMPING_SIGMA_SCALE);
     float lumaClamped = Clamp(luma, m1 - sigma, m1 + sigma);
     luma = Lerp(lumaClamped, luma, 1.0f / (1.0f + (c.gMaxFastAccumulatedFrameNum < c.gMaxAccumulatedFrameNum ? 1.0f : 0.0f) * frameNum * 2.0f));
 
@@ -206,9 +207,10 @@ NRD_D typename ReblurSignal<OCC>::type HistoryFixSignal(const ReblurCB& c, const
     return ChangeLuma(sig, luma);
 }
 
-template <bool DIFF, bool SPEC, bool PERF, bool OCC, bool SH>
+template <bool DIFF, bool SPEC, bool PERF, int KIND, bool SH>
 __global__ __launch_bounds__(TILE_X* TILE_Y) void ReblurHistoryFixKernel(ReblurCB c, HfPlanes P, RowRange rr) {
-    typedef ReblurSignal<OCC> Sig;
+    typedef ReblurSignal<KIND> Sig;
+    constexpr bool OCC = KIND == SIGNAL_OCCLUSION;
     typedef typename Sig::type S;
     __shared__ float s_DiffLuma[DIFF ? hf::BUF_Y * hf::BUF_STRIDE : 1];
     __shared__ float s_SpecLuma[SPEC ? hf::BUF_Y * hf::BUF_STRIDE : 1];
@@ -257,7 +259,7 @@ __global__ __launch_bounds__(TILE_X* TILE_Y) void ReblurHistoryFixKernel(ReblurC
         float4 diffSh = F4(0.0f);
         if (SH)
             diffSh = LoadRGBA16F(P.inDiffSh, px, py);
-        S diff = HistoryFixSignal<false, DIFF, SPEC, PERF, OCC, SH>(c, P, s, Sig::Load(P.inDiff, px, py), frameNum.x, stride.x, P.inDiff, P.inDiffFast, P.outDiffFast, s_DiffLuma, diffSh, P.inDiffSh);
+        S diff = HistoryFixSignal<false, DIFF, SPEC, PERF, KIND, SH>(c, P, s, Sig::Load(P.inDiff, px, py), frameNum.x, stride.x, P.inDiff, P.inDiffFast, P.outDiffFast, s_DiffLuma, diffSh, P.inDiffSh);
         Sig::Store(P.outDiff, px, py, diff);
         if (SH)
             StoreRGBA16F(P.outDiffSh, px, py, diffSh);
@@ -266,14 +268,14 @@ __global__ __launch_bounds__(TILE_X* TILE_Y) void ReblurHistoryFixKernel(ReblurC
         float4 specSh = F4(0.0f);
         if (SH)
             specSh = LoadRGBA16F(P.inSpecSh, px, py);
-        S spec = HistoryFixSignal<true, DIFF, SPEC, PERF, OCC, SH>(c, P, s, Sig::Load(P.inSpec, px, py), frameNum.y, stride.y, P.inSpec, P.inSpecFast, P.outSpecFast, s_SpecLuma, specSh, P.inSpecSh);
+        S spec = HistoryFixSignal<true, DIFF, SPEC, PERF, KIND, SH>(c, P, s, Sig::Load(P.inSpec, px, py), frameNum.y, stride.y, P.inSpec, P.inSpecFast, P.outSpecFast, s_SpecLuma, specSh, P.inSpecSh);
         Sig::Store(P.outSpec, px, py, spec);
         if (SH)
             StoreRGBA16F(P.outSpecSh, px, py, specSh);
     }
 }
 
-template <bool DIFF, bool SPEC, bool PERF, bool OCC, bool SH>
+template <bool DIFF, bool SPEC, bool PERF, int KIND, bool SH>
 static const char* LaunchHistoryFix(const PassArgs& a) {
     const ReblurCB& c = *(const ReblurCB*)a.constants;
     if (const char* err = CheckSupportedHistory(c))
@@ -302,7 +304,7 @@ static const char* LaunchHistoryFix(const PassArgs& a) {
     if (k != a.planesNum)
         return "REBLUR history fix: unexpected resource count";
     RowGrid g = GridForRows(c.gRectSizeMinusOne.x + 1, c.gRectSizeMinusOne.y + 1, TILE_X, TILE_Y, a.rowBegin, a.rowEnd);
-    hipLaunchKernelGGL((ReblurHistoryFixKernel<DIFF, SPEC, PERF, OCC, SH>), g.grid, dim3(TILE_X * TILE_Y), 0, a.stream, c, P, RowRange{g.firstBlockY, g.rowBegin, g.rowEnd});
+    hipLaunchKernelGGL((ReblurHistoryFixKernel<DIFF, SPEC, PERF, KIND, SH>), g.grid, dim3(TILE_X * TILE_Y), 0, a.stream, c, P, RowRange{g.firstBlockY, g.rowBegin, g.rowEnd});
     return nullptr;
 }
 
@@ -347,8 +349,10 @@ NRD_D void LumaStats(const ReblurCB& c, const float* s_Luma, int tx, int ty, flo
         luma = Clamp(luma, mn, mx);
 }
 
-template <bool DIFF, bool SPEC, bool PERF, bool SH>
+template <bool DIFF, bool SPEC, bool PERF, bool SH, int KIND> // KIND: radiance or directional occlusion (the occlusion family has no stabilisation pass)
 __global__ __launch_bounds__(TILE_X* TILE_Y) void ReblurTemporalStabilizationKernel(ReblurCB c, TsPlanes P, RowRange rr) {
+    typedef ReblurSignal<KIND> Sig;
+    typedef typename Sig::type S;
     __shared__ float s_DiffLuma[DIFF ? ts::BUF_Y * ts::BUF_STRIDE : 1];
     __shared__ float s_SpecLuma[SPEC ? ts::BUF_Y * ts::BUF_STRIDE : 1];
 
@@ -365,9 +369,9 @@ __global__ __launch_bounds__(TILE_X* TILE_Y) void ReblurTemporalStabilizationKer
             int lx = i % ts::BUF_X, ly = i / ts::BUF_X;
             int gx = ClampI(baseX + lx, 0, rw), gy = ClampI(baseY + ly, 0, rh);
             if (DIFF)
-                s_DiffLuma[ly * ts::BUF_STRIDE + lx] = GetLuma(LoadRGBA16F(P.inDiff, gx, gy));
+                s_DiffLuma[ly * ts::BUF_STRIDE + lx] = GetLuma(Sig::Load(P.inDiff, gx, gy));
             if (SPEC)
-                s_SpecLuma[ly * ts::BUF_STRIDE + lx] = GetLuma(LoadRGBA16F(P.inSpec, gx, gy));
+                s_SpecLuma[ly * ts::BUF_STRIDE + lx] = GetLuma(Sig::Load(P.inSpec, gx, gy));
         }
     }
     __syncthreads();
@@ -443,9 +447,9 @@ __global__ __launch_bounds__(TILE_X* TILE_Y) void ReblurTemporalStabilizationKer
         smbDiffLumaHistory = ColorClamp(diffLumaM1, diffLumaSigma * diffTemporalAccumulationParams.y, smbDiffLumaHistory);
         float diffLumaStabilized = Lerp(diffLuma, smbDiffLumaHistory, Min(diffHistoryWeight, c.gStabilizationStrength));
 
-        float4 diff = LoadRGBA16F(P.inDiff, px, py);
+        S diff = Sig::Load(P.inDiff, px, py);
         diff = ChangeLuma(diff, diffLumaStabilized);
-        StoreRGBA16F(P.outDiff, px, py, diff);
+        Sig::Store(P.outDiff, px, py, diff);
         StoreR16F(P.outDiffLuma, px, py, diffLumaStabilized);
         if (SH) {
             float4 diffSh = LoadRGBA16F(P.inDiffSh, px, py);
@@ -465,8 +469,8 @@ __global__ __launch_bounds__(TILE_X* TILE_Y) void ReblurTemporalStabilizationKer
         float virtualHistoryAmount = data2.x;
         float curvature = data2.y;
 
-        float4 spec = LoadRGBA16F(P.inSpec, px, py);
-        float hitDistForTracking = spec.w * GetHitDistanceNormalization(viewZ, ToF4(c.gHitDistParams), roughness);
+        S spec = Sig::Load(P.inSpec, px, py);
+        float hitDistForTracking = ExtractHitDist(spec) * GetHitDistanceNormalization(viewZ, ToF4(c.gHitDistParams), roughness);
         if (c.gSpecPrepassBlurRadius != 0.0f)
             hitDistForTracking = Min(hitDistForTracking, LoadR16F(P.inSpecHitDistForTracking, px, py));
 
@@ -512,7 +516,7 @@ __global__ __launch_bounds__(TILE_X* TILE_Y) void ReblurTemporalStabilizationKer
         float specLumaStabilized = Lerp(specLuma, specLumaHistory, Min(specHistoryWeight, c.gStabilizationStrength));
 
         spec = ChangeLuma(spec, specLumaStabilized);
-        StoreRGBA16F(P.outSpec, px, py, spec);
+        Sig::Store(P.outSpec, px, py, spec);
         StoreR16F(P.outSpecLuma, px, py, specLumaStabilized);
         if (SH) {
             float4 specSh = LoadRGBA16F(P.inSpecSh, px, py);
@@ -528,7 +532,7 @@ __global__ __launch_bounds__(TILE_X* TILE_Y) void ReblurTemporalStabilizationKer
     StoreR16U(P.outInternalData, px, py, PackInternalData(data1.x, data1.y, materialID));
 }
 
-template <bool DIFF, bool SPEC, bool PERF, bool SH>
+template <bool DIFF, bool SPEC, bool PERF, bool SH, int KIND>
 static const char* LaunchTemporalStabilization(const PassArgs& a) {
     const ReblurCB& c = *(const ReblurCB*)a.constants;
     if (const char* err = CheckSupportedHistory(c))
@@ -564,19 +568,19 @@ static const char* LaunchTemporalStabilization(const PassArgs& a) {
     if (k != a.planesNum)
         return "REBLUR temporal stabilization: unexpected resource count";
     RowGrid g = GridForRows(c.gRectSizeMinusOne.x + 1, c.gRectSizeMinusOne.y + 1, TILE_X, TILE_Y, a.rowBegin, a.rowEnd);
-    hipLaunchKernelGGL((ReblurTemporalStabilizationKernel<DIFF, SPEC, PERF, SH>), g.grid, dim3(TILE_X * TILE_Y), 0, a.stream, c, P, RowRange{g.firstBlockY, g.rowBegin, g.rowEnd});
+    hipLaunchKernelGGL((ReblurTemporalStabilizationKernel<DIFF, SPEC, PERF, SH, KIND>), g.grid, dim3(TILE_X * TILE_Y), 0, a.stream, c, P, RowRange{g.firstBlockY, g.rowBegin, g.rowEnd});
     return nullptr;
 }
 
 #define REBLUR_HISTORY_FAMILY(NAME, D, S)                                                                         \
     {"REBLUR_" NAME "_HistoryFix.cs", LaunchHistoryFix<D, S, false, false, false>},                               \
-    {"REBLUR_" NAME "_TemporalStabilization.cs", LaunchTemporalStabilization<D, S, false, false>},                \
+    {"REBLUR_" NAME "_TemporalStabilization.cs", LaunchTemporalStabilization<D, S, false, false, 0>},                \
     {"REBLUR_Perf_" NAME "_HistoryFix.cs", LaunchHistoryFix<D, S, true, false, false>},                           \
-    {"REBLUR_Perf_" NAME "_TemporalStabilization.cs", LaunchTemporalStabilization<D, S, true, false>},            \
+    {"REBLUR_Perf_" NAME "_TemporalStabilization.cs", LaunchTemporalStabilization<D, S, true, false, 0>},            \
     {"REBLUR_" NAME "Sh_HistoryFix.cs", LaunchHistoryFix<D, S, false, false, true>},                              \
-    {"REBLUR_" NAME "Sh_TemporalStabilization.cs", LaunchTemporalStabilization<D, S, false, true>},               \
+    {"REBLUR_" NAME "Sh_TemporalStabilization.cs", LaunchTemporalStabilization<D, S, false, true, 0>},               \
     {"REBLUR_Perf_" NAME "Sh_HistoryFix.cs", LaunchHistoryFix<D, S, true, false, true>},                          \
-    {"REBLUR_Perf_" NAME "Sh_TemporalStabilization.cs", LaunchTemporalStabilization<D, S, true, true>},           \
+    {"REBLUR_Perf_" NAME "Sh_TemporalStabilization.cs", LaunchTemporalStabilization<D, S, true, true, 0>},           \
     {"REBLUR_" NAME "Occlusion_HistoryFix.cs", LaunchHistoryFix<D, S, false, true, false>},                       \
     {"REBLUR_Perf_" NAME "Occlusion_HistoryFix.cs", LaunchHistoryFix<D, S, true, true, false>},
 
@@ -585,6 +589,10 @@ const PassEntry* GetReblurHistoryPasses(uint32_t& num) {
         REBLUR_HISTORY_FAMILY("Diffuse", true, false)
         REBLUR_HISTORY_FAMILY("Specular", false, true)
         REBLUR_HISTORY_FAMILY("DiffuseSpecular", true, true)
+        {"REBLUR_DiffuseDirectionalOcclusion_HistoryFix.cs", LaunchHistoryFix<true, false, false, 2, false>},
+        {"REBLUR_Perf_DiffuseDirectionalOcclusion_HistoryFix.cs", LaunchHistoryFix<true, false, true, 2, false>},
+        {"REBLUR_DiffuseDirectionalOcclusion_TemporalStabilization.cs", LaunchTemporalStabilization<true, false, false, false, 2>},
+        {"REBLUR_Perf_DiffuseDirectionalOcclusion_TemporalStabilization.cs", LaunchTemporalStabilization<true, false, true, false, 2>},
     };
     num = sizeof(k) / sizeof(k[0]);
     return k;

@@ -77,10 +77,11 @@ NRD_D float PoissonGaussianWeight(int n) { // = GetGaussianWeight( offset.z ), b
 
 // OCC = occlusion family: the signal is the hit distance alone (REBLUR_TYPE float, R16_UNORM planes)
 // SH = the *_SH denoisers: an SH1 plane (RGBA16F) rides on the same taps and weights (diffuse: all 4 components, specular: .xyz only)
-template <SpatialMode MODE, bool PERF, bool OCC, bool SH>
-NRD_D typename ReblurSignal<OCC>::type DiffuseSpatialFilter(const ReblurCB& c, const SpatialCtx& s, typename ReblurSignal<OCC>::type diff, const Plane& gIn_Diff, const Plane& gIn_ViewZ,
+template <SpatialMode MODE, bool PERF, int KIND, bool SH>
+NRD_D typename ReblurSignal<KIND>::type DiffuseSpatialFilter(const ReblurCB& c, const SpatialCtx& s, typename ReblurSignal<KIND>::type diff, const Plane& gIn_Diff, const Plane& gIn_ViewZ,
     const Plane& gIn_Normal_Roughness, float4& diffSh, const Plane& gIn_DiffSh) {
-    typedef ReblurSignal<OCC> Sig;
+    typedef ReblurSignal<KIND> Sig;
+    constexpr bool OCC = KIND == SIGNAL_OCCLUSION;
     typedef typename Sig::type S;
     if (MODE == PRE_BLUR && c.gDiffPrepassBlurRadius == 0.0f)
         return diff;
@@ -158,7 +159,7 @@ NRD_D typename ReblurSignal<OCC>::type DiffuseSpatialFilter(const ReblurCB& c, c
         w *= ComputeWeight(angle, normalWeightParam, 0.0f);
 
         S smp = Sig::Load(gIn_Diff, tz.x, tz.y);
-        smp = w == 0.0f ? Sig::Zero() : smp;
+        smp = Select(w == 0.0f, Sig::Zero(), smp);
 
         w *= Lerp(minHitDistWeight, 1.0f, ComputeExponentialWeight(ExtractHitDist(smp), hitDistanceWeightParams.x, hitDistanceWeightParams.y));
         w *= PoissonGaussianWeight<PERF>(n);
@@ -178,10 +179,11 @@ NRD_D typename ReblurSignal<OCC>::type DiffuseSpatialFilter(const ReblurCB& c, c
     return diff * invSum;
 }
 
-template <SpatialMode MODE, bool PERF, bool OCC, bool SH>
-NRD_D typename ReblurSignal<OCC>::type SpecularSpatialFilter(const ReblurCB& c, const SpatialCtx& s, typename ReblurSignal<OCC>::type spec, const Plane& gIn_Spec, const Plane& gIn_ViewZ,
+template <SpatialMode MODE, bool PERF, int KIND, bool SH>
+NRD_D typename ReblurSignal<KIND>::type SpecularSpatialFilter(const ReblurCB& c, const SpatialCtx& s, typename ReblurSignal<KIND>::type spec, const Plane& gIn_Spec, const Plane& gIn_ViewZ,
     const Plane& gIn_Normal_Roughness, const Plane& gOut_SpecHitDistForTracking, float4& specSh, const Plane& gIn_SpecSh) {
-    typedef ReblurSignal<OCC> Sig;
+    typedef ReblurSignal<KIND> Sig;
+    constexpr bool OCC = KIND == SIGNAL_OCCLUSION;
     typedef typename Sig::type S;
     float smc = GetSpecMagicCurve(s.roughness);
     if (MODE == PRE_BLUR && c.gSpecPrepassBlurRadius == 0.0f)
@@ -293,7 +295,7 @@ NRD_D typename ReblurSignal<OCC>::type SpecularSpatialFilter(const ReblurCB& c, 
         w *= ComputeWeight(Ns.w, roughnessWeightParams.x, roughnessWeightParams.y);
 
         S smp = Sig::Load(gIn_Spec, tz.x, tz.y);
-        smp = w == 0.0f ? Sig::Zero() : smp;
+        smp = Select(w == 0.0f, Sig::Zero(), smp);
 
         if (MODE == PRE_BLUR) {
             float hs = ExtractHitDist(smp) * GetHitDistanceNormalization(zs, hitDistParams, Ns.w);
@@ -362,9 +364,10 @@ struct SpatialPlanes {
     Plane inDiffSh, inSpecSh, outDiffSh, outSpecSh, outDiffShCopy, outSpecShCopy; // SH family
 };
 
-template <SpatialMode MODE, bool DIFF, bool SPEC, bool NO_TS, bool PERF, bool OCC, bool SH>
+template <SpatialMode MODE, bool DIFF, bool SPEC, bool NO_TS, bool PERF, int KIND, bool SH>
 __global__ __launch_bounds__(TILE_X* TILE_Y) void ReblurSpatialKernel(ReblurCB c, SpatialPlanes P, RowRange rr) {
-    typedef ReblurSignal<OCC> Sig;
+    typedef ReblurSignal<KIND> Sig;
+    constexpr bool OCC = KIND == SIGNAL_OCCLUSION;
     typedef typename Sig::type S;
     const int px = blockIdx.x * TILE_X + (threadIdx.x % TILE_X);
     const int py = (blockIdx.y + rr.firstBlockY) * TILE_Y + (threadIdx.x / TILE_X);
@@ -396,7 +399,7 @@ __global__ __launch_bounds__(TILE_X* TILE_Y) void ReblurSpatialKernel(ReblurCB c
         float4 diffSh = F4(0.0f);
         if (SH)
             diffSh = LoadRGBA16F(P.inDiffSh, px, py);
-        diff = DiffuseSpatialFilter<MODE, PERF, OCC, SH>(c, s, diff, P.inDiff, P.viewZ, P.decodedNR, diffSh, P.inDiffSh);
+        diff = DiffuseSpatialFilter<MODE, PERF, KIND, SH>(c, s, diff, P.inDiff, P.viewZ, P.decodedNR, diffSh, P.inDiffSh);
         Sig::Store(P.outDiff, px, py, diff);
         if (SH)
             StoreRGBA16F(P.outDiffSh, px, py, diffSh);
@@ -410,7 +413,7 @@ __global__ __launch_bounds__(TILE_X* TILE_Y) void ReblurSpatialKernel(ReblurCB c
         float4 specSh = F4(0.0f);
         if (SH)
             specSh = LoadRGBA16F(P.inSpecSh, px, py);
-        spec = SpecularSpatialFilter<MODE, PERF, OCC, SH>(c, s, spec, P.inSpec, P.viewZ, P.decodedNR, P.outHitDistForTracking, specSh, P.inSpecSh);
+        spec = SpecularSpatialFilter<MODE, PERF, KIND, SH>(c, s, spec, P.inSpec, P.viewZ, P.decodedNR, P.outHitDistForTracking, specSh, P.inSpecSh);
         Sig::Store(P.outSpec, px, py, spec);
         if (SH)
             StoreRGBA16F(P.outSpecSh, px, py, specSh);
@@ -431,8 +434,9 @@ static const char* CheckSupported(const ReblurCB& c) {
     return nullptr;
 }
 
-template <SpatialMode MODE, bool DIFF, bool SPEC, bool NO_TS, bool PERF, bool OCC, bool SH>
+template <SpatialMode MODE, bool DIFF, bool SPEC, bool NO_TS, bool PERF, int KIND, bool SH>
 static const char* LaunchSpatial(const PassArgs& a) {
+    constexpr bool OCC = KIND == SIGNAL_OCCLUSION;
     const ReblurCB& c = *(const ReblurCB*)a.constants;
     if (const char* err = CheckSupported(c))
         return err;
@@ -487,13 +491,13 @@ static const char* LaunchSpatial(const PassArgs& a) {
         return "REBLUR spatial pass: unexpected resource count";
 
     RowGrid g = GridForRows(c.gRectSizeMinusOne.x + 1, c.gRectSizeMinusOne.y + 1, TILE_X, TILE_Y, a.rowBegin, a.rowEnd);
-    hipLaunchKernelGGL((ReblurSpatialKernel<MODE, DIFF, SPEC, NO_TS, PERF, OCC, SH>), g.grid, dim3(TILE_X * TILE_Y), 0, a.stream, c, P, RowRange{g.firstBlockY, g.rowBegin, g.rowEnd});
+    hipLaunchKernelGGL((ReblurSpatialKernel<MODE, DIFF, SPEC, NO_TS, PERF, KIND, SH>), g.grid, dim3(TILE_X * TILE_Y), 0, a.stream, c, P, RowRange{g.firstBlockY, g.rowBegin, g.rowEnd});
     return nullptr;
 }
 
 // ================================================================================================ SplitScreen
 // OCC: the occlusion family binds its R16_UNORM planes to the radiance family's split-screen pipeline (the shader only scales .x there)
-template <bool DIFF, bool SPEC, bool OCC>
+template <bool DIFF, bool SPEC, int KIND>
 __global__ __launch_bounds__(256) void ReblurSplitScreenKernel(ReblurCB c, Plane viewZ, Plane inDiff, Plane inSpec, Plane outDiff, Plane outSpec, Plane inDiffSh, Plane inSpecSh, Plane outDiffSh,
     Plane outSpecSh, RowRange rr) {
     const int px = blockIdx.x * TILE_X + (threadIdx.x % TILE_X);
@@ -505,7 +509,8 @@ __global__ __launch_bounds__(256) void ReblurSplitScreenKernel(ReblurCB c, Plane
         return;
     float z = UnpackViewZ(c, LoadR32F(viewZ, px, py));
     float keep = z < c.gDenoisingRange ? 1.0f : 0.0f;
-    typedef ReblurSignal<OCC> Sig;
+    typedef ReblurSignal<KIND> Sig;
+    constexpr bool OCC = KIND == SIGNAL_OCCLUSION;
     if (DIFF)
         Sig::Store(outDiff, px, py, Sig::Load(inDiff, px, py) * keep);
     if (SPEC)
@@ -535,14 +540,18 @@ static const char* LaunchSplitScreen(const PassArgs& a) {
         return "REBLUR split screen: unexpected resource count";
     RowGrid g = GridForRows(c.gRectSizeMinusOne.x + 1, c.gRectSizeMinusOne.y + 1, TILE_X, TILE_Y, a.rowBegin, a.rowEnd);
     const RowRange rows = {g.firstBlockY, g.rowBegin, g.rowEnd};
-    const uint32_t bytesPerTexel = a.bytesPerTexel[1]; // 8 = RGBA16F (radiance family), 2 = R16_UNORM (occlusion family on the same pipeline)
+    // the occlusion family and directional occlusion bind their planes to the radiance family's pipeline: the codec follows the plane format
+    const uint32_t format = a.formats[1];
     for (uint32_t i = 1; i < k; i++)
-        if (a.bytesPerTexel[i] != bytesPerTexel)
+        if (a.formats[i] != format)
             return "REBLUR split screen: mixed signal formats";
-    if (bytesPerTexel == 8)
-        hipLaunchKernelGGL((ReblurSplitScreenKernel<DIFF, SPEC, false>), g.grid, dim3(256), 0, a.stream, c, viewZ, inDiff, inSpec, outDiff, outSpec, inDiffSh, inSpecSh, outDiffSh, outSpecSh, rows);
-    else if (bytesPerTexel == 2)
-        hipLaunchKernelGGL((ReblurSplitScreenKernel<DIFF, SPEC, true>), g.grid, dim3(256), 0, a.stream, c, viewZ, inDiff, inSpec, outDiff, outSpec, inDiffSh, inSpecSh, outDiffSh, outSpecSh, rows);
+    if (format == (uint32_t)FORMAT_RGBA16_SFLOAT)
+        hipLaunchKernelGGL((ReblurSplitScreenKernel<DIFF, SPEC, SIGNAL_RADIANCE>), g.grid, dim3(256), 0, a.stream, c, viewZ, inDiff, inSpec, outDiff, outSpec, inDiffSh, inSpecSh, outDiffSh, outSpecSh, rows);
+    else if (format == (uint32_t)FORMAT_R16_UNORM)
+        hipLaunchKernelGGL((ReblurSplitScreenKernel<DIFF, SPEC, SIGNAL_OCCLUSION>), g.grid, dim3(256), 0, a.stream, c, viewZ, inDiff, inSpec, outDiff, outSpec, inDiffSh, inSpecSh, outDiffSh, outSpecSh, rows);
+    else if (format == (uint32_t)FORMAT_RGBA16_SNORM)
+        hipLaunchKernelGGL((ReblurSplitScreenKernel<DIFF, SPEC, SIGNAL_DIRECTIONAL_OCCLUSION>), g.grid, dim3(256), 0, a.stream, c, viewZ, inDiff, inSpec, outDiff, outSpec, inDiffSh, inSpecSh, outDiffSh,
+            outSpecSh, rows);
     else
         return "REBLUR split screen: unexpected signal format";
     return nullptr;
@@ -556,9 +565,10 @@ struct HitDistPlanes {
     Plane tiles, viewZ, decodedNR, inDiff, inSpec, outDiff, outSpec;
 };
 
-template <bool DIFF, bool SPEC, int BORDER, bool PERF, bool OCC>
+template <bool DIFF, bool SPEC, int BORDER, bool PERF, int KIND>
 __global__ __launch_bounds__(TILE_X* TILE_Y) void ReblurHitDistReconstructionKernel(ReblurCB c, HitDistPlanes P, RowRange rr) {
-    typedef ReblurSignal<OCC> Sig;
+    typedef ReblurSignal<KIND> Sig;
+    constexpr bool OCC = KIND == SIGNAL_OCCLUSION;
     typedef typename Sig::type S;
     const int px = blockIdx.x * TILE_X + (threadIdx.x % TILE_X);
     const int py = (blockIdx.y + rr.firstBlockY) * TILE_Y + (threadIdx.x / TILE_X);
@@ -633,8 +643,11 @@ __global__ __launch_bounds__(TILE_X* TILE_Y) void ReblurHitDistReconstructionKer
         Sig::Store(P.outSpec, px, py, Sig::WithHitDist(centerSpec, center.y));
 }
 
-template <bool DIFF, bool SPEC, int BORDER, bool PERF, bool OCC>
+template <bool DIFF, bool SPEC, int BORDER, bool PERF, int KIND>
 static const char* LaunchHitDistReconstruction(const PassArgs& a) {
+    // REBLUR_DIFFUSE_DIRECTIONAL_OCCLUSION binds its RGBA16_SNORM planes to the radiance family's reconstruction pipeline
+    if (KIND == SIGNAL_RADIANCE && DIFF && !SPEC && a.planesNum == 5 && a.formats[3] == FORMAT_RGBA16_SNORM)
+        return LaunchHitDistReconstruction<DIFF, SPEC, BORDER, PERF, (DIFF && !SPEC) ? SIGNAL_DIRECTIONAL_OCCLUSION : KIND>(a);
     const ReblurCB& c = *(const ReblurCB*)a.constants;
     if (const char* err = CheckSupported(c))
         return err;
@@ -651,7 +664,7 @@ static const char* LaunchHitDistReconstruction(const PassArgs& a) {
     if (k != a.planesNum || !P.decodedNR.ptr)
         return "REBLUR hit distance reconstruction: unexpected resource count or missing decoded normal/roughness cache";
     RowGrid g = GridForRows(c.gRectSizeMinusOne.x + 1, c.gRectSizeMinusOne.y + 1, TILE_X, TILE_Y, a.rowBegin, a.rowEnd);
-    hipLaunchKernelGGL((ReblurHitDistReconstructionKernel<DIFF, SPEC, BORDER, PERF, OCC>), g.grid, dim3(TILE_X * TILE_Y), 0, a.stream, c, P, RowRange{g.firstBlockY, g.rowBegin, g.rowEnd});
+    hipLaunchKernelGGL((ReblurHitDistReconstructionKernel<DIFF, SPEC, BORDER, PERF, KIND>), g.grid, dim3(TILE_X * TILE_Y), 0, a.stream, c, P, RowRange{g.firstBlockY, g.rowBegin, g.rowEnd});
     return nullptr;
 }
 
@@ -677,6 +690,12 @@ static const char* LaunchHitDistReconstruction(const PassArgs& a) {
     REBLUR_SPATIAL_PASSES("REBLUR_Perf_", NAME, D, S, true)                                            \
     {"REBLUR_" NAME "_SplitScreen.cs", LaunchSplitScreen<D, S, false>},                                \
     {"REBLUR_" NAME "Sh_SplitScreen.cs", LaunchSplitScreen<D, S, true>},
+// REBLUR_DIFFUSE_DIRECTIONAL_OCCLUSION: the diffuse chain on RGBA16_SNORM texels
+#define REBLUR_DIRECTIONAL_OCCLUSION_SPATIAL(PREFIX, P)                                                                                       \
+    {PREFIX "DiffuseDirectionalOcclusion_PrePass.cs", LaunchSpatial<PRE_BLUR, true, false, false, P, 2, false>},                             \
+    {PREFIX "DiffuseDirectionalOcclusion_Blur.cs", LaunchSpatial<BLUR, true, false, false, P, 2, false>},                                    \
+    {PREFIX "DiffuseDirectionalOcclusion_PostBlur.cs", LaunchSpatial<POST_BLUR, true, false, false, P, 2, false>},                           \
+    {PREFIX "DiffuseDirectionalOcclusion_PostBlur_NoTemporalStabilization.cs", LaunchSpatial<POST_BLUR, true, false, true, P, 2, false>},
 
 const PassEntry* GetReblurSpatialPasses(uint32_t& num) {
     static const PassEntry k[] = {
@@ -684,6 +703,8 @@ const PassEntry* GetReblurSpatialPasses(uint32_t& num) {
         REBLUR_SPATIAL_FAMILY("Diffuse", true, false)
         REBLUR_SPATIAL_FAMILY("Specular", false, true)
         REBLUR_SPATIAL_FAMILY("DiffuseSpecular", true, true)
+        REBLUR_DIRECTIONAL_OCCLUSION_SPATIAL("REBLUR_", false)
+        REBLUR_DIRECTIONAL_OCCLUSION_SPATIAL("REBLUR_Perf_", true)
     };
     num = sizeof(k) / sizeof(k[0]);
     return k;

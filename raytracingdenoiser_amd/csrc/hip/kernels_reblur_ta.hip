@@ -34,9 +34,10 @@ struct TaPlanes {
 // PERF = REBLUR_PERFORMANCE_MODE: no Catmull-Rom history fetches (REBLUR_USE_CATROM_FOR_*_MOTION_IN_TA = 0, REBLUR_Config.hlsli:196-201)
 // OCC = occlusion family (REBLUR_OCCLUSION): hit-distance-only signals in R16_UNORM, no pre-pass output to read, no DATA2, no firefly suppressor
 // SH = the *_SH denoisers: the SH1 plane of every signal is accumulated with the same speeds (custom-weight bilinear history fetch)
-template <bool DIFF, bool SPEC, bool PERF, bool OCC, bool SH>
+template <bool DIFF, bool SPEC, bool PERF, int KIND, bool SH>
 __global__ __launch_bounds__(TILE_X* TILE_Y, 2) void ReblurTemporalAccumulationKernel(ReblurCB cArg, TaPlanes P, RowRange rr) {
-    typedef ReblurSignal<OCC> Sig;
+    typedef ReblurSignal<KIND> Sig;
+    constexpr bool OCC = KIND == SIGNAL_OCCLUSION;
     typedef typename Sig::type S;
     __shared__ float4 s_Normal_Roughness[BUF_Y * BUF_STRIDE];
     // The 832-byte constant block + ~20 planes need > 200 SGPRs (102 exist), which the compiler resolves by spilling scalars into
@@ -264,7 +265,7 @@ __global__ __launch_bounds__(TILE_X* TILE_Y, 2) void ReblurTemporalAccumulationK
     // 2x2 occlusion weights
     float4 smbOcclusionWeights = GetBilinearCustomWeights(smbBilinearFilter, F4(smbOcclusion0.z, smbOcclusion1.y, smbOcclusion2.y, smbOcclusion3.x));
     float3 occSum = smbOcclusion0 + smbOcclusion1 + smbOcclusion2 + smbOcclusion3;
-    bool smbAllowCatRom = (occSum.x + occSum.y + occSum.z) > 11.5f && !PERF;
+    bool smbAllowCatRom = (occSum.x + occSum.y + occSum.z) > 11.5f && !PERF && KIND != SIGNAL_DIRECTIONAL_OCCLUSION; // no Catmull-Rom in TA for directional occlusion (REBLUR_Config.hlsli:188-194)
 
     float fbits = smbOcclusion0.z * 1.0f;
     fbits += smbOcclusion1.y * 2.0f;
@@ -319,7 +320,7 @@ __global__ __launch_bounds__(TILE_X* TILE_Y, 2) void ReblurTemporalAccumulationK
         }
 
         float diffMaxRelativeIntensity = 0.0f, diffAntifireflyFactor = 0.0f;
-        if (!OCC) { // firefly suppressor
+        if (KIND == SIGNAL_RADIANCE) { // firefly suppressor (neither occlusion kind has it)
             diffMaxRelativeIntensity = c.gFireflySuppressorMinRelativeScale + REBLUR_FIREFLY_SUPPRESSOR_MAX_RELATIVE_INTENSITY / (diffAccumSpeed + 1.0f);
             diffAntifireflyFactor = diffAccumSpeed * c.gMaxBlurRadius * REBLUR_FIREFLY_SUPPRESSOR_RADIUS_SCALE;
             diffAntifireflyFactor /= 1.0f + diffAntifireflyFactor;
@@ -340,7 +341,7 @@ __global__ __launch_bounds__(TILE_X* TILE_Y, 2) void ReblurTemporalAccumulationK
         float diffFastAccumSpeed = Min(diffAccumSpeed, c.gMaxFastAccumulatedFrameNum);
         float diffFastNonLinearAccumSpeed = 1.0f / (1.0f + diffFastAccumSpeed);
         float diffFastResult = Lerp(smbDiffFastHistory, GetLuma(diff), diffFastNonLinearAccumSpeed);
-        if (!OCC) {
+        if (KIND == SIGNAL_RADIANCE) {
             float diffFastClamped = Min(diffFastResult, GetLuma(smbDiffHistory) * diffMaxRelativeIntensity * REBLUR_FIREFLY_SUPPRESSOR_FAST_RELATIVE_INTENSITY);
             diffFastResult = Lerp(diffFastResult, diffFastClamped, diffAntifireflyFactor);
         }
@@ -509,7 +510,7 @@ __global__ __launch_bounds__(TILE_X* TILE_Y, 2) void ReblurTemporalAccumulationK
         vmbFootprintQuality = Sqrt01(vmbFootprintQuality);
         vmbSpecAccumSpeed *= Lerp(vmbFootprintQuality, 1.0f, 1.0f / (1.0f + vmbSpecAccumSpeed));
 
-        bool vmbAllowCatRom = Sum(vmbOcclusion) > 3.5f && !PERF;
+        bool vmbAllowCatRom = Sum(vmbOcclusion) > 3.5f && !PERF && KIND != SIGNAL_DIRECTIONAL_OCCLUSION;
         vmbAllowCatRom = vmbAllowCatRom && smbAllowCatRom;
 
         float curvatureAngleTan = pixelSize * Abs(curvature);
@@ -658,7 +659,7 @@ __global__ __launch_bounds__(TILE_X* TILE_Y, 2) void ReblurTemporalAccumulationK
 
         // Firefly suppressor (not in the occlusion family)
         float specMaxRelativeIntensity = 0.0f, specAntifireflyFactor = 0.0f;
-        if (!OCC) {
+        if (KIND == SIGNAL_RADIANCE) {
             specMaxRelativeIntensity = c.gFireflySuppressorMinRelativeScale + REBLUR_FIREFLY_SUPPRESSOR_MAX_RELATIVE_INTENSITY / (specAccumSpeed + 1.0f);
             specAntifireflyFactor = specAccumSpeed * c.gMaxBlurRadius * REBLUR_FIREFLY_SUPPRESSOR_RADIUS_SCALE;
             specAntifireflyFactor /= 1.0f + specAntifireflyFactor;
@@ -684,7 +685,7 @@ __global__ __launch_bounds__(TILE_X* TILE_Y, 2) void ReblurTemporalAccumulationK
         float vmbSpecFast = Lerp(vmbSpecFastHistory, GetLuma(spec), vmbSpecFastNonLinearAccumSpeed);
         float specFastResult = Lerp(smbSpecFast, vmbSpecFast, virtualHistoryAmount);
 
-        if (!OCC) {
+        if (KIND == SIGNAL_RADIANCE) {
             float specFastClamped = Min(specFastResult, GetLuma(specHistory) * specMaxRelativeIntensity * REBLUR_FIREFLY_SUPPRESSOR_FAST_RELATIVE_INTENSITY);
             specFastResult = Lerp(specFastResult, specFastClamped, specAntifireflyFactor);
         }
@@ -704,8 +705,9 @@ __global__ __launch_bounds__(TILE_X* TILE_Y, 2) void ReblurTemporalAccumulationK
     StoreData1<DIFF, SPEC>(P.outData1, px, py, diffAccumSpeed, specAccumSpeed);
 }
 
-template <bool DIFF, bool SPEC, bool PERF, bool OCC, bool SH>
+template <bool DIFF, bool SPEC, bool PERF, int KIND, bool SH>
 static const char* LaunchTemporalAccumulation(const PassArgs& a) {
+    constexpr bool OCC = KIND == SIGNAL_OCCLUSION;
     const ReblurCB& c = *(const ReblurCB*)a.constants;
     if (c.gDiffCheckerboard != 2 || c.gSpecCheckerboard != 2)
         return "REBLUR: checkerboard modes are not implemented in the HIP back-end yet";
@@ -770,7 +772,7 @@ static const char* LaunchTemporalAccumulation(const PassArgs& a) {
     }
 
     RowGrid g = GridForRows(c.gRectSizeMinusOne.x + 1, c.gRectSizeMinusOne.y + 1, TILE_X, TILE_Y, a.rowBegin, a.rowEnd);
-    hipLaunchKernelGGL((ReblurTemporalAccumulationKernel<DIFF, SPEC, PERF, OCC, SH>), g.grid, dim3(TILE_X * TILE_Y), 0, a.stream, c, P, RowRange{g.firstBlockY, g.rowBegin, g.rowEnd});
+    hipLaunchKernelGGL((ReblurTemporalAccumulationKernel<DIFF, SPEC, PERF, KIND, SH>), g.grid, dim3(TILE_X * TILE_Y), 0, a.stream, c, P, RowRange{g.firstBlockY, g.rowBegin, g.rowEnd});
     return nullptr;
 }
 
@@ -786,6 +788,8 @@ const PassEntry* GetReblurTemporalAccumulationPasses(uint32_t& num) {
         REBLUR_TA_FAMILY("Diffuse", true, false)
         REBLUR_TA_FAMILY("Specular", false, true)
         REBLUR_TA_FAMILY("DiffuseSpecular", true, true)
+        {"REBLUR_DiffuseDirectionalOcclusion_TemporalAccumulation.cs", LaunchTemporalAccumulation<true, false, false, 2, false>},
+        {"REBLUR_Perf_DiffuseDirectionalOcclusion_TemporalAccumulation.cs", LaunchTemporalAccumulation<true, false, true, 2, false>},
     };
     num = sizeof(k) / sizeof(k[0]);
     return k;

@@ -8,10 +8,14 @@
 
 namespace nrdhip {
 
+// numeric values of the nrd::Format entries the format-dispatching launchers look at (checked against NRDDescs.h in executor.hip)
+enum : uint8_t { FORMAT_R16_UNORM = 13, FORMAT_RGBA16_SNORM = 24, FORMAT_RGBA16_SFLOAT = 27 };
+
 struct PassArgs {
     const Plane* planes;      // DispatchDesc::resources resolved to planes, same order (inputs then outputs)
     uint32_t planesNum;
     const uint8_t* bytesPerTexel; // per plane, for the few launchers shared between storage formats (SIGMA_Copy.cs)
+    const uint8_t* formats;       // per plane, nrd::Format (REBLUR hit-distance reconstruction / split screen serve three signal kinds)
     const void* constants;    // DispatchDesc::constantBufferData
     uint32_t constantsSize;
     hipStream_t stream;

@@ -57,6 +57,7 @@ NRD_D float DivSmallIntByConst(float k, float c, float rcpC) {
 }
 #define NRD_DIV_1023(k) DivSmallIntByConst(k, 1023.0f, 0.0009775171056389809f)
 #define NRD_DIV_255(k) DivSmallIntByConst(k, 255.0f, 0.003921568859368563f)
+#define NRD_DIV_32767(k) DivSmallIntByConst(k, 32767.0f, 3.0518509447574615e-05f) // also exact for the negative numerators of SNORM16
 #define NRD_DIV_65535(k) DivSmallIntByConst(k, 65535.0f, 1.5259021893143654e-05f)
 #define NRD_DIV_63(k) DivSmallIntByConst(k, 63.0f, 0.01587301678955555f)
 #define NRD_DIV_15(k) DivSmallIntByConst(k, 15.0f, 0.06666667014360428f)
@@ -118,6 +119,24 @@ NRD_D void StoreR8Unorm(const Plane& p, int x, int y, float v) { *TexelPtr<uint8
 // R16_UNORM (signals and fast history of the REBLUR occlusion family)
 NRD_D float LoadR16Unorm(const Plane& p, int x, int y) { return NRD_DIV_65535(float(*TexelPtr<const uint16_t>(p, x, y))); }
 NRD_D void StoreR16Unorm(const Plane& p, int x, int y, float v) { *TexelPtr<uint16_t>(p, x, y) = (uint16_t)ToUnorm(v, 65535.0f); }
+
+// RGBA16_SNORM (signal planes of REBLUR_DIFFUSE_DIRECTIONAL_OCCLUSION): decode max(i / 32767, -1); encode clamp, scale, round half away from 0
+NRD_D float FromSnorm16(uint32_t bits16) { return fmaxf(NRD_DIV_32767(float((int32_t)(int16_t)bits16)), -1.0f); }
+NRD_D uint32_t ToSnorm16(float x) {
+    float c = fminf(fmaxf(x, -1.0f), 1.0f) * 32767.0f;
+    int32_t i = c >= 0.0f ? (int32_t)floorf(c + 0.5f) : -(int32_t)floorf(-c + 0.5f);
+    return (uint32_t)i & 0xFFFFu;
+}
+NRD_D float4 LoadRGBA16Snorm(const Plane& p, int x, int y) {
+    uint2 raw = *TexelPtr<const uint2>(p, x, y);
+    return make_float4(FromSnorm16(raw.x & 0xFFFFu), FromSnorm16(raw.x >> 16), FromSnorm16(raw.y & 0xFFFFu), FromSnorm16(raw.y >> 16));
+}
+NRD_D void StoreRGBA16Snorm(const Plane& p, int x, int y, float4 v) {
+    uint2 raw;
+    raw.x = ToSnorm16(v.x) | (ToSnorm16(v.y) << 16);
+    raw.y = ToSnorm16(v.z) | (ToSnorm16(v.w) << 16);
+    *TexelPtr<uint2>(p, x, y) = raw;
+}
 
 NRD_D float2 LoadRG8Unorm(const Plane& p, int x, int y) {
     uint32_t raw = *TexelPtr<const uint16_t>(p, x, y);

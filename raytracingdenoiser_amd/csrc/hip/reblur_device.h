@@ -235,14 +235,39 @@ NRD_D float4 ClampNegativeToZero(float4 v) {
     float3 rgb = LinearToYCoCg(YCoCgToLinear(Xyz(v)));
     return F4(rgb, Sat(v.w));
 }
-// the float overloads of the occlusion family (REBLUR_TYPE = float: the normalised hit distance alone; reference REBLUR_Common.hlsli:148-170)
+// REBLUR_TYPE kinds (reference REBLUR_Common.hlsli:148-215): 0 radiance (float4, RGBA16F), 1 occlusion (float = the normalised hit distance
+// alone, R16_UNORM), 2 directional occlusion (float4 whose "luma" is .w, RGBA16_SNORM; otherwise the radiance arithmetic)
+enum { SIGNAL_RADIANCE = 0, SIGNAL_OCCLUSION = 1, SIGNAL_DIRECTIONAL_OCCLUSION = 2 };
+struct DirOcc { // distinct type so that GetLuma / ChangeLuma / ClampNegativeToZero overload
+    float4 v;
+};
+NRD_D DirOcc MakeDirOcc(float4 v) {
+    DirOcc r;
+    r.v = v;
+    return r;
+}
+NRD_D DirOcc operator+(DirOcc a, DirOcc b) { return MakeDirOcc(a.v + b.v); }
+NRD_D DirOcc operator*(DirOcc a, float b) { return MakeDirOcc(a.v * b); }
+NRD_D DirOcc Lerp(DirOcc a, DirOcc b, float t) { return MakeDirOcc(Lerp(a.v, b.v, t)); }
+NRD_D DirOcc Select(bool c, DirOcc a, DirOcc b) { return MakeDirOcc(Select(c, a.v, b.v)); }
+NRD_D float Select(bool c, float a, float b) { return c ? a : b; }
 NRD_D float ExtractHitDist(float4 v) { return v.w; }
 NRD_D float ExtractHitDist(float v) { return v; }
+NRD_D float ExtractHitDist(DirOcc s) { return s.v.w; }
 NRD_D float GetLuma(float v) { return v; }
+NRD_D float GetLuma(DirOcc s) { return s.v.w; }
 NRD_D float ChangeLuma(float, float newLuma) { return newLuma; }
+NRD_D DirOcc ChangeLuma(DirOcc s, float newLuma) {
+    float k = GetLumaScale(s.v.w, newLuma);
+    return MakeDirOcc(F4(s.v.x * k, s.v.y * k, s.v.z * k, newLuma));
+}
 NRD_D float ClampNegativeToZero(float v) { return Sat(v); }
+NRD_D DirOcc ClampNegativeToZero(DirOcc s) { return ChangeLuma(s, Sat(s.v.w)); }
 NRD_D float MixHistoryAndCurrent(const ReblurCB& c, float history, float current, float f, float roughness = 1.0f) {
     return Lerp(history, current, Max(f, GetMinAllowedLimitForHitDistNonLinearAccumSpeed(c, roughness)));
+}
+NRD_D DirOcc MixHistoryAndCurrent(const ReblurCB& c, DirOcc history, DirOcc current, float f, float roughness = 1.0f) {
+    return MakeDirOcc(MixHistoryAndCurrent(c, history.v, current.v, f, roughness));
 }
 NRD_D float ComputeAntilag(const ReblurCB& c, float history, float avg, float sigma, float accumSpeed) {
     float h = history, a = avg;
@@ -474,12 +499,13 @@ NRD_D float FetchHistoryBilinearR16F(const HistoryFilter& h, const Plane& tex) {
 }
 
 
-// REBLUR_TYPE and its storage: radiance + hit distance in RGBA16F with an R16F fast history, or (occlusion family) the hit distance
-// alone in R16_UNORM with an R16_UNORM fast history (reference Reblur.cpp:38-45)
-template <bool OCCLUSION>
+// REBLUR_TYPE and its storage (reference Reblur.cpp:38-45): radiance + hit distance in RGBA16F with an R16F fast history; the hit distance
+// alone in R16_UNORM with an R16_UNORM fast history (occlusion family); direction + hit distance in RGBA16_SNORM with an R16_UNORM fast
+// history (directional occlusion)
+template <int KIND>
 struct ReblurSignal;
 template <>
-struct ReblurSignal<false> {
+struct ReblurSignal<SIGNAL_RADIANCE> {
     typedef float4 type;
     static NRD_D float4 Zero() { return F4(0.0f); }
     static NRD_D float4 Load(const Plane& p, int x, int y) { return LoadRGBA16F(p, x, y); }
@@ -490,8 +516,17 @@ struct ReblurSignal<false> {
     static NRD_D void StoreFast(const Plane& p, int x, int y, float v) { StoreR16F(p, x, y, v); }
     static NRD_D float FetchFastBilinear(const HistoryFilter& h, const Plane& tex) { return FetchHistoryBilinearR16F(h, tex); }
 };
+NRD_D float FetchHistoryBilinearR16Unorm(const HistoryFilter& h, const Plane& tex) {
+    auto at = [&](int x, int y) { return InBounds(tex, x, y) ? LoadR16Unorm(tex, x, y) : 0.0f; };
+    float color = at(h.ox, h.oy) * h.bw.x;
+    color += at(h.ox + 1, h.oy) * h.bw.y;
+    color += at(h.ox, h.oy + 1) * h.bw.z;
+    color += at(h.ox + 1, h.oy + 1) * h.bw.w;
+    float s = Sum(h.bw);
+    return s < 0.0001f ? 0.0f : color / s;
+}
 template <>
-struct ReblurSignal<true> {
+struct ReblurSignal<SIGNAL_OCCLUSION> {
     typedef float type;
     static NRD_D float Zero() { return 0.0f; }
     static NRD_D float Load(const Plane& p, int x, int y) { return LoadR16Unorm(p, x, y); }
@@ -502,15 +537,21 @@ struct ReblurSignal<true> {
     }
     static NRD_D float LoadFast(const Plane& p, int x, int y) { return LoadR16Unorm(p, x, y); }
     static NRD_D void StoreFast(const Plane& p, int x, int y, float v) { StoreR16Unorm(p, x, y, v); }
-    static NRD_D float FetchFastBilinear(const HistoryFilter& h, const Plane& tex) {
-        auto at = [&](int x, int y) { return InBounds(tex, x, y) ? LoadR16Unorm(tex, x, y) : 0.0f; };
-        float color = at(h.ox, h.oy) * h.bw.x;
-        color += at(h.ox + 1, h.oy) * h.bw.y;
-        color += at(h.ox, h.oy + 1) * h.bw.z;
-        color += at(h.ox + 1, h.oy + 1) * h.bw.w;
-        float s = Sum(h.bw);
-        return s < 0.0001f ? 0.0f : color / s;
+    static NRD_D float FetchFastBilinear(const HistoryFilter& h, const Plane& tex) { return FetchHistoryBilinearR16Unorm(h, tex); }
+};
+template <>
+struct ReblurSignal<SIGNAL_DIRECTIONAL_OCCLUSION> {
+    typedef DirOcc type;
+    static NRD_D DirOcc Zero() { return MakeDirOcc(F4(0.0f)); }
+    static NRD_D DirOcc Load(const Plane& p, int x, int y) { return MakeDirOcc(LoadRGBA16Snorm(p, x, y)); }
+    static NRD_D void Store(const Plane& p, int x, int y, DirOcc s) { StoreRGBA16Snorm(p, x, y, s.v); }
+    static NRD_D DirOcc WithHitDist(DirOcc s, float hitDist) { return MakeDirOcc(F4(s.v.x, s.v.y, s.v.z, hitDist)); }
+    static NRD_D DirOcc FetchHistory(const HistoryFilter& h, const Plane& tex) {
+        return MakeDirOcc(FetchHistoryGeneric<float4>(h, tex, [](const Plane& p, int x, int y) { return LoadRGBA16Snorm(p, x, y); }, F4(0.0f)));
     }
+    static NRD_D float LoadFast(const Plane& p, int x, int y) { return LoadR16Unorm(p, x, y); }
+    static NRD_D void StoreFast(const Plane& p, int x, int y, float v) { StoreR16Unorm(p, x, y, v); }
+    static NRD_D float FetchFastBilinear(const HistoryFilter& h, const Plane& tex) { return FetchHistoryBilinearR16Unorm(h, tex); }
 };
 
 } // namespace nrdhip

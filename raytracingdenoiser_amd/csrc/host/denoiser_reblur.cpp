@@ -47,12 +47,18 @@ const uint16_t DUMMY = (uint16_t)ResourceType::IN_VIEWZ; // placeholder bound to
 
 // sh: the REBLUR_*_SH denoisers (reference Source/Denoisers/Reblur_{Diffuse,Specular,DiffuseSpecular}Sh.hpp): every signal carries a second
 // RGBA16F plane (SH1) through all passes; inputs / outputs are the IN_/OUT_*_SH0 and _SH1 slots
-void InstanceImpl::Add_Reblur(DenoiserData& d, bool hasDiff, bool hasSpec, bool sh) {
+// directionalOcclusion: REBLUR_DIFFUSE_DIRECTIONAL_OCCLUSION (reference Denoisers/Reblur_DiffuseDirectionalOcclusion.hpp) = the diffuse tables
+// with RGBA16_SNORM signal planes, an R16_UNORM fast history and the IN_/OUT_DIFF_DIRECTION_HITDIST slots
+void InstanceImpl::Add_Reblur(DenoiserData& d, bool hasDiff, bool hasSpec, bool sh, bool directionalOcclusion) {
     d.settings.reblur = ReblurSettings();
     d.settingsSize = sizeof(ReblurSettings);
 
     const char* baseFamily = hasDiff && hasSpec ? "DiffuseSpecular" : (hasDiff ? "Diffuse" : "Specular");
     const char* family = !sh ? baseFamily : (hasDiff && hasSpec ? "DiffuseSpecularSh" : (hasDiff ? "DiffuseSh" : "SpecularSh"));
+    if (directionalOcclusion)
+        family = "DiffuseDirectionalOcclusion";
+    const Format FMT_SIGNAL = directionalOcclusion ? Format::RGBA16_SNORM : nrd::FMT_SIGNAL;
+    const Format FMT_FAST = directionalOcclusion ? Format::R16_UNORM : nrd::FMT_FAST;
     const uint32_t constSize = sizeof(nrdc::ReblurConstants);
 
     // ---- permanent planes (history)
@@ -136,11 +142,11 @@ void InstanceImpl::Add_Reblur(DenoiserData& d, bool hasDiff, bool hasSpec, bool 
     AddTransient(FMT_TILES, 16);
 
     // The user-visible outputs double as scratch ("TEMP1")
-    const uint16_t OUT_DIFF = (uint16_t)(sh ? ResourceType::OUT_DIFF_SH0 : ResourceType::OUT_DIFF_RADIANCE_HITDIST);
+    const uint16_t OUT_DIFF = (uint16_t)(directionalOcclusion ? ResourceType::OUT_DIFF_DIRECTION_HITDIST : (sh ? ResourceType::OUT_DIFF_SH0 : ResourceType::OUT_DIFF_RADIANCE_HITDIST));
     const uint16_t OUT_SPEC = (uint16_t)(sh ? ResourceType::OUT_SPEC_SH0 : ResourceType::OUT_SPEC_RADIANCE_HITDIST);
     const uint16_t DIFF_TEMP1 = OUT_DIFF, DIFF_TEMP2 = T_DIFF_TMP2;
     const uint16_t SPEC_TEMP1 = OUT_SPEC, SPEC_TEMP2 = T_SPEC_TMP2;
-    const uint16_t IN_DIFF = (uint16_t)(sh ? ResourceType::IN_DIFF_SH0 : ResourceType::IN_DIFF_RADIANCE_HITDIST);
+    const uint16_t IN_DIFF = (uint16_t)(directionalOcclusion ? ResourceType::IN_DIFF_DIRECTION_HITDIST : (sh ? ResourceType::IN_DIFF_SH0 : ResourceType::IN_DIFF_RADIANCE_HITDIST));
     const uint16_t IN_SPEC = (uint16_t)(sh ? ResourceType::IN_SPEC_SH0 : ResourceType::IN_SPEC_RADIANCE_HITDIST);
     // SH1 planes: the user outputs double as scratch here too
     const uint16_t IN_DIFF_SH = (uint16_t)ResourceType::IN_DIFF_SH1, IN_SPEC_SH = (uint16_t)ResourceType::IN_SPEC_SH1;
@@ -337,7 +343,7 @@ void InstanceImpl::Add_Reblur(DenoiserData& d, bool hasDiff, bool hasSpec, bool 
     if (hasSpec) Out(OUT_SPEC);
     if (diffSh) Out(ResourceType::OUT_DIFF_SH1);
     if (specSh) Out(ResourceType::OUT_SPEC_SH1);
-    snprintf(shader, sizeof(shader), "REBLUR_%s_SplitScreen.cs", family);
+    snprintf(shader, sizeof(shader), "REBLUR_%s_SplitScreen.cs", directionalOcclusion ? baseFamily : family); // sic: the radiance family's shader
     EndPass(shader, 8, 16, constSize);
 
     Pass("Validation");
@@ -346,8 +352,8 @@ void InstanceImpl::Add_Reblur(DenoiserData& d, bool hasDiff, bool hasSpec, bool 
     In(ResourceType::IN_MV);
     In(T_DATA1);
     In(T_DATA2);
-    In(hasDiff ? IN_DIFF : DUMMY);
-    In(hasSpec ? IN_SPEC : DUMMY);
+    In(hasDiff ? IN_DIFF : IN_SPEC); // a single-signal denoiser binds its input twice (REBLUR_ADD_VALIDATION_DISPATCH call sites)
+    In(hasSpec ? IN_SPEC : IN_DIFF);
     Out(ResourceType::OUT_VALIDATION);
     EndPass("REBLUR_Validation.cs", 8, 16, sizeof(nrdc::ReblurValidationConstants), IGNORE_RS);
 }
@@ -355,8 +361,8 @@ void InstanceImpl::Add_Reblur(DenoiserData& d, bool hasDiff, bool hasSpec, bool 
 void InstanceImpl::Update_Reblur(const DenoiserData& d) {
     const ReblurSettings& s = d.settings.reblur;
     const CommonSettings& cs = m_CommonSettings;
-    const bool hasDiff = d.desc.denoiser != Denoiser::REBLUR_SPECULAR && d.desc.denoiser != Denoiser::REBLUR_SPECULAR_SH;
-    const bool hasSpec = d.desc.denoiser != Denoiser::REBLUR_DIFFUSE && d.desc.denoiser != Denoiser::REBLUR_DIFFUSE_SH;
+    const bool hasDiff = d.desc.denoiser != Denoiser::REBLUR_SPECULAR && d.desc.denoiser != Denoiser::REBLUR_SPECULAR_SH; // incl. REBLUR_DIFFUSE_DIRECTIONAL_OCCLUSION
+    const bool hasSpec = d.desc.denoiser != Denoiser::REBLUR_DIFFUSE && d.desc.denoiser != Denoiser::REBLUR_DIFFUSE_SH && d.desc.denoiser != Denoiser::REBLUR_DIFFUSE_DIRECTIONAL_OCCLUSION;
 
     const bool enableHitDistanceReconstruction = s.hitDistanceReconstructionMode != HitDistanceReconstructionMode::OFF && s.checkerboardMode == CheckerboardMode::OFF;
     const bool skipTemporalStabilization = s.maxStabilizedFrameNum == 0;

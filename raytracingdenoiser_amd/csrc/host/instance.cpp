@@ -136,6 +136,9 @@ Result InstanceImpl::Create(const InstanceCreationDesc& desc) {
             case Denoiser::REBLUR_DIFFUSE_SH:
                 Add_Reblur(data, true, false, true);
                 break;
+            case Denoiser::REBLUR_DIFFUSE_DIRECTIONAL_OCCLUSION:
+                Add_Reblur(data, true, false, false, true);
+                break;
             case Denoiser::REBLUR_SPECULAR_SH:
                 Add_Reblur(data, false, true, true);
                 break;
@@ -537,6 +540,7 @@ Result InstanceImpl::GetComputeDispatches(const Identifier* identifiers, uint32_
             case Denoiser::REBLUR_DIFFUSE_SH:
             case Denoiser::REBLUR_SPECULAR_SH:
             case Denoiser::REBLUR_DIFFUSE_SPECULAR_SH:
+            case Denoiser::REBLUR_DIFFUSE_DIRECTIONAL_OCCLUSION:
                 Update_Reblur(d);
                 break;
             case Denoiser::REBLUR_DIFFUSE_OCCLUSION:

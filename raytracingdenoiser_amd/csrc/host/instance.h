@@ -113,7 +113,7 @@ private:
     void Add_Reference(DenoiserData& d);
     void Update_Reference(const DenoiserData& d);
 
-    void Add_Reblur(DenoiserData& d, bool hasDiff, bool hasSpec, bool sh);
+    void Add_Reblur(DenoiserData& d, bool hasDiff, bool hasSpec, bool sh, bool directionalOcclusion = false);
     void Update_Reblur(const DenoiserData& d);
     void Add_ReblurOcclusion(DenoiserData& d, bool hasDiff, bool hasSpec);
     void Update_ReblurOcclusion(const DenoiserData& d);

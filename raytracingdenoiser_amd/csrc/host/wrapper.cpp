@@ -16,6 +16,7 @@ const nrd::Denoiser g_Supported[] = {
     nrd::Denoiser::REBLUR_DIFFUSE_SH,
     nrd::Denoiser::REBLUR_SPECULAR_SH,
     nrd::Denoiser::REBLUR_DIFFUSE_SPECULAR_SH,
+    nrd::Denoiser::REBLUR_DIFFUSE_DIRECTIONAL_OCCLUSION,
     nrd::Denoiser::REBLUR_DIFFUSE_OCCLUSION,
     nrd::Denoiser::REBLUR_SPECULAR_OCCLUSION,
     nrd::Denoiser::REBLUR_DIFFUSE_SPECULAR_OCCLUSION,

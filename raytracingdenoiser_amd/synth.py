@@ -221,6 +221,9 @@ def render_frame(width, height, frame, device="cpu", static_camera=False, noise=
         nhd = torch.where(is_sky, torch.zeros_like(hit_d), _norm_hit_dist(hit_d, view_z, torch.ones_like(rough)))
         out["diff"] = torch.cat([_ycocg(rad), nhd.unsqueeze(-1)], -1).clamp(-FP16_MAX, FP16_MAX).to(torch.float16).contiguous()
         out["diff_sh1"] = _reblur_sh1(rad, wd)
+        # REBLUR_FrontEnd_PackDirectionalOcclusion (NRD.hlsli:776-787): (direction * normHitDist, normHitDist) as RGBA16_SNORM texels
+        do = torch.cat([wd.clamp(-1.0, 1.0) * nhd.unsqueeze(-1), nhd.unsqueeze(-1)], -1).clamp(-1.0, 1.0) * 32767.0
+        out["diff_direction_hitdist"] = torch.where(do >= 0, torch.floor(do + 0.5), -torch.floor(-do + 0.5)).to(torch.int16).contiguous()
         if "relax" in want:
             _pack_relax(out, "diff", rad, torch.where(is_sky, torch.zeros_like(hit_d), hit_d), wd)
 

@@ -30,6 +30,7 @@ DENOISERS = {
     "REBLUR_DIFFUSE_SH": (api.Denoiser.REBLUR_DIFFUSE_SH, ("reblur",)),
     "REBLUR_SPECULAR_SH": (api.Denoiser.REBLUR_SPECULAR_SH, ("reblur",)),
     "REBLUR_DIFFUSE_SPECULAR_SH": (api.Denoiser.REBLUR_DIFFUSE_SPECULAR_SH, ("reblur",)),
+    "REBLUR_DIFFUSE_DIRECTIONAL_OCCLUSION": (api.Denoiser.REBLUR_DIFFUSE_DIRECTIONAL_OCCLUSION, ("reblur",)),
     "REBLUR_DIFFUSE_OCCLUSION": (api.Denoiser.REBLUR_DIFFUSE_OCCLUSION, ("reblur",)),
     "REBLUR_SPECULAR_OCCLUSION": (api.Denoiser.REBLUR_SPECULAR_OCCLUSION, ("reblur",)),
     "REBLUR_DIFFUSE_SPECULAR_OCCLUSION": (api.Denoiser.REBLUR_DIFFUSE_SPECULAR_OCCLUSION, ("reblur",)),
@@ -77,6 +78,8 @@ def _user_planes(name, frame):
         planes += [(RT.IN_DIFF_SH0, frame["diff"], F.RGBA16_SFLOAT), (RT.IN_DIFF_SH1, frame["diff_sh1"], F.RGBA16_SFLOAT)]
     if name in ("REBLUR_SPECULAR_SH", "REBLUR_DIFFUSE_SPECULAR_SH"):
         planes += [(RT.IN_SPEC_SH0, frame["spec"], F.RGBA16_SFLOAT), (RT.IN_SPEC_SH1, frame["spec_sh1"], F.RGBA16_SFLOAT)]
+    if name == "REBLUR_DIFFUSE_DIRECTIONAL_OCCLUSION":
+        planes.append((RT.IN_DIFF_DIRECTION_HITDIST, frame["diff_direction_hitdist"], F.RGBA16_SNORM))
     if name in ("REBLUR_DIFFUSE_OCCLUSION", "REBLUR_DIFFUSE_SPECULAR_OCCLUSION"):
         planes.append((RT.IN_DIFF_HITDIST, _hitdist_unorm16(frame["diff"]), F.R16_UNORM))
     if name in ("REBLUR_SPECULAR_OCCLUSION", "REBLUR_DIFFUSE_SPECULAR_OCCLUSION"):
@@ -109,6 +112,8 @@ def output_planes(name, width, height):
         outs += [(RT.OUT_DIFF_SH0, torch.float16, 4, F.RGBA16_SFLOAT), (RT.OUT_DIFF_SH1, torch.float16, 4, F.RGBA16_SFLOAT)]
     if name in ("REBLUR_SPECULAR_SH", "REBLUR_DIFFUSE_SPECULAR_SH"):
         outs += [(RT.OUT_SPEC_SH0, torch.float16, 4, F.RGBA16_SFLOAT), (RT.OUT_SPEC_SH1, torch.float16, 4, F.RGBA16_SFLOAT)]
+    if name == "REBLUR_DIFFUSE_DIRECTIONAL_OCCLUSION":
+        outs.append((RT.OUT_DIFF_DIRECTION_HITDIST, torch.int16, 4, F.RGBA16_SNORM))
     if name in ("REBLUR_DIFFUSE_OCCLUSION", "REBLUR_DIFFUSE_SPECULAR_OCCLUSION"):
         outs.append((RT.OUT_DIFF_HITDIST, torch.int16, 1, F.R16_UNORM))
     if name in ("REBLUR_SPECULAR_OCCLUSION", "REBLUR_DIFFUSE_SPECULAR_OCCLUSION"):
@@ -163,6 +168,8 @@ def decode_plane(raw, fmt, width):
         return body.reshape(h, width, 4).astype(np.float32)
     if fmt in (F.R16_UINT, F.R16_UNORM):
         return body.view(np.uint16).reshape(h, width, 1).astype(np.float32)
+    if fmt == F.RGBA16_SNORM:
+        return body.view(np.int16).reshape(h, width, 4).astype(np.float32)
     if fmt in (F.R32_UINT, F.R10_G10_B10_A2_UNORM):
         return body.view(np.uint32).reshape(h, width, 1).astype(np.float64)
     raise KeyError(fmt)
@@ -186,7 +193,7 @@ class OracleRun:
         self.ex = oracle_driver.OracleExecutor(self.inst, width, height, api.FORMAT_BYTES, threads=threads)
         self.outs = {}
         for rt, dtype, ch, fmt in output_planes(name, width, height):
-            arr = np.zeros((height, width, ch), dtype={torch.float16: np.float16, torch.int16: np.uint16}.get(dtype, np.uint8))
+            arr = np.zeros((height, width, ch), dtype={torch.float16: np.float16, torch.int16: np.uint16 if fmt == F.R16_UNORM else np.int16}.get(dtype, np.uint8))
             self.outs[rt] = (arr, fmt)
             self.ex.bind(rt, arr, fmt)
         self.last_dispatches = []
@@ -231,7 +238,7 @@ class HipRun:
     def output(self, rt):
         t, fmt = self.outs[rt]
         a = t.cpu().numpy()
-        return (a.view(np.uint16) if a.dtype == np.int16 else a).astype(np.float32)  # int16 tensors hold R16_UNORM bit patterns
+        return (a.view(np.uint16) if a.dtype == np.int16 and fmt == F.R16_UNORM else a).astype(np.float32)  # int16 tensors: R16_UNORM bit patterns or SNORM16 values
 
 
 def generate_sequence(name, width, height, frames, static_camera=False, noise=True, device="cpu", extra_want=()):

@@ -107,6 +107,10 @@ def test_hip_exact_constant_division_and_gaussian_constants():
         t, out = torch.from_numpy(k).cuda(), torch.empty(n, device="cuda")
         assert lib.nrdHipEvalNumerics(op, t.data_ptr(), None, out.data_ptr(), n, stream) == 0
         assert np.array_equal(out.cpu().numpy().view(np.uint32), (k / np.float32(c)).view(np.uint32))
+    k = np.arange(-32768, 32768, dtype=np.float32)  # SNORM16 decode (negative numerators too)
+    t, out = torch.from_numpy(k).cuda(), torch.empty(k.size, device="cuda")
+    assert lib.nrdHipEvalNumerics(15, t.data_ptr(), None, out.data_ptr(), k.size, stream) == 0
+    assert np.array_equal(out.cpu().numpy().view(np.uint32), (k / np.float32(32767.0)).view(np.uint32))
     z = np.array([1.0, 0.5, 0.3], dtype=np.float32)  # offset.z of g_Special8 (1, 0.5) and g_Special6 (1, 0.3)
     t, out = torch.from_numpy(z).cuda(), torch.empty(3, device="cuda")
     assert lib.nrdHipEvalNumerics(13, t.data_ptr(), None, out.data_ptr(), 3, stream) == 0

@@ -265,3 +265,34 @@ def test_hip_matches_oracle_sh_options():
     worst = parity.run_parity("REBLUR_SPECULAR_SH", width=160, height=96, frames=3, verbose=True,
                               settings_overrides=dict(diffusePrepassBlurRadius=0.0, specularPrepassBlurRadius=0.0), cs_kw=dict(splitScreen=0.4))
     assert worst <= parity.REL_TOL
+
+
+# ---------------------------------------------------------------------------------------------- directional occlusion
+def test_oracle_directional_occlusion_tables_and_denoising():
+    """REBLUR_DIFFUSE_DIRECTIONAL_OCCLUSION (reference Denoisers/Reblur_DiffuseDirectionalOcclusion.hpp): the diffuse chain on RGBA16_SNORM
+    (direction * hit distance, hit distance) texels with an R16_UNORM fast history; hit-distance reconstruction and split screen run on the
+    radiance family's pipelines."""
+    name = "REBLUR_DIFFUSE_DIRECTIONAL_OCCLUSION"
+    seq = parity.generate_sequence(name, W, H, 6)
+    ora = _run_oracle(name, seq)
+    assert [d.shader for d in ora.last_dispatches] == ["REBLUR_ClassifyTiles.cs"] + ["REBLUR_DiffuseDirectionalOcclusion_%s.cs" % p for p in
+                                                       ("PrePass", "TemporalAccumulation", "HistoryFix", "Blur", "PostBlur", "TemporalStabilization")]
+    assert [f for f, _ in ora.inst.permanent_pool][3:5] == [api.Format.RGBA16_SNORM, api.Format.R16_UNORM]
+    hd = _run_oracle(name, seq[:2], overrides=dict(hitDistanceReconstructionMode=1), cs_kw=dict(splitScreen=0.3))
+    shaders = [d.shader for d in hd.last_dispatches]
+    assert shaders[1] == "REBLUR_Diffuse_HitDistReconstruction.cs" and shaders[-1] == "REBLUR_Diffuse_SplitScreen.cs"
+    m = ~seq[-1]["is_sky"].numpy()
+    out = ora.output(RT.OUT_DIFF_DIRECTION_HITDIST)[m] / 32767.0
+    noisy = seq[-1]["diff_direction_hitdist"].numpy().astype(np.float32)[m] / 32767.0
+    assert abs(out[:, 3].mean() - noisy[:, 3].mean()) < 0.03 and out[:, 3].std() < 0.7 * noisy[:, 3].std() and out[:, :3].std() < 0.8 * noisy[:, :3].std()
+
+
+@pytest.mark.gpu
+def test_hip_matches_oracle_directional_occlusion():
+    name = "REBLUR_DIFFUSE_DIRECTIONAL_OCCLUSION"
+    worst = parity.run_parity(name, width=192, height=128, frames=6, verbose=True)
+    assert worst <= parity.REL_TOL
+    # odd size, reconstruction + split screen through the radiance family's pipelines, no stabilisation, performance mode
+    worst = parity.run_parity(name, width=211, height=117, frames=4, verbose=True, extra_want=("holes",), cs_kw=dict(splitScreen=0.3),
+                              settings_overrides=dict(hitDistanceReconstructionMode=1, maxStabilizedFrameNum=0, enablePerformanceMode=True))
+    assert worst <= parity.REL_TOL
