@@ -36,8 +36,11 @@ def test_library_desc():
 
 
 def test_create_errors():
-    with pytest.raises(RuntimeError, match="UNSUPPORTED"):
-        api.Instance([(0, api.Denoiser.REBLUR_DIFFUSE_DIRECTIONAL_OCCLUSION)])
+    for d in api.Denoiser:  # every denoiser of the reference can be instantiated ...
+        if d != api.Denoiser.MAX_NUM:
+            api.Instance([(0, d)])
+    with pytest.raises(RuntimeError, match="UNSUPPORTED|INVALID_ARGUMENT"):  # ... and nothing else
+        api.Instance([(0, api.Denoiser.MAX_NUM)])
     with pytest.raises(RuntimeError, match="NON_UNIQUE_IDENTIFIER"):
         api.Instance([(3, api.Denoiser.REFERENCE), (3, api.Denoiser.SIGMA_SHADOW)])
 
