@@ -523,6 +523,10 @@ extern "C" __attribute__((visibility("default"))) uint32_t nrdHipExecuteDispatch
         }
         if (err)
             return e->Fail(nrd::Result::UNSUPPORTED, err);
+        hipError_t launchError = hipGetLastError(); // launch-configuration errors surface here (no synchronisation)
+        if (launchError != hipSuccess)
+            return e->Fail(nrd::Result::FAILURE, std::string("HIP launch failed in pass '") + (d.name ? d.name : "?") + "' (" +
+                nrd::GetInstanceDesc(*e->instance).pipelines[d.pipelineIndex].shaderFileName + "): " + hipGetErrorString(launchError));
     }
 
     hipError_t err = hipGetLastError();

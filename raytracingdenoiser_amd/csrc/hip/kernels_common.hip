@@ -23,19 +23,29 @@ void LaunchDecodeNormalRoughness(const Plane& packed, const Plane& decoded, hipS
     hipLaunchKernelGGL(DecodeNormalRoughnessKernel, dim3((unsigned)((packed.w + 255) / 256), (unsigned)packed.h, 1), dim3(256), 0, stream, packed, decoded);
 }
 
-// ---- Clear: zero the whole plane (pitch included: padding bytes are never read) -----------------------------------
-__global__ __launch_bounds__(256) void ClearPlaneKernel(Plane out, uint32_t rowBytes16) {
-    uint32_t v = blockIdx.x * 256u + threadIdx.x;
-    uint32_t y = blockIdx.y;
-    if (v < rowBytes16)
-        ((uint4*)(out.ptr + (size_t)y * out.pitch))[v] = make_uint4(0, 0, 0, 0);
+// ---- Clear: zero every texel of the plane (row padding is never read). User planes may have any pitch / alignment, so a 16-byte
+// chunk is written with one store only when it is whole and aligned, bytewise otherwise (ragged row ends, 1-pixel-wide frames)
+__global__ __launch_bounds__(256) void ClearPlaneKernel(Plane out, uint32_t rowBytes) {
+    const uint32_t begin = (blockIdx.x * 256u + threadIdx.x) * 16u;
+    if (begin >= rowBytes)
+        return;
+    uint8_t* p = out.ptr + (size_t)blockIdx.y * out.pitch + begin;
+    const uint32_t n = rowBytes - begin < 16u ? rowBytes - begin : 16u;
+    if (n == 16u && ((uintptr_t)p & 15u) == 0) {
+        *(uint4*)p = make_uint4(0, 0, 0, 0);
+    } else {
+        for (uint32_t i = 0; i < n; i++)
+            p[i] = 0;
+    }
 }
 
 static const char* LaunchClear(const PassArgs& a) {
     const Plane& out = a.planes[0];
-    uint32_t rowBytes16 = out.pitch / 16; // pitch is a multiple of 256
-    dim3 grid((rowBytes16 + 255) / 256, (unsigned)out.h, 1);
-    hipLaunchKernelGGL(ClearPlaneKernel, grid, dim3(256), 0, a.stream, out, rowBytes16);
+    const uint32_t rowBytes = (uint32_t)out.w * a.bytesPerTexel[0];
+    if (rowBytes == 0 || out.h == 0)
+        return nullptr;
+    dim3 grid((rowBytes + 4095) / 4096, (unsigned)out.h, 1);
+    hipLaunchKernelGGL(ClearPlaneKernel, grid, dim3(256), 0, a.stream, out, rowBytes);
     return nullptr;
 }
 
