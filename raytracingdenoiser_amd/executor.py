@@ -54,8 +54,9 @@ class HipExecutor:
             raise RuntimeError("%s failed: %s (%s)" % (what, r.name, self.lib.nrdHipGetLastError(self.handle).decode()))
 
     def bind(self, resource_type, tensor, fmt):
-        """tensor: contiguous CUDA tensor whose rows are the plane rows (any dtype; [H, W, C] or [H, W])."""
-        assert tensor.is_cuda and tensor.is_contiguous()
+        """tensor: CUDA tensor whose rows are the plane rows (any dtype; [H, W, C] or [H, W]); rows must be dense, the row pitch may exceed
+        the row size (e.g. a [:, :W] view of a wider allocation)."""
+        assert tensor.is_cuda and tensor[0].is_contiguous()
         pitch = tensor.stride(0) * tensor.element_size()
         desc = api.HipPlaneDesc(tensor.data_ptr(), pitch, int(fmt), self.width, self.height)
         self._check(self.lib.nrdHipBindResource(self.handle, int(resource_type), C.byref(desc)), "nrdHipBindResource(%s)" % api.ResourceType(resource_type).name)

@@ -214,22 +214,34 @@ class OracleRun:
         return arr.astype(np.float32)
 
 
+def _padded(t, pad):
+    """a [H, W(, C)] CUDA copy of t living inside a wider allocation (row pitch = (W + pad) texels, first texel offset by one row)"""
+    shape = list(t.shape)
+    big = torch.full([shape[0] + 1, shape[1] + pad] + shape[2:], 77, dtype=t.dtype, device="cuda")
+    view = big[1:, : shape[1]]
+    view.copy_(t)
+    return view
+
+
 class HipRun:
-    def __init__(self, name, width, height):
+    def __init__(self, name, width, height, pad=0):
         from raytracingdenoiser_amd.executor import HipExecutor
 
-        self.name, self.width, self.height = name, width, height
+        self.name, self.width, self.height, self.pad = name, width, height, pad
         self.inst = api.Instance([(0, DENOISERS[name][0])])
         self.ex = HipExecutor(self.inst, width, height)
         self.outs = {}
         for rt, dtype, ch, fmt in output_planes(name, width, height):
             t = torch.zeros((height, width, ch), dtype=dtype, device="cuda")
+            if pad:
+                t = _padded(t, pad)
             self.outs[rt] = (t, fmt)
             self.ex.bind(rt, t, fmt)
 
     def step(self, frame, cs, settings=None):
         for rt, t, fmt in user_planes(self.name, frame):
-            self.ex.bind(rt, t.cuda().contiguous(), fmt)
+            t = t.cuda().contiguous()
+            self.ex.bind(rt, _padded(t, self.pad) if self.pad else t, fmt)
         if settings is not None:
             assert self.inst.set_denoiser_settings(0, settings) == api.Result.SUCCESS
         assert self.inst.set_common_settings(cs) == api.Result.SUCCESS
@@ -245,11 +257,11 @@ def generate_sequence(name, width, height, frames, static_camera=False, noise=Tr
     return [synth.render_frame(width, height, f, device=device, static_camera=static_camera, noise=noise, want=tuple(DENOISERS[name][1]) + tuple(extra_want)) for f in range(frames)]
 
 
-def run_parity(name, width=192, height=128, frames=4, verbose=False, settings_overrides=None, static_camera=False, check_pools=True, cs_kw=None, extra_want=()):
+def run_parity(name, width=192, height=128, frames=4, verbose=False, settings_overrides=None, static_camera=False, check_pools=True, cs_kw=None, extra_want=(), pad=0):
     """Returns the worst relative error between the HIP path and the oracle over all frames, user outputs and pool planes."""
     seq = generate_sequence(name, width, height, frames, static_camera=static_camera, extra_want=extra_want)
     cs_kw = cs_kw or {}
-    ora, hip = OracleRun(name, width, height), HipRun(name, width, height)
+    ora, hip = OracleRun(name, width, height), HipRun(name, width, height, pad=pad)
     worst = 0.0
     for f, frame in enumerate(seq):
         cam, cam_prev = frame["camera"], seq[max(f - 1, 0)]["camera"]

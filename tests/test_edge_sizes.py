@@ -15,3 +15,11 @@ def test_hip_matches_oracle_on_tiny_and_ragged_frames(name):
     for w, h in SIZES:
         worst = parity.run_parity(name, width=w, height=h, frames=3)
         assert worst <= parity.REL_TOL, (name, w, h, worst)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", ["REBLUR_DIFFUSE_SPECULAR", "REBLUR_DIFFUSE_SPECULAR_OCCLUSION", "RELAX_DIFFUSE_SPECULAR_SH", "SIGMA_SHADOW_TRANSLUCENCY"])
+def test_hip_matches_oracle_with_padded_user_planes(name):
+    # application planes that live inside wider allocations: row pitch > row size, odd base offsets (3 extra texels per row, one extra row)
+    worst = parity.run_parity(name, width=83, height=41, frames=3, pad=3)
+    assert worst <= parity.REL_TOL
