@@ -105,6 +105,9 @@ def parse_args():
     ap.add_argument("--width", type=int, default=0)
     ap.add_argument("--height", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--sharding", choices=["halo", "allgather"], default=os.environ.get("NRD_SHARDING", "halo"),
+                    help="multi-GPU scheme: halo = halo exchange between pass segments (point-to-point to the two neighbouring ranks), allgather = redundant halo compute + one all-gather per frame")
+    ap.add_argument("--max-motion-rows", type=int, default=32, help="halo scheme: largest vertical motion (rows per frame) the history halos cover")
     ap.add_argument("--cpu-frames", type=int, default=3)
     ap.add_argument("--distinct-frames", type=int, default=0, help="number of distinct generated frames to cycle through (0 = warmup + steps)")
     return ap.parse_args()
@@ -176,7 +179,9 @@ def main():
         t = torch.zeros((H, W, ch), dtype=dtype, device="cuda")
         ex.bind(rt, t, fmt)
         outputs.append(t)
-    shard = sharding.FrameSharder(ex, inst, W, H, rank, world, outputs) if distributed else None
+    shard = None
+    if distributed:
+        shard = sharding.HaloSharder(ex, inst, W, H, rank, world, max_motion_rows=args.max_motion_rows) if args.sharding == "halo" else sharding.FrameSharder(ex, inst, W, H, rank, world, outputs)
 
     settings = parity.denoiser_settings(name, seq[0], overrides)
     assert inst.set_denoiser_settings(0, settings) == api.Result.SUCCESS
@@ -282,7 +287,8 @@ def main():
         "dtype": "f32",
         "data": "synthetic",
         "config": {"workload": "%s %dx%d, %s, analytic scene + 1rpp noise, moving camera" % (name, W, H, "default settings" if overrides is None else "settings %s" % overrides),
-                   "parallelism": "1 GPU" if world == 1 else "row strips x%d + RCCL all-gather" % world,
+                   "parallelism": "1 GPU" if world == 1 else ("row strips x%d, halo exchange between pass segments (RCCL send/recv to the 2 neighbours, %.1f MB received per rank per frame)"
+                                                               % (world, shard.exchanged_bytes / max(total, 1) / 1e6) if args.sharding == "halo" else "row strips x%d + RCCL all-gather" % world),
                    "storage": "reference pool formats (fp16 history, R10G10B10A2 normals), %.0f B/px/frame compulsory traffic" % total_bpp},
         "roofline": roofline,
         "whole_chain": whole_chain,

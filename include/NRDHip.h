@@ -79,6 +79,17 @@ uint32_t nrdHipDenoise(NrdHipExecutor* executor, const uint32_t* identifiers, ui
 // (anything but the REBLUR chain in this build) always run on the whole frame.
 uint32_t nrdHipSetOwnedRows(NrdHipExecutor* executor, uint32_t rowBegin, uint32_t rowEnd);
 
+// Finer-grained sharding control for a host that exchanges halos between passes (raytracingdenoiser_amd/sharding.py, HaloSharder):
+//   nrdHipGetDispatchReach     reachRows[i] = how many rows above / below a pixel dispatch i reads from planes written earlier in the same
+//                              frame (0 = own row only, -1 = unknown: the pass must run on the whole frame); "instance" is an nrd::Instance*
+//                              (host-only: needs no device)
+//   nrdHipExecuteDispatchRange executes dispatches [first, first + count) of the list; rowBegin[i] / rowEnd[i] (indexed by the absolute
+//                              dispatch index; NULL or rowBegin[i] < 0 = whole frame) are the rows dispatch i has to produce. Ranges of one
+//                              list must be executed in order starting at first = 0 (the per-frame caches are rebuilt there).
+uint32_t nrdHipGetDispatchReach(void* instance, const void* dispatchDescs, uint32_t dispatchDescsNum, int32_t* reachRows);
+uint32_t nrdHipExecuteDispatchRange(NrdHipExecutor* executor, const void* dispatchDescs, uint32_t dispatchDescsNum, uint32_t first, uint32_t count, const int32_t* rowBegin,
+    const int32_t* rowEnd);
+
 // Per-pass GPU timing. When enabled, every dispatch is bracketed by hipEvents on the executor's stream.
 // nrdHipCollectPassTimings synchronises the stream, folds all brackets recorded since the last collect into per-pipeline
 // totals and returns the number of pipelines written: pipelineIndices[i] (index into InstanceDesc::pipelines),

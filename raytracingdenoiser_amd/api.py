@@ -253,7 +253,8 @@ NRD_SYMBOLS = ["CreateInstance", "DestroyInstance", "GetLibraryDesc", "GetInstan
                "GetComputeDispatches", "GetResourceTypeString", "GetDenoiserString"]
 NRD_HIP_SYMBOLS = ["nrdHipCreateExecutor", "nrdHipDestroyExecutor", "nrdHipBindResource", "nrdHipGetPoolPlane", "nrdHipExecuteDispatches",
                    "nrdHipDenoise", "nrdHipGetPoolMemoryUsage", "nrdHipGetLastError", "nrdHipEvalNumerics", "nrdHipGetArenaSize",
-                   "nrdHipCreateExecutorWithArena", "nrdHipSetProfiling", "nrdHipCollectPassTimings", "nrdHipSetOwnedRows"]
+                   "nrdHipCreateExecutorWithArena", "nrdHipSetProfiling", "nrdHipCollectPassTimings", "nrdHipSetOwnedRows", "nrdHipGetDispatchReach",
+                   "nrdHipExecuteDispatchRange"]
 
 _lib = None
 
@@ -293,6 +294,9 @@ def load_library(path=None):
     lib.nrdHipCreateExecutorWithArena.argtypes = [C.c_void_p, C.c_uint16, C.c_uint16, C.c_void_p, C.c_void_p, C.c_uint64, P(C.c_void_p)]
     lib.nrdHipCreateExecutorWithArena.restype = C.c_uint32
     lib.nrdHipSetOwnedRows.argtypes, lib.nrdHipSetOwnedRows.restype = [C.c_void_p, C.c_uint32, C.c_uint32], C.c_uint32
+    lib.nrdHipGetDispatchReach.argtypes, lib.nrdHipGetDispatchReach.restype = [C.c_void_p, C.c_void_p, C.c_uint32, C.POINTER(C.c_int32)], C.c_uint32
+    lib.nrdHipExecuteDispatchRange.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]
+    lib.nrdHipExecuteDispatchRange.restype = C.c_uint32
     lib.nrdHipSetProfiling.argtypes, lib.nrdHipSetProfiling.restype = [C.c_void_p, C.c_uint32], C.c_uint32
     lib.nrdHipCollectPassTimings.argtypes = [C.c_void_p, P(C.c_uint32), P(C.c_double), P(C.c_uint32), C.c_uint32, P(C.c_uint32)]
     lib.nrdHipCollectPassTimings.restype = C.c_uint32
@@ -358,6 +362,13 @@ class Instance:
         num = C.c_uint32()
         r = Result(self.lib.GetComputeDispatches(self.handle, arr, len(ids), C.byref(out), C.byref(num)))
         return r, out, num.value
+
+    def dispatch_reach(self, dispatch_ptr, num):
+        """rows above / below a pixel each dispatch reads from planes written earlier in the frame (-1 = unknown: whole-frame pass)"""
+        out = (C.c_int32 * max(num, 1))()
+        r = Result(self.lib.nrdHipGetDispatchReach(self.handle, C.cast(dispatch_ptr, C.c_void_p), num, out))
+        assert r == Result.SUCCESS, r
+        return list(out[:num])
 
     def get_compute_dispatches(self, identifiers=None):
         r, out, num = self.get_compute_dispatches_raw(identifiers)

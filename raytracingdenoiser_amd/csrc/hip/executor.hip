@@ -387,6 +387,30 @@ extern "C" __attribute__((visibility("default"))) uint32_t nrdHipSetOwnedRows(Nr
     return (uint32_t)nrd::Result::SUCCESS;
 }
 
+// Executes dispatches [first, first + count) of the list. rowBegin / rowEnd (indexed by absolute dispatch index, may be null = whole
+// frame; rowBegin[i] < 0 = whole frame for that dispatch) give the rows each pass has to produce. The per-list caches (decoded
+// normal/roughness, a-trous world positions) are (re)built when first == 0.
+static uint32_t ExecuteRange(NrdHipExecutor* e, const nrd::DispatchDesc* descs, uint32_t dispatchDescsNum, uint32_t first, uint32_t count, const int32_t* rowBegin, const int32_t* rowEnd);
+
+extern "C" __attribute__((visibility("default"))) uint32_t nrdHipGetDispatchReach(void* instance, const void* dispatchDescs, uint32_t dispatchDescsNum, int32_t* reachRows) {
+    if (!instance || (!dispatchDescs && dispatchDescsNum) || !reachRows)
+        return (uint32_t)nrd::Result::INVALID_ARGUMENT;
+    const nrd::DispatchDesc* descs = (const nrd::DispatchDesc*)dispatchDescs;
+    const nrd::InstanceDesc& idesc = nrd::GetInstanceDesc(*(nrd::Instance*)instance);
+    for (uint32_t i = 0; i < dispatchDescsNum; i++) {
+        const nrd::DispatchDesc& d = descs[i];
+        reachRows[i] = d.pipelineIndex < idesc.pipelinesNum ? PassReachRows(idesc.pipelines[d.pipelineIndex].shaderFileName, d.constantBufferData, d.constantBufferDataSize) : -1;
+    }
+    return (uint32_t)nrd::Result::SUCCESS;
+}
+
+extern "C" __attribute__((visibility("default"))) uint32_t nrdHipExecuteDispatchRange(NrdHipExecutor* e, const void* dispatchDescs, uint32_t dispatchDescsNum, uint32_t first, uint32_t count,
+    const int32_t* rowBegin, const int32_t* rowEnd) {
+    if (!e || (!dispatchDescs && dispatchDescsNum) || first > dispatchDescsNum || count > dispatchDescsNum - first || (rowBegin == nullptr) != (rowEnd == nullptr))
+        return (uint32_t)nrd::Result::INVALID_ARGUMENT;
+    return ExecuteRange(e, (const nrd::DispatchDesc*)dispatchDescs, dispatchDescsNum, first, count, rowBegin, rowEnd);
+}
+
 extern "C" __attribute__((visibility("default"))) uint32_t nrdHipExecuteDispatches(NrdHipExecutor* e, const void* dispatchDescs, uint32_t dispatchDescsNum) {
     if (!e || (!dispatchDescs && dispatchDescsNum))
         return (uint32_t)nrd::Result::INVALID_ARGUMENT;
@@ -409,7 +433,18 @@ extern "C" __attribute__((visibility("default"))) uint32_t nrdHipExecuteDispatch
             margin += reach;
         }
     }
+    if (!sharded)
+        return ExecuteRange(e, descs, dispatchDescsNum, 0, dispatchDescsNum, nullptr, nullptr);
+    std::vector<int32_t> rowBegin(dispatchDescsNum, -1), rowEnd(dispatchDescsNum, INT_MAX);
+    for (uint32_t i = 0; i < dispatchDescsNum; i++)
+        if (e->rowMargin[i] >= 0) {
+            rowBegin[i] = std::max(e->ownedRowBegin - e->rowMargin[i], 0);
+            rowEnd[i] = e->ownedRowEnd == INT_MAX ? INT_MAX : e->ownedRowEnd + e->rowMargin[i];
+        }
+    return ExecuteRange(e, descs, dispatchDescsNum, 0, dispatchDescsNum, rowBegin.data(), rowEnd.data());
+}
 
+static uint32_t ExecuteRange(NrdHipExecutor* e, const nrd::DispatchDesc* descs, uint32_t dispatchDescsNum, uint32_t first, uint32_t count, const int32_t* rowBegin, const int32_t* rowEnd) {
     // Decoded-guide cache: if any dispatch reads IN_NORMAL_ROUGHNESS, decode the bound plane once for the whole list
     Plane decoded = {};
     {
@@ -432,7 +467,8 @@ extern "C" __attribute__((visibility("default"))) uint32_t nrdHipExecuteDispatch
                 cache.w = packed.w;
                 cache.h = packed.h;
             }
-            LaunchDecodeNormalRoughness(packed, cache, e->stream);
+            if (first == 0) // later ranges of the same list reuse this frame's decode
+                LaunchDecodeNormalRoughness(packed, cache, e->stream);
             decoded = cache;
         }
     }
@@ -457,7 +493,7 @@ extern "C" __attribute__((visibility("default"))) uint32_t nrdHipExecuteDispatch
         }
     }
 
-    for (uint32_t i = 0; i < dispatchDescsNum; i++) {
+    for (uint32_t i = first; i < first + count; i++) {
         const nrd::DispatchDesc& d = descs[i];
         if (d.pipelineIndex >= e->launchers.size())
             return e->Fail(nrd::Result::INVALID_ARGUMENT, "nrdHipExecuteDispatches: pipeline index out of range");
@@ -505,9 +541,9 @@ extern "C" __attribute__((visibility("default"))) uint32_t nrdHipExecuteDispatch
         args.rowEnd = INT_MAX;
         args.decodedNormalRoughness = decoded;
         args.worldPosViewZ = worldPos;
-        if (sharded && e->rowMargin[i] >= 0) {
-            args.rowBegin = e->ownedRowBegin - e->rowMargin[i];
-            args.rowEnd = e->ownedRowEnd == INT_MAX ? INT_MAX : e->ownedRowEnd + e->rowMargin[i];
+        if (rowBegin && rowBegin[i] >= 0) {
+            args.rowBegin = rowBegin[i];
+            args.rowEnd = rowEnd[i];
         }
         NrdHipExecutor::Bracket bracket = {};
         if (e->profiling) {

@@ -93,6 +93,12 @@ class HipExecutor:
         off = d.data - self.arena.data_ptr()
         return self.arena[off : off + d.height * d.rowPitchBytes].view(d.height, d.rowPitchBytes)
 
+    def execute_range(self, dispatch_ptr, num, first, count, row_begin=None, row_end=None):
+        """dispatches [first, first + count) of the list; row_begin / row_end: per-dispatch rows to produce (lists of length num) or None"""
+        rb = (C.c_int32 * num)(*row_begin) if row_begin is not None else None
+        re = (C.c_int32 * num)(*row_end) if row_end is not None else None
+        self._check(self.lib.nrdHipExecuteDispatchRange(self.handle, C.cast(dispatch_ptr, C.c_void_p), num, first, count, rb, re), "nrdHipExecuteDispatchRange")
+
     def set_owned_rows(self, row_begin, row_end):
         self._check(self.lib.nrdHipSetOwnedRows(self.handle, row_begin, row_end), "nrdHipSetOwnedRows")
 

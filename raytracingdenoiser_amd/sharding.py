@@ -75,3 +75,193 @@ class FrameSharder:
     def denoise(self):
         self.ex.denoise()
         self.exchange()
+
+
+# ======================================================================================================================
+# Halo-exchange sharding: instead of recomputing the halo of every later pass (FrameSharder: up to ~110 extra rows per side at the
+# default radii, i.e. 2-4x redundant work on 180-row strips), the dispatch list is cut into SEGMENTS in front of every pass with a
+# large vertical reach (blur / post-blur / a-trous at large steps ...). Inside a segment a rank still recomputes the small halos
+# (temporal accumulation +-1, history fix ...); at a segment boundary it receives from its two neighbours the boundary band of every
+# plane the next passes read -- rows the neighbours own and have just produced -- with one grouped batch of point-to-point transfers
+# (RCCL send / recv over the xGMI links to the two neighbouring ranks; gloo in the CPU tests). The planes carried over from the
+# previous frame (histories, previous guides) are exchanged the same way at the start of the frame, widened by the largest vertical
+# motion the application promises (max_motion_rows). Everything is planned from the DispatchDesc list itself (which planes a pass
+# reads / writes, nrdHipGetDispatchReach for its reach), so any denoiser the executor can bound is covered; a frame with a pass of
+# unknown reach (the clears of a restart frame, hit-distance reconstruction) simply runs unsharded on every rank, which leaves all
+# planes complete everywhere. Results stay bit-identical to one GPU as long as motion <= max_motion_rows.
+class HaloPlan:
+    def __init__(self):
+        self.fallback = False      # run the whole frame on every rank, no exchange
+        self.steps = []            # [(exchange_items, first, count)] with exchange_items = [(plane_key, width_rows)]
+        self.row_begin, self.row_end = [], []
+        self.margins, self.reach = [], []
+
+
+def _is_user_input(resource_type):
+    from . import api
+
+    return api.ResourceType(resource_type).name.startswith("IN_")
+
+
+def plan_halo_exchange(dispatches, reach, rows, height, max_motion_rows=32, exchange_threshold=24, small_planes=(), min_strip=None):
+    """dispatches: api.Dispatch list of one frame; reach: nrdHipGetDispatchReach; rows: (row_begin, row_end) owned by this rank;
+    small_planes: keys of the down-sampled pool planes (tile maps): the passes writing them run on the whole frame on every rank (they
+    are tiny and only read user inputs), so these planes are complete everywhere and never exchanged."""
+    from . import api
+
+    plan = HaloPlan()
+    n = len(dispatches)
+    plan.reach = list(reach)
+    if rows is None or n == 0 or any(r < 0 for r in reach):
+        plan.fallback = True
+        return plan
+    rb, re = rows
+    per = min_strip if min_strip is not None else re - rb  # a halo must fit into the neighbouring strip
+    starts = [0] + [i for i in range(1, n) if reach[i] > exchange_threshold]
+    bounds = starts + [n]
+    seg_of = [0] * n
+    margins = [0] * n
+    for s in range(len(starts)):
+        a, b = bounds[s], bounds[s + 1]
+        m = 0
+        for i in range(b - 1, a - 1, -1):
+            seg_of[i] = s
+            margins[i] = m
+            m += reach[i]
+    plan.margins = margins
+
+    last_write = {}
+    whole_frame = set()
+    need = {}  # (key, writer index or -1) -> halo rows
+    for i, d in enumerate(dispatches):
+        reads = [(int(t), idx) for dt, t, idx in d.resources if dt == api.DescriptorType.TEXTURE and not _is_user_input(t) and (int(t), idx) not in small_planes]
+        writes = [(int(t), idx) for dt, t, idx in d.resources if dt == api.DescriptorType.STORAGE_TEXTURE and not _is_user_input(t)]
+        if any(key in small_planes for key in writes):
+            whole_frame.add(i)
+            if any(key not in small_planes for key in writes) or reads:
+                plan.fallback = True  # a tile-map pass that also touches full-resolution pool planes: not expected, stay safe
+                return plan
+            continue
+        for key in reads:
+            w = last_write.get(key, -1)
+            if w >= 0 and seg_of[w] == seg_of[i]:
+                continue  # produced in this segment with a sufficient margin
+            h = margins[i] + reach[i] + (max_motion_rows if w < 0 else 0)
+            if h > 0:
+                need[(key, w)] = max(need.get((key, w), 0), h)
+        for key in writes:
+            last_write[key] = i
+    if any(h > per for h in need.values()):
+        plan.fallback = True  # a halo would reach past the neighbouring strip
+        return plan
+
+    exchanges = [[] for _ in starts]
+    for (key, w), h in sorted(need.items()):
+        exchanges[0 if w < 0 else seg_of[w] + 1].append((key, h))
+    for s in range(len(starts)):
+        plan.steps.append((exchanges[s], bounds[s], bounds[s + 1] - bounds[s]))
+    plan.row_begin = [-1 if i in whole_frame else max(rb - margins[i], 0) for i in range(n)]
+    plan.row_end = [height if i in whole_frame else min(re + margins[i], height) for i in range(n)]
+    return plan
+
+
+def halo_transfers(rows, rank, world, items):
+    """[(plane_index, 'send' | 'recv', peer, row_begin, row_end)] for one exchange; items = [(plane_index, width_rows)]."""
+    rb, re = rows
+    ops = []
+    for k, w in items:
+        if rank > 0:
+            ops.append((k, "send", rank - 1, rb, rb + w))
+            ops.append((k, "recv", rank - 1, rb - w, rb))
+        if rank < world - 1:
+            ops.append((k, "send", rank + 1, re - w, re))
+            ops.append((k, "recv", rank + 1, re, re + w))
+    return ops
+
+
+def exchange_halos(planes, rows, rank, world, items, group=None):
+    """planes: list of 2D uint8 tensors [H, pitch]; items: [(index into planes, width)]. One grouped batch of sends / receives."""
+    import torch.distributed as dist
+
+    transfers = halo_transfers(rows, rank, world, items)
+    if not transfers:
+        return
+    staged = planes[0].is_cuda and dist.get_backend(group) != "nccl"  # gloo moves host memory: stage the bands (tests: two ranks sharing one GPU)
+    ops, landing = [], []
+    for k, kind, peer, r0, r1 in transfers:
+        band = planes[k][r0:r1]
+        if staged:
+            host = band.cpu() if kind == "send" else __import__("torch").empty(band.shape, dtype=band.dtype)
+            if kind == "recv":
+                landing.append((band, host))
+            band = host
+        ops.append(dist.P2POp(dist.isend if kind == "send" else dist.irecv, band, peer, group))
+    for req in dist.batch_isend_irecv(ops):
+        req.wait()
+    for band, host in landing:
+        band.copy_(host)
+
+
+class HaloSharder:
+    """Row-strip sharding with halo exchange between pass segments (see above). `denoise()` replaces executor.denoise()."""
+
+    def __init__(self, executor, instance, width, height, rank, world, group=None, max_motion_rows=32, exchange_threshold=24):
+        self.ex, self.inst = executor, instance
+        self.width, self.height, self.rank, self.world, self.group = width, height, rank, world, group
+        self.max_motion_rows, self.exchange_threshold = max_motion_rows, exchange_threshold
+        # point-to-point halos do not need equal strips: any height splits (the all-gather scheme needs height % world == 0)
+        self.rows = (rank * height // world, (rank + 1) * height // world) if world > 1 and height >= world else None
+        self.min_strip = height // world if world > 1 else height
+        self.exchanged_bytes = 0  # received bytes, for reporting
+
+    def pixels_per_rank(self):
+        if self.rows is None:
+            return self.width * self.height
+        return self.width * (self.rows[1] - self.rows[0])
+
+    def plane_tensor(self, key):
+        """2D uint8 view [H, pitch] of a pool plane or of a bound user plane"""
+        from . import api
+
+        t, idx = key
+        if t in (int(api.ResourceType.PERMANENT_POOL), int(api.ResourceType.TRANSIENT_POOL)):
+            return self.ex.pool_plane_tensor(api.ResourceType(t), idx)
+        bound = self.ex._bound[t]
+        assert bound.is_contiguous(), "halo exchange needs densely packed user planes"
+        return bound.view(-1).view(dtype=__import__("torch").uint8).view(self.height, -1)
+
+    def begin_frame(self):
+        """GetComputeDispatches + plan; returns (plan, dispatch pointer, count)"""
+        from . import api
+
+        r, ptr, n = self.inst.get_compute_dispatches_raw()
+        assert r == api.Result.SUCCESS, r
+        dispatches = [api.Dispatch(ptr[i], self.inst.pipelines) for i in range(n)]
+        small = {(int(pool), i) for pool, descs in ((api.ResourceType.PERMANENT_POOL, self.inst.permanent_pool), (api.ResourceType.TRANSIENT_POOL, self.inst.transient_pool))
+                 for i, (fmt, downsample) in enumerate(descs) if downsample != 1}
+        plan = plan_halo_exchange(dispatches, self.inst.dispatch_reach(ptr, n), self.rows, self.height, self.max_motion_rows, self.exchange_threshold, small, self.min_strip)
+        return plan, ptr, n
+
+    def run_step(self, plan, ptr, n, step):
+        _, first, count = plan.steps[step]
+        self.ex.execute_range(ptr, n, first, count, plan.row_begin, plan.row_end)
+
+    def exchange_step(self, plan, step):
+        items = plan.steps[step][0]
+        if not items or self.world == 1:
+            return
+        planes = [self.plane_tensor(key) for key, _ in items]
+        pairs = [(k, min(w, planes[k].shape[0])) for k, (_, w) in enumerate(items)]
+        exchange_halos(planes, self.rows, self.rank, self.world, pairs, self.group)
+        for k, w in pairs:
+            self.exchanged_bytes += planes[k].shape[1] * w * ((self.rank > 0) + (self.rank < self.world - 1))
+
+    def denoise(self):
+        plan, ptr, n = self.begin_frame()
+        if plan.fallback:
+            self.ex.execute_range(ptr, n, 0, n)
+            return plan
+        for step in range(len(plan.steps)):
+            self.exchange_step(plan, step)
+            self.run_step(plan, ptr, n, step)
+        return plan

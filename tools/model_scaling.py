@@ -28,6 +28,8 @@ def main():
     ap.add_argument("--frames", type=int, default=24)
     ap.add_argument("--warmup", type=int, default=16)
     ap.add_argument("--worlds", default="1,2,4,8")
+    ap.add_argument("--scheme", choices=["allgather", "halo"], default="halo", help="allgather = FrameSharder (redundant halo compute), halo = HaloSharder (halo exchange between segments)")
+    ap.add_argument("--max-motion-rows", type=int, default=32)
     args = ap.parse_args()
     name, (W, H), _, _ = bench.WORKLOADS[args.workload]
     total = args.warmup + args.frames
@@ -53,9 +55,13 @@ def main():
         ref_planes = planes_of(*ref)
         rank = world // 2
         run = make()
-        shard = sharding.FrameSharder(run[1], run[0], W, H, rank, world, run[2]) if world > 1 else None
+        halo = args.scheme == "halo" and world > 1
+        shard = None
+        if world > 1:
+            shard = sharding.HaloSharder(run[1], run[0], W, H, rank, world, max_motion_rows=args.max_motion_rows) if halo else sharding.FrameSharder(run[1], run[0], W, H, rank, world, run[2])
         run_planes = planes_of(*run)
         ms = []
+        exchanged = []
         for f in range(total):
             frame = seq[f]
             cs = parity.common_settings(frame["camera"], seq[max(f - 1, 0)]["camera"], W, H, f)
@@ -63,6 +69,40 @@ def main():
                 for rt, t, fmt in parity.user_planes(name, frame):
                     ex.bind(rt, t, fmt)
                 assert inst.set_common_settings(cs) == api.Result.SUCCESS
+            if halo:
+                # lock-step with the full-frame executor: it runs the same segments, and the bands the two neighbours would send are
+                # copied out of its planes before each segment (the copies stand in for the RCCL transfers and are not timed)
+                plan, ptr, n = shard.begin_frame()
+                r2, rptr, rn = ref[0].get_compute_dispatches_raw()
+                assert rn == n
+                t, got = 0.0, 0
+                steps = [(None, 0, n)] if plan.fallback else plan.steps
+                for step, (items, first, count) in enumerate(steps):
+                    if not plan.fallback:
+                        rb, re = shard.rows
+                        for key, w in items:
+                            dst = shard.plane_tensor(key)
+                            src = ref[1].pool_plane_tensor(api.ResourceType(key[0]), key[1]) if key[0] in (int(api.ResourceType.PERMANENT_POOL), int(api.ResourceType.TRANSIENT_POOL)) else \
+                                ref[1]._bound[key[0]].view(-1).view(dtype=torch.uint8).view(H, -1)
+                            lo, hi = max(rb - w, 0), min(re + w, H)
+                            dst[lo:rb].copy_(src[lo:rb])
+                            dst[re:hi].copy_(src[re:hi])
+                            got += dst.shape[1] * ((rb - lo) + (hi - re))
+                    torch.cuda.synchronize()
+                    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                    e0.record()
+                    if plan.fallback:
+                        run[1].execute_range(ptr, n, 0, n)
+                    else:
+                        shard.run_step(plan, ptr, n, step)
+                    e1.record()
+                    ref[1].execute_range(rptr, rn, first, count)
+                    torch.cuda.synchronize()
+                    t += e0.elapsed_time(e1)
+                if f >= args.warmup:
+                    ms.append(t)
+                    exchanged.append(got)
+                continue
             ref[1].denoise()
             torch.cuda.synchronize()
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -72,22 +112,22 @@ def main():
             torch.cuda.synchronize()
             if f >= args.warmup:
                 ms.append(e0.elapsed_time(e1))
-            if shard is not None and shard.rows is not None:  # what the all-gather delivers: every row this rank does not own
+            if shard is not None and not halo and shard.rows is not None:  # what the all-gather delivers: every row this rank does not own
                 rb, re = shard.rows
                 for src, dst in zip(ref_planes, run_planes):
                     dst[:rb].copy_(src[:rb])
                     dst[re:].copy_(src[re:])
         torch.cuda.synchronize()
-        gather_bytes = sum(p.shape[0] * p.shape[1] for p in run_planes) if world > 1 else 0
+        gather_bytes = sum(p.shape[0] * p.shape[1] for p in run_planes) if world > 1 and not halo else 0
         results.append({"world": world, "rank": rank, "rows": list(shard.rows) if shard and shard.rows else [0, H], "ms_per_frame": round(sum(ms) / len(ms), 4),
-                        "all_gather_bytes_per_frame": gather_bytes})
+                        "all_gather_bytes_per_frame": gather_bytes, "halo_bytes_received_per_frame": int(sum(exchanged) / len(exchanged)) if exchanged else 0})
         for inst, ex, _ in (ref, run):
             ex.destroy()
     base = results[0]["ms_per_frame"]
     for r in results:
         r["compute_speedup_bound"] = round(base / r["ms_per_frame"], 3)
         r["redundant_compute_factor"] = round(r["ms_per_frame"] * r["world"] / base, 3)
-    print(json.dumps({"workload": "%s %dx%d" % (name, W, H), "note": "per-rank compute only, middle strip, one MI355X; collective not included", "ranks": results}))
+    print(json.dumps({"workload": "%s %dx%d" % (name, W, H), "scheme": args.scheme, "note": "per-rank compute only, middle strip, one MI355X; transfers not included", "ranks": results}))
 
 
 if __name__ == "__main__":
