@@ -146,11 +146,13 @@ def main():
         if rank == 0:
             print("bench.py: --gpus %d but WORLD_SIZE=%d; launch with torch.distributed.run --nproc-per-node %d" % (args.gpus, world, args.gpus), file=sys.stderr)
     assert torch.cuda.is_available(), "bench.py needs a GPU: the HIP path has no CPU fallback"
-    torch.cuda.set_device(local_rank)
+    # one process per GPU; NRD_DIST_BACKEND=gloo + fewer GPUs than ranks is the single-GPU rehearsal of the N>1 path (tests/test_bench_multi.py)
+    torch.cuda.set_device(local_rank % torch.cuda.device_count())
+    backend = os.environ.get("NRD_DIST_BACKEND", "nccl")  # "nccl" is RCCL on ROCm
     if distributed:
         import torch.distributed as dist
 
-        dist.init_process_group("nccl")  # RCCL
+        dist.init_process_group(backend)
 
     import parity
     from raytracingdenoiser_amd import api
@@ -227,7 +229,7 @@ def main():
     ex.set_profiling(False)
 
     if distributed:
-        tt = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        tt = torch.tensor([elapsed], dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
 

@@ -361,3 +361,25 @@ def test_halo_sharding_two_processes_one_gpu():
     for p in procs:
         p.join(timeout=60)
     assert results == [(0, True, True), (1, True, True)]
+
+
+@pytest.mark.gpu
+def test_bench_two_ranks_rehearsal():
+    """bench.py exactly as the driver launches it for N = 2 (torch.distributed.run, one rank per process, barrier + max over ranks, rank 0 prints
+    the JSON line) -- with gloo and both ranks on the one GPU of the box, because RCCL needs one GPU per rank."""
+    import json
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, NRD_DIST_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    port = 29500 + (os.getpid() % 100)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", str(port),
+           os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "6", "--warmup", "3", "--width", "512", "--height", "600"]
+    out = subprocess.run(cmd, cwd=root, env=env, capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, out.stdout[-2000:]
+    r = json.loads(lines[0])
+    assert r["n_gpus"] == 2 and r["steps"] == 6 and r["warmup"] == 3 and r["value"] > 0 and r["scaling"] == "strong"
+    assert "halo exchange" in r["config"]["parallelism"] and r["roofline"]["kernel"].startswith("REBLUR_")
