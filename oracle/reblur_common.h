@@ -106,8 +106,11 @@ inline float GetFadeBasedOnAccumulatedFrames(const ReblurCB& c, float accumSpeed
     float b = c.gHistoryFixFrameNum * 4.0f / 3.0f + 2e-6f;
     return Math::LinearStep(a, b, accumSpeed);
 }
-inline float GetNonLinearAccumSpeed(float accumSpeed, float maxAccumSpeed, float confidence) { // hasData = true (no checkerboard)
-    return max(1.0f - confidence, 1.0f / (1.0f + min(accumSpeed, maxAccumSpeed)));
+inline float GetNonLinearAccumSpeed(const ReblurCB& c, float accumSpeed, float maxAccumSpeed, float confidence, bool hasData) { // REBLUR_Common.hlsli:111-124
+    float nonLinearAccumSpeed = max(1.0f - confidence, 1.0f / (1.0f + min(accumSpeed, maxAccumSpeed)));
+    if (!hasData)
+        nonLinearAccumSpeed *= lerp(1.0f - c.gCheckerboardResolveAccumSpeed, 1.0f, nonLinearAccumSpeed);
+    return nonLinearAccumSpeed;
 }
 inline float RemapRoughnessToResponsiveFactor(const ReblurCB& c, float roughness) {
     float amount = (roughness + NRD_EPS) / (c.gResponsiveAccumulationRoughnessThreshold + NRD_EPS);

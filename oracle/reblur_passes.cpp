@@ -59,18 +59,27 @@ struct SpatialCtx { // what PrePass / Blur / PostBlur share per pixel
     float4 rotator;
     float2 data1; // accumulated frames (diff, spec); unused by the pre-pass
     bool perf;    // REBLUR_PERFORMANCE_MODE (REBLUR_Config.hlsli:196-238): 6 taps of g_Special6, screen-space sampling for specular too
+    // checkerboard resolve of the pre-pass (REBLUR_PrePass.hlsli:43-56): left / right neighbour columns in the half-width input and their weights
+    int cbX0 = 0, cbX1 = 0;
+    float2 wc = float2(0.0f);
 };
 
+// Common.hlsli:297-307: a tap that lands on a pixel without data moves one pixel left / right (alternating with the tap counter); "pos" is a pixel centre
+inline float2 ApplyCheckerboardShift(float2 pos, uint32_t mode, uint32_t counter, uint32_t frameIndex) {
+    float2 posPositive = pos + 16384.0f;
+    uint32_t checkerboard = Sequence::CheckerBoard((uint32_t)posPositive.x, (uint32_t)posPositive.y, frameIndex);
+    float shift = (counter & 1u) == 0 ? -1.0f : 1.0f;
+    pos.x += shift * ((checkerboard != mode && mode != 2) ? 1.0f : 0.0f);
+    return pos;
+}
+
 template <typename S> // S = REBLUR_TYPE: float4 (radiance + hit distance) or float (occlusion: hit distance only)
-S DiffuseSpatialFilter(const ReblurCB& c, SpatialMode mode, const SpatialCtx& s, S diff, const Tex& gIn_Diff, const Tex& gIn_ViewZ, const Tex& gIn_Normal_Roughness,
-    float4* diffSh = nullptr, const Tex* gIn_DiffSh = nullptr) { // REBLUR_SH: the SH1 plane is filtered with the same weights (all 4 components)
+S DiffuseSpatialFilterTaps(const ReblurCB& c, SpatialMode mode, const SpatialCtx& s, S diff, const Tex& gIn_Diff, const Tex& gIn_ViewZ, const Tex& gIn_Normal_Roughness,
+    float4* diffSh, const Tex* gIn_DiffSh, float& sum) { // REBLUR_SH: the SH1 plane is filtered with the same weights (all 4 components)
     constexpr int KIND = SignalKind<S>::value;
     constexpr bool OCC = KIND == SIGNAL_OCCLUSION;
     typedef ReblurSignal<KIND> Sig;
-    if (mode == PRE_BLUR && c.gDiffPrepassBlurRadius == 0.0f)
-        return diff;
 
-    float sum = 1.0f;
     float fractionScale = 1.0f, radiusScale = 1.0f;
     if (mode == PRE_BLUR)
         fractionScale = REBLUR_PRE_BLUR_FRACTION_SCALE;
@@ -125,8 +134,13 @@ S DiffuseSpatialFilter(const ReblurCB& c, SpatialMode mode, const SpatialCtx& s,
         float3 offset = s.perf ? g_Special6[n] : g_Special8[n];
         float2 uv = s.pixelUv + Geometry::RotateVector(scaledRotator, float2(offset.x, offset.y));
         uv = floor(uv * c.gRectSize) + 0.5f; // snap to the pixel centre
+        if (mode == PRE_BLUR)
+            uv = ApplyCheckerboardShift(uv, c.gDiffCheckerboard, (uint32_t)n, c.gFrameIndex);
         uv *= c.gRectSizeInv;
         float2 uvScaled = min(uv * c.gResolutionScale, c.gResolutionScale - 0.5f * c.gResourceSizeInv); // ClampUvToViewport
+        float2 checkerboardUvScaled = uvScaled; // checkerboarded inputs live in the left half of the plane
+        if (mode == PRE_BLUR && c.gDiffCheckerboard != 2)
+            checkerboardUvScaled.x *= 0.5f;
 
         float zs = UnpackViewZ(c, gIn_ViewZ.SampleNearest(uvScaled).x);
         float materialIDs;
@@ -140,7 +154,7 @@ S DiffuseSpatialFilter(const ReblurCB& c, SpatialMode mode, const SpatialCtx& s,
         w *= CompareMaterials(s.materialID, materialIDs, c.gDiffMinMaterial) ? 1.0f : 0.0f;
         w *= ComputeWeight(angle, normalWeightParam, 0.0f);
 
-        S smp = Sig::From(gIn_Diff.SampleNearest(uvScaled));
+        S smp = Sig::From(gIn_Diff.SampleNearest(checkerboardUvScaled));
         smp = w == 0.0f ? S(0.0f) : smp; // Denanify
 
         w *= lerp(minHitDistWeight, 1.0f, ComputeExponentialWeight(ExtractHitDist(smp), hitDistanceWeightParams.x, hitDistanceWeightParams.y));
@@ -149,7 +163,7 @@ S DiffuseSpatialFilter(const ReblurCB& c, SpatialMode mode, const SpatialCtx& s,
         sum += w;
         diff = diff + smp * w;
         if (diffSh) {
-            float4 sh = gIn_DiffSh->SampleNearest(uvScaled);
+            float4 sh = gIn_DiffSh->SampleNearest(checkerboardUvScaled);
             sh = w == 0.0f ? float4(0.0f) : sh;
             *diffSh += sh * w;
         }
@@ -162,22 +176,41 @@ S DiffuseSpatialFilter(const ReblurCB& c, SpatialMode mode, const SpatialCtx& s,
     return diff;
 }
 
+// "sum" = 1 when the centre pixel carries data, 0 for the empty pixels of a checkerboarded input (pre-pass only)
+template <typename S>
+S DiffuseSpatialFilter(const ReblurCB& c, SpatialMode mode, const SpatialCtx& s, S diff, const Tex& gIn_Diff, const Tex& gIn_ViewZ, const Tex& gIn_Normal_Roughness,
+    float4* diffSh = nullptr, const Tex* gIn_DiffSh = nullptr, float sum = 1.0f) {
+    typedef ReblurSignal<SignalKind<S>::value> Sig;
+    if (!(mode == PRE_BLUR && c.gDiffPrepassBlurRadius == 0.0f))
+        diff = DiffuseSpatialFilterTaps<S>(c, mode, s, diff, gIn_Diff, gIn_ViewZ, gIn_Normal_Roughness, diffSh, gIn_DiffSh, sum);
+    if (mode == PRE_BLUR && sum == 0.0f) { // checkerboard resolve, if the pre-pass failed (REBLUR_Common_DiffuseSpatialFilter.hlsli:177-199)
+        S s0 = Sig::From(gIn_Diff.Load(s.cbX0, s.py)), s1 = Sig::From(gIn_Diff.Load(s.cbX1, s.py));
+        s0 = s.wc.x == 0.0f ? S(0.0f) : s0;
+        s1 = s.wc.y == 0.0f ? S(0.0f) : s1;
+        diff = s0 * s.wc.x + s1 * s.wc.y;
+        if (diffSh) {
+            float4 sh0 = gIn_DiffSh->Load(s.cbX0, s.py), sh1 = gIn_DiffSh->Load(s.cbX1, s.py);
+            sh0 = s.wc.x == 0.0f ? float4(0.0f) : sh0;
+            sh1 = s.wc.y == 0.0f ? float4(0.0f) : sh1;
+            *diffSh = sh0 * s.wc.x + sh1 * s.wc.y;
+        }
+    }
+    return diff;
+}
+
 // returns the filtered signal; for the pre-pass also produces hitDistForTracking (written only if the radius != 0)
 template <typename S>
-S SpecularSpatialFilter(const ReblurCB& c, SpatialMode mode, const SpatialCtx& s, S spec, const Tex& gIn_Spec, const Tex& gIn_ViewZ,
-    const Tex& gIn_Normal_Roughness, Tex* gOut_SpecHitDistForTracking, float4* specSh = nullptr, const Tex* gIn_SpecSh = nullptr) { // REBLUR_SH: .xyz only (.w = roughness for AA)
+S SpecularSpatialFilterTaps(const ReblurCB& c, SpatialMode mode, const SpatialCtx& s, S spec, const Tex& gIn_Spec, const Tex& gIn_ViewZ,
+    const Tex& gIn_Normal_Roughness, Tex* gOut_SpecHitDistForTracking, float4* specSh, const Tex* gIn_SpecSh, float& sum) { // REBLUR_SH: .xyz only (.w = roughness for AA)
     constexpr int KIND = SignalKind<S>::value;
     constexpr bool OCC = KIND == SIGNAL_OCCLUSION;
     typedef ReblurSignal<KIND> Sig;
     float smc = GetSpecMagicCurve(s.roughness);
-    if (mode == PRE_BLUR && c.gSpecPrepassBlurRadius == 0.0f)
-        return spec;
 
     RngHash rng;
     if (mode == PRE_BLUR)
         rng.Initialize((uint32_t)s.px, (uint32_t)s.py, c.gFrameIndex);
 
-    float sum = 1.0f;
     float fractionScale = 1.0f, radiusScale = 1.0f;
     if (mode == PRE_BLUR)
         fractionScale = REBLUR_PRE_BLUR_FRACTION_SCALE;
@@ -260,8 +293,13 @@ S SpecularSpatialFilter(const ReblurCB& c, SpatialMode mode, const SpatialCtx& s
             uv = GetKernelSampleCoordinates(c.gViewToClip, offset, s.Xv, T, B, s.rotator);
 
         uv = floor(uv * c.gRectSize) + 0.5f;
+        if (mode == PRE_BLUR)
+            uv = ApplyCheckerboardShift(uv, c.gSpecCheckerboard, (uint32_t)n, c.gFrameIndex);
         uv *= c.gRectSizeInv;
         float2 uvScaled = min(uv * c.gResolutionScale, c.gResolutionScale - 0.5f * c.gResourceSizeInv);
+        float2 checkerboardUvScaled = uvScaled;
+        if (mode == PRE_BLUR && c.gSpecCheckerboard != 2)
+            checkerboardUvScaled.x *= 0.5f;
 
         float zs = UnpackViewZ(c, gIn_ViewZ.SampleNearest(uvScaled).x);
         float materialIDs;
@@ -276,7 +314,7 @@ S SpecularSpatialFilter(const ReblurCB& c, SpatialMode mode, const SpatialCtx& s
         w *= ComputeWeight(angle, normalWeightParam, 0.0f);
         w *= ComputeWeight(Ns.w, roughnessWeightParams.x, roughnessWeightParams.y);
 
-        S smp = Sig::From(gIn_Spec.SampleNearest(uvScaled));
+        S smp = Sig::From(gIn_Spec.SampleNearest(checkerboardUvScaled));
         smp = w == 0.0f ? S(0.0f) : smp;
 
         if (mode == PRE_BLUR) {
@@ -299,7 +337,7 @@ S SpecularSpatialFilter(const ReblurCB& c, SpatialMode mode, const SpatialCtx& s
         sum += w;
         spec = spec + smp * w;
         if (specSh) {
-            float4 sh = gIn_SpecSh->SampleNearest(uvScaled);
+            float4 sh = gIn_SpecSh->SampleNearest(checkerboardUvScaled);
             sh = w == 0.0f ? float4(0.0f) : sh;
             specSh->x += sh.x * w, specSh->y += sh.y * w, specSh->z += sh.z * w;
         }
@@ -312,6 +350,27 @@ S SpecularSpatialFilter(const ReblurCB& c, SpatialMode mode, const SpatialCtx& s
 
     if (mode == PRE_BLUR)
         gOut_SpecHitDistForTracking->Store(s.px, s.py, hitDistForTracking == NRD_INF ? 0.0f : hitDistForTracking);
+    return spec;
+}
+
+template <typename S>
+S SpecularSpatialFilter(const ReblurCB& c, SpatialMode mode, const SpatialCtx& s, S spec, const Tex& gIn_Spec, const Tex& gIn_ViewZ,
+    const Tex& gIn_Normal_Roughness, Tex* gOut_SpecHitDistForTracking, float4* specSh = nullptr, const Tex* gIn_SpecSh = nullptr, float sum = 1.0f) {
+    typedef ReblurSignal<SignalKind<S>::value> Sig;
+    if (!(mode == PRE_BLUR && c.gSpecPrepassBlurRadius == 0.0f))
+        spec = SpecularSpatialFilterTaps<S>(c, mode, s, spec, gIn_Spec, gIn_ViewZ, gIn_Normal_Roughness, gOut_SpecHitDistForTracking, specSh, gIn_SpecSh, sum);
+    if (mode == PRE_BLUR && sum == 0.0f) { // checkerboard resolve, if the pre-pass failed (REBLUR_Common_SpecularSpatialFilter.hlsli:224-246; all 4 SH components)
+        S s0 = Sig::From(gIn_Spec.Load(s.cbX0, s.py)), s1 = Sig::From(gIn_Spec.Load(s.cbX1, s.py));
+        s0 = s.wc.x == 0.0f ? S(0.0f) : s0;
+        s1 = s.wc.y == 0.0f ? S(0.0f) : s1;
+        spec = s0 * s.wc.x + s1 * s.wc.y;
+        if (specSh) {
+            float4 sh0 = gIn_SpecSh->Load(s.cbX0, s.py), sh1 = gIn_SpecSh->Load(s.cbX1, s.py);
+            sh0 = s.wc.x == 0.0f ? float4(0.0f) : sh0;
+            sh1 = s.wc.y == 0.0f ? float4(0.0f) : sh1;
+            *specSh = sh0 * s.wc.x + sh1 * s.wc.y;
+        }
+    }
     return spec;
 }
 
@@ -370,18 +429,46 @@ void PrePass(const PassIO& io) {
             SpatialCtx s;
             if (!MakeSpatialCtx(c, px, py, gIn_Tiles, gIn_ViewZ, gIn_Normal_Roughness, c.gRotatorPre, PERF, s))
                 continue;
+            // checkerboard resolve weights (REBLUR_PrePass.hlsli:43-56)
+            const uint32_t checkerboard = Sequence::CheckerBoard((uint32_t)px, (uint32_t)py, c.gFrameIndex);
+            {
+                int x0 = max(px - 1, 0), x1 = min(px + 1, c.gRectSizeMinusOne[0]);
+                float viewZ0 = UnpackViewZ(c, gIn_ViewZ.Load(x0, py).x), viewZ1 = UnpackViewZ(c, gIn_ViewZ.Load(x1, py).x);
+                float thr = GetDisocclusionThreshold(NRD_DISOCCLUSION_THRESHOLD, s.frustumSize, s.NoV);
+                float2 wc = float2(thr >= fabsf(viewZ0 - s.viewZ) ? 1.0f : 0.0f, thr >= fabsf(viewZ1 - s.viewZ) ? 1.0f : 0.0f); // GetDisocclusionWeight = step
+                wc.x = (viewZ0 > c.gDenoisingRange || px < 1) ? 0.0f : wc.x;
+                wc.y = (viewZ1 > c.gDenoisingRange || px >= c.gRectSizeMinusOne[0]) ? 0.0f : wc.y;
+                wc *= Math::PositiveRcp(wc.x + wc.y);
+                s.wc = wc;
+                s.cbX0 = x0 >> 1;
+                s.cbX1 = x1 >> 1;
+            }
             if (DIFF) {
-                S diff = Sig::From(gIn_Diff->Load(px, py));
-                float4 diffSh = SH ? gIn_DiffSh->Load(px, py) : float4(0.0f);
-                diff = DiffuseSpatialFilter<S>(c, PRE_BLUR, s, diff, *gIn_Diff, gIn_ViewZ, gIn_Normal_Roughness, SH ? &diffSh : nullptr, gIn_DiffSh);
+                const int pos = c.gDiffCheckerboard == 2 ? px : px >> 1;
+                float sum = 1.0f;
+                S diff = Sig::From(gIn_Diff->Load(pos, py));
+                float4 diffSh = SH ? gIn_DiffSh->Load(pos, py) : float4(0.0f);
+                if (c.gDiffCheckerboard != 2 && checkerboard != c.gDiffCheckerboard) {
+                    sum = 0.0f;
+                    diff = S(0.0f);
+                    diffSh = float4(0.0f);
+                }
+                diff = DiffuseSpatialFilter<S>(c, PRE_BLUR, s, diff, *gIn_Diff, gIn_ViewZ, gIn_Normal_Roughness, SH ? &diffSh : nullptr, gIn_DiffSh, sum);
                 gOut_Diff->Store(px, py, diff);
                 if (SH)
                     gOut_DiffSh->Store(px, py, diffSh);
             }
             if (SPEC) {
-                S spec = Sig::From(gIn_Spec->Load(px, py));
-                float4 specSh = SH ? gIn_SpecSh->Load(px, py) : float4(0.0f);
-                spec = SpecularSpatialFilter<S>(c, PRE_BLUR, s, spec, *gIn_Spec, gIn_ViewZ, gIn_Normal_Roughness, gOut_SpecHitDistForTracking, SH ? &specSh : nullptr, gIn_SpecSh);
+                const int pos = c.gSpecCheckerboard == 2 ? px : px >> 1;
+                float sum = 1.0f;
+                S spec = Sig::From(gIn_Spec->Load(pos, py));
+                float4 specSh = SH ? gIn_SpecSh->Load(pos, py) : float4(0.0f);
+                if (c.gSpecCheckerboard != 2 && checkerboard != c.gSpecCheckerboard) {
+                    sum = 0.0f;
+                    spec = S(0.0f);
+                    specSh = float4(0.0f);
+                }
+                spec = SpecularSpatialFilter<S>(c, PRE_BLUR, s, spec, *gIn_Spec, gIn_ViewZ, gIn_Normal_Roughness, gOut_SpecHitDistForTracking, SH ? &specSh : nullptr, gIn_SpecSh, sum);
                 gOut_Spec->Store(px, py, spec);
                 if (SH)
                     gOut_SpecSh->Store(px, py, specSh);
@@ -566,7 +653,8 @@ void TemporalAccumulation(const PassIO& io) {
             auto sHitDistForTracking = [&](int x, int y) {
                 x = clamp(x, 0, rw);
                 y = clamp(y, 0, rh);
-                float hitDist = (OCC || c.gSpecPrepassBlurRadius == 0.0f) ? ExtractHitDist(Sig::From(gIn_Spec->Load(x, y))) : gIn_SpecHitDistForTracking->Load(x, y).x;
+                const int shift = (OCC && c.gSpecCheckerboard != 2) ? 1 : 0; // REBLUR_TemporalAccumulation.hlsli:21-27
+                float hitDist = (OCC || c.gSpecPrepassBlurRadius == 0.0f) ? ExtractHitDist(Sig::From(gIn_Spec->Load(x >> shift, y))) : gIn_SpecHitDistForTracking->Load(x, y).x;
                 return hitDist == 0.0f ? NRD_INF : hitDist;
             };
 
@@ -747,6 +835,24 @@ void TemporalAccumulation(const PassIO& io) {
 
             const float2 smbSamplePos = saturate(smbPixelUv) * c.gRectSizePrev;
 
+            // Checkerboard resolve (REBLUR_TemporalAccumulation.hlsli:307-321): only the occlusion family resolves here (the others did in the pre-pass)
+            const uint32_t checkerboard = Sequence::CheckerBoard((uint32_t)px, (uint32_t)py, c.gFrameIndex);
+            const bool diffHasData = c.gDiffCheckerboard == 2 || checkerboard == c.gDiffCheckerboard;
+            const bool specHasData = c.gSpecCheckerboard == 2 || checkerboard == c.gSpecCheckerboard;
+            int cbX0 = 0, cbX1 = 0;
+            float2 wc = float2(0.0f);
+            if (OCC) {
+                int x0 = max(px - 1, 0), x1 = min(px + 1, c.gRectSizeMinusOne[0]);
+                float viewZ0 = UnpackViewZ(c, gIn_ViewZ.Load(x0, py).x), viewZ1 = UnpackViewZ(c, gIn_ViewZ.Load(x1, py).x);
+                float thr = GetDisocclusionThreshold(NRD_DISOCCLUSION_THRESHOLD, frustumSize, NoV);
+                wc = float2(thr >= fabsf(viewZ0 - viewZ) ? 1.0f : 0.0f, thr >= fabsf(viewZ1 - viewZ) ? 1.0f : 0.0f);
+                wc.x = (viewZ0 > c.gDenoisingRange || px < 1) ? 0.0f : wc.x;
+                wc.y = (viewZ1 > c.gDenoisingRange || px >= c.gRectSizeMinusOne[0]) ? 0.0f : wc.y;
+                wc *= Math::PositiveRcp(wc.x + wc.y);
+                cbX0 = x0 >> 1;
+                cbX1 = x1 >> 1;
+            }
+
             // ---------------------------------------------------------------------------------------------- specular
             float specAccumSpeed = 0.0f, curvature = 0.0f, virtualHistoryAmount = 0.0f;
             if (SPEC) {
@@ -756,7 +862,13 @@ void TemporalAccumulation(const PassIO& io) {
                 smbSpecAccumSpeed *= lerp(specHistoryConfidence, 1.0f, 1.0f / (1.0f + smbSpecAccumSpeed));
                 smbSpecAccumSpeed = min(smbSpecAccumSpeed, c.gMaxAccumulatedFrameNum);
 
-                S spec = Sig::From(gIn_Spec->Load(px, py));
+                S spec = Sig::From(gIn_Spec->Load((OCC && c.gSpecCheckerboard != 2) ? px >> 1 : px, py));
+                if (OCC && !specHasData) {
+                    S s0 = Sig::From(gIn_Spec->Load(cbX0, py)), s1 = Sig::From(gIn_Spec->Load(cbX1, py));
+                    s0 = wc.x == 0.0f ? S(0.0f) : s0;
+                    s1 = wc.y == 0.0f ? S(0.0f) : s1;
+                    spec = s0 * wc.x + s1 * wc.y;
+                }
 
                 // Curvature estimation along predicted motion
                 {
@@ -1034,6 +1146,10 @@ void TemporalAccumulation(const PassIO& io) {
                 // Accumulation
                 float smbSpecNonLinearAccumSpeed = 1.0f / (1.0f + smbSpecAccumSpeed);
                 float vmbSpecNonLinearAccumSpeed = 1.0f / (1.0f + vmbSpecAccumSpeed);
+                if (!specHasData) {
+                    smbSpecNonLinearAccumSpeed *= lerp(1.0f - c.gCheckerboardResolveAccumSpeed, 1.0f, smbSpecNonLinearAccumSpeed);
+                    vmbSpecNonLinearAccumSpeed *= lerp(1.0f - c.gCheckerboardResolveAccumSpeed, 1.0f, vmbSpecNonLinearAccumSpeed);
+                }
 
                 S smbSpec = MixHistoryAndCurrent(c, smbSpecHistory, spec, smbSpecNonLinearAccumSpeed, roughnessModified);
                 S vmbSpec = MixHistoryAndCurrent(c, vmbSpecHistory, spec, vmbSpecNonLinearAccumSpeed, roughnessModified);
@@ -1075,8 +1191,8 @@ void TemporalAccumulation(const PassIO& io) {
                     gOut_SpecSh->Store(px, py, specShResult);
 
                 // Fast history
-                float smbSpecFastNonLinearAccumSpeed = GetNonLinearAccumSpeed(smbSpecAccumSpeed, c.gMaxFastAccumulatedFrameNum, surfaceHistoryConfidence);
-                float vmbSpecFastNonLinearAccumSpeed = GetNonLinearAccumSpeed(vmbSpecAccumSpeed, c.gMaxFastAccumulatedFrameNum, virtualHistoryConfidence);
+                float smbSpecFastNonLinearAccumSpeed = GetNonLinearAccumSpeed(c, smbSpecAccumSpeed, c.gMaxFastAccumulatedFrameNum, surfaceHistoryConfidence, specHasData);
+                float vmbSpecFastNonLinearAccumSpeed = GetNonLinearAccumSpeed(c, vmbSpecAccumSpeed, c.gMaxFastAccumulatedFrameNum, virtualHistoryConfidence, specHasData);
                 float smbSpecFast = lerp(smbSpecFastHistory, GetLuma(spec), smbSpecFastNonLinearAccumSpeed);
                 float vmbSpecFast = lerp(vmbSpecFastHistory, GetLuma(spec), vmbSpecFastNonLinearAccumSpeed);
                 float specFastResult = lerp(smbSpecFast, vmbSpecFast, virtualHistoryAmount);
@@ -1100,7 +1216,13 @@ void TemporalAccumulation(const PassIO& io) {
                 diffAccumSpeed *= lerp(diffHistoryConfidence, 1.0f, 1.0f / (1.0f + diffAccumSpeed));
                 diffAccumSpeed = min(diffAccumSpeed, c.gMaxAccumulatedFrameNum);
 
-                S diff = Sig::From(gIn_Diff->Load(px, py));
+                S diff = Sig::From(gIn_Diff->Load((OCC && c.gDiffCheckerboard != 2) ? px >> 1 : px, py));
+                if (OCC && !diffHasData) {
+                    S d0 = Sig::From(gIn_Diff->Load(cbX0, py)), d1 = Sig::From(gIn_Diff->Load(cbX1, py));
+                    d0 = wc.x == 0.0f ? S(0.0f) : d0;
+                    d1 = wc.y == 0.0f ? S(0.0f) : d1;
+                    diff = d0 * wc.x + d1 * wc.y;
+                }
 
                 HistoryFilter smbFilter = MakeHistoryFilter(smbSamplePos, smbOcclusionWeights, smbAllowCatRom);
                 S smbDiffHistory = Sig::From(FetchHistoryColor(smbFilter, *gHistory_Diff));
@@ -1108,6 +1230,8 @@ void TemporalAccumulation(const PassIO& io) {
                 smbDiffHistory = ClampNegativeToZero(smbDiffHistory);
 
                 float diffNonLinearAccumSpeed = 1.0f / (1.0f + diffAccumSpeed);
+                if (!diffHasData)
+                    diffNonLinearAccumSpeed *= lerp(1.0f - c.gCheckerboardResolveAccumSpeed, 1.0f, diffNonLinearAccumSpeed);
                 S diffResult = MixHistoryAndCurrent(c, smbDiffHistory, diff, diffNonLinearAccumSpeed);
                 float4 diffShResult = float4(0.0f);
                 if (SH) { // REBLUR_TemporalAccumulation.hlsli:883-886
@@ -1138,6 +1262,8 @@ void TemporalAccumulation(const PassIO& io) {
                 // Fast history
                 float diffFastAccumSpeed = min(diffAccumSpeed, c.gMaxFastAccumulatedFrameNum);
                 float diffFastNonLinearAccumSpeed = 1.0f / (1.0f + diffFastAccumSpeed);
+                if (!diffHasData)
+                    diffFastNonLinearAccumSpeed *= lerp(1.0f - c.gCheckerboardResolveAccumSpeed, 1.0f, diffFastNonLinearAccumSpeed);
                 float diffFastResult = lerp(smbDiffFastHistory, GetLuma(diff), diffFastNonLinearAccumSpeed);
                 if (KIND == SIGNAL_RADIANCE) {
                     float diffFastClamped = min(diffFastResult, GetLuma(smbDiffHistory) * diffMaxRelativeIntensity * REBLUR_FIREFLY_SUPPRESSOR_FAST_RELATIVE_INTENSITY);
@@ -1703,14 +1829,15 @@ void SplitScreen(const PassIO& io) {
                 continue;
             float viewZ = UnpackViewZ(c, gIn_ViewZ.Load(px, py).x);
             float keep = viewZ < c.gDenoisingRange ? 1.0f : 0.0f;
+            const int dx = c.gDiffCheckerboard != 2 ? px >> 1 : px, sx = c.gSpecCheckerboard != 2 ? px >> 1 : px; // checkerboarded inputs: left half
             if (DIFF)
-                gOut_Diff->Store(px, py, gIn_Diff->Load(px, py) * keep);
+                gOut_Diff->Store(px, py, gIn_Diff->Load(dx, py) * keep);
             if (SPEC)
-                gOut_Spec->Store(px, py, gIn_Spec->Load(px, py) * keep);
+                gOut_Spec->Store(px, py, gIn_Spec->Load(sx, py) * keep);
             if (DIFF && SH)
-                gOut_DiffSh->Store(px, py, gIn_DiffSh->Load(px, py) * keep);
+                gOut_DiffSh->Store(px, py, gIn_DiffSh->Load(dx, py) * keep);
             if (SPEC && SH)
-                gOut_SpecSh->Store(px, py, gIn_SpecSh->Load(px, py) * keep);
+                gOut_SpecSh->Store(px, py, gIn_SpecSh->Load(sx, py) * keep);
         }
 }
 

@@ -18,8 +18,6 @@ constexpr int TILE_X = 32;
 constexpr int TILE_Y = 8;
 
 static const char* CheckSupportedHistory(const ReblurCB& c) {
-    if (c.gDiffCheckerboard != 2 || c.gSpecCheckerboard != 2)
-        return "REBLUR: checkerboard modes are not implemented in the HIP back-end yet";
     if (c.gRectOrigin.x != 0 || c.gRectOrigin.y != 0 || c.gResolutionScale.x != 1.0f || c.gResolutionScale.y != 1.0f || c.gResolutionScalePrev.x != 1.0f || c.gResolutionScalePrev.y != 1.0f)
         return "REBLUR: dynamic resolution (rect != resource) is not implemented in the HIP back-end yet";
     if (c.gOrthoMode != 0.0f)

@@ -64,6 +64,9 @@ struct SpatialCtx {
     float3 N, Nv, Xv, Vv;
     float4 rotator;
     float2 data1;
+    // checkerboard resolve of the pre-pass (reference REBLUR_PrePass.hlsli:43-56): neighbour columns in the half-width input + their weights
+    int cbX0, cbX1;
+    float2 wc;
 };
 
 // PERF = REBLUR_PERFORMANCE_MODE (reference REBLUR_Config.hlsli:196-238): 6 taps of g_Special6 instead of 8 of g_Special8, and
@@ -77,16 +80,15 @@ NRD_D float PoissonGaussianWeight(int n) { // = GetGaussianWeight( offset.z ), b
 
 // OCC = occlusion family: the signal is the hit distance alone (REBLUR_TYPE float, R16_UNORM planes)
 // SH = the *_SH denoisers: an SH1 plane (RGBA16F) rides on the same taps and weights (diffuse: all 4 components, specular: .xyz only)
-template <SpatialMode MODE, bool PERF, int KIND, bool SH>
-NRD_D typename ReblurSignal<KIND>::type DiffuseSpatialFilter(const ReblurCB& c, const SpatialCtx& s, typename ReblurSignal<KIND>::type diff, const Plane& gIn_Diff, const Plane& gIn_ViewZ,
-    const Plane& gIn_Normal_Roughness, float4& diffSh, const Plane& gIn_DiffSh) {
+// CB = a checkerboard mode is on (pre-pass only): the noisy inputs live in the left half of their planes, a tap that lands on a pixel
+// without data moves one pixel sideways, and pixels the taps could not fill are resolved from the two horizontal neighbours
+template <SpatialMode MODE, bool PERF, int KIND, bool SH, bool CB>
+NRD_D typename ReblurSignal<KIND>::type DiffuseSpatialFilterTaps(const ReblurCB& c, const SpatialCtx& s, typename ReblurSignal<KIND>::type diff, const Plane& gIn_Diff, const Plane& gIn_ViewZ,
+    const Plane& gIn_Normal_Roughness, float4& diffSh, const Plane& gIn_DiffSh, float& sum) {
     typedef ReblurSignal<KIND> Sig;
     constexpr bool OCC = KIND == SIGNAL_OCCLUSION;
     typedef typename Sig::type S;
-    if (MODE == PRE_BLUR && c.gDiffPrepassBlurRadius == 0.0f)
-        return diff;
 
-    float sum = 1.0f;
     float fractionScale = 1.0f, radiusScale = 1.0f;
     if (MODE == PRE_BLUR)
         fractionScale = REBLUR_PRE_BLUR_FRACTION_SCALE;
@@ -141,11 +143,16 @@ NRD_D typename ReblurSignal<KIND>::type DiffuseSpatialFilter(const ReblurCB& c, 
         float3 offset = PERF ? F3(g_Special6[n][0], g_Special6[n][1], g_Special6[n][2]) : F3(g_Special8[n][0], g_Special8[n][1], g_Special8[n][2]);
         float2 uv = s.pixelUv + RotateVector(scaledRotator, F2(offset.x, offset.y));
         uv = Floor(uv * rectSize) + 0.5f;
+        if (MODE == PRE_BLUR && CB)
+            uv = ApplyCheckerboardShift(uv, c.gDiffCheckerboard, (uint32_t)n, c.gFrameIndex);
         uv = uv * rectSizeInv;
         float2 uvScaled = F2(Min(uv.x * resolutionScale.x, uvMax.x), Min(uv.y * resolutionScale.y, uvMax.y));
 
         // all planes of a pass have the resource size (checked by the executor): one texel index serves the three fetches
         const int2 tz = NearestTexel(gIn_ViewZ, uvScaled);
+        int2 ts = tz; // texel of the signal planes
+        if (MODE == PRE_BLUR && CB && c.gDiffCheckerboard != 2)
+            ts = NearestTexel(gIn_Diff, F2(uvScaled.x * 0.5f, uvScaled.y));
         float zs = UnpackViewZ(c, LoadR32F(gIn_ViewZ, tz.x, tz.y));
         float materialIDs;
         float4 Ns = LoadDecodedNormalRoughness(gIn_Normal_Roughness, tz.x, tz.y, materialIDs);
@@ -158,7 +165,7 @@ NRD_D typename ReblurSignal<KIND>::type DiffuseSpatialFilter(const ReblurCB& c, 
         w *= CompareMaterials(s.materialID, materialIDs, c.gDiffMinMaterial) ? 1.0f : 0.0f;
         w *= ComputeWeight(angle, normalWeightParam, 0.0f);
 
-        S smp = Sig::Load(gIn_Diff, tz.x, tz.y);
+        S smp = Sig::Load(gIn_Diff, ts.x, ts.y);
         smp = Select(w == 0.0f, Sig::Zero(), smp);
 
         w *= Lerp(minHitDistWeight, 1.0f, ComputeExponentialWeight(ExtractHitDist(smp), hitDistanceWeightParams.x, hitDistanceWeightParams.y));
@@ -167,7 +174,7 @@ NRD_D typename ReblurSignal<KIND>::type DiffuseSpatialFilter(const ReblurCB& c, 
         sum += w;
         diff = diff + smp * w;
         if (SH) {
-            float4 sh = LoadRGBA16F(gIn_DiffSh, tz.x, tz.y);
+            float4 sh = LoadRGBA16F(gIn_DiffSh, ts.x, ts.y);
             sh = Select(w == 0.0f, F4(0.0f), sh);
             diffSh = diffSh + sh * w;
         }
@@ -179,21 +186,39 @@ NRD_D typename ReblurSignal<KIND>::type DiffuseSpatialFilter(const ReblurCB& c, 
     return diff * invSum;
 }
 
-template <SpatialMode MODE, bool PERF, int KIND, bool SH>
-NRD_D typename ReblurSignal<KIND>::type SpecularSpatialFilter(const ReblurCB& c, const SpatialCtx& s, typename ReblurSignal<KIND>::type spec, const Plane& gIn_Spec, const Plane& gIn_ViewZ,
-    const Plane& gIn_Normal_Roughness, const Plane& gOut_SpecHitDistForTracking, float4& specSh, const Plane& gIn_SpecSh) {
+// "sum" = 1 when the centre pixel carries data, 0 for the empty pixels of a checkerboarded input
+template <SpatialMode MODE, bool PERF, int KIND, bool SH, bool CB>
+NRD_D typename ReblurSignal<KIND>::type DiffuseSpatialFilter(const ReblurCB& c, const SpatialCtx& s, typename ReblurSignal<KIND>::type diff, const Plane& gIn_Diff, const Plane& gIn_ViewZ,
+    const Plane& gIn_Normal_Roughness, float4& diffSh, const Plane& gIn_DiffSh, float sum) {
+    typedef ReblurSignal<KIND> Sig;
+    typedef typename Sig::type S;
+    if (!(MODE == PRE_BLUR && c.gDiffPrepassBlurRadius == 0.0f))
+        diff = DiffuseSpatialFilterTaps<MODE, PERF, KIND, SH, CB>(c, s, diff, gIn_Diff, gIn_ViewZ, gIn_Normal_Roughness, diffSh, gIn_DiffSh, sum);
+    if (MODE == PRE_BLUR && CB && sum == 0.0f) { // reference REBLUR_Common_DiffuseSpatialFilter.hlsli:177-199
+        S s0 = Select(s.wc.x == 0.0f, Sig::Zero(), Sig::Load(gIn_Diff, s.cbX0, s.py));
+        S s1 = Select(s.wc.y == 0.0f, Sig::Zero(), Sig::Load(gIn_Diff, s.cbX1, s.py));
+        diff = s0 * s.wc.x + s1 * s.wc.y;
+        if (SH) {
+            float4 sh0 = Select(s.wc.x == 0.0f, F4(0.0f), LoadRGBA16F(gIn_DiffSh, s.cbX0, s.py));
+            float4 sh1 = Select(s.wc.y == 0.0f, F4(0.0f), LoadRGBA16F(gIn_DiffSh, s.cbX1, s.py));
+            diffSh = sh0 * s.wc.x + sh1 * s.wc.y;
+        }
+    }
+    return diff;
+}
+
+template <SpatialMode MODE, bool PERF, int KIND, bool SH, bool CB>
+NRD_D typename ReblurSignal<KIND>::type SpecularSpatialFilterTaps(const ReblurCB& c, const SpatialCtx& s, typename ReblurSignal<KIND>::type spec, const Plane& gIn_Spec, const Plane& gIn_ViewZ,
+    const Plane& gIn_Normal_Roughness, const Plane& gOut_SpecHitDistForTracking, float4& specSh, const Plane& gIn_SpecSh, float& sum) {
     typedef ReblurSignal<KIND> Sig;
     constexpr bool OCC = KIND == SIGNAL_OCCLUSION;
     typedef typename Sig::type S;
     float smc = GetSpecMagicCurve(s.roughness);
-    if (MODE == PRE_BLUR && c.gSpecPrepassBlurRadius == 0.0f)
-        return spec;
 
     RngHash rng;
     if (MODE == PRE_BLUR)
         rng.Initialize((uint32_t)s.px, (uint32_t)s.py, c.gFrameIndex);
 
-    float sum = 1.0f;
     float fractionScale = 1.0f, radiusScale = 1.0f;
     if (MODE == PRE_BLUR)
         fractionScale = REBLUR_PRE_BLUR_FRACTION_SCALE;
@@ -276,11 +301,16 @@ NRD_D typename ReblurSignal<KIND>::type SpecularSpatialFilter(const ReblurCB& c,
             uv = GetKernelSampleCoordinates(c.gViewToClip, offset, s.Xv, T, B, s.rotator);
 
         uv = Floor(uv * rectSize) + 0.5f;
+        if (MODE == PRE_BLUR && CB)
+            uv = ApplyCheckerboardShift(uv, c.gSpecCheckerboard, (uint32_t)n, c.gFrameIndex);
         uv = uv * rectSizeInv;
         float2 uvScaled = F2(Min(uv.x * resolutionScale.x, uvMax.x), Min(uv.y * resolutionScale.y, uvMax.y));
 
         // all planes of a pass have the resource size (checked by the executor): one texel index serves the three fetches
         const int2 tz = NearestTexel(gIn_ViewZ, uvScaled);
+        int2 ts = tz; // texel of the signal planes
+        if (MODE == PRE_BLUR && CB && c.gSpecCheckerboard != 2)
+            ts = NearestTexel(gIn_Spec, F2(uvScaled.x * 0.5f, uvScaled.y));
         float zs = UnpackViewZ(c, LoadR32F(gIn_ViewZ, tz.x, tz.y));
         float materialIDs;
         float4 Ns = LoadDecodedNormalRoughness(gIn_Normal_Roughness, tz.x, tz.y, materialIDs);
@@ -294,7 +324,7 @@ NRD_D typename ReblurSignal<KIND>::type SpecularSpatialFilter(const ReblurCB& c,
         w *= ComputeWeight(angle, normalWeightParam, 0.0f);
         w *= ComputeWeight(Ns.w, roughnessWeightParams.x, roughnessWeightParams.y);
 
-        S smp = Sig::Load(gIn_Spec, tz.x, tz.y);
+        S smp = Sig::Load(gIn_Spec, ts.x, ts.y);
         smp = Select(w == 0.0f, Sig::Zero(), smp);
 
         if (MODE == PRE_BLUR) {
@@ -315,7 +345,7 @@ NRD_D typename ReblurSignal<KIND>::type SpecularSpatialFilter(const ReblurCB& c,
         sum += w;
         spec = spec + smp * w;
         if (SH) {
-            float4 sh = LoadRGBA16F(gIn_SpecSh, tz.x, tz.y);
+            float4 sh = LoadRGBA16F(gIn_SpecSh, ts.x, ts.y);
             sh = Select(w == 0.0f, F4(0.0f), sh);
             specSh.x += sh.x * w, specSh.y += sh.y * w, specSh.z += sh.z * w;
         }
@@ -328,6 +358,26 @@ NRD_D typename ReblurSignal<KIND>::type SpecularSpatialFilter(const ReblurCB& c,
 
     if (MODE == PRE_BLUR)
         StoreR16F(gOut_SpecHitDistForTracking, s.px, s.py, hitDistForTracking == NRD_INF ? 0.0f : hitDistForTracking);
+    return spec;
+}
+
+template <SpatialMode MODE, bool PERF, int KIND, bool SH, bool CB>
+NRD_D typename ReblurSignal<KIND>::type SpecularSpatialFilter(const ReblurCB& c, const SpatialCtx& s, typename ReblurSignal<KIND>::type spec, const Plane& gIn_Spec, const Plane& gIn_ViewZ,
+    const Plane& gIn_Normal_Roughness, const Plane& gOut_SpecHitDistForTracking, float4& specSh, const Plane& gIn_SpecSh, float sum) {
+    typedef ReblurSignal<KIND> Sig;
+    typedef typename Sig::type S;
+    if (!(MODE == PRE_BLUR && c.gSpecPrepassBlurRadius == 0.0f))
+        spec = SpecularSpatialFilterTaps<MODE, PERF, KIND, SH, CB>(c, s, spec, gIn_Spec, gIn_ViewZ, gIn_Normal_Roughness, gOut_SpecHitDistForTracking, specSh, gIn_SpecSh, sum);
+    if (MODE == PRE_BLUR && CB && sum == 0.0f) { // reference REBLUR_Common_SpecularSpatialFilter.hlsli:224-246 (all 4 SH components here)
+        S s0 = Select(s.wc.x == 0.0f, Sig::Zero(), Sig::Load(gIn_Spec, s.cbX0, s.py));
+        S s1 = Select(s.wc.y == 0.0f, Sig::Zero(), Sig::Load(gIn_Spec, s.cbX1, s.py));
+        spec = s0 * s.wc.x + s1 * s.wc.y;
+        if (SH) {
+            float4 sh0 = Select(s.wc.x == 0.0f, F4(0.0f), LoadRGBA16F(gIn_SpecSh, s.cbX0, s.py));
+            float4 sh1 = Select(s.wc.y == 0.0f, F4(0.0f), LoadRGBA16F(gIn_SpecSh, s.cbX1, s.py));
+            specSh = sh0 * s.wc.x + sh1 * s.wc.y;
+        }
+    }
     return spec;
 }
 
@@ -364,7 +414,7 @@ struct SpatialPlanes {
     Plane inDiffSh, inSpecSh, outDiffSh, outSpecSh, outDiffShCopy, outSpecShCopy; // SH family
 };
 
-template <SpatialMode MODE, bool DIFF, bool SPEC, bool NO_TS, bool PERF, int KIND, bool SH>
+template <SpatialMode MODE, bool DIFF, bool SPEC, bool NO_TS, bool PERF, int KIND, bool SH, bool CB>
 __global__ __launch_bounds__(TILE_X* TILE_Y) void ReblurSpatialKernel(ReblurCB c, SpatialPlanes P, RowRange rr) {
     typedef ReblurSignal<KIND> Sig;
     constexpr bool OCC = KIND == SIGNAL_OCCLUSION;
@@ -388,6 +438,20 @@ __global__ __launch_bounds__(TILE_X* TILE_Y) void ReblurSpatialKernel(ReblurCB c
     if (MODE != PRE_BLUR)
         s.data1 = LoadData1<DIFF, SPEC>(P.data1, px, py);
 
+    uint32_t checkerboard = 0;
+    if (MODE == PRE_BLUR && CB) { // checkerboard resolve weights (reference REBLUR_PrePass.hlsli:43-56)
+        checkerboard = CheckerBoard((uint32_t)px, (uint32_t)py, c.gFrameIndex);
+        const int x0 = px > 0 ? px - 1 : 0, x1 = px < c.gRectSizeMinusOne.x ? px + 1 : c.gRectSizeMinusOne.x;
+        const float viewZ0 = UnpackViewZ(c, LoadR32F(P.viewZ, x0, py)), viewZ1 = UnpackViewZ(c, LoadR32F(P.viewZ, x1, py));
+        const float thr = GetDisocclusionThreshold(NRD_DISOCCLUSION_THRESHOLD, s.frustumSize, s.NoV);
+        float2 wc = F2(thr >= Abs(viewZ0 - s.viewZ) ? 1.0f : 0.0f, thr >= Abs(viewZ1 - s.viewZ) ? 1.0f : 0.0f);
+        wc.x = (viewZ0 > c.gDenoisingRange || px < 1) ? 0.0f : wc.x;
+        wc.y = (viewZ1 > c.gDenoisingRange || px >= c.gRectSizeMinusOne.x) ? 0.0f : wc.y;
+        s.wc = wc * PositiveRcp(wc.x + wc.y);
+        s.cbX0 = x0 >> 1;
+        s.cbX1 = x1 >> 1;
+    }
+
     if (MODE == POST_BLUR) {
         StoreR32U(P.outNormalRoughness, px, py, LoadR32U(P.normalRoughness, px, py)); // packed texel copied verbatim
         if (NO_TS)
@@ -395,11 +459,18 @@ __global__ __launch_bounds__(TILE_X* TILE_Y) void ReblurSpatialKernel(ReblurCB c
     }
 
     if (DIFF) {
-        S diff = Sig::Load(P.inDiff, px, py);
+        const int pos = (MODE == PRE_BLUR && CB && c.gDiffCheckerboard != 2) ? px >> 1 : px;
+        float sum = 1.0f;
+        S diff = Sig::Load(P.inDiff, pos, py);
         float4 diffSh = F4(0.0f);
         if (SH)
-            diffSh = LoadRGBA16F(P.inDiffSh, px, py);
-        diff = DiffuseSpatialFilter<MODE, PERF, KIND, SH>(c, s, diff, P.inDiff, P.viewZ, P.decodedNR, diffSh, P.inDiffSh);
+            diffSh = LoadRGBA16F(P.inDiffSh, pos, py);
+        if (MODE == PRE_BLUR && CB && c.gDiffCheckerboard != 2 && checkerboard != c.gDiffCheckerboard) {
+            sum = 0.0f;
+            diff = Sig::Zero();
+            diffSh = F4(0.0f);
+        }
+        diff = DiffuseSpatialFilter<MODE, PERF, KIND, SH, CB>(c, s, diff, P.inDiff, P.viewZ, P.decodedNR, diffSh, P.inDiffSh, sum);
         Sig::Store(P.outDiff, px, py, diff);
         if (SH)
             StoreRGBA16F(P.outDiffSh, px, py, diffSh);
@@ -409,11 +480,18 @@ __global__ __launch_bounds__(TILE_X* TILE_Y) void ReblurSpatialKernel(ReblurCB c
             StoreRGBA16F(P.outDiffShCopy, px, py, diffSh);
     }
     if (SPEC) {
-        S spec = Sig::Load(P.inSpec, px, py);
+        const int pos = (MODE == PRE_BLUR && CB && c.gSpecCheckerboard != 2) ? px >> 1 : px;
+        float sum = 1.0f;
+        S spec = Sig::Load(P.inSpec, pos, py);
         float4 specSh = F4(0.0f);
         if (SH)
-            specSh = LoadRGBA16F(P.inSpecSh, px, py);
-        spec = SpecularSpatialFilter<MODE, PERF, KIND, SH>(c, s, spec, P.inSpec, P.viewZ, P.decodedNR, P.outHitDistForTracking, specSh, P.inSpecSh);
+            specSh = LoadRGBA16F(P.inSpecSh, pos, py);
+        if (MODE == PRE_BLUR && CB && c.gSpecCheckerboard != 2 && checkerboard != c.gSpecCheckerboard) {
+            sum = 0.0f;
+            spec = Sig::Zero();
+            specSh = F4(0.0f);
+        }
+        spec = SpecularSpatialFilter<MODE, PERF, KIND, SH, CB>(c, s, spec, P.inSpec, P.viewZ, P.decodedNR, P.outHitDistForTracking, specSh, P.inSpecSh, sum);
         Sig::Store(P.outSpec, px, py, spec);
         if (SH)
             StoreRGBA16F(P.outSpecSh, px, py, specSh);
@@ -425,8 +503,6 @@ __global__ __launch_bounds__(TILE_X* TILE_Y) void ReblurSpatialKernel(ReblurCB c
 }
 
 static const char* CheckSupported(const ReblurCB& c) {
-    if (c.gDiffCheckerboard != 2 || c.gSpecCheckerboard != 2)
-        return "REBLUR: checkerboard modes are not implemented in the HIP back-end yet";
     if (c.gRectOrigin.x != 0 || c.gRectOrigin.y != 0 || c.gResolutionScale.x != 1.0f || c.gResolutionScale.y != 1.0f)
         return "REBLUR: dynamic resolution (rect != resource) is not implemented in the HIP back-end yet";
     if (c.gOrthoMode != 0.0f)
@@ -491,7 +567,14 @@ static const char* LaunchSpatial(const PassArgs& a) {
         return "REBLUR spatial pass: unexpected resource count";
 
     RowGrid g = GridForRows(c.gRectSizeMinusOne.x + 1, c.gRectSizeMinusOne.y + 1, TILE_X, TILE_Y, a.rowBegin, a.rowEnd);
-    hipLaunchKernelGGL((ReblurSpatialKernel<MODE, DIFF, SPEC, NO_TS, PERF, KIND, SH>), g.grid, dim3(TILE_X * TILE_Y), 0, a.stream, c, P, RowRange{g.firstBlockY, g.rowBegin, g.rowEnd});
+    const RowRange rows = {g.firstBlockY, g.rowBegin, g.rowEnd};
+    if constexpr (MODE == PRE_BLUR) { // only the pre-pass reads the (possibly checkerboarded) noisy inputs
+        if (c.gDiffCheckerboard != 2 || c.gSpecCheckerboard != 2) {
+            hipLaunchKernelGGL((ReblurSpatialKernel<MODE, DIFF, SPEC, NO_TS, PERF, KIND, SH, true>), g.grid, dim3(TILE_X * TILE_Y), 0, a.stream, c, P, rows);
+            return nullptr;
+        }
+    }
+    hipLaunchKernelGGL((ReblurSpatialKernel<MODE, DIFF, SPEC, NO_TS, PERF, KIND, SH, false>), g.grid, dim3(TILE_X * TILE_Y), 0, a.stream, c, P, rows);
     return nullptr;
 }
 
@@ -511,14 +594,15 @@ __global__ __launch_bounds__(256) void ReblurSplitScreenKernel(ReblurCB c, Plane
     float keep = z < c.gDenoisingRange ? 1.0f : 0.0f;
     typedef ReblurSignal<KIND> Sig;
     constexpr bool OCC = KIND == SIGNAL_OCCLUSION;
+    const int dx = c.gDiffCheckerboard != 2 ? px >> 1 : px, sx = c.gSpecCheckerboard != 2 ? px >> 1 : px; // checkerboarded inputs: left half of the plane
     if (DIFF)
-        Sig::Store(outDiff, px, py, Sig::Load(inDiff, px, py) * keep);
+        Sig::Store(outDiff, px, py, Sig::Load(inDiff, dx, py) * keep);
     if (SPEC)
-        Sig::Store(outSpec, px, py, Sig::Load(inSpec, px, py) * keep);
+        Sig::Store(outSpec, px, py, Sig::Load(inSpec, sx, py) * keep);
     if (DIFF && inDiffSh.ptr) // SH family (uniform branch)
-        StoreRGBA16F(outDiffSh, px, py, LoadRGBA16F(inDiffSh, px, py) * keep);
+        StoreRGBA16F(outDiffSh, px, py, LoadRGBA16F(inDiffSh, dx, py) * keep);
     if (SPEC && inSpecSh.ptr)
-        StoreRGBA16F(outSpecSh, px, py, LoadRGBA16F(inSpecSh, px, py) * keep);
+        StoreRGBA16F(outSpecSh, px, py, LoadRGBA16F(inSpecSh, sx, py) * keep);
 }
 
 template <bool DIFF, bool SPEC, bool SH>

@@ -82,7 +82,8 @@ __global__ __launch_bounds__(TILE_X* TILE_Y, 2) void ReblurTemporalAccumulationK
             int gx = ClampI(baseX + lx, 0, rw), gy = ClampI(baseY + ly, 0, rh);
             s_Normal_Roughness[ly * BUF_STRIDE + lx] = LoadDecodedNormalRoughness(P.decodedNR, gx, gy);
             if (SPEC) {
-                float hitDist = (OCC || cArg.gSpecPrepassBlurRadius == 0.0f) ? ExtractHitDist(Sig::Load(P.inSpec, gx, gy)) : LoadR16F(P.inSpecHitDistForTracking, gx, gy);
+                const int shift = (OCC && cArg.gSpecCheckerboard != 2) ? 1 : 0; // checkerboarded occlusion input: left half (reference REBLUR_TemporalAccumulation.hlsli:21-27)
+                float hitDist = (OCC || cArg.gSpecPrepassBlurRadius == 0.0f) ? ExtractHitDist(Sig::Load(P.inSpec, gx >> shift, gy)) : LoadR16F(P.inSpecHitDistForTracking, gx, gy);
                 s_HitDistForTracking[ly * BUF_STRIDE + lx] = hitDist == 0.0f ? NRD_INF : hitDist;
             }
         }
@@ -295,6 +296,25 @@ __global__ __launch_bounds__(TILE_X* TILE_Y, 2) void ReblurTemporalAccumulationK
     const float2 smbSamplePos = Sat(smbPixelUv) * rectSizePrev;
 
     NRD_CONSTANTS_PHASE();
+    // Checkerboard (reference REBLUR_TemporalAccumulation.hlsli:307-321): pixels without data this frame accumulate slower; only the occlusion
+    // family resolves them here (it has no pre-pass), from the two horizontal neighbours in the half-width input
+    const uint32_t checkerboard = CheckerBoard((uint32_t)px, (uint32_t)py, c.gFrameIndex);
+    const bool diffHasData = c.gDiffCheckerboard == 2 || checkerboard == c.gDiffCheckerboard;
+    const bool specHasData = c.gSpecCheckerboard == 2 || checkerboard == c.gSpecCheckerboard;
+    int cbX0 = 0, cbX1 = 0;
+    float2 wc = F2(0.0f, 0.0f);
+    if (OCC && (c.gDiffCheckerboard != 2 || c.gSpecCheckerboard != 2)) {
+        const int x0 = px > 0 ? px - 1 : 0, x1 = px < c.gRectSizeMinusOne.x ? px + 1 : c.gRectSizeMinusOne.x;
+        const float viewZ0 = UnpackViewZ(c, LoadR32F(P.viewZ, x0, py)), viewZ1 = UnpackViewZ(c, LoadR32F(P.viewZ, x1, py));
+        const float thr = GetDisocclusionThreshold(NRD_DISOCCLUSION_THRESHOLD, frustumSize, NoV);
+        wc = F2(thr >= Abs(viewZ0 - viewZ) ? 1.0f : 0.0f, thr >= Abs(viewZ1 - viewZ) ? 1.0f : 0.0f);
+        wc.x = (viewZ0 > c.gDenoisingRange || px < 1) ? 0.0f : wc.x;
+        wc.y = (viewZ1 > c.gDenoisingRange || px >= c.gRectSizeMinusOne.x) ? 0.0f : wc.y;
+        wc = wc * PositiveRcp(wc.x + wc.y);
+        cbX0 = x0 >> 1;
+        cbX1 = x1 >> 1;
+    }
+
     // ------------------------------------------------------------------------------------------------ diffuse
     // (before the long specular section: everything the diffuse part needs from the shared footprint dies here, not after it)
     if (DIFF) {
@@ -304,7 +324,12 @@ __global__ __launch_bounds__(TILE_X* TILE_Y, 2) void ReblurTemporalAccumulationK
         diffAccumSpeed *= Lerp(diffHistoryConfidence, 1.0f, 1.0f / (1.0f + diffAccumSpeed));
         diffAccumSpeed = Min(diffAccumSpeed, c.gMaxAccumulatedFrameNum);
 
-        S diff = Sig::Load(P.inDiff, px, py);
+        S diff = Sig::Load(P.inDiff, (OCC && c.gDiffCheckerboard != 2) ? px >> 1 : px, py);
+        if (OCC && !diffHasData) {
+            S d0 = Select(wc.x == 0.0f, Sig::Zero(), Sig::Load(P.inDiff, cbX0, py));
+            S d1 = Select(wc.y == 0.0f, Sig::Zero(), Sig::Load(P.inDiff, cbX1, py));
+            diff = d0 * wc.x + d1 * wc.y;
+        }
 
         HistoryFilter smbFilter = MakeHistoryFilter(smbSamplePos, smbOcclusionWeights, smbAllowCatRom, P.historyDiff);
         S smbDiffHistory = Sig::FetchHistory(smbFilter, P.historyDiff);
@@ -312,6 +337,8 @@ __global__ __launch_bounds__(TILE_X* TILE_Y, 2) void ReblurTemporalAccumulationK
         smbDiffHistory = ClampNegativeToZero(smbDiffHistory);
 
         float diffNonLinearAccumSpeed = 1.0f / (1.0f + diffAccumSpeed);
+        if (!diffHasData)
+            diffNonLinearAccumSpeed *= Lerp(1.0f - c.gCheckerboardResolveAccumSpeed, 1.0f, diffNonLinearAccumSpeed);
         S diffResult = MixHistoryAndCurrent(c, smbDiffHistory, diff, diffNonLinearAccumSpeed);
         float4 diffShResult = F4(0.0f);
         if (SH) {
@@ -340,6 +367,8 @@ __global__ __launch_bounds__(TILE_X* TILE_Y, 2) void ReblurTemporalAccumulationK
 
         float diffFastAccumSpeed = Min(diffAccumSpeed, c.gMaxFastAccumulatedFrameNum);
         float diffFastNonLinearAccumSpeed = 1.0f / (1.0f + diffFastAccumSpeed);
+        if (!diffHasData)
+            diffFastNonLinearAccumSpeed *= Lerp(1.0f - c.gCheckerboardResolveAccumSpeed, 1.0f, diffFastNonLinearAccumSpeed);
         float diffFastResult = Lerp(smbDiffFastHistory, GetLuma(diff), diffFastNonLinearAccumSpeed);
         if (KIND == SIGNAL_RADIANCE) {
             float diffFastClamped = Min(diffFastResult, GetLuma(smbDiffHistory) * diffMaxRelativeIntensity * REBLUR_FIREFLY_SUPPRESSOR_FAST_RELATIVE_INTENSITY);
@@ -358,7 +387,12 @@ __global__ __launch_bounds__(TILE_X* TILE_Y, 2) void ReblurTemporalAccumulationK
         smbSpecAccumSpeed *= Lerp(specHistoryConfidence, 1.0f, 1.0f / (1.0f + smbSpecAccumSpeed));
         smbSpecAccumSpeed = Min(smbSpecAccumSpeed, c.gMaxAccumulatedFrameNum);
 
-        S spec = Sig::Load(P.inSpec, px, py);
+        S spec = Sig::Load(P.inSpec, (OCC && c.gSpecCheckerboard != 2) ? px >> 1 : px, py);
+        if (OCC && !specHasData) {
+            S s0 = Select(wc.x == 0.0f, Sig::Zero(), Sig::Load(P.inSpec, cbX0, py));
+            S s1 = Select(wc.y == 0.0f, Sig::Zero(), Sig::Load(P.inSpec, cbX1, py));
+            spec = s0 * wc.x + s1 * wc.y;
+        }
 
         NRD_CONSTANTS_PHASE();
         // Curvature estimation along predicted motion
@@ -638,6 +672,10 @@ __global__ __launch_bounds__(TILE_X* TILE_Y, 2) void ReblurTemporalAccumulationK
 
         float smbSpecNonLinearAccumSpeed = 1.0f / (1.0f + smbSpecAccumSpeed);
         float vmbSpecNonLinearAccumSpeed = 1.0f / (1.0f + vmbSpecAccumSpeed);
+        if (!specHasData) {
+            smbSpecNonLinearAccumSpeed *= Lerp(1.0f - c.gCheckerboardResolveAccumSpeed, 1.0f, smbSpecNonLinearAccumSpeed);
+            vmbSpecNonLinearAccumSpeed *= Lerp(1.0f - c.gCheckerboardResolveAccumSpeed, 1.0f, vmbSpecNonLinearAccumSpeed);
+        }
 
         S smbSpec = MixHistoryAndCurrent(c, smbSpecHistory, spec, smbSpecNonLinearAccumSpeed, roughnessModified);
         S vmbSpec = MixHistoryAndCurrent(c, vmbSpecHistory, spec, vmbSpecNonLinearAccumSpeed, roughnessModified);
@@ -679,8 +717,8 @@ __global__ __launch_bounds__(TILE_X* TILE_Y, 2) void ReblurTemporalAccumulationK
             StoreRGBA16F(P.outSpecSh, px, py, specShResult);
 
         // Fast history
-        float smbSpecFastNonLinearAccumSpeed = GetNonLinearAccumSpeed(smbSpecAccumSpeed, c.gMaxFastAccumulatedFrameNum, surfaceHistoryConfidence);
-        float vmbSpecFastNonLinearAccumSpeed = GetNonLinearAccumSpeed(vmbSpecAccumSpeed, c.gMaxFastAccumulatedFrameNum, virtualHistoryConfidence);
+        float smbSpecFastNonLinearAccumSpeed = GetNonLinearAccumSpeed(c, smbSpecAccumSpeed, c.gMaxFastAccumulatedFrameNum, surfaceHistoryConfidence, specHasData);
+        float vmbSpecFastNonLinearAccumSpeed = GetNonLinearAccumSpeed(c, vmbSpecAccumSpeed, c.gMaxFastAccumulatedFrameNum, virtualHistoryConfidence, specHasData);
         float smbSpecFast = Lerp(smbSpecFastHistory, GetLuma(spec), smbSpecFastNonLinearAccumSpeed);
         float vmbSpecFast = Lerp(vmbSpecFastHistory, GetLuma(spec), vmbSpecFastNonLinearAccumSpeed);
         float specFastResult = Lerp(smbSpecFast, vmbSpecFast, virtualHistoryAmount);
@@ -709,8 +747,6 @@ template <bool DIFF, bool SPEC, bool PERF, int KIND, bool SH>
 static const char* LaunchTemporalAccumulation(const PassArgs& a) {
     constexpr bool OCC = KIND == SIGNAL_OCCLUSION;
     const ReblurCB& c = *(const ReblurCB*)a.constants;
-    if (c.gDiffCheckerboard != 2 || c.gSpecCheckerboard != 2)
-        return "REBLUR: checkerboard modes are not implemented in the HIP back-end yet";
     if (c.gRectOrigin.x != 0 || c.gRectOrigin.y != 0 || c.gResolutionScale.x != 1.0f || c.gResolutionScale.y != 1.0f || c.gResolutionScalePrev.x != 1.0f || c.gResolutionScalePrev.y != 1.0f)
         return "REBLUR: dynamic resolution (rect != resource) is not implemented in the HIP back-end yet";
     if (c.gOrthoMode != 0.0f)

@@ -171,21 +171,29 @@ struct PrePassPlanes {
 
 struct PrePassTap {
     float2 uv;
-    int2 texel; // nearest texel of the guides (and of the signal: same size, no checkerboard)
+    int2 texel;       // nearest texel of the guides
+    int2 signalTexel; // nearest texel of the noisy signal: the same one, or in the left half of the plane for a checkerboarded input
 };
 
-NRD_D PrePassTap MakeTap(const RelaxCB& c, const Plane& guide, float2 pixelUv, float2 rectSize, float4 rotator, int i, float blurRadius) {
+// CB = a checkerboard mode is on (reference RELAX_PrePass.hlsli:29-60, :140-143): a tap that lands on a pixel without data moves one pixel sideways
+template <bool CB>
+NRD_D PrePassTap MakeTap(const RelaxCB& c, const Plane& guide, const Plane& signal, uint32_t checkerboardMode, float2 pixelUv, float2 rectSize, float4 rotator, int i, float blurRadius) {
     PrePassTap t;
     float2 uv = pixelUv * rectSize + RotateVector(rotator, F2(g_Poisson8[i][0], g_Poisson8[i][1])) * blurRadius;
     uv = Floor(uv) + 0.5f;
-    uv = uv * ToF2(c.shared.gRectSizeInv); // ApplyCheckerboardShift is the identity without checkerboarding
+    if (CB)
+        uv = ApplyCheckerboardShift(uv, checkerboardMode, (uint32_t)i, c.shared.gFrameIndex);
+    uv = uv * ToF2(c.shared.gRectSizeInv);
     float2 uvScaled = RelaxClampUvToViewport(c, uv);
     t.uv = uv;
     t.texel = NearestTexel(guide, uvScaled + ToF2(c.shared.gRectOffset));
+    t.signalTexel = t.texel;
+    if (CB)
+        t.signalTexel = NearestTexel(signal, F2(uvScaled.x * (checkerboardMode != 2u ? 0.5f : 1.0f), uvScaled.y));
     return t;
 }
 
-template <bool DIFF, bool SPEC, bool SH>
+template <bool DIFF, bool SPEC, bool SH, bool CB>
 __global__ __launch_bounds__(256) void RelaxPrePassKernel(PrePassPlanes P, RelaxCB c, RowRange rows) {
     const int blockY = blockIdx.y + rows.firstBlockY;
     const int px = blockIdx.x * TILE_X + (threadIdx.x & 31), py = blockY * TILE_Y + (threadIdx.x >> 5);
@@ -208,9 +216,43 @@ __global__ __launch_bounds__(256) void RelaxPrePassKernel(PrePassPlanes P, Relax
     const float2 pixelUv = F2(float(px) + 0.5f, float(py) + 0.5f) * ToF2(c.shared.gRectSizeInv);
     const float minRectDim = float(rectW < rectH ? rectW : rectH);
 
+    // Checkerboard resolve weights (reference RELAX_PrePass.hlsli:29-60)
+    uint32_t checkerboard = 0;
+    int cbx0 = 0, cbx1 = 0;
+    float materialID0 = 0.0f, materialID1 = 0.0f;
+    float2 checkerboardResolveWeights = F2(1.0f, 1.0f);
+    if (CB) {
+        checkerboard = CheckerBoard((uint32_t)px, (uint32_t)py, c.shared.gFrameIndex);
+        cbx0 = px > 0 ? px - 1 : 0;
+        cbx1 = px + 1 < rectW ? px + 1 : rectW - 1;
+        const float viewZ0 = RelaxUnpackViewZ(c, LoadR32F(P.viewZ, cbx0, py)), viewZ1 = RelaxUnpackViewZ(c, LoadR32F(P.viewZ, cbx1, py));
+        LoadDecodedNormalRoughness(P.decodedNR, cbx0, py, materialID0);
+        LoadDecodedNormalRoughness(P.decodedNR, cbx1, py, materialID1);
+        checkerboardResolveWeights = F2(LinearStep(0.03f, 0.0f, Abs(viewZ0 - centerViewZ) * Rcp(Max(viewZ0, centerViewZ))), // GetBilateralWeight
+            LinearStep(0.03f, 0.0f, Abs(viewZ1 - centerViewZ) * Rcp(Max(viewZ1, centerViewZ))));
+        checkerboardResolveWeights.x = (viewZ0 > c.shared.gDenoisingRange || px < 1) ? 0.0f : checkerboardResolveWeights.x;
+        checkerboardResolveWeights.y = (viewZ1 > c.shared.gDenoisingRange || px > rectW - 2) ? 0.0f : checkerboardResolveWeights.y;
+        cbx0 >>= 1;
+        cbx1 >>= 1;
+    }
+
     if (DIFF) {
-        float4 diffuseIllumination = LoadRGBA16F(P.diff.in, px, py);
-        float4 diffuseSH = SH ? LoadRGBA16F(P.diff.inSh, px, py) : F4(0.0f);
+        const bool packed = CB && c.shared.gDiffCheckerboard != 2u;
+        const int dpx = packed ? px >> 1 : px;
+        float4 diffuseIllumination = LoadRGBA16F(P.diff.in, dpx, py);
+        float4 diffuseSH = SH ? LoadRGBA16F(P.diff.inSh, dpx, py) : F4(0.0f);
+        if (packed && checkerboard != c.shared.gDiffCheckerboard) { // no data this frame: resolve from the two horizontal neighbours
+            float2 wc = checkerboardResolveWeights;
+            wc.x *= Cmp(CompareMaterials(centerMaterialID, materialID0, c.shared.gDiffMinMaterial));
+            wc.y *= Cmp(CompareMaterials(centerMaterialID, materialID1, c.shared.gDiffMinMaterial));
+            wc = wc * PositiveRcp(wc.x + wc.y);
+            float4 d0 = Denanify(wc.x, LoadRGBA16F(P.diff.in, cbx0, py)), d1 = Denanify(wc.y, LoadRGBA16F(P.diff.in, cbx1, py));
+            diffuseIllumination = d0 * wc.x + d1 * wc.y;
+            if (SH) {
+                float4 d0SH = Denanify(wc.x, LoadRGBA16F(P.diff.inSh, cbx0, py)), d1SH = Denanify(wc.y, LoadRGBA16F(P.diff.inSh, cbx1, py));
+                diffuseSH = d0SH * wc.x + d1SH * wc.y;
+            }
+        }
 
         if (c.shared.gDiffBlurRadius > 0.0f) {
             float frustumSize = PixelRadiusToWorld(c.shared.gUnproject, c.shared.gOrthoMode, minRectDim, centerViewZ);
@@ -226,7 +268,7 @@ __global__ __launch_bounds__(256) void RelaxPrePassKernel(PrePassPlanes P, Relax
 
 #pragma unroll 2
             for (int i = 0; i < 8; i++) {
-                PrePassTap t = MakeTap(c, P.viewZ, pixelUv, rectSize, rotator, i, blurRadius);
+                PrePassTap t = MakeTap<CB>(c, P.viewZ, P.diff.in, c.shared.gDiffCheckerboard, pixelUv, rectSize, rotator, i, blurRadius);
 
                 float sampleMaterialID;
                 float3 sampleNormal = Xyz(LoadDecodedNormalRoughness(P.decodedNR, t.texel.x, t.texel.y, sampleMaterialID));
@@ -240,14 +282,14 @@ __global__ __launch_bounds__(256) void RelaxPrePassKernel(PrePassPlanes P, Relax
                 float angle = AcosApprox(Dot(centerNormal, sampleNormal));
                 sampleWeight *= ComputeWeight(angle, normalWeightParam, 0.0f);
 
-                float4 sampleDiffuseIllumination = Denanify(sampleWeight, LoadRGBA16F(P.diff.in, t.texel.x, t.texel.y));
+                float4 sampleDiffuseIllumination = Denanify(sampleWeight, LoadRGBA16F(P.diff.in, t.signalTexel.x, t.signalTexel.y));
                 sampleWeight *= Lerp(c.shared.gMinHitDistanceWeight, 1.0f, ComputeExponentialWeight(sampleDiffuseIllumination.w, hitDistanceWeightParams.x, hitDistanceWeightParams.y));
                 sampleWeight *= GetGaussianWeight(g_Poisson8[i][2]);
 
                 weightSum += sampleWeight;
                 diffuseIllumination = diffuseIllumination + sampleDiffuseIllumination * sampleWeight;
                 if (SH) {
-                    float4 sampleDiffuseSH = Denanify(sampleWeight, LoadRGBA16F(P.diff.inSh, t.texel.x, t.texel.y));
+                    float4 sampleDiffuseSH = Denanify(sampleWeight, LoadRGBA16F(P.diff.inSh, t.signalTexel.x, t.signalTexel.y));
                     diffuseSH = diffuseSH + sampleDiffuseSH * sampleWeight;
                 }
             }
@@ -261,8 +303,22 @@ __global__ __launch_bounds__(256) void RelaxPrePassKernel(PrePassPlanes P, Relax
     }
 
     if (SPEC) {
-        float4 specularIllumination = LoadRGBA16F(P.spec.in, px, py);
-        float4 specularSH = SH ? LoadRGBA16F(P.spec.inSh, px, py) : F4(0.0f);
+        const bool packed = CB && c.shared.gSpecCheckerboard != 2u;
+        const int spx = packed ? px >> 1 : px;
+        float4 specularIllumination = LoadRGBA16F(P.spec.in, spx, py);
+        float4 specularSH = SH ? LoadRGBA16F(P.spec.inSh, spx, py) : F4(0.0f);
+        if (packed && checkerboard != c.shared.gSpecCheckerboard) {
+            float2 wc = checkerboardResolveWeights;
+            wc.x *= Cmp(CompareMaterials(centerMaterialID, materialID0, c.shared.gSpecMinMaterial));
+            wc.y *= Cmp(CompareMaterials(centerMaterialID, materialID1, c.shared.gSpecMinMaterial));
+            wc = wc * PositiveRcp(wc.x + wc.y);
+            float4 s0 = Denanify(wc.x, LoadRGBA16F(P.spec.in, cbx0, py)), s1 = Denanify(wc.y, LoadRGBA16F(P.spec.in, cbx1, py));
+            specularIllumination = s0 * wc.x + s1 * wc.y;
+            if (SH) {
+                float4 s0SH = Denanify(wc.x, LoadRGBA16F(P.spec.inSh, cbx0, py)), s1SH = Denanify(wc.y, LoadRGBA16F(P.spec.inSh, cbx1, py));
+                specularSH = s0SH * wc.x + s1SH * wc.y;
+            }
+        }
         specularIllumination.w = Max(0.0f, Min(c.shared.gDenoisingRange, specularIllumination.w));
 
         if (c.shared.gSpecBlurRadius > 0.0f) {
@@ -296,7 +352,7 @@ __global__ __launch_bounds__(256) void RelaxPrePassKernel(PrePassPlanes P, Relax
 
 #pragma unroll 2
             for (int i = 0; i < 8; i++) {
-                PrePassTap t = MakeTap(c, P.viewZ, pixelUv, rectSize, rotator, i, blurRadius);
+                PrePassTap t = MakeTap<CB>(c, P.viewZ, P.spec.in, c.shared.gSpecCheckerboard, pixelUv, rectSize, rotator, i, blurRadius);
 
                 float sampleMaterialID;
                 float4 sampleNormalRoughness = LoadDecodedNormalRoughness(P.decodedNR, t.texel.x, t.texel.y, sampleMaterialID);
@@ -314,7 +370,7 @@ __global__ __launch_bounds__(256) void RelaxPrePassKernel(PrePassPlanes P, Relax
                 float3 sampleWorldPos = GetCurrentWorldPosFromClipSpaceXY(c, t.uv * 2.0f - 1.0f, sampleViewZ);
                 sampleWeight *= GetPlaneDistanceWeight(centerWorldPos, centerNormal, centerViewZ, sampleWorldPos, c.shared.gDepthThreshold);
 
-                float4 sampleSpecularIllumination = Denanify(sampleWeight, LoadRGBA16F(P.spec.in, t.texel.x, t.texel.y));
+                float4 sampleSpecularIllumination = Denanify(sampleWeight, LoadRGBA16F(P.spec.in, t.signalTexel.x, t.signalTexel.y));
                 sampleWeight *= Lerp(specMinHitDistanceWeight, 1.0f, ComputeExponentialWeight(sampleSpecularIllumination.w, hitDistanceWeightParams.x, hitDistanceWeightParams.y));
                 sampleWeight *= GetGaussianWeight(g_Poisson8[i][2]);
 
@@ -326,7 +382,7 @@ __global__ __launch_bounds__(256) void RelaxPrePassKernel(PrePassPlanes P, Relax
                 weightSum += sampleWeight;
                 rgb = rgb + Xyz(sampleSpecularIllumination) * sampleWeight;
                 if (SH) {
-                    float4 sampleSpecularSH = Denanify(sampleWeight, LoadRGBA16F(P.spec.inSh, t.texel.x, t.texel.y));
+                    float4 sampleSpecularSH = Denanify(sampleWeight, LoadRGBA16F(P.spec.inSh, t.signalTexel.x, t.signalTexel.y));
                     specularSH = specularSH + sampleSpecularSH * sampleWeight;
                 }
                 if (sampleWeight != 0.0f)
@@ -365,7 +421,10 @@ const char* LaunchPrePass(const PassArgs& a) {
         return "RELAX PrePass: unexpected resource count or missing decoded normal/roughness cache";
     RelaxCB c = LoadRelaxConstants(a);
     RowGrid g = GridForRows(c.shared.gRectSize.x, c.shared.gRectSize.y, TILE_X, TILE_Y, a.rowBegin, a.rowEnd);
-    hipLaunchKernelGGL((RelaxPrePassKernel<DIFF, SPEC, SH>), g.grid, dim3(256), 0, a.stream, P, c, RowRange{g.firstBlockY, g.rowBegin, g.rowEnd});
+    if ((SPEC && c.shared.gSpecCheckerboard != 2u) || (DIFF && c.shared.gDiffCheckerboard != 2u))
+        hipLaunchKernelGGL((RelaxPrePassKernel<DIFF, SPEC, SH, true>), g.grid, dim3(256), 0, a.stream, P, c, RowRange{g.firstBlockY, g.rowBegin, g.rowEnd});
+    else
+        hipLaunchKernelGGL((RelaxPrePassKernel<DIFF, SPEC, SH, false>), g.grid, dim3(256), 0, a.stream, P, c, RowRange{g.firstBlockY, g.rowBegin, g.rowEnd});
     return nullptr;
 }
 
@@ -628,20 +687,22 @@ __global__ __launch_bounds__(256) void RelaxSplitScreenKernel(SplitScreenPlanes 
     float viewZ = RelaxUnpackViewZ(c, LoadR32F(P.viewZ, px, py));
     float keep = Cmp(viewZ < c.shared.gDenoisingRange);
     if (DIFF) {
-        float4 v = LoadRGBA16F(P.diff.in, px, py);
+        const int cx = c.shared.gDiffCheckerboard != 2u ? px >> 1 : px; // checkerboarded inputs live in the left half of the plane
+        float4 v = LoadRGBA16F(P.diff.in, cx, py);
         if (SH)
             v = F4(LinearToYCoCg(Xyz(v)), v.w);
         StoreRGBA16F(P.diff.out, px, py, v * keep);
         if (SH)
-            StoreRGBA16F(P.diff.outSh, px, py, LoadRGBA16F(P.diff.inSh, px, py) * keep);
+            StoreRGBA16F(P.diff.outSh, px, py, LoadRGBA16F(P.diff.inSh, cx, py) * keep);
     }
     if (SPEC) {
-        float4 v = LoadRGBA16F(P.spec.in, px, py);
+        const int cx = c.shared.gSpecCheckerboard != 2u ? px >> 1 : px;
+        float4 v = LoadRGBA16F(P.spec.in, cx, py);
         if (SH)
             v = F4(LinearToYCoCg(Xyz(v)), v.w);
         StoreRGBA16F(P.spec.out, px, py, v * keep);
         if (SH)
-            StoreRGBA16F(P.spec.outSh, px, py, LoadRGBA16F(P.spec.inSh, px, py) * keep);
+            StoreRGBA16F(P.spec.outSh, px, py, LoadRGBA16F(P.spec.inSh, cx, py) * keep);
     }
 }
 

@@ -290,8 +290,14 @@ __global__ __launch_bounds__(256, 3) void RelaxTemporalAccumulationKernel(RelaxC
             diffMaxFastAccumulatedFrameNum *= inDiffConfidence;
         }
         const float diffHistoryLength = historyLength;
-        const float diffuseAlpha = SMBReprojectionFound > 0.0f ? Max(1.0f / (diffMaxAccumulatedFrameNum + 1.0f), 1.0f / diffHistoryLength) : 1.0f;
-        const float diffuseAlphaResponsive = SMBReprojectionFound > 0.0f ? Max(1.0f / (diffMaxFastAccumulatedFrameNum + 1.0f), 1.0f / diffHistoryLength) : 1.0f;
+        float diffuseAlpha = SMBReprojectionFound > 0.0f ? Max(1.0f / (diffMaxAccumulatedFrameNum + 1.0f), 1.0f / diffHistoryLength) : 1.0f;
+        float diffuseAlphaResponsive = SMBReprojectionFound > 0.0f ? Max(1.0f / (diffMaxFastAccumulatedFrameNum + 1.0f), 1.0f / diffHistoryLength) : 1.0f;
+        // checkerboard: pixels without data this frame (resolved by the pre-pass) accumulate slower (reference RELAX_TemporalAccumulation.hlsli:596-606)
+        const bool diffHasData = c.shared.gDiffCheckerboard == 2u || CheckerBoard((uint32_t)px, (uint32_t)py, c.shared.gFrameIndex) == c.shared.gDiffCheckerboard;
+        if (!diffHasData && diffHistoryLength > 1.0f) {
+            diffuseAlpha *= 1.0f - c.shared.gCheckerboardResolveAccumSpeed;
+            diffuseAlphaResponsive *= 1.0f - c.shared.gCheckerboardResolveAccumSpeed;
+        }
 
         float4 accumulated = Lerp(prevDiffuseIllumAnd2ndMomentSMB, F4(diffuseIllumination, diffuse2ndMoment), diffuseAlpha);
         float3 accumulatedResponsive = Lerp(prevDiffuseResponsiveSMB, diffuseIllumination, diffuseAlphaResponsive);
@@ -513,6 +519,12 @@ __global__ __launch_bounds__(256, 3) void RelaxTemporalAccumulationKernel(RelaxC
         float specSMBResponsiveAlpha = 1.0f - specSMBConfidence;
         specSMBAlpha = Max(specSMBAlpha, 1.0f / (1.0f + specHistoryFrames));
         specSMBResponsiveAlpha = Max(specSMBAlpha, 1.0f / (1.0f + specHistoryResponsiveFrames));
+        // checkerboard (reference RELAX_TemporalAccumulation.hlsli:853-862, :880-887)
+        const bool specHasData = c.shared.gSpecCheckerboard == 2u || CheckerBoard((uint32_t)px, (uint32_t)py, c.shared.gFrameIndex) == c.shared.gSpecCheckerboard;
+        if (!specHasData && smbParallaxInPixelsMax < 0.5f) {
+            specSMBAlpha *= 1.0f - c.shared.gCheckerboardResolveAccumSpeed * (SMBReprojectionFound > 0.0f ? 1.0f : 0.0f);
+            specSMBResponsiveAlpha *= 1.0f - c.shared.gCheckerboardResolveAccumSpeed * (SMBReprojectionFound > 0.0f ? 1.0f : 0.0f);
+        }
 
         const float3 specRgb = Xyz(specularIllumination);
         const float3 accumulatedSpecularSMB = Lerp(Xyz(prevSpecularIllumAnd2ndMomentSMB), specRgb, specSMBAlpha);
@@ -527,6 +539,12 @@ __global__ __launch_bounds__(256, 3) void RelaxTemporalAccumulationKernel(RelaxC
         specVMBAlpha = Max(specVMBAlpha, 1.0f / (1.0f + specHistoryFrames));
         specVMBResponsiveAlpha = Max(specVMBResponsiveAlpha, 1.0f / (1.0f + specHistoryResponsiveFrames));
         specVMBHitTAlpha = Max(specVMBHitTAlpha, 1.0f / (1.0f + specHistoryFrames));
+        if (!specHasData && smbParallaxInPixelsMax < 0.5f) {
+            const float k = 1.0f - c.shared.gCheckerboardResolveAccumSpeed * (VMBReprojectionFound > 0.0f ? 1.0f : 0.0f);
+            specVMBAlpha *= k;
+            specVMBResponsiveAlpha *= k;
+            specVMBHitTAlpha *= k;
+        }
 
         const float3 accumulatedSpecularVMB = Lerp(Xyz(prevSpecularIllumAnd2ndMomentVMB), specRgb, specVMBAlpha);
         const float accumulatedSpecularVMBHitT = Lerp(prevReflectionHitTVMB, specularIllumination.w, Max(specVMBHitTAlpha, 0.1f));

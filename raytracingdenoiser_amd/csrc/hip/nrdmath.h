@@ -244,6 +244,15 @@ NRD_D float3 YCoCgToLinear(float3 c) { // reference NRD.hlsli:365-375
     return F3(Max(t + c.y, 0.0f), Max(c.x + c.z, 0.0f), Max(t - c.y, 0.0f));
 }
 NRD_D uint32_t CheckerBoard(uint32_t x, uint32_t y, uint32_t frameIndex) { return ((x ^ y) ^ frameIndex) & 1u; }
+// reference Common.hlsli:297-307: a tap landing on a pixel without data moves one pixel left / right, alternating with the tap counter
+// ("pos" = a pixel centre; mode 2 = checkerboard off)
+NRD_D float2 ApplyCheckerboardShift(float2 pos, uint32_t mode, uint32_t counter, uint32_t frameIndex) {
+    uint32_t checkerboard = CheckerBoard((uint32_t)(pos.x + 16384.0f), (uint32_t)(pos.y + 16384.0f), frameIndex);
+    float shift = (counter & 1u) == 0 ? -1.0f : 1.0f;
+    pos.x += shift * ((checkerboard != mode && mode != 2u) ? 1.0f : 0.0f);
+    return pos;
+}
+
 NRD_D uint32_t Bayer4x4ui(uint32_t x, uint32_t y, uint32_t frameIndex) {
     x &= 3u;
     y &= 3u;

@@ -212,7 +212,13 @@ NRD_D float GetFadeBasedOnAccumulatedFrames(const ReblurCB& c, float accumSpeed)
     float b = c.gHistoryFixFrameNum * 4.0f / 3.0f + 2e-6f;
     return LinearStep(a, b, accumSpeed);
 }
-NRD_D float GetNonLinearAccumSpeed(float accumSpeed, float maxAccumSpeed, float confidence) { return Max(1.0f - confidence, 1.0f / (1.0f + Min(accumSpeed, maxAccumSpeed))); }
+template <typename CB> // reference REBLUR_Common.hlsli:111-124; hasData = false for the empty pixels of a checkerboarded input
+NRD_D float GetNonLinearAccumSpeed(const CB& c, float accumSpeed, float maxAccumSpeed, float confidence, bool hasData) {
+    float nonLinearAccumSpeed = Max(1.0f - confidence, 1.0f / (1.0f + Min(accumSpeed, maxAccumSpeed)));
+    if (!hasData)
+        nonLinearAccumSpeed *= Lerp(1.0f - c.gCheckerboardResolveAccumSpeed, 1.0f, nonLinearAccumSpeed);
+    return nonLinearAccumSpeed;
+}
 NRD_D float RemapRoughnessToResponsiveFactor(const ReblurCB& c, float roughness) {
     float amount = (roughness + NRD_EPS) / (c.gResponsiveAccumulationRoughnessThreshold + NRD_EPS);
     return SmoothStep01(amount);

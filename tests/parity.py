@@ -59,7 +59,33 @@ def user_planes(name, frame):
     if "diff_confidence" in frame:  # generated with want=(..., "confidence"): optional guides, consumed when CommonSettings enables them
         extra = [(RT.IN_DIFF_CONFIDENCE, frame["diff_confidence"], F.R8_UNORM), (RT.IN_SPEC_CONFIDENCE, frame["spec_confidence"], F.R8_UNORM),
                  (RT.IN_DISOCCLUSION_THRESHOLD_MIX, frame["disocclusion_mix"], F.R8_UNORM)]
-    return _user_planes(name, frame) + extra
+    planes = _user_planes(name, frame)
+    if frame.get("_checkerboard"):  # (CheckerboardMode, frame index): noisy signals traced for every other pixel and packed into the left half
+        mode, frame_index = frame["_checkerboard"]
+        diff_mode, spec_mode = (0, 1) if mode == api.CheckerboardMode.BLACK else (1, 0)  # reference Reblur.cpp / Relax.cpp: BLACK -> diffuse 0, specular 1
+        planes = [(rt, checkerboard_pack(t, diff_mode if rt.name.startswith("IN_DIFF") else spec_mode, frame_index) if rt.name.startswith(("IN_DIFF", "IN_SPEC")) else t, fmt)
+                  for rt, t, fmt in planes]
+    return planes + extra
+
+
+def tag_checkerboard(frame, overrides, frame_index):
+    """marks a generated frame so that user_planes() hands out checkerboarded noisy inputs when the settings ask for them"""
+    mode = (overrides or {}).get("checkerboardMode")
+    frame["_checkerboard"] = (api.CheckerboardMode(mode), frame_index) if mode else None
+
+
+def checkerboard_pack(plane, mode, frame_index):
+    """Checkerboarded noisy input (reference README "checkerboard": the pixels with ((x ^ y) ^ frameIndex) & 1 == mode carry data and are packed into the
+    left half of the plane, column x >> 1). The right half is filled with a sentinel: nothing may read it."""
+    h, w = plane.shape[0], plane.shape[1]
+    y = torch.arange(h, device=plane.device)
+    b = (mode ^ (y & 1) ^ (frame_index & 1)).view(h, 1)  # per row: which pixel of each horizontal pair has data
+    k = torch.arange((w + 1) // 2, device=plane.device).view(1, -1)
+    src = (2 * k + b).clamp(max=w - 1)
+    idx = src.view(h, -1, *([1] * (plane.dim() - 2))).expand(h, src.shape[1], *plane.shape[2:])
+    out = torch.full_like(plane, 17)
+    out[:, : src.shape[1]] = torch.gather(plane, 1, idx)
+    return out.contiguous()
 
 
 def _hitdist_unorm16(signal):
@@ -266,6 +292,7 @@ def run_parity(name, width=192, height=128, frames=4, verbose=False, settings_ov
     for f, frame in enumerate(seq):
         cam, cam_prev = frame["camera"], seq[max(f - 1, 0)]["camera"]
         cs = common_settings(cam, cam_prev, width, height, f, **cs_kw)
+        tag_checkerboard(frame, settings_overrides, f)
         st = denoiser_settings(name, frame, settings_overrides)
         ora.step(frame, cs, st)
         hip.step(frame, common_settings(cam, cam_prev, width, height, f, **cs_kw), denoiser_settings(name, frame, settings_overrides))

@@ -16,6 +16,7 @@ def _run_oracle(name, seq, overrides=None, cs_kw=None):
     ora = parity.OracleRun(name, W, H)
     for f, frame in enumerate(seq):
         cs = parity.common_settings(frame["camera"], seq[max(f - 1, 0)]["camera"], W, H, f, **(cs_kw or {}))
+        parity.tag_checkerboard(frame, overrides, f)
         ora.step(frame, cs, parity.denoiser_settings(name, frame, overrides))
     return ora
 
@@ -295,4 +296,51 @@ def test_hip_matches_oracle_directional_occlusion():
     # odd size, reconstruction + split screen through the radiance family's pipelines, no stabilisation, performance mode
     worst = parity.run_parity(name, width=211, height=117, frames=4, verbose=True, extra_want=("holes",), cs_kw=dict(splitScreen=0.3),
                               settings_overrides=dict(hitDistanceReconstructionMode=1, maxStabilizedFrameNum=0, enablePerformanceMode=True))
+    assert worst <= parity.REL_TOL
+
+
+# ---------------------------------------------------------------------------------------------------- checkerboard modes
+def test_oracle_checkerboard_resolves_half_rate_inputs():
+    """CheckerboardMode BLACK / WHITE (reference NRDSettings.h CheckerboardMode, REBLUR_PrePass.hlsli:43-108): only every other pixel of the noisy
+    inputs is traced, packed into the left half of the plane. The pre-pass stays in the chain even with zero radii (reference Reblur.cpp:127-129),
+    nothing reads the unused right half (filled with a sentinel), and the result stays close to the full-rate one."""
+    name = "REBLUR_DIFFUSE_SPECULAR"
+    seq = parity.generate_sequence(name, W, H, 6)
+    full = _run_oracle(name, seq)
+    m = ~seq[-1]["is_sky"].numpy()
+    for mode in (api.CheckerboardMode.BLACK, api.CheckerboardMode.WHITE):
+        for radii in (None, dict(diffusePrepassBlurRadius=0.0, specularPrepassBlurRadius=0.0)):
+            ora = _run_oracle(name, seq, dict(checkerboardMode=int(mode), **(radii or {})))
+            assert "REBLUR_DiffuseSpecular_PrePass.cs" in [d.shader for d in ora.last_dispatches]
+            for rt in (RT.OUT_DIFF_RADIANCE_HITDIST, RT.OUT_SPEC_RADIANCE_HITDIST):
+                out, ref = ora.output(rt), full.output(rt)
+                assert not np.isnan(out).any() and out.max() < 8.0  # the sentinel is 17
+                assert np.abs(out[m] - ref[m]).mean() < 0.12 * np.abs(ref[m]).mean()
+    # split screen: the passthrough reads the packed column x >> 1
+    ora = _run_oracle(name, seq[:1], dict(checkerboardMode=1), cs_kw=dict(splitScreen=1.0))
+    packed = parity.checkerboard_pack(seq[0]["diff"], 0, 0).float().numpy()
+    out = ora.output(RT.OUT_DIFF_RADIANCE_HITDIST)
+    x = np.arange(W)
+    keep = (seq[0]["viewz"].numpy() < 5e5)[..., None]
+    assert np.array_equal(out, packed[:, x >> 1] * keep)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name,mode,overrides", [
+    ("REBLUR_DIFFUSE_SPECULAR", 1, None),
+    ("REBLUR_DIFFUSE_SPECULAR", 2, dict(diffusePrepassBlurRadius=0.0, specularPrepassBlurRadius=0.0)),  # resolve-only pre-pass
+    ("REBLUR_SPECULAR", 2, dict(enablePerformanceMode=True)),
+    ("REBLUR_DIFFUSE_SPECULAR_SH", 1, None),
+    ("REBLUR_DIFFUSE_SPECULAR_OCCLUSION", 1, None),   # no pre-pass: resolved inside temporal accumulation
+    ("REBLUR_SPECULAR_OCCLUSION", 2, None),
+    ("REBLUR_DIFFUSE_DIRECTIONAL_OCCLUSION", 2, None),
+])
+def test_hip_matches_oracle_checkerboard(name, mode, overrides):
+    worst = parity.run_parity(name, width=178, height=101, frames=5, verbose=True, settings_overrides=dict(checkerboardMode=mode, **(overrides or {})))
+    assert worst <= parity.REL_TOL
+
+
+@pytest.mark.gpu
+def test_hip_matches_oracle_checkerboard_split_screen():
+    worst = parity.run_parity("REBLUR_DIFFUSE_SPECULAR", width=160, height=96, frames=3, verbose=True, settings_overrides=dict(checkerboardMode=1), cs_kw=dict(splitScreen=0.5))
     assert worst <= parity.REL_TOL

@@ -18,6 +18,7 @@ def _run_oracle(name, seq, overrides=None, cs_kw=None, width=W, height=H):
     ora = parity.OracleRun(name, width, height)
     for f, frame in enumerate(seq):
         cs = parity.common_settings(frame["camera"], seq[max(f - 1, 0)]["camera"], width, height, f, **(cs_kw or {}))
+        parity.tag_checkerboard(frame, overrides, f)
         ora.step(frame, cs, parity.denoiser_settings(name, frame, overrides))
     return ora
 
@@ -236,4 +237,38 @@ def test_hip_matches_oracle_no_prepass_no_roughness_edge_stopping():
     worst = parity.run_parity("RELAX_DIFFUSE_SPECULAR", width=160, height=96, frames=4, verbose=True,
                               settings_overrides=dict(diffusePrepassBlurRadius=0.0, specularPrepassBlurRadius=0.0, enableRoughnessEdgeStopping=False, historyFixFrameNum=0,
                                                       spatialVarianceEstimationHistoryThreshold=0))
+    assert worst <= parity.REL_TOL
+
+
+# ---------------------------------------------------------------------------------------------------- checkerboard modes
+def test_oracle_checkerboard_resolves_half_rate_inputs():
+    """RelaxSettings::checkerboardMode (reference RELAX_PrePass.hlsli:29-60, RELAX_TemporalAccumulation.hlsli:577-606): every other pixel of the noisy
+    inputs is traced and packed into the left half of the plane; the unused right half (a sentinel here) is never read."""
+    name = "RELAX_DIFFUSE_SPECULAR"
+    seq = parity.generate_sequence(name, W, H, 6)
+    full = _run_oracle(name, seq)
+    m = ~seq[-1]["is_sky"].numpy()
+    for mode in (api.CheckerboardMode.BLACK, api.CheckerboardMode.WHITE):
+        ora = _run_oracle(name, seq, dict(checkerboardMode=int(mode)))
+        for rt in (RT.OUT_DIFF_RADIANCE_HITDIST, RT.OUT_SPEC_RADIANCE_HITDIST):
+            out, ref = ora.output(rt), full.output(rt)
+            assert not np.isnan(out).any() and out[..., :3].max() < 8.0  # the sentinel is 17
+            assert np.abs(out[m][:, :3] - ref[m][:, :3]).mean() < 0.15 * np.abs(ref[m][:, :3]).mean()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name,mode,overrides", [
+    ("RELAX_DIFFUSE_SPECULAR", 1, None),
+    ("RELAX_DIFFUSE_SPECULAR_SH", 2, None),
+    ("RELAX_SPECULAR", 1, dict(diffusePrepassBlurRadius=0.0, specularPrepassBlurRadius=0.0)),  # resolve-only pre-pass
+    ("RELAX_DIFFUSE_SH", 2, None),
+])
+def test_hip_matches_oracle_checkerboard(name, mode, overrides):
+    worst = parity.run_parity(name, width=178, height=101, frames=5, verbose=True, settings_overrides=dict(checkerboardMode=mode, **(overrides or {})))
+    assert worst <= parity.REL_TOL
+
+
+@pytest.mark.gpu
+def test_hip_matches_oracle_checkerboard_split_screen():
+    worst = parity.run_parity("RELAX_DIFFUSE_SPECULAR_SH", width=160, height=96, frames=3, verbose=True, settings_overrides=dict(checkerboardMode=2), cs_kw=dict(splitScreen=0.5))
     assert worst <= parity.REL_TOL
