@@ -52,7 +52,7 @@ uint32_t nrdHipCreateExecutorWithArena(void* instance, uint16_t resourceWidth, u
 // Formats accepted in this build (anything else -> UNSUPPORTED):
 //   IN_MV RGBA16_SFLOAT | IN_NORMAL_ROUGHNESS R10_G10_B10_A2_UNORM | IN_VIEWZ R32_SFLOAT
 //   IN/OUT_{DIFF,SPEC}_RADIANCE_HITDIST RGBA16_SFLOAT | IN/OUT_{DIFF,SPEC}_SH0, _SH1 RGBA16_SFLOAT (REBLUR / RELAX SH variants)
-//   IN/OUT_{DIFF,SPEC}_HITDIST R16_UNORM (REBLUR occlusion family) | IN/OUT_DIFF_DIRECTION_HITDIST RGBA16_SNORM | IN_PENUMBRA R16_SFLOAT | IN_TRANSLUCENCY RGBA8_UNORM
+//   IN/OUT_{DIFF,SPEC}_HITDIST R16_UNORM (REBLUR occlusion family) | IN/OUT_DIFF_DIRECTION_HITDIST RGBA16_SNORM | IN_PENUMBRA R16_SFLOAT | IN_TRANSLUCENCY, IN_BASECOLOR_METALNESS RGBA8_UNORM
 //   OUT_SHADOW_TRANSLUCENCY R8_UNORM (SIGMA_SHADOW) or RGBA8_UNORM (an instance holding SIGMA_SHADOW_TRANSLUCENCY)
 //   IN_SIGNAL / OUT_SIGNAL RGBA32_SFLOAT | IN_{DIFF,SPEC}_CONFIDENCE, IN_DISOCCLUSION_THRESHOLD_MIX R8_UNORM
 // include/NRD.hip.h has the device functions that produce / consume these encodings (the NRD.hlsli front-end and back-end).

@@ -84,6 +84,27 @@ inline void GetBasis(float3 N, float3& T, float3& B) {
 // ================================================================================================ [ml] Color / Sequence / Rng
 namespace Color {
 inline float Luminance(float3 c) { return c.x * 0.2126f + c.y * 0.7152f + c.z * 0.0722f; } // [nrd] NRD.hlsli:350-354
+// BRDF::ConvertBaseColorMetalnessToAlbedoRf0 [ml, restated: dielectric Rf0 = 0.04] and BRDF::EnvironmentTerm_Rtg [nrd] NRD.hlsli:490-517 (anchor:
+// "Ray Tracing Gems" ch. 32 eq. 4); matrix rows are evaluated left to right, rcp is an exact division
+inline void ConvertBaseColorMetalnessToAlbedoRf0(float3 baseColor, float metalness, float3& albedo, float3& Rf0) {
+    float k = fminf(fmaxf(1.0f - metalness, 0.0f), 1.0f);
+    albedo = float3(baseColor.x * k, baseColor.y * k, baseColor.z * k);
+    Rf0 = float3(0.04f + (baseColor.x - 0.04f) * metalness, 0.04f + (baseColor.y - 0.04f) * metalness, 0.04f + (baseColor.z - 0.04f) * metalness);
+}
+inline float3 EnvironmentTerm_Rtg(float3 Rf0, float NoV, float roughness) {
+    float m = fminf(fmaxf(roughness * roughness, 0.0f), 1.0f);
+    float x1 = NoV, x2 = NoV * NoV, x3 = NoV * x2;
+    float y1 = m, y2 = m * m, y3 = m * y2;
+    float biasNum = (0.99044f + -1.28514f * x1) + (1.29678f + -0.755907f * x1) * y1;
+    float biasDen = (1.0f + 2.92338f * x1 + 59.4188f * x3) + (20.3225f + -27.0302f * x1 + 222.592f * x3) * y1 + (121.563f + 626.13f * x1 + 316.627f * x3) * y3;
+    float scaleNum = (0.0365463f + 3.32707f * x1) + (9.0632f + -9.04756f * x1) * y1;
+    float scaleDen = (1.0f + 3.59685f * x2 + -1.36772f * x3) + (9.04401f + -16.3174f * x2 + 9.22949f * x3) * y1 + (5.56589f + 19.7886f * x2 + -20.2123f * x3) * y3;
+    float bias = biasNum * (1.0f / fmaxf(biasDen, 1e-6f));
+    float scale = scaleNum * (1.0f / fmaxf(scaleDen, 1e-6f));
+    (void)y2;
+    auto sat = [](float v) { return fminf(fmaxf(v, 0.0f), 1.0f); };
+    return float3(sat(Rf0.x * scale + bias), sat(Rf0.y * scale + bias), sat(Rf0.z * scale + bias));
+}
 inline float Clamp(float m1, float sigma, float x) { return clamp(x, m1 - sigma, m1 + sigma); }
 } // namespace Color
 

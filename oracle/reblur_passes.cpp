@@ -1509,7 +1509,7 @@ void TemporalStabilization(const PassIO& io) {
     Cursor cur(io);
     const Tex& gIn_Tiles = *cur.next();
     const Tex& gIn_Normal_Roughness = *cur.next();
-    cur.nextIf(SPEC); // gIn_BaseColor_Metalness (dummy: MV modification is off without base colour)
+    const Tex* gIn_BaseColor_Metalness = cur.nextIf(SPEC); // a dummy unless CommonSettings::isBaseColorMetalnessAvailable
     const Tex& gIn_ViewZ = *cur.next(); // PREV_VIEWZ (already holds this frame's viewZ)
     const Tex& gIn_Data1 = *cur.next();
     const Tex& gIn_Data2 = *cur.next();
@@ -1520,7 +1520,7 @@ void TemporalStabilization(const PassIO& io) {
     const Tex* gIn_SpecHitDistForTracking = cur.nextIf(SPEC);
     const Tex* gIn_DiffSh = cur.nextIf(DIFF && SH);
     const Tex* gIn_SpecSh = cur.nextIf(SPEC && SH);
-    const Tex& gInOut_Mv = *cur.next();
+    Tex& gInOut_Mv = *cur.next();
     Tex& gOut_InternalData = *cur.next();
     Tex* gOut_Diff = cur.nextIf(DIFF);
     Tex* gOut_Spec = cur.nextIf(SPEC);
@@ -1656,7 +1656,35 @@ void TemporalStabilization(const PassIO& io) {
                 float2 vmbPixelUv = Geometry::GetScreenUv(c.gWorldToClipPrev, Xvirtual);
                 vmbPixelUv = materialID == c.gCameraAttachedReflectionMaterialID ? pixelUv : vmbPixelUv;
 
-                // (MV modification needs IN_BASECOLOR_METALNESS: gSpecProbabilityThresholdsForMvModification.x = 2 disables it)
+                // Modify MVs if requested (REBLUR_TemporalStabilization.hlsli:250-285): where the surface is mostly specular, IN_MV is bent towards
+                // the motion of the reflected world (x = 2 without IN_BASECOLOR_METALNESS: off)
+                if (c.gSpecProbabilityThresholdsForMvModification.x < 1.0f) {
+                    float NoV = fabsf(dot(N, V));
+                    float4 baseColorMetalness = gIn_BaseColor_Metalness->Load((int)c.gRectOrigin[0] + px, (int)c.gRectOrigin[1] + py);
+                    float3 albedo, Rf0;
+                    Color::ConvertBaseColorMetalnessToAlbedoRf0(baseColorMetalness.xyz(), baseColorMetalness.w, albedo, Rf0);
+                    float3 Fenv = Color::EnvironmentTerm_Rtg(Rf0, NoV, roughness);
+                    float lumSpec = Color::Luminance(Fenv);
+                    float lumDiff = Color::Luminance(float3(albedo.x * (1.0f - Fenv.x), albedo.y * (1.0f - Fenv.y), albedo.z * (1.0f - Fenv.z)));
+                    float specProb = lumSpec / (lumDiff + lumSpec + NRD_EPS);
+                    float f = Math::SmoothStep(c.gSpecProbabilityThresholdsForMvModification.x, c.gSpecProbabilityThresholdsForMvModification.y, specProb);
+                    f *= 1.0f - GetSpecMagicCurve(roughness);
+                    f *= 1.0f - Math::Sqrt01(fabsf(curvature));
+                    if (f != 0.0f) {
+                        float3 specMv = Xvirtual - X; // world-space delta
+                        if (c.gMvScale.w == 0.0f) {
+                            specMv.x = vmbPixelUv.x - pixelUv.x;
+                            specMv.y = vmbPixelUv.y - pixelUv.y;
+                            specMv.z = Geometry::AffineTransform(c.gWorldToViewPrev, Xvirtual).z - viewZ;
+                        }
+                        // only .xy for 2D, .xyz for 2.5D and 3D MVs
+                        float3 newMv = float3(specMv.x / c.gMvScale.x, specMv.y / c.gMvScale.y, c.gMvScale.z == 0.0f ? inMv.z : specMv.z / c.gMvScale.z);
+                        inMv.x = lerp(inMv.x, newMv.x, f);
+                        inMv.y = lerp(inMv.y, newMv.y, f);
+                        inMv.z = lerp(inMv.z, newMv.z, f);
+                        gInOut_Mv.Store((int)c.gRectOrigin[0] + px, (int)c.gRectOrigin[1] + py, inMv);
+                    }
+                }
 
                 HistoryFilter smbFilter = MakeHistoryFilter(smbSamplePos, smbOcclusionWeights, smbAllowCatRom);
                 float smbSpecLumaHistory = FetchHistoryColor(smbFilter, *gHistory_SpecLumaStabilized).x;

@@ -20,7 +20,7 @@ using namespace nrdhip;
 
 namespace {
 
-static_assert((uint32_t)nrd::Format::R16_UNORM == FORMAT_R16_UNORM && (uint32_t)nrd::Format::RGBA16_SNORM == FORMAT_RGBA16_SNORM && (uint32_t)nrd::Format::RGBA16_SFLOAT == FORMAT_RGBA16_SFLOAT,
+static_assert((uint32_t)nrd::Format::RGBA8_UNORM == FORMAT_RGBA8_UNORM && (uint32_t)nrd::Format::R16_UNORM == FORMAT_R16_UNORM && (uint32_t)nrd::Format::RGBA16_SNORM == FORMAT_RGBA16_SNORM && (uint32_t)nrd::Format::RGBA16_SFLOAT == FORMAT_RGBA16_SFLOAT,
     "passes.h format constants");
 
 uint32_t BytesPerTexel(nrd::Format f) {
@@ -65,7 +65,7 @@ nrd::Format ExpectedUserFormat(nrd::ResourceType t, bool translucentShadow) {
         case R::IN_DIFF_DIRECTION_HITDIST: case R::OUT_DIFF_DIRECTION_HITDIST: return F::RGBA16_SNORM; // REBLUR_DIFFUSE_DIRECTIONAL_OCCLUSION
         case R::IN_DIFF_HITDIST: case R::IN_SPEC_HITDIST: case R::OUT_DIFF_HITDIST: case R::OUT_SPEC_HITDIST: return F::R16_UNORM; // REBLUR occlusion family
         case R::IN_PENUMBRA: return F::R16_SFLOAT;
-        case R::IN_TRANSLUCENCY: return F::RGBA8_UNORM;
+        case R::IN_TRANSLUCENCY: case R::IN_BASECOLOR_METALNESS: return F::RGBA8_UNORM;
         case R::OUT_SHADOW_TRANSLUCENCY: return translucentShadow ? F::RGBA8_UNORM : F::R8_UNORM;
         case R::IN_SIGNAL: case R::OUT_SIGNAL: return F::RGBA32_SFLOAT;
         default: return F::MAX_NUM;

@@ -319,6 +319,7 @@ struct TsPlanes {
         outSpecLuma;
     Plane inDiffSh, inSpecSh, outDiffSh, outSpecSh; // SH family
     Plane decodedNR;
+    Plane baseColorMetalness; // IN_BASECOLOR_METALNESS (RGBA8_UNORM), only read when the specular MV modification is on
 };
 
 // 3x3 luma statistics from the LDS tile: centre luma (min/max clamped), mean, sigma
@@ -477,6 +478,36 @@ __global__ __launch_bounds__(TILE_X* TILE_Y) void ReblurTemporalStabilizationKer
         float2 vmbPixelUv = GetScreenUv(c.gWorldToClipPrev, Xvirtual);
         vmbPixelUv = Select(materialID == c.gCameraAttachedReflectionMaterialID, pixelUv, vmbPixelUv);
 
+        // Modify MVs if requested (reference REBLUR_TemporalStabilization.hlsli:250-285): where the surface is mostly specular, IN_MV is bent towards
+        // the motion of the reflected world. A uniform branch: x = 2 unless CommonSettings::isBaseColorMetalnessAvailable
+        if (c.gSpecProbabilityThresholdsForMvModification.x < 1.0f) {
+            float NoV = Abs(Dot(N, V));
+            float4 baseColorMetalness = LoadRGBA8Unorm(P.baseColorMetalness, px, py);
+            float3 albedo, Rf0;
+            ConvertBaseColorMetalnessToAlbedoRf0(Xyz(baseColorMetalness), baseColorMetalness.w, albedo, Rf0);
+            float3 Fenv = EnvironmentTerm_Rtg(Rf0, NoV, roughness);
+            float lumSpec = Luminance(Fenv);
+            float lumDiff = Luminance(F3(albedo.x * (1.0f - Fenv.x), albedo.y * (1.0f - Fenv.y), albedo.z * (1.0f - Fenv.z)));
+            float specProb = lumSpec / (lumDiff + lumSpec + NRD_EPS);
+            float f = SmoothStep(c.gSpecProbabilityThresholdsForMvModification.x, c.gSpecProbabilityThresholdsForMvModification.y, specProb);
+            f *= 1.0f - GetSpecMagicCurve(roughness);
+            f *= 1.0f - Sqrt01(Abs(curvature));
+            if (f != 0.0f) {
+                float3 specMv = Xvirtual - X; // world-space delta
+                if (c.gMvScale.w == 0.0f) {
+                    specMv.x = vmbPixelUv.x - pixelUv.x;
+                    specMv.y = vmbPixelUv.y - pixelUv.y;
+                    specMv.z = AffineTransform(c.gWorldToViewPrev, Xvirtual).z - viewZ;
+                }
+                // only .xy for 2D, .xyz for 2.5D and 3D MVs
+                float3 newMv = F3(specMv.x / c.gMvScale.x, specMv.y / c.gMvScale.y, c.gMvScale.z == 0.0f ? inMv.z : specMv.z / c.gMvScale.z);
+                inMv.x = Lerp(inMv.x, newMv.x, f);
+                inMv.y = Lerp(inMv.y, newMv.y, f);
+                inMv.z = Lerp(inMv.z, newMv.z, f);
+                StoreRGBA16F(P.mv, px, py, inMv);
+            }
+        }
+
         HistoryFilter smbFilter = MakeHistoryFilter(smbSamplePos, smbOcclusionWeights, smbAllowCatRom, P.historySpecLuma);
         float smbSpecLumaHistory = FetchHistoryR16F(smbFilter, P.historySpecLuma);
 
@@ -535,8 +566,6 @@ static const char* LaunchTemporalStabilization(const PassArgs& a) {
     const ReblurCB& c = *(const ReblurCB*)a.constants;
     if (const char* err = CheckSupportedHistory(c))
         return err;
-    if (c.gSpecProbabilityThresholdsForMvModification.x < 1.0f)
-        return "REBLUR: specular MV modification (IN_BASECOLOR_METALNESS) is not implemented in the HIP back-end yet";
     TsPlanes P = {};
     uint32_t k = 0;
     P.tiles = a.planes[k++];
@@ -544,7 +573,9 @@ static const char* LaunchTemporalStabilization(const PassArgs& a) {
     P.decodedNR = a.decodedNormalRoughness;
     if (!P.decodedNR.ptr)
         return "REBLUR TemporalStabilization: the decoded normal/roughness cache is missing (IN_NORMAL_ROUGHNESS not bound?)";
-    if (SPEC) k++; // base colour / metalness (dummy)
+    if (SPEC) P.baseColorMetalness = a.planes[k++]; // a dummy unless CommonSettings::isBaseColorMetalnessAvailable
+    if (SPEC && c.gSpecProbabilityThresholdsForMvModification.x < 1.0f && (!P.baseColorMetalness.ptr || a.formats[k - 1] != (uint32_t)FORMAT_RGBA8_UNORM))
+        return "REBLUR TemporalStabilization: IN_BASECOLOR_METALNESS must be bound as RGBA8_UNORM when isBaseColorMetalnessAvailable is set";
     P.viewZ = a.planes[k++];
     P.data1 = a.planes[k++];
     P.data2 = a.planes[k++];

@@ -235,6 +235,25 @@ NRD_D void GetBasis(float3 N, float3& T, float3& B) {
 
 // ------------------------------------------------------------------------------------------------ Color:: / Packing:: / Sequence::
 NRD_D float Luminance(float3 c) { return c.x * 0.2126f + c.y * 0.7152f + c.z * 0.0722f; }
+// MathLib BRDF::ConvertBaseColorMetalnessToAlbedoRf0 (dielectric Rf0 = 0.04) and BRDF::EnvironmentTerm_Rtg (reference NRD.hlsli:490-517:
+// "Ray Tracing Gems" ch. 32 eq. 4, GGX VNDF + Schlick); the polynomial rows are summed left to right, rcp is an exact division
+NRD_D void ConvertBaseColorMetalnessToAlbedoRf0(float3 baseColor, float metalness, float3& albedo, float3& Rf0) {
+    float k = Sat(1.0f - metalness);
+    albedo = F3(baseColor.x * k, baseColor.y * k, baseColor.z * k);
+    Rf0 = F3(0.04f + (baseColor.x - 0.04f) * metalness, 0.04f + (baseColor.y - 0.04f) * metalness, 0.04f + (baseColor.z - 0.04f) * metalness);
+}
+NRD_D float3 EnvironmentTerm_Rtg(float3 Rf0, float NoV, float roughness) {
+    float m = Sat(roughness * roughness);
+    float x1 = NoV, x2 = NoV * NoV, x3 = NoV * x2;
+    float y1 = m, y3 = m * (m * m);
+    float biasNum = (0.99044f + -1.28514f * x1) + (1.29678f + -0.755907f * x1) * y1;
+    float biasDen = (1.0f + 2.92338f * x1 + 59.4188f * x3) + (20.3225f + -27.0302f * x1 + 222.592f * x3) * y1 + (121.563f + 626.13f * x1 + 316.627f * x3) * y3;
+    float scaleNum = (0.0365463f + 3.32707f * x1) + (9.0632f + -9.04756f * x1) * y1;
+    float scaleDen = (1.0f + 3.59685f * x2 + -1.36772f * x3) + (9.04401f + -16.3174f * x2 + 9.22949f * x3) * y1 + (5.56589f + 19.7886f * x2 + -20.2123f * x3) * y3;
+    float bias = biasNum * (1.0f / Max(biasDen, 1e-6f));
+    float scale = scaleNum * (1.0f / Max(scaleDen, 1e-6f));
+    return F3(Sat(Rf0.x * scale + bias), Sat(Rf0.y * scale + bias), Sat(Rf0.z * scale + bias));
+}
 NRD_D float ColorClamp(float m1, float sigma, float x) { return Clamp(x, m1 - sigma, m1 + sigma); }
 NRD_D float3 LinearToYCoCg(float3 c) { // reference NRD.hlsli:356-363
     return F3(c.x * 0.25f + c.y * 0.5f + c.z * 0.25f, c.x * 0.5f + c.y * 0.0f + c.z * -0.5f, c.x * -0.25f + c.y * 0.5f + c.z * -0.25f);

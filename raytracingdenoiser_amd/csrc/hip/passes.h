@@ -9,7 +9,7 @@
 namespace nrdhip {
 
 // numeric values of the nrd::Format entries the format-dispatching launchers look at (checked against NRDDescs.h in executor.hip)
-enum : uint8_t { FORMAT_R16_UNORM = 13, FORMAT_RGBA16_SNORM = 24, FORMAT_RGBA16_SFLOAT = 27 };
+enum : uint8_t { FORMAT_RGBA8_UNORM = 8, FORMAT_R16_UNORM = 13, FORMAT_RGBA16_SNORM = 24, FORMAT_RGBA16_SFLOAT = 27 };
 
 struct PassArgs {
     const Plane* planes;      // DispatchDesc::resources resolved to planes, same order (inputs then outputs)

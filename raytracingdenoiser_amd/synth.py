@@ -201,6 +201,22 @@ def render_frame(width, height, frame, device="cpu", static_camera=False, noise=
     out = {"camera": cam, "viewz": view_z.contiguous(), "is_sky": is_sky}
     out["normal_roughness"] = pack_normal_roughness(n, rough, torch.zeros_like(rough)).contiguous()
     out["mv"] = torch.zeros((height, width, 4), dtype=torch.float16, device=dev)  # static scene, world-space MVs scaled by 0
+    if "basecolor" in want:
+        # IN_BASECOLOR_METALNESS (RGBA8_UNORM): the surface albedo as base colour, metalness in bands {0, 0.5, 1} of the world position
+        metal = torch.remainder(torch.floor(p[..., 0] * 1.3) + torch.floor(p[..., 2] * 1.3), 3.0) * 0.5
+        bcm = torch.cat([alb.clamp(0.0, 1.0), metal.unsqueeze(-1)], -1)
+        bcm = torch.where(is_sky.unsqueeze(-1), torch.zeros_like(bcm), bcm)
+        out["basecolor_metalness"] = torch.floor(bcm * 255.0 + 0.5).to(torch.uint8).contiguous()
+    if "mv2d" in want:
+        # screen-space ("2.5D") motion vectors of the static scene under the moving camera: .xy in pixels towards the previous frame,
+        # .z = viewZprev - viewZ; for CommonSettings motionVectorScale = (1 / w, 1 / h, 1) [or (.., 0) for 2D], isMotionVectorInWorldSpace = false
+        camp = Camera(width, height, max(frame - 1, 0), static=static_camera)
+        Rp = torch.tensor([camp.right, camp.up, camp.fwd], device=dev, dtype=torch.float32)
+        pv = (p - torch.tensor(camp.pos, device=dev, dtype=torch.float32)) @ Rp.T
+        zp = pv[..., 2].clamp_min(1e-3)
+        up_, vp_ = 0.5 + 0.5 * pv[..., 0] / zp * camp.fx, 0.5 - 0.5 * pv[..., 1] / zp * camp.fy
+        mv = torch.stack([(up_ - u) * width, (vp_ - v) * height, pv[..., 2] - view_z, torch.zeros_like(u)], -1)
+        out["mv"] = torch.where(is_sky.unsqueeze(-1), torch.zeros_like(mv), mv).clamp(-FP16_MAX, FP16_MAX).to(torch.float16).contiguous()
 
     xi, yi = xs.to(torch.int64), ys.to(torch.int64)
     fr = frame if noise else 0

@@ -13,8 +13,10 @@ REL_TOL = 1e-3  # BASELINE.json north_star: <= 1e-3 relative per pixel (bit-exac
 
 
 def common_settings(cam, cam_prev, width, height, frame_index, **kw):
-    cs = api.CommonSettings(resourceSize=(width, height), rectSize=(width, height), resourceSizePrev=(width, height), rectSizePrev=(width, height),
-                            timeDeltaBetweenFrames=16.667, frameIndex=frame_index, isMotionVectorInWorldSpace=True, motionVectorScale=(0.0, 0.0, 0.0), **kw)
+    args = dict(resourceSize=(width, height), rectSize=(width, height), resourceSizePrev=(width, height), rectSizePrev=(width, height),
+                timeDeltaBetweenFrames=16.667, frameIndex=frame_index, isMotionVectorInWorldSpace=True, motionVectorScale=(0.0, 0.0, 0.0))
+    args.update(kw)
+    cs = api.CommonSettings(**args)
     for i in range(16):
         cs.viewToClipMatrix[i] = cam.view_to_clip[i]
         cs.viewToClipMatrixPrev[i] = cam_prev.view_to_clip[i]
@@ -65,6 +67,8 @@ def user_planes(name, frame):
         diff_mode, spec_mode = (0, 1) if mode == api.CheckerboardMode.BLACK else (1, 0)  # reference Reblur.cpp / Relax.cpp: BLACK -> diffuse 0, specular 1
         planes = [(rt, checkerboard_pack(t, diff_mode if rt.name.startswith("IN_DIFF") else spec_mode, frame_index) if rt.name.startswith(("IN_DIFF", "IN_SPEC")) else t, fmt)
                   for rt, t, fmt in planes]
+    if "basecolor_metalness" in frame:  # consumed when CommonSettings::isBaseColorMetalnessAvailable (REBLUR: specular motion written back into IN_MV)
+        extra.append((RT.IN_BASECOLOR_METALNESS, frame["basecolor_metalness"], F.RGBA8_UNORM))
     return planes + extra
 
 
@@ -223,10 +227,13 @@ class OracleRun:
             self.outs[rt] = (arr, fmt)
             self.ex.bind(rt, arr, fmt)
         self.last_dispatches = []
+        self.inputs = {}
 
     def step(self, frame, cs, settings=None):
         for rt, t, fmt in user_planes(self.name, frame):
-            self.ex.bind(rt, np.ascontiguousarray(t.cpu().numpy()), fmt)
+            arr = np.array(t.cpu().numpy(), copy=True, order="C")  # a private copy: IN_MV is an in/out plane (REBLUR specular MV modification)
+            self.inputs[rt] = arr
+            self.ex.bind(rt, arr, fmt)
         if settings is not None:
             assert self.inst.set_denoiser_settings(0, settings) == api.Result.SUCCESS
         assert self.inst.set_common_settings(cs) == api.Result.SUCCESS
@@ -263,11 +270,14 @@ class HipRun:
                 t = _padded(t, pad)
             self.outs[rt] = (t, fmt)
             self.ex.bind(rt, t, fmt)
+        self.inputs = {}
 
     def step(self, frame, cs, settings=None):
         for rt, t, fmt in user_planes(self.name, frame):
-            t = t.cuda().contiguous()
-            self.ex.bind(rt, _padded(t, self.pad) if self.pad else t, fmt)
+            t = t.cuda().clone().contiguous()  # a private copy: IN_MV is an in/out plane
+            t = _padded(t, self.pad) if self.pad else t
+            self.inputs[rt] = t
+            self.ex.bind(rt, t, fmt)
         if settings is not None:
             assert self.inst.set_denoiser_settings(0, settings) == api.Result.SUCCESS
         assert self.inst.set_common_settings(cs) == api.Result.SUCCESS
@@ -303,6 +313,13 @@ def run_parity(name, width=192, height=128, frames=4, verbose=False, settings_ov
             worst = max(worst, e)
             if verbose:
                 print("frame %d %-28s max rel err %.3g  bit-exact texels %.4f%%" % (f, rt.name, e, 100.0 * exact))
+        if RT.IN_MV in ora.inputs:  # in/out plane: REBLUR temporal stabilization may write specular motion back into it
+            want, got = ora.inputs[RT.IN_MV].astype(np.float32), hip.inputs[RT.IN_MV].cpu().numpy().astype(np.float32)
+            e = rel_error(got, want)
+            worst = max(worst, e)
+            if verbose and (e > 0 or cs_kw.get("isBaseColorMetalnessAvailable")):
+                src = frame["mv"].cpu().numpy().astype(np.float32)
+                print("frame %d IN_MV (in/out)               max rel err %.3g  texels modified by the pass %d" % (f, e, int(np.any(want != src, axis=-1).sum())))
         if check_pools:
             for pool in (RT.PERMANENT_POOL, RT.TRANSIENT_POOL):
                 descs = ora.inst.permanent_pool if pool == RT.PERMANENT_POOL else ora.inst.transient_pool

@@ -344,3 +344,59 @@ def test_hip_matches_oracle_checkerboard(name, mode, overrides):
 def test_hip_matches_oracle_checkerboard_split_screen():
     worst = parity.run_parity("REBLUR_DIFFUSE_SPECULAR", width=160, height=96, frames=3, verbose=True, settings_overrides=dict(checkerboardMode=1), cs_kw=dict(splitScreen=0.5))
     assert worst <= parity.REL_TOL
+
+
+# ---------------------------------------------------------------------------------------------------- motion vector conventions
+def _mv_settings(z_scale, **kw):
+    return dict(isMotionVectorInWorldSpace=False, motionVectorScale=(1.0 / W, 1.0 / H, z_scale), **kw)
+
+
+@pytest.mark.parametrize("z_scale", [1.0, 0.0])
+def test_oracle_screen_space_motion_vectors_agree_with_world_space_ones(z_scale):
+    """The scene is static, so "world-space MVs scaled by 0" and true 2D / 2.5D screen-space MVs (CommonSettings::motionVectorScale, NRDSettings.h) describe
+    the same motion: both reprojection paths of temporal accumulation / stabilization must land on (nearly: the MVs are fp16) the same result."""
+    name = "REBLUR_DIFFUSE_SPECULAR"
+    a = _run_oracle(name, parity.generate_sequence(name, W, H, 6))
+    b = _run_oracle(name, parity.generate_sequence(name, W, H, 6, extra_want=("mv2d",)), cs_kw=_mv_settings(z_scale))
+    for rt in (RT.OUT_DIFF_RADIANCE_HITDIST, RT.OUT_SPEC_RADIANCE_HITDIST):
+        ref, out = a.output(rt), b.output(rt)
+        assert np.mean(ref == out) > 0.9 and np.abs(ref - out).mean() < 1e-4 * np.abs(ref).mean() + 1e-5
+
+
+def test_oracle_specular_mv_modification_rewrites_in_mv():
+    """CommonSettings::isBaseColorMetalnessAvailable (reference REBLUR_TemporalStabilization.hlsli:250-285, Reblur.cpp:190, :359): on mostly-specular
+    surfaces temporal stabilization blends IN_MV towards the motion of the reflection; the denoised outputs do not depend on it."""
+    name = "REBLUR_DIFFUSE_SPECULAR"
+    seq = parity.generate_sequence(name, W, H, 4, extra_want=("mv2d", "basecolor"))
+    plain = _run_oracle(name, seq, cs_kw=_mv_settings(1.0))
+    assert np.array_equal(plain.inputs[RT.IN_MV], seq[-1]["mv"].numpy())  # off: IN_MV untouched
+    mod = _run_oracle(name, seq, cs_kw=_mv_settings(1.0, isBaseColorMetalnessAvailable=True))
+    assert [d.shader for d in mod.last_dispatches][-1] == "REBLUR_DiffuseSpecular_TemporalStabilization.cs"
+    src, out = seq[-1]["mv"].float().numpy(), mod.inputs[RT.IN_MV].astype(np.float32)
+    changed = np.any(src != out, axis=-1)
+    metal = seq[-1]["basecolor_metalness"].numpy()[..., 3] == 255
+    assert not np.isnan(out).any() and changed.mean() > 0.1
+    assert changed[metal & ~seq[-1]["is_sky"].numpy()].mean() > changed[~metal].mean()  # metals are all-specular
+    assert np.array_equal(out[..., 3], src[..., 3])
+    for rt in (RT.OUT_DIFF_RADIANCE_HITDIST, RT.OUT_SPEC_RADIANCE_HITDIST):
+        assert np.array_equal(plain.output(rt), mod.output(rt))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name,z_scale", [("REBLUR_DIFFUSE_SPECULAR", 1.0), ("REBLUR_DIFFUSE_SPECULAR", 0.0), ("REBLUR_SPECULAR_OCCLUSION", 1.0), ("REBLUR_DIFFUSE_SH", 0.0)])
+def test_hip_matches_oracle_screen_space_motion_vectors(name, z_scale):
+    worst = parity.run_parity(name, width=176, height=104, frames=5, verbose=True, extra_want=("mv2d",),
+                              cs_kw=dict(isMotionVectorInWorldSpace=False, motionVectorScale=(1.0 / 176, 1.0 / 104, z_scale)))
+    assert worst <= parity.REL_TOL
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name,world_space,z_scale", [("REBLUR_DIFFUSE_SPECULAR", False, 1.0), ("REBLUR_DIFFUSE_SPECULAR", False, 0.0), ("REBLUR_SPECULAR", True, 1.0),
+                                                      ("REBLUR_DIFFUSE_SPECULAR_SH", False, 1.0)])
+def test_hip_matches_oracle_specular_mv_modification(name, world_space, z_scale):
+    # the in/out IN_MV plane is compared as well (parity.run_parity)
+    w, h = 176, 104
+    cs_kw = dict(isBaseColorMetalnessAvailable=True, isMotionVectorInWorldSpace=world_space, motionVectorScale=(1.0, 1.0, 1.0) if world_space else (1.0 / w, 1.0 / h, z_scale))
+    worst = parity.run_parity(name, width=w, height=h, frames=4, verbose=True, extra_want=("basecolor",) if world_space else ("mv2d", "basecolor"), cs_kw=cs_kw,
+                              settings_overrides=dict(enablePerformanceMode=True) if name == "REBLUR_SPECULAR" else None)
+    assert worst <= parity.REL_TOL

@@ -272,3 +272,23 @@ def test_hip_matches_oracle_checkerboard(name, mode, overrides):
 def test_hip_matches_oracle_checkerboard_split_screen():
     worst = parity.run_parity("RELAX_DIFFUSE_SPECULAR_SH", width=160, height=96, frames=3, verbose=True, settings_overrides=dict(checkerboardMode=2), cs_kw=dict(splitScreen=0.5))
     assert worst <= parity.REL_TOL
+
+
+# ---------------------------------------------------------------------------------------------------- motion vector conventions
+@pytest.mark.parametrize("z_scale", [1.0, 0.0])
+def test_oracle_screen_space_motion_vectors_agree_with_world_space_ones(z_scale):
+    """static scene: true 2D / 2.5D screen-space MVs and "world-space MVs scaled by 0" describe the same motion (see tests/test_reblur.py)"""
+    name = "RELAX_DIFFUSE_SPECULAR"
+    a = _run_oracle(name, parity.generate_sequence(name, W, H, 6))
+    b = _run_oracle(name, parity.generate_sequence(name, W, H, 6, extra_want=("mv2d",)), cs_kw=dict(isMotionVectorInWorldSpace=False, motionVectorScale=(1.0 / W, 1.0 / H, z_scale)))
+    for rt in (RT.OUT_DIFF_RADIANCE_HITDIST, RT.OUT_SPEC_RADIANCE_HITDIST):
+        ref, out = a.output(rt), b.output(rt)
+        assert np.mean(ref == out) > 0.9 and np.abs(ref - out).mean() < 1e-4 * np.abs(ref).mean() + 1e-5
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name,z_scale", [("RELAX_DIFFUSE_SPECULAR", 1.0), ("RELAX_DIFFUSE_SPECULAR_SH", 0.0), ("RELAX_SPECULAR", 0.0)])
+def test_hip_matches_oracle_screen_space_motion_vectors(name, z_scale):
+    worst = parity.run_parity(name, width=176, height=104, frames=5, verbose=True, extra_want=("mv2d",),
+                              cs_kw=dict(isMotionVectorInWorldSpace=False, motionVectorScale=(1.0 / 176, 1.0 / 104, z_scale)))
+    assert worst <= parity.REL_TOL

@@ -127,3 +127,12 @@ def test_hip_matches_oracle_translucency(size):
 def test_hip_matches_oracle_translucency_without_stabilization():
     worst = parity.run_parity("SIGMA_SHADOW_TRANSLUCENCY", width=160, height=96, frames=3, verbose=True, settings_overrides=dict(maxStabilizedFrameNum=0))
     assert worst <= parity.REL_TOL
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name,z_scale", [("SIGMA_SHADOW", 1.0), ("SIGMA_SHADOW_TRANSLUCENCY", 0.0)])
+def test_hip_matches_oracle_screen_space_motion_vectors(name, z_scale):
+    # true 2D / 2.5D screen-space MVs instead of "world-space MVs scaled by 0" (CommonSettings::motionVectorScale): the other reprojection branch of TS
+    worst = parity.run_parity(name, width=176, height=104, frames=5, verbose=True, extra_want=("mv2d",),
+                              cs_kw=dict(isMotionVectorInWorldSpace=False, motionVectorScale=(1.0 / 176, 1.0 / 104, z_scale)))
+    assert worst <= parity.REL_TOL
