@@ -37,9 +37,10 @@ void ClassifyTiles(const PassIO& io) {
     const ReblurCB& c = *(const ReblurCB*)io.constants;
     const Tex& gIn_ViewZ = io.t[0];
     Tex& gOut_Tiles = io.t[1];
+    const int tilesW = ((int)c.gRectSize.x + 15) / 16, tilesH = ((int)c.gRectSize.y + 15) / 16; // one group per 16x16 tile of the RECT (dynamic resolution)
 #pragma omp parallel for schedule(static)
-    for (int ty = 0; ty < gOut_Tiles.H(); ty++)
-        for (int tx = 0; tx < gOut_Tiles.W(); tx++) {
+    for (int ty = 0; ty < tilesH; ty++)
+        for (int tx = 0; tx < tilesW; tx++) {
             int sum = 0;
             for (int j = 0; j < 16; j++)
                 for (int i = 0; i < 16; i++) {

@@ -344,6 +344,8 @@ extern "C" __attribute__((visibility("default"))) uint32_t nrdHipGetPoolPlane(Nr
 static int PassReachRows(const char* shader, const void* constants, uint32_t constantsSize) {
     if (!strncmp(shader, "RELAX_", 6) && constants && constantsSize >= sizeof(nrdc::RelaxConstants)) {
         const nrdc::RelaxConstants& c = *(const nrdc::RelaxConstants*)constants;
+        if (c.gRectSizePrev.x != float(c.gRectSize.x) || c.gRectSizePrev.y != float(c.gRectSize.y))
+            return -1; // dynamic resolution step: history rows map to different rows of this frame, no bounded halo -> whole frame
         if (strstr(shader, "_AtrousSmem") || strstr(shader, "_HistoryClamping"))
             return 2; // 5x5 windows
         if (strstr(shader, "_Atrous")) {
@@ -363,6 +365,8 @@ static int PassReachRows(const char* shader, const void* constants, uint32_t con
     if (strncmp(shader, "REBLUR_", 7) != 0 || !constants || constantsSize < sizeof(nrdc::ReblurConstants))
         return -1;
     const nrdc::ReblurConstants& c = *(const nrdc::ReblurConstants*)constants;
+    if (c.gRectSizePrev.x != c.gRectSize.x || c.gRectSizePrev.y != c.gRectSize.y)
+        return -1; // dynamic resolution step: history rows map to different rows of this frame, no bounded halo -> whole frame
     const float kSlack = 2.0f; // world-space specular taps are bounded by ~1x the pixel radius on screen; 2x is the safety factor
     if (strstr(shader, "_TemporalStabilization"))
         return 1;

@@ -18,8 +18,8 @@ constexpr int TILE_X = 32;
 constexpr int TILE_Y = 8;
 
 static const char* CheckSupportedHistory(const ReblurCB& c) {
-    if (c.gRectOrigin.x != 0 || c.gRectOrigin.y != 0 || c.gResolutionScale.x != 1.0f || c.gResolutionScale.y != 1.0f || c.gResolutionScalePrev.x != 1.0f || c.gResolutionScalePrev.y != 1.0f)
-        return "REBLUR: dynamic resolution (rect != resource) is not implemented in the HIP back-end yet";
+    if (c.gRectOrigin.x != 0 || c.gRectOrigin.y != 0) // rect < resource (dynamic resolution) is fine; only a shifted rect is not
+        return "REBLUR: a non-zero CommonSettings::rectOrigin is not implemented in the HIP back-end";
     if (c.gOrthoMode != 0.0f)
         return "REBLUR: orthographic projection is not supported (SURVEY.md section 8c)";
     return nullptr;

@@ -24,11 +24,11 @@ constexpr int TILE_X = 32;
 constexpr int TILE_Y = 8;
 
 // ================================================================================================ ClassifyTiles
-__global__ __launch_bounds__(256) void ReblurClassifyTilesKernel(Plane viewZ, Plane tiles, float viewZScale, float denoisingRange) {
+__global__ __launch_bounds__(256) void ReblurClassifyTilesKernel(Plane viewZ, Plane tiles, float viewZScale, float denoisingRange, int tilesPerRow, int tileRows) {
+    // tilesPerRow x tileRows = the tiles of the RECT (dynamic resolution: the reference dispatches ceil(rect / 16) groups; tiles beyond stay untouched)
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int tileIndex = blockIdx.x * 4 + wave;
-    const int tilesPerRow = tiles.w;
-    if (tileIndex >= tiles.w * tiles.h)
+    if (tileIndex >= tilesPerRow * tileRows)
         return;
     const int tx = tileIndex % tilesPerRow, ty = tileIndex / tilesPerRow;
     const int x = tx * 16 + (lane & 3) * 4, y = ty * 16 + (lane >> 2);
@@ -51,8 +51,11 @@ __global__ __launch_bounds__(256) void ReblurClassifyTilesKernel(Plane viewZ, Pl
 static const char* LaunchClassifyTiles(const PassArgs& a) {
     const ReblurCB& c = *(const ReblurCB*)a.constants;
     const Plane& tiles = a.planes[1];
-    int numTiles = tiles.w * tiles.h;
-    hipLaunchKernelGGL(ReblurClassifyTilesKernel, dim3((numTiles + 3) / 4), dim3(256), 0, a.stream, a.planes[0], tiles, c.gViewZScale, c.gDenoisingRange);
+    const int tilesPerRow = (c.gRectSizeMinusOne.x + 16) / 16, tileRows = (c.gRectSizeMinusOne.y + 16) / 16;
+    if (tilesPerRow > tiles.w || tileRows > tiles.h)
+        return "REBLUR ClassifyTiles: the rect does not fit the tile plane";
+    int numTiles = tilesPerRow * tileRows;
+    hipLaunchKernelGGL(ReblurClassifyTilesKernel, dim3((numTiles + 3) / 4), dim3(256), 0, a.stream, a.planes[0], tiles, c.gViewZScale, c.gDenoisingRange, tilesPerRow, tileRows);
     return nullptr;
 }
 
@@ -503,8 +506,8 @@ __global__ __launch_bounds__(TILE_X* TILE_Y) void ReblurSpatialKernel(ReblurCB c
 }
 
 static const char* CheckSupported(const ReblurCB& c) {
-    if (c.gRectOrigin.x != 0 || c.gRectOrigin.y != 0 || c.gResolutionScale.x != 1.0f || c.gResolutionScale.y != 1.0f)
-        return "REBLUR: dynamic resolution (rect != resource) is not implemented in the HIP back-end yet";
+    if (c.gRectOrigin.x != 0 || c.gRectOrigin.y != 0) // rect < resource (dynamic resolution) is fine; only a shifted rect is not
+        return "REBLUR: a non-zero CommonSettings::rectOrigin is not implemented in the HIP back-end";
     if (c.gOrthoMode != 0.0f)
         return "REBLUR: orthographic projection is not supported (SURVEY.md section 8c)";
     return nullptr;

@@ -24,12 +24,13 @@ __device__ __constant__ const float g_Poisson8[8][3] = { // reference Shaders/In
     {+0.5699277f, +0.3513750f, +0.6695386f}, {+0.2939128f, -0.1131226f, +0.3149309f}, {+0.7836658f, -0.4208784f, +0.8895339f}, {+0.1564120f, -0.8198990f, +0.8346850f}};
 
 // ================================================================================================ ClassifyTiles
-__global__ __launch_bounds__(256) void RelaxClassifyTilesKernel(Plane viewZ, Plane tiles, float denoisingRange) {
+__global__ __launch_bounds__(256) void RelaxClassifyTilesKernel(Plane viewZ, Plane tiles, float denoisingRange, int tilesPerRow, int tileRows) {
+    // tilesPerRow x tileRows = the tiles of the RECT (dynamic resolution: the reference dispatches ceil(rect / 16) groups; tiles beyond stay untouched)
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int tileIndex = blockIdx.x * 4 + wave;
-    if (tileIndex >= tiles.w * tiles.h)
+    if (tileIndex >= tilesPerRow * tileRows)
         return;
-    const int tx = tileIndex % tiles.w, ty = tileIndex / tiles.w;
+    const int tx = tileIndex % tilesPerRow, ty = tileIndex / tilesPerRow;
     const int x = tx * 16 + (lane & 3) * 4, y = ty * 16 + (lane >> 2);
 
     bool allSky = true;
@@ -50,8 +51,11 @@ const char* LaunchClassifyTiles(const PassArgs& a) {
         return e;
     const nrdc::RelaxConstants& c = *(const nrdc::RelaxConstants*)a.constants;
     const Plane& tiles = a.planes[1];
-    int numTiles = tiles.w * tiles.h;
-    hipLaunchKernelGGL(RelaxClassifyTilesKernel, dim3((numTiles + 3) / 4), dim3(256), 0, a.stream, a.planes[0], tiles, c.gDenoisingRange);
+    const int tilesPerRow = (c.gRectSize.x + 15) / 16, tileRows = (c.gRectSize.y + 15) / 16;
+    if (tilesPerRow > tiles.w || tileRows > tiles.h)
+        return "RELAX ClassifyTiles: the rect does not fit the tile plane";
+    int numTiles = tilesPerRow * tileRows;
+    hipLaunchKernelGGL(RelaxClassifyTilesKernel, dim3((numTiles + 3) / 4), dim3(256), 0, a.stream, a.planes[0], tiles, c.gDenoisingRange, tilesPerRow, tileRows);
     return nullptr;
 }
 

@@ -35,9 +35,8 @@ inline const char* CheckSupportedRelax(const PassArgs& a) {
     if (!a.constants || a.constantsSize < sizeof(nrdc::RelaxConstants))
         return "RELAX: constant block missing";
     const nrdc::RelaxConstants& c = *(const nrdc::RelaxConstants*)a.constants;
-    if (c.gRectOrigin.x != 0 || c.gRectOrigin.y != 0 || c.gResolutionScale.x != 1.0f || c.gResolutionScale.y != 1.0f || c.gRectSizePrev.x != float(c.gRectSize.x) ||
-        c.gRectSizePrev.y != float(c.gRectSize.y) || fabsf(c.gRectSizePrev.x * c.gResourceSizeInvPrev.x - 1.0f) > 1e-5f || fabsf(c.gRectSizePrev.y * c.gResourceSizeInvPrev.y - 1.0f) > 1e-5f) // w * (1 / w) need not round to 1
-        return "RELAX: dynamic resolution (rect != resource) is not implemented in the HIP back-end yet";
+    if (c.gRectOrigin.x != 0 || c.gRectOrigin.y != 0) // rect < resource (dynamic resolution) is fine; only a shifted rect is not
+        return "RELAX: a non-zero CommonSettings::rectOrigin is not implemented in the HIP back-end";
     if (c.gOrthoMode != 0.0f)
         return "RELAX: orthographic projection is not supported (SURVEY.md section 8c)";
     return nullptr;

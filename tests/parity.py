@@ -293,14 +293,40 @@ def generate_sequence(name, width, height, frames, static_camera=False, noise=Tr
     return [synth.render_frame(width, height, f, device=device, static_camera=static_camera, noise=noise, want=tuple(DENOISERS[name][1]) + tuple(extra_want)) for f in range(frames)]
 
 
-def run_parity(name, width=192, height=128, frames=4, verbose=False, settings_overrides=None, static_camera=False, check_pools=True, cs_kw=None, extra_want=(), pad=0):
-    """Returns the worst relative error between the HIP path and the oracle over all frames, user outputs and pool planes."""
-    seq = generate_sequence(name, width, height, frames, static_camera=static_camera, extra_want=extra_want)
-    cs_kw = cs_kw or {}
-    ora, hip = OracleRun(name, width, height), HipRun(name, width, height, pad=pad)
+def embed_in_resource(frame, resource):
+    """dynamic resolution: every plane of a generated (rect-sized) frame placed at the top-left of a resource-sized plane; the rest is a sentinel"""
+    rw, rh = resource
+    out = {}
+    for k, v in frame.items():
+        if torch.is_tensor(v) and v.dim() >= 2 and v.dtype != torch.bool:
+            big = torch.full([rh, rw] + list(v.shape[2:]), 33.0 if v.dtype.is_floating_point else 9, dtype=v.dtype, device=v.device)
+            big[: v.shape[0], : v.shape[1]] = v
+            v = big
+        out[k] = v
+    return out
+
+
+def run_parity(name, width=192, height=128, frames=4, verbose=False, settings_overrides=None, static_camera=False, check_pools=True, cs_kw=None, extra_want=(), pad=0, resource=None,
+               rect_sizes=None):
+    """Returns the worst relative error between the HIP path and the oracle over all frames, user outputs and pool planes.
+    resource = (w, h) >= (width, height): dynamic resolution, the frame is the top-left rect of resource-sized planes;
+    rect_sizes = [(w, h), ...]: the rect size of frame f is rect_sizes[f % len] (same aspect ratio as (width, height)), inside `resource`."""
+    if rect_sizes:
+        seq = [synth.render_frame(*rect_sizes[f % len(rect_sizes)], f, static_camera=static_camera, want=tuple(DENOISERS[name][1]) + tuple(extra_want)) for f in range(frames)]
+    else:
+        seq = generate_sequence(name, width, height, frames, static_camera=static_camera, extra_want=extra_want)
+    cs_kw = dict(cs_kw or {})
+    if resource:
+        seq = [embed_in_resource(fr, resource) for fr in seq]
+        cs_kw.update(resourceSize=resource, resourceSizePrev=resource)
+    rw, rh = resource or (width, height)
+    ora, hip = OracleRun(name, rw, rh), HipRun(name, rw, rh, pad=pad)
     worst = 0.0
     for f, frame in enumerate(seq):
         cam, cam_prev = frame["camera"], seq[max(f - 1, 0)]["camera"]
+        if rect_sizes:
+            width, height = rect_sizes[f % len(rect_sizes)]
+            cs_kw.update(rectSize=(width, height), rectSizePrev=rect_sizes[max(f - 1, 0) % len(rect_sizes)])
         cs = common_settings(cam, cam_prev, width, height, f, **cs_kw)
         tag_checkerboard(frame, settings_overrides, f)
         st = denoiser_settings(name, frame, settings_overrides)
