@@ -291,6 +291,7 @@ def main():
         "config": {"workload": "%s %dx%d, %s, analytic scene + 1rpp noise, moving camera" % (name, W, H, "default settings" if overrides is None else "settings %s" % overrides),
                    "parallelism": "1 GPU" if world == 1 else ("row strips x%d, halo exchange between pass segments (RCCL send/recv to the 2 neighbours, %.1f MB received per rank per frame)"
                                                                % (world, shard.exchanged_bytes / max(total, 1) / 1e6) if args.sharding == "halo" else "row strips x%d + RCCL all-gather" % world),
+                   "strips": (list(shard.bounds) if shard is not None and getattr(shard, "bounds", None) else None),  # halo scheme: rows owned by each rank (re-cut from the tile map)
                    "storage": "reference pool formats (fp16 history, R10G10B10A2 normals), %.0f B/px/frame compulsory traffic" % total_bpp},
         "roofline": roofline,
         "whole_chain": whole_chain,

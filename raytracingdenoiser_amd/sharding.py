@@ -202,17 +202,80 @@ def exchange_halos(planes, rows, rank, world, items, group=None):
         band.copy_(host)
 
 
-class HaloSharder:
-    """Row-strip sharding with halo exchange between pass segments (see above). `denoise()` replaces executor.denoise()."""
+def carried_over_planes(dispatches, small_planes=()):
+    """keys of the planes a frame reads before (or without) writing them: the history it inherits from the previous frame"""
+    from . import api
 
-    def __init__(self, executor, instance, width, height, rank, world, group=None, max_motion_rows=32, exchange_threshold=24):
+    written, carried = set(), []
+    for d in dispatches:
+        for dt, t, idx in d.resources:
+            key = (int(t), idx)
+            if dt == api.DescriptorType.TEXTURE and not _is_user_input(t) and key not in small_planes and key not in written and key not in carried:
+                carried.append(key)
+        for dt, t, idx in d.resources:
+            if dt == api.DescriptorType.STORAGE_TEXTURE:
+                written.add((int(t), idx))
+    return carried
+
+
+def balanced_bounds(tile_row_cost, height, world, min_rows, tile=16):
+    """Strip boundaries (rows, multiples of `tile` except the last) that minimise the largest strip cost; every strip is at least min_rows
+    high. tile_row_cost[t] = cost of tile row t. Returns None when the frame is too small for `world` such strips."""
+    T = len(tile_row_cost)
+    min_tiles = max(1, -(-min_rows // tile))
+    if T < world * min_tiles:
+        return None
+    prefix = [0.0]
+    for c in tile_row_cost:
+        prefix.append(prefix[-1] + float(c))
+    INF = float("inf")
+    best = [[INF] * (T + 1) for _ in range(world + 1)]
+    cut = [[0] * (T + 1) for _ in range(world + 1)]
+    best[0][0] = 0.0
+    for k in range(1, world + 1):
+        for t in range(k * min_tiles, T - (world - k) * min_tiles + 1):
+            for s in range((k - 1) * min_tiles, t - min_tiles + 1):
+                if best[k - 1][s] == INF:
+                    continue
+                v = max(best[k - 1][s], prefix[t] - prefix[s])
+                if v < best[k][t]:
+                    best[k][t], cut[k][t] = v, s
+    if best[world][T] == INF:
+        return None
+    cuts, t = [T], T
+    for k in range(world, 0, -1):
+        t = cut[k][t]
+        cuts.append(t)
+    cuts.reverse()
+    return [min(c * tile, height) for c in cuts[:-1]] + [height]
+
+
+class HaloSharder:
+    """Row-strip sharding with halo exchange between pass segments (see above). `denoise()` replaces executor.denoise().
+
+    balance: after a frame that ran unsharded (the restart frame, a dynamic-resolution step, ...) every rank holds every plane completely, so
+    the strips can be re-cut for free: they are then chosen from the tile map so that every rank gets the same number of non-sky tiles
+    (sky tiles cost almost nothing), not the same number of rows."""
+
+    SKY_TILE_COST = 0.03  # relative to a tile with geometry (early-out blocks still pay their launch and the tile test)
+
+    def __init__(self, executor, instance, width, height, rank, world, group=None, max_motion_rows=32, exchange_threshold=24, balance=True):
         self.ex, self.inst = executor, instance
         self.width, self.height, self.rank, self.world, self.group = width, height, rank, world, group
-        self.max_motion_rows, self.exchange_threshold = max_motion_rows, exchange_threshold
+        self.max_motion_rows, self.exchange_threshold, self.balance = max_motion_rows, exchange_threshold, balance
         # point-to-point halos do not need equal strips: any height splits (the all-gather scheme needs height % world == 0)
-        self.rows = (rank * height // world, (rank + 1) * height // world) if world > 1 and height >= world else None
-        self.min_strip = height // world if world > 1 else height
+        self.bounds = [r * height // world for r in range(world + 1)] if world > 1 and height >= world else None
+        self.complete = True      # every plane is complete on this rank: fresh (zeroed) arena, or the last frame ran unsharded
         self.exchanged_bytes = 0  # received bytes, for reporting
+        self.rebalanced = 0
+
+    @property
+    def rows(self):
+        return (self.bounds[self.rank], self.bounds[self.rank + 1]) if self.bounds else None
+
+    @property
+    def min_strip(self):
+        return min(b - a for a, b in zip(self.bounds, self.bounds[1:])) if self.bounds else self.height
 
     def pixels_per_rank(self):
         if self.rows is None:
@@ -230,17 +293,53 @@ class HaloSharder:
         assert bound.is_contiguous(), "halo exchange needs densely packed user planes"
         return bound.view(-1).view(dtype=__import__("torch").uint8).view(self.height, -1)
 
+    def _small_planes(self):
+        from . import api
+
+        return {(int(pool), i) for pool, descs in ((api.ResourceType.PERMANENT_POOL, self.inst.permanent_pool), (api.ResourceType.TRANSIENT_POOL, self.inst.transient_pool))
+                for i, (fmt, downsample) in enumerate(descs) if downsample != 1}
+
+    def _tile_row_cost(self):
+        """per 16-row band: tiles with geometry + a little for the sky tiles, from the tile map the previous frame left in the pool (R8: 255 = sky)"""
+        from . import api
+
+        for i, (fmt, downsample) in enumerate(self.inst.transient_pool):
+            if downsample == 16 and fmt == api.Format.R8_UNORM:
+                tiles = self.ex.pool_plane_tensor(api.ResourceType.TRANSIENT_POOL, i)[:, : (self.width + 15) // 16].cpu().numpy()
+                return [float((row == 0).sum()) + self.SKY_TILE_COST * len(row) for row in tiles]
+        return None
+
     def begin_frame(self):
-        """GetComputeDispatches + plan; returns (plan, dispatch pointer, count)"""
+        """GetComputeDispatches + plan; returns (plan, dispatch pointer, count). A plan that falls back while this rank's planes are incomplete
+        carries plan.complete_keys: the carried-over planes every rank has to receive in full before the frame runs."""
         from . import api
 
         r, ptr, n = self.inst.get_compute_dispatches_raw()
         assert r == api.Result.SUCCESS, r
         dispatches = [api.Dispatch(ptr[i], self.inst.pipelines) for i in range(n)]
-        small = {(int(pool), i) for pool, descs in ((api.ResourceType.PERMANENT_POOL, self.inst.permanent_pool), (api.ResourceType.TRANSIENT_POOL, self.inst.transient_pool))
-                 for i, (fmt, downsample) in enumerate(descs) if downsample != 1}
-        plan = plan_halo_exchange(dispatches, self.inst.dispatch_reach(ptr, n), self.rows, self.height, self.max_motion_rows, self.exchange_threshold, small, self.min_strip)
+        small, reach = self._small_planes(), self.inst.dispatch_reach(ptr, n)
+
+        def make_plan():
+            return plan_halo_exchange(dispatches, reach, self.rows, self.height, self.max_motion_rows, self.exchange_threshold, small, self.min_strip)
+
+        plan = make_plan()
+        if not plan.fallback and self.balance and self.complete and self.world > 1:
+            widest = max((w for items, _, _ in plan.steps for _, w in items), default=0)
+            cost = self._tile_row_cost()
+            new = balanced_bounds(cost, self.height, self.world, max(widest, 16)) if cost else None
+            if new and new != self.bounds:
+                old, self.bounds = self.bounds, new
+                replanned = make_plan()
+                if replanned.fallback:
+                    self.bounds = old
+                else:
+                    plan = replanned
+                    self.rebalanced += 1
+        plan.complete_keys = carried_over_planes(dispatches, small) if plan.fallback and not self.complete and self.world > 1 else []
         return plan, ptr, n
+
+    def finish_frame(self, plan):
+        self.complete = plan.fallback or self.world == 1
 
     def run_step(self, plan, ptr, n, step):
         _, first, count = plan.steps[step]
@@ -256,12 +355,36 @@ class HaloSharder:
         for k, w in pairs:
             self.exchanged_bytes += planes[k].shape[1] * w * ((self.rank > 0) + (self.rank < self.world - 1))
 
+    def complete_planes(self, keys):
+        """every rank receives every other rank's strip of the given planes (before an unsharded frame that follows a sharded one)"""
+        import torch
+        import torch.distributed as dist
+
+        for key in keys:
+            plane = self.plane_tensor(key)
+            staged = plane.is_cuda and dist.get_backend(self.group) != "nccl"  # gloo moves host memory (tests: two ranks sharing one GPU)
+            for src in range(self.world):
+                band = plane[self.bounds[src]:self.bounds[src + 1]]
+                if band.shape[0] == 0:
+                    continue
+                if staged:
+                    host = band.cpu() if src == self.rank else torch.empty(band.shape, dtype=band.dtype)
+                    dist.broadcast(host, src, self.group)
+                    if src != self.rank:
+                        band.copy_(host)
+                else:
+                    dist.broadcast(band, src, self.group)
+                if src != self.rank:
+                    self.exchanged_bytes += band.numel()
+
     def denoise(self):
         plan, ptr, n = self.begin_frame()
         if plan.fallback:
+            self.complete_planes(plan.complete_keys)
             self.ex.execute_range(ptr, n, 0, n)
-            return plan
-        for step in range(len(plan.steps)):
-            self.exchange_step(plan, step)
-            self.run_step(plan, ptr, n, step)
+        else:
+            for step in range(len(plan.steps)):
+                self.exchange_step(plan, step)
+                self.run_step(plan, ptr, n, step)
+        self.finish_frame(plan)
         return plan

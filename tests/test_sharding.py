@@ -199,18 +199,29 @@ def _local_exchange(ranks, plans, step):
                 sh.plane_tensor(key)[r0:r1].copy_(ranks[peer].plane_tensor(key)[r0:r1])
 
 
+def _local_completion(ranks, plans):
+    """what HaloSharder.complete_planes does with broadcasts, emulated with copies: every rank receives the other ranks' strips"""
+    for r, (sh, plan) in enumerate(zip(ranks, plans)):
+        for key in plan.complete_keys:
+            for src, other in enumerate(ranks):
+                if src != r:
+                    b0, b1 = other.bounds[src], other.bounds[src + 1]
+                    sh.plane_tensor(key)[b0:b1].copy_(other.plane_tensor(key)[b0:b1])
+
+
 @pytest.mark.gpu
-@pytest.mark.parametrize("name,world,height,overrides", [
-    ("REBLUR_DIFFUSE_SPECULAR", 2, 720, None),                       # default radii: segments in front of Blur and PostBlur, 123-row halos
-    ("REBLUR_DIFFUSE_SPECULAR", 3, 288, dict(maxBlurRadius=10.0)),    # three ranks: a middle strip with two neighbours
-    ("REBLUR_DIFFUSE_SPECULAR_OCCLUSION", 2, 360, dict(maxBlurRadius=15.0)),  # history = the user's OUT planes
-    ("RELAX_DIFFUSE_SPECULAR_SH", 2, 360, None),
+@pytest.mark.parametrize("name,world,height,overrides,balance,fallback_frame", [
+    ("REBLUR_DIFFUSE_SPECULAR", 2, 720, None, False, None),                     # default radii: segments in front of Blur and PostBlur, 123-row halos
+    ("REBLUR_DIFFUSE_SPECULAR", 2, 720, None, True, 3),                         # strips re-cut from the tile map; an unsharded frame in mid-sequence
+    ("REBLUR_DIFFUSE_SPECULAR", 3, 288, dict(maxBlurRadius=10.0), True, 2),      # three ranks: a middle strip with two neighbours
+    ("REBLUR_DIFFUSE_SPECULAR_OCCLUSION", 2, 360, dict(maxBlurRadius=15.0), True, 3),  # history = the user's OUT planes
+    ("RELAX_DIFFUSE_SPECULAR_SH", 2, 360, None, True, 2),
 ])
-def test_halo_sharding_virtual_ranks_reproduce_single_gpu(name, world, height, overrides):
+def test_halo_sharding_virtual_ranks_reproduce_single_gpu(name, world, height, overrides, balance, fallback_frame):
     import parity
     from raytracingdenoiser_amd.executor import HipExecutor
 
-    W, H, frames = 256, height, 5
+    W, H, frames = 256, height, 6
     RT = api.ResourceType
     seq = parity.generate_sequence(name, W, H, frames)
 
@@ -226,12 +237,16 @@ def test_halo_sharding_virtual_ranks_reproduce_single_gpu(name, world, height, o
     def prepare(inst, ex, f, frame):
         for rt, t, fmt in parity.user_planes(name, frame):
             ex.bind(rt, t.cuda().contiguous(), fmt)
-        inst.set_denoiser_settings(0, parity.denoiser_settings(name, frame, overrides))
+        ov = dict(overrides or {})
+        if f == fallback_frame:
+            ov["hitDistanceReconstructionMode"] = 1  # a pass of unknown reach: this frame runs unsharded on every rank
+        inst.set_denoiser_settings(0, parity.denoiser_settings(name, frame, ov))
         assert inst.set_common_settings(parity.common_settings(frame["camera"], seq[max(f - 1, 0)]["camera"], W, H, f)) == api.Result.SUCCESS
 
     ref_inst, ref_ex, ref_outs = make_run()
     runs = [make_run() for _ in range(world)]
-    ranks = [sharding.HaloSharder(ex, inst, W, H, r, world, max_motion_rows=16) for r, (inst, ex, outs) in enumerate(runs)]
+    ranks = [sharding.HaloSharder(ex, inst, W, H, r, world, max_motion_rows=16, balance=balance) for r, (inst, ex, outs) in enumerate(runs)]
+    uniform = list(ranks[0].bounds)
     sharded_frames = 0
     for f, frame in enumerate(seq):
         prepare(ref_inst, ref_ex, f, frame)
@@ -241,8 +256,11 @@ def test_halo_sharding_virtual_ranks_reproduce_single_gpu(name, world, height, o
             prepare(inst, ex, f, frame)
             begun.append(sh.begin_frame())
         plans = [b[0] for b in begun]
-        assert len({p.fallback for p in plans}) == 1
+        assert len({p.fallback for p in plans}) == 1 and all(sh.bounds == ranks[0].bounds for sh in ranks)  # every rank takes the same decisions
         if plans[0].fallback:
+            assert all(bool(p.complete_keys) == (f > 0) for p in plans)  # nothing to complete on the very first frame
+            torch.cuda.synchronize()
+            _local_completion(ranks, plans)
             for sh, (plan, ptr, n) in zip(ranks, begun):
                 sh.ex.execute_range(ptr, n, 0, n)
         else:
@@ -252,13 +270,30 @@ def test_halo_sharding_virtual_ranks_reproduce_single_gpu(name, world, height, o
                 _local_exchange(ranks, plans, step)
                 for sh, (plan, ptr, n) in zip(ranks, begun):
                     sh.run_step(plan, ptr, n, step)
+        for sh, plan in zip(ranks, plans):
+            sh.finish_frame(plan)
         torch.cuda.synchronize()
         # every rank's owned rows of every output equal the single-GPU result, every frame (history errors would surface one frame later)
         for r, ((inst, ex, outs), sh) in enumerate(zip(runs, ranks)):
             rb, re = sh.rows
             for o, ro in zip(outs, ref_outs):
                 assert torch.equal(o[rb:re], ro[rb:re]), (name, f, r)
-    assert sharded_frames == frames - 1
+    assert sharded_frames == frames - 1 - (fallback_frame is not None)
+    if balance:
+        assert ranks[0].rebalanced >= 1 and ranks[0].bounds != uniform and ranks[0].bounds[0] == 0 and ranks[0].bounds[-1] == H  # sky at the top: the top strip grows
+        assert ranks[0].bounds[1] > uniform[1]
+    else:
+        assert ranks[0].bounds == uniform
+
+
+def test_balanced_bounds():
+    # 30 cheap tile rows (sky) above 60 expensive ones, 8 ranks, strips of at least 123 rows: the geometry is spread over 128-row strips
+    b = sharding.balanced_bounds([0.5] * 30 + [10.0] * 60, 1440, 8, 123)
+    assert b == [0, 544, 672, 800, 928, 1056, 1184, 1312, 1440]
+    assert sharding.balanced_bounds([1.0] * 10, 160, 4, 16) == [0, 32, 64, 112, 160]       # uniform cost: near-uniform strips, tile aligned
+    assert sharding.balanced_bounds([1.0] * 10, 150, 4, 64) is None                         # 4 strips of >= 64 rows do not fit into 150 rows
+    b = sharding.balanced_bounds([1.0] * 7, 101, 2, 16)                                     # ragged height: the last strip ends at the frame height
+    assert b[0] == 0 and b[-1] == 101 and b[1] % 16 == 0
 
 
 def _halo_nccl_world1_worker(q):
@@ -330,17 +365,20 @@ def _halo_two_process_worker(rank, world, port, name, W, H, frames, q):
         for f, frame in enumerate(seq):
             for rt, t, fmt in parity.user_planes(name, frame):
                 ex.bind(rt, t.cuda().contiguous(), fmt)
-            inst.set_denoiser_settings(0, parity.denoiser_settings(name, frame))
+            # frame 2 carries a pass of unknown reach: it runs unsharded, after every rank has received the other strips of the history planes
+            inst.set_denoiser_settings(0, parity.denoiser_settings(name, frame, dict(hitDistanceReconstructionMode=1) if f == 2 else None))
             inst.set_common_settings(parity.common_settings(frame["camera"], seq[max(f - 1, 0)]["camera"], W, H, f))
             sh.denoise() if sharded else ex.denoise()
             torch.cuda.synchronize()
-            per_frame.append([o.clone() for o in outs])
-        return per_frame, (sh.rows if sharded else None), (sh.exchanged_bytes if sharded else 0)
+            rows = sh.rows if sharded else (0, H)
+            per_frame.append(([o.clone() for o in outs], rows))
+        return per_frame, (sh.rebalanced if sharded else 0), (sh.exchanged_bytes if sharded else 0)
 
     ref, _, _ = run(False)
-    got, rows, exchanged = run(True)
-    ok = all(torch.equal(a[rows[0]:rows[1]], b[rows[0]:rows[1]]) for fa, fb in zip(ref, got) for a, b in zip(fa, fb))
-    q.put((rank, ok, exchanged > 0))
+    got, rebalanced, exchanged = run(True)
+    # the owned strip can change from frame to frame (re-cut from the tile map after every unsharded frame)
+    ok = all(torch.equal(a[rows[0]:rows[1]], b[rows[0]:rows[1]]) for (fa, _), (fb, rows) in zip(ref, got) for a, b in zip(fa, fb))
+    q.put((rank, ok, exchanged > 0 and rebalanced >= 1))
     dist.barrier()
     dist.destroy_process_group()
 
@@ -354,7 +392,7 @@ def test_halo_sharding_two_processes_one_gpu():
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = 29400 + (os.getpid() % 100)
-    procs = [ctx.Process(target=_halo_two_process_worker, args=(r, 2, port, "REBLUR_DIFFUSE_SPECULAR", 192, 601, 4, q)) for r in range(2)]
+    procs = [ctx.Process(target=_halo_two_process_worker, args=(r, 2, port, "REBLUR_DIFFUSE_SPECULAR", 192, 601, 5, q)) for r in range(2)]
     for p in procs:
         p.start()
     results = sorted(q.get(timeout=400) for _ in procs)

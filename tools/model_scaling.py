@@ -1,9 +1,11 @@
 """Per-rank compute time of the row-strip sharding, measured on ONE GPU (the box has no second GPU to run the real thing).
 
-For N in (1, 2, 4, 8) the worst-placed rank (a middle strip: halo on both sides) runs the bench sequence with nrdHipSetOwnedRows;
-a full-frame executor runs next to it and its permanent planes / outputs are copied in after every frame, which is what the
-all-gather of the real run delivers. Reported: ms/frame of the strip executor (cuda events around denoise()), the redundant-
-compute factor against the ideal 1/N, and the bytes the all-gather moves per frame. The collective itself is NOT measured here.
+For N in (1, 2, 4, 8) every rank in turn (or only the middle strip, --all-ranks 0) runs the bench sequence as one virtual rank; a
+full-frame executor runs next to it in lock-step and the rows the other ranks would deliver (halo bands before each pass segment, or
+the all-gathered planes after the frame) are copied out of its planes, untimed. Reported per world size: the slowest rank's ms/frame
+(cuda events around its launches) = the compute bound of the frame time, the redundant-compute factor against the ideal 1/N, the
+strips (the halo scheme re-cuts them from the tile map, --balance 0 keeps them uniform) and the bytes received per frame. The
+transfers themselves are NOT measured here.
 usage: python tools/model_scaling.py [--workload reblur_ds] [--frames 24] [--warmup 16] > gpurun_out/scaling_model.json"""
 import argparse
 import json
@@ -28,6 +30,8 @@ def main():
     ap.add_argument("--frames", type=int, default=24)
     ap.add_argument("--warmup", type=int, default=16)
     ap.add_argument("--worlds", default="1,2,4,8")
+    ap.add_argument("--balance", type=int, default=1, help="halo scheme: strips re-cut from the tile map (1) or uniform (0)")
+    ap.add_argument("--all-ranks", type=int, default=1, help="measure every rank of each world size (the frame time is the slowest one) instead of the middle strip only")
     ap.add_argument("--scheme", choices=["allgather", "halo"], default="halo", help="allgather = FrameSharder (redundant halo compute), halo = HaloSharder (halo exchange between segments)")
     ap.add_argument("--max-motion-rows", type=int, default=32)
     args = ap.parse_args()
@@ -50,15 +54,14 @@ def main():
         return ps + [o.view(-1).view(dtype=torch.uint8).view(H, -1) for o in outs]
 
     results = []
-    for world in [int(w) for w in args.worlds.split(",")]:
+    for world, rank in [(int(w), r) for w in args.worlds.split(",") for r in (range(int(w)) if args.all_ranks else [int(w) // 2])]:
         ref = make()
         ref_planes = planes_of(*ref)
-        rank = world // 2
         run = make()
         halo = args.scheme == "halo" and world > 1
         shard = None
         if world > 1:
-            shard = sharding.HaloSharder(run[1], run[0], W, H, rank, world, max_motion_rows=args.max_motion_rows) if halo else sharding.FrameSharder(run[1], run[0], W, H, rank, world, run[2])
+            shard = sharding.HaloSharder(run[1], run[0], W, H, rank, world, max_motion_rows=args.max_motion_rows, balance=bool(args.balance)) if halo else sharding.FrameSharder(run[1], run[0], W, H, rank, world, run[2])
         run_planes = planes_of(*run)
         ms = []
         exchanged = []
@@ -99,6 +102,7 @@ def main():
                     ref[1].execute_range(rptr, rn, first, count)
                     torch.cuda.synchronize()
                     t += e0.elapsed_time(e1)
+                shard.finish_frame(plan)
                 if f >= args.warmup:
                     ms.append(t)
                     exchanged.append(got)
@@ -124,10 +128,15 @@ def main():
         for inst, ex, _ in (ref, run):
             ex.destroy()
     base = results[0]["ms_per_frame"]
-    for r in results:
-        r["compute_speedup_bound"] = round(base / r["ms_per_frame"], 3)
-        r["redundant_compute_factor"] = round(r["ms_per_frame"] * r["world"] / base, 3)
-    print(json.dumps({"workload": "%s %dx%d" % (name, W, H), "scheme": args.scheme, "note": "per-rank compute only, middle strip, one MI355X; transfers not included", "ranks": results}))
+    summary = []
+    for world in sorted({r["world"] for r in results}):
+        rs = [r for r in results if r["world"] == world]
+        slowest = max(r["ms_per_frame"] for r in rs)
+        summary.append({"world": world, "slowest_rank_ms": slowest, "mean_rank_ms": round(sum(r["ms_per_frame"] for r in rs) / len(rs), 4), "compute_speedup_bound": round(base / slowest, 3),
+                        "redundant_compute_factor": round(sum(r["ms_per_frame"] for r in rs) / base, 3),
+                        "max_halo_bytes_received_per_frame": max(r["halo_bytes_received_per_frame"] for r in rs), "strips": [r["rows"] for r in rs]})
+    print(json.dumps({"workload": "%s %dx%d" % (name, W, H), "scheme": args.scheme, "balance": bool(args.balance),
+                      "note": "per-rank compute only, %s, one MI355X; transfers not included" % ("every rank measured" if args.all_ranks else "middle strip"), "summary": summary, "ranks": results}))
 
 
 if __name__ == "__main__":
