@@ -367,7 +367,10 @@ static int PassReachRows(const char* shader, const void* constants, uint32_t con
     const nrdc::ReblurConstants& c = *(const nrdc::ReblurConstants*)constants;
     if (c.gRectSizePrev.x != c.gRectSize.x || c.gRectSizePrev.y != c.gRectSize.y)
         return -1; // dynamic resolution step: history rows map to different rows of this frame, no bounded halo -> whole frame
-    const float kSlack = 2.0f; // world-space specular taps are bounded by ~1x the pixel radius on screen; 2x is the safety factor
+    // World-space specular taps: |offset| <= worldRadius / skewFactor with skewFactor >= 0.25 + 0.75 roughness and blurRadius <= maxRadius * sqrt(roughness),
+    // i.e. <= 1.155 x the nominal pixel radius (at roughness 1/3), times z / z_tap <= 1 / (1 - radius * unproject / skew) (a few % at any sane
+    // field of view). 2x is the safety factor; NRD_HIP_SPECULAR_REACH_SLACK overrides it for experiments.
+    static const float kSlack = getenv("NRD_HIP_SPECULAR_REACH_SLACK") ? std::fmax(1.0f, (float)atof(getenv("NRD_HIP_SPECULAR_REACH_SLACK"))) : 2.0f;
     if (strstr(shader, "_TemporalStabilization"))
         return 1;
     if (strstr(shader, "_PostBlur"))

@@ -65,6 +65,7 @@ def main():
         run_planes = planes_of(*run)
         ms = []
         exchanged = []
+        exact = True
         for f in range(total):
             frame = seq[f]
             cs = parity.common_settings(frame["camera"], seq[max(f - 1, 0)]["camera"], W, H, f)
@@ -103,6 +104,8 @@ def main():
                     torch.cuda.synchronize()
                     t += e0.elapsed_time(e1)
                 shard.finish_frame(plan)
+                rb, re = shard.rows
+                exact = exact and all(torch.equal(a[rb:re], b[rb:re]) for a, b in zip(run[2], ref[2]))  # owned rows of every output == the full-frame run
                 if f >= args.warmup:
                     ms.append(t)
                     exchanged.append(got)
@@ -124,7 +127,8 @@ def main():
         torch.cuda.synchronize()
         gather_bytes = sum(p.shape[0] * p.shape[1] for p in run_planes) if world > 1 and not halo else 0
         results.append({"world": world, "rank": rank, "rows": list(shard.rows) if shard and shard.rows else [0, H], "ms_per_frame": round(sum(ms) / len(ms), 4),
-                        "all_gather_bytes_per_frame": gather_bytes, "halo_bytes_received_per_frame": int(sum(exchanged) / len(exchanged)) if exchanged else 0})
+                        "all_gather_bytes_per_frame": gather_bytes, "halo_bytes_received_per_frame": int(sum(exchanged) / len(exchanged)) if exchanged else 0,
+                        "owned_rows_bit_identical_to_full_frame_run": exact if halo else None})
         for inst, ex, _ in (ref, run):
             ex.destroy()
     base = results[0]["ms_per_frame"]
@@ -134,7 +138,8 @@ def main():
         slowest = max(r["ms_per_frame"] for r in rs)
         summary.append({"world": world, "slowest_rank_ms": slowest, "mean_rank_ms": round(sum(r["ms_per_frame"] for r in rs) / len(rs), 4), "compute_speedup_bound": round(base / slowest, 3),
                         "redundant_compute_factor": round(sum(r["ms_per_frame"] for r in rs) / base, 3),
-                        "max_halo_bytes_received_per_frame": max(r["halo_bytes_received_per_frame"] for r in rs), "strips": [r["rows"] for r in rs]})
+                        "max_halo_bytes_received_per_frame": max(r["halo_bytes_received_per_frame"] for r in rs), "strips": [r["rows"] for r in rs],
+                        "owned_rows_bit_identical_to_full_frame_run": all(r["owned_rows_bit_identical_to_full_frame_run"] is not False for r in rs)})
     print(json.dumps({"workload": "%s %dx%d" % (name, W, H), "scheme": args.scheme, "balance": bool(args.balance),
                       "note": "per-rank compute only, %s, one MI355X; transfers not included" % ("every rank measured" if args.all_ranks else "middle strip"), "summary": summary, "ranks": results}))
 
