@@ -95,6 +95,7 @@ class HaloPlan:
         self.steps = []            # [(exchange_items, first, count)] with exchange_items = [(plane_key, width_rows)]
         self.row_begin, self.row_end = [], []
         self.margins, self.reach = [], []
+        self.early = []            # per step: leading dispatches that do not touch the exchanged planes (run during the transfers)
 
 
 def _is_user_input(resource_type):
@@ -160,6 +161,14 @@ def plan_halo_exchange(dispatches, reach, rows, height, max_motion_rows=32, exch
         exchanges[0 if w < 0 else seg_of[w] + 1].append((key, h))
     for s in range(len(starts)):
         plan.steps.append((exchanges[s], bounds[s], bounds[s + 1] - bounds[s]))
+        # leading dispatches of the segment that neither read nor write a plane of this exchange: they can run while the transfers are in flight
+        keys = {key for key, _ in exchanges[s]}
+        early = 0
+        for i in range(bounds[s], bounds[s + 1]):
+            if any((int(t), idx) in keys for dt, t, idx in dispatches[i].resources):
+                break
+            early += 1
+        plan.early.append(early if keys else 0)
     plan.row_begin = [-1 if i in whole_frame else max(rb - margins[i], 0) for i in range(n)]
     plan.row_end = [height if i in whole_frame else min(re + margins[i], height) for i in range(n)]
     return plan
@@ -179,13 +188,15 @@ def halo_transfers(rows, rank, world, items):
     return ops
 
 
-def exchange_halos(planes, rows, rank, world, items, group=None):
-    """planes: list of 2D uint8 tensors [H, pitch]; items: [(index into planes, width)]. One grouped batch of sends / receives."""
+def start_halo_exchange(planes, rows, rank, world, items, group=None):
+    """planes: list of 2D uint8 tensors [H, pitch]; items: [(index into planes, width)]. Issues one grouped batch of sends / receives and
+    returns the pending requests: over RCCL the transfers then run on the communicator's stream, next to whatever the caller launches on the
+    compute stream until it calls finish_halo_exchange (which only makes the compute stream wait -- the host does not block)."""
     import torch.distributed as dist
 
     transfers = halo_transfers(rows, rank, world, items)
     if not transfers:
-        return
+        return None
     staged = planes[0].is_cuda and dist.get_backend(group) != "nccl"  # gloo moves host memory: stage the bands (tests: two ranks sharing one GPU)
     ops, landing = [], []
     for k, kind, peer, r0, r1 in transfers:
@@ -196,10 +207,21 @@ def exchange_halos(planes, rows, rank, world, items, group=None):
                 landing.append((band, host))
             band = host
         ops.append(dist.P2POp(dist.isend if kind == "send" else dist.irecv, band, peer, group))
-    for req in dist.batch_isend_irecv(ops):
+    return dist.batch_isend_irecv(ops), landing
+
+
+def finish_halo_exchange(pending):
+    if pending is None:
+        return
+    requests, landing = pending
+    for req in requests:
         req.wait()
     for band, host in landing:
         band.copy_(host)
+
+
+def exchange_halos(planes, rows, rank, world, items, group=None):
+    finish_halo_exchange(start_halo_exchange(planes, rows, rank, world, items, group))
 
 
 def carried_over_planes(dispatches, small_planes=()):
@@ -345,15 +367,18 @@ class HaloSharder:
         _, first, count = plan.steps[step]
         self.ex.execute_range(ptr, n, first, count, plan.row_begin, plan.row_end)
 
-    def exchange_step(self, plan, step):
+    def start_exchange(self, plan, step):
         items = plan.steps[step][0]
         if not items or self.world == 1:
-            return
+            return None
         planes = [self.plane_tensor(key) for key, _ in items]
         pairs = [(k, min(w, planes[k].shape[0])) for k, (_, w) in enumerate(items)]
-        exchange_halos(planes, self.rows, self.rank, self.world, pairs, self.group)
         for k, w in pairs:
             self.exchanged_bytes += planes[k].shape[1] * w * ((self.rank > 0) + (self.rank < self.world - 1))
+        return start_halo_exchange(planes, self.rows, self.rank, self.world, pairs, self.group)
+
+    def exchange_step(self, plan, step):
+        finish_halo_exchange(self.start_exchange(plan, step))
 
     def complete_planes(self, keys):
         """every rank receives every other rank's strip of the given planes (before an unsharded frame that follows a sharded one)"""
@@ -383,8 +408,13 @@ class HaloSharder:
             self.complete_planes(plan.complete_keys)
             self.ex.execute_range(ptr, n, 0, n)
         else:
-            for step in range(len(plan.steps)):
-                self.exchange_step(plan, step)
-                self.run_step(plan, ptr, n, step)
+            for step, (_, first, count) in enumerate(plan.steps):
+                # the passes in front of the first reader of an exchanged plane (tile classification, pre-pass: user inputs only) hide the transfers
+                pending = self.start_exchange(plan, step)
+                early = plan.early[step] if pending is not None else 0
+                if early:
+                    self.ex.execute_range(ptr, n, first, early, plan.row_begin, plan.row_end)
+                finish_halo_exchange(pending)
+                self.ex.execute_range(ptr, n, first + early, count - early, plan.row_begin, plan.row_end)
         self.finish_frame(plan)
         return plan
