@@ -349,6 +349,7 @@ class HaloSharder:
             widest = max((w for items, _, _ in plan.steps for _, w in items), default=0)
             cost = self._tile_row_cost()
             new = balanced_bounds(cost, self.height, self.world, max(widest, 16)) if cost else None
+            new = self._agree(new)
             if new and new != self.bounds:
                 old, self.bounds = self.bounds, new
                 replanned = make_plan()
@@ -359,6 +360,20 @@ class HaloSharder:
                     self.rebalanced += 1
         plan.complete_keys = carried_over_planes(dispatches, small) if plan.fallback and not self.complete and self.world > 1 else []
         return plan, ptr, n
+
+    def _agree(self, bounds):
+        """Every rank derives the same strips from the same tile map; rank 0's answer is nevertheless broadcast (a few bytes, only on the frame
+        after an unsharded one) so that a rank that somehow disagreed cannot desynchronise the transfer schedule."""
+        import torch
+        import torch.distributed as dist
+
+        if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(self.group) != self.world:
+            return bounds  # virtual ranks of the single-process tests
+        device = "cuda" if dist.get_backend(self.group) == "nccl" else "cpu"
+        t = torch.tensor(bounds if bounds else [-1] * (self.world + 1), dtype=torch.int64, device=device)
+        dist.broadcast(t, 0, self.group)
+        agreed = [int(v) for v in t.tolist()]
+        return agreed if agreed[0] == 0 else None
 
     def finish_frame(self, plan):
         self.complete = plan.fallback or self.world == 1
