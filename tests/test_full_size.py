@@ -1,0 +1,162 @@
+"""The HIP path at BASELINE.json's full sizes (1440p REBLUR, 4K RELAX, 1080p SIGMA): the oracle would need minutes there, so the results are held to
+size-independent properties of the chain (SURVEY.md section 8c known answers): constants are fixed points of the normalised filters, an
+all-sky frame and splitScreen >= 1 leave / pass the data untouched, the accumulated-frame counters count 1, 2, 3, ... on a static scene, the
+denoised mean equals the noisy mean while the variance drops, a frame cut into row strips (virtual ranks with halo exchange) equals the
+uncut frame bit for bit, and REFERENCE is the running mean evaluated in fp32."""
+import numpy as np
+import pytest
+import torch
+
+import parity
+from raytracingdenoiser_amd import api, sharding
+
+RT = api.ResourceType
+pytestmark = pytest.mark.gpu
+
+
+def _run(name, seq, w, h, overrides=None, cs_kw=None, every_frame=None):
+    run = parity.HipRun(name, w, h)
+    for f, frame in enumerate(seq):
+        cs = parity.common_settings(frame["camera"], seq[max(f - 1, 0)]["camera"], w, h, f, **(cs_kw or {}))
+        run.step(frame, cs, parity.denoiser_settings(name, frame, overrides))
+        if every_frame:
+            every_frame(f, run)
+    torch.cuda.synchronize()
+    return run
+
+
+@pytest.mark.parametrize("name,size,keys", [("REBLUR_DIFFUSE_SPECULAR", (2560, 1440), ("diff", "spec")), ("RELAX_DIFFUSE_SPECULAR", (3840, 2160), ("diff_relax", "spec_relax"))])
+def test_constant_signal_is_a_fixed_point_at_full_size(name, size, keys):
+    w, h = size
+    seq = parity.generate_sequence(name, w, h, 4, static_camera=True, noise=False, device="cuda")
+    const = torch.tensor([0.5, 0.0625, -0.03125, 0.25] if name.startswith("REBLUR") else [0.5, 0.25, 0.125, 2.0], dtype=torch.float16, device="cuda")
+    for fr in seq:
+        for k in keys:
+            fr[k] = const.expand(h, w, 4).contiguous()
+    run = _run(name, seq, w, h)
+    m = ~seq[-1]["is_sky"].cpu().numpy()
+    for rt in run.outs:
+        out = run.output(rt)[m]
+        assert np.max(np.abs(out[:, :3] - const.float().cpu().numpy()[:3])) < 4e-3, rt  # weighted means of a constant, up to fp16 storage rounding
+
+
+@pytest.mark.parametrize("name,size", [("REBLUR_DIFFUSE_SPECULAR", (2560, 1440)), ("RELAX_DIFFUSE_SPECULAR_SH", (3840, 2160)), ("SIGMA_SHADOW", (1920, 1080))])
+def test_all_sky_and_split_screen_at_full_size(name, size):
+    w, h = size
+    seq = parity.generate_sequence(name, w, h, 2, device="cuda")
+    sky = [dict(fr, viewz=torch.full_like(fr["viewz"], 1.0e6)) for fr in seq]
+    run = _run(name, sky, w, h)
+    for rt in run.outs:
+        assert not run.output(rt).any() or name.startswith("SIGMA")  # sky pixels are never written (cleared on the restart frame)
+    run = _run(name, seq, w, h, cs_kw=dict(splitScreen=1.0))
+    m = ~seq[-1]["is_sky"].cpu().numpy()
+    if name.startswith("REBLUR"):
+        assert np.array_equal(run.output(RT.OUT_DIFF_RADIANCE_HITDIST)[m], seq[-1]["diff"].float().cpu().numpy()[m])
+        assert np.array_equal(run.output(RT.OUT_SPEC_RADIANCE_HITDIST)[m], seq[-1]["spec"].float().cpu().numpy()[m])
+    elif name.startswith("RELAX"):
+        assert np.array_equal(run.output(RT.OUT_DIFF_SH1)[m], seq[-1]["diff_relax_sh1"].float().cpu().numpy()[m])  # SH1 passes through unchanged (SH0 goes to YCoCg)
+
+
+def test_accumulated_frames_count_up_at_full_size():
+    name, (w, h) = "REBLUR_DIFFUSE_SPECULAR", (2560, 1440)
+    seq = parity.generate_sequence(name, w, h, 6, static_camera=True, noise=False, device="cuda")
+    m = ~seq[0]["is_sky"].cpu().numpy()
+
+    def check(f, run):
+        raw, fmt, pw = run.ex.read_pool_plane(RT.PERMANENT_POOL, 2)  # PREV_INTERNAL_DATA (R16_UINT): 6 + 6 bits of accumulated frames
+        packed = raw[:, : pw * 2].copy().view(np.uint16)
+        assert np.median((packed & 63)[m]) == f + 1 and np.median(((packed >> 6) & 63)[m]) == f + 1
+
+    _run(name, seq, w, h, every_frame=check)
+
+
+@pytest.mark.parametrize("name,size,pairs", [
+    ("REBLUR_DIFFUSE_SPECULAR", (2560, 1440), ((RT.OUT_DIFF_RADIANCE_HITDIST, "diff"), (RT.OUT_SPEC_RADIANCE_HITDIST, "spec"))),
+    ("RELAX_DIFFUSE_SPECULAR", (3840, 2160), ((RT.OUT_DIFF_RADIANCE_HITDIST, "diff_relax"), (RT.OUT_SPEC_RADIANCE_HITDIST, "spec_relax"))),
+])
+def test_mean_is_kept_and_noise_drops_at_full_size(name, size, pairs):
+    w, h = size
+    seq = parity.generate_sequence(name, w, h, 8, device="cuda")
+    run = _run(name, seq, w, h)
+    m = ~seq[-1]["is_sky"].cpu().numpy()
+    for rt, key in pairs:
+        out, noisy = run.output(rt)[m][:, 0], seq[-1][key].float().cpu().numpy()[m][:, 0]
+        assert not np.isnan(out).any()
+        assert abs(out.mean() - noisy.mean()) < 0.03 * noisy.mean() and out.std() < 0.9 * noisy.std()
+
+
+def test_row_strips_equal_the_whole_frame_at_full_size():
+    """4 virtual ranks (halo exchange emulated by copies, strips re-cut from the tile map) at 1440p == the uncut frame, every output, every frame"""
+    from test_sharding import _local_exchange
+
+    from raytracingdenoiser_amd.executor import HipExecutor
+
+    name, (w, h), world = "REBLUR_DIFFUSE_SPECULAR", (2560, 1440), 4
+    seq = parity.generate_sequence(name, w, h, 4, device="cuda")
+
+    def make():
+        inst = api.Instance([(0, parity.DENOISERS[name][0])])
+        ex = HipExecutor(inst, w, h)
+        outs = []
+        for rt, dtype, ch, fmt in parity.output_planes(name, w, h):
+            outs.append(torch.zeros((h, w, ch), dtype=dtype, device="cuda"))
+            ex.bind(rt, outs[-1], fmt)
+        return inst, ex, outs
+
+    def prepare(inst, ex, f, frame):
+        for rt, t, fmt in parity.user_planes(name, frame):
+            ex.bind(rt, t, fmt)
+        inst.set_denoiser_settings(0, parity.denoiser_settings(name, frame))
+        assert inst.set_common_settings(parity.common_settings(frame["camera"], seq[max(f - 1, 0)]["camera"], w, h, f)) == api.Result.SUCCESS
+
+    ref = make()
+    runs = [make() for _ in range(world)]
+    ranks = [sharding.HaloSharder(ex, inst, w, h, r, world) for r, (inst, ex, outs) in enumerate(runs)]
+    for f, frame in enumerate(seq):
+        prepare(ref[0], ref[1], f, frame)
+        ref[1].denoise()
+        begun = []
+        for (inst, ex, outs), sh in zip(runs, ranks):
+            prepare(inst, ex, f, frame)
+            begun.append(sh.begin_frame())
+        plans = [b[0] for b in begun]
+        assert plans[0].fallback == (f == 0)
+        if plans[0].fallback:
+            for sh, (plan, ptr, n) in zip(ranks, begun):
+                sh.ex.execute_range(ptr, n, 0, n)
+        else:
+            for step in range(len(plans[0].steps)):
+                torch.cuda.synchronize()
+                _local_exchange(ranks, plans, step)
+                for sh, (plan, ptr, n) in zip(ranks, begun):
+                    sh.run_step(plan, ptr, n, step)
+        for sh, plan in zip(ranks, plans):
+            sh.finish_frame(plan)
+        torch.cuda.synchronize()
+        for (inst, ex, outs), sh in zip(runs, ranks):
+            rb, re = sh.rows
+            assert all(torch.equal(o[rb:re], ro[rb:re]) for o, ro in zip(outs, ref[2])), (f, sh.rank)
+    assert ranks[0].rebalanced == 1 and ranks[0].bounds[1] > h // world  # the sky strip at the top grew
+
+
+def test_reference_is_the_fp32_running_mean_at_full_size():
+    from raytracingdenoiser_amd.executor import HipExecutor
+
+    w, h, frames = 2560, 1440, 5
+    inst = api.Instance([(0, api.Denoiser.REFERENCE)])
+    ex = HipExecutor(inst, w, h)
+    out = torch.zeros((h, w, 4), dtype=torch.float32, device="cuda")
+    ex.bind(RT.OUT_SIGNAL, out, api.Format.RGBA32_SFLOAT)
+    g = torch.Generator(device="cuda").manual_seed(1)
+    mean = torch.zeros((h, w, 4), dtype=torch.float32, device="cuda")
+    cam = __import__("raytracingdenoiser_amd.synth", fromlist=["Camera"]).Camera(w, h, 0, static=True)
+    for f in range(frames):
+        x = torch.rand((h, w, 4), generator=g, dtype=torch.float32, device="cuda")
+        ex.bind(RT.IN_SIGNAL, x, api.Format.RGBA32_SFLOAT)
+        assert inst.set_denoiser_settings(0, api.ReferenceSettings()) == api.Result.SUCCESS
+        assert inst.set_common_settings(parity.common_settings(cam, cam, w, h, f)) == api.Result.SUCCESS
+        ex.denoise()
+        a = torch.tensor(1.0 / (1.0 + f), dtype=torch.float32, device="cuda")
+        mean = mean + (x - mean) * a  # lerp(history, input, 1 / (1 + N)) with the reference's operation order (reference Reference.hpp:73, REFERENCE_TemporalAccumulation.cs.hlsl:24)
+        torch.cuda.synchronize()
+        assert torch.equal(out, mean), f
