@@ -95,8 +95,9 @@ class HipExecutor:
 
     def execute_range(self, dispatch_ptr, num, first, count, row_begin=None, row_end=None):
         """dispatches [first, first + count) of the list; row_begin / row_end: per-dispatch rows to produce (lists of length num) or None"""
-        rb = (C.c_int32 * num)(*row_begin) if row_begin is not None else None
-        re = (C.c_int32 * num)(*row_end) if row_end is not None else None
+        # lists are converted per call; a caller on a hot path passes ready-made ctypes arrays (sharding.HaloPlan.c_rows)
+        rb = row_begin if row_begin is None or isinstance(row_begin, C.Array) else (C.c_int32 * num)(*row_begin)
+        re = row_end if row_end is None or isinstance(row_end, C.Array) else (C.c_int32 * num)(*row_end)
         self._check(self.lib.nrdHipExecuteDispatchRange(self.handle, C.cast(dispatch_ptr, C.c_void_p), num, first, count, rb, re), "nrdHipExecuteDispatchRange")
 
     def set_owned_rows(self, row_begin, row_end):

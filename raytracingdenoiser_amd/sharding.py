@@ -96,6 +96,17 @@ class HaloPlan:
         self.row_begin, self.row_end = [], []
         self.margins, self.reach = [], []
         self.early = []            # per step: leading dispatches that do not touch the exchanged planes (run during the transfers)
+        self.complete_keys = []
+        self._c_rows = None        # ctypes copies of row_begin / row_end (made once: plans are cached and reused every other frame)
+        self._ops = {}             # step -> (plane addresses, P2POp list, bytes received): the transfer batch, rebuilt only if a plane moved
+
+    def c_rows(self):
+        import ctypes as C
+
+        if self._c_rows is None:
+            n = len(self.row_begin)
+            self._c_rows = ((C.c_int32 * n)(*self.row_begin), (C.c_int32 * n)(*self.row_end))
+        return self._c_rows
 
 
 def _is_user_input(resource_type):
@@ -290,6 +301,7 @@ class HaloSharder:
         self.complete = True      # every plane is complete on this rank: fresh (zeroed) arena, or the last frame ran unsharded
         self.exchanged_bytes = 0  # received bytes, for reporting
         self.rebalanced = 0
+        self._plans = {}
 
     @property
     def rows(self):
@@ -336,10 +348,21 @@ class HaloSharder:
         carries plan.complete_keys: the carried-over planes every rank has to receive in full before the frame runs."""
         from . import api
 
+        import ctypes as C
+
         r, ptr, n = self.inst.get_compute_dispatches_raw()
         assert r == api.Result.SUCCESS, r
+        reach = self.inst.dispatch_reach(ptr, n)
+        # The plan depends on which planes each pass binds (ping-pong: period 2) and on the reach, not on the per-frame constants: steady-state
+        # frames hit this cache and skip the Python-side parsing and planning (~0.3 ms, as much as a strip's GPU time at 8 ranks).
+        signature = (tuple(self.bounds) if self.bounds else None, tuple(reach),
+                     tuple((ptr[i].pipelineIndex, C.string_at(C.addressof(ptr[i].resources.contents), ptr[i].resourcesNum * C.sizeof(api.ResourceDesc)) if ptr[i].resourcesNum else b"")
+                           for i in range(n)))
+        cached = self._plans.get(signature)
+        if cached is not None and not cached.fallback and not self.complete:
+            return cached, ptr, n
         dispatches = [api.Dispatch(ptr[i], self.inst.pipelines) for i in range(n)]
-        small, reach = self._small_planes(), self.inst.dispatch_reach(ptr, n)
+        small = self._small_planes()
 
         def make_plan():
             return plan_halo_exchange(dispatches, reach, self.rows, self.height, self.max_motion_rows, self.exchange_threshold, small, self.min_strip)
@@ -359,6 +382,10 @@ class HaloSharder:
                     plan = replanned
                     self.rebalanced += 1
         plan.complete_keys = carried_over_planes(dispatches, small) if plan.fallback and not self.complete and self.world > 1 else []
+        if not plan.fallback:
+            if len(self._plans) > 16:
+                self._plans.clear()
+            self._plans[(tuple(self.bounds) if self.bounds else None,) + signature[1:]] = plan  # keyed by the strips actually used (they may just have been re-cut)
         return plan, ptr, n
 
     def _agree(self, bounds):
@@ -380,17 +407,31 @@ class HaloSharder:
 
     def run_step(self, plan, ptr, n, step):
         _, first, count = plan.steps[step]
-        self.ex.execute_range(ptr, n, first, count, plan.row_begin, plan.row_end)
+        self.ex.execute_range(ptr, n, first, count, *plan.c_rows())
 
     def start_exchange(self, plan, step):
         items = plan.steps[step][0]
         if not items or self.world == 1:
             return None
+        import torch.distributed as dist
+
         planes = [self.plane_tensor(key) for key, _ in items]
+        where = tuple(p.data_ptr() for p in planes)
+        cached = plan._ops.get(step)
+        if cached is not None and cached[0] == where:  # same planes at the same addresses as last time: reissue the same batch
+            self.exchanged_bytes += cached[2]
+            return dist.batch_isend_irecv(cached[1]), []
         pairs = [(k, min(w, planes[k].shape[0])) for k, (_, w) in enumerate(items)]
-        for k, w in pairs:
-            self.exchanged_bytes += planes[k].shape[1] * w * ((self.rank > 0) + (self.rank < self.world - 1))
-        return start_halo_exchange(planes, self.rows, self.rank, self.world, pairs, self.group)
+        received = sum(planes[k].shape[1] * w * ((self.rank > 0) + (self.rank < self.world - 1)) for k, w in pairs)
+        self.exchanged_bytes += received
+        if planes[0].is_cuda and dist.get_backend(self.group) != "nccl":
+            return start_halo_exchange(planes, self.rows, self.rank, self.world, pairs, self.group)  # host-staged (tests): nothing to reuse
+        ops = [dist.P2POp(dist.isend if kind == "send" else dist.irecv, planes[k][r0:r1], peer, self.group)
+               for k, kind, peer, r0, r1 in halo_transfers(self.rows, self.rank, self.world, pairs)]
+        if not ops:
+            return None
+        plan._ops[step] = (where, ops, received)
+        return dist.batch_isend_irecv(ops), []
 
     def exchange_step(self, plan, step):
         finish_halo_exchange(self.start_exchange(plan, step))
@@ -428,8 +469,8 @@ class HaloSharder:
                 pending = self.start_exchange(plan, step)
                 early = plan.early[step] if pending is not None else 0
                 if early:
-                    self.ex.execute_range(ptr, n, first, early, plan.row_begin, plan.row_end)
+                    self.ex.execute_range(ptr, n, first, early, *plan.c_rows())
                 finish_halo_exchange(pending)
-                self.ex.execute_range(ptr, n, first + early, count - early, plan.row_begin, plan.row_end)
+                self.ex.execute_range(ptr, n, first + early, count - early, *plan.c_rows())
         self.finish_frame(plan)
         return plan
