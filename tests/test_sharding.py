@@ -140,6 +140,20 @@ def _halo_gloo_worker(rank, world, port, q):
         lo, hi = max(rows[0] - w, 0), min(rows[1] + w, h)
         ok &= torch.equal(p[lo:hi], t[lo:hi])                                        # own strip + halos are now correct
         ok &= bool((p[:lo] == 255).all()) and bool((p[hi:] == 255).all())            # nothing else was touched
+    # the sharder's own transfer path: the batch is built once per plan step and reissued from the cache on later frames (the RCCL hot path)
+    sh = sharding.HaloSharder(None, None, 64, h, rank, world, balance=False)
+    sh.plane_tensor = lambda key: planes[key[1]]
+    plan = sharding.HaloPlan()
+    plan.steps = [([((0, 0), 5), ((0, 1), 16)], 0, 1)]
+    for frame in range(3):
+        for p, t in zip(planes, truth):
+            p.fill_(255)
+            p[rows[0]:rows[1]] = t[rows[0]:rows[1]] + frame  # new data every frame (uint8 wrap-around is fine)
+        sharding.finish_halo_exchange(sh.start_exchange(plan, 0))
+        for p, t, w in zip(planes, truth, (5, 16)):
+            lo, hi = max(rows[0] - w, 0), min(rows[1] + w, h)
+            ok &= torch.equal(p[lo:hi], t[lo:hi] + frame)
+        ok &= (0 in plan._ops) == (world > 1)
     q.put((rank, ok))
     dist.destroy_process_group()
 
