@@ -90,6 +90,31 @@ uint32_t nrdHipGetDispatchReach(void* instance, const void* dispatchDescs, uint3
 uint32_t nrdHipExecuteDispatchRange(NrdHipExecutor* executor, const void* dispatchDescs, uint32_t dispatchDescsNum, uint32_t first, uint32_t count, const int32_t* rowBegin,
     const int32_t* rowEnd);
 
+// The halo-exchange plan of one dispatch list for rank `rank` of `world` ranks owning the row strips [stripBounds[r], stripBounds[r + 1]) (host-only,
+// no device needed; the C++ counterpart of raytracingdenoiser_amd/sharding.py plan_halo_exchange, for hosts that drive RCCL themselves):
+//   steps[s]   dispatches [firstDispatch, firstDispatch + dispatchCount) run between two exchanges; before them the rank sends / receives, for each of
+//              items[firstItem .. firstItem + itemCount), `widthRows` rows on either side of its strip boundaries to / from ranks rank - 1 and rank + 1
+//              (send its own top / bottom rows, receive into the rows just above / below its strip); the first `earlyCount` dispatches of the step touch
+//              none of these planes and may run while the transfers are in flight
+//   rowBegin / rowEnd (length dispatchDescsNum)   the rows every dispatch has to produce, ready for nrdHipExecuteDispatchRange (-1 = whole frame)
+//   info->fallback = 1   the list cannot be sharded (unknown reach, halo wider than a strip): every rank runs the whole frame, after having received
+//                        the other ranks' strips of the carried-over planes if the previous frame was sharded
+// Returns INVALID_ARGUMENT with info->stepsNum / itemsNum set when the capacities are too small.
+typedef struct NrdHipHaloItem {
+    uint32_t resourceType; // nrd::ResourceType: TRANSIENT_POOL / PERMANENT_POOL (+ indexInPool) or an OUT_* slot doubling as history
+    uint32_t indexInPool;
+    uint32_t widthRows;
+} NrdHipHaloItem;
+typedef struct NrdHipHaloStep {
+    uint32_t firstDispatch, dispatchCount, earlyCount, firstItem, itemCount;
+} NrdHipHaloStep;
+typedef struct NrdHipHaloPlanInfo {
+    uint32_t fallback, stepsNum, itemsNum;
+} NrdHipHaloPlanInfo;
+uint32_t nrdHipPlanHaloExchange(void* instance, const void* dispatchDescs, uint32_t dispatchDescsNum, const uint32_t* stripBounds, uint32_t world, uint32_t rank, uint32_t height,
+    uint32_t maxMotionRows, uint32_t exchangeThreshold, int32_t* rowBegin, int32_t* rowEnd, NrdHipHaloStep* steps, uint32_t stepsCapacity, NrdHipHaloItem* items, uint32_t itemsCapacity,
+    NrdHipHaloPlanInfo* info);
+
 // Per-pass GPU timing. When enabled, every dispatch is bracketed by hipEvents on the executor's stream.
 // nrdHipCollectPassTimings synchronises the stream, folds all brackets recorded since the last collect into per-pipeline
 // totals and returns the number of pipelines written: pipelineIndices[i] (index into InstanceDesc::pipelines),

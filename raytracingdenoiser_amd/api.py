@@ -251,10 +251,22 @@ class HipPlaneDesc(C.Structure):
 # every symbol the headers declare; tests assert each one resolves
 NRD_SYMBOLS = ["CreateInstance", "DestroyInstance", "GetLibraryDesc", "GetInstanceDesc", "SetCommonSettings", "SetDenoiserSettings",
                "GetComputeDispatches", "GetResourceTypeString", "GetDenoiserString"]
+class HipHaloItem(C.Structure):  # include/NRDHip.h NrdHipHaloItem
+    _fields_ = [("resourceType", C.c_uint32), ("indexInPool", C.c_uint32), ("widthRows", C.c_uint32)]
+
+
+class HipHaloStep(C.Structure):
+    _fields_ = [("firstDispatch", C.c_uint32), ("dispatchCount", C.c_uint32), ("earlyCount", C.c_uint32), ("firstItem", C.c_uint32), ("itemCount", C.c_uint32)]
+
+
+class HipHaloPlanInfo(C.Structure):
+    _fields_ = [("fallback", C.c_uint32), ("stepsNum", C.c_uint32), ("itemsNum", C.c_uint32)]
+
+
 NRD_HIP_SYMBOLS = ["nrdHipCreateExecutor", "nrdHipDestroyExecutor", "nrdHipBindResource", "nrdHipGetPoolPlane", "nrdHipExecuteDispatches",
                    "nrdHipDenoise", "nrdHipGetPoolMemoryUsage", "nrdHipGetLastError", "nrdHipEvalNumerics", "nrdHipGetArenaSize",
                    "nrdHipCreateExecutorWithArena", "nrdHipSetProfiling", "nrdHipCollectPassTimings", "nrdHipSetOwnedRows", "nrdHipGetDispatchReach",
-                   "nrdHipExecuteDispatchRange"]
+                   "nrdHipExecuteDispatchRange", "nrdHipPlanHaloExchange"]
 
 _lib = None
 
@@ -297,6 +309,9 @@ def load_library(path=None):
     lib.nrdHipGetDispatchReach.argtypes, lib.nrdHipGetDispatchReach.restype = [C.c_void_p, C.c_void_p, C.c_uint32, C.POINTER(C.c_int32)], C.c_uint32
     lib.nrdHipExecuteDispatchRange.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]
     lib.nrdHipExecuteDispatchRange.restype = C.c_uint32
+    lib.nrdHipPlanHaloExchange.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, P(C.c_uint32), C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, P(C.c_int32), P(C.c_int32),
+                                           P(HipHaloStep), C.c_uint32, P(HipHaloItem), C.c_uint32, P(HipHaloPlanInfo)]
+    lib.nrdHipPlanHaloExchange.restype = C.c_uint32
     lib.nrdHipSetProfiling.argtypes, lib.nrdHipSetProfiling.restype = [C.c_void_p, C.c_uint32], C.c_uint32
     lib.nrdHipCollectPassTimings.argtypes = [C.c_void_p, P(C.c_uint32), P(C.c_double), P(C.c_uint32), C.c_uint32, P(C.c_uint32)]
     lib.nrdHipCollectPassTimings.restype = C.c_uint32
@@ -369,6 +384,19 @@ class Instance:
         r = Result(self.lib.nrdHipGetDispatchReach(self.handle, C.cast(dispatch_ptr, C.c_void_p), num, out))
         assert r == Result.SUCCESS, r
         return list(out[:num])
+
+    def plan_halo_exchange(self, dispatch_ptr, num, strip_bounds, rank, height, max_motion_rows=32, exchange_threshold=24):
+        """nrdHipPlanHaloExchange: (fallback, steps [(items [((type, index), width)], first, count, early)], row_begin, row_end)"""
+        world = len(strip_bounds) - 1
+        bounds = (C.c_uint32 * (world + 1))(*strip_bounds)
+        rb, re = (C.c_int32 * max(num, 1))(), (C.c_int32 * max(num, 1))()
+        steps, items, info = (HipHaloStep * 64)(), (HipHaloItem * 1024)(), HipHaloPlanInfo()
+        r = Result(self.lib.nrdHipPlanHaloExchange(self.handle, C.cast(dispatch_ptr, C.c_void_p), num, bounds, world, rank, height, max_motion_rows, exchange_threshold, rb, re, steps, 64,
+                                                   items, 1024, C.byref(info)))
+        assert r == Result.SUCCESS, r
+        out = [([((items[k].resourceType, items[k].indexInPool), items[k].widthRows) for k in range(st.firstItem, st.firstItem + st.itemCount)], st.firstDispatch, st.dispatchCount,
+                st.earlyCount) for st in steps[: info.stepsNum]]
+        return bool(info.fallback), out, list(rb[:num]), list(re[:num])
 
     def get_compute_dispatches(self, identifiers=None):
         r, out, num = self.get_compute_dispatches_raw(identifiers)

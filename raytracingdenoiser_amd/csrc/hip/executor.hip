@@ -14,6 +14,7 @@
 #include <cstdio>
 #include <cstring>
 #include <string>
+#include <map>
 #include <vector>
 
 using namespace nrdhip;
@@ -407,6 +408,150 @@ extern "C" __attribute__((visibility("default"))) uint32_t nrdHipGetDispatchReac
     for (uint32_t i = 0; i < dispatchDescsNum; i++) {
         const nrd::DispatchDesc& d = descs[i];
         reachRows[i] = d.pipelineIndex < idesc.pipelinesNum ? PassReachRows(idesc.pipelines[d.pipelineIndex].shaderFileName, d.constantBufferData, d.constantBufferDataSize) : -1;
+    }
+    return (uint32_t)nrd::Result::SUCCESS;
+}
+
+// Halo-exchange plan of one dispatch list for one rank (include/NRDHip.h). The same algorithm as raytracingdenoiser_amd/sharding.py
+// plan_halo_exchange (tests/test_sharding.py holds the two against each other): segments start in front of every pass whose reach exceeds
+// the threshold; margins accumulate backwards from 0 at each segment end; a plane read from an earlier segment (or carried over from the
+// previous frame: widened by the motion bound) is exchanged in front of the reader's segment.
+extern "C" __attribute__((visibility("default"))) uint32_t nrdHipPlanHaloExchange(void* instance, const void* dispatchDescs, uint32_t num, const uint32_t* stripBounds, uint32_t world, uint32_t rank,
+    uint32_t height, uint32_t maxMotionRows, uint32_t exchangeThreshold, int32_t* rowBegin, int32_t* rowEnd, NrdHipHaloStep* steps, uint32_t stepsCapacity, NrdHipHaloItem* items,
+    uint32_t itemsCapacity, NrdHipHaloPlanInfo* info) {
+    if (!instance || (!dispatchDescs && num) || !info || !stripBounds || world == 0 || rank >= world || (num && (!rowBegin || !rowEnd)))
+        return (uint32_t)nrd::Result::INVALID_ARGUMENT;
+    const nrd::DispatchDesc* descs = (const nrd::DispatchDesc*)dispatchDescs;
+    const nrd::InstanceDesc& idesc = nrd::GetInstanceDesc(*(nrd::Instance*)instance);
+    *info = NrdHipHaloPlanInfo{};
+    auto fallback = [&]() {
+        info->fallback = 1;
+        info->stepsNum = info->itemsNum = 0;
+        for (uint32_t i = 0; i < num; i++) {
+            rowBegin[i] = -1;
+            rowEnd[i] = (int32_t)height;
+        }
+        return (uint32_t)nrd::Result::SUCCESS;
+    };
+    std::vector<int> reach(num);
+    bool known = num != 0 && world > 1;
+    for (uint32_t i = 0; i < num; i++) {
+        const nrd::DispatchDesc& d = descs[i];
+        reach[i] = d.pipelineIndex < idesc.pipelinesNum ? PassReachRows(idesc.pipelines[d.pipelineIndex].shaderFileName, d.constantBufferData, d.constantBufferDataSize) : -1;
+        known = known && reach[i] >= 0;
+    }
+    if (!known)
+        return fallback();
+    const int rb = (int)stripBounds[rank], re = (int)stripBounds[rank + 1];
+    int per = INT_MAX; // a halo must fit into the neighbouring strips
+    for (uint32_t r = 0; r < world; r++)
+        per = std::min(per, (int)stripBounds[r + 1] - (int)stripBounds[r]);
+
+    std::vector<uint32_t> starts(1, 0);
+    for (uint32_t i = 1; i < num; i++)
+        if (reach[i] > (int)exchangeThreshold)
+            starts.push_back(i);
+    std::vector<uint32_t> bounds(starts);
+    bounds.push_back(num);
+    std::vector<int> segOf(num), margins(num);
+    for (size_t s = 0; s < starts.size(); s++) {
+        int m = 0;
+        for (int i = (int)bounds[s + 1] - 1; i >= (int)bounds[s]; i--) {
+            segOf[i] = (int)s;
+            margins[i] = m;
+            m += reach[i];
+        }
+    }
+    typedef std::pair<uint32_t, uint32_t> Key; // (resource type, index in pool)
+    auto isUserInput = [](nrd::ResourceType t) { return (uint32_t)t < (uint32_t)nrd::ResourceType::OUT_DIFF_RADIANCE_HITDIST; };
+    auto isSmall = [&](const Key& k) { // down-sampled pool planes (tile maps): complete on every rank, never exchanged
+        if (k.first == (uint32_t)nrd::ResourceType::TRANSIENT_POOL)
+            return k.second < idesc.transientPoolSize && idesc.transientPool[k.second].downsampleFactor != 1;
+        if (k.first == (uint32_t)nrd::ResourceType::PERMANENT_POOL)
+            return k.second < idesc.permanentPoolSize && idesc.permanentPool[k.second].downsampleFactor != 1;
+        return false;
+    };
+    std::map<Key, int> lastWrite;
+    std::map<std::pair<Key, int>, int> need; // (plane, writer index or -1) -> halo rows
+    std::vector<char> wholeFrame(num, 0);
+    for (uint32_t i = 0; i < num; i++) {
+        const nrd::DispatchDesc& d = descs[i];
+        std::vector<Key> reads, writes;
+        bool writesSmall = false, writesLarge = false;
+        for (uint32_t r = 0; r < d.resourcesNum; r++) {
+            const nrd::ResourceDesc& res = d.resources[r];
+            if (isUserInput(res.type))
+                continue;
+            const Key key((uint32_t)res.type, res.indexInPool);
+            if (res.descriptorType == nrd::DescriptorType::TEXTURE) {
+                if (!isSmall(key))
+                    reads.push_back(key);
+            } else {
+                writes.push_back(key);
+                (isSmall(key) ? writesSmall : writesLarge) = true;
+            }
+        }
+        if (writesSmall) {
+            wholeFrame[i] = 1;
+            if (writesLarge || !reads.empty())
+                return fallback(); // a tile-map pass that also touches full-resolution planes: not expected, stay safe
+            continue;
+        }
+        for (const Key& key : reads) {
+            auto it = lastWrite.find(key);
+            const int w = it == lastWrite.end() ? -1 : it->second;
+            if (w >= 0 && segOf[w] == segOf[i])
+                continue; // produced in this segment with a sufficient margin
+            const int h = margins[i] + reach[i] + (w < 0 ? (int)maxMotionRows : 0);
+            if (h > 0) {
+                int& slot = need[std::make_pair(key, w)];
+                slot = std::max(slot, h);
+            }
+        }
+        for (const Key& key : writes)
+            lastWrite[key] = (int)i;
+    }
+    for (const auto& kv : need)
+        if (kv.second > per)
+            return fallback(); // a halo would reach past the neighbouring strip
+
+    std::vector<std::vector<NrdHipHaloItem>> exchanges(starts.size());
+    for (const auto& kv : need) {
+        const int w = kv.first.second;
+        exchanges[w < 0 ? 0 : segOf[w] + 1].push_back(NrdHipHaloItem{kv.first.first.first, kv.first.first.second, (uint32_t)kv.second});
+    }
+    uint32_t itemsNum = 0;
+    for (const auto& e : exchanges)
+        itemsNum += (uint32_t)e.size();
+    info->stepsNum = (uint32_t)starts.size();
+    info->itemsNum = itemsNum;
+    if (info->stepsNum > stepsCapacity || itemsNum > itemsCapacity || (info->stepsNum && !steps) || (itemsNum && !items))
+        return (uint32_t)nrd::Result::INVALID_ARGUMENT; // info tells the capacities needed
+    uint32_t cursor = 0;
+    for (size_t s = 0; s < starts.size(); s++) {
+        NrdHipHaloStep& st = steps[s];
+        st.firstDispatch = bounds[s];
+        st.dispatchCount = bounds[s + 1] - bounds[s];
+        st.firstItem = cursor;
+        st.itemCount = (uint32_t)exchanges[s].size();
+        for (const NrdHipHaloItem& it : exchanges[s])
+            items[cursor++] = it;
+        // leading dispatches that touch none of the exchanged planes: they can run while the transfers are in flight
+        st.earlyCount = 0;
+        if (st.itemCount)
+            for (uint32_t i = bounds[s]; i < bounds[s + 1]; i++) {
+                bool touches = false;
+                for (uint32_t r = 0; r < descs[i].resourcesNum && !touches; r++)
+                    for (const NrdHipHaloItem& it : exchanges[s])
+                        touches = touches || (it.resourceType == (uint32_t)descs[i].resources[r].type && it.indexInPool == descs[i].resources[r].indexInPool);
+                if (touches)
+                    break;
+                st.earlyCount++;
+            }
+    }
+    for (uint32_t i = 0; i < num; i++) {
+        rowBegin[i] = wholeFrame[i] ? -1 : std::max(rb - margins[i], 0);
+        rowEnd[i] = wholeFrame[i] ? (int32_t)height : std::min(re + margins[i], (int)height);
     }
     return (uint32_t)nrd::Result::SUCCESS;
 }

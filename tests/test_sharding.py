@@ -203,6 +203,50 @@ def test_halo_plan_for_reblur_and_relax():
         assert all(plan.row_begin[i] == rb - plan.margins[i] and plan.row_end[i] == re + plan.margins[i] for i in others)
 
 
+@pytest.mark.parametrize("name,size,world,overrides,cs_kw", [
+    ("REBLUR_DIFFUSE_SPECULAR", (2560, 1440), 8, None, None),
+    ("REBLUR_DIFFUSE_SPECULAR", (2560, 1440), 4, dict(enablePerformanceMode=True, maxBlurRadius=12.0), None),
+    ("REBLUR_DIFFUSE_SPECULAR", (640, 360), 8, None, None),                                   # 45-row strips: the PostBlur halo does not fit -> unsharded
+    ("REBLUR_DIFFUSE_SPECULAR_OCCLUSION", (1920, 1080), 4, None, None),                        # the user's OUT planes are the history
+    ("REBLUR_DIFFUSE_SH", (1920, 1080), 3, dict(hitDistanceReconstructionMode=1), None),       # a pass of unknown reach -> unsharded
+    ("RELAX_DIFFUSE_SPECULAR_SH", (3840, 2160), 8, None, None),
+    ("RELAX_SPECULAR", (1920, 1080), 2, dict(atrousIterationNum=8), None),
+    ("RELAX_DIFFUSE", (1920, 1080), 2, dict(enableAntiFirefly=True), None),                    # the whole-plane history copy has no bounded reach -> unsharded
+    ("SIGMA_SHADOW", (1920, 1080), 4, None, None),
+])
+def test_c_planner_equals_python_planner(name, size, world, overrides, cs_kw):
+    """nrdHipPlanHaloExchange (the plan a C++ host uses to drive RCCL itself) against sharding.plan_halo_exchange, for every rank, uneven strips,
+    the restart frame and two steady-state frames (ping-pong)"""
+    import parity
+
+    w, h = size
+    inst = api.Instance([(0, parity.DENOISERS[name][0])])
+    seq = parity.generate_sequence(name, 32, 18, 3)
+    small = {(int(pool), i) for pool, descs in ((api.ResourceType.PERMANENT_POOL, inst.permanent_pool), (api.ResourceType.TRANSIENT_POOL, inst.transient_pool))
+             for i, (fmt, d) in enumerate(descs) if d != 1}
+    bounds = [0] + [(r * h // world) + (7 if r % 2 else -5) for r in range(1, world)] + [h]  # uneven on purpose
+    sharded = 0
+    for f in range(3):
+        inst.set_denoiser_settings(0, parity.denoiser_settings(name, seq[f], overrides))
+        assert inst.set_common_settings(parity.common_settings(seq[f]["camera"], seq[max(f - 1, 0)]["camera"], w, h, f, **(cs_kw or {}))) == api.Result.SUCCESS
+        r, ptr, n = inst.get_compute_dispatches_raw()
+        ds = [api.Dispatch(ptr[i], inst.pipelines) for i in range(n)]
+        reach = inst.dispatch_reach(ptr, n)
+        for rank in range(world):
+            want = sharding.plan_halo_exchange(ds, reach, (bounds[rank], bounds[rank + 1]), h, 32, 24, small, min(b - a for a, b in zip(bounds, bounds[1:])))
+            fallback, steps, row_begin, row_end = inst.plan_halo_exchange(ptr, n, bounds, rank, h, 32, 24)
+            assert fallback == want.fallback, (f, rank)
+            if fallback:
+                assert steps == [] and row_begin == [-1] * n and row_end == [h] * n
+                continue
+            sharded += 1
+            assert [(items, first, count) for items, first, count, early in steps] == [([(tuple(k), wd) for k, wd in items], first, count) for items, first, count in want.steps]
+            assert [early for *_, early in steps] == want.early
+            assert row_begin == want.row_begin and row_end == want.row_end
+    expect_sharded = name.startswith(("REBLUR", "RELAX")) and size != (640, 360) and not (overrides or {}).get("hitDistanceReconstructionMode") and not (overrides or {}).get("enableAntiFirefly")
+    assert (sharded == 2 * world) == expect_sharded and (sharded > 0) == expect_sharded
+
+
 def _local_exchange(ranks, plans, step):
     """what exchange_halos does over RCCL, emulated with copies between the executors of one process"""
     for r, (sh, plan) in enumerate(zip(ranks, plans)):
