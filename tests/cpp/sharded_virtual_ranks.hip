@@ -167,6 +167,7 @@ int main(int argc, char** argv) {
         cs.motionVectorScale[0] = cs.motionVectorScale[1] = cs.motionVectorScale[2] = 0.0f;
         cs.isMotionVectorInWorldSpace = true;
         cs.frameIndex = (uint32_t)f;
+        cs.timeDeltaBetweenFrames = 16.667f; // 0 would make every instance measure its own wall-clock frame time (frame-rate dependent constants)
         cs.accumulationMode = f == 0 ? nrd::AccumulationMode::CLEAR_AND_RESTART : nrd::AccumulationMode::CONTINUE;
         nrd::ReblurSettings rs = {};
         rs.maxBlurRadius = 10.0f; // halos that fit a 96-row strip
@@ -216,8 +217,18 @@ int main(int argc, char** argv) {
             for (uint32_t r = 0; r < world; r++) {
                 CHECK(hipMemcpy(got.data(), k ? planes[1 + r].outSpec : planes[1 + r].outDiff, texels * 8, hipMemcpyDeviceToHost) == hipSuccess);
                 const size_t b = (size_t)ranks[r]->GetOwnedRowBegin() * W * 4, e = (size_t)ranks[r]->GetOwnedRowEnd() * W * 4;
+                size_t bad = 0, firstRow = 0, lastRow = 0;
                 for (size_t i = b; i < e; i++)
-                    mismatches += ref[i] != got[i];
+                    if (ref[i] != got[i]) {
+                        if (!bad)
+                            firstRow = i / ((size_t)W * 4);
+                        lastRow = i / ((size_t)W * 4);
+                        bad++;
+                    }
+                if (bad && getenv("NRD_TEST_VERBOSE"))
+                    printf("  frame %d %s rank %u (rows %u..%u): %zu mismatching values in rows %zu..%zu\n", f, k ? "spec" : "diff", r, ranks[r]->GetOwnedRowBegin(), ranks[r]->GetOwnedRowEnd(), bad, firstRow,
+                        lastRow);
+                mismatches += bad;
             }
         }
         size_t nonZero = 0;
