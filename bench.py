@@ -113,12 +113,30 @@ def parse_args():
     return ap.parse_args()
 
 
+def _usable_cores():
+    """host cores this process may actually use: the affinity mask, further limited by a cgroup CPU quota if there is one"""
+    cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            fields = open(path).read().split()
+            if path.endswith("cpu.max"):
+                quota, period = fields[0], float(fields[1])
+            else:
+                quota, period = fields[0], float(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if quota not in ("max", "-1"):
+                cores = max(1, min(cores, int(float(quota) / period + 0.5)))
+            break
+        except (OSError, ValueError, IndexError):
+            continue
+    return max(cores, 1)
+
+
 def cpu_baseline(name, width, height, frames, seq, overrides=None):
     """Times the CPU oracle on the first `frames` frames of the same sequence (all host cores, OpenMP over rows)."""
     import parity
     from oracle import driver as oracle_driver
 
-    cores = os.cpu_count() or 1
+    cores = _usable_cores()
     threads = oracle_driver.load().oracle_set_threads(cores)
     ora = parity.OracleRun(name, width, height, threads=threads)
     host_seq = [{k: (v.cpu() if torch.is_tensor(v) else v) for k, v in fr.items()} for fr in seq[:frames]]
