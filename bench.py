@@ -108,7 +108,7 @@ def parse_args():
     ap.add_argument("--sharding", choices=["halo", "allgather"], default=os.environ.get("NRD_SHARDING", "halo"),
                     help="multi-GPU scheme: halo = halo exchange between pass segments (point-to-point to the two neighbouring ranks), allgather = redundant halo compute + one all-gather per frame")
     ap.add_argument("--max-motion-rows", type=int, default=32, help="halo scheme: largest vertical motion (rows per frame) the history halos cover")
-    ap.add_argument("--cpu-frames", type=int, default=3)
+    ap.add_argument("--cpu-frames", type=int, default=8)
     ap.add_argument("--distinct-frames", type=int, default=0, help="number of distinct generated frames to cycle through (0 = warmup + steps)")
     return ap.parse_args()
 
