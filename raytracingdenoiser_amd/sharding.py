@@ -292,10 +292,13 @@ class HaloSharder:
 
     SKY_TILE_COST = 0.03  # relative to a tile with geometry (early-out blocks still pay their launch and the tile test)
 
-    def __init__(self, executor, instance, width, height, rank, world, group=None, max_motion_rows=32, exchange_threshold=24, balance=True):
+    def __init__(self, executor, instance, width, height, rank, world, group=None, max_motion_rows=32, exchange_threshold=24, balance=True, recut_every=0):
         self.ex, self.inst = executor, instance
         self.width, self.height, self.rank, self.world, self.group = width, height, rank, world, group
         self.max_motion_rows, self.exchange_threshold, self.balance = max_motion_rows, exchange_threshold, balance
+        # recut_every = N > 0: every N sharded frames one frame is run unsharded on purpose (after completing the planes), so that the strips
+        # are re-cut from a fresh tile map and follow the camera; costs one whole-frame time + one plane completion per N frames
+        self.recut_every, self._sharded_since_cut = recut_every, 0
         # point-to-point halos do not need equal strips: any height splits (the all-gather scheme needs height % world == 0)
         self.bounds = [r * height // world for r in range(world + 1)] if world > 1 and height >= world else None
         self.complete = True      # every plane is complete on this rank: fresh (zeroed) arena, or the last frame ran unsharded
@@ -359,7 +362,8 @@ class HaloSharder:
                      tuple((ptr[i].pipelineIndex, C.string_at(C.addressof(ptr[i].resources.contents), ptr[i].resourcesNum * C.sizeof(api.ResourceDesc)) if ptr[i].resourcesNum else b"")
                            for i in range(n)))
         cached = self._plans.get(signature)
-        if cached is not None and not cached.fallback and not self.complete:
+        recut = self.balance and self.recut_every > 0 and self._sharded_since_cut >= self.recut_every and self.world > 1
+        if cached is not None and not cached.fallback and not self.complete and not recut:
             return cached, ptr, n
         dispatches = [api.Dispatch(ptr[i], self.inst.pipelines) for i in range(n)]
         small = self._small_planes()
@@ -368,6 +372,9 @@ class HaloSharder:
             return plan_halo_exchange(dispatches, reach, self.rows, self.height, self.max_motion_rows, self.exchange_threshold, small, self.min_strip)
 
         plan = make_plan()
+        if recut and not plan.fallback:
+            plan = HaloPlan()
+            plan.fallback, plan.reach = True, list(reach)
         if not plan.fallback and self.balance and self.complete and self.world > 1:
             widest = max((w for items, _, _ in plan.steps for _, w in items), default=0)
             cost = self._tile_row_cost()
@@ -404,6 +411,7 @@ class HaloSharder:
 
     def finish_frame(self, plan):
         self.complete = plan.fallback or self.world == 1
+        self._sharded_since_cut = 0 if plan.fallback else self._sharded_since_cut + 1
 
     def run_step(self, plan, ptr, n, step):
         _, first, count = plan.steps[step]

@@ -274,6 +274,7 @@ def _local_completion(ranks, plans):
     ("REBLUR_DIFFUSE_SPECULAR", 3, 288, dict(maxBlurRadius=10.0), True, 2),      # three ranks: a middle strip with two neighbours
     ("REBLUR_DIFFUSE_SPECULAR_OCCLUSION", 2, 360, dict(maxBlurRadius=15.0), True, 3),  # history = the user's OUT planes
     ("RELAX_DIFFUSE_SPECULAR_SH", 2, 360, None, True, 2),
+    ("REBLUR_DIFFUSE_SPECULAR", 2, 480, dict(maxBlurRadius=15.0), "recut", None),  # a deliberate unsharded frame after every 2 sharded ones
 ])
 def test_halo_sharding_virtual_ranks_reproduce_single_gpu(name, world, height, overrides, balance, fallback_frame):
     import parity
@@ -303,7 +304,8 @@ def test_halo_sharding_virtual_ranks_reproduce_single_gpu(name, world, height, o
 
     ref_inst, ref_ex, ref_outs = make_run()
     runs = [make_run() for _ in range(world)]
-    ranks = [sharding.HaloSharder(ex, inst, W, H, r, world, max_motion_rows=16, balance=balance) for r, (inst, ex, outs) in enumerate(runs)]
+    recut = balance == "recut"
+    ranks = [sharding.HaloSharder(ex, inst, W, H, r, world, max_motion_rows=16, balance=bool(balance), recut_every=2 if recut else 0) for r, (inst, ex, outs) in enumerate(runs)]
     uniform = list(ranks[0].bounds)
     sharded_frames = 0
     for f, frame in enumerate(seq):
@@ -336,9 +338,9 @@ def test_halo_sharding_virtual_ranks_reproduce_single_gpu(name, world, height, o
             rb, re = sh.rows
             for o, ro in zip(outs, ref_outs):
                 assert torch.equal(o[rb:re], ro[rb:re]), (name, f, r)
-    assert sharded_frames == frames - 1 - (fallback_frame is not None)
+    assert sharded_frames == (4 if recut else frames - 1 - (fallback_frame is not None))  # recut: frames 0 and 3 run unsharded (0 | 1 2 | 3 | 4 5)
     if balance:
-        assert ranks[0].rebalanced >= 1 and ranks[0].bounds != uniform and ranks[0].bounds[0] == 0 and ranks[0].bounds[-1] == H  # sky at the top: the top strip grows
+        assert ranks[0].rebalanced >= 1  # (a re-cut that lands on the same strips does not count) and ranks[0].bounds != uniform and ranks[0].bounds[0] == 0 and ranks[0].bounds[-1] == H  # sky at the top: the top strip grows
         assert ranks[0].bounds[1] > uniform[1]
     else:
         assert ranks[0].bounds == uniform
