@@ -128,7 +128,8 @@ uint32_t nrdHipGetPoolMemoryUsage(const NrdHipExecutor* executor, uint64_t* perm
 // Diagnostics: evaluates one primitive of the device numerics contract (DESIGN.md "Numerics") elementwise on device
 // arrays, so a harness can pin the GPU's codecs and transcendentals bit-for-bit against another implementation.
 //   op: 0 exp2, 1 log2, 2 atan, 3 pow(x, y = in2), 4 fp32->fp16->fp32 round trip, 5 x / in2, 6 sqrt, 7 1/sqrt,
-//       8..12 small-integer / {1023, 255, 63, 15, 3} (the codecs' 3-op exact division), 13 exp(-0.66 x^2), 14 small-integer / 65535, 15 int16 / 32767
+//       8..12 small-integer / {1023, 255, 63, 15, 3} (the codecs' 3-op exact division), 13 exp(-0.66 x^2), 14 small-integer / 65535, 15 int16 / 32767;
+//       16 v_rcp_f32, 17 v_rsq_f32, 18 v_sqrt_f32 (the hardware approximations; no pass uses them -- probes for tools/hw_transcendentals.py)
 // in2 may be NULL for unary ops. Launches on hipStream (a hipStream_t as void*, may be NULL).
 uint32_t nrdHipEvalNumerics(uint32_t op, const float* in1, const float* in2, float* out, uint32_t count, void* hipStream);
 

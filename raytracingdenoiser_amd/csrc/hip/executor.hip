@@ -751,7 +751,7 @@ void LaunchEvalNumerics(uint32_t op, const float* in1, const float* in2, float* 
 }
 
 extern "C" __attribute__((visibility("default"))) uint32_t nrdHipEvalNumerics(uint32_t op, const float* in1, const float* in2, float* out, uint32_t count, void* hipStream) {
-    if (!in1 || !out || op > 15)
+    if (!in1 || !out || op > 18)
         return (uint32_t)nrd::Result::INVALID_ARGUMENT;
     if (count)
         nrdhip::LaunchEvalNumerics(op, in1, in2, out, count, (hipStream_t)hipStream);

@@ -110,6 +110,11 @@ __global__ __launch_bounds__(256) void EvalNumericsKernel(uint32_t op, const flo
         case 13: r = Exp(-0.66f * a * a); break; // GetGaussianWeight
         case 14: r = NRD_DIV_65535(a); break;
         case 15: r = NRD_DIV_32767(a); break;
+        // the hardware's one-instruction approximations (not used by any pass: the numerics contract is built on correctly rounded ops;
+        // probed so that their deviation from the correctly rounded results can be tabulated -- DESIGN.md section 8)
+        case 16: r = __builtin_amdgcn_rcpf(a); break;
+        case 17: r = __builtin_amdgcn_rsqf(a); break;
+        case 18: r = __builtin_amdgcn_sqrtf(a); break;
         default: break;
     }
     out[i] = r;
