@@ -18,6 +18,7 @@ class OraclePlane(C.Structure):
 
 
 _lib = None
+_hw_tables = None  # keeps the numpy arrays behind oracle_set_hw_tables alive
 
 
 def load():
@@ -34,6 +35,22 @@ def load():
         for name in ("oracle_exp2", "oracle_log2", "oracle_atan"):
             getattr(lib, name).argtypes, getattr(lib, name).restype = [C.c_float], C.c_float
         lib.oracle_pow.argtypes, lib.oracle_pow.restype = [C.c_float, C.c_float], C.c_float
+        lib.oracle_eval_hw.argtypes, lib.oracle_eval_hw.restype = [C.c_int, C.c_void_p, C.c_void_p, C.c_int], None
+        # sqrt / rsqrt follow gfx950's v_sqrt_f32 / v_rsq_f32: per-mantissa deviation (in ulps) from the correctly rounded result, measured on the
+        # device by tools/hw_transcendentals.py and committed next to the oracle
+        import zlib
+
+        global _hw_tables
+        _hw_tables = []
+        for name in ("hw_sqrt.i8.z", "hw_rsq.i8.z"):
+            path = os.path.join(_DIR, name)
+            if not os.path.exists(path):
+                raise RuntimeError("oracle: %s is missing (python tools/hw_transcendentals.py on the GPU writes it)" % path)
+            table = np.frombuffer(zlib.decompress(open(path, "rb").read()), dtype=np.int8)
+            assert table.size == 1 << 24 and int(np.abs(table).max()) <= 1, name
+            _hw_tables.append(np.ascontiguousarray(table))
+        lib.oracle_set_hw_tables.argtypes, lib.oracle_set_hw_tables.restype = [C.c_void_p, C.c_void_p], None
+        lib.oracle_set_hw_tables(_hw_tables[0].ctypes.data, _hw_tables[1].ctypes.data)
         _lib = lib
     return _lib
 

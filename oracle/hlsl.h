@@ -2,9 +2,10 @@
 // leg may load anything under oracle/. The shipped library (raytracingdenoiser_amd/lib/libNRD_hip.so) never does.
 //
 // HLSL-flavoured scalar/vector vocabulary for the CPU restatement of the NRD shader arithmetic, plus the
-// bit-reproducible transcendentals of the numerics contract (DESIGN.md "Numerics"): only + - * / sqrt, floor,
-// comparisons and integer bit operations are used, and this directory is compiled with -ffp-contract=off, so every
-// value is determined by IEEE-754 alone. Written independently of the HIP device header; the two must agree
+// bit-reproducible transcendentals of the numerics contract (DESIGN.md "Numerics"): only + - * /, floor, comparisons and
+// integer bit operations are used, and this directory is compiled with -ffp-contract=off, so every value is determined by
+// IEEE-754 alone -- except sqrt and 1/sqrt, which follow gfx950's v_sqrt_f32 / v_rsq_f32 (within 1 ulp of the correctly
+// rounded result) through per-mantissa delta tables measured on the device (HwSqrt / HwRsq below). Written independently of the HIP device header; the two must agree
 // bit-for-bit, which is what the parity tests check.
 //
 // PARITY UNPINNED: the reference ships no CPU implementation, no tests and no golden vectors, and its math library
@@ -39,7 +40,47 @@ inline float saturate(float x) { return min(max(x, 0.0f), 1.0f); }
 inline float lerp(float a, float b, float t) { return a + (b - a) * t; }
 inline float step(float edge, float x) { return x >= edge ? 1.0f : 0.0f; }
 inline float rcp(float x) { return 1.0f / x; }
-inline float rsqrt(float x) { return 1.0f / sqrtf(x); }
+
+// gfx950's v_sqrt_f32 and v_rsq_f32, bit for bit: result = (the float64 result rounded once) + delta ulps, delta in {-1, 0, +1} from
+// oracle/hw_sqrt.i8.z / hw_rsq.i8.z (tools/hw_transcendentals.py: every mantissa for both exponent parities; scaling by 4^k is exact).
+// Denormal inputs are flushed to (signed) zero, negative inputs give NaN, as the instructions do. The tables are handed over by
+// oracle/driver.py (oracle_set_hw_tables); without them the functions abort: there is no silent fallback to the exact result.
+extern const signed char* g_HwSqrtDelta; // 2^24 entries: [exponent parity << 23 | mantissa]
+extern const signed char* g_HwRsqDelta;
+[[noreturn]] void HwTablesMissing();
+inline float HwSqrt(float x) {
+    const uint32_t u = asuint(x), mag = u & 0x7fffffffu;
+    if (mag > 0x7f800000u)
+        return asfloat(0x7fc00000u); // NaN
+    if (mag < 0x00800000u)
+        return asfloat(u & 0x80000000u); // +-0 and flushed denormals -> +-0
+    if (u & 0x80000000u)
+        return asfloat(0x7fc00000u); // negative -> NaN
+    if (mag == 0x7f800000u)
+        return x; // +inf
+    if (!g_HwSqrtDelta)
+        HwTablesMissing();
+    const uint32_t parity = ((u >> 23) + 1u) & 1u; // unbiased exponent parity: biased 127 (x in [1, 2)) -> 0
+    const float exact = (float)sqrt((double)x);
+    return asfloat(asuint(exact) + (uint32_t)(int32_t)g_HwSqrtDelta[(parity << 23) | (u & 0x7fffffu)]);
+}
+inline float HwRsq(float x) {
+    const uint32_t u = asuint(x), mag = u & 0x7fffffffu;
+    if (mag > 0x7f800000u)
+        return asfloat(0x7fc00000u);
+    if (mag < 0x00800000u)
+        return asfloat((u & 0x80000000u) | 0x7f800000u); // +-0 and flushed denormals -> +-inf
+    if (u & 0x80000000u)
+        return asfloat(0x7fc00000u);
+    if (mag == 0x7f800000u)
+        return 0.0f;
+    if (!g_HwRsqDelta)
+        HwTablesMissing();
+    const uint32_t parity = ((u >> 23) + 1u) & 1u;
+    const float exact = (float)(1.0 / sqrt((double)x));
+    return asfloat(asuint(exact) + (uint32_t)(int32_t)g_HwRsqDelta[(parity << 23) | (u & 0x7fffffu)]);
+}
+inline float rsqrt(float x) { return HwRsq(x); }
 inline float frac(float x) { return x - floorf(x); }
 
 // 2^x: nearest-integer split, degree-7 Taylor of 2^f on [-0.5, 0.5], Horner
@@ -173,8 +214,8 @@ inline float dot(float3 a, float3 b) { return a.x * b.x + a.y * b.y + a.z * b.z;
 inline float dot(float4 a, float4 b) { return a.x * b.x + a.y * b.y + a.z * b.z + a.w * b.w; }
 inline float sum(float4 a) { return a.x + a.y + a.z + a.w; } // dot( a, 1.0 )
 inline float sum(float3 a) { return a.x + a.y + a.z; }
-inline float length(float2 v) { return sqrtf(dot(v, v)); }
-inline float length(float3 v) { return sqrtf(dot(v, v)); }
+inline float length(float2 v) { return HwSqrt(dot(v, v)); }
+inline float length(float3 v) { return HwSqrt(dot(v, v)); }
 inline float3 normalize(float3 v) { return v * rsqrt(dot(v, v)); }
 inline float3 cross(float3 a, float3 b) { return float3(a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x); }
 inline float3 reflect(float3 i, float3 n) { return i - n * (2.0f * dot(n, i)); }

@@ -31,10 +31,10 @@ inline float SmoothStep01(float x) {
 }
 inline float SmoothStep(float a, float b, float x) { return SmoothStep01(LinearStep(a, b, x)); }
 inline float4 SmoothStep(float a, float b, float4 x) { return float4(SmoothStep(a, b, x.x), SmoothStep(a, b, x.y), SmoothStep(a, b, x.z), SmoothStep(a, b, x.w)); }
-inline float Sqrt01(float x) { return sqrtf(saturate(x)); }
+inline float Sqrt01(float x) { return HwSqrt(saturate(x)); }
 inline float Pow01(float x, float y) { return pow(saturate(x), y); }
 inline float PositiveRcp(float x) { return 1.0f / max(x, 1e-15f); }
-inline float AcosApprox(float x) { return 1.41421356f * sqrtf(saturate(1.0f - x)); }
+inline float AcosApprox(float x) { return 1.41421356f * HwSqrt(saturate(1.0f - x)); }
 inline float LengthSquared(float3 v) { return dot(v, v); }
 inline float LengthSquared(float2 v) { return dot(v, v); }
 inline float Rsqrt(float x) { return rsqrt(x); }
@@ -183,7 +183,7 @@ inline float2 GetCatmullRomOrigin(float2 uv, float2 texSize) {
 inline float GetModifiedRoughnessFromNormalVariance(float linearRoughness, float3 nonNormalizedAverageNormal) {
     float l = length(nonNormalizedAverageNormal);
     float kappa = saturate(1.0f - l * l) / max(l * (3.0f - l * l), 1e-15f);
-    return sqrtf(saturate(linearRoughness * linearRoughness + kappa));
+    return HwSqrt(saturate(linearRoughness * linearRoughness + kappa));
 }
 } // namespace Filtering
 
@@ -193,7 +193,7 @@ inline float GetSpecularLobeTanHalfAngle(float linearRoughness, float percentOfV
     float r = saturate(linearRoughness);
     float p = saturate(percentOfVolume);
     float m = r * r;
-    return m * sqrtf(p / (1.0f - p + NRD_EPS));
+    return m * HwSqrt(p / (1.0f - p + NRD_EPS));
 }
 inline float GetSpecularDominantFactor(float NoV, float linearRoughness) { // [nrd] NRD.hlsli:386-392
     float a = 0.298475f * log(39.4115f - 39.0029f * linearRoughness);

@@ -3,6 +3,7 @@
 #include "passes.h"
 
 #include <cstdio>
+#include <cstdlib>
 #include <vector>
 
 #ifdef _OPENMP
@@ -10,6 +11,15 @@
 #endif
 
 using namespace orc;
+
+namespace orc {
+const signed char* g_HwSqrtDelta = nullptr;
+const signed char* g_HwRsqDelta = nullptr;
+void HwTablesMissing() {
+    fprintf(stderr, "oracle: the hardware sqrt / rsq delta tables are not loaded (oracle/hw_sqrt.i8.z, hw_rsq.i8.z through oracle/driver.py)\n");
+    abort();
+}
+} // namespace orc
 
 extern "C" {
 
@@ -40,6 +50,16 @@ __attribute__((visibility("default"))) int oracle_dispatch(const char* shaderFil
             }
     fprintf(stderr, "oracle_dispatch: unknown pass '%s'\n", shaderFileName);
     return 1;
+}
+
+// delta tables of the hardware sqrt / rsq emulation (oracle/hlsl.h); the memory stays owned by the caller (oracle/driver.py keeps it alive)
+__attribute__((visibility("default"))) void oracle_set_hw_tables(const signed char* sqrtDelta, const signed char* rsqDelta) {
+    orc::g_HwSqrtDelta = sqrtDelta;
+    orc::g_HwRsqDelta = rsqDelta;
+}
+__attribute__((visibility("default"))) void oracle_eval_hw(int op, const float* in, float* out, int n) { // 0 = HwSqrt, 1 = HwRsq
+    for (int i = 0; i < n; i++)
+        out[i] = op == 0 ? orc::HwSqrt(in[i]) : orc::HwRsq(in[i]);
 }
 
 __attribute__((visibility("default"))) int oracle_set_threads(int n) {

@@ -119,7 +119,7 @@ S DiffuseSpatialFilterTaps(const ReblurCB& c, SpatialMode mode, const SpatialCtx
     float2 hitDistanceWeightParams = GetHitDistanceWeightParams(ExtractHitDist(diff), diffNonLinearAccumSpeed);
     float minHitDistWeight = c.gMinHitDistanceWeight * fractionScale;
     if (mode != PRE_BLUR && !OCC) // REBLUR_Common_DiffuseSpatialFilter.hlsli:76
-        minHitDistWeight *= sqrtf(diffNonLinearAccumSpeed);
+        minHitDistWeight *= HwSqrt(diffNonLinearAccumSpeed);
 
     // Screen-space sampling (REBLUR_USE_SCREEN_SPACE_SAMPLING_FOR_DIFFUSE = 1)
     float2 skew = float2(1.0f);
@@ -263,7 +263,7 @@ S SpecularSpatialFilterTaps(const ReblurCB& c, SpatialMode mode, const SpatialCt
     float2 hitDistanceWeightParams = GetHitDistanceWeightParams(ExtractHitDist(spec), specNonLinearAccumSpeed, s.roughness);
     float minHitDistWeight = c.gMinHitDistanceWeight * fractionScale * smc;
     if (mode != PRE_BLUR && !OCC) // REBLUR_Common_SpecularSpatialFilter.hlsli:98
-        minHitDistWeight *= sqrtf(specNonLinearAccumSpeed);
+        minHitDistWeight *= HwSqrt(specNonLinearAccumSpeed);
 
     // Sampling set-up: screen space for the pre-pass (and for every pass in performance mode), world space along the (bent) lobe otherwise
     const bool screenSpace = mode == PRE_BLUR || s.perf; // REBLUR_USE_SCREEN_SPACE_SAMPLING_FOR_SPECULAR
@@ -273,7 +273,7 @@ S SpecularSpatialFilterTaps(const ReblurCB& c, SpatialMode mode, const SpatialCt
         float2 skew = c.gRectSizeInv * blurRadius;
         scaledRotator = Geometry::ScaleRotator(s.rotator, skew);
     } else {
-        float bentFactor = sqrtf(hitDistFactor);
+        float bentFactor = HwSqrt(hitDistFactor);
         float skewFactor = lerp(0.25f + 0.75f * s.roughness, 1.0f, NoD);
         skewFactor = lerp(skewFactor, 1.0f, specNonLinearAccumSpeed);
         skewFactor = lerp(1.0f, skewFactor, bentFactor);
@@ -692,7 +692,7 @@ void TemporalAccumulation(const PassIO& io) {
                 roughnessModified = Filtering::GetModifiedRoughnessFromNormalVariance(roughness, Navg);
                 roughnessM1 /= 9.0f;
                 roughnessM2 /= 9.0f;
-                roughnessSigma = sqrtf(fabsf(roughnessM2 - roughnessM1 * roughnessM1)); // GetStdDev
+                roughnessSigma = HwSqrt(fabsf(roughnessM2 - roughnessM1 * roughnessM1)); // GetStdDev
 
                 rng.Initialize((uint32_t)px, (uint32_t)py, c.gFrameIndex);
 
@@ -1304,7 +1304,7 @@ S HistoryFixSignal(const ReblurCB& c, bool isSpec, bool perf, int px, int py, S 
 
         float normalWeightParam = GetNormalWeightParam(nonLinearAccumSpeed, c.gLobeAngleFraction, r);
         float2 geometryWeightParams = GetGeometryWeightParams(c.gPlaneDistSensitivity, frustumSize, Xv, Nv);
-        float2 relaxedRoughnessWeightParams = GetRelaxedRoughnessWeightParams(roughness * roughness, sqrtf(c.gRoughnessFraction));
+        float2 relaxedRoughnessWeightParams = GetRelaxedRoughnessWeightParams(roughness * roughness, HwSqrt(c.gRoughnessFraction));
 
         float hitDistScale = _REBLUR_GetHitDistanceNormalization(viewZ, c.gHitDistParams, r);
         float hitDist = ExtractHitDist(sig) * hitDistScale;
@@ -1418,14 +1418,14 @@ S HistoryFixSignal(const ReblurCB& c, bool isSpec, bool perf, int px, int py, S 
         float invNorm = 1.0f / float((R * 2 + 1) * (R * 2 + 1) - 3 * 3);
         am1 *= invNorm;
         am2 *= invNorm;
-        float sigma = sqrtf(fabsf(am2 - am1 * am1)) * REBLUR_ANTI_FIREFLY_SIGMA_SCALE;
+        float sigma = HwSqrt(fabsf(am2 - am1 * am1)) * REBLUR_ANTI_FIREFLY_SIGMA_SCALE;
         luma = clamp(luma, am1 - sigma, am1 + sigma);
     }
 
     // Fast-history clamping
     m1 /= 25.0f;
     m2 /= 25.0f;
-    float sigma = sqrtf(fabsf(m2 - m1 * m1)) * (KIND != SIGNAL_RADIANCE ? REBLUR_COLOR_CLAMPING_SIGMA_SCALE_OCCLUSION : REBLUR_COLOR_CLAMPING_SIGMA_SCALE);
+    float sigma = HwSqrt(fabsf(m2 - m1 * m1)) * (KIND != SIGNAL_RADIANCE ? REBLUR_COLOR_CLAMPING_SIGMA_SCALE_OCCLUSION : REBLUR_COLOR_CLAMPING_SIGMA_SCALE);
     float lumaClamped = clamp(luma, m1 - sigma, m1 + sigma);
     luma = lerp(lumaClamped, luma, 1.0f / (1.0f + (c.gMaxFastAccumulatedFrameNum < c.gMaxAccumulatedFrameNum ? 1.0f : 0.0f) * frameNum * 2.0f));
 
@@ -1600,7 +1600,7 @@ void TemporalStabilization(const PassIO& io) {
                 M1 /= 9.0f;
                 M2 /= 9.0f;
                 m1 = M1;
-                sigma = sqrtf(fabsf(M2 - M1 * M1));
+                sigma = HwSqrt(fabsf(M2 - M1 * M1));
                 if (!PERF && c.gMaxBlurRadius != 0.0f) // RCRS (not in performance mode)
                     luma = clamp(luma, mn, mx);
             };

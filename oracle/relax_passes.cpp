@@ -55,7 +55,7 @@ static const float3 g_Poisson8[8] = { // reference Shaders/Include/Poisson.hlsli
 // ---- small vector helpers missing from hlsl.h
 inline float3 vmin(float3 a, float3 b) { return float3(min(a.x, b.x), min(a.y, b.y), min(a.z, b.z)); }
 inline float3 vmax(float3 a, float3 b) { return float3(max(a.x, b.x), max(a.y, b.y), max(a.z, b.z)); }
-inline float3 vsqrt(float3 a) { return float3(sqrtf(a.x), sqrtf(a.y), sqrtf(a.z)); }
+inline float3 vsqrt(float3 a) { return float3(HwSqrt(a.x), HwSqrt(a.y), HwSqrt(a.z)); }
 inline float4 vmax0(float4 a) { return float4(max(a.x, 0.0f), max(a.y, 0.0f), max(a.z, 0.0f), max(a.w, 0.0f)); }
 inline float4 vclamp(float4 a, float lo, float hi) { return float4(clamp(a.x, lo, hi), clamp(a.y, lo, hi), clamp(a.z, lo, hi), clamp(a.w, lo, hi)); }
 inline float Cmp(bool b) { return b ? 1.0f : 0.0f; }
@@ -769,7 +769,7 @@ void TemporalAccumulation(const PassIO& io) {
             footprintQuality *= lerp(0.1f, 1.0f, saturate(sizeQuality + fabsf(c.gOrthoMode)));
 
             if (footprintQuality < 1.0f) {
-                historyLength *= sqrtf(footprintQuality);
+                historyLength *= HwSqrt(footprintQuality);
                 historyLength = max(historyLength, 1.0f);
             }
             historyLength = c.gResetHistory != 0 ? 1.0f : historyLength;
@@ -1235,7 +1235,7 @@ inline ClampOut ClampSignal(const RelaxCB& c, bool isSpec, float3 fastM1, float3
     // history reset
     float slowL = Color::Luminance(slowIn.xyz());
     float noisyL = Color::Luminance(noisyM1);
-    float temporalSigma = c.gHistoryResetTemporalSigmaScale * sqrtf(max(0.0f, noisyM2 - noisyL * noisyL));
+    float temporalSigma = c.gHistoryResetTemporalSigmaScale * HwSqrt(max(0.0f, noisyM2 - noisyL * noisyL));
     float spatialSigma = c.gHistoryResetSpatialSigmaScale * sigma.x;
     float resetAmount = (isSpec ? 0.5f * c.gHistoryResetAmount : c.gHistoryResetAmount) * max(0.0f, fabsf(slowL - noisyL) - spatialSigma - temporalSigma) /
                         (1.0e-6f + max(slowL, noisyL) + spatialSigma + temporalSigma);
@@ -1441,7 +1441,7 @@ void AtrousSmem(const PassIO& io) {
                 float3 centerV(0.0f);
                 if (SPEC) {
                     centerSpecularLuminance = Color::Luminance(S(spec, px, py).xyz());
-                    specularPhiLIlluminationInv = 1.0f / max(1.0e-4f, c.gSpecPhiLuminance * sqrtf(centerSpecularVar));
+                    specularPhiLIlluminationInv = 1.0f / max(1.0e-4f, c.gSpecPhiLuminance * HwSqrt(centerSpecularVar));
                     roughnessWeightParams = GetRoughnessWeightParams(centerRoughness, c.gRoughnessFraction);
                     float diffuseLobeAngleFractionForSimplifiedSpecularNormalWeight = diffuseLobeAngleFraction;
                     float specularLobeAngleFraction = c.gLobeAngleFraction;
@@ -1466,7 +1466,7 @@ void AtrousSmem(const PassIO& io) {
                 float centerDiffuseLuminance = 0.0f, diffusePhiLIlluminationInv = 0.0f, diffuseLuminanceWeightRelaxation = 1.0f, diffuseNormalWeightParam = 0.0f;
                 if (DIFF) {
                     centerDiffuseLuminance = Color::Luminance(S(diff, px, py).xyz());
-                    diffusePhiLIlluminationInv = 1.0f / max(1.0e-4f, c.gDiffPhiLuminance * sqrtf(centerDiffuseVar));
+                    diffusePhiLIlluminationInv = 1.0f / max(1.0e-4f, c.gDiffPhiLuminance * HwSqrt(centerDiffuseVar));
                     if (c.gHasHistoryConfidence) {
                         float diffConfidenceDrivenRelaxation = saturate(c.gConfidenceDrivenRelaxationMultiplier * (1.0f - diff.confidence->Load(ox + px, oy + py).x));
                         float r = saturate(diffConfidenceDrivenRelaxation * c.gConfidenceDrivenNormalEdgeStoppingRelaxation);
@@ -1676,9 +1676,9 @@ void Atrous(const PassIO& io) {
             float centerRoughness = centerNormalRoughness.w;
             float historyLength = 255.0f * gIn_HistoryLength.Load(px, py).x;
 
-            float diffuseLobeAngleFraction = c.gLobeAngleFraction / sqrtf(float(c.gStepSize));
+            float diffuseLobeAngleFraction = c.gLobeAngleFraction / HwSqrt(float(c.gStepSize));
             if (SH)
-                diffuseLobeAngleFraction = 1.0f / sqrtf(float(c.gStepSize));
+                diffuseLobeAngleFraction = 1.0f / HwSqrt(float(c.gStepSize));
             diffuseLobeAngleFraction = lerp(0.99f, diffuseLobeAngleFraction, saturate(historyLength / 5.0f));
 
             float4 centerSpecular(0.0f), centerSpecularSH(0.0f), sumSpecular(0.0f), sumSpecularSH(0.0f);
@@ -1689,7 +1689,7 @@ void Atrous(const PassIO& io) {
                 centerSpecular = spec.in->Load(px, py);
                 centerSpecularLuminance = Color::Luminance(centerSpecular.xyz());
                 float centerSpecularVar = centerSpecular.w;
-                specularPhiLIlluminationInv = 1.0f / max(1.0e-4f, c.gSpecPhiLuminance * sqrtf(centerSpecularVar));
+                specularPhiLIlluminationInv = 1.0f / max(1.0e-4f, c.gSpecPhiLuminance * HwSqrt(centerSpecularVar));
 
                 roughnessWeightParams = GetRoughnessWeightParams(centerRoughness, c.gRoughnessFraction);
                 float diffuseLobeAngleFractionForSimplifiedSpecularNormalWeight = diffuseLobeAngleFraction;
@@ -1724,7 +1724,7 @@ void Atrous(const PassIO& io) {
                 centerDiffuse = diff.in->Load(px, py);
                 centerDiffuseLuminance = Color::Luminance(centerDiffuse.xyz());
                 float centerDiffuseVar = centerDiffuse.w;
-                diffusePhiLIlluminationInv = 1.0f / max(1.0e-4f, c.gDiffPhiLuminance * sqrtf(centerDiffuseVar));
+                diffusePhiLIlluminationInv = 1.0f / max(1.0e-4f, c.gDiffPhiLuminance * HwSqrt(centerDiffuseVar));
                 if (c.gHasHistoryConfidence) {
                     float diffConfidenceDrivenRelaxation = saturate(c.gConfidenceDrivenRelaxationMultiplier * (1.0f - diff.confidence->Load(ox + px, oy + py).x));
                     float r = saturate(diffConfidenceDrivenRelaxation * c.gConfidenceDrivenNormalEdgeStoppingRelaxation);

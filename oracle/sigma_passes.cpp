@@ -52,7 +52,7 @@ template <> struct SigmaType<true> {
     static float4 From(float4 v) { return v; }
     static float X(float4 v) { return v.x; }
 };
-inline float StdDev(float m1, float m2) { return sqrtf(fabsf(m2 - m1 * m1)); } // GetStdDev, Common.hlsli:227
+inline float StdDev(float m1, float m2) { return HwSqrt(fabsf(m2 - m1 * m1)); } // GetStdDev, Common.hlsli:227
 inline float4 StdDev(float4 m1, float4 m2) { return float4(StdDev(m1.x, m2.x), StdDev(m1.y, m2.y), StdDev(m1.z, m2.z), StdDev(m1.w, m2.w)); }
 inline float Clamp(float x, float a, float b) { return clamp(x, a, b); }
 inline float4 Clamp(float4 x, float4 a, float4 b) { return float4(clamp(x.x, a.x, b.x), clamp(x.y, a.y, b.y), clamp(x.z, a.z, b.z), clamp(x.w, a.w, b.w)); }

@@ -39,8 +39,11 @@ NRD_D float Sat(float x) { return Min(Max(x, 0.0f), 1.0f); }
 NRD_D float Lerp(float a, float b, float t) { return a + (b - a) * t; }
 NRD_D float Step(float edge, float x) { return x >= edge ? 1.0f : 0.0f; }
 NRD_D float Rcp(float x) { return 1.0f / x; }
-NRD_D float Sqrt(float x) { return __builtin_sqrtf(x); } // correctly rounded (hipcc default -fhip-fp32-correctly-rounded-divide-sqrt)
-NRD_D float Rsqrt(float x) { return 1.0f / __builtin_sqrtf(x); }
+// sqrt and 1/sqrt are the hardware's single instructions (v_sqrt_f32, v_rsq_f32: within 1 ulp of the correctly rounded result, denormals
+// flushed) instead of the ~14 / ~25-instruction correctly rounded expansions; the CPU oracle reproduces them bit for bit from per-mantissa
+// tables measured on the device (oracle/hlsl.h HwSqrt / HwRsq, tools/hw_transcendentals.py). Division stays correctly rounded.
+NRD_D float Sqrt(float x) { return __builtin_amdgcn_sqrtf(x); }
+NRD_D float Rsqrt(float x) { return __builtin_amdgcn_rsqf(x); }
 NRD_D float Abs(float x) { return fabsf(x); }
 NRD_D float Floor(float x) { return floorf(x); }
 NRD_D float Frac(float x) { return x - floorf(x); }

@@ -78,18 +78,25 @@ def test_hip_numerics_bit_exact_vs_oracle():
         ok = np.isfinite(want)
         bad = np.nonzero(got[ok].view(np.uint32) != want[ok].view(np.uint32))[0]
         assert bad.size == 0, "op %d: %d / %d differ from the oracle, e.g. in=%r got=%r want=%r" % (op, bad.size, ok.sum(), a32[ok][bad[:4]], got[ok][bad[:4]], want[ok][bad[:4]])
-    # IEEE division / sqrt on the device (correctly rounded) vs numpy
+    # IEEE division on the device (correctly rounded) vs numpy; sqrt / rsqrt = the hardware instructions vs the oracle's table emulation
     a = (rng.standard_normal(n) * 10.0 ** rng.integers(-6, 6, n)).astype(np.float32)
     b = (rng.standard_normal(n) * 10.0 ** rng.integers(-6, 6, n)).astype(np.float32)
     ta, tb, out = torch.from_numpy(a).cuda(), torch.from_numpy(b).cuda(), torch.empty(n, device="cuda")
     lib.nrdHipEvalNumerics(5, ta.data_ptr(), tb.data_ptr(), out.data_ptr(), n, torch.cuda.current_stream().cuda_stream)
     assert np.array_equal(out.cpu().numpy().view(np.uint32), (a / b).view(np.uint32))
-    pa = np.abs(a)
-    ta = torch.from_numpy(pa).cuda()
-    lib.nrdHipEvalNumerics(6, ta.data_ptr(), None, out.data_ptr(), n, torch.cuda.current_stream().cuda_stream)
-    assert np.array_equal(out.cpu().numpy().view(np.uint32), np.sqrt(pa).view(np.uint32))
-    lib.nrdHipEvalNumerics(7, ta.data_ptr(), None, out.data_ptr(), n, torch.cuda.current_stream().cuda_stream)
-    assert np.array_equal(out.cpu().numpy().view(np.uint32), (np.float32(1.0) / np.sqrt(pa)).view(np.uint32))
+    specials = np.array([0.0, -0.0, np.inf, 1e-45, 1e-39, -1e-39, 1.17549435e-38, 3.4e38, 1.0, 2.0, 4.0, 0.25, -1.0, -np.inf], dtype=np.float32)
+    wide = (np.abs(rng.standard_normal(200000)) * 10.0 ** rng.integers(-37, 38, 200000)).astype(np.float32)  # the whole exponent range
+    pa = np.concatenate([np.abs(a), wide, specials]).astype(np.float32)
+    ta, out = torch.from_numpy(pa).cuda(), torch.empty(pa.size, device="cuda")
+    for op, hw in ((6, 0), (7, 1)):
+        lib.nrdHipEvalNumerics(op, ta.data_ptr(), None, out.data_ptr(), pa.size, torch.cuda.current_stream().cuda_stream)
+        got, want = out.cpu().numpy(), np.empty_like(pa)
+        ora.oracle_eval_hw(hw, pa.ctypes.data, want.ctypes.data, pa.size)
+        same = (got.view(np.uint32) == want.view(np.uint32)) | (np.isnan(got) & np.isnan(want))
+        assert same.all(), "op %d: %d differ, e.g. in=%r got=%r want=%r" % (op, (~same).sum(), pa[~same][:6], got[~same][:6], want[~same][:6])
+        exact = (np.sqrt(pa.astype(np.float64)) if hw == 0 else 1.0 / np.sqrt(pa.astype(np.float64))).astype(np.float32)
+        normal = np.isfinite(exact) & (pa >= np.float32(1.17549435e-38)) & np.isfinite(pa)
+        assert np.abs(got[normal].view(np.int32).astype(np.int64) - exact[normal].view(np.int32)).max() <= 1  # within 1 ulp of the correctly rounded result
 
 
 @pytest.mark.gpu

@@ -28,6 +28,9 @@ def main():
         delta = got.view(np.int32).astype(np.int64) - want.view(np.int32).astype(np.int64)
         hist = {int(k): int(v) for k, v in zip(*np.unique(delta, return_counts=True))}
         packed = zlib.compress(delta.astype(np.int8).tobytes(), 9)
+        if os.environ.get("NRD_HW_TABLE_DIR") and op in (17, 18):  # the tables the oracle emulates v_rsq_f32 / v_sqrt_f32 with (oracle/hw_math.h)
+            with open(os.path.join(os.environ["NRD_HW_TABLE_DIR"], {17: "hw_rsq.i8.z", 18: "hw_sqrt.i8.z"}[op]), "wb") as fp:
+                fp.write(packed)
         print("%s over %d inputs in [%g, %g): deviation from the correctly rounded result in ulps -> count: %s; exact %.2f %%; int8 delta table %d bytes zlib-compressed" %
               (name, len(bits), lo, hi, hist, 100.0 * hist.get(0, 0) / len(bits), len(packed)))
     # special inputs
