@@ -2,9 +2,9 @@
 // restated NVIDIA-RTX/MathLib subset the shaders call ("ml.hlsli" -- NOT vendored in the reference, fetched unpinned
 // at configure time, reference CMakeLists.txt:118-127), and the NRD.hlsli front-end/back-end codecs.
 //
-// Reproducibility contract (DESIGN.md "Numerics"): everything here is built from + - * / sqrt, comparisons, floor
-// and integer bit operations only, all IEEE-754 correctly rounded on gfx950 and on x86-64, and this file is compiled
-// with -ffp-contract=off. The CPU oracle (oracle/) restates the same definitions independently, so the two can be
+// Reproducibility contract (DESIGN.md "Numerics"): everything here is built from + - * /, comparisons, floor and integer
+// bit operations -- IEEE-754 correctly rounded on gfx950 and on x86-64 -- plus sqrt and 1/sqrt as the hardware's v_sqrt_f32 /
+// v_rsq_f32, which the oracle reproduces from device-measured tables; this file is compiled with -ffp-contract=off. The CPU oracle (oracle/) restates the same definitions independently, so the two can be
 // compared bit-for-bit instead of through a loose tolerance that the chain's many thresholds would amplify.
 #pragma once
 
