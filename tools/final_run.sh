@@ -1,4 +1,6 @@
 #!/bin/bash
+# A short GPU-box session for the end of a round: bench lines + kernel trace of the headline workload, then the GPU tests that are not plain
+# "HIP matches oracle" parity cases (tools/measure_round.sh is the complete session). usage: bash tools/final_run.sh   (results in gpurun_out/)
 R=${GRAFT_REPO_ROOT:-$(pwd)}; cd $R; mkdir -p gpurun_out
 tag=r01_r
 timeout 120 python bench.py > gpurun_out/${tag}_bench.json 2> gpurun_out/${tag}_bench.err; tail -1 gpurun_out/${tag}_bench.json | cut -c1-200
