@@ -279,6 +279,13 @@ def load_library(path=None):
     path = path or LIB_PATH
     if not os.path.exists(path):
         raise RuntimeError("NRD HIP library not built: %s (run `python -c 'import __graft_entry__ as g; g.build()'`)" % path)
+    # Load order matters in a process that also uses PyTorch: torch bundles its own libamdhip64, and if this library came first the loader
+    # would bind it to the system ROCm copy instead -- two HIP runtimes in one process, and the one behind the executor then reports no
+    # device (nrdHipCreateExecutor -> FAILURE). Importing torch first makes both share torch's runtime; without torch nothing changes.
+    try:
+        import torch  # noqa: F401
+    except ImportError:
+        pass
     lib = C.CDLL(path)
     P = C.POINTER
     lib.CreateInstance.argtypes, lib.CreateInstance.restype = [P(InstanceCreationDesc), P(C.c_void_p)], C.c_uint32
