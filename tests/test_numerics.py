@@ -124,3 +124,28 @@ def test_hip_exact_constant_division_and_gaussian_constants():
     assert out.cpu().numpy().view(np.uint32).tolist() == [0x3F04505E, 0x3F590F90, 0x3F713C86]
     ora = oracle_driver.load()
     assert np.float32(ora.oracle_exp2(float(np.float32(np.float32(-0.66) * np.float32(1.0) * np.float32(1.0)) * np.float32(1.44269504)))).view(np.uint32) == 0x3F04505E
+
+
+def test_hw_sqrt_tables_are_sane():
+    """oracle/hw_sqrt.i8.z / hw_rsq.i8.z (the measured deviation of gfx950's v_sqrt_f32 / v_rsq_f32 from the correctly rounded results): every
+    entry is -1, 0 or +1 ulp (checked at load), exact squares stay exact, the emulation is within 1 ulp of the correctly rounded value over the
+    whole exponent range, flushes denormals and follows the instructions on zeros / infinities / negative inputs."""
+    ora = oracle_driver.load()
+    rng = np.random.default_rng(5)
+    x = (np.abs(rng.standard_normal(400000)) * 10.0 ** rng.integers(-37, 38, 400000)).astype(np.float32)
+    x = x[(x >= np.float32(1.17549435e-38)) & np.isfinite(x)]
+    for op, exact in ((0, np.sqrt(x.astype(np.float64))), (1, 1.0 / np.sqrt(x.astype(np.float64)))):
+        out = np.empty_like(x)
+        ora.oracle_eval_hw(op, x.ctypes.data, out.ctypes.data, x.size)
+        d = out.view(np.int32).astype(np.int64) - exact.astype(np.float32).view(np.int32)
+        assert np.abs(d).max() <= 1 and 0.8 < np.mean(d == 0) < 0.95
+    squares = (np.arange(1, 4096, dtype=np.float32) ** 2).astype(np.float32)
+    out = np.empty_like(squares)
+    ora.oracle_eval_hw(0, squares.ctypes.data, out.ctypes.data, squares.size)
+    assert np.array_equal(out, np.arange(1, 4096, dtype=np.float32))
+    special = np.array([0.0, -0.0, np.inf, 1e-45, 1e-39, -1e-39, -1.0], dtype=np.float32)
+    s, r = np.empty_like(special), np.empty_like(special)
+    ora.oracle_eval_hw(0, special.ctypes.data, s.ctypes.data, special.size)
+    ora.oracle_eval_hw(1, special.ctypes.data, r.ctypes.data, special.size)
+    assert s[:6].tolist() == [0.0, 0.0, np.inf, 0.0, 0.0, 0.0] and np.signbit(s[1]) and np.signbit(s[5]) and np.isnan(s[6])
+    assert r[:6].tolist() == [np.inf, -np.inf, 0.0, np.inf, np.inf, -np.inf] and np.isnan(r[6])
