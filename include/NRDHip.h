@@ -63,7 +63,9 @@ uint32_t nrdHipBindResource(NrdHipExecutor* executor, uint32_t resourceType, con
 uint32_t nrdHipGetPoolPlane(NrdHipExecutor* executor, uint32_t resourceType, uint32_t indexInPool, NrdHipPlaneDesc* plane);
 
 // Executes a dispatch list obtained from nrd::GetComputeDispatches on the executor's stream, in order.
-// "dispatchDescs" is a const nrd::DispatchDesc*.
+// "dispatchDescs" is a const nrd::DispatchDesc*. All-or-nothing: the whole list is checked first (a HIP kernel exists for every pass, all
+// resources are bound, every pass accepts its constants) and an error (UNSUPPORTED / INVALID_ARGUMENT + nrdHipGetLastError) is returned
+// BEFORE anything is enqueued.
 uint32_t nrdHipExecuteDispatches(NrdHipExecutor* executor, const void* dispatchDescs, uint32_t dispatchDescsNum);
 
 // nrd::GetComputeDispatches(identifiers) followed by nrdHipExecuteDispatches: one denoised frame.
@@ -121,6 +123,20 @@ uint32_t nrdHipPlanHaloExchange(void* instance, const void* dispatchDescs, uint3
 // milliseconds[i] (sum of durations) and launches[i] (count). Pass capacity >= InstanceDesc::pipelinesNum.
 uint32_t nrdHipSetProfiling(NrdHipExecutor* executor, uint32_t enable);
 uint32_t nrdHipCollectPassTimings(NrdHipExecutor* executor, uint32_t* pipelineIndices, double* milliseconds, uint32_t* launches, uint32_t capacity, uint32_t* written);
+
+// Graph mode (the HIP-graph counterpart of the command list the reference integration records per Denoise call, reference
+// Integration/NRDIntegration.hpp:516-623): with enable != 0 the kernel launches of a dispatch range are not enqueued one by one but as ONE
+// hipGraph launch. The executable graph is built once per topology (the sequence of kernels of the range; ping-pong and per-frame constants do
+// not change it) and on the following frames only the parameters of the nodes that changed are updated (hipGraphExecKernelNodeSetParams).
+// Results are bit-identical to eager launches; per-pass profiling (nrdHipSetProfiling) falls back to eager launches while it is on.
+// nrdHipGetGraphStats: graph launches, graphs built (topology misses) and node-parameter updates so far (any pointer may be NULL).
+uint32_t nrdHipSetGraphMode(NrdHipExecutor* executor, uint32_t enable);
+uint32_t nrdHipGetGraphStats(const NrdHipExecutor* executor, uint64_t* graphLaunches, uint64_t* graphBuilds, uint64_t* nodeUpdates);
+
+// Numerics mode this library was built in (DESIGN.md "Numerics"): 1 = fast (libNRD_hip.so, the product: hardware rcp / sqrt / exp2 / log2, FMA
+// contraction, fp32 denormals flushed; results within the NRD tolerance of the CPU oracle), 0 = exact (libNRD_hip_exact.so: the pinned IEEE
+// arithmetic of the oracle, bit-identical results; the regression build). The REFERENCE denoiser is bit-exact in both.
+uint32_t nrdHipGetNumericsMode(void);
 
 // Bytes held by the pool arena (permanent, transient).
 uint32_t nrdHipGetPoolMemoryUsage(const NrdHipExecutor* executor, uint64_t* permanentBytes, uint64_t* transientBytes);

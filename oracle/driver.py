@@ -51,8 +51,17 @@ def load():
             _hw_tables.append(np.ascontiguousarray(table))
         lib.oracle_set_hw_tables.argtypes, lib.oracle_set_hw_tables.restype = [C.c_void_p, C.c_void_p], None
         lib.oracle_set_hw_tables(_hw_tables[0].ctypes.data, _hw_tables[1].ctypes.data)
+        lib.oracle_set_ieee_mode.argtypes, lib.oracle_set_ieee_mode.restype = [C.c_int], C.c_int
+        if os.environ.get("ORACLE_EXACT_SQRT", "0") not in ("", "0"):
+            lib.oracle_set_ieee_mode(1)
         _lib = lib
     return _lib
+
+
+def set_ieee_mode(on):
+    """True: sqrt / rsqrt are the correctly rounded IEEE results (the oracle knows nothing about the device); False: they emulate gfx950's v_sqrt_f32 /
+    v_rsq_f32 from the measured tables (bit-exact regression against the exact build). Returns the previous setting."""
+    return bool(load().oracle_set_ieee_mode(1 if on else 0))
 
 
 def _pitch(width, bpt):

@@ -45,10 +45,15 @@ inline float rcp(float x) { return 1.0f / x; }
 // oracle/hw_sqrt.i8.z / hw_rsq.i8.z (tools/hw_transcendentals.py: every mantissa for both exponent parities; scaling by 4^k is exact).
 // Denormal inputs are flushed to (signed) zero, negative inputs give NaN, as the instructions do. The tables are handed over by
 // oracle/driver.py (oracle_set_hw_tables); without them the functions abort: there is no silent fallback to the exact result.
+// IEEE mode (oracle_set_ieee_mode / ORACLE_EXACT_SQRT=1): sqrt and 1/sqrt are the correctly rounded results instead (denormals kept), i.e. the oracle
+// is then "the HLSL math in IEEE-754 arithmetic" with no knowledge of the device -- the mode the tolerance tests of the fast product build compare with.
 extern const signed char* g_HwSqrtDelta; // 2^24 entries: [exponent parity << 23 | mantissa]
 extern const signed char* g_HwRsqDelta;
+extern int g_IeeeMode;
 [[noreturn]] void HwTablesMissing();
 inline float HwSqrt(float x) {
+    if (g_IeeeMode)
+        return (float)sqrt((double)x); // correctly rounded (53 >= 2 * 24 + 2 bits)
     const uint32_t u = asuint(x), mag = u & 0x7fffffffu;
     if (mag > 0x7f800000u)
         return asfloat(0x7fc00000u); // NaN
@@ -65,6 +70,8 @@ inline float HwSqrt(float x) {
     return asfloat(asuint(exact) + (uint32_t)(int32_t)g_HwSqrtDelta[(parity << 23) | (u & 0x7fffffu)]);
 }
 inline float HwRsq(float x) {
+    if (g_IeeeMode)
+        return (float)(1.0 / sqrt((double)x));
     const uint32_t u = asuint(x), mag = u & 0x7fffffffu;
     if (mag > 0x7f800000u)
         return asfloat(0x7fc00000u);

@@ -15,6 +15,7 @@ using namespace orc;
 namespace orc {
 const signed char* g_HwSqrtDelta = nullptr;
 const signed char* g_HwRsqDelta = nullptr;
+int g_IeeeMode = 0;
 void HwTablesMissing() {
     fprintf(stderr, "oracle: the hardware sqrt / rsq delta tables are not loaded (oracle/hw_sqrt.i8.z, hw_rsq.i8.z through oracle/driver.py)\n");
     abort();
@@ -56,6 +57,12 @@ __attribute__((visibility("default"))) int oracle_dispatch(const char* shaderFil
 __attribute__((visibility("default"))) void oracle_set_hw_tables(const signed char* sqrtDelta, const signed char* rsqDelta) {
     orc::g_HwSqrtDelta = sqrtDelta;
     orc::g_HwRsqDelta = rsqDelta;
+}
+// 1 = IEEE mode: correctly rounded sqrt / rsqrt instead of the device emulation (oracle/hlsl.h). Returns the previous mode.
+__attribute__((visibility("default"))) int oracle_set_ieee_mode(int on) {
+    const int prev = orc::g_IeeeMode;
+    orc::g_IeeeMode = on ? 1 : 0;
+    return prev;
 }
 __attribute__((visibility("default"))) void oracle_eval_hw(int op, const float* in, float* out, int n) { // 0 = HwSqrt, 1 = HwRsq
     for (int i = 0; i < n; i++)

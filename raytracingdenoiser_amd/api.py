@@ -10,7 +10,9 @@ import enum
 import os
 
 _PKG = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_PKG, "lib", "libNRD_hip.so")
+# the two numerics builds of the library (raytracingdenoiser_amd/build.py, DESIGN.md "Numerics"): "fast" is the product, "exact" the bit-exact regression build
+LIB_PATHS = {"fast": os.path.join(_PKG, "lib", "libNRD_hip.so"), "exact": os.path.join(_PKG, "lib", "libNRD_hip_exact.so")}
+LIB_PATH = LIB_PATHS["fast"]
 
 
 # ----------------------------------------------------------------------------------------------- enums
@@ -266,17 +268,25 @@ class HipHaloPlanInfo(C.Structure):
 NRD_HIP_SYMBOLS = ["nrdHipCreateExecutor", "nrdHipDestroyExecutor", "nrdHipBindResource", "nrdHipGetPoolPlane", "nrdHipExecuteDispatches",
                    "nrdHipDenoise", "nrdHipGetPoolMemoryUsage", "nrdHipGetLastError", "nrdHipEvalNumerics", "nrdHipGetArenaSize",
                    "nrdHipCreateExecutorWithArena", "nrdHipSetProfiling", "nrdHipCollectPassTimings", "nrdHipSetOwnedRows", "nrdHipGetDispatchReach",
-                   "nrdHipExecuteDispatchRange", "nrdHipPlanHaloExchange"]
+                   "nrdHipExecuteDispatchRange", "nrdHipPlanHaloExchange", "nrdHipSetGraphMode", "nrdHipGetGraphStats", "nrdHipGetNumericsMode"]
 
-_lib = None
+_libs = {}
 
 
-def load_library(path=None):
-    """dlopen lib/libNRD_hip.so and set prototypes. Raises if the library has not been built -- there is no fallback."""
-    global _lib
-    if _lib is not None and path is None:
-        return _lib
-    path = path or LIB_PATH
+def default_numerics():
+    """"fast" unless NRD_HIP_NUMERICS=exact selects the regression build for the whole process"""
+    n = os.environ.get("NRD_HIP_NUMERICS", "fast")
+    if n not in LIB_PATHS:
+        raise RuntimeError("NRD_HIP_NUMERICS must be one of %s" % sorted(LIB_PATHS))
+    return n
+
+
+def load_library(path=None, numerics=None):
+    """dlopen lib/libNRD_hip.so (numerics "fast", the default) or lib/libNRD_hip_exact.so and set prototypes. Raises if the library has not been
+    built -- there is no fallback. Both may live in one process (RTLD_LOCAL)."""
+    path = path or LIB_PATHS[numerics or default_numerics()]
+    if path in _libs:
+        return _libs[path]
     if not os.path.exists(path):
         raise RuntimeError("NRD HIP library not built: %s (run `python -c 'import __graft_entry__ as g; g.build()'`)" % path)
     # Load order matters in a process that also uses PyTorch: torch bundles its own libamdhip64, and if this library came first the loader
@@ -324,8 +334,10 @@ def load_library(path=None):
     lib.nrdHipCollectPassTimings.restype = C.c_uint32
     lib.nrdHipEvalNumerics.argtypes = [C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p]
     lib.nrdHipEvalNumerics.restype = C.c_uint32
-    if path == LIB_PATH:
-        _lib = lib
+    lib.nrdHipSetGraphMode.argtypes, lib.nrdHipSetGraphMode.restype = [C.c_void_p, C.c_uint32], C.c_uint32
+    lib.nrdHipGetGraphStats.argtypes, lib.nrdHipGetGraphStats.restype = [C.c_void_p, P(C.c_uint64), P(C.c_uint64), P(C.c_uint64)], C.c_uint32
+    lib.nrdHipGetNumericsMode.argtypes, lib.nrdHipGetNumericsMode.restype = [], C.c_uint32
+    _libs[path] = lib
     return lib
 
 
@@ -349,9 +361,9 @@ class Dispatch:
 class Instance:
     """Thin RAII wrapper over nrd::CreateInstance / DestroyInstance."""
 
-    def __init__(self, denoisers, lib=None):
-        """denoisers: list of (identifier, Denoiser)."""
-        self.lib = lib or load_library()
+    def __init__(self, denoisers, lib=None, numerics=None):
+        """denoisers: list of (identifier, Denoiser); numerics: "fast" / "exact" build of the library (default: NRD_HIP_NUMERICS or "fast")."""
+        self.lib = lib or load_library(numerics=numerics)
         self._descs = (DenoiserDesc * len(denoisers))(*[DenoiserDesc(i, int(d)) for i, d in denoisers])
         icd = InstanceCreationDesc()
         icd.denoisers = self._descs

@@ -1,7 +1,10 @@
-"""Builds the native pieces in-tree (no JIT cache): the product library and the test oracle.
+"""Builds the native pieces in-tree (no JIT cache): the product library (in its two numerics modes) and the test oracle.
 
-  lib/libNRD_hip.so   host dispatch compiler + HIP kernels + HIP executor (hipcc, gfx950)  -- THE PRODUCT
-  oracle/liboracle.so CPU restatement of the pass arithmetic (g++)                          -- TEST INFRASTRUCTURE ONLY
+  lib/libNRD_hip.so        host dispatch compiler + HIP kernels + HIP executor (hipcc, gfx950)  -- THE PRODUCT ("fast" numerics:
+                           hardware rcp / exp2 / log2, FMA contraction, fp32 denormals flushed -- DESIGN.md "Numerics")
+  lib/libNRD_hip_exact.so  the same sources with the pinned IEEE arithmetic (no contraction, correctly rounded division, polynomial
+                           transcendentals): bit-identical to the CPU oracle -- the regression build of the parity suite
+  oracle/liboracle.so      CPU restatement of the pass arithmetic (g++)                          -- TEST INFRASTRUCTURE ONLY
 
 hipcc cross-compiles gfx950 without a GPU, so this runs in the build container; the .so files travel to the GPU box.
 """
@@ -19,9 +22,19 @@ OBJ_DIR = os.path.join(PKG, "lib", "obj")
 ORACLE_DIR = os.path.join(ROOT, "oracle")
 
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-# -ffp-contract=off: no FMA contraction, so device arithmetic is bit-reproducible against the CPU oracle
-COMMON_FLAGS = ["-std=c++17", "-O3", "-fPIC", "-ffp-contract=off", "-fvisibility=hidden", "-Wno-return-type-c-linkage", "-I" + os.path.join(ROOT, "include")]
+COMMON_FLAGS = ["-std=c++17", "-O3", "-fPIC", "-fvisibility=hidden", "-Wno-return-type-c-linkage", "-I" + os.path.join(ROOT, "include")]
 HIP_FLAGS = ["--offload-arch=gfx950", "-fno-gpu-rdc", "-Wno-unused-result", "-Wno-return-type-c-linkage"]
+# exact: no FMA contraction, so device arithmetic is bit-reproducible against the CPU oracle (DESIGN.md "Numerics")
+# fast : contraction on, a / b = a * v_rcp_f32(b), sqrt / exp2 / log2 as single hardware instructions (-fapprox-func together with flushed fp32
+#        denormals is what makes hipcc emit them without range-scaling code); NaN / infinity semantics are kept (no -ffinite-math-only)
+NUMERICS_FLAGS = {
+    "exact": ["-ffp-contract=off"],
+    "fast": ["-DNRD_FAST=1", "-ffp-contract=fast", "-fapprox-func", "-fgpu-flush-denormals-to-zero"],
+}
+LIB_NAMES = {"fast": "libNRD_hip.so", "exact": "libNRD_hip_exact.so"}
+# translation units that keep the exact flags in both builds: the REFERENCE accumulator is specified bit-exact (BASELINE.json) and is a pure
+# streaming kernel, the host dispatch compiler must hand identical constants to both builds
+ALWAYS_EXACT = ("kernels_common.hip",)
 
 
 def _sources():
@@ -41,42 +54,50 @@ def _headers_digest():
     return h.hexdigest()
 
 
-def _compile(src, hdr_digest, verbose):
+def _flags(src, numerics):
+    exact = numerics == "exact" or os.path.basename(src) in ALWAYS_EXACT or src.endswith(".cpp")
+    return COMMON_FLAGS + NUMERICS_FLAGS["exact" if exact else "fast"] + ([] if numerics == "exact" else ["-DNRD_FAST_BUILD=1"])
+
+
+def _compile(src, hdr_digest, verbose, numerics):
+    flags = _flags(src, numerics)
     with open(src, "rb") as fp:
-        digest = hashlib.sha1(fp.read() + hdr_digest.encode() + " ".join(COMMON_FLAGS + HIP_FLAGS).encode()).hexdigest()[:16]
-    obj = os.path.join(OBJ_DIR, os.path.basename(src) + "." + digest + ".o")
+        digest = hashlib.sha1(fp.read() + hdr_digest.encode() + " ".join(flags + HIP_FLAGS).encode()).hexdigest()[:16]
+    obj_dir = os.path.join(OBJ_DIR, numerics)
+    os.makedirs(obj_dir, exist_ok=True)
+    obj = os.path.join(obj_dir, os.path.basename(src) + "." + digest + ".o")
     if os.path.exists(obj):
         return obj
-    for old in os.listdir(OBJ_DIR):
+    for old in os.listdir(obj_dir):
         if old.startswith(os.path.basename(src) + "."):
-            os.remove(os.path.join(OBJ_DIR, old))
+            os.remove(os.path.join(obj_dir, old))
     is_hip = src.endswith(".hip")
-    cmd = [HIPCC] + COMMON_FLAGS + (HIP_FLAGS + ["-x", "hip"] if is_hip else ["-x", "c++"]) + ["-c", src, "-o", obj]
+    cmd = [HIPCC] + flags + (HIP_FLAGS + ["-x", "hip"] if is_hip else ["-x", "c++"]) + ["-c", src, "-o", obj]
     if verbose:
         print("[build]", " ".join(cmd), flush=True)
     subprocess.run(cmd, check=True)
     return obj
 
 
-def _global_digest(srcs, hdr_digest):
-    h = hashlib.sha1((hdr_digest + " ".join(COMMON_FLAGS + HIP_FLAGS)).encode())
+def _global_digest(srcs, hdr_digest, numerics):
+    h = hashlib.sha1((hdr_digest + " ".join(COMMON_FLAGS + HIP_FLAGS + NUMERICS_FLAGS[numerics]) + numerics).encode())
     for s in srcs:
         with open(s, "rb") as fp:
             h.update(fp.read())
     return h.hexdigest()
 
 
-def build_product(verbose=False):
-    """hipcc --offload-arch=gfx950 every HIP translation unit and link lib/libNRD_hip.so. Returns the path."""
+def build_product(verbose=False, numerics="fast"):
+    """hipcc --offload-arch=gfx950 every HIP translation unit and link lib/libNRD_hip.so (numerics "fast") or lib/libNRD_hip_exact.so. Returns the path."""
     host, hip = _sources()
     hdr = _headers_digest()
-    out = os.path.join(LIB_DIR, "libNRD_hip.so")
-    whole = _global_digest(host + hip, hdr)
+    out = os.path.join(LIB_DIR, LIB_NAMES[numerics])
+    whole = _global_digest(host + hip, hdr, numerics)
     if os.path.exists(out) and os.path.exists(out + ".digest") and open(out + ".digest").read() == whole:
         return out  # prebuilt (e.g. shipped to the GPU box) and up to date
     os.makedirs(OBJ_DIR, exist_ok=True)
     with ThreadPoolExecutor(max_workers=min(8, os.cpu_count() or 1)) as pool:
-        objs = list(pool.map(lambda s: _compile(s, hdr, verbose), host + hip))
+        objs = list(pool.map(lambda s: _compile(s, hdr, verbose, numerics), host + hip))
     cmd = [HIPCC, "-shared", "-fPIC", "--offload-arch=gfx950", "-fno-gpu-rdc"] + objs + ["-o", out]
     if verbose:
         print("[build]", " ".join(cmd), flush=True)
@@ -84,6 +105,11 @@ def build_product(verbose=False):
     with open(out + ".digest", "w") as fp:
         fp.write(whole)
     return out
+
+
+def build_all(verbose=False):
+    """both numerics modes of the product"""
+    return [build_product(verbose, "fast"), build_product(verbose, "exact")]
 
 
 def build_oracle(verbose=False):
@@ -94,6 +120,7 @@ def build_oracle(verbose=False):
 
 
 if __name__ == "__main__":
-    print(build_product(verbose=True))
+    print(build_product(verbose=True, numerics="fast"))
+    print(build_product(verbose=True, numerics="exact"))
     if "--no-oracle" not in sys.argv:
         print(build_oracle(verbose=True))

@@ -105,6 +105,23 @@ struct NrdHipExecutor {
     std::vector<uint8_t> scratchBytesPerTexel, scratchFormats;
     bool translucentShadow = false; // a SIGMA_ShadowTranslucency_* pipeline exists: OUT_SHADOW_TRANSLUCENCY is RGBA8
     std::string lastError;
+    // per-list caches (decoded guides, a-trous world positions) are valid for the dispatch list being executed: cleared when a list
+    // completes, when IN_NORMAL_ROUGHNESS is rebound and when the cache is (re)allocated, so a range with first > 0 never reads stale guides
+    bool decodedFresh = false;
+
+    // graph mode (nrdHipSetGraphMode): the launches of a dispatch range become the kernel nodes of a hipGraph that is instantiated once per
+    // topology (sequence of kernels) and re-launched with updated node parameters (constants, ping-pong planes) on the following frames
+    bool graphMode = false;
+    struct CachedGraph {
+        std::vector<const void*> funcs; // topology key
+        std::vector<LaunchRecord> records; // parameters the executable graph currently holds
+        std::vector<hipGraphNode_t> nodes;
+        hipGraph_t graph = nullptr;
+        hipGraphExec_t exec = nullptr;
+        uint64_t lastUse = 0;
+    };
+    std::vector<CachedGraph> graphs;
+    uint64_t graphClock = 0, graphLaunches = 0, graphBuilds = 0, graphNodeUpdates = 0;
 
     uint32_t Fail(nrd::Result r, const std::string& msg) {
         lastError = msg;
@@ -235,6 +252,12 @@ extern "C" __attribute__((visibility("default"))) void nrdHipDestroyExecutor(Nrd
     }
     for (hipEvent_t ev : e->eventPool)
         (void)hipEventDestroy(ev);
+    for (auto& g : e->graphs) {
+        if (g.exec)
+            (void)hipGraphExecDestroy(g.exec);
+        if (g.graph)
+            (void)hipGraphDestroy(g.graph);
+    }
     if (e->arena && e->ownsArena)
         (void)hipFree(e->arena);
     if (e->decodedNormalRoughness.ptr)
@@ -314,6 +337,8 @@ extern "C" __attribute__((visibility("default"))) uint32_t nrdHipBindResource(Nr
     p.w = plane->width;
     p.h = plane->height;
     e->userBound[resourceType] = true;
+    if (resourceType == (uint32_t)nrd::ResourceType::IN_NORMAL_ROUGHNESS || resourceType == (uint32_t)nrd::ResourceType::IN_VIEWZ)
+        e->decodedFresh = false;
     return (uint32_t)nrd::Result::SUCCESS;
 }
 
@@ -596,9 +621,135 @@ extern "C" __attribute__((visibility("default"))) uint32_t nrdHipExecuteDispatch
     return ExecuteRange(e, descs, dispatchDescsNum, 0, dispatchDescsNum, rowBegin.data(), rowEnd.data());
 }
 
+// Resolves the resources of dispatch i and fills the launcher arguments (no launch). Returns nullptr or an error text.
+static const char* PrepareDispatch(NrdHipExecutor* e, const nrd::DispatchDesc& d, PassArgs& args, std::string& err) {
+    e->scratchPlanes.resize(d.resourcesNum);
+    e->scratchBytesPerTexel.resize(d.resourcesNum);
+    e->scratchFormats.resize(d.resourcesNum);
+    for (uint32_t r = 0; r < d.resourcesNum; r++) {
+        const nrd::ResourceDesc& res = d.resources[r];
+        if (res.type == nrd::ResourceType::PERMANENT_POOL) {
+            if (res.indexInPool >= e->permanent.size())
+                return "permanent pool index out of range";
+            e->scratchPlanes[r] = e->permanent[res.indexInPool];
+            e->scratchBytesPerTexel[r] = (uint8_t)BytesPerTexel(e->permanentFormat[res.indexInPool]);
+            e->scratchFormats[r] = (uint8_t)e->permanentFormat[res.indexInPool];
+        } else if (res.type == nrd::ResourceType::TRANSIENT_POOL) {
+            if (res.indexInPool >= e->transient.size())
+                return "transient pool index out of range";
+            e->scratchPlanes[r] = e->transient[res.indexInPool];
+            e->scratchBytesPerTexel[r] = (uint8_t)BytesPerTexel(e->transientFormat[res.indexInPool]);
+            e->scratchFormats[r] = (uint8_t)e->transientFormat[res.indexInPool];
+        } else {
+            uint32_t t = (uint32_t)res.type;
+            if (t >= (uint32_t)nrd::ResourceType::MAX_NUM || !e->userBound[t]) {
+                err = std::string("resource not bound: ") + (nrd::GetResourceTypeString(res.type) ? nrd::GetResourceTypeString(res.type) : "?");
+                return err.c_str();
+            }
+            e->scratchPlanes[r] = e->user[t];
+            e->scratchBytesPerTexel[r] = (uint8_t)BytesPerTexel(ExpectedUserFormat(res.type, e->translucentShadow));
+            e->scratchFormats[r] = (uint8_t)ExpectedUserFormat(res.type, e->translucentShadow);
+        }
+    }
+    args.planes = e->scratchPlanes.data();
+    args.planesNum = d.resourcesNum;
+    args.bytesPerTexel = e->scratchBytesPerTexel.data();
+    args.formats = e->scratchFormats.data();
+    args.constants = d.constantBufferData;
+    args.constantsSize = d.constantBufferDataSize;
+    args.gridWidth = d.gridWidth;
+    args.gridHeight = d.gridHeight;
+    args.stream = e->stream;
+    return nullptr;
+}
+
+// Graph mode: the recorded launches of a range as a linear chain of kernel nodes. One executable graph per topology (sequence of kernels);
+// on a topology hit only the nodes whose parameters changed (constants, ping-pong planes, row ranges) are updated before the launch.
+static uint32_t LaunchAsGraph(NrdHipExecutor* e, std::vector<LaunchRecord>& records) {
+    if (records.empty())
+        return (uint32_t)nrd::Result::SUCCESS;
+    std::vector<const void*> funcs(records.size());
+    for (size_t i = 0; i < records.size(); i++)
+        funcs[i] = records[i].func;
+    NrdHipExecutor::CachedGraph* hit = nullptr;
+    for (auto& g : e->graphs)
+        if (g.funcs == funcs)
+            hit = &g;
+    std::vector<void*> argPtrs;
+    auto paramsOf = [&](LaunchRecord& r) {
+        argPtrs.resize(r.offsets.size());
+        for (size_t k = 0; k < r.offsets.size(); k++)
+            argPtrs[k] = r.args.data() + r.offsets[k];
+        hipKernelNodeParams p = {};
+        p.func = (void*)r.func;
+        p.gridDim = r.grid;
+        p.blockDim = r.block;
+        p.sharedMemBytes = 0;
+        p.kernelParams = argPtrs.data();
+        p.extra = nullptr;
+        return p;
+    };
+    if (!hit) {
+        if (e->graphs.size() >= 8) { // evict the least recently used topology
+            size_t lru = 0;
+            for (size_t i = 1; i < e->graphs.size(); i++)
+                if (e->graphs[i].lastUse < e->graphs[lru].lastUse)
+                    lru = i;
+            (void)hipGraphExecDestroy(e->graphs[lru].exec);
+            (void)hipGraphDestroy(e->graphs[lru].graph);
+            e->graphs.erase(e->graphs.begin() + (long)lru);
+        }
+        NrdHipExecutor::CachedGraph g;
+        g.funcs = funcs;
+        if (hipGraphCreate(&g.graph, 0) != hipSuccess)
+            return e->Fail(nrd::Result::FAILURE, "hipGraphCreate failed");
+        g.nodes.resize(records.size());
+        for (size_t i = 0; i < records.size(); i++) {
+            hipKernelNodeParams p = paramsOf(records[i]);
+            hipError_t err = hipGraphAddKernelNode(&g.nodes[i], g.graph, i ? &g.nodes[i - 1] : nullptr, i ? 1 : 0, &p);
+            if (err != hipSuccess) {
+                (void)hipGraphDestroy(g.graph);
+                return e->Fail(nrd::Result::FAILURE, std::string("hipGraphAddKernelNode failed: ") + hipGetErrorString(err));
+            }
+        }
+        hipError_t err = hipGraphInstantiate(&g.exec, g.graph, nullptr, nullptr, 0);
+        if (err != hipSuccess) {
+            (void)hipGraphDestroy(g.graph);
+            return e->Fail(nrd::Result::FAILURE, std::string("hipGraphInstantiate failed: ") + hipGetErrorString(err));
+        }
+        g.records = records;
+        e->graphs.push_back(std::move(g));
+        hit = &e->graphs.back();
+        e->graphBuilds++;
+    } else {
+        for (size_t i = 0; i < records.size(); i++) {
+            LaunchRecord& have = hit->records[i];
+            LaunchRecord& want = records[i];
+            const bool same = have.args == want.args && have.grid.x == want.grid.x && have.grid.y == want.grid.y && have.grid.z == want.grid.z && have.block.x == want.block.x &&
+                              have.block.y == want.block.y && have.block.z == want.block.z;
+            if (same)
+                continue;
+            hipKernelNodeParams p = paramsOf(want);
+            hipError_t err = hipGraphExecKernelNodeSetParams(hit->exec, hit->nodes[i], &p);
+            if (err != hipSuccess)
+                return e->Fail(nrd::Result::FAILURE, std::string("hipGraphExecKernelNodeSetParams failed: ") + hipGetErrorString(err));
+            have = want;
+            e->graphNodeUpdates++;
+        }
+    }
+    hit->lastUse = ++e->graphClock;
+    hipError_t err = hipGraphLaunch(hit->exec, e->stream);
+    if (err != hipSuccess)
+        return e->Fail(nrd::Result::FAILURE, std::string("hipGraphLaunch failed: ") + hipGetErrorString(err));
+    e->graphLaunches++;
+    return (uint32_t)nrd::Result::SUCCESS;
+}
+
 static uint32_t ExecuteRange(NrdHipExecutor* e, const nrd::DispatchDesc* descs, uint32_t dispatchDescsNum, uint32_t first, uint32_t count, const int32_t* rowBegin, const int32_t* rowEnd) {
-    // Decoded-guide cache: if any dispatch reads IN_NORMAL_ROUGHNESS, decode the bound plane once for the whole list
+    const nrd::InstanceDesc& idesc = nrd::GetInstanceDesc(*e->instance);
+    // Decoded-guide cache: if any dispatch reads IN_NORMAL_ROUGHNESS, the bound plane is decoded once for the whole list
     Plane decoded = {};
+    bool decodeNow = false;
     {
         const uint32_t slot = (uint32_t)nrd::ResourceType::IN_NORMAL_ROUGHNESS;
         bool used = false;
@@ -618,16 +769,17 @@ static uint32_t ExecuteRange(NrdHipExecutor* e, const nrd::DispatchDesc* descs, 
                 cache.pitch = pitch;
                 cache.w = packed.w;
                 cache.h = packed.h;
+                e->decodedFresh = false;
             }
-            if (first == 0) // later ranges of the same list reuse this frame's decode
-                LaunchDecodeNormalRoughness(packed, cache, e->stream);
+            // first == 0 starts a new list (= a new frame); a later range decodes only if nothing valid is there (rebound plane, new cache,
+            // or a caller that skipped the first range)
+            decodeNow = first == 0 || !e->decodedFresh;
             decoded = cache;
         }
     }
     // World-position scratch of the RELAX a-trous chain (same geometry as the decoded-guide cache)
     Plane worldPos = {};
     if (decoded.ptr) {
-        const nrd::InstanceDesc& idesc = nrd::GetInstanceDesc(*e->instance);
         bool used = false;
         for (uint32_t i = 0; i < dispatchDescsNum && !used; i++)
             used = descs[i].pipelineIndex < idesc.pipelinesNum && strstr(idesc.pipelines[descs[i].pipelineIndex].shaderFileName, "_Atrous") != nullptr;
@@ -645,50 +797,11 @@ static uint32_t ExecuteRange(NrdHipExecutor* e, const nrd::DispatchDesc* descs, 
         }
     }
 
-    for (uint32_t i = first; i < first + count; i++) {
-        const nrd::DispatchDesc& d = descs[i];
-        if (d.pipelineIndex >= e->launchers.size())
-            return e->Fail(nrd::Result::INVALID_ARGUMENT, "nrdHipExecuteDispatches: pipeline index out of range");
-        PassLauncher launch = e->launchers[d.pipelineIndex];
-        if (!launch)
-            return e->Fail(nrd::Result::UNSUPPORTED, std::string("nrdHipExecuteDispatches: no HIP kernel for pass '") + (d.name ? d.name : "?") + "' (" +
-                nrd::GetInstanceDesc(*e->instance).pipelines[d.pipelineIndex].shaderFileName + ")");
-
-        e->scratchPlanes.resize(d.resourcesNum);
-        e->scratchBytesPerTexel.resize(d.resourcesNum);
-        e->scratchFormats.resize(d.resourcesNum);
-        for (uint32_t r = 0; r < d.resourcesNum; r++) {
-            const nrd::ResourceDesc& res = d.resources[r];
-            if (res.type == nrd::ResourceType::PERMANENT_POOL) {
-                if (res.indexInPool >= e->permanent.size())
-                    return e->Fail(nrd::Result::INVALID_ARGUMENT, "permanent pool index out of range");
-                e->scratchPlanes[r] = e->permanent[res.indexInPool];
-                e->scratchBytesPerTexel[r] = (uint8_t)BytesPerTexel(e->permanentFormat[res.indexInPool]);
-                e->scratchFormats[r] = (uint8_t)e->permanentFormat[res.indexInPool];
-            } else if (res.type == nrd::ResourceType::TRANSIENT_POOL) {
-                if (res.indexInPool >= e->transient.size())
-                    return e->Fail(nrd::Result::INVALID_ARGUMENT, "transient pool index out of range");
-                e->scratchPlanes[r] = e->transient[res.indexInPool];
-                e->scratchBytesPerTexel[r] = (uint8_t)BytesPerTexel(e->transientFormat[res.indexInPool]);
-                e->scratchFormats[r] = (uint8_t)e->transientFormat[res.indexInPool];
-            } else {
-                uint32_t t = (uint32_t)res.type;
-                if (t >= (uint32_t)nrd::ResourceType::MAX_NUM || !e->userBound[t])
-                    return e->Fail(nrd::Result::INVALID_ARGUMENT, std::string("resource not bound: ") + (nrd::GetResourceTypeString(res.type) ? nrd::GetResourceTypeString(res.type) : "?"));
-                e->scratchPlanes[r] = e->user[t];
-                e->scratchBytesPerTexel[r] = (uint8_t)BytesPerTexel(ExpectedUserFormat(res.type, e->translucentShadow));
-                e->scratchFormats[r] = (uint8_t)ExpectedUserFormat(res.type, e->translucentShadow);
-            }
-        }
-
-        PassArgs args;
-        args.planes = e->scratchPlanes.data();
-        args.planesNum = d.resourcesNum;
-        args.bytesPerTexel = e->scratchBytesPerTexel.data();
-        args.formats = e->scratchFormats.data();
-        args.constants = d.constantBufferData;
-        args.constantsSize = d.constantBufferDataSize;
-        args.stream = e->stream;
+    auto passName = [&](const nrd::DispatchDesc& d) {
+        return std::string("'") + (d.name ? d.name : "?") + "' (" + (d.pipelineIndex < idesc.pipelinesNum ? idesc.pipelines[d.pipelineIndex].shaderFileName : "?") + ")";
+    };
+    auto fill = [&](uint32_t i, PassArgs& args, std::string& msg) -> const char* {
+        const char* err = PrepareDispatch(e, descs[i], args, msg);
         args.rowBegin = 0;
         args.rowEnd = INT_MAX;
         args.decodedNormalRoughness = decoded;
@@ -697,30 +810,107 @@ static uint32_t ExecuteRange(NrdHipExecutor* e, const nrd::DispatchDesc* descs, 
             args.rowBegin = rowBegin[i];
             args.rowEnd = rowEnd[i];
         }
-        NrdHipExecutor::Bracket bracket = {};
-        if (e->profiling) {
-            bracket.start = AcquireEvent(e);
-            bracket.stop = AcquireEvent(e);
-            bracket.pipelineIndex = d.pipelineIndex;
-            (void)hipEventRecord(bracket.start, e->stream);
-        }
-        const char* err = launch(args);
-        if (e->profiling) {
-            (void)hipEventRecord(bracket.stop, e->stream);
-            e->brackets.push_back(bracket);
-        }
-        if (err)
-            return e->Fail(nrd::Result::UNSUPPORTED, err);
-        hipError_t launchError = hipGetLastError(); // launch-configuration errors surface here (no synchronisation)
-        if (launchError != hipSuccess)
-            return e->Fail(nrd::Result::FAILURE, std::string("HIP launch failed in pass '") + (d.name ? d.name : "?") + "' (" +
-                nrd::GetInstanceDesc(*e->instance).pipelines[d.pipelineIndex].shaderFileName + "): " + hipGetErrorString(launchError));
+        return err;
+    };
+
+    // ---- pre-flight: every pass of the range must have a launcher, bound resources and pass its own support checks BEFORE anything is enqueued
+    // (the reference integration's contract: a Denoise call either runs completely or not at all). In graph mode the same walk collects the launches.
+    const bool useGraph = e->graphMode && !e->profiling;
+    LaunchRecorder recorder;
+    recorder.keep = useGraph;
+    if (decodeNow) {
+        PassArgs args = {};
+        args.stream = e->stream;
+        args.recorder = &recorder;
+        LaunchDecodeNormalRoughness(args, e->user[(uint32_t)nrd::ResourceType::IN_NORMAL_ROUGHNESS], decoded);
     }
+    for (uint32_t i = first; i < first + count; i++) {
+        const nrd::DispatchDesc& d = descs[i];
+        if (d.pipelineIndex >= e->launchers.size())
+            return e->Fail(nrd::Result::INVALID_ARGUMENT, "nrdHipExecuteDispatches: pipeline index out of range");
+        PassLauncher launch = e->launchers[d.pipelineIndex];
+        if (!launch)
+            return e->Fail(nrd::Result::UNSUPPORTED, "nrdHipExecuteDispatches: no HIP kernel for pass " + passName(d) + "; nothing was launched");
+        if (d.constantBufferDataSize && !d.constantBufferData)
+            return e->Fail(nrd::Result::INVALID_ARGUMENT, "nrdHipExecuteDispatches: pass " + passName(d) + " has no constant data (constant arena overflow?); nothing was launched");
+        PassArgs args = {};
+        std::string msg;
+        if (const char* err = fill(i, args, msg))
+            return e->Fail(nrd::Result::INVALID_ARGUMENT, std::string(err) + " in pass " + passName(d) + "; nothing was launched");
+        args.recorder = &recorder;
+        if (const char* err = launch(args))
+            return e->Fail(nrd::Result::UNSUPPORTED, std::string(err) + " [pass " + passName(d) + "; nothing was launched]");
+    }
+
+    if (useGraph) {
+        uint32_t r = LaunchAsGraph(e, recorder.records);
+        if (r != (uint32_t)nrd::Result::SUCCESS)
+            return r;
+    } else {
+        if (decodeNow) {
+            PassArgs args = {};
+            args.stream = e->stream;
+            LaunchDecodeNormalRoughness(args, e->user[(uint32_t)nrd::ResourceType::IN_NORMAL_ROUGHNESS], decoded);
+        }
+        for (uint32_t i = first; i < first + count; i++) {
+            const nrd::DispatchDesc& d = descs[i];
+            PassArgs args = {};
+            std::string msg;
+            (void)fill(i, args, msg);
+            NrdHipExecutor::Bracket bracket = {};
+            if (e->profiling) {
+                bracket.start = AcquireEvent(e);
+                bracket.stop = AcquireEvent(e);
+                bracket.pipelineIndex = d.pipelineIndex;
+                (void)hipEventRecord(bracket.start, e->stream);
+            }
+            const char* err = e->launchers[d.pipelineIndex](args);
+            if (e->profiling) {
+                (void)hipEventRecord(bracket.stop, e->stream);
+                e->brackets.push_back(bracket);
+            }
+            if (err) // cannot happen after the pre-flight
+                return e->Fail(nrd::Result::UNSUPPORTED, err);
+            hipError_t launchError = hipGetLastError(); // launch-configuration errors surface here (no synchronisation)
+            if (launchError != hipSuccess)
+                return e->Fail(nrd::Result::FAILURE, "HIP launch failed in pass " + passName(d) + ": " + hipGetErrorString(launchError));
+        }
+    }
+    if (decoded.ptr)
+        e->decodedFresh = first + count < dispatchDescsNum; // the list is complete: the next call belongs to another frame
 
     hipError_t err = hipGetLastError();
     if (err != hipSuccess)
         return e->Fail(nrd::Result::FAILURE, std::string("HIP launch failed: ") + hipGetErrorString(err));
     return (uint32_t)nrd::Result::SUCCESS;
+}
+
+extern "C" __attribute__((visibility("default"))) uint32_t nrdHipSetGraphMode(NrdHipExecutor* e, uint32_t enable) {
+    if (!e)
+        return (uint32_t)nrd::Result::INVALID_ARGUMENT;
+    e->graphMode = enable != 0;
+    return (uint32_t)nrd::Result::SUCCESS;
+}
+
+extern "C" __attribute__((visibility("default"))) uint32_t nrdHipGetGraphStats(const NrdHipExecutor* e, uint64_t* graphLaunches, uint64_t* graphBuilds, uint64_t* nodeUpdates) {
+    if (!e)
+        return (uint32_t)nrd::Result::INVALID_ARGUMENT;
+    if (graphLaunches)
+        *graphLaunches = e->graphLaunches;
+    if (graphBuilds)
+        *graphBuilds = e->graphBuilds;
+    if (nodeUpdates)
+        *nodeUpdates = e->graphNodeUpdates;
+    return (uint32_t)nrd::Result::SUCCESS;
+}
+
+// 0 = exact (pinned IEEE arithmetic, bit-identical to the CPU oracle), 1 = fast (hardware rcp / exp2 / log2, FMA contraction): the build this library is
+extern "C" __attribute__((visibility("default"))) uint32_t nrdHipGetNumericsMode(void) {
+#ifdef NRD_FAST_BUILD
+    return 1;
+#else
+    return 0;
+#endif
 }
 
 extern "C" __attribute__((visibility("default"))) uint32_t nrdHipDenoise(NrdHipExecutor* e, const uint32_t* identifiers, uint32_t identifiersNum) {

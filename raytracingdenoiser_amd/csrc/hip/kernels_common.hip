@@ -5,6 +5,8 @@
 // MI355X mapping: rows are processed as 16-byte vectors, one 256-thread block covers 256 vectors of one row segment,
 // so every wave issues full 1 KiB coalesced transactions; ~48 B/px of traffic and no reuse => HBM-bound.
 #include "../common/pass_constants.h"
+
+#include <climits>
 #include "nrdmath.h"
 #include "passes.h"
 #include "reblur_device.h"
@@ -19,17 +21,17 @@ __global__ __launch_bounds__(256) void DecodeNormalRoughnessKernel(Plane packed,
         StoreRGBA32F(decoded, x, y, EncodeDecodedNormalRoughness(LoadR32U(packed, x, y)));
 }
 
-void LaunchDecodeNormalRoughness(const Plane& packed, const Plane& decoded, hipStream_t stream) {
-    hipLaunchKernelGGL(DecodeNormalRoughnessKernel, dim3((unsigned)((packed.w + 255) / 256), (unsigned)packed.h, 1), dim3(256), 0, stream, packed, decoded);
+void LaunchDecodeNormalRoughness(const PassArgs& a, const Plane& packed, const Plane& decoded) {
+    LaunchPass(a, DecodeNormalRoughnessKernel, dim3((unsigned)((packed.w + 255) / 256), (unsigned)packed.h, 1), dim3(256), packed, decoded);
 }
 
 // ---- Clear: zero every texel of the plane (row padding is never read). User planes may have any pitch / alignment, so a 16-byte
 // chunk is written with one store only when it is whole and aligned, bytewise otherwise (ragged row ends, 1-pixel-wide frames)
-__global__ __launch_bounds__(256) void ClearPlaneKernel(Plane out, uint32_t rowBytes) {
+__global__ __launch_bounds__(256) void ClearPlaneKernel(Plane out, uint32_t rowBytes, uint32_t firstRow) {
     const uint32_t begin = (blockIdx.x * 256u + threadIdx.x) * 16u;
     if (begin >= rowBytes)
         return;
-    uint8_t* p = out.ptr + (size_t)blockIdx.y * out.pitch + begin;
+    uint8_t* p = out.ptr + (size_t)(blockIdx.y + firstRow) * out.pitch + begin;
     const uint32_t n = rowBytes - begin < 16u ? rowBytes - begin : 16u;
     if (n == 16u && ((uintptr_t)p & 15u) == 0) {
         *(uint4*)p = make_uint4(0, 0, 0, 0);
@@ -44,16 +46,29 @@ static const char* LaunchClear(const PassArgs& a) {
     const uint32_t rowBytes = (uint32_t)out.w * a.bytesPerTexel[0];
     if (rowBytes == 0 || out.h == 0)
         return nullptr;
+    // always the whole plane: clears belong to restart frames, which the sharding planners run unsharded (reach unknown), and the plane may be a
+    // down-sampled one whose rows are not the frame's rows
     dim3 grid((rowBytes + 4095) / 4096, (unsigned)out.h, 1);
-    hipLaunchKernelGGL(ClearPlaneKernel, grid, dim3(256), 0, a.stream, out, rowBytes);
+    LaunchPass(a, ClearPlaneKernel, grid, dim3(256), out, rowBytes, 0u);
     return nullptr;
 }
 
+// columns [0, w) and rows [r0, r1) a REFERENCE pass covers: the dispatch grid (16x16 groups) clipped to the plane and to the rank's rows
+static void CoveredArea(const PassArgs& a, const Plane& plane, int& w, int& r0, int& r1) {
+    const int gw = a.gridWidth ? (int)a.gridWidth * 16 : plane.w, gh = a.gridHeight ? (int)a.gridHeight * 16 : plane.h;
+    w = gw < plane.w ? gw : plane.w;
+    const int h = gh < plane.h ? gh : plane.h;
+    r0 = a.rowBegin < 0 ? 0 : (a.rowBegin > h ? h : a.rowBegin);
+    r1 = a.rowEnd > h ? h : a.rowEnd;
+}
+
 // ---- REFERENCE accumulate: history = lerp(history, input, accumSpeed), in place -------------------------------------
-__global__ __launch_bounds__(256) void ReferenceAccumulateKernel(Plane input, Plane history, float accumSpeed) {
+// The reference launches 16x16 groups over the rect (Reference.hpp NRD_DECLARE_DIMS): the pass covers [0, 16 * gridWidth) x [0, 16 * gridHeight)
+// clipped to the texture, which is what (limitW, rows) carry; a rank of a sharded frame covers its rows only.
+__global__ __launch_bounds__(256) void ReferenceAccumulateKernel(Plane input, Plane history, float accumSpeed, int limitW, int firstRow) {
     int x = blockIdx.x * 256 + threadIdx.x;
-    int y = blockIdx.y;
-    if (x >= history.w)
+    int y = blockIdx.y + firstRow;
+    if (x >= limitW)
         return;
     float4 in = InBounds(input, x, y) ? LoadRGBA32F(input, x, y) : F4(0.0f);
     float4 h = LoadRGBA32F(history, x, y);
@@ -63,16 +78,20 @@ __global__ __launch_bounds__(256) void ReferenceAccumulateKernel(Plane input, Pl
 static const char* LaunchReferenceAccumulate(const PassArgs& a) {
     const auto* c = (const nrdc::ReferenceAccumulateConstants*)a.constants;
     const Plane& history = a.planes[1];
-    dim3 grid((unsigned)(history.w + 255) / 256, (unsigned)history.h, 1);
-    hipLaunchKernelGGL(ReferenceAccumulateKernel, grid, dim3(256), 0, a.stream, a.planes[0], history, c->gAccumSpeed);
+    int w, r0, r1;
+    CoveredArea(a, history, w, r0, r1);
+    if (w <= 0 || r1 <= r0)
+        return nullptr;
+    dim3 grid((unsigned)(w + 255) / 256, (unsigned)(r1 - r0), 1);
+    LaunchPass(a, ReferenceAccumulateKernel, grid, dim3(256), a.planes[0], history, c->gAccumSpeed, w, r0);
     return nullptr;
 }
 
 // ---- REFERENCE copy: out = history where pixelUv.x > splitScreen -----------------------------------------------------
-__global__ __launch_bounds__(256) void ReferenceCopyKernel(Plane history, Plane out, float rectSizeInvX, float splitScreen) {
+__global__ __launch_bounds__(256) void ReferenceCopyKernel(Plane history, Plane out, float rectSizeInvX, float splitScreen, int limitW, int firstRow) {
     int x = blockIdx.x * 256 + threadIdx.x;
-    int y = blockIdx.y;
-    if (x >= out.w || !InBounds(history, x, y))
+    int y = blockIdx.y + firstRow;
+    if (x >= limitW || !InBounds(history, x, y))
         return;
     float pixelUvX = (float(x) + 0.5f) * rectSizeInvX;
     if (pixelUvX > splitScreen)
@@ -82,8 +101,12 @@ __global__ __launch_bounds__(256) void ReferenceCopyKernel(Plane history, Plane 
 static const char* LaunchReferenceCopy(const PassArgs& a) {
     const auto* c = (const nrdc::ReferenceCopyConstants*)a.constants;
     const Plane& out = a.planes[1];
-    dim3 grid((unsigned)(out.w + 255) / 256, (unsigned)out.h, 1);
-    hipLaunchKernelGGL(ReferenceCopyKernel, grid, dim3(256), 0, a.stream, a.planes[0], out, c->gRectSizeInv.x, c->gSplitScreen);
+    int w, r0, r1;
+    CoveredArea(a, out, w, r0, r1);
+    if (w <= 0 || r1 <= r0)
+        return nullptr;
+    dim3 grid((unsigned)(w + 255) / 256, (unsigned)(r1 - r0), 1);
+    LaunchPass(a, ReferenceCopyKernel, grid, dim3(256), a.planes[0], out, c->gRectSizeInv.x, c->gSplitScreen, w, r0);
     return nullptr;
 }
 

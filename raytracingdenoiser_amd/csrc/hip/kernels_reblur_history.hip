@@ -302,7 +302,7 @@ static const char* LaunchHistoryFix(const PassArgs& a) {
     if (k != a.planesNum)
         return "REBLUR history fix: unexpected resource count";
     RowGrid g = GridForRows(c.gRectSizeMinusOne.x + 1, c.gRectSizeMinusOne.y + 1, TILE_X, TILE_Y, a.rowBegin, a.rowEnd);
-    hipLaunchKernelGGL((ReblurHistoryFixKernel<DIFF, SPEC, PERF, KIND, SH>), g.grid, dim3(TILE_X * TILE_Y), 0, a.stream, c, P, RowRange{g.firstBlockY, g.rowBegin, g.rowEnd});
+    LaunchPass(a, (ReblurHistoryFixKernel<DIFF, SPEC, PERF, KIND, SH>), g.grid, dim3(TILE_X * TILE_Y), c, P, RowRange{g.firstBlockY, g.rowBegin, g.rowEnd});
     return nullptr;
 }
 
@@ -597,7 +597,7 @@ static const char* LaunchTemporalStabilization(const PassArgs& a) {
     if (k != a.planesNum)
         return "REBLUR temporal stabilization: unexpected resource count";
     RowGrid g = GridForRows(c.gRectSizeMinusOne.x + 1, c.gRectSizeMinusOne.y + 1, TILE_X, TILE_Y, a.rowBegin, a.rowEnd);
-    hipLaunchKernelGGL((ReblurTemporalStabilizationKernel<DIFF, SPEC, PERF, SH, KIND>), g.grid, dim3(TILE_X * TILE_Y), 0, a.stream, c, P, RowRange{g.firstBlockY, g.rowBegin, g.rowEnd});
+    LaunchPass(a, (ReblurTemporalStabilizationKernel<DIFF, SPEC, PERF, SH, KIND>), g.grid, dim3(TILE_X * TILE_Y), c, P, RowRange{g.firstBlockY, g.rowBegin, g.rowEnd});
     return nullptr;
 }
 

@@ -55,7 +55,7 @@ static const char* LaunchClassifyTiles(const PassArgs& a) {
     if (tilesPerRow > tiles.w || tileRows > tiles.h)
         return "REBLUR ClassifyTiles: the rect does not fit the tile plane";
     int numTiles = tilesPerRow * tileRows;
-    hipLaunchKernelGGL(ReblurClassifyTilesKernel, dim3((numTiles + 3) / 4), dim3(256), 0, a.stream, a.planes[0], tiles, c.gViewZScale, c.gDenoisingRange, tilesPerRow, tileRows);
+    LaunchPass(a, ReblurClassifyTilesKernel, dim3((numTiles + 3) / 4), dim3(256), a.planes[0], tiles, c.gViewZScale, c.gDenoisingRange, tilesPerRow, tileRows);
     return nullptr;
 }
 
@@ -573,11 +573,11 @@ static const char* LaunchSpatial(const PassArgs& a) {
     const RowRange rows = {g.firstBlockY, g.rowBegin, g.rowEnd};
     if constexpr (MODE == PRE_BLUR) { // only the pre-pass reads the (possibly checkerboarded) noisy inputs
         if (c.gDiffCheckerboard != 2 || c.gSpecCheckerboard != 2) {
-            hipLaunchKernelGGL((ReblurSpatialKernel<MODE, DIFF, SPEC, NO_TS, PERF, KIND, SH, true>), g.grid, dim3(TILE_X * TILE_Y), 0, a.stream, c, P, rows);
+            LaunchPass(a, (ReblurSpatialKernel<MODE, DIFF, SPEC, NO_TS, PERF, KIND, SH, true>), g.grid, dim3(TILE_X * TILE_Y), c, P, rows);
             return nullptr;
         }
     }
-    hipLaunchKernelGGL((ReblurSpatialKernel<MODE, DIFF, SPEC, NO_TS, PERF, KIND, SH, false>), g.grid, dim3(TILE_X * TILE_Y), 0, a.stream, c, P, rows);
+    LaunchPass(a, (ReblurSpatialKernel<MODE, DIFF, SPEC, NO_TS, PERF, KIND, SH, false>), g.grid, dim3(TILE_X * TILE_Y), c, P, rows);
     return nullptr;
 }
 
@@ -633,11 +633,11 @@ static const char* LaunchSplitScreen(const PassArgs& a) {
         if (a.formats[i] != format)
             return "REBLUR split screen: mixed signal formats";
     if (format == (uint32_t)FORMAT_RGBA16_SFLOAT)
-        hipLaunchKernelGGL((ReblurSplitScreenKernel<DIFF, SPEC, SIGNAL_RADIANCE>), g.grid, dim3(256), 0, a.stream, c, viewZ, inDiff, inSpec, outDiff, outSpec, inDiffSh, inSpecSh, outDiffSh, outSpecSh, rows);
+        LaunchPass(a, (ReblurSplitScreenKernel<DIFF, SPEC, SIGNAL_RADIANCE>), g.grid, dim3(256), c, viewZ, inDiff, inSpec, outDiff, outSpec, inDiffSh, inSpecSh, outDiffSh, outSpecSh, rows);
     else if (format == (uint32_t)FORMAT_R16_UNORM)
-        hipLaunchKernelGGL((ReblurSplitScreenKernel<DIFF, SPEC, SIGNAL_OCCLUSION>), g.grid, dim3(256), 0, a.stream, c, viewZ, inDiff, inSpec, outDiff, outSpec, inDiffSh, inSpecSh, outDiffSh, outSpecSh, rows);
+        LaunchPass(a, (ReblurSplitScreenKernel<DIFF, SPEC, SIGNAL_OCCLUSION>), g.grid, dim3(256), c, viewZ, inDiff, inSpec, outDiff, outSpec, inDiffSh, inSpecSh, outDiffSh, outSpecSh, rows);
     else if (format == (uint32_t)FORMAT_RGBA16_SNORM)
-        hipLaunchKernelGGL((ReblurSplitScreenKernel<DIFF, SPEC, SIGNAL_DIRECTIONAL_OCCLUSION>), g.grid, dim3(256), 0, a.stream, c, viewZ, inDiff, inSpec, outDiff, outSpec, inDiffSh, inSpecSh, outDiffSh,
+        LaunchPass(a, (ReblurSplitScreenKernel<DIFF, SPEC, SIGNAL_DIRECTIONAL_OCCLUSION>), g.grid, dim3(256), c, viewZ, inDiff, inSpec, outDiff, outSpec, inDiffSh, inSpecSh, outDiffSh,
             outSpecSh, rows);
     else
         return "REBLUR split screen: unexpected signal format";
@@ -751,7 +751,7 @@ static const char* LaunchHitDistReconstruction(const PassArgs& a) {
     if (k != a.planesNum || !P.decodedNR.ptr)
         return "REBLUR hit distance reconstruction: unexpected resource count or missing decoded normal/roughness cache";
     RowGrid g = GridForRows(c.gRectSizeMinusOne.x + 1, c.gRectSizeMinusOne.y + 1, TILE_X, TILE_Y, a.rowBegin, a.rowEnd);
-    hipLaunchKernelGGL((ReblurHitDistReconstructionKernel<DIFF, SPEC, BORDER, PERF, KIND>), g.grid, dim3(TILE_X * TILE_Y), 0, a.stream, c, P, RowRange{g.firstBlockY, g.rowBegin, g.rowEnd});
+    LaunchPass(a, (ReblurHitDistReconstructionKernel<DIFF, SPEC, BORDER, PERF, KIND>), g.grid, dim3(TILE_X * TILE_Y), c, P, RowRange{g.firstBlockY, g.rowBegin, g.rowEnd});
     return nullptr;
 }
 

@@ -808,7 +808,7 @@ static const char* LaunchTemporalAccumulation(const PassArgs& a) {
     }
 
     RowGrid g = GridForRows(c.gRectSizeMinusOne.x + 1, c.gRectSizeMinusOne.y + 1, TILE_X, TILE_Y, a.rowBegin, a.rowEnd);
-    hipLaunchKernelGGL((ReblurTemporalAccumulationKernel<DIFF, SPEC, PERF, KIND, SH>), g.grid, dim3(TILE_X * TILE_Y), 0, a.stream, c, P, RowRange{g.firstBlockY, g.rowBegin, g.rowEnd});
+    LaunchPass(a, (ReblurTemporalAccumulationKernel<DIFF, SPEC, PERF, KIND, SH>), g.grid, dim3(TILE_X * TILE_Y), c, P, RowRange{g.firstBlockY, g.rowBegin, g.rowEnd});
     return nullptr;
 }
 

@@ -382,7 +382,7 @@ const char* LaunchAtrousSmem(const PassArgs& a) {
     RowGrid g = GridForRows((c.shared.gRectSize.x + 7) & ~7, (c.shared.gRectSize.y + 7) & ~7, TILE_X, TILE_Y, a.rowBegin, a.rowEnd);
     if (a.rowEnd >= c.shared.gRectSize.y) // the owner of the last rows also owns the rounding rows below the rect
         g.rowEnd = (c.shared.gRectSize.y + 7) & ~7;
-    hipLaunchKernelGGL((RelaxAtrousSmemKernel<DIFF, SPEC, SH>), g.grid, dim3(256), 0, a.stream, P, c, RowRange{g.firstBlockY, g.rowBegin, g.rowEnd});
+    LaunchPass(a, (RelaxAtrousSmemKernel<DIFF, SPEC, SH>), g.grid, dim3(256), P, c, RowRange{g.firstBlockY, g.rowBegin, g.rowEnd});
     return nullptr;
 }
 
@@ -582,7 +582,7 @@ const char* LaunchAtrous(const PassArgs& a) {
         return "RELAX Atrous: unexpected resource count";
     RelaxCB c = LoadRelaxConstants(a);
     RowGrid g = GridForRows(c.shared.gRectSize.x, c.shared.gRectSize.y, TILE_X, TILE_Y, a.rowBegin, a.rowEnd);
-    hipLaunchKernelGGL((RelaxAtrousKernel<DIFF, SPEC, SH>), g.grid, dim3(256), 0, a.stream, P, c, RowRange{g.firstBlockY, g.rowBegin, g.rowEnd});
+    LaunchPass(a, (RelaxAtrousKernel<DIFF, SPEC, SH>), g.grid, dim3(256), P, c, RowRange{g.firstBlockY, g.rowBegin, g.rowEnd});
     return nullptr;
 }
 

@@ -55,7 +55,7 @@ const char* LaunchClassifyTiles(const PassArgs& a) {
     if (tilesPerRow > tiles.w || tileRows > tiles.h)
         return "RELAX ClassifyTiles: the rect does not fit the tile plane";
     int numTiles = tilesPerRow * tileRows;
-    hipLaunchKernelGGL(RelaxClassifyTilesKernel, dim3((numTiles + 3) / 4), dim3(256), 0, a.stream, a.planes[0], tiles, c.gDenoisingRange, tilesPerRow, tileRows);
+    LaunchPass(a, RelaxClassifyTilesKernel, dim3((numTiles + 3) / 4), dim3(256), a.planes[0], tiles, c.gDenoisingRange, tilesPerRow, tileRows);
     return nullptr;
 }
 
@@ -162,7 +162,7 @@ const char* LaunchHitDistReconstruction(const PassArgs& a) {
         return "RELAX HitDistReconstruction: unexpected resource count or missing decoded normal/roughness cache";
     RelaxCB c = LoadRelaxConstants(a);
     RowGrid g = GridForRows(c.shared.gRectSize.x, c.shared.gRectSize.y, TILE_X, TILE_Y, a.rowBegin, a.rowEnd);
-    hipLaunchKernelGGL((RelaxHitDistReconstructionKernel<DIFF, SPEC, BORDER>), g.grid, dim3(256), 0, a.stream, P, c, RowRange{g.firstBlockY, g.rowBegin, g.rowEnd});
+    LaunchPass(a, (RelaxHitDistReconstructionKernel<DIFF, SPEC, BORDER>), g.grid, dim3(256), P, c, RowRange{g.firstBlockY, g.rowBegin, g.rowEnd});
     return nullptr;
 }
 
@@ -426,9 +426,9 @@ const char* LaunchPrePass(const PassArgs& a) {
     RelaxCB c = LoadRelaxConstants(a);
     RowGrid g = GridForRows(c.shared.gRectSize.x, c.shared.gRectSize.y, TILE_X, TILE_Y, a.rowBegin, a.rowEnd);
     if ((SPEC && c.shared.gSpecCheckerboard != 2u) || (DIFF && c.shared.gDiffCheckerboard != 2u))
-        hipLaunchKernelGGL((RelaxPrePassKernel<DIFF, SPEC, SH, true>), g.grid, dim3(256), 0, a.stream, P, c, RowRange{g.firstBlockY, g.rowBegin, g.rowEnd});
+        LaunchPass(a, (RelaxPrePassKernel<DIFF, SPEC, SH, true>), g.grid, dim3(256), P, c, RowRange{g.firstBlockY, g.rowBegin, g.rowEnd});
     else
-        hipLaunchKernelGGL((RelaxPrePassKernel<DIFF, SPEC, SH, false>), g.grid, dim3(256), 0, a.stream, P, c, RowRange{g.firstBlockY, g.rowBegin, g.rowEnd});
+        LaunchPass(a, (RelaxPrePassKernel<DIFF, SPEC, SH, false>), g.grid, dim3(256), P, c, RowRange{g.firstBlockY, g.rowBegin, g.rowEnd});
     return nullptr;
 }
 
@@ -550,7 +550,7 @@ const char* LaunchHistoryFix(const PassArgs& a) {
         return "RELAX HistoryFix: unexpected resource count or missing decoded normal/roughness cache";
     RelaxCB c = LoadRelaxConstants(a);
     RowGrid g = GridForRows(c.shared.gRectSize.x, c.shared.gRectSize.y, TILE_X, TILE_Y, a.rowBegin, a.rowEnd);
-    hipLaunchKernelGGL((RelaxHistoryFixKernel<DIFF, SPEC, SH>), g.grid, dim3(256), 0, a.stream, P, c, RowRange{g.firstBlockY, g.rowBegin, g.rowEnd});
+    LaunchPass(a, (RelaxHistoryFixKernel<DIFF, SPEC, SH>), g.grid, dim3(256), P, c, RowRange{g.firstBlockY, g.rowBegin, g.rowEnd});
     return nullptr;
 }
 
@@ -586,7 +586,7 @@ const char* LaunchCopy(const PassArgs& a) {
         return "RELAX Copy: unexpected resource count";
     RelaxCB c = LoadRelaxConstants(a);
     const int gridW = (c.shared.gRectSize.x + 7) & ~7, gridH = (c.shared.gRectSize.y + 7) & ~7; // the reference's 8x8 groups over the rect
-    hipLaunchKernelGGL((RelaxCopyKernel<DIFF, SPEC>), GridFor(gridW, gridH, TILE_X, TILE_Y), dim3(256), 0, a.stream, P, gridW, gridH);
+    LaunchPass(a, (RelaxCopyKernel<DIFF, SPEC>), GridFor(gridW, gridH, TILE_X, TILE_Y), dim3(256), P, gridW, gridH);
     return nullptr;
 }
 
@@ -669,7 +669,7 @@ const char* LaunchAntiFirefly(const PassArgs& a) {
         return "RELAX AntiFirefly: unexpected resource count or missing decoded normal/roughness cache";
     RelaxCB c = LoadRelaxConstants(a);
     RowGrid g = GridForRows(c.shared.gRectSize.x, c.shared.gRectSize.y, TILE_X, TILE_Y, a.rowBegin, a.rowEnd);
-    hipLaunchKernelGGL((RelaxAntiFireflyKernel<DIFF, SPEC>), g.grid, dim3(256), 0, a.stream, P, c, RowRange{g.firstBlockY, g.rowBegin, g.rowEnd});
+    LaunchPass(a, (RelaxAntiFireflyKernel<DIFF, SPEC>), g.grid, dim3(256), P, c, RowRange{g.firstBlockY, g.rowBegin, g.rowEnd});
     return nullptr;
 }
 
@@ -729,7 +729,7 @@ const char* LaunchSplitScreen(const PassArgs& a) {
         return "RELAX SplitScreen: unexpected resource count";
     RelaxCB c = LoadRelaxConstants(a);
     RowGrid g = GridForRows(c.shared.gRectSize.x, c.shared.gRectSize.y, TILE_X, TILE_Y, a.rowBegin, a.rowEnd);
-    hipLaunchKernelGGL((RelaxSplitScreenKernel<DIFF, SPEC, SH>), g.grid, dim3(256), 0, a.stream, P, c, RowRange{g.firstBlockY, g.rowBegin, g.rowEnd});
+    LaunchPass(a, (RelaxSplitScreenKernel<DIFF, SPEC, SH>), g.grid, dim3(256), P, c, RowRange{g.firstBlockY, g.rowBegin, g.rowEnd});
     return nullptr;
 }
 

@@ -639,7 +639,7 @@ const char* LaunchTemporalAccumulation(const PassArgs& a) {
     }
     RelaxCB c = LoadRelaxConstants(a);
     RowGrid g = GridForRows(c.shared.gRectSize.x, c.shared.gRectSize.y, TILE_X, TILE_Y, a.rowBegin, a.rowEnd);
-    hipLaunchKernelGGL((RelaxTemporalAccumulationKernel<DIFF, SPEC, SH>), g.grid, dim3(256), 0, a.stream, c, P, RowRange{g.firstBlockY, g.rowBegin, g.rowEnd});
+    LaunchPass(a, (RelaxTemporalAccumulationKernel<DIFF, SPEC, SH>), g.grid, dim3(256), c, P, RowRange{g.firstBlockY, g.rowBegin, g.rowEnd});
     return nullptr;
 }
 
@@ -846,7 +846,7 @@ const char* LaunchHistoryClamping(const PassArgs& a) {
         return "RELAX HistoryClamping: unexpected resource count";
     RelaxCB c = LoadRelaxConstants(a);
     RowGrid g = GridForRows(c.shared.gRectSize.x, c.shared.gRectSize.y, TILE_X, TILE_Y, a.rowBegin, a.rowEnd);
-    hipLaunchKernelGGL((RelaxHistoryClampingKernel<DIFF, SPEC, SH>), g.grid, dim3(256), 0, a.stream, P, c, RowRange{g.firstBlockY, g.rowBegin, g.rowEnd});
+    LaunchPass(a, (RelaxHistoryClampingKernel<DIFF, SPEC, SH>), g.grid, dim3(256), P, c, RowRange{g.firstBlockY, g.rowBegin, g.rowEnd});
     return nullptr;
 }
 

@@ -183,7 +183,7 @@ static const char* LaunchClassifyTiles(const PassArgs& a) {
         return "SIGMA classify tiles: unexpected resource count";
     const Plane& tiles = a.planes[a.planesNum - 1];
     int numTiles = tiles.w * tiles.h;
-    hipLaunchKernelGGL((SigmaClassifyTilesKernel<TRANSLUCENT>), dim3((numTiles + 3) / 4), dim3(256), 0, a.stream, c, a.planes[0], a.planes[1], TRANSLUCENT ? a.planes[2] : Plane{}, tiles);
+    LaunchPass(a, (SigmaClassifyTilesKernel<TRANSLUCENT>), dim3((numTiles + 3) / 4), dim3(256), c, a.planes[0], a.planes[1], TRANSLUCENT ? a.planes[2] : Plane{}, tiles);
     return nullptr;
 }
 
@@ -215,7 +215,7 @@ __global__ __launch_bounds__(256) void SigmaSmoothTilesKernel(SigmaCB c, Plane i
 static const char* LaunchSmoothTiles(const PassArgs& a) {
     const SigmaCB& c = *(const SigmaCB*)a.constants;
     const Plane& out = a.planes[1];
-    hipLaunchKernelGGL(SigmaSmoothTilesKernel, GridFor(out.w, out.h, 16, 16), dim3(256), 0, a.stream, c, a.planes[0], out);
+    LaunchPass(a, SigmaSmoothTilesKernel, GridFor(out.w, out.h, 16, 16), dim3(256), c, a.planes[0], out);
     return nullptr;
 }
 
@@ -251,9 +251,9 @@ static const char* LaunchCopy(const PassArgs& a) {
     if (a.planesNum != 5 || a.bytesPerTexel[1] != a.bytesPerTexel[3])
         return "SIGMA copy: unexpected resources";
     if (a.bytesPerTexel[3] == 4)
-        hipLaunchKernelGGL(SigmaCopyKernel<uint32_t>, grid, dim3(256), 0, a.stream, c, a.planes[0], a.planes[1], a.planes[2], out, a.planes[4]);
+        LaunchPass(a, SigmaCopyKernel<uint32_t>, grid, dim3(256), c, a.planes[0], a.planes[1], a.planes[2], out, a.planes[4]);
     else if (a.bytesPerTexel[3] == 1)
-        hipLaunchKernelGGL(SigmaCopyKernel<uint8_t>, grid, dim3(256), 0, a.stream, c, a.planes[0], a.planes[1], a.planes[2], out, a.planes[4]);
+        LaunchPass(a, SigmaCopyKernel<uint8_t>, grid, dim3(256), c, a.planes[0], a.planes[1], a.planes[2], out, a.planes[4]);
     else
         return "SIGMA copy: unexpected history format";
     return nullptr;
@@ -454,7 +454,7 @@ static const char* LaunchBlur(const PassArgs& a) {
     if (k != a.planesNum)
         return "SIGMA blur: unexpected resource count";
     dim3 grid = GridFor(c.gRectSizeMinusOne.x + 1, c.gRectSizeMinusOne.y + 1, TILE_X, TILE_Y);
-    hipLaunchKernelGGL((SigmaBlurKernel<FIRST_PASS, TRANSLUCENT>), grid, dim3(TILE_X * TILE_Y), 0, a.stream, c, P);
+    LaunchPass(a, (SigmaBlurKernel<FIRST_PASS, TRANSLUCENT>), grid, dim3(TILE_X * TILE_Y), c, P);
     return nullptr;
 }
 
@@ -621,7 +621,7 @@ static const char* LaunchTemporalStabilization(const PassArgs& a) {
         return "SIGMA temporal stabilization: unexpected resource count";
     TsPlanes P = {a.planes[0], a.planes[1], a.planes[2], a.planes[3], a.planes[4], a.planes[5], a.planes[6], a.planes[7], a.planes[8]};
     dim3 grid = GridFor(c.gRectSizeMinusOne.x + 1, c.gRectSizeMinusOne.y + 1, TILE_X, TILE_Y);
-    hipLaunchKernelGGL(SigmaTemporalStabilizationKernel<TRANSLUCENT>, grid, dim3(TILE_X * TILE_Y), 0, a.stream, c, P);
+    LaunchPass(a, SigmaTemporalStabilizationKernel<TRANSLUCENT>, grid, dim3(TILE_X * TILE_Y), c, P);
     return nullptr;
 }
 
@@ -650,7 +650,7 @@ static const char* LaunchSplitScreen(const PassArgs& a) {
     if (a.planesNum != (TRANSLUCENT ? 4u : 3u))
         return "SIGMA split screen: unexpected resource count";
     dim3 grid = GridFor(c.gRectSizeMinusOne.x + 1, c.gRectSizeMinusOne.y + 1, TILE_X, TILE_Y);
-    hipLaunchKernelGGL(SigmaSplitScreenKernel<TRANSLUCENT>, grid, dim3(256), 0, a.stream, c, a.planes[0], a.planes[1], TRANSLUCENT ? a.planes[2] : Plane{}, a.planes[a.planesNum - 1]);
+    LaunchPass(a, SigmaSplitScreenKernel<TRANSLUCENT>, grid, dim3(256), c, a.planes[0], a.planes[1], TRANSLUCENT ? a.planes[2] : Plane{}, a.planes[a.planesNum - 1]);
     return nullptr;
 }
 

@@ -38,7 +38,14 @@ NRD_D float Clamp(float x, float a, float b) { return Min(Max(x, a), b); }
 NRD_D float Sat(float x) { return Min(Max(x, 0.0f), 1.0f); }
 NRD_D float Lerp(float a, float b, float t) { return a + (b - a) * t; }
 NRD_D float Step(float edge, float x) { return x >= edge ? 1.0f : 0.0f; }
+// NRD_FAST (the default product build, DESIGN.md "Numerics"): hardware reciprocal / exp2 / log2 (v_rcp_f32, v_exp_f32, v_log_f32, within 1 ulp of the
+// correctly rounded result), FMA contraction, fp32 denormals flushed. Without it (libNRD_hip_exact.so) every operation is the pinned IEEE sequence
+// the CPU oracle restates, and the two agree bit for bit.
+#ifdef NRD_FAST
+NRD_D float Rcp(float x) { return __builtin_amdgcn_rcpf(x); }
+#else
 NRD_D float Rcp(float x) { return 1.0f / x; }
+#endif
 // sqrt and 1/sqrt are the hardware's single instructions (v_sqrt_f32, v_rsq_f32: within 1 ulp of the correctly rounded result, denormals
 // flushed) instead of the ~14 / ~25-instruction correctly rounded expansions; the CPU oracle reproduces them bit for bit from per-mantissa
 // tables measured on the device (oracle/hlsl.h HwSqrt / HwRsq, tools/hw_transcendentals.py). Division stays correctly rounded.
@@ -52,6 +59,10 @@ NRD_D float AsFloat(uint32_t x) { return __uint_as_float(x); }
 
 // ------------------------------------------------------------------------------------------------ reproducible transcendentals
 // 2^x: nearest-integer split + degree-7 Taylor of 2^f on [-0.5, 0.5] (truncation < 6e-9), Horner, no FMA.
+#ifdef NRD_FAST
+NRD_D float Exp2(float x) { return __builtin_amdgcn_exp2f(Clamp(x, -125.0f, 125.0f)); }
+NRD_D float Log2(float x) { return x > 0.0f ? __builtin_amdgcn_logf(x) : -126.0f; }
+#else
 NRD_D float Exp2(float x) {
     x = Clamp(x, -125.0f, 125.0f);
     float fi = floorf(x + 0.5f);
@@ -91,6 +102,7 @@ NRD_D float Log2(float x) {
     p = p * s2 + 2.0f;
     return float(e) + (p * s) * 1.44269504f;
 }
+#endif
 
 NRD_D float Exp(float x) { return Exp2(x * 1.44269504f); }
 NRD_D float Log(float x) { return Log2(x) * 0.69314718f; }
@@ -132,7 +144,11 @@ NRD_D float2 operator-(float2 a, float2 b) { return F2(a.x - b.x, a.y - b.y); }
 NRD_D float2 operator*(float2 a, float2 b) { return F2(a.x * b.x, a.y * b.y); }
 NRD_D float2 operator*(float2 a, float b) { return F2(a.x * b, a.y * b); }
 NRD_D float2 operator/(float2 a, float2 b) { return F2(a.x / b.x, a.y / b.y); }
+#ifdef NRD_FAST
+NRD_D float2 operator/(float2 a, float b) { float r = Rcp(b); return F2(a.x * r, a.y * r); }
+#else
 NRD_D float2 operator/(float2 a, float b) { return F2(a.x / b, a.y / b); }
+#endif
 NRD_D float2 operator+(float2 a, float b) { return F2(a.x + b, a.y + b); }
 NRD_D float2 operator-(float2 a, float b) { return F2(a.x - b, a.y - b); }
 
@@ -141,13 +157,21 @@ NRD_D float3 operator-(float3 a, float3 b) { return F3(a.x - b.x, a.y - b.y, a.z
 NRD_D float3 operator-(float3 a) { return F3(-a.x, -a.y, -a.z); }
 NRD_D float3 operator*(float3 a, float3 b) { return F3(a.x * b.x, a.y * b.y, a.z * b.z); }
 NRD_D float3 operator*(float3 a, float b) { return F3(a.x * b, a.y * b, a.z * b); }
+#ifdef NRD_FAST
+NRD_D float3 operator/(float3 a, float b) { float r = Rcp(b); return F3(a.x * r, a.y * r, a.z * r); }
+#else
 NRD_D float3 operator/(float3 a, float b) { return F3(a.x / b, a.y / b, a.z / b); }
+#endif
 
 NRD_D float4 operator+(float4 a, float4 b) { return F4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w); }
 NRD_D float4 operator-(float4 a, float4 b) { return F4(a.x - b.x, a.y - b.y, a.z - b.z, a.w - b.w); }
 NRD_D float4 operator*(float4 a, float4 b) { return F4(a.x * b.x, a.y * b.y, a.z * b.z, a.w * b.w); }
 NRD_D float4 operator*(float4 a, float b) { return F4(a.x * b, a.y * b, a.z * b, a.w * b); }
+#ifdef NRD_FAST
+NRD_D float4 operator/(float4 a, float b) { float r = Rcp(b); return F4(a.x * r, a.y * r, a.z * r, a.w * r); }
+#else
 NRD_D float4 operator/(float4 a, float b) { return F4(a.x / b, a.y / b, a.z / b, a.w / b); }
+#endif
 NRD_D float4 operator-(float4 a, float b) { return F4(a.x - b, a.y - b, a.z - b, a.w - b); }
 
 // component-wise select: `cond ? a : b` on two vector LVALUES is an lvalue conditional, which the compiler implements as a

@@ -6,7 +6,25 @@
 
 #include <hip/hip_runtime.h>
 
+#include <cstring>
+#include <vector>
+
 namespace nrdhip {
+
+// One kernel launch of a pass as data: what the launchers hand to the executor instead of launching when a recorder is attached.
+// The executor uses it for the pre-flight of a dispatch range (nothing is launched unless every pass of the range can be) and for
+// HIP-graph execution (kernel nodes built from / updated with these records: executor.hip "graph mode").
+struct LaunchRecord {
+    const void* func;
+    dim3 grid, block;
+    std::vector<uint8_t> args;     // kernel arguments, each copied to a 16-byte aligned offset
+    std::vector<uint32_t> offsets; // offset of every argument inside args
+};
+struct LaunchRecorder {
+    bool keep = false; // false = pre-flight only: launches are counted, not stored
+    uint32_t count = 0;
+    std::vector<LaunchRecord> records;
+};
 
 // numeric values of the nrd::Format entries the format-dispatching launchers look at (checked against NRDDescs.h in executor.hip)
 enum : uint8_t { FORMAT_RGBA8_UNORM = 8, FORMAT_R16_UNORM = 13, FORMAT_RGBA16_SNORM = 24, FORMAT_RGBA16_SFLOAT = 27 };
@@ -18,6 +36,7 @@ struct PassArgs {
     const uint8_t* formats;       // per plane, nrd::Format (REBLUR hit-distance reconstruction / split screen serve three signal kinds)
     const void* constants;    // DispatchDesc::constantBufferData
     uint32_t constantsSize;
+    uint32_t gridWidth, gridHeight; // DispatchDesc::gridWidth / gridHeight (the reference's thread-group counts: the area the pass covers)
     hipStream_t stream;
     // rows [rowBegin, rowEnd) this rank has to produce in this pass (multi-GPU row-strip sharding; the whole frame by default).
     // Pixels outside are left untouched; planes stay full-size, so all neighbourhood reads keep their single-GPU meaning.
@@ -28,7 +47,38 @@ struct PassArgs {
     // executor-internal scratch plane of the RELAX a-trous chain (float4 per pixel: world position, viewZ): written by the first
     // iteration (AtrousSmem) for every pixel, read by the taps of the dilated iterations; ptr == nullptr outside RELAX lists
     Plane worldPosViewZ;
+    // non-null: the launcher performs all its checks and hands its launch(es) to the recorder instead of enqueueing them
+    LaunchRecorder* recorder = nullptr;
 };
+
+namespace detail {
+template <typename T>
+inline void PackArg(LaunchRecord& r, const T& v) {
+    static_assert(std::is_trivially_copyable<T>::value, "kernel arguments are PODs");
+    size_t off = (r.args.size() + 15u) & ~(size_t)15u;
+    r.args.resize(off + sizeof(T));
+    memcpy(r.args.data() + off, &v, sizeof(T));
+    r.offsets.push_back((uint32_t)off);
+}
+} // namespace detail
+
+// every pass launch goes through here: launcher(args) -> LaunchPass(args, kernel, grid, block, kernel arguments...)
+template <typename... KArgs, typename... Args>
+inline void LaunchPass(const PassArgs& a, void (*kernel)(KArgs...), dim3 grid, dim3 block, const Args&... args) {
+    if (!a.recorder) {
+        hipLaunchKernelGGL(kernel, grid, block, 0, a.stream, KArgs(args)...);
+        return;
+    }
+    a.recorder->count++;
+    if (!a.recorder->keep)
+        return;
+    LaunchRecord r;
+    r.func = (const void*)kernel;
+    r.grid = grid;
+    r.block = block;
+    (void)std::initializer_list<int>{(detail::PackArg<KArgs>(r, KArgs(args)), 0)...};
+    a.recorder->records.push_back(std::move(r));
+}
 
 // returns nullptr on success, or a static message if the dispatch cannot be executed by this build (nothing is launched then)
 typedef const char* (*PassLauncher)(const PassArgs& args);
@@ -45,7 +95,7 @@ const PassEntry* GetSigmaPasses(uint32_t& num);
 const PassEntry* GetRelaxPasses(uint32_t& num);
 
 // decodes a whole R10G10B10A2 normal+roughness plane into the float4 cache (kernels_common.hip)
-void LaunchDecodeNormalRoughness(const Plane& packed, const Plane& decoded, hipStream_t stream);
+void LaunchDecodeNormalRoughness(const PassArgs& a, const Plane& packed, const Plane& decoded);
 
 inline dim3 GridFor(int w, int h, int tileW, int tileH) { return dim3((unsigned)((w + tileW - 1) / tileW), (unsigned)((h + tileH - 1) / tileH), 1); }
 

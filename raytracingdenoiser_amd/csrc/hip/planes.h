@@ -51,6 +51,9 @@ NRD_D T* TexelPtr(const Plane& p, int x, int y) {
 // of the ~11 of a generic correctly rounded division: q0 = k * RN(1/c), r = fma(-q0, c, k) (exact), q = fma(r, RN(1/c), q0).
 // Exhaustively verified for every numerator the codecs can produce (tests/test_numerics.py: c = 65535, 1023, 255, 63, 15, 3).
 NRD_D float DivSmallIntByConst(float k, float c, float rcpC) {
+#ifdef NRD_FAST
+    return k * rcpC; // within 1 ulp of the quotient
+#endif
     float q0 = k * rcpC;
     float r = __builtin_fmaf(-q0, c, k);
     return __builtin_fmaf(r, rcpC, q0);
@@ -69,6 +72,9 @@ NRD_D float HalfBitsToFloat(uint16_t h) { return __half2float(__ushort_as_half(h
 // v_fma_mixlo_f16, which rounds the exact product ONCE (to fp16) instead of twice (fp32, then fp16). That is a different
 // result whenever the fp32 product lands on an fp16 tie, and the numerics contract pins the two-step rounding.
 NRD_D uint16_t FloatToHalfBits(float f) {
+#ifdef NRD_FAST
+    return __half_as_ushort(__float2half_rn(f)); // the compiler may fuse the producing multiply (v_fma_mixlo_f16) and pack pairs (v_cvt_pk_f16_f32)
+#endif
     uint32_t h;
     asm("v_cvt_f16_f32 %0, %1" : "=v"(h) : "v"(f));
     return (uint16_t)h;

@@ -103,6 +103,16 @@ class HipExecutor:
     def set_owned_rows(self, row_begin, row_end):
         self._check(self.lib.nrdHipSetOwnedRows(self.handle, row_begin, row_end), "nrdHipSetOwnedRows")
 
+    def set_graph_mode(self, enable):
+        """one hipGraph launch per dispatch range instead of one launch per pass (include/NRDHip.h nrdHipSetGraphMode)"""
+        self._check(self.lib.nrdHipSetGraphMode(self.handle, 1 if enable else 0), "nrdHipSetGraphMode")
+
+    def graph_stats(self):
+        """(graph launches, graphs built, node-parameter updates)"""
+        a, b, c = C.c_uint64(), C.c_uint64(), C.c_uint64()
+        self._check(self.lib.nrdHipGetGraphStats(self.handle, C.byref(a), C.byref(b), C.byref(c)), "nrdHipGetGraphStats")
+        return a.value, b.value, c.value
+
     def set_profiling(self, enable):
         self._check(self.lib.nrdHipSetProfiling(self.handle, 1 if enable else 0), "nrdHipSetProfiling")
 

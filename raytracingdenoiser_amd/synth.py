@@ -179,10 +179,11 @@ def _pack_relax(out, name, radiance, hit_dist, direction):
     out[name + "_relax_sh1"] = sh1.clamp(-FP16_MAX, FP16_MAX).to(torch.float16).contiguous()
 
 
-def render_frame(width, height, frame, device="cpu", static_camera=False, noise=True, seed=7, want=("reblur",)):
-    """Returns a dict with the packed planes and the camera (for CommonSettings)."""
+def render_frame(width, height, frame, device="cpu", static_camera=False, noise=True, seed=7, want=("reblur",), camera_frame=None):
+    """Returns a dict with the packed planes and the camera (for CommonSettings). camera_frame: the frame index the camera pose is taken from
+    (default: frame) -- a camera that stops moving while the noise keeps changing."""
     dev = torch.device(device)
-    cam = Camera(width, height, frame, static=static_camera)
+    cam = Camera(width, height, frame if camera_frame is None else camera_frame, static=static_camera)
     ys, xs = torch.meshgrid(torch.arange(height, device=dev), torch.arange(width, device=dev), indexing="ij")
     u = (xs.to(torch.float32) + 0.5) / width
     v = (ys.to(torch.float32) + 0.5) / height
@@ -210,7 +211,7 @@ def render_frame(width, height, frame, device="cpu", static_camera=False, noise=
     if "mv2d" in want:
         # screen-space ("2.5D") motion vectors of the static scene under the moving camera: .xy in pixels towards the previous frame,
         # .z = viewZprev - viewZ; for CommonSettings motionVectorScale = (1 / w, 1 / h, 1) [or (.., 0) for 2D], isMotionVectorInWorldSpace = false
-        camp = Camera(width, height, max(frame - 1, 0), static=static_camera)
+        camp = Camera(width, height, max((frame if camera_frame is None else camera_frame) - 1, 0), static=static_camera)
         Rp = torch.tensor([camp.right, camp.up, camp.fwd], device=dev, dtype=torch.float32)
         pv = (p - torch.tensor(camp.pos, device=dev, dtype=torch.float32)) @ Rp.T
         zp = pv[..., 2].clamp_min(1e-3)

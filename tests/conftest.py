@@ -18,7 +18,8 @@ def _native_built():
     """Build (or reuse) the in-tree native libraries once per session. hipcc cross-compiles without a GPU."""
     from raytracingdenoiser_amd import build as b
 
-    b.build_product()
+    b.build_product(numerics="fast")   # lib/libNRD_hip.so: the product
+    b.build_product(numerics="exact")  # lib/libNRD_hip_exact.so: the bit-exact regression build
     b.build_oracle()
     yield
 

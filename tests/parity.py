@@ -205,6 +205,51 @@ def decode_plane(raw, fmt, width):
     raise KeyError(fmt)
 
 
+def error_stats(got, want, floor=1e-3, tol=REL_TOL):
+    """tolerance statistics of one plane: max / mean relative error (same definition as rel_error), the fraction of values above tol, the 99.9th
+    percentile, and the position of the worst value"""
+    got = got.astype(np.float64)
+    want = want.astype(np.float64)
+    both_nan = np.isnan(got) & np.isnan(want)
+    err = np.abs(got - want) / np.maximum(np.abs(want), floor)
+    err = np.where(both_nan, 0.0, err)
+    err = np.where(np.isnan(err), np.inf, err)
+    if not err.size:
+        return {"max": 0.0, "mean": 0.0, "frac_gt_tol": 0.0, "p999": 0.0, "n": 0, "worst_at": None, "bit_exact_frac": 1.0}
+    flat = int(np.argmax(err))
+    finite = np.where(np.isfinite(err), err, 1e30)
+    return {"max": float(err.max()), "mean": float(finite.mean()), "frac_gt_tol": float(np.mean(err > tol)), "p999": float(np.quantile(finite, 0.999)), "n": int(err.size),
+            "worst_at": [int(v) for v in np.unravel_index(flat, err.shape)], "bit_exact_frac": float(np.mean((got == want) | both_nan))}
+
+
+class ParityStats:
+    """accumulates error_stats over the frames of a run, per plane name"""
+
+    def __init__(self):
+        self.planes = {}
+
+    def add(self, name, frame, st):
+        p = self.planes.setdefault(name, {"max": 0.0, "frac_gt_tol": 0.0, "p999": 0.0, "mean": 0.0, "frames": 0, "worst": None, "bit_exact_frac": 1.0})
+        if st["max"] >= p["max"]:
+            p["worst"] = (frame, st["worst_at"], st["max"])
+        p["max"] = max(p["max"], st["max"])
+        p["frac_gt_tol"] = max(p["frac_gt_tol"], st["frac_gt_tol"])  # the worst frame
+        p["p999"] = max(p["p999"], st["p999"])
+        p["mean"] = max(p["mean"], st["mean"])
+        p["bit_exact_frac"] = min(p["bit_exact_frac"], st["bit_exact_frac"])
+        p["frames"] += 1
+
+    def outputs(self):
+        return {k: v for k, v in self.planes.items() if k.startswith("OUT_")}
+
+    def summary(self, only_outputs=True):
+        sel = self.outputs() if only_outputs else self.planes
+        if not sel:
+            return {"max_rel_err": 0.0, "frac_gt_tol": 0.0, "p999": 0.0, "mean": 0.0, "planes": 0}
+        return {"max_rel_err": max(v["max"] for v in sel.values()), "frac_gt_tol": max(v["frac_gt_tol"] for v in sel.values()), "p999": max(v["p999"] for v in sel.values()),
+                "mean": max(v["mean"] for v in sel.values()), "bit_exact_frac": min(v["bit_exact_frac"] for v in sel.values()), "planes": len(sel)}
+
+
 def rel_error(got, want, floor=1e-3):
     """max over texels of |got - want| / max(|want|, floor); NaNs count as infinite error unless both are NaN."""
     got = got.astype(np.float64)
@@ -257,11 +302,12 @@ def _padded(t, pad):
 
 
 class HipRun:
-    def __init__(self, name, width, height, pad=0):
+    def __init__(self, name, width, height, pad=0, numerics="exact"):
+        """numerics: which build of the library runs -- "exact" (libNRD_hip_exact.so, bit-identical to the oracle) or "fast" (libNRD_hip.so, the product)"""
         from raytracingdenoiser_amd.executor import HipExecutor
 
         self.name, self.width, self.height, self.pad = name, width, height, pad
-        self.inst = api.Instance([(0, DENOISERS[name][0])])
+        self.inst = api.Instance([(0, DENOISERS[name][0])], numerics=numerics)
         self.ex = HipExecutor(self.inst, width, height)
         self.outs = {}
         for rt, dtype, ch, fmt in output_planes(name, width, height):
@@ -290,6 +336,7 @@ class HipRun:
 
 
 def generate_sequence(name, width, height, frames, static_camera=False, noise=True, device="cpu", extra_want=()):
+    """frames 0 .. frames-1 of the synthetic sequence (analytic scene, moving camera, 1-rpp noise) with the planes the denoiser consumes"""
     return [synth.render_frame(width, height, f, device=device, static_camera=static_camera, noise=noise, want=tuple(DENOISERS[name][1]) + tuple(extra_want)) for f in range(frames)]
 
 
@@ -307,20 +354,39 @@ def embed_in_resource(frame, resource):
 
 
 def run_parity(name, width=192, height=128, frames=4, verbose=False, settings_overrides=None, static_camera=False, check_pools=True, cs_kw=None, extra_want=(), pad=0, resource=None,
-               rect_sizes=None):
+               rect_sizes=None, numerics="exact", ieee=False, stats=None, static_after=None, graph=False, device="cpu"):
     """Returns the worst relative error between the HIP path and the oracle over all frames, user outputs and pool planes.
+    numerics = "exact": the bit-exact regression build against the oracle that emulates the device's sqrt / rsqrt (expected error: 0);
+    numerics = "fast" (the product build) is compared with ieee = True, the oracle in plain IEEE arithmetic, and judged through `stats`
+    (a ParityStats that receives the per-plane tolerance statistics; the return value is then the worst error of the user OUTPUTS only).
+    static_after = N: the camera stops moving after frame N (long runs: accumulation counters saturate, anti-lag fires on the stop).
+    graph: the HIP side runs in graph mode (one hipGraph launch per frame).
     resource = (w, h) >= (width, height): dynamic resolution, the frame is the top-left rect of resource-sized planes;
     rect_sizes = [(w, h), ...]: the rect size of frame f is rect_sizes[f % len] (same aspect ratio as (width, height)), inside `resource`."""
+    prev_ieee = oracle_driver.set_ieee_mode(ieee)
+    try:
+        return _run_parity(name, width, height, frames, verbose, settings_overrides, static_camera, check_pools, cs_kw, extra_want, pad, resource, rect_sizes, numerics, stats, static_after,
+                           graph, device)
+    finally:
+        oracle_driver.set_ieee_mode(prev_ieee)
+
+
+def _run_parity(name, width, height, frames, verbose, settings_overrides, static_camera, check_pools, cs_kw, extra_want, pad, resource, rect_sizes, numerics, stats, static_after, graph, device):
     if rect_sizes:
         seq = [synth.render_frame(*rect_sizes[f % len(rect_sizes)], f, static_camera=static_camera, want=tuple(DENOISERS[name][1]) + tuple(extra_want)) for f in range(frames)]
+    elif static_after is not None:
+        # the camera of frame static_after is kept from there on; the noise keeps changing (render_frame seeds it with the frame index)
+        seq = [synth.render_frame(width, height, f, device=device, want=tuple(DENOISERS[name][1]) + tuple(extra_want), camera_frame=min(f, static_after)) for f in range(frames)]
     else:
-        seq = generate_sequence(name, width, height, frames, static_camera=static_camera, extra_want=extra_want)
+        seq = generate_sequence(name, width, height, frames, static_camera=static_camera, extra_want=extra_want, device=device)
     cs_kw = dict(cs_kw or {})
     if resource:
         seq = [embed_in_resource(fr, resource) for fr in seq]
         cs_kw.update(resourceSize=resource, resourceSizePrev=resource)
     rw, rh = resource or (width, height)
-    ora, hip = OracleRun(name, rw, rh), HipRun(name, rw, rh, pad=pad)
+    ora, hip = OracleRun(name, rw, rh), HipRun(name, rw, rh, pad=pad, numerics=numerics)
+    if graph:
+        hip.ex.set_graph_mode(True)
     worst = 0.0
     for f, frame in enumerate(seq):
         cam, cam_prev = frame["camera"], seq[max(f - 1, 0)]["camera"]
@@ -337,12 +403,17 @@ def run_parity(name, width=192, height=128, frames=4, verbose=False, settings_ov
             e = rel_error(got, want)
             exact = float(np.mean(got == want))
             worst = max(worst, e)
+            if stats is not None:
+                stats.add(rt.name, f, error_stats(got, want))
             if verbose:
                 print("frame %d %-28s max rel err %.3g  bit-exact texels %.4f%%" % (f, rt.name, e, 100.0 * exact))
         if RT.IN_MV in ora.inputs:  # in/out plane: REBLUR temporal stabilization may write specular motion back into it
             want, got = ora.inputs[RT.IN_MV].astype(np.float32), hip.inputs[RT.IN_MV].cpu().numpy().astype(np.float32)
             e = rel_error(got, want)
-            worst = max(worst, e)
+            if stats is None:
+                worst = max(worst, e)
+            else:
+                stats.add("IN_MV(in/out)", f, error_stats(got, want))
             if verbose and (e > 0 or cs_kw.get("isBaseColorMetalnessAvailable")):
                 src = frame["mv"].cpu().numpy().astype(np.float32)
                 print("frame %d IN_MV (in/out)               max rel err %.3g  texels modified by the pass %d" % (f, e, int(np.any(want != src, axis=-1).sum())))
@@ -355,7 +426,10 @@ def run_parity(name, width=192, height=128, frames=4, verbose=False, settings_ov
                     assert fmt == hfmt and w == hw
                     want, got = decode_plane(o_raw, fmt, w), decode_plane(h_raw, fmt, w)
                     e = rel_error(got, want)
-                    worst = max(worst, e)
+                    if stats is None:
+                        worst = max(worst, e)
+                    else:  # quantised internal planes (UNORM8 counters, packed bits) are reported, the verdict is taken on the user outputs
+                        stats.add("%s[%d] %s" % (pool.name, i, fmt.name), f, error_stats(got, want))
                     if verbose and e > 0:
                         bad = np.argwhere(np.any(got != want, axis=-1))
                         print("frame %d %s[%d] %-22s max rel err %.3g  differing texels %d  first %s" % (f, pool.name, i, fmt.name, e, len(bad), bad[:3].tolist()))

@@ -52,7 +52,7 @@ def test_hip_numerics_bit_exact_vs_oracle():
 
     from raytracingdenoiser_amd import api
 
-    lib = api.load_library()
+    lib = api.load_library(numerics="exact")  # the pinned arithmetic of the regression build
     ora = oracle_driver.load()
     rng = np.random.default_rng(11)
     n = 20000
@@ -107,7 +107,7 @@ def test_hip_exact_constant_division_and_gaussian_constants():
 
     from raytracingdenoiser_amd import api
 
-    lib = api.load_library()
+    lib = api.load_library(numerics="exact")
     stream = torch.cuda.current_stream().cuda_stream
     for op, c, n in ((8, 1023.0, 1024), (9, 255.0, 256), (10, 63.0, 64), (11, 15.0, 16), (12, 3.0, 4), (14, 65535.0, 65536)):
         k = np.arange(n, dtype=np.float32)
@@ -149,3 +149,44 @@ def test_hw_sqrt_tables_are_sane():
     ora.oracle_eval_hw(1, special.ctypes.data, r.ctypes.data, special.size)
     assert s[:6].tolist() == [0.0, 0.0, np.inf, 0.0, 0.0, 0.0] and np.signbit(s[1]) and np.signbit(s[5]) and np.isnan(s[6])
     assert r[:6].tolist() == [np.inf, -np.inf, 0.0, np.inf, np.inf, -np.inf] and np.isnan(r[6])
+
+
+@pytest.mark.gpu
+def test_fast_build_primitives_within_one_ulp_class():
+    """the product build (libNRD_hip.so): exp2 / log2 / pow / division / the codec reciprocals are the hardware instructions -- close to the exact results,
+    not equal to them. Bounds: division and the codec reciprocals within 2 ulp, exp2 within 4 ulp, log2 absolute 4e-7 * max(1, |log2 x|), pow relative 1e-5."""
+    import torch
+
+    from raytracingdenoiser_amd import api
+
+    lib = api.load_library(numerics="fast")
+    assert lib.nrdHipGetNumericsMode() == 1 and api.load_library(numerics="exact").nrdHipGetNumericsMode() == 0
+    stream = torch.cuda.current_stream().cuda_stream
+    rng = np.random.default_rng(3)
+    n = 50000
+
+    def run(op, a, b=None):
+        ta = torch.from_numpy(a.astype(np.float32)).cuda()
+        tb = torch.from_numpy(b.astype(np.float32)).cuda() if b is not None else None
+        out = torch.empty_like(ta)
+        assert lib.nrdHipEvalNumerics(op, ta.data_ptr(), tb.data_ptr() if tb is not None else None, out.data_ptr(), ta.numel(), stream) == 0
+        return out.cpu().numpy()
+
+    def ulps(got, want):
+        return np.abs(got.view(np.int32).astype(np.int64) - want.astype(np.float32).view(np.int32).astype(np.int64))
+
+    a = (rng.standard_normal(n) * 10.0 ** rng.integers(-6, 6, n)).astype(np.float32)
+    b = (rng.standard_normal(n) * 10.0 ** rng.integers(-6, 6, n)).astype(np.float32)
+    assert ulps(run(5, a, b), a.astype(np.float64) / b.astype(np.float64)).max() <= 2
+    x = rng.uniform(-40, 40, n).astype(np.float32)
+    assert ulps(run(0, x), np.exp2(x.astype(np.float64))).max() <= 4
+    p = np.exp(rng.uniform(-60, 60, n)).astype(np.float32)
+    want = np.log2(p.astype(np.float64))
+    assert np.max(np.abs(run(1, p) - want) / np.maximum(1.0, np.abs(want))) <= 4e-7
+    base, ex = rng.uniform(0.01, 1, n).astype(np.float32), rng.uniform(0.1, 40, n).astype(np.float32)
+    want = np.power(base.astype(np.float64), ex.astype(np.float64))
+    ok = want > 1e-30
+    assert np.max(np.abs(run(3, base, ex)[ok] - want[ok]) / want[ok]) <= 2e-5
+    for op, c, cnt in ((8, 1023.0, 1024), (9, 255.0, 256), (10, 63.0, 64), (14, 65535.0, 65536)):
+        k = np.arange(cnt, dtype=np.float32)
+        assert ulps(run(op, k)[1:], (k / np.float64(c))[1:]).max() <= 1
