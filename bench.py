@@ -11,8 +11,12 @@ GPU before the timed region). Prints ONE JSON line (see DESIGN.md "Measurement")
                 measured live with HIP events recorded on the executor's stream around every dispatch
   cpu_baseline  the CPU oracle (oracle/, kind "port": the reference has no CPU implementation) on the host cores,
                 on a bounded sample of the same workload (N = 1, rank 0 only)
+  parity        the planes the cpu_baseline leg computes anyway (first frames of the same sequence, full size) compared with the GPU's
 
-  python bench.py [--gpus N] [--steps K] [--warmup W] [--workload reblur_ds|relax_ds_sh|relax_ds] [--width 2560 --height 1440] [--no-cpu-baseline]
+--gpus N with N > 1 and no torch.distributed environment re-launches itself under torch.distributed.run (one rank per GPU, RCCL).
+
+  python bench.py [--gpus N] [--steps K] [--warmup W] [--workload reblur_ds|reblur_diffuse|relax_ds_sh|relax_ds|sigma_shadow] [--width 2560 --height 1440]
+                  [--numerics fast|exact] [--no-graph] [--no-cpu-baseline]
 """
 import argparse
 import json
@@ -26,7 +30,7 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 import torch
 
-HBM_PEAK_GBS = 8000.0  # MI355X HBM3E peak (MI355X_MICROARCH.md); ~6300 GB/s is what a float4 copy achieves
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E peak (MI355X_MICROARCH.md); ~6300 GB/s is what a float4 copy achieves (measured live below)
 
 # Published reference numbers for the exact metric (reference README.md:18, RTX 4080, 1440p native)
 PUBLISHED_MPIX_S = {("REBLUR_DIFFUSE_SPECULAR", 2560, 1440): 1603.0, ("RELAX_DIFFUSE_SPECULAR", 2560, 1440): 1229.0, ("RELAX_DIFFUSE_SPECULAR_SH", 2560, 1440): 760.0}
@@ -45,6 +49,16 @@ REBLUR_DS_BYTES_PER_PIXEL = {
     "REBLUR_DiffuseSpecular_Blur.cs": 46,
     "REBLUR_DiffuseSpecular_PostBlur.cs": 46,
     "REBLUR_DiffuseSpecular_TemporalStabilization.cs": 66,
+}
+# REBLUR_DIFFUSE (BASELINE.json configs[2]; SURVEY.md section 8a: 4 + 24 + 56 + 29 + 29 + 29 + 40 = 211 B/px)
+REBLUR_D_BYTES_PER_PIXEL = {
+    "REBLUR_ClassifyTiles.cs": 4,
+    "REBLUR_Diffuse_PrePass.cs": 24,
+    "REBLUR_Diffuse_TemporalAccumulation.cs": 56,
+    "REBLUR_Diffuse_HistoryFix.cs": 29,
+    "REBLUR_Diffuse_Blur.cs": 29,
+    "REBLUR_Diffuse_PostBlur.cs": 29,
+    "REBLUR_Diffuse_TemporalStabilization.cs": 40,
 }
 # RELAX: SH variant = BASELINE.json config 5; the a-trous entry is per iteration (42 B/px of it are reads)
 RELAX_DS_SH_BYTES_PER_PIXEL = {
@@ -89,6 +103,7 @@ SIGMA_TRANSLUCENCY_BYTES_PER_PIXEL = {
 WORKLOADS = {
     "reblur_ds": ("REBLUR_DIFFUSE_SPECULAR", (2560, 1440), REBLUR_DS_BYTES_PER_PIXEL, None),
     "reblur_ds_perf": ("REBLUR_DIFFUSE_SPECULAR", (2560, 1440), REBLUR_DS_PERF_BYTES_PER_PIXEL, {"enablePerformanceMode": True}),
+    "reblur_diffuse": ("REBLUR_DIFFUSE", (2560, 1440), REBLUR_D_BYTES_PER_PIXEL, None),
     "relax_ds_sh": ("RELAX_DIFFUSE_SPECULAR_SH", (3840, 2160), RELAX_DS_SH_BYTES_PER_PIXEL, None),
     "sigma_shadow": ("SIGMA_SHADOW", (1920, 1080), SIGMA_SHADOW_BYTES_PER_PIXEL, None),
     "sigma_translucency": ("SIGMA_SHADOW_TRANSLUCENCY", (1920, 1080), SIGMA_TRANSLUCENCY_BYTES_PER_PIXEL, None),
@@ -110,7 +125,30 @@ def parse_args():
     ap.add_argument("--max-motion-rows", type=int, default=32, help="halo scheme: largest vertical motion (rows per frame) the history halos cover")
     ap.add_argument("--cpu-frames", type=int, default=8)
     ap.add_argument("--distinct-frames", type=int, default=0, help="number of distinct generated frames to cycle through (0 = warmup + steps)")
+    ap.add_argument("--numerics", choices=["fast", "exact"], default=os.environ.get("NRD_HIP_NUMERICS", "fast"),
+                    help="fast = lib/libNRD_hip.so, the product (default); exact = lib/libNRD_hip_exact.so, the bit-exact regression build")
+    ap.add_argument("--no-graph", action="store_true", help="launch every pass on its own instead of one hipGraph per frame")
+    ap.add_argument("--no-parity", action="store_true", help="skip the GPU-vs-oracle comparison of the cpu_baseline frames")
     return ap.parse_args()
+
+
+def measure_copy_bandwidth(nbytes=1 << 30, reps=10):
+    """GB/s (read + write) of a device-to-device copy of nbytes: the achievable HBM rate the roofline is also quoted against (SURVEY.md section 8d:
+    "measured copy bandwidth on the same device")"""
+    src = torch.empty(nbytes // 16, 4, dtype=torch.float32, device="cuda").fill_(1.0)
+    dst = torch.empty_like(src)
+    for _ in range(3):
+        dst.copy_(src)
+    torch.cuda.synchronize()
+    start, stop = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    start.record()
+    for _ in range(reps):
+        dst.copy_(src)
+    stop.record()
+    torch.cuda.synchronize()
+    ms = start.elapsed_time(stop) / reps
+    del src, dst
+    return 2.0 * nbytes / (ms * 1e-3) / 1e9
 
 
 def _usable_cores():
@@ -131,38 +169,75 @@ def _usable_cores():
     return max(cores, 1)
 
 
-def cpu_baseline(name, width, height, frames, seq, overrides=None):
-    """Times the CPU oracle on the first `frames` frames of the same sequence (all host cores, OpenMP over rows)."""
+def cpu_baseline(name, width, height, frames, seq, overrides=None, numerics="fast", check_parity=True):
+    """Times the CPU oracle on the first `frames` frames of the same sequence (all host cores, OpenMP over rows). The oracle's outputs are then
+    compared with a fresh GPU run over the same frames (outside the timed region of either): returns (cpu_baseline, parity)."""
     import parity
     from oracle import driver as oracle_driver
 
     cores = _usable_cores()
     threads = oracle_driver.load().oracle_set_threads(cores)
-    ora = parity.OracleRun(name, width, height, threads=threads)
-    host_seq = [{k: (v.cpu() if torch.is_tensor(v) else v) for k, v in fr.items()} for fr in seq[:frames]]
-    t0 = time.perf_counter()
-    for f, frame in enumerate(host_seq):
-        cs = parity.common_settings(frame["camera"], host_seq[max(f - 1, 0)]["camera"], width, height, f)
-        ora.step(frame, cs, parity.denoiser_settings(name, frame, overrides))
-    dt = time.perf_counter() - t0
-    return {
+    # the product build is held against plain IEEE arithmetic, the exact build against the device-emulating oracle (bit-exact)
+    prev_mode = oracle_driver.set_ieee_mode(numerics == "fast")
+    try:
+        ora = parity.OracleRun(name, width, height, threads=threads)
+        host_seq = [{k: (v.cpu() if torch.is_tensor(v) else v) for k, v in fr.items()} for fr in seq[:frames]]
+        oracle_outputs = []
+        dt = 0.0
+        for f, frame in enumerate(host_seq):
+            cs = parity.common_settings(frame["camera"], host_seq[max(f - 1, 0)]["camera"], width, height, f)
+            t0 = time.perf_counter()
+            ora.step(frame, cs, parity.denoiser_settings(name, frame, overrides))
+            dt += time.perf_counter() - t0
+            if check_parity:
+                oracle_outputs.append({rt: ora.output(rt).copy() for rt in ora.outs})
+    finally:
+        oracle_driver.set_ieee_mode(prev_mode)
+    baseline = {
         "value": round(frames * width * height / dt / 1e6, 4),
         "unit": "Mpixels/s",
         "cores": threads,
         "kind": "port",
         "sample": "first %d frames of the same %dx%d %s sequence (incl. the CLEAR_AND_RESTART frame), %.1f s" % (frames, width, height, name, dt),
     }
+    par = None
+    if check_parity:
+        stats = parity.ParityStats()
+        hip = parity.HipRun(name, width, height, numerics=numerics)
+        for f, frame in enumerate(seq[:frames]):
+            cs = parity.common_settings(frame["camera"], seq[max(f - 1, 0)]["camera"], width, height, f)
+            hip.step(frame, cs, parity.denoiser_settings(name, frame, overrides))
+            for rt in hip.outs:
+                stats.add(rt.name, f, parity.error_stats(hip.output(rt), oracle_outputs[f][rt]))
+        sm = stats.summary(True)
+        par = {"vs": "CPU oracle, %s" % ("IEEE arithmetic" if numerics == "fast" else "device-emulated sqrt / rsqrt"), "frames": frames, "planes": sorted(stats.outputs()),
+               "max_rel_err": sm["max_rel_err"], "p999_rel_err": sm["p999"], "frac_gt_1e-3": sm["frac_gt_tol"], "mean_rel_err": sm["mean"], "bit_exact_frac": sm["bit_exact_frac"],
+               "definition": "|gpu - cpu| / max(|cpu|, 1e-3) per value of the user outputs, worst frame"}
+    return baseline, par
+
+
+def _relaunch_under_torchrun(n):
+    """`python bench.py --gpus N` without a torch.distributed environment: become N ranks (one per GPU) under torch.distributed.run"""
+    import socket
+    import subprocess
+
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.call(cmd, env=env)
 
 
 def main():
     args = parse_args()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(_relaunch_under_torchrun(args.gpus))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     distributed = world > 1
-    if args.gpus != world and not (args.gpus == 1 and world == 1):
-        if rank == 0:
-            print("bench.py: --gpus %d but WORLD_SIZE=%d; launch with torch.distributed.run --nproc-per-node %d" % (args.gpus, world, args.gpus), file=sys.stderr)
+    assert args.gpus == world, "bench.py: --gpus %d but WORLD_SIZE=%d (launch with torch.distributed.run --nproc-per-node %d, or without any launcher)" % (args.gpus, world, args.gpus)
     assert torch.cuda.is_available(), "bench.py needs a GPU: the HIP path has no CPU fallback"
     # one process per GPU; NRD_DIST_BACKEND=gloo + fewer GPUs than ranks is the single-GPU rehearsal of the N>1 path (tests/test_bench_multi.py)
     torch.cuda.set_device(local_rank % torch.cuda.device_count())
@@ -171,6 +246,7 @@ def main():
         import torch.distributed as dist
 
         dist.init_process_group(backend)
+        assert dist.get_world_size() == args.gpus
 
     import parity
     from raytracingdenoiser_amd import api
@@ -179,9 +255,10 @@ def main():
     from raytracingdenoiser_amd import sharding
 
     if rank == 0:
-        native_build.build_product()
+        native_build.build_product(numerics=args.numerics)
     if distributed:
         dist.barrier()
+    copy_gbs = measure_copy_bandwidth()
 
     name, default_size, bytes_per_pixel, overrides = WORKLOADS[args.workload]
     W, H = args.width or default_size[0], args.height or default_size[1]
@@ -192,8 +269,9 @@ def main():
     seq = parity.generate_sequence(name, W, H, distinct, device="cuda")
     torch.cuda.synchronize()
 
-    inst = api.Instance([(0, parity.DENOISERS[name][0])])
+    inst = api.Instance([(0, parity.DENOISERS[name][0])], numerics=args.numerics)
     ex = HipExecutor(inst, W, H)
+    ex.set_graph_mode(not args.no_graph)
     outputs = []
     for rt, dtype, ch, fmt in parity.output_planes(name, W, H):
         t = torch.zeros((H, W, ch), dtype=dtype, device="cuda")
@@ -237,12 +315,20 @@ def main():
         step(f)
     fence()
 
-    ex.set_profiling(True)
+    # ---- the timed region: exactly args.steps frames, barrier + synchronize on both sides
     t0 = time.perf_counter()
     for f in range(args.warmup, total):
         step(f)
     fence()
     elapsed = time.perf_counter() - t0
+    graph_stats = ex.graph_stats()
+
+    # ---- per-pass durations for the roofline: the SAME frames once more with HIP events around every dispatch on the executor's stream (eager launches:
+    # events cannot bracket the nodes of a graph). Outside the timed region; the history carried over differs, the work per pass does not.
+    ex.set_profiling(True)
+    for f in range(args.warmup, total):
+        step(f)
+    fence()
     timings = ex.collect_pass_timings()
     ex.set_profiling(False)
 
@@ -281,16 +367,18 @@ def main():
                 traffic = int((2.0 * k["FETCH_SIZE_KiB"] + k["WRITE_SIZE_KiB"]) * 1024)
                 traffic_source = entry.get("source")
         roofline = {"bound": "hbm", "kernel": dominant, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
+                    "measured_copy_GBps": round(copy_gbs, 1), "frac_of_measured_copy": round(achieved / copy_gbs, 4),
                     "traffic": traffic, "traffic_source": traffic_source, "avg_kernel_ms": passes[dominant]["avg_ms"],
                     "algorithmic_bytes_per_launch": passes[dominant]["bytes_per_launch"],
-                    "note": "the chain is VALU-bound, not HBM-bound (profiles/: SQ_ACTIVE_INST_VALU = 70-95 % of the SIMD cycles); see DESIGN.md section 3"}
+                    "note": "dominant = the pass with the longest average launch; per-pass durations from HIP events on the executor's stream (eager replay of the timed frames)"}
     # per frame: every pass once, except the dilated a-trous pass which runs (launches / steps) times
     per_frame = {k: p["launches"] / args.steps for k, p in passes.items()}
     gpu_ms = sum(p["avg_ms"] * per_frame[k] for k, p in passes.items())
     total_bpp = sum(bytes_per_pixel[k] * per_frame[k] for k in passes)
     whole_chain = {"algorithmic_bytes_per_pixel": round(total_bpp, 1), "algorithmic_bytes_per_frame": int(total_bpp * W * H), "sum_kernel_ms": round(gpu_ms, 4),
                    "GBps": round(total_bpp * rows / (gpu_ms * 1e-3) / 1e9, 1) if gpu_ms else None,
-                   "frac_of_peak": round(total_bpp * rows / (gpu_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if gpu_ms else None}
+                   "frac_of_peak": round(total_bpp * rows / (gpu_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if gpu_ms else None,
+                   "frac_of_measured_copy": round(total_bpp * rows / (gpu_ms * 1e-3) / 1e9 / copy_gbs, 4) if gpu_ms else None}
 
     result = {
         "metric": "Mpixels/s %s @%s%s" % (name, {(2560, 1440): "1440p", (3840, 2160): "4K", (1920, 1080): "1080p"}.get((W, H), "%dx%d" % (W, H)),
@@ -306,6 +394,9 @@ def main():
         "vs_baseline": round(mpix_s / PUBLISHED_MPIX_S[(name, W, H)], 3) if world == 1 and overrides is None and (name, W, H) in PUBLISHED_MPIX_S else None,
         "dtype": "f32",
         "data": "synthetic",
+        "numerics": args.numerics,
+        "launch": "eager" if args.no_graph else "hipGraph (%d launches, %d builds, %d node updates in the run)" % graph_stats,
+        "rccl_ranks": world if distributed and backend == "nccl" else (0 if not distributed else None),
         "config": {"workload": "%s %dx%d, %s, analytic scene + 1rpp noise, moving camera" % (name, W, H, "default settings" if overrides is None else "settings %s" % overrides),
                    "parallelism": "1 GPU" if world == 1 else ("row strips x%d, halo exchange between pass segments (RCCL send/recv to the 2 neighbours, %.1f MB received per rank per frame)"
                                                                % (world, shard.exchanged_bytes / max(total, 1) / 1e6) if args.sharding == "halo" else "row strips x%d + RCCL all-gather" % world),
@@ -316,9 +407,9 @@ def main():
         "passes": passes,
     }
     if not args.no_cpu_baseline and world == 1:
-        result["cpu_baseline"] = cpu_baseline(name, W, H, min(args.cpu_frames, distinct), seq, overrides)
+        result["cpu_baseline"], result["parity"] = cpu_baseline(name, W, H, min(args.cpu_frames, distinct), seq, overrides, numerics=args.numerics, check_parity=not args.no_parity)
     else:
-        result["cpu_baseline"] = None
+        result["cpu_baseline"], result["parity"] = None, None
     print(json.dumps(result))
     if distributed:
         dist.barrier()

@@ -1,0 +1,103 @@
+"""Executor behaviour that is not arithmetic: all-or-nothing pre-flight of a dispatch list, HIP-graph execution, the per-list guide cache."""
+import ctypes as C
+
+import numpy as np
+import pytest
+import torch
+
+import parity
+from raytracingdenoiser_amd import api
+
+RT = parity.RT
+
+
+def _run(name, frames, graph, numerics="fast", w=192, h=128, profile_every=None):
+    seq = parity.generate_sequence(name, w, h, frames)
+    hip = parity.HipRun(name, w, h, numerics=numerics)
+    hip.ex.set_graph_mode(graph)
+    outs = []
+    for f, frame in enumerate(seq):
+        cs = parity.common_settings(frame["camera"], seq[max(f - 1, 0)]["camera"], w, h, f)
+        hip.step(frame, cs, parity.denoiser_settings(name, frame))
+        outs.append({rt: hip.output(rt).copy() for rt in hip.outs})
+    pools = [hip.ex.read_pool_plane(RT.PERMANENT_POOL, i)[0].copy() for i in range(len(hip.inst.permanent_pool))]
+    return outs, pools, hip.ex.graph_stats()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", ["REBLUR_DIFFUSE_SPECULAR", "RELAX_DIFFUSE_SPECULAR_SH", "SIGMA_SHADOW", "REFERENCE_LIKE_REBLUR_DIFFUSE"])
+def test_graph_mode_is_bit_identical_to_eager(name):
+    name = "REBLUR_DIFFUSE" if name == "REFERENCE_LIKE_REBLUR_DIFFUSE" else name
+    eager, eager_pools, st0 = _run(name, 6, graph=False)
+    graph, graph_pools, st1 = _run(name, 6, graph=True)
+    assert st0 == (0, 0, 0)
+    launches, builds, updates = st1
+    assert launches == 6 and 1 <= builds <= 3 and updates > 0, st1  # frame 0 (clears) has its own topology; afterwards only node parameters change
+    for a, b in zip(eager, graph):
+        for rt in a:
+            assert np.array_equal(a[rt], b[rt]), rt
+    for a, b in zip(eager_pools, graph_pools):
+        assert np.array_equal(a, b)
+
+
+@pytest.mark.gpu
+def test_unsupported_dispatch_launches_nothing():
+    """CommonSettings::enableValidation appends REBLUR_Validation as the LAST dispatch of the list; while a pass of a list cannot run, nrdHipDenoise must
+    fail before anything is enqueued (reference Integration::Denoise contract) -- outputs and history stay untouched"""
+    name, w, h = "REBLUR_DIFFUSE_SPECULAR", 192, 128
+    seq = parity.generate_sequence(name, w, h, 3)
+    hip = parity.HipRun(name, w, h, numerics="fast")
+    for f in range(2):
+        cs = parity.common_settings(seq[f]["camera"], seq[max(f - 1, 0)]["camera"], w, h, f)
+        hip.step(seq[f], cs, parity.denoiser_settings(name, seq[f]))
+    before = {rt: hip.output(rt).copy() for rt in hip.outs}
+    pools = [hip.ex.read_pool_plane(RT.PERMANENT_POOL, i)[0].copy() for i in range(len(hip.inst.permanent_pool))]
+    # an orthographic projection is rejected by the REBLUR launchers themselves (a launcher-level check, in the middle of the list)
+    cs = parity.common_settings(seq[2]["camera"], seq[1]["camera"], w, h, 2)
+    for i in range(16):
+        cs.viewToClipMatrix[i] = [1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 0.01, 0, 0, 0, 0, 1][i]  # w = 1: orthographic
+    with pytest.raises(RuntimeError) as err:
+        hip.step(seq[2], cs, parity.denoiser_settings(name, seq[2]))
+    assert "nothing was launched" in str(err.value)
+    torch.cuda.synchronize()
+    for rt in before:
+        assert np.array_equal(before[rt], hip.output(rt))
+    for i, p in enumerate(pools):
+        assert np.array_equal(p, hip.ex.read_pool_plane(RT.PERMANENT_POOL, i)[0])
+
+
+@pytest.mark.gpu
+def test_range_without_first_range_still_decodes_guides():
+    """a dispatch range with first > 0 that was not preceded by first == 0 on the same list must not read stale decoded guides"""
+    name, w, h = "REBLUR_DIFFUSE", 192, 128
+    seq = parity.generate_sequence(name, w, h, 2)
+
+    def run(split):
+        hip = parity.HipRun(name, w, h, numerics="fast")
+        for f, frame in enumerate(seq):
+            for rt, t, fmt in parity.user_planes(name, frame):
+                t = t.cuda().clone().contiguous()
+                hip.inputs[rt] = t
+                hip.ex.bind(rt, t, fmt)
+            hip.inst.set_denoiser_settings(0, parity.denoiser_settings(name, frame))
+            hip.inst.set_common_settings(parity.common_settings(frame["camera"], seq[max(f - 1, 0)]["camera"], w, h, f))
+            r, ptr, num = hip.inst.get_compute_dispatches_raw()
+            assert r == api.Result.SUCCESS
+            if split and f == 1:
+                # the tile classification (dispatch 0) reads no guides; start the list at dispatch 1 after running dispatch 0 through ANOTHER call path
+                hip.ex.execute_range(ptr, num, 0, 1)
+                hip.ex.bind(RT.IN_NORMAL_ROUGHNESS, hip.inputs[RT.IN_NORMAL_ROUGHNESS], parity.F.R10_G10_B10_A2_UNORM)  # rebind: invalidates the cache
+                hip.ex.execute_range(ptr, num, 1, num - 1)
+            else:
+                hip.ex.execute_raw(ptr, num)
+        return {rt: hip.output(rt).copy() for rt in hip.outs}
+
+    a, b = run(False), run(True)
+    for rt in a:
+        assert np.array_equal(a[rt], b[rt])
+
+
+def test_numerics_mode_export_and_both_libraries_load():
+    fast, exact = api.load_library(numerics="fast"), api.load_library(numerics="exact")
+    assert fast.nrdHipGetNumericsMode() == 1 and exact.nrdHipGetNumericsMode() == 0
+    assert fast is not exact and api.load_library() is fast
