@@ -23,7 +23,10 @@ ORACLE_DIR = os.path.join(ROOT, "oracle")
 
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 COMMON_FLAGS = ["-std=c++17", "-O3", "-fPIC", "-fvisibility=hidden", "-Wno-return-type-c-linkage", "-I" + os.path.join(ROOT, "include")]
-HIP_FLAGS = ["--offload-arch=gfx950", "-fno-gpu-rdc", "-Wno-unused-result", "-Wno-return-type-c-linkage"]
+# -fno-slp-vectorize: gfx950 issues v_pk_{fma,mul,add}_f32 at HALF the rate of the scalar forms (profiles/r02_a_valu_bench.txt: 4.5 vs 2.3-2.6 cycles per
+# wave instruction), so packing two independent fp32 operations buys nothing, while the SLP vectoriser's register-pair shuffles cost v_movs and 30-50 VGPRs
+# (REBLUR blur pass: 124 -> 78 VGPRs at an unchanged instruction count). It never changes a rounding, so both numerics builds take it.
+HIP_FLAGS = ["--offload-arch=gfx950", "-fno-gpu-rdc", "-fno-slp-vectorize", "-Wno-unused-result", "-Wno-return-type-c-linkage"]
 # exact: no FMA contraction, so device arithmetic is bit-reproducible against the CPU oracle (DESIGN.md "Numerics")
 # fast : contraction on, a / b = a * v_rcp_f32(b), sqrt / exp2 / log2 as single hardware instructions (-fapprox-func together with flushed fp32
 #        denormals is what makes hipcc emit them without range-scaling code); NaN / infinity semantics are kept (no -ffinite-math-only)

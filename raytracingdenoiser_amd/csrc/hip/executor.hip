@@ -95,6 +95,7 @@ struct NrdHipExecutor {
     std::vector<Plane> permanent, transient;
     Plane decodedNormalRoughness = {}; // internal float4 cache of IN_NORMAL_ROUGHNESS (not an NRD pool plane; own allocation)
     Plane worldPosViewZ = {};          // internal float4 scratch of the RELAX a-trous chain (world position + viewZ per pixel)
+    Plane viewPos = {};                // internal float4 guide plane of the REBLUR lists (view-space position + viewZ + material ID per pixel)
     std::vector<nrd::Format> permanentFormat, transientFormat;
 
     Plane user[(size_t)nrd::ResourceType::MAX_NUM] = {};
@@ -264,6 +265,8 @@ extern "C" __attribute__((visibility("default"))) void nrdHipDestroyExecutor(Nrd
         (void)hipFree(e->decodedNormalRoughness.ptr);
     if (e->worldPosViewZ.ptr)
         (void)hipFree(e->worldPosViewZ.ptr);
+    if (e->viewPos.ptr)
+        (void)hipFree(e->viewPos.ptr);
     delete e;
 }
 
@@ -797,6 +800,42 @@ static uint32_t ExecuteRange(NrdHipExecutor* e, const nrd::DispatchDesc* descs, 
         }
     }
 
+    // View-position guide plane of the REBLUR lists (same geometry again): needs IN_VIEWZ and the frame's REBLUR constants
+    Plane viewPos = {};
+    const void* reblurConstants = nullptr;
+    if (decoded.ptr && e->userBound[(uint32_t)nrd::ResourceType::IN_VIEWZ]) {
+        for (uint32_t i = 0; i < dispatchDescsNum && !reblurConstants; i++)
+            if (descs[i].pipelineIndex < idesc.pipelinesNum && !strncmp(idesc.pipelines[descs[i].pipelineIndex].shaderFileName, "REBLUR_", 7) && descs[i].constantBufferData &&
+                descs[i].constantBufferDataSize >= sizeof(nrdc::ReblurConstants))
+                reblurConstants = descs[i].constantBufferData;
+        const Plane& z = e->user[(uint32_t)nrd::ResourceType::IN_VIEWZ];
+        if (reblurConstants && z.w == decoded.w && z.h == decoded.h) {
+            Plane& cache = e->viewPos;
+            if (!cache.ptr || cache.w != decoded.w || cache.h != decoded.h) {
+                if (cache.ptr)
+                    (void)hipFree(cache.ptr);
+                cache = decoded;
+                cache.ptr = nullptr;
+                if (hipMalloc((void**)&cache.ptr, (size_t)cache.pitch * (size_t)cache.h) != hipSuccess)
+                    return e->Fail(nrd::Result::FAILURE, "nrdHipExecuteDispatches: cannot allocate the view-position guide plane");
+                e->decodedFresh = false;
+                decodeNow = true;
+            }
+            viewPos = cache;
+        } else {
+            reblurConstants = nullptr;
+        }
+    }
+    auto decode = [&](LaunchRecorder* rec) {
+        PassArgs args = {};
+        args.stream = e->stream;
+        args.recorder = rec;
+        if (viewPos.ptr)
+            LaunchDecodeGuides(args, e->user[(uint32_t)nrd::ResourceType::IN_NORMAL_ROUGHNESS], e->user[(uint32_t)nrd::ResourceType::IN_VIEWZ], decoded, viewPos, reblurConstants);
+        else
+            LaunchDecodeNormalRoughness(args, e->user[(uint32_t)nrd::ResourceType::IN_NORMAL_ROUGHNESS], decoded);
+    };
+
     auto passName = [&](const nrd::DispatchDesc& d) {
         return std::string("'") + (d.name ? d.name : "?") + "' (" + (d.pipelineIndex < idesc.pipelinesNum ? idesc.pipelines[d.pipelineIndex].shaderFileName : "?") + ")";
     };
@@ -806,6 +845,7 @@ static uint32_t ExecuteRange(NrdHipExecutor* e, const nrd::DispatchDesc* descs, 
         args.rowEnd = INT_MAX;
         args.decodedNormalRoughness = decoded;
         args.worldPosViewZ = worldPos;
+        args.viewPos = viewPos;
         if (rowBegin && rowBegin[i] >= 0) {
             args.rowBegin = rowBegin[i];
             args.rowEnd = rowEnd[i];
@@ -818,12 +858,8 @@ static uint32_t ExecuteRange(NrdHipExecutor* e, const nrd::DispatchDesc* descs, 
     const bool useGraph = e->graphMode && !e->profiling;
     LaunchRecorder recorder;
     recorder.keep = useGraph;
-    if (decodeNow) {
-        PassArgs args = {};
-        args.stream = e->stream;
-        args.recorder = &recorder;
-        LaunchDecodeNormalRoughness(args, e->user[(uint32_t)nrd::ResourceType::IN_NORMAL_ROUGHNESS], decoded);
-    }
+    if (decodeNow)
+        decode(&recorder);
     for (uint32_t i = first; i < first + count; i++) {
         const nrd::DispatchDesc& d = descs[i];
         if (d.pipelineIndex >= e->launchers.size())
@@ -847,11 +883,8 @@ static uint32_t ExecuteRange(NrdHipExecutor* e, const nrd::DispatchDesc* descs, 
         if (r != (uint32_t)nrd::Result::SUCCESS)
             return r;
     } else {
-        if (decodeNow) {
-            PassArgs args = {};
-            args.stream = e->stream;
-            LaunchDecodeNormalRoughness(args, e->user[(uint32_t)nrd::ResourceType::IN_NORMAL_ROUGHNESS], decoded);
-        }
+        if (decodeNow)
+            decode(nullptr);
         for (uint32_t i = first; i < first + count; i++) {
             const nrd::DispatchDesc& d = descs[i];
             PassArgs args = {};

@@ -25,8 +25,8 @@ static const char* CheckSupportedHistory(const ReblurCB& c) {
     return nullptr;
 }
 
-NRD_D bool BlockHasGeometry(const Plane& tiles, int blockY) {
-    const int tileY = (blockY * TILE_Y) >> 4, tileX0 = (blockIdx.x * TILE_X) >> 4;
+NRD_D bool BlockHasGeometry(const Plane& tiles, int blockX, int blockY) {
+    const int tileY = (blockY * TILE_Y) >> 4, tileX0 = (blockX * TILE_X) >> 4;
     bool any = false;
     for (int t = 0; t < TILE_X / 16; t++)
         if (tileX0 + t < tiles.w && tileY < tiles.h)
@@ -215,13 +215,13 @@ __global__ __launch_bounds__(TILE_X* TILE_Y) void ReblurHistoryFixKernel(ReblurC
 
     const int tx = threadIdx.x % TILE_X, ty = threadIdx.x / TILE_X;
     const int blockY = blockIdx.y + rr.firstBlockY;
-    const int px = blockIdx.x * TILE_X + tx, py = blockY * TILE_Y + ty;
+    const int px = BlockTileX(rr) * TILE_X + tx, py = blockY * TILE_Y + ty;
     const int rw = c.gRectSizeMinusOne.x, rh = c.gRectSizeMinusOne.y;
 
-    if (!BlockHasGeometry(P.tiles, blockY))
+    if (!BlockHasGeometry(P.tiles, BlockTileX(rr), blockY))
         return;
     {
-        const int baseX = blockIdx.x * TILE_X - hf::BORDER, baseY = blockY * TILE_Y - hf::BORDER;
+        const int baseX = BlockTileX(rr) * TILE_X - hf::BORDER, baseY = blockY * TILE_Y - hf::BORDER;
         for (int i = threadIdx.x; i < hf::BUF_X * hf::BUF_Y; i += TILE_X * TILE_Y) {
             int lx = i % hf::BUF_X, ly = i / hf::BUF_X;
             int gx = ClampI(baseX + lx, 0, rw), gy = ClampI(baseY + ly, 0, rh);
@@ -302,7 +302,7 @@ static const char* LaunchHistoryFix(const PassArgs& a) {
     if (k != a.planesNum)
         return "REBLUR history fix: unexpected resource count";
     RowGrid g = GridForRows(c.gRectSizeMinusOne.x + 1, c.gRectSizeMinusOne.y + 1, TILE_X, TILE_Y, a.rowBegin, a.rowEnd);
-    LaunchPass(a, (ReblurHistoryFixKernel<DIFF, SPEC, PERF, KIND, SH>), g.grid, dim3(TILE_X * TILE_Y), c, P, RowRange{g.firstBlockY, g.rowBegin, g.rowEnd});
+    LaunchPass(a, (ReblurHistoryFixKernel<DIFF, SPEC, PERF, KIND, SH>), g.grid, dim3(TILE_X * TILE_Y), c, P, MakeRowRange(g));
     return nullptr;
 }
 
@@ -357,13 +357,13 @@ __global__ __launch_bounds__(TILE_X* TILE_Y) void ReblurTemporalStabilizationKer
 
     const int tx = threadIdx.x % TILE_X, ty = threadIdx.x / TILE_X;
     const int blockY = blockIdx.y + rr.firstBlockY;
-    const int px = blockIdx.x * TILE_X + tx, py = blockY * TILE_Y + ty;
+    const int px = BlockTileX(rr) * TILE_X + tx, py = blockY * TILE_Y + ty;
     const int rw = c.gRectSizeMinusOne.x, rh = c.gRectSizeMinusOne.y;
 
-    if (!BlockHasGeometry(P.tiles, blockY))
+    if (!BlockHasGeometry(P.tiles, BlockTileX(rr), blockY))
         return;
     {
-        const int baseX = blockIdx.x * TILE_X - ts::BORDER, baseY = blockY * TILE_Y - ts::BORDER;
+        const int baseX = BlockTileX(rr) * TILE_X - ts::BORDER, baseY = blockY * TILE_Y - ts::BORDER;
         for (int i = threadIdx.x; i < ts::BUF_X * ts::BUF_Y; i += TILE_X * TILE_Y) {
             int lx = i % ts::BUF_X, ly = i / ts::BUF_X;
             int gx = ClampI(baseX + lx, 0, rw), gy = ClampI(baseY + ly, 0, rh);
@@ -597,7 +597,7 @@ static const char* LaunchTemporalStabilization(const PassArgs& a) {
     if (k != a.planesNum)
         return "REBLUR temporal stabilization: unexpected resource count";
     RowGrid g = GridForRows(c.gRectSizeMinusOne.x + 1, c.gRectSizeMinusOne.y + 1, TILE_X, TILE_Y, a.rowBegin, a.rowEnd);
-    LaunchPass(a, (ReblurTemporalStabilizationKernel<DIFF, SPEC, PERF, SH, KIND>), g.grid, dim3(TILE_X * TILE_Y), c, P, RowRange{g.firstBlockY, g.rowBegin, g.rowEnd});
+    LaunchPass(a, (ReblurTemporalStabilizationKernel<DIFF, SPEC, PERF, SH, KIND>), g.grid, dim3(TILE_X * TILE_Y), c, P, MakeRowRange(g));
     return nullptr;
 }
 

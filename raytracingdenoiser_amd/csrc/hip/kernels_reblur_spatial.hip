@@ -72,6 +72,64 @@ struct SpatialCtx {
     float2 wc;
 };
 
+// ---- one tap of the Poisson kernels: position -> texel, guides of that texel ------------------------------------------------------------------
+// The reference snaps the tap to a pixel centre (floor(uv * rectSize) + 0.5), turns it back into a uv, scales / clamps it to the viewport, lets the
+// nearest-clamp sampler pick the texel and reconstructs the tap's view position from that uv and the fetched viewZ. FR ("full rect": rect == resource,
+// no checkerboard -- the launcher picks the variant) collapses that chain: the snapped pixel IS the texel (k = floor(uv * rectSize), clamped to the
+// rect; "in screen" <=> k was inside), and normal, view position, viewZ and material ID of a texel come as two 16-byte loads at ONE offset from
+// the per-frame guide planes (decoded normals + viewPos, passes.h) instead of being re-derived per tap. Same values bit for bit: a tap outside
+// the screen has weight 0 in both formulations, and inside the guide plane holds exactly ReconstructViewPosition( pixel centre uv, viewZ ).
+struct TapGuides {
+    float w;          // IsInScreenNearest
+    float3 Ns, Xvs;   // world-space normal, view-space position of the tap's texel
+    float roughnessS, materialIDs, zs;
+    int2 ts;          // texel of the signal planes
+    float2 uv;        // generic path only
+};
+
+template <SpatialMode MODE, bool CB, bool FR, bool NEED_ROUGHNESS>
+NRD_D TapGuides FetchTapGuides(const ReblurCB& c, float2 uv, const Plane& gIn_Signal, const Plane& gIn_ViewZ, const Plane& gIn_Normal_Roughness, const Plane& gIn_ViewPos, uint32_t checkerboardMode,
+    uint32_t n, bool compareMaterials) {
+    TapGuides t;
+    const float2 rectSize = ToF2(c.gRectSize), rectSizeInv = ToF2(c.gRectSizeInv);
+    uv = Floor(uv * rectSize);
+    if (FR) {
+        // clamp in the float domain (one v_med3_f32 per axis; the snapped coordinate is an integer-valued float): inside <=> the clamp changed nothing
+        const float cxf = __builtin_amdgcn_fmed3f(uv.x, 0.0f, rectSize.x - 1.0f), cyf = __builtin_amdgcn_fmed3f(uv.y, 0.0f, rectSize.y - 1.0f);
+        t.w = (cxf == uv.x && cyf == uv.y) ? 1.0f : 0.0f;
+        t.ts = make_int2((int)cxf, (int)cyf);
+        const uint32_t offset = __umul24((uint32_t)t.ts.y, gIn_Normal_Roughness.pitch) + (uint32_t)t.ts.x * 16u; // both guide planes share the layout
+        const float4 g0 = *(const float4*)(gIn_Normal_Roughness.ptr + offset), g1 = *(const float4*)(gIn_ViewPos.ptr + offset);
+        t.Ns = Xyz(g0);
+        t.Xvs = Xyz(g1);
+        t.zs = g1.z;
+        t.materialIDs = g1.w;
+        t.roughnessS = NEED_ROUGHNESS ? NRD_DIV_1023(float(AsUint(g0.w) & 0x3FFu)) : 0.0f;
+        t.uv = uv; // unused
+        return t;
+    }
+    uv = uv + 0.5f;
+    if (MODE == PRE_BLUR && CB)
+        uv = ApplyCheckerboardShift(uv, checkerboardMode, n, c.gFrameIndex);
+    uv = uv * rectSizeInv;
+    const float2 resolutionScale = ToF2(c.gResolutionScale);
+    const float2 uvMax = resolutionScale - ToF2(c.gResourceSizeInv) * 0.5f;
+    float2 uvScaled = F2(Min(uv.x * resolutionScale.x, uvMax.x), Min(uv.y * resolutionScale.y, uvMax.y));
+    // all planes of a pass have the resource size (checked by the executor): one texel index serves the three fetches
+    const int2 tz = NearestTexel(gIn_ViewZ, uvScaled);
+    t.ts = tz;
+    if (MODE == PRE_BLUR && CB && checkerboardMode != 2)
+        t.ts = NearestTexel(gIn_Signal, F2(uvScaled.x * 0.5f, uvScaled.y));
+    t.zs = UnpackViewZ(c, LoadR32F(gIn_ViewZ, tz.x, tz.y));
+    float4 Ns = LoadDecodedNormalRoughness(gIn_Normal_Roughness, tz.x, tz.y, t.materialIDs);
+    t.Ns = Xyz(Ns);
+    t.roughnessS = Ns.w;
+    t.Xvs = ReconstructViewPosition(uv, ToF4(c.gFrustum), t.zs, c.gOrthoMode);
+    t.w = IsInScreenNearest(uv);
+    t.uv = uv;
+    return t;
+}
+
 // PERF = REBLUR_PERFORMANCE_MODE (reference REBLUR_Config.hlsli:196-238): 6 taps of g_Special6 instead of 8 of g_Special8, and
 // screen-space sampling for the specular Blur / PostBlur too
 template <bool PERF>
@@ -85,9 +143,9 @@ NRD_D float PoissonGaussianWeight(int n) { // = GetGaussianWeight( offset.z ), b
 // SH = the *_SH denoisers: an SH1 plane (RGBA16F) rides on the same taps and weights (diffuse: all 4 components, specular: .xyz only)
 // CB = a checkerboard mode is on (pre-pass only): the noisy inputs live in the left half of their planes, a tap that lands on a pixel
 // without data moves one pixel sideways, and pixels the taps could not fill are resolved from the two horizontal neighbours
-template <SpatialMode MODE, bool PERF, int KIND, bool SH, bool CB>
+template <SpatialMode MODE, bool PERF, int KIND, bool SH, bool CB, bool FR>
 NRD_D typename ReblurSignal<KIND>::type DiffuseSpatialFilterTaps(const ReblurCB& c, const SpatialCtx& s, typename ReblurSignal<KIND>::type diff, const Plane& gIn_Diff, const Plane& gIn_ViewZ,
-    const Plane& gIn_Normal_Roughness, float4& diffSh, const Plane& gIn_DiffSh, float& sum) {
+    const Plane& gIn_Normal_Roughness, const Plane& gIn_ViewPos, float4& diffSh, const Plane& gIn_DiffSh, float& sum) {
     typedef ReblurSignal<KIND> Sig;
     constexpr bool OCC = KIND == SIGNAL_OCCLUSION;
     typedef typename Sig::type S;
@@ -130,8 +188,7 @@ NRD_D typename ReblurSignal<KIND>::type DiffuseSpatialFilterTaps(const ReblurCB&
     if (MODE != PRE_BLUR && !OCC)
         minHitDistWeight *= Sqrt(diffNonLinearAccumSpeed);
 
-    const float2 rectSize = ToF2(c.gRectSize), rectSizeInv = ToF2(c.gRectSizeInv), resolutionScale = ToF2(c.gResolutionScale);
-    const float2 uvMax = resolutionScale - ToF2(c.gResourceSizeInv) * 0.5f;
+    const float2 rectSizeInv = ToF2(c.gRectSizeInv);
 
     float2 skew = F2(1.0f, 1.0f);
     if (MODE != PRE_BLUR) {
@@ -140,32 +197,22 @@ NRD_D typename ReblurSignal<KIND>::type DiffuseSpatialFilterTaps(const ReblurCB&
     }
     skew = skew * (rectSizeInv * blurRadius);
     float4 scaledRotator = ScaleRotator(s.rotator, skew);
+    // material IDs are 0..3: with a minimum material >= 3 every comparison holds (the library default is 4 = "off")
+    const bool compareMaterials = c.gDiffMinMaterial < 3.0f;
 
 #pragma unroll
     for (int n = 0; n < (PERF ? 6 : 8); n++) {
         float3 offset = PERF ? F3(g_Special6[n][0], g_Special6[n][1], g_Special6[n][2]) : F3(g_Special8[n][0], g_Special8[n][1], g_Special8[n][2]);
-        float2 uv = s.pixelUv + RotateVector(scaledRotator, F2(offset.x, offset.y));
-        uv = Floor(uv * rectSize) + 0.5f;
-        if (MODE == PRE_BLUR && CB)
-            uv = ApplyCheckerboardShift(uv, c.gDiffCheckerboard, (uint32_t)n, c.gFrameIndex);
-        uv = uv * rectSizeInv;
-        float2 uvScaled = F2(Min(uv.x * resolutionScale.x, uvMax.x), Min(uv.y * resolutionScale.y, uvMax.y));
+        const float2 uvTap = s.pixelUv + RotateVector(scaledRotator, F2(offset.x, offset.y));
+        const TapGuides t = FetchTapGuides<MODE, CB, FR, false>(c, uvTap, gIn_Diff, gIn_ViewZ, gIn_Normal_Roughness, gIn_ViewPos, c.gDiffCheckerboard, (uint32_t)n, compareMaterials);
+        const int2 ts = t.ts;
 
-        // all planes of a pass have the resource size (checked by the executor): one texel index serves the three fetches
-        const int2 tz = NearestTexel(gIn_ViewZ, uvScaled);
-        int2 ts = tz; // texel of the signal planes
-        if (MODE == PRE_BLUR && CB && c.gDiffCheckerboard != 2)
-            ts = NearestTexel(gIn_Diff, F2(uvScaled.x * 0.5f, uvScaled.y));
-        float zs = UnpackViewZ(c, LoadR32F(gIn_ViewZ, tz.x, tz.y));
-        float materialIDs;
-        float4 Ns = LoadDecodedNormalRoughness(gIn_Normal_Roughness, tz.x, tz.y, materialIDs);
+        float angle = AcosApprox(Dot(s.N, t.Ns));
 
-        float angle = AcosApprox(Dot(s.N, Xyz(Ns)));
-        float3 Xvs = ReconstructViewPosition(uv, ToF4(c.gFrustum), zs, c.gOrthoMode);
-
-        float w = IsInScreenNearest(uv);
-        w *= ComputeWeight(Dot(s.Nv, Xvs), geometryWeightParams.x, geometryWeightParams.y);
-        w *= CompareMaterials(s.materialID, materialIDs, c.gDiffMinMaterial) ? 1.0f : 0.0f;
+        float w = t.w;
+        w *= ComputeWeight(Dot(s.Nv, t.Xvs), geometryWeightParams.x, geometryWeightParams.y);
+        if (compareMaterials)
+            w *= CompareMaterials(s.materialID, t.materialIDs, c.gDiffMinMaterial) ? 1.0f : 0.0f;
         w *= ComputeWeight(angle, normalWeightParam, 0.0f);
 
         S smp = Sig::Load(gIn_Diff, ts.x, ts.y);
@@ -190,13 +237,13 @@ NRD_D typename ReblurSignal<KIND>::type DiffuseSpatialFilterTaps(const ReblurCB&
 }
 
 // "sum" = 1 when the centre pixel carries data, 0 for the empty pixels of a checkerboarded input
-template <SpatialMode MODE, bool PERF, int KIND, bool SH, bool CB>
+template <SpatialMode MODE, bool PERF, int KIND, bool SH, bool CB, bool FR>
 NRD_D typename ReblurSignal<KIND>::type DiffuseSpatialFilter(const ReblurCB& c, const SpatialCtx& s, typename ReblurSignal<KIND>::type diff, const Plane& gIn_Diff, const Plane& gIn_ViewZ,
-    const Plane& gIn_Normal_Roughness, float4& diffSh, const Plane& gIn_DiffSh, float sum) {
+    const Plane& gIn_Normal_Roughness, const Plane& gIn_ViewPos, float4& diffSh, const Plane& gIn_DiffSh, float sum) {
     typedef ReblurSignal<KIND> Sig;
     typedef typename Sig::type S;
     if (!(MODE == PRE_BLUR && c.gDiffPrepassBlurRadius == 0.0f))
-        diff = DiffuseSpatialFilterTaps<MODE, PERF, KIND, SH, CB>(c, s, diff, gIn_Diff, gIn_ViewZ, gIn_Normal_Roughness, diffSh, gIn_DiffSh, sum);
+        diff = DiffuseSpatialFilterTaps<MODE, PERF, KIND, SH, CB, FR>(c, s, diff, gIn_Diff, gIn_ViewZ, gIn_Normal_Roughness, gIn_ViewPos, diffSh, gIn_DiffSh, sum);
     if (MODE == PRE_BLUR && CB && sum == 0.0f) { // reference REBLUR_Common_DiffuseSpatialFilter.hlsli:177-199
         S s0 = Select(s.wc.x == 0.0f, Sig::Zero(), Sig::Load(gIn_Diff, s.cbX0, s.py));
         S s1 = Select(s.wc.y == 0.0f, Sig::Zero(), Sig::Load(gIn_Diff, s.cbX1, s.py));
@@ -210,9 +257,9 @@ NRD_D typename ReblurSignal<KIND>::type DiffuseSpatialFilter(const ReblurCB& c, 
     return diff;
 }
 
-template <SpatialMode MODE, bool PERF, int KIND, bool SH, bool CB>
+template <SpatialMode MODE, bool PERF, int KIND, bool SH, bool CB, bool FR>
 NRD_D typename ReblurSignal<KIND>::type SpecularSpatialFilterTaps(const ReblurCB& c, const SpatialCtx& s, typename ReblurSignal<KIND>::type spec, const Plane& gIn_Spec, const Plane& gIn_ViewZ,
-    const Plane& gIn_Normal_Roughness, const Plane& gOut_SpecHitDistForTracking, float4& specSh, const Plane& gIn_SpecSh, float& sum) {
+    const Plane& gIn_Normal_Roughness, const Plane& gIn_ViewPos, const Plane& gOut_SpecHitDistForTracking, float4& specSh, const Plane& gIn_SpecSh, float& sum) {
     typedef ReblurSignal<KIND> Sig;
     constexpr bool OCC = KIND == SIGNAL_OCCLUSION;
     typedef typename Sig::type S;
@@ -273,8 +320,8 @@ NRD_D typename ReblurSignal<KIND>::type SpecularSpatialFilterTaps(const ReblurCB
     if (MODE != PRE_BLUR && !OCC)
         minHitDistWeight *= Sqrt(specNonLinearAccumSpeed);
 
-    const float2 rectSize = ToF2(c.gRectSize), rectSizeInv = ToF2(c.gRectSizeInv), resolutionScale = ToF2(c.gResolutionScale);
-    const float2 uvMax = resolutionScale - ToF2(c.gResourceSizeInv) * 0.5f;
+    const float2 rectSizeInv = ToF2(c.gRectSizeInv);
+    const bool compareMaterials = c.gSpecMinMaterial < 3.0f; // see the diffuse filter
 
     constexpr bool SCREEN_SPACE = MODE == PRE_BLUR || PERF; // REBLUR_USE_SCREEN_SPACE_SAMPLING_FOR_SPECULAR
     float4 scaledRotator = F4(0.0f);
@@ -303,27 +350,18 @@ NRD_D typename ReblurSignal<KIND>::type SpecularSpatialFilterTaps(const ReblurCB
         else
             uv = GetKernelSampleCoordinates(c.gViewToClip, offset, s.Xv, T, B, s.rotator);
 
-        uv = Floor(uv * rectSize) + 0.5f;
-        if (MODE == PRE_BLUR && CB)
-            uv = ApplyCheckerboardShift(uv, c.gSpecCheckerboard, (uint32_t)n, c.gFrameIndex);
-        uv = uv * rectSizeInv;
-        float2 uvScaled = F2(Min(uv.x * resolutionScale.x, uvMax.x), Min(uv.y * resolutionScale.y, uvMax.y));
+        const TapGuides t = FetchTapGuides<MODE, CB, FR, true>(c, uv, gIn_Spec, gIn_ViewZ, gIn_Normal_Roughness, gIn_ViewPos, c.gSpecCheckerboard, (uint32_t)n, compareMaterials);
+        const int2 ts = t.ts;
+        const float zs = t.zs;
+        const float3 Xvs = t.Xvs;
+        const float4 Ns = F4(t.Ns, t.roughnessS);
 
-        // all planes of a pass have the resource size (checked by the executor): one texel index serves the three fetches
-        const int2 tz = NearestTexel(gIn_ViewZ, uvScaled);
-        int2 ts = tz; // texel of the signal planes
-        if (MODE == PRE_BLUR && CB && c.gSpecCheckerboard != 2)
-            ts = NearestTexel(gIn_Spec, F2(uvScaled.x * 0.5f, uvScaled.y));
-        float zs = UnpackViewZ(c, LoadR32F(gIn_ViewZ, tz.x, tz.y));
-        float materialIDs;
-        float4 Ns = LoadDecodedNormalRoughness(gIn_Normal_Roughness, tz.x, tz.y, materialIDs);
+        float angle = AcosApprox(Dot(s.N, t.Ns));
 
-        float angle = AcosApprox(Dot(s.N, Xyz(Ns)));
-        float3 Xvs = ReconstructViewPosition(uv, ToF4(c.gFrustum), zs, c.gOrthoMode);
-
-        float w = IsInScreenNearest(uv);
+        float w = t.w;
         w *= ComputeWeight(Dot(s.Nv, Xvs), geometryWeightParams.x, geometryWeightParams.y);
-        w *= CompareMaterials(s.materialID, materialIDs, c.gSpecMinMaterial) ? 1.0f : 0.0f;
+        if (compareMaterials)
+            w *= CompareMaterials(s.materialID, t.materialIDs, c.gSpecMinMaterial) ? 1.0f : 0.0f;
         w *= ComputeWeight(angle, normalWeightParam, 0.0f);
         w *= ComputeWeight(Ns.w, roughnessWeightParams.x, roughnessWeightParams.y);
 
@@ -364,13 +402,13 @@ NRD_D typename ReblurSignal<KIND>::type SpecularSpatialFilterTaps(const ReblurCB
     return spec;
 }
 
-template <SpatialMode MODE, bool PERF, int KIND, bool SH, bool CB>
+template <SpatialMode MODE, bool PERF, int KIND, bool SH, bool CB, bool FR>
 NRD_D typename ReblurSignal<KIND>::type SpecularSpatialFilter(const ReblurCB& c, const SpatialCtx& s, typename ReblurSignal<KIND>::type spec, const Plane& gIn_Spec, const Plane& gIn_ViewZ,
-    const Plane& gIn_Normal_Roughness, const Plane& gOut_SpecHitDistForTracking, float4& specSh, const Plane& gIn_SpecSh, float sum) {
+    const Plane& gIn_Normal_Roughness, const Plane& gIn_ViewPos, const Plane& gOut_SpecHitDistForTracking, float4& specSh, const Plane& gIn_SpecSh, float sum) {
     typedef ReblurSignal<KIND> Sig;
     typedef typename Sig::type S;
     if (!(MODE == PRE_BLUR && c.gSpecPrepassBlurRadius == 0.0f))
-        spec = SpecularSpatialFilterTaps<MODE, PERF, KIND, SH, CB>(c, s, spec, gIn_Spec, gIn_ViewZ, gIn_Normal_Roughness, gOut_SpecHitDistForTracking, specSh, gIn_SpecSh, sum);
+        spec = SpecularSpatialFilterTaps<MODE, PERF, KIND, SH, CB, FR>(c, s, spec, gIn_Spec, gIn_ViewZ, gIn_Normal_Roughness, gIn_ViewPos, gOut_SpecHitDistForTracking, specSh, gIn_SpecSh, sum);
     if (MODE == PRE_BLUR && CB && sum == 0.0f) { // reference REBLUR_Common_SpecularSpatialFilter.hlsli:224-246 (all 4 SH components here)
         S s0 = Select(s.wc.x == 0.0f, Sig::Zero(), Sig::Load(gIn_Spec, s.cbX0, s.py));
         S s1 = Select(s.wc.y == 0.0f, Sig::Zero(), Sig::Load(gIn_Spec, s.cbX1, s.py));
@@ -408,6 +446,7 @@ NRD_D bool MakeSpatialCtx(const ReblurCB& c, int px, int py, float viewZ, const 
 struct SpatialPlanes {
     Plane tiles, normalRoughness, viewZ, data1;
     Plane decodedNR; // executor's float4 cache of normalRoughness (reblur_device.h "decoded guides")
+    Plane viewPos;   // executor's float4 guide plane (view position, viewZ, material ID; passes.h), same layout as decodedNR
     Plane inDiff, inSpec;
     Plane outDiff, outSpec;
     Plane outHitDistForTracking; // pre-pass
@@ -417,12 +456,15 @@ struct SpatialPlanes {
     Plane inDiffSh, inSpecSh, outDiffSh, outSpecSh, outDiffShCopy, outSpecShCopy; // SH family
 };
 
-template <SpatialMode MODE, bool DIFF, bool SPEC, bool NO_TS, bool PERF, int KIND, bool SH, bool CB>
+// FR: rect == resource and no checkerboard (FetchTapGuides)
+template <SpatialMode MODE, bool DIFF, bool SPEC, bool NO_TS, bool PERF, int KIND, bool SH, bool CB, bool FR>
 __global__ __launch_bounds__(TILE_X* TILE_Y) void ReblurSpatialKernel(ReblurCB c, SpatialPlanes P, RowRange rr) {
+    if (FR)
+        ShareLayout(P.viewPos, P.decodedNR);
     typedef ReblurSignal<KIND> Sig;
     constexpr bool OCC = KIND == SIGNAL_OCCLUSION;
     typedef typename Sig::type S;
-    const int px = blockIdx.x * TILE_X + (threadIdx.x % TILE_X);
+    const int px = BlockTileX(rr) * TILE_X + (threadIdx.x % TILE_X);
     const int py = (blockIdx.y + rr.firstBlockY) * TILE_Y + (threadIdx.x / TILE_X);
     if (px > c.gRectSizeMinusOne.x || py > c.gRectSizeMinusOne.y || py < rr.rowBegin || py >= rr.rowEnd)
         return;
@@ -473,7 +515,7 @@ __global__ __launch_bounds__(TILE_X* TILE_Y) void ReblurSpatialKernel(ReblurCB c
             diff = Sig::Zero();
             diffSh = F4(0.0f);
         }
-        diff = DiffuseSpatialFilter<MODE, PERF, KIND, SH, CB>(c, s, diff, P.inDiff, P.viewZ, P.decodedNR, diffSh, P.inDiffSh, sum);
+        diff = DiffuseSpatialFilter<MODE, PERF, KIND, SH, CB, FR>(c, s, diff, P.inDiff, P.viewZ, P.decodedNR, P.viewPos, diffSh, P.inDiffSh, sum);
         Sig::Store(P.outDiff, px, py, diff);
         if (SH)
             StoreRGBA16F(P.outDiffSh, px, py, diffSh);
@@ -494,7 +536,7 @@ __global__ __launch_bounds__(TILE_X* TILE_Y) void ReblurSpatialKernel(ReblurCB c
             spec = Sig::Zero();
             specSh = F4(0.0f);
         }
-        spec = SpecularSpatialFilter<MODE, PERF, KIND, SH, CB>(c, s, spec, P.inSpec, P.viewZ, P.decodedNR, P.outHitDistForTracking, specSh, P.inSpecSh, sum);
+        spec = SpecularSpatialFilter<MODE, PERF, KIND, SH, CB, FR>(c, s, spec, P.inSpec, P.viewZ, P.decodedNR, P.viewPos, P.outHitDistForTracking, specSh, P.inSpecSh, sum);
         Sig::Store(P.outSpec, px, py, spec);
         if (SH)
             StoreRGBA16F(P.outSpecSh, px, py, specSh);
@@ -503,6 +545,12 @@ __global__ __launch_bounds__(TILE_X* TILE_Y) void ReblurSpatialKernel(ReblurCB c
         if (MODE == POST_BLUR && NO_TS && SH)
             StoreRGBA16F(P.outSpecShCopy, px, py, specSh);
     }
+}
+
+// NRD_HIP_GENERIC_TAPS=1: never take the "full rect" variant (A/B runs and the test that holds the two variants against each other)
+static bool ForceGenericTaps() {
+    const char* v = getenv("NRD_HIP_GENERIC_TAPS");
+    return v && atoi(v) != 0;
 }
 
 static const char* CheckSupported(const ReblurCB& c) {
@@ -525,6 +573,7 @@ static const char* LaunchSpatial(const PassArgs& a) {
     P.tiles = a.planes[k++];
     P.normalRoughness = a.planes[k++];
     P.decodedNR = a.decodedNormalRoughness;
+    P.viewPos = a.viewPos;
     if (!P.decodedNR.ptr)
         return "REBLUR spatial pass: the decoded normal/roughness cache is missing (IN_NORMAL_ROUGHNESS not bound?)";
     if (MODE == PRE_BLUR) {
@@ -570,14 +619,20 @@ static const char* LaunchSpatial(const PassArgs& a) {
         return "REBLUR spatial pass: unexpected resource count";
 
     RowGrid g = GridForRows(c.gRectSizeMinusOne.x + 1, c.gRectSizeMinusOne.y + 1, TILE_X, TILE_Y, a.rowBegin, a.rowEnd);
-    const RowRange rows = {g.firstBlockY, g.rowBegin, g.rowEnd};
+    const RowRange rows = MakeRowRange(g);
     if constexpr (MODE == PRE_BLUR) { // only the pre-pass reads the (possibly checkerboarded) noisy inputs
         if (c.gDiffCheckerboard != 2 || c.gSpecCheckerboard != 2) {
-            LaunchPass(a, (ReblurSpatialKernel<MODE, DIFF, SPEC, NO_TS, PERF, KIND, SH, true>), g.grid, dim3(TILE_X * TILE_Y), c, P, rows);
+            LaunchPass(a, (ReblurSpatialKernel<MODE, DIFF, SPEC, NO_TS, PERF, KIND, SH, true, false>), g.grid, dim3(TILE_X * TILE_Y), c, P, rows);
             return nullptr;
         }
     }
-    LaunchPass(a, (ReblurSpatialKernel<MODE, DIFF, SPEC, NO_TS, PERF, KIND, SH, false>), g.grid, dim3(TILE_X * TILE_Y), c, P, rows);
+    // "full rect": the rect is the whole resource (no dynamic-resolution scaling) and the guide planes of this frame exist
+    const bool fullRect = P.viewPos.ptr && SameLayout(P.viewPos, P.decodedNR) && c.gResolutionScale.x == 1.0f && c.gResolutionScale.y == 1.0f && c.gRectSizeMinusOne.x + 1 == P.decodedNR.w &&
+                          c.gRectSizeMinusOne.y + 1 == P.decodedNR.h && P.viewZ.w == P.decodedNR.w && P.viewZ.h == P.decodedNR.h && !ForceGenericTaps();
+    if (fullRect)
+        LaunchPass(a, (ReblurSpatialKernel<MODE, DIFF, SPEC, NO_TS, PERF, KIND, SH, false, true>), g.grid, dim3(TILE_X * TILE_Y), c, P, rows);
+    else
+        LaunchPass(a, (ReblurSpatialKernel<MODE, DIFF, SPEC, NO_TS, PERF, KIND, SH, false, false>), g.grid, dim3(TILE_X * TILE_Y), c, P, rows);
     return nullptr;
 }
 
@@ -586,7 +641,7 @@ static const char* LaunchSpatial(const PassArgs& a) {
 template <bool DIFF, bool SPEC, int KIND>
 __global__ __launch_bounds__(256) void ReblurSplitScreenKernel(ReblurCB c, Plane viewZ, Plane inDiff, Plane inSpec, Plane outDiff, Plane outSpec, Plane inDiffSh, Plane inSpecSh, Plane outDiffSh,
     Plane outSpecSh, RowRange rr) {
-    const int px = blockIdx.x * TILE_X + (threadIdx.x % TILE_X);
+    const int px = BlockTileX(rr) * TILE_X + (threadIdx.x % TILE_X);
     const int py = (blockIdx.y + rr.firstBlockY) * TILE_Y + (threadIdx.x / TILE_X);
     if (px > c.gRectSizeMinusOne.x || py > c.gRectSizeMinusOne.y || py < rr.rowBegin || py >= rr.rowEnd)
         return;
@@ -626,7 +681,7 @@ static const char* LaunchSplitScreen(const PassArgs& a) {
     if (k != a.planesNum)
         return "REBLUR split screen: unexpected resource count";
     RowGrid g = GridForRows(c.gRectSizeMinusOne.x + 1, c.gRectSizeMinusOne.y + 1, TILE_X, TILE_Y, a.rowBegin, a.rowEnd);
-    const RowRange rows = {g.firstBlockY, g.rowBegin, g.rowEnd};
+    const RowRange rows = MakeRowRange(g);
     // the occlusion family and directional occlusion bind their planes to the radiance family's pipeline: the codec follows the plane format
     const uint32_t format = a.formats[1];
     for (uint32_t i = 1; i < k; i++)
@@ -657,7 +712,7 @@ __global__ __launch_bounds__(TILE_X* TILE_Y) void ReblurHitDistReconstructionKer
     typedef ReblurSignal<KIND> Sig;
     constexpr bool OCC = KIND == SIGNAL_OCCLUSION;
     typedef typename Sig::type S;
-    const int px = blockIdx.x * TILE_X + (threadIdx.x % TILE_X);
+    const int px = BlockTileX(rr) * TILE_X + (threadIdx.x % TILE_X);
     const int py = (blockIdx.y + rr.firstBlockY) * TILE_Y + (threadIdx.x / TILE_X);
     const int rw = c.gRectSizeMinusOne.x, rh = c.gRectSizeMinusOne.y;
     if (px > rw || py > rh || py < rr.rowBegin || py >= rr.rowEnd)
@@ -751,7 +806,7 @@ static const char* LaunchHitDistReconstruction(const PassArgs& a) {
     if (k != a.planesNum || !P.decodedNR.ptr)
         return "REBLUR hit distance reconstruction: unexpected resource count or missing decoded normal/roughness cache";
     RowGrid g = GridForRows(c.gRectSizeMinusOne.x + 1, c.gRectSizeMinusOne.y + 1, TILE_X, TILE_Y, a.rowBegin, a.rowEnd);
-    LaunchPass(a, (ReblurHitDistReconstructionKernel<DIFF, SPEC, BORDER, PERF, KIND>), g.grid, dim3(TILE_X * TILE_Y), c, P, RowRange{g.firstBlockY, g.rowBegin, g.rowEnd});
+    LaunchPass(a, (ReblurHitDistReconstructionKernel<DIFF, SPEC, BORDER, PERF, KIND>), g.grid, dim3(TILE_X * TILE_Y), c, P, MakeRowRange(g));
     return nullptr;
 }
 

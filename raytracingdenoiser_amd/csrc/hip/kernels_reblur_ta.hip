@@ -63,12 +63,12 @@ __global__ __launch_bounds__(TILE_X* TILE_Y, 2) void ReblurTemporalAccumulationK
 
     const int tx = threadIdx.x % TILE_X, ty = threadIdx.x / TILE_X;
     const int blockY = blockIdx.y + rr.firstBlockY;
-    const int px = blockIdx.x * TILE_X + tx, py = blockY * TILE_Y + ty;
+    const int px = BlockTileX(rr) * TILE_X + tx, py = blockY * TILE_Y + ty;
     const int rw = cArg.gRectSizeMinusOne.x, rh = cArg.gRectSizeMinusOne.y;
 
     // ---- cooperative preload (clamped to the rect), skipped when every 16x16 tile under this block is sky
     {
-        const int tileY = (blockY * TILE_Y) >> 4, tileX0 = (blockIdx.x * TILE_X) >> 4;
+        const int tileY = (blockY * TILE_Y) >> 4, tileX0 = (BlockTileX(rr) * TILE_X) >> 4;
         bool anyGeometry = false;
         for (int t = 0; t < TILE_X / 16; t++)
             if (tileX0 + t < P.tiles.w && tileY < P.tiles.h)
@@ -76,7 +76,7 @@ __global__ __launch_bounds__(TILE_X* TILE_Y, 2) void ReblurTemporalAccumulationK
         if (!anyGeometry)
             return; // uniform across the block
 
-        const int baseX = blockIdx.x * TILE_X - BORDER, baseY = blockY * TILE_Y - BORDER;
+        const int baseX = BlockTileX(rr) * TILE_X - BORDER, baseY = blockY * TILE_Y - BORDER;
         for (int i = threadIdx.x; i < BUF_X * BUF_Y; i += TILE_X * TILE_Y) {
             int lx = i % BUF_X, ly = i / BUF_X;
             int gx = ClampI(baseX + lx, 0, rw), gy = ClampI(baseY + ly, 0, rh);
@@ -808,7 +808,7 @@ static const char* LaunchTemporalAccumulation(const PassArgs& a) {
     }
 
     RowGrid g = GridForRows(c.gRectSizeMinusOne.x + 1, c.gRectSizeMinusOne.y + 1, TILE_X, TILE_Y, a.rowBegin, a.rowEnd);
-    LaunchPass(a, (ReblurTemporalAccumulationKernel<DIFF, SPEC, PERF, KIND, SH>), g.grid, dim3(TILE_X * TILE_Y), c, P, RowRange{g.firstBlockY, g.rowBegin, g.rowEnd});
+    LaunchPass(a, (ReblurTemporalAccumulationKernel<DIFF, SPEC, PERF, KIND, SH>), g.grid, dim3(TILE_X * TILE_Y), c, P, MakeRowRange(g));
     return nullptr;
 }
 

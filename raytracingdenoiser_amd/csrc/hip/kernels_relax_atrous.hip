@@ -83,19 +83,19 @@ __global__ __launch_bounds__(256) void RelaxAtrousSmemKernel(AtrousPlanes P, Rel
 
     const int blockY = blockIdx.y + rows.firstBlockY;
     const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
-    const int px = blockIdx.x * TILE_X + tx, py = blockY * TILE_Y + ty;
+    const int px = BlockTileX(rows) * TILE_X + tx, py = blockY * TILE_Y + ty;
     const int rectW = c.shared.gRectSize.x, rectH = c.shared.gRectSize.y;
     const bool inRows = py >= rows.rowBegin && py < rows.rowEnd;
 
     // Every thread the reference launches (8x8 groups over the rect) forwards the guides to the "previous frame" planes,
     // sky or not; threads of all-sky tiles read unwritten group-shared memory there, which we define as zero.
     const bool inGrid = px < ((rectW + 7) & ~7) && py < ((rectH + 7) & ~7);
-    const bool blockHasGeometry = RelaxBlockHasGeometry(P.tiles, blockY);
+    const bool blockHasGeometry = RelaxBlockHasGeometry(P.tiles, BlockTileX(rows), blockY);
 
     if (blockHasGeometry) {
         for (int idx = threadIdx.x; idx < sm::BUF_X * sm::BUF_Y; idx += 256) {
             int lx = idx % sm::BUF_X, ly = idx / sm::BUF_X;
-            int gx = ClampI(blockIdx.x * TILE_X - sm::BORDER + lx, 0, rectW - 1), gy = ClampI(blockY * TILE_Y - sm::BORDER + ly, 0, rectH - 1);
+            int gx = ClampI(BlockTileX(rows) * TILE_X - sm::BORDER + lx, 0, rectW - 1), gy = ClampI(blockY * TILE_Y - sm::BORDER + ly, 0, rectH - 1);
             int li = ly * sm::BUF_STRIDE + lx;
             if (SPEC) s_Spec[li] = LoadRGBA16F(P.spec.in, gx, gy);
             if (SPEC && SH) s_SpecSH[li] = LoadRGBA16F(P.spec.inSh, gx, gy);
@@ -382,7 +382,7 @@ const char* LaunchAtrousSmem(const PassArgs& a) {
     RowGrid g = GridForRows((c.shared.gRectSize.x + 7) & ~7, (c.shared.gRectSize.y + 7) & ~7, TILE_X, TILE_Y, a.rowBegin, a.rowEnd);
     if (a.rowEnd >= c.shared.gRectSize.y) // the owner of the last rows also owns the rounding rows below the rect
         g.rowEnd = (c.shared.gRectSize.y + 7) & ~7;
-    LaunchPass(a, (RelaxAtrousSmemKernel<DIFF, SPEC, SH>), g.grid, dim3(256), P, c, RowRange{g.firstBlockY, g.rowBegin, g.rowEnd});
+    LaunchPass(a, (RelaxAtrousSmemKernel<DIFF, SPEC, SH>), g.grid, dim3(256), P, c, MakeRowRange(g));
     return nullptr;
 }
 
@@ -390,7 +390,7 @@ const char* LaunchAtrousSmem(const PassArgs& a) {
 template <bool DIFF, bool SPEC, bool SH>
 __global__ __launch_bounds__(256) void RelaxAtrousKernel(AtrousPlanes P, RelaxCB c, RowRange rows) {
     const int blockY = blockIdx.y + rows.firstBlockY;
-    const int px = blockIdx.x * TILE_X + (threadIdx.x & 31), py = blockY * TILE_Y + (threadIdx.x >> 5);
+    const int px = BlockTileX(rows) * TILE_X + (threadIdx.x & 31), py = blockY * TILE_Y + (threadIdx.x >> 5);
     const int rectW = c.shared.gRectSize.x, rectH = c.shared.gRectSize.y;
     if (px >= rectW || py >= rectH || py < rows.rowBegin || py >= rows.rowEnd)
         return;
@@ -582,7 +582,7 @@ const char* LaunchAtrous(const PassArgs& a) {
         return "RELAX Atrous: unexpected resource count";
     RelaxCB c = LoadRelaxConstants(a);
     RowGrid g = GridForRows(c.shared.gRectSize.x, c.shared.gRectSize.y, TILE_X, TILE_Y, a.rowBegin, a.rowEnd);
-    LaunchPass(a, (RelaxAtrousKernel<DIFF, SPEC, SH>), g.grid, dim3(256), P, c, RowRange{g.firstBlockY, g.rowBegin, g.rowEnd});
+    LaunchPass(a, (RelaxAtrousKernel<DIFF, SPEC, SH>), g.grid, dim3(256), P, c, MakeRowRange(g));
     return nullptr;
 }
 

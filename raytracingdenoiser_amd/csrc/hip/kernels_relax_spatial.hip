@@ -71,7 +71,7 @@ struct HitDistPlanes {
 template <bool DIFF, bool SPEC, int BORDER>
 __global__ __launch_bounds__(256) void RelaxHitDistReconstructionKernel(HitDistPlanes P, RelaxCB c, RowRange rows) {
     const int blockY = blockIdx.y + rows.firstBlockY;
-    const int px = blockIdx.x * TILE_X + (threadIdx.x & 31), py = blockY * TILE_Y + (threadIdx.x >> 5);
+    const int px = BlockTileX(rows) * TILE_X + (threadIdx.x & 31), py = blockY * TILE_Y + (threadIdx.x >> 5);
     const int rectW = c.shared.gRectSize.x, rectH = c.shared.gRectSize.y;
     if (px >= rectW || py >= rectH || py < rows.rowBegin || py >= rows.rowEnd)
         return;
@@ -162,7 +162,7 @@ const char* LaunchHitDistReconstruction(const PassArgs& a) {
         return "RELAX HitDistReconstruction: unexpected resource count or missing decoded normal/roughness cache";
     RelaxCB c = LoadRelaxConstants(a);
     RowGrid g = GridForRows(c.shared.gRectSize.x, c.shared.gRectSize.y, TILE_X, TILE_Y, a.rowBegin, a.rowEnd);
-    LaunchPass(a, (RelaxHitDistReconstructionKernel<DIFF, SPEC, BORDER>), g.grid, dim3(256), P, c, RowRange{g.firstBlockY, g.rowBegin, g.rowEnd});
+    LaunchPass(a, (RelaxHitDistReconstructionKernel<DIFF, SPEC, BORDER>), g.grid, dim3(256), P, c, MakeRowRange(g));
     return nullptr;
 }
 
@@ -200,7 +200,7 @@ NRD_D PrePassTap MakeTap(const RelaxCB& c, const Plane& guide, const Plane& sign
 template <bool DIFF, bool SPEC, bool SH, bool CB>
 __global__ __launch_bounds__(256) void RelaxPrePassKernel(PrePassPlanes P, RelaxCB c, RowRange rows) {
     const int blockY = blockIdx.y + rows.firstBlockY;
-    const int px = blockIdx.x * TILE_X + (threadIdx.x & 31), py = blockY * TILE_Y + (threadIdx.x >> 5);
+    const int px = BlockTileX(rows) * TILE_X + (threadIdx.x & 31), py = blockY * TILE_Y + (threadIdx.x >> 5);
     const int rectW = c.shared.gRectSize.x, rectH = c.shared.gRectSize.y;
     if (px >= rectW || py >= rectH || py < rows.rowBegin || py >= rows.rowEnd)
         return;
@@ -426,9 +426,9 @@ const char* LaunchPrePass(const PassArgs& a) {
     RelaxCB c = LoadRelaxConstants(a);
     RowGrid g = GridForRows(c.shared.gRectSize.x, c.shared.gRectSize.y, TILE_X, TILE_Y, a.rowBegin, a.rowEnd);
     if ((SPEC && c.shared.gSpecCheckerboard != 2u) || (DIFF && c.shared.gDiffCheckerboard != 2u))
-        LaunchPass(a, (RelaxPrePassKernel<DIFF, SPEC, SH, true>), g.grid, dim3(256), P, c, RowRange{g.firstBlockY, g.rowBegin, g.rowEnd});
+        LaunchPass(a, (RelaxPrePassKernel<DIFF, SPEC, SH, true>), g.grid, dim3(256), P, c, MakeRowRange(g));
     else
-        LaunchPass(a, (RelaxPrePassKernel<DIFF, SPEC, SH, false>), g.grid, dim3(256), P, c, RowRange{g.firstBlockY, g.rowBegin, g.rowEnd});
+        LaunchPass(a, (RelaxPrePassKernel<DIFF, SPEC, SH, false>), g.grid, dim3(256), P, c, MakeRowRange(g));
     return nullptr;
 }
 
@@ -442,7 +442,7 @@ struct HistoryFixPlanes {
 template <bool DIFF, bool SPEC, bool SH>
 __global__ __launch_bounds__(256) void RelaxHistoryFixKernel(HistoryFixPlanes P, RelaxCB c, RowRange rows) {
     const int blockY = blockIdx.y + rows.firstBlockY;
-    const int px = blockIdx.x * TILE_X + (threadIdx.x & 31), py = blockY * TILE_Y + (threadIdx.x >> 5);
+    const int px = BlockTileX(rows) * TILE_X + (threadIdx.x & 31), py = blockY * TILE_Y + (threadIdx.x >> 5);
     const int rectW = c.shared.gRectSize.x, rectH = c.shared.gRectSize.y;
     if (px >= rectW || py >= rectH || py < rows.rowBegin || py >= rows.rowEnd)
         return;
@@ -550,7 +550,7 @@ const char* LaunchHistoryFix(const PassArgs& a) {
         return "RELAX HistoryFix: unexpected resource count or missing decoded normal/roughness cache";
     RelaxCB c = LoadRelaxConstants(a);
     RowGrid g = GridForRows(c.shared.gRectSize.x, c.shared.gRectSize.y, TILE_X, TILE_Y, a.rowBegin, a.rowEnd);
-    LaunchPass(a, (RelaxHistoryFixKernel<DIFF, SPEC, SH>), g.grid, dim3(256), P, c, RowRange{g.firstBlockY, g.rowBegin, g.rowEnd});
+    LaunchPass(a, (RelaxHistoryFixKernel<DIFF, SPEC, SH>), g.grid, dim3(256), P, c, MakeRowRange(g));
     return nullptr;
 }
 
@@ -636,7 +636,7 @@ NRD_D void AntiFireflySignal(const RelaxCB& c, const SignalPlanes& S, const Plan
 template <bool DIFF, bool SPEC>
 __global__ __launch_bounds__(256) void RelaxAntiFireflyKernel(AntiFireflyPlanes P, RelaxCB c, RowRange rows) {
     const int blockY = blockIdx.y + rows.firstBlockY;
-    const int px = blockIdx.x * TILE_X + (threadIdx.x & 31), py = blockY * TILE_Y + (threadIdx.x >> 5);
+    const int px = BlockTileX(rows) * TILE_X + (threadIdx.x & 31), py = blockY * TILE_Y + (threadIdx.x >> 5);
     if (px >= c.shared.gRectSize.x || py >= c.shared.gRectSize.y || py < rows.rowBegin || py >= rows.rowEnd)
         return;
     if (LoadR8Unorm(P.tiles, px >> 4, py >> 4) != 0.0f)
@@ -669,7 +669,7 @@ const char* LaunchAntiFirefly(const PassArgs& a) {
         return "RELAX AntiFirefly: unexpected resource count or missing decoded normal/roughness cache";
     RelaxCB c = LoadRelaxConstants(a);
     RowGrid g = GridForRows(c.shared.gRectSize.x, c.shared.gRectSize.y, TILE_X, TILE_Y, a.rowBegin, a.rowEnd);
-    LaunchPass(a, (RelaxAntiFireflyKernel<DIFF, SPEC>), g.grid, dim3(256), P, c, RowRange{g.firstBlockY, g.rowBegin, g.rowEnd});
+    LaunchPass(a, (RelaxAntiFireflyKernel<DIFF, SPEC>), g.grid, dim3(256), P, c, MakeRowRange(g));
     return nullptr;
 }
 
@@ -682,7 +682,7 @@ struct SplitScreenPlanes {
 template <bool DIFF, bool SPEC, bool SH>
 __global__ __launch_bounds__(256) void RelaxSplitScreenKernel(SplitScreenPlanes P, RelaxCB c, RowRange rows) {
     const int blockY = blockIdx.y + rows.firstBlockY;
-    const int px = blockIdx.x * TILE_X + (threadIdx.x & 31), py = blockY * TILE_Y + (threadIdx.x >> 5);
+    const int px = BlockTileX(rows) * TILE_X + (threadIdx.x & 31), py = blockY * TILE_Y + (threadIdx.x >> 5);
     if (px >= c.shared.gRectSize.x || py >= c.shared.gRectSize.y || py < rows.rowBegin || py >= rows.rowEnd)
         return;
     float2 pixelUv = F2(float(px) + 0.5f, float(py) + 0.5f) * ToF2(c.shared.gRectSizeInv);
@@ -729,7 +729,7 @@ const char* LaunchSplitScreen(const PassArgs& a) {
         return "RELAX SplitScreen: unexpected resource count";
     RelaxCB c = LoadRelaxConstants(a);
     RowGrid g = GridForRows(c.shared.gRectSize.x, c.shared.gRectSize.y, TILE_X, TILE_Y, a.rowBegin, a.rowEnd);
-    LaunchPass(a, (RelaxSplitScreenKernel<DIFF, SPEC, SH>), g.grid, dim3(256), P, c, RowRange{g.firstBlockY, g.rowBegin, g.rowEnd});
+    LaunchPass(a, (RelaxSplitScreenKernel<DIFF, SPEC, SH>), g.grid, dim3(256), P, c, MakeRowRange(g));
     return nullptr;
 }
 

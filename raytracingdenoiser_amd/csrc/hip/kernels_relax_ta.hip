@@ -59,16 +59,16 @@ __global__ __launch_bounds__(256, 3) void RelaxTemporalAccumulationKernel(RelaxC
 
     const int blockY = blockIdx.y + rows.firstBlockY;
     const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
-    const int px = blockIdx.x * TILE_X + tx, py = blockY * TILE_Y + ty;
+    const int px = BlockTileX(rows) * TILE_X + tx, py = blockY * TILE_Y + ty;
     const int rectW = cArg.shared.gRectSize.x, rectH = cArg.shared.gRectSize.y;
 
-    if (!RelaxBlockHasGeometry(P.tiles, blockY)) // uniform per workgroup
+    if (!RelaxBlockHasGeometry(P.tiles, BlockTileX(rows), blockY)) // uniform per workgroup
         return;
 
     // preload (normal, specular hitT) at rect-clamped coordinates
     for (int idx = threadIdx.x; idx < ta::BUF_X * ta::BUF_Y; idx += 256) {
         int lx = idx % ta::BUF_X, ly = idx / ta::BUF_X;
-        int gx = ClampI(blockIdx.x * TILE_X - ta::BORDER + lx, 0, rectW - 1), gy = ClampI(blockY * TILE_Y - ta::BORDER + ly, 0, rectH - 1);
+        int gx = ClampI(BlockTileX(rows) * TILE_X - ta::BORDER + lx, 0, rectW - 1), gy = ClampI(blockY * TILE_Y - ta::BORDER + ly, 0, rectH - 1);
         float4 v = LoadDecodedNormalRoughness(P.decodedNR, gx, gy);
         if (SPEC)
             v.w = LoadRGBA16F(P.spec.in, gx, gy).w;
@@ -639,7 +639,7 @@ const char* LaunchTemporalAccumulation(const PassArgs& a) {
     }
     RelaxCB c = LoadRelaxConstants(a);
     RowGrid g = GridForRows(c.shared.gRectSize.x, c.shared.gRectSize.y, TILE_X, TILE_Y, a.rowBegin, a.rowEnd);
-    LaunchPass(a, (RelaxTemporalAccumulationKernel<DIFF, SPEC, SH>), g.grid, dim3(256), c, P, RowRange{g.firstBlockY, g.rowBegin, g.rowEnd});
+    LaunchPass(a, (RelaxTemporalAccumulationKernel<DIFF, SPEC, SH>), g.grid, dim3(256), c, P, MakeRowRange(g));
     return nullptr;
 }
 
@@ -773,15 +773,15 @@ __global__ __launch_bounds__(256) void RelaxHistoryClampingKernel(HcPlanes P, Re
 
     const int blockY = blockIdx.y + rows.firstBlockY;
     const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
-    const int px = blockIdx.x * TILE_X + tx, py = blockY * TILE_Y + ty;
+    const int px = BlockTileX(rows) * TILE_X + tx, py = blockY * TILE_Y + ty;
     const int rectW = c.shared.gRectSize.x, rectH = c.shared.gRectSize.y;
 
-    if (!RelaxBlockHasGeometry(P.tiles, blockY))
+    if (!RelaxBlockHasGeometry(P.tiles, BlockTileX(rows), blockY))
         return;
 
     for (int idx = threadIdx.x; idx < hc::BUF_X * hc::BUF_Y; idx += 256) {
         int lx = idx % hc::BUF_X, ly = idx / hc::BUF_X;
-        int gx = ClampI(blockIdx.x * TILE_X - hc::BORDER + lx, 0, rectW - 1), gy = ClampI(blockY * TILE_Y - hc::BORDER + ly, 0, rectH - 1);
+        int gx = ClampI(BlockTileX(rows) * TILE_X - hc::BORDER + lx, 0, rectW - 1), gy = ClampI(blockY * TILE_Y - hc::BORDER + ly, 0, rectH - 1);
         float isValid = Cmp(LoadR32F(P.viewZ, gx, gy) < c.shared.gDenoisingRange); // raw viewZ as in the reference
         int li = ly * hc::BUF_STRIDE + lx;
         if (SPEC) {
@@ -846,7 +846,7 @@ const char* LaunchHistoryClamping(const PassArgs& a) {
         return "RELAX HistoryClamping: unexpected resource count";
     RelaxCB c = LoadRelaxConstants(a);
     RowGrid g = GridForRows(c.shared.gRectSize.x, c.shared.gRectSize.y, TILE_X, TILE_Y, a.rowBegin, a.rowEnd);
-    LaunchPass(a, (RelaxHistoryClampingKernel<DIFF, SPEC, SH>), g.grid, dim3(256), P, c, RowRange{g.firstBlockY, g.rowBegin, g.rowEnd});
+    LaunchPass(a, (RelaxHistoryClampingKernel<DIFF, SPEC, SH>), g.grid, dim3(256), P, c, MakeRowRange(g));
     return nullptr;
 }
 

@@ -6,6 +6,7 @@
 
 #include <hip/hip_runtime.h>
 
+#include <cstdlib>
 #include <cstring>
 #include <vector>
 
@@ -47,6 +48,10 @@ struct PassArgs {
     // executor-internal scratch plane of the RELAX a-trous chain (float4 per pixel: world position, viewZ): written by the first
     // iteration (AtrousSmem) for every pixel, read by the taps of the dilated iterations; ptr == nullptr outside RELAX lists
     Plane worldPosViewZ;
+    // executor-internal guide plane of the REBLUR lists (float4 per pixel: view-space position Xv.x, Xv.y, viewZ = |z * gViewZScale|, material ID), written
+    // together with the decoded normals once per frame; same pitch / size as decodedNormalRoughness, so one texel offset serves both. With it a tap of
+    // the spatial passes is two 16-byte loads and no per-tap position reconstruction. ptr == nullptr outside REBLUR lists.
+    Plane viewPos;
     // non-null: the launcher performs all its checks and hands its launch(es) to the recorder instead of enqueueing them
     LaunchRecorder* recorder = nullptr;
 };
@@ -96,14 +101,27 @@ const PassEntry* GetRelaxPasses(uint32_t& num);
 
 // decodes a whole R10G10B10A2 normal+roughness plane into the float4 cache (kernels_common.hip)
 void LaunchDecodeNormalRoughness(const PassArgs& a, const Plane& packed, const Plane& decoded);
+// same, plus the REBLUR view-position guide plane from IN_VIEWZ and the frame's REBLUR constants (kernels_common.hip)
+void LaunchDecodeGuides(const PassArgs& a, const Plane& packed, const Plane& viewZ, const Plane& decoded, const Plane& viewPos, const void* reblurConstants);
 
 inline dim3 GridFor(int w, int h, int tileW, int tileH) { return dim3((unsigned)((w + tileW - 1) / tileW), (unsigned)((h + tileH - 1) / tileH), 1); }
 
 // Grid covering rows [rowBegin, rowEnd) clipped to [0, h) with tileH-row blocks that stay aligned to the full-frame tiling;
 // firstBlockY is added to blockIdx.y inside the kernel.
+// XCD-aware tile order. The dispatcher places workgroup b on XCD b % 8, each XCD has its own 4 MiB L2, and the tap loops of the spatial passes
+// reach 30-60 px (a-trous: up to 20 px) around a 32x8 tile: with the plain order every XCD touches every 8th tile of a row and fetches the
+// halos of all of them from HBM (counter traffic 2-4x the algorithmic bytes, profiles/r01_*). With gridDim.x a multiple of 8 and
+//     tileX = (blockIdx.x % 8) * bandTiles + blockIdx.x / 8,      bandTiles = ceil(tilesX / 8)
+// XCD k owns the vertical band of tile columns [k * bandTiles, (k + 1) * bandTiles): neighbouring tiles share their halos in ONE L2, all eight
+// XCDs sweep the frame top to bottom together, and a horizontal sky band costs every XCD the same (the r01 experiment with bands of tile ROWS lost
+// 1.46x to that imbalance). Placement is a speed matter only: results do not depend on it. NRD_HIP_XCD_BANDS=0 restores the plain order.
+inline bool XcdBandsEnabled() {
+    static const bool on = !(getenv("NRD_HIP_XCD_BANDS") && atoi(getenv("NRD_HIP_XCD_BANDS")) == 0);
+    return on;
+}
 struct RowGrid {
     dim3 grid;
-    int firstBlockY, rowBegin, rowEnd;
+    int firstBlockY, rowBegin, rowEnd, bandTiles;
 };
 inline RowGrid GridForRows(int w, int h, int tileW, int tileH, int rowBegin, int rowEnd) {
     RowGrid g;
@@ -114,11 +132,20 @@ inline RowGrid GridForRows(int w, int h, int tileW, int tileH, int rowBegin, int
     g.firstBlockY = g.rowBegin / tileH;
     int lastBlockY = (g.rowEnd + tileH - 1) / tileH;
     int ny = lastBlockY - g.firstBlockY;
-    g.grid = dim3((unsigned)((w + tileW - 1) / tileW), (unsigned)(ny > 0 ? ny : 1), 1);
+    const int tilesX = (w + tileW - 1) / tileW;
+    g.bandTiles = (XcdBandsEnabled() && tilesX >= 16) ? (tilesX + 7) / 8 : 0;
+    g.grid = dim3((unsigned)(g.bandTiles ? 8 * g.bandTiles : tilesX), (unsigned)(ny > 0 ? ny : 1), 1);
     return g;
 }
 struct RowRange { // kernel argument
     int firstBlockY, rowBegin, rowEnd;
+    int bandTiles; // 0 = plain tile order
 };
+inline RowRange MakeRowRange(const RowGrid& g) { return RowRange{g.firstBlockY, g.rowBegin, g.rowEnd, g.bandTiles}; }
+// tile column of this workgroup (may lie beyond the frame in the last band: such workgroups find all their pixels outside the rect)
+__device__ __forceinline__ int BlockTileX(const RowRange& r) {
+    const unsigned bx = blockIdx.x;
+    return r.bandTiles ? (int)((bx & 7u) * (unsigned)r.bandTiles + (bx >> 3)) : (int)bx;
+}
 
 } // namespace nrdhip

@@ -185,8 +185,8 @@ NRD_D float ApplyThinLensEquation(float O, float curvature) { return O / (2.0f *
 NRD_D float4 Denanify(float w, float4 x) { return w == 0.0f ? F4(0.0f) : x; }
 
 // true when any of the 16x16 tiles overlapped by this workgroup's 32x8 block has geometry
-NRD_D bool RelaxBlockHasGeometry(const Plane& tiles, int blockY) {
-    const int tileY = (blockY * RELAX_TILE_Y) >> 4, tileX0 = (blockIdx.x * RELAX_TILE_X) >> 4;
+NRD_D bool RelaxBlockHasGeometry(const Plane& tiles, int blockX, int blockY) {
+    const int tileY = (blockY * RELAX_TILE_Y) >> 4, tileX0 = (blockX * RELAX_TILE_X) >> 4;
     bool any = false;
     for (int t = 0; t < RELAX_TILE_X / 16; t++)
         if (tileX0 + t < tiles.w && tileY < tiles.h)

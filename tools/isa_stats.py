@@ -10,7 +10,7 @@ import sys
 
 def demangle(names):
     try:
-        out = subprocess.run(["/opt/rocm/lib/llvm/bin/llvm-cxxfilt"], input="\n".join(names), capture_output=True, text=True).stdout.split("\n")
+        out = subprocess.run(["c++filt"], input="\n".join(names), capture_output=True, text=True).stdout.split("\n")
         return dict(zip(names, out))
     except OSError:
         return {n: n for n in names}
@@ -51,7 +51,7 @@ def main():
         d = names[name]
         if flt not in d and flt not in name:
             continue
-        short = re.sub(r"\(.*", "", d.replace("nrdhip::", "").replace("(anonymous namespace)::", "").replace("void ", ""))
+        short = re.sub(r"\(.*", "", d.replace("(nrdhip::SpatialMode)", "MODE").replace("nrdhip::", "").replace("(anonymous namespace)::", "").replace("void ", ""))
         line = "%-90s valu %5d (pk %4d, trans %3d) salu %4d vmem %3d lds %3d | vgpr %3d occ %d scratch %d lds %dB" % (short[:90], s["valu"], s["pk"], s["trans"], s["salu"], s["vmem"], s["lds"], s["vgpr"], s["occ"], s["scratch"], s["ldsb"])
         if b and name in b:
             t = b[name]
