@@ -384,6 +384,7 @@ class Instance:
         return self.lib.GetInstanceDesc(self.handle).contents
 
     def set_common_settings(self, cs):
+        self.last_common_settings = cs  # kept for hosts that derive per-frame bounds from the camera (sharding.HaloSharder)
         return Result(self.lib.SetCommonSettings(self.handle, C.byref(cs)))
 
     def set_denoiser_settings(self, identifier, settings):

@@ -780,26 +780,6 @@ static uint32_t ExecuteRange(NrdHipExecutor* e, const nrd::DispatchDesc* descs, 
             decoded = cache;
         }
     }
-    // World-position scratch of the RELAX a-trous chain (same geometry as the decoded-guide cache)
-    Plane worldPos = {};
-    if (decoded.ptr) {
-        bool used = false;
-        for (uint32_t i = 0; i < dispatchDescsNum && !used; i++)
-            used = descs[i].pipelineIndex < idesc.pipelinesNum && strstr(idesc.pipelines[descs[i].pipelineIndex].shaderFileName, "_Atrous") != nullptr;
-        if (used) {
-            Plane& cache = e->worldPosViewZ;
-            if (!cache.ptr || cache.w != decoded.w || cache.h != decoded.h) {
-                if (cache.ptr)
-                    (void)hipFree(cache.ptr);
-                cache = decoded;
-                cache.ptr = nullptr;
-                if (hipMalloc((void**)&cache.ptr, (size_t)cache.pitch * (size_t)cache.h) != hipSuccess)
-                    return e->Fail(nrd::Result::FAILURE, "nrdHipExecuteDispatches: cannot allocate the a-trous world-position scratch plane");
-            }
-            worldPos = cache;
-        }
-    }
-
     // View-position guide plane of the REBLUR lists (same geometry again): needs IN_VIEWZ and the frame's REBLUR constants
     Plane viewPos = {};
     const void* reblurConstants = nullptr;
@@ -826,11 +806,41 @@ static uint32_t ExecuteRange(NrdHipExecutor* e, const nrd::DispatchDesc* descs, 
             reblurConstants = nullptr;
         }
     }
+    // World-position guide plane of the RELAX lists (same geometry): IN_VIEWZ and the frame's RELAX constants
+    Plane worldPos = {};
+    const void* relaxConstants = nullptr;
+    if (decoded.ptr && !viewPos.ptr) {
+        for (uint32_t i = 0; i < dispatchDescsNum && !relaxConstants; i++)
+            if (descs[i].pipelineIndex < idesc.pipelinesNum && !strncmp(idesc.pipelines[descs[i].pipelineIndex].shaderFileName, "RELAX_", 6) && descs[i].constantBufferData &&
+                descs[i].constantBufferDataSize >= sizeof(nrdc::RelaxConstants))
+                relaxConstants = descs[i].constantBufferData;
+        if (relaxConstants) {
+            if (!e->userBound[(uint32_t)nrd::ResourceType::IN_VIEWZ])
+                return e->Fail(nrd::Result::INVALID_ARGUMENT, "resource not bound: IN_VIEWZ; nothing was launched");
+            const Plane& z = e->user[(uint32_t)nrd::ResourceType::IN_VIEWZ];
+            if (z.w != decoded.w || z.h != decoded.h)
+                return e->Fail(nrd::Result::INVALID_ARGUMENT, "IN_VIEWZ and IN_NORMAL_ROUGHNESS differ in size; nothing was launched");
+            Plane& cache = e->worldPosViewZ;
+            if (!cache.ptr || cache.w != decoded.w || cache.h != decoded.h) {
+                if (cache.ptr)
+                    (void)hipFree(cache.ptr);
+                cache = decoded;
+                cache.ptr = nullptr;
+                if (hipMalloc((void**)&cache.ptr, (size_t)cache.pitch * (size_t)cache.h) != hipSuccess)
+                    return e->Fail(nrd::Result::FAILURE, "nrdHipExecuteDispatches: cannot allocate the world-position guide plane");
+                e->decodedFresh = false;
+                decodeNow = true;
+            }
+            worldPos = cache;
+        }
+    }
     auto decode = [&](LaunchRecorder* rec) {
         PassArgs args = {};
         args.stream = e->stream;
         args.recorder = rec;
-        if (viewPos.ptr)
+        if (worldPos.ptr)
+            LaunchDecodeGuidesRelax(args, e->user[(uint32_t)nrd::ResourceType::IN_NORMAL_ROUGHNESS], e->user[(uint32_t)nrd::ResourceType::IN_VIEWZ], decoded, worldPos, relaxConstants);
+        else if (viewPos.ptr)
             LaunchDecodeGuides(args, e->user[(uint32_t)nrd::ResourceType::IN_NORMAL_ROUGHNESS], e->user[(uint32_t)nrd::ResourceType::IN_VIEWZ], decoded, viewPos, reblurConstants);
         else
             LaunchDecodeNormalRoughness(args, e->user[(uint32_t)nrd::ResourceType::IN_NORMAL_ROUGHNESS], decoded);

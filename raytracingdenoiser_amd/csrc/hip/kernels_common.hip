@@ -42,6 +42,27 @@ void LaunchDecodeGuides(const PassArgs& a, const Plane& packed, const Plane& vie
         make_float4(c.gFrustum.x, c.gFrustum.y, c.gFrustum.z, c.gFrustum.w), make_float2(c.gRectSizeInv.x, c.gRectSizeInv.y), c.gViewZScale);
 }
 
+// RELAX lists: the same decode plus (world position, viewZ) of every pixel -- GetCurrentWorldPosFromPixelPos( pixel, |z * gViewZScale| ) of RELAX_Common.hlsli:
+// the plane the a-trous taps read (formerly written by the first a-trous pass) and, being available from the start of the frame, the pre-pass taps too.
+__global__ __launch_bounds__(256) void DecodeGuidesRelaxKernel(Plane packed, Plane viewZ, Plane decoded, Plane worldPos, float3 frustumRight, float3 frustumUp, float3 frustumForward,
+    float2 rectSizeInv, float viewZScale) {
+    const int x = blockIdx.x * 256 + threadIdx.x, y = blockIdx.y;
+    if (x >= packed.w)
+        return;
+    StoreRGBA32F(decoded, x, y, EncodeDecodedNormalRoughness(LoadR32U(packed, x, y)));
+    const float z = Abs(LoadR32F(viewZ, x, y) * viewZScale);
+    const float2 clip = F2(float(x) + 0.5f, float(y) + 0.5f) * rectSizeInv * 2.0f - 1.0f;
+    const float3 d = frustumForward + frustumRight * clip.x - frustumUp * clip.y; // relax_device.h WorldPosFromClip, same operation order
+    StoreRGBA32F(worldPos, x, y, F4(z * d.x, z * d.y, z * d.z, z));
+}
+
+void LaunchDecodeGuidesRelax(const PassArgs& a, const Plane& packed, const Plane& viewZ, const Plane& decoded, const Plane& worldPos, const void* relaxConstants) {
+    const nrdc::RelaxConstants& c = *(const nrdc::RelaxConstants*)relaxConstants;
+    LaunchPass(a, DecodeGuidesRelaxKernel, dim3((unsigned)((packed.w + 255) / 256), (unsigned)packed.h, 1), dim3(256), packed, viewZ, decoded, worldPos,
+        make_float3(c.gFrustumRight.x, c.gFrustumRight.y, c.gFrustumRight.z), make_float3(c.gFrustumUp.x, c.gFrustumUp.y, c.gFrustumUp.z),
+        make_float3(c.gFrustumForward.x, c.gFrustumForward.y, c.gFrustumForward.z), make_float2(c.gRectSizeInv.x, c.gRectSizeInv.y), c.gViewZScale);
+}
+
 void LaunchDecodeNormalRoughness(const PassArgs& a, const Plane& packed, const Plane& decoded) {
     LaunchPass(a, DecodeNormalRoughnessKernel, dim3((unsigned)((packed.w + 255) / 256), (unsigned)packed.h, 1), dim3(256), packed, decoded);
 }

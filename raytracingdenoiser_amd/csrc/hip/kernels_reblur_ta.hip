@@ -34,8 +34,11 @@ struct TaPlanes {
 // PERF = REBLUR_PERFORMANCE_MODE: no Catmull-Rom history fetches (REBLUR_USE_CATROM_FOR_*_MOTION_IN_TA = 0, REBLUR_Config.hlsli:196-201)
 // OCC = occlusion family (REBLUR_OCCLUSION): hit-distance-only signals in R16_UNORM, no pre-pass output to read, no DATA2, no firefly suppressor
 // SH = the *_SH denoisers: the SH1 plane of every signal is accumulated with the same speeds (custom-weight bilinear history fetch)
-template <bool DIFF, bool SPEC, bool PERF, int KIND, bool SH>
-__global__ __launch_bounds__(TILE_X* TILE_Y, 2) void ReblurTemporalAccumulationKernel(ReblurCB cArg, TaPlanes P, RowRange rr) {
+// WAVES = waves per SIMD the register allocation aims at (__launch_bounds__): 2 = no spills; 3 keeps 40-80 B of scratch per lane for one more wave
+// of latency hiding behind the dependent gathers (NRD_HIP_TA_WAVES picks the variant at launch for A/B runs; the default follows the measurements in
+// DESIGN.md section 3)
+template <bool DIFF, bool SPEC, bool PERF, int KIND, bool SH, int WAVES>
+__global__ __launch_bounds__(TILE_X* TILE_Y, WAVES) void ReblurTemporalAccumulationKernel(ReblurCB cArg, TaPlanes P, RowRange rr) {
     typedef ReblurSignal<KIND> Sig;
     constexpr bool OCC = KIND == SIGNAL_OCCLUSION;
     typedef typename Sig::type S;
@@ -808,7 +811,11 @@ static const char* LaunchTemporalAccumulation(const PassArgs& a) {
     }
 
     RowGrid g = GridForRows(c.gRectSizeMinusOne.x + 1, c.gRectSizeMinusOne.y + 1, TILE_X, TILE_Y, a.rowBegin, a.rowEnd);
-    LaunchPass(a, (ReblurTemporalAccumulationKernel<DIFF, SPEC, PERF, KIND, SH>), g.grid, dim3(TILE_X * TILE_Y), c, P, MakeRowRange(g));
+    static const int waves = getenv("NRD_HIP_TA_WAVES") ? atoi(getenv("NRD_HIP_TA_WAVES")) : 2;
+    if (waves >= 3 && SPEC)
+        LaunchPass(a, (ReblurTemporalAccumulationKernel<DIFF, SPEC, PERF, KIND, SH, 3>), g.grid, dim3(TILE_X * TILE_Y), c, P, MakeRowRange(g));
+    else
+        LaunchPass(a, (ReblurTemporalAccumulationKernel<DIFF, SPEC, PERF, KIND, SH, 2>), g.grid, dim3(TILE_X * TILE_Y), c, P, MakeRowRange(g));
     return nullptr;
 }
 

@@ -25,7 +25,7 @@ struct AtrousPlanes {
     Plane tiles, historyLength, specReprojectionConfidence, normalRoughness, viewZ;
     Plane outNormalRoughness, outMaterialID, outViewZ; // AtrousSmem only
     Plane decodedNR; // executor's float4 cache of normalRoughness (reblur_device.h "decoded guides")
-    Plane worldPosViewZ; // executor's float4 scratch: (world position, viewZ) per pixel, written by AtrousSmem, read by the Atrous taps
+    Plane worldPosViewZ; // executor's float4 guide plane: (world position, viewZ) per pixel (passes.h), read by the Atrous taps
     SignalPlanes spec, diff;
 };
 
@@ -126,10 +126,7 @@ __global__ __launch_bounds__(256) void RelaxAtrousSmemKernel(AtrousPlanes P, Rel
         centerWorldPosMaterialID = s_WorldPos_MaterialID[lc];
     }
     const float centerViewZ = RelaxUnpackViewZ(c, viewZpacked);
-    // every pixel (sky included) gets its (world position, viewZ) for the taps of the following a-trous iterations: ~25 instructions
-    // here instead of at each of their 8 taps x 4 iterations
-    if (InBounds(P.worldPosViewZ, px, py))
-        StoreRGBA32F(P.worldPosViewZ, px, py, F4(GetCurrentWorldPosFromPixelPos(c, px, py, centerViewZ), centerViewZ));
+    // (world position, viewZ) of every pixel for the taps of the following a-trous iterations is in P.worldPosViewZ already (per-frame guide plane)
     if (centerViewZ > c.shared.gDenoisingRange)
         normalRoughness = F4(1.0f / 255.0f);
     const float centerMaterialID = centerWorldPosMaterialID.w;
@@ -389,6 +386,12 @@ const char* LaunchAtrousSmem(const PassArgs& a) {
 // ================================================================================================ Atrous
 template <bool DIFF, bool SPEC, bool SH>
 __global__ __launch_bounds__(256) void RelaxAtrousKernel(AtrousPlanes P, RelaxCB c, RowRange rows) {
+    // one layout for the two guide planes and one for the (up to four) RGBA16F signal planes: verified by the launcher
+    ShareLayout(P.worldPosViewZ, P.decodedNR);
+    {
+        const Plane sig = SPEC ? P.spec.in : P.diff.in;
+        ShareLayout(P.spec.in, sig), ShareLayout(P.diff.in, sig), ShareLayout(P.spec.inSh, sig), ShareLayout(P.diff.inSh, sig);
+    }
     const int blockY = blockIdx.y + rows.firstBlockY;
     const int px = BlockTileX(rows) * TILE_X + (threadIdx.x & 31), py = blockY * TILE_Y + (threadIdx.x >> 5);
     const int rectW = c.shared.gRectSize.x, rectH = c.shared.gRectSize.y;
@@ -485,6 +488,12 @@ __global__ __launch_bounds__(256) void RelaxAtrousKernel(AtrousPlanes P, RelaxCB
         offy = (int)(float(c.gStepSize) * 0.5f * (rnd.y - 0.5f));
     }
 
+    // The 8 taps, branch-free: a tap outside the rect reads the clamped texel (a valid address) and gets weight 0 through isInside, exactly what the
+    // reference's "Load outside = 0" amounts to (its geometry weight is multiplied by isInside); a tap whose guide weight is <= 1e-4 keeps weight 0
+    // instead of being skipped by a divergent branch, so all loads of a pixel can be in flight together instead of one dependent wait per tap and signal.
+    // (0 * sample adds nothing: the history planes hold finite fp16 values by construction.) Planes of one format share their layout (launcher check),
+    // so one texel offset serves the two guide planes and one the four signal planes.
+    const bool compareSpecMaterials = c.shared.gSpecMinMaterial < 3.0f, compareDiffMaterials = c.shared.gDiffMinMaterial < 3.0f; // IDs are 0..3: a minimum >= 3 disables the test
 #pragma unroll
     for (int yy = -1; yy <= 1; yy++)
 #pragma unroll
@@ -492,14 +501,17 @@ __global__ __launch_bounds__(256) void RelaxAtrousKernel(AtrousPlanes P, RelaxCB
             if (xx == 0 && yy == 0)
                 continue;
             const int qx = px + offx + xx * stepSize, qy = py + offy + yy * stepSize;
-            const bool isInside = qx >= 0 && qy >= 0 && qx < rectW && qy < rectH;
+            const bool isInside = (uint32_t)qx < (uint32_t)rectW && (uint32_t)qy < (uint32_t)rectH && InBounds(P.worldPosViewZ, qx, qy);
             const float kernelW = (xx == 0 ? 0.44198f : 0.27901f) * (yy == 0 ? 0.44198f : 0.27901f);
+            const int cx = ClampI(qx, 0, P.worldPosViewZ.w - 1), cy = ClampI(qy, 0, P.worldPosViewZ.h - 1);
+            const uint32_t guideOffset = __umul24((uint32_t)cy, P.decodedNR.pitch) + (uint32_t)cx * 16u;
+            const float4 g0 = *(const float4*)(P.decodedNR.ptr + guideOffset);
+            const float4 sampleWorldPosViewZ = *(const float4*)(P.worldPosViewZ.ptr + guideOffset);
 
             float sampleMaterialID;
-            const float4 sampleNormalRoughness = LoadDecodedNormalRoughnessOrZero(P.decodedNR, qx, qy, sampleMaterialID);
+            const float4 sampleNormalRoughness = DecodedToNormalRoughness(g0, sampleMaterialID);
             const float3 sampleNormal = Xyz(sampleNormalRoughness);
             const float sampleRoughness = sampleNormalRoughness.w;
-            const float4 sampleWorldPosViewZ = InBounds(P.worldPosViewZ, qx, qy) ? LoadRGBA32F(P.worldPosViewZ, qx, qy) : F4(0.0f); // Load outside = 0
             const float sampleViewZ = sampleWorldPosViewZ.w;
             const float3 sampleWorldPos = Xyz(sampleWorldPosViewZ);
 
@@ -507,6 +519,7 @@ __global__ __launch_bounds__(256) void RelaxAtrousKernel(AtrousPlanes P, RelaxCB
             geometryW *= kernelW;
             geometryW *= Cmp(isInside && sampleViewZ < c.shared.gDenoisingRange);
 
+            const uint32_t signalOffset = __umul24((uint32_t)cy, (SPEC ? P.spec.in : P.diff.in).pitch) + (uint32_t)cx * 8u;
             if (SPEC) {
                 float3 sampleV = -Normalize(sampleWorldPos + c.shared.gRoughnessEdgeStoppingRelaxation * centerWorldPos);
                 float angles = AcosApprox(Dot(centerNormal, sampleNormal));
@@ -515,38 +528,46 @@ __global__ __launch_bounds__(256) void RelaxAtrousKernel(AtrousPlanes P, RelaxCB
                 float roughnessWSpecular = ComputeWeight(sampleRoughness, sp.roughnessWeightParams.x, sp.roughnessWeightParams.y);
 
                 float wSpecular = geometryW * (c.shared.gRoughnessEdgeStoppingEnabled ? (normalWSpecular * roughnessWSpecular) : normalWSpecularSimplified);
-                wSpecular *= Cmp(CompareMaterials(sampleMaterialID, centerMaterialID, c.shared.gSpecMinMaterial));
-                if (wSpecular > 1e-4f) {
-                    float4 sampleSpecular = LoadRGBA16FOrZero(P.spec.in, qx, qy);
-                    float sampleSpecularLuminance = Luminance(Xyz(sampleSpecular));
-                    float specularLuminanceW = Abs(sp.centerLuminance - sampleSpecularLuminance) * sp.phiLIlluminationInv;
-                    specularLuminanceW = Min(c.shared.gSpecMaxLuminanceRelativeDifference, specularLuminanceW);
-                    specularLuminanceW *= sp.luminanceWeightRelaxation;
-                    wSpecular *= Exp(-specularLuminanceW);
+                if (compareSpecMaterials)
+                    wSpecular *= Cmp(CompareMaterials(sampleMaterialID, centerMaterialID, c.shared.gSpecMinMaterial));
+                const bool on = wSpecular > 1e-4f;
+                const uint2 raw = *(const uint2*)(P.spec.in.ptr + signalOffset);
+                float4 sampleSpecular = DecodeRGBA16F(raw.x, raw.y);
+                float sampleSpecularLuminance = Luminance(Xyz(sampleSpecular));
+                float specularLuminanceW = Abs(sp.centerLuminance - sampleSpecularLuminance) * sp.phiLIlluminationInv;
+                specularLuminanceW = Min(c.shared.gSpecMaxLuminanceRelativeDifference, specularLuminanceW);
+                specularLuminanceW *= sp.luminanceWeightRelaxation;
+                wSpecular *= Exp(-specularLuminanceW);
+                wSpecular = on ? wSpecular : 0.0f;
 
-                    sumWSpecular += wSpecular;
-                    sumSpecular = sumSpecular + F4(wSpecular, wSpecular, wSpecular, wSpecular * wSpecular) * sampleSpecular;
-                    if (SH)
-                        sumSpecularSH = sumSpecularSH + LoadRGBA16FOrZero(P.spec.inSh, qx, qy) * wSpecular;
+                sumWSpecular += wSpecular;
+                sumSpecular = sumSpecular + F4(wSpecular, wSpecular, wSpecular, wSpecular * wSpecular) * sampleSpecular;
+                if (SH) {
+                    const uint2 rawSh = *(const uint2*)(P.spec.inSh.ptr + signalOffset);
+                    sumSpecularSH = sumSpecularSH + DecodeRGBA16F(rawSh.x, rawSh.y) * wSpecular;
                 }
             }
             if (DIFF) {
                 float angled = AcosApprox(Dot(centerNormal, sampleNormal));
                 float normalWDiffuse = ComputeWeight(angled, dp.normalWeightParam, 0.0f);
                 float wDiffuse = geometryW * normalWDiffuse;
-                wDiffuse *= Cmp(CompareMaterials(sampleMaterialID, centerMaterialID, c.shared.gDiffMinMaterial));
-                if (wDiffuse > 1e-4f) {
-                    float4 sampleDiffuse = LoadRGBA16FOrZero(P.diff.in, qx, qy);
-                    float sampleDiffuseLuminance = Luminance(Xyz(sampleDiffuse));
-                    float diffuseLuminanceW = Abs(dp.centerLuminance - sampleDiffuseLuminance) * dp.phiLIlluminationInv;
-                    diffuseLuminanceW = Min(c.shared.gDiffMaxLuminanceRelativeDifference, diffuseLuminanceW);
-                    diffuseLuminanceW *= dp.luminanceWeightRelaxation;
-                    wDiffuse *= Exp(-diffuseLuminanceW);
+                if (compareDiffMaterials)
+                    wDiffuse *= Cmp(CompareMaterials(sampleMaterialID, centerMaterialID, c.shared.gDiffMinMaterial));
+                const bool on = wDiffuse > 1e-4f;
+                const uint2 raw = *(const uint2*)(P.diff.in.ptr + signalOffset);
+                float4 sampleDiffuse = DecodeRGBA16F(raw.x, raw.y);
+                float sampleDiffuseLuminance = Luminance(Xyz(sampleDiffuse));
+                float diffuseLuminanceW = Abs(dp.centerLuminance - sampleDiffuseLuminance) * dp.phiLIlluminationInv;
+                diffuseLuminanceW = Min(c.shared.gDiffMaxLuminanceRelativeDifference, diffuseLuminanceW);
+                diffuseLuminanceW *= dp.luminanceWeightRelaxation;
+                wDiffuse *= Exp(-diffuseLuminanceW);
+                wDiffuse = on ? wDiffuse : 0.0f;
 
-                    sumWDiffuse += wDiffuse;
-                    sumDiffuse = sumDiffuse + F4(wDiffuse, wDiffuse, wDiffuse, wDiffuse * wDiffuse) * sampleDiffuse;
-                    if (SH)
-                        sumDiffuseSH = sumDiffuseSH + LoadRGBA16FOrZero(P.diff.inSh, qx, qy) * wDiffuse;
+                sumWDiffuse += wDiffuse;
+                sumDiffuse = sumDiffuse + F4(wDiffuse, wDiffuse, wDiffuse, wDiffuse * wDiffuse) * sampleDiffuse;
+                if (SH) {
+                    const uint2 rawSh = *(const uint2*)(P.diff.inSh.ptr + signalOffset);
+                    sumDiffuseSH = sumDiffuseSH + DecodeRGBA16F(rawSh.x, rawSh.y) * wDiffuse;
                 }
             }
         }
@@ -580,6 +601,12 @@ const char* LaunchAtrous(const PassArgs& a) {
     AtrousPlanes P = {};
     if (!BindAtrous<DIFF, SPEC, SH, false>(a, P))
         return "RELAX Atrous: unexpected resource count";
+    {
+        const Plane sig = SPEC ? P.spec.in : P.diff.in;
+        if (!SameLayout(P.worldPosViewZ, P.decodedNR) || !SameLayout(P.spec.in, sig) || !SameLayout(P.diff.in, sig) || !SameLayout(P.spec.inSh, sig) || !SameLayout(P.diff.inSh, sig) ||
+            sig.w != P.decodedNR.w || sig.h != P.decodedNR.h)
+            return "RELAX Atrous: the signal planes must share one layout and the frame size";
+    }
     RelaxCB c = LoadRelaxConstants(a);
     RowGrid g = GridForRows(c.shared.gRectSize.x, c.shared.gRectSize.y, TILE_X, TILE_Y, a.rowBegin, a.rowEnd);
     LaunchPass(a, (RelaxAtrousKernel<DIFF, SPEC, SH>), g.grid, dim3(256), P, c, MakeRowRange(g));

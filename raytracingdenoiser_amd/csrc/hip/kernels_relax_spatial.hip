@@ -170,6 +170,7 @@ const char* LaunchHitDistReconstruction(const PassArgs& a) {
 struct PrePassPlanes {
     Plane tiles, normalRoughness, viewZ;
     Plane decodedNR; // executor's float4 cache of normalRoughness (reblur_device.h "decoded guides")
+    Plane worldPos;  // executor's float4 guide plane (world position, viewZ; passes.h), same layout as decodedNR
     SignalPlanes spec, diff;
 };
 
@@ -197,8 +198,48 @@ NRD_D PrePassTap MakeTap(const RelaxCB& c, const Plane& guide, const Plane& sign
     return t;
 }
 
-template <bool DIFF, bool SPEC, bool SH, bool CB>
+// Guides of one pre-pass tap. FR ("full rect": rect == resource, no checkerboard; picked by the launcher) reads them from the per-frame guide planes at
+// ONE texel offset -- the snapped tap position IS the texel, and the world position stored there is exactly GetCurrentWorldPosFromClipSpaceXY of that pixel
+// centre -- instead of re-deriving uv, texel index and world position per tap (see kernels_reblur_spatial.hip FetchTapGuides: same values bit for bit).
+struct PrePassGuides {
+    float inScreen;
+    float3 normal, worldPos;
+    float roughness, materialID, viewZ;
+    int2 signalTexel;
+};
+template <bool CB, bool FR>
+NRD_D PrePassGuides FetchPrePassGuides(const RelaxCB& c, const PrePassPlanes& P, const Plane& signal, uint32_t checkerboardMode, float2 pixelUv, float2 rectSize, float4 rotator, int i, float blurRadius) {
+    PrePassGuides g;
+    if (FR) {
+        float2 uv = pixelUv * rectSize + RotateVector(rotator, F2(g_Poisson8[i][0], g_Poisson8[i][1])) * blurRadius;
+        uv = Floor(uv);
+        const float cxf = __builtin_amdgcn_fmed3f(uv.x, 0.0f, rectSize.x - 1.0f), cyf = __builtin_amdgcn_fmed3f(uv.y, 0.0f, rectSize.y - 1.0f);
+        g.inScreen = (cxf == uv.x && cyf == uv.y) ? 1.0f : 0.0f;
+        g.signalTexel = make_int2((int)cxf, (int)cyf);
+        const uint32_t offset = __umul24((uint32_t)g.signalTexel.y, P.decodedNR.pitch) + (uint32_t)g.signalTexel.x * 16u;
+        const float4 g0 = *(const float4*)(P.decodedNR.ptr + offset), g1 = *(const float4*)(P.worldPos.ptr + offset);
+        const float4 nr = DecodedToNormalRoughness(g0, g.materialID);
+        g.normal = Xyz(nr);
+        g.roughness = nr.w;
+        g.worldPos = Xyz(g1);
+        g.viewZ = g1.w;
+        return g;
+    }
+    PrePassTap t = MakeTap<CB>(c, P.viewZ, signal, checkerboardMode, pixelUv, rectSize, rotator, i, blurRadius);
+    const float4 nr = LoadDecodedNormalRoughness(P.decodedNR, t.texel.x, t.texel.y, g.materialID);
+    g.normal = Xyz(nr);
+    g.roughness = nr.w;
+    g.viewZ = RelaxUnpackViewZ(c, LoadR32F(P.viewZ, t.texel.x, t.texel.y));
+    g.worldPos = GetCurrentWorldPosFromClipSpaceXY(c, t.uv * 2.0f - 1.0f, g.viewZ);
+    g.inScreen = IsInScreenNearest(t.uv);
+    g.signalTexel = t.signalTexel;
+    return g;
+}
+
+template <bool DIFF, bool SPEC, bool SH, bool CB, bool FR>
 __global__ __launch_bounds__(256) void RelaxPrePassKernel(PrePassPlanes P, RelaxCB c, RowRange rows) {
+    if (FR)
+        ShareLayout(P.worldPos, P.decodedNR);
     const int blockY = blockIdx.y + rows.firstBlockY;
     const int px = BlockTileX(rows) * TILE_X + (threadIdx.x & 31), py = blockY * TILE_Y + (threadIdx.x >> 5);
     const int rectW = c.shared.gRectSize.x, rectH = c.shared.gRectSize.y;
@@ -272,16 +313,14 @@ __global__ __launch_bounds__(256) void RelaxPrePassKernel(PrePassPlanes P, Relax
 
 #pragma unroll 2
             for (int i = 0; i < 8; i++) {
-                PrePassTap t = MakeTap<CB>(c, P.viewZ, P.diff.in, c.shared.gDiffCheckerboard, pixelUv, rectSize, rotator, i, blurRadius);
+                const PrePassGuides t = FetchPrePassGuides<CB, FR>(c, P, P.diff.in, c.shared.gDiffCheckerboard, pixelUv, rectSize, rotator, i, blurRadius);
+                const float sampleMaterialID = t.materialID, sampleViewZ = t.viewZ;
+                const float3 sampleNormal = t.normal, sampleWorldPos = t.worldPos;
 
-                float sampleMaterialID;
-                float3 sampleNormal = Xyz(LoadDecodedNormalRoughness(P.decodedNR, t.texel.x, t.texel.y, sampleMaterialID));
-                float sampleViewZ = RelaxUnpackViewZ(c, LoadR32F(P.viewZ, t.texel.x, t.texel.y));
-                float3 sampleWorldPos = GetCurrentWorldPosFromClipSpaceXY(c, t.uv * 2.0f - 1.0f, sampleViewZ);
-
-                float sampleWeight = IsInScreenNearest(t.uv);
+                float sampleWeight = t.inScreen;
                 sampleWeight *= Cmp(sampleViewZ < c.shared.gDenoisingRange);
-                sampleWeight *= Cmp(CompareMaterials(centerMaterialID, sampleMaterialID, c.shared.gDiffMinMaterial));
+                if (c.shared.gDiffMinMaterial < 3.0f) // material IDs are 0..3: a minimum >= 3 makes every comparison hold
+                    sampleWeight *= Cmp(CompareMaterials(centerMaterialID, sampleMaterialID, c.shared.gDiffMinMaterial));
                 sampleWeight *= GetPlaneDistanceWeight(centerWorldPos, centerNormal, centerViewZ, sampleWorldPos, c.shared.gDepthThreshold);
                 float angle = AcosApprox(Dot(centerNormal, sampleNormal));
                 sampleWeight *= ComputeWeight(angle, normalWeightParam, 0.0f);
@@ -356,22 +395,19 @@ __global__ __launch_bounds__(256) void RelaxPrePassKernel(PrePassPlanes P, Relax
 
 #pragma unroll 2
             for (int i = 0; i < 8; i++) {
-                PrePassTap t = MakeTap<CB>(c, P.viewZ, P.spec.in, c.shared.gSpecCheckerboard, pixelUv, rectSize, rotator, i, blurRadius);
+                const PrePassGuides t = FetchPrePassGuides<CB, FR>(c, P, P.spec.in, c.shared.gSpecCheckerboard, pixelUv, rectSize, rotator, i, blurRadius);
+                const float sampleMaterialID = t.materialID, sampleViewZ = t.viewZ, sampleRoughness = t.roughness;
+                const float3 sampleNormal = t.normal;
 
-                float sampleMaterialID;
-                float4 sampleNormalRoughness = LoadDecodedNormalRoughness(P.decodedNR, t.texel.x, t.texel.y, sampleMaterialID);
-                float3 sampleNormal = Xyz(sampleNormalRoughness);
-                float sampleRoughness = sampleNormalRoughness.w;
-                float sampleViewZ = RelaxUnpackViewZ(c, LoadR32F(P.viewZ, t.texel.x, t.texel.y));
-
-                float sampleWeight = IsInScreenNearest(t.uv);
+                float sampleWeight = t.inScreen;
                 sampleWeight *= Cmp(sampleViewZ < c.shared.gDenoisingRange);
-                sampleWeight *= Cmp(CompareMaterials(centerMaterialID, sampleMaterialID, c.shared.gSpecMinMaterial));
+                if (c.shared.gSpecMinMaterial < 3.0f)
+                    sampleWeight *= Cmp(CompareMaterials(centerMaterialID, sampleMaterialID, c.shared.gSpecMinMaterial));
                 sampleWeight *= ComputeWeight(sampleRoughness, roughnessWeightParams.x, roughnessWeightParams.y);
                 float angle = AcosApprox(Dot(centerNormal, sampleNormal));
                 sampleWeight *= ComputeWeight(angle, normalWeightParam, 0.0f);
 
-                float3 sampleWorldPos = GetCurrentWorldPosFromClipSpaceXY(c, t.uv * 2.0f - 1.0f, sampleViewZ);
+                const float3 sampleWorldPos = t.worldPos;
                 sampleWeight *= GetPlaneDistanceWeight(centerWorldPos, centerNormal, centerViewZ, sampleWorldPos, c.shared.gDepthThreshold);
 
                 float4 sampleSpecularIllumination = Denanify(sampleWeight, LoadRGBA16F(P.spec.in, t.signalTexel.x, t.signalTexel.y));
@@ -421,14 +457,20 @@ const char* LaunchPrePass(const PassArgs& a) {
     if (SH && SPEC) P.spec.outSh = cur.next();
     if (SH && DIFF) P.diff.outSh = cur.next();
     P.decodedNR = a.decodedNormalRoughness;
+    P.worldPos = a.worldPosViewZ;
     if (!cur.complete() || !P.decodedNR.ptr)
         return "RELAX PrePass: unexpected resource count or missing decoded normal/roughness cache";
     RelaxCB c = LoadRelaxConstants(a);
     RowGrid g = GridForRows(c.shared.gRectSize.x, c.shared.gRectSize.y, TILE_X, TILE_Y, a.rowBegin, a.rowEnd);
+    const char* forceGeneric = getenv("NRD_HIP_GENERIC_TAPS");
+    const bool fullRect = P.worldPos.ptr && SameLayout(P.worldPos, P.decodedNR) && c.shared.gResolutionScale.x == 1.0f && c.shared.gResolutionScale.y == 1.0f && c.shared.gRectSize.x == P.decodedNR.w &&
+                          c.shared.gRectSize.y == P.decodedNR.h && P.viewZ.w == P.decodedNR.w && P.viewZ.h == P.decodedNR.h && !(forceGeneric && atoi(forceGeneric) != 0);
     if ((SPEC && c.shared.gSpecCheckerboard != 2u) || (DIFF && c.shared.gDiffCheckerboard != 2u))
-        LaunchPass(a, (RelaxPrePassKernel<DIFF, SPEC, SH, true>), g.grid, dim3(256), P, c, MakeRowRange(g));
+        LaunchPass(a, (RelaxPrePassKernel<DIFF, SPEC, SH, true, false>), g.grid, dim3(256), P, c, MakeRowRange(g));
+    else if (fullRect)
+        LaunchPass(a, (RelaxPrePassKernel<DIFF, SPEC, SH, false, true>), g.grid, dim3(256), P, c, MakeRowRange(g));
     else
-        LaunchPass(a, (RelaxPrePassKernel<DIFF, SPEC, SH, false>), g.grid, dim3(256), P, c, MakeRowRange(g));
+        LaunchPass(a, (RelaxPrePassKernel<DIFF, SPEC, SH, false, false>), g.grid, dim3(256), P, c, MakeRowRange(g));
     return nullptr;
 }
 

@@ -45,8 +45,8 @@ struct PassArgs {
     // executor-internal cache of IN_NORMAL_ROUGHNESS decoded once per frame (float4 per texel: N.xyz, packed roughness | material
     // bits -- reblur_device.h "decoded guides"); ptr == nullptr when the dispatch list does not bind IN_NORMAL_ROUGHNESS
     Plane decodedNormalRoughness;
-    // executor-internal scratch plane of the RELAX a-trous chain (float4 per pixel: world position, viewZ): written by the first
-    // iteration (AtrousSmem) for every pixel, read by the taps of the dilated iterations; ptr == nullptr outside RELAX lists
+    // executor-internal guide plane of the RELAX lists (float4 per pixel: world position, viewZ), written together with the decoded normals once
+    // per frame; read by the taps of the pre-pass and of the a-trous iterations; same layout as decodedNormalRoughness; ptr == nullptr outside RELAX lists
     Plane worldPosViewZ;
     // executor-internal guide plane of the REBLUR lists (float4 per pixel: view-space position Xv.x, Xv.y, viewZ = |z * gViewZScale|, material ID), written
     // together with the decoded normals once per frame; same pitch / size as decodedNormalRoughness, so one texel offset serves both. With it a tap of
@@ -103,6 +103,8 @@ const PassEntry* GetRelaxPasses(uint32_t& num);
 void LaunchDecodeNormalRoughness(const PassArgs& a, const Plane& packed, const Plane& decoded);
 // same, plus the REBLUR view-position guide plane from IN_VIEWZ and the frame's REBLUR constants (kernels_common.hip)
 void LaunchDecodeGuides(const PassArgs& a, const Plane& packed, const Plane& viewZ, const Plane& decoded, const Plane& viewPos, const void* reblurConstants);
+// same for RELAX lists: the (world position, viewZ) plane from IN_VIEWZ and the frame's RELAX constants
+void LaunchDecodeGuidesRelax(const PassArgs& a, const Plane& packed, const Plane& viewZ, const Plane& decoded, const Plane& worldPos, const void* relaxConstants);
 
 inline dim3 GridFor(int w, int h, int tileW, int tileH) { return dim3((unsigned)((w + tileW - 1) / tileW), (unsigned)((h + tileH - 1) / tileH), 1); }
 
@@ -115,13 +117,16 @@ inline dim3 GridFor(int w, int h, int tileW, int tileH) { return dim3((unsigned)
 // XCD k owns the vertical band of tile columns [k * bandTiles, (k + 1) * bandTiles): neighbouring tiles share their halos in ONE L2, all eight
 // XCDs sweep the frame top to bottom together, and a horizontal sky band costs every XCD the same (the r01 experiment with bands of tile ROWS lost
 // 1.46x to that imbalance). Placement is a speed matter only: results do not depend on it. NRD_HIP_XCD_BANDS=0 restores the plain order.
-inline bool XcdBandsEnabled() {
-    static const bool on = !(getenv("NRD_HIP_XCD_BANDS") && atoi(getenv("NRD_HIP_XCD_BANDS")) == 0);
-    return on;
+// NRD_HIP_XCD_BANDS: 0 = plain order; 1 (default) = one band per XCD; n > 1 = stripes of n tile columns dealt round-robin to the XCDs (several stripes per
+// XCD: better balance when the cost varies across the frame, wider halos per stripe)
+inline int XcdBandsSetting() {
+    static const int v = getenv("NRD_HIP_XCD_BANDS") ? atoi(getenv("NRD_HIP_XCD_BANDS")) : 1;
+    return v;
 }
+inline bool XcdBandsEnabled() { return XcdBandsSetting() != 0; }
 struct RowGrid {
     dim3 grid;
-    int firstBlockY, rowBegin, rowEnd, bandTiles;
+    int firstBlockY, rowBegin, rowEnd, bandTiles, stripeTiles;
 };
 inline RowGrid GridForRows(int w, int h, int tileW, int tileH, int rowBegin, int rowEnd) {
     RowGrid g;
@@ -134,18 +139,30 @@ inline RowGrid GridForRows(int w, int h, int tileW, int tileH, int rowBegin, int
     int ny = lastBlockY - g.firstBlockY;
     const int tilesX = (w + tileW - 1) / tileW;
     g.bandTiles = (XcdBandsEnabled() && tilesX >= 16) ? (tilesX + 7) / 8 : 0;
+    g.stripeTiles = g.bandTiles;
+    if (g.bandTiles && XcdBandsSetting() > 1) { // stripes: the XCD's tile columns are dealt out in groups of stripeTiles
+        g.stripeTiles = XcdBandsSetting() < g.bandTiles ? XcdBandsSetting() : g.bandTiles;
+        g.bandTiles = ((g.bandTiles + g.stripeTiles - 1) / g.stripeTiles) * g.stripeTiles;
+    }
     g.grid = dim3((unsigned)(g.bandTiles ? 8 * g.bandTiles : tilesX), (unsigned)(ny > 0 ? ny : 1), 1);
     return g;
 }
 struct RowRange { // kernel argument
     int firstBlockY, rowBegin, rowEnd;
-    int bandTiles; // 0 = plain tile order
+    int bandTiles;   // tile columns per XCD; 0 = plain tile order
+    int stripeTiles; // width of a stripe (== bandTiles: one band per XCD)
 };
-inline RowRange MakeRowRange(const RowGrid& g) { return RowRange{g.firstBlockY, g.rowBegin, g.rowEnd, g.bandTiles}; }
-// tile column of this workgroup (may lie beyond the frame in the last band: such workgroups find all their pixels outside the rect)
+inline RowRange MakeRowRange(const RowGrid& g) { return RowRange{g.firstBlockY, g.rowBegin, g.rowEnd, g.bandTiles, g.stripeTiles}; }
+// tile column of this workgroup (may lie beyond the frame: such workgroups find all their pixels outside the rect)
 __device__ __forceinline__ int BlockTileX(const RowRange& r) {
     const unsigned bx = blockIdx.x;
-    return r.bandTiles ? (int)((bx & 7u) * (unsigned)r.bandTiles + (bx >> 3)) : (int)bx;
+    if (!r.bandTiles)
+        return (int)bx;
+    const unsigned xcd = bx & 7u, j = bx >> 3; // the j-th tile column of this XCD
+    if (r.stripeTiles == r.bandTiles)
+        return (int)(xcd * (unsigned)r.bandTiles + j);
+    const unsigned stripe = j / (unsigned)r.stripeTiles, within = j - stripe * (unsigned)r.stripeTiles;
+    return (int)((stripe * 8u + xcd) * (unsigned)r.stripeTiles + within);
 }
 
 } // namespace nrdhip

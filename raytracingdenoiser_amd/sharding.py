@@ -88,7 +88,7 @@ class FrameSharder:
 # motion the application promises (max_motion_rows). Everything is planned from the DispatchDesc list itself (which planes a pass
 # reads / writes, nrdHipGetDispatchReach for its reach), so any denoiser the executor can bound is covered; a frame with a pass of
 # unknown reach (the clears of a restart frame, hit-distance reconstruction) simply runs unsharded on every rank, which leaves all
-# planes complete everywhere. Results stay bit-identical to one GPU as long as motion <= max_motion_rows.
+# planes complete everywhere. Results stay bit-identical to one GPU as long as motion < max_motion_rows - 2 (HaloSharder checks the camera part every frame).
 class HaloPlan:
     def __init__(self):
         self.fallback = False      # run the whole frame on every rank, no exchange
@@ -283,8 +283,48 @@ def balanced_bounds(tile_row_cost, height, world, min_rows, tile=16):
     return [min(c * tile, height) for c in cuts[:-1]] + [height]
 
 
+def camera_motion_rows(cs, depth_range=(1.0, 1.0e4), grid=5):
+    """Upper estimate of the vertical reprojection distance (in rows) of STATIC surface points between the previous and the current camera of a
+    CommonSettings: a grid of screen positions x the two ends of a view-depth range is un-projected with the current matrices and re-projected with the
+    previous ones (rotation moves all depths alike, translation moves the nearest depth most: depth_range[0] must not exceed the view depth of the
+    nearest geometry, an application-level fact -- HaloSharder(near_depth=...)). Returns None for an orthographic projection.
+    Object motion (screen-space motion vectors) is not covered: the application passes its own bound to HaloSharder.denoise(motion_rows=...)."""
+    import numpy as np
+
+    def mat(m):
+        return np.array(list(m), dtype=np.float64).reshape(4, 4).T  # column-major in, M @ v out
+
+    P, Pp, V, Vp = mat(cs.viewToClipMatrix), mat(cs.viewToClipMatrixPrev), mat(cs.worldToViewMatrix), mat(cs.worldToViewMatrixPrev)
+    if abs(P[3, 2]) < 1e-12 or abs(P[0, 0]) < 1e-12 or abs(P[1, 1]) < 1e-12:
+        return None
+    sign = 1.0 if P[3, 2] > 0 else -1.0  # clip.w = +z (left-handed) or -z (right-handed)
+    h = float(cs.rectSize[1])
+    Vinv = np.linalg.inv(V)
+    worst = 0.0
+    for z in depth_range:
+        zv = sign * z
+        for j in range(grid):
+            for i in range(grid):
+                nx, ny = -1.0 + 2.0 * i / (grid - 1), -1.0 + 2.0 * j / (grid - 1)
+                w = P[3, 2] * zv + P[3, 3]
+                xv = (nx * w - P[0, 2] * zv - P[0, 3]) / P[0, 0]
+                yv = (ny * w - P[1, 2] * zv - P[1, 3]) / P[1, 1]
+                world = Vinv @ np.array([xv, yv, zv, 1.0])
+                clip = Pp @ (Vp @ world)
+                if clip[3] <= 1e-9:
+                    return float("inf")  # behind the previous camera: no bound
+                worst = max(worst, abs(clip[1] / clip[3] - ny) * 0.5 * h)
+    return worst
+
+
 class HaloSharder:
     """Row-strip sharding with halo exchange between pass segments (see above). `denoise()` replaces executor.denoise().
+
+    Motion contract: the history halos cover reprojection over fewer than max_motion_rows rows (the Catmull-Rom footprint needs motion + 2 rows, so
+    motion == max_motion_rows is already too much). Every frame the vertical camera motion of static geometry is estimated from the matrices of the
+    last CommonSettings (camera_motion_rows), doubled for the virtual motion of specular reflections, plus whatever bound the application passes for
+    moving objects (denoise(motion_rows=...)); a frame that exceeds the halo runs UNSHARDED on every rank (after completing the planes) instead of
+    silently reading stale rows. All ranks take the same decision from the same settings.
 
     balance: after a frame that ran unsharded (the restart frame, a dynamic-resolution step, ...) every rank holds every plane completely, so
     the strips can be re-cut for free: they are then chosen from the tile map so that every rank gets the same number of non-sky tiles
@@ -292,7 +332,8 @@ class HaloSharder:
 
     SKY_TILE_COST = 0.03  # relative to a tile with geometry (early-out blocks still pay their launch and the tile test)
 
-    def __init__(self, executor, instance, width, height, rank, world, group=None, max_motion_rows=32, exchange_threshold=24, balance=True, recut_every=0):
+    def __init__(self, executor, instance, width, height, rank, world, group=None, max_motion_rows=32, exchange_threshold=24, balance=True, recut_every=0, near_depth=1.0):
+        self.near_depth = near_depth  # view depth of the nearest geometry the camera-motion estimate has to cover (scene units)
         self.ex, self.inst = executor, instance
         self.width, self.height, self.rank, self.world, self.group = width, height, rank, world, group
         self.max_motion_rows, self.exchange_threshold, self.balance = max_motion_rows, exchange_threshold, balance
@@ -304,6 +345,7 @@ class HaloSharder:
         self.complete = True      # every plane is complete on this rank: fresh (zeroed) arena, or the last frame ran unsharded
         self.exchanged_bytes = 0  # received bytes, for reporting
         self.rebalanced = 0
+        self.motion_fallbacks = 0  # frames run unsharded because the motion estimate exceeded the history halo
         self._plans = {}
 
     @property
@@ -346,7 +388,18 @@ class HaloSharder:
                 return [float((row == 0).sum()) + self.SKY_TILE_COST * len(row) for row in tiles]
         return None
 
-    def begin_frame(self):
+    SPECULAR_MOTION_FACTOR = 2.0  # virtual (reflection) motion relative to the surface motion that the camera estimate bounds
+
+    def motion_exceeds_halo(self, motion_rows=None):
+        """True when this frame's reprojection may leave the history halo (see the class docstring)"""
+        cs = getattr(self.inst, "last_common_settings", None)
+        camera = camera_motion_rows(cs, (getattr(self, "near_depth", 1.0), 1.0e4)) if cs is not None else 0.0
+        if camera is None:
+            camera = 0.0  # orthographic: rejected by the launchers anyway
+        need = self.SPECULAR_MOTION_FACTOR * camera + (float(motion_rows) if motion_rows is not None else 0.0) + 2.0
+        return need >= self.max_motion_rows
+
+    def begin_frame(self, motion_rows=None):
         """GetComputeDispatches + plan; returns (plan, dispatch pointer, count). A plan that falls back while this rank's planes are incomplete
         carries plan.complete_keys: the carried-over planes every rank has to receive in full before the frame runs."""
         from . import api
@@ -363,6 +416,9 @@ class HaloSharder:
                            for i in range(n)))
         cached = self._plans.get(signature)
         recut = self.balance and self.recut_every > 0 and self._sharded_since_cut >= self.recut_every and self.world > 1
+        if self.world > 1 and self.motion_exceeds_halo(motion_rows):
+            recut = True  # same mechanics as a deliberate re-cut frame: complete the planes, run the whole frame everywhere
+            self.motion_fallbacks += 1
         if cached is not None and not cached.fallback and not self.complete and not recut:
             return cached, ptr, n
         dispatches = [api.Dispatch(ptr[i], self.inst.pipelines) for i in range(n)]
@@ -466,8 +522,9 @@ class HaloSharder:
                 if src != self.rank:
                     self.exchanged_bytes += band.numel()
 
-    def denoise(self):
-        plan, ptr, n = self.begin_frame()
+    def denoise(self, motion_rows=None):
+        """motion_rows: the application's bound on the vertical motion of moving objects this frame (rows); camera motion is estimated here"""
+        plan, ptr, n = self.begin_frame(motion_rows)
         if plan.fallback:
             self.complete_planes(plan.complete_keys)
             self.ex.execute_range(ptr, n, 0, n)

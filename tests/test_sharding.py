@@ -481,3 +481,44 @@ def test_bench_two_ranks_rehearsal():
     r = json.loads(lines[0])
     assert r["n_gpus"] == 2 and r["steps"] == 6 and r["warmup"] == 3 and r["value"] > 0 and r["scaling"] == "strong"
     assert "halo exchange" in r["config"]["parallelism"] and r["roofline"]["kernel"].startswith("REBLUR_")
+
+
+def test_camera_motion_estimate_and_fallback_decision():
+    """nothing checked that a frame's reprojection stays inside the history halo. camera_motion_rows bounds the vertical motion of static
+    geometry from the CommonSettings matrices; HaloSharder.motion_exceeds_halo turns it into the per-frame decision (no GPU needed)."""
+    import math
+
+    import parity
+    from raytracingdenoiser_amd import sharding, synth
+
+    w, h = 2560, 1440
+    a, b = synth.Camera(w, h, 10), synth.Camera(w, h, 11)
+    cs = parity.common_settings(b, a, w, h, 11)
+    slow = sharding.camera_motion_rows(cs)
+    assert 0.0 <= slow < 12.0, slow  # the bench sequence: 0.1 degree of yaw and a centimetre of dolly per frame, nearest geometry at >= 1 unit
+
+    # a camera pitching by 1.5 degrees per frame: ~37 rows at 1440p and 60 degrees of vertical field of view (the advisor's example)
+    def pitched(cam, deg):
+        c = synth.Camera(w, h, 10)
+        p = math.radians(deg)
+        m = [c.world_to_view[i] for i in range(16)]
+        R = [[1, 0, 0], [0, math.cos(p), -math.sin(p)], [0, math.sin(p), math.cos(p)]]
+        cols = [[m[4 * k + r] for r in range(4)] for k in range(4)]
+        out = [[sum(R[r][t] * cols[k][t] for t in range(3)) for r in range(3)] + [cols[k][3]] for k in range(4)]
+        c.world_to_view = [v for col in out for v in col]
+        return c
+
+    fast = sharding.camera_motion_rows(parity.common_settings(pitched(a, 1.5), a, w, h, 11))
+    assert 30.0 < fast < 45.0, fast
+
+    class FakeInstance:
+        pass
+
+    inst = FakeInstance()
+    sh = sharding.HaloSharder.__new__(sharding.HaloSharder)
+    sh.inst, sh.max_motion_rows = inst, 32
+    inst.last_common_settings = cs
+    assert not sh.motion_exceeds_halo()
+    assert sh.motion_exceeds_halo(motion_rows=29.0)  # the application's own bound for moving objects counts on top
+    inst.last_common_settings = parity.common_settings(pitched(a, 1.5), a, w, h, 11)
+    assert sh.motion_exceeds_halo()
