@@ -783,7 +783,7 @@ static uint32_t ExecuteRange(NrdHipExecutor* e, const nrd::DispatchDesc* descs, 
     // View-position guide plane of the REBLUR lists (same geometry again): needs IN_VIEWZ and the frame's REBLUR constants
     Plane viewPos = {};
     const void* reblurConstants = nullptr;
-    if (decoded.ptr && e->userBound[(uint32_t)nrd::ResourceType::IN_VIEWZ]) {
+    if (decoded.ptr && e->userBound[(uint32_t)nrd::ResourceType::IN_VIEWZ] && getenv("NRD_HIP_VIEWPOS_PLANE")) { // experiment switch: no pass reads the plane by default
         for (uint32_t i = 0; i < dispatchDescsNum && !reblurConstants; i++)
             if (descs[i].pipelineIndex < idesc.pipelinesNum && !strncmp(idesc.pipelines[descs[i].pipelineIndex].shaderFileName, "REBLUR_", 7) && descs[i].constantBufferData &&
                 descs[i].constantBufferDataSize >= sizeof(nrdc::ReblurConstants))

@@ -216,13 +216,14 @@ NRD_D PrePassGuides FetchPrePassGuides(const RelaxCB& c, const PrePassPlanes& P,
         const float cxf = __builtin_amdgcn_fmed3f(uv.x, 0.0f, rectSize.x - 1.0f), cyf = __builtin_amdgcn_fmed3f(uv.y, 0.0f, rectSize.y - 1.0f);
         g.inScreen = (cxf == uv.x && cyf == uv.y) ? 1.0f : 0.0f;
         g.signalTexel = make_int2((int)cxf, (int)cyf);
-        const uint32_t offset = __umul24((uint32_t)g.signalTexel.y, P.decodedNR.pitch) + (uint32_t)g.signalTexel.x * 16u;
-        const float4 g0 = *(const float4*)(P.decodedNR.ptr + offset), g1 = *(const float4*)(P.worldPos.ptr + offset);
-        const float4 nr = DecodedToNormalRoughness(g0, g.materialID);
+        // decoded normal (16 B) + viewZ (4 B); the world position is re-derived from viewZ: the taps are bound by the L1 / texture-address path, and a
+        // second 16-byte guide texel per tap made this pass 13 % SLOWER (profiles/r02_c_relax_bench_fast.json vs r02_b) despite fewer instructions
+        const float4 nr = LoadDecodedNormalRoughness(P.decodedNR, g.signalTexel.x, g.signalTexel.y, g.materialID);
         g.normal = Xyz(nr);
         g.roughness = nr.w;
-        g.worldPos = Xyz(g1);
-        g.viewZ = g1.w;
+        g.viewZ = RelaxUnpackViewZ(c, LoadR32F(P.viewZ, g.signalTexel.x, g.signalTexel.y));
+        const float2 uvc = (uv + 0.5f) * ToF2(c.shared.gRectSizeInv); // centre of the snapped pixel (= the texel's centre whenever the tap counts)
+        g.worldPos = GetCurrentWorldPosFromClipSpaceXY(c, uvc * 2.0f - 1.0f, g.viewZ);
         return g;
     }
     PrePassTap t = MakeTap<CB>(c, P.viewZ, signal, checkerboardMode, pixelUv, rectSize, rotator, i, blurRadius);
@@ -238,8 +239,6 @@ NRD_D PrePassGuides FetchPrePassGuides(const RelaxCB& c, const PrePassPlanes& P,
 
 template <bool DIFF, bool SPEC, bool SH, bool CB, bool FR>
 __global__ __launch_bounds__(256) void RelaxPrePassKernel(PrePassPlanes P, RelaxCB c, RowRange rows) {
-    if (FR)
-        ShareLayout(P.worldPos, P.decodedNR);
     const int blockY = blockIdx.y + rows.firstBlockY;
     const int px = BlockTileX(rows) * TILE_X + (threadIdx.x & 31), py = blockY * TILE_Y + (threadIdx.x >> 5);
     const int rectW = c.shared.gRectSize.x, rectH = c.shared.gRectSize.y;
@@ -463,7 +462,7 @@ const char* LaunchPrePass(const PassArgs& a) {
     RelaxCB c = LoadRelaxConstants(a);
     RowGrid g = GridForRows(c.shared.gRectSize.x, c.shared.gRectSize.y, TILE_X, TILE_Y, a.rowBegin, a.rowEnd);
     const char* forceGeneric = getenv("NRD_HIP_GENERIC_TAPS");
-    const bool fullRect = P.worldPos.ptr && SameLayout(P.worldPos, P.decodedNR) && c.shared.gResolutionScale.x == 1.0f && c.shared.gResolutionScale.y == 1.0f && c.shared.gRectSize.x == P.decodedNR.w &&
+    const bool fullRect = c.shared.gResolutionScale.x == 1.0f && c.shared.gResolutionScale.y == 1.0f && c.shared.gRectSize.x == P.decodedNR.w &&
                           c.shared.gRectSize.y == P.decodedNR.h && P.viewZ.w == P.decodedNR.w && P.viewZ.h == P.decodedNR.h && !(forceGeneric && atoi(forceGeneric) != 0);
     if ((SPEC && c.shared.gSpecCheckerboard != 2u) || (DIFF && c.shared.gDiffCheckerboard != 2u))
         LaunchPass(a, (RelaxPrePassKernel<DIFF, SPEC, SH, true, false>), g.grid, dim3(256), P, c, MakeRowRange(g));

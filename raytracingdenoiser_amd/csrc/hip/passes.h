@@ -117,10 +117,13 @@ inline dim3 GridFor(int w, int h, int tileW, int tileH) { return dim3((unsigned)
 // XCD k owns the vertical band of tile columns [k * bandTiles, (k + 1) * bandTiles): neighbouring tiles share their halos in ONE L2, all eight
 // XCDs sweep the frame top to bottom together, and a horizontal sky band costs every XCD the same (the r01 experiment with bands of tile ROWS lost
 // 1.46x to that imbalance). Placement is a speed matter only: results do not depend on it. NRD_HIP_XCD_BANDS=0 restores the plain order.
-// NRD_HIP_XCD_BANDS: 0 = plain order; 1 (default) = one band per XCD; n > 1 = stripes of n tile columns dealt round-robin to the XCDs (several stripes per
-// XCD: better balance when the cost varies across the frame, wider halos per stripe)
+// NRD_HIP_XCD_BANDS: 0 = plain order; 1 = one band per XCD; n > 1 = stripes of n tile columns dealt round-robin to the XCDs (several stripes per XCD);
+// default (-1) = stripes whose width is picked per launch: the widest of 4, 3, 2 tile columns that gives every XCD the same number of stripes.
+// Measured (profiles/r02_b_*, r02_c_*): one band per XCD cuts the counter traffic of the sparse-tap passes from 2-4x to 1.1-1.3x the algorithmic
+// bytes but runs 3-5 % SLOWER than the plain order (the passes are not HBM-bound, and a band's cost depends on what it shows); stripes of 2-3 tile
+// columns are the fastest order (REBLUR 1440p 1.014 ms vs 1.020 plain vs 1.056 banded; RELAX 4K 3.32 vs 3.37 vs 3.55).
 inline int XcdBandsSetting() {
-    static const int v = getenv("NRD_HIP_XCD_BANDS") ? atoi(getenv("NRD_HIP_XCD_BANDS")) : 1;
+    static const int v = getenv("NRD_HIP_XCD_BANDS") ? atoi(getenv("NRD_HIP_XCD_BANDS")) : -1;
     return v;
 }
 inline bool XcdBandsEnabled() { return XcdBandsSetting() != 0; }
@@ -140,8 +143,17 @@ inline RowGrid GridForRows(int w, int h, int tileW, int tileH, int rowBegin, int
     const int tilesX = (w + tileW - 1) / tileW;
     g.bandTiles = (XcdBandsEnabled() && tilesX >= 16) ? (tilesX + 7) / 8 : 0;
     g.stripeTiles = g.bandTiles;
-    if (g.bandTiles && XcdBandsSetting() > 1) { // stripes: the XCD's tile columns are dealt out in groups of stripeTiles
-        g.stripeTiles = XcdBandsSetting() < g.bandTiles ? XcdBandsSetting() : g.bandTiles;
+    int stripe = XcdBandsSetting();
+    if (g.bandTiles && stripe < 0) { // automatic: equal stripe counts per XCD if possible
+        stripe = 2;
+        for (int b = 4; b >= 2; b--)
+            if (tilesX % (8 * b) == 0) {
+                stripe = b;
+                break;
+            }
+    }
+    if (g.bandTiles && stripe > 1) { // stripes: the XCD's tile columns are dealt out in groups of stripeTiles
+        g.stripeTiles = stripe < g.bandTiles ? stripe : g.bandTiles;
         g.bandTiles = ((g.bandTiles + g.stripeTiles - 1) / g.stripeTiles) * g.stripeTiles;
     }
     g.grid = dim3((unsigned)(g.bandTiles ? 8 * g.bandTiles : tilesX), (unsigned)(ny > 0 ? ny : 1), 1);
