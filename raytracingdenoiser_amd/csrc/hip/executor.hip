@@ -95,7 +95,7 @@ struct NrdHipExecutor {
     std::vector<Plane> permanent, transient;
     Plane decodedNormalRoughness = {}; // internal float4 cache of IN_NORMAL_ROUGHNESS (not an NRD pool plane; own allocation)
     Plane worldPosViewZ = {};          // internal float4 scratch of the RELAX a-trous chain (world position + viewZ per pixel)
-    Plane viewPos = {};                // internal float4 guide plane of the REBLUR lists (view-space position + viewZ + material ID per pixel)
+    Plane viewPos = {};                // internal float4 guide plane of the REBLUR lists (decoded normal + viewZ per pixel)
     std::vector<nrd::Format> permanentFormat, transientFormat;
 
     Plane user[(size_t)nrd::ResourceType::MAX_NUM] = {};
@@ -783,7 +783,8 @@ static uint32_t ExecuteRange(NrdHipExecutor* e, const nrd::DispatchDesc* descs, 
     // View-position guide plane of the REBLUR lists (same geometry again): needs IN_VIEWZ and the frame's REBLUR constants
     Plane viewPos = {};
     const void* reblurConstants = nullptr;
-    if (decoded.ptr && e->userBound[(uint32_t)nrd::ResourceType::IN_VIEWZ] && getenv("NRD_HIP_VIEWPOS_PLANE")) { // experiment switch: no pass reads the plane by default
+    static const bool guidePlane = !(getenv("NRD_HIP_GUIDE_NZ") && atoi(getenv("NRD_HIP_GUIDE_NZ")) == 0); // A/B switch
+    if (decoded.ptr && e->userBound[(uint32_t)nrd::ResourceType::IN_VIEWZ] && guidePlane) {
         for (uint32_t i = 0; i < dispatchDescsNum && !reblurConstants; i++)
             if (descs[i].pipelineIndex < idesc.pipelinesNum && !strncmp(idesc.pipelines[descs[i].pipelineIndex].shaderFileName, "REBLUR_", 7) && descs[i].constantBufferData &&
                 descs[i].constantBufferDataSize >= sizeof(nrdc::ReblurConstants))

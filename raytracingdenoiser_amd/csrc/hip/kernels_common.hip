@@ -21,19 +21,16 @@ __global__ __launch_bounds__(256) void DecodeNormalRoughnessKernel(Plane packed,
         StoreRGBA32F(decoded, x, y, EncodeDecodedNormalRoughness(LoadR32U(packed, x, y)));
 }
 
-// REBLUR lists: the same decode plus (Xv.x, Xv.y, viewZ, materialID) of every pixel -- exactly what the spatial passes would otherwise re-derive at each of
-// their 16 taps per pixel and pass: ReconstructViewPosition( (pixel + 0.5) * gRectSizeInv, gFrustum, |z * gViewZScale| ) (perspective; the launchers reject
-// orthographic projections) and the material ID of UnpackNormalAndRoughness. 8 B read + 32 B written per pixel.
+// REBLUR lists: the same decode plus a (normal, viewZ = |z * gViewZScale|) plane: what a tap of the spatial passes needs from its texel, in ONE 16-byte load
+// instead of a 16-byte and a 4-byte one. 8 B read + 32 B written per pixel.
 __global__ __launch_bounds__(256) void DecodeGuidesKernel(Plane packed, Plane viewZ, Plane decoded, Plane viewPos, float4 frustum, float2 rectSizeInv, float viewZScale) {
     const int x = blockIdx.x * 256 + threadIdx.x, y = blockIdx.y;
     if (x >= packed.w)
         return;
     const uint32_t raw = LoadR32U(packed, x, y);
-    StoreRGBA32F(decoded, x, y, EncodeDecodedNormalRoughness(raw));
-    const float z = Abs(LoadR32F(viewZ, x, y) * viewZScale);
-    const float2 uv = F2(float(x) + 0.5f, float(y) + 0.5f) * rectSizeInv;
-    const float3 Xv = ReconstructViewPosition(uv, frustum, z, 0.0f);
-    StoreRGBA32F(viewPos, x, y, F4(Xv.x, Xv.y, z, NRD_DIV_3(float(raw >> 30)) * 3.0f));
+    const float4 d = EncodeDecodedNormalRoughness(raw);
+    StoreRGBA32F(decoded, x, y, d);
+    StoreRGBA32F(viewPos, x, y, F4(d.x, d.y, d.z, Abs(LoadR32F(viewZ, x, y) * viewZScale)));
 }
 
 void LaunchDecodeGuides(const PassArgs& a, const Plane& packed, const Plane& viewZ, const Plane& decoded, const Plane& viewPos, const void* reblurConstants) {

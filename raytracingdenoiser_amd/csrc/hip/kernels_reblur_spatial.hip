@@ -78,23 +78,7 @@ struct SpatialCtx {
 // no checkerboard -- the launcher picks the variant) collapses that chain: the snapped pixel IS the texel (k = floor(uv * rectSize), clamped to the
 // rect; "in screen" <=> k was inside). Same values bit for bit: a tap outside the screen has weight 0 in both formulations, inside the two agree
 // on texel and uv.
-// LDS staging of the tap footprint (Blur / PostBlur, radiance signals, FR): a 32x16-pixel workgroup stages the guides and both signals of its
-// (32 + 2 * HALO) x (16 + 2 * HALO) neighbourhood once -- coalesced row loads, ~1.3 loads per pixel and plane instead of 8 scattered ones -- and a
-// tap that lands inside reads LDS (one ds_read_b128 costs a CU ~13 cycles per wave, a scattered 16-byte global load ~150: profiles/r02_c_gather_bench.txt).
-// With an accumulated history the blur radii are 5-11 px (maxBlurRadius * sqrt(hit-distance factor / (1 + accumulated frames)), doubled in the
-// post-blur), so nearly every tap stays inside HALO = 12; a tap beyond it (young history: radii up to 30 / 60 px) takes the global path as before.
-// Same texel values either way, so results do not depend on where a tap was served from.
-struct LdsTile {
-    const float4* guide;   // N.xyz, viewZ
-    const uint16_t* bits;  // roughness | materialID << 10 (the 12 payload bits of the decoded-guide texel)
-    const uint2* diff;     // RGBA16F texels, raw
-    const uint2* spec;
-    int x0, y0;            // frame coordinates of slot (0, 0)
-};
-constexpr int LDS_HALO = 12, LDS_TILE_Y = 16, LDS_W = TILE_X + 2 * LDS_HALO, LDS_H = LDS_TILE_Y + 2 * LDS_HALO, LDS_SLOTS = LDS_W * LDS_H; // 56 x 40 = 2240
-
 struct TapGuides {
-    int lds;          // slot of the tap's texel in the staged tile, or -1
     float w;          // IsInScreenNearest
     float3 Ns, Xvs;   // world-space normal, view-space position of the tap's texel
     float roughnessS, materialIDs, zs;
@@ -102,11 +86,10 @@ struct TapGuides {
     float2 uv;        // generic path only
 };
 
-template <SpatialMode MODE, bool CB, bool FR, bool NEED_ROUGHNESS, bool LDS>
-NRD_D TapGuides FetchTapGuides(const ReblurCB& c, float2 uv, const Plane& gIn_Signal, const Plane& gIn_ViewZ, const Plane& gIn_Normal_Roughness, const LdsTile& tile, uint32_t checkerboardMode,
+template <SpatialMode MODE, bool CB, bool FR, bool NEED_ROUGHNESS>
+NRD_D TapGuides FetchTapGuides(const ReblurCB& c, float2 uv, const Plane& gIn_Signal, const Plane& gIn_ViewZ, const Plane& gIn_Normal_Roughness, const Plane& gIn_ViewPos, uint32_t checkerboardMode,
     uint32_t n, bool compareMaterials) {
     TapGuides t;
-    t.lds = -1;
     const float2 rectSize = ToF2(c.gRectSize), rectSizeInv = ToF2(c.gRectSizeInv);
     uv = Floor(uv * rectSize);
     if (FR) {
@@ -114,17 +97,21 @@ NRD_D TapGuides FetchTapGuides(const ReblurCB& c, float2 uv, const Plane& gIn_Si
         const float cxf = __builtin_amdgcn_fmed3f(uv.x, 0.0f, rectSize.x - 1.0f), cyf = __builtin_amdgcn_fmed3f(uv.y, 0.0f, rectSize.y - 1.0f);
         t.w = (cxf == uv.x && cyf == uv.y) ? 1.0f : 0.0f;
         t.ts = make_int2((int)cxf, (int)cyf);
-        // Guides of the texel: decoded normal (16 B) + viewZ (4 B). The taps are bound by the L1 / texture-address path, not by VALU (profiles/r02_c_gather_bench.txt:
-        // a 16-byte gather costs a CU ~150 cycles per wave, a 4-byte one ~40), so the view position is re-derived from viewZ (6 VALU) rather than fetched
-        // as a second 16-byte texel -- the r02_b A/B of exactly that variant bought nothing despite 19 % fewer instructions.
-        uint32_t bits;
-        const int lx = t.ts.x - tile.x0, ly = t.ts.y - tile.y0;
-        if (LDS && (uint32_t)lx < (uint32_t)LDS_W && (uint32_t)ly < (uint32_t)LDS_H) {
-            t.lds = ly * LDS_W + lx;
-            const float4 g = tile.guide[t.lds];
+        // Guides of the texel: decoded normal (16 B) + viewZ (4 B); the view position is re-derived from viewZ (6 VALU). Fetching it as a second 16-byte
+        // guide texel instead (r02_b / r02_c A/B) saved 19 % of the instructions and bought nothing: the extra 12 bytes per tap through the L1 / texture-address
+        // path cost as much (profiles/r02_c_gather_bench.txt prices a wave's 16-byte gather at 40-150 CU cycles, a 4-byte one at 6-40). Staging the whole tap
+        // footprint in LDS was measured too (r02_d: 32x16 workgroups, halo 12, 76 KB) and lost 15-20 % to the fill and the lower occupancy: neighbouring
+        // lanes' taps land on neighbouring texels, so the global path is better coalesced than a scattered gather.
+        // With the per-frame (normal, viewZ) guide plane (passes.h viewPos) a diffuse tap is ONE 16-byte guide load; a specular tap adds the 4 bytes that
+        // hold the roughness / material bits of the decoded-normal texel.
+        uint32_t bits = 0u;
+        if (gIn_ViewPos.ptr) {
+            const uint32_t offset = __umul24((uint32_t)t.ts.y, gIn_ViewPos.pitch) + (uint32_t)t.ts.x * 16u; // same layout as the decoded normals (launcher check)
+            const float4 g = *(const float4*)(gIn_ViewPos.ptr + offset);
             t.Ns = Xyz(g);
             t.zs = g.w;
-            bits = (NEED_ROUGHNESS || compareMaterials) ? (uint32_t)tile.bits[t.lds] : 0u;
+            if (NEED_ROUGHNESS || compareMaterials)
+                bits = *(const uint32_t*)(gIn_Normal_Roughness.ptr + offset + 12u);
         } else {
             const float4 g0 = LoadRGBA32F(gIn_Normal_Roughness, t.ts.x, t.ts.y);
             t.zs = UnpackViewZ(c, LoadR32F(gIn_ViewZ, t.ts.x, t.ts.y));
@@ -175,9 +162,9 @@ NRD_D float PoissonGaussianWeight(int n) { // = GetGaussianWeight( offset.z ), b
 // SH = the *_SH denoisers: an SH1 plane (RGBA16F) rides on the same taps and weights (diffuse: all 4 components, specular: .xyz only)
 // CB = a checkerboard mode is on (pre-pass only): the noisy inputs live in the left half of their planes, a tap that lands on a pixel
 // without data moves one pixel sideways, and pixels the taps could not fill are resolved from the two horizontal neighbours
-template <SpatialMode MODE, bool PERF, int KIND, bool SH, bool CB, bool FR, bool LDS>
+template <SpatialMode MODE, bool PERF, int KIND, bool SH, bool CB, bool FR>
 NRD_D typename ReblurSignal<KIND>::type DiffuseSpatialFilterTaps(const ReblurCB& c, const SpatialCtx& s, typename ReblurSignal<KIND>::type diff, const Plane& gIn_Diff, const Plane& gIn_ViewZ,
-    const Plane& gIn_Normal_Roughness, const LdsTile& tile, float4& diffSh, const Plane& gIn_DiffSh, float& sum) {
+    const Plane& gIn_Normal_Roughness, const Plane& gIn_ViewPos, float4& diffSh, const Plane& gIn_DiffSh, float& sum) {
     typedef ReblurSignal<KIND> Sig;
     constexpr bool OCC = KIND == SIGNAL_OCCLUSION;
     typedef typename Sig::type S;
@@ -236,7 +223,7 @@ NRD_D typename ReblurSignal<KIND>::type DiffuseSpatialFilterTaps(const ReblurCB&
     for (int n = 0; n < (PERF ? 6 : 8); n++) {
         float3 offset = PERF ? F3(g_Special6[n][0], g_Special6[n][1], g_Special6[n][2]) : F3(g_Special8[n][0], g_Special8[n][1], g_Special8[n][2]);
         const float2 uvTap = s.pixelUv + RotateVector(scaledRotator, F2(offset.x, offset.y));
-        const TapGuides t = FetchTapGuides<MODE, CB, FR, false, LDS>(c, uvTap, gIn_Diff, gIn_ViewZ, gIn_Normal_Roughness, tile, c.gDiffCheckerboard, (uint32_t)n, compareMaterials);
+        const TapGuides t = FetchTapGuides<MODE, CB, FR, false>(c, uvTap, gIn_Diff, gIn_ViewZ, gIn_Normal_Roughness, gIn_ViewPos, c.gDiffCheckerboard, (uint32_t)n, compareMaterials);
         const int2 ts = t.ts;
 
         float angle = AcosApprox(Dot(s.N, t.Ns));
@@ -247,17 +234,7 @@ NRD_D typename ReblurSignal<KIND>::type DiffuseSpatialFilterTaps(const ReblurCB&
             w *= CompareMaterials(s.materialID, t.materialIDs, c.gDiffMinMaterial) ? 1.0f : 0.0f;
         w *= ComputeWeight(angle, normalWeightParam, 0.0f);
 
-        S smp;
-        if constexpr (LDS) {
-            if (t.lds >= 0) {
-                const uint2 raw = tile.diff[t.lds];
-                smp = DecodeRGBA16F(raw.x, raw.y);
-            } else {
-                smp = Sig::Load(gIn_Diff, ts.x, ts.y);
-            }
-        } else {
-            smp = Sig::Load(gIn_Diff, ts.x, ts.y);
-        }
+        S smp = Sig::Load(gIn_Diff, ts.x, ts.y);
         smp = Select(w == 0.0f, Sig::Zero(), smp);
 
         w *= Lerp(minHitDistWeight, 1.0f, ComputeExponentialWeight(ExtractHitDist(smp), hitDistanceWeightParams.x, hitDistanceWeightParams.y));
@@ -279,13 +256,13 @@ NRD_D typename ReblurSignal<KIND>::type DiffuseSpatialFilterTaps(const ReblurCB&
 }
 
 // "sum" = 1 when the centre pixel carries data, 0 for the empty pixels of a checkerboarded input
-template <SpatialMode MODE, bool PERF, int KIND, bool SH, bool CB, bool FR, bool LDS>
+template <SpatialMode MODE, bool PERF, int KIND, bool SH, bool CB, bool FR>
 NRD_D typename ReblurSignal<KIND>::type DiffuseSpatialFilter(const ReblurCB& c, const SpatialCtx& s, typename ReblurSignal<KIND>::type diff, const Plane& gIn_Diff, const Plane& gIn_ViewZ,
-    const Plane& gIn_Normal_Roughness, const LdsTile& tile, float4& diffSh, const Plane& gIn_DiffSh, float sum) {
+    const Plane& gIn_Normal_Roughness, const Plane& gIn_ViewPos, float4& diffSh, const Plane& gIn_DiffSh, float sum) {
     typedef ReblurSignal<KIND> Sig;
     typedef typename Sig::type S;
     if (!(MODE == PRE_BLUR && c.gDiffPrepassBlurRadius == 0.0f))
-        diff = DiffuseSpatialFilterTaps<MODE, PERF, KIND, SH, CB, FR, LDS>(c, s, diff, gIn_Diff, gIn_ViewZ, gIn_Normal_Roughness, tile, diffSh, gIn_DiffSh, sum);
+        diff = DiffuseSpatialFilterTaps<MODE, PERF, KIND, SH, CB, FR>(c, s, diff, gIn_Diff, gIn_ViewZ, gIn_Normal_Roughness, gIn_ViewPos, diffSh, gIn_DiffSh, sum);
     if (MODE == PRE_BLUR && CB && sum == 0.0f) { // reference REBLUR_Common_DiffuseSpatialFilter.hlsli:177-199
         S s0 = Select(s.wc.x == 0.0f, Sig::Zero(), Sig::Load(gIn_Diff, s.cbX0, s.py));
         S s1 = Select(s.wc.y == 0.0f, Sig::Zero(), Sig::Load(gIn_Diff, s.cbX1, s.py));
@@ -299,9 +276,9 @@ NRD_D typename ReblurSignal<KIND>::type DiffuseSpatialFilter(const ReblurCB& c, 
     return diff;
 }
 
-template <SpatialMode MODE, bool PERF, int KIND, bool SH, bool CB, bool FR, bool LDS>
+template <SpatialMode MODE, bool PERF, int KIND, bool SH, bool CB, bool FR>
 NRD_D typename ReblurSignal<KIND>::type SpecularSpatialFilterTaps(const ReblurCB& c, const SpatialCtx& s, typename ReblurSignal<KIND>::type spec, const Plane& gIn_Spec, const Plane& gIn_ViewZ,
-    const Plane& gIn_Normal_Roughness, const LdsTile& tile, const Plane& gOut_SpecHitDistForTracking, float4& specSh, const Plane& gIn_SpecSh, float& sum) {
+    const Plane& gIn_Normal_Roughness, const Plane& gIn_ViewPos, const Plane& gOut_SpecHitDistForTracking, float4& specSh, const Plane& gIn_SpecSh, float& sum) {
     typedef ReblurSignal<KIND> Sig;
     constexpr bool OCC = KIND == SIGNAL_OCCLUSION;
     typedef typename Sig::type S;
@@ -392,7 +369,7 @@ NRD_D typename ReblurSignal<KIND>::type SpecularSpatialFilterTaps(const ReblurCB
         else
             uv = GetKernelSampleCoordinates(c.gViewToClip, offset, s.Xv, T, B, s.rotator);
 
-        const TapGuides t = FetchTapGuides<MODE, CB, FR, true, LDS>(c, uv, gIn_Spec, gIn_ViewZ, gIn_Normal_Roughness, tile, c.gSpecCheckerboard, (uint32_t)n, compareMaterials);
+        const TapGuides t = FetchTapGuides<MODE, CB, FR, true>(c, uv, gIn_Spec, gIn_ViewZ, gIn_Normal_Roughness, gIn_ViewPos, c.gSpecCheckerboard, (uint32_t)n, compareMaterials);
         const int2 ts = t.ts;
         const float zs = t.zs;
         const float3 Xvs = t.Xvs;
@@ -407,17 +384,7 @@ NRD_D typename ReblurSignal<KIND>::type SpecularSpatialFilterTaps(const ReblurCB
         w *= ComputeWeight(angle, normalWeightParam, 0.0f);
         w *= ComputeWeight(Ns.w, roughnessWeightParams.x, roughnessWeightParams.y);
 
-        S smp;
-        if constexpr (LDS) {
-            if (t.lds >= 0) {
-                const uint2 raw = tile.spec[t.lds];
-                smp = DecodeRGBA16F(raw.x, raw.y);
-            } else {
-                smp = Sig::Load(gIn_Spec, ts.x, ts.y);
-            }
-        } else {
-            smp = Sig::Load(gIn_Spec, ts.x, ts.y);
-        }
+        S smp = Sig::Load(gIn_Spec, ts.x, ts.y);
         smp = Select(w == 0.0f, Sig::Zero(), smp);
 
         if (MODE == PRE_BLUR) {
@@ -454,13 +421,13 @@ NRD_D typename ReblurSignal<KIND>::type SpecularSpatialFilterTaps(const ReblurCB
     return spec;
 }
 
-template <SpatialMode MODE, bool PERF, int KIND, bool SH, bool CB, bool FR, bool LDS>
+template <SpatialMode MODE, bool PERF, int KIND, bool SH, bool CB, bool FR>
 NRD_D typename ReblurSignal<KIND>::type SpecularSpatialFilter(const ReblurCB& c, const SpatialCtx& s, typename ReblurSignal<KIND>::type spec, const Plane& gIn_Spec, const Plane& gIn_ViewZ,
-    const Plane& gIn_Normal_Roughness, const LdsTile& tile, const Plane& gOut_SpecHitDistForTracking, float4& specSh, const Plane& gIn_SpecSh, float sum) {
+    const Plane& gIn_Normal_Roughness, const Plane& gIn_ViewPos, const Plane& gOut_SpecHitDistForTracking, float4& specSh, const Plane& gIn_SpecSh, float sum) {
     typedef ReblurSignal<KIND> Sig;
     typedef typename Sig::type S;
     if (!(MODE == PRE_BLUR && c.gSpecPrepassBlurRadius == 0.0f))
-        spec = SpecularSpatialFilterTaps<MODE, PERF, KIND, SH, CB, FR, LDS>(c, s, spec, gIn_Spec, gIn_ViewZ, gIn_Normal_Roughness, tile, gOut_SpecHitDistForTracking, specSh, gIn_SpecSh, sum);
+        spec = SpecularSpatialFilterTaps<MODE, PERF, KIND, SH, CB, FR>(c, s, spec, gIn_Spec, gIn_ViewZ, gIn_Normal_Roughness, gIn_ViewPos, gOut_SpecHitDistForTracking, specSh, gIn_SpecSh, sum);
     if (MODE == PRE_BLUR && CB && sum == 0.0f) { // reference REBLUR_Common_SpecularSpatialFilter.hlsli:224-246 (all 4 SH components here)
         S s0 = Select(s.wc.x == 0.0f, Sig::Zero(), Sig::Load(gIn_Spec, s.cbX0, s.py));
         S s1 = Select(s.wc.y == 0.0f, Sig::Zero(), Sig::Load(gIn_Spec, s.cbX1, s.py));
@@ -498,7 +465,7 @@ NRD_D bool MakeSpatialCtx(const ReblurCB& c, int px, int py, float viewZ, const 
 struct SpatialPlanes {
     Plane tiles, normalRoughness, viewZ, data1;
     Plane decodedNR; // executor's float4 cache of normalRoughness (reblur_device.h "decoded guides")
-    Plane viewPos;   // executor's float4 guide plane (view position, viewZ, material ID; passes.h), same layout as decodedNR
+    Plane viewPos;   // executor's float4 guide plane (normal, viewZ; passes.h), same layout as decodedNR; may be null
     Plane inDiff, inSpec;
     Plane outDiff, outSpec;
     Plane outHitDistForTracking; // pre-pass
@@ -508,43 +475,14 @@ struct SpatialPlanes {
     Plane inDiffSh, inSpecSh, outDiffSh, outSpecSh, outDiffShCopy, outSpecShCopy; // SH family
 };
 
-// FR: rect == resource and no checkerboard (FetchTapGuides); LDS: 32x16-pixel workgroups with the staged tap footprint (LdsTile; Blur / PostBlur, radiance, FR)
-template <SpatialMode MODE, bool DIFF, bool SPEC, bool NO_TS, bool PERF, int KIND, bool SH, bool CB, bool FR, bool LDS>
-__global__ __launch_bounds__(LDS ? TILE_X* LDS_TILE_Y : TILE_X* TILE_Y) void ReblurSpatialKernel(ReblurCB c, SpatialPlanes P, RowRange rr) {
+// FR: rect == resource and no checkerboard (FetchTapGuides)
+template <SpatialMode MODE, bool DIFF, bool SPEC, bool NO_TS, bool PERF, int KIND, bool SH, bool CB, bool FR>
+__global__ __launch_bounds__(TILE_X* TILE_Y) void ReblurSpatialKernel(ReblurCB c, SpatialPlanes P, RowRange rr) {
     typedef ReblurSignal<KIND> Sig;
     constexpr bool OCC = KIND == SIGNAL_OCCLUSION;
     typedef typename Sig::type S;
-    static_assert(!LDS || (FR && MODE != PRE_BLUR && KIND == SIGNAL_RADIANCE && !SH && !CB), "the staged variant serves the radiance Blur / PostBlur passes");
-    constexpr int TY = LDS ? LDS_TILE_Y : TILE_Y;
-    const int tileX0 = BlockTileX(rr) * TILE_X, tileY0 = (blockIdx.y + rr.firstBlockY) * TY;
-    const int px = tileX0 + (threadIdx.x % TILE_X);
-    const int py = tileY0 + (threadIdx.x / TILE_X);
-
-    __shared__ float4 s_Guide[LDS ? LDS_SLOTS : 1];
-    __shared__ uint16_t s_Bits[LDS ? LDS_SLOTS : 1];
-    __shared__ uint2 s_Diff[(LDS && DIFF) ? LDS_SLOTS : 1], s_Spec[(LDS && SPEC) ? LDS_SLOTS : 1];
-    LdsTile tile = {};
-    if (LDS) {
-        // both 16x16 tiles under the workgroup sky (or the workgroup beyond the rect): nothing to do -- uniform, so the barrier below stays legal
-        bool anyGeometry = false;
-        for (int t = 0; t < TILE_X / 16; t++)
-            if ((tileX0 >> 4) + t < P.tiles.w && (tileY0 >> 4) < P.tiles.h && tileX0 <= c.gRectSizeMinusOne.x && tileY0 <= c.gRectSizeMinusOne.y)
-                anyGeometry |= LoadR8Unorm(P.tiles, (tileX0 >> 4) + t, tileY0 >> 4) == 0.0f;
-        if (!anyGeometry)
-            return;
-        tile.guide = s_Guide, tile.bits = s_Bits, tile.diff = s_Diff, tile.spec = s_Spec;
-        tile.x0 = tileX0 - LDS_HALO, tile.y0 = tileY0 - LDS_HALO;
-        for (int i = threadIdx.x; i < LDS_SLOTS; i += TILE_X * LDS_TILE_Y) {
-            const int ly = i / LDS_W, lx = i - ly * LDS_W;
-            const int gx = ClampI(tile.x0 + lx, 0, c.gRectSizeMinusOne.x), gy = ClampI(tile.y0 + ly, 0, c.gRectSizeMinusOne.y); // slots beyond the frame are never addressed
-            const float4 g0 = LoadRGBA32F(P.decodedNR, gx, gy);
-            s_Guide[i] = F4(g0.x, g0.y, g0.z, UnpackViewZ(c, LoadR32F(P.viewZ, gx, gy)));
-            s_Bits[i] = (uint16_t)AsUint(g0.w);
-            if (DIFF) s_Diff[i] = *TexelPtr<const uint2>(P.inDiff, gx, gy);
-            if (SPEC) s_Spec[i] = *TexelPtr<const uint2>(P.inSpec, gx, gy);
-        }
-        __syncthreads();
-    }
+    const int px = BlockTileX(rr) * TILE_X + (threadIdx.x % TILE_X);
+    const int py = (blockIdx.y + rr.firstBlockY) * TILE_Y + (threadIdx.x / TILE_X);
     if (px > c.gRectSizeMinusOne.x || py > c.gRectSizeMinusOne.y || py < rr.rowBegin || py >= rr.rowEnd)
         return;
     if (LoadR8Unorm(P.tiles, px >> 4, py >> 4) != 0.0f)
@@ -594,7 +532,7 @@ __global__ __launch_bounds__(LDS ? TILE_X* LDS_TILE_Y : TILE_X* TILE_Y) void Reb
             diff = Sig::Zero();
             diffSh = F4(0.0f);
         }
-        diff = DiffuseSpatialFilter<MODE, PERF, KIND, SH, CB, FR, LDS>(c, s, diff, P.inDiff, P.viewZ, P.decodedNR, tile, diffSh, P.inDiffSh, sum);
+        diff = DiffuseSpatialFilter<MODE, PERF, KIND, SH, CB, FR>(c, s, diff, P.inDiff, P.viewZ, P.decodedNR, P.viewPos, diffSh, P.inDiffSh, sum);
         Sig::Store(P.outDiff, px, py, diff);
         if (SH)
             StoreRGBA16F(P.outDiffSh, px, py, diffSh);
@@ -615,7 +553,7 @@ __global__ __launch_bounds__(LDS ? TILE_X* LDS_TILE_Y : TILE_X* TILE_Y) void Reb
             spec = Sig::Zero();
             specSh = F4(0.0f);
         }
-        spec = SpecularSpatialFilter<MODE, PERF, KIND, SH, CB, FR, LDS>(c, s, spec, P.inSpec, P.viewZ, P.decodedNR, tile, P.outHitDistForTracking, specSh, P.inSpecSh, sum);
+        spec = SpecularSpatialFilter<MODE, PERF, KIND, SH, CB, FR>(c, s, spec, P.inSpec, P.viewZ, P.decodedNR, P.viewPos, P.outHitDistForTracking, specSh, P.inSpecSh, sum);
         Sig::Store(P.outSpec, px, py, spec);
         if (SH)
             StoreRGBA16F(P.outSpecSh, px, py, specSh);
@@ -652,7 +590,7 @@ static const char* LaunchSpatial(const PassArgs& a) {
     P.tiles = a.planes[k++];
     P.normalRoughness = a.planes[k++];
     P.decodedNR = a.decodedNormalRoughness;
-    P.viewPos = a.viewPos;
+    P.viewPos = (a.viewPos.ptr && SameLayout(a.viewPos, a.decodedNormalRoughness)) ? a.viewPos : Plane{};
     if (!P.decodedNR.ptr)
         return "REBLUR spatial pass: the decoded normal/roughness cache is missing (IN_NORMAL_ROUGHNESS not bound?)";
     if (MODE == PRE_BLUR) {
@@ -701,25 +639,17 @@ static const char* LaunchSpatial(const PassArgs& a) {
     const RowRange rows = MakeRowRange(g);
     if constexpr (MODE == PRE_BLUR) { // only the pre-pass reads the (possibly checkerboarded) noisy inputs
         if (c.gDiffCheckerboard != 2 || c.gSpecCheckerboard != 2) {
-            LaunchPass(a, (ReblurSpatialKernel<MODE, DIFF, SPEC, NO_TS, PERF, KIND, SH, true, false, false>), g.grid, dim3(TILE_X * TILE_Y), c, P, rows);
+            LaunchPass(a, (ReblurSpatialKernel<MODE, DIFF, SPEC, NO_TS, PERF, KIND, SH, true, false>), g.grid, dim3(TILE_X * TILE_Y), c, P, rows);
             return nullptr;
         }
     }
     // "full rect": the rect is the whole resource (no dynamic-resolution scaling) and the guide planes of this frame exist
     const bool fullRect = c.gResolutionScale.x == 1.0f && c.gResolutionScale.y == 1.0f && c.gRectSizeMinusOne.x + 1 == P.decodedNR.w &&
                           c.gRectSizeMinusOne.y + 1 == P.decodedNR.h && P.viewZ.w == P.decodedNR.w && P.viewZ.h == P.decodedNR.h && !ForceGenericTaps();
-    if constexpr (MODE != PRE_BLUR && KIND == SIGNAL_RADIANCE && !SH) {
-        static const bool stage = !(getenv("NRD_HIP_LDS_TAPS") && atoi(getenv("NRD_HIP_LDS_TAPS")) == 0); // A/B switch
-        if (fullRect && stage) {
-            RowGrid gl = GridForRows(c.gRectSizeMinusOne.x + 1, c.gRectSizeMinusOne.y + 1, TILE_X, LDS_TILE_Y, a.rowBegin, a.rowEnd);
-            LaunchPass(a, (ReblurSpatialKernel<MODE, DIFF, SPEC, NO_TS, PERF, KIND, SH, false, true, true>), gl.grid, dim3(TILE_X * LDS_TILE_Y), c, P, MakeRowRange(gl));
-            return nullptr;
-        }
-    }
     if (fullRect)
-        LaunchPass(a, (ReblurSpatialKernel<MODE, DIFF, SPEC, NO_TS, PERF, KIND, SH, false, true, false>), g.grid, dim3(TILE_X * TILE_Y), c, P, rows);
+        LaunchPass(a, (ReblurSpatialKernel<MODE, DIFF, SPEC, NO_TS, PERF, KIND, SH, false, true>), g.grid, dim3(TILE_X * TILE_Y), c, P, rows);
     else
-        LaunchPass(a, (ReblurSpatialKernel<MODE, DIFF, SPEC, NO_TS, PERF, KIND, SH, false, false, false>), g.grid, dim3(TILE_X * TILE_Y), c, P, rows);
+        LaunchPass(a, (ReblurSpatialKernel<MODE, DIFF, SPEC, NO_TS, PERF, KIND, SH, false, false>), g.grid, dim3(TILE_X * TILE_Y), c, P, rows);
     return nullptr;
 }
 

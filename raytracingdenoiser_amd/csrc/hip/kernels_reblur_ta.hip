@@ -180,10 +180,17 @@ __global__ __launch_bounds__(TILE_X* TILE_Y, WAVES) void ReblurTemporalAccumulat
     // Previous viewZ: 4x4 footprint as four 2x2 quads in (0,0)(1,0)(0,1)(1,1) order
     float2 catromOrigin = GetCatmullRomOrigin(smbPixelUv, rectSizePrev);
     const int cx = (int)catromOrigin.x, cy = (int)catromOrigin.y;
+    const bool footprintInterior = FootprintIsInterior(P.prevViewZ, cx, cy, 4, 4); // the four rows as four 16-byte loads (reblur_device.h "row-vector fetches")
+    float4 smbViewZ0, smbViewZ1, smbViewZ2, smbViewZ3;
+    if (footprintInterior) {
+        const float4 r0 = LoadRowR32Fx4(P.prevViewZ, cx, cy), r1 = LoadRowR32Fx4(P.prevViewZ, cx, cy + 1), r2 = LoadRowR32Fx4(P.prevViewZ, cx, cy + 2), r3 = LoadRowR32Fx4(P.prevViewZ, cx, cy + 3);
+        smbViewZ0 = F4(r0.x, r0.y, r1.x, r1.y), smbViewZ1 = F4(r0.z, r0.w, r1.z, r1.w), smbViewZ2 = F4(r2.x, r2.y, r3.x, r3.y), smbViewZ3 = F4(r2.z, r2.w, r3.z, r3.w);
+    } else {
 #define QUADZ(ox, oy) \
     F4(FetchClampedR32F(P.prevViewZ, cx + ox, cy + oy), FetchClampedR32F(P.prevViewZ, cx + ox + 1, cy + oy), FetchClampedR32F(P.prevViewZ, cx + ox, cy + oy + 1), FetchClampedR32F(P.prevViewZ, cx + ox + 1, cy + oy + 1))
-    float4 smbViewZ0 = QUADZ(0, 0), smbViewZ1 = QUADZ(2, 0), smbViewZ2 = QUADZ(0, 2), smbViewZ3 = QUADZ(2, 2);
+        smbViewZ0 = QUADZ(0, 0), smbViewZ1 = QUADZ(2, 0), smbViewZ2 = QUADZ(0, 2), smbViewZ3 = QUADZ(2, 2);
 #undef QUADZ
+    }
     float3 prevViewZ0 = F3(UnpackViewZ(c, smbViewZ0.y), UnpackViewZ(c, smbViewZ0.z), UnpackViewZ(c, smbViewZ0.w));
     float3 prevViewZ1 = F3(UnpackViewZ(c, smbViewZ1.x), UnpackViewZ(c, smbViewZ1.z), UnpackViewZ(c, smbViewZ1.w));
     float3 prevViewZ2 = F3(UnpackViewZ(c, smbViewZ2.x), UnpackViewZ(c, smbViewZ2.y), UnpackViewZ(c, smbViewZ2.w));
@@ -194,18 +201,28 @@ __global__ __launch_bounds__(TILE_X* TILE_Y, WAVES) void ReblurTemporalAccumulat
     float3 smbNavg;
     {
         int bx = (int)smbBilinearFilter.origin.x, by = (int)smbBilinearFilter.origin.y;
+        uint32_t n00, n10, n01, n11; // packed texels of the 2x2 footprint (0 outside the plane, as Load returns)
+        if (FootprintIsInterior(P.prevNormalRoughness, bx, by, 2, 2)) {
+            LoadRowR32Ux2(P.prevNormalRoughness, bx, by, n00, n10);
+            LoadRowR32Ux2(P.prevNormalRoughness, bx, by + 1, n01, n11);
+        } else {
+            n00 = InBounds(P.prevNormalRoughness, bx, by) ? LoadR32U(P.prevNormalRoughness, bx, by) : 0u;
+            n10 = InBounds(P.prevNormalRoughness, bx + 1, by) ? LoadR32U(P.prevNormalRoughness, bx + 1, by) : 0u;
+            n01 = InBounds(P.prevNormalRoughness, bx, by + 1) ? LoadR32U(P.prevNormalRoughness, bx, by + 1) : 0u;
+            n11 = InBounds(P.prevNormalRoughness, bx + 1, by + 1) ? LoadR32U(P.prevNormalRoughness, bx + 1, by + 1) : 0u;
+        }
         float sumw = 0.0f;
         float w = prevViewZ0.z < c.gDenoisingRange ? 1.0f : 0.0f;
-        smbNavg = Xyz(UnpackNormalAndRoughness(LoadR10G10B10A2OrZero(P.prevNormalRoughness, bx, by))) * w;
+        smbNavg = Xyz(UnpackNormalAndRoughness(DecodeR10G10B10A2(n00))) * w;
         sumw += w;
         w = prevViewZ1.y < c.gDenoisingRange ? 1.0f : 0.0f;
-        smbNavg = smbNavg + Xyz(UnpackNormalAndRoughness(LoadR10G10B10A2OrZero(P.prevNormalRoughness, bx + 1, by))) * w;
+        smbNavg = smbNavg + Xyz(UnpackNormalAndRoughness(DecodeR10G10B10A2(n10))) * w;
         sumw += w;
         w = prevViewZ2.y < c.gDenoisingRange ? 1.0f : 0.0f;
-        smbNavg = smbNavg + Xyz(UnpackNormalAndRoughness(LoadR10G10B10A2OrZero(P.prevNormalRoughness, bx, by + 1))) * w;
+        smbNavg = smbNavg + Xyz(UnpackNormalAndRoughness(DecodeR10G10B10A2(n01))) * w;
         sumw += w;
         w = prevViewZ3.x < c.gDenoisingRange ? 1.0f : 0.0f;
-        smbNavg = smbNavg + Xyz(UnpackNormalAndRoughness(LoadR10G10B10A2OrZero(P.prevNormalRoughness, bx + 1, by + 1))) * w;
+        smbNavg = smbNavg + Xyz(UnpackNormalAndRoughness(DecodeR10G10B10A2(n11))) * w;
         sumw += w;
         smbNavg = smbNavg / (sumw == 0.0f ? 1.0f : sumw);
     }
@@ -254,7 +271,16 @@ __global__ __launch_bounds__(TILE_X* TILE_Y, WAVES) void ReblurTemporalAccumulat
     q[1] = FetchClampedR16U(P.prevInternalData, cx + ox + 1, cy + oy);     \
     q[2] = FetchClampedR16U(P.prevInternalData, cx + ox, cy + oy + 1);     \
     q[3] = FetchClampedR16U(P.prevInternalData, cx + ox + 1, cy + oy + 1);
-    QUADU(id0, 0, 0) QUADU(id1, 2, 0) QUADU(id2, 0, 2) QUADU(id3, 2, 2)
+    if (footprintInterior) { // same geometry as the prev-viewZ footprint (launcher: same plane size): four 8-byte row loads
+        uint32_t r0[4], r1[4], r2[4], r3[4];
+        LoadRowR16Ux4(P.prevInternalData, cx, cy, r0), LoadRowR16Ux4(P.prevInternalData, cx, cy + 1, r1), LoadRowR16Ux4(P.prevInternalData, cx, cy + 2, r2), LoadRowR16Ux4(P.prevInternalData, cx, cy + 3, r3);
+        id0[0] = r0[0], id0[1] = r0[1], id0[2] = r1[0], id0[3] = r1[1];
+        id1[0] = r0[2], id1[1] = r0[3], id1[2] = r1[2], id1[3] = r1[3];
+        id2[0] = r2[0], id2[1] = r2[1], id2[2] = r3[0], id2[3] = r3[1];
+        id3[0] = r2[2], id3[1] = r2[3], id3[2] = r3[2], id3[3] = r3[3];
+    } else {
+        QUADU(id0, 0, 0) QUADU(id1, 2, 0) QUADU(id2, 0, 2) QUADU(id3, 2, 2)
+    }
 #undef QUADU
     float minMaterialID = Min(c.gSpecMinMaterial, c.gDiffMinMaterial);
 #define MATCMP(p) (CompareMaterials(materialID, UnpackInternalData(p).z, minMaterialID) ? 1.0f : 0.0f)
@@ -472,8 +498,17 @@ __global__ __launch_bounds__(TILE_X* TILE_Y, WAVES) void ReblurTemporalAccumulat
         Bilinear vmbBilinearFilter = GetBilinearFilter(vmbPixelUv, rectSizePrev);
         const int vx = (int)vmbBilinearFilter.origin.x, vy = (int)vmbBilinearFilter.origin.y;
         float2 relaxedRoughnessWeightParams = GetRelaxedRoughnessWeightParams(roughness * roughness, c.gRoughnessFraction, REBLUR_ROUGHNESS_SENSITIVITY_IN_TA);
-        float4 vmbRoughness = F4(FetchClampedR10G10B10A2(P.prevNormalRoughness, vx, vy).z, FetchClampedR10G10B10A2(P.prevNormalRoughness, vx + 1, vy).z,
-            FetchClampedR10G10B10A2(P.prevNormalRoughness, vx, vy + 1).z, FetchClampedR10G10B10A2(P.prevNormalRoughness, vx + 1, vy + 1).z);
+        const bool vmbInterior = FootprintIsInterior(P.prevViewZ, vx, vy, 2, 2); // one test for the three planes of this footprint (same size)
+        float4 vmbRoughness;
+        if (vmbInterior) {
+            uint32_t q00, q10, q01, q11;
+            LoadRowR32Ux2(P.prevNormalRoughness, vx, vy, q00, q10);
+            LoadRowR32Ux2(P.prevNormalRoughness, vx, vy + 1, q01, q11);
+            vmbRoughness = F4(DecodeR10G10B10A2(q00).z, DecodeR10G10B10A2(q10).z, DecodeR10G10B10A2(q01).z, DecodeR10G10B10A2(q11).z);
+        } else {
+            vmbRoughness = F4(FetchClampedR10G10B10A2(P.prevNormalRoughness, vx, vy).z, FetchClampedR10G10B10A2(P.prevNormalRoughness, vx + 1, vy).z,
+                FetchClampedR10G10B10A2(P.prevNormalRoughness, vx, vy + 1).z, FetchClampedR10G10B10A2(P.prevNormalRoughness, vx + 1, vy + 1).z);
+        }
         float4 roughnessWeight;
         roughnessWeight.x = ComputeNonExponentialWeightWithSigma(vmbRoughness.x * vmbRoughness.x, relaxedRoughnessWeightParams.x, relaxedRoughnessWeightParams.y, roughnessSigma);
         roughnessWeight.y = ComputeNonExponentialWeightWithSigma(vmbRoughness.y * vmbRoughness.y, relaxedRoughnessWeightParams.x, relaxedRoughnessWeightParams.y, roughnessSigma);
@@ -512,8 +547,14 @@ __global__ __launch_bounds__(TILE_X* TILE_Y, WAVES) void ReblurTemporalAccumulat
             vmbOcclusionThreshold = vmbOcclusionThreshold * IsInScreenBilinear(vmbBilinearFilter.origin, rectSizePrev);
             vmbOcclusionThreshold = vmbOcclusionThreshold - NRD_EPS;
 
-            float4 vmbViewZ = F4(UnpackViewZ(c, FetchClampedR32F(P.prevViewZ, vx, vy)), UnpackViewZ(c, FetchClampedR32F(P.prevViewZ, vx + 1, vy)),
-                UnpackViewZ(c, FetchClampedR32F(P.prevViewZ, vx, vy + 1)), UnpackViewZ(c, FetchClampedR32F(P.prevViewZ, vx + 1, vy + 1)));
+            float4 vmbViewZ;
+            if (vmbInterior) {
+                const float2 z0 = LoadRowR32Fx2(P.prevViewZ, vx, vy), z1 = LoadRowR32Fx2(P.prevViewZ, vx, vy + 1);
+                vmbViewZ = F4(UnpackViewZ(c, z0.x), UnpackViewZ(c, z0.y), UnpackViewZ(c, z1.x), UnpackViewZ(c, z1.y));
+            } else {
+                vmbViewZ = F4(UnpackViewZ(c, FetchClampedR32F(P.prevViewZ, vx, vy)), UnpackViewZ(c, FetchClampedR32F(P.prevViewZ, vx + 1, vy)),
+                    UnpackViewZ(c, FetchClampedR32F(P.prevViewZ, vx, vy + 1)), UnpackViewZ(c, FetchClampedR32F(P.prevViewZ, vx + 1, vy + 1)));
+            }
             float3 vmbVv = ReconstructViewPosition(vmbPixelUv, frustumPrev, 1.0f, 0.0f);
             float3 vmbV = RotateVectorInverse(c.gWorldToViewPrev, vmbVv);
             float NoXcurr = Dot(N, Xprev - cameraDelta);
@@ -525,10 +566,18 @@ __global__ __launch_bounds__(TILE_X* TILE_Y, WAVES) void ReblurTemporalAccumulat
         }
 
         // Virtual motion - disocclusion: materialID
-        float3 vmbInternalData00 = UnpackInternalData(FetchClampedR16U(P.prevInternalData, vx, vy));
-        float3 vmbInternalData10 = UnpackInternalData(FetchClampedR16U(P.prevInternalData, vx + 1, vy));
-        float3 vmbInternalData01 = UnpackInternalData(FetchClampedR16U(P.prevInternalData, vx, vy + 1));
-        float3 vmbInternalData11 = UnpackInternalData(FetchClampedR16U(P.prevInternalData, vx + 1, vy + 1));
+        uint32_t vmbId00, vmbId10, vmbId01, vmbId11;
+        if (vmbInterior) {
+            LoadRowR16Ux2(P.prevInternalData, vx, vy, vmbId00, vmbId10);
+            LoadRowR16Ux2(P.prevInternalData, vx, vy + 1, vmbId01, vmbId11);
+        } else {
+            vmbId00 = FetchClampedR16U(P.prevInternalData, vx, vy), vmbId10 = FetchClampedR16U(P.prevInternalData, vx + 1, vy);
+            vmbId01 = FetchClampedR16U(P.prevInternalData, vx, vy + 1), vmbId11 = FetchClampedR16U(P.prevInternalData, vx + 1, vy + 1);
+        }
+        float3 vmbInternalData00 = UnpackInternalData(vmbId00);
+        float3 vmbInternalData10 = UnpackInternalData(vmbId10);
+        float3 vmbInternalData01 = UnpackInternalData(vmbId01);
+        float3 vmbInternalData11 = UnpackInternalData(vmbId11);
         vmbOcclusion.x *= CompareMaterials(materialID, vmbInternalData00.z, c.gSpecMinMaterial) ? 1.0f : 0.0f;
         vmbOcclusion.y *= CompareMaterials(materialID, vmbInternalData10.z, c.gSpecMinMaterial) ? 1.0f : 0.0f;
         vmbOcclusion.z *= CompareMaterials(materialID, vmbInternalData01.z, c.gSpecMinMaterial) ? 1.0f : 0.0f;

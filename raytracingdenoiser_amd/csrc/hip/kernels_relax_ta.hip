@@ -194,10 +194,26 @@ __global__ __launch_bounds__(256, 3) void RelaxTemporalAccumulationKernel(RelaxC
 
         const float prevViewPosZ = AffineTransform(c.shared.gWorldToViewPrev, prevWorldPos).z;
         const float minMaterialID = Min(c.shared.gSpecMinMaterial, c.shared.gDiffMinMaterial);
+        // The 12 previous-depth taps (rows of 2 + 4 + 4 + 2 texels around the bilinear origin): four row loads when no coordinate needs clamping
+        // (reblur_device.h "row-vector fetches"), and no material reads at all while the material test is off (IDs are 0..3: a minimum >= 3 makes every
+        // comparison hold; the library default is 4).
+        const bool compareMaterials = minMaterialID < 3.0f;
+        float zRows[4][4];
+        const bool footprintInterior = FootprintIsInterior(P.prevViewZ, bx - 1, by - 1, 4, 4);
+        if (footprintInterior) {
+            const float2 r0 = LoadRowR32Fx2(P.prevViewZ, bx, by - 1), r3 = LoadRowR32Fx2(P.prevViewZ, bx, by + 2);
+            const float4 r1 = LoadRowR32Fx4(P.prevViewZ, bx - 1, by), r2 = LoadRowR32Fx4(P.prevViewZ, bx - 1, by + 1);
+            zRows[0][1] = r0.x, zRows[0][2] = r0.y, zRows[3][1] = r3.x, zRows[3][2] = r3.y;
+            zRows[1][0] = r1.x, zRows[1][1] = r1.y, zRows[1][2] = r1.z, zRows[1][3] = r1.w;
+            zRows[2][0] = r2.x, zRows[2][1] = r2.y, zRows[2][2] = r2.z, zRows[2][3] = r2.w;
+            zRows[0][0] = zRows[0][3] = zRows[3][0] = zRows[3][3] = 0.0f;
+        }
         auto Valid = [&](int dx, int dy, float threshold) {
-            float z = RelaxUnpackViewZ(c, FetchClampedR32F(P.prevViewZ, bx + dx, by + dy));
-            float m = FetchClampedR8Unorm(P.prevMaterialID, bx + dx, by + dy) * 255.0f;
+            float z = RelaxUnpackViewZ(c, footprintInterior ? zRows[dy + 1][dx + 1] : FetchClampedR32F(P.prevViewZ, bx + dx, by + dy));
             float v = Step(Abs(z - prevViewPosZ), threshold);
+            if (!compareMaterials)
+                return v;
+            float m = FetchClampedR8Unorm(P.prevMaterialID, bx + dx, by + dy) * 255.0f;
             return v * Cmp(CompareMaterials(currentMaterialID, m, minMaterialID));
         };
         const float3 tapsValid0 = F3(Valid(0, -1, smbDisocclusionThreshold.x), Valid(-1, 0, smbDisocclusionThreshold.x), Valid(0, 0, smbDisocclusionThreshold.x));
@@ -401,12 +417,21 @@ __global__ __launch_bounds__(256, 3) void RelaxTemporalAccumulationKernel(RelaxC
             vmbDisocclusionThreshold = vmbDisocclusionThreshold * IsInScreenBilinear(originF, rectSizePrev);
             vmbDisocclusionThreshold = vmbDisocclusionThreshold - NRD_EPS;
 
+            const bool compareSpecMaterials = c.shared.gSpecMinMaterial < 3.0f;
+            float zQuad[2][2];
+            const bool quadInterior = FootprintIsInterior(P.prevViewZ, bx, by, 2, 2);
+            if (quadInterior) {
+                const float2 r0 = LoadRowR32Fx2(P.prevViewZ, bx, by), r1 = LoadRowR32Fx2(P.prevViewZ, bx, by + 1);
+                zQuad[0][0] = r0.x, zQuad[0][1] = r0.y, zQuad[1][0] = r1.x, zQuad[1][1] = r1.y;
+            }
             auto TapValid = [&](int dx, int dy, float threshold) {
-                float z = RelaxUnpackViewZ(c, FetchClampedR32F(P.prevViewZ, bx + dx, by + dy));
+                float z = RelaxUnpackViewZ(c, quadInterior ? zQuad[dy][dx] : FetchClampedR32F(P.prevViewZ, bx + dx, by + dy));
                 float3 prevWorldPosInTap = GetPreviousWorldPosFromPixelPos(c, bx + dx, by + dy, z);
                 float3 posDiff = currentWorldPosShifted - prevWorldPosInTap;
                 float maxPlaneDistance = Abs(Dot(posDiff, currentNormal));
                 float valid = maxPlaneDistance > threshold ? 0.0f : 1.0f;
+                if (!compareSpecMaterials)
+                    return valid;
                 float m = FetchClampedR8Unorm(P.prevMaterialID, bx + dx, by + dy) * 255.0f;
                 return valid * Cmp(CompareMaterials(currentMaterialID, m, c.shared.gSpecMinMaterial));
             };

@@ -48,9 +48,9 @@ struct PassArgs {
     // executor-internal guide plane of the RELAX lists (float4 per pixel: world position, viewZ), written together with the decoded normals once
     // per frame; read by the taps of the pre-pass and of the a-trous iterations; same layout as decodedNormalRoughness; ptr == nullptr outside RELAX lists
     Plane worldPosViewZ;
-    // executor-internal guide plane of the REBLUR lists (float4 per pixel: view-space position Xv.x, Xv.y, viewZ = |z * gViewZScale|, material ID), written
-    // together with the decoded normals once per frame; same pitch / size as decodedNormalRoughness, so one texel offset serves both. With it a tap of
-    // the spatial passes is two 16-byte loads and no per-tap position reconstruction. ptr == nullptr outside REBLUR lists.
+    // executor-internal guide plane of the REBLUR lists (float4 per pixel: decoded normal, viewZ = |z * gViewZScale|), written together with the decoded
+    // normals once per frame; same pitch / size as decodedNormalRoughness, so one texel offset serves both. With it a diffuse tap of the spatial passes
+    // reads its guides in one 16-byte load. ptr == nullptr outside REBLUR lists.
     Plane viewPos;
     // non-null: the launcher performs all its checks and hands its launch(es) to the recorder instead of enqueueing them
     LaunchRecorder* recorder = nullptr;

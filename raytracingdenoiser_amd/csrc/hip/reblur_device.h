@@ -338,6 +338,37 @@ NRD_D float4 LoadRGBA16FOrZero(const Plane& p, int x, int y) { return InBounds(p
 NRD_D float LoadR16FOrZero(const Plane& p, int x, int y) { return InBounds(p, x, y) ? LoadR16F(p, x, y) : 0.0f; }
 NRD_D float4 LoadR10G10B10A2OrZero(const Plane& p, int x, int y) { return InBounds(p, x, y) ? LoadR10G10B10A2(p, x, y) : F4(0.0f); }
 
+// ---- row-vector fetches of small footprints ----------------------------------------------------------------------------------------
+// The temporal passes read 2x2 and 4x4 texel footprints at data-dependent positions. One load instruction per texel costs the L1 / address path as much
+// as a 16-byte one (profiles/r02_c_gather_bench.txt), so an INTERIOR footprint (no coordinate needs clamping) is fetched row by row with one vector load
+// per row: gfx950 takes dwordx2 / dwordx4 loads at any element-aligned address. Footprints that touch the border keep the per-texel clamped loads.
+struct alignas(4) F32x4U { float v[4]; };
+struct alignas(4) F32x2U { float v[2]; };
+struct alignas(4) U32x2U { uint32_t v[2]; };
+struct alignas(2) U16x4U { uint16_t v[4]; };
+struct alignas(2) U16x2U { uint16_t v[2]; };
+NRD_D bool FootprintIsInterior(const Plane& p, int x, int y, int nx, int ny) { return x >= 0 && y >= 0 && x + nx <= p.w && y + ny <= p.h; }
+NRD_D float4 LoadRowR32Fx4(const Plane& p, int x, int y) {
+    const F32x4U r = *(const F32x4U*)TexelPtr<const float>(p, x, y);
+    return F4(r.v[0], r.v[1], r.v[2], r.v[3]);
+}
+NRD_D float2 LoadRowR32Fx2(const Plane& p, int x, int y) {
+    const F32x2U r = *(const F32x2U*)TexelPtr<const float>(p, x, y);
+    return F2(r.v[0], r.v[1]);
+}
+NRD_D void LoadRowR32Ux2(const Plane& p, int x, int y, uint32_t& a, uint32_t& b) {
+    const U32x2U r = *(const U32x2U*)TexelPtr<const uint32_t>(p, x, y);
+    a = r.v[0], b = r.v[1];
+}
+NRD_D void LoadRowR16Ux4(const Plane& p, int x, int y, uint32_t* out) {
+    const U16x4U r = *(const U16x4U*)TexelPtr<const uint16_t>(p, x, y);
+    out[0] = r.v[0], out[1] = r.v[1], out[2] = r.v[2], out[3] = r.v[3];
+}
+NRD_D void LoadRowR16Ux2(const Plane& p, int x, int y, uint32_t& a, uint32_t& b) {
+    const U16x2U r = *(const U16x2U*)TexelPtr<const uint16_t>(p, x, y);
+    a = r.v[0], b = r.v[1];
+}
+
 // SampleLevel( gNearestClamp, uv, 0 ): texel index
 NRD_D int2 NearestTexel(const Plane& p, float2 uv) {
     return make_int2(ClampI((int)floorf(uv.x * float(p.w)), 0, p.w - 1), ClampI((int)floorf(uv.y * float(p.h)), 0, p.h - 1));
@@ -369,7 +400,15 @@ NRD_D float4 SampleLinearRGBA16F(const Plane& p, float2 pos) {
 }
 NRD_D float SampleLinearR16F(const Plane& p, float2 pos) {
     LinearTaps t = MakeLinearTaps(pos);
-    float s00 = FetchClampedR16F(p, t.x0, t.y0), s10 = FetchClampedR16F(p, t.x0 + 1, t.y0), s01 = FetchClampedR16F(p, t.x0, t.y0 + 1), s11 = FetchClampedR16F(p, t.x0 + 1, t.y0 + 1);
+    float s00, s10, s01, s11;
+    if (FootprintIsInterior(p, t.x0, t.y0, 2, 2)) {
+        uint32_t a, b, c2, d;
+        LoadRowR16Ux2(p, t.x0, t.y0, a, b);
+        LoadRowR16Ux2(p, t.x0, t.y0 + 1, c2, d);
+        s00 = HalfBitsToFloat((uint16_t)a), s10 = HalfBitsToFloat((uint16_t)b), s01 = HalfBitsToFloat((uint16_t)c2), s11 = HalfBitsToFloat((uint16_t)d);
+    } else {
+        s00 = FetchClampedR16F(p, t.x0, t.y0), s10 = FetchClampedR16F(p, t.x0 + 1, t.y0), s01 = FetchClampedR16F(p, t.x0, t.y0 + 1), s11 = FetchClampedR16F(p, t.x0 + 1, t.y0 + 1);
+    }
     return s00 * t.w00 + s10 * t.w10 + s01 * t.w01 + s11 * t.w11;
 }
 
@@ -483,7 +522,29 @@ NRD_D float4 FetchHistoryRGBA16F(const HistoryFilter& h, const Plane& tex) {
     return h.sum < 0.0001f ? F4(0.0f) : color / h.sum;
 }
 NRD_D float FetchHistoryR16F(const HistoryFilter& h, const Plane& tex) {
-    return FetchHistoryGeneric<float>(h, tex, [](const Plane& p, int x, int y) { return LoadR16F(p, x, y); }, 0.0f);
+    // interior bicubic footprint: the 12 texels are rows of 2 + 4 + 4 + 2 -> four row loads (4 / 8 / 8 / 4 bytes) instead of twelve 2-byte ones
+    const bool interior = h.x[3] - h.x[0] == 3 && h.y[3] - h.y[0] == 3;
+    if (!(interior && h.useBicubic))
+        return FetchHistoryGeneric<float>(h, tex, [](const Plane& p, int x, int y) { return LoadR16F(p, x, y); }, 0.0f);
+    uint32_t a0, a1, b[4], c2[4], d0, d1;
+    LoadRowR16Ux2(tex, h.x[1], h.y[0], a0, a1);
+    LoadRowR16Ux4(tex, h.x[0], h.y[1], b);
+    LoadRowR16Ux4(tex, h.x[0], h.y[2], c2);
+    LoadRowR16Ux2(tex, h.x[1], h.y[3], d0, d1);
+#define NRD_H(v) HalfBitsToFloat((uint16_t)(v))
+    const float fx = h.tc.x, fy = h.tc.y, gx = 1.0f - fx, gy = 1.0f - fy;
+    float s0 = NRD_H(a0) * gx + NRD_H(a1) * fx;
+    float s1 = NRD_H(b[0]) * gy + NRD_H(c2[0]) * fy;
+    float s2 = NRD_H(b[1]) * (gx * gy) + NRD_H(b[2]) * (fx * gy) + NRD_H(c2[1]) * (gx * fy) + NRD_H(c2[2]) * (fx * fy);
+    float s3 = NRD_H(b[3]) * gy + NRD_H(c2[3]) * fy;
+    float s4 = NRD_H(d0) * gx + NRD_H(d1) * fx;
+#undef NRD_H
+    float color = s0 * h.w.x;
+    color = color + s1 * h.w.y;
+    color = color + s2 * h.w.z;
+    color = color + s3 * h.w.w;
+    color = color + s4 * h.w4;
+    return h.sum < 0.0001f ? 0.0f : color / h.sum;
 }
 // custom-weight bilinear fetch of an RGBA16F plane (the SH1 histories; reference REBLUR_Common.hlsli:350-361 fetches them this way)
 NRD_D float4 FetchHistoryBilinearRGBA16F(const HistoryFilter& h, const Plane& tex) {
@@ -496,10 +557,19 @@ NRD_D float4 FetchHistoryBilinearRGBA16F(const HistoryFilter& h, const Plane& te
     return s < 0.0001f ? F4(0.0f) : color / s;
 }
 NRD_D float FetchHistoryBilinearR16F(const HistoryFilter& h, const Plane& tex) {
-    float color = LoadR16FOrZero(tex, h.ox, h.oy) * h.bw.x;
-    color += LoadR16FOrZero(tex, h.ox + 1, h.oy) * h.bw.y;
-    color += LoadR16FOrZero(tex, h.ox, h.oy + 1) * h.bw.z;
-    color += LoadR16FOrZero(tex, h.ox + 1, h.oy + 1) * h.bw.w;
+    float s00, s10, s01, s11;
+    if (FootprintIsInterior(tex, h.ox, h.oy, 2, 2)) { // two 4-byte row loads instead of four 2-byte ones (same texels)
+        uint32_t a, b, c2, d;
+        LoadRowR16Ux2(tex, h.ox, h.oy, a, b);
+        LoadRowR16Ux2(tex, h.ox, h.oy + 1, c2, d);
+        s00 = HalfBitsToFloat((uint16_t)a), s10 = HalfBitsToFloat((uint16_t)b), s01 = HalfBitsToFloat((uint16_t)c2), s11 = HalfBitsToFloat((uint16_t)d);
+    } else {
+        s00 = LoadR16FOrZero(tex, h.ox, h.oy), s10 = LoadR16FOrZero(tex, h.ox + 1, h.oy), s01 = LoadR16FOrZero(tex, h.ox, h.oy + 1), s11 = LoadR16FOrZero(tex, h.ox + 1, h.oy + 1);
+    }
+    float color = s00 * h.bw.x;
+    color += s10 * h.bw.y;
+    color += s01 * h.bw.z;
+    color += s11 * h.bw.w;
     float s = Sum(h.bw);
     return s < 0.0001f ? 0.0f : color / s;
 }

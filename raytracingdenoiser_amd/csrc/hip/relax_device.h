@@ -106,10 +106,17 @@ NRD_D float BilinearWithCustomWeightsImmediateFloat(float s00, float s10, float 
     return sumWeights < 0.0001f ? 0.0f : o * Rcp(sumWeights);
 }
 NRD_D float4 BilinearWithCustomWeightsRGBA16F(const Plane& tex, int ox, int oy, float4 w) {
-    float4 o = LoadRGBA16FOrZero(tex, ox, oy) * w.x;
-    o = o + LoadRGBA16FOrZero(tex, ox + 1, oy) * w.y;
-    o = o + LoadRGBA16FOrZero(tex, ox, oy + 1) * w.z;
-    o = o + LoadRGBA16FOrZero(tex, ox + 1, oy + 1) * w.w;
+    float4 s00, s10, s01, s11;
+    if (FootprintIsInterior(tex, ox, oy, 2, 2)) { // two 16-byte row loads instead of four 8-byte ones (same texels)
+        LoadRGBA16Fx2(tex, ox, oy, s00, s10);
+        LoadRGBA16Fx2(tex, ox, oy + 1, s01, s11);
+    } else {
+        s00 = LoadRGBA16FOrZero(tex, ox, oy), s10 = LoadRGBA16FOrZero(tex, ox + 1, oy), s01 = LoadRGBA16FOrZero(tex, ox, oy + 1), s11 = LoadRGBA16FOrZero(tex, ox + 1, oy + 1);
+    }
+    float4 o = s00 * w.x;
+    o = o + s10 * w.y;
+    o = o + s01 * w.z;
+    o = o + s11 * w.w;
     float sumWeights = Sum(w);
     return sumWeights < 0.0001f ? F4(0.0f) : o * Rcp(sumWeights);
 }
