@@ -104,13 +104,55 @@ class OracleExecutor:
         pitch = arr.strides[0]
         return OraclePlane(arr.ctypes.data, pitch, int(fmt), w, h)
 
-    def execute(self, dispatches):
+    # byte offsets of (gRectOrigin, gRectOffset) in the shared constant blocks and their sizes (reference REBLUR / RELAX / SIGMA _SHARED_CONSTANTS)
+    _ORIGIN_FIELDS = {"REBLUR_": (648, 616, 832), "RELAX_": (472, 416, 704), "SIGMA_": (448, 432, 516)}
+    _GUIDE_INPUTS = ("IN_MV", "IN_NORMAL_ROUGHNESS", "IN_VIEWZ", "IN_DIFF_CONFIDENCE", "IN_SPEC_CONFIDENCE", "IN_DISOCCLUSION_THRESHOLD_MIX", "IN_BASECOLOR_METALNESS")
+
+    def _rect_origin(self, dispatches):
+        import struct
+
         for d in dispatches:
-            planes = (OraclePlane * len(d.resources))(*[self._plane(r) for r in d.resources])
-            buf = C.create_string_buffer(d.constants, len(d.constants)) if d.constants else None
-            rc = self.lib.oracle_dispatch(d.shader.encode(), buf, len(d.constants), planes, len(d.resources))
-            if rc != 0:
-                raise RuntimeError("oracle has no pass '%s'" % d.shader)
+            for prefix, (origin, _, size) in self._ORIGIN_FIELDS.items():
+                if d.shader.startswith(prefix) and len(d.constants) >= size:
+                    return struct.unpack_from("<II", d.constants, origin)
+        return 0, 0
+
+    def execute(self, dispatches):
+        # CommonSettings::rectOrigin: the reference addresses its guide inputs at rectOrigin + pixel (Common.hlsli:200-206 and the WithRectOrigin /
+        # WithRectOffset call sites) and nothing else. As in the HIP executor, the passes are handed rect-at-origin copies of those inputs and constant
+        # blocks whose gRectOrigin / gRectOffset are zero.
+        ox, oy = self._rect_origin(dispatches)
+        saved = {}
+        if ox or oy:
+            guide = {int(getattr(self.api.ResourceType, n)) for n in self._GUIDE_INPUTS}
+            for key in [k for k in self.user if k in guide]:
+                arr, fmt, w, h = self.user[key]
+                twin = np.zeros_like(arr)
+                twin[: arr.shape[0] - oy, : arr.shape[1] - ox] = arr[oy:, ox:]
+                saved[key] = self.user[key]
+                self.user[key] = (twin, fmt, w, h)
+        try:
+            for d in dispatches:
+                planes = (OraclePlane * len(d.resources))(*[self._plane(r) for r in d.resources])
+                constants = d.constants
+                if (ox or oy) and constants:
+                    for prefix, (origin, offset, size) in self._ORIGIN_FIELDS.items():
+                        if d.shader.startswith(prefix) and len(constants) >= size:
+                            b = bytearray(constants)
+                            b[origin:origin + 8] = bytes(8)
+                            b[offset:offset + 8] = bytes(8)
+                            constants = bytes(b)
+                buf = C.create_string_buffer(constants, len(constants)) if constants else None
+                rc = self.lib.oracle_dispatch(d.shader.encode(), buf, len(constants), planes, len(d.resources))
+                if rc != 0:
+                    raise RuntimeError("oracle has no pass '%s'" % d.shader)
+        finally:
+            mv = int(self.api.ResourceType.IN_MV)
+            for key, original in saved.items():
+                if key == mv:  # in/out plane: REBLUR's specular MV modification writes it
+                    arr, twin = original[0], self.user[key][0]
+                    arr[oy:, ox:] = twin[: arr.shape[0] - oy, : arr.shape[1] - ox]
+                self.user[key] = original
 
     def pool_plane(self, pool, index):
         arr, fmt, w, _ = self.pools[pool][index]

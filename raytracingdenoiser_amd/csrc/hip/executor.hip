@@ -100,6 +100,10 @@ struct NrdHipExecutor {
 
     Plane user[(size_t)nrd::ResourceType::MAX_NUM] = {};
     bool userBound[(size_t)nrd::ResourceType::MAX_NUM] = {};
+    // CommonSettings::rectOrigin != 0: rect-at-origin copies of the guide inputs (kernels_common.hip "shifted rect"); own allocations, made on demand
+    Plane shifted[(size_t)nrd::ResourceType::MAX_NUM] = {};
+    int originX = 0, originY = 0;   // origin of the list being executed
+    std::vector<std::vector<uint8_t>> patchedConstants; // per dispatch of the range: the constant block with gRectOrigin / gRectOffset zeroed
 
     std::vector<PassLauncher> launchers; // per pipeline index (nullptr = pass not implemented in this build)
     std::vector<Plane> scratchPlanes;
@@ -267,6 +271,9 @@ extern "C" __attribute__((visibility("default"))) void nrdHipDestroyExecutor(Nrd
         (void)hipFree(e->worldPosViewZ.ptr);
     if (e->viewPos.ptr)
         (void)hipFree(e->viewPos.ptr);
+    for (Plane& p : e->shifted)
+        if (p.ptr)
+            (void)hipFree(p.ptr);
     delete e;
 }
 
@@ -624,6 +631,29 @@ extern "C" __attribute__((visibility("default"))) uint32_t nrdHipExecuteDispatch
     return ExecuteRange(e, descs, dispatchDescsNum, 0, dispatchDescsNum, rowBegin.data(), rowEnd.data());
 }
 
+// the inputs the reference addresses at rectOrigin + pixel (Common.hlsli WithRectOrigin / WithRectOffset call sites)
+static bool IsGuideInput(nrd::ResourceType t) {
+    using R = nrd::ResourceType;
+    return t == R::IN_MV || t == R::IN_NORMAL_ROUGHNESS || t == R::IN_VIEWZ || t == R::IN_DIFF_CONFIDENCE || t == R::IN_SPEC_CONFIDENCE || t == R::IN_DISOCCLUSION_THRESHOLD_MIX ||
+           t == R::IN_BASECOLOR_METALNESS;
+}
+// byte offsets of gRectOrigin (uint2) and gRectOffset (float2) in the shared constant block of a pass family, by shader name; false = the family has none
+static bool RectOriginOffsets(const char* shader, uint32_t size, size_t& origin, size_t& offset) {
+    if (!strncmp(shader, "REBLUR_", 7) && size >= sizeof(nrdc::ReblurConstants)) {
+        origin = offsetof(nrdc::ReblurConstants, gRectOrigin), offset = offsetof(nrdc::ReblurConstants, gRectOffset);
+        return true;
+    }
+    if (!strncmp(shader, "RELAX_", 6) && size >= sizeof(nrdc::RelaxConstants)) {
+        origin = offsetof(nrdc::RelaxConstants, gRectOrigin), offset = offsetof(nrdc::RelaxConstants, gRectOffset);
+        return true;
+    }
+    if (!strncmp(shader, "SIGMA_", 6) && size >= sizeof(nrdc::SigmaConstants)) {
+        origin = offsetof(nrdc::SigmaConstants, gRectOrigin), offset = offsetof(nrdc::SigmaConstants, gRectOffset);
+        return true;
+    }
+    return false;
+}
+
 // Resolves the resources of dispatch i and fills the launcher arguments (no launch). Returns nullptr or an error text.
 static const char* PrepareDispatch(NrdHipExecutor* e, const nrd::DispatchDesc& d, PassArgs& args, std::string& err) {
     e->scratchPlanes.resize(d.resourcesNum);
@@ -649,7 +679,7 @@ static const char* PrepareDispatch(NrdHipExecutor* e, const nrd::DispatchDesc& d
                 err = std::string("resource not bound: ") + (nrd::GetResourceTypeString(res.type) ? nrd::GetResourceTypeString(res.type) : "?");
                 return err.c_str();
             }
-            e->scratchPlanes[r] = e->user[t];
+            e->scratchPlanes[r] = (e->originX || e->originY) && IsGuideInput(res.type) && e->shifted[t].ptr ? e->shifted[t] : e->user[t];
             e->scratchBytesPerTexel[r] = (uint8_t)BytesPerTexel(ExpectedUserFormat(res.type, e->translucentShadow));
             e->scratchFormats[r] = (uint8_t)ExpectedUserFormat(res.type, e->translucentShadow);
         }
@@ -750,6 +780,52 @@ static uint32_t LaunchAsGraph(NrdHipExecutor* e, std::vector<LaunchRecord>& reco
 
 static uint32_t ExecuteRange(NrdHipExecutor* e, const nrd::DispatchDesc* descs, uint32_t dispatchDescsNum, uint32_t first, uint32_t count, const int32_t* rowBegin, const int32_t* rowEnd) {
     const nrd::InstanceDesc& idesc = nrd::GetInstanceDesc(*e->instance);
+    // ---- shifted rect: rect-at-origin copies of the guide inputs this list binds (kernels_common.hip "shifted rect")
+    e->originX = e->originY = 0;
+    for (uint32_t i = 0; i < dispatchDescsNum; i++) {
+        size_t oo, of;
+        if (descs[i].pipelineIndex < idesc.pipelinesNum && descs[i].constantBufferData &&
+            RectOriginOffsets(idesc.pipelines[descs[i].pipelineIndex].shaderFileName, descs[i].constantBufferDataSize, oo, of)) {
+            const uint32_t* o = (const uint32_t*)((const uint8_t*)descs[i].constantBufferData + oo);
+            e->originX = (int)o[0], e->originY = (int)o[1];
+            break;
+        }
+    }
+    const bool shiftedRect = e->originX != 0 || e->originY != 0;
+    std::vector<uint32_t> shiftTypes; // guide slots of this list that get a rect-at-origin twin
+    bool writesMv = false;
+    if (shiftedRect) {
+        for (uint32_t i = 0; i < dispatchDescsNum; i++)
+            for (uint32_t r = 0; r < descs[i].resourcesNum; r++) {
+                const nrd::ResourceDesc& res = descs[i].resources[r];
+                const uint32_t t = (uint32_t)res.type;
+                if (!IsGuideInput(res.type) || t >= (uint32_t)nrd::ResourceType::MAX_NUM || !e->userBound[t])
+                    continue;
+                writesMv = writesMv || (res.type == nrd::ResourceType::IN_MV && res.descriptorType == nrd::DescriptorType::STORAGE_TEXTURE);
+                bool known = false;
+                for (uint32_t k : shiftTypes)
+                    known = known || k == t;
+                if (known)
+                    continue;
+                if (e->originX >= e->user[t].w || e->originY >= e->user[t].h)
+                    return e->Fail(nrd::Result::INVALID_ARGUMENT, "CommonSettings::rectOrigin lies outside the bound planes; nothing was launched");
+                Plane& twin = e->shifted[t];
+                const Plane& src = e->user[t];
+                if (!twin.ptr || twin.w != src.w || twin.h != src.h || twin.pitch != src.pitch) {
+                    if (twin.ptr)
+                        (void)hipFree(twin.ptr);
+                    twin = src;
+                    twin.ptr = nullptr;
+                    if (hipMalloc((void**)&twin.ptr, (size_t)twin.pitch * (size_t)twin.h) != hipSuccess)
+                        return e->Fail(nrd::Result::FAILURE, "nrdHipExecuteDispatches: cannot allocate a shifted-rect guide plane");
+                    (void)hipMemsetAsync(twin.ptr, 0, (size_t)twin.pitch * (size_t)twin.h, e->stream);
+                    e->decodedFresh = false;
+                }
+                shiftTypes.push_back(t);
+            }
+    }
+    auto guidePlane = [&](nrd::ResourceType t) -> const Plane& { return shiftedRect && e->shifted[(uint32_t)t].ptr ? e->shifted[(uint32_t)t] : e->user[(uint32_t)t]; };
+
     // Decoded-guide cache: if any dispatch reads IN_NORMAL_ROUGHNESS, the bound plane is decoded once for the whole list
     Plane decoded = {};
     bool decodeNow = false;
@@ -783,8 +859,8 @@ static uint32_t ExecuteRange(NrdHipExecutor* e, const nrd::DispatchDesc* descs, 
     // View-position guide plane of the REBLUR lists (same geometry again): needs IN_VIEWZ and the frame's REBLUR constants
     Plane viewPos = {};
     const void* reblurConstants = nullptr;
-    static const bool guidePlane = !(getenv("NRD_HIP_GUIDE_NZ") && atoi(getenv("NRD_HIP_GUIDE_NZ")) == 0); // A/B switch
-    if (decoded.ptr && e->userBound[(uint32_t)nrd::ResourceType::IN_VIEWZ] && guidePlane) {
+    static const bool guideNz = !(getenv("NRD_HIP_GUIDE_NZ") && atoi(getenv("NRD_HIP_GUIDE_NZ")) == 0); // A/B switch
+    if (decoded.ptr && e->userBound[(uint32_t)nrd::ResourceType::IN_VIEWZ] && guideNz) {
         for (uint32_t i = 0; i < dispatchDescsNum && !reblurConstants; i++)
             if (descs[i].pipelineIndex < idesc.pipelinesNum && !strncmp(idesc.pipelines[descs[i].pipelineIndex].shaderFileName, "REBLUR_", 7) && descs[i].constantBufferData &&
                 descs[i].constantBufferDataSize >= sizeof(nrdc::ReblurConstants))
@@ -835,23 +911,49 @@ static uint32_t ExecuteRange(NrdHipExecutor* e, const nrd::DispatchDesc* descs, 
             worldPos = cache;
         }
     }
+    // once per list, in front of its first pass: the rect-at-origin twins of the guide inputs (shifted rect only), then the decoded guides
+    const bool prepareNow = decodeNow || (shiftedRect && (first == 0 || !e->decodedFresh));
+    auto shiftGuides = [&](LaunchRecorder* rec, bool back) {
+        PassArgs args = {};
+        args.stream = e->stream;
+        args.recorder = rec;
+        for (uint32_t t : shiftTypes)
+            if (!back || t == (uint32_t)nrd::ResourceType::IN_MV)
+                LaunchShiftPlane(args, e->user[t], e->shifted[t], e->originX, e->originY, BytesPerTexel(ExpectedUserFormat((nrd::ResourceType)t, e->translucentShadow)), back);
+    };
     auto decode = [&](LaunchRecorder* rec) {
+        if (shiftedRect)
+            shiftGuides(rec, false);
+        if (!decodeNow)
+            return;
         PassArgs args = {};
         args.stream = e->stream;
         args.recorder = rec;
         if (worldPos.ptr)
-            LaunchDecodeGuidesRelax(args, e->user[(uint32_t)nrd::ResourceType::IN_NORMAL_ROUGHNESS], e->user[(uint32_t)nrd::ResourceType::IN_VIEWZ], decoded, worldPos, relaxConstants);
+            LaunchDecodeGuidesRelax(args, guidePlane(nrd::ResourceType::IN_NORMAL_ROUGHNESS), guidePlane(nrd::ResourceType::IN_VIEWZ), decoded, worldPos, relaxConstants);
         else if (viewPos.ptr)
-            LaunchDecodeGuides(args, e->user[(uint32_t)nrd::ResourceType::IN_NORMAL_ROUGHNESS], e->user[(uint32_t)nrd::ResourceType::IN_VIEWZ], decoded, viewPos, reblurConstants);
+            LaunchDecodeGuides(args, guidePlane(nrd::ResourceType::IN_NORMAL_ROUGHNESS), guidePlane(nrd::ResourceType::IN_VIEWZ), decoded, viewPos, reblurConstants);
         else
-            LaunchDecodeNormalRoughness(args, e->user[(uint32_t)nrd::ResourceType::IN_NORMAL_ROUGHNESS], decoded);
+            LaunchDecodeNormalRoughness(args, guidePlane(nrd::ResourceType::IN_NORMAL_ROUGHNESS), decoded);
     };
+    // a pass of the list rewrites IN_MV (REBLUR specular MV modification): the twin goes back into the user's plane behind the last pass
+    const bool shiftBackMv = shiftedRect && writesMv && first + count == dispatchDescsNum;
 
     auto passName = [&](const nrd::DispatchDesc& d) {
         return std::string("'") + (d.name ? d.name : "?") + "' (" + (d.pipelineIndex < idesc.pipelinesNum ? idesc.pipelines[d.pipelineIndex].shaderFileName : "?") + ")";
     };
+    e->patchedConstants.assign(shiftedRect ? count : 0, std::vector<uint8_t>());
     auto fill = [&](uint32_t i, PassArgs& args, std::string& msg) -> const char* {
         const char* err = PrepareDispatch(e, descs[i], args, msg);
+        size_t oo, of;
+        if (shiftedRect && !err && descs[i].constantBufferData && RectOriginOffsets(idesc.pipelines[descs[i].pipelineIndex].shaderFileName, descs[i].constantBufferDataSize, oo, of)) {
+            // the passes run on rect-at-origin guides: they must see rectOrigin = rectOffset = 0
+            std::vector<uint8_t>& copy = e->patchedConstants[i - first];
+            copy.assign((const uint8_t*)descs[i].constantBufferData, (const uint8_t*)descs[i].constantBufferData + descs[i].constantBufferDataSize);
+            memset(copy.data() + oo, 0, 8);
+            memset(copy.data() + of, 0, 8);
+            args.constants = copy.data();
+        }
         args.rowBegin = 0;
         args.rowEnd = INT_MAX;
         args.decodedNormalRoughness = decoded;
@@ -869,7 +971,7 @@ static uint32_t ExecuteRange(NrdHipExecutor* e, const nrd::DispatchDesc* descs, 
     const bool useGraph = e->graphMode && !e->profiling;
     LaunchRecorder recorder;
     recorder.keep = useGraph;
-    if (decodeNow)
+    if (prepareNow)
         decode(&recorder);
     for (uint32_t i = first; i < first + count; i++) {
         const nrd::DispatchDesc& d = descs[i];
@@ -889,12 +991,15 @@ static uint32_t ExecuteRange(NrdHipExecutor* e, const nrd::DispatchDesc* descs, 
             return e->Fail(nrd::Result::UNSUPPORTED, std::string(err) + " [pass " + passName(d) + "; nothing was launched]");
     }
 
+    if (shiftBackMv)
+        shiftGuides(&recorder, true);
+
     if (useGraph) {
         uint32_t r = LaunchAsGraph(e, recorder.records);
         if (r != (uint32_t)nrd::Result::SUCCESS)
             return r;
     } else {
-        if (decodeNow)
+        if (prepareNow)
             decode(nullptr);
         for (uint32_t i = first; i < first + count; i++) {
             const nrd::DispatchDesc& d = descs[i];
@@ -919,8 +1024,10 @@ static uint32_t ExecuteRange(NrdHipExecutor* e, const nrd::DispatchDesc* descs, 
             if (launchError != hipSuccess)
                 return e->Fail(nrd::Result::FAILURE, "HIP launch failed in pass " + passName(d) + ": " + hipGetErrorString(launchError));
         }
+        if (shiftBackMv)
+            shiftGuides(nullptr, true);
     }
-    if (decoded.ptr)
+    if (decoded.ptr || shiftedRect)
         e->decodedFresh = first + count < dispatchDescsNum; // the list is complete: the next call belongs to another frame
 
     hipError_t err = hipGetLastError();

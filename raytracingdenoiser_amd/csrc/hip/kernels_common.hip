@@ -64,6 +64,35 @@ void LaunchDecodeNormalRoughness(const PassArgs& a, const Plane& packed, const P
     LaunchPass(a, DecodeNormalRoughnessKernel, dim3((unsigned)((packed.w + 255) / 256), (unsigned)packed.h, 1), dim3(256), packed, decoded);
 }
 
+// ---- shifted rect (CommonSettings::rectOrigin; reference Common.hlsli:200-206 WithRectOrigin / WithRectOffset) ------------------------------------
+// The reference addresses its GUIDE inputs (IN_MV, IN_NORMAL_ROUGHNESS, IN_VIEWZ, the confidence / threshold-mix inputs, IN_BASECOLOR_METALNESS) at
+// rectOrigin + pixel and everything else (noisy inputs, outputs, pool planes) at the pixel itself. The executor implements that without touching a pass:
+// the guides are copied once per frame into internal planes with the rect moved to (0, 0) -- 17 B/px of streaming for the usual guide set -- and the
+// passes see rectOrigin = 0. dst(x, y) = src(x + ox, y + oy); with back = 1 the copy runs the other way (IN_MV is an in/out plane).
+__global__ __launch_bounds__(256) void ShiftPlaneKernel(Plane user, Plane shifted, int ox, int oy, uint32_t bytesPerTexel, uint32_t back) {
+    const int x = blockIdx.x * 256 + threadIdx.x, y = blockIdx.y;
+    if (x + ox >= user.w || y + oy >= user.h)
+        return;
+    const uint8_t* src = user.ptr + (size_t)(y + oy) * user.pitch + (size_t)(x + ox) * bytesPerTexel;
+    uint8_t* dst = shifted.ptr + (size_t)y * shifted.pitch + (size_t)x * bytesPerTexel;
+    if (back) {
+        const uint8_t* t = dst;
+        dst = (uint8_t*)src;
+        src = t;
+    }
+    if (bytesPerTexel == 8)
+        *(uint2*)dst = *(const uint2*)src;
+    else if (bytesPerTexel == 4)
+        *(uint32_t*)dst = *(const uint32_t*)src;
+    else
+        for (uint32_t i = 0; i < bytesPerTexel; i++)
+            dst[i] = src[i];
+}
+
+void LaunchShiftPlane(const PassArgs& a, const Plane& user, const Plane& shifted, int ox, int oy, uint32_t bytesPerTexel, bool back) {
+    LaunchPass(a, ShiftPlaneKernel, dim3((unsigned)((user.w + 255) / 256), (unsigned)user.h, 1), dim3(256), user, shifted, ox, oy, bytesPerTexel, back ? 1u : 0u);
+}
+
 // ---- Clear: zero every texel of the plane (row padding is never read). User planes may have any pitch / alignment, so a 16-byte
 // chunk is written with one store only when it is whole and aligned, bytewise otherwise (ragged row ends, 1-pixel-wide frames)
 __global__ __launch_bounds__(256) void ClearPlaneKernel(Plane out, uint32_t rowBytes, uint32_t firstRow) {

@@ -571,8 +571,8 @@ static bool ForceGenericTaps() {
 }
 
 static const char* CheckSupported(const ReblurCB& c) {
-    if (c.gRectOrigin.x != 0 || c.gRectOrigin.y != 0) // rect < resource (dynamic resolution) is fine; only a shifted rect is not
-        return "REBLUR: a non-zero CommonSettings::rectOrigin is not implemented in the HIP back-end";
+    if (c.gRectOrigin.x != 0 || c.gRectOrigin.y != 0) // the executor moves the rect of the guide inputs to (0, 0) and zeroes this field (executor.hip "shifted rect")
+        return "internal error: a pass was handed a non-zero rectOrigin";
     if (c.gOrthoMode != 0.0f)
         return "REBLUR: orthographic projection is not supported (SURVEY.md section 8c)";
     return nullptr;

@@ -167,8 +167,8 @@ __global__ __launch_bounds__(256) void SigmaClassifyTilesKernel(SigmaCB c, Plane
 }
 
 static const char* CheckSupportedSigma(const SigmaCB& c) {
-    if (c.gRectOrigin.x != 0 || c.gRectOrigin.y != 0) // rect < resource (dynamic resolution) is fine; only a shifted rect is not
-        return "SIGMA: a non-zero CommonSettings::rectOrigin is not implemented in the HIP back-end";
+    if (c.gRectOrigin.x != 0 || c.gRectOrigin.y != 0) // the executor moves the rect of the guide inputs to (0, 0) and zeroes this field (executor.hip "shifted rect")
+        return "internal error: a pass was handed a non-zero rectOrigin";
     if (c.gOrthoMode != 0.0f)
         return "SIGMA: orthographic projection is not supported (SURVEY.md section 8c)";
     return nullptr;

@@ -106,6 +106,9 @@ void LaunchDecodeGuides(const PassArgs& a, const Plane& packed, const Plane& vie
 // same for RELAX lists: the (world position, viewZ) plane from IN_VIEWZ and the frame's RELAX constants
 void LaunchDecodeGuidesRelax(const PassArgs& a, const Plane& packed, const Plane& viewZ, const Plane& decoded, const Plane& worldPos, const void* relaxConstants);
 
+// copies a user guide plane into its rect-at-origin twin (or back): kernels_common.hip "shifted rect"
+void LaunchShiftPlane(const PassArgs& a, const Plane& user, const Plane& shifted, int ox, int oy, uint32_t bytesPerTexel, bool back);
+
 inline dim3 GridFor(int w, int h, int tileW, int tileH) { return dim3((unsigned)((w + tileW - 1) / tileW), (unsigned)((h + tileH - 1) / tileH), 1); }
 
 // Grid covering rows [rowBegin, rowEnd) clipped to [0, h) with tileH-row blocks that stay aligned to the full-frame tiling;

@@ -35,8 +35,8 @@ inline const char* CheckSupportedRelax(const PassArgs& a) {
     if (!a.constants || a.constantsSize < sizeof(nrdc::RelaxConstants))
         return "RELAX: constant block missing";
     const nrdc::RelaxConstants& c = *(const nrdc::RelaxConstants*)a.constants;
-    if (c.gRectOrigin.x != 0 || c.gRectOrigin.y != 0) // rect < resource (dynamic resolution) is fine; only a shifted rect is not
-        return "RELAX: a non-zero CommonSettings::rectOrigin is not implemented in the HIP back-end";
+    if (c.gRectOrigin.x != 0 || c.gRectOrigin.y != 0) // the executor moves the rect of the guide inputs to (0, 0) and zeroes this field (executor.hip "shifted rect")
+        return "internal error: a pass was handed a non-zero rectOrigin";
     if (c.gOrthoMode != 0.0f)
         return "RELAX: orthographic projection is not supported (SURVEY.md section 8c)";
     return nullptr;

@@ -1,6 +1,6 @@
 """Dynamic resolution (CommonSettings::rectSize < resourceSize, rectSizePrev != rectSize; reference NRDSettings.h "resourceSize / rectSize",
 Common.hlsli ClampUvToViewport, gResolutionScale[Prev]): the denoised rect is the top-left part of resource-sized planes and may change
-from frame to frame. A shifted rect (rectOrigin != 0) is rejected by the HIP back-end."""
+from frame to frame; a shifted rect (rectOrigin != 0: the guide inputs live at an offset inside their planes) is served through rect-at-origin copies."""
 import numpy as np
 import pytest
 import torch
@@ -123,13 +123,53 @@ def test_hip_matches_oracle_sub_rect_with_options():
     assert worst <= parity.REL_TOL
 
 
-@pytest.mark.gpu
-def test_shifted_rect_is_rejected_loudly():
-    from raytracingdenoiser_amd.executor import HipExecutor
+def _embed_guides_at(frame, resource, origin):
+    """a rect-sized generated frame inside resource-sized planes: guide inputs at `origin`, everything else (noisy inputs) at (0, 0) -- the layout the
+    reference addresses with CommonSettings::rectOrigin (WithRectOrigin: guides only)"""
+    rw, rh = resource
+    ox, oy = origin
+    guides = ("mv", "normal_roughness", "viewz", "diff_confidence", "spec_confidence", "disocclusion_mix", "basecolor_metalness")
+    out = {}
+    for k, v in frame.items():
+        if torch.is_tensor(v) and v.dim() >= 2 and v.dtype != torch.bool:
+            big = torch.full([rh, rw] + list(v.shape[2:]), 33.0 if v.dtype.is_floating_point else 9, dtype=v.dtype, device=v.device)
+            x0, y0 = (ox, oy) if k in guides else (0, 0)
+            big[y0 : y0 + v.shape[0], x0 : x0 + v.shape[1]] = v
+            v = big
+        out[k] = v
+    return out
 
-    name = "REBLUR_DIFFUSE"
-    frame = parity.embed_in_resource(synth.render_frame(*RECT, 0, want=tuple(parity.DENOISERS[name][1])), RESOURCE)
-    run = parity.HipRun(name, *RESOURCE)
-    cs = parity.common_settings(frame["camera"], frame["camera"], *RECT, 0, resourceSize=RESOURCE, resourceSizePrev=RESOURCE, rectOrigin=(16, 8))
-    with pytest.raises(RuntimeError, match="rectOrigin"):
-        run.step(frame, cs, parity.denoiser_settings(name, frame))
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", ["REBLUR_DIFFUSE_SPECULAR", "RELAX_DIFFUSE_SPECULAR", "SIGMA_SHADOW"])
+def test_shifted_rect_equals_the_rect_at_the_origin(name):
+    """CommonSettings::rectOrigin != 0 (reference NRD_USE_VIEWPORT_OFFSET, Common.hlsli:64, :200-206): the guide inputs live at rectOrigin inside their
+    resource-sized planes. The outputs must be those of the same frames with the guides at (0, 0) -- bit for bit, in both builds -- and the exact build must
+    still agree with the oracle."""
+    from raytracingdenoiser_amd import synth
+
+    frames, origin = 4, (16, 8)
+    seq = [synth.render_frame(*RECT, f, want=tuple(parity.DENOISERS[name][1])) for f in range(frames)]
+    for numerics in ("fast", "exact"):
+        results = []
+        for org in ((0, 0), origin):
+            run = parity.HipRun(name, *RESOURCE, numerics=numerics)
+            outs = []
+            for f, fr in enumerate(seq):
+                frame = _embed_guides_at(fr, RESOURCE, org)
+                cs = parity.common_settings(fr["camera"], seq[max(f - 1, 0)]["camera"], *RECT, f, resourceSize=RESOURCE, resourceSizePrev=RESOURCE, rectOrigin=org)
+                run.step(frame, cs, parity.denoiser_settings(name, frame))
+                outs.append({rt: run.output(rt)[: RECT[1], : RECT[0]].copy() for rt in run.outs})
+            results.append(outs)
+        for a, b in zip(*results):
+            for rt in a:
+                assert np.array_equal(a[rt], b[rt]), (numerics, rt)
+    # exact build vs oracle with the shifted rect
+    ora, hip = parity.OracleRun(name, *RESOURCE), parity.HipRun(name, *RESOURCE, numerics="exact")
+    for f, fr in enumerate(seq):
+        frame = _embed_guides_at(fr, RESOURCE, origin)
+        mk = lambda: parity.common_settings(fr["camera"], seq[max(f - 1, 0)]["camera"], *RECT, f, resourceSize=RESOURCE, resourceSizePrev=RESOURCE, rectOrigin=origin)
+        ora.step(frame, mk(), parity.denoiser_settings(name, frame))
+        hip.step(frame, mk(), parity.denoiser_settings(name, frame))
+        for rt in ora.outs:
+            assert parity.rel_error(hip.output(rt)[: RECT[1], : RECT[0]], ora.output(rt)[: RECT[1], : RECT[0]]) == 0.0, (f, rt)
