@@ -54,7 +54,7 @@ uint32_t nrdHipCreateExecutorWithArena(void* instance, uint16_t resourceWidth, u
 //   IN/OUT_{DIFF,SPEC}_RADIANCE_HITDIST RGBA16_SFLOAT | IN/OUT_{DIFF,SPEC}_SH0, _SH1 RGBA16_SFLOAT (REBLUR / RELAX SH variants)
 //   IN/OUT_{DIFF,SPEC}_HITDIST R16_UNORM (REBLUR occlusion family) | IN/OUT_DIFF_DIRECTION_HITDIST RGBA16_SNORM | IN_PENUMBRA R16_SFLOAT | IN_TRANSLUCENCY, IN_BASECOLOR_METALNESS RGBA8_UNORM
 //   OUT_SHADOW_TRANSLUCENCY R8_UNORM (SIGMA_SHADOW) or RGBA8_UNORM (an instance holding SIGMA_SHADOW_TRANSLUCENCY)
-//   IN_SIGNAL / OUT_SIGNAL RGBA32_SFLOAT | IN_{DIFF,SPEC}_CONFIDENCE, IN_DISOCCLUSION_THRESHOLD_MIX R8_UNORM
+//   IN_SIGNAL / OUT_SIGNAL RGBA32_SFLOAT | IN_{DIFF,SPEC}_CONFIDENCE, IN_DISOCCLUSION_THRESHOLD_MIX R8_UNORM | OUT_VALIDATION RGBA8_UNORM
 // include/NRD.hip.h has the device functions that produce / consume these encodings (the NRD.hlsli front-end and back-end).
 uint32_t nrdHipBindResource(NrdHipExecutor* executor, uint32_t resourceType, const NrdHipPlaneDesc* plane);
 

@@ -110,6 +110,16 @@ inline float Clamp(float m1, float sigma, float x) { return clamp(x, m1 - sigma,
 
 namespace Sequence {
 inline uint32_t CheckerBoard(uint32_t x, uint32_t y, uint32_t frameIndex) { return ((x ^ y) ^ frameIndex) & 1u; }
+// [ml] Math::ReverseBits4 and Color::ColorizeZucconi (validation overlays only). The colour ramp is A. Zucconi's six-coefficient fit of the visible
+// spectrum ("Improving the Rainbow", 2017) evaluated at x in [0, 1]; MathLib's exact variant is unavailable (parity unpinned, like the rest of [ml]).
+inline uint32_t ReverseBits4(uint32_t x) { return ((x & 1u) << 3) | ((x & 2u) << 1) | ((x & 4u) >> 1) | ((x & 8u) >> 3); }
+inline float ZucconiBump(float x, float yoffset) { return saturate((1.0f - x * x) - yoffset); }
+inline float3 ColorizeZucconi(float x) {
+    x = saturate(x);
+    return float3(ZucconiBump(3.54585104f * (x - 0.69549072f), 0.02312639f) + ZucconiBump(3.90307140f * (x - 0.11748627f), 0.84897130f),
+        ZucconiBump(2.93225262f * (x - 0.49228336f), 0.15225084f) + ZucconiBump(3.21182957f * (x - 0.86755042f), 0.88445281f),
+        ZucconiBump(2.41593945f * (x - 0.27699880f), 0.52607955f) + ZucconiBump(3.96587128f * (x - 0.66077860f), 0.73949448f));
+}
 inline uint32_t Bayer4x4ui(uint32_t x, uint32_t y, uint32_t frameIndex) {
     x &= 3u;
     y &= 3u;

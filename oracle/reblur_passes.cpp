@@ -1912,9 +1912,132 @@ void SplitScreen(const PassIO& io) {
     {"REBLUR_" NAME "_SplitScreen.cs", SplitScreen<D, S, false>},                                      \
     {"REBLUR_" NAME "Sh_SplitScreen.cs", SplitScreen<D, S, true>},
 
+// ================================================================================================ Validation
+// reference Shaders/Source/REBLUR_Validation.cs.hlsl:32-356 without the text overlay (MathLib's Text module and its font are not in the reference tree):
+// a 4 x 4 grid of viewports over OUT_VALIDATION -- normals, roughness, viewZ, motion-vector error, world units / jitter / rotators, virtual-history amount,
+// accumulated frames, hit distances; viewports nothing writes keep their previous content (the pass reads its own output).
+struct ReblurValidationCB {
+    ReblurCB shared;
+    uint32_t gHasDiffuse, gHasSpecular;
+};
+static void ReblurValidation(const PassIO& io) {
+    const ReblurValidationCB& vc = *(const ReblurValidationCB*)io.constants;
+    const ReblurCB& c = vc.shared;
+    const Tex &gIn_Normal_Roughness = io.t[0], &gIn_ViewZ = io.t[1], &gIn_Mv = io.t[2], &gIn_Data1 = io.t[3], &gIn_Data2 = io.t[4], &gIn_Diff = io.t[5], &gIn_Spec = io.t[6];
+    Tex& gOut_Validation = io.t[7];
+    const float VIEWPORT_SIZE = 0.25f;
+    static const float3 special8[8] = {float3(-1.0f, 0.0f, 1.0f), float3(0.0f, 1.0f, 1.0f), float3(1.0f, 0.0f, 1.0f), float3(0.0f, -1.0f, 1.0f),
+        float3(-0.25f * 1.41421356f, 0.25f * 1.41421356f, 0.5f), float3(0.25f * 1.41421356f, 0.25f * 1.41421356f, 0.5f), float3(0.25f * 1.41421356f, -0.25f * 1.41421356f, 0.5f),
+        float3(-0.25f * 1.41421356f, -0.25f * 1.41421356f, 0.5f)};
+#pragma omp parallel for schedule(static)
+    for (int py = 0; py < gOut_Validation.H(); py++)
+        for (int px = 0; px < gOut_Validation.W(); px++) {
+            if (c.gResetHistory != 0) {
+                gOut_Validation.Store(px, py, float4(0.0f));
+                continue;
+            }
+            float2 pixelUv = float2(float(px) + 0.5f, float(py) + 0.5f) / c.gResourceSize;
+            float2 scaled = pixelUv / VIEWPORT_SIZE;
+            float2 viewportId = floor(scaled);
+            float2 viewportUv = scaled - viewportId;
+            float viewportIndex = viewportId.y / VIEWPORT_SIZE + viewportId.x;
+            float2 viewportUvScaled = viewportUv * c.gResolutionScale;
+
+            float4 normalAndRoughness = NRD_FrontEnd_UnpackNormalAndRoughness(gIn_Normal_Roughness.SampleNearest(viewportUvScaled + c.gRectOffset));
+            float viewZ = UnpackViewZ(c, gIn_ViewZ.SampleNearest(viewportUvScaled + c.gRectOffset).x);
+            float4 mvRaw = gIn_Mv.SampleNearest(viewportUvScaled + c.gRectOffset);
+            float3 mv = float3(mvRaw.x * c.gMvScale.x, mvRaw.y * c.gMvScale.y, mvRaw.z * c.gMvScale.z);
+            float4 diff = gIn_Diff.SampleNearest(viewportUvScaled * float2(c.gDiffCheckerboard != 2 ? 0.5f : 1.0f, 1.0f));
+            float4 spec = gIn_Spec.SampleNearest(viewportUvScaled * float2(c.gSpecCheckerboard != 2 ? 0.5f : 1.0f, 1.0f));
+            float4 d1 = gIn_Data1.SampleNearest(viewportUvScaled);
+            float2 data1 = float2(d1.x, d1.y);
+            if (!vc.gHasDiffuse || !vc.gHasSpecular) // single-signal denoisers store one channel (R8_UNORM)
+                data1.y = data1.x;
+            data1 = data1 * REBLUR_MAX_ACCUM_FRAME_NUM;
+            uint32_t bits;
+            float2 data2 = UnpackData2(gIn_Data2.LoadUint((int)(viewportUvScaled.x * c.gResourceSize.x), (int)(viewportUvScaled.y * c.gResourceSize.y)), bits);
+
+            float3 N = normalAndRoughness.xyz();
+            float3 Xv = Geometry::ReconstructViewPosition(viewportUv, c.gFrustum, abs(viewZ), c.gOrthoMode);
+            float3 X = Geometry::RotateVector(c.gViewToWorld, Xv);
+            bool isInf = abs(viewZ) > c.gDenoisingRange;
+            bool checkerboard = Sequence::CheckerBoard((uint32_t)px >> 2, (uint32_t)py >> 2, 0) != 0;
+            float notInf = isInf ? 0.0f : 1.0f;
+
+            float4 result = gOut_Validation.Load(px, py);
+            if (viewportIndex == 0.0f) {
+                result = float4(N * 0.5f + 0.5f, 1.0f);
+            } else if (viewportIndex == 1.0f) {
+                result = float4(float3(normalAndRoughness.w), 1.0f);
+            } else if (viewportIndex == 2.0f) {
+                float f = 0.1f * abs(viewZ) / (1.0f + 0.1f * abs(viewZ));
+                float3 color = viewZ < 0.0f ? float3(0, 0, 1) : float3(0, 1, 0);
+                result = float4(isInf ? float3(1, 0, 0) : color * f, 1.0f);
+            } else if (viewportIndex == 3.0f) {
+                float2 viewportUvPrevExpected = Geometry::GetScreenUv(c.gWorldToClipPrev, X);
+                float2 viewportUvPrev = viewportUv + float2(mv.x, mv.y);
+                if (c.gMvScale.w != 0.0f)
+                    viewportUvPrev = Geometry::GetScreenUv(c.gWorldToClipPrev, X + mv);
+                float2 uvDelta = (viewportUvPrev - viewportUvPrevExpected) * c.gRectSize;
+                result = float4(IsInScreenNearest(viewportUvPrev) != 0.0f ? float3(abs(uvDelta.x), abs(uvDelta.y), 0.0f) : float3(0, 0, 1), 1.0f);
+            } else if (viewportIndex == 4.0f) {
+                float2 dim = float2(0.5f * c.gResourceSize.y / c.gResourceSize.x, 0.5f);
+                float2 dimInPixels = c.gResourceSize * VIEWPORT_SIZE * dim;
+                float2 remappedUv = (viewportUv - (1.0f - dim)) / dim;
+                float2 remappedUv2 = (viewportUv - float2(1.0f - dim.x, 0.0f)) / dim;
+                if (remappedUv.x > 0.0f && remappedUv.y > 0.0f) {
+                    float2 uv = c.gJitter + 0.5f;
+                    float2 su = saturate(uv);
+                    bool isValid = su.x == uv.x && su.y == uv.y;
+                    int ax = (int)(su.x * dimInPixels.x), ay = (int)(su.y * dimInPixels.y);
+                    int bx = (int)(remappedUv.x * dimInPixels.x), by = (int)(remappedUv.y * dimInPixels.y);
+                    int dx = ax - bx < 0 ? bx - ax : ax - bx, dy = ay - by < 0 ? by - ay : ay - by;
+                    if (dx <= 1 && dy <= 1 && isValid)
+                        result.x = result.y = result.z = 0.66f;
+                    if (dx <= 3 && dy <= 3 && !isValid)
+                        result.x = 1.0f, result.y = 0.0f, result.z = 0.0f;
+                } else if (remappedUv2.x > 0.0f && remappedUv2.y > 0.0f) {
+                    float scale = 0.5f;
+                    scale *= float(Sequence::ReverseBits4(c.gFrameIndex)) / 16.0f;
+                    int bx = (int)(remappedUv2.x * dimInPixels.x), by = (int)(remappedUv2.y * dimInPixels.y);
+                    const float4 rot[3] = {c.gRotatorPre, c.gRotator, c.gRotatorPost};
+                    for (int n = 0; n < 8; n++) {
+                        float3 offset = special8[n] * scale;
+                        for (int k = 0; k < 3; k++) {
+                            float2 uv = 0.5f + Geometry::RotateVector(rot[k], float2(offset.x, offset.y));
+                            float2 su = saturate(uv);
+                            int ax = (int)(su.x * dimInPixels.x), ay = (int)(su.y * dimInPixels.y);
+                            int dx = ax - bx < 0 ? bx - ax : ax - bx, dy = ay - by < 0 ? by - ay : ay - by;
+                            result[k] += (dx <= 1 && dy <= 1) ? 1.0f : 0.0f;
+                        }
+                    }
+                    result = c.gFrameIndex % 256 == 0 ? float4(0.0f) : float4(saturate(result.x), saturate(result.y), saturate(result.z), saturate(result.w));
+                } else {
+                    float roundingErrorCorrection = abs(viewZ) * 0.001f;
+                    float3 v = X + roundingErrorCorrection;
+                    result.x = frac(v.x) * notInf, result.y = frac(v.y) * notInf, result.z = frac(v.z) * notInf;
+                }
+                result.w = 1.0f;
+            } else if (viewportIndex == 7.0f && vc.gHasSpecular) {
+                result = float4(float3(data2.x * notInf), 1.0f);
+            } else if ((viewportIndex == 8.0f && vc.gHasDiffuse) || (viewportIndex == 11.0f && vc.gHasSpecular)) {
+                float frames = viewportIndex == 8.0f ? data1.x : data1.y;
+                float f = 1.0f - saturate(frames / max(c.gMaxAccumulatedFrameNum, 1.0f));
+                f = checkerboard && frames < 1.0f ? 0.75f : f;
+                result = float4(Sequence::ColorizeZucconi(viewportUv.y > 0.95f ? 1.0f - viewportUv.x : f * notInf), 1.0f);
+            } else if ((viewportIndex == 12.0f && vc.gHasDiffuse) || (viewportIndex == 15.0f && vc.gHasSpecular)) {
+                float h = viewportIndex == 12.0f ? diff.w : spec.w;
+                float3 v = h == 0.0f ? float3(1, 0, 0) : (h != saturate(h) ? float3(1, 0, 1) : float3(h));
+                result = float4(v * notInf, 1.0f);
+            }
+            gOut_Validation.Store(px, py, result);
+        }
+}
+
 const PassEntry* GetReblurPasses(uint32_t& n) {
     static const PassEntry k[] = {
         {"REBLUR_ClassifyTiles.cs", ClassifyTiles},
+        {"REBLUR_Validation.cs", ReblurValidation},
         REBLUR_FAMILY("Diffuse", true, false)
         REBLUR_FAMILY("Specular", false, true)
         REBLUR_FAMILY("DiffuseSpecular", true, true)

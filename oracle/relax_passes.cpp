@@ -1973,9 +1973,89 @@ void SplitScreen(const PassIO& io) {
     {"RELAX_" name "_HitDistReconstruction.cs", HitDistReconstruction<D, S, 1>},           \
     {"RELAX_" name "_HitDistReconstruction_5x5.cs", HitDistReconstruction<D, S, 2>}
 
+// ================================================================================================ Validation
+// reference Shaders/Source/RELAX_Validation.cs.hlsl:32-207 without the text overlay (see the REBLUR twin in reblur_passes.cpp)
+static void RelaxValidation(const PassIO& io) {
+    const RelaxCB& c = *(const RelaxCB*)io.constants;
+    const Tex &gIn_Normal_Roughness = io.t[0], &gIn_ViewZ = io.t[1], &gIn_Mv = io.t[2], &gIn_HistoryLength = io.t[3];
+    Tex& gOut_Validation = io.t[4];
+    const float VIEWPORT_SIZE = 0.25f;
+#pragma omp parallel for schedule(static)
+    for (int py = 0; py < gOut_Validation.H(); py++)
+        for (int px = 0; px < gOut_Validation.W(); px++) {
+            if (c.gResetHistory != 0) {
+                gOut_Validation.Store(px, py, float4(0.0f));
+                continue;
+            }
+            float2 pixelUv = float2(float(px) + 0.5f, float(py) + 0.5f) / c.gResourceSize;
+            float2 scaled = pixelUv / VIEWPORT_SIZE;
+            float2 viewportId = floor(scaled);
+            float2 viewportUv = scaled - viewportId;
+            float viewportIndex = viewportId.y / VIEWPORT_SIZE + viewportId.x;
+            float2 viewportUvScaled = viewportUv * c.gResolutionScale;
+
+            float4 normalAndRoughness = NRD_FrontEnd_UnpackNormalAndRoughness(gIn_Normal_Roughness.SampleNearest(viewportUvScaled + c.gRectOffset));
+            float viewZ = UnpackViewZ(c, gIn_ViewZ.SampleNearest(viewportUvScaled + c.gRectOffset).x);
+            float4 mvRaw = gIn_Mv.SampleNearest(viewportUvScaled + c.gRectOffset);
+            float3 mv = float3(mvRaw.x * c.gMvScale.x, mvRaw.y * c.gMvScale.y, mvRaw.z * c.gMvScale.z);
+            float historyLength = 255.0f * gIn_HistoryLength.SampleNearest(viewportUvScaled).x - 1.0f;
+
+            float3 N = normalAndRoughness.xyz();
+            float3 X = GetCurrentWorldPosFromClipSpaceXY(c, viewportUv * 2.0f - 1.0f, abs(viewZ));
+            bool isInf = abs(viewZ) > c.gDenoisingRange;
+            bool checkerboard = Sequence::CheckerBoard((uint32_t)px >> 2, (uint32_t)py >> 2, 0) != 0;
+            float notInf = isInf ? 0.0f : 1.0f;
+
+            float4 result = gOut_Validation.Load(px, py);
+            if (viewportIndex == 0.0f) {
+                result = float4(N * 0.5f + 0.5f, 1.0f);
+            } else if (viewportIndex == 1.0f) {
+                result = float4(float3(normalAndRoughness.w), 1.0f);
+            } else if (viewportIndex == 2.0f) {
+                float f = 0.1f * abs(viewZ) / (1.0f + 0.1f * abs(viewZ));
+                float3 color = viewZ < 0.0f ? float3(0, 0, 1) : float3(0, 1, 0);
+                result = float4(isInf ? float3(1, 0, 0) : color * f, 1.0f);
+            } else if (viewportIndex == 3.0f) {
+                float2 viewportUvPrevExpected = Geometry::GetScreenUv(c.gWorldToClipPrev, X);
+                float2 viewportUvPrev = viewportUv + float2(mv.x, mv.y);
+                if (c.gMvScale.w != 0.0f)
+                    viewportUvPrev = Geometry::GetScreenUv(c.gWorldToClipPrev, X + mv);
+                float2 uvDelta = (viewportUvPrev - viewportUvPrevExpected) * float2(float(c.gRectSize[0]), float(c.gRectSize[1]));
+                result = float4(IsInScreenNearest(viewportUvPrev) != 0.0f ? float3(abs(uvDelta.x), abs(uvDelta.y), 0.0f) : float3(0, 0, 1), 1.0f);
+            } else if (viewportIndex == 4.0f) {
+                float2 dim = float2(0.5f * c.gResourceSize.y / c.gResourceSize.x, 0.5f);
+                float2 remappedUv = (viewportUv - (1.0f - dim)) / dim;
+                if (remappedUv.x > 0.0f && remappedUv.y > 0.0f) {
+                    float2 dimInPixels = c.gResourceSize * VIEWPORT_SIZE * dim;
+                    float2 uv = c.gJitter + 0.5f;
+                    float2 su = saturate(uv);
+                    bool isValid = su.x == uv.x && su.y == uv.y;
+                    int ax = (int)(su.x * dimInPixels.x), ay = (int)(su.y * dimInPixels.y);
+                    int bx = (int)(remappedUv.x * dimInPixels.x), by = (int)(remappedUv.y * dimInPixels.y);
+                    int dx = ax - bx < 0 ? bx - ax : ax - bx, dy = ay - by < 0 ? by - ay : ay - by;
+                    if (dx <= 1 && dy <= 1 && isValid)
+                        result.x = result.y = result.z = 0.66f;
+                    if (dx <= 3 && dy <= 3 && !isValid)
+                        result.x = 1.0f, result.y = 0.0f, result.z = 0.0f;
+                } else {
+                    float roundingErrorCorrection = abs(viewZ) * 0.001f;
+                    float3 v = X + roundingErrorCorrection;
+                    result.x = frac(v.x) * notInf, result.y = frac(v.y) * notInf, result.z = frac(v.z) * notInf;
+                }
+                result.w = 1.0f;
+            } else if (viewportIndex == 8.0f) {
+                float f = 1.0f - saturate(historyLength / max(max(c.gDiffMaxAccumulatedFrameNum, c.gSpecMaxAccumulatedFrameNum), 1.0f));
+                f = checkerboard && historyLength < 2.0f ? 0.75f : f;
+                result = float4(Sequence::ColorizeZucconi(viewportUv.y > 0.95f ? 1.0f - viewportUv.x : f * notInf), 1.0f);
+            }
+            gOut_Validation.Store(px, py, result);
+        }
+}
+
 const PassEntry* GetRelaxPasses(uint32_t& n) {
     static const PassEntry k[] = {
         {"RELAX_ClassifyTiles.cs", ClassifyTiles},
+        {"RELAX_Validation.cs", RelaxValidation},
         RELAX_HITDIST("Diffuse", true, false),
         RELAX_HITDIST("Specular", false, true),
         RELAX_HITDIST("DiffuseSpecular", true, true),

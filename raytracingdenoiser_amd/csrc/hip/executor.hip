@@ -69,6 +69,7 @@ nrd::Format ExpectedUserFormat(nrd::ResourceType t, bool translucentShadow) {
         case R::IN_TRANSLUCENCY: case R::IN_BASECOLOR_METALNESS: return F::RGBA8_UNORM;
         case R::OUT_SHADOW_TRANSLUCENCY: return translucentShadow ? F::RGBA8_UNORM : F::R8_UNORM;
         case R::IN_SIGNAL: case R::OUT_SIGNAL: return F::RGBA32_SFLOAT;
+        case R::OUT_VALIDATION: return F::RGBA8_UNORM;
         default: return F::MAX_NUM;
     }
 }
@@ -204,14 +205,15 @@ static uint32_t CreateExecutorImpl(void* instance, uint16_t resourceWidth, uint1
 
     // pipeline index -> launcher
     e->launchers.assign(desc.pipelinesNum, nullptr);
-    const PassEntry* tables[4];
-    uint32_t counts[4];
+    const PassEntry* tables[5];
+    uint32_t counts[5];
     tables[0] = GetCommonPasses(counts[0]);
     tables[1] = GetReblurPasses(counts[1]);
     tables[2] = GetSigmaPasses(counts[2]);
     tables[3] = GetRelaxPasses(counts[3]);
+    tables[4] = GetValidationPasses(counts[4]);
     for (uint32_t p = 0; p < desc.pipelinesNum; p++)
-        for (int t = 0; t < 4; t++)
+        for (int t = 0; t < 5; t++)
             for (uint32_t i = 0; i < counts[t]; i++)
                 if (!strcmp(tables[t][i].shaderFileName, desc.pipelines[p].shaderFileName))
                     e->launchers[p] = tables[t][i].launch;

@@ -98,6 +98,7 @@ const PassEntry* GetCommonPasses(uint32_t& num);
 const PassEntry* GetReblurPasses(uint32_t& num);
 const PassEntry* GetSigmaPasses(uint32_t& num);
 const PassEntry* GetRelaxPasses(uint32_t& num);
+const PassEntry* GetValidationPasses(uint32_t& num);
 
 // decodes a whole R10G10B10A2 normal+roughness plane into the float4 cache (kernels_common.hip)
 void LaunchDecodeNormalRoughness(const PassArgs& a, const Plane& packed, const Plane& decoded);

@@ -399,7 +399,7 @@ void InstanceImpl::Update_Reblur(const DenoiserData& d) {
     if (cs.enableValidation) {
         auto* c = (nrdc::ReblurValidationConstants*)PushDispatch(d, PASS_VALIDATION);
         FillReblurConstants(s, c);
-        c->gHasDiffuse = hasDiff ? 1 : 0;
+        c->gHasDiffuse = hasDiff ? 1 : 0; // PushDispatch never returns null (arena overflow lands in the scratch block and fails the whole call)
         c->gHasSpecular = hasSpec ? 1 : 0;
     }
 }
@@ -623,7 +623,7 @@ void InstanceImpl::Update_ReblurOcclusion(const DenoiserData& d) {
     if (cs.enableValidation) {
         auto* c = (nrdc::ReblurValidationConstants*)PushDispatch(d, OCC_PASS_VALIDATION);
         FillReblurConstants(s, c);
-        c->gHasDiffuse = hasDiff ? 1 : 0;
+        c->gHasDiffuse = hasDiff ? 1 : 0; // PushDispatch never returns null (arena overflow lands in the scratch block and fails the whole call)
         c->gHasSpecular = hasSpec ? 1 : 0;
     }
 }

@@ -73,9 +73,11 @@ InstanceImpl::InstanceImpl(const AllocationCallbacks& cb)
     , m_ActiveDispatches(HostAllocator<DispatchDesc>(cb))
     , m_IndexRemap(HostAllocator<uint16_t>(cb))
     , m_Strings(HostAllocator<char*>(cb)) {
-    m_ConstantDataUnaligned = (uint8_t*)cb.Allocate(cb.userArg, CONSTANT_DATA_SIZE + 64, 64);
+    // the arena is followed by one scratch block: a dispatch that no longer fits writes its constants there (so the fillers never see null) and the
+    // whole GetComputeDispatches call fails
+    m_ConstantDataUnaligned = (uint8_t*)cb.Allocate(cb.userArg, CONSTANT_DATA_SIZE + CONSTANT_SCRATCH_SIZE + 64, 64);
     m_ConstantData = (uint8_t*)(((uintptr_t)m_ConstantDataUnaligned + 63) & ~(uintptr_t)63);
-    memset(m_ConstantData, 0, CONSTANT_DATA_SIZE);
+    memset(m_ConstantData, 0, CONSTANT_DATA_SIZE + CONSTANT_SCRATCH_SIZE);
 }
 
 InstanceImpl::~InstanceImpl() {
@@ -498,6 +500,7 @@ Result InstanceImpl::SetDenoiserSettings(Identifier identifier, const void* deno
 // ------------------------------------------------------------------------------------------------ per-frame list
 Result InstanceImpl::GetComputeDispatches(const Identifier* identifiers, uint32_t identifiersNum, const DispatchDesc*& dispatchDescs, uint32_t& dispatchDescsNum) {
     m_ConstantDataOffset = 0;
+    m_ConstantOverflow = false;
     m_ActiveDispatches.clear();
 
     if (!identifiers || !identifiersNum) {
@@ -578,6 +581,13 @@ Result InstanceImpl::GetComputeDispatches(const Identifier* identifiers, uint32_
             cur.constantBufferDataMatchesPreviousDispatch = true; // memcmp of 0 bytes "matches" in the reference too
     }
 
+    if (m_ConstantOverflow) { // more constant data than the arena holds: hand out nothing rather than dispatches sharing the scratch block
+        m_ActiveDispatches.clear();
+        dispatchDescs = nullptr;
+        dispatchDescsNum = 0;
+        return Result::FAILURE;
+    }
+
     dispatchDescs = m_ActiveDispatches.data();
     dispatchDescsNum = (uint32_t)m_ActiveDispatches.size();
     return dispatchDescsNum ? Result::SUCCESS : Result::INVALID_ARGUMENT;
@@ -600,15 +610,15 @@ void* InstanceImpl::PushDispatch(const DenoiserData& d, uint32_t localIndex) {
     desc.resourcesNum = t.resourcesNum;
     desc.pipelineIndex = t.pipelineIndex;
 
-    if (m_ConstantDataOffset + t.constantBufferDataSize > CONSTANT_DATA_SIZE)
-        desc.constantBufferData = nullptr;
-    else
+    if (m_ConstantDataOffset + t.constantBufferDataSize > CONSTANT_DATA_SIZE || t.constantBufferDataSize > CONSTANT_SCRATCH_SIZE) {
+        m_ConstantOverflow = true;
+        desc.constantBufferData = m_ConstantData + CONSTANT_DATA_SIZE; // scratch
+    } else {
         desc.constantBufferData = m_ConstantData + m_ConstantDataOffset;
-    desc.constantBufferDataSize = t.constantBufferDataSize;
-    m_ConstantDataOffset += (t.constantBufferDataSize + 15u) & ~15u;
-
-    if (desc.constantBufferData)
-        memset((void*)desc.constantBufferData, 0, desc.constantBufferDataSize);
+        m_ConstantDataOffset += (t.constantBufferDataSize + 15u) & ~15u;
+    }
+    desc.constantBufferDataSize = std::min<uint32_t>(t.constantBufferDataSize, (uint32_t)CONSTANT_SCRATCH_SIZE);
+    memset((void*)desc.constantBufferData, 0, desc.constantBufferDataSize);
 
     uint16_t w = m_CommonSettings.rectSize[0];
     uint16_t h = m_CommonSettings.rectSize[1];

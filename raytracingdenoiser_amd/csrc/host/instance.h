@@ -45,6 +45,7 @@ using Vector = std::vector<T, HostAllocator<T>>;
 constexpr uint16_t PERMANENT_POOL_START = 1000; // local plane ids >= 1000 index the denoiser's permanent planes
 constexpr uint16_t TRANSIENT_POOL_START = 2000; // local plane ids >= 2000 index the denoiser's transient planes
 constexpr size_t CONSTANT_DATA_SIZE = 128 * 1024;
+constexpr size_t CONSTANT_SCRATCH_SIZE = 4096; // >= the largest constant block (REBLUR: 832 bytes)
 constexpr uint16_t USE_MAX_DIMS = 0xFFFF; // grid from max(rect, rectPrev)
 constexpr uint16_t IGNORE_RS = 0xFFFE;    // grid from resourceSize
 constexpr uint16_t NO_SWAP = 0xFFFF;
@@ -191,6 +192,7 @@ private:
     uint8_t* m_ConstantDataUnaligned = nullptr;
     uint8_t* m_ConstantData = nullptr;
     size_t m_ConstantDataOffset = 0;
+    bool m_ConstantOverflow = false;
     size_t m_ResourceOffset = 0;
     size_t m_ClearPassIndex[2] = {};
     float m_OrthoMode = 0.0f;

@@ -131,9 +131,9 @@ def _user_planes(name, frame):
     return planes
 
 
-def output_planes(name, width, height):
+def output_planes(name, width, height, validation=False):
     """(ResourceType, dtype, channels, Format)"""
-    outs = []
+    outs = [(RT.OUT_VALIDATION, torch.uint8, 4, F.RGBA8_UNORM)] if validation else []
     if name in ("REBLUR_DIFFUSE", "REBLUR_DIFFUSE_SPECULAR"):
         outs.append((RT.OUT_DIFF_RADIANCE_HITDIST, torch.float16, 4, F.RGBA16_SFLOAT))
     if name in ("REBLUR_SPECULAR", "REBLUR_DIFFUSE_SPECULAR"):
@@ -262,12 +262,12 @@ def rel_error(got, want, floor=1e-3):
 
 
 class OracleRun:
-    def __init__(self, name, width, height, threads=0):
+    def __init__(self, name, width, height, threads=0, validation=False):
         self.name, self.width, self.height = name, width, height
         self.inst = api.Instance([(0, DENOISERS[name][0])])
         self.ex = oracle_driver.OracleExecutor(self.inst, width, height, api.FORMAT_BYTES, threads=threads)
         self.outs = {}
-        for rt, dtype, ch, fmt in output_planes(name, width, height):
+        for rt, dtype, ch, fmt in output_planes(name, width, height, validation):
             arr = np.zeros((height, width, ch), dtype={torch.float16: np.float16, torch.int16: np.uint16 if fmt == F.R16_UNORM else np.int16}.get(dtype, np.uint8))
             self.outs[rt] = (arr, fmt)
             self.ex.bind(rt, arr, fmt)
@@ -302,7 +302,7 @@ def _padded(t, pad):
 
 
 class HipRun:
-    def __init__(self, name, width, height, pad=0, numerics="exact"):
+    def __init__(self, name, width, height, pad=0, numerics="exact", validation=False):
         """numerics: which build of the library runs -- "exact" (libNRD_hip_exact.so, bit-identical to the oracle) or "fast" (libNRD_hip.so, the product)"""
         from raytracingdenoiser_amd.executor import HipExecutor
 
@@ -310,7 +310,7 @@ class HipRun:
         self.inst = api.Instance([(0, DENOISERS[name][0])], numerics=numerics)
         self.ex = HipExecutor(self.inst, width, height)
         self.outs = {}
-        for rt, dtype, ch, fmt in output_planes(name, width, height):
+        for rt, dtype, ch, fmt in output_planes(name, width, height, validation):
             t = torch.zeros((height, width, ch), dtype=dtype, device="cuda")
             if pad:
                 t = _padded(t, pad)
@@ -384,7 +384,8 @@ def _run_parity(name, width, height, frames, verbose, settings_overrides, static
         seq = [embed_in_resource(fr, resource) for fr in seq]
         cs_kw.update(resourceSize=resource, resourceSizePrev=resource)
     rw, rh = resource or (width, height)
-    ora, hip = OracleRun(name, rw, rh), HipRun(name, rw, rh, pad=pad, numerics=numerics)
+    validation = bool(cs_kw.get("enableValidation"))  # the debug overlay (OUT_VALIDATION, RGBA8) is bound and compared like any other output
+    ora, hip = OracleRun(name, rw, rh, validation=validation), HipRun(name, rw, rh, pad=pad, numerics=numerics, validation=validation)
     if graph:
         hip.ex.set_graph_mode(True)
     worst = 0.0

@@ -137,3 +137,16 @@ def test_ping_pong_alternates():
         seen.append((perm[2], perm[-1]))  # stabilized history read / written
     assert seen[0] != seen[1] and seen[0] == seen[2]
     assert seen[0] == (seen[1][1], seen[1][0])
+
+
+def test_constant_arena_overflow_fails_the_whole_call():
+    """The per-frame constant arena holds 128 KiB (reference InstanceImpl.h: CONSTANT_DATA_SIZE). An instance with more denoisers than that
+    covers must fail GetComputeDispatches as a whole (no dispatch with a null / shared constant block is handed out) and keep working for
+    a subset of its identifiers."""
+    many = [(i + 1, api.Denoiser.REBLUR_DIFFUSE_SPECULAR) for i in range(24)]  # 24 x ~9 dispatches x 832 bytes > 128 KiB
+    inst = api.Instance(many)
+    assert inst.set_common_settings(_settings(128, 128)) == api.Result.SUCCESS
+    r, out, n = inst.get_compute_dispatches_raw()
+    assert r == api.Result.FAILURE and n == 0 and not out
+    r, ds = inst.get_compute_dispatches([1, 2])
+    assert r == api.Result.SUCCESS and len(ds) > 10 and all(len(d.constants) in (0, 832) for d in ds)

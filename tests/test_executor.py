@@ -42,8 +42,8 @@ def test_graph_mode_is_bit_identical_to_eager(name):
 
 @pytest.mark.gpu
 def test_unsupported_dispatch_launches_nothing():
-    """CommonSettings::enableValidation appends REBLUR_Validation as the LAST dispatch of the list; while a pass of a list cannot run, nrdHipDenoise must
-    fail before anything is enqueued (reference Integration::Denoise contract) -- outputs and history stay untouched"""
+    """While one pass of a frame's list cannot run (here: a launcher-level rejection in the MIDDLE of the list), nrdHipDenoise must fail before anything
+    is enqueued (reference Integration::Denoise contract) -- outputs and history stay untouched"""
     name, w, h = "REBLUR_DIFFUSE_SPECULAR", 192, 128
     seq = parity.generate_sequence(name, w, h, 3)
     hip = parity.HipRun(name, w, h, numerics="fast")
