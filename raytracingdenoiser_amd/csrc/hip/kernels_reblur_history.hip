@@ -206,7 +206,7 @@ NRD_D typename ReblurSignal<KIND>::type HistoryFixSignal(const ReblurCB& c, cons
 }
 
 template <bool DIFF, bool SPEC, bool PERF, int KIND, bool SH>
-__global__ __launch_bounds__(TILE_X* TILE_Y) void ReblurHistoryFixKernel(ReblurCB c, HfPlanes P, RowRange rr) {
+__global__ __launch_bounds__(TILE_X* TILE_Y, NRD_WAVES_REBLUR_HF) void ReblurHistoryFixKernel(ReblurCB c, HfPlanes P, RowRange rr) {
     typedef ReblurSignal<KIND> Sig;
     constexpr bool OCC = KIND == SIGNAL_OCCLUSION;
     typedef typename Sig::type S;
@@ -348,8 +348,10 @@ NRD_D void LumaStats(const ReblurCB& c, const float* s_Luma, int tx, int ty, flo
         luma = Clamp(luma, mn, mx);
 }
 
-template <bool DIFF, bool SPEC, bool PERF, bool SH, int KIND> // KIND: radiance or directional occlusion (the occlusion family has no stabilisation pass)
-__global__ __launch_bounds__(TILE_X* TILE_Y) void ReblurTemporalStabilizationKernel(ReblurCB c, TsPlanes P, RowRange rr) {
+// KIND: radiance or directional occlusion (the occlusion family has no stabilisation pass)
+// MVMOD: the specular motion-vector modification is on this frame (CommonSettings::isBaseColorMetalnessAvailable); compiled out otherwise
+template <bool DIFF, bool SPEC, bool PERF, bool SH, int KIND, bool MVMOD>
+__global__ __launch_bounds__(TILE_X* TILE_Y, NRD_WAVES_REBLUR_TS) void ReblurTemporalStabilizationKernel(ReblurCB c, TsPlanes P, RowRange rr) {
     typedef ReblurSignal<KIND> Sig;
     typedef typename Sig::type S;
     __shared__ float s_DiffLuma[DIFF ? ts::BUF_Y * ts::BUF_STRIDE : 1];
@@ -480,7 +482,7 @@ __global__ __launch_bounds__(TILE_X* TILE_Y) void ReblurTemporalStabilizationKer
 
         // Modify MVs if requested (reference REBLUR_TemporalStabilization.hlsli:250-285): where the surface is mostly specular, IN_MV is bent towards
         // the motion of the reflected world. A uniform branch: x = 2 unless CommonSettings::isBaseColorMetalnessAvailable
-        if (c.gSpecProbabilityThresholdsForMvModification.x < 1.0f) {
+        if (MVMOD && c.gSpecProbabilityThresholdsForMvModification.x < 1.0f) {
             float NoV = Abs(Dot(N, V));
             float4 baseColorMetalness = LoadRGBA8Unorm(P.baseColorMetalness, px, py);
             float3 albedo, Rf0;
@@ -597,7 +599,10 @@ static const char* LaunchTemporalStabilization(const PassArgs& a) {
     if (k != a.planesNum)
         return "REBLUR temporal stabilization: unexpected resource count";
     RowGrid g = GridForRows(c.gRectSizeMinusOne.x + 1, c.gRectSizeMinusOne.y + 1, TILE_X, TILE_Y, a.rowBegin, a.rowEnd);
-    LaunchPass(a, (ReblurTemporalStabilizationKernel<DIFF, SPEC, PERF, SH, KIND>), g.grid, dim3(TILE_X * TILE_Y), c, P, MakeRowRange(g));
+    if (SPEC && c.gSpecProbabilityThresholdsForMvModification.x < 1.0f)
+        LaunchPass(a, (ReblurTemporalStabilizationKernel<DIFF, SPEC, PERF, SH, KIND, SPEC>), g.grid, dim3(TILE_X * TILE_Y), c, P, MakeRowRange(g));
+    else
+        LaunchPass(a, (ReblurTemporalStabilizationKernel<DIFF, SPEC, PERF, SH, KIND, false>), g.grid, dim3(TILE_X * TILE_Y), c, P, MakeRowRange(g));
     return nullptr;
 }
 

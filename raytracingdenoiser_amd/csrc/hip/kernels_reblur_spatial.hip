@@ -67,10 +67,19 @@ struct SpatialCtx {
     float3 N, Nv, Xv, Vv;
     float4 rotator;
     float2 data1;
+    float3 geo; // fast build, full-rect taps: dot(Nv, view position of texel k with depth z) = z * (k.x * geo.x + k.y * geo.y + geo.z)
     // checkerboard resolve of the pre-pass (reference REBLUR_PrePass.hlsli:43-56): neighbour columns in the half-width input + their weights
     int cbX0, cbX1;
     float2 wc;
 };
+
+// Fast build, full-rect variants: the screen-space taps are generated in pixel units (the rotator is scaled by the rect size once per pixel instead of
+// multiplying every tap's uv by it); the exact build keeps the reference's operation order
+#if NRD_FAST
+#define NRD_TAPS_IN_PIXELS(FR) ((FR) != 0)
+#else
+#define NRD_TAPS_IN_PIXELS(FR) false
+#endif
 
 // ---- one tap of the Poisson kernels: position -> texel, guides of that texel ------------------------------------------------------------------
 // The reference snaps the tap to a pixel centre (floor(uv * rectSize) + 0.5), turns it back into a uv, scales / clamps it to the viewport, lets the
@@ -81,52 +90,63 @@ struct SpatialCtx {
 struct TapGuides {
     float w;          // IsInScreenNearest
     float3 Ns, Xvs;   // world-space normal, view-space position of the tap's texel
+    float NvXvs;      // dot(centre view-space normal, Xvs) (the argument of the plane-distance weight)
     float roughnessS, materialIDs, zs;
     int2 ts;          // texel of the signal planes
     float2 uv;        // generic path only
 };
 
-template <SpatialMode MODE, bool CB, bool FR, bool NEED_ROUGHNESS>
-NRD_D TapGuides FetchTapGuides(const ReblurCB& c, float2 uv, const Plane& gIn_Signal, const Plane& gIn_ViewZ, const Plane& gIn_Normal_Roughness, const Plane& gIn_ViewPos, uint32_t checkerboardMode,
-    uint32_t n, bool compareMaterials) {
+// the "full rect" tap: k = the snapped pixel (integer-valued floats, not yet clamped)
+template <int FR, bool NEED_ROUGHNESS>
+NRD_D TapGuides FetchTapGuidesFullRect(const ReblurCB& c, const SpatialCtx& s, float2 k, const Plane& gIn_Normal_Roughness, const Plane& gIn_ViewPos, bool compareMaterials) {
     TapGuides t;
     const float2 rectSize = ToF2(c.gRectSize), rectSizeInv = ToF2(c.gRectSizeInv);
-    uv = Floor(uv * rectSize);
-    if (FR) {
-        // clamp in the float domain (one v_med3_f32 per axis; the snapped coordinate is an integer-valued float): inside <=> the clamp changed nothing
-        const float cxf = __builtin_amdgcn_fmed3f(uv.x, 0.0f, rectSize.x - 1.0f), cyf = __builtin_amdgcn_fmed3f(uv.y, 0.0f, rectSize.y - 1.0f);
-        t.w = (cxf == uv.x && cyf == uv.y) ? 1.0f : 0.0f;
-        t.ts = make_int2((int)cxf, (int)cyf);
-        // Guides of the texel: decoded normal (16 B) + viewZ (4 B); the view position is re-derived from viewZ (6 VALU). Fetching it as a second 16-byte
-        // guide texel instead (r02_b / r02_c A/B) saved 19 % of the instructions and bought nothing: the extra 12 bytes per tap through the L1 / texture-address
-        // path cost as much (profiles/r02_c_gather_bench.txt prices a wave's 16-byte gather at 40-150 CU cycles, a 4-byte one at 6-40). Staging the whole tap
-        // footprint in LDS was measured too (r02_d: 32x16 workgroups, halo 12, 76 KB) and lost 15-20 % to the fill and the lower occupancy: neighbouring
-        // lanes' taps land on neighbouring texels, so the global path is better coalesced than a scattered gather.
-        // With the per-frame (normal, viewZ) guide plane (passes.h viewPos) a diffuse tap is ONE 16-byte guide load; a specular tap adds the 4 bytes that
-        // hold the roughness / material bits of the decoded-normal texel.
-        uint32_t bits = 0u;
-        if (gIn_ViewPos.ptr) {
-            const uint32_t offset = __umul24((uint32_t)t.ts.y, gIn_ViewPos.pitch) + (uint32_t)t.ts.x * 16u; // same layout as the decoded normals (launcher check)
-            const float4 g = *(const float4*)(gIn_ViewPos.ptr + offset);
-            t.Ns = Xyz(g);
-            t.zs = g.w;
-            if (NEED_ROUGHNESS || compareMaterials)
-                bits = *(const uint32_t*)(gIn_Normal_Roughness.ptr + offset + 12u);
-        } else {
-            const float4 g0 = LoadRGBA32F(gIn_Normal_Roughness, t.ts.x, t.ts.y);
-            t.zs = UnpackViewZ(c, LoadR32F(gIn_ViewZ, t.ts.x, t.ts.y));
-            t.Ns = Xyz(g0);
-            bits = AsUint(g0.w);
-        }
-        const float2 uvc = (uv + 0.5f) * rectSizeInv; // centre of the snapped pixel; equals the clamped texel's centre whenever the tap counts (t.w != 0)
-        t.Xvs = ReconstructViewPosition(uvc, ToF4(c.gFrustum), t.zs, c.gOrthoMode);
-        t.materialIDs = 0.0f;
-        if (compareMaterials)
-            t.materialIDs = NRD_DIV_3(float(bits >> 10)) * 3.0f;
-        t.roughnessS = NEED_ROUGHNESS ? NRD_DIV_1023(float(bits & 0x3FFu)) : 0.0f;
-        t.uv = uv; // unused
-        return t;
+    // clamp in the float domain (one v_med3_f32 per axis; the snapped coordinate is an integer-valued float): inside <=> the clamp changed nothing
+    const float cxf = __builtin_amdgcn_fmed3f(k.x, 0.0f, rectSize.x - 1.0f), cyf = __builtin_amdgcn_fmed3f(k.y, 0.0f, rectSize.y - 1.0f);
+    t.w = (cxf == k.x && cyf == k.y) ? 1.0f : 0.0f;
+    t.ts = make_int2((int)cxf, (int)cyf);
+    // Guides of the texel: the per-frame (normal, viewZ) guide plane (passes.h viewPos) makes a diffuse tap ONE 16-byte guide load; a specular tap adds the
+    // 4 bytes that hold the roughness / material bits of the decoded-normal texel. The view position is re-derived from viewZ. Fetching it as a second
+    // 16-byte guide texel instead (r02_b / r02_c A/B) saved 19 % of the instructions and bought nothing: the extra 12 bytes per tap through the L1 /
+    // texture-address path cost as much (profiles/r02_c_gather_bench.txt prices a wave's 16-byte gather at 40-150 CU cycles, a 4-byte one at 6-40). Staging
+    // the whole tap footprint in LDS was measured too (r02_d: 32x16 workgroups, halo 12, 76 KB) and lost 15-20 % to the fill and the lower occupancy:
+    // neighbouring lanes' taps land on neighbouring texels, so the global path is better coalesced than a scattered gather.
+    // FR == 2: no material test in this frame (the launcher checks the constants) -- the tap is straight-line code, so the compiler can overlap the
+    // loads of neighbouring taps; a runtime test per tap (even a uniform one) ends the basic block and with it the scheduling window (r02_h: -17 % on
+    // the three spatial passes, 95 -> 76 VGPRs).
+    const bool materials = FR == 1 && compareMaterials;
+    uint32_t bits = 0u;
+    {
+        const uint32_t offset = __umul24((uint32_t)t.ts.y, gIn_ViewPos.pitch) + (uint32_t)t.ts.x * 16u; // same layout as the decoded normals (launcher check)
+        const float4 g = *(const float4*)(gIn_ViewPos.ptr + offset);
+        t.Ns = Xyz(g);
+        t.zs = g.w;
+        if (NEED_ROUGHNESS || FR == 1)
+            bits = *(const uint32_t*)(gIn_Normal_Roughness.ptr + offset + 12u);
     }
+    const float2 uvc = (k + 0.5f) * rectSizeInv; // centre of the snapped pixel; equals the clamped texel's centre whenever the tap counts (t.w != 0)
+    t.Xvs = ReconstructViewPosition(uvc, ToF4(c.gFrustum), t.zs, 0.0f); // perspective only (CheckSupported); dead code unless the caller needs the position
+#if NRD_FAST
+    t.NvXvs = t.zs * (k.x * s.geo.x + (k.y * s.geo.y + s.geo.z)); // 3 instructions instead of 13 (same value up to rounding: SpatialCtx::geo)
+#else
+    t.NvXvs = Dot(s.Nv, t.Xvs);
+#endif
+    t.materialIDs = 0.0f;
+    if (materials)
+        t.materialIDs = NRD_DIV_3(float(bits >> 10)) * 3.0f;
+    t.roughnessS = NEED_ROUGHNESS ? NRD_DIV_1023(float(bits & 0x3FFu)) : 0.0f;
+    t.uv = k; // unused
+    return t;
+}
+
+template <SpatialMode MODE, bool CB, int FR, bool NEED_ROUGHNESS>
+NRD_D TapGuides FetchTapGuides(const ReblurCB& c, const SpatialCtx& s, float2 uv, const Plane& gIn_Signal, const Plane& gIn_ViewZ, const Plane& gIn_Normal_Roughness, const Plane& gIn_ViewPos,
+    uint32_t checkerboardMode, uint32_t n, bool compareMaterials) {
+    const float2 rectSize = ToF2(c.gRectSize), rectSizeInv = ToF2(c.gRectSizeInv);
+    uv = Floor(uv * rectSize);
+    if (FR)
+        return FetchTapGuidesFullRect<FR, NEED_ROUGHNESS>(c, s, uv, gIn_Normal_Roughness, gIn_ViewPos, compareMaterials);
+    TapGuides t;
     uv = uv + 0.5f;
     if (MODE == PRE_BLUR && CB)
         uv = ApplyCheckerboardShift(uv, checkerboardMode, n, c.gFrameIndex);
@@ -144,6 +164,7 @@ NRD_D TapGuides FetchTapGuides(const ReblurCB& c, float2 uv, const Plane& gIn_Si
     t.Ns = Xyz(Ns);
     t.roughnessS = Ns.w;
     t.Xvs = ReconstructViewPosition(uv, ToF4(c.gFrustum), t.zs, c.gOrthoMode);
+    t.NvXvs = Dot(s.Nv, t.Xvs);
     t.w = IsInScreenNearest(uv);
     t.uv = uv;
     return t;
@@ -162,7 +183,7 @@ NRD_D float PoissonGaussianWeight(int n) { // = GetGaussianWeight( offset.z ), b
 // SH = the *_SH denoisers: an SH1 plane (RGBA16F) rides on the same taps and weights (diffuse: all 4 components, specular: .xyz only)
 // CB = a checkerboard mode is on (pre-pass only): the noisy inputs live in the left half of their planes, a tap that lands on a pixel
 // without data moves one pixel sideways, and pixels the taps could not fill are resolved from the two horizontal neighbours
-template <SpatialMode MODE, bool PERF, int KIND, bool SH, bool CB, bool FR>
+template <SpatialMode MODE, bool PERF, int KIND, bool SH, bool CB, int FR>
 NRD_D typename ReblurSignal<KIND>::type DiffuseSpatialFilterTaps(const ReblurCB& c, const SpatialCtx& s, typename ReblurSignal<KIND>::type diff, const Plane& gIn_Diff, const Plane& gIn_ViewZ,
     const Plane& gIn_Normal_Roughness, const Plane& gIn_ViewPos, float4& diffSh, const Plane& gIn_DiffSh, float& sum) {
     typedef ReblurSignal<KIND> Sig;
@@ -217,19 +238,26 @@ NRD_D typename ReblurSignal<KIND>::type DiffuseSpatialFilterTaps(const ReblurCB&
     skew = skew * (rectSizeInv * blurRadius);
     float4 scaledRotator = ScaleRotator(s.rotator, skew);
     // material IDs are 0..3: with a minimum material >= 3 every comparison holds (the library default is 4 = "off")
-    const bool compareMaterials = c.gDiffMinMaterial < 3.0f;
+    const bool compareMaterials = FR != 2 && c.gDiffMinMaterial < 3.0f;
+    const float4 rotatorInPixels = ScaleRotator(scaledRotator, ToF2(c.gRectSize));
+    const float2 pixelPos = F2(float(s.px) + 0.5f, float(s.py) + 0.5f);
 
 #pragma unroll
     for (int n = 0; n < (PERF ? 6 : 8); n++) {
         float3 offset = PERF ? F3(g_Special6[n][0], g_Special6[n][1], g_Special6[n][2]) : F3(g_Special8[n][0], g_Special8[n][1], g_Special8[n][2]);
-        const float2 uvTap = s.pixelUv + RotateVector(scaledRotator, F2(offset.x, offset.y));
-        const TapGuides t = FetchTapGuides<MODE, CB, FR, false>(c, uvTap, gIn_Diff, gIn_ViewZ, gIn_Normal_Roughness, gIn_ViewPos, c.gDiffCheckerboard, (uint32_t)n, compareMaterials);
+        TapGuides t;
+        if (NRD_TAPS_IN_PIXELS(FR)) {
+            t = FetchTapGuidesFullRect<FR, false>(c, s, Floor(pixelPos + RotateVector(rotatorInPixels, F2(offset.x, offset.y))), gIn_Normal_Roughness, gIn_ViewPos, compareMaterials);
+        } else {
+            const float2 uvTap = s.pixelUv + RotateVector(scaledRotator, F2(offset.x, offset.y));
+            t = FetchTapGuides<MODE, CB, FR, false>(c, s, uvTap, gIn_Diff, gIn_ViewZ, gIn_Normal_Roughness, gIn_ViewPos, c.gDiffCheckerboard, (uint32_t)n, compareMaterials);
+        }
         const int2 ts = t.ts;
 
         float angle = AcosApprox(Dot(s.N, t.Ns));
 
         float w = t.w;
-        w *= ComputeWeight(Dot(s.Nv, t.Xvs), geometryWeightParams.x, geometryWeightParams.y);
+        w *= ComputeWeight(t.NvXvs, geometryWeightParams.x, geometryWeightParams.y);
         if (compareMaterials)
             w *= CompareMaterials(s.materialID, t.materialIDs, c.gDiffMinMaterial) ? 1.0f : 0.0f;
         w *= ComputeWeight(angle, normalWeightParam, 0.0f);
@@ -256,7 +284,7 @@ NRD_D typename ReblurSignal<KIND>::type DiffuseSpatialFilterTaps(const ReblurCB&
 }
 
 // "sum" = 1 when the centre pixel carries data, 0 for the empty pixels of a checkerboarded input
-template <SpatialMode MODE, bool PERF, int KIND, bool SH, bool CB, bool FR>
+template <SpatialMode MODE, bool PERF, int KIND, bool SH, bool CB, int FR>
 NRD_D typename ReblurSignal<KIND>::type DiffuseSpatialFilter(const ReblurCB& c, const SpatialCtx& s, typename ReblurSignal<KIND>::type diff, const Plane& gIn_Diff, const Plane& gIn_ViewZ,
     const Plane& gIn_Normal_Roughness, const Plane& gIn_ViewPos, float4& diffSh, const Plane& gIn_DiffSh, float sum) {
     typedef ReblurSignal<KIND> Sig;
@@ -276,7 +304,7 @@ NRD_D typename ReblurSignal<KIND>::type DiffuseSpatialFilter(const ReblurCB& c, 
     return diff;
 }
 
-template <SpatialMode MODE, bool PERF, int KIND, bool SH, bool CB, bool FR>
+template <SpatialMode MODE, bool PERF, int KIND, bool SH, bool CB, int FR>
 NRD_D typename ReblurSignal<KIND>::type SpecularSpatialFilterTaps(const ReblurCB& c, const SpatialCtx& s, typename ReblurSignal<KIND>::type spec, const Plane& gIn_Spec, const Plane& gIn_ViewZ,
     const Plane& gIn_Normal_Roughness, const Plane& gIn_ViewPos, const Plane& gOut_SpecHitDistForTracking, float4& specSh, const Plane& gIn_SpecSh, float& sum) {
     typedef ReblurSignal<KIND> Sig;
@@ -340,7 +368,7 @@ NRD_D typename ReblurSignal<KIND>::type SpecularSpatialFilterTaps(const ReblurCB
         minHitDistWeight *= Sqrt(specNonLinearAccumSpeed);
 
     const float2 rectSizeInv = ToF2(c.gRectSizeInv);
-    const bool compareMaterials = c.gSpecMinMaterial < 3.0f; // see the diffuse filter
+    const bool compareMaterials = FR != 2 && c.gSpecMinMaterial < 3.0f; // see the diffuse filter
 
     constexpr bool SCREEN_SPACE = MODE == PRE_BLUR || PERF; // REBLUR_USE_SCREEN_SPACE_SAMPLING_FOR_SPECULAR
     float4 scaledRotator = F4(0.0f);
@@ -359,17 +387,40 @@ NRD_D typename ReblurSignal<KIND>::type SpecularSpatialFilterTaps(const ReblurCB
         T = T * (worldRadius * skewFactor);
         B = B * (worldRadius / skewFactor);
     }
+    const float4 rotatorInPixels = ScaleRotator(scaledRotator, ToF2(c.gRectSize));
+    const float2 pixelPos = F2(float(s.px) + 0.5f, float(s.py) + 0.5f);
+    // fast build, world-space taps: the projection is linear in the kernel offsets, clip(X + T * o.x + B * o.y) = clip(X) + o.x * M T + o.y * M B, so the
+    // three matrix products are done once per pixel and a tap costs 6 FMAs + one reciprocal instead of a 4x4 transform (o is the same for every pixel)
+    float3 clipX = F3(0.0f), clipT = F3(0.0f), clipB = F3(0.0f); // (x, y, w) rows of gViewToClip
+    if (!SCREEN_SPACE && NRD_TAPS_IN_PIXELS(FR)) {
+        const float* m = c.gViewToClip;
+        clipX = F3(m[0] * s.Xv.x + m[4] * s.Xv.y + m[8] * s.Xv.z + m[12], m[1] * s.Xv.x + m[5] * s.Xv.y + m[9] * s.Xv.z + m[13], m[3] * s.Xv.x + m[7] * s.Xv.y + m[11] * s.Xv.z + m[15]);
+        clipT = F3(m[0] * T.x + m[4] * T.y + m[8] * T.z, m[1] * T.x + m[5] * T.y + m[9] * T.z, m[3] * T.x + m[7] * T.y + m[11] * T.z);
+        clipB = F3(m[0] * B.x + m[4] * B.y + m[8] * B.z, m[1] * B.x + m[5] * B.y + m[9] * B.z, m[3] * B.x + m[7] * B.y + m[11] * B.z);
+    }
+    const float2 halfRect = ToF2(c.gRectSize) * 0.5f;
 
 #pragma unroll
     for (int n = 0; n < (PERF ? 6 : 8); n++) {
         float3 offset = PERF ? F3(g_Special6[n][0], g_Special6[n][1], g_Special6[n][2]) : F3(g_Special8[n][0], g_Special8[n][1], g_Special8[n][2]);
-        float2 uv;
-        if (SCREEN_SPACE)
-            uv = s.pixelUv + RotateVector(scaledRotator, F2(offset.x, offset.y));
-        else
-            uv = GetKernelSampleCoordinates(c.gViewToClip, offset, s.Xv, T, B, s.rotator);
-
-        const TapGuides t = FetchTapGuides<MODE, CB, FR, true>(c, uv, gIn_Spec, gIn_ViewZ, gIn_Normal_Roughness, gIn_ViewPos, c.gSpecCheckerboard, (uint32_t)n, compareMaterials);
+        TapGuides t;
+        if (!SCREEN_SPACE && NRD_TAPS_IN_PIXELS(FR)) {
+            const float2 o = RotateVector(s.rotator, F2(offset.x, offset.y));
+            const float3 clip = clipX + clipT * o.x + clipB * o.y;
+            const float rw = Rcp(clip.z);
+            // uv * rectSize with uv = (x / w * 0.5 + 0.5, -y / w * 0.5 + 0.5)
+            const float2 k = Floor(F2(clip.x * rw * halfRect.x + halfRect.x, clip.y * rw * -halfRect.y + halfRect.y));
+            t = FetchTapGuidesFullRect<FR, true>(c, s, k, gIn_Normal_Roughness, gIn_ViewPos, compareMaterials);
+        } else if (SCREEN_SPACE && NRD_TAPS_IN_PIXELS(FR)) {
+            t = FetchTapGuidesFullRect<FR, true>(c, s, Floor(pixelPos + RotateVector(rotatorInPixels, F2(offset.x, offset.y))), gIn_Normal_Roughness, gIn_ViewPos, compareMaterials);
+        } else {
+            float2 uv;
+            if (SCREEN_SPACE)
+                uv = s.pixelUv + RotateVector(scaledRotator, F2(offset.x, offset.y));
+            else
+                uv = GetKernelSampleCoordinates(c.gViewToClip, offset, s.Xv, T, B, s.rotator);
+            t = FetchTapGuides<MODE, CB, FR, true>(c, s, uv, gIn_Spec, gIn_ViewZ, gIn_Normal_Roughness, gIn_ViewPos, c.gSpecCheckerboard, (uint32_t)n, compareMaterials);
+        }
         const int2 ts = t.ts;
         const float zs = t.zs;
         const float3 Xvs = t.Xvs;
@@ -378,7 +429,7 @@ NRD_D typename ReblurSignal<KIND>::type SpecularSpatialFilterTaps(const ReblurCB
         float angle = AcosApprox(Dot(s.N, t.Ns));
 
         float w = t.w;
-        w *= ComputeWeight(Dot(s.Nv, Xvs), geometryWeightParams.x, geometryWeightParams.y);
+        w *= ComputeWeight(t.NvXvs, geometryWeightParams.x, geometryWeightParams.y);
         if (compareMaterials)
             w *= CompareMaterials(s.materialID, t.materialIDs, c.gSpecMinMaterial) ? 1.0f : 0.0f;
         w *= ComputeWeight(angle, normalWeightParam, 0.0f);
@@ -421,7 +472,7 @@ NRD_D typename ReblurSignal<KIND>::type SpecularSpatialFilterTaps(const ReblurCB
     return spec;
 }
 
-template <SpatialMode MODE, bool PERF, int KIND, bool SH, bool CB, bool FR>
+template <SpatialMode MODE, bool PERF, int KIND, bool SH, bool CB, int FR>
 NRD_D typename ReblurSignal<KIND>::type SpecularSpatialFilter(const ReblurCB& c, const SpatialCtx& s, typename ReblurSignal<KIND>::type spec, const Plane& gIn_Spec, const Plane& gIn_ViewZ,
     const Plane& gIn_Normal_Roughness, const Plane& gIn_ViewPos, const Plane& gOut_SpecHitDistForTracking, float4& specSh, const Plane& gIn_SpecSh, float sum) {
     typedef ReblurSignal<KIND> Sig;
@@ -459,8 +510,14 @@ NRD_D bool MakeSpatialCtx(const ReblurCB& c, int px, int py, float viewZ, const 
     s.frustumSize = GetFrustumSize(c.gMinRectDimMulUnproject, c.gOrthoMode, viewZ);
     s.rotator = rotator;
     s.data1 = F2(0.0f, 0.0f);
+    {   // Xv(k, z) = ((uvc * frustum.zw + frustum.xy) * z, z) with uvc = (k + 0.5) * rectSizeInv, so dot(Nv, Xv) = z * (k.x * geo.x + k.y * geo.y + geo.z)
+        const float4 f = ToF4(c.gFrustum);
+        const float2 r = ToF2(c.gRectSizeInv);
+        s.geo = F3(s.Nv.x * f.z * r.x, s.Nv.y * f.w * r.y, s.Nv.x * (0.5f * r.x * f.z + f.x) + s.Nv.y * (0.5f * r.y * f.w + f.y) + s.Nv.z);
+    }
     return true;
 }
+
 
 struct SpatialPlanes {
     Plane tiles, normalRoughness, viewZ, data1;
@@ -475,9 +532,9 @@ struct SpatialPlanes {
     Plane inDiffSh, inSpecSh, outDiffSh, outSpecSh, outDiffShCopy, outSpecShCopy; // SH family
 };
 
-// FR: rect == resource and no checkerboard (FetchTapGuides)
-template <SpatialMode MODE, bool DIFF, bool SPEC, bool NO_TS, bool PERF, int KIND, bool SH, bool CB, bool FR>
-__global__ __launch_bounds__(TILE_X* TILE_Y) void ReblurSpatialKernel(ReblurCB c, SpatialPlanes P, RowRange rr) {
+// FR: 0 = generic taps; 1 = rect == resource, no checkerboard, (normal, viewZ) guide plane present; 2 = 1 without material tests (FetchTapGuides)
+template <SpatialMode MODE, bool DIFF, bool SPEC, bool NO_TS, bool PERF, int KIND, bool SH, bool CB, int FR>
+__global__ __launch_bounds__(TILE_X* TILE_Y, NRD_WAVES_REBLUR_SPATIAL) void ReblurSpatialKernel(ReblurCB c, SpatialPlanes P, RowRange rr) {
     typedef ReblurSignal<KIND> Sig;
     constexpr bool OCC = KIND == SIGNAL_OCCLUSION;
     typedef typename Sig::type S;
@@ -639,17 +696,21 @@ static const char* LaunchSpatial(const PassArgs& a) {
     const RowRange rows = MakeRowRange(g);
     if constexpr (MODE == PRE_BLUR) { // only the pre-pass reads the (possibly checkerboarded) noisy inputs
         if (c.gDiffCheckerboard != 2 || c.gSpecCheckerboard != 2) {
-            LaunchPass(a, (ReblurSpatialKernel<MODE, DIFF, SPEC, NO_TS, PERF, KIND, SH, true, false>), g.grid, dim3(TILE_X * TILE_Y), c, P, rows);
+            LaunchPass(a, (ReblurSpatialKernel<MODE, DIFF, SPEC, NO_TS, PERF, KIND, SH, true, 0>), g.grid, dim3(TILE_X * TILE_Y), c, P, rows);
             return nullptr;
         }
     }
-    // "full rect": the rect is the whole resource (no dynamic-resolution scaling) and the guide planes of this frame exist
+    // "full rect": the rect is the whole resource (no dynamic-resolution scaling) and the (normal, viewZ) guide plane of this frame exists;
+    // variant 2 when neither signal tests material IDs this frame (IDs are 0..3: a minimum >= 3, the library default, makes every comparison hold)
     const bool fullRect = c.gResolutionScale.x == 1.0f && c.gResolutionScale.y == 1.0f && c.gRectSizeMinusOne.x + 1 == P.decodedNR.w &&
-                          c.gRectSizeMinusOne.y + 1 == P.decodedNR.h && P.viewZ.w == P.decodedNR.w && P.viewZ.h == P.decodedNR.h && !ForceGenericTaps();
-    if (fullRect)
-        LaunchPass(a, (ReblurSpatialKernel<MODE, DIFF, SPEC, NO_TS, PERF, KIND, SH, false, true>), g.grid, dim3(TILE_X * TILE_Y), c, P, rows);
+                          c.gRectSizeMinusOne.y + 1 == P.decodedNR.h && P.viewZ.w == P.decodedNR.w && P.viewZ.h == P.decodedNR.h && P.viewPos.ptr && !ForceGenericTaps();
+    const bool materials = (DIFF && c.gDiffMinMaterial < 3.0f) || (SPEC && c.gSpecMinMaterial < 3.0f);
+    if (fullRect && !materials)
+        LaunchPass(a, (ReblurSpatialKernel<MODE, DIFF, SPEC, NO_TS, PERF, KIND, SH, false, 2>), g.grid, dim3(TILE_X * TILE_Y), c, P, rows);
+    else if (fullRect)
+        LaunchPass(a, (ReblurSpatialKernel<MODE, DIFF, SPEC, NO_TS, PERF, KIND, SH, false, 1>), g.grid, dim3(TILE_X * TILE_Y), c, P, rows);
     else
-        LaunchPass(a, (ReblurSpatialKernel<MODE, DIFF, SPEC, NO_TS, PERF, KIND, SH, false, false>), g.grid, dim3(TILE_X * TILE_Y), c, P, rows);
+        LaunchPass(a, (ReblurSpatialKernel<MODE, DIFF, SPEC, NO_TS, PERF, KIND, SH, false, 0>), g.grid, dim3(TILE_X * TILE_Y), c, P, rows);
     return nullptr;
 }
 

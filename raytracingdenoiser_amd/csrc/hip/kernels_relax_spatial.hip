@@ -238,7 +238,7 @@ NRD_D PrePassGuides FetchPrePassGuides(const RelaxCB& c, const PrePassPlanes& P,
 }
 
 template <bool DIFF, bool SPEC, bool SH, bool CB, bool FR>
-__global__ __launch_bounds__(256) void RelaxPrePassKernel(PrePassPlanes P, RelaxCB c, RowRange rows) {
+__global__ __launch_bounds__(256, NRD_WAVES_RELAX_PREPASS) void RelaxPrePassKernel(PrePassPlanes P, RelaxCB c, RowRange rows) {
     const int blockY = blockIdx.y + rows.firstBlockY;
     const int px = BlockTileX(rows) * TILE_X + (threadIdx.x & 31), py = blockY * TILE_Y + (threadIdx.x >> 5);
     const int rectW = c.shared.gRectSize.x, rectH = c.shared.gRectSize.y;
@@ -310,7 +310,7 @@ __global__ __launch_bounds__(256) void RelaxPrePassKernel(PrePassPlanes P, Relax
             float2 hitDistanceWeightParams = GetHitDistanceWeightParams(diffuseIllumination.w, 1.0f / 9.0f);
             float weightSum = 1.0f;
 
-#pragma unroll 2
+#pragma unroll NRD_RELAX_PREPASS_UNROLL
             for (int i = 0; i < 8; i++) {
                 const PrePassGuides t = FetchPrePassGuides<CB, FR>(c, P, P.diff.in, c.shared.gDiffCheckerboard, pixelUv, rectSize, rotator, i, blurRadius);
                 const float sampleMaterialID = t.materialID, sampleViewZ = t.viewZ;
@@ -392,7 +392,7 @@ __global__ __launch_bounds__(256) void RelaxPrePassKernel(PrePassPlanes P, Relax
             float3 rgb = Xyz(specularIllumination);
             const float roughnessRelax = LinearStep(0.5f, 1.0f, centerRoughness);
 
-#pragma unroll 2
+#pragma unroll NRD_RELAX_PREPASS_UNROLL
             for (int i = 0; i < 8; i++) {
                 const PrePassGuides t = FetchPrePassGuides<CB, FR>(c, P, P.spec.in, c.shared.gSpecCheckerboard, pixelUv, rectSize, rotator, i, blurRadius);
                 const float sampleMaterialID = t.materialID, sampleViewZ = t.viewZ, sampleRoughness = t.roughness;
@@ -481,7 +481,7 @@ struct HistoryFixPlanes {
 };
 
 template <bool DIFF, bool SPEC, bool SH>
-__global__ __launch_bounds__(256) void RelaxHistoryFixKernel(HistoryFixPlanes P, RelaxCB c, RowRange rows) {
+__global__ __launch_bounds__(256, NRD_WAVES_RELAX_HF) void RelaxHistoryFixKernel(HistoryFixPlanes P, RelaxCB c, RowRange rows) {
     const int blockY = blockIdx.y + rows.firstBlockY;
     const int px = BlockTileX(rows) * TILE_X + (threadIdx.x & 31), py = blockY * TILE_Y + (threadIdx.x >> 5);
     const int rectW = c.shared.gRectSize.x, rectH = c.shared.gRectSize.y;

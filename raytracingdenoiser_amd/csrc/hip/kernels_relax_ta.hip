@@ -36,7 +36,7 @@ struct TaPlanes {
 };
 
 template <bool DIFF, bool SPEC, bool SH>
-__global__ __launch_bounds__(256, 3) void RelaxTemporalAccumulationKernel(RelaxCB cArg, TaPlanes P, RowRange rows) {
+__global__ __launch_bounds__(256, NRD_WAVES_RELAX_TA) void RelaxTemporalAccumulationKernel(RelaxCB cArg, TaPlanes P, RowRange rows) {
     __shared__ float4 s_NormalSpecHitT[ta::BUF_Y * ta::BUF_STRIDE];
     // The constant block + up to 35 planes need far more than the 102 SGPRs there are; left alone the compiler spills scalars into
     // VGPR lanes (v_writelane / v_readlane + hazard nops on every use). The body reads the constants from an LDS copy instead
@@ -792,7 +792,7 @@ NRD_D void ResolveSignal(const RelaxCB& c, const SignalPlanes& S, const float4* 
 }
 
 template <bool DIFF, bool SPEC, bool SH>
-__global__ __launch_bounds__(256) void RelaxHistoryClampingKernel(HcPlanes P, RelaxCB c, RowRange rows) {
+__global__ __launch_bounds__(256, NRD_WAVES_RELAX_HC) void RelaxHistoryClampingKernel(HcPlanes P, RelaxCB c, RowRange rows) {
     __shared__ float4 s_SpecFast[SPEC ? hc::BUF_SIZE : 1], s_SpecNoisy[SPEC ? hc::BUF_SIZE : 1];
     __shared__ float4 s_DiffFast[DIFF ? hc::BUF_SIZE : 1], s_DiffNoisy[DIFF ? hc::BUF_SIZE : 1];
 

@@ -10,6 +10,43 @@
 #include <cstring>
 #include <vector>
 
+// Tuning knobs of A/B builds (tools/build_variant.py -DNRD_WAVES_<KERNEL>=n): the waves-per-SIMD target handed to the register allocator through
+// __launch_bounds__(threads, n); 0 = no hint (the allocator keeps the occupancy the kernel reaches by itself). The defaults are the measured best.
+#ifndef NRD_WAVES_REBLUR_SPATIAL
+#define NRD_WAVES_REBLUR_SPATIAL 0
+#endif
+#ifndef NRD_WAVES_REBLUR_HF
+#if NRD_FAST
+#define NRD_WAVES_REBLUR_HF 6 // 111 -> 80 VGPRs without scratch: -12 % (profiles/r02_g_occ_reblur.json)
+#else
+#define NRD_WAVES_REBLUR_HF 0
+#endif
+#endif
+#ifndef NRD_WAVES_REBLUR_TS
+#define NRD_WAVES_REBLUR_TS 0
+#endif
+#ifndef NRD_WAVES_RELAX_ATROUS
+#define NRD_WAVES_RELAX_ATROUS 0
+#endif
+#ifndef NRD_WAVES_RELAX_ATROUS_SMEM
+#define NRD_WAVES_RELAX_ATROUS_SMEM 0
+#endif
+#ifndef NRD_WAVES_RELAX_PREPASS
+#define NRD_WAVES_RELAX_PREPASS 0
+#endif
+#ifndef NRD_WAVES_RELAX_TA
+#define NRD_WAVES_RELAX_TA 3
+#endif
+#ifndef NRD_WAVES_RELAX_HC
+#define NRD_WAVES_RELAX_HC 0
+#endif
+#ifndef NRD_WAVES_RELAX_HF
+#define NRD_WAVES_RELAX_HF 0
+#endif
+#ifndef NRD_RELAX_PREPASS_UNROLL // unroll factor of the 8-tap loops of the RELAX pre-pass
+#define NRD_RELAX_PREPASS_UNROLL 2
+#endif
+
 namespace nrdhip {
 
 // One kernel launch of a pass as data: what the launchers hand to the executor instead of launching when a recorder is attached.

@@ -201,7 +201,11 @@ NRD_D float GetEncodingAwareNormalWeight(float3 Ncurr, float3 Nprev, float maxAn
     return SmoothStep01(1.0f - (angle - curvatureAngle - thresholdAngle) / maxAngle);
 }
 NRD_D float GetDisocclusionThreshold(float disocclusionThreshold, float frustumSize, float NoV) { return frustumSize * Sat(disocclusionThreshold / Max(0.01f, NoV)); }
+#if NRD_EXPERIMENT_NO_MATERIALS // A/B builds only: what a compile-time "no material test in this frame" flag would buy (tools/build_variant.py)
+NRD_D bool CompareMaterials(float, float, float) { return true; }
+#else
 NRD_D bool CompareMaterials(float m0, float m, float minm) { return Max(m0, minm) == Max(m, minm); }
+#endif
 
 NRD_D float GetMinAllowedLimitForHitDistNonLinearAccumSpeed(const ReblurCB& c, float roughness) {
     float frameNum = 0.5f * GetSpecMagicCurve(roughness) * c.gMaxAccumulatedFrameNum;

@@ -1,0 +1,26 @@
+#!/bin/bash
+# Round-2 GPU session I: straight-line full-rect taps (FR 2), pixel-space / linearised taps of the fast build: parity (exact build bit-exact, fast build
+# distribution + quality equivalence), benches of the product build
+tag=${1:-r02_i}
+R=${GRAFT_REPO_ROOT:-$(pwd)}
+mkdir -p $R/gpurun_out
+cd $R
+timeout 900 python -m pytest tests/test_reblur.py tests/test_relax.py tests/test_dynamic_resolution.py -m gpu -q -x > gpurun_out/${tag}_pytest_gpu.log 2>&1; echo "pytest exit $?" >> gpurun_out/${tag}_pytest_gpu.log
+tail -3 gpurun_out/${tag}_pytest_gpu.log
+timeout 900 python -m pytest tests/test_full_parity.py -m gpu -q -k "denoises_as_well or (fast_build_within_tolerance_over_48 and REBLUR_DIFFUSE_SPECULAR) or (exact_build_bit_exact_at_baseline and REBLUR_DIFFUSE_SPECULAR)" > gpurun_out/${tag}_pytest_full_parity.log 2>&1; echo "pytest exit $?" >> gpurun_out/${tag}_pytest_full_parity.log
+tail -5 gpurun_out/${tag}_pytest_full_parity.log
+B="python bench.py --no-cpu-baseline --no-parity --steps 48 --warmup 16"
+timeout 300 $B > gpurun_out/${tag}_cur_reblur.json 2>> gpurun_out/${tag}_bench.err
+timeout 300 $B --workload relax_ds_sh > gpurun_out/${tag}_cur_relax.json 2>> gpurun_out/${tag}_bench.err
+timeout 300 $B --workload reblur_diffuse > gpurun_out/${tag}_cur_reblur_diffuse.json 2>> gpurun_out/${tag}_bench.err
+timeout 300 $B --numerics exact > gpurun_out/${tag}_exact_reblur.json 2>> gpurun_out/${tag}_bench.err
+python - <<PY
+import json,glob
+for f in sorted(glob.glob('gpurun_out/${tag}_*_re*.json')):
+    try:
+        d=json.loads(open(f).read().strip().split('\n')[-1])
+        print('%-34s %8.1f %.4f  '%(f.split('/')[-1][:-5], d['value'], d['ms_per_step']) + ' '.join('%s=%.3f'%(k.split('_')[-1].replace('.cs','')[:8],v['avg_ms']) for k,v in d['passes'].items()))
+    except Exception as e:
+        print(f, 'ERR', e)
+PY
+tail -3 gpurun_out/${tag}_bench.err
