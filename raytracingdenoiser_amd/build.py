@@ -34,6 +34,11 @@ NUMERICS_FLAGS = {
     "exact": ["-ffp-contract=off"],
     "fast": ["-DNRD_FAST=1", "-ffp-contract=fast", "-fapprox-func", "-fgpu-flush-denormals-to-zero"],
 }
+# fast build, per translation unit: value-changing reassociation (a * b + a * c -> a * (b + c), x * 0 -> 0, hoisted reciprocals). NaN / infinity semantics
+# stay (the passes test for both). Measured per pass (profiles/r02_j_reassoc_*.json): -2 % on the REBLUR frame and on RELAX temporal accumulation; the a-trous
+# kernels lose a wave of occupancy with it (+13 %), so they keep the plain flags.
+REASSOC_FLAGS = ["-fno-signed-zeros", "-freciprocal-math", "-fassociative-math", "-fno-trapping-math"]
+FAST_EXTRA = {"kernels_reblur_ta.hip": REASSOC_FLAGS, "kernels_reblur_spatial.hip": REASSOC_FLAGS, "kernels_reblur_history.hip": REASSOC_FLAGS, "kernels_relax_ta.hip": REASSOC_FLAGS}
 LIB_NAMES = {"fast": "libNRD_hip.so", "exact": "libNRD_hip_exact.so"}
 # translation units that keep the exact flags in both builds: the REFERENCE accumulator is specified bit-exact (BASELINE.json) and is a pure
 # streaming kernel, the host dispatch compiler must hand identical constants to both builds
@@ -59,7 +64,7 @@ def _headers_digest():
 
 def _flags(src, numerics):
     exact = numerics == "exact" or os.path.basename(src) in ALWAYS_EXACT or src.endswith(".cpp")
-    return COMMON_FLAGS + NUMERICS_FLAGS["exact" if exact else "fast"] + ([] if numerics == "exact" else ["-DNRD_FAST_BUILD=1"])
+    return COMMON_FLAGS + NUMERICS_FLAGS["exact" if exact else "fast"] + ([] if exact else FAST_EXTRA.get(os.path.basename(src), [])) + ([] if numerics == "exact" else ["-DNRD_FAST_BUILD=1"])
 
 
 def _compile(src, hdr_digest, verbose, numerics):
@@ -83,7 +88,7 @@ def _compile(src, hdr_digest, verbose, numerics):
 
 
 def _global_digest(srcs, hdr_digest, numerics):
-    h = hashlib.sha1((hdr_digest + " ".join(COMMON_FLAGS + HIP_FLAGS + NUMERICS_FLAGS[numerics]) + numerics).encode())
+    h = hashlib.sha1((hdr_digest + " ".join(COMMON_FLAGS + HIP_FLAGS + NUMERICS_FLAGS[numerics]) + numerics + repr(sorted(FAST_EXTRA.items()))).encode())
     for s in srcs:
         with open(s, "rb") as fp:
             h.update(fp.read())

@@ -106,7 +106,7 @@ NRD_D typename ReblurSignal<KIND>::type HistoryFixSignal(const ReblurCB& c, cons
                 float4 Ns = LoadDecodedNormalRoughness(P.decodedNR, sx, sy, materialIDs);
 
                 float angle = AcosApprox(Dot(Xyz(Ns), s.N));
-                float3 Xvs = ReconstructViewPosition(uv, ToF4(c.gFrustum), zs, c.gOrthoMode);
+                float3 Xvs = ReconstructViewPosition(uv, ToF4(c.gFrustum), zs, NRD_ORTHO_MODE(c));
 
                 float w = IsInScreenNearest(uv);
                 w *= ComputeWeight(Dot(s.Nv, Xvs), geometryWeightParams.x, geometryWeightParams.y);
@@ -246,9 +246,9 @@ __global__ __launch_bounds__(TILE_X* TILE_Y, NRD_WAVES_REBLUR_HF) void ReblurHis
     float4 normalAndRoughness = LoadDecodedNormalRoughness(P.decodedNR, px, py, s.materialID);
     s.N = Xyz(normalAndRoughness);
     s.roughness = normalAndRoughness.w;
-    s.frustumSize = GetFrustumSize(c.gMinRectDimMulUnproject, c.gOrthoMode, s.viewZ);
+    s.frustumSize = GetFrustumSize(c.gMinRectDimMulUnproject, NRD_ORTHO_MODE(c), s.viewZ);
     s.pixelUv = F2(float(px) + 0.5f, float(py) + 0.5f) * ToF2(c.gRectSizeInv);
-    s.Xv = ReconstructViewPosition(s.pixelUv, ToF4(c.gFrustum), s.viewZ, c.gOrthoMode);
+    s.Xv = ReconstructViewPosition(s.pixelUv, ToF4(c.gFrustum), s.viewZ, NRD_ORTHO_MODE(c));
     s.Nv = RotateVectorInverse(c.gViewToWorld, s.N);
     float2 frameNum = LoadData1<DIFF, SPEC>(P.data1, px, py);
     float2 stride = F2(c.gHistoryFixBasePixelStride / (2.0f + frameNum.x), c.gHistoryFixBasePixelStride / (2.0f + frameNum.y));
@@ -391,7 +391,7 @@ __global__ __launch_bounds__(TILE_X* TILE_Y, NRD_WAVES_REBLUR_TS) void ReblurTem
 
     // Position
     float2 pixelUv = F2(float(px) + 0.5f, float(py) + 0.5f) * rectSizeInv;
-    float3 Xv = ReconstructViewPosition(pixelUv, frustum, viewZ, c.gOrthoMode);
+    float3 Xv = ReconstructViewPosition(pixelUv, frustum, viewZ, NRD_ORTHO_MODE(c));
     float3 X = RotateVector(c.gViewToWorld, Xv);
 
     // Previous position and surface motion uv
@@ -403,7 +403,7 @@ __global__ __launch_bounds__(TILE_X* TILE_Y, NRD_WAVES_REBLUR_TS) void ReblurTem
         if (c.gMvScale.z == 0.0f)
             mv.z = AffineTransform(c.gWorldToViewPrev, X).z - viewZ;
         float viewZprev = viewZ + mv.z;
-        float3 Xvprevlocal = ReconstructViewPosition(smbPixelUv, frustumPrev, viewZprev, c.gOrthoMode);
+        float3 Xvprevlocal = ReconstructViewPosition(smbPixelUv, frustumPrev, viewZprev, NRD_ORTHO_MODE(c));
         Xprev = RotateVectorInverse(c.gWorldToViewPrev, Xvprevlocal) + cameraDelta;
     } else {
         Xprev = Xprev + mv;

@@ -163,7 +163,7 @@ NRD_D TapGuides FetchTapGuides(const ReblurCB& c, const SpatialCtx& s, float2 uv
     float4 Ns = LoadDecodedNormalRoughness(gIn_Normal_Roughness, tz.x, tz.y, t.materialIDs);
     t.Ns = Xyz(Ns);
     t.roughnessS = Ns.w;
-    t.Xvs = ReconstructViewPosition(uv, ToF4(c.gFrustum), t.zs, c.gOrthoMode);
+    t.Xvs = ReconstructViewPosition(uv, ToF4(c.gFrustum), t.zs, NRD_ORTHO_MODE(c));
     t.NvXvs = Dot(s.Nv, t.Xvs);
     t.w = IsInScreenNearest(uv);
     t.uv = uv;
@@ -352,7 +352,7 @@ NRD_D typename ReblurSignal<KIND>::type SpecularSpatialFilterTaps(const ReblurCB
     if (MODE == PRE_BLUR) {
         float lobeTanHalfAngle = GetSpecularLobeTanHalfAngle(s.roughness, REBLUR_MAX_PERCENT_OF_LOBE_VOLUME_FOR_PRE_PASS);
         float lobeRadius = hitDist * NoD * lobeTanHalfAngle;
-        float minBlurRadius = lobeRadius / PixelRadiusToWorld(c.gUnproject, c.gOrthoMode, 1.0f, s.viewZ + hitDist * Dv.w);
+        float minBlurRadius = lobeRadius / PixelRadiusToWorld(c.gUnproject, NRD_ORTHO_MODE(c), 1.0f, s.viewZ + hitDist * Dv.w);
         blurRadius = Min(blurRadius, minBlurRadius);
     }
     blurRadius *= radiusScale;
@@ -383,7 +383,7 @@ NRD_D typename ReblurSignal<KIND>::type SpecularSpatialFilterTaps(const ReblurCB
         skewFactor = Lerp(1.0f, skewFactor, bentFactor);
         float3 bentDv = Normalize(Lerp(s.Nv, Xyz(Dv), bentFactor));
         GetKernelBasis(bentDv, s.Nv, T, B);
-        float worldRadius = PixelRadiusToWorld(c.gUnproject, c.gOrthoMode, blurRadius, s.viewZ);
+        float worldRadius = PixelRadiusToWorld(c.gUnproject, NRD_ORTHO_MODE(c), blurRadius, s.viewZ);
         T = T * (worldRadius * skewFactor);
         B = B * (worldRadius / skewFactor);
     }
@@ -504,10 +504,10 @@ NRD_D bool MakeSpatialCtx(const ReblurCB& c, int px, int py, float viewZ, const 
     s.Nv = RotateVectorInverse(c.gViewToWorld, s.N);
     s.roughness = normalAndRoughness.w;
     s.pixelUv = F2(float(px) + 0.5f, float(py) + 0.5f) * ToF2(c.gRectSizeInv);
-    s.Xv = ReconstructViewPosition(s.pixelUv, ToF4(c.gFrustum), viewZ, c.gOrthoMode);
+    s.Xv = ReconstructViewPosition(s.pixelUv, ToF4(c.gFrustum), viewZ, NRD_ORTHO_MODE(c));
     s.Vv = GetViewVector(c, s.Xv, true);
     s.NoV = Abs(Dot(s.Nv, s.Vv));
-    s.frustumSize = GetFrustumSize(c.gMinRectDimMulUnproject, c.gOrthoMode, viewZ);
+    s.frustumSize = GetFrustumSize(c.gMinRectDimMulUnproject, NRD_ORTHO_MODE(c), viewZ);
     s.rotator = rotator;
     s.data1 = F2(0.0f, 0.0f);
     {   // Xv(k, z) = ((uvc * frustum.zw + frustum.xy) * z, z) with uvc = (k + 0.5) * rectSizeInv, so dot(Nv, Xv) = z * (k.x * geo.x + k.y * geo.y + geo.z)
@@ -808,9 +808,9 @@ __global__ __launch_bounds__(TILE_X* TILE_Y) void ReblurHitDistReconstructionKer
     const float2 rectSizeInv = ToF2(c.gRectSizeInv);
     const float4 frustum = ToF4(c.gFrustum);
     const float2 pixelUv = F2(float(px) + 0.5f, float(py) + 0.5f) * rectSizeInv;
-    const float3 Xv = ReconstructViewPosition(pixelUv, frustum, centerZ, c.gOrthoMode);
+    const float3 Xv = ReconstructViewPosition(pixelUv, frustum, centerZ, NRD_ORTHO_MODE(c));
     const float3 Nv = RotateVectorInverse(c.gViewToWorld, N);
-    const float frustumSize = GetFrustumSize(c.gMinRectDimMulUnproject, c.gOrthoMode, centerZ);
+    const float frustumSize = GetFrustumSize(c.gMinRectDimMulUnproject, NRD_ORTHO_MODE(c), centerZ);
 
     const float2 geometryWeightParams = GetGeometryWeightParams(c.gPlaneDistSensitivity, frustumSize, Xv, Nv);
     const float2 relaxedRoughnessWeightParams = GetRelaxedRoughnessWeightParams(roughness * roughness);
@@ -835,7 +835,7 @@ __global__ __launch_bounds__(TILE_X* TILE_Y) void ReblurHitDistReconstructionKer
             w *= GetGaussianWeight(Length(o) * 0.5f);
 
             const float2 uv = pixelUv + o * rectSizeInv;
-            const float3 Xvs = ReconstructViewPosition(uv, frustum, dataZ, c.gOrthoMode);
+            const float3 Xvs = ReconstructViewPosition(uv, frustum, dataZ, NRD_ORTHO_MODE(c));
             w *= ComputeWeight(Dot(Nv, Xvs), geometryWeightParams.x, geometryWeightParams.y);
 
             float2 ww = F2(w, w);

@@ -115,7 +115,7 @@ __global__ __launch_bounds__(TILE_X* TILE_Y, WAVES) void ReblurTemporalAccumulat
 
     // Current position
     float2 pixelUv = F2(float(px) + 0.5f, float(py) + 0.5f) * rectSizeInv;
-    float3 Xv = ReconstructViewPosition(pixelUv, frustum, viewZ, c.gOrthoMode);
+    float3 Xv = ReconstructViewPosition(pixelUv, frustum, viewZ, NRD_ORTHO_MODE(c));
     float3 X = RotateVector(c.gViewToWorld, Xv);
 
     // 3x3: averaged normal (2x2 part), roughness moments, min hit distance for tracking
@@ -170,7 +170,7 @@ __global__ __launch_bounds__(TILE_X* TILE_Y, WAVES) void ReblurTemporalAccumulat
         if (c.gMvScale.z == 0.0f)
             mv.z = AffineTransform(c.gWorldToViewPrev, X).z - viewZ;
         float viewZprev = viewZ + mv.z;
-        float3 Xvprevlocal = ReconstructViewPosition(smbPixelUv, frustumPrev, viewZprev, c.gOrthoMode);
+        float3 Xvprevlocal = ReconstructViewPosition(smbPixelUv, frustumPrev, viewZprev, NRD_ORTHO_MODE(c));
         Xprev = RotateVectorInverse(c.gWorldToViewPrev, Xvprevlocal) + cameraDelta;
     } else {
         Xprev = Xprev + mv;
@@ -191,17 +191,14 @@ __global__ __launch_bounds__(TILE_X* TILE_Y, WAVES) void ReblurTemporalAccumulat
         smbViewZ0 = QUADZ(0, 0), smbViewZ1 = QUADZ(2, 0), smbViewZ2 = QUADZ(0, 2), smbViewZ3 = QUADZ(2, 2);
 #undef QUADZ
     }
-    float3 prevViewZ0 = F3(UnpackViewZ(c, smbViewZ0.y), UnpackViewZ(c, smbViewZ0.z), UnpackViewZ(c, smbViewZ0.w));
-    float3 prevViewZ1 = F3(UnpackViewZ(c, smbViewZ1.x), UnpackViewZ(c, smbViewZ1.z), UnpackViewZ(c, smbViewZ1.w));
-    float3 prevViewZ2 = F3(UnpackViewZ(c, smbViewZ2.x), UnpackViewZ(c, smbViewZ2.y), UnpackViewZ(c, smbViewZ2.w));
-    float3 prevViewZ3 = F3(UnpackViewZ(c, smbViewZ3.x), UnpackViewZ(c, smbViewZ3.y), UnpackViewZ(c, smbViewZ3.z));
-
-    // Previous normal averaged over the valid pixels of the 2x2 footprint
+    // ---- every other request that depends only on the surface-motion position is issued here, in one batch with the depth footprint: the 2x2
+    // previous normals, the 4x4 previous internal data, the history texels of both signals (blended once the occlusion weights exist) and the
+    // noisy inputs. A wave of this kernel lives ~27 000 cycles of which ~14 000 were spent waiting on ~14 dependent request phases at 2 waves
+    // per SIMD (profiles/r02_c_reblur_ds_sq_pmc1.txt); the arithmetic in between now runs while the next phase's data is in flight.
     Bilinear smbBilinearFilter = GetBilinearFilter(smbPixelUv, rectSizePrev);
-    float3 smbNavg;
+    uint32_t n00, n10, n01, n11; // packed texels of the 2x2 normal footprint (0 outside the plane, as Load returns)
     {
-        int bx = (int)smbBilinearFilter.origin.x, by = (int)smbBilinearFilter.origin.y;
-        uint32_t n00, n10, n01, n11; // packed texels of the 2x2 footprint (0 outside the plane, as Load returns)
+        const int bx = (int)smbBilinearFilter.origin.x, by = (int)smbBilinearFilter.origin.y;
         if (FootprintIsInterior(P.prevNormalRoughness, bx, by, 2, 2)) {
             LoadRowR32Ux2(P.prevNormalRoughness, bx, by, n00, n10);
             LoadRowR32Ux2(P.prevNormalRoughness, bx, by + 1, n01, n11);
@@ -211,6 +208,48 @@ __global__ __launch_bounds__(TILE_X* TILE_Y, WAVES) void ReblurTemporalAccumulat
             n01 = InBounds(P.prevNormalRoughness, bx, by + 1) ? LoadR32U(P.prevNormalRoughness, bx, by + 1) : 0u;
             n11 = InBounds(P.prevNormalRoughness, bx + 1, by + 1) ? LoadR32U(P.prevNormalRoughness, bx + 1, by + 1) : 0u;
         }
+    }
+    uint32_t id0[4], id1[4], id2[4], id3[4];
+#define QUADU(q, ox, oy)                                                   \
+    q[0] = FetchClampedR16U(P.prevInternalData, cx + ox, cy + oy);         \
+    q[1] = FetchClampedR16U(P.prevInternalData, cx + ox + 1, cy + oy);     \
+    q[2] = FetchClampedR16U(P.prevInternalData, cx + ox, cy + oy + 1);     \
+    q[3] = FetchClampedR16U(P.prevInternalData, cx + ox + 1, cy + oy + 1);
+    if (footprintInterior) { // same geometry as the prev-viewZ footprint (launcher: same plane size): four 8-byte row loads
+        uint32_t r0[4], r1[4], r2[4], r3[4];
+        LoadRowR16Ux4(P.prevInternalData, cx, cy, r0), LoadRowR16Ux4(P.prevInternalData, cx, cy + 1, r1), LoadRowR16Ux4(P.prevInternalData, cx, cy + 2, r2), LoadRowR16Ux4(P.prevInternalData, cx, cy + 3, r3);
+        id0[0] = r0[0], id0[1] = r0[1], id0[2] = r1[0], id0[3] = r1[1];
+        id1[0] = r0[2], id1[1] = r0[3], id1[2] = r1[2], id1[3] = r1[3];
+        id2[0] = r2[0], id2[1] = r2[1], id2[2] = r3[0], id2[3] = r3[1];
+        id3[0] = r2[2], id3[1] = r2[3], id3[2] = r3[2], id3[3] = r3[3];
+    } else {
+        QUADU(id0, 0, 0) QUADU(id1, 2, 0) QUADU(id2, 0, 2) QUADU(id3, 2, 2)
+    }
+#undef QUADU
+    const float2 smbSamplePos = Sat(smbPixelUv) * rectSizePrev;
+    HistoryFilter smbFilter = MakeHistoryGeometry(smbSamplePos, DIFF ? P.historyDiff : P.historySpec); // both histories share a layout (checked by the launcher)
+    typename Sig::HistoryTexels smbDiffTexels, smbSpecTexels;
+    typename Sig::FastTexels smbDiffFastTexels, smbSpecFastTexels;
+    S diff = Sig::Zero(), spec = Sig::Zero();
+    if (DIFF) {
+        Sig::PrefetchHistory(smbFilter, P.historyDiff, smbDiffTexels, !PERF && KIND != SIGNAL_DIRECTIONAL_OCCLUSION);
+        Sig::PrefetchFast(smbFilter, P.historyDiffFast, smbDiffFastTexels);
+        diff = Sig::Load(P.inDiff, (OCC && c.gDiffCheckerboard != 2) ? px >> 1 : px, py);
+    }
+    if (SPEC) {
+        Sig::PrefetchHistory(smbFilter, P.historySpec, smbSpecTexels, !PERF && KIND != SIGNAL_DIRECTIONAL_OCCLUSION);
+        Sig::PrefetchFast(smbFilter, P.historySpecFast, smbSpecFastTexels);
+        spec = Sig::Load(P.inSpec, (OCC && c.gSpecCheckerboard != 2) ? px >> 1 : px, py);
+    }
+
+    float3 prevViewZ0 = F3(UnpackViewZ(c, smbViewZ0.y), UnpackViewZ(c, smbViewZ0.z), UnpackViewZ(c, smbViewZ0.w));
+    float3 prevViewZ1 = F3(UnpackViewZ(c, smbViewZ1.x), UnpackViewZ(c, smbViewZ1.z), UnpackViewZ(c, smbViewZ1.w));
+    float3 prevViewZ2 = F3(UnpackViewZ(c, smbViewZ2.x), UnpackViewZ(c, smbViewZ2.y), UnpackViewZ(c, smbViewZ2.w));
+    float3 prevViewZ3 = F3(UnpackViewZ(c, smbViewZ3.x), UnpackViewZ(c, smbViewZ3.y), UnpackViewZ(c, smbViewZ3.z));
+
+    // Previous normal averaged over the valid pixels of the 2x2 footprint
+    float3 smbNavg;
+    {
         float sumw = 0.0f;
         float w = prevViewZ0.z < c.gDenoisingRange ? 1.0f : 0.0f;
         smbNavg = Xyz(UnpackNormalAndRoughness(DecodeR10G10B10A2(n00))) * w;
@@ -230,14 +269,14 @@ __global__ __launch_bounds__(TILE_X* TILE_Y, WAVES) void ReblurTemporalAccumulat
 
     NRD_CONSTANTS_PHASE();
     // Parallax
-    float smbParallaxInPixels1 = ComputeParallaxInPixels(Xprev + cameraDelta, c.gOrthoMode == 0.0f ? smbPixelUv : pixelUv, c.gWorldToClipPrev, rectSize);
-    float smbParallaxInPixels2 = ComputeParallaxInPixels(Xprev - cameraDelta, c.gOrthoMode == 0.0f ? pixelUv : smbPixelUv, c.gWorldToClip, rectSize);
+    float smbParallaxInPixels1 = ComputeParallaxInPixels(Xprev + cameraDelta, NRD_ORTHO_MODE(c) == 0.0f ? smbPixelUv : pixelUv, c.gWorldToClipPrev, rectSize);
+    float smbParallaxInPixels2 = ComputeParallaxInPixels(Xprev - cameraDelta, NRD_ORTHO_MODE(c) == 0.0f ? pixelUv : smbPixelUv, c.gWorldToClip, rectSize);
     float smbParallaxInPixelsMax = Max(smbParallaxInPixels1, smbParallaxInPixels2);
     float smbParallaxInPixelsMin = Min(smbParallaxInPixels1, smbParallaxInPixels2);
 
     // Disocclusion: threshold
-    float pixelSize = PixelRadiusToWorld(c.gUnproject, c.gOrthoMode, 1.0f, viewZ);
-    float frustumSize = GetFrustumSize(c.gMinRectDimMulUnproject, c.gOrthoMode, viewZ);
+    float pixelSize = PixelRadiusToWorld(c.gUnproject, NRD_ORTHO_MODE(c), 1.0f, viewZ);
+    float frustumSize = GetFrustumSize(c.gMinRectDimMulUnproject, NRD_ORTHO_MODE(c), viewZ);
 
     float disocclusionThresholdMix = 0.0f;
     if (materialID == c.gStrandMaterialID)
@@ -264,24 +303,7 @@ __global__ __launch_bounds__(TILE_X* TILE_Y, WAVES) void ReblurTemporalAccumulat
     float3 smbOcclusion2 = Step(Abs(prevViewZ2 - F3(Xvprev.z)), smbDisocclusionThreshold.z);
     float3 smbOcclusion3 = Step(Abs(prevViewZ3 - F3(Xvprev.z)), smbDisocclusionThreshold.w);
 
-    // Disocclusion: materialID
-    uint32_t id0[4], id1[4], id2[4], id3[4];
-#define QUADU(q, ox, oy)                                                   \
-    q[0] = FetchClampedR16U(P.prevInternalData, cx + ox, cy + oy);         \
-    q[1] = FetchClampedR16U(P.prevInternalData, cx + ox + 1, cy + oy);     \
-    q[2] = FetchClampedR16U(P.prevInternalData, cx + ox, cy + oy + 1);     \
-    q[3] = FetchClampedR16U(P.prevInternalData, cx + ox + 1, cy + oy + 1);
-    if (footprintInterior) { // same geometry as the prev-viewZ footprint (launcher: same plane size): four 8-byte row loads
-        uint32_t r0[4], r1[4], r2[4], r3[4];
-        LoadRowR16Ux4(P.prevInternalData, cx, cy, r0), LoadRowR16Ux4(P.prevInternalData, cx, cy + 1, r1), LoadRowR16Ux4(P.prevInternalData, cx, cy + 2, r2), LoadRowR16Ux4(P.prevInternalData, cx, cy + 3, r3);
-        id0[0] = r0[0], id0[1] = r0[1], id0[2] = r1[0], id0[3] = r1[1];
-        id1[0] = r0[2], id1[1] = r0[3], id1[2] = r1[2], id1[3] = r1[3];
-        id2[0] = r2[0], id2[1] = r2[1], id2[2] = r3[0], id2[3] = r3[1];
-        id3[0] = r2[2], id3[1] = r2[3], id3[2] = r3[2], id3[3] = r3[3];
-    } else {
-        QUADU(id0, 0, 0) QUADU(id1, 2, 0) QUADU(id2, 0, 2) QUADU(id3, 2, 2)
-    }
-#undef QUADU
+    // Disocclusion: materialID (the 4x4 internal-data footprint was requested with the depth footprint)
     float minMaterialID = Min(c.gSpecMinMaterial, c.gDiffMinMaterial);
 #define MATCMP(p) (CompareMaterials(materialID, UnpackInternalData(p).z, minMaterialID) ? 1.0f : 0.0f)
     smbOcclusion0 = smbOcclusion0 * F3(MATCMP(id0[1]), MATCMP(id0[2]), MATCMP(id0[3]));
@@ -296,6 +318,8 @@ __global__ __launch_bounds__(TILE_X* TILE_Y, WAVES) void ReblurTemporalAccumulat
     float4 smbOcclusionWeights = GetBilinearCustomWeights(smbBilinearFilter, F4(smbOcclusion0.z, smbOcclusion1.y, smbOcclusion2.y, smbOcclusion3.x));
     float3 occSum = smbOcclusion0 + smbOcclusion1 + smbOcclusion2 + smbOcclusion3;
     bool smbAllowCatRom = (occSum.x + occSum.y + occSum.z) > 11.5f && !PERF && KIND != SIGNAL_DIRECTIONAL_OCCLUSION; // no Catmull-Rom in TA for directional occlusion (REBLUR_Config.hlsli:188-194)
+
+    SetHistoryWeights(smbFilter, smbOcclusionWeights, smbAllowCatRom);
 
     float fbits = smbOcclusion0.z * 1.0f;
     fbits += smbOcclusion1.y * 2.0f;
@@ -322,7 +346,6 @@ __global__ __launch_bounds__(TILE_X* TILE_Y, WAVES) void ReblurTemporalAccumulat
     smbFootprintQuality = Sqrt01(smbFootprintQuality);
     smbFootprintQuality *= sizeQuality;
 
-    const float2 smbSamplePos = Sat(smbPixelUv) * rectSizePrev;
 
     NRD_CONSTANTS_PHASE();
     // Checkerboard (reference REBLUR_TemporalAccumulation.hlsli:307-321): pixels without data this frame accumulate slower; only the occlusion
@@ -353,16 +376,14 @@ __global__ __launch_bounds__(TILE_X* TILE_Y, WAVES) void ReblurTemporalAccumulat
         diffAccumSpeed *= Lerp(diffHistoryConfidence, 1.0f, 1.0f / (1.0f + diffAccumSpeed));
         diffAccumSpeed = Min(diffAccumSpeed, c.gMaxAccumulatedFrameNum);
 
-        S diff = Sig::Load(P.inDiff, (OCC && c.gDiffCheckerboard != 2) ? px >> 1 : px, py);
         if (OCC && !diffHasData) {
             S d0 = Select(wc.x == 0.0f, Sig::Zero(), Sig::Load(P.inDiff, cbX0, py));
             S d1 = Select(wc.y == 0.0f, Sig::Zero(), Sig::Load(P.inDiff, cbX1, py));
             diff = d0 * wc.x + d1 * wc.y;
         }
 
-        HistoryFilter smbFilter = MakeHistoryFilter(smbSamplePos, smbOcclusionWeights, smbAllowCatRom, P.historyDiff);
-        S smbDiffHistory = Sig::FetchHistory(smbFilter, P.historyDiff);
-        float smbDiffFastHistory = Sig::FetchFastBilinear(smbFilter, P.historyDiffFast);
+        S smbDiffHistory = Sig::FetchHistory(smbFilter, P.historyDiff, smbDiffTexels);
+        float smbDiffFastHistory = Sig::FetchFastBilinear(smbFilter, P.historyDiffFast, smbDiffFastTexels);
         smbDiffHistory = ClampNegativeToZero(smbDiffHistory);
 
         float diffNonLinearAccumSpeed = 1.0f / (1.0f + diffAccumSpeed);
@@ -416,7 +437,6 @@ __global__ __launch_bounds__(TILE_X* TILE_Y, WAVES) void ReblurTemporalAccumulat
         smbSpecAccumSpeed *= Lerp(specHistoryConfidence, 1.0f, 1.0f / (1.0f + smbSpecAccumSpeed));
         smbSpecAccumSpeed = Min(smbSpecAccumSpeed, c.gMaxAccumulatedFrameNum);
 
-        S spec = Sig::Load(P.inSpec, (OCC && c.gSpecCheckerboard != 2) ? px >> 1 : px, py);
         if (OCC && !specHasData) {
             S s0 = Select(wc.x == 0.0f, Sig::Zero(), Sig::Load(P.inSpec, cbX0, py));
             S s1 = Select(wc.y == 0.0f, Sig::Zero(), Sig::Load(P.inSpec, cbX1, py));
@@ -426,26 +446,26 @@ __global__ __launch_bounds__(TILE_X* TILE_Y, WAVES) void ReblurTemporalAccumulat
         NRD_CONSTANTS_PHASE();
         // Curvature estimation along predicted motion
         {
-            float2 uvForZeroParallax = Select(c.gOrthoMode == 0.0f, smbPixelUv, pixelUv);
+            float2 uvForZeroParallax = Select(NRD_ORTHO_MODE(c) == 0.0f, smbPixelUv, pixelUv);
             float2 deltaUv = uvForZeroParallax - GetScreenUv(c.gWorldToClipPrev, Xprev + cameraDelta);
             deltaUv = deltaUv * rectSize;
             deltaUv = deltaUv / Max(smbParallaxInPixels1, 1.0f / 256.0f);
 
             float3 n10, x10;
             {
-                float3 xv = ReconstructViewPosition(pixelUv + F2(1.0f, 0.0f) * rectSizeInv, frustum, 1.0f, c.gOrthoMode);
+                float3 xv = ReconstructViewPosition(pixelUv + F2(1.0f, 0.0f) * rectSizeInv, frustum, 1.0f, NRD_ORTHO_MODE(c));
                 float3 x = RotateVector(c.gViewToWorld, xv);
                 float3 v = GetViewVector(c, x);
-                float3 o = Select(c.gOrthoMode == 0.0f, F3(0.0f), x);
+                float3 o = Select(NRD_ORTHO_MODE(c) == 0.0f, F3(0.0f), x);
                 x10 = o + v * Dot(X - o, N) / Dot(N, v);
                 n10 = Xyz(s_Normal_Roughness[(ty + BORDER) * BUF_STRIDE + tx + BORDER + 1]);
             }
             float3 n01, x01;
             {
-                float3 xv = ReconstructViewPosition(pixelUv + F2(0.0f, 1.0f) * rectSizeInv, frustum, 1.0f, c.gOrthoMode);
+                float3 xv = ReconstructViewPosition(pixelUv + F2(0.0f, 1.0f) * rectSizeInv, frustum, 1.0f, NRD_ORTHO_MODE(c));
                 float3 x = RotateVector(c.gViewToWorld, xv);
                 float3 v = GetViewVector(c, x);
-                float3 o = Select(c.gOrthoMode == 0.0f, F3(0.0f), x);
+                float3 o = Select(NRD_ORTHO_MODE(c) == 0.0f, F3(0.0f), x);
                 x01 = o + v * Dot(X - o, N) / Dot(N, v);
                 n01 = Xyz(s_Normal_Roughness[(ty + BORDER + 1) * BUF_STRIDE + tx + BORDER]);
             }
@@ -467,7 +487,7 @@ __global__ __launch_bounds__(TILE_X* TILE_Y, WAVES) void ReblurTemporalAccumulat
                 float2 uvScaled = F2(Min(motionUvHigh.x * resolutionScale.x, uvMax.x), Min(motionUvHigh.y * resolutionScale.y, uvMax.y));
                 int2 tz = NearestTexel(P.viewZ, uvScaled);
                 float zHigh = UnpackViewZ(c, LoadR32F(P.viewZ, tz.x, tz.y));
-                float3 xHigh = ReconstructViewPosition(motionUvHigh, frustum, zHigh, c.gOrthoMode);
+                float3 xHigh = ReconstructViewPosition(motionUvHigh, frustum, zHigh, NRD_ORTHO_MODE(c));
                 xHigh = RotateVector(c.gViewToWorld, xHigh);
                 int2 tn = NearestTexel(P.normalRoughness, uvScaled);
                 float3 nHigh = Xyz(LoadDecodedNormalRoughness(P.decodedNR, tn.x, tn.y));
@@ -494,21 +514,64 @@ __global__ __launch_bounds__(TILE_X* TILE_Y, WAVES) void ReblurTemporalAccumulat
         float2 vmbDelta = vmbPixelUv - smbPixelUv;
         float vmbPixelsTraveled = Length(vmbDelta * rectSize);
 
-        // Virtual motion - roughness
+        // ---- every request that depends only on the virtual-motion position, in one batch (see the surface-motion batch above): the 2x2 footprints of
+        // the previous normals / viewZ / internal data, the two stochastic normal taps, the tracking hit distance and the texels of the virtual history
         Bilinear vmbBilinearFilter = GetBilinearFilter(vmbPixelUv, rectSizePrev);
         const int vx = (int)vmbBilinearFilter.origin.x, vy = (int)vmbBilinearFilter.origin.y;
-        float2 relaxedRoughnessWeightParams = GetRelaxedRoughnessWeightParams(roughness * roughness, c.gRoughnessFraction, REBLUR_ROUGHNESS_SENSITIVITY_IN_TA);
         const bool vmbInterior = FootprintIsInterior(P.prevViewZ, vx, vy, 2, 2); // one test for the three planes of this footprint (same size)
-        float4 vmbRoughness;
+        uint32_t vq00, vq10, vq01, vq11;     // packed normal / roughness
+        float vz00, vz10, vz01, vz11;        // packed viewZ
+        uint32_t vmbId00, vmbId10, vmbId01, vmbId11;
         if (vmbInterior) {
-            uint32_t q00, q10, q01, q11;
-            LoadRowR32Ux2(P.prevNormalRoughness, vx, vy, q00, q10);
-            LoadRowR32Ux2(P.prevNormalRoughness, vx, vy + 1, q01, q11);
-            vmbRoughness = F4(DecodeR10G10B10A2(q00).z, DecodeR10G10B10A2(q10).z, DecodeR10G10B10A2(q01).z, DecodeR10G10B10A2(q11).z);
+            LoadRowR32Ux2(P.prevNormalRoughness, vx, vy, vq00, vq10);
+            LoadRowR32Ux2(P.prevNormalRoughness, vx, vy + 1, vq01, vq11);
+            const float2 z0 = LoadRowR32Fx2(P.prevViewZ, vx, vy), z1 = LoadRowR32Fx2(P.prevViewZ, vx, vy + 1);
+            vz00 = z0.x, vz10 = z0.y, vz01 = z1.x, vz11 = z1.y;
+            LoadRowR16Ux2(P.prevInternalData, vx, vy, vmbId00, vmbId10);
+            LoadRowR16Ux2(P.prevInternalData, vx, vy + 1, vmbId01, vmbId11);
         } else {
-            vmbRoughness = F4(FetchClampedR10G10B10A2(P.prevNormalRoughness, vx, vy).z, FetchClampedR10G10B10A2(P.prevNormalRoughness, vx + 1, vy).z,
-                FetchClampedR10G10B10A2(P.prevNormalRoughness, vx, vy + 1).z, FetchClampedR10G10B10A2(P.prevNormalRoughness, vx + 1, vy + 1).z);
+            const int x0 = ClampI(vx, 0, P.prevViewZ.w - 1), x1 = ClampI(vx + 1, 0, P.prevViewZ.w - 1), y0 = ClampI(vy, 0, P.prevViewZ.h - 1), y1 = ClampI(vy + 1, 0, P.prevViewZ.h - 1);
+            vq00 = LoadR32U(P.prevNormalRoughness, x0, y0), vq10 = LoadR32U(P.prevNormalRoughness, x1, y0), vq01 = LoadR32U(P.prevNormalRoughness, x0, y1), vq11 = LoadR32U(P.prevNormalRoughness, x1, y1);
+            vz00 = LoadR32F(P.prevViewZ, x0, y0), vz10 = LoadR32F(P.prevViewZ, x1, y0), vz01 = LoadR32F(P.prevViewZ, x0, y1), vz11 = LoadR32F(P.prevViewZ, x1, y1);
+            vmbId00 = LoadR16U(P.prevInternalData, x0, y0), vmbId10 = LoadR16U(P.prevInternalData, x1, y0), vmbId01 = LoadR16U(P.prevInternalData, x0, y1), vmbId11 = LoadR16U(P.prevInternalData, x1, y1);
         }
+        // stochastic nearest taps of the bilinear footprint at the virtual position and one step back along the virtual motion (the draws keep their order)
+        const float2 resolutionScalePrev = ToF2(c.gResolutionScalePrev);
+        auto stochasticTexel = [&](float2 uv) {
+            Bilinear f = GetBilinearFilter(uv, rectSizePrev);
+            float2 rnd = rng.GetFloat2();
+            f.origin = f.origin + F2(Step(rnd.x, f.weights.x), Step(rnd.y, f.weights.y));
+            float2 uvs = ((f.origin + 0.5f) / rectSizePrev) * resolutionScalePrev;
+            return NearestTexel(P.prevNormalRoughness, uvs);
+        };
+        const int2 st0 = stochasticTexel(vmbPixelUv);
+        const uint32_t stochasticRaw0 = LoadR32U(P.prevNormalRoughness, st0.x, st0.y);
+        const float stepBetweenTaps = Min(vmbPixelsTraveled * c.gFramerateScale, 2.0f) + vmbPixelsTraveled / 1.0f;
+        vmbDelta = vmbDelta * Rsqrt(LengthSquared(vmbDelta));
+        vmbDelta = vmbDelta / rectSizePrev;
+        const float2 vmbPixelUvPrevTap = vmbPixelUv + vmbDelta * 1.0f * stepBetweenTaps;
+        const int2 st1 = stochasticTexel(vmbPixelUvPrevTap);
+        const uint32_t stochasticRaw1 = LoadR32U(P.prevNormalRoughness, st1.x, st1.y);
+        // previous tracking hit distance: the 2x2 of the linear sample
+        const LinearTaps hitDistTaps = MakeLinearTaps(vmbPixelUv * resolutionScalePrev * F2(float(P.prevSpecHitDistForTracking.w), float(P.prevSpecHitDistForTracking.h)));
+        uint32_t hd00, hd10, hd01, hd11;
+        if (FootprintIsInterior(P.prevSpecHitDistForTracking, hitDistTaps.x0, hitDistTaps.y0, 2, 2)) {
+            LoadRowR16Ux2(P.prevSpecHitDistForTracking, hitDistTaps.x0, hitDistTaps.y0, hd00, hd10);
+            LoadRowR16Ux2(P.prevSpecHitDistForTracking, hitDistTaps.x0, hitDistTaps.y0 + 1, hd01, hd11);
+        } else {
+            hd00 = FetchClampedR16U(P.prevSpecHitDistForTracking, hitDistTaps.x0, hitDistTaps.y0), hd10 = FetchClampedR16U(P.prevSpecHitDistForTracking, hitDistTaps.x0 + 1, hitDistTaps.y0);
+            hd01 = FetchClampedR16U(P.prevSpecHitDistForTracking, hitDistTaps.x0, hitDistTaps.y0 + 1), hd11 = FetchClampedR16U(P.prevSpecHitDistForTracking, hitDistTaps.x0 + 1, hitDistTaps.y0 + 1);
+        }
+        // virtual history
+        HistoryFilter vmbFilter = MakeHistoryGeometry(Sat(vmbPixelUv) * rectSizePrev, P.historySpec);
+        typename Sig::HistoryTexels vmbSpecTexels;
+        typename Sig::FastTexels vmbSpecFastTexels;
+        Sig::PrefetchHistory(vmbFilter, P.historySpec, vmbSpecTexels, !PERF && KIND != SIGNAL_DIRECTIONAL_OCCLUSION);
+        Sig::PrefetchFast(vmbFilter, P.historySpecFast, vmbSpecFastTexels);
+
+        // Virtual motion - roughness
+        float2 relaxedRoughnessWeightParams = GetRelaxedRoughnessWeightParams(roughness * roughness, c.gRoughnessFraction, REBLUR_ROUGHNESS_SENSITIVITY_IN_TA);
+        const float4 vmbRoughness = F4(DecodeR10G10B10A2(vq00).z, DecodeR10G10B10A2(vq10).z, DecodeR10G10B10A2(vq01).z, DecodeR10G10B10A2(vq11).z);
         float4 roughnessWeight;
         roughnessWeight.x = ComputeNonExponentialWeightWithSigma(vmbRoughness.x * vmbRoughness.x, relaxedRoughnessWeightParams.x, relaxedRoughnessWeightParams.y, roughnessSigma);
         roughnessWeight.y = ComputeNonExponentialWeightWithSigma(vmbRoughness.y * vmbRoughness.y, relaxedRoughnessWeightParams.x, relaxedRoughnessWeightParams.y, roughnessSigma);
@@ -520,16 +583,7 @@ __global__ __launch_bounds__(TILE_X* TILE_Y, WAVES) void ReblurTemporalAccumulat
         float virtualHistoryRoughnessBasedConfidence = ApplyBilinearFilter(roughnessWeight.x, roughnessWeight.y, roughnessWeight.z, roughnessWeight.w, vmbBilinearFilter);
 
         // Virtual motion - normal: parallax; stochastic nearest tap of the bilinear footprint
-        const float2 resolutionScalePrev = ToF2(c.gResolutionScalePrev);
-        auto stochasticBilinearFetch = [&](float2 uv) {
-            Bilinear f = GetBilinearFilter(uv, rectSizePrev);
-            float2 rnd = rng.GetFloat2();
-            f.origin = f.origin + F2(Step(rnd.x, f.weights.x), Step(rnd.y, f.weights.y));
-            float2 uvs = ((f.origin + 0.5f) / rectSizePrev) * resolutionScalePrev;
-            int2 t = NearestTexel(P.prevNormalRoughness, uvs);
-            return UnpackNormalAndRoughness(LoadR10G10B10A2(P.prevNormalRoughness, t.x, t.y));
-        };
-        float4 vmbNormalAndRoughness = stochasticBilinearFetch(vmbPixelUv);
+        float4 vmbNormalAndRoughness = UnpackNormalAndRoughness(DecodeR10G10B10A2(stochasticRaw0));
         float3 vmbN = RotateVector(c.gWorldPrevToWorld, Xyz(vmbNormalAndRoughness));
         float Dfactor = GetSpecularDominantFactor(NoV, roughness);
         float virtualHistoryNormalBasedConfidence = 1.0f / (1.0f + 0.5f * Dfactor * Sat(Length(N - vmbN) - REBLUR_NORMAL_ULP) * vmbPixelsTraveled);
@@ -547,18 +601,11 @@ __global__ __launch_bounds__(TILE_X* TILE_Y, WAVES) void ReblurTemporalAccumulat
             vmbOcclusionThreshold = vmbOcclusionThreshold * IsInScreenBilinear(vmbBilinearFilter.origin, rectSizePrev);
             vmbOcclusionThreshold = vmbOcclusionThreshold - NRD_EPS;
 
-            float4 vmbViewZ;
-            if (vmbInterior) {
-                const float2 z0 = LoadRowR32Fx2(P.prevViewZ, vx, vy), z1 = LoadRowR32Fx2(P.prevViewZ, vx, vy + 1);
-                vmbViewZ = F4(UnpackViewZ(c, z0.x), UnpackViewZ(c, z0.y), UnpackViewZ(c, z1.x), UnpackViewZ(c, z1.y));
-            } else {
-                vmbViewZ = F4(UnpackViewZ(c, FetchClampedR32F(P.prevViewZ, vx, vy)), UnpackViewZ(c, FetchClampedR32F(P.prevViewZ, vx + 1, vy)),
-                    UnpackViewZ(c, FetchClampedR32F(P.prevViewZ, vx, vy + 1)), UnpackViewZ(c, FetchClampedR32F(P.prevViewZ, vx + 1, vy + 1)));
-            }
+            const float4 vmbViewZ = F4(UnpackViewZ(c, vz00), UnpackViewZ(c, vz10), UnpackViewZ(c, vz01), UnpackViewZ(c, vz11));
             float3 vmbVv = ReconstructViewPosition(vmbPixelUv, frustumPrev, 1.0f, 0.0f);
             float3 vmbV = RotateVectorInverse(c.gWorldToViewPrev, vmbVv);
             float NoXcurr = Dot(N, Xprev - cameraDelta);
-            float4 NoXprev = (c.gOrthoMode == 0.0f ? vmbViewZ : F4(c.gOrthoMode)) * (N.x * vmbV.x + N.y * vmbV.y) + vmbViewZ * (N.z * vmbV.z);
+            float4 NoXprev = (NRD_ORTHO_MODE(c) == 0.0f ? vmbViewZ : F4(NRD_ORTHO_MODE(c))) * (N.x * vmbV.x + N.y * vmbV.y) + vmbViewZ * (N.z * vmbV.z);
             float4 vmbPlaneDist = Abs(NoXprev - NoXcurr);
 
             vmbOcclusion = Step(vmbPlaneDist, vmbOcclusionThreshold);
@@ -566,14 +613,6 @@ __global__ __launch_bounds__(TILE_X* TILE_Y, WAVES) void ReblurTemporalAccumulat
         }
 
         // Virtual motion - disocclusion: materialID
-        uint32_t vmbId00, vmbId10, vmbId01, vmbId11;
-        if (vmbInterior) {
-            LoadRowR16Ux2(P.prevInternalData, vx, vy, vmbId00, vmbId10);
-            LoadRowR16Ux2(P.prevInternalData, vx, vy + 1, vmbId01, vmbId11);
-        } else {
-            vmbId00 = FetchClampedR16U(P.prevInternalData, vx, vy), vmbId10 = FetchClampedR16U(P.prevInternalData, vx + 1, vy);
-            vmbId01 = FetchClampedR16U(P.prevInternalData, vx, vy + 1), vmbId11 = FetchClampedR16U(P.prevInternalData, vx + 1, vy + 1);
-        }
         float3 vmbInternalData00 = UnpackInternalData(vmbId00);
         float3 vmbInternalData10 = UnpackInternalData(vmbId10);
         float3 vmbInternalData01 = UnpackInternalData(vmbId01);
@@ -620,14 +659,14 @@ __global__ __launch_bounds__(TILE_X* TILE_Y, WAVES) void ReblurTemporalAccumulat
         // Virtual motion - virtual parallax difference
         float virtualHistoryParallaxBasedConfidence;
         {
-            float hitDistForTrackingPrev =
-                SampleLinearR16F(P.prevSpecHitDistForTracking, vmbPixelUv * resolutionScalePrev * F2(float(P.prevSpecHitDistForTracking.w), float(P.prevSpecHitDistForTracking.h)));
+            float hitDistForTrackingPrev = HalfBitsToFloat((uint16_t)hd00) * hitDistTaps.w00 + HalfBitsToFloat((uint16_t)hd10) * hitDistTaps.w10 + HalfBitsToFloat((uint16_t)hd01) * hitDistTaps.w01 +
+                                           HalfBitsToFloat((uint16_t)hd11) * hitDistTaps.w11; // SampleLinearR16F on the texels requested above
             float3 XvirtualPrev = GetXvirtual(hitDistForTrackingPrev, curvature, X, Xprev, N, V, roughness);
 
             float2 vmbPixelUvPrev = GetScreenUv(c.gWorldToClipPrev, XvirtualPrev);
             vmbPixelUvPrev = Select(materialID == c.gCameraAttachedReflectionMaterialID, smbPixelUv, vmbPixelUvPrev);
 
-            float pixelSizeAtXvirtual = PixelRadiusToWorld(c.gUnproject, c.gOrthoMode, 1.0f, XvirtualLength);
+            float pixelSizeAtXvirtual = PixelRadiusToWorld(c.gUnproject, NRD_ORTHO_MODE(c), 1.0f, XvirtualLength);
             float r = (lobeTanHalfAngle + curvatureAngle) * Min(hitDistForTracking, hitDistForTrackingPrev) / pixelSizeAtXvirtual;
             float d = Length((vmbPixelUvPrev - vmbPixelUv) * rectSize);
 
@@ -636,15 +675,11 @@ __global__ __launch_bounds__(TILE_X* TILE_Y, WAVES) void ReblurTemporalAccumulat
         }
 
         // Virtual motion - normal & roughness prev-prev tests (1 iteration)
-        float stepBetweenTaps = Min(vmbPixelsTraveled * c.gFramerateScale, 2.0f) + vmbPixelsTraveled / 1.0f;
-        vmbDelta = vmbDelta * Rsqrt(LengthSquared(vmbDelta));
-        vmbDelta = vmbDelta / rectSizePrev;
-
         relaxedRoughnessWeightParams = GetRelaxedRoughnessWeightParams(vmbNormalAndRoughness.w * vmbNormalAndRoughness.w, c.gRoughnessFraction, REBLUR_ROUGHNESS_SENSITIVITY_IN_TA);
         {
             const float i = 1.0f;
-            float2 vmbPixelUvPrev = vmbPixelUv + vmbDelta * i * stepBetweenTaps;
-            float4 vmbNormalAndRoughnessPrev = stochasticBilinearFetch(vmbPixelUvPrev);
+            const float2 vmbPixelUvPrev = vmbPixelUvPrevTap;
+            float4 vmbNormalAndRoughnessPrev = UnpackNormalAndRoughness(DecodeR10G10B10A2(stochasticRaw1));
 
             float2 w;
             w.x = GetEncodingAwareNormalWeight(Xyz(vmbNormalAndRoughness), Xyz(vmbNormalAndRoughnessPrev), lobeHalfAngle, curvatureAngle * (1.0f + i * stepBetweenTaps), REBLUR_NORMAL_ULP);
@@ -662,9 +697,8 @@ __global__ __launch_bounds__(TILE_X* TILE_Y, WAVES) void ReblurTemporalAccumulat
 
         NRD_CONSTANTS_PHASE();
         // Sample surface history
-        HistoryFilter smbFilter = MakeHistoryFilter(smbSamplePos, smbOcclusionWeights, smbAllowCatRom, P.historySpec);
-        S smbSpecHistory = Sig::FetchHistory(smbFilter, P.historySpec);
-        float smbSpecFastHistory = Sig::FetchFastBilinear(smbFilter, P.historySpecFast);
+        S smbSpecHistory = Sig::FetchHistory(smbFilter, P.historySpec, smbSpecTexels);
+        float smbSpecFastHistory = Sig::FetchFastBilinear(smbFilter, P.historySpecFast, smbSpecFastTexels);
 
         float surfaceHistoryConfidence;
         {
@@ -715,9 +749,9 @@ __global__ __launch_bounds__(TILE_X* TILE_Y, WAVES) void ReblurTemporalAccumulat
 
         NRD_CONSTANTS_PHASE();
         // Sample virtual history
-        HistoryFilter vmbFilter = MakeHistoryFilter(Sat(vmbPixelUv) * rectSizePrev, vmbOcclusionWeights, vmbAllowCatRom, P.historySpec);
-        S vmbSpecHistory = Sig::FetchHistory(vmbFilter, P.historySpec);
-        float vmbSpecFastHistory = Sig::FetchFastBilinear(vmbFilter, P.historySpecFast);
+        SetHistoryWeights(vmbFilter, vmbOcclusionWeights, vmbAllowCatRom);
+        S vmbSpecHistory = Sig::FetchHistory(vmbFilter, P.historySpec, vmbSpecTexels);
+        float vmbSpecFastHistory = Sig::FetchFastBilinear(vmbFilter, P.historySpecFast, vmbSpecFastTexels);
 
         smbSpecHistory = ClampNegativeToZero(smbSpecHistory);
         vmbSpecHistory = ClampNegativeToZero(vmbSpecHistory);

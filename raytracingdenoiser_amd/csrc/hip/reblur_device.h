@@ -9,6 +9,14 @@
 #include "nrdmath.h"
 #include "planes.h"
 
+// The REBLUR launchers reject orthographic projections (CheckSupported), so the fast build folds gOrthoMode = 0 into the arithmetic; the exact build keeps
+// the reference's expressions (x * (1 - |0|) + 0 is not x for the compiler without -fno-signed-zeros)
+#if NRD_FAST
+#define NRD_ORTHO_MODE(c) 0.0f
+#else
+#define NRD_ORTHO_MODE(c) ((c).gOrthoMode)
+#endif
+
 namespace nrdhip {
 
 typedef nrdc::ReblurConstants ReblurCB;
@@ -101,10 +109,10 @@ NRD_D float2 UnpackData2(uint32_t p, uint32_t& bits) {
 // ---- helpers ------------------------------------------------------------------------------------------------------
 NRD_D float UnpackViewZ(const ReblurCB& c, float z) { return Abs(z * c.gViewZScale); }
 NRD_D float3 GetViewVector(const ReblurCB& c, float3 X, bool isViewSpace = false) {
-    return c.gOrthoMode == 0.0f ? Normalize(-X) : (isViewSpace ? F3(0.0f, 0.0f, -1.0f) : ToF3(c.gViewVectorWorld));
+    return NRD_ORTHO_MODE(c) == 0.0f ? Normalize(-X) : (isViewSpace ? F3(0.0f, 0.0f, -1.0f) : ToF3(c.gViewVectorWorld));
 }
 NRD_D float3 GetViewVectorPrev(const ReblurCB& c, float3 Xprev, float3 cameraDelta) {
-    return c.gOrthoMode == 0.0f ? Normalize(cameraDelta - Xprev) : ToF3(c.gViewVectorWorldPrev);
+    return NRD_ORTHO_MODE(c) == 0.0f ? Normalize(cameraDelta - Xprev) : ToF3(c.gViewVectorWorldPrev);
 }
 NRD_D float PixelRadiusToWorld(float unproject, float orthoMode, float pixelRadius, float viewZ) { return pixelRadius * unproject * Lerp(viewZ, 1.0f, Abs(orthoMode)); }
 NRD_D float GetFrustumSize(float minRectDimMulUnproject, float orthoMode, float viewZ) { return minRectDimMulUnproject * Lerp(viewZ, 1.0f, Abs(orthoMode)); }
@@ -427,13 +435,18 @@ NRD_D float SampleLinearR16F(const Plane& p, float2 pos) {
 struct HistoryFilter {
     float4 w;       // weights of fetches 0..3 (bicubic) or the custom bilinear weights of the 2x2 footprint
     float w4, sum;
+    float4 cw;      // the Catmull-Rom weights of fetches 0..3 and (cw4) of fetch 4, before the choice
+    float cw4;
     float2 tc;      // bilinear fractions inside the central 2x2
     int x[4], y[4]; // clamped texel coordinates k-1 .. k+2, j-1 .. j+2
     int ox, oy;     // origin of the shaders' Load-based bilinear path: int( centerPos ), truncation
     float4 bw;
     bool useBicubic;
 };
-NRD_D HistoryFilter MakeHistoryFilter(float2 samplePos, float4 bilinearCustomWeights, bool useBicubic, const Plane& dims) {
+// Two steps: the geometry (texel coordinates, fractions, Catmull-Rom weights) needs only the sample position -- TemporalAccumulation requests the texels
+// of a footprint as soon as the reprojected position exists --, the choice between Catmull-Rom and the custom-weight bilinear fallback needs the
+// occlusion tests that come later. Same arithmetic as the single-step form.
+NRD_D HistoryFilter MakeHistoryGeometry(float2 samplePos, const Plane& dims) {
     const float S = NRD_CATROM_SHARPNESS;
     HistoryFilter h;
     float2 origin = Floor(samplePos - 0.5f);
@@ -444,11 +457,8 @@ NRD_D HistoryFilter MakeHistoryFilter(float2 samplePos, float4 bilinearCustomWei
     float2 w2 = f * (f * (f * -(2.0f - S) + (3.0f - 2.0f * S)) + S);
     float2 w3 = f * (f * (f * S - S));
     float2 w12 = w1 + w2;
-    float4 w = F4(w12.x * w0.y, w0.x * w12.y, w12.x * w12.y, w3.x * w12.y);
-    float w4 = w12.x * w3.y;
-    h.w = useBicubic ? w : bilinearCustomWeights;
-    h.w4 = useBicubic ? w4 : 0.0f;
-    h.sum = Sum(h.w) + h.w4;
+    h.cw = F4(w12.x * w0.y, w0.x * w12.y, w12.x * w12.y, w3.x * w12.y);
+    h.cw4 = w12.x * w3.y;
     h.tc = w2 / w12;
     const int kx = (int)origin.x, ky = (int)origin.y;
 #pragma unroll
@@ -458,8 +468,18 @@ NRD_D HistoryFilter MakeHistoryFilter(float2 samplePos, float4 bilinearCustomWei
     }
     h.ox = (int)centerPos.x;
     h.oy = (int)centerPos.y;
+    return h;
+}
+NRD_D void SetHistoryWeights(HistoryFilter& h, float4 bilinearCustomWeights, bool useBicubic) {
+    h.w = Select(useBicubic, h.cw, bilinearCustomWeights); // component-wise: `?:` on HIP vector types selects between ADDRESSES and pins the struct to scratch
+    h.w4 = useBicubic ? h.cw4 : 0.0f;
+    h.sum = Sum(h.w) + h.w4;
     h.bw = bilinearCustomWeights;
     h.useBicubic = useBicubic;
+}
+NRD_D HistoryFilter MakeHistoryFilter(float2 samplePos, float4 bilinearCustomWeights, bool useBicubic, const Plane& dims) {
+    HistoryFilter h = MakeHistoryGeometry(samplePos, dims);
+    SetHistoryWeights(h, bilinearCustomWeights, useBicubic);
     return h;
 }
 // V = float4 / float; load(plane, x, y) reads one in-bounds texel
@@ -500,30 +520,72 @@ NRD_D void LoadRGBA16Fx2(const Plane& p, int x, int y, float4& a, float4& b) {
     a = DecodeRGBA16F(raw.v[0], raw.v[1]);
     b = DecodeRGBA16F(raw.v[2], raw.v[3]);
 }
+NRD_D bool HistoryFootprintIsInterior(const HistoryFilter& h) { return h.x[3] - h.x[0] == 3 && h.y[3] - h.y[0] == 3; }
+// The 12 texels of an interior footprint as 2 + 4 + 4 + 2 contiguous runs (6 requests of 16 bytes), undecoded. `loaded` is false for a footprint
+// that touches the border of the plane (then the fetch reads its clamped texels one by one when it is evaluated).
+struct Raw4 { // plain scalars (not a HIP vector type, whose union members end up in scratch when assigned under a condition)
+    uint32_t x, y, z, w;
+};
+struct HistoryTexelsRGBA16F {
+    Raw4 a, b0, b1, c0, c1, d; // two RGBA16F texels each
+    bool loaded;
+};
+NRD_D Raw4 LoadRGBA16Fx2Raw(const Plane& p, int x, int y) {
+    const RGBA16Fx2Raw raw = *(const RGBA16Fx2Raw*)TexelPtr<const uint2>(p, x, y);
+    Raw4 r;
+    r.x = raw.v[0], r.y = raw.v[1], r.z = raw.v[2], r.w = raw.v[3];
+    return r;
+}
+NRD_D void PrefetchHistoryRGBA16F(const HistoryFilter& h, const Plane& tex, HistoryTexelsRGBA16F& t) {
+    t.loaded = HistoryFootprintIsInterior(h);
+    t.a = t.b0 = t.b1 = t.c0 = t.c1 = t.d = Raw4{0u, 0u, 0u, 0u};
+    if (t.loaded) {
+        t.a = LoadRGBA16Fx2Raw(tex, h.x[1], h.y[0]);
+        t.b0 = LoadRGBA16Fx2Raw(tex, h.x[0], h.y[1]);
+        t.b1 = LoadRGBA16Fx2Raw(tex, h.x[2], h.y[1]);
+        t.c0 = LoadRGBA16Fx2Raw(tex, h.x[0], h.y[2]);
+        t.c1 = LoadRGBA16Fx2Raw(tex, h.x[2], h.y[2]);
+        t.d = LoadRGBA16Fx2Raw(tex, h.x[1], h.y[3]);
+    }
+}
+NRD_D float4 FetchHistoryRGBA16F(const HistoryFilter& h, const Plane& tex, const HistoryTexelsRGBA16F& t) {
+    if (!t.loaded)
+        return FetchHistoryGeneric<float4>(h, tex, [](const Plane& p, int x, int y) { return LoadRGBA16F(p, x, y); }, F4(0.0f));
+    const float4 b1 = DecodeRGBA16F(t.b0.z, t.b0.w), b2 = DecodeRGBA16F(t.b1.x, t.b1.y);
+    const float4 c1 = DecodeRGBA16F(t.c0.z, t.c0.w), c2 = DecodeRGBA16F(t.c1.x, t.c1.y);
+    float4 color;
+    if (h.useBicubic) {
+        const float4 a0 = DecodeRGBA16F(t.a.x, t.a.y), a1 = DecodeRGBA16F(t.a.z, t.a.w);
+        const float4 b0 = DecodeRGBA16F(t.b0.x, t.b0.y), b3 = DecodeRGBA16F(t.b1.z, t.b1.w);
+        const float4 c0 = DecodeRGBA16F(t.c0.x, t.c0.y), c3 = DecodeRGBA16F(t.c1.z, t.c1.w);
+        const float4 d0 = DecodeRGBA16F(t.d.x, t.d.y), d1 = DecodeRGBA16F(t.d.z, t.d.w);
+        const float fx = h.tc.x, fy = h.tc.y, gx = 1.0f - fx, gy = 1.0f - fy;
+        float4 s0 = a0 * gx + a1 * fx;
+        float4 s1 = b0 * gy + c0 * fy;
+        float4 s2 = b1 * (gx * gy) + b2 * (fx * gy) + c1 * (gx * fy) + c2 * (fx * fy);
+        float4 s3 = b3 * gy + c3 * fy;
+        float4 s4 = d0 * gx + d1 * fx;
+        color = s0 * h.w.x;
+        color = color + s1 * h.w.y;
+        color = color + s2 * h.w.z;
+        color = color + s3 * h.w.w;
+        color = color + s4 * h.w4;
+    } else { // the custom-weight bilinear fallback blends the central 2x2 (FetchHistoryGeneric, same order)
+        color = b1 * h.w.x;
+        color = color + b2 * h.w.y;
+        color = color + c1 * h.w.z;
+        color = color + c2 * h.w.w;
+    }
+    return h.sum < 0.0001f ? F4(0.0f) : color / h.sum;
+}
 NRD_D float4 FetchHistoryRGBA16F(const HistoryFilter& h, const Plane& tex) {
     // interior footprint (no coordinate was clamped): the 12 texels are 2 + 4 + 4 + 2 contiguous runs -> 6 requests instead of 12
-    const bool interior = h.x[3] - h.x[0] == 3 && h.y[3] - h.y[0] == 3;
+    const bool interior = HistoryFootprintIsInterior(h);
     if (!(interior && h.useBicubic))
         return FetchHistoryGeneric<float4>(h, tex, [](const Plane& p, int x, int y) { return LoadRGBA16F(p, x, y); }, F4(0.0f));
-    float4 a0, a1, b0, b1, b2, b3, c0, c1, c2, c3, d0, d1;
-    LoadRGBA16Fx2(tex, h.x[1], h.y[0], a0, a1);
-    LoadRGBA16Fx2(tex, h.x[0], h.y[1], b0, b1);
-    LoadRGBA16Fx2(tex, h.x[2], h.y[1], b2, b3);
-    LoadRGBA16Fx2(tex, h.x[0], h.y[2], c0, c1);
-    LoadRGBA16Fx2(tex, h.x[2], h.y[2], c2, c3);
-    LoadRGBA16Fx2(tex, h.x[1], h.y[3], d0, d1);
-    const float fx = h.tc.x, fy = h.tc.y, gx = 1.0f - fx, gy = 1.0f - fy;
-    float4 s0 = a0 * gx + a1 * fx;
-    float4 s1 = b0 * gy + c0 * fy;
-    float4 s2 = b1 * (gx * gy) + b2 * (fx * gy) + c1 * (gx * fy) + c2 * (fx * fy);
-    float4 s3 = b3 * gy + c3 * fy;
-    float4 s4 = d0 * gx + d1 * fx;
-    float4 color = s0 * h.w.x;
-    color = color + s1 * h.w.y;
-    color = color + s2 * h.w.z;
-    color = color + s3 * h.w.w;
-    color = color + s4 * h.w4;
-    return h.sum < 0.0001f ? F4(0.0f) : color / h.sum;
+    HistoryTexelsRGBA16F t;
+    PrefetchHistoryRGBA16F(h, tex, t);
+    return FetchHistoryRGBA16F(h, tex, t);
 }
 NRD_D float FetchHistoryR16F(const HistoryFilter& h, const Plane& tex) {
     // interior bicubic footprint: the 12 texels are rows of 2 + 4 + 4 + 2 -> four row loads (4 / 8 / 8 / 4 bytes) instead of twelve 2-byte ones
@@ -560,13 +622,22 @@ NRD_D float4 FetchHistoryBilinearRGBA16F(const HistoryFilter& h, const Plane& te
     float s = Sum(h.bw);
     return s < 0.0001f ? F4(0.0f) : color / s;
 }
-NRD_D float FetchHistoryBilinearR16F(const HistoryFilter& h, const Plane& tex) {
+struct BilinearTexelsR16F { // the 2x2 footprint of the Load-based bilinear path as two 4-byte row loads; `loaded` as above
+    uint32_t a, b, c, d;
+    bool loaded;
+};
+NRD_D void PrefetchBilinearR16F(const Plane& tex, int ox, int oy, BilinearTexelsR16F& t) {
+    t.loaded = FootprintIsInterior(tex, ox, oy, 2, 2);
+    t.a = t.b = t.c = t.d = 0u;
+    if (t.loaded) {
+        LoadRowR16Ux2(tex, ox, oy, t.a, t.b);
+        LoadRowR16Ux2(tex, ox, oy + 1, t.c, t.d);
+    }
+}
+NRD_D float FetchHistoryBilinearR16F(const HistoryFilter& h, const Plane& tex, const BilinearTexelsR16F& t) {
     float s00, s10, s01, s11;
-    if (FootprintIsInterior(tex, h.ox, h.oy, 2, 2)) { // two 4-byte row loads instead of four 2-byte ones (same texels)
-        uint32_t a, b, c2, d;
-        LoadRowR16Ux2(tex, h.ox, h.oy, a, b);
-        LoadRowR16Ux2(tex, h.ox, h.oy + 1, c2, d);
-        s00 = HalfBitsToFloat((uint16_t)a), s10 = HalfBitsToFloat((uint16_t)b), s01 = HalfBitsToFloat((uint16_t)c2), s11 = HalfBitsToFloat((uint16_t)d);
+    if (t.loaded) { // two 4-byte row loads instead of four 2-byte ones (same texels)
+        s00 = HalfBitsToFloat((uint16_t)t.a), s10 = HalfBitsToFloat((uint16_t)t.b), s01 = HalfBitsToFloat((uint16_t)t.c), s11 = HalfBitsToFloat((uint16_t)t.d);
     } else {
         s00 = LoadR16FOrZero(tex, h.ox, h.oy), s10 = LoadR16FOrZero(tex, h.ox + 1, h.oy), s01 = LoadR16FOrZero(tex, h.ox, h.oy + 1), s11 = LoadR16FOrZero(tex, h.ox + 1, h.oy + 1);
     }
@@ -576,6 +647,11 @@ NRD_D float FetchHistoryBilinearR16F(const HistoryFilter& h, const Plane& tex) {
     color += s11 * h.bw.w;
     float s = Sum(h.bw);
     return s < 0.0001f ? 0.0f : color / s;
+}
+NRD_D float FetchHistoryBilinearR16F(const HistoryFilter& h, const Plane& tex) {
+    BilinearTexelsR16F t;
+    PrefetchBilinearR16F(tex, h.ox, h.oy, t);
+    return FetchHistoryBilinearR16F(h, tex, t);
 }
 
 
@@ -595,6 +671,18 @@ struct ReblurSignal<SIGNAL_RADIANCE> {
     static NRD_D float LoadFast(const Plane& p, int x, int y) { return LoadR16F(p, x, y); }
     static NRD_D void StoreFast(const Plane& p, int x, int y, float v) { StoreR16F(p, x, y, v); }
     static NRD_D float FetchFastBilinear(const HistoryFilter& h, const Plane& tex) { return FetchHistoryBilinearR16F(h, tex); }
+    // two-step fetches (texels requested early, blended late)
+    typedef HistoryTexelsRGBA16F HistoryTexels;
+    typedef BilinearTexelsR16F FastTexels;
+    static NRD_D void PrefetchHistory(const HistoryFilter& h, const Plane& tex, HistoryTexels& t, bool enable) { // enable = false: blend from single-texel loads
+        t.loaded = false;
+        t.a = t.b0 = t.b1 = t.c0 = t.c1 = t.d = Raw4{0u, 0u, 0u, 0u};
+        if (enable)
+            PrefetchHistoryRGBA16F(h, tex, t);
+    }
+    static NRD_D float4 FetchHistory(const HistoryFilter& h, const Plane& tex, const HistoryTexels& t) { return FetchHistoryRGBA16F(h, tex, t); }
+    static NRD_D void PrefetchFast(const HistoryFilter& h, const Plane& tex, FastTexels& t) { PrefetchBilinearR16F(tex, h.ox, h.oy, t); }
+    static NRD_D float FetchFastBilinear(const HistoryFilter& h, const Plane& tex, const FastTexels& t) { return FetchHistoryBilinearR16F(h, tex, t); }
 };
 NRD_D float FetchHistoryBilinearR16Unorm(const HistoryFilter& h, const Plane& tex) {
     auto at = [&](int x, int y) { return InBounds(tex, x, y) ? LoadR16Unorm(tex, x, y) : 0.0f; };
@@ -618,6 +706,13 @@ struct ReblurSignal<SIGNAL_OCCLUSION> {
     static NRD_D float LoadFast(const Plane& p, int x, int y) { return LoadR16Unorm(p, x, y); }
     static NRD_D void StoreFast(const Plane& p, int x, int y, float v) { StoreR16Unorm(p, x, y, v); }
     static NRD_D float FetchFastBilinear(const HistoryFilter& h, const Plane& tex) { return FetchHistoryBilinearR16Unorm(h, tex); }
+    // no early requests for this storage: the two-step interface falls back to the plain fetch
+    struct HistoryTexels {};
+    struct FastTexels {};
+    static NRD_D void PrefetchHistory(const HistoryFilter&, const Plane&, HistoryTexels&, bool) {}
+    static NRD_D type FetchHistory(const HistoryFilter& h, const Plane& tex, const HistoryTexels&) { return FetchHistory(h, tex); }
+    static NRD_D void PrefetchFast(const HistoryFilter&, const Plane&, FastTexels&) {}
+    static NRD_D float FetchFastBilinear(const HistoryFilter& h, const Plane& tex, const FastTexels&) { return FetchFastBilinear(h, tex); }
 };
 template <>
 struct ReblurSignal<SIGNAL_DIRECTIONAL_OCCLUSION> {
@@ -632,6 +727,13 @@ struct ReblurSignal<SIGNAL_DIRECTIONAL_OCCLUSION> {
     static NRD_D float LoadFast(const Plane& p, int x, int y) { return LoadR16Unorm(p, x, y); }
     static NRD_D void StoreFast(const Plane& p, int x, int y, float v) { StoreR16Unorm(p, x, y, v); }
     static NRD_D float FetchFastBilinear(const HistoryFilter& h, const Plane& tex) { return FetchHistoryBilinearR16Unorm(h, tex); }
+    // no early requests for this storage: the two-step interface falls back to the plain fetch
+    struct HistoryTexels {};
+    struct FastTexels {};
+    static NRD_D void PrefetchHistory(const HistoryFilter&, const Plane&, HistoryTexels&, bool) {}
+    static NRD_D type FetchHistory(const HistoryFilter& h, const Plane& tex, const HistoryTexels&) { return FetchHistory(h, tex); }
+    static NRD_D void PrefetchFast(const HistoryFilter&, const Plane&, FastTexels&) {}
+    static NRD_D float FetchFastBilinear(const HistoryFilter& h, const Plane& tex, const FastTexels&) { return FetchFastBilinear(h, tex); }
 };
 
 } // namespace nrdhip
