@@ -34,9 +34,8 @@ struct TaPlanes {
 // PERF = REBLUR_PERFORMANCE_MODE: no Catmull-Rom history fetches (REBLUR_USE_CATROM_FOR_*_MOTION_IN_TA = 0, REBLUR_Config.hlsli:196-201)
 // OCC = occlusion family (REBLUR_OCCLUSION): hit-distance-only signals in R16_UNORM, no pre-pass output to read, no DATA2, no firefly suppressor
 // SH = the *_SH denoisers: the SH1 plane of every signal is accumulated with the same speeds (custom-weight bilinear history fetch)
-// WAVES = waves per SIMD the register allocation aims at (__launch_bounds__): 2 = no spills; 3 keeps 40-80 B of scratch per lane for one more wave
-// of latency hiding behind the dependent gathers (NRD_HIP_TA_WAVES picks the variant at launch for A/B runs; the default follows the measurements in
-// DESIGN.md section 3)
+// WAVES = waves per SIMD the register allocation aims at (__launch_bounds__): 2 for the kernels with a specular signal (3 would need scratch), 3 for
+// the diffuse-only ones (NRD_HIP_TA_WAVES overrides the choice at launch for A/B runs; measurements in DESIGN.md section 3)
 template <bool DIFF, bool SPEC, bool PERF, int KIND, bool SH, int WAVES>
 __global__ __launch_bounds__(TILE_X* TILE_Y, WAVES) void ReblurTemporalAccumulationKernel(ReblurCB cArg, TaPlanes P, RowRange rr) {
     typedef ReblurSignal<KIND> Sig;
@@ -181,51 +180,27 @@ __global__ __launch_bounds__(TILE_X* TILE_Y, WAVES) void ReblurTemporalAccumulat
     float2 catromOrigin = GetCatmullRomOrigin(smbPixelUv, rectSizePrev);
     const int cx = (int)catromOrigin.x, cy = (int)catromOrigin.y;
     const bool footprintInterior = FootprintIsInterior(P.prevViewZ, cx, cy, 4, 4); // the four rows as four 16-byte loads (reblur_device.h "row-vector fetches")
-    float4 smbViewZ0, smbViewZ1, smbViewZ2, smbViewZ3;
-    if (footprintInterior) {
-        const float4 r0 = LoadRowR32Fx4(P.prevViewZ, cx, cy), r1 = LoadRowR32Fx4(P.prevViewZ, cx, cy + 1), r2 = LoadRowR32Fx4(P.prevViewZ, cx, cy + 2), r3 = LoadRowR32Fx4(P.prevViewZ, cx, cy + 3);
-        smbViewZ0 = F4(r0.x, r0.y, r1.x, r1.y), smbViewZ1 = F4(r0.z, r0.w, r1.z, r1.w), smbViewZ2 = F4(r2.x, r2.y, r3.x, r3.y), smbViewZ3 = F4(r2.z, r2.w, r3.z, r3.w);
-    } else {
-#define QUADZ(ox, oy) \
-    F4(FetchClampedR32F(P.prevViewZ, cx + ox, cy + oy), FetchClampedR32F(P.prevViewZ, cx + ox + 1, cy + oy), FetchClampedR32F(P.prevViewZ, cx + ox, cy + oy + 1), FetchClampedR32F(P.prevViewZ, cx + ox + 1, cy + oy + 1))
-        smbViewZ0 = QUADZ(0, 0), smbViewZ1 = QUADZ(2, 0), smbViewZ2 = QUADZ(0, 2), smbViewZ3 = QUADZ(2, 2);
-#undef QUADZ
-    }
+    // Row loads from an origin clamped into the plane: always legal (pool planes have >= 4 texels per row pitch), exact for an interior footprint. The
+    // few footprints that touch the border are re-read texel by texel AFTER the batch. (Two symmetric arms -- row loads / clamped loads -- would be
+    // merged by the compiler into twelve scalar loads with selected addresses, which is what the row loads are there to avoid.)
+    const int fx4 = max(0, min(cx, P.prevViewZ.w - 4));
+    const int fy0 = ClampI(cy, 0, P.prevViewZ.h - 1), fy1 = ClampI(cy + 1, 0, P.prevViewZ.h - 1), fy2 = ClampI(cy + 2, 0, P.prevViewZ.h - 1), fy3 = ClampI(cy + 3, 0, P.prevViewZ.h - 1);
+    const float4 zr0 = LoadRowR32Fx4(P.prevViewZ, fx4, fy0), zr1 = LoadRowR32Fx4(P.prevViewZ, fx4, fy1), zr2 = LoadRowR32Fx4(P.prevViewZ, fx4, fy2), zr3 = LoadRowR32Fx4(P.prevViewZ, fx4, fy3);
     // ---- every other request that depends only on the surface-motion position is issued here, in one batch with the depth footprint: the 2x2
     // previous normals, the 4x4 previous internal data, the history texels of both signals (blended once the occlusion weights exist) and the
     // noisy inputs. A wave of this kernel lives ~27 000 cycles of which ~14 000 were spent waiting on ~14 dependent request phases at 2 waves
     // per SIMD (profiles/r02_c_reblur_ds_sq_pmc1.txt); the arithmetic in between now runs while the next phase's data is in flight.
+    // same geometry as the prev-viewZ footprint (launcher: same plane size): four undecoded 8-byte rows
+    const uint2 ir0 = LoadRowR16x4Raw(P.prevInternalData, fx4, fy0), ir1 = LoadRowR16x4Raw(P.prevInternalData, fx4, fy1), ir2 = LoadRowR16x4Raw(P.prevInternalData, fx4, fy2), ir3 = LoadRowR16x4Raw(P.prevInternalData, fx4, fy3);
     Bilinear smbBilinearFilter = GetBilinearFilter(smbPixelUv, rectSizePrev);
+    const int bx = (int)smbBilinearFilter.origin.x, by = (int)smbBilinearFilter.origin.y;
+    const bool normalsInterior = FootprintIsInterior(P.prevNormalRoughness, bx, by, 2, 2);
     uint32_t n00, n10, n01, n11; // packed texels of the 2x2 normal footprint (0 outside the plane, as Load returns)
     {
-        const int bx = (int)smbBilinearFilter.origin.x, by = (int)smbBilinearFilter.origin.y;
-        if (FootprintIsInterior(P.prevNormalRoughness, bx, by, 2, 2)) {
-            LoadRowR32Ux2(P.prevNormalRoughness, bx, by, n00, n10);
-            LoadRowR32Ux2(P.prevNormalRoughness, bx, by + 1, n01, n11);
-        } else {
-            n00 = InBounds(P.prevNormalRoughness, bx, by) ? LoadR32U(P.prevNormalRoughness, bx, by) : 0u;
-            n10 = InBounds(P.prevNormalRoughness, bx + 1, by) ? LoadR32U(P.prevNormalRoughness, bx + 1, by) : 0u;
-            n01 = InBounds(P.prevNormalRoughness, bx, by + 1) ? LoadR32U(P.prevNormalRoughness, bx, by + 1) : 0u;
-            n11 = InBounds(P.prevNormalRoughness, bx + 1, by + 1) ? LoadR32U(P.prevNormalRoughness, bx + 1, by + 1) : 0u;
-        }
+        const int nx = max(0, min(bx, P.prevNormalRoughness.w - 2));
+        LoadRowR32Ux2(P.prevNormalRoughness, nx, ClampI(by, 0, P.prevNormalRoughness.h - 1), n00, n10);
+        LoadRowR32Ux2(P.prevNormalRoughness, nx, ClampI(by + 1, 0, P.prevNormalRoughness.h - 1), n01, n11);
     }
-    uint32_t id0[4], id1[4], id2[4], id3[4];
-#define QUADU(q, ox, oy)                                                   \
-    q[0] = FetchClampedR16U(P.prevInternalData, cx + ox, cy + oy);         \
-    q[1] = FetchClampedR16U(P.prevInternalData, cx + ox + 1, cy + oy);     \
-    q[2] = FetchClampedR16U(P.prevInternalData, cx + ox, cy + oy + 1);     \
-    q[3] = FetchClampedR16U(P.prevInternalData, cx + ox + 1, cy + oy + 1);
-    if (footprintInterior) { // same geometry as the prev-viewZ footprint (launcher: same plane size): four 8-byte row loads
-        uint32_t r0[4], r1[4], r2[4], r3[4];
-        LoadRowR16Ux4(P.prevInternalData, cx, cy, r0), LoadRowR16Ux4(P.prevInternalData, cx, cy + 1, r1), LoadRowR16Ux4(P.prevInternalData, cx, cy + 2, r2), LoadRowR16Ux4(P.prevInternalData, cx, cy + 3, r3);
-        id0[0] = r0[0], id0[1] = r0[1], id0[2] = r1[0], id0[3] = r1[1];
-        id1[0] = r0[2], id1[1] = r0[3], id1[2] = r1[2], id1[3] = r1[3];
-        id2[0] = r2[0], id2[1] = r2[1], id2[2] = r3[0], id2[3] = r3[1];
-        id3[0] = r2[2], id3[1] = r2[3], id3[2] = r3[2], id3[3] = r3[3];
-    } else {
-        QUADU(id0, 0, 0) QUADU(id1, 2, 0) QUADU(id2, 0, 2) QUADU(id3, 2, 2)
-    }
-#undef QUADU
     const float2 smbSamplePos = Sat(smbPixelUv) * rectSizePrev;
     HistoryFilter smbFilter = MakeHistoryGeometry(smbSamplePos, DIFF ? P.historyDiff : P.historySpec); // both histories share a layout (checked by the launcher)
     typename Sig::HistoryTexels smbDiffTexels, smbSpecTexels;
@@ -240,6 +215,33 @@ __global__ __launch_bounds__(TILE_X* TILE_Y, WAVES) void ReblurTemporalAccumulat
         Sig::PrefetchHistory(smbFilter, P.historySpec, smbSpecTexels, !PERF && KIND != SIGNAL_DIRECTIONAL_OCCLUSION);
         Sig::PrefetchFast(smbFilter, P.historySpecFast, smbSpecFastTexels);
         spec = Sig::Load(P.inSpec, (OCC && c.gSpecCheckerboard != 2) ? px >> 1 : px, py);
+    }
+
+    // footprints on the border of the plane: clamped / zero-filled texel loads replace the row data
+    float4 smbViewZ0 = F4(zr0.x, zr0.y, zr1.x, zr1.y), smbViewZ1 = F4(zr0.z, zr0.w, zr1.z, zr1.w), smbViewZ2 = F4(zr2.x, zr2.y, zr3.x, zr3.y), smbViewZ3 = F4(zr2.z, zr2.w, zr3.z, zr3.w);
+    uint32_t id0[4], id1[4], id2[4], id3[4];
+    id0[0] = ir0.x & 0xFFFFu, id0[1] = ir0.x >> 16, id0[2] = ir1.x & 0xFFFFu, id0[3] = ir1.x >> 16;
+    id1[0] = ir0.y & 0xFFFFu, id1[1] = ir0.y >> 16, id1[2] = ir1.y & 0xFFFFu, id1[3] = ir1.y >> 16;
+    id2[0] = ir2.x & 0xFFFFu, id2[1] = ir2.x >> 16, id2[2] = ir3.x & 0xFFFFu, id2[3] = ir3.x >> 16;
+    id3[0] = ir2.y & 0xFFFFu, id3[1] = ir2.y >> 16, id3[2] = ir3.y & 0xFFFFu, id3[3] = ir3.y >> 16;
+    if (!footprintInterior) {
+#define QUADZ(ox, oy) \
+    F4(FetchClampedR32F(P.prevViewZ, cx + ox, cy + oy), FetchClampedR32F(P.prevViewZ, cx + ox + 1, cy + oy), FetchClampedR32F(P.prevViewZ, cx + ox, cy + oy + 1), FetchClampedR32F(P.prevViewZ, cx + ox + 1, cy + oy + 1))
+        smbViewZ0 = QUADZ(0, 0), smbViewZ1 = QUADZ(2, 0), smbViewZ2 = QUADZ(0, 2), smbViewZ3 = QUADZ(2, 2);
+#undef QUADZ
+#define QUADU(q, ox, oy)                                                   \
+    q[0] = FetchClampedR16U(P.prevInternalData, cx + ox, cy + oy);         \
+    q[1] = FetchClampedR16U(P.prevInternalData, cx + ox + 1, cy + oy);     \
+    q[2] = FetchClampedR16U(P.prevInternalData, cx + ox, cy + oy + 1);     \
+    q[3] = FetchClampedR16U(P.prevInternalData, cx + ox + 1, cy + oy + 1);
+        QUADU(id0, 0, 0) QUADU(id1, 2, 0) QUADU(id2, 0, 2) QUADU(id3, 2, 2)
+#undef QUADU
+    }
+    if (!normalsInterior) {
+        n00 = InBounds(P.prevNormalRoughness, bx, by) ? LoadR32U(P.prevNormalRoughness, bx, by) : 0u;
+        n10 = InBounds(P.prevNormalRoughness, bx + 1, by) ? LoadR32U(P.prevNormalRoughness, bx + 1, by) : 0u;
+        n01 = InBounds(P.prevNormalRoughness, bx, by + 1) ? LoadR32U(P.prevNormalRoughness, bx, by + 1) : 0u;
+        n11 = InBounds(P.prevNormalRoughness, bx + 1, by + 1) ? LoadR32U(P.prevNormalRoughness, bx + 1, by + 1) : 0u;
     }
 
     float3 prevViewZ0 = F3(UnpackViewZ(c, smbViewZ0.y), UnpackViewZ(c, smbViewZ0.z), UnpackViewZ(c, smbViewZ0.w));
@@ -520,21 +522,11 @@ __global__ __launch_bounds__(TILE_X* TILE_Y, WAVES) void ReblurTemporalAccumulat
         const int vx = (int)vmbBilinearFilter.origin.x, vy = (int)vmbBilinearFilter.origin.y;
         const bool vmbInterior = FootprintIsInterior(P.prevViewZ, vx, vy, 2, 2); // one test for the three planes of this footprint (same size)
         uint32_t vq00, vq10, vq01, vq11;     // packed normal / roughness
-        float vz00, vz10, vz01, vz11;        // packed viewZ
-        uint32_t vmbId00, vmbId10, vmbId01, vmbId11;
-        if (vmbInterior) {
-            LoadRowR32Ux2(P.prevNormalRoughness, vx, vy, vq00, vq10);
-            LoadRowR32Ux2(P.prevNormalRoughness, vx, vy + 1, vq01, vq11);
-            const float2 z0 = LoadRowR32Fx2(P.prevViewZ, vx, vy), z1 = LoadRowR32Fx2(P.prevViewZ, vx, vy + 1);
-            vz00 = z0.x, vz10 = z0.y, vz01 = z1.x, vz11 = z1.y;
-            LoadRowR16Ux2(P.prevInternalData, vx, vy, vmbId00, vmbId10);
-            LoadRowR16Ux2(P.prevInternalData, vx, vy + 1, vmbId01, vmbId11);
-        } else {
-            const int x0 = ClampI(vx, 0, P.prevViewZ.w - 1), x1 = ClampI(vx + 1, 0, P.prevViewZ.w - 1), y0 = ClampI(vy, 0, P.prevViewZ.h - 1), y1 = ClampI(vy + 1, 0, P.prevViewZ.h - 1);
-            vq00 = LoadR32U(P.prevNormalRoughness, x0, y0), vq10 = LoadR32U(P.prevNormalRoughness, x1, y0), vq01 = LoadR32U(P.prevNormalRoughness, x0, y1), vq11 = LoadR32U(P.prevNormalRoughness, x1, y1);
-            vz00 = LoadR32F(P.prevViewZ, x0, y0), vz10 = LoadR32F(P.prevViewZ, x1, y0), vz01 = LoadR32F(P.prevViewZ, x0, y1), vz11 = LoadR32F(P.prevViewZ, x1, y1);
-            vmbId00 = LoadR16U(P.prevInternalData, x0, y0), vmbId10 = LoadR16U(P.prevInternalData, x1, y0), vmbId01 = LoadR16U(P.prevInternalData, x0, y1), vmbId11 = LoadR16U(P.prevInternalData, x1, y1);
-        }
+        const int vfx = max(0, min(vx, P.prevViewZ.w - 2)), vfy0 = ClampI(vy, 0, P.prevViewZ.h - 1), vfy1 = ClampI(vy + 1, 0, P.prevViewZ.h - 1); // row loads as above
+        LoadRowR32Ux2(P.prevNormalRoughness, vfx, vfy0, vq00, vq10);
+        LoadRowR32Ux2(P.prevNormalRoughness, vfx, vfy1, vq01, vq11);
+        const float2 vzr0 = LoadRowR32Fx2(P.prevViewZ, vfx, vfy0), vzr1 = LoadRowR32Fx2(P.prevViewZ, vfx, vfy1);
+        const uint32_t vidr0 = LoadRowR16x2Raw(P.prevInternalData, vfx, vfy0), vidr1 = LoadRowR16x2Raw(P.prevInternalData, vfx, vfy1);
         // stochastic nearest taps of the bilinear footprint at the virtual position and one step back along the virtual motion (the draws keep their order)
         const float2 resolutionScalePrev = ToF2(c.gResolutionScalePrev);
         auto stochasticTexel = [&](float2 uv) {
@@ -554,20 +546,31 @@ __global__ __launch_bounds__(TILE_X* TILE_Y, WAVES) void ReblurTemporalAccumulat
         const uint32_t stochasticRaw1 = LoadR32U(P.prevNormalRoughness, st1.x, st1.y);
         // previous tracking hit distance: the 2x2 of the linear sample
         const LinearTaps hitDistTaps = MakeLinearTaps(vmbPixelUv * resolutionScalePrev * F2(float(P.prevSpecHitDistForTracking.w), float(P.prevSpecHitDistForTracking.h)));
-        uint32_t hd00, hd10, hd01, hd11;
-        if (FootprintIsInterior(P.prevSpecHitDistForTracking, hitDistTaps.x0, hitDistTaps.y0, 2, 2)) {
-            LoadRowR16Ux2(P.prevSpecHitDistForTracking, hitDistTaps.x0, hitDistTaps.y0, hd00, hd10);
-            LoadRowR16Ux2(P.prevSpecHitDistForTracking, hitDistTaps.x0, hitDistTaps.y0 + 1, hd01, hd11);
-        } else {
-            hd00 = FetchClampedR16U(P.prevSpecHitDistForTracking, hitDistTaps.x0, hitDistTaps.y0), hd10 = FetchClampedR16U(P.prevSpecHitDistForTracking, hitDistTaps.x0 + 1, hitDistTaps.y0);
-            hd01 = FetchClampedR16U(P.prevSpecHitDistForTracking, hitDistTaps.x0, hitDistTaps.y0 + 1), hd11 = FetchClampedR16U(P.prevSpecHitDistForTracking, hitDistTaps.x0 + 1, hitDistTaps.y0 + 1);
-        }
+        const bool hitDistInterior = FootprintIsInterior(P.prevSpecHitDistForTracking, hitDistTaps.x0, hitDistTaps.y0, 2, 2);
+        const int hx = max(0, min(hitDistTaps.x0, P.prevSpecHitDistForTracking.w - 2));
+        const uint32_t hdr0 = LoadRowR16x2Raw(P.prevSpecHitDistForTracking, hx, ClampI(hitDistTaps.y0, 0, P.prevSpecHitDistForTracking.h - 1));
+        const uint32_t hdr1 = LoadRowR16x2Raw(P.prevSpecHitDistForTracking, hx, ClampI(hitDistTaps.y0 + 1, 0, P.prevSpecHitDistForTracking.h - 1));
         // virtual history
         HistoryFilter vmbFilter = MakeHistoryGeometry(Sat(vmbPixelUv) * rectSizePrev, P.historySpec);
         typename Sig::HistoryTexels vmbSpecTexels;
         typename Sig::FastTexels vmbSpecFastTexels;
         Sig::PrefetchHistory(vmbFilter, P.historySpec, vmbSpecTexels, !PERF && KIND != SIGNAL_DIRECTIONAL_OCCLUSION);
         Sig::PrefetchFast(vmbFilter, P.historySpecFast, vmbSpecFastTexels);
+
+        // footprints on the border of the plane: clamped texel loads replace the row data
+        float vz00 = vzr0.x, vz10 = vzr0.y, vz01 = vzr1.x, vz11 = vzr1.y; // packed viewZ
+        uint32_t vmbId00 = vidr0 & 0xFFFFu, vmbId10 = vidr0 >> 16, vmbId01 = vidr1 & 0xFFFFu, vmbId11 = vidr1 >> 16;
+        uint32_t hd00 = hdr0 & 0xFFFFu, hd10 = hdr0 >> 16, hd01 = hdr1 & 0xFFFFu, hd11 = hdr1 >> 16;
+        if (!vmbInterior) {
+            const int x0 = ClampI(vx, 0, P.prevViewZ.w - 1), x1 = ClampI(vx + 1, 0, P.prevViewZ.w - 1), y0 = ClampI(vy, 0, P.prevViewZ.h - 1), y1 = ClampI(vy + 1, 0, P.prevViewZ.h - 1);
+            vq00 = LoadR32U(P.prevNormalRoughness, x0, y0), vq10 = LoadR32U(P.prevNormalRoughness, x1, y0), vq01 = LoadR32U(P.prevNormalRoughness, x0, y1), vq11 = LoadR32U(P.prevNormalRoughness, x1, y1);
+            vz00 = LoadR32F(P.prevViewZ, x0, y0), vz10 = LoadR32F(P.prevViewZ, x1, y0), vz01 = LoadR32F(P.prevViewZ, x0, y1), vz11 = LoadR32F(P.prevViewZ, x1, y1);
+            vmbId00 = LoadR16U(P.prevInternalData, x0, y0), vmbId10 = LoadR16U(P.prevInternalData, x1, y0), vmbId01 = LoadR16U(P.prevInternalData, x0, y1), vmbId11 = LoadR16U(P.prevInternalData, x1, y1);
+        }
+        if (!hitDistInterior) {
+            hd00 = FetchClampedR16U(P.prevSpecHitDistForTracking, hitDistTaps.x0, hitDistTaps.y0), hd10 = FetchClampedR16U(P.prevSpecHitDistForTracking, hitDistTaps.x0 + 1, hitDistTaps.y0);
+            hd01 = FetchClampedR16U(P.prevSpecHitDistForTracking, hitDistTaps.x0, hitDistTaps.y0 + 1), hd11 = FetchClampedR16U(P.prevSpecHitDistForTracking, hitDistTaps.x0 + 1, hitDistTaps.y0 + 1);
+        }
 
         // Virtual motion - roughness
         float2 relaxedRoughnessWeightParams = GetRelaxedRoughnessWeightParams(roughness * roughness, c.gRoughnessFraction, REBLUR_ROUGHNESS_SENSITIVITY_IN_TA);
@@ -894,8 +897,11 @@ static const char* LaunchTemporalAccumulation(const PassArgs& a) {
     }
 
     RowGrid g = GridForRows(c.gRectSizeMinusOne.x + 1, c.gRectSizeMinusOne.y + 1, TILE_X, TILE_Y, a.rowBegin, a.rowEnd);
-    static const int waves = getenv("NRD_HIP_TA_WAVES") ? atoi(getenv("NRD_HIP_TA_WAVES")) : 2;
-    if (waves >= 3 && SPEC)
+    // register budget: with a specular signal the batched requests need ~250 VGPRs (2 waves per SIMD); the diffuse-only kernel fits 168 without scratch,
+    // which keeps its third wave (r02_k: 0.135 ms at 2 waves against 0.109 before the batching)
+    static const int wavesEnv = getenv("NRD_HIP_TA_WAVES") ? atoi(getenv("NRD_HIP_TA_WAVES")) : 0;
+    const int waves = wavesEnv ? wavesEnv : (SPEC ? 2 : 3);
+    if (waves >= 3)
         LaunchPass(a, (ReblurTemporalAccumulationKernel<DIFF, SPEC, PERF, KIND, SH, 3>), g.grid, dim3(TILE_X * TILE_Y), c, P, MakeRowRange(g));
     else
         LaunchPass(a, (ReblurTemporalAccumulationKernel<DIFF, SPEC, PERF, KIND, SH, 2>), g.grid, dim3(TILE_X * TILE_Y), c, P, MakeRowRange(g));

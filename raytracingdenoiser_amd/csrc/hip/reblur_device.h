@@ -376,6 +376,18 @@ NRD_D void LoadRowR16Ux4(const Plane& p, int x, int y, uint32_t* out) {
     const U16x4U r = *(const U16x4U*)TexelPtr<const uint16_t>(p, x, y);
     out[0] = r.v[0], out[1] = r.v[1], out[2] = r.v[2], out[3] = r.v[3];
 }
+// undecoded rows: the halves are split where the values are used, so that a batch of requests contains no ALU work on loaded data (any such
+// instruction makes the wave wait for every request issued before it)
+NRD_D uint32_t LoadRowR16x2Raw(const Plane& p, int x, int y) {
+    uint32_t v;
+    __builtin_memcpy(&v, TexelPtr<const uint16_t>(p, x, y), 4);
+    return v;
+}
+NRD_D uint2 LoadRowR16x4Raw(const Plane& p, int x, int y) {
+    uint32_t v[2];
+    __builtin_memcpy(v, TexelPtr<const uint16_t>(p, x, y), 8);
+    return make_uint2(v[0], v[1]);
+}
 NRD_D void LoadRowR16Ux2(const Plane& p, int x, int y, uint32_t& a, uint32_t& b) {
     const U16x2U r = *(const U16x2U*)TexelPtr<const uint16_t>(p, x, y);
     a = r.v[0], b = r.v[1];
@@ -622,22 +634,22 @@ NRD_D float4 FetchHistoryBilinearRGBA16F(const HistoryFilter& h, const Plane& te
     float s = Sum(h.bw);
     return s < 0.0001f ? F4(0.0f) : color / s;
 }
-struct BilinearTexelsR16F { // the 2x2 footprint of the Load-based bilinear path as two 4-byte row loads; `loaded` as above
-    uint32_t a, b, c, d;
+struct BilinearTexelsR16F { // the 2x2 footprint of the Load-based bilinear path as two undecoded 4-byte rows; `loaded` as above
+    uint32_t r0, r1;
     bool loaded;
 };
 NRD_D void PrefetchBilinearR16F(const Plane& tex, int ox, int oy, BilinearTexelsR16F& t) {
     t.loaded = FootprintIsInterior(tex, ox, oy, 2, 2);
-    t.a = t.b = t.c = t.d = 0u;
+    t.r0 = t.r1 = 0u;
     if (t.loaded) {
-        LoadRowR16Ux2(tex, ox, oy, t.a, t.b);
-        LoadRowR16Ux2(tex, ox, oy + 1, t.c, t.d);
+        t.r0 = LoadRowR16x2Raw(tex, ox, oy);
+        t.r1 = LoadRowR16x2Raw(tex, ox, oy + 1);
     }
 }
 NRD_D float FetchHistoryBilinearR16F(const HistoryFilter& h, const Plane& tex, const BilinearTexelsR16F& t) {
     float s00, s10, s01, s11;
     if (t.loaded) { // two 4-byte row loads instead of four 2-byte ones (same texels)
-        s00 = HalfBitsToFloat((uint16_t)t.a), s10 = HalfBitsToFloat((uint16_t)t.b), s01 = HalfBitsToFloat((uint16_t)t.c), s11 = HalfBitsToFloat((uint16_t)t.d);
+        s00 = HalfBitsToFloat((uint16_t)(t.r0 & 0xFFFFu)), s10 = HalfBitsToFloat((uint16_t)(t.r0 >> 16)), s01 = HalfBitsToFloat((uint16_t)(t.r1 & 0xFFFFu)), s11 = HalfBitsToFloat((uint16_t)(t.r1 >> 16));
     } else {
         s00 = LoadR16FOrZero(tex, h.ox, h.oy), s10 = LoadR16FOrZero(tex, h.ox + 1, h.oy), s01 = LoadR16FOrZero(tex, h.ox, h.oy + 1), s11 = LoadR16FOrZero(tex, h.ox + 1, h.oy + 1);
     }
