@@ -128,6 +128,7 @@ def parse_args():
     ap.add_argument("--numerics", choices=["fast", "exact"], default=os.environ.get("NRD_HIP_NUMERICS", "fast"),
                     help="fast = lib/libNRD_hip.so, the product (default); exact = lib/libNRD_hip_exact.so, the bit-exact regression build")
     ap.add_argument("--no-graph", action="store_true", help="launch every pass on its own instead of one hipGraph per frame")
+    ap.add_argument("--no-exact-leg", action="store_true", help="skip the timing of the exact build beside the product build")
     ap.add_argument("--no-parity", action="store_true", help="skip the GPU-vs-oracle comparison of the cpu_baseline frames")
     return ap.parse_args()
 
@@ -406,6 +407,33 @@ def main():
         "whole_chain": whole_chain,
         "passes": passes,
     }
+    # ---- the same frames on the exact build (the library every bit-exact parity test runs): reported beside the product number, outside its timed region
+    if world == 1 and args.numerics == "fast" and not args.no_exact_leg:
+        native_build.build_product(numerics="exact")
+        inst_x = api.Instance([(0, parity.DENOISERS[name][0])], numerics="exact")
+        ex_x = HipExecutor(inst_x, W, H)
+        ex_x.set_graph_mode(not args.no_graph)
+        for (rt, dtype, ch, fmt), t in zip(parity.output_planes(name, W, H), outputs):
+            ex_x.bind(rt, t, fmt)
+        assert inst_x.set_denoiser_settings(0, settings) == api.Result.SUCCESS
+
+        def step_x(f):
+            for rt, t, fmt in parity.user_planes(name, frame_of(f)):
+                ex_x.bind(rt, t, fmt)
+            assert inst_x.set_common_settings(frames_cs[f]) == api.Result.SUCCESS
+            ex_x.denoise()
+
+        n_x = max(args.steps // 2, 1)
+        for f in range(min(args.warmup, 8)):
+            step_x(f)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for f in range(args.warmup, args.warmup + n_x):
+            step_x(f)
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        result["exact_build"] = {"value": round(n_x * W * H / dt / 1e6, 2), "unit": "Mpixels/s", "ms_per_step": round(dt * 1e3 / n_x, 4), "steps": n_x,
+                                 "note": "lib/libNRD_hip_exact.so: IEEE division, no contraction, polynomial transcendentals -- bit-identical to the CPU oracle (tests/test_full_parity.py)"}
     if not args.no_cpu_baseline and world == 1:
         result["cpu_baseline"], result["parity"] = cpu_baseline(name, W, H, min(args.cpu_frames, distinct), seq, overrides, numerics=args.numerics, check_parity=not args.no_parity)
     else:
