@@ -409,31 +409,34 @@ def main():
     }
     # ---- the same frames on the exact build (the library every bit-exact parity test runs): reported beside the product number, outside its timed region
     if world == 1 and args.numerics == "fast" and not args.no_exact_leg:
-        native_build.build_product(numerics="exact")
-        inst_x = api.Instance([(0, parity.DENOISERS[name][0])], numerics="exact")
-        ex_x = HipExecutor(inst_x, W, H)
-        ex_x.set_graph_mode(not args.no_graph)
-        for (rt, dtype, ch, fmt), t in zip(parity.output_planes(name, W, H), outputs):
-            ex_x.bind(rt, t, fmt)
-        assert inst_x.set_denoiser_settings(0, settings) == api.Result.SUCCESS
-
-        def step_x(f):
-            for rt, t, fmt in parity.user_planes(name, frame_of(f)):
+        try:
+            native_build.build_product(numerics="exact")
+            inst_x = api.Instance([(0, parity.DENOISERS[name][0])], numerics="exact")
+            ex_x = HipExecutor(inst_x, W, H)
+            ex_x.set_graph_mode(not args.no_graph)
+            for (rt, dtype, ch, fmt), t in zip(parity.output_planes(name, W, H), outputs):
                 ex_x.bind(rt, t, fmt)
-            assert inst_x.set_common_settings(frames_cs[f]) == api.Result.SUCCESS
-            ex_x.denoise()
+            assert inst_x.set_denoiser_settings(0, settings) == api.Result.SUCCESS
 
-        n_x = max(args.steps // 2, 1)
-        for f in range(min(args.warmup, 8)):
-            step_x(f)
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        for f in range(args.warmup, args.warmup + n_x):
-            step_x(f)
-        torch.cuda.synchronize()
-        dt = time.perf_counter() - t0
-        result["exact_build"] = {"value": round(n_x * W * H / dt / 1e6, 2), "unit": "Mpixels/s", "ms_per_step": round(dt * 1e3 / n_x, 4), "steps": n_x,
-                                 "note": "lib/libNRD_hip_exact.so: IEEE division, no contraction, polynomial transcendentals -- bit-identical to the CPU oracle (tests/test_full_parity.py)"}
+            def step_x(f):
+                for rt, t, fmt in parity.user_planes(name, frame_of(f)):
+                    ex_x.bind(rt, t, fmt)
+                assert inst_x.set_common_settings(frames_cs[f]) == api.Result.SUCCESS
+                ex_x.denoise()
+
+            n_x = max(args.steps // 2, 1)
+            for f in range(min(args.warmup, 8)):
+                step_x(f)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for f in range(args.warmup, args.warmup + n_x):
+                step_x(f)
+            torch.cuda.synchronize()
+            dt = time.perf_counter() - t0
+            result["exact_build"] = {"value": round(n_x * W * H / dt / 1e6, 2), "unit": "Mpixels/s", "ms_per_step": round(dt * 1e3 / n_x, 4), "steps": n_x,
+                                     "note": "lib/libNRD_hip_exact.so: IEEE division, no contraction, polynomial transcendentals -- bit-identical to the CPU oracle (tests/test_full_parity.py)"}
+        except Exception as e:  # the product line must be printed whatever happens to this side measurement
+            result["exact_build"] = {"error": repr(e)}
     if not args.no_cpu_baseline and world == 1:
         result["cpu_baseline"], result["parity"] = cpu_baseline(name, W, H, min(args.cpu_frames, distinct), seq, overrides, numerics=args.numerics, check_parity=not args.no_parity)
     else:
