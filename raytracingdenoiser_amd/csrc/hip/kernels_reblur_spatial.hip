@@ -73,12 +73,14 @@ struct SpatialCtx {
     float2 wc;
 };
 
-// Fast build, full-rect variants: the screen-space taps are generated in pixel units (the rotator is scaled by the rect size once per pixel instead of
-// multiplying every tap's uv by it); the exact build keeps the reference's operation order
-// (-DNRD_FAST_TAP_POSITIONS=0 keeps the reference's operation order for the tap positions in the fast build too: 4x fewer output values beyond 1e-3 of the
-// oracle after 3 frames at 1440p -- taps that differ by a few ulp cross a pixel boundary ~1e-4 of the time -- for ~0.02 ms per frame)
+// Tap POSITIONS of the fast build. -DNRD_FAST_TAP_POSITIONS=1 generates the screen-space taps in pixel units (the rotator is scaled by the rect size once per
+// pixel instead of multiplying every tap's uv by it) and the world-space specular taps through the linearity of the projection: -1.5 % frame time (0.789 against
+// 0.800 ms at 1440p, profiles/r02_final_bench.json / r02_final_taps0_bench.json). It is OFF by default: a position that differs from the oracle's by a few ulp
+// crosses a pixel boundary ~1e-4 of the time, with 16 taps x 3 passes per pixel that moves a tap in ~1 % of the pixels per frame, and a moved tap changes a
+// 1-rpp pixel by ~noise / 8 -- 2.3 % of the output values beyond 1e-3 of the oracle after 3 frames at 1440p (p99.9 = 0.12) against 0.74 % (p99.9 = 0.005)
+// with the reference's operation order (profiles/r02_m_pytest_full_parity.log, r02_final_taps0_parity.log). The exact build always keeps the reference's order.
 #ifndef NRD_FAST_TAP_POSITIONS
-#define NRD_FAST_TAP_POSITIONS 1
+#define NRD_FAST_TAP_POSITIONS 0
 #endif
 #if NRD_FAST && NRD_FAST_TAP_POSITIONS
 #define NRD_TAPS_IN_PIXELS(FR) ((FR) != 0)

@@ -200,7 +200,10 @@ def render_frame(width, height, frame, device="cpu", static_camera=False, noise=
     p = o + d * torch.where(is_sky, torch.zeros_like(t), t).unsqueeze(-1)
 
     out = {"camera": cam, "viewz": view_z.contiguous(), "is_sky": is_sky}
-    out["normal_roughness"] = pack_normal_roughness(n, rough, torch.zeros_like(rough)).contiguous()
+    material_id = torch.zeros_like(rough)
+    if "materials" in want:  # material IDs 0..3 in bands of the world position (consumed when minMaterialForDiffuse / ForSpecular < 3 or a special material ID matches)
+        material_id = torch.where(is_sky, torch.zeros_like(rough), torch.remainder(torch.floor(p[..., 0] * 0.9) + torch.floor(p[..., 2] * 0.9), 4.0))
+    out["normal_roughness"] = pack_normal_roughness(n, rough, material_id).contiguous()
     out["mv"] = torch.zeros((height, width, 4), dtype=torch.float16, device=dev)  # static scene, world-space MVs scaled by 0
     if "basecolor" in want:
         # IN_BASECOLOR_METALNESS (RGBA8_UNORM): the surface albedo as base colour, metalness in bands {0, 0.5, 1} of the world position

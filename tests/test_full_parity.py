@@ -15,7 +15,7 @@ Three kinds of runs, all through the C-ABI:
   build delivers against the device-emulating oracle; against anything else the honest statement is a distribution.
 * fast build (libNRD_hip.so, the product: hardware rcp / exp2 / log2, FMA contraction, reassociation, tap positions generated in pixel units) vs the
   oracle in IEEE mode: the same mechanism with more perturbed operations -- after 3 frames at 1440p 2.3 % of the output values are beyond 1e-3 (mean
-  relative error 4e-4; 0.6 % / 5e-5 while the tap positions still followed the reference's operation order, r02_a), after 48 frames 4-11 %.
+  relative error 4e-4) with -DNRD_FAST_TAP_POSITIONS=1; with the default (tap positions in the reference's operation order) 0.74 % / 6e-5; after 48 frames 4-11 %.
   The tests bound the mean error and the fraction beyond 1e-3, hold them against the exact-vs-IEEE figures of the same sequence (same mechanism, same
   order of magnitude) and check that the fast build DENOISES as well as the oracle (error against a converged image within 2 %).
 
@@ -72,11 +72,11 @@ def test_fast_build_within_tolerance_at_baseline_size(name, width, height, frame
     row = _report("fast_vs_ieee_oracle", name, (width, height), frames, stats)
     out = row["outputs"]
     sh = name.endswith("_SH")  # the SH1 planes are signed and small: relative errors against a 1e-3 floor are inflated there
-    # measured r02_m (final flags: taps generated in pixel units, linearised specular projection, reassociation): 2.3 % REBLUR_DS, 0.26 % REBLUR_D, 7e-6 SIGMA,
-    # 10.3 % RELAX SH (2 frames at 4K); mean 3.9e-4, 2.9e-5, 6e-8, 1.2e-3. (r02_a, taps in the reference's operation order: 0.6 % / mean 5e-5 for REBLUR_DS --
-    # a tap position that differs by a few ulp crosses a pixel boundary ~1e-4 of the time, 16 taps x 3 passes per pixel)
-    assert out["frac_gt_tol"] <= (0.2 if sh else 0.05), out
-    assert out["mean"] <= (5e-3 if sh else 1e-3), out
+    # measured r02_final (product flags: hardware transcendentals, contraction, reassociation; tap positions in the reference's operation order): 0.74 % of the
+    # REBLUR_DS output values beyond 1e-3, mean 6e-5, p99.9 0.005; r02_m with -DNRD_FAST_TAP_POSITIONS=1: 2.3 % / 3.9e-4 / 0.12 (a tap position that differs by a
+    # few ulp crosses a pixel boundary ~1e-4 of the time, 16 taps x 3 passes per pixel); REBLUR_D 0.26 %, SIGMA 7e-6, RELAX SH 10 % (2 frames at 4K)
+    assert out["frac_gt_tol"] <= (0.2 if sh else 0.03), out
+    assert out["mean"] <= (5e-3 if sh else 5e-4), out
 
 
 LONG = ["REBLUR_DIFFUSE_SPECULAR", "RELAX_DIFFUSE_SPECULAR_SH", "RELAX_DIFFUSE_SPECULAR", "SIGMA_SHADOW", "REBLUR_DIFFUSE_SPECULAR_OCCLUSION"]

@@ -400,3 +400,27 @@ def test_hip_matches_oracle_specular_mv_modification(name, world_space, z_scale)
     worst = parity.run_parity(name, width=w, height=h, frames=4, verbose=True, extra_want=("basecolor",) if world_space else ("mv2d", "basecolor"), cs_kw=cs_kw,
                               settings_overrides=dict(enablePerformanceMode=True) if name == "REBLUR_SPECULAR" else None)
     assert worst <= parity.REL_TOL
+
+
+def test_oracle_material_ids_separate_the_filters():
+    """with material IDs in the G-buffer and minMaterialFor* below 3 the passes stop blending across material borders (reference CompareMaterials,
+    REBLUR_Common.hlsli): the result must differ from the run that ignores them, and pixels deep inside one material band must not"""
+    w, h, frames = 96, 64, 3
+    seq = [parity.synth.render_frame(w, h, f, want=tuple(parity.DENOISERS["REBLUR_DIFFUSE_SPECULAR"][1]) + ("materials",)) for f in range(frames)]
+    outs = []
+    for over in (dict(minMaterialForDiffuse=0.0, minMaterialForSpecular=1.0), None):
+        ora = parity.OracleRun("REBLUR_DIFFUSE_SPECULAR", w, h)
+        for f, frame in enumerate(seq):
+            ora.step(frame, parity.common_settings(frame["camera"], seq[max(f - 1, 0)]["camera"], w, h, f), parity.denoiser_settings("REBLUR_DIFFUSE_SPECULAR", frame, over))
+        outs.append(ora.output(RT.OUT_DIFF_RADIANCE_HITDIST).copy())
+    assert np.isfinite(outs[0]).all() and not np.array_equal(outs[0], outs[1])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", ["REBLUR_DIFFUSE_SPECULAR", "REBLUR_DIFFUSE", "REBLUR_SPECULAR_OCCLUSION", "REBLUR_DIFFUSE_SPECULAR_SH"])
+def test_hip_matches_oracle_material_ids(name):
+    """material tests on (minMaterialFor* < 3) + the two special material IDs of CommonSettings: the full-rect tap variant WITH material tests (FR 1),
+    CompareMaterials in temporal accumulation / history fix, the strand-material disocclusion threshold and the camera-attached reflection material"""
+    worst = parity.run_parity(name, width=160, height=96, frames=4, extra_want=("materials",), settings_overrides=dict(minMaterialForDiffuse=0.0, minMaterialForSpecular=1.0),
+                              cs_kw=dict(strandMaterialID=1.0, cameraAttachedReflectionMaterialID=2.0))
+    assert worst == 0.0

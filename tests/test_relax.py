@@ -292,3 +292,11 @@ def test_hip_matches_oracle_screen_space_motion_vectors(name, z_scale):
     worst = parity.run_parity(name, width=176, height=104, frames=5, verbose=True, extra_want=("mv2d",),
                               cs_kw=dict(isMotionVectorInWorldSpace=False, motionVectorScale=(1.0 / 176, 1.0 / 104, z_scale)))
     assert worst <= parity.REL_TOL
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", ["RELAX_DIFFUSE_SPECULAR", "RELAX_DIFFUSE_SPECULAR_SH", "RELAX_SPECULAR"])
+def test_hip_matches_oracle_material_ids(name):
+    """material tests on (minMaterialFor* < 3): CompareMaterials in the pre-pass, temporal accumulation, history fix and the a-trous chain"""
+    worst = parity.run_parity(name, width=160, height=96, frames=4, extra_want=("materials",), settings_overrides=dict(minMaterialForDiffuse=0.0, minMaterialForSpecular=1.0))
+    assert worst == 0.0
