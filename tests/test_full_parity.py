@@ -88,7 +88,7 @@ def test_exact_build_bit_exact_over_48_frames(name):
     assert worst == 0.0, "exact build differs from the oracle within 48 frames: max rel err %g" % worst
 
 
-@pytest.mark.parametrize("name", LONG)
+@pytest.mark.parametrize("name", ["REBLUR_DIFFUSE_SPECULAR", "RELAX_DIFFUSE_SPECULAR_SH", "SIGMA_SHADOW"])  # one per family (three oracle runs of 48 frames each)
 def test_fast_build_within_tolerance_over_48_frames(name):
     stats = parity.ParityStats()
     parity.run_parity(name, 192, 128, 48, numerics="fast", ieee=True, stats=stats, static_after=39)
