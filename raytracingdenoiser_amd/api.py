@@ -285,8 +285,8 @@ def load_library(path=None, numerics=None):
     """dlopen lib/libNRD_hip.so (numerics "fast", the default) or lib/libNRD_hip_exact.so and set prototypes. Raises if the library has not been
     built -- there is no fallback. Both may live in one process (RTLD_LOCAL)."""
     numerics = numerics or default_numerics()
-    # tuning runs (tools/build_variant.py): NRD_HIP_FAST_LIBRARY points the "fast" slot at a variant build of the same sources
-    path = path or (numerics == "fast" and os.environ.get("NRD_HIP_FAST_LIBRARY")) or LIB_PATHS[numerics]
+    # tuning runs (tools/build_variant.py): NRD_HIP_FAST_LIBRARY / NRD_HIP_EXACT_LIBRARY point a slot at a variant build of the same sources
+    path = path or os.environ.get("NRD_HIP_FAST_LIBRARY" if numerics == "fast" else "NRD_HIP_EXACT_LIBRARY") or LIB_PATHS[numerics]
     if path in _libs:
         return _libs[path]
     if not os.path.exists(path):
