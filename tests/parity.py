@@ -425,6 +425,9 @@ def _run_parity(name, width, height, frames, verbose, settings_overrides, static
                     o_raw, fmt, w = ora.ex.pool_plane(pool, i)
                     h_raw, hfmt, hw = hip.ex.read_pool_plane(pool, i)
                     assert fmt == hfmt and w == hw
+                    row_bytes = w * api.FORMAT_BYTES[fmt]
+                    if stats is None and not verbose and np.array_equal(o_raw[:, :row_bytes], h_raw[:, :row_bytes]):
+                        continue  # identical bytes: relative error 0 without decoding 30 MB planes to float64 (the common case of the bit-exact runs)
                     want, got = decode_plane(o_raw, fmt, w), decode_plane(h_raw, fmt, w)
                     e = rel_error(got, want)
                     if stats is None:
