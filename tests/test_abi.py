@@ -150,3 +150,35 @@ def test_constant_arena_overflow_fails_the_whole_call():
     assert r == api.Result.FAILURE and n == 0 and not out
     r, ds = inst.get_compute_dispatches([1, 2])
     assert r == api.Result.SUCCESS and len(ds) > 10 and all(len(d.constants) in (0, 832) for d in ds)
+
+
+@pytest.mark.parametrize("field,value", [
+    ("viewZScale", 0.0), ("viewZScale", -1.0), ("resourceSize", (0, 64)), ("resourceSizePrev", (64, 0)), ("rectSize", (0, 64)), ("rectSizePrev", (64, 0)),
+    ("cameraJitter", (0.6, 0.0)), ("cameraJitter", (0.0, -0.51)), ("cameraJitterPrev", (-0.7, 0.0)), ("denoisingRange", 0.0),
+    ("disocclusionThreshold", 0.0), ("disocclusionThresholdAlternate", -0.1),
+])
+def test_set_common_settings_rejects_what_the_reference_asserts(field, value):
+    """reference InstanceImpl.cpp:300-337: each assert is a predicate of the Result (INVALID_ARGUMENT) here; the instance keeps working afterwards"""
+    inst = api.Instance([(1, api.Denoiser.REBLUR_DIFFUSE)])
+    assert inst.set_common_settings(_settings(64, 64)) == api.Result.SUCCESS  # the first use overwrites the *Prev fields with the current ones (reference :283-297)
+    bad = _settings(64, 64)
+    if isinstance(value, tuple):
+        for i, v in enumerate(value):
+            getattr(bad, field)[i] = v
+    else:
+        setattr(bad, field, value)
+    assert inst.set_common_settings(bad) == api.Result.INVALID_ARGUMENT
+    assert inst.set_common_settings(_settings(64, 64)) == api.Result.SUCCESS
+    r, ds = inst.get_compute_dispatches()
+    assert r == api.Result.SUCCESS and len(ds) > 0
+
+
+def test_screen_space_motion_vectors_need_a_scale():
+    """'mvScale.xy can't be 0' unless the motion vectors are in world space (reference InstanceImpl.cpp:315-316)"""
+    inst = api.Instance([(1, api.Denoiser.REBLUR_DIFFUSE)])
+    cs = _settings(64, 64)
+    cs.isMotionVectorInWorldSpace = False
+    cs.motionVectorScale[0], cs.motionVectorScale[1] = 0.0, 1.0
+    assert inst.set_common_settings(cs) == api.Result.INVALID_ARGUMENT
+    cs.isMotionVectorInWorldSpace = True
+    assert inst.set_common_settings(cs) == api.Result.SUCCESS
