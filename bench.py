@@ -12,11 +12,12 @@ GPU before the timed region). Prints ONE JSON line (see DESIGN.md "Measurement")
   cpu_baseline  the CPU oracle (oracle/, kind "port": the reference has no CPU implementation) on the host cores,
                 on a bounded sample of the same workload (N = 1, rank 0 only)
   parity        the planes the cpu_baseline leg computes anyway (first frames of the same sequence, full size) compared with the GPU's
+  exact_build   the same frames timed on lib/libNRD_hip_exact.so (the bit-exact regression build), beside the product's value (N = 1 only)
 
 --gpus N with N > 1 and no torch.distributed environment re-launches itself under torch.distributed.run (one rank per GPU, RCCL).
 
   python bench.py [--gpus N] [--steps K] [--warmup W] [--workload reblur_ds|reblur_diffuse|relax_ds_sh|relax_ds|sigma_shadow] [--width 2560 --height 1440]
-                  [--numerics fast|exact] [--no-graph] [--no-cpu-baseline]
+                  [--numerics fast|exact] [--no-graph] [--no-cpu-baseline] [--no-parity] [--no-exact-leg]
 """
 import argparse
 import json
