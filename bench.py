@@ -129,6 +129,7 @@ def parse_args():
     ap.add_argument("--numerics", choices=["fast", "exact"], default=os.environ.get("NRD_HIP_NUMERICS", "fast"),
                     help="fast = lib/libNRD_hip.so, the product (default); exact = lib/libNRD_hip_exact.so, the bit-exact regression build")
     ap.add_argument("--no-graph", action="store_true", help="launch every pass on its own instead of one hipGraph per frame")
+    ap.add_argument("--no-sky", action="store_true", help="a dome behind the scene: no sky pixels (34 %% of the default frame are sky and leave at the tile test)")
     ap.add_argument("--no-exact-leg", action="store_true", help="skip the timing of the exact build beside the product build")
     ap.add_argument("--no-parity", action="store_true", help="skip the GPU-vs-oracle comparison of the cpu_baseline frames")
     return ap.parse_args()
@@ -267,6 +268,9 @@ def main():
     total = args.warmup + args.steps
     distinct = args.distinct_frames or total
 
+    if args.no_sky:
+        from raytracingdenoiser_amd import synth
+        synth.BACKDROP = True
     # ---- synthetic inputs, generated straight into HBM (118 MB per 1440p frame; 96 frames = 11 GB of 288 GB)
     seq = parity.generate_sequence(name, W, H, distinct, device="cuda")
     torch.cuda.synchronize()
@@ -399,7 +403,8 @@ def main():
         "numerics": args.numerics,
         "launch": "eager" if args.no_graph else "hipGraph (%d launches, %d builds, %d node updates in the run)" % graph_stats,
         "rccl_ranks": world if distributed and backend == "nccl" else (0 if not distributed else None),
-        "config": {"workload": "%s %dx%d, %s, analytic scene + 1rpp noise, moving camera" % (name, W, H, "default settings" if overrides is None else "settings %s" % overrides),
+        "config": {"workload": "%s %dx%d, %s, analytic scene%s + 1rpp noise, moving camera" % (name, W, H, "default settings" if overrides is None else "settings %s" % overrides,
+                                                                                                 " with a backdrop dome (no sky pixels)" if args.no_sky else ""),
                    "parallelism": "1 GPU" if world == 1 else ("row strips x%d, halo exchange between pass segments (RCCL send/recv to the 2 neighbours, %.1f MB received per rank per frame)"
                                                                % (world, shard.exchanged_bytes / max(total, 1) / 1e6) if args.sharding == "halo" else "row strips x%d + RCCL all-gather" % world),
                    "strips": (list(shard.bounds) if shard is not None and getattr(shard, "bounds", None) else None),  # halo scheme: rows owned by each rank (re-cut from the tile map)

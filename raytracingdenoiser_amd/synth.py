@@ -13,6 +13,8 @@ import math
 
 import torch
 
+BACKDROP = False        # set by bench.py --no-sky: primary rays that miss the scene hit a dome of BACKDROP_RADIUS instead of the sky
+BACKDROP_RADIUS = 150.0
 SKY_VIEWZ = 1.0e6  # > CommonSettings::denoisingRange (5e5): exercises the tile early-outs
 HIT_DIST_PARAMS = (3.0, 0.1, 20.0, -25.0)
 FP16_MAX = 65504.0
@@ -194,6 +196,15 @@ def render_frame(width, height, frame, device="cpu", static_camera=False, noise=
     o = torch.tensor(cam.pos, device=dev, dtype=torch.float32).expand_as(d)
 
     t, n, alb, rough = _trace(o, d, dev)
+    if BACKDROP:  # a large dome behind the scene: no sky pixels at all (every pixel of the frame is denoised; bench.py --no-sky)
+        A, B, C = _dot(d, d), 2.0 * _dot(d, o), _dot(o, o) - BACKDROP_RADIUS * BACKDROP_RADIUS
+        td = (-B + torch.sqrt((B * B - 4.0 * A * C).clamp_min(0.0))) / (2.0 * A)
+        miss = torch.isinf(t)
+        pd = o + d * td.unsqueeze(-1)
+        t = torch.where(miss, td, t)
+        n = torch.where(miss.unsqueeze(-1), -pd / BACKDROP_RADIUS, n)
+        alb = torch.where(miss.unsqueeze(-1), torch.tensor([0.5, 0.5, 0.55], device=dev).expand_as(alb), alb)
+        rough = torch.where(miss, torch.full_like(rough, 0.7), rough)
     is_sky = torch.isinf(t)
     view_z = torch.where(is_sky, torch.full_like(t, SKY_VIEWZ), t)
     n = torch.where(is_sky.unsqueeze(-1), torch.tensor([0.0, 0.0, -1.0], device=dev).expand_as(n), _normalize(n))
