@@ -206,7 +206,7 @@ NRD_D typename ReblurSignal<KIND>::type HistoryFixSignal(const ReblurCB& c, cons
 }
 
 template <bool DIFF, bool SPEC, bool PERF, int KIND, bool SH>
-__global__ __launch_bounds__(TILE_X* TILE_Y, NRD_WAVES_REBLUR_HF) void ReblurHistoryFixKernel(ReblurCB c, HfPlanes P, RowRange rr) {
+__global__ __launch_bounds__(TILE_X* TILE_Y, SH ? 0 : NRD_WAVES_REBLUR_HF) void ReblurHistoryFixKernel(ReblurCB c, HfPlanes P, RowRange rr) {
     typedef ReblurSignal<KIND> Sig;
     constexpr bool OCC = KIND == SIGNAL_OCCLUSION;
     typedef typename Sig::type S;
