@@ -725,7 +725,7 @@ static uint32_t LaunchAsGraph(NrdHipExecutor* e, std::vector<LaunchRecord>& reco
         return p;
     };
     if (!hit) {
-        if (e->graphs.size() >= 8) { // evict the least recently used topology
+        if (e->graphs.size() >= 32) { // evict the least recently used topology (a sharded frame is launched as up to ~10 dispatch ranges, each its own topology)
             size_t lru = 0;
             for (size_t i = 1; i < e->graphs.size(); i++)
                 if (e->graphs[i].lastUse < e->graphs[lru].lastUse)
