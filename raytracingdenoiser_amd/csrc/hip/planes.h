@@ -71,12 +71,15 @@ NRD_D float HalfBitsToFloat(uint16_t h) { return __half2float(__ushort_as_half(h
 // The conversion is an opaque instruction on purpose: left to the compiler, "fp32 multiply -> convert" is fused into
 // v_fma_mixlo_f16, which rounds the exact product ONCE (to fp16) instead of twice (fp32, then fp16). That is a different
 // result whenever the fp32 product lands on an fp16 tie, and the numerics contract pins the two-step rounding.
+#ifndef NRD_OPAQUE_CVT_F16 // (the CPU emulation of these sources under tests/emu substitutes the one instruction it cannot assemble)
+#define NRD_OPAQUE_CVT_F16(h, f) asm("v_cvt_f16_f32 %0, %1" : "=v"(h) : "v"(f))
+#endif
 NRD_D uint16_t FloatToHalfBits(float f) {
 #ifdef NRD_FAST
     return __half_as_ushort(__float2half_rn(f)); // the compiler may fuse the producing multiply (v_fma_mixlo_f16) and pack pairs (v_cvt_pk_f16_f32)
 #endif
     uint32_t h;
-    asm("v_cvt_f16_f32 %0, %1" : "=v"(h) : "v"(f));
+    NRD_OPAQUE_CVT_F16(h, f);
     return (uint16_t)h;
 }
 

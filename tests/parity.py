@@ -354,7 +354,7 @@ def embed_in_resource(frame, resource):
 
 
 def run_parity(name, width=192, height=128, frames=4, verbose=False, settings_overrides=None, static_camera=False, check_pools=True, cs_kw=None, extra_want=(), pad=0, resource=None,
-               rect_sizes=None, numerics="exact", ieee=False, stats=None, static_after=None, graph=False, device="cpu"):
+               rect_sizes=None, numerics="exact", ieee=False, stats=None, static_after=None, graph=False, device="cpu", backend="hip"):
     """Returns the worst relative error between the HIP path and the oracle over all frames, user outputs and pool planes.
     numerics = "exact": the bit-exact regression build against the oracle that emulates the device's sqrt / rsqrt (expected error: 0);
     numerics = "fast" (the product build) is compared with ieee = True, the oracle in plain IEEE arithmetic, and judged through `stats`
@@ -366,12 +366,13 @@ def run_parity(name, width=192, height=128, frames=4, verbose=False, settings_ov
     prev_ieee = oracle_driver.set_ieee_mode(ieee)
     try:
         return _run_parity(name, width, height, frames, verbose, settings_overrides, static_camera, check_pools, cs_kw, extra_want, pad, resource, rect_sizes, numerics, stats, static_after,
-                           graph, device)
+                           graph, device, backend)
     finally:
         oracle_driver.set_ieee_mode(prev_ieee)
 
 
-def _run_parity(name, width, height, frames, verbose, settings_overrides, static_camera, check_pools, cs_kw, extra_want, pad, resource, rect_sizes, numerics, stats, static_after, graph, device):
+def _run_parity(name, width, height, frames, verbose, settings_overrides, static_camera, check_pools, cs_kw, extra_want, pad, resource, rect_sizes, numerics, stats, static_after, graph, device,
+                backend="hip"):
     if rect_sizes:
         seq = [synth.render_frame(*rect_sizes[f % len(rect_sizes)], f, static_camera=static_camera, want=tuple(DENOISERS[name][1]) + tuple(extra_want)) for f in range(frames)]
     elif static_after is not None:
@@ -385,7 +386,11 @@ def _run_parity(name, width, height, frames, verbose, settings_overrides, static
         cs_kw.update(resourceSize=resource, resourceSizePrev=resource)
     rw, rh = resource or (width, height)
     validation = bool(cs_kw.get("enableValidation"))  # the debug overlay (OUT_VALIDATION, RGBA8) is bound and compared like any other output
-    ora, hip = OracleRun(name, rw, rh, validation=validation), HipRun(name, rw, rh, pad=pad, numerics=numerics, validation=validation)
+    if backend == "emu":  # the device sources compiled for the CPU (tests/emu): the same comparison on a machine without a GPU
+        from emu.emu_run import EmuRun as DeviceRun
+    else:
+        DeviceRun = HipRun
+    ora, hip = OracleRun(name, rw, rh, validation=validation), DeviceRun(name, rw, rh, pad=pad, numerics=numerics, validation=validation)
     if graph:
         hip.ex.set_graph_mode(True)
     worst = 0.0
