@@ -36,21 +36,21 @@ def load():
             getattr(lib, name).argtypes, getattr(lib, name).restype = [C.c_float], C.c_float
         lib.oracle_pow.argtypes, lib.oracle_pow.restype = [C.c_float, C.c_float], C.c_float
         lib.oracle_eval_hw.argtypes, lib.oracle_eval_hw.restype = [C.c_int, C.c_void_p, C.c_void_p, C.c_int], None
-        # sqrt / rsqrt follow gfx950's v_sqrt_f32 / v_rsq_f32: per-mantissa deviation (in ulps) from the correctly rounded result, measured on the
-        # device by tools/hw_transcendentals.py and committed next to the oracle
+        # rcp / sqrt / rsqrt / exp2 / log2 follow gfx950's instructions: per-mantissa deviation (in ulps) from the reference results of oracle/hw_ref.h,
+        # measured on the device by tools/hw_tables.hip and committed next to the oracle (oracle/hw_math.h)
         import zlib
 
         global _hw_tables
         _hw_tables = []
-        for name in ("hw_sqrt.i8.z", "hw_rsq.i8.z"):
-            path = os.path.join(_DIR, name)
+        for name, size in (("hw_rcp", 1 << 23), ("hw_sqrt", 1 << 24), ("hw_rsq", 1 << 24), ("hw_exp2", (1 << 23) + 1), ("hw_log2", 1 << 23)):
+            path = os.path.join(_DIR, name + ".i8.z")
             if not os.path.exists(path):
-                raise RuntimeError("oracle: %s is missing (python tools/hw_transcendentals.py on the GPU writes it)" % path)
+                raise RuntimeError("oracle: %s is missing (tools/hw_tables.hip on the GPU writes it)" % path)
             table = np.frombuffer(zlib.decompress(open(path, "rb").read()), dtype=np.int8)
-            assert table.size == 1 << 24 and int(np.abs(table).max()) <= 1, name
+            assert table.size == size and int(np.abs(table).max()) <= 1, name
             _hw_tables.append(np.ascontiguousarray(table))
-        lib.oracle_set_hw_tables.argtypes, lib.oracle_set_hw_tables.restype = [C.c_void_p, C.c_void_p], None
-        lib.oracle_set_hw_tables(_hw_tables[0].ctypes.data, _hw_tables[1].ctypes.data)
+        lib.oracle_set_hw_tables.argtypes, lib.oracle_set_hw_tables.restype = [C.c_void_p] * 5, None
+        lib.oracle_set_hw_tables(*[t.ctypes.data for t in _hw_tables])
         lib.oracle_set_ieee_mode.argtypes, lib.oracle_set_ieee_mode.restype = [C.c_int], C.c_int
         if os.environ.get("ORACLE_EXACT_SQRT", "0") not in ("", "0"):
             lib.oracle_set_ieee_mode(1)
@@ -59,8 +59,8 @@ def load():
 
 
 def set_ieee_mode(on):
-    """True: sqrt / rsqrt are the correctly rounded IEEE results (the oracle knows nothing about the device); False: they emulate gfx950's v_sqrt_f32 /
-    v_rsq_f32 from the measured tables (bit-exact regression against the exact build). Returns the previous setting."""
+    """True: rcp / sqrt / rsqrt / exp2 / log2 are the reference results of oracle/hw_ref.h (the oracle knows nothing about the device); False: they
+    emulate gfx950's instructions from the measured tables (bit-exact comparison with the GPU). Returns the previous setting."""
     return bool(load().oracle_set_ieee_mode(1 if on else 0))
 
 

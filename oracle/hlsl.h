@@ -1,17 +1,24 @@
 // ORACLE -- TEST INFRASTRUCTURE, NOT PRODUCT CODE. Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline
 // leg may load anything under oracle/. The shipped library (raytracingdenoiser_amd/lib/libNRD_hip.so) never does.
 //
-// HLSL-flavoured scalar/vector vocabulary for the CPU restatement of the NRD shader arithmetic, plus the
-// bit-reproducible transcendentals of the numerics contract (DESIGN.md "Numerics"): only + - * /, floor, comparisons and
-// integer bit operations are used, and this directory is compiled with -ffp-contract=off, so every value is determined by
-// IEEE-754 alone -- except sqrt and 1/sqrt, which follow gfx950's v_sqrt_f32 / v_rsq_f32 (within 1 ulp of the correctly
-// rounded result) through per-mantissa delta tables measured on the device (HwSqrt / HwRsq below). Written independently of the HIP device header; the two must agree
-// bit-for-bit, which is what the parity tests check.
+// HLSL-flavoured scalar / vector vocabulary for the CPU restatement of the NRD shader arithmetic, under the numerics contract of the product
+// (DESIGN.md "Numerics"), which is what makes a bit-for-bit comparison with the GPU possible:
+//   * + - * and fused multiply-add are IEEE-754 binary32. This directory is compiled by clang with -ffp-contract=on -mfma: `a * b + c` written as
+//     ONE expression is a single fma (ISO C "FP_CONTRACT ON"), nothing else is fused -- the same front end makes the same decisions for the
+//     device sources. The expressions here are therefore written in the order and the shape of the HLSL they restate.
+//   * rcp / division / sqrt / rsqrt / exp2 / log2 follow gfx950's v_rcp_f32 / v_sqrt_f32 / v_rsq_f32 / v_exp_f32 / v_log_f32 (each within 1 ulp of the
+//     correctly rounded result) through per-mantissa deviation tables measured on the device: oracle/hw_math.h. `a / b` of a shader is
+//     Div(a, b) = a * rcp(b) here and on the device. IEEE mode (oracle_set_ieee_mode) replaces the five instructions by their reference
+//     results: "the HLSL math on an IEEE machine", the oracle without any knowledge of the device.
+//   * UNORM texel decoding (tex.h) is the exact quotient k / (2^n - 1) on both sides.
+// Written independently of the HIP device header; the two must agree bit for bit, which is what the parity tests check.
 //
 // PARITY UNPINNED: the reference ships no CPU implementation, no tests and no golden vectors, and its math library
 // (NVIDIA-RTX/MathLib, fetched unpinned at configure time -- reference CMakeLists.txt:118-127) is absent. Definitions
 // marked [ml] restate MathLib from its public behaviour and from anchors inside the reference.
 #pragma once
+
+#include "hw_math.h"
 
 #include <cmath>
 #include <cstdint>
@@ -39,70 +46,24 @@ inline int clamp(int x, int a, int b) { return min(max(x, a), b); }
 inline float saturate(float x) { return min(max(x, 0.0f), 1.0f); }
 inline float lerp(float a, float b, float t) { return a + (b - a) * t; }
 inline float step(float edge, float x) { return x >= edge ? 1.0f : 0.0f; }
-inline float rcp(float x) { return 1.0f / x; }
-
-// gfx950's v_sqrt_f32 and v_rsq_f32, bit for bit: result = (the float64 result rounded once) + delta ulps, delta in {-1, 0, +1} from
-// oracle/hw_sqrt.i8.z / hw_rsq.i8.z (tools/hw_transcendentals.py: every mantissa for both exponent parities; scaling by 4^k is exact).
-// Denormal inputs are flushed to (signed) zero, negative inputs give NaN, as the instructions do. The tables are handed over by
-// oracle/driver.py (oracle_set_hw_tables); without them the functions abort: there is no silent fallback to the exact result.
-// IEEE mode (oracle_set_ieee_mode / ORACLE_EXACT_SQRT=1): sqrt and 1/sqrt are the correctly rounded results instead (denormals kept), i.e. the oracle
-// is then "the HLSL math in IEEE-754 arithmetic" with no knowledge of the device -- the mode the tolerance tests of the fast product build compare with.
-extern const signed char* g_HwSqrtDelta; // 2^24 entries: [exponent parity << 23 | mantissa]
-extern const signed char* g_HwRsqDelta;
-extern int g_IeeeMode;
-[[noreturn]] void HwTablesMissing();
-inline float HwSqrt(float x) {
-    if (g_IeeeMode)
-        return (float)sqrt((double)x); // correctly rounded (53 >= 2 * 24 + 2 bits)
-    const uint32_t u = asuint(x), mag = u & 0x7fffffffu;
-    if (mag > 0x7f800000u)
-        return asfloat(0x7fc00000u); // NaN
-    if (mag < 0x00800000u)
-        return asfloat(u & 0x80000000u); // +-0 and flushed denormals -> +-0
-    if (u & 0x80000000u)
-        return asfloat(0x7fc00000u); // negative -> NaN
-    if (mag == 0x7f800000u)
-        return x; // +inf
-    if (!g_HwSqrtDelta)
-        HwTablesMissing();
-    const uint32_t parity = ((u >> 23) + 1u) & 1u; // unbiased exponent parity: biased 127 (x in [1, 2)) -> 0
-    const float exact = (float)sqrt((double)x);
-    return asfloat(asuint(exact) + (uint32_t)(int32_t)g_HwSqrtDelta[(parity << 23) | (u & 0x7fffffu)]);
-}
-inline float HwRsq(float x) {
-    if (g_IeeeMode)
-        return (float)(1.0 / sqrt((double)x));
-    const uint32_t u = asuint(x), mag = u & 0x7fffffffu;
-    if (mag > 0x7f800000u)
-        return asfloat(0x7fc00000u);
-    if (mag < 0x00800000u)
-        return asfloat((u & 0x80000000u) | 0x7f800000u); // +-0 and flushed denormals -> +-inf
-    if (u & 0x80000000u)
-        return asfloat(0x7fc00000u);
-    if (mag == 0x7f800000u)
-        return 0.0f;
-    if (!g_HwRsqDelta)
-        HwTablesMissing();
-    const uint32_t parity = ((u >> 23) + 1u) & 1u;
-    const float exact = (float)(1.0 / sqrt((double)x));
-    return asfloat(asuint(exact) + (uint32_t)(int32_t)g_HwRsqDelta[(parity << 23) | (u & 0x7fffffu)]);
-}
+// the transcendental instructions of the device (oracle/hw_math.h)
+inline float HwSqrt(float x) { return hwmath::HwSqrt(x); }
+inline float HwRsq(float x) { return hwmath::HwRsq(x); }
+inline float Rcp(float x) { return hwmath::HwRcp(x); }
+inline float rcp(float x) { return hwmath::HwRcp(x); }
+inline float Div(float a, float b) { return a * Rcp(b); } // the shaders' a / b
 inline float rsqrt(float x) { return HwRsq(x); }
 inline float frac(float x) { return x - floorf(x); }
 
-// 2^x: nearest-integer split, degree-7 Taylor of 2^f on [-0.5, 0.5], Horner
+// 2^x = v_exp_f32(1 + frac(x)) * 2^(floor(x) - 1), the instruction seeing [1, 2] only (oracle/hw_math.h)
 inline float exp2(float x) {
     x = clamp(x, -125.0f, 125.0f);
-    float fi = floorf(x + 0.5f);
-    float f = x - fi;
-    static const float c[8] = {1.0f, 6.9314718056e-1f, 2.4022650696e-1f, 5.5504108665e-2f, 9.6181291076e-3f, 1.3333558146e-3f, 1.5403530393e-4f, 1.5252733805e-5f};
-    float p = c[7];
-    for (int i = 6; i >= 0; i--)
-        p = p * f + c[i];
-    return p * asfloat((uint32_t)((int)fi + 127) << 23);
+    const float fl = floorf(x);
+    const float t = 1.0f + (x - fl);
+    return ldexpf(hwmath::HwExp2OnOneTwo(t), (int)fl - 1);
 }
 
-// log2(x) for x > 0 (else -126): m in [sqrt(1/2), sqrt(2)), 2 * atanh(s) / ln2 with s = (m - 1) / (m + 1)
+// log2(x) = e + v_log_f32(m), x = m * 2^e, m in [1, 2); x <= 0 and NaN return -126
 inline float log2(float x) {
     if (!(x > 0.0f))
         return -126.0f;
@@ -112,19 +73,8 @@ inline float log2(float x) {
         bits = asuint(x * 8388608.0f);
         e = (int)(bits >> 23) - 127 - 23;
     }
-    float m = asfloat((bits & 0x007FFFFFu) | 0x3F800000u);
-    if (m > 1.41421356f) {
-        m = m * 0.5f;
-        e += 1;
-    }
-    float s = (m - 1.0f) / (m + 1.0f);
-    float s2 = s * s;
-    float p = 0.22222222f;
-    p = p * s2 + 0.28571429f;
-    p = p * s2 + 0.4f;
-    p = p * s2 + 0.66666667f;
-    p = p * s2 + 2.0f;
-    return float(e) + (p * s) * 1.44269504f;
+    const float m = asfloat((bits & 0x007FFFFFu) | 0x3F800000u);
+    return float(e) + hwmath::HwLog2OnMantissa(m);
 }
 
 inline float exp(float x) { return exp2(x * 1.44269504f); }
@@ -137,10 +87,10 @@ inline float atan(float x) {
     float base = 0.0f, t = a;
     if (a > 2.41421356f) {
         base = 1.57079633f;
-        t = -1.0f / a;
+        t = -Rcp(a);
     } else if (a > 0.41421356f) {
         base = 0.78539816f;
-        t = (a - 1.0f) / (a + 1.0f);
+        t = Div(a - 1.0f, a + 1.0f);
     }
     float z = t * t;
     float p = 8.05374449538e-2f;
@@ -201,6 +151,21 @@ struct uint4 {
 ORC_OP2(+) ORC_OP2(-) ORC_OP2(*) ORC_OP2(/)
 ORC_OP3(+) ORC_OP3(-) ORC_OP3(*) ORC_OP3(/)
 ORC_OP4(+) ORC_OP4(-) ORC_OP4(*) ORC_OP4(/)
+// operator/ above is the IEEE division of the front-end helpers (application side, as include/NRD.hip.h); the passes divide with Div
+inline float2 Div(float2 a, float2 b) { return float2(Div(a.x, b.x), Div(a.y, b.y)); }
+inline float2 Div(float2 a, float b) {
+    float r = Rcp(b);
+    return float2(a.x * r, a.y * r);
+}
+inline float3 Div(float3 a, float b) {
+    float r = Rcp(b);
+    return float3(a.x * r, a.y * r, a.z * r);
+}
+inline float4 Div(float4 a, float b) {
+    float r = Rcp(b);
+    return float4(a.x * r, a.y * r, a.z * r, a.w * r);
+}
+inline float4 Div(float4 a, float4 b) { return float4(Div(a.x, b.x), Div(a.y, b.y), Div(a.z, b.z), Div(a.w, b.w)); }
 inline float3 operator-(float3 a) { return float3(-a.x, -a.y, -a.z); }
 inline float2 operator-(float2 a) { return float2(-a.x, -a.y); }
 inline float2& operator+=(float2& a, float2 b) { return a = a + b; }

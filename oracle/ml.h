@@ -24,7 +24,7 @@ constexpr float NRD_CURVATURE_Z_THRESHOLD = 0.1f;            // [com] Common.hls
 
 // ================================================================================================ [ml] Math
 namespace Math {
-inline float LinearStep(float a, float b, float x) { return saturate((x - a) / (b - a)); }
+inline float LinearStep(float a, float b, float x) { return saturate(Div(x - a, b - a)); }
 inline float SmoothStep01(float x) {
     x = saturate(x);
     return x * x * (3.0f - 2.0f * x);
@@ -33,7 +33,7 @@ inline float SmoothStep(float a, float b, float x) { return SmoothStep01(LinearS
 inline float4 SmoothStep(float a, float b, float4 x) { return float4(SmoothStep(a, b, x.x), SmoothStep(a, b, x.y), SmoothStep(a, b, x.z), SmoothStep(a, b, x.w)); }
 inline float Sqrt01(float x) { return HwSqrt(saturate(x)); }
 inline float Pow01(float x, float y) { return pow(saturate(x), y); }
-inline float PositiveRcp(float x) { return 1.0f / max(x, 1e-15f); }
+inline float PositiveRcp(float x) { return Rcp(max(x, 1e-15f)); }
 inline float AcosApprox(float x) { return 1.41421356f * HwSqrt(saturate(1.0f - x)); }
 inline float LengthSquared(float3 v) { return dot(v, v); }
 inline float LengthSquared(float2 v) { return dot(v, v); }
@@ -61,7 +61,7 @@ inline float4 ProjectiveTransform(const float4x4& M, float3 p) {
 }
 inline float2 GetScreenUv(const float4x4& worldToClip, float3 X) {
     float4 clip = ProjectiveTransform(worldToClip, X);
-    float2 uv = float2((clip.x / clip.w) * 0.5f + 0.5f, (clip.y / clip.w) * -0.5f + 0.5f);
+    float2 uv = float2((Div(clip.x, clip.w)) * 0.5f + 0.5f, (Div(clip.y, clip.w)) * -0.5f + 0.5f);
     return clip.w < 0.0f ? float2(99999.0f) : uv;
 }
 inline float3 ReconstructViewPosition(float2 uv, float4 frustum, float viewZ = 1.0f, float orthoMode = 0.0f) {
@@ -72,7 +72,7 @@ inline float2 RotateVector(float4 rotator, float2 v) { return float2(v.x * rotat
 inline float4 ScaleRotator(float4 r, float2 s) { return float4(r.x * s.x, r.y * s.x, r.z * s.y, r.w * s.y); }
 inline void GetBasis(float3 N, float3& T, float3& B) {
     float sz = N.z >= 0.0f ? 1.0f : -1.0f;
-    float a = 1.0f / (sz + N.z);
+    float a = Rcp(sz + N.z);
     float ya = N.y * a;
     float b = N.x * ya;
     float c = N.x * sz;
@@ -99,8 +99,8 @@ inline float3 EnvironmentTerm_Rtg(float3 Rf0, float NoV, float roughness) {
     float biasDen = (1.0f + 2.92338f * x1 + 59.4188f * x3) + (20.3225f + -27.0302f * x1 + 222.592f * x3) * y1 + (121.563f + 626.13f * x1 + 316.627f * x3) * y3;
     float scaleNum = (0.0365463f + 3.32707f * x1) + (9.0632f + -9.04756f * x1) * y1;
     float scaleDen = (1.0f + 3.59685f * x2 + -1.36772f * x3) + (9.04401f + -16.3174f * x2 + 9.22949f * x3) * y1 + (5.56589f + 19.7886f * x2 + -20.2123f * x3) * y3;
-    float bias = biasNum * (1.0f / fmaxf(biasDen, 1e-6f));
-    float scale = scaleNum * (1.0f / fmaxf(scaleDen, 1e-6f));
+    float bias = biasNum * (Rcp(fmaxf(biasDen, 1e-6f)));
+    float scale = scaleNum * (Rcp(fmaxf(scaleDen, 1e-6f)));
     (void)y2;
     auto sat = [](float v) { return fminf(fmaxf(v, 0.0f), 1.0f); };
     return float3(sat(Rf0.x * scale + bias), sat(Rf0.y * scale + bias), sat(Rf0.z * scale + bias));
@@ -127,7 +127,7 @@ inline uint32_t Bayer4x4ui(uint32_t x, uint32_t y, uint32_t frameIndex) {
     uint32_t b = (y + ((x & 1u) << 2)) << 2;
     return ((a >> b) + frameIndex) & 0xFu;
 }
-inline float Bayer4x4(uint32_t x, uint32_t y, uint32_t frameIndex) { return (float(Bayer4x4ui(x, y, frameIndex)) + 0.5f) / 16.0f; }
+inline float Bayer4x4(uint32_t x, uint32_t y, uint32_t frameIndex) { return (float(Bayer4x4ui(x, y, frameIndex)) + 0.5f) * 0.0625f; }
 } // namespace Sequence
 
 // Our own hash RNG (MathLib's Rng::Hash is unavailable): seeded per (pixel, frame), PCG output function
@@ -183,7 +183,7 @@ inline float ApplyBilinearFilter(float s00, float s10, float s01, float s11, Bil
 inline float ApplyBilinearCustomWeights(float s00, float s10, float s01, float s11, float4 w) {
     float sumw = w.x + w.y + w.z + w.w;
     float r = s00 * w.x + s10 * w.y + s01 * w.z + s11 * w.w;
-    return sumw < 0.0001f ? 0.0f : r / sumw;
+    return sumw < 0.0001f ? 0.0f : Div(r, sumw);
 }
 // top-left texel of the 4x4 Catmull-Rom footprint; [com] REBLUR_TemporalAccumulation.hlsli:152-171 fixes the convention
 inline float2 GetCatmullRomOrigin(float2 uv, float2 texSize) {
@@ -192,7 +192,7 @@ inline float2 GetCatmullRomOrigin(float2 uv, float2 texSize) {
 }
 inline float GetModifiedRoughnessFromNormalVariance(float linearRoughness, float3 nonNormalizedAverageNormal) {
     float l = length(nonNormalizedAverageNormal);
-    float kappa = saturate(1.0f - l * l) / max(l * (3.0f - l * l), 1e-15f);
+    float kappa = Div(saturate(1.0f - l * l), max(l * (3.0f - l * l), 1e-15f));
     return HwSqrt(saturate(linearRoughness * linearRoughness + kappa));
 }
 } // namespace Filtering
@@ -203,7 +203,7 @@ inline float GetSpecularLobeTanHalfAngle(float linearRoughness, float percentOfV
     float r = saturate(linearRoughness);
     float p = saturate(percentOfVolume);
     float m = r * r;
-    return m * HwSqrt(p / (1.0f - p + NRD_EPS));
+    return m * HwSqrt(Div(p, 1.0f - p + NRD_EPS));
 }
 inline float GetSpecularDominantFactor(float NoV, float linearRoughness) { // [nrd] NRD.hlsli:386-392
     float a = 0.298475f * log(39.4115f - 39.0029f * linearRoughness);
@@ -238,7 +238,7 @@ inline float3 _NRD_DecodeUnitVector(float2 p) {                                 
     return n;
 }
 inline float2 _NRD_EncodeUnitVector(float3 v) { // NRD.hlsli:322-330 (unsigned)
-    v /= fabsf(v.x) + fabsf(v.y) + fabsf(v.z);
+    v /= fabsf(v.x) + fabsf(v.y) + fabsf(v.z); // front end (application side): IEEE division, as include/NRD.hip.h
     float2 octWrap = float2((1.0f - fabsf(v.y)) * (step(0.0f, v.x) * 2.0f - 1.0f), (1.0f - fabsf(v.x)) * (step(0.0f, v.y) * 2.0f - 1.0f));
     float2 r = v.z >= 0.0f ? float2(v.x, v.y) : octWrap;
     return r * 0.5f + 0.5f;
@@ -288,7 +288,7 @@ inline float PixelRadiusToWorld(float unproject, float orthoMode, float pixelRad
     return pixelRadius * unproject * lerp(viewZ, 1.0f, fabsf(orthoMode));
 }
 inline float GetFrustumSize(float minRectDimMulUnproject, float orthoMode, float viewZ) { return minRectDimMulUnproject * lerp(viewZ, 1.0f, fabsf(orthoMode)); } // :242-248
-inline float GetHitDistFactor(float hitDist, float frustumSize) { return saturate(hitDist / frustumSize); }                                                // :250-253
+inline float GetHitDistFactor(float hitDist, float frustumSize) { return saturate(Div(hitDist, frustumSize)); }                                                // :250-253
 inline float IsInScreenNearest(float2 uv) { return (uv.x > 0.0f && uv.y > 0.0f && uv.x < 1.0f && uv.y < 1.0f) ? 1.0f : 0.0f; }                          // :281-284
 inline float4 IsInScreenBilinear(float2 footprintOrigin, float2 rectSize) {                                                                              // :288-296
     float4 p = float4(footprintOrigin.x, footprintOrigin.y, footprintOrigin.x + 1.0f, footprintOrigin.y + 1.0f);
@@ -306,7 +306,7 @@ inline float ComputeParallaxInPixels(float3 X, float2 uvForZeroParallax, const f
     float2 parallaxInUv = uv - uvForZeroParallax;
     return length(parallaxInUv * rectSize);
 }
-inline float ApplyThinLensEquation(float O, float curvature) { return O / (2.0f * curvature * O + 1.0f); } // :404-409
+inline float ApplyThinLensEquation(float O, float curvature) { return Div(O, 2.0f * curvature * O + 1.0f); } // :404-409
 
 // Virtual (reflected) position, NRD_USE_SPECULAR_MOTION_V2 = 1 branch; :411-461
 inline float3 GetXvirtual(float hitDist, float curvature, float3 X, float3 Xprev, float3 N, float3 V, float roughness) {
@@ -319,16 +319,16 @@ inline float3 GetXvirtual(float hitDist, float curvature, float3 X, float3 Xprev
     float3 O = float3(dot(T, reflectionRay), dot(B, reflectionRay), dot(N, reflectionRay)); // basis rows * ray
     O.z = -O.z;
 
-    float mag = 1.0f / (2.0f * curvature * O.z - 1.0f);
+    float mag = Rcp(2.0f * curvature * O.z - 1.0f);
     float f = length(X);
     f *= 1.0f - fabsf(dot(N, V));
     f *= max(curvature, 0.0f);
-    mag *= 1.0f / (1.0f + f);
+    mag *= Rcp(1.0f + f);
 
     float3 I = O * mag;
     Iw *= length(I);
 
-    float closenessToSurface = saturate(length(Iw) / (hitDist + NRD_EPS));
+    float closenessToSurface = saturate(Div(length(Iw), hitDist + NRD_EPS));
     float3 origin = lerp(Xprev, X, closenessToSurface * D.w);
     return origin - Iw * D.w;
 }
@@ -339,8 +339,8 @@ inline float2 GetKernelSampleCoordinates(const float4x4& mToClip, float3 offset,
     float3 p = X + T * o.x + B * o.y;
     float4 clip4 = Geometry::ProjectiveTransform(mToClip, p);
     float3 clip = float3(clip4.x, clip4.y, clip4.w);
-    clip.x /= clip.z;
-    clip.y /= clip.z;
+    clip.x = Div(clip.x, clip.z);
+    clip.y = Div(clip.y, clip.z);
     clip.y = -clip.y;
     return float2(clip.x * 0.5f + 0.5f, clip.y * 0.5f + 0.5f);
 }
@@ -349,28 +349,28 @@ inline float GetNormalWeightParam(float nonLinearAccumSpeed, float lobeAngleFrac
     float tanHalfAngle = ImportanceSampling::GetSpecularLobeTanHalfAngle(roughness, percentOfVolume);
     float angle = atan(tanHalfAngle);
     angle = max(angle, NRD_NORMAL_ENCODING_ERROR);
-    return 1.0f / angle;
+    return Rcp(angle);
 }
 inline float2 GetGeometryWeightParams(float planeDistSensitivity, float frustumSize, float3 Xv, float3 Nv) { // :501-508
     float norm = planeDistSensitivity * frustumSize;
-    float a = 1.0f / norm;
+    float a = Rcp(norm);
     float b = dot(Nv, Xv) * a;
     return float2(a, -b);
 }
 inline float2 GetHitDistanceWeightParams(float hitDist, float nonLinearAccumSpeed, float roughness = 1.0f) { // :510-521
     float smc = GetSpecMagicCurve(roughness);
     float norm = lerp(0.0005f, 1.0f, min(nonLinearAccumSpeed, smc));
-    float a = 1.0f / norm;
+    float a = Rcp(norm);
     float b = hitDist * a;
     return float2(a, -b);
 }
 inline float2 GetRoughnessWeightParams(float roughness, float fraction, float sensitivity = NRD_ROUGHNESS_SENSITIVITY) { // :523-529
-    float a = 1.0f / lerp(sensitivity, 1.0f, saturate(roughness * fraction));
+    float a = Rcp(lerp(sensitivity, 1.0f, saturate(roughness * fraction)));
     float b = roughness * a;
     return float2(a, -b);
 }
 inline float2 GetRelaxedRoughnessWeightParams(float m, float fraction = 1.0f, float sensitivity = NRD_ROUGHNESS_SENSITIVITY) { // :531-540
-    float a = 1.0f / lerp(sensitivity, 1.0f, lerp(m * m, m, fraction));
+    float a = Rcp(lerp(sensitivity, 1.0f, lerp(m * m, m, fraction)));
     float b = m * a;
     return float2(a, -b);
 }
@@ -383,10 +383,10 @@ inline float GetGaussianWeight(float r) { return exp(-0.66f * r * r); }         
 inline float GetEncodingAwareNormalWeight(float3 Ncurr, float3 Nprev, float maxAngle, float curvatureAngle, float thresholdAngle) { // :578-589 (remap = false)
     float cosa = dot(Ncurr, Nprev);
     float angle = Math::AcosApprox(cosa);
-    return Math::SmoothStep01(1.0f - (angle - curvatureAngle - thresholdAngle) / maxAngle);
+    return Math::SmoothStep01(1.0f - Div(angle - curvatureAngle - thresholdAngle, maxAngle));
 }
 inline float GetDisocclusionThreshold(float disocclusionThreshold, float frustumSize, float NoV) { // :593-596
-    return frustumSize * saturate(disocclusionThreshold / max(0.01f, NoV));
+    return frustumSize * saturate(Div(disocclusionThreshold, max(0.01f, NoV)));
 }
 
 } // namespace orc

@@ -12,15 +12,18 @@
 
 using namespace orc;
 
-namespace orc {
-const signed char* g_HwSqrtDelta = nullptr;
-const signed char* g_HwRsqDelta = nullptr;
+namespace hwmath {
+const signed char* g_RcpDelta = nullptr;
+const signed char* g_SqrtDelta = nullptr;
+const signed char* g_RsqDelta = nullptr;
+const signed char* g_Exp2Delta = nullptr;
+const signed char* g_Log2Delta = nullptr;
 int g_IeeeMode = 0;
-void HwTablesMissing() {
-    fprintf(stderr, "oracle: the hardware sqrt / rsq delta tables are not loaded (oracle/hw_sqrt.i8.z, hw_rsq.i8.z through oracle/driver.py)\n");
+void TablesMissing(const char* which) {
+    fprintf(stderr, "oracle: hardware deviation table missing or argument out of its range: %s (oracle/hw_*.i8.z through oracle/driver.py)\n", which);
     abort();
 }
-} // namespace orc
+} // namespace hwmath
 
 extern "C" {
 
@@ -53,20 +56,24 @@ __attribute__((visibility("default"))) int oracle_dispatch(const char* shaderFil
     return 1;
 }
 
-// delta tables of the hardware sqrt / rsq emulation (oracle/hlsl.h); the memory stays owned by the caller (oracle/driver.py keeps it alive)
-__attribute__((visibility("default"))) void oracle_set_hw_tables(const signed char* sqrtDelta, const signed char* rsqDelta) {
-    orc::g_HwSqrtDelta = sqrtDelta;
-    orc::g_HwRsqDelta = rsqDelta;
+// deviation tables of the five transcendental instructions (oracle/hw_math.h); the memory stays owned by the caller (oracle/driver.py keeps it alive)
+__attribute__((visibility("default"))) void oracle_set_hw_tables(const signed char* rcp, const signed char* sqrt, const signed char* rsq, const signed char* exp2, const signed char* log2) {
+    hwmath::g_RcpDelta = rcp;
+    hwmath::g_SqrtDelta = sqrt;
+    hwmath::g_RsqDelta = rsq;
+    hwmath::g_Exp2Delta = exp2;
+    hwmath::g_Log2Delta = log2;
 }
-// 1 = IEEE mode: correctly rounded sqrt / rsqrt instead of the device emulation (oracle/hlsl.h). Returns the previous mode.
+// 1 = IEEE mode: the reference results instead of the device emulation (oracle/hw_math.h). Returns the previous mode.
 __attribute__((visibility("default"))) int oracle_set_ieee_mode(int on) {
-    const int prev = orc::g_IeeeMode;
-    orc::g_IeeeMode = on ? 1 : 0;
+    const int prev = hwmath::g_IeeeMode;
+    hwmath::g_IeeeMode = on ? 1 : 0;
     return prev;
 }
-__attribute__((visibility("default"))) void oracle_eval_hw(int op, const float* in, float* out, int n) { // 0 = HwSqrt, 1 = HwRsq
+// 0 = v_sqrt_f32, 1 = v_rsq_f32, 2 = v_rcp_f32, 3 = the contract's exp2, 4 = the contract's log2
+__attribute__((visibility("default"))) void oracle_eval_hw(int op, const float* in, float* out, int n) {
     for (int i = 0; i < n; i++)
-        out[i] = op == 0 ? orc::HwSqrt(in[i]) : orc::HwRsq(in[i]);
+        out[i] = op == 0 ? orc::HwSqrt(in[i]) : op == 1 ? orc::HwRsq(in[i]) : op == 2 ? orc::Rcp(in[i]) : op == 3 ? orc::exp2(in[i]) : orc::log2(in[i]);
 }
 
 __attribute__((visibility("default"))) int oracle_set_threads(int n) {

@@ -52,14 +52,14 @@ enum SpatialMode { PRE_BLUR = 0, BLUR = 1, POST_BLUR = 2 };
 
 // ---- storage packing: REBLUR_Common.hlsli:13-80 ; Packing::RgbaToUint / UintToRgba with 6,6,4,0 bits [ml] ---------
 inline uint32_t PackInternalData(float diffAccumSpeed, float specAccumSpeed, float materialID) {
-    float tx = diffAccumSpeed / REBLUR_MAX_ACCUM_FRAME_NUM, ty = specAccumSpeed / REBLUR_MAX_ACCUM_FRAME_NUM, tz = materialID / REBLUR_MAX_MATERIALID_NUM;
+    float tx = Div(diffAccumSpeed, REBLUR_MAX_ACCUM_FRAME_NUM), ty = Div(specAccumSpeed, REBLUR_MAX_ACCUM_FRAME_NUM), tz = Div(materialID, REBLUR_MAX_MATERIALID_NUM);
     uint32_t p = (uint32_t)floorf(saturate(tx) * 63.0f + 0.5f);
     p |= (uint32_t)floorf(saturate(ty) * 63.0f + 0.5f) << 6;
     p |= (uint32_t)floorf(saturate(tz) * 15.0f + 0.5f) << 12;
     return p;
 }
 inline float3 UnpackInternalData(uint32_t p) {
-    float3 t = float3(float(p & 63u) / 63.0f, float((p >> 6) & 63u) / 63.0f, float((p >> 12) & 15u) / 15.0f);
+    float3 t = float3(float(p & 63u) / 63.0f, float((p >> 6) & 63u) / 63.0f, float((p >> 12) & 15u) / 15.0f); // UNORM decode: the exact quotient (tex.h)
     t.x *= REBLUR_MAX_ACCUM_FRAME_NUM;
     t.y *= REBLUR_MAX_ACCUM_FRAME_NUM;
     t.z *= REBLUR_MAX_MATERIALID_NUM;
@@ -67,7 +67,7 @@ inline float3 UnpackInternalData(uint32_t p) {
 }
 // DATA1 is RG8 (diffuse+specular) or R8 (single signal: both channels alias .x)
 inline float2 PackData1(float diffAccumSpeed, float specAccumSpeed, bool hasDiff) {
-    float2 r = float2(saturate(diffAccumSpeed / REBLUR_MAX_ACCUM_FRAME_NUM), saturate(specAccumSpeed / REBLUR_MAX_ACCUM_FRAME_NUM));
+    float2 r = float2(saturate(Div(diffAccumSpeed, REBLUR_MAX_ACCUM_FRAME_NUM)), saturate(Div(specAccumSpeed, REBLUR_MAX_ACCUM_FRAME_NUM)));
     if (!hasDiff)
         r.x = r.y;
     return r;
@@ -86,7 +86,7 @@ inline uint32_t PackData2(float fbits, float curvature, float virtualHistoryAmou
 }
 inline float2 UnpackData2(uint32_t p, uint32_t& bits) {
     bits = p & 0xFFu;
-    return float2(float((p >> 8) & 0xFFu) / 255.0f, f16tof32(p >> 16));
+    return float2(float((p >> 8) & 0xFFu) / 255.0f, f16tof32(p >> 16)); // UNORM decode: the exact quotient
 }
 
 // ---- helpers: REBLUR_Common.hlsli:84-274 --------------------------------------------------------------------------
@@ -99,24 +99,24 @@ inline float3 GetViewVectorPrev(const ReblurCB& c, float3 Xprev, float3 cameraDe
 }
 inline float GetMinAllowedLimitForHitDistNonLinearAccumSpeed(const ReblurCB& c, float roughness) {
     float frameNum = 0.5f * GetSpecMagicCurve(roughness) * c.gMaxAccumulatedFrameNum;
-    return 1.0f / (1.0f + frameNum);
+    return Rcp(1.0f + frameNum);
 }
 inline float GetFadeBasedOnAccumulatedFrames(const ReblurCB& c, float accumSpeed) {
-    float a = c.gHistoryFixFrameNum * 2.0f / 3.0f + 1e-6f;
-    float b = c.gHistoryFixFrameNum * 4.0f / 3.0f + 2e-6f;
+    float a = Div(c.gHistoryFixFrameNum * 2.0f, 3.0f) + 1e-6f;
+    float b = Div(c.gHistoryFixFrameNum * 4.0f, 3.0f) + 2e-6f;
     return Math::LinearStep(a, b, accumSpeed);
 }
 inline float GetNonLinearAccumSpeed(const ReblurCB& c, float accumSpeed, float maxAccumSpeed, float confidence, bool hasData) { // REBLUR_Common.hlsli:111-124
-    float nonLinearAccumSpeed = max(1.0f - confidence, 1.0f / (1.0f + min(accumSpeed, maxAccumSpeed)));
+    float nonLinearAccumSpeed = max(1.0f - confidence, Rcp(1.0f + min(accumSpeed, maxAccumSpeed)));
     if (!hasData)
         nonLinearAccumSpeed *= lerp(1.0f - c.gCheckerboardResolveAccumSpeed, 1.0f, nonLinearAccumSpeed);
     return nonLinearAccumSpeed;
 }
 inline float RemapRoughnessToResponsiveFactor(const ReblurCB& c, float roughness) {
-    float amount = (roughness + NRD_EPS) / (c.gResponsiveAccumulationRoughnessThreshold + NRD_EPS);
+    float amount = Div(roughness + NRD_EPS, c.gResponsiveAccumulationRoughnessThreshold + NRD_EPS);
     return Math::SmoothStep01(amount);
 }
-inline float GetLumaScale(float currLuma, float newLuma) { return (newLuma + NRD_EPS) / (currLuma + NRD_EPS); }
+inline float GetLumaScale(float currLuma, float newLuma) { return Div(newLuma + NRD_EPS, currLuma + NRD_EPS); }
 inline float4 MixHistoryAndCurrent(const ReblurCB& c, float4 history, float4 current, float f, float roughness = 1.0f) {
     float4 r;
     r.x = lerp(history.x, current.x, f);
@@ -195,8 +195,8 @@ inline float ComputeAntilag(const ReblurCB& c, float history, float avg, float s
     float s = sigma * c.gAntilagParams.x;
     float magic = c.gAntilagParams.y * c.gFramerateScale * c.gFramerateScale;
     float hc = Color::Clamp(a, s, h);
-    float d = fabsf(h - hc) / (max(h, hc) + NRD_EPS);
-    return 1.0f / (1.0f + d * accumSpeed / magic);
+    float d = Div(fabsf(h - hc), max(h, hc) + NRD_EPS);
+    return Rcp(1.0f + Div(d * accumSpeed, magic));
 }
 inline void GetKernelBasis(float3 D, float3 N, float3& T, float3& B) {
     Geometry::GetBasis(N, T, B);
@@ -209,7 +209,7 @@ inline void GetKernelBasis(float3 D, float3 N, float3& T, float3& B) {
 inline float2 GetTemporalAccumulationParams(const ReblurCB& c, float isInScreenMulFootprintQuality, float accumSpeed) {
     accumSpeed *= REBLUR_SAMPLES_PER_FRAME;
     float w = isInScreenMulFootprintQuality;
-    w *= accumSpeed / (1.0f + accumSpeed);
+    w *= Div(accumSpeed, 1.0f + accumSpeed);
     return float2(w, 1.0f + 3.0f * c.gFramerateScale * w);
 }
 inline bool CompareMaterials(float m0, float m, float minm) { return max(m0, minm) == max(m, minm); } // Common.hlsli:226-230
@@ -248,7 +248,7 @@ inline HistoryFilter MakeHistoryFilter(float2 samplePos, float4 bilinearCustomWe
     h.w = useBicubic ? w : bilinearCustomWeights;
     h.w4 = useBicubic ? w4 : 0.0f;
     h.sum = sum(h.w) + h.w4;
-    h.tc = w2 / w12;
+    h.tc = Div(w2, w12);
     h.kx = (int)origin.x;
     h.ky = (int)origin.y;
     h.ox = (int)centerPos.x; // int3( centerPos, 0 ): truncation of k + 0.5
@@ -278,7 +278,7 @@ inline float4 FetchHistoryColor(const HistoryFilter& h, const Tex& tex) {
         color += T(0, 1) * h.w.z;
         color += T(1, 1) * h.w.w;
     }
-    return h.sum < 0.0001f ? float4(0.0f) : color / h.sum;
+    return h.sum < 0.0001f ? float4(0.0f) : Div(color, h.sum);
 }
 inline float4 FetchHistoryBilinear(const HistoryFilter& h, const Tex& tex) {
     float4 color = tex.Load(h.ox, h.oy) * h.bw.x;
@@ -286,7 +286,7 @@ inline float4 FetchHistoryBilinear(const HistoryFilter& h, const Tex& tex) {
     color += tex.Load(h.ox, h.oy + 1) * h.bw.z;
     color += tex.Load(h.ox + 1, h.oy + 1) * h.bw.w;
     float s = sum(h.bw);
-    return s < 0.0001f ? float4(0.0f) : color / s;
+    return s < 0.0001f ? float4(0.0f) : Div(color, s);
 }
 
 } // namespace orc

@@ -105,7 +105,7 @@ S DiffuseSpatialFilterTaps(const ReblurCB& c, SpatialMode mode, const SpatialCtx
     } else {
         float boost = 1.0f - GetFadeBasedOnAccumulatedFrames(c, s.data1.x);
         boost *= 1.0f - BRDF::Pow5(s.NoV);
-        diffNonLinearAccumSpeed = 1.0f / (1.0f + REBLUR_SAMPLES_PER_FRAME * (1.0f - boost) * s.data1.x);
+        diffNonLinearAccumSpeed = Rcp(1.0f + REBLUR_SAMPLES_PER_FRAME * (1.0f - boost) * s.data1.x);
         blurRadius = c.gMaxBlurRadius;
         areaFactor = hitDistFactor * diffNonLinearAccumSpeed;
     }
@@ -115,7 +115,7 @@ S DiffuseSpatialFilterTaps(const ReblurCB& c, SpatialMode mode, const SpatialCtx
 
     // Weights
     float2 geometryWeightParams = GetGeometryWeightParams(c.gPlaneDistSensitivity, s.frustumSize, s.Xv, s.Nv);
-    float normalWeightParam = GetNormalWeightParam(diffNonLinearAccumSpeed, c.gLobeAngleFraction) / fractionScale;
+    float normalWeightParam = Div(GetNormalWeightParam(diffNonLinearAccumSpeed, c.gLobeAngleFraction), fractionScale);
     float2 hitDistanceWeightParams = GetHitDistanceWeightParams(ExtractHitDist(diff), diffNonLinearAccumSpeed);
     float minHitDistWeight = c.gMinHitDistanceWeight * fractionScale;
     if (mode != PRE_BLUR && !OCC) // REBLUR_Common_DiffuseSpatialFilter.hlsli:76
@@ -125,7 +125,7 @@ S DiffuseSpatialFilterTaps(const ReblurCB& c, SpatialMode mode, const SpatialCtx
     float2 skew = float2(1.0f);
     if (mode != PRE_BLUR) {
         skew = lerp(float2(1.0f - fabsf(s.Nv.x), 1.0f - fabsf(s.Nv.y)), float2(1.0f), s.NoV);
-        skew /= max(skew.x, skew.y);
+        skew = Div(skew, max(skew.x, skew.y));
     }
     skew *= c.gRectSizeInv * blurRadius;
     float4 scaledRotator = Geometry::ScaleRotator(s.rotator, skew);
@@ -240,7 +240,7 @@ S SpecularSpatialFilterTaps(const ReblurCB& c, SpatialMode mode, const SpatialCt
         float boost = 1.0f - GetFadeBasedOnAccumulatedFrames(c, s.data1.y);
         boost *= 1.0f - BRDF::Pow5(s.NoV);
         boost *= smc;
-        specNonLinearAccumSpeed = 1.0f / (1.0f + REBLUR_SAMPLES_PER_FRAME * (1.0f - boost) * s.data1.y);
+        specNonLinearAccumSpeed = Rcp(1.0f + REBLUR_SAMPLES_PER_FRAME * (1.0f - boost) * s.data1.y);
         blurRadius = c.gMaxBlurRadius;
         areaFactor = s.roughness * hitDistFactor * specNonLinearAccumSpeed;
     }
@@ -249,7 +249,7 @@ S SpecularSpatialFilterTaps(const ReblurCB& c, SpatialMode mode, const SpatialCt
     if (mode == PRE_BLUR) {
         float lobeTanHalfAngle = ImportanceSampling::GetSpecularLobeTanHalfAngle(s.roughness, REBLUR_MAX_PERCENT_OF_LOBE_VOLUME_FOR_PRE_PASS);
         float lobeRadius = hitDist * NoD * lobeTanHalfAngle;
-        float minBlurRadius = lobeRadius / PixelRadiusToWorld(c.gUnproject, c.gOrthoMode, 1.0f, s.viewZ + hitDist * Dv.w);
+        float minBlurRadius = Div(lobeRadius, PixelRadiusToWorld(c.gUnproject, c.gOrthoMode, 1.0f, s.viewZ + hitDist * Dv.w));
         blurRadius = min(blurRadius, minBlurRadius);
     }
     blurRadius *= radiusScale;
@@ -258,7 +258,7 @@ S SpecularSpatialFilterTaps(const ReblurCB& c, SpatialMode mode, const SpatialCt
     // Weights
     float roughnessFractionScaled = saturate(c.gRoughnessFraction * fractionScale);
     float2 geometryWeightParams = GetGeometryWeightParams(c.gPlaneDistSensitivity, s.frustumSize, s.Xv, s.Nv);
-    float normalWeightParam = GetNormalWeightParam(specNonLinearAccumSpeed, c.gLobeAngleFraction, s.roughness) / fractionScale;
+    float normalWeightParam = Div(GetNormalWeightParam(specNonLinearAccumSpeed, c.gLobeAngleFraction, s.roughness), fractionScale);
     float2 roughnessWeightParams = GetRoughnessWeightParams(s.roughness, roughnessFractionScaled);
     float2 hitDistanceWeightParams = GetHitDistanceWeightParams(ExtractHitDist(spec), specNonLinearAccumSpeed, s.roughness);
     float minHitDistWeight = c.gMinHitDistanceWeight * fractionScale * smc;
@@ -281,7 +281,7 @@ S SpecularSpatialFilterTaps(const ReblurCB& c, SpatialMode mode, const SpatialCt
         GetKernelBasis(bentDv, s.Nv, T, B);
         float worldRadius = PixelRadiusToWorld(c.gUnproject, c.gOrthoMode, blurRadius, s.viewZ);
         T *= worldRadius * skewFactor;
-        B *= worldRadius / skewFactor;
+        B *= Div(worldRadius, skewFactor);
     }
 
     const int sampleNum = s.perf ? 6 : 8;
@@ -322,14 +322,14 @@ S SpecularSpatialFilterTaps(const ReblurCB& c, SpatialMode mode, const SpatialCt
             // stochastic min hit distance for tracking, ignoring zeros
             float hs = ExtractHitDist(smp) * _REBLUR_GetHitDistanceNormalization(zs, c.gHitDistParams, Ns.w);
             float d = length(Xvs - s.Xv) + NRD_EPS;
-            float geometryWeight = w * saturate(hs / d);
+            float geometryWeight = w * saturate(Div(hs, d));
             if (rng.GetFloat() < geometryWeight)
                 hitDistForTracking = min(hitDistForTracking, hs);
 
             w *= c.gUsePrepassNotOnlyForSpecularMotionEstimation;
 
             // samples close to the reflection contact should not be blurred
-            float t = hs / (d + hitDist);
+            float t = Div(hs, d + hitDist);
             w *= lerp(saturate(t), 1.0f, Math::LinearStep(0.5f, 1.0f, s.roughness));
         }
         w *= lerp(minHitDistWeight, 1.0f, ComputeExponentialWeight(ExtractHitDist(smp), hitDistanceWeightParams.x, hitDistanceWeightParams.y));
@@ -679,7 +679,7 @@ void TemporalAccumulation(const PassIO& io) {
                         roughnessM2 += roughnessSq * roughnessSq;
                     }
                 }
-            Navg /= 4.0f;
+            Navg = Div(Navg, 4.0f);
 
             float materialID;
             float4 normalAndRoughness = NRD_FrontEnd_UnpackNormalAndRoughness(gIn_Normal_Roughness.Load(px, py), materialID);
@@ -690,8 +690,8 @@ void TemporalAccumulation(const PassIO& io) {
             RngHash rng;
             if (SPEC) {
                 roughnessModified = Filtering::GetModifiedRoughnessFromNormalVariance(roughness, Navg);
-                roughnessM1 /= 9.0f;
-                roughnessM2 /= 9.0f;
+                roughnessM1 = Div(roughnessM1, 9.0f);
+                roughnessM2 = Div(roughnessM2, 9.0f);
                 roughnessSigma = HwSqrt(fabsf(roughnessM2 - roughnessM1 * roughnessM1)); // GetStdDev
 
                 rng.Initialize((uint32_t)px, (uint32_t)py, c.gFrameIndex);
@@ -749,7 +749,7 @@ void TemporalAccumulation(const PassIO& io) {
                 w = prevViewZ3.x < c.gDenoisingRange ? 1.0f : 0.0f;
                 smbNavg += NRD_FrontEnd_UnpackNormalAndRoughness(gPrev_Normal_Roughness.Load(bx + 1, by + 1)).xyz() * w;
                 sumw += w;
-                smbNavg /= sumw == 0.0f ? 1.0f : sumw;
+                smbNavg = Div(smbNavg, sumw == 0.0f ? 1.0f : sumw);
             }
             smbNavg = Geometry::RotateVector(c.gWorldPrevToWorld, smbNavg);
 
@@ -765,7 +765,7 @@ void TemporalAccumulation(const PassIO& io) {
 
             float disocclusionThresholdMix = 0.0f;
             if (materialID == c.gStrandMaterialID)
-                disocclusionThresholdMix = saturate(c.gStrandThickness / pixelSize); // NRD_GetNormalizedStrandThickness
+                disocclusionThresholdMix = saturate(Div(c.gStrandThickness, pixelSize)); // NRD_GetNormalizedStrandThickness
             if (c.gHasDisocclusionThresholdMix)
                 disocclusionThresholdMix = gIn_DisocclusionThresholdMix.Load((int)c.gRectOrigin[0] + px, (int)c.gRectOrigin[1] + py).x;
             float disocclusionThreshold = lerp(c.gDisocclusionThreshold, c.gDisocclusionThresholdAlternate, disocclusionThresholdMix);
@@ -775,7 +775,7 @@ void TemporalAccumulation(const PassIO& io) {
 
             float3 V = GetViewVector(c, X);
             float NoV = fabsf(dot(N, V));
-            float NoVstrict = lerp(NoV, 1.0f, saturate(smbParallaxInPixelsMax / 30.0f));
+            float NoVstrict = lerp(NoV, 1.0f, saturate(Div(smbParallaxInPixelsMax, 30.0f)));
             float4 smbDisocclusionThreshold = float4(GetDisocclusionThreshold(disocclusionThreshold, frustumSize, NoVstrict));
             smbDisocclusionThreshold *= dot(smbNavg, Navg) > REBLUR_ALMOST_ZERO_ANGLE - 0.25f * smallParallax ? 1.0f : 0.0f;
             smbDisocclusionThreshold *= IsInScreenBilinear(smbBilinearFilter.origin, c.gRectSizePrev);
@@ -826,7 +826,7 @@ void TemporalAccumulation(const PassIO& io) {
             // Footprint quality
             float3 smbVprev = GetViewVectorPrev(c, Xprev, c.gCameraDelta.xyz());
             float NoVprev = fabsf(dot(N, smbVprev));
-            float sizeQuality = (NoVprev + 1e-3f) / (NoV + 1e-3f);
+            float sizeQuality = Div(NoVprev + 1e-3f, NoV + 1e-3f);
             sizeQuality *= sizeQuality;
             sizeQuality = lerp(0.1f, 1.0f, saturate(sizeQuality));
 
@@ -860,7 +860,7 @@ void TemporalAccumulation(const PassIO& io) {
                 float specHistoryConfidence = smbFootprintQuality;
                 if (c.gHasHistoryConfidence)
                     specHistoryConfidence *= gIn_SpecConfidence->Load((int)c.gRectOrigin[0] + px, (int)c.gRectOrigin[1] + py).x;
-                smbSpecAccumSpeed *= lerp(specHistoryConfidence, 1.0f, 1.0f / (1.0f + smbSpecAccumSpeed));
+                smbSpecAccumSpeed *= lerp(specHistoryConfidence, 1.0f, Rcp(1.0f + smbSpecAccumSpeed));
                 smbSpecAccumSpeed = min(smbSpecAccumSpeed, c.gMaxAccumulatedFrameNum);
 
                 S spec = Sig::From(gIn_Spec->Load((OCC && c.gSpecCheckerboard != 2) ? px >> 1 : px, py));
@@ -876,7 +876,7 @@ void TemporalAccumulation(const PassIO& io) {
                     float2 uvForZeroParallax = c.gOrthoMode == 0.0f ? smbPixelUv : pixelUv;
                     float2 deltaUv = uvForZeroParallax - Geometry::GetScreenUv(c.gWorldToClipPrev, Xprev + c.gCameraDelta.xyz());
                     deltaUv *= c.gRectSize;
-                    deltaUv /= max(smbParallaxInPixels1, 1.0f / 256.0f);
+                    deltaUv = Div(deltaUv, max(smbParallaxInPixels1, 1.0f / 256.0f));
 
                     // 10 edge
                     float3 n10, x10;
@@ -885,7 +885,7 @@ void TemporalAccumulation(const PassIO& io) {
                         float3 x = Geometry::RotateVector(c.gViewToWorld, xv);
                         float3 v = GetViewVector(c, x);
                         float3 o = c.gOrthoMode == 0.0f ? float3(0.0f) : x;
-                        x10 = o + v * dot(X - o, N) / dot(N, v);
+                        x10 = o + Div(v * dot(X - o, N), dot(N, v));
                         n10 = sNR(px + 1, py).xyz();
                     }
                     // 01 edge
@@ -895,12 +895,12 @@ void TemporalAccumulation(const PassIO& io) {
                         float3 x = Geometry::RotateVector(c.gViewToWorld, xv);
                         float3 v = GetViewVector(c, x);
                         float3 o = c.gOrthoMode == 0.0f ? float3(0.0f) : x;
-                        x01 = o + v * dot(X - o, N) / dot(N, v);
+                        x01 = o + Div(v * dot(X - o, N), dot(N, v));
                         n01 = sNR(px, py + 1).xyz();
                     }
                     // Mix
                     float2 w = abs(deltaUv) + 1.0f / 256.0f;
-                    w /= w.x + w.y;
+                    w = Div(w, w.x + w.y);
                     float3 x = x10 * w.x + x01 * w.y;
                     float3 n = normalize(n10 * w.x + n01 * w.y);
 
@@ -958,13 +958,13 @@ void TemporalAccumulation(const PassIO& io) {
                     Filtering::Bilinear f = Filtering::GetBilinearFilter(uv, c.gRectSizePrev);
                     float2 rnd = rng.GetFloat2();
                     f.origin += step(rnd, f.weights);
-                    float2 uvs = ((f.origin + 0.5f) / c.gRectSizePrev) * c.gResolutionScalePrev;
+                    float2 uvs = (Div(f.origin + 0.5f, c.gRectSizePrev)) * c.gResolutionScalePrev;
                     return NRD_FrontEnd_UnpackNormalAndRoughness(gPrev_Normal_Roughness.SampleNearest(uvs));
                 };
                 float4 vmbNormalAndRoughness = stochasticBilinearFetch(vmbPixelUv);
                 float3 vmbN = Geometry::RotateVector(c.gWorldPrevToWorld, vmbNormalAndRoughness.xyz());
                 float Dfactor = ImportanceSampling::GetSpecularDominantFactor(NoV, roughness);
-                float virtualHistoryNormalBasedConfidence = 1.0f / (1.0f + 0.5f * Dfactor * saturate(length(N - vmbN) - REBLUR_NORMAL_ULP) * vmbPixelsTraveled);
+                float virtualHistoryNormalBasedConfidence = Rcp(1.0f + 0.5f * Dfactor * saturate(length(N - vmbN) - REBLUR_NORMAL_ULP) * vmbPixelsTraveled);
 
                 // Patch "smbNavg" if "smb" motion is invalid
                 smbNavg = smbFootprintQuality == 0.0f ? vmbN : smbNavg;
@@ -1012,18 +1012,18 @@ void TemporalAccumulation(const PassIO& io) {
 
                 float vmbFootprintQuality = Filtering::ApplyBilinearFilter(vmbOcclusion.x, vmbOcclusion.y, vmbOcclusion.z, vmbOcclusion.w, vmbBilinearFilter);
                 vmbFootprintQuality = Math::Sqrt01(vmbFootprintQuality);
-                vmbSpecAccumSpeed *= lerp(vmbFootprintQuality, 1.0f, 1.0f / (1.0f + vmbSpecAccumSpeed));
+                vmbSpecAccumSpeed *= lerp(vmbFootprintQuality, 1.0f, Rcp(1.0f + vmbSpecAccumSpeed));
 
                 bool vmbAllowCatRom = sum(vmbOcclusion) > 3.5f && !PERF && KIND != SIGNAL_DIRECTIONAL_OCCLUSION; // REBLUR_USE_CATROM_FOR_VIRTUAL_MOTION_IN_TA
                 vmbAllowCatRom = vmbAllowCatRom && smbAllowCatRom;
 
                 // How many radians can the travelled pixels be?
                 float curvatureAngleTan = pixelSize * fabsf(curvature);
-                curvatureAngleTan *= max(vmbPixelsTraveled / max(NoV, 0.01f), 1.0f);
+                curvatureAngleTan *= max(Div(vmbPixelsTraveled, max(NoV, 0.01f)), 1.0f);
                 curvatureAngleTan *= 2.0f;
                 float curvatureAngle = atan(curvatureAngleTan);
 
-                float percentOfVolume = NRD_MAX_PERCENT_OF_LOBE_VOLUME / (1.0f + vmbSpecAccumSpeed);
+                float percentOfVolume = Div(NRD_MAX_PERCENT_OF_LOBE_VOLUME, 1.0f + vmbSpecAccumSpeed);
                 float lobeTanHalfAngle = ImportanceSampling::GetSpecularLobeTanHalfAngle(roughnessModified, percentOfVolume);
                 float lobeHalfAngle = atan(lobeTanHalfAngle);
                 lobeHalfAngle = max(lobeHalfAngle, NRD_NORMAL_ENCODING_ERROR);
@@ -1047,7 +1047,7 @@ void TemporalAccumulation(const PassIO& io) {
                     vmbPixelUvPrev = materialID == c.gCameraAttachedReflectionMaterialID ? smbPixelUv : vmbPixelUvPrev;
 
                     float pixelSizeAtXvirtual = PixelRadiusToWorld(c.gUnproject, c.gOrthoMode, 1.0f, XvirtualLength);
-                    float r = (lobeTanHalfAngle + curvatureAngle) * min(hitDistForTracking, hitDistForTrackingPrev) / pixelSizeAtXvirtual;
+                    float r = Div((lobeTanHalfAngle + curvatureAngle) * min(hitDistForTracking, hitDistForTrackingPrev), pixelSizeAtXvirtual);
                     float d = length((vmbPixelUvPrev - vmbPixelUv) * c.gRectSize);
 
                     r = max(r, 0.1f);
@@ -1055,9 +1055,9 @@ void TemporalAccumulation(const PassIO& io) {
                 }
 
                 // Virtual motion - normal & roughness prev-prev tests (1 iteration)
-                float stepBetweenTaps = min(vmbPixelsTraveled * c.gFramerateScale, 2.0f) + vmbPixelsTraveled / 1.0f;
+                float stepBetweenTaps = min(vmbPixelsTraveled * c.gFramerateScale, 2.0f) + vmbPixelsTraveled * 1.0f;
                 vmbDelta *= Math::Rsqrt(Math::LengthSquared(vmbDelta));
-                vmbDelta = vmbDelta / c.gRectSizePrev;
+                vmbDelta = Div(vmbDelta, c.gRectSizePrev);
 
                 relaxedRoughnessWeightParams = GetRelaxedRoughnessWeightParams(vmbNormalAndRoughness.w * vmbNormalAndRoughness.w, c.gRoughnessFraction, REBLUR_ROUGHNESS_SENSITIVITY_IN_TA);
                 {
@@ -1088,14 +1088,14 @@ void TemporalAccumulation(const PassIO& io) {
                 // Surface motion confidence
                 float surfaceHistoryConfidence;
                 {
-                    float a = atan(smbParallaxInPixelsMax * pixelSize / length(X));
-                    float nonLinearAccumSpeed = 1.0f / (1.0f + smbSpecAccumSpeed);
+                    float a = atan(Div(smbParallaxInPixelsMax * pixelSize, length(X)));
+                    float nonLinearAccumSpeed = Rcp(1.0f + smbSpecAccumSpeed);
                     float h = lerp(ExtractHitDist(smbSpecHistory), ExtractHitDist(spec), nonLinearAccumSpeed) * hitDistNormalization;
 
                     float tana0 = ImportanceSampling::GetSpecularLobeTanHalfAngle(roughnessModified, NRD_MAX_PERCENT_OF_LOBE_VOLUME);
                     tana0 *= lerp(NoV, 1.0f, roughnessModified);
                     tana0 *= nonLinearAccumSpeed;
-                    tana0 /= GetHitDistFactor(h, frustumSize) + NRD_EPS;
+                    tana0 = Div(tana0, GetHitDistFactor(h, frustumSize) + NRD_EPS);
 
                     float a0 = atan(tana0);
                     a0 = max(a0, NRD_NORMAL_ENCODING_ERROR);
@@ -1133,7 +1133,7 @@ void TemporalAccumulation(const PassIO& io) {
 
                 // Fallback to "smb" if "vmb" history is short (works in both directions)
                 float magic = vmbSpecAccumSpeed > smbSpecAccumSpeed ? 8.0f : 0.5f;
-                virtualHistoryAmount *= 1.0f + (vmbSpecAccumSpeed - smbSpecAccumSpeed) / (magic * max(vmbSpecAccumSpeed, smbSpecAccumSpeed) + 1.0f);
+                virtualHistoryAmount *= 1.0f + Div(vmbSpecAccumSpeed - smbSpecAccumSpeed, magic * max(vmbSpecAccumSpeed, smbSpecAccumSpeed) + 1.0f);
                 virtualHistoryAmount = saturate(virtualHistoryAmount);
 
                 // Sample virtual history
@@ -1145,8 +1145,8 @@ void TemporalAccumulation(const PassIO& io) {
                 vmbSpecHistory = ClampNegativeToZero(vmbSpecHistory);
 
                 // Accumulation
-                float smbSpecNonLinearAccumSpeed = 1.0f / (1.0f + smbSpecAccumSpeed);
-                float vmbSpecNonLinearAccumSpeed = 1.0f / (1.0f + vmbSpecAccumSpeed);
+                float smbSpecNonLinearAccumSpeed = Rcp(1.0f + smbSpecAccumSpeed);
+                float vmbSpecNonLinearAccumSpeed = Rcp(1.0f + vmbSpecAccumSpeed);
                 if (!specHasData) {
                     smbSpecNonLinearAccumSpeed *= lerp(1.0f - c.gCheckerboardResolveAccumSpeed, 1.0f, smbSpecNonLinearAccumSpeed);
                     vmbSpecNonLinearAccumSpeed *= lerp(1.0f - c.gCheckerboardResolveAccumSpeed, 1.0f, vmbSpecNonLinearAccumSpeed);
@@ -1173,9 +1173,9 @@ void TemporalAccumulation(const PassIO& io) {
                 // Firefly suppressor (not in the occlusion family: REBLUR_TemporalAccumulation.hlsli:757, 788)
                 float specMaxRelativeIntensity = 0.0f, specAntifireflyFactor = 0.0f;
                 if (KIND == SIGNAL_RADIANCE) {
-                    specMaxRelativeIntensity = c.gFireflySuppressorMinRelativeScale + REBLUR_FIREFLY_SUPPRESSOR_MAX_RELATIVE_INTENSITY / (specAccumSpeed + 1.0f);
+                    specMaxRelativeIntensity = c.gFireflySuppressorMinRelativeScale + Div(REBLUR_FIREFLY_SUPPRESSOR_MAX_RELATIVE_INTENSITY, specAccumSpeed + 1.0f);
                     specAntifireflyFactor = specAccumSpeed * c.gMaxBlurRadius * REBLUR_FIREFLY_SUPPRESSOR_RADIUS_SCALE;
-                    specAntifireflyFactor /= 1.0f + specAntifireflyFactor;
+                    specAntifireflyFactor = Div(specAntifireflyFactor, 1.0f + specAntifireflyFactor);
 
                     float specLumaResult = GetLuma(specResult);
                     float specLumaClamped = min(specLumaResult, GetLuma(specHistory) * specMaxRelativeIntensity);
@@ -1214,7 +1214,7 @@ void TemporalAccumulation(const PassIO& io) {
                 float diffHistoryConfidence = smbFootprintQuality;
                 if (c.gHasHistoryConfidence)
                     diffHistoryConfidence *= gIn_DiffConfidence->Load((int)c.gRectOrigin[0] + px, (int)c.gRectOrigin[1] + py).x;
-                diffAccumSpeed *= lerp(diffHistoryConfidence, 1.0f, 1.0f / (1.0f + diffAccumSpeed));
+                diffAccumSpeed *= lerp(diffHistoryConfidence, 1.0f, Rcp(1.0f + diffAccumSpeed));
                 diffAccumSpeed = min(diffAccumSpeed, c.gMaxAccumulatedFrameNum);
 
                 S diff = Sig::From(gIn_Diff->Load((OCC && c.gDiffCheckerboard != 2) ? px >> 1 : px, py));
@@ -1230,7 +1230,7 @@ void TemporalAccumulation(const PassIO& io) {
                 float smbDiffFastHistory = FetchHistoryBilinear(smbFilter, *gHistory_DiffFast).x;
                 smbDiffHistory = ClampNegativeToZero(smbDiffHistory);
 
-                float diffNonLinearAccumSpeed = 1.0f / (1.0f + diffAccumSpeed);
+                float diffNonLinearAccumSpeed = Rcp(1.0f + diffAccumSpeed);
                 if (!diffHasData)
                     diffNonLinearAccumSpeed *= lerp(1.0f - c.gCheckerboardResolveAccumSpeed, 1.0f, diffNonLinearAccumSpeed);
                 S diffResult = MixHistoryAndCurrent(c, smbDiffHistory, diff, diffNonLinearAccumSpeed);
@@ -1243,9 +1243,9 @@ void TemporalAccumulation(const PassIO& io) {
                 // Firefly suppressor (not in the occlusion family: REBLUR_TemporalAccumulation.hlsli:889, 918)
                 float diffMaxRelativeIntensity = 0.0f, diffAntifireflyFactor = 0.0f;
                 if (KIND == SIGNAL_RADIANCE) {
-                    diffMaxRelativeIntensity = c.gFireflySuppressorMinRelativeScale + REBLUR_FIREFLY_SUPPRESSOR_MAX_RELATIVE_INTENSITY / (diffAccumSpeed + 1.0f);
+                    diffMaxRelativeIntensity = c.gFireflySuppressorMinRelativeScale + Div(REBLUR_FIREFLY_SUPPRESSOR_MAX_RELATIVE_INTENSITY, diffAccumSpeed + 1.0f);
                     diffAntifireflyFactor = diffAccumSpeed * c.gMaxBlurRadius * REBLUR_FIREFLY_SUPPRESSOR_RADIUS_SCALE;
-                    diffAntifireflyFactor /= 1.0f + diffAntifireflyFactor;
+                    diffAntifireflyFactor = Div(diffAntifireflyFactor, 1.0f + diffAntifireflyFactor);
 
                     float diffLumaResult = GetLuma(diffResult);
                     float diffLumaClamped = min(diffLumaResult, GetLuma(smbDiffHistory) * diffMaxRelativeIntensity);
@@ -1262,7 +1262,7 @@ void TemporalAccumulation(const PassIO& io) {
 
                 // Fast history
                 float diffFastAccumSpeed = min(diffAccumSpeed, c.gMaxFastAccumulatedFrameNum);
-                float diffFastNonLinearAccumSpeed = 1.0f / (1.0f + diffFastAccumSpeed);
+                float diffFastNonLinearAccumSpeed = Rcp(1.0f + diffFastAccumSpeed);
                 if (!diffHasData)
                     diffFastNonLinearAccumSpeed *= lerp(1.0f - c.gCheckerboardResolveAccumSpeed, 1.0f, diffFastNonLinearAccumSpeed);
                 float diffFastResult = lerp(smbDiffFastHistory, GetLuma(diff), diffFastNonLinearAccumSpeed);
@@ -1299,7 +1299,7 @@ S HistoryFixSignal(const ReblurCB& c, bool isSpec, bool perf, int px, int py, S 
     // History reconstruction: 5x5 minus centre minus corners, sparse
     if (stride != 0.0f) {
         int stridei = (int)(stride + 0.5f);
-        float nonLinearAccumSpeed = 1.0f / (1.0f + frameNum);
+        float nonLinearAccumSpeed = Rcp(1.0f + frameNum);
         float r = isSpec ? roughness : 1.0f;
 
         float normalWeightParam = GetNormalWeightParam(nonLinearAccumSpeed, c.gLobeAngleFraction, r);
@@ -1313,7 +1313,7 @@ S HistoryFixSignal(const ReblurCB& c, bool isSpec, bool perf, int px, int py, S 
 
         float sumw = 1.0f + frameNum;
         if (perf) // REBLUR_HistoryFix.hlsli:88-90 / 292-294
-            sumw = 1.0f + 1.0f / (1.0f + c.gMaxAccumulatedFrameNum) - nonLinearAccumSpeed;
+            sumw = 1.0f + Rcp(1.0f + c.gMaxAccumulatedFrameNum) - nonLinearAccumSpeed;
         sig = sig * sumw;
         if (sh) {
             sh->x *= sumw, sh->y *= sumw, sh->z *= sumw;
@@ -1356,7 +1356,7 @@ S HistoryFixSignal(const ReblurCB& c, bool isSpec, bool perf, int px, int py, S 
                 w *= ComputeExponentialWeight(hsFactor, hitDistanceWeightParams.x, hitDistanceWeightParams.y);
 
                 if (isSpec) { // low roughness: hit distances work as a non-noisy guide
-                    float d = fabsf(hitDist - hs) / (max(hitDist, hs) + 0.001f);
+                    float d = Div(fabsf(hitDist - hs), max(hitDist, hs) + 0.001f);
                     float b = Math::LinearStep(0.03f, 0.05f, roughness);
                     w *= Math::SmoothStep(0.2f + b, 0.05f + b, d);
                 }
@@ -1386,7 +1386,7 @@ S HistoryFixSignal(const ReblurCB& c, bool isSpec, bool perf, int px, int py, S 
     float center = sLuma(px, py);
     float m1 = center, m2 = center * center;
 
-    float f = saturate(frameNum / (c.gHistoryFixFrameNum + NRD_EPS));
+    float f = saturate(Div(frameNum, c.gHistoryFixFrameNum + NRD_EPS));
     if (isSpec)
         f = lerp(1.0f, f, smc);
     center = lerp(GetLuma(sig), center, f);
@@ -1415,7 +1415,7 @@ S HistoryFixSignal(const ReblurCB& c, bool isSpec, bool perf, int px, int py, S 
                 am1 += d;
                 am2 += d * d;
             }
-        float invNorm = 1.0f / float((R * 2 + 1) * (R * 2 + 1) - 3 * 3);
+        float invNorm = Rcp(float((R * 2 + 1) * (R * 2 + 1) - 3 * 3));
         am1 *= invNorm;
         am2 *= invNorm;
         float sigma = HwSqrt(fabsf(am2 - am1 * am1)) * REBLUR_ANTI_FIREFLY_SIGMA_SCALE;
@@ -1423,11 +1423,11 @@ S HistoryFixSignal(const ReblurCB& c, bool isSpec, bool perf, int px, int py, S 
     }
 
     // Fast-history clamping
-    m1 /= 25.0f;
-    m2 /= 25.0f;
+    m1 = Div(m1, 25.0f);
+    m2 = Div(m2, 25.0f);
     float sigma = HwSqrt(fabsf(m2 - m1 * m1)) * (KIND != SIGNAL_RADIANCE ? REBLUR_COLOR_CLAMPING_SIGMA_SCALE_OCCLUSION : REBLUR_COLOR_CLAMPING_SIGMA_SCALE);
     float lumaClamped = clamp(luma, m1 - sigma, m1 + sigma);
-    luma = lerp(lumaClamped, luma, 1.0f / (1.0f + (c.gMaxFastAccumulatedFrameNum < c.gMaxAccumulatedFrameNum ? 1.0f : 0.0f) * frameNum * 2.0f));
+    luma = lerp(lumaClamped, luma, Rcp(1.0f + (c.gMaxFastAccumulatedFrameNum < c.gMaxAccumulatedFrameNum ? 1.0f : 0.0f) * frameNum * 2.0f));
 
     if (sh) { // REBLUR_HistoryFix.hlsli:247-249
         float k = GetLumaScale(length(sh->xyz()), luma);
@@ -1480,7 +1480,7 @@ void HistoryFix(const PassIO& io) {
             float3 Xv = Geometry::ReconstructViewPosition(pixelUv, c.gFrustum, viewZ, c.gOrthoMode);
             float3 Nv = Geometry::RotateVectorInverse(c.gViewToWorld, N);
             float2 frameNum = UnpackData1(gIn_Data1.Load(px, py), DIFF);
-            float2 stride = c.gHistoryFixBasePixelStride / (2.0f + frameNum);
+            float2 stride = Div(c.gHistoryFixBasePixelStride, 2.0f + frameNum);
 
             if (DIFF) {
                 float4 diffSh = SH ? gIn_DiffSh->Load(px, py) : float4(0.0f);
@@ -1597,8 +1597,8 @@ void TemporalStabilization(const PassIO& io) {
                         mn = min(mn, d);
                         mx = max(mx, d);
                     }
-                M1 /= 9.0f;
-                M2 /= 9.0f;
+                M1 = Div(M1, 9.0f);
+                M2 = Div(M2, 9.0f);
                 m1 = M1;
                 sigma = HwSqrt(fabsf(M2 - M1 * M1));
                 if (!PERF && c.gMaxBlurRadius != 0.0f) // RCRS (not in performance mode)
@@ -1667,7 +1667,7 @@ void TemporalStabilization(const PassIO& io) {
                     float3 Fenv = Color::EnvironmentTerm_Rtg(Rf0, NoV, roughness);
                     float lumSpec = Color::Luminance(Fenv);
                     float lumDiff = Color::Luminance(float3(albedo.x * (1.0f - Fenv.x), albedo.y * (1.0f - Fenv.y), albedo.z * (1.0f - Fenv.z)));
-                    float specProb = lumSpec / (lumDiff + lumSpec + NRD_EPS);
+                    float specProb = Div(lumSpec, lumDiff + lumSpec + NRD_EPS);
                     float f = Math::SmoothStep(c.gSpecProbabilityThresholdsForMvModification.x, c.gSpecProbabilityThresholdsForMvModification.y, specProb);
                     f *= 1.0f - GetSpecMagicCurve(roughness);
                     f *= 1.0f - Math::Sqrt01(fabsf(curvature));
@@ -1679,7 +1679,7 @@ void TemporalStabilization(const PassIO& io) {
                             specMv.z = Geometry::AffineTransform(c.gWorldToViewPrev, Xvirtual).z - viewZ;
                         }
                         // only .xy for 2D, .xyz for 2.5D and 3D MVs
-                        float3 newMv = float3(specMv.x / c.gMvScale.x, specMv.y / c.gMvScale.y, c.gMvScale.z == 0.0f ? inMv.z : specMv.z / c.gMvScale.z);
+                        float3 newMv = float3(Div(specMv.x, c.gMvScale.x), Div(specMv.y, c.gMvScale.y), c.gMvScale.z == 0.0f ? inMv.z : Div(specMv.z, c.gMvScale.z));
                         inMv.x = lerp(inMv.x, newMv.x, f);
                         inMv.y = lerp(inMv.y, newMv.y, f);
                         inMv.z = lerp(inMv.z, newMv.z, f);
@@ -1827,7 +1827,7 @@ void HitDistReconstruction(const PassIO& io) {
                     center += data * ww;
                     sum += ww;
                 }
-            center = center / max(sum, float2(NRD_EPS));
+            center = Div(center, max(sum, float2(NRD_EPS)));
 
             if (DIFF)
                 gOut_Diff->Store(px, py, Sig::WithHitDist(Sig::From(gIn_Diff->Load(px, py)), center.x));
@@ -1936,11 +1936,11 @@ static void ReblurValidation(const PassIO& io) {
                 gOut_Validation.Store(px, py, float4(0.0f));
                 continue;
             }
-            float2 pixelUv = float2(float(px) + 0.5f, float(py) + 0.5f) / c.gResourceSize;
-            float2 scaled = pixelUv / VIEWPORT_SIZE;
+            float2 pixelUv = Div(float2(float(px) + 0.5f, float(py) + 0.5f), c.gResourceSize);
+            float2 scaled = pixelUv * 4.0f; // / VIEWPORT_SIZE
             float2 viewportId = floor(scaled);
             float2 viewportUv = scaled - viewportId;
-            float viewportIndex = viewportId.y / VIEWPORT_SIZE + viewportId.x;
+            float viewportIndex = viewportId.y * 4.0f + viewportId.x; // / VIEWPORT_SIZE
             float2 viewportUvScaled = viewportUv * c.gResolutionScale;
 
             float4 normalAndRoughness = NRD_FrontEnd_UnpackNormalAndRoughness(gIn_Normal_Roughness.SampleNearest(viewportUvScaled + c.gRectOffset));
@@ -1970,7 +1970,7 @@ static void ReblurValidation(const PassIO& io) {
             } else if (viewportIndex == 1.0f) {
                 result = float4(float3(normalAndRoughness.w), 1.0f);
             } else if (viewportIndex == 2.0f) {
-                float f = 0.1f * abs(viewZ) / (1.0f + 0.1f * abs(viewZ));
+                float f = Div(0.1f * abs(viewZ), 1.0f + 0.1f * abs(viewZ));
                 float3 color = viewZ < 0.0f ? float3(0, 0, 1) : float3(0, 1, 0);
                 result = float4(isInf ? float3(1, 0, 0) : color * f, 1.0f);
             } else if (viewportIndex == 3.0f) {
@@ -1981,10 +1981,10 @@ static void ReblurValidation(const PassIO& io) {
                 float2 uvDelta = (viewportUvPrev - viewportUvPrevExpected) * c.gRectSize;
                 result = float4(IsInScreenNearest(viewportUvPrev) != 0.0f ? float3(abs(uvDelta.x), abs(uvDelta.y), 0.0f) : float3(0, 0, 1), 1.0f);
             } else if (viewportIndex == 4.0f) {
-                float2 dim = float2(0.5f * c.gResourceSize.y / c.gResourceSize.x, 0.5f);
+                float2 dim = float2(Div(0.5f * c.gResourceSize.y, c.gResourceSize.x), 0.5f);
                 float2 dimInPixels = c.gResourceSize * VIEWPORT_SIZE * dim;
-                float2 remappedUv = (viewportUv - (1.0f - dim)) / dim;
-                float2 remappedUv2 = (viewportUv - float2(1.0f - dim.x, 0.0f)) / dim;
+                float2 remappedUv = Div(viewportUv - (1.0f - dim), dim);
+                float2 remappedUv2 = Div(viewportUv - float2(1.0f - dim.x, 0.0f), dim);
                 if (remappedUv.x > 0.0f && remappedUv.y > 0.0f) {
                     float2 uv = c.gJitter + 0.5f;
                     float2 su = saturate(uv);
@@ -1998,7 +1998,7 @@ static void ReblurValidation(const PassIO& io) {
                         result.x = 1.0f, result.y = 0.0f, result.z = 0.0f;
                 } else if (remappedUv2.x > 0.0f && remappedUv2.y > 0.0f) {
                     float scale = 0.5f;
-                    scale *= float(Sequence::ReverseBits4(c.gFrameIndex)) / 16.0f;
+                    scale *= float(Sequence::ReverseBits4(c.gFrameIndex)) * 0.0625f;
                     int bx = (int)(remappedUv2.x * dimInPixels.x), by = (int)(remappedUv2.y * dimInPixels.y);
                     const float4 rot[3] = {c.gRotatorPre, c.gRotator, c.gRotatorPost};
                     for (int n = 0; n < 8; n++) {
@@ -2022,7 +2022,7 @@ static void ReblurValidation(const PassIO& io) {
                 result = float4(float3(data2.x * notInf), 1.0f);
             } else if ((viewportIndex == 8.0f && vc.gHasDiffuse) || (viewportIndex == 11.0f && vc.gHasSpecular)) {
                 float frames = viewportIndex == 8.0f ? data1.x : data1.y;
-                float f = 1.0f - saturate(frames / max(c.gMaxAccumulatedFrameNum, 1.0f));
+                float f = 1.0f - saturate(Div(frames, max(c.gMaxAccumulatedFrameNum, 1.0f)));
                 f = checkerboard && frames < 1.0f ? 0.75f : f;
                 result = float4(Sequence::ColorizeZucconi(viewportUv.y > 0.95f ? 1.0f - viewportUv.x : f * notInf), 1.0f);
             } else if ((viewportIndex == 12.0f && vc.gHasDiffuse) || (viewportIndex == 15.0f && vc.gHasSpecular)) {

@@ -103,12 +103,12 @@ inline float3 GetPreviousWorldPosFromClipSpaceXY(const RelaxCB& c, float2 clip, 
     return WorldPosFromClip(c, c.gPrevFrustumRight, c.gPrevFrustumUp, c.gPrevFrustumForward, clip, viewZ);
 }
 inline float3 GetPreviousWorldPosFromPixelPos(const RelaxCB& c, int px, int py, float viewZ) {
-    float2 clip = float2(float(px) + 0.5f, float(py) + 0.5f) * (1.0f / c.gRectSizePrev) * 2.0f - 1.0f;
+    float2 clip = float2(float(px) + 0.5f, float(py) + 0.5f) * float2(Rcp(c.gRectSizePrev.x), Rcp(c.gRectSizePrev.y)) * 2.0f - 1.0f;
     return GetPreviousWorldPosFromClipSpaceXY(c, clip, viewZ);
 }
 inline float GetPlaneDistanceWeight(float3 centerWorldPos, float3 centerNormal, float centerViewZ, float3 sampleWorldPos, float threshold) { // :104-109
     float d = fabsf(dot(sampleWorldPos - centerWorldPos, centerNormal));
-    return d / centerViewZ > threshold ? 0.0f : 1.0f;
+    return Div(d, centerViewZ) > threshold ? 0.0f : 1.0f;
 }
 inline float GetPlaneDistanceWeight_Atrous(float3 centerWorldPos, float3 centerNormal, float3 sampleWorldPos, float threshold) { // :111-116
     float d = fabsf(dot(sampleWorldPos - centerWorldPos, centerNormal));
@@ -117,11 +117,11 @@ inline float GetPlaneDistanceWeight_Atrous(float3 centerWorldPos, float3 centerN
 inline float GetSpecLobeTanHalfAngle(float roughness, float percentOfVolume = 0.75f) { // :118-126 (the "old" lobe formula)
     roughness = saturate(roughness);
     percentOfVolume = saturate(percentOfVolume);
-    return roughness * roughness * percentOfVolume / (1.0f - percentOfVolume + NRD_EPS);
+    return Div(roughness * roughness * percentOfVolume, 1.0f - percentOfVolume + NRD_EPS);
 }
 inline float2 GetNormalWeightParams_ATrous(float roughness, float numFramesInHistory, float specularReprojectionConfidence, float normalEdgeStoppingRelaxation,
     float specularLobeAngleFraction, float specularLobeAngleSlack) { // :128-148
-    float relaxation = saturate(numFramesInHistory / 5.0f);
+    float relaxation = saturate(Div(numFramesInHistory, 5.0f));
     relaxation *= lerp(1.0f, specularReprojectionConfidence, normalEdgeStoppingRelaxation);
     float f = 0.9f + 0.1f * relaxation;
     float angle = atan(GetSpecLobeTanHalfAngle(roughness, specularLobeAngleFraction));
@@ -140,7 +140,7 @@ inline float GetSpecularNormalWeight_ATrous(float2 params0, float3 n0, float3 n,
 }
 inline float GetNormalWeightParam2(float roughness, float angleFraction) { // :162-168
     float angle = atan(GetSpecLobeTanHalfAngle(roughness, angleFraction));
-    return 1.0f / max(angle, RELAX_NORMAL_ULP);
+    return Rcp(max(angle, RELAX_NORMAL_ULP));
 }
 inline float GetBilateralWeight(float z, float zc) { return Math::LinearStep(0.03f, 0.0f, fabsf(z - zc) * rcp(max(z, zc))); } // :171-172
 
@@ -154,7 +154,7 @@ inline float GetEncodingAwareNormalWeightR(float3 Ncurr, float3 Nprev, float max
 // Geometry::GetScreenUv( M, X, false ): no back-projection override
 inline float2 ScreenUvNoKill(const float4x4& worldToClip, float3 X) {
     float4 clip = Geometry::ProjectiveTransform(worldToClip, X);
-    return float2((clip.x / clip.w) * 0.5f + 0.5f, (clip.y / clip.w) * -0.5f + 0.5f);
+    return float2((Div(clip.x, clip.w)) * 0.5f + 0.5f, (Div(clip.y, clip.w)) * -0.5f + 0.5f);
 }
 // Common.hlsli:297-307
 inline float2 ApplyCheckerboardShift(float2 pos, uint32_t mode, uint32_t counter, uint32_t frameIndex) {
@@ -279,11 +279,11 @@ void HitDistReconstruction(const PassIO& io) {
                 }
 
             if (SPEC) {
-                sumSpecularHitDist /= max(sumSpecularWeight, 1e-6f);
+                sumSpecularHitDist = Div(sumSpecularHitDist, max(sumSpecularWeight, 1e-6f));
                 spec.out->Store(px, py, float4(spec.in->Load(px, py).xyz(), sumSpecularHitDist));
             }
             if (DIFF) {
-                sumDiffuseHitDist /= max(sumDiffuseWeight, 1e-6f);
+                sumDiffuseHitDist = Div(sumDiffuseHitDist, max(sumDiffuseWeight, 1e-6f));
                 diff.out->Store(px, py, float4(diff.in->Load(px, py).xyz(), sumDiffuseHitDist));
             }
         }
@@ -420,9 +420,9 @@ void PrePass(const PassIO& io) {
                             diffuseSH += sampleDiffuseSH * sampleWeight;
                         }
                     }
-                    diffuseIllumination = diffuseIllumination / weightSum;
+                    diffuseIllumination = Div(diffuseIllumination, weightSum);
                     if (SH)
-                        diffuseSH = diffuseSH / weightSum;
+                        diffuseSH = Div(diffuseSH, weightSum);
                 }
                 diff.out->Store(px, py, vclamp(diffuseIllumination, 0.0f, NRD_FP16_MAX));
                 if (SH)
@@ -467,7 +467,7 @@ void PrePass(const PassIO& io) {
                     float blurRadius = c.gSpecBlurRadius * hitDistFactor * smc;
                     float lobeTanHalfAngle = ImportanceSampling::GetSpecularLobeTanHalfAngle(centerRoughness, 0.75f);
                     float lobeRadius = hitDist * NoD * lobeTanHalfAngle;
-                    float minBlurRadius = lobeRadius / PixelRadiusToWorld(c.gUnproject, c.gOrthoMode, 1.0f, centerViewZ + hitDist * D.w);
+                    float minBlurRadius = Div(lobeRadius, PixelRadiusToWorld(c.gUnproject, c.gOrthoMode, 1.0f, centerViewZ + hitDist * D.w));
                     blurRadius = min(blurRadius, minBlurRadius);
                     if (specularIllumination.w == 0.0f)
                         blurRadius = max(blurRadius, 1.0f);
@@ -509,7 +509,7 @@ void PrePass(const PassIO& io) {
                         // samples close to the reflection contact should not be pre-blurred
                         float d = length(sampleWorldPos - centerWorldPos);
                         float h = sampleSpecularIllumination.w;
-                        float t = h / (specularIllumination.w + d);
+                        float t = Div(h, specularIllumination.w + d);
                         sampleWeight *= lerp(saturate(t), 1.0f, Math::LinearStep(0.5f, 1.0f, centerRoughness));
 
                         weightSum += sampleWeight;
@@ -521,10 +521,10 @@ void PrePass(const PassIO& io) {
                         if (sampleWeight != 0.0f)
                             minHitT = min(minHitT, sampleSpecularIllumination.w == 0.0f ? NRD_INF : sampleSpecularIllumination.w);
                     }
-                    rgb = rgb / weightSum;
+                    rgb = Div(rgb, weightSum);
                     specularIllumination = float4(rgb, minHitT == NRD_INF ? 0.0f : minHitT);
                     if (SH)
-                        specularSH = specularSH / weightSum;
+                        specularSH = Div(specularSH, weightSum);
                 }
                 spec.out->Store(px, py, vclamp(specularIllumination, 0.0f, NRD_FP16_MAX));
                 if (SH)
@@ -643,7 +643,7 @@ void TemporalAccumulation(const PassIO& io) {
                     minHitDist3x3 = min(minHitDist3x3, normalSpecHitT.w == 0.0f ? NRD_INF : normalSpecHitT.w);
                     currentNormalAveraged += normalSpecHitT.xyz();
                 }
-            currentNormalAveraged /= 9.0f;
+            currentNormalAveraged = Div(currentNormalAveraged, 9.0f);
 
             float currentRoughnessModified = SPEC ? Filtering::GetModifiedRoughnessFromNormalVariance(currentRoughness, currentNormalAveraged) : 0.0f;
 
@@ -663,7 +663,7 @@ void TemporalAccumulation(const PassIO& io) {
             // disocclusion threshold
             float disocclusionThresholdMix = 0.0f;
             if (currentMaterialID == c.gStrandMaterialID)
-                disocclusionThresholdMix = saturate(c.gStrandThickness / pixelSize); // NRD_GetNormalizedStrandThickness
+                disocclusionThresholdMix = saturate(Div(c.gStrandThickness, pixelSize)); // NRD_GetNormalizedStrandThickness
             if (c.gHasDisocclusionThresholdMix)
                 disocclusionThresholdMix = gIn_DisocclusionThresholdMix.Load(ox + px, oy + py).x;
             float disocclusionThreshold = lerp(c.gDisocclusionThreshold, c.gDisocclusionThresholdAlternate, disocclusionThresholdMix);
@@ -687,7 +687,7 @@ void TemporalAccumulation(const PassIO& io) {
                 auto M = [&](int dx, int dy) { return gPrev_MaterialID.FetchClamped(bx + dx, by + dy).x * 255.0f; };
 
                 float frustumSize = pixelSize * float(min(rectW, rectH));
-                float disocclusionThresholdSlopeScale = 1.0f / lerp(lerp(0.05f, 1.0f, NoV), 1.0f, saturate(smbParallaxInPixelsMax / 30.0f));
+                float disocclusionThresholdSlopeScale = Rcp(lerp(lerp(0.05f, 1.0f, NoV), 1.0f, saturate(Div(smbParallaxInPixelsMax, 30.0f))));
                 float4 smbDisocclusionThreshold = float4(saturate(disocclusionThreshold * disocclusionThresholdSlopeScale) * frustumSize);
                 smbDisocclusionThreshold *= IsInScreenBilinear(originF, c.gRectSizePrev);
                 smbDisocclusionThreshold -= NRD_EPS;
@@ -763,7 +763,7 @@ void TemporalAccumulation(const PassIO& io) {
             // avoid footprint stretching due to the changed viewing angle
             float3 Vprev = c.gOrthoMode == 0.0f ? -normalize(prevWorldPos - c.gCameraDelta.xyz()) : -normalize(c.gPrevFrustumForward.xyz());
             float NoVprev = fabsf(dot(currentNormal, Vprev));
-            float sizeQuality = (NoVprev + 1e-3f) / (NoV + 1e-3f);
+            float sizeQuality = Div(NoVprev + 1e-3f, NoV + 1e-3f);
             sizeQuality *= sizeQuality;
             sizeQuality *= sizeQuality;
             footprintQuality *= lerp(0.1f, 1.0f, saturate(sizeQuality + fabsf(c.gOrthoMode)));
@@ -789,8 +789,8 @@ void TemporalAccumulation(const PassIO& io) {
                     diffMaxFastAccumulatedFrameNum *= inDiffConfidence;
                 }
                 float diffHistoryLength = historyLength;
-                float diffuseAlpha = SMBReprojectionFound > 0.0f ? max(1.0f / (diffMaxAccumulatedFrameNum + 1.0f), 1.0f / diffHistoryLength) : 1.0f;
-                float diffuseAlphaResponsive = SMBReprojectionFound > 0.0f ? max(1.0f / (diffMaxFastAccumulatedFrameNum + 1.0f), 1.0f / diffHistoryLength) : 1.0f;
+                float diffuseAlpha = SMBReprojectionFound > 0.0f ? max(Rcp(diffMaxAccumulatedFrameNum + 1.0f), Rcp(diffHistoryLength)) : 1.0f;
+                float diffuseAlphaResponsive = SMBReprojectionFound > 0.0f ? max(Rcp(diffMaxFastAccumulatedFrameNum + 1.0f), Rcp(diffHistoryLength)) : 1.0f;
 
                 bool diffHasData = true;
                 if (c.gDiffCheckerboard != 2u)
@@ -810,7 +810,7 @@ void TemporalAccumulation(const PassIO& io) {
                 }
             }
 
-            gOut_HistoryLength.Store(px, py, historyLength / 255.0f);
+            gOut_HistoryLength.Store(px, py, Div(historyLength, 255.0f));
 
             if (SPEC) {
                 float specMaxAccumulatedFrameNum = c.gSpecMaxAccumulatedFrameNum;
@@ -832,13 +832,13 @@ void TemporalAccumulation(const PassIO& io) {
                     float2 uvForZeroParallax = c.gOrthoMode == 0.0f ? prevUVSMB : pixelUv;
                     float2 deltaUv = uvForZeroParallax - Geometry::GetScreenUv(c.gWorldToClipPrev, prevWorldPos + c.gCameraDelta.xyz());
                     deltaUv *= rectSize;
-                    deltaUv /= max(smbParallaxInPixels1, 1.0f / 256.0f);
+                    deltaUv = Div(deltaUv, max(smbParallaxInPixels1, 1.0f / 256.0f));
 
                     auto Edge = [&](float2 duv, int sx, int sy, float3& nOut, float3& xOut) {
                         float3 x = GetCurrentWorldPosFromClipSpaceXY(c, (pixelUv + duv * c.gRectSizeInv) * 2.0f - 1.0f, 1.0f);
                         float3 v = c.gOrthoMode == 0.0f ? normalize(-x) : c.gFrustumForward.xyz();
                         float3 o = c.gOrthoMode == 0.0f ? float3(0.0f) : x;
-                        xOut = o + v * dot(currentWorldPos - o, currentNormal) / dot(currentNormal, v); // line-plane intersection
+                        xOut = o + Div(v * dot(currentWorldPos - o, currentNormal), dot(currentNormal, v)); // line-plane intersection
                         nOut = Shared(px + sx, py + sy).xyz();
                     };
                     float3 n10, x10, n01, x01;
@@ -846,7 +846,7 @@ void TemporalAccumulation(const PassIO& io) {
                     Edge(float2(0.0f, 1.0f), 0, 1, n01, x01);
 
                     float2 w = abs(deltaUv) + 1.0f / 256.0f;
-                    w /= w.x + w.y;
+                    w = Div(w, w.x + w.y);
                     float3 x = x10 * w.x + x01 * w.y;
                     float3 n = normalize(n10 * w.x + n01 * w.y);
 
@@ -946,7 +946,7 @@ void TemporalAccumulation(const PassIO& io) {
                 float uvDiffLengthInPixels = length(uvDiff * rectSize);
 
                 float tanCurvature = fabsf(curvature * pixelSize);
-                tanCurvature *= max(uvDiffLengthInPixels / max(NoV, 0.01f), 1.0f);
+                tanCurvature *= max(Div(uvDiffLengthInPixels, max(NoV, 0.01f)), 1.0f);
                 float curvatureAngle = atan(tanCurvature);
 
                 float lobeHalfAngle = max(atan(GetSpecLobeTanHalfAngle(currentRoughnessModified)), RELAX_NORMAL_ULP);
@@ -961,8 +961,8 @@ void TemporalAccumulation(const PassIO& io) {
 
                 // look back 1 and 2 frames
                 uvDiff *= Math::Rsqrt(Math::LengthSquared(uvDiff));
-                uvDiff = uvDiff / c.gRectSizePrev;
-                uvDiff *= saturate(uvDiffLengthInPixels / 0.1f) + uvDiffLengthInPixels / 2.0f;
+                uvDiff = Div(uvDiff, c.gRectSizePrev);
+                uvDiff *= saturate(Div(uvDiffLengthInPixels, 0.1f)) + uvDiffLengthInPixels * 0.5f;
                 float2 backUV1 = prevUVVMB + 1.0f * uvDiff;
                 float2 backUV2 = prevUVVMB + 2.0f * uvDiff;
                 float4 backNormalRoughness1 = UnpackPrevNormalRoughness(gPrev_Normal_Roughness.SampleLinearTexel(backUV1 * resolutionScalePrev * PrevSize(gPrev_Normal_Roughness)));
@@ -985,7 +985,7 @@ void TemporalAccumulation(const PassIO& io) {
                 float maxDist = max(hitDist1, hitDist2);
                 float dHitT = fabsf(hitDist1 - hitDist2);
                 float dHitTMultiplier = lerp(20.0f, 0.0f, SMC);
-                float virtualHistoryHitDistConfidence = 1.0f - saturate(dHitTMultiplier * dHitT / (currentLinearZ + maxDist));
+                float virtualHistoryHitDistConfidence = 1.0f - saturate(Div(dHitTMultiplier * dHitT, currentLinearZ + maxDist));
                 virtualHistoryHitDistConfidence = lerp(virtualHistoryHitDistConfidence, 1.0f, SMC);
 
                 // virtual UV discrepancy
@@ -999,17 +999,17 @@ void TemporalAccumulation(const PassIO& io) {
 
                 float lobeTanHalfAngle = GetSpecLobeTanHalfAngle(currentRoughness, 0.6f);
                 lobeTanHalfAngle = max(lobeTanHalfAngle, 0.5f * c.gRectSizeInv.x);
-                float unproj1 = min(hitDist, hitDistForTrackingPrev) / PixelRadiusToWorld(c.gUnproject, c.gOrthoMode, 1.0f, max(virtualWorldPosLength, virtualWorldPosLengthPrev));
+                float unproj1 = Div(min(hitDist, hitDistForTrackingPrev), PixelRadiusToWorld(c.gUnproject, c.gOrthoMode, 1.0f, max(virtualWorldPosLength, virtualWorldPosLengthPrev)));
                 float lobeRadiusInPixels = lobeTanHalfAngle * unproj1;
                 float deltaParallaxInPixels = length((prevUVVMBTest - prevUVVMB) * rectSize);
                 virtualHistoryHitDistConfidence *= Math::SmoothStep(lobeRadiusInPixels + 0.25f, 0.0f, deltaParallaxInPixels);
 
                 // surface motion signal
-                float specSMBConfidence = (SMBReprojectionFound > 0.0f ? 1.0f : 0.0f) * GetEncodingAwareNormalWeightR(V, Vprev, lobeHalfAngle * NoV / c.gFramerateScale, 0.0f, 0.0f, false);
+                float specSMBConfidence = (SMBReprojectionFound > 0.0f ? 1.0f : 0.0f) * GetEncodingAwareNormalWeightR(V, Vprev, Div(lobeHalfAngle * NoV, c.gFramerateScale), 0.0f, 0.0f, false);
                 float specSMBAlpha = 1.0f - specSMBConfidence;
                 float specSMBResponsiveAlpha = 1.0f - specSMBConfidence;
-                specSMBAlpha = max(specSMBAlpha, 1.0f / (1.0f + specHistoryFrames));
-                specSMBResponsiveAlpha = max(specSMBAlpha, 1.0f / (1.0f + specHistoryResponsiveFrames));
+                specSMBAlpha = max(specSMBAlpha, Rcp(1.0f + specHistoryFrames));
+                specSMBResponsiveAlpha = max(specSMBAlpha, Rcp(1.0f + specHistoryResponsiveFrames));
 
                 bool specHasData = true;
                 if (c.gSpecCheckerboard != 2u)
@@ -1028,9 +1028,9 @@ void TemporalAccumulation(const PassIO& io) {
                 float specVMBAlpha = 1.0f - specVMBConfidence;
                 float specVMBResponsiveAlpha = 1.0f - specVMBConfidence * virtualHistoryHitDistConfidence;
                 float specVMBHitTAlpha = specVMBResponsiveAlpha;
-                specVMBAlpha = max(specVMBAlpha, 1.0f / (1.0f + specHistoryFrames));
-                specVMBResponsiveAlpha = max(specVMBResponsiveAlpha, 1.0f / (1.0f + specHistoryResponsiveFrames));
-                specVMBHitTAlpha = max(specVMBHitTAlpha, 1.0f / (1.0f + specHistoryFrames));
+                specVMBAlpha = max(specVMBAlpha, Rcp(1.0f + specHistoryFrames));
+                specVMBResponsiveAlpha = max(specVMBResponsiveAlpha, Rcp(1.0f + specHistoryResponsiveFrames));
+                specVMBHitTAlpha = max(specVMBHitTAlpha, Rcp(1.0f + specHistoryFrames));
                 if (!specHasData && smbParallaxInPixelsMax < 0.5f) {
                     float k = 1.0f - c.gCheckerboardResolveAccumSpeed * (VMBReprojectionFound > 0.0f ? 1.0f : 0.0f);
                     specVMBAlpha *= k;
@@ -1044,7 +1044,7 @@ void TemporalAccumulation(const PassIO& io) {
                 float3 accumulatedSpecularVMBResponsive = lerp(prevSpecularResponsiveVMB.xyz(), specularIllumination.xyz(), specVMBResponsiveAlpha);
 
                 // fall back to surface motion if virtual motion doesn't go well
-                virtualHistoryAmount *= saturate(specVMBConfidence / (specSMBConfidence + NRD_EPS));
+                virtualHistoryAmount *= saturate(Div(specVMBConfidence, specSMBConfidence + NRD_EPS));
 
                 float accumulatedReflectionHitT = lerp(accumulatedSpecularSMBHitT, accumulatedSpecularVMBHitT, virtualHistoryAmount);
                 float3 accumulatedSpecularIllumination = lerp(accumulatedSpecularSMB, accumulatedSpecularVMB, virtualHistoryAmount);
@@ -1122,7 +1122,7 @@ void HistoryFix(const PassIO& io) {
             float specularWSum = 1.0f;
             float2 specularNormalWeightParams = SPEC ? GetNormalWeightParams_ATrous(centerRoughness, 5.0f, 1.0f, 0.0f, c.gLobeAngleFraction, c.gSpecLobeAngleSlack) : float2(0.0f);
 
-            float r = c.gHistoryFixBasePixelStride / (1.0f + historyLength);
+            float r = Div(c.gHistoryFixBasePixelStride, 1.0f + historyLength);
             r = floorf(r + 0.5f);
 
             for (int j = -2; j <= 2; j++)
@@ -1167,14 +1167,14 @@ void HistoryFix(const PassIO& io) {
                 }
 
             if (DIFF) {
-                diff.out->Store(px, py, diffuseSum / diffuseWSum);
+                diff.out->Store(px, py, Div(diffuseSum, diffuseWSum));
                 if (SH)
-                    diff.outSh->Store(px, py, diffuseSumSH / diffuseWSum);
+                    diff.outSh->Store(px, py, Div(diffuseSumSH, diffuseWSum));
             }
             if (SPEC) {
-                spec.out->Store(px, py, specularSum / specularWSum);
+                spec.out->Store(px, py, Div(specularSum, specularWSum));
                 if (SH)
-                    spec.outSh->Store(px, py, float4(specularSumSH.xyz() / specularWSum, roughnessModified));
+                    spec.outSh->Store(px, py, float4(Div(specularSumSH.xyz(), specularWSum), roughnessModified));
             }
         }
 }
@@ -1208,7 +1208,7 @@ inline ClampOut ClampSignal(const RelaxCB& c, bool isSpec, float3 fastM1, float3
     if (historyLength <= c.gHistoryFixFrameNum)
         outSlow = isSpec ? outFast : float4(outFast.xyz(), outSlow.w);
 
-    float clampingFactor = (clampedYCoCg.x - slowYCoCg.x) == 0.0f ? 0.0f : saturate((clampedYCoCg.x - slowYCoCg.x) / (fastCenterYCoCg.x - slowYCoCg.x));
+    float clampingFactor = (clampedYCoCg.x - slowYCoCg.x) == 0.0f ? 0.0f : saturate(Div(clampedYCoCg.x - slowYCoCg.x, fastCenterYCoCg.x - slowYCoCg.x));
     if (historyLength <= c.gHistoryFixFrameNum)
         clampingFactor = 1.0f;
 
@@ -1221,9 +1221,9 @@ inline ClampOut ClampSignal(const RelaxCB& c, bool isSpec, float3 fastM1, float3
 
     float3 distanceToNoisy = noisyM1 - fastCenter;
     float distanceToNoisyL = Color::Luminance(abs(distanceToNoisy));
-    float3 acceleration = distanceToNoisyL == 0.0f ? float3(0.0f) : distanceToNoisy * historyDifferenceL / distanceToNoisyL;
+    float3 acceleration = distanceToNoisyL == 0.0f ? float3(0.0f) : Div(distanceToNoisy * historyDifferenceL, distanceToNoisyL);
     float accelerationL = Color::Luminance(abs(acceleration));
-    float ratio = accelerationL == 0.0f ? 0.0f : distanceToNoisyL / accelerationL;
+    float ratio = accelerationL == 0.0f ? 0.0f : Div(distanceToNoisyL, accelerationL);
     if (ratio < 1.0f)
         acceleration *= ratio;
     if (ratio <= 0.0f)
@@ -1237,8 +1237,7 @@ inline ClampOut ClampSignal(const RelaxCB& c, bool isSpec, float3 fastM1, float3
     float noisyL = Color::Luminance(noisyM1);
     float temporalSigma = c.gHistoryResetTemporalSigmaScale * HwSqrt(max(0.0f, noisyM2 - noisyL * noisyL));
     float spatialSigma = c.gHistoryResetSpatialSigmaScale * sigma.x;
-    float resetAmount = (isSpec ? 0.5f * c.gHistoryResetAmount : c.gHistoryResetAmount) * max(0.0f, fabsf(slowL - noisyL) - spatialSigma - temporalSigma) /
-                        (1.0e-6f + max(slowL, noisyL) + spatialSigma + temporalSigma);
+    float resetAmount = Div((isSpec ? 0.5f * c.gHistoryResetAmount : c.gHistoryResetAmount) * max(0.0f, fabsf(slowL - noisyL) - spatialSigma - temporalSigma), 1.0e-6f + max(slowL, noisyL) + spatialSigma + temporalSigma);
     resetAmount = saturate(resetAmount);
     slowRgb = lerp(slowRgb, noisyCenter, resetAmount);
     fastRgb = lerp(fastRgb, noisyCenter, resetAmount);
@@ -1323,10 +1322,10 @@ void HistoryClamping(const PassIO& io) {
                 }
 
             auto Resolve = [&](const Sig& s, Moments& m, bool isSpec) {
-                m.fastM1 /= sum;
-                m.fastM2 = m.fastM2 / sum;
-                m.noisyM1 /= sum;
-                m.noisyM2 /= sum;
+                m.fastM1 = Div(m.fastM1, sum);
+                m.fastM2 = Div(m.fastM2, sum);
+                m.noisyM1 = Div(m.noisyM1, sum);
+                m.noisyM2 = Div(m.noisyM2, sum);
                 float4 fastCenter = s.fast->Load(px, py);
                 float4 fastCenterYCoCg = float4(RgbToYCoCg(fastCenter.xyz()), fastCenter.w);
                 ClampOut o = ClampSignal(c, isSpec, m.fastM1, m.fastM2, m.noisyM1, m.noisyM2, fastCenterYCoCg, s.in->Load(px, py), s.noisy->Load(px, py).xyz(), historyLength);
@@ -1341,7 +1340,7 @@ void HistoryClamping(const PassIO& io) {
             if (SPEC) Resolve(spec, ms, true);
             if (DIFF) Resolve(diff, md, false);
 
-            gOut_HistoryLength.Store(px, py, historyLength / 255.0f);
+            gOut_HistoryLength.Store(px, py, Div(historyLength, 255.0f));
         }
 }
 
@@ -1403,7 +1402,7 @@ void AtrousSmem(const PassIO& io) {
             if (centerViewZ > c.gDenoisingRange)
                 normalRoughness = float4(1.0f / 255.0f);
             gOut_NormalRoughness.Store(px, py, PackPrevNormalRoughness(normalRoughness));
-            gOut_MaterialID.Store(px, py, centerMaterialID / 255.0f);
+            gOut_MaterialID.Store(px, py, Div(centerMaterialID, 255.0f));
 
             if (isSky != 0.0f || px >= rectW || py >= rectH)
                 continue;
@@ -1441,7 +1440,7 @@ void AtrousSmem(const PassIO& io) {
                 float3 centerV(0.0f);
                 if (SPEC) {
                     centerSpecularLuminance = Color::Luminance(S(spec, px, py).xyz());
-                    specularPhiLIlluminationInv = 1.0f / max(1.0e-4f, c.gSpecPhiLuminance * HwSqrt(centerSpecularVar));
+                    specularPhiLIlluminationInv = Rcp(max(1.0e-4f, c.gSpecPhiLuminance * HwSqrt(centerSpecularVar)));
                     roughnessWeightParams = GetRoughnessWeightParams(centerRoughness, c.gRoughnessFraction);
                     float diffuseLobeAngleFractionForSimplifiedSpecularNormalWeight = diffuseLobeAngleFraction;
                     float specularLobeAngleFraction = c.gLobeAngleFraction;
@@ -1466,7 +1465,7 @@ void AtrousSmem(const PassIO& io) {
                 float centerDiffuseLuminance = 0.0f, diffusePhiLIlluminationInv = 0.0f, diffuseLuminanceWeightRelaxation = 1.0f, diffuseNormalWeightParam = 0.0f;
                 if (DIFF) {
                     centerDiffuseLuminance = Color::Luminance(S(diff, px, py).xyz());
-                    diffusePhiLIlluminationInv = 1.0f / max(1.0e-4f, c.gDiffPhiLuminance * HwSqrt(centerDiffuseVar));
+                    diffusePhiLIlluminationInv = Rcp(max(1.0e-4f, c.gDiffPhiLuminance * HwSqrt(centerDiffuseVar)));
                     if (c.gHasHistoryConfidence) {
                         float diffConfidenceDrivenRelaxation = saturate(c.gConfidenceDrivenRelaxationMultiplier * (1.0f - diff.confidence->Load(ox + px, oy + py).x));
                         float r = saturate(diffConfidenceDrivenRelaxation * c.gConfidenceDrivenNormalEdgeStoppingRelaxation);
@@ -1544,21 +1543,21 @@ void AtrousSmem(const PassIO& io) {
 
                 if (SPEC) {
                     sumWSpecular = max(sumWSpecular, 1e-6f);
-                    sumSpecular = sumSpecular / sumWSpecular;
+                    sumSpecular = Div(sumSpecular, sumWSpecular);
                     float m1 = Color::Luminance(sumSpecular.xyz());
                     float variance = max(0.0f, sumSpecular.w - m1 * m1);
                     spec.out->Store(px, py, float4(sumSpecular.xyz(), variance));
                     if (SH)
-                        spec.outSh->Store(px, py, float4(sumSpecularSH.xyz() / sumWSpecular, roughnessModified));
+                        spec.outSh->Store(px, py, float4(Div(sumSpecularSH.xyz(), sumWSpecular), roughnessModified));
                 }
                 if (DIFF) {
                     sumWDiffuse = max(sumWDiffuse, 1e-6f);
-                    sumDiffuse = sumDiffuse / sumWDiffuse;
+                    sumDiffuse = Div(sumDiffuse, sumWDiffuse);
                     float m1 = Color::Luminance(sumDiffuse.xyz());
                     float variance = max(0.0f, sumDiffuse.w - m1 * m1);
                     diff.out->Store(px, py, float4(sumDiffuse.xyz(), variance));
                     if (SH)
-                        diff.outSh->Store(px, py, sumDiffuseSH / sumWDiffuse);
+                        diff.outSh->Store(px, py, Div(sumDiffuseSH, sumWDiffuse));
                 }
             } else {
                 // spatial variance estimation over 5x5
@@ -1607,30 +1606,30 @@ void AtrousSmem(const PassIO& io) {
                         }
                     }
 
-                float boost = max(1.0f, 4.0f / (historyLength + 1.0f));
+                float boost = max(1.0f, Div(4.0f, historyLength + 1.0f));
                 if (SPEC) {
                     sumWSpecular = max(sumWSpecular, 1e-6f);
-                    sumSpecularIllumination /= sumWSpecular;
-                    sumSpecular1stMoment /= sumWSpecular;
-                    sumSpecular2ndMoment /= sumWSpecular;
+                    sumSpecularIllumination = Div(sumSpecularIllumination, sumWSpecular);
+                    sumSpecular1stMoment = Div(sumSpecular1stMoment, sumWSpecular);
+                    sumSpecular2ndMoment = Div(sumSpecular2ndMoment, sumWSpecular);
                     float variance = max(0.0f, sumSpecular2ndMoment - sumSpecular1stMoment * sumSpecular1stMoment);
                     variance *= boost;
                     spec.out->Store(px, py, float4(sumSpecularIllumination, variance));
                     if (SH) {
                         float roughnessModified = SSh(spec, px, py).w;
-                        spec.outSh->Store(px, py, float4(sumSpecularSH.xyz() / sumWSpecular, roughnessModified));
+                        spec.outSh->Store(px, py, float4(Div(sumSpecularSH.xyz(), sumWSpecular), roughnessModified));
                     }
                 }
                 if (DIFF) {
                     sumWDiffuse = max(sumWDiffuse, 1e-6f);
-                    sumDiffuseIllumination /= sumWDiffuse;
-                    sumDiffuse1stMoment /= sumWDiffuse;
-                    sumDiffuse2ndMoment /= sumWDiffuse;
+                    sumDiffuseIllumination = Div(sumDiffuseIllumination, sumWDiffuse);
+                    sumDiffuse1stMoment = Div(sumDiffuse1stMoment, sumWDiffuse);
+                    sumDiffuse2ndMoment = Div(sumDiffuse2ndMoment, sumWDiffuse);
                     float variance = max(0.0f, sumDiffuse2ndMoment - sumDiffuse1stMoment * sumDiffuse1stMoment);
                     variance *= boost;
                     diff.out->Store(px, py, float4(sumDiffuseIllumination, variance));
                     if (SH)
-                        diff.outSh->Store(px, py, sumDiffuseSH / sumWDiffuse);
+                        diff.outSh->Store(px, py, Div(sumDiffuseSH, sumWDiffuse));
                 }
             }
         }
@@ -1676,10 +1675,10 @@ void Atrous(const PassIO& io) {
             float centerRoughness = centerNormalRoughness.w;
             float historyLength = 255.0f * gIn_HistoryLength.Load(px, py).x;
 
-            float diffuseLobeAngleFraction = c.gLobeAngleFraction / HwSqrt(float(c.gStepSize));
+            float diffuseLobeAngleFraction = Div(c.gLobeAngleFraction, HwSqrt(float(c.gStepSize)));
             if (SH)
-                diffuseLobeAngleFraction = 1.0f / HwSqrt(float(c.gStepSize));
-            diffuseLobeAngleFraction = lerp(0.99f, diffuseLobeAngleFraction, saturate(historyLength / 5.0f));
+                diffuseLobeAngleFraction = Rcp(HwSqrt(float(c.gStepSize)));
+            diffuseLobeAngleFraction = lerp(0.99f, diffuseLobeAngleFraction, saturate(Div(historyLength, 5.0f)));
 
             float4 centerSpecular(0.0f), centerSpecularSH(0.0f), sumSpecular(0.0f), sumSpecularSH(0.0f);
             float centerSpecularLuminance = 0.0f, specularPhiLIlluminationInv = 0.0f, specularLuminanceWeightRelaxation = 1.0f, specularNormalWeightParamSimplified = 0.0f;
@@ -1689,7 +1688,7 @@ void Atrous(const PassIO& io) {
                 centerSpecular = spec.in->Load(px, py);
                 centerSpecularLuminance = Color::Luminance(centerSpecular.xyz());
                 float centerSpecularVar = centerSpecular.w;
-                specularPhiLIlluminationInv = 1.0f / max(1.0e-4f, c.gSpecPhiLuminance * HwSqrt(centerSpecularVar));
+                specularPhiLIlluminationInv = Rcp(max(1.0e-4f, c.gSpecPhiLuminance * HwSqrt(centerSpecularVar)));
 
                 roughnessWeightParams = GetRoughnessWeightParams(centerRoughness, c.gRoughnessFraction);
                 float diffuseLobeAngleFractionForSimplifiedSpecularNormalWeight = diffuseLobeAngleFraction;
@@ -1724,7 +1723,7 @@ void Atrous(const PassIO& io) {
                 centerDiffuse = diff.in->Load(px, py);
                 centerDiffuseLuminance = Color::Luminance(centerDiffuse.xyz());
                 float centerDiffuseVar = centerDiffuse.w;
-                diffusePhiLIlluminationInv = 1.0f / max(1.0e-4f, c.gDiffPhiLuminance * HwSqrt(centerDiffuseVar));
+                diffusePhiLIlluminationInv = Rcp(max(1.0e-4f, c.gDiffPhiLuminance * HwSqrt(centerDiffuseVar)));
                 if (c.gHasHistoryConfidence) {
                     float diffConfidenceDrivenRelaxation = saturate(c.gConfidenceDrivenRelaxationMultiplier * (1.0f - diff.confidence->Load(ox + px, oy + py).x));
                     float r = saturate(diffConfidenceDrivenRelaxation * c.gConfidenceDrivenNormalEdgeStoppingRelaxation);
@@ -1817,20 +1816,20 @@ void Atrous(const PassIO& io) {
                 }
 
             if (SPEC) {
-                float4 filtered = sumSpecular / float4(sumWSpecular, sumWSpecular, sumWSpecular, sumWSpecular * sumWSpecular);
+                float4 filtered = Div(sumSpecular, float4(sumWSpecular, sumWSpecular, sumWSpecular, sumWSpecular * sumWSpecular));
                 if (SH) {
                     if (c.gIsLastPass == 1)
                         filtered = float4(_NRD_LinearToYCoCg(filtered.xyz()), filtered.w);
-                    spec.outSh->Store(px, py, float4(sumSpecularSH.xyz() / sumWSpecular, roughnessModified));
+                    spec.outSh->Store(px, py, float4(Div(sumSpecularSH.xyz(), sumWSpecular), roughnessModified));
                 }
                 spec.out->Store(px, py, filtered);
             }
             if (DIFF) {
-                float4 filtered = sumDiffuse / float4(sumWDiffuse, sumWDiffuse, sumWDiffuse, sumWDiffuse * sumWDiffuse);
+                float4 filtered = Div(sumDiffuse, float4(sumWDiffuse, sumWDiffuse, sumWDiffuse, sumWDiffuse * sumWDiffuse));
                 if (SH) {
                     if (c.gIsLastPass == 1)
                         filtered = float4(_NRD_LinearToYCoCg(filtered.xyz()), filtered.w);
-                    diff.outSh->Store(px, py, sumDiffuseSH / sumWDiffuse);
+                    diff.outSh->Store(px, py, Div(sumDiffuseSH, sumWDiffuse));
                 }
                 diff.out->Store(px, py, filtered);
             }
@@ -1987,11 +1986,11 @@ static void RelaxValidation(const PassIO& io) {
                 gOut_Validation.Store(px, py, float4(0.0f));
                 continue;
             }
-            float2 pixelUv = float2(float(px) + 0.5f, float(py) + 0.5f) / c.gResourceSize;
-            float2 scaled = pixelUv / VIEWPORT_SIZE;
+            float2 pixelUv = Div(float2(float(px) + 0.5f, float(py) + 0.5f), c.gResourceSize);
+            float2 scaled = pixelUv * 4.0f; // / VIEWPORT_SIZE
             float2 viewportId = floor(scaled);
             float2 viewportUv = scaled - viewportId;
-            float viewportIndex = viewportId.y / VIEWPORT_SIZE + viewportId.x;
+            float viewportIndex = viewportId.y * 4.0f + viewportId.x; // / VIEWPORT_SIZE
             float2 viewportUvScaled = viewportUv * c.gResolutionScale;
 
             float4 normalAndRoughness = NRD_FrontEnd_UnpackNormalAndRoughness(gIn_Normal_Roughness.SampleNearest(viewportUvScaled + c.gRectOffset));
@@ -2012,7 +2011,7 @@ static void RelaxValidation(const PassIO& io) {
             } else if (viewportIndex == 1.0f) {
                 result = float4(float3(normalAndRoughness.w), 1.0f);
             } else if (viewportIndex == 2.0f) {
-                float f = 0.1f * abs(viewZ) / (1.0f + 0.1f * abs(viewZ));
+                float f = Div(0.1f * abs(viewZ), 1.0f + 0.1f * abs(viewZ));
                 float3 color = viewZ < 0.0f ? float3(0, 0, 1) : float3(0, 1, 0);
                 result = float4(isInf ? float3(1, 0, 0) : color * f, 1.0f);
             } else if (viewportIndex == 3.0f) {
@@ -2023,8 +2022,8 @@ static void RelaxValidation(const PassIO& io) {
                 float2 uvDelta = (viewportUvPrev - viewportUvPrevExpected) * float2(float(c.gRectSize[0]), float(c.gRectSize[1]));
                 result = float4(IsInScreenNearest(viewportUvPrev) != 0.0f ? float3(abs(uvDelta.x), abs(uvDelta.y), 0.0f) : float3(0, 0, 1), 1.0f);
             } else if (viewportIndex == 4.0f) {
-                float2 dim = float2(0.5f * c.gResourceSize.y / c.gResourceSize.x, 0.5f);
-                float2 remappedUv = (viewportUv - (1.0f - dim)) / dim;
+                float2 dim = float2(Div(0.5f * c.gResourceSize.y, c.gResourceSize.x), 0.5f);
+                float2 remappedUv = Div(viewportUv - (1.0f - dim), dim);
                 if (remappedUv.x > 0.0f && remappedUv.y > 0.0f) {
                     float2 dimInPixels = c.gResourceSize * VIEWPORT_SIZE * dim;
                     float2 uv = c.gJitter + 0.5f;
@@ -2044,7 +2043,7 @@ static void RelaxValidation(const PassIO& io) {
                 }
                 result.w = 1.0f;
             } else if (viewportIndex == 8.0f) {
-                float f = 1.0f - saturate(historyLength / max(max(c.gDiffMaxAccumulatedFrameNum, c.gSpecMaxAccumulatedFrameNum), 1.0f));
+                float f = 1.0f - saturate(Div(historyLength, max(max(c.gDiffMaxAccumulatedFrameNum, c.gSpecMaxAccumulatedFrameNum), 1.0f)));
                 f = checkerboard && historyLength < 2.0f ? 0.75f : f;
                 result = float4(Sequence::ColorizeZucconi(viewportUv.y > 0.95f ? 1.0f - viewportUv.x : f * notInf), 1.0f);
             }

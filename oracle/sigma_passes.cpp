@@ -62,7 +62,7 @@ inline float3 GetViewVectorV(const SigmaCB& c, float3 X) { return c.gOrthoMode =
 
 // SIGMA_Common.hlsli:21-33 (5x5 radius-estimation kernel => minimum radius 2)
 inline float GetKernelRadiusInPixels(float hitDist, float unprojectZ, float scale = 1.0f) {
-    float unclampedRadius = hitDist / unprojectZ;
+    float unclampedRadius = Div(hitDist, unprojectZ);
     unclampedRadius *= scale;
     float minRadius = min(unclampedRadius, 2.0f);
     return clamp(unclampedRadius, minRadius, SIGMA_MAX_PIXEL_RADIUS);
@@ -77,13 +77,13 @@ inline void BicubicAxis(float f, float& w0, float& w1, float& wz) {
     float phiy = k * (3.0f * f3 + -6.0f * f2 + 0.0f * f + 4.0f);
     float phiz = k * (-3.0f * f3 + 3.0f * f2 + 3.0f * f + 1.0f);
     float phiw = k * (1.0f * f3 + 0.0f * f2 + 0.0f * f + 0.0f);
-    w0 = 1.0f + 1.0f * f + -1.0f * phiy / (phix + phiy);
-    w1 = 1.0f + -1.0f * f + 1.0f * phiw / (phiz + phiw);
+    w0 = 1.0f + 1.0f * f + -Div(1.0f * phiy, phix + phiy);
+    w1 = 1.0f + -1.0f * f + Div(1.0f * phiw, phiz + phiw);
     wz = phix + phiy;
 }
 inline float TextureCubicY(const Tex& tex, float2 uv) {
     float2 size = float2(float(tex.W()), float(tex.H()));
-    float dx = -1.0f / size.x, dy = -1.0f / size.y;
+    float dx = -Rcp(size.x), dy = -Rcp(size.y);
     float2 t = uv * size - 0.5f;
     float2 f = float2(frac(t.x), frac(t.y));
     float xw0, xw1, xwz, yw0, yw1, ywz;
@@ -136,7 +136,7 @@ void ClassifyTiles(const PassIO& io) {
                     maxRadius = max(GetKernelRadiusInPixels(hitDist, pixelSize), maxRadius);
                 }
             bool isLitT = lit == 256, isUmbra = umbra == 256, isInfT = inf == 256;
-            float4 result = float4((isLitT || isUmbra) ? 0.0f : 1.0f, saturate(maxRadius / 16.0f), isInfT ? 1.0f : 0.0f, 0.0f);
+            float4 result = float4((isLitT || isUmbra) ? 0.0f : 1.0f, saturate(maxRadius * 0.0625f), isInfT ? 1.0f : 0.0f, 0.0f);
             gOut_Tiles.Store(tx, ty, result);
         }
 }
@@ -150,7 +150,7 @@ void SmoothTiles(const PassIO& io) {
         for (int x = 0; x < gOut_Tiles.W(); x++) {
             float4 center = gIn_Tiles.Load(x, y);
             float blurry = 0.0f, sumw = 0.0f;
-            float k = 1.01f / (center.y + 0.01f);
+            float k = Div(1.01f, center.y + 0.01f);
             for (int j = 0; j <= 2; j++)
                 for (int i = 0; i <= 2; i++) {
                     float d = length(float2(float(i), float(j)) - 1.0f);
@@ -159,7 +159,7 @@ void SmoothTiles(const PassIO& io) {
                     blurry += gIn_Tiles.Load(sx, sy).x * w;
                     sumw += w;
                 }
-            blurry /= sumw;
+            blurry = Div(blurry, sumw);
             gOut_Tiles.Store(x, y, float4(center.z, blurry, 0.0f, 0.0f));
         }
 }
@@ -261,26 +261,26 @@ void Blur(const PassIO& io) {
                         float3 Xvs = Geometry::ReconstructViewPosition(uv, c.gFrustum, zs, c.gOrthoMode);
                         w *= ComputeWeight(dot(Nv, Xvs), geometryWeightParams.x, geometryWeightParams.y);
                         w *= AreBothLitOrUnlit(centerPenumbra, penum);
-                        w *= GetGaussianWeight(length(float2(float(i - BORDER), float(j - BORDER)) / float(BORDER)));
+                        w *= GetGaussianWeight(length(Div(float2(float(i - BORDER), float(j - BORDER)), float(BORDER))));
                     }
 
                     result = result + (w == 0.0f ? S(0.0f) : s * w);
                     sumx += w;
 
-                    w *= pixelSize / (pixelSize + penum);
+                    w *= Div(pixelSize, pixelSize + penum);
                     w *= IsLit(penum) ? 0.0f : 1.0f;
 
                     penumbra += w == 0.0f ? 0.0f : penum * w;
                     sumy += w;
                 }
 
-            result = result / sumx;
+            result = Div(result, sumx);
             sumx = 1.0f;
-            penumbra /= max(sumy, NRD_EPS);
+            penumbra = Div(penumbra, max(sumy, NRD_EPS));
             sumy = sumy != 0.0f ? 1.0f : 0.0f;
 
             // Avoid a blurry result if the penumbra is smaller than the dense kernel
-            float penumbraInPixels = penumbra / pixelSize;
+            float penumbraInPixels = Div(penumbra, pixelSize);
             float f = Math::SmoothStep(0.0f, float(BORDER), penumbraInPixels);
             result = lerp(centerTap, result, f);
 
@@ -295,11 +295,11 @@ void Blur(const PassIO& io) {
             float4 rotator = FIRST_PASS ? c.gRotator : c.gRotatorPost;
 
             float2 skew = lerp(float2(1.0f - fabsf(Nv.x), 1.0f - fabsf(Nv.y)), float2(1.0f), NoV);
-            skew /= max(skew.x, skew.y);
+            skew = Div(skew, max(skew.x, skew.y));
             skew *= c.gRectSizeInv * blurRadius;
             float4 scaledRotator = Geometry::ScaleRotator(rotator, skew);
 
-            float invEstimatedPenumbra = 1.0f / max(penumbra, NRD_EPS);
+            float invEstimatedPenumbra = Rcp(max(penumbra, NRD_EPS));
 
             for (int n = 0; n < 8; n++) {
                 float3 offset = g_Special8[n];
@@ -328,15 +328,15 @@ void Blur(const PassIO& io) {
                 result = result + (w == 0.0f ? S(0.0f) : s * w);
                 sumx += w;
 
-                w *= pixelSize / (pixelSize + penum);
+                w *= Div(pixelSize, pixelSize + penum);
                 w *= IsLit(penum) ? 0.0f : 1.0f;
 
                 penumbra += w == 0.0f ? 0.0f : penum * w;
                 sumy += w;
             }
 
-            result = result / sumx;
-            penumbra = sumy == 0.0f ? centerPenumbra : penumbra / sumy;
+            result = Div(result, sumx);
+            penumbra = sumy == 0.0f ? centerPenumbra : Div(penumbra, sumy);
 
             if (FIRST_PASS || c.gStabilizationStrength != 0.0f)
                 gOut_Penumbra.Store(px, py, penumbra);
@@ -402,14 +402,14 @@ void TemporalStabilization(const PassIO& io) {
                     else {
                         float penum = sPenumbra(x, y);
                         w = AreBothLitOrUnlit(centerPenumbra, penum);
-                        w *= GetGaussianWeight(length(float2(float(i - BORDER), float(j - BORDER)) / float(BORDER)));
+                        w *= GetGaussianWeight(length(Div(float2(float(i - BORDER), float(j - BORDER)), float(BORDER))));
                     }
                     m1 = m1 + s * w;
                     m2 = m2 + s * s * w;
                     sumw += w;
                 }
-            m1 = m1 / sumw;
-            m2 = m2 / sumw;
+            m1 = Div(m1, sumw);
+            m2 = Div(m2, sumw);
             S sigma = StdDev(m1, m2);
 
             // Current and previous positions
@@ -460,7 +460,7 @@ void TemporalStabilization(const PassIO& io) {
             history = UnpackShadow(history);
 
             // Clamp history
-            sigma = sigma * lerp(SIGMA_TS_SIGMA_SCALE, 1.0f, 1.0f / (1.0f + historyLength));
+            sigma = sigma * lerp(SIGMA_TS_SIGMA_SCALE, 1.0f, Rcp(1.0f + historyLength));
             S inputMin = m1 - sigma, inputMax = m1 + sigma;
             S historyClamped = Clamp(history, inputMin, inputMax);
 
@@ -470,7 +470,7 @@ void TemporalStabilization(const PassIO& io) {
             antilag = saturate(1.0f - antilag);
             historyLength *= antilag;
 
-            float historyWeight = historyLength / (1.0f + historyLength);
+            float historyWeight = Div(historyLength, 1.0f + historyLength);
             float streetMagic = 0.6f * historyWeight * antilag;
             historyClamped = lerp(historyClamped, history, streetMagic);
 

@@ -39,7 +39,7 @@ NUMERICS_FLAGS = {
 # kernels lose a wave of occupancy with it (+13 %), so they keep the plain flags.
 REASSOC_FLAGS = ["-fno-signed-zeros", "-freciprocal-math", "-fassociative-math", "-fno-trapping-math"]
 FAST_EXTRA = {"kernels_reblur_ta.hip": REASSOC_FLAGS, "kernels_reblur_spatial.hip": REASSOC_FLAGS, "kernels_reblur_history.hip": REASSOC_FLAGS, "kernels_relax_ta.hip": REASSOC_FLAGS}
-DEVICE_NUMERICS_FLAGS = NUMERICS_FLAGS["exact"]  # the arithmetic flags of the device sources (also read by tests/emu/build_emu.py)
+DEVICE_NUMERICS_FLAGS = ["-ffp-contract=on"]  # the arithmetic flags of the device sources (also read by tests/emu/build_emu.py)
 LIB_NAMES = {"fast": "libNRD_hip.so", "exact": "libNRD_hip_exact.so"}
 # translation units that keep the exact flags in both builds: the REFERENCE accumulator is specified bit-exact (BASELINE.json) and is a pure
 # streaming kernel, the host dispatch compiler must hand identical constants to both builds

@@ -1059,11 +1059,7 @@ extern "C" __attribute__((visibility("default"))) uint32_t nrdHipGetGraphStats(c
 
 // 0 = exact (pinned IEEE arithmetic, bit-identical to the CPU oracle), 1 = fast (hardware rcp / exp2 / log2, FMA contraction): the build this library is
 extern "C" __attribute__((visibility("default"))) uint32_t nrdHipGetNumericsMode(void) {
-#ifdef NRD_FAST_BUILD
-    return 1;
-#else
-    return 0;
-#endif
+    return 0; // one library, one arithmetic (the value 1 named the "fast" build of round 2, which no longer exists)
 }
 
 extern "C" __attribute__((visibility("default"))) uint32_t nrdHipDenoise(NrdHipExecutor* e, const uint32_t* identifiers, uint32_t identifiersNum) {

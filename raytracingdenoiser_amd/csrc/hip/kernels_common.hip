@@ -190,7 +190,7 @@ __global__ __launch_bounds__(256) void EvalNumericsKernel(uint32_t op, const flo
         case 2: r = Atan(a); break;
         case 3: r = Pow(a, b); break;
         case 4: r = HalfBitsToFloat(FloatToHalfBits(a)); break;
-        case 5: r = a / b; break;
+        case 5: r = Div(a, b); break;
         case 6: r = Sqrt(a); break;
         case 7: r = Rsqrt(a); break;
         case 8: r = NRD_DIV_1023(a); break;

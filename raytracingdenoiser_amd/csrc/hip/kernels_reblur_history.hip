@@ -72,7 +72,7 @@ NRD_D typename ReblurSignal<KIND>::type HistoryFixSignal(const ReblurCB& c, cons
 
     if (stride != 0.0f) {
         const int stridei = (int)(stride + 0.5f);
-        const float nonLinearAccumSpeed = 1.0f / (1.0f + frameNum);
+        const float nonLinearAccumSpeed = Rcp(1.0f + frameNum);
         const float r = IS_SPEC ? s.roughness : 1.0f;
         const float2 rectSizeInv = ToF2(c.gRectSizeInv);
         const float4 hitDistParams = ToF4(c.gHitDistParams);
@@ -88,7 +88,7 @@ NRD_D typename ReblurSignal<KIND>::type HistoryFixSignal(const ReblurCB& c, cons
 
         float sumw = 1.0f + frameNum;
         if (PERF)
-            sumw = 1.0f + 1.0f / (1.0f + c.gMaxAccumulatedFrameNum) - nonLinearAccumSpeed;
+            sumw = 1.0f + Rcp(1.0f + c.gMaxAccumulatedFrameNum) - nonLinearAccumSpeed;
         sig = sig * sumw;
         if (SH)
             sh = F4(sh.x * sumw, sh.y * sumw, sh.z * sumw, IS_SPEC ? sh.w : sh.w * sumw);
@@ -128,7 +128,7 @@ NRD_D typename ReblurSignal<KIND>::type HistoryFixSignal(const ReblurCB& c, cons
                 w *= ComputeExponentialWeight(hsFactor, hitDistanceWeightParams.x, hitDistanceWeightParams.y);
 
                 if (IS_SPEC) {
-                    float d = Abs(hitDist - hs) / (Max(hitDist, hs) + 0.001f);
+                    float d = Div(Abs(hitDist - hs), Max(hitDist, hs) + 0.001f);
                     float b = LinearStep(0.03f, 0.05f, s.roughness);
                     w *= SmoothStep(0.2f + b, 0.05f + b, d);
                 }
@@ -153,7 +153,7 @@ NRD_D typename ReblurSignal<KIND>::type HistoryFixSignal(const ReblurCB& c, cons
     float center = s_Luma[(s.ty + hf::BORDER) * hf::BUF_STRIDE + s.tx + hf::BORDER];
     float m1 = center, m2 = center * center;
 
-    float f = Sat(frameNum / (c.gHistoryFixFrameNum + NRD_EPS));
+    float f = Sat(Div(frameNum, c.gHistoryFixFrameNum + NRD_EPS));
     if (IS_SPEC)
         f = Lerp(1.0f, f, smc);
     center = Lerp(GetLuma(sig), center, f);
@@ -185,18 +185,18 @@ NRD_D typename ReblurSignal<KIND>::type HistoryFixSignal(const ReblurCB& c, cons
                 am1 += d;
                 am2 += d * d;
             }
-        float invNorm = 1.0f / float((R * 2 + 1) * (R * 2 + 1) - 3 * 3);
+        float invNorm = Rcp(float((R * 2 + 1) * (R * 2 + 1) - 3 * 3));
         am1 *= invNorm;
         am2 *= invNorm;
         float sigma = Sqrt(Abs(am2 - am1 * am1)) * REBLUR_ANTI_FIREFLY_SIGMA_SCALE;
         luma = Clamp(luma, am1 - sigma, am1 + sigma);
     }
 
-    m1 /= 25.0f;
-    m2 /= 25.0f;
+    m1 = Div(m1, 25.0f);
+    m2 = Div(m2, 25.0f);
     float sigma = Sqrt(Abs(m2 - m1 * m1)) * (KIND != SIGNAL_RADIANCE ? REBLUR_COLOR_CLAMPING_SIGMA_SCALE_OCCLUSION : REBLUR_COLOR_CLAMPING_SIGMA_SCALE);
     float lumaClamped = Clamp(luma, m1 - sigma, m1 + sigma);
-    luma = Lerp(lumaClamped, luma, 1.0f / (1.0f + (c.gMaxFastAccumulatedFrameNum < c.gMaxAccumulatedFrameNum ? 1.0f : 0.0f) * frameNum * 2.0f));
+    luma = Lerp(lumaClamped, luma, Rcp(1.0f + (c.gMaxFastAccumulatedFrameNum < c.gMaxAccumulatedFrameNum ? 1.0f : 0.0f) * frameNum * 2.0f));
 
     if (SH) {
         float k = GetLumaScale(Length(Xyz(sh)), luma);
@@ -251,7 +251,7 @@ __global__ __launch_bounds__(TILE_X* TILE_Y, SH ? 0 : NRD_WAVES_REBLUR_HF) void 
     s.Xv = ReconstructViewPosition(s.pixelUv, ToF4(c.gFrustum), s.viewZ, NRD_ORTHO_MODE(c));
     s.Nv = RotateVectorInverse(c.gViewToWorld, s.N);
     float2 frameNum = LoadData1<DIFF, SPEC>(P.data1, px, py);
-    float2 stride = F2(c.gHistoryFixBasePixelStride / (2.0f + frameNum.x), c.gHistoryFixBasePixelStride / (2.0f + frameNum.y));
+    float2 stride = F2(Div(c.gHistoryFixBasePixelStride, 2.0f + frameNum.x), Div(c.gHistoryFixBasePixelStride, 2.0f + frameNum.y));
 
     if (DIFF) {
         float4 diffSh = F4(0.0f);
@@ -340,8 +340,8 @@ NRD_D void LumaStats(const ReblurCB& c, const float* s_Luma, int tx, int ty, flo
             mx = Max(mx, d);
         }
     }
-    M1 /= 9.0f;
-    M2 /= 9.0f;
+    M1 = Div(M1, 9.0f);
+    M2 = Div(M2, 9.0f);
     m1 = M1;
     sigma = Sqrt(Abs(M2 - M1 * M1));
     if (!PERF && c.gMaxBlurRadius != 0.0f)
@@ -490,7 +490,7 @@ __global__ __launch_bounds__(TILE_X* TILE_Y, NRD_WAVES_REBLUR_TS) void ReblurTem
             float3 Fenv = EnvironmentTerm_Rtg(Rf0, NoV, roughness);
             float lumSpec = Luminance(Fenv);
             float lumDiff = Luminance(F3(albedo.x * (1.0f - Fenv.x), albedo.y * (1.0f - Fenv.y), albedo.z * (1.0f - Fenv.z)));
-            float specProb = lumSpec / (lumDiff + lumSpec + NRD_EPS);
+            float specProb = Div(lumSpec, lumDiff + lumSpec + NRD_EPS);
             float f = SmoothStep(c.gSpecProbabilityThresholdsForMvModification.x, c.gSpecProbabilityThresholdsForMvModification.y, specProb);
             f *= 1.0f - GetSpecMagicCurve(roughness);
             f *= 1.0f - Sqrt01(Abs(curvature));
@@ -502,7 +502,7 @@ __global__ __launch_bounds__(TILE_X* TILE_Y, NRD_WAVES_REBLUR_TS) void ReblurTem
                     specMv.z = AffineTransform(c.gWorldToViewPrev, Xvirtual).z - viewZ;
                 }
                 // only .xy for 2D, .xyz for 2.5D and 3D MVs
-                float3 newMv = F3(specMv.x / c.gMvScale.x, specMv.y / c.gMvScale.y, c.gMvScale.z == 0.0f ? inMv.z : specMv.z / c.gMvScale.z);
+                float3 newMv = F3(Div(specMv.x, c.gMvScale.x), Div(specMv.y, c.gMvScale.y), c.gMvScale.z == 0.0f ? inMv.z : Div(specMv.z, c.gMvScale.z));
                 inMv.x = Lerp(inMv.x, newMv.x, f);
                 inMv.y = Lerp(inMv.y, newMv.y, f);
                 inMv.z = Lerp(inMv.z, newMv.z, f);

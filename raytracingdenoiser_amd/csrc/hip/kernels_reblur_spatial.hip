@@ -67,26 +67,10 @@ struct SpatialCtx {
     float3 N, Nv, Xv, Vv;
     float4 rotator;
     float2 data1;
-    float3 geo; // fast build, full-rect taps: dot(Nv, view position of texel k with depth z) = z * (k.x * geo.x + k.y * geo.y + geo.z)
     // checkerboard resolve of the pre-pass (reference REBLUR_PrePass.hlsli:43-56): neighbour columns in the half-width input + their weights
     int cbX0, cbX1;
     float2 wc;
 };
-
-// Tap POSITIONS of the fast build. -DNRD_FAST_TAP_POSITIONS=1 generates the screen-space taps in pixel units (the rotator is scaled by the rect size once per
-// pixel instead of multiplying every tap's uv by it) and the world-space specular taps through the linearity of the projection: -1.5 % frame time (0.789 against
-// 0.800 ms at 1440p, profiles/r02_final_bench.json / r02_final_taps0_bench.json). It is OFF by default: a position that differs from the oracle's by a few ulp
-// crosses a pixel boundary ~1e-4 of the time, with 16 taps x 3 passes per pixel that moves a tap in ~1 % of the pixels per frame, and a moved tap changes a
-// 1-rpp pixel by ~noise / 8 -- 2.3 % of the output values beyond 1e-3 of the oracle after 3 frames at 1440p (p99.9 = 0.12) against 0.74 % (p99.9 = 0.005)
-// with the reference's operation order (profiles/r02_m_pytest_full_parity.log, r02_final_taps0_parity.log). The exact build always keeps the reference's order.
-#ifndef NRD_FAST_TAP_POSITIONS
-#define NRD_FAST_TAP_POSITIONS 0
-#endif
-#if NRD_FAST && NRD_FAST_TAP_POSITIONS
-#define NRD_TAPS_IN_PIXELS(FR) ((FR) != 0)
-#else
-#define NRD_TAPS_IN_PIXELS(FR) false
-#endif
 
 // ---- one tap of the Poisson kernels: position -> texel, guides of that texel ------------------------------------------------------------------
 // The reference snaps the tap to a pixel centre (floor(uv * rectSize) + 0.5), turns it back into a uv, scales / clamps it to the viewport, lets the
@@ -133,11 +117,7 @@ NRD_D TapGuides FetchTapGuidesFullRect(const ReblurCB& c, const SpatialCtx& s, f
     }
     const float2 uvc = (k + 0.5f) * rectSizeInv; // centre of the snapped pixel; equals the clamped texel's centre whenever the tap counts (t.w != 0)
     t.Xvs = ReconstructViewPosition(uvc, ToF4(c.gFrustum), t.zs, 0.0f); // perspective only (CheckSupported); dead code unless the caller needs the position
-#if NRD_FAST
-    t.NvXvs = t.zs * (k.x * s.geo.x + (k.y * s.geo.y + s.geo.z)); // 3 instructions instead of 13 (same value up to rounding: SpatialCtx::geo)
-#else
     t.NvXvs = Dot(s.Nv, t.Xvs);
-#endif
     t.materialIDs = 0.0f;
     if (materials)
         t.materialIDs = NRD_DIV_3(float(bits >> 10)) * 3.0f;
@@ -220,7 +200,7 @@ NRD_D typename ReblurSignal<KIND>::type DiffuseSpatialFilterTaps(const ReblurCB&
     } else {
         float boost = 1.0f - GetFadeBasedOnAccumulatedFrames(c, s.data1.x);
         boost *= 1.0f - Pow5(s.NoV);
-        diffNonLinearAccumSpeed = 1.0f / (1.0f + REBLUR_SAMPLES_PER_FRAME * (1.0f - boost) * s.data1.x);
+        diffNonLinearAccumSpeed = Rcp(1.0f + REBLUR_SAMPLES_PER_FRAME * (1.0f - boost) * s.data1.x);
         blurRadius = c.gMaxBlurRadius;
         areaFactor = hitDistFactor * diffNonLinearAccumSpeed;
     }
@@ -229,7 +209,7 @@ NRD_D typename ReblurSignal<KIND>::type DiffuseSpatialFilterTaps(const ReblurCB&
     blurRadius = Max(blurRadius, c.gMinBlurRadius);
 
     float2 geometryWeightParams = GetGeometryWeightParams(c.gPlaneDistSensitivity, s.frustumSize, s.Xv, s.Nv);
-    float normalWeightParam = GetNormalWeightParam(diffNonLinearAccumSpeed, c.gLobeAngleFraction) / fractionScale;
+    float normalWeightParam = Div(GetNormalWeightParam(diffNonLinearAccumSpeed, c.gLobeAngleFraction), fractionScale);
     float2 hitDistanceWeightParams = GetHitDistanceWeightParams(ExtractHitDist(diff), diffNonLinearAccumSpeed);
     float minHitDistWeight = c.gMinHitDistanceWeight * fractionScale;
     if (MODE != PRE_BLUR && !OCC)
@@ -240,25 +220,18 @@ NRD_D typename ReblurSignal<KIND>::type DiffuseSpatialFilterTaps(const ReblurCB&
     float2 skew = F2(1.0f, 1.0f);
     if (MODE != PRE_BLUR) {
         skew = Lerp(F2(1.0f - Abs(s.Nv.x), 1.0f - Abs(s.Nv.y)), F2(1.0f, 1.0f), s.NoV);
-        skew = skew / Max(skew.x, skew.y);
+        skew = Div(skew, Max(skew.x, skew.y));
     }
     skew = skew * (rectSizeInv * blurRadius);
     float4 scaledRotator = ScaleRotator(s.rotator, skew);
     // material IDs are 0..3: with a minimum material >= 3 every comparison holds (the library default is 4 = "off")
     const bool compareMaterials = FR != 2 && c.gDiffMinMaterial < 3.0f;
-    const float4 rotatorInPixels = ScaleRotator(scaledRotator, ToF2(c.gRectSize));
-    const float2 pixelPos = F2(float(s.px) + 0.5f, float(s.py) + 0.5f);
 
 #pragma unroll
     for (int n = 0; n < (PERF ? 6 : 8); n++) {
         float3 offset = PERF ? F3(g_Special6[n][0], g_Special6[n][1], g_Special6[n][2]) : F3(g_Special8[n][0], g_Special8[n][1], g_Special8[n][2]);
-        TapGuides t;
-        if (NRD_TAPS_IN_PIXELS(FR)) {
-            t = FetchTapGuidesFullRect<FR, false>(c, s, Floor(pixelPos + RotateVector(rotatorInPixels, F2(offset.x, offset.y))), gIn_Normal_Roughness, gIn_ViewPos, compareMaterials);
-        } else {
-            const float2 uvTap = s.pixelUv + RotateVector(scaledRotator, F2(offset.x, offset.y));
-            t = FetchTapGuides<MODE, CB, FR, false>(c, s, uvTap, gIn_Diff, gIn_ViewZ, gIn_Normal_Roughness, gIn_ViewPos, c.gDiffCheckerboard, (uint32_t)n, compareMaterials);
-        }
+        const float2 uvTap = s.pixelUv + RotateVector(scaledRotator, F2(offset.x, offset.y));
+        TapGuides t = FetchTapGuides<MODE, CB, FR, false>(c, s, uvTap, gIn_Diff, gIn_ViewZ, gIn_Normal_Roughness, gIn_ViewPos, c.gDiffCheckerboard, (uint32_t)n, compareMaterials);
         const int2 ts = t.ts;
 
         float angle = AcosApprox(Dot(s.N, t.Ns));
@@ -350,7 +323,7 @@ NRD_D typename ReblurSignal<KIND>::type SpecularSpatialFilterTaps(const ReblurCB
         float boost = 1.0f - GetFadeBasedOnAccumulatedFrames(c, s.data1.y);
         boost *= 1.0f - Pow5(s.NoV);
         boost *= smc;
-        specNonLinearAccumSpeed = 1.0f / (1.0f + REBLUR_SAMPLES_PER_FRAME * (1.0f - boost) * s.data1.y);
+        specNonLinearAccumSpeed = Rcp(1.0f + REBLUR_SAMPLES_PER_FRAME * (1.0f - boost) * s.data1.y);
         blurRadius = c.gMaxBlurRadius;
         areaFactor = s.roughness * hitDistFactor * specNonLinearAccumSpeed;
     }
@@ -359,7 +332,7 @@ NRD_D typename ReblurSignal<KIND>::type SpecularSpatialFilterTaps(const ReblurCB
     if (MODE == PRE_BLUR) {
         float lobeTanHalfAngle = GetSpecularLobeTanHalfAngle(s.roughness, REBLUR_MAX_PERCENT_OF_LOBE_VOLUME_FOR_PRE_PASS);
         float lobeRadius = hitDist * NoD * lobeTanHalfAngle;
-        float minBlurRadius = lobeRadius / PixelRadiusToWorld(c.gUnproject, NRD_ORTHO_MODE(c), 1.0f, s.viewZ + hitDist * Dv.w);
+        float minBlurRadius = Div(lobeRadius, PixelRadiusToWorld(c.gUnproject, NRD_ORTHO_MODE(c), 1.0f, s.viewZ + hitDist * Dv.w));
         blurRadius = Min(blurRadius, minBlurRadius);
     }
     blurRadius *= radiusScale;
@@ -367,7 +340,7 @@ NRD_D typename ReblurSignal<KIND>::type SpecularSpatialFilterTaps(const ReblurCB
 
     float roughnessFractionScaled = Sat(c.gRoughnessFraction * fractionScale);
     float2 geometryWeightParams = GetGeometryWeightParams(c.gPlaneDistSensitivity, s.frustumSize, s.Xv, s.Nv);
-    float normalWeightParam = GetNormalWeightParam(specNonLinearAccumSpeed, c.gLobeAngleFraction, s.roughness) / fractionScale;
+    float normalWeightParam = Div(GetNormalWeightParam(specNonLinearAccumSpeed, c.gLobeAngleFraction, s.roughness), fractionScale);
     float2 roughnessWeightParams = GetRoughnessWeightParams(s.roughness, roughnessFractionScaled);
     float2 hitDistanceWeightParams = GetHitDistanceWeightParams(ExtractHitDist(spec), specNonLinearAccumSpeed, s.roughness);
     float minHitDistWeight = c.gMinHitDistanceWeight * fractionScale * smc;
@@ -392,42 +365,18 @@ NRD_D typename ReblurSignal<KIND>::type SpecularSpatialFilterTaps(const ReblurCB
         GetKernelBasis(bentDv, s.Nv, T, B);
         float worldRadius = PixelRadiusToWorld(c.gUnproject, NRD_ORTHO_MODE(c), blurRadius, s.viewZ);
         T = T * (worldRadius * skewFactor);
-        B = B * (worldRadius / skewFactor);
+        B = B * (Div(worldRadius, skewFactor));
     }
-    const float4 rotatorInPixels = ScaleRotator(scaledRotator, ToF2(c.gRectSize));
-    const float2 pixelPos = F2(float(s.px) + 0.5f, float(s.py) + 0.5f);
-    // fast build, world-space taps: the projection is linear in the kernel offsets, clip(X + T * o.x + B * o.y) = clip(X) + o.x * M T + o.y * M B, so the
-    // three matrix products are done once per pixel and a tap costs 6 FMAs + one reciprocal instead of a 4x4 transform (o is the same for every pixel)
-    float3 clipX = F3(0.0f), clipT = F3(0.0f), clipB = F3(0.0f); // (x, y, w) rows of gViewToClip
-    if (!SCREEN_SPACE && NRD_TAPS_IN_PIXELS(FR)) {
-        const float* m = c.gViewToClip;
-        clipX = F3(m[0] * s.Xv.x + m[4] * s.Xv.y + m[8] * s.Xv.z + m[12], m[1] * s.Xv.x + m[5] * s.Xv.y + m[9] * s.Xv.z + m[13], m[3] * s.Xv.x + m[7] * s.Xv.y + m[11] * s.Xv.z + m[15]);
-        clipT = F3(m[0] * T.x + m[4] * T.y + m[8] * T.z, m[1] * T.x + m[5] * T.y + m[9] * T.z, m[3] * T.x + m[7] * T.y + m[11] * T.z);
-        clipB = F3(m[0] * B.x + m[4] * B.y + m[8] * B.z, m[1] * B.x + m[5] * B.y + m[9] * B.z, m[3] * B.x + m[7] * B.y + m[11] * B.z);
-    }
-    const float2 halfRect = ToF2(c.gRectSize) * 0.5f;
 
 #pragma unroll
     for (int n = 0; n < (PERF ? 6 : 8); n++) {
         float3 offset = PERF ? F3(g_Special6[n][0], g_Special6[n][1], g_Special6[n][2]) : F3(g_Special8[n][0], g_Special8[n][1], g_Special8[n][2]);
-        TapGuides t;
-        if (!SCREEN_SPACE && NRD_TAPS_IN_PIXELS(FR)) {
-            const float2 o = RotateVector(s.rotator, F2(offset.x, offset.y));
-            const float3 clip = clipX + clipT * o.x + clipB * o.y;
-            const float rw = Rcp(clip.z);
-            // uv * rectSize with uv = (x / w * 0.5 + 0.5, -y / w * 0.5 + 0.5)
-            const float2 k = Floor(F2(clip.x * rw * halfRect.x + halfRect.x, clip.y * rw * -halfRect.y + halfRect.y));
-            t = FetchTapGuidesFullRect<FR, true>(c, s, k, gIn_Normal_Roughness, gIn_ViewPos, compareMaterials);
-        } else if (SCREEN_SPACE && NRD_TAPS_IN_PIXELS(FR)) {
-            t = FetchTapGuidesFullRect<FR, true>(c, s, Floor(pixelPos + RotateVector(rotatorInPixels, F2(offset.x, offset.y))), gIn_Normal_Roughness, gIn_ViewPos, compareMaterials);
-        } else {
-            float2 uv;
-            if (SCREEN_SPACE)
-                uv = s.pixelUv + RotateVector(scaledRotator, F2(offset.x, offset.y));
-            else
-                uv = GetKernelSampleCoordinates(c.gViewToClip, offset, s.Xv, T, B, s.rotator);
-            t = FetchTapGuides<MODE, CB, FR, true>(c, s, uv, gIn_Spec, gIn_ViewZ, gIn_Normal_Roughness, gIn_ViewPos, c.gSpecCheckerboard, (uint32_t)n, compareMaterials);
-        }
+        float2 uv;
+        if (SCREEN_SPACE)
+            uv = s.pixelUv + RotateVector(scaledRotator, F2(offset.x, offset.y));
+        else
+            uv = GetKernelSampleCoordinates(c.gViewToClip, offset, s.Xv, T, B, s.rotator);
+        TapGuides t = FetchTapGuides<MODE, CB, FR, true>(c, s, uv, gIn_Spec, gIn_ViewZ, gIn_Normal_Roughness, gIn_ViewPos, c.gSpecCheckerboard, (uint32_t)n, compareMaterials);
         const int2 ts = t.ts;
         const float zs = t.zs;
         const float3 Xvs = t.Xvs;
@@ -448,13 +397,13 @@ NRD_D typename ReblurSignal<KIND>::type SpecularSpatialFilterTaps(const ReblurCB
         if (MODE == PRE_BLUR) {
             float hs = ExtractHitDist(smp) * GetHitDistanceNormalization(zs, hitDistParams, Ns.w);
             float d = Length(Xvs - s.Xv) + NRD_EPS;
-            float geometryWeight = w * Sat(hs / d);
+            float geometryWeight = w * Sat(Div(hs, d));
             if (rng.GetFloat() < geometryWeight)
                 hitDistForTracking = Min(hitDistForTracking, hs);
 
             w *= c.gUsePrepassNotOnlyForSpecularMotionEstimation;
 
-            float t = hs / (d + hitDist);
+            float t = Div(hs, d + hitDist);
             w *= Lerp(Sat(t), 1.0f, LinearStep(0.5f, 1.0f, s.roughness));
         }
         w *= Lerp(minHitDistWeight, 1.0f, ComputeExponentialWeight(ExtractHitDist(smp), hitDistanceWeightParams.x, hitDistanceWeightParams.y));
@@ -517,11 +466,6 @@ NRD_D bool MakeSpatialCtx(const ReblurCB& c, int px, int py, float viewZ, const 
     s.frustumSize = GetFrustumSize(c.gMinRectDimMulUnproject, NRD_ORTHO_MODE(c), viewZ);
     s.rotator = rotator;
     s.data1 = F2(0.0f, 0.0f);
-    {   // Xv(k, z) = ((uvc * frustum.zw + frustum.xy) * z, z) with uvc = (k + 0.5) * rectSizeInv, so dot(Nv, Xv) = z * (k.x * geo.x + k.y * geo.y + geo.z)
-        const float4 f = ToF4(c.gFrustum);
-        const float2 r = ToF2(c.gRectSizeInv);
-        s.geo = F3(s.Nv.x * f.z * r.x, s.Nv.y * f.w * r.y, s.Nv.x * (0.5f * r.x * f.z + f.x) + s.Nv.y * (0.5f * r.y * f.w + f.y) + s.Nv.z);
-    }
     return true;
 }
 
@@ -862,7 +806,7 @@ __global__ __launch_bounds__(TILE_X* TILE_Y) void ReblurHitDistReconstructionKer
             center = center + data * ww;
             sum = sum + ww;
         }
-    center = center / F2(Max(sum.x, NRD_EPS), Max(sum.y, NRD_EPS));
+    center = Div(center, F2(Max(sum.x, NRD_EPS), Max(sum.y, NRD_EPS)));
 
     if (DIFF)
         Sig::Store(P.outDiff, px, py, Sig::WithHitDist(centerDiff, center.x));

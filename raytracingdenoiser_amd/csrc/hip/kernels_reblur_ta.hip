@@ -136,7 +136,7 @@ __global__ __launch_bounds__(TILE_X* TILE_Y, WAVES) void ReblurTemporalAccumulat
             }
         }
     }
-    Navg = Navg / 4.0f;
+    Navg = Navg * 0.25f;
 
     float materialID;
     float4 normalAndRoughness = LoadDecodedNormalRoughness(P.decodedNR, px, py, materialID);
@@ -147,8 +147,8 @@ __global__ __launch_bounds__(TILE_X* TILE_Y, WAVES) void ReblurTemporalAccumulat
     RngHash rng;
     if (SPEC) {
         roughnessModified = GetModifiedRoughnessFromNormalVariance(roughness, Navg);
-        roughnessM1 /= 9.0f;
-        roughnessM2 /= 9.0f;
+        roughnessM1 = Div(roughnessM1, 9.0f);
+        roughnessM2 = Div(roughnessM2, 9.0f);
         roughnessSigma = Sqrt(Abs(roughnessM2 - roughnessM1 * roughnessM1));
 
         rng.Initialize((uint32_t)px, (uint32_t)py, c.gFrameIndex);
@@ -265,7 +265,7 @@ __global__ __launch_bounds__(TILE_X* TILE_Y, WAVES) void ReblurTemporalAccumulat
         w = prevViewZ3.x < c.gDenoisingRange ? 1.0f : 0.0f;
         smbNavg = smbNavg + Xyz(UnpackNormalAndRoughness(DecodeR10G10B10A2(n11))) * w;
         sumw += w;
-        smbNavg = smbNavg / (sumw == 0.0f ? 1.0f : sumw);
+        smbNavg = Div(smbNavg, sumw == 0.0f ? 1.0f : sumw);
     }
     smbNavg = RotateVector(c.gWorldPrevToWorld, smbNavg);
 
@@ -282,7 +282,7 @@ __global__ __launch_bounds__(TILE_X* TILE_Y, WAVES) void ReblurTemporalAccumulat
 
     float disocclusionThresholdMix = 0.0f;
     if (materialID == c.gStrandMaterialID)
-        disocclusionThresholdMix = Sat(c.gStrandThickness / pixelSize);
+        disocclusionThresholdMix = Sat(Div(c.gStrandThickness, pixelSize));
     if (c.gHasDisocclusionThresholdMix)
         disocclusionThresholdMix = LoadR8Unorm(P.disocclusionThresholdMix, px, py);
     float disocclusionThreshold = Lerp(c.gDisocclusionThreshold, c.gDisocclusionThresholdAlternate, disocclusionThresholdMix);
@@ -292,7 +292,7 @@ __global__ __launch_bounds__(TILE_X* TILE_Y, WAVES) void ReblurTemporalAccumulat
 
     float3 V = GetViewVector(c, X);
     float NoV = Abs(Dot(N, V));
-    float NoVstrict = Lerp(NoV, 1.0f, Sat(smbParallaxInPixelsMax / 30.0f));
+    float NoVstrict = Lerp(NoV, 1.0f, Sat(Div(smbParallaxInPixelsMax, 30.0f)));
     float4 smbDisocclusionThreshold = F4(GetDisocclusionThreshold(disocclusionThreshold, frustumSize, NoVstrict));
     smbDisocclusionThreshold = smbDisocclusionThreshold * (Dot(smbNavg, Navg) > REBLUR_ALMOST_ZERO_ANGLE - 0.25f * smallParallax ? 1.0f : 0.0f);
     smbDisocclusionThreshold = smbDisocclusionThreshold * IsInScreenBilinear(smbBilinearFilter.origin, rectSizePrev);
@@ -340,7 +340,7 @@ __global__ __launch_bounds__(TILE_X* TILE_Y, WAVES) void ReblurTemporalAccumulat
     // Footprint quality
     float3 smbVprev = GetViewVectorPrev(c, Xprev, cameraDelta);
     float NoVprev = Abs(Dot(N, smbVprev));
-    float sizeQuality = (NoVprev + 1e-3f) / (NoV + 1e-3f);
+    float sizeQuality = Div(NoVprev + 1e-3f, NoV + 1e-3f);
     sizeQuality *= sizeQuality;
     sizeQuality = Lerp(0.1f, 1.0f, Sat(sizeQuality));
 
@@ -375,7 +375,7 @@ __global__ __launch_bounds__(TILE_X* TILE_Y, WAVES) void ReblurTemporalAccumulat
         float diffHistoryConfidence = smbFootprintQuality;
         if (c.gHasHistoryConfidence)
             diffHistoryConfidence *= LoadR8Unorm(P.diffConfidence, px, py);
-        diffAccumSpeed *= Lerp(diffHistoryConfidence, 1.0f, 1.0f / (1.0f + diffAccumSpeed));
+        diffAccumSpeed *= Lerp(diffHistoryConfidence, 1.0f, Rcp(1.0f + diffAccumSpeed));
         diffAccumSpeed = Min(diffAccumSpeed, c.gMaxAccumulatedFrameNum);
 
         if (OCC && !diffHasData) {
@@ -388,7 +388,7 @@ __global__ __launch_bounds__(TILE_X* TILE_Y, WAVES) void ReblurTemporalAccumulat
         float smbDiffFastHistory = Sig::FetchFastBilinear(smbFilter, P.historyDiffFast, smbDiffFastTexels);
         smbDiffHistory = ClampNegativeToZero(smbDiffHistory);
 
-        float diffNonLinearAccumSpeed = 1.0f / (1.0f + diffAccumSpeed);
+        float diffNonLinearAccumSpeed = Rcp(1.0f + diffAccumSpeed);
         if (!diffHasData)
             diffNonLinearAccumSpeed *= Lerp(1.0f - c.gCheckerboardResolveAccumSpeed, 1.0f, diffNonLinearAccumSpeed);
         S diffResult = MixHistoryAndCurrent(c, smbDiffHistory, diff, diffNonLinearAccumSpeed);
@@ -400,9 +400,9 @@ __global__ __launch_bounds__(TILE_X* TILE_Y, WAVES) void ReblurTemporalAccumulat
 
         float diffMaxRelativeIntensity = 0.0f, diffAntifireflyFactor = 0.0f;
         if (KIND == SIGNAL_RADIANCE) { // firefly suppressor (neither occlusion kind has it)
-            diffMaxRelativeIntensity = c.gFireflySuppressorMinRelativeScale + REBLUR_FIREFLY_SUPPRESSOR_MAX_RELATIVE_INTENSITY / (diffAccumSpeed + 1.0f);
+            diffMaxRelativeIntensity = c.gFireflySuppressorMinRelativeScale + Div(REBLUR_FIREFLY_SUPPRESSOR_MAX_RELATIVE_INTENSITY, diffAccumSpeed + 1.0f);
             diffAntifireflyFactor = diffAccumSpeed * c.gMaxBlurRadius * REBLUR_FIREFLY_SUPPRESSOR_RADIUS_SCALE;
-            diffAntifireflyFactor /= 1.0f + diffAntifireflyFactor;
+            diffAntifireflyFactor = Div(diffAntifireflyFactor, 1.0f + diffAntifireflyFactor);
 
             float diffLumaResult = GetLuma(diffResult);
             float diffLumaClamped = Min(diffLumaResult, GetLuma(smbDiffHistory) * diffMaxRelativeIntensity);
@@ -418,7 +418,7 @@ __global__ __launch_bounds__(TILE_X* TILE_Y, WAVES) void ReblurTemporalAccumulat
             StoreRGBA16F(P.outDiffSh, px, py, diffShResult);
 
         float diffFastAccumSpeed = Min(diffAccumSpeed, c.gMaxFastAccumulatedFrameNum);
-        float diffFastNonLinearAccumSpeed = 1.0f / (1.0f + diffFastAccumSpeed);
+        float diffFastNonLinearAccumSpeed = Rcp(1.0f + diffFastAccumSpeed);
         if (!diffHasData)
             diffFastNonLinearAccumSpeed *= Lerp(1.0f - c.gCheckerboardResolveAccumSpeed, 1.0f, diffFastNonLinearAccumSpeed);
         float diffFastResult = Lerp(smbDiffFastHistory, GetLuma(diff), diffFastNonLinearAccumSpeed);
@@ -436,7 +436,7 @@ __global__ __launch_bounds__(TILE_X* TILE_Y, WAVES) void ReblurTemporalAccumulat
         float specHistoryConfidence = smbFootprintQuality;
         if (c.gHasHistoryConfidence)
             specHistoryConfidence *= LoadR8Unorm(P.specConfidence, px, py);
-        smbSpecAccumSpeed *= Lerp(specHistoryConfidence, 1.0f, 1.0f / (1.0f + smbSpecAccumSpeed));
+        smbSpecAccumSpeed *= Lerp(specHistoryConfidence, 1.0f, Rcp(1.0f + smbSpecAccumSpeed));
         smbSpecAccumSpeed = Min(smbSpecAccumSpeed, c.gMaxAccumulatedFrameNum);
 
         if (OCC && !specHasData) {
@@ -451,7 +451,7 @@ __global__ __launch_bounds__(TILE_X* TILE_Y, WAVES) void ReblurTemporalAccumulat
             float2 uvForZeroParallax = Select(NRD_ORTHO_MODE(c) == 0.0f, smbPixelUv, pixelUv);
             float2 deltaUv = uvForZeroParallax - GetScreenUv(c.gWorldToClipPrev, Xprev + cameraDelta);
             deltaUv = deltaUv * rectSize;
-            deltaUv = deltaUv / Max(smbParallaxInPixels1, 1.0f / 256.0f);
+            deltaUv = Div(deltaUv, Max(smbParallaxInPixels1, 1.0f / 256.0f));
 
             float3 n10, x10;
             {
@@ -459,7 +459,7 @@ __global__ __launch_bounds__(TILE_X* TILE_Y, WAVES) void ReblurTemporalAccumulat
                 float3 x = RotateVector(c.gViewToWorld, xv);
                 float3 v = GetViewVector(c, x);
                 float3 o = Select(NRD_ORTHO_MODE(c) == 0.0f, F3(0.0f), x);
-                x10 = o + v * Dot(X - o, N) / Dot(N, v);
+                x10 = o + Div(v * Dot(X - o, N), Dot(N, v));
                 n10 = Xyz(s_Normal_Roughness[(ty + BORDER) * BUF_STRIDE + tx + BORDER + 1]);
             }
             float3 n01, x01;
@@ -468,11 +468,11 @@ __global__ __launch_bounds__(TILE_X* TILE_Y, WAVES) void ReblurTemporalAccumulat
                 float3 x = RotateVector(c.gViewToWorld, xv);
                 float3 v = GetViewVector(c, x);
                 float3 o = Select(NRD_ORTHO_MODE(c) == 0.0f, F3(0.0f), x);
-                x01 = o + v * Dot(X - o, N) / Dot(N, v);
+                x01 = o + Div(v * Dot(X - o, N), Dot(N, v));
                 n01 = Xyz(s_Normal_Roughness[(ty + BORDER + 1) * BUF_STRIDE + tx + BORDER]);
             }
             float2 w = Abs(deltaUv) + 1.0f / 256.0f;
-            w = w / (w.x + w.y);
+            w = Div(w, w.x + w.y);
             float3 x = x10 * w.x + x01 * w.y;
             float3 n = Normalize(n10 * w.x + n01 * w.y);
 
@@ -533,14 +533,14 @@ __global__ __launch_bounds__(TILE_X* TILE_Y, WAVES) void ReblurTemporalAccumulat
             Bilinear f = GetBilinearFilter(uv, rectSizePrev);
             float2 rnd = rng.GetFloat2();
             f.origin = f.origin + F2(Step(rnd.x, f.weights.x), Step(rnd.y, f.weights.y));
-            float2 uvs = ((f.origin + 0.5f) / rectSizePrev) * resolutionScalePrev;
+            float2 uvs = (Div(f.origin + 0.5f, rectSizePrev)) * resolutionScalePrev;
             return NearestTexel(P.prevNormalRoughness, uvs);
         };
         const int2 st0 = stochasticTexel(vmbPixelUv);
         const uint32_t stochasticRaw0 = LoadR32U(P.prevNormalRoughness, st0.x, st0.y);
-        const float stepBetweenTaps = Min(vmbPixelsTraveled * c.gFramerateScale, 2.0f) + vmbPixelsTraveled / 1.0f;
+        const float stepBetweenTaps = Min(vmbPixelsTraveled * c.gFramerateScale, 2.0f) + vmbPixelsTraveled * 1.0f;
         vmbDelta = vmbDelta * Rsqrt(LengthSquared(vmbDelta));
-        vmbDelta = vmbDelta / rectSizePrev;
+        vmbDelta = Div(vmbDelta, rectSizePrev);
         const float2 vmbPixelUvPrevTap = vmbPixelUv + vmbDelta * 1.0f * stepBetweenTaps;
         const int2 st1 = stochasticTexel(vmbPixelUvPrevTap);
         const uint32_t stochasticRaw1 = LoadR32U(P.prevNormalRoughness, st1.x, st1.y);
@@ -589,7 +589,7 @@ __global__ __launch_bounds__(TILE_X* TILE_Y, WAVES) void ReblurTemporalAccumulat
         float4 vmbNormalAndRoughness = UnpackNormalAndRoughness(DecodeR10G10B10A2(stochasticRaw0));
         float3 vmbN = RotateVector(c.gWorldPrevToWorld, Xyz(vmbNormalAndRoughness));
         float Dfactor = GetSpecularDominantFactor(NoV, roughness);
-        float virtualHistoryNormalBasedConfidence = 1.0f / (1.0f + 0.5f * Dfactor * Sat(Length(N - vmbN) - REBLUR_NORMAL_ULP) * vmbPixelsTraveled);
+        float virtualHistoryNormalBasedConfidence = Rcp(1.0f + 0.5f * Dfactor * Sat(Length(N - vmbN) - REBLUR_NORMAL_ULP) * vmbPixelsTraveled);
 
         smbNavg = Select(smbFootprintQuality == 0.0f, vmbN, smbNavg);
 
@@ -636,17 +636,17 @@ __global__ __launch_bounds__(TILE_X* TILE_Y, WAVES) void ReblurTemporalAccumulat
 
         float vmbFootprintQuality = ApplyBilinearFilter(vmbOcclusion.x, vmbOcclusion.y, vmbOcclusion.z, vmbOcclusion.w, vmbBilinearFilter);
         vmbFootprintQuality = Sqrt01(vmbFootprintQuality);
-        vmbSpecAccumSpeed *= Lerp(vmbFootprintQuality, 1.0f, 1.0f / (1.0f + vmbSpecAccumSpeed));
+        vmbSpecAccumSpeed *= Lerp(vmbFootprintQuality, 1.0f, Rcp(1.0f + vmbSpecAccumSpeed));
 
         bool vmbAllowCatRom = Sum(vmbOcclusion) > 3.5f && !PERF && KIND != SIGNAL_DIRECTIONAL_OCCLUSION;
         vmbAllowCatRom = vmbAllowCatRom && smbAllowCatRom;
 
         float curvatureAngleTan = pixelSize * Abs(curvature);
-        curvatureAngleTan *= Max(vmbPixelsTraveled / Max(NoV, 0.01f), 1.0f);
+        curvatureAngleTan *= Max(Div(vmbPixelsTraveled, Max(NoV, 0.01f)), 1.0f);
         curvatureAngleTan *= 2.0f;
         float curvatureAngle = Atan(curvatureAngleTan);
 
-        float percentOfVolume = NRD_MAX_PERCENT_OF_LOBE_VOLUME / (1.0f + vmbSpecAccumSpeed);
+        float percentOfVolume = Div(NRD_MAX_PERCENT_OF_LOBE_VOLUME, 1.0f + vmbSpecAccumSpeed);
         float lobeTanHalfAngle = GetSpecularLobeTanHalfAngle(roughnessModified, percentOfVolume);
         float lobeHalfAngle = Atan(lobeTanHalfAngle);
         lobeHalfAngle = Max(lobeHalfAngle, NRD_NORMAL_ENCODING_ERROR);
@@ -670,7 +670,7 @@ __global__ __launch_bounds__(TILE_X* TILE_Y, WAVES) void ReblurTemporalAccumulat
             vmbPixelUvPrev = Select(materialID == c.gCameraAttachedReflectionMaterialID, smbPixelUv, vmbPixelUvPrev);
 
             float pixelSizeAtXvirtual = PixelRadiusToWorld(c.gUnproject, NRD_ORTHO_MODE(c), 1.0f, XvirtualLength);
-            float r = (lobeTanHalfAngle + curvatureAngle) * Min(hitDistForTracking, hitDistForTrackingPrev) / pixelSizeAtXvirtual;
+            float r = Div((lobeTanHalfAngle + curvatureAngle) * Min(hitDistForTracking, hitDistForTrackingPrev), pixelSizeAtXvirtual);
             float d = Length((vmbPixelUvPrev - vmbPixelUv) * rectSize);
 
             r = Max(r, 0.1f);
@@ -705,14 +705,14 @@ __global__ __launch_bounds__(TILE_X* TILE_Y, WAVES) void ReblurTemporalAccumulat
 
         float surfaceHistoryConfidence;
         {
-            float a = Atan(smbParallaxInPixelsMax * pixelSize / Length(X));
-            float nonLinearAccumSpeed = 1.0f / (1.0f + smbSpecAccumSpeed);
+            float a = Atan(Div(smbParallaxInPixelsMax * pixelSize, Length(X)));
+            float nonLinearAccumSpeed = Rcp(1.0f + smbSpecAccumSpeed);
             float h = Lerp(ExtractHitDist(smbSpecHistory), ExtractHitDist(spec), nonLinearAccumSpeed) * hitDistNormalization;
 
             float tana0 = GetSpecularLobeTanHalfAngle(roughnessModified, NRD_MAX_PERCENT_OF_LOBE_VOLUME);
             tana0 *= Lerp(NoV, 1.0f, roughnessModified);
             tana0 *= nonLinearAccumSpeed;
-            tana0 /= GetHitDistFactor(h, frustumSize) + NRD_EPS;
+            tana0 = Div(tana0, GetHitDistFactor(h, frustumSize) + NRD_EPS);
 
             float a0 = Atan(tana0);
             a0 = Max(a0, NRD_NORMAL_ENCODING_ERROR);
@@ -747,7 +747,7 @@ __global__ __launch_bounds__(TILE_X* TILE_Y, WAVES) void ReblurTemporalAccumulat
         vmbSpecAccumSpeed = Min(vmbSpecAccumSpeed, vmbMaxFrameNum);
 
         float magic = vmbSpecAccumSpeed > smbSpecAccumSpeed ? 8.0f : 0.5f;
-        virtualHistoryAmount *= 1.0f + (vmbSpecAccumSpeed - smbSpecAccumSpeed) / (magic * Max(vmbSpecAccumSpeed, smbSpecAccumSpeed) + 1.0f);
+        virtualHistoryAmount *= 1.0f + Div(vmbSpecAccumSpeed - smbSpecAccumSpeed, magic * Max(vmbSpecAccumSpeed, smbSpecAccumSpeed) + 1.0f);
         virtualHistoryAmount = Sat(virtualHistoryAmount);
 
         NRD_CONSTANTS_PHASE();
@@ -759,8 +759,8 @@ __global__ __launch_bounds__(TILE_X* TILE_Y, WAVES) void ReblurTemporalAccumulat
         smbSpecHistory = ClampNegativeToZero(smbSpecHistory);
         vmbSpecHistory = ClampNegativeToZero(vmbSpecHistory);
 
-        float smbSpecNonLinearAccumSpeed = 1.0f / (1.0f + smbSpecAccumSpeed);
-        float vmbSpecNonLinearAccumSpeed = 1.0f / (1.0f + vmbSpecAccumSpeed);
+        float smbSpecNonLinearAccumSpeed = Rcp(1.0f + smbSpecAccumSpeed);
+        float vmbSpecNonLinearAccumSpeed = Rcp(1.0f + vmbSpecAccumSpeed);
         if (!specHasData) {
             smbSpecNonLinearAccumSpeed *= Lerp(1.0f - c.gCheckerboardResolveAccumSpeed, 1.0f, smbSpecNonLinearAccumSpeed);
             vmbSpecNonLinearAccumSpeed *= Lerp(1.0f - c.gCheckerboardResolveAccumSpeed, 1.0f, vmbSpecNonLinearAccumSpeed);
@@ -787,9 +787,9 @@ __global__ __launch_bounds__(TILE_X* TILE_Y, WAVES) void ReblurTemporalAccumulat
         // Firefly suppressor (not in the occlusion family)
         float specMaxRelativeIntensity = 0.0f, specAntifireflyFactor = 0.0f;
         if (KIND == SIGNAL_RADIANCE) {
-            specMaxRelativeIntensity = c.gFireflySuppressorMinRelativeScale + REBLUR_FIREFLY_SUPPRESSOR_MAX_RELATIVE_INTENSITY / (specAccumSpeed + 1.0f);
+            specMaxRelativeIntensity = c.gFireflySuppressorMinRelativeScale + Div(REBLUR_FIREFLY_SUPPRESSOR_MAX_RELATIVE_INTENSITY, specAccumSpeed + 1.0f);
             specAntifireflyFactor = specAccumSpeed * c.gMaxBlurRadius * REBLUR_FIREFLY_SUPPRESSOR_RADIUS_SCALE;
-            specAntifireflyFactor /= 1.0f + specAntifireflyFactor;
+            specAntifireflyFactor = Div(specAntifireflyFactor, 1.0f + specAntifireflyFactor);
 
             float specLumaResult = GetLuma(specResult);
             float specLumaClamped = Min(specLumaResult, GetLuma(specHistory) * specMaxRelativeIntensity);

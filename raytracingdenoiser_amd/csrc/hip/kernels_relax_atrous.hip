@@ -132,7 +132,7 @@ __global__ __launch_bounds__(256, NRD_WAVES_RELAX_ATROUS_SMEM) void RelaxAtrousS
     const float centerMaterialID = centerWorldPosMaterialID.w;
     if (InBounds(P.outNormalRoughness, px, py)) {
         StoreRGBA8Unorm(P.outNormalRoughness, px, py, PackPrevNormalRoughness(normalRoughness));
-        StoreR8Unorm(P.outMaterialID, px, py, centerMaterialID / 255.0f);
+        StoreR8Unorm(P.outMaterialID, px, py, Div(centerMaterialID, 255.0f));
     }
 
     if (tileIsSky || px >= rectW || py >= rectH)
@@ -169,7 +169,7 @@ __global__ __launch_bounds__(256, NRD_WAVES_RELAX_ATROUS_SMEM) void RelaxAtrousS
         float3 centerV = F3(0.0f);
         if (SPEC) {
             sp.centerLuminance = Luminance(Xyz(s_Spec[lc]));
-            sp.phiLIlluminationInv = 1.0f / Max(1.0e-4f, c.shared.gSpecPhiLuminance * Sqrt(centerSpecularVar));
+            sp.phiLIlluminationInv = Rcp(Max(1.0e-4f, c.shared.gSpecPhiLuminance * Sqrt(centerSpecularVar)));
             sp.roughnessWeightParams = GetRoughnessWeightParams(centerRoughness, c.shared.gRoughnessFraction);
             float diffuseLobeAngleFractionForSimplifiedSpecularNormalWeight = diffuseLobeAngleFraction;
             float specularLobeAngleFraction = c.shared.gLobeAngleFraction;
@@ -195,7 +195,7 @@ __global__ __launch_bounds__(256, NRD_WAVES_RELAX_ATROUS_SMEM) void RelaxAtrousS
         dp.luminanceWeightRelaxation = 1.0f;
         if (DIFF) {
             dp.centerLuminance = Luminance(Xyz(s_Diff[lc]));
-            dp.phiLIlluminationInv = 1.0f / Max(1.0e-4f, c.shared.gDiffPhiLuminance * Sqrt(centerDiffuseVar));
+            dp.phiLIlluminationInv = Rcp(Max(1.0e-4f, c.shared.gDiffPhiLuminance * Sqrt(centerDiffuseVar)));
             if (c.shared.gHasHistoryConfidence) {
                 float diffConfidenceDrivenRelaxation = Sat(c.shared.gConfidenceDrivenRelaxationMultiplier * (1.0f - LoadR8Unorm(P.diff.confidence, px, py)));
                 float r = Sat(diffConfidenceDrivenRelaxation * c.shared.gConfidenceDrivenNormalEdgeStoppingRelaxation);
@@ -276,21 +276,21 @@ __global__ __launch_bounds__(256, NRD_WAVES_RELAX_ATROUS_SMEM) void RelaxAtrousS
 
         if (SPEC) {
             sumWSpecular = Max(sumWSpecular, 1e-6f);
-            sumSpecular = sumSpecular / sumWSpecular;
+            sumSpecular = Div(sumSpecular, sumWSpecular);
             float m1 = Luminance(Xyz(sumSpecular));
             float variance = Max(0.0f, sumSpecular.w - m1 * m1);
             StoreRGBA16F(P.spec.out, px, py, F4(Xyz(sumSpecular), variance));
             if (SH)
-                StoreRGBA16F(P.spec.outSh, px, py, F4(Xyz(sumSpecularSH) / sumWSpecular, roughnessModified));
+                StoreRGBA16F(P.spec.outSh, px, py, F4(Div(Xyz(sumSpecularSH), sumWSpecular), roughnessModified));
         }
         if (DIFF) {
             sumWDiffuse = Max(sumWDiffuse, 1e-6f);
-            sumDiffuse = sumDiffuse / sumWDiffuse;
+            sumDiffuse = Div(sumDiffuse, sumWDiffuse);
             float m1 = Luminance(Xyz(sumDiffuse));
             float variance = Max(0.0f, sumDiffuse.w - m1 * m1);
             StoreRGBA16F(P.diff.out, px, py, F4(Xyz(sumDiffuse), variance));
             if (SH)
-                StoreRGBA16F(P.diff.outSh, px, py, sumDiffuseSH / sumWDiffuse);
+                StoreRGBA16F(P.diff.outSh, px, py, Div(sumDiffuseSH, sumWDiffuse));
         }
     } else {
         // spatial variance estimation over 5x5
@@ -339,30 +339,30 @@ __global__ __launch_bounds__(256, NRD_WAVES_RELAX_ATROUS_SMEM) void RelaxAtrousS
                 }
             }
 
-        const float boost = Max(1.0f, 4.0f / (historyLength + 1.0f));
+        const float boost = Max(1.0f, Div(4.0f, historyLength + 1.0f));
         if (SPEC) {
             sumWSpecular = Max(sumWSpecular, 1e-6f);
-            sumSpecularIllumination = sumSpecularIllumination / sumWSpecular;
-            sumSpecular1stMoment /= sumWSpecular;
-            sumSpecular2ndMoment /= sumWSpecular;
+            sumSpecularIllumination = Div(sumSpecularIllumination, sumWSpecular);
+            sumSpecular1stMoment = Div(sumSpecular1stMoment, sumWSpecular);
+            sumSpecular2ndMoment = Div(sumSpecular2ndMoment, sumWSpecular);
             float variance = Max(0.0f, sumSpecular2ndMoment - sumSpecular1stMoment * sumSpecular1stMoment);
             variance *= boost;
             StoreRGBA16F(P.spec.out, px, py, F4(sumSpecularIllumination, variance));
             if (SH) {
                 float roughnessModified = s_SpecSH[lc].w;
-                StoreRGBA16F(P.spec.outSh, px, py, F4(Xyz(sumSpecularSH) / sumWSpecular, roughnessModified));
+                StoreRGBA16F(P.spec.outSh, px, py, F4(Div(Xyz(sumSpecularSH), sumWSpecular), roughnessModified));
             }
         }
         if (DIFF) {
             sumWDiffuse = Max(sumWDiffuse, 1e-6f);
-            sumDiffuseIllumination = sumDiffuseIllumination / sumWDiffuse;
-            sumDiffuse1stMoment /= sumWDiffuse;
-            sumDiffuse2ndMoment /= sumWDiffuse;
+            sumDiffuseIllumination = Div(sumDiffuseIllumination, sumWDiffuse);
+            sumDiffuse1stMoment = Div(sumDiffuse1stMoment, sumWDiffuse);
+            sumDiffuse2ndMoment = Div(sumDiffuse2ndMoment, sumWDiffuse);
             float variance = Max(0.0f, sumDiffuse2ndMoment - sumDiffuse1stMoment * sumDiffuse1stMoment);
             variance *= boost;
             StoreRGBA16F(P.diff.out, px, py, F4(sumDiffuseIllumination, variance));
             if (SH)
-                StoreRGBA16F(P.diff.outSh, px, py, sumDiffuseSH / sumWDiffuse);
+                StoreRGBA16F(P.diff.outSh, px, py, Div(sumDiffuseSH, sumWDiffuse));
         }
     }
 }
@@ -384,13 +384,10 @@ const char* LaunchAtrousSmem(const PassArgs& a) {
 }
 
 // ================================================================================================ Atrous
-// NRD_ATROUS_GUIDES_VIEWZ (fast build only: the re-derived position differs from the stored one in the last bits): the taps read viewZ and re-derive the world position
+// NRD_ATROUS_GUIDES_VIEWZ: the taps read viewZ (4 bytes) and re-derive the world position instead of fetching the stored (position, viewZ) texel (16 bytes): -6 % per
+// iteration (profiles/r02_g_atrz_relax.json). With the contraction decided by the source the re-derived position IS the stored one, bit for bit.
 #ifndef NRD_ATROUS_GUIDES_VIEWZ
-#if NRD_FAST
-#define NRD_ATROUS_GUIDES_VIEWZ 1 // -6 % per iteration (profiles/r02_g_atrz_relax.json)
-#else
-#define NRD_ATROUS_GUIDES_VIEWZ 0
-#endif
+#define NRD_ATROUS_GUIDES_VIEWZ 1
 #endif
 template <bool DIFF, bool SPEC, bool SH>
 __global__ __launch_bounds__(256, NRD_WAVES_RELAX_ATROUS) void RelaxAtrousKernel(AtrousPlanes P, RelaxCB c, RowRange rows) {
@@ -419,10 +416,10 @@ __global__ __launch_bounds__(256, NRD_WAVES_RELAX_ATROUS) void RelaxAtrousKernel
     const float historyLength = 255.0f * LoadR8Unorm(P.historyLength, px, py);
     const int stepSize = (int)c.gStepSize;
 
-    float diffuseLobeAngleFraction = c.shared.gLobeAngleFraction / Sqrt(float(c.gStepSize));
+    float diffuseLobeAngleFraction = Div(c.shared.gLobeAngleFraction, Sqrt(float(c.gStepSize)));
     if (SH)
-        diffuseLobeAngleFraction = 1.0f / Sqrt(float(c.gStepSize));
-    diffuseLobeAngleFraction = Lerp(0.99f, diffuseLobeAngleFraction, Sat(historyLength / 5.0f));
+        diffuseLobeAngleFraction = Rcp(Sqrt(float(c.gStepSize)));
+    diffuseLobeAngleFraction = Lerp(0.99f, diffuseLobeAngleFraction, Sat(Div(historyLength, 5.0f)));
 
     SpecParams sp = {};
     sp.luminanceWeightRelaxation = 1.0f;
@@ -432,7 +429,7 @@ __global__ __launch_bounds__(256, NRD_WAVES_RELAX_ATROUS) void RelaxAtrousKernel
         const float4 centerSpecular = LoadRGBA16F(P.spec.in, px, py);
         sp.centerLuminance = Luminance(Xyz(centerSpecular));
         const float centerSpecularVar = centerSpecular.w;
-        sp.phiLIlluminationInv = 1.0f / Max(1.0e-4f, c.shared.gSpecPhiLuminance * Sqrt(centerSpecularVar));
+        sp.phiLIlluminationInv = Rcp(Max(1.0e-4f, c.shared.gSpecPhiLuminance * Sqrt(centerSpecularVar)));
 
         sp.roughnessWeightParams = GetRoughnessWeightParams(centerRoughness, c.shared.gRoughnessFraction);
         float diffuseLobeAngleFractionForSimplifiedSpecularNormalWeight = diffuseLobeAngleFraction;
@@ -468,7 +465,7 @@ __global__ __launch_bounds__(256, NRD_WAVES_RELAX_ATROUS) void RelaxAtrousKernel
         const float4 centerDiffuse = LoadRGBA16F(P.diff.in, px, py);
         dp.centerLuminance = Luminance(Xyz(centerDiffuse));
         const float centerDiffuseVar = centerDiffuse.w;
-        dp.phiLIlluminationInv = 1.0f / Max(1.0e-4f, c.shared.gDiffPhiLuminance * Sqrt(centerDiffuseVar));
+        dp.phiLIlluminationInv = Rcp(Max(1.0e-4f, c.shared.gDiffPhiLuminance * Sqrt(centerDiffuseVar)));
         if (c.shared.gHasHistoryConfidence) {
             float diffConfidenceDrivenRelaxation = Sat(c.shared.gConfidenceDrivenRelaxationMultiplier * (1.0f - LoadR8Unorm(P.diff.confidence, px, py)));
             float r = Sat(diffConfidenceDrivenRelaxation * c.shared.gConfidenceDrivenNormalEdgeStoppingRelaxation);
@@ -596,20 +593,20 @@ __global__ __launch_bounds__(256, NRD_WAVES_RELAX_ATROUS) void RelaxAtrousKernel
         }
 
     if (SPEC) {
-        float4 filtered = sumSpecular / F4(sumWSpecular, sumWSpecular, sumWSpecular, sumWSpecular * sumWSpecular);
+        float4 filtered = Div(sumSpecular, F4(sumWSpecular, sumWSpecular, sumWSpecular, sumWSpecular * sumWSpecular));
         if (SH) {
             if (c.gIsLastPass == 1)
                 filtered = F4(LinearToYCoCg(Xyz(filtered)), filtered.w);
-            StoreRGBA16F(P.spec.outSh, px, py, F4(Xyz(sumSpecularSH) / sumWSpecular, roughnessModified));
+            StoreRGBA16F(P.spec.outSh, px, py, F4(Div(Xyz(sumSpecularSH), sumWSpecular), roughnessModified));
         }
         StoreRGBA16F(P.spec.out, px, py, filtered);
     }
     if (DIFF) {
-        float4 filtered = sumDiffuse / F4(sumWDiffuse, sumWDiffuse, sumWDiffuse, sumWDiffuse * sumWDiffuse);
+        float4 filtered = Div(sumDiffuse, F4(sumWDiffuse, sumWDiffuse, sumWDiffuse, sumWDiffuse * sumWDiffuse));
         if (SH) {
             if (c.gIsLastPass == 1)
                 filtered = F4(LinearToYCoCg(Xyz(filtered)), filtered.w);
-            StoreRGBA16F(P.diff.outSh, px, py, sumDiffuseSH / sumWDiffuse);
+            StoreRGBA16F(P.diff.outSh, px, py, Div(sumDiffuseSH, sumWDiffuse));
         }
         StoreRGBA16F(P.diff.out, px, py, filtered);
     }

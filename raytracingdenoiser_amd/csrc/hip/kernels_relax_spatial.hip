@@ -135,11 +135,11 @@ __global__ __launch_bounds__(256) void RelaxHitDistReconstructionKernel(HitDistP
         }
 
     if (SPEC) {
-        sumSpecularHitDist /= Max(sumSpecularWeight, 1e-6f);
+        sumSpecularHitDist = Div(sumSpecularHitDist, Max(sumSpecularWeight, 1e-6f));
         StoreRGBA16F(P.spec.out, px, py, F4(Xyz(centerSpec), sumSpecularHitDist));
     }
     if (DIFF) {
-        sumDiffuseHitDist /= Max(sumDiffuseWeight, 1e-6f);
+        sumDiffuseHitDist = Div(sumDiffuseHitDist, Max(sumDiffuseWeight, 1e-6f));
         StoreRGBA16F(P.diff.out, px, py, F4(Xyz(centerDiff), sumDiffuseHitDist));
     }
 }
@@ -335,9 +335,9 @@ __global__ __launch_bounds__(256, NRD_WAVES_RELAX_PREPASS) void RelaxPrePassKern
                     diffuseSH = diffuseSH + sampleDiffuseSH * sampleWeight;
                 }
             }
-            diffuseIllumination = diffuseIllumination / weightSum;
+            diffuseIllumination = Div(diffuseIllumination, weightSum);
             if (SH)
-                diffuseSH = diffuseSH / weightSum;
+                diffuseSH = Div(diffuseSH, weightSum);
         }
         StoreRGBA16F(P.diff.out, px, py, Clamp4(diffuseIllumination, 0.0f, NRD_FP16_MAX));
         if (SH)
@@ -376,7 +376,7 @@ __global__ __launch_bounds__(256, NRD_WAVES_RELAX_PREPASS) void RelaxPrePassKern
             float blurRadius = c.shared.gSpecBlurRadius * hitDistFactor * smc;
             float lobeTanHalfAngle = GetSpecularLobeTanHalfAngle(centerRoughness, 0.75f);
             float lobeRadius = hitDist * NoD * lobeTanHalfAngle;
-            float minBlurRadius = lobeRadius / PixelRadiusToWorld(c.shared.gUnproject, c.shared.gOrthoMode, 1.0f, centerViewZ + hitDist * D.w);
+            float minBlurRadius = Div(lobeRadius, PixelRadiusToWorld(c.shared.gUnproject, c.shared.gOrthoMode, 1.0f, centerViewZ + hitDist * D.w));
             blurRadius = Min(blurRadius, minBlurRadius);
             if (specularIllumination.w == 0.0f)
                 blurRadius = Max(blurRadius, 1.0f);
@@ -415,7 +415,7 @@ __global__ __launch_bounds__(256, NRD_WAVES_RELAX_PREPASS) void RelaxPrePassKern
 
                 float d = Length(sampleWorldPos - centerWorldPos);
                 float h = sampleSpecularIllumination.w;
-                float tt = h / (specularIllumination.w + d);
+                float tt = Div(h, specularIllumination.w + d);
                 sampleWeight *= Lerp(Sat(tt), 1.0f, roughnessRelax);
 
                 weightSum += sampleWeight;
@@ -427,10 +427,10 @@ __global__ __launch_bounds__(256, NRD_WAVES_RELAX_PREPASS) void RelaxPrePassKern
                 if (sampleWeight != 0.0f)
                     minHitT = Min(minHitT, sampleSpecularIllumination.w == 0.0f ? NRD_INF : sampleSpecularIllumination.w);
             }
-            rgb = rgb / weightSum;
+            rgb = Div(rgb, weightSum);
             specularIllumination = F4(rgb, minHitT == NRD_INF ? 0.0f : minHitT);
             if (SH)
-                specularSH = specularSH / weightSum;
+                specularSH = Div(specularSH, weightSum);
         }
         StoreRGBA16F(P.spec.out, px, py, Clamp4(specularIllumination, 0.0f, NRD_FP16_MAX));
         if (SH)
@@ -512,7 +512,7 @@ __global__ __launch_bounds__(256, NRD_WAVES_RELAX_HF) void RelaxHistoryFixKernel
     float2 specularNormalWeightParams = SPEC ? GetNormalWeightParams_ATrous(centerRoughness, 5.0f, 1.0f, 0.0f, c.shared.gLobeAngleFraction, c.shared.gSpecLobeAngleSlack) : F2(0.0f, 0.0f);
     const float normalPower = Max(c.shared.gHistoryFixEdgeStoppingNormalPower, 0.01f);
 
-    float r = c.shared.gHistoryFixBasePixelStride / (1.0f + historyLength);
+    float r = Div(c.shared.gHistoryFixBasePixelStride, 1.0f + historyLength);
     r = floorf(r + 0.5f);
 
     for (int j = -2; j <= 2; j++)
@@ -557,14 +557,14 @@ __global__ __launch_bounds__(256, NRD_WAVES_RELAX_HF) void RelaxHistoryFixKernel
         }
 
     if (DIFF) {
-        StoreRGBA16F(P.diff.out, px, py, diffuseSum / diffuseWSum);
+        StoreRGBA16F(P.diff.out, px, py, Div(diffuseSum, diffuseWSum));
         if (SH)
-            StoreRGBA16F(P.diff.outSh, px, py, diffuseSumSH / diffuseWSum);
+            StoreRGBA16F(P.diff.outSh, px, py, Div(diffuseSumSH, diffuseWSum));
     }
     if (SPEC) {
-        StoreRGBA16F(P.spec.out, px, py, specularSum / specularWSum);
+        StoreRGBA16F(P.spec.out, px, py, Div(specularSum, specularWSum));
         if (SH)
-            StoreRGBA16F(P.spec.outSh, px, py, F4(Xyz(specularSumSH) / specularWSum, roughnessModified));
+            StoreRGBA16F(P.spec.outSh, px, py, F4(Div(Xyz(specularSumSH), specularWSum), roughnessModified));
     }
 }
 

@@ -145,7 +145,7 @@ __global__ __launch_bounds__(256, NRD_WAVES_RELAX_TA) void RelaxTemporalAccumula
             minHitDist3x3 = Min(minHitDist3x3, normalSpecHitT.w == 0.0f ? NRD_INF : normalSpecHitT.w);
             currentNormalAveraged = currentNormalAveraged + Xyz(normalSpecHitT);
         }
-    currentNormalAveraged = currentNormalAveraged / 9.0f;
+    currentNormalAveraged = Div(currentNormalAveraged, 9.0f);
 
     const float currentRoughnessModified = SPEC ? GetModifiedRoughnessFromNormalVariance(currentRoughness, currentNormalAveraged) : 0.0f;
 
@@ -166,7 +166,7 @@ __global__ __launch_bounds__(256, NRD_WAVES_RELAX_TA) void RelaxTemporalAccumula
     // disocclusion threshold
     float disocclusionThresholdMix = 0.0f;
     if (currentMaterialID == c.shared.gStrandMaterialID)
-        disocclusionThresholdMix = Sat(c.shared.gStrandThickness / pixelSize);
+        disocclusionThresholdMix = Sat(Div(c.shared.gStrandThickness, pixelSize));
     if (c.shared.gHasDisocclusionThresholdMix)
         disocclusionThresholdMix = LoadR8Unorm(P.disocclusionThresholdMix, px, py);
     const float disocclusionThreshold = Lerp(c.shared.gDisocclusionThreshold, c.shared.gDisocclusionThresholdAlternate, disocclusionThresholdMix);
@@ -187,7 +187,7 @@ __global__ __launch_bounds__(256, NRD_WAVES_RELAX_TA) void RelaxTemporalAccumula
         const float2 bilinearWeights = F2(Frac(prevPixelPosFloat.x - 0.5f), Frac(prevPixelPosFloat.y - 0.5f));
 
         const float frustumSize = pixelSize * float(rectW < rectH ? rectW : rectH);
-        const float disocclusionThresholdSlopeScale = 1.0f / Lerp(Lerp(0.05f, 1.0f, NoV), 1.0f, Sat(smbParallaxInPixelsMax / 30.0f));
+        const float disocclusionThresholdSlopeScale = Rcp(Lerp(Lerp(0.05f, 1.0f, NoV), 1.0f, Sat(Div(smbParallaxInPixelsMax, 30.0f))));
         float4 smbDisocclusionThreshold = F4(Sat(disocclusionThreshold * disocclusionThresholdSlopeScale) * frustumSize);
         smbDisocclusionThreshold = smbDisocclusionThreshold * IsInScreenBilinear(originF, rectSizePrev);
         smbDisocclusionThreshold = smbDisocclusionThreshold - NRD_EPS;
@@ -282,7 +282,7 @@ __global__ __launch_bounds__(256, NRD_WAVES_RELAX_TA) void RelaxTemporalAccumula
     // avoid footprint stretching due to the changed viewing angle
     const float3 Vprev = -Normalize(prevWorldPos - cameraDelta);
     const float NoVprev = Abs(Dot(currentNormal, Vprev));
-    float sizeQuality = (NoVprev + 1e-3f) / (NoV + 1e-3f);
+    float sizeQuality = Div(NoVprev + 1e-3f, NoV + 1e-3f);
     sizeQuality *= sizeQuality;
     sizeQuality *= sizeQuality;
     footprintQuality *= Lerp(0.1f, 1.0f, Sat(sizeQuality + Abs(c.shared.gOrthoMode)));
@@ -306,8 +306,8 @@ __global__ __launch_bounds__(256, NRD_WAVES_RELAX_TA) void RelaxTemporalAccumula
             diffMaxFastAccumulatedFrameNum *= inDiffConfidence;
         }
         const float diffHistoryLength = historyLength;
-        float diffuseAlpha = SMBReprojectionFound > 0.0f ? Max(1.0f / (diffMaxAccumulatedFrameNum + 1.0f), 1.0f / diffHistoryLength) : 1.0f;
-        float diffuseAlphaResponsive = SMBReprojectionFound > 0.0f ? Max(1.0f / (diffMaxFastAccumulatedFrameNum + 1.0f), 1.0f / diffHistoryLength) : 1.0f;
+        float diffuseAlpha = SMBReprojectionFound > 0.0f ? Max(Rcp(diffMaxAccumulatedFrameNum + 1.0f), Rcp(diffHistoryLength)) : 1.0f;
+        float diffuseAlphaResponsive = SMBReprojectionFound > 0.0f ? Max(Rcp(diffMaxFastAccumulatedFrameNum + 1.0f), Rcp(diffHistoryLength)) : 1.0f;
         // checkerboard: pixels without data this frame (resolved by the pre-pass) accumulate slower (reference RELAX_TemporalAccumulation.hlsli:596-606)
         const bool diffHasData = c.shared.gDiffCheckerboard == 2u || CheckerBoard((uint32_t)px, (uint32_t)py, c.shared.gFrameIndex) == c.shared.gDiffCheckerboard;
         if (!diffHasData && diffHistoryLength > 1.0f) {
@@ -325,7 +325,7 @@ __global__ __launch_bounds__(256, NRD_WAVES_RELAX_TA) void RelaxTemporalAccumula
         }
     }
 
-    StoreR8Unorm(P.outHistoryLength, px, py, historyLength / 255.0f);
+    StoreR8Unorm(P.outHistoryLength, px, py, Div(historyLength, 255.0f));
 
     if (SPEC) {
         float specMaxAccumulatedFrameNum = c.shared.gSpecMaxAccumulatedFrameNum;
@@ -347,24 +347,24 @@ __global__ __launch_bounds__(256, NRD_WAVES_RELAX_TA) void RelaxTemporalAccumula
         {
             float2 deltaUv = prevUVSMB - GetScreenUv(c.shared.gWorldToClipPrev, prevWorldPos + cameraDelta);
             deltaUv = deltaUv * rectSize;
-            deltaUv = deltaUv / Max(smbParallaxInPixels1, 1.0f / 256.0f);
+            deltaUv = Div(deltaUv, Max(smbParallaxInPixels1, 1.0f / 256.0f));
 
             float3 n10, x10, n01, x01;
             {
                 float3 x = GetCurrentWorldPosFromClipSpaceXY(c, (pixelUv + F2(1.0f, 0.0f) * rectSizeInv) * 2.0f - 1.0f, 1.0f);
                 float3 v = Normalize(-x);
-                x10 = F3(0.0f) + v * Dot(currentWorldPos - F3(0.0f), currentNormal) / Dot(currentNormal, v);
+                x10 = F3(0.0f) + Div(v * Dot(currentWorldPos - F3(0.0f), currentNormal), Dot(currentNormal, v));
                 n10 = Xyz(Shared(1, 0));
             }
             {
                 float3 x = GetCurrentWorldPosFromClipSpaceXY(c, (pixelUv + F2(0.0f, 1.0f) * rectSizeInv) * 2.0f - 1.0f, 1.0f);
                 float3 v = Normalize(-x);
-                x01 = F3(0.0f) + v * Dot(currentWorldPos - F3(0.0f), currentNormal) / Dot(currentNormal, v);
+                x01 = F3(0.0f) + Div(v * Dot(currentWorldPos - F3(0.0f), currentNormal), Dot(currentNormal, v));
                 n01 = Xyz(Shared(0, 1));
             }
 
             float2 w = Abs(deltaUv) + 1.0f / 256.0f;
-            w = w / (w.x + w.y);
+            w = Div(w, w.x + w.y);
             float3 x = x10 * w.x + x01 * w.y;
             float3 n = Normalize(n10 * w.x + n01 * w.y);
 
@@ -477,7 +477,7 @@ __global__ __launch_bounds__(256, NRD_WAVES_RELAX_TA) void RelaxTemporalAccumula
         const float uvDiffLengthInPixels = Length(uvDiff * rectSize);
 
         float tanCurvature = Abs(curvature * pixelSize);
-        tanCurvature *= Max(uvDiffLengthInPixels / Max(NoV, 0.01f), 1.0f);
+        tanCurvature *= Max(Div(uvDiffLengthInPixels, Max(NoV, 0.01f)), 1.0f);
         const float curvatureAngle = Atan(tanCurvature);
 
         const float lobeHalfAngle = Max(Atan(GetSpecLobeTanHalfAngleOld(currentRoughnessModified)), RELAX_NORMAL_ULP);
@@ -492,8 +492,8 @@ __global__ __launch_bounds__(256, NRD_WAVES_RELAX_TA) void RelaxTemporalAccumula
 
         // look back 1 and 2 frames
         uvDiff = uvDiff * Rsqrt(LengthSquared(uvDiff));
-        uvDiff = uvDiff / rectSizePrev;
-        uvDiff = uvDiff * (Sat(uvDiffLengthInPixels / 0.1f) + uvDiffLengthInPixels / 2.0f);
+        uvDiff = Div(uvDiff, rectSizePrev);
+        uvDiff = uvDiff * (Sat(Div(uvDiffLengthInPixels, 0.1f)) + uvDiffLengthInPixels * 0.5f);
         const float2 backUV1 = prevUVVMB + uvDiff * 1.0f;
         const float2 backUV2 = prevUVVMB + uvDiff * 2.0f;
         const float2 prevNrSize = F2(float(P.prevNormalRoughness.w), float(P.prevNormalRoughness.h));
@@ -518,7 +518,7 @@ __global__ __launch_bounds__(256, NRD_WAVES_RELAX_TA) void RelaxTemporalAccumula
         const float maxDist = Max(hitDist1, hitDist2);
         const float dHitT = Abs(hitDist1 - hitDist2);
         const float dHitTMultiplier = Lerp(20.0f, 0.0f, SMC);
-        float virtualHistoryHitDistConfidence = 1.0f - Sat(dHitTMultiplier * dHitT / (currentLinearZ + maxDist));
+        float virtualHistoryHitDistConfidence = 1.0f - Sat(Div(dHitTMultiplier * dHitT, currentLinearZ + maxDist));
         virtualHistoryHitDistConfidence = Lerp(virtualHistoryHitDistConfidence, 1.0f, SMC);
 
         // virtual UV discrepancy
@@ -532,18 +532,18 @@ __global__ __launch_bounds__(256, NRD_WAVES_RELAX_TA) void RelaxTemporalAccumula
 
         float lobeTanHalfAngle = GetSpecLobeTanHalfAngleOld(currentRoughness, 0.6f);
         lobeTanHalfAngle = Max(lobeTanHalfAngle, 0.5f * rectSizeInv.x);
-        const float unproj1 = Min(hitDist, hitDistForTrackingPrev) / PixelRadiusToWorld(c.shared.gUnproject, c.shared.gOrthoMode, 1.0f, Max(virtualWorldPosLength, virtualWorldPosLengthPrev));
+        const float unproj1 = Div(Min(hitDist, hitDistForTrackingPrev), PixelRadiusToWorld(c.shared.gUnproject, c.shared.gOrthoMode, 1.0f, Max(virtualWorldPosLength, virtualWorldPosLengthPrev)));
         const float lobeRadiusInPixels = lobeTanHalfAngle * unproj1;
         const float deltaParallaxInPixels = Length((prevUVVMBTest - prevUVVMB) * rectSize);
         virtualHistoryHitDistConfidence *= SmoothStep(lobeRadiusInPixels + 0.25f, 0.0f, deltaParallaxInPixels);
 
         NRD_CONSTANTS_PHASE();
         // surface motion signal
-        const float specSMBConfidence = (SMBReprojectionFound > 0.0f ? 1.0f : 0.0f) * GetEncodingAwareNormalWeightR(V, Vprev, lobeHalfAngle * NoV / c.shared.gFramerateScale, 0.0f, 0.0f, false);
+        const float specSMBConfidence = (SMBReprojectionFound > 0.0f ? 1.0f : 0.0f) * GetEncodingAwareNormalWeightR(V, Vprev, Div(lobeHalfAngle * NoV, c.shared.gFramerateScale), 0.0f, 0.0f, false);
         float specSMBAlpha = 1.0f - specSMBConfidence;
         float specSMBResponsiveAlpha = 1.0f - specSMBConfidence;
-        specSMBAlpha = Max(specSMBAlpha, 1.0f / (1.0f + specHistoryFrames));
-        specSMBResponsiveAlpha = Max(specSMBAlpha, 1.0f / (1.0f + specHistoryResponsiveFrames));
+        specSMBAlpha = Max(specSMBAlpha, Rcp(1.0f + specHistoryFrames));
+        specSMBResponsiveAlpha = Max(specSMBAlpha, Rcp(1.0f + specHistoryResponsiveFrames));
         // checkerboard (reference RELAX_TemporalAccumulation.hlsli:853-862, :880-887)
         const bool specHasData = c.shared.gSpecCheckerboard == 2u || CheckerBoard((uint32_t)px, (uint32_t)py, c.shared.gFrameIndex) == c.shared.gSpecCheckerboard;
         if (!specHasData && smbParallaxInPixelsMax < 0.5f) {
@@ -561,9 +561,9 @@ __global__ __launch_bounds__(256, NRD_WAVES_RELAX_TA) void RelaxTemporalAccumula
         float specVMBAlpha = 1.0f - specVMBConfidence;
         float specVMBResponsiveAlpha = 1.0f - specVMBConfidence * virtualHistoryHitDistConfidence;
         float specVMBHitTAlpha = specVMBResponsiveAlpha;
-        specVMBAlpha = Max(specVMBAlpha, 1.0f / (1.0f + specHistoryFrames));
-        specVMBResponsiveAlpha = Max(specVMBResponsiveAlpha, 1.0f / (1.0f + specHistoryResponsiveFrames));
-        specVMBHitTAlpha = Max(specVMBHitTAlpha, 1.0f / (1.0f + specHistoryFrames));
+        specVMBAlpha = Max(specVMBAlpha, Rcp(1.0f + specHistoryFrames));
+        specVMBResponsiveAlpha = Max(specVMBResponsiveAlpha, Rcp(1.0f + specHistoryResponsiveFrames));
+        specVMBHitTAlpha = Max(specVMBHitTAlpha, Rcp(1.0f + specHistoryFrames));
         if (!specHasData && smbParallaxInPixelsMax < 0.5f) {
             const float k = 1.0f - c.shared.gCheckerboardResolveAccumSpeed * (VMBReprojectionFound > 0.0f ? 1.0f : 0.0f);
             specVMBAlpha *= k;
@@ -577,7 +577,7 @@ __global__ __launch_bounds__(256, NRD_WAVES_RELAX_TA) void RelaxTemporalAccumula
         const float3 accumulatedSpecularVMBResponsive = Lerp(Xyz(prevSpecularResponsiveVMB), specRgb, specVMBResponsiveAlpha);
 
         // fall back to surface motion if virtual motion doesn't go well
-        virtualHistoryAmount *= Sat(specVMBConfidence / (specSMBConfidence + NRD_EPS));
+        virtualHistoryAmount *= Sat(Div(specVMBConfidence, specSMBConfidence + NRD_EPS));
 
         const float accumulatedReflectionHitT = Lerp(accumulatedSpecularSMBHitT, accumulatedSpecularVMBHitT, virtualHistoryAmount);
         const float3 accumulatedSpecularIllumination = Lerp(accumulatedSpecularSMB, accumulatedSpecularVMB, virtualHistoryAmount);
@@ -711,7 +711,7 @@ NRD_D ClampOut ClampSignal(const RelaxCB& c, float3 fastM1, float3 fastM2, float
     if (isFixed)
         outSlow = IS_SPEC ? outFast : F4(Xyz(outFast), outSlow.w);
 
-    float clampingFactor = (clampedYCoCg.x - slowYCoCg.x) == 0.0f ? 0.0f : Sat((clampedYCoCg.x - slowYCoCg.x) / (fastCenterYCoCg.x - slowYCoCg.x));
+    float clampingFactor = (clampedYCoCg.x - slowYCoCg.x) == 0.0f ? 0.0f : Sat(Div(clampedYCoCg.x - slowYCoCg.x, fastCenterYCoCg.x - slowYCoCg.x));
     if (isFixed)
         clampingFactor = 1.0f;
 
@@ -723,9 +723,9 @@ NRD_D ClampOut ClampSignal(const RelaxCB& c, float3 fastM1, float3 fastM2, float
 
     float3 distanceToNoisy = noisyM1 - fastCenter;
     float distanceToNoisyL = Luminance(Abs(distanceToNoisy));
-    float3 acceleration = distanceToNoisyL == 0.0f ? F3(0.0f) : distanceToNoisy * historyDifferenceL / distanceToNoisyL;
+    float3 acceleration = distanceToNoisyL == 0.0f ? F3(0.0f) : Div(distanceToNoisy * historyDifferenceL, distanceToNoisyL);
     float accelerationL = Luminance(Abs(acceleration));
-    float ratio = accelerationL == 0.0f ? 0.0f : distanceToNoisyL / accelerationL;
+    float ratio = accelerationL == 0.0f ? 0.0f : Div(distanceToNoisyL, accelerationL);
     if (ratio < 1.0f)
         acceleration = acceleration * ratio;
     if (ratio <= 0.0f)
@@ -738,8 +738,7 @@ NRD_D ClampOut ClampSignal(const RelaxCB& c, float3 fastM1, float3 fastM2, float
     float noisyL = Luminance(noisyM1);
     float temporalSigma = c.shared.gHistoryResetTemporalSigmaScale * Sqrt(Max(0.0f, noisyM2 - noisyL * noisyL));
     float spatialSigma = c.shared.gHistoryResetSpatialSigmaScale * sigma.x;
-    float resetAmount = (IS_SPEC ? 0.5f * c.shared.gHistoryResetAmount : c.shared.gHistoryResetAmount) * Max(0.0f, Abs(slowL - noisyL) - spatialSigma - temporalSigma) /
-                        (1.0e-6f + Max(slowL, noisyL) + spatialSigma + temporalSigma);
+    float resetAmount = Div((IS_SPEC ? 0.5f * c.shared.gHistoryResetAmount : c.shared.gHistoryResetAmount) * Max(0.0f, Abs(slowL - noisyL) - spatialSigma - temporalSigma), 1.0e-6f + Max(slowL, noisyL) + spatialSigma + temporalSigma);
     resetAmount = Sat(resetAmount);
     slowRgb = Lerp(slowRgb, noisyCenter, resetAmount);
     fastRgb = Lerp(fastRgb, noisyCenter, resetAmount);
@@ -775,10 +774,10 @@ NRD_D void ResolveSignal(const RelaxCB& c, const SignalPlanes& S, const float4* 
                 sum += noisy.w;
             }
         }
-    fastM1 = fastM1 / sum;
-    fastM2 = fastM2 / sum;
-    noisyM1 = noisyM1 / sum;
-    noisyM2 /= sum;
+    fastM1 = Div(fastM1, sum);
+    fastM2 = Div(fastM2, sum);
+    noisyM1 = Div(noisyM1, sum);
+    noisyM2 = Div(noisyM2, sum);
 
     const int lc = ly * hc::BUF_STRIDE + lx;
     ClampOut o = ClampSignal<IS_SPEC>(c, fastM1, fastM2, noisyM1, noisyM2, s_Fast[lc], LoadRGBA16F(S.in, px, py), Xyz(s_Noisy[lc]), historyLength);
@@ -836,7 +835,7 @@ __global__ __launch_bounds__(256, NRD_WAVES_RELAX_HC) void RelaxHistoryClampingK
         ResolveSignal<true, SH>(c, P.spec, s_SpecFast, s_SpecNoisy, px, py, lx, ly, historyLength);
     if (DIFF)
         ResolveSignal<false, SH>(c, P.diff, s_DiffFast, s_DiffNoisy, px, py, lx, ly, historyLength);
-    StoreR8Unorm(P.outHistoryLength, px, py, historyLength / 255.0f);
+    StoreR8Unorm(P.outHistoryLength, px, py, Div(historyLength, 255.0f));
 }
 
 template <bool DIFF, bool SPEC, bool SH>

@@ -67,7 +67,7 @@ NRD_D float4 ClampV(float4 x, float4 a, float4 b) { return F4(Clamp(x.x, a.x, b.
 NRD_D float SatV(float x) { return Sat(x); }
 NRD_D float4 SatV(float4 x) { return F4(Sat(x.x), Sat(x.y), Sat(x.z), Sat(x.w)); }
 NRD_D float GetKernelRadiusInPixels(float hitDist, float unprojectZ, float scale = 1.0f) {
-    float unclampedRadius = hitDist / unprojectZ;
+    float unclampedRadius = Div(hitDist, unprojectZ);
     unclampedRadius *= scale;
     float minRadius = Min(unclampedRadius, 2.0f);
     return Clamp(unclampedRadius, minRadius, SIGMA_MAX_PIXEL_RADIUS);
@@ -91,13 +91,13 @@ NRD_D void BicubicAxis(float f, float& w0, float& w1, float& wz) {
     float phiy = k * (3.0f * f3 + -6.0f * f2 + 0.0f * f + 4.0f);
     float phiz = k * (-3.0f * f3 + 3.0f * f2 + 3.0f * f + 1.0f);
     float phiw = k * (1.0f * f3 + 0.0f * f2 + 0.0f * f + 0.0f);
-    w0 = 1.0f + 1.0f * f + -1.0f * phiy / (phix + phiy);
-    w1 = 1.0f + -1.0f * f + 1.0f * phiw / (phiz + phiw);
+    w0 = 1.0f + 1.0f * f + -Div(1.0f * phiy, phix + phiy);
+    w1 = 1.0f + -1.0f * f + Div(1.0f * phiw, phiz + phiw);
     wz = phix + phiy;
 }
 NRD_D float TextureCubicY(const Plane& tex, float2 uv) {
     float2 size = F2(float(tex.w), float(tex.h));
-    float dx = -1.0f / size.x, dy = -1.0f / size.y;
+    float dx = -Rcp(size.x), dy = -Rcp(size.y);
     float2 t = uv * size - 0.5f;
     float2 f = F2(Frac(t.x), Frac(t.y));
     float xw0, xw1, xwz, yw0, yw1, ywz;
@@ -160,7 +160,7 @@ __global__ __launch_bounds__(256) void SigmaClassifyTilesKernel(SigmaCB c, Plane
 
     if (lane == 0) {
         uint32_t r = ToUnorm((allLit || allUmbra) ? 0.0f : 1.0f, 255.0f);
-        r |= ToUnorm(Sat(maxRadius / 16.0f), 255.0f) << 8;
+        r |= ToUnorm(Sat(maxRadius * 0.0625f), 255.0f) << 8;
         r |= ToUnorm(allInf ? 1.0f : 0.0f, 255.0f) << 16;
         *TexelPtr<uint32_t>(tiles, tx, ty) = r; // RGBA8_UNORM, .w = 0
     }
@@ -195,7 +195,7 @@ __global__ __launch_bounds__(256) void SigmaSmoothTilesKernel(SigmaCB c, Plane i
     uint32_t raw = *TexelPtr<const uint32_t>(inTiles, x, y);
     float centerY = NRD_DIV_255(float((raw >> 8) & 0xFFu)), centerZ = NRD_DIV_255(float((raw >> 16) & 0xFFu));
     float blurry = 0.0f, sumw = 0.0f;
-    float k = 1.01f / (centerY + 0.01f);
+    float k = Div(1.01f, centerY + 0.01f);
 #pragma unroll
     for (int j = 0; j <= 2; j++) {
 #pragma unroll
@@ -208,7 +208,7 @@ __global__ __launch_bounds__(256) void SigmaSmoothTilesKernel(SigmaCB c, Plane i
             sumw += w;
         }
     }
-    blurry /= sumw;
+    blurry = Div(blurry, sumw);
     StoreRG8Unorm(outTiles, x, y, F2(centerZ, blurry));
 }
 
@@ -352,13 +352,13 @@ __global__ __launch_bounds__(TILE_X* TILE_Y) void SigmaBlurKernel(SigmaCB c, Blu
                 float3 Xvs = ReconstructViewPosition(uv, frustum, zs, c.gOrthoMode);
                 w *= ComputeWeight(Dot(Nv, Xvs), geometryWeightParams.x, geometryWeightParams.y);
                 w *= AreBothLitOrUnlit(centerPenumbra, penum);
-                w *= GetGaussianWeight(Length(F2(float(i - BORDER), float(j - BORDER)) / float(BORDER)));
+                w *= GetGaussianWeight(Length(Div(F2(float(i - BORDER), float(j - BORDER)), float(BORDER))));
             }
 
             result = result + ZeroIf(w == 0.0f, s * w);
             sumx += w;
 
-            w *= pixelSize / (pixelSize + penum);
+            w *= Div(pixelSize, pixelSize + penum);
             w *= IsLit(penum) ? 0.0f : 1.0f;
 
             penumbra += w == 0.0f ? 0.0f : penum * w;
@@ -366,12 +366,12 @@ __global__ __launch_bounds__(TILE_X* TILE_Y) void SigmaBlurKernel(SigmaCB c, Blu
         }
     }
 
-    result = result / sumx;
+    result = Div(result, sumx);
     sumx = 1.0f;
-    penumbra /= Max(sumy, NRD_EPS);
+    penumbra = Div(penumbra, Max(sumy, NRD_EPS));
     sumy = sumy != 0.0f ? 1.0f : 0.0f;
 
-    float penumbraInPixels = penumbra / pixelSize;
+    float penumbraInPixels = Div(penumbra, pixelSize);
     float f = SmoothStep(0.0f, float(BORDER), penumbraInPixels);
     result = Lerp(centerTap, result, f);
 
@@ -385,11 +385,11 @@ __global__ __launch_bounds__(TILE_X* TILE_Y) void SigmaBlurKernel(SigmaCB c, Blu
     float4 rotator = ToF4(FIRST_PASS ? c.gRotator : c.gRotatorPost);
 
     float2 skew = Lerp(F2(1.0f - Abs(Nv.x), 1.0f - Abs(Nv.y)), F2(1.0f, 1.0f), NoV);
-    skew = skew / Max(skew.x, skew.y);
+    skew = Div(skew, Max(skew.x, skew.y));
     skew = skew * (rectSizeInv * blurRadius);
     float4 scaledRotator = ScaleRotator(rotator, skew);
 
-    float invEstimatedPenumbra = 1.0f / Max(penumbra, NRD_EPS);
+    float invEstimatedPenumbra = Rcp(Max(penumbra, NRD_EPS));
     const float2 uvMax = resolutionScale - ToF2(c.gResourceSizeInv) * 0.5f;
 
 #pragma unroll
@@ -421,15 +421,15 @@ __global__ __launch_bounds__(TILE_X* TILE_Y) void SigmaBlurKernel(SigmaCB c, Blu
         result = result + ZeroIf(w == 0.0f, s * w);
         sumx += w;
 
-        w *= pixelSize / (pixelSize + penum);
+        w *= Div(pixelSize, pixelSize + penum);
         w *= IsLit(penum) ? 0.0f : 1.0f;
 
         penumbra += w == 0.0f ? 0.0f : penum * w;
         sumy += w;
     }
 
-    result = result / sumx;
-    penumbra = sumy == 0.0f ? centerPenumbra : penumbra / sumy;
+    result = Div(result, sumx);
+    penumbra = sumy == 0.0f ? centerPenumbra : Div(penumbra, sumy);
 
     if (FIRST_PASS || c.gStabilizationStrength != 0.0f)
         StoreR16F(P.outPenumbra, px, py, penumbra);
@@ -538,15 +538,15 @@ __global__ __launch_bounds__(TILE_X* TILE_Y) void SigmaTemporalStabilizationKern
             else {
                 float penum = s_Penumbra[o];
                 w = AreBothLitOrUnlit(centerPenumbra, penum);
-                w *= GetGaussianWeight(Length(F2(float(i - BORDER), float(j - BORDER)) / float(BORDER)));
+                w *= GetGaussianWeight(Length(Div(F2(float(i - BORDER), float(j - BORDER)), float(BORDER))));
             }
             m1 = m1 + s * w;
             m2 = m2 + s * s * w;
             sumw += w;
         }
     }
-    m1 = m1 / sumw;
-    m2 = m2 / sumw;
+    m1 = Div(m1, sumw);
+    m2 = Div(m2, sumw);
     S sigma = StdDev(m1, m2);
 
     float3 Xv = ReconstructViewPosition(pixelUv, ToF4(c.gFrustum), viewZ, c.gOrthoMode);
@@ -592,7 +592,7 @@ __global__ __launch_bounds__(TILE_X* TILE_Y) void SigmaTemporalStabilizationKern
     history = SatV(history);
     history = UnpackShadow(history);
 
-    sigma = sigma * Lerp(SIGMA_TS_SIGMA_SCALE, 1.0f, 1.0f / (1.0f + historyLength));
+    sigma = sigma * Lerp(SIGMA_TS_SIGMA_SCALE, 1.0f, Rcp(1.0f + historyLength));
     S inputMin = m1 - sigma, inputMax = m1 + sigma;
     S historyClamped = ClampV(history, inputMin, inputMax);
 
@@ -601,7 +601,7 @@ __global__ __launch_bounds__(TILE_X* TILE_Y) void SigmaTemporalStabilizationKern
     antilag = Sat(1.0f - antilag);
     historyLength *= antilag;
 
-    float historyWeight = historyLength / (1.0f + historyLength);
+    float historyWeight = Div(historyLength, 1.0f + historyLength);
     float streetMagic = 0.6f * historyWeight * antilag;
     historyClamped = Lerp(historyClamped, history, streetMagic);
 

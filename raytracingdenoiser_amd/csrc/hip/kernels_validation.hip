@@ -50,11 +50,11 @@ struct Viewport {
 };
 NRD_D Viewport MakeViewport(int px, int py, float2 resourceSize, float2 resolutionScale) {
     Viewport v;
-    const float2 pixelUv = F2(float(px) + 0.5f, float(py) + 0.5f) / resourceSize;
-    const float2 scaled = pixelUv / VIEWPORT_SIZE;
+    const float2 pixelUv = Div(F2(float(px) + 0.5f, float(py) + 0.5f), resourceSize);
+    const float2 scaled = pixelUv * 4.0f; // / VIEWPORT_SIZE
     const float2 id = Floor(scaled);
     v.uv = scaled - id;
-    v.index = id.y / VIEWPORT_SIZE + id.x;
+    v.index = id.y * 4.0f + id.x; // / VIEWPORT_SIZE
     v.uvScaled = v.uv * resolutionScale;
     return v;
 }
@@ -123,7 +123,7 @@ __global__ __launch_bounds__(256) void ReblurValidationKernel(nrdc::ReblurValida
     } else if (v.index == 1.0f) {
         result = F4(F3(normalAndRoughness.w), 1.0f);
     } else if (v.index == 2.0f) {
-        const float f = 0.1f * Abs(viewZ) / (1.0f + 0.1f * Abs(viewZ));
+        const float f = Div(0.1f * Abs(viewZ), 1.0f + 0.1f * Abs(viewZ));
         const float3 color = viewZ < 0.0f ? F3(0.0f, 0.0f, 1.0f) : F3(0.0f, 1.0f, 0.0f);
         result = F4(isInf ? F3(1.0f, 0.0f, 0.0f) : color * f, 1.0f);
     } else if (v.index == 3.0f) {
@@ -134,15 +134,15 @@ __global__ __launch_bounds__(256) void ReblurValidationKernel(nrdc::ReblurValida
         const float2 uvDelta = (prev - expected) * ToF2(c.gRectSize);
         result = F4(IsInScreenNearest(prev) != 0.0f ? F3(Abs(uvDelta.x), Abs(uvDelta.y), 0.0f) : F3(0.0f, 0.0f, 1.0f), 1.0f);
     } else if (v.index == 4.0f) {
-        const float2 dim = F2(0.5f * c.gResourceSize.y / c.gResourceSize.x, 0.5f);
+        const float2 dim = F2(Div(0.5f * c.gResourceSize.y, c.gResourceSize.x), 0.5f);
         const float2 dimInPixels = ToF2(c.gResourceSize) * VIEWPORT_SIZE * dim;
-        const float2 remappedUv = (v.uv - (F2(1.0f, 1.0f) - dim)) / dim;
-        const float2 remappedUv2 = (v.uv - F2(1.0f - dim.x, 0.0f)) / dim;
+        const float2 remappedUv = Div(v.uv - (F2(1.0f, 1.0f) - dim), dim);
+        const float2 remappedUv2 = Div(v.uv - F2(1.0f - dim.x, 0.0f), dim);
         if (remappedUv.x > 0.0f && remappedUv.y > 0.0f) {
             JitterMark(ToF2(c.gJitter), remappedUv, dimInPixels, result);
         } else if (remappedUv2.x > 0.0f && remappedUv2.y > 0.0f) {
             float scale = 0.5f;
-            scale *= float(ReverseBits4(c.gFrameIndex)) / 16.0f;
+            scale *= float(ReverseBits4(c.gFrameIndex)) * 0.0625f;
             const int bx = (int)(remappedUv2.x * dimInPixels.x), by = (int)(remappedUv2.y * dimInPixels.y);
             const float4 rot[3] = {ToF4(c.gRotatorPre), ToF4(c.gRotator), ToF4(c.gRotatorPost)};
             float acc[3] = {result.x, result.y, result.z};
@@ -167,7 +167,7 @@ __global__ __launch_bounds__(256) void ReblurValidationKernel(nrdc::ReblurValida
         result = F4(F3(data2.x * notInf), 1.0f);
     } else if ((v.index == 8.0f && vc.gHasDiffuse) || (v.index == 11.0f && vc.gHasSpecular)) {
         const float frames = v.index == 8.0f ? data1.x : data1.y;
-        float f = 1.0f - Sat(frames / Max(c.gMaxAccumulatedFrameNum, 1.0f));
+        float f = 1.0f - Sat(Div(frames, Max(c.gMaxAccumulatedFrameNum, 1.0f)));
         f = checkerboard && frames < 1.0f ? 0.75f : f;
         result = F4(ColorizeZucconi(v.uv.y > 0.95f ? 1.0f - v.uv.x : f * notInf), 1.0f);
     } else if ((v.index == 12.0f && vc.gHasDiffuse) || (v.index == 15.0f && vc.gHasSpecular)) {
@@ -228,7 +228,7 @@ __global__ __launch_bounds__(256) void RelaxValidationKernel(RelaxCB c, RelaxVal
     } else if (v.index == 1.0f) {
         result = F4(F3(normalAndRoughness.w), 1.0f);
     } else if (v.index == 2.0f) {
-        const float f = 0.1f * Abs(viewZ) / (1.0f + 0.1f * Abs(viewZ));
+        const float f = Div(0.1f * Abs(viewZ), 1.0f + 0.1f * Abs(viewZ));
         const float3 color = viewZ < 0.0f ? F3(0.0f, 0.0f, 1.0f) : F3(0.0f, 1.0f, 0.0f);
         result = F4(isInf ? F3(1.0f, 0.0f, 0.0f) : color * f, 1.0f);
     } else if (v.index == 3.0f) {
@@ -239,8 +239,8 @@ __global__ __launch_bounds__(256) void RelaxValidationKernel(RelaxCB c, RelaxVal
         const float2 uvDelta = (prev - expected) * F2(float(c.shared.gRectSize.x), float(c.shared.gRectSize.y));
         result = F4(IsInScreenNearest(prev) != 0.0f ? F3(Abs(uvDelta.x), Abs(uvDelta.y), 0.0f) : F3(0.0f, 0.0f, 1.0f), 1.0f);
     } else if (v.index == 4.0f) {
-        const float2 dim = F2(0.5f * c.shared.gResourceSize.y / c.shared.gResourceSize.x, 0.5f);
-        const float2 remappedUv = (v.uv - (F2(1.0f, 1.0f) - dim)) / dim;
+        const float2 dim = F2(Div(0.5f * c.shared.gResourceSize.y, c.shared.gResourceSize.x), 0.5f);
+        const float2 remappedUv = Div(v.uv - (F2(1.0f, 1.0f) - dim), dim);
         if (remappedUv.x > 0.0f && remappedUv.y > 0.0f) {
             JitterMark(ToF2(c.shared.gJitter), remappedUv, ToF2(c.shared.gResourceSize) * VIEWPORT_SIZE * dim, result);
         } else {
@@ -250,7 +250,7 @@ __global__ __launch_bounds__(256) void RelaxValidationKernel(RelaxCB c, RelaxVal
         }
         result.w = 1.0f;
     } else if (v.index == 8.0f) {
-        float f = 1.0f - Sat(historyLength / Max(Max(c.shared.gDiffMaxAccumulatedFrameNum, c.shared.gSpecMaxAccumulatedFrameNum), 1.0f));
+        float f = 1.0f - Sat(Div(historyLength, Max(Max(c.shared.gDiffMaxAccumulatedFrameNum, c.shared.gSpecMaxAccumulatedFrameNum), 1.0f)));
         f = checkerboard && historyLength < 2.0f ? 0.75f : f;
         result = F4(ColorizeZucconi(v.uv.y > 0.95f ? 1.0f - v.uv.x : f * notInf), 1.0f);
     }

@@ -1,11 +1,18 @@
-// Device math for the NRD pass chain: HLSL intrinsics with pinned definitions, bit-reproducible transcendentals, the
-// restated NVIDIA-RTX/MathLib subset the shaders call ("ml.hlsli" -- NOT vendored in the reference, fetched unpinned
-// at configure time, reference CMakeLists.txt:118-127), and the NRD.hlsli front-end/back-end codecs.
+// Device math for the NRD pass chain: HLSL intrinsics with pinned definitions, the restated NVIDIA-RTX/MathLib subset the shaders call
+// ("ml.hlsli" -- NOT vendored in the reference, fetched unpinned at configure time, reference CMakeLists.txt:118-127), and the NRD.hlsli
+// front-end / back-end codecs.
 //
-// Reproducibility contract (DESIGN.md "Numerics"): everything here is built from + - * /, comparisons, floor and integer
-// bit operations -- IEEE-754 correctly rounded on gfx950 and on x86-64 -- plus sqrt and 1/sqrt as the hardware's v_sqrt_f32 /
-// v_rsq_f32, which the oracle reproduces from device-measured tables; this file is compiled with -ffp-contract=off. The CPU oracle (oracle/) restates the same definitions independently, so the two can be
-// compared bit-for-bit instead of through a loose tolerance that the chain's many thresholds would amplify.
+// Numerics contract (DESIGN.md "Numerics"): ONE arithmetic, fast on gfx950 and reproducible bit for bit on a CPU.
+//   * + - * and fused multiply-add are IEEE-754 binary32, correctly rounded on both machines. Which multiply-adds are fused is decided by the
+//     SOURCE, not by an optimiser: this file is compiled with -ffp-contract=on (ISO C "FP_CONTRACT ON": `a * b + c` written as ONE expression is a
+//     single fma; nothing is fused across statements, function calls or overloaded vector operators). The CPU oracle is compiled by the same
+//     front end with the same flag.
+//   * 1/x is the hardware's v_rcp_f32, a / b is a * v_rcp_f32(b) (Div); sqrt and 1/sqrt are v_sqrt_f32 / v_rsq_f32; 2^x and log2 x go through
+//     v_exp_f32 / v_log_f32 on ONE binade with the range reduction spelled out (Exp2 / Log2 below). Each instruction is within 1 ulp of the
+//     correctly rounded result; the oracle reproduces it exactly from deviation tables measured on the device (oracle/hw_math.h).
+//   * No IEEE division, no libm call, no reassociation, fp32 denormals kept (the five instructions flush theirs, and so does the oracle).
+// The CPU oracle (oracle/) restates the same definitions independently; the two are compared bit for bit, because a loose tolerance would be
+// amplified by the chain's many thresholds (tap snapping, `> 11.5` material tests, fp16 ties, 6-bit counters).
 #pragma once
 
 #include <hip/hip_runtime.h>
@@ -38,17 +45,19 @@ NRD_D float Clamp(float x, float a, float b) { return Min(Max(x, a), b); }
 NRD_D float Sat(float x) { return Min(Max(x, 0.0f), 1.0f); }
 NRD_D float Lerp(float a, float b, float t) { return a + (b - a) * t; }
 NRD_D float Step(float edge, float x) { return x >= edge ? 1.0f : 0.0f; }
-// NRD_FAST (the default product build, DESIGN.md "Numerics"): hardware reciprocal / exp2 / log2 (v_rcp_f32, v_exp_f32, v_log_f32, within 1 ulp of the
-// correctly rounded result), FMA contraction, fp32 denormals flushed. Without it (libNRD_hip_exact.so) every operation is the pinned IEEE sequence
-// the CPU oracle restates, and the two agree bit for bit.
-#ifdef NRD_FAST
-NRD_D float Rcp(float x) { return __builtin_amdgcn_rcpf(x); }
-#else
-NRD_D float Rcp(float x) { return 1.0f / x; }
+// v_rcp_f32. The empty asm keeps the argument opaque to the optimiser: LLVM folds this intrinsic of a compile-time constant into the CORRECTLY
+// ROUNDED reciprocal, which is not what the instruction returns for 11 % of the mantissas (profiles/r03_a_hw_tables_report.txt) -- a constant
+// that reaches a division after inlining would then differ from the oracle by one ulp. The other four intrinsics are not folded.
+#ifndef NRD_OPAQUE_VALUE
+#define NRD_OPAQUE_VALUE(x) asm("" : "+v"(x))
 #endif
-// sqrt and 1/sqrt are the hardware's single instructions (v_sqrt_f32, v_rsq_f32: within 1 ulp of the correctly rounded result, denormals
-// flushed) instead of the ~14 / ~25-instruction correctly rounded expansions; the CPU oracle reproduces them bit for bit from per-mantissa
-// tables measured on the device (oracle/hlsl.h HwSqrt / HwRsq, tools/hw_transcendentals.py). Division stays correctly rounded.
+NRD_D float Rcp(float x) {
+    NRD_OPAQUE_VALUE(x);
+    return __builtin_amdgcn_rcpf(x);
+}
+// a / b of the contract: one multiplication by the hardware reciprocal (2 instructions instead of the ~11 of a correctly rounded division)
+NRD_D float Div(float a, float b) { return a * Rcp(b); }
+// sqrt and 1/sqrt: v_sqrt_f32, v_rsq_f32 (within 1 ulp of the correctly rounded result, denormals flushed)
 NRD_D float Sqrt(float x) { return __builtin_amdgcn_sqrtf(x); }
 NRD_D float Rsqrt(float x) { return __builtin_amdgcn_rsqf(x); }
 NRD_D float Abs(float x) { return fabsf(x); }
@@ -57,28 +66,17 @@ NRD_D float Frac(float x) { return x - floorf(x); }
 NRD_D uint32_t AsUint(float x) { return __float_as_uint(x); }
 NRD_D float AsFloat(uint32_t x) { return __uint_as_float(x); }
 
-// ------------------------------------------------------------------------------------------------ reproducible transcendentals
-// 2^x: nearest-integer split + degree-7 Taylor of 2^f on [-0.5, 0.5] (truncation < 6e-9), Horner, no FMA.
-#ifdef NRD_FAST
-NRD_D float Exp2(float x) { return __builtin_amdgcn_exp2f(Clamp(x, -125.0f, 125.0f)); }
-NRD_D float Log2(float x) { return x > 0.0f ? __builtin_amdgcn_logf(x) : -126.0f; }
-#else
+// ------------------------------------------------------------------------------------------------ transcendentals
+// 2^x = v_exp_f32(1 + frac(x)) * 2^(floor(x) - 1): the instruction only ever sees an argument in [1, 2] (x - floor(x) is exact; adding 1 rounds it to
+// 2^-23, a relative error of 2^-24 ln 2 in the result). v_exp_f32 of the raw argument would be one instruction shorter, but for negative and for
+// small arguments it is NOT this reduced form (it keeps extra internal bits) and cannot be tabulated for the oracle.
 NRD_D float Exp2(float x) {
     x = Clamp(x, -125.0f, 125.0f);
-    float fi = floorf(x + 0.5f);
-    float f = x - fi;
-    float p = 1.5252733805e-5f;
-    p = p * f + 1.5403530393e-4f;
-    p = p * f + 1.3333558146e-3f;
-    p = p * f + 9.6181291076e-3f;
-    p = p * f + 5.5504108665e-2f;
-    p = p * f + 2.4022650696e-1f;
-    p = p * f + 6.9314718056e-1f;
-    p = p * f + 1.0f;
-    return p * AsFloat((uint32_t)((int)fi + 127) << 23);
+    const float fl = floorf(x);
+    const float t = 1.0f + (x - fl);
+    return ldexpf(__builtin_amdgcn_exp2f(t), (int)fl - 1);
 }
-
-// log2(x), x > 0 (x <= 0 returns -126): mantissa folded to [sqrt(1/2), sqrt(2)), atanh series in s = (m-1)/(m+1).
+// log2(x) = e + v_log_f32(m), x = m * 2^e with m in [1, 2) (one fp32 addition; x <= 0 and NaN return -126)
 NRD_D float Log2(float x) {
     if (!(x > 0.0f))
         return -126.0f;
@@ -88,21 +86,9 @@ NRD_D float Log2(float x) {
         bits = AsUint(x * 8388608.0f);
         e = (int)(bits >> 23) - 127 - 23;
     }
-    float m = AsFloat((bits & 0x007FFFFFu) | 0x3F800000u); // [1, 2)
-    if (m > 1.41421356f) {
-        m = m * 0.5f;
-        e += 1;
-    }
-    float s = (m - 1.0f) / (m + 1.0f);
-    float s2 = s * s;
-    float p = 0.22222222f; // 2/9
-    p = p * s2 + 0.28571429f;     // 2/7
-    p = p * s2 + 0.4f;            // 2/5
-    p = p * s2 + 0.66666667f;     // 2/3
-    p = p * s2 + 2.0f;
-    return float(e) + (p * s) * 1.44269504f;
+    const float m = AsFloat((bits & 0x007FFFFFu) | 0x3F800000u);
+    return float(e) + __builtin_amdgcn_logf(m);
 }
-#endif
 
 NRD_D float Exp(float x) { return Exp2(x * 1.44269504f); }
 NRD_D float Log(float x) { return Log2(x) * 0.69314718f; }
@@ -116,10 +102,10 @@ NRD_D float Atan(float x) {
     float t = a;
     if (a > 2.41421356f) {
         base = 1.57079633f;
-        t = -1.0f / a;
+        t = -Rcp(a);
     } else if (a > 0.41421356f) {
         base = 0.78539816f;
-        t = (a - 1.0f) / (a + 1.0f);
+        t = Div(a - 1.0f, a + 1.0f);
     }
     float z = t * t;
     float p = 8.05374449538e-2f;
@@ -143,12 +129,8 @@ NRD_D float2 operator+(float2 a, float2 b) { return F2(a.x + b.x, a.y + b.y); }
 NRD_D float2 operator-(float2 a, float2 b) { return F2(a.x - b.x, a.y - b.y); }
 NRD_D float2 operator*(float2 a, float2 b) { return F2(a.x * b.x, a.y * b.y); }
 NRD_D float2 operator*(float2 a, float b) { return F2(a.x * b, a.y * b); }
-NRD_D float2 operator/(float2 a, float2 b) { return F2(a.x / b.x, a.y / b.y); }
-#ifdef NRD_FAST
-NRD_D float2 operator/(float2 a, float b) { float r = Rcp(b); return F2(a.x * r, a.y * r); }
-#else
-NRD_D float2 operator/(float2 a, float b) { return F2(a.x / b, a.y / b); }
-#endif
+NRD_D float2 Div(float2 a, float2 b) { return F2(Div(a.x, b.x), Div(a.y, b.y)); }
+NRD_D float2 Div(float2 a, float b) { float r = Rcp(b); return F2(a.x * r, a.y * r); }
 NRD_D float2 operator+(float2 a, float b) { return F2(a.x + b, a.y + b); }
 NRD_D float2 operator-(float2 a, float b) { return F2(a.x - b, a.y - b); }
 
@@ -157,21 +139,14 @@ NRD_D float3 operator-(float3 a, float3 b) { return F3(a.x - b.x, a.y - b.y, a.z
 NRD_D float3 operator-(float3 a) { return F3(-a.x, -a.y, -a.z); }
 NRD_D float3 operator*(float3 a, float3 b) { return F3(a.x * b.x, a.y * b.y, a.z * b.z); }
 NRD_D float3 operator*(float3 a, float b) { return F3(a.x * b, a.y * b, a.z * b); }
-#ifdef NRD_FAST
-NRD_D float3 operator/(float3 a, float b) { float r = Rcp(b); return F3(a.x * r, a.y * r, a.z * r); }
-#else
-NRD_D float3 operator/(float3 a, float b) { return F3(a.x / b, a.y / b, a.z / b); }
-#endif
+NRD_D float3 Div(float3 a, float b) { float r = Rcp(b); return F3(a.x * r, a.y * r, a.z * r); }
 
 NRD_D float4 operator+(float4 a, float4 b) { return F4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w); }
 NRD_D float4 operator-(float4 a, float4 b) { return F4(a.x - b.x, a.y - b.y, a.z - b.z, a.w - b.w); }
 NRD_D float4 operator*(float4 a, float4 b) { return F4(a.x * b.x, a.y * b.y, a.z * b.z, a.w * b.w); }
 NRD_D float4 operator*(float4 a, float b) { return F4(a.x * b, a.y * b, a.z * b, a.w * b); }
-#ifdef NRD_FAST
-NRD_D float4 operator/(float4 a, float b) { float r = Rcp(b); return F4(a.x * r, a.y * r, a.z * r, a.w * r); }
-#else
-NRD_D float4 operator/(float4 a, float b) { return F4(a.x / b, a.y / b, a.z / b, a.w / b); }
-#endif
+NRD_D float4 Div(float4 a, float b) { float r = Rcp(b); return F4(a.x * r, a.y * r, a.z * r, a.w * r); }
+NRD_D float4 Div(float4 a, float4 b) { return F4(Div(a.x, b.x), Div(a.y, b.y), Div(a.z, b.z), Div(a.w, b.w)); }
 NRD_D float4 operator-(float4 a, float b) { return F4(a.x - b, a.y - b, a.z - b, a.w - b); }
 
 // component-wise select: `cond ? a : b` on two vector LVALUES is an lvalue conditional, which the compiler implements as a
@@ -204,7 +179,7 @@ NRD_D float4 Step(float4 edge, float4 x) { return F4(Step(edge.x, x.x), Step(edg
 NRD_D float3 Step(float3 edge, float x) { return F3(Step(edge.x, x), Step(edge.y, x), Step(edge.z, x)); }
 
 // ------------------------------------------------------------------------------------------------ Math::
-NRD_D float LinearStep(float a, float b, float x) { return Sat((x - a) / (b - a)); }
+NRD_D float LinearStep(float a, float b, float x) { return Sat(Div(x - a, b - a)); }
 NRD_D float SmoothStep01(float x) {
     x = Sat(x);
     return x * x * (3.0f - 2.0f * x);
@@ -212,7 +187,7 @@ NRD_D float SmoothStep01(float x) {
 NRD_D float SmoothStep(float a, float b, float x) { return SmoothStep01(LinearStep(a, b, x)); }
 NRD_D float Sqrt01(float x) { return Sqrt(Sat(x)); }
 NRD_D float Pow01(float x, float y) { return Pow(Sat(x), y); }
-NRD_D float PositiveRcp(float x) { return 1.0f / Max(x, 1e-15f); }
+NRD_D float PositiveRcp(float x) { return Rcp(Max(x, 1e-15f)); }
 NRD_D float AcosApprox(float x) { return 1.41421356f * Sqrt(Sat(1.0f - x)); } // sqrt(2) * sqrt(saturate(1 - x))
 NRD_D float Pow5(float x) {                                                  // BRDF::Pow5 = (1 - x)^5 on saturated input
     float t = Sat(1.0f - x);
@@ -238,7 +213,7 @@ NRD_D float4 ProjectiveTransform(const float* m, float3 p) {
 // clip -> uv with y flipped; points behind the camera are sent far off-screen
 NRD_D float2 GetScreenUv(const float* worldToClip, float3 X) {
     float4 clip = ProjectiveTransform(worldToClip, X);
-    float2 uv = F2((clip.x / clip.w) * 0.5f + 0.5f, (clip.y / clip.w) * -0.5f + 0.5f);
+    float2 uv = F2(Div(clip.x, clip.w) * 0.5f + 0.5f, Div(clip.y, clip.w) * -0.5f + 0.5f);
     return clip.w < 0.0f ? F2(99999.0f, 99999.0f) : uv;
 }
 // inverse of the above for a known viewZ: Xv.xy = (uv * frustum.zw + frustum.xy) * viewZ (perspective)
@@ -252,7 +227,7 @@ NRD_D float4 ScaleRotator(float4 r, float2 s) { return F4(r.x * s.x, r.y * s.x, 
 // branch-free orthonormal basis (Duff et al. 2017): T, B such that {T, B, N} is right-handed
 NRD_D void GetBasis(float3 N, float3& T, float3& B) {
     float sz = N.z >= 0.0f ? 1.0f : -1.0f;
-    float a = 1.0f / (sz + N.z);
+    float a = Rcp(sz + N.z);
     float ya = N.y * a;
     float b = N.x * ya;
     float c = N.x * sz;
@@ -277,8 +252,8 @@ NRD_D float3 EnvironmentTerm_Rtg(float3 Rf0, float NoV, float roughness) {
     float biasDen = (1.0f + 2.92338f * x1 + 59.4188f * x3) + (20.3225f + -27.0302f * x1 + 222.592f * x3) * y1 + (121.563f + 626.13f * x1 + 316.627f * x3) * y3;
     float scaleNum = (0.0365463f + 3.32707f * x1) + (9.0632f + -9.04756f * x1) * y1;
     float scaleDen = (1.0f + 3.59685f * x2 + -1.36772f * x3) + (9.04401f + -16.3174f * x2 + 9.22949f * x3) * y1 + (5.56589f + 19.7886f * x2 + -20.2123f * x3) * y3;
-    float bias = biasNum * (1.0f / Max(biasDen, 1e-6f));
-    float scale = scaleNum * (1.0f / Max(scaleDen, 1e-6f));
+    float bias = biasNum * Rcp(Max(biasDen, 1e-6f));
+    float scale = scaleNum * Rcp(Max(scaleDen, 1e-6f));
     return F3(Sat(Rf0.x * scale + bias), Sat(Rf0.y * scale + bias), Sat(Rf0.z * scale + bias));
 }
 NRD_D float ColorClamp(float m1, float sigma, float x) { return Clamp(x, m1 - sigma, m1 + sigma); }
@@ -306,7 +281,7 @@ NRD_D uint32_t Bayer4x4ui(uint32_t x, uint32_t y, uint32_t frameIndex) {
     uint32_t b = (y + ((x & 1u) << 2)) << 2;
     return ((a >> b) + frameIndex) & 0xFu;
 }
-NRD_D float Bayer4x4(uint32_t x, uint32_t y, uint32_t frameIndex) { return (float(Bayer4x4ui(x, y, frameIndex)) + 0.5f) / 16.0f; }
+NRD_D float Bayer4x4(uint32_t x, uint32_t y, uint32_t frameIndex) { return (float(Bayer4x4ui(x, y, frameIndex)) + 0.5f) * 0.0625f; }
 
 // Rng::Hash -- OUR definition (MathLib's is unavailable): PCG-style state seeded from (pixel, frame)
 struct RngHash {
@@ -361,7 +336,7 @@ NRD_D float ApplyBilinearFilter(float s00, float s10, float s01, float s11, Bili
 NRD_D float ApplyBilinearCustomWeights(float s00, float s10, float s01, float s11, float4 w) {
     float sum = w.x + w.y + w.z + w.w;
     float r = s00 * w.x + s10 * w.y + s01 * w.z + s11 * w.w;
-    return sum < 0.0001f ? 0.0f : r / sum;
+    return sum < 0.0001f ? 0.0f : Div(r, sum);
 }
 // top-left texel of the 4x4 Catmull-Rom footprint (reference REBLUR_TemporalAccumulation.hlsli:152-171)
 NRD_D float2 GetCatmullRomOrigin(float2 uv, float2 texSize) {
@@ -370,7 +345,7 @@ NRD_D float2 GetCatmullRomOrigin(float2 uv, float2 texSize) {
 }
 NRD_D float GetModifiedRoughnessFromNormalVariance(float linearRoughness, float3 nonNormalizedAverageNormal) {
     float l = Length(nonNormalizedAverageNormal);
-    float kappa = Sat(1.0f - l * l) / Max(l * (3.0f - l * l), 1e-15f);
+    float kappa = Div(Sat(1.0f - l * l), Max(l * (3.0f - l * l), 1e-15f));
     return Sqrt(Sat(linearRoughness * linearRoughness + kappa));
 }
 
@@ -379,7 +354,7 @@ NRD_D float GetSpecularLobeTanHalfAngle(float linearRoughness, float percentOfVo
     float r = Sat(linearRoughness);
     float p = Sat(percentOfVolume);
     float m = r * r;
-    return m * Sqrt(p / (1.0f - p + NRD_EPS)); // the "fixed" MathLib form (see reference Reblur.cpp:384, RELAX_Common.hlsli:113-122)
+    return m * Sqrt(Div(p, 1.0f - p + NRD_EPS)); // the "fixed" MathLib form (see reference Reblur.cpp:384, RELAX_Common.hlsli:113-122)
 }
 NRD_D float GetSpecularDominantFactor(float NoV, float linearRoughness) { // G2 fit, reference NRD.hlsli:386-392
     float a = 0.298475f * Log(39.4115f - 39.0029f * linearRoughness);

@@ -16,11 +16,7 @@
 #define NRD_WAVES_REBLUR_SPATIAL 0
 #endif
 #ifndef NRD_WAVES_REBLUR_HF
-#if NRD_FAST
-#define NRD_WAVES_REBLUR_HF 6 // 111 -> 80 VGPRs without scratch: -12 % (profiles/r02_g_occ_reblur.json)
-#else
 #define NRD_WAVES_REBLUR_HF 0
-#endif
 #endif
 #ifndef NRD_WAVES_REBLUR_TS
 #define NRD_WAVES_REBLUR_TS 0

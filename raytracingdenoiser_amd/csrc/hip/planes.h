@@ -51,9 +51,6 @@ NRD_D T* TexelPtr(const Plane& p, int x, int y) {
 // of the ~11 of a generic correctly rounded division: q0 = k * RN(1/c), r = fma(-q0, c, k) (exact), q = fma(r, RN(1/c), q0).
 // Exhaustively verified for every numerator the codecs can produce (tests/test_numerics.py: c = 65535, 1023, 255, 63, 15, 3).
 NRD_D float DivSmallIntByConst(float k, float c, float rcpC) {
-#ifdef NRD_FAST
-    return k * rcpC; // within 1 ulp of the quotient
-#endif
     float q0 = k * rcpC;
     float r = __builtin_fmaf(-q0, c, k);
     return __builtin_fmaf(r, rcpC, q0);
@@ -75,9 +72,6 @@ NRD_D float HalfBitsToFloat(uint16_t h) { return __half2float(__ushort_as_half(h
 #define NRD_OPAQUE_CVT_F16(h, f) asm("v_cvt_f16_f32 %0, %1" : "=v"(h) : "v"(f))
 #endif
 NRD_D uint16_t FloatToHalfBits(float f) {
-#ifdef NRD_FAST
-    return __half_as_ushort(__float2half_rn(f)); // the compiler may fuse the producing multiply (v_fma_mixlo_f16) and pack pairs (v_cvt_pk_f16_f32)
-#endif
     uint32_t h;
     NRD_OPAQUE_CVT_F16(h, f);
     return (uint16_t)h;
@@ -107,10 +101,20 @@ NRD_D float4 LoadRGBA16F(const Plane& p, int x, int y) {
     r.w = HalfBitsToFloat((uint16_t)(raw.y >> 16));
     return r;
 }
+// two conversions and the packing in ONE instruction (gfx950's v_cvt_pk_f16_f32: each half rounded to nearest even exactly as v_cvt_f16_f32 does,
+// tests/test_numerics.py); opaque for the same reason as above
+#ifndef NRD_OPAQUE_CVT_PK_F16
+#define NRD_OPAQUE_CVT_PK_F16(r, a, b) asm("v_cvt_pk_f16_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b))
+#endif
+NRD_D uint32_t FloatsToHalf2Bits(float lo, float hi) {
+    uint32_t r;
+    NRD_OPAQUE_CVT_PK_F16(r, lo, hi);
+    return r;
+}
 NRD_D void StoreRGBA16F(const Plane& p, int x, int y, float4 v) {
     uint2 raw;
-    raw.x = (uint32_t)FloatToHalfBits(v.x) | ((uint32_t)FloatToHalfBits(v.y) << 16);
-    raw.y = (uint32_t)FloatToHalfBits(v.z) | ((uint32_t)FloatToHalfBits(v.w) << 16);
+    raw.x = FloatsToHalf2Bits(v.x, v.y);
+    raw.y = FloatsToHalf2Bits(v.z, v.w);
     *TexelPtr<uint2>(p, x, y) = raw;
 }
 

@@ -9,13 +9,8 @@
 #include "nrdmath.h"
 #include "planes.h"
 
-// The REBLUR launchers reject orthographic projections (CheckSupported), so the fast build folds gOrthoMode = 0 into the arithmetic; the exact build keeps
-// the reference's expressions (x * (1 - |0|) + 0 is not x for the compiler without -fno-signed-zeros)
-#if NRD_FAST
-#define NRD_ORTHO_MODE(c) 0.0f
-#else
+// The REBLUR launchers reject orthographic projections (CheckSupported); the arithmetic keeps the reference's expressions with gOrthoMode = 0
 #define NRD_ORTHO_MODE(c) ((c).gOrthoMode)
-#endif
 
 namespace nrdhip {
 
@@ -49,9 +44,9 @@ NRD_D float2 ToF2(nrdc::F2 v) { return F2(v.x, v.y); }
 
 // ---- Poisson-like 8-tap kernel (reference Common.hlsli:181-192) ------------------------------------------------------
 // GetGaussianWeight( offset.z ) = Exp( -0.66 z^2 ) only ever sees z = 1 and z = 0.5: the two results of OUR Exp() are
-// baked in as bit patterns (0x3f04505e, 0x3f590f90; tests/test_numerics.py re-derives them on the GPU).
-#define REBLUR_GAUSSIAN_WEIGHT_Z1 0.5168513059616089f
-#define REBLUR_GAUSSIAN_WEIGHT_Z05 0.8478937149047852f
+// baked in as bit patterns (0x3f04505f, 0x3f590f8f; tests/test_numerics.py re-derives them on the GPU).
+#define REBLUR_GAUSSIAN_WEIGHT_Z1 0.5168513655662537f
+#define REBLUR_GAUSSIAN_WEIGHT_Z05 0.8478936553001404f
 #define REBLUR_GAUSSIAN_WEIGHT_Z03 0.9423297643661499f // 0x3f713c86: the inner ring of g_Special6 (performance mode)
 // g_Special6 (reference Common.hlsli:170-179): 0.5 * sqrt(3) and 0.15 * sqrt(3) rounded to fp32
 __device__ __constant__ const float g_Special6[6][3] = {{-0.8660254f, -0.5f, 1.0f}, {0.0f, 1.0f, 1.0f}, {0.8660254f, -0.5f, 1.0f},
@@ -62,7 +57,7 @@ __device__ __constant__ const float g_Special8[8][3] = {{-1.0f, 0.0f, 1.0f}, {0.
 
 // ---- storage packing ----------------------------------------------------------------------------------------------
 NRD_D uint32_t PackInternalData(float diffAccumSpeed, float specAccumSpeed, float materialID) {
-    float tx = diffAccumSpeed / REBLUR_MAX_ACCUM_FRAME_NUM, ty = specAccumSpeed / REBLUR_MAX_ACCUM_FRAME_NUM, tz = materialID / REBLUR_MAX_MATERIALID_NUM;
+    float tx = Div(diffAccumSpeed, REBLUR_MAX_ACCUM_FRAME_NUM), ty = Div(specAccumSpeed, REBLUR_MAX_ACCUM_FRAME_NUM), tz = Div(materialID, REBLUR_MAX_MATERIALID_NUM);
     uint32_t p = (uint32_t)floorf(Sat(tx) * 63.0f + 0.5f);
     p |= (uint32_t)floorf(Sat(ty) * 63.0f + 0.5f) << 6;
     p |= (uint32_t)floorf(Sat(tz) * 15.0f + 0.5f) << 12;
@@ -78,7 +73,7 @@ NRD_D float3 UnpackInternalData(uint32_t p) {
 // DATA1: RG8_UNORM for diffuse+specular, R8_UNORM for a single signal (both channels alias)
 template <bool DIFF, bool SPEC>
 NRD_D void StoreData1(const Plane& p, int x, int y, float diffAccumSpeed, float specAccumSpeed) {
-    float rx = Sat(diffAccumSpeed / REBLUR_MAX_ACCUM_FRAME_NUM), ry = Sat(specAccumSpeed / REBLUR_MAX_ACCUM_FRAME_NUM);
+    float rx = Sat(Div(diffAccumSpeed, REBLUR_MAX_ACCUM_FRAME_NUM)), ry = Sat(Div(specAccumSpeed, REBLUR_MAX_ACCUM_FRAME_NUM));
     if (DIFF && SPEC)
         StoreRG8Unorm(p, x, y, F2(rx, ry));
     else
@@ -116,7 +111,7 @@ NRD_D float3 GetViewVectorPrev(const ReblurCB& c, float3 Xprev, float3 cameraDel
 }
 NRD_D float PixelRadiusToWorld(float unproject, float orthoMode, float pixelRadius, float viewZ) { return pixelRadius * unproject * Lerp(viewZ, 1.0f, Abs(orthoMode)); }
 NRD_D float GetFrustumSize(float minRectDimMulUnproject, float orthoMode, float viewZ) { return minRectDimMulUnproject * Lerp(viewZ, 1.0f, Abs(orthoMode)); }
-NRD_D float GetHitDistFactor(float hitDist, float frustumSize) { return Sat(hitDist / frustumSize); }
+NRD_D float GetHitDistFactor(float hitDist, float frustumSize) { return Sat(Div(hitDist, frustumSize)); }
 NRD_D float IsInScreenNearest(float2 uv) { return (uv.x > 0.0f && uv.y > 0.0f && uv.x < 1.0f && uv.y < 1.0f) ? 1.0f : 0.0f; }
 NRD_D float4 IsInScreenBilinear(float2 footprintOrigin, float2 rectSize) {
     float4 p = F4(footprintOrigin.x, footprintOrigin.y, footprintOrigin.x + 1.0f, footprintOrigin.y + 1.0f);
@@ -144,16 +139,16 @@ NRD_D float3 GetXvirtual(float hitDist, float curvature, float3 X, float3 Xprev,
     float3 O = F3(Dot(T, reflectionRay), Dot(B, reflectionRay), Dot(N, reflectionRay));
     O.z = -O.z;
 
-    float mag = 1.0f / (2.0f * curvature * O.z - 1.0f);
+    float mag = Rcp(2.0f * curvature * O.z - 1.0f);
     float f = Length(X);
     f *= 1.0f - Abs(Dot(N, V));
     f *= Max(curvature, 0.0f);
-    mag *= 1.0f / (1.0f + f);
+    mag *= Rcp(1.0f + f);
 
     float3 I = O * mag;
     Iw = Iw * Length(I);
 
-    float closenessToSurface = Sat(Length(Iw) / (hitDist + NRD_EPS));
+    float closenessToSurface = Sat(Div(Length(Iw), hitDist + NRD_EPS));
     float3 origin = Lerp(Xprev, X, closenessToSurface * D.w);
     return origin - Iw * D.w;
 }
@@ -162,8 +157,8 @@ NRD_D float2 GetKernelSampleCoordinates(const float* mToClip, float3 offset, flo
     float3 p = X + T * o.x + B * o.y;
     float4 clip4 = ProjectiveTransform(mToClip, p);
     float3 clip = F3(clip4.x, clip4.y, clip4.w);
-    clip.x /= clip.z;
-    clip.y /= clip.z;
+    clip.x = Div(clip.x, clip.z);
+    clip.y = Div(clip.y, clip.z);
     clip.y = -clip.y;
     return F2(clip.x * 0.5f + 0.5f, clip.y * 0.5f + 0.5f);
 }
@@ -172,28 +167,28 @@ NRD_D float GetNormalWeightParam(float nonLinearAccumSpeed, float lobeAngleFract
     float tanHalfAngle = GetSpecularLobeTanHalfAngle(roughness, percentOfVolume);
     float angle = Atan(tanHalfAngle);
     angle = Max(angle, NRD_NORMAL_ENCODING_ERROR);
-    return 1.0f / angle;
+    return Rcp(angle);
 }
 NRD_D float2 GetGeometryWeightParams(float planeDistSensitivity, float frustumSize, float3 Xv, float3 Nv) {
     float norm = planeDistSensitivity * frustumSize;
-    float a = 1.0f / norm;
+    float a = Rcp(norm);
     float b = Dot(Nv, Xv) * a;
     return F2(a, -b);
 }
 NRD_D float2 GetHitDistanceWeightParams(float hitDist, float nonLinearAccumSpeed, float roughness = 1.0f) {
     float smc = GetSpecMagicCurve(roughness);
     float norm = Lerp(0.0005f, 1.0f, Min(nonLinearAccumSpeed, smc));
-    float a = 1.0f / norm;
+    float a = Rcp(norm);
     float b = hitDist * a;
     return F2(a, -b);
 }
 NRD_D float2 GetRoughnessWeightParams(float roughness, float fraction, float sensitivity = NRD_ROUGHNESS_SENSITIVITY) {
-    float a = 1.0f / Lerp(sensitivity, 1.0f, Sat(roughness * fraction));
+    float a = Rcp(Lerp(sensitivity, 1.0f, Sat(roughness * fraction)));
     float b = roughness * a;
     return F2(a, -b);
 }
 NRD_D float2 GetRelaxedRoughnessWeightParams(float m, float fraction = 1.0f, float sensitivity = NRD_ROUGHNESS_SENSITIVITY) {
-    float a = 1.0f / Lerp(sensitivity, 1.0f, Lerp(m * m, m, fraction));
+    float a = Rcp(Lerp(sensitivity, 1.0f, Lerp(m * m, m, fraction)));
     float b = m * a;
     return F2(a, -b);
 }
@@ -206,9 +201,9 @@ NRD_D float GetGaussianWeight(float r) { return Exp(-0.66f * r * r); }
 NRD_D float GetEncodingAwareNormalWeight(float3 Ncurr, float3 Nprev, float maxAngle, float curvatureAngle, float thresholdAngle) {
     float cosa = Dot(Ncurr, Nprev);
     float angle = AcosApprox(cosa);
-    return SmoothStep01(1.0f - (angle - curvatureAngle - thresholdAngle) / maxAngle);
+    return SmoothStep01(1.0f - Div(angle - curvatureAngle - thresholdAngle, maxAngle));
 }
-NRD_D float GetDisocclusionThreshold(float disocclusionThreshold, float frustumSize, float NoV) { return frustumSize * Sat(disocclusionThreshold / Max(0.01f, NoV)); }
+NRD_D float GetDisocclusionThreshold(float disocclusionThreshold, float frustumSize, float NoV) { return frustumSize * Sat(Div(disocclusionThreshold, Max(0.01f, NoV))); }
 #if NRD_EXPERIMENT_NO_MATERIALS // A/B builds only: what a compile-time "no material test in this frame" flag would buy (tools/build_variant.py)
 NRD_D bool CompareMaterials(float, float, float) { return true; }
 #else
@@ -217,25 +212,25 @@ NRD_D bool CompareMaterials(float m0, float m, float minm) { return Max(m0, minm
 
 NRD_D float GetMinAllowedLimitForHitDistNonLinearAccumSpeed(const ReblurCB& c, float roughness) {
     float frameNum = 0.5f * GetSpecMagicCurve(roughness) * c.gMaxAccumulatedFrameNum;
-    return 1.0f / (1.0f + frameNum);
+    return Rcp(1.0f + frameNum);
 }
 NRD_D float GetFadeBasedOnAccumulatedFrames(const ReblurCB& c, float accumSpeed) {
-    float a = c.gHistoryFixFrameNum * 2.0f / 3.0f + 1e-6f;
-    float b = c.gHistoryFixFrameNum * 4.0f / 3.0f + 2e-6f;
+    float a = Div(c.gHistoryFixFrameNum * 2.0f, 3.0f) + 1e-6f;
+    float b = Div(c.gHistoryFixFrameNum * 4.0f, 3.0f) + 2e-6f;
     return LinearStep(a, b, accumSpeed);
 }
 template <typename CB> // reference REBLUR_Common.hlsli:111-124; hasData = false for the empty pixels of a checkerboarded input
 NRD_D float GetNonLinearAccumSpeed(const CB& c, float accumSpeed, float maxAccumSpeed, float confidence, bool hasData) {
-    float nonLinearAccumSpeed = Max(1.0f - confidence, 1.0f / (1.0f + Min(accumSpeed, maxAccumSpeed)));
+    float nonLinearAccumSpeed = Max(1.0f - confidence, Rcp(1.0f + Min(accumSpeed, maxAccumSpeed)));
     if (!hasData)
         nonLinearAccumSpeed *= Lerp(1.0f - c.gCheckerboardResolveAccumSpeed, 1.0f, nonLinearAccumSpeed);
     return nonLinearAccumSpeed;
 }
 NRD_D float RemapRoughnessToResponsiveFactor(const ReblurCB& c, float roughness) {
-    float amount = (roughness + NRD_EPS) / (c.gResponsiveAccumulationRoughnessThreshold + NRD_EPS);
+    float amount = Div(roughness + NRD_EPS, c.gResponsiveAccumulationRoughnessThreshold + NRD_EPS);
     return SmoothStep01(amount);
 }
-NRD_D float GetLumaScale(float currLuma, float newLuma) { return (newLuma + NRD_EPS) / (currLuma + NRD_EPS); }
+NRD_D float GetLumaScale(float currLuma, float newLuma) { return Div(newLuma + NRD_EPS, currLuma + NRD_EPS); }
 NRD_D float4 MixHistoryAndCurrent(const ReblurCB& c, float4 history, float4 current, float f, float roughness = 1.0f) {
     float4 r;
     r.x = Lerp(history.x, current.x, f);
@@ -292,8 +287,8 @@ NRD_D float ComputeAntilag(const ReblurCB& c, float history, float avg, float si
     float s = sigma * c.gAntilagParams.x;
     float magic = c.gAntilagParams.y * c.gFramerateScale * c.gFramerateScale;
     float hc = ColorClamp(a, s, h);
-    float d = Abs(h - hc) / (Max(h, hc) + NRD_EPS);
-    return 1.0f / (1.0f + d * accumSpeed / magic);
+    float d = Div(Abs(h - hc), Max(h, hc) + NRD_EPS);
+    return Rcp(1.0f + Div(d * accumSpeed, magic));
 }
 NRD_D void GetKernelBasis(float3 D, float3 N, float3& T, float3& B) {
     GetBasis(N, T, B);
@@ -306,7 +301,7 @@ NRD_D void GetKernelBasis(float3 D, float3 N, float3& T, float3& B) {
 NRD_D float2 GetTemporalAccumulationParams(const ReblurCB& c, float isInScreenMulFootprintQuality, float accumSpeed) {
     accumSpeed *= REBLUR_SAMPLES_PER_FRAME;
     float w = isInScreenMulFootprintQuality;
-    w *= accumSpeed / (1.0f + accumSpeed);
+    w *= Div(accumSpeed, 1.0f + accumSpeed);
     return F2(w, 1.0f + 3.0f * c.gFramerateScale * w);
 }
 
@@ -471,7 +466,7 @@ NRD_D HistoryFilter MakeHistoryGeometry(float2 samplePos, const Plane& dims) {
     float2 w12 = w1 + w2;
     h.cw = F4(w12.x * w0.y, w0.x * w12.y, w12.x * w12.y, w3.x * w12.y);
     h.cw4 = w12.x * w3.y;
-    h.tc = w2 / w12;
+    h.tc = Div(w2, w12);
     const int kx = (int)origin.x, ky = (int)origin.y;
 #pragma unroll
     for (int i = 0; i < 4; i++) {
@@ -517,7 +512,7 @@ NRD_D V FetchHistoryGeneric(const HistoryFilter& h, const Plane& tex, LoadFn loa
         color = color + t01 * h.w.z;
         color = color + t11 * h.w.w;
     }
-    return h.sum < 0.0001f ? zero : color / h.sum;
+    return h.sum < 0.0001f ? zero : Div(color, h.sum);
 }
 // Two / four horizontally adjacent RGBA16F texels with one 16-byte request each (8-byte aligned: legal for global_load_dwordx4).
 // The temporal passes are limited by the number of L1 requests, not by bytes: one request per texel pair halves them.
@@ -588,7 +583,7 @@ NRD_D float4 FetchHistoryRGBA16F(const HistoryFilter& h, const Plane& tex, const
         color = color + c1 * h.w.z;
         color = color + c2 * h.w.w;
     }
-    return h.sum < 0.0001f ? F4(0.0f) : color / h.sum;
+    return h.sum < 0.0001f ? F4(0.0f) : Div(color, h.sum);
 }
 NRD_D float4 FetchHistoryRGBA16F(const HistoryFilter& h, const Plane& tex) {
     // interior footprint (no coordinate was clamped): the 12 texels are 2 + 4 + 4 + 2 contiguous runs -> 6 requests instead of 12
@@ -622,7 +617,7 @@ NRD_D float FetchHistoryR16F(const HistoryFilter& h, const Plane& tex) {
     color = color + s2 * h.w.z;
     color = color + s3 * h.w.w;
     color = color + s4 * h.w4;
-    return h.sum < 0.0001f ? 0.0f : color / h.sum;
+    return h.sum < 0.0001f ? 0.0f : Div(color, h.sum);
 }
 // custom-weight bilinear fetch of an RGBA16F plane (the SH1 histories; reference REBLUR_Common.hlsli:350-361 fetches them this way)
 NRD_D float4 FetchHistoryBilinearRGBA16F(const HistoryFilter& h, const Plane& tex) {
@@ -632,7 +627,7 @@ NRD_D float4 FetchHistoryBilinearRGBA16F(const HistoryFilter& h, const Plane& te
     color = color + at(h.ox, h.oy + 1) * h.bw.z;
     color = color + at(h.ox + 1, h.oy + 1) * h.bw.w;
     float s = Sum(h.bw);
-    return s < 0.0001f ? F4(0.0f) : color / s;
+    return s < 0.0001f ? F4(0.0f) : Div(color, s);
 }
 struct BilinearTexelsR16F { // the 2x2 footprint of the Load-based bilinear path as two undecoded 4-byte rows; `loaded` as above
     uint32_t r0, r1;
@@ -658,7 +653,7 @@ NRD_D float FetchHistoryBilinearR16F(const HistoryFilter& h, const Plane& tex, c
     color += s01 * h.bw.z;
     color += s11 * h.bw.w;
     float s = Sum(h.bw);
-    return s < 0.0001f ? 0.0f : color / s;
+    return s < 0.0001f ? 0.0f : Div(color, s);
 }
 NRD_D float FetchHistoryBilinearR16F(const HistoryFilter& h, const Plane& tex) {
     BilinearTexelsR16F t;
@@ -703,7 +698,7 @@ NRD_D float FetchHistoryBilinearR16Unorm(const HistoryFilter& h, const Plane& te
     color += at(h.ox, h.oy + 1) * h.bw.z;
     color += at(h.ox + 1, h.oy + 1) * h.bw.w;
     float s = Sum(h.bw);
-    return s < 0.0001f ? 0.0f : color / s;
+    return s < 0.0001f ? 0.0f : Div(color, s);
 }
 template <>
 struct ReblurSignal<SIGNAL_OCCLUSION> {

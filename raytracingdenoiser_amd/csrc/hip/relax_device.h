@@ -77,7 +77,6 @@ NRD_D float LoadR32FOrZero(const Plane& p, int x, int y) { return InBounds(p, x,
 NRD_D float LoadR8UnormOrZero(const Plane& p, int x, int y) { return InBounds(p, x, y) ? LoadR8Unorm(p, x, y) : 0.0f; }
 
 NRD_D float4 operator*(float a, float4 b) { return F4(a * b.x, a * b.y, a * b.z, a * b.w); }
-NRD_D float4 operator/(float4 a, float4 b) { return F4(a.x / b.x, a.y / b.y, a.z / b.z, a.w / b.w); }
 NRD_D float3 operator*(float a, float3 b) { return F3(a * b.x, a * b.y, a * b.z); }
 NRD_D float3 Min3(float3 a, float3 b) { return F3(Min(a.x, b.x), Min(a.y, b.y), Min(a.z, b.z)); }
 NRD_D float3 Max3(float3 a, float3 b) { return F3(Max(a.x, b.x), Max(a.y, b.y), Max(a.z, b.z)); }
@@ -133,13 +132,13 @@ NRD_D float3 GetPreviousWorldPosFromClipSpaceXY(const RelaxCB& c, float2 clip, f
     return WorldPosFromClip(ToF3(c.shared.gPrevFrustumRight), ToF3(c.shared.gPrevFrustumUp), ToF3(c.shared.gPrevFrustumForward), clip, viewZ);
 }
 NRD_D float3 GetPreviousWorldPosFromPixelPos(const RelaxCB& c, int px, int py, float viewZ) {
-    float2 rcpSize = F2(1.0f / c.shared.gRectSizePrev.x, 1.0f / c.shared.gRectSizePrev.y);
+    float2 rcpSize = F2(Rcp(c.shared.gRectSizePrev.x), Rcp(c.shared.gRectSizePrev.y));
     float2 clip = F2(float(px) + 0.5f, float(py) + 0.5f) * rcpSize * 2.0f - 1.0f;
     return GetPreviousWorldPosFromClipSpaceXY(c, clip, viewZ);
 }
 NRD_D float GetPlaneDistanceWeight(float3 centerWorldPos, float3 centerNormal, float centerViewZ, float3 sampleWorldPos, float threshold) {
     float d = Abs(Dot(sampleWorldPos - centerWorldPos, centerNormal));
-    return d / centerViewZ > threshold ? 0.0f : 1.0f;
+    return Div(d, centerViewZ) > threshold ? 0.0f : 1.0f;
 }
 NRD_D float GetPlaneDistanceWeight_Atrous(float3 centerWorldPos, float3 centerNormal, float3 sampleWorldPos, float threshold) {
     float d = Abs(Dot(sampleWorldPos - centerWorldPos, centerNormal));
@@ -148,11 +147,11 @@ NRD_D float GetPlaneDistanceWeight_Atrous(float3 centerWorldPos, float3 centerNo
 NRD_D float GetSpecLobeTanHalfAngleOld(float roughness, float percentOfVolume = 0.75f) { // RELAX keeps the pre-fix lobe formula
     roughness = Sat(roughness);
     percentOfVolume = Sat(percentOfVolume);
-    return roughness * roughness * percentOfVolume / (1.0f - percentOfVolume + NRD_EPS);
+    return Div(roughness * roughness * percentOfVolume, 1.0f - percentOfVolume + NRD_EPS);
 }
 NRD_D float2 GetNormalWeightParams_ATrous(float roughness, float numFramesInHistory, float specularReprojectionConfidence, float normalEdgeStoppingRelaxation,
     float specularLobeAngleFraction, float specularLobeAngleSlack) {
-    float relaxation = Sat(numFramesInHistory / 5.0f);
+    float relaxation = Sat(Div(numFramesInHistory, 5.0f));
     relaxation *= Lerp(1.0f, specularReprojectionConfidence, normalEdgeStoppingRelaxation);
     float f = 0.9f + 0.1f * relaxation;
     float angle = Atan(GetSpecLobeTanHalfAngleOld(roughness, specularLobeAngleFraction));
@@ -171,7 +170,7 @@ NRD_D float GetSpecularNormalWeight_ATrous(float2 params0, float3 n0, float3 n, 
 }
 NRD_D float GetNormalWeightParam2(float roughness, float angleFraction) {
     float angle = Atan(GetSpecLobeTanHalfAngleOld(roughness, angleFraction));
-    return 1.0f / Max(angle, RELAX_NORMAL_ULP);
+    return Rcp(Max(angle, RELAX_NORMAL_ULP));
 }
 NRD_D float GetEncodingAwareNormalWeightR(float3 Ncurr, float3 Nprev, float maxAngle, float curvatureAngle, float thresholdAngle, bool remap) {
     float w = GetEncodingAwareNormalWeight(Ncurr, Nprev, maxAngle, curvatureAngle, thresholdAngle);
@@ -181,14 +180,14 @@ NRD_D float GetEncodingAwareNormalWeightR(float3 Ncurr, float3 Nprev, float maxA
 }
 NRD_D float2 ScreenUvNoKill(const float* worldToClip, float3 X) {
     float4 clip = ProjectiveTransform(worldToClip, X);
-    return F2((clip.x / clip.w) * 0.5f + 0.5f, (clip.y / clip.w) * -0.5f + 0.5f);
+    return F2((Div(clip.x, clip.w)) * 0.5f + 0.5f, (Div(clip.y, clip.w)) * -0.5f + 0.5f);
 }
 NRD_D float2 RelaxClampUvToViewport(const RelaxCB& c, float2 uv) {
     float2 a = uv * ToF2(c.shared.gResolutionScale);
     float2 b = ToF2(c.shared.gResolutionScale) - ToF2(c.shared.gResourceSizeInv) * 0.5f;
     return F2(Min(a.x, b.x), Min(a.y, b.y));
 }
-NRD_D float ApplyThinLensEquation(float O, float curvature) { return O / (2.0f * curvature * O + 1.0f); } // reference Common.hlsli:404-409
+NRD_D float ApplyThinLensEquation(float O, float curvature) { return Div(O, 2.0f * curvature * O + 1.0f); } // reference Common.hlsli:404-409
 NRD_D float4 Denanify(float w, float4 x) { return w == 0.0f ? F4(0.0f) : x; }
 
 // true when any of the 16x16 tiles overlapped by this workgroup's 32x8 block has geometry

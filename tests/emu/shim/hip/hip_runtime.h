@@ -132,6 +132,9 @@ inline float emu_fmed3f(float a, float b, float c) { return std::max(std::min(a,
 #define __builtin_amdgcn_kernarg_segment_ptr() ((void*)emu::t_kernarg)
 // the one opaque instruction of the device sources (planes.h FloatToHalfBits): fp32 -> fp16, round to nearest even, denormals kept
 #define NRD_OPAQUE_CVT_F16(h, f) (h) = hwmath::F32ToF16Bits(f)
+#define NRD_OPAQUE_CVT_PK_F16(r, a, b) (r) = (uint32_t)hwmath::F32ToF16Bits(a) | ((uint32_t)hwmath::F32ToF16Bits(b) << 16)
+// nrdmath.h Rcp: the device hides the argument from the constant folder; nothing to hide from here
+#define NRD_OPAQUE_VALUE(x) ((void)0)
 
 // ------------------------------------------------------------------------------------------------ runtime API (host side of executor.hip)
 typedef int hipError_t;
