@@ -257,36 +257,57 @@ inline HistoryFilter MakeHistoryFilter(float2 samplePos, float4 bilinearCustomWe
     h.useBicubic = useBicubic;
     return h;
 }
-inline float4 FetchHistoryColor(const HistoryFilter& h, const Tex& tex) {
-    auto T = [&](int dx, int dy) { return tex.FetchClamped(h.kx + dx, h.ky + dy); };
-    float4 color;
+// V = float4 (RGBA planes) or float (single-channel planes: `get` picks .x). The scalar instantiation is NOT the .x of the vector one: with
+// -ffp-contract=on `a * b + c` on scalars is one fma, while the overloaded vector operators round the product first (hlsl.h) -- exactly as the
+// device's FetchHistoryGeneric<float4> / <float> and its scalar row-load paths do.
+template <typename V, typename Get>
+inline V FetchHistoryT(const HistoryFilter& h, const Tex& tex, Get get, V zero) {
+    auto T = [&](int dx, int dy) { return get(tex.FetchClamped(h.kx + dx, h.ky + dy)); };
+    V color;
     if (h.useBicubic) {
         float fx = h.tc.x, fy = h.tc.y, gx = 1.0f - fx, gy = 1.0f - fy;
-        float4 s0 = T(0, -1) * gx + T(1, -1) * fx;
-        float4 s1 = T(-1, 0) * gy + T(-1, 1) * fy;
-        float4 s2 = T(0, 0) * (gx * gy) + T(1, 0) * (fx * gy) + T(0, 1) * (gx * fy) + T(1, 1) * (fx * fy);
-        float4 s3 = T(2, 0) * gy + T(2, 1) * fy;
-        float4 s4 = T(0, 2) * gx + T(1, 2) * fx;
+        V s0 = T(0, -1) * gx + T(1, -1) * fx;
+        V s1 = T(-1, 0) * gy + T(-1, 1) * fy;
+        V s2 = T(0, 0) * (gx * gy) + T(1, 0) * (fx * gy) + T(0, 1) * (gx * fy) + T(1, 1) * (fx * fy);
+        V s3 = T(2, 0) * gy + T(2, 1) * fy;
+        V s4 = T(0, 2) * gx + T(1, 2) * fx;
         color = s0 * h.w.x;
-        color += s1 * h.w.y;
-        color += s2 * h.w.z;
-        color += s3 * h.w.w;
-        color += s4 * h.w4;
+        color = color + s1 * h.w.y;
+        color = color + s2 * h.w.z;
+        color = color + s3 * h.w.w;
+        color = color + s4 * h.w4;
     } else {
         color = T(0, 0) * h.w.x;
-        color += T(1, 0) * h.w.y;
-        color += T(0, 1) * h.w.z;
-        color += T(1, 1) * h.w.w;
+        color = color + T(1, 0) * h.w.y;
+        color = color + T(0, 1) * h.w.z;
+        color = color + T(1, 1) * h.w.w;
     }
-    return h.sum < 0.0001f ? float4(0.0f) : Div(color, h.sum);
+    return h.sum < 0.0001f ? zero : Div(color, h.sum);
+}
+inline float4 FetchHistoryColor(const HistoryFilter& h, const Tex& tex) {
+    return FetchHistoryT<float4>(h, tex, [](float4 t) { return t; }, float4(0.0f));
+}
+inline float FetchHistoryScalar(const HistoryFilter& h, const Tex& tex) {
+    return FetchHistoryT<float>(h, tex, [](float4 t) { return t.x; }, 0.0f);
+}
+template <typename V, typename Get>
+inline V FetchHistoryBilinearT(const HistoryFilter& h, const Tex& tex, Get get, V zero) {
+    V color = get(tex.Load(h.ox, h.oy)) * h.bw.x;
+    color = color + get(tex.Load(h.ox + 1, h.oy)) * h.bw.y;
+    color = color + get(tex.Load(h.ox, h.oy + 1)) * h.bw.z;
+    color = color + get(tex.Load(h.ox + 1, h.oy + 1)) * h.bw.w;
+    float s = sum(h.bw);
+    return s < 0.0001f ? zero : Div(color, s);
 }
 inline float4 FetchHistoryBilinear(const HistoryFilter& h, const Tex& tex) {
-    float4 color = tex.Load(h.ox, h.oy) * h.bw.x;
-    color += tex.Load(h.ox + 1, h.oy) * h.bw.y;
-    color += tex.Load(h.ox, h.oy + 1) * h.bw.z;
-    color += tex.Load(h.ox + 1, h.oy + 1) * h.bw.w;
-    float s = sum(h.bw);
-    return s < 0.0001f ? float4(0.0f) : Div(color, s);
+    return FetchHistoryBilinearT<float4>(h, tex, [](float4 t) { return t; }, float4(0.0f));
 }
+inline float FetchHistoryBilinearScalar(const HistoryFilter& h, const Tex& tex) {
+    return FetchHistoryBilinearT<float>(h, tex, [](float4 t) { return t.x; }, 0.0f);
+}
+// the history of a signal in its own type (REBLUR_TYPE)
+inline float4 FetchSignalHistory(const HistoryFilter& h, const Tex& tex, float4) { return FetchHistoryColor(h, tex); }
+inline float FetchSignalHistory(const HistoryFilter& h, const Tex& tex, float) { return FetchHistoryScalar(h, tex); }
+inline DirOcc FetchSignalHistory(const HistoryFilter& h, const Tex& tex, DirOcc) { return DirOcc(FetchHistoryColor(h, tex)); }
 
 } // namespace orc

@@ -1040,7 +1040,7 @@ void TemporalAccumulation(const PassIO& io) {
                 // Virtual motion - virtual parallax difference
                 float virtualHistoryParallaxBasedConfidence;
                 {
-                    float hitDistForTrackingPrev = gPrev_SpecHitDistForTracking->SampleLinearTexel(vmbPixelUv * c.gResolutionScalePrev * float2(float(gPrev_SpecHitDistForTracking->W()), float(gPrev_SpecHitDistForTracking->H()))).x;
+                    float hitDistForTrackingPrev = gPrev_SpecHitDistForTracking->SampleLinearTexelScalar(vmbPixelUv * c.gResolutionScalePrev * float2(float(gPrev_SpecHitDistForTracking->W()), float(gPrev_SpecHitDistForTracking->H())));
                     float3 XvirtualPrev = GetXvirtual(hitDistForTrackingPrev, curvature, X, Xprev, N, V, roughness);
 
                     float2 vmbPixelUvPrev = Geometry::GetScreenUv(c.gWorldToClipPrev, XvirtualPrev);
@@ -1082,8 +1082,8 @@ void TemporalAccumulation(const PassIO& io) {
 
                 // Sample surface history
                 HistoryFilter smbFilter = MakeHistoryFilter(smbSamplePos, smbOcclusionWeights, smbAllowCatRom);
-                S smbSpecHistory = Sig::From(FetchHistoryColor(smbFilter, *gHistory_Spec));
-                float smbSpecFastHistory = FetchHistoryBilinear(smbFilter, *gHistory_SpecFast).x;
+                S smbSpecHistory = FetchSignalHistory(smbFilter, *gHistory_Spec, S());
+                float smbSpecFastHistory = FetchHistoryBilinearScalar(smbFilter, *gHistory_SpecFast);
 
                 // Surface motion confidence
                 float surfaceHistoryConfidence;
@@ -1138,8 +1138,8 @@ void TemporalAccumulation(const PassIO& io) {
 
                 // Sample virtual history
                 HistoryFilter vmbFilter = MakeHistoryFilter(saturate(vmbPixelUv) * c.gRectSizePrev, vmbOcclusionWeights, vmbAllowCatRom);
-                S vmbSpecHistory = Sig::From(FetchHistoryColor(vmbFilter, *gHistory_Spec));
-                float vmbSpecFastHistory = FetchHistoryBilinear(vmbFilter, *gHistory_SpecFast).x;
+                S vmbSpecHistory = FetchSignalHistory(vmbFilter, *gHistory_Spec, S());
+                float vmbSpecFastHistory = FetchHistoryBilinearScalar(vmbFilter, *gHistory_SpecFast);
 
                 smbSpecHistory = ClampNegativeToZero(smbSpecHistory);
                 vmbSpecHistory = ClampNegativeToZero(vmbSpecHistory);
@@ -1226,8 +1226,8 @@ void TemporalAccumulation(const PassIO& io) {
                 }
 
                 HistoryFilter smbFilter = MakeHistoryFilter(smbSamplePos, smbOcclusionWeights, smbAllowCatRom);
-                S smbDiffHistory = Sig::From(FetchHistoryColor(smbFilter, *gHistory_Diff));
-                float smbDiffFastHistory = FetchHistoryBilinear(smbFilter, *gHistory_DiffFast).x;
+                S smbDiffHistory = FetchSignalHistory(smbFilter, *gHistory_Diff, S());
+                float smbDiffFastHistory = FetchHistoryBilinearScalar(smbFilter, *gHistory_DiffFast);
                 smbDiffHistory = ClampNegativeToZero(smbDiffHistory);
 
                 float diffNonLinearAccumSpeed = Rcp(1.0f + diffAccumSpeed);
@@ -1610,7 +1610,7 @@ void TemporalStabilization(const PassIO& io) {
                 stats(*gIn_Diff, diffLuma, diffLumaM1, diffLumaSigma);
 
                 HistoryFilter smbFilter = MakeHistoryFilter(smbSamplePos, smbOcclusionWeights, smbAllowCatRom);
-                float smbDiffLumaHistory = FetchHistoryColor(smbFilter, *gHistory_DiffLumaStabilized).x;
+                float smbDiffLumaHistory = FetchHistoryScalar(smbFilter, *gHistory_DiffLumaStabilized);
                 smbDiffLumaHistory = max(smbDiffLumaHistory, 0.0f);
 
                 float diffAntilag = ComputeAntilag(c, smbDiffLumaHistory, diffLumaM1, diffLumaSigma, smbFootprintQuality * data1.x);
@@ -1688,7 +1688,7 @@ void TemporalStabilization(const PassIO& io) {
                 }
 
                 HistoryFilter smbFilter = MakeHistoryFilter(smbSamplePos, smbOcclusionWeights, smbAllowCatRom);
-                float smbSpecLumaHistory = FetchHistoryColor(smbFilter, *gHistory_SpecLumaStabilized).x;
+                float smbSpecLumaHistory = FetchHistoryScalar(smbFilter, *gHistory_SpecLumaStabilized);
 
                 // Virtual motion footprint
                 Filtering::Bilinear vmbBilinearFilter = Filtering::GetBilinearFilter(vmbPixelUv, c.gRectSizePrev);
@@ -1699,7 +1699,7 @@ void TemporalStabilization(const PassIO& io) {
                 vmbFootprintQuality = Math::Sqrt01(vmbFootprintQuality);
 
                 HistoryFilter vmbFilter = MakeHistoryFilter(saturate(vmbPixelUv) * c.gRectSizePrev, vmbOcclusionWeights, vmbAllowCatRom);
-                float vmbSpecLumaHistory = FetchHistoryColor(vmbFilter, *gHistory_SpecLumaStabilized).x;
+                float vmbSpecLumaHistory = FetchHistoryScalar(vmbFilter, *gHistory_SpecLumaStabilized);
 
                 smbSpecLumaHistory = max(smbSpecLumaHistory, 0.0f);
                 vmbSpecLumaHistory = max(vmbSpecLumaHistory, 0.0f);

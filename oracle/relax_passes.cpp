@@ -926,7 +926,7 @@ void TemporalAccumulation(const PassIO& io) {
                             prevSpecularVMBResponsiveSH = BilinearWithCustomWeightsFloat4(*spec.fastSh, bx, by, bilinearCustomWeights);
                         }
 
-                        prevReflectionHitTVMB = gPrev_SpecHitDist->SampleLinearTexel(prevUVVMB * resolutionScalePrev * PrevSize(*gPrev_SpecHitDist)).x;
+                        prevReflectionHitTVMB = gPrev_SpecHitDist->SampleLinearTexelScalar(prevUVVMB * resolutionScalePrev * PrevSize(*gPrev_SpecHitDist));
                         prevReflectionHitTVMB = max(0.001f, prevReflectionHitTVMB);
 
                         float4 prevNormalRoughness = UnpackPrevNormalRoughness(gPrev_Normal_Roughness.SampleLinearTexel(prevUVVMB * resolutionScalePrev * PrevSize(gPrev_Normal_Roughness)));

@@ -165,6 +165,17 @@ struct Tex {
         float w00 = (1.0f - fx) * (1.0f - fy), w10 = fx * (1.0f - fy), w01 = (1.0f - fx) * fy, w11 = fx * fy;
         return s00 * w00 + s10 * w10 + s01 * w01 + s11 * w11;
     }
+    // the same sample of a single-channel plane, in scalar arithmetic: NOT the .x of the above under -ffp-contract=on (the scalar sum is a chain of
+    // fmas, the overloaded vector operators round every product first -- hlsl.h); the device's SampleLinearR16F is scalar
+    float SampleLinearTexelScalar(float2 pos) const {
+        float tx = pos.x - 0.5f, ty = pos.y - 0.5f;
+        float fx0 = floorf(tx), fy0 = floorf(ty);
+        float fx = tx - fx0, fy = ty - fy0;
+        int x0 = (int)fx0, y0 = (int)fy0;
+        float s00 = FetchClamped(x0, y0).x, s10 = FetchClamped(x0 + 1, y0).x, s01 = FetchClamped(x0, y0 + 1).x, s11 = FetchClamped(x0 + 1, y0 + 1).x;
+        float w00 = (1.0f - fx) * (1.0f - fy), w10 = fx * (1.0f - fy), w01 = (1.0f - fx) * fy, w11 = fx * fy;
+        return s00 * w00 + s10 * w10 + s01 * w01 + s11 * w11;
+    }
 
     // typed stores
     void Store(int x, int y, float4 v) {

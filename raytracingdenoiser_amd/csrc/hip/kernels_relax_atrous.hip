@@ -498,13 +498,6 @@ __global__ __launch_bounds__(256, NRD_WAVES_RELAX_ATROUS) void RelaxAtrousKernel
     // instead of being skipped by a divergent branch, so all loads of a pixel can be in flight together instead of one dependent wait per tap and signal.
     // (0 * sample adds nothing: the history planes hold finite fp16 values by construction.) Planes of one format share their layout (launcher check),
     // so one texel offset serves the two guide planes and one the four signal planes.
-#if NRD_ATROUS_GUIDES_VIEWZ
-    // direction of texel (x, y): forward + right * clip.x - up * clip.y with clip = (texel + 0.5) * rectSizeInv * 2 - 1, as dir0 + x * dirDx + y * dirDy
-    const float3 fr = ToF3(c.shared.gFrustumRight), fu = ToF3(c.shared.gFrustumUp);
-    const float2 clipStep = ToF2(c.shared.gRectSizeInv) * 2.0f;
-    const float3 dirDx = fr * clipStep.x, dirDy = fu * (-clipStep.y);
-    const float3 dir0 = ToF3(c.shared.gFrustumForward) + fr * (0.5f * clipStep.x - 1.0f) - fu * (0.5f * clipStep.y - 1.0f);
-#endif
     const bool compareSpecMaterials = c.shared.gSpecMinMaterial < 3.0f, compareDiffMaterials = c.shared.gDiffMinMaterial < 3.0f; // IDs are 0..3: a minimum >= 3 disables the test
 #pragma unroll
     for (int yy = -1; yy <= 1; yy++)
@@ -520,10 +513,10 @@ __global__ __launch_bounds__(256, NRD_WAVES_RELAX_ATROUS) void RelaxAtrousKernel
             const float4 g0 = *(const float4*)(P.decodedNR.ptr + guideOffset);
 #if NRD_ATROUS_GUIDES_VIEWZ
             // 4 bytes of viewZ instead of the 16-byte (world position, viewZ) texel: the taps are bound by the bytes that cross the L1 (gather probe:
-            // 39.6 cycles per 16-byte wave-load against 6.4 per 4-byte one), the position costs 11 VALU to re-derive (WorldPosFromClip, affine in the texel)
+            // 39.6 cycles per 16-byte wave-load against 6.4 per 4-byte one); the position is re-derived with the very expression that wrote the guide
+            // plane (DecodeGuidesRelaxKernel = relax_device.h GetCurrentWorldPosFromPixelPos), ~20 VALU, so it IS the stored value
             const float tapZ = RelaxUnpackViewZ(c, *(const float*)(P.viewZ.ptr + (__umul24((uint32_t)cy, P.viewZ.pitch) + (uint32_t)cx * 4u)));
-            const float3 tapDir = dir0 + dirDx * float(cx) + dirDy * float(cy);
-            const float4 sampleWorldPosViewZ = F4(tapZ * tapDir.x, tapZ * tapDir.y, tapZ * tapDir.z, tapZ);
+            const float4 sampleWorldPosViewZ = F4(GetCurrentWorldPosFromPixelPos(c, cx, cy, tapZ), tapZ);
 #else
             const float4 sampleWorldPosViewZ = *(const float4*)(P.worldPosViewZ.ptr + guideOffset);
 #endif

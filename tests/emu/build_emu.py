@@ -20,7 +20,7 @@ OUT = os.path.join(HERE, "libNRD_emu.so")
 
 def flags():
     return ["-std=c++17", "-O1", "-fPIC", "-fopenmp", "-fdeclspec", "-fvisibility=hidden", "-Wno-return-type-c-linkage", "-Wno-unused-value", "-mfma", "-mf16c",
-            "-I" + os.path.join(HERE, "shim"), "-I" + os.path.join(ROOT, "oracle"), "-I" + os.path.join(ROOT, "include")] + B.DEVICE_NUMERICS_FLAGS
+            "-I" + os.path.join(HERE, "shim"), "-I" + os.path.join(ROOT, "oracle"), "-I" + os.path.join(ROOT, "include")] + B.DEVICE_NUMERICS_FLAGS + os.environ.get("NRD_EMU_EXTRA_FLAGS", "").split()
 
 
 def _digest(paths, extra):
@@ -50,7 +50,8 @@ def build(verbose=False):
         for old in os.listdir(OBJ_DIR):
             if old.startswith(os.path.basename(src) + "."):
                 os.remove(os.path.join(OBJ_DIR, old))
-        cmd = [CLANG] + flags() + ["-x", "c++", "-c", src, "-o", obj]
+        # the host dispatch compiler keeps -ffp-contract=off as in the product build (raytracingdenoiser_amd/build.py): both sides must be handed the same constants
+        cmd = [CLANG] + flags() + (["-ffp-contract=off"] if src.endswith(".cpp") and "csrc" in src else []) + ["-x", "c++", "-c", src, "-o", obj]
         if verbose:
             print("[emu]", " ".join(cmd), flush=True)
         subprocess.run(cmd, check=True)
