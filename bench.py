@@ -11,13 +11,13 @@ GPU before the timed region). Prints ONE JSON line (see DESIGN.md "Measurement")
                 measured live with HIP events recorded on the executor's stream around every dispatch
   cpu_baseline  the CPU oracle (oracle/, kind "port": the reference has no CPU implementation) on the host cores,
                 on a bounded sample of the same workload (N = 1, rank 0 only)
-  parity        the planes the cpu_baseline leg computes anyway (first frames of the same sequence, full size) compared with the GPU's
-  exact_build   the same frames timed on lib/libNRD_hip_exact.so (the bit-exact regression build), beside the product's value (N = 1 only)
+  parity        the planes the cpu_baseline leg computes anyway (first frames of the same sequence, full size) compared with the GPU's: the library that is
+                timed is the library that is checked, and the expected maximum relative error is 0 (bit-identical user outputs)
 
 --gpus N with N > 1 and no torch.distributed environment re-launches itself under torch.distributed.run (one rank per GPU, RCCL).
 
   python bench.py [--gpus N] [--steps K] [--warmup W] [--workload reblur_ds|reblur_diffuse|relax_ds_sh|relax_ds|sigma_shadow] [--width 2560 --height 1440]
-                  [--numerics fast|exact] [--no-graph] [--no-cpu-baseline] [--no-parity] [--no-exact-leg]
+                  [--no-graph] [--no-sky] [--no-cpu-baseline] [--no-parity]
 """
 import argparse
 import json
@@ -27,9 +27,12 @@ import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
-sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 import torch
+
+from raytracingdenoiser_amd import api, scene, sharding, synth
+from raytracingdenoiser_amd import build as native_build
+from raytracingdenoiser_amd.executor import HipExecutor
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E peak (MI355X_MICROARCH.md); ~6300 GB/s is what a float4 copy achieves (measured live below)
 
@@ -126,32 +129,21 @@ def parse_args():
     ap.add_argument("--max-motion-rows", type=int, default=32, help="halo scheme: largest vertical motion (rows per frame) the history halos cover")
     ap.add_argument("--cpu-frames", type=int, default=8)
     ap.add_argument("--distinct-frames", type=int, default=0, help="number of distinct generated frames to cycle through (0 = warmup + steps)")
-    ap.add_argument("--numerics", choices=["fast", "exact"], default=os.environ.get("NRD_HIP_NUMERICS", "fast"),
-                    help="fast = lib/libNRD_hip.so, the product (default); exact = lib/libNRD_hip_exact.so, the bit-exact regression build")
     ap.add_argument("--no-graph", action="store_true", help="launch every pass on its own instead of one hipGraph per frame")
     ap.add_argument("--no-sky", action="store_true", help="a dome behind the scene: no sky pixels (34 %% of the default frame are sky and leave at the tile test)")
-    ap.add_argument("--no-exact-leg", action="store_true", help="skip the timing of the exact build beside the product build")
     ap.add_argument("--no-parity", action="store_true", help="skip the GPU-vs-oracle comparison of the cpu_baseline frames")
     return ap.parse_args()
 
 
-def measure_copy_bandwidth(nbytes=1 << 30, reps=10):
-    """GB/s (read + write) of a device-to-device copy of nbytes: the achievable HBM rate the roofline is also quoted against (SURVEY.md section 8d:
-    "measured copy bandwidth on the same device")"""
-    src = torch.empty(nbytes // 16, 4, dtype=torch.float32, device="cuda").fill_(1.0)
-    dst = torch.empty_like(src)
-    for _ in range(3):
-        dst.copy_(src)
-    torch.cuda.synchronize()
-    start, stop = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    start.record()
-    for _ in range(reps):
-        dst.copy_(src)
-    stop.record()
-    torch.cuda.synchronize()
-    ms = start.elapsed_time(stop) / reps
-    del src, dst
-    return 2.0 * nbytes / (ms * 1e-3) / 1e9
+def measure_copy_bandwidth(lib, nbytes=1 << 30, reps=10):
+    """GB/s (read + write) of the library's own 16-bytes-per-lane copy kernel over nbytes (include/NRDHip.h nrdHipMeasureCopyBandwidth): the achievable
+    HBM rate the roofline is also quoted against ("measured copy bandwidth on the same device")"""
+    import ctypes as C
+
+    out = C.c_double()
+    r = lib.nrdHipMeasureCopyBandwidth(nbytes, reps, C.c_void_p(torch.cuda.current_stream().cuda_stream), C.byref(out))
+    assert r == 0, "nrdHipMeasureCopyBandwidth failed"
+    return out.value
 
 
 def _usable_cores():
@@ -172,25 +164,26 @@ def _usable_cores():
     return max(cores, 1)
 
 
-def cpu_baseline(name, width, height, frames, seq, overrides=None, numerics="fast", check_parity=True):
+def cpu_baseline(name, width, height, frames, seq, overrides=None, check_parity=True):
     """Times the CPU oracle on the first `frames` frames of the same sequence (all host cores, OpenMP over rows). The oracle's outputs are then
-    compared with a fresh GPU run over the same frames (outside the timed region of either): returns (cpu_baseline, parity)."""
+    compared with a fresh GPU run over the same frames (outside the timed region of either): returns (cpu_baseline, parity).
+    The only place of this file that touches tests/ and oracle/ (the checker, never the thing measured)."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
     import parity
     from oracle import driver as oracle_driver
 
     cores = _usable_cores()
     threads = oracle_driver.load().oracle_set_threads(cores)
-    # the product build is held against plain IEEE arithmetic, the exact build against the device-emulating oracle (bit-exact)
-    prev_mode = oracle_driver.set_ieee_mode(numerics == "fast")
+    prev_mode = oracle_driver.set_ieee_mode(False)  # the oracle emulates the device's five transcendental instructions: a bit-for-bit comparison
     try:
         ora = parity.OracleRun(name, width, height, threads=threads)
         host_seq = [{k: (v.cpu() if torch.is_tensor(v) else v) for k, v in fr.items()} for fr in seq[:frames]]
         oracle_outputs = []
         dt = 0.0
         for f, frame in enumerate(host_seq):
-            cs = parity.common_settings(frame["camera"], host_seq[max(f - 1, 0)]["camera"], width, height, f)
+            cs = scene.common_settings(frame["camera"], host_seq[max(f - 1, 0)]["camera"], width, height, f)
             t0 = time.perf_counter()
-            ora.step(frame, cs, parity.denoiser_settings(name, frame, overrides))
+            ora.step(frame, cs, scene.denoiser_settings(name, frame, overrides))
             dt += time.perf_counter() - t0
             if check_parity:
                 oracle_outputs.append({rt: ora.output(rt).copy() for rt in ora.outs})
@@ -206,14 +199,15 @@ def cpu_baseline(name, width, height, frames, seq, overrides=None, numerics="fas
     par = None
     if check_parity:
         stats = parity.ParityStats()
-        hip = parity.HipRun(name, width, height, numerics=numerics)
+        hip = parity.GpuRun(name, width, height)
         for f, frame in enumerate(seq[:frames]):
-            cs = parity.common_settings(frame["camera"], seq[max(f - 1, 0)]["camera"], width, height, f)
-            hip.step(frame, cs, parity.denoiser_settings(name, frame, overrides))
+            cs = scene.common_settings(frame["camera"], seq[max(f - 1, 0)]["camera"], width, height, f)
+            hip.step(frame, cs, scene.denoiser_settings(name, frame, overrides))
             for rt in hip.outs:
                 stats.add(rt.name, f, parity.error_stats(hip.output(rt), oracle_outputs[f][rt]))
         sm = stats.summary(True)
-        par = {"vs": "CPU oracle, %s" % ("IEEE arithmetic" if numerics == "fast" else "device-emulated sqrt / rsqrt"), "frames": frames, "planes": sorted(stats.outputs()),
+        par = {"vs": "CPU oracle (oracle/), the device's v_rcp / v_sqrt / v_rsq / v_exp / v_log emulated from measured tables", "library": "lib/libNRD_hip.so (the library timed above)",
+               "frames": frames, "planes": sorted(stats.outputs()),
                "max_rel_err": sm["max_rel_err"], "p999_rel_err": sm["p999"], "frac_gt_1e-3": sm["frac_gt_tol"], "mean_rel_err": sm["mean"], "bit_exact_frac": sm["bit_exact_frac"],
                "definition": "|gpu - cpu| / max(|cpu|, 1e-3) per value of the user outputs, worst frame"}
     return baseline, par
@@ -251,17 +245,11 @@ def main():
         dist.init_process_group(backend)
         assert dist.get_world_size() == args.gpus
 
-    import parity
-    from raytracingdenoiser_amd import api
-    from raytracingdenoiser_amd import build as native_build
-    from raytracingdenoiser_amd.executor import HipExecutor
-    from raytracingdenoiser_amd import sharding
-
     if rank == 0:
-        native_build.build_product(numerics=args.numerics)
+        native_build.build_product()
     if distributed:
         dist.barrier()
-    copy_gbs = measure_copy_bandwidth()
+    copy_gbs = measure_copy_bandwidth(api.load_library())
 
     name, default_size, bytes_per_pixel, overrides = WORKLOADS[args.workload]
     W, H = args.width or default_size[0], args.height or default_size[1]
@@ -269,17 +257,17 @@ def main():
     distinct = args.distinct_frames or total
 
     if args.no_sky:
-        from raytracingdenoiser_amd import synth
         synth.BACKDROP = True
     # ---- synthetic inputs, generated straight into HBM (118 MB per 1440p frame; 96 frames = 11 GB of 288 GB)
-    seq = parity.generate_sequence(name, W, H, distinct, device="cuda")
+    seq = scene.generate_sequence(name, W, H, distinct, device="cuda")
     torch.cuda.synchronize()
+    denoised_fraction = 1.0 - float(torch.stack([fr["is_sky"].float().mean() for fr in seq[:: max(1, len(seq) // 8)]]).mean())  # sky pixels leave at the tile test
 
-    inst = api.Instance([(0, parity.DENOISERS[name][0])], numerics=args.numerics)
+    inst = api.Instance([(0, scene.DENOISERS[name][0])])
     ex = HipExecutor(inst, W, H)
     ex.set_graph_mode(not args.no_graph)
     outputs = []
-    for rt, dtype, ch, fmt in parity.output_planes(name, W, H):
+    for rt, dtype, ch, fmt in scene.output_planes(name, W, H):
         t = torch.zeros((H, W, ch), dtype=dtype, device="cuda")
         ex.bind(rt, t, fmt)
         outputs.append(t)
@@ -287,7 +275,7 @@ def main():
     if distributed:
         shard = sharding.HaloSharder(ex, inst, W, H, rank, world, max_motion_rows=args.max_motion_rows) if args.sharding == "halo" else sharding.FrameSharder(ex, inst, W, H, rank, world, outputs)
 
-    settings = parity.denoiser_settings(name, seq[0], overrides)
+    settings = scene.denoiser_settings(name, seq[0], overrides)
     assert inst.set_denoiser_settings(0, settings) == api.Result.SUCCESS
     def frame_of(f):
         # distinct < total: walk the generated frames back and forth so consecutive frames always have neighbouring cameras
@@ -300,11 +288,11 @@ def main():
     frames_cs = []
     for f in range(total):
         cur, prev = frame_of(f), frame_of(max(f - 1, 0))
-        frames_cs.append(parity.common_settings(cur["camera"], prev["camera"], W, H, f))
+        frames_cs.append(scene.common_settings(cur["camera"], prev["camera"], W, H, f))
 
     def step(f):
         frame = frame_of(f)
-        for rt, t, fmt in parity.user_planes(name, frame):
+        for rt, t, fmt in scene.user_planes(name, frame):
             ex.bind(rt, t, fmt)
         assert inst.set_common_settings(frames_cs[f]) == api.Result.SUCCESS
         if shard is not None:
@@ -374,9 +362,12 @@ def main():
                 traffic_source = entry.get("source")
         roofline = {"bound": "hbm", "kernel": dominant, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
                     "measured_copy_GBps": round(copy_gbs, 1), "frac_of_measured_copy": round(achieved / copy_gbs, 4),
+                    "denoised_pixel_fraction": round(denoised_fraction, 4), "frac_denoised_pixels": round(achieved / HBM_PEAK_GBS * denoised_fraction, 4),
                     "traffic": traffic, "traffic_source": traffic_source, "avg_kernel_ms": passes[dominant]["avg_ms"],
                     "algorithmic_bytes_per_launch": passes[dominant]["bytes_per_launch"],
-                    "note": "dominant = the pass with the longest average launch; per-pass durations from HIP events on the executor's stream (eager replay of the timed frames)"}
+                    "note": "dominant = the pass with the longest average launch; per-pass durations from HIP events on the executor's stream (eager replay of the timed frames); "
+                            "frac counts the algorithmic bytes of EVERY pixel of the frame as the metric does, frac_denoised_pixels only those of the pixels that are not sky; "
+                            "measured_copy_GBps = the library's own 16-B/lane copy kernel on this GPU"}
     # per frame: every pass once, except the dilated a-trous pass which runs (launches / steps) times
     per_frame = {k: p["launches"] / args.steps for k, p in passes.items()}
     gpu_ms = sum(p["avg_ms"] * per_frame[k] for k, p in passes.items())
@@ -400,7 +391,7 @@ def main():
         "vs_baseline": round(mpix_s / PUBLISHED_MPIX_S[(name, W, H)], 3) if world == 1 and overrides is None and (name, W, H) in PUBLISHED_MPIX_S else None,
         "dtype": "f32",
         "data": "synthetic",
-        "numerics": args.numerics,
+        "numerics": "exact",  # one library, one arithmetic: what is timed here is bit-identical to the CPU oracle (see "parity")
         "launch": "eager" if args.no_graph else "hipGraph (%d launches, %d builds, %d node updates in the run)" % graph_stats,
         "rccl_ranks": world if distributed and backend == "nccl" else (0 if not distributed else None),
         "config": {"workload": "%s %dx%d, %s, analytic scene%s + 1rpp noise, moving camera" % (name, W, H, "default settings" if overrides is None else "settings %s" % overrides,
@@ -413,38 +404,8 @@ def main():
         "whole_chain": whole_chain,
         "passes": passes,
     }
-    # ---- the same frames on the exact build (the library every bit-exact parity test runs): reported beside the product number, outside its timed region
-    if world == 1 and args.numerics == "fast" and not args.no_exact_leg:
-        try:
-            native_build.build_product(numerics="exact")
-            inst_x = api.Instance([(0, parity.DENOISERS[name][0])], numerics="exact")
-            ex_x = HipExecutor(inst_x, W, H)
-            ex_x.set_graph_mode(not args.no_graph)
-            for (rt, dtype, ch, fmt), t in zip(parity.output_planes(name, W, H), outputs):
-                ex_x.bind(rt, t, fmt)
-            assert inst_x.set_denoiser_settings(0, settings) == api.Result.SUCCESS
-
-            def step_x(f):
-                for rt, t, fmt in parity.user_planes(name, frame_of(f)):
-                    ex_x.bind(rt, t, fmt)
-                assert inst_x.set_common_settings(frames_cs[f]) == api.Result.SUCCESS
-                ex_x.denoise()
-
-            n_x = max(args.steps // 2, 1)
-            for f in range(min(args.warmup, 8)):
-                step_x(f)
-            torch.cuda.synchronize()
-            t0 = time.perf_counter()
-            for f in range(args.warmup, args.warmup + n_x):
-                step_x(f)
-            torch.cuda.synchronize()
-            dt = time.perf_counter() - t0
-            result["exact_build"] = {"value": round(n_x * W * H / dt / 1e6, 2), "unit": "Mpixels/s", "ms_per_step": round(dt * 1e3 / n_x, 4), "steps": n_x,
-                                     "note": "lib/libNRD_hip_exact.so: IEEE division, no contraction, polynomial transcendentals -- bit-identical to the CPU oracle (tests/test_full_parity.py)"}
-        except Exception as e:  # the product line must be printed whatever happens to this side measurement
-            result["exact_build"] = {"error": repr(e)}
     if not args.no_cpu_baseline and world == 1:
-        result["cpu_baseline"], result["parity"] = cpu_baseline(name, W, H, min(args.cpu_frames, distinct), seq, overrides, numerics=args.numerics, check_parity=not args.no_parity)
+        result["cpu_baseline"], result["parity"] = cpu_baseline(name, W, H, min(args.cpu_frames, distinct), seq, overrides, check_parity=not args.no_parity)
     else:
         result["cpu_baseline"], result["parity"] = None, None
     print(json.dumps(result))

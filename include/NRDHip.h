@@ -133,9 +133,9 @@ uint32_t nrdHipCollectPassTimings(NrdHipExecutor* executor, uint32_t* pipelineIn
 uint32_t nrdHipSetGraphMode(NrdHipExecutor* executor, uint32_t enable);
 uint32_t nrdHipGetGraphStats(const NrdHipExecutor* executor, uint64_t* graphLaunches, uint64_t* graphBuilds, uint64_t* nodeUpdates);
 
-// Numerics mode this library was built in (DESIGN.md "Numerics"): 1 = fast (libNRD_hip.so, the product: hardware rcp / sqrt / exp2 / log2, FMA
-// contraction, fp32 denormals flushed; results within the NRD tolerance of the CPU oracle), 0 = exact (libNRD_hip_exact.so: the pinned IEEE
-// arithmetic of the oracle, bit-identical results; the regression build). The REFERENCE denoiser is bit-exact in both.
+// Numerics mode of the library (DESIGN.md "Numerics"). Always 0 = the pinned arithmetic: IEEE + - * and source-determined fused multiply-adds, division /
+// sqrt / exp2 / log2 through v_rcp_f32 / v_sqrt_f32 / v_rsq_f32 / v_exp_f32 / v_log_f32 -- bit-identical to the CPU oracle, which emulates those five
+// instructions from measured tables. (Round 2 also shipped a faster, inexact build that answered 1; it is gone: one library, one arithmetic.)
 uint32_t nrdHipGetNumericsMode(void);
 
 // Bytes held by the pool arena (permanent, transient).
@@ -143,11 +143,16 @@ uint32_t nrdHipGetPoolMemoryUsage(const NrdHipExecutor* executor, uint64_t* perm
 
 // Diagnostics: evaluates one primitive of the device numerics contract (DESIGN.md "Numerics") elementwise on device
 // arrays, so a harness can pin the GPU's codecs and transcendentals bit-for-bit against another implementation.
-//   op: 0 exp2, 1 log2, 2 atan, 3 pow(x, y = in2), 4 fp32->fp16->fp32 round trip, 5 x / in2, 6 sqrt, 7 1/sqrt,
+//   op: 0 exp2, 1 log2, 2 atan, 3 pow(x, y = in2), 4 fp32->fp16->fp32 round trip, 5 Div(x, in2) = x * v_rcp_f32(in2), 6 sqrt, 7 1/sqrt,
 //       8..12 small-integer / {1023, 255, 63, 15, 3} (the codecs' 3-op exact division), 13 exp(-0.66 x^2), 14 small-integer / 65535, 15 int16 / 32767;
-//       16 v_rcp_f32, 17 v_rsq_f32, 18 v_sqrt_f32 (the hardware approximations; no pass uses them -- probes for tools/hw_transcendentals.py)
+//       16 v_rcp_f32, 17 v_rsq_f32, 18 v_sqrt_f32 (the raw instructions), 19 v_cvt_pk_f16_f32(x, in2) (the packed word as float bits), 20 Rcp
 // in2 may be NULL for unary ops. Launches on hipStream (a hipStream_t as void*, may be NULL).
 uint32_t nrdHipEvalNumerics(uint32_t op, const float* in1, const float* in2, float* out, uint32_t count, void* hipStream);
+
+// Diagnostics: the streaming bandwidth this GPU delivers to a plain 16-bytes-per-lane copy kernel (read + write, GB/s) -- the "measured copy
+// bandwidth on the same device" the roofline fractions of bench.py are also quoted against. Allocates 2 * bytes of scratch
+// device memory, runs `repetitions` timed copies after 3 warm-up copies (HIP events on hipStream) and frees the scratch again.
+uint32_t nrdHipMeasureCopyBandwidth(uint64_t bytes, uint32_t repetitions, void* hipStream, double* gigabytesPerSecond);
 
 // Last error text of this executor (never NULL).
 const char* nrdHipGetLastError(const NrdHipExecutor* executor);

@@ -28,7 +28,16 @@ static void ReferenceAccumulate(const PassIO& io) {
         for (int x = 0; x < gInOut_History.W(); x++) {
             float4 input = gIn_Input.Load(x, y);
             float4 history = gInOut_History.Load(x, y);
-            float4 result = lerp(history, input, c.gAccumSpeed);
+            // the sequential fp32 running mean with three roundings per component (BASELINE.json: bit-exact; tests/test_reference.py holds it against
+            // numpy): no fused multiply-add here, whatever the contraction mode of the build
+            float4 result;
+            {
+#pragma clang fp contract(off)
+                result.x = history.x + (input.x - history.x) * c.gAccumSpeed;
+                result.y = history.y + (input.y - history.y) * c.gAccumSpeed;
+                result.z = history.z + (input.z - history.z) * c.gAccumSpeed;
+                result.w = history.w + (input.w - history.w) * c.gAccumSpeed;
+            }
             gInOut_History.Store(x, y, result);
         }
 }

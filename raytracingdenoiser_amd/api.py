@@ -10,9 +10,8 @@ import enum
 import os
 
 _PKG = os.path.dirname(os.path.abspath(__file__))
-# the two numerics builds of the library (raytracingdenoiser_amd/build.py, DESIGN.md "Numerics"): "fast" is the product, "exact" the bit-exact regression build
-LIB_PATHS = {"fast": os.path.join(_PKG, "lib", "libNRD_hip.so"), "exact": os.path.join(_PKG, "lib", "libNRD_hip_exact.so")}
-LIB_PATH = LIB_PATHS["fast"]
+# the product library (raytracingdenoiser_amd/build.py): one library, one arithmetic (DESIGN.md "Numerics")
+LIB_PATH = os.path.join(_PKG, "lib", "libNRD_hip.so")
 
 
 # ----------------------------------------------------------------------------------------------- enums
@@ -268,25 +267,15 @@ class HipHaloPlanInfo(C.Structure):
 NRD_HIP_SYMBOLS = ["nrdHipCreateExecutor", "nrdHipDestroyExecutor", "nrdHipBindResource", "nrdHipGetPoolPlane", "nrdHipExecuteDispatches",
                    "nrdHipDenoise", "nrdHipGetPoolMemoryUsage", "nrdHipGetLastError", "nrdHipEvalNumerics", "nrdHipGetArenaSize",
                    "nrdHipCreateExecutorWithArena", "nrdHipSetProfiling", "nrdHipCollectPassTimings", "nrdHipSetOwnedRows", "nrdHipGetDispatchReach",
-                   "nrdHipExecuteDispatchRange", "nrdHipPlanHaloExchange", "nrdHipSetGraphMode", "nrdHipGetGraphStats", "nrdHipGetNumericsMode"]
+                   "nrdHipExecuteDispatchRange", "nrdHipPlanHaloExchange", "nrdHipSetGraphMode", "nrdHipGetGraphStats", "nrdHipGetNumericsMode", "nrdHipMeasureCopyBandwidth"]
 
 _libs = {}
 
 
-def default_numerics():
-    """"fast" unless NRD_HIP_NUMERICS=exact selects the regression build for the whole process"""
-    n = os.environ.get("NRD_HIP_NUMERICS", "fast")
-    if n not in LIB_PATHS:
-        raise RuntimeError("NRD_HIP_NUMERICS must be one of %s" % sorted(LIB_PATHS))
-    return n
-
-
-def load_library(path=None, numerics=None):
-    """dlopen lib/libNRD_hip.so (numerics "fast", the default) or lib/libNRD_hip_exact.so and set prototypes. Raises if the library has not been
-    built -- there is no fallback. Both may live in one process (RTLD_LOCAL)."""
-    numerics = numerics or default_numerics()
-    # tuning runs (tools/build_variant.py): NRD_HIP_FAST_LIBRARY / NRD_HIP_EXACT_LIBRARY point a slot at a variant build of the same sources
-    path = path or os.environ.get("NRD_HIP_FAST_LIBRARY" if numerics == "fast" else "NRD_HIP_EXACT_LIBRARY") or LIB_PATHS[numerics]
+def load_library(path=None):
+    """dlopen lib/libNRD_hip.so and set prototypes. Raises if the library has not been built -- there is no fallback.
+    NRD_HIP_LIBRARY=<path> points at an A/B variant build of the same sources (tools/build_variant.py)."""
+    path = path or os.environ.get("NRD_HIP_LIBRARY") or LIB_PATH
     if path in _libs:
         return _libs[path]
     if not os.path.exists(path):
@@ -339,6 +328,7 @@ def load_library(path=None, numerics=None):
     lib.nrdHipSetGraphMode.argtypes, lib.nrdHipSetGraphMode.restype = [C.c_void_p, C.c_uint32], C.c_uint32
     lib.nrdHipGetGraphStats.argtypes, lib.nrdHipGetGraphStats.restype = [C.c_void_p, P(C.c_uint64), P(C.c_uint64), P(C.c_uint64)], C.c_uint32
     lib.nrdHipGetNumericsMode.argtypes, lib.nrdHipGetNumericsMode.restype = [], C.c_uint32
+    lib.nrdHipMeasureCopyBandwidth.argtypes, lib.nrdHipMeasureCopyBandwidth.restype = [C.c_uint64, C.c_uint32, C.c_void_p, P(C.c_double)], C.c_uint32
     _libs[path] = lib
     return lib
 
@@ -363,9 +353,9 @@ class Dispatch:
 class Instance:
     """Thin RAII wrapper over nrd::CreateInstance / DestroyInstance."""
 
-    def __init__(self, denoisers, lib=None, numerics=None):
-        """denoisers: list of (identifier, Denoiser); numerics: "fast" / "exact" build of the library (default: NRD_HIP_NUMERICS or "fast")."""
-        self.lib = lib or load_library(numerics=numerics)
+    def __init__(self, denoisers, lib=None):
+        """denoisers: list of (identifier, Denoiser)"""
+        self.lib = lib or load_library()
         self._descs = (DenoiserDesc * len(denoisers))(*[DenoiserDesc(i, int(d)) for i, d in denoisers])
         icd = InstanceCreationDesc()
         icd.denoisers = self._descs

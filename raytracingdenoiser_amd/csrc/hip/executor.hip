@@ -1087,10 +1087,44 @@ extern "C" __attribute__((visibility("default"))) const char* nrdHipGetLastError
 
 namespace nrdhip {
 void LaunchEvalNumerics(uint32_t op, const float* in1, const float* in2, float* out, uint32_t count, hipStream_t stream);
+void LaunchCopyProbe(const void* src, void* dst, uint64_t bytes, hipStream_t stream);
+}
+
+extern "C" __attribute__((visibility("default"))) uint32_t nrdHipMeasureCopyBandwidth(uint64_t bytes, uint32_t repetitions, void* hipStream, double* gigabytesPerSecond) {
+    if (!gigabytesPerSecond || bytes < 16 || !repetitions)
+        return (uint32_t)nrd::Result::INVALID_ARGUMENT;
+    hipStream_t stream = (hipStream_t)hipStream;
+    bytes &= ~(uint64_t)15;
+    void *src = nullptr, *dst = nullptr;
+    if (hipMalloc(&src, bytes) != hipSuccess || hipMalloc(&dst, bytes) != hipSuccess) {
+        (void)hipFree(src);
+        return (uint32_t)nrd::Result::FAILURE;
+    }
+    (void)hipMemsetAsync(src, 1, bytes, stream);
+    hipEvent_t t0, t1;
+    (void)hipEventCreate(&t0);
+    (void)hipEventCreate(&t1);
+    for (int i = 0; i < 3; i++)
+        nrdhip::LaunchCopyProbe(src, dst, bytes, stream);
+    (void)hipEventRecord(t0, stream);
+    for (uint32_t i = 0; i < repetitions; i++)
+        nrdhip::LaunchCopyProbe(src, dst, bytes, stream);
+    (void)hipEventRecord(t1, stream);
+    const bool ok = hipStreamSynchronize(stream) == hipSuccess;
+    float ms = 0.0f;
+    (void)hipEventElapsedTime(&ms, t0, t1);
+    (void)hipEventDestroy(t0);
+    (void)hipEventDestroy(t1);
+    (void)hipFree(src);
+    (void)hipFree(dst);
+    if (!ok || ms <= 0.0f)
+        return (uint32_t)nrd::Result::FAILURE;
+    *gigabytesPerSecond = 2.0 * (double)bytes * repetitions / ((double)ms * 1e-3) / 1e9;
+    return (uint32_t)nrd::Result::SUCCESS;
 }
 
 extern "C" __attribute__((visibility("default"))) uint32_t nrdHipEvalNumerics(uint32_t op, const float* in1, const float* in2, float* out, uint32_t count, void* hipStream) {
-    if (!in1 || !out || op > 18)
+    if (!in1 || !out || op > 20)
         return (uint32_t)nrd::Result::INVALID_ARGUMENT;
     if (count)
         nrdhip::LaunchEvalNumerics(op, in1, in2, out, count, (hipStream_t)hipStream);

@@ -140,7 +140,17 @@ __global__ __launch_bounds__(256) void ReferenceAccumulateKernel(Plane input, Pl
         return;
     float4 in = InBounds(input, x, y) ? LoadRGBA32F(input, x, y) : F4(0.0f);
     float4 h = LoadRGBA32F(history, x, y);
-    StoreRGBA32F(history, x, y, Lerp(h, in, accumSpeed));
+    // BASELINE.json specifies this accumulator bit-exactly: the sequential fp32 running mean hist + (in - hist) * a with THREE roundings, which is what
+    // tests/test_reference.py computes in numpy independently of the oracle. Hence no fused multiply-add here, whatever the file's contraction mode.
+    float4 r;
+    {
+#pragma clang fp contract(off)
+        r.x = h.x + (in.x - h.x) * accumSpeed;
+        r.y = h.y + (in.y - h.y) * accumSpeed;
+        r.z = h.z + (in.z - h.z) * accumSpeed;
+        r.w = h.w + (in.w - h.w) * accumSpeed;
+    }
+    StoreRGBA32F(history, x, y, r);
 }
 
 static const char* LaunchReferenceAccumulate(const PassArgs& a) {
@@ -201,14 +211,25 @@ __global__ __launch_bounds__(256) void EvalNumericsKernel(uint32_t op, const flo
         case 13: r = Exp(-0.66f * a * a); break; // GetGaussianWeight
         case 14: r = NRD_DIV_65535(a); break;
         case 15: r = NRD_DIV_32767(a); break;
-        // the hardware's one-instruction approximations (not used by any pass: the numerics contract is built on correctly rounded ops;
-        // probed so that their deviation from the correctly rounded results can be tabulated -- DESIGN.md section 8)
+        // the raw transcendental instructions
         case 16: r = __builtin_amdgcn_rcpf(a); break;
         case 17: r = __builtin_amdgcn_rsqf(a); break;
         case 18: r = __builtin_amdgcn_sqrtf(a); break;
+        case 19: r = AsFloat(FloatsToHalf2Bits(a, b)); break; // v_cvt_pk_f16_f32: two fp16 conversions in one instruction
+        case 20: r = Rcp(a); break;
         default: break;
     }
     out[i] = r;
+}
+
+// ---- streaming copy probe (include/NRDHip.h: nrdHipMeasureCopyBandwidth): 16 bytes per lane, grid-stride over a 256-CU-sized grid ---------------
+__global__ __launch_bounds__(256) void CopyProbeKernel(const uint4* __restrict__ src, uint4* __restrict__ dst, uint64_t count) {
+    const uint64_t stride = (uint64_t)gridDim.x * 256u;
+    for (uint64_t i = (uint64_t)blockIdx.x * 256u + threadIdx.x; i < count; i += stride)
+        dst[i] = src[i];
+}
+void LaunchCopyProbe(const void* src, void* dst, uint64_t bytes, hipStream_t stream) {
+    hipLaunchKernelGGL(CopyProbeKernel, dim3(256 * 32), dim3(256), 0, stream, (const uint4*)src, (uint4*)dst, bytes / 16u);
 }
 
 void LaunchEvalNumerics(uint32_t op, const float* in1, const float* in2, float* out, uint32_t count, hipStream_t stream) {

@@ -1,5 +1,7 @@
 """Parity harness: runs the same synthetic frame sequence through the CPU oracle and through the HIP path (both driven
 by the SAME nrd::GetComputeDispatches lists from the product's host) and compares planes. Used by tests/ and smoke()."""
+import os
+
 import numpy as np
 import torch
 
@@ -12,169 +14,9 @@ F = api.Format
 REL_TOL = 1e-3  # BASELINE.json north_star: <= 1e-3 relative per pixel (bit-exact for REFERENCE)
 
 
-def common_settings(cam, cam_prev, width, height, frame_index, **kw):
-    args = dict(resourceSize=(width, height), rectSize=(width, height), resourceSizePrev=(width, height), rectSizePrev=(width, height),
-                timeDeltaBetweenFrames=16.667, frameIndex=frame_index, isMotionVectorInWorldSpace=True, motionVectorScale=(0.0, 0.0, 0.0))
-    args.update(kw)
-    cs = api.CommonSettings(**args)
-    for i in range(16):
-        cs.viewToClipMatrix[i] = cam.view_to_clip[i]
-        cs.viewToClipMatrixPrev[i] = cam_prev.view_to_clip[i]
-        cs.worldToViewMatrix[i] = cam.world_to_view[i]
-        cs.worldToViewMatrixPrev[i] = cam_prev.world_to_view[i]
-    return cs
-
-
-DENOISERS = {
-    "REBLUR_DIFFUSE": (api.Denoiser.REBLUR_DIFFUSE, ("reblur",)),
-    "REBLUR_SPECULAR": (api.Denoiser.REBLUR_SPECULAR, ("reblur",)),
-    "REBLUR_DIFFUSE_SPECULAR": (api.Denoiser.REBLUR_DIFFUSE_SPECULAR, ("reblur",)),
-    "REBLUR_DIFFUSE_SH": (api.Denoiser.REBLUR_DIFFUSE_SH, ("reblur",)),
-    "REBLUR_SPECULAR_SH": (api.Denoiser.REBLUR_SPECULAR_SH, ("reblur",)),
-    "REBLUR_DIFFUSE_SPECULAR_SH": (api.Denoiser.REBLUR_DIFFUSE_SPECULAR_SH, ("reblur",)),
-    "REBLUR_DIFFUSE_DIRECTIONAL_OCCLUSION": (api.Denoiser.REBLUR_DIFFUSE_DIRECTIONAL_OCCLUSION, ("reblur",)),
-    "REBLUR_DIFFUSE_OCCLUSION": (api.Denoiser.REBLUR_DIFFUSE_OCCLUSION, ("reblur",)),
-    "REBLUR_SPECULAR_OCCLUSION": (api.Denoiser.REBLUR_SPECULAR_OCCLUSION, ("reblur",)),
-    "REBLUR_DIFFUSE_SPECULAR_OCCLUSION": (api.Denoiser.REBLUR_DIFFUSE_SPECULAR_OCCLUSION, ("reblur",)),
-    "SIGMA_SHADOW": (api.Denoiser.SIGMA_SHADOW, ("sigma",)),
-    "SIGMA_SHADOW_TRANSLUCENCY": (api.Denoiser.SIGMA_SHADOW_TRANSLUCENCY, ("sigma",)),
-    "RELAX_DIFFUSE": (api.Denoiser.RELAX_DIFFUSE, ("relax",)),
-    "RELAX_DIFFUSE_SH": (api.Denoiser.RELAX_DIFFUSE_SH, ("relax",)),
-    "RELAX_SPECULAR": (api.Denoiser.RELAX_SPECULAR, ("relax",)),
-    "RELAX_SPECULAR_SH": (api.Denoiser.RELAX_SPECULAR_SH, ("relax",)),
-    "RELAX_DIFFUSE_SPECULAR": (api.Denoiser.RELAX_DIFFUSE_SPECULAR, ("relax",)),
-    "RELAX_DIFFUSE_SPECULAR_SH": (api.Denoiser.RELAX_DIFFUSE_SPECULAR_SH, ("relax",)),
-}
-
-
-def _relax_signals(name):
-    """(has diffuse, has specular, SH) of a RELAX variant name"""
-    body = name[len("RELAX_"):]
-    sh = body.endswith("_SH")
-    body = body[:-3] if sh else body
-    return "DIFFUSE" in body, "SPECULAR" in body, sh
-
-
-def user_planes(name, frame):
-    """(ResourceType, tensor, Format) inputs of a denoiser for one generated frame."""
-    extra = []
-    if "diff_confidence" in frame:  # generated with want=(..., "confidence"): optional guides, consumed when CommonSettings enables them
-        extra = [(RT.IN_DIFF_CONFIDENCE, frame["diff_confidence"], F.R8_UNORM), (RT.IN_SPEC_CONFIDENCE, frame["spec_confidence"], F.R8_UNORM),
-                 (RT.IN_DISOCCLUSION_THRESHOLD_MIX, frame["disocclusion_mix"], F.R8_UNORM)]
-    planes = _user_planes(name, frame)
-    if frame.get("_checkerboard"):  # (CheckerboardMode, frame index): noisy signals traced for every other pixel and packed into the left half
-        mode, frame_index = frame["_checkerboard"]
-        diff_mode, spec_mode = (0, 1) if mode == api.CheckerboardMode.BLACK else (1, 0)  # reference Reblur.cpp / Relax.cpp: BLACK -> diffuse 0, specular 1
-        planes = [(rt, checkerboard_pack(t, diff_mode if rt.name.startswith("IN_DIFF") else spec_mode, frame_index) if rt.name.startswith(("IN_DIFF", "IN_SPEC")) else t, fmt)
-                  for rt, t, fmt in planes]
-    if "basecolor_metalness" in frame:  # consumed when CommonSettings::isBaseColorMetalnessAvailable (REBLUR: specular motion written back into IN_MV)
-        extra.append((RT.IN_BASECOLOR_METALNESS, frame["basecolor_metalness"], F.RGBA8_UNORM))
-    return planes + extra
-
-
-def tag_checkerboard(frame, overrides, frame_index):
-    """marks a generated frame so that user_planes() hands out checkerboarded noisy inputs when the settings ask for them"""
-    mode = (overrides or {}).get("checkerboardMode")
-    frame["_checkerboard"] = (api.CheckerboardMode(mode), frame_index) if mode else None
-
-
-def checkerboard_pack(plane, mode, frame_index):
-    """Checkerboarded noisy input (reference README "checkerboard": the pixels with ((x ^ y) ^ frameIndex) & 1 == mode carry data and are packed into the
-    left half of the plane, column x >> 1). The right half is filled with a sentinel: nothing may read it."""
-    h, w = plane.shape[0], plane.shape[1]
-    y = torch.arange(h, device=plane.device)
-    b = (mode ^ (y & 1) ^ (frame_index & 1)).view(h, 1)  # per row: which pixel of each horizontal pair has data
-    k = torch.arange((w + 1) // 2, device=plane.device).view(1, -1)
-    src = (2 * k + b).clamp(max=w - 1)
-    idx = src.view(h, -1, *([1] * (plane.dim() - 2))).expand(h, src.shape[1], *plane.shape[2:])
-    out = torch.full_like(plane, 17)
-    out[:, : src.shape[1]] = torch.gather(plane, 1, idx)
-    return out.contiguous()
-
-
-def _hitdist_unorm16(signal):
-    """normalised hit distance (.w of a packed REBLUR signal) as R16_UNORM texels (int16 tensor holding the uint16 bit patterns)"""
-    q = torch.floor(signal[..., 3].float().clamp(0.0, 1.0) * 65535.0 + 0.5).to(torch.int32)
-    return torch.where(q >= 32768, q - 65536, q).to(torch.int16).contiguous()
-
-
-def _user_planes(name, frame):
-    planes = [(RT.IN_MV, frame["mv"], F.RGBA16_SFLOAT), (RT.IN_NORMAL_ROUGHNESS, frame["normal_roughness"], F.R10_G10_B10_A2_UNORM), (RT.IN_VIEWZ, frame["viewz"], F.R32_SFLOAT)]
-    if name in ("REBLUR_DIFFUSE", "REBLUR_DIFFUSE_SPECULAR"):
-        planes.append((RT.IN_DIFF_RADIANCE_HITDIST, frame["diff"], F.RGBA16_SFLOAT))
-    if name in ("REBLUR_SPECULAR", "REBLUR_DIFFUSE_SPECULAR"):
-        planes.append((RT.IN_SPEC_RADIANCE_HITDIST, frame["spec"], F.RGBA16_SFLOAT))
-    if name in ("REBLUR_DIFFUSE_SH", "REBLUR_DIFFUSE_SPECULAR_SH"):
-        planes += [(RT.IN_DIFF_SH0, frame["diff"], F.RGBA16_SFLOAT), (RT.IN_DIFF_SH1, frame["diff_sh1"], F.RGBA16_SFLOAT)]
-    if name in ("REBLUR_SPECULAR_SH", "REBLUR_DIFFUSE_SPECULAR_SH"):
-        planes += [(RT.IN_SPEC_SH0, frame["spec"], F.RGBA16_SFLOAT), (RT.IN_SPEC_SH1, frame["spec_sh1"], F.RGBA16_SFLOAT)]
-    if name == "REBLUR_DIFFUSE_DIRECTIONAL_OCCLUSION":
-        planes.append((RT.IN_DIFF_DIRECTION_HITDIST, frame["diff_direction_hitdist"], F.RGBA16_SNORM))
-    if name in ("REBLUR_DIFFUSE_OCCLUSION", "REBLUR_DIFFUSE_SPECULAR_OCCLUSION"):
-        planes.append((RT.IN_DIFF_HITDIST, _hitdist_unorm16(frame["diff"]), F.R16_UNORM))
-    if name in ("REBLUR_SPECULAR_OCCLUSION", "REBLUR_DIFFUSE_SPECULAR_OCCLUSION"):
-        planes.append((RT.IN_SPEC_HITDIST, _hitdist_unorm16(frame["spec"]), F.R16_UNORM))
-    if name.startswith("SIGMA_SHADOW"):
-        planes.append((RT.IN_PENUMBRA, frame["penumbra"], F.R16_SFLOAT))
-    if name == "SIGMA_SHADOW_TRANSLUCENCY":
-        planes.append((RT.IN_TRANSLUCENCY, frame["translucency"], F.RGBA8_UNORM))
-    if name.startswith("RELAX"):
-        has_diff, has_spec, sh = _relax_signals(name)
-        if has_diff:
-            planes.append((RT.IN_DIFF_SH0 if sh else RT.IN_DIFF_RADIANCE_HITDIST, frame["diff_relax"], F.RGBA16_SFLOAT))
-            if sh:
-                planes.append((RT.IN_DIFF_SH1, frame["diff_relax_sh1"], F.RGBA16_SFLOAT))
-        if has_spec:
-            planes.append((RT.IN_SPEC_SH0 if sh else RT.IN_SPEC_RADIANCE_HITDIST, frame["spec_relax"], F.RGBA16_SFLOAT))
-            if sh:
-                planes.append((RT.IN_SPEC_SH1, frame["spec_relax_sh1"], F.RGBA16_SFLOAT))
-    return planes
-
-
-def output_planes(name, width, height, validation=False):
-    """(ResourceType, dtype, channels, Format)"""
-    outs = [(RT.OUT_VALIDATION, torch.uint8, 4, F.RGBA8_UNORM)] if validation else []
-    if name in ("REBLUR_DIFFUSE", "REBLUR_DIFFUSE_SPECULAR"):
-        outs.append((RT.OUT_DIFF_RADIANCE_HITDIST, torch.float16, 4, F.RGBA16_SFLOAT))
-    if name in ("REBLUR_SPECULAR", "REBLUR_DIFFUSE_SPECULAR"):
-        outs.append((RT.OUT_SPEC_RADIANCE_HITDIST, torch.float16, 4, F.RGBA16_SFLOAT))
-    if name in ("REBLUR_DIFFUSE_SH", "REBLUR_DIFFUSE_SPECULAR_SH"):
-        outs += [(RT.OUT_DIFF_SH0, torch.float16, 4, F.RGBA16_SFLOAT), (RT.OUT_DIFF_SH1, torch.float16, 4, F.RGBA16_SFLOAT)]
-    if name in ("REBLUR_SPECULAR_SH", "REBLUR_DIFFUSE_SPECULAR_SH"):
-        outs += [(RT.OUT_SPEC_SH0, torch.float16, 4, F.RGBA16_SFLOAT), (RT.OUT_SPEC_SH1, torch.float16, 4, F.RGBA16_SFLOAT)]
-    if name == "REBLUR_DIFFUSE_DIRECTIONAL_OCCLUSION":
-        outs.append((RT.OUT_DIFF_DIRECTION_HITDIST, torch.int16, 4, F.RGBA16_SNORM))
-    if name in ("REBLUR_DIFFUSE_OCCLUSION", "REBLUR_DIFFUSE_SPECULAR_OCCLUSION"):
-        outs.append((RT.OUT_DIFF_HITDIST, torch.int16, 1, F.R16_UNORM))
-    if name in ("REBLUR_SPECULAR_OCCLUSION", "REBLUR_DIFFUSE_SPECULAR_OCCLUSION"):
-        outs.append((RT.OUT_SPEC_HITDIST, torch.int16, 1, F.R16_UNORM))
-    if name == "SIGMA_SHADOW":
-        outs.append((RT.OUT_SHADOW_TRANSLUCENCY, torch.uint8, 1, F.R8_UNORM))
-    if name == "SIGMA_SHADOW_TRANSLUCENCY":
-        outs.append((RT.OUT_SHADOW_TRANSLUCENCY, torch.uint8, 4, F.RGBA8_UNORM))
-    if name.startswith("RELAX"):
-        has_diff, has_spec, sh = _relax_signals(name)
-        if has_diff:
-            outs.append((RT.OUT_DIFF_SH0 if sh else RT.OUT_DIFF_RADIANCE_HITDIST, torch.float16, 4, F.RGBA16_SFLOAT))
-            if sh:
-                outs.append((RT.OUT_DIFF_SH1, torch.float16, 4, F.RGBA16_SFLOAT))
-        if has_spec:
-            outs.append((RT.OUT_SPEC_SH0 if sh else RT.OUT_SPEC_RADIANCE_HITDIST, torch.float16, 4, F.RGBA16_SFLOAT))
-            if sh:
-                outs.append((RT.OUT_SPEC_SH1, torch.float16, 4, F.RGBA16_SFLOAT))
-    return outs
-
-
-def denoiser_settings(name, frame, overrides=None):
-    if name.startswith("REBLUR"):
-        s = api.ReblurSettings(**(overrides or {}))
-    elif name.startswith("SIGMA_SHADOW"):
-        s = api.SigmaSettings(lightDirection=frame["light_dir"], **(overrides or {}))
-    elif name.startswith("RELAX"):
-        s = api.RelaxSettings(**(overrides or {}))
-    else:
-        raise KeyError(name)
-    return s
+# the workload description (planes, settings, frame generator) lives in the package: bench.py uses it without touching tests/ or the oracle
+from raytracingdenoiser_amd.scene import (DENOISERS, _relax_signals, checkerboard_pack, common_settings, denoiser_settings, embed_in_resource, generate_sequence,  # noqa: E402,F401
+                                          output_planes, tag_checkerboard, user_planes)
 
 
 def decode_plane(raw, fmt, width):
@@ -301,13 +143,22 @@ def _padded(t, pad):
     return view
 
 
-class HipRun:
-    def __init__(self, name, width, height, pad=0, numerics="exact", validation=False):
-        """numerics: which build of the library runs -- "exact" (libNRD_hip_exact.so, bit-identical to the oracle) or "fast" (libNRD_hip.so, the product)"""
+def HipRun(name, width, height, pad=0, validation=False):
+    """the device side of a parity run: the GPU through lib/libNRD_hip.so, or -- NRD_PARITY_BACKEND=emu, a developer mode for machines without a GPU -- the
+    device sources compiled for the CPU (tests/emu)"""
+    if os.environ.get("NRD_PARITY_BACKEND") == "emu":
+        from emu.emu_run import EmuRun
+
+        return EmuRun(name, width, height, pad=pad, validation=validation)
+    return GpuRun(name, width, height, pad=pad, validation=validation)
+
+
+class GpuRun:
+    def __init__(self, name, width, height, pad=0, validation=False):
         from raytracingdenoiser_amd.executor import HipExecutor
 
         self.name, self.width, self.height, self.pad = name, width, height, pad
-        self.inst = api.Instance([(0, DENOISERS[name][0])], numerics=numerics)
+        self.inst = api.Instance([(0, DENOISERS[name][0])])
         self.ex = HipExecutor(self.inst, width, height)
         self.outs = {}
         for rt, dtype, ch, fmt in output_planes(name, width, height, validation):
@@ -335,43 +186,26 @@ class HipRun:
         return (a.view(np.uint16) if a.dtype == np.int16 and fmt == F.R16_UNORM else a).astype(np.float32)  # int16 tensors: R16_UNORM bit patterns or SNORM16 values
 
 
-def generate_sequence(name, width, height, frames, static_camera=False, noise=True, device="cpu", extra_want=()):
-    """frames 0 .. frames-1 of the synthetic sequence (analytic scene, moving camera, 1-rpp noise) with the planes the denoiser consumes"""
-    return [synth.render_frame(width, height, f, device=device, static_camera=static_camera, noise=noise, want=tuple(DENOISERS[name][1]) + tuple(extra_want)) for f in range(frames)]
-
-
-def embed_in_resource(frame, resource):
-    """dynamic resolution: every plane of a generated (rect-sized) frame placed at the top-left of a resource-sized plane; the rest is a sentinel"""
-    rw, rh = resource
-    out = {}
-    for k, v in frame.items():
-        if torch.is_tensor(v) and v.dim() >= 2 and v.dtype != torch.bool:
-            big = torch.full([rh, rw] + list(v.shape[2:]), 33.0 if v.dtype.is_floating_point else 9, dtype=v.dtype, device=v.device)
-            big[: v.shape[0], : v.shape[1]] = v
-            v = big
-        out[k] = v
-    return out
-
-
 def run_parity(name, width=192, height=128, frames=4, verbose=False, settings_overrides=None, static_camera=False, check_pools=True, cs_kw=None, extra_want=(), pad=0, resource=None,
-               rect_sizes=None, numerics="exact", ieee=False, stats=None, static_after=None, graph=False, device="cpu", backend="hip"):
+               rect_sizes=None, ieee=False, stats=None, static_after=None, graph=False, device="cpu", backend=None):
     """Returns the worst relative error between the HIP path and the oracle over all frames, user outputs and pool planes.
-    numerics = "exact": the bit-exact regression build against the oracle that emulates the device's sqrt / rsqrt (expected error: 0);
-    numerics = "fast" (the product build) is compared with ieee = True, the oracle in plain IEEE arithmetic, and judged through `stats`
+    The library is compared with the oracle that emulates the device's rcp / sqrt / rsqrt / exp2 / log2 instructions: expected error 0, bit for bit.
+    ieee = True compares it with the oracle in plain IEEE arithmetic instead (no knowledge of the device) and is judged through `stats`
     (a ParityStats that receives the per-plane tolerance statistics; the return value is then the worst error of the user OUTPUTS only).
+    backend: "hip" = the GPU; "emu" = the device sources compiled for the CPU (tests/emu); default: NRD_PARITY_BACKEND or "hip".
     static_after = N: the camera stops moving after frame N (long runs: accumulation counters saturate, anti-lag fires on the stop).
     graph: the HIP side runs in graph mode (one hipGraph launch per frame).
     resource = (w, h) >= (width, height): dynamic resolution, the frame is the top-left rect of resource-sized planes;
     rect_sizes = [(w, h), ...]: the rect size of frame f is rect_sizes[f % len] (same aspect ratio as (width, height)), inside `resource`."""
     prev_ieee = oracle_driver.set_ieee_mode(ieee)
     try:
-        return _run_parity(name, width, height, frames, verbose, settings_overrides, static_camera, check_pools, cs_kw, extra_want, pad, resource, rect_sizes, numerics, stats, static_after,
-                           graph, device, backend)
+        return _run_parity(name, width, height, frames, verbose, settings_overrides, static_camera, check_pools, cs_kw, extra_want, pad, resource, rect_sizes, stats, static_after,
+                           graph, device, backend or os.environ.get("NRD_PARITY_BACKEND", "hip"))
     finally:
         oracle_driver.set_ieee_mode(prev_ieee)
 
 
-def _run_parity(name, width, height, frames, verbose, settings_overrides, static_camera, check_pools, cs_kw, extra_want, pad, resource, rect_sizes, numerics, stats, static_after, graph, device,
+def _run_parity(name, width, height, frames, verbose, settings_overrides, static_camera, check_pools, cs_kw, extra_want, pad, resource, rect_sizes, stats, static_after, graph, device,
                 backend="hip"):
     if rect_sizes:
         seq = [synth.render_frame(*rect_sizes[f % len(rect_sizes)], f, static_camera=static_camera, want=tuple(DENOISERS[name][1]) + tuple(extra_want)) for f in range(frames)]
@@ -389,8 +223,8 @@ def _run_parity(name, width, height, frames, verbose, settings_overrides, static
     if backend == "emu":  # the device sources compiled for the CPU (tests/emu): the same comparison on a machine without a GPU
         from emu.emu_run import EmuRun as DeviceRun
     else:
-        DeviceRun = HipRun
-    ora, hip = OracleRun(name, rw, rh, validation=validation), DeviceRun(name, rw, rh, pad=pad, numerics=numerics, validation=validation)
+        DeviceRun = GpuRun
+    ora, hip = OracleRun(name, rw, rh, validation=validation), DeviceRun(name, rw, rh, pad=pad, validation=validation)
     if graph:
         hip.ex.set_graph_mode(True)
     worst = 0.0

@@ -1,5 +1,6 @@
 """Executor behaviour that is not arithmetic: all-or-nothing pre-flight of a dispatch list, HIP-graph execution, the per-list guide cache."""
 import ctypes as C
+import os
 
 import numpy as np
 import pytest
@@ -11,9 +12,9 @@ from raytracingdenoiser_amd import api
 RT = parity.RT
 
 
-def _run(name, frames, graph, numerics="fast", w=192, h=128, profile_every=None):
+def _run(name, frames, graph, w=192, h=128, profile_every=None):
     seq = parity.generate_sequence(name, w, h, frames)
-    hip = parity.HipRun(name, w, h, numerics=numerics)
+    hip = parity.HipRun(name, w, h)
     hip.ex.set_graph_mode(graph)
     outs = []
     for f, frame in enumerate(seq):
@@ -46,7 +47,7 @@ def test_unsupported_dispatch_launches_nothing():
     is enqueued (reference Integration::Denoise contract) -- outputs and history stay untouched"""
     name, w, h = "REBLUR_DIFFUSE_SPECULAR", 192, 128
     seq = parity.generate_sequence(name, w, h, 3)
-    hip = parity.HipRun(name, w, h, numerics="fast")
+    hip = parity.HipRun(name, w, h)
     for f in range(2):
         cs = parity.common_settings(seq[f]["camera"], seq[max(f - 1, 0)]["camera"], w, h, f)
         hip.step(seq[f], cs, parity.denoiser_settings(name, seq[f]))
@@ -73,7 +74,7 @@ def test_range_without_first_range_still_decodes_guides():
     seq = parity.generate_sequence(name, w, h, 2)
 
     def run(split):
-        hip = parity.HipRun(name, w, h, numerics="fast")
+        hip = parity.HipRun(name, w, h)
         for f, frame in enumerate(seq):
             for rt, t, fmt in parity.user_planes(name, frame):
                 t = t.cuda().clone().contiguous()
@@ -97,7 +98,8 @@ def test_range_without_first_range_still_decodes_guides():
         assert np.array_equal(a[rt], b[rt])
 
 
-def test_numerics_mode_export_and_both_libraries_load():
-    fast, exact = api.load_library(numerics="fast"), api.load_library(numerics="exact")
-    assert fast.nrdHipGetNumericsMode() == 1 and exact.nrdHipGetNumericsMode() == 0
-    assert fast is not exact and api.load_library() is fast
+def test_one_library_one_arithmetic():
+    """round 2 shipped a "fast" and an "exact" build; there is ONE library now and it reports the pinned arithmetic (mode 0)"""
+    lib = api.load_library()
+    assert lib.nrdHipGetNumericsMode() == 0
+    assert api.load_library() is lib and not os.path.exists(os.path.join(os.path.dirname(api.LIB_PATH), "libNRD_hip_exact.so"))

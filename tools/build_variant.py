@@ -1,11 +1,9 @@
-"""A/B builds of the product library for tuning runs: the fast-numerics sources with extra compiler flags / -D switches, linked to
-raytracingdenoiser_amd/lib/variants/<name>/libNRD_hip.so (objects under /tmp). bench.py picks one up through NRD_HIP_FAST_LIBRARY=<path>.
+"""A/B builds of the product library for tuning runs: the same sources with extra compiler flags / -D switches, linked to
+raytracingdenoiser_amd/lib/variants/<name>/libNRD_hip.so (objects under /tmp). bench.py and the tests pick one up through NRD_HIP_LIBRARY=<path>.
 usage: python tools/build_variant.py NAME [extra hipcc flags ...]      e.g.  python tools/build_variant.py ilp -mllvm -amdgpu-sched-strategy=max-ilp
-       NAME ending in "_exact" builds the exact-numerics variant (libNRD_hip_exact.so, for NRD_HIP_EXACT_LIBRARY)"""
+A variant that changes arithmetic must be held against the oracle like the product:  NRD_HIP_LIBRARY=<path> python -m pytest tests -m gpu"""
 import os
-import subprocess
 import sys
-from concurrent.futures import ThreadPoolExecutor
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from raytracingdenoiser_amd import build as B  # noqa: E402
@@ -13,27 +11,8 @@ from raytracingdenoiser_amd import build as B  # noqa: E402
 
 def main():
     name, extra = sys.argv[1], sys.argv[2:]
-    numerics = "exact" if name.endswith("_exact") else "fast"
-    host, hip = B._sources()
-    obj_dir = os.path.join("/tmp/nrd_variants", name)
-    out_dir = os.path.join(B.LIB_DIR, "variants", name)
-    os.makedirs(obj_dir, exist_ok=True)
-    os.makedirs(out_dir, exist_ok=True)
-
-    def compile_one(src):
-        obj = os.path.join(obj_dir, os.path.basename(src) + ".o")
-        is_hip = src.endswith(".hip")
-        # kernels_common.hip and the host keep the exact flags, as in the product build; the extra flags apply to the device passes only
-        tuned = is_hip and os.path.basename(src) not in B.ALWAYS_EXACT
-        cmd = [B.HIPCC] + B._flags(src, numerics) + (B.HIP_FLAGS + ["-x", "hip"] if is_hip else ["-x", "c++"]) + (extra if tuned else []) + ["-c", src, "-o", obj]
-        subprocess.run(cmd, check=True)
-        return obj
-
-    with ThreadPoolExecutor(max_workers=min(8, os.cpu_count() or 1)) as pool:
-        objs = list(pool.map(compile_one, host + hip))
-    out = os.path.join(out_dir, B.LIB_NAMES[numerics])
-    subprocess.run([B.HIPCC, "-shared", "-fPIC", "--offload-arch=gfx950", "-fno-gpu-rdc"] + objs + ["-o", out], check=True)
-    print(out)
+    out = os.path.join(B.LIB_DIR, "variants", name, B.LIB_NAME)
+    print(B.build_product(verbose=False, out=out, extra=extra, obj_dir=os.path.join("/tmp/nrd_variants", name)))
 
 
 if __name__ == "__main__":
