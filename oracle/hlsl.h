@@ -166,6 +166,20 @@ inline float4 Div(float4 a, float b) {
     return float4(a.x * r, a.y * r, a.z * r, a.w * r);
 }
 inline float4 Div(float4 a, float4 b) { return float4(Div(a.x, b.x), Div(a.y, b.y), Div(a.z, b.z), Div(a.w, b.w)); }
+// a * s + c with ONE rounding per component (the overloaded operators round the product first): the accumulations of the tap loops, as on the device
+inline float Mad(float a, float s, float c) { return a * s + c; }
+inline float2 Mad(float2 a, float s, float2 c) { return float2(a.x * s + c.x, a.y * s + c.y); }
+inline float2 Mad(float2 a, float2 s, float2 c) { return float2(a.x * s.x + c.x, a.y * s.y + c.y); }
+inline float3 Mad(float3 a, float s, float3 c) { return float3(a.x * s + c.x, a.y * s + c.y, a.z * s + c.z); }
+inline float4 Mad(float4 a, float s, float4 c) { return float4(a.x * s + c.x, a.y * s + c.y, a.z * s + c.z, a.w * s + c.w); }
+// a * wa + b * wb (+ c * wc + d * wd): per component the very expression a scalar blend is written as, so vector and scalar blends fuse alike
+inline float WSum(float a, float wa, float b, float wb) { return a * wa + b * wb; }
+inline float4 WSum(float4 a, float wa, float4 b, float wb) { return float4(a.x * wa + b.x * wb, a.y * wa + b.y * wb, a.z * wa + b.z * wb, a.w * wa + b.w * wb); }
+inline float WSum(float a, float wa, float b, float wb, float c, float wc, float d, float wd) { return a * wa + b * wb + c * wc + d * wd; }
+inline float4 WSum(float4 a, float wa, float4 b, float wb, float4 c, float wc, float4 d, float wd) {
+    return float4(a.x * wa + b.x * wb + c.x * wc + d.x * wd, a.y * wa + b.y * wb + c.y * wc + d.y * wd, a.z * wa + b.z * wb + c.z * wc + d.z * wd, a.w * wa + b.w * wb + c.w * wc + d.w * wd);
+}
+inline float4 Mad(float4 a, float4 s, float4 c) { return float4(a.x * s.x + c.x, a.y * s.y + c.y, a.z * s.z + c.z, a.w * s.w + c.w); }
 inline float3 operator-(float3 a) { return float3(-a.x, -a.y, -a.z); }
 inline float2 operator-(float2 a) { return float2(-a.x, -a.y); }
 inline float2& operator+=(float2& a, float2 b) { return a = a + b; }

@@ -149,6 +149,7 @@ struct DirOcc { // distinct type so that GetLuma / ChangeLuma / ClampNegativeToZ
 };
 inline DirOcc operator+(DirOcc a, DirOcc b) { return DirOcc(a.v + b.v); }
 inline DirOcc operator*(DirOcc a, float b) { return DirOcc(a.v * b); }
+inline DirOcc Mad(DirOcc a, float s, DirOcc c) { return DirOcc(Mad(a.v, s, c.v)); }
 inline DirOcc lerp(DirOcc a, DirOcc b, float t) { return DirOcc(lerp(a.v, b.v, t)); }
 
 template <int KIND> struct ReblurSignal;
@@ -266,21 +267,21 @@ inline V FetchHistoryT(const HistoryFilter& h, const Tex& tex, Get get, V zero) 
     V color;
     if (h.useBicubic) {
         float fx = h.tc.x, fy = h.tc.y, gx = 1.0f - fx, gy = 1.0f - fy;
-        V s0 = T(0, -1) * gx + T(1, -1) * fx;
-        V s1 = T(-1, 0) * gy + T(-1, 1) * fy;
-        V s2 = T(0, 0) * (gx * gy) + T(1, 0) * (fx * gy) + T(0, 1) * (gx * fy) + T(1, 1) * (fx * fy);
-        V s3 = T(2, 0) * gy + T(2, 1) * fy;
-        V s4 = T(0, 2) * gx + T(1, 2) * fx;
+        V s0 = WSum(T(0, -1), gx, T(1, -1), fx);
+        V s1 = WSum(T(-1, 0), gy, T(-1, 1), fy);
+        V s2 = WSum(T(0, 0), gx * gy, T(1, 0), fx * gy, T(0, 1), gx * fy, T(1, 1), fx * fy);
+        V s3 = WSum(T(2, 0), gy, T(2, 1), fy);
+        V s4 = WSum(T(0, 2), gx, T(1, 2), fx);
         color = s0 * h.w.x;
-        color = color + s1 * h.w.y;
-        color = color + s2 * h.w.z;
-        color = color + s3 * h.w.w;
-        color = color + s4 * h.w4;
+        color = Mad(s1, h.w.y, color);
+        color = Mad(s2, h.w.z, color);
+        color = Mad(s3, h.w.w, color);
+        color = Mad(s4, h.w4, color);
     } else {
         color = T(0, 0) * h.w.x;
-        color = color + T(1, 0) * h.w.y;
-        color = color + T(0, 1) * h.w.z;
-        color = color + T(1, 1) * h.w.w;
+        color = Mad(T(1, 0), h.w.y, color);
+        color = Mad(T(0, 1), h.w.z, color);
+        color = Mad(T(1, 1), h.w.w, color);
     }
     return h.sum < 0.0001f ? zero : Div(color, h.sum);
 }
@@ -293,9 +294,9 @@ inline float FetchHistoryScalar(const HistoryFilter& h, const Tex& tex) {
 template <typename V, typename Get>
 inline V FetchHistoryBilinearT(const HistoryFilter& h, const Tex& tex, Get get, V zero) {
     V color = get(tex.Load(h.ox, h.oy)) * h.bw.x;
-    color = color + get(tex.Load(h.ox + 1, h.oy)) * h.bw.y;
-    color = color + get(tex.Load(h.ox, h.oy + 1)) * h.bw.z;
-    color = color + get(tex.Load(h.ox + 1, h.oy + 1)) * h.bw.w;
+    color = Mad(get(tex.Load(h.ox + 1, h.oy)), h.bw.y, color);
+    color = Mad(get(tex.Load(h.ox, h.oy + 1)), h.bw.z, color);
+    color = Mad(get(tex.Load(h.ox + 1, h.oy + 1)), h.bw.w, color);
     float s = sum(h.bw);
     return s < 0.0001f ? zero : Div(color, s);
 }

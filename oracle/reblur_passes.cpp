@@ -162,11 +162,11 @@ S DiffuseSpatialFilterTaps(const ReblurCB& c, SpatialMode mode, const SpatialCtx
         w *= GetGaussianWeight(offset.z);
 
         sum += w;
-        diff = diff + smp * w;
+        diff = Mad(smp, w, diff);
         if (diffSh) {
             float4 sh = gIn_DiffSh->SampleNearest(checkerboardUvScaled);
             sh = w == 0.0f ? float4(0.0f) : sh;
-            *diffSh += sh * w;
+            *diffSh = Mad(sh, w, *diffSh);
         }
     }
 
@@ -336,7 +336,7 @@ S SpecularSpatialFilterTaps(const ReblurCB& c, SpatialMode mode, const SpatialCt
         w *= GetGaussianWeight(offset.z);
 
         sum += w;
-        spec = spec + smp * w;
+        spec = Mad(smp, w, spec);
         if (specSh) {
             float4 sh = gIn_SpecSh->SampleNearest(checkerboardUvScaled);
             sh = w == 0.0f ? float4(0.0f) : sh;
@@ -1362,7 +1362,7 @@ S HistoryFixSignal(const ReblurCB& c, bool isSpec, bool perf, int px, int py, S 
                 }
 
                 sumw += w;
-                sig = sig + smp * w;
+                sig = Mad(smp, w, sig);
                 if (sh) {
                     float4 t = gIn_Sh->Load(sx, sy);
                     t = w == 0.0f ? float4(0.0f) : t;
@@ -1824,7 +1824,7 @@ void HitDistReconstruction(const PassIO& io) {
                     data.y = ww.y == 0.0f ? 0.0f : data.y;
                     ww = ww * float2(data.x != 0.0f ? 1.0f : 0.0f, data.y != 0.0f ? 1.0f : 0.0f);
 
-                    center += data * ww;
+                    center = Mad(data, ww, center);
                     sum += ww;
                 }
             center = Div(center, max(sum, float2(NRD_EPS)));

@@ -83,9 +83,9 @@ inline float BilinearWithCustomWeightsImmediateFloat(float s00, float s10, float
 }
 inline float4 BilinearWithCustomWeightsFloat4(const Tex& tex, int ox, int oy, float4 w) { // :55-66
     float4 o = tex.Load(ox, oy) * w.x;
-    o += tex.Load(ox + 1, oy) * w.y;
-    o += tex.Load(ox, oy + 1) * w.z;
-    o += tex.Load(ox + 1, oy + 1) * w.w;
+    o = Mad(tex.Load(ox + 1, oy), w.y, o);
+    o = Mad(tex.Load(ox, oy + 1), w.z, o);
+    o = Mad(tex.Load(ox + 1, oy + 1), w.w, o);
     float sumWeights = sum(w);
     return sumWeights < 0.0001f ? float4(0.0f) : o * rcp(sumWeights);
 }
@@ -414,10 +414,10 @@ void PrePass(const PassIO& io) {
                         sampleWeight *= GetGaussianWeight(g_Poisson8[i].z);
 
                         weightSum += sampleWeight;
-                        diffuseIllumination += sampleDiffuseIllumination * sampleWeight;
+                        diffuseIllumination = Mad(sampleDiffuseIllumination, sampleWeight, diffuseIllumination);
                         if (SH) {
                             float4 sampleDiffuseSH = Denanify(sampleWeight, diff.inSh->SampleNearest(cbUv));
-                            diffuseSH += sampleDiffuseSH * sampleWeight;
+                            diffuseSH = Mad(sampleDiffuseSH, sampleWeight, diffuseSH);
                         }
                     }
                     diffuseIllumination = Div(diffuseIllumination, weightSum);
@@ -513,10 +513,10 @@ void PrePass(const PassIO& io) {
                         sampleWeight *= lerp(saturate(t), 1.0f, Math::LinearStep(0.5f, 1.0f, centerRoughness));
 
                         weightSum += sampleWeight;
-                        rgb += sampleSpecularIllumination.xyz() * sampleWeight;
+                        rgb = Mad(sampleSpecularIllumination.xyz(), sampleWeight, rgb);
                         if (SH) {
                             float4 sampleSpecularSH = Denanify(sampleWeight, spec.inSh->SampleNearest(cbUv));
-                            specularSH += sampleSpecularSH * sampleWeight;
+                            specularSH = Mad(sampleSpecularSH, sampleWeight, specularSH);
                         }
                         if (sampleWeight != 0.0f)
                             minHitT = min(minHitT, sampleSpecularIllumination.w == 0.0f ? NRD_INF : sampleSpecularIllumination.w);
@@ -1516,9 +1516,9 @@ void AtrousSmem(const PassIO& io) {
                             wSpecular *= Cmp(CompareMaterials(sampleMaterialID, centerMaterialID, c.gSpecMinMaterial));
 
                             sumWSpecular += wSpecular;
-                            sumSpecular += wSpecular * sampleSpecular;
+                            sumSpecular = Mad(sampleSpecular, wSpecular, sumSpecular);
                             if (SH)
-                                sumSpecularSH += wSpecular * SSh(spec, qx, qy);
+                                sumSpecularSH = Mad(SSh(spec, qx, qy), wSpecular, sumSpecularSH);
                         }
                         if (DIFF) {
                             float angled = Math::AcosApprox(dot(centerNormal, sampleNormal));
@@ -1535,9 +1535,9 @@ void AtrousSmem(const PassIO& io) {
                             wDiffuse *= Cmp(CompareMaterials(sampleMaterialID, centerMaterialID, c.gDiffMinMaterial));
 
                             sumWDiffuse += wDiffuse;
-                            sumDiffuse += wDiffuse * sampleDiffuse;
+                            sumDiffuse = Mad(sampleDiffuse, wDiffuse, sumDiffuse);
                             if (SH)
-                                sumDiffuseSH += wDiffuse * SSh(diff, qx, qy);
+                                sumDiffuseSH = Mad(SSh(diff, qx, qy), wDiffuse, sumDiffuseSH);
                         }
                     }
 
@@ -1586,11 +1586,11 @@ void AtrousSmem(const PassIO& io) {
                             float specularW = normalW * depthW;
                             specularW *= Cmp(CompareMaterials(sampleMaterialID, centerMaterialID, c.gSpecMinMaterial));
                             sumWSpecular += specularW;
-                            sumSpecularIllumination += sampleSpecular.xyz() * specularW;
+                            sumSpecularIllumination = Mad(sampleSpecular.xyz(), specularW, sumSpecularIllumination);
                             sumSpecular1stMoment += sample1stMoment * specularW;
                             sumSpecular2ndMoment += sampleSpecular.w * specularW;
                             if (SH)
-                                sumSpecularSH += SSh(spec, qx, qy) * specularW;
+                                sumSpecularSH = Mad(SSh(spec, qx, qy), specularW, sumSpecularSH);
                         }
                         if (DIFF) {
                             float4 sampleDiffuse = S(diff, qx, qy);
@@ -1598,11 +1598,11 @@ void AtrousSmem(const PassIO& io) {
                             float diffuseW = normalW * depthW;
                             diffuseW *= Cmp(CompareMaterials(sampleMaterialID, centerMaterialID, c.gDiffMinMaterial));
                             sumWDiffuse += diffuseW;
-                            sumDiffuseIllumination += sampleDiffuse.xyz() * diffuseW;
+                            sumDiffuseIllumination = Mad(sampleDiffuse.xyz(), diffuseW, sumDiffuseIllumination);
                             sumDiffuse1stMoment += sample1stMoment * diffuseW;
                             sumDiffuse2ndMoment += sampleDiffuse.w * diffuseW;
                             if (SH)
-                                sumDiffuseSH += SSh(diff, qx, qy) * diffuseW;
+                                sumDiffuseSH = Mad(SSh(diff, qx, qy), diffuseW, sumDiffuseSH);
                         }
                     }
 
@@ -1789,9 +1789,9 @@ void Atrous(const PassIO& io) {
                             wSpecular *= exp(-specularLuminanceW);
 
                             sumWSpecular += wSpecular;
-                            sumSpecular += float4(wSpecular, wSpecular, wSpecular, wSpecular * wSpecular) * sampleSpecular;
+                            sumSpecular = Mad(sampleSpecular, float4(wSpecular, wSpecular, wSpecular, wSpecular * wSpecular), sumSpecular);
                             if (SH)
-                                sumSpecularSH += spec.inSh->Load(qx, qy) * wSpecular;
+                                sumSpecularSH = Mad(spec.inSh->Load(qx, qy), wSpecular, sumSpecularSH);
                         }
                     }
                     if (DIFF) {
@@ -1808,9 +1808,9 @@ void Atrous(const PassIO& io) {
                             wDiffuse *= exp(-diffuseLuminanceW);
 
                             sumWDiffuse += wDiffuse;
-                            sumDiffuse += float4(wDiffuse, wDiffuse, wDiffuse, wDiffuse * wDiffuse) * sampleDiffuse;
+                            sumDiffuse = Mad(sampleDiffuse, float4(wDiffuse, wDiffuse, wDiffuse, wDiffuse * wDiffuse), sumDiffuse);
                             if (SH)
-                                sumDiffuseSH += diff.inSh->Load(qx, qy) * wDiffuse;
+                                sumDiffuseSH = Mad(diff.inSh->Load(qx, qy), wDiffuse, sumDiffuseSH);
                         }
                     }
                 }

@@ -404,7 +404,7 @@ void TemporalStabilization(const PassIO& io) {
                         w = AreBothLitOrUnlit(centerPenumbra, penum);
                         w *= GetGaussianWeight(length(Div(float2(float(i - BORDER), float(j - BORDER)), float(BORDER))));
                     }
-                    m1 = m1 + s * w;
+                    m1 = Mad(s, w, m1);
                     m2 = m2 + s * s * w;
                     sumw += w;
                 }

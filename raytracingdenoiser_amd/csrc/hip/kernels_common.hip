@@ -222,14 +222,20 @@ __global__ __launch_bounds__(256) void EvalNumericsKernel(uint32_t op, const flo
     out[i] = r;
 }
 
-// ---- streaming copy probe (include/NRDHip.h: nrdHipMeasureCopyBandwidth): 16 bytes per lane, grid-stride over a 256-CU-sized grid ---------------
+// ---- streaming copy probe (include/NRDHip.h: nrdHipMeasureCopyBandwidth): 16 bytes per lane, four independent loads in flight per lane, grid-stride
+// over 2048 workgroups (8 per CU: cdna_hip_programming.md guideline 11)
 __global__ __launch_bounds__(256) void CopyProbeKernel(const uint4* __restrict__ src, uint4* __restrict__ dst, uint64_t count) {
     const uint64_t stride = (uint64_t)gridDim.x * 256u;
-    for (uint64_t i = (uint64_t)blockIdx.x * 256u + threadIdx.x; i < count; i += stride)
+    uint64_t i = (uint64_t)blockIdx.x * 256u + threadIdx.x;
+    for (; i + 3 * stride < count; i += 4 * stride) {
+        const uint4 a = src[i], b = src[i + stride], c = src[i + 2 * stride], d = src[i + 3 * stride];
+        dst[i] = a, dst[i + stride] = b, dst[i + 2 * stride] = c, dst[i + 3 * stride] = d;
+    }
+    for (; i < count; i += stride)
         dst[i] = src[i];
 }
 void LaunchCopyProbe(const void* src, void* dst, uint64_t bytes, hipStream_t stream) {
-    hipLaunchKernelGGL(CopyProbeKernel, dim3(256 * 32), dim3(256), 0, stream, (const uint4*)src, (uint4*)dst, bytes / 16u);
+    hipLaunchKernelGGL(CopyProbeKernel, dim3(2048), dim3(256), 0, stream, (const uint4*)src, (uint4*)dst, bytes / 16u);
 }
 
 void LaunchEvalNumerics(uint32_t op, const float* in1, const float* in2, float* out, uint32_t count, hipStream_t stream) {

@@ -134,7 +134,7 @@ NRD_D typename ReblurSignal<KIND>::type HistoryFixSignal(const ReblurCB& c, cons
                 }
 
                 sumw += w;
-                sig = sig + smp * w;
+                sig = Mad(smp, w, sig);
                 if (SH) {
                     float4 t = LoadRGBA16F(gIn_Sh, sx, sy);
                     t = Select(w == 0.0f, F4(0.0f), t);

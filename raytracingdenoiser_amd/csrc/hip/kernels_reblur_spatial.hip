@@ -249,11 +249,11 @@ NRD_D typename ReblurSignal<KIND>::type DiffuseSpatialFilterTaps(const ReblurCB&
         w *= PoissonGaussianWeight<PERF>(n);
 
         sum += w;
-        diff = diff + smp * w;
+        diff = Mad(smp, w, diff);
         if (SH) {
             float4 sh = LoadRGBA16F(gIn_DiffSh, ts.x, ts.y);
             sh = Select(w == 0.0f, F4(0.0f), sh);
-            diffSh = diffSh + sh * w;
+            diffSh = Mad(sh, w, diffSh);
         }
     }
 
@@ -410,7 +410,7 @@ NRD_D typename ReblurSignal<KIND>::type SpecularSpatialFilterTaps(const ReblurCB
         w *= PoissonGaussianWeight<PERF>(n);
 
         sum += w;
-        spec = spec + smp * w;
+        spec = Mad(smp, w, spec);
         if (SH) {
             float4 sh = LoadRGBA16F(gIn_SpecSh, ts.x, ts.y);
             sh = Select(w == 0.0f, F4(0.0f), sh);
@@ -803,7 +803,7 @@ __global__ __launch_bounds__(TILE_X* TILE_Y) void ReblurHitDistReconstructionKer
             data.y = ww.y == 0.0f ? 0.0f : data.y;
             ww = ww * F2(data.x != 0.0f ? 1.0f : 0.0f, data.y != 0.0f ? 1.0f : 0.0f);
 
-            center = center + data * ww;
+            center = Mad(data, ww, center);
             sum = sum + ww;
         }
     center = Div(center, F2(Max(sum.x, NRD_EPS), Max(sum.y, NRD_EPS)));

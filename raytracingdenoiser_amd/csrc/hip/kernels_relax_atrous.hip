@@ -249,9 +249,9 @@ __global__ __launch_bounds__(256, NRD_WAVES_RELAX_ATROUS_SMEM) void RelaxAtrousS
                     wSpecular *= Cmp(CompareMaterials(sampleMaterialID, centerMaterialID, c.shared.gSpecMinMaterial));
 
                     sumWSpecular += wSpecular;
-                    sumSpecular = sumSpecular + wSpecular * sampleSpecular;
+                    sumSpecular = Mad(sampleSpecular, wSpecular, sumSpecular);
                     if (SH)
-                        sumSpecularSH = sumSpecularSH + wSpecular * s_SpecSH[li];
+                        sumSpecularSH = Mad(s_SpecSH[li], wSpecular, sumSpecularSH);
                 }
                 if (DIFF) {
                     float angled = AcosApprox(Dot(centerNormal, sampleNormal));
@@ -268,9 +268,9 @@ __global__ __launch_bounds__(256, NRD_WAVES_RELAX_ATROUS_SMEM) void RelaxAtrousS
                     wDiffuse *= Cmp(CompareMaterials(sampleMaterialID, centerMaterialID, c.shared.gDiffMinMaterial));
 
                     sumWDiffuse += wDiffuse;
-                    sumDiffuse = sumDiffuse + wDiffuse * sampleDiffuse;
+                    sumDiffuse = Mad(sampleDiffuse, wDiffuse, sumDiffuse);
                     if (SH)
-                        sumDiffuseSH = sumDiffuseSH + wDiffuse * s_DiffSH[li];
+                        sumDiffuseSH = Mad(s_DiffSH[li], wDiffuse, sumDiffuseSH);
                 }
             }
 
@@ -319,11 +319,11 @@ __global__ __launch_bounds__(256, NRD_WAVES_RELAX_ATROUS_SMEM) void RelaxAtrousS
                     float specularW = normalW * depthW;
                     specularW *= Cmp(CompareMaterials(sampleMaterialID, centerMaterialID, c.shared.gSpecMinMaterial));
                     sumWSpecular += specularW;
-                    sumSpecularIllumination = sumSpecularIllumination + Xyz(sampleSpecular) * specularW;
+                    sumSpecularIllumination = Mad(Xyz(sampleSpecular), specularW, sumSpecularIllumination);
                     sumSpecular1stMoment += sample1stMoment * specularW;
                     sumSpecular2ndMoment += sampleSpecular.w * specularW;
                     if (SH)
-                        sumSpecularSH = sumSpecularSH + s_SpecSH[li] * specularW;
+                        sumSpecularSH = Mad(s_SpecSH[li], specularW, sumSpecularSH);
                 }
                 if (DIFF) {
                     float4 sampleDiffuse = s_Diff[li];
@@ -331,11 +331,11 @@ __global__ __launch_bounds__(256, NRD_WAVES_RELAX_ATROUS_SMEM) void RelaxAtrousS
                     float diffuseW = normalW * depthW;
                     diffuseW *= Cmp(CompareMaterials(sampleMaterialID, centerMaterialID, c.shared.gDiffMinMaterial));
                     sumWDiffuse += diffuseW;
-                    sumDiffuseIllumination = sumDiffuseIllumination + Xyz(sampleDiffuse) * diffuseW;
+                    sumDiffuseIllumination = Mad(Xyz(sampleDiffuse), diffuseW, sumDiffuseIllumination);
                     sumDiffuse1stMoment += sample1stMoment * diffuseW;
                     sumDiffuse2ndMoment += sampleDiffuse.w * diffuseW;
                     if (SH)
-                        sumDiffuseSH = sumDiffuseSH + s_DiffSH[li] * diffuseW;
+                        sumDiffuseSH = Mad(s_DiffSH[li], diffuseW, sumDiffuseSH);
                 }
             }
 
@@ -554,10 +554,10 @@ __global__ __launch_bounds__(256, NRD_WAVES_RELAX_ATROUS) void RelaxAtrousKernel
                 wSpecular = on ? wSpecular : 0.0f;
 
                 sumWSpecular += wSpecular;
-                sumSpecular = sumSpecular + F4(wSpecular, wSpecular, wSpecular, wSpecular * wSpecular) * sampleSpecular;
+                sumSpecular = Mad(sampleSpecular, F4(wSpecular, wSpecular, wSpecular, wSpecular * wSpecular), sumSpecular);
                 if (SH) {
                     const uint2 rawSh = *(const uint2*)(P.spec.inSh.ptr + signalOffset);
-                    sumSpecularSH = sumSpecularSH + DecodeRGBA16F(rawSh.x, rawSh.y) * wSpecular;
+                    sumSpecularSH = Mad(DecodeRGBA16F(rawSh.x, rawSh.y), wSpecular, sumSpecularSH);
                 }
             }
             if (DIFF) {
@@ -577,10 +577,10 @@ __global__ __launch_bounds__(256, NRD_WAVES_RELAX_ATROUS) void RelaxAtrousKernel
                 wDiffuse = on ? wDiffuse : 0.0f;
 
                 sumWDiffuse += wDiffuse;
-                sumDiffuse = sumDiffuse + F4(wDiffuse, wDiffuse, wDiffuse, wDiffuse * wDiffuse) * sampleDiffuse;
+                sumDiffuse = Mad(sampleDiffuse, F4(wDiffuse, wDiffuse, wDiffuse, wDiffuse * wDiffuse), sumDiffuse);
                 if (SH) {
                     const uint2 rawSh = *(const uint2*)(P.diff.inSh.ptr + signalOffset);
-                    sumDiffuseSH = sumDiffuseSH + DecodeRGBA16F(rawSh.x, rawSh.y) * wDiffuse;
+                    sumDiffuseSH = Mad(DecodeRGBA16F(rawSh.x, rawSh.y), wDiffuse, sumDiffuseSH);
                 }
             }
         }

@@ -329,10 +329,10 @@ __global__ __launch_bounds__(256, NRD_WAVES_RELAX_PREPASS) void RelaxPrePassKern
                 sampleWeight *= GetGaussianWeight(g_Poisson8[i][2]);
 
                 weightSum += sampleWeight;
-                diffuseIllumination = diffuseIllumination + sampleDiffuseIllumination * sampleWeight;
+                diffuseIllumination = Mad(sampleDiffuseIllumination, sampleWeight, diffuseIllumination);
                 if (SH) {
                     float4 sampleDiffuseSH = Denanify(sampleWeight, LoadRGBA16F(P.diff.inSh, t.signalTexel.x, t.signalTexel.y));
-                    diffuseSH = diffuseSH + sampleDiffuseSH * sampleWeight;
+                    diffuseSH = Mad(sampleDiffuseSH, sampleWeight, diffuseSH);
                 }
             }
             diffuseIllumination = Div(diffuseIllumination, weightSum);
@@ -419,10 +419,10 @@ __global__ __launch_bounds__(256, NRD_WAVES_RELAX_PREPASS) void RelaxPrePassKern
                 sampleWeight *= Lerp(Sat(tt), 1.0f, roughnessRelax);
 
                 weightSum += sampleWeight;
-                rgb = rgb + Xyz(sampleSpecularIllumination) * sampleWeight;
+                rgb = Mad(Xyz(sampleSpecularIllumination), sampleWeight, rgb);
                 if (SH) {
                     float4 sampleSpecularSH = Denanify(sampleWeight, LoadRGBA16F(P.spec.inSh, t.signalTexel.x, t.signalTexel.y));
-                    specularSH = specularSH + sampleSpecularSH * sampleWeight;
+                    specularSH = Mad(sampleSpecularSH, sampleWeight, specularSH);
                 }
                 if (sampleWeight != 0.0f)
                     minHitT = Min(minHitT, sampleSpecularIllumination.w == 0.0f ? NRD_INF : sampleSpecularIllumination.w);

@@ -540,7 +540,7 @@ __global__ __launch_bounds__(TILE_X* TILE_Y) void SigmaTemporalStabilizationKern
                 w = AreBothLitOrUnlit(centerPenumbra, penum);
                 w *= GetGaussianWeight(Length(Div(F2(float(i - BORDER), float(j - BORDER)), float(BORDER))));
             }
-            m1 = m1 + s * w;
+            m1 = Mad(s, w, m1);
             m2 = m2 + s * s * w;
             sumw += w;
         }

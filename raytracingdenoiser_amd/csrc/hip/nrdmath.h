@@ -148,6 +148,21 @@ NRD_D float4 operator*(float4 a, float b) { return F4(a.x * b, a.y * b, a.z * b,
 NRD_D float4 Div(float4 a, float b) { float r = Rcp(b); return F4(a.x * r, a.y * r, a.z * r, a.w * r); }
 NRD_D float4 Div(float4 a, float4 b) { return F4(Div(a.x, b.x), Div(a.y, b.y), Div(a.z, b.z), Div(a.w, b.w)); }
 NRD_D float4 operator-(float4 a, float b) { return F4(a.x - b, a.y - b, a.z - b, a.w - b); }
+// a * s + c with ONE rounding per component. The overloaded operators above cannot fuse (`c + a * s` rounds the product first: the contraction rule of
+// this build looks at expressions, not through function calls), so the accumulations of the tap loops spell the fused form out -- on both sides.
+NRD_D float Mad(float a, float s, float c) { return a * s + c; }
+NRD_D float2 Mad(float2 a, float s, float2 c) { return F2(a.x * s + c.x, a.y * s + c.y); }
+NRD_D float2 Mad(float2 a, float2 s, float2 c) { return F2(a.x * s.x + c.x, a.y * s.y + c.y); }
+NRD_D float3 Mad(float3 a, float s, float3 c) { return F3(a.x * s + c.x, a.y * s + c.y, a.z * s + c.z); }
+NRD_D float4 Mad(float4 a, float s, float4 c) { return F4(a.x * s + c.x, a.y * s + c.y, a.z * s + c.z, a.w * s + c.w); }
+// a * wa + b * wb (+ c * wc + d * wd): per component the very expression a scalar blend is written as, so vector and scalar blends fuse alike
+NRD_D float WSum(float a, float wa, float b, float wb) { return a * wa + b * wb; }
+NRD_D float4 WSum(float4 a, float wa, float4 b, float wb) { return F4(a.x * wa + b.x * wb, a.y * wa + b.y * wb, a.z * wa + b.z * wb, a.w * wa + b.w * wb); }
+NRD_D float WSum(float a, float wa, float b, float wb, float c, float wc, float d, float wd) { return a * wa + b * wb + c * wc + d * wd; }
+NRD_D float4 WSum(float4 a, float wa, float4 b, float wb, float4 c, float wc, float4 d, float wd) {
+    return F4(a.x * wa + b.x * wb + c.x * wc + d.x * wd, a.y * wa + b.y * wb + c.y * wc + d.y * wd, a.z * wa + b.z * wb + c.z * wc + d.z * wd, a.w * wa + b.w * wb + c.w * wc + d.w * wd);
+}
+NRD_D float4 Mad(float4 a, float4 s, float4 c) { return F4(a.x * s.x + c.x, a.y * s.y + c.y, a.z * s.z + c.z, a.w * s.w + c.w); }
 
 // component-wise select: `cond ? a : b` on two vector LVALUES is an lvalue conditional, which the compiler implements as a
 // select between the addresses of two stack copies (scratch memory traffic); selecting per component keeps it in registers

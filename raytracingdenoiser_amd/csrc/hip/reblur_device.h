@@ -261,6 +261,7 @@ NRD_D DirOcc MakeDirOcc(float4 v) {
 }
 NRD_D DirOcc operator+(DirOcc a, DirOcc b) { return MakeDirOcc(a.v + b.v); }
 NRD_D DirOcc operator*(DirOcc a, float b) { return MakeDirOcc(a.v * b); }
+NRD_D DirOcc Mad(DirOcc a, float s, DirOcc c) { return MakeDirOcc(Mad(a.v, s, c.v)); }
 NRD_D DirOcc Lerp(DirOcc a, DirOcc b, float t) { return MakeDirOcc(Lerp(a.v, b.v, t)); }
 NRD_D DirOcc Select(bool c, DirOcc a, DirOcc b) { return MakeDirOcc(Select(c, a.v, b.v)); }
 NRD_D float Select(bool c, float a, float b) { return c ? a : b; }
@@ -496,21 +497,21 @@ NRD_D V FetchHistoryGeneric(const HistoryFilter& h, const Plane& tex, LoadFn loa
     V color;
     if (h.useBicubic) {
         const float fx = h.tc.x, fy = h.tc.y, gx = 1.0f - fx, gy = 1.0f - fy;
-        V s0 = load(tex, h.x[1], h.y[0]) * gx + load(tex, h.x[2], h.y[0]) * fx;
-        V s1 = load(tex, h.x[0], h.y[1]) * gy + load(tex, h.x[0], h.y[2]) * fy;
-        V s2 = t00 * (gx * gy) + t10 * (fx * gy) + t01 * (gx * fy) + t11 * (fx * fy);
-        V s3 = load(tex, h.x[3], h.y[1]) * gy + load(tex, h.x[3], h.y[2]) * fy;
-        V s4 = load(tex, h.x[1], h.y[3]) * gx + load(tex, h.x[2], h.y[3]) * fx;
+        V s0 = WSum(load(tex, h.x[1], h.y[0]), gx, load(tex, h.x[2], h.y[0]), fx);
+        V s1 = WSum(load(tex, h.x[0], h.y[1]), gy, load(tex, h.x[0], h.y[2]), fy);
+        V s2 = WSum(t00, gx * gy, t10, fx * gy, t01, gx * fy, t11, fx * fy);
+        V s3 = WSum(load(tex, h.x[3], h.y[1]), gy, load(tex, h.x[3], h.y[2]), fy);
+        V s4 = WSum(load(tex, h.x[1], h.y[3]), gx, load(tex, h.x[2], h.y[3]), fx);
         color = s0 * h.w.x;
-        color = color + s1 * h.w.y;
-        color = color + s2 * h.w.z;
-        color = color + s3 * h.w.w;
-        color = color + s4 * h.w4;
+        color = Mad(s1, h.w.y, color);
+        color = Mad(s2, h.w.z, color);
+        color = Mad(s3, h.w.w, color);
+        color = Mad(s4, h.w4, color);
     } else {
         color = t00 * h.w.x;
-        color = color + t10 * h.w.y;
-        color = color + t01 * h.w.z;
-        color = color + t11 * h.w.w;
+        color = Mad(t10, h.w.y, color);
+        color = Mad(t01, h.w.z, color);
+        color = Mad(t11, h.w.w, color);
     }
     return h.sum < 0.0001f ? zero : Div(color, h.sum);
 }
@@ -567,21 +568,21 @@ NRD_D float4 FetchHistoryRGBA16F(const HistoryFilter& h, const Plane& tex, const
         const float4 c0 = DecodeRGBA16F(t.c0.x, t.c0.y), c3 = DecodeRGBA16F(t.c1.z, t.c1.w);
         const float4 d0 = DecodeRGBA16F(t.d.x, t.d.y), d1 = DecodeRGBA16F(t.d.z, t.d.w);
         const float fx = h.tc.x, fy = h.tc.y, gx = 1.0f - fx, gy = 1.0f - fy;
-        float4 s0 = a0 * gx + a1 * fx;
-        float4 s1 = b0 * gy + c0 * fy;
-        float4 s2 = b1 * (gx * gy) + b2 * (fx * gy) + c1 * (gx * fy) + c2 * (fx * fy);
-        float4 s3 = b3 * gy + c3 * fy;
-        float4 s4 = d0 * gx + d1 * fx;
+        float4 s0 = WSum(a0, gx, a1, fx);
+        float4 s1 = WSum(b0, gy, c0, fy);
+        float4 s2 = WSum(b1, gx * gy, b2, fx * gy, c1, gx * fy, c2, fx * fy);
+        float4 s3 = WSum(b3, gy, c3, fy);
+        float4 s4 = WSum(d0, gx, d1, fx);
         color = s0 * h.w.x;
-        color = color + s1 * h.w.y;
-        color = color + s2 * h.w.z;
-        color = color + s3 * h.w.w;
-        color = color + s4 * h.w4;
+        color = Mad(s1, h.w.y, color);
+        color = Mad(s2, h.w.z, color);
+        color = Mad(s3, h.w.w, color);
+        color = Mad(s4, h.w4, color);
     } else { // the custom-weight bilinear fallback blends the central 2x2 (FetchHistoryGeneric, same order)
         color = b1 * h.w.x;
-        color = color + b2 * h.w.y;
-        color = color + c1 * h.w.z;
-        color = color + c2 * h.w.w;
+        color = Mad(b2, h.w.y, color);
+        color = Mad(c1, h.w.z, color);
+        color = Mad(c2, h.w.w, color);
     }
     return h.sum < 0.0001f ? F4(0.0f) : Div(color, h.sum);
 }
@@ -623,9 +624,9 @@ NRD_D float FetchHistoryR16F(const HistoryFilter& h, const Plane& tex) {
 NRD_D float4 FetchHistoryBilinearRGBA16F(const HistoryFilter& h, const Plane& tex) {
     auto at = [&](int x, int y) { return InBounds(tex, x, y) ? LoadRGBA16F(tex, x, y) : F4(0.0f); };
     float4 color = at(h.ox, h.oy) * h.bw.x;
-    color = color + at(h.ox + 1, h.oy) * h.bw.y;
-    color = color + at(h.ox, h.oy + 1) * h.bw.z;
-    color = color + at(h.ox + 1, h.oy + 1) * h.bw.w;
+    color = Mad(at(h.ox + 1, h.oy), h.bw.y, color);
+    color = Mad(at(h.ox, h.oy + 1), h.bw.z, color);
+    color = Mad(at(h.ox + 1, h.oy + 1), h.bw.w, color);
     float s = Sum(h.bw);
     return s < 0.0001f ? F4(0.0f) : Div(color, s);
 }

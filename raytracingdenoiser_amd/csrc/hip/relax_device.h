@@ -113,9 +113,9 @@ NRD_D float4 BilinearWithCustomWeightsRGBA16F(const Plane& tex, int ox, int oy, 
         s00 = LoadRGBA16FOrZero(tex, ox, oy), s10 = LoadRGBA16FOrZero(tex, ox + 1, oy), s01 = LoadRGBA16FOrZero(tex, ox, oy + 1), s11 = LoadRGBA16FOrZero(tex, ox + 1, oy + 1);
     }
     float4 o = s00 * w.x;
-    o = o + s10 * w.y;
-    o = o + s01 * w.z;
-    o = o + s11 * w.w;
+    o = Mad(s10, w.y, o);
+    o = Mad(s01, w.z, o);
+    o = Mad(s11, w.w, o);
     float sumWeights = Sum(w);
     return sumWeights < 0.0001f ? F4(0.0f) : o * Rcp(sumWeights);
 }
