@@ -336,7 +336,7 @@ inline float3 GetXvirtual(float hitDist, float curvature, float3 X, float3 Xprev
 // :465-482
 inline float2 GetKernelSampleCoordinates(const float4x4& mToClip, float3 offset, float3 X, float3 T, float3 B, float4 rotator) {
     float2 o = Geometry::RotateVector(rotator, float2(offset.x, offset.y));
-    float3 p = X + T * o.x + B * o.y;
+    float3 p = Mad(B, o.y, Mad(T, o.x, X));
     float4 clip4 = Geometry::ProjectiveTransform(mToClip, p);
     float3 clip = float3(clip4.x, clip4.y, clip4.w);
     clip.x = Div(clip.x, clip.z);

@@ -59,6 +59,11 @@ struct SpatialCtx { // what PrePass / Blur / PostBlur share per pixel
     float3 N, Nv, Xv, Vv;
     float4 rotator;
     float2 data1; // accumulated frames (diff, spec); unused by the pre-pass
+    // Plane distance of a tap: the shaders evaluate dot(Nv, Xv(tap)) with Xv = ReconstructViewPosition(uv, frustum, z) (REBLUR_Common_*SpatialFilter.hlsli
+    // "ComputeWeight( dot( Nv, Xvs ), ... )"). Every tap position is a pixel centre, uv = (k + 0.5) * rectSizeInv with integer k, and the perspective
+    // Xv is linear in uv, so the product is expanded once per PIXEL: dot(Nv, Xv((k + 0.5) * rectSizeInv, z)) = z * (k.x * geo.x + k.y * geo.y + geo.z).
+    // This expanded form is the specification of both sides (3 operations per tap instead of 13); orthographic projection is rejected up front.
+    float3 geo;
     bool perf;    // REBLUR_PERFORMANCE_MODE (REBLUR_Config.hlsli:196-238): 6 taps of g_Special6, screen-space sampling for specular too
     // checkerboard resolve of the pre-pass (REBLUR_PrePass.hlsli:43-56): left / right neighbour columns in the half-width input and their weights
     int cbX0 = 0, cbX1 = 0;
@@ -137,6 +142,7 @@ S DiffuseSpatialFilterTaps(const ReblurCB& c, SpatialMode mode, const SpatialCtx
         uv = floor(uv * c.gRectSize) + 0.5f; // snap to the pixel centre
         if (mode == PRE_BLUR)
             uv = ApplyCheckerboardShift(uv, c.gDiffCheckerboard, (uint32_t)n, c.gFrameIndex);
+        const float2 k = uv - 0.5f; // the tap's pixel (exact: a pixel centre minus one half)
         uv *= c.gRectSizeInv;
         float2 uvScaled = min(uv * c.gResolutionScale, c.gResolutionScale - 0.5f * c.gResourceSizeInv); // ClampUvToViewport
         float2 checkerboardUvScaled = uvScaled; // checkerboarded inputs live in the left half of the plane
@@ -148,10 +154,9 @@ S DiffuseSpatialFilterTaps(const ReblurCB& c, SpatialMode mode, const SpatialCtx
         float4 Ns = NRD_FrontEnd_UnpackNormalAndRoughness(gIn_Normal_Roughness.SampleNearest(uvScaled), materialIDs);
 
         float angle = Math::AcosApprox(dot(s.N, Ns.xyz()));
-        float3 Xvs = Geometry::ReconstructViewPosition(uv, c.gFrustum, zs, c.gOrthoMode);
 
         float w = IsInScreenNearest(uv);
-        w *= ComputeWeight(dot(s.Nv, Xvs), geometryWeightParams.x, geometryWeightParams.y);
+        w *= ComputeWeight(zs * (k.x * s.geo.x + (k.y * s.geo.y + s.geo.z)), geometryWeightParams.x, geometryWeightParams.y); // dot( Nv, Xvs ), expanded (SpatialCtx::geo)
         w *= CompareMaterials(s.materialID, materialIDs, c.gDiffMinMaterial) ? 1.0f : 0.0f;
         w *= ComputeWeight(angle, normalWeightParam, 0.0f);
 
@@ -296,6 +301,7 @@ S SpecularSpatialFilterTaps(const ReblurCB& c, SpatialMode mode, const SpatialCt
         uv = floor(uv * c.gRectSize) + 0.5f;
         if (mode == PRE_BLUR)
             uv = ApplyCheckerboardShift(uv, c.gSpecCheckerboard, (uint32_t)n, c.gFrameIndex);
+        const float2 k = uv - 0.5f; // the tap's pixel (exact: a pixel centre minus one half)
         uv *= c.gRectSizeInv;
         float2 uvScaled = min(uv * c.gResolutionScale, c.gResolutionScale - 0.5f * c.gResourceSizeInv);
         float2 checkerboardUvScaled = uvScaled;
@@ -310,7 +316,7 @@ S SpecularSpatialFilterTaps(const ReblurCB& c, SpatialMode mode, const SpatialCt
         float3 Xvs = Geometry::ReconstructViewPosition(uv, c.gFrustum, zs, c.gOrthoMode);
 
         float w = IsInScreenNearest(uv);
-        w *= ComputeWeight(dot(s.Nv, Xvs), geometryWeightParams.x, geometryWeightParams.y);
+        w *= ComputeWeight(zs * (k.x * s.geo.x + (k.y * s.geo.y + s.geo.z)), geometryWeightParams.x, geometryWeightParams.y); // dot( Nv, Xvs ), expanded (SpatialCtx::geo)
         w *= CompareMaterials(s.materialID, materialIDs, c.gSpecMinMaterial) ? 1.0f : 0.0f;
         w *= ComputeWeight(angle, normalWeightParam, 0.0f);
         w *= ComputeWeight(Ns.w, roughnessWeightParams.x, roughnessWeightParams.y);
@@ -401,6 +407,11 @@ bool MakeSpatialCtx(const ReblurCB& c, int px, int py, const Tex& gIn_Tiles, con
     s.frustumSize = GetFrustumSize(c.gMinRectDimMulUnproject, c.gOrthoMode, s.viewZ);
     s.rotator = rotator; // NRD_FRAME rotator mode: the per-frame base rotator, no per-pixel component
     s.data1 = float2(0.0f);
+    {
+        const float4 f = c.gFrustum;
+        const float2 r = c.gRectSizeInv;
+        s.geo = float3(s.Nv.x * f.z * r.x, s.Nv.y * f.w * r.y, s.Nv.x * (0.5f * r.x * f.z + f.x) + s.Nv.y * (0.5f * r.y * f.w + f.y) + s.Nv.z);
+    }
     return true;
 }
 

@@ -67,6 +67,9 @@ struct SpatialCtx {
     float3 N, Nv, Xv, Vv;
     float4 rotator;
     float2 data1;
+    // plane distance of a tap, expanded once per pixel: every tap position is a pixel centre uv = (k + 0.5) * rectSizeInv and the perspective view position is
+    // linear in uv, so dot(Nv, Xv(uv, z)) = z * (k.x * geo.x + k.y * geo.y + geo.z) -- 3 operations per tap instead of 13. The oracle states the same form.
+    float3 geo;
     // checkerboard resolve of the pre-pass (reference REBLUR_PrePass.hlsli:43-56): neighbour columns in the half-width input + their weights
     int cbX0, cbX1;
     float2 wc;
@@ -117,7 +120,7 @@ NRD_D TapGuides FetchTapGuidesFullRect(const ReblurCB& c, const SpatialCtx& s, f
     }
     const float2 uvc = (k + 0.5f) * rectSizeInv; // centre of the snapped pixel; equals the clamped texel's centre whenever the tap counts (t.w != 0)
     t.Xvs = ReconstructViewPosition(uvc, ToF4(c.gFrustum), t.zs, 0.0f); // perspective only (CheckSupported); dead code unless the caller needs the position
-    t.NvXvs = Dot(s.Nv, t.Xvs);
+    t.NvXvs = t.zs * (k.x * s.geo.x + (k.y * s.geo.y + s.geo.z));
     t.materialIDs = 0.0f;
     if (materials)
         t.materialIDs = NRD_DIV_3(float(bits >> 10)) * 3.0f;
@@ -137,6 +140,7 @@ NRD_D TapGuides FetchTapGuides(const ReblurCB& c, const SpatialCtx& s, float2 uv
     uv = uv + 0.5f;
     if (MODE == PRE_BLUR && CB)
         uv = ApplyCheckerboardShift(uv, checkerboardMode, n, c.gFrameIndex);
+    const float2 k = uv - 0.5f; // the tap's pixel (exact)
     uv = uv * rectSizeInv;
     const float2 resolutionScale = ToF2(c.gResolutionScale);
     const float2 uvMax = resolutionScale - ToF2(c.gResourceSizeInv) * 0.5f;
@@ -151,7 +155,7 @@ NRD_D TapGuides FetchTapGuides(const ReblurCB& c, const SpatialCtx& s, float2 uv
     t.Ns = Xyz(Ns);
     t.roughnessS = Ns.w;
     t.Xvs = ReconstructViewPosition(uv, ToF4(c.gFrustum), t.zs, NRD_ORTHO_MODE(c));
-    t.NvXvs = Dot(s.Nv, t.Xvs);
+    t.NvXvs = t.zs * (k.x * s.geo.x + (k.y * s.geo.y + s.geo.z));
     t.w = IsInScreenNearest(uv);
     t.uv = uv;
     return t;
@@ -466,6 +470,11 @@ NRD_D bool MakeSpatialCtx(const ReblurCB& c, int px, int py, float viewZ, const 
     s.frustumSize = GetFrustumSize(c.gMinRectDimMulUnproject, NRD_ORTHO_MODE(c), viewZ);
     s.rotator = rotator;
     s.data1 = F2(0.0f, 0.0f);
+    {
+        const float4 f = ToF4(c.gFrustum);
+        const float2 r = ToF2(c.gRectSizeInv);
+        s.geo = F3(s.Nv.x * f.z * r.x, s.Nv.y * f.w * r.y, s.Nv.x * (0.5f * r.x * f.z + f.x) + s.Nv.y * (0.5f * r.y * f.w + f.y) + s.Nv.z);
+    }
     return true;
 }
 

@@ -16,7 +16,7 @@
 #define NRD_WAVES_REBLUR_SPATIAL 0
 #endif
 #ifndef NRD_WAVES_REBLUR_HF
-#define NRD_WAVES_REBLUR_HF 0
+#define NRD_WAVES_REBLUR_HF 5 // 111 -> 84 VGPRs without scratch (6 would need 12 B of scratch)
 #endif
 #ifndef NRD_WAVES_REBLUR_TS
 #define NRD_WAVES_REBLUR_TS 0

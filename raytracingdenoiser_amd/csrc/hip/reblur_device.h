@@ -154,7 +154,7 @@ NRD_D float3 GetXvirtual(float hitDist, float curvature, float3 X, float3 Xprev,
 }
 NRD_D float2 GetKernelSampleCoordinates(const float* mToClip, float3 offset, float3 X, float3 T, float3 B, float4 rotator) {
     float2 o = RotateVector(rotator, F2(offset.x, offset.y));
-    float3 p = X + T * o.x + B * o.y;
+    float3 p = Mad(B, o.y, Mad(T, o.x, X));
     float4 clip4 = ProjectiveTransform(mToClip, p);
     float3 clip = F3(clip4.x, clip4.y, clip4.w);
     clip.x = Div(clip.x, clip.z);
