@@ -63,16 +63,12 @@ inline float exp2(float x) {
     return ldexpf(hwmath::HwExp2OnOneTwo(t), (int)fl - 1);
 }
 
-// log2(x) = e + v_log_f32(m), x = m * 2^e, m in [1, 2); x <= 0 and NaN return -126
+// log2(x) = e + v_log_f32(m), x = m * 2^e, m in [1, 2); zero, denormals, negative numbers and NaN return -126 (= log2 of the smallest normal); +inf 128
 inline float log2(float x) {
-    if (!(x > 0.0f))
+    if (!(x >= 1.17549435e-38f))
         return -126.0f;
-    uint32_t bits = asuint(x);
-    int e = (int)(bits >> 23) - 127;
-    if (e == -127) {
-        bits = asuint(x * 8388608.0f);
-        e = (int)(bits >> 23) - 127 - 23;
-    }
+    const uint32_t bits = asuint(x);
+    const int e = (int)(bits >> 23) - 127;
     const float m = asfloat((bits & 0x007FFFFFu) | 0x3F800000u);
     return float(e) + hwmath::HwLog2OnMantissa(m);
 }

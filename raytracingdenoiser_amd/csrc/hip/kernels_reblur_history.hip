@@ -192,8 +192,8 @@ NRD_D typename ReblurSignal<KIND>::type HistoryFixSignal(const ReblurCB& c, cons
         luma = Clamp(luma, am1 - sigma, am1 + sigma);
     }
 
-    m1 = Div(m1, 25.0f);
-    m2 = Div(m2, 25.0f);
+    m1 = m1 * (1.0f / 25.0f);
+    m2 = m2 * (1.0f / 25.0f);
     float sigma = Sqrt(Abs(m2 - m1 * m1)) * (KIND != SIGNAL_RADIANCE ? REBLUR_COLOR_CLAMPING_SIGMA_SCALE_OCCLUSION : REBLUR_COLOR_CLAMPING_SIGMA_SCALE);
     float lumaClamped = Clamp(luma, m1 - sigma, m1 + sigma);
     luma = Lerp(lumaClamped, luma, Rcp(1.0f + (c.gMaxFastAccumulatedFrameNum < c.gMaxAccumulatedFrameNum ? 1.0f : 0.0f) * frameNum * 2.0f));
@@ -340,8 +340,8 @@ NRD_D void LumaStats(const ReblurCB& c, const float* s_Luma, int tx, int ty, flo
             mx = Max(mx, d);
         }
     }
-    M1 = Div(M1, 9.0f);
-    M2 = Div(M2, 9.0f);
+    M1 = M1 * (1.0f / 9.0f);
+    M2 = M2 * (1.0f / 9.0f);
     m1 = M1;
     sigma = Sqrt(Abs(M2 - M1 * M1));
     if (!PERF && c.gMaxBlurRadius != 0.0f)

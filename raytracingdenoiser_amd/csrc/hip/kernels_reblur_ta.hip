@@ -147,8 +147,8 @@ __global__ __launch_bounds__(TILE_X* TILE_Y, WAVES) void ReblurTemporalAccumulat
     RngHash rng;
     if (SPEC) {
         roughnessModified = GetModifiedRoughnessFromNormalVariance(roughness, Navg);
-        roughnessM1 = Div(roughnessM1, 9.0f);
-        roughnessM2 = Div(roughnessM2, 9.0f);
+        roughnessM1 = roughnessM1 * (1.0f / 9.0f);
+        roughnessM2 = roughnessM2 * (1.0f / 9.0f);
         roughnessSigma = Sqrt(Abs(roughnessM2 - roughnessM1 * roughnessM1));
 
         rng.Initialize((uint32_t)px, (uint32_t)py, c.gFrameIndex);
@@ -292,7 +292,7 @@ __global__ __launch_bounds__(TILE_X* TILE_Y, WAVES) void ReblurTemporalAccumulat
 
     float3 V = GetViewVector(c, X);
     float NoV = Abs(Dot(N, V));
-    float NoVstrict = Lerp(NoV, 1.0f, Sat(Div(smbParallaxInPixelsMax, 30.0f)));
+    float NoVstrict = Lerp(NoV, 1.0f, Sat(smbParallaxInPixelsMax * (1.0f / 30.0f)));
     float4 smbDisocclusionThreshold = F4(GetDisocclusionThreshold(disocclusionThreshold, frustumSize, NoVstrict));
     smbDisocclusionThreshold = smbDisocclusionThreshold * (Dot(smbNavg, Navg) > REBLUR_ALMOST_ZERO_ANGLE - 0.25f * smallParallax ? 1.0f : 0.0f);
     smbDisocclusionThreshold = smbDisocclusionThreshold * IsInScreenBilinear(smbBilinearFilter.origin, rectSizePrev);

@@ -132,7 +132,7 @@ __global__ __launch_bounds__(256, NRD_WAVES_RELAX_ATROUS_SMEM) void RelaxAtrousS
     const float centerMaterialID = centerWorldPosMaterialID.w;
     if (InBounds(P.outNormalRoughness, px, py)) {
         StoreRGBA8Unorm(P.outNormalRoughness, px, py, PackPrevNormalRoughness(normalRoughness));
-        StoreR8Unorm(P.outMaterialID, px, py, Div(centerMaterialID, 255.0f));
+        StoreR8Unorm(P.outMaterialID, px, py, centerMaterialID * (1.0f / 255.0f));
     }
 
     if (tileIsSky || px >= rectW || py >= rectH)
@@ -419,7 +419,7 @@ __global__ __launch_bounds__(256, NRD_WAVES_RELAX_ATROUS) void RelaxAtrousKernel
     float diffuseLobeAngleFraction = Div(c.shared.gLobeAngleFraction, Sqrt(float(c.gStepSize)));
     if (SH)
         diffuseLobeAngleFraction = Rcp(Sqrt(float(c.gStepSize)));
-    diffuseLobeAngleFraction = Lerp(0.99f, diffuseLobeAngleFraction, Sat(Div(historyLength, 5.0f)));
+    diffuseLobeAngleFraction = Lerp(0.99f, diffuseLobeAngleFraction, Sat(historyLength * (1.0f / 5.0f)));
 
     SpecParams sp = {};
     sp.luminanceWeightRelaxation = 1.0f;

@@ -145,7 +145,7 @@ __global__ __launch_bounds__(256, NRD_WAVES_RELAX_TA) void RelaxTemporalAccumula
             minHitDist3x3 = Min(minHitDist3x3, normalSpecHitT.w == 0.0f ? NRD_INF : normalSpecHitT.w);
             currentNormalAveraged = currentNormalAveraged + Xyz(normalSpecHitT);
         }
-    currentNormalAveraged = Div(currentNormalAveraged, 9.0f);
+    currentNormalAveraged = currentNormalAveraged * (1.0f / 9.0f);
 
     const float currentRoughnessModified = SPEC ? GetModifiedRoughnessFromNormalVariance(currentRoughness, currentNormalAveraged) : 0.0f;
 
@@ -187,7 +187,7 @@ __global__ __launch_bounds__(256, NRD_WAVES_RELAX_TA) void RelaxTemporalAccumula
         const float2 bilinearWeights = F2(Frac(prevPixelPosFloat.x - 0.5f), Frac(prevPixelPosFloat.y - 0.5f));
 
         const float frustumSize = pixelSize * float(rectW < rectH ? rectW : rectH);
-        const float disocclusionThresholdSlopeScale = Rcp(Lerp(Lerp(0.05f, 1.0f, NoV), 1.0f, Sat(Div(smbParallaxInPixelsMax, 30.0f))));
+        const float disocclusionThresholdSlopeScale = Rcp(Lerp(Lerp(0.05f, 1.0f, NoV), 1.0f, Sat(smbParallaxInPixelsMax * (1.0f / 30.0f))));
         float4 smbDisocclusionThreshold = F4(Sat(disocclusionThreshold * disocclusionThresholdSlopeScale) * frustumSize);
         smbDisocclusionThreshold = smbDisocclusionThreshold * IsInScreenBilinear(originF, rectSizePrev);
         smbDisocclusionThreshold = smbDisocclusionThreshold - NRD_EPS;
@@ -325,7 +325,7 @@ __global__ __launch_bounds__(256, NRD_WAVES_RELAX_TA) void RelaxTemporalAccumula
         }
     }
 
-    StoreR8Unorm(P.outHistoryLength, px, py, Div(historyLength, 255.0f));
+    StoreR8Unorm(P.outHistoryLength, px, py, historyLength * (1.0f / 255.0f));
 
     if (SPEC) {
         float specMaxAccumulatedFrameNum = c.shared.gSpecMaxAccumulatedFrameNum;
@@ -493,7 +493,7 @@ __global__ __launch_bounds__(256, NRD_WAVES_RELAX_TA) void RelaxTemporalAccumula
         // look back 1 and 2 frames
         uvDiff = uvDiff * Rsqrt(LengthSquared(uvDiff));
         uvDiff = Div(uvDiff, rectSizePrev);
-        uvDiff = uvDiff * (Sat(Div(uvDiffLengthInPixels, 0.1f)) + uvDiffLengthInPixels * 0.5f);
+        uvDiff = uvDiff * (Sat(uvDiffLengthInPixels * (1.0f / 0.1f)) + uvDiffLengthInPixels * 0.5f);
         const float2 backUV1 = prevUVVMB + uvDiff * 1.0f;
         const float2 backUV2 = prevUVVMB + uvDiff * 2.0f;
         const float2 prevNrSize = F2(float(P.prevNormalRoughness.w), float(P.prevNormalRoughness.h));
@@ -835,7 +835,7 @@ __global__ __launch_bounds__(256, NRD_WAVES_RELAX_HC) void RelaxHistoryClampingK
         ResolveSignal<true, SH>(c, P.spec, s_SpecFast, s_SpecNoisy, px, py, lx, ly, historyLength);
     if (DIFF)
         ResolveSignal<false, SH>(c, P.diff, s_DiffFast, s_DiffNoisy, px, py, lx, ly, historyLength);
-    StoreR8Unorm(P.outHistoryLength, px, py, Div(historyLength, 255.0f));
+    StoreR8Unorm(P.outHistoryLength, px, py, historyLength * (1.0f / 255.0f));
 }
 
 template <bool DIFF, bool SPEC, bool SH>

@@ -76,18 +76,14 @@ NRD_D float Exp2(float x) {
     const float t = 1.0f + (x - fl);
     return ldexpf(__builtin_amdgcn_exp2f(t), (int)fl - 1);
 }
-// log2(x) = e + v_log_f32(m), x = m * 2^e with m in [1, 2) (one fp32 addition; x <= 0 and NaN return -126)
+// log2(x) = e + v_log_f32(m), x = m * 2^e with m in [1, 2) (one fp32 addition). Anything that is not a positive normal number -- zero, denormals, negative
+// numbers, NaN -- returns -126 = log2 of the smallest normal (straight-line code: the result is selected, not branched to; +inf returns 128)
 NRD_D float Log2(float x) {
-    if (!(x > 0.0f))
-        return -126.0f;
-    uint32_t bits = AsUint(x);
-    int e = (int)(bits >> 23) - 127;
-    if (e == -127) { // denormal input: renormalise
-        bits = AsUint(x * 8388608.0f);
-        e = (int)(bits >> 23) - 127 - 23;
-    }
+    const uint32_t bits = AsUint(x);
+    const int e = (int)(bits >> 23) - 127;
     const float m = AsFloat((bits & 0x007FFFFFu) | 0x3F800000u);
-    return float(e) + __builtin_amdgcn_logf(m);
+    const float r = float(e) + __builtin_amdgcn_logf(m);
+    return x >= 1.17549435e-38f ? r : -126.0f;
 }
 
 NRD_D float Exp(float x) { return Exp2(x * 1.44269504f); }

@@ -215,8 +215,8 @@ NRD_D float GetMinAllowedLimitForHitDistNonLinearAccumSpeed(const ReblurCB& c, f
     return Rcp(1.0f + frameNum);
 }
 NRD_D float GetFadeBasedOnAccumulatedFrames(const ReblurCB& c, float accumSpeed) {
-    float a = Div(c.gHistoryFixFrameNum * 2.0f, 3.0f) + 1e-6f;
-    float b = Div(c.gHistoryFixFrameNum * 4.0f, 3.0f) + 2e-6f;
+    float a = c.gHistoryFixFrameNum * 2.0f * (1.0f / 3.0f) + 1e-6f;
+    float b = c.gHistoryFixFrameNum * 4.0f * (1.0f / 3.0f) + 2e-6f;
     return LinearStep(a, b, accumSpeed);
 }
 template <typename CB> // reference REBLUR_Common.hlsli:111-124; hasData = false for the empty pixels of a checkerboarded input

@@ -151,7 +151,7 @@ NRD_D float GetSpecLobeTanHalfAngleOld(float roughness, float percentOfVolume = 
 }
 NRD_D float2 GetNormalWeightParams_ATrous(float roughness, float numFramesInHistory, float specularReprojectionConfidence, float normalEdgeStoppingRelaxation,
     float specularLobeAngleFraction, float specularLobeAngleSlack) {
-    float relaxation = Sat(Div(numFramesInHistory, 5.0f));
+    float relaxation = Sat(numFramesInHistory * (1.0f / 5.0f));
     relaxation *= Lerp(1.0f, specularReprojectionConfidence, normalEdgeStoppingRelaxation);
     float f = 0.9f + 0.1f * relaxation;
     float angle = Atan(GetSpecLobeTanHalfAngleOld(roughness, specularLobeAngleFraction));
