@@ -730,6 +730,8 @@ static uint32_t LaunchAsGraph(NrdHipExecutor* e, std::vector<LaunchRecord>& reco
             for (size_t i = 1; i < e->graphs.size(); i++)
                 if (e->graphs[i].lastUse < e->graphs[lru].lastUse)
                     lru = i;
+            // its last launch may still be in flight on the stream: wait before the executable graph goes away (evictions are rare -- 32 topologies)
+            (void)hipStreamSynchronize(e->stream);
             (void)hipGraphExecDestroy(e->graphs[lru].exec);
             (void)hipGraphDestroy(e->graphs[lru].graph);
             e->graphs.erase(e->graphs.begin() + (long)lru);
@@ -885,10 +887,11 @@ static uint32_t ExecuteRange(NrdHipExecutor* e, const nrd::DispatchDesc* descs, 
             reblurConstants = nullptr;
         }
     }
-    // World-position guide plane of the RELAX lists (same geometry): IN_VIEWZ and the frame's RELAX constants
+    // World-position guide plane of the RELAX lists (same geometry): IN_VIEWZ and the frame's RELAX constants. Independent of the REBLUR plane: one
+    // dispatch list may hold both families (e.g. REBLUR_DIFFUSE + RELAX_SPECULAR in one instance), and then both guide planes are written
     Plane worldPos = {};
     const void* relaxConstants = nullptr;
-    if (decoded.ptr && !viewPos.ptr) {
+    if (decoded.ptr) {
         for (uint32_t i = 0; i < dispatchDescsNum && !relaxConstants; i++)
             if (descs[i].pipelineIndex < idesc.pipelinesNum && !strncmp(idesc.pipelines[descs[i].pipelineIndex].shaderFileName, "RELAX_", 6) && descs[i].constantBufferData &&
                 descs[i].constantBufferDataSize >= sizeof(nrdc::RelaxConstants))
@@ -931,11 +934,12 @@ static uint32_t ExecuteRange(NrdHipExecutor* e, const nrd::DispatchDesc* descs, 
         PassArgs args = {};
         args.stream = e->stream;
         args.recorder = rec;
+        // each decode kernel writes the decoded normals too (identical values): with both families in the list both run
         if (worldPos.ptr)
             LaunchDecodeGuidesRelax(args, guidePlane(nrd::ResourceType::IN_NORMAL_ROUGHNESS), guidePlane(nrd::ResourceType::IN_VIEWZ), decoded, worldPos, relaxConstants);
-        else if (viewPos.ptr)
+        if (viewPos.ptr)
             LaunchDecodeGuides(args, guidePlane(nrd::ResourceType::IN_NORMAL_ROUGHNESS), guidePlane(nrd::ResourceType::IN_VIEWZ), decoded, viewPos, reblurConstants);
-        else
+        if (!worldPos.ptr && !viewPos.ptr)
             LaunchDecodeNormalRoughness(args, guidePlane(nrd::ResourceType::IN_NORMAL_ROUGHNESS), decoded);
     };
     // a pass of the list rewrites IN_MV (REBLUR specular MV modification): the twin goes back into the user's plane behind the last pass

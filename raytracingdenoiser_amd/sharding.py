@@ -283,38 +283,52 @@ def balanced_bounds(tile_row_cost, height, world, min_rows, tile=16):
     return [min(c * tile, height) for c in cuts[:-1]] + [height]
 
 
+_motion_cache = {}
+
+
 def camera_motion_rows(cs, depth_range=(1.0, 1.0e4), grid=5):
-    """Upper estimate of the vertical reprojection distance (in rows) of STATIC surface points between the previous and the current camera of a
+    """Estimate of the vertical reprojection distance (in rows) of STATIC surface points between the previous and the current camera of a
     CommonSettings: a grid of screen positions x the two ends of a view-depth range is un-projected with the current matrices and re-projected with the
     previous ones (rotation moves all depths alike, translation moves the nearest depth most: depth_range[0] must not exceed the view depth of the
-    nearest geometry, an application-level fact -- HaloSharder(near_depth=...)). Returns None for an orthographic projection.
-    Object motion (screen-space motion vectors) is not covered: the application passes its own bound to HaloSharder.denoise(motion_rows=...)."""
+    nearest geometry, an application-level fact -- HaloSharder(near_depth=...)). A heuristic on a 5 x 5 sample, not a proven upper bound: the caller
+    doubles it and adds a margin. Returns None for an orthographic projection, infinity when no bound can be given (a singular view matrix, points
+    behind the previous camera). One matrix product for all samples; the result is cached on the matrix bytes (a static camera costs a dict lookup)."""
     import numpy as np
+
+    raw = bytes(cs.viewToClipMatrix) + bytes(cs.viewToClipMatrixPrev) + bytes(cs.worldToViewMatrix) + bytes(cs.worldToViewMatrixPrev)
+    key = (raw, float(cs.rectSize[1]), tuple(depth_range), grid)
+    hit = _motion_cache.get(key)
+    if hit is not None:
+        return hit[0]
 
     def mat(m):
         return np.array(list(m), dtype=np.float64).reshape(4, 4).T  # column-major in, M @ v out
 
+    def remember(value):
+        if len(_motion_cache) > 64:
+            _motion_cache.clear()
+        _motion_cache[key] = (value,)
+        return value
+
     P, Pp, V, Vp = mat(cs.viewToClipMatrix), mat(cs.viewToClipMatrixPrev), mat(cs.worldToViewMatrix), mat(cs.worldToViewMatrixPrev)
     if abs(P[3, 2]) < 1e-12 or abs(P[0, 0]) < 1e-12 or abs(P[1, 1]) < 1e-12:
-        return None
+        return remember(None)
+    try:
+        Vinv = np.linalg.inv(V)
+    except np.linalg.LinAlgError:
+        return remember(float("inf"))  # singular / unset view matrix: treated as exceeding any halo
+    if not np.all(np.isfinite(Vinv)):
+        return remember(float("inf"))
     sign = 1.0 if P[3, 2] > 0 else -1.0  # clip.w = +z (left-handed) or -z (right-handed)
     h = float(cs.rectSize[1])
-    Vinv = np.linalg.inv(V)
-    worst = 0.0
-    for z in depth_range:
-        zv = sign * z
-        for j in range(grid):
-            for i in range(grid):
-                nx, ny = -1.0 + 2.0 * i / (grid - 1), -1.0 + 2.0 * j / (grid - 1)
-                w = P[3, 2] * zv + P[3, 3]
-                xv = (nx * w - P[0, 2] * zv - P[0, 3]) / P[0, 0]
-                yv = (ny * w - P[1, 2] * zv - P[1, 3]) / P[1, 1]
-                world = Vinv @ np.array([xv, yv, zv, 1.0])
-                clip = Pp @ (Vp @ world)
-                if clip[3] <= 1e-9:
-                    return float("inf")  # behind the previous camera: no bound
-                worst = max(worst, abs(clip[1] / clip[3] - ny) * 0.5 * h)
-    return worst
+    n = np.linspace(-1.0, 1.0, grid)
+    nx, ny, zv = [a.ravel() for a in np.meshgrid(n, n, sign * np.asarray(depth_range, dtype=np.float64), indexing="ij")]
+    w = P[3, 2] * zv + P[3, 3]
+    view = np.stack([(nx * w - P[0, 2] * zv - P[0, 3]) / P[0, 0], (ny * w - P[1, 2] * zv - P[1, 3]) / P[1, 1], zv, np.ones_like(zv)])
+    clip = (Pp @ Vp @ Vinv) @ view
+    if np.any(clip[3] <= 1e-9):
+        return remember(float("inf"))  # behind the previous camera: no bound
+    return remember(float(np.max(np.abs(clip[1] / clip[3] - ny)) * 0.5 * h))
 
 
 class HaloSharder:

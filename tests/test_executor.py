@@ -103,3 +103,59 @@ def test_one_library_one_arithmetic():
     lib = api.load_library()
     assert lib.nrdHipGetNumericsMode() == 0
     assert api.load_library() is lib and not os.path.exists(os.path.join(os.path.dirname(api.LIB_PATH), "libNRD_hip_exact.so"))
+
+
+@pytest.mark.gpu
+def test_mixed_reblur_and_relax_instance_matches_the_oracle():
+    """ONE instance with a REBLUR and a RELAX denoiser (a legal combination in the reference: REBLUR_DIFFUSE + RELAX_SPECULAR in one
+    GetComputeDispatches list). The executor writes BOTH per-frame guide planes (view position for the REBLUR taps, world position for the RELAX taps);
+    outputs of both denoisers must equal the oracle's bit for bit."""
+    from oracle import driver as oracle_driver
+
+    w, h, frames = 192, 128, 4
+    denoisers = [(0, api.Denoiser.REBLUR_DIFFUSE), (1, api.Denoiser.RELAX_SPECULAR)]
+    emu = os.environ.get("NRD_PARITY_BACKEND") == "emu"
+    if emu:
+        from emu import emu_run
+
+        lib = emu_run.load()
+    else:
+        lib = api.load_library()
+    seq = [parity.synth.render_frame(w, h, f, want=("reblur", "relax")) for f in range(frames)]
+    inst_o, inst_d = api.Instance(denoisers), api.Instance(denoisers, lib=lib)
+    ora = oracle_driver.OracleExecutor(inst_o, w, h, api.FORMAT_BYTES)
+    if emu:
+        dev = emu_run.EmuExecutor(inst_d, w, h)
+        to_dev, to_host = (lambda a: np.array(a, copy=True, order="C")), (lambda a: a)
+    else:
+        from raytracingdenoiser_amd.executor import HipExecutor
+
+        dev = HipExecutor(inst_d, w, h)
+        to_dev, to_host = (lambda a: torch.from_numpy(np.ascontiguousarray(a)).cuda()), (lambda t: t.cpu().numpy())
+    outs = {}
+    for rt in (RT.OUT_DIFF_RADIANCE_HITDIST, RT.OUT_SPEC_RADIANCE_HITDIST):
+        a, b = np.zeros((h, w, 4), np.float16), to_dev(np.zeros((h, w, 4), np.float16))
+        ora.bind(rt, a, parity.F.RGBA16_SFLOAT)
+        dev.bind(rt, b, parity.F.RGBA16_SFLOAT)
+        outs[rt] = (a, b)
+    for f, frame in enumerate(seq):
+        planes = [(RT.IN_MV, frame["mv"], parity.F.RGBA16_SFLOAT), (RT.IN_NORMAL_ROUGHNESS, frame["normal_roughness"], parity.F.R10_G10_B10_A2_UNORM), (RT.IN_VIEWZ, frame["viewz"], parity.F.R32_SFLOAT),
+                  (RT.IN_DIFF_RADIANCE_HITDIST, frame["diff"], parity.F.RGBA16_SFLOAT), (RT.IN_SPEC_RADIANCE_HITDIST, frame["spec_relax"], parity.F.RGBA16_SFLOAT)]
+        keep = []
+        for rt, t, fmt in planes:
+            a = np.array(t.numpy(), copy=True, order="C")
+            b = to_dev(a)
+            keep.append((a, b))
+            ora.bind(rt, a, fmt)
+            dev.bind(rt, b, fmt)
+        for inst in (inst_o, inst_d):
+            assert inst.set_denoiser_settings(0, api.ReblurSettings()) == api.Result.SUCCESS
+            assert inst.set_denoiser_settings(1, api.RelaxSettings()) == api.Result.SUCCESS
+            assert inst.set_common_settings(parity.common_settings(frame["camera"], seq[max(f - 1, 0)]["camera"], w, h, f)) == api.Result.SUCCESS
+        r, ds = inst_o.get_compute_dispatches()
+        assert r == api.Result.SUCCESS and any(d.shader.startswith("REBLUR_") for d in ds) and any(d.shader.startswith("RELAX_") for d in ds)
+        ora.execute(ds)
+        dev.denoise()
+        for rt, (a, b) in outs.items():
+            got = to_host(b)
+            assert np.array_equal(got.view(np.uint16), a.view(np.uint16)), (f, rt, int((got.view(np.uint16) != a.view(np.uint16)).sum()))
