@@ -384,12 +384,21 @@ const char* LaunchAtrousSmem(const PassArgs& a) {
 }
 
 // ================================================================================================ Atrous
-// NRD_ATROUS_GUIDES_VIEWZ: the taps read viewZ (4 bytes) and re-derive the world position instead of fetching the stored (position, viewZ) texel (16 bytes): -6 % per
-// iteration (profiles/r02_g_atrz_relax.json). With the contraction decided by the source the re-derived position IS the stored one, bit for bit.
-#ifndef NRD_ATROUS_GUIDES_VIEWZ
-#define NRD_ATROUS_GUIDES_VIEWZ 1
+// One iteration of the dilated 3x3 (reference RELAX_Atrous.hlsli:10-240): 8 taps at +-step texels, edge-stopping weights from the guides (plane distance,
+// normal, roughness, material) and from the luminance difference, variance filtered with the squared weights.
+//
+// Two tap sources, one arithmetic:
+//   STEP = 2 / 4  LDS tile. The 32x8 workgroup stages the (32 + 2 step) x (8 + 2 step) texels its taps can reach -- 36x12 / 40x16 -- ONCE: per texel one
+//                 coalesced read of every plane (1.7 / 2.5 texels per pixel instead of 9 gathers per pixel through the L1), and everything that depends on the
+//                 texel alone is computed at the fill instead of in each of the up-to-8 taps that visit it: the world position (re-derived from viewZ with the
+//                 expression that wrote the guide plane, ~20 VALU) and the fp16 -> fp32 decode of the radiance planes. Taps are ds_read_b128 / b64.
+//   STEP = 0      global gathers (steps 8, 16, ...: the reach no longer fits a tile, and a per-pixel hashed offset breaks the regular stencil anyway).
+// RES: RelaxSettings::enableRoughnessEdgeStopping, a compile-time variant picked by the launcher -- the taps then compute either the lobe-aware normal weight
+// and the roughness weight, or the simplified normal weight, never both (the reference selects per tap between two fully evaluated expressions).
+#ifndef NRD_ATROUS_LDS_TILES
+#define NRD_ATROUS_LDS_TILES 1 // 0: every iteration gathers from global memory (A/B and the emulation's cross-check)
 #endif
-template <bool DIFF, bool SPEC, bool SH>
+template <bool DIFF, bool SPEC, bool SH, int STEP, bool RES>
 __global__ __launch_bounds__(256, NRD_WAVES_RELAX_ATROUS) void RelaxAtrousKernel(AtrousPlanes P, RelaxCB c, RowRange rows) {
     // one layout for the two guide planes and one for the (up to four) RGBA16F signal planes: verified by the launcher
     ShareLayout(P.worldPosViewZ, P.decodedNR);
@@ -397,24 +406,67 @@ __global__ __launch_bounds__(256, NRD_WAVES_RELAX_ATROUS) void RelaxAtrousKernel
         const Plane sig = SPEC ? P.spec.in : P.diff.in;
         ShareLayout(P.spec.in, sig), ShareLayout(P.diff.in, sig), ShareLayout(P.spec.inSh, sig), ShareLayout(P.diff.inSh, sig);
     }
+    constexpr bool TILED = STEP != 0;
+    constexpr int TW = TILE_X + 2 * STEP, TH = TILE_Y + 2 * STEP, TS = TW + 1, TN = TILED ? TH * TS : 1; // row stride padded by one texel
+    __shared__ float4 s_NR[TN], s_Pos[TN];
+    __shared__ float4 s_Spec[SPEC ? TN : 1], s_Diff[DIFF ? TN : 1];
+    __shared__ uint2 s_SpecSh[SPEC && SH ? TN : 1], s_DiffSh[DIFF && SH ? TN : 1];
+
     const int blockY = blockIdx.y + rows.firstBlockY;
-    const int px = BlockTileX(rows) * TILE_X + (threadIdx.x & 31), py = blockY * TILE_Y + (threadIdx.x >> 5);
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    const int blockX0 = BlockTileX(rows) * TILE_X, blockY0 = blockY * TILE_Y;
+    const int px = blockX0 + tx, py = blockY0 + ty;
     const int rectW = c.shared.gRectSize.x, rectH = c.shared.gRectSize.y;
+    const uint32_t sigPitch = (SPEC ? P.spec.in : P.diff.in).pitch;
+    if (TILED) {
+        // uniform early-outs: a workgroup beyond the rect, or over sky tiles only (TILE_X = 32 = two 16x16 tiles, TILE_Y = 8: one tile row)
+        if (blockX0 >= rectW || blockY0 >= rectH)
+            return;
+        bool anyGeometry = false;
+        for (int t = 0; t < TILE_X / 16; t++)
+            if ((blockX0 >> 4) + t < P.tiles.w && (blockY0 >> 4) < P.tiles.h)
+                anyGeometry |= LoadR8Unorm(P.tiles, (blockX0 >> 4) + t, blockY0 >> 4) == 0.0f;
+        if (!anyGeometry)
+            return;
+        for (int i = threadIdx.x; i < TW * TH; i += 256) {
+            const int lx = i % TW, ly = i / TW;
+            const int cx = ClampI(blockX0 - STEP + lx, 0, P.worldPosViewZ.w - 1), cy = ClampI(blockY0 - STEP + ly, 0, P.worldPosViewZ.h - 1); // the taps' clamped texel
+            const int li = ly * TS + lx;
+            s_NR[li] = *(const float4*)(P.decodedNR.ptr + (__umul24((uint32_t)cy, P.decodedNR.pitch) + (uint32_t)cx * 16u));
+            const float z = RelaxUnpackViewZ(c, *(const float*)(P.viewZ.ptr + (__umul24((uint32_t)cy, P.viewZ.pitch) + (uint32_t)cx * 4u)));
+            s_Pos[li] = F4(GetCurrentWorldPosFromPixelPos(c, cx, cy, z), z);
+            const uint32_t signalOffset = __umul24((uint32_t)cy, sigPitch) + (uint32_t)cx * 8u;
+            if (SPEC) {
+                const uint2 raw = *(const uint2*)(P.spec.in.ptr + signalOffset);
+                s_Spec[li] = DecodeRGBA16F(raw.x, raw.y);
+                if (SH)
+                    s_SpecSh[li] = *(const uint2*)(P.spec.inSh.ptr + signalOffset);
+            }
+            if (DIFF) {
+                const uint2 raw = *(const uint2*)(P.diff.in.ptr + signalOffset);
+                s_Diff[li] = DecodeRGBA16F(raw.x, raw.y);
+                if (SH)
+                    s_DiffSh[li] = *(const uint2*)(P.diff.inSh.ptr + signalOffset);
+            }
+        }
+        __syncthreads();
+    }
     if (px >= rectW || py >= rectH || py < rows.rowBegin || py >= rows.rowEnd)
         return;
     if (LoadR8Unorm(P.tiles, px >> 4, py >> 4) != 0.0f)
         return;
-    const float4 centerWorldPosViewZ = LoadRGBA32F(P.worldPosViewZ, px, py);
+    const int lc = TILED ? (ty + STEP) * TS + tx + STEP : 0; // the pixel's own texel in the tile
+    const float4 centerWorldPosViewZ = TILED ? s_Pos[lc] : LoadRGBA32F(P.worldPosViewZ, px, py);
     const float centerViewZ = centerWorldPosViewZ.w;
     if (centerViewZ > c.shared.gDenoisingRange)
         return;
 
     float centerMaterialID;
-    const float4 centerNormalRoughness = LoadDecodedNormalRoughness(P.decodedNR, px, py, centerMaterialID);
+    const float4 centerNormalRoughness = TILED ? DecodedToNormalRoughness(s_NR[lc], centerMaterialID) : LoadDecodedNormalRoughness(P.decodedNR, px, py, centerMaterialID);
     const float3 centerNormal = Xyz(centerNormalRoughness);
     const float centerRoughness = centerNormalRoughness.w;
     const float historyLength = 255.0f * LoadR8Unorm(P.historyLength, px, py);
-    const int stepSize = (int)c.gStepSize;
+    const int stepSize = TILED ? STEP : (int)c.gStepSize;
 
     float diffuseLobeAngleFraction = Div(c.shared.gLobeAngleFraction, Sqrt(float(c.gStepSize)));
     if (SH)
@@ -426,7 +478,7 @@ __global__ __launch_bounds__(256, NRD_WAVES_RELAX_ATROUS) void RelaxAtrousKernel
     float4 sumSpecular = F4(0.0f), sumSpecularSH = F4(0.0f);
     float sumWSpecular = 0.44198f * 0.44198f, roughnessModified = 0.0f;
     if (SPEC) {
-        const float4 centerSpecular = LoadRGBA16F(P.spec.in, px, py);
+        const float4 centerSpecular = TILED ? s_Spec[lc] : LoadRGBA16F(P.spec.in, px, py);
         sp.centerLuminance = Luminance(Xyz(centerSpecular));
         const float centerSpecularVar = centerSpecular.w;
         sp.phiLIlluminationInv = Rcp(Max(1.0e-4f, c.shared.gSpecPhiLuminance * Sqrt(centerSpecularVar)));
@@ -451,7 +503,11 @@ __global__ __launch_bounds__(256, NRD_WAVES_RELAX_ATROUS) void RelaxAtrousKernel
 
         sumSpecular = centerSpecular * F4(sumWSpecular, sumWSpecular, sumWSpecular, sumWSpecular * sumWSpecular);
         if (SH) {
-            const float4 centerSpecularSH = LoadRGBA16F(P.spec.inSh, px, py);
+            float4 centerSpecularSH;
+            if (TILED)
+                centerSpecularSH = DecodeRGBA16F(s_SpecSh[lc].x, s_SpecSh[lc].y);
+            else
+                centerSpecularSH = LoadRGBA16F(P.spec.inSh, px, py);
             sumSpecularSH = centerSpecularSH * sumWSpecular;
             roughnessModified = centerSpecularSH.w;
         }
@@ -462,7 +518,7 @@ __global__ __launch_bounds__(256, NRD_WAVES_RELAX_ATROUS) void RelaxAtrousKernel
     float4 sumDiffuse = F4(0.0f), sumDiffuseSH = F4(0.0f);
     float sumWDiffuse = 0.44198f * 0.44198f;
     if (DIFF) {
-        const float4 centerDiffuse = LoadRGBA16F(P.diff.in, px, py);
+        const float4 centerDiffuse = TILED ? s_Diff[lc] : LoadRGBA16F(P.diff.in, px, py);
         dp.centerLuminance = Luminance(Xyz(centerDiffuse));
         const float centerDiffuseVar = centerDiffuse.w;
         dp.phiLIlluminationInv = Rcp(Max(1.0e-4f, c.shared.gDiffPhiLuminance * Sqrt(centerDiffuseVar)));
@@ -475,8 +531,12 @@ __global__ __launch_bounds__(256, NRD_WAVES_RELAX_ATROUS) void RelaxAtrousKernel
         }
         dp.normalWeightParam = GetNormalWeightParam2(1.0f, diffuseLobeAngleFraction);
         sumDiffuse = centerDiffuse * F4(sumWDiffuse, sumWDiffuse, sumWDiffuse, sumWDiffuse * sumWDiffuse);
-        if (SH)
-            sumDiffuseSH = LoadRGBA16F(P.diff.inSh, px, py) * sumWDiffuse;
+        if (SH) {
+            if (TILED)
+                sumDiffuseSH = DecodeRGBA16F(s_DiffSh[lc].x, s_DiffSh[lc].y) * sumWDiffuse;
+            else
+                sumDiffuseSH = LoadRGBA16F(P.diff.inSh, px, py) * sumWDiffuse;
+        }
     }
 
     const float3 centerWorldPos = Xyz(centerWorldPosViewZ);
@@ -485,7 +545,7 @@ __global__ __launch_bounds__(256, NRD_WAVES_RELAX_ATROUS) void RelaxAtrousKernel
 
     // random offsets against ringing at large steps
     int offx = 0, offy = 0;
-    if (c.gStepSize > 4) {
+    if (!TILED && c.gStepSize > 4) {
         RngHash rng;
         rng.Initialize((uint32_t)px, (uint32_t)py, c.shared.gFrameIndex);
         float2 rnd = rng.GetFloat2();
@@ -508,18 +568,49 @@ __global__ __launch_bounds__(256, NRD_WAVES_RELAX_ATROUS) void RelaxAtrousKernel
             const int qx = px + offx + xx * stepSize, qy = py + offy + yy * stepSize;
             const bool isInside = (uint32_t)qx < (uint32_t)rectW && (uint32_t)qy < (uint32_t)rectH && InBounds(P.worldPosViewZ, qx, qy);
             const float kernelW = (xx == 0 ? 0.44198f : 0.27901f) * (yy == 0 ? 0.44198f : 0.27901f);
-            const int cx = ClampI(qx, 0, P.worldPosViewZ.w - 1), cy = ClampI(qy, 0, P.worldPosViewZ.h - 1);
-            const uint32_t guideOffset = __umul24((uint32_t)cy, P.decodedNR.pitch) + (uint32_t)cx * 16u;
-            const float4 g0 = *(const float4*)(P.decodedNR.ptr + guideOffset);
+            float4 g0, sampleWorldPosViewZ, sampleSpecular = F4(0.0f), sampleDiffuse = F4(0.0f);
+            uint2 rawSpecSh = make_uint2(0u, 0u), rawDiffSh = make_uint2(0u, 0u);
+            if (TILED) {
+                const int li = lc + yy * STEP * TS + xx * STEP; // the tile holds the clamped texel of every tap position
+                g0 = s_NR[li];
+                sampleWorldPosViewZ = s_Pos[li];
+                if (SPEC) {
+                    sampleSpecular = s_Spec[li];
+                    if (SH)
+                        rawSpecSh = s_SpecSh[li];
+                }
+                if (DIFF) {
+                    sampleDiffuse = s_Diff[li];
+                    if (SH)
+                        rawDiffSh = s_DiffSh[li];
+                }
+            } else {
+                const int cx = ClampI(qx, 0, P.worldPosViewZ.w - 1), cy = ClampI(qy, 0, P.worldPosViewZ.h - 1);
+                const uint32_t guideOffset = __umul24((uint32_t)cy, P.decodedNR.pitch) + (uint32_t)cx * 16u;
+                g0 = *(const float4*)(P.decodedNR.ptr + guideOffset);
 #if NRD_ATROUS_GUIDES_VIEWZ
-            // 4 bytes of viewZ instead of the 16-byte (world position, viewZ) texel: the taps are bound by the bytes that cross the L1 (gather probe:
-            // 39.6 cycles per 16-byte wave-load against 6.4 per 4-byte one); the position is re-derived with the very expression that wrote the guide
-            // plane (DecodeGuidesRelaxKernel = relax_device.h GetCurrentWorldPosFromPixelPos), ~20 VALU, so it IS the stored value
-            const float tapZ = RelaxUnpackViewZ(c, *(const float*)(P.viewZ.ptr + (__umul24((uint32_t)cy, P.viewZ.pitch) + (uint32_t)cx * 4u)));
-            const float4 sampleWorldPosViewZ = F4(GetCurrentWorldPosFromPixelPos(c, cx, cy, tapZ), tapZ);
+                // 4 bytes of viewZ instead of the 16-byte (world position, viewZ) texel: the taps are bound by the bytes that cross the L1 (gather probe:
+                // 39.6 cycles per 16-byte wave-load against 6.4 per 4-byte one); the position is re-derived with the very expression that wrote the guide
+                // plane (DecodeGuidesRelaxKernel = relax_device.h GetCurrentWorldPosFromPixelPos), ~20 VALU, so it IS the stored value
+                const float tapZ = RelaxUnpackViewZ(c, *(const float*)(P.viewZ.ptr + (__umul24((uint32_t)cy, P.viewZ.pitch) + (uint32_t)cx * 4u)));
+                sampleWorldPosViewZ = F4(GetCurrentWorldPosFromPixelPos(c, cx, cy, tapZ), tapZ);
 #else
-            const float4 sampleWorldPosViewZ = *(const float4*)(P.worldPosViewZ.ptr + guideOffset);
+                sampleWorldPosViewZ = *(const float4*)(P.worldPosViewZ.ptr + guideOffset);
 #endif
+                const uint32_t signalOffset = __umul24((uint32_t)cy, sigPitch) + (uint32_t)cx * 8u;
+                if (SPEC) {
+                    const uint2 raw = *(const uint2*)(P.spec.in.ptr + signalOffset);
+                    sampleSpecular = DecodeRGBA16F(raw.x, raw.y);
+                    if (SH)
+                        rawSpecSh = *(const uint2*)(P.spec.inSh.ptr + signalOffset);
+                }
+                if (DIFF) {
+                    const uint2 raw = *(const uint2*)(P.diff.in.ptr + signalOffset);
+                    sampleDiffuse = DecodeRGBA16F(raw.x, raw.y);
+                    if (SH)
+                        rawDiffSh = *(const uint2*)(P.diff.inSh.ptr + signalOffset);
+                }
+            }
 
             float sampleMaterialID;
             const float4 sampleNormalRoughness = DecodedToNormalRoughness(g0, sampleMaterialID);
@@ -532,20 +623,21 @@ __global__ __launch_bounds__(256, NRD_WAVES_RELAX_ATROUS) void RelaxAtrousKernel
             geometryW *= kernelW;
             geometryW *= Cmp(isInside && sampleViewZ < c.shared.gDenoisingRange);
 
-            const uint32_t signalOffset = __umul24((uint32_t)cy, (SPEC ? P.spec.in : P.diff.in).pitch) + (uint32_t)cx * 8u;
             if (SPEC) {
-                float3 sampleV = -Normalize(sampleWorldPos + c.shared.gRoughnessEdgeStoppingRelaxation * centerWorldPos);
-                float angles = AcosApprox(Dot(centerNormal, sampleNormal));
-                float normalWSpecularSimplified = ComputeWeight(angles, sp.normalWeightParamSimplified, 0.0f);
-                float normalWSpecular = GetSpecularNormalWeight_ATrous(sp.normalWeightParams, centerNormal, sampleNormal, centerV, sampleV);
-                float roughnessWSpecular = ComputeWeight(sampleRoughness, sp.roughnessWeightParams.x, sp.roughnessWeightParams.y);
-
-                float wSpecular = geometryW * (c.shared.gRoughnessEdgeStoppingEnabled ? (normalWSpecular * roughnessWSpecular) : normalWSpecularSimplified);
+                float wSpecular;
+                if (RES) { // gRoughnessEdgeStoppingEnabled != 0 (launcher)
+                    float3 sampleV = -Normalize(sampleWorldPos + c.shared.gRoughnessEdgeStoppingRelaxation * centerWorldPos);
+                    float normalWSpecular = GetSpecularNormalWeight_ATrous(sp.normalWeightParams, centerNormal, sampleNormal, centerV, sampleV);
+                    float roughnessWSpecular = ComputeWeight(sampleRoughness, sp.roughnessWeightParams.x, sp.roughnessWeightParams.y);
+                    wSpecular = geometryW * (normalWSpecular * roughnessWSpecular);
+                } else {
+                    float angles = AcosApprox(Dot(centerNormal, sampleNormal));
+                    float normalWSpecularSimplified = ComputeWeight(angles, sp.normalWeightParamSimplified, 0.0f);
+                    wSpecular = geometryW * normalWSpecularSimplified;
+                }
                 if (compareSpecMaterials)
                     wSpecular *= Cmp(CompareMaterials(sampleMaterialID, centerMaterialID, c.shared.gSpecMinMaterial));
                 const bool on = wSpecular > 1e-4f;
-                const uint2 raw = *(const uint2*)(P.spec.in.ptr + signalOffset);
-                float4 sampleSpecular = DecodeRGBA16F(raw.x, raw.y);
                 float sampleSpecularLuminance = Luminance(Xyz(sampleSpecular));
                 float specularLuminanceW = Abs(sp.centerLuminance - sampleSpecularLuminance) * sp.phiLIlluminationInv;
                 specularLuminanceW = Min(c.shared.gSpecMaxLuminanceRelativeDifference, specularLuminanceW);
@@ -555,10 +647,8 @@ __global__ __launch_bounds__(256, NRD_WAVES_RELAX_ATROUS) void RelaxAtrousKernel
 
                 sumWSpecular += wSpecular;
                 sumSpecular = Mad(sampleSpecular, F4(wSpecular, wSpecular, wSpecular, wSpecular * wSpecular), sumSpecular);
-                if (SH) {
-                    const uint2 rawSh = *(const uint2*)(P.spec.inSh.ptr + signalOffset);
-                    sumSpecularSH = Mad(DecodeRGBA16F(rawSh.x, rawSh.y), wSpecular, sumSpecularSH);
-                }
+                if (SH)
+                    sumSpecularSH = Mad(DecodeRGBA16F(rawSpecSh.x, rawSpecSh.y), wSpecular, sumSpecularSH);
             }
             if (DIFF) {
                 float angled = AcosApprox(Dot(centerNormal, sampleNormal));
@@ -567,8 +657,6 @@ __global__ __launch_bounds__(256, NRD_WAVES_RELAX_ATROUS) void RelaxAtrousKernel
                 if (compareDiffMaterials)
                     wDiffuse *= Cmp(CompareMaterials(sampleMaterialID, centerMaterialID, c.shared.gDiffMinMaterial));
                 const bool on = wDiffuse > 1e-4f;
-                const uint2 raw = *(const uint2*)(P.diff.in.ptr + signalOffset);
-                float4 sampleDiffuse = DecodeRGBA16F(raw.x, raw.y);
                 float sampleDiffuseLuminance = Luminance(Xyz(sampleDiffuse));
                 float diffuseLuminanceW = Abs(dp.centerLuminance - sampleDiffuseLuminance) * dp.phiLIlluminationInv;
                 diffuseLuminanceW = Min(c.shared.gDiffMaxLuminanceRelativeDifference, diffuseLuminanceW);
@@ -578,10 +666,8 @@ __global__ __launch_bounds__(256, NRD_WAVES_RELAX_ATROUS) void RelaxAtrousKernel
 
                 sumWDiffuse += wDiffuse;
                 sumDiffuse = Mad(sampleDiffuse, F4(wDiffuse, wDiffuse, wDiffuse, wDiffuse * wDiffuse), sumDiffuse);
-                if (SH) {
-                    const uint2 rawSh = *(const uint2*)(P.diff.inSh.ptr + signalOffset);
-                    sumDiffuseSH = Mad(DecodeRGBA16F(rawSh.x, rawSh.y), wDiffuse, sumDiffuseSH);
-                }
+                if (SH)
+                    sumDiffuseSH = Mad(DecodeRGBA16F(rawDiffSh.x, rawDiffSh.y), wDiffuse, sumDiffuseSH);
             }
         }
 
@@ -605,6 +691,11 @@ __global__ __launch_bounds__(256, NRD_WAVES_RELAX_ATROUS) void RelaxAtrousKernel
     }
 }
 
+static bool AtrousLdsTilesEnabled() {
+    static const bool v = !(getenv("NRD_HIP_ATROUS_LDS") && atoi(getenv("NRD_HIP_ATROUS_LDS")) == 0); // run-time A/B switch (results are identical)
+    return NRD_ATROUS_LDS_TILES && v;
+}
+
 template <bool DIFF, bool SPEC, bool SH>
 const char* LaunchAtrous(const PassArgs& a) {
     if (const char* e = CheckSupportedRelax(a))
@@ -622,7 +713,17 @@ const char* LaunchAtrous(const PassArgs& a) {
     }
     RelaxCB c = LoadRelaxConstants(a);
     RowGrid g = GridForRows(c.shared.gRectSize.x, c.shared.gRectSize.y, TILE_X, TILE_Y, a.rowBegin, a.rowEnd);
-    LaunchPass(a, (RelaxAtrousKernel<DIFF, SPEC, SH>), g.grid, dim3(256), P, c, MakeRowRange(g));
+    const RowRange rr = MakeRowRange(g);
+    const int step = AtrousLdsTilesEnabled() && (c.gStepSize == 2 || c.gStepSize == 4) ? (int)c.gStepSize : 0;
+    const bool res = !SPEC || c.shared.gRoughnessEdgeStoppingEnabled != 0; // (irrelevant without a specular signal: one instantiation)
+#define NRD_LAUNCH_ATROUS(STEP, RES) LaunchPass(a, (RelaxAtrousKernel<DIFF, SPEC, SH, STEP, RES>), g.grid, dim3(256), P, c, rr)
+    if (step == 2)
+        res ? NRD_LAUNCH_ATROUS(2, true) : NRD_LAUNCH_ATROUS(2, SPEC ? false : true);
+    else if (step == 4)
+        res ? NRD_LAUNCH_ATROUS(4, true) : NRD_LAUNCH_ATROUS(4, SPEC ? false : true);
+    else
+        res ? NRD_LAUNCH_ATROUS(0, true) : NRD_LAUNCH_ATROUS(0, SPEC ? false : true);
+#undef NRD_LAUNCH_ATROUS
     return nullptr;
 }
 
