@@ -34,6 +34,7 @@ from raytracingdenoiser_amd import api, scene, sharding, synth
 from raytracingdenoiser_amd import build as native_build
 from raytracingdenoiser_amd.executor import HipExecutor
 
+VALU_CYCLES_PER_INSTRUCTION = 3.0  # average over the instruction mix of the pass kernels (profiles/r02_b_valu_bench.txt price list x tools/isa_stats.py --cost)
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E peak (MI355X_MICROARCH.md); ~6300 GB/s is what a float4 copy achieves (measured live below)
 
 # Published reference numbers for the exact metric (reference README.md:18, RTX 4080, 1440p native)
@@ -353,17 +354,23 @@ def main():
     roofline = None
     if dominant:
         achieved = passes[dominant]["GBps"]
-        traffic, traffic_source = None, None
+        traffic, traffic_source, valu = None, None, None
         if world == 1 and os.path.exists(PMC_TRAFFIC_FILE):
-            entry = json.load(open(PMC_TRAFFIC_FILE)).get("%s_%dx%d" % (name, W, H), {})
+            entry = json.load(open(PMC_TRAFFIC_FILE)).get("%s_%dx%d%s" % (name, W, H, "_nosky" if args.no_sky else ""), {})
             k = entry.get("kernels", {}).get(dominant)
             if k:
                 traffic = int((2.0 * k["FETCH_SIZE_KiB"] + k["WRITE_SIZE_KiB"]) * 1024)
                 traffic_source = entry.get("source")
+                if k.get("SQ_INSTS_VALU"):
+                    # the bound these kernels actually sit at: VALU issue. Executed wave instructions x the measured average issue cost of the
+                    # kernels' instruction mix (~3.0 SIMD cycles: 2.4 for fma / mul / add, 4.1 for the rest, 8.1 for transcendentals) over 1024 SIMDs at 2.4 GHz
+                    issue_ms = k["SQ_INSTS_VALU"] * VALU_CYCLES_PER_INSTRUCTION / (1024 * 2.4e6)
+                    valu = {"executed_valu_per_wave": k["valu_per_wave"], "waves_per_launch": int(k["SQ_WAVES"]), "cycles_per_instruction": VALU_CYCLES_PER_INSTRUCTION,
+                            "issue_bound_ms": round(issue_ms, 4), "frac_of_issue_bound": round(issue_ms / passes[dominant]["avg_ms"], 3)}
         roofline = {"bound": "hbm", "kernel": dominant, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
                     "measured_copy_GBps": round(copy_gbs, 1), "frac_of_measured_copy": round(achieved / copy_gbs, 4),
                     "denoised_pixel_fraction": round(denoised_fraction, 4), "frac_denoised_pixels": round(achieved / HBM_PEAK_GBS * denoised_fraction, 4),
-                    "traffic": traffic, "traffic_source": traffic_source, "avg_kernel_ms": passes[dominant]["avg_ms"],
+                    "traffic": traffic, "traffic_source": traffic_source, "valu": valu, "avg_kernel_ms": passes[dominant]["avg_ms"],
                     "algorithmic_bytes_per_launch": passes[dominant]["bytes_per_launch"],
                     "note": "dominant = the pass with the longest average launch; per-pass durations from HIP events on the executor's stream (eager replay of the timed frames); "
                             "frac counts the algorithmic bytes of EVERY pixel of the frame as the metric does, frac_denoised_pixels only those of the pixels that are not sky; "

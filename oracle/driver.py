@@ -36,6 +36,7 @@ def load():
             getattr(lib, name).argtypes, getattr(lib, name).restype = [C.c_float], C.c_float
         lib.oracle_pow.argtypes, lib.oracle_pow.restype = [C.c_float, C.c_float], C.c_float
         lib.oracle_eval_hw.argtypes, lib.oracle_eval_hw.restype = [C.c_int, C.c_void_p, C.c_void_p, C.c_int], None
+        lib.oracle_frontend.argtypes, lib.oracle_frontend.restype = [C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int], None
         # rcp / sqrt / rsqrt / exp2 / log2 follow gfx950's instructions: per-mantissa deviation (in ulps) from the reference results of oracle/hw_ref.h,
         # measured on the device by tools/hw_tables.hip and committed next to the oracle (oracle/hw_math.h)
         import zlib

@@ -1,5 +1,6 @@
 // ORACLE -- TEST INFRASTRUCTURE, NOT PRODUCT CODE (see oracle/hlsl.h).
 // C entry points used by tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg (through oracle/driver.py).
+#include "ml.h"
 #include "passes.h"
 
 #include <cstdio>
@@ -85,6 +86,38 @@ __attribute__((visibility("default"))) int oracle_set_threads(int n) {
     (void)n;
     return 1;
 #endif
+}
+
+// The front-end / back-end functions the oracle restates for its own passes (ml.h [nrd]), row by row: tests/test_frontend_header.py holds the
+// device results of include/NRD.hip.h against them. op 0: (N.xyz, roughness, materialID) -> the R10G10B10A2 texel word (as float bits);
+// 1: word -> (N.xyz, roughness, materialID); 2: (hitDist, viewZ, roughness) -> normalised hit distance with the library-default hitDistParams;
+// 3: (radiance.xyz, normHitDist) -> REBLUR packed; 4: packed -> REBLUR unpacked; 5: x -> SIGMA_BackEnd_UnpackShadow
+__attribute__((visibility("default"))) void oracle_frontend(int op, const float* in, int inStride, float* out, int outStride, int n) {
+    for (int i = 0; i < n; i++) {
+        const float* a = in + (size_t)i * inStride;
+        float* o = out + (size_t)i * outStride;
+        if (op == 0) {
+            float4 p = NRD_FrontEnd_PackNormalAndRoughness(float3(a[0], a[1], a[2]), a[3], a[4]);
+            uint32_t w = ToUnorm(p.x, 1023.0f) | (ToUnorm(p.y, 1023.0f) << 10) | (ToUnorm(p.z, 1023.0f) << 20) | (ToUnorm(p.w, 3.0f) << 30);
+            memcpy(o, &w, 4);
+        } else if (op == 1) {
+            uint32_t w;
+            memcpy(&w, a, 4);
+            float4 texel(float(w & 0x3FFu) / 1023.0f, float((w >> 10) & 0x3FFu) / 1023.0f, float((w >> 20) & 0x3FFu) / 1023.0f, float(w >> 30) / 3.0f);
+            float4 r = NRD_FrontEnd_UnpackNormalAndRoughness(texel, o[4]);
+            o[0] = r.x, o[1] = r.y, o[2] = r.z, o[3] = r.w;
+        } else if (op == 2) {
+            o[0] = REBLUR_FrontEnd_GetNormHitDist(a[0], a[1], float4(3.0f, 0.1f, 20.0f, -25.0f), a[2]);
+        } else if (op == 3) {
+            float4 r = REBLUR_FrontEnd_PackRadianceAndNormHitDist(float3(a[0], a[1], a[2]), a[3]);
+            o[0] = r.x, o[1] = r.y, o[2] = r.z, o[3] = r.w;
+        } else if (op == 4) {
+            float4 r = REBLUR_BackEnd_UnpackRadianceAndNormHitDist(float4(a[0], a[1], a[2], a[3]));
+            o[0] = r.x, o[1] = r.y, o[2] = r.z, o[3] = r.w;
+        } else {
+            o[0] = a[0] * a[0];
+        }
+    }
 }
 
 // scalar probes so the tests can pin the numerics contract (codecs + transcendentals) value by value

@@ -2,9 +2,12 @@
 // with a GPU the same functions run on the DEVICE over the same inputs and must agree (bit-exact for the packers and codecs, which
 // use only + - * / sqrt; 2e-4 relative for the resolves, which use exp / log / pow from the platform's math library).
 // usage: frontend_check [--no-gpu]
+//        frontend_check --dump FILE COUNT   evaluates COUNT samples ON THE DEVICE and writes inputs and results as raw float32 / uint32 rows
+//                                           (tests/test_frontend_header.py holds them against models that do not include this header)
 #include "NRD.hip.h"
 
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <vector>
 
@@ -96,7 +99,47 @@ __global__ void EvaluateKernel(Result* out, uint32_t count) {
 
 static bool Close(float a, float b, float rel) { return fabsf(a - b) <= rel * fmaxf(fmaxf(fabsf(a), fabsf(b)), 1e-3f); }
 
+// one row of 32-bit words per sample: the inputs, then every result (field order = DUMP_FIELDS in tests/test_frontend_header.py)
+static void Append(std::vector<uint32_t>& row, float v) {
+    uint32_t u;
+    memcpy(&u, &v, 4);
+    row.push_back(u);
+}
+static void Append(std::vector<uint32_t>& row, float2 v) { Append(row, v.x), Append(row, v.y); }
+static void Append(std::vector<uint32_t>& row, float3 v) { Append(row, v.x), Append(row, v.y), Append(row, v.z); }
+static void Append(std::vector<uint32_t>& row, float4 v) { Append(row, v.x), Append(row, v.y), Append(row, v.z), Append(row, v.w); }
+
+static int Dump(const char* path, uint32_t count) {
+    Result* dOut = nullptr;
+    CHECK(hipMalloc((void**)&dOut, sizeof(Result) * (size_t)count) == hipSuccess);
+    hipLaunchKernelGGL(EvaluateKernel, dim3((count + 255) / 256), dim3(256), 0, 0, dOut, count);
+    std::vector<Result> dev(count);
+    CHECK(hipMemcpy(dev.data(), dOut, sizeof(Result) * (size_t)count, hipMemcpyDeviceToHost) == hipSuccess);
+    (void)hipFree(dOut);
+    FILE* fp = fopen(path, "wb");
+    CHECK(fp != nullptr);
+    std::vector<uint32_t> row;
+    for (uint32_t i = 0; i < count; i++) {
+        const Sample s = MakeSample(i);
+        const Result& r = dev[i];
+        row.clear();
+        Append(row, s.N), Append(row, s.V), Append(row, s.radiance), Append(row, s.direction), Append(row, s.albedo), Append(row, s.Rf0);
+        Append(row, s.roughness), Append(row, s.materialID), Append(row, s.hitDist), Append(row, s.viewZ), Append(row, Dir(i, 21));
+        row.push_back(r.normalRoughnessWord);
+        Append(row, r.unpackedNR), Append(row, r.reblurPacked), Append(row, r.reblurUnpacked), Append(row, r.sh0), Append(row, r.sh1), Append(row, r.relaxPacked), Append(row, r.relaxSh1);
+        Append(row, r.dirOcc), Append(row, r.translucency), Append(row, r.normHitDist), Append(row, r.penumbra), Append(row, r.penumbraLocal), Append(row, r.shadow), Append(row, r.materialID);
+        Append(row, r.diffFactor), Append(row, r.specFactor), Append(row, r.sgDiffuse), Append(row, r.sgSpecular), Append(row, r.shDiffuse), Append(row, r.shSpecular), Append(row, r.sgColor);
+        Append(row, r.sgDir), Append(row, r.rejitter);
+        fwrite(row.data(), 4, row.size(), fp);
+    }
+    fclose(fp);
+    printf("dumped %u samples x %zu words\n", count, row.size());
+    return 0;
+}
+
 int main(int argc, char** argv) {
+    if (argc > 3 && !strcmp(argv[1], "--dump"))
+        return Dump(argv[2], (uint32_t)atoi(argv[3]));
     const bool noGpu = argc > 1 && !strcmp(argv[1], "--no-gpu");
     const uint32_t count = 4096;
     std::vector<Result> host(count);

@@ -67,3 +67,122 @@ def test_frontend_header_device_matches_host():
     r = subprocess.run([EXE], capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stdout + r.stderr
     assert "frontend check OK" in r.stdout
+
+
+# ---- the device results of the header against implementations that do NOT include it ---------------------------------------------
+DUMP_FIELDS = [("N", 3), ("V", 3), ("radiance", 3), ("direction", 3), ("albedo", 3), ("Rf0", 3), ("roughness", 1), ("materialID_in", 1), ("hitDist", 1), ("viewZ", 1), ("Nw", 3),
+               ("word", 1), ("unpackedNR", 4), ("reblurPacked", 4), ("reblurUnpacked", 4), ("sh0", 4), ("sh1", 4), ("relaxPacked", 4), ("relaxSh1", 4), ("dirOcc", 4), ("translucency", 4),
+               ("normHitDist", 1), ("penumbra", 1), ("penumbraLocal", 1), ("shadow", 1), ("materialID", 1), ("diffFactor", 3), ("specFactor", 3), ("sgDiffuse", 3), ("sgSpecular", 3),
+               ("shDiffuse", 3), ("shSpecular", 3), ("sgColor", 3), ("sgDir", 3), ("rejitter", 2)]
+
+
+def _load_dump(path, count):
+    words = sum(n for _, n in DUMP_FIELDS)
+    raw = np.fromfile(path, dtype=np.uint32).reshape(count, words)
+    out, k = {}, 0
+    for name, n in DUMP_FIELDS:
+        col = raw[:, k:k + n]
+        out[name] = col.copy() if name == "word" else col.view(np.float32).copy()
+        k += n
+    return out
+
+
+def _ulps(a, b):
+    a, b = np.ascontiguousarray(a, dtype=np.float32), np.ascontiguousarray(b, dtype=np.float32)
+    ia, ib = a.view(np.int32).astype(np.int64), b.view(np.int32).astype(np.int64)
+    ia, ib = np.where(ia < 0, -(ia & 0x7FFFFFFF), ia), np.where(ib < 0, -(ib & 0x7FFFFFFF), ib)
+    return np.abs(ia - ib)
+
+
+@pytest.mark.gpu
+def test_frontend_header_device_results_match_the_oracle_and_a_float64_model():
+    """131072 samples evaluated ON THE DEVICE by include/NRD.hip.h (tests/cpp/frontend_check --dump) against
+      * the oracle's own restatements of the functions its passes consume (oracle/ml.h [nrd], through oracle_frontend): the R10G10B10A2 words bit for bit,
+        the floats within a few ulp (the header is application-side IEEE code, the oracle the device contract: dot products fuse differently);
+      * tests/frontend_model.py, a float64 numpy restatement of reference NRD.hlsli:300-1130 written without the header: packers, unpackers, material
+        factors, SG / SH resolves, re-jitter.
+    Neither expected-value side includes NRD.hip.h."""
+    import ctypes as C
+
+    import frontend_model as M
+    from oracle import driver as oracle_driver
+
+    _build()
+    count = 131072
+    path = os.path.join(os.path.dirname(EXE), "frontend_dump.bin")
+    r = subprocess.run([EXE, "--dump", path, str(count)], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout + r.stderr
+    d = _load_dump(path, count)
+    os.remove(path)
+    f64 = {k: v.astype(np.float64) for k, v in d.items() if k != "word"}
+    scal = lambda k: f64[k][:, 0]
+
+    # ---- vs the oracle (float32, the arithmetic of the passes; IEEE mode: the header knows nothing about v_rsq_f32 / v_exp_f32)
+    lib = oracle_driver.load()
+    prev = oracle_driver.set_ieee_mode(True)
+    try:
+        def ora(op, cols, nout):
+            a = np.ascontiguousarray(np.concatenate(cols, axis=1), dtype=np.float32)
+            o = np.zeros((count, nout), dtype=np.float32)
+            lib.oracle_frontend(op, a.ctypes.data, a.shape[1], o.ctypes.data, nout, count)
+            return o
+
+        word = ora(0, [d["N"], d["roughness"], d["materialID_in"]], 1).view(np.uint32)[:, 0]
+        assert np.array_equal(word, d["word"][:, 0]), "R10G10B10A2 words differ in %d of %d samples" % (int((word != d["word"][:, 0]).sum()), count)
+        unpacked = ora(1, [d["word"].view(np.float32)], 5)
+        assert _ulps(unpacked[:, :4], d["unpackedNR"]).max() <= 4 and np.array_equal(unpacked[:, 4], d["materialID"][:, 0])
+        nhd = ora(2, [d["hitDist"], d["viewZ"], d["roughness"]], 1)
+        assert np.max(np.abs(nhd - d["normHitDist"])) <= 2e-6
+        packed = ora(3, [d["radiance"], d["normHitDist"]], 4)
+        assert _ulps(packed, d["reblurPacked"]).max() <= 2
+        unp = ora(4, [d["reblurPacked"]], 4)
+        assert _ulps(unp, d["reblurUnpacked"]).max() <= 2
+        assert np.array_equal(ora(5, [d["roughness"]], 1), d["shadow"])
+    finally:
+        oracle_driver.set_ieee_mode(prev)
+
+    # ---- vs the float64 model of NRD.hlsli
+    def close(got, want, rel, what, floor=1e-3):
+        err = np.abs(got.astype(np.float64) - want) / np.maximum(np.abs(want), floor)
+        assert np.all(np.isfinite(got)) and err.max() <= rel, "%s: max relative error %.3g (allowed %.3g) at sample %d" % (what, err.max(), rel, int(np.argmax(err.max(axis=-1) if err.ndim > 1 else err)))
+
+    hdp = (3.0, 0.1, 20.0, -25.0)
+    N, V, rad, dirn, rough = f64["N"], f64["V"], f64["radiance"], f64["direction"], scal("roughness")
+    assert np.array_equal(M.store_r10g10b10a2(M.pack_normal_and_roughness(N, rough, scal("materialID_in"))), d["word"][:, 0]) or \
+        int((M.store_r10g10b10a2(M.pack_normal_and_roughness(N, rough, scal("materialID_in"))) != d["word"][:, 0]).sum()) <= count // 2000  # float64 vs float32 at quantisation ties
+    un, mat = M.unpack_normal_and_roughness(M.load_r10g10b10a2(d["word"][:, 0]))
+    close(d["unpackedNR"], un, 2e-6, "NRD_FrontEnd_UnpackNormalAndRoughness")
+    assert np.array_equal(mat, scal("materialID"))
+    nhd = M.reblur_get_norm_hit_dist(scal("hitDist"), scal("viewZ"), hdp, rough)
+    close(d["normHitDist"][:, 0], nhd, 5e-6, "REBLUR_FrontEnd_GetNormHitDist")
+    nhd32 = scal("normHitDist")
+    close(d["reblurPacked"], M.reblur_pack_radiance_and_norm_hit_dist(rad, nhd32), 2e-6, "REBLUR_FrontEnd_PackRadianceAndNormHitDist")
+    close(d["reblurUnpacked"], M.reblur_unpack_radiance_and_norm_hit_dist(f64["reblurPacked"]), 2e-6, "REBLUR_BackEnd_UnpackRadianceAndNormHitDist")
+    sh0, sh1 = M.reblur_pack_sh(rad, nhd32, dirn)
+    close(d["sh0"], sh0, 2e-6, "REBLUR_FrontEnd_PackSh out0")
+    close(d["sh1"], sh1, 2e-6, "REBLUR_FrontEnd_PackSh out1")
+    r0, r1 = M.relax_pack_sh(rad, scal("hitDist"), dirn)
+    close(d["relaxPacked"], r0, 1e-7, "RELAX_FrontEnd_PackSh out0")
+    close(d["relaxSh1"], r1, 2e-6, "RELAX_FrontEnd_PackSh out1")
+    close(d["dirOcc"], M.reblur_pack_directional_occlusion(dirn, nhd32), 2e-6, "REBLUR_FrontEnd_PackDirectionalOcclusion")
+    occluder = np.where(np.arange(count) % 5 == 0, M.NRD_FP16_MAX, scal("hitDist"))
+    close(d["penumbra"][:, 0], M.sigma_pack_penumbra(occluder, np.float64(np.float32(0.02))), 1e-6, "SIGMA_FrontEnd_PackPenumbra (directional)")
+    close(d["penumbraLocal"][:, 0], M.sigma_pack_penumbra_local(scal("hitDist"), scal("hitDist") + 10.0, 0.5), 2e-6, "SIGMA_FrontEnd_PackPenumbra (local)")
+    close(d["translucency"], M.sigma_pack_translucency(occluder, f64["albedo"]), 1e-7, "SIGMA_FrontEnd_PackTranslucency")
+    close(d["shadow"][:, 0], rough * rough, 1e-6, "SIGMA_BackEnd_UnpackShadow")
+    df, sf = M.material_factors(N, V, f64["albedo"], f64["Rf0"], rough)
+    close(d["diffFactor"], df, 2e-5, "NRD_MaterialFactors diff")
+    close(d["specFactor"], sf, 2e-5, "NRD_MaterialFactors spec")
+    sg = M.unpack_sh(f64["sh0"], f64["sh1"])  # the SG the device resolved: from its own packed words (float32 inputs, float64 arithmetic)
+    close(d["sgColor"], M.sg_extract_color(sg), 2e-6, "NRD_SG_ExtractColor")
+    close(d["sgDir"], M.sg_extract_direction(sg), 2e-6, "NRD_SG_ExtractDirection")
+    close(d["sgDiffuse"], M.sg_resolve_diffuse(sg, N), 1e-4, "NRD_SG_ResolveDiffuse")
+    close(d["sgSpecular"], M.sg_resolve_specular(sg, N, V, rough), 2e-3, "NRD_SG_ResolveSpecular", floor=1e-2)  # exp(d - a - b) with sharpness up to 2e6: float32 cancellation
+    close(d["shDiffuse"], M.sh_resolve_diffuse(sg, N), 1e-5, "NRD_SH_ResolveDiffuse")
+    close(d["shSpecular"], M.sh_resolve_specular(sg, N, V, rough), 1e-4, "NRD_SH_ResolveSpecular")
+    Z = scal("viewZ")
+    Ze, Zw = (d["viewZ"][:, 0] * np.float32(1.001)).astype(np.float64), (d["viewZ"][:, 0] * np.float32(0.999)).astype(np.float64)
+    rj = M.sg_rejitter(sg, sg, f64["Rf0"], V, rough, Z, Ze, Zw, Z, Z, N, N, f64["Nw"], N, N)
+    near_threshold = np.abs(np.abs(Ze - Z) - M.NRD_REJITTER_VIEWZ_THRESHOLD * np.abs(Z) / (np.abs(M.dot(N, V)) * 0.95 + 0.05)) < 1e-5 * np.abs(Z)  # float32 decides the 4-neighbour test differently
+    ok = ~near_threshold & (np.abs(M.dot(f64["Nw"], N)) > 1e-6)
+    close(d["rejitter"][ok], rj[ok], 5e-4, "NRD_SG_ReJitter")

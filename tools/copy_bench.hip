@@ -4,12 +4,13 @@
 
 #include <cstdio>
 
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4))); // a native vector: what the nontemporal builtins accept
 template <int UNROLL, bool NT>
-__global__ __launch_bounds__(256) void Copy(const uint4* __restrict__ src, uint4* __restrict__ dst, size_t count) {
+__global__ __launch_bounds__(256) void Copy(const u32x4* __restrict__ src, u32x4* __restrict__ dst, size_t count) {
     const size_t stride = (size_t)gridDim.x * 256u;
     size_t i = (size_t)blockIdx.x * 256u + threadIdx.x;
     for (; i + (UNROLL - 1) * stride < count; i += UNROLL * stride) {
-        uint4 v[UNROLL];
+        u32x4 v[UNROLL];
 #pragma unroll
         for (int k = 0; k < UNROLL; k++)
             v[k] = NT ? __builtin_nontemporal_load(src + i + k * stride) : src[i + k * stride];
@@ -26,7 +27,7 @@ __global__ __launch_bounds__(256) void Copy(const uint4* __restrict__ src, uint4
 }
 
 template <int UNROLL, bool NT>
-static void Run(const char* name, const uint4* src, uint4* dst, size_t bytes, int blocks) {
+static void Run(const char* name, const u32x4* src, u32x4* dst, size_t bytes, int blocks) {
     hipEvent_t a, b;
     hipEventCreate(&a), hipEventCreate(&b);
     for (int i = 0; i < 3; i++)
@@ -44,7 +45,7 @@ static void Run(const char* name, const uint4* src, uint4* dst, size_t bytes, in
 
 int main() {
     for (size_t bytes : {(size_t)1 << 30, (size_t)256 << 20}) {
-        uint4 *src, *dst;
+        u32x4 *src, *dst;
         hipMalloc(&src, bytes), hipMalloc(&dst, bytes);
         hipMemset(src, 1, bytes);
         printf("---- %zu MiB\n", bytes >> 20);

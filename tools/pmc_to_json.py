@@ -1,5 +1,6 @@
 """Folds the FETCH_SIZE / WRITE_SIZE summaries written by tools/pmc_run.sh into profiles/pmc_traffic.json (read by bench.py).
-usage: python tools/pmc_to_json.py <workload key, e.g. REBLUR_DIFFUSE_SPECULAR_2560x1440> <fetch summary.txt> <write summary.txt> <source note>"""
+usage: python tools/pmc_to_json.py <workload key, e.g. REBLUR_DIFFUSE_SPECULAR_2560x1440> <fetch summary.txt> <write summary.txt> <source note> [<SQ summary.txt>]
+The optional SQ summary (the counter set with SQ_INSTS_VALU and SQ_WAVES) adds the executed VALU instructions per wave and the waves per launch."""
 import json
 import os
 import re
@@ -21,8 +22,25 @@ def parse(path):
     return out
 
 
+def parse_columns(path):
+    """{kernel: {counter: value}} of a multi-counter summary (tools/pmc_summary.py: header row names the counters, truncated to 16 characters)"""
+    lines = open(path).read().splitlines()
+    header = lines[0].split()
+    counters = header[3:]
+    out = {}
+    for line in lines[1:]:
+        fields = line.rsplit(None, len(counters) + 2)
+        if len(fields) == len(counters) + 3:
+            try:
+                out[fields[0].strip()] = dict(zip(counters, [float(v) if v != "-" else None for v in fields[3:]]))
+            except ValueError:
+                pass
+    return out
+
+
 def main():
     key, fetch_file, write_file, source = sys.argv[1:5]
+    sq = parse_columns(sys.argv[5]) if len(sys.argv) > 5 else {}
     family = {"REBLUR_DIFFUSE_SPECULAR": "REBLUR_DiffuseSpecular_", "RELAX_DIFFUSE_SPECULAR_SH": "RELAX_DiffuseSpecularSh_", "RELAX_DIFFUSE_SPECULAR": "RELAX_DiffuseSpecular_"}[key.rsplit("_", 1)[0]]
     fetch, write = parse(fetch_file), parse(write_file)
     kernels = {}
@@ -31,8 +49,11 @@ def main():
             if frag in kname:
                 shader = (family.split("_")[0] + "_" + suffix) if suffix == "ClassifyTiles.cs" else family + suffix
                 w = next((v for k, v in write.items() if k == kname), None)
-                if w is not None:
+                if w is not None and shader not in kernels:  # (several variants of one pass, e.g. the a-trous steps: the first = longest-running one)
                     kernels[shader] = {"FETCH_SIZE_KiB": f, "WRITE_SIZE_KiB": w}
+                    c = sq.get(kname)
+                    if c and c.get("SQ_INSTS_VALU") and c.get("SQ_WAVES"):
+                        kernels[shader].update({"SQ_INSTS_VALU": c["SQ_INSTS_VALU"], "SQ_WAVES": c["SQ_WAVES"], "valu_per_wave": round(c["SQ_INSTS_VALU"] / c["SQ_WAVES"], 1)})
                 break
     path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles", "pmc_traffic.json")
     data = json.load(open(path)) if os.path.exists(path) else {}
