@@ -222,20 +222,17 @@ __global__ __launch_bounds__(256) void EvalNumericsKernel(uint32_t op, const flo
     out[i] = r;
 }
 
-// ---- streaming copy probe (include/NRDHip.h: nrdHipMeasureCopyBandwidth): 16 bytes per lane, four independent loads in flight per lane, grid-stride
-// over 2048 workgroups (8 per CU: cdna_hip_programming.md guideline 11)
+// ---- streaming copy probe (include/NRDHip.h: nrdHipMeasureCopyBandwidth): one 16-byte element per lane, the grid covers the buffer -- the shape the
+// pass kernels have (one pixel per lane, no grid-stride loop). tools/copy_bench.hip compared the alternatives on the device (profiles/r03_e_copy_bench.txt):
+// this one reaches 6.2-6.3 TB/s on 1 GiB, grid-stride loops over 1024-16384 workgroups 4.1-5.4 TB/s, hipMemcpyAsync 4.8-5.5 TB/s.
 __global__ __launch_bounds__(256) void CopyProbeKernel(const uint4* __restrict__ src, uint4* __restrict__ dst, uint64_t count) {
-    const uint64_t stride = (uint64_t)gridDim.x * 256u;
-    uint64_t i = (uint64_t)blockIdx.x * 256u + threadIdx.x;
-    for (; i + 3 * stride < count; i += 4 * stride) {
-        const uint4 a = src[i], b = src[i + stride], c = src[i + 2 * stride], d = src[i + 3 * stride];
-        dst[i] = a, dst[i + stride] = b, dst[i + 2 * stride] = c, dst[i + 3 * stride] = d;
-    }
-    for (; i < count; i += stride)
+    const uint64_t i = (uint64_t)blockIdx.x * 256u + threadIdx.x;
+    if (i < count)
         dst[i] = src[i];
 }
 void LaunchCopyProbe(const void* src, void* dst, uint64_t bytes, hipStream_t stream) {
-    hipLaunchKernelGGL(CopyProbeKernel, dim3(2048), dim3(256), 0, stream, (const uint4*)src, (uint4*)dst, bytes / 16u);
+    const uint64_t count = bytes / 16u;
+    hipLaunchKernelGGL(CopyProbeKernel, dim3((unsigned)((count + 255u) / 256u)), dim3(256), 0, stream, (const uint4*)src, (uint4*)dst, count);
 }
 
 void LaunchEvalNumerics(uint32_t op, const float* in1, const float* in2, float* out, uint32_t count, hipStream_t stream) {

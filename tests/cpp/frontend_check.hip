@@ -109,13 +109,18 @@ static void Append(std::vector<uint32_t>& row, float2 v) { Append(row, v.x), App
 static void Append(std::vector<uint32_t>& row, float3 v) { Append(row, v.x), Append(row, v.y), Append(row, v.z); }
 static void Append(std::vector<uint32_t>& row, float4 v) { Append(row, v.x), Append(row, v.y), Append(row, v.z), Append(row, v.w); }
 
-static int Dump(const char* path, uint32_t count) {
-    Result* dOut = nullptr;
-    CHECK(hipMalloc((void**)&dOut, sizeof(Result) * (size_t)count) == hipSuccess);
-    hipLaunchKernelGGL(EvaluateKernel, dim3((count + 255) / 256), dim3(256), 0, 0, dOut, count);
+static int Dump(const char* path, uint32_t count, bool onHost) {
     std::vector<Result> dev(count);
-    CHECK(hipMemcpy(dev.data(), dOut, sizeof(Result) * (size_t)count, hipMemcpyDeviceToHost) == hipSuccess);
-    (void)hipFree(dOut);
+    if (onHost) { // (debugging the comparison without a GPU; the test dumps the DEVICE results)
+        for (uint32_t i = 0; i < count; i++)
+            dev[i] = Evaluate(i);
+    } else {
+        Result* dOut = nullptr;
+        CHECK(hipMalloc((void**)&dOut, sizeof(Result) * (size_t)count) == hipSuccess);
+        hipLaunchKernelGGL(EvaluateKernel, dim3((count + 255) / 256), dim3(256), 0, 0, dOut, count);
+        CHECK(hipMemcpy(dev.data(), dOut, sizeof(Result) * (size_t)count, hipMemcpyDeviceToHost) == hipSuccess);
+        (void)hipFree(dOut);
+    }
     FILE* fp = fopen(path, "wb");
     CHECK(fp != nullptr);
     std::vector<uint32_t> row;
@@ -138,8 +143,8 @@ static int Dump(const char* path, uint32_t count) {
 }
 
 int main(int argc, char** argv) {
-    if (argc > 3 && !strcmp(argv[1], "--dump"))
-        return Dump(argv[2], (uint32_t)atoi(argv[3]));
+    if (argc > 3 && (!strcmp(argv[1], "--dump") || !strcmp(argv[1], "--dump-host")))
+        return Dump(argv[2], (uint32_t)atoi(argv[3]), !strcmp(argv[1], "--dump-host"));
     const bool noGpu = argc > 1 && !strcmp(argv[1], "--no-gpu");
     const uint32_t count = 4096;
     std::vector<Result> host(count);

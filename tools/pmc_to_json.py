@@ -41,7 +41,8 @@ def parse_columns(path):
 def main():
     key, fetch_file, write_file, source = sys.argv[1:5]
     sq = parse_columns(sys.argv[5]) if len(sys.argv) > 5 else {}
-    family = {"REBLUR_DIFFUSE_SPECULAR": "REBLUR_DiffuseSpecular_", "RELAX_DIFFUSE_SPECULAR_SH": "RELAX_DiffuseSpecularSh_", "RELAX_DIFFUSE_SPECULAR": "RELAX_DiffuseSpecular_"}[key.rsplit("_", 1)[0]]
+    base = key[: -len("_nosky")] if key.endswith("_nosky") else key
+    family = {"REBLUR_DIFFUSE_SPECULAR": "REBLUR_DiffuseSpecular_", "RELAX_DIFFUSE_SPECULAR_SH": "RELAX_DiffuseSpecularSh_", "RELAX_DIFFUSE_SPECULAR": "RELAX_DiffuseSpecular_"}[base.rsplit("_", 1)[0]]
     fetch, write = parse(fetch_file), parse(write_file)
     kernels = {}
     for kname, f in fetch.items():
