@@ -194,8 +194,11 @@ NRD_D float2 GetRelaxedRoughnessWeightParams(float m, float fraction = 1.0f, flo
 }
 NRD_D float ExpApprox(float x) { return Rcp(x * x - x + 1.0f); }
 NRD_D float ComputeExponentialWeight(float x, float px, float py) { return ExpApprox(-NRD_EXP_WEIGHT_DEFAULT_SCALE * Abs(x * px + py)); }
-NRD_D float ComputeNonExponentialWeight(float x, float px, float py) { return SmoothStep(1.0f, 0.0f, Abs(x * px + py)); }
-NRD_D float ComputeNonExponentialWeightWithSigma(float x, float px, float py, float sigma) { return SmoothStep(1.0f, 0.0f, Abs(x * px + py) - sigma * px); }
+// SmoothStep(1, 0, t) = SmoothStep01(LinearStep(1, 0, t)) and LinearStep(1, 0, t) = saturate(Div(t - 1, -1)) = saturate(1 - t) EXACTLY: v_rcp_f32(-1) is -1
+// and negation commutes with rounding. Written as 1 - t it is one instruction (a subtraction with the clamp modifier) instead of three, same bits.
+NRD_D float SmoothStepOneToZero(float t) { return SmoothStep01(1.0f - t); }
+NRD_D float ComputeNonExponentialWeight(float x, float px, float py) { return SmoothStepOneToZero(Abs(x * px + py)); }
+NRD_D float ComputeNonExponentialWeightWithSigma(float x, float px, float py, float sigma) { return SmoothStepOneToZero(Abs(x * px + py) - sigma * px); }
 NRD_D float ComputeWeight(float x, float px, float py) { return ComputeNonExponentialWeight(x, px, py); }
 NRD_D float GetGaussianWeight(float r) { return Exp(-0.66f * r * r); }
 NRD_D float GetEncodingAwareNormalWeight(float3 Ncurr, float3 Nprev, float maxAngle, float curvatureAngle, float thresholdAngle) {
