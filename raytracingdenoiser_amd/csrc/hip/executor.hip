@@ -797,6 +797,7 @@ static uint32_t ExecuteRange(NrdHipExecutor* e, const nrd::DispatchDesc* descs, 
     }
     const bool shiftedRect = e->originX != 0 || e->originY != 0;
     std::vector<uint32_t> shiftTypes; // guide slots of this list that get a rect-at-origin twin
+    std::vector<uint32_t> newTwins;   // twins allocated by this call: cleared on the stream once the pre-flight has passed (nothing is enqueued before it)
     bool writesMv = false;
     if (shiftedRect) {
         for (uint32_t i = 0; i < dispatchDescsNum; i++)
@@ -822,7 +823,7 @@ static uint32_t ExecuteRange(NrdHipExecutor* e, const nrd::DispatchDesc* descs, 
                     twin.ptr = nullptr;
                     if (hipMalloc((void**)&twin.ptr, (size_t)twin.pitch * (size_t)twin.h) != hipSuccess)
                         return e->Fail(nrd::Result::FAILURE, "nrdHipExecuteDispatches: cannot allocate a shifted-rect guide plane");
-                    (void)hipMemsetAsync(twin.ptr, 0, (size_t)twin.pitch * (size_t)twin.h, e->stream);
+                    newTwins.push_back(t);
                     e->decodedFresh = false;
                 }
                 shiftTypes.push_back(t);
@@ -973,12 +974,15 @@ static uint32_t ExecuteRange(NrdHipExecutor* e, const nrd::DispatchDesc* descs, 
     };
 
     // ---- pre-flight: every pass of the range must have a launcher, bound resources and pass its own support checks BEFORE anything is enqueued
-    // (the reference integration's contract: a Denoise call either runs completely or not at all). In graph mode the same walk collects the launches.
+    // (the reference integration's contract: a Denoise call either runs completely or not at all). The same walk records every launch (kernel, grid,
+    // arguments); the records are then either turned into / matched against a graph or launched one by one -- the launchers run once per frame.
     const bool useGraph = e->graphMode && !e->profiling;
     LaunchRecorder recorder;
-    recorder.keep = useGraph;
+    recorder.keep = true;
     if (prepareNow)
         decode(&recorder);
+    const uint32_t prepareRecords = (uint32_t)recorder.records.size(); // shift / decode kernels in front of the first pass
+    std::vector<uint32_t> recordEnd(count); // records [recordEnd[k-1], recordEnd[k]) belong to pass first + k
     for (uint32_t i = first; i < first + count; i++) {
         const nrd::DispatchDesc& d = descs[i];
         if (d.pipelineIndex >= e->launchers.size())
@@ -995,23 +999,31 @@ static uint32_t ExecuteRange(NrdHipExecutor* e, const nrd::DispatchDesc* descs, 
         args.recorder = &recorder;
         if (const char* err = launch(args))
             return e->Fail(nrd::Result::UNSUPPORTED, std::string(err) + " [pass " + passName(d) + "; nothing was launched]");
+        recordEnd[i - first] = (uint32_t)recorder.records.size();
     }
-
+    const uint32_t passRecordsEnd = (uint32_t)recorder.records.size();
     if (shiftBackMv)
         shiftGuides(&recorder, true);
+
+    // ---- from here on work is enqueued
+    for (uint32_t t : newTwins)
+        (void)hipMemsetAsync(e->shifted[t].ptr, 0, (size_t)e->shifted[t].pitch * (size_t)e->shifted[t].h, e->stream);
 
     if (useGraph) {
         uint32_t r = LaunchAsGraph(e, recorder.records);
         if (r != (uint32_t)nrd::Result::SUCCESS)
             return r;
     } else {
-        if (prepareNow)
-            decode(nullptr);
+        auto enqueue = [&](uint32_t begin, uint32_t end) -> hipError_t {
+            for (uint32_t k = begin; k < end; k++)
+                recorder.records[k].launch(recorder.records[k], e->stream);
+            return hipGetLastError(); // launch-configuration errors surface here (no synchronisation)
+        };
+        if (enqueue(0, prepareRecords) != hipSuccess) // outside the timing bracket of the first pass
+            return e->Fail(nrd::Result::FAILURE, "HIP launch failed while preparing the guide planes");
         for (uint32_t i = first; i < first + count; i++) {
             const nrd::DispatchDesc& d = descs[i];
-            PassArgs args = {};
-            std::string msg;
-            (void)fill(i, args, msg);
+            const uint32_t from = i == first ? prepareRecords : recordEnd[i - first - 1];
             NrdHipExecutor::Bracket bracket = {};
             if (e->profiling) {
                 bracket.start = AcquireEvent(e);
@@ -1019,19 +1031,16 @@ static uint32_t ExecuteRange(NrdHipExecutor* e, const nrd::DispatchDesc* descs, 
                 bracket.pipelineIndex = d.pipelineIndex;
                 (void)hipEventRecord(bracket.start, e->stream);
             }
-            const char* err = e->launchers[d.pipelineIndex](args);
+            hipError_t launchError = enqueue(from, recordEnd[i - first]);
             if (e->profiling) {
                 (void)hipEventRecord(bracket.stop, e->stream);
                 e->brackets.push_back(bracket);
             }
-            if (err) // cannot happen after the pre-flight
-                return e->Fail(nrd::Result::UNSUPPORTED, err);
-            hipError_t launchError = hipGetLastError(); // launch-configuration errors surface here (no synchronisation)
             if (launchError != hipSuccess)
                 return e->Fail(nrd::Result::FAILURE, "HIP launch failed in pass " + passName(d) + ": " + hipGetErrorString(launchError));
         }
-        if (shiftBackMv)
-            shiftGuides(nullptr, true);
+        if (enqueue(passRecordsEnd, (uint32_t)recorder.records.size()) != hipSuccess) // the IN_MV twin back into the user's plane
+            return e->Fail(nrd::Result::FAILURE, "HIP launch failed while copying IN_MV back");
     }
     if (decoded.ptr || shiftedRect)
         e->decodedFresh = first + count < dispatchDescsNum; // the list is complete: the next call belongs to another frame

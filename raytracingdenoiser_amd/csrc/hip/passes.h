@@ -8,6 +8,7 @@
 
 #include <cstdlib>
 #include <cstring>
+#include <utility>
 #include <vector>
 
 // Tuning knobs of A/B builds (tools/build_variant.py -DNRD_WAVES_<KERNEL>=n): the waves-per-SIMD target handed to the register allocator through
@@ -53,6 +54,7 @@ struct LaunchRecord {
     dim3 grid, block;
     std::vector<uint8_t> args;     // kernel arguments, each copied to a 16-byte aligned offset
     std::vector<uint32_t> offsets; // offset of every argument inside args
+    void (*launch)(const LaunchRecord&, hipStream_t); // typed launch of this very record (eager path: the launchers themselves run once, in the pre-flight)
 };
 struct LaunchRecorder {
     bool keep = false; // false = pre-flight only: launches are counted, not stored
@@ -98,6 +100,14 @@ inline void PackArg(LaunchRecord& r, const T& v) {
     memcpy(r.args.data() + off, &v, sizeof(T));
     r.offsets.push_back((uint32_t)off);
 }
+template <typename... KArgs, size_t... I>
+inline void ReplayImpl(const LaunchRecord& r, hipStream_t stream, std::index_sequence<I...>) {
+    hipLaunchKernelGGL((void (*)(KArgs...))r.func, r.grid, r.block, 0, stream, (*(const KArgs*)(r.args.data() + r.offsets[I]))...);
+}
+template <typename... KArgs>
+inline void Replay(const LaunchRecord& r, hipStream_t stream) {
+    ReplayImpl<KArgs...>(r, stream, std::index_sequence_for<KArgs...>());
+}
 } // namespace detail
 
 // every pass launch goes through here: launcher(args) -> LaunchPass(args, kernel, grid, block, kernel arguments...)
@@ -114,6 +124,7 @@ inline void LaunchPass(const PassArgs& a, void (*kernel)(KArgs...), dim3 grid, d
     r.func = (const void*)kernel;
     r.grid = grid;
     r.block = block;
+    r.launch = &detail::Replay<KArgs...>;
     (void)std::initializer_list<int>{(detail::PackArg<KArgs>(r, KArgs(args)), 0)...};
     a.recorder->records.push_back(std::move(r));
 }
