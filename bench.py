@@ -317,6 +317,7 @@ def main():
     fence()
     elapsed = time.perf_counter() - t0
     graph_stats = ex.graph_stats()
+    tile_fallback = ex.tile_fallback_stats()  # REBLUR TemporalAccumulation: tiles of the last frame whose surface-motion window did not fit the LDS window
 
     # ---- per-pass durations for the roofline: the SAME frames once more with HIP events around every dispatch on the executor's stream (eager launches:
     # events cannot bracket the nodes of a graph). Outside the timed region; the history carried over differs, the work per pass does not.
@@ -399,6 +400,7 @@ def main():
         "dtype": "f32",
         "data": "synthetic",
         "numerics": "exact",  # one library, one arithmetic: what is timed here is bit-identical to the CPU oracle (see "parity")
+        "tile_fallback": {"tiles": tile_fallback[0], "of": tile_fallback[1], "what": "32x8-pixel tiles of the last frame left to the plain TemporalAccumulation kernel (LDS window too small)"},
         "launch": "eager" if args.no_graph else "hipGraph (%d launches, %d builds, %d node updates in the run)" % graph_stats,
         "rccl_ranks": world if distributed and backend == "nccl" else (0 if not distributed else None),
         "config": {"workload": "%s %dx%d, %s, analytic scene%s + 1rpp noise, moving camera" % (name, W, H, "default settings" if overrides is None else "settings %s" % overrides,

@@ -133,6 +133,11 @@ uint32_t nrdHipCollectPassTimings(NrdHipExecutor* executor, uint32_t* pipelineIn
 uint32_t nrdHipSetGraphMode(NrdHipExecutor* executor, uint32_t enable);
 uint32_t nrdHipGetGraphStats(const NrdHipExecutor* executor, uint64_t* graphLaunches, uint64_t* graphBuilds, uint64_t* nodeUpdates);
 
+// Diagnostics of the passes that run as a fast kernel plus a fallback kernel (REBLUR TemporalAccumulation: the surface-motion footprints of a 32x8-pixel tile come
+// from one LDS-staged window of the previous frame; a tile whose window would be too large is left to the plain kernel -- DESIGN.md section 3). Reads the tile
+// flags of the LAST frame back (synchronises the stream): tiles the fallback kernel processed and tiles in total. Results never depend on the split.
+uint32_t nrdHipGetTileFallbackStats(NrdHipExecutor* executor, uint32_t* fallbackTiles, uint32_t* totalTiles);
+
 // Numerics mode of the library (DESIGN.md "Numerics"). Always 0 = the pinned arithmetic: IEEE + - * and source-determined fused multiply-adds, division /
 // sqrt / exp2 / log2 through v_rcp_f32 / v_sqrt_f32 / v_rsq_f32 / v_exp_f32 / v_log_f32 -- bit-identical to the CPU oracle, which emulates those five
 // instructions from measured tables. (Round 2 also shipped a faster, inexact build that answered 1; it is gone: one library, one arithmetic.)

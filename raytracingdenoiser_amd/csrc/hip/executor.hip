@@ -96,6 +96,7 @@ struct NrdHipExecutor {
     std::vector<Plane> permanent, transient;
     Plane decodedNormalRoughness = {}; // internal float4 cache of IN_NORMAL_ROUGHNESS (not an NRD pool plane; own allocation)
     Plane worldPosViewZ = {};          // internal float4 scratch of the RELAX a-trous chain (world position + viewZ per pixel)
+    Plane tileFlags = {};              // one byte per 32x8-pixel workgroup tile: hand-over between the two kernels of a split pass (kernels_reblur_ta.hip "window")
     Plane viewPos = {};                // internal float4 guide plane of the REBLUR lists (decoded normal + viewZ per pixel)
     std::vector<nrd::Format> permanentFormat, transientFormat;
 
@@ -203,6 +204,18 @@ static uint32_t CreateExecutorImpl(void* instance, uint16_t resourceWidth, uint1
             p.ptr = e->arena + (uintptr_t)p.ptr;
     }
 
+    // per-tile flags of the passes that run as a fast kernel plus a fallback kernel for the tiles the fast one declines (tiny: one byte per 32x8 pixels)
+    e->tileFlags.w = (resourceWidth + 31) / 32;
+    e->tileFlags.h = (resourceHeight + 7) / 8;
+    e->tileFlags.pitch = (uint32_t)e->tileFlags.w;
+    if (hipMalloc((void**)&e->tileFlags.ptr, (size_t)e->tileFlags.pitch * (size_t)e->tileFlags.h) != hipSuccess) {
+        if (e->arena && e->ownsArena)
+            (void)hipFree(e->arena);
+        delete e;
+        return (uint32_t)nrd::Result::FAILURE;
+    }
+    (void)hipMemsetAsync(e->tileFlags.ptr, 0, (size_t)e->tileFlags.pitch * (size_t)e->tileFlags.h, e->stream);
+
     // pipeline index -> launcher
     e->launchers.assign(desc.pipelinesNum, nullptr);
     const PassEntry* tables[5];
@@ -273,6 +286,8 @@ extern "C" __attribute__((visibility("default"))) void nrdHipDestroyExecutor(Nrd
         (void)hipFree(e->worldPosViewZ.ptr);
     if (e->viewPos.ptr)
         (void)hipFree(e->viewPos.ptr);
+    if (e->tileFlags.ptr)
+        (void)hipFree(e->tileFlags.ptr);
     for (Plane& p : e->shifted)
         if (p.ptr)
             (void)hipFree(p.ptr);
@@ -966,6 +981,7 @@ static uint32_t ExecuteRange(NrdHipExecutor* e, const nrd::DispatchDesc* descs, 
         args.decodedNormalRoughness = decoded;
         args.worldPosViewZ = worldPos;
         args.viewPos = viewPos;
+        args.tileFlags = e->tileFlags;
         if (rowBegin && rowBegin[i] >= 0) {
             args.rowBegin = rowBegin[i];
             args.rowEnd = rowEnd[i];
@@ -1048,6 +1064,22 @@ static uint32_t ExecuteRange(NrdHipExecutor* e, const nrd::DispatchDesc* descs, 
     hipError_t err = hipGetLastError();
     if (err != hipSuccess)
         return e->Fail(nrd::Result::FAILURE, std::string("HIP launch failed: ") + hipGetErrorString(err));
+    return (uint32_t)nrd::Result::SUCCESS;
+}
+
+extern "C" __attribute__((visibility("default"))) uint32_t nrdHipGetTileFallbackStats(NrdHipExecutor* e, uint32_t* fallbackTiles, uint32_t* totalTiles) {
+    if (!e || !e->tileFlags.ptr)
+        return (uint32_t)nrd::Result::INVALID_ARGUMENT;
+    std::vector<uint8_t> host((size_t)e->tileFlags.pitch * (size_t)e->tileFlags.h);
+    if (hipStreamSynchronize(e->stream) != hipSuccess || hipMemcpy(host.data(), e->tileFlags.ptr, host.size(), hipMemcpyDeviceToHost) != hipSuccess)
+        return e->Fail(nrd::Result::FAILURE, "nrdHipGetTileFallbackStats: cannot read the tile flags back");
+    uint32_t n = 0;
+    for (uint8_t f : host)
+        n += f == 1 ? 1u : 0u;
+    if (fallbackTiles)
+        *fallbackTiles = n;
+    if (totalTiles)
+        *totalTiles = (uint32_t)host.size();
     return (uint32_t)nrd::Result::SUCCESS;
 }
 

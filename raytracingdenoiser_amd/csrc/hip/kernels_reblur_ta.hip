@@ -11,6 +11,7 @@
 // plane) and the accumulation itself. The kernel is latency/ALU bound, not HBM bound: ~66 B/px are read and 28 B/px
 // written against several hundred dependent VALU ops per pixel, so occupancy (VGPRs) is the lever, not bytes.
 #include "passes.h"
+#include <climits>
 #include "reblur_device.h"
 
 namespace nrdhip {
@@ -22,7 +23,16 @@ constexpr int BUF_X = TILE_X + 2 * BORDER; // 34
 constexpr int BUF_Y = TILE_Y + 2 * BORDER; // 10
 constexpr int BUF_STRIDE = BUF_X + 1;      // 35 float4 slots per row
 
+// The surface-motion window (MODE 1, below): the texels of the previous frame a workgroup's pixels reproject to, staged in LDS
+#ifndef NRD_TA_WIN_H
+#define NRD_TA_WIN_W 64 // at most 64: one lane per column when the window is filled
+#define NRD_TA_WIN_H 16
+#endif
+constexpr int WIN_W = NRD_TA_WIN_W;
+constexpr int WIN_H = NRD_TA_WIN_H;
+
 struct TaPlanes {
+    Plane tileFlags; // executor scratch, one byte per workgroup tile (passes.h): set by the window kernel for the tiles it leaves to the fallback kernel
     Plane tiles, normalRoughness, viewZ, mv, prevViewZ, prevNormalRoughness, prevInternalData;
     Plane decodedNR; // executor's float4 cache of normalRoughness (reblur_device.h "decoded guides")
     Plane disocclusionThresholdMix, diffConfidence, specConfidence; // R8_UNORM user inputs; dummies unless the gHas* flags are set
@@ -31,12 +41,55 @@ struct TaPlanes {
     Plane inDiffSh, inSpecSh, historyDiffSh, historySpecSh, outDiffSh, outSpecSh; // SH family (RGBA16F)
 };
 
+// MODE 1: the two-step fetches of reblur_device.h with the texels taken from the LDS window instead of being requested from memory. A footprint on the border of
+// the plane needs no special case: texel (i, j) is the texel at the clamped coordinate (h.x[i], h.y[j]) -- what FetchHistoryGeneric reads one by one -- and
+// the blend of the row-loaded path is the same arithmetic as the generic one.
+NRD_D void WindowHistoryTexels(const HistoryFilter& h, const uint2* win, int wx0, int wy0, HistoryTexelsRGBA16F& t) {
+    int xo[4], yo[4];
+#pragma unroll
+    for (int i = 0; i < 4; i++)
+        xo[i] = h.x[i] - wx0, yo[i] = (h.y[i] - wy0) * WIN_W;
+    const uint2 a0 = win[yo[0] + xo[1]], a1 = win[yo[0] + xo[2]];
+    const uint2 b0 = win[yo[1] + xo[0]], b1 = win[yo[1] + xo[1]], b2 = win[yo[1] + xo[2]], b3 = win[yo[1] + xo[3]];
+    const uint2 c0 = win[yo[2] + xo[0]], c1 = win[yo[2] + xo[1]], c2 = win[yo[2] + xo[2]], c3 = win[yo[2] + xo[3]];
+    const uint2 d0 = win[yo[3] + xo[1]], d1 = win[yo[3] + xo[2]];
+    t.a = Raw4{a0.x, a0.y, a1.x, a1.y};
+    t.b0 = Raw4{b0.x, b0.y, b1.x, b1.y}, t.b1 = Raw4{b2.x, b2.y, b3.x, b3.y};
+    t.c0 = Raw4{c0.x, c0.y, c1.x, c1.y}, t.c1 = Raw4{c2.x, c2.y, c3.x, c3.y};
+    t.d = Raw4{d0.x, d0.y, d1.x, d1.y};
+    t.loaded = true;
+}
+template <typename T>
+NRD_D void WindowHistoryTexels(const HistoryFilter&, const uint2*, int, int, T&) {} // other storage kinds have no window kernel
+// the 2x2 of the Load-based bilinear path (texels outside the plane read as 0); `shift` selects the half of the window dword (0 diffuse, 16 specular)
+NRD_D void WindowFastTexels(const HistoryFilter& h, const uint32_t* win, int wx0, int wy0, const Plane& dims, int shift, BilinearTexelsR16F& t) {
+    const int x0 = ClampI(h.ox, 0, dims.w - 1) - wx0, x1 = ClampI(h.ox + 1, 0, dims.w - 1) - wx0;
+    const int y0 = (ClampI(h.oy, 0, dims.h - 1) - wy0) * WIN_W, y1 = (ClampI(h.oy + 1, 0, dims.h - 1) - wy0) * WIN_W;
+    const uint32_t f00 = InBounds(dims, h.ox, h.oy) ? (win[y0 + x0] >> shift) & 0xFFFFu : 0u, f10 = InBounds(dims, h.ox + 1, h.oy) ? (win[y0 + x1] >> shift) & 0xFFFFu : 0u;
+    const uint32_t f01 = InBounds(dims, h.ox, h.oy + 1) ? (win[y1 + x0] >> shift) & 0xFFFFu : 0u, f11 = InBounds(dims, h.ox + 1, h.oy + 1) ? (win[y1 + x1] >> shift) & 0xFFFFu : 0u;
+    t.r0 = f00 | (f10 << 16);
+    t.r1 = f01 | (f11 << 16);
+    t.loaded = true;
+}
+template <typename T>
+NRD_D void WindowFastTexels(const HistoryFilter&, const uint32_t*, int, int, const Plane&, int, T&) {}
+
+
 // PERF = REBLUR_PERFORMANCE_MODE: no Catmull-Rom history fetches (REBLUR_USE_CATROM_FOR_*_MOTION_IN_TA = 0, REBLUR_Config.hlsli:196-201)
 // OCC = occlusion family (REBLUR_OCCLUSION): hit-distance-only signals in R16_UNORM, no pre-pass output to read, no DATA2, no firefly suppressor
 // SH = the *_SH denoisers: the SH1 plane of every signal is accumulated with the same speeds (custom-weight bilinear history fetch)
 // WAVES = waves per SIMD the register allocation aims at (__launch_bounds__): 2 for the kernels with a specular signal (3 would need scratch), 3 for
 // the diffuse-only ones (NRD_HIP_TA_WAVES overrides the choice at launch for A/B runs; measurements in DESIGN.md section 3)
-template <bool DIFF, bool SPEC, bool PERF, int KIND, bool SH, int WAVES>
+//
+// MODE 1 = "window" kernel. Everything the pass reads at the surface-motion position -- the 4x4 previous-depth / internal-data footprint, the 2x2 previous
+// normals, the 12 + 12 history texels of the two signals and their fast histories: 320 bytes per pixel through the L1, ~90 VGPRs of requests in flight, and
+// the reason the kernel cannot hold a third wave -- comes from ONE rectangle of the previous frame per workgroup, because neighbouring pixels reproject to
+// neighbouring texels: the bounding box of the (clamped) texel coordinates its pixels need is reduced over the workgroup, the rectangle is copied into LDS
+// with coalesced row loads (each texel once: ~1.7 texels per pixel instead of 44), and the per-pixel code reads the very same texels from there, right
+// where they are used. Results are bit-identical by construction (same texels, same arithmetic). A workgroup whose box does not fit WIN_W x WIN_H
+// (a silhouette with large parallax, a jump of the camera) writes 1 into its byte of P.tileFlags and leaves; MODE 2, the unchanged global-memory kernel
+// behind a flag test, is launched right after and processes exactly those tiles. MODE 0 = the plain kernel (all other signal kinds / the performance mode).
+template <bool DIFF, bool SPEC, bool PERF, int KIND, bool SH, int WAVES, int MODE>
 __global__ __launch_bounds__(TILE_X* TILE_Y, WAVES) void ReblurTemporalAccumulationKernel(ReblurCB cArg, TaPlanes P, RowRange rr) {
     typedef ReblurSignal<KIND> Sig;
     constexpr bool OCC = KIND == SIGNAL_OCCLUSION;
@@ -62,9 +115,19 @@ __global__ __launch_bounds__(TILE_X* TILE_Y, WAVES) void ReblurTemporalAccumulat
             ShareLayout(P.outSpecHitDistForTracking, r16);
     }
     __shared__ float s_HitDistForTracking[BUF_Y * BUF_STRIDE];
+    constexpr int WIN_TEXELS = MODE == 1 ? WIN_W * WIN_H : 1;
+    __shared__ float s_WinZ[WIN_TEXELS];       // packed previous viewZ
+    __shared__ uint32_t s_WinN[WIN_TEXELS];    // packed previous normal / roughness
+    __shared__ uint32_t s_WinId[WIN_TEXELS];   // previous internal data (16 bits)
+    __shared__ uint32_t s_WinFast[WIN_TEXELS]; // fast histories: diffuse in the low, specular in the high half
+    __shared__ uint2 s_WinDiff[WIN_TEXELS], s_WinSpec[WIN_TEXELS]; // RGBA16F history texels, undecoded
+    __shared__ int s_WinBox[4][4];
 
     const int tx = threadIdx.x % TILE_X, ty = threadIdx.x / TILE_X;
     const int blockY = blockIdx.y + rr.firstBlockY;
+    uint8_t* const tileFlag = MODE != 0 ? P.tileFlags.ptr + (uint32_t)blockY * P.tileFlags.pitch + (uint32_t)BlockTileX(rr) : nullptr;
+    if (MODE == 2 && *tileFlag == 0)
+        return; // the window kernel has done this tile (uniform)
     const int px = BlockTileX(rr) * TILE_X + tx, py = blockY * TILE_Y + ty;
     const int rw = cArg.gRectSizeMinusOne.x, rh = cArg.gRectSizeMinusOne.y;
 
@@ -75,8 +138,11 @@ __global__ __launch_bounds__(TILE_X* TILE_Y, WAVES) void ReblurTemporalAccumulat
         for (int t = 0; t < TILE_X / 16; t++)
             if (tileX0 + t < P.tiles.w && tileY < P.tiles.h)
                 anyGeometry |= LoadR8Unorm(P.tiles, tileX0 + t, tileY) == 0.0f;
-        if (!anyGeometry)
+        if (!anyGeometry) {
+            if (MODE == 1 && threadIdx.x == 0)
+                *tileFlag = 0;
             return; // uniform across the block
+        }
 
         const int baseX = BlockTileX(rr) * TILE_X - BORDER, baseY = blockY * TILE_Y - BORDER;
         for (int i = threadIdx.x; i < BUF_X * BUF_Y; i += TILE_X * TILE_Y) {
@@ -100,12 +166,18 @@ __global__ __launch_bounds__(TILE_X* TILE_Y, WAVES) void ReblurTemporalAccumulat
 // memory barrier: the LDS loads cannot be hoisted above it)
 #define NRD_CONSTANTS_PHASE() asm volatile("" ::: "memory")
 
-    if (px > rw || py > rh || py < rr.rowBegin || py >= rr.rowEnd)
+    // MODE 1: every thread stays until the window is filled. A thread without a pixel to denoise runs the prologue on a position clamped into the rect
+    // (lpx, lpy: its loads stay legal, its values are never used), stores nothing and is left out of the bounding box.
+    const int lpx = MODE == 1 ? min(px, rw) : px, lpy = MODE == 1 ? min(py, rh) : py;
+    bool active = !(px > rw || py > rh || py < rr.rowBegin || py >= rr.rowEnd);
+    if (MODE != 1 && !active)
         return;
-    if (LoadR8Unorm(P.tiles, px >> 4, py >> 4) != 0.0f)
+    active = active && LoadR8Unorm(P.tiles, lpx >> 4, lpy >> 4) == 0.0f;
+    if (MODE != 1 && !active)
         return;
-    const float viewZ = UnpackViewZ(c, LoadR32F(P.viewZ, px, py));
-    if (viewZ > c.gDenoisingRange)
+    const float viewZ = UnpackViewZ(c, LoadR32F(P.viewZ, lpx, lpy));
+    active = active && !(viewZ > c.gDenoisingRange);
+    if (MODE != 1 && !active)
         return;
 
     const float2 rectSize = ToF2(c.gRectSize), rectSizeInv = ToF2(c.gRectSizeInv), rectSizePrev = ToF2(c.gRectSizePrev);
@@ -139,7 +211,7 @@ __global__ __launch_bounds__(TILE_X* TILE_Y, WAVES) void ReblurTemporalAccumulat
     Navg = Navg * 0.25f;
 
     float materialID;
-    float4 normalAndRoughness = LoadDecodedNormalRoughness(P.decodedNR, px, py, materialID);
+    float4 normalAndRoughness = LoadDecodedNormalRoughness(P.decodedNR, lpx, lpy, materialID);
     float3 N = Xyz(normalAndRoughness);
     float roughness = normalAndRoughness.w;
 
@@ -156,12 +228,13 @@ __global__ __launch_bounds__(TILE_X* TILE_Y, WAVES) void ReblurTemporalAccumulat
         hitDistForTracking = hitDistForTracking == NRD_INF ? 0.0f : hitDistForTracking;
         hitDistNormalization = GetHitDistanceNormalization(viewZ, hitDistParams, roughness);
         hitDistForTracking *= (OCC || c.gSpecPrepassBlurRadius == 0.0f) ? hitDistNormalization : 1.0f;
-        StoreR16F(P.outSpecHitDistForTracking, px, py, hitDistForTracking);
+        if (active)
+            StoreR16F(P.outSpecHitDistForTracking, px, py, hitDistForTracking);
     }
 
     NRD_CONSTANTS_PHASE();
     // Previous position and surface motion uv
-    float4 mvRaw = LoadRGBA16F(P.mv, px, py);
+    float4 mvRaw = LoadRGBA16F(P.mv, lpx, lpy);
     float3 mv = F3(mvRaw.x, mvRaw.y, mvRaw.z) * F3(c.gMvScale.x, c.gMvScale.y, c.gMvScale.z);
     float3 Xprev = X;
     float2 smbPixelUv = pixelUv + F2(mv.x, mv.y);
@@ -179,69 +252,143 @@ __global__ __launch_bounds__(TILE_X* TILE_Y, WAVES) void ReblurTemporalAccumulat
     // Previous viewZ: 4x4 footprint as four 2x2 quads in (0,0)(1,0)(0,1)(1,1) order
     float2 catromOrigin = GetCatmullRomOrigin(smbPixelUv, rectSizePrev);
     const int cx = (int)catromOrigin.x, cy = (int)catromOrigin.y;
-    const bool footprintInterior = FootprintIsInterior(P.prevViewZ, cx, cy, 4, 4); // the four rows as four 16-byte loads (reblur_device.h "row-vector fetches")
-    // Row loads from an origin clamped into the plane: always legal (pool planes have >= 4 texels per row pitch), exact for an interior footprint. The
-    // few footprints that touch the border are re-read texel by texel AFTER the batch. (Two symmetric arms -- row loads / clamped loads -- would be
-    // merged by the compiler into twelve scalar loads with selected addresses, which is what the row loads are there to avoid.)
-    const int fx4 = max(0, min(cx, P.prevViewZ.w - 4));
-    const int fy0 = ClampI(cy, 0, P.prevViewZ.h - 1), fy1 = ClampI(cy + 1, 0, P.prevViewZ.h - 1), fy2 = ClampI(cy + 2, 0, P.prevViewZ.h - 1), fy3 = ClampI(cy + 3, 0, P.prevViewZ.h - 1);
-    const float4 zr0 = LoadRowR32Fx4(P.prevViewZ, fx4, fy0), zr1 = LoadRowR32Fx4(P.prevViewZ, fx4, fy1), zr2 = LoadRowR32Fx4(P.prevViewZ, fx4, fy2), zr3 = LoadRowR32Fx4(P.prevViewZ, fx4, fy3);
-    // ---- every other request that depends only on the surface-motion position is issued here, in one batch with the depth footprint: the 2x2
-    // previous normals, the 4x4 previous internal data, the history texels of both signals (blended once the occlusion weights exist) and the
-    // noisy inputs. A wave of this kernel lives ~27 000 cycles of which ~14 000 were spent waiting on ~14 dependent request phases at 2 waves
-    // per SIMD (profiles/r02_c_reblur_ds_sq_pmc1.txt); the arithmetic in between now runs while the next phase's data is in flight.
-    // same geometry as the prev-viewZ footprint (launcher: same plane size): four undecoded 8-byte rows
-    const uint2 ir0 = LoadRowR16x4Raw(P.prevInternalData, fx4, fy0), ir1 = LoadRowR16x4Raw(P.prevInternalData, fx4, fy1), ir2 = LoadRowR16x4Raw(P.prevInternalData, fx4, fy2), ir3 = LoadRowR16x4Raw(P.prevInternalData, fx4, fy3);
     Bilinear smbBilinearFilter = GetBilinearFilter(smbPixelUv, rectSizePrev);
     const int bx = (int)smbBilinearFilter.origin.x, by = (int)smbBilinearFilter.origin.y;
-    const bool normalsInterior = FootprintIsInterior(P.prevNormalRoughness, bx, by, 2, 2);
-    uint32_t n00, n10, n01, n11; // packed texels of the 2x2 normal footprint (0 outside the plane, as Load returns)
-    {
-        const int nx = max(0, min(bx, P.prevNormalRoughness.w - 2));
-        LoadRowR32Ux2(P.prevNormalRoughness, nx, ClampI(by, 0, P.prevNormalRoughness.h - 1), n00, n10);
-        LoadRowR32Ux2(P.prevNormalRoughness, nx, ClampI(by + 1, 0, P.prevNormalRoughness.h - 1), n01, n11);
-    }
     const float2 smbSamplePos = Sat(smbPixelUv) * rectSizePrev;
     HistoryFilter smbFilter = MakeHistoryGeometry(smbSamplePos, DIFF ? P.historyDiff : P.historySpec); // both histories share a layout (checked by the launcher)
     typename Sig::HistoryTexels smbDiffTexels, smbSpecTexels;
     typename Sig::FastTexels smbDiffFastTexels, smbSpecFastTexels;
     S diff = Sig::Zero(), spec = Sig::Zero();
-    if (DIFF) {
-        Sig::PrefetchHistory(smbFilter, P.historyDiff, smbDiffTexels, !PERF && KIND != SIGNAL_DIRECTIONAL_OCCLUSION);
-        Sig::PrefetchFast(smbFilter, P.historyDiffFast, smbDiffFastTexels);
-        diff = Sig::Load(P.inDiff, (OCC && c.gDiffCheckerboard != 2) ? px >> 1 : px, py);
-    }
-    if (SPEC) {
-        Sig::PrefetchHistory(smbFilter, P.historySpec, smbSpecTexels, !PERF && KIND != SIGNAL_DIRECTIONAL_OCCLUSION);
-        Sig::PrefetchFast(smbFilter, P.historySpecFast, smbSpecFastTexels);
-        spec = Sig::Load(P.inSpec, (OCC && c.gSpecCheckerboard != 2) ? px >> 1 : px, py);
-    }
-
-    // footprints on the border of the plane: clamped / zero-filled texel loads replace the row data
-    float4 smbViewZ0 = F4(zr0.x, zr0.y, zr1.x, zr1.y), smbViewZ1 = F4(zr0.z, zr0.w, zr1.z, zr1.w), smbViewZ2 = F4(zr2.x, zr2.y, zr3.x, zr3.y), smbViewZ3 = F4(zr2.z, zr2.w, zr3.z, zr3.w);
+    float4 smbViewZ0, smbViewZ1, smbViewZ2, smbViewZ3;
     uint32_t id0[4], id1[4], id2[4], id3[4];
-    id0[0] = ir0.x & 0xFFFFu, id0[1] = ir0.x >> 16, id0[2] = ir1.x & 0xFFFFu, id0[3] = ir1.x >> 16;
-    id1[0] = ir0.y & 0xFFFFu, id1[1] = ir0.y >> 16, id1[2] = ir1.y & 0xFFFFu, id1[3] = ir1.y >> 16;
-    id2[0] = ir2.x & 0xFFFFu, id2[1] = ir2.x >> 16, id2[2] = ir3.x & 0xFFFFu, id2[3] = ir3.x >> 16;
-    id3[0] = ir2.y & 0xFFFFu, id3[1] = ir2.y >> 16, id3[2] = ir3.y & 0xFFFFu, id3[3] = ir3.y >> 16;
-    if (!footprintInterior) {
-#define QUADZ(ox, oy) \
-    F4(FetchClampedR32F(P.prevViewZ, cx + ox, cy + oy), FetchClampedR32F(P.prevViewZ, cx + ox + 1, cy + oy), FetchClampedR32F(P.prevViewZ, cx + ox, cy + oy + 1), FetchClampedR32F(P.prevViewZ, cx + ox + 1, cy + oy + 1))
-        smbViewZ0 = QUADZ(0, 0), smbViewZ1 = QUADZ(2, 0), smbViewZ2 = QUADZ(0, 2), smbViewZ3 = QUADZ(2, 2);
-#undef QUADZ
-#define QUADU(q, ox, oy)                                                   \
-    q[0] = FetchClampedR16U(P.prevInternalData, cx + ox, cy + oy);         \
-    q[1] = FetchClampedR16U(P.prevInternalData, cx + ox + 1, cy + oy);     \
-    q[2] = FetchClampedR16U(P.prevInternalData, cx + ox, cy + oy + 1);     \
-    q[3] = FetchClampedR16U(P.prevInternalData, cx + ox + 1, cy + oy + 1);
-        QUADU(id0, 0, 0) QUADU(id1, 2, 0) QUADU(id2, 0, 2) QUADU(id3, 2, 2)
-#undef QUADU
-    }
-    if (!normalsInterior) {
-        n00 = InBounds(P.prevNormalRoughness, bx, by) ? LoadR32U(P.prevNormalRoughness, bx, by) : 0u;
-        n10 = InBounds(P.prevNormalRoughness, bx + 1, by) ? LoadR32U(P.prevNormalRoughness, bx + 1, by) : 0u;
-        n01 = InBounds(P.prevNormalRoughness, bx, by + 1) ? LoadR32U(P.prevNormalRoughness, bx, by + 1) : 0u;
-        n11 = InBounds(P.prevNormalRoughness, bx + 1, by + 1) ? LoadR32U(P.prevNormalRoughness, bx + 1, by + 1) : 0u;
+    uint32_t n00, n10, n01, n11; // packed texels of the 2x2 normal footprint (0 outside the plane, as Load returns)
+    int wx0 = 0, wy0 = 0;        // MODE 1: plane coordinates of the window's first texel
+    if (MODE == 1) {
+        // ---- the window: bounding box of the clamped texel coordinates this workgroup's pixels read at the surface-motion position
+        const int W1 = P.prevViewZ.w - 1, H1 = P.prevViewZ.h - 1; // every plane staged here has the size of prevViewZ (checked by the launcher)
+        int loX = INT_MAX, loY = INT_MAX, hiX = INT_MIN, hiY = INT_MIN;
+        if (active) {
+            loX = min(min(ClampI(cx, 0, W1), ClampI(bx, 0, W1)), min(smbFilter.x[0], ClampI(smbFilter.ox, 0, W1)));
+            hiX = max(max(ClampI(cx + 3, 0, W1), ClampI(bx + 1, 0, W1)), max(smbFilter.x[3], ClampI(smbFilter.ox + 1, 0, W1)));
+            loY = min(min(ClampI(cy, 0, H1), ClampI(by, 0, H1)), min(smbFilter.y[0], ClampI(smbFilter.oy, 0, H1)));
+            hiY = max(max(ClampI(cy + 3, 0, H1), ClampI(by + 1, 0, H1)), max(smbFilter.y[3], ClampI(smbFilter.oy + 1, 0, H1)));
+        }
+#pragma unroll
+        for (int m = 32; m >= 1; m >>= 1) {
+            loX = min(loX, __shfl_xor(loX, m)), loY = min(loY, __shfl_xor(loY, m));
+            hiX = max(hiX, __shfl_xor(hiX, m)), hiY = max(hiY, __shfl_xor(hiY, m));
+        }
+        const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+        if (lane == 0)
+            s_WinBox[wave][0] = loX, s_WinBox[wave][1] = loY, s_WinBox[wave][2] = hiX, s_WinBox[wave][3] = hiY;
+        __syncthreads();
+        loX = min(min(s_WinBox[0][0], s_WinBox[1][0]), min(s_WinBox[2][0], s_WinBox[3][0]));
+        loY = min(min(s_WinBox[0][1], s_WinBox[1][1]), min(s_WinBox[2][1], s_WinBox[3][1]));
+        hiX = max(max(s_WinBox[0][2], s_WinBox[1][2]), max(s_WinBox[2][2], s_WinBox[3][2]));
+        hiY = max(max(s_WinBox[0][3], s_WinBox[1][3]), max(s_WinBox[2][3], s_WinBox[3][3]));
+        const bool empty = hiX < loX; // no pixel to denoise in this tile
+        const int bw = hiX - loX + 1, bh = hiY - loY + 1;
+        if (empty || bw > WIN_W || bh > WIN_H) { // uniform
+            if (threadIdx.x == 0)
+                *tileFlag = empty ? 0 : 1; // 1: the fallback kernel (MODE 2) does this tile
+            return;
+        }
+        if (threadIdx.x == 0)
+            *tileFlag = 0;
+        wx0 = loX, wy0 = loY;
+        // ---- fill: one wave per row of the box, one lane per column -- coalesced row segments, every texel once
+        if (lane < bw)
+            for (int r = wave; r < bh; r += 4) {
+                const int x = wx0 + lane, y = wy0 + r, o = r * WIN_W + lane;
+                s_WinZ[o] = LoadR32F(P.prevViewZ, x, y);
+                s_WinN[o] = LoadR32U(P.prevNormalRoughness, x, y);
+                s_WinId[o] = LoadR16U(P.prevInternalData, x, y);
+                s_WinFast[o] = (DIFF ? LoadR16U(P.historyDiffFast, x, y) : 0u) | (SPEC ? LoadR16U(P.historySpecFast, x, y) << 16 : 0u);
+                if (DIFF)
+                    s_WinDiff[o] = *TexelPtr<const uint2>(P.historyDiff, x, y);
+                if (SPEC)
+                    s_WinSpec[o] = *TexelPtr<const uint2>(P.historySpec, x, y);
+            }
+        __syncthreads();
+        if (!active)
+            return;
+        // ---- the footprints, read where the plain kernel has its request batch: texel (i, j) of a footprint is the texel at the clamped coordinate
+        int xo[4], yo[4];
+#pragma unroll
+        for (int i = 0; i < 4; i++)
+            xo[i] = ClampI(cx + i, 0, W1) - wx0, yo[i] = (ClampI(cy + i, 0, H1) - wy0) * WIN_W;
+#define WIN_Z(i, j) s_WinZ[yo[j] + xo[i]]
+#define WIN_ID(i, j) s_WinId[yo[j] + xo[i]]
+        smbViewZ0 = F4(WIN_Z(0, 0), WIN_Z(1, 0), WIN_Z(0, 1), WIN_Z(1, 1)), smbViewZ1 = F4(WIN_Z(2, 0), WIN_Z(3, 0), WIN_Z(2, 1), WIN_Z(3, 1));
+        smbViewZ2 = F4(WIN_Z(0, 2), WIN_Z(1, 2), WIN_Z(0, 3), WIN_Z(1, 3)), smbViewZ3 = F4(WIN_Z(2, 2), WIN_Z(3, 2), WIN_Z(2, 3), WIN_Z(3, 3));
+        id0[0] = WIN_ID(0, 0), id0[1] = WIN_ID(1, 0), id0[2] = WIN_ID(0, 1), id0[3] = WIN_ID(1, 1);
+        id1[0] = WIN_ID(2, 0), id1[1] = WIN_ID(3, 0), id1[2] = WIN_ID(2, 1), id1[3] = WIN_ID(3, 1);
+        id2[0] = WIN_ID(0, 2), id2[1] = WIN_ID(1, 2), id2[2] = WIN_ID(0, 3), id2[3] = WIN_ID(1, 3);
+        id3[0] = WIN_ID(2, 2), id3[1] = WIN_ID(3, 2), id3[2] = WIN_ID(2, 3), id3[3] = WIN_ID(3, 3);
+#undef WIN_Z
+#undef WIN_ID
+        const int nx0 = ClampI(bx, 0, W1) - wx0, nx1 = ClampI(bx + 1, 0, W1) - wx0, ny0 = (ClampI(by, 0, H1) - wy0) * WIN_W, ny1 = (ClampI(by + 1, 0, H1) - wy0) * WIN_W;
+        n00 = InBounds(P.prevNormalRoughness, bx, by) ? s_WinN[ny0 + nx0] : 0u;
+        n10 = InBounds(P.prevNormalRoughness, bx + 1, by) ? s_WinN[ny0 + nx1] : 0u;
+        n01 = InBounds(P.prevNormalRoughness, bx, by + 1) ? s_WinN[ny1 + nx0] : 0u;
+        n11 = InBounds(P.prevNormalRoughness, bx + 1, by + 1) ? s_WinN[ny1 + nx1] : 0u;
+    } else {
+        const bool footprintInterior = FootprintIsInterior(P.prevViewZ, cx, cy, 4, 4); // the four rows as four 16-byte loads (reblur_device.h "row-vector fetches")
+        // Row loads from an origin clamped into the plane: always legal (pool planes have >= 4 texels per row pitch), exact for an interior footprint. The
+        // few footprints that touch the border are re-read texel by texel AFTER the batch. (Two symmetric arms -- row loads / clamped loads -- would be
+        // merged by the compiler into twelve scalar loads with selected addresses, which is what the row loads are there to avoid.)
+        const int fx4 = max(0, min(cx, P.prevViewZ.w - 4));
+        const int fy0 = ClampI(cy, 0, P.prevViewZ.h - 1), fy1 = ClampI(cy + 1, 0, P.prevViewZ.h - 1), fy2 = ClampI(cy + 2, 0, P.prevViewZ.h - 1), fy3 = ClampI(cy + 3, 0, P.prevViewZ.h - 1);
+        const float4 zr0 = LoadRowR32Fx4(P.prevViewZ, fx4, fy0), zr1 = LoadRowR32Fx4(P.prevViewZ, fx4, fy1), zr2 = LoadRowR32Fx4(P.prevViewZ, fx4, fy2), zr3 = LoadRowR32Fx4(P.prevViewZ, fx4, fy3);
+        // ---- every other request that depends only on the surface-motion position is issued here, in one batch with the depth footprint: the 2x2
+        // previous normals, the 4x4 previous internal data, the history texels of both signals (blended once the occlusion weights exist) and the
+        // noisy inputs. A wave of this kernel lives ~27 000 cycles of which ~14 000 were spent waiting on ~14 dependent request phases at 2 waves
+        // per SIMD (profiles/r02_c_reblur_ds_sq_pmc1.txt); the arithmetic in between now runs while the next phase's data is in flight.
+        // same geometry as the prev-viewZ footprint (launcher: same plane size): four undecoded 8-byte rows
+        const uint2 ir0 = LoadRowR16x4Raw(P.prevInternalData, fx4, fy0), ir1 = LoadRowR16x4Raw(P.prevInternalData, fx4, fy1), ir2 = LoadRowR16x4Raw(P.prevInternalData, fx4, fy2), ir3 = LoadRowR16x4Raw(P.prevInternalData, fx4, fy3);
+        const bool normalsInterior = FootprintIsInterior(P.prevNormalRoughness, bx, by, 2, 2);
+        {
+            const int nx = max(0, min(bx, P.prevNormalRoughness.w - 2));
+            LoadRowR32Ux2(P.prevNormalRoughness, nx, ClampI(by, 0, P.prevNormalRoughness.h - 1), n00, n10);
+            LoadRowR32Ux2(P.prevNormalRoughness, nx, ClampI(by + 1, 0, P.prevNormalRoughness.h - 1), n01, n11);
+        }
+        if (DIFF) {
+            Sig::PrefetchHistory(smbFilter, P.historyDiff, smbDiffTexels, !PERF && KIND != SIGNAL_DIRECTIONAL_OCCLUSION);
+            Sig::PrefetchFast(smbFilter, P.historyDiffFast, smbDiffFastTexels);
+            diff = Sig::Load(P.inDiff, (OCC && c.gDiffCheckerboard != 2) ? px >> 1 : px, py);
+        }
+        if (SPEC) {
+            Sig::PrefetchHistory(smbFilter, P.historySpec, smbSpecTexels, !PERF && KIND != SIGNAL_DIRECTIONAL_OCCLUSION);
+            Sig::PrefetchFast(smbFilter, P.historySpecFast, smbSpecFastTexels);
+            spec = Sig::Load(P.inSpec, (OCC && c.gSpecCheckerboard != 2) ? px >> 1 : px, py);
+        }
+
+        // footprints on the border of the plane: clamped / zero-filled texel loads replace the row data
+        smbViewZ0 = F4(zr0.x, zr0.y, zr1.x, zr1.y), smbViewZ1 = F4(zr0.z, zr0.w, zr1.z, zr1.w), smbViewZ2 = F4(zr2.x, zr2.y, zr3.x, zr3.y), smbViewZ3 = F4(zr2.z, zr2.w, zr3.z, zr3.w);
+        id0[0] = ir0.x & 0xFFFFu, id0[1] = ir0.x >> 16, id0[2] = ir1.x & 0xFFFFu, id0[3] = ir1.x >> 16;
+        id1[0] = ir0.y & 0xFFFFu, id1[1] = ir0.y >> 16, id1[2] = ir1.y & 0xFFFFu, id1[3] = ir1.y >> 16;
+        id2[0] = ir2.x & 0xFFFFu, id2[1] = ir2.x >> 16, id2[2] = ir3.x & 0xFFFFu, id2[3] = ir3.x >> 16;
+        id3[0] = ir2.y & 0xFFFFu, id3[1] = ir2.y >> 16, id3[2] = ir3.y & 0xFFFFu, id3[3] = ir3.y >> 16;
+        if (!footprintInterior) {
+    #define QUADZ(ox, oy) \
+        F4(FetchClampedR32F(P.prevViewZ, cx + ox, cy + oy), FetchClampedR32F(P.prevViewZ, cx + ox + 1, cy + oy), FetchClampedR32F(P.prevViewZ, cx + ox, cy + oy + 1), FetchClampedR32F(P.prevViewZ, cx + ox + 1, cy + oy + 1))
+            smbViewZ0 = QUADZ(0, 0), smbViewZ1 = QUADZ(2, 0), smbViewZ2 = QUADZ(0, 2), smbViewZ3 = QUADZ(2, 2);
+    #undef QUADZ
+    #define QUADU(q, ox, oy)                                                   \
+        q[0] = FetchClampedR16U(P.prevInternalData, cx + ox, cy + oy);         \
+        q[1] = FetchClampedR16U(P.prevInternalData, cx + ox + 1, cy + oy);     \
+        q[2] = FetchClampedR16U(P.prevInternalData, cx + ox, cy + oy + 1);     \
+        q[3] = FetchClampedR16U(P.prevInternalData, cx + ox + 1, cy + oy + 1);
+            QUADU(id0, 0, 0) QUADU(id1, 2, 0) QUADU(id2, 0, 2) QUADU(id3, 2, 2)
+    #undef QUADU
+        }
+        if (!normalsInterior) {
+            n00 = InBounds(P.prevNormalRoughness, bx, by) ? LoadR32U(P.prevNormalRoughness, bx, by) : 0u;
+            n10 = InBounds(P.prevNormalRoughness, bx + 1, by) ? LoadR32U(P.prevNormalRoughness, bx + 1, by) : 0u;
+            n01 = InBounds(P.prevNormalRoughness, bx, by + 1) ? LoadR32U(P.prevNormalRoughness, bx, by + 1) : 0u;
+            n11 = InBounds(P.prevNormalRoughness, bx + 1, by + 1) ? LoadR32U(P.prevNormalRoughness, bx + 1, by + 1) : 0u;
+        }
+
     }
 
     float3 prevViewZ0 = F3(UnpackViewZ(c, smbViewZ0.y), UnpackViewZ(c, smbViewZ0.z), UnpackViewZ(c, smbViewZ0.w));
@@ -372,6 +519,8 @@ __global__ __launch_bounds__(TILE_X* TILE_Y, WAVES) void ReblurTemporalAccumulat
     // ------------------------------------------------------------------------------------------------ diffuse
     // (before the long specular section: everything the diffuse part needs from the shared footprint dies here, not after it)
     if (DIFF) {
+        if (MODE == 1) // (the plain kernel requests its inputs with the surface-motion batch)
+            diff = Sig::Load(P.inDiff, px, py);
         float diffHistoryConfidence = smbFootprintQuality;
         if (c.gHasHistoryConfidence)
             diffHistoryConfidence *= LoadR8Unorm(P.diffConfidence, px, py);
@@ -384,6 +533,10 @@ __global__ __launch_bounds__(TILE_X* TILE_Y, WAVES) void ReblurTemporalAccumulat
             diff = d0 * wc.x + d1 * wc.y;
         }
 
+        if (MODE == 1) {
+            WindowHistoryTexels(smbFilter, s_WinDiff, wx0, wy0, smbDiffTexels);
+            WindowFastTexels(smbFilter, s_WinFast, wx0, wy0, P.historyDiffFast, 0, smbDiffFastTexels);
+        }
         S smbDiffHistory = Sig::FetchHistory(smbFilter, P.historyDiff, smbDiffTexels);
         float smbDiffFastHistory = Sig::FetchFastBilinear(smbFilter, P.historyDiffFast, smbDiffFastTexels);
         smbDiffHistory = ClampNegativeToZero(smbDiffHistory);
@@ -433,6 +586,20 @@ __global__ __launch_bounds__(TILE_X* TILE_Y, WAVES) void ReblurTemporalAccumulat
     // ------------------------------------------------------------------------------------------------ specular
     float specAccumSpeed = 0.0f, curvature = 0.0f, virtualHistoryAmount = 0.0f;
     if (SPEC) {
+        // surface history: the window kernel blends it here, from LDS, so that the footprint geometry (~30 VGPRs) dies before the virtual-motion section;
+        // the plain kernel blends the texels it requested with the surface-motion batch after that section
+        S smbSpecHistory = Sig::Zero();
+        float smbSpecFastHistory = 0.0f;
+        float4 smbSpecShHistory = F4(0.0f);
+        if (MODE == 1) {
+            spec = Sig::Load(P.inSpec, px, py);
+            WindowHistoryTexels(smbFilter, s_WinSpec, wx0, wy0, smbSpecTexels);
+            WindowFastTexels(smbFilter, s_WinFast, wx0, wy0, P.historySpecFast, 16, smbSpecFastTexels);
+            smbSpecHistory = Sig::FetchHistory(smbFilter, P.historySpec, smbSpecTexels);
+            smbSpecFastHistory = Sig::FetchFastBilinear(smbFilter, P.historySpecFast, smbSpecFastTexels);
+            if (SH)
+                smbSpecShHistory = FetchHistoryBilinearRGBA16F(smbFilter, P.historySpecSh);
+        }
         float specHistoryConfidence = smbFootprintQuality;
         if (c.gHasHistoryConfidence)
             specHistoryConfidence *= LoadR8Unorm(P.specConfidence, px, py);
@@ -554,8 +721,10 @@ __global__ __launch_bounds__(TILE_X* TILE_Y, WAVES) void ReblurTemporalAccumulat
         HistoryFilter vmbFilter = MakeHistoryGeometry(Sat(vmbPixelUv) * rectSizePrev, P.historySpec);
         typename Sig::HistoryTexels vmbSpecTexels;
         typename Sig::FastTexels vmbSpecFastTexels;
-        Sig::PrefetchHistory(vmbFilter, P.historySpec, vmbSpecTexels, !PERF && KIND != SIGNAL_DIRECTIONAL_OCCLUSION);
-        Sig::PrefetchFast(vmbFilter, P.historySpecFast, vmbSpecFastTexels);
+        if (MODE != 1) { // the window kernel runs three waves per SIMD and requests these where they are blended: their ~28 VGPRs are what the third wave costs
+            Sig::PrefetchHistory(vmbFilter, P.historySpec, vmbSpecTexels, !PERF && KIND != SIGNAL_DIRECTIONAL_OCCLUSION);
+            Sig::PrefetchFast(vmbFilter, P.historySpecFast, vmbSpecFastTexels);
+        }
 
         // footprints on the border of the plane: clamped texel loads replace the row data
         float vz00 = vzr0.x, vz10 = vzr0.y, vz01 = vzr1.x, vz11 = vzr1.y; // packed viewZ
@@ -700,8 +869,10 @@ __global__ __launch_bounds__(TILE_X* TILE_Y, WAVES) void ReblurTemporalAccumulat
 
         NRD_CONSTANTS_PHASE();
         // Sample surface history
-        S smbSpecHistory = Sig::FetchHistory(smbFilter, P.historySpec, smbSpecTexels);
-        float smbSpecFastHistory = Sig::FetchFastBilinear(smbFilter, P.historySpecFast, smbSpecFastTexels);
+        if (MODE != 1) {
+            smbSpecHistory = Sig::FetchHistory(smbFilter, P.historySpec, smbSpecTexels);
+            smbSpecFastHistory = Sig::FetchFastBilinear(smbFilter, P.historySpecFast, smbSpecFastTexels);
+        }
 
         float surfaceHistoryConfidence;
         {
@@ -753,6 +924,10 @@ __global__ __launch_bounds__(TILE_X* TILE_Y, WAVES) void ReblurTemporalAccumulat
         NRD_CONSTANTS_PHASE();
         // Sample virtual history
         SetHistoryWeights(vmbFilter, vmbOcclusionWeights, vmbAllowCatRom);
+        if (MODE == 1) {
+            Sig::PrefetchHistory(vmbFilter, P.historySpec, vmbSpecTexels, !PERF && KIND != SIGNAL_DIRECTIONAL_OCCLUSION);
+            Sig::PrefetchFast(vmbFilter, P.historySpecFast, vmbSpecFastTexels);
+        }
         S vmbSpecHistory = Sig::FetchHistory(vmbFilter, P.historySpec, vmbSpecTexels);
         float vmbSpecFastHistory = Sig::FetchFastBilinear(vmbFilter, P.historySpecFast, vmbSpecFastTexels);
 
@@ -772,7 +947,8 @@ __global__ __launch_bounds__(TILE_X* TILE_Y, WAVES) void ReblurTemporalAccumulat
 
         float4 specShResult = F4(0.0f);
         if (SH) {
-            float4 smbSpecShHistory = FetchHistoryBilinearRGBA16F(smbFilter, P.historySpecSh);
+            if (MODE != 1)
+                smbSpecShHistory = FetchHistoryBilinearRGBA16F(smbFilter, P.historySpecSh);
             float4 vmbSpecShHistory = FetchHistoryBilinearRGBA16F(vmbFilter, P.historySpecSh);
             float4 specSh = LoadRGBA16F(P.inSpecSh, px, py);
             float4 smbShSpec = Lerp(smbSpecShHistory, specSh, smbSpecNonLinearAccumSpeed);
@@ -900,11 +1076,22 @@ static const char* LaunchTemporalAccumulation(const PassArgs& a) {
     // register budget: with a specular signal the batched requests need ~250 VGPRs (2 waves per SIMD); the diffuse-only kernel fits 168 without scratch,
     // which keeps its third wave (r02_k: 0.135 ms at 2 waves against 0.109 before the batching)
     static const int wavesEnv = getenv("NRD_HIP_TA_WAVES") ? atoi(getenv("NRD_HIP_TA_WAVES")) : 0;
+    static const bool windowEnv = !(getenv("NRD_HIP_TA_WINDOW") && atoi(getenv("NRD_HIP_TA_WINDOW")) == 0); // A/B switch
+    constexpr bool HAS_WINDOW = DIFF && SPEC && !PERF && KIND == SIGNAL_RADIANCE; // the window kernel exists for the radiance + hit distance kind with both signals
+    if (HAS_WINDOW && windowEnv && !wavesEnv) {
+        if (!a.tileFlags.ptr || (uint32_t)a.tileFlags.w * TILE_X < (uint32_t)P.viewZ.w || (uint32_t)a.tileFlags.h * TILE_Y < (uint32_t)P.viewZ.h)
+            return "REBLUR temporal accumulation: the executor's tile-flag scratch is missing or too small";
+        P.tileFlags = a.tileFlags;
+        // window kernel (LDS-staged surface-motion footprints, 3 waves per SIMD), then the plain kernel on the tiles the first one declined
+        LaunchPass(a, (ReblurTemporalAccumulationKernel<DIFF, SPEC, PERF, KIND, SH, 3, HAS_WINDOW ? 1 : 0>), g.grid, dim3(TILE_X * TILE_Y), c, P, MakeRowRange(g));
+        LaunchPass(a, (ReblurTemporalAccumulationKernel<DIFF, SPEC, PERF, KIND, SH, 2, HAS_WINDOW ? 2 : 0>), g.grid, dim3(TILE_X * TILE_Y), c, P, MakeRowRange(g));
+        return nullptr;
+    }
     const int waves = wavesEnv ? wavesEnv : (SPEC ? 2 : 3);
     if (waves >= 3)
-        LaunchPass(a, (ReblurTemporalAccumulationKernel<DIFF, SPEC, PERF, KIND, SH, 3>), g.grid, dim3(TILE_X * TILE_Y), c, P, MakeRowRange(g));
+        LaunchPass(a, (ReblurTemporalAccumulationKernel<DIFF, SPEC, PERF, KIND, SH, 3, 0>), g.grid, dim3(TILE_X * TILE_Y), c, P, MakeRowRange(g));
     else
-        LaunchPass(a, (ReblurTemporalAccumulationKernel<DIFF, SPEC, PERF, KIND, SH, 2>), g.grid, dim3(TILE_X * TILE_Y), c, P, MakeRowRange(g));
+        LaunchPass(a, (ReblurTemporalAccumulationKernel<DIFF, SPEC, PERF, KIND, SH, 2, 0>), g.grid, dim3(TILE_X * TILE_Y), c, P, MakeRowRange(g));
     return nullptr;
 }
 

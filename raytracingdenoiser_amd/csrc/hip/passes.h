@@ -87,6 +87,10 @@ struct PassArgs {
     // normals once per frame; same pitch / size as decodedNormalRoughness, so one texel offset serves both. With it a diffuse tap of the spatial passes
     // reads its guides in one 16-byte load. ptr == nullptr outside REBLUR lists.
     Plane viewPos;
+    // executor-internal scratch, one byte per 32x8-pixel workgroup tile of the full-resolution planes: a pass that runs as a fast kernel plus a fallback kernel
+    // (REBLUR TemporalAccumulation with its LDS window) hands the tiles the fast kernel declined to the fallback through it. Written completely by the fast
+    // kernel before the fallback reads it (stream order), so it needs no clearing.
+    Plane tileFlags;
     // non-null: the launcher performs all its checks and hands its launch(es) to the recorder instead of enqueueing them
     LaunchRecorder* recorder = nullptr;
 };

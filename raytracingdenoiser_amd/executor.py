@@ -113,6 +113,12 @@ class HipExecutor:
         self._check(self.lib.nrdHipGetGraphStats(self.handle, C.byref(a), C.byref(b), C.byref(c)), "nrdHipGetGraphStats")
         return a.value, b.value, c.value
 
+    def tile_fallback_stats(self):
+        """(tiles of the last frame left to a fallback kernel, tiles in total) -- include/NRDHip.h nrdHipGetTileFallbackStats"""
+        a, b = C.c_uint32(), C.c_uint32()
+        self._check(self.lib.nrdHipGetTileFallbackStats(self.handle, C.byref(a), C.byref(b)), "nrdHipGetTileFallbackStats")
+        return a.value, b.value
+
     def set_profiling(self, enable):
         self._check(self.lib.nrdHipSetProfiling(self.handle, 1 if enable else 0), "nrdHipSetProfiling")
 

@@ -89,6 +89,11 @@ class EmuExecutor:
         buf = (C.c_uint8 * (d.height * d.rowPitchBytes)).from_address(d.data)
         return np.frombuffer(buf, dtype=np.uint8).reshape(d.height, d.rowPitchBytes).copy(), api.Format(d.format), d.width
 
+    def tile_fallback_stats(self):
+        a, b = C.c_uint32(), C.c_uint32()
+        self._check(self.lib.nrdHipGetTileFallbackStats(self.handle, C.byref(a), C.byref(b)), "nrdHipGetTileFallbackStats")
+        return a.value, b.value
+
     def set_graph_mode(self, enable):
         pass  # graphs are a launch mechanism of the real runtime (graph == eager is a GPU test, tests/test_executor.py); the emulation always launches eagerly
 

@@ -238,6 +238,8 @@ def _run_parity(name, width, height, frames, verbose, settings_overrides, static
         st = denoiser_settings(name, frame, settings_overrides)
         ora.step(frame, cs, st)
         hip.step(frame, common_settings(cam, cam_prev, width, height, f, **cs_kw), denoiser_settings(name, frame, settings_overrides))
+        if verbose and hasattr(hip.ex, "tile_fallback_stats"):
+            print("frame %d tiles left to a fallback kernel: %d of %d" % ((f,) + tuple(hip.ex.tile_fallback_stats())))
         for rt in ora.outs:
             want, got = ora.output(rt), hip.output(rt)
             e = rel_error(got, want)
