@@ -12,6 +12,7 @@
 // written against several hundred dependent VALU ops per pixel, so occupancy (VGPRs) is the lever, not bytes.
 #include "passes.h"
 #include <climits>
+#include <cstdio>
 #include "reblur_device.h"
 
 namespace nrdhip {
@@ -33,6 +34,7 @@ constexpr int WIN_H = NRD_TA_WIN_H;
 
 struct TaPlanes {
     Plane tileFlags; // executor scratch, one byte per workgroup tile (passes.h): set by the window kernel for the tiles it leaves to the fallback kernel
+    int winMaxW, winMaxH; // largest box the window kernel accepts (<= WIN_W x WIN_H; smaller values exercise the fallback kernel: NRD_HIP_TA_WINDOW_LIMIT)
     Plane tiles, normalRoughness, viewZ, mv, prevViewZ, prevNormalRoughness, prevInternalData;
     Plane decodedNR; // executor's float4 cache of normalRoughness (reblur_device.h "decoded guides")
     Plane disocclusionThresholdMix, diffConfidence, specConfidence; // R8_UNORM user inputs; dummies unless the gHas* flags are set
@@ -288,7 +290,7 @@ __global__ __launch_bounds__(TILE_X* TILE_Y, WAVES) void ReblurTemporalAccumulat
         hiY = max(max(s_WinBox[0][3], s_WinBox[1][3]), max(s_WinBox[2][3], s_WinBox[3][3]));
         const bool empty = hiX < loX; // no pixel to denoise in this tile
         const int bw = hiX - loX + 1, bh = hiY - loY + 1;
-        if (empty || bw > WIN_W || bh > WIN_H) { // uniform
+        if (empty || bw > P.winMaxW || bh > P.winMaxH) { // uniform
             if (threadIdx.x == 0)
                 *tileFlag = empty ? 0 : 1; // 1: the fallback kernel (MODE 2) does this tile
             return;
@@ -1082,6 +1084,12 @@ static const char* LaunchTemporalAccumulation(const PassArgs& a) {
         if (!a.tileFlags.ptr || (uint32_t)a.tileFlags.w * TILE_X < (uint32_t)P.viewZ.w || (uint32_t)a.tileFlags.h * TILE_Y < (uint32_t)P.viewZ.h)
             return "REBLUR temporal accumulation: the executor's tile-flag scratch is missing or too small";
         P.tileFlags = a.tileFlags;
+        static const char* limitEnv = getenv("NRD_HIP_TA_WINDOW_LIMIT"); // "WxH", test hook: a smaller box sends tiles to the fallback kernel (results do not change)
+        int limW = WIN_W, limH = WIN_H;
+        if (limitEnv && sscanf(limitEnv, "%dx%d", &limW, &limH) != 2)
+            limW = WIN_W, limH = WIN_H;
+        P.winMaxW = limW < WIN_W ? limW : WIN_W;
+        P.winMaxH = limH < WIN_H ? limH : WIN_H;
         // window kernel (LDS-staged surface-motion footprints, 3 waves per SIMD), then the plain kernel on the tiles the first one declined
         LaunchPass(a, (ReblurTemporalAccumulationKernel<DIFF, SPEC, PERF, KIND, SH, 3, HAS_WINDOW ? 1 : 0>), g.grid, dim3(TILE_X * TILE_Y), c, P, MakeRowRange(g));
         LaunchPass(a, (ReblurTemporalAccumulationKernel<DIFF, SPEC, PERF, KIND, SH, 2, HAS_WINDOW ? 2 : 0>), g.grid, dim3(TILE_X * TILE_Y), c, P, MakeRowRange(g));

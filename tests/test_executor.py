@@ -159,3 +159,27 @@ def test_mixed_reblur_and_relax_instance_matches_the_oracle():
         for rt, (a, b) in outs.items():
             got = to_host(b)
             assert np.array_equal(got.view(np.uint16), a.view(np.uint16)), (f, rt, int((got.view(np.uint16) != a.view(np.uint16)).sum()))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", ["REBLUR_DIFFUSE_SPECULAR", "REBLUR_DIFFUSE_SPECULAR_SH"])
+def test_temporal_accumulation_window_and_fallback_kernels_match_the_oracle(name):
+    """REBLUR TemporalAccumulation runs as a window kernel (the surface-motion footprints of a tile come from one LDS-staged rectangle of the previous frame)
+    plus the plain kernel for the tiles whose rectangle does not fit. On the test scenes every tile fits, so the plain kernel would never run: the test hook
+    NRD_HIP_TA_WINDOW_LIMIT shrinks the accepted rectangle (read once per process, hence the subprocess) until a good part of the tiles takes each path --
+    all outputs and pool planes must still equal the oracle's bit for bit, and with NRD_HIP_TA_WINDOW=0 (plain kernel only) as well."""
+    import re
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = ("import sys; sys.path[:0] = [%r, %r]; import parity; "
+            "print('worst', parity.run_parity(%r, width=256, height=160, frames=5, verbose=True))") % (root, os.path.join(root, "tests"), name)
+    fallback = {}
+    for tag, extra in (("default", {}), ("limited", {"NRD_HIP_TA_WINDOW_LIMIT": "35x11"}), ("off", {"NRD_HIP_TA_WINDOW": "0"})):
+        out = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, **extra), capture_output=True, text=True, timeout=1200)
+        assert out.returncode == 0, out.stderr[-2000:]
+        assert float(re.search(r"worst ([0-9.eE+-]+)", out.stdout).group(1)) == 0.0, (tag, out.stdout[-2000:])
+        fallback[tag] = [int(m) for m in re.findall(r"tiles left to a fallback kernel: (\d+) of", out.stdout)]
+    assert sum(fallback["default"]) == 0 and sum(fallback["off"]) == 0, fallback  # everything fits / the flags are not touched without the window kernel
+    assert all(n > 0 for n in fallback["limited"]), fallback                      # both kernels had tiles in every frame
