@@ -1079,7 +1079,7 @@ static const char* LaunchTemporalAccumulation(const PassArgs& a) {
     // which keeps its third wave (r02_k: 0.135 ms at 2 waves against 0.109 before the batching)
     static const int wavesEnv = getenv("NRD_HIP_TA_WAVES") ? atoi(getenv("NRD_HIP_TA_WAVES")) : 0;
     static const bool windowEnv = !(getenv("NRD_HIP_TA_WINDOW") && atoi(getenv("NRD_HIP_TA_WINDOW")) == 0); // A/B switch
-    constexpr bool HAS_WINDOW = DIFF && SPEC && !PERF && KIND == SIGNAL_RADIANCE; // the window kernel exists for the radiance + hit distance kind with both signals
+    constexpr bool HAS_WINDOW = !PERF && KIND == SIGNAL_RADIANCE; // the window kernel exists for the radiance + hit distance kind (RGBA16F histories fetched with Catmull-Rom)
     if (HAS_WINDOW && windowEnv && !wavesEnv) {
         if (!a.tileFlags.ptr || (uint32_t)a.tileFlags.w * TILE_X < (uint32_t)P.viewZ.w || (uint32_t)a.tileFlags.h * TILE_Y < (uint32_t)P.viewZ.h)
             return "REBLUR temporal accumulation: the executor's tile-flag scratch is missing or too small";
@@ -1092,7 +1092,7 @@ static const char* LaunchTemporalAccumulation(const PassArgs& a) {
         P.winMaxH = limH < WIN_H ? limH : WIN_H;
         // window kernel (LDS-staged surface-motion footprints, 3 waves per SIMD), then the plain kernel on the tiles the first one declined
         LaunchPass(a, (ReblurTemporalAccumulationKernel<DIFF, SPEC, PERF, KIND, SH, 3, HAS_WINDOW ? 1 : 0>), g.grid, dim3(TILE_X * TILE_Y), c, P, MakeRowRange(g));
-        LaunchPass(a, (ReblurTemporalAccumulationKernel<DIFF, SPEC, PERF, KIND, SH, 2, HAS_WINDOW ? 2 : 0>), g.grid, dim3(TILE_X * TILE_Y), c, P, MakeRowRange(g));
+        LaunchPass(a, (ReblurTemporalAccumulationKernel<DIFF, SPEC, PERF, KIND, SH, SPEC ? 2 : 3, HAS_WINDOW ? 2 : 0>), g.grid, dim3(TILE_X * TILE_Y), c, P, MakeRowRange(g));
         return nullptr;
     }
     const int waves = wavesEnv ? wavesEnv : (SPEC ? 2 : 3);
