@@ -34,7 +34,13 @@ def main():
     ap.add_argument("--all-ranks", type=int, default=1, help="measure every rank of each world size (the frame time is the slowest one) instead of the middle strip only")
     ap.add_argument("--scheme", choices=["allgather", "halo"], default="halo", help="allgather = FrameSharder (redundant halo compute), halo = HaloSharder (halo exchange between segments)")
     ap.add_argument("--max-motion-rows", type=int, default=32)
+    ap.add_argument("--no-sky", action="store_true", help="the bench scene with a backdrop dome: every pixel is denoised (bench.py --no-sky)")
+    ap.add_argument("--link-GBps", type=float, default=50.0, help="what one xGMI link delivers to one neighbour (modelled transfers)")
     args = ap.parse_args()
+    if args.no_sky:
+        from raytracingdenoiser_amd import synth
+
+        synth.BACKDROP = True
     name, (W, H), _, _ = bench.WORKLOADS[args.workload]
     total = args.warmup + args.frames
     seq = parity.generate_sequence(name, W, H, total, device="cuda")
@@ -140,8 +146,20 @@ def main():
                         "redundant_compute_factor": round(sum(r["ms_per_frame"] for r in rs) / base, 3),
                         "max_halo_bytes_received_per_frame": max(r["halo_bytes_received_per_frame"] for r in rs), "strips": [r["rows"] for r in rs],
                         "owned_rows_bit_identical_to_full_frame_run": all(r["owned_rows_bit_identical_to_full_frame_run"] is not False for r in rs)})
-    print(json.dumps({"workload": "%s %dx%d" % (name, W, H), "scheme": args.scheme, "balance": bool(args.balance),
-                      "note": "per-rank compute only, %s, one MI355X; transfers not included" % ("every rank measured" if args.all_ranks else "middle strip"), "summary": summary, "ranks": results}))
+    # MODELLED transfers (nothing here ran on more than one GPU): an inner rank receives its bands from two neighbours over two different xGMI links, so the
+    # slower direction carries about half of what the rank receives; three bounds per world size -- no overlap at all (compute + transfer), perfect overlap
+    # (max of the two), and the speed-up against the measured one-GPU frame each would give
+    for srow in summary:
+        per_link = srow["max_halo_bytes_received_per_frame"] / (2.0 if srow["world"] > 2 else 1.0)
+        xfer_ms = per_link / (args.link_GBps * 1e9) * 1e3
+        srow["modelled_transfer_ms_per_frame_at_%g_GBps_per_link" % args.link_GBps] = round(xfer_ms, 4)
+        srow["modelled_frame_ms_no_overlap"] = round(srow["slowest_rank_ms"] + xfer_ms, 4)
+        srow["modelled_frame_ms_full_overlap"] = round(max(srow["slowest_rank_ms"], xfer_ms), 4)
+        srow["modelled_speedup_no_overlap"] = round(base / (srow["slowest_rank_ms"] + xfer_ms), 3)
+        srow["modelled_speedup_full_overlap"] = round(base / max(srow["slowest_rank_ms"], xfer_ms), 3)
+    print(json.dumps({"workload": "%s %dx%d%s" % (name, W, H, " (no sky)" if args.no_sky else ""), "scheme": args.scheme, "balance": bool(args.balance),
+                      "note": "MODELLED, not measured on several GPUs: per-rank compute measured with virtual ranks on one MI355X (%s); transfers = halo bytes / %g GB/s per link, "
+                              "neighbours only" % ("every rank measured" if args.all_ranks else "middle strip", args.link_GBps), "summary": summary, "ranks": results}))
 
 
 if __name__ == "__main__":
