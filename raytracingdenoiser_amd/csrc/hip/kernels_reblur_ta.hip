@@ -43,26 +43,8 @@ struct TaPlanes {
     Plane inDiffSh, inSpecSh, historyDiffSh, historySpecSh, outDiffSh, outSpecSh; // SH family (RGBA16F)
 };
 
-// MODE 1: the two-step fetches of reblur_device.h with the texels taken from the LDS window instead of being requested from memory. A footprint on the border of
-// the plane needs no special case: texel (i, j) is the texel at the clamped coordinate (h.x[i], h.y[j]) -- what FetchHistoryGeneric reads one by one -- and
-// the blend of the row-loaded path is the same arithmetic as the generic one.
-NRD_D void WindowHistoryTexels(const HistoryFilter& h, const uint2* win, int wx0, int wy0, HistoryTexelsRGBA16F& t) {
-    int xo[4], yo[4];
-#pragma unroll
-    for (int i = 0; i < 4; i++)
-        xo[i] = h.x[i] - wx0, yo[i] = (h.y[i] - wy0) * WIN_W;
-    const uint2 a0 = win[yo[0] + xo[1]], a1 = win[yo[0] + xo[2]];
-    const uint2 b0 = win[yo[1] + xo[0]], b1 = win[yo[1] + xo[1]], b2 = win[yo[1] + xo[2]], b3 = win[yo[1] + xo[3]];
-    const uint2 c0 = win[yo[2] + xo[0]], c1 = win[yo[2] + xo[1]], c2 = win[yo[2] + xo[2]], c3 = win[yo[2] + xo[3]];
-    const uint2 d0 = win[yo[3] + xo[1]], d1 = win[yo[3] + xo[2]];
-    t.a = Raw4{a0.x, a0.y, a1.x, a1.y};
-    t.b0 = Raw4{b0.x, b0.y, b1.x, b1.y}, t.b1 = Raw4{b2.x, b2.y, b3.x, b3.y};
-    t.c0 = Raw4{c0.x, c0.y, c1.x, c1.y}, t.c1 = Raw4{c2.x, c2.y, c3.x, c3.y};
-    t.d = Raw4{d0.x, d0.y, d1.x, d1.y};
-    t.loaded = true;
-}
 template <typename T>
-NRD_D void WindowHistoryTexels(const HistoryFilter&, const uint2*, int, int, T&) {} // other storage kinds have no window kernel
+NRD_D void WindowHistoryTexels(const HistoryFilter&, const uint2*, int, int, int, T&) {} // other storage kinds have no window kernel
 // the 2x2 of the Load-based bilinear path (texels outside the plane read as 0); `shift` selects the half of the window dword (0 diffuse, 16 specular)
 NRD_D void WindowFastTexels(const HistoryFilter& h, const uint32_t* win, int wx0, int wy0, const Plane& dims, int shift, BilinearTexelsR16F& t) {
     const int x0 = ClampI(h.ox, 0, dims.w - 1) - wx0, x1 = ClampI(h.ox + 1, 0, dims.w - 1) - wx0;
@@ -536,7 +518,7 @@ __global__ __launch_bounds__(TILE_X* TILE_Y, WAVES) void ReblurTemporalAccumulat
         }
 
         if (MODE == 1) {
-            WindowHistoryTexels(smbFilter, s_WinDiff, wx0, wy0, smbDiffTexels);
+            WindowHistoryTexels(smbFilter, s_WinDiff, wx0, wy0, WIN_W, smbDiffTexels);
             WindowFastTexels(smbFilter, s_WinFast, wx0, wy0, P.historyDiffFast, 0, smbDiffFastTexels);
         }
         S smbDiffHistory = Sig::FetchHistory(smbFilter, P.historyDiff, smbDiffTexels);
@@ -595,7 +577,7 @@ __global__ __launch_bounds__(TILE_X* TILE_Y, WAVES) void ReblurTemporalAccumulat
         float4 smbSpecShHistory = F4(0.0f);
         if (MODE == 1) {
             spec = Sig::Load(P.inSpec, px, py);
-            WindowHistoryTexels(smbFilter, s_WinSpec, wx0, wy0, smbSpecTexels);
+            WindowHistoryTexels(smbFilter, s_WinSpec, wx0, wy0, WIN_W, smbSpecTexels);
             WindowFastTexels(smbFilter, s_WinFast, wx0, wy0, P.historySpecFast, 16, smbSpecFastTexels);
             smbSpecHistory = Sig::FetchHistory(smbFilter, P.historySpec, smbSpecTexels);
             smbSpecFastHistory = Sig::FetchFastBilinear(smbFilter, P.historySpecFast, smbSpecFastTexels);

@@ -12,6 +12,8 @@
 //     per signal, feed the 5x5 moments; everything else is per-pixel arithmetic.
 // LDS rows are padded to an odd float4 count (35 / 37) so the rows a wave touches start in different banks.
 #include "relax_device.h"
+#include <climits>
+#include <cstdio>
 
 namespace nrdhip {
 
@@ -28,16 +30,34 @@ constexpr int BUF_Y = TILE_Y + 2 * BORDER; // 10
 constexpr int BUF_STRIDE = BUF_X + 1;      // 35
 } // namespace ta
 
+// The surface-motion window (MODE 1; same scheme as kernels_reblur_ta.hip): the texels of the previous frame a workgroup's pixels reproject to, staged in LDS
+constexpr int WIN_W = 64; // at most 64: one lane per column when the window is filled
+constexpr int WIN_H = 16;
+
 struct TaPlanes {
+    Plane tileFlags;      // executor scratch, one byte per workgroup tile (passes.h)
+    int winMaxW, winMaxH; // largest box the window kernel accepts (NRD_HIP_TA_WINDOW_LIMIT shrinks it for tests)
     Plane tiles, mv, normalRoughness, viewZ, prevNormalRoughness, prevViewZ, prevSpecHitDist, prevHistoryLength, prevMaterialID, disocclusionThresholdMix;
     Plane outSpecHitDist, outHistoryLength, outSpecReprojectionConfidence;
     Plane decodedNR; // executor's float4 cache of normalRoughness (reblur_device.h "decoded guides")
     SignalPlanes spec, diff;
 };
 
-template <bool DIFF, bool SPEC, bool SH>
+// MODE 0 = plain kernel. MODE 1 = window kernel: everything read at the surface-motion position (the 12 previous-depth / material taps, the bilinear previous
+// normal, FOUR 12-texel Catmull-Rom history fetches, history length, previous hit distance: ~450 bytes per pixel through the L1) comes from one rectangle of
+// the previous frame per workgroup, copied into LDS with coalesced row loads -- every texel once -- and read from there; bit-identical by construction (same
+// texels at the same clamped coordinates, same arithmetic). A tile whose rectangle does not fit sets its byte of P.tileFlags and is done by MODE 2, the plain
+// kernel behind a flag test, launched right after. The SH histories (2x2 bilinear only) and the virtual-motion fetches stay in global memory.
+template <bool DIFF, bool SPEC, bool SH, int MODE>
 __global__ __launch_bounds__(256, NRD_WAVES_RELAX_TA) void RelaxTemporalAccumulationKernel(RelaxCB cArg, TaPlanes P, RowRange rows) {
     __shared__ float4 s_NormalSpecHitT[ta::BUF_Y * ta::BUF_STRIDE];
+    constexpr int WIN_TEXELS = MODE == 1 ? WIN_W * WIN_H : 1;
+    __shared__ float s_WinZ[WIN_TEXELS];       // packed previous viewZ
+    __shared__ uint32_t s_WinN[WIN_TEXELS];    // previous normal / roughness (RGBA8)
+    __shared__ uint32_t s_WinMisc[WIN_TEXELS]; // previous history length (bits 0-7), material ID (8-15), specular hit distance (fp16, 16-31)
+    __shared__ uint2 s_WinDiffPrev[(MODE == 1 && DIFF) ? WIN_W * WIN_H : 1], s_WinDiffFast[(MODE == 1 && DIFF) ? WIN_W * WIN_H : 1]; // RGBA16F history texels, undecoded
+    __shared__ uint2 s_WinSpecPrev[(MODE == 1 && SPEC) ? WIN_W * WIN_H : 1], s_WinSpecFast[(MODE == 1 && SPEC) ? WIN_W * WIN_H : 1];
+    __shared__ int s_WinBox[4][4];
     // The constant block + up to 35 planes need far more than the 102 SGPRs there are; left alone the compiler spills scalars into
     // VGPR lanes (v_writelane / v_readlane + hazard nops on every use). The body reads the constants from an LDS copy instead
     // (uniform-address ds_read, off the VALU), re-read per phase; only the prologue touches the kernel-argument copy.
@@ -62,8 +82,14 @@ __global__ __launch_bounds__(256, NRD_WAVES_RELAX_TA) void RelaxTemporalAccumula
     const int px = BlockTileX(rows) * TILE_X + tx, py = blockY * TILE_Y + ty;
     const int rectW = cArg.shared.gRectSize.x, rectH = cArg.shared.gRectSize.y;
 
-    if (!RelaxBlockHasGeometry(P.tiles, BlockTileX(rows), blockY)) // uniform per workgroup
+    uint8_t* const tileFlag = MODE != 0 ? P.tileFlags.ptr + (uint32_t)blockY * P.tileFlags.pitch + (uint32_t)BlockTileX(rows) : nullptr;
+    if (MODE == 2 && *tileFlag == 0)
+        return; // the window kernel has done this tile (uniform)
+    if (!RelaxBlockHasGeometry(P.tiles, BlockTileX(rows), blockY)) { // uniform per workgroup
+        if (MODE == 1 && threadIdx.x == 0)
+            *tileFlag = 0;
         return;
+    }
 
     // preload (normal, specular hitT) at rect-clamped coordinates
     for (int idx = threadIdx.x; idx < ta::BUF_X * ta::BUF_Y; idx += 256) {
@@ -84,18 +110,24 @@ __global__ __launch_bounds__(256, NRD_WAVES_RELAX_TA) void RelaxTemporalAccumula
     const RelaxCB& c = s_Constants;
 #define NRD_CONSTANTS_PHASE() asm volatile("" ::: "memory")
 
-    if (px >= rectW || py >= rectH || py < rows.rowBegin || py >= rows.rowEnd)
+    // MODE 1: every thread stays until the window is filled; a thread without a pixel to denoise runs the prologue on a position clamped into the rect
+    // (its loads stay legal, its values are never used) and is left out of the bounding box
+    const int lpx = MODE == 1 ? min(px, rectW - 1) : px, lpy = MODE == 1 ? min(py, rectH - 1) : py;
+    bool active = !(px >= rectW || py >= rectH || py < rows.rowBegin || py >= rows.rowEnd);
+    if (MODE != 1 && !active)
         return;
-    if (LoadR8Unorm(P.tiles, px >> 4, py >> 4) != 0.0f)
+    active = active && LoadR8Unorm(P.tiles, lpx >> 4, lpy >> 4) == 0.0f;
+    if (MODE != 1 && !active)
         return;
-    const float currentLinearZ = RelaxUnpackViewZ(c, LoadR32F(P.viewZ, px, py));
-    if (currentLinearZ > c.shared.gDenoisingRange)
+    const float currentLinearZ = RelaxUnpackViewZ(c, LoadR32F(P.viewZ, lpx, lpy));
+    active = active && !(currentLinearZ > c.shared.gDenoisingRange);
+    if (MODE != 1 && !active)
         return;
 
     auto Shared = [&](int dx, int dy) { return s_NormalSpecHitT[(ty + ta::BORDER + dy) * ta::BUF_STRIDE + (tx + ta::BORDER + dx)]; };
 
     float currentMaterialID;
-    float4 currentNormalRoughness = LoadDecodedNormalRoughness(P.decodedNR, px, py, currentMaterialID);
+    float4 currentNormalRoughness = LoadDecodedNormalRoughness(P.decodedNR, lpx, lpy, currentMaterialID);
     const float3 currentNormal = Xyz(currentNormalRoughness);
     const float currentRoughness = currentNormalRoughness.w;
 
@@ -112,7 +144,7 @@ __global__ __launch_bounds__(256, NRD_WAVES_RELAX_TA) void RelaxTemporalAccumula
 
     // previous position
     const float2 pixelUv = F2(float(px) + 0.5f, float(py) + 0.5f) * rectSizeInv;
-    float4 mvRaw = LoadRGBA16F(P.mv, px, py);
+    float4 mvRaw = LoadRGBA16F(P.mv, lpx, lpy);
     float3 mv = Xyz(mvRaw) * ToF3(c.shared.gMvScale);
     float3 prevWorldPos = currentWorldPos;
     float2 prevUVSMB = pixelUv + F2(mv.x, mv.y);
@@ -126,10 +158,10 @@ __global__ __launch_bounds__(256, NRD_WAVES_RELAX_TA) void RelaxTemporalAccumula
     }
 
     // noisy inputs
-    const float3 diffuseIllumination = DIFF ? Xyz(LoadRGBA16F(P.diff.in, px, py)) : F3(0.0f);
-    const float4 diffuseSH = (DIFF && SH) ? LoadRGBA16F(P.diff.inSh, px, py) : F4(0.0f);
-    const float4 specularIllumination = SPEC ? LoadRGBA16F(P.spec.in, px, py) : F4(0.0f);
-    const float4 specularSH = (SPEC && SH) ? LoadRGBA16F(P.spec.inSh, px, py) : F4(0.0f);
+    const float3 diffuseIllumination = DIFF ? Xyz(LoadRGBA16F(P.diff.in, lpx, lpy)) : F3(0.0f);
+    const float4 diffuseSH = (DIFF && SH) ? LoadRGBA16F(P.diff.inSh, lpx, lpy) : F4(0.0f);
+    const float4 specularIllumination = SPEC ? LoadRGBA16F(P.spec.in, lpx, lpy) : F4(0.0f);
+    const float4 specularSH = (SPEC && SH) ? LoadRGBA16F(P.spec.inSh, lpx, lpy) : F4(0.0f);
 
     // average normal and min hit distance in 3x3
     float hitTM1 = Shared(0, 0).w;
@@ -168,7 +200,7 @@ __global__ __launch_bounds__(256, NRD_WAVES_RELAX_TA) void RelaxTemporalAccumula
     if (currentMaterialID == c.shared.gStrandMaterialID)
         disocclusionThresholdMix = Sat(Div(c.shared.gStrandThickness, pixelSize));
     if (c.shared.gHasDisocclusionThresholdMix)
-        disocclusionThresholdMix = LoadR8Unorm(P.disocclusionThresholdMix, px, py);
+        disocclusionThresholdMix = LoadR8Unorm(P.disocclusionThresholdMix, lpx, lpy);
     const float disocclusionThreshold = Lerp(c.shared.gDisocclusionThreshold, c.shared.gDisocclusionThresholdAlternate, disocclusionThresholdMix);
 
     NRD_CONSTANTS_PHASE();
@@ -185,6 +217,63 @@ __global__ __launch_bounds__(256, NRD_WAVES_RELAX_TA) void RelaxTemporalAccumula
         const float2 originF = Floor(prevPixelPosFloat - 0.5f);
         const int bx = (int)originF.x, by = (int)originF.y;
         const float2 bilinearWeights = F2(Frac(prevPixelPosFloat.x - 0.5f), Frac(prevPixelPosFloat.y - 0.5f));
+        const float minMaterialID = Min(c.shared.gSpecMinMaterial, c.shared.gDiffMinMaterial);
+        // no material reads at all while the material test is off (IDs are 0..3: a minimum >= 3 makes every comparison hold; the library default is 4)
+        const bool compareMaterials = minMaterialID < 3.0f;
+
+        // ---- MODE 1: the window. Every surface-motion read of this pixel is a texel at a clamped coordinate within [bx - 1, bx + 2] x [by - 1, by + 2]
+        int wx0 = 0, wy0 = 0;
+        const int W1 = P.prevViewZ.w - 1, H1 = P.prevViewZ.h - 1; // every plane staged here has the size of prevViewZ (checked by the launcher)
+        if (MODE == 1) {
+            int loX = INT_MAX, loY = INT_MAX, hiX = INT_MIN, hiY = INT_MIN;
+            if (active)
+                loX = ClampI(bx - 1, 0, W1), hiX = ClampI(bx + 2, 0, W1), loY = ClampI(by - 1, 0, H1), hiY = ClampI(by + 2, 0, H1);
+#pragma unroll
+            for (int m = 32; m >= 1; m >>= 1) {
+                loX = min(loX, __shfl_xor(loX, m)), loY = min(loY, __shfl_xor(loY, m));
+                hiX = max(hiX, __shfl_xor(hiX, m)), hiY = max(hiY, __shfl_xor(hiY, m));
+            }
+            const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+            if (lane == 0)
+                s_WinBox[wave][0] = loX, s_WinBox[wave][1] = loY, s_WinBox[wave][2] = hiX, s_WinBox[wave][3] = hiY;
+            __syncthreads();
+            loX = min(min(s_WinBox[0][0], s_WinBox[1][0]), min(s_WinBox[2][0], s_WinBox[3][0]));
+            loY = min(min(s_WinBox[0][1], s_WinBox[1][1]), min(s_WinBox[2][1], s_WinBox[3][1]));
+            hiX = max(max(s_WinBox[0][2], s_WinBox[1][2]), max(s_WinBox[2][2], s_WinBox[3][2]));
+            hiY = max(max(s_WinBox[0][3], s_WinBox[1][3]), max(s_WinBox[2][3], s_WinBox[3][3]));
+            const bool empty = hiX < loX; // no pixel to denoise in this tile
+            const int bw = hiX - loX + 1, bh = hiY - loY + 1;
+            if (empty || bw > P.winMaxW || bh > P.winMaxH) { // uniform
+                if (threadIdx.x == 0)
+                    *tileFlag = empty ? 0 : 1; // 1: the fallback kernel (MODE 2) does this tile
+                return;
+            }
+            if (threadIdx.x == 0)
+                *tileFlag = 0;
+            wx0 = loX, wy0 = loY;
+            // fill: one wave per row of the box, one lane per column -- coalesced row segments, every texel once
+            if (lane < bw)
+                for (int r = wave; r < bh; r += 4) {
+                    const int x = wx0 + lane, y = wy0 + r, o = r * WIN_W + lane;
+                    s_WinZ[o] = LoadR32F(P.prevViewZ, x, y);
+                    s_WinN[o] = *TexelPtr<const uint32_t>(P.prevNormalRoughness, x, y);
+                    uint32_t misc = *TexelPtr<const uint8_t>(P.prevHistoryLength, x, y);
+                    if (compareMaterials)
+                        misc |= (uint32_t)*TexelPtr<const uint8_t>(P.prevMaterialID, x, y) << 8;
+                    if (SPEC)
+                        misc |= LoadR16U(P.prevSpecHitDist, x, y) << 16;
+                    s_WinMisc[o] = misc;
+                    if (DIFF)
+                        s_WinDiffPrev[o] = *TexelPtr<const uint2>(P.diff.prev, x, y), s_WinDiffFast[o] = *TexelPtr<const uint2>(P.diff.fast, x, y);
+                    if (SPEC)
+                        s_WinSpecPrev[o] = *TexelPtr<const uint2>(P.spec.prev, x, y), s_WinSpecFast[o] = *TexelPtr<const uint2>(P.spec.fast, x, y);
+                }
+            __syncthreads();
+            if (!active)
+                return;
+        }
+        // window index of the texel at the clamped coordinate
+        auto Win = [&](int x, int y) { return (ClampI(y, 0, H1) - wy0) * WIN_W + (ClampI(x, 0, W1) - wx0); };
 
         const float frustumSize = pixelSize * float(rectW < rectH ? rectW : rectH);
         const float disocclusionThresholdSlopeScale = Rcp(Lerp(Lerp(0.05f, 1.0f, NoV), 1.0f, Sat(smbParallaxInPixelsMax * (1.0f / 30.0f))));
@@ -193,13 +282,10 @@ __global__ __launch_bounds__(256, NRD_WAVES_RELAX_TA) void RelaxTemporalAccumula
         smbDisocclusionThreshold = smbDisocclusionThreshold - NRD_EPS;
 
         const float prevViewPosZ = AffineTransform(c.shared.gWorldToViewPrev, prevWorldPos).z;
-        const float minMaterialID = Min(c.shared.gSpecMinMaterial, c.shared.gDiffMinMaterial);
         // The 12 previous-depth taps (rows of 2 + 4 + 4 + 2 texels around the bilinear origin): four row loads when no coordinate needs clamping
-        // (reblur_device.h "row-vector fetches"), and no material reads at all while the material test is off (IDs are 0..3: a minimum >= 3 makes every
-        // comparison hold; the library default is 4).
-        const bool compareMaterials = minMaterialID < 3.0f;
+        // (reblur_device.h "row-vector fetches")
         float zRows[4][4];
-        const bool footprintInterior = FootprintIsInterior(P.prevViewZ, bx - 1, by - 1, 4, 4);
+        const bool footprintInterior = MODE != 1 && FootprintIsInterior(P.prevViewZ, bx - 1, by - 1, 4, 4);
         if (footprintInterior) {
             const float2 r0 = LoadRowR32Fx2(P.prevViewZ, bx, by - 1), r3 = LoadRowR32Fx2(P.prevViewZ, bx, by + 2);
             const float4 r1 = LoadRowR32Fx4(P.prevViewZ, bx - 1, by), r2 = LoadRowR32Fx4(P.prevViewZ, bx - 1, by + 1);
@@ -209,11 +295,11 @@ __global__ __launch_bounds__(256, NRD_WAVES_RELAX_TA) void RelaxTemporalAccumula
             zRows[0][0] = zRows[0][3] = zRows[3][0] = zRows[3][3] = 0.0f;
         }
         auto Valid = [&](int dx, int dy, float threshold) {
-            float z = RelaxUnpackViewZ(c, footprintInterior ? zRows[dy + 1][dx + 1] : FetchClampedR32F(P.prevViewZ, bx + dx, by + dy));
+            float z = RelaxUnpackViewZ(c, MODE == 1 ? s_WinZ[Win(bx + dx, by + dy)] : footprintInterior ? zRows[dy + 1][dx + 1] : FetchClampedR32F(P.prevViewZ, bx + dx, by + dy));
             float v = Step(Abs(z - prevViewPosZ), threshold);
             if (!compareMaterials)
                 return v;
-            float m = FetchClampedR8Unorm(P.prevMaterialID, bx + dx, by + dy) * 255.0f;
+            float m = (MODE == 1 ? NRD_DIV_255(float((s_WinMisc[Win(bx + dx, by + dy)] >> 8) & 0xFFu)) : FetchClampedR8Unorm(P.prevMaterialID, bx + dx, by + dy)) * 255.0f;
             return v * Cmp(CompareMaterials(currentMaterialID, m, minMaterialID));
         };
         const float3 tapsValid0 = F3(Valid(0, -1, smbDisocclusionThreshold.x), Valid(-1, 0, smbDisocclusionThreshold.x), Valid(0, 0, smbDisocclusionThreshold.x));
@@ -225,7 +311,15 @@ __global__ __launch_bounds__(256, NRD_WAVES_RELAX_TA) void RelaxTemporalAccumula
         float bicubicFootprintValid = (tapsSum.x + tapsSum.y + tapsSum.z) > 11.5f ? 1.0f : 0.0f;
         float4 bilinearTapsValid = F4(tapsValid0.z, tapsValid1.y, tapsValid2.y, tapsValid3.x);
 
-        float3 prevNormalFlat = Xyz(UnpackPrevNormalRoughness(SampleLinearRGBA8Unorm(P.prevNormalRoughness, F2(float(bx) + 1.0f, float(by) + 1.0f))));
+        float3 prevNormalFlat;
+        if (MODE == 1) { // SampleLinearRGBA8Unorm on window texels (same taps, same weights, same order)
+            const LinearTaps t = MakeLinearTaps(F2(float(bx) + 1.0f, float(by) + 1.0f));
+            const float4 s00 = DecodeRGBA8Unorm(s_WinN[Win(t.x0, t.y0)]), s10 = DecodeRGBA8Unorm(s_WinN[Win(t.x0 + 1, t.y0)]), s01 = DecodeRGBA8Unorm(s_WinN[Win(t.x0, t.y0 + 1)]),
+                         s11 = DecodeRGBA8Unorm(s_WinN[Win(t.x0 + 1, t.y0 + 1)]);
+            prevNormalFlat = Xyz(UnpackPrevNormalRoughness(s00 * t.w00 + s10 * t.w10 + s01 * t.w01 + s11 * t.w11));
+        } else {
+            prevNormalFlat = Xyz(UnpackPrevNormalRoughness(SampleLinearRGBA8Unorm(P.prevNormalRoughness, F2(float(bx) + 1.0f, float(by) + 1.0f))));
+        }
         prevNormalFlat = RotateVector(c.shared.gWorldPrevToWorld, prevNormalFlat);
         if (Dot(smbNormal, prevNormalFlat) < 0.0f) {
             bilinearTapsValid = F4(0.0f);
@@ -239,13 +333,20 @@ __global__ __launch_bounds__(256, NRD_WAVES_RELAX_TA) void RelaxTemporalAccumula
         const bool useBicubic = bicubicFootprintValid > 0.0f;
 
         const HistoryFilter hf = MakeHistoryFilter(prevPixelPosFloat, bilinearCustomWeights, useBicubic, SPEC ? P.spec.prev : P.diff.prev);
+        auto History = [&](const Plane& tex, const uint2* win) { // the 12-texel fetch: from the window (MODE 1) or from memory
+            if (MODE != 1)
+                return FetchHistoryRGBA16F(hf, tex);
+            HistoryTexelsRGBA16F t;
+            WindowHistoryTexels(hf, win, wx0, wy0, WIN_W, t);
+            return FetchHistoryRGBA16F(hf, tex, t);
+        };
         if (DIFF) {
-            prevDiffuseIllumAnd2ndMomentSMB = Max0(FetchHistoryRGBA16F(hf, P.diff.prev));
-            prevDiffuseResponsiveSMB = Xyz(Max0(FetchHistoryRGBA16F(hf, P.diff.fast)));
+            prevDiffuseIllumAnd2ndMomentSMB = Max0(History(P.diff.prev, s_WinDiffPrev));
+            prevDiffuseResponsiveSMB = Xyz(Max0(History(P.diff.fast, s_WinDiffFast)));
         }
         if (SPEC) {
-            prevSpecularIllumAnd2ndMomentSMB = Max0(FetchHistoryRGBA16F(hf, P.spec.prev));
-            prevSpecularResponsiveSMB = Xyz(Max0(FetchHistoryRGBA16F(hf, P.spec.fast)));
+            prevSpecularIllumAnd2ndMomentSMB = Max0(History(P.spec.prev, s_WinSpecPrev));
+            prevSpecularResponsiveSMB = Xyz(Max0(History(P.spec.fast, s_WinSpecFast)));
         }
         if (SH) {
             if (DIFF) {
@@ -258,13 +359,22 @@ __global__ __launch_bounds__(256, NRD_WAVES_RELAX_TA) void RelaxTemporalAccumula
             }
         }
 
-        historyLength = 255.0f * BilinearWithCustomWeightsImmediateFloat(FetchClampedR8Unorm(P.prevHistoryLength, bx, by), FetchClampedR8Unorm(P.prevHistoryLength, bx + 1, by),
-                                     FetchClampedR8Unorm(P.prevHistoryLength, bx, by + 1), FetchClampedR8Unorm(P.prevHistoryLength, bx + 1, by + 1), bilinearCustomWeights);
-        if (SPEC) {
-            prevReflectionHitTSMB = BilinearWithCustomWeightsImmediateFloat(FetchClampedR16F(P.prevSpecHitDist, bx, by), FetchClampedR16F(P.prevSpecHitDist, bx + 1, by),
-                FetchClampedR16F(P.prevSpecHitDist, bx, by + 1), FetchClampedR16F(P.prevSpecHitDist, bx + 1, by + 1), bilinearCustomWeights);
-            prevReflectionHitTSMB = Max(0.001f, prevReflectionHitTSMB);
+        if (MODE == 1) {
+            const uint32_t m00 = s_WinMisc[Win(bx, by)], m10 = s_WinMisc[Win(bx + 1, by)], m01 = s_WinMisc[Win(bx, by + 1)], m11 = s_WinMisc[Win(bx + 1, by + 1)];
+            historyLength = 255.0f * BilinearWithCustomWeightsImmediateFloat(NRD_DIV_255(float(m00 & 0xFFu)), NRD_DIV_255(float(m10 & 0xFFu)), NRD_DIV_255(float(m01 & 0xFFu)),
+                                         NRD_DIV_255(float(m11 & 0xFFu)), bilinearCustomWeights);
+            if (SPEC)
+                prevReflectionHitTSMB = BilinearWithCustomWeightsImmediateFloat(HalfBitsToFloat((uint16_t)(m00 >> 16)), HalfBitsToFloat((uint16_t)(m10 >> 16)), HalfBitsToFloat((uint16_t)(m01 >> 16)),
+                    HalfBitsToFloat((uint16_t)(m11 >> 16)), bilinearCustomWeights);
+        } else {
+            historyLength = 255.0f * BilinearWithCustomWeightsImmediateFloat(FetchClampedR8Unorm(P.prevHistoryLength, bx, by), FetchClampedR8Unorm(P.prevHistoryLength, bx + 1, by),
+                                         FetchClampedR8Unorm(P.prevHistoryLength, bx, by + 1), FetchClampedR8Unorm(P.prevHistoryLength, bx + 1, by + 1), bilinearCustomWeights);
+            if (SPEC)
+                prevReflectionHitTSMB = BilinearWithCustomWeightsImmediateFloat(FetchClampedR16F(P.prevSpecHitDist, bx, by), FetchClampedR16F(P.prevSpecHitDist, bx + 1, by),
+                    FetchClampedR16F(P.prevSpecHitDist, bx, by + 1), FetchClampedR16F(P.prevSpecHitDist, bx + 1, by + 1), bilinearCustomWeights);
         }
+        if (SPEC)
+            prevReflectionHitTSMB = Max(0.001f, prevReflectionHitTSMB);
 
         SMBReprojectionFound = bicubicFootprintValid > 0.0f ? 2.0f : 1.0f;
         footprintQuality = bicubicFootprintValid > 0.0f ? 1.0f : Sum(bilinearCustomWeights);
@@ -664,7 +774,23 @@ const char* LaunchTemporalAccumulation(const PassArgs& a) {
     }
     RelaxCB c = LoadRelaxConstants(a);
     RowGrid g = GridForRows(c.shared.gRectSize.x, c.shared.gRectSize.y, TILE_X, TILE_Y, a.rowBegin, a.rowEnd);
-    LaunchPass(a, (RelaxTemporalAccumulationKernel<DIFF, SPEC, SH>), g.grid, dim3(256), c, P, MakeRowRange(g));
+    static const bool windowEnv = !(getenv("NRD_HIP_TA_WINDOW") && atoi(getenv("NRD_HIP_TA_WINDOW")) == 0); // A/B switch
+    if (windowEnv) {
+        if (!a.tileFlags.ptr || (uint32_t)a.tileFlags.w * TILE_X < (uint32_t)P.viewZ.w || (uint32_t)a.tileFlags.h * TILE_Y < (uint32_t)P.viewZ.h)
+            return "RELAX TemporalAccumulation: the executor's tile-flag scratch is missing or too small";
+        P.tileFlags = a.tileFlags;
+        static const char* limitEnv = getenv("NRD_HIP_TA_WINDOW_LIMIT"); // "WxH", test hook: a smaller box sends tiles to the fallback kernel (results do not change)
+        int limW = WIN_W, limH = WIN_H;
+        if (limitEnv && sscanf(limitEnv, "%dx%d", &limW, &limH) != 2)
+            limW = WIN_W, limH = WIN_H;
+        P.winMaxW = limW < WIN_W ? limW : WIN_W;
+        P.winMaxH = limH < WIN_H ? limH : WIN_H;
+        // window kernel (LDS-staged surface-motion reads), then the plain kernel on the tiles the first one declined
+        LaunchPass(a, (RelaxTemporalAccumulationKernel<DIFF, SPEC, SH, 1>), g.grid, dim3(256), c, P, MakeRowRange(g));
+        LaunchPass(a, (RelaxTemporalAccumulationKernel<DIFF, SPEC, SH, 2>), g.grid, dim3(256), c, P, MakeRowRange(g));
+        return nullptr;
+    }
+    LaunchPass(a, (RelaxTemporalAccumulationKernel<DIFF, SPEC, SH, 0>), g.grid, dim3(256), c, P, MakeRowRange(g));
     return nullptr;
 }
 

@@ -159,10 +159,10 @@ NRD_D void StoreRG8Unorm(const Plane& p, int x, int y, float2 v) {
     *TexelPtr<uint16_t>(p, x, y) = (uint16_t)(ToUnorm(v.x, 255.0f) | (ToUnorm(v.y, 255.0f) << 8));
 }
 
-NRD_D float4 LoadRGBA8Unorm(const Plane& p, int x, int y) {
-    uint32_t raw = *TexelPtr<const uint32_t>(p, x, y);
+NRD_D float4 DecodeRGBA8Unorm(uint32_t raw) {
     return make_float4(NRD_DIV_255(float(raw & 0xFFu)), NRD_DIV_255(float((raw >> 8) & 0xFFu)), NRD_DIV_255(float((raw >> 16) & 0xFFu)), NRD_DIV_255(float(raw >> 24)));
 }
+NRD_D float4 LoadRGBA8Unorm(const Plane& p, int x, int y) { return DecodeRGBA8Unorm(*TexelPtr<const uint32_t>(p, x, y)); }
 NRD_D void StoreRGBA8Unorm(const Plane& p, int x, int y, float4 v) {
     *TexelPtr<uint32_t>(p, x, y) = ToUnorm(v.x, 255.0f) | (ToUnorm(v.y, 255.0f) << 8) | (ToUnorm(v.z, 255.0f) << 16) | (ToUnorm(v.w, 255.0f) << 24);
 }

@@ -559,6 +559,25 @@ NRD_D void PrefetchHistoryRGBA16F(const HistoryFilter& h, const Plane& tex, Hist
         t.d = LoadRGBA16Fx2Raw(tex, h.x[1], h.y[3]);
     }
 }
+// Window kernels (kernels_reblur_ta.hip MODE 1, kernels_relax_ta.hip): the two-step fetch with the texels taken from an LDS window of the previous frame (row
+// stride winStride, first texel = plane texel (wx0, wy0)) instead of being requested from memory. A footprint on the border of
+// the plane needs no special case: texel (i, j) is the texel at the clamped coordinate (h.x[i], h.y[j]) -- what FetchHistoryGeneric reads one by one -- and
+// the blend of the row-loaded path is the same arithmetic as the generic one.
+NRD_D void WindowHistoryTexels(const HistoryFilter& h, const uint2* win, int wx0, int wy0, int winStride, HistoryTexelsRGBA16F& t) {
+    int xo[4], yo[4];
+#pragma unroll
+    for (int i = 0; i < 4; i++)
+        xo[i] = h.x[i] - wx0, yo[i] = (h.y[i] - wy0) * winStride;
+    const uint2 a0 = win[yo[0] + xo[1]], a1 = win[yo[0] + xo[2]];
+    const uint2 b0 = win[yo[1] + xo[0]], b1 = win[yo[1] + xo[1]], b2 = win[yo[1] + xo[2]], b3 = win[yo[1] + xo[3]];
+    const uint2 c0 = win[yo[2] + xo[0]], c1 = win[yo[2] + xo[1]], c2 = win[yo[2] + xo[2]], c3 = win[yo[2] + xo[3]];
+    const uint2 d0 = win[yo[3] + xo[1]], d1 = win[yo[3] + xo[2]];
+    t.a = Raw4{a0.x, a0.y, a1.x, a1.y};
+    t.b0 = Raw4{b0.x, b0.y, b1.x, b1.y}, t.b1 = Raw4{b2.x, b2.y, b3.x, b3.y};
+    t.c0 = Raw4{c0.x, c0.y, c1.x, c1.y}, t.c1 = Raw4{c2.x, c2.y, c3.x, c3.y};
+    t.d = Raw4{d0.x, d0.y, d1.x, d1.y};
+    t.loaded = true;
+}
 NRD_D float4 FetchHistoryRGBA16F(const HistoryFilter& h, const Plane& tex, const HistoryTexelsRGBA16F& t) {
     if (!t.loaded)
         return FetchHistoryGeneric<float4>(h, tex, [](const Plane& p, int x, int y) { return LoadRGBA16F(p, x, y); }, F4(0.0f));

@@ -162,9 +162,9 @@ def test_mixed_reblur_and_relax_instance_matches_the_oracle():
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("name", ["REBLUR_DIFFUSE_SPECULAR", "REBLUR_DIFFUSE_SPECULAR_SH"])
+@pytest.mark.parametrize("name", ["REBLUR_DIFFUSE_SPECULAR", "REBLUR_DIFFUSE_SPECULAR_SH", "RELAX_DIFFUSE_SPECULAR_SH", "RELAX_DIFFUSE"])
 def test_temporal_accumulation_window_and_fallback_kernels_match_the_oracle(name):
-    """REBLUR TemporalAccumulation runs as a window kernel (the surface-motion footprints of a tile come from one LDS-staged rectangle of the previous frame)
+    """REBLUR / RELAX TemporalAccumulation runs as a window kernel (the surface-motion footprints of a tile come from one LDS-staged rectangle of the previous frame)
     plus the plain kernel for the tiles whose rectangle does not fit. On the test scenes every tile fits, so the plain kernel would never run: the test hook
     NRD_HIP_TA_WINDOW_LIMIT shrinks the accepted rectangle (read once per process, hence the subprocess) until a good part of the tiles takes each path --
     all outputs and pool planes must still equal the oracle's bit for bit, and with NRD_HIP_TA_WINDOW=0 (plain kernel only) as well."""
