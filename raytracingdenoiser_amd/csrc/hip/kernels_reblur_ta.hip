@@ -73,8 +73,9 @@ NRD_D void WindowFastTexels(const HistoryFilter&, const uint32_t*, int, int, con
 // where they are used. Results are bit-identical by construction (same texels, same arithmetic). A workgroup whose box does not fit WIN_W x WIN_H
 // (a silhouette with large parallax, a jump of the camera) writes 1 into its byte of P.tileFlags and leaves; MODE 2, the unchanged global-memory kernel
 // behind a flag test, is launched right after and processes exactly those tiles. MODE 0 = the plain kernel (all other signal kinds / the performance mode).
-template <bool DIFF, bool SPEC, bool PERF, int KIND, bool SH, int WAVES, int MODE>
-__global__ __launch_bounds__(TILE_X* TILE_Y, WAVES) void ReblurTemporalAccumulationKernel(ReblurCB cArg, TaPlanes P, RowRange rr) {
+// The pass for one 32x8 tile (tile column tileX, tile row blockY of the frame); the kernel below is a thin wrapper
+template <bool DIFF, bool SPEC, bool PERF, int KIND, bool SH, int MODE>
+__device__ __forceinline__ void ReblurTemporalAccumulationTile(const ReblurCB& cArg, TaPlanes P, const RowRange& rr, const int tileX, const int blockY) {
     typedef ReblurSignal<KIND> Sig;
     constexpr bool OCC = KIND == SIGNAL_OCCLUSION;
     typedef typename Sig::type S;
@@ -108,27 +109,25 @@ __global__ __launch_bounds__(TILE_X* TILE_Y, WAVES) void ReblurTemporalAccumulat
     __shared__ int s_WinBox[4][4];
 
     const int tx = threadIdx.x % TILE_X, ty = threadIdx.x / TILE_X;
-    const int blockY = blockIdx.y + rr.firstBlockY;
-    uint8_t* const tileFlag = MODE != 0 ? P.tileFlags.ptr + (uint32_t)blockY * P.tileFlags.pitch + (uint32_t)BlockTileX(rr) : nullptr;
-    if (MODE == 2 && *tileFlag == 0)
-        return; // the window kernel has done this tile (uniform)
-    const int px = BlockTileX(rr) * TILE_X + tx, py = blockY * TILE_Y + ty;
+    // (workgroups of the XCD-aware grid may lie beyond the frame: they have no pixels and no flag)
+    uint8_t* const tileFlag = (MODE == 1 && tileX < P.tileFlags.w && blockY < P.tileFlags.h) ? P.tileFlags.ptr + (uint32_t)blockY * P.tileFlags.pitch + (uint32_t)tileX : nullptr;
+    const int px = tileX * TILE_X + tx, py = blockY * TILE_Y + ty;
     const int rw = cArg.gRectSizeMinusOne.x, rh = cArg.gRectSizeMinusOne.y;
 
     // ---- cooperative preload (clamped to the rect), skipped when every 16x16 tile under this block is sky
     {
-        const int tileY = (blockY * TILE_Y) >> 4, tileX0 = (BlockTileX(rr) * TILE_X) >> 4;
+        const int tileY = (blockY * TILE_Y) >> 4, tileX0 = (tileX * TILE_X) >> 4;
         bool anyGeometry = false;
         for (int t = 0; t < TILE_X / 16; t++)
             if (tileX0 + t < P.tiles.w && tileY < P.tiles.h)
                 anyGeometry |= LoadR8Unorm(P.tiles, tileX0 + t, tileY) == 0.0f;
         if (!anyGeometry) {
-            if (MODE == 1 && threadIdx.x == 0)
+            if (MODE == 1 && threadIdx.x == 0 && tileFlag)
                 *tileFlag = 0;
             return; // uniform across the block
         }
 
-        const int baseX = BlockTileX(rr) * TILE_X - BORDER, baseY = blockY * TILE_Y - BORDER;
+        const int baseX = tileX * TILE_X - BORDER, baseY = blockY * TILE_Y - BORDER;
         for (int i = threadIdx.x; i < BUF_X * BUF_Y; i += TILE_X * TILE_Y) {
             int lx = i % BUF_X, ly = i / BUF_X;
             int gx = ClampI(baseX + lx, 0, rw), gy = ClampI(baseY + ly, 0, rh);
@@ -273,11 +272,11 @@ __global__ __launch_bounds__(TILE_X* TILE_Y, WAVES) void ReblurTemporalAccumulat
         const bool empty = hiX < loX; // no pixel to denoise in this tile
         const int bw = hiX - loX + 1, bh = hiY - loY + 1;
         if (empty || bw > P.winMaxW || bh > P.winMaxH) { // uniform
-            if (threadIdx.x == 0)
+            if (threadIdx.x == 0 && tileFlag)
                 *tileFlag = empty ? 0 : 1; // 1: the fallback kernel (MODE 2) does this tile
             return;
         }
-        if (threadIdx.x == 0)
+        if (threadIdx.x == 0 && tileFlag)
             *tileFlag = 0;
         wx0 = loX, wy0 = loY;
         // ---- fill: one wave per row of the box, one lane per column -- coalesced row segments, every texel once
@@ -992,6 +991,31 @@ __global__ __launch_bounds__(TILE_X* TILE_Y, WAVES) void ReblurTemporalAccumulat
     StoreData1<DIFF, SPEC>(P.outData1, px, py, diffAccumSpeed, specAccumSpeed);
 }
 
+// MODE 0 / 1: one workgroup per tile (XCD-aware order). MODE 2 (fallback behind the window kernel): one workgroup per FALLBACK_TILES tile columns, which walks
+// them and runs the pass on the flagged ones -- normally none, and a launch of 1/8 of the workgroups that reads 8 flags each costs ~2 us where one workgroup per
+// tile cost 14 us (r03_i_reblur_ds_kernel_stats.txt).
+constexpr int FALLBACK_TILES = 8;
+template <bool DIFF, bool SPEC, bool PERF, int KIND, bool SH, int WAVES, int MODE>
+__global__ __launch_bounds__(TILE_X* TILE_Y, WAVES) void ReblurTemporalAccumulationKernel(ReblurCB cArg, TaPlanes P, RowRange rr) {
+    const int blockY = blockIdx.y + rr.firstBlockY;
+    if (MODE != 2) {
+        ReblurTemporalAccumulationTile<DIFF, SPEC, PERF, KIND, SH, MODE>(cArg, P, rr, BlockTileX(rr), blockY);
+        return;
+    }
+    if (blockY >= P.tileFlags.h)
+        return;
+#pragma nounroll
+    for (int k = 0; k < FALLBACK_TILES; k++) {
+        const int tileX = (int)blockIdx.x * FALLBACK_TILES + k;
+        if (tileX >= P.tileFlags.w)
+            break;
+        if (P.tileFlags.ptr[(uint32_t)blockY * P.tileFlags.pitch + (uint32_t)tileX] == 0)
+            continue; // the window kernel has done this tile (uniform)
+        __syncthreads(); // the LDS tiles of the previous iteration are free
+        ReblurTemporalAccumulationTile<DIFF, SPEC, PERF, KIND, SH, MODE>(cArg, P, rr, tileX, blockY);
+    }
+}
+
 template <bool DIFF, bool SPEC, bool PERF, int KIND, bool SH>
 static const char* LaunchTemporalAccumulation(const PassArgs& a) {
     constexpr bool OCC = KIND == SIGNAL_OCCLUSION;
@@ -1061,7 +1085,9 @@ static const char* LaunchTemporalAccumulation(const PassArgs& a) {
     // which keeps its third wave (r02_k: 0.135 ms at 2 waves against 0.109 before the batching)
     static const int wavesEnv = getenv("NRD_HIP_TA_WAVES") ? atoi(getenv("NRD_HIP_TA_WAVES")) : 0;
     static const bool windowEnv = !(getenv("NRD_HIP_TA_WINDOW") && atoi(getenv("NRD_HIP_TA_WINDOW")) == 0); // A/B switch
-    constexpr bool HAS_WINDOW = !PERF && KIND == SIGNAL_RADIANCE; // the window kernel exists for the radiance + hit distance kind (RGBA16F histories fetched with Catmull-Rom)
+    // the window kernel pays where the pass is heaviest: radiance + hit distance with BOTH signals (0.267 + 0.002 ms against 0.298). Measured and left out: the
+    // single-signal denoisers (REBLUR_DIFFUSE: 0.126 + launch of the fallback against 0.112 -- the plain kernel already runs 3 waves and is VALU-bound, r03_i)
+    constexpr bool HAS_WINDOW = DIFF && SPEC && !PERF && KIND == SIGNAL_RADIANCE;
     if (HAS_WINDOW && windowEnv && !wavesEnv) {
         if (!a.tileFlags.ptr || (uint32_t)a.tileFlags.w * TILE_X < (uint32_t)P.viewZ.w || (uint32_t)a.tileFlags.h * TILE_Y < (uint32_t)P.viewZ.h)
             return "REBLUR temporal accumulation: the executor's tile-flag scratch is missing or too small";
@@ -1074,7 +1100,9 @@ static const char* LaunchTemporalAccumulation(const PassArgs& a) {
         P.winMaxH = limH < WIN_H ? limH : WIN_H;
         // window kernel (LDS-staged surface-motion footprints, 3 waves per SIMD), then the plain kernel on the tiles the first one declined
         LaunchPass(a, (ReblurTemporalAccumulationKernel<DIFF, SPEC, PERF, KIND, SH, 3, HAS_WINDOW ? 1 : 0>), g.grid, dim3(TILE_X * TILE_Y), c, P, MakeRowRange(g));
-        LaunchPass(a, (ReblurTemporalAccumulationKernel<DIFF, SPEC, PERF, KIND, SH, SPEC ? 2 : 3, HAS_WINDOW ? 2 : 0>), g.grid, dim3(TILE_X * TILE_Y), c, P, MakeRowRange(g));
+        dim3 fallbackGrid = g.grid;
+        fallbackGrid.x = (unsigned)((a.tileFlags.w + FALLBACK_TILES - 1) / FALLBACK_TILES);
+        LaunchPass(a, (ReblurTemporalAccumulationKernel<DIFF, SPEC, PERF, KIND, SH, SPEC ? 2 : 3, HAS_WINDOW ? 2 : 0>), fallbackGrid, dim3(TILE_X * TILE_Y), c, P, MakeRowRange(g));
         return nullptr;
     }
     const int waves = wavesEnv ? wavesEnv : (SPEC ? 2 : 3);

@@ -49,7 +49,7 @@ struct TaPlanes {
 // texels at the same clamped coordinates, same arithmetic). A tile whose rectangle does not fit sets its byte of P.tileFlags and is done by MODE 2, the plain
 // kernel behind a flag test, launched right after. The SH histories (2x2 bilinear only) and the virtual-motion fetches stay in global memory.
 template <bool DIFF, bool SPEC, bool SH, int MODE>
-__global__ __launch_bounds__(256, NRD_WAVES_RELAX_TA) void RelaxTemporalAccumulationKernel(RelaxCB cArg, TaPlanes P, RowRange rows) {
+__device__ __forceinline__ void RelaxTemporalAccumulationTile(const RelaxCB& cArg, TaPlanes P, const RowRange& rows, const int tileX, const int blockY) {
     __shared__ float4 s_NormalSpecHitT[ta::BUF_Y * ta::BUF_STRIDE];
     constexpr int WIN_TEXELS = MODE == 1 ? WIN_W * WIN_H : 1;
     __shared__ float s_WinZ[WIN_TEXELS];       // packed previous viewZ
@@ -77,16 +77,14 @@ __global__ __launch_bounds__(256, NRD_WAVES_RELAX_TA) void RelaxTemporalAccumula
         }
     }
 
-    const int blockY = blockIdx.y + rows.firstBlockY;
     const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
-    const int px = BlockTileX(rows) * TILE_X + tx, py = blockY * TILE_Y + ty;
+    const int px = tileX * TILE_X + tx, py = blockY * TILE_Y + ty;
     const int rectW = cArg.shared.gRectSize.x, rectH = cArg.shared.gRectSize.y;
 
-    uint8_t* const tileFlag = MODE != 0 ? P.tileFlags.ptr + (uint32_t)blockY * P.tileFlags.pitch + (uint32_t)BlockTileX(rows) : nullptr;
-    if (MODE == 2 && *tileFlag == 0)
-        return; // the window kernel has done this tile (uniform)
-    if (!RelaxBlockHasGeometry(P.tiles, BlockTileX(rows), blockY)) { // uniform per workgroup
-        if (MODE == 1 && threadIdx.x == 0)
+    // (workgroups of the XCD-aware grid may lie beyond the frame: they have no pixels and no flag)
+    uint8_t* const tileFlag = (MODE == 1 && tileX < P.tileFlags.w && blockY < P.tileFlags.h) ? P.tileFlags.ptr + (uint32_t)blockY * P.tileFlags.pitch + (uint32_t)tileX : nullptr;
+    if (!RelaxBlockHasGeometry(P.tiles, tileX, blockY)) { // uniform per workgroup
+        if (MODE == 1 && threadIdx.x == 0 && tileFlag)
             *tileFlag = 0;
         return;
     }
@@ -94,7 +92,7 @@ __global__ __launch_bounds__(256, NRD_WAVES_RELAX_TA) void RelaxTemporalAccumula
     // preload (normal, specular hitT) at rect-clamped coordinates
     for (int idx = threadIdx.x; idx < ta::BUF_X * ta::BUF_Y; idx += 256) {
         int lx = idx % ta::BUF_X, ly = idx / ta::BUF_X;
-        int gx = ClampI(BlockTileX(rows) * TILE_X - ta::BORDER + lx, 0, rectW - 1), gy = ClampI(blockY * TILE_Y - ta::BORDER + ly, 0, rectH - 1);
+        int gx = ClampI(tileX * TILE_X - ta::BORDER + lx, 0, rectW - 1), gy = ClampI(blockY * TILE_Y - ta::BORDER + ly, 0, rectH - 1);
         float4 v = LoadDecodedNormalRoughness(P.decodedNR, gx, gy);
         if (SPEC)
             v.w = LoadRGBA16F(P.spec.in, gx, gy).w;
@@ -244,11 +242,11 @@ __global__ __launch_bounds__(256, NRD_WAVES_RELAX_TA) void RelaxTemporalAccumula
             const bool empty = hiX < loX; // no pixel to denoise in this tile
             const int bw = hiX - loX + 1, bh = hiY - loY + 1;
             if (empty || bw > P.winMaxW || bh > P.winMaxH) { // uniform
-                if (threadIdx.x == 0)
+                if (threadIdx.x == 0 && tileFlag)
                     *tileFlag = empty ? 0 : 1; // 1: the fallback kernel (MODE 2) does this tile
                 return;
             }
-            if (threadIdx.x == 0)
+            if (threadIdx.x == 0 && tileFlag)
                 *tileFlag = 0;
             wx0 = loX, wy0 = loY;
             // fill: one wave per row of the box, one lane per column -- coalesced row segments, every texel once
@@ -716,6 +714,30 @@ __global__ __launch_bounds__(256, NRD_WAVES_RELAX_TA) void RelaxTemporalAccumula
     }
 }
 
+// MODE 0 / 1: one workgroup per tile (XCD-aware order). MODE 2 (fallback behind the window kernel): one workgroup per FALLBACK_TILES tile columns, which walks
+// them and runs the pass on the flagged ones (kernels_reblur_ta.hip has the measurement behind this shape)
+constexpr int FALLBACK_TILES = 8;
+template <bool DIFF, bool SPEC, bool SH, int MODE>
+__global__ __launch_bounds__(256, NRD_WAVES_RELAX_TA) void RelaxTemporalAccumulationKernel(RelaxCB cArg, TaPlanes P, RowRange rows) {
+    const int blockY = blockIdx.y + rows.firstBlockY;
+    if (MODE != 2) {
+        RelaxTemporalAccumulationTile<DIFF, SPEC, SH, MODE>(cArg, P, rows, BlockTileX(rows), blockY);
+        return;
+    }
+    if (blockY >= P.tileFlags.h)
+        return;
+#pragma nounroll
+    for (int k = 0; k < FALLBACK_TILES; k++) {
+        const int tileX = (int)blockIdx.x * FALLBACK_TILES + k;
+        if (tileX >= P.tileFlags.w)
+            break;
+        if (P.tileFlags.ptr[(uint32_t)blockY * P.tileFlags.pitch + (uint32_t)tileX] == 0)
+            continue; // the window kernel has done this tile (uniform)
+        __syncthreads(); // the LDS tiles of the previous iteration are free
+        RelaxTemporalAccumulationTile<DIFF, SPEC, SH, MODE>(cArg, P, rows, tileX, blockY);
+    }
+}
+
 template <bool DIFF, bool SPEC, bool SH>
 const char* LaunchTemporalAccumulation(const PassArgs& a) {
     if (const char* e = CheckSupportedRelax(a))
@@ -787,7 +809,9 @@ const char* LaunchTemporalAccumulation(const PassArgs& a) {
         P.winMaxH = limH < WIN_H ? limH : WIN_H;
         // window kernel (LDS-staged surface-motion reads), then the plain kernel on the tiles the first one declined
         LaunchPass(a, (RelaxTemporalAccumulationKernel<DIFF, SPEC, SH, 1>), g.grid, dim3(256), c, P, MakeRowRange(g));
-        LaunchPass(a, (RelaxTemporalAccumulationKernel<DIFF, SPEC, SH, 2>), g.grid, dim3(256), c, P, MakeRowRange(g));
+        dim3 fallbackGrid = g.grid;
+        fallbackGrid.x = (unsigned)((a.tileFlags.w + FALLBACK_TILES - 1) / FALLBACK_TILES);
+        LaunchPass(a, (RelaxTemporalAccumulationKernel<DIFF, SPEC, SH, 2>), fallbackGrid, dim3(256), c, P, MakeRowRange(g));
         return nullptr;
     }
     LaunchPass(a, (RelaxTemporalAccumulationKernel<DIFF, SPEC, SH, 0>), g.grid, dim3(256), c, P, MakeRowRange(g));
