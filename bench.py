@@ -34,7 +34,7 @@ from raytracingdenoiser_amd import api, scene, sharding, synth
 from raytracingdenoiser_amd import build as native_build
 from raytracingdenoiser_amd.executor import HipExecutor
 
-VALU_CYCLES_PER_INSTRUCTION = 3.0  # average over the instruction mix of the pass kernels (profiles/r02_b_valu_bench.txt price list x tools/isa_stats.py --cost)
+VALU_CYCLES_PER_INSTRUCTION = 4.2  # SQ_ACTIVE_INST_VALU x 4 / SQ_INSTS_VALU of every pass kernel measured so far (profiles/pmc_traffic.json); used when a counter run lacks the counter
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E peak (MI355X_MICROARCH.md); ~6300 GB/s is what a float4 copy achieves (measured live below)
 
 # Published reference numbers for the exact metric (reference README.md:18, RTX 4080, 1440p native)
@@ -363,11 +363,13 @@ def main():
                 traffic = int((2.0 * k["FETCH_SIZE_KiB"] + k["WRITE_SIZE_KiB"]) * 1024)
                 traffic_source = entry.get("source")
                 if k.get("SQ_INSTS_VALU"):
-                    # the bound these kernels actually sit at: VALU issue. Executed wave instructions x the measured average issue cost of the
-                    # kernels' instruction mix (~3.0 SIMD cycles: 2.4 for fma / mul / add, 4.1 for the rest, 8.1 for transcendentals) over 1024 SIMDs at 2.4 GHz
-                    issue_ms = k["SQ_INSTS_VALU"] * VALU_CYCLES_PER_INSTRUCTION / (1024 * 2.4e6)
-                    valu = {"executed_valu_per_wave": k["valu_per_wave"], "waves_per_launch": int(k["SQ_WAVES"]), "cycles_per_instruction": VALU_CYCLES_PER_INSTRUCTION,
-                            "issue_bound_ms": round(issue_ms, 4), "frac_of_issue_bound": round(issue_ms / passes[dominant]["avg_ms"], 3)}
+                    # the bound these kernels actually sit at: VALU issue. Executed wave instructions x the average issue cost of this kernel's
+                    # instruction mix -- measured where the counter run has SQ_ACTIVE_INST_VALU (unit: 4 cycles), else the price-list average -- over 1024 SIMDs at 2.4 GHz
+                    cpi = k.get("valu_cycles_per_instruction", VALU_CYCLES_PER_INSTRUCTION)
+                    issue_ms = k["SQ_INSTS_VALU"] * cpi / (1024 * 2.4e6)
+                    valu = {"executed_valu_per_wave": k["valu_per_wave"], "waves_per_launch": int(k["SQ_WAVES"]), "cycles_per_instruction": cpi,
+                            "issue_bound_ms": round(issue_ms, 4), "frac_of_issue_bound": round(issue_ms / passes[dominant]["avg_ms"], 3),
+                            "valu_busy_frac_in_counter_run": k.get("valu_busy_frac")}
         roofline = {"bound": "hbm", "kernel": dominant, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
                     "measured_copy_GBps": round(copy_gbs, 1), "frac_of_measured_copy": round(achieved / copy_gbs, 4),
                     "denoised_pixel_fraction": round(denoised_fraction, 4), "frac_denoised_pixels": round(achieved / HBM_PEAK_GBS * denoised_fraction, 4),

@@ -1004,15 +1004,23 @@ __global__ __launch_bounds__(TILE_X* TILE_Y, WAVES) void ReblurTemporalAccumulat
     }
     if (blockY >= P.tileFlags.h)
         return;
+    // the FALLBACK_TILES flags of this workgroup with ONE memory latency: lane k of every wave reads flag k, the set bits are OR-ed across the wave
+    // (read one after the other, the eight dependent loads were the whole cost of this kernel: 14 us per launch with nothing to do, r03_j)
+    const int lane = threadIdx.x & 63, firstTile = (int)blockIdx.x * FALLBACK_TILES;
+    int mask = 0;
+    if (lane < FALLBACK_TILES && firstTile + lane < P.tileFlags.w)
+        mask = P.tileFlags.ptr[(uint32_t)blockY * P.tileFlags.pitch + (uint32_t)(firstTile + lane)] != 0 ? 1 << lane : 0;
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1)
+        mask |= __shfl_xor(mask, m);
+    if (mask == 0)
+        return; // the window kernel has done all these tiles (uniform; the usual case)
 #pragma nounroll
     for (int k = 0; k < FALLBACK_TILES; k++) {
-        const int tileX = (int)blockIdx.x * FALLBACK_TILES + k;
-        if (tileX >= P.tileFlags.w)
-            break;
-        if (P.tileFlags.ptr[(uint32_t)blockY * P.tileFlags.pitch + (uint32_t)tileX] == 0)
-            continue; // the window kernel has done this tile (uniform)
+        if (!(mask & (1 << k)))
+            continue;
         __syncthreads(); // the LDS tiles of the previous iteration are free
-        ReblurTemporalAccumulationTile<DIFF, SPEC, PERF, KIND, SH, MODE>(cArg, P, rr, tileX, blockY);
+        ReblurTemporalAccumulationTile<DIFF, SPEC, PERF, KIND, SH, MODE>(cArg, P, rr, firstTile + k, blockY);
     }
 }
 

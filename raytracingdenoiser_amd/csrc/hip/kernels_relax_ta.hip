@@ -726,15 +726,23 @@ __global__ __launch_bounds__(256, NRD_WAVES_RELAX_TA) void RelaxTemporalAccumula
     }
     if (blockY >= P.tileFlags.h)
         return;
+    // the FALLBACK_TILES flags of this workgroup with ONE memory latency: lane k of every wave reads flag k, the set bits are OR-ed across the wave
+    // (read one after the other, the eight dependent loads were the whole cost of this kernel: 14 us per launch with nothing to do, r03_j)
+    const int lane = threadIdx.x & 63, firstTile = (int)blockIdx.x * FALLBACK_TILES;
+    int mask = 0;
+    if (lane < FALLBACK_TILES && firstTile + lane < P.tileFlags.w)
+        mask = P.tileFlags.ptr[(uint32_t)blockY * P.tileFlags.pitch + (uint32_t)(firstTile + lane)] != 0 ? 1 << lane : 0;
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1)
+        mask |= __shfl_xor(mask, m);
+    if (mask == 0)
+        return; // the window kernel has done all these tiles (uniform; the usual case)
 #pragma nounroll
     for (int k = 0; k < FALLBACK_TILES; k++) {
-        const int tileX = (int)blockIdx.x * FALLBACK_TILES + k;
-        if (tileX >= P.tileFlags.w)
-            break;
-        if (P.tileFlags.ptr[(uint32_t)blockY * P.tileFlags.pitch + (uint32_t)tileX] == 0)
-            continue; // the window kernel has done this tile (uniform)
+        if (!(mask & (1 << k)))
+            continue;
         __syncthreads(); // the LDS tiles of the previous iteration are free
-        RelaxTemporalAccumulationTile<DIFF, SPEC, SH, MODE>(cArg, P, rows, tileX, blockY);
+        RelaxTemporalAccumulationTile<DIFF, SPEC, SH, MODE>(cArg, P, rows, firstTile + k, blockY);
     }
 }
 
@@ -796,7 +804,10 @@ const char* LaunchTemporalAccumulation(const PassArgs& a) {
     }
     RelaxCB c = LoadRelaxConstants(a);
     RowGrid g = GridForRows(c.shared.gRectSize.x, c.shared.gRectSize.y, TILE_X, TILE_Y, a.rowBegin, a.rowEnd);
-    static const bool windowEnv = !(getenv("NRD_HIP_TA_WINDOW") && atoi(getenv("NRD_HIP_TA_WINDOW")) == 0); // A/B switch
+    // The window kernel is opt-in here (NRD_HIP_RELAX_TA_WINDOW=1): measured at 4K it runs 753 us against the plain kernel's 766 us and the fallback launch behind
+    // it costs more than that difference (profiles/r03_j_relax_ds_sh_kernel_stats.txt, r03_j_relax_ds_sh_{,nowindow_}bench.json) -- the plain kernel already
+    // keeps three waves per SIMD and its SIMDs 72 % busy with VALU work, so the L1 bytes the window saves buy little. Kept for A/B runs and for larger frames.
+    static const bool windowEnv = getenv("NRD_HIP_RELAX_TA_WINDOW") && atoi(getenv("NRD_HIP_RELAX_TA_WINDOW")) != 0;
     if (windowEnv) {
         if (!a.tileFlags.ptr || (uint32_t)a.tileFlags.w * TILE_X < (uint32_t)P.viewZ.w || (uint32_t)a.tileFlags.h * TILE_Y < (uint32_t)P.viewZ.h)
             return "RELAX TemporalAccumulation: the executor's tile-flag scratch is missing or too small";

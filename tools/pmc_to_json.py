@@ -41,6 +41,12 @@ def parse_columns(path):
 def main():
     key, fetch_file, write_file, source = sys.argv[1:5]
     sq = parse_columns(sys.argv[5]) if len(sys.argv) > 5 else {}
+    sq_avg_us = {}
+    if len(sys.argv) > 5:
+        for line in open(sys.argv[5]).read().splitlines()[1:]:
+            m = re.match(r"(.*?)\s+(\d+)\s+([\d.]+)\s+[\d.e+-]+", line)
+            if m:
+                sq_avg_us[m.group(1).strip()] = float(m.group(3))
     base = key[: -len("_nosky")] if key.endswith("_nosky") else key
     family = {"REBLUR_DIFFUSE_SPECULAR": "REBLUR_DiffuseSpecular_", "RELAX_DIFFUSE_SPECULAR_SH": "RELAX_DiffuseSpecularSh_", "RELAX_DIFFUSE_SPECULAR": "RELAX_DiffuseSpecular_"}[base.rsplit("_", 1)[0]]
     fetch, write = parse(fetch_file), parse(write_file)
@@ -55,6 +61,12 @@ def main():
                     c = sq.get(kname)
                     if c and c.get("SQ_INSTS_VALU") and c.get("SQ_WAVES"):
                         kernels[shader].update({"SQ_INSTS_VALU": c["SQ_INSTS_VALU"], "SQ_WAVES": c["SQ_WAVES"], "valu_per_wave": round(c["SQ_INSTS_VALU"] / c["SQ_WAVES"], 1)})
+                        active = c.get("SQ_ACTIVE_INST_V") or c.get("SQ_ACTIVE_INST_VALU")  # (pmc_summary.py truncates the counter names to 16 characters)
+                        if active and sq_avg_us.get(kname):
+                            # SQ_ACTIVE_INST_VALU counts in units of 4 cycles, summed over the SIMDs: cycles per executed instruction and the fraction of the
+                            # kernel's duration (in THIS counter run) its 1024 SIMDs spent executing VALU instructions, at the 2.4 GHz peak clock
+                            kernels[shader].update({"SQ_ACTIVE_INST_VALU": active, "pmc_run_avg_us": sq_avg_us[kname], "valu_cycles_per_instruction": round(4.0 * active / c["SQ_INSTS_VALU"], 2),
+                                                    "valu_busy_frac": round(4.0 * active / (1024 * 2400.0 * sq_avg_us[kname]), 3)})
                 break
     path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles", "pmc_traffic.json")
     data = json.load(open(path)) if os.path.exists(path) else {}
