@@ -7,9 +7,10 @@
 // with border-clamped loads -- every texel is decoded once per workgroup instead of 9+2 times per pixel. The row stride
 // of the float4 tile is 35 slots (560 B): rows of a wave start on different 16-byte slots, so the ds_read_b128 taps
 // of the two rows do not collide. Everything after that is per-pixel: reprojection, the 4x4 previous-depth footprint,
-// disocclusion tests, virtual-motion tracking, Catmull-Rom history fetches (5 bilinear fetches, i.e. 20 fp16 texels per
-// plane) and the accumulation itself. The kernel is latency/ALU bound, not HBM bound: ~66 B/px are read and 28 B/px
-// written against several hundred dependent VALU ops per pixel, so occupancy (VGPRs) is the lever, not bytes.
+// disocclusion tests, virtual-motion tracking, Catmull-Rom history fetches (12 fp16 texels per plane) and the accumulation
+// itself. The kernel is bound by VALU issue, not by HBM and (since the window kernel, MODE 1 below) not by latency either:
+// ~94 B/px of compulsory traffic against ~3 700 executed VALU instructions per wave of denoised pixels, its SIMDs 91 % busy
+// with them (profiles/r03_i_reblur_ds_pmc3.txt).
 #include "passes.h"
 #include <climits>
 #include <cstdio>
@@ -992,8 +993,8 @@ __device__ __forceinline__ void ReblurTemporalAccumulationTile(const ReblurCB& c
 }
 
 // MODE 0 / 1: one workgroup per tile (XCD-aware order). MODE 2 (fallback behind the window kernel): one workgroup per FALLBACK_TILES tile columns, which walks
-// them and runs the pass on the flagged ones -- normally none, and a launch of 1/8 of the workgroups that reads 8 flags each costs ~2 us where one workgroup per
-// tile cost 14 us (r03_i_reblur_ds_kernel_stats.txt).
+// them and runs the pass on the flagged ones -- normally none: 4 us per launch where one workgroup per tile with a flag test in front cost 14 us
+// (profiles/r03_k_reblur_ds_kernel_stats.txt against r03_i_reblur_ds_kernel_stats.txt).
 constexpr int FALLBACK_TILES = 8;
 template <bool DIFF, bool SPEC, bool PERF, int KIND, bool SH, int WAVES, int MODE>
 __global__ __launch_bounds__(TILE_X* TILE_Y, WAVES) void ReblurTemporalAccumulationKernel(ReblurCB cArg, TaPlanes P, RowRange rr) {
