@@ -924,9 +924,9 @@ NRD_D void ResolveSignal(const RelaxCB& c, const SignalPlanes& S, const float4* 
 #pragma unroll
         for (int dy = -2; dy <= 2; dy++) {
             const int li = (ly + dy) * hc::BUF_STRIDE + (lx + dx);
-            float4 noisy = s_Noisy[li];
-            if (noisy.w != 0.0f) {
-                float3 sampleYCoCg = Xyz(s_Fast[li]);
+            const float4 noisy = LdsFloat4(&s_Noisy[li]), fast = LdsFloat4(&s_Fast[li]); // whole texels, unconditionally: one ds_read_b128 each (planes.h "LDS texels")
+            if (noisy.w != 0.0f) { // (kept as a branch: the select form of this body costs 36 % more instructions and 165 VGPRs)
+                float3 sampleYCoCg = Xyz(fast);
                 fastM1 = fastM1 + sampleYCoCg;
                 fastM2 = fastM2 + sampleYCoCg * sampleYCoCg;
                 float noisyLuminance = Luminance(Xyz(noisy));
@@ -941,7 +941,7 @@ NRD_D void ResolveSignal(const RelaxCB& c, const SignalPlanes& S, const float4* 
     noisyM2 = Div(noisyM2, sum);
 
     const int lc = ly * hc::BUF_STRIDE + lx;
-    ClampOut o = ClampSignal<IS_SPEC>(c, fastM1, fastM2, noisyM1, noisyM2, s_Fast[lc], LoadRGBA16F(S.in, px, py), Xyz(s_Noisy[lc]), historyLength);
+    ClampOut o = ClampSignal<IS_SPEC>(c, fastM1, fastM2, noisyM1, noisyM2, LdsFloat4(&s_Fast[lc]), LoadRGBA16F(S.in, px, py), Xyz(LdsFloat4(&s_Noisy[lc])), historyLength);
     StoreRGBA16F(S.out, px, py, o.slow);
     StoreRGBA16F(S.outFast, px, py, o.fast);
     if (SH) {

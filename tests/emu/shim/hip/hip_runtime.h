@@ -135,6 +135,7 @@ inline float emu_fmed3f(float a, float b, float c) { return std::max(std::min(a,
 #define NRD_OPAQUE_CVT_PK_F16(r, a, b) (r) = (uint32_t)hwmath::F32ToF16Bits(a) | ((uint32_t)hwmath::F32ToF16Bits(b) << 16)
 // nrdmath.h Rcp: the device hides the argument from the constant folder; nothing to hide from here
 #define NRD_OPAQUE_VALUE(x) ((void)0)
+#define NRD_LDS_WHOLE_TEXEL(v) ((void)0)
 
 // ------------------------------------------------------------------------------------------------ runtime API (host side of executor.hip)
 typedef int hipError_t;
