@@ -1,8 +1,8 @@
 """Static instruction statistics per kernel of a `hipcc -S --cuda-device-only` listing (optionally next to a second listing).
 usage: python tools/isa_stats.py a.s [b.s] [--filter substr] [--top N]
 Columns: VALU / SALU / VMEM / LDS instruction counts, VGPRs, occupancy (waves per SIMD), scratch bytes, LDS bytes.
---cost adds a static cost estimate from the measured gfx950 price lists (profiles/r02_b_valu_bench.txt, r02_c_gather_bench.txt): SIMD cycles of VALU issue per wave
-and CU cycles of the L1 request path per wave, and the time both bounds give for --pixels P (default 2560x1440) on 256 CUs at 2.4 GHz. Static = every
+--cost adds a static cost estimate from the measured gfx950 price lists (profiles/r02_b_valu_bench.txt, r02_c_gather_bench.txt): SIMD cycles of VALU issue per wave,
+CU cycles of the L1 request path per wave and (conflict-free) LDS-array cycles per wave, and the time both bounds give for --pixels P (default 2560x1440) on 256 CUs at 2.4 GHz. Static = every
 instruction of the kernel counted once (loops once, both sides of branches), so it is an upper bound for straight-line kernels and a rough guide otherwise.
 The tap loops of the pass kernels are fully unrolled, so the static VALU count of the hot path is close to the dynamic one."""
 import collections
@@ -40,6 +40,17 @@ FULL_RATE = ("v_fma_f32", "v_fmac_f32", "v_mul_f32", "v_add_f32", "v_sub_f32", "
              "v_fmaak_f32", "v_fmamk_f32", "v_mad_f32", "v_mac_f32", "v_add_co_u32", "v_not_b32")
 TRANS = ("v_rcp", "v_sqrt", "v_rsq", "v_exp", "v_log", "v_sin", "v_cos")
 LOAD_COST = {"dwordx4": 39.6, "dwordx3": 30.0, "dwordx2": 18.4, "dword": 6.4, "ushort": 6.4, "ubyte": 6.4, "sbyte": 6.4, "sshort": 6.4, "short": 6.4, "byte": 6.4}
+
+
+# LDS-array cycles per wave64 instruction, conflict-free (MI355X_MICROARCH.md "LDS": banking and cycles are per instruction). A dword read at a 16-byte lane
+# stride (one component of a float4 texel) is a 4-way conflict on top: the pattern that bound RELAX HistoryClamping in round 3.
+LDS_COST = {"ds_read_b32": 2, "ds_read_u8": 2, "ds_read_u16": 2, "ds_read_i8": 2, "ds_read_i16": 2, "ds_read_b64": 2, "ds_read_b96": 8, "ds_read_b128": 4, "ds_read2_b32": 4, "ds_read2st64_b32": 4,
+            "ds_read2_b64": 8, "ds_read2st64_b64": 8, "ds_write_b8": 4, "ds_write_b16": 4, "ds_write_b32": 4, "ds_write_b64": 6, "ds_write2_b32": 6, "ds_write_b96": 10, "ds_write_b128": 13,
+            "ds_write2_b64": 13, "ds_bpermute_b32": 2, "ds_swizzle_b32": 2}
+
+
+def lds_cycles(counter):
+    return sum(n * LDS_COST.get(ins, 4) for ins, n in counter.items() if ins.startswith("ds_"))
 
 
 def cost(counter):
@@ -90,8 +101,9 @@ def main():
             valu, l1 = cost(s["counter"])
             waves = pixels / 64.0
             # 1024 SIMDs issue VALU, 256 CUs serve L1 requests
-            print("    static cost per wave: VALU %.0f SIMD cycles, L1 path %.0f CU cycles  ->  %d px: VALU bound %.3f ms, L1 bound %.3f ms" % (
-                valu, l1, pixels, waves * valu / 1024 / 2.4e6, waves * l1 / 256 / 2.4e6))
+            lds = lds_cycles(s["counter"])
+            print("    static cost per wave: VALU %.0f SIMD cycles, L1 path %.0f CU cycles, LDS array %.0f CU cycles  ->  %d px: VALU bound %.3f ms, L1 bound %.3f ms, LDS bound %.3f ms" % (
+                valu, l1, lds, pixels, waves * valu / 1024 / 2.4e6, waves * l1 / 256 / 2.4e6, waves * lds / 256 / 2.4e6))
         if top:
             print("    " + "  ".join("%s %d" % kv for kv in s["counter"].most_common(top)))
 
