@@ -127,7 +127,7 @@ def parse_args():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--sharding", choices=["halo", "allgather"], default=os.environ.get("NRD_SHARDING", "halo"),
                     help="multi-GPU scheme: halo = halo exchange between pass segments (point-to-point to the two neighbouring ranks), allgather = redundant halo compute + one all-gather per frame")
-    ap.add_argument("--max-motion-rows", type=int, default=32, help="halo scheme: largest vertical motion (rows per frame) the history halos cover")
+    ap.add_argument("--max-motion-rows", type=int, default=None, help="halo scheme: largest vertical motion (rows per frame) the history halos cover (default: 32 up to 1440p, scaled with the height above)")
     ap.add_argument("--cpu-frames", type=int, default=8)
     ap.add_argument("--distinct-frames", type=int, default=0, help="number of distinct generated frames to cycle through (0 = warmup + steps)")
     ap.add_argument("--no-graph", action="store_true", help="launch every pass on its own instead of one hipGraph per frame")

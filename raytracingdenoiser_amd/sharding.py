@@ -346,7 +346,14 @@ class HaloSharder:
 
     SKY_TILE_COST = 0.03  # relative to a tile with geometry (early-out blocks still pay their launch and the tile test)
 
-    def __init__(self, executor, instance, width, height, rank, world, group=None, max_motion_rows=32, exchange_threshold=24, balance=True, recut_every=0, near_depth=1.0):
+    @staticmethod
+    def default_motion_rows(height):
+        """history-halo width when the caller names none: 32 rows up to 1440p, growing with the frame height above it (motion in rows scales with the resolution:
+        with a fixed 32 the 4K bench sequence exceeded the halo on every frame and ran unsharded, profiles/r03_i_scaling_model_relax_ds_sh.json)"""
+        return max(32, -(-height * 32 // 1440))
+
+    def __init__(self, executor, instance, width, height, rank, world, group=None, max_motion_rows=None, exchange_threshold=24, balance=True, recut_every=0, near_depth=1.0):
+        max_motion_rows = self.default_motion_rows(height) if max_motion_rows is None else max_motion_rows
         self.near_depth = near_depth  # view depth of the nearest geometry the camera-motion estimate has to cover (scene units)
         self.ex, self.inst = executor, instance
         self.width, self.height, self.rank, self.world, self.group = width, height, rank, world, group

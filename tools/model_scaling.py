@@ -33,7 +33,7 @@ def main():
     ap.add_argument("--balance", type=int, default=1, help="halo scheme: strips re-cut from the tile map (1) or uniform (0)")
     ap.add_argument("--all-ranks", type=int, default=1, help="measure every rank of each world size (the frame time is the slowest one) instead of the middle strip only")
     ap.add_argument("--scheme", choices=["allgather", "halo"], default="halo", help="allgather = FrameSharder (redundant halo compute), halo = HaloSharder (halo exchange between segments)")
-    ap.add_argument("--max-motion-rows", type=int, default=32)
+    ap.add_argument("--max-motion-rows", type=int, default=None, help="history-halo width in rows (default: HaloSharder.default_motion_rows)")
     ap.add_argument("--no-sky", action="store_true", help="the bench scene with a backdrop dome: every pixel is denoised (bench.py --no-sky)")
     ap.add_argument("--link-GBps", type=float, default=50.0, help="what one xGMI link delivers to one neighbour (modelled transfers)")
     args = ap.parse_args()
