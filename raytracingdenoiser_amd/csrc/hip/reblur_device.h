@@ -338,7 +338,19 @@ NRD_D float4 LoadDecodedNormalRoughnessOrZero(const Plane& decoded, int x, int y
 }
 
 // ---- clamp-addressed fetches (what a clamp sampler / gather does at the border) ------------------------------------------
-NRD_D int ClampI(int x, int a, int b) { return x < a ? a : (x > b ? b : x); }
+// clamp(x, a, b) for a <= b (every call site: 0 <= size - 1, or a non-empty rect). The compiler cannot know a <= b and emits v_max_i32 + v_min_i32; the median
+// of three is ONE instruction and the same value. (The 4x4 / 12-texel footprints of the temporal passes clamp ~100 coordinates per pixel: 6 % of
+// TemporalAccumulation's instructions.) Compile-time constant arguments keep the plain form so that they still fold.
+#ifndef NRD_MED3_I32 // (the CPU emulation of these sources under tests/emu uses the plain form)
+#define NRD_MED3_I32(r, x, a, b) asm("v_med3_i32 %0, %1, %2, %3" : "=v"(r) : "v"(x), "v"(a), "v"(b))
+#endif
+NRD_D int ClampI(int x, int a, int b) {
+    if (__builtin_constant_p(x) || (__builtin_constant_p(a) && __builtin_constant_p(b)))
+        return x < a ? a : (x > b ? b : x);
+    int r;
+    NRD_MED3_I32(r, x, a, b);
+    return r;
+}
 NRD_D float FetchClampedR32F(const Plane& p, int x, int y) { return LoadR32F(p, ClampI(x, 0, p.w - 1), ClampI(y, 0, p.h - 1)); }
 NRD_D float FetchClampedR16F(const Plane& p, int x, int y) { return LoadR16F(p, ClampI(x, 0, p.w - 1), ClampI(y, 0, p.h - 1)); }
 NRD_D float4 FetchClampedRGBA16F(const Plane& p, int x, int y) { return LoadRGBA16F(p, ClampI(x, 0, p.w - 1), ClampI(y, 0, p.h - 1)); }

@@ -136,6 +136,7 @@ inline float emu_fmed3f(float a, float b, float c) { return std::max(std::min(a,
 // nrdmath.h Rcp: the device hides the argument from the constant folder; nothing to hide from here
 #define NRD_OPAQUE_VALUE(x) ((void)0)
 #define NRD_LDS_WHOLE_TEXEL(v) ((void)0)
+#define NRD_MED3_I32(r, x, a, b) ((r) = (x) < (a) ? (a) : ((x) > (b) ? (b) : (x)))
 
 // ------------------------------------------------------------------------------------------------ runtime API (host side of executor.hip)
 typedef int hipError_t;
