@@ -109,6 +109,43 @@ class EmuExecutor:
             pass
 
 
+class EmuTorchExecutor(EmuExecutor):
+    """EmuExecutor with the tensor-facing side of raytracingdenoiser_amd.executor.HipExecutor (planes as torch CPU tensors that alias host memory), so that the
+    multi-GPU plumbing of raytracingdenoiser_amd/sharding.py -- which only ever talks to an executor through bind / _bound / pool_plane_tensor / execute_range --
+    runs unmodified on the CPU emulation of the kernels: real processes, real gloo messages, emulated passes (tests/test_sharding.py)."""
+
+    def __init__(self, instance, width, height):
+        import torch
+
+        super().__init__(instance, width, height)
+        self._arena_tensor = torch.from_numpy(self.arena)  # shares the memory of the numpy arena
+
+    def bind(self, resource_type, tensor, fmt):
+        import torch
+
+        if not isinstance(tensor, torch.Tensor):
+            tensor = torch.from_numpy(tensor)
+        assert not tensor.is_cuda and tensor[0].is_contiguous()
+        desc = api.HipPlaneDesc(tensor.data_ptr(), tensor.stride(0) * tensor.element_size(), int(fmt), self.width, self.height)
+        self._check(self.lib.nrdHipBindResource(self.handle, int(resource_type), C.byref(desc)), "nrdHipBindResource(%s)" % api.ResourceType(resource_type).name)
+        self._bound[int(resource_type)] = tensor
+
+    def pool_plane_desc(self, pool, index):
+        d = api.HipPlaneDesc()
+        self._check(self.lib.nrdHipGetPoolPlane(self.handle, int(pool), index, C.byref(d)), "nrdHipGetPoolPlane")
+        return d
+
+    def pool_plane_tensor(self, pool, index):
+        d = self.pool_plane_desc(pool, index)
+        off = d.data - self._arena_tensor.data_ptr()
+        return self._arena_tensor[off: off + d.height * d.rowPitchBytes].view(d.height, d.rowPitchBytes)
+
+    def execute_range(self, dispatch_ptr, num, first, count, row_begin=None, row_end=None):
+        rb = row_begin if row_begin is None or isinstance(row_begin, C.Array) else (C.c_int32 * num)(*row_begin)
+        re = row_end if row_end is None or isinstance(row_end, C.Array) else (C.c_int32 * num)(*row_end)
+        self._check(self.lib.nrdHipExecuteDispatchRange(self.handle, C.cast(dispatch_ptr, C.c_void_p), num, first, count, rb, re), "nrdHipExecuteDispatchRange")
+
+
 class _HostTensor:
     """what parity.py needs from a CUDA tensor, over a numpy array"""
 

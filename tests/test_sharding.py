@@ -461,6 +461,76 @@ def test_halo_sharding_two_processes_one_gpu():
     assert results == [(0, True, True), (1, True, True)]
 
 
+def _halo_two_process_emulated_worker(rank, world, port, name, W, H, frames, overrides, q):
+    import numpy as np
+    import torch.distributed as dist
+
+    import parity
+    from emu import emu_run
+
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    lib = emu_run.load()
+    seq = parity.generate_sequence(name, W, H, frames, device="cpu")
+    np_dtype = {torch.float16: np.float16, torch.int16: np.int16, torch.uint8: np.uint8}
+
+    def run(sharded):
+        inst = api.Instance([(0, parity.DENOISERS[name][0])], lib=lib)
+        ex = emu_run.EmuTorchExecutor(inst, W, H)
+        outs = []
+        for rt, dtype, ch, fmt in parity.output_planes(name, W, H):
+            outs.append(torch.zeros((H, W, ch), dtype=dtype))
+            ex.bind(rt, outs[-1], fmt)
+        sh = sharding.HaloSharder(ex, inst, W, H, rank, world, max_motion_rows=16) if sharded else None
+        per_frame, sharded_frames = [], 0
+        for f, frame in enumerate(seq):
+            for rt, t, fmt in parity.user_planes(name, frame):
+                ex.bind(rt, t.cpu().contiguous(), fmt)
+            inst.set_denoiser_settings(0, parity.denoiser_settings(name, frame, overrides))
+            inst.set_common_settings(parity.common_settings(frame["camera"], seq[max(f - 1, 0)]["camera"], W, H, f))
+            if sharded:
+                sharded_frames += 0 if sh.denoise().fallback else 1
+            else:
+                ex.denoise()
+            per_frame.append(([o.clone() for o in outs], sh.rows if sharded else (0, H)))
+        return per_frame, sharded_frames, (sh.exchanged_bytes if sharded else 0)
+
+    ref, _, _ = run(False)
+    got, sharded_frames, exchanged = run(True)
+    ok = all(torch.equal(a[rows[0]:rows[1]], b[rows[0]:rows[1]]) for (fa, _), (fb, rows) in zip(ref, got) for a, b in zip(fa, fb))
+    q.put((rank, ok, sharded_frames, exchanged > 0))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("name,world,W,H,overrides", [
+    ("REBLUR_DIFFUSE_SPECULAR", 2, 96, 240, dict(maxBlurRadius=4.0, diffusePrepassBlurRadius=6.0, specularPrepassBlurRadius=6.0)),  # small radii: the halos fit 120-row strips
+    ("REBLUR_DIFFUSE_SPECULAR", 3, 64, 300, dict(maxBlurRadius=4.0, diffusePrepassBlurRadius=6.0, specularPrepassBlurRadius=6.0)),  # a middle strip with two neighbours
+    ("RELAX_DIFFUSE_SPECULAR", 2, 96, 240, dict(atrousIterationNum=3, diffusePrepassBlurRadius=6.0, specularPrepassBlurRadius=6.0)),
+])
+def test_halo_sharding_processes_over_gloo_on_emulated_kernels(name, world, W, H, overrides):
+    """The N > 1 path end to end WITHOUT a GPU: `world` processes over gloo, each planning its strip from the dispatch list, exchanging halo bands by message passing
+    and running its pass segments -- on the CPU emulation of the device sources (tests/emu: the .hip files compiled for x86, test infrastructure). Every rank's
+    owned rows of every output, every frame, must equal a full-frame run of the same emulated kernels bit for bit; the frames after the restart frame must really
+    be sharded (an unsharded fallback would pass trivially)."""
+    import torch.multiprocessing as mp
+
+    from emu import emu_run
+
+    emu_run.load()  # build the emulation library once, before the workers race for it
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29500 + (os.getpid() % 100) + world
+    frames = 4
+    procs = [ctx.Process(target=_halo_two_process_emulated_worker, args=(r, world, port, name, W, H, frames, overrides, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    results = sorted(q.get(timeout=900) for _ in procs)
+    for p in procs:
+        p.join(timeout=60)
+    assert results == [(r, True, frames - 1, True) for r in range(world)], results
+
+
 @pytest.mark.gpu
 def test_bench_two_ranks_rehearsal():
     """bench.py exactly as the driver launches it for N = 2 (torch.distributed.run, one rank per process, barrier + max over ranks, rank 0 prints
