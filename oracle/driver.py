@@ -72,7 +72,9 @@ def _pitch(width, bpt):
 class OracleExecutor:
     """CPU twin of raytracingdenoiser_amd.executor.HipExecutor."""
 
-    def __init__(self, instance, width, height, format_bytes, threads=0):
+    def __init__(self, instance, width, height, format_bytes, threads=0, promote_fp16=False):
+        """promote_fp16: create every fp16 pool plane as fp32 -- what the reference's integration layer offers as `promoteFloat16to32`
+        (reference Integration/NRDIntegration.h:73-78); used by the per-pass comparison with oracle/_ref to look below the fp16 storage granularity"""
         from raytracingdenoiser_amd import api  # ctypes plumbing of the public NRD API only
 
         self.api = api
@@ -85,6 +87,8 @@ class OracleExecutor:
         for pool_type, descs in ((api.ResourceType.PERMANENT_POOL, instance.permanent_pool), (api.ResourceType.TRANSIENT_POOL, instance.transient_pool)):
             planes = []
             for fmt, ds in descs:
+                if promote_fp16:
+                    fmt = {api.Format.RGBA16_SFLOAT: api.Format.RGBA32_SFLOAT, api.Format.R16_SFLOAT: api.Format.R32_SFLOAT}.get(fmt, fmt)
                 w, h = (width + ds - 1) // ds, (height + ds - 1) // ds
                 planes.append((np.zeros((h, _pitch(w, format_bytes[fmt])), dtype=np.uint8), fmt, w, h))
             self.pools[pool_type] = planes
@@ -95,15 +99,25 @@ class OracleExecutor:
         assert array.flags["C_CONTIGUOUS"]
         self.user[int(resource_type)] = (array, fmt, self.width, self.height)
 
-    def _plane(self, res):
+    def _array(self, res):
+        """(numpy array, format, width, height) behind one DispatchDesc resource"""
         _, rtype, index = res
         api = self.api
         if rtype in (api.ResourceType.PERMANENT_POOL, api.ResourceType.TRANSIENT_POOL):
-            arr, fmt, w, h = self.pools[rtype][index]
-        else:
-            arr, fmt, w, h = self.user[int(rtype)]
+            return self.pools[rtype][index]
+        return self.user[int(rtype)]
+
+    def _plane(self, res):
+        arr, fmt, w, h = self._array(res)
         pitch = arr.strides[0]
         return OraclePlane(arr.ctypes.data, pitch, int(fmt), w, h)
+
+    def _run(self, d, constants, planes):
+        """one pass on the CPU: oracle/liboracle.so, the hand-written restatement (RefExecutor: oracle/_ref/libnrdref.so, the reference's own shader text)"""
+        buf = C.create_string_buffer(constants, len(constants)) if constants else None
+        rc = self.lib.oracle_dispatch(d.shader.encode(), buf, len(constants), planes, len(d.resources))
+        if rc != 0:
+            raise RuntimeError("oracle has no pass '%s'" % d.shader)
 
     # byte offsets of (gRectOrigin, gRectOffset) in the shared constant blocks and their sizes (reference REBLUR / RELAX / SIGMA _SHARED_CONSTANTS)
     _ORIGIN_FIELDS = {"REBLUR_": (648, 616, 832), "RELAX_": (472, 416, 704), "SIGMA_": (448, 432, 516)}
@@ -143,10 +157,7 @@ class OracleExecutor:
                             b[origin:origin + 8] = bytes(8)
                             b[offset:offset + 8] = bytes(8)
                             constants = bytes(b)
-                buf = C.create_string_buffer(constants, len(constants)) if constants else None
-                rc = self.lib.oracle_dispatch(d.shader.encode(), buf, len(constants), planes, len(d.resources))
-                if rc != 0:
-                    raise RuntimeError("oracle has no pass '%s'" % d.shader)
+                self._run(d, constants, planes)
         finally:
             mv = int(self.api.ResourceType.IN_MV)
             for key, original in saved.items():
@@ -158,3 +169,120 @@ class OracleExecutor:
     def pool_plane(self, pool, index):
         arr, fmt, w, _ = self.pools[pool][index]
         return arr, fmt, w
+
+
+# ---- oracle/_ref: the reference's own HLSL shaders compiled as C++ (oracle/ref/Makefile) ------------------------------------------------------------
+REF_LIB_PATH = os.path.join(_DIR, "_ref", "libnrdref.so")
+_ref_lib = None
+
+
+def ref_available():
+    return os.path.exists(REF_LIB_PATH)
+
+
+def load_ref():
+    global _ref_lib
+    if _ref_lib is None:
+        if not ref_available():
+            raise RuntimeError("oracle/_ref not built: run `make -C oracle/ref -j8` (needs /root/reference)")
+        lib = C.CDLL(REF_LIB_PATH)
+        lib.nrdref_dispatch.argtypes = [C.c_char_p, C.c_void_p, C.c_uint32, C.POINTER(OraclePlane), C.c_uint32, C.c_uint32, C.c_uint32]
+        lib.nrdref_dispatch.restype = C.c_int
+        lib.nrdref_has.argtypes, lib.nrdref_has.restype = [C.c_char_p], C.c_int
+        lib.nrdref_count.argtypes, lib.nrdref_count.restype = [], C.c_int
+        lib.nrdref_name.argtypes, lib.nrdref_name.restype = [C.c_int], C.c_char_p
+        lib.nrdref_set_threads.argtypes, lib.nrdref_set_threads.restype = [C.c_int], C.c_int
+        _ref_lib = lib
+    return _ref_lib
+
+
+def ref_shaders():
+    lib = load_ref()
+    return sorted(lib.nrdref_name(i).decode() for i in range(lib.nrdref_count()))
+
+
+class RefExecutor(OracleExecutor):
+    """The same driver over oracle/_ref/libnrdref.so: every pass is the reference's own shader text, executed in plain IEEE arithmetic."""
+
+    def __init__(self, *a, **kw):
+        super().__init__(*a, **kw)
+        self.ref = load_ref()
+
+    def _run(self, d, constants, planes):
+        buf = C.create_string_buffer(constants, len(constants)) if constants else None
+        rc = self.ref.nrdref_dispatch(d.shader.encode(), buf, len(constants), planes, len(d.resources), d.grid[0], d.grid[1])
+        if rc != 0:
+            raise RuntimeError("oracle/_ref cannot run '%s' (code %d)" % (d.shader, rc))
+
+
+_strict_lib = None
+
+
+def load_strict():
+    """oracle/liboracle_strict.so: the oracle's sources without contraction and with true divisions, always in IEEE mode (oracle/Makefile)"""
+    global _strict_lib
+    if _strict_lib is None:
+        path = os.path.join(_DIR, "liboracle_strict.so")
+        if not os.path.exists(path):
+            raise RuntimeError("oracle/liboracle_strict.so not built: run `make -C oracle all`")
+        lib = C.CDLL(path)
+        lib.oracle_dispatch.argtypes = [C.c_char_p, C.c_void_p, C.c_uint32, C.POINTER(OraclePlane), C.c_uint32]
+        lib.oracle_dispatch.restype = C.c_int
+        lib.oracle_set_ieee_mode.argtypes, lib.oracle_set_ieee_mode.restype = [C.c_int], C.c_int
+        lib.oracle_set_ieee_mode(1)
+        _strict_lib = lib
+    return _strict_lib
+
+
+class ComparingExecutor(OracleExecutor):
+    """Runs every pass TWICE on identical inputs -- the hand-written oracle and the reference's own shader (oracle/_ref) -- and hands both sets of
+    output planes to `on_pass(dispatch, [(resource, fmt, width, oracle_array, ref_array, [oracle arrays in other arithmetics]), ...])`. The sequence continues on the oracle's results, so there
+    is no recurrence in the comparison: every difference is the difference of ONE pass."""
+
+    def __init__(self, *a, on_pass=None, strict=True, sensitivity=False, **kw):
+        """strict: "the oracle" is liboracle_strict.so (no contraction, true divisions) -- the arithmetic of the reference text; False: liboracle.so in
+        whatever mode set_ieee_mode selected (the arithmetic contract the HIP library is held against)"""
+        super().__init__(*a, **kw)
+        if strict:
+            self.lib = load_strict()
+        self.ref = load_ref()
+        self.on_pass = on_pass
+        self.sensitivity = sensitivity
+
+    def _run(self, d, constants, planes):
+        arrays = [self._array(r) for r in d.resources]
+        before = [a[0].copy() for a in arrays]
+        buf = C.create_string_buffer(constants, len(constants)) if constants else None
+
+        def restore():
+            for a, b in zip(arrays, before):
+                a[0][...] = b
+
+        # the same pass in the oracle's OTHER arithmetics (same source text, different roundings): where these move a texel, the texel sits on a
+        # discontinuity of the pass (a snapped tap, a threshold, an ill-conditioned quotient) -- the attribution of the outliers
+        alts = []
+        if self.sensitivity:
+            main = load()
+            for ieee in (1, 0):
+                prev = main.oracle_set_ieee_mode(ieee)
+                try:
+                    rc = main.oracle_dispatch(d.shader.encode(), buf, len(constants), planes, len(d.resources))
+                finally:
+                    main.oracle_set_ieee_mode(prev)
+                if rc != 0:
+                    raise RuntimeError("oracle has no pass '%s'" % d.shader)
+                alts.append([a[0].copy() for a in arrays])
+                restore()
+        rc = self.ref.nrdref_dispatch(d.shader.encode(), buf, len(constants), planes, len(d.resources), d.grid[0], d.grid[1])
+        if rc != 0:
+            raise RuntimeError("oracle/_ref cannot run '%s' (code %d)" % (d.shader, rc))
+        theirs_all = [a[0].copy() for a in arrays]
+        restore()
+        super()._run(d, constants, planes)  # last: the sequence continues on these results
+        report = []
+        for i, (res, a, b, theirs) in enumerate(zip(d.resources, arrays, before, theirs_all)):
+            m = a[0]
+            if res[0] == self.api.DescriptorType.STORAGE_TEXTURE or not np.array_equal(b, m) or not np.array_equal(b, theirs):
+                report.append((res, a[1], a[2], m.copy(), theirs, [alt[i] for alt in alts]))
+        if self.on_pass:
+            self.on_pass(d, report)

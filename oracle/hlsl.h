@@ -51,7 +51,13 @@ inline float HwSqrt(float x) { return hwmath::HwSqrt(x); }
 inline float HwRsq(float x) { return hwmath::HwRsq(x); }
 inline float Rcp(float x) { return hwmath::HwRcp(x); }
 inline float rcp(float x) { return hwmath::HwRcp(x); }
-inline float Div(float a, float b) { return a * Rcp(b); } // the shaders' a / b
+// the shaders' a / b. ORC_STRICT_IEEE (oracle/Makefile: liboracle_strict.so, compiled without contraction) is the build that is held against the reference's own shader
+// text (oracle/_ref): there a division is a division, and what remains between the two is the re-association of a few expressions (DESIGN.md "Numerics")
+#ifdef ORC_STRICT_IEEE
+inline float Div(float a, float b) { return a / b; }
+#else
+inline float Div(float a, float b) { return a * Rcp(b); }
+#endif
 inline float rsqrt(float x) { return HwRsq(x); }
 inline float frac(float x) { return x - floorf(x); }
 
@@ -150,18 +156,36 @@ ORC_OP4(+) ORC_OP4(-) ORC_OP4(*) ORC_OP4(/)
 // operator/ above is the IEEE division of the front-end helpers (application side, as include/NRD.hip.h); the passes divide with Div
 inline float2 Div(float2 a, float2 b) { return float2(Div(a.x, b.x), Div(a.y, b.y)); }
 inline float2 Div(float2 a, float b) {
+#ifdef ORC_STRICT_IEEE
+    return float2(a.x / b, a.y / b);
+#else
     float r = Rcp(b);
     return float2(a.x * r, a.y * r);
+#endif
 }
 inline float3 Div(float3 a, float b) {
+#ifdef ORC_STRICT_IEEE
+    return float3(a.x / b, a.y / b, a.z / b);
+#else
     float r = Rcp(b);
     return float3(a.x * r, a.y * r, a.z * r);
+#endif
 }
 inline float4 Div(float4 a, float b) {
+#ifdef ORC_STRICT_IEEE
+    return float4(a.x / b, a.y / b, a.z / b, a.w / b);
+#else
     float r = Rcp(b);
     return float4(a.x * r, a.y * r, a.z * r, a.w * r);
+#endif
 }
 inline float4 Div(float4 a, float4 b) { return float4(Div(a.x, b.x), Div(a.y, b.y), Div(a.z, b.z), Div(a.w, b.w)); }
+// x / c for a literal c: the arithmetic contract multiplies by the reciprocal constant (DESIGN.md "Numerics"), the reference text divides
+#ifdef ORC_STRICT_IEEE
+#define DivConst(x, c) ((x) / (c))
+#else
+#define DivConst(x, c) ((x) * (1.0f / (c)))
+#endif
 // a * s + c with ONE rounding per component (the overloaded operators round the product first): the accumulations of the tap loops, as on the device
 inline float Mad(float a, float s, float c) { return a * s + c; }
 inline float2 Mad(float2 a, float s, float2 c) { return float2(a.x * s + c.x, a.y * s + c.y); }

@@ -102,8 +102,8 @@ inline float GetMinAllowedLimitForHitDistNonLinearAccumSpeed(const ReblurCB& c, 
     return Rcp(1.0f + frameNum);
 }
 inline float GetFadeBasedOnAccumulatedFrames(const ReblurCB& c, float accumSpeed) {
-    float a = c.gHistoryFixFrameNum * 2.0f * (1.0f / 3.0f) + 1e-6f;
-    float b = c.gHistoryFixFrameNum * 4.0f * (1.0f / 3.0f) + 2e-6f;
+    float a = DivConst(c.gHistoryFixFrameNum * 2.0f, 3.0f) + 1e-6f;
+    float b = DivConst(c.gHistoryFixFrameNum * 4.0f, 3.0f) + 2e-6f;
     return Math::LinearStep(a, b, accumSpeed);
 }
 inline float GetNonLinearAccumSpeed(const ReblurCB& c, float accumSpeed, float maxAccumSpeed, float confidence, bool hasData) { // REBLUR_Common.hlsli:111-124

@@ -701,8 +701,8 @@ void TemporalAccumulation(const PassIO& io) {
             RngHash rng;
             if (SPEC) {
                 roughnessModified = Filtering::GetModifiedRoughnessFromNormalVariance(roughness, Navg);
-                roughnessM1 = roughnessM1 * (1.0f / 9.0f);
-                roughnessM2 = roughnessM2 * (1.0f / 9.0f);
+                roughnessM1 = DivConst(roughnessM1, 9.0f);
+                roughnessM2 = DivConst(roughnessM2, 9.0f);
                 roughnessSigma = HwSqrt(fabsf(roughnessM2 - roughnessM1 * roughnessM1)); // GetStdDev
 
                 rng.Initialize((uint32_t)px, (uint32_t)py, c.gFrameIndex);
@@ -786,7 +786,7 @@ void TemporalAccumulation(const PassIO& io) {
 
             float3 V = GetViewVector(c, X);
             float NoV = fabsf(dot(N, V));
-            float NoVstrict = lerp(NoV, 1.0f, saturate(smbParallaxInPixelsMax * (1.0f / 30.0f)));
+            float NoVstrict = lerp(NoV, 1.0f, saturate(DivConst(smbParallaxInPixelsMax, 30.0f)));
             float4 smbDisocclusionThreshold = float4(GetDisocclusionThreshold(disocclusionThreshold, frustumSize, NoVstrict));
             smbDisocclusionThreshold *= dot(smbNavg, Navg) > REBLUR_ALMOST_ZERO_ANGLE - 0.25f * smallParallax ? 1.0f : 0.0f;
             smbDisocclusionThreshold *= IsInScreenBilinear(smbBilinearFilter.origin, c.gRectSizePrev);
@@ -1434,8 +1434,8 @@ S HistoryFixSignal(const ReblurCB& c, bool isSpec, bool perf, int px, int py, S 
     }
 
     // Fast-history clamping
-    m1 = m1 * (1.0f / 25.0f);
-    m2 = m2 * (1.0f / 25.0f);
+    m1 = DivConst(m1, 25.0f);
+    m2 = DivConst(m2, 25.0f);
     float sigma = HwSqrt(fabsf(m2 - m1 * m1)) * (KIND != SIGNAL_RADIANCE ? REBLUR_COLOR_CLAMPING_SIGMA_SCALE_OCCLUSION : REBLUR_COLOR_CLAMPING_SIGMA_SCALE);
     float lumaClamped = clamp(luma, m1 - sigma, m1 + sigma);
     luma = lerp(lumaClamped, luma, Rcp(1.0f + (c.gMaxFastAccumulatedFrameNum < c.gMaxAccumulatedFrameNum ? 1.0f : 0.0f) * frameNum * 2.0f));
@@ -1608,8 +1608,8 @@ void TemporalStabilization(const PassIO& io) {
                         mn = min(mn, d);
                         mx = max(mx, d);
                     }
-                M1 = M1 * (1.0f / 9.0f);
-                M2 = M2 * (1.0f / 9.0f);
+                M1 = DivConst(M1, 9.0f);
+                M2 = DivConst(M2, 9.0f);
                 m1 = M1;
                 sigma = HwSqrt(fabsf(M2 - M1 * M1));
                 if (!PERF && c.gMaxBlurRadius != 0.0f) // RCRS (not in performance mode)

@@ -97,7 +97,7 @@ def translate(text, shader_name):
     # ---- float literals (not inside linemarkers / preprocessor leftovers: those carry no decimal point)
     text = re.sub(r"(?<![\w.])(\d+\.\d*(?:[eE][+-]?\d+)?|\.\d+(?:[eE][+-]?\d+)?|\d+[eE][+-]?\d+)(?![\w.])", r"\1f", text)
 
-    uses_barrier = "GroupMemoryBarrierWithGroupSync" in text
+    uses_barrier = "GroupMemoryBarrier" in text  # (with or without GroupSync: hlsl_shim.h)
     head = ('// GENERATED by oracle/ref/hlsl2cpp.py from the reference shader entry %s -- never committed (oracle/_ref/ is git-ignored)\n'
             '#include "hlsl_shim.h"\n'
             'namespace hlsl { namespace {\n'

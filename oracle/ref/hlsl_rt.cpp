@@ -248,7 +248,7 @@ __attribute__((visibility("default"))) int nrdref_dispatch(const char* shaderFil
         fprintf(stderr, "nrdref_dispatch: unknown shader '%s'\n", shaderFileName);
         return 1;
     }
-    if (!t->constants.empty()) {
+    if (!t->constants.empty() && constantsSize) { // (a dispatch without constant data leaves the shader's constants untouched: Clear_*.cs never reads its dummy)
         const uint32_t used = UnpackConstants(*t, (const uint8_t*)constants, constantsSize);
         if (used == 0 || ((used + 15u) & ~15u) != ((constantsSize + 15u) & ~15u)) {
             fprintf(stderr, "nrdref_dispatch: '%s' declares %u bytes of constants, the dispatch carries %u\n", shaderFileName, used, constantsSize);

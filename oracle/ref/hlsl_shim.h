@@ -762,7 +762,9 @@ template <class T> struct RWTexture2D : TextureBase<T> {
 };
 
 inline void GroupMemoryBarrierWithGroupSync() { hlsl_rt::Barrier(); }
-inline void GroupMemoryBarrier() {} // the threads of a group run one after the other between barriers: nothing to order
+// The *_ClassifyTiles shaders order their group-shared atomics with GroupMemoryBarrier() alone (32 threads = one lock-step warp on the hardware they were
+// written for): a thread that ran to completion before the others have started would read half-built counters. Here it is a full group barrier.
+inline void GroupMemoryBarrier() { hlsl_rt::Barrier(); }
 // group threads are fibers of one OS thread: the atomics on group-shared memory are plain read-modify-writes
 template <class A, class B> inline void InterlockedAdd(A& dest, const B& v) { dest = (A)(dest + (A)v); }
 template <class A, class B, class C> inline void InterlockedAdd(A& dest, const B& v, C& original) {
@@ -775,13 +777,20 @@ template <class A, class B> inline void InterlockedOr(A& dest, const B& v) { des
 
 } // namespace hlsl
 
+// SRV or UAV is decided by the resource's TYPE, not by the macro that declared it: reference Shaders/Resources/REFERENCE_Copy.resources.hlsli:19 declares its
+// input texture with NRD_OUTPUT( Texture2D<float4>, gIn_Input, t, 0 ) -- harmless for the shader compilers (both macros expand to `type name : register( t0 )`)
+namespace hlsl_rt {
+template <class T> struct is_uav { static constexpr bool value = false; };
+template <class T> struct is_uav<hlsl::RWTexture2D<T>> { static constexpr bool value = true; };
+} // namespace hlsl_rt
+
 // what the binding macros of the prelude (oracle/ref/prelude.hlsli) leave in the preprocessed shader text
 #define HLSL_CONSTANT(type, name) \
     static type name;             \
     static hlsl_rt::ConstantAdder name##_reg(hlsl_table(), &name);
 #define HLSL_INPUT(type, name, index) \
     static type name;                 \
-    static hlsl_rt::ResourceAdder name##_reg(hlsl_table(), &name.p, false, index, #name);
+    static hlsl_rt::ResourceAdder name##_reg(hlsl_table(), &name.p, hlsl_rt::is_uav<type>::value, index, #name);
 #define HLSL_OUTPUT(type, name, index) \
     static type name;                  \
-    static hlsl_rt::ResourceAdder name##_reg(hlsl_table(), &name.p, true, index, #name);
+    static hlsl_rt::ResourceAdder name##_reg(hlsl_table(), &name.p, hlsl_rt::is_uav<type>::value, index, #name);

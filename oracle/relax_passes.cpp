@@ -121,7 +121,7 @@ inline float GetSpecLobeTanHalfAngle(float roughness, float percentOfVolume = 0.
 }
 inline float2 GetNormalWeightParams_ATrous(float roughness, float numFramesInHistory, float specularReprojectionConfidence, float normalEdgeStoppingRelaxation,
     float specularLobeAngleFraction, float specularLobeAngleSlack) { // :128-148
-    float relaxation = saturate(numFramesInHistory * (1.0f / 5.0f));
+    float relaxation = saturate(DivConst(numFramesInHistory, 5.0f));
     relaxation *= lerp(1.0f, specularReprojectionConfidence, normalEdgeStoppingRelaxation);
     float f = 0.9f + 0.1f * relaxation;
     float angle = atan(GetSpecLobeTanHalfAngle(roughness, specularLobeAngleFraction));
@@ -643,7 +643,7 @@ void TemporalAccumulation(const PassIO& io) {
                     minHitDist3x3 = min(minHitDist3x3, normalSpecHitT.w == 0.0f ? NRD_INF : normalSpecHitT.w);
                     currentNormalAveraged += normalSpecHitT.xyz();
                 }
-            currentNormalAveraged = currentNormalAveraged * (1.0f / 9.0f);
+            currentNormalAveraged = DivConst(currentNormalAveraged, 9.0f);
 
             float currentRoughnessModified = SPEC ? Filtering::GetModifiedRoughnessFromNormalVariance(currentRoughness, currentNormalAveraged) : 0.0f;
 
@@ -687,7 +687,7 @@ void TemporalAccumulation(const PassIO& io) {
                 auto M = [&](int dx, int dy) { return gPrev_MaterialID.FetchClamped(bx + dx, by + dy).x * 255.0f; };
 
                 float frustumSize = pixelSize * float(min(rectW, rectH));
-                float disocclusionThresholdSlopeScale = Rcp(lerp(lerp(0.05f, 1.0f, NoV), 1.0f, saturate(smbParallaxInPixelsMax * (1.0f / 30.0f))));
+                float disocclusionThresholdSlopeScale = Rcp(lerp(lerp(0.05f, 1.0f, NoV), 1.0f, saturate(DivConst(smbParallaxInPixelsMax, 30.0f))));
                 float4 smbDisocclusionThreshold = float4(saturate(disocclusionThreshold * disocclusionThresholdSlopeScale) * frustumSize);
                 smbDisocclusionThreshold *= IsInScreenBilinear(originF, c.gRectSizePrev);
                 smbDisocclusionThreshold -= NRD_EPS;
@@ -810,7 +810,7 @@ void TemporalAccumulation(const PassIO& io) {
                 }
             }
 
-            gOut_HistoryLength.Store(px, py, historyLength * (1.0f / 255.0f));
+            gOut_HistoryLength.Store(px, py, DivConst(historyLength, 255.0f));
 
             if (SPEC) {
                 float specMaxAccumulatedFrameNum = c.gSpecMaxAccumulatedFrameNum;
@@ -962,7 +962,7 @@ void TemporalAccumulation(const PassIO& io) {
                 // look back 1 and 2 frames
                 uvDiff *= Math::Rsqrt(Math::LengthSquared(uvDiff));
                 uvDiff = Div(uvDiff, c.gRectSizePrev);
-                uvDiff *= saturate(uvDiffLengthInPixels * (1.0f / 0.1f)) + uvDiffLengthInPixels * 0.5f;
+                uvDiff *= saturate(DivConst(uvDiffLengthInPixels, 0.1f)) + uvDiffLengthInPixels * 0.5f;
                 float2 backUV1 = prevUVVMB + 1.0f * uvDiff;
                 float2 backUV2 = prevUVVMB + 2.0f * uvDiff;
                 float4 backNormalRoughness1 = UnpackPrevNormalRoughness(gPrev_Normal_Roughness.SampleLinearTexel(backUV1 * resolutionScalePrev * PrevSize(gPrev_Normal_Roughness)));
@@ -1340,7 +1340,7 @@ void HistoryClamping(const PassIO& io) {
             if (SPEC) Resolve(spec, ms, true);
             if (DIFF) Resolve(diff, md, false);
 
-            gOut_HistoryLength.Store(px, py, historyLength * (1.0f / 255.0f));
+            gOut_HistoryLength.Store(px, py, DivConst(historyLength, 255.0f));
         }
 }
 
@@ -1402,7 +1402,7 @@ void AtrousSmem(const PassIO& io) {
             if (centerViewZ > c.gDenoisingRange)
                 normalRoughness = float4(1.0f / 255.0f);
             gOut_NormalRoughness.Store(px, py, PackPrevNormalRoughness(normalRoughness));
-            gOut_MaterialID.Store(px, py, centerMaterialID * (1.0f / 255.0f));
+            gOut_MaterialID.Store(px, py, DivConst(centerMaterialID, 255.0f));
 
             if (isSky != 0.0f || px >= rectW || py >= rectH)
                 continue;
@@ -1678,7 +1678,7 @@ void Atrous(const PassIO& io) {
             float diffuseLobeAngleFraction = Div(c.gLobeAngleFraction, HwSqrt(float(c.gStepSize)));
             if (SH)
                 diffuseLobeAngleFraction = Rcp(HwSqrt(float(c.gStepSize)));
-            diffuseLobeAngleFraction = lerp(0.99f, diffuseLobeAngleFraction, saturate(historyLength * (1.0f / 5.0f)));
+            diffuseLobeAngleFraction = lerp(0.99f, diffuseLobeAngleFraction, saturate(DivConst(historyLength, 5.0f)));
 
             float4 centerSpecular(0.0f), centerSpecularSH(0.0f), sumSpecular(0.0f), sumSpecularSH(0.0f);
             float centerSpecularLuminance = 0.0f, specularPhiLIlluminationInv = 0.0f, specularLuminanceWeightRelaxation = 1.0f, specularNormalWeightParamSimplified = 0.0f;

@@ -3,6 +3,8 @@
   lib/libNRD_hip.so    host dispatch compiler + HIP kernels + HIP executor (hipcc, gfx950)  -- THE PRODUCT. One library, one arithmetic
                        (DESIGN.md "Numerics"): the arithmetic the benchmark times is the arithmetic the parity suite holds against the oracle bit for bit.
   oracle/liboracle.so  CPU restatement of the pass arithmetic (ROCm's clang, x86-64)         -- TEST INFRASTRUCTURE ONLY
+  oracle/liboracle_strict.so  the same sources without contraction / with true divisions     -- TEST INFRASTRUCTURE ONLY (held against oracle/_ref)
+  oracle/_ref/libnrdref.so    the reference's own HLSL shaders compiled as C++ (oracle/ref/) -- TEST INFRASTRUCTURE ONLY, built where /root/reference exists
 
 hipcc cross-compiles gfx950 without a GPU, so this runs in the build container; the .so files travel to the GPU box.
 """
@@ -116,7 +118,19 @@ def build_oracle(verbose=False):
     return os.path.join(ORACLE_DIR, "liboracle.so")
 
 
+def build_ref(verbose=False, reference="/root/reference"):
+    """oracle/_ref/libnrdref.so: the reference's own HLSL shaders compiled as C++ (oracle/ref/Makefile). Test infrastructure, like the oracle. Only possible
+    where the reference tree is present (the build container); elsewhere the prebuilt library that travelled with the snapshot is used. Returns the path or None."""
+    out = os.path.join(ORACLE_DIR, "_ref", "libnrdref.so")
+    if not os.path.isdir(os.path.join(reference, "Shaders", "Source")):
+        return out if os.path.exists(out) else None
+    cmd = ["make", "-C", os.path.join(ORACLE_DIR, "ref"), "-j8", "REFERENCE=" + reference] + ([] if verbose else ["-s"])
+    subprocess.run(cmd, check=True)
+    return out
+
+
 if __name__ == "__main__":
     print(build_product(verbose=True))
     if "--no-oracle" not in sys.argv:
         print(build_oracle(verbose=True))
+        print(build_ref(verbose=False))
