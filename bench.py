@@ -132,6 +132,8 @@ def parse_args():
     ap.add_argument("--distinct-frames", type=int, default=0, help="number of distinct generated frames to cycle through (0 = warmup + steps)")
     ap.add_argument("--no-graph", action="store_true", help="launch every pass on its own instead of one hipGraph per frame")
     ap.add_argument("--no-sky", action="store_true", help="a dome behind the scene: no sky pixels (34 %% of the default frame are sky and leave at the tile test)")
+    ap.add_argument("--uniform", action="store_true", help="tuning runs: every input plane constant (the value of one ground pixel), static camera -- the scene on which an L1-resident A/B build "
+                    "(NRD_EXPERIMENT_L1_RESIDENT, csrc/hip/planes.h) computes the same values as the product and so measures each kernel's issue floor")
     ap.add_argument("--no-parity", action="store_true", help="skip the GPU-vs-oracle comparison of the cpu_baseline frames")
     return ap.parse_args()
 
@@ -261,6 +263,13 @@ def main():
         synth.BACKDROP = True
     # ---- synthetic inputs, generated straight into HBM (118 MB per 1440p frame; 96 frames = 11 GB of 288 GB)
     seq = scene.generate_sequence(name, W, H, distinct, device="cuda")
+    if args.uniform:
+        py, px = int(H * 0.8), W // 2
+        seq = seq[:1]
+        distinct = 1
+        for k, v in list(seq[0].items()):
+            if torch.is_tensor(v) and v.dim() >= 2 and v.shape[0] == H and v.shape[1] == W:
+                seq[0][k] = v[py:py + 1, px:px + 1].expand_as(v).contiguous()
     torch.cuda.synchronize()
     denoised_fraction = 1.0 - float(torch.stack([fr["is_sky"].float().mean() for fr in seq[:: max(1, len(seq) // 8)]]).mean())  # sky pixels leave at the tile test
 

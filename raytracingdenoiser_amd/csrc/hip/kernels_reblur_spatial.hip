@@ -111,7 +111,7 @@ NRD_D TapGuides FetchTapGuidesFullRect(const ReblurCB& c, const SpatialCtx& s, f
     const bool materials = FR == 1 && compareMaterials;
     uint32_t bits = 0u;
     {
-        const uint32_t offset = __umul24((uint32_t)t.ts.y, gIn_ViewPos.pitch) + (uint32_t)t.ts.x * 16u; // same layout as the decoded normals (launcher check)
+        const uint32_t offset = TexelOffset(gIn_ViewPos, t.ts.x, t.ts.y, 16u, true); // same layout as the decoded normals (launcher check)
         const float4 g = *(const float4*)(gIn_ViewPos.ptr + offset);
         t.Ns = Xyz(g);
         t.zs = g.w;
@@ -246,8 +246,7 @@ NRD_D typename ReblurSignal<KIND>::type DiffuseSpatialFilterTaps(const ReblurCB&
             w *= CompareMaterials(s.materialID, t.materialIDs, c.gDiffMinMaterial) ? 1.0f : 0.0f;
         w *= ComputeWeight(angle, normalWeightParam, 0.0f);
 
-        S smp = Sig::Load(gIn_Diff, ts.x, ts.y);
-        smp = Select(w == 0.0f, Sig::Zero(), smp);
+        S smp = Sig::LoadOrZero(gIn_Diff, ts.x, ts.y, w == 0.0f);
 
         w *= Lerp(minHitDistWeight, 1.0f, ComputeExponentialWeight(ExtractHitDist(smp), hitDistanceWeightParams.x, hitDistanceWeightParams.y));
         w *= PoissonGaussianWeight<PERF>(n);
@@ -395,8 +394,7 @@ NRD_D typename ReblurSignal<KIND>::type SpecularSpatialFilterTaps(const ReblurCB
         w *= ComputeWeight(angle, normalWeightParam, 0.0f);
         w *= ComputeWeight(Ns.w, roughnessWeightParams.x, roughnessWeightParams.y);
 
-        S smp = Sig::Load(gIn_Spec, ts.x, ts.y);
-        smp = Select(w == 0.0f, Sig::Zero(), smp);
+        S smp = Sig::LoadOrZero(gIn_Spec, ts.x, ts.y, w == 0.0f);
 
         if (MODE == PRE_BLUR) {
             float hs = ExtractHitDist(smp) * GetHitDistanceNormalization(zs, hitDistParams, Ns.w);

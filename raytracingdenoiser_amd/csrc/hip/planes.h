@@ -11,6 +11,7 @@
 #include <hip/hip_runtime.h>
 
 #include <cstdint>
+#include <type_traits>
 
 namespace nrdhip {
 
@@ -42,9 +43,21 @@ NRD_D bool InBounds(const Plane& p, int x, int y) { return (unsigned)x < (unsign
 
 // 32-bit byte offsets (planes are far below 4 GiB) from a 24-bit multiply (row index and pitch are both < 2^24): one full-rate
 // v_mad_u32_u24 instead of a quarter-rate v_mul_lo_u32 or 64-bit multiply-adds per access
+// NRD_EXPERIMENT_L1_RESIDENT (A/B builds only, tools/build_variant.py; never the product): every LOAD is redirected into a 128-byte window of two rows in the
+// middle of its plane -- the same instruction stream plus two VALU operations per address, but every request is an L1 hit. Run on a scene whose planes
+// are constant (bench.py --uniform) the redirected loads return the very values the real ones would, so the control flow is the same and the time of
+// this build is the kernel's issue floor: arithmetic + address generation + L1-hit latency, no L2 / HBM.
+#ifndef NRD_EXPERIMENT_L1_RESIDENT
+#define NRD_EXPERIMENT_L1_RESIDENT 0
+#endif
+NRD_D uint32_t TexelOffset(const Plane& p, int x, int y, uint32_t bytesPerTexel, bool isLoad) {
+    if (NRD_EXPERIMENT_L1_RESIDENT && isLoad)
+        return __umul24((uint32_t)(p.h >> 1) + ((uint32_t)y & 1u), p.pitch) + (((uint32_t)x * bytesPerTexel) & 127u);
+    return __umul24((uint32_t)y, p.pitch) + (uint32_t)x * bytesPerTexel;
+}
 template <typename T>
 NRD_D T* TexelPtr(const Plane& p, int x, int y) {
-    return (T*)(p.ptr + (__umul24((uint32_t)y, p.pitch) + (uint32_t)x * (uint32_t)sizeof(T)));
+    return (T*)(p.ptr + TexelOffset(p, x, y, (uint32_t)sizeof(T), std::is_const<T>::value));
 }
 
 // k / c for a small non-negative integer k held in a float, bit-identical to the IEEE quotient but 3 VALU ops instead

@@ -707,6 +707,18 @@ struct ReblurSignal<SIGNAL_RADIANCE> {
     typedef float4 type;
     static NRD_D float4 Zero() { return F4(0.0f); }
     static NRD_D float4 Load(const Plane& p, int x, int y) { return LoadRGBA16F(p, x, y); }
+    // Denanify( w, s ) of the tap loops (reference Common.hlsli:219: `w == 0 ? 0 : s`): the selection is made on the two raw dwords, before the fp16 -> fp32
+    // conversions -- 2 selects instead of 4, and the conversions then sit directly in front of the accumulating multiply-adds, where the compiler folds
+    // them into v_fma_mix_f32 (the conversion of an fp16 value is exact, so cvt + fma and fma_mix are the same number). Same values bit for bit.
+    static NRD_D float4 LoadOrZero(const Plane& p, int x, int y, bool zero) {
+#if NRD_EXPERIMENT_LEGACY_DENANIFY // A/B builds only (tools/build_variant.py): the selection after the conversions, as up to round 3
+        return Select(zero, F4(0.0f), LoadRGBA16F(p, x, y));
+#endif
+        uint2 raw = *TexelPtr<const uint2>(p, x, y);
+        raw.x = zero ? 0u : raw.x;
+        raw.y = zero ? 0u : raw.y;
+        return F4(HalfBitsToFloat((uint16_t)(raw.x & 0xFFFFu)), HalfBitsToFloat((uint16_t)(raw.x >> 16)), HalfBitsToFloat((uint16_t)(raw.y & 0xFFFFu)), HalfBitsToFloat((uint16_t)(raw.y >> 16)));
+    }
     static NRD_D void Store(const Plane& p, int x, int y, float4 v) { StoreRGBA16F(p, x, y, v); }
     static NRD_D float4 WithHitDist(float4 s, float hitDist) { return F4(s.x, s.y, s.z, hitDist); }
     static NRD_D float4 FetchHistory(const HistoryFilter& h, const Plane& tex) { return FetchHistoryRGBA16F(h, tex); }
@@ -740,6 +752,7 @@ struct ReblurSignal<SIGNAL_OCCLUSION> {
     typedef float type;
     static NRD_D float Zero() { return 0.0f; }
     static NRD_D float Load(const Plane& p, int x, int y) { return LoadR16Unorm(p, x, y); }
+    static NRD_D float LoadOrZero(const Plane& p, int x, int y, bool zero) { return zero ? 0.0f : LoadR16Unorm(p, x, y); }
     static NRD_D void Store(const Plane& p, int x, int y, float v) { StoreR16Unorm(p, x, y, v); }
     static NRD_D float WithHitDist(float, float hitDist) { return hitDist; }
     static NRD_D float FetchHistory(const HistoryFilter& h, const Plane& tex) {
@@ -761,6 +774,7 @@ struct ReblurSignal<SIGNAL_DIRECTIONAL_OCCLUSION> {
     typedef DirOcc type;
     static NRD_D DirOcc Zero() { return MakeDirOcc(F4(0.0f)); }
     static NRD_D DirOcc Load(const Plane& p, int x, int y) { return MakeDirOcc(LoadRGBA16Snorm(p, x, y)); }
+    static NRD_D DirOcc LoadOrZero(const Plane& p, int x, int y, bool zero) { return Select(zero, Zero(), Load(p, x, y)); }
     static NRD_D void Store(const Plane& p, int x, int y, DirOcc s) { StoreRGBA16Snorm(p, x, y, s.v); }
     static NRD_D DirOcc WithHitDist(DirOcc s, float hitDist) { return MakeDirOcc(F4(s.v.x, s.v.y, s.v.z, hitDist)); }
     static NRD_D DirOcc FetchHistory(const HistoryFilter& h, const Plane& tex) {
