@@ -392,7 +392,15 @@ const char* LaunchAtrousSmem(const PassArgs& a) {
 //                 coalesced read of every plane (1.7 / 2.5 texels per pixel instead of 9 gathers per pixel through the L1), and everything that depends on the
 //                 texel alone is computed at the fill instead of in each of the up-to-8 taps that visit it: the world position (re-derived from viewZ with the
 //                 expression that wrote the guide plane, ~20 VALU) and the fp16 -> fp32 decode of the radiance planes. Taps are ds_read_b128 / b64.
-//   STEP = 0      global gathers (steps 8, 16, ...: the reach no longer fits a tile, and a per-pixel hashed offset breaks the regular stencil anyway).
+//   STEP = 8 / 16 LDS bands (round 4). At these steps every pixel shifts its taps by a hashed offset of up to +-step/4 texels (reference RELAX_Atrous.hlsli:122-128), so the
+//                 64 lanes of a wave-load pick 64 texels out of a 40 x 10 region: ~40 cache lines for 1 KB of useful data, six planes, eight taps -- the
+//                 global variant moves ~6x its useful bytes from L2 to L1 and runs at twice the time of a build whose loads all hit the L1
+//                 (profiles/r04_c_relax_ds_sh_uniform_*_kernel_stats.txt: 601 vs 301 us). The union of all tap positions does not fit the LDS (step 16: 72 x 48
+//                 texels x 64 B = 216 KB), the three tap ROWS do: for yy = -1, 0, 1 the workgroup stages the band of (32 + 2 step + 2 r) x (8 + 2 r) texels
+//                 (r = step / 4) its taps of that row can reach -- 52 x 12 / 72 x 16 texels x 64 B = 39 / 73 KB, every plane read once with coalesced row
+//                 loads, the (world position, viewZ) texel from the per-frame guide plane --, then does the row's 3 (2) taps from LDS. Same texels, same
+//                 arithmetic, same tap order as the global variant.
+//   STEP = 0      global gathers (steps 32 and beyond of 6..8 iterations; the cross-check of the two LDS variants).
 // RES: RelaxSettings::enableRoughnessEdgeStopping, a compile-time variant picked by the launcher -- the taps then compute either the lobe-aware normal weight
 // and the roughness weight, or the simplified normal weight, never both (the reference selects per tap between two fully evaluated expressions).
 #ifndef NRD_ATROUS_LDS_TILES
@@ -406,19 +414,23 @@ __global__ __launch_bounds__(256, NRD_WAVES_RELAX_ATROUS) void RelaxAtrousKernel
         const Plane sig = SPEC ? P.spec.in : P.diff.in;
         ShareLayout(P.spec.in, sig), ShareLayout(P.diff.in, sig), ShareLayout(P.spec.inSh, sig), ShareLayout(P.diff.inSh, sig);
     }
-    constexpr bool TILED = STEP != 0;
+    constexpr bool TILED = STEP == 2 || STEP == 4, BANDED = STEP == 8 || STEP == 16;
+    static_assert(TILED || BANDED || STEP == 0, "RelaxAtrousKernel: STEP");
     constexpr int TW = TILE_X + 2 * STEP, TH = TILE_Y + 2 * STEP, TS = TW + 1, TN = TILED ? TH * TS : 1; // row stride padded by one texel
     __shared__ float4 s_NR[TN], s_Pos[TN];
     __shared__ float4 s_Spec[SPEC ? TN : 1], s_Diff[DIFF ? TN : 1];
     __shared__ uint2 s_SpecSh[SPEC && SH ? TN : 1], s_DiffSh[DIFF && SH ? TN : 1];
+    // one band of tap positions: hashed offsets reach R texels beyond the regular stencil; undecoded signal texels (8 B each)
+    constexpr int R = STEP / 4, BW = TILE_X + 2 * STEP + 2 * R, BH = TILE_Y + 2 * R, BS = BW + 1, BN = BANDED ? BH * BS : 1;
+    __shared__ float4 b_NR[BN], b_Pos[BN];
+    __shared__ uint2 b_Spec[SPEC && BANDED ? BN : 1], b_Diff[DIFF && BANDED ? BN : 1], b_SpecSh[SPEC && SH && BANDED ? BN : 1], b_DiffSh[DIFF && SH && BANDED ? BN : 1];
 
     const int blockY = blockIdx.y + rows.firstBlockY;
     const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
     const int blockX0 = BlockTileX(rows) * TILE_X, blockY0 = blockY * TILE_Y;
     const int px = blockX0 + tx, py = blockY0 + ty;
     const int rectW = c.shared.gRectSize.x, rectH = c.shared.gRectSize.y;
-    const uint32_t sigPitch = (SPEC ? P.spec.in : P.diff.in).pitch;
-    if (TILED) {
+    if (TILED || BANDED) {
         // uniform early-outs: a workgroup beyond the rect, or over sky tiles only (TILE_X = 32 = two 16x16 tiles, TILE_Y = 8: one tile row)
         if (blockX0 >= rectW || blockY0 >= rectH)
             return;
@@ -428,14 +440,16 @@ __global__ __launch_bounds__(256, NRD_WAVES_RELAX_ATROUS) void RelaxAtrousKernel
                 anyGeometry |= LoadR8Unorm(P.tiles, (blockX0 >> 4) + t, blockY0 >> 4) == 0.0f;
         if (!anyGeometry)
             return;
+    }
+    if (TILED) {
         for (int i = threadIdx.x; i < TW * TH; i += 256) {
             const int lx = i % TW, ly = i / TW;
             const int cx = ClampI(blockX0 - STEP + lx, 0, P.worldPosViewZ.w - 1), cy = ClampI(blockY0 - STEP + ly, 0, P.worldPosViewZ.h - 1); // the taps' clamped texel
             const int li = ly * TS + lx;
-            s_NR[li] = *(const float4*)(P.decodedNR.ptr + (__umul24((uint32_t)cy, P.decodedNR.pitch) + (uint32_t)cx * 16u));
-            const float z = RelaxUnpackViewZ(c, *(const float*)(P.viewZ.ptr + (__umul24((uint32_t)cy, P.viewZ.pitch) + (uint32_t)cx * 4u)));
+            s_NR[li] = *(const float4*)(P.decodedNR.ptr + TexelOffset(P.decodedNR, cx, cy, 16u, true));
+            const float z = RelaxUnpackViewZ(c, *(const float*)(P.viewZ.ptr + TexelOffset(P.viewZ, cx, cy, 4u, true)));
             s_Pos[li] = F4(GetCurrentWorldPosFromPixelPos(c, cx, cy, z), z);
-            const uint32_t signalOffset = __umul24((uint32_t)cy, sigPitch) + (uint32_t)cx * 8u;
+            const uint32_t signalOffset = TexelOffset(SPEC ? P.spec.in : P.diff.in, cx, cy, 8u, true); // (the four signal planes share one layout: launcher check)
             if (SPEC) {
                 const uint2 raw = *(const uint2*)(P.spec.in.ptr + signalOffset);
                 s_Spec[li] = DecodeRGBA16F(raw.x, raw.y);
@@ -451,22 +465,34 @@ __global__ __launch_bounds__(256, NRD_WAVES_RELAX_ATROUS) void RelaxAtrousKernel
         }
         __syncthreads();
     }
-    if (px >= rectW || py >= rectH || py < rows.rowBegin || py >= rows.rowEnd)
+    // BANDED: every thread of the workgroup stages the bands and meets the barriers of the tap loop; a thread without a pixel to filter computes on the
+    // workgroup's first pixel (a valid address: the uniform early-out above) and stores nothing
+    bool active = !(px >= rectW || py >= rectH || py < rows.rowBegin || py >= rows.rowEnd);
+    if (!BANDED && !active)
         return;
-    if (LoadR8Unorm(P.tiles, px >> 4, py >> 4) != 0.0f)
-        return;
+    const int pxv = BANDED && !active ? blockX0 : px, pyv = BANDED && !active ? blockY0 : py;
+#define px pxv
+#define py pyv
+    if (LoadR8Unorm(P.tiles, px >> 4, py >> 4) != 0.0f) {
+        if (!BANDED)
+            return;
+        active = false;
+    }
     const int lc = TILED ? (ty + STEP) * TS + tx + STEP : 0; // the pixel's own texel in the tile
     const float4 centerWorldPosViewZ = TILED ? s_Pos[lc] : LoadRGBA32F(P.worldPosViewZ, px, py);
     const float centerViewZ = centerWorldPosViewZ.w;
-    if (centerViewZ > c.shared.gDenoisingRange)
-        return;
+    if (centerViewZ > c.shared.gDenoisingRange) {
+        if (!BANDED)
+            return;
+        active = false;
+    }
 
     float centerMaterialID;
     const float4 centerNormalRoughness = TILED ? DecodedToNormalRoughness(s_NR[lc], centerMaterialID) : LoadDecodedNormalRoughness(P.decodedNR, px, py, centerMaterialID);
     const float3 centerNormal = Xyz(centerNormalRoughness);
     const float centerRoughness = centerNormalRoughness.w;
     const float historyLength = 255.0f * LoadR8Unorm(P.historyLength, px, py);
-    const int stepSize = TILED ? STEP : (int)c.gStepSize;
+    const int stepSize = TILED || BANDED ? STEP : (int)c.gStepSize;
 
     float diffuseLobeAngleFraction = Div(c.shared.gLobeAngleFraction, Sqrt(float(c.gStepSize)));
     if (SH)
@@ -545,7 +571,7 @@ __global__ __launch_bounds__(256, NRD_WAVES_RELAX_ATROUS) void RelaxAtrousKernel
 
     // random offsets against ringing at large steps
     int offx = 0, offy = 0;
-    if (!TILED && c.gStepSize > 4) {
+    if (!TILED && c.gStepSize > 4) { // (BANDED: STEP is 8 or 16, always true)
         RngHash rng;
         rng.Initialize((uint32_t)px, (uint32_t)py, c.shared.gFrameIndex);
         float2 rnd = rng.GetFloat2();
@@ -560,7 +586,32 @@ __global__ __launch_bounds__(256, NRD_WAVES_RELAX_ATROUS) void RelaxAtrousKernel
     // so one texel offset serves the two guide planes and one the four signal planes.
     const bool compareSpecMaterials = c.shared.gSpecMinMaterial < 3.0f, compareDiffMaterials = c.shared.gDiffMinMaterial < 3.0f; // IDs are 0..3: a minimum >= 3 disables the test
 #pragma unroll
-    for (int yy = -1; yy <= 1; yy++)
+    for (int yy = -1; yy <= 1; yy++) {
+        const int bandX0 = blockX0 - STEP - R, bandY0 = blockY0 + yy * STEP - R; // texel (unclamped) of the band's LDS element (0, 0)
+        if (BANDED) {
+            if (yy != -1)
+                __syncthreads(); // the taps of the previous band have been read
+            for (int i = threadIdx.x; i < BW * BH; i += 256) {
+                const int lx = i % BW, ly = i / BW;
+                const int cx = ClampI(bandX0 + lx, 0, P.worldPosViewZ.w - 1), cy = ClampI(bandY0 + ly, 0, P.worldPosViewZ.h - 1); // the taps' clamped texel
+                const int li = ly * BS + lx;
+                const uint32_t guideOffset = TexelOffset(P.decodedNR, cx, cy, 16u, true);
+                b_NR[li] = *(const float4*)(P.decodedNR.ptr + guideOffset);
+                b_Pos[li] = *(const float4*)(P.worldPosViewZ.ptr + guideOffset);
+                const uint32_t signalOffset = TexelOffset(SPEC ? P.spec.in : P.diff.in, cx, cy, 8u, true);
+                if (SPEC) {
+                    b_Spec[li] = *(const uint2*)(P.spec.in.ptr + signalOffset);
+                    if (SH)
+                        b_SpecSh[li] = *(const uint2*)(P.spec.inSh.ptr + signalOffset);
+                }
+                if (DIFF) {
+                    b_Diff[li] = *(const uint2*)(P.diff.in.ptr + signalOffset);
+                    if (SH)
+                        b_DiffSh[li] = *(const uint2*)(P.diff.inSh.ptr + signalOffset);
+                }
+            }
+            __syncthreads();
+        }
 #pragma unroll
         for (int xx = -1; xx <= 1; xx++) {
             if (xx == 0 && yy == 0)
@@ -584,20 +635,36 @@ __global__ __launch_bounds__(256, NRD_WAVES_RELAX_ATROUS) void RelaxAtrousKernel
                     if (SH)
                         rawDiffSh = s_DiffSh[li];
                 }
+            } else if (BANDED) {
+                const int li = (qy - bandY0) * BS + (qx - bandX0); // |offset| <= R: inside the band (which holds the clamped texel of every position)
+                g0 = LdsFloat4(&b_NR[li]);
+                sampleWorldPosViewZ = LdsFloat4(&b_Pos[li]);
+                if (SPEC) {
+                    const uint2 raw = b_Spec[li];
+                    sampleSpecular = DecodeRGBA16F(raw.x, raw.y);
+                    if (SH)
+                        rawSpecSh = b_SpecSh[li];
+                }
+                if (DIFF) {
+                    const uint2 raw = b_Diff[li];
+                    sampleDiffuse = DecodeRGBA16F(raw.x, raw.y);
+                    if (SH)
+                        rawDiffSh = b_DiffSh[li];
+                }
             } else {
                 const int cx = ClampI(qx, 0, P.worldPosViewZ.w - 1), cy = ClampI(qy, 0, P.worldPosViewZ.h - 1);
-                const uint32_t guideOffset = __umul24((uint32_t)cy, P.decodedNR.pitch) + (uint32_t)cx * 16u;
+                const uint32_t guideOffset = TexelOffset(P.decodedNR, cx, cy, 16u, true);
                 g0 = *(const float4*)(P.decodedNR.ptr + guideOffset);
 #if NRD_ATROUS_GUIDES_VIEWZ
                 // 4 bytes of viewZ instead of the 16-byte (world position, viewZ) texel: the taps are bound by the bytes that cross the L1 (gather probe:
                 // 39.6 cycles per 16-byte wave-load against 6.4 per 4-byte one); the position is re-derived with the very expression that wrote the guide
                 // plane (DecodeGuidesRelaxKernel = relax_device.h GetCurrentWorldPosFromPixelPos), ~20 VALU, so it IS the stored value
-                const float tapZ = RelaxUnpackViewZ(c, *(const float*)(P.viewZ.ptr + (__umul24((uint32_t)cy, P.viewZ.pitch) + (uint32_t)cx * 4u)));
+                const float tapZ = RelaxUnpackViewZ(c, *(const float*)(P.viewZ.ptr + TexelOffset(P.viewZ, cx, cy, 4u, true)));
                 sampleWorldPosViewZ = F4(GetCurrentWorldPosFromPixelPos(c, cx, cy, tapZ), tapZ);
 #else
                 sampleWorldPosViewZ = *(const float4*)(P.worldPosViewZ.ptr + guideOffset);
 #endif
-                const uint32_t signalOffset = __umul24((uint32_t)cy, sigPitch) + (uint32_t)cx * 8u;
+                const uint32_t signalOffset = TexelOffset(SPEC ? P.spec.in : P.diff.in, cx, cy, 8u, true); // (the four signal planes share one layout: launcher check)
                 if (SPEC) {
                     const uint2 raw = *(const uint2*)(P.spec.in.ptr + signalOffset);
                     sampleSpecular = DecodeRGBA16F(raw.x, raw.y);
@@ -670,6 +737,9 @@ __global__ __launch_bounds__(256, NRD_WAVES_RELAX_ATROUS) void RelaxAtrousKernel
                     sumDiffuseSH = Mad(DecodeRGBA16F(rawDiffSh.x, rawDiffSh.y), wDiffuse, sumDiffuseSH);
             }
         }
+    }
+    if (BANDED && !active)
+        return;
 
     if (SPEC) {
         float4 filtered = Div(sumSpecular, F4(sumWSpecular, sumWSpecular, sumWSpecular, sumWSpecular * sumWSpecular));
@@ -689,10 +759,16 @@ __global__ __launch_bounds__(256, NRD_WAVES_RELAX_ATROUS) void RelaxAtrousKernel
         }
         StoreRGBA16F(P.diff.out, px, py, filtered);
     }
+#undef px
+#undef py
 }
 
 static bool AtrousLdsTilesEnabled() {
     static const bool v = !(getenv("NRD_HIP_ATROUS_LDS") && atoi(getenv("NRD_HIP_ATROUS_LDS")) == 0); // run-time A/B switch (results are identical)
+    return NRD_ATROUS_LDS_TILES && v;
+}
+static bool AtrousLdsBandsEnabled() {
+    static const bool v = !(getenv("NRD_HIP_ATROUS_BANDS") && atoi(getenv("NRD_HIP_ATROUS_BANDS")) == 0); // run-time A/B switch (results are identical)
     return NRD_ATROUS_LDS_TILES && v;
 }
 
@@ -714,13 +790,17 @@ const char* LaunchAtrous(const PassArgs& a) {
     RelaxCB c = LoadRelaxConstants(a);
     RowGrid g = GridForRows(c.shared.gRectSize.x, c.shared.gRectSize.y, TILE_X, TILE_Y, a.rowBegin, a.rowEnd);
     const RowRange rr = MakeRowRange(g);
-    const int step = AtrousLdsTilesEnabled() && (c.gStepSize == 2 || c.gStepSize == 4) ? (int)c.gStepSize : 0;
+    const int step = (AtrousLdsTilesEnabled() && (c.gStepSize == 2 || c.gStepSize == 4)) || (AtrousLdsBandsEnabled() && (c.gStepSize == 8 || c.gStepSize == 16)) ? (int)c.gStepSize : 0;
     const bool res = !SPEC || c.shared.gRoughnessEdgeStoppingEnabled != 0; // (irrelevant without a specular signal: one instantiation)
 #define NRD_LAUNCH_ATROUS(STEP, RES) LaunchPass(a, (RelaxAtrousKernel<DIFF, SPEC, SH, STEP, RES>), g.grid, dim3(256), P, c, rr)
     if (step == 2)
         res ? NRD_LAUNCH_ATROUS(2, true) : NRD_LAUNCH_ATROUS(2, SPEC ? false : true);
     else if (step == 4)
         res ? NRD_LAUNCH_ATROUS(4, true) : NRD_LAUNCH_ATROUS(4, SPEC ? false : true);
+    else if (step == 8)
+        res ? NRD_LAUNCH_ATROUS(8, true) : NRD_LAUNCH_ATROUS(8, SPEC ? false : true);
+    else if (step == 16)
+        res ? NRD_LAUNCH_ATROUS(16, true) : NRD_LAUNCH_ATROUS(16, SPEC ? false : true);
     else
         res ? NRD_LAUNCH_ATROUS(0, true) : NRD_LAUNCH_ATROUS(0, SPEC ? false : true);
 #undef NRD_LAUNCH_ATROUS

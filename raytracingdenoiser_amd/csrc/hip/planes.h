@@ -51,6 +51,8 @@ NRD_D bool InBounds(const Plane& p, int x, int y) { return (unsigned)x < (unsign
 #define NRD_EXPERIMENT_L1_RESIDENT 0
 #endif
 NRD_D uint32_t TexelOffset(const Plane& p, int x, int y, uint32_t bytesPerTexel, bool isLoad) {
+    if (NRD_EXPERIMENT_L1_RESIDENT == 2 && isLoad)
+        return 0u; // every load reads texel (0, 0): the compiler keeps ONE load per plane and the addressing disappears -- the arithmetic alone (a lower bound of the floor)
     if (NRD_EXPERIMENT_L1_RESIDENT && isLoad)
         return __umul24((uint32_t)(p.h >> 1) + ((uint32_t)y & 1u), p.pitch) + (((uint32_t)x * bytesPerTexel) & 127u);
     return __umul24((uint32_t)y, p.pitch) + (uint32_t)x * bytesPerTexel;

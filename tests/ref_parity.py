@@ -41,7 +41,8 @@ class PassStats:
             for i, (suffix, kind, fa, fb) in enumerate(fields):
                 self._add(shader, slot + suffix, fmt.name, kind, fa, fb, [af[i][2] for af in alt_fields])
             return
-        kind = "float" if fmt in (F.R32_SFLOAT, F.RGBA32_SFLOAT) else "f16" if fmt in (F.RGBA16_SFLOAT, F.R16_SFLOAT) else "exact" if fmt in (F.R16_UINT, F.R32_UINT, F.R8_UINT, F.R10_G10_B10_A2_UNORM) else "code"
+        kind = ("float" if fmt in (F.R32_SFLOAT, F.RGBA32_SFLOAT) else "f16" if fmt in (F.RGBA16_SFLOAT, F.R16_SFLOAT) else "exact" if fmt in (F.R16_UINT, F.R32_UINT, F.R8_UINT, F.R10_G10_B10_A2_UNORM)
+                else "code16" if fmt in (F.R16_UNORM, F.RGBA16_SNORM) else "code")
         self._add(shader, slot, fmt.name, kind, a, b, [parity.decode_plane(_raw(alt), fmt, width).astype(np.float64) for alt in alts])
 
     def _add(self, shader, slot, fmt_name, kind, a, b, alts):
@@ -50,7 +51,7 @@ class PassStats:
             alts = [c.astype(np.uint16).view(np.float16).astype(np.float64) for c in alts]
             kind = "f16"
         key = (shader, slot, fmt_name)
-        r = self.rows.setdefault(key, {"n": 0, "exact": 0, "within_tol": 0, "within_1e3": 0, "max": 0.0, "worst": None, "frames": 0, "outliers": 0, "outliers_sensitive": 0})
+        r = self.rows.setdefault(key, {"n": 0, "exact": 0, "within_tol": 0, "within_1e3": 0, "within_1e3_vec": 0, "max": 0.0, "worst": None, "frames": 0, "outliers": 0, "outliers_sensitive": 0})
         is_float = kind in ("float", "f16")
         if is_float:
             both_nan = np.isnan(a) & np.isnan(b)
@@ -66,7 +67,7 @@ class PassStats:
             ok = (err <= self.tol) | one_ulp
         else:  # quantised codes (UNORM / SNORM): equal, or one code apart; packed bits and indices: equal
             err = np.abs(a - b)
-            ok = err <= (1.0 if kind == "code" else 0.0)
+            ok = err <= (1.0 if kind in ("code", "code16") else 0.0)
         out = ~ok if not is_float else (err > 1e-3) & ~ok
         if alts and np.any(out):
             # an outlier is "sensitive" when the oracle's own result at that texel moves by a comparable amount under a change of rounding alone
@@ -79,7 +80,18 @@ class PassStats:
         r["n"] += a.size
         r["exact"] += int(np.sum(a == b) + (np.sum(np.isnan(a) & np.isnan(b)) if is_float else 0))
         r["within_tol"] += int(np.sum(ok))
-        r["within_1e3"] += int(np.sum(err <= 1e-3)) if is_float else int(np.sum(ok))
+        # 16-bit UNORM / SNORM codes resolve 1.5e-5 of full scale: the north-star's 1e-3 is measured on the value (floor: 1e-3 of full scale); 8-bit codes do not
+        within = (err <= 1e-3) if is_float else ((np.abs(a - b) <= 1e-3 * np.maximum(np.abs(b), 65.535)) | ok) if kind == "code16" else ok
+        r["within_1e3"] += int(np.sum(within))
+        if is_float and a.ndim == 3 and a.shape[-1] == 4:
+            # colour / direction texels: the first three channels relative to the texel's largest of them (a component that cancels to ~0 inherits the
+            # absolute error of its neighbours: YCoCg chroma, SH1 direction), the fourth (hit distance, variance, ...) relative to itself
+            scale = np.maximum(np.max(np.abs(b[..., :3]), axis=-1, keepdims=True), 1e-3)
+            err_vec = np.concatenate([np.abs(a - b)[..., :3] / scale, err[..., 3:]], axis=-1)
+            err_vec = np.where(np.isnan(err_vec), np.where(both_nan, 0.0, np.inf), err_vec)
+            r["within_1e3_vec"] += int(np.sum(err_vec <= 1e-3))
+        else:
+            r["within_1e3_vec"] += int(np.sum(within))
         r["frames"] += 1
         m = float(np.max(np.where(np.isfinite(err), err, 1e30))) if err.size else 0.0
         if m >= r["max"]:
@@ -91,7 +103,7 @@ class PassStats:
         for (shader, slot, fmt), r in sorted(self.rows.items()):
             n = max(r["n"], 1)
             out.append({"pass": shader, "output": slot, "format": fmt, "texel_values": r["n"], "bit_exact_frac": r["exact"] / n, "within_tol_frac": r["within_tol"] / n,
-                        "within_1e-3_frac": r["within_1e3"] / n, "max_err": r["max"], "worst_at": r["worst"], "dispatches": r["frames"], "outliers": r["outliers"], "outliers_sensitive": r["outliers_sensitive"]})
+                        "within_1e-3_frac": r["within_1e3"] / n, "within_1e-3_vec_frac": r["within_1e3_vec"] / n, "max_err": r["max"], "worst_at": r["worst"], "dispatches": r["frames"], "outliers": r["outliers"], "outliers_sensitive": r["outliers_sensitive"]})
         return out
 
 

@@ -69,15 +69,26 @@ def test_bit_exact_over_48_frames(name):
     assert worst == 0.0, "the library differs from the oracle within 48 frames: max rel err %g" % worst
 
 
-@pytest.mark.parametrize("name", ["REBLUR_DIFFUSE_SPECULAR", "RELAX_DIFFUSE_SPECULAR_SH"])
-def test_vs_ieee_oracle_32_frames(name):
+# measured (profiles/r03 parity_report, profiles/r04_ieee_parity.jsonl): REBLUR_DS 3.3 % beyond 1e-3 / 85 % bit-exact, RELAX_DS_SH 5.5 % / 86 % -- the bounds sit just above
+@pytest.mark.parametrize("name,max_frac,min_exact", [("REBLUR_DIFFUSE_SPECULAR", 0.05, 0.84), ("RELAX_DIFFUSE_SPECULAR_SH", 0.07, 0.84)])
+def test_vs_ieee_oracle_32_frames(name, max_frac, min_exact):
     """what the device's v_rcp / v_sqrt / v_rsq / v_exp / v_log (each within 1 ulp of the reference result) cost against an oracle that knows nothing about them"""
     stats = parity.ParityStats()
     parity.run_parity(name, 192, 128, 32, ieee=True, stats=stats)
     row = _report("vs_ieee_oracle_32f", name, (192, 128), 32, stats)
     out = row["outputs"]
-    assert 0.0 < out["frac_gt_tol"] <= 0.25, out  # the amplification the module docstring describes (round 2, sqrt / rsqrt alone: 2.1 % REBLUR_DS, 5.1 % RELAX SH)
-    assert out["bit_exact_frac"] >= 0.5, out
+    assert 0.0 < out["frac_gt_tol"] <= max_frac, out  # the amplification the module docstring describes (round 2, sqrt / rsqrt alone: 2.1 % REBLUR_DS, 5.1 % RELAX SH)
+    assert out["bit_exact_frac"] >= min_exact, out
+
+
+def test_vs_ieee_oracle_at_baseline_size():
+    """the headline configuration (REBLUR_DIFFUSE_SPECULAR 2560x1440) against the IEEE oracle after a few frames (keep the device-agnostic statistic at
+    the BASELINE size): mean <= 5e-4, <= 3 % of the output values beyond 1e-3"""
+    stats = parity.ParityStats()
+    parity.run_parity("REBLUR_DIFFUSE_SPECULAR", 2560, 1440, 4, ieee=True, stats=stats, device="cuda", check_pools=False)
+    row = _report("vs_ieee_oracle_1440p", "REBLUR_DIFFUSE_SPECULAR", (2560, 1440), 4, stats)
+    out = row["outputs"]
+    assert out["mean"] <= 5e-4 and out["frac_gt_tol"] <= 0.03 and out["bit_exact_frac"] >= 0.9, out
 
 
 @pytest.mark.parametrize("name,plane", [("REBLUR_DIFFUSE_SPECULAR", "OUT_DIFF_RADIANCE_HITDIST"), ("RELAX_DIFFUSE_SPECULAR", "OUT_DIFF_RADIANCE_HITDIST")])

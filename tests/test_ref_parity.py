@@ -38,7 +38,7 @@ TOL_FLOOR = 0.9995  # >= 99.95 % within the north-star's 1e-3
 #   RELAX specular reprojection confidence: on the scene's horizon row the curvature estimate divides by NoV -> 0 and flips the confidence by whole steps
 #   REBLUR specular motion-vector patch (REBLUR_TemporalStabilization.hlsli:268-285): mv = ( vmbPixelUv - pixelUv ) / scale, a difference of nearly equal uvs --
 #   an absolute error of 1e-7 in uv is a relative error of 1e-3 in a 0.02-pixel motion vector; the values agree to 3e-4 of a pixel
-EXCEPTIONS = {("RELAX_", "TemporalAccumulation", "", "R8_UNORM"): (0.998, 0.998), ("REBLUR_", "TemporalStabilization", "IN_MV", "RGBA16_SFLOAT"): (0.99, 0.995)}
+EXCEPTIONS = {("RELAX_", "TemporalAccumulation", "", "R8_UNORM"): (0.998, 0.997), ("REBLUR_", "TemporalStabilization", "IN_MV", "RGBA16_SFLOAT"): (0.99, 0.995)}
 
 
 def _floor(row, default, which):
@@ -93,6 +93,21 @@ def test_every_pass_matches_the_reference_shader_text_remaining_denoisers(name):
 def test_options_match_the_reference_shader_text(name, overrides, cs_kw):
     extra = (("mv2d",) if cs_kw and not cs_kw.get("isMotionVectorInWorldSpace", True) else ()) + (("basecolor",) if cs_kw and cs_kw.get("isBaseColorMetalnessAvailable") else ())
     _check(ref_parity.run_per_pass(name, frames=3, settings_overrides=overrides, cs_kw=cs_kw, extra_want=extra, sensitivity=False), min_rows=10)
+
+
+@pytest.mark.parametrize("name", ["REBLUR_DIFFUSE_SPECULAR", "RELAX_DIFFUSE_SPECULAR_SH", "SIGMA_SHADOW"])
+def test_the_librarys_arithmetic_against_the_reference_shader_text_one_pass_at_a_time(name):
+    """The oracle in DEVICE mode is, bit for bit, what the HIP library computes (tests -m gpu). Held against the reference's text pass by pass on identical inputs,
+    this is the single-pass statistic VERDICT r03 asked for: the arithmetic contract (a * v_rcp(b), source-chosen fmas, the device's exp2 / log2 / sqrt) without any
+    recurrence. Colour / direction channels are measured against the texel's largest channel: the plane-distance weight |x * px + py| (|py| ~ 1e2..1e3) moves
+    by ulp(py) ~ 1e-4 when the multiply-add is fused, and a chroma or SH1 component that cancels to ~0 inherits that absolute error."""
+    stats = ref_parity.run_per_pass(name, frames=3, sensitivity=False, strict=False, ieee=False)
+    rows = stats.table()
+    assert len(rows) >= 10
+    bad = [r for r in rows if r["within_1e-3_vec_frac"] < _floor(r, 0.999, 1)]
+    assert not bad, "\n".join("%s %s %s: within 1e-3 (vector) %.6f, max %.3g" % (r["pass"], r["output"], r["format"], r["within_1e-3_vec_frac"], r["max_err"]) for r in bad)
+    if name == "SIGMA_SHADOW":
+        assert min(r["bit_exact_frac"] for r in rows) >= 0.9999
 
 
 def test_reference_accumulator_text_is_the_sequential_running_mean_bit_for_bit():

@@ -6,7 +6,8 @@ frame sequence with every pass on identical inputs (oracle.driver.ComparingExecu
 differ, in program order. The oracle keeps the identifiers of the HLSL it restates, so the first differing name IS the expression (or the threshold) that
 separates the two.
 
-usage: python tools/ref_trace.py DENOISER FRAMES FRAME X Y SHADER_SUBSTRING ORACLE_FILE:START:END [--contract] [--head N]
+usage: python tools/ref_trace.py DENOISER FRAMES FRAME X Y SHADER_SUBSTRING ORACLE_FILE:START:END [--contract | --device] [--head N]
+  (default: the strict-IEEE oracle build; --contract: contraction on + a * rcp(b), IEEE transcendentals; --device: the arithmetic of the HIP library)
   e.g. python tools/ref_trace.py REBLUR_DIFFUSE_OCCLUSION 3 1 40 42 HistoryFix oracle/reblur_passes.cpp:1294:1515
 """
 import glob
@@ -99,7 +100,7 @@ def find_shader(name, substring):
     return hits[0]
 
 
-def run(name, frames, frame, x, y, shader, lib_oracle, lib_ref, contract, log):
+def run(name, frames, frame, x, y, shader, lib_oracle, lib_ref, contract, log, device=False):
     code = r'''
 import os, sys
 sys.path.insert(0, %(root)r); sys.path.insert(0, os.path.join(%(root)r, "tests"))
@@ -112,7 +113,7 @@ traced = C.CDLL(%(lib_oracle)r)
 traced.oracle_dispatch.argtypes = [C.c_char_p, C.c_void_p, C.c_uint32, C.POINTER(driver.OraclePlane), C.c_uint32]
 traced.oracle_dispatch.restype = C.c_int
 traced.oracle_set_ieee_mode.argtypes, traced.oracle_set_ieee_mode.restype = [C.c_int], C.c_int
-traced.oracle_set_ieee_mode(1)
+traced.oracle_set_ieee_mode(0 if %(device)r else 1)
 if %(contract)r:
     main = driver.load()  # loads the deviation tables; hand them to the traced copy
     traced.oracle_set_hw_tables.argtypes = [C.c_void_p] * 5
@@ -128,7 +129,7 @@ for f, frame in enumerate(seq):
     os.write(2, ("MARK FRAME %%d\n" %% f).encode())
     cam, camp = frame["camera"], seq[max(f - 1, 0)]["camera"]
     run.step(frame, parity.common_settings(cam, camp, 192, 128, f), parity.denoiser_settings(name, frame, None))
-''' % dict(root=ROOT, lib_ref=lib_ref, lib_oracle=lib_oracle, contract=contract, name=name, frames=frames)
+''' % dict(root=ROOT, lib_ref=lib_ref, lib_oracle=lib_oracle, contract=contract, device=device, name=name, frames=frames)
     env = dict(os.environ, NRD_TRACE_X=str(x), NRD_TRACE_Y=str(y), OMP_NUM_THREADS="1")
     with open(log, "w") as fp:
         subprocess.run([sys.executable, "-c", code], check=True, env=env, stderr=fp)
@@ -165,9 +166,11 @@ def compare(log, frame, head):
 
 def main():
     args = sys.argv[1:]
-    contract = "--contract" in args
-    if contract:
-        args.remove("--contract")
+    contract = "--contract" in args or "--device" in args
+    device = "--device" in args
+    for flag in ("--contract", "--device"):
+        if flag in args:
+            args.remove(flag)
     head = 40
     if "--head" in args:
         i = args.index("--head")
@@ -180,7 +183,7 @@ def main():
     lib_o = build_oracle(spec, contract)
     lib_r = build_ref(shader)
     log = os.path.join(TMP, "trace.log")
-    run(name, int(frames), int(frame), int(x), int(y), shader, lib_o, lib_r, contract, log)
+    run(name, int(frames), int(frame), int(x), int(y), shader, lib_o, lib_r, contract, log, device)
     compare(log, int(frame), head)
 
 
