@@ -1,9 +1,10 @@
 // ORACLE -- TEST INFRASTRUCTURE, NOT PRODUCT CODE (see oracle/hlsl.h).
 //
-// CPU restatement of the REBLUR pass chain for the radiance+hit-distance denoisers (REBLUR_DIFFUSE, REBLUR_SPECULAR,
-// REBLUR_DIFFUSE_SPECULAR), quality mode, checkerboard OFF, hit-distance reconstruction OFF, no optional inputs
-// (history confidence / disocclusion threshold mix / base colour). One function per reference shader; every pixel is
-// independent inside a pass, so the LDS preloads of the shaders become clamped plane reads here.
+// CPU restatement of the REBLUR pass chain, all ten denoisers of the family from one set of templates: radiance + hit distance (REBLUR_DIFFUSE / _SPECULAR /
+// _DIFFUSE_SPECULAR), their _SH variants, the _OCCLUSION variants and _DIFFUSE_DIRECTIONAL_OCCLUSION; quality and performance mode, checkerboard modes,
+// hit-distance reconstruction 3x3 / 5x5, anti-firefly, with and without temporal stabilisation, and the optional inputs (history confidence, disocclusion
+// threshold mix, base colour / metalness for the specular motion-vector patch). One function per reference shader; every pixel is independent inside a
+// pass, so the LDS preloads of the shaders become clamped plane reads here. Pinned pass by pass against the reference's own shader text: tests/test_ref_parity.py.
 //   ClassifyTiles           reference Shaders/Source/REBLUR_ClassifyTiles.cs.hlsl:20-55
 //   PrePass                 reference Shaders/Include/REBLUR_PrePass.hlsli:11-108
 //   spatial filters         reference Shaders/Include/REBLUR_Common_DiffuseSpatialFilter.hlsli:22-213,

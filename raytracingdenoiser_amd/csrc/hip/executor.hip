@@ -96,6 +96,7 @@ struct NrdHipExecutor {
     std::vector<Plane> permanent, transient;
     Plane decodedNormalRoughness = {}; // internal float4 cache of IN_NORMAL_ROUGHNESS (not an NRD pool plane; own allocation)
     Plane worldPosViewZ = {};          // internal float4 scratch of the RELAX a-trous chain (world position + viewZ per pixel)
+    int windowRegion[3] = {0, 0, 0};   // {tile columns, first tile row, end tile row} of the last window-kernel launch (passes.h PassArgs::windowRegion)
     Plane tileFlags = {};              // one byte per 32x8-pixel workgroup tile: hand-over between the two kernels of a split pass (kernels_reblur_ta.hip "window")
     Plane viewPos = {};                // internal float4 guide plane of the REBLUR lists (decoded normal + viewZ per pixel)
     std::vector<nrd::Format> permanentFormat, transientFormat;
@@ -812,7 +813,6 @@ static uint32_t ExecuteRange(NrdHipExecutor* e, const nrd::DispatchDesc* descs, 
     }
     const bool shiftedRect = e->originX != 0 || e->originY != 0;
     std::vector<uint32_t> shiftTypes; // guide slots of this list that get a rect-at-origin twin
-    std::vector<uint32_t> newTwins;   // twins allocated by this call: cleared on the stream once the pre-flight has passed (nothing is enqueued before it)
     bool writesMv = false;
     if (shiftedRect) {
         for (uint32_t i = 0; i < dispatchDescsNum; i++)
@@ -838,7 +838,9 @@ static uint32_t ExecuteRange(NrdHipExecutor* e, const nrd::DispatchDesc* descs, 
                     twin.ptr = nullptr;
                     if (hipMalloc((void**)&twin.ptr, (size_t)twin.pitch * (size_t)twin.h) != hipSuccess)
                         return e->Fail(nrd::Result::FAILURE, "nrdHipExecuteDispatches: cannot allocate a shifted-rect guide plane");
-                    newTwins.push_back(t);
+                    // cleared at once (a pre-flight failure further down used to leave the new twin uninitialised for the next call); a memset of
+                    // a private buffer enqueues no pass work, so "nothing is launched before the pre-flight has passed" still holds
+                    (void)hipMemsetAsync(twin.ptr, 0, (size_t)twin.pitch * (size_t)twin.h, e->stream);
                     e->decodedFresh = false;
                 }
                 shiftTypes.push_back(t);
@@ -982,6 +984,7 @@ static uint32_t ExecuteRange(NrdHipExecutor* e, const nrd::DispatchDesc* descs, 
         args.worldPosViewZ = worldPos;
         args.viewPos = viewPos;
         args.tileFlags = e->tileFlags;
+        args.windowRegion = e->windowRegion;
         if (rowBegin && rowBegin[i] >= 0) {
             args.rowBegin = rowBegin[i];
             args.rowEnd = rowEnd[i];
@@ -1022,9 +1025,6 @@ static uint32_t ExecuteRange(NrdHipExecutor* e, const nrd::DispatchDesc* descs, 
         shiftGuides(&recorder, true);
 
     // ---- from here on work is enqueued
-    for (uint32_t t : newTwins)
-        (void)hipMemsetAsync(e->shifted[t].ptr, 0, (size_t)e->shifted[t].pitch * (size_t)e->shifted[t].h, e->stream);
-
     if (useGraph) {
         uint32_t r = LaunchAsGraph(e, recorder.records);
         if (r != (uint32_t)nrd::Result::SUCCESS)
@@ -1073,13 +1073,18 @@ extern "C" __attribute__((visibility("default"))) uint32_t nrdHipGetTileFallback
     std::vector<uint8_t> host((size_t)e->tileFlags.pitch * (size_t)e->tileFlags.h);
     if (hipStreamSynchronize(e->stream) != hipSuccess || hipMemcpy(host.data(), e->tileFlags.ptr, host.size(), hipMemcpyDeviceToHost) != hipSuccess)
         return e->Fail(nrd::Result::FAILURE, "nrdHipGetTileFallbackStats: cannot read the tile flags back");
-    uint32_t n = 0;
-    for (uint8_t f : host)
-        n += f == 1 ? 1u : 0u;
+    // only the region the last window kernel covered holds flags of that frame: the rect's tile columns, this rank's tile rows
+    const int cols = e->windowRegion[0] < e->tileFlags.w ? e->windowRegion[0] : e->tileFlags.w, rowBegin = e->windowRegion[1], rowEnd = e->windowRegion[2] < e->tileFlags.h ? e->windowRegion[2] : e->tileFlags.h;
+    uint32_t n = 0, total = 0;
+    for (int y = rowBegin; y < rowEnd; y++)
+        for (int x = 0; x < cols; x++) {
+            n += host[(size_t)y * e->tileFlags.pitch + (size_t)x] == 1 ? 1u : 0u;
+            total++;
+        }
     if (fallbackTiles)
         *fallbackTiles = n;
     if (totalTiles)
-        *totalTiles = (uint32_t)host.size();
+        *totalTiles = total;
     return (uint32_t)nrd::Result::SUCCESS;
 }
 
@@ -1102,7 +1107,7 @@ extern "C" __attribute__((visibility("default"))) uint32_t nrdHipGetGraphStats(c
     return (uint32_t)nrd::Result::SUCCESS;
 }
 
-// 0 = exact (pinned IEEE arithmetic, bit-identical to the CPU oracle), 1 = fast (hardware rcp / exp2 / log2, FMA contraction): the build this library is
+// always 0: the library has one arithmetic (DESIGN.md "Numerics"), bit-identical to the CPU oracle in device mode; kept for callers of the round-2 interface
 extern "C" __attribute__((visibility("default"))) uint32_t nrdHipGetNumericsMode(void) {
     return 0; // one library, one arithmetic (the value 1 named the "fast" build of round 2, which no longer exists)
 }

@@ -220,6 +220,13 @@ __global__ __launch_bounds__(TILE_X* TILE_Y, SH ? 0 : NRD_WAVES_REBLUR_HF) void 
 
     if (!BlockHasGeometry(P.tiles, BlockTileX(rr), blockY))
         return;
+    // the pixel's own inputs, requested in front of the tile fill (see ReblurTemporalStabilizationKernel; this pass ran 32 % above its L1-resident time)
+    const int qx = min(px, rw), qy = min(max(py, 0), rh);
+    const float preTile = LoadR8Unorm(P.tiles, qx >> 4, qy >> 4);
+    const float preViewZ = LoadR32F(P.viewZ, qx, qy);
+    float preMaterialID;
+    const float4 preNormalAndRoughness = LoadDecodedNormalRoughness(P.decodedNR, qx, qy, preMaterialID);
+    const float2 preData1 = LoadData1<DIFF, SPEC>(P.data1, qx, qy);
     {
         const int baseX = BlockTileX(rr) * TILE_X - hf::BORDER, baseY = blockY * TILE_Y - hf::BORDER;
         for (int i = threadIdx.x; i < hf::BUF_X * hf::BUF_Y; i += TILE_X * TILE_Y) {
@@ -235,22 +242,23 @@ __global__ __launch_bounds__(TILE_X* TILE_Y, SH ? 0 : NRD_WAVES_REBLUR_HF) void 
 
     if (px > rw || py > rh || py < rr.rowBegin || py >= rr.rowEnd)
         return;
-    if (LoadR8Unorm(P.tiles, px >> 4, py >> 4) != 0.0f)
+    if (preTile != 0.0f)
         return;
     HfPixel s;
-    s.viewZ = UnpackViewZ(c, LoadR32F(P.viewZ, px, py));
+    s.viewZ = UnpackViewZ(c, preViewZ);
     if (s.viewZ > c.gDenoisingRange)
         return;
 
     s.px = px, s.py = py, s.tx = tx, s.ty = ty;
-    float4 normalAndRoughness = LoadDecodedNormalRoughness(P.decodedNR, px, py, s.materialID);
+    s.materialID = preMaterialID;
+    float4 normalAndRoughness = preNormalAndRoughness;
     s.N = Xyz(normalAndRoughness);
     s.roughness = normalAndRoughness.w;
     s.frustumSize = GetFrustumSize(c.gMinRectDimMulUnproject, NRD_ORTHO_MODE(c), s.viewZ);
     s.pixelUv = F2(float(px) + 0.5f, float(py) + 0.5f) * ToF2(c.gRectSizeInv);
     s.Xv = ReconstructViewPosition(s.pixelUv, ToF4(c.gFrustum), s.viewZ, NRD_ORTHO_MODE(c));
     s.Nv = RotateVectorInverse(c.gViewToWorld, s.N);
-    float2 frameNum = LoadData1<DIFF, SPEC>(P.data1, px, py);
+    float2 frameNum = preData1;
     float2 stride = F2(Div(c.gHistoryFixBasePixelStride, 2.0f + frameNum.x), Div(c.gHistoryFixBasePixelStride, 2.0f + frameNum.y));
 
     if (DIFF) {
@@ -364,6 +372,17 @@ __global__ __launch_bounds__(TILE_X* TILE_Y, NRD_WAVES_REBLUR_TS) void ReblurTem
 
     if (!BlockHasGeometry(P.tiles, BlockTileX(rr), blockY))
         return;
+    // The pixel's own inputs do not depend on the luma tile: they are requested in FRONT of the tile fill, so that one memory latency covers both. Behind the
+    // barrier (rounds 1-3) they were a second, fully exposed latency in front of a third (the history fetch at the reprojected position): this pass ran 26 % above
+    // the time of a build whose loads all hit the L1 (profiles/r04_c_reblur_ds_uniform_*_kernel_stats.txt). Clamped coordinates: threads outside the rect leave later.
+    const int qx = min(px, rw), qy = min(max(py, 0), rh);
+    const float preTile = LoadR8Unorm(P.tiles, qx >> 4, qy >> 4);
+    const float preViewZ = LoadR32F(P.viewZ, qx, qy);
+    const float4 preMv = LoadRGBA16F(P.mv, qx, qy);
+    float preMaterialID;
+    const float4 preNormalAndRoughness = LoadDecodedNormalRoughness(P.decodedNR, qx, qy, preMaterialID);
+    const float2 preData1 = LoadData1<DIFF, SPEC>(P.data1, qx, qy);
+    const uint32_t preData2 = SPEC ? LoadR32U(P.data2, qx, qy) : LoadR8U(P.data2, qx, qy);
     {
         const int baseX = BlockTileX(rr) * TILE_X - ts::BORDER, baseY = blockY * TILE_Y - ts::BORDER;
         for (int i = threadIdx.x; i < ts::BUF_X * ts::BUF_Y; i += TILE_X * TILE_Y) {
@@ -379,9 +398,9 @@ __global__ __launch_bounds__(TILE_X* TILE_Y, NRD_WAVES_REBLUR_TS) void ReblurTem
 
     if (px > rw || py > rh || py < rr.rowBegin || py >= rr.rowEnd)
         return;
-    if (LoadR8Unorm(P.tiles, px >> 4, py >> 4) != 0.0f)
+    if (preTile != 0.0f)
         return;
-    const float viewZ = UnpackViewZ(c, LoadR32F(P.viewZ, px, py));
+    const float viewZ = UnpackViewZ(c, preViewZ);
     if (viewZ > c.gDenoisingRange)
         return;
 
@@ -395,7 +414,7 @@ __global__ __launch_bounds__(TILE_X* TILE_Y, NRD_WAVES_REBLUR_TS) void ReblurTem
     float3 X = RotateVector(c.gViewToWorld, Xv);
 
     // Previous position and surface motion uv
-    float4 inMv = LoadRGBA16F(P.mv, px, py);
+    float4 inMv = preMv;
     float3 mv = F3(inMv.x, inMv.y, inMv.z) * F3(c.gMvScale.x, c.gMvScale.y, c.gMvScale.z);
     float3 Xprev = X;
     float2 smbPixelUv = pixelUv + F2(mv.x, mv.y);
@@ -410,14 +429,14 @@ __global__ __launch_bounds__(TILE_X* TILE_Y, NRD_WAVES_REBLUR_TS) void ReblurTem
         smbPixelUv = GetScreenUv(c.gWorldToClipPrev, Xprev);
     }
 
-    float materialID;
-    float4 normalAndRoughness = LoadDecodedNormalRoughness(P.decodedNR, px, py, materialID);
+    float materialID = preMaterialID;
+    float4 normalAndRoughness = preNormalAndRoughness;
     float3 N = Xyz(normalAndRoughness);
     float roughness = normalAndRoughness.w;
 
     uint32_t bits;
-    float2 data1 = LoadData1<DIFF, SPEC>(P.data1, px, py);
-    float2 data2 = UnpackData2(SPEC ? LoadR32U(P.data2, px, py) : LoadR8U(P.data2, px, py), bits);
+    float2 data1 = preData1;
+    float2 data2 = UnpackData2(preData2, bits);
 
     // Surface motion footprint
     Bilinear smbBilinearFilter = GetBilinearFilter(smbPixelUv, rectSizePrev);

@@ -115,6 +115,11 @@ __device__ __forceinline__ void ReblurTemporalAccumulationTile(const ReblurCB& c
     const int px = tileX * TILE_X + tx, py = blockY * TILE_Y + ty;
     const int rw = cArg.gRectSizeMinusOne.x, rh = cArg.gRectSizeMinusOne.y;
 
+    // The pixel's own guides do not depend on the LDS tile: they are requested in FRONT of the fill (below, behind the uniform sky test), so that one memory latency
+    // covers both; behind the barrier they were a second exposed latency in front of the window fill / the history footprints (the pass ran 19 % above the time of
+    // a build whose loads all hit the L1, profiles/r04_c_reblur_ds_uniform_*_kernel_stats.txt)
+    float preTile = 0.0f, preViewZ = 0.0f, preMaterialID = 0.0f;
+    float4 preMv = F4(0.0f), preNormalAndRoughness = F4(0.0f);
     // ---- cooperative preload (clamped to the rect), skipped when every 16x16 tile under this block is sky
     {
         const int tileY = (blockY * TILE_Y) >> 4, tileX0 = (tileX * TILE_X) >> 4;
@@ -128,6 +133,13 @@ __device__ __forceinline__ void ReblurTemporalAccumulationTile(const ReblurCB& c
             return; // uniform across the block
         }
 
+        if (MODE == 1) { // (the plain kernels sit at their register budget: there the guides are requested behind the barrier as before)
+            const int qx = min(px, rw), qy = min(max(py, 0), rh);
+            preTile = LoadR8Unorm(P.tiles, qx >> 4, qy >> 4);
+            preViewZ = LoadR32F(P.viewZ, qx, qy);
+            preMv = LoadRGBA16F(P.mv, qx, qy);
+            preNormalAndRoughness = LoadDecodedNormalRoughness(P.decodedNR, qx, qy, preMaterialID);
+        }
         const int baseX = tileX * TILE_X - BORDER, baseY = blockY * TILE_Y - BORDER;
         for (int i = threadIdx.x; i < BUF_X * BUF_Y; i += TILE_X * TILE_Y) {
             int lx = i % BUF_X, ly = i / BUF_X;
@@ -156,10 +168,14 @@ __device__ __forceinline__ void ReblurTemporalAccumulationTile(const ReblurCB& c
     bool active = !(px > rw || py > rh || py < rr.rowBegin || py >= rr.rowEnd);
     if (MODE != 1 && !active)
         return;
-    active = active && LoadR8Unorm(P.tiles, lpx >> 4, lpy >> 4) == 0.0f;
-    if (MODE != 1 && !active)
-        return;
-    const float viewZ = UnpackViewZ(c, LoadR32F(P.viewZ, lpx, lpy));
+    if (MODE != 1) {
+        preTile = LoadR8Unorm(P.tiles, lpx >> 4, lpy >> 4);
+        if (preTile != 0.0f)
+            return;
+        preViewZ = LoadR32F(P.viewZ, lpx, lpy);
+    }
+    active = active && preTile == 0.0f; // (MODE 1: the prefetch position is (lpx, lpy) for every thread that stays)
+    const float viewZ = UnpackViewZ(c, preViewZ);
     active = active && !(viewZ > c.gDenoisingRange);
     if (MODE != 1 && !active)
         return;
@@ -194,8 +210,10 @@ __device__ __forceinline__ void ReblurTemporalAccumulationTile(const ReblurCB& c
     }
     Navg = Navg * 0.25f;
 
-    float materialID;
-    float4 normalAndRoughness = LoadDecodedNormalRoughness(P.decodedNR, lpx, lpy, materialID);
+    if (MODE != 1)
+        preNormalAndRoughness = LoadDecodedNormalRoughness(P.decodedNR, lpx, lpy, preMaterialID);
+    float materialID = preMaterialID;
+    float4 normalAndRoughness = preNormalAndRoughness;
     float3 N = Xyz(normalAndRoughness);
     float roughness = normalAndRoughness.w;
 
@@ -218,7 +236,7 @@ __device__ __forceinline__ void ReblurTemporalAccumulationTile(const ReblurCB& c
 
     NRD_CONSTANTS_PHASE();
     // Previous position and surface motion uv
-    float4 mvRaw = LoadRGBA16F(P.mv, lpx, lpy);
+    float4 mvRaw = MODE == 1 ? preMv : LoadRGBA16F(P.mv, lpx, lpy);
     float3 mv = F3(mvRaw.x, mvRaw.y, mvRaw.z) * F3(c.gMvScale.x, c.gMvScale.y, c.gMvScale.z);
     float3 Xprev = X;
     float2 smbPixelUv = pixelUv + F2(mv.x, mv.y);
@@ -1101,6 +1119,10 @@ static const char* LaunchTemporalAccumulation(const PassArgs& a) {
         if (!a.tileFlags.ptr || (uint32_t)a.tileFlags.w * TILE_X < (uint32_t)P.viewZ.w || (uint32_t)a.tileFlags.h * TILE_Y < (uint32_t)P.viewZ.h)
             return "REBLUR temporal accumulation: the executor's tile-flag scratch is missing or too small";
         P.tileFlags = a.tileFlags;
+        // both kernels of the pass only look at the flags of the rect's tile columns (dynamic resolution: columns beyond keep whatever an earlier, larger rect left)
+        P.tileFlags.w = min(a.tileFlags.w, (int)((c.gRectSizeMinusOne.x + 1) + TILE_X - 1) / TILE_X);
+        if (a.windowRegion)
+            a.windowRegion[0] = P.tileFlags.w, a.windowRegion[1] = g.firstBlockY, a.windowRegion[2] = g.firstBlockY + (int)g.grid.y;
         static const char* limitEnv = getenv("NRD_HIP_TA_WINDOW_LIMIT"); // "WxH", test hook: a smaller box sends tiles to the fallback kernel (results do not change)
         int limW = WIN_W, limH = WIN_H;
         if (limitEnv && sscanf(limitEnv, "%dx%d", &limW, &limH) != 2)
@@ -1110,7 +1132,7 @@ static const char* LaunchTemporalAccumulation(const PassArgs& a) {
         // window kernel (LDS-staged surface-motion footprints, 3 waves per SIMD), then the plain kernel on the tiles the first one declined
         LaunchPass(a, (ReblurTemporalAccumulationKernel<DIFF, SPEC, PERF, KIND, SH, 3, HAS_WINDOW ? 1 : 0>), g.grid, dim3(TILE_X * TILE_Y), c, P, MakeRowRange(g));
         dim3 fallbackGrid = g.grid;
-        fallbackGrid.x = (unsigned)((a.tileFlags.w + FALLBACK_TILES - 1) / FALLBACK_TILES);
+        fallbackGrid.x = (unsigned)((P.tileFlags.w + FALLBACK_TILES - 1) / FALLBACK_TILES);
         LaunchPass(a, (ReblurTemporalAccumulationKernel<DIFF, SPEC, PERF, KIND, SH, SPEC ? 2 : 3, HAS_WINDOW ? 2 : 0>), fallbackGrid, dim3(TILE_X * TILE_Y), c, P, MakeRowRange(g));
         return nullptr;
     }

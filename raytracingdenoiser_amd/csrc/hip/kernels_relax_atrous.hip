@@ -392,14 +392,16 @@ const char* LaunchAtrousSmem(const PassArgs& a) {
 //                 coalesced read of every plane (1.7 / 2.5 texels per pixel instead of 9 gathers per pixel through the L1), and everything that depends on the
 //                 texel alone is computed at the fill instead of in each of the up-to-8 taps that visit it: the world position (re-derived from viewZ with the
 //                 expression that wrote the guide plane, ~20 VALU) and the fp16 -> fp32 decode of the radiance planes. Taps are ds_read_b128 / b64.
-//   STEP = 8 / 16 LDS bands (round 4). At these steps every pixel shifts its taps by a hashed offset of up to +-step/4 texels (reference RELAX_Atrous.hlsli:122-128), so the
+//   STEP = 8      LDS bands (round 4; written for 8 and 16, used for 8). At these steps every pixel shifts its taps by a hashed offset of up to +-step/4 texels (reference RELAX_Atrous.hlsli:122-128), so the
 //                 64 lanes of a wave-load pick 64 texels out of a 40 x 10 region: ~40 cache lines for 1 KB of useful data, six planes, eight taps -- the
 //                 global variant moves ~6x its useful bytes from L2 to L1 and runs at twice the time of a build whose loads all hit the L1
 //                 (profiles/r04_c_relax_ds_sh_uniform_*_kernel_stats.txt: 601 vs 301 us). The union of all tap positions does not fit the LDS (step 16: 72 x 48
 //                 texels x 64 B = 216 KB), the three tap ROWS do: for yy = -1, 0, 1 the workgroup stages the band of (32 + 2 step + 2 r) x (8 + 2 r) texels
 //                 (r = step / 4) its taps of that row can reach -- 52 x 12 / 72 x 16 texels x 64 B = 39 / 73 KB, every plane read once with coalesced row
 //                 loads, the (world position, viewZ) texel from the per-frame guide plane --, then does the row's 3 (2) taps from LDS. Same texels, same
-//                 arithmetic, same tap order as the global variant.
+//                 arithmetic, same tap order as the global variant. Measured at 4K (profiles/r04_d_relax_ds_sh_kernel_stats.txt): step 8: 321 us against 391-405 of the
+//                 gathers; step 16: 535 us -- three bands of 72 x 16 texels are 13.5 staged texels per pixel (step 8: 7.3), 221 KB per tile through the L1 and the
+//                 LDS write port, at two workgroups per CU: worse than the gathers it replaces, so step 16 keeps them (NRD_HIP_ATROUS_BANDS=16 forces the bands).
 //   STEP = 0      global gathers (steps 32 and beyond of 6..8 iterations; the cross-check of the two LDS variants).
 // RES: RelaxSettings::enableRoughnessEdgeStopping, a compile-time variant picked by the launcher -- the taps then compute either the lobe-aware normal weight
 // and the roughness weight, or the simplified normal weight, never both (the reference selects per tap between two fully evaluated expressions).
@@ -591,6 +593,7 @@ __global__ __launch_bounds__(256, NRD_WAVES_RELAX_ATROUS) void RelaxAtrousKernel
         if (BANDED) {
             if (yy != -1)
                 __syncthreads(); // the taps of the previous band have been read
+            // (measured and dropped, r04_e: requesting all of a thread's texels before the first LDS store -- 160 instead of 106 VGPRs, one wave per SIMD less, 376 instead of 321 us)
             for (int i = threadIdx.x; i < BW * BH; i += 256) {
                 const int lx = i % BW, ly = i / BW;
                 const int cx = ClampI(bandX0 + lx, 0, P.worldPosViewZ.w - 1), cy = ClampI(bandY0 + ly, 0, P.worldPosViewZ.h - 1); // the taps' clamped texel
@@ -767,9 +770,9 @@ static bool AtrousLdsTilesEnabled() {
     static const bool v = !(getenv("NRD_HIP_ATROUS_LDS") && atoi(getenv("NRD_HIP_ATROUS_LDS")) == 0); // run-time A/B switch (results are identical)
     return NRD_ATROUS_LDS_TILES && v;
 }
-static bool AtrousLdsBandsEnabled() {
-    static const bool v = !(getenv("NRD_HIP_ATROUS_BANDS") && atoi(getenv("NRD_HIP_ATROUS_BANDS")) == 0); // run-time A/B switch (results are identical)
-    return NRD_ATROUS_LDS_TILES && v;
+static int AtrousLdsBandsMaxStep() { // run-time A/B switch (results are identical): 0 = off, 8 = step 8 (default), 16 = steps 8 and 16
+    static const int v = getenv("NRD_HIP_ATROUS_BANDS") ? atoi(getenv("NRD_HIP_ATROUS_BANDS")) : 8;
+    return NRD_ATROUS_LDS_TILES ? v : 0;
 }
 
 template <bool DIFF, bool SPEC, bool SH>
@@ -790,7 +793,7 @@ const char* LaunchAtrous(const PassArgs& a) {
     RelaxCB c = LoadRelaxConstants(a);
     RowGrid g = GridForRows(c.shared.gRectSize.x, c.shared.gRectSize.y, TILE_X, TILE_Y, a.rowBegin, a.rowEnd);
     const RowRange rr = MakeRowRange(g);
-    const int step = (AtrousLdsTilesEnabled() && (c.gStepSize == 2 || c.gStepSize == 4)) || (AtrousLdsBandsEnabled() && (c.gStepSize == 8 || c.gStepSize == 16)) ? (int)c.gStepSize : 0;
+    const int step = (AtrousLdsTilesEnabled() && (c.gStepSize == 2 || c.gStepSize == 4)) || ((c.gStepSize == 8 || c.gStepSize == 16) && (int)c.gStepSize <= AtrousLdsBandsMaxStep()) ? (int)c.gStepSize : 0;
     const bool res = !SPEC || c.shared.gRoughnessEdgeStoppingEnabled != 0; // (irrelevant without a specular signal: one instantiation)
 #define NRD_LAUNCH_ATROUS(STEP, RES) LaunchPass(a, (RelaxAtrousKernel<DIFF, SPEC, SH, STEP, RES>), g.grid, dim3(256), P, c, rr)
     if (step == 2)

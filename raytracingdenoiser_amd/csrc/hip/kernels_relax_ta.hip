@@ -89,6 +89,16 @@ __device__ __forceinline__ void RelaxTemporalAccumulationTile(const RelaxCB& cAr
         return;
     }
 
+    // The pixel's own guides do not depend on the LDS tile: requested in FRONT of the fill, so that one memory latency covers both. Behind the barrier they were
+    // a second exposed latency in front of the third and fourth (previous-frame footprints at the surface-motion, then at the virtual-motion position): the
+    // pass ran 39 % above the time of a build whose loads all hit the L1 (profiles/r04_c_relax_ds_sh_uniform_*_kernel_stats.txt).
+    const int qx = min(px, rectW - 1), qy = min(max(py, 0), rectH - 1);
+    const float preTile = LoadR8Unorm(P.tiles, qx >> 4, qy >> 4);
+    const float preViewZ = LoadR32F(P.viewZ, qx, qy);
+    const float4 preMv = LoadRGBA16F(P.mv, qx, qy);
+    float preMaterialID;
+    const float4 preNormalRoughness = LoadDecodedNormalRoughness(P.decodedNR, qx, qy, preMaterialID);
+
     // preload (normal, specular hitT) at rect-clamped coordinates
     for (int idx = threadIdx.x; idx < ta::BUF_X * ta::BUF_Y; idx += 256) {
         int lx = idx % ta::BUF_X, ly = idx / ta::BUF_X;
@@ -114,18 +124,18 @@ __device__ __forceinline__ void RelaxTemporalAccumulationTile(const RelaxCB& cAr
     bool active = !(px >= rectW || py >= rectH || py < rows.rowBegin || py >= rows.rowEnd);
     if (MODE != 1 && !active)
         return;
-    active = active && LoadR8Unorm(P.tiles, lpx >> 4, lpy >> 4) == 0.0f;
+    active = active && preTile == 0.0f; // (qx, qy) = (lpx, lpy) for every thread that stays
     if (MODE != 1 && !active)
         return;
-    const float currentLinearZ = RelaxUnpackViewZ(c, LoadR32F(P.viewZ, lpx, lpy));
+    const float currentLinearZ = RelaxUnpackViewZ(c, preViewZ);
     active = active && !(currentLinearZ > c.shared.gDenoisingRange);
     if (MODE != 1 && !active)
         return;
 
     auto Shared = [&](int dx, int dy) { return s_NormalSpecHitT[(ty + ta::BORDER + dy) * ta::BUF_STRIDE + (tx + ta::BORDER + dx)]; };
 
-    float currentMaterialID;
-    float4 currentNormalRoughness = LoadDecodedNormalRoughness(P.decodedNR, lpx, lpy, currentMaterialID);
+    float currentMaterialID = preMaterialID;
+    float4 currentNormalRoughness = preNormalRoughness;
     const float3 currentNormal = Xyz(currentNormalRoughness);
     const float currentRoughness = currentNormalRoughness.w;
 
@@ -142,7 +152,7 @@ __device__ __forceinline__ void RelaxTemporalAccumulationTile(const RelaxCB& cAr
 
     // previous position
     const float2 pixelUv = F2(float(px) + 0.5f, float(py) + 0.5f) * rectSizeInv;
-    float4 mvRaw = LoadRGBA16F(P.mv, lpx, lpy);
+    float4 mvRaw = preMv;
     float3 mv = Xyz(mvRaw) * ToF3(c.shared.gMvScale);
     float3 prevWorldPos = currentWorldPos;
     float2 prevUVSMB = pixelUv + F2(mv.x, mv.y);
@@ -812,6 +822,10 @@ const char* LaunchTemporalAccumulation(const PassArgs& a) {
         if (!a.tileFlags.ptr || (uint32_t)a.tileFlags.w * TILE_X < (uint32_t)P.viewZ.w || (uint32_t)a.tileFlags.h * TILE_Y < (uint32_t)P.viewZ.h)
             return "RELAX TemporalAccumulation: the executor's tile-flag scratch is missing or too small";
         P.tileFlags = a.tileFlags;
+        // both kernels of the pass only look at the flags of the rect's tile columns (dynamic resolution: columns beyond keep whatever an earlier, larger rect left)
+        P.tileFlags.w = min(a.tileFlags.w, (int)((c.shared.gRectSize.x) + TILE_X - 1) / TILE_X);
+        if (a.windowRegion)
+            a.windowRegion[0] = P.tileFlags.w, a.windowRegion[1] = g.firstBlockY, a.windowRegion[2] = g.firstBlockY + (int)g.grid.y;
         static const char* limitEnv = getenv("NRD_HIP_TA_WINDOW_LIMIT"); // "WxH", test hook: a smaller box sends tiles to the fallback kernel (results do not change)
         int limW = WIN_W, limH = WIN_H;
         if (limitEnv && sscanf(limitEnv, "%dx%d", &limW, &limH) != 2)
@@ -821,7 +835,7 @@ const char* LaunchTemporalAccumulation(const PassArgs& a) {
         // window kernel (LDS-staged surface-motion reads), then the plain kernel on the tiles the first one declined
         LaunchPass(a, (RelaxTemporalAccumulationKernel<DIFF, SPEC, SH, 1>), g.grid, dim3(256), c, P, MakeRowRange(g));
         dim3 fallbackGrid = g.grid;
-        fallbackGrid.x = (unsigned)((a.tileFlags.w + FALLBACK_TILES - 1) / FALLBACK_TILES);
+        fallbackGrid.x = (unsigned)((P.tileFlags.w + FALLBACK_TILES - 1) / FALLBACK_TILES);
         LaunchPass(a, (RelaxTemporalAccumulationKernel<DIFF, SPEC, SH, 2>), fallbackGrid, dim3(256), c, P, MakeRowRange(g));
         return nullptr;
     }
@@ -916,7 +930,8 @@ NRD_D ClampOut ClampSignal(const RelaxCB& c, float3 fastM1, float3 fastM2, float
 }
 
 template <bool IS_SPEC, bool SH>
-NRD_D void ResolveSignal(const RelaxCB& c, const SignalPlanes& S, const float4* s_Fast, const float4* s_Noisy, int px, int py, int lx, int ly, float historyLength) {
+NRD_D void ResolveSignal(const RelaxCB& c, const SignalPlanes& S, const float4* s_Fast, const float4* s_Noisy, int px, int py, int lx, int ly, float historyLength, float4 inSignal, uint2 inSh,
+    uint2 inFastSh) { // inSignal / inSh / inFastSh: the pixel's own texels of S.in / S.inSh / S.fastSh (requested by the caller in front of the tile fill)
     float3 fastM1 = F3(0.0f), fastM2 = F3(0.0f), noisyM1 = F3(0.0f);
     float noisyM2 = 0.0f, sum = 0.0f;
 #pragma unroll
@@ -941,11 +956,11 @@ NRD_D void ResolveSignal(const RelaxCB& c, const SignalPlanes& S, const float4* 
     noisyM2 = Div(noisyM2, sum);
 
     const int lc = ly * hc::BUF_STRIDE + lx;
-    ClampOut o = ClampSignal<IS_SPEC>(c, fastM1, fastM2, noisyM1, noisyM2, LdsFloat4(&s_Fast[lc]), LoadRGBA16F(S.in, px, py), Xyz(LdsFloat4(&s_Noisy[lc])), historyLength);
+    ClampOut o = ClampSignal<IS_SPEC>(c, fastM1, fastM2, noisyM1, noisyM2, LdsFloat4(&s_Fast[lc]), inSignal, Xyz(LdsFloat4(&s_Noisy[lc])), historyLength);
     StoreRGBA16F(S.out, px, py, o.slow);
     StoreRGBA16F(S.outFast, px, py, o.fast);
     if (SH) {
-        float4 sh = LoadRGBA16F(S.inSh, px, py), shFast = LoadRGBA16F(S.fastSh, px, py);
+        float4 sh = DecodeRGBA16F(inSh.x, inSh.y), shFast = DecodeRGBA16F(inFastSh.x, inFastSh.y);
         StoreRGBA16F(S.outSh, px, py, Lerp(sh, shFast, o.clampingFactor));
         StoreRGBA16F(S.outFastSh, px, py, shFast);
     }
@@ -963,6 +978,24 @@ __global__ __launch_bounds__(256, NRD_WAVES_RELAX_HC) void RelaxHistoryClampingK
 
     if (!RelaxBlockHasGeometry(P.tiles, BlockTileX(rows), blockY))
         return;
+
+    // The pixel's own inputs do not depend on the LDS tiles: requested in FRONT of the fill, one memory latency covers both (behind the barrier they were a second,
+    // exposed one: the pass ran 34 % above the time of a build whose loads all hit the L1, profiles/r04_c_relax_ds_sh_uniform_*_kernel_stats.txt). Undecoded SH texels.
+    const int qx = min(px, rectW - 1), qy = min(max(py, 0), rectH - 1);
+    const float preTile = LoadR8Unorm(P.tiles, qx >> 4, qy >> 4);
+    const float preHistoryLength = LoadR8Unorm(P.historyLength, qx, qy);
+    float4 preSpec = F4(0.0f), preDiff = F4(0.0f);
+    uint2 preSpecSh = make_uint2(0u, 0u), preSpecFastSh = make_uint2(0u, 0u), preDiffSh = make_uint2(0u, 0u), preDiffFastSh = make_uint2(0u, 0u);
+    if (SPEC) {
+        preSpec = LoadRGBA16F(P.spec.in, qx, qy);
+        if (SH)
+            preSpecSh = *TexelPtr<const uint2>(P.spec.inSh, qx, qy), preSpecFastSh = *TexelPtr<const uint2>(P.spec.fastSh, qx, qy);
+    }
+    if (DIFF) {
+        preDiff = LoadRGBA16F(P.diff.in, qx, qy);
+        if (SH)
+            preDiffSh = *TexelPtr<const uint2>(P.diff.inSh, qx, qy), preDiffFastSh = *TexelPtr<const uint2>(P.diff.fastSh, qx, qy);
+    }
 
     for (int idx = threadIdx.x; idx < hc::BUF_X * hc::BUF_Y; idx += 256) {
         int lx = idx % hc::BUF_X, ly = idx / hc::BUF_X;
@@ -984,18 +1017,18 @@ __global__ __launch_bounds__(256, NRD_WAVES_RELAX_HC) void RelaxHistoryClampingK
 
     if (px >= rectW || py >= rectH || py < rows.rowBegin || py >= rows.rowEnd)
         return;
-    if (LoadR8Unorm(P.tiles, px >> 4, py >> 4) != 0.0f)
+    if (preTile != 0.0f)
         return;
     const int lx = tx + hc::BORDER, ly = ty + hc::BORDER;
     const float centerValid = SPEC ? s_SpecNoisy[ly * hc::BUF_STRIDE + lx].w : s_DiffNoisy[ly * hc::BUF_STRIDE + lx].w;
     if (centerValid == 0.0f)
         return;
 
-    const float historyLength = 255.0f * LoadR8Unorm(P.historyLength, px, py);
+    const float historyLength = 255.0f * preHistoryLength;
     if (SPEC)
-        ResolveSignal<true, SH>(c, P.spec, s_SpecFast, s_SpecNoisy, px, py, lx, ly, historyLength);
+        ResolveSignal<true, SH>(c, P.spec, s_SpecFast, s_SpecNoisy, px, py, lx, ly, historyLength, preSpec, preSpecSh, preSpecFastSh);
     if (DIFF)
-        ResolveSignal<false, SH>(c, P.diff, s_DiffFast, s_DiffNoisy, px, py, lx, ly, historyLength);
+        ResolveSignal<false, SH>(c, P.diff, s_DiffFast, s_DiffNoisy, px, py, lx, ly, historyLength, preDiff, preDiffSh, preDiffFastSh);
     StoreR8Unorm(P.outHistoryLength, px, py, historyLength * (1.0f / 255.0f));
 }
 

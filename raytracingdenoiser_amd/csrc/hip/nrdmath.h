@@ -55,7 +55,13 @@ NRD_D float Rcp(float x) {
     NRD_OPAQUE_VALUE(x);
     return __builtin_amdgcn_rcpf(x);
 }
-// a / b of the contract: one multiplication by the hardware reciprocal (2 instructions instead of the ~11 of a correctly rounded division)
+// a / b of the contract: one multiplication by the hardware reciprocal (2 instructions instead of the ~11 of a correctly rounded division).
+// Where this is NOT the IEEE quotient (the oracle reproduces every case bit for bit: tests/test_numerics.py "div_edge_cases"):
+//   * v_rcp_f32 flushes: |b| > 2^126 gives rcp = +-0 and a quotient of 0 (IEEE: a small non-zero number); a denormal b gives rcp = +-inf, so
+//     a / b = +-inf for a != 0 (IEEE agrees up to overflow) and 0 / denormal = 0 * inf = NaN (IEEE: 0);
+//   * Div(x, x) is 1 only up to one ulp (x * rcp(x) rounds twice);
+//   * the call sites of the passes keep their denominators away from both ends (Max(.., eps), +NRD_EPS, PositiveRcp), as the reference's shaders do for the
+//     same reason -- HLSL's a / b is a * rcp(b) on every GPU the reference runs on, with the same flush behaviour.
 NRD_D float Div(float a, float b) { return a * Rcp(b); }
 // sqrt and 1/sqrt: v_sqrt_f32, v_rsq_f32 (within 1 ulp of the correctly rounded result, denormals flushed)
 NRD_D float Sqrt(float x) { return __builtin_amdgcn_sqrtf(x); }

@@ -91,6 +91,10 @@ struct PassArgs {
     // (REBLUR TemporalAccumulation with its LDS window) hands the tiles the fast kernel declined to the fallback through it. Written completely by the fast
     // kernel before the fallback reads it (stream order), so it needs no clearing.
     Plane tileFlags;
+    // executor-owned int[3], filled by the launcher of such a split pass: {tile columns, first tile row, end tile row} the fast kernel covered in this launch --
+    // the rect's tiles in this rank's rows. Only there do the flags describe the last frame (nrdHipGetTileFallbackStats); bytes outside keep stale values of a
+    // larger rect / other ranks' rows, which nothing reads.
+    int* windowRegion = nullptr;
     // non-null: the launcher performs all its checks and hands its launch(es) to the recorder instead of enqueueing them
     LaunchRecorder* recorder = nullptr;
 };

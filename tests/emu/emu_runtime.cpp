@@ -32,6 +32,7 @@ void TablesMissing(const char* which) {
 
 namespace emu {
 
+long g_Med3Violations = 0;
 thread_local ThreadCtx* t_cur = nullptr;
 thread_local const void* t_kernarg = nullptr;
 
@@ -301,3 +302,5 @@ __attribute__((visibility("default"))) int nrdEmuSetThreads(int n) {
 #endif
 }
 }
+
+extern "C" __attribute__((visibility("default"))) long emu_med3_violations() { return emu::g_Med3Violations; }

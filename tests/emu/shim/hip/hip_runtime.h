@@ -136,7 +136,18 @@ inline float emu_fmed3f(float a, float b, float c) { return std::max(std::min(a,
 // nrdmath.h Rcp: the device hides the argument from the constant folder; nothing to hide from here
 #define NRD_OPAQUE_VALUE(x) ((void)0)
 #define NRD_LDS_WHOLE_TEXEL(v) ((void)0)
-#define NRD_MED3_I32(r, x, a, b) ((r) = (x) < (a) ? (a) : ((x) > (b) ? (b) : (x)))
+// ClampI = v_med3_i32: the MEDIAN of three like the instruction, not the clamp it stands for -- with a > b (an empty plane: clamp to [0, -1]) the two differ, and
+// the device computes the median. Call sites with a > b are counted (emu_med3_violations(), asserted to be 0 by tests/test_emulation.py: ADVICE r03).
+namespace emu {
+extern long g_Med3Violations;
+inline int Med3(int x, int a, int b) {
+    if (a > b)
+        __atomic_add_fetch(&g_Med3Violations, 1, __ATOMIC_RELAXED);
+    const int lo = x < a ? x : a, hi = x < a ? a : x; // sort (x, a)
+    return b < lo ? lo : (b > hi ? hi : b);            // the middle of (lo, hi, b)
+}
+} // namespace emu
+#define NRD_MED3_I32(r, x, a, b) ((r) = emu::Med3((x), (a), (b)))
 
 // ------------------------------------------------------------------------------------------------ runtime API (host side of executor.hip)
 typedef int hipError_t;

@@ -16,3 +16,9 @@ import parity
 def test_emulated_device_sources_match_the_oracle_bit_for_bit(name, width, height, frames):
     worst = parity.run_parity(name, width=width, height=height, frames=frames, backend="emu")
     assert worst == 0.0, (name, worst)
+    # every ClampI( x, a, b ) call site ran with a <= b: v_med3_i32 (what the device executes) is then the clamp the source means
+    from emu import emu_run
+
+    lib = emu_run.load()
+    lib.emu_med3_violations.restype = __import__("ctypes").c_long
+    assert lib.emu_med3_violations() == 0

@@ -87,6 +87,20 @@ def test_hip_numerics_bit_exact_vs_oracle():
     ora.oracle_eval_hw(2, b.ctypes.data, rb.ctypes.data, n)
     assert np.array_equal(out.cpu().numpy().view(np.uint32), (a * rb).view(np.uint32))
     assert np.abs(rb.view(np.int32).astype(np.int64) - (1.0 / b.astype(np.float64)).astype(np.float32).view(np.int32)).max() <= 1
+    # div_edge_cases (the contract is spelled out at nrdmath.h Div): denominators that v_rcp_f32 flushes (denormals -> +-inf, |b| > 2^126 -> +-0),
+    # zeros, infinities, NaN against numerators 0, +-1, tiny, huge: the device and the oracle agree bit for bit (NaN for NaN), including 0 * inf = NaN
+    num = np.array([0.0, -0.0, 1.0, -1.0, 1e-38, 3e38, 1e-45], dtype=np.float32)
+    den = np.array([1e-39, -1e-39, 1e-45, 0.0, -0.0, 2.0 ** 126, 1.8e38, 3.4e38, -3.4e38, np.inf, -np.inf, np.nan, 1.17549435e-38, 3.0], dtype=np.float32)
+    ea, eb = np.repeat(num, den.size).astype(np.float32), np.tile(den, num.size).astype(np.float32)
+    ta, tb, out = torch.from_numpy(ea).cuda(), torch.from_numpy(eb).cuda(), torch.empty(ea.size, device="cuda")
+    lib.nrdHipEvalNumerics(5, ta.data_ptr(), tb.data_ptr(), out.data_ptr(), ea.size, torch.cuda.current_stream().cuda_stream)
+    erb = np.empty_like(eb)
+    ora.oracle_eval_hw(2, eb.ctypes.data, erb.ctypes.data, eb.size)
+    with np.errstate(invalid="ignore", over="ignore"):
+        want = ea * erb
+    got = out.cpu().numpy()
+    same = (got.view(np.uint32) == want.view(np.uint32)) | (np.isnan(got) & np.isnan(want))
+    assert same.all(), list(zip(ea[~same], eb[~same], got[~same], want[~same]))[:8]
     specials = np.array([0.0, -0.0, np.inf, 1e-45, 1e-39, -1e-39, 1.17549435e-38, 3.4e38, 1.0, 2.0, 4.0, 0.25, -1.0, -np.inf], dtype=np.float32)
     wide = (np.abs(rng.standard_normal(200000)) * 10.0 ** rng.integers(-37, 38, 200000)).astype(np.float32)  # the whole exponent range
     pa = np.concatenate([np.abs(a), wide, specials]).astype(np.float32)
@@ -140,6 +154,24 @@ def test_hip_constant_division_and_gaussian_constants():
     assert out.cpu().numpy().view(np.uint32).tolist() == [0x3F04505F, 0x3F590F8F, 0x3F713C86]
     ora = oracle_driver.load()
     assert np.float32(ora.oracle_exp2(float(np.float32(np.float32(-0.66) * np.float32(1.0) * np.float32(1.0)) * np.float32(1.44269504)))).view(np.uint32) == 0x3F04505F
+
+
+def test_oracle_division_contract_edge_cases():
+    """a / b = a * v_rcp_f32(b): where that is not the IEEE quotient (documented at nrdmath.h Div and oracle/hlsl.h)"""
+    ora = oracle_driver.load()
+    prev = oracle_driver.set_ieee_mode(False)
+    try:
+        den = np.array([1e-39, 3.4e38, 2.0 ** 126, 2.0 ** 126 * 1.5, 3.0, np.inf, 0.0], dtype=np.float32)
+        r = np.empty_like(den)
+        ora.oracle_eval_hw(2, den.ctypes.data, r.ctypes.data, den.size)
+    finally:
+        oracle_driver.set_ieee_mode(prev)
+    assert np.isposinf(r[0])  # a denormal denominator is flushed: rcp = inf, so 0 / denormal = 0 * inf = NaN where IEEE gives 0
+    assert r[1] == 0.0 and r[3] == 0.0  # 1 / b would be denormal: flushed to 0 (IEEE: 2.9e-39)
+    assert r[2] == np.float32(2.0 ** -126)  # the smallest normal result survives
+    assert abs(float(r[4]) * 3.0 - 1.0) < 2e-7 and r[5] == 0.0 and np.isposinf(r[6])
+    with np.errstate(invalid="ignore"):
+        assert np.isnan(np.float32(0.0) * r[0])
 
 
 def test_hw_tables_are_sane():
