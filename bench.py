@@ -34,7 +34,6 @@ from raytracingdenoiser_amd import api, scene, sharding, synth
 from raytracingdenoiser_amd import build as native_build
 from raytracingdenoiser_amd.executor import HipExecutor
 
-VALU_CYCLES_PER_INSTRUCTION = 4.2  # SQ_ACTIVE_INST_VALU x 4 / SQ_INSTS_VALU of every pass kernel measured so far (profiles/pmc_traffic.json); used when a counter run lacks the counter
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E peak (MI355X_MICROARCH.md); ~6300 GB/s is what a float4 copy achieves (measured live below)
 
 # Published reference numbers for the exact metric (reference README.md:18, RTX 4080, 1440p native)
@@ -42,6 +41,7 @@ PUBLISHED_MPIX_S = {("REBLUR_DIFFUSE_SPECULAR", 2560, 1440): 1603.0, ("RELAX_DIF
 
 # HBM traffic per launch from hardware counters: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes, tools/pmc_run.sh), stored
 # by tools/pmc_to_json.py. FETCH_SIZE is doubled (MI355X_MICROARCH.md "HBM": gfx950 tallies 128-B requests at 64 B); both are KiB.
+ISSUE_FLOOR_FILE = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "issue_floor.json")
 PMC_TRAFFIC_FILE = os.path.join(ROOT, "profiles", "pmc_traffic.json")
 
 # Algorithmic (compulsory) bytes per pixel and per pass for REBLUR_DIFFUSE_SPECULAR with the reference pool formats
@@ -134,6 +134,7 @@ def parse_args():
     ap.add_argument("--no-sky", action="store_true", help="a dome behind the scene: no sky pixels (34 %% of the default frame are sky and leave at the tile test)")
     ap.add_argument("--uniform", action="store_true", help="tuning runs: every input plane constant (the value of one ground pixel), static camera -- the scene on which an L1-resident A/B build "
                     "(NRD_EXPERIMENT_L1_RESIDENT, csrc/hip/planes.h) computes the same values as the product and so measures each kernel's issue floor")
+    ap.add_argument("--dry-plan", action="store_true", help="no GPU: print the multi-GPU plan of --gpus N ranks for this workload (strips, halo bands, bytes, RCCL operations) and exit")
     ap.add_argument("--no-parity", action="store_true", help="skip the GPU-vs-oracle comparison of the cpu_baseline frames")
     return ap.parse_args()
 
@@ -167,7 +168,7 @@ def _usable_cores():
     return max(cores, 1)
 
 
-def cpu_baseline(name, width, height, frames, seq, overrides=None, check_parity=True):
+def cpu_baseline(name, width, height, frames, seq, overrides=None, check_parity=True, ieee_frames=4):
     """Times the CPU oracle on the first `frames` frames of the same sequence (all host cores, OpenMP over rows). The oracle's outputs are then
     compared with a fresh GPU run over the same frames (outside the timed region of either): returns (cpu_baseline, parity).
     The only place of this file that touches tests/ and oracle/ (the checker, never the thing measured)."""
@@ -213,6 +214,28 @@ def cpu_baseline(name, width, height, frames, seq, overrides=None, check_parity=
                "frames": frames, "planes": sorted(stats.outputs()),
                "max_rel_err": sm["max_rel_err"], "p999_rel_err": sm["p999"], "frac_gt_1e-3": sm["frac_gt_tol"], "mean_rel_err": sm["mean"], "bit_exact_frac": sm["bit_exact_frac"],
                "definition": "|gpu - cpu| / max(|cpu|, 1e-3) per value of the user outputs, worst frame"}
+        if ieee_frames:
+            # the second statement: the same GPU frames against the oracle in plain IEEE arithmetic -- an oracle that knows nothing about the device.
+            # A distribution by nature (DESIGN.md "Numerics": tap snaps + recurrence amplify the device's 1-ulp transcendentals), printed beside the 0.
+            prev_mode = oracle_driver.set_ieee_mode(True)
+            try:
+                ora2, hip2, st2 = parity.OracleRun(name, width, height, threads=threads), parity.GpuRun(name, width, height), parity.ParityStats()
+                for f, frame in enumerate(seq[:ieee_frames]):
+                    host = {k: (v.cpu() if torch.is_tensor(v) else v) for k, v in frame.items()}
+                    cs = scene.common_settings(frame["camera"], seq[max(f - 1, 0)]["camera"], width, height, f)
+                    ora2.step(host, cs, scene.denoiser_settings(name, host, overrides))
+                    hip2.step(frame, scene.common_settings(frame["camera"], seq[max(f - 1, 0)]["camera"], width, height, f), scene.denoiser_settings(name, frame, overrides))
+                    for rt in hip2.outs:
+                        st2.add(rt.name, f, parity.error_stats(hip2.output(rt), ora2.output(rt)))
+            finally:
+                oracle_driver.set_ieee_mode(prev_mode)
+            s2 = st2.summary(True)
+            par["vs_ieee"] = {"vs": "the same oracle in plain IEEE arithmetic (no knowledge of the device)", "frames": ieee_frames, "max_rel_err": s2["max_rel_err"], "p999_rel_err": s2["p999"],
+                              "frac_gt_1e-3": s2["frac_gt_tol"], "mean_rel_err": s2["mean"], "bit_exact_frac": s2["bit_exact_frac"]}
+        ref_summary = os.path.join(ROOT, "profiles", "r04_ref_parity_summary.txt")
+        if os.path.exists(ref_summary):
+            par["vs_reference_text"] = {"what": "the oracle pass by pass on identical inputs against the reference's own HLSL shaders compiled as C++ (oracle/_ref, tests/test_ref_parity.py)",
+                                        "recorded_in": "profiles/r04_ref_parity_summary.txt (CPU-only statistic, not measured in this run)"}
     return baseline, par
 
 
@@ -231,6 +254,10 @@ def _relaunch_under_torchrun(n):
 
 def main():
     args = parse_args()
+    if args.dry_plan:
+        name, default_size, _, overrides = WORKLOADS[args.workload]
+        print(json.dumps(sharding.dry_plan(name, args.width or default_size[0], args.height or default_size[1], max(args.gpus, 1), overrides, args.max_motion_rows), indent=1))
+        return
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         sys.exit(_relaunch_under_torchrun(args.gpus))
     rank = int(os.environ.get("RANK", "0"))
@@ -372,17 +399,23 @@ def main():
                 traffic = int((2.0 * k["FETCH_SIZE_KiB"] + k["WRITE_SIZE_KiB"]) * 1024)
                 traffic_source = entry.get("source")
                 if k.get("SQ_INSTS_VALU"):
-                    # the bound these kernels actually sit at: VALU issue. Executed wave instructions x the average issue cost of this kernel's
-                    # instruction mix -- measured where the counter run has SQ_ACTIVE_INST_VALU (unit: 4 cycles), else the price-list average -- over 1024 SIMDs at 2.4 GHz
-                    cpi = k.get("valu_cycles_per_instruction", VALU_CYCLES_PER_INSTRUCTION)
-                    issue_ms = k["SQ_INSTS_VALU"] * cpi / (1024 * 2.4e6)
-                    valu = {"executed_valu_per_wave": k["valu_per_wave"], "waves_per_launch": int(k["SQ_WAVES"]), "cycles_per_instruction": cpi,
-                            "issue_bound_ms": round(issue_ms, 4), "frac_of_issue_bound": round(issue_ms / passes[dominant]["avg_ms"], 3),
-                            "valu_busy_frac_in_counter_run": k.get("valu_busy_frac")}
+                    valu = {"executed_valu_per_wave": k["valu_per_wave"], "waves_per_launch": int(k["SQ_WAVES"]), "source": entry.get("source")}
+        # What the dominant kernel is bound by, measured directly (round 4; the counter-derived "VALU busy" of round 3 read up to 109 % and is gone): its time in
+        # a build whose loads all hit the L1, on a scene where that build computes the same values (bench.py --uniform, csrc/hip/planes.h NRD_EXPERIMENT_L1_RESIDENT).
+        issue_floor = None
+        if world == 1 and os.path.exists(ISSUE_FLOOR_FILE):
+            fl = json.load(open(ISSUE_FLOOR_FILE))
+            frag = {"TemporalAccumulation": "TemporalAccumulationKernel", "TemporalStabilization": "TemporalStabilizationKernel", "HistoryFix": "HistoryFixKernel", "HistoryClamping": "HistoryClampingKernel",
+                    "AtrousSmem": "AtrousSmemKernel", "PrePass": "PrePassKernel" if name.startswith("RELAX") else "ReblurSpatialKernel", "Blur": "ReblurSpatialKernel", "PostBlur": "ReblurSpatialKernel",
+                    "Atrous": "RelaxAtrousKernel"}.get(dominant.rsplit("_", 1)[-1].replace(".cs", ""))
+            rows_fl = next((v for k2, v in fl.get("workloads", {}).items() if k2.startswith(name + " ")), {})
+            hit = next((v for k2, v in rows_fl.items() if frag and k2.startswith(frag)), None)
+            if hit:
+                issue_floor = dict(hit, source=fl.get("source"), what="uniform scene, every pixel denoised: this kernel's time / its time with every load an L1 hit (not measured in this run)")
         roofline = {"bound": "hbm", "kernel": dominant, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
                     "measured_copy_GBps": round(copy_gbs, 1), "frac_of_measured_copy": round(achieved / copy_gbs, 4),
                     "denoised_pixel_fraction": round(denoised_fraction, 4), "frac_denoised_pixels": round(achieved / HBM_PEAK_GBS * denoised_fraction, 4),
-                    "traffic": traffic, "traffic_source": traffic_source, "valu": valu, "avg_kernel_ms": passes[dominant]["avg_ms"],
+                    "traffic": traffic, "traffic_source": traffic_source, "valu": valu, "issue_floor": issue_floor, "avg_kernel_ms": passes[dominant]["avg_ms"],
                     "algorithmic_bytes_per_launch": passes[dominant]["bytes_per_launch"],
                     "note": "dominant = the pass with the longest average launch; per-pass durations from HIP events on the executor's stream (eager replay of the timed frames); "
                             "frac counts the algorithmic bytes of EVERY pixel of the frame as the metric does, frac_denoised_pixels only those of the pixels that are not sky; "
@@ -411,7 +444,7 @@ def main():
         "dtype": "f32",
         "data": "synthetic",
         "numerics": "exact",  # one library, one arithmetic: what is timed here is bit-identical to the CPU oracle (see "parity")
-        "tile_fallback": {"tiles": tile_fallback[0], "of": tile_fallback[1], "what": "32x8-pixel tiles of the last frame left to the plain TemporalAccumulation kernel (LDS window too small)"},
+        "tile_fallback": {"tiles": tile_fallback[0], "of": tile_fallback[1], "what": "32x8-pixel tiles of the last frame's rect left to the plain TemporalAccumulation kernel (LDS window too small)"},
         "launch": "eager" if args.no_graph else "hipGraph (%d launches, %d builds, %d node updates in the run)" % graph_stats,
         "rccl_ranks": world if distributed and backend == "nccl" else (0 if not distributed else None),
         "config": {"workload": "%s %dx%d, %s, analytic scene%s + 1rpp noise, moving camera" % (name, W, H, "default settings" if overrides is None else "settings %s" % overrides,
@@ -423,6 +456,10 @@ def main():
         "roofline": roofline,
         "whole_chain": whole_chain,
         "passes": passes,
+        # which regime of the temporal chain the timed frames are in: SURVEY section 8d specifies 32 warm-up frames + the mean of 64 (this file's
+        # default); a shorter warm-up times frames whose history is still growing (maxAccumulatedFrameNum 30), with wider blur radii: slightly more work per frame
+        "protocol": {"timed_frames": "%d..%d after the CLEAR_AND_RESTART frame 0" % (args.warmup, total - 1),
+                     "regime": "steady state (history saturated: SURVEY 8d, 32 warm-up + 64 timed)" if args.warmup >= 30 else "accumulating (history below maxAccumulatedFrameNum = 30 during part of the timed frames)"},
     }
     if not args.no_cpu_baseline and world == 1:
         result["cpu_baseline"], result["parity"] = cpu_baseline(name, W, H, min(args.cpu_frames, distinct), seq, overrides, check_parity=not args.no_parity)

@@ -227,6 +227,11 @@ __global__ __launch_bounds__(TILE_X* TILE_Y, SH ? 0 : NRD_WAVES_REBLUR_HF) void 
     float preMaterialID;
     const float4 preNormalAndRoughness = LoadDecodedNormalRoughness(P.decodedNR, qx, qy, preMaterialID);
     const float2 preData1 = LoadData1<DIFF, SPEC>(P.data1, qx, qy);
+    S preDiff = Sig::Zero(), preSpec = Sig::Zero();
+    if (DIFF)
+        preDiff = Sig::Load(P.inDiff, qx, qy);
+    if (SPEC)
+        preSpec = Sig::Load(P.inSpec, qx, qy);
     {
         const int baseX = BlockTileX(rr) * TILE_X - hf::BORDER, baseY = blockY * TILE_Y - hf::BORDER;
         for (int i = threadIdx.x; i < hf::BUF_X * hf::BUF_Y; i += TILE_X * TILE_Y) {
@@ -265,7 +270,7 @@ __global__ __launch_bounds__(TILE_X* TILE_Y, SH ? 0 : NRD_WAVES_REBLUR_HF) void 
         float4 diffSh = F4(0.0f);
         if (SH)
             diffSh = LoadRGBA16F(P.inDiffSh, px, py);
-        S diff = HistoryFixSignal<false, DIFF, SPEC, PERF, KIND, SH>(c, P, s, Sig::Load(P.inDiff, px, py), frameNum.x, stride.x, P.inDiff, P.inDiffFast, P.outDiffFast, s_DiffLuma, diffSh, P.inDiffSh);
+        S diff = HistoryFixSignal<false, DIFF, SPEC, PERF, KIND, SH>(c, P, s, preDiff, frameNum.x, stride.x, P.inDiff, P.inDiffFast, P.outDiffFast, s_DiffLuma, diffSh, P.inDiffSh);
         Sig::Store(P.outDiff, px, py, diff);
         if (SH)
             StoreRGBA16F(P.outDiffSh, px, py, diffSh);
@@ -274,7 +279,7 @@ __global__ __launch_bounds__(TILE_X* TILE_Y, SH ? 0 : NRD_WAVES_REBLUR_HF) void 
         float4 specSh = F4(0.0f);
         if (SH)
             specSh = LoadRGBA16F(P.inSpecSh, px, py);
-        S spec = HistoryFixSignal<true, DIFF, SPEC, PERF, KIND, SH>(c, P, s, Sig::Load(P.inSpec, px, py), frameNum.y, stride.y, P.inSpec, P.inSpecFast, P.outSpecFast, s_SpecLuma, specSh, P.inSpecSh);
+        S spec = HistoryFixSignal<true, DIFF, SPEC, PERF, KIND, SH>(c, P, s, preSpec, frameNum.y, stride.y, P.inSpec, P.inSpecFast, P.outSpecFast, s_SpecLuma, specSh, P.inSpecSh);
         Sig::Store(P.outSpec, px, py, spec);
         if (SH)
             StoreRGBA16F(P.outSpecSh, px, py, specSh);
@@ -383,6 +388,11 @@ __global__ __launch_bounds__(TILE_X* TILE_Y, NRD_WAVES_REBLUR_TS) void ReblurTem
     const float4 preNormalAndRoughness = LoadDecodedNormalRoughness(P.decodedNR, qx, qy, preMaterialID);
     const float2 preData1 = LoadData1<DIFF, SPEC>(P.data1, qx, qy);
     const uint32_t preData2 = SPEC ? LoadR32U(P.data2, qx, qy) : LoadR8U(P.data2, qx, qy);
+    S preDiff = Sig::Zero(), preSpec = Sig::Zero();
+    if (DIFF)
+        preDiff = Sig::Load(P.inDiff, qx, qy);
+    if (SPEC)
+        preSpec = Sig::Load(P.inSpec, qx, qy);
     {
         const int baseX = BlockTileX(rr) * TILE_X - ts::BORDER, baseY = blockY * TILE_Y - ts::BORDER;
         for (int i = threadIdx.x; i < ts::BUF_X * ts::BUF_Y; i += TILE_X * TILE_Y) {
@@ -467,7 +477,7 @@ __global__ __launch_bounds__(TILE_X* TILE_Y, NRD_WAVES_REBLUR_TS) void ReblurTem
         smbDiffLumaHistory = ColorClamp(diffLumaM1, diffLumaSigma * diffTemporalAccumulationParams.y, smbDiffLumaHistory);
         float diffLumaStabilized = Lerp(diffLuma, smbDiffLumaHistory, Min(diffHistoryWeight, c.gStabilizationStrength));
 
-        S diff = Sig::Load(P.inDiff, px, py);
+        S diff = preDiff;
         diff = ChangeLuma(diff, diffLumaStabilized);
         Sig::Store(P.outDiff, px, py, diff);
         StoreR16F(P.outDiffLuma, px, py, diffLumaStabilized);
@@ -489,7 +499,7 @@ __global__ __launch_bounds__(TILE_X* TILE_Y, NRD_WAVES_REBLUR_TS) void ReblurTem
         float virtualHistoryAmount = data2.x;
         float curvature = data2.y;
 
-        S spec = Sig::Load(P.inSpec, px, py);
+        S spec = preSpec;
         float hitDistForTracking = ExtractHitDist(spec) * GetHitDistanceNormalization(viewZ, ToF4(c.gHitDistParams), roughness);
         if (c.gSpecPrepassBlurRadius != 0.0f)
             hitDistForTracking = Min(hitDistForTracking, LoadR16F(P.inSpecHitDistForTracking, px, py));

@@ -92,6 +92,7 @@ __global__ __launch_bounds__(256, NRD_WAVES_RELAX_ATROUS_SMEM) void RelaxAtrousS
     const bool inGrid = px < ((rectW + 7) & ~7) && py < ((rectH + 7) & ~7);
     const bool blockHasGeometry = RelaxBlockHasGeometry(P.tiles, BlockTileX(rows), blockY);
 
+    // (measured and dropped, r04_g: requesting the pixel's own small inputs in front of the tile fill as the temporal passes do -- 0.327 against 0.310 ms)
     if (blockHasGeometry) {
         for (int idx = threadIdx.x; idx < sm::BUF_X * sm::BUF_Y; idx += 256) {
             int lx = idx % sm::BUF_X, ly = idx / sm::BUF_X;

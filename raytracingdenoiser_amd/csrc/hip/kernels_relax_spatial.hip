@@ -324,14 +324,14 @@ __global__ __launch_bounds__(256, NRD_WAVES_RELAX_PREPASS) void RelaxPrePassKern
                 float angle = AcosApprox(Dot(centerNormal, sampleNormal));
                 sampleWeight *= ComputeWeight(angle, normalWeightParam, 0.0f);
 
-                float4 sampleDiffuseIllumination = Denanify(sampleWeight, LoadRGBA16F(P.diff.in, t.signalTexel.x, t.signalTexel.y));
+                float4 sampleDiffuseIllumination = LoadDenanifiedRGBA16F(sampleWeight, P.diff.in, t.signalTexel.x, t.signalTexel.y);
                 sampleWeight *= Lerp(c.shared.gMinHitDistanceWeight, 1.0f, ComputeExponentialWeight(sampleDiffuseIllumination.w, hitDistanceWeightParams.x, hitDistanceWeightParams.y));
                 sampleWeight *= GetGaussianWeight(g_Poisson8[i][2]);
 
                 weightSum += sampleWeight;
                 diffuseIllumination = Mad(sampleDiffuseIllumination, sampleWeight, diffuseIllumination);
                 if (SH) {
-                    float4 sampleDiffuseSH = Denanify(sampleWeight, LoadRGBA16F(P.diff.inSh, t.signalTexel.x, t.signalTexel.y));
+                    float4 sampleDiffuseSH = LoadDenanifiedRGBA16F(sampleWeight, P.diff.inSh, t.signalTexel.x, t.signalTexel.y);
                     diffuseSH = Mad(sampleDiffuseSH, sampleWeight, diffuseSH);
                 }
             }
@@ -409,7 +409,7 @@ __global__ __launch_bounds__(256, NRD_WAVES_RELAX_PREPASS) void RelaxPrePassKern
                 const float3 sampleWorldPos = t.worldPos;
                 sampleWeight *= GetPlaneDistanceWeight(centerWorldPos, centerNormal, centerViewZ, sampleWorldPos, c.shared.gDepthThreshold);
 
-                float4 sampleSpecularIllumination = Denanify(sampleWeight, LoadRGBA16F(P.spec.in, t.signalTexel.x, t.signalTexel.y));
+                float4 sampleSpecularIllumination = LoadDenanifiedRGBA16F(sampleWeight, P.spec.in, t.signalTexel.x, t.signalTexel.y);
                 sampleWeight *= Lerp(specMinHitDistanceWeight, 1.0f, ComputeExponentialWeight(sampleSpecularIllumination.w, hitDistanceWeightParams.x, hitDistanceWeightParams.y));
                 sampleWeight *= GetGaussianWeight(g_Poisson8[i][2]);
 
@@ -421,7 +421,7 @@ __global__ __launch_bounds__(256, NRD_WAVES_RELAX_PREPASS) void RelaxPrePassKern
                 weightSum += sampleWeight;
                 rgb = Mad(Xyz(sampleSpecularIllumination), sampleWeight, rgb);
                 if (SH) {
-                    float4 sampleSpecularSH = Denanify(sampleWeight, LoadRGBA16F(P.spec.inSh, t.signalTexel.x, t.signalTexel.y));
+                    float4 sampleSpecularSH = LoadDenanifiedRGBA16F(sampleWeight, P.spec.inSh, t.signalTexel.x, t.signalTexel.y);
                     specularSH = Mad(sampleSpecularSH, sampleWeight, specularSH);
                 }
                 if (sampleWeight != 0.0f)
@@ -487,10 +487,13 @@ __global__ __launch_bounds__(256, NRD_WAVES_RELAX_HF) void RelaxHistoryFixKernel
     const int rectW = c.shared.gRectSize.x, rectH = c.shared.gRectSize.y;
     if (px >= rectW || py >= rectH || py < rows.rowBegin || py >= rows.rowEnd)
         return;
-    if (LoadR8Unorm(P.tiles, px >> 4, py >> 4) != 0.0f)
-        return;
+    // the three loads that decide whether the pixel has anything to do, requested together (one memory latency instead of two: in the steady state nearly every
+    // pixel leaves here, and the pass ran 60 % above the time of a build whose loads all hit the L1, profiles/r04_c_relax_ds_sh_uniform_*_kernel_stats.txt)
+    const float tileFlag = LoadR8Unorm(P.tiles, px >> 4, py >> 4);
     float centerViewZ = RelaxUnpackViewZ(c, LoadR32F(P.viewZ, px, py));
     float historyLength = 255.0f * LoadR8Unorm(P.historyLength, px, py);
+    if (tileFlag != 0.0f)
+        return;
     if (centerViewZ > c.shared.gDenoisingRange || (historyLength > c.shared.gHistoryFixFrameNum || c.shared.gHistoryFixFrameNum == 1.0f))
         return;
 

@@ -189,6 +189,14 @@ NRD_D float2 RelaxClampUvToViewport(const RelaxCB& c, float2 uv) {
 }
 NRD_D float ApplyThinLensEquation(float O, float curvature) { return Div(O, 2.0f * curvature * O + 1.0f); } // reference Common.hlsli:404-409
 NRD_D float4 Denanify(float w, float4 x) { return w == 0.0f ? F4(0.0f) : x; }
+// Denanify( w, tex[ p ] ) of the tap loops, with the selection made on the two raw dwords (2 selects instead of 4; the fp16 -> fp32 conversions then feed the
+// accumulating multiply-adds directly and fold into v_fma_mix_f32: same values bit for bit -- reblur_device.h ReblurSignal::LoadOrZero has the measurement)
+NRD_D float4 LoadDenanifiedRGBA16F(float w, const Plane& p, int x, int y) {
+    uint2 raw = *TexelPtr<const uint2>(p, x, y);
+    raw.x = w == 0.0f ? 0u : raw.x;
+    raw.y = w == 0.0f ? 0u : raw.y;
+    return F4(HalfBitsToFloat((uint16_t)(raw.x & 0xFFFFu)), HalfBitsToFloat((uint16_t)(raw.x >> 16)), HalfBitsToFloat((uint16_t)(raw.y & 0xFFFFu)), HalfBitsToFloat((uint16_t)(raw.y >> 16)));
+}
 
 // true when any of the 16x16 tiles overlapped by this workgroup's 32x8 block has geometry
 NRD_D bool RelaxBlockHasGeometry(const Plane& tiles, int blockX, int blockY) {

@@ -560,3 +560,61 @@ class HaloSharder:
                 self.ex.execute_range(ptr, n, first + early, count - early, *plan.c_rows())
         self.finish_frame(plan)
         return plan
+
+
+def dry_plan(name, width, height, world, overrides=None, max_motion_rows=None, exchange_threshold=24):
+    """The per-rank plan of the halo scheme for one steady-state frame WITHOUT any GPU: strips, the pass segments, per exchange step the
+    planes and rows each rank receives from its two neighbours, the bytes, and the RCCL operation list (one grouped batch of send / recv per step and
+    neighbour pair). Pure host work: the dispatch list comes from nrd::GetComputeDispatches, the reach from nrdHipGetDispatchReach, the planner is the one
+    HaloSharder uses. Returns a JSON-able dict; `bench.py --gpus N --dry-plan` prints it."""
+    from . import api, scene, synth
+
+    inst = api.Instance([(0, scene.DENOISERS[name][0])])
+    frames = [synth.render_frame(32, 18, f, device="cpu", want=()) for f in range(3)]  # cameras of the bench sequence (the planes themselves are not needed)
+    settings = scene.denoiser_settings(name, frames[0], overrides)
+    assert inst.set_denoiser_settings(0, settings) == api.Result.SUCCESS
+    max_motion_rows = HaloSharder.default_motion_rows(height) if max_motion_rows is None else max_motion_rows
+    dispatches = reach = None
+    for f in range(3):  # frame 0 restarts (clears: unsharded); frames 1, 2 are the two ping-pong phases of the steady state
+        assert inst.set_common_settings(scene.common_settings(frames[f]["camera"], frames[max(f - 1, 0)]["camera"], width, height, f)) == api.Result.SUCCESS
+        r, ptr, n = inst.get_compute_dispatches_raw()
+        assert r == api.Result.SUCCESS
+        reach = inst.dispatch_reach(ptr, n)
+        dispatches = [api.Dispatch(ptr[i], inst.pipelines) for i in range(n)]
+    small = {(int(pool), i) for pool, descs in ((api.ResourceType.PERMANENT_POOL, inst.permanent_pool), (api.ResourceType.TRANSIENT_POOL, inst.transient_pool))
+             for i, (fmt, ds) in enumerate(descs) if ds != 1}
+    bounds = [r * height // world for r in range(world + 1)]
+    min_strip = min(b - a for a, b in zip(bounds, bounds[1:]))
+
+    def row_bytes(key):
+        t, idx = key
+        if t == int(api.ResourceType.PERMANENT_POOL):
+            fmt = inst.permanent_pool[idx][0]
+        elif t == int(api.ResourceType.TRANSIENT_POOL):
+            fmt = inst.transient_pool[idx][0]
+        else:
+            fmt = {int(rt): f for rt, _, _, f in scene.output_planes(name, width, height)}.get(t)
+        return (width * api.FORMAT_BYTES[fmt] + 255) & ~255 if fmt is not None else 0
+
+    def label(key):
+        t, idx = key
+        rt = api.ResourceType(t)
+        return "%s[%d]" % (rt.name, idx) if "POOL" in rt.name else rt.name
+
+    out = {"denoiser": name, "size": [width, height], "ranks": world, "strips": bounds, "history_halo_rows": max_motion_rows, "passes": [d.shader for d in dispatches], "reach_rows": list(reach),
+           "per_rank": []}
+    for rank in range(world):
+        plan = plan_halo_exchange(dispatches, reach, (bounds[rank], bounds[rank + 1]), height, max_motion_rows, exchange_threshold, small, min_strip)
+        entry = {"rank": rank, "rows": [bounds[rank], bounds[rank + 1]], "fallback_unsharded": bool(plan.fallback), "steps": []}
+        total = 0
+        for si, (items, first, count) in enumerate(plan.steps):
+            neighbours = [r for r in (rank - 1, rank + 1) if 0 <= r < world]
+            recv = sum(w * row_bytes(key) for key, w in items) * len(neighbours)
+            total += recv
+            entry["steps"].append({"before_pass": dispatches[first].shader, "passes_in_segment": count, "planes": [{"plane": label(key), "rows_from_each_neighbour": w, "bytes_per_neighbour": w * row_bytes(key)} for key, w in items],
+                                   "rccl": ["group { " + ", ".join("recv(%d rows of %d planes from rank %d), send(same to rank %d)" % (max((w for _, w in items), default=0), len(items), nb, nb) for nb in neighbours) + " }"] if items else [],
+                                   "received_bytes": recv, "overlaps_with": "the first %d pass(es) of the segment (they do not touch these planes)" % plan.early[si] if si < len(plan.early) and plan.early[si] else None})
+        entry["received_bytes_per_frame"] = total
+        entry["transfer_ms_at_50GBps_per_link"] = round(total / max(len([r for r in (rank - 1, rank + 1) if 0 <= r < world]), 1) / 50e9 * 1e3, 3)
+        out["per_rank"].append(entry)
+    return out
