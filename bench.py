@@ -127,6 +127,8 @@ def parse_args():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--sharding", choices=["halo", "allgather"], default=os.environ.get("NRD_SHARDING", "halo"),
                     help="multi-GPU scheme: halo = halo exchange between pass segments (point-to-point to the two neighbouring ranks), allgather = redundant halo compute + one all-gather per frame")
+    ap.add_argument("--motion-bound", choices=("measure", "estimate"), default="measure", help="halo scheme: where the per-frame motion bound comes from -- measure: a device reduction over "
+                    "IN_VIEWZ / IN_MV of every strip + MAX over ranks (nrdHipMeasureMotionRows); estimate: the 5 x 5 camera heuristic of round 3 (no synchronisation)")
     ap.add_argument("--max-motion-rows", type=int, default=None, help="halo scheme: largest vertical motion (rows per frame) the history halos cover (default: 32 up to 1440p, scaled with the height above)")
     ap.add_argument("--cpu-frames", type=int, default=8)
     ap.add_argument("--distinct-frames", type=int, default=0, help="number of distinct generated frames to cycle through (0 = warmup + steps)")
@@ -310,7 +312,7 @@ def main():
         outputs.append(t)
     shard = None
     if distributed:
-        shard = sharding.HaloSharder(ex, inst, W, H, rank, world, max_motion_rows=args.max_motion_rows) if args.sharding == "halo" else sharding.FrameSharder(ex, inst, W, H, rank, world, outputs)
+        shard = sharding.HaloSharder(ex, inst, W, H, rank, world, max_motion_rows=args.max_motion_rows, measure_motion=args.motion_bound == "measure") if args.sharding == "halo" else sharding.FrameSharder(ex, inst, W, H, rank, world, outputs)
 
     settings = scene.denoiser_settings(name, seq[0], overrides)
     assert inst.set_denoiser_settings(0, settings) == api.Result.SUCCESS
@@ -452,6 +454,9 @@ def main():
                    "parallelism": "1 GPU" if world == 1 else ("row strips x%d, halo exchange between pass segments (RCCL send/recv to the 2 neighbours, %.1f MB received per rank per frame)"
                                                                % (world, shard.exchanged_bytes / max(total, 1) / 1e6) if args.sharding == "halo" else "row strips x%d + RCCL all-gather" % world),
                    "strips": (list(shard.bounds) if shard is not None and getattr(shard, "bounds", None) else None),  # halo scheme: rows owned by each rank (re-cut from the tile map)
+                   "motion_bound": (None if shard is None or args.sharding != "halo" else
+                                    {"source": "device reduction per strip + MAX over ranks (nrdHipMeasureMotionRows)" if args.motion_bound == "measure" else "camera estimate (5 x 5 samples)",
+                                     "last_measured_rows": shard.measured_motion_rows, "halo_rows": shard.max_motion_rows, "frames_run_unsharded_for_motion": shard.motion_fallbacks}),
                    "storage": "reference pool formats (fp16 history, R10G10B10A2 normals), %.0f B/px/frame compulsory traffic" % total_bpp},
         "roofline": roofline,
         "whole_chain": whole_chain,

@@ -117,6 +117,15 @@ uint32_t nrdHipPlanHaloExchange(void* instance, const void* dispatchDescs, uint3
     uint32_t maxMotionRows, uint32_t exchangeThreshold, int32_t* rowBegin, int32_t* rowEnd, NrdHipHaloStep* steps, uint32_t stepsCapacity, NrdHipHaloItem* items, uint32_t itemsCapacity,
     NrdHipHaloPlanInfo* info);
 
+// The motion side of the sharding contract, measured on the device: *maxRows = the largest vertical distance (in rows of the previous rect) over which the
+// surface-motion reprojection of the temporal passes (reference REBLUR_TemporalAccumulation.hlsli:136-150, RELAX_TemporalAccumulation.hlsli:560-575,
+// SIGMA_TemporalStabilization.hlsli) moves a denoised pixel of rows [rowBegin, rowEnd) of the rect -- from the bound IN_VIEWZ / IN_MV planes and the constants
+// of the given dispatch list (the list of THIS frame, before it is executed). One streaming kernel over the strip (12 B per pixel), a 4-byte read-back and
+// a stream synchronisation. A rank calls it on its own strip, takes the MAX over ranks, and runs the frame unsharded when the result + 2 rows (bicubic
+// footprint) does not fit the history halo it planned with (maxMotionRows below). 0 for lists without a temporal denoiser; pixels whose previous position
+// lies behind the previous camera (or whose motion vector is NaN) report a huge value on purpose.
+uint32_t nrdHipMeasureMotionRows(NrdHipExecutor* executor, const void* dispatchDescs, uint32_t dispatchDescsNum, uint32_t rowBegin, uint32_t rowEnd, float* maxRows);
+
 // Per-pass GPU timing. When enabled, every dispatch is bracketed by hipEvents on the executor's stream.
 // nrdHipCollectPassTimings synchronises the stream, folds all brackets recorded since the last collect into per-pipeline
 // totals and returns the number of pipelines written: pipelineIndices[i] (index into InstanceDesc::pipelines),

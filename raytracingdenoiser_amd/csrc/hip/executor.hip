@@ -99,6 +99,7 @@ struct NrdHipExecutor {
     int windowRegion[3] = {0, 0, 0};   // {tile columns, first tile row, end tile row} of the last window-kernel launch (passes.h PassArgs::windowRegion)
     Plane tileFlags = {};              // one byte per 32x8-pixel workgroup tile: hand-over between the two kernels of a split pass (kernels_reblur_ta.hip "window")
     Plane viewPos = {};                // internal float4 guide plane of the REBLUR lists (decoded normal + viewZ per pixel)
+    uint32_t* motionBits = nullptr;    // nrdHipMeasureMotionRows: the reduction's result (float bits), own 4-byte allocation made on first use
     std::vector<nrd::Format> permanentFormat, transientFormat;
 
     Plane user[(size_t)nrd::ResourceType::MAX_NUM] = {};
@@ -289,6 +290,8 @@ extern "C" __attribute__((visibility("default"))) void nrdHipDestroyExecutor(Nrd
         (void)hipFree(e->viewPos.ptr);
     if (e->tileFlags.ptr)
         (void)hipFree(e->tileFlags.ptr);
+    if (e->motionBits)
+        (void)hipFree(e->motionBits);
     for (Plane& p : e->shifted)
         if (p.ptr)
             (void)hipFree(p.ptr);
@@ -1085,6 +1088,86 @@ extern "C" __attribute__((visibility("default"))) uint32_t nrdHipGetTileFallback
         *fallbackTiles = n;
     if (totalTiles)
         *totalTiles = total;
+    return (uint32_t)nrd::Result::SUCCESS;
+}
+
+// Multi-GPU: how far does THIS frame's surface-motion reprojection reach vertically, over the rows [rowBegin, rowEnd) of the rect? (include/NRDHip.h)
+extern "C" __attribute__((visibility("default"))) uint32_t nrdHipMeasureMotionRows(NrdHipExecutor* e, const void* dispatchDescs, uint32_t dispatchDescsNum, uint32_t rowBegin, uint32_t rowEnd,
+    float* maxRows) {
+    if (!e || !maxRows || (!dispatchDescs && dispatchDescsNum))
+        return (uint32_t)nrd::Result::INVALID_ARGUMENT;
+    *maxRows = 0.0f;
+    const nrd::DispatchDesc* descs = (const nrd::DispatchDesc*)dispatchDescs;
+    const nrd::InstanceDesc& idesc = nrd::GetInstanceDesc(*e->instance);
+    MotionParams p = {};
+    bool found = false;
+    int originX = 0, originY = 0;
+    for (uint32_t i = 0; i < dispatchDescsNum && !found; i++) {
+        const nrd::DispatchDesc& d = descs[i];
+        if (d.pipelineIndex >= idesc.pipelinesNum || !d.constantBufferData)
+            continue;
+        const char* shader = idesc.pipelines[d.pipelineIndex].shaderFileName;
+        auto common = [&](const auto& c) {
+            memcpy(p.worldToClipPrev, c.gWorldToClipPrev, sizeof(p.worldToClipPrev));
+            const float mvScale[4] = {c.gMvScale.x, c.gMvScale.y, c.gMvScale.z, c.gMvScale.w};
+            memcpy(p.mvScale, mvScale, sizeof(mvScale));
+            p.rectSizeInv[0] = c.gRectSizeInv.x, p.rectSizeInv[1] = c.gRectSizeInv.y;
+            p.rectHeightPrev = c.gRectSizePrev.y;
+            p.viewZScale = c.gViewZScale, p.denoisingRange = c.gDenoisingRange;
+            p.rectW = (int)c.gRectSize.x, p.rectH = (int)c.gRectSize.y;
+            originX = (int)c.gRectOrigin.x, originY = (int)c.gRectOrigin.y;
+            found = true;
+        };
+        auto frustum = [&](const auto& c) {
+            const float f[4] = {c.gFrustum.x, c.gFrustum.y, c.gFrustum.z, c.gFrustum.w};
+            memcpy(p.frustum, f, sizeof(f));
+        };
+        if (!strncmp(shader, "REBLUR_", 7) && d.constantBufferDataSize >= sizeof(nrdc::ReblurConstants)) {
+            nrdc::ReblurConstants c;
+            memcpy(&c, d.constantBufferData, sizeof(c));
+            common(c);
+            frustum(c);
+            memcpy(p.viewToWorld, c.gViewToWorld, sizeof(p.viewToWorld));
+        } else if (!strncmp(shader, "RELAX_", 6) && d.constantBufferDataSize >= sizeof(nrdc::RelaxConstants)) {
+            nrdc::RelaxConstants c;
+            memcpy(&c, d.constantBufferData, sizeof(c));
+            common(c);
+            p.relaxForm = 1;
+            const float r[4] = {c.gFrustumRight.x, c.gFrustumRight.y, c.gFrustumRight.z, 0.0f}, u[4] = {c.gFrustumUp.x, c.gFrustumUp.y, c.gFrustumUp.z, 0.0f},
+                        f[4] = {c.gFrustumForward.x, c.gFrustumForward.y, c.gFrustumForward.z, 0.0f};
+            memcpy(p.frustumRight, r, sizeof(r));
+            memcpy(p.frustumUp, u, sizeof(u));
+            memcpy(p.frustumForward, f, sizeof(f));
+        } else if (!strncmp(shader, "SIGMA_", 6) && d.constantBufferDataSize >= sizeof(nrdc::SigmaConstants)) {
+            nrdc::SigmaConstants c;
+            memcpy(&c, d.constantBufferData, sizeof(c));
+            common(c);
+            frustum(c);
+            for (int r = 0; r < 3; r++) // view -> world = the transposed rotation of gWorldToView (column-major storage)
+                for (int k = 0; k < 3; k++)
+                    p.viewToWorld[k * 4 + r] = c.gWorldToView[r * 4 + k];
+        }
+    }
+    if (!found)
+        return (uint32_t)nrd::Result::SUCCESS; // no temporal denoiser in the list (REFERENCE, empty list): nothing reprojects
+    const uint32_t tz = (uint32_t)nrd::ResourceType::IN_VIEWZ, tm = (uint32_t)nrd::ResourceType::IN_MV;
+    if (!e->userBound[tz] || !e->userBound[tm])
+        return e->Fail(nrd::Result::INVALID_ARGUMENT, "nrdHipMeasureMotionRows: IN_VIEWZ and IN_MV have to be bound");
+    Plane z = e->user[tz], mv = e->user[tm];
+    if (originX + p.rectW > z.w || originY + p.rectH > z.h || originX + p.rectW > mv.w || originY + p.rectH > mv.h)
+        return e->Fail(nrd::Result::INVALID_ARGUMENT, "nrdHipMeasureMotionRows: the rect leaves the bound IN_VIEWZ / IN_MV planes");
+    z.ptr += (size_t)originY * z.pitch + (size_t)originX * 4;
+    mv.ptr += (size_t)originY * mv.pitch + (size_t)originX * 8;
+    if (!e->motionBits && hipMalloc((void**)&e->motionBits, sizeof(uint32_t)) != hipSuccess)
+        return e->Fail(nrd::Result::FAILURE, "nrdHipMeasureMotionRows: cannot allocate the result word");
+    const int r0 = (int)(rowBegin < (uint32_t)p.rectH ? rowBegin : (uint32_t)p.rectH), r1 = (int)(rowEnd < (uint32_t)p.rectH ? rowEnd : (uint32_t)p.rectH);
+    uint32_t bits = 0;
+    if (hipMemsetAsync(e->motionBits, 0, sizeof(uint32_t), e->stream) != hipSuccess)
+        return e->Fail(nrd::Result::FAILURE, "nrdHipMeasureMotionRows: hipMemsetAsync failed");
+    LaunchMotionRows(e->stream, z, mv, p, r0, r1, e->motionBits);
+    if (hipStreamSynchronize(e->stream) != hipSuccess || hipMemcpy(&bits, e->motionBits, sizeof(bits), hipMemcpyDeviceToHost) != hipSuccess)
+        return e->Fail(nrd::Result::FAILURE, "nrdHipMeasureMotionRows: cannot read the result back");
+    memcpy(maxRows, &bits, sizeof(bits));
     return (uint32_t)nrd::Result::SUCCESS;
 }
 

@@ -250,4 +250,45 @@ const PassEntry* GetCommonPasses(uint32_t& num) {
     return kPasses;
 }
 
+// ================================================================================================ motion bound of a row strip (multi-GPU)
+// max over the denoised pixels of rows [rowBegin, rowEnd) of | reprojected row - row |, the surface-motion reprojection of the temporal passes (reference
+// REBLUR_TemporalAccumulation.hlsli:136-150, RELAX_TemporalAccumulation.hlsli:560-575: previous position from IN_MV in its three conventions). One streaming pass
+// over IN_VIEWZ + IN_MV (12 B per pixel), wave reduction + one atomicMax on the float's bits (non-negative floats order like their bit patterns).
+__global__ __launch_bounds__(256) void MotionRowsKernel(Plane viewZ, Plane mv, MotionParams p, int rowBegin, int rowEnd, uint32_t* outMaxBits) {
+    const int px = blockIdx.x * 64 + (threadIdx.x & 63), py = rowBegin + blockIdx.y * 4 + (threadIdx.x >> 6);
+    // viewZ / mv: the user's planes, already offset to the rect origin by the caller
+    float rows = 0.0f;
+    if (px < p.rectW && py < rowEnd && py < p.rectH) {
+        const float z = Abs(LoadR32F(viewZ, px, py) * p.viewZScale);
+        if (!(z > p.denoisingRange)) {
+            const float2 uv = F2((float(px) + 0.5f) * p.rectSizeInv[0], (float(py) + 0.5f) * p.rectSizeInv[1]);
+            const float4 m = LoadRGBA16F(mv, px, py);
+            float2 uvPrev = F2(uv.x + m.x * p.mvScale[0], uv.y + m.y * p.mvScale[1]);
+            if (p.mvScale[3] != 0.0f) { // world-space motion: previous world position through the previous view-projection
+                float3 X;
+                if (p.relaxForm) {
+                    const float cx = uv.x * 2.0f - 1.0f, cy = uv.y * 2.0f - 1.0f;
+                    X = F3(z * (p.frustumForward[0] + p.frustumRight[0] * cx - p.frustumUp[0] * cy), z * (p.frustumForward[1] + p.frustumRight[1] * cx - p.frustumUp[1] * cy),
+                        z * (p.frustumForward[2] + p.frustumRight[2] * cx - p.frustumUp[2] * cy));
+                } else {
+                    X = RotateVector(p.viewToWorld, ReconstructViewPosition(uv, F4(p.frustum[0], p.frustum[1], p.frustum[2], p.frustum[3]), z, 0.0f));
+                }
+                uvPrev = GetScreenUv(p.worldToClipPrev, F3(X.x + m.x * p.mvScale[0], X.y + m.y * p.mvScale[1], X.z + m.z * p.mvScale[2])); // behind the previous camera: far off screen
+            }
+            rows = Abs(uvPrev.y - uv.y) * p.rectHeightPrev;
+            rows = rows == rows ? rows : 1.0e9f; // NaN motion vectors count as unbounded
+        }
+    }
+    for (int o = 32; o >= 1; o >>= 1)
+        rows = fmaxf(rows, __shfl_xor(rows, o));
+    if ((threadIdx.x & 63) == 0 && rows > 0.0f)
+        atomicMax(outMaxBits, __float_as_uint(rows));
+}
+
+void LaunchMotionRows(hipStream_t stream, const Plane& viewZ, const Plane& mv, const MotionParams& p, int rowBegin, int rowEnd, uint32_t* outMaxBits) {
+    if (rowEnd <= rowBegin)
+        return;
+    hipLaunchKernelGGL(MotionRowsKernel, dim3((unsigned)(p.rectW + 63) / 64, (unsigned)(rowEnd - rowBegin + 3) / 4), dim3(256), 0, stream, viewZ, mv, p, rowBegin, rowEnd, outMaxBits);
+}
+
 } // namespace nrdhip

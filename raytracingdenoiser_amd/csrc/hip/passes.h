@@ -49,6 +49,19 @@ namespace nrdhip {
 // One kernel launch of a pass as data: what the launchers hand to the executor instead of launching when a recorder is attached.
 // The executor uses it for the pre-flight of a dispatch range (nothing is launched unless every pass of the range can be) and for
 // HIP-graph execution (kernel nodes built from / updated with these records: executor.hip "graph mode").
+// nrdHipMeasureMotionRows (multi-GPU: the history halo must cover the frame's reprojection): what the reduction kernel needs of the shared constants of either family
+struct MotionParams {
+    float worldToClipPrev[16];
+    float viewToWorld[16];      // REBLUR form: X = viewToWorld * ( frustum-reconstructed view position )
+    float frustum[4];
+    float frustumRight[4], frustumUp[4], frustumForward[4]; // RELAX form: X = viewZ * ( forward + right * ndc.x - up * ndc.y )
+    float mvScale[4];
+    float rectSizeInv[2];
+    float rectHeightPrev, viewZScale, denoisingRange;
+    int rectW, rectH, relaxForm;
+};
+void LaunchMotionRows(hipStream_t stream, const Plane& viewZ, const Plane& mv, const MotionParams& p, int rowBegin, int rowEnd, uint32_t* outMaxBits);
+
 struct LaunchRecord {
     const void* func;
     dim3 grid, block;

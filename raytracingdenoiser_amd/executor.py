@@ -119,6 +119,12 @@ class HipExecutor:
         self._check(self.lib.nrdHipGetTileFallbackStats(self.handle, C.byref(a), C.byref(b)), "nrdHipGetTileFallbackStats")
         return a.value, b.value
 
+    def measure_motion_rows(self, ptr, n, row_begin=0, row_end=0xFFFFFFFF):
+        """largest vertical surface-motion reprojection distance (rows) over rows [row_begin, row_end) of this frame's rect -- include/NRDHip.h nrdHipMeasureMotionRows"""
+        out = C.c_float()
+        self._check(self.lib.nrdHipMeasureMotionRows(self.handle, C.cast(ptr, C.c_void_p), n, row_begin, min(row_end, 0xFFFFFFFF), C.byref(out)), "nrdHipMeasureMotionRows")
+        return out.value
+
     def set_profiling(self, enable):
         self._check(self.lib.nrdHipSetProfiling(self.handle, 1 if enable else 0), "nrdHipSetProfiling")
 

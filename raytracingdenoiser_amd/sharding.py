@@ -339,6 +339,9 @@ class HaloSharder:
     last CommonSettings (camera_motion_rows), doubled for the virtual motion of specular reflections, plus whatever bound the application passes for
     moving objects (denoise(motion_rows=...)); a frame that exceeds the halo runs UNSHARDED on every rank (after completing the planes) instead of
     silently reading stale rows. All ranks take the same decision from the same settings.
+    measure_motion=True replaces the estimate AND the application's promise by a measurement: every rank reduces IN_VIEWZ / IN_MV of its own strip on the
+    device (nrdHipMeasureMotionRows: the temporal passes' own surface-motion reprojection, moving objects included), the ranks take the MAX (one 4-byte
+    all-reduce per frame), and the virtual-motion factor is applied to that.
 
     balance: after a frame that ran unsharded (the restart frame, a dynamic-resolution step, ...) every rank holds every plane completely, so
     the strips can be re-cut for free: they are then chosen from the tile map so that every rank gets the same number of non-sky tiles
@@ -352,8 +355,10 @@ class HaloSharder:
         with a fixed 32 the 4K bench sequence exceeded the halo on every frame and ran unsharded, profiles/r03_i_scaling_model_relax_ds_sh.json)"""
         return max(32, -(-height * 32 // 1440))
 
-    def __init__(self, executor, instance, width, height, rank, world, group=None, max_motion_rows=None, exchange_threshold=24, balance=True, recut_every=0, near_depth=1.0):
+    def __init__(self, executor, instance, width, height, rank, world, group=None, max_motion_rows=None, exchange_threshold=24, balance=True, recut_every=0, near_depth=1.0,
+                 measure_motion=False):
         max_motion_rows = self.default_motion_rows(height) if max_motion_rows is None else max_motion_rows
+        self.measure_motion, self.measured_motion_rows = measure_motion, None  # the last measurement (rows), for reporting
         self.near_depth = near_depth  # view depth of the nearest geometry the camera-motion estimate has to cover (scene units)
         self.ex, self.inst = executor, instance
         self.width, self.height, self.rank, self.world, self.group = width, height, rank, world, group
@@ -411,8 +416,22 @@ class HaloSharder:
 
     SPECULAR_MOTION_FACTOR = 2.0  # virtual (reflection) motion relative to the surface motion that the camera estimate bounds
 
-    def motion_exceeds_halo(self, motion_rows=None):
-        """True when this frame's reprojection may leave the history halo (see the class docstring)"""
+    def _max_over_ranks(self, value):
+        import torch
+        import torch.distributed as dist
+
+        if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(self.group) != self.world:
+            return value  # virtual ranks of the single-process tests
+        t = torch.tensor([value], dtype=torch.float32, device="cuda" if dist.get_backend(self.group) == "nccl" else "cpu")
+        dist.all_reduce(t, dist.ReduceOp.MAX, self.group)
+        return float(t.item())
+
+    def motion_exceeds_halo(self, motion_rows=None, dispatches=None):
+        """True when this frame's reprojection may leave the history halo (see the class docstring); dispatches = (ptr, n) of this frame's list (measure_motion)"""
+        if getattr(self, "measure_motion", False) and dispatches is not None:
+            rows = self.rows or (0, self.height)
+            self.measured_motion_rows = self._max_over_ranks(self.ex.measure_motion_rows(dispatches[0], dispatches[1], rows[0], rows[1]))
+            return self.SPECULAR_MOTION_FACTOR * self.measured_motion_rows + 2.0 >= self.max_motion_rows
         cs = getattr(self.inst, "last_common_settings", None)
         camera = camera_motion_rows(cs, (getattr(self, "near_depth", 1.0), 1.0e4)) if cs is not None else 0.0
         if camera is None:
@@ -437,7 +456,7 @@ class HaloSharder:
                            for i in range(n)))
         cached = self._plans.get(signature)
         recut = self.balance and self.recut_every > 0 and self._sharded_since_cut >= self.recut_every and self.world > 1
-        if self.world > 1 and self.motion_exceeds_halo(motion_rows):
+        if self.world > 1 and self.motion_exceeds_halo(motion_rows, (ptr, n)):
             recut = True  # same mechanics as a deliberate re-cut frame: complete the planes, run the whole frame everywhere
             self.motion_fallbacks += 1
         if cached is not None and not cached.fallback and not self.complete and not recut:

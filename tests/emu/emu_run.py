@@ -94,6 +94,11 @@ class EmuExecutor:
         self._check(self.lib.nrdHipGetTileFallbackStats(self.handle, C.byref(a), C.byref(b)), "nrdHipGetTileFallbackStats")
         return a.value, b.value
 
+    def measure_motion_rows(self, ptr, n, row_begin=0, row_end=0xFFFFFFFF):
+        out = C.c_float()
+        self._check(self.lib.nrdHipMeasureMotionRows(self.handle, C.cast(ptr, C.c_void_p), n, row_begin, min(row_end, 0xFFFFFFFF), C.byref(out)), "nrdHipMeasureMotionRows")
+        return out.value
+
     def set_graph_mode(self, enable):
         pass  # graphs are a launch mechanism of the real runtime (graph == eager is a GPU test, tests/test_executor.py); the emulation always launches eagerly
 

@@ -112,6 +112,12 @@ inline uint32_t max(uint32_t a, uint32_t b) { return a > b ? a : b; }
 inline float min(float a, float b) { return fminf(a, b); }
 inline float max(float a, float b) { return fmaxf(a, b); }
 inline uint32_t __umul24(uint32_t a, uint32_t b) { return (a & 0xFFFFFFu) * (b & 0xFFFFFFu); }
+inline uint32_t atomicMax(uint32_t* p, uint32_t v) { // blocks of a grid run on several OS threads
+    uint32_t old = __atomic_load_n(p, __ATOMIC_RELAXED);
+    while (old < v && !__atomic_compare_exchange_n(p, &old, v, true, __ATOMIC_RELAXED, __ATOMIC_RELAXED)) {
+    }
+    return old;
+}
 inline uint32_t __float_as_uint(float f) {
     uint32_t u;
     memcpy(&u, &f, 4);

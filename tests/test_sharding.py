@@ -461,7 +461,7 @@ def test_halo_sharding_two_processes_one_gpu():
     assert results == [(0, True, True), (1, True, True)]
 
 
-def _halo_two_process_emulated_worker(rank, world, port, name, W, H, frames, overrides, q):
+def _halo_two_process_emulated_worker(rank, world, port, name, W, H, frames, overrides, measure, q):
     import numpy as np
     import torch.distributed as dist
 
@@ -472,7 +472,18 @@ def _halo_two_process_emulated_worker(rank, world, port, name, W, H, frames, ove
     dist.init_process_group("gloo", rank=rank, world_size=world)
     lib = emu_run.load()
     seq = parity.generate_sequence(name, W, H, frames, device="cpu")
-    np_dtype = {torch.float16: np.float16, torch.int16: np.int16, torch.uint8: np.uint8}
+    steps = [(frame, {}) for frame in seq]
+    if measure:
+        # one more frame whose motion vectors (2D convention) leave the 16-row history halo at ONE pixel of the LAST rank's strip: only that rank can see it on
+        # its own rows, every rank has to run the frame unsharded (HaloSharder(measure_motion=True): device reduction per strip + MAX over ranks)
+        fast = dict(seq[-1])
+        mv = torch.zeros_like(fast["mv"])
+        z = fast["viewz"].clone()
+        z.view(H, W)[H - 7, 11] = 5.0
+        mv[H - 7, 11, 1] = -40.0
+        fast["mv"], fast["viewz"] = mv, z
+        steps.append((fast, dict(isMotionVectorInWorldSpace=False, motionVectorScale=(1.0 / W, 1.0 / H, 0.0))))
+        steps.append((seq[-1], {}))  # and back to a sharded frame
 
     def run(sharded):
         inst = api.Instance([(0, parity.DENOISERS[name][0])], lib=lib)
@@ -481,38 +492,43 @@ def _halo_two_process_emulated_worker(rank, world, port, name, W, H, frames, ove
         for rt, dtype, ch, fmt in parity.output_planes(name, W, H):
             outs.append(torch.zeros((H, W, ch), dtype=dtype))
             ex.bind(rt, outs[-1], fmt)
-        sh = sharding.HaloSharder(ex, inst, W, H, rank, world, max_motion_rows=16) if sharded else None
-        per_frame, sharded_frames = [], 0
-        for f, frame in enumerate(seq):
+        sh = sharding.HaloSharder(ex, inst, W, H, rank, world, max_motion_rows=16, measure_motion=measure) if sharded else None
+        per_frame, sharded_frames, measured = [], 0, []
+        for f, (frame, cs_kw) in enumerate(steps):
             for rt, t, fmt in parity.user_planes(name, frame):
                 ex.bind(rt, t.cpu().contiguous(), fmt)
             inst.set_denoiser_settings(0, parity.denoiser_settings(name, frame, overrides))
-            inst.set_common_settings(parity.common_settings(frame["camera"], seq[max(f - 1, 0)]["camera"], W, H, f))
+            inst.set_common_settings(parity.common_settings(frame["camera"], steps[max(f - 1, 0)][0]["camera"], W, H, f, **cs_kw))
             if sharded:
                 sharded_frames += 0 if sh.denoise().fallback else 1
+                measured.append(sh.measured_motion_rows)
             else:
                 ex.denoise()
             per_frame.append(([o.clone() for o in outs], sh.rows if sharded else (0, H)))
-        return per_frame, sharded_frames, (sh.exchanged_bytes if sharded else 0)
+        return per_frame, sharded_frames, (sh.exchanged_bytes if sharded else 0), (sh.motion_fallbacks if sharded else 0), measured
 
-    ref, _, _ = run(False)
-    got, sharded_frames, exchanged = run(True)
+    ref = run(False)[0]
+    got, sharded_frames, exchanged, motion_fallbacks, measured = run(True)
     ok = all(torch.equal(a[rows[0]:rows[1]], b[rows[0]:rows[1]]) for (fa, _), (fb, rows) in zip(ref, got) for a, b in zip(fa, fb))
+    if measure:
+        # every rank saw the same (reduced) value on every frame; the fast frame measured its 40 rows and was the only motion fallback
+        ok = ok and motion_fallbacks == 1 and abs(measured[frames] - 40.0) < 0.05 and all(m is not None and m < 7.0 for i, m in enumerate(measured) if i != frames)
     q.put((rank, ok, sharded_frames, exchanged > 0))
     dist.barrier()
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("name,world,W,H,overrides", [
-    ("REBLUR_DIFFUSE_SPECULAR", 2, 96, 240, dict(maxBlurRadius=4.0, diffusePrepassBlurRadius=6.0, specularPrepassBlurRadius=6.0)),  # small radii: the halos fit 120-row strips
-    ("REBLUR_DIFFUSE_SPECULAR", 3, 64, 300, dict(maxBlurRadius=4.0, diffusePrepassBlurRadius=6.0, specularPrepassBlurRadius=6.0)),  # a middle strip with two neighbours
-    ("RELAX_DIFFUSE_SPECULAR", 2, 96, 240, dict(atrousIterationNum=3, diffusePrepassBlurRadius=6.0, specularPrepassBlurRadius=6.0)),
+@pytest.mark.parametrize("name,world,W,H,overrides,measure", [
+    ("REBLUR_DIFFUSE_SPECULAR", 2, 96, 240, dict(maxBlurRadius=4.0, diffusePrepassBlurRadius=6.0, specularPrepassBlurRadius=6.0), False),  # small radii: the halos fit 120-row strips
+    ("REBLUR_DIFFUSE_SPECULAR", 3, 64, 300, dict(maxBlurRadius=4.0, diffusePrepassBlurRadius=6.0, specularPrepassBlurRadius=6.0), True),  # a middle strip with two neighbours
+    ("RELAX_DIFFUSE_SPECULAR", 2, 96, 240, dict(atrousIterationNum=3, diffusePrepassBlurRadius=6.0, specularPrepassBlurRadius=6.0), True),
 ])
-def test_halo_sharding_processes_over_gloo_on_emulated_kernels(name, world, W, H, overrides):
+def test_halo_sharding_processes_over_gloo_on_emulated_kernels(name, world, W, H, overrides, measure):
     """The N > 1 path end to end WITHOUT a GPU: `world` processes over gloo, each planning its strip from the dispatch list, exchanging halo bands by message passing
     and running its pass segments -- on the CPU emulation of the device sources (tests/emu: the .hip files compiled for x86, test infrastructure). Every rank's
     owned rows of every output, every frame, must equal a full-frame run of the same emulated kernels bit for bit; the frames after the restart frame must really
-    be sharded (an unsharded fallback would pass trivially)."""
+    be sharded (an unsharded fallback would pass trivially). measure: the motion side of the contract comes from the device (nrdHipMeasureMotionRows on the
+    rank's own rows + an all-reduce), and a frame whose motion leaves the halo on one rank's rows only is run unsharded by all of them."""
     import torch.multiprocessing as mp
 
     from emu import emu_run
@@ -522,13 +538,14 @@ def test_halo_sharding_processes_over_gloo_on_emulated_kernels(name, world, W, H
     q = ctx.Queue()
     port = 29500 + (os.getpid() % 100) + world
     frames = 4
-    procs = [ctx.Process(target=_halo_two_process_emulated_worker, args=(r, world, port, name, W, H, frames, overrides, q)) for r in range(world)]
+    procs = [ctx.Process(target=_halo_two_process_emulated_worker, args=(r, world, port, name, W, H, frames, overrides, measure, q)) for r in range(world)]
     for p in procs:
         p.start()
     results = sorted(q.get(timeout=900) for _ in procs)
     for p in procs:
         p.join(timeout=60)
-    assert results == [(r, True, frames - 1, True) for r in range(world)], results
+    # sharded frames: all but the restart frame (+ with measure: the frame after the fast one; the fast one itself falls back)
+    assert results == [(r, True, frames - 1 + (1 if measure else 0), True) for r in range(world)], results
 
 
 @pytest.mark.gpu
