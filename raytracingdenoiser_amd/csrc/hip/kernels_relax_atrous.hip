@@ -406,6 +406,17 @@ const char* LaunchAtrousSmem(const PassArgs& a) {
 //   STEP = 0      global gathers (steps 32 and beyond of 6..8 iterations; the cross-check of the two LDS variants).
 // RES: RelaxSettings::enableRoughnessEdgeStopping, a compile-time variant picked by the launcher -- the taps then compute either the lobe-aware normal weight
 // and the roughness weight, or the simplified normal weight, never both (the reference selects per tap between two fully evaluated expressions).
+// The gathering taps (STEP = 0; steps 16 and beyond by default) fetch the 4-byte inputs the guide planes were made from instead of the 16-byte guide texels, and redo
+// the decode: the taps are bound by what crosses the L1 (profiles/r02_c_gather_bench.txt: a scattered wave-load of 16 B per lane costs 149.7 CU cycles, of 4 B 41.7)
+//   NRD_ATROUS_GUIDES_VIEWZ   viewZ + relax_device.h GetCurrentWorldPosFromPixelPos instead of the (world position, viewZ) texel (-6 %, r02_g_atrz_relax.json; the
+//                             default since round 2 -- the define was lost in round 3's LDS-tile commit and restored in round 4)
+//   NRD_ATROUS_GUIDES_RAW_NR  IN_NORMAL_ROUGHNESS + EncodeDecodedNormalRoughness instead of the decoded float4
+#ifndef NRD_ATROUS_GUIDES_VIEWZ
+#define NRD_ATROUS_GUIDES_VIEWZ 1
+#endif
+#ifndef NRD_ATROUS_GUIDES_RAW_NR
+#define NRD_ATROUS_GUIDES_RAW_NR 1
+#endif
 #ifndef NRD_ATROUS_LDS_TILES
 #define NRD_ATROUS_LDS_TILES 1 // 0: every iteration gathers from global memory (A/B and the emulation's cross-check)
 #endif
@@ -658,7 +669,13 @@ __global__ __launch_bounds__(256, NRD_WAVES_RELAX_ATROUS) void RelaxAtrousKernel
             } else {
                 const int cx = ClampI(qx, 0, P.worldPosViewZ.w - 1), cy = ClampI(qy, 0, P.worldPosViewZ.h - 1);
                 const uint32_t guideOffset = TexelOffset(P.decodedNR, cx, cy, 16u, true);
+#if NRD_ATROUS_GUIDES_RAW_NR
+                // same reasoning for the normal: 4 bytes of IN_NORMAL_ROUGHNESS through the L1 (41.7 cycles per scattered wave-load against 149.7 for the 16-byte decoded texel,
+                // profiles/r02_c_gather_bench.txt) and the decode that wrote the guide plane (kernels_common.hip DecodeGuidesRelaxKernel) redone per tap: it IS the stored value
+                g0 = EncodeDecodedNormalRoughness(*(const uint32_t*)(P.normalRoughness.ptr + TexelOffset(P.normalRoughness, cx, cy, 4u, true)));
+#else
                 g0 = *(const float4*)(P.decodedNR.ptr + guideOffset);
+#endif
 #if NRD_ATROUS_GUIDES_VIEWZ
                 // 4 bytes of viewZ instead of the 16-byte (world position, viewZ) texel: the taps are bound by the bytes that cross the L1 (gather probe:
                 // 39.6 cycles per 16-byte wave-load against 6.4 per 4-byte one); the position is re-derived with the very expression that wrote the guide
