@@ -411,7 +411,7 @@ def main():
                     "AtrousSmem": "AtrousSmemKernel", "PrePass": "PrePassKernel" if name.startswith("RELAX") else "ReblurSpatialKernel", "Blur": "ReblurSpatialKernel", "PostBlur": "ReblurSpatialKernel",
                     "Atrous": "RelaxAtrousKernel"}.get(dominant.rsplit("_", 1)[-1].replace(".cs", ""))
             rows_fl = next((v for k2, v in fl.get("workloads", {}).items() if k2.startswith(name + " ")), {})
-            hit = next((v for k2, v in rows_fl.items() if frag and k2.startswith(frag)), None)
+            hit = next((v for k2, v in rows_fl.items() if frag and frag in k2), None)  # (the first match: the window kernel precedes its fallback)
             if hit:
                 issue_floor = dict(hit, source=fl.get("source"), what="uniform scene, every pixel denoised: this kernel's time / its time with every load an L1 hit (not measured in this run)")
         roofline = {"bound": "hbm", "kernel": dominant, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
