@@ -215,6 +215,34 @@ class RefExecutor(OracleExecutor):
             raise RuntimeError("oracle/_ref cannot run '%s' (code %d)" % (d.shader, rc))
 
 
+def _digest(constants, arrays):
+    """sha1 over the constant block and every bound plane as a pass finds them: identifies "the same pass on the same inputs" across runs"""
+    import hashlib
+
+    h = hashlib.sha1(constants or b"")
+    for a in arrays:
+        h.update(np.ascontiguousarray(a).view(np.uint8).tobytes())
+    return h.hexdigest()
+
+
+class StrictRecordingExecutor(OracleExecutor):
+    """The strict oracle alone; `on_pass(dispatch, inputs_digest, [(resource, fmt, width, array), ...] for every bound slot)` after every pass (the arrays are
+    live views: use them inside the callback): the replay side of the golden fixtures of tests/golden/ref_text_*.npz (recorded with ComparingExecutor from
+    the reference's compiled shader text)."""
+
+    def __init__(self, *a, on_pass=None, **kw):
+        super().__init__(*a, **kw)
+        self.lib = load_strict()
+        self.on_pass = on_pass
+
+    def _run(self, d, constants, planes):
+        arrays = [self._array(r) for r in d.resources]
+        digest = _digest(constants, [a[0] for a in arrays])
+        super()._run(d, constants, planes)
+        if self.on_pass:
+            self.on_pass(d, digest, [(res, a[1], a[2], a[0]) for res, a in zip(d.resources, arrays)])
+
+
 _strict_lib = None
 
 
@@ -252,6 +280,7 @@ class ComparingExecutor(OracleExecutor):
     def _run(self, d, constants, planes):
         arrays = [self._array(r) for r in d.resources]
         before = [a[0].copy() for a in arrays]
+        self.last_inputs_digest = _digest(constants, before)
         buf = C.create_string_buffer(constants, len(constants)) if constants else None
 
         def restore():

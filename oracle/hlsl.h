@@ -13,9 +13,11 @@
 //   * UNORM texel decoding (tex.h) is the exact quotient k / (2^n - 1) on both sides.
 // Written independently of the HIP device header; the two must agree bit for bit, which is what the parity tests check.
 //
-// PARITY UNPINNED: the reference ships no CPU implementation, no tests and no golden vectors, and its math library
-// (NVIDIA-RTX/MathLib, fetched unpinned at configure time -- reference CMakeLists.txt:118-127) is absent. Definitions
-// marked [ml] restate MathLib from its public behaviour and from anchors inside the reference.
+// PARITY: pinned to the reference's own shader text since round 4. The reference ships no CPU implementation, no tests and no golden vectors, but its
+// shaders compile as C++ over a small HLSL shim (oracle/ref/ -> oracle/_ref/libnrdref.so, built from the sources where they lie under /root/reference), and
+// every pass of this restatement is compared with them on identical inputs (tests/test_ref_parity.py; fixtures recorded from them: tests/golden/ref_text_*.npz,
+// tests/test_ref_golden.py). What stays "parity unpinned" is MathLib alone (NVIDIA-RTX/MathLib, fetched unpinned at configure time -- reference
+// CMakeLists.txt:118-127 -- and absent): definitions marked [ml] restate it from its public behaviour and from anchors inside the reference.
 #pragma once
 
 #include "hw_math.h"
