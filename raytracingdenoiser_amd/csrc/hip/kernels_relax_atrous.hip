@@ -417,14 +417,11 @@ const char* LaunchAtrousSmem(const PassArgs& a) {
 #ifndef NRD_ATROUS_GUIDES_RAW_NR
 #define NRD_ATROUS_GUIDES_RAW_NR 1
 #endif
-#ifndef NRD_WAVES_RELAX_ATROUS_BANDS
-#define NRD_WAVES_RELAX_ATROUS_BANDS 3 // the banded variants keep a band of texels in registers: 168 VGPRs (step 8: no scratch)
-#endif
 #ifndef NRD_ATROUS_LDS_TILES
 #define NRD_ATROUS_LDS_TILES 1 // 0: every iteration gathers from global memory (A/B and the emulation's cross-check)
 #endif
 template <bool DIFF, bool SPEC, bool SH, int STEP, bool RES>
-__global__ __launch_bounds__(256, STEP >= 8 ? NRD_WAVES_RELAX_ATROUS_BANDS : NRD_WAVES_RELAX_ATROUS) void RelaxAtrousKernel(AtrousPlanes P, RelaxCB c, RowRange rows) {
+__global__ __launch_bounds__(256, NRD_WAVES_RELAX_ATROUS) void RelaxAtrousKernel(AtrousPlanes P, RelaxCB c, RowRange rows) {
     // one layout for the two guide planes and one for the (up to four) RGBA16F signal planes: verified by the launcher
     ShareLayout(P.worldPosViewZ, P.decodedNR);
     {
@@ -437,12 +434,9 @@ __global__ __launch_bounds__(256, STEP >= 8 ? NRD_WAVES_RELAX_ATROUS_BANDS : NRD
     __shared__ float4 s_NR[TN], s_Pos[TN];
     __shared__ float4 s_Spec[SPEC ? TN : 1], s_Diff[DIFF ? TN : 1];
     __shared__ uint2 s_SpecSh[SPEC && SH ? TN : 1], s_DiffSh[DIFF && SH ? TN : 1];
-    // one band of tap positions: hashed offsets reach R texels beyond the regular stencil; undecoded texels -- packed normal 4 B, viewZ 4 B, signals 8 B each -- the
-    // guides are decoded per tap with the functions that write the guide planes, as in the gathering taps. NT texels per thread and band travel through registers:
-    // the band of the NEXT tap row is requested before the taps of the current one are filtered (one fill latency per workgroup instead of three)
-    constexpr int R = STEP / 4, BW = TILE_X + 2 * STEP + 2 * R, BH = TILE_Y + 2 * R, BS = BW + 1, BN = BANDED ? BH * BS : 1, NT = BANDED ? (BW * BH + 255) / 256 : 1;
-    __shared__ uint32_t b_NR[BN];
-    __shared__ float b_Z[BN];
+    // one band of tap positions: hashed offsets reach R texels beyond the regular stencil; undecoded signal texels (8 B each)
+    constexpr int R = STEP / 4, BW = TILE_X + 2 * STEP + 2 * R, BH = TILE_Y + 2 * R, BS = BW + 1, BN = BANDED ? BH * BS : 1;
+    __shared__ float4 b_NR[BN], b_Pos[BN];
     __shared__ uint2 b_Spec[SPEC && BANDED ? BN : 1], b_Diff[DIFF && BANDED ? BN : 1], b_SpecSh[SPEC && SH && BANDED ? BN : 1], b_DiffSh[DIFF && SH && BANDED ? BN : 1];
 
     const int blockY = blockIdx.y + rows.firstBlockY;
@@ -605,62 +599,35 @@ __global__ __launch_bounds__(256, STEP >= 8 ? NRD_WAVES_RELAX_ATROUS_BANDS : NRD
     // (0 * sample adds nothing: the history planes hold finite fp16 values by construction.) Planes of one format share their layout (launcher check),
     // so one texel offset serves the two guide planes and one the four signal planes.
     const bool compareSpecMaterials = c.shared.gSpecMinMaterial < 3.0f, compareDiffMaterials = c.shared.gDiffMinMaterial < 3.0f; // IDs are 0..3: a minimum >= 3 disables the test
-    uint32_t r_NR[NT];
-    float r_Z[NT];
-    uint2 r_Sig[4][NT];
-    auto requestBand = [&](int yy) {
-        const int x0 = blockX0 - STEP - R, y0 = blockY0 + yy * STEP - R;
-#pragma unroll
-        for (int k = 0; k < NT; k++) {
-            const int i = (int)threadIdx.x + k * 256;
-            if (i < BW * BH) {
-                const int cx = ClampI(x0 + i % BW, 0, P.worldPosViewZ.w - 1), cy = ClampI(y0 + i / BW, 0, P.worldPosViewZ.h - 1); // the taps' clamped texel
-                r_NR[k] = *(const uint32_t*)(P.normalRoughness.ptr + TexelOffset(P.normalRoughness, cx, cy, 4u, true));
-                r_Z[k] = *(const float*)(P.viewZ.ptr + TexelOffset(P.viewZ, cx, cy, 4u, true));
-                const uint32_t signalOffset = TexelOffset(SPEC ? P.spec.in : P.diff.in, cx, cy, 8u, true);
-                if (SPEC) {
-                    r_Sig[0][k] = *(const uint2*)(P.spec.in.ptr + signalOffset);
-                    if (SH)
-                        r_Sig[1][k] = *(const uint2*)(P.spec.inSh.ptr + signalOffset);
-                }
-                if (DIFF) {
-                    r_Sig[2][k] = *(const uint2*)(P.diff.in.ptr + signalOffset);
-                    if (SH)
-                        r_Sig[3][k] = *(const uint2*)(P.diff.inSh.ptr + signalOffset);
-                }
-            }
-        }
-    };
-    if (BANDED)
-        requestBand(-1);
 #pragma unroll
     for (int yy = -1; yy <= 1; yy++) {
         const int bandX0 = blockX0 - STEP - R, bandY0 = blockY0 + yy * STEP - R; // texel (unclamped) of the band's LDS element (0, 0)
         if (BANDED) {
             if (yy != -1)
                 __syncthreads(); // the taps of the previous band have been read
-#pragma unroll
-            for (int k = 0; k < NT; k++) {
-                const int i = (int)threadIdx.x + k * 256;
-                if (i < BW * BH) {
-                    const int li = (i / BW) * BS + i % BW;
-                    b_NR[li] = r_NR[k];
-                    b_Z[li] = r_Z[k];
-                    if (SPEC) {
-                        b_Spec[li] = r_Sig[0][k];
-                        if (SH)
-                            b_SpecSh[li] = r_Sig[1][k];
-                    }
-                    if (DIFF) {
-                        b_Diff[li] = r_Sig[2][k];
-                        if (SH)
-                            b_DiffSh[li] = r_Sig[3][k];
-                    }
+            // (measured and dropped, r04_e: requesting all of a thread's texels before the first LDS store -- 160 instead of 106 VGPRs, one wave per SIMD less, 376 instead of 321 us)
+            // (measured and dropped, r04_j: undecoded 40-byte band texels decoded per tap + the NEXT band requested into registers before this band's taps -- 168 VGPRs,
+            //  three waves: step 8 368 instead of 322 us, step 16 660 us against 414 for its gathers)
+            for (int i = threadIdx.x; i < BW * BH; i += 256) {
+                const int lx = i % BW, ly = i / BW;
+                const int cx = ClampI(bandX0 + lx, 0, P.worldPosViewZ.w - 1), cy = ClampI(bandY0 + ly, 0, P.worldPosViewZ.h - 1); // the taps' clamped texel
+                const int li = ly * BS + lx;
+                const uint32_t guideOffset = TexelOffset(P.decodedNR, cx, cy, 16u, true);
+                b_NR[li] = *(const float4*)(P.decodedNR.ptr + guideOffset);
+                b_Pos[li] = *(const float4*)(P.worldPosViewZ.ptr + guideOffset);
+                const uint32_t signalOffset = TexelOffset(SPEC ? P.spec.in : P.diff.in, cx, cy, 8u, true);
+                if (SPEC) {
+                    b_Spec[li] = *(const uint2*)(P.spec.in.ptr + signalOffset);
+                    if (SH)
+                        b_SpecSh[li] = *(const uint2*)(P.spec.inSh.ptr + signalOffset);
+                }
+                if (DIFF) {
+                    b_Diff[li] = *(const uint2*)(P.diff.in.ptr + signalOffset);
+                    if (SH)
+                        b_DiffSh[li] = *(const uint2*)(P.diff.inSh.ptr + signalOffset);
                 }
             }
             __syncthreads();
-            if (yy != 1)
-                requestBand(yy + 1); // in flight while this band's taps are filtered
         }
 #pragma unroll
         for (int xx = -1; xx <= 1; xx++) {
@@ -687,9 +654,8 @@ __global__ __launch_bounds__(256, STEP >= 8 ? NRD_WAVES_RELAX_ATROUS_BANDS : NRD
                 }
             } else if (BANDED) {
                 const int li = (qy - bandY0) * BS + (qx - bandX0); // |offset| <= R: inside the band (which holds the clamped texel of every position)
-                g0 = EncodeDecodedNormalRoughness(b_NR[li]);
-                const float tapZ = RelaxUnpackViewZ(c, b_Z[li]);
-                sampleWorldPosViewZ = F4(GetCurrentWorldPosFromPixelPos(c, ClampI(qx, 0, P.worldPosViewZ.w - 1), ClampI(qy, 0, P.worldPosViewZ.h - 1), tapZ), tapZ);
+                g0 = LdsFloat4(&b_NR[li]);
+                sampleWorldPosViewZ = LdsFloat4(&b_Pos[li]);
                 if (SPEC) {
                     const uint2 raw = b_Spec[li];
                     sampleSpecular = DecodeRGBA16F(raw.x, raw.y);
