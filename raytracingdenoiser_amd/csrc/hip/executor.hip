@@ -443,6 +443,24 @@ static int PassReachRows(const char* shader, const void* constants, uint32_t con
     return -1; // incl. _HitDistReconstruction (the pre-pass then gathers from its output at blur-radius distance)
 }
 
+// Rows above / below a produced pixel at which dispatch i reads the per-frame GUIDE planes (decoded normals, view / world positions): PassReachRows, except for the
+// pre-passes, whose taps read nothing written earlier in the frame (reach 0 for the halo plan) but do read the guides at blur-radius distance. -1 = unknown.
+static int GuideReachRows(const char* shader, const void* constants, uint32_t constantsSize) {
+    const int reach = PassReachRows(shader, constants, constantsSize);
+    if (reach < 0 || !strstr(shader, "_PrePass"))
+        return reach;
+    static const float kSlack = getenv("NRD_HIP_SPECULAR_REACH_SLACK") ? std::fmax(1.0f, (float)atof(getenv("NRD_HIP_SPECULAR_REACH_SLACK"))) : 2.0f;
+    float radius;
+    if (!strncmp(shader, "RELAX_", 6)) {
+        const nrdc::RelaxConstants& c = *(const nrdc::RelaxConstants*)constants;
+        radius = std::fmax(c.gDiffBlurRadius, c.gSpecBlurRadius);
+    } else {
+        const nrdc::ReblurConstants& c = *(const nrdc::ReblurConstants*)constants;
+        radius = std::fmax(std::fmax(c.gDiffPrepassBlurRadius, c.gSpecPrepassBlurRadius), c.gMinBlurRadius);
+    }
+    return (int)std::ceil(kSlack * radius) + 2;
+}
+
 extern "C" __attribute__((visibility("default"))) uint32_t nrdHipSetOwnedRows(NrdHipExecutor* e, uint32_t rowBegin, uint32_t rowEnd) {
     if (!e || rowBegin > rowEnd)
         return (uint32_t)nrd::Result::INVALID_ARGUMENT;
@@ -947,6 +965,33 @@ static uint32_t ExecuteRange(NrdHipExecutor* e, const nrd::DispatchDesc* descs, 
             if (!back || t == (uint32_t)nrd::ResourceType::IN_MV)
                 LaunchShiftPlane(args, e->user[t], e->shifted[t], e->originX, e->originY, BytesPerTexel(ExpectedUserFormat((nrd::ResourceType)t, e->translucentShadow)), back);
     };
+    // multi-GPU: the guide planes are needed on the rows the passes of this rank read them at -- every dispatch's rows widened by its guide reach, rounded out to the
+    // 16-row tile grid; the rest of the planes keeps whatever it held (nothing of this list reads it). Whole frame when any dispatch runs on the whole frame.
+    int guideRow0 = 0, guideRow1 = INT_MAX;
+    if (rowBegin && rowEnd && decodeNow) {
+        int lo = INT_MAX, hi = 0;
+        bool whole = dispatchDescsNum == 0;
+        for (uint32_t i = 0; i < dispatchDescsNum && !whole; i++) {
+            bool readsGuides = false; // the guide planes stand in for IN_NORMAL_ROUGHNESS (and IN_VIEWZ next to it): a pass that does not bind it (tile classification) reads none of them
+            for (uint32_t r = 0; r < descs[i].resourcesNum && !readsGuides; r++)
+                readsGuides = descs[i].resources[r].type == nrd::ResourceType::IN_NORMAL_ROUGHNESS;
+            if (!readsGuides)
+                continue;
+            const int reach = descs[i].pipelineIndex < idesc.pipelinesNum ? GuideReachRows(idesc.pipelines[descs[i].pipelineIndex].shaderFileName, descs[i].constantBufferData, descs[i].constantBufferDataSize) : -1;
+            whole = rowBegin[i] < 0 || reach < 0;
+            if (!whole) {
+                lo = std::min(lo, (int)rowBegin[i] - reach);
+                hi = std::max(hi, (int)rowEnd[i] + reach);
+            }
+        }
+        if (!whole && hi > lo) {
+            guideRow0 = std::max(lo, 0) & ~15;
+            guideRow1 = (hi + 15) & ~15;
+        }
+        static const bool trace = getenv("NRD_HIP_TRACE_GUIDE_ROWS") != nullptr; // debugging aid of the sharding tests
+        if (trace)
+            fprintf(stderr, "[nrdhip] guide planes decoded on rows [%d, %d) of %d\n", guideRow0, guideRow1 == INT_MAX ? (int)e->height : std::min(guideRow1, (int)e->height), (int)e->height);
+    }
     auto decode = [&](LaunchRecorder* rec) {
         if (shiftedRect)
             shiftGuides(rec, false);
@@ -955,6 +1000,8 @@ static uint32_t ExecuteRange(NrdHipExecutor* e, const nrd::DispatchDesc* descs, 
         PassArgs args = {};
         args.stream = e->stream;
         args.recorder = rec;
+        args.rowBegin = guideRow0;
+        args.rowEnd = guideRow1;
         // each decode kernel writes the decoded normals too (identical values): with both families in the list both run
         if (worldPos.ptr)
             LaunchDecodeGuidesRelax(args, guidePlane(nrd::ResourceType::IN_NORMAL_ROUGHNESS), guidePlane(nrd::ResourceType::IN_VIEWZ), decoded, worldPos, relaxConstants);

@@ -13,39 +13,74 @@
 
 namespace nrdhip {
 
+struct GuideRows {
+    int launchBegin, launchEnd; // rows the grid covers
+    int validBegin, validEnd;   // rows that receive decoded values (the others, test hook only: NaNs)
+};
+
 // ---- decoded guides: IN_NORMAL_ROUGHNESS (R10G10B10A2) -> float4 cache, once per frame (reblur_device.h "decoded guides") -----
 // 4 B read + 16 B written per texel, one texel per lane: a wave reads 256 B and writes 1 KiB, both contiguous.
-__global__ __launch_bounds__(256) void DecodeNormalRoughnessKernel(Plane packed, Plane decoded) {
-    const int x = blockIdx.x * 256 + threadIdx.x, y = blockIdx.y;
-    if (x < packed.w)
-        StoreRGBA32F(decoded, x, y, EncodeDecodedNormalRoughness(LoadR32U(packed, x, y)));
+__global__ __launch_bounds__(256) void DecodeNormalRoughnessKernel(Plane packed, Plane decoded, GuideRows rows) {
+    const int x = blockIdx.x * 256 + threadIdx.x, y = blockIdx.y + rows.launchBegin;
+    if (x >= packed.w)
+        return;
+    if (y < rows.validBegin || y >= rows.validEnd) { // test hook only (NRD_HIP_POISON_GUIDES): rows nothing may read
+        StoreRGBA32F(decoded, x, y, F4(__uint_as_float(0x7FC00000u)));
+        return;
+    }
+    StoreRGBA32F(decoded, x, y, EncodeDecodedNormalRoughness(LoadR32U(packed, x, y)));
 }
 
 // REBLUR lists: the same decode plus a (normal, viewZ = |z * gViewZScale|) plane: what a tap of the spatial passes needs from its texel, in ONE 16-byte load
 // instead of a 16-byte and a 4-byte one. 8 B read + 32 B written per pixel.
-__global__ __launch_bounds__(256) void DecodeGuidesKernel(Plane packed, Plane viewZ, Plane decoded, Plane viewPos, float4 frustum, float2 rectSizeInv, float viewZScale) {
-    const int x = blockIdx.x * 256 + threadIdx.x, y = blockIdx.y;
+__global__ __launch_bounds__(256) void DecodeGuidesKernel(Plane packed, Plane viewZ, Plane decoded, Plane viewPos, float4 frustum, float2 rectSizeInv, float viewZScale, GuideRows rows) {
+    const int x = blockIdx.x * 256 + threadIdx.x, y = blockIdx.y + rows.launchBegin;
     if (x >= packed.w)
         return;
+    if (y < rows.validBegin || y >= rows.validEnd) { // test hook only (NRD_HIP_POISON_GUIDES)
+        StoreRGBA32F(decoded, x, y, F4(__uint_as_float(0x7FC00000u)));
+        StoreRGBA32F(viewPos, x, y, F4(__uint_as_float(0x7FC00000u)));
+        return;
+    }
     const uint32_t raw = LoadR32U(packed, x, y);
     const float4 d = EncodeDecodedNormalRoughness(raw);
     StoreRGBA32F(decoded, x, y, d);
     StoreRGBA32F(viewPos, x, y, F4(d.x, d.y, d.z, Abs(LoadR32F(viewZ, x, y) * viewZScale)));
 }
 
+// rows the guide kernels have to cover: PassArgs::rowBegin / rowEnd when the executor set them (multi-GPU: the strip + the reach of the passes that read the guides), else all.
+// NRD_HIP_POISON_GUIDES=1 (test hook): the kernels run over the whole planes and write NaNs outside those rows, so that a pass reading a row it did not declare shows up
+static GuideRows MakeGuideRows(const PassArgs& a, const Plane& p) {
+    static const bool poison = getenv("NRD_HIP_POISON_GUIDES") && atoi(getenv("NRD_HIP_POISON_GUIDES")) != 0;
+    GuideRows r;
+    r.validBegin = a.rowEnd > a.rowBegin && a.rowBegin > 0 ? a.rowBegin : 0;
+    r.validEnd = a.rowEnd > a.rowBegin && a.rowEnd < p.h ? a.rowEnd : p.h;
+    r.launchBegin = poison ? 0 : r.validBegin;
+    r.launchEnd = poison ? p.h : r.validEnd;
+    return r;
+}
+
 void LaunchDecodeGuides(const PassArgs& a, const Plane& packed, const Plane& viewZ, const Plane& decoded, const Plane& viewPos, const void* reblurConstants) {
     const nrdc::ReblurConstants& c = *(const nrdc::ReblurConstants*)reblurConstants;
-    LaunchPass(a, DecodeGuidesKernel, dim3((unsigned)((packed.w + 255) / 256), (unsigned)packed.h, 1), dim3(256), packed, viewZ, decoded, viewPos,
-        make_float4(c.gFrustum.x, c.gFrustum.y, c.gFrustum.z, c.gFrustum.w), make_float2(c.gRectSizeInv.x, c.gRectSizeInv.y), c.gViewZScale);
+    const GuideRows rows = MakeGuideRows(a, packed);
+    if (rows.launchEnd <= rows.launchBegin)
+        return;
+    LaunchPass(a, DecodeGuidesKernel, dim3((unsigned)((packed.w + 255) / 256), (unsigned)(rows.launchEnd - rows.launchBegin), 1), dim3(256), packed, viewZ, decoded, viewPos,
+        make_float4(c.gFrustum.x, c.gFrustum.y, c.gFrustum.z, c.gFrustum.w), make_float2(c.gRectSizeInv.x, c.gRectSizeInv.y), c.gViewZScale, rows);
 }
 
 // RELAX lists: the same decode plus (world position, viewZ) of every pixel -- GetCurrentWorldPosFromPixelPos( pixel, |z * gViewZScale| ) of RELAX_Common.hlsli:
 // the plane the a-trous taps read (formerly written by the first a-trous pass) and, being available from the start of the frame, the pre-pass taps too.
 __global__ __launch_bounds__(256) void DecodeGuidesRelaxKernel(Plane packed, Plane viewZ, Plane decoded, Plane worldPos, float3 frustumRight, float3 frustumUp, float3 frustumForward,
-    float2 rectSizeInv, float viewZScale) {
-    const int x = blockIdx.x * 256 + threadIdx.x, y = blockIdx.y;
+    float2 rectSizeInv, float viewZScale, GuideRows rows) {
+    const int x = blockIdx.x * 256 + threadIdx.x, y = blockIdx.y + rows.launchBegin;
     if (x >= packed.w)
         return;
+    if (y < rows.validBegin || y >= rows.validEnd) { // test hook only (NRD_HIP_POISON_GUIDES)
+        StoreRGBA32F(decoded, x, y, F4(__uint_as_float(0x7FC00000u)));
+        StoreRGBA32F(worldPos, x, y, F4(__uint_as_float(0x7FC00000u)));
+        return;
+    }
     StoreRGBA32F(decoded, x, y, EncodeDecodedNormalRoughness(LoadR32U(packed, x, y)));
     const float z = Abs(LoadR32F(viewZ, x, y) * viewZScale);
     const float2 clip = F2(float(x) + 0.5f, float(y) + 0.5f) * rectSizeInv * 2.0f - 1.0f;
@@ -55,13 +90,18 @@ __global__ __launch_bounds__(256) void DecodeGuidesRelaxKernel(Plane packed, Pla
 
 void LaunchDecodeGuidesRelax(const PassArgs& a, const Plane& packed, const Plane& viewZ, const Plane& decoded, const Plane& worldPos, const void* relaxConstants) {
     const nrdc::RelaxConstants& c = *(const nrdc::RelaxConstants*)relaxConstants;
-    LaunchPass(a, DecodeGuidesRelaxKernel, dim3((unsigned)((packed.w + 255) / 256), (unsigned)packed.h, 1), dim3(256), packed, viewZ, decoded, worldPos,
+    const GuideRows rows = MakeGuideRows(a, packed);
+    if (rows.launchEnd <= rows.launchBegin)
+        return;
+    LaunchPass(a, DecodeGuidesRelaxKernel, dim3((unsigned)((packed.w + 255) / 256), (unsigned)(rows.launchEnd - rows.launchBegin), 1), dim3(256), packed, viewZ, decoded, worldPos,
         make_float3(c.gFrustumRight.x, c.gFrustumRight.y, c.gFrustumRight.z), make_float3(c.gFrustumUp.x, c.gFrustumUp.y, c.gFrustumUp.z),
-        make_float3(c.gFrustumForward.x, c.gFrustumForward.y, c.gFrustumForward.z), make_float2(c.gRectSizeInv.x, c.gRectSizeInv.y), c.gViewZScale);
+        make_float3(c.gFrustumForward.x, c.gFrustumForward.y, c.gFrustumForward.z), make_float2(c.gRectSizeInv.x, c.gRectSizeInv.y), c.gViewZScale, rows);
 }
 
 void LaunchDecodeNormalRoughness(const PassArgs& a, const Plane& packed, const Plane& decoded) {
-    LaunchPass(a, DecodeNormalRoughnessKernel, dim3((unsigned)((packed.w + 255) / 256), (unsigned)packed.h, 1), dim3(256), packed, decoded);
+    const GuideRows rows = MakeGuideRows(a, packed);
+    if (rows.launchEnd > rows.launchBegin)
+        LaunchPass(a, DecodeNormalRoughnessKernel, dim3((unsigned)((packed.w + 255) / 256), (unsigned)(rows.launchEnd - rows.launchBegin), 1), dim3(256), packed, decoded, rows);
 }
 
 // ---- shifted rect (CommonSettings::rectOrigin; reference Common.hlsli:200-206 WithRectOrigin / WithRectOffset) ------------------------------------
