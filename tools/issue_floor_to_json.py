@@ -25,9 +25,12 @@ def parse(path):
 
 def main():
     tag = sys.argv[1]
-    data = {"source": "profiles/%s_*_uniform_{product,l1,alu}_kernel_stats.txt (rocprofv3 --kernel-trace of bench.py --uniform --no-graph, every pixel denoised)" % tag, "workloads": {}}
+    data = {"source": "profiles/%s_*_uniform_{product,l1[,alu]}_kernel_stats.txt (rocprofv3 --kernel-trace of bench.py --uniform --no-graph, every pixel denoised)" % tag, "workloads": {}}
     for w, size in (("reblur_ds", "REBLUR_DIFFUSE_SPECULAR 2560x1440"), ("relax_ds_sh", "RELAX_DIFFUSE_SPECULAR_SH 3840x2160")):
-        t = {lib: parse(os.path.join(ROOT, "profiles", "%s_%s_uniform_%s_kernel_stats.txt" % (tag, w, lib))) for lib in ("product", "l1", "alu")}
+        t = {}
+        for lib in ("product", "l1", "alu"):
+            path = os.path.join(ROOT, "profiles", "%s_%s_uniform_%s_kernel_stats.txt" % (tag, w, lib))
+            t[lib] = parse(path) if os.path.exists(path) else {}  # (the arithmetic-only build is optional)
         rows = {}
         for k, us in sorted(t["product"].items(), key=lambda kv: -kv[1]):
             if k in t["l1"] and not k.startswith(("CopyProbe", "ClearPlane")):

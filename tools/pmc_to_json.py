@@ -61,12 +61,10 @@ def main():
                     c = sq.get(kname)
                     if c and c.get("SQ_INSTS_VALU") and c.get("SQ_WAVES"):
                         kernels[shader].update({"SQ_INSTS_VALU": c["SQ_INSTS_VALU"], "SQ_WAVES": c["SQ_WAVES"], "valu_per_wave": round(c["SQ_INSTS_VALU"] / c["SQ_WAVES"], 1)})
-                        active = c.get("SQ_ACTIVE_INST_V") or c.get("SQ_ACTIVE_INST_VALU")  # (pmc_summary.py truncates the counter names to 16 characters)
-                        if active and sq_avg_us.get(kname):
-                            # SQ_ACTIVE_INST_VALU counts in units of 4 cycles, summed over the SIMDs: cycles per executed instruction and the fraction of the
-                            # kernel's duration (in THIS counter run) its 1024 SIMDs spent executing VALU instructions, at the 2.4 GHz peak clock
-                            kernels[shader].update({"SQ_ACTIVE_INST_VALU": active, "pmc_run_avg_us": sq_avg_us[kname], "valu_cycles_per_instruction": round(4.0 * active / c["SQ_INSTS_VALU"], 2),
-                                                    "valu_busy_frac": round(4.0 * active / (1024 * 2400.0 * sq_avg_us[kname]), 3)})
+                        # (round 3 also derived "cycles per instruction" and a "VALU busy" fraction from SQ_ACTIVE_INST_VALU; the counter advances in 4-cycle quanta, the
+                        #  fractions read above 1.0 and are gone: profiles/issue_floor.json holds the measured floors instead -- DESIGN.md section 3.1)
+                        if sq_avg_us.get(kname):
+                            kernels[shader]["pmc_run_avg_us"] = sq_avg_us[kname]
                 break
     path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles", "pmc_traffic.json")
     data = json.load(open(path)) if os.path.exists(path) else {}
