@@ -3,7 +3,7 @@
 // nrdHipPlanHaloExchange (include/NRDHip.h); before a segment the rank swaps the boundary bands of the planes the segment reads with
 // its two neighbours; a list that cannot be bounded (restart frame, hit-distance reconstruction, SIGMA, a dynamic-resolution step) runs
 // unsharded on every rank, after the carried-over planes have been completed everywhere. Owned rows are bit-identical to a single-GPU
-// run as long as the vertical motion stays below maxMotionRows.
+// run as long as the vertical motion stays below maxMotionRows (promised by the application, or measured every frame: measureMotion).
 //
 // The transfers go through an nrd::HaloTransport. nrd::RcclHaloTransport (below, compiled when NRD_SHARDED_WITH_RCCL is defined: needs
 // <rccl/rccl.h> and the HIP runtime) issues them as grouped ncclSend / ncclRecv on its own stream, so the passes that do not touch the
@@ -38,6 +38,12 @@ public:
     virtual bool Wait(void* computeStream) = 0;
     // rows [rowBegin, rowEnd) of a plane travel from rank root to every other rank (used before an unsharded frame that follows sharded ones)
     virtual bool Broadcast(const HaloTransfer& band, uint32_t root, void* computeStream) = 0;
+    // value = the maximum of the ranks' values (one float per frame: the measured motion bound, ShardedIntegrationHipCreationDesc::measureMotion). A host
+    // that drives the ranks itself (PrepareFrame / PlanFrame) never calls it; the default suits a single rank.
+    virtual bool MaxOverRanks(float& value, void* computeStream) {
+        (void)value, (void)computeStream;
+        return true;
+    }
 };
 
 struct ShardedIntegrationHipCreationDesc {
@@ -46,6 +52,10 @@ struct ShardedIntegrationHipCreationDesc {
     uint32_t rank = 0, world = 1;
     uint32_t maxMotionRows = 32;     // the largest vertical motion (rows per frame) the history halos cover
     uint32_t exchangeThreshold = 24; // passes reaching further than this start a new segment (their inputs are exchanged, not recomputed)
+    // false: maxMotionRows is the application's promise about every frame. true: it is CHECKED every frame -- nrdHipMeasureMotionRows reduces the frame's own
+    // IN_VIEWZ / IN_MV over this rank's strip (the temporal passes' surface-motion reprojection, moving objects included), the ranks take the maximum
+    // (HaloTransport::MaxOverRanks) and a frame with 2 x motion + 2 >= maxMotionRows (virtual motion of specular reflections, bicubic footprint) runs unsharded.
+    bool measureMotion = false;
 };
 
 class ShardedIntegrationHip {
@@ -82,6 +92,18 @@ public:
     // One frame = BeginFrame, then for every step ExchangeStep + RunStep, then EndFrame; Denoise() does exactly that. The step-wise form
     // exists for hosts that interleave their own work and for the virtual-rank test.
     inline bool BeginFrame(const Identifier* denoisers, uint32_t denoisersNum, const UserPoolHip& userPool) {
+        float rows = -1.0f;
+        if (!PrepareFrame(denoisers, denoisersNum, userPool, &rows))
+            return false;
+        if (rows >= 0.0f && !m_Desc.transport->MaxOverRanks(rows, m_Desc.integration.hipStream))
+            return Fail("transport max-reduction failed");
+        return PlanFrame(rows);
+    }
+    // BeginFrame in two halves, for hosts (and the virtual-rank test) that reduce the measured motion over the ranks themselves:
+    //   PrepareFrame   binds the user planes, asks the instance for the frame's dispatch list and -- with measureMotion -- measures this strip's motion
+    //                  (*localMotionRows; -1 when nothing was measured)
+    //   PlanFrame      plans the halo exchange; motionRowsOverRanks >= 0 is held against maxMotionRows (the SAME value on every rank), < 0 = no check
+    inline bool PrepareFrame(const Identifier* denoisers, uint32_t denoisersNum, const UserPoolHip& userPool, float* localMotionRows = nullptr) {
         m_Error = nullptr;
         NrdHipExecutor* ex = m_Integration.GetExecutor();
         for (size_t slot = 0; slot < userPool.size(); slot++)
@@ -92,6 +114,15 @@ public:
             }
         if (GetComputeDispatches(*m_Integration.GetInstance(), denoisers, denoisersNum, m_Dispatches, m_DispatchesNum) != Result::SUCCESS)
             return Fail("GetComputeDispatches failed");
+        float rows = -1.0f;
+        if (m_Desc.measureMotion && m_Desc.world > 1 &&
+            nrdHipMeasureMotionRows(ex, m_Dispatches, m_DispatchesNum, m_Bounds[m_Desc.rank], m_Bounds[m_Desc.rank + 1], &rows) != (uint32_t)Result::SUCCESS)
+            return false;
+        if (localMotionRows)
+            *localMotionRows = rows;
+        return true;
+    }
+    inline bool PlanFrame(float motionRowsOverRanks = -1.0f) {
         m_RowBegin.assign(m_DispatchesNum, -1);
         m_RowEnd.assign(m_DispatchesNum, 0);
         m_Steps.resize(64);
@@ -100,12 +131,18 @@ public:
         if (nrdHipPlanHaloExchange(m_Integration.GetInstance(), m_Dispatches, m_DispatchesNum, m_Bounds.data(), m_Desc.world, m_Desc.rank, m_Desc.integration.resourceHeight, m_Desc.maxMotionRows,
                 m_Desc.exchangeThreshold, m_RowBegin.data(), m_RowEnd.data(), m_Steps.data(), (uint32_t)m_Steps.size(), m_Items.data(), (uint32_t)m_Items.size(), &info) != (uint32_t)Result::SUCCESS)
             return Fail("nrdHipPlanHaloExchange failed");
-        m_Fallback = info.fallback != 0 || m_Desc.world == 1;
+        m_LastMotionRows = motionRowsOverRanks;
+        const bool motionExceedsHalo = motionRowsOverRanks >= 0.0f && !(2.0f * motionRowsOverRanks + 2.0f < float(m_Desc.maxMotionRows)); // (a NaN exceeds)
+        if (motionExceedsHalo && !info.fallback && m_Desc.world > 1)
+            m_MotionFallbacks++;
+        m_Fallback = info.fallback != 0 || motionExceedsHalo || m_Desc.world == 1;
         m_Steps.resize(m_Fallback ? 1 : info.stepsNum);
         if (m_Fallback)
             m_Steps[0] = NrdHipHaloStep{0, m_DispatchesNum, 0, 0, 0};
         return true;
     }
+    inline float GetLastMotionRows() const { return m_LastMotionRows; }        // what the last PlanFrame was given (-1: nothing)
+    inline uint32_t GetMotionFallbacksNum() const { return m_MotionFallbacks; } // frames run unsharded because the measured motion did not fit the history halo
     inline uint32_t GetStepsNum() const { return (uint32_t)m_Steps.size(); }
 
     // Issues the transfers of a step (for an unsharded frame after sharded ones: the completion of the carried-over planes)
@@ -230,6 +267,8 @@ private:
     std::vector<NrdHipHaloStep> m_Steps;
     std::vector<NrdHipHaloItem> m_Items;
     bool m_Fallback = true, m_Complete = true, m_Pending = false;
+    float m_LastMotionRows = -1.0f;
+    uint32_t m_MotionFallbacks = 0;
     const char* m_Error = nullptr;
 };
 
@@ -254,6 +293,8 @@ public:
         if (m_Stream) (void)hipStreamDestroy(m_Stream);
         if (m_Ready) (void)hipEventDestroy(m_Ready);
         if (m_Done) (void)hipEventDestroy(m_Done);
+        if (m_Scalar) (void)hipFree(m_Scalar);
+        m_Scalar = nullptr;
         m_Stream = nullptr;
         m_Ready = m_Done = nullptr;
     }
@@ -270,11 +311,19 @@ public:
     inline bool Broadcast(const HaloTransfer& band, uint32_t root, void* computeStream) override {
         return ncclBroadcast(band.data, band.data, band.bytes, ncclUint8, (int)root, m_Comm, (hipStream_t)computeStream) == ncclSuccess;
     }
+    inline bool MaxOverRanks(float& value, void* computeStream) override { // 4 bytes through an all-reduce on the compute stream, then read back
+        hipStream_t s = (hipStream_t)computeStream;
+        if (!m_Scalar && hipMalloc((void**)&m_Scalar, sizeof(float)) != hipSuccess)
+            return false;
+        return hipMemcpyAsync(m_Scalar, &value, sizeof(float), hipMemcpyHostToDevice, s) == hipSuccess && ncclAllReduce(m_Scalar, m_Scalar, 1, ncclFloat, ncclMax, m_Comm, s) == ncclSuccess &&
+               hipMemcpyAsync(&value, m_Scalar, sizeof(float), hipMemcpyDeviceToHost, s) == hipSuccess && hipStreamSynchronize(s) == hipSuccess;
+    }
 
 private:
     ncclComm_t m_Comm = nullptr;
     hipStream_t m_Stream = nullptr;
     hipEvent_t m_Ready = nullptr, m_Done = nullptr;
+    float* m_Scalar = nullptr;
 };
 
 } // namespace nrd

@@ -4,7 +4,10 @@
 // ordering. Every rank's owned rows of every output must equal a plain single-GPU nrd::IntegrationHip run, bit for bit, every frame -- including a
 // frame that cannot be sharded in mid-sequence (hit-distance reconstruction on) and the completion of the history planes in front of it.
 // REBLUR_DIFFUSE_SPECULAR on a procedural G-buffer packed with include/NRD.hip.h (the front-end an application's own kernels would use).
-// usage: sharded_virtual_ranks [world = 3]          --compile-only check: build with -DNRD_SHARDED_WITH_RCCL to also compile the RCCL transport
+// usage: sharded_virtual_ranks [world = 3] [measure]   --compile-only check: build with -DNRD_SHARDED_WITH_RCCL to also compile the RCCL transport
+// measure: ShardedIntegrationHipCreationDesc::measureMotion -- the motion bound comes from nrdHipMeasureMotionRows on every rank's strip (PrepareFrame), the test takes the
+// maximum (what HaloTransport::MaxOverRanks does between real ranks) and hands it to PlanFrame; in frame 4 ONE pixel of the last strip moves 30 rows (2D motion vectors):
+// every rank has to run that frame unsharded, and the next one sharded again.
 #include "NRD.h"
 #include "NRDHip.h"
 #include "NRDIntegrationHip.hpp"
@@ -65,6 +68,8 @@ struct Planes { // the user planes of one executor
 
 int main(int argc, char** argv) {
     const uint32_t world = argc > 1 ? (uint32_t)atoi(argv[1]) : 3;
+    const bool measure = argc > 2 && !strcmp(argv[2], "measure");
+    const int fastFrame = 4;
     const uint16_t W = 192, H = 288;
     const int frames = 6, unshardedFrame = 3;
     const size_t texels = (size_t)W * H;
@@ -96,6 +101,7 @@ int main(int argc, char** argv) {
         sdesc.rank = r;
         sdesc.world = world;
         sdesc.maxMotionRows = 8;
+        sdesc.measureMotion = measure;
         CHECK(ranks[r]->Initialize(sdesc, icd));
     }
 
@@ -166,6 +172,16 @@ int main(int argc, char** argv) {
         cs.resourceSize[1] = cs.resourceSizePrev[1] = cs.rectSize[1] = cs.rectSizePrev[1] = H;
         cs.motionVectorScale[0] = cs.motionVectorScale[1] = cs.motionVectorScale[2] = 0.0f;
         cs.isMotionVectorInWorldSpace = true;
+        if (measure) { // 2D motion vectors in pixels: zero everywhere (static scene, static camera), except one pixel of the last strip in the fast frame
+            cs.isMotionVectorInWorldSpace = false;
+            cs.motionVectorScale[0] = 1.0f / float(W), cs.motionVectorScale[1] = 1.0f / float(H);
+            std::vector<__half> hMv(texels * 4, __float2half(0.0f));
+            if (f == fastFrame)
+                hMv[((size_t)(H - 9) * W + 17) * 4 + 1] = __float2half(-30.0f);
+            for (Planes& p : planes)
+                CHECK(hipMemcpyAsync(p.mv, hMv.data(), texels * 8, hipMemcpyHostToDevice, stream) == hipSuccess);
+            CHECK(hipStreamSynchronize(stream) == hipSuccess); // hMv goes out of scope
+        }
         cs.frameIndex = (uint32_t)f;
         cs.timeDeltaBetweenFrames = 16.667f; // 0 would make every instance measure its own wall-clock frame time (frame-rate dependent constants)
         cs.accumulationMode = f == 0 ? nrd::AccumulationMode::CLEAR_AND_RESTART : nrd::AccumulationMode::CONTINUE;
@@ -185,14 +201,33 @@ int main(int argc, char** argv) {
         for (uint32_t r = 0; r < world; r++) {
             ranks[r]->NewFrame();
             CHECK(ranks[r]->SetCommonSettings(cs) && ranks[r]->SetDenoiserSettings(1, &rs));
-            if (!ranks[r]->BeginFrame(&id, 1, pool(planes[1 + r]))) {
+            if (!measure && !ranks[r]->BeginFrame(&id, 1, pool(planes[1 + r]))) {
                 printf("rank %u BeginFrame failed: %s\n", r, ranks[r]->GetLastError());
                 return 1;
             }
+        }
+        if (measure) { // PrepareFrame on every rank, the maximum of the measured rows, PlanFrame with it
+            float rowsMax = -1.0f;
+            for (uint32_t r = 0; r < world; r++) {
+                float rows = -1.0f;
+                if (!ranks[r]->PrepareFrame(&id, 1, pool(planes[1 + r]), &rows)) {
+                    printf("rank %u PrepareFrame failed: %s\n", r, ranks[r]->GetLastError());
+                    return 1;
+                }
+                if (world > 1) {
+                    CHECK(rows >= 0.0f);
+                    CHECK(f != fastFrame || (r + 1 == world ? fabsf(rows - 30.0f) < 0.05f : rows == 0.0f)); // only the last strip sees the moving pixel
+                }
+                rowsMax = fmaxf(rowsMax, rows);
+            }
+            for (uint32_t r = 0; r < world; r++)
+                CHECK(ranks[r]->PlanFrame(rowsMax));
+        }
+        for (uint32_t r = 0; r < world; r++) {
             CHECK(r == 0 || ranks[r]->GetStepsNum() == steps);
             steps = ranks[r]->GetStepsNum();
         }
-        const bool expectSharded = world > 1 && f != 0 && f != unshardedFrame;
+        const bool expectSharded = world > 1 && f != 0 && f != unshardedFrame && !(measure && f == fastFrame);
         CHECK((steps > 1) == expectSharded);
         shardedFrames += steps > 1;
         for (uint32_t s = 0; s < steps; s++) { // lock-step: every rank's transfers of step s see the peers' rows of step s - 1
@@ -247,7 +282,10 @@ int main(int argc, char** argv) {
         ranks[r]->Destroy();
         delete ranks[r];
     }
-    if (mismatches || (world > 1 && (shardedFrames != (size_t)frames - 2 || received == 0)))
+    if (measure && world > 1)
+        for (uint32_t r = 0; r < world; r++)
+            CHECK(ranks[r]->GetMotionFallbacksNum() == 1);
+    if (mismatches || (world > 1 && (shardedFrames != (size_t)frames - 2 - (measure ? 1 : 0) || received == 0)))
         return 1;
     printf("sharded integration OK\n");
     return 0;

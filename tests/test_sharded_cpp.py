@@ -40,3 +40,13 @@ def test_virtual_ranks_reproduce_the_single_gpu_run(world):
     r = subprocess.run([EXE, str(world)], capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
     assert "0 mismatching values" in r.stdout and "sharded integration OK" in r.stdout
+
+
+@pytest.mark.gpu
+def test_virtual_ranks_with_the_motion_bound_measured_on_the_device():
+    """ShardedIntegrationHipCreationDesc::measureMotion: every rank measures its strip (PrepareFrame -> nrdHipMeasureMotionRows), the maximum goes into PlanFrame; the frame
+    in which one pixel of the last strip moves 30 rows is run unsharded by all ranks, the next one sharded again; owned rows bit-identical throughout"""
+    _build()
+    r = subprocess.run([EXE, "3", "measure"], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
+    assert "0 mismatching values" in r.stdout and "sharded integration OK" in r.stdout
