@@ -388,7 +388,10 @@ def main():
         if bpp is None or n == 0:
             continue
         avg_ms = ms / n
-        passes[shader] = {"avg_ms": round(avg_ms, 4), "launches": n, "bytes_per_launch": bpp * rows, "GBps": round(bpp * rows / (avg_ms * 1e-3) / 1e9, 1)}
+        gbps = bpp * rows / (avg_ms * 1e-3) / 1e9
+        # (several launches of one shader -- the a-trous iterations -- are averaged; frac_* = this pass's algorithmic bytes against the 8 TB/s peak and against the copy rate measured above)
+        passes[shader] = {"avg_ms": round(avg_ms, 4), "launches": n, "bytes_per_launch": bpp * rows, "GBps": round(gbps, 1), "frac_of_peak": round(gbps / HBM_PEAK_GBS, 4),
+                          "frac_of_measured_copy": round(gbps / copy_gbs, 4)}
     dominant = max(passes, key=lambda k: passes[k]["avg_ms"]) if passes else None
     roofline = None
     if dominant:
