@@ -214,6 +214,11 @@ __device__ __forceinline__ void RelaxTemporalAccumulationTile(const RelaxCB& cAr
     NRD_CONSTANTS_PHASE();
     // ---------------------------------------------------------------- surface motion based history
     float footprintQuality, historyLength, SMBReprojectionFound;
+    float hitDist = 0.0f, curvature = 0.0f, hitDistFocused = 0.0f; // SPEC: the early virtual-motion geometry (set inside the surface-motion section)
+    float2 prevUVVMB = F2(0.0f, 0.0f), vmbPixelPosFloat = F2(0.0f, 0.0f), vmbOriginF = F2(0.0f, 0.0f), vmbBilinearWeights = F2(0.0f, 0.0f);
+    int vbx = 0, vby = 0;
+    float zQuad[2][2] = {{0.0f, 0.0f}, {0.0f, 0.0f}};
+    bool quadInterior = false;
     float4 prevDiffuseIllumAnd2ndMomentSMB = F4(0.0f), prevDiffuseSH = F4(0.0f), prevDiffuseResponsiveSH = F4(0.0f);
     float3 prevDiffuseResponsiveSMB = F3(0.0f);
     float4 prevSpecularIllumAnd2ndMomentSMB = F4(0.0f), prevSpecularSMBSH = F4(0.0f), prevSpecularSMBResponsiveSH = F4(0.0f);
@@ -302,6 +307,79 @@ __device__ __forceinline__ void RelaxTemporalAccumulationTile(const RelaxCB& cAr
             zRows[2][0] = r2.x, zRows[2][1] = r2.y, zRows[2][2] = r2.z, zRows[2][3] = r2.w;
             zRows[0][0] = zRows[0][3] = zRows[3][0] = zRows[3][3] = 0.0f;
         }
+        // ---- early virtual-motion geometry (SPEC). Curvature, the focused hit distance and the virtual-motion position depend on THIS frame's data only, so they are computed
+        // here, behind the requests of the surface-motion depth rows, and the previous-depth quad at the virtual position is requested before the surface-motion taps are
+        // validated: its latency overlaps with that work instead of following the surface-motion history fetches (same expressions, same order: value-identical)
+        if (SPEC) {
+            hitDist = minHitDist3x3 == NRD_INF ? 0.0f : minHitDist3x3;
+
+            // curvature along the direction of motion
+            {
+                float2 deltaUv = prevUVSMB - GetScreenUv(c.shared.gWorldToClipPrev, prevWorldPos + cameraDelta);
+                deltaUv = deltaUv * rectSize;
+                deltaUv = Div(deltaUv, Max(smbParallaxInPixels1, 1.0f / 256.0f));
+
+                float3 n10, x10, n01, x01;
+                {
+                    float3 x = GetCurrentWorldPosFromClipSpaceXY(c, (pixelUv + F2(1.0f, 0.0f) * rectSizeInv) * 2.0f - 1.0f, 1.0f);
+                    float3 v = Normalize(-x);
+                    x10 = F3(0.0f) + Div(v * Dot(currentWorldPos - F3(0.0f), currentNormal), Dot(currentNormal, v));
+                    n10 = Xyz(Shared(1, 0));
+                }
+                {
+                    float3 x = GetCurrentWorldPosFromClipSpaceXY(c, (pixelUv + F2(0.0f, 1.0f) * rectSizeInv) * 2.0f - 1.0f, 1.0f);
+                    float3 v = Normalize(-x);
+                    x01 = F3(0.0f) + Div(v * Dot(currentWorldPos - F3(0.0f), currentNormal), Dot(currentNormal, v));
+                    n01 = Xyz(Shared(0, 1));
+                }
+
+                float2 w = Abs(deltaUv) + 1.0f / 256.0f;
+                w = Div(w, w.x + w.y);
+                float3 x = x10 * w.x + x01 * w.y;
+                float3 n = Normalize(n10 * w.x + n01 * w.y);
+
+                float deltaUvLenFixed = smbParallaxInPixelsMin;
+                deltaUvLenFixed *= 1.0f;
+                deltaUvLenFixed *= 1.0f + c.shared.gFramerateScale * Bayer4x4((uint32_t)px, (uint32_t)py, c.shared.gFrameIndex);
+
+                float2 motionUvHigh = pixelUv + deltaUv * deltaUvLenFixed * rectSizeInv;
+                motionUvHigh = (Floor(motionUvHigh * rectSize) + 0.5f) * rectSizeInv;
+                if (deltaUvLenFixed > 1.0f && IsInScreenNearest(motionUvHigh) != 0.0f) {
+                    float2 uvScaled = RelaxClampUvToViewport(c, motionUvHigh) + ToF2(c.shared.gRectOffset);
+                    int2 q = NearestTexel(P.viewZ, uvScaled);
+                    float zHigh = RelaxUnpackViewZ(c, LoadR32F(P.viewZ, q.x, q.y));
+                    float3 xHigh = GetCurrentWorldPosFromClipSpaceXY(c, motionUvHigh * 2.0f - 1.0f, zHigh);
+                    float3 nHigh = Xyz(LoadDecodedNormalRoughness(P.decodedNR, q.x, q.y));
+                    float zError = Abs(zHigh - currentLinearZ) * Rcp(Max(zHigh, currentLinearZ));
+                    bool cmp = zError < NRD_CURVATURE_Z_THRESHOLD;
+                    n = Select(cmp, nHigh, n);
+                    x = Select(cmp, xHigh, x);
+                }
+
+                float3 edge = x - currentWorldPos;
+                float edgeLenSq = LengthSquared(edge);
+                curvature = Dot(n - currentNormal, edge) * PositiveRcp(edgeLenSq);
+            }
+
+            hitDistFocused = ApplyThinLensEquation(hitDist, curvature);
+
+            const float3 virtualViewVector = Normalize(currentViewVector) * hitDistFocused;
+            const float3 prevVirtualWorldPos = prevWorldPos + virtualViewVector;
+
+            prevUVVMB = ScreenUvNoKill(c.shared.gWorldToClipPrev, prevVirtualWorldPos);
+            prevUVVMB = Select(currentMaterialID == c.shared.gCameraAttachedReflectionMaterialID, prevUVSMB, prevUVVMB);
+
+            vmbPixelPosFloat = prevUVVMB * rectSizePrev;
+            vmbOriginF = Floor(vmbPixelPosFloat - 0.5f);
+            vbx = (int)vmbOriginF.x, vby = (int)vmbOriginF.y;
+            vmbBilinearWeights = F2(Frac(vmbPixelPosFloat.x - 0.5f), Frac(vmbPixelPosFloat.y - 0.5f));
+            quadInterior = FootprintIsInterior(P.prevViewZ, vbx, vby, 2, 2);
+            if (quadInterior) {
+                const float2 r0 = LoadRowR32Fx2(P.prevViewZ, vbx, vby), r1 = LoadRowR32Fx2(P.prevViewZ, vbx, vby + 1);
+                zQuad[0][0] = r0.x, zQuad[0][1] = r0.y, zQuad[1][0] = r1.x, zQuad[1][1] = r1.y;
+            }
+        }
+
         auto Valid = [&](int dx, int dy, float threshold) {
             float z = RelaxUnpackViewZ(c, MODE == 1 ? s_WinZ[Win(bx + dx, by + dy)] : footprintInterior ? zRows[dy + 1][dx + 1] : FetchClampedR32F(P.prevViewZ, bx + dx, by + dy));
             float v = Step(Abs(z - prevViewPosZ), threshold);
@@ -457,78 +535,16 @@ __device__ __forceinline__ void RelaxTemporalAccumulationTile(const RelaxCB& cAr
         const float specHistoryFrames = Min(specMaxAccumulatedFrameNum, specHistoryLength);
         const float specHistoryResponsiveFrames = Min(specMaxFastAccumulatedFrameNum, specHistoryLength);
 
-        const float hitDist = minHitDist3x3 == NRD_INF ? 0.0f : minHitDist3x3;
-
-        NRD_CONSTANTS_PHASE();
-        // curvature along the direction of motion
-        float curvature;
-        {
-            float2 deltaUv = prevUVSMB - GetScreenUv(c.shared.gWorldToClipPrev, prevWorldPos + cameraDelta);
-            deltaUv = deltaUv * rectSize;
-            deltaUv = Div(deltaUv, Max(smbParallaxInPixels1, 1.0f / 256.0f));
-
-            float3 n10, x10, n01, x01;
-            {
-                float3 x = GetCurrentWorldPosFromClipSpaceXY(c, (pixelUv + F2(1.0f, 0.0f) * rectSizeInv) * 2.0f - 1.0f, 1.0f);
-                float3 v = Normalize(-x);
-                x10 = F3(0.0f) + Div(v * Dot(currentWorldPos - F3(0.0f), currentNormal), Dot(currentNormal, v));
-                n10 = Xyz(Shared(1, 0));
-            }
-            {
-                float3 x = GetCurrentWorldPosFromClipSpaceXY(c, (pixelUv + F2(0.0f, 1.0f) * rectSizeInv) * 2.0f - 1.0f, 1.0f);
-                float3 v = Normalize(-x);
-                x01 = F3(0.0f) + Div(v * Dot(currentWorldPos - F3(0.0f), currentNormal), Dot(currentNormal, v));
-                n01 = Xyz(Shared(0, 1));
-            }
-
-            float2 w = Abs(deltaUv) + 1.0f / 256.0f;
-            w = Div(w, w.x + w.y);
-            float3 x = x10 * w.x + x01 * w.y;
-            float3 n = Normalize(n10 * w.x + n01 * w.y);
-
-            float deltaUvLenFixed = smbParallaxInPixelsMin;
-            deltaUvLenFixed *= 1.0f;
-            deltaUvLenFixed *= 1.0f + c.shared.gFramerateScale * Bayer4x4((uint32_t)px, (uint32_t)py, c.shared.gFrameIndex);
-
-            float2 motionUvHigh = pixelUv + deltaUv * deltaUvLenFixed * rectSizeInv;
-            motionUvHigh = (Floor(motionUvHigh * rectSize) + 0.5f) * rectSizeInv;
-            if (deltaUvLenFixed > 1.0f && IsInScreenNearest(motionUvHigh) != 0.0f) {
-                float2 uvScaled = RelaxClampUvToViewport(c, motionUvHigh) + ToF2(c.shared.gRectOffset);
-                int2 q = NearestTexel(P.viewZ, uvScaled);
-                float zHigh = RelaxUnpackViewZ(c, LoadR32F(P.viewZ, q.x, q.y));
-                float3 xHigh = GetCurrentWorldPosFromClipSpaceXY(c, motionUvHigh * 2.0f - 1.0f, zHigh);
-                float3 nHigh = Xyz(LoadDecodedNormalRoughness(P.decodedNR, q.x, q.y));
-                float zError = Abs(zHigh - currentLinearZ) * Rcp(Max(zHigh, currentLinearZ));
-                bool cmp = zError < NRD_CURVATURE_Z_THRESHOLD;
-                n = Select(cmp, nHigh, n);
-                x = Select(cmp, xHigh, x);
-            }
-
-            float3 edge = x - currentWorldPos;
-            float edgeLenSq = LengthSquared(edge);
-            curvature = Dot(n - currentNormal, edge) * PositiveRcp(edgeLenSq);
-        }
-
-        const float hitDistFocused = ApplyThinLensEquation(hitDist, curvature);
+        // (hitDist, curvature, hitDistFocused and the virtual-motion position were computed in front of the surface-motion fetches: "early virtual-motion geometry")
 
         NRD_CONSTANTS_PHASE();
         // ---------------------------------------------------------------- virtual motion based history
         float4 prevSpecularIllumAnd2ndMomentVMB = F4(0.0f), prevSpecularResponsiveVMB = F4(0.0f), prevSpecularVMBSH = F4(0.0f), prevSpecularVMBResponsiveSH = F4(0.0f);
         float3 prevNormalVMB = currentNormal;
         float prevRoughnessVMB = 0.0f, prevReflectionHitTVMB = c.shared.gDenoisingRange, VMBReprojectionFound;
-        float2 prevUVVMB;
         {
-            const float3 virtualViewVector = Normalize(currentViewVector) * hitDistFocused;
-            const float3 prevVirtualWorldPos = prevWorldPos + virtualViewVector;
-
-            prevUVVMB = ScreenUvNoKill(c.shared.gWorldToClipPrev, prevVirtualWorldPos);
-            prevUVVMB = Select(currentMaterialID == c.shared.gCameraAttachedReflectionMaterialID, prevUVSMB, prevUVVMB);
-
-            const float2 prevVirtualPixelPosFloat = prevUVVMB * rectSizePrev;
-            const float2 originF = Floor(prevVirtualPixelPosFloat - 0.5f);
-            const int bx = (int)originF.x, by = (int)originF.y;
-            const float2 bilinearWeights = F2(Frac(prevVirtualPixelPosFloat.x - 0.5f), Frac(prevVirtualPixelPosFloat.y - 0.5f));
-
+            const float2 prevVirtualPixelPosFloat = vmbPixelPosFloat, originF = vmbOriginF, bilinearWeights = vmbBilinearWeights;
+            const int bx = vbx, by = vby;
             const float3 currentWorldPosShifted = currentWorldPos - cameraDelta;
 
             float4 vmbDisocclusionThreshold = F4(disocclusionThreshold * currentLinearZ);
@@ -536,12 +552,6 @@ __device__ __forceinline__ void RelaxTemporalAccumulationTile(const RelaxCB& cAr
             vmbDisocclusionThreshold = vmbDisocclusionThreshold - NRD_EPS;
 
             const bool compareSpecMaterials = c.shared.gSpecMinMaterial < 3.0f;
-            float zQuad[2][2];
-            const bool quadInterior = FootprintIsInterior(P.prevViewZ, bx, by, 2, 2);
-            if (quadInterior) {
-                const float2 r0 = LoadRowR32Fx2(P.prevViewZ, bx, by), r1 = LoadRowR32Fx2(P.prevViewZ, bx, by + 1);
-                zQuad[0][0] = r0.x, zQuad[0][1] = r0.y, zQuad[1][0] = r1.x, zQuad[1][1] = r1.y;
-            }
             auto TapValid = [&](int dx, int dy, float threshold) {
                 float z = RelaxUnpackViewZ(c, quadInterior ? zQuad[dy][dx] : FetchClampedR32F(P.prevViewZ, bx + dx, by + dy));
                 float3 prevWorldPosInTap = GetPreviousWorldPosFromPixelPos(c, bx + dx, by + dy, z);
