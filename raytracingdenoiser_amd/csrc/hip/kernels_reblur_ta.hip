@@ -616,6 +616,8 @@ __device__ __forceinline__ void ReblurTemporalAccumulationTile(const ReblurCB& c
 
         NRD_CONSTANTS_PHASE();
         // Curvature estimation along predicted motion
+        // (measured and dropped, r04_m: requesting the high-parallax tap below in front of the surface-motion section -- 9 more live VGPRs in a kernel that sits at its budget of
+        //  168, 32 B of scratch: TemporalAccumulation 0.279 ms against 0.264; the same move pays in RELAX's kernel, which has the registers: kernels_relax_ta.hip)
         {
             float2 uvForZeroParallax = Select(NRD_ORTHO_MODE(c) == 0.0f, smbPixelUv, pixelUv);
             float2 deltaUv = uvForZeroParallax - GetScreenUv(c.gWorldToClipPrev, Xprev + cameraDelta);
