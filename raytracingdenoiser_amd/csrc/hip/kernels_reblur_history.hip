@@ -205,6 +205,9 @@ NRD_D typename ReblurSignal<KIND>::type HistoryFixSignal(const ReblurCB& c, cons
     return ChangeLuma(sig, luma);
 }
 
+#ifndef NRD_REBLUR_HF_ROTATE
+#define NRD_REBLUR_HF_ROTATE 1 // (0.0857 -> 0.0658 ms at 1440p, r04_q: the young pixels this pass reconstructs are the columns entering the screen -- on ONE XCD in the striped order)
+#endif
 template <bool DIFF, bool SPEC, bool PERF, int KIND, bool SH>
 __global__ __launch_bounds__(TILE_X* TILE_Y, SH ? 0 : NRD_WAVES_REBLUR_HF) void ReblurHistoryFixKernel(ReblurCB c, HfPlanes P, RowRange rr) {
     typedef ReblurSignal<KIND> Sig;
@@ -215,10 +218,11 @@ __global__ __launch_bounds__(TILE_X* TILE_Y, SH ? 0 : NRD_WAVES_REBLUR_HF) void 
 
     const int tx = threadIdx.x % TILE_X, ty = threadIdx.x / TILE_X;
     const int blockY = blockIdx.y + rr.firstBlockY;
-    const int px = BlockTileX(rr) * TILE_X + tx, py = blockY * TILE_Y + ty;
+    const int tileX = NRD_REBLUR_HF_ROTATE ? BlockTileXRotated(rr, blockY) : BlockTileX(rr); // (A/B switch: passes.h BlockTileXRotated)
+    const int px = tileX * TILE_X + tx, py = blockY * TILE_Y + ty;
     const int rw = c.gRectSizeMinusOne.x, rh = c.gRectSizeMinusOne.y;
 
-    if (!BlockHasGeometry(P.tiles, BlockTileX(rr), blockY))
+    if (!BlockHasGeometry(P.tiles, tileX, blockY))
         return;
     // the pixel's own inputs, requested in front of the tile fill (see ReblurTemporalStabilizationKernel; this pass ran 32 % above its L1-resident time)
     const int qx = min(px, rw), qy = min(max(py, 0), rh);
@@ -233,7 +237,7 @@ __global__ __launch_bounds__(TILE_X* TILE_Y, SH ? 0 : NRD_WAVES_REBLUR_HF) void 
     if (SPEC)
         preSpec = Sig::Load(P.inSpec, qx, qy);
     {
-        const int baseX = BlockTileX(rr) * TILE_X - hf::BORDER, baseY = blockY * TILE_Y - hf::BORDER;
+        const int baseX = tileX * TILE_X - hf::BORDER, baseY = blockY * TILE_Y - hf::BORDER;
         for (int i = threadIdx.x; i < hf::BUF_X * hf::BUF_Y; i += TILE_X * TILE_Y) {
             int lx = i % hf::BUF_X, ly = i / hf::BUF_X;
             int gx = ClampI(baseX + lx, 0, rw), gy = ClampI(baseY + ly, 0, rh);

@@ -480,10 +480,14 @@ struct HistoryFixPlanes {
     SignalPlanes spec, diff;
 };
 
+#ifndef NRD_RELAX_HF_ROTATE
+#define NRD_RELAX_HF_ROTATE 1
+#endif
 template <bool DIFF, bool SPEC, bool SH>
 __global__ __launch_bounds__(256, NRD_WAVES_RELAX_HF) void RelaxHistoryFixKernel(HistoryFixPlanes P, RelaxCB c, RowRange rows) {
     const int blockY = blockIdx.y + rows.firstBlockY;
-    const int px = BlockTileX(rows) * TILE_X + (threadIdx.x & 31), py = blockY * TILE_Y + (threadIdx.x >> 5);
+    // (rotated tile order: the pixels with young history -- all this pass works on -- are the columns entering the screen and the silhouettes; passes.h BlockTileXRotated)
+    const int px = (NRD_RELAX_HF_ROTATE ? BlockTileXRotated(rows, blockY) : BlockTileX(rows)) * TILE_X + (threadIdx.x & 31), py = blockY * TILE_Y + (threadIdx.x >> 5);
     const int rectW = c.shared.gRectSize.x, rectH = c.shared.gRectSize.y;
     if (px >= rectW || py >= rectH || py < rows.rowBegin || py >= rows.rowEnd)
         return;

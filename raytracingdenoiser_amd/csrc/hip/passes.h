@@ -235,7 +235,12 @@ struct RowRange { // kernel argument
 };
 inline RowRange MakeRowRange(const RowGrid& g) { return RowRange{g.firstBlockY, g.rowBegin, g.rowEnd, g.bandTiles, g.stripeTiles}; }
 // tile column of this workgroup (may lie beyond the frame: such workgroups find all their pixels outside the rect)
-__device__ __forceinline__ int BlockTileX(const RowRange& r) {
+// NRD_XCD_STAIRCASE_ROWS = K > 0 (A/B switch, off): in EVERY pass the stripes move on by one XCD every K tile rows (see BlockTileXRotated below, which is that with K = 1 for the passes
+// that want it unconditionally)
+#ifndef NRD_XCD_STAIRCASE_ROWS
+#define NRD_XCD_STAIRCASE_ROWS 0
+#endif
+__device__ __forceinline__ int BlockTileXPlain(const RowRange& r) {
     const unsigned bx = blockIdx.x;
     if (!r.bandTiles)
         return (int)bx;
@@ -244,6 +249,24 @@ __device__ __forceinline__ int BlockTileX(const RowRange& r) {
         return (int)(xcd * (unsigned)r.bandTiles + j);
     const unsigned stripe = j / (unsigned)r.stripeTiles, within = j - stripe * (unsigned)r.stripeTiles;
     return (int)((stripe * 8u + xcd) * (unsigned)r.stripeTiles + within);
+}
+__device__ __forceinline__ int BlockTileX(const RowRange& r) {
+    const int t = BlockTileXPlain(r);
+    if (NRD_XCD_STAIRCASE_ROWS == 0 || !r.bandTiles)
+        return t;
+    const unsigned blockY = blockIdx.y + (unsigned)r.firstBlockY;
+    return (int)(((unsigned)t + (blockY / (unsigned)(NRD_XCD_STAIRCASE_ROWS ? NRD_XCD_STAIRCASE_ROWS : 1)) * (unsigned)r.stripeTiles) % gridDim.x);
+}
+
+// The same with the tile columns of tile row `blockY` moved on by one stripe per row: the stripes of one XCD form a staircase instead of a column. For passes whose work is
+// concentrated in a vertical feature -- the columns that enter the screen under a yawing camera, where RELAX HistoryFix does all of its work -- the XCD-aware order
+// puts that feature on ONE XCD (32 of the 256 CUs); rotated, every XCD gets every eighth tile row of it. Costs the L2 locality of vertical neighbours: only for passes
+// that read no vertical halo worth keeping.
+__device__ __forceinline__ int BlockTileXRotated(const RowRange& r, int blockY) {
+    const int t = BlockTileXPlain(r);
+    if (!r.bandTiles)
+        return t;
+    return (int)(((unsigned)t + (unsigned)blockY * (unsigned)r.stripeTiles) % gridDim.x);
 }
 
 } // namespace nrdhip
