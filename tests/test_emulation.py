@@ -12,6 +12,8 @@ import parity
     ("RELAX_DIFFUSE_SPECULAR_SH", 80, 56, 3),   # LDS-tiled a-trous steps 2 / 4, global steps 8 / 16, history clamping
     ("SIGMA_SHADOW", 96, 64, 3),
     ("REBLUR_DIFFUSE_OCCLUSION", 67, 45, 3),    # odd size: clamped footprints, workgroups beyond the frame
+    ("REBLUR_DIFFUSE", 544, 24, 3),             # 17 tile columns: the XCD-striped tile order and its rotated form in HistoryFix (passes.h BlockTileX / BlockTileXRotated)
+    ("RELAX_DIFFUSE", 544, 24, 3),
 ])
 def test_emulated_device_sources_match_the_oracle_bit_for_bit(name, width, height, frames):
     worst = parity.run_parity(name, width=width, height=height, frames=frames, backend="emu")
