@@ -17,7 +17,7 @@ GPU before the timed region). Prints ONE JSON line (see DESIGN.md "Measurement")
 --gpus N with N > 1 and no torch.distributed environment re-launches itself under torch.distributed.run (one rank per GPU, RCCL).
 
   python bench.py [--gpus N] [--steps K] [--warmup W] [--workload reblur_ds|reblur_diffuse|relax_ds_sh|relax_ds|sigma_shadow] [--width 2560 --height 1440]
-                  [--no-graph] [--no-sky] [--no-cpu-baseline] [--no-parity]
+                  [--graph] [--no-sky] [--no-cpu-baseline] [--no-parity]
 """
 import argparse
 import json
@@ -132,7 +132,9 @@ def parse_args():
     ap.add_argument("--max-motion-rows", type=int, default=None, help="halo scheme: largest vertical motion (rows per frame) the history halos cover (default: 32 up to 1440p, scaled with the height above)")
     ap.add_argument("--cpu-frames", type=int, default=8)
     ap.add_argument("--distinct-frames", type=int, default=0, help="number of distinct generated frames to cycle through (0 = warmup + steps)")
-    ap.add_argument("--no-graph", action="store_true", help="launch every pass on its own instead of one hipGraph per frame")
+    ap.add_argument("--graph", action="store_true", help="launch each frame as ONE hipGraph (nrdHipSetGraphMode) instead of one launch per pass: bit-identical, less host work per frame, "
+                    "but 4-6 us per frame slower than back-to-back launches on this runtime (profiles/r04_t_*: 0.7734 against 0.7689 ms) -- the default is therefore eager since round 4")
+    ap.add_argument("--no-graph", action="store_true", help="(the default since round 4; kept for the scripts that pass it)")
     ap.add_argument("--no-sky", action="store_true", help="a dome behind the scene: no sky pixels (34 %% of the default frame are sky and leave at the tile test)")
     ap.add_argument("--uniform", action="store_true", help="tuning runs: every input plane constant (the value of one ground pixel), static camera -- the scene on which an L1-resident A/B build "
                     "(NRD_EXPERIMENT_L1_RESIDENT, csrc/hip/planes.h) computes the same values as the product and so measures each kernel's issue floor")
@@ -304,7 +306,8 @@ def main():
 
     inst = api.Instance([(0, scene.DENOISERS[name][0])])
     ex = HipExecutor(inst, W, H)
-    ex.set_graph_mode(not args.no_graph)
+    use_graph = args.graph and not args.no_graph
+    ex.set_graph_mode(use_graph)
     outputs = []
     for rt, dtype, ch, fmt in scene.output_planes(name, W, H):
         t = torch.zeros((H, W, ch), dtype=dtype, device="cuda")
@@ -450,7 +453,7 @@ def main():
         "data": "synthetic",
         "numerics": "exact",  # one library, one arithmetic: what is timed here is bit-identical to the CPU oracle (see "parity")
         "tile_fallback": {"tiles": tile_fallback[0], "of": tile_fallback[1], "what": "32x8-pixel tiles of the last frame's rect left to the plain TemporalAccumulation kernel (LDS window too small)"},
-        "launch": "eager" if args.no_graph else "hipGraph (%d launches, %d builds, %d node updates in the run)" % graph_stats,
+        "launch": "eager (one launch per pass, back to back)" if not use_graph else "hipGraph (%d launches, %d builds, %d node updates in the run)" % graph_stats,
         "rccl_ranks": world if distributed and backend == "nccl" else (0 if not distributed else None),
         "config": {"workload": "%s %dx%d, %s, analytic scene%s + 1rpp noise, moving camera" % (name, W, H, "default settings" if overrides is None else "settings %s" % overrides,
                                                                                                  " with a backdrop dome (no sky pixels)" if args.no_sky else ""),
