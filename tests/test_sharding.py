@@ -538,12 +538,18 @@ def test_halo_sharding_processes_over_gloo_on_emulated_kernels(name, world, W, H
     q = ctx.Queue()
     port = 29500 + (os.getpid() % 100) + world
     frames = 4
-    procs = [ctx.Process(target=_halo_two_process_emulated_worker, args=(r, world, port, name, W, H, frames, overrides, measure, q)) for r in range(world)]
-    for p in procs:
-        p.start()
-    results = sorted(q.get(timeout=900) for _ in procs)
-    for p in procs:
-        p.join(timeout=60)
+    # the workers (fresh processes) decode their guide planes only on the rows their passes declared (executor.hip GuideReachRows) and, with this hook, write NaNs
+    # everywhere else: a pass that reads a guide row outside its declared reach cannot stay bit-identical
+    os.environ["NRD_HIP_POISON_GUIDES"] = "1"
+    try:
+        procs = [ctx.Process(target=_halo_two_process_emulated_worker, args=(r, world, port, name, W, H, frames, overrides, measure, q)) for r in range(world)]
+        for p in procs:
+            p.start()
+        results = sorted(q.get(timeout=900) for _ in procs)
+        for p in procs:
+            p.join(timeout=60)
+    finally:
+        del os.environ["NRD_HIP_POISON_GUIDES"]
     # sharded frames: all but the restart frame (+ with measure: the frame after the fast one; the fast one itself falls back)
     assert results == [(r, True, frames - 1 + (1 if measure else 0), True) for r in range(world)], results
 
