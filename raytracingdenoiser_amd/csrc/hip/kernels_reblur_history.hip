@@ -217,7 +217,7 @@ __global__ __launch_bounds__(TILE_X* TILE_Y, SH ? 0 : NRD_WAVES_REBLUR_HF) void 
     __shared__ float s_SpecLuma[SPEC ? hf::BUF_Y * hf::BUF_STRIDE : 1];
 
     const int tx = threadIdx.x % TILE_X, ty = threadIdx.x / TILE_X;
-    const int blockY = blockIdx.y + rr.firstBlockY;
+    const int blockY = BlockTileY(rr);
     const int tileX = NRD_REBLUR_HF_ROTATE ? BlockTileXRotated(rr, blockY) : BlockTileX(rr); // (A/B switch: passes.h BlockTileXRotated)
     const int px = tileX * TILE_X + tx, py = blockY * TILE_Y + ty;
     const int rw = c.gRectSizeMinusOne.x, rh = c.gRectSizeMinusOne.y;
@@ -375,7 +375,7 @@ __global__ __launch_bounds__(TILE_X* TILE_Y, NRD_WAVES_REBLUR_TS) void ReblurTem
     __shared__ float s_SpecLuma[SPEC ? ts::BUF_Y * ts::BUF_STRIDE : 1];
 
     const int tx = threadIdx.x % TILE_X, ty = threadIdx.x / TILE_X;
-    const int blockY = blockIdx.y + rr.firstBlockY;
+    const int blockY = BlockTileY(rr);
     const int px = BlockTileX(rr) * TILE_X + tx, py = blockY * TILE_Y + ty;
     const int rw = c.gRectSizeMinusOne.x, rh = c.gRectSizeMinusOne.y;
 

@@ -497,7 +497,7 @@ __global__ __launch_bounds__(TILE_X* TILE_Y, NRD_WAVES_REBLUR_SPATIAL) void Rebl
     constexpr bool OCC = KIND == SIGNAL_OCCLUSION;
     typedef typename Sig::type S;
     const int px = BlockTileX(rr) * TILE_X + (threadIdx.x % TILE_X);
-    const int py = (blockIdx.y + rr.firstBlockY) * TILE_Y + (threadIdx.x / TILE_X);
+    const int py = (BlockTileY(rr)) * TILE_Y + (threadIdx.x / TILE_X);
     if (px > c.gRectSizeMinusOne.x || py > c.gRectSizeMinusOne.y || py < rr.rowBegin || py >= rr.rowEnd)
         return;
     if (LoadR8Unorm(P.tiles, px >> 4, py >> 4) != 0.0f)
@@ -678,7 +678,7 @@ template <bool DIFF, bool SPEC, int KIND>
 __global__ __launch_bounds__(256) void ReblurSplitScreenKernel(ReblurCB c, Plane viewZ, Plane inDiff, Plane inSpec, Plane outDiff, Plane outSpec, Plane inDiffSh, Plane inSpecSh, Plane outDiffSh,
     Plane outSpecSh, RowRange rr) {
     const int px = BlockTileX(rr) * TILE_X + (threadIdx.x % TILE_X);
-    const int py = (blockIdx.y + rr.firstBlockY) * TILE_Y + (threadIdx.x / TILE_X);
+    const int py = (BlockTileY(rr)) * TILE_Y + (threadIdx.x / TILE_X);
     if (px > c.gRectSizeMinusOne.x || py > c.gRectSizeMinusOne.y || py < rr.rowBegin || py >= rr.rowEnd)
         return;
     float pixelUvX = (float(px) + 0.5f) * c.gRectSizeInv.x;
@@ -749,7 +749,7 @@ __global__ __launch_bounds__(TILE_X* TILE_Y) void ReblurHitDistReconstructionKer
     constexpr bool OCC = KIND == SIGNAL_OCCLUSION;
     typedef typename Sig::type S;
     const int px = BlockTileX(rr) * TILE_X + (threadIdx.x % TILE_X);
-    const int py = (blockIdx.y + rr.firstBlockY) * TILE_Y + (threadIdx.x / TILE_X);
+    const int py = (BlockTileY(rr)) * TILE_Y + (threadIdx.x / TILE_X);
     const int rw = c.gRectSizeMinusOne.x, rh = c.gRectSizeMinusOne.y;
     if (px > rw || py > rh || py < rr.rowBegin || py >= rr.rowEnd)
         return;

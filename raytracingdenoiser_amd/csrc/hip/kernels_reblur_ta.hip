@@ -1018,7 +1018,7 @@ __device__ __forceinline__ void ReblurTemporalAccumulationTile(const ReblurCB& c
 constexpr int FALLBACK_TILES = 8;
 template <bool DIFF, bool SPEC, bool PERF, int KIND, bool SH, int WAVES, int MODE>
 __global__ __launch_bounds__(TILE_X* TILE_Y, WAVES) void ReblurTemporalAccumulationKernel(ReblurCB cArg, TaPlanes P, RowRange rr) {
-    const int blockY = blockIdx.y + rr.firstBlockY;
+    const int blockY = BlockTileY(rr, true);
     if (MODE != 2) {
         ReblurTemporalAccumulationTile<DIFF, SPEC, PERF, KIND, SH, MODE>(cArg, P, rr, BlockTileX(rr), blockY);
         return;

@@ -81,7 +81,7 @@ __global__ __launch_bounds__(256, NRD_WAVES_RELAX_ATROUS_SMEM) void RelaxAtrousS
     __shared__ float4 s_Diff[DIFF ? sm::BUF_SIZE : 1], s_DiffSH[(DIFF && SH) ? sm::BUF_SIZE : 1];
     __shared__ float4 s_Normal_Roughness[sm::BUF_SIZE], s_WorldPos_MaterialID[sm::BUF_SIZE];
 
-    const int blockY = blockIdx.y + rows.firstBlockY;
+    const int blockY = BlockTileY(rows, true);
     const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
     const int px = BlockTileX(rows) * TILE_X + tx, py = blockY * TILE_Y + ty;
     const int rectW = c.shared.gRectSize.x, rectH = c.shared.gRectSize.y;
@@ -439,7 +439,7 @@ __global__ __launch_bounds__(256, NRD_WAVES_RELAX_ATROUS) void RelaxAtrousKernel
     __shared__ float4 b_NR[BN], b_Pos[BN];
     __shared__ uint2 b_Spec[SPEC && BANDED ? BN : 1], b_Diff[DIFF && BANDED ? BN : 1], b_SpecSh[SPEC && SH && BANDED ? BN : 1], b_DiffSh[DIFF && SH && BANDED ? BN : 1];
 
-    const int blockY = blockIdx.y + rows.firstBlockY;
+    const int blockY = BlockTileY(rows, true);
     const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
     const int blockX0 = BlockTileX(rows) * TILE_X, blockY0 = blockY * TILE_Y;
     const int px = blockX0 + tx, py = blockY0 + ty;

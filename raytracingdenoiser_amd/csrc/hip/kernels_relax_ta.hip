@@ -739,7 +739,7 @@ __device__ __forceinline__ void RelaxTemporalAccumulationTile(const RelaxCB& cAr
 constexpr int FALLBACK_TILES = 8;
 template <bool DIFF, bool SPEC, bool SH, int MODE>
 __global__ __launch_bounds__(256, NRD_WAVES_RELAX_TA) void RelaxTemporalAccumulationKernel(RelaxCB cArg, TaPlanes P, RowRange rows) {
-    const int blockY = blockIdx.y + rows.firstBlockY;
+    const int blockY = BlockTileY(rows, true);
     if (MODE != 2) {
         RelaxTemporalAccumulationTile<DIFF, SPEC, SH, MODE>(cArg, P, rows, BlockTileX(rows), blockY);
         return;
@@ -981,7 +981,7 @@ __global__ __launch_bounds__(256, NRD_WAVES_RELAX_HC) void RelaxHistoryClampingK
     __shared__ float4 s_SpecFast[SPEC ? hc::BUF_SIZE : 1], s_SpecNoisy[SPEC ? hc::BUF_SIZE : 1];
     __shared__ float4 s_DiffFast[DIFF ? hc::BUF_SIZE : 1], s_DiffNoisy[DIFF ? hc::BUF_SIZE : 1];
 
-    const int blockY = blockIdx.y + rows.firstBlockY;
+    const int blockY = BlockTileY(rows, true);
     const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
     const int px = BlockTileX(rows) * TILE_X + tx, py = blockY * TILE_Y + ty;
     const int rectW = c.shared.gRectSize.x, rectH = c.shared.gRectSize.y;
