@@ -94,6 +94,16 @@ namespace Color
     }
 }
 
+// MathLib's debug text (font tables, Text::Print_*): NOT available and not restated -- the overlay shaders are compiled with a Text that prints nothing, which is what the
+// HIP library's validation kernels implement ("without MathLib's debug text", DESIGN.md section 1). Everything else the *_Validation shaders draw is the reference's own text.
+namespace Text
+{
+    static const uint Char_Minus = 45;
+    uint4 Init( int2 pixelPos, float2 origin, uint scale ) { return uint4( 0, 0, 0, 0 ); }
+    void Print_ch( uint c, inout uint4 state ) {}
+    bool IsForeground( uint4 state ) { return false; }
+}
+
 namespace Packing
 {
     // round( saturate( c ) * ( 2^bits - 1 ) ), least significant field first

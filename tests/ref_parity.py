@@ -121,7 +121,7 @@ def run_per_pass(name, width=192, height=128, frames=4, settings_overrides=None,
     prev = oracle_driver.set_ieee_mode(ieee)
     try:
         seq = parity.generate_sequence(name, width, height, frames, static_camera=static_camera, extra_want=extra_want, device="cpu")
-        run = parity.OracleRun(name, width, height)
+        run = parity.OracleRun(name, width, height, validation=bool((cs_kw or {}).get("enableValidation")))  # (the overlay plane OUT_VALIDATION is bound and compared like any output)
         cmp_ex = oracle_driver.ComparingExecutor(run.inst, width, height, api.FORMAT_BYTES, on_pass=on_pass, promote_fp16=promote_fp16, strict=strict, sensitivity=sensitivity)
         cmp_ex.user = run.ex.user  # the bound output planes
         if promote_fp16:  # the user's OUT_* planes double as scratch of the pass chain: promote the fp16 ones too

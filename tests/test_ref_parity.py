@@ -61,7 +61,7 @@ def test_the_library_holds_every_shader_the_dispatch_lists_can_name():
     missing = set()
     for name, (denoiser, _) in parity.DENOISERS.items():
         inst = api.Instance([(0, denoiser)])
-        missing |= {p for p in inst.pipelines if p not in shaders and "Validation" not in p}
+        missing |= {p for p in inst.pipelines if p not in shaders}
     assert not missing, missing  # (the validation overlays need MathLib's font tables: not built)
     assert len(shaders) >= 230
 
@@ -151,3 +151,12 @@ def test_a_whole_sequence_through_the_reference_text_denoises_like_the_oracle():
             assert st["frac_gt_tol"] <= 0.03 and st["bit_exact_frac"] >= 0.9, (rt.name, st)
     finally:
         oracle_driver.set_ieee_mode(prev)
+
+
+@pytest.mark.parametrize("name", ["REBLUR_DIFFUSE_SPECULAR", "RELAX_DIFFUSE_SPECULAR"])
+def test_validation_overlays_match_the_reference_text(name):
+    """CommonSettings::enableValidation: REBLUR_Validation.cs / RELAX_Validation.cs of the reference, compiled with a Text:: that prints nothing (MathLib's font tables are not
+    available -- oracle/ref/ml.hlsli), against the oracle's overlay: every viewport (normals, roughness, viewZ, motion vectors, world units, accumulated frames, ...) bit for bit"""
+    stats = ref_parity.run_per_pass(name, frames=3, cs_kw={"enableValidation": True}, sensitivity=False)
+    rows = [r for r in _check(stats, min_rows=10) if "Validation" in r["pass"]]
+    assert rows and all(r["bit_exact_frac"] == 1.0 and r["texel_values"] > 1e5 for r in rows), rows
