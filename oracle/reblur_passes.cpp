@@ -777,7 +777,7 @@ void TemporalAccumulation(const PassIO& io) {
 
             float disocclusionThresholdMix = 0.0f;
             if (materialID == c.gStrandMaterialID)
-                disocclusionThresholdMix = saturate(Div(c.gStrandThickness, pixelSize)); // NRD_GetNormalizedStrandThickness
+                disocclusionThresholdMix = Div(pixelSize, pixelSize + c.gStrandThickness); // NRD_GetNormalizedStrandThickness, NRD.hlsli:1158-1161 (round 4: was restated as saturate( thickness / pixelSize ); found by the per-pass comparison with the reference text)
             if (c.gHasDisocclusionThresholdMix)
                 disocclusionThresholdMix = gIn_DisocclusionThresholdMix.Load((int)c.gRectOrigin[0] + px, (int)c.gRectOrigin[1] + py).x;
             float disocclusionThreshold = lerp(c.gDisocclusionThreshold, c.gDisocclusionThresholdAlternate, disocclusionThresholdMix);

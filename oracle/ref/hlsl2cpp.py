@@ -84,7 +84,8 @@ def translate(text, shader_name):
     text = re.sub(r"(?<=[(,])(\s*)(?:inout|out)\s+((?:const\s+)?\w+)\s+(\w+)", r"\1\2& \3", text)
     text = re.sub(r"(?<=[(,])(\s*)in\s+((?:const\s+)?\w+\s+\w+)", r"\1\2", text)
 
-    # ---- group-shared memory
+    # ---- group-shared memory (+ the list of the arrays, for the per-group clear of hlsl_rt.cpp RunGroup)
+    shared_names = re.findall(r"\bgroupshared\s+[\w:<>]+\s+(\w+)\s*(?:\[[^\]]*\]\s*)*;", text)
     text = re.sub(r"\bgroupshared\b", "static thread_local", text)
 
     # ---- swizzles of scalars (and the same spelling on vectors: identical meaning)
@@ -102,9 +103,12 @@ def translate(text, shader_name):
             '#include "hlsl_shim.h"\n'
             'namespace hlsl { namespace {\n'
             'static hlsl_rt::ShaderTable* hlsl_table() { static hlsl_rt::ShaderTable* t = hlsl_rt::NewTable(); return t; }\n' % shader_name)
+    clear = "".join(" memset( (void*)&%s, 0, sizeof( %s ) );" % (n, n) for n in shared_names)
     tail = ('\nstatic void hlsl_thunk( const hlsl_rt::ThreadIds& ids ) { hlsl_cs_main( %s ); }\n'
+            'static void hlsl_clear_groupshared() {%s }\n'
             'static hlsl_rt::ShaderAdder hlsl_register( hlsl_table(), "%s", %d, %d, %s, hlsl_thunk );\n'
-            '} }\n' % (", ".join(thunk_args), shader_name, group[0], group[1], "true" if uses_barrier else "false"))
+            'static int hlsl_clear_registered = ( hlsl_rt::SetGroupSharedClear( hlsl_table(), hlsl_clear_groupshared ), 0 );\n'
+            '} }\n' % (", ".join(thunk_args), clear, shader_name, group[0], group[1], "true" if uses_barrier else "false"))
     return head + text + tail
 
 

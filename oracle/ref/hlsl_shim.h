@@ -636,6 +636,7 @@ struct ResourceReg {
 };
 struct ShaderTable; // per translation unit
 ShaderTable* NewTable();
+void SetGroupSharedClear(ShaderTable* t, void (*clear)());
 void AddConstant(ShaderTable* t, void* ptr, CbKind kind);
 void AddResource(ShaderTable* t, Plane* plane, bool output, int index, const char* name);
 void RegisterShader(ShaderTable* t, const char* fileName, int groupX, int groupY, bool usesBarrier, void (*thunk)(const ThreadIds&));

@@ -129,9 +129,12 @@ namespace Packing
         const uint Gshift = Rbits;
         const uint Bshift = Gshift + Gbits;
         const uint Ashift = Bshift + Bbits;
-        const float4 scale = 1.0 / max( float4( float( Rmask ), float( Gmask ), float( Bmask ), float( Amask ) ), 1.0 );
+        // field / ( 2^bits - 1 ) as a true quotient. [ml ambiguity] A reciprocal scale ( v * ( 1.0 / mask ) ), the other plausible MathLib form, is not exact: with the 4-bit
+        // material field of REBLUR's internal data ( mask 15 ) the IDs 3, 6, 7, 12, 13, 14 unpack to m * 15 * ( 1 / 15 ) = m + 1 ulp and CompareMaterials( m, m ) fails --
+        // material 3 of the 2-bit G-buffer field would never match its own history. The restatement ( oracle/ml.h, csrc/hip ) keeps IDs exact; so does this stand-in.
+        const float4 denom = max( float4( float( Rmask ), float( Gmask ), float( Bmask ), float( Amask ) ), 1.0 );
         uint4 v = uint4( p & Rmask, ( p >> Gshift ) & Gmask, ( p >> Bshift ) & Bmask, ( p >> Ashift ) & Amask );
-        return float4( v ) * scale;
+        return float4( v ) / denom;
     }
 }
 

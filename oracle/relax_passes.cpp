@@ -663,7 +663,7 @@ void TemporalAccumulation(const PassIO& io) {
             // disocclusion threshold
             float disocclusionThresholdMix = 0.0f;
             if (currentMaterialID == c.gStrandMaterialID)
-                disocclusionThresholdMix = saturate(Div(c.gStrandThickness, pixelSize)); // NRD_GetNormalizedStrandThickness
+                disocclusionThresholdMix = Div(pixelSize, pixelSize + c.gStrandThickness); // NRD_GetNormalizedStrandThickness, NRD.hlsli:1158-1161 (round 4: was restated as saturate( thickness / pixelSize ); found by the per-pass comparison with the reference text)
             if (c.gHasDisocclusionThresholdMix)
                 disocclusionThresholdMix = gIn_DisocclusionThresholdMix.Load(ox + px, oy + py).x;
             float disocclusionThreshold = lerp(c.gDisocclusionThreshold, c.gDisocclusionThresholdAlternate, disocclusionThresholdMix);

@@ -431,7 +431,7 @@ __device__ __forceinline__ void ReblurTemporalAccumulationTile(const ReblurCB& c
 
     float disocclusionThresholdMix = 0.0f;
     if (materialID == c.gStrandMaterialID)
-        disocclusionThresholdMix = Sat(Div(c.gStrandThickness, pixelSize));
+        disocclusionThresholdMix = Div(pixelSize, pixelSize + c.gStrandThickness); // NRD_GetNormalizedStrandThickness (reference NRD.hlsli:1158-1161)
     if (c.gHasDisocclusionThresholdMix)
         disocclusionThresholdMix = LoadR8Unorm(P.disocclusionThresholdMix, px, py);
     float disocclusionThreshold = Lerp(c.gDisocclusionThreshold, c.gDisocclusionThresholdAlternate, disocclusionThresholdMix);

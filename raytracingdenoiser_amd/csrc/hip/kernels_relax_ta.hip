@@ -206,7 +206,7 @@ __device__ __forceinline__ void RelaxTemporalAccumulationTile(const RelaxCB& cAr
     // disocclusion threshold
     float disocclusionThresholdMix = 0.0f;
     if (currentMaterialID == c.shared.gStrandMaterialID)
-        disocclusionThresholdMix = Sat(Div(c.shared.gStrandThickness, pixelSize));
+        disocclusionThresholdMix = Div(pixelSize, pixelSize + c.shared.gStrandThickness); // NRD_GetNormalizedStrandThickness (reference NRD.hlsli:1158-1161)
     if (c.shared.gHasDisocclusionThresholdMix)
         disocclusionThresholdMix = LoadR8Unorm(P.disocclusionThresholdMix, lpx, lpy);
     const float disocclusionThreshold = Lerp(c.shared.gDisocclusionThreshold, c.shared.gDisocclusionThresholdAlternate, disocclusionThresholdMix);

@@ -9,6 +9,7 @@ separates the two.
 usage: python tools/ref_trace.py DENOISER FRAMES FRAME X Y SHADER_SUBSTRING ORACLE_FILE:START:END [--contract | --device] [--head N]
   (default: the strict-IEEE oracle build; --contract: contraction on + a * rcp(b), IEEE transcendentals; --device: the arithmetic of the HIP library)
   e.g. python tools/ref_trace.py REBLUR_DIFFUSE_OCCLUSION 3 1 40 42 HistoryFix oracle/reblur_passes.cpp:1294:1515
+  options of the run through the environment: NRD_TRACE_OVERRIDES='{"minMaterialForDiffuse": 0}' NRD_TRACE_CS='{"strandMaterialID": 1}' NRD_TRACE_WANT=materials
 """
 import glob
 import os
@@ -119,7 +120,11 @@ if %(contract)r:
     traced.oracle_set_hw_tables.argtypes = [C.c_void_p] * 5
     traced.oracle_set_hw_tables(*[t.ctypes.data for t in driver._hw_tables])
 name = %(name)r
-seq = parity.generate_sequence(name, 192, 128, %(frames)d, device="cpu")
+import json
+overrides = json.loads(os.environ.get("NRD_TRACE_OVERRIDES", "null"))  # settings_overrides of tests/ref_parity.run_per_pass, as JSON
+cs_kw = json.loads(os.environ.get("NRD_TRACE_CS", "{}"))               # CommonSettings keywords, as JSON
+want = tuple(w for w in os.environ.get("NRD_TRACE_WANT", "").split(",") if w)  # extra_want of the frame generator ("materials", "confidence", ...)
+seq = parity.generate_sequence(name, 192, 128, %(frames)d, device="cpu", extra_want=want)
 run = parity.OracleRun(name, 192, 128)
 ex = driver.ComparingExecutor(run.inst, 192, 128, api.FORMAT_BYTES, strict=False)
 ex.lib = traced
@@ -128,7 +133,7 @@ run.ex = ex
 for f, frame in enumerate(seq):
     os.write(2, ("MARK FRAME %%d\n" %% f).encode())
     cam, camp = frame["camera"], seq[max(f - 1, 0)]["camera"]
-    run.step(frame, parity.common_settings(cam, camp, 192, 128, f), parity.denoiser_settings(name, frame, None))
+    run.step(frame, parity.common_settings(cam, camp, 192, 128, f, **cs_kw), parity.denoiser_settings(name, frame, overrides))
 ''' % dict(root=ROOT, lib_ref=lib_ref, lib_oracle=lib_oracle, contract=contract, device=device, name=name, frames=frames)
     env = dict(os.environ, NRD_TRACE_X=str(x), NRD_TRACE_Y=str(y), OMP_NUM_THREADS="1")
     with open(log, "w") as fp:
