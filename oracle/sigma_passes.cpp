@@ -112,9 +112,12 @@ void ClassifyTiles(const PassIO& io) {
     const Tex& gIn_Penumbra = io.t[k++];
     const Tex* gIn_Shadow_Translucency = TRANSLUCENT ? &io.t[k++] : nullptr;
     Tex& gOut_Tiles = io.t[k++];
+    // one thread group per 16x16 tile of the RECT (the dispatch grid of Sigma.cpp: ceil( rectSize / 16 )): tiles of the plane beyond it are left alone, as in the reference
+    // (round 4: this loop used to walk the whole resource-sized tile plane; found by the per-pass comparison under dynamic resolution)
+    const int tilesW = min(gOut_Tiles.W(), ((int)c.gRectSize.x + 15) / 16), tilesH = min(gOut_Tiles.H(), ((int)c.gRectSize.y + 15) / 16);
 #pragma omp parallel for schedule(static)
-    for (int ty = 0; ty < gOut_Tiles.H(); ty++)
-        for (int tx = 0; tx < gOut_Tiles.W(); tx++) {
+    for (int ty = 0; ty < tilesH; ty++)
+        for (int tx = 0; tx < tilesW; tx++) {
             uint32_t lit = 0, umbra = 0, inf = 0;
             float maxRadius = 0.0f;
             for (int j = 0; j < 16; j++)

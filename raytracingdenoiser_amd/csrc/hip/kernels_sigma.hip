@@ -125,10 +125,12 @@ NRD_D float LoadTileX(const Plane& tiles, int tx, int ty) { // .x of the RG8 smo
 template <bool TRANSLUCENT>
 __global__ __launch_bounds__(256) void SigmaClassifyTilesKernel(SigmaCB c, Plane viewZ, Plane penumbra, Plane translucency, Plane tiles) {
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    // the tiles of the RECT (the reference's dispatch grid, ceil( rectSize / 16 ) groups): tiles of the plane beyond it are left alone
+    const int tilesW = min(tiles.w, ((int)c.gRectSize.x + 15) >> 4), tilesH = min(tiles.h, ((int)c.gRectSize.y + 15) >> 4);
     const int tileIndex = blockIdx.x * 4 + wave;
-    if (tileIndex >= tiles.w * tiles.h)
+    if (tileIndex >= tilesW * tilesH)
         return;
-    const int tx = tileIndex % tiles.w, ty = tileIndex / tiles.w;
+    const int tx = tileIndex % tilesW, ty = tileIndex / tilesW;
     const int x0 = tx * 16 + (lane & 3) * 4, y = ty * 16 + (lane >> 2);
 
     bool allLit = true, allUmbra = true, allInf = true;

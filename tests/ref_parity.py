@@ -107,8 +107,11 @@ class PassStats:
         return out
 
 
-def run_per_pass(name, width=192, height=128, frames=4, settings_overrides=None, cs_kw=None, extra_want=(), static_camera=False, tol=1e-5, ieee=True, verbose=False, promote_fp16=False, strict=True, sensitivity=True):
-    """Runs `frames` frames of denoiser `name` through the oracle and, pass by pass on identical inputs, through oracle/_ref. Returns PassStats."""
+def run_per_pass(name, width=192, height=128, frames=4, settings_overrides=None, cs_kw=None, extra_want=(), static_camera=False, tol=1e-5, ieee=True, verbose=False, promote_fp16=False, strict=True, sensitivity=True,
+                 resource=None, rect_sizes=None):
+    """Runs `frames` frames of denoiser `name` through the oracle and, pass by pass on identical inputs, through oracle/_ref. Returns PassStats.
+    resource = (w, h) >= (width, height): dynamic resolution, the frame is the top-left rect of resource-sized planes; rect_sizes = [(w, h), ...]: the rect of frame f is
+    rect_sizes[f % len] inside `resource` (tests/parity.py run_parity has the same two options)."""
     stats = PassStats(tol)
 
     def on_pass(d, report):
@@ -120,9 +123,17 @@ def run_per_pass(name, width=192, height=128, frames=4, settings_overrides=None,
 
     prev = oracle_driver.set_ieee_mode(ieee)
     try:
-        seq = parity.generate_sequence(name, width, height, frames, static_camera=static_camera, extra_want=extra_want, device="cpu")
-        run = parity.OracleRun(name, width, height, validation=bool((cs_kw or {}).get("enableValidation")))  # (the overlay plane OUT_VALIDATION is bound and compared like any output)
-        cmp_ex = oracle_driver.ComparingExecutor(run.inst, width, height, api.FORMAT_BYTES, on_pass=on_pass, promote_fp16=promote_fp16, strict=strict, sensitivity=sensitivity)
+        if rect_sizes:
+            seq = [parity.synth.render_frame(*rect_sizes[f % len(rect_sizes)], f, static_camera=static_camera, want=tuple(parity.DENOISERS[name][1]) + tuple(extra_want)) for f in range(frames)]
+        else:
+            seq = parity.generate_sequence(name, width, height, frames, static_camera=static_camera, extra_want=extra_want, device="cpu")
+        cs_kw = dict(cs_kw or {})
+        if resource:
+            seq = [parity.embed_in_resource(fr, resource) for fr in seq]
+            cs_kw.update(resourceSize=resource, resourceSizePrev=resource)
+        rw, rh = resource or (width, height)
+        run = parity.OracleRun(name, rw, rh, validation=bool((cs_kw or {}).get("enableValidation")))  # (the overlay plane OUT_VALIDATION is bound and compared like any output)
+        cmp_ex = oracle_driver.ComparingExecutor(run.inst, rw, rh, api.FORMAT_BYTES, on_pass=on_pass, promote_fp16=promote_fp16, strict=strict, sensitivity=sensitivity)
         cmp_ex.user = run.ex.user  # the bound output planes
         if promote_fp16:  # the user's OUT_* planes double as scratch of the pass chain: promote the fp16 ones too
             for rt, (arr, fmt) in list(run.outs.items()):
@@ -131,9 +142,11 @@ def run_per_pass(name, width=192, height=128, frames=4, settings_overrides=None,
                     run.outs[rt] = (big, F.RGBA32_SFLOAT)
                     cmp_ex.bind(rt, big, F.RGBA32_SFLOAT)
         run.ex = cmp_ex
-        cs_kw = dict(cs_kw or {})
         for f, frame in enumerate(seq):
             cam, cam_prev = frame["camera"], seq[max(f - 1, 0)]["camera"]
+            if rect_sizes:
+                width, height = rect_sizes[f % len(rect_sizes)]
+                cs_kw.update(rectSize=(width, height), rectSizePrev=rect_sizes[max(f - 1, 0) % len(rect_sizes)])
             cs = parity.common_settings(cam, cam_prev, width, height, f, **cs_kw)
             parity.tag_checkerboard(frame, settings_overrides, f)
             run.step(frame, cs, parity.denoiser_settings(name, frame, settings_overrides))

@@ -120,6 +120,18 @@ def test_options_match_the_reference_shader_text(name, overrides, cs_kw):
     _check(stats, min_rows=10)
 
 
+@pytest.mark.parametrize("name, kw", [
+    ("REBLUR_DIFFUSE_SPECULAR", dict(resource=(192, 128), rect_sizes=[(192, 128), (144, 96), (96, 64)])),  # the rect changes every frame (gRectSizePrev != gRectSize, resolution scales)
+    ("RELAX_DIFFUSE_SPECULAR_SH", dict(resource=(192, 128), rect_sizes=[(144, 96), (192, 128)])),
+    ("SIGMA_SHADOW_TRANSLUCENCY", dict(resource=(192, 128), rect_sizes=[(192, 128), (150, 100), (96, 64)])),
+    ("SIGMA_SHADOW", dict(width=144, height=96, resource=(192, 128))),  # found in round 4: the tile classification wrote the tiles of the PLANE, the reference's grid covers the RECT
+])
+def test_dynamic_resolution_matches_the_reference_shader_text(name, kw):
+    rows = _check(ref_parity.run_per_pass(name, frames=4, sensitivity=False, **kw), min_rows=10)
+    if name.startswith("SIGMA"):
+        assert min(r["bit_exact_frac"] for r in rows) >= 0.9999
+
+
 @pytest.mark.parametrize("name", ["REBLUR_DIFFUSE_SPECULAR", "RELAX_DIFFUSE_SPECULAR_SH", "SIGMA_SHADOW"])
 def test_the_librarys_arithmetic_against_the_reference_shader_text_one_pass_at_a_time(name):
     """The oracle in DEVICE mode is, bit for bit, what the HIP library computes (tests -m gpu). Held against the reference's text pass by pass on identical inputs,
