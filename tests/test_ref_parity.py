@@ -97,6 +97,16 @@ def test_every_pass_matches_the_reference_shader_text_remaining_denoisers(name):
     ("REBLUR_DIFFUSE_SPECULAR", None, dict(splitScreen=0.4)),
     ("RELAX_DIFFUSE_SPECULAR", None, dict(splitScreen=0.4)),
     ("SIGMA_SHADOW", None, dict(splitScreen=0.4)),
+    ("REBLUR_DIFFUSE_SPECULAR", None, dict(isMotionVectorInWorldSpace=False, motionVectorScale=(1.0 / 192, 1.0 / 128, 0.0))),  # 2D motion vectors
+    ("RELAX_DIFFUSE_SPECULAR", None, dict(isMotionVectorInWorldSpace=False, motionVectorScale=(1.0 / 192, 1.0 / 128, 1.0))),  # 2.5D
+    ("REBLUR_DIFFUSE_SPECULAR", None, dict(cameraJitter=(0.3, -0.2), cameraJitterPrev=(-0.1, 0.25))),
+    ("RELAX_DIFFUSE_SPECULAR", None, dict(cameraJitter=(0.3, -0.2), cameraJitterPrev=(-0.1, 0.25))),
+    ("RELAX_DIFFUSE_SPECULAR", {"atrousIterationNum": 2, "diffuseMaxAccumulatedFrameNum": 4, "specularMaxAccumulatedFrameNum": 6, "historyFixFrameNum": 1}, None),
+    ("RELAX_DIFFUSE_SPECULAR_SH", {"atrousIterationNum": 8}, None),
+    ("REBLUR_DIFFUSE_SPECULAR_OCCLUSION", {"hitDistanceReconstructionMode": 2, "checkerboardMode": 1}, None),
+    ("REBLUR_DIFFUSE_SPECULAR_SH", {"enableAntiFirefly": True, "maxAccumulatedFrameNum": 5, "maxFastAccumulatedFrameNum": 2}, None),
+    ("REBLUR_DIFFUSE_SPECULAR", None, dict(denoisingRange=20.0, disocclusionThreshold=0.003)),
+    ("SIGMA_SHADOW", {"maxStabilizedFrameNum": 0}, None),
     # material IDs in the G-buffer, material tests on, the strand and the camera-attached-reflection materials in use. This case found a misreading in round 4
     # (NRD_GetNormalizedStrandThickness restated as saturate( thickness / pixelSize ); NRD.hlsli:1158-1161 says pixelSize / ( pixelSize + thickness )) and an
     # ambiguity of the un-vendored MathLib (Packing::UintToRgba with a reciprocal scale does not return material 3 of a 4-bit field exactly: oracle/ref/ml.hlsli)
