@@ -138,6 +138,8 @@ class OracleExecutor:
         # blocks whose gRectOrigin / gRectOffset are zero.
         ox, oy = self._rect_origin(dispatches)
         saved = {}
+        self._origin_of_frame = (ox, oy)
+        self._unshifted = saved  # (ComparingExecutor hands the reference's viewport-offset build the planes and constants as the application passed them)
         if ox or oy:
             guide = {int(getattr(self.api.ResourceType, n)) for n in self._GUIDE_INPUTS}
             for key in [k for k in self.user if k in guide]:
@@ -173,27 +175,28 @@ class OracleExecutor:
 
 # ---- oracle/_ref: the reference's own HLSL shaders compiled as C++ (oracle/ref/Makefile) ------------------------------------------------------------
 REF_LIB_PATH = os.path.join(_DIR, "_ref", "libnrdref.so")
-_ref_lib = None
+REF_VO_LIB_PATH = os.path.join(_DIR, "_ref", "libnrdref_vo.so")  # the NRD_USE_VIEWPORT_OFFSET = 1 build of one denoiser per family (oracle/ref/Makefile "vo")
+_ref_libs = {}
 
 
-def ref_available():
-    return os.path.exists(REF_LIB_PATH)
+def ref_available(path=None):
+    return os.path.exists(path or REF_LIB_PATH)
 
 
-def load_ref():
-    global _ref_lib
-    if _ref_lib is None:
-        if not ref_available():
-            raise RuntimeError("oracle/_ref not built: run `make -C oracle/ref -j8` (needs /root/reference)")
-        lib = C.CDLL(REF_LIB_PATH)
+def load_ref(path=None):
+    path = path or REF_LIB_PATH
+    if path not in _ref_libs:
+        if not os.path.exists(path):
+            raise RuntimeError("%s not built: run `make -C oracle/ref -j8 [vo]` (needs /root/reference)" % os.path.relpath(path, os.path.dirname(_DIR)))
+        lib = C.CDLL(path)
         lib.nrdref_dispatch.argtypes = [C.c_char_p, C.c_void_p, C.c_uint32, C.POINTER(OraclePlane), C.c_uint32, C.c_uint32, C.c_uint32]
         lib.nrdref_dispatch.restype = C.c_int
         lib.nrdref_has.argtypes, lib.nrdref_has.restype = [C.c_char_p], C.c_int
         lib.nrdref_count.argtypes, lib.nrdref_count.restype = [], C.c_int
         lib.nrdref_name.argtypes, lib.nrdref_name.restype = [C.c_int], C.c_char_p
         lib.nrdref_set_threads.argtypes, lib.nrdref_set_threads.restype = [C.c_int], C.c_int
-        _ref_lib = lib
-    return _ref_lib
+        _ref_libs[path] = lib
+    return _ref_libs[path]
 
 
 def ref_shaders():
@@ -267,13 +270,13 @@ class ComparingExecutor(OracleExecutor):
     output planes to `on_pass(dispatch, [(resource, fmt, width, oracle_array, ref_array, [oracle arrays in other arithmetics]), ...])`. The sequence continues on the oracle's results, so there
     is no recurrence in the comparison: every difference is the difference of ONE pass."""
 
-    def __init__(self, *a, on_pass=None, strict=True, sensitivity=False, **kw):
+    def __init__(self, *a, on_pass=None, strict=True, sensitivity=False, ref_lib_path=None, **kw):
         """strict: "the oracle" is liboracle_strict.so (no contraction, true divisions) -- the arithmetic of the reference text; False: liboracle.so in
         whatever mode set_ieee_mode selected (the arithmetic contract the HIP library is held against)"""
         super().__init__(*a, **kw)
         if strict:
             self.lib = load_strict()
-        self.ref = load_ref()
+        self.ref = load_ref(ref_lib_path)
         self.on_pass = on_pass
         self.sensitivity = sensitivity
 
@@ -302,12 +305,36 @@ class ComparingExecutor(OracleExecutor):
                     raise RuntimeError("oracle has no pass '%s'" % d.shader)
                 alts.append([a[0].copy() for a in arrays])
                 restore()
-        rc = self.ref.nrdref_dispatch(d.shader.encode(), buf, len(constants), planes, len(d.resources), d.grid[0], d.grid[1])
+        ref_buf, ref_size, ref_planes = buf, len(constants), planes
+        unshifted = getattr(self, "_unshifted", None)
+        if unshifted:
+            # CommonSettings::rectOrigin != 0: the oracle's passes run on rect-at-origin twins of the guide inputs with gRectOrigin / gRectOffset zeroed (execute()); the reference
+            # -- its NRD_USE_VIEWPORT_OFFSET = 1 build, REF_VO_LIB_PATH -- gets what the application passed: the planes as bound and the constant block of the dispatch
+            ref_buf, ref_size = C.create_string_buffer(d.constants, len(d.constants)), len(d.constants)
+            def plane_of(res):
+                arr, fmt, w, h = unshifted.get(int(res[1]), None) or self._array(res)
+                return OraclePlane(arr.ctypes.data, arr.strides[0], int(fmt), w, h)
+            ref_planes = (OraclePlane * len(d.resources))(*[plane_of(r) for r in d.resources])
+            written = {i: unshifted[int(r[1])][0] for i, r in enumerate(d.resources) if r[0] == self.api.DescriptorType.STORAGE_TEXTURE and int(r[1]) in unshifted}
+            written_before = {i: a.copy() for i, a in written.items()}
+        rc = self.ref.nrdref_dispatch(d.shader.encode(), ref_buf, ref_size, ref_planes, len(d.resources), d.grid[0], d.grid[1])
         if rc != 0:
             raise RuntimeError("oracle/_ref cannot run '%s' (code %d)" % (d.shader, rc))
         theirs_all = [a[0].copy() for a in arrays]
+        if unshifted:
+            # an application plane the pass WRITES (IN_MV: Clear_Float on restart, REBLUR's specular motion-vector patch): the reference wrote the plane as bound; what is
+            # compared with the oracle's rect-at-origin twin is the same window of it
+            ox, oy = self._origin_of_frame
+            for i, arr in written.items():
+                theirs_all[i] = np.zeros_like(arr)
+                theirs_all[i][: arr.shape[0] - oy, : arr.shape[1] - ox] = arr[oy:, ox:]
+                arr[...] = written_before[i]
         restore()
         super()._run(d, constants, planes)  # last: the sequence continues on these results
+        if unshifted:
+            for i, arr in written.items():  # ... in the application's plane too (the following passes of the frame read it at rectOrigin + pixel)
+                twin = arrays[i][0]
+                arr[oy:, ox:] = twin[: arr.shape[0] - oy, : arr.shape[1] - ox]
         report = []
         for i, (res, a, b, theirs) in enumerate(zip(d.resources, arrays, before, theirs_all)):
             m = a[0]

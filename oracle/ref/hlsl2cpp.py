@@ -29,9 +29,11 @@ SEMANTICS = {"SV_GroupThreadId": "groupThreadId", "SV_GroupId": "groupId", "SV_D
              "SV_GroupThreadID": "groupThreadId", "SV_GroupID": "groupId", "SV_DispatchThreadID": "dispatchThreadId"}
 
 
-def preprocess(entry, reference):
+def preprocess(entry, reference, include_first=None):
+    """include_first: a directory searched in front of the reference's own Include directory (the viewport-offset build of oracle/ref/Makefile puts a Common.hlsli there whose
+    NRD_USE_VIEWPORT_OFFSET is 1 -- the reference makes that switch an edit of the file, Common.hlsli:64)"""
     shaders = os.path.join(reference, "Shaders")
-    cmd = [CLANG, "-E", "-x", "c", "-undef", "-nostdinc", "-Wno-everything", "-I", HERE, "-I", os.path.join(shaders, "Include"), "-I", os.path.join(shaders, "Resources"),
+    cmd = [CLANG, "-E", "-x", "c", "-undef", "-nostdinc", "-Wno-everything", "-I", HERE] + (["-I", include_first] if include_first else []) + ["-I", os.path.join(shaders, "Include"), "-I", os.path.join(shaders, "Resources"),
            "-include", os.path.join(HERE, "prelude.hlsli"), "-DNRD_NORMAL_ENCODING=2", "-DNRD_ROUGHNESS_ENCODING=1", entry]
     return subprocess.run(cmd, check=True, capture_output=True, text=True).stdout
 
@@ -119,6 +121,11 @@ def main():
         i = args.index("--reference")
         reference = args[i + 1]
         del args[i:i + 2]
+    include_first = None
+    if "--include-first" in args:
+        i = args.index("--include-first")
+        include_first = args[i + 1]
+        del args[i:i + 2]
     keep = "--keep-preprocessed" in args
     if keep:
         args.remove("--keep-preprocessed")
@@ -126,7 +133,7 @@ def main():
     name = os.path.basename(entry)
     assert name.endswith(".cs.hlsl"), name
     shader_name = name[:-len(".hlsl")]
-    pre = preprocess(entry, reference)
+    pre = preprocess(entry, reference, include_first)
     if keep:
         with open(out + ".i", "w") as fp:
             fp.write(pre)

@@ -26,6 +26,25 @@ def _split_packed(shader, fmt, a, b):
     return None
 
 
+def embed_guides_at(frame, resource, origin):
+    """a rect-sized generated frame inside resource-sized planes: guide inputs at `origin`, everything else (noisy inputs) at (0, 0) -- the layout the reference
+    addresses with CommonSettings::rectOrigin (Common.hlsli:200-206 WithRectOrigin: guides only)"""
+    import torch
+
+    rw, rh = resource
+    ox, oy = origin
+    guides = ("mv", "normal_roughness", "viewz", "diff_confidence", "spec_confidence", "disocclusion_mix", "basecolor_metalness")
+    out = {}
+    for k, v in frame.items():
+        if torch.is_tensor(v) and v.dim() >= 2 and v.dtype != torch.bool:
+            big = torch.full([rh, rw] + list(v.shape[2:]), 33.0 if v.dtype.is_floating_point else 9, dtype=v.dtype, device=v.device)
+            x0, y0 = (ox, oy) if k in guides else (0, 0)
+            big[y0 : y0 + v.shape[0], x0 : x0 + v.shape[1]] = v
+            v = big
+        out[k] = v
+    return out
+
+
 class PassStats:
     """per (pass, output plane): texel counts by size of the difference between the two oracles"""
 
@@ -108,10 +127,11 @@ class PassStats:
 
 
 def run_per_pass(name, width=192, height=128, frames=4, settings_overrides=None, cs_kw=None, extra_want=(), static_camera=False, tol=1e-5, ieee=True, verbose=False, promote_fp16=False, strict=True, sensitivity=True,
-                 resource=None, rect_sizes=None):
+                 resource=None, rect_sizes=None, rect_origin=None):
     """Runs `frames` frames of denoiser `name` through the oracle and, pass by pass on identical inputs, through oracle/_ref. Returns PassStats.
     resource = (w, h) >= (width, height): dynamic resolution, the frame is the top-left rect of resource-sized planes; rect_sizes = [(w, h), ...]: the rect of frame f is
-    rect_sizes[f % len] inside `resource` (tests/parity.py run_parity has the same two options)."""
+    rect_sizes[f % len] inside `resource` (tests/parity.py run_parity has the same two options). rect_origin = (ox, oy) with `resource`: CommonSettings::rectOrigin -- the guide
+    inputs live at that offset inside their planes, everything else at (0, 0); compared with the reference's NRD_USE_VIEWPORT_OFFSET = 1 build (oracle/_ref/libnrdref_vo.so)."""
     stats = PassStats(tol)
 
     def on_pass(d, report):
@@ -129,11 +149,14 @@ def run_per_pass(name, width=192, height=128, frames=4, settings_overrides=None,
             seq = parity.generate_sequence(name, width, height, frames, static_camera=static_camera, extra_want=extra_want, device="cpu")
         cs_kw = dict(cs_kw or {})
         if resource:
-            seq = [parity.embed_in_resource(fr, resource) for fr in seq]
+            seq = [embed_guides_at(fr, resource, rect_origin) if rect_origin else parity.embed_in_resource(fr, resource) for fr in seq]
             cs_kw.update(resourceSize=resource, resourceSizePrev=resource)
+            if rect_origin:
+                cs_kw.update(rectOrigin=rect_origin)
         rw, rh = resource or (width, height)
         run = parity.OracleRun(name, rw, rh, validation=bool((cs_kw or {}).get("enableValidation")))  # (the overlay plane OUT_VALIDATION is bound and compared like any output)
-        cmp_ex = oracle_driver.ComparingExecutor(run.inst, rw, rh, api.FORMAT_BYTES, on_pass=on_pass, promote_fp16=promote_fp16, strict=strict, sensitivity=sensitivity)
+        cmp_ex = oracle_driver.ComparingExecutor(run.inst, rw, rh, api.FORMAT_BYTES, on_pass=on_pass, promote_fp16=promote_fp16, strict=strict, sensitivity=sensitivity,
+                                                      ref_lib_path=oracle_driver.REF_VO_LIB_PATH if rect_origin else None)
         cmp_ex.user = run.ex.user  # the bound output planes
         if promote_fp16:  # the user's OUT_* planes double as scratch of the pass chain: promote the fp16 ones too
             for rt, (arr, fmt) in list(run.outs.items()):

@@ -54,7 +54,7 @@ def build_oracle(spec, contract):
 def build_ref(shader):
     import autotrace
 
-    gen = os.path.join(ROOT, "oracle", "_ref", "gen")
+    gen = os.path.join(ROOT, "oracle", "_ref", os.environ.get("NRD_TRACE_GEN", "gen"))  # NRD_TRACE_GEN=gen_vo: the viewport-offset build (oracle/ref/Makefile "vo")
     src = os.path.join(gen, shader[:-3] + ".cpp")  # "<name>.cs" -> "<name>.cpp"
     dst = os.path.join(TMP, "ref_traced.cpp")
     text = open(src).read().split("\n")
@@ -80,6 +80,8 @@ def build_ref(shader):
     subprocess.run([CXX, "-std=c++17", "-O1", "-fPIC", "-ffp-contract=off", "-fno-fast-math", "-fvisibility=hidden", "-I", os.path.join(ROOT, "oracle", "ref"), "-Wno-gnu-anonymous-struct",
                     "-Wno-nested-anon-types", "-Wno-constant-logical-operand", "-Wno-unused-value", "-c", dst, "-o", obj], check=True)
     others = [o for o in glob.glob(os.path.join(gen, "*.o")) if os.path.basename(o) != shader[:-3] + ".o"]
+    if not any(os.path.basename(o) == "hlsl_rt.o" for o in others):
+        others.append(os.path.join(ROOT, "oracle", "_ref", "gen", "hlsl_rt.o"))
     lib = os.path.join(TMP, "libnrdref_trace.so")
     subprocess.run([CXX, "-shared", "-fopenmp", "-Wl,-rpath,/opt/rocm/lib/llvm/lib", "-o", lib, obj] + others, check=True)
     return lib
@@ -124,7 +126,13 @@ import json
 overrides = json.loads(os.environ.get("NRD_TRACE_OVERRIDES", "null"))  # settings_overrides of tests/ref_parity.run_per_pass, as JSON
 cs_kw = json.loads(os.environ.get("NRD_TRACE_CS", "{}"))               # CommonSettings keywords, as JSON
 want = tuple(w for w in os.environ.get("NRD_TRACE_WANT", "").split(",") if w)  # extra_want of the frame generator ("materials", "confidence", ...)
-seq = parity.generate_sequence(name, 192, 128, %(frames)d, device="cpu", extra_want=want)
+origin = tuple(int(v) for v in os.environ["NRD_TRACE_ORIGIN"].split(",")) if os.environ.get("NRD_TRACE_ORIGIN") else None  # rectOrigin: a 144x96 rect in 192x128 planes
+RW, RH = (144, 96) if origin else (192, 128)
+seq = parity.generate_sequence(name, RW, RH, %(frames)d, device="cpu", extra_want=want)
+if origin:
+    import ref_parity
+    seq = [ref_parity.embed_guides_at(fr, (192, 128), origin) for fr in seq]
+    cs_kw.update(resourceSize=(192, 128), resourceSizePrev=(192, 128), rectOrigin=origin)
 run = parity.OracleRun(name, 192, 128)
 ex = driver.ComparingExecutor(run.inst, 192, 128, api.FORMAT_BYTES, strict=False)
 ex.lib = traced
@@ -133,7 +141,7 @@ run.ex = ex
 for f, frame in enumerate(seq):
     os.write(2, ("MARK FRAME %%d\n" %% f).encode())
     cam, camp = frame["camera"], seq[max(f - 1, 0)]["camera"]
-    run.step(frame, parity.common_settings(cam, camp, 192, 128, f, **cs_kw), parity.denoiser_settings(name, frame, overrides))
+    run.step(frame, parity.common_settings(cam, camp, RW, RH, f, **cs_kw), parity.denoiser_settings(name, frame, overrides))
 ''' % dict(root=ROOT, lib_ref=lib_ref, lib_oracle=lib_oracle, contract=contract, device=device, name=name, frames=frames)
     env = dict(os.environ, NRD_TRACE_X=str(x), NRD_TRACE_Y=str(y), OMP_NUM_THREADS="1")
     with open(log, "w") as fp:
