@@ -142,6 +142,19 @@ def test_dynamic_resolution_matches_the_reference_shader_text(name, kw):
         assert min(r["bit_exact_frac"] for r in rows) >= 0.9999
 
 
+@pytest.mark.parametrize("name, size", [
+    ("REBLUR_DIFFUSE_SPECULAR", (65, 47)), ("REBLUR_DIFFUSE_SPECULAR", (17, 9)), ("REBLUR_DIFFUSE_SPECULAR", (211, 117)),
+    ("RELAX_DIFFUSE_SPECULAR", (65, 47)), ("RELAX_DIFFUSE_SPECULAR", (17, 9)),
+    ("SIGMA_SHADOW", (65, 47)), ("SIGMA_SHADOW", (17, 9)), ("SIGMA_SHADOW", (211, 117)),
+])
+def test_ragged_and_tiny_frames_match_the_reference_shader_text(name, size):
+    """frames that are not multiples of the 8x16 / 16x16 / 32x8 groups and tiles of the reference (clamped footprints, partial tiles, groups beyond the rect, a frame
+    smaller than one tile) -- the sizes tests/test_edge_sizes.py and tests/test_reblur.py hold the HIP library to the oracle on"""
+    rows = _check(ref_parity.run_per_pass(name, frames=3, sensitivity=False, width=size[0], height=size[1]), min_rows=10)
+    if name.startswith("SIGMA"):
+        assert all(r["bit_exact_frac"] == 1.0 for r in rows)
+
+
 # CommonSettings::rectOrigin ("enable NRD_USE_VIEWPORT_OFFSET if used": Common.hlsli:64, 200-206 -- an edit of the shader source, so oracle/ref/Makefile builds a second
 # library, libnrdref_vo.so, from a generated copy of that one file). NRDSettings.h describes the origin as the window of the rect inside the guide inputs (IN_MV,
 # IN_NORMAL_ROUGHNESS, IN_VIEWZ, the confidences, the mix, IN_BASECOLOR_METALNESS); the library and the oracle address EVERY read of those inputs at origin + pixel.
