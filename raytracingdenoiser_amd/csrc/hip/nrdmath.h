@@ -39,8 +39,15 @@ namespace nrdhip {
 #define NRD_CURVATURE_Z_THRESHOLD 0.1f
 
 // ------------------------------------------------------------------------------------------------ scalar intrinsics
+#if defined(NRD_NATIVE_MINMAX) && NRD_NATIVE_MINMAX
+// EXPERIMENT (tools/build_variant.py, not the product, not mirrored by the oracle): v_min_f32 / v_max_f32 -- what an HLSL compiler emits for min / max. Differs from the
+// compare + select below only when an operand is NaN (the other operand is returned) or the operands are zeros of opposite sign; priced in DESIGN.md section 8.
+NRD_D float Min(float a, float b) { return __builtin_fminf(a, b); }
+NRD_D float Max(float a, float b) { return __builtin_fmaxf(a, b); }
+#else
 NRD_D float Min(float a, float b) { return a < b ? a : b; }
 NRD_D float Max(float a, float b) { return a > b ? a : b; }
+#endif
 NRD_D float Clamp(float x, float a, float b) { return Min(Max(x, a), b); }
 NRD_D float Sat(float x) { return Min(Max(x, 0.0f), 1.0f); }
 NRD_D float Lerp(float a, float b, float t) { return a + (b - a) * t; }
