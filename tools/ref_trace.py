@@ -169,7 +169,10 @@ def compare(log, frame, head):
         for k in range(min(len(a), len(b))):
             if a[k][0] != b[k][0]:
                 rel = abs(float(a[k][1]) - float(b[k][1])) / max(abs(float(a[k][1])), 1e-30)
-                print("DIFF %-40s #%d ref %s %-16s ora %s %-16s rel %.2g" % (tag, k, a[k][0], a[k][1], b[k][0], b[k][1], rel))
+                # the k-th occurrence of a name is compared with the k-th occurrence on the other side: only meaningful when both sides assign the name equally often
+                # (a declaration with an initialiser on one side, a loop that runs a different number of times on the other: marked, read with care)
+                note = "" if len(a) == len(b) else "   [occurrences: ref %d, ora %d -- possibly misaligned]" % (len(a), len(b))
+                print("DIFF %-40s #%d ref %s %-16s ora %s %-16s rel %.2g%s" % (tag, k, a[k][0], a[k][1], b[k][0], b[k][1], rel, note))
                 shown += 1
                 break
         if shown >= head:
