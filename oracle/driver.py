@@ -176,7 +176,31 @@ class OracleExecutor:
 # ---- oracle/_ref: the reference's own HLSL shaders compiled as C++ (oracle/ref/Makefile) ------------------------------------------------------------
 REF_LIB_PATH = os.path.join(_DIR, "_ref", "libnrdref.so")
 REF_VO_LIB_PATH = os.path.join(_DIR, "_ref", "libnrdref_vo.so")  # the NRD_USE_VIEWPORT_OFFSET = 1 build of one denoiser per family (oracle/ref/Makefile "vo")
+REF_HOST_LIB_PATH = os.path.join(_DIR, "_ref", "libnrdhost.so")  # the reference's own HOST sources (Source/*.cpp) over a MathLib stand-in (oracle/ref/host/Makefile)
 _ref_libs = {}
+
+
+def load_ref_host():
+    """oracle/_ref/libnrdhost.so with the prototypes of the reference's C entry points (NRD.h) -- the same ctypes structures raytracingdenoiser_amd.api binds the product with, so
+    api.Instance(denoisers, lib=load_ref_host()) IS the reference's nrd::Instance"""
+    from raytracingdenoiser_amd import api
+
+    if REF_HOST_LIB_PATH in _ref_libs:
+        return _ref_libs[REF_HOST_LIB_PATH]
+    lib = C.CDLL(REF_HOST_LIB_PATH)
+    P = C.POINTER
+    lib.CreateInstance.argtypes, lib.CreateInstance.restype = [P(api.InstanceCreationDesc), P(C.c_void_p)], C.c_uint32
+    lib.DestroyInstance.argtypes, lib.DestroyInstance.restype = [C.c_void_p], None
+    lib.GetLibraryDesc.argtypes, lib.GetLibraryDesc.restype = [], P(api.LibraryDesc)
+    lib.GetInstanceDesc.argtypes, lib.GetInstanceDesc.restype = [C.c_void_p], P(api.InstanceDesc)
+    lib.SetCommonSettings.argtypes, lib.SetCommonSettings.restype = [C.c_void_p, P(api.CommonSettings)], C.c_uint32
+    lib.SetDenoiserSettings.argtypes, lib.SetDenoiserSettings.restype = [C.c_void_p, C.c_uint32, C.c_void_p], C.c_uint32
+    lib.GetComputeDispatches.argtypes = [C.c_void_p, P(C.c_uint32), C.c_uint32, P(P(api.DispatchDesc)), P(C.c_uint32)]
+    lib.GetComputeDispatches.restype = C.c_uint32
+    lib.GetResourceTypeString.argtypes, lib.GetResourceTypeString.restype = [C.c_uint32], C.c_char_p
+    lib.GetDenoiserString.argtypes, lib.GetDenoiserString.restype = [C.c_uint32], C.c_char_p
+    _ref_libs[REF_HOST_LIB_PATH] = lib
+    return lib
 
 
 def ref_available(path=None):

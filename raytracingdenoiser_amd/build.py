@@ -124,6 +124,8 @@ def build_ref(verbose=False, reference="/root/reference"):
     out = os.path.join(ORACLE_DIR, "_ref", "libnrdref.so")
     if not os.path.isdir(os.path.join(reference, "Shaders", "Source")):
         return out if os.path.exists(out) else None
+    # oracle/_ref/libnrdhost.so: the reference's own host sources over a MathLib stand-in (oracle/ref/host/Makefile)
+    subprocess.run(["make", "-C", os.path.join(ORACLE_DIR, "ref", "host"), "-j8", "REFERENCE=" + reference] + ([] if verbose else ["-s"]), check=True)
     for target in ([], ["vo"]):  # "vo": one denoiser per family with NRD_USE_VIEWPORT_OFFSET = 1 (CommonSettings::rectOrigin; oracle/ref/Makefile)
         cmd = ["make", "-C", os.path.join(ORACLE_DIR, "ref"), "-j8", "REFERENCE=" + reference] + target + ([] if verbose else ["-s"])
         subprocess.run(cmd, check=True)

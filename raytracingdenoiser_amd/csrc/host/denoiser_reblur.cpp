@@ -156,7 +156,7 @@ void InstanceImpl::Add_Reblur(DenoiserData& d, bool hasDiff, bool hasSpec, bool 
 
     char passName[96], shader[128];
     auto Pass = [&](const char* what) {
-        snprintf(passName, sizeof(passName), "REBLUR_%s - %s", family, what);
+        snprintf(passName, sizeof(passName), "REBLUR_%s - %s", directionalOcclusion ? "DirectionalOcclusion" : family, what); // (sic: Reblur_DiffuseDirectionalOcclusion.hpp:13 DENOISER_NAME)
         BeginPass(InternString(passName));
     };
     // registers the {quality, performance} pair of a pass
@@ -355,7 +355,7 @@ void InstanceImpl::Add_Reblur(DenoiserData& d, bool hasDiff, bool hasSpec, bool 
     In(hasDiff ? IN_DIFF : IN_SPEC); // a single-signal denoiser binds its input twice (REBLUR_ADD_VALIDATION_DISPATCH call sites)
     In(hasSpec ? IN_SPEC : IN_DIFF);
     Out(ResourceType::OUT_VALIDATION);
-    EndPass("REBLUR_Validation.cs", 8, 16, sizeof(nrdc::ReblurValidationConstants), IGNORE_RS);
+    EndPass("REBLUR_Validation.cs", 8, 16, (uint32_t(sizeof(nrdc::ReblurValidationConstants)) + 15u) & ~15u, IGNORE_RS); // (rounded like the reference host struct)
 }
 
 void InstanceImpl::Update_Reblur(const DenoiserData& d) {
@@ -594,7 +594,7 @@ void InstanceImpl::Add_ReblurOcclusion(DenoiserData& d, bool hasDiff, bool hasSp
     In(hasDiff ? IN_DIFF : IN_SPEC);
     In(hasSpec ? IN_SPEC : IN_DIFF);
     Out(ResourceType::OUT_VALIDATION);
-    EndPass("REBLUR_Validation.cs", 8, 16, sizeof(nrdc::ReblurValidationConstants), IGNORE_RS);
+    EndPass("REBLUR_Validation.cs", 8, 16, (uint32_t(sizeof(nrdc::ReblurValidationConstants)) + 15u) & ~15u, IGNORE_RS); // (rounded like the reference host struct)
 }
 
 void InstanceImpl::Update_ReblurOcclusion(const DenoiserData& d) {

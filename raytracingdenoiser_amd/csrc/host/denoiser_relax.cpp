@@ -57,7 +57,8 @@ void InstanceImpl::Add_Relax(DenoiserData& d, bool hasDiff, bool hasSpec, bool s
     d.settings.relax = RelaxSettings();
     d.settingsSize = sizeof(RelaxSettings);
     const uint32_t constSize = sizeof(nrdc::RelaxConstants);
-    const uint32_t atrousConstSize = sizeof(nrdc::RelaxAtrousConstants);
+    // (the reference's host struct holds 16-byte aligned float4 members: its sizeof -- the dispatch's constantBufferDataSize -- is the 712 bytes of fields rounded up to 720)
+    const uint32_t atrousConstSize = (uint32_t(sizeof(nrdc::RelaxAtrousConstants)) + 15u) & ~15u;
 
     // ---- pools; "spec" planes precede "diff" planes, an SH1 plane directly follows its SH0 plane
     uint16_t nextPermanent = PERMANENT_POOL_START, nextTransient = TRANSIENT_POOL_START;
@@ -81,8 +82,15 @@ void InstanceImpl::Add_Relax(DenoiserData& d, bool hasDiff, bool hasSpec, bool s
         s.responsivePrev = Permanent(Format::RGBA16_SFLOAT);
         if (sh) s.responsivePrevSh = Permanent(Format::RGBA16_SFLOAT);
     };
-    if (hasSpec) AddSignalHistory(spec);
-    if (hasDiff) AddSignalHistory(diff);
+    if (hasSpec && hasDiff && !sh) { // sic: the one variant whose table interleaves the two signals (Relax_DiffuseSpecular.hpp:19-22; found by tests/test_ref_host.py)
+        spec.prev = Permanent(Format::RGBA16_SFLOAT);
+        diff.prev = Permanent(Format::RGBA16_SFLOAT);
+        spec.responsivePrev = Permanent(Format::RGBA16_SFLOAT);
+        diff.responsivePrev = Permanent(Format::RGBA16_SFLOAT);
+    } else {
+        if (hasSpec) AddSignalHistory(spec);
+        if (hasDiff) AddSignalHistory(diff);
+    }
     uint16_t P_HIT_T_CURR = 0, P_HIT_T_PREV = 0;
     if (hasSpec) {
         P_HIT_T_CURR = Permanent(Format::R16_SFLOAT);

@@ -77,7 +77,9 @@ static void FillSigmaConstants(const SigmaSettings& s, const CommonSettings& cs,
 void InstanceImpl::Add_SigmaShadow(DenoiserData& d, bool translucent) {
     d.settings.sigma = SigmaSettings();
     d.settingsSize = sizeof(SigmaSettings);
-    const uint32_t constSize = sizeof(nrdc::SigmaConstants);
+    // the reference's host-side struct of the shared constants holds 16-byte aligned float4 members, so its sizeof -- the constantBufferDataSize of every SIGMA dispatch --
+    // is the 516 bytes of fields rounded up to 528 (Sigma.cpp:93-96 SharedConstants; what a D3D constant buffer of this block occupies too); the tail is zero
+    const uint32_t constSize = (uint32_t(sizeof(nrdc::SigmaConstants)) + 15u) & ~15u;
     const Format shadowFormat = translucent ? Format::RGBA8_UNORM : Format::R8_UNORM;
     char family[40], passName[96], shader[96];
     snprintf(family, sizeof(family), "%s", translucent ? "SIGMA_ShadowTranslucency" : "SIGMA_Shadow");

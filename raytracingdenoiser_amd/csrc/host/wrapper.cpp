@@ -9,17 +9,17 @@ namespace {
 
 // Denoisers this build implements end-to-end (host tables + HIP kernels). Everything else reports UNSUPPORTED from
 // CreateInstance, exactly like a reference build asked for a denoiser it was compiled without.
-const nrd::Denoiser g_Supported[] = {
+const nrd::Denoiser g_Supported[] = { // in enum order, like the reference's list (Wrapper.cpp:23-44)
     nrd::Denoiser::REBLUR_DIFFUSE,
-    nrd::Denoiser::REBLUR_SPECULAR,
-    nrd::Denoiser::REBLUR_DIFFUSE_SPECULAR,
+    nrd::Denoiser::REBLUR_DIFFUSE_OCCLUSION,
     nrd::Denoiser::REBLUR_DIFFUSE_SH,
+    nrd::Denoiser::REBLUR_SPECULAR,
+    nrd::Denoiser::REBLUR_SPECULAR_OCCLUSION,
     nrd::Denoiser::REBLUR_SPECULAR_SH,
+    nrd::Denoiser::REBLUR_DIFFUSE_SPECULAR,
+    nrd::Denoiser::REBLUR_DIFFUSE_SPECULAR_OCCLUSION,
     nrd::Denoiser::REBLUR_DIFFUSE_SPECULAR_SH,
     nrd::Denoiser::REBLUR_DIFFUSE_DIRECTIONAL_OCCLUSION,
-    nrd::Denoiser::REBLUR_DIFFUSE_OCCLUSION,
-    nrd::Denoiser::REBLUR_SPECULAR_OCCLUSION,
-    nrd::Denoiser::REBLUR_DIFFUSE_SPECULAR_OCCLUSION,
     nrd::Denoiser::RELAX_DIFFUSE,
     nrd::Denoiser::RELAX_DIFFUSE_SH,
     nrd::Denoiser::RELAX_SPECULAR,
