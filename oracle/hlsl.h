@@ -16,7 +16,8 @@
 // PARITY: pinned to the reference's own shader text since round 4. The reference ships no CPU implementation, no tests and no golden vectors, but its
 // shaders compile as C++ over a small HLSL shim (oracle/ref/ -> oracle/_ref/libnrdref.so, built from the sources where they lie under /root/reference), and
 // every pass of this restatement is compared with them on identical inputs (tests/test_ref_parity.py; fixtures recorded from them: tests/golden/ref_text_*.npz,
-// tests/test_ref_golden.py). What stays "parity unpinned" is MathLib alone (NVIDIA-RTX/MathLib, fetched unpinned at configure time -- reference
+// tests/test_ref_golden.py); the reference's host sources compile too (oracle/ref/host/ -> oracle/_ref/libnrdhost.so) and pin the dispatch lists and constant blocks the passes are
+// handed (tests/test_ref_host.py). What stays "parity unpinned" is MathLib alone (NVIDIA-RTX/MathLib, fetched unpinned at configure time -- reference
 // CMakeLists.txt:118-127 -- and absent): definitions marked [ml] restate it from its public behaviour and from anchors inside the reference.
 #pragma once
 
