@@ -207,3 +207,75 @@ def test_reference_accumulator_tables():
         (ra, da), (rb, db) = a.get_compute_dispatches(), b.get_compute_dispatches()
         assert ra == rb
         assert [(d.shader, d.name, d.grid, d.resources, d.constants) for d in da] == [(d.shader, d.name, d.grid, d.resources, d.constants) for d in db], f
+
+
+def _fuzz_struct(rng, obj, keep=()):
+    """every scalar field of a ctypes settings struct set to a random value of its type (floats in [0, 2) with an occasional 0 / large value, counters 0..40, mode bytes 0..2, flags)"""
+    import ctypes as C
+
+    def value(t, name):
+        if t is C.c_float:
+            r = rng.random()
+            return 0.0 if r < 0.05 else (float(rng.integers(1, 500)) if r < 0.1 else float(np.float32(rng.random() * 2.0)))
+        if t is C.c_bool:
+            return bool(rng.integers(0, 2))
+        if t is C.c_ubyte:
+            return int(rng.integers(0, 3))
+        if t is C.c_uint:
+            return int(rng.integers(0, 41))
+        if t is C.c_ushort:
+            return int(rng.integers(1, 300))
+        raise TypeError((name, t))
+
+    for name, t in obj._fields_:
+        if name in keep:
+            continue
+        if hasattr(t, "_length_"):
+            arr = getattr(obj, name)
+            for i in range(t._length_):
+                arr[i] = value(t._type_, name)
+        else:
+            setattr(obj, name, value(t, name))
+    return obj
+
+
+@pytest.mark.parametrize("name", ["REBLUR_DIFFUSE_SPECULAR", "REBLUR_SPECULAR_OCCLUSION", "REBLUR_DIFFUSE_SH", "RELAX_DIFFUSE_SPECULAR", "RELAX_SPECULAR_SH", "SIGMA_SHADOW_TRANSLUCENCY"])
+def test_fuzzed_settings_produce_the_same_dispatches(name):
+    """40 frames of random denoiser settings and random common settings (valid cameras from the scene generator, everything else drawn at random, invalid combinations included: the two
+    hosts must then agree on the error code): whatever a field does to the dispatch list or to a constant, it does the same in both"""
+    ref = oracle_driver.load_ref_host()
+    den = parity.DENOISERS[name][0]
+    a, b = api.Instance([(0, den)]), api.Instance([(0, den)], lib=ref)
+    rng = np.random.default_rng(sum(map(ord, name)))
+    seq = parity.generate_sequence(name, 96, 64, 4, device="cpu")
+    accepted = dispatches = 0
+    for f in range(40):
+        cam, camp = seq[f % 4]["camera"], seq[(f - 1) % 4]["camera"]
+        cs = parity.common_settings(cam, camp, 96, 64, f)
+        _fuzz_struct(rng, cs, keep=("viewToClipMatrix", "viewToClipMatrixPrev", "worldToViewMatrix", "worldToViewMatrixPrev", "worldPrevToWorldMatrix", "frameIndex", "timeDeltaBetweenFrames"))
+        cs.frameIndex = f
+        for k in range(2):  # rect inside the resource (the hosts do not check it; the shaders would read outside)
+            cs.rectSize[k] = min(cs.rectSize[k], cs.resourceSize[k])
+            cs.rectSizePrev[k] = min(cs.rectSizePrev[k], cs.resourceSizePrev[k])
+            cs.cameraJitter[k], cs.cameraJitterPrev[k] = cs.cameraJitter[k] * 0.3 - 0.25, cs.cameraJitterPrev[k] * 0.3 - 0.25
+        st = _fuzz_struct(rng, parity.denoiser_settings(name, seq[f % 4], None))
+        ra, rb = a.set_common_settings(cs), b.set_common_settings(cs)
+        assert ra == rb, (f, ra, rb)
+        assert a.set_denoiser_settings(0, st) == b.set_denoiser_settings(0, st)
+        if ra != api.Result.SUCCESS:
+            continue
+        accepted += 1
+        (ra, da), (rb, db) = a.get_compute_dispatches(), b.get_compute_dispatches()
+        assert ra == rb
+        assert [(d.shader, d.name, d.grid, d.resources) for d in da] == [(d.shader, d.name, d.grid, d.resources) for d in db], f
+        for x, y in zip(da, db):
+            dispatches += 1
+            if x.constants != y.constants:
+                assert len(x.constants) == len(y.constants)
+                ia, ib = np.frombuffer(x.constants, np.uint32), np.frombuffer(y.constants, np.uint32)
+                fa, fb = np.frombuffer(x.constants, np.float32), np.frombuffer(y.constants, np.float32)
+                ne = np.nonzero(ia != ib)[0]
+                with np.errstate(all="ignore"):
+                    rel = np.abs(fa[ne] - fb[ne]) / np.maximum(np.abs(fb[ne]), 1e-6)
+                assert np.nanmax(rel) <= 1e-6, (f, x.shader, ne[:8].tolist(), fa[ne][:4], fb[ne][:4])
+    assert accepted >= 10 and dispatches >= 60, (accepted, dispatches)
