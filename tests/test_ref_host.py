@@ -279,3 +279,28 @@ def test_fuzzed_settings_produce_the_same_dispatches(name):
                     rel = np.abs(fa[ne] - fb[ne]) / np.maximum(np.abs(fb[ne]), 1e-6)
                 assert np.nanmax(rel) <= 1e-6, (f, x.shader, ne[:8].tolist(), fa[ne][:4], fb[ne][:4])
     assert accepted >= 10 and dispatches >= 60, (accepted, dispatches)
+
+
+@pytest.mark.skipif(not oracle_driver.ref_available(), reason="oracle/_ref/libnrdref.so not built")
+@pytest.mark.parametrize("name", ["REBLUR_DIFFUSE_SPECULAR", "RELAX_DIFFUSE_SPECULAR_SH", "SIGMA_SHADOW", "REBLUR_DIFFUSE_SPECULAR_SH"])  # (the last: the KNOWN pool difference changes no output)
+def test_the_complete_reference_host_and_shader_text_equals_the_products_host_driving_the_same_text(name):
+    """The reference end to end on the CPU -- its own host code emitting the dispatches, its own shader text executing them (oracle/_ref/libnrdhost.so + libnrdref.so) -- against
+    the product's host emitting the dispatches for the same shader text: every user output of every frame bit for bit. (That the product's KERNELS compute what that text computes is
+    tests/test_ref_parity.py and the GPU suite; this closes the loop over the host.)"""
+    w, h, frames = 96, 64, 4
+    seq = parity.generate_sequence(name, w, h, frames, device="cpu")
+    runs = []
+    for lib in (None, oracle_driver.load_ref_host()):
+        run = parity.OracleRun(name, w, h)
+        if lib is not None:
+            run.inst = api.Instance([(0, parity.DENOISERS[name][0])], lib=lib)
+        ex = oracle_driver.RefExecutor(run.inst, w, h, api.FORMAT_BYTES)
+        ex.user = run.ex.user
+        run.ex = ex
+        runs.append(run)
+    for f, frame in enumerate(seq):
+        cam, cam_prev = frame["camera"], seq[max(f - 1, 0)]["camera"]
+        for run in runs:
+            run.step(frame, parity.common_settings(cam, cam_prev, w, h, f), parity.denoiser_settings(name, frame, None))
+        for rt in runs[0].outs:
+            assert np.array_equal(np.asarray(runs[0].output(rt)), np.asarray(runs[1].output(rt)), equal_nan=True), (f, rt.name)
