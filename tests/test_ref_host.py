@@ -304,3 +304,33 @@ def test_the_complete_reference_host_and_shader_text_equals_the_products_host_dr
             run.step(frame, parity.common_settings(cam, cam_prev, w, h, f), parity.denoiser_settings(name, frame, None))
         for rt in runs[0].outs:
             assert np.array_equal(np.asarray(runs[0].output(rt)), np.asarray(runs[1].output(rt)), equal_nan=True), (f, rt.name)
+
+
+def _instance_desc_view(inst):
+    d = inst.desc
+    pipes = []
+    for i in range(d.pipelinesNum):
+        p = d.pipelines[i]
+        pipes.append((p.shaderFileName, p.shaderEntryPointName, p.hasConstantData, p.computeShaderDXBC.size, p.computeShaderDXIL.size, p.computeShaderSPIRV.size,
+                      [(p.resourceRanges[k].descriptorType, p.resourceRanges[k].baseRegisterIndex, p.resourceRanges[k].descriptorsNum) for k in range(p.resourceRangesNum)]))
+    pool = d.descriptorPoolDesc
+    return dict(constantBufferMaxDataSize=d.constantBufferMaxDataSize, constantBufferSpaceIndex=d.constantBufferSpaceIndex, constantBufferRegisterIndex=d.constantBufferRegisterIndex,
+                samplers=[d.samplers[i] for i in range(d.samplersNum)], samplersSpaceIndex=d.samplersSpaceIndex, samplersBaseRegisterIndex=d.samplersBaseRegisterIndex,
+                resourcesSpaceIndex=d.resourcesSpaceIndex, pipelines=pipes,
+                descriptorPool=(pool.setsMaxNum, pool.constantBuffersMaxNum, pool.samplersMaxNum, pool.texturesMaxNum, pool.storageTexturesMaxNum))
+
+
+@pytest.mark.parametrize("name", list(parity.DENOISERS) + ["REFERENCE", "MIXED"])
+def test_the_whole_instance_desc(name):
+    """every field of nrd::InstanceDesc an integration layer allocates from: register / space indices, samplers, per-pipeline resource ranges, entry-point names, the
+    descriptor-pool budget, the largest constant block"""
+    ref = oracle_driver.load_ref_host()
+    if name == "MIXED":
+        dens = [(1, parity.DENOISERS["REBLUR_DIFFUSE_SPECULAR_OCCLUSION"][0]), (2, parity.DENOISERS["RELAX_SPECULAR"][0]), (3, parity.DENOISERS["SIGMA_SHADOW_TRANSLUCENCY"][0]), (4, api.Denoiser.REFERENCE)]
+    else:
+        dens = [(0, api.Denoiser.REFERENCE if name == "REFERENCE" else parity.DENOISERS[name][0])]
+    va, vb = _instance_desc_view(api.Instance(dens)), _instance_desc_view(api.Instance(dens, lib=ref))
+    for key in va:
+        if name in KNOWN and key == "descriptorPool":
+            continue  # (one texture fewer in the transient pool: see KNOWN)
+        assert va[key] == vb[key], (key, va[key], vb[key])
