@@ -193,3 +193,70 @@ def test_frontend_header_device_results_match_the_oracle_and_a_float64_model():
     ok = ~near_threshold & (np.abs(M.dot(f64["Nw"], N)) > 1e-6)
     close(d["rejitter"][ok & (rough >= 0.1)], rj[ok & (rough >= 0.1)], 5e-4, "NRD_SG_ReJitter (roughness >= 0.1)")
     close(d["rejitter"][ok & (rough < 0.1)], rj[ok & (rough < 0.1)], 1e-2, "NRD_SG_ReJitter (roughness < 0.1: the GGX terms with m^2 -> 0 in float32)")
+
+
+@pytest.mark.skipif(not __import__("oracle.driver", fromlist=["x"]).ref_available(), reason="oracle/_ref/libnrdref.so not built (needs /root/reference)")
+def test_frontend_header_equals_the_reference_nrd_hlsli_text():
+    """include/NRD.hip.h evaluated on the host (frontend_check --dump-host; the GPU test above holds device == host) against the REFERENCE'S OWN NRD.hlsli: a probe shader of this
+    repository (oracle/ref/probes/NRD_FrontEndProbe.cs.hlsl) that only calls the reference's functions on the same 16 384 rows of inputs is compiled through the path of every reference
+    entry (oracle/ref/hlsl2cpp.py -> oracle/_ref/libnrdref.so). NRD.hlsli does not use MathLib, so this comparison has no stand-in in it. Every packer, unpacker, the material factors,
+    the SG colour / direction, the diffuse resolves: BIT FOR BIT. NRD_SG_ResolveSpecular: bit for bit for roughness >= 0.05 -- below, its SG inner product evaluates
+    exp( d - sharpness_a - sharpness_b ) with sharpness = 2 / roughness^4 > 3e5 (NRD.hlsli:586, 1030), a cancellation in which one ulp of d moves the result by whole factors in ANY two
+    fp32 evaluations; NRD_SH_ResolveSpecular and NRD_SG_ReJitter within 4e-6 of the texel's largest component, >= 98 % of the values bit for bit (a sum of products associates differently)."""
+    import ctypes as C
+
+    from oracle import driver as oracle_driver
+    from raytracingdenoiser_amd import api
+
+    _build()
+    W = H = 128
+    count = W * H
+    path = os.path.join(os.path.dirname(EXE), "frontend_dump_host.bin")
+    r = subprocess.run([EXE, "--dump-host", path, str(count)], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout + r.stderr
+    d = _load_dump(path, count)
+    os.remove(path)
+    F = api.Format
+
+    def tex(cols):
+        a, k = np.zeros((H, W, 4), np.float32), 0
+        for col in cols:
+            col = np.asarray(col, np.float32).reshape(count, -1)
+            a[..., k:k + col.shape[1]] = col.reshape(H, W, -1)
+            k += col.shape[1]
+        return a
+
+    i = np.arange(count)
+    ins = [tex([d["N"], d["roughness"]]), tex([d["V"], d["materialID_in"]]), tex([d["radiance"], d["hitDist"]]), tex([d["direction"], d["viewZ"]]),
+           tex([d["albedo"], (i % 5 == 0).astype(np.float32)]), tex([d["Rf0"]]), tex([d["Nw"]])]
+    word_in = np.ascontiguousarray(d["word"][:, 0].reshape(H, W).astype(np.uint32))
+    word_out = np.zeros((H, W), np.uint32)
+    outs = [np.zeros((H, W, 4), np.float32) for _ in range(19)]
+    P = oracle_driver.OraclePlane
+    planes = [P(a.ctypes.data, a.strides[0], int(F.RGBA32_SFLOAT), W, H) for a in ins]
+    planes += [P(word_in.ctypes.data, word_in.strides[0], int(F.R10_G10_B10_A2_UNORM), W, H), P(word_out.ctypes.data, word_out.strides[0], int(F.R10_G10_B10_A2_UNORM), W, H)]
+    planes += [P(a.ctypes.data, a.strides[0], int(F.RGBA32_SFLOAT), W, H) for a in outs]
+    arr = (P * len(planes))(*planes)
+    consts = np.array([3.0, 0.1, 20.0, -25.0], np.float32).tobytes() + np.array([W], np.uint32).tobytes() + bytes(12)
+    buf = C.create_string_buffer(consts, len(consts))
+    assert oracle_driver.load_ref().nrdref_dispatch(b"NRD_FrontEndProbe.cs", buf, len(consts), arr, len(planes), W // 8, H // 8) == 0
+
+    assert np.array_equal(word_out.reshape(-1), d["word"][:, 0])  # NRD_FrontEnd_PackNormalAndRoughness through an R10G10B10A2_UNORM store
+    exact = {"unpackedNR": 0, "reblurPacked": 2, "reblurUnpacked": 3, "sh0": 4, "sh1": 5, "relaxPacked": 6, "relaxSh1": 7, "dirOcc": 8, "translucency": 9, "specFactor": 11,
+             "sgDiffuse": 12, "shDiffuse": 14, "sgColor": 16, "sgDir": 17}
+    for name, k in exact.items():
+        got = outs[k].reshape(count, 4)[:, : d[name].shape[1]]
+        assert np.array_equal(got.view(np.uint32), np.ascontiguousarray(d[name]).view(np.uint32)), name
+    scalars = outs[1].reshape(count, 4)
+    for k, name in enumerate(["normHitDist", "penumbra", "penumbraLocal", "shadow"]):
+        assert np.array_equal(scalars[:, k].view(np.uint32), np.ascontiguousarray(d[name][:, 0]).view(np.uint32)), name
+    dm = outs[10].reshape(count, 4)
+    assert np.array_equal(dm[:, :3].view(np.uint32), np.ascontiguousarray(d["diffFactor"]).view(np.uint32)) and np.array_equal(dm[:, 3], d["materialID"][:, 0])
+    well = d["roughness"][:, 0] >= 0.05
+    assert well.sum() > 0.9 * count
+    assert np.array_equal(outs[13].reshape(count, 4)[well][:, :3].view(np.uint32), np.ascontiguousarray(d["sgSpecular"][well]).view(np.uint32))
+    for k, name, n in ((15, "shSpecular", 3), (18, "rejitter", 2)):  # relative to the texel's largest component: a chroma that cancels to ~1e-8 carries the rounding of the O(1) terms
+        got, want = outs[k].reshape(count, 4)[well][:, :n].astype(np.float64), d[name][well].astype(np.float64)
+        err = np.abs(got - want) / np.maximum(np.abs(want).max(axis=1, keepdims=True), 1e-3)
+        assert err.max() <= 4e-6, (name, err.max())
+        assert (got == want).mean() >= 0.98, name
