@@ -71,8 +71,8 @@ def _compare(name, frames, settings_overrides=None, cs_kw=None, size=(96, 64), r
                     rel = np.abs(fa[ne] - fb[ne]) / np.maximum(np.abs(fb[ne]), 1e-6)
                 if not np.nanmax(rel) <= 1e-6:
                     issues.append("frame %d %s constants: dwords %s, product %s, reference %s" % (f, x.shader, ne[:8].tolist(), fa[ne][:4], fb[ne][:4]))
-    known = KNOWN.get(name, ())
-    left = [i for i in issues if not any(k.split(" grid")[0] in i and ("grid" not in k or "grid" in i) for k in known)]
+    known = KNOWN.get(name, ())  # each entry: words that all occur in the message of an expected difference
+    left = [i for i in issues if not any(all(word in i for word in k.split()) for k in known)]
     assert not left, "\n".join(left[:12])
     assert compared >= frames * 2
     return issues
