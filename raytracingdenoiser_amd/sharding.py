@@ -589,7 +589,8 @@ def dry_plan(name, width, height, world, overrides=None, max_motion_rows=None, e
     from . import api, scene, synth
 
     inst = api.Instance([(0, scene.DENOISERS[name][0])])
-    frames = [synth.render_frame(32, 18, f, device="cpu", want=()) for f in range(3)]  # cameras of the bench sequence (the planes themselves are not needed)
+    # cameras of the bench sequence (the planes themselves are not needed; the SIGMA settings carry the scene's light direction, which comes with its planes)
+    frames = [synth.render_frame(32, 18, f, device="cpu", want=("sigma",) if name.startswith("SIGMA") else ()) for f in range(3)]
     settings = scene.denoiser_settings(name, frames[0], overrides)
     assert inst.set_denoiser_settings(0, settings) == api.Result.SUCCESS
     max_motion_rows = HaloSharder.default_motion_rows(height) if max_motion_rows is None else max_motion_rows

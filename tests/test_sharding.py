@@ -615,3 +615,17 @@ def test_camera_motion_estimate_and_fallback_decision():
     assert sh.motion_exceeds_halo(motion_rows=29.0)  # the application's own bound for moving objects counts on top
     inst.last_common_settings = parity.common_settings(pitched(a, 1.5), a, w, h, 11)
     assert sh.motion_exceeds_halo()
+
+
+def test_dry_plan_runs_for_every_bench_workload():
+    """bench.py --gpus N --dry-plan: host only (no GPU, no process group) for all workloads, including the SIGMA one whose settings need the scene's light direction"""
+    import bench
+    from raytracingdenoiser_amd import sharding
+
+    for workload, (name, size, _, overrides) in bench.WORKLOADS.items():
+        plan = sharding.dry_plan(name, size[0], size[1], 4, overrides)
+        assert plan["denoiser"] == name and plan["ranks"] == 4 and len(plan["per_rank"]) == 4, workload
+        if name.startswith("SIGMA"):
+            assert all(r["fallback_unsharded"] for r in plan["per_rank"])  # its passes declare no reach: the 0.1-ms chain runs as replicas (DESIGN.md section 6)
+        else:
+            assert not plan["per_rank"][1]["fallback_unsharded"] and plan["per_rank"][1]["received_bytes_per_frame"] > 0, workload
