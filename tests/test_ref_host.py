@@ -239,7 +239,7 @@ def _fuzz_struct(rng, obj, keep=()):
     return obj
 
 
-@pytest.mark.parametrize("name", ["REBLUR_DIFFUSE_SPECULAR", "REBLUR_SPECULAR_OCCLUSION", "REBLUR_DIFFUSE_SH", "RELAX_DIFFUSE_SPECULAR", "RELAX_SPECULAR_SH", "SIGMA_SHADOW_TRANSLUCENCY"])
+@pytest.mark.parametrize("name", [n for n in parity.DENOISERS if n not in KNOWN])
 def test_fuzzed_settings_produce_the_same_dispatches(name):
     """40 frames of random denoiser settings and random common settings (valid cameras from the scene generator, everything else drawn at random, invalid combinations included: the two
     hosts must then agree on the error code): whatever a field does to the dispatch list or to a constant, it does the same in both"""
