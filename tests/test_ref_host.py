@@ -239,7 +239,7 @@ def _fuzz_struct(rng, obj, keep=()):
     return obj
 
 
-@pytest.mark.parametrize("name", [n for n in parity.DENOISERS if n not in KNOWN])
+@pytest.mark.parametrize("name", list(parity.DENOISERS))
 def test_fuzzed_settings_produce_the_same_dispatches(name):
     """40 frames of random denoiser settings and random common settings (valid cameras from the scene generator, everything else drawn at random, invalid combinations included: the two
     hosts must then agree on the error code): whatever a field does to the dispatch list or to a constant, it does the same in both"""
@@ -267,7 +267,8 @@ def test_fuzzed_settings_produce_the_same_dispatches(name):
         accepted += 1
         (ra, da), (rb, db) = a.get_compute_dispatches(), b.get_compute_dispatches()
         assert ra == rb
-        assert [(d.shader, d.name, d.grid, d.resources) for d in da] == [(d.shader, d.name, d.grid, d.resources) for d in db], f
+        tile_clear = lambda d: name in KNOWN and d.shader == "Clear_Float.cs" and d.resources[0][1:] == (api.ResourceType.TRANSIENT_POOL, 9)  # (KNOWN: only its grid differs)
+        assert [(d.shader, d.name, None if tile_clear(d) else d.grid, d.resources) for d in da] == [(d.shader, d.name, None if tile_clear(d) else d.grid, d.resources) for d in db], f
         for x, y in zip(da, db):
             dispatches += 1
             if x.constants != y.constants:
