@@ -31,7 +31,7 @@ def pytest_collection_modifyitems(config, items):
     # Developer mode without a GPU: NRD_PARITY_BACKEND=emu runs the parity tests of the -m gpu suite on the CPU emulation of the device sources
     # (tests/emu: the .hip files compiled for x86 over a HIP shim). Tests that need the real runtime (graphs, streams, torch.cuda tensors, RCCL) stay skipped.
     emu = os.environ.get("NRD_PARITY_BACKEND") == "emu"
-    cuda_only = ("test_sharding", "test_sharded_cpp", "test_integration_cpp", "test_frontend_header", "test_full_size", "test_graph_mode", "test_unsupported_dispatch", "test_range_without", "test_numerics", "test_abi", "test_reference", "bit_exact_at_baseline_size",
+    cuda_only = ("test_sharding", "test_sharded_cpp", "test_integration_cpp", "test_frontend_header", "test_full_size", "test_graph_mode", "test_unsupported_dispatch", "test_range_without", "test_numerics", "test_abi", "test_reference", "at_baseline_size",
                  "test_motion_rows.py::test_motion_rows_")  # (the last: its emulated twins run in the CPU suite)
     skip = pytest.mark.skip(reason="no GPU in this container")
     for item in items:
