@@ -215,6 +215,7 @@ def cpu_baseline(name, width, height, frames, seq, overrides=None, check_parity=
                 stats.add(rt.name, f, parity.error_stats(hip.output(rt), oracle_outputs[f][rt]))
         sm = stats.summary(True)
         par = {"vs": "CPU oracle (oracle/), the device's v_rcp / v_sqrt / v_rsq / v_exp / v_log emulated from measured tables", "library": "lib/libNRD_hip.so (the library timed above)",
+               "oracle_pinned_to": "the reference's own shader text and host code compiled as C++ (oracle/_ref; tests/test_ref_parity.py, tests/test_ref_host.py; DESIGN.md 4.1)",
                "frames": frames, "planes": sorted(stats.outputs()),
                "max_rel_err": sm["max_rel_err"], "p999_rel_err": sm["p999"], "frac_gt_1e-3": sm["frac_gt_tol"], "mean_rel_err": sm["mean"], "bit_exact_frac": sm["bit_exact_frac"],
                "definition": "|gpu - cpu| / max(|cpu|, 1e-3) per value of the user outputs, worst frame"}
