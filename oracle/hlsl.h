@@ -61,7 +61,13 @@ inline float Div(float a, float b) { return a / b; }
 #else
 inline float Div(float a, float b) { return a * Rcp(b); }
 #endif
+// strict build: HLSL leaves rsqrt's rounding open; the build that is compared with the reference's compiled text (oracle/ref/hlsl_shim.h: 1.0f / sqrtf(x)) takes the same
+// two-rounding form, so that what remains between the two is association, not the choice of this one primitive
+#ifdef ORC_STRICT_IEEE
+inline float rsqrt(float x) { return 1.0f / sqrtf(x); }
+#else
 inline float rsqrt(float x) { return HwRsq(x); }
+#endif
 inline float frac(float x) { return x - floorf(x); }
 
 // 2^x = v_exp_f32(1 + frac(x)) * 2^(floor(x) - 1), the instruction seeing [1, 2] only (oracle/hw_math.h)

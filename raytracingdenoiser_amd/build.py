@@ -63,35 +63,70 @@ def _flags(src, extra=()):
     return COMMON_FLAGS + HOST_NUMERICS_FLAGS + ["-x", "c++"]
 
 
+def _portable(flags):
+    """the flags as they enter a digest: without the absolute path of this checkout (the snapshot that travels to a GPU box lives under another path -- until round 5 the
+    `-I<root>/include` flag made the shipped library look stale there, and every test session on the box recompiled it)"""
+    return " ".join(flags).replace(ROOT, "<root>")
+
+
 def _compile(src, hdr_digest, verbose, obj_dir, extra=()):
     flags = _flags(src, extra)
     with open(src, "rb") as fp:
-        digest = hashlib.sha1(fp.read() + hdr_digest.encode() + " ".join(flags).encode()).hexdigest()[:16]
+        digest = hashlib.sha1(fp.read() + hdr_digest.encode() + _portable(flags).encode()).hexdigest()[:16]
     os.makedirs(obj_dir, exist_ok=True)
     obj = os.path.join(obj_dir, os.path.basename(src) + "." + digest + ".o")
     if os.path.exists(obj):
         return obj
     for old in os.listdir(obj_dir):
-        if old.startswith(os.path.basename(src) + "."):
-            os.remove(os.path.join(obj_dir, old))
-    cmd = [HIPCC] + flags + ["-c", src, "-o", obj]
+        if old.startswith(os.path.basename(src) + ".") and old.endswith(".o"):
+            try:
+                os.remove(os.path.join(obj_dir, old))
+            except FileNotFoundError:
+                pass
+    cmd = [HIPCC] + flags + ["-c", src, "-o", obj + ".tmp%d" % os.getpid()]
     if verbose:
         print("[build]", " ".join(cmd), flush=True)
     subprocess.run(cmd, check=True)
+    os.replace(obj + ".tmp%d" % os.getpid(), obj)
     return obj
 
 
 def _global_digest(srcs, hdr_digest, extra=()):
-    h = hashlib.sha1((hdr_digest + " ".join(COMMON_FLAGS + HIP_FLAGS + DEVICE_NUMERICS_FLAGS + HOST_NUMERICS_FLAGS + list(extra))).encode())
+    h = hashlib.sha1((hdr_digest + _portable(COMMON_FLAGS + HIP_FLAGS + DEVICE_NUMERICS_FLAGS + HOST_NUMERICS_FLAGS + list(extra))).encode())
     for s in srcs:
         with open(s, "rb") as fp:
             h.update(fp.read())
     return h.hexdigest()
 
 
+class _BuildLock:
+    """one builder at a time (pytest-xdist starts several workers whose session fixtures all call the build functions): an advisory lock on a file next to the outputs"""
+
+    def __init__(self, name):
+        os.makedirs(LIB_DIR, exist_ok=True)
+        self.path = os.path.join(LIB_DIR, "." + name + ".lock")
+
+    def __enter__(self):
+        import fcntl
+
+        self.fp = open(self.path, "w")
+        fcntl.flock(self.fp, fcntl.LOCK_EX)
+
+    def __exit__(self, *exc):
+        import fcntl
+
+        fcntl.flock(self.fp, fcntl.LOCK_UN)
+        self.fp.close()
+
+
 def build_product(verbose=False, out=None, extra=(), obj_dir=None):
     """hipcc --offload-arch=gfx950 every HIP translation unit and link lib/libNRD_hip.so (or `out`, for the A/B variants of tools/build_variant.py).
     Returns the path."""
+    with _BuildLock("product"):
+        return _build_product(verbose, out, extra, obj_dir)
+
+
+def _build_product(verbose, out, extra, obj_dir):
     host, hip = _sources()
     hdr = _headers_digest()
     out = out or os.path.join(LIB_DIR, LIB_NAME)
@@ -114,7 +149,8 @@ def build_product(verbose=False, out=None, extra=(), obj_dir=None):
 def build_oracle(verbose=False):
     """ROCm's clang (x86-64) on the CPU oracle (test infrastructure). Returns the path of oracle/liboracle.so."""
     cmd = ["make", "-C", ORACLE_DIR, "-j8"] + ([] if verbose else ["-s"])
-    subprocess.run(cmd, check=True)
+    with _BuildLock("oracle"):
+        subprocess.run(cmd, check=True)
     return os.path.join(ORACLE_DIR, "liboracle.so")
 
 
@@ -124,6 +160,11 @@ def build_ref(verbose=False, reference="/root/reference"):
     out = os.path.join(ORACLE_DIR, "_ref", "libnrdref.so")
     if not os.path.isdir(os.path.join(reference, "Shaders", "Source")):
         return out if os.path.exists(out) else None
+    with _BuildLock("ref"):
+        return _build_ref(verbose, reference, out)
+
+
+def _build_ref(verbose, reference, out):
     # oracle/_ref/libnrdhost.so: the reference's own host sources over a MathLib stand-in (oracle/ref/host/Makefile)
     subprocess.run(["make", "-C", os.path.join(ORACLE_DIR, "ref", "host"), "-j8", "REFERENCE=" + reference] + ([] if verbose else ["-s"]), check=True)
     for target in ([], ["vo"]):  # "vo": one denoiser per family with NRD_USE_VIEWPORT_OFFSET = 1 (CommonSettings::rectOrigin; oracle/ref/Makefile)

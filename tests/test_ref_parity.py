@@ -32,17 +32,22 @@ from raytracingdenoiser_amd import api
 pytestmark = pytest.mark.skipif(not oracle_driver.ref_available(), reason="oracle/_ref/libnrdref.so not built (needs /root/reference: make -C oracle/ref -j8)")
 
 # floors per plane, measured values are listed in profiles/r04_ref_parity.jsonl (3 frames at 192x128: restart frame, 2 frames of accumulation under camera motion)
-OK_FLOOR = 0.999  # >= 99.9 % of the values of every output plane of every pass within 1e-5 or one unit of the stored format
-TOL_FLOOR = 0.9995  # >= 99.95 % within the north-star's 1e-3
+# Round 5: the strict build takes rsqrt as 1 / sqrt (two roundings, as the compiled reference text does: oracle/hlsl.h) instead of the correctly rounded reciprocal square root --
+# that ONE primitive was behind nearly every "outlier" of round 4 (tap snaps on the horizon rows, the RELAX confidence plane): the floors are an order of magnitude tighter now.
+OK_FLOOR = 0.9997  # >= 99.97 % of the values of every output plane of every pass within 1e-5 or one unit of the stored format (round 4: 99.9 %)
+TOL_FLOOR = 0.9999  # >= 99.99 % within the north-star's 1e-3 (round 4: 99.95 %)
 # planes whose values are ill-conditioned by construction (see the module docstring), (pass substring, output substring, format) -> (ok floor, 1e-3 floor):
 #   RELAX specular reprojection confidence: on the scene's horizon row the curvature estimate divides by NoV -> 0 and flips the confidence by whole steps
 #   REBLUR specular motion-vector patch (REBLUR_TemporalStabilization.hlsli:268-285): mv = ( vmbPixelUv - pixelUv ) / scale, a difference of nearly equal uvs --
 #   an absolute error of 1e-7 in uv is a relative error of 1e-3 in a 0.02-pixel motion vector; the values agree to 3e-4 of a pixel
-EXCEPTIONS = {("RELAX_", "TemporalAccumulation", "", "R8_UNORM"): (0.998, 0.997), ("REBLUR_", "TemporalStabilization", "IN_MV", "RGBA16_SFLOAT"): (0.99, 0.995)}
+EXCEPTIONS = {("REBLUR_", "TemporalStabilization", "IN_MV", "RGBA16_SFLOAT"): (0.99, 0.995)}
+# the DEVICE arithmetic only (a * v_rcp(b), fused multiply-adds, the device's transcendentals; test_the_librarys_arithmetic_...): the strict restatement equals the reference text
+# on the R8_UNORM confidence planes bit for bit since round 5
+DEVICE_EXCEPTIONS = {**EXCEPTIONS, ("RELAX_", "TemporalAccumulation", "", "R8_UNORM"): (0.998, 0.997)}
 
 
-def _floor(row, default, which):
-    for (family, pass_name, output, fmt), value in EXCEPTIONS.items():
+def _floor(row, default, which, exceptions=None):
+    for (family, pass_name, output, fmt), value in (EXCEPTIONS if exceptions is None else exceptions).items():
         if row["pass"].startswith(family) and pass_name in row["pass"] and output in row["output"] and row["format"] == fmt:
             return min(default, value[which])
     return default
@@ -66,22 +71,12 @@ def test_the_library_holds_every_shader_the_dispatch_lists_can_name():
     assert len(shaders) >= 230
 
 
-# one denoiser of every family and signal kind in the default suite; the remaining permutations of the same shader files with NRD_REF_FULL=1
-CORE = ["REBLUR_DIFFUSE_SPECULAR", "REBLUR_DIFFUSE_SPECULAR_OCCLUSION", "REBLUR_DIFFUSE_DIRECTIONAL_OCCLUSION", "REBLUR_SPECULAR_SH", "RELAX_DIFFUSE_SPECULAR_SH", "RELAX_DIFFUSE_SPECULAR",
-        "SIGMA_SHADOW", "SIGMA_SHADOW_TRANSLUCENCY"]
-
-
-@pytest.mark.parametrize("name", CORE)
+# all 19 denoisers (the 11 that only re-run the same shader files in other permutations were opt-in behind NRD_REF_FULL until round 4; they cost 14 s)
+@pytest.mark.parametrize("name", list(parity.DENOISERS))
 def test_every_pass_matches_the_reference_shader_text(name):
-    rows = _check(ref_parity.run_per_pass(name, frames=3, sensitivity=False), min_rows=10)
-    if name.startswith("SIGMA"):  # integer-ish arithmetic on UNORM8 planes: the two are identical, texel for texel
+    rows = _check(ref_parity.run_per_pass(name, frames=3, sensitivity=False), min_rows=10 if name != "REFERENCE" else 1)
+    if name.startswith("SIGMA") or name == "REFERENCE":  # integer-ish arithmetic on UNORM8 planes / one unfused lerp: the two are identical, texel for texel
         assert all(r["bit_exact_frac"] == 1.0 for r in rows)
-
-
-@pytest.mark.skipif(not __import__("os").environ.get("NRD_REF_FULL"), reason="the remaining 11 denoisers run the same shader files in other permutations (NRD_REF_FULL=1; tools/ref_report.py)")
-@pytest.mark.parametrize("name", [n for n in parity.DENOISERS if n not in CORE])
-def test_every_pass_matches_the_reference_shader_text_remaining_denoisers(name):
-    _check(ref_parity.run_per_pass(name, frames=3, sensitivity=False), min_rows=10)
 
 
 @pytest.mark.parametrize("name, overrides, cs_kw", [
@@ -120,13 +115,6 @@ def test_options_match_the_reference_shader_text(name, overrides, cs_kw):
     extra = (("mv2d",) if cs_kw and not cs_kw.get("isMotionVectorInWorldSpace", True) else ()) + (("basecolor",) if cs_kw and cs_kw.get("isBaseColorMetalnessAvailable") else ())
     extra += (("confidence",) if cs_kw and cs_kw.get("isHistoryConfidenceAvailable") else ()) + (("materials",) if materials else ())
     stats = ref_parity.run_per_pass(name, frames=3, settings_overrides=overrides, cs_kw=cs_kw, extra_want=extra, sensitivity=False)
-    if materials and name.startswith("RELAX"):
-        # the specular reprojection confidence (R8_UNORM) of the exception list: with the camera-attached material the virtual position collapses onto the surface position for
-        # a third of the pixels, and the ~100 texels of the horizon rows (NoV -> 0 in the curvature estimate) weigh 0.4 % of the plane instead of 0.2 %
-        for row in stats.table():
-            if "TemporalAccumulation" in row["pass"] and row["format"] == "R8_UNORM":
-                assert row["within_tol_frac"] >= 0.994 and row["within_1e-3_frac"] >= 0.994, row
-                stats.rows.pop((row["pass"], row["output"], row["format"]))
     _check(stats, min_rows=10)
 
 
@@ -199,7 +187,7 @@ def test_the_librarys_arithmetic_against_the_reference_shader_text_one_pass_at_a
     stats = ref_parity.run_per_pass(name, frames=3, sensitivity=False, strict=False, ieee=False)
     rows = stats.table()
     assert len(rows) >= 10
-    bad = [r for r in rows if r["within_1e-3_vec_frac"] < _floor(r, 0.999, 1)]
+    bad = [r for r in rows if r["within_1e-3_vec_frac"] < _floor(r, 0.999, 1, DEVICE_EXCEPTIONS)]
     assert not bad, "\n".join("%s %s %s: within 1e-3 (vector) %.6f, max %.3g" % (r["pass"], r["output"], r["format"], r["within_1e-3_vec_frac"], r["max_err"]) for r in bad)
     if name == "SIGMA_SHADOW":
         assert min(r["bit_exact_frac"] for r in rows) >= 0.9999

@@ -29,9 +29,11 @@ def main():
                 for r in rows:
                     fp.write(json.dumps(dict(r, arithmetic=mode, denoiser=name, frames=3, size=[192, 128])) + "\n")
                 n = sum(r["texel_values"] for r in rows)
-                line = "%-7s %-40s outputs %3d  values %9d  bit-exact %.5f  min ok %.6f  min within 1e-3 %.6f  min within 1e-3 (vector) %.6f  outliers %d (sensitive %d)" % (
+                worst = min(rows, key=lambda r: (r["within_1e-3_frac"], r["bit_exact_frac"]))  # the plane furthest from the north-star's tolerance, per component (both metrics, worst plane named)
+                line = "%-7s %-40s outputs %3d  values %9d  bit-exact %.5f  min ok %.6f  min within 1e-3 %.6f  min within 1e-3 (vector) %.6f  outliers %d (sensitive %d)  worst plane: %s %s %s (bit-exact %.4f, per component %.6f, vector %.6f, max %.3g)" % (
                     mode, name, len(rows), n, sum(r["bit_exact_frac"] * r["texel_values"] for r in rows) / n, min(r["within_tol_frac"] for r in rows), min(r["within_1e-3_frac"] for r in rows),
-                    min(r["within_1e-3_vec_frac"] for r in rows), sum(r["outliers"] for r in rows), sum(r["outliers_sensitive"] for r in rows))
+                    min(r["within_1e-3_vec_frac"] for r in rows), sum(r["outliers"] for r in rows), sum(r["outliers_sensitive"] for r in rows),
+                    worst["pass"], worst["output"], worst["format"], worst["bit_exact_frac"], worst["within_1e-3_frac"], worst["within_1e-3_vec_frac"], worst["max_err"])
                 print(line, flush=True)
                 summary.append(line)
     with open(os.path.join(ROOT, "profiles", tag + "_ref_parity_summary.txt"), "w") as fp:
