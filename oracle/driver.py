@@ -35,6 +35,7 @@ def load():
         for name in ("oracle_exp2", "oracle_log2", "oracle_atan"):
             getattr(lib, name).argtypes, getattr(lib, name).restype = [C.c_float], C.c_float
         lib.oracle_pow.argtypes, lib.oracle_pow.restype = [C.c_float, C.c_float], C.c_float
+        lib.oracle_pow01.argtypes, lib.oracle_pow01.restype = [C.c_float, C.c_float], C.c_float
         lib.oracle_eval_hw.argtypes, lib.oracle_eval_hw.restype = [C.c_int, C.c_void_p, C.c_void_p, C.c_int], None
         lib.oracle_frontend.argtypes, lib.oracle_frontend.restype = [C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int], None
         # rcp / sqrt / rsqrt / exp2 / log2 follow gfx950's instructions: per-mantissa deviation (in ulps) from the reference results of oracle/hw_ref.h,
@@ -52,6 +53,11 @@ def load():
             _hw_tables.append(np.ascontiguousarray(table))
         lib.oracle_set_hw_tables.argtypes, lib.oracle_set_hw_tables.restype = [C.c_void_p] * 5, None
         lib.oracle_set_hw_tables(*[t.ctypes.data for t in _hw_tables])
+        neg = np.ascontiguousarray(np.frombuffer(zlib.decompress(open(os.path.join(_DIR, "hw_exp2neg.i8.z"), "rb").read()), dtype=np.int8))  # v_exp_f32 on [-2, -1] (round 5, tools/hw_exp_neg.hip)
+        assert neg.size == (1 << 23) + 1 and int(np.abs(neg).max()) <= 1
+        _hw_tables.append(neg)
+        lib.oracle_set_hw_table_exp2neg.argtypes, lib.oracle_set_hw_table_exp2neg.restype = [C.c_void_p], None
+        lib.oracle_set_hw_table_exp2neg(neg.ctypes.data)
         lib.oracle_set_ieee_mode.argtypes, lib.oracle_set_ieee_mode.restype = [C.c_int], C.c_int
         if os.environ.get("ORACLE_EXACT_SQRT", "0") not in ("", "0"):
             lib.oracle_set_ieee_mode(1)

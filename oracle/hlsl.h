@@ -88,7 +88,31 @@ inline float log2(float x) {
     return float(e) + hwmath::HwLog2OnMantissa(m);
 }
 
+// round 5 (csrc/hip/nrdmath.h Exp2NonPos / SatExp2 / ExpNegAbs): 2^x for x <= 0 as 2 * v_exp_f32(x - 1); the strict build keeps the reference's plain forms
+inline float Exp2NonPos(float x) {
+#ifdef ORC_STRICT_IEEE
+    return exp2(x);
+#else
+    const float t = x - 1.0f;
+    return 2.0f * hwmath::HwExp2OnNegative(t);
+#endif
+}
+inline float SatExp2(float x) {
+#ifdef ORC_STRICT_IEEE
+    return saturate(exp2(x));
+#else
+    return Exp2NonPos(min(x, 0.0f));
+#endif
+}
 inline float exp(float x) { return exp2(x * 1.44269504f); }
+inline float ExpNegAbs(float w) {
+#ifdef ORC_STRICT_IEEE
+    return exp(-fabsf(w));
+#else
+    const float t = -fabsf(w) * 1.44269504f - 1.0f; // ONE fused multiply-add (-ffp-contract=on), as on the device
+    return 2.0f * hwmath::HwExp2OnNegative(t);
+#endif
+}
 inline float log(float x) { return log2(x) * 0.69314718f; }
 inline float pow(float x, float y) { return x <= 0.0f ? 0.0f : exp2(y * log2(x)); }
 

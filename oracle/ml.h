@@ -32,7 +32,14 @@ inline float SmoothStep01(float x) {
 inline float SmoothStep(float a, float b, float x) { return SmoothStep01(LinearStep(a, b, x)); }
 inline float4 SmoothStep(float a, float b, float4 x) { return float4(SmoothStep(a, b, x.x), SmoothStep(a, b, x.y), SmoothStep(a, b, x.z), SmoothStep(a, b, x.w)); }
 inline float Sqrt01(float x) { return HwSqrt(saturate(x)); }
-inline float Pow01(float x, float y) { return pow(saturate(x), y); }
+inline float Pow01(float x, float y) { // csrc/hip/nrdmath.h Pow01 (round 5): exponents are >= 0 at every call site
+#ifdef ORC_STRICT_IEEE
+    return pow(saturate(x), y);
+#else
+    x = saturate(x);
+    return x <= 0.0f ? 0.0f : Exp2NonPos(min(y * log2(x), 0.0f));
+#endif
+}
 inline float PositiveRcp(float x) { return Rcp(max(x, 1e-15f)); }
 inline float AcosApprox(float x) { return 1.41421356f * HwSqrt(saturate(1.0f - x)); }
 inline float LengthSquared(float3 v) { return dot(v, v); }
@@ -207,7 +214,7 @@ inline float GetSpecularLobeTanHalfAngle(float linearRoughness, float percentOfV
 }
 inline float GetSpecularDominantFactor(float NoV, float linearRoughness) { // [nrd] NRD.hlsli:386-392
     float a = 0.298475f * log(39.4115f - 39.0029f * linearRoughness);
-    float f = pow(saturate(1.0f - NoV), 10.8649f) * (1.0f - a) + a;
+    float f = Math::Pow01(1.0f - NoV, 10.8649f) * (1.0f - a) + a;
     return saturate(f);
 }
 inline float4 GetSpecularDominantDirection(float3 N, float3 V, float linearRoughness) { // [nrd] NRD.hlsli:394-400
@@ -251,7 +258,7 @@ inline float3 _NRD_YCoCgToLinear(float3 c) { // NRD.hlsli:365-375
     return float3(max(t + c.y, 0.0f), max(c.x + c.z, 0.0f), max(t - c.y, 0.0f));
 }
 inline float _REBLUR_GetHitDistanceNormalization(float viewZ, float4 hitDistParams, float roughness) { // NRD.hlsli:520-523
-    return (hitDistParams.x + fabsf(viewZ) * hitDistParams.y) * lerp(1.0f, hitDistParams.z, saturate(exp2(hitDistParams.w * roughness * roughness)));
+    return (hitDistParams.x + fabsf(viewZ) * hitDistParams.y) * lerp(1.0f, hitDistParams.z, SatExp2(hitDistParams.w * roughness * roughness));
 }
 // NRD.hlsli:600-637 with NRD_NORMAL_ENCODING = R10G10B10A2_UNORM (2), NRD_ROUGHNESS_ENCODING = LINEAR (1)
 inline float4 NRD_FrontEnd_UnpackNormalAndRoughness(float4 p, float& materialID) {
@@ -297,7 +304,7 @@ inline float4 IsInScreenBilinear(float2 footprintOrigin, float2 rectSize) {     
     return float4(r.x * r.y, r.z * r.y, r.x * r.w, r.z * r.w); // r.xzxz * r.yyww
 }
 inline float GetSpecMagicCurve(float roughness, float power = 0.25f) { // :312-318
-    float f = 1.0f - exp2(-200.0f * roughness * roughness);
+    float f = 1.0f - Exp2NonPos(-200.0f * roughness * roughness);
     f *= Math::Pow01(roughness, power);
     return f;
 }

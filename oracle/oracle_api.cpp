@@ -19,6 +19,7 @@ const signed char* g_SqrtDelta = nullptr;
 const signed char* g_RsqDelta = nullptr;
 const signed char* g_Exp2Delta = nullptr;
 const signed char* g_Log2Delta = nullptr;
+const signed char* g_Exp2NegDelta = nullptr;
 int g_IeeeMode = 0;
 void TablesMissing(const char* which) {
     fprintf(stderr, "oracle: hardware deviation table missing or argument out of its range: %s (oracle/hw_*.i8.z through oracle/driver.py)\n", which);
@@ -65,17 +66,19 @@ __attribute__((visibility("default"))) void oracle_set_hw_tables(const signed ch
     hwmath::g_Exp2Delta = exp2;
     hwmath::g_Log2Delta = log2;
 }
+__attribute__((visibility("default"))) void oracle_set_hw_table_exp2neg(const signed char* exp2neg) { hwmath::g_Exp2NegDelta = exp2neg; }
 // 1 = IEEE mode: the reference results instead of the device emulation (oracle/hw_math.h). Returns the previous mode.
 __attribute__((visibility("default"))) int oracle_set_ieee_mode(int on) {
     const int prev = hwmath::g_IeeeMode;
     hwmath::g_IeeeMode = on ? 1 : 0;
     return prev;
 }
-// 0 = v_sqrt_f32, 1 = v_rsq_f32, 2 = v_rcp_f32, 3 = the contract's exp2, 4 = the contract's log2
+// 0 = v_sqrt_f32, 1 = v_rsq_f32, 2 = v_rcp_f32, 3 = the contract's exp2, 4 = the contract's log2, 5 = Exp2NonPos, 6 = SatExp2, 7 = ExpNegAbs (round 5)
 __attribute__((visibility("default"))) void oracle_eval_hw(int op, const float* in, float* out, int n) {
     for (int i = 0; i < n; i++)
-        out[i] = op == 0 ? orc::HwSqrt(in[i]) : op == 1 ? orc::HwRsq(in[i]) : op == 2 ? orc::Rcp(in[i]) : op == 3 ? orc::exp2(in[i]) : orc::log2(in[i]);
+        out[i] = op == 0 ? orc::HwSqrt(in[i]) : op == 1 ? orc::HwRsq(in[i]) : op == 2 ? orc::Rcp(in[i]) : op == 3 ? orc::exp2(in[i]) : op == 4 ? orc::log2(in[i]) : op == 5 ? orc::Exp2NonPos(in[i]) : op == 6 ? orc::SatExp2(in[i]) : orc::ExpNegAbs(in[i]);
 }
+__attribute__((visibility("default"))) float oracle_pow01(float x, float y) { return orc::Math::Pow01(x, y); }
 
 __attribute__((visibility("default"))) int oracle_set_threads(int n) {
 #ifdef _OPENMP

@@ -1510,7 +1510,7 @@ void AtrousSmem(const PassIO& io) {
                             specularLuminanceW = min(c.gSpecMaxLuminanceRelativeDifference, specularLuminanceW);
                             specularLuminanceW *= specularLuminanceWeightRelaxation;
 
-                            float wSpecular = geometryW * exp(-specularLuminanceW);
+                            float wSpecular = geometryW * ExpNegAbs(specularLuminanceW);
                             wSpecular *= c.gRoughnessEdgeStoppingEnabled ? (normalWSpecular * roughnessWSpecular) : normalWSpecularSimplified;
                             wSpecular = isCenter ? kernelW : wSpecular;
                             wSpecular *= Cmp(CompareMaterials(sampleMaterialID, centerMaterialID, c.gSpecMinMaterial));
@@ -1530,7 +1530,7 @@ void AtrousSmem(const PassIO& io) {
                             diffuseLuminanceW = min(c.gDiffMaxLuminanceRelativeDifference, diffuseLuminanceW);
                             diffuseLuminanceW *= diffuseLuminanceWeightRelaxation;
 
-                            float wDiffuse = geometryW * normalWDiffuse * exp(-diffuseLuminanceW);
+                            float wDiffuse = geometryW * normalWDiffuse * ExpNegAbs(diffuseLuminanceW);
                             wDiffuse = isCenter ? kernelW : wDiffuse;
                             wDiffuse *= Cmp(CompareMaterials(sampleMaterialID, centerMaterialID, c.gDiffMinMaterial));
 
@@ -1786,7 +1786,7 @@ void Atrous(const PassIO& io) {
                             float specularLuminanceW = fabsf(centerSpecularLuminance - sampleSpecularLuminance) * specularPhiLIlluminationInv;
                             specularLuminanceW = min(c.gSpecMaxLuminanceRelativeDifference, specularLuminanceW);
                             specularLuminanceW *= specularLuminanceWeightRelaxation;
-                            wSpecular *= exp(-specularLuminanceW);
+                            wSpecular *= ExpNegAbs(specularLuminanceW);
 
                             sumWSpecular += wSpecular;
                             sumSpecular = Mad(sampleSpecular, float4(wSpecular, wSpecular, wSpecular, wSpecular * wSpecular), sumSpecular);
@@ -1805,7 +1805,7 @@ void Atrous(const PassIO& io) {
                             float diffuseLuminanceW = fabsf(centerDiffuseLuminance - sampleDiffuseLuminance) * diffusePhiLIlluminationInv;
                             diffuseLuminanceW = min(c.gDiffMaxLuminanceRelativeDifference, diffuseLuminanceW);
                             diffuseLuminanceW *= diffuseLuminanceWeightRelaxation;
-                            wDiffuse *= exp(-diffuseLuminanceW);
+                            wDiffuse *= ExpNegAbs(diffuseLuminanceW);
 
                             sumWDiffuse += wDiffuse;
                             sumDiffuse = Mad(sampleDiffuse, float4(wDiffuse, wDiffuse, wDiffuse, wDiffuse * wDiffuse), sumDiffuse);

@@ -257,6 +257,11 @@ __global__ __launch_bounds__(256) void EvalNumericsKernel(uint32_t op, const flo
         case 18: r = __builtin_amdgcn_sqrtf(a); break;
         case 19: r = AsFloat(FloatsToHalf2Bits(a, b)); break; // v_cvt_pk_f16_f32: two fp16 conversions in one instruction
         case 20: r = Rcp(a); break;
+        // round 5: the one-addition forms of 2^x for x <= 0 (nrdmath.h)
+        case 21: r = Exp2NonPos(a); break;
+        case 22: r = SatExp2(a); break;
+        case 23: r = ExpNegAbs(a); break;
+        case 24: r = Pow01(a, b); break;
         default: break;
     }
     out[i] = r;

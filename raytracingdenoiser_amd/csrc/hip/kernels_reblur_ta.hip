@@ -455,13 +455,18 @@ __device__ __forceinline__ void ReblurTemporalAccumulationTile(const ReblurCB& c
     float3 smbOcclusion3 = Step(Abs(prevViewZ3 - F3(Xvprev.z)), smbDisocclusionThreshold.w);
 
     // Disocclusion: materialID (the 4x4 internal-data footprint was requested with the depth footprint)
+    // Material IDs are 0..3 (the 2-bit field of IN_NORMAL_ROUGHNESS; the internal data keeps them in 4 bits): with a minimum material >= 3 every comparison
+    // max(m0, min) == max(m, min) holds (the library default is 4 = "off"), so the twelve unpack + compare chains (~11 instructions each, 6 % of this kernel's executed
+    // instructions) sit behind a UNIFORM test of the constants -- same values, as in the spatial passes (kernels_reblur_spatial.hip "compareMaterials").
     float minMaterialID = Min(c.gSpecMinMaterial, c.gDiffMinMaterial);
+    if (minMaterialID < 3.0f) {
 #define MATCMP(p) (CompareMaterials(materialID, UnpackInternalData(p).z, minMaterialID) ? 1.0f : 0.0f)
-    smbOcclusion0 = smbOcclusion0 * F3(MATCMP(id0[1]), MATCMP(id0[2]), MATCMP(id0[3]));
-    smbOcclusion1 = smbOcclusion1 * F3(MATCMP(id1[0]), MATCMP(id1[2]), MATCMP(id1[3]));
-    smbOcclusion2 = smbOcclusion2 * F3(MATCMP(id2[0]), MATCMP(id2[1]), MATCMP(id2[3]));
-    smbOcclusion3 = smbOcclusion3 * F3(MATCMP(id3[0]), MATCMP(id3[1]), MATCMP(id3[2]));
+        smbOcclusion0 = smbOcclusion0 * F3(MATCMP(id0[1]), MATCMP(id0[2]), MATCMP(id0[3]));
+        smbOcclusion1 = smbOcclusion1 * F3(MATCMP(id1[0]), MATCMP(id1[2]), MATCMP(id1[3]));
+        smbOcclusion2 = smbOcclusion2 * F3(MATCMP(id2[0]), MATCMP(id2[1]), MATCMP(id2[3]));
+        smbOcclusion3 = smbOcclusion3 * F3(MATCMP(id3[0]), MATCMP(id3[1]), MATCMP(id3[2]));
 #undef MATCMP
+    }
     const uint32_t smbInternalData0 = id0[3], smbInternalData1 = id1[2], smbInternalData2 = id2[1], smbInternalData3 = id3[0];
 
     NRD_CONSTANTS_PHASE();
@@ -793,10 +798,12 @@ __device__ __forceinline__ void ReblurTemporalAccumulationTile(const ReblurCB& c
         float3 vmbInternalData10 = UnpackInternalData(vmbId10);
         float3 vmbInternalData01 = UnpackInternalData(vmbId01);
         float3 vmbInternalData11 = UnpackInternalData(vmbId11);
-        vmbOcclusion.x *= CompareMaterials(materialID, vmbInternalData00.z, c.gSpecMinMaterial) ? 1.0f : 0.0f;
-        vmbOcclusion.y *= CompareMaterials(materialID, vmbInternalData10.z, c.gSpecMinMaterial) ? 1.0f : 0.0f;
-        vmbOcclusion.z *= CompareMaterials(materialID, vmbInternalData01.z, c.gSpecMinMaterial) ? 1.0f : 0.0f;
-        vmbOcclusion.w *= CompareMaterials(materialID, vmbInternalData11.z, c.gSpecMinMaterial) ? 1.0f : 0.0f;
+        if (c.gSpecMinMaterial < 3.0f) { // uniform; see the surface-motion footprint above
+            vmbOcclusion.x *= CompareMaterials(materialID, vmbInternalData00.z, c.gSpecMinMaterial) ? 1.0f : 0.0f;
+            vmbOcclusion.y *= CompareMaterials(materialID, vmbInternalData10.z, c.gSpecMinMaterial) ? 1.0f : 0.0f;
+            vmbOcclusion.z *= CompareMaterials(materialID, vmbInternalData01.z, c.gSpecMinMaterial) ? 1.0f : 0.0f;
+            vmbOcclusion.w *= CompareMaterials(materialID, vmbInternalData11.z, c.gSpecMinMaterial) ? 1.0f : 0.0f;
+        }
 
         fbits += vmbOcclusion.x * 16.0f;
         fbits += vmbOcclusion.y * 32.0f;

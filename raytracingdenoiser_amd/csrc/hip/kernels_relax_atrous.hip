@@ -244,7 +244,7 @@ __global__ __launch_bounds__(256, NRD_WAVES_RELAX_ATROUS_SMEM) void RelaxAtrousS
                     specularLuminanceW = Min(c.shared.gSpecMaxLuminanceRelativeDifference, specularLuminanceW);
                     specularLuminanceW *= sp.luminanceWeightRelaxation;
 
-                    float wSpecular = geometryW * Exp(-specularLuminanceW);
+                    float wSpecular = geometryW * ExpNegAbs(specularLuminanceW);
                     wSpecular *= c.shared.gRoughnessEdgeStoppingEnabled ? (normalWSpecular * roughnessWSpecular) : normalWSpecularSimplified;
                     wSpecular = isCenter ? kernelW : wSpecular;
                     wSpecular *= Cmp(CompareMaterials(sampleMaterialID, centerMaterialID, c.shared.gSpecMinMaterial));
@@ -264,7 +264,7 @@ __global__ __launch_bounds__(256, NRD_WAVES_RELAX_ATROUS_SMEM) void RelaxAtrousS
                     diffuseLuminanceW = Min(c.shared.gDiffMaxLuminanceRelativeDifference, diffuseLuminanceW);
                     diffuseLuminanceW *= dp.luminanceWeightRelaxation;
 
-                    float wDiffuse = geometryW * normalWDiffuse * Exp(-diffuseLuminanceW);
+                    float wDiffuse = geometryW * normalWDiffuse * ExpNegAbs(diffuseLuminanceW);
                     wDiffuse = isCenter ? kernelW : wDiffuse;
                     wDiffuse *= Cmp(CompareMaterials(sampleMaterialID, centerMaterialID, c.shared.gDiffMinMaterial));
 
@@ -732,7 +732,7 @@ __global__ __launch_bounds__(256, NRD_WAVES_RELAX_ATROUS) void RelaxAtrousKernel
                 float specularLuminanceW = Abs(sp.centerLuminance - sampleSpecularLuminance) * sp.phiLIlluminationInv;
                 specularLuminanceW = Min(c.shared.gSpecMaxLuminanceRelativeDifference, specularLuminanceW);
                 specularLuminanceW *= sp.luminanceWeightRelaxation;
-                wSpecular *= Exp(-specularLuminanceW);
+                wSpecular *= ExpNegAbs(specularLuminanceW);
                 wSpecular = on ? wSpecular : 0.0f;
 
                 sumWSpecular += wSpecular;
@@ -751,7 +751,7 @@ __global__ __launch_bounds__(256, NRD_WAVES_RELAX_ATROUS) void RelaxAtrousKernel
                 float diffuseLuminanceW = Abs(dp.centerLuminance - sampleDiffuseLuminance) * dp.phiLIlluminationInv;
                 diffuseLuminanceW = Min(c.shared.gDiffMaxLuminanceRelativeDifference, diffuseLuminanceW);
                 diffuseLuminanceW *= dp.luminanceWeightRelaxation;
-                wDiffuse *= Exp(-diffuseLuminanceW);
+                wDiffuse *= ExpNegAbs(diffuseLuminanceW);
                 wDiffuse = on ? wDiffuse : 0.0f;
 
                 sumWDiffuse += wDiffuse;

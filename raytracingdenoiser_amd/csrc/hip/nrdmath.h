@@ -99,6 +99,22 @@ NRD_D float Log2(float x) {
     return x >= 1.17549435e-38f ? r : -126.0f;
 }
 
+// 2^x for x <= 0 (round 5): 2 * v_exp_f32(x - 1) -- one subtraction in front of the instruction instead of the eight-instruction reduction above. The instruction then only
+// ever sees an argument <= -1, where it is a sign-magnitude function of ONE binade (tools/hw_exp_neg.hip, profiles/r05_b_hw_exp_neg_report.txt: v_exp_f32(-w) ==
+// v_exp_f32(-(1 + frac(w))) * 2^-(floor(w) - 1) for every w >= 1, 0 mismatches over six binades x 2^23 mantissas, results below 2^-126 flushed to 0), so the oracle reproduces
+// it from one more deviation table over [-2, -1] (oracle/hw_exp2neg.i8.z). x - 1 rounds x to 2^-24 for |x| < 1 -- the same precision class as 1 + frac(x) above.
+// Callers guarantee x <= 0 (or -0, NaN): a positive argument would leave the measured domain (the oracle aborts on it).
+NRD_D float Exp2NonPos(float x) {
+    const float t = x - 1.0f;
+    return 2.0f * __builtin_amdgcn_exp2f(t);
+}
+// saturate(2^x) for any x: 2^min(x, 0) (2^x <= 1 for x <= 0, and saturate(2^x) = 1 = 2^0 for x > 0)
+NRD_D float SatExp2(float x) { return Exp2NonPos(Min(x, 0.0f)); }
+// e^-|w|: the argument of the instruction is ONE fused multiply-add, fma(-|w|, log2 e, -1) (sign and magnitude are free source modifiers)
+NRD_D float ExpNegAbs(float w) {
+    const float t = -Abs(w) * 1.44269504f - 1.0f;
+    return 2.0f * __builtin_amdgcn_exp2f(t);
+}
 NRD_D float Exp(float x) { return Exp2(x * 1.44269504f); }
 NRD_D float Log(float x) { return Log2(x) * 0.69314718f; }
 // x^y for x >= 0 (0^y = 0 for the y > 0 the chain uses)
@@ -210,7 +226,12 @@ NRD_D float SmoothStep01(float x) {
 }
 NRD_D float SmoothStep(float a, float b, float x) { return SmoothStep01(LinearStep(a, b, x)); }
 NRD_D float Sqrt01(float x) { return Sqrt(Sat(x)); }
-NRD_D float Pow01(float x, float y) { return Pow(Sat(x), y); }
+// saturate(x)^y for y >= 0 (every call site: constant exponents, and a product of factors in [0, 1] x [1, 32]): log2 of a number in (0, 1] is <= 0, so the product
+// goes to Exp2NonPos; the min guards the domain of the instruction's table, not the mathematics
+NRD_D float Pow01(float x, float y) {
+    x = Sat(x);
+    return x <= 0.0f ? 0.0f : Exp2NonPos(Min(y * Log2(x), 0.0f));
+}
 NRD_D float PositiveRcp(float x) { return Rcp(Max(x, 1e-15f)); }
 NRD_D float AcosApprox(float x) { return 1.41421356f * Sqrt(Sat(1.0f - x)); } // sqrt(2) * sqrt(saturate(1 - x))
 NRD_D float Pow5(float x) {                                                  // BRDF::Pow5 = (1 - x)^5 on saturated input
@@ -382,7 +403,7 @@ NRD_D float GetSpecularLobeTanHalfAngle(float linearRoughness, float percentOfVo
 }
 NRD_D float GetSpecularDominantFactor(float NoV, float linearRoughness) { // G2 fit, reference NRD.hlsli:386-392
     float a = 0.298475f * Log(39.4115f - 39.0029f * linearRoughness);
-    float f = Pow(Sat(1.0f - NoV), 10.8649f) * (1.0f - a) + a;
+    float f = Pow01(1.0f - NoV, 10.8649f) * (1.0f - a) + a;
     return Sat(f);
 }
 NRD_D float4 GetSpecularDominantDirection(float3 N, float3 V, float linearRoughness) {
@@ -414,7 +435,7 @@ NRD_D float4 UnpackNormalAndRoughness(float4 p) {
     return UnpackNormalAndRoughness(p, unused);
 }
 NRD_D float GetHitDistanceNormalization(float viewZ, float4 hitDistParams, float roughness) { // reference NRD.hlsli:520-523
-    return (hitDistParams.x + Abs(viewZ) * hitDistParams.y) * Lerp(1.0f, hitDistParams.z, Sat(Exp2(hitDistParams.w * roughness * roughness)));
+    return (hitDistParams.x + Abs(viewZ) * hitDistParams.y) * Lerp(1.0f, hitDistParams.z, SatExp2(hitDistParams.w * roughness * roughness));
 }
 
 } // namespace nrdhip

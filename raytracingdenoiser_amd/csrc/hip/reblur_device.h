@@ -120,7 +120,7 @@ NRD_D float4 IsInScreenBilinear(float2 footprintOrigin, float2 rectSize) {
     return F4(r.x * r.y, r.z * r.y, r.x * r.w, r.z * r.w);
 }
 NRD_D float GetSpecMagicCurve(float roughness, float power = 0.25f) {
-    float f = 1.0f - Exp2(-200.0f * roughness * roughness);
+    float f = 1.0f - Exp2NonPos(-200.0f * roughness * roughness);
     f *= Pow01(roughness, power);
     return f;
 }

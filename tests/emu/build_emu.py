@@ -32,13 +32,18 @@ def _digest(paths, extra):
 
 
 def build(verbose=False):
+    with B._BuildLock("emu"):  # pytest-xdist workers build at the same time otherwise
+        return _build(verbose)
+
+
+def _build(verbose):
     host, hip = B._sources()
     srcs = host + hip + [os.path.join(HERE, "emu_runtime.cpp")]
     hdrs = []
     for base in (os.path.join(ROOT, "include"), B.CSRC, os.path.join(HERE, "shim"), os.path.join(ROOT, "oracle")):
         for d, _, files in os.walk(base):
             hdrs += [os.path.join(d, f) for f in files if f.endswith(".h")]
-    hdr_digest = _digest(hdrs, " ".join(flags()))
+    hdr_digest = _digest(hdrs, B._portable(flags()))
     os.makedirs(OBJ_DIR, exist_ok=True)
 
     def compile_one(src):

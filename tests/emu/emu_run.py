@@ -43,6 +43,10 @@ def load():
         lib.nrdEmuSetHwTables.argtypes, lib.nrdEmuSetHwTables.restype = [C.c_void_p] * 5, None
         lib.nrdEmuSetThreads.argtypes, lib.nrdEmuSetThreads.restype = [C.c_int], C.c_int
         lib.nrdEmuSetHwTables(*[t.ctypes.data for t in hw_tables()])
+        global _neg_table
+        _neg_table = np.ascontiguousarray(np.frombuffer(zlib.decompress(open(os.path.join(ROOT, "oracle", "hw_exp2neg.i8.z"), "rb").read()), dtype=np.int8))
+        lib.nrdEmuSetHwTableExp2Neg.argtypes, lib.nrdEmuSetHwTableExp2Neg.restype = [C.c_void_p], None
+        lib.nrdEmuSetHwTableExp2Neg(_neg_table.ctypes.data)
         _lib = lib
     return _lib
 

@@ -22,6 +22,7 @@ const signed char* g_RcpDelta = nullptr;
 const signed char* g_SqrtDelta = nullptr;
 const signed char* g_RsqDelta = nullptr;
 const signed char* g_Exp2Delta = nullptr;
+const signed char* g_Exp2NegDelta = nullptr;
 const signed char* g_Log2Delta = nullptr;
 int g_IeeeMode = 0;
 void TablesMissing(const char* which) {
@@ -291,6 +292,7 @@ __attribute__((visibility("default"))) void nrdEmuSetHwTables(const signed char*
     hwmath::g_Exp2Delta = exp2;
     hwmath::g_Log2Delta = log2;
 }
+__attribute__((visibility("default"))) void nrdEmuSetHwTableExp2Neg(const signed char* exp2neg) { hwmath::g_Exp2NegDelta = exp2neg; }
 __attribute__((visibility("default"))) int nrdEmuSetThreads(int n) {
 #ifdef _OPENMP
     if (n > 0)

@@ -44,6 +44,20 @@ def test_oracle_transcendentals_are_accurate():
     assert np.max(np.abs(_vec(lib.oracle_atan, a) - np.arctan(a.astype(np.float64)))) < 3e-7
     assert lib.oracle_exp2(0.0) == 1.0 and lib.oracle_exp2(3.0) == 8.0 and lib.oracle_log2(8.0) == 3.0 and lib.oracle_log2(1.0) == 0.0
     assert lib.oracle_pow(0.0, 2.0) == 0.0 and abs(lib.oracle_pow(0.5, 4.0) - 0.0625) < 1e-7
+    # round 5: the forms for non-positive arguments (oracle/hlsl.h Exp2NonPos / SatExp2 / ExpNegAbs, ml.h Pow01)
+    xn = -np.concatenate([np.abs(rng.standard_normal(4000)) * 10.0 ** rng.integers(-10, 2, 4000), [0.0, 1.0, 2.0, 100.0]]).astype(np.float32)
+    for op, exact in ((5, np.exp2(xn.astype(np.float64))), (6, np.exp2(xn.astype(np.float64))), (7, np.exp(xn.astype(np.float64)))):
+        out = np.empty_like(xn)
+        lib.oracle_eval_hw(op, xn.ctypes.data, out.ctypes.data, xn.size)
+        ok = exact > 1.2e-38
+        # x - 1 is exact for |x| >= 1 except where it crosses into the next binade (half an ulp of |x|: a relative error of |x| * 2^-24 * ln 2 in 2^x)
+        # (e^-|w| multiplies by the fp32 constant log2 e first: the product carries half an ulp of |w| * 1.44 as well, as the plain exp() always did)
+        assert np.all(np.abs(out[ok] / exact[ok] - 1.0) < 4e-7 + (1.2e-7 if op == 7 else 5e-8) * np.abs(xn[ok].astype(np.float64))), op
+    pos = np.array([0.5, 3.0, 1e30], dtype=np.float32)
+    out = np.empty_like(pos)
+    lib.oracle_eval_hw(6, pos.ctypes.data, out.ctypes.data, pos.size)
+    assert np.all(out == 1.0)  # saturate(2^x) = 1 for x > 0
+    assert lib.oracle_pow01(0.5, 4.0) == 0.0625 and lib.oracle_pow01(-1.0, 2.0) == 0.0 and lib.oracle_pow01(1.0, 7.0) == 1.0 and lib.oracle_pow01(3.0, 2.0) == 1.0
 
 
 @pytest.mark.gpu
@@ -118,6 +132,27 @@ def test_hip_numerics_bit_exact_vs_oracle():
             exact = (np.sqrt(x64) if hw == 0 else 1.0 / np.sqrt(x64) if hw == 1 else 1.0 / x64).astype(np.float32)
         normal = np.isfinite(exact) & (np.abs(src) >= np.float32(1.17549435e-38)) & np.isfinite(src) & (np.abs(exact) >= np.float32(1.17549435e-38))
         assert np.abs(got[normal].view(np.int32).astype(np.int64) - exact[normal].view(np.int32)).max() <= 1  # within 1 ulp of the correctly rounded result
+    # round 5: 2^x for x <= 0 as 2 * v_exp_f32(x - 1) (nrdmath.h Exp2NonPos / SatExp2 / ExpNegAbs / Pow01): the instruction on arguments <= -1 against the oracle's
+    # sign-magnitude model of it (oracle/hw_math.h HwExp2OnNegative, table oracle/hw_exp2neg.i8.z) -- dense over every binade the chain can produce, and the specials
+    neg = -np.concatenate([np.abs(rng.standard_normal(400000)) * 10.0 ** rng.integers(-12, 3, 400000), rng.uniform(0, 130, 200000), [0.0, 1.0, 2.0, 124.9, 125.0, 125.5, 126.0, 127.0, 149.0, 1e30, np.inf, 1e-45, 1e-39]]).astype(np.float32)
+    anysign = np.concatenate([neg, -neg[:200000], [np.nan]]).astype(np.float32)
+    for op, hw, src in ((21, 5, neg), (22, 6, anysign), (23, 7, anysign)):
+        ta, out = torch.from_numpy(src).cuda(), torch.empty(src.size, device="cuda")
+        lib.nrdHipEvalNumerics(op, ta.data_ptr(), None, out.data_ptr(), src.size, torch.cuda.current_stream().cuda_stream)
+        got, want = out.cpu().numpy(), np.empty_like(src)
+        ora.oracle_eval_hw(hw, src.ctypes.data, want.ctypes.data, src.size)
+        same = (got.view(np.uint32) == want.view(np.uint32)) | (np.isnan(got) & np.isnan(want))
+        assert same.all(), "op %d: %d differ, e.g. in=%r got=%r want=%r" % (op, (~same).sum(), src[~same][:6], got[~same][:6], want[~same][:6])
+        with np.errstate(over="ignore", invalid="ignore"):
+            x64 = src.astype(np.float64)
+            exact = np.exp2(x64) if op == 21 else np.minimum(np.exp2(x64), 1.0) if op == 22 else np.exp(-np.abs(x64))
+        normal = np.isfinite(exact) & (exact >= 1.2e-38)
+        assert np.all(np.abs(got[normal] / exact[normal] - 1.0) < 4e-7 + (1.2e-7 if op == 23 else 5e-8) * np.abs(x64[normal]))  # (see test_oracle_transcendentals_are_accurate)
+    pa01, pb01 = rng.uniform(-0.2, 1.2, n).astype(np.float32), rng.uniform(0.0, 40, n).astype(np.float32)
+    ta, tb, out = torch.from_numpy(pa01).cuda(), torch.from_numpy(pb01).cuda(), torch.empty(n, device="cuda")
+    lib.nrdHipEvalNumerics(24, ta.data_ptr(), tb.data_ptr(), out.data_ptr(), n, torch.cuda.current_stream().cuda_stream)
+    want = np.array([ora.oracle_pow01(float(v), float(w)) for v, w in zip(pa01, pb01)], dtype=np.float32)
+    assert np.array_equal(out.cpu().numpy().view(np.uint32), want.view(np.uint32))
     # v_cvt_pk_f16_f32 (StoreRGBA16F): each half is the round-to-nearest-even conversion of its own operand
     xs = np.concatenate([rng.standard_normal(n) * 10.0 ** rng.integers(-9, 6, n), [65504.0, 65519.9, 65520.0, 1e9, 2.0 ** -24, 2.0 ** -25, 2.0 ** -25 * 1.0001, 6.1e-5, 0.0, -0.0]]).astype(np.float32)
     ys = xs[::-1].copy()
