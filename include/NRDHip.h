@@ -159,7 +159,8 @@ uint32_t nrdHipGetPoolMemoryUsage(const NrdHipExecutor* executor, uint64_t* perm
 // arrays, so a harness can pin the GPU's codecs and transcendentals bit-for-bit against another implementation.
 //   op: 0 exp2, 1 log2, 2 atan, 3 pow(x, y = in2), 4 fp32->fp16->fp32 round trip, 5 Div(x, in2) = x * v_rcp_f32(in2), 6 sqrt, 7 1/sqrt,
 //       8..12 small-integer / {1023, 255, 63, 15, 3} (the codecs' 3-op exact division), 13 exp(-0.66 x^2), 14 small-integer / 65535, 15 int16 / 32767;
-//       16 v_rcp_f32, 17 v_rsq_f32, 18 v_sqrt_f32 (the raw instructions), 19 v_cvt_pk_f16_f32(x, in2) (the packed word as float bits), 20 Rcp
+//       16 v_rcp_f32, 17 v_rsq_f32, 18 v_sqrt_f32 (the raw instructions), 19 v_cvt_pk_f16_f32(x, in2) (the packed word as float bits), 20 Rcp;
+//       21 Exp2NonPos(x) = 2 * v_exp_f32(x - 1) for x <= 0, 22 SatExp2(x) = saturate(2^x), 23 ExpNegAbs(x) = e^-|x|, 24 Pow01(x, in2) = saturate(x)^in2 for in2 >= 0 (round 5)
 // in2 may be NULL for unary ops. Launches on hipStream (a hipStream_t as void*, may be NULL).
 uint32_t nrdHipEvalNumerics(uint32_t op, const float* in1, const float* in2, float* out, uint32_t count, void* hipStream);
 

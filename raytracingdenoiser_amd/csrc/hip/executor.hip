@@ -447,6 +447,13 @@ static int PassReachRows(const char* shader, const void* constants, uint32_t con
 // pre-passes, whose taps read nothing written earlier in the frame (reach 0 for the halo plan) but do read the guides at blur-radius distance. -1 = unknown.
 static int GuideReachRows(const char* shader, const void* constants, uint32_t constantsSize) {
     const int reach = PassReachRows(shader, constants, constantsSize);
+    // TemporalAccumulation with a specular signal (REBLUR and RELAX): the curvature estimate's high-parallax tap reads the decoded normals smbParallaxInPixelsMin * (1 + gFramerateScale *
+    // Bayer) pixels away along the motion direction (reference REBLUR_TemporalAccumulation.hlsli:398-420) -- many ROWS under vertical camera translation, and bounded by neither the
+    // halo reach (1) nor the measured surface motion (a rotation can cancel the translation's parallax on screen). Unknown reach: the guide planes are decoded on the whole frame
+    // (18 us more per 1440p frame at 8 ranks; ADVICE r04 -- the rows happened to be covered by the pre-pass's guide reach at the default radii, and by nothing without a pre-pass:
+    // tests/test_sharding.py, the "_camera_rise" cases)
+    if (reach >= 0 && strstr(shader, "_TemporalAccumulation") && strstr(shader, "Specular"))
+        return -1;
     if (reach < 0 || !strstr(shader, "_PrePass"))
         return reach;
     static const float kSlack = getenv("NRD_HIP_SPECULAR_REACH_SLACK") ? std::fmax(1.0f, (float)atof(getenv("NRD_HIP_SPECULAR_REACH_SLACK"))) : 2.0f;
@@ -1304,7 +1311,7 @@ extern "C" __attribute__((visibility("default"))) uint32_t nrdHipMeasureCopyBand
 }
 
 extern "C" __attribute__((visibility("default"))) uint32_t nrdHipEvalNumerics(uint32_t op, const float* in1, const float* in2, float* out, uint32_t count, void* hipStream) {
-    if (!in1 || !out || op > 20)
+    if (!in1 || !out || op > 24)
         return (uint32_t)nrd::Result::INVALID_ARGUMENT;
     if (count)
         nrdhip::LaunchEvalNumerics(op, in1, in2, out, count, (hipStream_t)hipStream);

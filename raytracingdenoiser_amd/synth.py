@@ -27,6 +27,9 @@ SPHERES = [  # centre xyz, radius, albedo rgb, roughness
 LIGHT_DIR = (0.35, 0.8, -0.48)  # direction TO the sun (normalised below)
 
 
+CAMERA_RISE = 0.0  # scene units per frame of VERTICAL camera translation (tests: vertical parallax of many rows per frame; 0 = the bench / parity camera path)
+
+
 class Camera:
     """LH camera: +x right, +y up, +z forward; clip = viewToClip * view (D3D style, depth = z / w)."""
 
@@ -35,7 +38,7 @@ class Camera:
         t = 0.0 if static else float(frame)
         yaw = math.radians(0.1 * t) + math.radians(8.0)
         pitch = math.radians(-9.0)
-        self.pos = (0.2 + 0.004 * t, 1.5, -1.0 + 0.01 * t)
+        self.pos = (0.2 + 0.004 * t, 1.5 + CAMERA_RISE * t, -1.0 + 0.01 * t)
         cy, sy, cp, sp = math.cos(yaw), math.sin(yaw), math.cos(pitch), math.sin(pitch)
         fwd = (sy * cp, sp, cy * cp)
         right = (cy, 0.0, -sy)

@@ -85,14 +85,15 @@ def test_mean_is_kept_and_noise_drops_at_full_size(name, size, pairs):
         assert abs(out.mean() - noisy.mean()) < 0.03 * noisy.mean() and out.std() < 0.9 * noisy.std()
 
 
-def test_row_strips_equal_the_whole_frame_at_full_size():
-    """4 virtual ranks (halo exchange emulated by copies, strips re-cut from the tile map) at 1440p == the uncut frame, every output, every frame"""
-    from test_sharding import _local_exchange
+def _virtual_rank_run(name, w, h, world, frames, scheme):
+    """`world` virtual ranks on the one GPU (each its own instance, executor, arena and output planes; transfers emulated by copies between them: what RCCL would move) against
+    an uncut frame. scheme "halo": HaloSharder -- halo exchange between pass segments, strips re-cut from the tile map, then the output all-gather (sharding.output_gather_ops);
+    "allgather": FrameSharder -- redundant halo compute + one all-gather of every permanent plane and output. Returns per frame (sharded?, every rank's outputs == the uncut frame's)."""
+    from test_sharding import _local_completion, _local_exchange
 
     from raytracingdenoiser_amd.executor import HipExecutor
 
-    name, (w, h), world = "REBLUR_DIFFUSE_SPECULAR", (2560, 1440), 4
-    seq = parity.generate_sequence(name, w, h, 4, device="cuda")
+    seq = parity.generate_sequence(name, w, h, frames, device="cuda")
 
     def make():
         inst = api.Instance([(0, parity.DENOISERS[name][0])])
@@ -111,32 +112,80 @@ def test_row_strips_equal_the_whole_frame_at_full_size():
 
     ref = make()
     runs = [make() for _ in range(world)]
-    ranks = [sharding.HaloSharder(ex, inst, w, h, r, world) for r, (inst, ex, outs) in enumerate(runs)]
+    if scheme == "halo":
+        ranks = [sharding.HaloSharder(ex, inst, w, h, r, world) for r, (inst, ex, outs) in enumerate(runs)]
+    else:
+        ranks = [sharding.FrameSharder(ex, inst, w, h, r, world, outs) for r, (inst, ex, outs) in enumerate(runs)]
+        assert all(sh.rows is not None for sh in ranks)
+    result = []
     for f, frame in enumerate(seq):
         prepare(ref[0], ref[1], f, frame)
         ref[1].denoise()
-        begun = []
-        for (inst, ex, outs), sh in zip(runs, ranks):
-            prepare(inst, ex, f, frame)
-            begun.append(sh.begin_frame())
-        plans = [b[0] for b in begun]
-        assert plans[0].fallback == (f == 0)
-        if plans[0].fallback:
-            for sh, (plan, ptr, n) in zip(ranks, begun):
-                sh.ex.execute_range(ptr, n, 0, n)
-        else:
-            for step in range(len(plans[0].steps)):
+        if scheme == "halo":
+            begun = []
+            for (inst, ex, outs), sh in zip(runs, ranks):
+                prepare(inst, ex, f, frame)
+                begun.append(sh.begin_frame())
+            plans = [b[0] for b in begun]
+            assert len({p.fallback for p in plans}) == 1 and all(sh.bounds == ranks[0].bounds for sh in ranks)
+            if plans[0].fallback:
                 torch.cuda.synchronize()
-                _local_exchange(ranks, plans, step)
+                _local_completion(ranks, plans)
                 for sh, (plan, ptr, n) in zip(ranks, begun):
-                    sh.run_step(plan, ptr, n, step)
-        for sh, plan in zip(ranks, plans):
-            sh.finish_frame(plan)
+                    sh.ex.execute_range(ptr, n, 0, n)
+            else:
+                for step in range(len(plans[0].steps)):
+                    torch.cuda.synchronize()
+                    _local_exchange(ranks, plans, step)
+                    for sh, (plan, ptr, n) in zip(ranks, begun):
+                        sh.run_step(plan, ptr, n, step)
+                torch.cuda.synchronize()
+                # owned rows first (before the reassembly can paper over anything), then the output all-gather, replayed with copies
+                for (inst, ex, outs), sh in zip(runs, ranks):
+                    rb, re = sh.rows
+                    assert all(torch.equal(o[rb:re], ro[rb:re]) for o, ro in zip(outs, ref[2])), (f, sh.rank)
+                assert plans[0].output_keys and len(plans[0].output_keys) == len(ref[2])
+                for key, src, r0, r1 in sharding.output_gather_ops(ranks[0].bounds, plans[0].output_keys):
+                    for dst, sh in enumerate(ranks):
+                        if dst != src:
+                            sh.plane_tensor(key)[r0:r1].copy_(ranks[src].plane_tensor(key)[r0:r1])
+            for sh, plan in zip(ranks, plans):
+                sh.finish_frame(plan)
+            sharded = not plans[0].fallback
+        else:
+            for (inst, ex, outs), sh in zip(runs, ranks):
+                prepare(inst, ex, f, frame)
+                sh.ex.denoise()
+            torch.cuda.synchronize()
+            for src, sh in enumerate(ranks):  # FrameSharder.exchange: the in-place all-gather of every plane's owned rows, replayed with copies
+                rb, re = sh.rows
+                for dst, other in enumerate(ranks):
+                    if dst != src:
+                        for mine, theirs in zip(sh.planes, other.planes):
+                            theirs[rb:re].copy_(mine[rb:re])
+            sharded = True
         torch.cuda.synchronize()
-        for (inst, ex, outs), sh in zip(runs, ranks):
-            rb, re = sh.rows
-            assert all(torch.equal(o[rb:re], ro[rb:re]) for o, ro in zip(outs, ref[2])), (f, sh.rank)
-    assert ranks[0].rebalanced == 1 and ranks[0].bounds[1] > h // world  # the sky strip at the top grew
+        result.append((sharded, all(torch.equal(o, ro) for (inst, ex, outs) in runs for o, ro in zip(outs, ref[2]))))
+    return result, ranks
+
+
+def test_row_strips_equal_the_whole_frame_at_full_size():
+    """4 virtual ranks (halo exchange emulated by copies, strips re-cut from the tile map) at 1440p == the uncut frame, every output, every frame"""
+    result, ranks = _virtual_rank_run("REBLUR_DIFFUSE_SPECULAR", 2560, 1440, 4, 4, "halo")
+    assert [s for s, _ in result] == [False, True, True, True] and all(ok for _, ok in result)
+    assert ranks[0].rebalanced == 1 and ranks[0].bounds[1] > 1440 // 4  # the sky strip at the top grew
+
+
+# BASELINE.json configs[3] and configs[4] at N = 8 (VERDICT r04 item 3b): the screen cut into 8 row strips, both multi-GPU schemes; afterwards EVERY rank holds the complete,
+# bit-identical output planes of every frame -- the north-star's "single all-gather to reassemble the output plane"
+@pytest.mark.parametrize("name,size,scheme", [
+    ("REBLUR_DIFFUSE_SPECULAR", (2560, 1440), "halo"), ("REBLUR_DIFFUSE_SPECULAR", (2560, 1440), "allgather"),
+    ("RELAX_DIFFUSE_SPECULAR_SH", (3840, 2160), "halo"), ("RELAX_DIFFUSE_SPECULAR_SH", (3840, 2160), "allgather"),
+])
+def test_eight_virtual_ranks_hold_the_complete_output(name, size, scheme):
+    result, ranks = _virtual_rank_run(name, size[0], size[1], 8, 3, scheme)
+    assert all(ok for _, ok in result), result
+    assert [s for s, _ in result][1:] == [True, True]  # the frames after the restart frame are really cut into strips
 
 
 def test_reference_is_the_fp32_running_mean_at_full_size():

@@ -138,7 +138,7 @@ def test_hip_numerics_bit_exact_vs_oracle():
     anysign = np.concatenate([neg, -neg[:200000], [np.nan]]).astype(np.float32)
     for op, hw, src in ((21, 5, neg), (22, 6, anysign), (23, 7, anysign)):
         ta, out = torch.from_numpy(src).cuda(), torch.empty(src.size, device="cuda")
-        lib.nrdHipEvalNumerics(op, ta.data_ptr(), None, out.data_ptr(), src.size, torch.cuda.current_stream().cuda_stream)
+        assert lib.nrdHipEvalNumerics(op, ta.data_ptr(), None, out.data_ptr(), src.size, torch.cuda.current_stream().cuda_stream) == 0
         got, want = out.cpu().numpy(), np.empty_like(src)
         ora.oracle_eval_hw(hw, src.ctypes.data, want.ctypes.data, src.size)
         same = (got.view(np.uint32) == want.view(np.uint32)) | (np.isnan(got) & np.isnan(want))
@@ -150,7 +150,7 @@ def test_hip_numerics_bit_exact_vs_oracle():
         assert np.all(np.abs(got[normal] / exact[normal] - 1.0) < 4e-7 + (1.2e-7 if op == 23 else 5e-8) * np.abs(x64[normal]))  # (see test_oracle_transcendentals_are_accurate)
     pa01, pb01 = rng.uniform(-0.2, 1.2, n).astype(np.float32), rng.uniform(0.0, 40, n).astype(np.float32)
     ta, tb, out = torch.from_numpy(pa01).cuda(), torch.from_numpy(pb01).cuda(), torch.empty(n, device="cuda")
-    lib.nrdHipEvalNumerics(24, ta.data_ptr(), tb.data_ptr(), out.data_ptr(), n, torch.cuda.current_stream().cuda_stream)
+    assert lib.nrdHipEvalNumerics(24, ta.data_ptr(), tb.data_ptr(), out.data_ptr(), n, torch.cuda.current_stream().cuda_stream) == 0
     want = np.array([ora.oracle_pow01(float(v), float(w)) for v, w in zip(pa01, pb01)], dtype=np.float32)
     assert np.array_equal(out.cpu().numpy().view(np.uint32), want.view(np.uint32))
     # v_cvt_pk_f16_f32 (StoreRGBA16F): each half is the round-to-nearest-even conversion of its own operand
