@@ -129,7 +129,8 @@ uint32_t nrdHipMeasureMotionRows(NrdHipExecutor* executor, const void* dispatchD
 // Per-pass GPU timing. When enabled, every dispatch is bracketed by hipEvents on the executor's stream.
 // nrdHipCollectPassTimings synchronises the stream, folds all brackets recorded since the last collect into per-pipeline
 // totals and returns the number of pipelines written: pipelineIndices[i] (index into InstanceDesc::pipelines),
-// milliseconds[i] (sum of durations) and launches[i] (count). Pass capacity >= InstanceDesc::pipelinesNum.
+// milliseconds[i] (sum of durations) and launches[i] (count). One more row than there are pipelines: index == InstanceDesc::pipelinesNum is the per-frame guide
+// preparation (the decode / rect-shift kernels in front of the first pass of a list). Pass capacity >= InstanceDesc::pipelinesNum + 1.
 uint32_t nrdHipSetProfiling(NrdHipExecutor* executor, uint32_t enable);
 uint32_t nrdHipCollectPassTimings(NrdHipExecutor* executor, uint32_t* pipelineIndices, double* milliseconds, uint32_t* launches, uint32_t capacity, uint32_t* written);
 

@@ -56,6 +56,9 @@ struct ShardedIntegrationHipCreationDesc {
     // IN_VIEWZ / IN_MV over this rank's strip (the temporal passes' surface-motion reprojection, moving objects included), the ranks take the maximum
     // (HaloTransport::MaxOverRanks) and a frame with 2 x motion + 2 >= maxMotionRows (virtual motion of specular reflections, bicubic footprint) runs unsharded.
     bool measureMotion = false;
+    // Denoise() ends with GatherOutputs(): every rank receives the other ranks' rows of the OUT_* planes the frame wrote (BASELINE configs[3]: "screen tiled across the GPUs
+    // with RCCL all-gather"; the reference's nrd::Integration::Denoise hands back complete outputs, NRDIntegration.hpp:516-623)
+    bool gatherOutputs = true;
 };
 
 class ShardedIntegrationHip {
@@ -203,6 +206,37 @@ public:
     }
     inline void EndFrame() { m_Complete = m_Fallback; }
 
+    // The reassembly of the outputs: after a sharded frame every rank receives, IN PLACE in its bound OUT_* planes, the rows of every other rank -- one band per source rank
+    // and plane through HaloTransport::Broadcast (over RCCL: ncclBroadcast, i.e. an all-gather spelled as the group of its broadcasts; strips re-cut by a load balancer
+    // are unequal). The bound OUT_* planes are working planes of the pass chain: the application consumes them before its next Denoise(), as with the reference's
+    // nrd::Integration. (The Python host stages its rows into separate complete planes and lets the all-gather overlap the next frame: sharding.py HaloSharder.)
+    inline bool GatherOutputs() {
+        if (m_Fallback || m_Desc.world == 1)
+            return true; // every rank computed every row
+        NrdHipExecutor* ex = m_Integration.GetExecutor();
+        (void)ex;
+        std::set<uint32_t> outputs;
+        for (uint32_t i = 0; i < m_DispatchesNum; i++)
+            for (uint32_t r = 0; r < m_Dispatches[i].resourcesNum; r++) {
+                const ResourceDesc& res = m_Dispatches[i].resources[r];
+                if (res.descriptorType == DescriptorType::STORAGE_TEXTURE && (uint32_t)res.type >= (uint32_t)ResourceType::OUT_DIFF_RADIANCE_HITDIST && (uint32_t)res.type < (uint32_t)ResourceType::TRANSIENT_POOL)
+                    outputs.insert((uint32_t)res.type);
+            }
+        for (uint32_t type : outputs)
+            for (uint32_t src = 0; src < m_Desc.world; src++) {
+                HaloTransfer band;
+                if (m_Bounds[src + 1] == m_Bounds[src])
+                    continue;
+                if (!MakeTransfer(type, 0, m_Bounds[src], m_Bounds[src + 1], src == m_Desc.rank, src, band))
+                    return false;
+                if (!m_Desc.transport->Broadcast(band, src, m_Desc.integration.hipStream))
+                    return Fail("transport broadcast failed while gathering the outputs");
+                m_GatheredBytes += src == m_Desc.rank ? 0 : band.bytes;
+            }
+        return true;
+    }
+    inline size_t GetGatheredBytes() const { return m_GatheredBytes; }
+
     inline bool Denoise(const Identifier* denoisers, uint32_t denoisersNum, const UserPoolHip& userPool) {
         if (!BeginFrame(denoisers, denoisersNum, userPool))
             return false;
@@ -210,7 +244,7 @@ public:
             if (!ExchangeStep(s) || !RunStep(s))
                 return false;
         EndFrame();
-        return true;
+        return !m_Desc.gatherOutputs || GatherOutputs();
     }
 
     // The plane behind a (resourceType, indexInPool) key: a pool plane of the executor or the user plane bound to that slot
@@ -267,6 +301,7 @@ private:
     std::vector<NrdHipHaloStep> m_Steps;
     std::vector<NrdHipHaloItem> m_Items;
     bool m_Fallback = true, m_Complete = true, m_Pending = false;
+    size_t m_GatheredBytes = 0;
     float m_LastMotionRows = -1.0f;
     uint32_t m_MotionFallbacks = 0;
     const char* m_Error = nullptr;

@@ -321,8 +321,9 @@ extern "C" __attribute__((visibility("default"))) uint32_t nrdHipCollectPassTimi
         return (uint32_t)nrd::Result::INVALID_ARGUMENT;
     if (hipStreamSynchronize(e->stream) != hipSuccess)
         return e->Fail(nrd::Result::FAILURE, "hipStreamSynchronize failed");
-    std::vector<double> ms(e->launchers.size(), 0.0);
-    std::vector<uint32_t> n(e->launchers.size(), 0);
+    // (one slot more than there are pipelines: index == pipelinesNum is the per-frame guide preparation -- decode / shift kernels in front of the first pass)
+    std::vector<double> ms(e->launchers.size() + 1, 0.0);
+    std::vector<uint32_t> n(e->launchers.size() + 1, 0);
     for (auto& b : e->brackets) {
         float t = 0.0f;
         if (hipEventElapsedTime(&t, b.start, b.stop) == hipSuccess && b.pipelineIndex < ms.size()) {
@@ -1092,8 +1093,23 @@ static uint32_t ExecuteRange(NrdHipExecutor* e, const nrd::DispatchDesc* descs, 
                 recorder.records[k].launch(recorder.records[k], e->stream);
             return hipGetLastError(); // launch-configuration errors surface here (no synchronisation)
         };
-        if (enqueue(0, prepareRecords) != hipSuccess) // outside the timing bracket of the first pass
-            return e->Fail(nrd::Result::FAILURE, "HIP launch failed while preparing the guide planes");
+        {   // outside the timing bracket of the first pass; profiled as a row of its own (pipeline index == number of pipelines: include/NRDHip.h nrdHipCollectPassTimings)
+            NrdHipExecutor::Bracket bracket = {};
+            const bool timed = e->profiling && prepareRecords > 0;
+            if (timed) {
+                bracket.start = AcquireEvent(e);
+                bracket.stop = AcquireEvent(e);
+                bracket.pipelineIndex = (uint32_t)e->launchers.size();
+                (void)hipEventRecord(bracket.start, e->stream);
+            }
+            const hipError_t prepareError = enqueue(0, prepareRecords);
+            if (timed) {
+                (void)hipEventRecord(bracket.stop, e->stream);
+                e->brackets.push_back(bracket);
+            }
+            if (prepareError != hipSuccess)
+                return e->Fail(nrd::Result::FAILURE, "HIP launch failed while preparing the guide planes");
+        }
         for (uint32_t i = first; i < first + count; i++) {
             const nrd::DispatchDesc& d = descs[i];
             const uint32_t from = i == first ? prepareRecords : recordEnd[i - first - 1];

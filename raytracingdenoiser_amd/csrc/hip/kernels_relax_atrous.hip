@@ -75,7 +75,9 @@ constexpr int BUF_STRIDE = BUF_X + 1;      // 37
 constexpr int BUF_SIZE = BUF_Y * BUF_STRIDE;
 } // namespace sm
 
-template <bool DIFF, bool SPEC, bool SH>
+// MAT: material tests compiled in (the launcher picks the variant from the constants: material IDs are 0..3, a minimum material >= 3 -- the library default is 4 -- makes
+// every comparison hold; a run-time test per tap, even a uniform one, is turned into compare + select by the compiler and saves nothing)
+template <bool DIFF, bool SPEC, bool SH, bool MAT>
 __global__ __launch_bounds__(256, NRD_WAVES_RELAX_ATROUS_SMEM) void RelaxAtrousSmemKernel(AtrousPlanes P, RelaxCB c, RowRange rows) {
     __shared__ float4 s_Spec[SPEC ? sm::BUF_SIZE : 1], s_SpecSH[(SPEC && SH) ? sm::BUF_SIZE : 1];
     __shared__ float4 s_Diff[DIFF ? sm::BUF_SIZE : 1], s_DiffSH[(DIFF && SH) ? sm::BUF_SIZE : 1];
@@ -145,6 +147,7 @@ __global__ __launch_bounds__(256, NRD_WAVES_RELAX_ATROUS_SMEM) void RelaxAtrousS
     const float3 centerNormal = Xyz(normalRoughness);
     const float centerRoughness = normalRoughness.w;
     const float historyLength = 255.0f * LoadR8Unorm(P.historyLength, px, py);
+    constexpr bool compareSpecMaterials = MAT, compareDiffMaterials = MAT;
 
     if (historyLength >= c.shared.gHistoryThreshold) {
         // 3x3 gaussian-filtered variance
@@ -247,7 +250,8 @@ __global__ __launch_bounds__(256, NRD_WAVES_RELAX_ATROUS_SMEM) void RelaxAtrousS
                     float wSpecular = geometryW * ExpNegAbs(specularLuminanceW);
                     wSpecular *= c.shared.gRoughnessEdgeStoppingEnabled ? (normalWSpecular * roughnessWSpecular) : normalWSpecularSimplified;
                     wSpecular = isCenter ? kernelW : wSpecular;
-                    wSpecular *= Cmp(CompareMaterials(sampleMaterialID, centerMaterialID, c.shared.gSpecMinMaterial));
+                    if (compareSpecMaterials)
+                        wSpecular *= Cmp(CompareMaterials(sampleMaterialID, centerMaterialID, c.shared.gSpecMinMaterial));
 
                     sumWSpecular += wSpecular;
                     sumSpecular = Mad(sampleSpecular, wSpecular, sumSpecular);
@@ -266,7 +270,8 @@ __global__ __launch_bounds__(256, NRD_WAVES_RELAX_ATROUS_SMEM) void RelaxAtrousS
 
                     float wDiffuse = geometryW * normalWDiffuse * ExpNegAbs(diffuseLuminanceW);
                     wDiffuse = isCenter ? kernelW : wDiffuse;
-                    wDiffuse *= Cmp(CompareMaterials(sampleMaterialID, centerMaterialID, c.shared.gDiffMinMaterial));
+                    if (compareDiffMaterials)
+                        wDiffuse *= Cmp(CompareMaterials(sampleMaterialID, centerMaterialID, c.shared.gDiffMinMaterial));
 
                     sumWDiffuse += wDiffuse;
                     sumDiffuse = Mad(sampleDiffuse, wDiffuse, sumDiffuse);
@@ -318,7 +323,8 @@ __global__ __launch_bounds__(256, NRD_WAVES_RELAX_ATROUS_SMEM) void RelaxAtrousS
                     float4 sampleSpecular = s_Spec[li];
                     float sample1stMoment = Luminance(Xyz(sampleSpecular));
                     float specularW = normalW * depthW;
-                    specularW *= Cmp(CompareMaterials(sampleMaterialID, centerMaterialID, c.shared.gSpecMinMaterial));
+                    if (compareSpecMaterials)
+                        specularW *= Cmp(CompareMaterials(sampleMaterialID, centerMaterialID, c.shared.gSpecMinMaterial));
                     sumWSpecular += specularW;
                     sumSpecularIllumination = Mad(Xyz(sampleSpecular), specularW, sumSpecularIllumination);
                     sumSpecular1stMoment += sample1stMoment * specularW;
@@ -330,7 +336,8 @@ __global__ __launch_bounds__(256, NRD_WAVES_RELAX_ATROUS_SMEM) void RelaxAtrousS
                     float4 sampleDiffuse = s_Diff[li];
                     float sample1stMoment = Luminance(Xyz(sampleDiffuse));
                     float diffuseW = normalW * depthW;
-                    diffuseW *= Cmp(CompareMaterials(sampleMaterialID, centerMaterialID, c.shared.gDiffMinMaterial));
+                    if (compareDiffMaterials)
+                        diffuseW *= Cmp(CompareMaterials(sampleMaterialID, centerMaterialID, c.shared.gDiffMinMaterial));
                     sumWDiffuse += diffuseW;
                     sumDiffuseIllumination = Mad(Xyz(sampleDiffuse), diffuseW, sumDiffuseIllumination);
                     sumDiffuse1stMoment += sample1stMoment * diffuseW;
@@ -380,7 +387,10 @@ const char* LaunchAtrousSmem(const PassArgs& a) {
     RowGrid g = GridForRows((c.shared.gRectSize.x + 7) & ~7, (c.shared.gRectSize.y + 7) & ~7, TILE_X, TILE_Y, a.rowBegin, a.rowEnd);
     if (a.rowEnd >= c.shared.gRectSize.y) // the owner of the last rows also owns the rounding rows below the rect
         g.rowEnd = (c.shared.gRectSize.y + 7) & ~7;
-    LaunchPass(a, (RelaxAtrousSmemKernel<DIFF, SPEC, SH>), g.grid, dim3(256), P, c, MakeRowRange(g));
+    if (c.shared.gSpecMinMaterial < 3.0f || c.shared.gDiffMinMaterial < 3.0f)
+        LaunchPass(a, (RelaxAtrousSmemKernel<DIFF, SPEC, SH, true>), g.grid, dim3(256), P, c, MakeRowRange(g));
+    else
+        LaunchPass(a, (RelaxAtrousSmemKernel<DIFF, SPEC, SH, false>), g.grid, dim3(256), P, c, MakeRowRange(g));
     return nullptr;
 }
 
@@ -420,7 +430,7 @@ const char* LaunchAtrousSmem(const PassArgs& a) {
 #ifndef NRD_ATROUS_LDS_TILES
 #define NRD_ATROUS_LDS_TILES 1 // 0: every iteration gathers from global memory (A/B and the emulation's cross-check)
 #endif
-template <bool DIFF, bool SPEC, bool SH, int STEP, bool RES>
+template <bool DIFF, bool SPEC, bool SH, int STEP, bool RES, bool MAT>
 __global__ __launch_bounds__(256, NRD_WAVES_RELAX_ATROUS) void RelaxAtrousKernel(AtrousPlanes P, RelaxCB c, RowRange rows) {
     // one layout for the two guide planes and one for the (up to four) RGBA16F signal planes: verified by the launcher
     ShareLayout(P.worldPosViewZ, P.decodedNR);
@@ -598,7 +608,7 @@ __global__ __launch_bounds__(256, NRD_WAVES_RELAX_ATROUS) void RelaxAtrousKernel
     // instead of being skipped by a divergent branch, so all loads of a pixel can be in flight together instead of one dependent wait per tap and signal.
     // (0 * sample adds nothing: the history planes hold finite fp16 values by construction.) Planes of one format share their layout (launcher check),
     // so one texel offset serves the two guide planes and one the four signal planes.
-    const bool compareSpecMaterials = c.shared.gSpecMinMaterial < 3.0f, compareDiffMaterials = c.shared.gDiffMinMaterial < 3.0f; // IDs are 0..3: a minimum >= 3 disables the test
+    constexpr bool compareSpecMaterials = MAT, compareDiffMaterials = MAT; // compile-time variant (RelaxAtrousSmemKernel): IDs are 0..3, a minimum >= 3 disables the test
 #pragma unroll
     for (int yy = -1; yy <= 1; yy++) {
         const int bandX0 = blockX0 - STEP - R, bandY0 = blockY0 + yy * STEP - R; // texel (unclamped) of the band's LDS element (0, 0)
@@ -815,7 +825,9 @@ const char* LaunchAtrous(const PassArgs& a) {
     const RowRange rr = MakeRowRange(g);
     const int step = (AtrousLdsTilesEnabled() && (c.gStepSize == 2 || c.gStepSize == 4)) || ((c.gStepSize == 8 || c.gStepSize == 16) && (int)c.gStepSize <= AtrousLdsBandsMaxStep()) ? (int)c.gStepSize : 0;
     const bool res = !SPEC || c.shared.gRoughnessEdgeStoppingEnabled != 0; // (irrelevant without a specular signal: one instantiation)
-#define NRD_LAUNCH_ATROUS(STEP, RES) LaunchPass(a, (RelaxAtrousKernel<DIFF, SPEC, SH, STEP, RES>), g.grid, dim3(256), P, c, rr)
+    const bool mat = c.shared.gSpecMinMaterial < 3.0f || c.shared.gDiffMinMaterial < 3.0f;
+#define NRD_LAUNCH_ATROUS_M(STEP, RES, MAT) LaunchPass(a, (RelaxAtrousKernel<DIFF, SPEC, SH, STEP, RES, MAT>), g.grid, dim3(256), P, c, rr)
+#define NRD_LAUNCH_ATROUS(STEP, RES) (mat ? NRD_LAUNCH_ATROUS_M(STEP, RES, true) : NRD_LAUNCH_ATROUS_M(STEP, RES, false))
     if (step == 2)
         res ? NRD_LAUNCH_ATROUS(2, true) : NRD_LAUNCH_ATROUS(2, SPEC ? false : true);
     else if (step == 4)
@@ -826,6 +838,7 @@ const char* LaunchAtrous(const PassArgs& a) {
         res ? NRD_LAUNCH_ATROUS(16, true) : NRD_LAUNCH_ATROUS(16, SPEC ? false : true);
     else
         res ? NRD_LAUNCH_ATROUS(0, true) : NRD_LAUNCH_ATROUS(0, SPEC ? false : true);
+#undef NRD_LAUNCH_ATROUS_M
 #undef NRD_LAUNCH_ATROUS
     return nullptr;
 }

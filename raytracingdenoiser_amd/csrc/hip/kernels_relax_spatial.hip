@@ -237,7 +237,9 @@ NRD_D PrePassGuides FetchPrePassGuides(const RelaxCB& c, const PrePassPlanes& P,
     return g;
 }
 
-template <bool DIFF, bool SPEC, bool SH, bool CB, bool FR>
+// MAT: material tests compiled in (launcher; only the full-rect variant has a MAT = false twin). Material IDs are 0..3: with a minimum material >= 3 (the default is 4) every
+// comparison holds. A run-time test inside the tap loop -- even a uniform one -- is if-converted into compare + select and saves nothing (round 5: a-trous 1 340 -> 1 200 instructions).
+template <bool DIFF, bool SPEC, bool SH, bool CB, bool FR, bool MAT = true>
 __global__ __launch_bounds__(256, NRD_WAVES_RELAX_PREPASS) void RelaxPrePassKernel(PrePassPlanes P, RelaxCB c, RowRange rows) {
     const int blockY = BlockTileY(rows, true);
     const int px = BlockTileX(rows) * TILE_X + (threadIdx.x & 31), py = blockY * TILE_Y + (threadIdx.x >> 5);
@@ -318,7 +320,7 @@ __global__ __launch_bounds__(256, NRD_WAVES_RELAX_PREPASS) void RelaxPrePassKern
 
                 float sampleWeight = t.inScreen;
                 sampleWeight *= Cmp(sampleViewZ < c.shared.gDenoisingRange);
-                if (c.shared.gDiffMinMaterial < 3.0f) // material IDs are 0..3: a minimum >= 3 makes every comparison hold
+                if (MAT && c.shared.gDiffMinMaterial < 3.0f) // material IDs are 0..3: a minimum >= 3 makes every comparison hold
                     sampleWeight *= Cmp(CompareMaterials(centerMaterialID, sampleMaterialID, c.shared.gDiffMinMaterial));
                 sampleWeight *= GetPlaneDistanceWeight(centerWorldPos, centerNormal, centerViewZ, sampleWorldPos, c.shared.gDepthThreshold);
                 float angle = AcosApprox(Dot(centerNormal, sampleNormal));
@@ -400,7 +402,7 @@ __global__ __launch_bounds__(256, NRD_WAVES_RELAX_PREPASS) void RelaxPrePassKern
 
                 float sampleWeight = t.inScreen;
                 sampleWeight *= Cmp(sampleViewZ < c.shared.gDenoisingRange);
-                if (c.shared.gSpecMinMaterial < 3.0f)
+                if (MAT && c.shared.gSpecMinMaterial < 3.0f)
                     sampleWeight *= Cmp(CompareMaterials(centerMaterialID, sampleMaterialID, c.shared.gSpecMinMaterial));
                 sampleWeight *= ComputeWeight(sampleRoughness, roughnessWeightParams.x, roughnessWeightParams.y);
                 float angle = AcosApprox(Dot(centerNormal, sampleNormal));
@@ -466,6 +468,8 @@ const char* LaunchPrePass(const PassArgs& a) {
                           c.shared.gRectSize.y == P.decodedNR.h && P.viewZ.w == P.decodedNR.w && P.viewZ.h == P.decodedNR.h && !(forceGeneric && atoi(forceGeneric) != 0);
     if ((SPEC && c.shared.gSpecCheckerboard != 2u) || (DIFF && c.shared.gDiffCheckerboard != 2u))
         LaunchPass(a, (RelaxPrePassKernel<DIFF, SPEC, SH, true, false>), g.grid, dim3(256), P, c, MakeRowRange(g));
+    else if (fullRect && !(c.shared.gSpecMinMaterial < 3.0f || c.shared.gDiffMinMaterial < 3.0f))
+        LaunchPass(a, (RelaxPrePassKernel<DIFF, SPEC, SH, false, true, false>), g.grid, dim3(256), P, c, MakeRowRange(g));
     else if (fullRect)
         LaunchPass(a, (RelaxPrePassKernel<DIFF, SPEC, SH, false, true>), g.grid, dim3(256), P, c, MakeRowRange(g));
     else

@@ -48,7 +48,9 @@ struct TaPlanes {
 // the previous frame per workgroup, copied into LDS with coalesced row loads -- every texel once -- and read from there; bit-identical by construction (same
 // texels at the same clamped coordinates, same arithmetic). A tile whose rectangle does not fit sets its byte of P.tileFlags and is done by MODE 2, the plain
 // kernel behind a flag test, launched right after. The SH histories (2x2 bilinear only) and the virtual-motion fetches stay in global memory.
-template <bool DIFF, bool SPEC, bool SH, int MODE>
+// MAT: material tests compiled in (the launcher picks MAT = false when both minimum materials are >= 3: IDs are 0..3, every comparison then holds; inside the unrolled
+// footprint loops a run-time test is if-converted into compare + select and saves nothing)
+template <bool DIFF, bool SPEC, bool SH, int MODE, bool MAT = true>
 __device__ __forceinline__ void RelaxTemporalAccumulationTile(const RelaxCB& cArg, TaPlanes P, const RowRange& rows, const int tileX, const int blockY) {
     __shared__ float4 s_NormalSpecHitT[ta::BUF_Y * ta::BUF_STRIDE];
     constexpr int WIN_TEXELS = MODE == 1 ? WIN_W * WIN_H : 1;
@@ -232,7 +234,7 @@ __device__ __forceinline__ void RelaxTemporalAccumulationTile(const RelaxCB& cAr
         const float2 bilinearWeights = F2(Frac(prevPixelPosFloat.x - 0.5f), Frac(prevPixelPosFloat.y - 0.5f));
         const float minMaterialID = Min(c.shared.gSpecMinMaterial, c.shared.gDiffMinMaterial);
         // no material reads at all while the material test is off (IDs are 0..3: a minimum >= 3 makes every comparison hold; the library default is 4)
-        const bool compareMaterials = minMaterialID < 3.0f;
+        const bool compareMaterials = MAT && minMaterialID < 3.0f;
 
         // ---- MODE 1: the window. Every surface-motion read of this pixel is a texel at a clamped coordinate within [bx - 1, bx + 2] x [by - 1, by + 2]
         int wx0 = 0, wy0 = 0;
@@ -551,7 +553,7 @@ __device__ __forceinline__ void RelaxTemporalAccumulationTile(const RelaxCB& cAr
             vmbDisocclusionThreshold = vmbDisocclusionThreshold * IsInScreenBilinear(originF, rectSizePrev);
             vmbDisocclusionThreshold = vmbDisocclusionThreshold - NRD_EPS;
 
-            const bool compareSpecMaterials = c.shared.gSpecMinMaterial < 3.0f;
+            const bool compareSpecMaterials = MAT && c.shared.gSpecMinMaterial < 3.0f;
             auto TapValid = [&](int dx, int dy, float threshold) {
                 float z = RelaxUnpackViewZ(c, quadInterior ? zQuad[dy][dx] : FetchClampedR32F(P.prevViewZ, bx + dx, by + dy));
                 float3 prevWorldPosInTap = GetPreviousWorldPosFromPixelPos(c, bx + dx, by + dy, z);
@@ -737,11 +739,11 @@ __device__ __forceinline__ void RelaxTemporalAccumulationTile(const RelaxCB& cAr
 // MODE 0 / 1: one workgroup per tile (XCD-aware order). MODE 2 (fallback behind the window kernel): one workgroup per FALLBACK_TILES tile columns, which walks
 // them and runs the pass on the flagged ones (kernels_reblur_ta.hip has the measurement behind this shape)
 constexpr int FALLBACK_TILES = 8;
-template <bool DIFF, bool SPEC, bool SH, int MODE>
+template <bool DIFF, bool SPEC, bool SH, int MODE, bool MAT = true>
 __global__ __launch_bounds__(256, NRD_WAVES_RELAX_TA) void RelaxTemporalAccumulationKernel(RelaxCB cArg, TaPlanes P, RowRange rows) {
     const int blockY = BlockTileY(rows, true);
     if (MODE != 2) {
-        RelaxTemporalAccumulationTile<DIFF, SPEC, SH, MODE>(cArg, P, rows, BlockTileX(rows), blockY);
+        RelaxTemporalAccumulationTile<DIFF, SPEC, SH, MODE, MAT>(cArg, P, rows, BlockTileX(rows), blockY);
         return;
     }
     if (blockY >= P.tileFlags.h)
@@ -849,7 +851,10 @@ const char* LaunchTemporalAccumulation(const PassArgs& a) {
         LaunchPass(a, (RelaxTemporalAccumulationKernel<DIFF, SPEC, SH, 2>), fallbackGrid, dim3(256), c, P, MakeRowRange(g));
         return nullptr;
     }
-    LaunchPass(a, (RelaxTemporalAccumulationKernel<DIFF, SPEC, SH, 0>), g.grid, dim3(256), c, P, MakeRowRange(g));
+    if (c.shared.gSpecMinMaterial < 3.0f || c.shared.gDiffMinMaterial < 3.0f)
+        LaunchPass(a, (RelaxTemporalAccumulationKernel<DIFF, SPEC, SH, 0>), g.grid, dim3(256), c, P, MakeRowRange(g));
+    else
+        LaunchPass(a, (RelaxTemporalAccumulationKernel<DIFF, SPEC, SH, 0, false>), g.grid, dim3(256), c, P, MakeRowRange(g));
     return nullptr;
 }
 

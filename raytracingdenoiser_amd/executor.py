@@ -130,10 +130,13 @@ class HipExecutor:
 
     def collect_pass_timings(self):
         """{shaderFileName: (total_ms, launches)} for all dispatches since the last collect (synchronises the stream)."""
-        n = len(self.instance.pipelines)
+        n = len(self.instance.pipelines) + 1  # + the per-frame guide preparation (decode / shift kernels in front of the first pass), reported under GUIDE_PREPARATION
         idx, ms, cnt, written = (C.c_uint32 * n)(), (C.c_double * n)(), (C.c_uint32 * n)(), C.c_uint32()
         self._check(self.lib.nrdHipCollectPassTimings(self.handle, idx, ms, cnt, n, C.byref(written)), "nrdHipCollectPassTimings")
-        return {self.instance.pipelines[idx[i]]: (ms[i], cnt[i]) for i in range(written.value)}
+        names = list(self.instance.pipelines) + [self.GUIDE_PREPARATION]
+        return {names[idx[i]]: (ms[i], cnt[i]) for i in range(written.value)}
+
+    GUIDE_PREPARATION = "(guide planes: DecodeGuidesKernel)"
 
     def pool_memory(self):
         p, t = C.c_uint64(), C.c_uint64()

@@ -397,13 +397,13 @@ class HaloSharder:
         self.motion_fallbacks = 0  # frames run unsharded because the motion estimate exceeded the history halo
         self._plans = {}
         # Output reassembly (BASELINE.json configs[3]: "screen tiled across 8 x MI355X with RCCL all-gather"; the reference's Integration::Denoise hands back COMPLETE outputs,
-        # NRDIntegration.hpp:516-623): after the last pass every rank all-gathers its rows of the user's OUT_* planes. Issued asynchronously -- over RCCL the collective runs on
-        # the communicator's stream behind an event of the compute stream -- and awaited only in front of the first pass of the NEXT frame that touches an OUT_* plane (they
-        # double as scratch of the pass chain), so tile classification, the pre-pass and temporal accumulation of frame f + 1 run while the rows of frame f travel.
-        # wait_outputs() is what a consumer of the outputs calls.
+        # NRDIntegration.hpp:516-623). The bound OUT_* planes are working planes of the pass chain (the pre-pass of the NEXT frame already overwrites them), so the complete
+        # planes are separate tensors owned by the sharder (complete_output): after the last pass a rank copies its rows into them (device-to-device, microseconds) and the ranks
+        # all-gather them in place -- asynchronously over RCCL, on the communicator's stream behind an event of the compute stream -- while the whole next frame runs.
+        # wait_outputs() is what a consumer of the outputs calls before complete_output().
         self.gather_outputs = gather_outputs
         self._pending_gather = None
-        self._gather_first_use = 0
+        self._complete = {}
         self.gathered_bytes = 0   # bytes received by this rank in output all-gathers, for reporting
         self.gather_frames = 0
 
@@ -519,6 +519,11 @@ class HaloSharder:
                     self.rebalanced += 1
         plan.complete_keys = carried_over_planes(dispatches, small) if plan.fallback and not self.complete and self.world > 1 else []
         plan.output_keys, plan.first_output_use = output_planes_of(dispatches)
+        if plan.complete_keys and self.gather_outputs:
+            # the OUT_* planes too: texels the frame does not write (a pixel that turned into sky) keep what the LAST frame that wrote them left there -- on a single GPU that
+            # is the previous frame's value, on a rank that did not own the row it would be a value from before the strips were cut. Nothing reads those texels, but the
+            # reassembled planes are held bit for bit against a single GPU, unwritten texels included.
+            plan.complete_keys = plan.complete_keys + [k for k in plan.output_keys if k not in plan.complete_keys]
         if not plan.fallback:
             if len(self._plans) > 16:
                 self._plans.clear()
@@ -596,22 +601,48 @@ class HaloSharder:
                 if src != self.rank:
                     self.exchanged_bytes += band.numel()
 
+    def complete_output(self, resource_type):
+        """the COMPLETE output plane of the last frame (all ranks' rows), as a tensor shaped like the bound OUT_* tensor -- valid after wait_outputs(). The bound OUT_* planes
+        themselves are working planes of the pass chain (the next frame's pre-pass overwrites them) and hold this rank's rows only."""
+        key = (int(resource_type), 0)
+        return self._complete[key] if key in self._complete else self.ex._bound[key[0]]  # (one rank: the bound plane is the complete plane)
+
+    def _complete_plane(self, key):
+        """[H, pitch] uint8 view of the complete copy of an output plane (allocated on first use, same shape as the bound tensor)"""
+        import torch
+
+        bound = self.ex._bound[key[0]]
+        t = self._complete.get(key)
+        if t is None or t.shape != bound.shape or t.dtype != bound.dtype or t.device != bound.device:
+            t = self._complete[key] = torch.zeros_like(bound)
+        return t.view(-1).view(dtype=torch.uint8).view(self.height, -1)
+
+    def stage_outputs(self, plan):
+        """this rank's rows of every OUT_* plane (the whole plane after an unsharded frame) -> the complete copies. Device-to-device on the compute stream, behind the last pass."""
+        self.wait_outputs()  # the previous frame's all-gather still reads / writes the complete copies (it finished a frame ago; over RCCL this is an event wait, no host block)
+        rb, re = (0, self.height) if plan.fallback or self.rows is None else self.rows
+        for key in plan.output_keys:
+            self._complete_plane(key)[rb:re].copy_(self.plane_tensor(key)[rb:re], non_blocking=True)
+
     def start_output_gather(self, plan):
-        """ONE all-gather per OUT_* plane of the rows each rank owns (grouped into one RCCL launch where torch allows it). Equal strips: in place, every rank's rows already sit
-        at their offset (all_gather_into_tensor); strips re-cut by the load balancer are unequal: the list form, which RCCL runs as a group of broadcasts into the row views.
-        Returns the pending work (None: nothing to do / done synchronously)."""
+        """ONE all-gather per OUT_* plane (grouped into one RCCL launch where torch allows it), in place on the complete copies: equal strips -- every rank's rows already sit at
+        their offset (all_gather_into_tensor); strips re-cut by the load balancer are unequal -- the list form, which RCCL runs as a group of broadcasts into the row views.
+        Asynchronous over RCCL: the collective runs on the communicator's stream behind an event of the compute stream (the staging copies), next to the WHOLE next frame --
+        nothing of the next frame touches the complete copies. Returns the pending work (None: nothing to do / done synchronously)."""
         import torch.distributed as dist
 
-        if not self.gather_outputs or self.world == 1 or plan.fallback or not plan.output_keys or self.bounds is None:
+        if not self.gather_outputs or not plan.output_keys or self.world == 1:
             return None
+        self.stage_outputs(plan)
+        if plan.fallback or self.bounds is None:
+            return None  # an unsharded frame: every rank computed every row
         if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(self.group) != self.world:
-            return None  # virtual ranks of the single-process tests: they replay output_gather_ops() with copies
-        planes = [self.plane_tensor(key) for key in plan.output_keys]
+            return None  # virtual ranks of the single-process tests: they replay output_gather_ops() with copies between the ranks' complete planes
+        planes = [self._complete_plane(key) for key in plan.output_keys]
         rb, re = self.rows
         heights = [b - a for a, b in zip(self.bounds, self.bounds[1:])]
         self.gathered_bytes += sum(p.shape[1] * (p.shape[0] - (re - rb)) for p in planes)
         self.gather_frames += 1
-        self._gather_first_use = plan.first_output_use
         if dist.get_backend(self.group) != "nccl":  # gloo (CPU tests, or two ranks sharing one GPU with host staging): synchronous
             import torch
 
@@ -628,7 +659,7 @@ class HaloSharder:
                     else:
                         dist.broadcast(band, src, self.group)
             return None
-        uniform = len(set(heights)) == 1 and all(p.shape[0] == self.height for p in planes)
+        uniform = len(set(heights)) == 1
 
         def issue():
             works = []
@@ -654,33 +685,16 @@ class HaloSharder:
         return issue()
 
     def wait_outputs(self):
-        """the compute stream waits for the pending output all-gather (no host block over RCCL); every rank then holds the complete OUT_* planes of the last frame"""
+        """the compute stream waits for the pending output all-gather (no host block over RCCL); complete_output() then holds every rank's rows of the last frame"""
         pending, self._pending_gather = self._pending_gather, None
         if pending:
             for work in pending:
                 work.wait()
 
-    def _execute(self, plan, ptr, n, first, count, rows=True):
-        """execute_range with the previous frame's output gather awaited in front of the first pass that touches an OUT_* plane"""
-        if count <= 0:
-            return
-        args = plan.c_rows() if rows else ()
-        if self._pending_gather and first + count > self._gather_first_use:
-            head = max(min(self._gather_first_use - first, count), 0)
-            if head:
-                self.ex.execute_range(ptr, n, first, head, *args)
-            self.wait_outputs()
-            first, count = first + head, count - head
-        if count:
-            self.ex.execute_range(ptr, n, first, count, *args)
-
     def denoise(self, motion_rows=None):
         """motion_rows: the application's bound on the vertical motion of moving objects this frame (rows); camera motion is estimated here"""
         plan, ptr, n = self.begin_frame(motion_rows)
-        if self._pending_gather:
-            self._gather_first_use = min(self._gather_first_use, plan.first_output_use)  # (this frame's list decides where the planes are touched first)
         if plan.fallback:
-            self.wait_outputs()
             self.complete_planes(plan.complete_keys)
             self.ex.execute_range(ptr, n, 0, n)
         else:
@@ -688,10 +702,11 @@ class HaloSharder:
                 # the passes in front of the first reader of an exchanged plane (tile classification, pre-pass: user inputs only) hide the transfers
                 pending = self.start_exchange(plan, step)
                 early = plan.early[step] if pending is not None else 0
-                self._execute(plan, ptr, n, first, early)
+                if early:
+                    self.ex.execute_range(ptr, n, first, early, *plan.c_rows())
                 finish_halo_exchange(pending)
-                self._execute(plan, ptr, n, first + early, count - early)
-            self._pending_gather = self.start_output_gather(plan)
+                self.ex.execute_range(ptr, n, first + early, count - early, *plan.c_rows())
+        self._pending_gather = self.start_output_gather(plan)
         self.finish_frame(plan)
         return plan
 
@@ -749,7 +764,14 @@ def dry_plan(name, width, height, world, overrides=None, max_motion_rows=None, e
             entry["steps"].append({"before_pass": dispatches[first].shader, "passes_in_segment": count, "planes": [{"plane": label(key), "rows_from_each_neighbour": w, "bytes_per_neighbour": w * row_bytes(key)} for key, w in items],
                                    "rccl": ["group { " + ", ".join("recv(%d rows of %d planes from rank %d), send(same to rank %d)" % (max((w for _, w in items), default=0), len(items), nb, nb) for nb in neighbours) + " }"] if items else [],
                                    "received_bytes": recv, "overlaps_with": "the first %d pass(es) of the segment (they do not touch these planes)" % plan.early[si] if si < len(plan.early) and plan.early[si] else None})
-        entry["received_bytes_per_frame"] = total
+        out_keys, first_use = output_planes_of(dispatches)
+        own = bounds[rank + 1] - bounds[rank]
+        gathered = sum(row_bytes(key) * (height - own) for key in out_keys) if not plan.fallback else 0
+        entry["output_all_gather"] = {"planes": [label(key) for key in out_keys], "rows_contributed": own, "received_bytes": gathered,
+                                      "rccl": "all_gather_into_tensor per plane, one group (equal strips: in place; re-cut strips: the list form)" if out_keys and not plan.fallback else None,
+                                      "overlaps_with": "the whole next frame (the complete planes are separate tensors: a rank stages its rows with a device copy behind the last pass)",
+                                      "ms_at_7_links_x_50GBps": round(gathered / (7 * 50e9) * 1e3, 3)}
+        entry["received_bytes_per_frame"] = total + gathered
         entry["transfer_ms_at_50GBps_per_link"] = round(total / max(len([r for r in (rank - 1, rank + 1) if 0 <= r < world]), 1) / 50e9 * 1e3, 3)
         out["per_rank"].append(entry)
     return out

@@ -138,7 +138,7 @@ int main(int argc, char** argv) {
             hNR[i] = NRD_StoreR10G10B10A2(NRD_FrontEnd_PackNormalAndRoughness(N, 0.15f + 0.7f * float((x / 24 + y / 24) & 1), 0.0f));
         }
 
-    size_t mismatches = 0, shardedFrames = 0;
+    size_t mismatches = 0, shardedFrames = 0, gatherMismatches = 0;
     for (int f = 0; f < frames; f++) {
         const float4 hitDistParams = make_float4(3.0f, 0.1f, 20.0f, -25.0f);
         for (uint32_t y = 0; y < H; y++)
@@ -245,6 +245,7 @@ int main(int argc, char** argv) {
         for (uint32_t r = 0; r < world; r++)
             ranks[r]->EndFrame();
         CHECK(hipStreamSynchronize(stream) == hipSuccess);
+        // the owned rows are compared below BEFORE the reassembly could paper over anything; the gather itself is checked after that comparison
 
         std::vector<uint16_t> ref(texels * 4), got(texels * 4);
         for (int k = 0; k < 2; k++) {
@@ -266,6 +267,22 @@ int main(int argc, char** argv) {
                 mismatches += bad;
             }
         }
+        // the reassembly (ShardedIntegrationHip::GatherOutputs, what Denoise() ends with): afterwards EVERY rank holds the complete output planes, bit for bit
+        for (uint32_t r = 0; r < world; r++)
+            CHECK(ranks[r]->GatherOutputs());
+        CHECK(hipStreamSynchronize(stream) == hipSuccess);
+        for (int k = 0; k < 2; k++) {
+            CHECK(hipMemcpy(ref.data(), k ? planes[0].outSpec : planes[0].outDiff, texels * 8, hipMemcpyDeviceToHost) == hipSuccess);
+            for (uint32_t r = 0; r < world; r++) {
+                CHECK(hipMemcpy(got.data(), k ? planes[1 + r].outSpec : planes[1 + r].outDiff, texels * 8, hipMemcpyDeviceToHost) == hipSuccess);
+                size_t bad = 0;
+                for (size_t i = 0; i < texels * 4; i++)
+                    bad += ref[i] != got[i];
+                if (bad && getenv("NRD_TEST_VERBOSE"))
+                    printf("  frame %d %s rank %u: %zu mismatching values in the COMPLETE plane after the gather\n", f, k ? "spec" : "diff", r, bad);
+                gatherMismatches += bad;
+            }
+        }
         size_t nonZero = 0;
         for (size_t i = 0; i < texels * 4; i++)
             nonZero += ref[i] != 0;
@@ -285,6 +302,9 @@ int main(int argc, char** argv) {
     if (measure && world > 1)
         for (uint32_t r = 0; r < world; r++)
             CHECK(ranks[r]->GetMotionFallbacksNum() == 1);
+    printf("%zu mismatching values in the complete planes after the output gather\n", gatherMismatches);
+    if (gatherMismatches)
+        return 1;
     if (mismatches || (world > 1 && (shardedFrames != (size_t)frames - 2 - (measure ? 1 : 0) || received == 0)))
         return 1;
     printf("sharded integration OK\n");

@@ -145,10 +145,14 @@ def _virtual_rank_run(name, w, h, world, frames, scheme):
                     rb, re = sh.rows
                     assert all(torch.equal(o[rb:re], ro[rb:re]) for o, ro in zip(outs, ref[2])), (f, sh.rank)
                 assert plans[0].output_keys and len(plans[0].output_keys) == len(ref[2])
+            # the reassembly: every rank stages its rows in its complete planes (HaloSharder.stage_outputs), then the all-gather (sharding.output_gather_ops), replayed with copies
+            for sh, plan in zip(ranks, plans):
+                sh.stage_outputs(plan)
+            if not plans[0].fallback:
                 for key, src, r0, r1 in sharding.output_gather_ops(ranks[0].bounds, plans[0].output_keys):
                     for dst, sh in enumerate(ranks):
                         if dst != src:
-                            sh.plane_tensor(key)[r0:r1].copy_(ranks[src].plane_tensor(key)[r0:r1])
+                            sh._complete_plane(key)[r0:r1].copy_(ranks[src]._complete_plane(key)[r0:r1])
             for sh, plan in zip(ranks, plans):
                 sh.finish_frame(plan)
             sharded = not plans[0].fallback
@@ -165,7 +169,11 @@ def _virtual_rank_run(name, w, h, world, frames, scheme):
                             theirs[rb:re].copy_(mine[rb:re])
             sharded = True
         torch.cuda.synchronize()
-        result.append((sharded, all(torch.equal(o, ro) for (inst, ex, outs) in runs for o, ro in zip(outs, ref[2]))))
+        rts = [rt for rt, dtype, ch, fmt in parity.output_planes(name, w, h)]
+        if scheme == "halo":  # the complete planes are the sharder's (the bound OUT_* planes are working planes of the pass chain and hold the rank's rows)
+            result.append((sharded, all(torch.equal(sh.complete_output(rt), ro) for sh in ranks for rt, ro in zip(rts, ref[2]))))
+        else:
+            result.append((sharded, all(torch.equal(o, ro) for (inst, ex, outs) in runs for o, ro in zip(outs, ref[2]))))
     return result, ranks
 
 

@@ -1,6 +1,7 @@
 """Row-strip sharding. CPU: the strip all-gather with gloo, world_size 2. GPU: N virtual ranks on one
 MI355X (one executor per rank, all-gather emulated by copies) must reproduce the single-GPU planes bit for bit."""
 import os
+import sys
 
 import numpy as np
 import pytest
@@ -429,9 +430,11 @@ def _halo_two_process_worker(rank, world, port, name, W, H, frames, q):
             inst.set_denoiser_settings(0, parity.denoiser_settings(name, frame, dict(hitDistanceReconstructionMode=1) if f == 2 else None))
             inst.set_common_settings(parity.common_settings(frame["camera"], seq[max(f - 1, 0)]["camera"], W, H, f))
             sh.denoise() if sharded else ex.denoise()
+            if sharded:
+                sh.wait_outputs()
             torch.cuda.synchronize()
             rows = sh.rows if sharded else (0, H)
-            per_frame.append(([o.clone() for o in outs], rows))
+            per_frame.append(([sh.complete_output(rt).clone() for rt, dtype, ch, fmt in parity.output_planes(name, W, H)] if sharded else [o.clone() for o in outs], rows))
         return per_frame, (sh.rebalanced if sharded else 0), (sh.exchanged_bytes if sharded else 0)
 
     ref, _, _ = run(False)
@@ -506,15 +509,24 @@ def _halo_two_process_emulated_worker(rank, world, port, name, W, H, frames, ove
             if sharded:
                 sharded_frames += 0 if sh.denoise().fallback else 1
                 measured.append(sh.measured_motion_rows)
+                sh.wait_outputs()
+                per_frame.append(([sh.complete_output(rt).clone() for rt, dtype, ch, fmt in parity.output_planes(name, W, H)], sh.rows))  # the reassembled planes
             else:
                 ex.denoise()
-            per_frame.append(([o.clone() for o in outs], sh.rows if sharded else (0, H)))
+                per_frame.append(([o.clone() for o in outs], (0, H)))
         return per_frame, sharded_frames, (sh.exchanged_bytes if sharded else 0), (sh.motion_fallbacks if sharded else 0), measured
 
     ref = run(False)[0]
     got, sharded_frames, exchanged, motion_fallbacks, measured = run(True)
     # round 5: HaloSharder.denoise() ends with the output all-gather (synchronous over gloo), so EVERY rank holds the COMPLETE output planes of every frame -- not only its rows
     ok = all(torch.equal(a, b) for (fa, _), (fb, rows) in zip(ref, got) for a, b in zip(fa, fb))
+    if os.environ.get("NRD_TEST_DEBUG"):
+        print("rank", rank, [[bool(torch.equal(a, b)) for a, b in zip(fa, fb)] for (fa, _), (fb, rows) in zip(ref, got)], [r for _, r in got], motion_fallbacks, measured, file=sys.stderr, flush=True)
+        for f, ((fa, _), (fb, rows)) in enumerate(zip(ref, got)):
+            for a, b in zip(fa, fb):
+                if not torch.equal(a, b):
+                    bad = (a != b).reshape(a.shape[0], -1).any(dim=1).nonzero().flatten().tolist()
+                    print("rank", rank, "frame", f, "rows differing", bad[:5], "...", bad[-5:], len(bad), file=sys.stderr, flush=True)
     if measure:
         # every rank saw the same (reduced) value on every frame; the fast frame measured its 40 rows and was the only motion fallback
         ok = ok and motion_fallbacks == 1 and abs(measured[frames] - 40.0) < 0.05 and all(m is not None and m < 7.0 for i, m in enumerate(measured) if i != frames)
