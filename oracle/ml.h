@@ -351,6 +351,27 @@ inline float2 GetKernelSampleCoordinates(const float4x4& mToClip, float3 offset,
     clip.y = -clip.y;
     return float2(clip.x * 0.5f + 0.5f, clip.y * 0.5f + 0.5f);
 }
+// round 5 (csrc/hip/reblur_device.h KernelProjection): the same position, affine in the unrotated Poisson offset and expanded once per pixel; the strict build keeps the
+// reference's expression above
+struct KernelProjection {
+    float3 c0, u, v;
+};
+inline KernelProjection MakeKernelProjection(const float4x4& M, float3 X, float3 T, float3 B, float4 r) {
+    const float* m = M.m;
+    const float3 Tr = Mad(B, r.z, T * r.x), Br = Mad(B, r.w, T * r.y);
+    KernelProjection k;
+    k.c0 = float3(m[0] * X.x + m[4] * X.y + m[8] * X.z + m[12], m[1] * X.x + m[5] * X.y + m[9] * X.z + m[13], m[3] * X.x + m[7] * X.y + m[11] * X.z + m[15]);
+    k.u = float3(m[0] * Tr.x + m[4] * Tr.y + m[8] * Tr.z, m[1] * Tr.x + m[5] * Tr.y + m[9] * Tr.z, m[3] * Tr.x + m[7] * Tr.y + m[11] * Tr.z);
+    k.v = float3(m[0] * Br.x + m[4] * Br.y + m[8] * Br.z, m[1] * Br.x + m[5] * Br.y + m[9] * Br.z, m[3] * Br.x + m[7] * Br.y + m[11] * Br.z);
+    return k;
+}
+inline float2 KernelSampleUv(const KernelProjection& k, float ox, float oy) {
+    float3 clip = Mad(k.v, oy, Mad(k.u, ox, k.c0));
+    clip.x = Div(clip.x, clip.z);
+    clip.y = Div(clip.y, clip.z);
+    clip.y = -clip.y;
+    return float2(clip.x * 0.5f + 0.5f, clip.y * 0.5f + 0.5f);
+}
 inline float GetNormalWeightParam(float nonLinearAccumSpeed, float lobeAngleFraction, float roughness = 1.0f) { // :486-499
     float percentOfVolume = NRD_MAX_PERCENT_OF_LOBE_VOLUME * lerp(lobeAngleFraction, 1.0f, nonLinearAccumSpeed);
     float tanHalfAngle = ImportanceSampling::GetSpecularLobeTanHalfAngle(roughness, percentOfVolume);

@@ -289,6 +289,11 @@ S SpecularSpatialFilterTaps(const ReblurCB& c, SpatialMode mode, const SpatialCt
         T *= worldRadius * skewFactor;
         B *= Div(worldRadius, skewFactor);
     }
+#ifndef ORC_STRICT_IEEE
+    KernelProjection kernelProjection = {};
+    if (!screenSpace)
+        kernelProjection = MakeKernelProjection(c.gViewToClip, s.Xv, T, B, s.rotator);
+#endif
 
     const int sampleNum = s.perf ? 6 : 8;
     for (int n = 0; n < sampleNum; n++) {
@@ -297,7 +302,11 @@ S SpecularSpatialFilterTaps(const ReblurCB& c, SpatialMode mode, const SpatialCt
         if (screenSpace)
             uv = s.pixelUv + Geometry::RotateVector(scaledRotator, float2(offset.x, offset.y));
         else
+#ifdef ORC_STRICT_IEEE
             uv = GetKernelSampleCoordinates(c.gViewToClip, offset, s.Xv, T, B, s.rotator);
+#else
+            uv = KernelSampleUv(kernelProjection, offset.x, offset.y);
+#endif
 
         uv = floor(uv * c.gRectSize) + 0.5f;
         if (mode == PRE_BLUR)

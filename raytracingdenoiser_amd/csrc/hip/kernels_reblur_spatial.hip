@@ -370,6 +370,9 @@ NRD_D typename ReblurSignal<KIND>::type SpecularSpatialFilterTaps(const ReblurCB
         T = T * (worldRadius * skewFactor);
         B = B * (Div(worldRadius, skewFactor));
     }
+    KernelProjection kernelProjection = {};
+    if (!SCREEN_SPACE)
+        kernelProjection = MakeKernelProjection(c.gViewToClip, s.Xv, T, B, s.rotator);
 
 #pragma unroll
     for (int n = 0; n < (PERF ? 6 : 8); n++) {
@@ -378,7 +381,7 @@ NRD_D typename ReblurSignal<KIND>::type SpecularSpatialFilterTaps(const ReblurCB
         if (SCREEN_SPACE)
             uv = s.pixelUv + RotateVector(scaledRotator, F2(offset.x, offset.y));
         else
-            uv = GetKernelSampleCoordinates(c.gViewToClip, offset, s.Xv, T, B, s.rotator);
+            uv = KernelSampleUv(kernelProjection, offset.x, offset.y);
         TapGuides t = FetchTapGuides<MODE, CB, FR, true>(c, s, uv, gIn_Spec, gIn_ViewZ, gIn_Normal_Roughness, gIn_ViewPos, c.gSpecCheckerboard, (uint32_t)n, compareMaterials);
         const int2 ts = t.ts;
         const float zs = t.zs;
