@@ -59,6 +59,7 @@ def main():
         ps = [ex.pool_plane_tensor(api.ResourceType.PERMANENT_POOL, i) for i, (fmt, ds) in enumerate(inst.permanent_pool) if ds == 1]
         return ps + [o.view(-1).view(dtype=torch.uint8).view(H, -1) for o in outs]
 
+    out_row_bytes = sum(W * ch * torch.empty(0, dtype=dtype).element_size() for rt, dtype, ch, fmt in parity.output_planes(name, W, H))  # bytes of one row of all OUT_* planes
     results = []
     for world, rank in [(int(w), r) for w in args.worlds.split(",") for r in (range(int(w)) if args.all_ranks else [int(w) // 2])]:
         ref = make()
@@ -157,6 +158,14 @@ def main():
         srow["modelled_frame_ms_full_overlap"] = round(max(srow["slowest_rank_ms"], xfer_ms), 4)
         srow["modelled_speedup_no_overlap"] = round(base / (srow["slowest_rank_ms"] + xfer_ms), 3)
         srow["modelled_speedup_full_overlap"] = round(base / max(srow["slowest_rank_ms"], xfer_ms), 3)
+        # round 5: the output all-gather (HaloSharder.start_output_gather): every rank sends its rows of the OUT_* planes to each of the other ranks over that rank's own link of
+        # the xGMI mesh, next to the WHOLE next frame (the complete planes are separate tensors) -- a bound on the frame RATE, max(compute, gather), not an addend
+        if srow["world"] > 1 and args.scheme == "halo":
+            tallest = max(r[1] - r[0] for r in srow["strips"])
+            gather_ms = tallest * out_row_bytes / (args.link_GBps * 1e9) * 1e3
+            srow["output_all_gather_bytes_per_link"] = tallest * out_row_bytes
+            srow["modelled_output_gather_ms_per_link"] = round(gather_ms, 4)
+            srow["modelled_frame_ms_full_overlap_with_gather"] = round(max(srow["slowest_rank_ms"], xfer_ms, gather_ms), 4)
     print(json.dumps({"workload": "%s %dx%d%s" % (name, W, H, " (no sky)" if args.no_sky else ""), "scheme": args.scheme, "balance": bool(args.balance),
                       "note": "MODELLED, not measured on several GPUs: per-rank compute measured with virtual ranks on one MI355X (%s); transfers = halo bytes / %g GB/s per link, "
                               "neighbours only" % ("every rank measured" if args.all_ranks else "middle strip", args.link_GBps), "summary": summary, "ranks": results}))
