@@ -274,12 +274,13 @@ def output_gather_ops(bounds, keys):
     return [(key, src, bounds[src], bounds[src + 1]) for key in keys for src in range(len(bounds) - 1) if bounds[src + 1] > bounds[src]]
 
 
-def balanced_bounds(tile_row_cost, height, world, min_rows, tile=16):
+def balanced_bounds(tile_row_cost, height, world, min_rows, tile=16, max_rows=None):
     """Strip boundaries (rows, multiples of `tile` except the last) that minimise the largest strip cost; every strip is at least min_rows
-    high. tile_row_cost[t] = cost of tile row t. Returns None when the frame is too small for `world` such strips."""
+    high (and at most max_rows, if given). tile_row_cost[t] = cost of tile row t. Returns None when the frame is too small for `world` such strips."""
     T = len(tile_row_cost)
     min_tiles = max(1, -(-min_rows // tile))
-    if T < world * min_tiles:
+    max_tiles = T if max_rows is None else max(min_tiles, max_rows // tile)
+    if T < world * min_tiles or T > world * max_tiles:
         return None
     prefix = [0.0]
     for c in tile_row_cost:
@@ -290,7 +291,7 @@ def balanced_bounds(tile_row_cost, height, world, min_rows, tile=16):
     best[0][0] = 0.0
     for k in range(1, world + 1):
         for t in range(k * min_tiles, T - (world - k) * min_tiles + 1):
-            for s in range((k - 1) * min_tiles, t - min_tiles + 1):
+            for s in range(max((k - 1) * min_tiles, t - max_tiles), t - min_tiles + 1):
                 if best[k - 1][s] == INF:
                     continue
                 v = max(best[k - 1][s], prefix[t] - prefix[s])
@@ -507,7 +508,11 @@ class HaloSharder:
         if not plan.fallback and self.balance and self.complete and self.world > 1:
             widest = max((w for items, _, _ in plan.steps for _, w in items), default=0)
             cost = self._tile_row_cost()
-            new = balanced_bounds(cost, self.height, self.world, max(widest, 16)) if cost else None
+            # with the output all-gather a strip is also a MESSAGE: every rank sends its rows of the OUT_* planes to each peer over that peer's link, so the tallest strip
+            # bounds the frame rate -- a sky strip is cheap to compute and as expensive to send as any other. Strips are therefore capped at 1.5 x the uniform height
+            # (1440p, 8 ranks, MODELLED at 50 GB/s per link: 544-row sky strip 0.45 ms per frame on its links against 0.22 ms of compute; capped at 270 rows: 0.22 ms)
+            cap = (3 * self.height // (2 * self.world) + 15) & ~15 if self.gather_outputs else None
+            new = balanced_bounds(cost, self.height, self.world, max(widest, 16), max_rows=cap) if cost else None
             new = self._agree(new)
             if new and new != self.bounds:
                 old, self.bounds = self.bounds, new
