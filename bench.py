@@ -238,10 +238,22 @@ def cpu_baseline(name, width, height, frames, seq, overrides=None, check_parity=
             s2 = st2.summary(True)
             par["vs_ieee"] = {"vs": "the same oracle in plain IEEE arithmetic (no knowledge of the device)", "frames": ieee_frames, "max_rel_err": s2["max_rel_err"], "p999_rel_err": s2["p999"],
                               "frac_gt_1e-3": s2["frac_gt_tol"], "mean_rel_err": s2["mean"], "bit_exact_frac": s2["bit_exact_frac"]}
-        ref_summary = os.path.join(ROOT, "profiles", "r04_ref_parity_summary.txt")
+        ref_summary = os.path.join(ROOT, "profiles", "r05_ref_parity_summary.txt")
         if os.path.exists(ref_summary):
-            par["vs_reference_text"] = {"what": "the oracle pass by pass on identical inputs against the reference's own HLSL shaders compiled as C++ (oracle/_ref, tests/test_ref_parity.py)",
-                                        "recorded_in": "profiles/r04_ref_parity_summary.txt (CPU-only statistic, not measured in this run)"}
+            # the recorded per-pass comparison with the reference's compiled shader text (tools/ref_report.py; CPU-only, not re-measured here): both metrics of the DEVICE
+            # arithmetic -- what this library computes -- for this denoiser, and the plane furthest from the north-star's 1e-3
+            row = next((line for line in open(ref_summary) if line.startswith("device") and line.split()[1] == name), None)
+            detail = None
+            if row:
+                import re
+                m = re.search(r"bit-exact ([\d.]+)\s+min ok ([\d.]+)\s+min within 1e-3 ([\d.]+)\s+min within 1e-3 \(vector\) ([\d.]+).*worst plane: (.*?) \(bit-exact ([\d.]+), per component ([\d.]+), vector ([\d.]+), max ([\d.eE+-]+)\)", row)
+                if m:
+                    detail = {"bit_exact_frac_all_planes": float(m.group(1)), "min_within_1e-5_or_1ulp_frac": float(m.group(2)), "min_within_1e-3_frac_per_component": float(m.group(3)),
+                              "min_within_1e-3_frac_vector_metric": float(m.group(4)), "worst_plane": m.group(5), "worst_plane_bit_exact_frac": float(m.group(6)),
+                              "worst_plane_within_1e-3_per_component": float(m.group(7)), "worst_plane_within_1e-3_vector": float(m.group(8)), "worst_plane_max_rel_err": float(m.group(9))}
+            par["vs_reference_text"] = {"what": "the oracle in the DEVICE arithmetic, pass by pass on identical inputs, against the reference's own HLSL shaders compiled as C++ (oracle/_ref, tests/test_ref_parity.py): "
+                                                "one pass, no recurrence; 3 frames at 192x128", "device_arithmetic": detail,
+                                        "recorded_in": "profiles/r05_ref_parity_summary.txt (CPU-only statistic, not measured in this run)"}
     return baseline, par
 
 
