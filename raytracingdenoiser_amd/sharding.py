@@ -636,16 +636,21 @@ class HaloSharder:
         nothing of the next frame touches the complete copies. Returns the pending work (None: nothing to do / done synchronously)."""
         import torch.distributed as dist
 
-        if not self.gather_outputs or not plan.output_keys or self.world == 1:
+        if not self.gather_outputs or not plan.output_keys:
             return None
+        in_group = dist.is_available() and dist.is_initialized() and dist.get_world_size(self.group) == self.world
+        if self.world == 1 and not in_group:
+            return None  # a plain single-GPU run: the bound planes are the complete planes
         self.stage_outputs(plan)
-        if plan.fallback or self.bounds is None:
+        if plan.fallback and self.world > 1:
             return None  # an unsharded frame: every rank computed every row
-        if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(self.group) != self.world:
+        if not in_group:
             return None  # virtual ranks of the single-process tests: they replay output_gather_ops() with copies between the ranks' complete planes
+        # (a process group of ONE rank runs the collective all the same: the only way this box can exercise the RCCL path -- tests/test_sharding.py)
+        bounds = self.bounds or [0, self.height]
         planes = [self._complete_plane(key) for key in plan.output_keys]
-        rb, re = self.rows
-        heights = [b - a for a, b in zip(self.bounds, self.bounds[1:])]
+        rb, re = bounds[self.rank], bounds[self.rank + 1]
+        heights = [b - a for a, b in zip(bounds, bounds[1:])]
         self.gathered_bytes += sum(p.shape[1] * (p.shape[0] - (re - rb)) for p in planes)
         self.gather_frames += 1
         if dist.get_backend(self.group) != "nccl":  # gloo (CPU tests, or two ranks sharing one GPU with host staging): synchronous
@@ -653,7 +658,7 @@ class HaloSharder:
 
             for p in planes:
                 for src in range(self.world):
-                    band = p[self.bounds[src]:self.bounds[src + 1]]
+                    band = p[bounds[src]:bounds[src + 1]]
                     if band.shape[0] == 0:
                         continue
                     if p.is_cuda:
@@ -664,7 +669,7 @@ class HaloSharder:
                     else:
                         dist.broadcast(band, src, self.group)
             return None
-        uniform = len(set(heights)) == 1
+        uniform = len(set(heights)) == 1 and not __import__("os").environ.get("NRD_HIP_GATHER_LIST_FORM")  # (test hook: the list form with equal strips too)
 
         def issue():
             works = []
@@ -672,7 +677,7 @@ class HaloSharder:
                 if uniform:
                     works.append(dist.all_gather_into_tensor(p.view(-1), p[rb:re].reshape(-1), group=self.group, async_op=True))
                 else:
-                    works.append(dist.all_gather([p[self.bounds[r]:self.bounds[r + 1]] for r in range(self.world)], p[rb:re], group=self.group, async_op=True))
+                    works.append(dist.all_gather([p[bounds[r]:bounds[r + 1]] for r in range(self.world)], p[rb:re], group=self.group, async_op=True))
             return works
 
         if hasattr(dist, "_coalescing_manager") and uniform:

@@ -383,24 +383,37 @@ def _halo_nccl_world1_worker(q):
             inst.set_denoiser_settings(0, parity.denoiser_settings(name, frame))
             inst.set_common_settings(parity.common_settings(frame["camera"], seq[max(f - 1, 0)]["camera"], W, H, f))
             sh.denoise() if sharded else ex.denoise()
+        if sharded:
+            sh.wait_outputs()  # the output all-gather of the last frame: with one rank it is the whole plane gathered onto itself -- the RCCL code path (grouped, asynchronous) this box can run
         torch.cuda.synchronize()
         results.append([o.clone() for o in outs])
-    q.put(all(torch.equal(a, b) for a, b in zip(*results)))
+        if sharded:
+            assert sh.gather_frames >= 1
+            results.append([sh.complete_output(rt).clone() for rt, dtype, ch, fmt in parity.output_planes(name, W, H)])
+    q.put(all(torch.equal(a, b) for a, b in zip(results[0], results[1])) and all(torch.equal(a, b) for a, b in zip(results[0], results[2])))
     dist.destroy_process_group()
 
 
 @pytest.mark.gpu
-def test_halo_sharder_under_rccl_world1():
+@pytest.mark.parametrize("list_form", [False, True])
+def test_halo_sharder_under_rccl_world1(list_form):
     # world size 1: no neighbours, so no transfers -- but the whole HaloSharder.denoise() path (planning, segment execution) runs under the
     # RCCL process group exactly as bench.py drives it, and must reproduce executor.denoise()
     import torch.multiprocessing as mp
 
+    # (round 5: HaloSharder.denoise() ends with the output all-gather; a group of one rank gathers the plane onto itself -- the grouped asynchronous
+    # all_gather_into_tensor and, list_form, the list form RCCL runs for unequal strips: the only RCCL collectives this one-GPU box can execute)
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    p = ctx.Process(target=_halo_nccl_world1_worker, args=(q,))
-    p.start()
-    assert q.get(timeout=240) is True
-    p.join(timeout=60)
+    if list_form:
+        os.environ["NRD_HIP_GATHER_LIST_FORM"] = "1"
+    try:
+        p = ctx.Process(target=_halo_nccl_world1_worker, args=(q,))
+        p.start()
+        assert q.get(timeout=240) is True
+        p.join(timeout=60)
+    finally:
+        os.environ.pop("NRD_HIP_GATHER_LIST_FORM", None)
 
 
 def _halo_two_process_worker(rank, world, port, name, W, H, frames, q):
