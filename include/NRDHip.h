@@ -123,7 +123,8 @@ uint32_t nrdHipPlanHaloExchange(void* instance, const void* dispatchDescs, uint3
 // of the given dispatch list (the list of THIS frame, before it is executed). One streaming kernel over the strip (12 B per pixel), a 4-byte read-back and
 // a stream synchronisation. A rank calls it on its own strip, takes the MAX over ranks, and runs the frame unsharded when the result + 2 rows (bicubic
 // footprint) does not fit the history halo it planned with (maxMotionRows below). 0 for lists without a temporal denoiser; pixels whose previous position
-// lies behind the previous camera (or whose motion vector is NaN) report a huge value on purpose.
+// lies behind the previous camera (or whose motion vector is NaN) report a huge value on purpose. The value bounds the SURFACE motion only: hosts double it for the
+// virtual motion of specular reflections, which is a heuristic (a curved reflector can exceed it), not a check.
 uint32_t nrdHipMeasureMotionRows(NrdHipExecutor* executor, const void* dispatchDescs, uint32_t dispatchDescsNum, uint32_t rowBegin, uint32_t rowEnd, float* maxRows);
 
 // Per-pass GPU timing. When enabled, every dispatch is bracketed by hipEvents on the executor's stream.

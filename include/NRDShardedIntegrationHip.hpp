@@ -55,6 +55,8 @@ struct ShardedIntegrationHipCreationDesc {
     // false: maxMotionRows is the application's promise about every frame. true: it is CHECKED every frame -- nrdHipMeasureMotionRows reduces the frame's own
     // IN_VIEWZ / IN_MV over this rank's strip (the temporal passes' surface-motion reprojection, moving objects included), the ranks take the maximum
     // (HaloTransport::MaxOverRanks) and a frame with 2 x motion + 2 >= maxMotionRows (virtual motion of specular reflections, bicubic footprint) runs unsharded.
+    // NOTE: the measurement bounds the SURFACE-motion reprojection. The virtual-motion (specular) reprojection is ASSUMED to reach at most twice as far (the factor 2 above):
+    // a heuristic, not a check -- a strongly curved reflector or a very long hit distance can exceed it, and stale history-halo rows would then be read without notice.
     bool measureMotion = false;
     // Denoise() ends with GatherOutputs(): every rank receives the other ranks' rows of the OUT_* planes the frame wrote (BASELINE configs[3]: "screen tiled across the GPUs
     // with RCCL all-gather"; the reference's nrd::Integration::Denoise hands back complete outputs, NRDIntegration.hpp:516-623)

@@ -455,7 +455,12 @@ class HaloSharder:
         import torch.distributed as dist
 
         if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(self.group) != self.world:
-            return value  # virtual ranks of the single-process tests
+            # virtual ranks of a single process: nobody reduces for them, and a rank deciding on its LOCAL maximum could take a different fallback decision than its
+            # neighbours -- the host that drives virtual ranks has to reduce the measurements itself
+            if self.world > 1:
+                raise RuntimeError("HaloSharder(measure_motion=True) with %d ranks but no process group of that size: reduce the measured motion over the ranks yourself "
+                                   "(ex.measure_motion_rows per rank, then denoise(motion_rows=max)) or create the sharder with measure_motion=False" % self.world)
+            return value
         t = torch.tensor([value], dtype=torch.float32, device="cuda" if dist.get_backend(self.group) == "nccl" else "cpu")
         dist.all_reduce(t, dist.ReduceOp.MAX, self.group)
         return float(t.item())
