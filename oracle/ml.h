@@ -134,7 +134,7 @@ inline uint32_t Bayer4x4ui(uint32_t x, uint32_t y, uint32_t frameIndex) {
     uint32_t b = (y + ((x & 1u) << 2)) << 2;
     return ((a >> b) + frameIndex) & 0xFu;
 }
-inline float Bayer4x4(uint32_t x, uint32_t y, uint32_t frameIndex) { return (float(Bayer4x4ui(x, y, frameIndex)) + 0.5f) * 0.0625f; }
+inline float Bayer4x4(uint32_t x, uint32_t y, uint32_t frameIndex) { return float(Bayer4x4ui(x, y, frameIndex)) * 0.0625f; } // (round 5: i / 16, csrc/hip/nrdmath.h)
 } // namespace Sequence
 
 // Our own hash RNG (MathLib's Rng::Hash is unavailable): seeded per (pixel, frame), PCG output function

@@ -13,7 +13,7 @@ inline uint32_t Bayer4x4ui(uint2 pos, uint32_t frameIndex) {
     uint32_t b = (y + ((x & 1u) << 2)) << 2;
     return ((a >> b) + frameIndex) & 0xFu;
 }
-inline float Bayer4x4(uint2 pos, uint32_t frameIndex) { return (float(Bayer4x4ui(pos, frameIndex)) + 0.5f) / 16.0f; }
+inline float Bayer4x4(uint2 pos, uint32_t frameIndex) { return float(Bayer4x4ui(pos, frameIndex)) / 16.0f; } // RESULT: [0; 1) (round 5: i / 16, as csrc/host/hostmath.h)
 } // namespace Sequence
 namespace Geometry {
 inline float4 GetRotator(float angle) {

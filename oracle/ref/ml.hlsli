@@ -148,7 +148,7 @@ namespace Sequence
         uint b = ( q.y + ( ( q.x & 1u ) << 2 ) ) << 2;
         return ( ( a >> b ) + frameIndex ) & 0xFu;
     }
-    float Bayer4x4( uint2 p, uint frameIndex ) { return ( float( Bayer4x4ui( p, frameIndex ) ) + 0.5 ) * 0.0625; }
+    float Bayer4x4( uint2 p, uint frameIndex ) { return float( Bayer4x4ui( p, frameIndex ) ) * 0.0625; } // RESULT: [0; 1) (round 5: i / 16)
 }
 
 namespace Rng

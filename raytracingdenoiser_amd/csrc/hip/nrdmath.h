@@ -326,7 +326,8 @@ NRD_D uint32_t Bayer4x4ui(uint32_t x, uint32_t y, uint32_t frameIndex) {
     uint32_t b = (y + ((x & 1u) << 2)) << 2;
     return ((a >> b) + frameIndex) & 0xFu;
 }
-NRD_D float Bayer4x4(uint32_t x, uint32_t y, uint32_t frameIndex) { return (float(Bayer4x4ui(x, y, frameIndex)) + 0.5f) * 0.0625f; }
+// round 5: i / 16, "RESULT: [0; 1)" -- the form both the builder's and the round-4 reviewer's recollection of NVIDIA-RTX/MathLib agree on (until then (i + 0.5) / 16; MathLib is not vendored: unpinned either way)
+NRD_D float Bayer4x4(uint32_t x, uint32_t y, uint32_t frameIndex) { return float(Bayer4x4ui(x, y, frameIndex)) * 0.0625f; }
 
 // Rng::Hash -- OUR definition (MathLib's is unavailable): PCG-style state seeded from (pixel, frame)
 struct RngHash {

@@ -163,7 +163,8 @@ inline uint32_t Bayer4x4ui(uint32_t x, uint32_t y, uint32_t frameIndex) {
     return ((a >> b) + frameIndex) & 0xFu;
 }
 
-inline float Bayer4x4(uint32_t x, uint32_t y, uint32_t frameIndex) { return (float(Bayer4x4ui(x, y, frameIndex)) + 0.5f) / 16.0f; }
+// round 5: i / 16, "RESULT: [0; 1)" -- the form both the builder's and the round-4 reviewer's recollection of NVIDIA-RTX/MathLib agree on (until then (i + 0.5) / 16; MathLib is not vendored: unpinned either way)
+inline float Bayer4x4(uint32_t x, uint32_t y, uint32_t frameIndex) { return float(Bayer4x4ui(x, y, frameIndex)) / 16.0f; }
 
 // Rotator = (cos, sin, -sin, cos); v' = v.x * r.xz + v.y * r.yw  (reference Common.hlsli:465 default (1,0,0,1))
 inline Vec4 GetRotator(float angle) {
