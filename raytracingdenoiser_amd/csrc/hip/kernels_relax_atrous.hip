@@ -446,7 +446,12 @@ __global__ __launch_bounds__(256, NRD_WAVES_RELAX_ATROUS) void RelaxAtrousKernel
     __shared__ uint2 s_SpecSh[SPEC && SH ? TN : 1], s_DiffSh[DIFF && SH ? TN : 1];
     // one band of tap positions: hashed offsets reach R texels beyond the regular stencil; undecoded signal texels (8 B each)
     constexpr int R = STEP / 4, BW = TILE_X + 2 * STEP + 2 * R, BH = TILE_Y + 2 * R, BS = BW + 1, BN = BANDED ? BH * BS : 1;
-    __shared__ float4 b_NR[BN], b_Pos[BN];
+    // BAND_RAW (step 16, round 5): the band holds the UNDECODED guides -- the packed normal (4 B) and viewZ (4 B) the gathering taps read, decoded per tap with the very functions
+    // that wrote the guide planes -- so a 72 x 16-texel band is 46 KB instead of 74 (three workgroups per CU instead of two; the decoded bands lost to the gathers at step 16: r04_d)
+    constexpr bool BAND_RAW = STEP == 16;
+    __shared__ float4 b_NR[BAND_RAW ? 1 : BN], b_Pos[BAND_RAW ? 1 : BN];
+    __shared__ uint32_t br_NR[BAND_RAW ? BN : 1];
+    __shared__ float br_Z[BAND_RAW ? BN : 1];
     __shared__ uint2 b_Spec[SPEC && BANDED ? BN : 1], b_Diff[DIFF && BANDED ? BN : 1], b_SpecSh[SPEC && SH && BANDED ? BN : 1], b_DiffSh[DIFF && SH && BANDED ? BN : 1];
 
     const int blockY = BlockTileY(rows, true);
@@ -622,9 +627,14 @@ __global__ __launch_bounds__(256, NRD_WAVES_RELAX_ATROUS) void RelaxAtrousKernel
                 const int lx = i % BW, ly = i / BW;
                 const int cx = ClampI(bandX0 + lx, 0, P.worldPosViewZ.w - 1), cy = ClampI(bandY0 + ly, 0, P.worldPosViewZ.h - 1); // the taps' clamped texel
                 const int li = ly * BS + lx;
-                const uint32_t guideOffset = TexelOffset(P.decodedNR, cx, cy, 16u, true);
-                b_NR[li] = *(const float4*)(P.decodedNR.ptr + guideOffset);
-                b_Pos[li] = *(const float4*)(P.worldPosViewZ.ptr + guideOffset);
+                if (BAND_RAW) {
+                    br_NR[li] = *(const uint32_t*)(P.normalRoughness.ptr + TexelOffset(P.normalRoughness, cx, cy, 4u, true));
+                    br_Z[li] = *(const float*)(P.viewZ.ptr + TexelOffset(P.viewZ, cx, cy, 4u, true));
+                } else {
+                    const uint32_t guideOffset = TexelOffset(P.decodedNR, cx, cy, 16u, true);
+                    b_NR[li] = *(const float4*)(P.decodedNR.ptr + guideOffset);
+                    b_Pos[li] = *(const float4*)(P.worldPosViewZ.ptr + guideOffset);
+                }
                 const uint32_t signalOffset = TexelOffset(SPEC ? P.spec.in : P.diff.in, cx, cy, 8u, true);
                 if (SPEC) {
                     b_Spec[li] = *(const uint2*)(P.spec.in.ptr + signalOffset);
@@ -664,8 +674,15 @@ __global__ __launch_bounds__(256, NRD_WAVES_RELAX_ATROUS) void RelaxAtrousKernel
                 }
             } else if (BANDED) {
                 const int li = (qy - bandY0) * BS + (qx - bandX0); // |offset| <= R: inside the band (which holds the clamped texel of every position)
-                g0 = LdsFloat4(&b_NR[li]);
-                sampleWorldPosViewZ = LdsFloat4(&b_Pos[li]);
+                if (BAND_RAW) { // the decode of the gathering taps below, on the band's undecoded texel: same functions, same values
+                    const int cx = ClampI(qx, 0, P.worldPosViewZ.w - 1), cy = ClampI(qy, 0, P.worldPosViewZ.h - 1);
+                    g0 = EncodeDecodedNormalRoughness(br_NR[li]);
+                    const float tapZ = RelaxUnpackViewZ(c, br_Z[li]);
+                    sampleWorldPosViewZ = F4(GetCurrentWorldPosFromPixelPos(c, cx, cy, tapZ), tapZ);
+                } else {
+                    g0 = LdsFloat4(&b_NR[li]);
+                    sampleWorldPosViewZ = LdsFloat4(&b_Pos[li]);
+                }
                 if (SPEC) {
                     const uint2 raw = b_Spec[li];
                     sampleSpecular = DecodeRGBA16F(raw.x, raw.y);
