@@ -434,9 +434,11 @@ def main():
     # ---- roofline of the dominant kernel (live HIP-event timings of this very run)
     rows = W * H if shard is None else shard.pixels_per_rank()
     passes = {}
+    # one GPU: the tile-classification kernel writes the guide planes too (kernels_common.hip DecodeGuidesClassifyKernel) and there is no separate guide row
+    guides_in_classify = timings.get(HipExecutor.GUIDE_PREPARATION, (0.0, 0))[1] == 0
     for shader, (ms, n) in timings.items():
         bpp = bytes_per_pixel.get(shader)
-        if shader == HipExecutor.GUIDE_PREPARATION:
+        if shader == HipExecutor.GUIDE_PREPARATION or (guides_in_classify and shader in ("REBLUR_ClassifyTiles.cs", "RELAX_ClassifyTiles.cs")):
             bpp = GUIDE_BYTES_PER_PIXEL  # 8 B read (packed normal, viewZ) + 2 x 16 B written: not part of the reference's compulsory traffic, a cost of this design
         if bpp is None or n == 0:
             continue

@@ -131,7 +131,8 @@ uint32_t nrdHipMeasureMotionRows(NrdHipExecutor* executor, const void* dispatchD
 // nrdHipCollectPassTimings synchronises the stream, folds all brackets recorded since the last collect into per-pipeline
 // totals and returns the number of pipelines written: pipelineIndices[i] (index into InstanceDesc::pipelines),
 // milliseconds[i] (sum of durations) and launches[i] (count). One more row than there are pipelines: index == InstanceDesc::pipelinesNum is the per-frame guide
-// preparation (the decode / rect-shift kernels in front of the first pass of a list). Pass capacity >= InstanceDesc::pipelinesNum + 1.
+// preparation (the decode / rect-shift kernels in front of the first pass of a list; absent when the list's tile-classification kernel writes the guide planes itself --
+// whole-frame decode of a REBLUR-only or RELAX-only list without a shifted rect: that time is then part of the *_ClassifyTiles.cs row). Pass capacity >= InstanceDesc::pipelinesNum + 1.
 uint32_t nrdHipSetProfiling(NrdHipExecutor* executor, uint32_t enable);
 uint32_t nrdHipCollectPassTimings(NrdHipExecutor* executor, uint32_t* pipelineIndices, double* milliseconds, uint32_t* launches, uint32_t capacity, uint32_t* written);
 

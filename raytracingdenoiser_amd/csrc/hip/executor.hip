@@ -1000,10 +1000,29 @@ static uint32_t ExecuteRange(NrdHipExecutor* e, const nrd::DispatchDesc* descs, 
         if (trace)
             fprintf(stderr, "[nrdhip] guide planes decoded on rows [%d, %d) of %d\n", guideRow0, guideRow1 == INT_MAX ? (int)e->height : std::min(guideRow1, (int)e->height), (int)e->height);
     }
+    // Whole-frame decode of a single-family list that starts (behind its clears, if any) with that family's tile classification: the classification kernel writes the guide
+    // planes too (kernels_common.hip DecodeGuidesClassifyKernel) and no decode kernel is launched here. Not with a shifted rect (the twins are prepared first), not
+    // under row sharding (the strips decode only their rows), not with both families in one list. NRD_HIP_FUSE_CLASSIFY=0: the two separate kernels (A/B switch).
+    uint32_t fuseDispatch = UINT32_MAX;
+    static const bool fuseClassify = !(getenv("NRD_HIP_FUSE_CLASSIFY") && atoi(getenv("NRD_HIP_FUSE_CLASSIFY")) == 0);
+    if (fuseClassify && decodeNow && !shiftedRect && !rowBegin && (viewPos.ptr != nullptr) != (worldPos.ptr != nullptr)) {
+        const char* classify = viewPos.ptr ? "REBLUR_ClassifyTiles.cs" : "RELAX_ClassifyTiles.cs";
+        for (uint32_t i = first; i < first + count; i++) {
+            const char* shader = descs[i].pipelineIndex < idesc.pipelinesNum ? idesc.pipelines[descs[i].pipelineIndex].shaderFileName : "";
+            if (!strncmp(shader, "Clear_", 6))
+                continue;
+            if (!strcmp(shader, classify) && descs[i].constantBufferData && descs[i].constantBufferDataSize >= (viewPos.ptr ? sizeof(nrdc::ReblurConstants) : sizeof(nrdc::RelaxConstants)))
+                fuseDispatch = i;
+            break;
+        }
+        static const bool trace = getenv("NRD_HIP_TRACE_GUIDE_ROWS") != nullptr;
+        if (trace && fuseDispatch != UINT32_MAX)
+            fprintf(stderr, "[nrdhip] guide planes written by the tile classification kernel (dispatch %u)\n", fuseDispatch);
+    }
     auto decode = [&](LaunchRecorder* rec) {
         if (shiftedRect)
             shiftGuides(rec, false);
-        if (!decodeNow)
+        if (!decodeNow || fuseDispatch != UINT32_MAX)
             return;
         PassArgs args = {};
         args.stream = e->stream;
@@ -1043,6 +1062,8 @@ static uint32_t ExecuteRange(NrdHipExecutor* e, const nrd::DispatchDesc* descs, 
         args.viewPos = viewPos;
         args.tileFlags = e->tileFlags;
         args.windowRegion = e->windowRegion;
+        if (i == fuseDispatch)
+            args.fuseGuidesFrom = guidePlane(nrd::ResourceType::IN_NORMAL_ROUGHNESS);
         if (rowBegin && rowBegin[i] >= 0) {
             args.rowBegin = rowBegin[i];
             args.rowEnd = rowEnd[i];

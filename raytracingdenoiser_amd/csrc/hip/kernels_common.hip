@@ -98,6 +98,58 @@ void LaunchDecodeGuidesRelax(const PassArgs& a, const Plane& packed, const Plane
         make_float3(c.gFrustumForward.x, c.gFrustumForward.y, c.gFrustumForward.z), make_float2(c.gRectSizeInv.x, c.gRectSizeInv.y), c.gViewZScale, rows);
 }
 
+// ---- guide decode + tile classification in one launch (round 5) -------------------------------------------------------------------------------------
+// The first pass of a REBLUR / RELAX list (ClassifyTiles: one wave per 16x16 tile votes "all sky" over IN_VIEWZ) reads nothing the decode kernels write and
+// streams the same IN_VIEWZ. When the guide planes are due for the whole frame the executor hands the packed plane to that pass's launcher
+// (PassArgs::fuseGuidesFrom) and skips its own decode launch: one wave per tile reads viewZ ONCE (4 rows x 64 B per load, 4 loads in flight), decodes its 256
+// texels, writes both guide planes (256-byte row segments, the four waves of a workgroup side by side: 1 KiB per row) and casts the tile vote -- no LDS, no
+// barrier. Values are those of the two separate kernels (same expressions); saves a launch, a dependent-launch gap and 4 B/px.
+template <bool RELAX>
+__global__ __launch_bounds__(256) void DecodeGuidesClassifyKernel(Plane packed, Plane viewZ, Plane decoded, Plane guide, Plane tiles, float3 frustumRight, float3 frustumUp, float3 frustumForward,
+    float2 rectSizeInv, float viewZScale, float denoisingRange, int tilesPerRow, int tileRows) {
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int tx = blockIdx.x * 4 + wave, ty = blockIdx.y;
+    const int x = tx * 16 + (lane & 15), y0 = ty * 16 + (lane >> 4);
+    bool allSky = true;
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        const int y = y0 + k * 4;
+        const bool inside = x < packed.w && y < packed.h;
+        const float zRaw = inside ? LoadR32F(viewZ, x, y) : 0.0f; // out-of-bounds load = 0 => a partial edge tile is never sky (as in the stand-alone classification)
+        allSky = allSky && (RELAX ? Abs(zRaw) : Abs(zRaw * viewZScale)) > denoisingRange;
+        if (!inside)
+            continue;
+        const float4 d = EncodeDecodedNormalRoughness(LoadR32U(packed, x, y));
+        StoreRGBA32F(decoded, x, y, d);
+        const float z = Abs(zRaw * viewZScale);
+        if (RELAX) {
+            const float2 clip = F2(float(x) + 0.5f, float(y) + 0.5f) * rectSizeInv * 2.0f - 1.0f;
+            const float3 dir = frustumForward + frustumRight * clip.x - frustumUp * clip.y; // DecodeGuidesRelaxKernel, same operation order
+            StoreRGBA32F(guide, x, y, F4(z * dir.x, z * dir.y, z * dir.z, z));
+        } else {
+            StoreRGBA32F(guide, x, y, F4(d.x, d.y, d.z, z));
+        }
+    }
+    const bool tileIsSky = __all(allSky);
+    if (lane == 0 && tx < tilesPerRow && ty < tileRows) // the tiles of the RECT; tiles beyond stay untouched
+        StoreR8Unorm(tiles, tx, ty, tileIsSky ? 1.0f : 0.0f);
+}
+
+void LaunchDecodeGuidesClassify(const PassArgs& a, const Plane& viewZ, const Plane& tiles, const void* reblurConstants, int tilesPerRow, int tileRows) {
+    const nrdc::ReblurConstants& c = *(const nrdc::ReblurConstants*)reblurConstants;
+    const Plane& packed = a.fuseGuidesFrom;
+    LaunchPass(a, (DecodeGuidesClassifyKernel<false>), dim3((unsigned)((packed.w + 63) / 64), (unsigned)((packed.h + 15) / 16), 1), dim3(256), packed, viewZ, a.decodedNormalRoughness, a.viewPos, tiles,
+        make_float3(0.0f, 0.0f, 0.0f), make_float3(0.0f, 0.0f, 0.0f), make_float3(0.0f, 0.0f, 0.0f), make_float2(0.0f, 0.0f), c.gViewZScale, c.gDenoisingRange, tilesPerRow, tileRows);
+}
+
+void LaunchDecodeGuidesClassifyRelax(const PassArgs& a, const Plane& viewZ, const Plane& tiles, const void* relaxConstants, int tilesPerRow, int tileRows) {
+    const nrdc::RelaxConstants& c = *(const nrdc::RelaxConstants*)relaxConstants;
+    const Plane& packed = a.fuseGuidesFrom;
+    LaunchPass(a, (DecodeGuidesClassifyKernel<true>), dim3((unsigned)((packed.w + 63) / 64), (unsigned)((packed.h + 15) / 16), 1), dim3(256), packed, viewZ, a.decodedNormalRoughness, a.worldPosViewZ, tiles,
+        make_float3(c.gFrustumRight.x, c.gFrustumRight.y, c.gFrustumRight.z), make_float3(c.gFrustumUp.x, c.gFrustumUp.y, c.gFrustumUp.z),
+        make_float3(c.gFrustumForward.x, c.gFrustumForward.y, c.gFrustumForward.z), make_float2(c.gRectSizeInv.x, c.gRectSizeInv.y), c.gViewZScale, c.gDenoisingRange, tilesPerRow, tileRows);
+}
+
 void LaunchDecodeNormalRoughness(const PassArgs& a, const Plane& packed, const Plane& decoded) {
     const GuideRows rows = MakeGuideRows(a, packed);
     if (rows.launchEnd > rows.launchBegin)

@@ -54,6 +54,10 @@ static const char* LaunchClassifyTiles(const PassArgs& a) {
     const int tilesPerRow = (c.gRectSizeMinusOne.x + 16) / 16, tileRows = (c.gRectSizeMinusOne.y + 16) / 16;
     if (tilesPerRow > tiles.w || tileRows > tiles.h)
         return "REBLUR ClassifyTiles: the rect does not fit the tile plane";
+    if (a.fuseGuidesFrom.ptr) { // the frame's guide planes are due: one kernel decodes them and classifies (kernels_common.hip)
+        LaunchDecodeGuidesClassify(a, a.planes[0], tiles, a.constants, tilesPerRow, tileRows);
+        return nullptr;
+    }
     int numTiles = tilesPerRow * tileRows;
     LaunchPass(a, ReblurClassifyTilesKernel, dim3((numTiles + 3) / 4), dim3(256), a.planes[0], tiles, c.gViewZScale, c.gDenoisingRange, tilesPerRow, tileRows);
     return nullptr;

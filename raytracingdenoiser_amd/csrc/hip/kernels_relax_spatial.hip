@@ -54,6 +54,10 @@ const char* LaunchClassifyTiles(const PassArgs& a) {
     const int tilesPerRow = (c.gRectSize.x + 15) / 16, tileRows = (c.gRectSize.y + 15) / 16;
     if (tilesPerRow > tiles.w || tileRows > tiles.h)
         return "RELAX ClassifyTiles: the rect does not fit the tile plane";
+    if (a.fuseGuidesFrom.ptr) { // the frame's guide planes are due: one kernel decodes them and classifies (kernels_common.hip)
+        LaunchDecodeGuidesClassifyRelax(a, a.planes[0], tiles, a.constants, tilesPerRow, tileRows);
+        return nullptr;
+    }
     int numTiles = tilesPerRow * tileRows;
     LaunchPass(a, RelaxClassifyTilesKernel, dim3((numTiles + 3) / 4), dim3(256), a.planes[0], tiles, c.gDenoisingRange, tilesPerRow, tileRows);
     return nullptr;

@@ -100,6 +100,10 @@ struct PassArgs {
     // normals once per frame; same pitch / size as decodedNormalRoughness, so one texel offset serves both. With it a diffuse tap of the spatial passes
     // reads its guides in one 16-byte load. ptr == nullptr outside REBLUR lists.
     Plane viewPos;
+    // ptr != nullptr only for the tile-classification pass of a REBLUR / RELAX list whose guide planes are due for the whole frame: the launcher writes the planes above
+    // from this packed IN_NORMAL_ROUGHNESS plane in the same kernel that classifies the tiles (kernels_common.hip DecodeGuidesClassifyKernel); the executor then
+    // launches no decode kernel of its own
+    Plane fuseGuidesFrom;
     // executor-internal scratch, one byte per 32x8-pixel workgroup tile of the full-resolution planes: a pass that runs as a fast kernel plus a fallback kernel
     // (REBLUR TemporalAccumulation with its LDS window) hands the tiles the fast kernel declined to the fallback through it. Written completely by the fast
     // kernel before the fallback reads it (stream order), so it needs no clearing.
@@ -171,6 +175,10 @@ void LaunchDecodeNormalRoughness(const PassArgs& a, const Plane& packed, const P
 void LaunchDecodeGuides(const PassArgs& a, const Plane& packed, const Plane& viewZ, const Plane& decoded, const Plane& viewPos, const void* reblurConstants);
 // same for RELAX lists: the (world position, viewZ) plane from IN_VIEWZ and the frame's RELAX constants
 void LaunchDecodeGuidesRelax(const PassArgs& a, const Plane& packed, const Plane& viewZ, const Plane& decoded, const Plane& worldPos, const void* relaxConstants);
+
+// tile classification + guide decode in one launch (PassArgs::fuseGuidesFrom set): called by the ClassifyTiles launchers of REBLUR / RELAX with their pass's planes
+void LaunchDecodeGuidesClassify(const PassArgs& a, const Plane& viewZ, const Plane& tiles, const void* reblurConstants, int tilesPerRow, int tileRows);
+void LaunchDecodeGuidesClassifyRelax(const PassArgs& a, const Plane& viewZ, const Plane& tiles, const void* relaxConstants, int tilesPerRow, int tileRows);
 
 // copies a user guide plane into its rect-at-origin twin (or back): kernels_common.hip "shifted rect"
 void LaunchShiftPlane(const PassArgs& a, const Plane& user, const Plane& shifted, int ox, int oy, uint32_t bytesPerTexel, bool back);

@@ -136,6 +136,7 @@ class HipExecutor:
         names = list(self.instance.pipelines) + [self.GUIDE_PREPARATION]
         return {names[idx[i]]: (ms[i], cnt[i]) for i in range(written.value)}
 
+    # absent (0 launches) when the tile-classification kernel of the list writes the guide planes itself: single-GPU REBLUR / RELAX lists (include/NRDHip.h)
     GUIDE_PREPARATION = "(guide planes: DecodeGuidesKernel)"
 
     def pool_memory(self):

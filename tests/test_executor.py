@@ -184,3 +184,24 @@ def test_temporal_accumulation_window_and_fallback_kernels_match_the_oracle(name
         fallback[tag] = [int(m) for m in re.findall(r"tiles left to a fallback kernel: (\d+) of", out.stdout)]
     assert sum(fallback["default"]) == 0 and sum(fallback["off"]) == 0, fallback  # everything fits / the flags are not touched without the window kernel
     assert all(n > 0 for n in fallback["limited"]), fallback                      # both kernels had tiles in every frame
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", ["REBLUR_DIFFUSE_SPECULAR", "RELAX_DIFFUSE_SPECULAR_SH"])
+def test_guide_planes_from_the_classification_kernel_or_from_their_own_kernel(name):
+    """The per-frame guide planes (decoded normals + view / world position) are written by the tile-classification kernel of the list (one launch, IN_VIEWZ read once:
+    kernels_common.hip DecodeGuidesClassifyKernel) or, with NRD_HIP_FUSE_CLASSIFY=0 (and always under row sharding / a shifted rect), by a kernel of their own in front of
+    the first pass. Both ways every output and pool plane equals the oracle's bit for bit -- on a size with partial tiles on both edges, the first frame being a
+    CLEAR_AND_RESTART list (clears in front of the classification)."""
+    import re
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = ("import sys; sys.path[:0] = [%r, %r]; import parity; "
+            "print('worst', parity.run_parity(%r, width=250, height=150, frames=3))") % (root, os.path.join(root, "tests"), name)
+    for switch, fused_frames in (("1", 3), ("0", 0)):
+        out = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, NRD_HIP_FUSE_CLASSIFY=switch, NRD_HIP_TRACE_GUIDE_ROWS="1"), capture_output=True, text=True, timeout=1200)
+        assert out.returncode == 0, out.stderr[-2000:]
+        assert float(re.search(r"worst ([0-9.eE+-]+)", out.stdout).group(1)) == 0.0, (switch, out.stdout[-2000:])
+        assert out.stderr.count("guide planes written by the tile classification kernel") == fused_frames, (switch, out.stderr[-2000:])
