@@ -127,8 +127,8 @@ NRD_D TapGuides FetchTapGuidesFullRect(const ReblurCB& c, const SpatialCtx& s, f
     t.NvXvs = t.zs * (k.x * s.geo.x + (k.y * s.geo.y + s.geo.z));
     t.materialIDs = 0.0f;
     if (materials)
-        t.materialIDs = NRD_DIV_3(float(bits >> 10)) * 3.0f;
-    t.roughnessS = NEED_ROUGHNESS ? NRD_DIV_1023(float(bits & 0x3FFu)) : 0.0f;
+        t.materialIDs = DecodedMaterialID(bits);
+    t.roughnessS = NEED_ROUGHNESS ? DecodedRoughness(bits) : 0.0f;
     t.uv = k; // unused
     return t;
 }

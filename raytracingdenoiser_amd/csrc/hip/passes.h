@@ -90,7 +90,7 @@ struct PassArgs {
     // rows [rowBegin, rowEnd) this rank has to produce in this pass (multi-GPU row-strip sharding; the whole frame by default).
     // Pixels outside are left untouched; planes stay full-size, so all neighbourhood reads keep their single-GPU meaning.
     int rowBegin, rowEnd;
-    // executor-internal cache of IN_NORMAL_ROUGHNESS decoded once per frame (float4 per texel: N.xyz, packed roughness | material
+    // executor-internal cache of IN_NORMAL_ROUGHNESS decoded once per frame (float4 per texel: N.xyz, roughness float | material
     // bits -- reblur_device.h "decoded guides"); ptr == nullptr when the dispatch list does not bind IN_NORMAL_ROUGHNESS
     Plane decodedNormalRoughness;
     // executor-internal guide plane of the RELAX lists (float4 per pixel: world position, viewZ), written together with the decoded normals once

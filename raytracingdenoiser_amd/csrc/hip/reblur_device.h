@@ -338,18 +338,22 @@ NRD_D float2 GetTemporalAccumulationParams(const ReblurCB& c, float isInScreenMu
 // ---- decoded guides ----------------------------------------------------------------------------------------------------
 // NRD_FrontEnd_UnpackNormalAndRoughness costs ~60 VALU instructions (oct decode, rsqrt = sqrt + divide) and the spatial passes
 // evaluate it at every tap of every pass. The executor therefore decodes IN_NORMAL_ROUGHNESS ONCE per frame into a float4 plane
-// (N.xyz as computed by UnpackNormalAndRoughness, w = the 12 roughness | materialID bits of the packed texel) and the kernels
-// fetch 16 bytes instead of re-deriving the normal: same values bit for bit, 4x the tap bytes (L2-served), ~55 instructions
-// less per tap -- the kernels are VALU-bound (profiles/), not bandwidth-bound.
+// (N.xyz as computed by UnpackNormalAndRoughness, w = the roughness AS A FLOAT with the two materialID bits of the packed texel in bits 31:30 -- a
+// roughness is in [0, 1], so its float has both clear) and the kernels fetch 16 bytes instead of re-deriving the normal: same values bit for bit, 4x
+// the tap bytes (L2-served), ~55 instructions less per tap -- the kernels are VALU-bound (profiles/), not bandwidth-bound. Round 5: the roughness used
+// to travel as its 10-bit integer and cost every specular tap a mask, a conversion and the exact division by 1023 (5 instructions; now one v_and).
+NRD_D float DecodedRoughness(uint32_t w) { return AsFloat(w & 0x3FFFFFFFu); }
+NRD_D float DecodedMaterialID(uint32_t w) { return NRD_DIV_3(float(w >> 30)) * 3.0f; } // = p.w * 3 of UnpackNormalAndRoughness
 NRD_D float4 EncodeDecodedNormalRoughness(uint32_t raw) {
     float unused;
     float4 nr = UnpackNormalAndRoughness(DecodeR10G10B10A2(raw), unused);
-    return F4(nr.x, nr.y, nr.z, AsFloat(raw >> 20));
+    const float roughness = NRD_DIV_1023(float((raw >> 20) & 0x3FFu)); // = DecodeR10G10B10A2(raw).z
+    return F4(nr.x, nr.y, nr.z, AsFloat(AsUint(roughness) | (raw & 0xC0000000u)));
 }
 NRD_D float4 DecodedToNormalRoughness(float4 d, float& materialID) {
     const uint32_t bits = AsUint(d.w);
-    materialID = NRD_DIV_3(float(bits >> 10)) * 3.0f; // = p.w * 3 of UnpackNormalAndRoughness
-    return F4(d.x, d.y, d.z, NRD_DIV_1023(float(bits & 0x3FFu)));
+    materialID = DecodedMaterialID(bits);
+    return F4(d.x, d.y, d.z, DecodedRoughness(bits));
 }
 NRD_D float4 LoadDecodedNormalRoughness(const Plane& decoded, int x, int y, float& materialID) { return DecodedToNormalRoughness(LoadRGBA32F(decoded, x, y), materialID); }
 NRD_D float4 LoadDecodedNormalRoughness(const Plane& decoded, int x, int y) {
