@@ -23,6 +23,11 @@ __device__ __constant__ const float g_Poisson8[8][3] = { // reference Shaders/In
     {-0.4706069f, -0.4427112f, +0.6461146f}, {-0.9057375f, +0.3003471f, +0.9542373f}, {-0.3487388f, +0.4037880f, +0.5335386f}, {+0.1023042f, +0.6439373f, +0.6520134f},
     {+0.5699277f, +0.3513750f, +0.6695386f}, {+0.2939128f, -0.1131226f, +0.3149309f}, {+0.7836658f, -0.4208784f, +0.8895339f}, {+0.1564120f, -0.8198990f, +0.8346850f}};
 
+// GetGaussianWeight( g_Poisson8[i].z ) = Exp( -0.66 z^2 ) of the eight constants above as OUR Exp() returns them, baked (bit patterns 0x3f425921 0x3f0c5bdb 0x3f5426ba
+// 0x3f415e51 0x3f3e6f61 0x3f6fc76c 0x3f17db60 0x3f21a332; tests/test_numerics.py re-derives them on the GPU): the tap loops are not fully unrolled, so the
+// compiler evaluated two multiplications and an exponential per tap and signal
+__device__ __constant__ const float g_Poisson8Gaussian[8] = {0.7591725f, 0.5482766f, 0.8287159f, 0.7553454f, 0.743887f, 0.9366367f, 0.59319115f, 0.6313964f};
+
 // ================================================================================================ ClassifyTiles
 __global__ __launch_bounds__(256) void RelaxClassifyTilesKernel(Plane viewZ, Plane tiles, float denoisingRange, int tilesPerRow, int tileRows) {
     // tilesPerRow x tileRows = the tiles of the RECT (dynamic resolution: the reference dispatches ceil(rect / 16) groups; tiles beyond stay untouched)
@@ -332,7 +337,7 @@ __global__ __launch_bounds__(256, NRD_WAVES_RELAX_PREPASS) void RelaxPrePassKern
 
                 float4 sampleDiffuseIllumination = LoadDenanifiedRGBA16F(sampleWeight, P.diff.in, t.signalTexel.x, t.signalTexel.y);
                 sampleWeight *= Lerp(c.shared.gMinHitDistanceWeight, 1.0f, ComputeExponentialWeight(sampleDiffuseIllumination.w, hitDistanceWeightParams.x, hitDistanceWeightParams.y));
-                sampleWeight *= GetGaussianWeight(g_Poisson8[i][2]);
+                sampleWeight *= g_Poisson8Gaussian[i]; // GetGaussianWeight( offset.z )
 
                 weightSum += sampleWeight;
                 diffuseIllumination = Mad(sampleDiffuseIllumination, sampleWeight, diffuseIllumination);
@@ -417,7 +422,7 @@ __global__ __launch_bounds__(256, NRD_WAVES_RELAX_PREPASS) void RelaxPrePassKern
 
                 float4 sampleSpecularIllumination = LoadDenanifiedRGBA16F(sampleWeight, P.spec.in, t.signalTexel.x, t.signalTexel.y);
                 sampleWeight *= Lerp(specMinHitDistanceWeight, 1.0f, ComputeExponentialWeight(sampleSpecularIllumination.w, hitDistanceWeightParams.x, hitDistanceWeightParams.y));
-                sampleWeight *= GetGaussianWeight(g_Poisson8[i][2]);
+                sampleWeight *= g_Poisson8Gaussian[i]; // GetGaussianWeight( offset.z )
 
                 float d = Length(sampleWorldPos - centerWorldPos);
                 float h = sampleSpecularIllumination.w;

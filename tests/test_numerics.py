@@ -189,6 +189,11 @@ def test_hip_constant_division_and_gaussian_constants():
     assert out.cpu().numpy().view(np.uint32).tolist() == [0x3F04505F, 0x3F590F8F, 0x3F713C86]
     ora = oracle_driver.load()
     assert np.float32(ora.oracle_exp2(float(np.float32(np.float32(-0.66) * np.float32(1.0) * np.float32(1.0)) * np.float32(1.44269504)))).view(np.uint32) == 0x3F04505F
+    # RELAX pre-pass: the z column of g_Poisson8 (reference Shaders/Include/Poisson.hlsli:40-50) against kernels_relax_spatial.hip g_Poisson8Gaussian
+    z = np.array([0.6461146, 0.9542373, 0.5335386, 0.6520134, 0.6695386, 0.3149309, 0.8895339, 0.8346850], dtype=np.float32)
+    t, out = torch.from_numpy(z).cuda(), torch.empty(8, device="cuda")
+    assert lib.nrdHipEvalNumerics(13, t.data_ptr(), None, out.data_ptr(), 8, stream) == 0
+    assert out.cpu().numpy().view(np.uint32).tolist() == [0x3F425921, 0x3F0C5BDB, 0x3F5426BA, 0x3F415E51, 0x3F3E6F61, 0x3F6FC76C, 0x3F17DB60, 0x3F21A332]
 
 
 def test_oracle_division_contract_edge_cases():
