@@ -284,13 +284,16 @@ def main():
     distributed = world > 1
     assert args.gpus == world, "bench.py: --gpus %d but WORLD_SIZE=%d (launch with torch.distributed.run --nproc-per-node %d, or without any launcher)" % (args.gpus, world, args.gpus)
     assert torch.cuda.is_available(), "bench.py needs a GPU: the HIP path has no CPU fallback"
-    # one process per GPU; NRD_DIST_BACKEND=gloo + fewer GPUs than ranks is the single-GPU rehearsal of the N>1 path (tests/test_bench_multi.py)
+    # one process per GPU; NRD_DIST_BACKEND=gloo + fewer GPUs than ranks is the single-GPU rehearsal of the N>1 path (tests/test_sharding.py test_bench_two_ranks_rehearsal)
     torch.cuda.set_device(local_rank % torch.cuda.device_count())
     backend = os.environ.get("NRD_DIST_BACKEND", "nccl")  # "nccl" is RCCL on ROCm
     if distributed:
         import torch.distributed as dist
 
-        dist.init_process_group(backend)
+        import datetime
+
+        # a collective that never completes (a peer died, a link is down) ends the run after 5 minutes instead of hanging it for the default 10 / 30
+        dist.init_process_group(backend, timeout=datetime.timedelta(seconds=int(os.environ.get("NRD_DIST_TIMEOUT_S", "300"))))
         assert dist.get_world_size() == args.gpus
 
     if rank == 0:
