@@ -99,6 +99,7 @@ struct NrdHipExecutor {
     int windowRegion[3] = {0, 0, 0};   // {tile columns, first tile row, end tile row} of the last window-kernel launch (passes.h PassArgs::windowRegion)
     Plane tileFlags = {};              // one byte per 32x8-pixel workgroup tile: hand-over between the two kernels of a split pass (kernels_reblur_ta.hip "window")
     Plane viewPos = {};                // internal float4 guide plane of the REBLUR lists (decoded normal + viewZ per pixel)
+    Plane roughnessWord = {};          // internal 4-B/px copy of the decoded normals' w word, written with viewPos (passes.h PassArgs::roughnessWord)
     uint32_t* motionBits = nullptr;    // nrdHipMeasureMotionRows: the reduction's result (float bits), own 4-byte allocation made on first use
     std::vector<nrd::Format> permanentFormat, transientFormat;
 
@@ -288,6 +289,8 @@ extern "C" __attribute__((visibility("default"))) void nrdHipDestroyExecutor(Nrd
         (void)hipFree(e->worldPosViewZ.ptr);
     if (e->viewPos.ptr)
         (void)hipFree(e->viewPos.ptr);
+    if (e->roughnessWord.ptr)
+        (void)hipFree(e->roughnessWord.ptr);
     if (e->tileFlags.ptr)
         (void)hipFree(e->tileFlags.ptr);
     if (e->motionBits)
@@ -926,6 +929,19 @@ static uint32_t ExecuteRange(NrdHipExecutor* e, const nrd::DispatchDesc* descs, 
                 cache.ptr = nullptr;
                 if (hipMalloc((void**)&cache.ptr, (size_t)cache.pitch * (size_t)cache.h) != hipSuccess)
                     return e->Fail(nrd::Result::FAILURE, "nrdHipExecuteDispatches: cannot allocate the view-position guide plane");
+                // its companion, a quarter of the size: the w word of the decoded normals alone (same texel grid, a quarter of the pitch)
+                Plane& word = e->roughnessWord;
+                if (word.ptr)
+                    (void)hipFree(word.ptr);
+                word = decoded;
+                word.ptr = nullptr;
+                word.pitch = decoded.pitch / 4u;
+                if (hipMalloc((void**)&word.ptr, (size_t)word.pitch * (size_t)word.h) != hipSuccess) {
+                    (void)hipFree(cache.ptr); // the two live and die together: a later call starts over
+                    cache = Plane{};
+                    word = Plane{};
+                    return e->Fail(nrd::Result::FAILURE, "nrdHipExecuteDispatches: cannot allocate the roughness-word guide plane");
+                }
                 e->decodedFresh = false;
                 decodeNow = true;
             }
@@ -1033,7 +1049,7 @@ static uint32_t ExecuteRange(NrdHipExecutor* e, const nrd::DispatchDesc* descs, 
         if (worldPos.ptr)
             LaunchDecodeGuidesRelax(args, guidePlane(nrd::ResourceType::IN_NORMAL_ROUGHNESS), guidePlane(nrd::ResourceType::IN_VIEWZ), decoded, worldPos, relaxConstants);
         if (viewPos.ptr)
-            LaunchDecodeGuides(args, guidePlane(nrd::ResourceType::IN_NORMAL_ROUGHNESS), guidePlane(nrd::ResourceType::IN_VIEWZ), decoded, viewPos, reblurConstants);
+            LaunchDecodeGuides(args, guidePlane(nrd::ResourceType::IN_NORMAL_ROUGHNESS), guidePlane(nrd::ResourceType::IN_VIEWZ), decoded, viewPos, e->roughnessWord, reblurConstants);
         if (!worldPos.ptr && !viewPos.ptr)
             LaunchDecodeNormalRoughness(args, guidePlane(nrd::ResourceType::IN_NORMAL_ROUGHNESS), decoded);
     };
@@ -1060,6 +1076,7 @@ static uint32_t ExecuteRange(NrdHipExecutor* e, const nrd::DispatchDesc* descs, 
         args.decodedNormalRoughness = decoded;
         args.worldPosViewZ = worldPos;
         args.viewPos = viewPos;
+        args.roughnessWord = viewPos.ptr ? e->roughnessWord : Plane{};
         args.tileFlags = e->tileFlags;
         args.windowRegion = e->windowRegion;
         if (i == fuseDispatch)

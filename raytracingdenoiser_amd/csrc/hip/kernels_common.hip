@@ -33,19 +33,21 @@ __global__ __launch_bounds__(256) void DecodeNormalRoughnessKernel(Plane packed,
 
 // REBLUR lists: the same decode plus a (normal, viewZ = |z * gViewZScale|) plane: what a tap of the spatial passes needs from its texel, in ONE 16-byte load
 // instead of a 16-byte and a 4-byte one. 8 B read + 32 B written per pixel.
-__global__ __launch_bounds__(256) void DecodeGuidesKernel(Plane packed, Plane viewZ, Plane decoded, Plane viewPos, float4 frustum, float2 rectSizeInv, float viewZScale, GuideRows rows) {
+__global__ __launch_bounds__(256) void DecodeGuidesKernel(Plane packed, Plane viewZ, Plane decoded, Plane viewPos, Plane roughnessWord, float4 frustum, float2 rectSizeInv, float viewZScale, GuideRows rows) {
     const int x = blockIdx.x * 256 + threadIdx.x, y = blockIdx.y + rows.launchBegin;
     if (x >= packed.w)
         return;
     if (y < rows.validBegin || y >= rows.validEnd) { // test hook only (NRD_HIP_POISON_GUIDES)
         StoreRGBA32F(decoded, x, y, F4(__uint_as_float(0x7FC00000u)));
         StoreRGBA32F(viewPos, x, y, F4(__uint_as_float(0x7FC00000u)));
+        StoreR32U(roughnessWord, x, y, 0x7FC00000u);
         return;
     }
     const uint32_t raw = LoadR32U(packed, x, y);
     const float4 d = EncodeDecodedNormalRoughness(raw);
     StoreRGBA32F(decoded, x, y, d);
     StoreRGBA32F(viewPos, x, y, F4(d.x, d.y, d.z, Abs(LoadR32F(viewZ, x, y) * viewZScale)));
+    StoreR32U(roughnessWord, x, y, AsUint(d.w)); // passes.h PassArgs::roughnessWord
 }
 
 // rows the guide kernels have to cover: PassArgs::rowBegin / rowEnd when the executor set them (multi-GPU: the strip + the reach of the passes that read the guides), else all.
@@ -60,12 +62,12 @@ static GuideRows MakeGuideRows(const PassArgs& a, const Plane& p) {
     return r;
 }
 
-void LaunchDecodeGuides(const PassArgs& a, const Plane& packed, const Plane& viewZ, const Plane& decoded, const Plane& viewPos, const void* reblurConstants) {
+void LaunchDecodeGuides(const PassArgs& a, const Plane& packed, const Plane& viewZ, const Plane& decoded, const Plane& viewPos, const Plane& roughnessWord, const void* reblurConstants) {
     const nrdc::ReblurConstants& c = *(const nrdc::ReblurConstants*)reblurConstants;
     const GuideRows rows = MakeGuideRows(a, packed);
     if (rows.launchEnd <= rows.launchBegin)
         return;
-    LaunchPass(a, DecodeGuidesKernel, dim3((unsigned)((packed.w + 255) / 256), (unsigned)(rows.launchEnd - rows.launchBegin), 1), dim3(256), packed, viewZ, decoded, viewPos,
+    LaunchPass(a, DecodeGuidesKernel, dim3((unsigned)((packed.w + 255) / 256), (unsigned)(rows.launchEnd - rows.launchBegin), 1), dim3(256), packed, viewZ, decoded, viewPos, roughnessWord,
         make_float4(c.gFrustum.x, c.gFrustum.y, c.gFrustum.z, c.gFrustum.w), make_float2(c.gRectSizeInv.x, c.gRectSizeInv.y), c.gViewZScale, rows);
 }
 
@@ -99,21 +101,22 @@ void LaunchDecodeGuidesRelax(const PassArgs& a, const Plane& packed, const Plane
 }
 
 // ---- guide decode + tile classification in one launch (round 5) -------------------------------------------------------------------------------------
-// The first pass of a REBLUR / RELAX list (ClassifyTiles: one wave per 16x16 tile votes "all sky" over IN_VIEWZ) reads nothing the decode kernels write and
-// streams the same IN_VIEWZ. When the guide planes are due for the whole frame the executor hands the packed plane to that pass's launcher
-// (PassArgs::fuseGuidesFrom) and skips its own decode launch: one wave per tile reads viewZ ONCE (4 rows x 64 B per load, 4 loads in flight), decodes its 256
-// texels, writes both guide planes (256-byte row segments, the four waves of a workgroup side by side: 1 KiB per row) and casts the tile vote -- no LDS, no
-// barrier. Values are those of the two separate kernels (same expressions); saves a launch, a dependent-launch gap and 4 B/px.
+// The first pass of a REBLUR / RELAX list (ClassifyTiles: "all sky" per 16x16 tile over IN_VIEWZ) reads nothing the decode kernels write and streams the same
+// IN_VIEWZ. When the guide planes are due for the whole frame the executor hands the packed plane to that pass's launcher (PassArgs::fuseGuidesFrom) and skips its own
+// decode launch. A workgroup covers 64 x 16 pixels = four tiles side by side; wave w takes rows 4w .. 4w+3 of it, a lane one column: viewZ is read ONCE, every
+// store of a wave is one contiguous run (1 KiB of a float4 plane, 256 B of the roughness-word plane), the four row loads of a lane are in flight together. The tile
+// vote is a 16-lane AND (four xor-shuffles) per wave and tile, combined over the four waves through 16 ints of LDS. Values are those of the separate kernels (same
+// expressions); saves a launch, a dependent-launch gap and 4 B/px.
 template <bool RELAX>
-__global__ __launch_bounds__(256) void DecodeGuidesClassifyKernel(Plane packed, Plane viewZ, Plane decoded, Plane guide, Plane tiles, float3 frustumRight, float3 frustumUp, float3 frustumForward,
-    float2 rectSizeInv, float viewZScale, float denoisingRange, int tilesPerRow, int tileRows) {
+__global__ __launch_bounds__(256) void DecodeGuidesClassifyKernel(Plane packed, Plane viewZ, Plane decoded, Plane guide, Plane roughnessWord, Plane tiles, float3 frustumRight, float3 frustumUp,
+    float3 frustumForward, float2 rectSizeInv, float viewZScale, float denoisingRange, int tilesPerRow, int tileRows) {
+    __shared__ int s_sky[4][4]; // [wave][tile of the workgroup]
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const int tx = blockIdx.x * 4 + wave, ty = blockIdx.y;
-    const int x = tx * 16 + (lane & 15), y0 = ty * 16 + (lane >> 4);
+    const int x = blockIdx.x * 64 + lane, y0 = blockIdx.y * 16 + wave * 4;
     bool allSky = true;
 #pragma unroll
     for (int k = 0; k < 4; k++) {
-        const int y = y0 + k * 4;
+        const int y = y0 + k;
         const bool inside = x < packed.w && y < packed.h;
         const float zRaw = inside ? LoadR32F(viewZ, x, y) : 0.0f; // out-of-bounds load = 0 => a partial edge tile is never sky (as in the stand-alone classification)
         allSky = allSky && (RELAX ? Abs(zRaw) : Abs(zRaw * viewZScale)) > denoisingRange;
@@ -128,24 +131,33 @@ __global__ __launch_bounds__(256) void DecodeGuidesClassifyKernel(Plane packed, 
             StoreRGBA32F(guide, x, y, F4(z * dir.x, z * dir.y, z * dir.z, z));
         } else {
             StoreRGBA32F(guide, x, y, F4(d.x, d.y, d.z, z));
+            StoreR32U(roughnessWord, x, y, AsUint(d.w)); // passes.h PassArgs::roughnessWord
         }
     }
-    const bool tileIsSky = __all(allSky);
-    if (lane == 0 && tx < tilesPerRow && ty < tileRows) // the tiles of the RECT; tiles beyond stay untouched
-        StoreR8Unorm(tiles, tx, ty, tileIsSky ? 1.0f : 0.0f);
+    int sky = allSky ? 1 : 0;
+    for (int m = 1; m < 16; m <<= 1) // over the 16 columns of one tile (the lanes of a wave that share lane >> 4)
+        sky &= __shfl_xor(sky, m);
+    if ((lane & 15) == 0)
+        s_sky[wave][lane >> 4] = sky;
+    __syncthreads();
+    if (threadIdx.x < 4) {
+        const int t = threadIdx.x, tx = blockIdx.x * 4 + t, ty = blockIdx.y;
+        if (tx < tilesPerRow && ty < tileRows) // the tiles of the RECT; tiles beyond stay untouched
+            StoreR8Unorm(tiles, tx, ty, (s_sky[0][t] & s_sky[1][t] & s_sky[2][t] & s_sky[3][t]) ? 1.0f : 0.0f);
+    }
 }
 
 void LaunchDecodeGuidesClassify(const PassArgs& a, const Plane& viewZ, const Plane& tiles, const void* reblurConstants, int tilesPerRow, int tileRows) {
     const nrdc::ReblurConstants& c = *(const nrdc::ReblurConstants*)reblurConstants;
     const Plane& packed = a.fuseGuidesFrom;
-    LaunchPass(a, (DecodeGuidesClassifyKernel<false>), dim3((unsigned)((packed.w + 63) / 64), (unsigned)((packed.h + 15) / 16), 1), dim3(256), packed, viewZ, a.decodedNormalRoughness, a.viewPos, tiles,
+    LaunchPass(a, (DecodeGuidesClassifyKernel<false>), dim3((unsigned)((packed.w + 63) / 64), (unsigned)((packed.h + 15) / 16), 1), dim3(256), packed, viewZ, a.decodedNormalRoughness, a.viewPos, a.roughnessWord, tiles,
         make_float3(0.0f, 0.0f, 0.0f), make_float3(0.0f, 0.0f, 0.0f), make_float3(0.0f, 0.0f, 0.0f), make_float2(0.0f, 0.0f), c.gViewZScale, c.gDenoisingRange, tilesPerRow, tileRows);
 }
 
 void LaunchDecodeGuidesClassifyRelax(const PassArgs& a, const Plane& viewZ, const Plane& tiles, const void* relaxConstants, int tilesPerRow, int tileRows) {
     const nrdc::RelaxConstants& c = *(const nrdc::RelaxConstants*)relaxConstants;
     const Plane& packed = a.fuseGuidesFrom;
-    LaunchPass(a, (DecodeGuidesClassifyKernel<true>), dim3((unsigned)((packed.w + 63) / 64), (unsigned)((packed.h + 15) / 16), 1), dim3(256), packed, viewZ, a.decodedNormalRoughness, a.worldPosViewZ, tiles,
+    LaunchPass(a, (DecodeGuidesClassifyKernel<true>), dim3((unsigned)((packed.w + 63) / 64), (unsigned)((packed.h + 15) / 16), 1), dim3(256), packed, viewZ, a.decodedNormalRoughness, a.worldPosViewZ, Plane{}, tiles,
         make_float3(c.gFrustumRight.x, c.gFrustumRight.y, c.gFrustumRight.z), make_float3(c.gFrustumUp.x, c.gFrustumUp.y, c.gFrustumUp.z),
         make_float3(c.gFrustumForward.x, c.gFrustumForward.y, c.gFrustumForward.z), make_float2(c.gRectSizeInv.x, c.gRectSizeInv.y), c.gViewZScale, c.gDenoisingRange, tilesPerRow, tileRows);
 }

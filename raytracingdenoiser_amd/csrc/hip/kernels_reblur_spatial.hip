@@ -77,6 +77,8 @@ struct SpatialCtx {
     // checkerboard resolve of the pre-pass (reference REBLUR_PrePass.hlsli:43-56): neighbour columns in the half-width input + their weights
     int cbX0, cbX1;
     float2 wc;
+    // uniform: base of the executor's roughness-word plane (passes.h PassArgs::roughnessWord; a quarter of the guide planes' pitch), full-rect variants only
+    const uint8_t* roughnessWord;
 };
 
 // ---- one tap of the Poisson kernels: position -> texel, guides of that texel ------------------------------------------------------------------
@@ -104,7 +106,7 @@ NRD_D TapGuides FetchTapGuidesFullRect(const ReblurCB& c, const SpatialCtx& s, f
     t.w = (cxf == k.x && cyf == k.y) ? 1.0f : 0.0f;
     t.ts = make_int2((int)cxf, (int)cyf);
     // Guides of the texel: the per-frame (normal, viewZ) guide plane (passes.h viewPos) makes a diffuse tap ONE 16-byte guide load; a specular tap adds the
-    // 4 bytes that hold the roughness / material bits of the decoded-normal texel. The view position is re-derived from viewZ. Fetching it as a second
+    // 4 bytes that hold the roughness / material bits of the decoded-normal texel (from their compact copy, passes.h roughnessWord). The view position is re-derived from viewZ. Fetching it as a second
     // 16-byte guide texel instead (r02_b / r02_c A/B) saved 19 % of the instructions and bought nothing: the extra 12 bytes per tap through the L1 /
     // texture-address path cost as much (profiles/r02_c_gather_bench.txt prices a wave's 16-byte gather at 40-150 CU cycles, a 4-byte one at 6-40). Staging
     // the whole tap footprint in LDS was measured too (r02_d: 32x16 workgroups, halo 12, 76 KB) and lost 15-20 % to the fill and the lower occupancy:
@@ -120,7 +122,7 @@ NRD_D TapGuides FetchTapGuidesFullRect(const ReblurCB& c, const SpatialCtx& s, f
         t.Ns = Xyz(g);
         t.zs = g.w;
         if (NEED_ROUGHNESS || FR == 1)
-            bits = *(const uint32_t*)(gIn_Normal_Roughness.ptr + offset + 12u);
+            bits = *(const uint32_t*)(s.roughnessWord + (offset >> 2)); // (the same word sits at offset + 12 of the decoded-normal texel: 4 bytes in 16 of a 4x larger plane)
     }
     const float2 uvc = (k + 0.5f) * rectSizeInv; // centre of the snapped pixel; equals the clamped texel's centre whenever the tap counts (t.w != 0)
     t.Xvs = ReconstructViewPosition(uvc, ToF4(c.gFrustum), t.zs, 0.0f); // perspective only (CheckSupported); dead code unless the caller needs the position
@@ -475,6 +477,7 @@ NRD_D bool MakeSpatialCtx(const ReblurCB& c, int px, int py, float viewZ, const 
     s.frustumSize = GetFrustumSize(c.gMinRectDimMulUnproject, NRD_ORTHO_MODE(c), viewZ);
     s.rotator = rotator;
     s.data1 = F2(0.0f, 0.0f);
+    s.roughnessWord = nullptr;
     {
         const float4 f = ToF4(c.gFrustum);
         const float2 r = ToF2(c.gRectSizeInv);
@@ -488,6 +491,7 @@ struct SpatialPlanes {
     Plane tiles, normalRoughness, viewZ, data1;
     Plane decodedNR; // executor's float4 cache of normalRoughness (reblur_device.h "decoded guides")
     Plane viewPos;   // executor's float4 guide plane (normal, viewZ; passes.h), same layout as decodedNR; may be null
+    Plane roughnessWord; // executor's 4-B/px copy of decodedNR's w word, a quarter of its pitch; null unless viewPos is there
     Plane inDiff, inSpec;
     Plane outDiff, outSpec;
     Plane outHitDistForTracking; // pre-pass
@@ -521,6 +525,7 @@ __global__ __launch_bounds__(TILE_X* TILE_Y, NRD_WAVES_REBLUR_SPATIAL) void Rebl
 
     if (MODE != PRE_BLUR)
         s.data1 = LoadData1<DIFF, SPEC>(P.data1, px, py);
+    s.roughnessWord = P.roughnessWord.ptr;
 
     uint32_t checkerboard = 0;
     if (MODE == PRE_BLUR && CB) { // checkerboard resolve weights (reference REBLUR_PrePass.hlsli:43-56)
@@ -613,6 +618,10 @@ static const char* LaunchSpatial(const PassArgs& a) {
     P.normalRoughness = a.planes[k++];
     P.decodedNR = a.decodedNormalRoughness;
     P.viewPos = (a.viewPos.ptr && SameLayout(a.viewPos, a.decodedNormalRoughness)) ? a.viewPos : Plane{};
+    if (P.viewPos.ptr && a.roughnessWord.ptr && a.roughnessWord.w == P.viewPos.w && a.roughnessWord.h == P.viewPos.h && a.roughnessWord.pitch * 4u == P.viewPos.pitch)
+        P.roughnessWord = a.roughnessWord;
+    else
+        P.viewPos = Plane{}; // (the full-rect taps need both)
     if (!P.decodedNR.ptr)
         return "REBLUR spatial pass: the decoded normal/roughness cache is missing (IN_NORMAL_ROUGHNESS not bound?)";
     if (MODE == PRE_BLUR) {

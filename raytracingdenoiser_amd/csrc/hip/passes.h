@@ -104,6 +104,10 @@ struct PassArgs {
     // from this packed IN_NORMAL_ROUGHNESS plane in the same kernel that classifies the tiles (kernels_common.hip DecodeGuidesClassifyKernel); the executor then
     // launches no decode kernel of its own
     Plane fuseGuidesFrom;
+    // executor-internal compact copy (4 B per pixel, pitch = decodedNormalRoughness.pitch / 4) of the w word of the decoded normals -- roughness float | material bits --
+    // of the REBLUR lists: what a SPECULAR tap of the spatial passes needs besides its (normal, viewZ) texel. Reading it from the 16-byte texels of decodedNormalRoughness
+    // pulled that whole plane (59 MB at 1440p) through the L2 for 4 bytes in 16; from here it is a quarter of that (round 5: pre-pass -5 %, Blur / PostBlur -2 %).
+    Plane roughnessWord;
     // executor-internal scratch, one byte per 32x8-pixel workgroup tile of the full-resolution planes: a pass that runs as a fast kernel plus a fallback kernel
     // (REBLUR TemporalAccumulation with its LDS window) hands the tiles the fast kernel declined to the fallback through it. Written completely by the fast
     // kernel before the fallback reads it (stream order), so it needs no clearing.
@@ -172,7 +176,7 @@ const PassEntry* GetValidationPasses(uint32_t& num);
 // decodes a whole R10G10B10A2 normal+roughness plane into the float4 cache (kernels_common.hip)
 void LaunchDecodeNormalRoughness(const PassArgs& a, const Plane& packed, const Plane& decoded);
 // same, plus the REBLUR view-position guide plane from IN_VIEWZ and the frame's REBLUR constants (kernels_common.hip)
-void LaunchDecodeGuides(const PassArgs& a, const Plane& packed, const Plane& viewZ, const Plane& decoded, const Plane& viewPos, const void* reblurConstants);
+void LaunchDecodeGuides(const PassArgs& a, const Plane& packed, const Plane& viewZ, const Plane& decoded, const Plane& viewPos, const Plane& roughnessWord, const void* reblurConstants);
 // same for RELAX lists: the (world position, viewZ) plane from IN_VIEWZ and the frame's RELAX constants
 void LaunchDecodeGuidesRelax(const PassArgs& a, const Plane& packed, const Plane& viewZ, const Plane& decoded, const Plane& worldPos, const void* relaxConstants);
 
