@@ -366,6 +366,15 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    # The interpreter's cyclic garbage collector stays out of the measured loops: the frame sequence keeps ~10^5 live Python objects, a generation-2 pass over them takes
+    # 5-10 ms -- as long as the whole 20-frame timed region (seen on one box: 1.22 ms per step in the wall clock with 0.71 ms per frame on the GPU, profiles/r05_q_*).
+    # No work is skipped: reference counting still frees everything the loops allocate; the collector runs again behind the measurements.
+    import gc
+
+    gc.collect()
+    gc.freeze()
+    gc.disable()
+
     for f in range(args.warmup):
         step(f)
     fence()
@@ -419,6 +428,8 @@ def main():
                 "frames": len(srt), "camera_cut": {"restart_frame_ms": round(cut_ms[0], 4), "following_frames_ms": [round(v, 4) for v in cut_ms[1:]],
                                                   "what": "one CLEAR_AND_RESTART frame after the timed sequence (pool clears + every pixel through the history-fix reconstruction), then 4 frames of regrowing history"},
                 "note": "GPU time between consecutive frame boundaries (events on the executor's stream) of a replay of the timed frames, rank 0"}
+    gc.enable()  # (the measured loops are over)
+    gc.unfreeze()
 
     if distributed:
         tt = torch.tensor([elapsed], dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")

@@ -913,14 +913,17 @@ static uint32_t ExecuteRange(NrdHipExecutor* e, const nrd::DispatchDesc* descs, 
     // View-position guide plane of the REBLUR lists (same geometry again): needs IN_VIEWZ and the frame's REBLUR constants
     Plane viewPos = {};
     const void* reblurConstants = nullptr;
-    static const bool guideNz = !(getenv("NRD_HIP_GUIDE_NZ") && atoi(getenv("NRD_HIP_GUIDE_NZ")) == 0); // A/B switch
-    if (decoded.ptr && e->userBound[(uint32_t)nrd::ResourceType::IN_VIEWZ] && guideNz) {
+    if (decoded.ptr) {
         for (uint32_t i = 0; i < dispatchDescsNum && !reblurConstants; i++)
             if (descs[i].pipelineIndex < idesc.pipelinesNum && !strncmp(idesc.pipelines[descs[i].pipelineIndex].shaderFileName, "REBLUR_", 7) && descs[i].constantBufferData &&
                 descs[i].constantBufferDataSize >= sizeof(nrdc::ReblurConstants))
                 reblurConstants = descs[i].constantBufferData;
         const Plane& z = e->user[(uint32_t)nrd::ResourceType::IN_VIEWZ];
-        if (reblurConstants && z.w == decoded.w && z.h == decoded.h) {
+        if (reblurConstants) { // the REBLUR kernels read normal + roughness from this pair only (reblur_device.h NormalRoughnessGuide): it has to exist
+            if (!e->userBound[(uint32_t)nrd::ResourceType::IN_VIEWZ])
+                return e->Fail(nrd::Result::INVALID_ARGUMENT, "resource not bound: IN_VIEWZ; nothing was launched");
+            if (z.w != decoded.w || z.h != decoded.h)
+                return e->Fail(nrd::Result::INVALID_ARGUMENT, "IN_VIEWZ and IN_NORMAL_ROUGHNESS differ in size; nothing was launched");
             Plane& cache = e->viewPos;
             if (!cache.ptr || cache.w != decoded.w || cache.h != decoded.h) {
                 if (cache.ptr)
@@ -946,8 +949,6 @@ static uint32_t ExecuteRange(NrdHipExecutor* e, const nrd::DispatchDesc* descs, 
                 decodeNow = true;
             }
             viewPos = cache;
-        } else {
-            reblurConstants = nullptr;
         }
     }
     // World-position guide plane of the RELAX lists (same geometry): IN_VIEWZ and the frame's RELAX constants. Independent of the REBLUR plane: one
@@ -1045,13 +1046,12 @@ static uint32_t ExecuteRange(NrdHipExecutor* e, const nrd::DispatchDesc* descs, 
         args.recorder = rec;
         args.rowBegin = guideRow0;
         args.rowEnd = guideRow1;
-        // each decode kernel writes the decoded normals too (identical values): with both families in the list both run
+        // RELAX: float4 (normal, roughness | material) + float4 (world position, viewZ); REBLUR: float4 (normal, viewZ) + the roughness | material word. A list with
+        // both families gets both sets; a list with neither (SIGMA, REFERENCE: they read the packed plane themselves) gets none
         if (worldPos.ptr)
             LaunchDecodeGuidesRelax(args, guidePlane(nrd::ResourceType::IN_NORMAL_ROUGHNESS), guidePlane(nrd::ResourceType::IN_VIEWZ), decoded, worldPos, relaxConstants);
         if (viewPos.ptr)
-            LaunchDecodeGuides(args, guidePlane(nrd::ResourceType::IN_NORMAL_ROUGHNESS), guidePlane(nrd::ResourceType::IN_VIEWZ), decoded, viewPos, e->roughnessWord, reblurConstants);
-        if (!worldPos.ptr && !viewPos.ptr)
-            LaunchDecodeNormalRoughness(args, guidePlane(nrd::ResourceType::IN_NORMAL_ROUGHNESS), decoded);
+            LaunchDecodeGuides(args, guidePlane(nrd::ResourceType::IN_NORMAL_ROUGHNESS), guidePlane(nrd::ResourceType::IN_VIEWZ), viewPos, e->roughnessWord, reblurConstants);
     };
     // a pass of the list rewrites IN_MV (REBLUR specular MV modification): the twin goes back into the user's plane behind the last pass
     const bool shiftBackMv = shiftedRect && writesMv && first + count == dispatchDescsNum;

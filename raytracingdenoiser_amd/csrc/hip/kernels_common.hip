@@ -18,36 +18,21 @@ struct GuideRows {
     int validBegin, validEnd;   // rows that receive decoded values (the others, test hook only: NaNs)
 };
 
-// ---- decoded guides: IN_NORMAL_ROUGHNESS (R10G10B10A2) -> float4 cache, once per frame (reblur_device.h "decoded guides") -----
-// 4 B read + 16 B written per texel, one texel per lane: a wave reads 256 B and writes 1 KiB, both contiguous.
-__global__ __launch_bounds__(256) void DecodeNormalRoughnessKernel(Plane packed, Plane decoded, GuideRows rows) {
-    const int x = blockIdx.x * 256 + threadIdx.x, y = blockIdx.y + rows.launchBegin;
-    if (x >= packed.w)
-        return;
-    if (y < rows.validBegin || y >= rows.validEnd) { // test hook only (NRD_HIP_POISON_GUIDES): rows nothing may read
-        StoreRGBA32F(decoded, x, y, F4(__uint_as_float(0x7FC00000u)));
-        return;
-    }
-    StoreRGBA32F(decoded, x, y, EncodeDecodedNormalRoughness(LoadR32U(packed, x, y)));
-}
-
-// REBLUR lists: the same decode plus a (normal, viewZ = |z * gViewZScale|) plane: what a tap of the spatial passes needs from its texel, in ONE 16-byte load
-// instead of a 16-byte and a 4-byte one. 8 B read + 32 B written per pixel.
-__global__ __launch_bounds__(256) void DecodeGuidesKernel(Plane packed, Plane viewZ, Plane decoded, Plane viewPos, Plane roughnessWord, float4 frustum, float2 rectSizeInv, float viewZScale, GuideRows rows) {
+// ---- decoded guides, once per frame (reblur_device.h "decoded guides") ------------------------------------------------------------------------------
+// REBLUR lists: a (normal, viewZ = |z * gViewZScale|) float4 plane -- what a tap of the spatial passes needs from its texel in ONE 16-byte load -- and the
+// roughness | material word at 4 B per pixel. 8 B read + 20 B written per pixel, one texel per lane: a wave's accesses are contiguous runs.
+__global__ __launch_bounds__(256) void DecodeGuidesKernel(Plane packed, Plane viewZ, Plane viewPos, Plane roughnessWord, float viewZScale, GuideRows rows) {
     const int x = blockIdx.x * 256 + threadIdx.x, y = blockIdx.y + rows.launchBegin;
     if (x >= packed.w)
         return;
     if (y < rows.validBegin || y >= rows.validEnd) { // test hook only (NRD_HIP_POISON_GUIDES)
-        StoreRGBA32F(decoded, x, y, F4(__uint_as_float(0x7FC00000u)));
         StoreRGBA32F(viewPos, x, y, F4(__uint_as_float(0x7FC00000u)));
         StoreR32U(roughnessWord, x, y, 0x7FC00000u);
         return;
     }
-    const uint32_t raw = LoadR32U(packed, x, y);
-    const float4 d = EncodeDecodedNormalRoughness(raw);
-    StoreRGBA32F(decoded, x, y, d);
+    const float4 d = EncodeDecodedNormalRoughness(LoadR32U(packed, x, y));
     StoreRGBA32F(viewPos, x, y, F4(d.x, d.y, d.z, Abs(LoadR32F(viewZ, x, y) * viewZScale)));
-    StoreR32U(roughnessWord, x, y, AsUint(d.w)); // passes.h PassArgs::roughnessWord
+    StoreR32U(roughnessWord, x, y, AsUint(d.w));
 }
 
 // rows the guide kernels have to cover: PassArgs::rowBegin / rowEnd when the executor set them (multi-GPU: the strip + the reach of the passes that read the guides), else all.
@@ -62,13 +47,12 @@ static GuideRows MakeGuideRows(const PassArgs& a, const Plane& p) {
     return r;
 }
 
-void LaunchDecodeGuides(const PassArgs& a, const Plane& packed, const Plane& viewZ, const Plane& decoded, const Plane& viewPos, const Plane& roughnessWord, const void* reblurConstants) {
+void LaunchDecodeGuides(const PassArgs& a, const Plane& packed, const Plane& viewZ, const Plane& viewPos, const Plane& roughnessWord, const void* reblurConstants) {
     const nrdc::ReblurConstants& c = *(const nrdc::ReblurConstants*)reblurConstants;
     const GuideRows rows = MakeGuideRows(a, packed);
     if (rows.launchEnd <= rows.launchBegin)
         return;
-    LaunchPass(a, DecodeGuidesKernel, dim3((unsigned)((packed.w + 255) / 256), (unsigned)(rows.launchEnd - rows.launchBegin), 1), dim3(256), packed, viewZ, decoded, viewPos, roughnessWord,
-        make_float4(c.gFrustum.x, c.gFrustum.y, c.gFrustum.z, c.gFrustum.w), make_float2(c.gRectSizeInv.x, c.gRectSizeInv.y), c.gViewZScale, rows);
+    LaunchPass(a, DecodeGuidesKernel, dim3((unsigned)((packed.w + 255) / 256), (unsigned)(rows.launchEnd - rows.launchBegin), 1), dim3(256), packed, viewZ, viewPos, roughnessWord, c.gViewZScale, rows);
 }
 
 // RELAX lists: the same decode plus (world position, viewZ) of every pixel -- GetCurrentWorldPosFromPixelPos( pixel, |z * gViewZScale| ) of RELAX_Common.hlsli:
@@ -123,9 +107,9 @@ __global__ __launch_bounds__(256) void DecodeGuidesClassifyKernel(Plane packed, 
         if (!inside)
             continue;
         const float4 d = EncodeDecodedNormalRoughness(LoadR32U(packed, x, y));
-        StoreRGBA32F(decoded, x, y, d);
         const float z = Abs(zRaw * viewZScale);
         if (RELAX) {
+            StoreRGBA32F(decoded, x, y, d);
             const float2 clip = F2(float(x) + 0.5f, float(y) + 0.5f) * rectSizeInv * 2.0f - 1.0f;
             const float3 dir = frustumForward + frustumRight * clip.x - frustumUp * clip.y; // DecodeGuidesRelaxKernel, same operation order
             StoreRGBA32F(guide, x, y, F4(z * dir.x, z * dir.y, z * dir.z, z));
@@ -160,12 +144,6 @@ void LaunchDecodeGuidesClassifyRelax(const PassArgs& a, const Plane& viewZ, cons
     LaunchPass(a, (DecodeGuidesClassifyKernel<true>), dim3((unsigned)((packed.w + 63) / 64), (unsigned)((packed.h + 15) / 16), 1), dim3(256), packed, viewZ, a.decodedNormalRoughness, a.worldPosViewZ, Plane{}, tiles,
         make_float3(c.gFrustumRight.x, c.gFrustumRight.y, c.gFrustumRight.z), make_float3(c.gFrustumUp.x, c.gFrustumUp.y, c.gFrustumUp.z),
         make_float3(c.gFrustumForward.x, c.gFrustumForward.y, c.gFrustumForward.z), make_float2(c.gRectSizeInv.x, c.gRectSizeInv.y), c.gViewZScale, c.gDenoisingRange, tilesPerRow, tileRows);
-}
-
-void LaunchDecodeNormalRoughness(const PassArgs& a, const Plane& packed, const Plane& decoded) {
-    const GuideRows rows = MakeGuideRows(a, packed);
-    if (rows.launchEnd > rows.launchBegin)
-        LaunchPass(a, DecodeNormalRoughnessKernel, dim3((unsigned)((packed.w + 255) / 256), (unsigned)(rows.launchEnd - rows.launchBegin), 1), dim3(256), packed, decoded, rows);
 }
 
 // ---- shifted rect (CommonSettings::rectOrigin; reference Common.hlsli:200-206 WithRectOrigin / WithRectOffset) ------------------------------------

@@ -45,7 +45,7 @@ constexpr int BUF_STRIDE = BUF_X + 1;      // 37
 struct HfPlanes {
     Plane tiles, normalRoughness, data1, viewZ, inDiff, inSpec, inDiffFast, inSpecFast, outDiff, outSpec, outDiffFast, outSpecFast;
     Plane inDiffSh, inSpecSh, outDiffSh, outSpecSh; // SH family
-    Plane decodedNR; // executor's float4 cache of normalRoughness (reblur_device.h "decoded guides")
+    NormalRoughnessGuide decodedNR; // executor's decoded guides of IN_NORMAL_ROUGHNESS (reblur_device.h NormalRoughnessGuide)
 };
 
 struct HfPixel {
@@ -299,9 +299,8 @@ static const char* LaunchHistoryFix(const PassArgs& a) {
     uint32_t k = 0;
     P.tiles = a.planes[k++];
     P.normalRoughness = a.planes[k++];
-    P.decodedNR = a.decodedNormalRoughness;
-    if (!P.decodedNR.ptr)
-        return "REBLUR HistoryFix: the decoded normal/roughness cache is missing (IN_NORMAL_ROUGHNESS not bound?)";
+    if (const char* err = MakeNormalRoughnessGuide(a, P.decodedNR))
+        return err;
     P.data1 = a.planes[k++];
     P.viewZ = a.planes[k++];
     if (DIFF) P.inDiff = a.planes[k++];
@@ -335,7 +334,7 @@ struct TsPlanes {
     Plane tiles, normalRoughness, viewZ, data1, data2, inDiff, inSpec, historyDiffLuma, historySpecLuma, inSpecHitDistForTracking, mv, outInternalData, outDiff, outSpec, outDiffLuma,
         outSpecLuma;
     Plane inDiffSh, inSpecSh, outDiffSh, outSpecSh; // SH family
-    Plane decodedNR;
+    NormalRoughnessGuide decodedNR;
     Plane baseColorMetalness; // IN_BASECOLOR_METALNESS (RGBA8_UNORM), only read when the specular MV modification is on
 };
 
@@ -605,9 +604,8 @@ static const char* LaunchTemporalStabilization(const PassArgs& a) {
     uint32_t k = 0;
     P.tiles = a.planes[k++];
     P.normalRoughness = a.planes[k++];
-    P.decodedNR = a.decodedNormalRoughness;
-    if (!P.decodedNR.ptr)
-        return "REBLUR TemporalStabilization: the decoded normal/roughness cache is missing (IN_NORMAL_ROUGHNESS not bound?)";
+    if (const char* err = MakeNormalRoughnessGuide(a, P.decodedNR))
+        return err;
     if (SPEC) P.baseColorMetalness = a.planes[k++]; // a dummy unless CommonSettings::isBaseColorMetalnessAvailable
     if (SPEC && c.gSpecProbabilityThresholdsForMvModification.x < 1.0f && (!P.baseColorMetalness.ptr || a.formats[k - 1] != (uint32_t)FORMAT_RGBA8_UNORM))
         return "REBLUR TemporalStabilization: IN_BASECOLOR_METALNESS must be bound as RGBA8_UNORM when isBaseColorMetalnessAvailable is set";

@@ -77,8 +77,6 @@ struct SpatialCtx {
     // checkerboard resolve of the pre-pass (reference REBLUR_PrePass.hlsli:43-56): neighbour columns in the half-width input + their weights
     int cbX0, cbX1;
     float2 wc;
-    // uniform: base of the executor's roughness-word plane (passes.h PassArgs::roughnessWord; a quarter of the guide planes' pitch), full-rect variants only
-    const uint8_t* roughnessWord;
 };
 
 // ---- one tap of the Poisson kernels: position -> texel, guides of that texel ------------------------------------------------------------------
@@ -98,7 +96,7 @@ struct TapGuides {
 
 // the "full rect" tap: k = the snapped pixel (integer-valued floats, not yet clamped)
 template <int FR, bool NEED_ROUGHNESS>
-NRD_D TapGuides FetchTapGuidesFullRect(const ReblurCB& c, const SpatialCtx& s, float2 k, const Plane& gIn_Normal_Roughness, const Plane& gIn_ViewPos, bool compareMaterials) {
+NRD_D TapGuides FetchTapGuidesFullRect(const ReblurCB& c, const SpatialCtx& s, float2 k, const NormalRoughnessGuide& gIn_Normal_Roughness, const Plane& gIn_ViewPos, bool compareMaterials) {
     TapGuides t;
     const float2 rectSize = ToF2(c.gRectSize), rectSizeInv = ToF2(c.gRectSizeInv);
     // clamp in the float domain (one v_med3_f32 per axis; the snapped coordinate is an integer-valued float): inside <=> the clamp changed nothing
@@ -122,7 +120,7 @@ NRD_D TapGuides FetchTapGuidesFullRect(const ReblurCB& c, const SpatialCtx& s, f
         t.Ns = Xyz(g);
         t.zs = g.w;
         if (NEED_ROUGHNESS || FR == 1)
-            bits = *(const uint32_t*)(s.roughnessWord + (offset >> 2)); // (the same word sits at offset + 12 of the decoded-normal texel: 4 bytes in 16 of a 4x larger plane)
+            bits = *(const uint32_t*)(gIn_Normal_Roughness.word.ptr + (offset >> 2)); // (a quarter of the guide planes' pitch: reblur_device.h NormalRoughnessGuide)
     }
     const float2 uvc = (k + 0.5f) * rectSizeInv; // centre of the snapped pixel; equals the clamped texel's centre whenever the tap counts (t.w != 0)
     t.Xvs = ReconstructViewPosition(uvc, ToF4(c.gFrustum), t.zs, 0.0f); // perspective only (CheckSupported); dead code unless the caller needs the position
@@ -136,7 +134,7 @@ NRD_D TapGuides FetchTapGuidesFullRect(const ReblurCB& c, const SpatialCtx& s, f
 }
 
 template <SpatialMode MODE, bool CB, int FR, bool NEED_ROUGHNESS>
-NRD_D TapGuides FetchTapGuides(const ReblurCB& c, const SpatialCtx& s, float2 uv, const Plane& gIn_Signal, const Plane& gIn_ViewZ, const Plane& gIn_Normal_Roughness, const Plane& gIn_ViewPos,
+NRD_D TapGuides FetchTapGuides(const ReblurCB& c, const SpatialCtx& s, float2 uv, const Plane& gIn_Signal, const Plane& gIn_ViewZ, const NormalRoughnessGuide& gIn_Normal_Roughness, const Plane& gIn_ViewPos,
     uint32_t checkerboardMode, uint32_t n, bool compareMaterials) {
     const float2 rectSize = ToF2(c.gRectSize), rectSizeInv = ToF2(c.gRectSizeInv);
     uv = Floor(uv * rectSize);
@@ -182,7 +180,7 @@ NRD_D float PoissonGaussianWeight(int n) { // = GetGaussianWeight( offset.z ), b
 // without data moves one pixel sideways, and pixels the taps could not fill are resolved from the two horizontal neighbours
 template <SpatialMode MODE, bool PERF, int KIND, bool SH, bool CB, int FR>
 NRD_D typename ReblurSignal<KIND>::type DiffuseSpatialFilterTaps(const ReblurCB& c, const SpatialCtx& s, typename ReblurSignal<KIND>::type diff, const Plane& gIn_Diff, const Plane& gIn_ViewZ,
-    const Plane& gIn_Normal_Roughness, const Plane& gIn_ViewPos, float4& diffSh, const Plane& gIn_DiffSh, float& sum) {
+    const NormalRoughnessGuide& gIn_Normal_Roughness, const Plane& gIn_ViewPos, float4& diffSh, const Plane& gIn_DiffSh, float& sum) {
     typedef ReblurSignal<KIND> Sig;
     constexpr bool OCC = KIND == SIGNAL_OCCLUSION;
     typedef typename Sig::type S;
@@ -275,7 +273,7 @@ NRD_D typename ReblurSignal<KIND>::type DiffuseSpatialFilterTaps(const ReblurCB&
 // "sum" = 1 when the centre pixel carries data, 0 for the empty pixels of a checkerboarded input
 template <SpatialMode MODE, bool PERF, int KIND, bool SH, bool CB, int FR>
 NRD_D typename ReblurSignal<KIND>::type DiffuseSpatialFilter(const ReblurCB& c, const SpatialCtx& s, typename ReblurSignal<KIND>::type diff, const Plane& gIn_Diff, const Plane& gIn_ViewZ,
-    const Plane& gIn_Normal_Roughness, const Plane& gIn_ViewPos, float4& diffSh, const Plane& gIn_DiffSh, float sum) {
+    const NormalRoughnessGuide& gIn_Normal_Roughness, const Plane& gIn_ViewPos, float4& diffSh, const Plane& gIn_DiffSh, float sum) {
     typedef ReblurSignal<KIND> Sig;
     typedef typename Sig::type S;
     if (!(MODE == PRE_BLUR && c.gDiffPrepassBlurRadius == 0.0f))
@@ -295,7 +293,7 @@ NRD_D typename ReblurSignal<KIND>::type DiffuseSpatialFilter(const ReblurCB& c, 
 
 template <SpatialMode MODE, bool PERF, int KIND, bool SH, bool CB, int FR>
 NRD_D typename ReblurSignal<KIND>::type SpecularSpatialFilterTaps(const ReblurCB& c, const SpatialCtx& s, typename ReblurSignal<KIND>::type spec, const Plane& gIn_Spec, const Plane& gIn_ViewZ,
-    const Plane& gIn_Normal_Roughness, const Plane& gIn_ViewPos, const Plane& gOut_SpecHitDistForTracking, float4& specSh, const Plane& gIn_SpecSh, float& sum) {
+    const NormalRoughnessGuide& gIn_Normal_Roughness, const Plane& gIn_ViewPos, const Plane& gOut_SpecHitDistForTracking, float4& specSh, const Plane& gIn_SpecSh, float& sum) {
     typedef ReblurSignal<KIND> Sig;
     constexpr bool OCC = KIND == SIGNAL_OCCLUSION;
     typedef typename Sig::type S;
@@ -441,7 +439,7 @@ NRD_D typename ReblurSignal<KIND>::type SpecularSpatialFilterTaps(const ReblurCB
 
 template <SpatialMode MODE, bool PERF, int KIND, bool SH, bool CB, int FR>
 NRD_D typename ReblurSignal<KIND>::type SpecularSpatialFilter(const ReblurCB& c, const SpatialCtx& s, typename ReblurSignal<KIND>::type spec, const Plane& gIn_Spec, const Plane& gIn_ViewZ,
-    const Plane& gIn_Normal_Roughness, const Plane& gIn_ViewPos, const Plane& gOut_SpecHitDistForTracking, float4& specSh, const Plane& gIn_SpecSh, float sum) {
+    const NormalRoughnessGuide& gIn_Normal_Roughness, const Plane& gIn_ViewPos, const Plane& gOut_SpecHitDistForTracking, float4& specSh, const Plane& gIn_SpecSh, float sum) {
     typedef ReblurSignal<KIND> Sig;
     typedef typename Sig::type S;
     if (!(MODE == PRE_BLUR && c.gSpecPrepassBlurRadius == 0.0f))
@@ -460,7 +458,7 @@ NRD_D typename ReblurSignal<KIND>::type SpecularSpatialFilter(const ReblurCB& c,
 }
 
 // per-pixel context; false = early-out (sky tile, outside the rect, beyond the denoising range)
-NRD_D bool MakeSpatialCtx(const ReblurCB& c, int px, int py, float viewZ, const Plane& gIn_Normal_Roughness, float4 rotator, SpatialCtx& s) {
+NRD_D bool MakeSpatialCtx(const ReblurCB& c, int px, int py, float viewZ, const NormalRoughnessGuide& gIn_Normal_Roughness, float4 rotator, SpatialCtx& s) {
     s.viewZ = viewZ;
     if (viewZ > c.gDenoisingRange)
         return false;
@@ -477,7 +475,6 @@ NRD_D bool MakeSpatialCtx(const ReblurCB& c, int px, int py, float viewZ, const 
     s.frustumSize = GetFrustumSize(c.gMinRectDimMulUnproject, NRD_ORTHO_MODE(c), viewZ);
     s.rotator = rotator;
     s.data1 = F2(0.0f, 0.0f);
-    s.roughnessWord = nullptr;
     {
         const float4 f = ToF4(c.gFrustum);
         const float2 r = ToF2(c.gRectSizeInv);
@@ -489,9 +486,8 @@ NRD_D bool MakeSpatialCtx(const ReblurCB& c, int px, int py, float viewZ, const 
 
 struct SpatialPlanes {
     Plane tiles, normalRoughness, viewZ, data1;
-    Plane decodedNR; // executor's float4 cache of normalRoughness (reblur_device.h "decoded guides")
-    Plane viewPos;   // executor's float4 guide plane (normal, viewZ; passes.h), same layout as decodedNR; may be null
-    Plane roughnessWord; // executor's 4-B/px copy of decodedNR's w word, a quarter of its pitch; null unless viewPos is there
+    NormalRoughnessGuide decodedNR; // executor's decoded guides: float4 (normal, viewZ) + the roughness | material word (reblur_device.h NormalRoughnessGuide)
+    Plane viewPos;                  // = decodedNR.nz: what a tap reads in one 16-byte load
     Plane inDiff, inSpec;
     Plane outDiff, outSpec;
     Plane outHitDistForTracking; // pre-pass
@@ -525,7 +521,6 @@ __global__ __launch_bounds__(TILE_X* TILE_Y, NRD_WAVES_REBLUR_SPATIAL) void Rebl
 
     if (MODE != PRE_BLUR)
         s.data1 = LoadData1<DIFF, SPEC>(P.data1, px, py);
-    s.roughnessWord = P.roughnessWord.ptr;
 
     uint32_t checkerboard = 0;
     if (MODE == PRE_BLUR && CB) { // checkerboard resolve weights (reference REBLUR_PrePass.hlsli:43-56)
@@ -616,14 +611,9 @@ static const char* LaunchSpatial(const PassArgs& a) {
     uint32_t k = 0;
     P.tiles = a.planes[k++];
     P.normalRoughness = a.planes[k++];
-    P.decodedNR = a.decodedNormalRoughness;
-    P.viewPos = (a.viewPos.ptr && SameLayout(a.viewPos, a.decodedNormalRoughness)) ? a.viewPos : Plane{};
-    if (P.viewPos.ptr && a.roughnessWord.ptr && a.roughnessWord.w == P.viewPos.w && a.roughnessWord.h == P.viewPos.h && a.roughnessWord.pitch * 4u == P.viewPos.pitch)
-        P.roughnessWord = a.roughnessWord;
-    else
-        P.viewPos = Plane{}; // (the full-rect taps need both)
-    if (!P.decodedNR.ptr)
-        return "REBLUR spatial pass: the decoded normal/roughness cache is missing (IN_NORMAL_ROUGHNESS not bound?)";
+    if (const char* err = MakeNormalRoughnessGuide(a, P.decodedNR))
+        return err;
+    P.viewPos = P.decodedNR.nz;
     if (MODE == PRE_BLUR) {
         P.viewZ = a.planes[k++];
         if (DIFF) P.inDiff = a.planes[k++];
@@ -676,8 +666,8 @@ static const char* LaunchSpatial(const PassArgs& a) {
     }
     // "full rect": the rect is the whole resource (no dynamic-resolution scaling) and the (normal, viewZ) guide plane of this frame exists;
     // variant 2 when neither signal tests material IDs this frame (IDs are 0..3: a minimum >= 3, the library default, makes every comparison hold)
-    const bool fullRect = c.gResolutionScale.x == 1.0f && c.gResolutionScale.y == 1.0f && c.gRectSizeMinusOne.x + 1 == P.decodedNR.w &&
-                          c.gRectSizeMinusOne.y + 1 == P.decodedNR.h && P.viewZ.w == P.decodedNR.w && P.viewZ.h == P.decodedNR.h && P.viewPos.ptr && !ForceGenericTaps();
+    const bool fullRect = c.gResolutionScale.x == 1.0f && c.gResolutionScale.y == 1.0f && c.gRectSizeMinusOne.x + 1 == P.decodedNR.nz.w &&
+                          c.gRectSizeMinusOne.y + 1 == P.decodedNR.nz.h && P.viewZ.w == P.decodedNR.nz.w && P.viewZ.h == P.decodedNR.nz.h && !ForceGenericTaps();
     const bool materials = (DIFF && c.gDiffMinMaterial < 3.0f) || (SPEC && c.gSpecMinMaterial < 3.0f);
     if (fullRect && !materials)
         LaunchPass(a, (ReblurSpatialKernel<MODE, DIFF, SPEC, NO_TS, PERF, KIND, SH, false, 2>), g.grid, dim3(TILE_X * TILE_Y), c, P, rows);
@@ -756,7 +746,8 @@ static const char* LaunchSplitScreen(const PassArgs& a) {
 // An optional pass (HitDistanceReconstructionMode != OFF): the 3x3 / 5x5 window is read straight from L1/L2 at rect-clamped
 // coordinates -- 8 / 24 taps of (decoded normal 16 B, viewZ 4 B, hit distance 2 x 8 B) -- instead of staging an LDS tile.
 struct HitDistPlanes {
-    Plane tiles, viewZ, decodedNR, inDiff, inSpec, outDiff, outSpec;
+    Plane tiles, viewZ, inDiff, inSpec, outDiff, outSpec;
+    NormalRoughnessGuide decodedNR;
 };
 
 template <bool DIFF, bool SPEC, int BORDER, bool PERF, int KIND>
@@ -854,9 +845,10 @@ static const char* LaunchHitDistReconstruction(const PassArgs& a) {
     if (SPEC) P.inSpec = a.planes[k++];
     if (DIFF) P.outDiff = a.planes[k++];
     if (SPEC) P.outSpec = a.planes[k++];
-    P.decodedNR = a.decodedNormalRoughness;
-    if (k != a.planesNum || !P.decodedNR.ptr)
-        return "REBLUR hit distance reconstruction: unexpected resource count or missing decoded normal/roughness cache";
+    if (k != a.planesNum)
+        return "REBLUR hit distance reconstruction: unexpected resource count";
+    if (const char* err = MakeNormalRoughnessGuide(a, P.decodedNR))
+        return err;
     RowGrid g = GridForRows(c.gRectSizeMinusOne.x + 1, c.gRectSizeMinusOne.y + 1, TILE_X, TILE_Y, a.rowBegin, a.rowEnd);
     LaunchPass(a, (ReblurHitDistReconstructionKernel<DIFF, SPEC, BORDER, PERF, KIND>), g.grid, dim3(TILE_X * TILE_Y), c, P, MakeRowRange(g));
     return nullptr;

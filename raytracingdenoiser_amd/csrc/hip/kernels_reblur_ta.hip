@@ -37,7 +37,7 @@ struct TaPlanes {
     Plane tileFlags; // executor scratch, one byte per workgroup tile (passes.h): set by the window kernel for the tiles it leaves to the fallback kernel
     int winMaxW, winMaxH; // largest box the window kernel accepts (<= WIN_W x WIN_H; smaller values exercise the fallback kernel: NRD_HIP_TA_WINDOW_LIMIT)
     Plane tiles, normalRoughness, viewZ, mv, prevViewZ, prevNormalRoughness, prevInternalData;
-    Plane decodedNR; // executor's float4 cache of normalRoughness (reblur_device.h "decoded guides")
+    NormalRoughnessGuide decodedNR; // executor's decoded guides of IN_NORMAL_ROUGHNESS (reblur_device.h NormalRoughnessGuide)
     Plane disocclusionThresholdMix, diffConfidence, specConfidence; // R8_UNORM user inputs; dummies unless the gHas* flags are set
     Plane inDiff, inSpec, historyDiff, historySpec, historyDiffFast, historySpecFast, prevSpecHitDistForTracking, inSpecHitDistForTracking;
     Plane outDiff, outSpec, outDiffFast, outSpecFast, outSpecHitDistForTracking, outData1, outData2;
@@ -1065,9 +1065,8 @@ static const char* LaunchTemporalAccumulation(const PassArgs& a) {
     uint32_t k = 0;
     P.tiles = a.planes[k++];
     P.normalRoughness = a.planes[k++];
-    P.decodedNR = a.decodedNormalRoughness;
-    if (!P.decodedNR.ptr)
-        return "REBLUR TemporalAccumulation: the decoded normal/roughness cache is missing (IN_NORMAL_ROUGHNESS not bound?)";
+    if (const char* err = MakeNormalRoughnessGuide(a, P.decodedNR))
+        return err;
     P.viewZ = a.planes[k++];
     P.mv = a.planes[k++];
     P.prevViewZ = a.planes[k++];

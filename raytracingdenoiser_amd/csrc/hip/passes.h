@@ -173,10 +173,8 @@ const PassEntry* GetSigmaPasses(uint32_t& num);
 const PassEntry* GetRelaxPasses(uint32_t& num);
 const PassEntry* GetValidationPasses(uint32_t& num);
 
-// decodes a whole R10G10B10A2 normal+roughness plane into the float4 cache (kernels_common.hip)
-void LaunchDecodeNormalRoughness(const PassArgs& a, const Plane& packed, const Plane& decoded);
 // same, plus the REBLUR view-position guide plane from IN_VIEWZ and the frame's REBLUR constants (kernels_common.hip)
-void LaunchDecodeGuides(const PassArgs& a, const Plane& packed, const Plane& viewZ, const Plane& decoded, const Plane& viewPos, const Plane& roughnessWord, const void* reblurConstants);
+void LaunchDecodeGuides(const PassArgs& a, const Plane& packed, const Plane& viewZ, const Plane& viewPos, const Plane& roughnessWord, const void* reblurConstants);
 // same for RELAX lists: the (world position, viewZ) plane from IN_VIEWZ and the frame's RELAX constants
 void LaunchDecodeGuidesRelax(const PassArgs& a, const Plane& packed, const Plane& viewZ, const Plane& decoded, const Plane& worldPos, const void* relaxConstants);
 

@@ -356,6 +356,40 @@ NRD_D float4 DecodedToNormalRoughness(float4 d, float& materialID) {
     return F4(d.x, d.y, d.z, DecodedRoughness(bits));
 }
 NRD_D float4 LoadDecodedNormalRoughness(const Plane& decoded, int x, int y, float& materialID) { return DecodedToNormalRoughness(LoadRGBA32F(decoded, x, y), materialID); }
+// REBLUR lists keep the decoded guides as TWO planes (passes.h viewPos + roughnessWord): float4 (normal, viewZ) and the roughness | material word at a quarter of the
+// pitch -- the spatial taps want exactly these (a diffuse tap one 16-byte load, a specular tap 4 bytes more), and every other REBLUR kernel reads its normal + roughness from
+// the same pair, so the float4 (normal, word) plane of the RELAX lists is neither written nor read here (round 5: 16 B/px less per frame, one 59 MB plane less in the L2).
+struct NormalRoughnessGuide {
+    Plane nz, word;
+};
+NRD_D void ShareSize(NormalRoughnessGuide& g, const Plane& ref) { ShareSize(g.nz, ref), ShareSize(g.word, ref); }
+inline bool SameSize(const NormalRoughnessGuide& g, const Plane& ref) { return SameSize(g.nz, ref) && SameSize(g.word, ref); }
+// launcher side: nullptr, or why the pair the executor handed over cannot be used
+inline const char* MakeNormalRoughnessGuide(const PassArgs& a, NormalRoughnessGuide& g) {
+    g.nz = a.viewPos;
+    g.word = a.roughnessWord;
+    if (!g.nz.ptr || !g.word.ptr)
+        return "REBLUR: the decoded guide planes are missing (IN_NORMAL_ROUGHNESS / IN_VIEWZ not bound?)";
+    if (g.word.w != g.nz.w || g.word.h != g.nz.h || g.word.pitch * 4u != g.nz.pitch)
+        return "REBLUR: internal error: the roughness-word plane does not match the (normal, viewZ) guide plane";
+    return nullptr;
+}
+NRD_D float4 LoadDecodedNormalRoughness(const NormalRoughnessGuide& g, int x, int y, float& materialID, float& viewZ) {
+    const uint32_t offset = TexelOffset(g.nz, x, y, 16u, true);
+    const float4 t = *(const float4*)(g.nz.ptr + offset);
+    const uint32_t w = *(const uint32_t*)(g.word.ptr + (offset >> 2));
+    materialID = DecodedMaterialID(w);
+    viewZ = t.w;
+    return F4(t.x, t.y, t.z, DecodedRoughness(w));
+}
+NRD_D float4 LoadDecodedNormalRoughness(const NormalRoughnessGuide& g, int x, int y, float& materialID) {
+    float unused;
+    return LoadDecodedNormalRoughness(g, x, y, materialID, unused);
+}
+NRD_D float4 LoadDecodedNormalRoughness(const NormalRoughnessGuide& g, int x, int y) {
+    float unused, unused2;
+    return LoadDecodedNormalRoughness(g, x, y, unused, unused2);
+}
 NRD_D float4 LoadDecodedNormalRoughness(const Plane& decoded, int x, int y) {
     float unused;
     return LoadDecodedNormalRoughness(decoded, x, y, unused);
