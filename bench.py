@@ -34,7 +34,8 @@ from raytracingdenoiser_amd import api, scene, sharding, synth
 from raytracingdenoiser_amd import build as native_build
 from raytracingdenoiser_amd.executor import HipExecutor
 
-GUIDE_BYTES_PER_PIXEL = 40  # the per-frame guide decode: IN_NORMAL_ROUGHNESS + IN_VIEWZ read (8 B), two float4 guide planes written
+# the per-frame guide decode: IN_NORMAL_ROUGHNESS + IN_VIEWZ read (8 B); written: REBLUR float4 (normal, viewZ) + the 4-byte roughness word, RELAX two float4 planes
+GUIDE_BYTES_PER_PIXEL = {"REBLUR": 28, "RELAX": 40}
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E peak (MI355X_MICROARCH.md); ~6300 GB/s is what a float4 copy achieves (measured live below)
 
 # Published reference numbers for the exact metric (reference README.md:18, RTX 4080, 1440p native)
@@ -453,7 +454,7 @@ def main():
     for shader, (ms, n) in timings.items():
         bpp = bytes_per_pixel.get(shader)
         if shader == HipExecutor.GUIDE_PREPARATION or (guides_in_classify and shader in ("REBLUR_ClassifyTiles.cs", "RELAX_ClassifyTiles.cs")):
-            bpp = GUIDE_BYTES_PER_PIXEL  # 8 B read (packed normal, viewZ) + 2 x 16 B written: not part of the reference's compulsory traffic, a cost of this design
+            bpp = GUIDE_BYTES_PER_PIXEL.get(name.split("_")[0])  # not part of the reference's compulsory traffic: a cost of this design (None: SIGMA / REFERENCE decode nothing)
         if bpp is None or n == 0:
             continue
         avg_ms = ms / n
