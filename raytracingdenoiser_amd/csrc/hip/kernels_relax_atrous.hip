@@ -394,6 +394,249 @@ const char* LaunchAtrousSmem(const PassArgs& a) {
     return nullptr;
 }
 
+// ================================================================================================ the arithmetic of one a-trous pixel
+// Shared by every tap source of RelaxAtrousKernel (LDS tiles, LDS bands, global gathers) and by the marching kernel below: what is computed once per pixel
+// (AtrousBegin), per tap (AtrousTap: reference RELAX_Atrous.hlsli:130-215) and at the end (AtrousEnd: `:217-240`). One source text, so one arithmetic.
+template <bool DIFF, bool SPEC, bool SH>
+struct AtrousPixel {
+    float3 centerWorldPos, centerNormal, centerV;
+    float centerRoughness, centerMaterialID, depthThreshold;
+    SpecParams sp;
+    DiffParams dp;
+    float4 sumSpecular, sumSpecularSH, sumDiffuse, sumDiffuseSH;
+    float sumWSpecular, sumWDiffuse, roughnessModified;
+};
+
+// the small per-pixel inputs, as UNORM8 bytes (the marching kernel requests them one step ahead) and decoded (= LoadR8Unorm of the byte)
+struct AtrousPixelBytes {
+    uint32_t historyLength, specReprojectionConfidence, specConfidence, diffConfidence;
+};
+struct AtrousPixelInputs {
+    float historyLength, specReprojectionConfidence, specConfidence, diffConfidence; // in [0, 1]; the confidences only with gHasHistoryConfidence
+};
+template <bool DIFF, bool SPEC>
+NRD_D AtrousPixelBytes LoadAtrousPixelBytes(const AtrousPlanes& P, const RelaxCB& c, int px, int py) {
+    AtrousPixelBytes b = {};
+    b.historyLength = LoadR8U(P.historyLength, px, py);
+    if (SPEC)
+        b.specReprojectionConfidence = LoadR8U(P.specReprojectionConfidence, px, py);
+    if (c.shared.gHasHistoryConfidence) {
+        if (SPEC)
+            b.specConfidence = LoadR8U(P.spec.confidence, px, py);
+        if (DIFF)
+            b.diffConfidence = LoadR8U(P.diff.confidence, px, py);
+    }
+    return b;
+}
+NRD_D AtrousPixelInputs DecodeAtrousPixelBytes(const AtrousPixelBytes& b) {
+    AtrousPixelInputs in;
+    in.historyLength = NRD_DIV_255(float(b.historyLength));
+    in.specReprojectionConfidence = NRD_DIV_255(float(b.specReprojectionConfidence));
+    in.specConfidence = NRD_DIV_255(float(b.specConfidence));
+    in.diffConfidence = NRD_DIV_255(float(b.diffConfidence));
+    return in;
+}
+
+// centerSpecularSH / centerDiffuseSH: the decoded SH1 texels (read only with SH)
+template <bool DIFF, bool SPEC, bool SH>
+NRD_D void AtrousBegin(AtrousPixel<DIFF, SPEC, SH>& a, const AtrousPlanes& P, const RelaxCB& c, int px, int py, float4 centerWorldPosViewZ, float4 centerNormalRoughness,
+    float centerMaterialID, float4 centerSpecular, float4 centerSpecularSH, float4 centerDiffuse, float4 centerDiffuseSH, const AtrousPixelInputs& in) {
+    const float centerViewZ = centerWorldPosViewZ.w;
+    a.centerMaterialID = centerMaterialID;
+    a.centerNormal = Xyz(centerNormalRoughness);
+    a.centerRoughness = centerNormalRoughness.w;
+    const float centerRoughness = a.centerRoughness;
+    const float historyLength = 255.0f * in.historyLength;
+
+    float diffuseLobeAngleFraction = Div(c.shared.gLobeAngleFraction, Sqrt(float(c.gStepSize)));
+    if (SH)
+        diffuseLobeAngleFraction = Rcp(Sqrt(float(c.gStepSize)));
+    diffuseLobeAngleFraction = Lerp(0.99f, diffuseLobeAngleFraction, Sat(historyLength * (1.0f / 5.0f)));
+
+    SpecParams sp = {};
+    sp.luminanceWeightRelaxation = 1.0f;
+    float4 sumSpecular = F4(0.0f), sumSpecularSH = F4(0.0f);
+    float sumWSpecular = 0.44198f * 0.44198f, roughnessModified = 0.0f;
+    if (SPEC) {
+        sp.centerLuminance = Luminance(Xyz(centerSpecular));
+        const float centerSpecularVar = centerSpecular.w;
+        sp.phiLIlluminationInv = Rcp(Max(1.0e-4f, c.shared.gSpecPhiLuminance * Sqrt(centerSpecularVar)));
+
+        sp.roughnessWeightParams = GetRoughnessWeightParams(centerRoughness, c.shared.gRoughnessFraction);
+        float diffuseLobeAngleFractionForSimplifiedSpecularNormalWeight = diffuseLobeAngleFraction;
+        float specularLobeAngleFraction = c.shared.gLobeAngleFraction;
+        const float specularReprojectionConfidence = in.specReprojectionConfidence;
+        if (c.gStepSize <= 4)
+            sp.luminanceWeightRelaxation = Lerp(1.0f, specularReprojectionConfidence, c.shared.gLuminanceEdgeStoppingRelaxation);
+        if (c.shared.gHasHistoryConfidence) {
+            float specConfidenceDrivenRelaxation = Sat(c.shared.gConfidenceDrivenRelaxationMultiplier * (1.0f - in.specConfidence));
+            float r = Sat(specConfidenceDrivenRelaxation * c.shared.gConfidenceDrivenNormalEdgeStoppingRelaxation);
+            diffuseLobeAngleFractionForSimplifiedSpecularNormalWeight = Lerp(diffuseLobeAngleFraction, 1.0f, r);
+            specularLobeAngleFraction = Lerp(specularLobeAngleFraction, 1.0f, r);
+            r = Sat(specConfidenceDrivenRelaxation * c.shared.gConfidenceDrivenLuminanceEdgeStoppingRelaxation);
+            sp.luminanceWeightRelaxation *= 1.0f - r;
+        }
+        sp.normalWeightParamSimplified = GetNormalWeightParam2(1.0f, diffuseLobeAngleFractionForSimplifiedSpecularNormalWeight);
+        sp.normalWeightParams = GetNormalWeightParams_ATrous(centerRoughness, historyLength, specularReprojectionConfidence, c.shared.gNormalEdgeStoppingRelaxation, specularLobeAngleFraction,
+            c.shared.gSpecLobeAngleSlack);
+
+        sumSpecular = centerSpecular * F4(sumWSpecular, sumWSpecular, sumWSpecular, sumWSpecular * sumWSpecular);
+        if (SH) {
+            sumSpecularSH = centerSpecularSH * sumWSpecular;
+            roughnessModified = centerSpecularSH.w;
+        }
+    }
+
+    DiffParams dp = {};
+    dp.luminanceWeightRelaxation = 1.0f;
+    float4 sumDiffuse = F4(0.0f), sumDiffuseSH = F4(0.0f);
+    float sumWDiffuse = 0.44198f * 0.44198f;
+    if (DIFF) {
+        dp.centerLuminance = Luminance(Xyz(centerDiffuse));
+        const float centerDiffuseVar = centerDiffuse.w;
+        dp.phiLIlluminationInv = Rcp(Max(1.0e-4f, c.shared.gDiffPhiLuminance * Sqrt(centerDiffuseVar)));
+        if (c.shared.gHasHistoryConfidence) {
+            float diffConfidenceDrivenRelaxation = Sat(c.shared.gConfidenceDrivenRelaxationMultiplier * (1.0f - in.diffConfidence));
+            float r = Sat(diffConfidenceDrivenRelaxation * c.shared.gConfidenceDrivenNormalEdgeStoppingRelaxation);
+            diffuseLobeAngleFraction = Lerp(diffuseLobeAngleFraction, 1.0f, r);
+            r = Sat(diffConfidenceDrivenRelaxation * c.shared.gConfidenceDrivenLuminanceEdgeStoppingRelaxation);
+            dp.luminanceWeightRelaxation = 1.0f - r;
+        }
+        dp.normalWeightParam = GetNormalWeightParam2(1.0f, diffuseLobeAngleFraction);
+        sumDiffuse = centerDiffuse * F4(sumWDiffuse, sumWDiffuse, sumWDiffuse, sumWDiffuse * sumWDiffuse);
+        if (SH)
+            sumDiffuseSH = centerDiffuseSH * sumWDiffuse;
+    }
+
+    a.centerWorldPos = Xyz(centerWorldPosViewZ);
+    a.centerV = -Normalize(a.centerWorldPos);
+    a.depthThreshold = c.shared.gDepthThreshold * centerViewZ;
+    a.sp = sp, a.dp = dp;
+    a.sumSpecular = sumSpecular, a.sumSpecularSH = sumSpecularSH, a.sumDiffuse = sumDiffuse, a.sumDiffuseSH = sumDiffuseSH;
+    a.sumWSpecular = sumWSpecular, a.sumWDiffuse = sumWDiffuse, a.roughnessModified = roughnessModified;
+}
+
+// One tap. Branch-free: a tap outside the rect reads the clamped texel (a valid address) and gets weight 0 through isInside, exactly what the
+// reference's "Load outside = 0" amounts to (its geometry weight is multiplied by isInside); a tap whose guide weight is <= 1e-4 keeps weight 0
+// instead of being skipped by a divergent branch, so all loads of a pixel can be in flight together instead of one dependent wait per tap and signal.
+// (0 * sample adds nothing: the history planes hold finite fp16 values by construction.)
+// g0 = the tap's decoded (normal, roughness | material word) texel, rawSpecSh / rawDiffSh = its undecoded SH1 texels.
+template <bool DIFF, bool SPEC, bool SH, bool RES, bool MAT>
+NRD_D void AtrousTap(AtrousPixel<DIFF, SPEC, SH>& a, const RelaxCB& c, float kernelW, bool isInside, float4 g0, float4 sampleWorldPosViewZ, float4 sampleSpecular, float4 sampleDiffuse,
+    uint2 rawSpecSh, uint2 rawDiffSh) {
+    constexpr bool compareSpecMaterials = MAT, compareDiffMaterials = MAT; // compile-time variant (RelaxAtrousSmemKernel): IDs are 0..3, a minimum >= 3 disables the test
+    const float3 centerWorldPos = a.centerWorldPos, centerNormal = a.centerNormal, centerV = a.centerV;
+    const float centerMaterialID = a.centerMaterialID;
+    float sampleMaterialID;
+    const float4 sampleNormalRoughness = DecodedToNormalRoughness(g0, sampleMaterialID);
+    const float3 sampleNormal = Xyz(sampleNormalRoughness);
+    const float sampleRoughness = sampleNormalRoughness.w;
+    const float sampleViewZ = sampleWorldPosViewZ.w;
+    const float3 sampleWorldPos = Xyz(sampleWorldPosViewZ);
+
+    float geometryW = GetPlaneDistanceWeight_Atrous(centerWorldPos, centerNormal, sampleWorldPos, a.depthThreshold);
+    geometryW *= kernelW;
+    geometryW *= Cmp(isInside && sampleViewZ < c.shared.gDenoisingRange);
+
+    if (SPEC) {
+        const SpecParams& sp = a.sp;
+        float wSpecular;
+        if (RES) { // gRoughnessEdgeStoppingEnabled != 0 (launcher)
+            float3 sampleV = -Normalize(sampleWorldPos + c.shared.gRoughnessEdgeStoppingRelaxation * centerWorldPos);
+            float normalWSpecular = GetSpecularNormalWeight_ATrous(sp.normalWeightParams, centerNormal, sampleNormal, centerV, sampleV);
+            float roughnessWSpecular = ComputeWeight(sampleRoughness, sp.roughnessWeightParams.x, sp.roughnessWeightParams.y);
+            wSpecular = geometryW * (normalWSpecular * roughnessWSpecular);
+        } else {
+            float angles = AcosApprox(Dot(centerNormal, sampleNormal));
+            float normalWSpecularSimplified = ComputeWeight(angles, sp.normalWeightParamSimplified, 0.0f);
+            wSpecular = geometryW * normalWSpecularSimplified;
+        }
+        if (compareSpecMaterials)
+            wSpecular *= Cmp(CompareMaterials(sampleMaterialID, centerMaterialID, c.shared.gSpecMinMaterial));
+        const bool on = wSpecular > 1e-4f;
+        float sampleSpecularLuminance = Luminance(Xyz(sampleSpecular));
+        float specularLuminanceW = Abs(sp.centerLuminance - sampleSpecularLuminance) * sp.phiLIlluminationInv;
+        specularLuminanceW = Min(c.shared.gSpecMaxLuminanceRelativeDifference, specularLuminanceW);
+        specularLuminanceW *= sp.luminanceWeightRelaxation;
+        wSpecular *= ExpNegAbs(specularLuminanceW);
+        wSpecular = on ? wSpecular : 0.0f;
+
+        a.sumWSpecular += wSpecular;
+        a.sumSpecular = Mad(sampleSpecular, F4(wSpecular, wSpecular, wSpecular, wSpecular * wSpecular), a.sumSpecular);
+        if (SH)
+            a.sumSpecularSH = Mad(DecodeRGBA16F(rawSpecSh.x, rawSpecSh.y), wSpecular, a.sumSpecularSH);
+    }
+    if (DIFF) {
+        const DiffParams& dp = a.dp;
+        float angled = AcosApprox(Dot(centerNormal, sampleNormal));
+        float normalWDiffuse = ComputeWeight(angled, dp.normalWeightParam, 0.0f);
+        float wDiffuse = geometryW * normalWDiffuse;
+        if (compareDiffMaterials)
+            wDiffuse *= Cmp(CompareMaterials(sampleMaterialID, centerMaterialID, c.shared.gDiffMinMaterial));
+        const bool on = wDiffuse > 1e-4f;
+        float sampleDiffuseLuminance = Luminance(Xyz(sampleDiffuse));
+        float diffuseLuminanceW = Abs(dp.centerLuminance - sampleDiffuseLuminance) * dp.phiLIlluminationInv;
+        diffuseLuminanceW = Min(c.shared.gDiffMaxLuminanceRelativeDifference, diffuseLuminanceW);
+        diffuseLuminanceW *= dp.luminanceWeightRelaxation;
+        wDiffuse *= ExpNegAbs(diffuseLuminanceW);
+        wDiffuse = on ? wDiffuse : 0.0f;
+
+        a.sumWDiffuse += wDiffuse;
+        a.sumDiffuse = Mad(sampleDiffuse, F4(wDiffuse, wDiffuse, wDiffuse, wDiffuse * wDiffuse), a.sumDiffuse);
+        if (SH)
+            a.sumDiffuseSH = Mad(DecodeRGBA16F(rawDiffSh.x, rawDiffSh.y), wDiffuse, a.sumDiffuseSH);
+    }
+}
+
+// the pixel's output texels, packed as StoreRGBA16F packs them (the marching kernel keeps them in registers until the next step: its stores then do not sit in front of a wait)
+template <bool DIFF, bool SPEC, bool SH>
+struct AtrousResult {
+    uint2 spec, specSh, diff, diffSh;
+};
+NRD_D uint2 PackRGBA16F(float4 v) { return make_uint2(FloatsToHalf2Bits(v.x, v.y), FloatsToHalf2Bits(v.z, v.w)); } // = planes.h StoreRGBA16F
+template <bool DIFF, bool SPEC, bool SH>
+NRD_D AtrousResult<DIFF, SPEC, SH> AtrousFinish(const AtrousPixel<DIFF, SPEC, SH>& a, const RelaxCB& c) {
+    AtrousResult<DIFF, SPEC, SH> r = {};
+    if (SPEC) {
+        const float sumWSpecular = a.sumWSpecular;
+        float4 filtered = Div(a.sumSpecular, F4(sumWSpecular, sumWSpecular, sumWSpecular, sumWSpecular * sumWSpecular));
+        if (SH) {
+            if (c.gIsLastPass == 1)
+                filtered = F4(LinearToYCoCg(Xyz(filtered)), filtered.w);
+            r.specSh = PackRGBA16F(F4(Div(Xyz(a.sumSpecularSH), sumWSpecular), a.roughnessModified));
+        }
+        r.spec = PackRGBA16F(filtered);
+    }
+    if (DIFF) {
+        const float sumWDiffuse = a.sumWDiffuse;
+        float4 filtered = Div(a.sumDiffuse, F4(sumWDiffuse, sumWDiffuse, sumWDiffuse, sumWDiffuse * sumWDiffuse));
+        if (SH) {
+            if (c.gIsLastPass == 1)
+                filtered = F4(LinearToYCoCg(Xyz(filtered)), filtered.w);
+            r.diffSh = PackRGBA16F(Div(a.sumDiffuseSH, sumWDiffuse));
+        }
+        r.diff = PackRGBA16F(filtered);
+    }
+    return r;
+}
+template <bool DIFF, bool SPEC, bool SH>
+NRD_D void AtrousStore(const AtrousResult<DIFF, SPEC, SH>& r, const AtrousPlanes& P, int px, int py) {
+    if (SPEC) {
+        if (SH)
+            *TexelPtr<uint2>(P.spec.outSh, px, py) = r.specSh;
+        *TexelPtr<uint2>(P.spec.out, px, py) = r.spec;
+    }
+    if (DIFF) {
+        if (SH)
+            *TexelPtr<uint2>(P.diff.outSh, px, py) = r.diffSh;
+        *TexelPtr<uint2>(P.diff.out, px, py) = r.diff;
+    }
+}
+template <bool DIFF, bool SPEC, bool SH>
+NRD_D void AtrousEnd(const AtrousPixel<DIFF, SPEC, SH>& a, const AtrousPlanes& P, const RelaxCB& c, int px, int py) {
+    AtrousStore(AtrousFinish(a, c), P, px, py);
+}
+
 // ================================================================================================ Atrous
 // One iteration of the dilated 3x3 (reference RELAX_Atrous.hlsli:10-240): 8 taps at +-step texels, edge-stopping weights from the guides (plane distance,
 // normal, roughness, material) and from the luminance difference, variance filtered with the squared weights.
@@ -448,14 +691,24 @@ __global__ __launch_bounds__(256, NRD_WAVES_RELAX_ATROUS) void RelaxAtrousKernel
     constexpr int R = STEP / 4, BW = TILE_X + 2 * STEP + 2 * R, BH = TILE_Y + 2 * R, BS = BW + 1, BN = BANDED ? BH * BS : 1;
     // BAND_RAW (step 16, round 5): the band holds the UNDECODED guides -- the packed normal (4 B) and viewZ (4 B) the gathering taps read, decoded per tap with the very functions
     // that wrote the guide planes -- so a 72 x 16-texel band is 46 KB instead of 74 (three workgroups per CU instead of two; the decoded bands lost to the gathers at step 16: r04_d)
-    constexpr bool BAND_RAW = STEP == 16;
+#ifndef NRD_ATROUS_BAND_RAW_MIN_STEP
+#define NRD_ATROUS_BAND_RAW_MIN_STEP 16
+#endif
+    constexpr bool BAND_RAW = STEP >= NRD_ATROUS_BAND_RAW_MIN_STEP;
     __shared__ float4 b_NR[BAND_RAW ? 1 : BN], b_Pos[BAND_RAW ? 1 : BN];
     __shared__ uint32_t br_NR[BAND_RAW ? BN : 1];
     __shared__ float br_Z[BAND_RAW ? BN : 1];
     __shared__ uint2 b_Spec[SPEC && BANDED ? BN : 1], b_Diff[DIFF && BANDED ? BN : 1], b_SpecSh[SPEC && SH && BANDED ? BN : 1], b_DiffSh[DIFF && SH && BANDED ? BN : 1];
 
     const int blockY = BlockTileY(rows, true);
-    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    // lanes -> pixels of the 32x8 workgroup. The LDS variants: a wave = 2 rows of 32 pixels. The gathering variant (A/B, NRD_ATROUS_GATHER_WAVE_16x4): a wave = 16 x 4 pixels -- its
+    // hashed taps then fall into ~22 cache lines of an 8-byte plane (11 rows x 23 texels) instead of ~31 (9 rows x 39 texels): fewer L1 requests per wave-load
+#ifndef NRD_ATROUS_GATHER_WAVE_16x4
+#define NRD_ATROUS_GATHER_WAVE_16x4 1
+#endif
+    constexpr bool WAVE_16x4 = NRD_ATROUS_GATHER_WAVE_16x4 && STEP == 0;
+    const int tx = WAVE_16x4 ? (int)((threadIdx.x & 15u) | ((threadIdx.x >> 2) & 16u)) : (int)(threadIdx.x & 31u);
+    const int ty = WAVE_16x4 ? (int)(((threadIdx.x >> 4) & 3u) | ((threadIdx.x >> 5) & 4u)) : (int)(threadIdx.x >> 5);
     const int blockX0 = BlockTileX(rows) * TILE_X, blockY0 = blockY * TILE_Y;
     const int px = blockX0 + tx, py = blockY0 + ty;
     const int rectW = c.shared.gRectSize.x, rectH = c.shared.gRectSize.y;
@@ -518,85 +771,31 @@ __global__ __launch_bounds__(256, NRD_WAVES_RELAX_ATROUS) void RelaxAtrousKernel
 
     float centerMaterialID;
     const float4 centerNormalRoughness = TILED ? DecodedToNormalRoughness(s_NR[lc], centerMaterialID) : LoadDecodedNormalRoughness(P.decodedNR, px, py, centerMaterialID);
-    const float3 centerNormal = Xyz(centerNormalRoughness);
-    const float centerRoughness = centerNormalRoughness.w;
-    const float historyLength = 255.0f * LoadR8Unorm(P.historyLength, px, py);
     const int stepSize = TILED || BANDED ? STEP : (int)c.gStepSize;
-
-    float diffuseLobeAngleFraction = Div(c.shared.gLobeAngleFraction, Sqrt(float(c.gStepSize)));
-    if (SH)
-        diffuseLobeAngleFraction = Rcp(Sqrt(float(c.gStepSize)));
-    diffuseLobeAngleFraction = Lerp(0.99f, diffuseLobeAngleFraction, Sat(historyLength * (1.0f / 5.0f)));
-
-    SpecParams sp = {};
-    sp.luminanceWeightRelaxation = 1.0f;
-    float4 sumSpecular = F4(0.0f), sumSpecularSH = F4(0.0f);
-    float sumWSpecular = 0.44198f * 0.44198f, roughnessModified = 0.0f;
-    if (SPEC) {
-        const float4 centerSpecular = TILED ? s_Spec[lc] : LoadRGBA16F(P.spec.in, px, py);
-        sp.centerLuminance = Luminance(Xyz(centerSpecular));
-        const float centerSpecularVar = centerSpecular.w;
-        sp.phiLIlluminationInv = Rcp(Max(1.0e-4f, c.shared.gSpecPhiLuminance * Sqrt(centerSpecularVar)));
-
-        sp.roughnessWeightParams = GetRoughnessWeightParams(centerRoughness, c.shared.gRoughnessFraction);
-        float diffuseLobeAngleFractionForSimplifiedSpecularNormalWeight = diffuseLobeAngleFraction;
-        float specularLobeAngleFraction = c.shared.gLobeAngleFraction;
-        const float specularReprojectionConfidence = LoadR8Unorm(P.specReprojectionConfidence, px, py);
-        if (c.gStepSize <= 4)
-            sp.luminanceWeightRelaxation = Lerp(1.0f, specularReprojectionConfidence, c.shared.gLuminanceEdgeStoppingRelaxation);
-        if (c.shared.gHasHistoryConfidence) {
-            float specConfidenceDrivenRelaxation = Sat(c.shared.gConfidenceDrivenRelaxationMultiplier * (1.0f - LoadR8Unorm(P.spec.confidence, px, py)));
-            float r = Sat(specConfidenceDrivenRelaxation * c.shared.gConfidenceDrivenNormalEdgeStoppingRelaxation);
-            diffuseLobeAngleFractionForSimplifiedSpecularNormalWeight = Lerp(diffuseLobeAngleFraction, 1.0f, r);
-            specularLobeAngleFraction = Lerp(specularLobeAngleFraction, 1.0f, r);
-            r = Sat(specConfidenceDrivenRelaxation * c.shared.gConfidenceDrivenLuminanceEdgeStoppingRelaxation);
-            sp.luminanceWeightRelaxation *= 1.0f - r;
+    AtrousPixel<DIFF, SPEC, SH> a;
+    {
+        float4 centerSpecular = F4(0.0f), centerSpecularSH = F4(0.0f), centerDiffuse = F4(0.0f), centerDiffuseSH = F4(0.0f);
+        if (SPEC) {
+            centerSpecular = TILED ? s_Spec[lc] : LoadRGBA16F(P.spec.in, px, py);
+            if (SH) {
+                if (TILED)
+                    centerSpecularSH = DecodeRGBA16F(s_SpecSh[lc].x, s_SpecSh[lc].y);
+                else
+                    centerSpecularSH = LoadRGBA16F(P.spec.inSh, px, py);
+            }
         }
-        sp.normalWeightParamSimplified = GetNormalWeightParam2(1.0f, diffuseLobeAngleFractionForSimplifiedSpecularNormalWeight);
-        sp.normalWeightParams = GetNormalWeightParams_ATrous(centerRoughness, historyLength, specularReprojectionConfidence, c.shared.gNormalEdgeStoppingRelaxation, specularLobeAngleFraction,
-            c.shared.gSpecLobeAngleSlack);
-
-        sumSpecular = centerSpecular * F4(sumWSpecular, sumWSpecular, sumWSpecular, sumWSpecular * sumWSpecular);
-        if (SH) {
-            float4 centerSpecularSH;
-            if (TILED)
-                centerSpecularSH = DecodeRGBA16F(s_SpecSh[lc].x, s_SpecSh[lc].y);
-            else
-                centerSpecularSH = LoadRGBA16F(P.spec.inSh, px, py);
-            sumSpecularSH = centerSpecularSH * sumWSpecular;
-            roughnessModified = centerSpecularSH.w;
+        if (DIFF) {
+            centerDiffuse = TILED ? s_Diff[lc] : LoadRGBA16F(P.diff.in, px, py);
+            if (SH) {
+                if (TILED)
+                    centerDiffuseSH = DecodeRGBA16F(s_DiffSh[lc].x, s_DiffSh[lc].y);
+                else
+                    centerDiffuseSH = LoadRGBA16F(P.diff.inSh, px, py);
+            }
         }
+        AtrousBegin(a, P, c, px, py, centerWorldPosViewZ, centerNormalRoughness, centerMaterialID, centerSpecular, centerSpecularSH, centerDiffuse, centerDiffuseSH,
+            DecodeAtrousPixelBytes(LoadAtrousPixelBytes<DIFF, SPEC>(P, c, px, py)));
     }
-
-    DiffParams dp = {};
-    dp.luminanceWeightRelaxation = 1.0f;
-    float4 sumDiffuse = F4(0.0f), sumDiffuseSH = F4(0.0f);
-    float sumWDiffuse = 0.44198f * 0.44198f;
-    if (DIFF) {
-        const float4 centerDiffuse = TILED ? s_Diff[lc] : LoadRGBA16F(P.diff.in, px, py);
-        dp.centerLuminance = Luminance(Xyz(centerDiffuse));
-        const float centerDiffuseVar = centerDiffuse.w;
-        dp.phiLIlluminationInv = Rcp(Max(1.0e-4f, c.shared.gDiffPhiLuminance * Sqrt(centerDiffuseVar)));
-        if (c.shared.gHasHistoryConfidence) {
-            float diffConfidenceDrivenRelaxation = Sat(c.shared.gConfidenceDrivenRelaxationMultiplier * (1.0f - LoadR8Unorm(P.diff.confidence, px, py)));
-            float r = Sat(diffConfidenceDrivenRelaxation * c.shared.gConfidenceDrivenNormalEdgeStoppingRelaxation);
-            diffuseLobeAngleFraction = Lerp(diffuseLobeAngleFraction, 1.0f, r);
-            r = Sat(diffConfidenceDrivenRelaxation * c.shared.gConfidenceDrivenLuminanceEdgeStoppingRelaxation);
-            dp.luminanceWeightRelaxation = 1.0f - r;
-        }
-        dp.normalWeightParam = GetNormalWeightParam2(1.0f, diffuseLobeAngleFraction);
-        sumDiffuse = centerDiffuse * F4(sumWDiffuse, sumWDiffuse, sumWDiffuse, sumWDiffuse * sumWDiffuse);
-        if (SH) {
-            if (TILED)
-                sumDiffuseSH = DecodeRGBA16F(s_DiffSh[lc].x, s_DiffSh[lc].y) * sumWDiffuse;
-            else
-                sumDiffuseSH = LoadRGBA16F(P.diff.inSh, px, py) * sumWDiffuse;
-        }
-    }
-
-    const float3 centerWorldPos = Xyz(centerWorldPosViewZ);
-    const float3 centerV = -Normalize(centerWorldPos);
-    const float depthThreshold = c.shared.gDepthThreshold * centerViewZ;
 
     // random offsets against ringing at large steps
     int offx = 0, offy = 0;
@@ -608,12 +807,7 @@ __global__ __launch_bounds__(256, NRD_WAVES_RELAX_ATROUS) void RelaxAtrousKernel
         offy = (int)(float(c.gStepSize) * 0.5f * (rnd.y - 0.5f));
     }
 
-    // The 8 taps, branch-free: a tap outside the rect reads the clamped texel (a valid address) and gets weight 0 through isInside, exactly what the
-    // reference's "Load outside = 0" amounts to (its geometry weight is multiplied by isInside); a tap whose guide weight is <= 1e-4 keeps weight 0
-    // instead of being skipped by a divergent branch, so all loads of a pixel can be in flight together instead of one dependent wait per tap and signal.
-    // (0 * sample adds nothing: the history planes hold finite fp16 values by construction.) Planes of one format share their layout (launcher check),
-    // so one texel offset serves the two guide planes and one the four signal planes.
-    constexpr bool compareSpecMaterials = MAT, compareDiffMaterials = MAT; // compile-time variant (RelaxAtrousSmemKernel): IDs are 0..3, a minimum >= 3 disables the test
+    // The 8 taps (AtrousTap). Planes of one format share their layout (launcher check), so one texel offset serves the two guide planes and one the four signal planes.
 #pragma unroll
     for (int yy = -1; yy <= 1; yy++) {
         const int bandX0 = blockX0 - STEP - R, bandY0 = blockY0 + yy * STEP - R; // texel (unclamped) of the band's LDS element (0, 0)
@@ -729,88 +923,337 @@ __global__ __launch_bounds__(256, NRD_WAVES_RELAX_ATROUS) void RelaxAtrousKernel
                 }
             }
 
-            float sampleMaterialID;
-            const float4 sampleNormalRoughness = DecodedToNormalRoughness(g0, sampleMaterialID);
-            const float3 sampleNormal = Xyz(sampleNormalRoughness);
-            const float sampleRoughness = sampleNormalRoughness.w;
-            const float sampleViewZ = sampleWorldPosViewZ.w;
-            const float3 sampleWorldPos = Xyz(sampleWorldPosViewZ);
-
-            float geometryW = GetPlaneDistanceWeight_Atrous(centerWorldPos, centerNormal, sampleWorldPos, depthThreshold);
-            geometryW *= kernelW;
-            geometryW *= Cmp(isInside && sampleViewZ < c.shared.gDenoisingRange);
-
-            if (SPEC) {
-                float wSpecular;
-                if (RES) { // gRoughnessEdgeStoppingEnabled != 0 (launcher)
-                    float3 sampleV = -Normalize(sampleWorldPos + c.shared.gRoughnessEdgeStoppingRelaxation * centerWorldPos);
-                    float normalWSpecular = GetSpecularNormalWeight_ATrous(sp.normalWeightParams, centerNormal, sampleNormal, centerV, sampleV);
-                    float roughnessWSpecular = ComputeWeight(sampleRoughness, sp.roughnessWeightParams.x, sp.roughnessWeightParams.y);
-                    wSpecular = geometryW * (normalWSpecular * roughnessWSpecular);
-                } else {
-                    float angles = AcosApprox(Dot(centerNormal, sampleNormal));
-                    float normalWSpecularSimplified = ComputeWeight(angles, sp.normalWeightParamSimplified, 0.0f);
-                    wSpecular = geometryW * normalWSpecularSimplified;
-                }
-                if (compareSpecMaterials)
-                    wSpecular *= Cmp(CompareMaterials(sampleMaterialID, centerMaterialID, c.shared.gSpecMinMaterial));
-                const bool on = wSpecular > 1e-4f;
-                float sampleSpecularLuminance = Luminance(Xyz(sampleSpecular));
-                float specularLuminanceW = Abs(sp.centerLuminance - sampleSpecularLuminance) * sp.phiLIlluminationInv;
-                specularLuminanceW = Min(c.shared.gSpecMaxLuminanceRelativeDifference, specularLuminanceW);
-                specularLuminanceW *= sp.luminanceWeightRelaxation;
-                wSpecular *= ExpNegAbs(specularLuminanceW);
-                wSpecular = on ? wSpecular : 0.0f;
-
-                sumWSpecular += wSpecular;
-                sumSpecular = Mad(sampleSpecular, F4(wSpecular, wSpecular, wSpecular, wSpecular * wSpecular), sumSpecular);
-                if (SH)
-                    sumSpecularSH = Mad(DecodeRGBA16F(rawSpecSh.x, rawSpecSh.y), wSpecular, sumSpecularSH);
-            }
-            if (DIFF) {
-                float angled = AcosApprox(Dot(centerNormal, sampleNormal));
-                float normalWDiffuse = ComputeWeight(angled, dp.normalWeightParam, 0.0f);
-                float wDiffuse = geometryW * normalWDiffuse;
-                if (compareDiffMaterials)
-                    wDiffuse *= Cmp(CompareMaterials(sampleMaterialID, centerMaterialID, c.shared.gDiffMinMaterial));
-                const bool on = wDiffuse > 1e-4f;
-                float sampleDiffuseLuminance = Luminance(Xyz(sampleDiffuse));
-                float diffuseLuminanceW = Abs(dp.centerLuminance - sampleDiffuseLuminance) * dp.phiLIlluminationInv;
-                diffuseLuminanceW = Min(c.shared.gDiffMaxLuminanceRelativeDifference, diffuseLuminanceW);
-                diffuseLuminanceW *= dp.luminanceWeightRelaxation;
-                wDiffuse *= ExpNegAbs(diffuseLuminanceW);
-                wDiffuse = on ? wDiffuse : 0.0f;
-
-                sumWDiffuse += wDiffuse;
-                sumDiffuse = Mad(sampleDiffuse, F4(wDiffuse, wDiffuse, wDiffuse, wDiffuse * wDiffuse), sumDiffuse);
-                if (SH)
-                    sumDiffuseSH = Mad(DecodeRGBA16F(rawDiffSh.x, rawDiffSh.y), wDiffuse, sumDiffuseSH);
-            }
+            AtrousTap<DIFF, SPEC, SH, RES, MAT>(a, c, kernelW, isInside, g0, sampleWorldPosViewZ, sampleSpecular, sampleDiffuse, rawSpecSh, rawDiffSh);
         }
     }
     if (BANDED && !active)
         return;
 
-    if (SPEC) {
-        float4 filtered = Div(sumSpecular, F4(sumWSpecular, sumWSpecular, sumWSpecular, sumWSpecular * sumWSpecular));
-        if (SH) {
-            if (c.gIsLastPass == 1)
-                filtered = F4(LinearToYCoCg(Xyz(filtered)), filtered.w);
-            StoreRGBA16F(P.spec.outSh, px, py, F4(Div(Xyz(sumSpecularSH), sumWSpecular), roughnessModified));
-        }
-        StoreRGBA16F(P.spec.out, px, py, filtered);
-    }
-    if (DIFF) {
-        float4 filtered = Div(sumDiffuse, F4(sumWDiffuse, sumWDiffuse, sumWDiffuse, sumWDiffuse * sumWDiffuse));
-        if (SH) {
-            if (c.gIsLastPass == 1)
-                filtered = F4(LinearToYCoCg(Xyz(filtered)), filtered.w);
-            StoreRGBA16F(P.diff.outSh, px, py, Div(sumDiffuseSH, sumWDiffuse));
-        }
-        StoreRGBA16F(P.diff.out, px, py, filtered);
-    }
+    AtrousEnd(a, P, c, px, py);
 #undef px
 #undef py
+}
+
+// ================================================================================================ Atrous, marching (round 6): steps 8 and 16
+// At steps 8 and 16 every pixel shifts its eight taps by a hashed offset (reference RELAX_Atrous.hlsli:122-128), so the lanes of a wave read scattered texels. Round 4 staged the three tap
+// rows of a 32x8 tile as LDS bands (step 8: 7.3 staged texels of 64 B per pixel -- the kernel is bound by what the FILL moves through the L1, 467 B per pixel), step 16 gathers from
+// global memory (6 scattered loads per tap: 2.05x its issue floor, r05). This kernel removes the redundancy instead of pricing it: a workgroup owns a column STRIPE of 32 pixels and
+// marches down it 16 rows at a time, keeping the rows its taps can reach in an LDS RING of undecoded texels (packed normal 4 B, viewZ 4 B, four signal planes 8 B each = 40 B):
+//   step 16: ring of 56 rows x 72 columns = 161 280 B (one workgroup of 512 threads per CU);  step 8: 36 rows x 56 columns = 80 640 B (two per CU)
+// Every row of the stripe is read from global memory ONCE per stripe (+ the 2.25x / 1.75x column halo) -- 2.6 / 2.0 staged texels per pixel instead of 7.3 (bands) or 8 scattered taps --
+// by LDS-DMA (global_load_lds_dwordx4: 64 lanes x 16 B land contiguously in LDS, no VGPR round trip, no ds_write), and the rows of the NEXT step are requested as soon as the
+// rows they replace are dead: after the yy = -1 taps of this step the top H rows of the ring are read by nothing any more (step 8: half of them, the other half after the yy = 0
+// taps), so the fill of step n + 1 runs under the yy = 0 / +1 taps of step n. The taps read the ring with ds_read_b32 / b64 at their hashed positions and decode per tap with the
+// functions that wrote the guide planes (the BAND_RAW / gathering variants above: same values bit for bit).
+// A stripe is cut into SEGMENTS of m.segSteps steps (a workgroup = one segment of one stripe; the ring is filled completely at its first step with geometry and after every run of sky steps).
+#ifndef NRD_LDS_DMA16 // (the CPU emulation of these sources under tests/emu substitutes a per-lane copy: shim/hip/hip_runtime.h)
+// gsrc: this lane's 16 source bytes; ldsWaveBase: wave-uniform LDS byte address; the lane's bytes land at ldsWaveBase + lane * 16. The compiler neither counts nor waits for it (inline asm):
+// NRD_LDS_DMA_WAIT() + __syncthreads() in front of the first read (cdna_hip_programming.md section 5.7: M0 written in the statement that reads it, s_nop 0 before the load).
+#define NRD_LDS_DMA16(gsrc, ldsWaveBase)                                                                                                                        \
+    do {                                                                                                                                                        \
+        unsigned keepM0_;                                                                                                                                       \
+        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0" : "=&s"(keepM0_) : "v"(gsrc), "s"(ldsWaveBase) : "memory"); \
+    } while (0)
+#define NRD_LDS_DMA_WAIT() asm volatile("s_waitcnt vmcnt(0)" ::: "memory")
+#define NRD_WAVE_UNIFORM(x) __builtin_amdgcn_readfirstlane(x)
+#define NRD_LDS_ADDRESS(p) ((uint32_t)(uintptr_t)(p)) // the low half of a flat address inside the shared aperture is the LDS byte address
+#define NRD_LDS_POINTER(T, address) ((__attribute__((address_space(3))) T*)(uintptr_t)(address))
+typedef uint32_t LdsAddress;
+#endif
+namespace march {
+constexpr int W = 32, H = 16, THREADS = W * H;
+constexpr int RoundUp(int v, int m) { return (v + m - 1) / m * m; }
+constexpr int MinI(int a, int b) { return a < b ? a : b; }
+template <int STEP>
+struct Geo {
+    static constexpr int R = STEP / 4;                               // the hashed offset lies in [-R, R - 1]: (int)(STEP / 2 * (rnd - 0.5)), rnd in [0, 1) (0 happens: 2^-24 per pixel)
+    static constexpr int LEFT = RoundUp(STEP + R, 4);                // ring column 0 = stripe column - LEFT: a multiple of 4 texels, so the 16-byte pieces of the 4-byte planes stay aligned
+    static constexpr int BW = RoundUp(LEFT + W + STEP + R - 1, 4);   // ring columns
+    static constexpr int TOP = STEP + R;                             // ring row 0 of a step = its first pixel row - TOP
+    static constexpr int SPAN = H + 2 * (STEP + R) - 1;              // rows the taps of a step can reach
+    static constexpr int CH = STEP >= 16 ? 8 : 4;                    // rows per chunk (the unit of a fill: contiguous in LDS, never split by the ring's wrap-around)
+    static constexpr int RR = RoundUp(SPAN, CH);                     // ring rows
+    static constexpr int FREE1 = MinI(STEP, H);                      // rows (from the step's row 0) dead after the yy = -1 taps: neither the other taps of this step nor yy = -1 of the next read them
+    static constexpr int FREE2 = MinI(2 * STEP, H) - FREE1;          // ... more after the yy = 0 taps
+    static_assert(FREE1 + FREE2 == H && FREE1 % CH == 0 && FREE2 % CH == 0 && H % CH == 0, "march::Geo: the prefetch points must free the H rows of the next step in whole chunks");
+    static_assert(LEFT >= STEP + R && BW % 4 == 0 && RR >= SPAN, "march::Geo");
+};
+struct Range { // kernel argument
+    int firstY;   // pixel row of step 0 (a multiple of H)
+    int numSteps, segSteps, numSegs;
+    int numStripes, stripesPerXcd;
+    int rowBegin, rowEnd; // rows this rank produces (multi-GPU row strips); the whole rect otherwise
+};
+} // namespace march
+
+// the ring, one array per plane (structure of arrays: what the DMA's lane-linear destination allows)
+template <bool DIFF, bool SPEC, bool SH, int N>
+struct MarchRing {
+    uint32_t nr[N];
+    float z[N];
+    uint2 spec[SPEC ? N : 1], specSh[SPEC && SH ? N : 1], diff[DIFF ? N : 1], diffSh[DIFF && SH ? N : 1];
+};
+
+// The fill. A chunk (CH ring rows of one plane, contiguous in LDS) is cut into pieces of 16 bytes (4 texels of the 4-byte planes, 2 of the 8-byte ones) and 64 pieces make a JOB = one
+// wave-wide global_load_lds_dwordx4; a chunk's JOBS jobs are dealt to the 8 waves round-robin -- job k of every chunk is always done by wave k % 8 as its slot k / 8 --, so what a lane
+// needs of a job beyond the chunk's first row is a constant of the kernel: the row of its piece inside the chunk and the first texel column of its piece. A job then costs a clamp, a
+// multiply-add and the 64-bit address. Pieces on or beyond the left / right plane border (first and last stripe only) are written texel by texel with the clamped addressing of the
+// taps instead (a DMA piece is 16 contiguous source bytes); rows beyond the plane read the clamped row.
+template <int STEP, bool DIFF, bool SPEC, bool SH>
+struct MarchFiller {
+    typedef march::Geo<STEP> G;
+    static constexpr int P4 = G::CH * G::BW / 4, P8 = G::CH * G::BW / 2, J4 = (P4 + 63) / 64, J8 = (P8 + 63) / 64;
+    static constexpr int NSIG = (SPEC ? (SH ? 2 : 1) : 0) + (DIFF ? (SH ? 2 : 1) : 0);
+    static constexpr int JOBS = 2 * J4 + NSIG * J8, SLOTS = (JOBS + march::THREADS / 64 - 1) / (march::THREADS / 64);
+    int rowInChunk[SLOTS]; // < 0: this lane has no piece in the job
+    int x[SLOTS];          // first texel column of the piece
+    int wave, lane;
+
+    NRD_D void Init(int x0) {
+        lane = (int)(threadIdx.x & 63u);
+        wave = NRD_WAVE_UNIFORM((int)(threadIdx.x >> 6));
+#pragma unroll
+        for (int i = 0; i < SLOTS; i++) {
+            const int k = wave + i * (march::THREADS / 64);
+            const bool wide = k >= 2 * J4; // a signal plane (8-byte texels)
+            const int part = wide ? (k - 2 * J4) % J8 : k % J4;
+            const int perRow = wide ? G::BW / 2 : G::BW / 4, pieces = wide ? P8 : P4;
+            const int piece = part * 64 + lane;
+            const int r = piece / perRow, cp = piece - r * perRow;
+            rowInChunk[i] = k < JOBS && piece < pieces ? r : -1;
+            x[i] = x0 + cp * (wide ? 2 : 4);
+        }
+    }
+    // rows [row0, row0 + numRows) -> their ring chunks (every thread of the workgroup calls it; numRows and row0 - segTop are multiples of CH)
+    template <typename Ring>
+    NRD_D void Fill(Ring& ring, const AtrousPlanes& P, int segTop, int row0, int numRows) const {
+        const int w = P.viewZ.w, h = P.viewZ.h;
+#pragma unroll
+        for (int i = 0; i < SLOTS; i++) {
+            const int k = wave + i * (march::THREADS / 64);
+            if (k >= JOBS)
+                continue;
+            // the job's plane (uniform): packed normal, viewZ, then the signal planes that exist in the order spec, specSh, diff, diffSh
+            const uint8_t* src;
+            uint32_t pitch, part;
+            LdsAddress dst;
+            const bool wide = k >= 2 * J4;
+            if (k < J4)
+                src = P.normalRoughness.ptr, pitch = P.normalRoughness.pitch, dst = NRD_LDS_ADDRESS(ring.nr), part = (uint32_t)k;
+            else if (k < 2 * J4)
+                src = P.viewZ.ptr, pitch = P.viewZ.pitch, dst = NRD_LDS_ADDRESS(ring.z), part = (uint32_t)(k - J4);
+            else {
+                const int ks = k - 2 * J4, sig = ks / J8;
+                const int which = SPEC ? (SH ? sig : (sig == 0 ? 0 : 2)) : (SH ? sig + 2 : 2);
+                pitch = (SPEC ? P.spec.in : P.diff.in).pitch, part = (uint32_t)(ks - sig * J8);
+                if (SPEC && which == 0)
+                    src = P.spec.in.ptr, dst = NRD_LDS_ADDRESS(ring.spec);
+                else if (SPEC && SH && which == 1)
+                    src = P.spec.inSh.ptr, dst = NRD_LDS_ADDRESS(ring.specSh);
+                else if (DIFF && which == 2)
+                    src = P.diff.in.ptr, dst = NRD_LDS_ADDRESS(ring.diff);
+                else
+                    src = P.diff.inSh.ptr, dst = NRD_LDS_ADDRESS(ring.diffSh);
+            }
+            const uint32_t bpt = wide ? 8u : 4u, texels = wide ? 2u : 4u;
+            const bool dma = x[i] >= 0 && x[i] + (int)texels <= w; // (all pieces of all but the first and last stripe)
+            for (int row = row0; row < row0 + numRows; row += G::CH) {
+                const LdsAddress chunkBase = dst + ((uint32_t)(row - segTop) % (uint32_t)G::RR) * ((uint32_t)G::BW * bpt); // LDS byte address of the chunk in this plane
+                if (rowInChunk[i] >= 0) {
+                    const int cy = ClampI(row + rowInChunk[i], 0, h - 1);
+                    Plane pl = {const_cast<uint8_t*>(src), pitch, w, h};
+                    if (dma)
+                        NRD_LDS_DMA16(src + TexelOffset(pl, x[i], cy, bpt, true), NRD_WAVE_UNIFORM(chunkBase + part * 1024u));
+                    else
+                        for (uint32_t t = 0; t < texels; t++) {
+                            const uint8_t* texel = src + TexelOffset(pl, ClampI(x[i] + (int)t, 0, w - 1), cy, bpt, true);
+                            const LdsAddress at = chunkBase + (part * 64u + (uint32_t)lane) * 16u + t * bpt;
+                            *NRD_LDS_POINTER(uint32_t, at) = *(const uint32_t*)texel;
+                            if (wide)
+                                *NRD_LDS_POINTER(uint32_t, at + 4u) = *(const uint32_t*)(texel + 4);
+                        }
+                }
+            }
+        }
+    }
+};
+
+template <bool DIFF, bool SPEC, bool SH, int STEP, bool RES, bool MAT>
+__global__ __launch_bounds__(march::THREADS, STEP == 8 ? 4 : 2) void RelaxAtrousMarchKernel(AtrousPlanes P, RelaxCB c, march::Range m) {
+    using G = march::Geo<STEP>;
+    constexpr int W = march::W, H = march::H;
+    static_assert(STEP == 8 || STEP == 16, "RelaxAtrousMarchKernel: STEP");
+    {
+        const Plane sig = SPEC ? P.spec.in : P.diff.in;
+        ShareLayout(P.spec.in, sig), ShareLayout(P.diff.in, sig), ShareLayout(P.spec.inSh, sig), ShareLayout(P.diff.inSh, sig);
+        ShareSize(P.viewZ, sig), ShareSize(P.normalRoughness, sig); // (the launcher checked that the two guide inputs have the frame size)
+    }
+    __shared__ MarchRing<DIFF, SPEC, SH, G::RR * G::BW> ring;
+
+    // workgroup -> (stripe, segment): blockIdx.x % 8 is the XCD (passes.h): an XCD owns stripesPerXcd adjacent stripes, whose column halos then meet in ONE L2;
+    // segments are dealt bottom-up (the sky, at the top as usual, drains last)
+    const int xcd = (int)(blockIdx.x & 7u), j = (int)(blockIdx.x >> 3);
+    const int seg = m.numSegs - 1 - j / m.stripesPerXcd, stripe = xcd * m.stripesPerXcd + (j - (j / m.stripesPerXcd) * m.stripesPerXcd);
+    if (stripe >= m.numStripes)
+        return;
+    const int rectW = c.shared.gRectSize.x, rectH = c.shared.gRectSize.y;
+    const int blockX0 = stripe * W, x0 = blockX0 - G::LEFT;
+    const int step0 = seg * m.segSteps, numSteps = (step0 + m.segSteps < m.numSteps ? step0 + m.segSteps : m.numSteps) - step0; // (<= 32: launcher)
+    const int segY0 = m.firstY + step0 * H, segTop = segY0 - G::TOP;
+    const int tx = (int)(threadIdx.x & 31u), ty = (int)(threadIdx.x >> 5);
+    const int px = blockX0 + tx;
+    const int lcol = tx + G::LEFT;
+    MarchFiller<STEP, DIFF, SPEC, SH> filler;
+    filler.Init(x0);
+    auto fill = [&](int row0, int numRows) { filler.Fill(ring, P, segTop, row0, numRows); };
+
+    // the tile flags of the segment, once: bit 2 i + t = tile t (of the two 16x16 tiles of a 32x16 step) of step i has geometry
+    uint64_t geometry = 0;
+    for (int i = 0; i < numSteps; i++) {
+        const int tileY = (segY0 + i * H) >> 4;
+#pragma unroll
+        for (int t = 0; t < W / 16; t++)
+            if ((blockX0 >> 4) + t < P.tiles.w && tileY < P.tiles.h && segY0 + i * H < rectH && LoadR8U(P.tiles, (blockX0 >> 4) + t, tileY) == 0u)
+                geometry |= (uint64_t)1 << (2 * i + t);
+    }
+    if (geometry == 0)
+        return;
+
+    // a pixel of step i takes part when it lies in the rect, in this rank's rows and in a tile with geometry (the viewZ test follows when the ring holds its texel)
+    auto isActive = [&](int i) {
+        const int py = segY0 + i * H + ty;
+        return i < numSteps && px < rectW && py < rectH && py >= m.rowBegin && py < m.rowEnd && ((geometry >> (2 * i + (tx >> 4))) & 1u) != 0u;
+    };
+
+    int ringFor = -1; // the step whose rows the ring holds or has in flight
+    // software pipeline over the steps: the small per-pixel inputs of step i + 1 are requested during step i, the outputs of step i are stored during step i + 1 --
+    // with one workgroup (step 16) or two (step 8) per CU whose waves meet at barriers, a load or a store in front of a wait is latency nobody hides
+    int first = 0;
+    while (((geometry >> (2 * first)) & 3u) == 0u)
+        first++;
+    // (step 8 runs two workgroups per CU, which hide each other's waits, inside 128 VGPRs: no pipeline there)
+    constexpr bool PIPELINED = STEP == 16;
+    AtrousPixelBytes bytes = {};
+    if (PIPELINED && isActive(first))
+        bytes = LoadAtrousPixelBytes<DIFF, SPEC>(P, c, px, segY0 + first * H + ty);
+    AtrousResult<DIFF, SPEC, SH> pending = {};
+    int pendingY = -1; // >= 0: `pending` waits to be stored at (px, pendingY)
+
+    for (int i = first; i < numSteps; i++) {
+        if (((geometry >> (2 * i)) & 3u) == 0u)
+            continue;
+        const int y0 = segY0 + i * H, top = y0 - G::TOP;
+        int next = i + 1; // the next step with geometry (numSteps: none)
+        while (next < numSteps && ((geometry >> (2 * next)) & 3u) == 0u)
+            next++;
+        const bool nextAdjacent = next == i + 1 && next < numSteps;
+        if (ringFor != i) { // first step with geometry of the segment, or the step behind a run of sky steps: the whole ring
+            __syncthreads(); // (the taps of an earlier step may still be reading the ring)
+            fill(top, G::RR);
+        }
+        const int py = y0 + ty;
+        bool active = isActive(i);
+        if (!PIPELINED && active)
+            bytes = LoadAtrousPixelBytes<DIFF, SPEC>(P, c, px, py);
+        const AtrousPixelInputs in = DecodeAtrousPixelBytes(bytes); // (PIPELINED: requested one step ago)
+        // the hashed offset of the pixel (reference RELAX_Atrous.hlsli:122-128)
+        int offx, offy;
+        {
+            RngHash rng;
+            rng.Initialize((uint32_t)px, (uint32_t)py, c.shared.gFrameIndex);
+            float2 rnd = rng.GetFloat2();
+            offx = (int)(float(c.gStepSize) * 0.5f * (rnd.x - 0.5f));
+            offy = (int)(float(c.gStepSize) * 0.5f * (rnd.y - 0.5f));
+        }
+        NRD_LDS_DMA_WAIT(); // this wave's pieces have landed ...
+        __syncthreads();    // ... and everybody else's
+        ringFor = i;
+        if (pendingY >= 0) // the previous step's outputs: their latency runs under this step's taps
+            AtrousStore(pending, P, px, pendingY);
+        pendingY = -1;
+        if (PIPELINED && next < numSteps && isActive(next))
+            bytes = LoadAtrousPixelBytes<DIFF, SPEC>(P, c, px, segY0 + next * H + ty);
+
+        AtrousPixel<DIFF, SPEC, SH> a;
+        if (active) {
+            const int lc = (int)((uint32_t)(py - segTop) % (uint32_t)G::RR) * G::BW + lcol;
+            const float centerViewZ = RelaxUnpackViewZ(c, ring.z[lc]);
+            if (centerViewZ > c.shared.gDenoisingRange)
+                active = false;
+            else {
+                const float4 centerWorldPosViewZ = F4(GetCurrentWorldPosFromPixelPos(c, px, py, centerViewZ), centerViewZ); // = the texel of the (world position, viewZ) guide plane
+                float centerMaterialID;
+                const float4 centerNormalRoughness = DecodedToNormalRoughness(EncodeDecodedNormalRoughness(ring.nr[lc]), centerMaterialID); // = the texel of the decoded guide plane
+                float4 centerSpecular = F4(0.0f), centerSpecularSH = F4(0.0f), centerDiffuse = F4(0.0f), centerDiffuseSH = F4(0.0f);
+                if (SPEC) {
+                    centerSpecular = DecodeRGBA16F(ring.spec[lc].x, ring.spec[lc].y);
+                    if (SH)
+                        centerSpecularSH = DecodeRGBA16F(ring.specSh[lc].x, ring.specSh[lc].y);
+                }
+                if (DIFF) {
+                    centerDiffuse = DecodeRGBA16F(ring.diff[lc].x, ring.diff[lc].y);
+                    if (SH)
+                        centerDiffuseSH = DecodeRGBA16F(ring.diffSh[lc].x, ring.diffSh[lc].y);
+                }
+                AtrousBegin(a, P, c, px, py, centerWorldPosViewZ, centerNormalRoughness, centerMaterialID, centerSpecular, centerSpecularSH, centerDiffuse, centerDiffuseSH, in);
+            }
+        }
+#pragma unroll
+        for (int yy = -1; yy <= 1; yy++) {
+            if (yy != -1) { // the rows only the finished taps read are dead: the rows of the next step go there, under the remaining taps
+                const int freeRows = yy == 0 ? G::FREE1 : G::FREE2;
+                if (freeRows > 0) {
+                    __syncthreads();
+                    if (nextAdjacent)
+                        fill(top + G::RR + (yy == 0 ? 0 : G::FREE1), freeRows);
+                }
+            }
+            if (active) {
+                const int qy = py + offy + yy * STEP;
+                const int rowBase = (int)((uint32_t)(qy - segTop) % (uint32_t)G::RR) * G::BW + lcol + offx;
+                const int cy = ClampI(qy, 0, P.viewZ.h - 1);
+#pragma unroll
+                for (int xx = -1; xx <= 1; xx++) {
+                    if (xx == 0 && yy == 0)
+                        continue;
+                    const int qx = px + offx + xx * STEP;
+                    const bool isInside = (uint32_t)qx < (uint32_t)rectW && (uint32_t)qy < (uint32_t)rectH && InBounds(P.viewZ, qx, qy);
+                    const float kernelW = (xx == 0 ? 0.44198f : 0.27901f) * (yy == 0 ? 0.44198f : 0.27901f);
+                    const int li = rowBase + xx * STEP; // the ring holds the clamped texel of every tap position
+                    const int cx = ClampI(qx, 0, P.viewZ.w - 1);
+                    const float4 g0 = EncodeDecodedNormalRoughness(ring.nr[li]);
+                    const float tapZ = RelaxUnpackViewZ(c, ring.z[li]);
+                    const float4 sampleWorldPosViewZ = F4(GetCurrentWorldPosFromPixelPos(c, cx, cy, tapZ), tapZ);
+                    float4 sampleSpecular = F4(0.0f), sampleDiffuse = F4(0.0f);
+                    uint2 rawSpecSh = make_uint2(0u, 0u), rawDiffSh = make_uint2(0u, 0u);
+                    if (SPEC) {
+                        const uint2 raw = ring.spec[li];
+                        sampleSpecular = DecodeRGBA16F(raw.x, raw.y);
+                        if (SH)
+                            rawSpecSh = ring.specSh[li];
+                    }
+                    if (DIFF) {
+                        const uint2 raw = ring.diff[li];
+                        sampleDiffuse = DecodeRGBA16F(raw.x, raw.y);
+                        if (SH)
+                            rawDiffSh = ring.diffSh[li];
+                    }
+                    AtrousTap<DIFF, SPEC, SH, RES, MAT>(a, c, kernelW, isInside, g0, sampleWorldPosViewZ, sampleSpecular, sampleDiffuse, rawSpecSh, rawDiffSh);
+                }
+            }
+        }
+        if (active) {
+            pending = AtrousFinish(a, c);
+            if (PIPELINED)
+                pendingY = py;
+            else
+                AtrousStore(pending, P, px, py);
+        }
+        if (nextAdjacent)
+            ringFor = next;
+    }
+    if (pendingY >= 0)
+        AtrousStore(pending, P, px, pendingY);
 }
 
 static bool AtrousLdsTilesEnabled() {
@@ -820,6 +1263,16 @@ static bool AtrousLdsTilesEnabled() {
 static int AtrousLdsBandsMaxStep() { // run-time A/B switch (results are identical): 0 = off, 8 = step 8 (default), 16 = steps 8 and 16
     static const int v = getenv("NRD_HIP_ATROUS_BANDS") ? atoi(getenv("NRD_HIP_ATROUS_BANDS")) : 8;
     return NRD_ATROUS_LDS_TILES ? v : 0;
+}
+
+// run-time A/B switches of the marching kernel (results are identical): NRD_HIP_ATROUS_MARCH = 0 (off) / 8 / 16 (steps 8 and 16: default); NRD_HIP_ATROUS_MARCH_SEG = steps of 16 rows per segment
+static int AtrousMarchMaxStep() {
+    static const int v = getenv("NRD_HIP_ATROUS_MARCH") ? atoi(getenv("NRD_HIP_ATROUS_MARCH")) : 0;
+    return v;
+}
+static int AtrousMarchSegSteps() {
+    static const int v = getenv("NRD_HIP_ATROUS_MARCH_SEG") && atoi(getenv("NRD_HIP_ATROUS_MARCH_SEG")) > 0 ? atoi(getenv("NRD_HIP_ATROUS_MARCH_SEG")) : 8;
+    return v;
 }
 
 template <bool DIFF, bool SPEC, bool SH>
@@ -840,9 +1293,32 @@ const char* LaunchAtrous(const PassArgs& a) {
     RelaxCB c = LoadRelaxConstants(a);
     RowGrid g = GridForRows(c.shared.gRectSize.x, c.shared.gRectSize.y, TILE_X, TILE_Y, a.rowBegin, a.rowEnd);
     const RowRange rr = MakeRowRange(g);
-    const int step = (AtrousLdsTilesEnabled() && (c.gStepSize == 2 || c.gStepSize == 4)) || ((c.gStepSize == 8 || c.gStepSize == 16) && (int)c.gStepSize <= AtrousLdsBandsMaxStep()) ? (int)c.gStepSize : 0;
     const bool res = !SPEC || c.shared.gRoughnessEdgeStoppingEnabled != 0; // (irrelevant without a specular signal: one instantiation)
     const bool mat = c.shared.gSpecMinMaterial < 3.0f || c.shared.gDiffMinMaterial < 3.0f;
+    if ((c.gStepSize == 8 || c.gStepSize == 16) && (int)c.gStepSize <= AtrousMarchMaxStep() && g.rowEnd > g.rowBegin && P.viewZ.w == P.decodedNR.w && P.viewZ.h == P.decodedNR.h &&
+        P.normalRoughness.w == P.decodedNR.w && P.normalRoughness.h == P.decodedNR.h) {
+        march::Range m;
+        m.firstY = g.rowBegin / march::H * march::H;
+        m.numSteps = (g.rowEnd - m.firstY + march::H - 1) / march::H;
+        m.segSteps = AtrousMarchSegSteps() < m.numSteps ? AtrousMarchSegSteps() : m.numSteps;
+        if (m.segSteps > 32) // (the kernel keeps the segment's tile flags in a 64-bit mask)
+            m.segSteps = 32;
+        m.numSegs = (m.numSteps + m.segSteps - 1) / m.segSteps;
+        m.numStripes = (c.shared.gRectSize.x + march::W - 1) / march::W;
+        m.stripesPerXcd = (m.numStripes + 7) / 8;
+        m.rowBegin = g.rowBegin, m.rowEnd = g.rowEnd;
+        const dim3 grid((unsigned)(8 * m.stripesPerXcd * m.numSegs));
+#define NRD_LAUNCH_MARCH_M(STEP, RES, MAT) LaunchPass(a, (RelaxAtrousMarchKernel<DIFF, SPEC, SH, STEP, RES, MAT>), grid, dim3(march::THREADS), P, c, m)
+#define NRD_LAUNCH_MARCH(STEP, RES) (mat ? NRD_LAUNCH_MARCH_M(STEP, RES, true) : NRD_LAUNCH_MARCH_M(STEP, RES, false))
+        if (c.gStepSize == 8)
+            res ? NRD_LAUNCH_MARCH(8, true) : NRD_LAUNCH_MARCH(8, SPEC ? false : true);
+        else
+            res ? NRD_LAUNCH_MARCH(16, true) : NRD_LAUNCH_MARCH(16, SPEC ? false : true);
+#undef NRD_LAUNCH_MARCH_M
+#undef NRD_LAUNCH_MARCH
+        return nullptr;
+    }
+    const int step = (AtrousLdsTilesEnabled() && (c.gStepSize == 2 || c.gStepSize == 4)) || ((c.gStepSize == 8 || c.gStepSize == 16) && (int)c.gStepSize <= AtrousLdsBandsMaxStep()) ? (int)c.gStepSize : 0;
 #define NRD_LAUNCH_ATROUS_M(STEP, RES, MAT) LaunchPass(a, (RelaxAtrousKernel<DIFF, SPEC, SH, STEP, RES, MAT>), g.grid, dim3(256), P, c, rr)
 #define NRD_LAUNCH_ATROUS(STEP, RES) (mat ? NRD_LAUNCH_ATROUS_M(STEP, RES, true) : NRD_LAUNCH_ATROUS_M(STEP, RES, false))
     if (step == 2)

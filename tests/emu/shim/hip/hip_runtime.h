@@ -142,6 +142,14 @@ inline float emu_fmed3f(float a, float b, float c) { return std::max(std::min(a,
 // nrdmath.h Rcp: the device hides the argument from the constant folder; nothing to hide from here
 #define NRD_OPAQUE_VALUE(x) ((void)0)
 #define NRD_LDS_WHOLE_TEXEL(v) ((void)0)
+// LDS-DMA of the marching a-trous kernel (kernels_relax_atrous.hip): lane l of the wave copies its 16 source bytes to ldsWaveBase + 16 l, at once (no asynchrony to model:
+// the device code waits for the DMA and meets a barrier in front of every read)
+#define NRD_LDS_ADDRESS(p) ((uintptr_t)(p))
+#define NRD_WAVE_UNIFORM(x) (x)
+#define NRD_LDS_DMA16(gsrc, ldsWaveBase) memcpy((void*)((uintptr_t)(ldsWaveBase) + (uintptr_t)(threadIdx.x & 63u) * 16u), (const void*)(gsrc), 16)
+#define NRD_LDS_DMA_WAIT() ((void)0)
+#define NRD_LDS_POINTER(T, address) ((T*)(uintptr_t)(address))
+typedef uintptr_t LdsAddress;
 // ClampI = v_med3_i32: the MEDIAN of three like the instruction, not the clamp it stands for -- with a > b (an empty plane: clamp to [0, -1]) the two differ, and
 // the device computes the median. Call sites with a > b are counted (emu_med3_violations(), asserted to be 0 by tests/test_emulation.py: ADVICE r03).
 namespace emu {

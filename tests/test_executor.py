@@ -187,6 +187,27 @@ def test_temporal_accumulation_window_and_fallback_kernels_match_the_oracle(name
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("name", ["RELAX_DIFFUSE_SPECULAR_SH", "RELAX_SPECULAR"])
+def test_atrous_tap_sources_match_the_oracle(name):
+    """The a-trous iterations read their taps from LDS tiles (steps 2, 4), LDS bands (step 8) or global gathers with 16 x 4-pixel waves (step 16 and beyond) by default;
+    NRD_HIP_ATROUS_MARCH=16 selects the marching kernel of round 6 for steps 8 and 16 (an LDS ring filled by LDS-DMA: measured slower, kept as an A/B switch), with segments of
+    2 steps so that complete refills, prefetched rows and the first / last stripe's clamped columns all occur; NRD_HIP_ATROUS_LDS=0 + NRD_HIP_ATROUS_BANDS=0 gathers everything.
+    One arithmetic: every variant equals the oracle bit for bit (7 iterations: steps up to 64; a size with partial stripes, steps and tiles)."""
+    import re
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = ("import sys; sys.path[:0] = [%r, %r]; import parity; "
+            "print('worst', parity.run_parity(%r, width=211, height=117, frames=3, settings_overrides=dict(atrousIterationNum=7)))") % (root, os.path.join(root, "tests"), name)
+    for tag, extra in (("default", {}), ("march", {"NRD_HIP_ATROUS_MARCH": "16", "NRD_HIP_ATROUS_MARCH_SEG": "2"}), ("bands16", {"NRD_HIP_ATROUS_BANDS": "16"}),
+                       ("gathers", {"NRD_HIP_ATROUS_LDS": "0", "NRD_HIP_ATROUS_BANDS": "0"})):
+        out = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, **extra), capture_output=True, text=True, timeout=1200)
+        assert out.returncode == 0, (tag, out.stderr[-2000:])
+        assert float(re.search(r"worst ([0-9.eE+-]+)", out.stdout).group(1)) == 0.0, (tag, out.stdout[-2000:])
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("name", ["REBLUR_DIFFUSE_SPECULAR", "RELAX_DIFFUSE_SPECULAR_SH"])
 def test_guide_planes_from_the_classification_kernel_or_from_their_own_kernel(name):
     """The per-frame guide planes (decoded normals + view / world position) are written by the tile-classification kernel of the list (one launch, IN_VIEWZ read once:
