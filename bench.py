@@ -37,6 +37,7 @@ from raytracingdenoiser_amd.executor import HipExecutor
 # the per-frame guide decode: IN_NORMAL_ROUGHNESS + IN_VIEWZ read (8 B); written: REBLUR float4 (normal, viewZ) + the 4-byte roughness word, RELAX two float4 planes
 GUIDE_BYTES_PER_PIXEL = {"REBLUR": 28, "RELAX": 40}
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E peak (MI355X_MICROARCH.md); ~6300 GB/s is what a float4 copy achieves (measured live below)
+VALU_SIMDS, VALU_CLOCK_GHZ = 1024, 2.4  # 256 CUs x 4 SIMD-32; a wave64 v_fma_f32 issues over 2 cycles (MI355X_MICROARCH.md "Per-instruction cycle constants")
 
 # Published reference numbers for the exact metric (reference README.md:18, RTX 4080, 1440p native)
 PUBLISHED_MPIX_S = {("REBLUR_DIFFUSE_SPECULAR", 2560, 1440): 1603.0, ("RELAX_DIFFUSE_SPECULAR", 2560, 1440): 1229.0, ("RELAX_DIFFUSE_SPECULAR_SH", 2560, 1440): 760.0}
@@ -467,14 +468,26 @@ def main():
     if dominant:
         achieved = passes[dominant]["GBps"]
         traffic, traffic_source, valu = None, None, None
+        # the recorded evidence (hardware counters, issue floors) carries the digest of the library it was taken from; `stale` = the library timed here is another one
+        digest_file = os.path.join(native_build.LIB_DIR, native_build.LIB_NAME + ".digest")
+        lib_digest = open(digest_file).read().strip() if os.path.exists(digest_file) and not os.environ.get("NRD_HIP_LIBRARY") else None
+        stale = {}
         if world == 1 and os.path.exists(PMC_TRAFFIC_FILE):
             entry = json.load(open(PMC_TRAFFIC_FILE)).get("%s_%dx%d%s" % (name, W, H, "_nosky" if args.no_sky else ""), {})
             k = entry.get("kernels", {}).get(dominant)
             if k:
+                stale["counters"] = entry.get("library_digest") is None or entry.get("library_digest") != lib_digest
                 traffic = int((2.0 * k["FETCH_SIZE_KiB"] + k["WRITE_SIZE_KiB"]) * 1024)
                 traffic_source = entry.get("source")
                 if k.get("SQ_INSTS_VALU"):
-                    valu = {"executed_valu_per_wave": k["valu_per_wave"], "waves_per_launch": int(k["SQ_WAVES"]), "source": entry.get("source")}
+                    # the OTHER roofline of a kernel that computes: executed VALU instructions against the issue rate of the chip -- a wave64 VALU instruction occupies its
+                    # SIMD-32 for 2 cycles (MI355X_MICROARCH.md "Per-instruction cycle constants": v_fma_f32), 256 CUs x 4 SIMDs, 2.4 GHz. The instruction count is the recorded
+                    # counter (SQ_INSTS_VALU / launch), the time is this run's: frac = the share of the kernel's time the VALU pipes would need if every instruction were an fma.
+                    issue_ms = k["SQ_INSTS_VALU"] * 2.0 / (VALU_SIMDS * VALU_CLOCK_GHZ * 1e9) * 1e3
+                    valu = {"executed_valu_per_wave": k["valu_per_wave"], "waves_per_launch": int(k["SQ_WAVES"]), "source": entry.get("source"),
+                            "fma_issue_bound_ms": round(issue_ms, 4), "frac": round(issue_ms / passes[dominant]["avg_ms"], 4),
+                            "what": "SQ_INSTS_VALU x 2 cycles / (1024 SIMDs x 2.4 GHz) against this run's kernel time: the pure-FMA issue bound (selects, conversions, integer "
+                                    "instructions issue at 4, transcendentals at 8 cycles: the measured issue floor below is the tight bound)"}
         # What the dominant kernel is bound by, measured directly (round 4; the counter-derived "VALU busy" of round 3 read up to 109 % and is gone): its time in
         # a build whose loads all hit the L1, on a scene where that build computes the same values (bench.py --uniform, csrc/hip/planes.h NRD_EXPERIMENT_L1_RESIDENT).
         issue_floor = None
@@ -487,12 +500,22 @@ def main():
             hit = next((v for k2, v in rows_fl.items() if frag and frag in k2), None)  # (the first match: the window kernel precedes its fallback)
             if hit:
                 issue_floor = dict(hit, source=fl.get("source"), what="uniform scene, every pixel denoised: this kernel's time / its time with every load an L1 hit (not measured in this run)")
-        roofline = {"bound": "hbm", "kernel": dominant, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
+                stale["issue_floor"] = fl.get("library_digest") is None or fl.get("library_digest") != lib_digest
+        # what the evidence says bounds the kernel: at most 25 % above its L1-resident time -> instruction issue; beyond that the memory system behind the L1 (the request path of
+        # scattered taps / dependent round trips); HBM itself is a quarter busy (frac). `bound` names that; achieved / peak / frac stay the HBM roofline BASELINE.json asks for.
+        bound = "hbm"
+        if issue_floor and issue_floor.get("measured_over_floor"):
+            bound = "valu-issue" if issue_floor["measured_over_floor"] <= 1.25 else "l1-request"
+        roofline = {"bound": bound, "roofline_class": "hbm", "kernel": dominant, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
                     "measured_copy_GBps": round(copy_gbs, 1), "frac_of_measured_copy": round(achieved / copy_gbs, 4),
                     "denoised_pixel_fraction": round(denoised_fraction, 4), "frac_denoised_pixels": round(achieved / HBM_PEAK_GBS * denoised_fraction, 4),
                     "traffic": traffic, "traffic_source": traffic_source, "valu": valu, "issue_floor": issue_floor, "avg_kernel_ms": passes[dominant]["avg_ms"],
+                    "library_digest": lib_digest, "stale": (any(stale.values()) if stale else None), "stale_fields": sorted(k2 for k2, v in stale.items() if v),
                     "algorithmic_bytes_per_launch": passes[dominant]["bytes_per_launch"],
-                    "note": "dominant = the pass with the longest average launch; per-pass durations from HIP events on the executor's stream (eager replay of the timed frames); "
+                    "note": "bound = what the recorded issue-floor evidence says limits the kernel (valu-issue: within 25 % of its L1-resident time; l1-request: the memory system behind the L1); "
+                            "achieved / peak / frac = its algorithmic bytes against the HBM peak (roofline_class), valu.frac = its executed VALU instructions against the chip's fma issue rate; "
+                            "traffic / valu / issue_floor are recorded measurements (profiles/), stamped with the digest of the library they were taken from: stale = not the library timed here; "
+                            "dominant = the pass with the longest average launch; per-pass durations from HIP events on the executor's stream (eager replay of the timed frames); "
                             "frac counts the algorithmic bytes of EVERY pixel of the frame as the metric does, frac_denoised_pixels only those of the pixels that are not sky; "
                             "measured_copy_GBps = the library's own 16-B/lane copy kernel on this GPU"}
     # per frame: every pass once, except the dilated a-trous pass which runs (launches / steps) times
@@ -529,7 +552,7 @@ def main():
                    "strips": (list(shard.bounds) if shard is not None and getattr(shard, "bounds", None) else None),  # halo scheme: rows owned by each rank (re-cut from the tile map)
                    # the north-star's reassembly (BASELINE.json configs[3]): every rank ends the frame with the complete OUT_* planes
                    "reassembly": (None if shard is None else
-                                  "all-gather of the owned rows of every OUT_* plane after the last pass (RCCL, asynchronous: awaited in front of the next frame's first pass that touches an OUT_* plane), "
+                                  "all-gather of the owned rows of every OUT_* plane after the last pass into separate complete planes (RCCL, asynchronous: it overlaps the whole next frame and is awaited by wait_outputs()), "
                                   "%.2f MB received per rank per frame, inside the timed region" % (shard.gathered_bytes / max(shard.gather_frames, 1) / 1e6) if args.sharding == "halo" else
                                   "in-place all-gather of every permanent plane and output (FrameSharder)"),
                    "halo_bytes_received_per_rank_per_frame": (int(shard.exchanged_bytes / max(total + args.steps + 5, 1)) if shard is not None and args.sharding == "halo" else None),

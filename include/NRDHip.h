@@ -150,9 +150,9 @@ uint32_t nrdHipGetGraphStats(const NrdHipExecutor* executor, uint64_t* graphLaun
 // flags of the LAST frame back (synchronises the stream): tiles the fallback kernel processed and tiles in total. Results never depend on the split.
 uint32_t nrdHipGetTileFallbackStats(NrdHipExecutor* executor, uint32_t* fallbackTiles, uint32_t* totalTiles);
 
-// Numerics mode of the library (DESIGN.md "Numerics"). Always 0 = the pinned arithmetic: IEEE + - * and source-determined fused multiply-adds, division /
-// sqrt / exp2 / log2 through v_rcp_f32 / v_sqrt_f32 / v_rsq_f32 / v_exp_f32 / v_log_f32 -- bit-identical to the CPU oracle, which emulates those five
-// instructions from measured tables. (Round 2 also shipped a faster, inexact build that answered 1; it is gone: one library, one arithmetic.)
+// DEPRECATED (kept so that round-2 callers still link; do not use in new code). Always 0: there is one library and one arithmetic (DESIGN.md "Numerics": IEEE + - * and
+// source-determined fused multiply-adds, division / sqrt / exp2 / log2 through v_rcp_f32 / v_sqrt_f32 / v_rsq_f32 / v_exp_f32 / v_log_f32 -- bit-identical to the CPU oracle).
+__attribute__((deprecated("one library, one arithmetic: the answer is always 0")))
 uint32_t nrdHipGetNumericsMode(void);
 
 // Bytes held by the pool arena (permanent, transient).

@@ -9,6 +9,10 @@
 
 #include "../common/pass_constants.h"
 
+namespace nrd { // csrc/host/instance.h (the host side of this library; not part of the public API)
+uint16_t TransientAliasOf(const Instance& instance, Identifier identifier, uint16_t indexInPool);
+}
+
 #include <climits>
 #include <cmath>
 #include <cstdio>
@@ -720,9 +724,13 @@ static const char* PrepareDispatch(NrdHipExecutor* e, const nrd::DispatchDesc& d
         } else if (res.type == nrd::ResourceType::TRANSIENT_POOL) {
             if (res.indexInPool >= e->transient.size())
                 return "transient pool index out of range";
-            e->scratchPlanes[r] = e->transient[res.indexInPool];
-            e->scratchBytesPerTexel[r] = (uint8_t)BytesPerTexel(e->transientFormat[res.indexInPool]);
-            e->scratchFormats[r] = (uint8_t)e->transientFormat[res.indexInPool];
+            // (the identity, except for an instance created under NRD_HIP_REFERENCE_QUIRKS: csrc/host/instance.h)
+            const uint16_t index = nrd::TransientAliasOf(*e->instance, d.identifier, res.indexInPool);
+            if (index >= e->transient.size())
+                return "transient pool index out of range";
+            e->scratchPlanes[r] = e->transient[index];
+            e->scratchBytesPerTexel[r] = (uint8_t)BytesPerTexel(e->transientFormat[index]);
+            e->scratchFormats[r] = (uint8_t)e->transientFormat[index];
         } else {
             uint32_t t = (uint32_t)res.type;
             if (t >= (uint32_t)nrd::ResourceType::MAX_NUM || !e->userBound[t]) {
@@ -880,9 +888,11 @@ static uint32_t ExecuteRange(NrdHipExecutor* e, const nrd::DispatchDesc* descs, 
     }
     auto guidePlane = [&](nrd::ResourceType t) -> const Plane& { return shiftedRect && e->shifted[(uint32_t)t].ptr ? e->shifted[(uint32_t)t] : e->user[(uint32_t)t]; };
 
-    // Decoded-guide cache: if any dispatch reads IN_NORMAL_ROUGHNESS, the bound plane is decoded once for the whole list
+    // Guide planes: if any dispatch reads IN_NORMAL_ROUGHNESS, the bound plane is decoded once for the whole list -- into the planes of the families the list holds (below).
+    // `decoded` = their common geometry (float4 texels at the packed plane's size); its ptr -- the float4 (normal, roughness | material) cache -- is set for RELAX lists only,
+    // the one family that reads it (REBLUR- and SIGMA-only executors used to hold a dead 16 B/px plane: 59 MB at 1440p)
     Plane decoded = {};
-    bool decodeNow = false;
+    bool decodeNow = false, usesNormalRoughness = false;
     {
         const uint32_t slot = (uint32_t)nrd::ResourceType::IN_NORMAL_ROUGHNESS;
         bool used = false;
@@ -891,29 +901,19 @@ static uint32_t ExecuteRange(NrdHipExecutor* e, const nrd::DispatchDesc* descs, 
                 used = descs[i].resources[r].type == nrd::ResourceType::IN_NORMAL_ROUGHNESS && descs[i].resources[r].descriptorType == nrd::DescriptorType::TEXTURE;
         if (used && e->userBound[slot]) {
             const Plane& packed = e->user[slot];
-            Plane& cache = e->decodedNormalRoughness;
-            if (!cache.ptr || cache.w != packed.w || cache.h != packed.h) {
-                if (cache.ptr)
-                    (void)hipFree(cache.ptr);
-                cache = Plane{};
-                const uint32_t pitch = ((uint32_t)packed.w * 16u + 255u) & ~255u;
-                if (hipMalloc((void**)&cache.ptr, (size_t)pitch * (size_t)packed.h) != hipSuccess)
-                    return e->Fail(nrd::Result::FAILURE, "nrdHipExecuteDispatches: cannot allocate the decoded normal/roughness cache");
-                cache.pitch = pitch;
-                cache.w = packed.w;
-                cache.h = packed.h;
-                e->decodedFresh = false;
-            }
+            usesNormalRoughness = true;
+            decoded.pitch = ((uint32_t)packed.w * 16u + 255u) & ~255u;
+            decoded.w = packed.w;
+            decoded.h = packed.h;
             // first == 0 starts a new list (= a new frame); a later range decodes only if nothing valid is there (rebound plane, new cache,
             // or a caller that skipped the first range)
             decodeNow = first == 0 || !e->decodedFresh;
-            decoded = cache;
         }
     }
     // View-position guide plane of the REBLUR lists (same geometry again): needs IN_VIEWZ and the frame's REBLUR constants
     Plane viewPos = {};
     const void* reblurConstants = nullptr;
-    if (decoded.ptr) {
+    if (usesNormalRoughness) {
         for (uint32_t i = 0; i < dispatchDescsNum && !reblurConstants; i++)
             if (descs[i].pipelineIndex < idesc.pipelinesNum && !strncmp(idesc.pipelines[descs[i].pipelineIndex].shaderFileName, "REBLUR_", 7) && descs[i].constantBufferData &&
                 descs[i].constantBufferDataSize >= sizeof(nrdc::ReblurConstants))
@@ -955,7 +955,7 @@ static uint32_t ExecuteRange(NrdHipExecutor* e, const nrd::DispatchDesc* descs, 
     // dispatch list may hold both families (e.g. REBLUR_DIFFUSE + RELAX_SPECULAR in one instance), and then both guide planes are written
     Plane worldPos = {};
     const void* relaxConstants = nullptr;
-    if (decoded.ptr) {
+    if (usesNormalRoughness) {
         for (uint32_t i = 0; i < dispatchDescsNum && !relaxConstants; i++)
             if (descs[i].pipelineIndex < idesc.pipelinesNum && !strncmp(idesc.pipelines[descs[i].pipelineIndex].shaderFileName, "RELAX_", 6) && descs[i].constantBufferData &&
                 descs[i].constantBufferDataSize >= sizeof(nrdc::RelaxConstants))
@@ -966,6 +966,20 @@ static uint32_t ExecuteRange(NrdHipExecutor* e, const nrd::DispatchDesc* descs, 
             const Plane& z = e->user[(uint32_t)nrd::ResourceType::IN_VIEWZ];
             if (z.w != decoded.w || z.h != decoded.h)
                 return e->Fail(nrd::Result::INVALID_ARGUMENT, "IN_VIEWZ and IN_NORMAL_ROUGHNESS differ in size; nothing was launched");
+            Plane& nr = e->decodedNormalRoughness; // the float4 (normal, roughness | material) plane: RELAX lists only
+            if (!nr.ptr || nr.w != decoded.w || nr.h != decoded.h) {
+                if (nr.ptr)
+                    (void)hipFree(nr.ptr);
+                nr = decoded;
+                nr.ptr = nullptr;
+                if (hipMalloc((void**)&nr.ptr, (size_t)nr.pitch * (size_t)nr.h) != hipSuccess) {
+                    nr = Plane{};
+                    return e->Fail(nrd::Result::FAILURE, "nrdHipExecuteDispatches: cannot allocate the decoded normal/roughness cache");
+                }
+                e->decodedFresh = false;
+                decodeNow = true;
+            }
+            decoded.ptr = nr.ptr;
             Plane& cache = e->worldPosViewZ;
             if (!cache.ptr || cache.w != decoded.w || cache.h != decoded.h) {
                 if (cache.ptr)
@@ -1169,7 +1183,7 @@ static uint32_t ExecuteRange(NrdHipExecutor* e, const nrd::DispatchDesc* descs, 
         if (enqueue(passRecordsEnd, (uint32_t)recorder.records.size()) != hipSuccess) // the IN_MV twin back into the user's plane
             return e->Fail(nrd::Result::FAILURE, "HIP launch failed while copying IN_MV back");
     }
-    if (decoded.ptr || shiftedRect)
+    if (usesNormalRoughness || shiftedRect)
         e->decodedFresh = first + count < dispatchDescsNum; // the list is complete: the next call belongs to another frame
 
     hipError_t err = hipGetLastError();

@@ -26,8 +26,10 @@ __global__ __launch_bounds__(256) void DecodeGuidesKernel(Plane packed, Plane vi
     if (x >= packed.w)
         return;
     if (y < rows.validBegin || y >= rows.validEnd) { // test hook only (NRD_HIP_POISON_GUIDES)
+        // (the readers mask the word with 0x3FFFFFFF -- reblur_device.h DecodedRoughness --, so no bit pattern of it decodes to a NaN: all ones decode to a roughness of 1.9999999,
+        //  far outside [0, 1], and material 3, which changes every weight that uses them; the normals next to it are NaNs. ADVICE r05: 0x7FC00000 decoded to a plausible 1.5 / material 1)
         StoreRGBA32F(viewPos, x, y, F4(__uint_as_float(0x7FC00000u)));
-        StoreR32U(roughnessWord, x, y, 0x7FC00000u);
+        StoreR32U(roughnessWord, x, y, 0xFFFFFFFFu);
         return;
     }
     const float4 d = EncodeDecodedNormalRoughness(LoadR32U(packed, x, y));
@@ -63,7 +65,7 @@ __global__ __launch_bounds__(256) void DecodeGuidesRelaxKernel(Plane packed, Pla
     if (x >= packed.w)
         return;
     if (y < rows.validBegin || y >= rows.validEnd) { // test hook only (NRD_HIP_POISON_GUIDES)
-        StoreRGBA32F(decoded, x, y, F4(__uint_as_float(0x7FC00000u)));
+        StoreRGBA32F(decoded, x, y, F4(__uint_as_float(0x7FC00000u), __uint_as_float(0x7FC00000u), __uint_as_float(0x7FC00000u), __uint_as_float(0xFFFFFFFFu))); // (.w: see DecodeGuidesKernel)
         StoreRGBA32F(worldPos, x, y, F4(__uint_as_float(0x7FC00000u)));
         return;
     }

@@ -138,8 +138,21 @@ void InstanceImpl::Add_Reblur(DenoiserData& d, bool hasDiff, bool hasSpec, bool 
             AddTransient(FMT_SIGNAL);
         }
     }
+    // NRD_HIP_REFERENCE_QUIRKS: REBLUR_DIFFUSE_SPECULAR_SH as the reference describes it (Reblur_DiffuseSpecularSh.hpp:61-85) -- its Transient enum lists 10 planes, the code adds
+    // 11 textures: a full-resolution REBLUR_FORMAT texture sits where the enum says TILES and the tile texture behind it is never named. The dispatches keep naming index TILES;
+    // the HIP executor binds the real tile plane there (InstanceImpl::TransientAlias).
+    const bool extraTextureOfTheReference = m_ReferenceQuirks && sh && hasDiff && hasSpec && !directionalOcclusion;
     const uint16_t T_TILES = next++;
+    if (extraTextureOfTheReference) {
+        AddTransient(FMT_SIGNAL);
+        next++;
+    }
     AddTransient(FMT_TILES, 16);
+    if (extraTextureOfTheReference) { // (global pool indices: planes may be shared with the other denoisers of the instance, hence the alias is this denoiser's alone)
+        m_TransientAliases.push_back(d.desc.identifier);
+        m_TransientAliases.push_back(m_IndexRemap[m_IndexRemap.size() - 2]);
+        m_TransientAliases.push_back(m_IndexRemap[m_IndexRemap.size() - 1]);
+    }
 
     // The user-visible outputs double as scratch ("TEMP1")
     const uint16_t OUT_DIFF = (uint16_t)(directionalOcclusion ? ResourceType::OUT_DIFF_DIRECTION_HITDIST : (sh ? ResourceType::OUT_DIFF_SH0 : ResourceType::OUT_DIFF_RADIANCE_HITDIST));

@@ -72,7 +72,9 @@ InstanceImpl::InstanceImpl(const AllocationCallbacks& cb)
     , m_Passes(HostAllocator<PassTemplate>(cb))
     , m_ActiveDispatches(HostAllocator<DispatchDesc>(cb))
     , m_IndexRemap(HostAllocator<uint16_t>(cb))
+    , m_TransientAliases(HostAllocator<uint32_t>(cb))
     , m_Strings(HostAllocator<char*>(cb)) {
+    m_ReferenceQuirks = ReferenceQuirksEnabled();
     // the arena is followed by one scratch block: a dispatch that no longer fits writes its constants there (so the fillers never see null) and the
     // whole GetComputeDispatches call fails
     m_ConstantDataUnaligned = (uint8_t*)cb.Allocate(cb.userArg, CONSTANT_DATA_SIZE + CONSTANT_SCRATCH_SIZE + 64, 64);

@@ -18,6 +18,13 @@
 
 namespace nrd {
 
+// NRD_HIP_REFERENCE_QUIRKS=1 (environment, read when asked): reproduce what callers of the reference observe where this library deliberately differs -- the (shifted)
+// GetResourceTypeString table of Source/Wrapper.cpp:58-95 and the 11 transient textures of REBLUR_DIFFUSE_SPECULAR_SH (INTEGRATION.md "Reference quirks")
+bool ReferenceQuirksEnabled();
+class InstanceImpl;
+// index of the transient plane the HIP executor binds where a dispatch of denoiser `identifier` names `indexInPool` (the identity without the quirks switch)
+uint16_t TransientAliasOf(const Instance& instance, Identifier identifier, uint16_t indexInPool);
+
 // ---- allocation through the user callbacks (reference Source/StdAllocator.h) ------------------------------------
 void CheckAndSetDefaultAllocator(AllocationCallbacks& cb);
 
@@ -107,6 +114,16 @@ public:
     Result GetComputeDispatches(const Identifier* identifiers, uint32_t identifiersNum, const DispatchDesc*& dispatchDescs, uint32_t& dispatchDescsNum);
 
     const InstanceDesc& GetDesc() const { return m_Desc; }
+    // NRD_HIP_REFERENCE_QUIRKS (wrapper.cpp ReferenceQuirksEnabled, read at creation): the instance reproduces what a caller of the reference observes where this library
+    // otherwise corrects it -- today: REBLUR_DIFFUSE_SPECULAR_SH describes the reference's 11 transient textures, whose Transient::TILES index names a full-resolution
+    // RGBA16F texture (Reblur_DiffuseSpecularSh.hpp:61-85). The HIP executor then binds the real tile plane wherever a dispatch names that index: TransientAlias.
+    bool ReferenceQuirks() const { return m_ReferenceQuirks; }
+    uint16_t TransientAlias(Identifier identifier, uint16_t indexInPool) const {
+        for (size_t i = 0; i + 2 < m_TransientAliases.size(); i += 3)
+            if (m_TransientAliases[i] == identifier && m_TransientAliases[i + 1] == indexInPool)
+                return (uint16_t)m_TransientAliases[i + 2];
+        return indexInPool;
+    }
     const AllocationCallbacks& GetAllocationCallbacks() const { return m_Callbacks; }
 
 private:
@@ -165,6 +182,7 @@ private:
     Vector<PassTemplate> m_Passes;
     Vector<DispatchDesc> m_ActiveDispatches;
     Vector<uint16_t> m_IndexRemap;
+    Vector<uint32_t> m_TransientAliases; // triples (denoiser identifier, index its dispatches name, index the executor binds): reference quirks only
     Vector<char*> m_Strings;
 
     InstanceDesc m_Desc = {};
@@ -205,6 +223,7 @@ private:
     uint16_t m_TransientPoolOffset = 0;
     uint16_t m_PermanentPoolOffset = 0;
     bool m_IsFirstUse = true;
+    bool m_ReferenceQuirks = false;
 
     // wall-clock fallback when CommonSettings::timeDeltaBetweenFrames == 0 (reference Source/Timer.cpp)
     std::chrono::steady_clock::time_point m_LastTime;

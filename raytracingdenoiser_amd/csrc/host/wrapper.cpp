@@ -53,6 +53,17 @@ const char* const g_ResourceTypeNames[] = {
 };
 static_assert(sizeof(g_ResourceTypeNames) / sizeof(char*) == (size_t)nrd::ResourceType::MAX_NUM, "name table");
 
+// the reference's own table (Source/Wrapper.cpp:58-95): entries 3..15 are out of step with the ResourceType enum (the confidence / threshold-mix / base-colour inputs were moved up in
+// the enum, not in the table). Returned under NRD_HIP_REFERENCE_QUIRKS for callers that rely on what the reference prints.
+const char* const g_ResourceTypeNamesOfTheReference[] = {
+    "IN_MV", "IN_NORMAL_ROUGHNESS", "IN_VIEWZ", "IN_DIFF_RADIANCE_HITDIST", "IN_SPEC_RADIANCE_HITDIST", "IN_DIFF_HITDIST", "IN_SPEC_HITDIST", "IN_DIFF_DIRECTION_HITDIST",
+    "IN_DIFF_SH0", "IN_DIFF_SH1", "IN_SPEC_SH0", "IN_SPEC_SH1", "IN_DIFF_CONFIDENCE", "IN_SPEC_CONFIDENCE", "IN_DISOCCLUSION_THRESHOLD_MIX", "IN_BASECOLOR_METALNESS",
+    "IN_PENUMBRA", "IN_TRANSLUCENCY", "IN_SIGNAL", "OUT_DIFF_RADIANCE_HITDIST", "OUT_SPEC_RADIANCE_HITDIST", "OUT_DIFF_SH0", "OUT_DIFF_SH1", "OUT_SPEC_SH0",
+    "OUT_SPEC_SH1", "OUT_DIFF_HITDIST", "OUT_SPEC_HITDIST", "OUT_DIFF_DIRECTION_HITDIST", "OUT_SHADOW_TRANSLUCENCY", "OUT_SIGNAL",
+    "OUT_VALIDATION", "TRANSIENT_POOL", "PERMANENT_POOL",
+};
+static_assert(sizeof(g_ResourceTypeNamesOfTheReference) / sizeof(char*) == (size_t)nrd::ResourceType::MAX_NUM, "name table");
+
 const char* const g_DenoiserNames[] = {
     "REBLUR_DIFFUSE", "REBLUR_DIFFUSE_OCCLUSION", "REBLUR_DIFFUSE_SH", "REBLUR_SPECULAR", "REBLUR_SPECULAR_OCCLUSION",
     "REBLUR_SPECULAR_SH", "REBLUR_DIFFUSE_SPECULAR", "REBLUR_DIFFUSE_SPECULAR_OCCLUSION", "REBLUR_DIFFUSE_SPECULAR_SH",
@@ -107,9 +118,18 @@ NRD_EXPORT nrd::Result NRD_CALL nrd::GetComputeDispatches(Instance& instance, co
     return ((InstanceImpl&)instance).GetComputeDispatches(identifiers, identifiersNum, dispatchDescs, dispatchDescsNum);
 }
 
+bool nrd::ReferenceQuirksEnabled() {
+    const char* v = getenv("NRD_HIP_REFERENCE_QUIRKS");
+    return v && atoi(v) != 0;
+}
+
+uint16_t nrd::TransientAliasOf(const Instance& instance, Identifier identifier, uint16_t indexInPool) { return ((const InstanceImpl&)instance).TransientAlias(identifier, indexInPool); }
+
 NRD_EXPORT const char* nrd::GetResourceTypeString(ResourceType resourceType) {
     uint32_t i = (uint32_t)resourceType;
-    return i < (uint32_t)ResourceType::MAX_NUM ? g_ResourceTypeNames[i] : nullptr;
+    if (i >= (uint32_t)ResourceType::MAX_NUM)
+        return nullptr;
+    return ReferenceQuirksEnabled() ? g_ResourceTypeNamesOfTheReference[i] : g_ResourceTypeNames[i];
 }
 
 NRD_EXPORT const char* nrd::GetDenoiserString(Denoiser denoiser) {

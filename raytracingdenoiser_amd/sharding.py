@@ -98,7 +98,6 @@ class HaloPlan:
         self.early = []            # per step: leading dispatches that do not touch the exchanged planes (run during the transfers)
         self.complete_keys = []
         self.output_keys = []      # the user's OUT_* planes this frame writes: all-gathered after the last pass (HaloSharder.gather_outputs)
-        self.first_output_use = 0  # index of the first dispatch that touches one of them (the previous frame's gather has to have landed by then)
         self._c_rows = None        # ctypes copies of row_begin / row_end (made once: plans are cached and reused every other frame)
         self._ops = {}             # step -> (plane addresses, P2POp list, bytes received): the transfer batch, rebuilt only if a plane moved
 
@@ -219,7 +218,7 @@ def start_halo_exchange(planes, rows, rank, world, items, group=None):
             if kind == "recv":
                 landing.append((band, host))
             band = host
-        ops.append(dist.P2POp(dist.isend if kind == "send" else dist.irecv, band, peer, group))
+        ops.append(dist.P2POp(dist.isend if kind == "send" else dist.irecv, band, global_rank(group, peer), group))
     return dist.batch_isend_irecv(ops), landing
 
 
@@ -253,19 +252,24 @@ def carried_over_planes(dispatches, small_planes=()):
     return carried
 
 
+def global_rank(group, rank_in_group):
+    """torch.distributed addresses point-to-point peers and broadcast sources by GLOBAL rank; strips are numbered by the rank inside the sharder's group (the two
+    only coincide for the default group)"""
+    import torch.distributed as dist
+
+    return rank_in_group if group is None or group is dist.group.WORLD else dist.get_global_rank(group, rank_in_group)
+
+
 def output_planes_of(dispatches):
-    """(keys of the user's OUT_* planes the list writes, index of the first dispatch that reads or writes one of them)"""
+    """keys of the user's OUT_* planes the list writes"""
     from . import api
 
-    keys, first = [], None
-    for i, d in enumerate(dispatches):
+    keys = []
+    for d in dispatches:
         for dt, t, idx in d.resources:
-            if api.ResourceType(t).name.startswith("OUT_"):
-                if dt == api.DescriptorType.STORAGE_TEXTURE and (int(t), idx) not in keys:
-                    keys.append((int(t), idx))
-                if first is None:
-                    first = i
-    return keys, (first if first is not None else len(dispatches))
+            if api.ResourceType(t).name.startswith("OUT_") and dt == api.DescriptorType.STORAGE_TEXTURE and (int(t), idx) not in keys:
+                keys.append((int(t), idx))
+    return keys
 
 
 def output_gather_ops(bounds, keys):
@@ -528,7 +532,7 @@ class HaloSharder:
                     plan = replanned
                     self.rebalanced += 1
         plan.complete_keys = carried_over_planes(dispatches, small) if plan.fallback and not self.complete and self.world > 1 else []
-        plan.output_keys, plan.first_output_use = output_planes_of(dispatches)
+        plan.output_keys = output_planes_of(dispatches)
         if plan.complete_keys and self.gather_outputs:
             # the OUT_* planes too: texels the frame does not write (a pixel that turned into sky) keep what the LAST frame that wrote them left there -- on a single GPU that
             # is the previous frame's value, on a rank that did not own the row it would be a value from before the strips were cut. Nothing reads those texels, but the
@@ -550,7 +554,7 @@ class HaloSharder:
             return bounds  # virtual ranks of the single-process tests
         device = "cuda" if dist.get_backend(self.group) == "nccl" else "cpu"
         t = torch.tensor(bounds if bounds else [-1] * (self.world + 1), dtype=torch.int64, device=device)
-        dist.broadcast(t, 0, self.group)
+        dist.broadcast(t, global_rank(self.group, 0), self.group)
         agreed = [int(v) for v in t.tolist()]
         return agreed if agreed[0] == 0 else None
 
@@ -579,7 +583,7 @@ class HaloSharder:
         self.exchanged_bytes += received
         if planes[0].is_cuda and dist.get_backend(self.group) != "nccl":
             return start_halo_exchange(planes, self.rows, self.rank, self.world, pairs, self.group)  # host-staged (tests): nothing to reuse
-        ops = [dist.P2POp(dist.isend if kind == "send" else dist.irecv, planes[k][r0:r1], peer, self.group)
+        ops = [dist.P2POp(dist.isend if kind == "send" else dist.irecv, planes[k][r0:r1], global_rank(self.group, peer), self.group)
                for k, kind, peer, r0, r1 in halo_transfers(self.rows, self.rank, self.world, pairs)]
         if not ops:
             return None
@@ -603,11 +607,11 @@ class HaloSharder:
                     continue
                 if staged:
                     host = band.cpu() if src == self.rank else torch.empty(band.shape, dtype=band.dtype)
-                    dist.broadcast(host, src, self.group)
+                    dist.broadcast(host, global_rank(self.group, src), self.group)
                     if src != self.rank:
                         band.copy_(host)
                 else:
-                    dist.broadcast(band, src, self.group)
+                    dist.broadcast(band, global_rank(self.group, src), self.group)
                 if src != self.rank:
                     self.exchanged_bytes += band.numel()
 
@@ -668,11 +672,11 @@ class HaloSharder:
                         continue
                     if p.is_cuda:
                         host = band.cpu() if src == self.rank else torch.empty(band.shape, dtype=band.dtype)
-                        dist.broadcast(host, src, self.group)
+                        dist.broadcast(host, global_rank(self.group, src), self.group)
                         if src != self.rank:
                             band.copy_(host)
                     else:
-                        dist.broadcast(band, src, self.group)
+                        dist.broadcast(band, global_rank(self.group, src), self.group)
             return None
         uniform = len(set(heights)) == 1 and not __import__("os").environ.get("NRD_HIP_GATHER_LIST_FORM")  # (test hook: the list form with equal strips too)
 
@@ -779,7 +783,7 @@ def dry_plan(name, width, height, world, overrides=None, max_motion_rows=None, e
             entry["steps"].append({"before_pass": dispatches[first].shader, "passes_in_segment": count, "planes": [{"plane": label(key), "rows_from_each_neighbour": w, "bytes_per_neighbour": w * row_bytes(key)} for key, w in items],
                                    "rccl": ["group { " + ", ".join("recv(%d rows of %d planes from rank %d), send(same to rank %d)" % (max((w for _, w in items), default=0), len(items), nb, nb) for nb in neighbours) + " }"] if items else [],
                                    "received_bytes": recv, "overlaps_with": "the first %d pass(es) of the segment (they do not touch these planes)" % plan.early[si] if si < len(plan.early) and plan.early[si] else None})
-        out_keys, first_use = output_planes_of(dispatches)
+        out_keys = output_planes_of(dispatches)
         own = bounds[rank + 1] - bounds[rank]
         gathered = sum(row_bytes(key) * (height - own) for key in out_keys) if not plan.fallback else 0
         entry["output_all_gather"] = {"planes": [label(key) for key in out_keys], "rows_contributed": own, "received_bytes": gathered,

@@ -187,6 +187,30 @@ def test_temporal_accumulation_window_and_fallback_kernels_match_the_oracle(name
 
 
 @pytest.mark.gpu
+def test_executor_runs_an_instance_created_under_the_reference_quirks_switch():
+    """NRD_HIP_REFERENCE_QUIRKS=1: REBLUR_DIFFUSE_SPECULAR_SH describes the reference's 11 transient textures and its dispatches name a full-resolution RGBA16F texture as the
+    tile map (Reblur_DiffuseSpecularSh.hpp:61-85); the executor binds the real tile plane there (InstanceImpl::TransientAlias). Same inputs, same outputs, bit for bit, as the
+    instance without the switch -- whose outputs the parity suite holds against the oracle."""
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = ("import sys, hashlib; sys.path[:0] = [%r, %r]; import parity; name = 'REBLUR_DIFFUSE_SPECULAR_SH'; w, h = 176, 112; "
+            "seq = parity.generate_sequence(name, w, h, 4); run = parity.HipRun(name, w, h); digest = hashlib.sha1(); "
+            "[(run.step(fr, parity.common_settings(fr['camera'], seq[max(f - 1, 0)]['camera'], w, h, f), parity.denoiser_settings(name, fr, None)), "
+            "  [digest.update(run.output(rt).tobytes()) for rt in sorted(run.outs, key=int)]) for f, fr in enumerate(seq)]; "
+            "print('planes', len(run.inst.transient_pool), 'digest', digest.hexdigest())") % (root, os.path.join(root, "tests"))
+    seen = {}
+    for switch in ("0", "1"):
+        out = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, NRD_HIP_REFERENCE_QUIRKS=switch), capture_output=True, text=True, timeout=1200)
+        assert out.returncode == 0, (switch, out.stderr[-2000:])
+        words = out.stdout.split()
+        seen[switch] = (int(words[words.index("planes") + 1]), words[words.index("digest") + 1])
+    assert seen["0"][0] == 10 and seen["1"][0] == 11, seen
+    assert seen["0"][1] == seen["1"][1], seen
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("name", ["RELAX_DIFFUSE_SPECULAR_SH", "RELAX_SPECULAR"])
 def test_atrous_tap_sources_match_the_oracle(name):
     """The a-trous iterations read their taps from LDS tiles (steps 2, 4), LDS bands (step 8) or global gathers with 16 x 4-pixel waves (step 16 and beyond) by default;

@@ -335,3 +335,28 @@ def test_the_whole_instance_desc(name):
         if name in KNOWN and key == "descriptorPool":
             continue  # (one texture fewer in the transient pool: see KNOWN)
         assert va[key] == vb[key], (key, va[key], vb[key])
+
+
+def test_reference_quirks_switch_reproduces_what_callers_of_the_reference_observe(monkeypatch):
+    """NRD_HIP_REFERENCE_QUIRKS=1: where the library corrects the reference -- the GetResourceTypeString table and the transient pool of
+    REBLUR_DIFFUSE_SPECULAR_SH -- it answers what the reference answers: zero differences over the frame sequence, the InstanceDesc and the strings; without the switch the
+    two KNOWN differences are back (the other tests of this file)."""
+    monkeypatch.setenv("NRD_HIP_REFERENCE_QUIRKS", "1")
+    ref, mine = oracle_driver.load_ref_host(), api.load_library()
+    for rt in api.ResourceType:
+        if rt.name != "MAX_NUM":
+            assert mine.GetResourceTypeString(int(rt)) == ref.GetResourceTypeString(int(rt)), rt
+    name = "REBLUR_DIFFUSE_SPECULAR_SH"
+    assert _compare(name, frames=4) == []
+    dens = [(0, parity.DENOISERS[name][0])]
+    va, vb = _instance_desc_view(api.Instance(dens)), _instance_desc_view(api.Instance(dens, lib=ref))
+    assert va == vb
+    a, b = api.Instance(dens), api.Instance(dens, lib=ref)
+    assert a.transient_pool == b.transient_pool and len(a.transient_pool) == 11
+    # a mixed instance: the alias is the SH denoiser's alone (the planes of the pool are shared between the denoisers of an instance)
+    mixed = [(1, parity.DENOISERS[name][0]), (2, parity.DENOISERS["RELAX_SPECULAR"][0]), (3, parity.DENOISERS["REBLUR_DIFFUSE"][0])]
+    a, b = api.Instance(mixed), api.Instance(mixed, lib=ref)
+    assert a.transient_pool == b.transient_pool and a.permanent_pool == b.permanent_pool
+    monkeypatch.delenv("NRD_HIP_REFERENCE_QUIRKS")
+    assert mine.GetResourceTypeString(int(api.ResourceType.IN_DIFF_CONFIDENCE)) == b"IN_DIFF_CONFIDENCE"
+    assert len(api.Instance(dens).transient_pool) == 10

@@ -25,7 +25,10 @@ def parse(path):
 
 def main():
     tag = sys.argv[1]
-    data = {"source": "profiles/%s_*_uniform_{product,l1[,alu]}_kernel_stats.txt (rocprofv3 --kernel-trace of bench.py --uniform --no-graph, every pixel denoised)" % tag, "workloads": {}}
+    digest_path = os.path.join(ROOT, "raytracingdenoiser_amd", "lib", "libNRD_hip.so.digest")
+    data = {"source": "profiles/%s_*_uniform_{product,l1[,alu]}_kernel_stats.txt (rocprofv3 --kernel-trace of bench.py --uniform --no-graph, every pixel denoised)" % tag,
+            "library_digest": open(digest_path).read().strip() if os.path.exists(digest_path) else None,  # (the product library of the session: bench.py marks the floors stale when it times another)
+            "workloads": {}}
     for w, size in (("reblur_ds", "REBLUR_DIFFUSE_SPECULAR 2560x1440"), ("relax_ds_sh", "RELAX_DIFFUSE_SPECULAR_SH 3840x2160")):
         t = {}
         for lib in ("product", "l1", "alu"):

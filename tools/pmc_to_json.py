@@ -13,6 +13,13 @@ KERNEL_TO_SHADER = [  # kernel-name fragments -> shader file name suffix (family
 ]
 
 
+def library_digest():
+    """the digest of the library the counters were taken from (raytracingdenoiser_amd/build.py writes it next to the .so: sources + headers + flags). bench.py compares it with
+    the library it times and marks the recorded fields stale when they differ (the r05 driver line quoted counters from a library one kernel change older)."""
+    path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "raytracingdenoiser_amd", "lib", "libNRD_hip.so.digest")
+    return open(path).read().strip() if os.path.exists(path) else None
+
+
 def parse(path):
     out = {}
     for line in open(path).read().splitlines()[1:]:
@@ -68,7 +75,7 @@ def main():
                 break
     path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles", "pmc_traffic.json")
     data = json.load(open(path)) if os.path.exists(path) else {}
-    data[key] = {"source": source, "kernels": kernels}
+    data[key] = {"source": source, "library_digest": library_digest(), "kernels": kernels}
     json.dump(data, open(path, "w"), indent=1, sort_keys=True)
     print(json.dumps(data[key], indent=1))
 
