@@ -178,7 +178,10 @@ def test_rect_origin_matches_the_reference_text_built_with_viewport_offset(name)
         assert min(r["bit_exact_frac"] for r in rows) >= 0.9999
 
 
-@pytest.mark.parametrize("name", ["REBLUR_DIFFUSE_SPECULAR", "RELAX_DIFFUSE_SPECULAR_SH", "SIGMA_SHADOW"])
+# all 19 denoisers since round 6 (rounds 4-5 enforced three and reported the rest in profiles/r05_ref_parity_summary.txt). Measured, the planes below 99.95 %:
+# REBLUR *Specular* TemporalAccumulation curvature 99.924 % (cancellation between nearly parallel normals), RELAX *Specular* TemporalAccumulation reprojection confidence
+# (R8_UNORM) 99.71 %, RELAX *SpecularSh TemporalAccumulation SH1 (RGBA16_SFLOAT) 99.93 %; everything else >= 99.95 %
+@pytest.mark.parametrize("name", list(parity.DENOISERS))
 def test_the_librarys_arithmetic_against_the_reference_shader_text_one_pass_at_a_time(name):
     """The oracle in DEVICE mode is, bit for bit, what the HIP library computes (tests -m gpu). Held against the reference's text pass by pass on identical inputs,
     this is the single-pass statistic VERDICT r03 asked for: the arithmetic contract (a * v_rcp(b), source-chosen fmas, the device's exp2 / log2 / sqrt) without any
@@ -186,10 +189,10 @@ def test_the_librarys_arithmetic_against_the_reference_shader_text_one_pass_at_a
     by ulp(py) ~ 1e-4 when the multiply-add is fused, and a chroma or SH1 component that cancels to ~0 inherits that absolute error."""
     stats = ref_parity.run_per_pass(name, frames=3, sensitivity=False, strict=False, ieee=False)
     rows = stats.table()
-    assert len(rows) >= 10
+    assert len(rows) >= (10 if name != "REFERENCE" else 1)
     bad = [r for r in rows if r["within_1e-3_vec_frac"] < _floor(r, 0.999, 1, DEVICE_EXCEPTIONS)]
     assert not bad, "\n".join("%s %s %s: within 1e-3 (vector) %.6f, max %.3g" % (r["pass"], r["output"], r["format"], r["within_1e-3_vec_frac"], r["max_err"]) for r in bad)
-    if name == "SIGMA_SHADOW":
+    if name.startswith("SIGMA"):
         assert min(r["bit_exact_frac"] for r in rows) >= 0.9999
 
 
