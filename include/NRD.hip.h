@@ -13,8 +13,9 @@
 //   SG / SH      NRD_SG, NRD_SG_ExtractColor / Direction / RoughnessAA, NRD_SG_Rotate, NRD_SG_ResolveDiffuse / Specular,
 //                NRD_SH_ResolveDiffuse / Specular, NRD_SG_ReJitter                                               NRD.hlsli:541-586, 937-1111
 //
-// Build configuration = the library's (nrd::GetLibraryDesc): NRD_NORMAL_ENCODING R10G10B10A2_UNORM (oct-packed normal, 2 bits of
-// material id), NRD_ROUGHNESS_ENCODING LINEAR. All functions are __host__ __device__ (the same code serves a CPU reference of the
+// Build configuration = the library's (nrd::GetLibraryDesc().normalEncoding / roughnessEncoding): define NRD_NORMAL_ENCODING (0..4) and NRD_ROUGHNESS_ENCODING (0..2) to the
+// values the linked libNRD_hip.so was built with before including this file, as the reference asks for NRDEncoding.hlsli (NRD.hlsli:290-309); undefined, they take the
+// library's defaults R10G10B10A2_UNORM (oct-packed normal, 2 bits of material id) and LINEAR. All functions are __host__ __device__ (the same code serves a CPU reference of the
 // application) and use only fp32 arithmetic; "sanitize" keeps the reference default (true).
 // Include from a .hip / hipcc translation unit; needs nothing from libNRD_hip.so.
 #pragma once
@@ -25,6 +26,22 @@
 #include <stdint.h>
 
 #define NRD_HIP_FN __host__ __device__ inline
+
+// normal encoding variants (match nrd::NormalEncoding) and roughness encoding variants (match nrd::RoughnessEncoding): reference NRD.hlsli:298-309
+#define NRD_NORMAL_ENCODING_RGBA8_UNORM 0
+#define NRD_NORMAL_ENCODING_RGBA8_SNORM 1
+#define NRD_NORMAL_ENCODING_R10G10B10A2_UNORM 2 // supports material ID bits
+#define NRD_NORMAL_ENCODING_RGBA16_UNORM 3
+#define NRD_NORMAL_ENCODING_RGBA16_SNORM 4
+#define NRD_ROUGHNESS_ENCODING_SQ_LINEAR 0   // linearRoughness * linearRoughness
+#define NRD_ROUGHNESS_ENCODING_LINEAR 1      // linearRoughness
+#define NRD_ROUGHNESS_ENCODING_SQRT_LINEAR 2 // sqrt( linearRoughness )
+#ifndef NRD_NORMAL_ENCODING
+#define NRD_NORMAL_ENCODING NRD_NORMAL_ENCODING_R10G10B10A2_UNORM
+#endif
+#ifndef NRD_ROUGHNESS_ENCODING
+#define NRD_ROUGHNESS_ENCODING NRD_ROUGHNESS_ENCODING_LINEAR
+#endif
 
 #define NRD_FP16_MAX 65504.0f
 #define NRD_PI 3.14159265358979323846f
@@ -254,22 +271,55 @@ NRD_HIP_FN float _NRD_SG_InnerProduct(NRD_SG a, NRD_SG b) {
 // FRONT-END - GENERAL
 //=================================================================================================================================
 
-// IN_NORMAL_ROUGHNESS (the four UNORM channel values of the R10G10B10A2 texel) => X
+// IN_NORMAL_ROUGHNESS (the channel values of the texel as a texture unit returns them) => X                 reference NRD.hlsli:600-637
 NRD_HIP_FN float4 NRD_FrontEnd_UnpackNormalAndRoughness(float4 p, float& materialID) {
-    float3 n = _NRD_DecodeUnitVector(make_float2(p.x, p.y), false, false);
+    float3 n;
+    float r;
+#if (NRD_NORMAL_ENCODING == NRD_NORMAL_ENCODING_R10G10B10A2_UNORM)
+    n = _NRD_DecodeUnitVector(make_float2(p.x, p.y), false, false);
+    r = p.z;
     materialID = p.w * 3.0f;
+#else
+#if (NRD_NORMAL_ENCODING == NRD_NORMAL_ENCODING_RGBA8_UNORM || NRD_NORMAL_ENCODING == NRD_NORMAL_ENCODING_RGBA16_UNORM)
+    n = make_float3(p.x * 2.0f - 1.0f, p.y * 2.0f - 1.0f, p.z * 2.0f - 1.0f);
+#else
+    n = make_float3(p.x, p.y, p.z);
+#endif
+    r = p.w;
+    materialID = 0.0f;
+#endif
     n = _NRD_SafeNormalize(n);
-    return make_float4(n.x, n.y, n.z, p.z);
+#if (NRD_ROUGHNESS_ENCODING == NRD_ROUGHNESS_ENCODING_SQRT_LINEAR)
+    r *= r;
+#elif (NRD_ROUGHNESS_ENCODING == NRD_ROUGHNESS_ENCODING_SQ_LINEAR)
+    r = sqrtf(nrd_hip_detail::saturate(r));
+#endif
+    return make_float4(n.x, n.y, n.z, r);
 }
 NRD_HIP_FN float4 NRD_FrontEnd_UnpackNormalAndRoughness(float4 p) {
     float unused;
     return NRD_FrontEnd_UnpackNormalAndRoughness(p, unused);
 }
 
-// X => IN_NORMAL_ROUGHNESS (UNORM channel values; store with NRD_StoreR10G10B10A2)
+// X => IN_NORMAL_ROUGHNESS (channel values; store with NRD_StoreNormalRoughnessTexel)                         reference NRD.hlsli:640-667
 NRD_HIP_FN float4 NRD_FrontEnd_PackNormalAndRoughness(float3 N, float roughness, float materialID) {
+#if (NRD_ROUGHNESS_ENCODING == NRD_ROUGHNESS_ENCODING_SQRT_LINEAR)
+    roughness = sqrtf(nrd_hip_detail::saturate(roughness));
+#elif (NRD_ROUGHNESS_ENCODING == NRD_ROUGHNESS_ENCODING_SQ_LINEAR)
+    roughness *= roughness;
+#endif
+#if (NRD_NORMAL_ENCODING == NRD_NORMAL_ENCODING_R10G10B10A2_UNORM)
     float2 e = _NRD_EncodeUnitVector(N, false);
     return make_float4(e.x, e.y, roughness, nrd_hip_detail::saturate(materialID / 3.0f));
+#else
+    (void)materialID; // these encodings carry none
+    const float m = fmaxf(fabsf(N.x), fmaxf(fabsf(N.y), fabsf(N.z))); // best fit (optional)
+    N = make_float3(N.x / m, N.y / m, N.z / m);
+#if (NRD_NORMAL_ENCODING == NRD_NORMAL_ENCODING_RGBA8_UNORM || NRD_NORMAL_ENCODING == NRD_NORMAL_ENCODING_RGBA16_UNORM)
+    N = make_float3(N.x * 0.5f + 0.5f, N.y * 0.5f + 0.5f, N.z * 0.5f + 0.5f);
+#endif
+    return make_float4(N.x, N.y, N.z, roughness);
+#endif
 }
 
 // the texel word of an R10_G10_B10_A2_UNORM plane (what nrdHipBindResource expects for IN_NORMAL_ROUGHNESS)
@@ -279,6 +329,51 @@ NRD_HIP_FN uint32_t NRD_StoreR10G10B10A2(float4 unorm) {
 }
 NRD_HIP_FN float4 NRD_LoadR10G10B10A2(uint32_t word) {
     return make_float4(float(word & 0x3FFu) / 1023.0f, float((word >> 10) & 0x3FFu) / 1023.0f, float((word >> 20) & 0x3FFu) / 1023.0f, float(word >> 30) / 3.0f);
+}
+
+// the texel of the format nrdHipBindResource expects for IN_NORMAL_ROUGHNESS under the library's encoding: RGBA8_UNORM / RGBA8_SNORM / R10_G10_B10_A2_UNORM (one 32-bit word,
+// channel x in the low bits), RGBA16_UNORM / RGBA16_SNORM (64 bits, channel x in the low 16). UNORM: floor(saturate(v) * max + 0.5); SNORM: clamp, scale, round half away from 0
+#if (NRD_NORMAL_ENCODING <= NRD_NORMAL_ENCODING_R10G10B10A2_UNORM)
+typedef uint32_t NRD_NormalRoughnessTexel;
+#else
+typedef uint64_t NRD_NormalRoughnessTexel;
+#endif
+NRD_HIP_FN NRD_NormalRoughnessTexel NRD_StoreNormalRoughnessTexel(float4 p) {
+    using namespace nrd_hip_detail;
+    const float v[4] = {p.x, p.y, p.z, p.w};
+    (void)v;
+#if (NRD_NORMAL_ENCODING == NRD_NORMAL_ENCODING_R10G10B10A2_UNORM)
+    return NRD_StoreR10G10B10A2(p);
+#elif (NRD_NORMAL_ENCODING == NRD_NORMAL_ENCODING_RGBA8_UNORM)
+    return toUnorm(p.x, 255.0f) | (toUnorm(p.y, 255.0f) << 8) | (toUnorm(p.z, 255.0f) << 16) | (toUnorm(p.w, 255.0f) << 24);
+#elif (NRD_NORMAL_ENCODING == NRD_NORMAL_ENCODING_RGBA16_UNORM)
+    return (uint64_t)toUnorm(p.x, 65535.0f) | ((uint64_t)toUnorm(p.y, 65535.0f) << 16) | ((uint64_t)toUnorm(p.z, 65535.0f) << 32) | ((uint64_t)toUnorm(p.w, 65535.0f) << 48);
+#else
+    const float scale = NRD_NORMAL_ENCODING == NRD_NORMAL_ENCODING_RGBA8_SNORM ? 127.0f : 32767.0f;
+    const int bits = NRD_NORMAL_ENCODING == NRD_NORMAL_ENCODING_RGBA8_SNORM ? 8 : 16;
+    NRD_NormalRoughnessTexel t = 0;
+    for (int k = 0; k < 4; k++) {
+        const float c = fminf(fmaxf(v[k], -1.0f), 1.0f) * scale;
+        const int32_t i = c >= 0.0f ? (int32_t)floorf(c + 0.5f) : -(int32_t)floorf(-c + 0.5f);
+        t |= (NRD_NormalRoughnessTexel)((uint32_t)i & ((1u << bits) - 1u)) << (bits * k);
+    }
+    return t;
+#endif
+}
+NRD_HIP_FN float4 NRD_LoadNormalRoughnessTexel(NRD_NormalRoughnessTexel t) {
+#if (NRD_NORMAL_ENCODING == NRD_NORMAL_ENCODING_R10G10B10A2_UNORM)
+    return NRD_LoadR10G10B10A2(t);
+#elif (NRD_NORMAL_ENCODING == NRD_NORMAL_ENCODING_RGBA8_UNORM)
+    return make_float4(float(t & 0xFFu) / 255.0f, float((t >> 8) & 0xFFu) / 255.0f, float((t >> 16) & 0xFFu) / 255.0f, float(t >> 24) / 255.0f);
+#elif (NRD_NORMAL_ENCODING == NRD_NORMAL_ENCODING_RGBA8_SNORM)
+    return make_float4(fmaxf(float((int8_t)(t & 0xFFu)) / 127.0f, -1.0f), fmaxf(float((int8_t)((t >> 8) & 0xFFu)) / 127.0f, -1.0f), fmaxf(float((int8_t)((t >> 16) & 0xFFu)) / 127.0f, -1.0f),
+        fmaxf(float((int8_t)(t >> 24)) / 127.0f, -1.0f));
+#elif (NRD_NORMAL_ENCODING == NRD_NORMAL_ENCODING_RGBA16_UNORM)
+    return make_float4(float(t & 0xFFFFu) / 65535.0f, float((t >> 16) & 0xFFFFu) / 65535.0f, float((t >> 32) & 0xFFFFu) / 65535.0f, float(t >> 48) / 65535.0f);
+#else
+    return make_float4(fmaxf(float((int16_t)(t & 0xFFFFu)) / 32767.0f, -1.0f), fmaxf(float((int16_t)((t >> 16) & 0xFFFFu)) / 32767.0f, -1.0f),
+        fmaxf(float((int16_t)((t >> 32) & 0xFFFFu)) / 32767.0f, -1.0f), fmaxf(float((int16_t)(t >> 48)) / 32767.0f, -1.0f));
+#endif
 }
 
 // material de-modulation factors: divide irradiance by them before NRD, multiply the denoised radiance by them after

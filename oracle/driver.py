@@ -10,7 +10,10 @@ import os
 import numpy as np
 
 _DIR = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_DIR, "liboracle.so")
+# the G-buffer encoding is a build configuration of the whole stack (raytracingdenoiser_amd/build.py encoding()): a non-default pair has its own oracle libraries
+_NE, _RE = int(os.environ.get("NRD_NORMAL_ENCODING", "2")), int(os.environ.get("NRD_ROUGHNESS_ENCODING", "1"))
+ENCODING_SUFFIX = "" if (_NE, _RE) == (2, 1) else "_enc%d%d" % (_NE, _RE)
+LIB_PATH = os.path.join(_DIR, "liboracle%s.so" % ENCODING_SUFFIX)
 
 
 class OraclePlane(C.Structure):
@@ -180,9 +183,10 @@ class OracleExecutor:
 
 
 # ---- oracle/_ref: the reference's own HLSL shaders compiled as C++ (oracle/ref/Makefile) ------------------------------------------------------------
-REF_LIB_PATH = os.path.join(_DIR, "_ref", "libnrdref.so")
+_REF_DIR = os.path.join(_DIR, "_ref", ENCODING_SUFFIX.lstrip("_")) if ENCODING_SUFFIX else os.path.join(_DIR, "_ref")  # (oracle/ref/Makefile "enc": one denoiser per family + RELAX SH)
+REF_LIB_PATH = os.path.join(_REF_DIR, "libnrdref.so")
 REF_VO_LIB_PATH = os.path.join(_DIR, "_ref", "libnrdref_vo.so")  # the NRD_USE_VIEWPORT_OFFSET = 1 build of one denoiser per family (oracle/ref/Makefile "vo")
-REF_HOST_LIB_PATH = os.path.join(_DIR, "_ref", "libnrdhost.so")  # the reference's own HOST sources (Source/*.cpp) over a MathLib stand-in (oracle/ref/host/Makefile)
+REF_HOST_LIB_PATH = os.path.join(_REF_DIR, "libnrdhost.so")  # the reference's own HOST sources (Source/*.cpp) over a MathLib stand-in (oracle/ref/host/Makefile)
 _ref_libs = {}
 
 
@@ -283,7 +287,7 @@ def load_strict():
     """oracle/liboracle_strict.so: the oracle's sources without contraction and with true divisions, always in IEEE mode (oracle/Makefile)"""
     global _strict_lib
     if _strict_lib is None:
-        path = os.path.join(_DIR, "liboracle_strict.so")
+        path = os.path.join(_DIR, "liboracle_strict%s.so" % ENCODING_SUFFIX)
         if not os.path.exists(path):
             raise RuntimeError("oracle/liboracle_strict.so not built: run `make -C oracle all`")
         lib = C.CDLL(path)

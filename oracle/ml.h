@@ -14,7 +14,15 @@ namespace orc {
 constexpr float NRD_FP16_MAX = 65504.0f;
 constexpr float NRD_EPS = 1e-6f;
 constexpr float NRD_INF = 1e6f;
-constexpr float NRD_NORMAL_ENCODING_ERROR = 0.75f / 255.0f; // [com] Common.hlsli:76-78, R10G10B10A2 encoding
+// the library's G-buffer encoding: a build configuration of the whole stack (CMakeLists.txt:28-29; oracle/Makefile SUFFIX / EXTRA), default R10G10B10A2_UNORM + LINEAR
+#ifndef NRD_NORMAL_ENCODING
+#define NRD_NORMAL_ENCODING 2
+#endif
+#ifndef NRD_ROUGHNESS_ENCODING
+#define NRD_ROUGHNESS_ENCODING 1
+#endif
+constexpr float NRD_NORMAL_ENCODING_ERROR = (NRD_NORMAL_ENCODING < 2 ? 1.5f : NRD_NORMAL_ENCODING == 2 ? 0.75f : 0.5f) / 255.0f; // [com] Common.hlsli:76-85
+constexpr bool NRD_STOCHASTIC_BILINEAR = NRD_NORMAL_ENCODING == 2; // REBLUR_USE_STF == 1 && R10G10B10A2 (Common.hlsli:76-85, 359-372): otherwise gLinearClamp at the unmodified uv
 constexpr float NRD_ROUGHNESS_SENSITIVITY = 0.01f;           // [com] Common.hlsli:66
 constexpr float NRD_EXP_WEIGHT_DEFAULT_SCALE = 3.0f;         // [com] Common.hlsli:65
 constexpr float NRD_CATROM_SHARPNESS = 0.5f;                 // [com] Common.hlsli:63
@@ -260,19 +268,50 @@ inline float3 _NRD_YCoCgToLinear(float3 c) { // NRD.hlsli:365-375
 inline float _REBLUR_GetHitDistanceNormalization(float viewZ, float4 hitDistParams, float roughness) { // NRD.hlsli:520-523
     return (hitDistParams.x + fabsf(viewZ) * hitDistParams.y) * lerp(1.0f, hitDistParams.z, SatExp2(hitDistParams.w * roughness * roughness));
 }
-// NRD.hlsli:600-637 with NRD_NORMAL_ENCODING = R10G10B10A2_UNORM (2), NRD_ROUGHNESS_ENCODING = LINEAR (1)
+// NRD.hlsli:600-637
 inline float4 NRD_FrontEnd_UnpackNormalAndRoughness(float4 p, float& materialID) {
+    float4 r;
+#if NRD_NORMAL_ENCODING == 2
     float3 n = _NRD_DecodeUnitVector(float2(p.x, p.y));
+    r.w = p.z;
     materialID = p.w * 3.0f;
-    return float4(_NRD_SafeNormalize(n), p.z);
+#else
+#if NRD_NORMAL_ENCODING == 0 || NRD_NORMAL_ENCODING == 3
+    float3 n = float3(p.x * 2.0f - 1.0f, p.y * 2.0f - 1.0f, p.z * 2.0f - 1.0f);
+#else
+    float3 n = p.xyz();
+#endif
+    r.w = p.w;
+    materialID = 0.0f;
+#endif
+    n = _NRD_SafeNormalize(n);
+#if NRD_ROUGHNESS_ENCODING == 2
+    r.w *= r.w;
+#elif NRD_ROUGHNESS_ENCODING == 0
+    r.w = HwSqrt(saturate(r.w));
+#endif
+    return float4(n, r.w);
 }
 inline float4 NRD_FrontEnd_UnpackNormalAndRoughness(float4 p) {
     float unused;
     return NRD_FrontEnd_UnpackNormalAndRoughness(p, unused);
 }
 inline float4 NRD_FrontEnd_PackNormalAndRoughness(float3 N, float roughness, float materialID) { // NRD.hlsli:640-667
+#if NRD_ROUGHNESS_ENCODING == 2
+    roughness = HwSqrt(saturate(roughness));
+#elif NRD_ROUGHNESS_ENCODING == 0
+    roughness *= roughness;
+#endif
+#if NRD_NORMAL_ENCODING == 2
     float2 e = _NRD_EncodeUnitVector(N);
     return float4(e.x, e.y, roughness, saturate(materialID / 3.0f));
+#else
+    N = N / max(fabsf(N.x), max(fabsf(N.y), fabsf(N.z))); // best fit (optional)
+#if NRD_NORMAL_ENCODING == 0 || NRD_NORMAL_ENCODING == 3
+    N = N * 0.5f + 0.5f;
+#endif
+    return float4(N, roughness);
+#endif
 }
 inline float REBLUR_FrontEnd_GetNormHitDist(float hitDist, float viewZ, float4 hitDistParams, float roughness) { // NRD.hlsli:722-727
     return saturate(hitDist / _REBLUR_GetHitDistanceNormalization(viewZ, hitDistParams, roughness));

@@ -587,7 +587,12 @@ void PostBlur(const PassIO& io) {
                 continue;
             s.data1 = UnpackData1(gIn_Data1.Load(px, py), DIFF);
 
-            gOut_Normal_Roughness.CopyTexelFrom(gIn_Normal_Roughness, px, py, 4); // same R10G10B10A2 format: the packed value round-trips exactly
+            // REBLUR_PostBlur.hlsli:47 stores the float4 it loaded: the same format on both sides for encodings 0..3 (the texel round-trips exactly: a copy of its
+            // 4 / 8 bytes), SNORM16 -> fp16 for encoding 4 (Reblur.cpp:52-62)
+            if (NRD_NORMAL_ENCODING == 4)
+                gOut_Normal_Roughness.Store(px, py, gIn_Normal_Roughness.Load(px, py));
+            else
+                gOut_Normal_Roughness.CopyTexelFrom(gIn_Normal_Roughness, px, py, NRD_NORMAL_ENCODING <= 2 ? 4 : 8);
             if (NO_TS)
                 gOut_InternalData->StoreUint(px, py, PackInternalData(s.data1.x + 1.0f, s.data1.y + 1.0f, s.materialID));
 
@@ -964,8 +969,10 @@ void TemporalAccumulation(const PassIO& io) {
                 Filtering::Bilinear vmbBilinearFilter = Filtering::GetBilinearFilter(vmbPixelUv, c.gRectSizePrev);
                 int vx = (int)vmbBilinearFilter.origin.x, vy = (int)vmbBilinearFilter.origin.y;
                 float2 relaxedRoughnessWeightParams = GetRelaxedRoughnessWeightParams(roughness * roughness, c.gRoughnessFraction, REBLUR_ROUGHNESS_SENSITIVITY_IN_TA);
-                float4 vmbRoughness = float4(gPrev_Normal_Roughness.FetchClamped(vx, vy).z, gPrev_Normal_Roughness.FetchClamped(vx + 1, vy).z,
-                    gPrev_Normal_Roughness.FetchClamped(vx, vy + 1).z, gPrev_Normal_Roughness.FetchClamped(vx + 1, vy + 1).z);
+                // (REBLUR_TemporalAccumulation.hlsli:463-467: GatherBlue for R10G10B10A2, GatherAlpha for the RGBA encodings -- the STORED roughness either way)
+                constexpr int RC = NRD_NORMAL_ENCODING == 2 ? 2 : 3;
+                float4 vmbRoughness = float4(gPrev_Normal_Roughness.FetchClamped(vx, vy)[RC], gPrev_Normal_Roughness.FetchClamped(vx + 1, vy)[RC],
+                    gPrev_Normal_Roughness.FetchClamped(vx, vy + 1)[RC], gPrev_Normal_Roughness.FetchClamped(vx + 1, vy + 1)[RC]);
                 float4 roughnessWeight;
                 for (int k = 0; k < 4; k++)
                     roughnessWeight[k] = ComputeNonExponentialWeightWithSigma(vmbRoughness[k] * vmbRoughness[k], relaxedRoughnessWeightParams.x, relaxedRoughnessWeightParams.y, roughnessSigma);
@@ -976,6 +983,8 @@ void TemporalAccumulation(const PassIO& io) {
 
                 // Virtual motion - normal: parallax. Stochastic nearest tap of the bilinear footprint (REBLUR_USE_STF = 1)
                 auto stochasticBilinearFetch = [&](float2 uv) {
+                    if (!NRD_STOCHASTIC_BILINEAR) // Common.hlsli:76-85, 359-372: gLinearClamp at the unmodified uv, no draws (every encoding but R10G10B10A2)
+                        return NRD_FrontEnd_UnpackNormalAndRoughness(gPrev_Normal_Roughness.SampleLinearTexel(uv * c.gResolutionScalePrev * float2(float(gPrev_Normal_Roughness.W()), float(gPrev_Normal_Roughness.H()))));
                     Filtering::Bilinear f = Filtering::GetBilinearFilter(uv, c.gRectSizePrev);
                     float2 rnd = rng.GetFloat2();
                     f.origin += step(rnd, f.weights);
@@ -1089,7 +1098,8 @@ void TemporalAccumulation(const PassIO& io) {
                     float2 w;
                     w.x = GetEncodingAwareNormalWeight(vmbNormalAndRoughness.xyz(), vmbNormalAndRoughnessPrev.xyz(), lobeHalfAngle, curvatureAngle * (1.0f + i * stepBetweenTaps), REBLUR_NORMAL_ULP);
                     w.y = ComputeNonExponentialWeightWithSigma(vmbNormalAndRoughnessPrev.w * vmbNormalAndRoughnessPrev.w, relaxedRoughnessWeightParams.x, relaxedRoughnessWeightParams.y, roughnessSigma);
-                    w = lerp(float2(1.0f), w, saturate(stepBetweenTaps)); // cures "StochasticBilinear" issues
+                    if (NRD_STOCHASTIC_BILINEAR)
+                        w = lerp(float2(1.0f), w, saturate(stepBetweenTaps)); // cures "StochasticBilinear" issues (`:599-602`)
                     w = IsInScreenNearest(vmbPixelUvPrev) != 0.0f ? w : float2(1.0f);
 
                     virtualHistoryNormalBasedConfidence = min(virtualHistoryNormalBasedConfidence, w.x);

@@ -29,12 +29,12 @@ SEMANTICS = {"SV_GroupThreadId": "groupThreadId", "SV_GroupId": "groupId", "SV_D
              "SV_GroupThreadID": "groupThreadId", "SV_GroupID": "groupId", "SV_DispatchThreadID": "dispatchThreadId"}
 
 
-def preprocess(entry, reference, include_first=None):
+def preprocess(entry, reference, include_first=None, encoding=(2, 1)):
     """include_first: a directory searched in front of the reference's own Include directory (the viewport-offset build of oracle/ref/Makefile puts a Common.hlsli there whose
     NRD_USE_VIEWPORT_OFFSET is 1 -- the reference makes that switch an edit of the file, Common.hlsli:64)"""
     shaders = os.path.join(reference, "Shaders")
     cmd = [CLANG, "-E", "-x", "c", "-undef", "-nostdinc", "-Wno-everything", "-I", HERE] + (["-I", include_first] if include_first else []) + ["-I", os.path.join(shaders, "Include"), "-I", os.path.join(shaders, "Resources"),
-           "-include", os.path.join(HERE, "prelude.hlsli"), "-DNRD_NORMAL_ENCODING=2", "-DNRD_ROUGHNESS_ENCODING=1", entry]
+           "-include", os.path.join(HERE, "prelude.hlsli"), "-DNRD_NORMAL_ENCODING=%d" % encoding[0], "-DNRD_ROUGHNESS_ENCODING=%d" % encoding[1], entry]
     return subprocess.run(cmd, check=True, capture_output=True, text=True).stdout
 
 
@@ -126,6 +126,12 @@ def main():
         i = args.index("--include-first")
         include_first = args[i + 1]
         del args[i:i + 2]
+    encoding = [2, 1]  # the reference's CMake defaults (CMakeLists.txt:28-29); oracle/ref/Makefile "enc" builds others
+    for k, flag in enumerate(("--normal-encoding", "--roughness-encoding")):
+        if flag in args:
+            i = args.index(flag)
+            encoding[k] = int(args[i + 1])
+            del args[i:i + 2]
     keep = "--keep-preprocessed" in args
     if keep:
         args.remove("--keep-preprocessed")
@@ -133,7 +139,7 @@ def main():
     name = os.path.basename(entry)
     assert name.endswith(".cs.hlsl"), name
     shader_name = name[:-len(".hlsl")]
-    pre = preprocess(entry, reference, include_first)
+    pre = preprocess(entry, reference, include_first, tuple(encoding))
     if keep:
         with open(out + ".i", "w") as fp:
             fp.write(pre)

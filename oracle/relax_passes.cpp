@@ -1402,7 +1402,8 @@ void AtrousSmem(const PassIO& io) {
             if (centerViewZ > c.gDenoisingRange)
                 normalRoughness = float4(1.0f / 255.0f);
             gOut_NormalRoughness.Store(px, py, PackPrevNormalRoughness(normalRoughness));
-            gOut_MaterialID.Store(px, py, DivConst(centerMaterialID, 255.0f));
+            if (NRD_NORMAL_ENCODING == 2) // RELAX_AtrousSmem.hlsli:139-141: only the R10G10B10A2 encoding carries material IDs
+                gOut_MaterialID.Store(px, py, DivConst(centerMaterialID, 255.0f));
 
             if (isSky != 0.0f || px >= rectW || py >= rectH)
                 continue;

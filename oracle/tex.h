@@ -19,9 +19,11 @@ enum Fmt : uint32_t {
     FMT_R8_UINT = 2,
     FMT_RG8_UNORM = 4,
     FMT_RGBA8_UNORM = 8,
+    FMT_RGBA8_SNORM = 9,
     FMT_R16_UNORM = 13,
     FMT_R16_UINT = 15,
     FMT_R16_SFLOAT = 17,
+    FMT_RGBA16_UNORM = 23,
     FMT_RGBA16_SNORM = 24,
     FMT_RGBA16_SFLOAT = 27,
     FMT_R32_UINT = 28,
@@ -121,6 +123,14 @@ struct Tex {
                 return float4(float(r[x * 2]) / 255.0f, float(r[x * 2 + 1]) / 255.0f, 0, 0);
             case FMT_RGBA8_UNORM:
                 return float4(float(r[x * 4]) / 255.0f, float(r[x * 4 + 1]) / 255.0f, float(r[x * 4 + 2]) / 255.0f, float(r[x * 4 + 3]) / 255.0f);
+            case FMT_RGBA8_SNORM: { // (IN_NORMAL_ROUGHNESS / PREV_NORMAL_ROUGHNESS of NRD_NORMAL_ENCODING 1: ml.h)
+                const int8_t* b = (const int8_t*)r + x * 4;
+                return float4(max(float(b[0]) / 127.0f, -1.0f), max(float(b[1]) / 127.0f, -1.0f), max(float(b[2]) / 127.0f, -1.0f), max(float(b[3]) / 127.0f, -1.0f));
+            }
+            case FMT_RGBA16_UNORM: { // (NRD_NORMAL_ENCODING 3)
+                const uint16_t* h = (const uint16_t*)r + x * 4;
+                return float4(float(h[0]) / 65535.0f, float(h[1]) / 65535.0f, float(h[2]) / 65535.0f, float(h[3]) / 65535.0f);
+            }
             case FMT_R10_G10_B10_A2_UNORM: {
                 uint32_t v = ((const uint32_t*)r)[x];
                 return float4(float(v & 0x3FFu) / 1023.0f, float((v >> 10) & 0x3FFu) / 1023.0f, float((v >> 20) & 0x3FFu) / 1023.0f, float(v >> 30) / 3.0f);
@@ -217,6 +227,20 @@ struct Tex {
                 r[x * 4] = (uint8_t)ToUnorm(v.x, 255.0f), r[x * 4 + 1] = (uint8_t)ToUnorm(v.y, 255.0f), r[x * 4 + 2] = (uint8_t)ToUnorm(v.z, 255.0f),
                 r[x * 4 + 3] = (uint8_t)ToUnorm(v.w, 255.0f);
                 break;
+            case FMT_RGBA8_SNORM: {
+                int8_t* b = (int8_t*)r + x * 4;
+                const float q[4] = {v.x, v.y, v.z, v.w};
+                for (int k = 0; k < 4; k++) { // clamp, scale, round half away from zero (as ToSnorm16)
+                    float t = min(max(q[k], -1.0f), 1.0f) * 127.0f;
+                    b[k] = (int8_t)(t >= 0.0f ? (int32_t)floorf(t + 0.5f) : -(int32_t)floorf(-t + 0.5f));
+                }
+                break;
+            }
+            case FMT_RGBA16_UNORM: {
+                uint16_t* h = (uint16_t*)r + x * 4;
+                h[0] = (uint16_t)ToUnorm(v.x, 65535.0f), h[1] = (uint16_t)ToUnorm(v.y, 65535.0f), h[2] = (uint16_t)ToUnorm(v.z, 65535.0f), h[3] = (uint16_t)ToUnorm(v.w, 65535.0f);
+                break;
+            }
             case FMT_R10_G10_B10_A2_UNORM:
                 ((uint32_t*)r)[x] = ToUnorm(v.x, 1023.0f) | (ToUnorm(v.y, 1023.0f) << 10) | (ToUnorm(v.z, 1023.0f) << 20) | (ToUnorm(v.w, 3.0f) << 30);
                 break;

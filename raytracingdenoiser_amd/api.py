@@ -11,7 +11,19 @@ import os
 
 _PKG = os.path.dirname(os.path.abspath(__file__))
 # the product library (raytracingdenoiser_amd/build.py): one library, one arithmetic (DESIGN.md "Numerics")
-LIB_PATH = os.path.join(_PKG, "lib", "libNRD_hip.so")
+def _encoding():
+    """(NRD_NORMAL_ENCODING, NRD_ROUGHNESS_ENCODING) of the library this process binds: a build configuration, as in the reference (CMakeLists.txt:28-29); build.py builds one
+    library per encoding -- lib/libNRD_hip.so for the default (2, 1), lib/enc<N><R>/libNRD_hip.so otherwise -- and the environment variables of the same names pick one"""
+    n, r = int(os.environ.get("NRD_NORMAL_ENCODING", "2")), int(os.environ.get("NRD_ROUGHNESS_ENCODING", "1"))
+    if not (0 <= n <= 4 and 0 <= r <= 2):
+        raise ValueError("NRD_NORMAL_ENCODING must be 0..4 and NRD_ROUGHNESS_ENCODING 0..2, got %d / %d" % (n, r))
+    return n, r
+
+
+NORMAL_ENCODING, ROUGHNESS_ENCODING = _encoding()
+ENCODING_SUFFIX = "" if (NORMAL_ENCODING, ROUGHNESS_ENCODING) == (2, 1) else "_enc%d%d" % (NORMAL_ENCODING, ROUGHNESS_ENCODING)
+NORMAL_ROUGHNESS_FORMAT_NAME = ["RGBA8_UNORM", "RGBA8_SNORM", "R10_G10_B10_A2_UNORM", "RGBA16_UNORM", "RGBA16_SNORM"][NORMAL_ENCODING]  # the format IN_NORMAL_ROUGHNESS is bound in
+LIB_PATH = os.path.join(_PKG, "lib", ENCODING_SUFFIX.lstrip("_"), "libNRD_hip.so") if ENCODING_SUFFIX else os.path.join(_PKG, "lib", "libNRD_hip.so")
 
 
 # ----------------------------------------------------------------------------------------------- enums
@@ -53,7 +65,7 @@ Format = enum.IntEnum("Format", {n: i for i, n in enumerate(_FORMATS)})
 
 FORMAT_BYTES = {
     Format.R8_UNORM: 1, Format.R8_UINT: 1, Format.RG8_UNORM: 2, Format.R16_UINT: 2, Format.R16_SFLOAT: 2, Format.R16_UNORM: 2,
-    Format.RGBA8_UNORM: 4, Format.R32_UINT: 4, Format.R32_SFLOAT: 4, Format.R10_G10_B10_A2_UNORM: 4, Format.RG16_SFLOAT: 4,
+    Format.RGBA8_UNORM: 4, Format.RGBA8_SNORM: 4, Format.RGBA16_UNORM: 8, Format.R32_UINT: 4, Format.R32_SFLOAT: 4, Format.R10_G10_B10_A2_UNORM: 4, Format.RG16_SFLOAT: 4,
     Format.RGBA16_SFLOAT: 8, Format.RGBA16_SNORM: 8, Format.RGBA32_SFLOAT: 16, Format.R11_G11_B10_UFLOAT: 4,
 }
 

@@ -39,6 +39,32 @@ DEVICE_NUMERICS_FLAGS = ["-ffp-contract=on"]
 HOST_NUMERICS_FLAGS = ["-ffp-contract=off"]
 
 
+def encoding():
+    """(NRD_NORMAL_ENCODING, NRD_ROUGHNESS_ENCODING) of this build: a BUILD configuration of the whole stack, as in the reference (CMakeLists.txt:28-29), taken from the environment
+    variables of the same names; default (2, 1) = R10_G10_B10_A2_UNORM + LINEAR. Every native piece -- the product, the oracle, oracle/_ref, tests/emu -- is built per encoding into
+    its own file (suffix below), so one checkout holds several and a process picks one through its environment."""
+    n, r = int(os.environ.get("NRD_NORMAL_ENCODING", "2")), int(os.environ.get("NRD_ROUGHNESS_ENCODING", "1"))
+    if not (0 <= n <= 4 and 0 <= r <= 2):
+        raise ValueError("NRD_NORMAL_ENCODING must be 0..4 and NRD_ROUGHNESS_ENCODING 0..2 (nrd::NormalEncoding / nrd::RoughnessEncoding), got %d / %d" % (n, r))
+    return n, r
+
+
+def encoding_suffix():
+    n, r = encoding()
+    return "" if (n, r) == (2, 1) else "_enc%d%d" % (n, r)
+
+
+def encoding_flags():
+    n, r = encoding()
+    return [] if (n, r) == (2, 1) else ["-DNRD_NORMAL_ENCODING=%d" % n, "-DNRD_ROUGHNESS_ENCODING=%d" % r]
+
+
+def product_path():
+    """lib/libNRD_hip.so, or lib/enc<N><R>/libNRD_hip.so for a non-default encoding (same file name: it is the library an application links)"""
+    sfx = encoding_suffix()
+    return os.path.join(LIB_DIR, sfx.lstrip("_"), LIB_NAME) if sfx else os.path.join(LIB_DIR, LIB_NAME)
+
+
 def _sources():
     host = sorted(os.path.join(CSRC, "host", f) for f in os.listdir(os.path.join(CSRC, "host")) if f.endswith(".cpp"))
     hip = sorted(os.path.join(CSRC, "hip", f) for f in os.listdir(os.path.join(CSRC, "hip")) if f.endswith(".hip"))
@@ -59,8 +85,8 @@ def _headers_digest():
 def _flags(src, extra=()):
     """compiler flags of one translation unit; `extra` = A/B switches of tools/build_variant.py (device sources only)"""
     if src.endswith(".hip"):
-        return COMMON_FLAGS + DEVICE_NUMERICS_FLAGS + HIP_FLAGS + list(extra) + ["-x", "hip"]
-    return COMMON_FLAGS + HOST_NUMERICS_FLAGS + ["-x", "c++"]
+        return COMMON_FLAGS + encoding_flags() + DEVICE_NUMERICS_FLAGS + HIP_FLAGS + list(extra) + ["-x", "hip"]
+    return COMMON_FLAGS + encoding_flags() + HOST_NUMERICS_FLAGS + ["-x", "c++"]
 
 
 def _portable(flags):
@@ -92,7 +118,7 @@ def _compile(src, hdr_digest, verbose, obj_dir, extra=()):
 
 
 def _global_digest(srcs, hdr_digest, extra=()):
-    h = hashlib.sha1((hdr_digest + _portable(COMMON_FLAGS + HIP_FLAGS + DEVICE_NUMERICS_FLAGS + HOST_NUMERICS_FLAGS + list(extra))).encode())
+    h = hashlib.sha1((hdr_digest + _portable(COMMON_FLAGS + encoding_flags() + HIP_FLAGS + DEVICE_NUMERICS_FLAGS + HOST_NUMERICS_FLAGS + list(extra))).encode())
     for s in srcs:
         with open(s, "rb") as fp:
             h.update(fp.read())
@@ -129,12 +155,12 @@ def build_product(verbose=False, out=None, extra=(), obj_dir=None):
 def _build_product(verbose, out, extra, obj_dir):
     host, hip = _sources()
     hdr = _headers_digest()
-    out = out or os.path.join(LIB_DIR, LIB_NAME)
+    out = out or product_path()
     whole = _global_digest(host + hip, hdr, extra)
     if os.path.exists(out) and os.path.exists(out + ".digest") and open(out + ".digest").read() == whole:
         return out  # prebuilt (e.g. shipped to the GPU box) and up to date
     os.makedirs(os.path.dirname(out), exist_ok=True)
-    obj_dir = obj_dir or os.path.join(OBJ_DIR, "product")
+    obj_dir = obj_dir or os.path.join(OBJ_DIR, "product" + encoding_suffix())
     with ThreadPoolExecutor(max_workers=min(8, os.cpu_count() or 1)) as pool:
         objs = list(pool.map(lambda s: _compile(s, hdr, verbose, obj_dir, extra), host + hip))
     cmd = [HIPCC, "-shared", "-fPIC", "--offload-arch=gfx950", "-fno-gpu-rdc"] + objs + ["-o", out]
@@ -148,19 +174,27 @@ def _build_product(verbose, out, extra, obj_dir):
 
 def build_oracle(verbose=False):
     """ROCm's clang (x86-64) on the CPU oracle (test infrastructure). Returns the path of oracle/liboracle.so."""
-    cmd = ["make", "-C", ORACLE_DIR, "-j8"] + ([] if verbose else ["-s"])
+    sfx = encoding_suffix()
+    cmd = ["make", "-C", ORACLE_DIR, "-j8"] + ([] if verbose else ["-s"]) + (["SUFFIX=" + sfx, "EXTRA=" + " ".join(encoding_flags())] if sfx else [])
     with _BuildLock("oracle"):
         subprocess.run(cmd, check=True)
-    return os.path.join(ORACLE_DIR, "liboracle.so")
+    return os.path.join(ORACLE_DIR, "liboracle%s.so" % sfx)
 
 
 def build_ref(verbose=False, reference="/root/reference"):
     """oracle/_ref/libnrdref.so: the reference's own HLSL shaders compiled as C++ (oracle/ref/Makefile). Test infrastructure, like the oracle. Only possible
     where the reference tree is present (the build container); elsewhere the prebuilt library that travelled with the snapshot is used. Returns the path or None."""
-    out = os.path.join(ORACLE_DIR, "_ref", "libnrdref.so")
+    sfx = encoding_suffix()
+    out = os.path.join(ORACLE_DIR, "_ref", sfx.lstrip("_"), "libnrdref.so") if sfx else os.path.join(ORACLE_DIR, "_ref", "libnrdref.so")
     if not os.path.isdir(os.path.join(reference, "Shaders", "Source")):
         return out if os.path.exists(out) else None
     with _BuildLock("ref"):
+        if sfx:  # another encoding: the reference's host and one denoiser per family (oracle/ref/Makefile "enc")
+            n, r = encoding()
+            quiet = [] if verbose else ["-s"]
+            subprocess.run(["make", "-C", os.path.join(ORACLE_DIR, "ref", "host"), "-j8", "REFERENCE=" + reference, "NE=%d" % n, "RE=%d" % r] + quiet, check=True)
+            subprocess.run(["make", "-C", os.path.join(ORACLE_DIR, "ref"), "-j8", "REFERENCE=" + reference, "enc", "NE=%d" % n, "RE=%d" % r] + quiet, check=True)
+            return out
         return _build_ref(verbose, reference, out)
 
 
@@ -170,6 +204,28 @@ def _build_ref(verbose, reference, out):
     for target in ([], ["vo"]):  # "vo": one denoiser per family with NRD_USE_VIEWPORT_OFFSET = 1 (CommonSettings::rectOrigin; oracle/ref/Makefile)
         cmd = ["make", "-C", os.path.join(ORACLE_DIR, "ref"), "-j8", "REFERENCE=" + reference] + target + ([] if verbose else ["-s"])
         subprocess.run(cmd, check=True)
+    return out
+
+
+# the non-default encodings the test-suite exercises (tests/test_encodings.py): all four other normal encodings, both non-linear roughness encodings
+TESTED_ENCODINGS = [(0, 0), (4, 2), (1, 1), (3, 1)]
+
+
+def build_encoding_variants(encodings=TESTED_ENCODINGS, verbose=False, reference="/root/reference"):
+    """product + oracle (+ oracle/_ref where the reference tree is present) of the given non-default encodings; each into its own files (encoding_suffix). Returns the product paths."""
+    out, saved = [], {k: os.environ.get(k) for k in ("NRD_NORMAL_ENCODING", "NRD_ROUGHNESS_ENCODING")}
+    try:
+        for n, r in encodings:
+            os.environ["NRD_NORMAL_ENCODING"], os.environ["NRD_ROUGHNESS_ENCODING"] = str(n), str(r)
+            out.append(build_product(verbose=verbose))
+            build_oracle(verbose=verbose)
+            build_ref(verbose=verbose, reference=reference)
+    finally:
+        for k, v in saved.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
     return out
 
 

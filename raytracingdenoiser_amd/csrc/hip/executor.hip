@@ -5,6 +5,7 @@
 #include "NRD.h"
 #include "NRDHip.h"
 
+#include "nrdmath.h" // NRD_NORMAL_ENCODING
 #include "passes.h"
 
 #include "../common/pass_constants.h"
@@ -60,7 +61,8 @@ nrd::Format ExpectedUserFormat(nrd::ResourceType t, bool translucentShadow) {
     using F = nrd::Format;
     switch (t) {
         case R::IN_MV: return F::RGBA16_SFLOAT;
-        case R::IN_NORMAL_ROUGHNESS: return F::R10_G10_B10_A2_UNORM;
+        case R::IN_NORMAL_ROUGHNESS: // the format of the library's normal encoding (nrdmath.h NRD_NORMAL_ENCODING, nrd::GetLibraryDesc().normalEncoding; reblur_device.h NrRaw)
+            return NRD_NORMAL_ENCODING == 0 ? F::RGBA8_UNORM : NRD_NORMAL_ENCODING == 1 ? F::RGBA8_SNORM : NRD_NORMAL_ENCODING == 2 ? F::R10_G10_B10_A2_UNORM : NRD_NORMAL_ENCODING == 3 ? F::RGBA16_UNORM : F::RGBA16_SNORM;
         case R::IN_VIEWZ: return F::R32_SFLOAT;
         case R::IN_DIFF_CONFIDENCE: case R::IN_SPEC_CONFIDENCE: case R::IN_DISOCCLUSION_THRESHOLD_MIX: return F::R8_UNORM;
         case R::IN_DIFF_RADIANCE_HITDIST: case R::IN_SPEC_RADIANCE_HITDIST: return F::RGBA16_SFLOAT;

@@ -32,7 +32,7 @@ __global__ __launch_bounds__(256) void DecodeGuidesKernel(Plane packed, Plane vi
         StoreR32U(roughnessWord, x, y, 0xFFFFFFFFu);
         return;
     }
-    const float4 d = EncodeDecodedNormalRoughness(LoadR32U(packed, x, y));
+    const float4 d = EncodeDecodedNormalRoughness(LoadNrRaw(packed, x, y));
     StoreRGBA32F(viewPos, x, y, F4(d.x, d.y, d.z, Abs(LoadR32F(viewZ, x, y) * viewZScale)));
     StoreR32U(roughnessWord, x, y, AsUint(d.w));
 }
@@ -69,7 +69,7 @@ __global__ __launch_bounds__(256) void DecodeGuidesRelaxKernel(Plane packed, Pla
         StoreRGBA32F(worldPos, x, y, F4(__uint_as_float(0x7FC00000u)));
         return;
     }
-    StoreRGBA32F(decoded, x, y, EncodeDecodedNormalRoughness(LoadR32U(packed, x, y)));
+    StoreRGBA32F(decoded, x, y, EncodeDecodedNormalRoughness(LoadNrRaw(packed, x, y)));
     const float z = Abs(LoadR32F(viewZ, x, y) * viewZScale);
     const float2 clip = F2(float(x) + 0.5f, float(y) + 0.5f) * rectSizeInv * 2.0f - 1.0f;
     const float3 d = frustumForward + frustumRight * clip.x - frustumUp * clip.y; // relax_device.h WorldPosFromClip, same operation order
@@ -108,7 +108,7 @@ __global__ __launch_bounds__(256) void DecodeGuidesClassifyKernel(Plane packed, 
         allSky = allSky && (RELAX ? Abs(zRaw) : Abs(zRaw * viewZScale)) > denoisingRange;
         if (!inside)
             continue;
-        const float4 d = EncodeDecodedNormalRoughness(LoadR32U(packed, x, y));
+        const float4 d = EncodeDecodedNormalRoughness(LoadNrRaw(packed, x, y));
         const float z = Abs(zRaw * viewZScale);
         if (RELAX) {
             StoreRGBA32F(decoded, x, y, d);

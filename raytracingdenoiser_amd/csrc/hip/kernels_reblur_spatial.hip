@@ -537,7 +537,7 @@ __global__ __launch_bounds__(TILE_X* TILE_Y, NRD_WAVES_REBLUR_SPATIAL) void Rebl
     }
 
     if (MODE == POST_BLUR) {
-        StoreR32U(P.outNormalRoughness, px, py, LoadR32U(P.normalRoughness, px, py)); // packed texel copied verbatim
+        StoreNrRaw(P.outNormalRoughness, px, py, InToPrevNormalRoughnessTexel(LoadNrRaw(P.normalRoughness, px, py))); // the texel as read (reblur_device.h: a copy of the bits, fp16 for encoding 4)
         if (NO_TS)
             StoreR16U(P.outInternalData, px, py, PackInternalData(s.data1.x + 1.0f, s.data1.y + 1.0f, s.materialID));
     }

@@ -1,5 +1,5 @@
 // REBLUR TemporalAccumulation as a HIP kernel for gfx950.
-//   reference Shaders/Include/REBLUR_TemporalAccumulation.hlsli:11-931 (quality mode, R10G10B10A2 normals, no optional inputs)
+//   reference Shaders/Include/REBLUR_TemporalAccumulation.hlsli:11-931 (the library's normal encoding: nrdmath.h NRD_NORMAL_ENCODING)
 //
 // MI355X mapping. 32x8-pixel workgroups (4 waves of 2 rows x 32 px). The 3x3 neighbourhood statistics (averaged
 // normal, roughness variance, minimum hit distance for tracking) and the two curvature edge normals come from a
@@ -103,7 +103,7 @@ __device__ __forceinline__ void ReblurTemporalAccumulationTile(const ReblurCB& c
     __shared__ float s_HitDistForTracking[BUF_Y * BUF_STRIDE];
     constexpr int WIN_TEXELS = MODE == 1 ? WIN_W * WIN_H : 1;
     __shared__ float s_WinZ[WIN_TEXELS];       // packed previous viewZ
-    __shared__ uint32_t s_WinN[WIN_TEXELS];    // packed previous normal / roughness
+    __shared__ NrRaw s_WinN[WIN_TEXELS];       // packed previous normal / roughness
     __shared__ uint32_t s_WinId[WIN_TEXELS];   // previous internal data (16 bits)
     __shared__ uint32_t s_WinFast[WIN_TEXELS]; // fast histories: diffuse in the low, specular in the high half
     __shared__ uint2 s_WinDiff[WIN_TEXELS], s_WinSpec[WIN_TEXELS]; // RGBA16F history texels, undecoded
@@ -263,7 +263,7 @@ __device__ __forceinline__ void ReblurTemporalAccumulationTile(const ReblurCB& c
     S diff = Sig::Zero(), spec = Sig::Zero();
     float4 smbViewZ0, smbViewZ1, smbViewZ2, smbViewZ3;
     uint32_t id0[4], id1[4], id2[4], id3[4];
-    uint32_t n00, n10, n01, n11; // packed texels of the 2x2 normal footprint (0 outside the plane, as Load returns)
+    NrRaw n00, n10, n01, n11; // packed texels of the 2x2 normal footprint (0 outside the plane, as Load returns)
     int wx0 = 0, wy0 = 0;        // MODE 1: plane coordinates of the window's first texel
     if (MODE == 1) {
         // ---- the window: bounding box of the clamped texel coordinates this workgroup's pixels read at the surface-motion position
@@ -303,7 +303,7 @@ __device__ __forceinline__ void ReblurTemporalAccumulationTile(const ReblurCB& c
             for (int r = wave; r < bh; r += 4) {
                 const int x = wx0 + lane, y = wy0 + r, o = r * WIN_W + lane;
                 s_WinZ[o] = LoadR32F(P.prevViewZ, x, y);
-                s_WinN[o] = LoadR32U(P.prevNormalRoughness, x, y);
+                s_WinN[o] = LoadNrRaw(P.prevNormalRoughness, x, y);
                 s_WinId[o] = LoadR16U(P.prevInternalData, x, y);
                 s_WinFast[o] = (DIFF ? LoadR16U(P.historyDiffFast, x, y) : 0u) | (SPEC ? LoadR16U(P.historySpecFast, x, y) << 16 : 0u);
                 if (DIFF)
@@ -330,10 +330,10 @@ __device__ __forceinline__ void ReblurTemporalAccumulationTile(const ReblurCB& c
 #undef WIN_Z
 #undef WIN_ID
         const int nx0 = ClampI(bx, 0, W1) - wx0, nx1 = ClampI(bx + 1, 0, W1) - wx0, ny0 = (ClampI(by, 0, H1) - wy0) * WIN_W, ny1 = (ClampI(by + 1, 0, H1) - wy0) * WIN_W;
-        n00 = InBounds(P.prevNormalRoughness, bx, by) ? s_WinN[ny0 + nx0] : 0u;
-        n10 = InBounds(P.prevNormalRoughness, bx + 1, by) ? s_WinN[ny0 + nx1] : 0u;
-        n01 = InBounds(P.prevNormalRoughness, bx, by + 1) ? s_WinN[ny1 + nx0] : 0u;
-        n11 = InBounds(P.prevNormalRoughness, bx + 1, by + 1) ? s_WinN[ny1 + nx1] : 0u;
+        n00 = InBounds(P.prevNormalRoughness, bx, by) ? s_WinN[ny0 + nx0] : NrRawZero();
+        n10 = InBounds(P.prevNormalRoughness, bx + 1, by) ? s_WinN[ny0 + nx1] : NrRawZero();
+        n01 = InBounds(P.prevNormalRoughness, bx, by + 1) ? s_WinN[ny1 + nx0] : NrRawZero();
+        n11 = InBounds(P.prevNormalRoughness, bx + 1, by + 1) ? s_WinN[ny1 + nx1] : NrRawZero();
     } else {
         const bool footprintInterior = FootprintIsInterior(P.prevViewZ, cx, cy, 4, 4); // the four rows as four 16-byte loads (reblur_device.h "row-vector fetches")
         // Row loads from an origin clamped into the plane: always legal (pool planes have >= 4 texels per row pitch), exact for an interior footprint. The
@@ -351,8 +351,8 @@ __device__ __forceinline__ void ReblurTemporalAccumulationTile(const ReblurCB& c
         const bool normalsInterior = FootprintIsInterior(P.prevNormalRoughness, bx, by, 2, 2);
         {
             const int nx = max(0, min(bx, P.prevNormalRoughness.w - 2));
-            LoadRowR32Ux2(P.prevNormalRoughness, nx, ClampI(by, 0, P.prevNormalRoughness.h - 1), n00, n10);
-            LoadRowR32Ux2(P.prevNormalRoughness, nx, ClampI(by + 1, 0, P.prevNormalRoughness.h - 1), n01, n11);
+            LoadRowNrRawx2(P.prevNormalRoughness, nx, ClampI(by, 0, P.prevNormalRoughness.h - 1), n00, n10);
+            LoadRowNrRawx2(P.prevNormalRoughness, nx, ClampI(by + 1, 0, P.prevNormalRoughness.h - 1), n01, n11);
         }
         if (DIFF) {
             Sig::PrefetchHistory(smbFilter, P.historyDiff, smbDiffTexels, !PERF && KIND != SIGNAL_DIRECTIONAL_OCCLUSION);
@@ -385,10 +385,10 @@ __device__ __forceinline__ void ReblurTemporalAccumulationTile(const ReblurCB& c
     #undef QUADU
         }
         if (!normalsInterior) {
-            n00 = InBounds(P.prevNormalRoughness, bx, by) ? LoadR32U(P.prevNormalRoughness, bx, by) : 0u;
-            n10 = InBounds(P.prevNormalRoughness, bx + 1, by) ? LoadR32U(P.prevNormalRoughness, bx + 1, by) : 0u;
-            n01 = InBounds(P.prevNormalRoughness, bx, by + 1) ? LoadR32U(P.prevNormalRoughness, bx, by + 1) : 0u;
-            n11 = InBounds(P.prevNormalRoughness, bx + 1, by + 1) ? LoadR32U(P.prevNormalRoughness, bx + 1, by + 1) : 0u;
+            n00 = InBounds(P.prevNormalRoughness, bx, by) ? LoadNrRaw(P.prevNormalRoughness, bx, by) : NrRawZero();
+            n10 = InBounds(P.prevNormalRoughness, bx + 1, by) ? LoadNrRaw(P.prevNormalRoughness, bx + 1, by) : NrRawZero();
+            n01 = InBounds(P.prevNormalRoughness, bx, by + 1) ? LoadNrRaw(P.prevNormalRoughness, bx, by + 1) : NrRawZero();
+            n11 = InBounds(P.prevNormalRoughness, bx + 1, by + 1) ? LoadNrRaw(P.prevNormalRoughness, bx + 1, by + 1) : NrRawZero();
         }
 
     }
@@ -403,16 +403,16 @@ __device__ __forceinline__ void ReblurTemporalAccumulationTile(const ReblurCB& c
     {
         float sumw = 0.0f;
         float w = prevViewZ0.z < c.gDenoisingRange ? 1.0f : 0.0f;
-        smbNavg = Xyz(UnpackNormalAndRoughness(DecodeR10G10B10A2(n00))) * w;
+        smbNavg = Xyz(UnpackNormalAndRoughness(DecodePrevNormalRoughnessTexel(n00))) * w;
         sumw += w;
         w = prevViewZ1.y < c.gDenoisingRange ? 1.0f : 0.0f;
-        smbNavg = smbNavg + Xyz(UnpackNormalAndRoughness(DecodeR10G10B10A2(n10))) * w;
+        smbNavg = smbNavg + Xyz(UnpackNormalAndRoughness(DecodePrevNormalRoughnessTexel(n10))) * w;
         sumw += w;
         w = prevViewZ2.y < c.gDenoisingRange ? 1.0f : 0.0f;
-        smbNavg = smbNavg + Xyz(UnpackNormalAndRoughness(DecodeR10G10B10A2(n01))) * w;
+        smbNavg = smbNavg + Xyz(UnpackNormalAndRoughness(DecodePrevNormalRoughnessTexel(n01))) * w;
         sumw += w;
         w = prevViewZ3.x < c.gDenoisingRange ? 1.0f : 0.0f;
-        smbNavg = smbNavg + Xyz(UnpackNormalAndRoughness(DecodeR10G10B10A2(n11))) * w;
+        smbNavg = smbNavg + Xyz(UnpackNormalAndRoughness(DecodePrevNormalRoughnessTexel(n11))) * w;
         sumw += w;
         smbNavg = Div(smbNavg, sumw == 0.0f ? 1.0f : sumw);
     }
@@ -697,10 +697,10 @@ __device__ __forceinline__ void ReblurTemporalAccumulationTile(const ReblurCB& c
         Bilinear vmbBilinearFilter = GetBilinearFilter(vmbPixelUv, rectSizePrev);
         const int vx = (int)vmbBilinearFilter.origin.x, vy = (int)vmbBilinearFilter.origin.y;
         const bool vmbInterior = FootprintIsInterior(P.prevViewZ, vx, vy, 2, 2); // one test for the three planes of this footprint (same size)
-        uint32_t vq00, vq10, vq01, vq11;     // packed normal / roughness
+        NrRaw vq00, vq10, vq01, vq11;        // packed normal / roughness
         const int vfx = max(0, min(vx, P.prevViewZ.w - 2)), vfy0 = ClampI(vy, 0, P.prevViewZ.h - 1), vfy1 = ClampI(vy + 1, 0, P.prevViewZ.h - 1); // row loads as above
-        LoadRowR32Ux2(P.prevNormalRoughness, vfx, vfy0, vq00, vq10);
-        LoadRowR32Ux2(P.prevNormalRoughness, vfx, vfy1, vq01, vq11);
+        LoadRowNrRawx2(P.prevNormalRoughness, vfx, vfy0, vq00, vq10);
+        LoadRowNrRawx2(P.prevNormalRoughness, vfx, vfy1, vq01, vq11);
         const float2 vzr0 = LoadRowR32Fx2(P.prevViewZ, vfx, vfy0), vzr1 = LoadRowR32Fx2(P.prevViewZ, vfx, vfy1);
         const uint32_t vidr0 = LoadRowR16x2Raw(P.prevInternalData, vfx, vfy0), vidr1 = LoadRowR16x2Raw(P.prevInternalData, vfx, vfy1);
         // stochastic nearest taps of the bilinear footprint at the virtual position and one step back along the virtual motion (the draws keep their order)
@@ -712,14 +712,26 @@ __device__ __forceinline__ void ReblurTemporalAccumulationTile(const ReblurCB& c
             float2 uvs = (Div(f.origin + 0.5f, rectSizePrev)) * resolutionScalePrev;
             return NearestTexel(P.prevNormalRoughness, uvs);
         };
-        const int2 st0 = stochasticTexel(vmbPixelUv);
-        const uint32_t stochasticRaw0 = LoadR32U(P.prevNormalRoughness, st0.x, st0.y);
+        // (encodings other than R10G10B10A2: no stochastic tap and no draws -- Common.hlsli:76-85 STOCHASTIC_BILINEAR_FILTER = gLinearClamp, `:359-372` StochasticBilinear( uv ) = uv --
+        //  the two samples are true bilinear fetches of the encoded texels)
+        constexpr bool STOCHASTIC_NORMALS = NRD_NORMAL_ENCODING == NRD_NORMAL_ENCODING_R10G10B10A2_UNORM;
+        const float2 prevNormalRoughnessSize = F2(float(P.prevNormalRoughness.w), float(P.prevNormalRoughness.h));
+        NrRaw stochasticRaw0 = NrRawZero(), stochasticRaw1 = NrRawZero();
+        float4 vmbLinear0 = F4(0.0f), vmbLinear1 = F4(0.0f);
+        if (STOCHASTIC_NORMALS) {
+            const int2 st0 = stochasticTexel(vmbPixelUv);
+            stochasticRaw0 = LoadNrRaw(P.prevNormalRoughness, st0.x, st0.y);
+        } else
+            vmbLinear0 = SampleLinearPrevNormalRoughness(P.prevNormalRoughness, vmbPixelUv * resolutionScalePrev * prevNormalRoughnessSize);
         const float stepBetweenTaps = Min(vmbPixelsTraveled * c.gFramerateScale, 2.0f) + vmbPixelsTraveled * 1.0f;
         vmbDelta = vmbDelta * Rsqrt(LengthSquared(vmbDelta));
         vmbDelta = Div(vmbDelta, rectSizePrev);
         const float2 vmbPixelUvPrevTap = vmbPixelUv + vmbDelta * 1.0f * stepBetweenTaps;
-        const int2 st1 = stochasticTexel(vmbPixelUvPrevTap);
-        const uint32_t stochasticRaw1 = LoadR32U(P.prevNormalRoughness, st1.x, st1.y);
+        if (STOCHASTIC_NORMALS) {
+            const int2 st1 = stochasticTexel(vmbPixelUvPrevTap);
+            stochasticRaw1 = LoadNrRaw(P.prevNormalRoughness, st1.x, st1.y);
+        } else
+            vmbLinear1 = SampleLinearPrevNormalRoughness(P.prevNormalRoughness, vmbPixelUvPrevTap * resolutionScalePrev * prevNormalRoughnessSize);
         // previous tracking hit distance: the 2x2 of the linear sample
         const LinearTaps hitDistTaps = MakeLinearTaps(vmbPixelUv * resolutionScalePrev * F2(float(P.prevSpecHitDistForTracking.w), float(P.prevSpecHitDistForTracking.h)));
         const bool hitDistInterior = FootprintIsInterior(P.prevSpecHitDistForTracking, hitDistTaps.x0, hitDistTaps.y0, 2, 2);
@@ -741,7 +753,7 @@ __device__ __forceinline__ void ReblurTemporalAccumulationTile(const ReblurCB& c
         uint32_t hd00 = hdr0 & 0xFFFFu, hd10 = hdr0 >> 16, hd01 = hdr1 & 0xFFFFu, hd11 = hdr1 >> 16;
         if (!vmbInterior) {
             const int x0 = ClampI(vx, 0, P.prevViewZ.w - 1), x1 = ClampI(vx + 1, 0, P.prevViewZ.w - 1), y0 = ClampI(vy, 0, P.prevViewZ.h - 1), y1 = ClampI(vy + 1, 0, P.prevViewZ.h - 1);
-            vq00 = LoadR32U(P.prevNormalRoughness, x0, y0), vq10 = LoadR32U(P.prevNormalRoughness, x1, y0), vq01 = LoadR32U(P.prevNormalRoughness, x0, y1), vq11 = LoadR32U(P.prevNormalRoughness, x1, y1);
+            vq00 = LoadNrRaw(P.prevNormalRoughness, x0, y0), vq10 = LoadNrRaw(P.prevNormalRoughness, x1, y0), vq01 = LoadNrRaw(P.prevNormalRoughness, x0, y1), vq11 = LoadNrRaw(P.prevNormalRoughness, x1, y1);
             vz00 = LoadR32F(P.prevViewZ, x0, y0), vz10 = LoadR32F(P.prevViewZ, x1, y0), vz01 = LoadR32F(P.prevViewZ, x0, y1), vz11 = LoadR32F(P.prevViewZ, x1, y1);
             vmbId00 = LoadR16U(P.prevInternalData, x0, y0), vmbId10 = LoadR16U(P.prevInternalData, x1, y0), vmbId01 = LoadR16U(P.prevInternalData, x0, y1), vmbId11 = LoadR16U(P.prevInternalData, x1, y1);
         }
@@ -752,7 +764,7 @@ __device__ __forceinline__ void ReblurTemporalAccumulationTile(const ReblurCB& c
 
         // Virtual motion - roughness
         float2 relaxedRoughnessWeightParams = GetRelaxedRoughnessWeightParams(roughness * roughness, c.gRoughnessFraction, REBLUR_ROUGHNESS_SENSITIVITY_IN_TA);
-        const float4 vmbRoughness = F4(DecodeR10G10B10A2(vq00).z, DecodeR10G10B10A2(vq10).z, DecodeR10G10B10A2(vq01).z, DecodeR10G10B10A2(vq11).z);
+        const float4 vmbRoughness = F4(PrevNormalRoughnessTexelRoughness(vq00), PrevNormalRoughnessTexelRoughness(vq10), PrevNormalRoughnessTexelRoughness(vq01), PrevNormalRoughnessTexelRoughness(vq11));
         float4 roughnessWeight;
         roughnessWeight.x = ComputeNonExponentialWeightWithSigma(vmbRoughness.x * vmbRoughness.x, relaxedRoughnessWeightParams.x, relaxedRoughnessWeightParams.y, roughnessSigma);
         roughnessWeight.y = ComputeNonExponentialWeightWithSigma(vmbRoughness.y * vmbRoughness.y, relaxedRoughnessWeightParams.x, relaxedRoughnessWeightParams.y, roughnessSigma);
@@ -764,7 +776,7 @@ __device__ __forceinline__ void ReblurTemporalAccumulationTile(const ReblurCB& c
         float virtualHistoryRoughnessBasedConfidence = ApplyBilinearFilter(roughnessWeight.x, roughnessWeight.y, roughnessWeight.z, roughnessWeight.w, vmbBilinearFilter);
 
         // Virtual motion - normal: parallax; stochastic nearest tap of the bilinear footprint
-        float4 vmbNormalAndRoughness = UnpackNormalAndRoughness(DecodeR10G10B10A2(stochasticRaw0));
+        float4 vmbNormalAndRoughness = UnpackNormalAndRoughness(STOCHASTIC_NORMALS ? DecodePrevNormalRoughnessTexel(stochasticRaw0) : vmbLinear0);
         float3 vmbN = RotateVector(c.gWorldPrevToWorld, Xyz(vmbNormalAndRoughness));
         float Dfactor = GetSpecularDominantFactor(NoV, roughness);
         float virtualHistoryNormalBasedConfidence = Rcp(1.0f + 0.5f * Dfactor * Sat(Length(N - vmbN) - REBLUR_NORMAL_ULP) * vmbPixelsTraveled);
@@ -862,12 +874,13 @@ __device__ __forceinline__ void ReblurTemporalAccumulationTile(const ReblurCB& c
         {
             const float i = 1.0f;
             const float2 vmbPixelUvPrev = vmbPixelUvPrevTap;
-            float4 vmbNormalAndRoughnessPrev = UnpackNormalAndRoughness(DecodeR10G10B10A2(stochasticRaw1));
+            float4 vmbNormalAndRoughnessPrev = UnpackNormalAndRoughness(STOCHASTIC_NORMALS ? DecodePrevNormalRoughnessTexel(stochasticRaw1) : vmbLinear1);
 
             float2 w;
             w.x = GetEncodingAwareNormalWeight(Xyz(vmbNormalAndRoughness), Xyz(vmbNormalAndRoughnessPrev), lobeHalfAngle, curvatureAngle * (1.0f + i * stepBetweenTaps), REBLUR_NORMAL_ULP);
             w.y = ComputeNonExponentialWeightWithSigma(vmbNormalAndRoughnessPrev.w * vmbNormalAndRoughnessPrev.w, relaxedRoughnessWeightParams.x, relaxedRoughnessWeightParams.y, roughnessSigma);
-            w = Lerp(F2(1.0f, 1.0f), w, Sat(stepBetweenTaps));
+            if (STOCHASTIC_NORMALS) // "cures issues of StochasticBilinear" (REBLUR_TemporalAccumulation.hlsli:599-602): R10G10B10A2 only
+                w = Lerp(F2(1.0f, 1.0f), w, Sat(stepBetweenTaps));
             w = Select(IsInScreenNearest(vmbPixelUvPrev) != 0.0f, w, F2(1.0f, 1.0f));
 
             virtualHistoryNormalBasedConfidence = Min(virtualHistoryNormalBasedConfidence, w.x);

@@ -135,7 +135,8 @@ __global__ __launch_bounds__(256, NRD_WAVES_RELAX_ATROUS_SMEM) void RelaxAtrousS
     const float centerMaterialID = centerWorldPosMaterialID.w;
     if (InBounds(P.outNormalRoughness, px, py)) {
         StoreRGBA8Unorm(P.outNormalRoughness, px, py, PackPrevNormalRoughness(normalRoughness));
-        StoreR8Unorm(P.outMaterialID, px, py, centerMaterialID * (1.0f / 255.0f));
+        if (NRD_NORMAL_ENCODING == NRD_NORMAL_ENCODING_R10G10B10A2_UNORM) // reference RELAX_AtrousSmem.hlsli:139-141: the only encoding with material IDs
+            StoreR8Unorm(P.outMaterialID, px, py, centerMaterialID * (1.0f / 255.0f));
     }
 
     if (tileIsSky || px >= rectW || py >= rectH)
@@ -696,7 +697,7 @@ __global__ __launch_bounds__(256, NRD_WAVES_RELAX_ATROUS) void RelaxAtrousKernel
 #endif
     constexpr bool BAND_RAW = STEP >= NRD_ATROUS_BAND_RAW_MIN_STEP;
     __shared__ float4 b_NR[BAND_RAW ? 1 : BN], b_Pos[BAND_RAW ? 1 : BN];
-    __shared__ uint32_t br_NR[BAND_RAW ? BN : 1];
+    __shared__ NrRaw br_NR[BAND_RAW ? BN : 1];
     __shared__ float br_Z[BAND_RAW ? BN : 1];
     __shared__ uint2 b_Spec[SPEC && BANDED ? BN : 1], b_Diff[DIFF && BANDED ? BN : 1], b_SpecSh[SPEC && SH && BANDED ? BN : 1], b_DiffSh[DIFF && SH && BANDED ? BN : 1];
 
@@ -822,7 +823,7 @@ __global__ __launch_bounds__(256, NRD_WAVES_RELAX_ATROUS) void RelaxAtrousKernel
                 const int cx = ClampI(bandX0 + lx, 0, P.worldPosViewZ.w - 1), cy = ClampI(bandY0 + ly, 0, P.worldPosViewZ.h - 1); // the taps' clamped texel
                 const int li = ly * BS + lx;
                 if (BAND_RAW) {
-                    br_NR[li] = *(const uint32_t*)(P.normalRoughness.ptr + TexelOffset(P.normalRoughness, cx, cy, 4u, true));
+                    br_NR[li] = *(const NrRaw*)(P.normalRoughness.ptr + TexelOffset(P.normalRoughness, cx, cy, NR_TEXEL_BYTES, true));
                     br_Z[li] = *(const float*)(P.viewZ.ptr + TexelOffset(P.viewZ, cx, cy, 4u, true));
                 } else {
                     const uint32_t guideOffset = TexelOffset(P.decodedNR, cx, cy, 16u, true);
@@ -895,7 +896,7 @@ __global__ __launch_bounds__(256, NRD_WAVES_RELAX_ATROUS) void RelaxAtrousKernel
 #if NRD_ATROUS_GUIDES_RAW_NR
                 // same reasoning for the normal: 4 bytes of IN_NORMAL_ROUGHNESS through the L1 (41.7 cycles per scattered wave-load against 149.7 for the 16-byte decoded texel,
                 // profiles/r02_c_gather_bench.txt) and the decode that wrote the guide plane (kernels_common.hip DecodeGuidesRelaxKernel) redone per tap: it IS the stored value
-                g0 = EncodeDecodedNormalRoughness(*(const uint32_t*)(P.normalRoughness.ptr + TexelOffset(P.normalRoughness, cx, cy, 4u, true)));
+                g0 = EncodeDecodedNormalRoughness(*(const NrRaw*)(P.normalRoughness.ptr + TexelOffset(P.normalRoughness, cx, cy, NR_TEXEL_BYTES, true)));
 #else
                 g0 = *(const float4*)(P.decodedNR.ptr + guideOffset);
 #endif
@@ -985,6 +986,15 @@ struct Range { // kernel argument
     int rowBegin, rowEnd; // rows this rank produces (multi-GPU row strips); the whole rect otherwise
 };
 } // namespace march
+
+// the ring's normal plane holds 4-byte texels: the marching kernel serves the 4-byte encodings (nrdmath.h NRD_NORMAL_ENCODING 0..2) and is never launched for the others (AtrousMarchMaxStep)
+NRD_D float4 EncodeDecodedRingWord(uint32_t w) {
+#if NRD_NORMAL_ENCODING <= NRD_NORMAL_ENCODING_R10G10B10A2_UNORM
+    return EncodeDecodedNormalRoughness(w);
+#else
+    return F4(0.0f);
+#endif
+}
 
 // the ring, one array per plane (structure of arrays: what the DMA's lane-linear destination allows)
 template <bool DIFF, bool SPEC, bool SH, int N>
@@ -1183,7 +1193,7 @@ __global__ __launch_bounds__(march::THREADS, STEP == 8 ? 4 : 2) void RelaxAtrous
             else {
                 const float4 centerWorldPosViewZ = F4(GetCurrentWorldPosFromPixelPos(c, px, py, centerViewZ), centerViewZ); // = the texel of the (world position, viewZ) guide plane
                 float centerMaterialID;
-                const float4 centerNormalRoughness = DecodedToNormalRoughness(EncodeDecodedNormalRoughness(ring.nr[lc]), centerMaterialID); // = the texel of the decoded guide plane
+                const float4 centerNormalRoughness = DecodedToNormalRoughness(EncodeDecodedRingWord(ring.nr[lc]), centerMaterialID); // = the texel of the decoded guide plane
                 float4 centerSpecular = F4(0.0f), centerSpecularSH = F4(0.0f), centerDiffuse = F4(0.0f), centerDiffuseSH = F4(0.0f);
                 if (SPEC) {
                     centerSpecular = DecodeRGBA16F(ring.spec[lc].x, ring.spec[lc].y);
@@ -1221,7 +1231,7 @@ __global__ __launch_bounds__(march::THREADS, STEP == 8 ? 4 : 2) void RelaxAtrous
                     const float kernelW = (xx == 0 ? 0.44198f : 0.27901f) * (yy == 0 ? 0.44198f : 0.27901f);
                     const int li = rowBase + xx * STEP; // the ring holds the clamped texel of every tap position
                     const int cx = ClampI(qx, 0, P.viewZ.w - 1);
-                    const float4 g0 = EncodeDecodedNormalRoughness(ring.nr[li]);
+                    const float4 g0 = EncodeDecodedRingWord(ring.nr[li]);
                     const float tapZ = RelaxUnpackViewZ(c, ring.z[li]);
                     const float4 sampleWorldPosViewZ = F4(GetCurrentWorldPosFromPixelPos(c, cx, cy, tapZ), tapZ);
                     float4 sampleSpecular = F4(0.0f), sampleDiffuse = F4(0.0f);
@@ -1268,7 +1278,7 @@ static int AtrousLdsBandsMaxStep() { // run-time A/B switch (results are identic
 // run-time A/B switches of the marching kernel (results are identical): NRD_HIP_ATROUS_MARCH = 0 (off) / 8 / 16 (steps 8 and 16: default); NRD_HIP_ATROUS_MARCH_SEG = steps of 16 rows per segment
 static int AtrousMarchMaxStep() {
     static const int v = getenv("NRD_HIP_ATROUS_MARCH") ? atoi(getenv("NRD_HIP_ATROUS_MARCH")) : 0;
-    return v;
+    return sizeof(NrRaw) == 4 ? v : 0; // (the ring's normal plane and its DMA jobs are laid out for 4-byte texels: encodings 0..2)
 }
 static int AtrousMarchSegSteps() {
     static const int v = getenv("NRD_HIP_ATROUS_MARCH_SEG") && atoi(getenv("NRD_HIP_ATROUS_MARCH_SEG")) > 0 ? atoi(getenv("NRD_HIP_ATROUS_MARCH_SEG")) : 8;

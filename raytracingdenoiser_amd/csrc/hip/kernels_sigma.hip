@@ -327,7 +327,7 @@ __global__ __launch_bounds__(TILE_X* TILE_Y) void SigmaBlurKernel(SigmaCB c, Blu
     }
 
     float3 Xv = ReconstructViewPosition(pixelUv, frustum, viewZ, c.gOrthoMode);
-    float3 N = Xyz(UnpackNormalAndRoughness(LoadR10G10B10A2(P.normalRoughness, px, py)));
+    float3 N = Xyz(UnpackNormalAndRoughness(LoadInNormalRoughnessTexel(P.normalRoughness, px, py)));
     float3 Nv = RotateVector(c.gWorldToView, N);
 
     float pixelSize = PixelRadiusToWorld(c.gUnproject, c.gOrthoMode, 1.0f, viewZ);

@@ -91,7 +91,7 @@ __global__ __launch_bounds__(256) void ReblurValidationKernel(nrdc::ReblurValida
     const float2 guideUv = v.uvScaled + ToF2(c.gRectOffset);
 
     const int2 tn = NearestTexel(P.normalRoughness, guideUv);
-    const float4 normalAndRoughness = UnpackNormalAndRoughness(LoadR10G10B10A2(P.normalRoughness, tn.x, tn.y));
+    const float4 normalAndRoughness = UnpackNormalAndRoughness(LoadInNormalRoughnessTexel(P.normalRoughness, tn.x, tn.y));
     const int2 tz = NearestTexel(P.viewZ, guideUv);
     const float viewZ = UnpackViewZ(c, LoadR32F(P.viewZ, tz.x, tz.y));
     const int2 tm = NearestTexel(P.mv, guideUv);
@@ -207,7 +207,7 @@ __global__ __launch_bounds__(256) void RelaxValidationKernel(RelaxCB c, RelaxVal
     const float2 guideUv = v.uvScaled + ToF2(c.shared.gRectOffset);
 
     const int2 tn = NearestTexel(P.normalRoughness, guideUv);
-    const float4 normalAndRoughness = UnpackNormalAndRoughness(LoadR10G10B10A2(P.normalRoughness, tn.x, tn.y));
+    const float4 normalAndRoughness = UnpackNormalAndRoughness(LoadInNormalRoughnessTexel(P.normalRoughness, tn.x, tn.y));
     const int2 tz = NearestTexel(P.viewZ, guideUv);
     const float viewZ = RelaxUnpackViewZ(c, LoadR32F(P.viewZ, tz.x, tz.y));
     const int2 tm = NearestTexel(P.mv, guideUv);

@@ -19,6 +19,8 @@
 
 #include <cstdint>
 
+#include "../common/encoding.h"
+
 namespace nrdhip {
 
 #ifndef NRD_D
@@ -30,7 +32,14 @@ namespace nrdhip {
 #define NRD_PI 3.14159265358979323846f
 #define NRD_EPS 1e-6f
 #define NRD_INF 1e6f
-#define NRD_NORMAL_ENCODING_ERROR (0.75f / 255.0f) // R10G10B10A2 oct normals, reference Common.hlsli:76-78
+// reference Common.hlsli:76-85
+#if NRD_NORMAL_ENCODING < NRD_NORMAL_ENCODING_R10G10B10A2_UNORM
+#define NRD_NORMAL_ENCODING_ERROR (1.5f / 255.0f)
+#elif NRD_NORMAL_ENCODING == NRD_NORMAL_ENCODING_R10G10B10A2_UNORM
+#define NRD_NORMAL_ENCODING_ERROR (0.75f / 255.0f)
+#else
+#define NRD_NORMAL_ENCODING_ERROR (0.5f / 255.0f)
+#endif
 #define NRD_ROUGHNESS_SENSITIVITY 0.01f
 #define NRD_EXP_WEIGHT_DEFAULT_SCALE 3.0f
 #define NRD_CATROM_SHARPNESS 0.5f
@@ -425,11 +434,29 @@ NRD_D float3 DecodeUnitVectorOct(float2 p) { // unsigned input, not normalised; 
     n.y -= t * (Step(0.0f, n.y) * 2.0f - 1.0f);
     return n;
 }
-// IN_NORMAL_ROUGHNESS (R10G10B10A2_UNORM, oct normal, linear roughness, 2-bit material id) -> (N, roughness), materialID
-NRD_D float4 UnpackNormalAndRoughness(float4 p, float& materialID) { // reference NRD.hlsli:600-637
+// the IN_NORMAL_ROUGHNESS texel as the texture unit returns it -> (N, linear roughness), materialID; reference NRD.hlsli:600-637
+// (R10G10B10A2_UNORM: oct normal, roughness, 2-bit material id; the four RGBA encodings: the normal in xyz -- biased for the UNORM ones --, roughness in w, no material id)
+NRD_D float4 UnpackNormalAndRoughness(float4 p, float& materialID) {
+#if NRD_NORMAL_ENCODING == NRD_NORMAL_ENCODING_R10G10B10A2_UNORM
     float3 n = DecodeUnitVectorOct(F2(p.x, p.y));
+    float r = p.z;
     materialID = p.w * 3.0f;
-    return F4(SafeNormalize(n), p.z);
+#else
+#if NRD_NORMAL_ENCODING == NRD_NORMAL_ENCODING_RGBA8_UNORM || NRD_NORMAL_ENCODING == NRD_NORMAL_ENCODING_RGBA16_UNORM
+    float3 n = F3(p.x * 2.0f - 1.0f, p.y * 2.0f - 1.0f, p.z * 2.0f - 1.0f);
+#else
+    float3 n = F3(p.x, p.y, p.z);
+#endif
+    float r = p.w;
+    materialID = 0.0f;
+#endif
+    n = SafeNormalize(n);
+#if NRD_ROUGHNESS_ENCODING == NRD_ROUGHNESS_ENCODING_SQRT_LINEAR
+    r *= r;
+#elif NRD_ROUGHNESS_ENCODING == NRD_ROUGHNESS_ENCODING_SQ_LINEAR
+    r = Sqrt(Sat(r));
+#endif
+    return F4(n, r);
 }
 NRD_D float4 UnpackNormalAndRoughness(float4 p) {
     float unused;

@@ -74,6 +74,7 @@ NRD_D float DivSmallIntByConst(float k, float c, float rcpC) {
 #define NRD_DIV_255(k) DivSmallIntByConst(k, 255.0f, 0.003921568859368563f)
 #define NRD_DIV_32767(k) DivSmallIntByConst(k, 32767.0f, 3.0518509447574615e-05f) // also exact for the negative numerators of SNORM16
 #define NRD_DIV_65535(k) DivSmallIntByConst(k, 65535.0f, 1.5259021893143654e-05f)
+#define NRD_DIV_127(k) DivSmallIntByConst(k, 127.0f, 0.007874015718698502f) // SNORM8: numerators -128..127
 #define NRD_DIV_63(k) DivSmallIntByConst(k, 63.0f, 0.01587301678955555f)
 #define NRD_DIV_15(k) DivSmallIntByConst(k, 15.0f, 0.06666667014360428f)
 #define NRD_DIV_3(k) DivSmallIntByConst(k, 3.0f, 0.3333333432674408f)
@@ -206,5 +207,16 @@ NRD_D float4 DecodeR10G10B10A2(uint32_t raw) {
     return r;
 }
 NRD_D float4 LoadR10G10B10A2(const Plane& p, int x, int y) { return DecodeR10G10B10A2(*TexelPtr<const uint32_t>(p, x, y)); }
+
+// the texel formats of the other normal encodings (nrdmath.h NRD_NORMAL_ENCODING): RGBA8_SNORM, RGBA16_UNORM, RGBA16_SNORM (decode max(i / (2^(n-1) - 1), -1)), RGBA16_SFLOAT
+NRD_D float FromSnorm8(uint32_t bits8) { return fmaxf(NRD_DIV_127(float((int32_t)(int8_t)bits8)), -1.0f); }
+NRD_D float4 DecodeRGBA8Snorm(uint32_t raw) { return make_float4(FromSnorm8(raw & 0xFFu), FromSnorm8((raw >> 8) & 0xFFu), FromSnorm8((raw >> 16) & 0xFFu), FromSnorm8(raw >> 24)); }
+NRD_D float4 DecodeRGBA16Unorm(uint2 raw) {
+    return make_float4(NRD_DIV_65535(float(raw.x & 0xFFFFu)), NRD_DIV_65535(float(raw.x >> 16)), NRD_DIV_65535(float(raw.y & 0xFFFFu)), NRD_DIV_65535(float(raw.y >> 16)));
+}
+NRD_D float4 DecodeRGBA16Snorm(uint2 raw) { return make_float4(FromSnorm16(raw.x & 0xFFFFu), FromSnorm16(raw.x >> 16), FromSnorm16(raw.y & 0xFFFFu), FromSnorm16(raw.y >> 16)); }
+NRD_D float4 DecodeRGBA16Float(uint2 raw) {
+    return make_float4(HalfBitsToFloat((uint16_t)(raw.x & 0xFFFFu)), HalfBitsToFloat((uint16_t)(raw.x >> 16)), HalfBitsToFloat((uint16_t)(raw.y & 0xFFFFu)), HalfBitsToFloat((uint16_t)(raw.y >> 16)));
+}
 
 } // namespace nrdhip

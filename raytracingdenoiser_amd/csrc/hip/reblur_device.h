@@ -342,13 +342,80 @@ NRD_D float2 GetTemporalAccumulationParams(const ReblurCB& c, float isInScreenMu
 // roughness is in [0, 1], so its float has both clear) and the kernels fetch 16 bytes instead of re-deriving the normal: same values bit for bit, 4x
 // the tap bytes (L2-served), ~55 instructions less per tap -- the kernels are VALU-bound (profiles/), not bandwidth-bound. Round 5: the roughness used
 // to travel as its 10-bit integer and cost every specular tap a mask, a conversion and the exact division by 1023 (5 instructions; now one v_and).
+// The encodings without material bits (every NRD_NORMAL_ENCODING but R10G10B10A2) keep the plain float there: materialID is 0 by definition (NRD.hlsli:617).
+#if NRD_NORMAL_ENCODING == NRD_NORMAL_ENCODING_R10G10B10A2_UNORM
 NRD_D float DecodedRoughness(uint32_t w) { return AsFloat(w & 0x3FFFFFFFu); }
 NRD_D float DecodedMaterialID(uint32_t w) { return NRD_DIV_3(float(w >> 30)) * 3.0f; } // = p.w * 3 of UnpackNormalAndRoughness
-NRD_D float4 EncodeDecodedNormalRoughness(uint32_t raw) {
+#else
+NRD_D float DecodedRoughness(uint32_t w) { return AsFloat(w); }
+NRD_D float DecodedMaterialID(uint32_t) { return 0.0f; }
+#endif
+
+// ---- the normal / roughness texel of the library's encoding (nrdmath.h NRD_NORMAL_ENCODING) -------------------------------------------------------------
+// NrRaw = one undecoded texel of IN_NORMAL_ROUGHNESS, and of REBLUR's PREV_NORMAL_ROUGHNESS (reference Reblur.cpp:52-62: the pool plane follows the encoding):
+//   encoding                0 RGBA8_UNORM   1 RGBA8_SNORM   2 R10G10B10A2_UNORM   3 RGBA16_UNORM   4 RGBA16_SNORM
+//   IN_NORMAL_ROUGHNESS     RGBA8_UNORM     RGBA8_SNORM     R10_G10_B10_A2_UNORM  RGBA16_UNORM     RGBA16_SNORM      (the format the application binds: executor.hip)
+//   PREV_NORMAL_ROUGHNESS   RGBA8_UNORM     RGBA8_SNORM     R10_G10_B10_A2_UNORM  RGBA16_UNORM     RGBA16_SFLOAT
+// Decode*NormalRoughnessTexel return the float4 the reference's texture unit would hand to NRD_FrontEnd_UnpackNormalAndRoughness.
+#if NRD_NORMAL_ENCODING <= NRD_NORMAL_ENCODING_R10G10B10A2_UNORM
+typedef uint32_t NrRaw;
+NRD_D NrRaw NrRawZero() { return 0u; }
+#else
+typedef uint2 NrRaw;
+NRD_D NrRaw NrRawZero() { return make_uint2(0u, 0u); }
+#endif
+constexpr uint32_t NR_TEXEL_BYTES = (uint32_t)sizeof(NrRaw);
+NRD_D NrRaw LoadNrRaw(const Plane& p, int x, int y) { return *TexelPtr<const NrRaw>(p, x, y); }
+NRD_D void StoreNrRaw(const Plane& p, int x, int y, NrRaw v) { *TexelPtr<NrRaw>(p, x, y) = v; }
+NRD_D float4 DecodeInNormalRoughnessTexel(NrRaw raw) {
+#if NRD_NORMAL_ENCODING == NRD_NORMAL_ENCODING_RGBA8_UNORM
+    return DecodeRGBA8Unorm(raw);
+#elif NRD_NORMAL_ENCODING == NRD_NORMAL_ENCODING_RGBA8_SNORM
+    return DecodeRGBA8Snorm(raw);
+#elif NRD_NORMAL_ENCODING == NRD_NORMAL_ENCODING_R10G10B10A2_UNORM
+    return DecodeR10G10B10A2(raw);
+#elif NRD_NORMAL_ENCODING == NRD_NORMAL_ENCODING_RGBA16_UNORM
+    return DecodeRGBA16Unorm(raw);
+#else
+    return DecodeRGBA16Snorm(raw);
+#endif
+}
+NRD_D float4 DecodePrevNormalRoughnessTexel(NrRaw raw) {
+#if NRD_NORMAL_ENCODING == NRD_NORMAL_ENCODING_RGBA16_SNORM
+    return DecodeRGBA16Float(raw);
+#else
+    return DecodeInNormalRoughnessTexel(raw);
+#endif
+}
+// REBLUR PostBlur forwards the texel it read to PREV_NORMAL_ROUGHNESS (REBLUR_PostBlur.hlsli:47): a copy of the bits where the two planes share the format,
+// a conversion of the four SNORM16 values to fp16 for encoding 4
+NRD_D NrRaw InToPrevNormalRoughnessTexel(NrRaw raw) {
+#if NRD_NORMAL_ENCODING == NRD_NORMAL_ENCODING_RGBA16_SNORM
+    const float4 v = DecodeRGBA16Snorm(raw);
+    return make_uint2(FloatsToHalf2Bits(v.x, v.y), FloatsToHalf2Bits(v.z, v.w));
+#else
+    return raw;
+#endif
+}
+// the roughness channel of a PREV_NORMAL_ROUGHNESS texel AS STORED (REBLUR_TemporalAccumulation.hlsli:463-467: GatherBlue for R10G10B10A2, GatherAlpha otherwise;
+// not passed through the roughness encoding, as in the reference)
+NRD_D float PrevNormalRoughnessTexelRoughness(NrRaw raw) {
+#if NRD_NORMAL_ENCODING == NRD_NORMAL_ENCODING_R10G10B10A2_UNORM
+    return DecodeR10G10B10A2(raw).z;
+#else
+    return DecodePrevNormalRoughnessTexel(raw).w;
+#endif
+}
+NRD_D float4 LoadInNormalRoughnessTexel(const Plane& p, int x, int y) { return DecodeInNormalRoughnessTexel(LoadNrRaw(p, x, y)); }
+
+NRD_D float4 EncodeDecodedNormalRoughness(NrRaw raw) {
     float unused;
-    float4 nr = UnpackNormalAndRoughness(DecodeR10G10B10A2(raw), unused);
-    const float roughness = NRD_DIV_1023(float((raw >> 20) & 0x3FFu)); // = DecodeR10G10B10A2(raw).z
-    return F4(nr.x, nr.y, nr.z, AsFloat(AsUint(roughness) | (raw & 0xC0000000u)));
+    float4 nr = UnpackNormalAndRoughness(DecodeInNormalRoughnessTexel(raw), unused);
+#if NRD_NORMAL_ENCODING == NRD_NORMAL_ENCODING_R10G10B10A2_UNORM
+    return F4(nr.x, nr.y, nr.z, AsFloat(AsUint(nr.w) | (raw & 0xC0000000u)));
+#else
+    return nr;
+#endif
 }
 NRD_D float4 DecodedToNormalRoughness(float4 d, float& materialID) {
     const uint32_t bits = AsUint(d.w);
@@ -447,6 +514,16 @@ NRD_D void LoadRowR32Ux2(const Plane& p, int x, int y, uint32_t& a, uint32_t& b)
     const U32x2U r = *(const U32x2U*)TexelPtr<const uint32_t>(p, x, y);
     a = r.v[0], b = r.v[1];
 }
+// two texels of a row in the library's normal encoding (NrRaw: 4 or 8 bytes per texel)
+NRD_D void LoadRowNrRawx2(const Plane& p, int x, int y, NrRaw& a, NrRaw& b) {
+#if NRD_NORMAL_ENCODING <= NRD_NORMAL_ENCODING_R10G10B10A2_UNORM
+    LoadRowR32Ux2(p, x, y, a, b);
+#else
+    uint32_t v[4];
+    __builtin_memcpy(v, TexelPtr<const NrRaw>(p, x, y), 16);
+    a = make_uint2(v[0], v[1]), b = make_uint2(v[2], v[3]);
+#endif
+}
 NRD_D void LoadRowR16Ux4(const Plane& p, int x, int y, uint32_t* out) {
     const U16x4U r = *(const U16x4U*)TexelPtr<const uint16_t>(p, x, y);
     out[0] = r.v[0], out[1] = r.v[1], out[2] = r.v[2], out[3] = r.v[3];
@@ -495,6 +572,14 @@ NRD_D float4 SampleLinearRGBA16F(const Plane& p, float2 pos) {
     LinearTaps t = MakeLinearTaps(pos);
     float4 s00 = FetchClampedRGBA16F(p, t.x0, t.y0), s10 = FetchClampedRGBA16F(p, t.x0 + 1, t.y0), s01 = FetchClampedRGBA16F(p, t.x0, t.y0 + 1),
            s11 = FetchClampedRGBA16F(p, t.x0 + 1, t.y0 + 1);
+    return s00 * t.w00 + s10 * t.w10 + s01 * t.w01 + s11 * t.w11;
+}
+NRD_D NrRaw FetchClampedNrRaw(const Plane& p, int x, int y) { return LoadNrRaw(p, ClampI(x, 0, p.w - 1), ClampI(y, 0, p.h - 1)); }
+// gPrev_Normal_Roughness.SampleLevel( gLinearClamp, ... ) of the encodings without the stochastic tap (REBLUR_TemporalAccumulation.hlsli:473, 593): the ENCODED texels are blended
+NRD_D float4 SampleLinearPrevNormalRoughness(const Plane& p, float2 pos) {
+    LinearTaps t = MakeLinearTaps(pos);
+    float4 s00 = DecodePrevNormalRoughnessTexel(FetchClampedNrRaw(p, t.x0, t.y0)), s10 = DecodePrevNormalRoughnessTexel(FetchClampedNrRaw(p, t.x0 + 1, t.y0)),
+           s01 = DecodePrevNormalRoughnessTexel(FetchClampedNrRaw(p, t.x0, t.y0 + 1)), s11 = DecodePrevNormalRoughnessTexel(FetchClampedNrRaw(p, t.x0 + 1, t.y0 + 1));
     return s00 * t.w00 + s10 * t.w10 + s01 * t.w01 + s11 * t.w11;
 }
 NRD_D float SampleLinearR16F(const Plane& p, float2 pos) {

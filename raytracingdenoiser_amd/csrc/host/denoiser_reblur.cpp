@@ -36,7 +36,9 @@ enum : uint32_t {
 constexpr Format FMT_SIGNAL = Format::RGBA16_SFLOAT;           // YCoCg radiance + normalised hit distance
 constexpr Format FMT_FAST = Format::R16_SFLOAT;                // fast-history luma
 constexpr Format FMT_PREV_VIEWZ = Format::R32_SFLOAT;
-constexpr Format FMT_PREV_NORMAL_ROUGHNESS = Format::R10_G10_B10_A2_UNORM; // follows the library's normal encoding
+// follows the library's normal encoding (reference Reblur.cpp:52-62)
+constexpr Format FMT_PREV_NORMAL_ROUGHNESS = NRD_NORMAL_ENCODING == 0 ? Format::RGBA8_UNORM : NRD_NORMAL_ENCODING == 1 ? Format::RGBA8_SNORM : NRD_NORMAL_ENCODING == 2 ? Format::R10_G10_B10_A2_UNORM
+    : NRD_NORMAL_ENCODING == 3 ? Format::RGBA16_UNORM : Format::RGBA16_SFLOAT;
 constexpr Format FMT_PREV_INTERNAL_DATA = Format::R16_UINT;    // 6+6 bits of accumulated frames, 4 bits material id
 constexpr Format FMT_TILES = Format::R8_UNORM;
 constexpr Format FMT_HITDIST_FOR_TRACKING = Format::R16_SFLOAT;

@@ -395,6 +395,9 @@ Result InstanceImpl::SetCommonSettings(const CommonSettings& commonSettings) {
     ok &= cs.denoisingRange > 0.0f;
     ok &= cs.disocclusionThreshold > 0.0f;
     ok &= cs.disocclusionThresholdAlternate > 0.0f;
+    // encodings without material bits decode material 0 everywhere: a special material 0 would claim every pixel (reference InstanceImpl.cpp:333-337)
+    ok &= cs.strandMaterialID != 0.0f || NRD_NORMAL_ENCODING == NRD_NORMAL_ENCODING_R10G10B10A2_UNORM;
+    ok &= cs.cameraAttachedReflectionMaterialID != 0.0f || NRD_NORMAL_ENCODING == NRD_NORMAL_ENCODING_R10G10B10A2_UNORM;
     // (strand / camera-attached material id 0 is legal with the R10G10B10A2 encoding this build uses)
 
     // Per-frame kernel rotators (reference :339-349)

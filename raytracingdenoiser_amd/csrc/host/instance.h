@@ -8,6 +8,7 @@
 
 #include "NRD.h"
 
+#include "../common/encoding.h"
 #include "../common/pass_constants.h"
 #include "hostmath.h"
 

@@ -38,9 +38,10 @@ const nrd::LibraryDesc g_LibraryDesc = {
     NRD_VERSION_MAJOR,
     NRD_VERSION_MINOR,
     NRD_VERSION_BUILD,
-    nrd::NormalEncoding::R10_G10_B10_A2_UNORM,
-    nrd::RoughnessEncoding::LINEAR,
+    (nrd::NormalEncoding)NRD_NORMAL_ENCODING, // the build's choice (csrc/common/encoding.h; reference Wrapper.cpp:54-55)
+    (nrd::RoughnessEncoding)NRD_ROUGHNESS_ENCODING,
 };
+static_assert(NRD_NORMAL_ENCODING < (int)nrd::NormalEncoding::MAX_NUM && NRD_ROUGHNESS_ENCODING < (int)nrd::RoughnessEncoding::MAX_NUM, "encoding out of bounds");
 
 // In ResourceType enum order (the reference table at Wrapper.cpp:58-95 is shifted for entries 3..15; ours is not)
 const char* const g_ResourceTypeNames[] = {

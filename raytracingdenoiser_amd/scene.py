@@ -96,7 +96,7 @@ def _hitdist_unorm16(signal):
 
 
 def _user_planes(name, frame):
-    planes = [(RT.IN_MV, frame["mv"], F.RGBA16_SFLOAT), (RT.IN_NORMAL_ROUGHNESS, frame["normal_roughness"], F.R10_G10_B10_A2_UNORM), (RT.IN_VIEWZ, frame["viewz"], F.R32_SFLOAT)]
+    planes = [(RT.IN_MV, frame["mv"], F.RGBA16_SFLOAT), (RT.IN_NORMAL_ROUGHNESS, frame["normal_roughness"], F[api.NORMAL_ROUGHNESS_FORMAT_NAME]), (RT.IN_VIEWZ, frame["viewz"], F.R32_SFLOAT)]
     if name in ("REBLUR_DIFFUSE", "REBLUR_DIFFUSE_SPECULAR"):
         planes.append((RT.IN_DIFF_RADIANCE_HITDIST, frame["diff"], F.RGBA16_SFLOAT))
     if name in ("REBLUR_SPECULAR", "REBLUR_DIFFUSE_SPECULAR"):

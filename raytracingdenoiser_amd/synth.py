@@ -3,7 +3,7 @@
 An analytic scene (ground plane y = 0, three spheres, sky) seen by a slowly dollying / yawing left-handed pinhole
 camera, "path traced" with one diffuse and one specular bounce ray per pixel against the same analytic primitives.
 Outputs are packed exactly as an application would hand them to NRD:
-  IN_VIEWZ R32F | IN_NORMAL_ROUGHNESS R10G10B10A2 (NRD_FrontEnd_PackNormalAndRoughness, reference NRD.hlsli:640-667)
+  IN_VIEWZ R32F | IN_NORMAL_ROUGHNESS in the library's encoding, R10G10B10A2 by default (NRD_FrontEnd_PackNormalAndRoughness, reference NRD.hlsli:640-667)
   IN_MV RGBA16F | IN_DIFF/SPEC_RADIANCE_HITDIST RGBA16F (REBLUR_FrontEnd_PackRadianceAndNormHitDist, NRD.hlsli:732-743,
   hit distances normalised with REBLUR_FrontEnd_GetNormHitDist, NRD.hlsli:722-727) | IN_PENUMBRA R16F (+ IN_TRANSLUCENCY RGBA8) for SIGMA.
 Pure torch, device-agnostic: tests generate on the CPU (and feed the same tensors to the oracle and to the GPU), the
@@ -143,13 +143,39 @@ def _oct_encode(n):
     return xy * 0.5 + 0.5
 
 
-def pack_normal_roughness(n, roughness, material_id):
-    """NRD_FrontEnd_PackNormalAndRoughness -> R10G10B10A2_UNORM words (int32 tensor)."""
-    e = _oct_encode(n)
+def pack_normal_roughness(n, roughness, material_id, encoding=None):
+    """NRD_FrontEnd_PackNormalAndRoughness (reference NRD.hlsli:640-667) in the library's G-buffer encoding (api.NORMAL_ENCODING / ROUGHNESS_ENCODING, or `encoding` = (n, r)):
+    R10G10B10A2_UNORM words (int32 [H, W]) for normal encoding 2; RGBA8_UNORM / RGBA8_SNORM words (int32 [H, W], byte 0 = x) for 0 / 1; RGBA16_UNORM / RGBA16_SNORM texels
+    (int16 [H, W, 4]) for 3 / 4. Encodings other than 2 carry no material ID."""
+    from . import api
+
+    ne, re = encoding if encoding is not None else (api.NORMAL_ENCODING, api.ROUGHNESS_ENCODING)
+    if re == 2:
+        roughness = roughness.clamp(0.0, 1.0).sqrt()
+    elif re == 0:
+        roughness = roughness * roughness
     q = lambda v, m: torch.floor(v.clamp(0.0, 1.0) * m + 0.5).to(torch.int64)
-    word = q(e[..., 0], 1023.0) | (q(e[..., 1], 1023.0) << 10) | (q(roughness, 1023.0) << 20) | (q(material_id / 3.0, 3.0) << 30)
-    word = torch.where(word >= 2 ** 31, word - 2 ** 32, word)
-    return word.to(torch.int32)
+    if ne == 2:
+        e = _oct_encode(n)
+        word = q(e[..., 0], 1023.0) | (q(e[..., 1], 1023.0) << 10) | (q(roughness, 1023.0) << 20) | (q(material_id / 3.0, 3.0) << 30)
+        word = torch.where(word >= 2 ** 31, word - 2 ** 32, word)
+        return word.to(torch.int32)
+    n = n / n.abs().max(-1, keepdim=True).values  # "best fit (optional)"
+    p = torch.cat([n, roughness.unsqueeze(-1)], -1)
+    if ne in (0, 3):
+        p = torch.cat([n * 0.5 + 0.5, roughness.unsqueeze(-1)], -1)
+        c = q(p, 255.0 if ne == 0 else 65535.0)
+    else:  # SNORM: clamp, scale, round half away from zero
+        t = p.clamp(-1.0, 1.0) * (127.0 if ne == 1 else 32767.0)
+        c = torch.where(t >= 0, torch.floor(t + 0.5), -torch.floor(-t + 0.5)).to(torch.int64)
+    if ne <= 1:
+        c = c & 0xFF
+        word = c[..., 0] | (c[..., 1] << 8) | (c[..., 2] << 16) | (c[..., 3] << 24)
+        word = torch.where(word >= 2 ** 31, word - 2 ** 32, word)
+        return word.to(torch.int32)
+    c = c & 0xFFFF
+    c = torch.where(c >= 2 ** 15, c - 2 ** 16, c)
+    return c.to(torch.int16)
 
 
 def _ycocg(c):

@@ -16,7 +16,7 @@ struct Sample {
     float roughness, materialID, hitDist, viewZ;
 };
 struct Result {
-    uint32_t normalRoughnessWord;
+    uint32_t normalRoughnessWord, normalRoughnessWordHi; // the IN_NORMAL_ROUGHNESS texel (the high word only with the 64-bit encodings)
     float4 unpackedNR, reblurPacked, reblurUnpacked, sh0, sh1, relaxPacked, relaxSh1, dirOcc, translucency;
     float normHitDist, penumbra, penumbraLocal, shadow, materialID;
     float3 diffFactor, specFactor, sgDiffuse, sgSpecular, shDiffuse, shSpecular, sgColor, sgDir;
@@ -59,8 +59,10 @@ __host__ __device__ inline Result Evaluate(uint32_t i) {
     const float4 hitDistParams = make_float4(3.0f, 0.1f, 20.0f, -25.0f);
     Result r;
     float4 nr = NRD_FrontEnd_PackNormalAndRoughness(s.N, s.roughness, s.materialID);
-    r.normalRoughnessWord = NRD_StoreR10G10B10A2(nr);
-    r.unpackedNR = NRD_FrontEnd_UnpackNormalAndRoughness(NRD_LoadR10G10B10A2(r.normalRoughnessWord), r.materialID);
+    const NRD_NormalRoughnessTexel texel = NRD_StoreNormalRoughnessTexel(nr); // the texel of the library's encoding (32 or 64 bits)
+    r.normalRoughnessWord = (uint32_t)texel;
+    r.normalRoughnessWordHi = (uint32_t)((uint64_t)texel >> 32);
+    r.unpackedNR = NRD_FrontEnd_UnpackNormalAndRoughness(NRD_LoadNormalRoughnessTexel(texel), r.materialID);
     r.normHitDist = REBLUR_FrontEnd_GetNormHitDist(s.hitDist, s.viewZ, hitDistParams, s.roughness);
     r.reblurPacked = REBLUR_FrontEnd_PackRadianceAndNormHitDist(s.radiance, r.normHitDist);
     r.reblurUnpacked = REBLUR_BackEnd_UnpackRadianceAndNormHitDist(r.reblurPacked);
@@ -155,11 +157,14 @@ int main(int argc, char** argv) {
     for (uint32_t i = 0; i < count; i++) {
         const Sample s = MakeSample(i);
         const Result& r = host[i];
-        // the packed normal decodes to within the 10-bit oct quantisation, roughness to 1/1023, the material id exactly
-        CHECK(r.materialID == s.materialID);
-        CHECK(fabsf(r.unpackedNR.w - s.roughness) <= 0.5f / 1023.0f + 1e-6f);
+        // the packed normal decodes to within the quantisation of the encoding (10-bit oct by default), the roughness to half a code of its channel (in the ENCODED domain:
+        // linear / squared / square root), the material id exactly where the encoding has one (R10G10B10A2) and as 0 elsewhere
+        const float codes = NRD_NORMAL_ENCODING == 2 ? 1023.0f : NRD_NORMAL_ENCODING == 0 ? 255.0f : NRD_NORMAL_ENCODING == 1 ? 127.0f : NRD_NORMAL_ENCODING == 3 ? 65535.0f : 32767.0f;
+        auto enc = [](float x) { return NRD_ROUGHNESS_ENCODING == 0 ? x * x : NRD_ROUGHNESS_ENCODING == 2 ? sqrtf(x) : x; };
+        CHECK(r.materialID == (NRD_NORMAL_ENCODING == 2 ? s.materialID : 0.0f));
+        CHECK(fabsf(enc(r.unpackedNR.w) - enc(s.roughness)) <= 0.5f / codes + 2e-6f);
         float d = r.unpackedNR.x * s.N.x + r.unpackedNR.y * s.N.y + r.unpackedNR.z * s.N.z;
-        CHECK(d > 0.99999f); // < ~0.26 degrees
+        CHECK(d > (NRD_NORMAL_ENCODING == 2 ? 0.99999f : NRD_NORMAL_ENCODING < 2 ? 0.9999f : 0.999999f)); // < ~0.26 degrees for the default
         // YCoCg round trip and the SG colour
         CHECK(fabsf(r.reblurUnpacked.x - s.radiance.x) < 1e-5f && fabsf(r.reblurUnpacked.y - s.radiance.y) < 1e-5f && fabsf(r.reblurUnpacked.z - s.radiance.z) < 1e-5f);
         CHECK(fabsf(r.sgColor.x - s.radiance.x) < 1e-5f && fabsf(r.sgColor.z - s.radiance.z) < 1e-5f);
@@ -187,7 +192,7 @@ int main(int argc, char** argv) {
     }
     uint32_t checksum = 0;
     for (uint32_t i = 0; i < count; i++)
-        checksum = checksum * 31u + host[i].normalRoughnessWord;
+        checksum = checksum * 31u + host[i].normalRoughnessWord, checksum = sizeof(NRD_NormalRoughnessTexel) == 8 ? checksum * 31u + host[i].normalRoughnessWordHi : checksum;
     printf("host OK: %u samples, normal/roughness word checksum %08x\n", count, checksum);
     if (noGpu)
         return 0;
@@ -203,7 +208,7 @@ int main(int argc, char** argv) {
     for (uint32_t i = 0; i < count; i++) {
         const Result &h = host[i], &d = dev[i];
         // packers and codecs: bit-exact
-        exactMismatch += h.normalRoughnessWord != d.normalRoughnessWord;
+        exactMismatch += h.normalRoughnessWord != d.normalRoughnessWord || h.normalRoughnessWordHi != d.normalRoughnessWordHi;
         exactMismatch += memcmp(&h.unpackedNR, &d.unpackedNR, 16) != 0;
         exactMismatch += memcmp(&h.reblurUnpacked, &d.reblurUnpacked, 12) != 0;
         exactMismatch += memcmp(&h.relaxPacked, &d.relaxPacked, 16) != 0 || memcmp(&h.relaxSh1, &d.relaxSh1, 16) != 0;

@@ -14,13 +14,13 @@ sys.path.insert(0, ROOT)
 from raytracingdenoiser_amd import build as B  # noqa: E402
 
 CLANG = os.environ.get("NRD_EMU_CXX", "/opt/rocm/lib/llvm/bin/clang++")
-OBJ_DIR = os.path.join(HERE, "obj")
-OUT = os.path.join(HERE, "libNRD_emu.so")
+OBJ_DIR = os.path.join(HERE, "obj" + B.encoding_suffix())  # (one emulation library per G-buffer encoding: raytracingdenoiser_amd/build.py encoding())
+OUT = os.path.join(HERE, "libNRD_emu%s.so" % B.encoding_suffix())
 
 
 def flags():
     return ["-std=c++17", "-O1", "-fPIC", "-fopenmp", "-fdeclspec", "-fvisibility=hidden", "-Wno-return-type-c-linkage", "-Wno-unused-value", "-mfma", "-mf16c",
-            "-I" + os.path.join(HERE, "shim"), "-I" + os.path.join(ROOT, "oracle"), "-I" + os.path.join(ROOT, "include")] + B.DEVICE_NUMERICS_FLAGS + os.environ.get("NRD_EMU_EXTRA_FLAGS", "").split()
+            "-I" + os.path.join(HERE, "shim"), "-I" + os.path.join(ROOT, "oracle"), "-I" + os.path.join(ROOT, "include")] + B.encoding_flags() + B.DEVICE_NUMERICS_FLAGS + os.environ.get("NRD_EMU_EXTRA_FLAGS", "").split()
 
 
 def _digest(paths, extra):

@@ -10,12 +10,12 @@ import numpy as np
 import pytest
 import torch
 
-from raytracingdenoiser_amd import synth
+from raytracingdenoiser_amd import api, synth
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 SRC = os.path.join(ROOT, "tests", "cpp", "frontend_check.hip")
 HDR = os.path.join(ROOT, "include", "NRD.hip.h")
-EXE = os.path.join(ROOT, "tests", "cpp", "build", "frontend_check")
+EXE = os.path.join(ROOT, "tests", "cpp", "build", "frontend_check" + api.ENCODING_SUFFIX)  # (one harness per G-buffer encoding: tests/test_encodings.py)
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 
 
@@ -23,7 +23,8 @@ def _build():
     os.makedirs(os.path.dirname(EXE), exist_ok=True)
     if os.path.exists(EXE) and os.path.getmtime(EXE) > max(os.path.getmtime(SRC), os.path.getmtime(HDR)):
         return
-    cmd = [HIPCC, "-std=c++17", "-O2", "-ffp-contract=off", "--offload-arch=gfx950", "-I" + os.path.join(ROOT, "include"), SRC, "-o", EXE]
+    cmd = [HIPCC, "-std=c++17", "-O2", "-ffp-contract=off", "--offload-arch=gfx950", "-DNRD_NORMAL_ENCODING=%d" % api.NORMAL_ENCODING, "-DNRD_ROUGHNESS_ENCODING=%d" % api.ROUGHNESS_ENCODING,
+           "-I" + os.path.join(ROOT, "include"), SRC, "-o", EXE]
     subprocess.run(cmd, check=True, capture_output=True, text=True)
 
 
@@ -45,8 +46,8 @@ def _expected_word_checksum(count):
     n = np.where((l < np.float32(0.05))[:, None], np.array([0, 0, 1], np.float32)[None], v / np.maximum(l, np.float32(1e-20))[:, None]).astype(np.float32)
     roughness = _u(i, 18)
     material = (_pcg(i + 77) & 3).astype(np.float32)
-    words = synth.pack_normal_roughness(torch.from_numpy(n), torch.from_numpy(roughness), torch.from_numpy(material)).numpy().view(np.uint32)
-    c = 0
+    words = np.ascontiguousarray(synth.pack_normal_roughness(torch.from_numpy(n), torch.from_numpy(roughness), torch.from_numpy(material)).numpy()).view(np.uint32).reshape(-1)
+    c = 0  # (int16 [n, 4] texels of the 64-bit encodings: low word, then high word of every sample, as the harness folds them)
     for w in words.tolist():
         c = (c * 31 + w) & 0xFFFFFFFF
     return c
