@@ -29,11 +29,12 @@ SEMANTICS = {"SV_GroupThreadId": "groupThreadId", "SV_GroupId": "groupId", "SV_D
              "SV_GroupThreadID": "groupThreadId", "SV_GroupID": "groupId", "SV_DispatchThreadID": "dispatchThreadId"}
 
 
-def preprocess(entry, reference, include_first=None, encoding=(2, 1)):
+def preprocess(entry, reference, include_first=None, encoding=(2, 1), mathlib=None, defs=()):
     """include_first: a directory searched in front of the reference's own Include directory (the viewport-offset build of oracle/ref/Makefile puts a Common.hlsli there whose
     NRD_USE_VIEWPORT_OFFSET is 1 -- the reference makes that switch an edit of the file, Common.hlsli:64)"""
     shaders = os.path.join(reference, "Shaders")
-    cmd = [CLANG, "-E", "-x", "c", "-undef", "-nostdinc", "-Wno-everything", "-I", HERE] + (["-I", include_first] if include_first else []) + ["-I", os.path.join(shaders, "Include"), "-I", os.path.join(shaders, "Resources"),
+    # mathlib: a directory holding NVIDIA-RTX/MathLib's ml.hlsli (the reference's un-vendored submodule, CMakeLists.txt:118-127), searched in front of the stand-in beside this file
+    cmd = [CLANG, "-E", "-x", "c", "-undef", "-nostdinc", "-Wno-everything"] + (["-I", mathlib] if mathlib else []) + ["-I", HERE] + list(defs) + (["-I", include_first] if include_first else []) + ["-I", os.path.join(shaders, "Include"), "-I", os.path.join(shaders, "Resources"),
            "-include", os.path.join(HERE, "prelude.hlsli"), "-DNRD_NORMAL_ENCODING=%d" % encoding[0], "-DNRD_ROUGHNESS_ENCODING=%d" % encoding[1], entry]
     return subprocess.run(cmd, check=True, capture_output=True, text=True).stdout
 
@@ -132,6 +133,13 @@ def main():
             i = args.index(flag)
             encoding[k] = int(args[i + 1])
             del args[i:i + 2]
+    mathlib = None
+    if "--mathlib" in args:
+        i = args.index("--mathlib")
+        mathlib = args[i + 1] or None
+        del args[i:i + 2]
+    defs = [a for a in args if a.startswith("-D")]
+    args = [a for a in args if not a.startswith("-D")]
     keep = "--keep-preprocessed" in args
     if keep:
         args.remove("--keep-preprocessed")
@@ -139,7 +147,7 @@ def main():
     name = os.path.basename(entry)
     assert name.endswith(".cs.hlsl"), name
     shader_name = name[:-len(".hlsl")]
-    pre = preprocess(entry, reference, include_first, tuple(encoding))
+    pre = preprocess(entry, reference, include_first, tuple(encoding), mathlib, defs)
     if keep:
         with open(out + ".i", "w") as fp:
             fp.write(pre)

@@ -146,7 +146,12 @@ namespace Sequence
         uint2 q = p & 3u;
         uint a = 2068378560u * ( 1u - ( q.x >> 1 ) ) + 1500172770u * ( q.x >> 1 );
         uint b = ( q.y + ( ( q.x & 1u ) << 2 ) ) << 2;
-        return ( ( a >> b ) + frameIndex ) & 0xFu;
+#if( NRD_MATHLIB_BAYER_REVERSEBITS == 1 ) // the alternative the round-5 review recalls as MathLib's default (ML_BAYER_REVERSEBITS); default here: 0, see oracle/ref/Makefile MATHLIB_DEFS
+        uint sampleOffset = Math::ReverseBits4( frameIndex );
+#else
+        uint sampleOffset = frameIndex;
+#endif
+        return ( ( a >> b ) + sampleOffset ) & 0xFu;
     }
     float Bayer4x4( uint2 p, uint frameIndex ) { return float( Bayer4x4ui( p, frameIndex ) ) * 0.0625; } // RESULT: [0; 1) (round 5: i / 16)
 }

@@ -155,12 +155,26 @@ inline float Weyl1D(float p, uint32_t n) {
     return t - std::floor(t);
 }
 
+// NRD_MATHLIB_BAYER_REVERSEBITS (default 0): MathLib is not vendored in the reference tree, so Sequence::Bayer4x4ui is a restatement; the round-5 reviewer recalls a MathLib
+// default ML_BAYER_REVERSEBITS that advances the dither index by ReverseBits4( frameIndex ) instead of frameIndex. Unverifiable here; 1 selects that alternative in every place the
+// function is restated (product host + device, oracle, both MathLib stand-ins under oracle/ref) -- it changes the dither PHASE per frame, nothing else (INTEGRATION.md "MathLib").
+#ifndef NRD_MATHLIB_BAYER_REVERSEBITS
+#define NRD_MATHLIB_BAYER_REVERSEBITS 0
+#endif
+inline uint32_t BayerFrameOffset(uint32_t frameIndex) {
+#if NRD_MATHLIB_BAYER_REVERSEBITS
+    const uint32_t v = frameIndex & 0xFu;
+    return ((v & 1u) << 3) | ((v & 2u) << 1) | ((v & 4u) >> 1) | ((v & 8u) >> 3); // ReverseBits4
+#else
+    return frameIndex;
+#endif
+}
 inline uint32_t Bayer4x4ui(uint32_t x, uint32_t y, uint32_t frameIndex) {
     x &= 3u;
     y &= 3u;
     uint32_t a = 2068378560u * (1u - (x >> 1)) + 1500172770u * (x >> 1);
     uint32_t b = (y + ((x & 1u) << 2)) << 2;
-    return ((a >> b) + frameIndex) & 0xFu;
+    return ((a >> b) + BayerFrameOffset(frameIndex)) & 0xFu;
 }
 
 // round 5: i / 16, "RESULT: [0; 1)" -- the form both the builder's and the round-4 reviewer's recollection of NVIDIA-RTX/MathLib agree on (until then (i + 0.5) / 16; MathLib is not vendored: unpinned either way)
