@@ -406,9 +406,31 @@ extern "C" __attribute__((visibility("default"))) uint32_t nrdHipGetPoolPlane(Nr
     return (uint32_t)nrd::Result::SUCCESS;
 }
 
+// Rows a tap of REBLUR's Blur / PostBlur can lie from its pixel (kernels_reblur_spatial.hip; reference REBLUR_Common_SpatialFilter.hlsli):
+//   diffuse taps: screen space, |offset| <= blurRadius * skew with skew <= 1 and blurRadius = max( scale * maxBlurRadius * sqrt( areaFactor <= 1 ), minBlurRadius );
+//   specular taps: a ring in WORLD space with the half-axes worldRadius * skewFactor and worldRadius / skewFactor, worldRadius = blurRadius * unproject * viewZ (the ring's size
+//     in pixels at the pixel's own depth), skewFactor >= 0.25 + 0.75 * roughness, and blurRadius <= scale * maxBlurRadius * sqrt( roughness ) unless the minimum radius wins:
+//       scale * maxBlurRadius * sqrt( r ) / ( 0.25 + 0.75 r ) <= 1.1547 * scale * maxBlurRadius (at r = 1 / 3),   minBlurRadius / ( 0.25 + 0.75 r ) <= 4 * minBlurRadius (r = 0);
+//     projected, a world offset L at depth z lands L / ( unproject * z_tap ) pixels away with z_tap >= z - L: a factor 1 / ( 1 - t ), t = L / z = ringPixels * unproject, the tangent
+//     of the ring's angular radius. A ring half as large as its distance (tiny frames with huge radii) has no useful bound: -1 = whole frame.
+// + 2: the bilinear footprint of a tap and the rounding of its position. (Rounds 2-5 declared 2 x max( scale * maxBlurRadius, minBlurRadius ) + 2: 62 / 122 rows at the default
+// radius of 30 where the bound is 39 / 79 -- most of the redundant rows of the 8-rank plan, VERDICT r05 item 5a -- and too FEW rows where the minimum radius dominates: 4 x, not 2 x.)
+// NRD_HIP_SPECULAR_REACH_SLACK scales the bound (experiments; tests/test_sharding.py under-declares with it to show that its poisoned-halo check fires).
+static int ReblurBlurReachRows(float scaledMaxRadius, float minRadius, float unproject) {
+    static const float kScale = getenv("NRD_HIP_SPECULAR_REACH_SLACK") ? std::fmax(0.05f, (float)atof(getenv("NRD_HIP_SPECULAR_REACH_SLACK"))) : 1.0f;
+    const float diffuse = std::fmax(scaledMaxRadius, minRadius);
+    const float ring = std::fmax(1.1547006f * scaledMaxRadius, 4.0f * minRadius);
+    const float t = ring * unproject;
+    if (!(t < 0.5f))
+        return -1;
+    return (int)std::ceil(kScale * std::fmax(diffuse, ring / (1.0f - t))) + 2;
+}
+
 // Rows of its INPUT planes (produced earlier in the same frame) a pass reads around an output row. -1 = unknown pass: it and
 // everything before it run on the whole frame.
 static int PassReachRows(const char* shader, const void* constants, uint32_t constantsSize) {
+    if (!strncmp(shader, "Clear_", 6))
+        return 0; // the clears of a restart frame: texel-local (the launch covers the whole plane on every rank, which is what a single GPU's plane holds afterwards)
     if (!strncmp(shader, "RELAX_", 6) && constants && constantsSize >= sizeof(nrdc::RelaxConstants)) {
         const nrdc::RelaxConstants& c = *(const nrdc::RelaxConstants*)constants;
         if (c.gRectSizePrev.x != float(c.gRectSize.x) || c.gRectSizePrev.y != float(c.gRectSize.y))
@@ -425,36 +447,48 @@ static int PassReachRows(const char* shader, const void* constants, uint32_t con
             return 2 * (int)std::floor(c.gHistoryFixBasePixelStride / 2.0f + 0.5f); // 5x5 taps at stride <= base / (1 + 1)
         if (strstr(shader, "_TemporalAccumulation") || strstr(shader, "_AntiFirefly"))
             return 1;
-        if (strstr(shader, "_PrePass") || strstr(shader, "_SplitScreen") || strstr(shader, "ClassifyTiles"))
-            return 0; // read user inputs only
-        return -1; // incl. _Copy and _HitDistReconstruction (the pre-pass then gathers from its output at blur-radius distance) (whole-plane copy of the history, only with anti-firefly): everything up to it runs on the whole frame
+        if (strstr(shader, "_PrePass") || strstr(shader, "_SplitScreen") || strstr(shader, "ClassifyTiles") || strstr(shader, "_HitDistReconstruction") || strstr(shader, "_Copy"))
+            return 0; // read user inputs only (the pre-pass behind a reconstruction pass: DispatchReachRows) / copy texel to texel (the copy's launch covers the whole plane: a superset)
+        return -1;
+    }
+    if (!strncmp(shader, "SIGMA_", 6) && constants && constantsSize >= sizeof(nrdc::SigmaConstants)) {
+        // round 6. Blur / PostBlur: screen-space taps at <= SIGMA_MAX_PIXEL_RADIUS = 32 pixels (skew <= 1; reference SIGMA_Common.hlsli:21-33, SIGMA_Config.hlsli:34),
+        // snapped to a texel centre (+ 1), around the 5x5 radius-estimation window (2); TemporalStabilization: 5x5 moments. The tile passes write down-sampled planes (every rank
+        // runs them on the whole frame: nrdHipPlanHaloExchange); Copy and SplitScreen work texel to texel.
+        const nrdc::SigmaConstants& c = *(const nrdc::SigmaConstants*)constants;
+        if (c.gRectSizePrev.x != c.gRectSize.x || c.gRectSizePrev.y != c.gRectSize.y)
+            return -1;
+        if (strstr(shader, "_PostBlur") || strstr(shader, "_Blur"))
+            return 32 + 1 + 2;
+        if (strstr(shader, "_TemporalStabilization"))
+            return 2;
+        if (strstr(shader, "ClassifyTiles") || strstr(shader, "SmoothTiles") || strstr(shader, "_Copy") || strstr(shader, "_SplitScreen"))
+            return 0;
+        return -1;
     }
     if (strncmp(shader, "REBLUR_", 7) != 0 || !constants || constantsSize < sizeof(nrdc::ReblurConstants))
         return -1;
     const nrdc::ReblurConstants& c = *(const nrdc::ReblurConstants*)constants;
     if (c.gRectSizePrev.x != c.gRectSize.x || c.gRectSizePrev.y != c.gRectSize.y)
         return -1; // dynamic resolution step: history rows map to different rows of this frame, no bounded halo -> whole frame
-    // World-space specular taps: |offset| <= worldRadius / skewFactor with skewFactor >= 0.25 + 0.75 roughness and blurRadius <= maxRadius * sqrt(roughness),
-    // i.e. <= 1.155 x the nominal pixel radius (at roughness 1/3), times z / z_tap <= 1 / (1 - radius * unproject / skew) (a few % at any sane
-    // field of view). 2x is the safety factor; NRD_HIP_SPECULAR_REACH_SLACK overrides it for experiments.
-    static const float kSlack = getenv("NRD_HIP_SPECULAR_REACH_SLACK") ? std::fmax(1.0f, (float)atof(getenv("NRD_HIP_SPECULAR_REACH_SLACK"))) : 2.0f;
     if (strstr(shader, "_TemporalStabilization"))
         return 1;
     if (strstr(shader, "_PostBlur"))
-        return (int)std::ceil(kSlack * std::fmax(2.0f * c.gMaxBlurRadius, c.gMinBlurRadius)) + 2;
+        return ReblurBlurReachRows(2.0f * c.gMaxBlurRadius, c.gMinBlurRadius, c.gUnproject); // REBLUR_POST_BLUR_RADIUS_SCALE = 2
     if (strstr(shader, "_Blur"))
-        return (int)std::ceil(kSlack * std::fmax(c.gMaxBlurRadius, c.gMinBlurRadius)) + 2;
+        return ReblurBlurReachRows(c.gMaxBlurRadius, c.gMinBlurRadius, c.gUnproject);
     if (strstr(shader, "_HistoryFix"))
         return 2 * (int)std::floor(c.gHistoryFixBasePixelStride / 2.0f) + 4 + 2;
     if (strstr(shader, "_TemporalAccumulation"))
         return 1;
-    if (strstr(shader, "_PrePass") || strstr(shader, "_SplitScreen") || strstr(shader, "ClassifyTiles"))
-        return 0; // read user inputs only
-    return -1; // incl. _HitDistReconstruction (the pre-pass then gathers from its output at blur-radius distance)
+    if (strstr(shader, "_PrePass") || strstr(shader, "_SplitScreen") || strstr(shader, "ClassifyTiles") || strstr(shader, "_HitDistReconstruction"))
+        return 0; // read user inputs only (the pre-pass behind a reconstruction pass: DispatchReachRows)
+    return -1;
 }
 
 // Rows above / below a produced pixel at which dispatch i reads the per-frame GUIDE planes (decoded normals, view / world positions): PassReachRows, except for the
 // pre-passes, whose taps read nothing written earlier in the frame (reach 0 for the halo plan) but do read the guides at blur-radius distance. -1 = unknown.
+static int PrePassTapRows(const char* shader, const void* constants);
 static int GuideReachRows(const char* shader, const void* constants, uint32_t constantsSize) {
     const int reach = PassReachRows(shader, constants, constantsSize);
     // TemporalAccumulation with a specular signal (REBLUR and RELAX): the curvature estimate's high-parallax tap reads the decoded normals smbParallaxInPixelsMin * (1 + gFramerateScale *
@@ -466,7 +500,14 @@ static int GuideReachRows(const char* shader, const void* constants, uint32_t co
         return -1;
     if (reach < 0 || !strstr(shader, "_PrePass"))
         return reach;
-    static const float kSlack = getenv("NRD_HIP_SPECULAR_REACH_SLACK") ? std::fmax(1.0f, (float)atof(getenv("NRD_HIP_SPECULAR_REACH_SLACK"))) : 2.0f;
+    return PrePassTapRows(shader, constants);
+}
+
+// Rows a tap of a pre-pass (REBLUR or RELAX) can lie from its pixel. Where they land on planes written earlier in the frame -- the output of a hit-distance reconstruction pass --
+// this is the pass's reach for the halo plan (DispatchReachRows); it always is its reach on the per-frame guide planes (GuideReachRows).
+static int PrePassTapRows(const char* shader, const void* constants) {
+    // the pre-pass taps of both families are SCREEN-space (REBLUR: skew 1 for diffuse, REBLUR_USE_SCREEN_SPACE_SAMPLING_FOR_SPECULAR in the pre-pass; RELAX: pixelUv + rotator *
+    // blurRadius): the radius itself bounds them (rounds 2-5 doubled it)
     float radius;
     if (!strncmp(shader, "RELAX_", 6)) {
         const nrdc::RelaxConstants& c = *(const nrdc::RelaxConstants*)constants;
@@ -475,7 +516,32 @@ static int GuideReachRows(const char* shader, const void* constants, uint32_t co
         const nrdc::ReblurConstants& c = *(const nrdc::ReblurConstants*)constants;
         radius = std::fmax(std::fmax(c.gDiffPrepassBlurRadius, c.gSpecPrepassBlurRadius), c.gMinBlurRadius);
     }
-    return (int)std::ceil(kSlack * radius) + 2;
+    return (int)std::ceil(std::fmax(radius, 1.0f)) + 2; // (RELAX: a zero hit distance widens the radius to at least one pixel)
+}
+
+// PassReachRows of dispatch i in the context of its list: a pre-pass reads user inputs only (reach 0) UNLESS a hit-distance reconstruction pass ran in front of it -- then its taps
+// gather from that pass's output, a full-resolution plane written earlier in the frame, at blur-radius distance (rounds 2-5 ran such frames unsharded).
+static int DispatchReachRows(const nrd::InstanceDesc& idesc, const nrd::DispatchDesc* descs, uint32_t i) {
+    const nrd::DispatchDesc& d = descs[i];
+    if (d.pipelineIndex >= idesc.pipelinesNum)
+        return -1;
+    const char* shader = idesc.pipelines[d.pipelineIndex].shaderFileName;
+    const int reach = PassReachRows(shader, d.constantBufferData, d.constantBufferDataSize);
+    if (reach != 0 || !strstr(shader, "_PrePass"))
+        return reach;
+    for (uint32_t r = 0; r < d.resourcesNum; r++) {
+        const nrd::ResourceDesc& in = d.resources[r];
+        if (in.descriptorType != nrd::DescriptorType::TEXTURE || (uint32_t)in.type < (uint32_t)nrd::ResourceType::OUT_DIFF_RADIANCE_HITDIST)
+            continue; // a user input: complete on every rank
+        for (uint32_t j = 0; j < i; j++)
+            for (uint32_t w = 0; w < descs[j].resourcesNum; w++) {
+                const nrd::ResourceDesc& out = descs[j].resources[w];
+                if (out.descriptorType == nrd::DescriptorType::STORAGE_TEXTURE && out.type == in.type && out.indexInPool == in.indexInPool && descs[j].pipelineIndex < idesc.pipelinesNum &&
+                    strstr(idesc.pipelines[descs[j].pipelineIndex].shaderFileName, "_HitDistReconstruction"))
+                    return PrePassTapRows(shader, d.constantBufferData);
+            }
+    }
+    return reach;
 }
 
 extern "C" __attribute__((visibility("default"))) uint32_t nrdHipSetOwnedRows(NrdHipExecutor* e, uint32_t rowBegin, uint32_t rowEnd) {
@@ -498,7 +564,7 @@ extern "C" __attribute__((visibility("default"))) uint32_t nrdHipGetDispatchReac
     const nrd::InstanceDesc& idesc = nrd::GetInstanceDesc(*(nrd::Instance*)instance);
     for (uint32_t i = 0; i < dispatchDescsNum; i++) {
         const nrd::DispatchDesc& d = descs[i];
-        reachRows[i] = d.pipelineIndex < idesc.pipelinesNum ? PassReachRows(idesc.pipelines[d.pipelineIndex].shaderFileName, d.constantBufferData, d.constantBufferDataSize) : -1;
+        reachRows[i] = DispatchReachRows(idesc, descs, i);
     }
     return (uint32_t)nrd::Result::SUCCESS;
 }
@@ -528,7 +594,7 @@ extern "C" __attribute__((visibility("default"))) uint32_t nrdHipPlanHaloExchang
     bool known = num != 0 && world > 1;
     for (uint32_t i = 0; i < num; i++) {
         const nrd::DispatchDesc& d = descs[i];
-        reach[i] = d.pipelineIndex < idesc.pipelinesNum ? PassReachRows(idesc.pipelines[d.pipelineIndex].shaderFileName, d.constantBufferData, d.constantBufferDataSize) : -1;
+        reach[i] = DispatchReachRows(idesc, descs, i);
         known = known && reach[i] >= 0;
     }
     if (!known)
@@ -591,9 +657,14 @@ extern "C" __attribute__((visibility("default"))) uint32_t nrdHipPlanHaloExchang
         for (const Key& key : reads) {
             auto it = lastWrite.find(key);
             const int w = it == lastWrite.end() ? -1 : it->second;
+            // a plane written by SIGMA's Copy IS last frame's history (SIGMA_Copy.hlsli: previous output -> HISTORY, texel to texel): TemporalStabilization samples it at
+            // the reprojected position, so its readers need the motion bound like readers of a carried-over plane
+            const bool historyCopy = w >= 0 && descs[w].pipelineIndex < idesc.pipelinesNum && !strncmp(idesc.pipelines[descs[w].pipelineIndex].shaderFileName, "SIGMA_Copy", 10);
+            if (historyCopy && segOf[w] == segOf[i])
+                return fallback(); // (never with the default threshold: Blur's reach starts a segment between the two)
             if (w >= 0 && segOf[w] == segOf[i])
                 continue; // produced in this segment with a sufficient margin
-            const int h = margins[i] + reach[i] + (w < 0 ? (int)maxMotionRows : 0);
+            const int h = margins[i] + reach[i] + ((w < 0 || historyCopy) ? (int)maxMotionRows : 0);
             if (h > 0) {
                 int& slot = need[std::make_pair(key, w)];
                 slot = std::max(slot, h);
@@ -667,11 +738,13 @@ extern "C" __attribute__((visibility("default"))) uint32_t nrdHipExecuteDispatch
         int margin = 0;
         for (int i = (int)dispatchDescsNum - 1; i >= 0; i--) {
             const nrd::DispatchDesc& d = descs[i];
-            int reach = d.pipelineIndex < idesc.pipelinesNum ? PassReachRows(idesc.pipelines[d.pipelineIndex].shaderFileName, d.constantBufferData, d.constantBufferDataSize) : -1;
+            int reach = DispatchReachRows(idesc, descs, i);
             if (reach < 0 || margin < 0) {
                 margin = -1; // whole frame from here backwards
                 continue;
             }
+            if (d.pipelineIndex < idesc.pipelinesNum && !strncmp(idesc.pipelines[d.pipelineIndex].shaderFileName, "SIGMA_Copy", 10))
+                continue; // its output is last frame's history, which TemporalStabilization samples at the REPROJECTED position: the texel-to-texel copy (10 B/px) covers the whole frame, the margin walks on
             e->rowMargin[i] = margin;
             margin += reach;
         }

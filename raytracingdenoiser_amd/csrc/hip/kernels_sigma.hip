@@ -221,14 +221,29 @@ static const char* LaunchSmoothTiles(const PassArgs& a) {
     return nullptr;
 }
 
+// Multi-GPU row strips (PassArgs::rowBegin / rowEnd; round 6: SIGMA's passes are sharded like REBLUR's and RELAX's): the grid covers the tile rows that intersect the strip and the
+// kernel adds blockY0 to blockIdx.y. Rows of the first / last tile row that lie outside the strip are produced as well (a superset is always correct). Unsharded: the whole rect.
+struct RowBand {
+    int blockY0;
+    unsigned blocksY;
+};
+static RowBand MakeRowBand(const PassArgs& a, int h, int tileH) {
+    const int rb = a.rowBegin < 0 ? 0 : (a.rowBegin > h ? h : a.rowBegin), re = (a.rowEnd > h || a.rowEnd <= a.rowBegin) ? h : a.rowEnd;
+    RowBand b;
+    b.blockY0 = rb / tileH;
+    const int last = (re + tileH - 1) / tileH;
+    b.blocksY = (unsigned)(last > b.blockY0 ? last - b.blockY0 : 1);
+    return b;
+}
+
 // ================================================================================================ Copy
 template <typename TEXEL> // uint8_t (R8 shadow) or uint32_t (RGBA8 shadow + translucency)
-__global__ __launch_bounds__(256) void SigmaCopyKernel(SigmaCB c, Plane tiles, Plane inHistory, Plane inHistoryLength, Plane outHistory, Plane outHistoryLength) {
+__global__ __launch_bounds__(256) void SigmaCopyKernel(SigmaCB c, Plane tiles, Plane inHistory, Plane inHistoryLength, Plane outHistory, Plane outHistoryLength, int blockY0) {
     // 4 pixels per thread: 4 (or 16) bytes of shadow history and 16 bytes of R32_UINT history length
     struct alignas(sizeof(TEXEL) * 4) Texel4 {
         TEXEL v[4];
     };
-    const int x = (blockIdx.x * 64 + (threadIdx.x & 63)) * 4, y = blockIdx.y * 4 + (threadIdx.x >> 6);
+    const int x = (blockIdx.x * 64 + (threadIdx.x & 63)) * 4, y = ((int)blockIdx.y + blockY0) * 4 + (threadIdx.x >> 6);
     if (y >= outHistory.h || x >= outHistory.w)
         return;
     if (LoadTileX(tiles, x >> 4, y >> 4) != 0.0f && !c.gIsRectChanged)
@@ -249,13 +264,14 @@ __global__ __launch_bounds__(256) void SigmaCopyKernel(SigmaCB c, Plane tiles, P
 static const char* LaunchCopy(const PassArgs& a) {
     const SigmaCB& c = *(const SigmaCB*)a.constants;
     const Plane& out = a.planes[3];
-    dim3 grid((unsigned)((out.w + 255) / 256), (unsigned)((out.h + 3) / 4), 1);
+    const RowBand band = MakeRowBand(a, out.h, 4);
+    dim3 grid((unsigned)((out.w + 255) / 256), band.blocksY, 1);
     if (a.planesNum != 5 || a.bytesPerTexel[1] != a.bytesPerTexel[3])
         return "SIGMA copy: unexpected resources";
     if (a.bytesPerTexel[3] == 4)
-        LaunchPass(a, SigmaCopyKernel<uint32_t>, grid, dim3(256), c, a.planes[0], a.planes[1], a.planes[2], out, a.planes[4]);
+        LaunchPass(a, SigmaCopyKernel<uint32_t>, grid, dim3(256), c, a.planes[0], a.planes[1], a.planes[2], out, a.planes[4], band.blockY0);
     else if (a.bytesPerTexel[3] == 1)
-        LaunchPass(a, SigmaCopyKernel<uint8_t>, grid, dim3(256), c, a.planes[0], a.planes[1], a.planes[2], out, a.planes[4]);
+        LaunchPass(a, SigmaCopyKernel<uint8_t>, grid, dim3(256), c, a.planes[0], a.planes[1], a.planes[2], out, a.planes[4], band.blockY0);
     else
         return "SIGMA copy: unexpected history format";
     return nullptr;
@@ -267,7 +283,7 @@ struct BlurPlanes {
 };
 
 template <bool FIRST_PASS, bool TRANSLUCENT>
-__global__ __launch_bounds__(TILE_X* TILE_Y) void SigmaBlurKernel(SigmaCB c, BlurPlanes P) {
+__global__ __launch_bounds__(TILE_X* TILE_Y) void SigmaBlurKernel(SigmaCB c, BlurPlanes P, int blockY0) {
     typedef SigmaType<TRANSLUCENT> ST;
     typedef typename ST::type S;
     constexpr bool READS_SHADOW = !FIRST_PASS || TRANSLUCENT; // the translucent first pass reads IN_TRANSLUCENCY (not unpacked)
@@ -276,17 +292,18 @@ __global__ __launch_bounds__(TILE_X* TILE_Y) void SigmaBlurKernel(SigmaCB c, Blu
     __shared__ S s_Shadow[BUF_Y * BUF_STRIDE];
 
     const int tx = threadIdx.x % TILE_X, ty = threadIdx.x / TILE_X;
-    const int px = blockIdx.x * TILE_X + tx, py = blockIdx.y * TILE_Y + ty;
+    const int blockY = (int)blockIdx.y + blockY0; // (multi-GPU row strips: RowBand)
+    const int px = blockIdx.x * TILE_X + tx, py = blockY * TILE_Y + ty;
     const int rw = c.gRectSizeMinusOne.x, rh = c.gRectSizeMinusOne.y;
 
     {
-        const int tileY = (blockIdx.y * TILE_Y) >> 4, tileX0 = (blockIdx.x * TILE_X) >> 4;
+        const int tileY = (blockY * TILE_Y) >> 4, tileX0 = (blockIdx.x * TILE_X) >> 4;
         bool anyGeometry = false;
         for (int t = 0; t < TILE_X / 16; t++)
             anyGeometry |= InBounds(P.tiles, tileX0 + t, tileY) && LoadTileX(P.tiles, tileX0 + t, tileY) == 0.0f;
         if (!anyGeometry)
             return;
-        const int baseX = blockIdx.x * TILE_X - BORDER, baseY = blockIdx.y * TILE_Y - BORDER;
+        const int baseX = blockIdx.x * TILE_X - BORDER, baseY = blockY * TILE_Y - BORDER;
         for (int i = threadIdx.x; i < BUF_X * BUF_Y; i += TILE_X * TILE_Y) {
             int lx = i % BUF_X, ly = i / BUF_X;
             int gx = ClampI(baseX + lx, 0, rw), gy = ClampI(baseY + ly, 0, rh);
@@ -456,7 +473,9 @@ static const char* LaunchBlur(const PassArgs& a) {
     if (k != a.planesNum)
         return "SIGMA blur: unexpected resource count";
     dim3 grid = GridFor(c.gRectSizeMinusOne.x + 1, c.gRectSizeMinusOne.y + 1, TILE_X, TILE_Y);
-    LaunchPass(a, (SigmaBlurKernel<FIRST_PASS, TRANSLUCENT>), grid, dim3(TILE_X * TILE_Y), c, P);
+    const RowBand band = MakeRowBand(a, c.gRectSizeMinusOne.y + 1, TILE_Y);
+    grid.y = band.blocksY;
+    LaunchPass(a, (SigmaBlurKernel<FIRST_PASS, TRANSLUCENT>), grid, dim3(TILE_X * TILE_Y), c, P, band.blockY0);
     return nullptr;
 }
 
@@ -479,24 +498,25 @@ NRD_D typename SigmaType<TRANSLUCENT>::type FetchShadowHistory(const HistoryFilt
 }
 
 template <bool TRANSLUCENT>
-__global__ __launch_bounds__(TILE_X* TILE_Y) void SigmaTemporalStabilizationKernel(SigmaCB c, TsPlanes P) {
+__global__ __launch_bounds__(TILE_X* TILE_Y) void SigmaTemporalStabilizationKernel(SigmaCB c, TsPlanes P, int blockY0) {
     typedef SigmaType<TRANSLUCENT> ST;
     typedef typename ST::type S;
     __shared__ float s_Penumbra[BUF_Y * BUF_STRIDE];
     __shared__ S s_Shadow[BUF_Y * BUF_STRIDE];
 
     const int tx = threadIdx.x % TILE_X, ty = threadIdx.x / TILE_X;
-    const int px = blockIdx.x * TILE_X + tx, py = blockIdx.y * TILE_Y + ty;
+    const int blockY = (int)blockIdx.y + blockY0; // (multi-GPU row strips: RowBand)
+    const int px = blockIdx.x * TILE_X + tx, py = blockY * TILE_Y + ty;
     const int rw = c.gRectSizeMinusOne.x, rh = c.gRectSizeMinusOne.y;
 
     {
-        const int tileY = (blockIdx.y * TILE_Y) >> 4, tileX0 = (blockIdx.x * TILE_X) >> 4;
+        const int tileY = (blockY * TILE_Y) >> 4, tileX0 = (blockIdx.x * TILE_X) >> 4;
         bool anyGeometry = false;
         for (int t = 0; t < TILE_X / 16; t++)
             anyGeometry |= InBounds(P.tiles, tileX0 + t, tileY) && LoadTileX(P.tiles, tileX0 + t, tileY) == 0.0f;
         if (!anyGeometry)
             return;
-        const int baseX = blockIdx.x * TILE_X - BORDER, baseY = blockIdx.y * TILE_Y - BORDER;
+        const int baseX = blockIdx.x * TILE_X - BORDER, baseY = blockY * TILE_Y - BORDER;
         for (int i = threadIdx.x; i < BUF_X * BUF_Y; i += TILE_X * TILE_Y) {
             int lx = i % BUF_X, ly = i / BUF_X;
             int gx = ClampI(baseX + lx, 0, rw), gy = ClampI(baseY + ly, 0, rh);
@@ -623,15 +643,17 @@ static const char* LaunchTemporalStabilization(const PassArgs& a) {
         return "SIGMA temporal stabilization: unexpected resource count";
     TsPlanes P = {a.planes[0], a.planes[1], a.planes[2], a.planes[3], a.planes[4], a.planes[5], a.planes[6], a.planes[7], a.planes[8]};
     dim3 grid = GridFor(c.gRectSizeMinusOne.x + 1, c.gRectSizeMinusOne.y + 1, TILE_X, TILE_Y);
-    LaunchPass(a, SigmaTemporalStabilizationKernel<TRANSLUCENT>, grid, dim3(TILE_X * TILE_Y), c, P);
+    const RowBand band = MakeRowBand(a, c.gRectSizeMinusOne.y + 1, TILE_Y);
+    grid.y = band.blocksY;
+    LaunchPass(a, SigmaTemporalStabilizationKernel<TRANSLUCENT>, grid, dim3(TILE_X * TILE_Y), c, P, band.blockY0);
     return nullptr;
 }
 
 // ================================================================================================ SplitScreen
 template <bool TRANSLUCENT>
-__global__ __launch_bounds__(256) void SigmaSplitScreenKernel(SigmaCB c, Plane viewZ, Plane penumbra, Plane translucency, Plane outShadow) {
+__global__ __launch_bounds__(256) void SigmaSplitScreenKernel(SigmaCB c, Plane viewZ, Plane penumbra, Plane translucency, Plane outShadow, int blockY0) {
     typedef SigmaType<TRANSLUCENT> ST;
-    const int px = blockIdx.x * TILE_X + (threadIdx.x % TILE_X), py = blockIdx.y * TILE_Y + (threadIdx.x / TILE_X);
+    const int px = blockIdx.x * TILE_X + (threadIdx.x % TILE_X), py = ((int)blockIdx.y + blockY0) * TILE_Y + (threadIdx.x / TILE_X);
     if (px > c.gRectSizeMinusOne.x || py > c.gRectSizeMinusOne.y)
         return;
     float pixelUvX = (float(px) + 0.5f) * c.gRectSizeInv.x;
@@ -652,7 +674,9 @@ static const char* LaunchSplitScreen(const PassArgs& a) {
     if (a.planesNum != (TRANSLUCENT ? 4u : 3u))
         return "SIGMA split screen: unexpected resource count";
     dim3 grid = GridFor(c.gRectSizeMinusOne.x + 1, c.gRectSizeMinusOne.y + 1, TILE_X, TILE_Y);
-    LaunchPass(a, SigmaSplitScreenKernel<TRANSLUCENT>, grid, dim3(256), c, a.planes[0], a.planes[1], TRANSLUCENT ? a.planes[2] : Plane{}, a.planes[a.planesNum - 1]);
+    const RowBand band = MakeRowBand(a, c.gRectSizeMinusOne.y + 1, TILE_Y);
+    grid.y = band.blocksY;
+    LaunchPass(a, SigmaSplitScreenKernel<TRANSLUCENT>, grid, dim3(256), c, a.planes[0], a.planes[1], TRANSLUCENT ? a.planes[2] : Plane{}, a.planes[a.planesNum - 1], band.blockY0);
     return nullptr;
 }
 

@@ -157,9 +157,15 @@ def plan_halo_exchange(dispatches, reach, rows, height, max_motion_rows=32, exch
             continue
         for key in reads:
             w = last_write.get(key, -1)
+            # a plane written by SIGMA's Copy IS last frame's history (previous output -> HISTORY, texel to texel): TemporalStabilization samples it at the reprojected
+            # position, so its readers need the motion bound like readers of a carried-over plane (executor.hip nrdHipPlanHaloExchange: the same rule)
+            history_copy = w >= 0 and dispatches[w].shader.startswith("SIGMA_Copy")
+            if history_copy and seg_of[w] == seg_of[i]:
+                plan.fallback = True
+                return plan
             if w >= 0 and seg_of[w] == seg_of[i]:
                 continue  # produced in this segment with a sufficient margin
-            h = margins[i] + reach[i] + (max_motion_rows if w < 0 else 0)
+            h = margins[i] + reach[i] + (max_motion_rows if w < 0 or history_copy else 0)
             if h > 0:
                 need[(key, w)] = max(need.get((key, w), 0), h)
         for key in writes:
@@ -499,6 +505,10 @@ class HaloSharder:
                            for i in range(n)))
         cached = self._plans.get(signature)
         recut = self.balance and self.recut_every > 0 and self._sharded_since_cut >= self.recut_every and self.world > 1
+        if self.balance and self.world > 1 and self.complete and any(self.inst.pipelines[ptr[i].pipelineIndex].startswith("Clear_") for i in range(n) if ptr[i].pipelineIndex < len(self.inst.pipelines)):
+            # a restart frame (its list clears the history) with balancing on: run it whole on every rank -- nothing has to be completed for it, and its tile map is what the
+            # strips are cut from in front of the next frame. (Without balancing the restart frame is sharded like any other since round 6: clears are texel-local.)
+            recut = True
         if self.world > 1 and self.motion_exceeds_halo(motion_rows, (ptr, n)):
             recut = True  # same mechanics as a deliberate re-cut frame: complete the planes, run the whole frame everywhere
             self.motion_fallbacks += 1

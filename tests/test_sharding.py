@@ -190,7 +190,13 @@ def test_halo_plan_for_reblur_and_relax():
             ds = [api.Dispatch(ptr[i], inst.pipelines) for i in range(n)]
             small = {(int(api.ResourceType.TRANSIENT_POOL), i) for i, (fmt, d) in enumerate(inst.transient_pool) if d != 1}
             plans.append((sharding.plan_halo_exchange(ds, inst.dispatch_reach(ptr, n), sharding.strip_rows(h, 3, world), h, small_planes=small), ds))
-        assert plans[0][0].fallback  # the restart frame clears planes: reach unknown -> every rank runs the whole frame
+        # the restart frame is sharded too since round 6: its clears are texel-local (reach 0), and a plane that is cleared before it is read is not carried over -- nothing
+        # of last frame's is exchanged for it
+        restart, rds = plans[0]
+        clears = [i for i, d in enumerate(rds) if d.shader.startswith("Clear_")]
+        cleared = {(int(t), idx) for i in clears for dt, t, idx in rds[i].resources if dt == api.DescriptorType.STORAGE_TEXTURE}
+        assert clears and not restart.fallback and all(restart.reach[i] == 0 for i in clears)
+        assert all(key not in cleared for items, _, _ in restart.steps for key, _ in items if items is restart.steps[0][0])
         plan, ds = plans[1]
         assert not plan.fallback and len(plan.steps) == expect_segments
         rb, re = sharding.strip_rows(h, 3, world)
@@ -209,10 +215,11 @@ def test_halo_plan_for_reblur_and_relax():
     ("REBLUR_DIFFUSE_SPECULAR", (2560, 1440), 4, dict(enablePerformanceMode=True, maxBlurRadius=12.0), None),
     ("REBLUR_DIFFUSE_SPECULAR", (640, 360), 8, None, None),                                   # 45-row strips: the PostBlur halo does not fit -> unsharded
     ("REBLUR_DIFFUSE_SPECULAR_OCCLUSION", (1920, 1080), 4, None, None),                        # the user's OUT planes are the history
-    ("REBLUR_DIFFUSE_SH", (1920, 1080), 3, dict(hitDistanceReconstructionMode=1), None),       # a pass of unknown reach -> unsharded
+    ("REBLUR_DIFFUSE_SH", (1920, 1080), 3, dict(hitDistanceReconstructionMode=1), None),       # the pre-pass gathers from the reconstruction's output: reach = its blur radius
+    ("RELAX_DIFFUSE_SPECULAR", (1920, 1080), 3, dict(hitDistanceReconstructionMode=2), None),
     ("RELAX_DIFFUSE_SPECULAR_SH", (3840, 2160), 8, None, None),
     ("RELAX_SPECULAR", (1920, 1080), 2, dict(atrousIterationNum=8), None),
-    ("RELAX_DIFFUSE", (1920, 1080), 2, dict(enableAntiFirefly=True), None),                    # the whole-plane history copy has no bounded reach -> unsharded
+    ("RELAX_DIFFUSE", (1920, 1080), 2, dict(enableAntiFirefly=True), None),                    # Copy (texel to texel) + AntiFirefly (3x3)
     ("SIGMA_SHADOW", (1920, 1080), 4, None, None),
 ])
 def test_c_planner_equals_python_planner(name, size, world, overrides, cs_kw):
@@ -244,8 +251,10 @@ def test_c_planner_equals_python_planner(name, size, world, overrides, cs_kw):
             assert [(items, first, count) for items, first, count, early in steps] == [([(tuple(k), wd) for k, wd in items], first, count) for items, first, count in want.steps]
             assert [early for *_, early in steps] == want.early
             assert row_begin == want.row_begin and row_end == want.row_end
-    expect_sharded = name.startswith(("REBLUR", "RELAX")) and size != (640, 360) and not (overrides or {}).get("hitDistanceReconstructionMode") and not (overrides or {}).get("enableAntiFirefly")
-    assert (sharded == 2 * world) == expect_sharded and (sharded > 0) == expect_sharded
+    # round 6: every frame of every family is sharded -- restart frames (texel-local clears), hit-distance reconstruction (the pre-pass behind it reaches its blur radius), RELAX's
+    # anti-firefly pair, SIGMA (Blur / PostBlur 35 rows, TemporalStabilization 2 + the motion bound on the history Copy forwards) -- unless a halo does not fit the strips
+    expect_sharded = size != (640, 360)
+    assert sharded == (3 * world if expect_sharded else 0)
 
 
 def _local_exchange(ranks, plans, step):
@@ -256,6 +265,23 @@ def _local_exchange(ranks, plans, step):
             if kind == "recv":
                 key = items[k][0]
                 sh.plane_tensor(key)[r0:r1].copy_(ranks[peer].plane_tensor(key)[r0:r1])
+
+
+def _poison_beyond_halo(ranks, plans, step):
+    """every row of an exchanged plane that lies OUTSIDE the strip + the halo the plan declared is overwritten with 0xFF bytes (NaN in the fp16 / fp32 planes, the
+    largest code in the UNORM / UINT ones) before the segment runs. A pass that reads further than nrdHipGetDispatchReach says then produces NaNs (or visibly different values) in the
+    rows the rank owns, instead of quietly reading whatever an earlier frame left there."""
+    for sh, plan in zip(ranks, plans):
+        rb, re = sh.rows
+        for key, width in plan.steps[step][0]:
+            t = sh.plane_tensor(key)
+            rows = t.shape[0]
+            scale = rows / float(sh.height)  # (no down-sampled plane is ever exchanged: small_planes)
+            assert scale == 1.0
+            if rb - width > 0:
+                t[: rb - width].fill_(0xFF)
+            if re + width < rows:
+                t[re + width:].fill_(0xFF)
 
 
 def _local_completion(ranks, plans):
@@ -276,6 +302,9 @@ def _local_completion(ranks, plans):
     ("REBLUR_DIFFUSE_SPECULAR_OCCLUSION", 2, 360, dict(maxBlurRadius=15.0), True, 3),  # history = the user's OUT planes
     ("RELAX_DIFFUSE_SPECULAR_SH", 2, 360, None, True, 2),
     ("REBLUR_DIFFUSE_SPECULAR", 2, 480, dict(maxBlurRadius=15.0), "recut", None),  # a deliberate unsharded frame after every 2 sharded ones
+    ("REBLUR_DIFFUSE_SPECULAR", 2, 720, dict(maxBlurRadius=60.0), False, None),     # huge radii: Blur / PostBlur reach 80 / 181 rows (round 6: the derived bound; 2 x the radius said 122 / 242)
+    ("SIGMA_SHADOW", 2, 360, None, False, None),                                    # round 6: SIGMA's passes declare their reach and take row bands
+    ("REBLUR_DIFFUSE_SPECULAR", 2, 480, dict(maxBlurRadius=0.0, minBlurRadius=5.0), False, None),  # the minimum radius wins: specular rings reach 4 x, which 2 x the radius did not cover
 ])
 def test_halo_sharding_virtual_ranks_reproduce_single_gpu(name, world, height, overrides, balance, fallback_frame):
     import parity
@@ -299,7 +328,7 @@ def test_halo_sharding_virtual_ranks_reproduce_single_gpu(name, world, height, o
             ex.bind(rt, t.cuda().contiguous(), fmt)
         ov = dict(overrides or {})
         if f == fallback_frame:
-            ov["hitDistanceReconstructionMode"] = 1  # a pass of unknown reach: this frame runs unsharded on every rank
+            ov["maxBlurRadius"] = 400.0  # rings comparable to their distance from the camera have no bounded reach (executor.hip ReblurBlurReachRows): this frame runs unsharded on every rank
         inst.set_denoiser_settings(0, parity.denoiser_settings(name, frame, ov))
         assert inst.set_common_settings(parity.common_settings(frame["camera"], seq[max(f - 1, 0)]["camera"], W, H, f)) == api.Result.SUCCESS
 
@@ -329,6 +358,7 @@ def test_halo_sharding_virtual_ranks_reproduce_single_gpu(name, world, height, o
             for step in range(len(plans[0].steps)):
                 torch.cuda.synchronize()
                 _local_exchange(ranks, plans, step)
+                _poison_beyond_halo(ranks, plans, step)
                 for sh, (plan, ptr, n) in zip(ranks, begun):
                     sh.run_step(plan, ptr, n, step)
         for sh, plan in zip(ranks, plans):
@@ -339,12 +369,27 @@ def test_halo_sharding_virtual_ranks_reproduce_single_gpu(name, world, height, o
             rb, re = sh.rows
             for o, ro in zip(outs, ref_outs):
                 assert torch.equal(o[rb:re], ro[rb:re]), (name, f, r)
-    assert sharded_frames == (4 if recut else frames - 1 - (fallback_frame is not None))  # recut: frames 0 and 3 run unsharded (0 | 1 2 | 3 | 4 5)
+    # the restart frame: run whole where the strips are balanced (its tile map is what they are cut from), sharded otherwise (round 6); recut: frames 0 and 3 run unsharded (0 | 1 2 | 3 | 4 5)
+    assert sharded_frames == (4 if recut else frames - (1 if balance else 0) - (fallback_frame is not None))
     if balance:
         assert ranks[0].rebalanced >= 1  # (a re-cut that lands on the same strips does not count) and ranks[0].bounds != uniform and ranks[0].bounds[0] == 0 and ranks[0].bounds[-1] == H  # sky at the top: the top strip grows
         assert ranks[0].bounds[1] > uniform[1]
     else:
         assert ranks[0].bounds == uniform
+
+
+@pytest.mark.gpu
+def test_the_poisoned_halo_check_fires_when_the_reach_is_under_declared():
+    """negative control of the test above: the same default-radius case in a child process whose NRD_HIP_SPECULAR_REACH_SLACK halves the declared Blur / PostBlur reach must FAIL"""
+    import subprocess
+    import sys
+
+    case = "test_halo_sharding_virtual_ranks_reproduce_single_gpu and REBLUR_DIFFUSE_SPECULAR-2-720-None-False-None"
+    cmd = [sys.executable, "-m", "pytest", os.path.abspath(__file__), "-q", "-x", "-n", "0", "-m", "gpu", "-p", "no:cacheprovider", "-k", case]
+    ok = subprocess.run(cmd, env=dict(os.environ), capture_output=True, text=True, timeout=900)
+    assert ok.returncode == 0 and "1 passed" in ok.stdout, ok.stdout[-2000:]
+    bad = subprocess.run(cmd, env=dict(os.environ, NRD_HIP_SPECULAR_REACH_SLACK="0.5"), capture_output=True, text=True, timeout=900)
+    assert bad.returncode != 0 and "1 failed" in bad.stdout, bad.stdout[-2000:]
 
 
 def test_balanced_bounds():
@@ -439,8 +484,9 @@ def _halo_two_process_worker(rank, world, port, name, W, H, frames, q):
         for f, frame in enumerate(seq):
             for rt, t, fmt in parity.user_planes(name, frame):
                 ex.bind(rt, t.cuda().contiguous(), fmt)
-            # frame 2 carries a pass of unknown reach: it runs unsharded, after every rank has received the other strips of the history planes
-            inst.set_denoiser_settings(0, parity.denoiser_settings(name, frame, dict(hitDistanceReconstructionMode=1) if f == 2 else None))
+            # frame 2 has a pass without a bounded reach (blur rings as large as their distance: ReblurBlurReachRows): it runs unsharded, after every rank has received the
+            # other strips of the history planes
+            inst.set_denoiser_settings(0, parity.denoiser_settings(name, frame, dict(maxBlurRadius=400.0) if f == 2 else None))
             inst.set_common_settings(parity.common_settings(frame["camera"], seq[max(f - 1, 0)]["camera"], W, H, f))
             sh.denoise() if sharded else ex.denoise()
             if sharded:
@@ -490,6 +536,7 @@ def _halo_two_process_emulated_worker(rank, world, port, name, W, H, frames, ove
     lib = emu_run.load()
     overrides = dict(overrides or {})
     rise, halo, near = overrides.pop("_camera_rise", 0.0), overrides.pop("_history_halo", 16), overrides.pop("_near_depth", 1.0)
+    balance = overrides.pop("_balance", True)  # False: uniform strips for good -- then the restart frame is sharded too (round 6)
     parity.synth.CAMERA_RISE = rise  # (a fresh process: nothing to restore)
     seq = parity.generate_sequence(name, W, H, frames, device="cpu")
     steps = [(frame, {}) for frame in seq]
@@ -512,7 +559,7 @@ def _halo_two_process_emulated_worker(rank, world, port, name, W, H, frames, ove
         for rt, dtype, ch, fmt in parity.output_planes(name, W, H):
             outs.append(torch.zeros((H, W, ch), dtype=dtype))
             ex.bind(rt, outs[-1], fmt)
-        sh = sharding.HaloSharder(ex, inst, W, H, rank, world, max_motion_rows=halo, measure_motion=measure, near_depth=near) if sharded else None
+        sh = sharding.HaloSharder(ex, inst, W, H, rank, world, max_motion_rows=halo, measure_motion=measure, near_depth=near, balance=balance) if sharded else None
         per_frame, sharded_frames, measured = [], 0, []
         for f, (frame, cs_kw) in enumerate(steps):
             for rt, t, fmt in parity.user_planes(name, frame):
@@ -556,6 +603,11 @@ def _halo_two_process_emulated_worker(rank, world, port, name, W, H, frames, ove
     # high-parallax tap of TemporalAccumulation reads the decoded normals many rows away along the motion direction -- the guide planes must be decoded there (poisoned otherwise)
     ("REBLUR_DIFFUSE_SPECULAR", 2, 64, 480, dict(maxBlurRadius=4.0, diffusePrepassBlurRadius=0.0, specularPrepassBlurRadius=0.0, _camera_rise=0.25, _history_halo=110, _near_depth=2.5), False),
     ("RELAX_DIFFUSE_SPECULAR", 2, 64, 480, dict(atrousIterationNum=3, diffusePrepassBlurRadius=0.0, specularPrepassBlurRadius=0.0, _camera_rise=0.25, _history_halo=110, _near_depth=2.5), False),
+    # round 6: the passes that used to run unsharded on every rank
+    ("SIGMA_SHADOW", 2, 96, 240, None, False),                                                   # BASELINE config 2's denoiser: Blur / PostBlur 35 rows, the history Copy + motion
+    ("SIGMA_SHADOW_TRANSLUCENCY", 3, 64, 420, dict(_balance=False), False),                      # uniform strips: the restart frame (its clears) is sharded as well
+    ("REBLUR_DIFFUSE_SPECULAR", 2, 96, 240, dict(maxBlurRadius=4.0, diffusePrepassBlurRadius=6.0, specularPrepassBlurRadius=6.0, hitDistanceReconstructionMode=2), False),  # 5x5 reconstruction
+    ("RELAX_DIFFUSE_SPECULAR", 2, 96, 240, dict(atrousIterationNum=3, diffusePrepassBlurRadius=6.0, specularPrepassBlurRadius=6.0, hitDistanceReconstructionMode=1, enableAntiFirefly=True, _balance=False), False),
 ])
 def test_halo_sharding_processes_over_gloo_on_emulated_kernels(name, world, W, H, overrides, measure):
     """The N > 1 path end to end WITHOUT a GPU: `world` processes over gloo, each planning its strip from the dispatch list, exchanging halo bands by message passing
@@ -584,8 +636,10 @@ def test_halo_sharding_processes_over_gloo_on_emulated_kernels(name, world, W, H
             p.join(timeout=60)
     finally:
         del os.environ["NRD_HIP_POISON_GUIDES"]
-    # sharded frames: all but the restart frame (+ with measure: the frame after the fast one; the fast one itself falls back)
-    assert results == [(r, True, frames - 1 + (1 if measure else 0), True) for r in range(world)], results
+    # sharded frames: all but the restart frame -- which is run whole where the strips are balanced (they are cut from its tile map) and sharded like any other frame since
+    # round 6 where they are not (+ with measure: the frame after the fast one; the fast one itself falls back)
+    restart_sharded = (overrides or {}).get("_balance", True) is False
+    assert results == [(r, True, frames - 1 + (1 if restart_sharded else 0) + (1 if measure else 0), True) for r in range(world)], results
 
 
 @pytest.mark.gpu
@@ -659,7 +713,7 @@ def test_dry_plan_runs_for_every_bench_workload():
     for workload, (name, size, _, overrides) in bench.WORKLOADS.items():
         plan = sharding.dry_plan(name, size[0], size[1], 4, overrides)
         assert plan["denoiser"] == name and plan["ranks"] == 4 and len(plan["per_rank"]) == 4, workload
+        # (round 6: SIGMA is sharded like the others -- until round 5 its passes declared no reach and the chain ran as replicas)
+        assert not plan["per_rank"][1]["fallback_unsharded"] and plan["per_rank"][1]["received_bytes_per_frame"] > 0, workload
         if name.startswith("SIGMA"):
-            assert all(r["fallback_unsharded"] for r in plan["per_rank"])  # its passes declare no reach: the 0.1-ms chain runs as replicas
-        else:
-            assert not plan["per_rank"][1]["fallback_unsharded"] and plan["per_rank"][1]["received_bytes_per_frame"] > 0, workload
+            assert plan["reach_rows"] == [0, 0, 0, 35, 35, 2]
