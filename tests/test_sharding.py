@@ -327,8 +327,6 @@ def test_halo_sharding_virtual_ranks_reproduce_single_gpu(name, world, height, o
         for rt, t, fmt in parity.user_planes(name, frame):
             ex.bind(rt, t.cuda().contiguous(), fmt)
         ov = dict(overrides or {})
-        if f == fallback_frame:
-            ov["maxBlurRadius"] = 400.0  # rings comparable to their distance from the camera have no bounded reach (executor.hip ReblurBlurReachRows): this frame runs unsharded on every rank
         inst.set_denoiser_settings(0, parity.denoiser_settings(name, frame, ov))
         assert inst.set_common_settings(parity.common_settings(frame["camera"], seq[max(f - 1, 0)]["camera"], W, H, f)) == api.Result.SUCCESS
 
@@ -344,7 +342,8 @@ def test_halo_sharding_virtual_ranks_reproduce_single_gpu(name, world, height, o
         begun = []
         for (inst, ex, outs), sh in zip(runs, ranks):
             prepare(inst, ex, f, frame)
-            begun.append(sh.begin_frame())
+            # the fallback frame: the application reports object motion beyond the history halo (begin_frame's motion_rows) -- this frame runs unsharded on every rank
+            begun.append(sh.begin_frame(motion_rows=1000.0 if f == fallback_frame else None))
         plans = [b[0] for b in begun]
         assert len({p.fallback for p in plans}) == 1 and all(sh.bounds == ranks[0].bounds for sh in ranks)  # every rank takes the same decisions
         if plans[0].fallback:
