@@ -126,6 +126,9 @@ uint32_t nrdHipPlanHaloExchange(void* instance, const void* dispatchDescs, uint3
 // lies behind the previous camera (or whose motion vector is NaN) report a huge value on purpose. The value bounds the SURFACE motion only: hosts double it for the
 // virtual motion of specular reflections, which is a heuristic (a curved reflector can exceed it), not a check.
 uint32_t nrdHipMeasureMotionRows(NrdHipExecutor* executor, const void* dispatchDescs, uint32_t dispatchDescsNum, uint32_t rowBegin, uint32_t rowEnd, float* maxRows);
+// The same measurement without the host round trip: enqueued on the executor's stream, the result (a float) lands in 4 bytes of the CALLER'S device memory in stream order -- the
+// buffer a multi-GPU host hands to its MAX all-reduce (RCCL reads it on the device); the host then synchronises once, on the reduced value.
+uint32_t nrdHipMeasureMotionRowsAsync(NrdHipExecutor* executor, const void* dispatchDescs, uint32_t dispatchDescsNum, uint32_t rowBegin, uint32_t rowEnd, void* deviceMaxRows);
 
 // Per-pass GPU timing. When enabled, every dispatch is bracketed by hipEvents on the executor's stream.
 // nrdHipCollectPassTimings synchronises the stream, folds all brackets recorded since the last collect into per-pipeline

@@ -44,6 +44,14 @@ public:
         (void)value, (void)computeStream;
         return true;
     }
+    // The same reduction without the host in the middle (round 6): DeviceScalar() = 4 bytes of device memory the transport can all-reduce in place (nullptr: this transport
+    // has only the host form above). BeginFrame then lets nrdHipMeasureMotionRowsAsync write the strip's value there in stream order, MaxOverRanksInPlace reduces it on the
+    // device and synchronises ONCE to hand the result back -- instead of synchronise, read back, upload, reduce, read back.
+    virtual void* DeviceScalar() { return nullptr; }
+    virtual bool MaxOverRanksInPlace(float& value, void* computeStream) {
+        (void)value, (void)computeStream;
+        return false;
+    }
 };
 
 struct ShardedIntegrationHipCreationDesc {
@@ -98,6 +106,16 @@ public:
     // exists for hosts that interleave their own work and for the virtual-rank test.
     inline bool BeginFrame(const Identifier* denoisers, uint32_t denoisersNum, const UserPoolHip& userPool) {
         float rows = -1.0f;
+        void* deviceScalar = (m_Desc.measureMotion && m_Desc.world > 1) ? m_Desc.transport->DeviceScalar() : nullptr;
+        if (deviceScalar) { // the measurement stays on the device until it is reduced
+            if (!PrepareFrame(denoisers, denoisersNum, userPool, nullptr, false))
+                return false;
+            if (nrdHipMeasureMotionRowsAsync(m_Integration.GetExecutor(), m_Dispatches, m_DispatchesNum, m_Bounds[m_Desc.rank], m_Bounds[m_Desc.rank + 1], deviceScalar) != (uint32_t)Result::SUCCESS)
+                return false;
+            if (!m_Desc.transport->MaxOverRanksInPlace(rows, m_Desc.integration.hipStream))
+                return Fail("transport max-reduction failed");
+            return PlanFrame(rows);
+        }
         if (!PrepareFrame(denoisers, denoisersNum, userPool, &rows))
             return false;
         if (rows >= 0.0f && !m_Desc.transport->MaxOverRanks(rows, m_Desc.integration.hipStream))
@@ -108,7 +126,7 @@ public:
     //   PrepareFrame   binds the user planes, asks the instance for the frame's dispatch list and -- with measureMotion -- measures this strip's motion
     //                  (*localMotionRows; -1 when nothing was measured)
     //   PlanFrame      plans the halo exchange; motionRowsOverRanks >= 0 is held against maxMotionRows (the SAME value on every rank), < 0 = no check
-    inline bool PrepareFrame(const Identifier* denoisers, uint32_t denoisersNum, const UserPoolHip& userPool, float* localMotionRows = nullptr) {
+    inline bool PrepareFrame(const Identifier* denoisers, uint32_t denoisersNum, const UserPoolHip& userPool, float* localMotionRows = nullptr, bool measure = true) {
         m_Error = nullptr;
         NrdHipExecutor* ex = m_Integration.GetExecutor();
         for (size_t slot = 0; slot < userPool.size(); slot++)
@@ -120,7 +138,7 @@ public:
         if (GetComputeDispatches(*m_Integration.GetInstance(), denoisers, denoisersNum, m_Dispatches, m_DispatchesNum) != Result::SUCCESS)
             return Fail("GetComputeDispatches failed");
         float rows = -1.0f;
-        if (m_Desc.measureMotion && m_Desc.world > 1 &&
+        if (measure && m_Desc.measureMotion && m_Desc.world > 1 &&
             nrdHipMeasureMotionRows(ex, m_Dispatches, m_DispatchesNum, m_Bounds[m_Desc.rank], m_Bounds[m_Desc.rank + 1], &rows) != (uint32_t)Result::SUCCESS)
             return false;
         if (localMotionRows)
@@ -354,6 +372,13 @@ public:
             return false;
         return hipMemcpyAsync(m_Scalar, &value, sizeof(float), hipMemcpyHostToDevice, s) == hipSuccess && ncclAllReduce(m_Scalar, m_Scalar, 1, ncclFloat, ncclMax, m_Comm, s) == ncclSuccess &&
                hipMemcpyAsync(&value, m_Scalar, sizeof(float), hipMemcpyDeviceToHost, s) == hipSuccess && hipStreamSynchronize(s) == hipSuccess;
+    }
+
+    inline void* DeviceScalar() override { return (m_Scalar || hipMalloc((void**)&m_Scalar, sizeof(float)) == hipSuccess) ? m_Scalar : nullptr; }
+    inline bool MaxOverRanksInPlace(float& value, void* computeStream) override { // the value is on the device already (nrdHipMeasureMotionRowsAsync): reduce, one read-back
+        hipStream_t s = (hipStream_t)computeStream;
+        return m_Scalar && ncclAllReduce(m_Scalar, m_Scalar, 1, ncclFloat, ncclMax, m_Comm, s) == ncclSuccess && hipMemcpyAsync(&value, m_Scalar, sizeof(float), hipMemcpyDeviceToHost, s) == hipSuccess &&
+               hipStreamSynchronize(s) == hipSuccess;
     }
 
 private:

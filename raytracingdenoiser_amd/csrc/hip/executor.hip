@@ -1289,15 +1289,47 @@ extern "C" __attribute__((visibility("default"))) uint32_t nrdHipGetTileFallback
 }
 
 // Multi-GPU: how far does THIS frame's surface-motion reprojection reach vertically, over the rows [rowBegin, rowEnd) of the rect? (include/NRDHip.h)
+// the measurement enqueued on the executor's stream: deviceWord (4 bytes of device memory) receives the float's bits when the stream gets there; found = false: the list has no
+// temporal denoiser and nothing was enqueued
+static uint32_t EnqueueMotionRows(NrdHipExecutor* e, const void* dispatchDescs, uint32_t dispatchDescsNum, uint32_t rowBegin, uint32_t rowEnd, uint32_t* deviceWord, bool& found);
+
 extern "C" __attribute__((visibility("default"))) uint32_t nrdHipMeasureMotionRows(NrdHipExecutor* e, const void* dispatchDescs, uint32_t dispatchDescsNum, uint32_t rowBegin, uint32_t rowEnd,
     float* maxRows) {
     if (!e || !maxRows || (!dispatchDescs && dispatchDescsNum))
         return (uint32_t)nrd::Result::INVALID_ARGUMENT;
     *maxRows = 0.0f;
+    if (!e->motionBits && hipMalloc((void**)&e->motionBits, sizeof(uint32_t)) != hipSuccess)
+        return e->Fail(nrd::Result::FAILURE, "nrdHipMeasureMotionRows: cannot allocate the result word");
+    bool found = false;
+    const uint32_t r = EnqueueMotionRows(e, dispatchDescs, dispatchDescsNum, rowBegin, rowEnd, e->motionBits, found);
+    if (r != (uint32_t)nrd::Result::SUCCESS || !found)
+        return r;
+    uint32_t bits = 0;
+    if (hipStreamSynchronize(e->stream) != hipSuccess || hipMemcpy(&bits, e->motionBits, sizeof(bits), hipMemcpyDeviceToHost) != hipSuccess)
+        return e->Fail(nrd::Result::FAILURE, "nrdHipMeasureMotionRows: cannot read the result back");
+    memcpy(maxRows, &bits, sizeof(bits));
+    return (uint32_t)nrd::Result::SUCCESS;
+}
+
+// The same measurement WITHOUT the host round trip (round 6): the result lands in 4 bytes of the CALLER'S device memory, in stream order. A multi-GPU host
+// hands that word straight to its MAX all-reduce (RCCL reads it on the device) and synchronises once, on the reduced value -- instead of stream-synchronise, read back, upload,
+// reduce, read back. 0.0f is written when the list has no temporal denoiser.
+extern "C" __attribute__((visibility("default"))) uint32_t nrdHipMeasureMotionRowsAsync(NrdHipExecutor* e, const void* dispatchDescs, uint32_t dispatchDescsNum, uint32_t rowBegin, uint32_t rowEnd,
+    void* deviceMaxRows) {
+    if (!e || !deviceMaxRows || (!dispatchDescs && dispatchDescsNum))
+        return (uint32_t)nrd::Result::INVALID_ARGUMENT;
+    bool found = false;
+    const uint32_t r = EnqueueMotionRows(e, dispatchDescs, dispatchDescsNum, rowBegin, rowEnd, (uint32_t*)deviceMaxRows, found);
+    if (r == (uint32_t)nrd::Result::SUCCESS && !found && hipMemsetAsync(deviceMaxRows, 0, sizeof(uint32_t), e->stream) != hipSuccess)
+        return e->Fail(nrd::Result::FAILURE, "nrdHipMeasureMotionRowsAsync: hipMemsetAsync failed");
+    return r;
+}
+
+static uint32_t EnqueueMotionRows(NrdHipExecutor* e, const void* dispatchDescs, uint32_t dispatchDescsNum, uint32_t rowBegin, uint32_t rowEnd, uint32_t* deviceWord, bool& found) {
+    found = false;
     const nrd::DispatchDesc* descs = (const nrd::DispatchDesc*)dispatchDescs;
     const nrd::InstanceDesc& idesc = nrd::GetInstanceDesc(*e->instance);
     MotionParams p = {};
-    bool found = false;
     int originX = 0, originY = 0;
     for (uint32_t i = 0; i < dispatchDescsNum && !found; i++) {
         const nrd::DispatchDesc& d = descs[i];
@@ -1355,16 +1387,10 @@ extern "C" __attribute__((visibility("default"))) uint32_t nrdHipMeasureMotionRo
         return e->Fail(nrd::Result::INVALID_ARGUMENT, "nrdHipMeasureMotionRows: the rect leaves the bound IN_VIEWZ / IN_MV planes");
     z.ptr += (size_t)originY * z.pitch + (size_t)originX * 4;
     mv.ptr += (size_t)originY * mv.pitch + (size_t)originX * 8;
-    if (!e->motionBits && hipMalloc((void**)&e->motionBits, sizeof(uint32_t)) != hipSuccess)
-        return e->Fail(nrd::Result::FAILURE, "nrdHipMeasureMotionRows: cannot allocate the result word");
     const int r0 = (int)(rowBegin < (uint32_t)p.rectH ? rowBegin : (uint32_t)p.rectH), r1 = (int)(rowEnd < (uint32_t)p.rectH ? rowEnd : (uint32_t)p.rectH);
-    uint32_t bits = 0;
-    if (hipMemsetAsync(e->motionBits, 0, sizeof(uint32_t), e->stream) != hipSuccess)
+    if (hipMemsetAsync(deviceWord, 0, sizeof(uint32_t), e->stream) != hipSuccess)
         return e->Fail(nrd::Result::FAILURE, "nrdHipMeasureMotionRows: hipMemsetAsync failed");
-    LaunchMotionRows(e->stream, z, mv, p, r0, r1, e->motionBits);
-    if (hipStreamSynchronize(e->stream) != hipSuccess || hipMemcpy(&bits, e->motionBits, sizeof(bits), hipMemcpyDeviceToHost) != hipSuccess)
-        return e->Fail(nrd::Result::FAILURE, "nrdHipMeasureMotionRows: cannot read the result back");
-    memcpy(maxRows, &bits, sizeof(bits));
+    LaunchMotionRows(e->stream, z, mv, p, r0, r1, deviceWord);
     return (uint32_t)nrd::Result::SUCCESS;
 }
 

@@ -125,6 +125,13 @@ class HipExecutor:
         self._check(self.lib.nrdHipMeasureMotionRows(self.handle, C.cast(ptr, C.c_void_p), n, row_begin, min(row_end, 0xFFFFFFFF), C.byref(out)), "nrdHipMeasureMotionRows")
         return out.value
 
+    def measure_motion_rows_async(self, ptr, n, row_begin, row_end, device_word):
+        """the same measurement enqueued on the executor's stream: the result lands in device_word (a 1-element float32 CUDA tensor) in stream order, no host synchronisation
+        -- include/NRDHip.h nrdHipMeasureMotionRowsAsync. The caller all-reduces the tensor and reads it once."""
+        assert device_word.is_cuda and device_word.numel() == 1 and device_word.element_size() == 4
+        self._check(self.lib.nrdHipMeasureMotionRowsAsync(self.handle, C.cast(ptr, C.c_void_p), n, row_begin, min(row_end, 0xFFFFFFFF), C.c_void_p(device_word.data_ptr())),
+                    "nrdHipMeasureMotionRowsAsync")
+
     def set_profiling(self, enable):
         self._check(self.lib.nrdHipSetProfiling(self.handle, 1 if enable else 0), "nrdHipSetProfiling")
 

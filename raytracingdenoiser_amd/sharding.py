@@ -475,11 +475,29 @@ class HaloSharder:
         dist.all_reduce(t, dist.ReduceOp.MAX, self.group)
         return float(t.item())
 
+    def _measure_motion_over_ranks(self, dispatches, rows):
+        """MAX over ranks of every rank's measurement on its own rows. Over RCCL the value never visits the host before it is reduced (round 6): the kernel
+        writes into a device word, the all-reduce reads it there in stream order, and the host synchronises ONCE, on the reduced value -- until round 5: stream-synchronise,
+        4-byte read-back, upload, all-reduce, read-back. Over gloo (CPU tensors; the tests) and for a single rank the host form is used."""
+        import torch.distributed as dist
+
+        real_group = dist.is_available() and dist.is_initialized() and dist.get_world_size(self.group) == self.world
+        if real_group and dist.get_backend(self.group) == "nccl" and hasattr(self.ex, "measure_motion_rows_async"):
+            import torch
+
+            if getattr(self, "_motion_word", None) is None:
+                self._motion_word = torch.zeros(1, dtype=torch.float32, device="cuda")
+            self.ex.measure_motion_rows_async(dispatches[0], dispatches[1], rows[0], rows[1], self._motion_word)
+            if self.world > 1:
+                dist.all_reduce(self._motion_word, dist.ReduceOp.MAX, self.group)
+            return float(self._motion_word.item())
+        return self._max_over_ranks(self.ex.measure_motion_rows(dispatches[0], dispatches[1], rows[0], rows[1]))
+
     def motion_exceeds_halo(self, motion_rows=None, dispatches=None):
         """True when this frame's reprojection may leave the history halo (see the class docstring); dispatches = (ptr, n) of this frame's list (measure_motion)"""
         if getattr(self, "measure_motion", False) and dispatches is not None:
             rows = self.rows or (0, self.height)
-            self.measured_motion_rows = self._max_over_ranks(self.ex.measure_motion_rows(dispatches[0], dispatches[1], rows[0], rows[1]))
+            self.measured_motion_rows = self._measure_motion_over_ranks(dispatches, rows)
             return self.SPECULAR_MOTION_FACTOR * self.measured_motion_rows + 2.0 >= self.max_motion_rows
         cs = getattr(self.inst, "last_common_settings", None)
         camera = camera_motion_rows(cs, (getattr(self, "near_depth", 1.0), 1.0e4)) if cs is not None else 0.0

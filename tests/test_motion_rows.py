@@ -78,6 +78,13 @@ def _check_world_space(name, backend):
         got = h.measure(*rows)
         assert got == pytest.approx(want, rel=2e-3, abs=2e-3), (name, rows, got, want)
     assert h.measure() > 0.05  # the sequence's camera moves
+    if backend == "hip":
+        # nrdHipMeasureMotionRowsAsync (round 6): the same kernel, the result left in the caller's device memory in stream order -- equal to the synchronous form bit for bit
+        word = torch.full((1,), -1.0, dtype=torch.float32, device="cuda")
+        for rows in ((0, H), (H // 2, H), (50, 50)):
+            h.ex.measure_motion_rows_async(h.ptr, h.n, rows[0], rows[1], word)
+            torch.cuda.synchronize()
+            assert float(word.item()) == h.measure(*rows), rows
     assert h.measure(0, 10 * H) == h.measure()  # rowEnd is clamped to the rect
 
 

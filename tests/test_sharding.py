@@ -433,6 +433,9 @@ def _halo_nccl_world1_worker(q):
         results.append([o.clone() for o in outs])
         if sharded:
             assert sh.gather_frames >= 1
+            # the device-resident motion reduction (round 6): kernel -> device word -> RCCL all-reduce (MAX; one rank here) -> one read-back == the synchronous measurement
+            r, ptr, n = inst.get_compute_dispatches_raw()
+            assert sh._measure_motion_over_ranks((ptr, n), (0, H)) == ex.measure_motion_rows(ptr, n, 0, H) > 0.0
             results.append([sh.complete_output(rt).clone() for rt, dtype, ch, fmt in parity.output_planes(name, W, H)])
     q.put(all(torch.equal(a, b) for a, b in zip(results[0], results[1])) and all(torch.equal(a, b) for a, b in zip(results[0], results[2])))
     dist.destroy_process_group()
