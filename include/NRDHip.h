@@ -128,6 +128,12 @@ uint32_t nrdHipPlanHaloExchange(void* instance, const void* dispatchDescs, uint3
 uint32_t nrdHipMeasureMotionRows(NrdHipExecutor* executor, const void* dispatchDescs, uint32_t dispatchDescsNum, uint32_t rowBegin, uint32_t rowEnd, float* maxRows);
 // The same measurement without the host round trip: enqueued on the executor's stream, the result (a float) lands in 4 bytes of the CALLER'S device memory in stream order -- the
 // buffer a multi-GPU host hands to its MAX all-reduce (RCCL reads it on the device); the host then synchronises once, on the reduced value.
+// What the measurement above cannot bound: the temporal passes of the SPECULAR denoisers also read last frame's planes at the virtual-motion position and at look-back taps behind
+// it, whose distance depends on hit distances and surface curvature. So the kernels report it: with a device word registered here, every temporal pass (REBLUR / RELAX
+// TemporalAccumulation, SIGMA TemporalStabilization) leaves in it -- atomicMax on the bits of a non-negative float -- the largest number of rows one of its pixels read away from its
+// own row (sample positions only: add 3 rows for the bicubic footprint). The word belongs to the caller: clear it in stream order before a frame, read it (or MAX-all-reduce it over
+// the ranks) after, hold it against the history halo that frame was run with, and size the next frame's decision with it. nullptr (the default) switches the tracking off.
+uint32_t nrdHipSetHistoryReachWord(NrdHipExecutor* executor, void* deviceWord);
 uint32_t nrdHipMeasureMotionRowsAsync(NrdHipExecutor* executor, const void* dispatchDescs, uint32_t dispatchDescsNum, uint32_t rowBegin, uint32_t rowEnd, void* deviceMaxRows);
 
 // Per-pass GPU timing. When enabled, every dispatch is bracketed by hipEvents on the executor's stream.

@@ -280,7 +280,7 @@ NRD_HIP_SYMBOLS = ["nrdHipCreateExecutor", "nrdHipDestroyExecutor", "nrdHipBindR
                    "nrdHipDenoise", "nrdHipGetPoolMemoryUsage", "nrdHipGetLastError", "nrdHipEvalNumerics", "nrdHipGetArenaSize",
                    "nrdHipCreateExecutorWithArena", "nrdHipSetProfiling", "nrdHipCollectPassTimings", "nrdHipSetOwnedRows", "nrdHipGetDispatchReach",
                    "nrdHipExecuteDispatchRange", "nrdHipPlanHaloExchange", "nrdHipSetGraphMode", "nrdHipGetGraphStats", "nrdHipGetTileFallbackStats", "nrdHipGetNumericsMode", "nrdHipMeasureCopyBandwidth",
-                   "nrdHipMeasureMotionRows", "nrdHipMeasureMotionRowsAsync"]
+                   "nrdHipMeasureMotionRows", "nrdHipMeasureMotionRowsAsync", "nrdHipSetHistoryReachWord"]
 
 _libs = {}
 
@@ -342,6 +342,7 @@ def load_library(path=None):
     lib.nrdHipGetGraphStats.argtypes, lib.nrdHipGetGraphStats.restype = [C.c_void_p, P(C.c_uint64), P(C.c_uint64), P(C.c_uint64)], C.c_uint32
     lib.nrdHipGetTileFallbackStats.argtypes, lib.nrdHipGetTileFallbackStats.restype = [C.c_void_p, P(C.c_uint32), P(C.c_uint32)], C.c_uint32
     lib.nrdHipMeasureMotionRows.argtypes, lib.nrdHipMeasureMotionRows.restype = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, P(C.c_float)], C.c_uint32
+    lib.nrdHipSetHistoryReachWord.argtypes, lib.nrdHipSetHistoryReachWord.restype = [C.c_void_p, C.c_void_p], C.c_uint32
     if hasattr(lib, "nrdHipMeasureMotionRowsAsync"):  # (absent from the CPU emulation of the device sources: tests/emu)
         lib.nrdHipMeasureMotionRowsAsync.argtypes, lib.nrdHipMeasureMotionRowsAsync.restype = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_void_p], C.c_uint32
     lib.nrdHipGetNumericsMode.argtypes, lib.nrdHipGetNumericsMode.restype = [], C.c_uint32

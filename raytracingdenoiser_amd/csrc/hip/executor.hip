@@ -106,6 +106,7 @@ struct NrdHipExecutor {
     Plane tileFlags = {};              // one byte per 32x8-pixel workgroup tile: hand-over between the two kernels of a split pass (kernels_reblur_ta.hip "window")
     Plane viewPos = {};                // internal float4 guide plane of the REBLUR lists (decoded normal + viewZ per pixel)
     Plane roughnessWord = {};          // internal 4-B/px copy of the decoded normals' w word, written with viewPos (passes.h PassArgs::roughnessWord)
+    uint32_t* historyReachWord = nullptr; // nrdHipSetHistoryReachWord: the CALLER'S device word the temporal passes report their history reach into (passes.h); null = not tracked
     uint32_t* motionBits = nullptr;    // nrdHipMeasureMotionRows: the reduction's result (float bits), own 4-byte allocation made on first use
     std::vector<nrd::Format> permanentFormat, transientFormat;
 
@@ -1167,6 +1168,7 @@ static uint32_t ExecuteRange(NrdHipExecutor* e, const nrd::DispatchDesc* descs, 
         args.viewPos = viewPos;
         args.roughnessWord = viewPos.ptr ? e->roughnessWord : Plane{};
         args.tileFlags = e->tileFlags;
+        args.historyReachWord = e->historyReachWord;
         args.windowRegion = e->windowRegion;
         if (i == fuseDispatch)
             args.fuseGuidesFrom = guidePlane(nrd::ResourceType::IN_NORMAL_ROUGHNESS);
@@ -1391,6 +1393,15 @@ static uint32_t EnqueueMotionRows(NrdHipExecutor* e, const void* dispatchDescs, 
     if (hipMemsetAsync(deviceWord, 0, sizeof(uint32_t), e->stream) != hipSuccess)
         return e->Fail(nrd::Result::FAILURE, "nrdHipMeasureMotionRows: hipMemsetAsync failed");
     LaunchMotionRows(e->stream, z, mv, p, r0, r1, deviceWord);
+    return (uint32_t)nrd::Result::SUCCESS;
+}
+
+// Multi-GPU: where the temporal passes report how far (rows) they read last frame's planes from a pixel's own row (include/NRDHip.h). The word belongs to the caller, who clears
+// it (in stream order) before a frame and reads / all-reduces it after; nullptr switches the tracking off (the default: the kernels then skip it on a uniform branch).
+extern "C" __attribute__((visibility("default"))) uint32_t nrdHipSetHistoryReachWord(NrdHipExecutor* e, void* deviceWord) {
+    if (!e)
+        return (uint32_t)nrd::Result::INVALID_ARGUMENT;
+    e->historyReachWord = (uint32_t*)deviceWord; // (graph mode: a kernel argument like any other -- the node parameters are updated when they change)
     return (uint32_t)nrd::Result::SUCCESS;
 }
 

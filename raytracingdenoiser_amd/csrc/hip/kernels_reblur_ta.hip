@@ -34,6 +34,7 @@ constexpr int WIN_W = NRD_TA_WIN_W;
 constexpr int WIN_H = NRD_TA_WIN_H;
 
 struct TaPlanes {
+    uint32_t* historyReach; // passes.h PassArgs::historyReachWord (multi-GPU hosts; nullptr otherwise)
     Plane tileFlags; // executor scratch, one byte per workgroup tile (passes.h): set by the window kernel for the tiles it leaves to the fallback kernel
     int winMaxW, winMaxH; // largest box the window kernel accepts (<= WIN_W x WIN_H; smaller values exercise the fallback kernel: NRD_HIP_TA_WINDOW_LIMIT)
     Plane tiles, normalRoughness, viewZ, mv, prevViewZ, prevNormalRoughness, prevInternalData;
@@ -250,6 +251,8 @@ __device__ __forceinline__ void ReblurTemporalAccumulationTile(const ReblurCB& c
         Xprev = Xprev + mv;
         smbPixelUv = GetScreenUv(c.gWorldToClipPrev, Xprev);
     }
+
+    TrackHistoryReach(P.historyReach, active ? HistoryReachRows(smbPixelUv.y, rectSizePrev.y, py) : 0.0f); // (multi-GPU hosts; a null word otherwise)
 
     // Previous viewZ: 4x4 footprint as four 2x2 quads in (0,0)(1,0)(0,1)(1,1) order
     float2 catromOrigin = GetCatmullRomOrigin(smbPixelUv, rectSizePrev);
@@ -732,6 +735,7 @@ __device__ __forceinline__ void ReblurTemporalAccumulationTile(const ReblurCB& c
             stochasticRaw1 = LoadNrRaw(P.prevNormalRoughness, st1.x, st1.y);
         } else
             vmbLinear1 = SampleLinearPrevNormalRoughness(P.prevNormalRoughness, vmbPixelUvPrevTap * resolutionScalePrev * prevNormalRoughnessSize);
+        TrackHistoryReach(P.historyReach, Max(HistoryReachRows(vmbPixelUv.y, rectSizePrev.y, py), HistoryReachRows(vmbPixelUvPrevTap.y, rectSizePrev.y, py))); // virtual motion + the look-back tap
         // previous tracking hit distance: the 2x2 of the linear sample
         const LinearTaps hitDistTaps = MakeLinearTaps(vmbPixelUv * resolutionScalePrev * F2(float(P.prevSpecHitDistForTracking.w), float(P.prevSpecHitDistForTracking.h)));
         const bool hitDistInterior = FootprintIsInterior(P.prevSpecHitDistForTracking, hitDistTaps.x0, hitDistTaps.y0, 2, 2);
@@ -1075,6 +1079,7 @@ static const char* LaunchTemporalAccumulation(const PassArgs& a) {
         return "REBLUR: orthographic projection is not supported (SURVEY.md section 8c)";
 
     TaPlanes P = {};
+    P.historyReach = a.historyReachWord;
     uint32_t k = 0;
     P.tiles = a.planes[k++];
     P.normalRoughness = a.planes[k++];

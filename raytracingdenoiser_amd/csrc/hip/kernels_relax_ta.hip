@@ -35,6 +35,7 @@ constexpr int WIN_W = 64; // at most 64: one lane per column when the window is 
 constexpr int WIN_H = 16;
 
 struct TaPlanes {
+    uint32_t* historyReach; // passes.h PassArgs::historyReachWord (multi-GPU hosts; nullptr otherwise)
     Plane tileFlags;      // executor scratch, one byte per workgroup tile (passes.h)
     int winMaxW, winMaxH; // largest box the window kernel accepts (NRD_HIP_TA_WINDOW_LIMIT shrinks it for tests)
     Plane tiles, mv, normalRoughness, viewZ, prevNormalRoughness, prevViewZ, prevSpecHitDist, prevHistoryLength, prevMaterialID, disocclusionThresholdMix;
@@ -166,6 +167,8 @@ __device__ __forceinline__ void RelaxTemporalAccumulationTile(const RelaxCB& cAr
         prevWorldPos = prevWorldPos + mv;
         prevUVSMB = GetScreenUv(c.shared.gWorldToClipPrev, prevWorldPos);
     }
+
+    TrackHistoryReach(P.historyReach, active ? HistoryReachRows(prevUVSMB.y, rectSizePrev.y, py) : 0.0f); // (multi-GPU hosts; a null word otherwise: reblur_device.h)
 
     // noisy inputs
     const float3 diffuseIllumination = DIFF ? Xyz(LoadRGBA16F(P.diff.in, lpx, lpy)) : F3(0.0f);
@@ -626,6 +629,7 @@ __device__ __forceinline__ void RelaxTemporalAccumulationTile(const RelaxCB& cAr
         uvDiff = uvDiff * (Sat(uvDiffLengthInPixels * (1.0f / 0.1f)) + uvDiffLengthInPixels * 0.5f);
         const float2 backUV1 = prevUVVMB + uvDiff * 1.0f;
         const float2 backUV2 = prevUVVMB + uvDiff * 2.0f;
+        TrackHistoryReach(P.historyReach, Max(HistoryReachRows(prevUVVMB.y, rectSizePrev.y, py), HistoryReachRows(backUV2.y, rectSizePrev.y, py))); // virtual motion + the look-back taps
         const float2 prevNrSize = F2(float(P.prevNormalRoughness.w), float(P.prevNormalRoughness.h));
         const float4 backNormalRoughness1 = UnpackPrevNormalRoughness(SampleLinearRGBA8Unorm(P.prevNormalRoughness, backUV1 * resolutionScalePrev * prevNrSize));
         const float4 backNormalRoughness2 = UnpackPrevNormalRoughness(SampleLinearRGBA8Unorm(P.prevNormalRoughness, backUV2 * resolutionScalePrev * prevNrSize));
@@ -774,6 +778,7 @@ const char* LaunchTemporalAccumulation(const PassArgs& a) {
         return e;
     PlaneCursor cur(a);
     TaPlanes P = {};
+    P.historyReach = a.historyReachWord;
     P.tiles = cur.next();
     if (SPEC) P.spec.in = cur.next();
     if (DIFF) P.diff.in = cur.next();

@@ -498,7 +498,7 @@ NRD_D typename SigmaType<TRANSLUCENT>::type FetchShadowHistory(const HistoryFilt
 }
 
 template <bool TRANSLUCENT>
-__global__ __launch_bounds__(TILE_X* TILE_Y) void SigmaTemporalStabilizationKernel(SigmaCB c, TsPlanes P, int blockY0) {
+__global__ __launch_bounds__(TILE_X* TILE_Y) void SigmaTemporalStabilizationKernel(SigmaCB c, TsPlanes P, int blockY0, uint32_t* historyReach) {
     typedef SigmaType<TRANSLUCENT> ST;
     typedef typename ST::type S;
     __shared__ float s_Penumbra[BUF_Y * BUF_STRIDE];
@@ -589,6 +589,7 @@ __global__ __launch_bounds__(TILE_X* TILE_Y) void SigmaTemporalStabilizationKern
         smbPixelUv = GetScreenUv(c.gWorldToClipPrev, Xprev);
     }
 
+    TrackHistoryReach(historyReach, HistoryReachRows(smbPixelUv.y, rectSizePrev.y, py)); // (multi-GPU hosts; a null word otherwise: reblur_device.h)
     Bilinear smbBilinearFilter = GetBilinearFilter(smbPixelUv, rectSizePrev);
     const int bx = (int)smbBilinearFilter.origin.x, by = (int)smbBilinearFilter.origin.y;
     uint32_t d0 = FetchClampedR32U(P.historyLength, bx, by), d1 = FetchClampedR32U(P.historyLength, bx + 1, by), d2 = FetchClampedR32U(P.historyLength, bx, by + 1),
@@ -645,7 +646,7 @@ static const char* LaunchTemporalStabilization(const PassArgs& a) {
     dim3 grid = GridFor(c.gRectSizeMinusOne.x + 1, c.gRectSizeMinusOne.y + 1, TILE_X, TILE_Y);
     const RowBand band = MakeRowBand(a, c.gRectSizeMinusOne.y + 1, TILE_Y);
     grid.y = band.blocksY;
-    LaunchPass(a, SigmaTemporalStabilizationKernel<TRANSLUCENT>, grid, dim3(TILE_X * TILE_Y), c, P, band.blockY0);
+    LaunchPass(a, SigmaTemporalStabilizationKernel<TRANSLUCENT>, grid, dim3(TILE_X * TILE_Y), c, P, band.blockY0, a.historyReachWord);
     return nullptr;
 }
 

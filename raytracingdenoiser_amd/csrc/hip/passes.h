@@ -116,6 +116,10 @@ struct PassArgs {
     // the rect's tiles in this rank's rows. Only there do the flags describe the last frame (nrdHipGetTileFallbackStats); bytes outside keep stale values of a
     // larger rect / other ranks' rows, which nothing reads.
     int* windowRegion = nullptr;
+    // multi-GPU (round 6): 4 bytes of device memory in which the temporal passes leave, as the bits of a non-negative float, the largest number of ROWS a pixel of theirs read last
+    // frame's planes away from its own row -- surface motion, virtual (specular) motion and the look-back taps behind it (reblur_device.h TrackHistoryReach). nullptr: not tracked.
+    // A row-strip host holds it against the history halo it exchanged (nrdHipSetHistoryReachWord).
+    uint32_t* historyReachWord = nullptr;
     // non-null: the launcher performs all its checks and hands its launch(es) to the recorder instead of enqueueing them
     LaunchRecorder* recorder = nullptr;
 };

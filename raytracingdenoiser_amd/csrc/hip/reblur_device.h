@@ -574,6 +574,40 @@ NRD_D float4 SampleLinearRGBA16F(const Plane& p, float2 pos) {
            s11 = FetchClampedRGBA16F(p, t.x0 + 1, t.y0 + 1);
     return s00 * t.w00 + s10 * t.w10 + s01 * t.w01 + s11 * t.w11;
 }
+// ---- multi-GPU: how far from its own row does a pixel read LAST FRAME'S planes? -------------------------------------------------------------------------
+// A row-strip rank holds last frame's planes only on its strip + a halo. The surface-motion reprojection is bounded by what nrdHipMeasureMotionRows measures, but the specular
+// passes also read at the VIRTUAL-motion position and at look-back taps behind it (REBLUR_TemporalAccumulation.hlsli:455-610, RELAX_TemporalAccumulation.hlsli:420-520), whose
+// distance depends on hit distances and curvature: no a-priori bound (profiles/r06_i_scaling_model_relax_ds_sh.json: one rank of four read 50+ rows beyond a 9-row surface motion).
+// So the kernels REPORT it: uvY = the sample's uv.y in the previous frame's rect (clamped: a sample outside the screen is rejected, whatever its texels hold), the wave's maximum
+// of |uvY * rectHeight - row| goes into *word with one atomicMax on the float's bits. The wave reduction walks the active lanes with v_readlane (exact under divergence: lanes
+// that left the kernel do not take part) and only those that exceed what the word already holds: in steady state no lane does and the cost is a load, a compare and a ballot.
+NRD_D float HistoryReachRows(float uvY, float rectHeight, int row) {
+    const float d = fabsf(fminf(fmaxf(uvY, 0.0f), 1.0f) * rectHeight - (float(row) + 0.5f));
+    return uvY == uvY ? d : 0.0f; // (a NaN position -- the direction of a zero motion -- is rejected by the in-screen tests like one outside the screen)
+}
+NRD_D void TrackHistoryReach(uint32_t* word, float rows) {
+    if (!word) // (uniform: a kernel argument)
+        return;
+    const uint32_t bits = __float_as_uint(rows);
+#ifdef NRD_EMU
+    if (bits > *word) // (the CPU emulation of these sources has no wave intrinsics outside convergent code)
+        atomicMax(word, bits);
+#else
+    const uint32_t seen = __builtin_nontemporal_load(word);
+    unsigned long long mask = __ballot(bits > seen);
+    if (!mask)
+        return;
+    uint32_t m = 0u;
+    while (mask) {
+        const int lane = __builtin_ctzll(mask);
+        m = max(m, (uint32_t)__builtin_amdgcn_readlane((int)bits, lane));
+        mask &= mask - 1ull;
+    }
+    if (bits == m) // the lane(s) holding the maximum
+        atomicMax(word, m);
+#endif
+}
+
 NRD_D NrRaw FetchClampedNrRaw(const Plane& p, int x, int y) { return LoadNrRaw(p, ClampI(x, 0, p.w - 1), ClampI(y, 0, p.h - 1)); }
 // gPrev_Normal_Roughness.SampleLevel( gLinearClamp, ... ) of the encodings without the stochastic tap (REBLUR_TemporalAccumulation.hlsli:473, 593): the ENCODED texels are blended
 NRD_D float4 SampleLinearPrevNormalRoughness(const Plane& p, float2 pos) {

@@ -132,6 +132,12 @@ class HipExecutor:
         self._check(self.lib.nrdHipMeasureMotionRowsAsync(self.handle, C.cast(ptr, C.c_void_p), n, row_begin, min(row_end, 0xFFFFFFFF), C.c_void_p(device_word.data_ptr())),
                     "nrdHipMeasureMotionRowsAsync")
 
+    def set_history_reach_word(self, device_word):
+        """device_word: a 1-element float32 CUDA tensor (kept alive by the caller) the temporal passes report their history reach into (rows; atomicMax) -- or None to switch the
+        tracking off. include/NRDHip.h nrdHipSetHistoryReachWord."""
+        assert device_word is None or (device_word.numel() == 1 and device_word.element_size() == 4)
+        self._check(self.lib.nrdHipSetHistoryReachWord(self.handle, C.c_void_p(device_word.data_ptr() if device_word is not None else 0)), "nrdHipSetHistoryReachWord")
+
     def set_profiling(self, enable):
         self._check(self.lib.nrdHipSetProfiling(self.handle, 1 if enable else 0), "nrdHipSetProfiling")
 

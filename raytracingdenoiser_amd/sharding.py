@@ -406,6 +406,14 @@ class HaloSharder:
         self.exchanged_bytes = 0  # received bytes, for reporting
         self.rebalanced = 0
         self.motion_fallbacks = 0  # frames run unsharded because the motion estimate exceeded the history halo
+        # History reach (round 6): what the measured SURFACE motion cannot bound -- the specular passes' virtual-motion position and the look-back taps behind it -- is REPORTED by
+        # the temporal kernels themselves (include/NRDHip.h nrdHipSetHistoryReachWord: rows, MAX over the rank's pixels). With measure_motion the word rides on the same per-frame
+        # all-reduce as the motion measurement: frame f is decided with max(2 x motion_f + 2, 1.25 x reach_{f-1} + 3), and a frame whose own reach turns out to have left the halo
+        # it ran with is COUNTED (history_halo_violations; the next frame then falls back by the rule above, so stale rows are read for one frame at most -- and never unnoticed).
+        self.history_reach_rows = 0.0     # the last value known (the previous frame's, over all ranks)
+        self.history_halo_violations = 0  # sharded frames whose temporal passes read beyond the halo they were given
+        self._last_frame_sharded = False
+        self._words = None                # [motion of this frame, history reach of the previous one]: float32 x 2 on the executor's device
         self._plans = {}
         # Output reassembly (BASELINE.json configs[3]: "screen tiled across 8 x MI355X with RCCL all-gather"; the reference's Integration::Denoise hands back COMPLETE outputs,
         # NRDIntegration.hpp:516-623). The bound OUT_* planes are working planes of the pass chain (the pre-pass of the NEXT frame already overwrites them), so the complete
@@ -460,45 +468,59 @@ class HaloSharder:
 
     SPECULAR_MOTION_FACTOR = 2.0  # virtual (reflection) motion relative to the surface motion that the camera estimate bounds
 
-    def _max_over_ranks(self, value):
+    HISTORY_REACH_MARGIN, HISTORY_FOOTPRINT_ROWS = 1.25, 3.0  # frame f's reach is predicted from frame f - 1's; the bicubic footprint around a sample position
+
+    def _measure_motion_over_ranks(self, dispatches, rows):
+        """MAX over ranks of (this frame's surface motion on the rank's own rows, the history reach the temporal kernels reported LAST frame). Over RCCL the values never visit
+        the host before they are reduced (round 6): the kernels write into device words, the all-reduce reads them there in stream order, and the host
+        synchronises ONCE, on the reduced pair -- until round 5: stream-synchronise, 4-byte read-back, upload, all-reduce, read-back. Over gloo (the tests: CPU emulation, or two
+        ranks sharing one GPU) the pair is staged through the host. Returns the motion; the reach lands in self.history_reach_rows."""
         import torch
         import torch.distributed as dist
 
-        if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(self.group) != self.world:
-            # virtual ranks of a single process: nobody reduces for them, and a rank deciding on its LOCAL maximum could take a different fallback decision than its
-            # neighbours -- the host that drives virtual ranks has to reduce the measurements itself
-            if self.world > 1:
-                raise RuntimeError("HaloSharder(measure_motion=True) with %d ranks but no process group of that size: reduce the measured motion over the ranks yourself "
-                                   "(ex.measure_motion_rows per rank, then denoise(motion_rows=max)) or create the sharder with measure_motion=False" % self.world)
-            return value
-        t = torch.tensor([value], dtype=torch.float32, device="cuda" if dist.get_backend(self.group) == "nccl" else "cpu")
-        dist.all_reduce(t, dist.ReduceOp.MAX, self.group)
-        return float(t.item())
-
-    def _measure_motion_over_ranks(self, dispatches, rows):
-        """MAX over ranks of every rank's measurement on its own rows. Over RCCL the value never visits the host before it is reduced (round 6): the kernel
-        writes into a device word, the all-reduce reads it there in stream order, and the host synchronises ONCE, on the reduced value -- until round 5: stream-synchronise,
-        4-byte read-back, upload, all-reduce, read-back. Over gloo (CPU tensors; the tests) and for a single rank the host form is used."""
-        import torch.distributed as dist
-
         real_group = dist.is_available() and dist.is_initialized() and dist.get_world_size(self.group) == self.world
-        if real_group and dist.get_backend(self.group) == "nccl" and hasattr(self.ex, "measure_motion_rows_async"):
-            import torch
+        if self.world > 1 and not real_group:
+            # virtual ranks of a single process: nobody reduces for them, and a rank deciding on its LOCAL maximum could take a different fallback decision than its
+            # neighbours (ADVICE r04) -- the host that drives virtual ranks has to reduce the measurements itself (begin_frame(motion_rows=..., history_reach=...))
+            raise RuntimeError("HaloSharder(measure_motion=True) with %d ranks but no process group of that size: reduce the measured motion over the ranks yourself "
+                               "(ex.measure_motion_rows per rank, then denoise(motion_rows=max)) or create the sharder with measure_motion=False" % self.world)
+        on_device = hasattr(self.ex, "measure_motion_rows_async") and getattr(self.ex, "arena", None) is not None and self.ex.arena.is_cuda
+        if self._words is None:
+            self._words = torch.zeros(2, dtype=torch.float32, device="cuda" if on_device else "cpu")
+            if hasattr(self.ex, "set_history_reach_word"):
+                self.ex.set_history_reach_word(self._words[1:])
+        if on_device:
+            self.ex.measure_motion_rows_async(dispatches[0], dispatches[1], rows[0], rows[1], self._words[:1])
+        else:
+            self._words[0] = self.ex.measure_motion_rows(dispatches[0], dispatches[1], rows[0], rows[1])
+        if self.world > 1:
+            if dist.get_backend(self.group) == "nccl":
+                dist.all_reduce(self._words, dist.ReduceOp.MAX, self.group)
+                motion, reach = self._words.tolist()  # the one synchronisation of the frame's planning
+            else:
+                host = self._words.cpu()
+                dist.all_reduce(host, dist.ReduceOp.MAX, self.group)
+                motion, reach = host.tolist()
+        else:
+            motion, reach = self._words.tolist()
+        self._words[1:].zero_()  # this frame's temporal passes report into a cleared word (stream order: behind the reduction, in front of the frame's launches)
+        self.history_reach_rows = float(reach)
+        if self._last_frame_sharded and reach + self.HISTORY_FOOTPRINT_ROWS > self.max_motion_rows:
+            self.history_halo_violations += 1
+        return float(motion)
 
-            if getattr(self, "_motion_word", None) is None:
-                self._motion_word = torch.zeros(1, dtype=torch.float32, device="cuda")
-            self.ex.measure_motion_rows_async(dispatches[0], dispatches[1], rows[0], rows[1], self._motion_word)
-            if self.world > 1:
-                dist.all_reduce(self._motion_word, dist.ReduceOp.MAX, self.group)
-            return float(self._motion_word.item())
-        return self._max_over_ranks(self.ex.measure_motion_rows(dispatches[0], dispatches[1], rows[0], rows[1]))
-
-    def motion_exceeds_halo(self, motion_rows=None, dispatches=None):
-        """True when this frame's reprojection may leave the history halo (see the class docstring); dispatches = (ptr, n) of this frame's list (measure_motion)"""
+    def motion_exceeds_halo(self, motion_rows=None, dispatches=None, history_reach=None):
+        """True when this frame's reprojection may leave the history halo (see the class docstring); dispatches = (ptr, n) of this frame's list (measure_motion);
+        history_reach: hosts that reduce over (virtual) ranks themselves pass what the temporal kernels reported LAST frame, MAX over the ranks (nrdHipSetHistoryReachWord)"""
+        if history_reach is not None:
+            self.history_reach_rows = float(history_reach)
+            if self.HISTORY_REACH_MARGIN * self.history_reach_rows + self.HISTORY_FOOTPRINT_ROWS >= self.max_motion_rows:
+                return True
         if getattr(self, "measure_motion", False) and dispatches is not None:
             rows = self.rows or (0, self.height)
             self.measured_motion_rows = self._measure_motion_over_ranks(dispatches, rows)
-            return self.SPECULAR_MOTION_FACTOR * self.measured_motion_rows + 2.0 >= self.max_motion_rows
+            need = max(self.SPECULAR_MOTION_FACTOR * self.measured_motion_rows + 2.0, self.HISTORY_REACH_MARGIN * self.history_reach_rows + self.HISTORY_FOOTPRINT_ROWS)
+            return need >= self.max_motion_rows
         cs = getattr(self.inst, "last_common_settings", None)
         camera = camera_motion_rows(cs, (getattr(self, "near_depth", 1.0), 1.0e4)) if cs is not None else 0.0
         if camera is None:
@@ -506,7 +528,7 @@ class HaloSharder:
         need = self.SPECULAR_MOTION_FACTOR * camera + (float(motion_rows) if motion_rows is not None else 0.0) + 2.0
         return need >= self.max_motion_rows
 
-    def begin_frame(self, motion_rows=None):
+    def begin_frame(self, motion_rows=None, history_reach=None):
         """GetComputeDispatches + plan; returns (plan, dispatch pointer, count). A plan that falls back while this rank's planes are incomplete
         carries plan.complete_keys: the carried-over planes every rank has to receive in full before the frame runs."""
         from . import api
@@ -527,7 +549,7 @@ class HaloSharder:
             # a restart frame (its list clears the history) with balancing on: run it whole on every rank -- nothing has to be completed for it, and its tile map is what the
             # strips are cut from in front of the next frame. (Without balancing the restart frame is sharded like any other since round 6: clears are texel-local.)
             recut = True
-        if self.world > 1 and self.motion_exceeds_halo(motion_rows, (ptr, n)):
+        if self.world > 1 and self.motion_exceeds_halo(motion_rows, (ptr, n), history_reach):
             recut = True  # same mechanics as a deliberate re-cut frame: complete the planes, run the whole frame everywhere
             self.motion_fallbacks += 1
         if cached is not None and not cached.fallback and not self.complete and not recut:
@@ -588,6 +610,7 @@ class HaloSharder:
 
     def finish_frame(self, plan):
         self.complete = plan.fallback or self.world == 1
+        self._last_frame_sharded = not plan.fallback and self.world > 1
         self._sharded_since_cut = 0 if plan.fallback else self._sharded_since_cut + 1
 
     def run_step(self, plan, ptr, n, step):

@@ -103,6 +103,11 @@ class EmuExecutor:
         self._check(self.lib.nrdHipMeasureMotionRows(self.handle, C.cast(ptr, C.c_void_p), n, row_begin, min(row_end, 0xFFFFFFFF), C.byref(out)), "nrdHipMeasureMotionRows")
         return out.value
 
+    def set_history_reach_word(self, word):
+        """word: a 1-element float32 CPU tensor / array (the emulated kernels run on the host) or None -- raytracingdenoiser_amd/executor.py set_history_reach_word"""
+        ptr = 0 if word is None else (word.data_ptr() if hasattr(word, "data_ptr") else word.ctypes.data)
+        self._check(self.lib.nrdHipSetHistoryReachWord(self.handle, C.c_void_p(ptr)), "nrdHipSetHistoryReachWord")
+
     def set_graph_mode(self, enable):
         pass  # graphs are a launch mechanism of the real runtime (graph == eager is a GPU test, tests/test_executor.py); the emulation always launches eagerly
 

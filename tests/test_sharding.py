@@ -552,7 +552,10 @@ def _halo_two_process_emulated_worker(rank, world, port, name, W, H, frames, ove
         mv[H - 7, 11, 1] = -40.0
         fast["mv"], fast["viewz"] = mv, z
         steps.append((fast, dict(isMotionVectorInWorldSpace=False, motionVectorScale=(1.0 / W, 1.0 / H, 0.0))))
-        steps.append((seq[-1], {}))  # and back to a sharded frame
+        steps.append((seq[-1], {}))  # the frame after: still unsharded -- the temporal kernels REPORTED a 40-row history reach for the fast frame, and a frame is decided with
+        steps.append((seq[-1], {}))  # 1.25 x the reach of the one before it (round 6: HaloSharder.history_reach_rows) -- and then back to a sharded frame
+
+    sh_stats = {"violations": 0, "reach_after_fast": 0.0}
 
     def run(sharded):
         inst = api.Instance([(0, parity.DENOISERS[name][0])], lib=lib)
@@ -571,11 +574,15 @@ def _halo_two_process_emulated_worker(rank, world, port, name, W, H, frames, ove
             if sharded:
                 sharded_frames += 0 if sh.denoise().fallback else 1
                 measured.append(sh.measured_motion_rows)
+                if measure and f == frames + 1:
+                    sh_stats["reach_after_fast"] = sh.history_reach_rows
                 sh.wait_outputs()
                 per_frame.append(([sh.complete_output(rt).clone() for rt, dtype, ch, fmt in parity.output_planes(name, W, H)], sh.rows))  # the reassembled planes
             else:
                 ex.denoise()
                 per_frame.append(([o.clone() for o in outs], (0, H)))
+        if sharded:
+            sh_stats["violations"] = sh.history_halo_violations
         return per_frame, sharded_frames, (sh.exchanged_bytes if sharded else 0), (sh.motion_fallbacks if sharded else 0), measured
 
     ref = run(False)[0]
@@ -591,7 +598,8 @@ def _halo_two_process_emulated_worker(rank, world, port, name, W, H, frames, ove
                     print("rank", rank, "frame", f, "rows differing", bad[:5], "...", bad[-5:], len(bad), file=sys.stderr, flush=True)
     if measure:
         # every rank saw the same (reduced) value on every frame; the fast frame measured its 40 rows and was the only motion fallback
-        ok = ok and motion_fallbacks == 1 and abs(measured[frames] - 40.0) < 0.05 and all(m is not None and m < 7.0 for i, m in enumerate(measured) if i != frames)
+        ok = ok and motion_fallbacks == 2 and abs(measured[frames] - 40.0) < 0.05 and all(m is not None and m < 7.0 for i, m in enumerate(measured) if i != frames)
+        ok = ok and sh_stats["violations"] == 0 and sh_stats["reach_after_fast"] >= 39.0  # no SHARDED frame read beyond its halo; the fast frame's reach was seen one frame later
     q.put((rank, ok, sharded_frames, exchanged > 0))
     dist.barrier()
     dist.destroy_process_group()

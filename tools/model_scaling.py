@@ -70,6 +70,8 @@ def main():
         if world > 1:
             shard = sharding.HaloSharder(run[1], run[0], W, H, rank, world, max_motion_rows=args.max_motion_rows, balance=bool(args.balance)) if halo else sharding.FrameSharder(run[1], run[0], W, H, rank, world, run[2])
         run_planes = planes_of(*run)
+        reach_word = torch.zeros(1, dtype=torch.float32, device="cuda")
+        ref[1].set_history_reach_word(reach_word)
         ms = []
         exchanged = []
         exact = True
@@ -83,7 +85,11 @@ def main():
             if halo:
                 # lock-step with the full-frame executor: it runs the same segments, and the bands the two neighbours would send are
                 # copied out of its planes before each segment (the copies stand in for the RCCL transfers and are not timed)
-                plan, ptr, n = shard.begin_frame()
+                # what a real group's per-frame all-reduce carries (HaloSharder._measure_motion_over_ranks): the history reach the temporal kernels reported LAST frame, MAX over
+                # the ranks -- here read from the full-frame executor, whose kernels see every rank's pixels
+                reach_prev = float(reach_word.item())
+                reach_word.zero_()
+                plan, ptr, n = shard.begin_frame(history_reach=reach_prev)
                 r2, rptr, rn = ref[0].get_compute_dispatches_raw()
                 assert rn == n
                 t, got = 0.0, 0
