@@ -20,6 +20,7 @@ uint16_t TransientAliasOf(const Instance& instance, Identifier identifier, uint1
 #include <cstring>
 #include <string>
 #include <map>
+#include <set>
 #include <vector>
 
 using namespace nrdhip;
@@ -630,6 +631,7 @@ extern "C" __attribute__((visibility("default"))) uint32_t nrdHipPlanHaloExchang
         return false;
     };
     std::map<Key, int> lastWrite;
+    std::set<Key> cleared; // planes a Clear_ pass of this list wrote (every texel, on every rank)
     std::map<std::pair<Key, int>, int> need; // (plane, writer index or -1) -> halo rows
     std::vector<char> wholeFrame(num, 0);
     for (uint32_t i = 0; i < num; i++) {
@@ -663,16 +665,28 @@ extern "C" __attribute__((visibility("default"))) uint32_t nrdHipPlanHaloExchang
             const bool historyCopy = w >= 0 && descs[w].pipelineIndex < idesc.pipelinesNum && !strncmp(idesc.pipelines[descs[w].pipelineIndex].shaderFileName, "SIGMA_Copy", 10);
             if (historyCopy && segOf[w] == segOf[i])
                 return fallback(); // (never with the default threshold: Blur's reach starts a segment between the two)
-            if (w >= 0 && segOf[w] == segOf[i])
-                continue; // produced in this segment with a sufficient margin
+            if (w >= 0 && segOf[w] == segOf[i]) {
+                // produced in this segment with a sufficient margin -- where it was WRITTEN: every pass skips the sky, and a reader with a neighbourhood also reads the texels next
+                // to the geometry that the writer left alone (they hold what the plane held at the end of the last frame -- on a rank only inside its strip). The rows of the
+                // reader's neighbourhood outside the strip are therefore fetched from their owner at the frame start, before the writer runs (sharding.py plan_halo_exchange)
+                if (reach[i] > 0 && !cleared.count(key)) { // (a plane cleared earlier in this frame holds zeros wherever nothing was written since: the same on every rank)
+                    int& slot = need[std::make_pair(key, -1)];
+                    slot = std::max(slot, margins[i] + reach[i]);
+                }
+                continue;
+            }
             const int h = margins[i] + reach[i] + ((w < 0 || historyCopy) ? (int)maxMotionRows : 0);
             if (h > 0) {
                 int& slot = need[std::make_pair(key, w)];
                 slot = std::max(slot, h);
             }
         }
-        for (const Key& key : writes)
+        const bool isClear = d.pipelineIndex < idesc.pipelinesNum && !strncmp(idesc.pipelines[d.pipelineIndex].shaderFileName, "Clear_", 6);
+        for (const Key& key : writes) {
             lastWrite[key] = (int)i;
+            if (isClear)
+                cleared.insert(key);
+        }
     }
     for (const auto& kv : need)
         if (kv.second > per)

@@ -735,7 +735,6 @@ __device__ __forceinline__ void ReblurTemporalAccumulationTile(const ReblurCB& c
             stochasticRaw1 = LoadNrRaw(P.prevNormalRoughness, st1.x, st1.y);
         } else
             vmbLinear1 = SampleLinearPrevNormalRoughness(P.prevNormalRoughness, vmbPixelUvPrevTap * resolutionScalePrev * prevNormalRoughnessSize);
-        TrackHistoryReach(P.historyReach, Max(HistoryReachRows(vmbPixelUv.y, rectSizePrev.y, py), HistoryReachRows(vmbPixelUvPrevTap.y, rectSizePrev.y, py))); // virtual motion + the look-back tap
         // previous tracking hit distance: the 2x2 of the linear sample
         const LinearTaps hitDistTaps = MakeLinearTaps(vmbPixelUv * resolutionScalePrev * F2(float(P.prevSpecHitDistForTracking.w), float(P.prevSpecHitDistForTracking.h)));
         const bool hitDistInterior = FootprintIsInterior(P.prevSpecHitDistForTracking, hitDistTaps.x0, hitDistTaps.y0, 2, 2);
@@ -894,6 +893,9 @@ __device__ __forceinline__ void ReblurTemporalAccumulationTile(const ReblurCB& c
         float virtualHistoryConfidenceForSmbRelaxation = virtualHistoryNormalBasedConfidence * virtualHistoryRoughnessBasedConfidence;
         float virtualHistoryConfidence = virtualHistoryNormalBasedConfidence * virtualHistoryRoughnessBasedConfidence * virtualHistoryParallaxBasedConfidence;
         virtualHistoryAmount *= virtualHistoryRoughnessBasedConfidence;
+        // multi-GPU hosts: the virtual-motion position and the look-back tap behind it, where they still COUNT (the virtual history is blended with this weight; the positions of
+        // rejected samples -- grazing reflections project anywhere on the screen -- would say nothing about a halo)
+        TrackHistoryReach(P.historyReach, virtualHistoryAmount != 0.0f ? Max(HistoryReachRows(vmbPixelUv.y, rectSizePrev.y, py), HistoryReachRows(vmbPixelUvPrevTap.y, rectSizePrev.y, py)) : 0.0f);
 
         NRD_CONSTANTS_PHASE();
         // Sample surface history

@@ -629,7 +629,6 @@ __device__ __forceinline__ void RelaxTemporalAccumulationTile(const RelaxCB& cAr
         uvDiff = uvDiff * (Sat(uvDiffLengthInPixels * (1.0f / 0.1f)) + uvDiffLengthInPixels * 0.5f);
         const float2 backUV1 = prevUVVMB + uvDiff * 1.0f;
         const float2 backUV2 = prevUVVMB + uvDiff * 2.0f;
-        TrackHistoryReach(P.historyReach, Max(HistoryReachRows(prevUVVMB.y, rectSizePrev.y, py), HistoryReachRows(backUV2.y, rectSizePrev.y, py))); // virtual motion + the look-back taps
         const float2 prevNrSize = F2(float(P.prevNormalRoughness.w), float(P.prevNormalRoughness.h));
         const float4 backNormalRoughness1 = UnpackPrevNormalRoughness(SampleLinearRGBA8Unorm(P.prevNormalRoughness, backUV1 * resolutionScalePrev * prevNrSize));
         const float4 backNormalRoughness2 = UnpackPrevNormalRoughness(SampleLinearRGBA8Unorm(P.prevNormalRoughness, backUV2 * resolutionScalePrev * prevNrSize));
@@ -642,6 +641,9 @@ __device__ __forceinline__ void RelaxTemporalAccumulationTile(const RelaxCB& cAr
         float rw = ComputeWeight(backNormalRoughness1.w * backNormalRoughness1.w, relaxedRoughnessWeightParams.x, relaxedRoughnessWeightParams.y);
         rw *= ComputeWeight(backNormalRoughness2.w * backNormalRoughness2.w, relaxedRoughnessWeightParams.x, relaxedRoughnessWeightParams.y);
         virtualHistoryAmount *= rw * 0.9f + 0.1f;
+        // multi-GPU hosts: the virtual-motion position and the look-back taps behind it, where they still COUNT -- everything fetched there enters the result through
+        // virtualHistoryAmount, and the positions of rejected samples (grazing reflections project anywhere on the screen: 1 400 rows at 4K) would say nothing about a halo
+        TrackHistoryReach(P.historyReach, virtualHistoryAmount != 0.0f ? Max(HistoryReachRows(prevUVVMB.y, rectSizePrev.y, py), HistoryReachRows(backUV2.y, rectSizePrev.y, py)) : 0.0f);
 
         NRD_CONSTANTS_PHASE();
         // hit distance confidence

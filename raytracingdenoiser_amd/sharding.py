@@ -144,6 +144,7 @@ def plan_halo_exchange(dispatches, reach, rows, height, max_motion_rows=32, exch
     plan.margins = margins
 
     last_write = {}
+    cleared = set()  # planes a Clear_ pass of this frame wrote (every texel, on every rank)
     whole_frame = set()
     need = {}  # (key, writer index or -1) -> halo rows
     for i, d in enumerate(dispatches):
@@ -164,12 +165,21 @@ def plan_halo_exchange(dispatches, reach, rows, height, max_motion_rows=32, exch
                 plan.fallback = True
                 return plan
             if w >= 0 and seg_of[w] == seg_of[i]:
-                continue  # produced in this segment with a sufficient margin
+                # produced in this segment with a sufficient margin -- where it was WRITTEN. Every pass skips the sky, and a reader with a neighbourhood (reach > 0) also reads the
+                # texels next to the geometry that the writer left alone (RELAX TemporalAccumulation takes the specular hit distance of its 3x3 from the pre-pass output, sky or
+                # not: RELAX_TemporalAccumulation.hlsli:363, 433-450). On one GPU such a texel holds what the plane held at the end of the last frame; on a rank that is only true
+                # inside its strip. So the rows of the reader's neighbourhood that lie outside the strip are fetched from their owner at the frame start, BEFORE the writer runs
+                # (round 6: found by the 4-rank 4K model run, whose second strip starts just below the horizon).
+                if reach[i] > 0 and key not in cleared:  # (a plane cleared earlier in this frame holds zeros wherever nothing was written since: the same on every rank)
+                    need[(key, -1)] = max(need.get((key, -1), 0), margins[i] + reach[i])
+                continue
             h = margins[i] + reach[i] + (max_motion_rows if w < 0 or history_copy else 0)
             if h > 0:
                 need[(key, w)] = max(need.get((key, w), 0), h)
         for key in writes:
             last_write[key] = i
+            if d.shader.startswith("Clear_"):
+                cleared.add(key)
     if any(h > per for h in need.values()):
         plan.fallback = True  # a halo would reach past the neighbouring strip
         return plan

@@ -19,6 +19,7 @@ def main():
     workload, world, rank = sys.argv[1], int(sys.argv[2]), int(sys.argv[3])
     frames = int(sys.argv[4]) if len(sys.argv) > 4 else 24
     balance = bool(int(sys.argv[5])) if len(sys.argv) > 5 else True
+    motion_rows = int(sys.argv[6]) if len(sys.argv) > 6 else None  # the history halo (rows); default: HaloSharder.default_motion_rows
     name, (W, H), _, overrides = bench.WORKLOADS[workload]
     seq = parity.generate_sequence(name, W, H, frames, device="cuda")  # (as tools/model_scaling.py)
 
@@ -32,7 +33,7 @@ def main():
         return inst, ex, outs
 
     ref, run = make(), make()
-    sh = sharding.HaloSharder(run[1], run[0], W, H, rank, world, balance=balance)
+    sh = sharding.HaloSharder(run[1], run[0], W, H, rank, world, balance=balance, max_motion_rows=motion_rows)
     reach_word = torch.zeros(1, dtype=torch.float32, device="cuda")  # the full-frame run's temporal kernels report the history reach of ALL rows (nrdHipSetHistoryReachWord)
     ref[1].set_history_reach_word(reach_word)
     RT = api.ResourceType
@@ -73,32 +74,62 @@ def main():
                 lo, hi = max(rb - w, 0), min(re + w, H)
                 plane(run, key)[lo:rb].copy_(plane(ref, key)[lo:rb])
                 plane(run, key)[re:hi].copy_(plane(ref, key)[re:hi])
-            sh.run_step(plan, ptr, n, step)
-            ref[1].execute_range(rptr, rn, first, count)
-            torch.cuda.synchronize()
-            last_writer = {}
+            rbs, res = plan.c_rows()
             for i in range(first, first + count):
-                for dt, t, idx in ds[i].resources:
-                    if dt == api.DescriptorType.STORAGE_TEXTURE:
-                        last_writer[(int(t), idx)] = i
-            for i in range(first, first + count):
-                if plan.row_begin[i] < 0:
-                    continue
+                whole = plan.row_begin[i] < 0
                 m = plan.margins[i]
-                lo, hi = max(rb - m, 0), min(re + m, H)
+                lo, hi = (0, H) if whole else (max(rb - m, 0), min(re + m, H))
+                # (a) the inputs of pass i, right before it runs, on the rows its declared reach covers (planes carried over from last frame: + nothing here -- their motion-dependent
+                #     reads are what the history reach reports; a stale row inside [lo - reach, hi + reach) is a planning error)
+                r = max(plan.reach[i], 0)
+                for dt, t, idx in ds[i].resources:
+                    key = (int(t), idx)
+                    if dt != api.DescriptorType.TEXTURE or int(t) < int(RT.OUT_DIFF_RADIANCE_HITDIST):
+                        continue
+                    a, b = plane(run, key), plane(ref, key)
+                    if a.shape[0] != H:
+                        continue
+                    ilo, ihi = max(lo - r, 0), min(hi + r, H)
+                    if not torch.equal(a[ilo:ihi], b[ilo:ihi]):
+                        bad = (a[ilo:ihi] != b[ilo:ihi]).any(dim=1).nonzero().flatten() + ilo
+                        print("frame %d pass %d %s: INPUT plane %s is stale in rows %d..%d (%d rows) of [%d, %d) = produced rows [%d, %d) +- reach %d" % (
+                            f, i, ds[i].shader, key, int(bad.min()), int(bad.max()), len(bad), ilo, ihi, lo, hi, r))
+                # (b) the pass, on both
+                before = {(int(t), idx): plane(run, (int(t), idx)).clone() for dt, t, idx in ds[i].resources if dt == api.DescriptorType.STORAGE_TEXTURE and plane(run, (int(t), idx)).shape[0] == H}
+                before_ref = {k: plane(ref, k).clone() for k in before}
+                run[1].execute_range(ptr, n, i, 1, rbs, res)
+                ref[1].execute_range(rptr, rn, i, 1)
+                torch.cuda.synchronize()
+                # (c) its outputs on the rows it had to produce
                 for dt, t, idx in ds[i].resources:
                     if dt != api.DescriptorType.STORAGE_TEXTURE:
                         continue
                     key = (int(t), idx)
-                    if last_writer[key] != i:
-                        continue  # overwritten later in this segment (ping-pong / scratch use of the OUT planes): only its last version can be compared after the segment
                     a, b = plane(run, key), plane(ref, key)
+                    if whole:  # tile maps: complete on every rank
+                        if not torch.equal(a, b):
+                            bad = (a != b).nonzero()
+                            print("frame %d pass %d %s (whole frame): OUTPUT plane %s differs at %d places, first (row, byte) %s: run %d ref %d" % (f, i, ds[i].shader, key, len(bad), bad[0].tolist(), int(a[tuple(bad[0].tolist())]), int(b[tuple(bad[0].tolist())])))
+                            return 1
+                        continue
                     if a.shape[0] != H:
                         continue
-                    if not torch.equal(a[lo:hi], b[lo:hi]):
-                        bad = (a[lo:hi] != b[lo:hi]).any(dim=1).nonzero().flatten() + lo
-                        print("frame %d step %d pass %d %s (reach %d margin %d): plane %s differs in rows %d..%d (%d rows) of the needed [%d, %d); strip [%d, %d)" % (
-                            f, step, i, ds[i].shader, plan.reach[i], m, key, int(bad.min()), int(bad.max()), len(bad), lo, hi, rb, re))
+                    # only what the pass WROTE on either side counts: a texel neither wrote (sky) keeps whatever an earlier frame left there, which differs between a rank and a
+                    # full-frame run outside the rank's strip and is read by nobody
+                    wrote = (a[lo:hi] != before[key][lo:hi]) | (b[lo:hi] != before_ref[key][lo:hi])
+                    if bool(((a[lo:hi] != b[lo:hi]) & wrote).any()):
+                        dmask = (a[lo:hi] != b[lo:hi]) & wrote
+                        bad = dmask.any(dim=1).nonzero().flatten() + lo
+                        cols = dmask.any(dim=0).nonzero().flatten()
+                        print("frame %d step %d pass %d %s (reach %d margin %d): OUTPUT plane %s differs in rows %d..%d (%d rows), byte columns %d..%d, of the produced [%d, %d); strip [%d, %d)" % (
+                            f, step, i, ds[i].shader, plan.reach[i], m, key, int(bad.min()), int(bad.max()), len(bad), int(cols.min()), int(cols.max()), lo, hi, rb, re))
+                        d = dmask
+                        unwritten = int(((a[lo:hi] == before[key][lo:hi]) & d).sum()), int(d.sum())
+                        yy, xx = d.nonzero()[0].tolist()
+                        print("   %d of the %d differing bytes still hold what the plane held BEFORE the pass (= never written by this rank); first at row %d byte %d: run %d ref %d before %d" % (
+                            unwritten[0], unwritten[1], yy + lo, xx, int(a[yy + lo, xx]), int(b[yy + lo, xx]), int(before[key][yy + lo, xx])))
+                        rowsum = d.any(dim=1).nonzero().flatten() + lo
+                        print("   differing rows:", rowsum.tolist()[:40])
                         return 1
         sh.finish_frame(plan)
         print("frame", f, "ok", "strip", sh.rows)
