@@ -186,9 +186,11 @@ int main(int argc, char** argv) {
         cs.timeDeltaBetweenFrames = 16.667f; // 0 would make every instance measure its own wall-clock frame time (frame-rate dependent constants)
         cs.accumulationMode = f == 0 ? nrd::AccumulationMode::CLEAR_AND_RESTART : nrd::AccumulationMode::CONTINUE;
         nrd::ReblurSettings rs = {};
-        rs.maxBlurRadius = 10.0f; // halos that fit a 96-row strip
+        // halos that fit a 96-row strip -- except on one frame, whose blur rings are as large as their distance from the camera and therefore have no bounded reach
+        // (executor.hip ReblurBlurReachRows): that frame runs unsharded on every rank. (Until round 5 a hit-distance reconstruction pass served as the trigger; it is sharded now.)
+        rs.maxBlurRadius = f == unshardedFrame ? 400.0f : 10.0f;
         rs.diffusePrepassBlurRadius = rs.specularPrepassBlurRadius = 12.0f;
-        rs.hitDistanceReconstructionMode = f == unshardedFrame ? nrd::HitDistanceReconstructionMode::AREA_3X3 : nrd::HitDistanceReconstructionMode::OFF;
+        rs.hitDistanceReconstructionMode = nrd::HitDistanceReconstructionMode::OFF;
 
         nrd::Identifier id = 1;
         single.NewFrame();
@@ -227,7 +229,7 @@ int main(int argc, char** argv) {
             CHECK(r == 0 || ranks[r]->GetStepsNum() == steps);
             steps = ranks[r]->GetStepsNum();
         }
-        const bool expectSharded = world > 1 && f != 0 && f != unshardedFrame && !(measure && f == fastFrame);
+        const bool expectSharded = world > 1 && f != unshardedFrame && !(measure && f == fastFrame); // (the restart frame too since round 6: clears are texel-local)
         CHECK((steps > 1) == expectSharded);
         shardedFrames += steps > 1;
         for (uint32_t s = 0; s < steps; s++) { // lock-step: every rank's transfers of step s see the peers' rows of step s - 1
@@ -305,7 +307,7 @@ int main(int argc, char** argv) {
     printf("%zu mismatching values in the complete planes after the output gather\n", gatherMismatches);
     if (gatherMismatches)
         return 1;
-    if (mismatches || (world > 1 && (shardedFrames != (size_t)frames - 2 - (measure ? 1 : 0) || received == 0)))
+    if (mismatches || (world > 1 && (shardedFrames != (size_t)frames - 1 - (measure ? 1 : 0) || received == 0)))
         return 1;
     printf("sharded integration OK\n");
     return 0;

@@ -75,6 +75,7 @@ def main():
         ms = []
         exchanged = []
         exact = True
+        unsharded_frames = 0
         for f in range(total):
             frame = seq[f]
             cs = parity.common_settings(frame["camera"], seq[max(f - 1, 0)]["camera"], W, H, f)
@@ -94,6 +95,12 @@ def main():
                 assert rn == n
                 t, got = 0.0, 0
                 steps = [(None, 0, n)] if plan.fallback else plan.steps
+                if plan.fallback:
+                    unsharded_frames += 1 if f >= args.warmup else 0
+                    for key in plan.complete_keys:  # what HaloSharder.complete_planes broadcasts before an unsharded frame that follows sharded ones (untimed, like the halo copies)
+                        src = ref[1].pool_plane_tensor(api.ResourceType(key[0]), key[1]) if key[0] in (int(api.ResourceType.PERMANENT_POOL), int(api.ResourceType.TRANSIENT_POOL)) else \
+                            ref[1]._bound[key[0]].view(-1).view(dtype=torch.uint8).view(H, -1)
+                        shard.plane_tensor(key).copy_(src)
                 for step, (items, first, count) in enumerate(steps):
                     if not plan.fallback:
                         rb, re = shard.rows
@@ -141,7 +148,7 @@ def main():
         gather_bytes = sum(p.shape[0] * p.shape[1] for p in run_planes) if world > 1 and not halo else 0
         results.append({"world": world, "rank": rank, "rows": list(shard.rows) if shard and shard.rows else [0, H], "ms_per_frame": round(sum(ms) / len(ms), 4),
                         "all_gather_bytes_per_frame": gather_bytes, "halo_bytes_received_per_frame": int(sum(exchanged) / len(exchanged)) if exchanged else 0,
-                        "owned_rows_bit_identical_to_full_frame_run": exact if halo else None})
+                        "owned_rows_bit_identical_to_full_frame_run": exact if halo else None, "timed_frames_run_unsharded": unsharded_frames})
         for inst, ex, _ in (ref, run):
             ex.destroy()
     base = results[0]["ms_per_frame"]
