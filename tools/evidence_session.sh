@@ -8,7 +8,7 @@
 #   5. hardware counters, one rocprofv3 --pmc pass per set (tools/pmc_run.sh: FETCH_SIZE; WRITE_SIZE; SQ issue / waits; TCC hit / miss; LDS instructions + bank conflicts)
 #   6. the N = 1 / 2 / 4 / 8 compute model of the halo scheme (tools/model_scaling.py: virtual ranks on one GPU -- MODELLED, no transfers)
 cd "$(dirname "$0")/.." && export TMPDIR=/tmp
-tag=${1:-r05_z}; quick=$2; mkdir -p gpurun_out
+tag=${1:-r06_z}; quick=$2; mkdir -p gpurun_out
 V=raytracingdenoiser_amd/lib/variants
 ( time timeout 1500 python -m pytest tests -m gpu -x -q --durations=25 ) > gpurun_out/${tag}_pytest_gpu.log 2>&1; echo "pytest exit $?" >> gpurun_out/${tag}_pytest_gpu.log; tail -4 gpurun_out/${tag}_pytest_gpu.log
 timeout 300 python __graft_entry__.py smoke > gpurun_out/${tag}_smoke.log 2>&1; tail -1 gpurun_out/${tag}_smoke.log
@@ -38,8 +38,8 @@ if [[ -z "$quick" ]]; then
     bash tools/pmc_run.sh ${tag}_${w} --workload $w --steps 8 --warmup 4 --no-parity > /dev/null 2>&1
   done
   PMC_SETS="FETCH_SIZE;WRITE_SIZE;SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_ANY SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_WAVES" bash tools/pmc_run.sh ${tag}_reblur_ds_nosky --workload reblur_ds --no-sky --steps 8 --warmup 4 --no-parity > /dev/null 2>&1
-  for w in reblur_ds relax_ds_sh; do
-    timeout 600 python tools/model_scaling.py --workload $w > gpurun_out/${tag}_scaling_model_${w}.json 2> gpurun_out/${tag}_scaling_model_${w}.err
+  for w in reblur_ds relax_ds_sh sigma_shadow; do
+    timeout 900 python tools/model_scaling.py --workload $w > gpurun_out/${tag}_scaling_model_${w}.json 2> gpurun_out/${tag}_scaling_model_${w}.err
   done
 fi
 python - <<PY
