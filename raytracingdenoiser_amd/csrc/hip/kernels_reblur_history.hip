@@ -374,7 +374,7 @@ __global__ __launch_bounds__(TILE_X* TILE_Y, NRD_WAVES_REBLUR_TS) void ReblurTem
     __shared__ float s_SpecLuma[SPEC ? ts::BUF_Y * ts::BUF_STRIDE : 1];
 
     const int tx = threadIdx.x % TILE_X, ty = threadIdx.x / TILE_X;
-    const int blockY = BlockTileY(rr);
+    const int blockY = BlockTileY(rr, NRD_ALT_TILE_ORDER != 0); // (A/B: kernels_reblur_spatial.hip)
     const int px = BlockTileX(rr) * TILE_X + tx, py = blockY * TILE_Y + ty;
     const int rw = c.gRectSizeMinusOne.x, rh = c.gRectSizeMinusOne.y;
 

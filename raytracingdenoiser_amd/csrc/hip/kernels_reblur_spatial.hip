@@ -504,7 +504,10 @@ __global__ __launch_bounds__(TILE_X* TILE_Y, NRD_WAVES_REBLUR_SPATIAL) void Rebl
     constexpr bool OCC = KIND == SIGNAL_OCCLUSION;
     typedef typename Sig::type S;
     const int px = BlockTileX(rr) * TILE_X + (threadIdx.x % TILE_X);
-    const int py = (BlockTileY(rr)) * TILE_Y + (threadIdx.x / TILE_X);
+    // NRD_ALT_TILE_ORDER (A/B, round 6): the passes of the chain alternate their walk through the tile rows as the reference's NRD_CTA_ORDER_DEFAULT / _REVERSED do
+    // (Common.hlsli:92-106: "helps to reuse data already stored in caches") -- PrePass top-down, TemporalAccumulation bottom-up, HistoryFix top-down, Blur bottom-up, PostBlur
+    // top-down, TemporalStabilization bottom-up: every pass starts on the rows its predecessor wrote last
+    const int py = (BlockTileY(rr, NRD_ALT_TILE_ORDER && MODE == BLUR)) * TILE_Y + (threadIdx.x / TILE_X);
     if (px > c.gRectSizeMinusOne.x || py > c.gRectSizeMinusOne.y || py < rr.rowBegin || py >= rr.rowEnd)
         return;
     if (LoadR8Unorm(P.tiles, px >> 4, py >> 4) != 0.0f)

@@ -253,6 +253,9 @@ inline RowRange MakeRowRange(const RowGrid& g) { return RowRange{g.firstBlockY, 
 // last are the ones that leave at the tile test, and the stream of sky tiles runs in the shadow of the draining geometry tiles instead of in front of them. Measured per
 // pass (profiles/r04_v_*, r04_w_*): the temporal-accumulation kernels and the RELAX passes gain 1-1.5 %, the REBLUR spatial passes lose 1-2 % (their L2 working set follows
 // the dispatch front): each kernel names its order. NRD_REVERSE_TILE_ROWS = 0 / 1 forces top-down / bottom-up everywhere (A/B).
+#ifndef NRD_ALT_TILE_ORDER
+#define NRD_ALT_TILE_ORDER 0 // 1: REBLUR's Blur and TemporalStabilization walk the tile rows bottom-up (kernels_reblur_spatial.hip: the reference's alternating CTA order)
+#endif
 #ifndef NRD_REVERSE_TILE_ROWS
 #define NRD_REVERSE_TILE_ROWS -1
 #endif
