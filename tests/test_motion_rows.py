@@ -143,3 +143,57 @@ def test_motion_rows_world_space(name):
 def test_motion_rows_screen_space(name):
     _check_screen_space(name, "hip")
     _check_errors("hip")
+
+
+# ---- nrdHipSetHistoryReachWord (round 6): the temporal passes REPORT how far from its own row a pixel read last frame's planes -------------------------------------------
+def _check_history_reach(name, backend):
+    """2D motion vectors of 1.5 rows everywhere, 21 rows at one pixel of geometry, 90 rows at a sky pixel: the word holds 21 after the frame (a diffuse / shadow signal has no virtual
+    motion: its reach IS the surface motion, and equals what nrdHipMeasureMotionRows measured on the inputs); a specular signal reports at least that; nothing is reported
+    without a word, and the outputs do not depend on the tracking"""
+    if backend == "emu":
+        from emu.emu_run import EmuRun as Run
+    else:
+        Run = parity.GpuRun
+    seq = parity.generate_sequence(name, W, H, 3, device="cpu")
+    frame = dict(seq[2])
+    mv = torch.zeros_like(frame["mv"])
+    mv[..., 1] = 1.5
+    z = frame["viewz"].clone()
+    zv = z.view(H, W)
+    zv[100, 3], zv[5, 5] = 3.0, 1.0e6  # geometry, sky
+    mv[100, 3, 1] = 21.0
+    mv[5, 5, 1] = 90.0
+    frame["mv"], frame["viewz"] = mv, z
+    cs_kw = dict(isMotionVectorInWorldSpace=False, motionVectorScale=(1.0 / W, 1.0 / H, 0.0))
+    outs = []
+    for tracked in (False, True):
+        run = Run(name, W, H)
+        word = (np.zeros(1, dtype=np.float32) if backend == "emu" else torch.zeros(1, dtype=torch.float32, device="cuda")) if tracked else None
+        for f in range(3):
+            fr = frame if f == 2 else seq[f]
+            cam, cam_prev = fr["camera"], seq[max(f - 1, 0)]["camera"]
+            if f == 2 and tracked:
+                run.ex.set_history_reach_word(word)
+            run.step(fr, parity.common_settings(cam, cam_prev, W, H, f, **(cs_kw if f == 2 else {})), parity.denoiser_settings(name, fr, None))
+        outs.append({rt: run.output(rt) for rt in run.outs})
+        if tracked:
+            reach = float(word[0] if backend == "emu" else word.item())
+            if "SPECULAR" in name:
+                assert reach >= 20.99, reach
+            else:
+                assert abs(reach - 21.0) < 0.01, reach
+            run.ex.set_history_reach_word(None)
+    for rt in outs[0]:
+        assert np.array_equal(outs[0][rt], outs[1][rt], equal_nan=True), rt
+
+
+@pytest.mark.parametrize("name", ["REBLUR_DIFFUSE", "RELAX_DIFFUSE", "SIGMA_SHADOW", "REBLUR_DIFFUSE_SPECULAR", "RELAX_DIFFUSE_SPECULAR"])
+def test_emulated_history_reach_word(name):
+    _check_history_reach(name, "emu")
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", ["REBLUR_DIFFUSE", "RELAX_DIFFUSE", "SIGMA_SHADOW", "REBLUR_DIFFUSE_SPECULAR", "RELAX_DIFFUSE_SPECULAR_SH"])
+def test_history_reach_word(name):
+    """the device form of TrackHistoryReach: ballot + v_readlane over the active lanes, one atomicMax per wave"""
+    _check_history_reach(name, "hip")
