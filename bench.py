@@ -559,7 +559,10 @@ def main():
                    "gather_bytes_received_per_rank_per_frame": (int(shard.gathered_bytes / max(shard.gather_frames, 1)) if shard is not None and args.sharding == "halo" else None),
                    "motion_bound": (None if shard is None or args.sharding != "halo" else
                                     {"source": "device reduction per strip + MAX over ranks (nrdHipMeasureMotionRows)" if args.motion_bound == "measure" else "camera estimate (5 x 5 samples)",
-                                     "last_measured_rows": shard.measured_motion_rows, "halo_rows": shard.max_motion_rows, "frames_run_unsharded_for_motion": shard.motion_fallbacks}),
+                                     "last_measured_rows": shard.measured_motion_rows, "halo_rows": shard.max_motion_rows, "frames_run_unsharded_for_motion": shard.motion_fallbacks,
+                                     # (round 6) what the measured surface motion cannot bound -- virtual motion and look-back taps of the specular signal -- as the temporal kernels
+                                     # reported it for the previous frame (nrdHipSetHistoryReachWord), and the sharded frames that turned out to have read beyond their halo
+                                     "last_history_reach_rows": shard.history_reach_rows, "history_halo_violations": shard.history_halo_violations}),
                    "storage": "reference pool formats (fp16 history, R10G10B10A2 normals), %.0f B/px/frame compulsory traffic" % total_bpp},
         "roofline": roofline,
         "whole_chain": whole_chain,

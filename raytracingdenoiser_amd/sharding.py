@@ -436,6 +436,21 @@ class HaloSharder:
         self.gathered_bytes = 0   # bytes received by this rank in output all-gathers, for reporting
         self.gather_frames = 0
 
+    def close(self):
+        """unregisters the history-reach word (it lives in a tensor of this object; the executor may outlive it)"""
+        if self._words is not None and hasattr(self.ex, "set_history_reach_word"):
+            try:
+                self.ex.set_history_reach_word(None)
+            except Exception:
+                pass  # (the executor is gone already)
+        self._words = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
     @property
     def rows(self):
         return (self.bounds[self.rank], self.bounds[self.rank + 1]) if self.bounds else None
