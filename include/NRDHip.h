@@ -50,7 +50,8 @@ uint32_t nrdHipCreateExecutorWithArena(void* instance, uint16_t resourceWidth, u
 
 // Binds an application plane to an IN_* / OUT_* slot. The bytes are not copied; the binding persists until rebound.
 // Formats accepted in this build (anything else -> UNSUPPORTED):
-//   IN_MV RGBA16_SFLOAT | IN_NORMAL_ROUGHNESS R10_G10_B10_A2_UNORM | IN_VIEWZ R32_SFLOAT
+//   IN_MV RGBA16_SFLOAT | IN_NORMAL_ROUGHNESS R10_G10_B10_A2_UNORM (the format of the library's normal encoding, nrd::GetLibraryDesc().normalEncoding: RGBA8_UNORM /
+//   RGBA8_SNORM / R10_G10_B10_A2_UNORM / RGBA16_UNORM / RGBA16_SNORM for encodings 0..4 -- a build option as in the reference) | IN_VIEWZ R32_SFLOAT
 //   IN/OUT_{DIFF,SPEC}_RADIANCE_HITDIST RGBA16_SFLOAT | IN/OUT_{DIFF,SPEC}_SH0, _SH1 RGBA16_SFLOAT (REBLUR / RELAX SH variants)
 //   IN/OUT_{DIFF,SPEC}_HITDIST R16_UNORM (REBLUR occlusion family) | IN/OUT_DIFF_DIRECTION_HITDIST RGBA16_SNORM | IN_PENUMBRA R16_SFLOAT | IN_TRANSLUCENCY, IN_BASECOLOR_METALNESS RGBA8_UNORM
 //   OUT_SHADOW_TRANSLUCENCY R8_UNORM (SIGMA_SHADOW) or RGBA8_UNORM (an instance holding SIGMA_SHADOW_TRANSLUCENCY)
