@@ -47,9 +47,12 @@ public:
     // The same reduction without the host in the middle (round 6): DeviceScalar() = 4 bytes of device memory the transport can all-reduce in place (nullptr: this transport
     // has only the host form above). BeginFrame then lets nrdHipMeasureMotionRowsAsync write the strip's value there in stream order, MaxOverRanksInPlace reduces it on the
     // device and synchronises ONCE to hand the result back -- instead of synchronise, read back, upload, reduce, read back.
+    // The buffer holds TWO floats: [0] this frame's surface motion (nrdHipMeasureMotionRowsAsync), [1] the history reach the temporal kernels reported for the PREVIOUS frame
+    // (nrdHipSetHistoryReachWord: virtual motion and look-back taps of the specular signal, which no measurement of the inputs bounds). MaxOverRanksInPlace reduces both with one
+    // collective, hands them back and clears [1] behind the reduction (in stream order) for this frame's kernels.
     virtual void* DeviceScalar() { return nullptr; }
-    virtual bool MaxOverRanksInPlace(float& value, void* computeStream) {
-        (void)value, (void)computeStream;
+    virtual bool MaxOverRanksInPlace(float& value, float& historyReach, void* computeStream) {
+        (void)value, (void)historyReach, (void)computeStream;
         return false;
     }
 };
@@ -112,9 +115,15 @@ public:
                 return false;
             if (nrdHipMeasureMotionRowsAsync(m_Integration.GetExecutor(), m_Dispatches, m_DispatchesNum, m_Bounds[m_Desc.rank], m_Bounds[m_Desc.rank + 1], deviceScalar) != (uint32_t)Result::SUCCESS)
                 return false;
-            if (!m_Desc.transport->MaxOverRanksInPlace(rows, m_Desc.integration.hipStream))
+            if (!m_ReachRegistered) { // the second float of the transport's buffer is where this rank's temporal passes report their history reach from now on
+                if (nrdHipSetHistoryReachWord(m_Integration.GetExecutor(), (float*)deviceScalar + 1) != (uint32_t)Result::SUCCESS)
+                    return false;
+                m_ReachRegistered = true;
+            }
+            float reach = 0.0f;
+            if (!m_Desc.transport->MaxOverRanksInPlace(rows, reach, m_Desc.integration.hipStream))
                 return Fail("transport max-reduction failed");
-            return PlanFrame(rows);
+            return PlanFrame(rows, reach);
         }
         if (!PrepareFrame(denoisers, denoisersNum, userPool, &rows))
             return false;
@@ -145,7 +154,9 @@ public:
             *localMotionRows = rows;
         return true;
     }
-    inline bool PlanFrame(float motionRowsOverRanks = -1.0f) {
+    // historyReachOverRanks >= 0: what the temporal kernels reported LAST frame (rows, MAX over the ranks): this frame also runs unsharded when 1.25 x that + 3 rows (bicubic
+    // footprint) does not fit the history halo, and a sharded last frame whose reach + 3 exceeded the halo is counted (GetHistoryHaloViolationsNum) -- the rule of the Python host
+    inline bool PlanFrame(float motionRowsOverRanks = -1.0f, float historyReachOverRanks = -1.0f) {
         m_RowBegin.assign(m_DispatchesNum, -1);
         m_RowEnd.assign(m_DispatchesNum, 0);
         m_Steps.resize(64);
@@ -155,7 +166,11 @@ public:
                 m_Desc.exchangeThreshold, m_RowBegin.data(), m_RowEnd.data(), m_Steps.data(), (uint32_t)m_Steps.size(), m_Items.data(), (uint32_t)m_Items.size(), &info) != (uint32_t)Result::SUCCESS)
             return Fail("nrdHipPlanHaloExchange failed");
         m_LastMotionRows = motionRowsOverRanks;
-        const bool motionExceedsHalo = motionRowsOverRanks >= 0.0f && !(2.0f * motionRowsOverRanks + 2.0f < float(m_Desc.maxMotionRows)); // (a NaN exceeds)
+        m_LastHistoryReach = historyReachOverRanks;
+        if (historyReachOverRanks >= 0.0f && m_LastFrameSharded && !(historyReachOverRanks + 3.0f <= float(m_Desc.maxMotionRows)))
+            m_HistoryHaloViolations++;
+        const bool motionExceedsHalo = (motionRowsOverRanks >= 0.0f && !(2.0f * motionRowsOverRanks + 2.0f < float(m_Desc.maxMotionRows))) || // (a NaN exceeds)
+                                       (historyReachOverRanks >= 0.0f && !(1.25f * historyReachOverRanks + 3.0f < float(m_Desc.maxMotionRows)));
         if (motionExceedsHalo && !info.fallback && m_Desc.world > 1)
             m_MotionFallbacks++;
         m_Fallback = info.fallback != 0 || motionExceedsHalo || m_Desc.world == 1;
@@ -165,6 +180,8 @@ public:
         return true;
     }
     inline float GetLastMotionRows() const { return m_LastMotionRows; }        // what the last PlanFrame was given (-1: nothing)
+    inline float GetLastHistoryReachRows() const { return m_LastHistoryReach; } // the previous frame's history reach as the last PlanFrame was given it (-1: nothing)
+    inline uint32_t GetHistoryHaloViolationsNum() const { return m_HistoryHaloViolations; } // sharded frames whose temporal passes read beyond the halo they ran with
     inline uint32_t GetMotionFallbacksNum() const { return m_MotionFallbacks; } // frames run unsharded because the measured motion did not fit the history halo
     inline uint32_t GetStepsNum() const { return (uint32_t)m_Steps.size(); }
 
@@ -224,7 +241,10 @@ public:
         m_Pending = false;
         return nrdHipExecuteDispatchRange(ex, m_Dispatches, m_DispatchesNum, st.firstDispatch + early, st.dispatchCount - early, rowBegin, rowEnd) == (uint32_t)Result::SUCCESS;
     }
-    inline void EndFrame() { m_Complete = m_Fallback; }
+    inline void EndFrame() {
+        m_Complete = m_Fallback;
+        m_LastFrameSharded = !m_Fallback && m_Desc.world > 1;
+    }
 
     // The reassembly of the outputs: after a sharded frame every rank receives, IN PLACE in its bound OUT_* planes, the rows of every other rank -- one band per source rank
     // and plane through HaloTransport::Broadcast (over RCCL: ncclBroadcast, i.e. an all-gather spelled as the group of its broadcasts; strips re-cut by a load balancer
@@ -322,8 +342,9 @@ private:
     std::vector<NrdHipHaloItem> m_Items;
     bool m_Fallback = true, m_Complete = true, m_Pending = false;
     size_t m_GatheredBytes = 0;
-    float m_LastMotionRows = -1.0f;
-    uint32_t m_MotionFallbacks = 0;
+    float m_LastMotionRows = -1.0f, m_LastHistoryReach = -1.0f;
+    uint32_t m_MotionFallbacks = 0, m_HistoryHaloViolations = 0;
+    bool m_ReachRegistered = false, m_LastFrameSharded = false;
     const char* m_Error = nullptr;
 };
 
@@ -374,11 +395,19 @@ public:
                hipMemcpyAsync(&value, m_Scalar, sizeof(float), hipMemcpyDeviceToHost, s) == hipSuccess && hipStreamSynchronize(s) == hipSuccess;
     }
 
-    inline void* DeviceScalar() override { return (m_Scalar || hipMalloc((void**)&m_Scalar, sizeof(float)) == hipSuccess) ? m_Scalar : nullptr; }
-    inline bool MaxOverRanksInPlace(float& value, void* computeStream) override { // the value is on the device already (nrdHipMeasureMotionRowsAsync): reduce, one read-back
+    inline void* DeviceScalar() override {
+        if (!m_Scalar && (hipMalloc((void**)&m_Scalar, 2 * sizeof(float)) != hipSuccess || hipMemset(m_Scalar, 0, 2 * sizeof(float)) != hipSuccess))
+            m_Scalar = nullptr;
+        return m_Scalar;
+    }
+    inline bool MaxOverRanksInPlace(float& value, float& historyReach, void* computeStream) override { // both values are on the device already: one collective, one read-back
         hipStream_t s = (hipStream_t)computeStream;
-        return m_Scalar && ncclAllReduce(m_Scalar, m_Scalar, 1, ncclFloat, ncclMax, m_Comm, s) == ncclSuccess && hipMemcpyAsync(&value, m_Scalar, sizeof(float), hipMemcpyDeviceToHost, s) == hipSuccess &&
-               hipStreamSynchronize(s) == hipSuccess;
+        float host[2] = {0.0f, 0.0f};
+        const bool ok = m_Scalar && ncclAllReduce(m_Scalar, m_Scalar, 2, ncclFloat, ncclMax, m_Comm, s) == ncclSuccess &&
+                        hipMemcpyAsync(host, m_Scalar, sizeof(host), hipMemcpyDeviceToHost, s) == hipSuccess && hipMemsetAsync(m_Scalar + 1, 0, sizeof(float), s) == hipSuccess &&
+                        hipStreamSynchronize(s) == hipSuccess;
+        value = host[0], historyReach = host[1];
+        return ok;
     }
 
 private:

@@ -105,6 +105,13 @@ int main(int argc, char** argv) {
         CHECK(ranks[r]->Initialize(sdesc, icd));
     }
 
+    // one device word per rank for the history reach its temporal kernels report (nrdHipSetHistoryReachWord; the measure mode reduces them by hand, like the motion)
+    float* reachWords = nullptr;
+    CHECK(hipMalloc((void**)&reachWords, sizeof(float) * world) == hipSuccess && hipMemset(reachWords, 0, sizeof(float) * world) == hipSuccess);
+    if (measure)
+        for (uint32_t r = 0; r < world; r++)
+            CHECK(nrdHipSetHistoryReachWord(ranks[r]->GetIntegration().GetExecutor(), reachWords + r) == (uint32_t)nrd::Result::SUCCESS);
+
     std::vector<Planes> planes(world + 1);
     for (Planes& p : planes) {
         CHECK(hipMalloc(&p.mv, texels * 8) == hipSuccess && hipMalloc(&p.normalRoughness, texels * 4) == hipSuccess && hipMalloc(&p.viewZ, texels * 4) == hipSuccess);
@@ -209,6 +216,15 @@ int main(int argc, char** argv) {
             }
         }
         if (measure) { // PrepareFrame on every rank, the maximum of the measured rows, PlanFrame with it
+            // ... and with what the temporal kernels of every rank reported for the PREVIOUS frame (nrdHipSetHistoryReachWord; round 6): the frame behind the fast one still runs
+            // unsharded, because 1.25 x the 30 rows the fast frame's kernels read does not fit the 8-row halo either
+            std::vector<float> reach(world, 0.0f);
+            CHECK(hipMemcpy(reach.data(), reachWords, sizeof(float) * world, hipMemcpyDeviceToHost) == hipSuccess && hipMemset(reachWords, 0, sizeof(float) * world) == hipSuccess);
+            float reachMax = 0.0f;
+            for (uint32_t r = 0; r < world; r++)
+                reachMax = fmaxf(reachMax, reach[r]);
+            CHECK(world == 1 || f != fastFrame + 1 || fabsf(reachMax - 30.0f) < 0.05f);
+            CHECK(world == 1 || f == fastFrame + 1 || reachMax == 0.0f); // a static scene under a static camera reads last frame's planes where it stands
             float rowsMax = -1.0f;
             for (uint32_t r = 0; r < world; r++) {
                 float rows = -1.0f;
@@ -223,13 +239,13 @@ int main(int argc, char** argv) {
                 rowsMax = fmaxf(rowsMax, rows);
             }
             for (uint32_t r = 0; r < world; r++)
-                CHECK(ranks[r]->PlanFrame(rowsMax));
+                CHECK(ranks[r]->PlanFrame(rowsMax, reachMax));
         }
         for (uint32_t r = 0; r < world; r++) {
             CHECK(r == 0 || ranks[r]->GetStepsNum() == steps);
             steps = ranks[r]->GetStepsNum();
         }
-        const bool expectSharded = world > 1 && f != unshardedFrame && !(measure && f == fastFrame); // (the restart frame too since round 6: clears are texel-local)
+        const bool expectSharded = world > 1 && f != unshardedFrame && !(measure && (f == fastFrame || f == fastFrame + 1)); // (the restart frame too since round 6: clears are texel-local)
         CHECK((steps > 1) == expectSharded);
         shardedFrames += steps > 1;
         for (uint32_t s = 0; s < steps; s++) { // lock-step: every rank's transfers of step s see the peers' rows of step s - 1
@@ -297,17 +313,19 @@ int main(int argc, char** argv) {
     printf("%u virtual ranks, %zu sharded frames, %zu bytes received through the transport, %zu mismatching values\n", world, shardedFrames, received, mismatches);
 
     single.Destroy();
+    if (measure && world > 1)
+        for (uint32_t r = 0; r < world; r++)
+            CHECK(ranks[r]->GetMotionFallbacksNum() == 2 && ranks[r]->GetHistoryHaloViolationsNum() == 0 && fabsf(ranks[r]->GetLastHistoryReachRows() - 30.0f) < 0.05f);
     for (uint32_t r = 0; r < world; r++) {
+        (void)nrdHipSetHistoryReachWord(ranks[r]->GetIntegration().GetExecutor(), nullptr);
         ranks[r]->Destroy();
         delete ranks[r];
     }
-    if (measure && world > 1)
-        for (uint32_t r = 0; r < world; r++)
-            CHECK(ranks[r]->GetMotionFallbacksNum() == 1);
+    (void)hipFree(reachWords);
     printf("%zu mismatching values in the complete planes after the output gather\n", gatherMismatches);
     if (gatherMismatches)
         return 1;
-    if (mismatches || (world > 1 && (shardedFrames != (size_t)frames - 1 - (measure ? 1 : 0) || received == 0)))
+    if (mismatches || (world > 1 && (shardedFrames != (size_t)frames - 1 - (measure ? 2 : 0) || received == 0)))
         return 1;
     printf("sharded integration OK\n");
     return 0;
