@@ -27,6 +27,7 @@
     do {                                                    \
         if (!(x)) {                                         \
             printf("FAILED: %s (line %d)\n", #x, __LINE__); \
+            fflush(stdout);                                 \
             return 1;                                       \
         }                                                   \
     } while (0)
@@ -224,7 +225,7 @@ int main(int argc, char** argv) {
             for (uint32_t r = 0; r < world; r++)
                 reachMax = fmaxf(reachMax, reach[r]);
             CHECK(world == 1 || f != fastFrame + 1 || fabsf(reachMax - 30.0f) < 0.05f);
-            CHECK(world == 1 || f == fastFrame + 1 || reachMax == 0.0f); // a static scene under a static camera reads last frame's planes where it stands
+            CHECK(world == 1 || f == fastFrame + 1 || reachMax < 0.5f); // a static scene under a static camera reads last frame's planes where it stands (up to the rounding of uv * size)
             float rowsMax = -1.0f;
             for (uint32_t r = 0; r < world; r++) {
                 float rows = -1.0f;
