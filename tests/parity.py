@@ -42,6 +42,10 @@ def decode_plane(raw, fmt, width):
         return body.view(np.uint16).reshape(h, width, 1).astype(np.float32)
     if fmt == F.RGBA16_SNORM:
         return body.view(np.int16).reshape(h, width, 4).astype(np.float32)
+    if fmt == F.RGBA8_SNORM:  # (PREV_NORMAL_ROUGHNESS of NRD_NORMAL_ENCODING 1)
+        return body.view(np.int8).reshape(h, width, 4).astype(np.float32)
+    if fmt == F.RGBA16_UNORM:  # (NRD_NORMAL_ENCODING 3)
+        return body.view(np.uint16).reshape(h, width, 4).astype(np.float32)
     if fmt in (F.R32_UINT, F.R10_G10_B10_A2_UNORM):
         return body.view(np.uint32).reshape(h, width, 1).astype(np.float64)
     raise KeyError(fmt)
