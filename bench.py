@@ -554,7 +554,7 @@ def main():
                    "reassembly": (None if shard is None else
                                   "all-gather of the owned rows of every OUT_* plane after the last pass into separate complete planes (RCCL, asynchronous: it overlaps the whole next frame and is awaited by wait_outputs()), "
                                   "%.2f MB received per rank per frame, inside the timed region" % (shard.gathered_bytes / max(shard.gather_frames, 1) / 1e6) if args.sharding == "halo" else
-                                  "in-place all-gather of every permanent plane and output (FrameSharder)"),
+                                  "in-place all-gather of every permanent and transient full-resolution plane and every output (FrameSharder)"),
                    "halo_bytes_received_per_rank_per_frame": (int(shard.exchanged_bytes / max(total + args.steps + 5, 1)) if shard is not None and args.sharding == "halo" else None),
                    "gather_bytes_received_per_rank_per_frame": (int(shard.gathered_bytes / max(shard.gather_frames, 1)) if shard is not None and args.sharding == "halo" else None),
                    "motion_bound": (None if shard is None or args.sharding != "halo" else

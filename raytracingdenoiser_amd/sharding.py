@@ -61,6 +61,12 @@ class FrameSharder:
             for t in outputs:  # user outputs: [H, W, C] tensors -> byte rows
                 assert t.is_contiguous() and t.shape[0] == height
                 self.planes.append(t.view(-1).view(dtype=__import__("torch").uint8).view(height, -1))
+            # The full-resolution transient planes too (round 6, "texels nobody writes" -- DESIGN.md section 6): every pass skips the sky, so a transient plane keeps in its sky texels
+            # what the LAST writer of an earlier frame left there, and passes with a neighbourhood read those texels (RELAX TemporalAccumulation: the pre-pass output's hit distances).
+            # A rank's last writer covers only strip + its own margin; reassembling the planes makes their unwritten texels those of one GPU everywhere.
+            for i, (fmt, downsample) in enumerate(instance.transient_pool):
+                if downsample == 1:
+                    self.planes.append(executor.pool_plane_tensor(api.ResourceType.TRANSIENT_POOL, i))
 
     def pixels_per_rank(self):
         """Pixels of the OWNED strip (the algorithmic work of a rank; halo rows are redundant work, not useful output)."""

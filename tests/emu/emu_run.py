@@ -154,6 +154,9 @@ class EmuTorchExecutor(EmuExecutor):
         off = d.data - self._arena_tensor.data_ptr()
         return self._arena_tensor[off: off + d.height * d.rowPitchBytes].view(d.height, d.rowPitchBytes)
 
+    def set_owned_rows(self, row_begin, row_end):
+        self._check(self.lib.nrdHipSetOwnedRows(self.handle, row_begin, row_end), "nrdHipSetOwnedRows")
+
     def execute_range(self, dispatch_ptr, num, first, count, row_begin=None, row_end=None):
         rb = row_begin if row_begin is None or isinstance(row_begin, C.Array) else (C.c_int32 * num)(*row_begin)
         re = row_end if row_end is None or isinstance(row_end, C.Array) else (C.c_int32 * num)(*row_end)

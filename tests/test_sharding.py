@@ -118,10 +118,76 @@ def test_virtual_ranks_reproduce_single_gpu(name, world, height, overrides):
                     for ps, pd in zip(src.planes, dst.planes):
                         pd[rb:re].copy_(ps[rb:re])
         torch.cuda.synchronize()
-        ref_planes = [ref_ex.pool_plane_tensor(RT.PERMANENT_POOL, i) for i in range(len(ref_inst.permanent_pool))] + [o.view(-1).view(dtype=torch.uint8).view(H, -1) for o in ref_outs]
+        # the same list FrameSharder holds: full-resolution permanent planes, the outputs, full-resolution transient planes (round 6: their unwritten -- sky -- texels are read by later frames)
+        ref_planes = ([ref_ex.pool_plane_tensor(RT.PERMANENT_POOL, i) for i, (_, ds) in enumerate(ref_inst.permanent_pool) if ds == 1]
+                      + [o.view(-1).view(dtype=torch.uint8).view(H, -1) for o in ref_outs]
+                      + [ref_ex.pool_plane_tensor(RT.TRANSIENT_POOL, i) for i, (_, ds) in enumerate(ref_inst.transient_pool) if ds == 1])
+        assert len(ref_planes) == len(ranks[0][3].planes)
         for r, (_, _, _, s) in enumerate(ranks):
             for k, (a, b) in enumerate(zip(s.planes, ref_planes)):
                 assert torch.equal(a, b), "frame %d rank %d plane %d differs from the single-GPU run" % (f, r, k)
+
+
+@pytest.mark.parametrize("name,world,height,overrides", [
+    ("RELAX_DIFFUSE_SPECULAR_SH", 2, 192, dict(atrousIterationNum=3)),
+    ("REBLUR_DIFFUSE_SPECULAR", 3, 240, dict(maxBlurRadius=4.0, diffusePrepassBlurRadius=6.0, specularPrepassBlurRadius=6.0)),
+])
+def test_allgather_sharding_on_emulated_kernels(name, world, height, overrides):
+    """FrameSharder on the CPU emulation of the device sources (no GPU): virtual ranks, the all-gather replayed with copies, a horizon that moves DOWN through the first strip
+    boundary frame by frame -- texels that were geometry turn into sky and keep what their last writer left. Every plane FrameSharder holds (permanent, outputs, and since round 6
+    the transient ones) equals the uncut frame's after every frame."""
+    import parity
+    from emu import emu_run
+
+    W, H, frames = 128, height, 5
+    RT = api.ResourceType
+    lib = emu_run.load()
+    seq = parity.generate_sequence(name, W, H, frames, device="cpu")
+    for f, fr in enumerate(seq):
+        z = fr["viewz"].clone()
+        z.view(H, W)[: H // world - 26 + 5 * f] = 1.0e6
+        fr["viewz"] = z
+
+    def make_run():
+        inst = api.Instance([(0, parity.DENOISERS[name][0])], lib=lib)
+        ex = emu_run.EmuTorchExecutor(inst, W, H)
+        outs = []
+        for rt, dtype, ch, fmt in parity.output_planes(name, W, H):
+            outs.append(torch.zeros((H, W, ch), dtype=dtype))
+            ex.bind(rt, outs[-1], fmt)
+        return inst, ex, outs
+
+    def planes_of(inst, ex, outs):
+        return ([ex.pool_plane_tensor(RT.PERMANENT_POOL, i) for i, (_, ds) in enumerate(inst.permanent_pool) if ds == 1]
+                + [o.view(-1).view(dtype=torch.uint8).view(H, -1) for o in outs]
+                + [ex.pool_plane_tensor(RT.TRANSIENT_POOL, i) for i, (_, ds) in enumerate(inst.transient_pool) if ds == 1])
+
+    ref = make_run()
+    ranks = []
+    for r in range(world):
+        run = make_run()
+        ranks.append(run + (sharding.FrameSharder(run[1], run[0], W, H, r, world, run[2]),))
+    assert all(s.rows is not None and s.rows[1] - s.rows[0] < H for *_, s in ranks)
+    keep = []
+    for f, frame in enumerate(seq):
+        for inst, ex in [ref[:2]] + [rk[:2] for rk in ranks]:
+            for rt, t, fmt in parity.user_planes(name, frame):
+                keep.append(t.contiguous())
+                ex.bind(rt, keep[-1], fmt)
+            inst.set_denoiser_settings(0, parity.denoiser_settings(name, frame, overrides))
+            assert inst.set_common_settings(parity.common_settings(frame["camera"], seq[max(f - 1, 0)]["camera"], W, H, f)) == api.Result.SUCCESS
+            ex.denoise()
+        for *_, src in ranks:
+            rb, re = src.rows
+            for *_, dst in ranks:
+                if dst is not src:
+                    for ps, pd in zip(src.planes, dst.planes):
+                        pd[rb:re].copy_(ps[rb:re])
+        ref_planes = planes_of(*ref)
+        for r, (*_, s) in enumerate(ranks):
+            assert len(s.planes) == len(ref_planes)
+            for k, (a, b) in enumerate(zip(s.planes, ref_planes)):
+                assert torch.equal(a, b), "frame %d rank %d plane %d differs from the uncut frame" % (f, r, k)
 
 
 # ---------------------------------------------------------------------------------------------- halo-exchange sharding
