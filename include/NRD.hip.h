@@ -12,6 +12,7 @@
 //   SIGMA        SIGMA_FrontEnd_PackPenumbra (2 overloads), PackTranslucency; SIGMA_BackEnd_UnpackShadow        NRD.hlsli:828-855, 931
 //   SG / SH      NRD_SG, NRD_SG_ExtractColor / Direction / RoughnessAA, NRD_SG_Rotate, NRD_SG_ResolveDiffuse / Specular,
 //                NRD_SH_ResolveDiffuse / Specular, NRD_SG_ReJitter                                               NRD.hlsli:541-586, 937-1111
+//   misc         NRD_IsValidRadiance, REBLUR_GetHitDist, NRD_GetNormalizedStrandThickness                         NRD.hlsli:1136-1162
 //
 // Build configuration = the library's (nrd::GetLibraryDesc().normalEncoding / roughnessEncoding): define NRD_NORMAL_ENCODING (0..4) and NRD_ROUGHNESS_ENCODING (0..2) to the
 // values the linked libNRD_hip.so was built with before including this file, as the reference asks for NRDEncoding.hlsli (NRD.hlsli:290-309); undefined, they take the
@@ -257,6 +258,8 @@ NRD_HIP_FN float3 _NRD_SG_ExtractDirection(NRD_SG sg) {
 }
 
 NRD_HIP_FN float _NRD_SG_IntegralApprox(NRD_SG sg) { return 2.0f * NRD_PI * (sg.c0 / sg.sharpness); }
+
+NRD_HIP_FN float _NRD_SG_Integral(NRD_SG sg) { return _NRD_SG_IntegralApprox(sg) * (1.0f - expf(-2.0f * sg.sharpness)); }
 
 NRD_HIP_FN float _NRD_SG_InnerProduct(NRD_SG a, NRD_SG b) {
     using namespace nrd_hip_detail;
@@ -675,3 +678,22 @@ NRD_HIP_FN float3 NRD_SH_ResolveSpecular(NRD_SG sh, float3 N, float3 V, float ro
     float Y = dot(D, sh.c1) + 0.5f * sh.c0;
     return _NRD_YCoCgToLinear_Corrected(Y, sh.c0, sh.chroma);
 }
+
+//=================================================================================================================================
+// MISC ( NRD.hlsli:1136-1162 )
+//=================================================================================================================================
+
+NRD_HIP_FN bool _NRD_IsInvalid(float x) { return nrd_hip_detail::isInvalid(x); }
+NRD_HIP_FN bool _NRD_IsInvalid(float3 x) { return nrd_hip_detail::isInvalid(x); }
+
+// Needs to be used to avoid summing up NAN/INF values in many rays per pixel scenarios
+NRD_HIP_FN bool NRD_IsValidRadiance(float3 radiance) { return !_NRD_IsInvalid(radiance); }
+
+// Scales normalized hit distance back to real length
+NRD_HIP_FN float REBLUR_GetHitDist(float normHitDist, float viewZ, float4 hitDistParams, float roughness) {
+    return normHitDist * _REBLUR_GetHitDistanceNormalization(viewZ, hitDistParams, roughness);
+}
+
+// Normalized strand thickness factor in range [0; 1]: 0 - thick enough (in pixels) for a stable multi-pixel projection, 1 - "pixel soup".
+// pixelSize = size of a pixel in world units at "viewZ" = gUnproject * ( isOrtho ? 1.0 : abs( viewZ ) )
+NRD_HIP_FN float NRD_GetNormalizedStrandThickness(float strandThickness, float pixelSize) { return pixelSize / (pixelSize + strandThickness); }

@@ -189,6 +189,17 @@ int main(int argc, char** argv) {
         NRD_FrontEnd_SpecHitDistAveraging_Add(acc, 2.0f);
         NRD_FrontEnd_SpecHitDistAveraging_End(acc);
         CHECK(acc == 2.0f && NRD_FrontEnd_TrimHitDistance(0.01f, 0.1f) == 0.0f);
+        // MISC (NRD.hlsli:1136-1162)
+        const float4 hitDistParams = make_float4(3.0f, 0.1f, 20.0f, -25.0f);
+        for (float hitDist : {0.0f, 0.37f, 2.5f})  // REBLUR_GetHitDist inverts REBLUR_FrontEnd_GetNormHitDist below the saturation point
+            CHECK(Close(REBLUR_GetHitDist(REBLUR_FrontEnd_GetNormHitDist(hitDist, 12.0f, hitDistParams, 0.4f), 12.0f, hitDistParams, 0.4f), hitDist, 1e-5f));
+        CHECK(REBLUR_GetHitDist(1.0f, -10.0f, hitDistParams, 0.0f) == (3.0f + 10.0f * 0.1f) * 20.0f);  // roughness 0: exp2( 0 ) = 1 -> the full z scale
+        CHECK(NRD_IsValidRadiance(make_float3(1.0f, 0.0f, 65504.0f)) && !NRD_IsValidRadiance(make_float3(1.0f, NAN, 0.0f)) && !NRD_IsValidRadiance(make_float3(INFINITY, 0.0f, 0.0f)));
+        CHECK(_NRD_IsInvalid(-INFINITY) && !_NRD_IsInvalid(0.0f));
+        CHECK(NRD_GetNormalizedStrandThickness(0.0f, 0.01f) == 1.0f && NRD_GetNormalizedStrandThickness(0.03f, 0.01f) == 0.25f);
+        NRD_SG wide = sg;
+        wide.sharpness = 1.5f;  // (_NRD_SG_Create leaves 0: the denoiser fills it) a wide lobe, where the exponential term counts
+        CHECK(Close(_NRD_SG_Integral(wide), _NRD_SG_IntegralApprox(wide) * (1.0f - expf(-2.0f * wide.sharpness)), 1e-6f) && _NRD_SG_Integral(wide) < _NRD_SG_IntegralApprox(wide));
     }
     uint32_t checksum = 0;
     for (uint32_t i = 0; i < count; i++)
