@@ -41,6 +41,7 @@ NRD_OUTPUTS_START
     NRD_OUTPUT( RWTexture2D<float4>, gOut_SgColor, u, 17 )
     NRD_OUTPUT( RWTexture2D<float4>, gOut_SgDir, u, 18 )
     NRD_OUTPUT( RWTexture2D<float4>, gOut_ReJitter, u, 19 )
+    NRD_OUTPUT( RWTexture2D<float4>, gOut_Misc, u, 20 )
 NRD_OUTPUTS_END
 
 [numthreads( 8, 8, 1 )]
@@ -103,4 +104,11 @@ NRD_EXPORT void NRD_CS_MAIN( uint2 pixelPos : SV_DispatchThreadId )
     gOut_ShDiffuse[ pixelPos ] = float4( NRD_SH_ResolveDiffuse( sg, N ), 0.0 );
     gOut_ShSpecular[ pixelPos ] = float4( NRD_SH_ResolveSpecular( sg, N, V, roughness ), 0.0 );
     gOut_ReJitter[ pixelPos ] = float4( NRD_SG_ReJitter( sg, sg, Rf0, V, roughness, viewZ, viewZ * 1.001, viewZ * 0.999, viewZ, viewZ, N, N, Nw, N, N ), 0.0, 0.0 );
+
+    // MISC ( NRD.hlsli:575-580, 1136-1162 )
+    NRD_SG wide = sg;
+    wide.sharpness = 0.5 + 4.0 * roughness;
+    float poison = e.w != 0.0 ? 0.0 : 1.0;
+    gOut_Misc[ pixelPos ] = float4( REBLUR_GetHitDist( normHitDist, viewZ, gHitDistParams, roughness ), NRD_GetNormalizedStrandThickness( hitDist * 0.01, viewZ * 0.001 ), _NRD_SG_Integral( wide ),
+        NRD_IsValidRadiance( radiance / poison ) ? 1.0 : 0.0 );
 }

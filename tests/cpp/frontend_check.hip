@@ -21,6 +21,7 @@ struct Result {
     float normHitDist, penumbra, penumbraLocal, shadow, materialID;
     float3 diffFactor, specFactor, sgDiffuse, sgSpecular, shDiffuse, shSpecular, sgColor, sgDir;
     float2 rejitter;
+    float4 misc; // REBLUR_GetHitDist, NRD_GetNormalizedStrandThickness, _NRD_SG_Integral, NRD_IsValidRadiance (NRD.hlsli:575-580, 1136-1162)
 };
 
 __host__ __device__ inline uint32_t Hash(uint32_t v) {
@@ -82,6 +83,11 @@ __host__ __device__ inline Result Evaluate(uint32_t i) {
     r.shDiffuse = NRD_SH_ResolveDiffuse(sg, s.N);
     r.shSpecular = NRD_SH_ResolveSpecular(sg, s.N, s.V, s.roughness);
     r.rejitter = NRD_SG_ReJitter(sg, sg, s.Rf0, s.V, s.roughness, s.viewZ, s.viewZ * 1.001f, s.viewZ * 0.999f, s.viewZ, s.viewZ, s.N, s.N, Dir(i, 21), s.N, s.N);
+    NRD_SG wide = sg;
+    wide.sharpness = 0.5f + 4.0f * s.roughness; // (the packers leave 0: the denoiser fills it)
+    const float poison = i % 5 == 0 ? 0.0f : 1.0f;
+    r.misc = make_float4(REBLUR_GetHitDist(r.normHitDist, s.viewZ, hitDistParams, s.roughness), NRD_GetNormalizedStrandThickness(s.hitDist * 0.01f, s.viewZ * 0.001f), _NRD_SG_Integral(wide),
+                         NRD_IsValidRadiance(make_float3(s.radiance.x / poison, s.radiance.y / poison, s.radiance.z / poison)) ? 1.0f : 0.0f);
     return r;
 }
 
@@ -136,7 +142,7 @@ static int Dump(const char* path, uint32_t count, bool onHost) {
         Append(row, r.unpackedNR), Append(row, r.reblurPacked), Append(row, r.reblurUnpacked), Append(row, r.sh0), Append(row, r.sh1), Append(row, r.relaxPacked), Append(row, r.relaxSh1);
         Append(row, r.dirOcc), Append(row, r.translucency), Append(row, r.normHitDist), Append(row, r.penumbra), Append(row, r.penumbraLocal), Append(row, r.shadow), Append(row, r.materialID);
         Append(row, r.diffFactor), Append(row, r.specFactor), Append(row, r.sgDiffuse), Append(row, r.sgSpecular), Append(row, r.shDiffuse), Append(row, r.shSpecular), Append(row, r.sgColor);
-        Append(row, r.sgDir), Append(row, r.rejitter);
+        Append(row, r.sgDir), Append(row, r.rejitter), Append(row, r.misc);
         fwrite(row.data(), 4, row.size(), fp);
     }
     fclose(fp);

@@ -74,7 +74,7 @@ def test_frontend_header_device_matches_host():
 DUMP_FIELDS = [("N", 3), ("V", 3), ("radiance", 3), ("direction", 3), ("albedo", 3), ("Rf0", 3), ("roughness", 1), ("materialID_in", 1), ("hitDist", 1), ("viewZ", 1), ("Nw", 3),
                ("word", 1), ("unpackedNR", 4), ("reblurPacked", 4), ("reblurUnpacked", 4), ("sh0", 4), ("sh1", 4), ("relaxPacked", 4), ("relaxSh1", 4), ("dirOcc", 4), ("translucency", 4),
                ("normHitDist", 1), ("penumbra", 1), ("penumbraLocal", 1), ("shadow", 1), ("materialID", 1), ("diffFactor", 3), ("specFactor", 3), ("sgDiffuse", 3), ("sgSpecular", 3),
-               ("shDiffuse", 3), ("shSpecular", 3), ("sgColor", 3), ("sgDir", 3), ("rejitter", 2)]
+               ("shDiffuse", 3), ("shSpecular", 3), ("sgColor", 3), ("sgDir", 3), ("rejitter", 2), ("misc", 4)]
 
 
 def _load_dump(path, count):
@@ -232,7 +232,7 @@ def test_frontend_header_equals_the_reference_nrd_hlsli_text():
            tex([d["albedo"], (i % 5 == 0).astype(np.float32)]), tex([d["Rf0"]]), tex([d["Nw"]])]
     word_in = np.ascontiguousarray(d["word"][:, 0].reshape(H, W).astype(np.uint32))
     word_out = np.zeros((H, W), np.uint32)
-    outs = [np.zeros((H, W, 4), np.float32) for _ in range(19)]
+    outs = [np.zeros((H, W, 4), np.float32) for _ in range(20)]
     P = oracle_driver.OraclePlane
     planes = [P(a.ctypes.data, a.strides[0], int(F.RGBA32_SFLOAT), W, H) for a in ins]
     planes += [P(word_in.ctypes.data, word_in.strides[0], int(F.R10_G10_B10_A2_UNORM), W, H), P(word_out.ctypes.data, word_out.strides[0], int(F.R10_G10_B10_A2_UNORM), W, H)]
@@ -244,7 +244,8 @@ def test_frontend_header_equals_the_reference_nrd_hlsli_text():
 
     assert np.array_equal(word_out.reshape(-1), d["word"][:, 0])  # NRD_FrontEnd_PackNormalAndRoughness through an R10G10B10A2_UNORM store
     exact = {"unpackedNR": 0, "reblurPacked": 2, "reblurUnpacked": 3, "sh0": 4, "sh1": 5, "relaxPacked": 6, "relaxSh1": 7, "dirOcc": 8, "translucency": 9, "specFactor": 11,
-             "sgDiffuse": 12, "shDiffuse": 14, "sgColor": 16, "sgDir": 17}
+             "sgDiffuse": 12, "shDiffuse": 14, "sgColor": 16, "sgDir": 17,
+             "misc": 19}  # REBLUR_GetHitDist, NRD_GetNormalizedStrandThickness, _NRD_SG_Integral, NRD_IsValidRadiance (every fifth row holds inf / NaN radiance)
     for name, k in exact.items():
         got = outs[k].reshape(count, 4)[:, : d[name].shape[1]]
         assert np.array_equal(got.view(np.uint32), np.ascontiguousarray(d[name]).view(np.uint32)), name
