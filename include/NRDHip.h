@@ -38,6 +38,8 @@ typedef struct NrdHipPlaneDesc {
 // Creates the executor for an nrd::Instance (include/NRD.h) and allocates its permanent + transient pool planes
 // (one hipMalloc arena, 256-byte aligned rows) for textures of resourceWidth x resourceHeight.
 // "instance" is an nrd::Instance*; "hipStream" is a hipStream_t (NULL = default stream).
+// Size limit: planes are addressed with 32-bit byte offsets, so a plane of 16-byte texels must stay below 4 GiB -- every size up to 16384 x 16383 (or 65535 x 4095) is accepted,
+// larger ones return UNSUPPORTED (as does a user plane whose row pitch reaches 16 MiB or whose pitch x height reaches 4 GiB, in nrdHipBindResource).
 uint32_t nrdHipCreateExecutor(void* instance, uint16_t resourceWidth, uint16_t resourceHeight, void* hipStream, NrdHipExecutor** executor);
 void nrdHipDestroyExecutor(NrdHipExecutor* executor);
 

@@ -167,10 +167,19 @@ static bool PlanPool(const nrd::TextureDesc* descs, uint32_t num, uint16_t w, ui
     return true;
 }
 
+// The kernels address a plane with 32-bit byte offsets built by a 24-bit multiply (planes.h TexelOffset): row pitch < 2^24 bytes, pitch x rows < 2^32 bytes (strictly: the offset of the row one past the end must not wrap either). Every frame size a
+// 16-bit resource size can name stays below that except the very largest with 16-byte texels (RGBA32F pool planes, the decoded-guide cache: 16384 x 16384 texels and more) -- refused
+// at creation / binding instead of wrapping around.
+static bool PlaneAddressable(uint64_t pitchBytes, uint64_t rows) { return pitchBytes < (1ull << 24) && pitchBytes * rows < (1ull << 32); }
+
 static uint32_t CreateExecutorImpl(void* instance, uint16_t resourceWidth, uint16_t resourceHeight, void* hipStream, void* userArena, uint64_t userArenaSize, NrdHipExecutor** executor) {
     if (!instance || !executor || !resourceWidth || !resourceHeight)
         return (uint32_t)nrd::Result::INVALID_ARGUMENT;
     *executor = nullptr;
+    if (!PlaneAddressable(((uint64_t)resourceWidth * 16u + 255u) & ~255ull, resourceHeight)) {
+        fprintf(stderr, "nrdHipCreateExecutor: %u x %u is beyond the 4 GiB a plane of 16-byte texels may span (32-bit byte offsets)\n", resourceWidth, resourceHeight);
+        return (uint32_t)nrd::Result::UNSUPPORTED;
+    }
 
     int deviceCount = 0;
     if (hipGetDeviceCount(&deviceCount) != hipSuccess || deviceCount == 0) {
@@ -373,6 +382,8 @@ extern "C" __attribute__((visibility("default"))) uint32_t nrdHipBindResource(Nr
     if (!plane->data || plane->width != e->width || plane->height != e->height || plane->rowPitchBytes < plane->width * bpt || (plane->rowPitchBytes % bpt) != 0 ||
         ((uintptr_t)plane->data % bpt) != 0)
         return e->Fail(nrd::Result::INVALID_ARGUMENT, "nrdHipBindResource: bad pointer, size or pitch");
+    if (!PlaneAddressable(plane->rowPitchBytes, plane->height))
+        return e->Fail(nrd::Result::UNSUPPORTED, "nrdHipBindResource: row pitch >= 16 MiB or plane > 4 GiB (planes are addressed with 32-bit byte offsets)");
 
     Plane& p = e->user[resourceType];
     p.ptr = (uint8_t*)plane->data;
