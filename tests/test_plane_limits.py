@@ -59,3 +59,12 @@ def test_bind_refuses_a_pitch_the_offset_arithmetic_cannot_hold():
         return inst, HipExecutor(inst, w, h)
 
     _check_bind_limits(make)
+
+
+@pytest.mark.gpu
+def test_bit_exact_at_7680x4320():
+    """beyond BASELINE.json's sizes: 8K UHD -- x beyond 4096, 129 600 tiles of 32 x 8 pixels (more than 16 bits of tile indices), 530-MB planes. SIGMA_SHADOW here (8 s);
+    REBLUR_DIFFUSE_SPECULAR and RELAX_DIFFUSE_SPECULAR_SH take 63 / 93 s and are run by tools/parity_8k.py: profiles/r06_8k_parity.log -- max relative error 0 for all three."""
+    import parity
+
+    assert parity.run_parity("SIGMA_SHADOW", 7680, 4320, 2, device="cuda") == 0.0
