@@ -40,7 +40,7 @@ def pytest_collection_modifyitems(config, items):
     # (tests/emu: the .hip files compiled for x86 over a HIP shim). Tests that need the real runtime (graphs, streams, torch.cuda tensors, RCCL) stay skipped.
     emu = os.environ.get("NRD_PARITY_BACKEND") == "emu"
     cuda_only = ("test_sharding", "test_sharded_cpp", "test_integration_cpp", "test_frontend_header", "test_full_size", "test_graph_mode", "test_unsupported_dispatch", "test_range_without", "test_numerics", "test_abi", "test_reference", "at_baseline_size",
-                 "test_motion_rows.py::test_motion_rows_", "test_motion_rows.py::test_history_reach_word", "test_encodings", "at_1280x720", "poisoned_halo")  # (the last: its emulated twins run in the CPU suite)
+                 "test_motion_rows.py::test_motion_rows_", "test_motion_rows.py::test_history_reach_word", "test_encodings", "at_1280x720", "poisoned_halo", "test_plane_limits")  # (the last: its emulated twins run in the CPU suite)
     skip = pytest.mark.skip(reason="no GPU in this container")
     for item in items:
         if "gpu" in item.keywords and not (emu and not any(m in item.nodeid for m in cuda_only)):
