@@ -576,7 +576,6 @@ extern "C" __attribute__((visibility("default"))) uint32_t nrdHipGetDispatchReac
     const nrd::DispatchDesc* descs = (const nrd::DispatchDesc*)dispatchDescs;
     const nrd::InstanceDesc& idesc = nrd::GetInstanceDesc(*(nrd::Instance*)instance);
     for (uint32_t i = 0; i < dispatchDescsNum; i++) {
-        const nrd::DispatchDesc& d = descs[i];
         reachRows[i] = DispatchReachRows(idesc, descs, i);
     }
     return (uint32_t)nrd::Result::SUCCESS;
@@ -606,7 +605,6 @@ extern "C" __attribute__((visibility("default"))) uint32_t nrdHipPlanHaloExchang
     std::vector<int> reach(num);
     bool known = num != 0 && world > 1;
     for (uint32_t i = 0; i < num; i++) {
-        const nrd::DispatchDesc& d = descs[i];
         reach[i] = DispatchReachRows(idesc, descs, i);
         known = known && reach[i] >= 0;
     }

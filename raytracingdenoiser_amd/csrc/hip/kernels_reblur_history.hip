@@ -60,7 +60,6 @@ template <bool IS_SPEC, bool DIFF, bool SPEC, bool PERF, int KIND, bool SH>
 NRD_D typename ReblurSignal<KIND>::type HistoryFixSignal(const ReblurCB& c, const HfPlanes& P, const HfPixel& s, typename ReblurSignal<KIND>::type sig, float frameNum, float strideBase,
     const Plane& gIn_Signal, const Plane& gIn_Fast, const Plane& gOut_Fast, const float* s_Luma, float4& sh, const Plane& gIn_Sh) { // SH: the SH1 plane rides along (specular: .xyz only)
     typedef ReblurSignal<KIND> Sig;
-    constexpr bool OCC = KIND == SIGNAL_OCCLUSION;
     typedef typename Sig::type S;
     const int rw = c.gRectSizeMinusOne.x, rh = c.gRectSizeMinusOne.y;
     const float smc = GetSpecMagicCurve(s.roughness);
@@ -211,7 +210,6 @@ NRD_D typename ReblurSignal<KIND>::type HistoryFixSignal(const ReblurCB& c, cons
 template <bool DIFF, bool SPEC, bool PERF, int KIND, bool SH>
 __global__ __launch_bounds__(TILE_X* TILE_Y, SH ? 0 : NRD_WAVES_REBLUR_HF) void ReblurHistoryFixKernel(ReblurCB c, HfPlanes P, RowRange rr) {
     typedef ReblurSignal<KIND> Sig;
-    constexpr bool OCC = KIND == SIGNAL_OCCLUSION;
     typedef typename Sig::type S;
     __shared__ float s_DiffLuma[DIFF ? hf::BUF_Y * hf::BUF_STRIDE : 1];
     __shared__ float s_SpecLuma[SPEC ? hf::BUF_Y * hf::BUF_STRIDE : 1];

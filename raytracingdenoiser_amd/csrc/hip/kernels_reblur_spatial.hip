@@ -696,7 +696,6 @@ __global__ __launch_bounds__(256) void ReblurSplitScreenKernel(ReblurCB c, Plane
     float z = UnpackViewZ(c, LoadR32F(viewZ, px, py));
     float keep = z < c.gDenoisingRange ? 1.0f : 0.0f;
     typedef ReblurSignal<KIND> Sig;
-    constexpr bool OCC = KIND == SIGNAL_OCCLUSION;
     const int dx = c.gDiffCheckerboard != 2 ? px >> 1 : px, sx = c.gSpecCheckerboard != 2 ? px >> 1 : px; // checkerboarded inputs: left half of the plane
     if (DIFF)
         Sig::Store(outDiff, px, py, Sig::Load(inDiff, dx, py) * keep);
@@ -756,7 +755,6 @@ struct HitDistPlanes {
 template <bool DIFF, bool SPEC, int BORDER, bool PERF, int KIND>
 __global__ __launch_bounds__(TILE_X* TILE_Y) void ReblurHitDistReconstructionKernel(ReblurCB c, HitDistPlanes P, RowRange rr) {
     typedef ReblurSignal<KIND> Sig;
-    constexpr bool OCC = KIND == SIGNAL_OCCLUSION;
     typedef typename Sig::type S;
     const int px = BlockTileX(rr) * TILE_X + (threadIdx.x % TILE_X);
     const int py = (BlockTileY(rr)) * TILE_Y + (threadIdx.x / TILE_X);

@@ -892,7 +892,7 @@ __global__ __launch_bounds__(256, NRD_WAVES_RELAX_ATROUS) void RelaxAtrousKernel
                 }
             } else {
                 const int cx = ClampI(qx, 0, P.worldPosViewZ.w - 1), cy = ClampI(qy, 0, P.worldPosViewZ.h - 1);
-                const uint32_t guideOffset = TexelOffset(P.decodedNR, cx, cy, 16u, true);
+                [[maybe_unused]] const uint32_t guideOffset = TexelOffset(P.decodedNR, cx, cy, 16u, true);
 #if NRD_ATROUS_GUIDES_RAW_NR
                 // same reasoning for the normal: 4 bytes of IN_NORMAL_ROUGHNESS through the L1 (41.7 cycles per scattered wave-load against 149.7 for the 16-byte decoded texel,
                 // profiles/r02_c_gather_bench.txt) and the decode that wrote the guide plane (kernels_common.hip DecodeGuidesRelaxKernel) redone per tap: it IS the stored value
