@@ -36,12 +36,17 @@ def main():
     ap.add_argument("--max-motion-rows", type=int, default=None, help="history-halo width in rows (default: HaloSharder.default_motion_rows)")
     ap.add_argument("--no-sky", action="store_true", help="the bench scene with a backdrop dome: every pixel is denoised (bench.py --no-sky)")
     ap.add_argument("--link-GBps", type=float, default=50.0, help="what one xGMI link delivers to one neighbour (modelled transfers)")
+    ap.add_argument("--denoiser", default=None, help="any denoiser of the library instead of a bench workload (verification sweeps), with --size and --settings")
+    ap.add_argument("--size", default="1280x720")
+    ap.add_argument("--settings", default=None, help="JSON object of denoiser-settings overrides, e.g. '{\"hitDistanceReconstructionMode\": 1}'")
     args = ap.parse_args()
     if args.no_sky:
         from raytracingdenoiser_amd import synth
 
         synth.BACKDROP = True
-    name, (W, H), _, _ = bench.WORKLOADS[args.workload]
+    name, (W, H), _, overrides = bench.WORKLOADS[args.workload]
+    if args.denoiser:
+        name, (W, H), overrides = args.denoiser, tuple(int(v) for v in args.size.split("x")), (json.loads(args.settings) if args.settings else None)
     total = args.warmup + args.frames
     seq = parity.generate_sequence(name, W, H, total, device="cuda")
 
@@ -52,12 +57,14 @@ def main():
         for rt, dtype, ch, fmt in parity.output_planes(name, W, H):
             outs.append(torch.zeros((H, W, ch), dtype=dtype, device="cuda"))
             ex.bind(rt, outs[-1], fmt)
-        assert inst.set_denoiser_settings(0, parity.denoiser_settings(name, seq[0])) == api.Result.SUCCESS
+        assert inst.set_denoiser_settings(0, parity.denoiser_settings(name, seq[0], overrides)) == api.Result.SUCCESS
         return inst, ex, outs
 
     def planes_of(inst, ex, outs):
+        # what FrameSharder reassembles every frame: full-resolution permanent planes, the outputs and -- round 6 -- the full-resolution transient planes
         ps = [ex.pool_plane_tensor(api.ResourceType.PERMANENT_POOL, i) for i, (fmt, ds) in enumerate(inst.permanent_pool) if ds == 1]
-        return ps + [o.view(-1).view(dtype=torch.uint8).view(H, -1) for o in outs]
+        ps += [o.view(-1).view(dtype=torch.uint8).view(H, -1) for o in outs]
+        return ps + [ex.pool_plane_tensor(api.ResourceType.TRANSIENT_POOL, i) for i, (fmt, ds) in enumerate(inst.transient_pool) if ds == 1]
 
     out_row_bytes = sum(W * ch * torch.empty(0, dtype=dtype).element_size() for rt, dtype, ch, fmt in parity.output_planes(name, W, H))  # bytes of one row of all OUT_* planes
     results = []
@@ -141,6 +148,8 @@ def main():
                 ms.append(e0.elapsed_time(e1))
             if shard is not None and not halo and shard.rows is not None:  # what the all-gather delivers: every row this rank does not own
                 rb, re = shard.rows
+                assert len(run_planes) == len(shard.planes)
+                exact = exact and all(torch.equal(a[rb:re], b[rb:re]) for a, b in zip(run[2], ref[2]))  # owned rows of every output == the full-frame run, before the reassembly
                 for src, dst in zip(ref_planes, run_planes):
                     dst[:rb].copy_(src[:rb])
                     dst[re:].copy_(src[re:])
