@@ -309,17 +309,22 @@ private:
         t = HaloTransfer{send, peer, type, index, row0, row1, (uint8_t*)p.data + (size_t)row0 * p.rowPitchBytes, (size_t)(row1 - row0) * p.rowPitchBytes};
         return true;
     }
-    // planes a frame reads before (or without) writing them: the history it inherits; tile maps (down-sampled planes) are complete everywhere
+    // planes an unsharded frame needs complete on every rank before it runs: those it reads before (or without) writing them -- the history it inherits -- and those a pass with a
+    // neighbourhood (nrdHipGetDispatchReach != 0) reads after an earlier pass of the frame wrote them: every pass skips the sky, so such a plane keeps in its sky texels what the last
+    // frame left there, and a rank is only complete inside its own strip (sharding.py carried_over_planes; round 6). Tile maps (down-sampled planes) are complete everywhere.
     inline std::vector<std::pair<uint32_t, uint32_t>> CarriedOverPlanes() const {
         std::set<std::pair<uint32_t, uint32_t>> written;
         std::vector<std::pair<uint32_t, uint32_t>> carried;
+        std::vector<int32_t> reach(m_DispatchesNum, -1);
+        (void)nrdHipGetDispatchReach(m_Integration.GetInstance(), m_Dispatches, m_DispatchesNum, reach.data());
         for (uint32_t i = 0; i < m_DispatchesNum; i++) {
             const DispatchDesc& d = m_Dispatches[i];
+            const bool neighbourhood = reach[i] != 0; // (-1 = unbounded)
             for (uint32_t r = 0; r < d.resourcesNum; r++) {
                 const ResourceDesc& res = d.resources[r];
                 const std::pair<uint32_t, uint32_t> key((uint32_t)res.type, res.indexInPool);
                 NrdHipPlaneDesc p = {};
-                if (res.descriptorType != DescriptorType::TEXTURE || (uint32_t)res.type < (uint32_t)ResourceType::OUT_DIFF_RADIANCE_HITDIST || written.count(key) ||
+                if (res.descriptorType != DescriptorType::TEXTURE || (uint32_t)res.type < (uint32_t)ResourceType::OUT_DIFF_RADIANCE_HITDIST || (written.count(key) && !neighbourhood) ||
                     std::find(carried.begin(), carried.end(), key) != carried.end() || !GetPlane(key.first, key.second, p) || p.height != m_Desc.integration.resourceHeight)
                     continue;
                 carried.push_back(key);

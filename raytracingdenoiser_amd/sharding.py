@@ -258,15 +258,19 @@ def exchange_halos(planes, rows, rank, world, items, group=None):
     finish_halo_exchange(start_halo_exchange(planes, rows, rank, world, items, group))
 
 
-def carried_over_planes(dispatches, small_planes=()):
-    """keys of the planes a frame reads before (or without) writing them: the history it inherits from the previous frame"""
+def carried_over_planes(dispatches, small_planes=(), reach=None):
+    """keys of the planes an UNSHARDED frame needs complete on every rank before it runs: those it reads before (or without) writing them -- the history it inherits from the previous
+    frame -- and, given the per-dispatch reach, those a pass with a neighbourhood (reach != 0; -1 = unbounded) reads AFTER an earlier pass of the frame wrote them: every pass skips the
+    sky, so such a plane keeps in its sky texels what the last frame left there ("texels nobody writes"), and on a rank that is only complete inside its own strip.
+    (Round 6: found by a dynamic-resolution step -- an unsharded frame in which silhouettes move by whole pixels -- with 3 uniform strips.)"""
     from . import api
 
     written, carried = set(), []
-    for d in dispatches:
+    for i, d in enumerate(dispatches):
+        neighbourhood = reach is not None and reach[i] != 0
         for dt, t, idx in d.resources:
             key = (int(t), idx)
-            if dt == api.DescriptorType.TEXTURE and not _is_user_input(t) and key not in small_planes and key not in written and key not in carried:
+            if dt == api.DescriptorType.TEXTURE and not _is_user_input(t) and key not in small_planes and (key not in written or neighbourhood) and key not in carried:
                 carried.append(key)
         for dt, t, idx in d.resources:
             if dt == api.DescriptorType.STORAGE_TEXTURE:
@@ -612,7 +616,7 @@ class HaloSharder:
                 else:
                     plan = replanned
                     self.rebalanced += 1
-        plan.complete_keys = carried_over_planes(dispatches, small) if plan.fallback and not self.complete and self.world > 1 else []
+        plan.complete_keys = carried_over_planes(dispatches, small, reach) if plan.fallback and not self.complete and self.world > 1 else []
         plan.output_keys = output_planes_of(dispatches)
         if plan.complete_keys and self.gather_outputs:
             # the OUT_* planes too: texels the frame does not write (a pixel that turned into sky) keep what the LAST frame that wrote them left there -- on a single GPU that

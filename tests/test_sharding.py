@@ -447,6 +447,117 @@ def test_halo_sharding_virtual_ranks_reproduce_single_gpu(name, world, height, o
         assert ranks[0].bounds == uniform
 
 
+# ---- dynamic resolution under sharding (round 6): a sub-rect of the resource is cut into strips like a full frame; a resolution STEP has no bounded halo (nrdHipGetDispatchReach: -1) and
+# runs unsharded after the planes have been completed -- and "completed" has to include the planes whose sky texels a neighbourhood pass reads after an earlier pass of the SAME frame
+# wrote them (sharding.carried_over_planes): at a step the silhouettes move by whole pixels, and a rank's copy of such a plane is stale outside its strip. Found with 3 uniform strips.
+DYNRES_STEPS = [(1.0, 1.0), (1.0, 1.0), (0.8125, 0.8125), (0.8125, 0.8125), (0.8125, 0.8125), (1.0, 1.0), (1.0, 1.0), (0.5, 0.5), (0.5, 0.5)]
+
+
+def _dynamic_resolution_case(name, world, resource, balance, backend, overrides=None, steps=DYNRES_STEPS):
+    import parity
+    from raytracingdenoiser_amd import synth
+
+    RW, RH = resource
+    sizes = [(int(RW * a), int(RH * b)) for a, b in steps]
+    device = "cuda" if backend == "hip" else "cpu"
+    raw = [synth.render_frame(*sizes[f], f, want=tuple(parity.DENOISERS[name][1]), device=device) for f in range(len(sizes))]
+    if backend == "hip":
+        from raytracingdenoiser_amd.executor import HipExecutor as Executor
+
+        lib = None
+    else:
+        from emu import emu_run
+
+        Executor, lib = emu_run.EmuTorchExecutor, emu_run.load()
+
+    def make_run():
+        inst = api.Instance([(0, parity.DENOISERS[name][0])], **({"lib": lib} if lib is not None else {}))
+        ex = Executor(inst, RW, RH)
+        outs = []
+        for rt, dtype, ch, fmt in parity.output_planes(name, RW, RH):
+            outs.append(torch.zeros((RH, RW, ch), dtype=dtype, device=device))
+            ex.bind(rt, outs[-1], fmt)
+        return inst, ex, outs
+
+    keep = []
+
+    def prepare(inst, ex, f):
+        frame = parity.embed_in_resource(raw[f], resource)
+        for rt, t, fmt in parity.user_planes(name, frame):
+            keep.append(t.contiguous())
+            ex.bind(rt, keep[-1], fmt)
+        inst.set_denoiser_settings(0, parity.denoiser_settings(name, frame, dict(overrides or {})))
+        w, h = sizes[f]
+        cs = parity.common_settings(raw[f]["camera"], raw[max(f - 1, 0)]["camera"], w, h, f, resourceSize=resource, resourceSizePrev=resource, rectSize=(w, h), rectSizePrev=sizes[max(f - 1, 0)])
+        assert inst.set_common_settings(cs) == api.Result.SUCCESS
+
+    def sync():
+        if backend == "hip":
+            torch.cuda.synchronize()
+
+    ref = make_run()
+    runs = [make_run() for _ in range(world)]
+    ranks = [sharding.HaloSharder(ex, inst, RW, RH, r, world, balance=balance) for r, (inst, ex, outs) in enumerate(runs)]
+    how = []
+    for f in range(len(sizes)):
+        prepare(ref[0], ref[1], f)
+        ref[1].denoise()
+        begun = []
+        for (inst, ex, outs), sh in zip(runs, ranks):
+            prepare(inst, ex, f)
+            begun.append(sh.begin_frame())
+        plans = [b[0] for b in begun]
+        assert len({p.fallback for p in plans}) == 1
+        how.append("whole" if plans[0].fallback else "strips")
+        if plans[0].fallback:
+            sync()
+            _local_completion(ranks, plans)
+            for sh, (plan, ptr, n) in zip(ranks, begun):
+                sh.ex.execute_range(ptr, n, 0, n)
+        else:
+            for step in range(len(plans[0].steps)):
+                sync()
+                _local_exchange(ranks, plans, step)
+                _poison_beyond_halo(ranks, plans, step)
+                for sh, (plan, ptr, n) in zip(ranks, begun):
+                    sh.run_step(plan, ptr, n, step)
+        for sh, plan in zip(ranks, plans):
+            sh.finish_frame(plan)
+        sync()
+        for r, ((inst, ex, outs), sh) in enumerate(zip(runs, ranks)):
+            rb, re = sh.rows
+            for o, ro in zip(outs, ref[2]):
+                assert torch.equal(o[rb:re], ro[rb:re]), (name, world, "frame", f, how[-1], sizes[f], "rank", r)
+    # the frame after every change of the rect size runs whole, a constant sub-rect is cut into strips
+    changed = [f > 0 and sizes[f] != sizes[f - 1] for f in range(len(sizes))]
+    assert all(how[f] == "whole" for f in range(len(sizes)) if changed[f]) and sum(h == "strips" for h in how) >= len(sizes) - sum(changed) - (1 if balance else 0), how
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name,world,balance", [("REBLUR_DIFFUSE_SPECULAR", 3, False), ("REBLUR_DIFFUSE_SPECULAR", 2, True), ("RELAX_DIFFUSE_SPECULAR", 3, False), ("RELAX_DIFFUSE_SPECULAR_SH", 2, True),
+                                                ("SIGMA_SHADOW", 3, False)])
+def test_halo_sharding_under_dynamic_resolution(name, world, balance):
+    _dynamic_resolution_case(name, world, (256, 480), balance, "hip")
+
+
+@pytest.mark.parametrize("name,world,resource,overrides", [
+    ("REBLUR_DIFFUSE_SPECULAR", 3, (256, 480), None),
+    ("RELAX_DIFFUSE_SPECULAR", 3, (128, 240), dict(atrousIterationNum=3, diffusePrepassBlurRadius=6.0, specularPrepassBlurRadius=6.0)),
+])
+def test_halo_sharding_under_dynamic_resolution_on_emulated_kernels(name, world, resource, overrides):
+    """the same on the CPU emulation of the device sources (no GPU)"""
+    _dynamic_resolution_case(name, world, resource, False, "emu", overrides)
+
+
+def test_an_unsharded_frame_needs_the_same_frame_planes_completed_too(monkeypatch):
+    """negative control: with the completion list of rounds 2-5 (planes read before they are written, nothing else) the resolution step of the REBLUR case above is NOT
+    bit-identical on the middle rank"""
+    orig = sharding.carried_over_planes
+    monkeypatch.setattr(sharding, "carried_over_planes", lambda dispatches, small_planes=(), reach=None: orig(dispatches, small_planes, None))
+    with pytest.raises(AssertionError, match="whole"):
+        _dynamic_resolution_case("REBLUR_DIFFUSE_SPECULAR", 3, (256, 480), False, "emu")
+
+
 @pytest.mark.gpu
 def test_the_poisoned_halo_check_fires_when_the_reach_is_under_declared():
     """negative control of the test above: the same default-radius case in a child process whose NRD_HIP_SPECULAR_REACH_SLACK halves the declared Blur / PostBlur reach must FAIL"""
