@@ -454,13 +454,23 @@ DYNRES_STEPS = [(1.0, 1.0), (1.0, 1.0), (0.8125, 0.8125), (0.8125, 0.8125), (0.8
 
 
 def _dynamic_resolution_case(name, world, resource, balance, backend, overrides=None, steps=DYNRES_STEPS):
+    how, sizes = _scenario_case(name, world, resource, balance, backend, [dict(scale=s, settings=overrides) for s in steps])
+    # the frame after every change of the rect size runs whole, a constant sub-rect is cut into strips
+    changed = [f > 0 and sizes[f] != sizes[f - 1] for f in range(len(sizes))]
+    assert all(how[f] == "whole" for f in range(len(sizes)) if changed[f]) and sum(h == "strips" for h in how) >= len(sizes) - sum(changed) - (1 if balance else 0), how
+
+
+def _scenario_case(name, world, resource, balance, backend, scenario):
+    """`world` virtual ranks (HaloSharder, transfers replayed with copies, rows beyond the declared halos poisoned) against an uncut run over a SCENARIO: one dict per frame with
+    scale = (sx, sy) of the rect inside the resource (default 1, 1), camera = index of the generated camera path (default: the frame index), cs = CommonSettings fields,
+    settings = denoiser-settings overrides. Every rank's owned rows of every output are compared after every frame. Returns (["whole" | "strips" per frame], rect sizes)."""
     import parity
     from raytracingdenoiser_amd import synth
 
     RW, RH = resource
-    sizes = [(int(RW * a), int(RH * b)) for a, b in steps]
+    sizes = [(int(RW * e.get("scale", (1.0, 1.0))[0]), int(RH * e.get("scale", (1.0, 1.0))[1])) for e in scenario]
     device = "cuda" if backend == "hip" else "cpu"
-    raw = [synth.render_frame(*sizes[f], f, want=tuple(parity.DENOISERS[name][1]), device=device) for f in range(len(sizes))]
+    raw = [synth.render_frame(*sizes[f], scenario[f].get("camera", f), want=tuple(parity.DENOISERS[name][1]), device=device) for f in range(len(sizes))]
     if backend == "hip":
         from raytracingdenoiser_amd.executor import HipExecutor as Executor
 
@@ -486,10 +496,11 @@ def _dynamic_resolution_case(name, world, resource, balance, backend, overrides=
         for rt, t, fmt in parity.user_planes(name, frame):
             keep.append(t.contiguous())
             ex.bind(rt, keep[-1], fmt)
-        inst.set_denoiser_settings(0, parity.denoiser_settings(name, frame, dict(overrides or {})))
+        assert inst.set_denoiser_settings(0, parity.denoiser_settings(name, frame, dict(scenario[f].get("settings") or {}))) == api.Result.SUCCESS
         w, h = sizes[f]
-        cs = parity.common_settings(raw[f]["camera"], raw[max(f - 1, 0)]["camera"], w, h, f, resourceSize=resource, resourceSizePrev=resource, rectSize=(w, h), rectSizePrev=sizes[max(f - 1, 0)])
-        assert inst.set_common_settings(cs) == api.Result.SUCCESS
+        kw = dict(resourceSize=resource, resourceSizePrev=resource, rectSize=(w, h), rectSizePrev=sizes[max(f - 1, 0)])
+        kw.update(scenario[f].get("cs") or {})
+        assert inst.set_common_settings(parity.common_settings(raw[f]["camera"], raw[max(f - 1, 0)]["camera"], w, h, f, **kw)) == api.Result.SUCCESS
 
     def sync():
         if backend == "hip":
@@ -528,9 +539,7 @@ def _dynamic_resolution_case(name, world, resource, balance, backend, overrides=
             rb, re = sh.rows
             for o, ro in zip(outs, ref[2]):
                 assert torch.equal(o[rb:re], ro[rb:re]), (name, world, "frame", f, how[-1], sizes[f], "rank", r)
-    # the frame after every change of the rect size runs whole, a constant sub-rect is cut into strips
-    changed = [f > 0 and sizes[f] != sizes[f - 1] for f in range(len(sizes))]
-    assert all(how[f] == "whole" for f in range(len(sizes)) if changed[f]) and sum(h == "strips" for h in how) >= len(sizes) - sum(changed) - (1 if balance else 0), how
+    return how, sizes
 
 
 @pytest.mark.gpu
@@ -556,6 +565,47 @@ def test_an_unsharded_frame_needs_the_same_frame_planes_completed_too(monkeypatc
     monkeypatch.setattr(sharding, "carried_over_planes", lambda dispatches, small_planes=(), reach=None: orig(dispatches, small_planes, None))
     with pytest.raises(AssertionError, match="whole"):
         _dynamic_resolution_case("REBLUR_DIFFUSE_SPECULAR", 3, (256, 480), False, "emu")
+
+
+# ---- other kinds of frames in mid-sequence (round 6): history restarts with and without clears, a camera cut (the motion exceeds every halo: that frame runs whole), split screen,
+# settings that change the pass list and every reach from one frame to the next (blur radii, anti-firefly, hit-distance reconstruction, performance mode, a-trous iterations)
+def _scenarios(name):
+    AM = api.AccumulationMode
+    settings = {
+        "REBLUR_DIFFUSE_SPECULAR": [{}, {}, {}, dict(maxBlurRadius=12.0), dict(maxBlurRadius=12.0), dict(maxBlurRadius=12.0, enableAntiFirefly=True),
+                                    dict(enableAntiFirefly=True, hitDistanceReconstructionMode=1), dict(hitDistanceReconstructionMode=1), {}, dict(enablePerformanceMode=True), {}],
+        "RELAX_DIFFUSE_SPECULAR": [{}, {}, {}, dict(atrousIterationNum=3), dict(atrousIterationNum=3), dict(atrousIterationNum=3, enableAntiFirefly=True),
+                                   dict(enableAntiFirefly=True, hitDistanceReconstructionMode=1), dict(hitDistanceReconstructionMode=1), {}, dict(atrousIterationNum=6), {}],
+        "SIGMA_SHADOW": [{}, {}, {}, dict(maxStabilizedFrameNum=0), {}, {}],
+    }[name]
+    return {
+        "restarts": [{}, {}, {}, dict(cs=dict(accumulationMode=int(AM.RESTART))), {}, {}, dict(cs=dict(accumulationMode=int(AM.CLEAR_AND_RESTART))), {}, {}],
+        "camera_cut": [dict(camera=c) for c in (0, 1, 2, 3, 40, 41, 42, 5, 6)],
+        "split_screen": [{}, {}, {}, dict(cs=dict(splitScreen=0.5)), dict(cs=dict(splitScreen=0.5)), {}, {}],
+        "settings_change": [dict(settings=e) for e in settings],
+    }
+
+
+def _check_scenario(name, kind, world, balance, backend):
+    how, _ = _scenario_case(name, world, (256, 480), balance, backend, _scenarios(name)[kind])
+    if kind == "camera_cut":
+        assert how[4] == "whole" and how[7] == "whole" and how[5] == "strips", how  # the cuts run unsharded, the frames between them in strips
+    else:
+        assert how.count("whole") == (1 if balance else 0), how
+
+
+@pytest.mark.parametrize("name,kind,world,balance", [("REBLUR_DIFFUSE_SPECULAR", "settings_change", 3, False), ("RELAX_DIFFUSE_SPECULAR", "camera_cut", 3, True),
+                                                     ("SIGMA_SHADOW", "restarts", 2, False)])
+def test_halo_sharding_scenarios_on_emulated_kernels(name, kind, world, balance):
+    _check_scenario(name, kind, world, balance, "emu")
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", ["REBLUR_DIFFUSE_SPECULAR", "RELAX_DIFFUSE_SPECULAR", "SIGMA_SHADOW"])
+@pytest.mark.parametrize("kind", ["restarts", "camera_cut", "split_screen", "settings_change"])
+def test_halo_sharding_scenarios(name, kind):
+    for world, balance in ((2, False), (3, False), (3, True)):
+        _check_scenario(name, kind, world, balance, "hip")
 
 
 @pytest.mark.gpu
