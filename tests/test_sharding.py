@@ -462,8 +462,8 @@ def _dynamic_resolution_case(name, world, resource, balance, backend, overrides=
 
 def _scenario_case(name, world, resource, balance, backend, scenario):
     """`world` virtual ranks (HaloSharder, transfers replayed with copies, rows beyond the declared halos poisoned) against an uncut run over a SCENARIO: one dict per frame with
-    scale = (sx, sy) of the rect inside the resource (default 1, 1), camera = index of the generated camera path (default: the frame index), cs = CommonSettings fields,
-    settings = denoiser-settings overrides. Every rank's owned rows of every output are compared after every frame. Returns (["whole" | "strips" per frame], rect sizes)."""
+    scale = (sx, sy) of the rect inside the resource (default 1, 1), origin = CommonSettings::rectOrigin, camera = index of the generated camera path (default: the frame index),
+    cs = CommonSettings fields, settings = denoiser-settings overrides. Every rank's owned rows of every output are compared after every frame. Returns (["whole" | "strips" per frame], rect sizes)."""
     import parity
     from raytracingdenoiser_amd import synth
 
@@ -492,13 +492,20 @@ def _scenario_case(name, world, resource, balance, backend, scenario):
     keep = []
 
     def prepare(inst, ex, f):
-        frame = parity.embed_in_resource(raw[f], resource)
+        origin = scenario[f].get("origin")  # CommonSettings::rectOrigin: the guide inputs live at an offset inside their planes (served through rect-at-origin copies)
+        if origin:
+            from test_dynamic_resolution import _embed_guides_at
+
+            frame = _embed_guides_at(raw[f], resource, origin)
+        else:
+            frame = parity.embed_in_resource(raw[f], resource)
         for rt, t, fmt in parity.user_planes(name, frame):
             keep.append(t.contiguous())
             ex.bind(rt, keep[-1], fmt)
         assert inst.set_denoiser_settings(0, parity.denoiser_settings(name, frame, dict(scenario[f].get("settings") or {}))) == api.Result.SUCCESS
         w, h = sizes[f]
         kw = dict(resourceSize=resource, resourceSizePrev=resource, rectSize=(w, h), rectSizePrev=sizes[max(f - 1, 0)])
+        kw.update(dict(rectOrigin=origin) if origin else {})
         kw.update(scenario[f].get("cs") or {})
         assert inst.set_common_settings(parity.common_settings(raw[f]["camera"], raw[max(f - 1, 0)]["camera"], w, h, f, **kw)) == api.Result.SUCCESS
 
@@ -583,6 +590,7 @@ def _scenarios(name):
         "camera_cut": [dict(camera=c) for c in (0, 1, 2, 3, 40, 41, 42, 5, 6)],
         "split_screen": [{}, {}, {}, dict(cs=dict(splitScreen=0.5)), dict(cs=dict(splitScreen=0.5)), {}, {}],
         "settings_change": [dict(settings=e) for e in settings],
+        "shifted_rect": [dict(scale=(0.8125, 0.8125), origin=o) for o in ((0, 0), (0, 0), (16, 8), (16, 8), (16, 8), (32, 40), (32, 40), (0, 0), (0, 0))],  # CommonSettings::rectOrigin
     }
 
 
@@ -602,7 +610,7 @@ def test_halo_sharding_scenarios_on_emulated_kernels(name, kind, world, balance)
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("name", ["REBLUR_DIFFUSE_SPECULAR", "RELAX_DIFFUSE_SPECULAR", "SIGMA_SHADOW"])
-@pytest.mark.parametrize("kind", ["restarts", "camera_cut", "split_screen", "settings_change"])
+@pytest.mark.parametrize("kind", ["restarts", "camera_cut", "split_screen", "settings_change", "shifted_rect"])
 def test_halo_sharding_scenarios(name, kind):
     for world, balance in ((2, False), (3, False), (3, True)):
         _check_scenario(name, kind, world, balance, "hip")
