@@ -539,13 +539,25 @@ def _scenario_case(name, world, resource, balance, backend, scenario):
                 _poison_beyond_halo(ranks, plans, step)
                 for sh, (plan, ptr, n) in zip(ranks, begun):
                     sh.run_step(plan, ptr, n, step)
-        for sh, plan in zip(ranks, plans):
-            sh.finish_frame(plan)
         sync()
-        for r, ((inst, ex, outs), sh) in enumerate(zip(runs, ranks)):
+        for r, ((inst, ex, outs), sh) in enumerate(zip(runs, ranks)):  # owned rows first: before the reassembly can paper over anything
             rb, re = sh.rows
             for o, ro in zip(outs, ref[2]):
                 assert torch.equal(o[rb:re], ro[rb:re]), (name, world, "frame", f, how[-1], sizes[f], "rank", r)
+        # the reassembly (HaloSharder.stage_outputs + the output all-gather, replayed with copies): afterwards EVERY rank holds the complete OUT_* planes, texels no frame wrote included
+        for sh, plan in zip(ranks, plans):
+            sh.stage_outputs(plan)
+        if not plans[0].fallback:
+            for key, src, r0, r1 in sharding.output_gather_ops(ranks[0].bounds, plans[0].output_keys):
+                for dst, sh in enumerate(ranks):
+                    if dst != src:
+                        sh._complete_plane(key)[r0:r1].copy_(ranks[src]._complete_plane(key)[r0:r1])
+        for sh, plan in zip(ranks, plans):
+            sh.finish_frame(plan)
+        sync()
+        for r, sh in enumerate(ranks):
+            for (rt, dtype, ch, fmt), ro in zip(parity.output_planes(name, RW, RH), ref[2]):
+                assert torch.equal(sh.complete_output(rt), ro), (name, world, "frame", f, how[-1], sizes[f], "rank", r, "complete output", api.ResourceType(rt).name)
     return how, sizes
 
 
