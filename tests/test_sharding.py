@@ -460,7 +460,7 @@ def _dynamic_resolution_case(name, world, resource, balance, backend, overrides=
     assert all(how[f] == "whole" for f in range(len(sizes)) if changed[f]) and sum(h == "strips" for h in how) >= len(sizes) - sum(changed) - (1 if balance else 0), how
 
 
-def _scenario_case(name, world, resource, balance, backend, scenario):
+def _scenario_case(name, world, resource, balance, backend, scenario, graph=False):
     """`world` virtual ranks (HaloSharder, transfers replayed with copies, rows beyond the declared halos poisoned) against an uncut run over a SCENARIO: one dict per frame with
     scale = (sx, sy) of the rect inside the resource (default 1, 1), origin = CommonSettings::rectOrigin, camera = index of the generated camera path (default: the frame index),
     cs = CommonSettings fields, settings = denoiser-settings overrides. Every rank's owned rows of every output are compared after every frame. Returns (["whole" | "strips" per frame], rect sizes)."""
@@ -515,6 +515,9 @@ def _scenario_case(name, world, resource, balance, backend, scenario):
 
     ref = make_run()
     runs = [make_run() for _ in range(world)]
+    if graph:  # the ranks launch every pass segment as a hipGraph (nrdHipSetGraphMode), the uncut run stays eager
+        for inst, ex, outs in runs:
+            ex.set_graph_mode(True)
     ranks = [sharding.HaloSharder(ex, inst, RW, RH, r, world, balance=balance) for r, (inst, ex, outs) in enumerate(runs)]
     how = []
     for f in range(len(sizes)):
@@ -606,8 +609,8 @@ def _scenarios(name):
     }
 
 
-def _check_scenario(name, kind, world, balance, backend):
-    how, _ = _scenario_case(name, world, (256, 480), balance, backend, _scenarios(name)[kind])
+def _check_scenario(name, kind, world, balance, backend, graph=False):
+    how, _ = _scenario_case(name, world, (256, 480), balance, backend, _scenarios(name)[kind], graph=graph)
     if kind == "camera_cut":
         assert how[4] == "whole" and how[7] == "whole" and how[5] == "strips", how  # the cuts run unsharded, the frames between them in strips
     else:
@@ -626,6 +629,7 @@ def test_halo_sharding_scenarios_on_emulated_kernels(name, kind, world, balance)
 def test_halo_sharding_scenarios(name, kind):
     for world, balance in ((2, False), (3, False), (3, True)):
         _check_scenario(name, kind, world, balance, "hip")
+    _check_scenario(name, kind, 3, False, "hip", graph=True)  # pass segments with row ranges as hipGraphs: graphs are re-parametrised or rebuilt as the lists and ranges change
 
 
 @pytest.mark.gpu
