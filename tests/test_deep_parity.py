@@ -47,7 +47,8 @@ def test_gpu_sequence_against_the_reference_shader_text(name, max_frac, min_exac
 # ---- the saturated-history regime at the BASELINE size: the protocol of SURVEY 8d times frames 32..95; held bit for bit here at frames 32..39 of the
 # headline configuration. The first 32 frames run on the GPU alone -- the oracle does 1440p at ~0.6 frames / s --, then every plane of the GPU's state (user outputs, which double
 # as history, and both pools) is handed to the oracle and the two run frames 32..39 side by side: all outputs and pool planes equal on every frame.
-SATURATED = [("REBLUR_DIFFUSE_SPECULAR", 2560, 1440, 32, 8), ("RELAX_DIFFUSE_SPECULAR_SH", 3840, 2160, 32, 2)]
+SATURATED = [("REBLUR_DIFFUSE_SPECULAR", 2560, 1440, 32, 8), ("RELAX_DIFFUSE_SPECULAR_SH", 3840, 2160, 32, 2),
+             ("SIGMA_SHADOW", 1920, 1080, 32, 6), ("REBLUR_DIFFUSE", 2560, 1440, 32, 6)]  # BASELINE.json configs[1] and [2] (3 + 10 s); four more configurations: tools/parity_saturated.py
 
 
 @pytest.mark.parametrize("name,width,height,warm,frames", SATURATED, ids=["%s_%dx%d_frames_%d_%d" % (c[0], c[1], c[2], c[3], c[3] + c[4] - 1) for c in SATURATED])
