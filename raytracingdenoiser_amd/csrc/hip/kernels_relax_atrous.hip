@@ -620,22 +620,35 @@ NRD_D AtrousResult<DIFF, SPEC, SH> AtrousFinish(const AtrousPixel<DIFF, SPEC, SH
     }
     return r;
 }
-template <bool DIFF, bool SPEC, bool SH>
+// NT: the packed texels stored with the non-temporal hint -- a compile-time choice of the kernel, made by the launcher for frames above NRD_NT_STORE_PIXELS (planes.h)
+template <bool NT>
+NRD_D void AtrousStoreTexel(const Plane& p, int px, int py, uint2 v) {
+    if constexpr (NT) {
+        typedef uint32_t V2 __attribute__((ext_vector_type(2)));
+        V2 raw;
+        raw.x = v.x;
+        raw.y = v.y;
+        __builtin_nontemporal_store(raw, (V2*)TexelPtr<uint2>(p, px, py));
+    } else {
+        *TexelPtr<uint2>(p, px, py) = v;
+    }
+}
+template <bool DIFF, bool SPEC, bool SH, bool NT = false>
 NRD_D void AtrousStore(const AtrousResult<DIFF, SPEC, SH>& r, const AtrousPlanes& P, int px, int py) {
     if (SPEC) {
         if (SH)
-            *TexelPtr<uint2>(P.spec.outSh, px, py) = r.specSh;
-        *TexelPtr<uint2>(P.spec.out, px, py) = r.spec;
+            AtrousStoreTexel<NT>(P.spec.outSh, px, py, r.specSh);
+        AtrousStoreTexel<NT>(P.spec.out, px, py, r.spec);
     }
     if (DIFF) {
         if (SH)
-            *TexelPtr<uint2>(P.diff.outSh, px, py) = r.diffSh;
-        *TexelPtr<uint2>(P.diff.out, px, py) = r.diff;
+            AtrousStoreTexel<NT>(P.diff.outSh, px, py, r.diffSh);
+        AtrousStoreTexel<NT>(P.diff.out, px, py, r.diff);
     }
 }
-template <bool DIFF, bool SPEC, bool SH>
+template <bool DIFF, bool SPEC, bool SH, bool NT = false>
 NRD_D void AtrousEnd(const AtrousPixel<DIFF, SPEC, SH>& a, const AtrousPlanes& P, const RelaxCB& c, int px, int py) {
-    AtrousStore(AtrousFinish(a, c), P, px, py);
+    AtrousStore<DIFF, SPEC, SH, NT>(AtrousFinish(a, c), P, px, py);
 }
 
 // ================================================================================================ Atrous
@@ -674,7 +687,7 @@ NRD_D void AtrousEnd(const AtrousPixel<DIFF, SPEC, SH>& a, const AtrousPlanes& P
 #ifndef NRD_ATROUS_LDS_TILES
 #define NRD_ATROUS_LDS_TILES 1 // 0: every iteration gathers from global memory (A/B and the emulation's cross-check)
 #endif
-template <bool DIFF, bool SPEC, bool SH, int STEP, bool RES, bool MAT>
+template <bool DIFF, bool SPEC, bool SH, int STEP, bool RES, bool MAT, bool NT = false>
 __global__ __launch_bounds__(256, NRD_WAVES_RELAX_ATROUS) void RelaxAtrousKernel(AtrousPlanes P, RelaxCB c, RowRange rows) {
     // one layout for the two guide planes and one for the (up to four) RGBA16F signal planes: verified by the launcher
     ShareLayout(P.worldPosViewZ, P.decodedNR);
@@ -930,7 +943,7 @@ __global__ __launch_bounds__(256, NRD_WAVES_RELAX_ATROUS) void RelaxAtrousKernel
     if (BANDED && !active)
         return;
 
-    AtrousEnd(a, P, c, px, py);
+    AtrousEnd<DIFF, SPEC, SH, NT>(a, P, c, px, py);
 #undef px
 #undef py
 }
@@ -1330,7 +1343,9 @@ const char* LaunchAtrous(const PassArgs& a) {
     }
     const int step = (AtrousLdsTilesEnabled() && (c.gStepSize == 2 || c.gStepSize == 4)) || ((c.gStepSize == 8 || c.gStepSize == 16) && (int)c.gStepSize <= AtrousLdsBandsMaxStep()) ? (int)c.gStepSize : 0;
 #define NRD_LAUNCH_ATROUS_M(STEP, RES, MAT) LaunchPass(a, (RelaxAtrousKernel<DIFF, SPEC, SH, STEP, RES, MAT>), g.grid, dim3(256), P, c, rr)
-#define NRD_LAUNCH_ATROUS(STEP, RES) (mat ? NRD_LAUNCH_ATROUS_M(STEP, RES, true) : NRD_LAUNCH_ATROUS_M(STEP, RES, false))
+    // frames larger than the caches: the instantiation with hinted stores (planes.h NRD_NT_STORE_PIXELS; RELAX 4K: -2..3 % per iteration). Only the twin without material tests has one.
+    const bool nt = !mat && (uint32_t)P.viewZ.w * (uint32_t)P.viewZ.h > NRD_NT_STORE_PIXELS;
+#define NRD_LAUNCH_ATROUS(STEP, RES) (mat ? NRD_LAUNCH_ATROUS_M(STEP, RES, true) : nt ? LaunchPass(a, (RelaxAtrousKernel<DIFF, SPEC, SH, STEP, RES, false, true>), g.grid, dim3(256), P, c, rr) : NRD_LAUNCH_ATROUS_M(STEP, RES, false))
     if (step == 2)
         res ? NRD_LAUNCH_ATROUS(2, true) : NRD_LAUNCH_ATROUS(2, SPEC ? false : true);
     else if (step == 4)

@@ -248,7 +248,8 @@ NRD_D PrePassGuides FetchPrePassGuides(const RelaxCB& c, const PrePassPlanes& P,
 
 // MAT: material tests compiled in (launcher; only the full-rect variant has a MAT = false twin). Material IDs are 0..3: with a minimum material >= 3 (the default is 4) every
 // comparison holds. A run-time test inside the tap loop -- even a uniform one -- is if-converted into compare + select and saves nothing (round 5: a-trous 1 340 -> 1 200 instructions).
-template <bool DIFF, bool SPEC, bool SH, bool CB, bool FR, bool MAT = true>
+// NT: outputs stored with the non-temporal hint (planes.h StoreRGBA16FHinted; the launcher picks it for frames above NRD_NT_STORE_PIXELS: 4K -6 % for this pass, round 6)
+template <bool DIFF, bool SPEC, bool SH, bool CB, bool FR, bool MAT = true, bool NT = false>
 __global__ __launch_bounds__(256, NRD_WAVES_RELAX_PREPASS) void RelaxPrePassKernel(PrePassPlanes P, RelaxCB c, RowRange rows) {
     const int blockY = BlockTileY(rows, true);
     const int px = BlockTileX(rows) * TILE_X + (threadIdx.x & 31), py = blockY * TILE_Y + (threadIdx.x >> 5);
@@ -350,9 +351,9 @@ __global__ __launch_bounds__(256, NRD_WAVES_RELAX_PREPASS) void RelaxPrePassKern
             if (SH)
                 diffuseSH = Div(diffuseSH, weightSum);
         }
-        StoreRGBA16F(P.diff.out, px, py, Clamp4(diffuseIllumination, 0.0f, NRD_FP16_MAX));
+        StoreRGBA16FHinted<NT>(P.diff.out, px, py, Clamp4(diffuseIllumination, 0.0f, NRD_FP16_MAX));
         if (SH)
-            StoreRGBA16F(P.diff.outSh, px, py, Clamp4(diffuseSH, -NRD_FP16_MAX, NRD_FP16_MAX));
+            StoreRGBA16FHinted<NT>(P.diff.outSh, px, py, Clamp4(diffuseSH, -NRD_FP16_MAX, NRD_FP16_MAX));
     }
 
     if (SPEC) {
@@ -443,9 +444,9 @@ __global__ __launch_bounds__(256, NRD_WAVES_RELAX_PREPASS) void RelaxPrePassKern
             if (SH)
                 specularSH = Div(specularSH, weightSum);
         }
-        StoreRGBA16F(P.spec.out, px, py, Clamp4(specularIllumination, 0.0f, NRD_FP16_MAX));
+        StoreRGBA16FHinted<NT>(P.spec.out, px, py, Clamp4(specularIllumination, 0.0f, NRD_FP16_MAX));
         if (SH)
-            StoreRGBA16F(P.spec.outSh, px, py, Clamp4(specularSH, -NRD_FP16_MAX, NRD_FP16_MAX));
+            StoreRGBA16FHinted<NT>(P.spec.outSh, px, py, Clamp4(specularSH, -NRD_FP16_MAX, NRD_FP16_MAX));
     }
 }
 
@@ -477,6 +478,8 @@ const char* LaunchPrePass(const PassArgs& a) {
                           c.shared.gRectSize.y == P.decodedNR.h && P.viewZ.w == P.decodedNR.w && P.viewZ.h == P.decodedNR.h && !(forceGeneric && atoi(forceGeneric) != 0);
     if ((SPEC && c.shared.gSpecCheckerboard != 2u) || (DIFF && c.shared.gDiffCheckerboard != 2u))
         LaunchPass(a, (RelaxPrePassKernel<DIFF, SPEC, SH, true, false>), g.grid, dim3(256), P, c, MakeRowRange(g));
+    else if (fullRect && !(c.shared.gSpecMinMaterial < 3.0f || c.shared.gDiffMinMaterial < 3.0f) && (uint32_t)P.decodedNR.w * (uint32_t)P.decodedNR.h > NRD_NT_STORE_PIXELS)
+        LaunchPass(a, (RelaxPrePassKernel<DIFF, SPEC, SH, false, true, false, true>), g.grid, dim3(256), P, c, MakeRowRange(g)); // (a frame larger than the caches: hinted stores)
     else if (fullRect && !(c.shared.gSpecMinMaterial < 3.0f || c.shared.gDiffMinMaterial < 3.0f))
         LaunchPass(a, (RelaxPrePassKernel<DIFF, SPEC, SH, false, true, false>), g.grid, dim3(256), P, c, MakeRowRange(g));
     else if (fullRect)

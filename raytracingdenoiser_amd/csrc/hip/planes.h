@@ -149,6 +149,26 @@ NRD_D void StoreRGBA16F(const Plane& p, int x, int y, float4 v) {
     *TexelPtr<uint2>(p, x, y) = raw;
 }
 
+// The same store with the non-temporal hint as a compile-time choice of the kernel (NT = true: "global_store_dwordx2 ... nt"). For passes whose output exceeds the caches -- a 4K
+// frame writes 270-560 MB per pass, more than the L2 and the memory-side cache hold together -- a plain store only evicts what the gathers of the same pass re-read; below that size
+// the next pass finds its input cached and the hint would throw it away, so the LAUNCHER picks the instantiation by frame size (NRD_NT_STORE_PIXELS; profiles/HISTORY.md, round 6:
+// a run-time branch in the store helpers cost the kernels that never take it 4 %, and LLVM merges a hinted and a plain store in two arms of a branch into one plain store).
+#ifndef NRD_NT_STORE_PIXELS
+#define NRD_NT_STORE_PIXELS 6000000u
+#endif
+template <bool NT>
+NRD_D void StoreRGBA16FHinted(const Plane& p, int x, int y, float4 v) {
+    if constexpr (NT) {
+        typedef uint32_t V2 __attribute__((ext_vector_type(2)));
+        V2 raw;
+        raw.x = FloatsToHalf2Bits(v.x, v.y);
+        raw.y = FloatsToHalf2Bits(v.z, v.w);
+        __builtin_nontemporal_store(raw, (V2*)TexelPtr<uint2>(p, x, y));
+    } else {
+        StoreRGBA16F(p, x, y, v);
+    }
+}
+
 // ---- RGBA32_SFLOAT --------------------------------------------------------------------------------------------------
 NRD_D float4 LoadRGBA32F(const Plane& p, int x, int y) { return *TexelPtr<const float4>(p, x, y); }
 NRD_D void StoreRGBA32F(const Plane& p, int x, int y, float4 v) { *TexelPtr<float4>(p, x, y) = v; }
