@@ -8,7 +8,7 @@
 #   5. hardware counters, one rocprofv3 --pmc pass per set (tools/pmc_run.sh: FETCH_SIZE; WRITE_SIZE; SQ issue / waits; TCC hit / miss; LDS instructions + bank conflicts)
 #   6. the N = 1 / 2 / 4 / 8 compute model of the halo scheme (tools/model_scaling.py: virtual ranks on one GPU -- MODELLED, no transfers)
 cd "$(dirname "$0")/.." && export TMPDIR=/tmp
-tag=${1:-r06_end}; quick=$2; mkdir -p gpurun_out
+tag=${1:-r06_last}; quick=$2; mkdir -p gpurun_out
 V=raytracingdenoiser_amd/lib/variants
 ( time timeout 1500 python -m pytest tests -m gpu -x -q --durations=25 ) > gpurun_out/${tag}_pytest_gpu.log 2>&1; echo "pytest exit $?" >> gpurun_out/${tag}_pytest_gpu.log; tail -4 gpurun_out/${tag}_pytest_gpu.log
 timeout 300 python __graft_entry__.py smoke > gpurun_out/${tag}_smoke.log 2>&1; tail -1 gpurun_out/${tag}_smoke.log
